@@ -1,0 +1,182 @@
+/*
+ * mina_verify.h -- C-ABI of libminaverify.so, the MI355X-native (gfx950) Kimchi/Pickles IPA batch
+ * verifier that sits behind the byte contract of lambdaclass/mina_bridge.
+ *
+ * What each entry point replaces (reference = /root/reference; "pin" = un-vendored crate pinned in
+ * core/Cargo.toml:14-25, whose source is not in the tree -- see SURVEY.md section 0 and 8b):
+ *
+ *   (whole library)
+ *       the verifier the bytes built at core/src/aligned.rs:31-58 are handed to
+ *       (`ProvingSystemId::Mina` / `MinaAccount`; README.md:275-279,358-362: Aligned's
+ *       `verify_mina_state_ffi` / `verify_account_inclusion_ffi`); this header exports the hot path
+ *       of that verifier -- the combined IPA check and its kernels.
+ *   mina_srs_*
+ *       poly-commitment `SRS::create` and the loader for srs/vesta.srs, srs/pallas.srs
+ *       (MessagePack `SRS{g,h}`; format in SURVEY.md section 0).
+ *   mina_msm*
+ *       ark-ec 0.3 `VariableBaseMSM::multi_scalar_mul` (pin core/Cargo.toml:20,49; README.md:538-540).
+ *   mina_b_poly*, mina_ipa_*
+ *       poly-commitment `b_poly`, `b_poly_coefficients`, `SRS::verify` (pin core/Cargo.toml:16;
+ *       README.md:469-475,534-544).
+ *   mina_poseidon_*, mina_challenge_to_field
+ *       mina-poseidon `ArithmeticSponge` (PlonkSpongeConstantsKimchi), kimchi `ScalarChallenge::to_field`
+ *       (pin core/Cargo.toml:14; README.md:443).
+ *   mina_to_group
+ *       groupmap `BWParameters::to_group` (core/Cargo.lock:2825-2827).
+ *
+ * Conventions
+ *   - plain C types only; caller owns every host buffer; the library owns device memory, SRS tables
+ *     and streams inside a `mina_ctx`.  No exceptions cross the ABI: every function returns 0 (MINA_OK)
+ *     or a negative error code; verdicts are separate outputs.
+ *   - field element: 32-byte little-endian canonical integer (< modulus), the ark `CanonicalSerialize`
+ *     form used at core/src/sol/serialization.rs:63-86.
+ *   - affine point: x || y, 64 bytes; the point at infinity is 64 zero bytes.
+ *   - `field`: 0 = Fp (Pallas base, Vesta scalar), 1 = Fq (Vesta base, Pallas scalar).
+ *   - `curve`: 0 = Pallas (base Fp, scalar Fq), 1 = Vesta (base Fq, scalar Fp).
+ *   - entry points ending in `_dev` take device pointers (HBM-resident inputs) and run on the
+ *     context's stream without synchronising unless stated.
+ *   - a context is bound to one GPU; calls on one context are serialised by the caller
+ *     (one context per thread / per rank).
+ */
+#ifndef MINA_VERIFY_H
+#define MINA_VERIFY_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MINA_OK 0
+#define MINA_ERR_ARG (-1)
+#define MINA_ERR_HIP (-2)
+#define MINA_ERR_STATE (-3)   /* e.g. SRS not loaded */
+#define MINA_ERR_FORMAT (-4)  /* malformed bytes */
+
+#define MINA_FIELD_FP 0
+#define MINA_FIELD_FQ 1
+#define MINA_CURVE_PALLAS 0
+#define MINA_CURVE_VESTA 1
+
+typedef struct mina_ctx mina_ctx;
+
+/* ---- context -------------------------------------------------------------------------------- */
+int mina_ctx_create(int device_id, mina_ctx **out);
+void mina_ctx_destroy(mina_ctx *ctx);
+/* last error text of the calling thread (never NULL) */
+const char *mina_last_error(void);
+/* block until everything queued on the context's stream has finished */
+int mina_ctx_synchronize(mina_ctx *ctx);
+/* the hipStream_t the `_dev` entry points are queued on (for event timing by the caller) */
+void *mina_ctx_stream(mina_ctx *ctx);
+
+/* ---- SRS (a6) -------------------------------------------------------------------------------- */
+/* Regenerate SRS{g[0..depth), h} exactly as poly-commitment `SRS::create(depth)` does
+ * (BLAKE2b-512 -> field -> BW group map, K4 on the GPU) and build the MSM window tables in HBM. */
+int mina_srs_create(mina_ctx *ctx, int curve, uint32_t depth);
+/* Load from the MessagePack bytes of srs/vesta.srs / srs/pallas.srs (33-byte compressed points). */
+int mina_srs_load(mina_ctx *ctx, int curve, const uint8_t *msgpack, size_t len);
+/* depth of the loaded SRS (0 if none) */
+uint32_t mina_srs_depth(mina_ctx *ctx, int curve);
+/* copy g[first..first+count) (affine, canonical bytes) / h to host */
+int mina_srs_get_g(mina_ctx *ctx, int curve, uint32_t first, uint32_t count, uint8_t *out_affine);
+int mina_srs_get_h(mina_ctx *ctx, int curve, uint8_t *out_affine);
+/* serialise back to the reference's file format; *len receives the size (2 293 801 for depth 2^16) */
+int mina_srs_serialize(mina_ctx *ctx, int curve, uint8_t *out, size_t cap, size_t *len);
+
+/* ---- K1: multi-scalar multiplication (a7) ---------------------------------------------------- */
+/* out = sum_i scalars[i] * bases[i]; any points (variable-base Pippenger). */
+int mina_msm(mina_ctx *ctx, int curve, size_t n, const uint8_t *bases_affine, const uint8_t *scalars,
+             uint8_t *out_affine);
+/* out = sum_i scalars[i] * g[i], g = loaded SRS of `curve`, n <= depth (fixed-base window tables). */
+int mina_msm_srs(mina_ctx *ctx, int curve, size_t n, const uint8_t *scalars, uint8_t *out_affine);
+/* Same with scalars already in HBM (n x 32 bytes, canonical).  Queued on the context stream; the
+ * 68-byte result record {x[32], y[32], u32 is_infinity} is written to `d_out` (device memory). */
+int mina_msm_srs_dev(mina_ctx *ctx, int curve, size_t n, const void *d_scalars, void *d_out);
+
+/* ---- K2: IPA challenge polynomial (a9) ------------------------------------------------------- */
+/* b_poly(chals, x) for `npoints` evaluation points */
+int mina_b_poly(mina_ctx *ctx, int field, uint32_t k, const uint8_t *chals, size_t npoints,
+                const uint8_t *xs, uint8_t *out);
+/* s[0..2^k) = b_poly_coefficients(chals) */
+int mina_b_poly_coefficients(mina_ctx *ctx, int field, uint32_t k, const uint8_t *chals, uint8_t *out);
+/* folded[j] = sum_b weights[b] * b_poly_coefficients(chals[b])[j], j < 2^k  (batch fold of a8) */
+int mina_b_poly_fold(mina_ctx *ctx, int field, uint32_t k, size_t batch, const uint8_t *chals /* batch*k */,
+                     const uint8_t *weights /* batch */, uint8_t *out /* 2^k */);
+int mina_b_poly_fold_dev(mina_ctx *ctx, int field, uint32_t k, size_t batch, const void *d_chals,
+                         const void *d_weights, void *d_out);
+
+/* ---- K3: Poseidon (a12) / challenges (a13) --------------------------------------------------- */
+/* Install the sponge constants of `field`: mds[9] row-major then rc[55*3], 32-byte LE each.
+ * The constants are parameters of the engine (the real fp_kimchi/fq_kimchi tables are not in the
+ * reference tree). */
+int mina_poseidon_set_params(mina_ctx *ctx, int field, const uint8_t *params /* (9+165)*32 */);
+/* in-place permutation of n states (3 field elements each) */
+int mina_poseidon_permute(mina_ctx *ctx, int field, size_t n, uint8_t *states /* n*96 */);
+int mina_poseidon_permute_dev(mina_ctx *ctx, int field, size_t n, void *d_states);
+/* n independent sponges: absorb `len` elements each (inputs: n*len*32 bytes), squeeze one. */
+int mina_poseidon_hash(mina_ctx *ctx, int field, size_t n, size_t len, const uint8_t *inputs, uint8_t *out);
+/* ScalarChallenge::to_field: n 128-bit challenges (16 bytes LE each) -> field, endo = endo_r of the
+ * curve whose scalar field is `field`. */
+int mina_challenge_to_field(mina_ctx *ctx, int field, size_t n, const uint8_t *chal128, uint8_t *out);
+
+/* ---- K4: group map (a14) --------------------------------------------------------------------- */
+int mina_to_group(mina_ctx *ctx, int curve, size_t n, const uint8_t *t, uint8_t *out_affine);
+
+/* ---- field self-test hooks (used by the parity tests only) ----------------------------------- */
+int mina_field_mul(mina_ctx *ctx, int field, size_t n, const uint8_t *a, const uint8_t *b, uint8_t *out);
+int mina_field_inv(mina_ctx *ctx, int field, size_t n, const uint8_t *a, uint8_t *out);
+int mina_field_sqrt(mina_ctx *ctx, int field, size_t n, const uint8_t *a, uint8_t *out, uint8_t *out_is_square);
+
+/* ---- a8 / a10: combined IPA check ------------------------------------------------------------ */
+/* Accumulator check (a10) for `batch` proofs on the SRS of `curve`:
+ *   verdicts[b] = ( MSM(g[0..2^k), b_poly_coefficients(chals_b)) == sg_b ).
+ * `prechallenges`: batch*k 128-bit values (16 bytes LE), expanded with ScalarChallenge::to_field.
+ * Implemented as ONE folded MSM with the caller-supplied batching randomisers `rho` (batch field
+ * elements; upstream draws them from an RNG) and per-proof bisection on failure. */
+int mina_accumulator_check_batch(mina_ctx *ctx, int curve, uint32_t k, size_t batch,
+                                 const uint8_t *prechallenges /* batch*k*16 */, const uint8_t *sg /* batch*64 */,
+                                 const uint8_t *rho /* batch*32 */, uint8_t *verdicts /* batch */);
+
+/* Same with everything in HBM: prechallenges (batch*k*16 B), sg (batch*64 B, canonical), rho (batch*32 B,
+ * may be NULL when batch == 1).  Queued on the context stream, no host synchronisation: the u32 word at
+ * `d_verdict` becomes 1 iff the (folded) check holds. */
+int mina_accumulator_check_dev(mina_ctx *ctx, int curve, uint32_t k, size_t batch, const void *d_prechallenges,
+                               const void *d_sg, const void *d_rho, void *d_verdict);
+
+/* Combined IPA opening check `SRS::verify` (a8).  One entry = one upstream `BatchEvaluationProof`
+ * (sponge, evaluation_points, polyscale, evalscale, evaluations[].commitment, opening,
+ * combined_inner_product), single-chunk commitments without degree bounds. */
+typedef struct {
+    uint32_t k;                 /* IPA rounds; the opening is over g[0..2^k) */
+    const uint8_t *lr;          /* k pairs (L_j, R_j): 2*k*64 bytes */
+    const uint8_t *delta;       /* 64 */
+    const uint8_t *sg;          /* 64 */
+    const uint8_t *z1, *z2;     /* 32 each (scalar field) */
+    uint32_t n_evalpoints;      /* evaluation points */
+    const uint8_t *evalpoints;  /* n_evalpoints * 32 (scalar field) */
+    uint32_t n_comms;           /* commitments being opened */
+    const uint8_t *comms;       /* n_comms * 64 */
+    const uint8_t *combined_inner_product; /* 32 (scalar field) */
+    const uint8_t *polyscale;   /* xi, 32 */
+    const uint8_t *evalscale;   /* r, 32 */
+    const uint8_t *sponge_state;/* 3 * 32: Fq-sponge state (base field) handed over by the caller ... */
+    uint32_t sponge_mode;       /* ... 0 = Absorbed(count), 1 = Squeezed(count) (mina-poseidon SpongeState) */
+    uint32_t sponge_count;
+} mina_ipa_opening;
+
+int mina_ipa_batch_check(mina_ctx *ctx, int curve, size_t batch, const mina_ipa_opening *openings,
+                         const uint8_t *rand_base /* 32 */, const uint8_t *sg_rand_base /* 32 */,
+                         uint8_t *verdict /* 1 byte: 1 = all openings valid */);
+
+/* ---- top-level byte contract (a15, a16): NOT YET EXPORTED ------------------------------------
+ * mina_verify_state / mina_verify_account (same (ptr,len,ptr,len) shape as Aligned's
+ * verify_mina_state_ffi / verify_account_inclusion_ffi) need the bincode/binprot container parsers and
+ * the blockchain-snark verifier index, neither of which exists in the reference tree (SURVEY.md 8f rows
+ * 1-2).  They are specified in INTEGRATION.md and will be added once those land. */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MINA_VERIFY_H */

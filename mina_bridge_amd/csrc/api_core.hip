@@ -1,0 +1,136 @@
+// api_core.hip -- context lifetime, field constants, field self-test hooks, K4 group map entry point.
+#include "ctx.h"
+#include "sponge.cuh"
+
+static thread_local std::string g_err = "";
+int mb_fail(int code, const std::string &msg) { g_err = msg; return code; }
+
+// ------------------------------------------------------------------------------------------------
+// Host-side derivation of the per-field constants (no table of magic numbers: everything follows
+// from the modulus and the generator 5).
+template <int F> static fe_t host_modulus() { fe_t p; for (int i = 0; i < 8; ++i) p.v[i] = modulus_limb<F>(i); return p; }
+static void fe_shr1(fe_t &a) { for (int i = 0; i < 7; ++i) a.v[i] = (a.v[i] >> 1) | (a.v[i + 1] << 31); a.v[7] >>= 1; }
+static fe_t fe_sub_small(const fe_t &a, uint32_t k) { fe_t r = a; uint64_t br = k; for (int i = 0; i < 8 && br; ++i) { uint64_t t = (uint64_t)r.v[i] - br; r.v[i] = (uint32_t)t; br = (t >> 32) & 1u; } return r; }
+static fe_t fe_div3(const fe_t &a) { fe_t r; uint64_t rem = 0; for (int i = 7; i >= 0; --i) { uint64_t cur = (rem << 32) | a.v[i]; r.v[i] = (uint32_t)(cur / 3); rem = cur % 3; } return r; }
+
+template <int F> static FieldK make_field_consts() {
+    FieldK k;
+    fe_t p = host_modulus<F>();
+    // R mod p and R^2 mod p by modular doubling of 1 (fe_add works on any residues)
+    fe_t a = fe_zero(); a.v[0] = 1;
+    for (int i = 0; i < 512; ++i) { a = fe_add<F>(a, a); if (i == 255) k.one = a; }
+    k.r2 = a;
+    fe_t pm1 = fe_sub_small(p, 1);
+    k.pm2 = fe_sub_small(p, 2);
+    k.pm1d2 = pm1; fe_shr1(k.pm1d2);
+    k.half = k.pm1d2;
+    fe_t t = pm1; for (int i = 0; i < 32; ++i) fe_shr1(t);
+    k.tm1d2 = fe_sub_small(t, 1); fe_shr1(k.tm1d2);
+    fe_t five = fe_zero(); five.v[0] = 5; k.five = fe_to_mont<F>(five, k.r2);
+    k.root = fe_pow<F>(k.five, t, k.one);
+    fe_t three = fe_zero(); three.v[0] = 3; three = fe_to_mont<F>(three, k.r2);
+    fe_t six = fe_zero(); six.v[0] = 6; k.bw_fu = fe_to_mont<F>(six, k.r2);
+    fe_t two = fe_dbl<F>(k.one);
+    fe_sqrt<F>(k.bw_s, fe_neg<F>(three), k);
+    k.bw_c = fe_mul<F>(fe_sub<F>(k.bw_s, k.one), fe_inv<F>(two, k));
+    k.bw_inv3 = fe_inv<F>(three, k);
+    fe_t w = fe_pow<F>(k.five, fe_div3(pm1), k.one);
+    k.endo = fe_sqr<F>(w);
+    return k;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------
+extern "C" const char *mina_last_error(void) { return g_err.c_str(); }
+
+extern "C" int mina_ctx_create(int device_id, mina_ctx **out) {
+    if (!out) return fail(MINA_ERR_ARG, "out is null");
+    *out = nullptr;
+    int ndev = 0;
+    HIPC(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) return fail(MINA_ERR_HIP, "no HIP device: libminaverify has no CPU fallback");
+    if (device_id < 0 || device_id >= ndev) return fail(MINA_ERR_ARG, "bad device id");
+    HIPC(hipSetDevice(device_id));
+    mina_ctx *c = new mina_ctx();
+    c->device = device_id;
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return fail(MINA_ERR_HIP, "hipStreamCreate failed"); }
+    c->fk[FIELD_FP] = make_field_consts<FIELD_FP>();
+    c->fk[FIELD_FQ] = make_field_consts<FIELD_FQ>();
+    *out = c;
+    return MINA_OK;
+}
+
+extern "C" void mina_ctx_destroy(mina_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (int i = 0; i < 2; ++i) { c->srs[i].table.release(); c->srs[i].h.release(); c->pparams[i].release(); }
+    MsmWorkspace &w = c->ws;
+    DevBuf *all[] = {&w.scalars, &w.points, &w.ekey, &w.eval, &w.eoff, &w.count, &w.start, &w.task_start, &w.sorted, &w.partial,
+                     &w.buckets, &w.red_r, &w.red_ws, &w.set_total, &w.out_words, &w.out_xyzz, &c->tmp_a, &c->tmp_b, &c->tmp_c,
+                     &c->tmp_d, &c->bp_ltab, &c->bp_htab, &c->bp_partial, &c->ipa_chals, &c->ipa_folded, &c->ipa_xyzz_a, &c->ipa_xyzz_b,
+                     &c->ipa_points, &c->ipa_scalars, &c->ipa_sigma, &c->ipa_in_a, &c->ipa_in_b, &c->ipa_in_c, &c->ipa_verdict};
+    for (DevBuf *b : all) b->release();
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+extern "C" int mina_ctx_synchronize(mina_ctx *c) {
+    if (!c) return fail(MINA_ERR_ARG, "null ctx");
+    HIPC(hipStreamSynchronize(c->stream));
+    return MINA_OK;
+}
+extern "C" void *mina_ctx_stream(mina_ctx *c) { return c ? (void *)c->stream : nullptr; }
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int mina_to_group(mina_ctx *c, int curve, size_t n, const uint8_t *t, uint8_t *out) {
+    if (!c || (n && (!t || !out))) return fail(MINA_ERR_ARG, "null argument");
+    if (curve != 0 && curve != 1) return fail(MINA_ERR_ARG, "bad curve");
+    if (n == 0) return MINA_OK;
+    HIPC(hipSetDevice(c->device));
+    int rc;
+    if ((rc = h2d(c, c->tmp_a, t, n * 32))) return rc;
+    if ((rc = c->tmp_b.ensure(n * 64))) return rc;
+    const int F = base_field_of(curve);
+    DISPATCH_FIELD(F, { to_group_kernel<F_><<<cdiv(n, 128), 128, 0, c->stream>>>((uint32_t)n, c->fk[F_], c->tmp_a.as<uint32_t>(), c->tmp_b.as<uint32_t>()); });
+    return d2h_sync(c, out, c->tmp_b, n * 64);
+}
+
+extern "C" int mina_field_mul(mina_ctx *c, int field, size_t n, const uint8_t *a, const uint8_t *b, uint8_t *out) {
+    if (!c || (n && (!a || !b || !out))) return fail(MINA_ERR_ARG, "null argument");
+    if (bad_field(field)) return fail(MINA_ERR_ARG, "bad field");
+    if (n == 0) return MINA_OK;
+    HIPC(hipSetDevice(c->device));
+    int rc;
+    if ((rc = h2d(c, c->tmp_a, a, n * 32))) return rc;
+    if ((rc = h2d(c, c->tmp_b, b, n * 32))) return rc;
+    if ((rc = c->tmp_c.ensure(n * 32))) return rc;
+    DISPATCH_FIELD(field, { field_mul_kernel<F_><<<cdiv(n, 256), 256, 0, c->stream>>>((uint32_t)n, c->fk[F_], c->tmp_a.as<uint32_t>(), c->tmp_b.as<uint32_t>(), c->tmp_c.as<uint32_t>()); });
+    return d2h_sync(c, out, c->tmp_c, n * 32);
+}
+extern "C" int mina_field_inv(mina_ctx *c, int field, size_t n, const uint8_t *a, uint8_t *out) {
+    if (!c || (n && (!a || !out))) return fail(MINA_ERR_ARG, "null argument");
+    if (bad_field(field)) return fail(MINA_ERR_ARG, "bad field");
+    if (n == 0) return MINA_OK;
+    HIPC(hipSetDevice(c->device));
+    int rc;
+    if ((rc = h2d(c, c->tmp_a, a, n * 32))) return rc;
+    if ((rc = c->tmp_c.ensure(n * 32))) return rc;
+    DISPATCH_FIELD(field, { field_inv_kernel<F_><<<cdiv(n, 256), 256, 0, c->stream>>>((uint32_t)n, c->fk[F_], c->tmp_a.as<uint32_t>(), c->tmp_c.as<uint32_t>()); });
+    return d2h_sync(c, out, c->tmp_c, n * 32);
+}
+extern "C" int mina_field_sqrt(mina_ctx *c, int field, size_t n, const uint8_t *a, uint8_t *out, uint8_t *ok) {
+    if (!c || (n && (!a || !out || !ok))) return fail(MINA_ERR_ARG, "null argument");
+    if (bad_field(field)) return fail(MINA_ERR_ARG, "bad field");
+    if (n == 0) return MINA_OK;
+    HIPC(hipSetDevice(c->device));
+    int rc;
+    if ((rc = h2d(c, c->tmp_a, a, n * 32))) return rc;
+    if ((rc = c->tmp_c.ensure(n * 32))) return rc;
+    if ((rc = c->tmp_d.ensure(n))) return rc;
+    DISPATCH_FIELD(field, { field_sqrt_kernel<F_><<<cdiv(n, 256), 256, 0, c->stream>>>((uint32_t)n, c->fk[F_], c->tmp_a.as<uint32_t>(), c->tmp_c.as<uint32_t>(), c->tmp_d.as<uint8_t>()); });
+    HIPC(hipMemcpyAsync(ok, c->tmp_d.p, n, hipMemcpyDeviceToHost, c->stream));
+    return d2h_sync(c, out, c->tmp_c, n * 32);
+}
+

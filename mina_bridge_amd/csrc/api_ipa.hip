@@ -1,0 +1,327 @@
+// api_ipa.hip -- the combined IPA checks on top of K1..K4.
+//
+// Replaces poly-commitment `SRS::verify` (batched opening check) and openmina `accumulator_check`
+// (pins core/Cargo.toml:16,23; README.md:469-475, 534-544).  Per proof b (rho = rand_base^b,
+// sigma = sg_rand_base^b) upstream pushes onto ONE multi-scalar multiplication
+//     g[j] += sigma * s_b[j]          h -= rho z2          sg: -rho z1 - sigma        U: -rho z1 b0 + rho c cip
+//     L_j: rho c / chal_j             R_j: rho c chal_j    comm_i: rho c xi^i         delta: rho
+// and asserts the result is the identity.  Here the g-part is K2 (fold) + K1 (fixed-base tables) and the
+// per-proof points go through the variable-base K1 path; the two partial results are compared on the GPU.
+// The Fiat-Shamir transcript of each proof runs as one lane of `ipa_prepare_kernel` (throughput layout:
+// one proof per lane; a wave-cooperative sponge is the planned latency optimisation).
+#include "ctx.h"
+#include "msm.cuh"
+#include "sponge.cuh"
+
+namespace mb {
+
+// mina-poseidon `ArithmeticSponge` state machine (rate 2) over base field F, Montgomery state.
+template <int F> struct DevSponge {
+    fe_t s[3]; int squeezed; int count; const PoseidonParams *pp;
+    __device__ void absorb(const fe_t &x) {
+        if (!squeezed) {
+            if (count == 2) { poseidon_permute<F>(s, pp); s[0] = fe_add<F>(s[0], x); count = 1; }
+            else { s[count] = fe_add<F>(s[count], x); ++count; }
+        } else { s[0] = fe_add<F>(s[0], x); squeezed = 0; count = 1; }
+    }
+    __device__ fe_t squeeze() {
+        if (!squeezed || count == 2) { poseidon_permute<F>(s, pp); squeezed = 1; count = 1; return s[0]; }
+        return s[count++];
+    }
+};
+
+struct IpaShape { uint32_t batch, k, npts, ncomms, per; };   // per = 2k + ncomms + 4 points per proof
+
+template <int F> __device__ __forceinline__ fe_t load_fe(const uint32_t *p) { fe_t r; for (int i = 0; i < 8; ++i) r.v[i] = p[i]; return r; }
+__device__ __forceinline__ void store_fe(uint32_t *p, const fe_t &a) { for (int i = 0; i < 8; ++i) p[i] = a.v[i]; }
+
+template <int FB> __device__ __forceinline__ affine_t load_point_mont(const uint32_t *p, const FieldK &kb) {
+    affine_t a; a.x = fe_to_mont<FB>(load_fe<FB>(p), kb.r2); a.y = fe_to_mont<FB>(load_fe<FB>(p + 8), kb.r2); return a;
+}
+
+// One lane per proof.  CURVE fixes (base field FB, scalar field FS).
+template <int CURVE>
+__global__ void __launch_bounds__(64)
+ipa_prepare_kernel(IpaShape sh, FieldK kb, FieldK ks, const PoseidonParams *__restrict__ pp,
+                   const uint32_t *__restrict__ sponge_state /* b*24 */, const uint32_t *__restrict__ sponge_pos /* b*2 */,
+                   const uint32_t *__restrict__ cip /* b*8 */,
+                   const uint32_t *__restrict__ lr /* b*2k*16 */, const uint32_t *__restrict__ delta /* b*16 */,
+                   const uint32_t *__restrict__ sg /* b*16 */, const uint32_t *__restrict__ z1, const uint32_t *__restrict__ z2,
+                   const uint32_t *__restrict__ evalpoints /* b*npts*8 */, const uint32_t *__restrict__ evalscale,
+                   const uint32_t *__restrict__ polyscale, const uint32_t *__restrict__ comms /* b*ncomms*16 */,
+                   const uint32_t *__restrict__ rand_base, const uint32_t *__restrict__ sg_rand_base,
+                   const affine_t *__restrict__ srs_h,
+                   affine_t *__restrict__ out_points /* b*per */, uint32_t *__restrict__ out_scalars /* b*per*8 canonical */,
+                   uint32_t *__restrict__ out_chals /* b*k*8 canonical */, uint32_t *__restrict__ out_sigma /* b*8 canonical */) {
+    constexpr int FB = (CURVE == CURVE_PALLAS) ? FIELD_FP : FIELD_FQ;
+    constexpr int FS = (CURVE == CURVE_PALLAS) ? FIELD_FQ : FIELD_FP;
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= sh.batch) return;
+    const uint32_t k = sh.k;
+
+    // ---- Fq-sponge transcript (base field)
+    DevSponge<FB> sp; sp.pp = pp; sp.squeezed = 0; sp.count = 0;
+    for (int i = 0; i < 3; ++i) sp.s[i] = fe_to_mont<FB>(load_fe<FB>(sponge_state + (size_t)b * 24 + i * 8), kb.r2);
+    sp.squeezed = (int)sponge_pos[2 * b]; sp.count = (int)sponge_pos[2 * b + 1];
+    const fe_t cip_m = fe_to_mont<FS>(load_fe<FS>(cip + (size_t)b * 8), ks.r2);
+    {   // absorb_fr(shift_scalar(cip))
+        fe_t two255 = ks.one; for (int i = 0; i < 255; ++i) two255 = fe_dbl<FS>(two255);
+        if (CURVE == CURVE_PALLAS) {
+            // scalar modulus > base modulus: x = cip - 2^255 ; absorb (x >> 1), then (x & 1)
+            fe_t x = fe_from_mont<FS>(fe_sub<FS>(cip_m, two255));
+            fe_t lowbit = fe_zero(); lowbit.v[0] = x.v[0] & 1u;
+            fe_t hi = x; for (int i = 0; i < 7; ++i) hi.v[i] = (hi.v[i] >> 1) | (hi.v[i + 1] << 31); hi.v[7] >>= 1;
+            sp.absorb(fe_to_mont<FB>(hi, kb.r2));
+            sp.absorb(fe_to_mont<FB>(lowbit, kb.r2));
+        } else {
+            // scalar modulus < base modulus: x = (cip - (2^255 + 1)) / 2, absorbed as one base-field element
+            fe_t inv2 = fe_inv<FS>(fe_dbl<FS>(ks.one), ks);
+            fe_t x = fe_from_mont<FS>(fe_mul<FS>(fe_sub<FS>(cip_m, fe_add<FS>(two255, ks.one)), inv2));
+            sp.absorb(fe_to_mont<FB>(x, kb.r2));
+        }
+    }
+    const fe_t t = sp.squeeze();                              // challenge_fq
+    const affine_t U = bw_to_group<FB>(t, kb);
+
+    affine_t *pts = out_points + (size_t)b * sh.per;
+    uint32_t *scs = out_scalars + (size_t)b * sh.per * 8;
+
+    // rho = rand_base^b, sigma = sg_rand_base^b
+    fe_t rho = ks.one, sigma = ks.one;
+    {
+        fe_t rb = fe_to_mont<FS>(load_fe<FS>(rand_base), ks.r2), sb = fe_to_mont<FS>(load_fe<FS>(sg_rand_base), ks.r2);
+        for (uint32_t e = b; e; e >>= 1) {
+            if (e & 1u) { rho = fe_mul<FS>(rho, rb); sigma = fe_mul<FS>(sigma, sb); }
+            rb = fe_sqr<FS>(rb); sb = fe_sqr<FS>(sb);
+        }
+    }
+
+    // challenges: absorb L_j, R_j ; squeeze 128 bits ; endo-expand.  Points go straight to the output list.
+    // layout of the per-proof list: [h, sg, U, delta, L_0, R_0, ..., L_{k-1}, R_{k-1}, comm_0 .. comm_{m-1}]
+    for (uint32_t j = 0; j < k; ++j) {
+        const uint32_t *lp = lr + ((size_t)b * 2 * k + 2 * j) * 16;
+        affine_t L = load_point_mont<FB>(lp, kb), R = load_point_mont<FB>(lp + 16, kb);
+        sp.absorb(L.x); sp.absorb(L.y);                     // infinity is (0,0): absorbs two zeros, as upstream
+        sp.absorb(R.x); sp.absorb(R.y);
+        fe_t sq = fe_from_mont<FB>(sp.squeeze());
+        uint64_t lo = (uint64_t)sq.v[0] | ((uint64_t)sq.v[1] << 32), hi = (uint64_t)sq.v[2] | ((uint64_t)sq.v[3] << 32);
+        fe_t chal = challenge_to_field<FS>(lo, hi, ks);
+        store_fe(out_chals + ((size_t)b * k + j) * 8, fe_from_mont<FS>(chal));
+        pts[4 + 2 * j] = L; pts[5 + 2 * j] = R;
+    }
+    const affine_t D = load_point_mont<FB>(delta + (size_t)b * 16, kb);
+    sp.absorb(D.x); sp.absorb(D.y);
+    fe_t c;
+    {
+        fe_t sq = fe_from_mont<FB>(sp.squeeze());
+        uint64_t lo = (uint64_t)sq.v[0] | ((uint64_t)sq.v[1] << 32), hi = (uint64_t)sq.v[2] | ((uint64_t)sq.v[3] << 32);
+        c = challenge_to_field<FS>(lo, hi, ks);
+    }
+
+    // b0 = sum_p r^p * b_poly(chal, pt_p)
+    const fe_t r = fe_to_mont<FS>(load_fe<FS>(evalscale + (size_t)b * 8), ks.r2);
+    fe_t b0 = fe_zero(), scale = ks.one;
+    for (uint32_t p = 0; p < sh.npts; ++p) {
+        fe_t pw = fe_to_mont<FS>(load_fe<FS>(evalpoints + ((size_t)b * sh.npts + p) * 8), ks.r2), acc = ks.one;
+        for (int i = (int)k - 1; i >= 0; --i) {
+            fe_t ch = fe_to_mont<FS>(load_fe<FS>(out_chals + ((size_t)b * k + i) * 8), ks.r2);
+            acc = fe_mul<FS>(acc, fe_add<FS>(ks.one, fe_mul<FS>(ch, pw)));
+            pw = fe_sqr<FS>(pw);
+        }
+        b0 = fe_add<FS>(b0, fe_mul<FS>(scale, acc));
+        scale = fe_mul<FS>(scale, r);
+    }
+
+    const fe_t z1m = fe_to_mont<FS>(load_fe<FS>(z1 + (size_t)b * 8), ks.r2);
+    const fe_t z2m = fe_to_mont<FS>(load_fe<FS>(z2 + (size_t)b * 8), ks.r2);
+    const fe_t neg_rho = fe_neg<FS>(rho);
+    const fe_t rho_c = fe_mul<FS>(rho, c);
+
+    pts[0] = *srs_h;                         store_fe(scs + 0 * 8, fe_from_mont<FS>(fe_mul<FS>(neg_rho, z2m)));
+    pts[1] = load_point_mont<FB>(sg + (size_t)b * 16, kb);
+    store_fe(scs + 1 * 8, fe_from_mont<FS>(fe_sub<FS>(fe_mul<FS>(neg_rho, z1m), sigma)));
+    pts[2] = U;
+    store_fe(scs + 2 * 8, fe_from_mont<FS>(fe_add<FS>(fe_mul<FS>(fe_mul<FS>(neg_rho, z1m), b0), fe_mul<FS>(rho_c, cip_m))));
+    pts[3] = D;                              store_fe(scs + 3 * 8, fe_from_mont<FS>(rho));
+    for (uint32_t j = 0; j < k; ++j) {
+        fe_t ch = fe_to_mont<FS>(load_fe<FS>(out_chals + ((size_t)b * k + j) * 8), ks.r2);
+        store_fe(scs + (size_t)(4 + 2 * j) * 8, fe_from_mont<FS>(fe_mul<FS>(rho_c, fe_inv<FS>(ch, ks))));
+        store_fe(scs + (size_t)(5 + 2 * j) * 8, fe_from_mont<FS>(fe_mul<FS>(rho_c, ch)));
+    }
+    const fe_t xi = fe_to_mont<FS>(load_fe<FS>(polyscale + (size_t)b * 8), ks.r2);
+    fe_t xi_i = ks.one;
+    for (uint32_t i = 0; i < sh.ncomms; ++i) {
+        pts[4 + 2 * k + i] = load_point_mont<FB>(comms + ((size_t)b * sh.ncomms + i) * 16, kb);
+        store_fe(scs + (size_t)(4 + 2 * k + i) * 8, fe_from_mont<FS>(fe_mul<FS>(rho_c, xi_i)));
+        xi_i = fe_mul<FS>(xi_i, xi);
+    }
+    store_fe(out_sigma + (size_t)b * 8, fe_from_mont<FS>(sigma));
+}
+
+// verdict[0] = 1 iff  A + sign * B == identity  (sign = +1: A == -B ; sign = -1: A == B)
+template <int F>
+__global__ void xyzz_compare_kernel(const xyzz_t *__restrict__ a, const xyzz_t *__restrict__ b, int negate_b, uint32_t *__restrict__ verdict) {
+    if (threadIdx.x || blockIdx.x) return;
+    xyzz_t A = *a, B = *b;
+    if (negate_b) B.y = fe_neg<F>(B.y);
+    bool ai = xyzz_is_inf(A), bi = xyzz_is_inf(B), eq;
+    if (ai || bi) eq = ai && bi;
+    else eq = fe_eq(fe_mul<F>(A.x, B.zz), fe_mul<F>(B.x, A.zz)) && fe_eq(fe_mul<F>(A.y, B.zzz), fe_mul<F>(B.y, A.zzz));
+    *verdict = eq ? 1u : 0u;
+}
+
+// A (xyzz) == affine point q (canonical words; zeros = infinity) ?
+template <int F>
+__global__ void xyzz_eq_affine_kernel(const xyzz_t *__restrict__ a, const uint32_t *__restrict__ q_words, fe_t r2, uint32_t *__restrict__ verdict) {
+    if (threadIdx.x || blockIdx.x) return;
+    xyzz_t A = *a;
+    fe_t qx = fe_to_mont<F>(load_fe<F>(q_words), r2), qy = fe_to_mont<F>(load_fe<F>(q_words + 8), r2);
+    bool qi = fe_is_zero(qx) && fe_is_zero(qy), ai = xyzz_is_inf(A), eq;
+    if (ai || qi) eq = ai && qi;
+    else eq = fe_eq(fe_mul<F>(qx, A.zz), A.x) && fe_eq(fe_mul<F>(qy, A.zzz), A.y);
+    *verdict = eq ? 1u : 0u;
+}
+
+}  // namespace mb
+
+// ------------------------------------------------------------------------------------------------
+// a10: accumulator check
+static int accumulator_check_dev(mina_ctx *c, int curve, uint32_t k, size_t batch, const uint32_t *d_prechal,
+                                 const uint32_t *d_sg_words, const uint32_t *d_rho, uint32_t *d_verdict) {
+    SrsState &s = c->srs[curve];
+    if (s.depth == 0) return fail(MINA_ERR_STATE, "SRS not loaded for this curve");
+    if (k < 1 || k > 20 || ((size_t)1 << k) > s.depth) return fail(MINA_ERR_ARG, "2^k exceeds the SRS depth");
+    const int FS = scalar_field_of(curve), FB = base_field_of(curve);
+    const uint32_t n = 1u << k;
+    int rc;
+    if ((rc = c->ipa_chals.ensure(batch * k * 32))) return rc;
+    if ((rc = c->ipa_folded.ensure((size_t)n * 32))) return rc;
+    if ((rc = c->ipa_xyzz_a.ensure(sizeof(xyzz_t)))) return rc;
+    if ((rc = c->ipa_xyzz_b.ensure(sizeof(xyzz_t)))) return rc;
+    DISPATCH_FIELD(FS, { challenge_to_field_kernel<F_><<<cdiv(batch * k, 64), 64, 0, c->stream>>>((uint32_t)(batch * k), c->fk[F_], d_prechal, c->ipa_chals.as<uint32_t>()); });
+    if ((rc = mina_b_poly_fold_dev(c, FS, k, batch, c->ipa_chals.p, batch > 1 ? d_rho : nullptr, c->ipa_folded.p))) return rc;
+    if ((rc = mb_msm_fixed(c, curve, n, c->ipa_folded.as<uint32_t>(), nullptr, c->ipa_xyzz_a.p))) return rc;
+    if (batch == 1) {
+        DISPATCH_FIELD(FB, { xyzz_eq_affine_kernel<F_><<<1, 64, 0, c->stream>>>(c->ipa_xyzz_a.as<xyzz_t>(), d_sg_words, c->fk[F_].r2, d_verdict); });
+    } else {
+        if ((rc = c->ipa_points.ensure(batch * sizeof(affine_t)))) return rc;
+        DISPATCH_FIELD(FB, { points_to_mont_kernel<F_><<<cdiv(batch, 256), 256, 0, c->stream>>>((uint32_t)batch, d_sg_words, c->fk[F_].r2, c->ipa_points.as<affine_t>()); });
+        if ((rc = mb_msm_variable(c, curve, (uint32_t)batch, d_rho, c->ipa_points.p, nullptr, c->ipa_xyzz_b.p))) return rc;
+        DISPATCH_FIELD(FB, { xyzz_compare_kernel<F_><<<1, 64, 0, c->stream>>>(c->ipa_xyzz_a.as<xyzz_t>(), c->ipa_xyzz_b.as<xyzz_t>(), 0, d_verdict); });
+    }
+    HIPC(hipGetLastError());
+    return MINA_OK;
+}
+
+extern "C" int mina_accumulator_check_dev(mina_ctx *c, int curve, uint32_t k, size_t batch, const void *d_prechallenges,
+                                          const void *d_sg, const void *d_rho, void *d_verdict) {
+    if (!c || !d_prechallenges || !d_sg || !d_verdict || (batch > 1 && !d_rho)) return fail(MINA_ERR_ARG, "null argument");
+    if (curve != 0 && curve != 1) return fail(MINA_ERR_ARG, "bad curve");
+    if (batch == 0 || batch > (1u << 20)) return fail(MINA_ERR_ARG, "bad batch");
+    HIPC(hipSetDevice(c->device));
+    return accumulator_check_dev(c, curve, k, batch, (const uint32_t *)d_prechallenges, (const uint32_t *)d_sg, (const uint32_t *)d_rho, (uint32_t *)d_verdict);
+}
+
+extern "C" int mina_accumulator_check_batch(mina_ctx *c, int curve, uint32_t k, size_t batch, const uint8_t *prechallenges,
+                                            const uint8_t *sg, const uint8_t *rho, uint8_t *verdicts) {
+    if (!c || !prechallenges || !sg || !verdicts || (batch > 1 && !rho)) return fail(MINA_ERR_ARG, "null argument");
+    if (curve != 0 && curve != 1) return fail(MINA_ERR_ARG, "bad curve");
+    if (batch == 0 || batch > (1u << 20)) return fail(MINA_ERR_ARG, "bad batch");
+    HIPC(hipSetDevice(c->device));
+    int rc;
+    if ((rc = h2d(c, c->ipa_in_a, prechallenges, batch * k * 16))) return rc;
+    if ((rc = h2d(c, c->ipa_in_b, sg, batch * 64))) return rc;
+    if (batch > 1 && (rc = h2d(c, c->ipa_in_c, rho, batch * 32))) return rc;
+    if ((rc = c->ipa_verdict.ensure(4))) return rc;
+    if ((rc = accumulator_check_dev(c, curve, k, batch, c->ipa_in_a.as<uint32_t>(), c->ipa_in_b.as<uint32_t>(),
+                                    batch > 1 ? c->ipa_in_c.as<uint32_t>() : nullptr, c->ipa_verdict.as<uint32_t>()))) return rc;
+    uint32_t v = 0;
+    if ((rc = d2h_sync(c, &v, c->ipa_verdict, 4))) return rc;
+    if (v || batch == 1) { memset(verdicts, v ? 1 : 0, batch); return MINA_OK; }
+    // the folded check failed: find the culprits one proof at a time (rare path)
+    for (size_t b = 0; b < batch; ++b) {
+        if ((rc = accumulator_check_dev(c, curve, k, 1, c->ipa_in_a.as<uint32_t>() + b * k * 4, c->ipa_in_b.as<uint32_t>() + b * 16,
+                                        nullptr, c->ipa_verdict.as<uint32_t>()))) return rc;
+        if ((rc = d2h_sync(c, &v, c->ipa_verdict, 4))) return rc;
+        verdicts[b] = v ? 1 : 0;
+    }
+    return MINA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// a8: combined opening check
+extern "C" int mina_ipa_batch_check(mina_ctx *c, int curve, size_t batch, const mina_ipa_opening *op, const uint8_t *rand_base,
+                                    const uint8_t *sg_rand_base, uint8_t *verdict) {
+    if (!c || !op || !rand_base || !sg_rand_base || !verdict) return fail(MINA_ERR_ARG, "null argument");
+    if (curve != 0 && curve != 1) return fail(MINA_ERR_ARG, "bad curve");
+    if (batch == 0 || batch > (1u << 16)) return fail(MINA_ERR_ARG, "bad batch");
+    SrsState &s = c->srs[curve];
+    if (s.depth == 0) return fail(MINA_ERR_STATE, "SRS not loaded for this curve");
+    const int FB = base_field_of(curve), FS = scalar_field_of(curve);
+    if (!c->have_pparams[FB]) return fail(MINA_ERR_STATE, "Poseidon constants not installed for the base field");
+    const uint32_t k = op[0].k, npts = op[0].n_evalpoints, m = op[0].n_comms;
+    if (k < 1 || k > 20 || ((size_t)1 << k) > s.depth) return fail(MINA_ERR_ARG, "2^k exceeds the SRS depth");
+    for (size_t b = 0; b < batch; ++b) {
+        const mina_ipa_opening &o = op[b];
+        if (o.k != k || o.n_evalpoints != npts || o.n_comms != m) return fail(MINA_ERR_ARG, "openings of one batch must share k, n_evalpoints, n_comms");
+        if (!o.lr || !o.delta || !o.sg || !o.z1 || !o.z2 || !o.combined_inner_product || !o.polyscale || !o.evalscale || !o.sponge_state ||
+            (npts && !o.evalpoints) || (m && !o.comms)) return fail(MINA_ERR_ARG, "null field in opening");
+    }
+    HIPC(hipSetDevice(c->device));
+    mb::IpaShape sh; sh.batch = (uint32_t)batch; sh.k = k; sh.npts = npts; sh.ncomms = m; sh.per = 2 * k + m + 4;
+
+    // pack (host) -> one staging blob -> HBM
+    const size_t o_state = 0, o_cip = o_state + batch * 96, o_lr = o_cip + batch * 32, o_delta = o_lr + batch * 2 * k * 64,
+                 o_sg = o_delta + batch * 64, o_z1 = o_sg + batch * 64, o_z2 = o_z1 + batch * 32, o_pts = o_z2 + batch * 32,
+                 o_r = o_pts + batch * npts * 32, o_xi = o_r + batch * 32, o_comms = o_xi + batch * 32, o_rb = o_comms + batch * m * 64,
+                 o_sb = o_rb + 32, o_pos = o_sb + 32, total = o_pos + batch * 8;
+    std::vector<uint8_t> blob(total);
+    for (size_t b = 0; b < batch; ++b) {
+        const mina_ipa_opening &o = op[b];
+        memcpy(&blob[o_state + b * 96], o.sponge_state, 96);
+        memcpy(&blob[o_cip + b * 32], o.combined_inner_product, 32);
+        { uint32_t pos[2] = {o.sponge_mode, o.sponge_count}; memcpy(&blob[o_pos + b * 8], pos, 8); }
+        if (o.sponge_mode > 1 || o.sponge_count > 2) return fail(MINA_ERR_ARG, "bad sponge position");
+        memcpy(&blob[o_lr + b * 2 * k * 64], o.lr, (size_t)2 * k * 64);
+        memcpy(&blob[o_delta + b * 64], o.delta, 64);
+        memcpy(&blob[o_sg + b * 64], o.sg, 64);
+        memcpy(&blob[o_z1 + b * 32], o.z1, 32);
+        memcpy(&blob[o_z2 + b * 32], o.z2, 32);
+        if (npts) memcpy(&blob[o_pts + b * npts * 32], o.evalpoints, (size_t)npts * 32);
+        memcpy(&blob[o_r + b * 32], o.evalscale, 32);
+        memcpy(&blob[o_xi + b * 32], o.polyscale, 32);
+        if (m) memcpy(&blob[o_comms + b * m * 64], o.comms, (size_t)m * 64);
+    }
+    memcpy(&blob[o_rb], rand_base, 32);
+    memcpy(&blob[o_sb], sg_rand_base, 32);
+    int rc;
+    if ((rc = h2d(c, c->ipa_in_a, blob.data(), total))) return rc;
+    const uint8_t *d = c->ipa_in_a.as<uint8_t>();
+    auto W = [&](size_t off) { return reinterpret_cast<const uint32_t *>(d + off); };
+    const size_t npoints = batch * sh.per;
+    if ((rc = c->ipa_points.ensure(npoints * sizeof(affine_t)))) return rc;
+    if ((rc = c->ipa_scalars.ensure(npoints * 32))) return rc;
+    if ((rc = c->ipa_chals.ensure(batch * k * 32))) return rc;
+    if ((rc = c->ipa_sigma.ensure(batch * 32))) return rc;
+    if ((rc = c->ipa_folded.ensure(((size_t)1 << k) * 32))) return rc;
+    if ((rc = c->ipa_xyzz_a.ensure(sizeof(xyzz_t)))) return rc;
+    if ((rc = c->ipa_xyzz_b.ensure(sizeof(xyzz_t)))) return rc;
+    if ((rc = c->ipa_verdict.ensure(4))) return rc;
+    const PoseidonParams *pp = c->pparams[FB].as<PoseidonParams>();
+#define IPA_PREP(CV)                                                                                                          \
+    mb::ipa_prepare_kernel<CV><<<cdiv(batch, 64), 64, 0, c->stream>>>(                                                         \
+        sh, c->fk[FB], c->fk[FS], pp, W(o_state), W(o_pos), W(o_cip), W(o_lr), W(o_delta), W(o_sg), W(o_z1), W(o_z2), W(o_pts), W(o_r), \
+        W(o_xi), W(o_comms), W(o_rb), W(o_sb), s.h.as<affine_t>(), c->ipa_points.as<affine_t>(), c->ipa_scalars.as<uint32_t>(), \
+        c->ipa_chals.as<uint32_t>(), c->ipa_sigma.as<uint32_t>())
+    if (curve == CURVE_PALLAS) IPA_PREP(CURVE_PALLAS); else IPA_PREP(CURVE_VESTA);
+#undef IPA_PREP
+    HIPC(hipGetLastError());
+    if ((rc = mina_b_poly_fold_dev(c, FS, k, batch, c->ipa_chals.p, c->ipa_sigma.p, c->ipa_folded.p))) return rc;
+    if ((rc = mb_msm_fixed(c, curve, 1u << k, c->ipa_folded.as<uint32_t>(), nullptr, c->ipa_xyzz_a.p))) return rc;
+    if ((rc = mb_msm_variable(c, curve, (uint32_t)npoints, c->ipa_scalars.as<uint32_t>(), c->ipa_points.p, nullptr, c->ipa_xyzz_b.p))) return rc;
+    DISPATCH_FIELD(FB, { xyzz_compare_kernel<F_><<<1, 64, 0, c->stream>>>(c->ipa_xyzz_a.as<xyzz_t>(), c->ipa_xyzz_b.as<xyzz_t>(), 1, c->ipa_verdict.as<uint32_t>()); });
+    uint32_t v = 0;
+    if ((rc = d2h_sync(c, &v, c->ipa_verdict, 4))) return rc;
+    *verdict = v ? 1 : 0;
+    return MINA_OK;
+}

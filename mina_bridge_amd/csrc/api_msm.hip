@@ -1,0 +1,129 @@
+// api_msm.hip -- K1 host driver: queues the MSM kernel pipeline of msm.cuh on the context stream.
+#include "ctx.h"
+#include "msm.cuh"
+
+// ------------------------------------------------------------------------------------------------
+// MSM driver
+static MsmShape fixed_shape(const SrsState &s, uint32_t n) {
+    MsmShape sh; sh.n = n; sh.c = s.c; sh.W = s.W; sh.NB = 1u << (s.c - 1); sh.nsets = 1; sh.table_stride = s.depth; return sh;
+}
+static MsmShape variable_shape(uint32_t n) {
+    MsmShape sh; sh.n = n;
+    sh.c = n < 2048 ? 8 : (n < 32768 ? 11 : 14);
+    sh.W = (256 + sh.c - 1) / sh.c; sh.NB = 1u << (sh.c - 1); sh.nsets = sh.W; sh.table_stride = 0; return sh;
+}
+
+template <int F>
+static int run_msm(mina_ctx *c, const MsmShape &sh, const uint32_t *d_scalars, const affine_t *d_points,
+                   uint32_t *d_out_words /* 17 words */, xyzz_t *d_out_xyzz) {
+    MsmWorkspace &w = c->ws;
+    const FieldK &fk = c->fk[F];
+    const uint32_t nb_total = sh.NB * sh.nsets;
+    const size_t entries = (size_t)sh.n * sh.W;
+    const size_t max_tasks = entries / MSM_TASK_LEN + nb_total + 1;
+    const uint32_t groups = nb_total / 64;
+    int rc;
+    if ((rc = w.ekey.ensure(entries * 4))) return rc;
+    if ((rc = w.eval.ensure(entries * 4))) return rc;
+    if ((rc = w.eoff.ensure(entries * 4))) return rc;
+    if ((rc = w.sorted.ensure(entries * 4))) return rc;
+    if ((rc = w.count.ensure((size_t)nb_total * 4))) return rc;
+    if ((rc = w.start.ensure(((size_t)nb_total + 1) * 4))) return rc;
+    if ((rc = w.task_start.ensure(((size_t)nb_total + 1) * 4))) return rc;
+    if ((rc = w.partial.ensure(max_tasks * sizeof(xyzz_t)))) return rc;
+    if ((rc = w.buckets.ensure((size_t)nb_total * sizeof(xyzz_t)))) return rc;
+    if ((rc = w.red_r.ensure((size_t)groups * sizeof(xyzz_t)))) return rc;
+    if ((rc = w.red_ws.ensure((size_t)groups * sizeof(xyzz_t)))) return rc;
+    if ((rc = w.set_total.ensure((size_t)sh.nsets * sizeof(xyzz_t)))) return rc;
+
+    hipStream_t st = c->stream;
+    HIPC(hipMemsetAsync(w.count.p, 0, (size_t)nb_total * 4, st));
+    msm_digits_kernel<<<cdiv(sh.n, 256), 256, 0, st>>>(sh, d_scalars, w.count.as<uint32_t>(), w.ekey.as<uint32_t>(),
+                                                       w.eval.as<uint32_t>(), w.eoff.as<uint32_t>());
+    msm_scan_kernel<<<1, 1024, 0, st>>>(nb_total, w.count.as<uint32_t>(), w.start.as<uint32_t>(), w.task_start.as<uint32_t>());
+    msm_scatter_kernel<<<cdiv(entries, 256), 256, 0, st>>>(entries, w.ekey.as<uint32_t>(), w.eval.as<uint32_t>(),
+                                                           w.eoff.as<uint32_t>(), w.start.as<uint32_t>(), w.sorted.as<uint32_t>());
+    msm_accumulate_kernel<F><<<cdiv(max_tasks, 256), 256, 0, st>>>(nb_total, w.start.as<uint32_t>(), w.task_start.as<uint32_t>(),
+                                                                   w.sorted.as<uint32_t>(), d_points, fk.one, w.partial.as<xyzz_t>());
+    msm_bucket_sum_kernel<F><<<cdiv(nb_total, 256), 256, 0, st>>>(nb_total, w.task_start.as<uint32_t>(), w.partial.as<xyzz_t>(),
+                                                                  w.buckets.as<xyzz_t>());
+    msm_reduce_a_kernel<F><<<groups, 64, 0, st>>>(nb_total, w.buckets.as<xyzz_t>(), w.red_r.as<xyzz_t>(), w.red_ws.as<xyzz_t>());
+    msm_reduce_bc_kernel<F><<<sh.nsets, 64, 0, st>>>(sh.NB / 64, w.red_r.as<xyzz_t>(), w.red_ws.as<xyzz_t>(), w.set_total.as<xyzz_t>());
+    msm_finish_kernel<F><<<1, 64, 0, st>>>(sh.nsets, sh.c, w.set_total.as<xyzz_t>(), fk.one, fk.pm2, d_out_xyzz, d_out_words);
+    HIPC(hipGetLastError());
+    return MINA_OK;
+}
+
+static void words_to_point_bytes(const uint32_t w[17], uint8_t *out) {
+    if (w[16]) { memset(out, 0, 64); return; }
+    memcpy(out, w, 64);
+}
+
+int mb_msm_fixed(mina_ctx *c, int curve, uint32_t n, const uint32_t *d_scalars, uint32_t *d_out_words, void *d_out_xyzz) {
+    SrsState &s = c->srs[curve];
+    if (s.depth == 0) return fail(MINA_ERR_STATE, "SRS not loaded for this curve");
+    if (n == 0 || n > s.depth) return fail(MINA_ERR_ARG, "n must be in 1..depth");
+    MsmShape sh = fixed_shape(s, n);
+    int rc = MINA_OK;
+    DISPATCH_FIELD(base_field_of(curve), { rc = run_msm<F_>(c, sh, d_scalars, s.table.as<affine_t>(), d_out_words, (xyzz_t *)d_out_xyzz); });
+    return rc;
+}
+
+int mb_msm_variable(mina_ctx *c, int curve, uint32_t n, const uint32_t *d_scalars, const void *d_points_mont,
+                    uint32_t *d_out_words, void *d_out_xyzz) {
+    if (n == 0) return fail(MINA_ERR_ARG, "n must be positive");
+    MsmShape sh = variable_shape(n);
+    int rc = MINA_OK;
+    DISPATCH_FIELD(base_field_of(curve), { rc = run_msm<F_>(c, sh, d_scalars, (const affine_t *)d_points_mont, d_out_words, (xyzz_t *)d_out_xyzz); });
+    return rc;
+}
+
+extern "C" int mina_msm(mina_ctx *c, int curve, size_t n, const uint8_t *bases, const uint8_t *scalars, uint8_t *out) {
+    if (!c || !out || (n && (!bases || !scalars))) return fail(MINA_ERR_ARG, "null argument");
+    if (curve != 0 && curve != 1) return fail(MINA_ERR_ARG, "bad curve");
+    if (n == 0) { memset(out, 0, 64); return MINA_OK; }
+    if (n > (1u << 24)) return fail(MINA_ERR_ARG, "n too large");
+    HIPC(hipSetDevice(c->device));
+    int rc;
+    MsmWorkspace &w = c->ws;
+    if ((rc = w.scalars.ensure(n * 32))) return rc;
+    if ((rc = w.points.ensure(n * sizeof(affine_t)))) return rc;
+    if ((rc = c->tmp_a.ensure(n * 64))) return rc;
+    if ((rc = w.out_words.ensure(17 * 4))) return rc;
+    HIPC(hipMemcpyAsync(w.scalars.p, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
+    HIPC(hipMemcpyAsync(c->tmp_a.p, bases, n * 64, hipMemcpyHostToDevice, c->stream));
+    DISPATCH_FIELD(base_field_of(curve), {
+        points_to_mont_kernel<F_><<<cdiv(n, 256), 256, 0, c->stream>>>((uint32_t)n, c->tmp_a.as<uint32_t>(), c->fk[F_].r2, w.points.as<affine_t>());
+    });
+    if ((rc = mb_msm_variable(c, curve, (uint32_t)n, w.scalars.as<uint32_t>(), w.points.p, w.out_words.as<uint32_t>(), nullptr))) return rc;
+    uint32_t hw[17];
+    HIPC(hipMemcpyAsync(hw, w.out_words.p, sizeof hw, hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    words_to_point_bytes(hw, out);
+    return MINA_OK;
+}
+
+extern "C" int mina_msm_srs_dev(mina_ctx *c, int curve, size_t n, const void *d_scalars, void *d_out) {
+    if (!c || !d_scalars || !d_out) return fail(MINA_ERR_ARG, "null argument");
+    if (curve != 0 && curve != 1) return fail(MINA_ERR_ARG, "bad curve");
+    if (n > 0xffffffffu) return fail(MINA_ERR_ARG, "n too large");
+    HIPC(hipSetDevice(c->device));
+    return mb_msm_fixed(c, curve, (uint32_t)n, (const uint32_t *)d_scalars, (uint32_t *)d_out, nullptr);
+}
+
+extern "C" int mina_msm_srs(mina_ctx *c, int curve, size_t n, const uint8_t *scalars, uint8_t *out) {
+    if (!c || !out || (n && !scalars)) return fail(MINA_ERR_ARG, "null argument");
+    if (curve != 0 && curve != 1) return fail(MINA_ERR_ARG, "bad curve");
+    if (n == 0) { memset(out, 0, 64); return MINA_OK; }
+    HIPC(hipSetDevice(c->device));
+    int rc;
+    if ((rc = c->ws.scalars.ensure(n * 32))) return rc;
+    if ((rc = c->ws.out_words.ensure(17 * 4))) return rc;
+    HIPC(hipMemcpyAsync(c->ws.scalars.p, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
+    if ((rc = mina_msm_srs_dev(c, curve, n, c->ws.scalars.p, c->ws.out_words.p))) return rc;
+    uint32_t hw[17];
+    HIPC(hipMemcpyAsync(hw, c->ws.out_words.p, sizeof hw, hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    words_to_point_bytes(hw, out);
+    return MINA_OK;
+}

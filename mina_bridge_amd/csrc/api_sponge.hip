@@ -1,0 +1,135 @@
+// api_sponge.hip -- K2 (b_poly) and K3 (Poseidon, endo challenges) entry points.
+#include "ctx.h"
+#include "sponge.cuh"
+
+// ------------------------------------------------------------------------------------------------
+// // K2
+static BpolyShape bp_shape(uint32_t k, size_t batch) { BpolyShape s; s.k = k; s.lb = k / 2; s.hb = k - s.lb; s.batch = (uint32_t)batch; return s; }
+
+template <int F>
+static int run_bpoly_fold(mina_ctx *c, uint32_t k, size_t batch, const uint32_t *d_chals, const uint32_t *d_weights, uint32_t *d_out) {
+    BpolyShape sh = bp_shape(k, batch);
+    const uint32_t nl = 1u << sh.lb, nh = 1u << sh.hb, n = 1u << k;
+    const uint32_t lo_blocks = cdiv(nl, 256), hi_tiles = cdiv(nh, BP_HT);
+    uint32_t slices = 1;
+    // enough blocks to fill 256 CUs x 4 when the batch is large
+    while (slices * 2 <= batch && (size_t)lo_blocks * hi_tiles * slices < 2048 && slices < 64) slices *= 2;
+    int rc;
+    if ((rc = c->bp_ltab.ensure(batch * nl * sizeof(fe_t)))) return rc;
+    if ((rc = c->bp_htab.ensure(batch * nh * sizeof(fe_t)))) return rc;
+    if ((rc = c->bp_partial.ensure((size_t)slices * n * sizeof(fe_t)))) return rc;
+    bpoly_tables_kernel<F><<<cdiv(batch * (nl + nh), 256), 256, 0, c->stream>>>(sh, c->fk[F], d_chals, d_weights, c->bp_ltab.as<fe_t>(), c->bp_htab.as<fe_t>());
+    bpoly_fold_kernel<F><<<lo_blocks * hi_tiles * slices, 256, 0, c->stream>>>(sh, slices, c->bp_ltab.as<fe_t>(), c->bp_htab.as<fe_t>(), c->bp_partial.as<fe_t>());
+    bpoly_finish_kernel<F><<<cdiv(n, 256), 256, 0, c->stream>>>(n, slices, c->bp_partial.as<fe_t>(), d_out);
+    HIPC(hipGetLastError());
+    return MINA_OK;
+}
+
+extern "C" int mina_b_poly_fold_dev(mina_ctx *c, int field, uint32_t k, size_t batch, const void *d_chals, const void *d_weights, void *d_out) {
+    if (!c || !d_chals || !d_out) return fail(MINA_ERR_ARG, "null argument");
+    if (bad_field(field)) return fail(MINA_ERR_ARG, "bad field");
+    if (k < 1 || k > 20 || batch == 0 || batch > (1u << 24)) return fail(MINA_ERR_ARG, "bad k or batch");
+    HIPC(hipSetDevice(c->device));
+    int rc = MINA_OK;
+    DISPATCH_FIELD(field, { rc = run_bpoly_fold<F_>(c, k, batch, (const uint32_t *)d_chals, (const uint32_t *)d_weights, (uint32_t *)d_out); });
+    return rc;
+}
+
+extern "C" int mina_b_poly_fold(mina_ctx *c, int field, uint32_t k, size_t batch, const uint8_t *chals, const uint8_t *weights, uint8_t *out) {
+    if (!c || !chals || !out) return fail(MINA_ERR_ARG, "null argument");
+    if (bad_field(field)) return fail(MINA_ERR_ARG, "bad field");
+    if (k < 1 || k > 20 || batch == 0) return fail(MINA_ERR_ARG, "bad k or batch");
+    HIPC(hipSetDevice(c->device));
+    int rc;
+    if ((rc = h2d(c, c->tmp_a, chals, batch * k * 32))) return rc;
+    if (weights && (rc = h2d(c, c->tmp_b, weights, batch * 32))) return rc;
+    if ((rc = c->tmp_c.ensure(((size_t)1 << k) * 32))) return rc;
+    if ((rc = mina_b_poly_fold_dev(c, field, k, batch, c->tmp_a.p, weights ? c->tmp_b.p : nullptr, c->tmp_c.p))) return rc;
+    return d2h_sync(c, out, c->tmp_c, ((size_t)1 << k) * 32);
+}
+
+extern "C" int mina_b_poly_coefficients(mina_ctx *c, int field, uint32_t k, const uint8_t *chals, uint8_t *out) {
+    return mina_b_poly_fold(c, field, k, 1, chals, nullptr, out);
+}
+
+extern "C" int mina_b_poly(mina_ctx *c, int field, uint32_t k, const uint8_t *chals, size_t npoints, const uint8_t *xs, uint8_t *out) {
+    if (!c || !chals || (npoints && (!xs || !out))) return fail(MINA_ERR_ARG, "null argument");
+    if (bad_field(field)) return fail(MINA_ERR_ARG, "bad field");
+    if (k < 1 || k > 32) return fail(MINA_ERR_ARG, "bad k");
+    if (npoints == 0) return MINA_OK;
+    HIPC(hipSetDevice(c->device));
+    int rc;
+    if ((rc = h2d(c, c->tmp_a, chals, (size_t)k * 32))) return rc;
+    if ((rc = h2d(c, c->tmp_b, xs, npoints * 32))) return rc;
+    if ((rc = c->tmp_c.ensure(npoints * 32))) return rc;
+    DISPATCH_FIELD(field, { bpoly_eval_kernel<F_><<<cdiv(npoints, 64), 64, 0, c->stream>>>(k, (uint32_t)npoints, c->fk[F_], c->tmp_a.as<uint32_t>(), c->tmp_b.as<uint32_t>(), c->tmp_c.as<uint32_t>()); });
+    return d2h_sync(c, out, c->tmp_c, npoints * 32);
+}
+
+// ------------------------------------------------------------------------------------------------
+// // K3
+template <int F> static void params_to_mont(const uint8_t *params, const FieldK &fk, PoseidonParams &pp) {
+    auto load = [&](size_t idx) { fe_t w; memcpy(w.v, params + idx * 32, 32); return fe_to_mont<F>(w, fk.r2); };
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) pp.mds[i][j] = load(3 * i + j);
+    for (int r = 0; r < 55; ++r) for (int j = 0; j < 3; ++j) pp.rc[r][j] = load(9 + 3 * r + j);
+}
+
+extern "C" int mina_poseidon_set_params(mina_ctx *c, int field, const uint8_t *params) {
+    if (!c || !params) return fail(MINA_ERR_ARG, "null argument");
+    if (bad_field(field)) return fail(MINA_ERR_ARG, "bad field");
+    HIPC(hipSetDevice(c->device));
+    PoseidonParams pp;
+    DISPATCH_FIELD(field, { params_to_mont<F_>(params, c->fk[F_], pp); });
+    int rc;
+    if ((rc = c->pparams[field].ensure(sizeof pp))) return rc;
+    HIPC(hipMemcpyAsync(c->pparams[field].p, &pp, sizeof pp, hipMemcpyHostToDevice, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    c->have_pparams[field] = true;
+    return MINA_OK;
+}
+
+extern "C" int mina_poseidon_permute_dev(mina_ctx *c, int field, size_t n, void *d_states) {
+    if (!c || !d_states) return fail(MINA_ERR_ARG, "null argument");
+    if (bad_field(field)) return fail(MINA_ERR_ARG, "bad field");
+    if (!c->have_pparams[field]) return fail(MINA_ERR_STATE, "Poseidon constants not installed for this field");
+    if (n == 0) return MINA_OK;
+    HIPC(hipSetDevice(c->device));
+    DISPATCH_FIELD(field, { poseidon_permute_kernel<F_><<<cdiv(n, 256), 256, 0, c->stream>>>((uint32_t)n, c->fk[F_], c->pparams[field].as<PoseidonParams>(), (uint32_t *)d_states); });
+    HIPC(hipGetLastError());
+    return MINA_OK;
+}
+
+extern "C" int mina_poseidon_permute(mina_ctx *c, int field, size_t n, uint8_t *states) {
+    if (!c || (n && !states)) return fail(MINA_ERR_ARG, "null argument");
+    if (n == 0) return MINA_OK;
+    int rc;
+    HIPC(hipSetDevice(c->device));
+    if ((rc = h2d(c, c->tmp_a, states, n * 96))) return rc;
+    if ((rc = mina_poseidon_permute_dev(c, field, n, c->tmp_a.p))) return rc;
+    return d2h_sync(c, states, c->tmp_a, n * 96);
+}
+
+extern "C" int mina_poseidon_hash(mina_ctx *c, int field, size_t n, size_t len, const uint8_t *inputs, uint8_t *out) {
+    if (!c || (n && !out) || (n && len && !inputs)) return fail(MINA_ERR_ARG, "null argument");
+    if (bad_field(field)) return fail(MINA_ERR_ARG, "bad field");
+    if (!c->have_pparams[field]) return fail(MINA_ERR_STATE, "Poseidon constants not installed for this field");
+    if (n == 0) return MINA_OK;
+    HIPC(hipSetDevice(c->device));
+    int rc;
+    if ((rc = h2d(c, c->tmp_a, inputs, n * len * 32))) return rc;
+    if ((rc = c->tmp_c.ensure(n * 32))) return rc;
+    DISPATCH_FIELD(field, { poseidon_hash_kernel<F_><<<cdiv(n, 256), 256, 0, c->stream>>>((uint32_t)n, (uint32_t)len, c->fk[F_], c->pparams[field].as<PoseidonParams>(), c->tmp_a.as<uint32_t>(), c->tmp_c.as<uint32_t>()); });
+    return d2h_sync(c, out, c->tmp_c, n * 32);
+}
+
+extern "C" int mina_challenge_to_field(mina_ctx *c, int field, size_t n, const uint8_t *chal128, uint8_t *out) {
+    if (!c || (n && (!chal128 || !out))) return fail(MINA_ERR_ARG, "null argument");
+    if (bad_field(field)) return fail(MINA_ERR_ARG, "bad field");
+    if (n == 0) return MINA_OK;
+    HIPC(hipSetDevice(c->device));
+    int rc;
+    if ((rc = h2d(c, c->tmp_a, chal128, n * 16))) return rc;
+    if ((rc = c->tmp_c.ensure(n * 32))) return rc;
+    DISPATCH_FIELD(field, { challenge_to_field_kernel<F_><<<cdiv(n, 64), 64, 0, c->stream>>>((uint32_t)n, c->fk[F_], c->tmp_a.as<uint32_t>(), c->tmp_c.as<uint32_t>()); });
+    return d2h_sync(c, out, c->tmp_c, n * 32);
+}

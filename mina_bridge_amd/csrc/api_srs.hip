@@ -1,0 +1,143 @@
+// api_srs.hip -- SRS generation / loading / export and the fixed-base window tables (a6).
+#include "ctx.h"
+#include "msm.cuh"
+
+// ------------------------------------------------------------------------------------------------
+// SRS
+template <int F> static int build_tables(mina_ctx *c, SrsState &s) {
+    const FieldK &fk = c->fk[F];
+    msm_build_table_kernel<F><<<cdiv(s.depth, 256), 256, 0, c->stream>>>(s.depth, s.depth, s.c, s.W, fk.one, fk.pm2, s.table.as<affine_t>());
+    HIPC(hipGetLastError());
+    HIPC(hipStreamSynchronize(c->stream));
+    return MINA_OK;
+}
+
+static int srs_alloc(mina_ctx *c, int curve, uint32_t depth) {
+    SrsState &s = c->srs[curve];
+    s.depth = 0; s.c = 16; s.W = 16;
+    int rc;
+    if ((rc = s.table.ensure((size_t)s.W * depth * sizeof(affine_t)))) return rc;
+    if ((rc = s.h.ensure(sizeof(affine_t)))) return rc;
+    return MINA_OK;
+}
+
+extern "C" int mina_srs_create(mina_ctx *c, int curve, uint32_t depth) {
+    if (!c) return fail(MINA_ERR_ARG, "null ctx");
+    if (curve != 0 && curve != 1) return fail(MINA_ERR_ARG, "bad curve");
+    if (depth == 0 || depth > (1u << 20)) return fail(MINA_ERR_ARG, "depth must be in 1..2^20");
+    HIPC(hipSetDevice(c->device));
+    int rc = srs_alloc(c, curve, depth);
+    if (rc) return rc;
+    SrsState &s = c->srs[curve];
+    const int F = base_field_of(curve);
+    DISPATCH_FIELD(F, {
+        srs_create_kernel<F_><<<cdiv((size_t)depth + 1, 256), 256, 0, c->stream>>>(depth, c->fk[F_], s.table.as<affine_t>(), s.h.as<affine_t>());
+    });
+    HIPC(hipGetLastError());
+    s.depth = depth;
+    DISPATCH_FIELD(F, { rc = build_tables<F_>(c, s); });
+    if (rc) s.depth = 0;
+    return rc;
+}
+
+extern "C" int mina_srs_load(mina_ctx *c, int curve, const uint8_t *d, size_t len) {
+    if (!c || !d) return fail(MINA_ERR_ARG, "null argument");
+    if (curve != 0 && curve != 1) return fail(MINA_ERR_ARG, "bad curve");
+    // fixarray(2) [ array32(n) [ bin8(33) ... ], bin8(33) ]
+    if (len < 6 || d[0] != 0x92 || d[1] != 0xdd) return fail(MINA_ERR_FORMAT, "not an SRS MessagePack blob");
+    uint32_t n = ((uint32_t)d[2] << 24) | ((uint32_t)d[3] << 16) | ((uint32_t)d[4] << 8) | d[5];
+    if (n == 0 || n > (1u << 20) || len != 6 + (size_t)(n + 1) * 35) return fail(MINA_ERR_FORMAT, "bad SRS length");
+    std::vector<uint8_t> blobs((size_t)(n + 1) * 33);
+    for (size_t i = 0; i <= n; ++i) {
+        const uint8_t *e = d + 6 + i * 35;
+        if (e[0] != 0xc4 || e[1] != 33) return fail(MINA_ERR_FORMAT, "bad point header");
+        memcpy(&blobs[i * 33], e + 2, 33);
+    }
+    HIPC(hipSetDevice(c->device));
+    int rc = srs_alloc(c, curve, n);
+    if (rc) return rc;
+    SrsState &s = c->srs[curve];
+    if ((rc = c->tmp_a.ensure(blobs.size()))) return rc;
+    if ((rc = c->tmp_b.ensure(4))) return rc;
+    HIPC(hipMemcpyAsync(c->tmp_a.p, blobs.data(), blobs.size(), hipMemcpyHostToDevice, c->stream));
+    HIPC(hipMemsetAsync(c->tmp_b.p, 0, 4, c->stream));
+    const int F = base_field_of(curve);
+    DISPATCH_FIELD(F, {
+        decompress_kernel<F_><<<cdiv(n, 256), 256, 0, c->stream>>>(n, c->fk[F_], c->tmp_a.as<uint8_t>(), s.table.as<affine_t>(), c->tmp_b.as<uint32_t>());
+        decompress_kernel<F_><<<1, 64, 0, c->stream>>>(1, c->fk[F_], c->tmp_a.as<uint8_t>() + (size_t)n * 33, s.h.as<affine_t>(), c->tmp_b.as<uint32_t>());
+    });
+    uint32_t bad = 0;
+    HIPC(hipMemcpyAsync(&bad, c->tmp_b.p, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    if (bad) return fail(MINA_ERR_FORMAT, "SRS contains a point that is not on the curve");
+    s.depth = n;
+    DISPATCH_FIELD(F, { rc = build_tables<F_>(c, s); });
+    if (rc) s.depth = 0;
+    return rc;
+}
+
+extern "C" uint32_t mina_srs_depth(mina_ctx *c, int curve) {
+    if (!c || (curve != 0 && curve != 1)) return 0;
+    return c->srs[curve].depth;
+}
+
+extern "C" int mina_srs_get_g(mina_ctx *c, int curve, uint32_t first, uint32_t count, uint8_t *out) {
+    if (!c || !out) return fail(MINA_ERR_ARG, "null argument");
+    if (curve != 0 && curve != 1) return fail(MINA_ERR_ARG, "bad curve");
+    SrsState &s = c->srs[curve];
+    if (s.depth == 0) return fail(MINA_ERR_STATE, "SRS not loaded");
+    if ((uint64_t)first + count > s.depth) return fail(MINA_ERR_ARG, "range outside SRS");
+    if (count == 0) return MINA_OK;
+    HIPC(hipSetDevice(c->device));
+    int rc;
+    if ((rc = c->tmp_a.ensure((size_t)count * 64))) return rc;
+    const int F = base_field_of(curve);
+    DISPATCH_FIELD(F, { points_from_mont_kernel<F_><<<cdiv(count, 256), 256, 0, c->stream>>>(count, s.table.as<affine_t>() + first, c->tmp_a.as<uint32_t>()); });
+    HIPC(hipMemcpyAsync(out, c->tmp_a.p, (size_t)count * 64, hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    return MINA_OK;
+}
+
+extern "C" int mina_srs_get_h(mina_ctx *c, int curve, uint8_t *out) {
+    if (!c || !out) return fail(MINA_ERR_ARG, "null argument");
+    if (curve != 0 && curve != 1) return fail(MINA_ERR_ARG, "bad curve");
+    SrsState &s = c->srs[curve];
+    if (s.depth == 0) return fail(MINA_ERR_STATE, "SRS not loaded");
+    HIPC(hipSetDevice(c->device));
+    int rc;
+    if ((rc = c->tmp_a.ensure(64))) return rc;
+    const int F = base_field_of(curve);
+    DISPATCH_FIELD(F, { points_from_mont_kernel<F_><<<1, 64, 0, c->stream>>>(1, s.h.as<affine_t>(), c->tmp_a.as<uint32_t>()); });
+    HIPC(hipMemcpyAsync(out, c->tmp_a.p, 64, hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    return MINA_OK;
+}
+
+extern "C" int mina_srs_serialize(mina_ctx *c, int curve, uint8_t *out, size_t cap, size_t *len) {
+    if (!c || !len) return fail(MINA_ERR_ARG, "null argument");
+    if (curve != 0 && curve != 1) return fail(MINA_ERR_ARG, "bad curve");
+    SrsState &s = c->srs[curve];
+    if (s.depth == 0) return fail(MINA_ERR_STATE, "SRS not loaded");
+    const size_t need = 6 + (size_t)(s.depth + 1) * 35;
+    *len = need;
+    if (!out || cap < need) return fail(MINA_ERR_ARG, "output buffer too small");
+    HIPC(hipSetDevice(c->device));
+    int rc;
+    if ((rc = c->tmp_a.ensure((size_t)(s.depth + 1) * 33))) return rc;
+    const int F = base_field_of(curve);
+    DISPATCH_FIELD(F, {
+        compress_kernel<F_><<<cdiv(s.depth, 256), 256, 0, c->stream>>>(s.depth, c->fk[F_], s.table.as<affine_t>(), c->tmp_a.as<uint8_t>());
+        compress_kernel<F_><<<1, 64, 0, c->stream>>>(1, c->fk[F_], s.h.as<affine_t>(), c->tmp_a.as<uint8_t>() + (size_t)s.depth * 33);
+    });
+    std::vector<uint8_t> blobs((size_t)(s.depth + 1) * 33);
+    HIPC(hipMemcpyAsync(blobs.data(), c->tmp_a.p, blobs.size(), hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipStreamSynchronize(c->stream));
+    out[0] = 0x92; out[1] = 0xdd;
+    out[2] = (uint8_t)(s.depth >> 24); out[3] = (uint8_t)(s.depth >> 16); out[4] = (uint8_t)(s.depth >> 8); out[5] = (uint8_t)s.depth;
+    for (size_t i = 0; i <= s.depth; ++i) {
+        uint8_t *e = out + 6 + i * 35;
+        e[0] = 0xc4; e[1] = 33; memcpy(e + 2, &blobs[i * 33], 33);
+    }
+    return MINA_OK;
+}
+

@@ -1,0 +1,92 @@
+// ctx.h -- shared host-side state of libminaverify.so (one mina_ctx = one GPU).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mina_verify.h"
+#include "groupmap.cuh"
+
+using namespace mb;
+
+int mb_fail(int code, const std::string &msg);      // records the thread-local error text, returns code
+#define fail mb_fail
+
+#define HIPC(expr)                                                                                 \
+    do {                                                                                           \
+        hipError_t e__ = (expr);                                                                   \
+        if (e__ != hipSuccess)                                                                     \
+            return fail(MINA_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e__));         \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr; size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return MINA_OK;
+        if (p) { if (hipFree(p) != hipSuccess) return MINA_ERR_HIP; p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 8 + 256;
+        if (hipMalloc(&p, want) != hipSuccess) return fail(MINA_ERR_HIP, "hipMalloc failed");
+        cap = want; return MINA_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() { return reinterpret_cast<T *>(p); }
+};
+
+struct SrsState {
+    uint32_t depth = 0;
+    uint32_t c = 16, W = 16;           // fixed-base window shape
+    DevBuf table;                      // W * depth affine_t; window 0 = g itself
+    DevBuf h;                          // 1 affine_t
+};
+
+struct MsmWorkspace {
+    DevBuf scalars, points, ekey, eval, eoff, count, start, task_start, sorted, partial, buckets, red_r, red_ws, set_total, out_words, out_xyzz;
+};
+
+struct mina_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    FieldK fk[2];
+    SrsState srs[2];
+    MsmWorkspace ws;
+    DevBuf pparams[2]; bool have_pparams[2] = {false, false};
+    DevBuf tmp_a, tmp_b, tmp_c, tmp_d;       // staging for the host-buffer entry points
+    DevBuf bp_ltab, bp_htab, bp_partial;
+    DevBuf ipa_chals, ipa_folded, ipa_xyzz_a, ipa_xyzz_b, ipa_points, ipa_scalars, ipa_sigma, ipa_in_a, ipa_in_b, ipa_in_c, ipa_verdict;
+};
+
+static inline int base_field_of(int curve) { return curve == CURVE_PALLAS ? FIELD_FP : FIELD_FQ; }
+static inline int scalar_field_of(int curve) { return curve == CURVE_PALLAS ? FIELD_FQ : FIELD_FP; }
+static inline bool bad_field(int f) { return f != 0 && f != 1; }
+
+#define DISPATCH_FIELD(field, ...)                           \
+    do { if ((field) == FIELD_FP) { constexpr int F_ = FIELD_FP; __VA_ARGS__; } else { constexpr int F_ = FIELD_FQ; __VA_ARGS__; } } while (0)
+
+static inline uint32_t cdiv(size_t a, size_t b) { return (uint32_t)((a + b - 1) / b); }
+
+
+// small host<->device helpers for the byte-buffer entry points
+static inline int h2d(mina_ctx *c, DevBuf &b, const void *src, size_t bytes) {
+    int rc = b.ensure(bytes ? bytes : 4);
+    if (rc) return rc;
+    if (bytes) HIPC(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, c->stream));
+    return MINA_OK;
+}
+static inline int d2h_sync(mina_ctx *c, void *dst, const DevBuf &b, size_t bytes) {
+    if (bytes) HIPC(hipMemcpyAsync(dst, b.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    HIPC(hipGetLastError());
+    HIPC(hipStreamSynchronize(c->stream));
+    return MINA_OK;
+}
+
+// cross-file entry points (C++ linkage)
+struct xyzz_dev;   // opaque: mb::xyzz_t in HBM
+// fixed-base MSM over the SRS table of `curve`; writes the 17-word affine record and/or the XYZZ value
+int mb_msm_fixed(mina_ctx *c, int curve, uint32_t n, const uint32_t *d_scalars, uint32_t *d_out_words, void *d_out_xyzz);
+// variable-base MSM over Montgomery affine points already in HBM
+int mb_msm_variable(mina_ctx *c, int curve, uint32_t n, const uint32_t *d_scalars, const void *d_points_mont,
+                    uint32_t *d_out_words, void *d_out_xyzz);

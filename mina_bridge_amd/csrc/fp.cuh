@@ -1,0 +1,164 @@
+// fp.cuh -- Pasta prime-field arithmetic for gfx950 (and the host driver).
+//
+// Replaces (on the device) ark-ff 0.3 `Fp256<FpParameters>` Montgomery arithmetic used by every
+// routine on the verifier path (pin: core/Cargo.toml:19-22,47-57 -> lambdaclass/openmina_algebra).
+//
+// Representation: 8 x u32 little-endian limbs, Montgomery form with R = 2^256, always fully
+// reduced to [0, p).  Both Pasta primes have the shape p = 2^254 + t (t < 2^126) and p = 1 mod 2^32:
+//   limbs   = { 1, p1, p2, p3, 0, 0, 0, 0x40000000 }
+//   -p^-1 mod 2^32 = 0xffffffff  ->  the Montgomery quotient digit is m = -t0 (no multiply)
+//   m * p needs only 3 real 32x32 products (p1..p3); p0 = 1 is an add, p7 = 2^30 is a shift.
+// so one Montgomery product costs 64 + 24 = 88 `v_mad_u64_u32` instead of 128.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define MB_HD __host__ __device__ __forceinline__
+#else
+#define MB_HD inline
+#endif
+
+namespace mb {
+
+enum : int { FIELD_FP = 0, FIELD_FQ = 1 };     // Fp: Pallas base / Vesta scalar.  Fq: Vesta base / Pallas scalar
+enum : int { CURVE_PALLAS = 0, CURVE_VESTA = 1 };
+
+struct alignas(16) fe_t { uint32_t v[8]; };
+
+template <int F> struct FieldP;
+template <> struct FieldP<FIELD_FP> {
+    static constexpr uint32_t P1 = 0x992d30edu, P2 = 0x094cf91bu, P3 = 0x224698fcu;
+};
+template <> struct FieldP<FIELD_FQ> {
+    static constexpr uint32_t P1 = 0x8c46eb21u, P2 = 0x0994a8ddu, P3 = 0x224698fcu;
+};
+static constexpr uint32_t P7 = 0x40000000u;
+
+template <int F> MB_HD uint32_t modulus_limb(int i) {
+    switch (i) {
+        case 0: return 1u;
+        case 1: return FieldP<F>::P1;
+        case 2: return FieldP<F>::P2;
+        case 3: return FieldP<F>::P3;
+        case 7: return P7;
+        default: return 0u;
+    }
+}
+
+MB_HD bool fe_is_zero(const fe_t &a) {
+    return (a.v[0] | a.v[1] | a.v[2] | a.v[3] | a.v[4] | a.v[5] | a.v[6] | a.v[7]) == 0;
+}
+MB_HD bool fe_eq(const fe_t &a, const fe_t &b) {
+    uint32_t d = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) d |= a.v[i] ^ b.v[i];
+    return d == 0;
+}
+MB_HD fe_t fe_zero() { fe_t r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = 0;
+    return r; }
+
+// r = a - p if a >= p else a        (a < 2p)
+template <int F> MB_HD fe_t fe_cond_sub_p(const fe_t &a) {
+    fe_t d; uint32_t br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        uint64_t t = (uint64_t)a.v[i] - modulus_limb<F>(i) - br;
+        d.v[i] = (uint32_t)t; br = (uint32_t)(t >> 32) & 1u;
+    }
+    fe_t r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = br ? a.v[i] : d.v[i];
+    return r;
+}
+
+template <int F> MB_HD fe_t fe_add(const fe_t &a, const fe_t &b) {
+    fe_t s; uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        uint64_t t = (uint64_t)a.v[i] + b.v[i] + c;
+        s.v[i] = (uint32_t)t; c = (uint32_t)(t >> 32);
+    }
+    // a + b < 2p < 2^256: no carry out of limb 7
+    return fe_cond_sub_p<F>(s);
+}
+
+template <int F> MB_HD fe_t fe_sub(const fe_t &a, const fe_t &b) {
+    fe_t d; uint32_t br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        uint64_t t = (uint64_t)a.v[i] - b.v[i] - br;
+        d.v[i] = (uint32_t)t; br = (uint32_t)(t >> 32) & 1u;
+    }
+    // if borrow: add p back
+    uint32_t mask = 0u - br, c = 0;
+    fe_t r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        uint64_t t = (uint64_t)d.v[i] + (modulus_limb<F>(i) & mask) + c;
+        r.v[i] = (uint32_t)t; c = (uint32_t)(t >> 32);
+    }
+    return r;
+}
+
+template <int F> MB_HD fe_t fe_neg(const fe_t &a) { return fe_sub<F>(fe_zero(), a); }
+template <int F> MB_HD fe_t fe_dbl(const fe_t &a) { return fe_add<F>(a, a); }
+
+// Montgomery product, CIOS over 32-bit digits, specialised to the Pasta prime shape.
+template <int F> MB_HD fe_t fe_mul(const fe_t &a, const fe_t &b) {
+    uint32_t t[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) t[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        uint64_t c = 0;
+        const uint32_t bi = b.v[i];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            c = (uint64_t)a.v[j] * bi + t[j] + c;
+            t[j] = (uint32_t)c; c >>= 32;
+        }
+        t[8] += (uint32_t)c;                                 // t < 2^288 here, no further carry
+        const uint32_t m = 0u - t[0];
+        uint64_t k = (t[0] != 0) ? 1u : 0u;                  // carry of t0 + m * 1
+        k = (uint64_t)m * FieldP<F>::P1 + t[1] + k; t[0] = (uint32_t)k; k >>= 32;
+        k = (uint64_t)m * FieldP<F>::P2 + t[2] + k; t[1] = (uint32_t)k; k >>= 32;
+        k = (uint64_t)m * FieldP<F>::P3 + t[3] + k; t[2] = (uint32_t)k; k >>= 32;
+        k = (uint64_t)t[4] + k; t[3] = (uint32_t)k; k >>= 32;
+        k = (uint64_t)t[5] + k; t[4] = (uint32_t)k; k >>= 32;
+        k = (uint64_t)t[6] + k; t[5] = (uint32_t)k; k >>= 32;
+        k = ((uint64_t)m << 30) + t[7] + k; t[6] = (uint32_t)k; k >>= 32;
+        k = (uint64_t)t[8] + k; t[7] = (uint32_t)k; t[8] = (uint32_t)(k >> 32);
+    }
+    fe_t r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = t[i];
+    return fe_cond_sub_p<F>(r);                               // t < 2p
+}
+template <int F> MB_HD fe_t fe_sqr(const fe_t &a) { return fe_mul<F>(a, a); }
+
+// Constants (computed once on the host, see fp_host.h) that kernels need by value.
+template <int F> struct FieldConsts {
+    fe_t one;    // R mod p
+    fe_t r2;     // R^2 mod p
+};
+
+// canonical little-endian bytes (as 8 u32 words) <-> Montgomery
+template <int F> MB_HD fe_t fe_to_mont(const fe_t &a, const fe_t &r2) { return fe_mul<F>(a, r2); }
+template <int F> MB_HD fe_t fe_from_mont(const fe_t &a) {
+    fe_t one = fe_zero(); one.v[0] = 1; return fe_mul<F>(a, one);
+}
+
+// a^e, e given as 8 x u32 plain integer (fixed, public exponents only: inversion / sqrt / Legendre)
+template <int F> MB_HD fe_t fe_pow(const fe_t &a, const fe_t &e, const fe_t &one) {
+    fe_t acc = one; bool started = false;
+    for (int i = 255; i >= 0; --i) {
+        if (started) acc = fe_sqr<F>(acc);
+        if ((e.v[i >> 5] >> (i & 31)) & 1u) { acc = fe_mul<F>(acc, a); started = true; }
+    }
+    return acc;
+}
+
+}  // namespace mb

@@ -1,0 +1,105 @@
+// microbench.hip -- gfx950 VALU instruction-rate probe for 256-bit modular arithmetic.
+// Measures wave-instruction issue cost (cycles per wave64 instruction per SIMD) of the candidate
+// building blocks: v_mad_u64_u32, v_mul_lo_u32, v_mul_hi_u32, v_mad_u32_u24, v_fma_f64, v_add_co chains,
+// plus the library's fe_mul / fe_sqr / fe_add and the XYZZ mixed add.  Output: one JSON line per probe.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include "ec.cuh"
+
+using namespace mb;
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+constexpr int ITERS = 256;     // loop trips
+constexpr int UNROLL = 16;     // independent chains per trip body (ILP)
+
+template <int OP>
+__global__ void __launch_bounds__(256) probe(uint32_t *out, uint32_t seed) {
+    uint32_t a[UNROLL], b[UNROLL];
+    uint64_t acc[UNROLL];
+    double d[UNROLL];
+    for (int i = 0; i < UNROLL; ++i) { a[i] = seed * (i + 3) + threadIdx.x; b[i] = seed ^ (0x9e3779b9u * (i + 1)); acc[i] = a[i]; d[i] = (double)a[i]; }
+    for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+        for (int i = 0; i < UNROLL; ++i) {
+            if (OP == 0) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc[i]) : "v"(a[i]), "v"(b[i]) : "vcc");
+            if (OP == 1) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b[i]));
+            if (OP == 2) asm volatile("v_mul_hi_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b[i]));
+            if (OP == 3) asm volatile("v_mad_u32_u24 %0, %0, %1, %0" : "+v"(a[i]) : "v"(b[i]));
+            if (OP == 4) asm volatile("v_fma_f64 %0, %0, %1, %0" : "+v"(d[i]) : "v"(d[(i + 1) % UNROLL]));
+            if (OP == 5) asm volatile("v_add_co_u32 %0, vcc, %0, %1\n\tv_addc_co_u32 %2, vcc, %2, %1, vcc" : "+v"(a[i]), "+v"(b[i]), "+v"(a[(i + 1) % UNROLL]) : : "vcc");
+            if (OP == 6) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b[i]));
+            if (OP == 7) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(a[i]) : "v"(b[i]));
+            if (OP == 8) asm volatile("v_mul_hi_u32_u24 %0, %0, %1" : "+v"(a[i]) : "v"(b[i]));
+            if (OP == 9) asm volatile("v_lshlrev_b64 %0, 3, %0" : "+v"(acc[i]));
+            if (OP == 10) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_addc_co_u32 %3, vcc, 0, %3, vcc" : "+v"(acc[i]), "+v"(a[i]) : "v"(a[(i + 1) % UNROLL]), "v"(b[i]) : "vcc");
+        }
+    }
+    uint32_t r = 0;
+    for (int i = 0; i < UNROLL; ++i) r ^= a[i] ^ b[i] ^ (uint32_t)acc[i] ^ (uint32_t)(acc[i] >> 32) ^ (uint32_t)d[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+
+template <int OP>
+__global__ void __launch_bounds__(256) probe_field(uint32_t *out, uint32_t seed) {
+    fe_t x, y;
+    for (int i = 0; i < 8; ++i) { x.v[i] = seed * (i + 1) + threadIdx.x; y.v[i] = seed ^ (0x85ebca6bu * (i + 2)); }
+    x.v[7] &= 0x3fffffffu; y.v[7] &= 0x3fffffffu;
+    fe_t one = fe_zero(); one.v[0] = 1;
+    xyzz_t acc; acc.x = x; acc.y = y; acc.zz = one; acc.zzz = one;
+    for (int it = 0; it < ITERS; ++it) {
+        if (OP == 0) x = fe_mul<FIELD_FQ>(x, y);
+        if (OP == 1) x = fe_sqr<FIELD_FQ>(x);
+        if (OP == 2) x = fe_add<FIELD_FQ>(x, y);
+        if (OP == 3) x = fe_sub<FIELD_FQ>(x, y);
+        if (OP == 4) { xyzz_add_affine<FIELD_FQ>(acc, x, y, one); }
+        if (OP == 5) { x = fe_mul<FIELD_FQ>(x, y); y = fe_mul<FIELD_FQ>(y, y); }   // two independent products per trip
+    }
+    uint32_t r = 0;
+    for (int i = 0; i < 8; ++i) r ^= x.v[i] ^ y.v[i] ^ acc.x.v[i] ^ acc.y.v[i] ^ acc.zz.v[i] ^ acc.zzz.v[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+
+template <class K>
+static double time_kernel(K launch, int reps) {
+    hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    launch(); CHECK(hipDeviceSynchronize());
+    CHECK(hipEventRecord(e0));
+    for (int i = 0; i < reps; ++i) launch();
+    CHECK(hipEventRecord(e1)); CHECK(hipEventSynchronize(e1));
+    float ms = 0; CHECK(hipEventElapsedTime(&ms, e0, e1));
+    return ms * 1e-3 / reps;
+}
+
+int main() {
+    hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, 0));
+    const int cus = prop.multiProcessorCount; const double clk = prop.clockRate * 1e3;   // Hz
+    printf("{\"device\": \"%s\", \"cus\": %d, \"clock_mhz\": %.0f}\n", prop.gcnArchName, cus, clk / 1e6);
+    const int waves_per_simd = 2;                     // 2 waves/SIMD: enough to cover VALU latency with UNROLL=16
+    const int blocks = cus * waves_per_simd;          // 256-thread blocks: 4 waves -> one per SIMD
+    uint32_t *out; CHECK(hipMalloc(&out, (size_t)blocks * 256 * 4));
+    const char *names[] = {"v_mad_u64_u32", "v_mul_lo_u32", "v_mul_hi_u32", "v_mad_u32_u24", "v_fma_f64", "add_co+addc_co(2 instr)",
+                           "v_add_u32", "v_mul_u32_u24", "v_mul_hi_u32_u24", "v_lshlrev_b64", "mad_u64_u32+addc(2 instr)"};
+#define RUN(OP)                                                                                              \
+    {                                                                                                        \
+        double t = time_kernel([&] { probe<OP><<<blocks, 256>>>(out, 12345u); }, 5);                         \
+        double wave_instr_per_simd = (double)ITERS * UNROLL * waves_per_simd;                                \
+        printf("{\"probe\": \"%s\", \"cycles_per_wave_instr_per_simd\": %.2f, \"time_us\": %.1f}\n", names[OP], \
+               t * clk / wave_instr_per_simd, t * 1e6);                                                      \
+    }
+    RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8) RUN(9) RUN(10)
+    const char *fnames[] = {"fe_mul (dependent)", "fe_sqr (dependent)", "fe_add", "fe_sub", "xyzz_add_affine", "2x fe_mul (independent)"};
+    for (int wps = 1; wps <= 3; ++wps) {
+        const int fb = cus * wps;
+#define RUNF(OP)                                                                                             \
+    {                                                                                                        \
+        double t = time_kernel([&] { probe_field<OP><<<fb, 256>>>(out, 777u); }, 3);                         \
+        printf("{\"probe\": \"%s\", \"waves_per_simd\": %d, \"cycles_per_op_per_wave\": %.0f, \"ns_per_op_latency\": %.0f, \"chip_Gop_per_s\": %.1f}\n", \
+               fnames[OP], wps, t * clk / ITERS / wps, t * 1e9 / ITERS, (double)fb * 256 * ITERS / t / 1e9); \
+    }
+        RUNF(0) RUNF(1) RUNF(2) RUNF(3) RUNF(4) RUNF(5)
+    }
+    CHECK(hipFree(out));
+    return 0;
+}

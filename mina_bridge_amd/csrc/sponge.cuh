@@ -1,0 +1,217 @@
+// sponge.cuh -- K2 (IPA challenge polynomial) and K3 (Poseidon sponge, endo challenges) for gfx950.
+//
+// Replaces (pins core/Cargo.toml:14,16):
+//   poly-commitment `b_poly`, `b_poly_coefficients` and the `sg_rand_base_i * s` fold inside `SRS::verify`;
+//   mina-poseidon `ArithmeticSponge` with `PlonkSpongeConstantsKimchi`
+//     (width 3, rate 2, 55 full rounds, sbox x^7, no initial ARK; round = sbox -> MDS -> + rc);
+//   kimchi `ScalarChallenge::to_field`.
+#pragma once
+#include "groupmap.cuh"
+
+namespace mb {
+
+// ---------------------------------------------------------------- K2
+// b_poly_coefficients(c)[j] = prod_{bit q of j set} c[k-1-q].  Split j = hi * 2^lb + lo:
+//   s[j] = H[hi] * L[lo],  L[lo] = prod over low bits, H[hi] = weight * prod over high bits.
+// Tables live in HBM: per proof 2^lb + 2^hb entries (k=16: 512 entries = 16 KiB).
+struct BpolyShape { uint32_t k, lb, hb, batch; };
+
+template <int F>
+__global__ void bpoly_tables_kernel(BpolyShape sh, FieldK fk, const uint32_t *__restrict__ chals /* batch*k*8 canonical */,
+                                    const uint32_t *__restrict__ weights /* batch*8 canonical, may be null */,
+                                    fe_t *__restrict__ ltab, fe_t *__restrict__ htab) {
+    const uint32_t nl = 1u << sh.lb, nh = 1u << sh.hb, per = nl + nh;
+    size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (size_t)sh.batch * per) return;
+    uint32_t b = (uint32_t)(gid / per), e = (uint32_t)(gid % per);
+    const uint32_t *cb = chals + (size_t)b * sh.k * 8;
+    fe_t acc; uint32_t bits, base;
+    if (e < nl) { bits = e; base = 0; acc = fk.one; }
+    else {
+        bits = e - nl; base = sh.lb;
+        if (weights) { fe_t w; for (int i = 0; i < 8; ++i) w.v[i] = weights[(size_t)b * 8 + i]; acc = fe_to_mont<F>(w, fk.r2); }
+        else acc = fk.one;
+    }
+    for (uint32_t q = 0; bits; ++q, bits >>= 1) {
+        if (!(bits & 1u)) continue;
+        fe_t c; const uint32_t *cp = cb + (size_t)(sh.k - 1 - (base + q)) * 8;
+        for (int i = 0; i < 8; ++i) c.v[i] = cp[i];
+        acc = fe_mul<F>(acc, fe_to_mont<F>(c, fk.r2));
+    }
+    if (e < nl) ltab[(size_t)b * nl + e] = acc; else htab[(size_t)b * nh + (e - nl)] = acc;
+}
+
+// One lane per `lo`; each block covers BP_HT consecutive `hi` values and a slice of the batch.
+//   partial[slice][j] = sum_{b in slice} H_b[hi] * L_b[lo]      (Montgomery)
+static constexpr int BP_HT = 4;
+template <int F>
+__global__ void __launch_bounds__(256)
+bpoly_fold_kernel(BpolyShape sh, uint32_t slices, const fe_t *__restrict__ ltab, const fe_t *__restrict__ htab,
+                  fe_t *__restrict__ partial) {
+    const uint32_t nl = 1u << sh.lb, nh = 1u << sh.hb;
+    const uint32_t lo_blocks = (nl + blockDim.x - 1) / blockDim.x;
+    const uint32_t hi_tiles = (nh + BP_HT - 1) / BP_HT;
+    uint32_t bid = blockIdx.x;
+    const uint32_t lo_blk = bid % lo_blocks; bid /= lo_blocks;
+    const uint32_t tile = bid % hi_tiles; const uint32_t slice = bid / hi_tiles;
+    const uint32_t lo = lo_blk * blockDim.x + threadIdx.x;
+    if (lo >= nl) return;
+    const uint32_t b0 = (uint32_t)((uint64_t)sh.batch * slice / slices);
+    const uint32_t b1 = (uint32_t)((uint64_t)sh.batch * (slice + 1) / slices);
+    fe_t acc[BP_HT];
+#pragma unroll
+    for (int t = 0; t < BP_HT; ++t) acc[t] = fe_zero();
+    for (uint32_t b = b0; b < b1; ++b) {
+        const fe_t l = ltab[(size_t)b * nl + lo];
+#pragma unroll
+        for (int t = 0; t < BP_HT; ++t) {
+            uint32_t hi = tile * BP_HT + t;
+            if (hi < nh) acc[t] = fe_add<F>(acc[t], fe_mul<F>(l, htab[(size_t)b * nh + hi]));
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < BP_HT; ++t) {
+        uint32_t hi = tile * BP_HT + t;
+        if (hi < nh) partial[(size_t)slice * ((size_t)1 << sh.k) + ((size_t)hi << sh.lb) + lo] = acc[t];
+    }
+}
+
+// out[j] (canonical words) = sum over slices of partial[slice][j]
+template <int F>
+__global__ void bpoly_finish_kernel(uint32_t n, uint32_t slices, const fe_t *__restrict__ partial, uint32_t *__restrict__ out_words) {
+    uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    fe_t acc = partial[j];
+    for (uint32_t s = 1; s < slices; ++s) acc = fe_add<F>(acc, partial[(size_t)s * n + j]);
+    acc = fe_from_mont<F>(acc);
+    uint4 *o = reinterpret_cast<uint4 *>(out_words + (size_t)j * 8);
+    o[0] = make_uint4(acc.v[0], acc.v[1], acc.v[2], acc.v[3]);
+    o[1] = make_uint4(acc.v[4], acc.v[5], acc.v[6], acc.v[7]);
+}
+
+// b_poly(chals, x) = prod_i (1 + chals[i] * x^(2^(k-1-i)))
+template <int F>
+__global__ void bpoly_eval_kernel(uint32_t k, uint32_t npoints, FieldK fk, const uint32_t *__restrict__ chals,
+                                  const uint32_t *__restrict__ xs, uint32_t *__restrict__ out_words) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npoints) return;
+    fe_t x; for (int i = 0; i < 8; ++i) x.v[i] = xs[(size_t)p * 8 + i];
+    fe_t pw = fe_to_mont<F>(x, fk.r2), r = fk.one;
+    for (int i = (int)k - 1; i >= 0; --i) {            // pw = x^(2^(k-1-i))
+        fe_t c; for (int q = 0; q < 8; ++q) c.v[q] = chals[(size_t)i * 8 + q];
+        r = fe_mul<F>(r, fe_add<F>(fk.one, fe_mul<F>(fe_to_mont<F>(c, fk.r2), pw)));
+        pw = fe_sqr<F>(pw);
+    }
+    r = fe_from_mont<F>(r);
+    for (int i = 0; i < 8; ++i) out_words[(size_t)p * 8 + i] = r.v[i];
+}
+
+// ---------------------------------------------------------------- K3
+struct PoseidonParams { fe_t mds[3][3]; fe_t rc[55][3]; };     // Montgomery, in HBM (read with uniform addresses)
+
+template <int F>
+__device__ __forceinline__ void poseidon_permute(fe_t s[3], const PoseidonParams *__restrict__ pp) {
+#pragma unroll 1
+    for (int r = 0; r < 55; ++r) {
+        fe_t t[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            fe_t x2 = fe_sqr<F>(s[i]);
+            fe_t x4 = fe_sqr<F>(x2);
+            t[i] = fe_mul<F>(fe_mul<F>(x4, x2), s[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            fe_t acc = fe_mul<F>(pp->mds[i][0], t[0]);
+            acc = fe_add<F>(acc, fe_mul<F>(pp->mds[i][1], t[1]));
+            acc = fe_add<F>(acc, fe_mul<F>(pp->mds[i][2], t[2]));
+            s[i] = fe_add<F>(acc, pp->rc[r][i]);
+        }
+    }
+}
+
+template <int F>
+__global__ void __launch_bounds__(256)
+poseidon_permute_kernel(uint32_t n, FieldK fk, const PoseidonParams *__restrict__ pp, uint32_t *__restrict__ states) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fe_t s[3];
+    for (int j = 0; j < 3; ++j) { fe_t w; for (int q = 0; q < 8; ++q) w.v[q] = states[(size_t)i * 24 + j * 8 + q]; s[j] = fe_to_mont<F>(w, fk.r2); }
+    poseidon_permute<F>(s, pp);
+    for (int j = 0; j < 3; ++j) { fe_t w = fe_from_mont<F>(s[j]); for (int q = 0; q < 8; ++q) states[(size_t)i * 24 + j * 8 + q] = w.v[q]; }
+}
+
+// n independent sponges: absorb len elements, squeeze one (rate 2)
+template <int F>
+__global__ void __launch_bounds__(256)
+poseidon_hash_kernel(uint32_t n, uint32_t len, FieldK fk, const PoseidonParams *__restrict__ pp,
+                     const uint32_t *__restrict__ inputs, uint32_t *__restrict__ out_words) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fe_t s[3] = {fe_zero(), fe_zero(), fe_zero()};
+    uint32_t count = 0;
+    for (uint32_t e = 0; e < len; ++e) {
+        fe_t w; for (int q = 0; q < 8; ++q) w.v[q] = inputs[((size_t)i * len + e) * 8 + q];
+        w = fe_to_mont<F>(w, fk.r2);
+        if (count == 2) { poseidon_permute<F>(s, pp); count = 0; }
+        s[count] = fe_add<F>(s[count], w); ++count;
+    }
+    poseidon_permute<F>(s, pp);
+    fe_t w = fe_from_mont<F>(s[0]);
+    for (int q = 0; q < 8; ++q) out_words[(size_t)i * 8 + q] = w.v[q];
+}
+
+// ScalarChallenge::to_field
+template <int F> MB_HD fe_t challenge_to_field(uint64_t lo, uint64_t hi, const FieldK &fk) {
+    fe_t two = fe_dbl<F>(fk.one), a = two, b = two, neg1 = fe_neg<F>(fk.one);
+    for (int i = 63; i >= 0; --i) {
+        a = fe_dbl<F>(a); b = fe_dbl<F>(b);
+        uint32_t bit0 = (2 * i < 64) ? (uint32_t)(lo >> (2 * i)) & 1u : (uint32_t)(hi >> (2 * i - 64)) & 1u;
+        uint32_t bit1 = (2 * i + 1 < 64) ? (uint32_t)(lo >> (2 * i + 1)) & 1u : (uint32_t)(hi >> (2 * i + 1 - 64)) & 1u;
+        const fe_t &s = bit0 ? fk.one : neg1;
+        if (bit1 == 0) b = fe_add<F>(b, s); else a = fe_add<F>(a, s);
+    }
+    return fe_add<F>(fe_mul<F>(a, fk.endo), b);
+}
+
+#if defined(__HIPCC__)
+template <int F>
+__global__ void challenge_to_field_kernel(uint32_t n, FieldK fk, const uint32_t *__restrict__ chal /* n*4 words */, uint32_t *__restrict__ out_words) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t lo = (uint64_t)chal[(size_t)i * 4] | ((uint64_t)chal[(size_t)i * 4 + 1] << 32);
+    uint64_t hi = (uint64_t)chal[(size_t)i * 4 + 2] | ((uint64_t)chal[(size_t)i * 4 + 3] << 32);
+    fe_t r = fe_from_mont<F>(challenge_to_field<F>(lo, hi, fk));
+    for (int q = 0; q < 8; ++q) out_words[(size_t)i * 8 + q] = r.v[q];
+}
+
+// vector field ops for the self-test hooks
+template <int F>
+__global__ void field_mul_kernel(uint32_t n, FieldK fk, const uint32_t *a, const uint32_t *b, uint32_t *out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fe_t x, y; for (int q = 0; q < 8; ++q) { x.v[q] = a[(size_t)i * 8 + q]; y.v[q] = b[(size_t)i * 8 + q]; }
+    fe_t r = fe_from_mont<F>(fe_mul<F>(fe_to_mont<F>(x, fk.r2), fe_to_mont<F>(y, fk.r2)));
+    for (int q = 0; q < 8; ++q) out[(size_t)i * 8 + q] = r.v[q];
+}
+template <int F>
+__global__ void field_inv_kernel(uint32_t n, FieldK fk, const uint32_t *a, uint32_t *out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fe_t x; for (int q = 0; q < 8; ++q) x.v[q] = a[(size_t)i * 8 + q];
+    fe_t r = fe_from_mont<F>(fe_inv<F>(fe_to_mont<F>(x, fk.r2), fk));
+    for (int q = 0; q < 8; ++q) out[(size_t)i * 8 + q] = r.v[q];
+}
+template <int F>
+__global__ void field_sqrt_kernel(uint32_t n, FieldK fk, const uint32_t *a, uint32_t *out, uint8_t *ok) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fe_t x; for (int q = 0; q < 8; ++q) x.v[q] = a[(size_t)i * 8 + q];
+    fe_t r; bool sq = fe_sqrt<F>(r, fe_to_mont<F>(x, fk.r2), fk);
+    r = sq ? fe_from_mont<F>(r) : fe_zero();
+    ok[i] = sq ? 1 : 0;
+    for (int q = 0; q < 8; ++q) out[(size_t)i * 8 + q] = r.v[q];
+}
+#endif
+
+}  // namespace mb

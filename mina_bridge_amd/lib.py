@@ -1,0 +1,307 @@
+"""ctypes binding of libminaverify.so -- the host-side mirror of include/mina_verify.h.
+
+The library is HIP-only (gfx950).  There is NO CPU fallback: if the shared object is missing, or no
+GPU is visible, loading / context creation raises.  Nothing here imports `oracle/`.
+
+Byte conventions (same as the C-ABI): field element = 32-byte LE canonical; affine point = x||y
+(64 B), infinity = zeros; numpy uint8 arrays in and out.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libminaverify.so")
+
+FIELD_FP, FIELD_FQ = 0, 1
+CURVE_PALLAS, CURVE_VESTA = 0, 1
+
+# every symbol include/mina_verify.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "mina_ctx_create", "mina_ctx_destroy", "mina_last_error", "mina_ctx_synchronize", "mina_ctx_stream",
+    "mina_srs_create", "mina_srs_load", "mina_srs_depth", "mina_srs_get_g", "mina_srs_get_h", "mina_srs_serialize",
+    "mina_msm", "mina_msm_srs", "mina_msm_srs_dev",
+    "mina_b_poly", "mina_b_poly_coefficients", "mina_b_poly_fold", "mina_b_poly_fold_dev",
+    "mina_poseidon_set_params", "mina_poseidon_permute", "mina_poseidon_permute_dev", "mina_poseidon_hash",
+    "mina_challenge_to_field", "mina_to_group",
+    "mina_field_mul", "mina_field_inv", "mina_field_sqrt",
+    "mina_accumulator_check_batch", "mina_accumulator_check_dev", "mina_ipa_batch_check",
+]
+
+
+class MinaError(RuntimeError):
+    pass
+
+
+class IpaOpening(ctypes.Structure):
+    _fields_ = [
+        ("k", ctypes.c_uint32),
+        ("lr", ctypes.c_void_p), ("delta", ctypes.c_void_p), ("sg", ctypes.c_void_p),
+        ("z1", ctypes.c_void_p), ("z2", ctypes.c_void_p),
+        ("n_evalpoints", ctypes.c_uint32), ("evalpoints", ctypes.c_void_p),
+        ("n_comms", ctypes.c_uint32), ("comms", ctypes.c_void_p),
+        ("combined_inner_product", ctypes.c_void_p), ("polyscale", ctypes.c_void_p), ("evalscale", ctypes.c_void_p),
+        ("sponge_state", ctypes.c_void_p), ("sponge_mode", ctypes.c_uint32), ("sponge_count", ctypes.c_uint32),
+    ]
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen libminaverify.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MinaError(
+            f"{LIB_PATH} is missing: build it with `python -m mina_bridge_amd.build` (hipcc, gfx950). "
+            "There is no CPU fallback."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.mina_last_error.restype = ctypes.c_char_p
+    lib.mina_ctx_stream.restype = ctypes.c_void_p
+    lib.mina_ctx_stream.argtypes = [ctypes.c_void_p]
+    lib.mina_srs_depth.restype = ctypes.c_uint32
+    lib.mina_ctx_destroy.restype = None
+    _lib = lib
+    return lib
+
+
+def _u8(x) -> np.ndarray:
+    if isinstance(x, (bytes, bytearray)):
+        return np.frombuffer(bytes(x), dtype=np.uint8).copy()
+    return np.ascontiguousarray(x, dtype=np.uint8)
+
+
+def _p(a):
+    if a is None:
+        return None
+    if isinstance(a, int):
+        return ctypes.c_void_p(a)
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def scalar_field_of(curve: int) -> int:
+    return FIELD_FQ if curve == CURVE_PALLAS else FIELD_FP
+
+
+def base_field_of(curve: int) -> int:
+    return FIELD_FP if curve == CURVE_PALLAS else FIELD_FQ
+
+
+class MinaContext:
+    """One GPU: stream + SRS tables + workspace.  Mirrors `mina_ctx`."""
+
+    def __init__(self, device: int = 0):
+        self._lib = load_library()
+        h = ctypes.c_void_p()
+        rc = self._lib.mina_ctx_create(int(device), ctypes.byref(h))
+        if rc != 0:
+            raise MinaError(f"mina_ctx_create failed ({rc}): {self._lib.mina_last_error().decode()}")
+        self._h = h
+        self.device = device
+
+    # -- plumbing
+    def _ck(self, rc: int, what: str):
+        if rc != 0:
+            raise MinaError(f"{what} failed ({rc}): {self._lib.mina_last_error().decode()}")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mina_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        self._ck(self._lib.mina_ctx_synchronize(self._h), "mina_ctx_synchronize")
+
+    @property
+    def stream(self) -> int:
+        return int(self._lib.mina_ctx_stream(self._h) or 0)
+
+    # -- SRS
+    def srs_create(self, curve: int, depth: int):
+        self._ck(self._lib.mina_srs_create(self._h, curve, ctypes.c_uint32(depth)), "mina_srs_create")
+
+    def srs_load(self, curve: int, blob: bytes):
+        b = _u8(blob)
+        self._ck(self._lib.mina_srs_load(self._h, curve, _p(b), ctypes.c_size_t(b.size)), "mina_srs_load")
+
+    def srs_depth(self, curve: int) -> int:
+        return int(self._lib.mina_srs_depth(self._h, curve))
+
+    def srs_get_g(self, curve: int, first: int, count: int) -> np.ndarray:
+        out = np.empty((count, 64), np.uint8)
+        self._ck(self._lib.mina_srs_get_g(self._h, curve, ctypes.c_uint32(first), ctypes.c_uint32(count), _p(out)), "mina_srs_get_g")
+        return out
+
+    def srs_get_h(self, curve: int) -> np.ndarray:
+        out = np.empty(64, np.uint8)
+        self._ck(self._lib.mina_srs_get_h(self._h, curve, _p(out)), "mina_srs_get_h")
+        return out
+
+    def srs_serialize(self, curve: int) -> bytes:
+        depth = self.srs_depth(curve)
+        cap = 6 + (depth + 1) * 35
+        out = np.empty(cap, np.uint8)
+        ln = ctypes.c_size_t(0)
+        self._ck(self._lib.mina_srs_serialize(self._h, curve, _p(out), ctypes.c_size_t(cap), ctypes.byref(ln)), "mina_srs_serialize")
+        return out[: ln.value].tobytes()
+
+    # -- K1
+    def msm(self, curve: int, bases, scalars) -> np.ndarray:
+        bases, scalars = _u8(bases), _u8(scalars)
+        n = scalars.size // 32
+        assert bases.size == n * 64
+        out = np.empty(64, np.uint8)
+        self._ck(self._lib.mina_msm(self._h, curve, ctypes.c_size_t(n), _p(bases), _p(scalars), _p(out)), "mina_msm")
+        return out
+
+    def msm_srs(self, curve: int, scalars) -> np.ndarray:
+        scalars = _u8(scalars)
+        n = scalars.size // 32
+        out = np.empty(64, np.uint8)
+        self._ck(self._lib.mina_msm_srs(self._h, curve, ctypes.c_size_t(n), _p(scalars), _p(out)), "mina_msm_srs")
+        return out
+
+    def msm_srs_dev(self, curve: int, n: int, d_scalars: int, d_out: int):
+        self._ck(self._lib.mina_msm_srs_dev(self._h, curve, ctypes.c_size_t(n), ctypes.c_void_p(d_scalars), ctypes.c_void_p(d_out)), "mina_msm_srs_dev")
+
+    # -- K2
+    def b_poly(self, field: int, chals, xs) -> np.ndarray:
+        chals, xs = _u8(chals), _u8(xs)
+        k, npts = chals.size // 32, xs.size // 32
+        out = np.empty((npts, 32), np.uint8)
+        self._ck(self._lib.mina_b_poly(self._h, field, ctypes.c_uint32(k), _p(chals), ctypes.c_size_t(npts), _p(xs), _p(out)), "mina_b_poly")
+        return out
+
+    def b_poly_coefficients(self, field: int, chals) -> np.ndarray:
+        chals = _u8(chals)
+        k = chals.size // 32
+        out = np.empty((1 << k, 32), np.uint8)
+        self._ck(self._lib.mina_b_poly_coefficients(self._h, field, ctypes.c_uint32(k), _p(chals), _p(out)), "mina_b_poly_coefficients")
+        return out
+
+    def b_poly_fold(self, field: int, k: int, chals, weights=None) -> np.ndarray:
+        chals = _u8(chals)
+        batch = chals.size // (32 * k)
+        w = _u8(weights) if weights is not None else None
+        out = np.empty((1 << k, 32), np.uint8)
+        self._ck(self._lib.mina_b_poly_fold(self._h, field, ctypes.c_uint32(k), ctypes.c_size_t(batch), _p(chals), _p(w), _p(out)), "mina_b_poly_fold")
+        return out
+
+    def b_poly_fold_dev(self, field: int, k: int, batch: int, d_chals: int, d_weights: int, d_out: int):
+        self._ck(self._lib.mina_b_poly_fold_dev(self._h, field, ctypes.c_uint32(k), ctypes.c_size_t(batch), ctypes.c_void_p(d_chals),
+                                                 ctypes.c_void_p(d_weights) if d_weights else None, ctypes.c_void_p(d_out)), "mina_b_poly_fold_dev")
+
+    # -- K3
+    def poseidon_set_params(self, field: int, params):
+        params = _u8(params)
+        assert params.size == (9 + 165) * 32
+        self._ck(self._lib.mina_poseidon_set_params(self._h, field, _p(params)), "mina_poseidon_set_params")
+
+    def poseidon_permute(self, field: int, states) -> np.ndarray:
+        st = _u8(states).copy()
+        n = st.size // 96
+        self._ck(self._lib.mina_poseidon_permute(self._h, field, ctypes.c_size_t(n), _p(st)), "mina_poseidon_permute")
+        return st.reshape(n, 96)
+
+    def poseidon_permute_dev(self, field: int, n: int, d_states: int):
+        self._ck(self._lib.mina_poseidon_permute_dev(self._h, field, ctypes.c_size_t(n), ctypes.c_void_p(d_states)), "mina_poseidon_permute_dev")
+
+    def poseidon_hash(self, field: int, inputs, n: int, length: int) -> np.ndarray:
+        inputs = _u8(inputs) if length else np.zeros(32, np.uint8)
+        out = np.empty((n, 32), np.uint8)
+        self._ck(self._lib.mina_poseidon_hash(self._h, field, ctypes.c_size_t(n), ctypes.c_size_t(length), _p(inputs), _p(out)), "mina_poseidon_hash")
+        return out
+
+    def challenge_to_field(self, field: int, chal128) -> np.ndarray:
+        ch = _u8(chal128)
+        n = ch.size // 16
+        out = np.empty((n, 32), np.uint8)
+        self._ck(self._lib.mina_challenge_to_field(self._h, field, ctypes.c_size_t(n), _p(ch), _p(out)), "mina_challenge_to_field")
+        return out
+
+    # -- K4
+    def to_group(self, curve: int, t) -> np.ndarray:
+        t = _u8(t)
+        n = t.size // 32
+        out = np.empty((n, 64), np.uint8)
+        self._ck(self._lib.mina_to_group(self._h, curve, ctypes.c_size_t(n), _p(t), _p(out)), "mina_to_group")
+        return out
+
+    # -- field hooks
+    def field_mul(self, field: int, a, b) -> np.ndarray:
+        a, b = _u8(a), _u8(b)
+        n = a.size // 32
+        out = np.empty((n, 32), np.uint8)
+        self._ck(self._lib.mina_field_mul(self._h, field, ctypes.c_size_t(n), _p(a), _p(b), _p(out)), "mina_field_mul")
+        return out
+
+    def field_inv(self, field: int, a) -> np.ndarray:
+        a = _u8(a)
+        n = a.size // 32
+        out = np.empty((n, 32), np.uint8)
+        self._ck(self._lib.mina_field_inv(self._h, field, ctypes.c_size_t(n), _p(a), _p(out)), "mina_field_inv")
+        return out
+
+    def field_sqrt(self, field: int, a):
+        a = _u8(a)
+        n = a.size // 32
+        out = np.empty((n, 32), np.uint8)
+        ok = np.empty(n, np.uint8)
+        self._ck(self._lib.mina_field_sqrt(self._h, field, ctypes.c_size_t(n), _p(a), _p(out), _p(ok)), "mina_field_sqrt")
+        return out, ok
+
+    # -- a10 / a8
+    def accumulator_check_batch(self, curve: int, k: int, prechallenges, sg, rho=None) -> np.ndarray:
+        pre, sg = _u8(prechallenges), _u8(sg)
+        batch = sg.size // 64
+        assert pre.size == batch * k * 16
+        r = _u8(rho) if rho is not None else None
+        out = np.empty(batch, np.uint8)
+        self._ck(self._lib.mina_accumulator_check_batch(self._h, curve, ctypes.c_uint32(k), ctypes.c_size_t(batch), _p(pre), _p(sg), _p(r), _p(out)),
+                 "mina_accumulator_check_batch")
+        return out
+
+    def accumulator_check_dev(self, curve: int, k: int, batch: int, d_pre: int, d_sg: int, d_rho: int, d_verdict: int):
+        self._ck(self._lib.mina_accumulator_check_dev(self._h, curve, ctypes.c_uint32(k), ctypes.c_size_t(batch), ctypes.c_void_p(d_pre),
+                                                       ctypes.c_void_p(d_sg), ctypes.c_void_p(d_rho) if d_rho else None, ctypes.c_void_p(d_verdict)),
+                 "mina_accumulator_check_dev")
+
+    def ipa_batch_check(self, curve: int, openings: list, rand_base, sg_rand_base) -> bool:
+        """`openings`: list of dicts with the fields of `mina_ipa_opening` (numpy uint8 arrays)."""
+        keep = []
+        arr = (IpaOpening * len(openings))()
+
+        def ptr(x):
+            a = _u8(x)
+            keep.append(a)
+            return a.ctypes.data
+
+        for i, o in enumerate(openings):
+            e = arr[i]
+            e.k = int(o["k"])
+            e.lr, e.delta, e.sg = ptr(o["lr"]), ptr(o["delta"]), ptr(o["sg"])
+            e.z1, e.z2 = ptr(o["z1"]), ptr(o["z2"])
+            e.n_evalpoints = int(o["n_evalpoints"])
+            e.evalpoints = ptr(o["evalpoints"])
+            e.n_comms = int(o["n_comms"])
+            e.comms = ptr(o["comms"])
+            e.combined_inner_product = ptr(o["combined_inner_product"])
+            e.polyscale, e.evalscale = ptr(o["polyscale"]), ptr(o["evalscale"])
+            e.sponge_state = ptr(o["sponge_state"])
+            e.sponge_mode, e.sponge_count = int(o["sponge_mode"]), int(o["sponge_count"])
+        rb, sb = _u8(rand_base), _u8(sg_rand_base)
+        v = np.zeros(1, np.uint8)
+        self._ck(self._lib.mina_ipa_batch_check(self._h, curve, ctypes.c_size_t(len(openings)), arr, _p(rb), _p(sb), _p(v)), "mina_ipa_batch_check")
+        return bool(v[0])

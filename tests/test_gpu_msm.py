@@ -1,0 +1,95 @@
+"""GPU parity for K1 (MSM) through the C-ABI: bit-exact affine result vs the CPU oracle."""
+import numpy as np
+import pytest
+
+from conftest import rand_scalars
+
+pytestmark = pytest.mark.gpu
+
+P = 0x40000000000000000000000000000000224698FC094CF91B992D30ED00000001
+Q = 0x40000000000000000000000000000000224698FC0994A8DD8C46EB2100000001
+SCALAR_MOD = {0: Q, 1: P}
+
+
+@pytest.mark.parametrize("curve", [1, 0])
+@pytest.mark.parametrize("n", [1, 2, 31, 32, 257, 1000])
+def test_msm_variable_base_small(ctx, oracle, srs_oracle, curve, n):
+    g, _ = srs_oracle[curve]
+    sc = rand_scalars(n, SCALAR_MOD[curve], seed=100 + n)
+    assert (ctx.msm(curve, g[:n], sc) == oracle.msm_pippenger(curve, g[:n], sc, threads=4)).all()
+
+
+@pytest.mark.parametrize("curve", [1, 0])
+def test_msm_edge_cases(ctx, oracle, srs_oracle, curve):
+    g, _ = srs_oracle[curve]
+    r = SCALAR_MOD[curve]
+    n = 64
+    base = g[:n].copy()
+    cases = {
+        "zeros": oracle.ints_to_le([0] * n),
+        "ones": oracle.ints_to_le([1] * n),
+        "r_minus_1": oracle.ints_to_le([r - 1] * n),
+        "one_nonzero": oracle.ints_to_le([0] * (n - 1) + [12345678901234567890]),
+        "pow2": oracle.ints_to_le([1 << (i * 4 % 254) for i in range(n)]),
+        "digit_boundaries": oracle.ints_to_le([(1 << 254) - 1, 0x8000, 0x7FFF, 0x8001, 0xFFFF, 0x10000, (1 << 240) | 0x8000] + [0x80008000800080008000] * (n - 7)),
+    }
+    for name, sc in cases.items():
+        got, exp = ctx.msm(curve, base, sc), oracle.msm_naive(curve, base, sc)
+        assert (got == exp).all(), name
+    # empty input -> identity
+    assert not ctx.msm(curve, np.zeros((0, 64), np.uint8), np.zeros((0, 32), np.uint8)).any()
+    # repeated points (bucket collisions P = Q), P and -P (cancellation), infinity among the bases
+    rep = np.repeat(g[:1], n, axis=0)
+    sc = oracle.ints_to_le([7] * n)
+    assert (ctx.msm(curve, rep, sc) == oracle.msm_naive(curve, rep, sc)).all()
+    neg = g[:2].copy()
+    m = P if curve == 0 else Q
+    y = oracle.le_to_int(neg[0, 32:])
+    neg[1, :32] = neg[0, :32]
+    neg[1, 32:] = oracle.int_to_le(m - y)
+    sc2 = oracle.ints_to_le([99, 99])
+    assert not ctx.msm(curve, neg, sc2).any()                      # P*99 + (-P)*99 = identity
+    withinf = base.copy(); withinf[3] = 0; withinf[10] = 0
+    sc3 = rand_scalars(n, r, seed=77)
+    assert (ctx.msm(curve, withinf, sc3) == oracle.msm_naive(curve, withinf, sc3)).all()
+
+
+@pytest.mark.parametrize("curve,n", [(1, 65536), (0, 32768), (1, 1000), (0, 65536)])
+def test_msm_srs_fixed_base_uniform(ctx_srs, oracle, srs_oracle, curve, n):
+    """BASELINE config C2 (ii): uniform scalars on the real SRS, full size, bit-exact."""
+    g, _ = srs_oracle[curve]
+    sc = rand_scalars(n, SCALAR_MOD[curve], seed=4242 + n + curve)
+    assert (ctx_srs.msm_srs(curve, sc) == oracle.msm_pippenger(curve, g[:n], sc, threads=8)).all()
+
+
+@pytest.mark.parametrize("dist", ["bits128", "all_equal", "zeros_plus_one", "r_minus_1", "b_poly"])
+def test_msm_srs_distributions(ctx_srs, oracle, srs_oracle, dist):
+    """BASELINE config C2 (i),(iii),(iv) on Vesta 2^16."""
+    curve, n, r = 1, 65536, P
+    g, _ = srs_oracle[curve]
+    if dist == "bits128":
+        sc = rand_scalars(n, r, seed=9, bits=128)
+    elif dist == "all_equal":
+        sc = np.repeat(rand_scalars(1, r, seed=10), n, axis=0)      # every window: ONE bucket holds all 2^16 points
+    elif dist == "zeros_plus_one":
+        sc = np.zeros((n, 32), np.uint8); sc[n - 1] = rand_scalars(1, r, seed=12)[0]
+    elif dist == "r_minus_1":
+        sc = np.repeat(oracle.ints_to_le([r - 1]), n, axis=0)
+    else:
+        pre = rand_scalars(16, r, seed=13, bits=128)[:, :16]
+        _, endo_r = oracle.endo(curve)
+        chals = np.stack([oracle.challenge_to_field(0, pre[i].copy(), endo_r) for i in range(16)])
+        sc = oracle.b_poly_coefficients(0, chals)
+    assert (ctx_srs.msm_srs(curve, sc) == oracle.msm_pippenger(curve, g[:n], sc, threads=8)).all()
+
+
+def test_msm_linearity_property(ctx_srs, oracle):
+    """size-independent property at full size: MSM(a) + MSM(b) == MSM(a + b mod r)"""
+    curve, n, r = 1, 65536, P
+    a = rand_scalars(n, r, seed=31)
+    b = rand_scalars(n, r, seed=32)
+    ai = [int.from_bytes(x.tobytes(), "little") for x in a]
+    bi = [int.from_bytes(x.tobytes(), "little") for x in b]
+    s = oracle.ints_to_le([(x + y) % r for x, y in zip(ai, bi)])
+    pa, pb, ps = ctx_srs.msm_srs(curve, a), ctx_srs.msm_srs(curve, b), ctx_srs.msm_srs(curve, s)
+    assert (oracle.point_add(curve, pa, pb) == ps).all()

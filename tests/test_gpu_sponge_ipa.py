@@ -1,0 +1,108 @@
+"""GPU parity for K2 (b_poly), K3 (Poseidon / endo challenges) and the a10 accumulator check."""
+import numpy as np
+import pytest
+
+from conftest import rand_scalars
+
+pytestmark = pytest.mark.gpu
+
+P = 0x40000000000000000000000000000000224698FC094CF91B992D30ED00000001
+Q = 0x40000000000000000000000000000000224698FC0994A8DD8C46EB2100000001
+MODS = {0: P, 1: Q}
+
+
+@pytest.mark.parametrize("field", [0, 1])
+@pytest.mark.parametrize("k", [1, 2, 5, 9, 16])
+def test_b_poly_coefficients(ctx, oracle, field, k):
+    chals = rand_scalars(k, MODS[field], seed=50 + k)
+    assert (ctx.b_poly_coefficients(field, chals) == oracle.b_poly_coefficients(field, chals)).all()
+
+
+@pytest.mark.parametrize("field", [0, 1])
+def test_b_poly_eval_and_identity(ctx, oracle, field):
+    k = 12
+    chals = rand_scalars(k, MODS[field], seed=3)
+    xs = rand_scalars(9, MODS[field], seed=4)
+    got = ctx.b_poly(field, chals, xs)
+    exp = np.stack([oracle.b_poly(field, chals, x) for x in xs])
+    assert (got == exp).all()
+    # property: sum_j s_j x^j == b_poly(chals, x)
+    s = [oracle.le_to_int(v) for v in ctx.b_poly_coefficients(field, chals)]
+    x = oracle.le_to_int(xs[0]); m = MODS[field]
+    acc = 0
+    for c in reversed(s):
+        acc = (acc * x + c) % m
+    assert acc == oracle.le_to_int(got[0])
+
+
+@pytest.mark.parametrize("field", [0, 1])
+@pytest.mark.parametrize("k,batch", [(6, 1), (6, 7), (10, 33), (16, 5)])
+def test_b_poly_fold(ctx, oracle, field, k, batch):
+    m = MODS[field]
+    chals = rand_scalars(batch * k, m, seed=60 + k + batch)
+    w = rand_scalars(batch, m, seed=61)
+    got = ctx.b_poly_fold(field, k, chals, w)
+    acc = [0] * (1 << k)
+    for b in range(batch):
+        s = oracle.b_poly_coefficients(field, chals[b * k:(b + 1) * k])
+        wb = oracle.le_to_int(w[b])
+        for j in range(1 << k):
+            acc[j] = (acc[j] + wb * int.from_bytes(s[j].tobytes(), "little")) % m
+    assert (got == oracle.ints_to_le(acc)).all()
+
+
+@pytest.mark.parametrize("field", [0, 1])
+def test_poseidon_permute_and_hash(ctx, oracle, field):
+    import mina_bridge_amd as m
+    params = m.poseidon_params.default_params_bytes(field)
+    st = np.concatenate([np.zeros((1, 96), np.uint8), rand_scalars(3 * 700, MODS[field], seed=8).reshape(700, 96)])
+    assert (ctx.poseidon_permute(field, st) == oracle.poseidon_permute(field, params, st)).all()
+    for length in (0, 1, 2, 3, 5, 8):
+        n = 37
+        inp = rand_scalars(n * max(length, 1), MODS[field], seed=90 + length)[: n * length]
+        got = ctx.poseidon_hash(field, inp, n, length)
+        exp = np.stack([oracle.poseidon_hash(field, params, inp[i * length:(i + 1) * length]) for i in range(n)])
+        assert (got == exp).all(), length
+
+
+@pytest.mark.parametrize("field", [0, 1])
+def test_challenge_to_field(ctx, oracle, field):
+    curve = 1 if field == 0 else 0       # the curve whose scalar field is `field`
+    _, endo_r = oracle.endo(curve)
+    ch = np.concatenate([np.zeros((1, 16), np.uint8), np.full((1, 16), 255, np.uint8), rand_scalars(300, MODS[field], seed=2)[:, :16]])
+    got = ctx.challenge_to_field(field, ch)
+    exp = np.stack([oracle.challenge_to_field(field, c.copy(), endo_r) for c in ch])
+    assert (got == exp).all()
+
+
+def make_accumulator_instance(oracle, srs_oracle, curve, k, seed):
+    """prechallenges + the matching sg = <b_poly_coefficients(chals), g> computed by the CPU oracle"""
+    fs = 1 if curve == 0 else 0
+    g, _ = srs_oracle[curve]
+    _, endo_r = oracle.endo(curve)
+    pre = rand_scalars(k, MODS[fs], seed=seed, bits=128)[:, :16].copy()
+    chals = np.stack([oracle.challenge_to_field(fs, pre[i].copy(), endo_r) for i in range(k)])
+    s = oracle.b_poly_coefficients(fs, chals)
+    sg = oracle.msm_pippenger(curve, g[: 1 << k], s, threads=8)
+    return pre, sg
+
+
+@pytest.mark.parametrize("curve,k", [(1, 16), (0, 15), (1, 8)])
+def test_accumulator_check_single(ctx_srs, oracle, srs_oracle, curve, k):
+    """BASELINE config C2: one state proof's 2^16 Vesta accumulator check; accept + tampered reject."""
+    pre, sg = make_accumulator_instance(oracle, srs_oracle, curve, k, seed=700 + k)
+    assert ctx_srs.accumulator_check_batch(curve, k, pre, sg).tolist() == [1]
+    bad = pre.copy(); bad[3, 0] ^= 1
+    assert ctx_srs.accumulator_check_batch(curve, k, bad, sg).tolist() == [0]
+    g, _ = srs_oracle[curve]
+    assert ctx_srs.accumulator_check_batch(curve, k, pre, g[5]).tolist() == [0]
+
+
+def test_accumulator_check_batch_with_culprit(ctx_srs, oracle, srs_oracle):
+    curve, k, batch = 1, 10, 6
+    inst = [make_accumulator_instance(oracle, srs_oracle, curve, k, seed=800 + b) for b in range(batch)]
+    pre = np.concatenate([i[0] for i in inst]); sg = np.stack([i[1] for i in inst])
+    rho = rand_scalars(batch, P, seed=5)
+    assert ctx_srs.accumulator_check_batch(curve, k, pre, sg, rho).tolist() == [1] * batch
+    sg_bad = sg.copy(); sg_bad[4] = sg[0]
+    assert ctx_srs.accumulator_check_batch(curve, k, pre, sg_bad, rho).tolist() == [1, 1, 1, 1, 0, 1]
