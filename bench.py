@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the MI355X-native Kimchi/Pickles IPA hot path (BASELINE.json metric).
+
+A "step" = one pass of the hot path over one batch of synthetic state proofs: for each proof the 2^16-base
+Vesta IPA accumulator check of BASELINE config C2 -- 16 128-bit prechallenges (already in HBM) ->
+ScalarChallenge::to_field -> b_poly_coefficients (K2) -> 2^16-point MSM over the Vesta SRS (K1) -> compare
+with the proof's sg -- through the C-ABI (`mina_accumulator_check_dev`), verdict left in HBM.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Multi-GPU: proof-level sharding, no data-path collective (SURVEY.md 8e variant 1): every rank verifies its
+own proofs against its replica of the SRS tables; weak scaling.  One JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CURVE_VESTA = 1
+FIELD_FP = 0
+K_ROUNDS = 16
+N_BASES = 1 << K_ROUNDS
+MSM_ALGORITHMIC_BYTES = N_BASES * (64 + 32) + 96      # 6 291 552 B for n = 2^16
+HBM_PEAK_GBPS = 8000.0                                # MI355X_MICROARCH.md: 8 TB/s spec
+PS_ACCUMULATE_BIT = 1 << 3
+
+
+def make_instances(ctx, count: int, seed: int):
+    """`count` synthetic accumulator-check instances made consistent with the GPU path itself
+    (sg = MSM(g, b_poly_coefficients(chals)) through the library; parity of that path vs the CPU oracle is
+    what tests/ establish).  Returns (prechallenges[count,16,16], sg[count,64])."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    pre = rng.integers(0, 256, size=(count, K_ROUNDS, 16), dtype=np.uint8)
+    sgs = np.empty((count, 64), np.uint8)
+    for i in range(count):
+        chals = ctx.challenge_to_field(FIELD_FP, pre[i])
+        s = ctx.b_poly_coefficients(FIELD_FP, chals)
+        sgs[i] = ctx.msm_srs(CURVE_VESTA, s)
+    return pre, sgs
+
+
+def cpu_baseline(pre_one: np.ndarray, sg_one: np.ndarray, budget_s: float = 12.0):
+    """The CPU restatement (oracle/, kind="port") of the same step, on the host cores of this box."""
+    from oracle import oracle as O
+    O.lib()
+    cores = min(os.cpu_count() or 1, 20)          # ark Pippenger has 20 windows at n = 2^16 -> 20 useful threads
+    g, _ = O.srs_create(CURVE_VESTA, N_BASES, threads=os.cpu_count() or 1)
+    _, endo_r = O.endo(CURVE_VESTA)
+
+    def one():
+        chals = np.stack([O.challenge_to_field(FIELD_FP, pre_one[i].copy(), endo_r) for i in range(K_ROUNDS)])
+        s = O.b_poly_coefficients(FIELD_FP, chals)
+        return O.msm_pippenger(CURVE_VESTA, g, s, threads=cores)
+
+    ok = bool((one() == sg_one).all())
+    t0 = time.perf_counter()
+    reps = 0
+    while True:
+        one()
+        reps += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s or reps >= 200:
+            break
+    return {"value": reps / el, "unit": "proofs/s", "cores": cores, "kind": "port",
+            "sample": f"{reps} single-proof accumulator checks (to_field + b_poly_coefficients + ark-style Pippenger c=13, "
+                      f"one thread per window) in {el:.1f}s; matches GPU sg: {ok}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=1, help="proofs folded into one MSM per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import mina_bridge_amd as m
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    dist_on = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if dist_on:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    ctx = m.MinaContext(local_rank)
+    ctx.srs_create(CURVE_VESTA, N_BASES)                       # SRS regenerated on the GPU (K4) + window tables
+    B = args.batch
+    pre, sgs = make_instances(ctx, B, seed=0x6D696E61 + rank)
+    dev = torch.device("cuda", local_rank)
+    d_pre = torch.from_numpy(pre.reshape(-1)).to(dev)
+    d_sg = torch.from_numpy(sgs.reshape(-1)).to(dev)
+    rho = np.random.Generator(np.random.PCG64(99 + rank)).integers(0, 256, size=(B, 32), dtype=np.uint8)
+    rho[:, 31] &= 0x3F
+    d_rho = torch.from_numpy(rho.reshape(-1)).to(dev)
+    d_verdict = torch.zeros(1, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+
+    def step():
+        ctx.accumulator_check_dev(CURVE_VESTA, K_ROUNDS, B, d_pre.data_ptr(), d_sg.data_ptr(),
+                                  d_rho.data_ptr() if B > 1 else 0, d_verdict.data_ptr())
+
+    for _ in range(args.warmup):
+        step()
+    ctx.synchronize()
+    assert int(d_verdict.item()) == 1, "warm-up verdict must be ACCEPT"
+
+    def barrier():
+        if dist_on:
+            dist.barrier()
+
+    ctx.prof_enable(PS_ACCUMULATE_BIT)                         # HIP events around the dominant kernel, on the ctx stream
+    barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    ctx.synchronize(); torch.cuda.synchronize(); barrier()
+    elapsed = time.perf_counter() - t0
+    prof = ctx.prof_read()
+    ctx.prof_enable(0)
+    assert int(d_verdict.item()) == 1, "timed-region verdict must be ACCEPT"
+
+    if dist_on:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        launches, total_ms = prof.get("msm_accumulate", [0, 0.0])
+        kern_s = (total_ms / launches) * 1e-3 if launches else float("nan")
+        achieved = MSM_ALGORITHMIC_BYTES / kern_s / 1e9 if launches else None
+        out = {
+            "metric": "Mina state proofs verified/sec (batch)",
+            "value": args.gpus * args.steps * B / elapsed,
+            "unit": "proofs/s",
+            "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32x8-montgomery (255-bit prime field, integer)", "data": "synthetic",
+            "config": {"workload": "C2: per-proof 2^16-base Vesta IPA accumulator check (to_field + b_poly_coefficients + MSM over "
+                                   "vesta.srs + compare), bit-exact vs CPU oracle", "curve": "vesta", "n_bases": N_BASES,
+                       "proofs_per_step": B, "sharding": f"proof-level, {args.gpus} rank(s), no collective"},
+            "roofline": {"bound": "hbm", "kernel": "msm_accumulate_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": None,
+                         "algorithmic_bytes_per_launch": MSM_ALGORITHMIC_BYTES, "avg_launch_us": kern_s * 1e6,
+                         "note": "integer-VALU-bound path (SURVEY.md 8d): HBM fraction reported as the metric demands"},
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(pre[0], sgs[0])
+        print(json.dumps(out), flush=True)
+    if dist_on:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

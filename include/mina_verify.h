@@ -71,6 +71,12 @@ int mina_ctx_synchronize(mina_ctx *ctx);
 /* the hipStream_t the `_dev` entry points are queued on (for event timing by the caller) */
 void *mina_ctx_stream(mina_ctx *ctx);
 
+/* HIP-event stage timing on the context stream.  `stage_mask` has one bit per pipeline stage (0 = off,
+ * -1 = all; bit 3 = the MSM bucket-accumulate kernel).  mina_prof_read synchronises and writes a JSON object
+ * {"stage": [launches, total_ms], ...} covering everything recorded since the previous read. */
+int mina_prof_enable(mina_ctx *ctx, int stage_mask);
+int mina_prof_read(mina_ctx *ctx, char *buf, size_t cap);
+
 /* ---- SRS (a6) -------------------------------------------------------------------------------- */
 /* Regenerate SRS{g[0..depth), h} exactly as poly-commitment `SRS::create(depth)` does
  * (BLAKE2b-512 -> field -> BW group map, K4 on the GPU) and build the MSM window tables in HBM. */

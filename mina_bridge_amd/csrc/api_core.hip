@@ -72,6 +72,7 @@ extern "C" void mina_ctx_destroy(mina_ctx *c) {
                      &c->tmp_d, &c->bp_ltab, &c->bp_htab, &c->bp_partial, &c->ipa_chals, &c->ipa_folded, &c->ipa_xyzz_a, &c->ipa_xyzz_b,
                      &c->ipa_points, &c->ipa_scalars, &c->ipa_sigma, &c->ipa_in_a, &c->ipa_in_b, &c->ipa_in_c, &c->ipa_verdict};
     for (DevBuf *b : all) b->release();
+    for (auto &r : c->prof.recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -134,3 +135,53 @@ extern "C" int mina_field_sqrt(mina_ctx *c, int field, size_t n, const uint8_t *
     return d2h_sync(c, out, c->tmp_c, n * 32);
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// stage timing
+static const char *PROF_NAMES[PS_COUNT] = {"msm_digits", "msm_scan", "msm_scatter", "msm_accumulate", "msm_bucket_sum", "msm_reduce_a",
+                                           "msm_reduce_bc", "msm_finish", "bpoly_tables", "bpoly_fold", "bpoly_finish", "challenges", "compare"};
+void mb_prof_begin(mina_ctx *c, int stage) {
+    ProfState &p = c->prof;
+    if (p.used == p.recs.size()) {
+        ProfState::Rec r; r.stage = stage;
+        if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return;
+        p.recs.push_back(r);
+    }
+    p.recs[p.used].stage = stage;
+    (void)hipEventRecord(p.recs[p.used].a, c->stream);
+}
+void mb_prof_end(mina_ctx *c, int stage) {
+    ProfState &p = c->prof;
+    if (p.used >= p.recs.size() || p.recs[p.used].stage != stage) return;
+    (void)hipEventRecord(p.recs[p.used].b, c->stream);
+    ++p.used;
+}
+extern "C" int mina_prof_enable(mina_ctx *c, int stage_mask) {
+    if (!c) return fail(MINA_ERR_ARG, "null ctx");
+    c->prof.mask = stage_mask; c->prof.used = 0;
+    return MINA_OK;
+}
+// Synchronises the stream, writes {"stage": [launches, total_ms], ...} for everything recorded since the last
+// read / enable, and resets the recording.
+extern "C" int mina_prof_read(mina_ctx *c, char *buf, size_t cap) {
+    if (!c || !buf || cap < 8) return fail(MINA_ERR_ARG, "bad argument");
+    HIPC(hipSetDevice(c->device));
+    HIPC(hipStreamSynchronize(c->stream));
+    double tot[PS_COUNT] = {0}; int cnt[PS_COUNT] = {0};
+    for (size_t i = 0; i < c->prof.used; ++i) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, c->prof.recs[i].a, c->prof.recs[i].b) == hipSuccess) { tot[c->prof.recs[i].stage] += ms; cnt[c->prof.recs[i].stage]++; }
+    }
+    c->prof.used = 0;
+    std::string o = "{";
+    bool first = true;
+    for (int s = 0; s < PS_COUNT; ++s) {
+        if (!cnt[s]) continue;
+        char tmp[128]; snprintf(tmp, sizeof tmp, "%s\"%s\": [%d, %.6f]", first ? "" : ", ", PROF_NAMES[s], cnt[s], tot[s]);
+        o += tmp; first = false;
+    }
+    o += "}";
+    if (o.size() + 1 > cap) return fail(MINA_ERR_ARG, "buffer too small");
+    memcpy(buf, o.c_str(), o.size() + 1);
+    return MINA_OK;
+}

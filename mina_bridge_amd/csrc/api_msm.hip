@@ -38,18 +38,18 @@ static int run_msm(mina_ctx *c, const MsmShape &sh, const uint32_t *d_scalars, c
 
     hipStream_t st = c->stream;
     HIPC(hipMemsetAsync(w.count.p, 0, (size_t)nb_total * 4, st));
-    msm_digits_kernel<<<cdiv(sh.n, 256), 256, 0, st>>>(sh, d_scalars, w.count.as<uint32_t>(), w.ekey.as<uint32_t>(),
-                                                       w.eval.as<uint32_t>(), w.eoff.as<uint32_t>());
-    msm_scan_kernel<<<1, 1024, 0, st>>>(nb_total, w.count.as<uint32_t>(), w.start.as<uint32_t>(), w.task_start.as<uint32_t>());
-    msm_scatter_kernel<<<cdiv(entries, 256), 256, 0, st>>>(entries, w.ekey.as<uint32_t>(), w.eval.as<uint32_t>(),
-                                                           w.eoff.as<uint32_t>(), w.start.as<uint32_t>(), w.sorted.as<uint32_t>());
-    msm_accumulate_kernel<F><<<cdiv(max_tasks, 256), 256, 0, st>>>(nb_total, w.start.as<uint32_t>(), w.task_start.as<uint32_t>(),
-                                                                   w.sorted.as<uint32_t>(), d_points, fk.one, w.partial.as<xyzz_t>());
-    msm_bucket_sum_kernel<F><<<cdiv(nb_total, 256), 256, 0, st>>>(nb_total, w.task_start.as<uint32_t>(), w.partial.as<xyzz_t>(),
-                                                                  w.buckets.as<xyzz_t>());
-    msm_reduce_a_kernel<F><<<groups, 64, 0, st>>>(nb_total, w.buckets.as<xyzz_t>(), w.red_r.as<xyzz_t>(), w.red_ws.as<xyzz_t>());
-    msm_reduce_bc_kernel<F><<<sh.nsets, 64, 0, st>>>(sh.NB / 64, w.red_r.as<xyzz_t>(), w.red_ws.as<xyzz_t>(), w.set_total.as<xyzz_t>());
-    msm_finish_kernel<F><<<1, 64, 0, st>>>(sh.nsets, sh.c, w.set_total.as<xyzz_t>(), fk.one, fk.pm2, d_out_xyzz, d_out_words);
+    { ProfScope ps_(c, PS_DIGITS); msm_digits_kernel<<<cdiv(sh.n, 256), 256, 0, st>>>(sh, d_scalars, w.count.as<uint32_t>(), w.ekey.as<uint32_t>(),
+                                                       w.eval.as<uint32_t>(), w.eoff.as<uint32_t>()); }
+    { ProfScope ps_(c, PS_SCAN); msm_scan_kernel<<<1, 1024, 0, st>>>(nb_total, w.count.as<uint32_t>(), w.start.as<uint32_t>(), w.task_start.as<uint32_t>()); }
+    { ProfScope ps_(c, PS_SCATTER); msm_scatter_kernel<<<cdiv(entries, 256), 256, 0, st>>>(entries, w.ekey.as<uint32_t>(), w.eval.as<uint32_t>(),
+                                                           w.eoff.as<uint32_t>(), w.start.as<uint32_t>(), w.sorted.as<uint32_t>()); }
+    { ProfScope ps_(c, PS_ACCUMULATE); msm_accumulate_kernel<F><<<cdiv(max_tasks, 256), 256, 0, st>>>(nb_total, w.start.as<uint32_t>(), w.task_start.as<uint32_t>(),
+                                                                   w.sorted.as<uint32_t>(), d_points, fk.one, w.partial.as<xyzz_t>()); }
+    { ProfScope ps_(c, PS_BUCKET_SUM); msm_bucket_sum_kernel<F><<<cdiv(nb_total, 256), 256, 0, st>>>(nb_total, w.task_start.as<uint32_t>(), w.partial.as<xyzz_t>(),
+                                                                  w.buckets.as<xyzz_t>()); }
+    { ProfScope ps_(c, PS_REDUCE_A); msm_reduce_a_kernel<F><<<groups, 64, 0, st>>>(nb_total, w.buckets.as<xyzz_t>(), w.red_r.as<xyzz_t>(), w.red_ws.as<xyzz_t>()); }
+    { ProfScope ps_(c, PS_REDUCE_BC); msm_reduce_bc_kernel<F><<<sh.nsets, 64, 0, st>>>(sh.NB / 64, w.red_r.as<xyzz_t>(), w.red_ws.as<xyzz_t>(), w.set_total.as<xyzz_t>()); }
+    { ProfScope ps_(c, PS_FINISH); msm_finish_kernel<F><<<1, 64, 0, st>>>(sh.nsets, sh.c, w.set_total.as<xyzz_t>(), fk.one, fk.pm2, d_out_xyzz, d_out_words); }
     HIPC(hipGetLastError());
     return MINA_OK;
 }

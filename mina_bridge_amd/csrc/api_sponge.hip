@@ -18,9 +18,9 @@ static int run_bpoly_fold(mina_ctx *c, uint32_t k, size_t batch, const uint32_t 
     if ((rc = c->bp_ltab.ensure(batch * nl * sizeof(fe_t)))) return rc;
     if ((rc = c->bp_htab.ensure(batch * nh * sizeof(fe_t)))) return rc;
     if ((rc = c->bp_partial.ensure((size_t)slices * n * sizeof(fe_t)))) return rc;
-    bpoly_tables_kernel<F><<<cdiv(batch * (nl + nh), 256), 256, 0, c->stream>>>(sh, c->fk[F], d_chals, d_weights, c->bp_ltab.as<fe_t>(), c->bp_htab.as<fe_t>());
-    bpoly_fold_kernel<F><<<lo_blocks * hi_tiles * slices, 256, 0, c->stream>>>(sh, slices, c->bp_ltab.as<fe_t>(), c->bp_htab.as<fe_t>(), c->bp_partial.as<fe_t>());
-    bpoly_finish_kernel<F><<<cdiv(n, 256), 256, 0, c->stream>>>(n, slices, c->bp_partial.as<fe_t>(), d_out);
+    { ProfScope ps_(c, PS_BPOLY_TABLES); bpoly_tables_kernel<F><<<cdiv(batch * (nl + nh), 256), 256, 0, c->stream>>>(sh, c->fk[F], d_chals, d_weights, c->bp_ltab.as<fe_t>(), c->bp_htab.as<fe_t>()); }
+    { ProfScope ps_(c, PS_BPOLY_FOLD); bpoly_fold_kernel<F><<<lo_blocks * hi_tiles * slices, 256, 0, c->stream>>>(sh, slices, c->bp_ltab.as<fe_t>(), c->bp_htab.as<fe_t>(), c->bp_partial.as<fe_t>()); }
+    { ProfScope ps_(c, PS_BPOLY_FINISH); bpoly_finish_kernel<F><<<cdiv(n, 256), 256, 0, c->stream>>>(n, slices, c->bp_partial.as<fe_t>(), d_out); }
     HIPC(hipGetLastError());
     return MINA_OK;
 }

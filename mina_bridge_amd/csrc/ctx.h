@@ -47,8 +47,18 @@ struct MsmWorkspace {
     DevBuf scalars, points, ekey, eval, eoff, count, start, task_start, sorted, partial, buckets, red_r, red_ws, set_total, out_words, out_xyzz;
 };
 
+// HIP-event stage timing on the context stream (off by default; bench.py turns it on for the timed region)
+enum ProfStage : int { PS_DIGITS = 0, PS_SCAN, PS_SCATTER, PS_ACCUMULATE, PS_BUCKET_SUM, PS_REDUCE_A, PS_REDUCE_BC, PS_FINISH,
+                       PS_BPOLY_TABLES, PS_BPOLY_FOLD, PS_BPOLY_FINISH, PS_CHALLENGES, PS_COMPARE, PS_COUNT };
+struct ProfState {
+    int mask = 0;                                   // bit per stage; 0 = off
+    struct Rec { hipEvent_t a, b; int stage; };
+    std::vector<Rec> recs; size_t used = 0;
+};
+
 struct mina_ctx {
     int device = 0;
+    ProfState prof;
     hipStream_t stream = nullptr;
     FieldK fk[2];
     SrsState srs[2];
@@ -82,6 +92,14 @@ static inline int d2h_sync(mina_ctx *c, void *dst, const DevBuf &b, size_t bytes
     HIPC(hipStreamSynchronize(c->stream));
     return MINA_OK;
 }
+
+void mb_prof_begin(mina_ctx *c, int stage);
+void mb_prof_end(mina_ctx *c, int stage);
+struct ProfScope {
+    mina_ctx *c; int stage;
+    ProfScope(mina_ctx *c_, int s_) : c(c_), stage(s_) { if (c->prof.mask & (1 << stage)) mb_prof_begin(c, stage); }
+    ~ProfScope() { if (c->prof.mask & (1 << stage)) mb_prof_end(c, stage); }
+};
 
 // cross-file entry points (C++ linkage)
 struct xyzz_dev;   // opaque: mb::xyzz_t in HBM
