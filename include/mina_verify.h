@@ -71,6 +71,10 @@ int mina_ctx_synchronize(mina_ctx *ctx);
 /* the hipStream_t the `_dev` entry points are queued on (for event timing by the caller) */
 void *mina_ctx_stream(mina_ctx *ctx);
 
+/* Pipelining: the `_dev` entry points are issued round-robin over `lanes` internal streams (1..16, default 1),
+ * each with its own workspace, so independent calls overlap on the GPU.  mina_ctx_synchronize waits for all. */
+int mina_ctx_set_pipeline(mina_ctx *ctx, int lanes);
+
 /* HIP-event stage timing on the context stream.  `stage_mask` has one bit per pipeline stage (0 = off,
  * -1 = all; bit 3 = the MSM bucket-accumulate kernel).  mina_prof_read synchronises and writes a JSON object
  * {"stage": [launches, total_ms], ...} covering everything recorded since the previous read. */

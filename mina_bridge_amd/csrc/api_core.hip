@@ -53,8 +53,9 @@ extern "C" int mina_ctx_create(int device_id, mina_ctx **out) {
     HIPC(hipSetDevice(device_id));
     mina_ctx *c = new mina_ctx();
     c->device = device_id;
-    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    hipError_t e = hipStreamCreateWithFlags(&c->lanes[0].stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return fail(MINA_ERR_HIP, "hipStreamCreate failed"); }
+    c->use_lane0();
     c->fk[FIELD_FP] = make_field_consts<FIELD_FP>();
     c->fk[FIELD_FQ] = make_field_consts<FIELD_FQ>();
     *out = c;
@@ -64,25 +65,32 @@ extern "C" int mina_ctx_create(int device_id, mina_ctx **out) {
 extern "C" void mina_ctx_destroy(mina_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    (void)hipStreamSynchronize(c->stream);
+    for (int i = 0; i < MB_MAX_LANES; ++i) if (c->lanes[i].stream) (void)hipStreamSynchronize(c->lanes[i].stream);
     for (int i = 0; i < 2; ++i) { c->srs[i].table.release(); c->srs[i].h.release(); c->pparams[i].release(); }
-    MsmWorkspace &w = c->ws;
-    DevBuf *all[] = {&w.scalars, &w.points, &w.ekey, &w.eval, &w.eoff, &w.count, &w.start, &w.task_start, &w.sorted, &w.partial,
-                     &w.buckets, &w.red_r, &w.red_ws, &w.set_total, &w.out_words, &w.out_xyzz, &c->tmp_a, &c->tmp_b, &c->tmp_c,
-                     &c->tmp_d, &c->bp_ltab, &c->bp_htab, &c->bp_partial, &c->ipa_chals, &c->ipa_folded, &c->ipa_xyzz_a, &c->ipa_xyzz_b,
-                     &c->ipa_points, &c->ipa_scalars, &c->ipa_sigma, &c->ipa_in_a, &c->ipa_in_b, &c->ipa_in_c, &c->ipa_verdict};
-    for (DevBuf *b : all) b->release();
+    for (int i = 0; i < MB_MAX_LANES; ++i) c->lanes[i].release_all();
     for (auto &r : c->prof.recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
-    (void)hipStreamDestroy(c->stream);
+    for (int i = 0; i < MB_MAX_LANES; ++i) if (c->lanes[i].stream) (void)hipStreamDestroy(c->lanes[i].stream);
     delete c;
 }
 
 extern "C" int mina_ctx_synchronize(mina_ctx *c) {
     if (!c) return fail(MINA_ERR_ARG, "null ctx");
-    HIPC(hipStreamSynchronize(c->stream));
+    HIPC(hipSetDevice(c->device));
+    for (int i = 0; i < c->nlanes; ++i) HIPC(hipStreamSynchronize(c->lanes[i].stream));
     return MINA_OK;
 }
-extern "C" void *mina_ctx_stream(mina_ctx *c) { return c ? (void *)c->stream : nullptr; }
+extern "C" void *mina_ctx_stream(mina_ctx *c) { return c ? (void *)c->lanes[0].stream : nullptr; }
+
+extern "C" int mina_ctx_set_pipeline(mina_ctx *c, int lanes) {
+    if (!c) return fail(MINA_ERR_ARG, "null ctx");
+    if (lanes < 1 || lanes > MB_MAX_LANES) return fail(MINA_ERR_ARG, "lanes must be in 1..16");
+    HIPC(hipSetDevice(c->device));
+    for (int i = 0; i < c->nlanes; ++i) HIPC(hipStreamSynchronize(c->lanes[i].stream));
+    for (int i = 0; i < lanes; ++i)
+        if (!c->lanes[i].stream) HIPC(hipStreamCreateWithFlags(&c->lanes[i].stream, hipStreamNonBlocking));
+    c->nlanes = lanes; c->rr = 0; c->use_lane0();
+    return MINA_OK;
+}
 
 // ------------------------------------------------------------------------------------------------
 extern "C" int mina_to_group(mina_ctx *c, int curve, size_t n, const uint8_t *t, uint8_t *out) {
@@ -90,12 +98,13 @@ extern "C" int mina_to_group(mina_ctx *c, int curve, size_t n, const uint8_t *t,
     if (curve != 0 && curve != 1) return fail(MINA_ERR_ARG, "bad curve");
     if (n == 0) return MINA_OK;
     HIPC(hipSetDevice(c->device));
+    c->use_lane0();
     int rc;
-    if ((rc = h2d(c, c->tmp_a, t, n * 32))) return rc;
-    if ((rc = c->tmp_b.ensure(n * 64))) return rc;
+    if ((rc = h2d(c, c->L->tmp_a, t, n * 32))) return rc;
+    if ((rc = c->L->tmp_b.ensure(n * 64))) return rc;
     const int F = base_field_of(curve);
-    DISPATCH_FIELD(F, { to_group_kernel<F_><<<cdiv(n, 128), 128, 0, c->stream>>>((uint32_t)n, c->fk[F_], c->tmp_a.as<uint32_t>(), c->tmp_b.as<uint32_t>()); });
-    return d2h_sync(c, out, c->tmp_b, n * 64);
+    DISPATCH_FIELD(F, { to_group_kernel<F_><<<cdiv(n, 128), 128, 0, c->L->stream>>>((uint32_t)n, c->fk[F_], c->L->tmp_a.as<uint32_t>(), c->L->tmp_b.as<uint32_t>()); });
+    return d2h_sync(c, out, c->L->tmp_b, n * 64);
 }
 
 extern "C" int mina_field_mul(mina_ctx *c, int field, size_t n, const uint8_t *a, const uint8_t *b, uint8_t *out) {
@@ -103,36 +112,39 @@ extern "C" int mina_field_mul(mina_ctx *c, int field, size_t n, const uint8_t *a
     if (bad_field(field)) return fail(MINA_ERR_ARG, "bad field");
     if (n == 0) return MINA_OK;
     HIPC(hipSetDevice(c->device));
+    c->use_lane0();
     int rc;
-    if ((rc = h2d(c, c->tmp_a, a, n * 32))) return rc;
-    if ((rc = h2d(c, c->tmp_b, b, n * 32))) return rc;
-    if ((rc = c->tmp_c.ensure(n * 32))) return rc;
-    DISPATCH_FIELD(field, { field_mul_kernel<F_><<<cdiv(n, 256), 256, 0, c->stream>>>((uint32_t)n, c->fk[F_], c->tmp_a.as<uint32_t>(), c->tmp_b.as<uint32_t>(), c->tmp_c.as<uint32_t>()); });
-    return d2h_sync(c, out, c->tmp_c, n * 32);
+    if ((rc = h2d(c, c->L->tmp_a, a, n * 32))) return rc;
+    if ((rc = h2d(c, c->L->tmp_b, b, n * 32))) return rc;
+    if ((rc = c->L->tmp_c.ensure(n * 32))) return rc;
+    DISPATCH_FIELD(field, { field_mul_kernel<F_><<<cdiv(n, 256), 256, 0, c->L->stream>>>((uint32_t)n, c->fk[F_], c->L->tmp_a.as<uint32_t>(), c->L->tmp_b.as<uint32_t>(), c->L->tmp_c.as<uint32_t>()); });
+    return d2h_sync(c, out, c->L->tmp_c, n * 32);
 }
 extern "C" int mina_field_inv(mina_ctx *c, int field, size_t n, const uint8_t *a, uint8_t *out) {
     if (!c || (n && (!a || !out))) return fail(MINA_ERR_ARG, "null argument");
     if (bad_field(field)) return fail(MINA_ERR_ARG, "bad field");
     if (n == 0) return MINA_OK;
     HIPC(hipSetDevice(c->device));
+    c->use_lane0();
     int rc;
-    if ((rc = h2d(c, c->tmp_a, a, n * 32))) return rc;
-    if ((rc = c->tmp_c.ensure(n * 32))) return rc;
-    DISPATCH_FIELD(field, { field_inv_kernel<F_><<<cdiv(n, 256), 256, 0, c->stream>>>((uint32_t)n, c->fk[F_], c->tmp_a.as<uint32_t>(), c->tmp_c.as<uint32_t>()); });
-    return d2h_sync(c, out, c->tmp_c, n * 32);
+    if ((rc = h2d(c, c->L->tmp_a, a, n * 32))) return rc;
+    if ((rc = c->L->tmp_c.ensure(n * 32))) return rc;
+    DISPATCH_FIELD(field, { field_inv_kernel<F_><<<cdiv(n, 256), 256, 0, c->L->stream>>>((uint32_t)n, c->fk[F_], c->L->tmp_a.as<uint32_t>(), c->L->tmp_c.as<uint32_t>()); });
+    return d2h_sync(c, out, c->L->tmp_c, n * 32);
 }
 extern "C" int mina_field_sqrt(mina_ctx *c, int field, size_t n, const uint8_t *a, uint8_t *out, uint8_t *ok) {
     if (!c || (n && (!a || !out || !ok))) return fail(MINA_ERR_ARG, "null argument");
     if (bad_field(field)) return fail(MINA_ERR_ARG, "bad field");
     if (n == 0) return MINA_OK;
     HIPC(hipSetDevice(c->device));
+    c->use_lane0();
     int rc;
-    if ((rc = h2d(c, c->tmp_a, a, n * 32))) return rc;
-    if ((rc = c->tmp_c.ensure(n * 32))) return rc;
-    if ((rc = c->tmp_d.ensure(n))) return rc;
-    DISPATCH_FIELD(field, { field_sqrt_kernel<F_><<<cdiv(n, 256), 256, 0, c->stream>>>((uint32_t)n, c->fk[F_], c->tmp_a.as<uint32_t>(), c->tmp_c.as<uint32_t>(), c->tmp_d.as<uint8_t>()); });
-    HIPC(hipMemcpyAsync(ok, c->tmp_d.p, n, hipMemcpyDeviceToHost, c->stream));
-    return d2h_sync(c, out, c->tmp_c, n * 32);
+    if ((rc = h2d(c, c->L->tmp_a, a, n * 32))) return rc;
+    if ((rc = c->L->tmp_c.ensure(n * 32))) return rc;
+    if ((rc = c->L->tmp_d.ensure(n))) return rc;
+    DISPATCH_FIELD(field, { field_sqrt_kernel<F_><<<cdiv(n, 256), 256, 0, c->L->stream>>>((uint32_t)n, c->fk[F_], c->L->tmp_a.as<uint32_t>(), c->L->tmp_c.as<uint32_t>(), c->L->tmp_d.as<uint8_t>()); });
+    HIPC(hipMemcpyAsync(ok, c->L->tmp_d.p, n, hipMemcpyDeviceToHost, c->L->stream));
+    return d2h_sync(c, out, c->L->tmp_c, n * 32);
 }
 
 
@@ -148,12 +160,12 @@ void mb_prof_begin(mina_ctx *c, int stage) {
         p.recs.push_back(r);
     }
     p.recs[p.used].stage = stage;
-    (void)hipEventRecord(p.recs[p.used].a, c->stream);
+    (void)hipEventRecord(p.recs[p.used].a, c->L->stream);
 }
 void mb_prof_end(mina_ctx *c, int stage) {
     ProfState &p = c->prof;
     if (p.used >= p.recs.size() || p.recs[p.used].stage != stage) return;
-    (void)hipEventRecord(p.recs[p.used].b, c->stream);
+    (void)hipEventRecord(p.recs[p.used].b, c->L->stream);
     ++p.used;
 }
 extern "C" int mina_prof_enable(mina_ctx *c, int stage_mask) {
@@ -166,7 +178,7 @@ extern "C" int mina_prof_enable(mina_ctx *c, int stage_mask) {
 extern "C" int mina_prof_read(mina_ctx *c, char *buf, size_t cap) {
     if (!c || !buf || cap < 8) return fail(MINA_ERR_ARG, "bad argument");
     HIPC(hipSetDevice(c->device));
-    HIPC(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < c->nlanes; ++i) HIPC(hipStreamSynchronize(c->lanes[i].stream));
     double tot[PS_COUNT] = {0}; int cnt[PS_COUNT] = {0};
     for (size_t i = 0; i < c->prof.used; ++i) {
         float ms = 0;

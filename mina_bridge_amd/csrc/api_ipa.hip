@@ -194,20 +194,20 @@ static int accumulator_check_dev(mina_ctx *c, int curve, uint32_t k, size_t batc
     const int FS = scalar_field_of(curve), FB = base_field_of(curve);
     const uint32_t n = 1u << k;
     int rc;
-    if ((rc = c->ipa_chals.ensure(batch * k * 32))) return rc;
-    if ((rc = c->ipa_folded.ensure((size_t)n * 32))) return rc;
-    if ((rc = c->ipa_xyzz_a.ensure(sizeof(xyzz_t)))) return rc;
-    if ((rc = c->ipa_xyzz_b.ensure(sizeof(xyzz_t)))) return rc;
-    DISPATCH_FIELD(FS, { challenge_to_field_kernel<F_><<<cdiv(batch * k, 64), 64, 0, c->stream>>>((uint32_t)(batch * k), c->fk[F_], d_prechal, c->ipa_chals.as<uint32_t>()); });
-    if ((rc = mina_b_poly_fold_dev(c, FS, k, batch, c->ipa_chals.p, batch > 1 ? d_rho : nullptr, c->ipa_folded.p))) return rc;
-    if ((rc = mb_msm_fixed(c, curve, n, c->ipa_folded.as<uint32_t>(), nullptr, c->ipa_xyzz_a.p))) return rc;
+    if ((rc = c->L->ipa_chals.ensure(batch * k * 32))) return rc;
+    if ((rc = c->L->ipa_folded.ensure((size_t)n * 32))) return rc;
+    if ((rc = c->L->ipa_xyzz_a.ensure(sizeof(xyzz_t)))) return rc;
+    if ((rc = c->L->ipa_xyzz_b.ensure(sizeof(xyzz_t)))) return rc;
+    DISPATCH_FIELD(FS, { challenge_to_field_kernel<F_><<<cdiv(batch * k, 64), 64, 0, c->L->stream>>>((uint32_t)(batch * k), c->fk[F_], d_prechal, c->L->ipa_chals.as<uint32_t>()); });
+    if ((rc = mb_bpoly_fold(c, FS, k, batch, c->L->ipa_chals.as<uint32_t>(), batch > 1 ? d_rho : nullptr, c->L->ipa_folded.as<uint32_t>()))) return rc;
+    if ((rc = mb_msm_fixed(c, curve, n, c->L->ipa_folded.as<uint32_t>(), nullptr, c->L->ipa_xyzz_a.p))) return rc;
     if (batch == 1) {
-        DISPATCH_FIELD(FB, { xyzz_eq_affine_kernel<F_><<<1, 64, 0, c->stream>>>(c->ipa_xyzz_a.as<xyzz_t>(), d_sg_words, c->fk[F_].r2, d_verdict); });
+        DISPATCH_FIELD(FB, { xyzz_eq_affine_kernel<F_><<<1, 64, 0, c->L->stream>>>(c->L->ipa_xyzz_a.as<xyzz_t>(), d_sg_words, c->fk[F_].r2, d_verdict); });
     } else {
-        if ((rc = c->ipa_points.ensure(batch * sizeof(affine_t)))) return rc;
-        DISPATCH_FIELD(FB, { points_to_mont_kernel<F_><<<cdiv(batch, 256), 256, 0, c->stream>>>((uint32_t)batch, d_sg_words, c->fk[F_].r2, c->ipa_points.as<affine_t>()); });
-        if ((rc = mb_msm_variable(c, curve, (uint32_t)batch, d_rho, c->ipa_points.p, nullptr, c->ipa_xyzz_b.p))) return rc;
-        DISPATCH_FIELD(FB, { xyzz_compare_kernel<F_><<<1, 64, 0, c->stream>>>(c->ipa_xyzz_a.as<xyzz_t>(), c->ipa_xyzz_b.as<xyzz_t>(), 0, d_verdict); });
+        if ((rc = c->L->ipa_points.ensure(batch * sizeof(affine_t)))) return rc;
+        DISPATCH_FIELD(FB, { points_to_mont_kernel<F_><<<cdiv(batch, 256), 256, 0, c->L->stream>>>((uint32_t)batch, d_sg_words, c->fk[F_].r2, c->L->ipa_points.as<affine_t>()); });
+        if ((rc = mb_msm_variable(c, curve, (uint32_t)batch, d_rho, c->L->ipa_points.p, nullptr, c->L->ipa_xyzz_b.p))) return rc;
+        DISPATCH_FIELD(FB, { xyzz_compare_kernel<F_><<<1, 64, 0, c->L->stream>>>(c->L->ipa_xyzz_a.as<xyzz_t>(), c->L->ipa_xyzz_b.as<xyzz_t>(), 0, d_verdict); });
     }
     HIPC(hipGetLastError());
     return MINA_OK;
@@ -219,6 +219,7 @@ extern "C" int mina_accumulator_check_dev(mina_ctx *c, int curve, uint32_t k, si
     if (curve != 0 && curve != 1) return fail(MINA_ERR_ARG, "bad curve");
     if (batch == 0 || batch > (1u << 20)) return fail(MINA_ERR_ARG, "bad batch");
     HIPC(hipSetDevice(c->device));
+    c->next_lane();
     return accumulator_check_dev(c, curve, k, batch, (const uint32_t *)d_prechallenges, (const uint32_t *)d_sg, (const uint32_t *)d_rho, (uint32_t *)d_verdict);
 }
 
@@ -228,21 +229,22 @@ extern "C" int mina_accumulator_check_batch(mina_ctx *c, int curve, uint32_t k, 
     if (curve != 0 && curve != 1) return fail(MINA_ERR_ARG, "bad curve");
     if (batch == 0 || batch > (1u << 20)) return fail(MINA_ERR_ARG, "bad batch");
     HIPC(hipSetDevice(c->device));
+    c->use_lane0();
     int rc;
-    if ((rc = h2d(c, c->ipa_in_a, prechallenges, batch * k * 16))) return rc;
-    if ((rc = h2d(c, c->ipa_in_b, sg, batch * 64))) return rc;
-    if (batch > 1 && (rc = h2d(c, c->ipa_in_c, rho, batch * 32))) return rc;
-    if ((rc = c->ipa_verdict.ensure(4))) return rc;
-    if ((rc = accumulator_check_dev(c, curve, k, batch, c->ipa_in_a.as<uint32_t>(), c->ipa_in_b.as<uint32_t>(),
-                                    batch > 1 ? c->ipa_in_c.as<uint32_t>() : nullptr, c->ipa_verdict.as<uint32_t>()))) return rc;
+    if ((rc = h2d(c, c->L->ipa_in_a, prechallenges, batch * k * 16))) return rc;
+    if ((rc = h2d(c, c->L->ipa_in_b, sg, batch * 64))) return rc;
+    if (batch > 1 && (rc = h2d(c, c->L->ipa_in_c, rho, batch * 32))) return rc;
+    if ((rc = c->L->ipa_verdict.ensure(4))) return rc;
+    if ((rc = accumulator_check_dev(c, curve, k, batch, c->L->ipa_in_a.as<uint32_t>(), c->L->ipa_in_b.as<uint32_t>(),
+                                    batch > 1 ? c->L->ipa_in_c.as<uint32_t>() : nullptr, c->L->ipa_verdict.as<uint32_t>()))) return rc;
     uint32_t v = 0;
-    if ((rc = d2h_sync(c, &v, c->ipa_verdict, 4))) return rc;
+    if ((rc = d2h_sync(c, &v, c->L->ipa_verdict, 4))) return rc;
     if (v || batch == 1) { memset(verdicts, v ? 1 : 0, batch); return MINA_OK; }
     // the folded check failed: find the culprits one proof at a time (rare path)
     for (size_t b = 0; b < batch; ++b) {
-        if ((rc = accumulator_check_dev(c, curve, k, 1, c->ipa_in_a.as<uint32_t>() + b * k * 4, c->ipa_in_b.as<uint32_t>() + b * 16,
-                                        nullptr, c->ipa_verdict.as<uint32_t>()))) return rc;
-        if ((rc = d2h_sync(c, &v, c->ipa_verdict, 4))) return rc;
+        if ((rc = accumulator_check_dev(c, curve, k, 1, c->L->ipa_in_a.as<uint32_t>() + b * k * 4, c->L->ipa_in_b.as<uint32_t>() + b * 16,
+                                        nullptr, c->L->ipa_verdict.as<uint32_t>()))) return rc;
+        if ((rc = d2h_sync(c, &v, c->L->ipa_verdict, 4))) return rc;
         verdicts[b] = v ? 1 : 0;
     }
     return MINA_OK;
@@ -268,6 +270,7 @@ extern "C" int mina_ipa_batch_check(mina_ctx *c, int curve, size_t batch, const 
             (npts && !o.evalpoints) || (m && !o.comms)) return fail(MINA_ERR_ARG, "null field in opening");
     }
     HIPC(hipSetDevice(c->device));
+    c->use_lane0();
     mb::IpaShape sh; sh.batch = (uint32_t)batch; sh.k = k; sh.npts = npts; sh.ncomms = m; sh.per = 2 * k + m + 4;
 
     // pack (host) -> one staging blob -> HBM
@@ -295,33 +298,33 @@ extern "C" int mina_ipa_batch_check(mina_ctx *c, int curve, size_t batch, const 
     memcpy(&blob[o_rb], rand_base, 32);
     memcpy(&blob[o_sb], sg_rand_base, 32);
     int rc;
-    if ((rc = h2d(c, c->ipa_in_a, blob.data(), total))) return rc;
-    const uint8_t *d = c->ipa_in_a.as<uint8_t>();
+    if ((rc = h2d(c, c->L->ipa_in_a, blob.data(), total))) return rc;
+    const uint8_t *d = c->L->ipa_in_a.as<uint8_t>();
     auto W = [&](size_t off) { return reinterpret_cast<const uint32_t *>(d + off); };
     const size_t npoints = batch * sh.per;
-    if ((rc = c->ipa_points.ensure(npoints * sizeof(affine_t)))) return rc;
-    if ((rc = c->ipa_scalars.ensure(npoints * 32))) return rc;
-    if ((rc = c->ipa_chals.ensure(batch * k * 32))) return rc;
-    if ((rc = c->ipa_sigma.ensure(batch * 32))) return rc;
-    if ((rc = c->ipa_folded.ensure(((size_t)1 << k) * 32))) return rc;
-    if ((rc = c->ipa_xyzz_a.ensure(sizeof(xyzz_t)))) return rc;
-    if ((rc = c->ipa_xyzz_b.ensure(sizeof(xyzz_t)))) return rc;
-    if ((rc = c->ipa_verdict.ensure(4))) return rc;
+    if ((rc = c->L->ipa_points.ensure(npoints * sizeof(affine_t)))) return rc;
+    if ((rc = c->L->ipa_scalars.ensure(npoints * 32))) return rc;
+    if ((rc = c->L->ipa_chals.ensure(batch * k * 32))) return rc;
+    if ((rc = c->L->ipa_sigma.ensure(batch * 32))) return rc;
+    if ((rc = c->L->ipa_folded.ensure(((size_t)1 << k) * 32))) return rc;
+    if ((rc = c->L->ipa_xyzz_a.ensure(sizeof(xyzz_t)))) return rc;
+    if ((rc = c->L->ipa_xyzz_b.ensure(sizeof(xyzz_t)))) return rc;
+    if ((rc = c->L->ipa_verdict.ensure(4))) return rc;
     const PoseidonParams *pp = c->pparams[FB].as<PoseidonParams>();
 #define IPA_PREP(CV)                                                                                                          \
-    mb::ipa_prepare_kernel<CV><<<cdiv(batch, 64), 64, 0, c->stream>>>(                                                         \
+    mb::ipa_prepare_kernel<CV><<<cdiv(batch, 64), 64, 0, c->L->stream>>>(                                                         \
         sh, c->fk[FB], c->fk[FS], pp, W(o_state), W(o_pos), W(o_cip), W(o_lr), W(o_delta), W(o_sg), W(o_z1), W(o_z2), W(o_pts), W(o_r), \
-        W(o_xi), W(o_comms), W(o_rb), W(o_sb), s.h.as<affine_t>(), c->ipa_points.as<affine_t>(), c->ipa_scalars.as<uint32_t>(), \
-        c->ipa_chals.as<uint32_t>(), c->ipa_sigma.as<uint32_t>())
+        W(o_xi), W(o_comms), W(o_rb), W(o_sb), s.h.as<affine_t>(), c->L->ipa_points.as<affine_t>(), c->L->ipa_scalars.as<uint32_t>(), \
+        c->L->ipa_chals.as<uint32_t>(), c->L->ipa_sigma.as<uint32_t>())
     if (curve == CURVE_PALLAS) IPA_PREP(CURVE_PALLAS); else IPA_PREP(CURVE_VESTA);
 #undef IPA_PREP
     HIPC(hipGetLastError());
-    if ((rc = mina_b_poly_fold_dev(c, FS, k, batch, c->ipa_chals.p, c->ipa_sigma.p, c->ipa_folded.p))) return rc;
-    if ((rc = mb_msm_fixed(c, curve, 1u << k, c->ipa_folded.as<uint32_t>(), nullptr, c->ipa_xyzz_a.p))) return rc;
-    if ((rc = mb_msm_variable(c, curve, (uint32_t)npoints, c->ipa_scalars.as<uint32_t>(), c->ipa_points.p, nullptr, c->ipa_xyzz_b.p))) return rc;
-    DISPATCH_FIELD(FB, { xyzz_compare_kernel<F_><<<1, 64, 0, c->stream>>>(c->ipa_xyzz_a.as<xyzz_t>(), c->ipa_xyzz_b.as<xyzz_t>(), 1, c->ipa_verdict.as<uint32_t>()); });
+    if ((rc = mb_bpoly_fold(c, FS, k, batch, c->L->ipa_chals.as<uint32_t>(), c->L->ipa_sigma.as<uint32_t>(), c->L->ipa_folded.as<uint32_t>()))) return rc;
+    if ((rc = mb_msm_fixed(c, curve, 1u << k, c->L->ipa_folded.as<uint32_t>(), nullptr, c->L->ipa_xyzz_a.p))) return rc;
+    if ((rc = mb_msm_variable(c, curve, (uint32_t)npoints, c->L->ipa_scalars.as<uint32_t>(), c->L->ipa_points.p, nullptr, c->L->ipa_xyzz_b.p))) return rc;
+    DISPATCH_FIELD(FB, { xyzz_compare_kernel<F_><<<1, 64, 0, c->L->stream>>>(c->L->ipa_xyzz_a.as<xyzz_t>(), c->L->ipa_xyzz_b.as<xyzz_t>(), 1, c->L->ipa_verdict.as<uint32_t>()); });
     uint32_t v = 0;
-    if ((rc = d2h_sync(c, &v, c->ipa_verdict, 4))) return rc;
+    if ((rc = d2h_sync(c, &v, c->L->ipa_verdict, 4))) return rc;
     *verdict = v ? 1 : 0;
     return MINA_OK;
 }

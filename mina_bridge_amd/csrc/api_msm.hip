@@ -16,7 +16,7 @@ static MsmShape variable_shape(uint32_t n) {
 template <int F>
 static int run_msm(mina_ctx *c, const MsmShape &sh, const uint32_t *d_scalars, const affine_t *d_points,
                    uint32_t *d_out_words /* 17 words */, xyzz_t *d_out_xyzz) {
-    MsmWorkspace &w = c->ws;
+    MsmWorkspace &w = c->L->ws;
     const FieldK &fk = c->fk[F];
     const uint32_t nb_total = sh.NB * sh.nsets;
     const size_t entries = (size_t)sh.n * sh.W;
@@ -36,7 +36,7 @@ static int run_msm(mina_ctx *c, const MsmShape &sh, const uint32_t *d_scalars, c
     if ((rc = w.red_ws.ensure((size_t)groups * sizeof(xyzz_t)))) return rc;
     if ((rc = w.set_total.ensure((size_t)sh.nsets * sizeof(xyzz_t)))) return rc;
 
-    hipStream_t st = c->stream;
+    hipStream_t st = c->L->stream;
     HIPC(hipMemsetAsync(w.count.p, 0, (size_t)nb_total * 4, st));
     { ProfScope ps_(c, PS_DIGITS); msm_digits_kernel<<<cdiv(sh.n, 256), 256, 0, st>>>(sh, d_scalars, w.count.as<uint32_t>(), w.ekey.as<uint32_t>(),
                                                        w.eval.as<uint32_t>(), w.eoff.as<uint32_t>()); }
@@ -84,21 +84,22 @@ extern "C" int mina_msm(mina_ctx *c, int curve, size_t n, const uint8_t *bases, 
     if (n == 0) { memset(out, 0, 64); return MINA_OK; }
     if (n > (1u << 24)) return fail(MINA_ERR_ARG, "n too large");
     HIPC(hipSetDevice(c->device));
+    c->use_lane0();
     int rc;
-    MsmWorkspace &w = c->ws;
+    MsmWorkspace &w = c->L->ws;
     if ((rc = w.scalars.ensure(n * 32))) return rc;
     if ((rc = w.points.ensure(n * sizeof(affine_t)))) return rc;
-    if ((rc = c->tmp_a.ensure(n * 64))) return rc;
+    if ((rc = c->L->tmp_a.ensure(n * 64))) return rc;
     if ((rc = w.out_words.ensure(17 * 4))) return rc;
-    HIPC(hipMemcpyAsync(w.scalars.p, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
-    HIPC(hipMemcpyAsync(c->tmp_a.p, bases, n * 64, hipMemcpyHostToDevice, c->stream));
+    HIPC(hipMemcpyAsync(w.scalars.p, scalars, n * 32, hipMemcpyHostToDevice, c->L->stream));
+    HIPC(hipMemcpyAsync(c->L->tmp_a.p, bases, n * 64, hipMemcpyHostToDevice, c->L->stream));
     DISPATCH_FIELD(base_field_of(curve), {
-        points_to_mont_kernel<F_><<<cdiv(n, 256), 256, 0, c->stream>>>((uint32_t)n, c->tmp_a.as<uint32_t>(), c->fk[F_].r2, w.points.as<affine_t>());
+        points_to_mont_kernel<F_><<<cdiv(n, 256), 256, 0, c->L->stream>>>((uint32_t)n, c->L->tmp_a.as<uint32_t>(), c->fk[F_].r2, w.points.as<affine_t>());
     });
     if ((rc = mb_msm_variable(c, curve, (uint32_t)n, w.scalars.as<uint32_t>(), w.points.p, w.out_words.as<uint32_t>(), nullptr))) return rc;
     uint32_t hw[17];
-    HIPC(hipMemcpyAsync(hw, w.out_words.p, sizeof hw, hipMemcpyDeviceToHost, c->stream));
-    HIPC(hipStreamSynchronize(c->stream));
+    HIPC(hipMemcpyAsync(hw, w.out_words.p, sizeof hw, hipMemcpyDeviceToHost, c->L->stream));
+    HIPC(hipStreamSynchronize(c->L->stream));
     words_to_point_bytes(hw, out);
     return MINA_OK;
 }
@@ -108,6 +109,7 @@ extern "C" int mina_msm_srs_dev(mina_ctx *c, int curve, size_t n, const void *d_
     if (curve != 0 && curve != 1) return fail(MINA_ERR_ARG, "bad curve");
     if (n > 0xffffffffu) return fail(MINA_ERR_ARG, "n too large");
     HIPC(hipSetDevice(c->device));
+    c->next_lane();
     return mb_msm_fixed(c, curve, (uint32_t)n, (const uint32_t *)d_scalars, (uint32_t *)d_out, nullptr);
 }
 
@@ -115,15 +117,17 @@ extern "C" int mina_msm_srs(mina_ctx *c, int curve, size_t n, const uint8_t *sca
     if (!c || !out || (n && !scalars)) return fail(MINA_ERR_ARG, "null argument");
     if (curve != 0 && curve != 1) return fail(MINA_ERR_ARG, "bad curve");
     if (n == 0) { memset(out, 0, 64); return MINA_OK; }
+    if (n > 0xffffffffu) return fail(MINA_ERR_ARG, "n too large");
     HIPC(hipSetDevice(c->device));
+    c->use_lane0();
     int rc;
-    if ((rc = c->ws.scalars.ensure(n * 32))) return rc;
-    if ((rc = c->ws.out_words.ensure(17 * 4))) return rc;
-    HIPC(hipMemcpyAsync(c->ws.scalars.p, scalars, n * 32, hipMemcpyHostToDevice, c->stream));
-    if ((rc = mina_msm_srs_dev(c, curve, n, c->ws.scalars.p, c->ws.out_words.p))) return rc;
+    if ((rc = c->L->ws.scalars.ensure(n * 32))) return rc;
+    if ((rc = c->L->ws.out_words.ensure(17 * 4))) return rc;
+    HIPC(hipMemcpyAsync(c->L->ws.scalars.p, scalars, n * 32, hipMemcpyHostToDevice, c->L->stream));
+    if ((rc = mb_msm_fixed(c, curve, (uint32_t)n, c->L->ws.scalars.as<uint32_t>(), c->L->ws.out_words.as<uint32_t>(), nullptr))) return rc;
     uint32_t hw[17];
-    HIPC(hipMemcpyAsync(hw, c->ws.out_words.p, sizeof hw, hipMemcpyDeviceToHost, c->stream));
-    HIPC(hipStreamSynchronize(c->stream));
+    HIPC(hipMemcpyAsync(hw, c->L->ws.out_words.p, sizeof hw, hipMemcpyDeviceToHost, c->L->stream));
+    HIPC(hipStreamSynchronize(c->L->stream));
     words_to_point_bytes(hw, out);
     return MINA_OK;
 }

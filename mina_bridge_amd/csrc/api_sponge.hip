@@ -15,24 +15,29 @@ static int run_bpoly_fold(mina_ctx *c, uint32_t k, size_t batch, const uint32_t 
     // enough blocks to fill 256 CUs x 4 when the batch is large
     while (slices * 2 <= batch && (size_t)lo_blocks * hi_tiles * slices < 2048 && slices < 64) slices *= 2;
     int rc;
-    if ((rc = c->bp_ltab.ensure(batch * nl * sizeof(fe_t)))) return rc;
-    if ((rc = c->bp_htab.ensure(batch * nh * sizeof(fe_t)))) return rc;
-    if ((rc = c->bp_partial.ensure((size_t)slices * n * sizeof(fe_t)))) return rc;
-    { ProfScope ps_(c, PS_BPOLY_TABLES); bpoly_tables_kernel<F><<<cdiv(batch * (nl + nh), 256), 256, 0, c->stream>>>(sh, c->fk[F], d_chals, d_weights, c->bp_ltab.as<fe_t>(), c->bp_htab.as<fe_t>()); }
-    { ProfScope ps_(c, PS_BPOLY_FOLD); bpoly_fold_kernel<F><<<lo_blocks * hi_tiles * slices, 256, 0, c->stream>>>(sh, slices, c->bp_ltab.as<fe_t>(), c->bp_htab.as<fe_t>(), c->bp_partial.as<fe_t>()); }
-    { ProfScope ps_(c, PS_BPOLY_FINISH); bpoly_finish_kernel<F><<<cdiv(n, 256), 256, 0, c->stream>>>(n, slices, c->bp_partial.as<fe_t>(), d_out); }
+    if ((rc = c->L->bp_ltab.ensure(batch * nl * sizeof(fe_t)))) return rc;
+    if ((rc = c->L->bp_htab.ensure(batch * nh * sizeof(fe_t)))) return rc;
+    if ((rc = c->L->bp_partial.ensure((size_t)slices * n * sizeof(fe_t)))) return rc;
+    { ProfScope ps_(c, PS_BPOLY_TABLES); bpoly_tables_kernel<F><<<cdiv(batch * (nl + nh), 256), 256, 0, c->L->stream>>>(sh, c->fk[F], d_chals, d_weights, c->L->bp_ltab.as<fe_t>(), c->L->bp_htab.as<fe_t>()); }
+    { ProfScope ps_(c, PS_BPOLY_FOLD); bpoly_fold_kernel<F><<<lo_blocks * hi_tiles * slices, 256, 0, c->L->stream>>>(sh, slices, c->L->bp_ltab.as<fe_t>(), c->L->bp_htab.as<fe_t>(), c->L->bp_partial.as<fe_t>()); }
+    { ProfScope ps_(c, PS_BPOLY_FINISH); bpoly_finish_kernel<F><<<cdiv(n, 256), 256, 0, c->L->stream>>>(n, slices, c->L->bp_partial.as<fe_t>(), d_out); }
     HIPC(hipGetLastError());
     return MINA_OK;
 }
 
-extern "C" int mina_b_poly_fold_dev(mina_ctx *c, int field, uint32_t k, size_t batch, const void *d_chals, const void *d_weights, void *d_out) {
-    if (!c || !d_chals || !d_out) return fail(MINA_ERR_ARG, "null argument");
+int mb_bpoly_fold(mina_ctx *c, int field, uint32_t k, size_t batch, const uint32_t *d_chals, const uint32_t *d_weights, uint32_t *d_out) {
     if (bad_field(field)) return fail(MINA_ERR_ARG, "bad field");
     if (k < 1 || k > 20 || batch == 0 || batch > (1u << 24)) return fail(MINA_ERR_ARG, "bad k or batch");
-    HIPC(hipSetDevice(c->device));
     int rc = MINA_OK;
-    DISPATCH_FIELD(field, { rc = run_bpoly_fold<F_>(c, k, batch, (const uint32_t *)d_chals, (const uint32_t *)d_weights, (uint32_t *)d_out); });
+    DISPATCH_FIELD(field, { rc = run_bpoly_fold<F_>(c, k, batch, d_chals, d_weights, d_out); });
     return rc;
+}
+
+extern "C" int mina_b_poly_fold_dev(mina_ctx *c, int field, uint32_t k, size_t batch, const void *d_chals, const void *d_weights, void *d_out) {
+    if (!c || !d_chals || !d_out) return fail(MINA_ERR_ARG, "null argument");
+    HIPC(hipSetDevice(c->device));
+    c->next_lane();
+    return mb_bpoly_fold(c, field, k, batch, (const uint32_t *)d_chals, (const uint32_t *)d_weights, (uint32_t *)d_out);
 }
 
 extern "C" int mina_b_poly_fold(mina_ctx *c, int field, uint32_t k, size_t batch, const uint8_t *chals, const uint8_t *weights, uint8_t *out) {
@@ -40,12 +45,13 @@ extern "C" int mina_b_poly_fold(mina_ctx *c, int field, uint32_t k, size_t batch
     if (bad_field(field)) return fail(MINA_ERR_ARG, "bad field");
     if (k < 1 || k > 20 || batch == 0) return fail(MINA_ERR_ARG, "bad k or batch");
     HIPC(hipSetDevice(c->device));
+    c->use_lane0();
     int rc;
-    if ((rc = h2d(c, c->tmp_a, chals, batch * k * 32))) return rc;
-    if (weights && (rc = h2d(c, c->tmp_b, weights, batch * 32))) return rc;
-    if ((rc = c->tmp_c.ensure(((size_t)1 << k) * 32))) return rc;
-    if ((rc = mina_b_poly_fold_dev(c, field, k, batch, c->tmp_a.p, weights ? c->tmp_b.p : nullptr, c->tmp_c.p))) return rc;
-    return d2h_sync(c, out, c->tmp_c, ((size_t)1 << k) * 32);
+    if ((rc = h2d(c, c->L->tmp_a, chals, batch * k * 32))) return rc;
+    if (weights && (rc = h2d(c, c->L->tmp_b, weights, batch * 32))) return rc;
+    if ((rc = c->L->tmp_c.ensure(((size_t)1 << k) * 32))) return rc;
+    if ((rc = mb_bpoly_fold(c, field, k, batch, c->L->tmp_a.as<uint32_t>(), weights ? c->L->tmp_b.as<uint32_t>() : nullptr, c->L->tmp_c.as<uint32_t>()))) return rc;
+    return d2h_sync(c, out, c->L->tmp_c, ((size_t)1 << k) * 32);
 }
 
 extern "C" int mina_b_poly_coefficients(mina_ctx *c, int field, uint32_t k, const uint8_t *chals, uint8_t *out) {
@@ -58,12 +64,13 @@ extern "C" int mina_b_poly(mina_ctx *c, int field, uint32_t k, const uint8_t *ch
     if (k < 1 || k > 32) return fail(MINA_ERR_ARG, "bad k");
     if (npoints == 0) return MINA_OK;
     HIPC(hipSetDevice(c->device));
+    c->use_lane0();
     int rc;
-    if ((rc = h2d(c, c->tmp_a, chals, (size_t)k * 32))) return rc;
-    if ((rc = h2d(c, c->tmp_b, xs, npoints * 32))) return rc;
-    if ((rc = c->tmp_c.ensure(npoints * 32))) return rc;
-    DISPATCH_FIELD(field, { bpoly_eval_kernel<F_><<<cdiv(npoints, 64), 64, 0, c->stream>>>(k, (uint32_t)npoints, c->fk[F_], c->tmp_a.as<uint32_t>(), c->tmp_b.as<uint32_t>(), c->tmp_c.as<uint32_t>()); });
-    return d2h_sync(c, out, c->tmp_c, npoints * 32);
+    if ((rc = h2d(c, c->L->tmp_a, chals, (size_t)k * 32))) return rc;
+    if ((rc = h2d(c, c->L->tmp_b, xs, npoints * 32))) return rc;
+    if ((rc = c->L->tmp_c.ensure(npoints * 32))) return rc;
+    DISPATCH_FIELD(field, { bpoly_eval_kernel<F_><<<cdiv(npoints, 64), 64, 0, c->L->stream>>>(k, (uint32_t)npoints, c->fk[F_], c->L->tmp_a.as<uint32_t>(), c->L->tmp_b.as<uint32_t>(), c->L->tmp_c.as<uint32_t>()); });
+    return d2h_sync(c, out, c->L->tmp_c, npoints * 32);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -78,23 +85,30 @@ extern "C" int mina_poseidon_set_params(mina_ctx *c, int field, const uint8_t *p
     if (!c || !params) return fail(MINA_ERR_ARG, "null argument");
     if (bad_field(field)) return fail(MINA_ERR_ARG, "bad field");
     HIPC(hipSetDevice(c->device));
+    c->use_lane0();
     PoseidonParams pp;
     DISPATCH_FIELD(field, { params_to_mont<F_>(params, c->fk[F_], pp); });
     int rc;
     if ((rc = c->pparams[field].ensure(sizeof pp))) return rc;
-    HIPC(hipMemcpyAsync(c->pparams[field].p, &pp, sizeof pp, hipMemcpyHostToDevice, c->stream));
-    HIPC(hipStreamSynchronize(c->stream));
+    HIPC(hipMemcpyAsync(c->pparams[field].p, &pp, sizeof pp, hipMemcpyHostToDevice, c->L->stream));
+    HIPC(hipStreamSynchronize(c->L->stream));
     c->have_pparams[field] = true;
     return MINA_OK;
 }
 
+static int poseidon_permute_on_lane(mina_ctx *c, int field, size_t n, void *d_states);
 extern "C" int mina_poseidon_permute_dev(mina_ctx *c, int field, size_t n, void *d_states) {
     if (!c || !d_states) return fail(MINA_ERR_ARG, "null argument");
+    HIPC(hipSetDevice(c->device));
+    c->next_lane();
+    return poseidon_permute_on_lane(c, field, n, d_states);
+}
+static int poseidon_permute_on_lane(mina_ctx *c, int field, size_t n, void *d_states) {
     if (bad_field(field)) return fail(MINA_ERR_ARG, "bad field");
     if (!c->have_pparams[field]) return fail(MINA_ERR_STATE, "Poseidon constants not installed for this field");
     if (n == 0) return MINA_OK;
     HIPC(hipSetDevice(c->device));
-    DISPATCH_FIELD(field, { poseidon_permute_kernel<F_><<<cdiv(n, 256), 256, 0, c->stream>>>((uint32_t)n, c->fk[F_], c->pparams[field].as<PoseidonParams>(), (uint32_t *)d_states); });
+    DISPATCH_FIELD(field, { poseidon_permute_kernel<F_><<<cdiv(n, 256), 256, 0, c->L->stream>>>((uint32_t)n, c->fk[F_], c->pparams[field].as<PoseidonParams>(), (uint32_t *)d_states); });
     HIPC(hipGetLastError());
     return MINA_OK;
 }
@@ -104,9 +118,10 @@ extern "C" int mina_poseidon_permute(mina_ctx *c, int field, size_t n, uint8_t *
     if (n == 0) return MINA_OK;
     int rc;
     HIPC(hipSetDevice(c->device));
-    if ((rc = h2d(c, c->tmp_a, states, n * 96))) return rc;
-    if ((rc = mina_poseidon_permute_dev(c, field, n, c->tmp_a.p))) return rc;
-    return d2h_sync(c, states, c->tmp_a, n * 96);
+    c->use_lane0();
+    if ((rc = h2d(c, c->L->tmp_a, states, n * 96))) return rc;
+    if ((rc = poseidon_permute_on_lane(c, field, n, c->L->tmp_a.p))) return rc;
+    return d2h_sync(c, states, c->L->tmp_a, n * 96);
 }
 
 extern "C" int mina_poseidon_hash(mina_ctx *c, int field, size_t n, size_t len, const uint8_t *inputs, uint8_t *out) {
@@ -115,11 +130,12 @@ extern "C" int mina_poseidon_hash(mina_ctx *c, int field, size_t n, size_t len, 
     if (!c->have_pparams[field]) return fail(MINA_ERR_STATE, "Poseidon constants not installed for this field");
     if (n == 0) return MINA_OK;
     HIPC(hipSetDevice(c->device));
+    c->use_lane0();
     int rc;
-    if ((rc = h2d(c, c->tmp_a, inputs, n * len * 32))) return rc;
-    if ((rc = c->tmp_c.ensure(n * 32))) return rc;
-    DISPATCH_FIELD(field, { poseidon_hash_kernel<F_><<<cdiv(n, 256), 256, 0, c->stream>>>((uint32_t)n, (uint32_t)len, c->fk[F_], c->pparams[field].as<PoseidonParams>(), c->tmp_a.as<uint32_t>(), c->tmp_c.as<uint32_t>()); });
-    return d2h_sync(c, out, c->tmp_c, n * 32);
+    if ((rc = h2d(c, c->L->tmp_a, inputs, n * len * 32))) return rc;
+    if ((rc = c->L->tmp_c.ensure(n * 32))) return rc;
+    DISPATCH_FIELD(field, { poseidon_hash_kernel<F_><<<cdiv(n, 256), 256, 0, c->L->stream>>>((uint32_t)n, (uint32_t)len, c->fk[F_], c->pparams[field].as<PoseidonParams>(), c->L->tmp_a.as<uint32_t>(), c->L->tmp_c.as<uint32_t>()); });
+    return d2h_sync(c, out, c->L->tmp_c, n * 32);
 }
 
 extern "C" int mina_challenge_to_field(mina_ctx *c, int field, size_t n, const uint8_t *chal128, uint8_t *out) {
@@ -127,9 +143,10 @@ extern "C" int mina_challenge_to_field(mina_ctx *c, int field, size_t n, const u
     if (bad_field(field)) return fail(MINA_ERR_ARG, "bad field");
     if (n == 0) return MINA_OK;
     HIPC(hipSetDevice(c->device));
+    c->use_lane0();
     int rc;
-    if ((rc = h2d(c, c->tmp_a, chal128, n * 16))) return rc;
-    if ((rc = c->tmp_c.ensure(n * 32))) return rc;
-    DISPATCH_FIELD(field, { challenge_to_field_kernel<F_><<<cdiv(n, 64), 64, 0, c->stream>>>((uint32_t)n, c->fk[F_], c->tmp_a.as<uint32_t>(), c->tmp_c.as<uint32_t>()); });
-    return d2h_sync(c, out, c->tmp_c, n * 32);
+    if ((rc = h2d(c, c->L->tmp_a, chal128, n * 16))) return rc;
+    if ((rc = c->L->tmp_c.ensure(n * 32))) return rc;
+    DISPATCH_FIELD(field, { challenge_to_field_kernel<F_><<<cdiv(n, 64), 64, 0, c->L->stream>>>((uint32_t)n, c->fk[F_], c->L->tmp_a.as<uint32_t>(), c->L->tmp_c.as<uint32_t>()); });
+    return d2h_sync(c, out, c->L->tmp_c, n * 32);
 }

@@ -6,9 +6,9 @@
 // SRS
 template <int F> static int build_tables(mina_ctx *c, SrsState &s) {
     const FieldK &fk = c->fk[F];
-    msm_build_table_kernel<F><<<cdiv(s.depth, 256), 256, 0, c->stream>>>(s.depth, s.depth, s.c, s.W, fk.one, fk.pm2, s.table.as<affine_t>());
+    msm_build_table_kernel<F><<<cdiv(s.depth, 256), 256, 0, c->L->stream>>>(s.depth, s.depth, s.c, s.W, fk.one, fk.pm2, s.table.as<affine_t>());
     HIPC(hipGetLastError());
-    HIPC(hipStreamSynchronize(c->stream));
+    HIPC(hipStreamSynchronize(c->L->stream));
     return MINA_OK;
 }
 
@@ -26,12 +26,13 @@ extern "C" int mina_srs_create(mina_ctx *c, int curve, uint32_t depth) {
     if (curve != 0 && curve != 1) return fail(MINA_ERR_ARG, "bad curve");
     if (depth == 0 || depth > (1u << 20)) return fail(MINA_ERR_ARG, "depth must be in 1..2^20");
     HIPC(hipSetDevice(c->device));
+    c->use_lane0();
     int rc = srs_alloc(c, curve, depth);
     if (rc) return rc;
     SrsState &s = c->srs[curve];
     const int F = base_field_of(curve);
     DISPATCH_FIELD(F, {
-        srs_create_kernel<F_><<<cdiv((size_t)depth + 1, 256), 256, 0, c->stream>>>(depth, c->fk[F_], s.table.as<affine_t>(), s.h.as<affine_t>());
+        srs_create_kernel<F_><<<cdiv((size_t)depth + 1, 256), 256, 0, c->L->stream>>>(depth, c->fk[F_], s.table.as<affine_t>(), s.h.as<affine_t>());
     });
     HIPC(hipGetLastError());
     s.depth = depth;
@@ -54,21 +55,22 @@ extern "C" int mina_srs_load(mina_ctx *c, int curve, const uint8_t *d, size_t le
         memcpy(&blobs[i * 33], e + 2, 33);
     }
     HIPC(hipSetDevice(c->device));
+    c->use_lane0();
     int rc = srs_alloc(c, curve, n);
     if (rc) return rc;
     SrsState &s = c->srs[curve];
-    if ((rc = c->tmp_a.ensure(blobs.size()))) return rc;
-    if ((rc = c->tmp_b.ensure(4))) return rc;
-    HIPC(hipMemcpyAsync(c->tmp_a.p, blobs.data(), blobs.size(), hipMemcpyHostToDevice, c->stream));
-    HIPC(hipMemsetAsync(c->tmp_b.p, 0, 4, c->stream));
+    if ((rc = c->L->tmp_a.ensure(blobs.size()))) return rc;
+    if ((rc = c->L->tmp_b.ensure(4))) return rc;
+    HIPC(hipMemcpyAsync(c->L->tmp_a.p, blobs.data(), blobs.size(), hipMemcpyHostToDevice, c->L->stream));
+    HIPC(hipMemsetAsync(c->L->tmp_b.p, 0, 4, c->L->stream));
     const int F = base_field_of(curve);
     DISPATCH_FIELD(F, {
-        decompress_kernel<F_><<<cdiv(n, 256), 256, 0, c->stream>>>(n, c->fk[F_], c->tmp_a.as<uint8_t>(), s.table.as<affine_t>(), c->tmp_b.as<uint32_t>());
-        decompress_kernel<F_><<<1, 64, 0, c->stream>>>(1, c->fk[F_], c->tmp_a.as<uint8_t>() + (size_t)n * 33, s.h.as<affine_t>(), c->tmp_b.as<uint32_t>());
+        decompress_kernel<F_><<<cdiv(n, 256), 256, 0, c->L->stream>>>(n, c->fk[F_], c->L->tmp_a.as<uint8_t>(), s.table.as<affine_t>(), c->L->tmp_b.as<uint32_t>());
+        decompress_kernel<F_><<<1, 64, 0, c->L->stream>>>(1, c->fk[F_], c->L->tmp_a.as<uint8_t>() + (size_t)n * 33, s.h.as<affine_t>(), c->L->tmp_b.as<uint32_t>());
     });
     uint32_t bad = 0;
-    HIPC(hipMemcpyAsync(&bad, c->tmp_b.p, 4, hipMemcpyDeviceToHost, c->stream));
-    HIPC(hipStreamSynchronize(c->stream));
+    HIPC(hipMemcpyAsync(&bad, c->L->tmp_b.p, 4, hipMemcpyDeviceToHost, c->L->stream));
+    HIPC(hipStreamSynchronize(c->L->stream));
     if (bad) return fail(MINA_ERR_FORMAT, "SRS contains a point that is not on the curve");
     s.depth = n;
     DISPATCH_FIELD(F, { rc = build_tables<F_>(c, s); });
@@ -89,12 +91,13 @@ extern "C" int mina_srs_get_g(mina_ctx *c, int curve, uint32_t first, uint32_t c
     if ((uint64_t)first + count > s.depth) return fail(MINA_ERR_ARG, "range outside SRS");
     if (count == 0) return MINA_OK;
     HIPC(hipSetDevice(c->device));
+    c->use_lane0();
     int rc;
-    if ((rc = c->tmp_a.ensure((size_t)count * 64))) return rc;
+    if ((rc = c->L->tmp_a.ensure((size_t)count * 64))) return rc;
     const int F = base_field_of(curve);
-    DISPATCH_FIELD(F, { points_from_mont_kernel<F_><<<cdiv(count, 256), 256, 0, c->stream>>>(count, s.table.as<affine_t>() + first, c->tmp_a.as<uint32_t>()); });
-    HIPC(hipMemcpyAsync(out, c->tmp_a.p, (size_t)count * 64, hipMemcpyDeviceToHost, c->stream));
-    HIPC(hipStreamSynchronize(c->stream));
+    DISPATCH_FIELD(F, { points_from_mont_kernel<F_><<<cdiv(count, 256), 256, 0, c->L->stream>>>(count, s.table.as<affine_t>() + first, c->L->tmp_a.as<uint32_t>()); });
+    HIPC(hipMemcpyAsync(out, c->L->tmp_a.p, (size_t)count * 64, hipMemcpyDeviceToHost, c->L->stream));
+    HIPC(hipStreamSynchronize(c->L->stream));
     return MINA_OK;
 }
 
@@ -104,12 +107,13 @@ extern "C" int mina_srs_get_h(mina_ctx *c, int curve, uint8_t *out) {
     SrsState &s = c->srs[curve];
     if (s.depth == 0) return fail(MINA_ERR_STATE, "SRS not loaded");
     HIPC(hipSetDevice(c->device));
+    c->use_lane0();
     int rc;
-    if ((rc = c->tmp_a.ensure(64))) return rc;
+    if ((rc = c->L->tmp_a.ensure(64))) return rc;
     const int F = base_field_of(curve);
-    DISPATCH_FIELD(F, { points_from_mont_kernel<F_><<<1, 64, 0, c->stream>>>(1, s.h.as<affine_t>(), c->tmp_a.as<uint32_t>()); });
-    HIPC(hipMemcpyAsync(out, c->tmp_a.p, 64, hipMemcpyDeviceToHost, c->stream));
-    HIPC(hipStreamSynchronize(c->stream));
+    DISPATCH_FIELD(F, { points_from_mont_kernel<F_><<<1, 64, 0, c->L->stream>>>(1, s.h.as<affine_t>(), c->L->tmp_a.as<uint32_t>()); });
+    HIPC(hipMemcpyAsync(out, c->L->tmp_a.p, 64, hipMemcpyDeviceToHost, c->L->stream));
+    HIPC(hipStreamSynchronize(c->L->stream));
     return MINA_OK;
 }
 
@@ -122,16 +126,17 @@ extern "C" int mina_srs_serialize(mina_ctx *c, int curve, uint8_t *out, size_t c
     *len = need;
     if (!out || cap < need) return fail(MINA_ERR_ARG, "output buffer too small");
     HIPC(hipSetDevice(c->device));
+    c->use_lane0();
     int rc;
-    if ((rc = c->tmp_a.ensure((size_t)(s.depth + 1) * 33))) return rc;
+    if ((rc = c->L->tmp_a.ensure((size_t)(s.depth + 1) * 33))) return rc;
     const int F = base_field_of(curve);
     DISPATCH_FIELD(F, {
-        compress_kernel<F_><<<cdiv(s.depth, 256), 256, 0, c->stream>>>(s.depth, c->fk[F_], s.table.as<affine_t>(), c->tmp_a.as<uint8_t>());
-        compress_kernel<F_><<<1, 64, 0, c->stream>>>(1, c->fk[F_], s.h.as<affine_t>(), c->tmp_a.as<uint8_t>() + (size_t)s.depth * 33);
+        compress_kernel<F_><<<cdiv(s.depth, 256), 256, 0, c->L->stream>>>(s.depth, c->fk[F_], s.table.as<affine_t>(), c->L->tmp_a.as<uint8_t>());
+        compress_kernel<F_><<<1, 64, 0, c->L->stream>>>(1, c->fk[F_], s.h.as<affine_t>(), c->L->tmp_a.as<uint8_t>() + (size_t)s.depth * 33);
     });
     std::vector<uint8_t> blobs((size_t)(s.depth + 1) * 33);
-    HIPC(hipMemcpyAsync(blobs.data(), c->tmp_a.p, blobs.size(), hipMemcpyDeviceToHost, c->stream));
-    HIPC(hipStreamSynchronize(c->stream));
+    HIPC(hipMemcpyAsync(blobs.data(), c->L->tmp_a.p, blobs.size(), hipMemcpyDeviceToHost, c->L->stream));
+    HIPC(hipStreamSynchronize(c->L->stream));
     out[0] = 0x92; out[1] = 0xdd;
     out[2] = (uint8_t)(s.depth >> 24); out[3] = (uint8_t)(s.depth >> 16); out[4] = (uint8_t)(s.depth >> 8); out[5] = (uint8_t)s.depth;
     for (size_t i = 0; i <= s.depth; ++i) {

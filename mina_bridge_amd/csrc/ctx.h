@@ -56,17 +56,38 @@ struct ProfState {
     std::vector<Rec> recs; size_t used = 0;
 };
 
-struct mina_ctx {
-    int device = 0;
-    ProfState prof;
+// A pipeline lane: one HIP stream + every scratch buffer a call needs.  Independent `_dev` calls are
+// issued round-robin over the lanes so that the low-occupancy tail of one MSM overlaps the wide phases of
+// the next (SRS tables, field constants and Poseidon constants are shared, read-only).
+struct Lane {
     hipStream_t stream = nullptr;
-    FieldK fk[2];
-    SrsState srs[2];
     MsmWorkspace ws;
-    DevBuf pparams[2]; bool have_pparams[2] = {false, false};
     DevBuf tmp_a, tmp_b, tmp_c, tmp_d;       // staging for the host-buffer entry points
     DevBuf bp_ltab, bp_htab, bp_partial;
     DevBuf ipa_chals, ipa_folded, ipa_xyzz_a, ipa_xyzz_b, ipa_points, ipa_scalars, ipa_sigma, ipa_in_a, ipa_in_b, ipa_in_c, ipa_verdict;
+    void release_all() {
+        MsmWorkspace &w = ws;
+        DevBuf *all[] = {&w.scalars, &w.points, &w.ekey, &w.eval, &w.eoff, &w.count, &w.start, &w.task_start, &w.sorted, &w.partial,
+                         &w.buckets, &w.red_r, &w.red_ws, &w.set_total, &w.out_words, &w.out_xyzz, &tmp_a, &tmp_b, &tmp_c, &tmp_d,
+                         &bp_ltab, &bp_htab, &bp_partial, &ipa_chals, &ipa_folded, &ipa_xyzz_a, &ipa_xyzz_b, &ipa_points, &ipa_scalars,
+                         &ipa_sigma, &ipa_in_a, &ipa_in_b, &ipa_in_c, &ipa_verdict};
+        for (DevBuf *b : all) b->release();
+    }
+};
+static constexpr int MB_MAX_LANES = 16;
+
+struct mina_ctx {
+    int device = 0;
+    ProfState prof;
+    Lane lanes[MB_MAX_LANES];
+    int nlanes = 1;
+    unsigned rr = 0;                 // round-robin cursor of the `_dev` entry points
+    Lane *L = nullptr;               // lane the current call runs on
+    FieldK fk[2];
+    SrsState srs[2];
+    DevBuf pparams[2]; bool have_pparams[2] = {false, false};
+    void use_lane0() { L = &lanes[0]; }
+    void next_lane() { L = &lanes[rr++ % (unsigned)nlanes]; }
 };
 
 static inline int base_field_of(int curve) { return curve == CURVE_PALLAS ? FIELD_FP : FIELD_FQ; }
@@ -83,13 +104,13 @@ static inline uint32_t cdiv(size_t a, size_t b) { return (uint32_t)((a + b - 1) 
 static inline int h2d(mina_ctx *c, DevBuf &b, const void *src, size_t bytes) {
     int rc = b.ensure(bytes ? bytes : 4);
     if (rc) return rc;
-    if (bytes) HIPC(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, c->stream));
+    if (bytes) HIPC(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, c->L->stream));
     return MINA_OK;
 }
 static inline int d2h_sync(mina_ctx *c, void *dst, const DevBuf &b, size_t bytes) {
-    if (bytes) HIPC(hipMemcpyAsync(dst, b.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    if (bytes) HIPC(hipMemcpyAsync(dst, b.p, bytes, hipMemcpyDeviceToHost, c->L->stream));
     HIPC(hipGetLastError());
-    HIPC(hipStreamSynchronize(c->stream));
+    HIPC(hipStreamSynchronize(c->L->stream));
     return MINA_OK;
 }
 
@@ -106,5 +127,7 @@ struct xyzz_dev;   // opaque: mb::xyzz_t in HBM
 // fixed-base MSM over the SRS table of `curve`; writes the 17-word affine record and/or the XYZZ value
 int mb_msm_fixed(mina_ctx *c, int curve, uint32_t n, const uint32_t *d_scalars, uint32_t *d_out_words, void *d_out_xyzz);
 // variable-base MSM over Montgomery affine points already in HBM
+// K2 fold on the current lane (no lane switch)
+int mb_bpoly_fold(mina_ctx *c, int field, uint32_t k, size_t batch, const uint32_t *d_chals, const uint32_t *d_weights, uint32_t *d_out);
 int mb_msm_variable(mina_ctx *c, int curve, uint32_t n, const uint32_t *d_scalars, const void *d_points_mont,
                     uint32_t *d_out_words, void *d_out_xyzz);

@@ -106,8 +106,9 @@ template <int F> MB_HD fe_t fe_sub(const fe_t &a, const fe_t &b) {
 template <int F> MB_HD fe_t fe_neg(const fe_t &a) { return fe_sub<F>(fe_zero(), a); }
 template <int F> MB_HD fe_t fe_dbl(const fe_t &a) { return fe_add<F>(a, a); }
 
-// Montgomery product, CIOS over 32-bit digits, specialised to the Pasta prime shape.
-template <int F> MB_HD fe_t fe_mul(const fe_t &a, const fe_t &b) {
+// Montgomery product, CIOS over 32-bit digits, specialised to the Pasta prime shape (portable form:
+// host code and the reference for the device version below).
+template <int F> MB_HD fe_t fe_mul_portable(const fe_t &a, const fe_t &b) {
     uint32_t t[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) t[i] = 0;
@@ -136,6 +137,66 @@ template <int F> MB_HD fe_t fe_mul(const fe_t &a, const fe_t &b) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) r.v[i] = t[i];
     return fe_cond_sub_p<F>(r);                               // t < 2p
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// ---- gfx950 device version: product scanning (FIPS) with a 96-bit column accumulator (acc:64, hi:32).
+// One `v_mad_u64_u32` per 32x32 product accumulates straight into `acc`; its carry-out goes to an SGPR pair
+// that the following `v_addc_co_u32` folds into `hi` -- no 64-bit addend assembly, no v_mov traffic.
+// 64 (a*b) + 24 (m*p1..p3) multiply-accumulates; p0 = 1 and p7 = 2^30 are adds/shifts.
+__device__ __forceinline__ void mb_mac(uint64_t &acc, uint32_t &hi, uint32_t x, uint32_t y) {
+    uint64_t cc;
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+v"(acc), "+v"(hi), "=&s"(cc) : "v"(x), "v"(y));
+}
+__device__ __forceinline__ void mb_acc_add(uint64_t &acc, uint32_t &hi, uint64_t v) {
+    acc += v; hi += (acc < v) ? 1u : 0u;
+}
+template <int F> __device__ __forceinline__ fe_t fe_mul_device(const fe_t &a, const fe_t &b) {
+    uint64_t acc = 0; uint32_t hi = 0;
+    uint32_t m[8]; fe_t r;
+    const uint32_t p1 = FieldP<F>::P1, p2 = FieldP<F>::P2, p3 = FieldP<F>::P3;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+#pragma unroll
+        for (int i = 0; i <= k; ++i) mb_mac(acc, hi, a.v[i], b.v[k - i]);
+#pragma unroll
+        for (int i = 0; i < k; ++i) {
+            const int j = k - i;
+            if (j == 1) mb_mac(acc, hi, m[i], p1);
+            if (j == 2) mb_mac(acc, hi, m[i], p2);
+            if (j == 3) mb_mac(acc, hi, m[i], p3);
+            if (j == 7) mb_acc_add(acc, hi, (uint64_t)m[i] << 30);
+        }
+        m[k] = 0u - (uint32_t)acc;
+        mb_acc_add(acc, hi, (uint64_t)m[k]);                 // + m_k * p0 : low word becomes 0
+        acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
+    }
+#pragma unroll
+    for (int k = 8; k < 15; ++k) {
+#pragma unroll
+        for (int i = k - 7; i < 8; ++i) mb_mac(acc, hi, a.v[i], b.v[k - i]);
+#pragma unroll
+        for (int i = k - 7; i < 8; ++i) {
+            const int j = k - i;
+            if (j == 1) mb_mac(acc, hi, m[i], p1);
+            if (j == 2) mb_mac(acc, hi, m[i], p2);
+            if (j == 3) mb_mac(acc, hi, m[i], p3);
+            if (j == 7) mb_acc_add(acc, hi, (uint64_t)m[i] << 30);
+        }
+        r.v[k - 8] = (uint32_t)acc;
+        acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
+    }
+    r.v[7] = (uint32_t)acc;                                   // result < 2p < 2^256
+    return fe_cond_sub_p<F>(r);
+}
+#endif
+template <int F> MB_HD fe_t fe_mul(const fe_t &a, const fe_t &b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return fe_mul_device<F>(a, b);
+#else
+    return fe_mul_portable<F>(a, b);
+#endif
 }
 template <int F> MB_HD fe_t fe_sqr(const fe_t &a) { return fe_mul<F>(a, a); }
 

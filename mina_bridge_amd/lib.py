@@ -21,7 +21,7 @@ CURVE_PALLAS, CURVE_VESTA = 0, 1
 
 # every symbol include/mina_verify.h declares (checked by tests/test_abi.py)
 EXPORTS = [
-    "mina_ctx_create", "mina_ctx_destroy", "mina_last_error", "mina_ctx_synchronize", "mina_ctx_stream", "mina_prof_enable", "mina_prof_read",
+    "mina_ctx_create", "mina_ctx_destroy", "mina_last_error", "mina_ctx_synchronize", "mina_ctx_stream", "mina_ctx_set_pipeline", "mina_prof_enable", "mina_prof_read",
     "mina_srs_create", "mina_srs_load", "mina_srs_depth", "mina_srs_get_g", "mina_srs_get_h", "mina_srs_serialize",
     "mina_msm", "mina_msm_srs", "mina_msm_srs_dev",
     "mina_b_poly", "mina_b_poly_coefficients", "mina_b_poly_fold", "mina_b_poly_fold_dev",
@@ -127,6 +127,9 @@ class MinaContext:
     @property
     def stream(self) -> int:
         return int(self._lib.mina_ctx_stream(self._h) or 0)
+
+    def set_pipeline(self, lanes: int):
+        self._ck(self._lib.mina_ctx_set_pipeline(self._h, int(lanes)), "mina_ctx_set_pipeline")
 
     def prof_enable(self, stage_mask: int = -1):
         self._ck(self._lib.mina_prof_enable(self._h, int(stage_mask)), "mina_prof_enable")
