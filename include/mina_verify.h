@@ -101,6 +101,8 @@ int mina_msm(mina_ctx *ctx, int curve, size_t n, const uint8_t *bases_affine, co
              uint8_t *out_affine);
 /* out = sum_i scalars[i] * g[i], g = loaded SRS of `curve`, n <= depth (fixed-base window tables). */
 int mina_msm_srs(mina_ctx *ctx, int curve, size_t n, const uint8_t *scalars, uint8_t *out_affine);
+/* out = sum_i scalars[i] * g[first + i]: the slice of the SRS owned by one rank when an MSM is sharded by bases. */
+int mina_msm_srs_range(mina_ctx *ctx, int curve, uint32_t first, size_t n, const uint8_t *scalars, uint8_t *out_affine);
 /* Same with scalars already in HBM (n x 32 bytes, canonical).  Queued on the context stream; the
  * 68-byte result record {x[32], y[32], u32 is_infinity} is written to `d_out` (device memory). */
 int mina_msm_srs_dev(mina_ctx *ctx, int curve, size_t n, const void *d_scalars, void *d_out);

@@ -4,13 +4,13 @@
 
 // ------------------------------------------------------------------------------------------------
 // MSM driver
-static MsmShape fixed_shape(const SrsState &s, uint32_t n) {
-    MsmShape sh; sh.n = n; sh.c = s.c; sh.W = s.W; sh.NB = 1u << (s.c - 1); sh.nsets = 1; sh.table_stride = s.depth; return sh;
+static MsmShape fixed_shape(const SrsState &s, uint32_t first, uint32_t n) {
+    MsmShape sh; sh.n = n; sh.c = s.c; sh.W = s.W; sh.NB = 1u << (s.c - 1); sh.nsets = 1; sh.table_stride = s.depth; sh.base_first = first; return sh;
 }
 static MsmShape variable_shape(uint32_t n) {
     MsmShape sh; sh.n = n;
     sh.c = n < 2048 ? 8 : (n < 32768 ? 11 : 14);
-    sh.W = (256 + sh.c - 1) / sh.c; sh.NB = 1u << (sh.c - 1); sh.nsets = sh.W; sh.table_stride = 0; return sh;
+    sh.W = (256 + sh.c - 1) / sh.c; sh.NB = 1u << (sh.c - 1); sh.nsets = sh.W; sh.table_stride = 0; sh.base_first = 0; return sh;
 }
 
 template <int F>
@@ -59,11 +59,11 @@ static void words_to_point_bytes(const uint32_t w[17], uint8_t *out) {
     memcpy(out, w, 64);
 }
 
-int mb_msm_fixed(mina_ctx *c, int curve, uint32_t n, const uint32_t *d_scalars, uint32_t *d_out_words, void *d_out_xyzz) {
+int mb_msm_fixed(mina_ctx *c, int curve, uint32_t n, const uint32_t *d_scalars, uint32_t *d_out_words, void *d_out_xyzz, uint32_t first) {
     SrsState &s = c->srs[curve];
     if (s.depth == 0) return fail(MINA_ERR_STATE, "SRS not loaded for this curve");
-    if (n == 0 || n > s.depth) return fail(MINA_ERR_ARG, "n must be in 1..depth");
-    MsmShape sh = fixed_shape(s, n);
+    if (n == 0 || (uint64_t)first + n > s.depth) return fail(MINA_ERR_ARG, "base range must lie inside the SRS");
+    MsmShape sh = fixed_shape(s, first, n);
     int rc = MINA_OK;
     DISPATCH_FIELD(base_field_of(curve), { rc = run_msm<F_>(c, sh, d_scalars, s.table.as<affine_t>(), d_out_words, (xyzz_t *)d_out_xyzz); });
     return rc;
@@ -125,6 +125,25 @@ extern "C" int mina_msm_srs(mina_ctx *c, int curve, size_t n, const uint8_t *sca
     if ((rc = c->L->ws.out_words.ensure(17 * 4))) return rc;
     HIPC(hipMemcpyAsync(c->L->ws.scalars.p, scalars, n * 32, hipMemcpyHostToDevice, c->L->stream));
     if ((rc = mb_msm_fixed(c, curve, (uint32_t)n, c->L->ws.scalars.as<uint32_t>(), c->L->ws.out_words.as<uint32_t>(), nullptr))) return rc;
+    uint32_t hw[17];
+    HIPC(hipMemcpyAsync(hw, c->L->ws.out_words.p, sizeof hw, hipMemcpyDeviceToHost, c->L->stream));
+    HIPC(hipStreamSynchronize(c->L->stream));
+    words_to_point_bytes(hw, out);
+    return MINA_OK;
+}
+
+extern "C" int mina_msm_srs_range(mina_ctx *c, int curve, uint32_t first, size_t n, const uint8_t *scalars, uint8_t *out) {
+    if (!c || !out || (n && !scalars)) return fail(MINA_ERR_ARG, "null argument");
+    if (curve != 0 && curve != 1) return fail(MINA_ERR_ARG, "bad curve");
+    if (n == 0) { memset(out, 0, 64); return MINA_OK; }
+    if (n > 0xffffffffu) return fail(MINA_ERR_ARG, "n too large");
+    HIPC(hipSetDevice(c->device));
+    c->use_lane0();
+    int rc;
+    if ((rc = c->L->ws.scalars.ensure(n * 32))) return rc;
+    if ((rc = c->L->ws.out_words.ensure(17 * 4))) return rc;
+    HIPC(hipMemcpyAsync(c->L->ws.scalars.p, scalars, n * 32, hipMemcpyHostToDevice, c->L->stream));
+    if ((rc = mb_msm_fixed(c, curve, (uint32_t)n, c->L->ws.scalars.as<uint32_t>(), c->L->ws.out_words.as<uint32_t>(), nullptr, first))) return rc;
     uint32_t hw[17];
     HIPC(hipMemcpyAsync(hw, c->L->ws.out_words.p, sizeof hw, hipMemcpyDeviceToHost, c->L->stream));
     HIPC(hipStreamSynchronize(c->L->stream));

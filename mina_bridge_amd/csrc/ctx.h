@@ -125,7 +125,7 @@ struct ProfScope {
 // cross-file entry points (C++ linkage)
 struct xyzz_dev;   // opaque: mb::xyzz_t in HBM
 // fixed-base MSM over the SRS table of `curve`; writes the 17-word affine record and/or the XYZZ value
-int mb_msm_fixed(mina_ctx *c, int curve, uint32_t n, const uint32_t *d_scalars, uint32_t *d_out_words, void *d_out_xyzz);
+int mb_msm_fixed(mina_ctx *c, int curve, uint32_t n, const uint32_t *d_scalars, uint32_t *d_out_words, void *d_out_xyzz, uint32_t first = 0);
 // variable-base MSM over Montgomery affine points already in HBM
 // K2 fold on the current lane (no lane switch)
 int mb_bpoly_fold(mina_ctx *c, int field, uint32_t k, size_t batch, const uint32_t *d_chals, const uint32_t *d_weights, uint32_t *d_out);

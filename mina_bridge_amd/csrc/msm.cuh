@@ -30,6 +30,7 @@ struct MsmShape {
     uint32_t NB;       // buckets per bucket set = 2^(c-1)
     uint32_t nsets;    // 1 (shared buckets, fixed-base table) or W (variable-base)
     uint32_t table_stride;  // fixed-base: points per window in the table (>= n); 0 for variable-base
+    uint32_t base_first;    // fixed-base: index of the first SRS base used (scalar i multiplies g[base_first + i])
 };
 
 // ---------------------------------------------------------------- device helpers
@@ -61,7 +62,7 @@ static __global__ void msm_digits_kernel(MsmShape sh, const uint32_t *__restrict
         size_t e = (size_t)w * sh.n + i;
         if (d == 0) { ekey[e] = MSM_INVALID; continue; }
         uint32_t bucket = (sh.nsets == 1 ? 0u : w * sh.NB) + (d - 1);
-        uint32_t pt = (sh.table_stride ? w * sh.table_stride + i : i) | (neg << 31);
+        uint32_t pt = (sh.table_stride ? w * sh.table_stride + sh.base_first + i : i) | (neg << 31);
         ekey[e] = bucket;
         eval[e] = pt;
         eoff[e] = atomicAdd(&count[bucket], 1u);

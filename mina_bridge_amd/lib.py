@@ -23,7 +23,7 @@ CURVE_PALLAS, CURVE_VESTA = 0, 1
 EXPORTS = [
     "mina_ctx_create", "mina_ctx_destroy", "mina_last_error", "mina_ctx_synchronize", "mina_ctx_stream", "mina_ctx_set_pipeline", "mina_prof_enable", "mina_prof_read",
     "mina_srs_create", "mina_srs_load", "mina_srs_depth", "mina_srs_get_g", "mina_srs_get_h", "mina_srs_serialize",
-    "mina_msm", "mina_msm_srs", "mina_msm_srs_dev",
+    "mina_msm", "mina_msm_srs", "mina_msm_srs_range", "mina_msm_srs_dev",
     "mina_b_poly", "mina_b_poly_coefficients", "mina_b_poly_fold", "mina_b_poly_fold_dev",
     "mina_poseidon_set_params", "mina_poseidon_permute", "mina_poseidon_permute_dev", "mina_poseidon_hash",
     "mina_challenge_to_field", "mina_to_group",
@@ -183,6 +183,13 @@ class MinaContext:
         n = scalars.size // 32
         out = np.empty(64, np.uint8)
         self._ck(self._lib.mina_msm_srs(self._h, curve, ctypes.c_size_t(n), _p(scalars), _p(out)), "mina_msm_srs")
+        return out
+
+    def msm_srs_range(self, curve: int, first: int, scalars) -> np.ndarray:
+        scalars = _u8(scalars)
+        n = scalars.size // 32
+        out = np.empty(64, np.uint8)
+        self._ck(self._lib.mina_msm_srs_range(self._h, curve, ctypes.c_uint32(first), ctypes.c_size_t(n), _p(scalars), _p(out)), "mina_msm_srs_range")
         return out
 
     def msm_srs_dev(self, curve: int, n: int, d_scalars: int, d_out: int):

@@ -93,3 +93,47 @@ def test_msm_linearity_property(ctx_srs, oracle):
     s = oracle.ints_to_le([(x + y) % r for x, y in zip(ai, bi)])
     pa, pb, ps = ctx_srs.msm_srs(curve, a), ctx_srs.msm_srs(curve, b), ctx_srs.msm_srs(curve, s)
     assert (oracle.point_add(curve, pa, pb) == ps).all()
+
+
+def test_msm_srs_range_slices_sum_to_full(ctx_srs, oracle, srs_oracle):
+    """base-sliced sharding (SURVEY.md 8e variant 2): per-rank slices of the SRS, partial points added = full MSM"""
+    curve, n, r = 1, 65536, P
+    g, _ = srs_oracle[curve]
+    sc = rand_scalars(n, r, seed=555)
+    full = ctx_srs.msm_srs(curve, sc)
+    for world in (2, 8):
+        acc = np.zeros(64, np.uint8)
+        for rank in range(world):
+            lo, hi = n * rank // world, n * (rank + 1) // world
+            part = ctx_srs.msm_srs_range(curve, lo, sc[lo:hi])
+            if rank == 3:
+                assert (part == oracle.msm_pippenger(curve, g[lo:hi], sc[lo:hi], threads=8)).all()
+            acc = oracle.point_add(curve, acc, part)
+        assert (acc == full).all()
+
+
+def test_sharded_driver_single_rank_on_gpu(ctx_srs, oracle, srs_oracle):
+    """the real MinaContext behind ShardedAccumulatorCheck (world_size 1, gloo group for the collectives)"""
+    import socket
+    import torch.distributed as dist
+    from mina_bridge_amd.sharded import ShardedAccumulatorCheck
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+    try:
+        curve, k, B = 1, 8, 4
+        g, _ = srs_oracle[curve]
+        _, endo_r = oracle.endo(curve)
+        pre = rand_scalars(B * k, P, seed=66, bits=128)[:, :16].reshape(B, k, 16).copy()
+        sg = np.empty((B, 64), np.uint8)
+        for b in range(B):
+            chals = np.stack([oracle.challenge_to_field(0, pre[b, i].copy(), endo_r) for i in range(k)])
+            sg[b] = oracle.msm_pippenger(curve, g[: 1 << k], oracle.b_poly_coefficients(0, chals), threads=4)
+        rho = rand_scalars(B, P, seed=67)
+        sh = ShardedAccumulatorCheck(ctx_srs, curve, k)
+        assert sh.verify_proof_level(pre, sg, rho).tolist() == [1] * B
+        assert sh.verify_base_sliced(pre, sg, rho) is True
+        sg[2] = g[0]
+        assert sh.verify_proof_level(pre, sg, rho).tolist() == [1, 1, 0, 1]
+        assert sh.verify_base_sliced(pre, sg, rho) is False
+    finally:
+        dist.destroy_process_group()
