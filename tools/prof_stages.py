@@ -1,6 +1,6 @@
 # per-stage HIP-event breakdown of one accumulator-check step (dev tool)
 import sys, json, numpy as np, torch
-sys.path.insert(0,'.')
+sys.path.insert(0,'.'); import os; os.environ.setdefault('GPU_MAX_HW_QUEUES','16')
 import mina_bridge_amd as m, bench
 ctx=m.MinaContext(0); ctx.srs_create(1,65536)
 B=int(sys.argv[1]) if len(sys.argv)>1 else 1
