@@ -35,10 +35,16 @@ static int run_msm(mina_ctx *c, const MsmShape &sh, const uint32_t *d_scalars, c
     if ((rc = w.red_r.ensure((size_t)groups * sizeof(xyzz_t)))) return rc;
     if ((rc = w.red_ws.ensure((size_t)groups * sizeof(xyzz_t)))) return rc;
     if ((rc = w.set_total.ensure((size_t)sh.nsets * sizeof(xyzz_t)))) return rc;
+    {
+        const size_t ns = (size_t)sh.nsets * ((sh.NB / 64 + 63) / 64);
+        if ((rc = w.red2_r.ensure(ns * sizeof(xyzz_t)))) return rc;
+        if ((rc = w.red2_w.ensure(ns * sizeof(xyzz_t)))) return rc;
+        if ((rc = w.red2_p.ensure(ns * sizeof(xyzz_t)))) return rc;
+    }
 
     hipStream_t st = c->L->stream;
     HIPC(hipMemsetAsync(w.count.p, 0, (size_t)nb_total * 4, st));
-    { ProfScope ps_(c, PS_DIGITS); msm_digits_kernel<<<cdiv(sh.n, 256), 256, 0, st>>>(sh, d_scalars, w.count.as<uint32_t>(), w.ekey.as<uint32_t>(),
+    { ProfScope ps_(c, PS_DIGITS); msm_digits_kernel<<<cdiv(entries, 256), 256, 0, st>>>(sh, d_scalars, w.count.as<uint32_t>(), w.ekey.as<uint32_t>(),
                                                        w.eval.as<uint32_t>(), w.eoff.as<uint32_t>()); }
     { ProfScope ps_(c, PS_SCAN); msm_scan_kernel<<<1, 1024, 0, st>>>(nb_total, w.count.as<uint32_t>(), w.start.as<uint32_t>(), w.task_start.as<uint32_t>()); }
     { ProfScope ps_(c, PS_SCATTER); msm_scatter_kernel<<<cdiv(entries, 256), 256, 0, st>>>(entries, w.ekey.as<uint32_t>(), w.eval.as<uint32_t>(),
@@ -48,7 +54,13 @@ static int run_msm(mina_ctx *c, const MsmShape &sh, const uint32_t *d_scalars, c
     { ProfScope ps_(c, PS_BUCKET_SUM); msm_bucket_sum_kernel<F><<<cdiv(nb_total, 256), 256, 0, st>>>(nb_total, w.task_start.as<uint32_t>(), w.partial.as<xyzz_t>(),
                                                                   w.buckets.as<xyzz_t>()); }
     { ProfScope ps_(c, PS_REDUCE_A); msm_reduce_a_kernel<F><<<groups, 64, 0, st>>>(nb_total, w.buckets.as<xyzz_t>(), w.red_r.as<xyzz_t>(), w.red_ws.as<xyzz_t>()); }
-    { ProfScope ps_(c, PS_REDUCE_BC); msm_reduce_bc_kernel<F><<<sh.nsets, 64, 0, st>>>(sh.NB / 64, w.red_r.as<xyzz_t>(), w.red_ws.as<xyzz_t>(), w.set_total.as<xyzz_t>()); }
+    {
+        const uint32_t gps = sh.NB / 64, nsuper = (gps + 63) / 64;
+        { ProfScope ps_(c, PS_REDUCE_BC); msm_reduce_b_kernel<F><<<dim3(nsuper, sh.nsets), 128, 0, st>>>(gps, nsuper, w.red_r.as<xyzz_t>(), w.red_ws.as<xyzz_t>(),
+                                                                                              w.red2_r.as<xyzz_t>(), w.red2_w.as<xyzz_t>(), w.red2_p.as<xyzz_t>()); }
+        { ProfScope ps_(c, PS_REDUCE_C); msm_reduce_c_kernel<F><<<sh.nsets, 192, 0, st>>>(nsuper, w.red2_r.as<xyzz_t>(), w.red2_w.as<xyzz_t>(), w.red2_p.as<xyzz_t>(),
+                                                                                  w.set_total.as<xyzz_t>()); }
+    }
     { ProfScope ps_(c, PS_FINISH); msm_finish_kernel<F><<<1, 64, 0, st>>>(sh.nsets, sh.c, w.set_total.as<xyzz_t>(), fk.one, fk.pm2, d_out_xyzz, d_out_words); }
     HIPC(hipGetLastError());
     return MINA_OK;

@@ -74,7 +74,7 @@ template <int F> MB_HD fe_t fe_cond_sub_p(const fe_t &a) {
     return r;
 }
 
-template <int F> MB_HD fe_t fe_add(const fe_t &a, const fe_t &b) {
+template <int F> MB_HD fe_t fe_add_portable(const fe_t &a, const fe_t &b) {
     fe_t s; uint32_t c = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -85,7 +85,7 @@ template <int F> MB_HD fe_t fe_add(const fe_t &a, const fe_t &b) {
     return fe_cond_sub_p<F>(s);
 }
 
-template <int F> MB_HD fe_t fe_sub(const fe_t &a, const fe_t &b) {
+template <int F> MB_HD fe_t fe_sub_portable(const fe_t &a, const fe_t &b) {
     fe_t d; uint32_t br = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -101,6 +101,94 @@ template <int F> MB_HD fe_t fe_sub(const fe_t &a, const fe_t &b) {
         r.v[i] = (uint32_t)t; c = (uint32_t)(t >> 32);
     }
     return r;
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// gfx950: straight VCC carry chains (24 / 22 VALU instructions) instead of compiler-emulated 64-bit carries.
+template <int F> __device__ __forceinline__ fe_t fe_add_device(const fe_t &a, const fe_t &b) {
+    fe_t r;
+    uint32_t s0, s1, s2, s3, s4, s5, s6, s7, d0, d1, d2, d3, d4, d5, d6, d7;
+    asm("v_add_co_u32_e32 %0, vcc, %16, %24\n\t"
+        "v_addc_co_u32_e32 %1, vcc, %17, %25, vcc\n\t"
+        "v_addc_co_u32_e32 %2, vcc, %18, %26, vcc\n\t"
+        "v_addc_co_u32_e32 %3, vcc, %19, %27, vcc\n\t"
+        "v_addc_co_u32_e32 %4, vcc, %20, %28, vcc\n\t"
+        "v_addc_co_u32_e32 %5, vcc, %21, %29, vcc\n\t"
+        "v_addc_co_u32_e32 %6, vcc, %22, %30, vcc\n\t"
+        "v_addc_co_u32_e32 %7, vcc, %23, %31, vcc\n\t"
+        "v_subrev_co_u32_e32 %8, vcc, 1, %0\n\t"
+        "v_subbrev_co_u32_e32 %9, vcc, %32, %1, vcc\n\t"
+        "v_subbrev_co_u32_e32 %10, vcc, %33, %2, vcc\n\t"
+        "v_subbrev_co_u32_e32 %11, vcc, %34, %3, vcc\n\t"
+        "v_subbrev_co_u32_e32 %12, vcc, 0, %4, vcc\n\t"
+        "v_subbrev_co_u32_e32 %13, vcc, 0, %5, vcc\n\t"
+        "v_subbrev_co_u32_e32 %14, vcc, 0, %6, vcc\n\t"
+        "v_subbrev_co_u32_e32 %15, vcc, %35, %7, vcc\n\t"
+        "v_cndmask_b32_e32 %8, %8, %0, vcc\n\t"
+        "v_cndmask_b32_e32 %9, %9, %1, vcc\n\t"
+        "v_cndmask_b32_e32 %10, %10, %2, vcc\n\t"
+        "v_cndmask_b32_e32 %11, %11, %3, vcc\n\t"
+        "v_cndmask_b32_e32 %12, %12, %4, vcc\n\t"
+        "v_cndmask_b32_e32 %13, %13, %5, vcc\n\t"
+        "v_cndmask_b32_e32 %14, %14, %6, vcc\n\t"
+        "v_cndmask_b32_e32 %15, %15, %7, vcc"
+        : "=&v"(s0), "=&v"(s1), "=&v"(s2), "=&v"(s3), "=&v"(s4), "=&v"(s5), "=&v"(s6), "=&v"(s7),
+          "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&v"(d4), "=&v"(d5), "=&v"(d6), "=&v"(d7)
+        : "v"(a.v[0]), "v"(a.v[1]), "v"(a.v[2]), "v"(a.v[3]), "v"(a.v[4]), "v"(a.v[5]), "v"(a.v[6]), "v"(a.v[7]),
+          "v"(b.v[0]), "v"(b.v[1]), "v"(b.v[2]), "v"(b.v[3]), "v"(b.v[4]), "v"(b.v[5]), "v"(b.v[6]), "v"(b.v[7]),
+          "v"(FieldP<F>::P1), "v"(FieldP<F>::P2), "v"(FieldP<F>::P3), "v"(P7)
+        : "vcc");
+    r.v[0] = d0; r.v[1] = d1; r.v[2] = d2; r.v[3] = d3; r.v[4] = d4; r.v[5] = d5; r.v[6] = d6; r.v[7] = d7;
+    return r;
+}
+template <int F> __device__ __forceinline__ fe_t fe_sub_device(const fe_t &a, const fe_t &b) {
+    fe_t r;
+    uint32_t d0, d1, d2, d3, d4, d5, d6, d7, m, t1, t2, t3, t7;
+    asm("v_sub_co_u32_e32 %0, vcc, %13, %21\n\t"
+        "v_subb_co_u32_e32 %1, vcc, %14, %22, vcc\n\t"
+        "v_subb_co_u32_e32 %2, vcc, %15, %23, vcc\n\t"
+        "v_subb_co_u32_e32 %3, vcc, %16, %24, vcc\n\t"
+        "v_subb_co_u32_e32 %4, vcc, %17, %25, vcc\n\t"
+        "v_subb_co_u32_e32 %5, vcc, %18, %26, vcc\n\t"
+        "v_subb_co_u32_e32 %6, vcc, %19, %27, vcc\n\t"
+        "v_subb_co_u32_e32 %7, vcc, %20, %28, vcc\n\t"
+        "v_cndmask_b32_e64 %8, 0, -1, vcc\n\t"
+        "v_and_b32_e32 %9, %29, %8\n\t"
+        "v_and_b32_e32 %10, %30, %8\n\t"
+        "v_and_b32_e32 %11, %31, %8\n\t"
+        "v_and_b32_e32 %12, %32, %8\n\t"
+        "v_and_b32_e32 %8, 1, %8\n\t"
+        "v_add_co_u32_e32 %0, vcc, %0, %8\n\t"
+        "v_addc_co_u32_e32 %1, vcc, %1, %9, vcc\n\t"
+        "v_addc_co_u32_e32 %2, vcc, %2, %10, vcc\n\t"
+        "v_addc_co_u32_e32 %3, vcc, %3, %11, vcc\n\t"
+        "v_addc_co_u32_e32 %4, vcc, 0, %4, vcc\n\t"
+        "v_addc_co_u32_e32 %5, vcc, 0, %5, vcc\n\t"
+        "v_addc_co_u32_e32 %6, vcc, 0, %6, vcc\n\t"
+        "v_addc_co_u32_e32 %7, vcc, %7, %12, vcc"
+        : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&v"(d4), "=&v"(d5), "=&v"(d6), "=&v"(d7),
+          "=&v"(m), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t7)
+        : "v"(a.v[0]), "v"(a.v[1]), "v"(a.v[2]), "v"(a.v[3]), "v"(a.v[4]), "v"(a.v[5]), "v"(a.v[6]), "v"(a.v[7]),
+          "v"(b.v[0]), "v"(b.v[1]), "v"(b.v[2]), "v"(b.v[3]), "v"(b.v[4]), "v"(b.v[5]), "v"(b.v[6]), "v"(b.v[7]),
+          "v"(FieldP<F>::P1), "v"(FieldP<F>::P2), "v"(FieldP<F>::P3), "v"(P7)
+        : "vcc");
+    r.v[0] = d0; r.v[1] = d1; r.v[2] = d2; r.v[3] = d3; r.v[4] = d4; r.v[5] = d5; r.v[6] = d6; r.v[7] = d7;
+    return r;
+}
+#endif
+template <int F> MB_HD fe_t fe_add(const fe_t &a, const fe_t &b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return fe_add_device<F>(a, b);
+#else
+    return fe_add_portable<F>(a, b);
+#endif
+}
+template <int F> MB_HD fe_t fe_sub(const fe_t &a, const fe_t &b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return fe_sub_device<F>(a, b);
+#else
+    return fe_sub_portable<F>(a, b);
+#endif
 }
 
 template <int F> MB_HD fe_t fe_neg(const fe_t &a) { return fe_sub<F>(fe_zero(), a); }

@@ -43,42 +43,68 @@ __device__ __forceinline__ uint32_t scalar_bits(const uint32_t *s, uint32_t lo, 
     return (uint32_t)(v >> sh) & ((1u << c) - 1u);
 }
 
-// K1a: signed digits + per-bucket slot via one returning atomic per non-zero digit
+// raw unsigned digit of window w
+__device__ __forceinline__ uint32_t raw_digit(const uint32_t *s, uint32_t w, uint32_t c) { return scalar_bits(s, w * c, c); }
+
+// K1a: signed digits + per-bucket slot via one returning atomic.  One lane per (window, scalar): every atomic
+// of the launch is independent, so their latency overlaps (a lane that walked its 16 windows serially paid 16
+// dependent round trips).  Digit rule: d = raw + carry_in; d > 2^(c-1) -> d - 2^c, carry out.  carry_in of window w
+// is resolved by looking at the lower windows, which almost always stops at w-1.
 static __global__ void msm_digits_kernel(MsmShape sh, const uint32_t *__restrict__ scalars /* n x 8 */,
-                                  uint32_t *__restrict__ count, uint32_t *__restrict__ ekey,
-                                  uint32_t *__restrict__ eval, uint32_t *__restrict__ eoff) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= sh.n) return;
+                                         uint32_t *__restrict__ count, uint32_t *__restrict__ ekey,
+                                         uint32_t *__restrict__ eval, uint32_t *__restrict__ eoff) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= (size_t)sh.n * sh.W) return;
+    const uint32_t w = (uint32_t)(e / sh.n), i = (uint32_t)(e % sh.n);
     uint32_t s[8];
     const uint4 *sp = reinterpret_cast<const uint4 *>(scalars + (size_t)i * 8);
     uint4 a = sp[0], b = sp[1];
     s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
-    uint32_t carry = 0;
     const uint32_t half = 1u << (sh.c - 1);
-    for (uint32_t w = 0; w < sh.W; ++w) {
-        uint32_t d = scalar_bits(s, w * sh.c, sh.c) + carry;
-        uint32_t neg = 0;
-        if (d > half) { d = (1u << sh.c) - d; neg = 1; carry = 1; } else carry = 0;
-        size_t e = (size_t)w * sh.n + i;
-        if (d == 0) { ekey[e] = MSM_INVALID; continue; }
-        uint32_t bucket = (sh.nsets == 1 ? 0u : w * sh.NB) + (d - 1);
-        uint32_t pt = (sh.table_stride ? w * sh.table_stride + sh.base_first + i : i) | (neg << 31);
-        ekey[e] = bucket;
-        eval[e] = pt;
-        eoff[e] = atomicAdd(&count[bucket], 1u);
+    uint32_t carry = 0;
+    for (int j = (int)w - 1; j >= 0; --j) {
+        uint32_t r = raw_digit(s, (uint32_t)j, sh.c);
+        if (r > half) { carry = 1; break; }
+        if (r < half) { carry = 0; break; }
+        // r == half: window j carries iff it received a carry itself -> keep looking down
     }
+    uint32_t d = raw_digit(s, w, sh.c) + carry;
+    uint32_t neg = 0;
+    if (d > half) { d = (1u << sh.c) - d; neg = 1; }
+    if (d == 0) { ekey[e] = MSM_INVALID; return; }
+    const uint32_t bucket = (sh.nsets == 1 ? 0u : w * sh.NB) + (d - 1);
+    ekey[e] = bucket;
+    eval[e] = (sh.table_stride ? w * sh.table_stride + sh.base_first + i : i) | (neg << 31);
+    eoff[e] = atomicAdd(&count[bucket], 1u);
 }
 
-// K1b: exclusive scans of count[] and of ceil(count/L) (single block; nb_total <= 2^20)
-static __global__ void msm_scan_kernel(uint32_t nb_total, const uint32_t *__restrict__ count,
-                                uint32_t *__restrict__ start /* nb_total+1 */,
-                                uint32_t *__restrict__ task_start /* nb_total+1 */) {
+// K1b: exclusive scans of count[] and of ceil(count/L) (single block of 1024 lanes; each lane owns a contiguous
+// chunk that it reads once with 16-byte loads and keeps in registers when it fits).
+static __global__ void __launch_bounds__(1024)
+msm_scan_kernel(uint32_t nb_total, const uint32_t *__restrict__ count, uint32_t *__restrict__ start /* nb_total+1 */,
+                uint32_t *__restrict__ task_start /* nb_total+1 */) {
     __shared__ uint32_t s_cnt[1024], s_tsk[1024];
     const uint32_t tid = threadIdx.x, nt = blockDim.x;
-    const uint32_t per = (nb_total + nt - 1) / nt;
-    const uint32_t lo = tid * per, hi = min(lo + per, nb_total);
+    uint32_t per = (nb_total + nt - 1) / nt;
+    per = (per + 3u) & ~3u;                                   // multiple of 4 -> uint4 loads stay aligned
+    const uint32_t lo = min(tid * per, nb_total), hi = min(lo + per, nb_total);
+    constexpr uint32_t CACHE = 32;
+    uint32_t cached[CACHE];
+    const bool fits = per <= CACHE;
     uint32_t sc = 0, st = 0;
-    for (uint32_t b = lo; b < hi; ++b) { uint32_t c = count[b]; sc += c; st += (c + MSM_TASK_LEN - 1) / MSM_TASK_LEN; }
+    if (fits) {
+#pragma unroll
+        for (uint32_t q = 0; q < CACHE; q += 4) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (lo + q + 3 < hi) v = *reinterpret_cast<const uint4 *>(count + lo + q);
+            else { if (lo + q < hi) v.x = count[lo + q]; if (lo + q + 1 < hi) v.y = count[lo + q + 1]; if (lo + q + 2 < hi) v.z = count[lo + q + 2]; }
+            cached[q] = v.x; cached[q + 1] = v.y; cached[q + 2] = v.z; cached[q + 3] = v.w;
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < CACHE; ++q) { sc += cached[q]; st += (cached[q] + MSM_TASK_LEN - 1) / MSM_TASK_LEN; }
+    } else {
+        for (uint32_t b = lo; b < hi; ++b) { uint32_t c = count[b]; sc += c; st += (c + MSM_TASK_LEN - 1) / MSM_TASK_LEN; }
+    }
     s_cnt[tid] = sc; s_tsk[tid] = st;
     __syncthreads();
     for (uint32_t d = 1; d < nt; d <<= 1) {
@@ -88,11 +114,19 @@ static __global__ void msm_scan_kernel(uint32_t nb_total, const uint32_t *__rest
         s_cnt[tid] += vc; s_tsk[tid] += vt;
         __syncthreads();
     }
-    uint32_t pc = s_cnt[tid] - sc, pt = s_tsk[tid] - st;   // exclusive prefix of this thread's chunk
-    for (uint32_t b = lo; b < hi; ++b) {
-        uint32_t c = count[b];
-        start[b] = pc; task_start[b] = pt;
-        pc += c; pt += (c + MSM_TASK_LEN - 1) / MSM_TASK_LEN;
+    uint32_t pc = s_cnt[tid] - sc, pt = s_tsk[tid] - st;   // exclusive prefix of this lane's chunk
+    if (fits) {
+#pragma unroll
+        for (uint32_t q = 0; q < CACHE; ++q) {
+            if (lo + q < hi) { start[lo + q] = pc; task_start[lo + q] = pt; }
+            pc += cached[q]; pt += (cached[q] + MSM_TASK_LEN - 1) / MSM_TASK_LEN;
+        }
+    } else {
+        for (uint32_t b = lo; b < hi; ++b) {
+            uint32_t c = count[b];
+            start[b] = pc; task_start[b] = pt;
+            pc += c; pt += (c + MSM_TASK_LEN - 1) / MSM_TASK_LEN;
+        }
     }
     if (tid == nt - 1) { start[nb_total] = s_cnt[tid]; task_start[nb_total] = s_tsk[tid]; }
 }
@@ -173,28 +207,28 @@ __device__ __forceinline__ xyzz_t shfl_down_xyzz(const xyzz_t &a, int d) {
     xyzz_t r; r.x = shfl_down_fe(a.x, d); r.y = shfl_down_fe(a.y, d);
     r.zz = shfl_down_fe(a.zz, d); r.zzz = shfl_down_fe(a.zzz, d); return r;
 }
-// lane 0 gets sum over lanes of v
-template <int F> __device__ __forceinline__ xyzz_t wave_sum(xyzz_t v) {
+// lane 0 gets the sum over lanes [0, width) of v  (width = power of two <= 64; lanes >= width must hold infinity)
+template <int F> __device__ __forceinline__ xyzz_t wave_sum(xyzz_t v, int width = 64) {
     const int lane = threadIdx.x & 63;
 #pragma unroll 1
-    for (int d = 32; d >= 1; d >>= 1) {
+    for (int d = width >> 1; d >= 1; d >>= 1) {
         xyzz_t o = shfl_down_xyzz(v, d);
-        if (lane + d < 64) xyzz_add<F>(v, o);
+        if (lane + d < width) xyzz_add<F>(v, o);
     }
     return v;
 }
-// lane 0 gets  sum_l v_l  (in `sum`) and  sum_l l * v_l  (returned)
-template <int F> __device__ __forceinline__ xyzz_t wave_weighted_sum(xyzz_t v, xyzz_t &sum) {
+// lane 0 gets  sum_l v_l  (in `sum`) and  sum_l l * v_l  (returned), l < width
+template <int F> __device__ __forceinline__ xyzz_t wave_weighted_sum(xyzz_t v, xyzz_t &sum, int width = 64) {
     const int lane = threadIdx.x & 63;
     // suffix scan: s_l = sum_{i >= l} v_i
 #pragma unroll 1
-    for (int d = 1; d < 64; d <<= 1) {
+    for (int d = 1; d < width; d <<= 1) {
         xyzz_t o = shfl_down_xyzz(v, d);
-        if (lane + d < 64) xyzz_add<F>(v, o);
+        if (lane + d < width) xyzz_add<F>(v, o);
     }
     sum = v;                                   // lane 0: total
     if (lane == 0) v = xyzz_inf();             // sum_{l>=1} s_l = sum_l l * v_l
-    return wave_sum<F>(v);
+    return wave_sum<F>(v, width);
 }
 
 // K1f: level A of the bucket reduction: one wave per 64 consecutive buckets of one set.
@@ -211,44 +245,59 @@ msm_reduce_a_kernel(uint32_t nb_total, const xyzz_t *__restrict__ buckets, xyzz_
     if (lane == 0) { out_r[g] = sum; out_ws[g] = ws; }
 }
 
-// K1g: levels B+C.  One block per bucket set; `groups` = NB/64 (<= 4096) level-A results of that set.
-//   set total = sum_b (b+1) B_b = P + Rall + 64 * sum_g g * R_g,   P = sum_g WS_g,  Rall = sum_g R_g
+// K1g: level B.  Block (v, set) = super-group v (64 consecutive level-A groups) of one bucket set; two waves:
+//   wave 0:  R'_v = sum_u R_{64v+u},  WS'_v = sum_u u * R_{64v+u}        wave 1:  P'_v = sum_u WS_{64v+u}
 template <int F>
-__global__ void __launch_bounds__(64)
-msm_reduce_bc_kernel(uint32_t groups, const xyzz_t *__restrict__ in_r, const xyzz_t *__restrict__ in_ws,
-                     xyzz_t *__restrict__ set_total) {
-    const uint32_t set = blockIdx.x, lane = threadIdx.x;
-    const xyzz_t *r = in_r + (size_t)set * groups;
-    const xyzz_t *ws = in_ws + (size_t)set * groups;
-    // level B: lane handles super-groups v = lane, lane+64, ... each = 64 consecutive groups.
-    // groups <= 64: a single super-group, handled directly as level C input.
-    __shared__ xyzz_t sh_r[64], sh_w[64], sh_p[64];
-    const uint32_t nsuper = (groups + 63) / 64;          // <= 64
-    for (uint32_t v = 0; v < nsuper; ++v) {
-        uint32_t g = v * 64 + lane;
-        xyzz_t rv = (g < groups) ? r[g] : xyzz_inf();
-        xyzz_t pv = (g < groups) ? ws[g] : xyzz_inf();
+__global__ void __launch_bounds__(128)
+msm_reduce_b_kernel(uint32_t groups, uint32_t nsuper, const xyzz_t *__restrict__ in_r, const xyzz_t *__restrict__ in_ws,
+                    xyzz_t *__restrict__ out_r, xyzz_t *__restrict__ out_w, xyzz_t *__restrict__ out_p) {
+    const uint32_t v = blockIdx.x, set = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t g = v * 64 + lane;
+    const size_t base = (size_t)set * groups;
+    if (wave == 0) {
+        xyzz_t rv = (g < groups) ? in_r[base + g] : xyzz_inf();
         xyzz_t sum;
-        xyzz_t wsum = wave_weighted_sum<F>(rv, sum);    // sum_u u * R_{64v+u}, sum_u R
+        xyzz_t wsum = wave_weighted_sum<F>(rv, sum);
+        if (lane == 0) { out_r[(size_t)set * nsuper + v] = sum; out_w[(size_t)set * nsuper + v] = wsum; }
+    } else {
+        xyzz_t pv = (g < groups) ? in_ws[base + g] : xyzz_inf();
         xyzz_t psum = wave_sum<F>(pv);
-        if (lane == 0) { sh_r[v] = sum; sh_w[v] = wsum; sh_p[v] = psum; }
+        if (lane == 0) out_p[(size_t)set * nsuper + v] = psum;
+    }
+}
+
+// K1g': level C.  One block per bucket set over its nsuper (<= 64) super-groups; three waves work concurrently:
+//   set total = sum_b (b+1) B_b = P + Rall + 64 * ( sum_v WS'_v + 64 * sum_v v * R'_v )
+template <int F>
+__global__ void __launch_bounds__(192)
+msm_reduce_c_kernel(uint32_t nsuper, const xyzz_t *__restrict__ in_r, const xyzz_t *__restrict__ in_w,
+                    const xyzz_t *__restrict__ in_p, xyzz_t *__restrict__ set_total) {
+    const uint32_t set = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ xyzz_t sh_vw, sh_rall, sh_ws, sh_p;
+    int width = 1; while (width < (int)nsuper) width <<= 1;
+    const size_t base = (size_t)set * nsuper;
+    if (wave == 0) {
+        xyzz_t rv = (lane < nsuper) ? in_r[base + lane] : xyzz_inf();
+        xyzz_t rall;
+        xyzz_t vw = wave_weighted_sum<F>(rv, rall, width);
+        if (lane == 0) { sh_vw = vw; sh_rall = rall; }
+    } else if (wave == 1) {
+        xyzz_t wv = (lane < nsuper) ? in_w[base + lane] : xyzz_inf();
+        xyzz_t s = wave_sum<F>(wv, width);
+        if (lane == 0) sh_ws = s;
+    } else {
+        xyzz_t pv = (lane < nsuper) ? in_p[base + lane] : xyzz_inf();
+        xyzz_t s = wave_sum<F>(pv, width);
+        if (lane == 0) sh_p = s;
     }
     __syncthreads();
-    // level C over super-groups: sum_g g R_g = sum_v (64 v R'_v + WS'_v)
-    xyzz_t rv = (lane < nsuper) ? sh_r[lane] : xyzz_inf();
-    xyzz_t wv = (lane < nsuper) ? sh_w[lane] : xyzz_inf();
-    xyzz_t pv = (lane < nsuper) ? sh_p[lane] : xyzz_inf();
-    xyzz_t rall;
-    xyzz_t vw = wave_weighted_sum<F>(rv, rall);          // sum_v v R'_v ; Rall
-    xyzz_t wsum = wave_sum<F>(wv);                        // sum_v WS'_v
-    xyzz_t psum = wave_sum<F>(pv);                        // P
-    if (lane == 0) {
-        xyzz_t t = vw;
+    if (threadIdx.x == 0) {
+        xyzz_t t = sh_vw;
         for (int i = 0; i < 6; ++i) t = xyzz_dbl<F>(t);   // 64 * sum_v v R'_v
-        xyzz_add<F>(t, wsum);                             // = sum_g g R_g
+        xyzz_add<F>(t, sh_ws);                            // = sum_g g R_g
         for (int i = 0; i < 6; ++i) t = xyzz_dbl<F>(t);   // * 64
-        xyzz_add<F>(t, psum);
-        xyzz_add<F>(t, rall);
+        xyzz_add<F>(t, sh_p);
+        xyzz_add<F>(t, sh_rall);
         set_total[set] = t;
     }
 }

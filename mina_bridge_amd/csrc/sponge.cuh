@@ -161,17 +161,22 @@ poseidon_hash_kernel(uint32_t n, uint32_t len, FieldK fk, const PoseidonParams *
     for (int q = 0; q < 8; ++q) out_words[(size_t)i * 8 + q] = w.v[q];
 }
 
-// ScalarChallenge::to_field
+// ScalarChallenge::to_field.  Upstream runs 64 rounds of "double a and b, add +-1 to one of them" in the field;
+// a and b stay small integers (2^65 + a signed 64-bit sum), so they are assembled with integer bit masks and
+// only the final a * endo + b touches the field (2 conversions + 1 product instead of ~200 field ops).
 template <int F> MB_HD fe_t challenge_to_field(uint64_t lo, uint64_t hi, const FieldK &fk) {
-    fe_t two = fe_dbl<F>(fk.one), a = two, b = two, neg1 = fe_neg<F>(fk.one);
-    for (int i = 63; i >= 0; --i) {
-        a = fe_dbl<F>(a); b = fe_dbl<F>(b);
-        uint32_t bit0 = (2 * i < 64) ? (uint32_t)(lo >> (2 * i)) & 1u : (uint32_t)(hi >> (2 * i - 64)) & 1u;
-        uint32_t bit1 = (2 * i + 1 < 64) ? (uint32_t)(lo >> (2 * i + 1)) & 1u : (uint32_t)(hi >> (2 * i + 1 - 64)) & 1u;
-        const fe_t &s = bit0 ? fk.one : neg1;
-        if (bit1 == 0) b = fe_add<F>(b, s); else a = fe_add<F>(a, s);
+    uint64_t pa = 0, na = 0, pb = 0, nb = 0;
+    for (int i = 0; i < 64; ++i) {
+        const uint64_t w = (i < 32) ? lo : hi;
+        const int sh = (2 * i) & 63;
+        const uint64_t r0 = (w >> sh) & 1u, r1 = (w >> (sh + 1)) & 1u;
+        const uint64_t bit = (uint64_t)1 << i;
+        if (r1) { if (r0) pa |= bit; else na |= bit; } else { if (r0) pb |= bit; else nb |= bit; }
     }
-    return fe_add<F>(fe_mul<F>(a, fk.endo), b);
+    fe_t a = fe_zero(), b = fe_zero();
+    { uint64_t l = pa - na; uint32_t h = (pa >= na) ? 2u : 1u; a.v[0] = (uint32_t)l; a.v[1] = (uint32_t)(l >> 32); a.v[2] = h; }
+    { uint64_t l = pb - nb; uint32_t h = (pb >= nb) ? 2u : 1u; b.v[0] = (uint32_t)l; b.v[1] = (uint32_t)(l >> 32); b.v[2] = h; }
+    return fe_add<F>(fe_mul<F>(fe_to_mont<F>(a, fk.r2), fk.endo), fe_to_mont<F>(b, fk.r2));
 }
 
 #if defined(__HIPCC__)
