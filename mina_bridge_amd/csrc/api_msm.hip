@@ -21,7 +21,6 @@ static int run_msm(mina_ctx *c, const MsmShape &sh, const uint32_t *d_scalars, c
     const uint32_t nb_total = sh.NB * sh.nsets;
     const size_t entries = (size_t)sh.n * sh.W;
     const size_t max_tasks = entries / MSM_TASK_LEN + nb_total + 1;
-    const uint32_t groups = nb_total / 64;
     int rc;
     if ((rc = w.ekey.ensure(entries * 4))) return rc;
     if ((rc = w.eval.ensure(entries * 4))) return rc;
@@ -30,36 +29,39 @@ static int run_msm(mina_ctx *c, const MsmShape &sh, const uint32_t *d_scalars, c
     if ((rc = w.count.ensure((size_t)nb_total * 4))) return rc;
     if ((rc = w.start.ensure(((size_t)nb_total + 1) * 4))) return rc;
     if ((rc = w.task_start.ensure(((size_t)nb_total + 1) * 4))) return rc;
+    if ((rc = w.rem_pos.ensure((size_t)nb_total * 4))) return rc;
+    if ((rc = w.rem_bucket.ensure((size_t)nb_total * 4))) return rc;
+    if ((rc = w.info.ensure(16))) return rc;
     if ((rc = w.partial.ensure(max_tasks * sizeof(xyzz_t)))) return rc;
     if ((rc = w.buckets.ensure((size_t)nb_total * sizeof(xyzz_t)))) return rc;
-    if ((rc = w.red_r.ensure((size_t)groups * sizeof(xyzz_t)))) return rc;
-    if ((rc = w.red_ws.ensure((size_t)groups * sizeof(xyzz_t)))) return rc;
+    if (sh.NB < 128 || sh.NB > 32768) return fail(MINA_ERR_ARG, "unsupported bucket count");
+    if ((rc = w.red_r.ensure((size_t)(sh.NB / 128) * sh.nsets * sizeof(xyzz_t)))) return rc;
+    if ((rc = w.red_ws.ensure((size_t)128 * sh.nsets * sizeof(xyzz_t)))) return rc;
     if ((rc = w.set_total.ensure((size_t)sh.nsets * sizeof(xyzz_t)))) return rc;
-    {
-        const size_t ns = (size_t)sh.nsets * ((sh.NB / 64 + 63) / 64);
-        if ((rc = w.red2_r.ensure(ns * sizeof(xyzz_t)))) return rc;
-        if ((rc = w.red2_w.ensure(ns * sizeof(xyzz_t)))) return rc;
-        if ((rc = w.red2_p.ensure(ns * sizeof(xyzz_t)))) return rc;
-    }
 
     hipStream_t st = c->L->stream;
     HIPC(hipMemsetAsync(w.count.p, 0, (size_t)nb_total * 4, st));
     { ProfScope ps_(c, PS_DIGITS); msm_digits_kernel<<<cdiv(entries, 256), 256, 0, st>>>(sh, d_scalars, w.count.as<uint32_t>(), w.ekey.as<uint32_t>(),
                                                        w.eval.as<uint32_t>(), w.eoff.as<uint32_t>()); }
-    { ProfScope ps_(c, PS_SCAN); msm_scan_kernel<<<1, 1024, 0, st>>>(nb_total, w.count.as<uint32_t>(), w.start.as<uint32_t>(), w.task_start.as<uint32_t>()); }
+    { ProfScope ps_(c, PS_SCAN); msm_scan_kernel<<<1, 1024, 0, st>>>(nb_total, w.count.as<uint32_t>(), w.start.as<uint32_t>(), w.task_start.as<uint32_t>(),
+                                                                   w.rem_pos.as<uint32_t>(), w.rem_bucket.as<uint32_t>(), w.info.as<uint32_t>()); }
     { ProfScope ps_(c, PS_SCATTER); msm_scatter_kernel<<<cdiv(entries, 256), 256, 0, st>>>(entries, w.ekey.as<uint32_t>(), w.eval.as<uint32_t>(),
                                                            w.eoff.as<uint32_t>(), w.start.as<uint32_t>(), w.sorted.as<uint32_t>()); }
     { ProfScope ps_(c, PS_ACCUMULATE); msm_accumulate_kernel<F><<<cdiv(max_tasks, 256), 256, 0, st>>>(nb_total, w.start.as<uint32_t>(), w.task_start.as<uint32_t>(),
-                                                                   w.sorted.as<uint32_t>(), d_points, fk.one, w.partial.as<xyzz_t>()); }
-    { ProfScope ps_(c, PS_BUCKET_SUM); msm_bucket_sum_kernel<F><<<cdiv(nb_total, 256), 256, 0, st>>>(nb_total, w.task_start.as<uint32_t>(), w.partial.as<xyzz_t>(),
+                                                                   w.rem_bucket.as<uint32_t>(), w.info.as<uint32_t>(), w.sorted.as<uint32_t>(), d_points, fk.one, w.partial.as<xyzz_t>()); }
+    { ProfScope ps_(c, PS_BUCKET_SUM); msm_bucket_sum_kernel<F><<<cdiv(nb_total, 256), 256, 0, st>>>(nb_total, w.task_start.as<uint32_t>(), w.rem_pos.as<uint32_t>(), w.info.as<uint32_t>(), w.partial.as<xyzz_t>(),
                                                                   w.buckets.as<xyzz_t>()); }
-    { ProfScope ps_(c, PS_REDUCE_A); msm_reduce_a_kernel<F><<<groups, 64, 0, st>>>(nb_total, w.buckets.as<xyzz_t>(), w.red_r.as<xyzz_t>(), w.red_ws.as<xyzz_t>()); }
     {
-        const uint32_t gps = sh.NB / 64, nsuper = (gps + 63) / 64;
-        { ProfScope ps_(c, PS_REDUCE_BC); msm_reduce_b_kernel<F><<<dim3(nsuper, sh.nsets), 128, 0, st>>>(gps, nsuper, w.red_r.as<xyzz_t>(), w.red_ws.as<xyzz_t>(),
-                                                                                              w.red2_r.as<xyzz_t>(), w.red2_w.as<xyzz_t>(), w.red2_p.as<xyzz_t>()); }
-        { ProfScope ps_(c, PS_REDUCE_C); msm_reduce_c_kernel<F><<<sh.nsets, 192, 0, st>>>(nsuper, w.red2_r.as<xyzz_t>(), w.red2_w.as<xyzz_t>(), w.red2_p.as<xyzz_t>(),
-                                                                                  w.set_total.as<xyzz_t>()); }
+        // 2-D bucket reduction: C = 128 columns, R = NB / C rows (NB is a power of two in [128, 32768])
+        const uint32_t C = 128, log2C = 7, R = sh.NB / C;
+        SegSum rows, cols;
+        rows.nseg = R * sh.nsets; rows.per_set = R; rows.len = C; rows.seg_stride = C; rows.elem_stride = 1; rows.lanes = C / SEG_CHUNK;
+        cols.nseg = C * sh.nsets; cols.per_set = C; cols.len = R; cols.seg_stride = 1; cols.elem_stride = C;
+        { uint32_t l = 1; while (l * SEG_CHUNK < R && l < 64) l <<= 1; cols.lanes = l; }
+        const uint32_t threads_rows = rows.nseg * rows.lanes, threads_cols = cols.nseg * cols.lanes;
+        const uint32_t blocks = cdiv(threads_rows > threads_cols ? threads_rows : threads_cols, 256);
+        { ProfScope ps_(c, PS_REDUCE_A); msm_segsum_kernel<F><<<dim3(blocks, 2), 256, 0, st>>>(sh.NB, rows, cols, w.buckets.as<xyzz_t>(), w.red_r.as<xyzz_t>(), w.red_ws.as<xyzz_t>()); }
+        { ProfScope ps_(c, PS_REDUCE_BC); msm_reduce2d_kernel<F><<<sh.nsets, 384, 0, st>>>(R, C, log2C, w.red_r.as<xyzz_t>(), w.red_ws.as<xyzz_t>(), w.set_total.as<xyzz_t>()); }
     }
     { ProfScope ps_(c, PS_FINISH); msm_finish_kernel<F><<<1, 64, 0, st>>>(sh.nsets, sh.c, w.set_total.as<xyzz_t>(), fk.one, fk.pm2, d_out_xyzz, d_out_words); }
     HIPC(hipGetLastError());

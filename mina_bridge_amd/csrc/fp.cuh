@@ -240,44 +240,98 @@ __device__ __forceinline__ void mb_mac(uint64_t &acc, uint32_t &hi, uint32_t x, 
 __device__ __forceinline__ void mb_acc_add(uint64_t &acc, uint32_t &hi, uint64_t v) {
     acc += v; hi += (acc < v) ? 1u : 0u;
 }
+// acc(96 bit) += m * p0 where m = -lo: the low word becomes 0 and carries (lo != 0) into the upper 64 bits; then >> 32.
+__device__ __forceinline__ void mb_fold_shift(uint64_t &acc, uint32_t &hi, uint32_t lo, uint32_t mid) {
+    uint32_t nlo, nhi;
+    asm("v_cmp_ne_u32_e32 vcc, 0, %2\n\tv_addc_co_u32_e32 %0, vcc, 0, %3, vcc\n\tv_addc_co_u32_e32 %1, vcc, 0, %4, vcc"
+        : "=&v"(nlo), "=&v"(nhi) : "v"(lo), "v"(mid), "v"(hi) : "vcc");
+    acc = ((uint64_t)nhi << 32) | nlo; hi = 0;
+}
 template <int F> __device__ __forceinline__ fe_t fe_mul_device(const fe_t &a, const fe_t &b) {
-    uint64_t acc = 0; uint32_t hi = 0;
-    uint32_t m[8]; fe_t r;
+    // generated by tools/gen_fe_mul.py -- product scanning, one asm statement per column
+    uint64_t acc = 0, cc; uint32_t hi = 0, lo, mid; fe_t r;
+    uint32_t m0, m1, m2, m3, m4, m5, m6, m7;
     const uint32_t p1 = FieldP<F>::P1, p2 = FieldP<F>::P2, p3 = FieldP<F>::P3;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-#pragma unroll
-        for (int i = 0; i <= k; ++i) mb_mac(acc, hi, a.v[i], b.v[k - i]);
-#pragma unroll
-        for (int i = 0; i < k; ++i) {
-            const int j = k - i;
-            if (j == 1) mb_mac(acc, hi, m[i], p1);
-            if (j == 2) mb_mac(acc, hi, m[i], p2);
-            if (j == 3) mb_mac(acc, hi, m[i], p3);
-            if (j == 7) mb_acc_add(acc, hi, (uint64_t)m[i] << 30);
-        }
-        m[k] = 0u - (uint32_t)acc;
-        mb_acc_add(acc, hi, (uint64_t)m[k]);                 // + m_k * p0 : low word becomes 0
-        acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
-    }
-#pragma unroll
-    for (int k = 8; k < 15; ++k) {
-#pragma unroll
-        for (int i = k - 7; i < 8; ++i) mb_mac(acc, hi, a.v[i], b.v[k - i]);
-#pragma unroll
-        for (int i = k - 7; i < 8; ++i) {
-            const int j = k - i;
-            if (j == 1) mb_mac(acc, hi, m[i], p1);
-            if (j == 2) mb_mac(acc, hi, m[i], p2);
-            if (j == 3) mb_mac(acc, hi, m[i], p3);
-            if (j == 7) mb_acc_add(acc, hi, (uint64_t)m[i] << 30);
-        }
-        r.v[k - 8] = (uint32_t)acc;
-        acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
-    }
-    r.v[7] = (uint32_t)acc;                                   // result < 2p < 2^256
+    // column 0: 1 products
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[0]));
+    lo = (uint32_t)acc; mid = (uint32_t)(acc >> 32); m0 = 0u - lo;
+    mb_fold_shift(acc, hi, lo, mid);                          // + m_k * p0 (low word -> 0), then >> 32
+    // column 1: 3 products
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[1]), "v"(a.v[1]), "v"(b.v[0]), "v"(m0), "v"(p1));
+    lo = (uint32_t)acc; mid = (uint32_t)(acc >> 32); m1 = 0u - lo;
+    mb_fold_shift(acc, hi, lo, mid);                          // + m_k * p0 (low word -> 0), then >> 32
+    // column 2: 5 products
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[2]), "v"(a.v[1]), "v"(b.v[1]), "v"(a.v[2]), "v"(b.v[0]), "v"(m0), "v"(p2), "v"(m1), "v"(p1));
+    lo = (uint32_t)acc; mid = (uint32_t)(acc >> 32); m2 = 0u - lo;
+    mb_fold_shift(acc, hi, lo, mid);                          // + m_k * p0 (low word -> 0), then >> 32
+    // column 3: 7 products
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[3]), "v"(a.v[1]), "v"(b.v[2]), "v"(a.v[2]), "v"(b.v[1]), "v"(a.v[3]), "v"(b.v[0]), "v"(m0), "v"(p3), "v"(m1), "v"(p2), "v"(m2), "v"(p1));
+    lo = (uint32_t)acc; mid = (uint32_t)(acc >> 32); m3 = 0u - lo;
+    mb_fold_shift(acc, hi, lo, mid);                          // + m_k * p0 (low word -> 0), then >> 32
+    // column 4: 8 products
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[4]), "v"(a.v[1]), "v"(b.v[3]), "v"(a.v[2]), "v"(b.v[2]), "v"(a.v[3]), "v"(b.v[1]), "v"(a.v[4]), "v"(b.v[0]), "v"(m1), "v"(p3), "v"(m2), "v"(p2), "v"(m3), "v"(p1));
+    lo = (uint32_t)acc; mid = (uint32_t)(acc >> 32); m4 = 0u - lo;
+    mb_fold_shift(acc, hi, lo, mid);                          // + m_k * p0 (low word -> 0), then >> 32
+    // column 5: 9 products
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[5]), "v"(a.v[1]), "v"(b.v[4]), "v"(a.v[2]), "v"(b.v[3]), "v"(a.v[3]), "v"(b.v[2]), "v"(a.v[4]), "v"(b.v[1]), "v"(a.v[5]), "v"(b.v[0]), "v"(m2), "v"(p3), "v"(m3), "v"(p2), "v"(m4), "v"(p1));
+    lo = (uint32_t)acc; mid = (uint32_t)(acc >> 32); m5 = 0u - lo;
+    mb_fold_shift(acc, hi, lo, mid);                          // + m_k * p0 (low word -> 0), then >> 32
+    // column 6: 10 products
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[6]), "v"(a.v[1]), "v"(b.v[5]), "v"(a.v[2]), "v"(b.v[4]), "v"(a.v[3]), "v"(b.v[3]), "v"(a.v[4]), "v"(b.v[2]), "v"(a.v[5]), "v"(b.v[1]), "v"(a.v[6]), "v"(b.v[0]), "v"(m3), "v"(p3), "v"(m4), "v"(p2), "v"(m5), "v"(p1));
+    lo = (uint32_t)acc; mid = (uint32_t)(acc >> 32); m6 = 0u - lo;
+    mb_fold_shift(acc, hi, lo, mid);                          // + m_k * p0 (low word -> 0), then >> 32
+    // column 7: 11 products
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[7]), "v"(a.v[1]), "v"(b.v[6]), "v"(a.v[2]), "v"(b.v[5]), "v"(a.v[3]), "v"(b.v[4]), "v"(a.v[4]), "v"(b.v[3]), "v"(a.v[5]), "v"(b.v[2]), "v"(a.v[6]), "v"(b.v[1]), "v"(a.v[7]), "v"(b.v[0]), "v"(m4), "v"(p3), "v"(m5), "v"(p2), "v"(m6), "v"(p1));
+    mb_acc_add(acc, hi, (uint64_t)m0 << 30);            // m0 * p7 (p7 = 2^30)
+    lo = (uint32_t)acc; mid = (uint32_t)(acc >> 32); m7 = 0u - lo;
+    mb_fold_shift(acc, hi, lo, mid);                          // + m_k * p0 (low word -> 0), then >> 32
+    // column 8: 10 products
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a.v[1]), "v"(b.v[7]), "v"(a.v[2]), "v"(b.v[6]), "v"(a.v[3]), "v"(b.v[5]), "v"(a.v[4]), "v"(b.v[4]), "v"(a.v[5]), "v"(b.v[3]), "v"(a.v[6]), "v"(b.v[2]), "v"(a.v[7]), "v"(b.v[1]), "v"(m5), "v"(p3), "v"(m6), "v"(p2), "v"(m7), "v"(p1));
+    mb_acc_add(acc, hi, (uint64_t)m1 << 30);            // m1 * p7 (p7 = 2^30)
+    r.v[0] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
+    // column 9: 8 products
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a.v[2]), "v"(b.v[7]), "v"(a.v[3]), "v"(b.v[6]), "v"(a.v[4]), "v"(b.v[5]), "v"(a.v[5]), "v"(b.v[4]), "v"(a.v[6]), "v"(b.v[3]), "v"(a.v[7]), "v"(b.v[2]), "v"(m6), "v"(p3), "v"(m7), "v"(p2));
+    mb_acc_add(acc, hi, (uint64_t)m2 << 30);            // m2 * p7 (p7 = 2^30)
+    r.v[1] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
+    // column 10: 6 products
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a.v[3]), "v"(b.v[7]), "v"(a.v[4]), "v"(b.v[6]), "v"(a.v[5]), "v"(b.v[5]), "v"(a.v[6]), "v"(b.v[4]), "v"(a.v[7]), "v"(b.v[3]), "v"(m7), "v"(p3));
+    mb_acc_add(acc, hi, (uint64_t)m3 << 30);            // m3 * p7 (p7 = 2^30)
+    r.v[2] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
+    // column 11: 4 products
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a.v[4]), "v"(b.v[7]), "v"(a.v[5]), "v"(b.v[6]), "v"(a.v[6]), "v"(b.v[5]), "v"(a.v[7]), "v"(b.v[4]));
+    mb_acc_add(acc, hi, (uint64_t)m4 << 30);            // m4 * p7 (p7 = 2^30)
+    r.v[3] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
+    // column 12: 3 products
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a.v[5]), "v"(b.v[7]), "v"(a.v[6]), "v"(b.v[6]), "v"(a.v[7]), "v"(b.v[5]));
+    mb_acc_add(acc, hi, (uint64_t)m5 << 30);            // m5 * p7 (p7 = 2^30)
+    r.v[4] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
+    // column 13: 2 products
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a.v[6]), "v"(b.v[7]), "v"(a.v[7]), "v"(b.v[6]));
+    mb_acc_add(acc, hi, (uint64_t)m6 << 30);            // m6 * p7 (p7 = 2^30)
+    r.v[5] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
+    // column 14: 1 products
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a.v[7]), "v"(b.v[7]));
+    mb_acc_add(acc, hi, (uint64_t)m7 << 30);            // m7 * p7 (p7 = 2^30)
+    r.v[6] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
+    r.v[7] = (uint32_t)acc;                                       // result < 2p < 2^256
     return fe_cond_sub_p<F>(r);
 }
+
 #endif
 template <int F> MB_HD fe_t fe_mul(const fe_t &a, const fe_t &b) {
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -78,12 +78,19 @@ static __global__ void msm_digits_kernel(MsmShape sh, const uint32_t *__restrict
     eoff[e] = atomicAdd(&count[bucket], 1u);
 }
 
-// K1b: exclusive scans of count[] and of ceil(count/L) (single block of 1024 lanes; each lane owns a contiguous
-// chunk that it reads once with 16-byte loads and keeps in registers when it fits).
+// K1b: single-block scan (1024 lanes, each owning a contiguous chunk of buckets read once with 16-byte loads).
+// Produces, per bucket b with cnt entries (f = cnt / L full tasks, r = cnt % L):
+//   start[b]       exclusive prefix of cnt                       (start[nb] = total entries)
+//   full_start[b]  exclusive prefix of f                         (full_start[nb] = Ft, number of full tasks)
+//   rem_pos[b]     index of b's remainder task among all remainder tasks, ordered by DESCENDING r so that the
+//                  lanes of a wave run the same number of adds; MSM_INVALID if r == 0
+//   rem_bucket[q]  inverse map; info[0] = Ft, info[1] = number of remainder tasks
 static __global__ void __launch_bounds__(1024)
 msm_scan_kernel(uint32_t nb_total, const uint32_t *__restrict__ count, uint32_t *__restrict__ start /* nb_total+1 */,
-                uint32_t *__restrict__ task_start /* nb_total+1 */) {
-    __shared__ uint32_t s_cnt[1024], s_tsk[1024];
+                uint32_t *__restrict__ full_start /* nb_total+1 */, uint32_t *__restrict__ rem_pos /* nb_total */,
+                uint32_t *__restrict__ rem_bucket /* nb_total */, uint32_t *__restrict__ info /* 2 */) {
+    constexpr int NCLS = MSM_TASK_LEN - 1;                     // class kappa = L-1-r  (r = L-1 .. 1)
+    __shared__ uint32_t s_cnt[1024], s_ful[1024], s_cls[NCLS][1024];
     const uint32_t tid = threadIdx.x, nt = blockDim.x;
     uint32_t per = (nb_total + nt - 1) / nt;
     per = (per + 3u) & ~3u;                                   // multiple of 4 -> uint4 loads stay aligned
@@ -91,7 +98,6 @@ msm_scan_kernel(uint32_t nb_total, const uint32_t *__restrict__ count, uint32_t 
     constexpr uint32_t CACHE = 32;
     uint32_t cached[CACHE];
     const bool fits = per <= CACHE;
-    uint32_t sc = 0, st = 0;
     if (fits) {
 #pragma unroll
         for (uint32_t q = 0; q < CACHE; q += 4) {
@@ -100,35 +106,67 @@ msm_scan_kernel(uint32_t nb_total, const uint32_t *__restrict__ count, uint32_t 
             else { if (lo + q < hi) v.x = count[lo + q]; if (lo + q + 1 < hi) v.y = count[lo + q + 1]; if (lo + q + 2 < hi) v.z = count[lo + q + 2]; }
             cached[q] = v.x; cached[q + 1] = v.y; cached[q + 2] = v.z; cached[q + 3] = v.w;
         }
+    }
+    uint32_t sc = 0, sf = 0, cls[NCLS];
 #pragma unroll
-        for (uint32_t q = 0; q < CACHE; ++q) { sc += cached[q]; st += (cached[q] + MSM_TASK_LEN - 1) / MSM_TASK_LEN; }
-    } else {
-        for (uint32_t b = lo; b < hi; ++b) { uint32_t c = count[b]; sc += c; st += (c + MSM_TASK_LEN - 1) / MSM_TASK_LEN; }
-    }
-    s_cnt[tid] = sc; s_tsk[tid] = st;
-    __syncthreads();
-    for (uint32_t d = 1; d < nt; d <<= 1) {
-        uint32_t vc = 0, vt = 0;
-        if (tid >= d) { vc = s_cnt[tid - d]; vt = s_tsk[tid - d]; }
-        __syncthreads();
-        s_cnt[tid] += vc; s_tsk[tid] += vt;
-        __syncthreads();
-    }
-    uint32_t pc = s_cnt[tid] - sc, pt = s_tsk[tid] - st;   // exclusive prefix of this lane's chunk
+    for (int k = 0; k < NCLS; ++k) cls[k] = 0;
+    auto tally = [&](uint32_t c) {
+        sc += c; sf += c / MSM_TASK_LEN;
+        const uint32_t r = c % MSM_TASK_LEN;
+#pragma unroll
+        for (int k = 0; k < NCLS; ++k) cls[k] += (r == (uint32_t)(MSM_TASK_LEN - 1 - k)) ? 1u : 0u;
+    };
     if (fits) {
 #pragma unroll
-        for (uint32_t q = 0; q < CACHE; ++q) {
-            if (lo + q < hi) { start[lo + q] = pc; task_start[lo + q] = pt; }
-            pc += cached[q]; pt += (cached[q] + MSM_TASK_LEN - 1) / MSM_TASK_LEN;
-        }
+        for (uint32_t q = 0; q < CACHE; ++q) tally(cached[q]);          // entries beyond hi are 0 (r = 0: no class)
     } else {
-        for (uint32_t b = lo; b < hi; ++b) {
-            uint32_t c = count[b];
-            start[b] = pc; task_start[b] = pt;
-            pc += c; pt += (c + MSM_TASK_LEN - 1) / MSM_TASK_LEN;
-        }
+        for (uint32_t b = lo; b < hi; ++b) tally(count[b]);
     }
-    if (tid == nt - 1) { start[nb_total] = s_cnt[tid]; task_start[nb_total] = s_tsk[tid]; }
+    s_cnt[tid] = sc; s_ful[tid] = sf;
+#pragma unroll
+    for (int k = 0; k < NCLS; ++k) s_cls[k][tid] = cls[k];
+    __syncthreads();
+    for (uint32_t d = 1; d < nt; d <<= 1) {
+        uint32_t vc = 0, vf = 0, vk[NCLS];
+#pragma unroll
+        for (int k = 0; k < NCLS; ++k) vk[k] = 0;
+        if (tid >= d) {
+            vc = s_cnt[tid - d]; vf = s_ful[tid - d];
+#pragma unroll
+            for (int k = 0; k < NCLS; ++k) vk[k] = s_cls[k][tid - d];
+        }
+        __syncthreads();
+        s_cnt[tid] += vc; s_ful[tid] += vf;
+#pragma unroll
+        for (int k = 0; k < NCLS; ++k) s_cls[k][tid] += vk[k];
+        __syncthreads();
+    }
+    uint32_t crank[NCLS]; uint32_t run = 0;
+#pragma unroll
+    for (int k = 0; k < NCLS; ++k) {
+        crank[k] = run + (s_cls[k][tid] - cls[k]);           // class offset + exclusive prefix within the class
+        run += s_cls[k][nt - 1];
+    }
+    uint32_t pc = s_cnt[tid] - sc, pf = s_ful[tid] - sf;     // exclusive prefixes of this lane's chunk
+    auto emit = [&](uint32_t b, uint32_t c) {
+        start[b] = pc; full_start[b] = pf;
+        pc += c; pf += c / MSM_TASK_LEN;
+        const uint32_t r = c % MSM_TASK_LEN;
+        uint32_t pos = MSM_INVALID;
+        if (r) {
+#pragma unroll
+            for (int k = 0; k < NCLS; ++k) if (r == (uint32_t)(MSM_TASK_LEN - 1 - k)) { pos = crank[k]; crank[k] += 1; }
+            rem_bucket[pos] = b;
+        }
+        rem_pos[b] = pos;
+    };
+    if (fits) {
+#pragma unroll
+        for (uint32_t q = 0; q < CACHE; ++q) if (lo + q < hi) emit(lo + q, cached[q]);
+    } else {
+        for (uint32_t b = lo; b < hi; ++b) emit(b, count[b]);
+    }
+    if (tid == nt - 1) { start[nb_total] = s_cnt[tid]; full_start[nb_total] = s_ful[tid]; info[0] = s_ful[tid]; info[1] = run; }
 }
 
 // K1c: scatter point references into bucket order
@@ -153,29 +191,46 @@ __device__ __forceinline__ affine_t load_affine(const affine_t *__restrict__ p) 
     return r;
 }
 
-// K1d: level-1 accumulate.  One lane per task = <= L consecutive sorted entries of one bucket.
+// K1d: level-1 accumulate.  One lane per task.  Tasks [0, Ft) are the full tasks (exactly L consecutive sorted
+// entries of one bucket, bucket found by binary search in full_start); tasks [Ft, Ft+Rt) are the per-bucket remainders,
+// ordered by descending length.  A wave therefore runs lanes of (almost) identical trip count.
 template <int F>
 __global__ void __launch_bounds__(256)
-msm_accumulate_kernel(uint32_t nb_total, const uint32_t *__restrict__ start, const uint32_t *__restrict__ task_start,
+msm_accumulate_kernel(uint32_t nb_total, const uint32_t *__restrict__ start, const uint32_t *__restrict__ full_start,
+                      const uint32_t *__restrict__ rem_bucket, const uint32_t *__restrict__ info,
                       const uint32_t *__restrict__ sorted, const affine_t *__restrict__ points, fe_t one,
                       xyzz_t *__restrict__ partial) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t ntasks = task_start[nb_total];
-    if (t >= ntasks) return;
-    // bucket of task t: largest b with task_start[b] <= t  (task_start is non-decreasing)
-    uint32_t lo = 0, hi = nb_total;            // invariant: task_start[lo] <= t < task_start[hi]
-    while (hi - lo > 1) {
-        uint32_t mid = (lo + hi) >> 1;
-        if (task_start[mid] <= t) lo = mid; else hi = mid;
+    const uint32_t nfull = info[0], nrem = info[1];
+    if (t >= nfull + nrem) return;
+    uint32_t b, j;
+    if (t < nfull) {
+        uint32_t lo = 0, hi = nb_total;        // invariant: full_start[lo] <= t < full_start[hi]
+        while (hi - lo > 1) {
+            uint32_t mid = (lo + hi) >> 1;
+            if (full_start[mid] <= t) lo = mid; else hi = mid;
+        }
+        b = lo; j = t - full_start[b];
+    } else {
+        b = rem_bucket[t - nfull];
+        j = (start[b + 1] - start[b]) / MSM_TASK_LEN;        // after the bucket's full tasks
     }
-    const uint32_t b = lo;
-    const uint32_t j = t - task_start[b];
     const uint32_t beg = start[b] + j * MSM_TASK_LEN;
-    const uint32_t end = min(beg + MSM_TASK_LEN, start[b + 1]);
+    const uint32_t cnt = min((uint32_t)MSM_TASK_LEN, start[b + 1] - beg);
+    // all (<= L) references first, then software-pipelined gathers: the 64-B point of entry e+1 is in flight
+    // while the mixed add of entry e runs (a gather from the 64 MiB table is an L2 miss most of the time).
+    uint32_t refs[MSM_TASK_LEN];
+#pragma unroll
+    for (int e = 0; e < MSM_TASK_LEN; ++e) refs[e] = ((uint32_t)e < cnt) ? sorted[beg + e] : 0u;
     xyzz_t acc = xyzz_inf();
-    for (uint32_t e = beg; e < end; ++e) {
-        uint32_t ref = sorted[e];
-        affine_t p = load_affine(points + (ref & 0x7fffffffu));
+    affine_t nxt = load_affine(points + (refs[0] & 0x7fffffffu));
+#pragma unroll 1
+    for (uint32_t e = 0; e < cnt; ++e) {
+        affine_t p = nxt;
+        const uint32_t ref = refs[0];
+#pragma unroll
+        for (int q = 0; q + 1 < MSM_TASK_LEN; ++q) refs[q] = refs[q + 1];      // rotate (register moves, no indexing)
+        if (e + 1 < cnt) nxt = load_affine(points + (refs[0] & 0x7fffffffu));
         if (aff_is_inf(p)) continue;
         if (ref >> 31) p.y = fe_neg<F>(p.y);
         xyzz_add_affine<F>(acc, p.x, p.y, one);
@@ -183,15 +238,15 @@ msm_accumulate_kernel(uint32_t nb_total, const uint32_t *__restrict__ start, con
     partial[t] = acc;
 }
 
-// K1e: level-2: bucket b = sum of its task partials
+// K1e: level-2: bucket b = sum of its task partials (its full tasks are contiguous, plus at most one remainder task)
 template <int F>
 __global__ void __launch_bounds__(256)
-msm_bucket_sum_kernel(uint32_t nb_total, const uint32_t *__restrict__ task_start, const xyzz_t *__restrict__ partial,
-                      xyzz_t *__restrict__ buckets) {
+msm_bucket_sum_kernel(uint32_t nb_total, const uint32_t *__restrict__ full_start, const uint32_t *__restrict__ rem_pos,
+                      const uint32_t *__restrict__ info, const xyzz_t *__restrict__ partial, xyzz_t *__restrict__ buckets) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nb_total) return;
-    const uint32_t lo = task_start[b], hi = task_start[b + 1];
-    xyzz_t acc = xyzz_inf();
+    const uint32_t lo = full_start[b], hi = full_start[b + 1], rp = rem_pos[b];
+    xyzz_t acc = (rp != MSM_INVALID) ? partial[info[0] + rp] : xyzz_inf();
     for (uint32_t t = lo; t < hi; ++t) xyzz_add<F>(acc, partial[t]);
     buckets[b] = acc;
 }
@@ -231,75 +286,85 @@ template <int F> __device__ __forceinline__ xyzz_t wave_weighted_sum(xyzz_t v, x
     return wave_sum<F>(v, width);
 }
 
-// K1f: level A of the bucket reduction: one wave per 64 consecutive buckets of one set.
-//   out_r[g] = sum_l B[64g+l],  out_ws[g] = sum_l l * B[64g+l]
-template <int F>
-__global__ void __launch_bounds__(64)
-msm_reduce_a_kernel(uint32_t nb_total, const xyzz_t *__restrict__ buckets, xyzz_t *__restrict__ out_r,
-                    xyzz_t *__restrict__ out_ws) {
-    const uint32_t g = blockIdx.x, lane = threadIdx.x;
-    const uint32_t b = g * 64 + lane;
-    xyzz_t v = (b < nb_total) ? buckets[b] : xyzz_inf();
-    xyzz_t sum;
-    xyzz_t ws = wave_weighted_sum<F>(v, sum);
-    if (lane == 0) { out_r[g] = sum; out_ws[g] = ws; }
-}
+// ---------------------------------------------------------------- bucket reduction  sum_b (b+1) * B_b
+// 2-D scheme: view a bucket set as R rows x C columns (b = r*C + c, C = 128).  Then
+//     sum_b (b+1) B_b = Tot + C * sum_r r*Row_r + sum_c c*Col_c,    Row_r = sum_c B[r][c], Col_c = sum_r B[r][c], Tot = sum_r Row_r
+// K1f computes all row and column sums as PLAIN sums (each lane adds 8 buckets serially, then a short shuffle tree):
+// 2 adds per bucket in total and ~70 % of the add slots useful, against 16 % for a per-wave log-depth weighted
+// reduction.  K1g then does the two small weighted sums (R <= 256 rows, 128 columns) with wave suffix-scans.
+struct SegSum {            // one family of segments (rows or columns)
+    uint32_t nseg;         // segments in total (all sets)
+    uint32_t per_set;      // segments per bucket set
+    uint32_t len;          // elements per segment
+    uint32_t seg_stride;   // distance between first elements of consecutive segments of one set
+    uint32_t elem_stride;  // distance between consecutive elements of a segment
+    uint32_t lanes;        // lanes cooperating on one segment (power of two, <= 64)
+};
+static constexpr int SEG_CHUNK = 8;
 
-// K1g: level B.  Block (v, set) = super-group v (64 consecutive level-A groups) of one bucket set; two waves:
-//   wave 0:  R'_v = sum_u R_{64v+u},  WS'_v = sum_u u * R_{64v+u}        wave 1:  P'_v = sum_u WS_{64v+u}
 template <int F>
-__global__ void __launch_bounds__(128)
-msm_reduce_b_kernel(uint32_t groups, uint32_t nsuper, const xyzz_t *__restrict__ in_r, const xyzz_t *__restrict__ in_ws,
-                    xyzz_t *__restrict__ out_r, xyzz_t *__restrict__ out_w, xyzz_t *__restrict__ out_p) {
-    const uint32_t v = blockIdx.x, set = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t g = v * 64 + lane;
-    const size_t base = (size_t)set * groups;
-    if (wave == 0) {
-        xyzz_t rv = (g < groups) ? in_r[base + g] : xyzz_inf();
-        xyzz_t sum;
-        xyzz_t wsum = wave_weighted_sum<F>(rv, sum);
-        if (lane == 0) { out_r[(size_t)set * nsuper + v] = sum; out_w[(size_t)set * nsuper + v] = wsum; }
-    } else {
-        xyzz_t pv = (g < groups) ? in_ws[base + g] : xyzz_inf();
-        xyzz_t psum = wave_sum<F>(pv);
-        if (lane == 0) out_p[(size_t)set * nsuper + v] = psum;
+__global__ void __launch_bounds__(256)
+msm_segsum_kernel(uint32_t nb_per_set, SegSum rows, SegSum cols, const xyzz_t *__restrict__ buckets,
+                  xyzz_t *__restrict__ out_rows, xyzz_t *__restrict__ out_cols) {
+    const bool is_col = blockIdx.y != 0;
+    const SegSum sg = is_col ? cols : rows;
+    xyzz_t *__restrict__ out = is_col ? out_cols : out_rows;
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t seg = gid / sg.lanes, sub = gid % sg.lanes;
+    const bool live = seg < sg.nseg;
+    xyzz_t acc = xyzz_inf();
+    if (live) {
+        const size_t base = (size_t)(seg / sg.per_set) * nb_per_set + (size_t)(seg % sg.per_set) * sg.seg_stride;
+        const uint32_t per_lane = (sg.len + sg.lanes - 1) / sg.lanes;
+        const uint32_t e0 = sub * per_lane, e1 = min(e0 + per_lane, sg.len);
+        for (uint32_t e = e0; e < e1; ++e) xyzz_add<F>(acc, buckets[base + (size_t)e * sg.elem_stride]);
     }
+#pragma unroll 1
+    for (uint32_t d = sg.lanes >> 1; d >= 1; d >>= 1) {      // whole wave executes the shuffles; groups never straddle a wave
+        xyzz_t o = shfl_down_xyzz(acc, (int)d);
+        if (sub + d < sg.lanes) xyzz_add<F>(acc, o);
+    }
+    if (live && sub == 0) out[seg] = acc;
 }
 
-// K1g': level C.  One block per bucket set over its nsuper (<= 64) super-groups; three waves work concurrently:
-//   set total = sum_b (b+1) B_b = P + Rall + 64 * ( sum_v WS'_v + 64 * sum_v v * R'_v )
+// K1g: one block of 6 waves per bucket set.  Waves 0-3: weighted sum over the (<= 256) rows; waves 4-5: over the
+// (<= 128) columns; then three lanes combine concurrently.
 template <int F>
-__global__ void __launch_bounds__(192)
-msm_reduce_c_kernel(uint32_t nsuper, const xyzz_t *__restrict__ in_r, const xyzz_t *__restrict__ in_w,
-                    const xyzz_t *__restrict__ in_p, xyzz_t *__restrict__ set_total) {
+__global__ void __launch_bounds__(384)
+msm_reduce2d_kernel(uint32_t R, uint32_t C, uint32_t log2C, const xyzz_t *__restrict__ rows, const xyzz_t *__restrict__ cols,
+                    xyzz_t *__restrict__ set_total) {
     const uint32_t set = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    __shared__ xyzz_t sh_vw, sh_rall, sh_ws, sh_p;
-    int width = 1; while (width < (int)nsuper) width <<= 1;
-    const size_t base = (size_t)set * nsuper;
-    if (wave == 0) {
-        xyzz_t rv = (lane < nsuper) ? in_r[base + lane] : xyzz_inf();
-        xyzz_t rall;
-        xyzz_t vw = wave_weighted_sum<F>(rv, rall, width);
-        if (lane == 0) { sh_vw = vw; sh_rall = rall; }
-    } else if (wave == 1) {
-        xyzz_t wv = (lane < nsuper) ? in_w[base + lane] : xyzz_inf();
-        xyzz_t s = wave_sum<F>(wv, width);
-        if (lane == 0) sh_ws = s;
-    } else {
-        xyzz_t pv = (lane < nsuper) ? in_p[base + lane] : xyzz_inf();
-        xyzz_t s = wave_sum<F>(pv, width);
-        if (lane == 0) sh_p = s;
+    __shared__ xyzz_t sh_s[6], sh_w[6], sh_colw, sh_tot;
+    {
+        xyzz_t v = xyzz_inf();
+        if (wave < 4) { uint32_t r = wave * 64 + lane; if (r < R) v = rows[(size_t)set * R + r]; }
+        else { uint32_t c = (wave - 4) * 64 + lane; if (c < C) v = cols[(size_t)set * C + c]; }
+        const bool needed = (wave < 4) ? (wave * 64 < R) : ((wave - 4) * 64 < C);
+        xyzz_t sum = xyzz_inf(), ws = xyzz_inf();
+        if (needed) ws = wave_weighted_sum<F>(v, sum);        // wave-uniform branch
+        if (lane == 0) { sh_s[wave] = sum; sh_w[wave] = ws; }
     }
     __syncthreads();
+    xyzz_t t = xyzz_inf();
     if (threadIdx.x == 0) {
-        xyzz_t t = sh_vw;
-        for (int i = 0; i < 6; ++i) t = xyzz_dbl<F>(t);   // 64 * sum_v v R'_v
-        xyzz_add<F>(t, sh_ws);                            // = sum_g g R_g
-        for (int i = 0; i < 6; ++i) t = xyzz_dbl<F>(t);   // * 64
-        xyzz_add<F>(t, sh_p);
-        xyzz_add<F>(t, sh_rall);
-        set_total[set] = t;
+        // sum_r r*Row_r = W0+W1+W2+W3 + 64*(S1 + 2 S2 + 3 S3)
+        xyzz_t a = sh_s[1]; xyzz_add<F>(a, sh_s[3]);
+        xyzz_t b = sh_s[2]; xyzz_add<F>(b, sh_s[3]);
+        t = xyzz_dbl<F>(b); xyzz_add<F>(t, a);
+        for (int i = 0; i < 6; ++i) t = xyzz_dbl<F>(t);
+        xyzz_add<F>(t, sh_w[0]); xyzz_add<F>(t, sh_w[1]); xyzz_add<F>(t, sh_w[2]); xyzz_add<F>(t, sh_w[3]);
+        for (uint32_t i = 0; i < log2C; ++i) t = xyzz_dbl<F>(t);          // * C
+    } else if (threadIdx.x == 64) {
+        xyzz_t u = sh_s[5];
+        for (int i = 0; i < 6; ++i) u = xyzz_dbl<F>(u);
+        xyzz_add<F>(u, sh_w[4]); xyzz_add<F>(u, sh_w[5]);
+        sh_colw = u;                                                       // sum_c c*Col_c
+    } else if (threadIdx.x == 128) {
+        xyzz_t u = sh_s[0]; xyzz_add<F>(u, sh_s[1]); xyzz_add<F>(u, sh_s[2]); xyzz_add<F>(u, sh_s[3]);
+        sh_tot = u;                                                        // Tot
     }
+    __syncthreads();
+    if (threadIdx.x == 0) { xyzz_add<F>(t, sh_colw); xyzz_add<F>(t, sh_tot); set_total[set] = t; }
 }
 
 // K1h: Horner over bucket sets (variable-base), then normalise to affine (Montgomery) + canonical words.
