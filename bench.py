@@ -35,6 +35,16 @@ N_BASES = 1 << K_ROUNDS
 MSM_ALGORITHMIC_BYTES = N_BASES * (64 + 32) + 96      # 6 291 552 B for n = 2^16
 HBM_PEAK_GBPS = 8000.0                                # MI355X_MICROARCH.md: 8 TB/s spec
 PS_ACCUMULATE_BIT = 1 << 3
+# HBM-side bytes per launch of the dominant kernel from the rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, KiB * 1024;
+# profiles/r01b_rocprof.md section 2).  14x the algorithmic bytes by design: the fixed-base window tables gather 16
+# precomputed 64-B points per base and write 128-B XYZZ partials.
+ACCUMULATE_TRAFFIC_BYTES = 88_290_000
+# VALU side of the roofline (the path is integer-multiply bound): one Montgomery product is 88
+# v_mad_u64_u32 (8 cycles per wave64 instruction, profiles/r01_microbench_valu.jsonl) -> issue floor 704 cycles.
+MODMUL_ISSUE_FLOOR_CYCLES = 88 * 8
+MIXED_ADDS_PER_MSM = 16 * N_BASES * (1 - 2 ** -16)    # one per non-zero signed 16-bit digit
+MODMUL_PER_MIXED_ADD = 10                                # XYZZ madd-2008-s: 8M + 2S
+CHIP_SIMDS, CLOCK_HZ = 1024, 2.4e9
 
 
 def make_instances(ctx, count: int, seed: int):
@@ -164,10 +174,18 @@ def main():
                                    "vesta.srs + compare), bit-exact vs CPU oracle", "curve": "vesta", "n_bases": N_BASES,
                        "proofs_per_step": B, "pipeline_lanes": args.pipeline, "sharding": f"proof-level, {args.gpus} rank(s), no collective"},
             "roofline": {"bound": "hbm", "kernel": "msm_accumulate_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": None,
+                         "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": ACCUMULATE_TRAFFIC_BYTES,
+                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r01b_rocprof.md",
+                         "traffic_GBps": ACCUMULATE_TRAFFIC_BYTES / kern_s / 1e9 if launches else None,
                          "algorithmic_bytes_per_launch": MSM_ALGORITHMIC_BYTES, "avg_launch_us": kern_s * 1e6,
                          "note": "integer-VALU-bound path (SURVEY.md 8d): HBM fraction reported as the metric demands"},
         }
+        if launches:
+            peak = CHIP_SIMDS * 64 * CLOCK_HZ / MODMUL_ISSUE_FLOOR_CYCLES          # modmul/s if only the 88 mads issued
+            got = MIXED_ADDS_PER_MSM * MODMUL_PER_MIXED_ADD / kern_s
+            out["roofline_valu"] = {"bound": "int32 multiply issue (v_mad_u64_u32)", "achieved": got / 1e9, "peak": peak / 1e9,
+                                    "unit": "G modmul/s", "frac": got / peak,
+                                    "note": "same kernel, same launches; durations overlap with other lanes' kernels when pipeline_lanes > 1"}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pre[0], sgs[0])
         print(json.dumps(out), flush=True)
