@@ -152,6 +152,16 @@ def main():
     prof = ctx.prof_read()
     ctx.prof_enable(0)
     assert int(d_verdict.item()) == 1, "timed-region verdict must be ACCEPT"
+    # the same kernel with nothing else on the GPU: one lane, HIP events on that lane's stream
+    ctx.set_pipeline(1)
+    for _ in range(4):
+        step()
+    ctx.synchronize()
+    ctx.prof_enable(PS_ACCUMULATE_BIT)
+    for _ in range(32):
+        step()
+    prof_iso = ctx.prof_read()
+    ctx.prof_enable(0)
 
     if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -159,7 +169,9 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
-        launches, total_ms = prof.get("msm_accumulate", [0, 0.0])
+        launches_o, total_ms_o = prof.get("msm_accumulate", [0, 0.0])
+        overlapped_us = (total_ms_o / launches_o) * 1e3 if launches_o else None
+        launches, total_ms = prof_iso.get("msm_accumulate", [0, 0.0])
         kern_s = (total_ms / launches) * 1e-3 if launches else float("nan")
         achieved = MSM_ALGORITHMIC_BYTES / kern_s / 1e9 if launches else None
         out = {
@@ -178,14 +190,17 @@ def main():
                          "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r01b_rocprof.md",
                          "traffic_GBps": ACCUMULATE_TRAFFIC_BYTES / kern_s / 1e9 if launches else None,
                          "algorithmic_bytes_per_launch": MSM_ALGORITHMIC_BYTES, "avg_launch_us": kern_s * 1e6,
-                         "note": "integer-VALU-bound path (SURVEY.md 8d): HBM fraction reported as the metric demands"},
+                         "avg_launch_us_in_timed_region": overlapped_us,
+                         "note": "avg_launch_us: HIP events on the lane stream, 32 launches with nothing else on the GPU, right after the "
+                                 "timed region; in the timed region the launches of 16 lanes overlap and time-share the CUs (second figure). "
+                                 "Integer-VALU-bound path (SURVEY.md 8d): HBM fraction reported as the metric demands, see roofline_valu"},
         }
         if launches:
             peak = CHIP_SIMDS * 64 * CLOCK_HZ / MODMUL_ISSUE_FLOOR_CYCLES          # modmul/s if only the 88 mads issued
             got = MIXED_ADDS_PER_MSM * MODMUL_PER_MIXED_ADD / kern_s
             out["roofline_valu"] = {"bound": "int32 multiply issue (v_mad_u64_u32)", "achieved": got / 1e9, "peak": peak / 1e9,
                                     "unit": "G modmul/s", "frac": got / peak,
-                                    "note": "same kernel, same launches; durations overlap with other lanes' kernels when pipeline_lanes > 1"}
+                                    "note": "same isolated launches as roofline"}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(pre[0], sgs[0])
         print(json.dumps(out), flush=True)

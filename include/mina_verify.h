@@ -133,6 +133,16 @@ int mina_poseidon_hash(mina_ctx *ctx, int field, size_t n, size_t len, const uin
  * curve whose scalar field is `field`. */
 int mina_challenge_to_field(mina_ctx *ctx, int field, size_t n, const uint8_t *chal128, uint8_t *out);
 
+/* ---- a16: Merkle-path fold of Proof-of-Account (core/src/proof/account_proof.rs:9-14,30-35; README.md:358-362) ------
+ * roots[i] = fold of leaves[i] along its path: node <- H_h(node, sib) for dirs = 0 (`MerkleNode::Left(sib)`: the node is
+ * the left input) or H_h(sib, node) for dirs = 1 (`MerkleNode::Right(sib)`), h = 0..depth-1, with the per-height salt
+ * "MinaMklTree%03d" (mina `hash_with_kimchi`).  depth <= 64.  Runs 4 lanes per path (cooperative Poseidon). */
+int mina_merkle_roots(mina_ctx *ctx, int field, size_t n, uint32_t depth, const uint8_t *leaves /* n*32 */,
+                      const uint8_t *siblings /* n*depth*32 */, const uint8_t *dirs /* n*depth */, uint8_t *roots_out /* n*32 */);
+/* verdicts[i] = (root of path i == expected_roots[i]) -- the ledger-hash comparison of verify_account_inclusion */
+int mina_merkle_verify_batch(mina_ctx *ctx, int field, size_t n, uint32_t depth, const uint8_t *leaves, const uint8_t *siblings,
+                             const uint8_t *dirs, const uint8_t *expected_roots, uint8_t *verdicts);
+
 /* ---- K4: group map (a14) --------------------------------------------------------------------- */
 int mina_to_group(mina_ctx *ctx, int curve, size_t n, const uint8_t *t, uint8_t *out_affine);
 

@@ -93,6 +93,7 @@ extern "C" int mina_poseidon_set_params(mina_ctx *c, int field, const uint8_t *p
     HIPC(hipMemcpyAsync(c->pparams[field].p, &pp, sizeof pp, hipMemcpyHostToDevice, c->L->stream));
     HIPC(hipStreamSynchronize(c->L->stream));
     c->have_pparams[field] = true;
+    c->merkle_depth[field] = 0;
     return MINA_OK;
 }
 
@@ -134,7 +135,12 @@ extern "C" int mina_poseidon_hash(mina_ctx *c, int field, size_t n, size_t len, 
     int rc;
     if ((rc = h2d(c, c->L->tmp_a, inputs, n * len * 32))) return rc;
     if ((rc = c->L->tmp_c.ensure(n * 32))) return rc;
-    DISPATCH_FIELD(field, { poseidon_hash_kernel<F_><<<cdiv(n, 256), 256, 0, c->L->stream>>>((uint32_t)n, (uint32_t)len, c->fk[F_], c->pparams[field].as<PoseidonParams>(), c->L->tmp_a.as<uint32_t>(), c->L->tmp_c.as<uint32_t>()); });
+    // below ~64k sponges the chip is not full with one lane per sponge: use the 4-lane cooperative form (3x shorter chain)
+    if (n < 65536) {
+        DISPATCH_FIELD(field, { poseidon_hash_quad_kernel<F_><<<cdiv(n * 4, 256), 256, 0, c->L->stream>>>((uint32_t)n, (uint32_t)len, c->fk[F_], c->pparams[field].as<PoseidonParams>(), c->L->tmp_a.as<uint32_t>(), c->L->tmp_c.as<uint32_t>()); });
+    } else {
+        DISPATCH_FIELD(field, { poseidon_hash_kernel<F_><<<cdiv(n, 256), 256, 0, c->L->stream>>>((uint32_t)n, (uint32_t)len, c->fk[F_], c->pparams[field].as<PoseidonParams>(), c->L->tmp_a.as<uint32_t>(), c->L->tmp_c.as<uint32_t>()); });
+    }
     return d2h_sync(c, out, c->L->tmp_c, n * 32);
 }
 
@@ -149,4 +155,58 @@ extern "C" int mina_challenge_to_field(mina_ctx *c, int field, size_t n, const u
     if ((rc = c->L->tmp_c.ensure(n * 32))) return rc;
     DISPATCH_FIELD(field, { challenge_to_field_kernel<F_><<<cdiv(n, 64), 64, 0, c->L->stream>>>((uint32_t)n, c->fk[F_], c->L->tmp_a.as<uint32_t>(), c->L->tmp_c.as<uint32_t>()); });
     return d2h_sync(c, out, c->L->tmp_c, n * 32);
+}
+
+// ------------------------------------------------------------------------------------------------
+// a16: Merkle-path fold (Proof-of-Account)
+static int merkle_prepare_salts(mina_ctx *c, int field, uint32_t depth) {
+    if (c->merkle_depth[field] >= depth) return MINA_OK;
+    // prefix element of height h: the 20 bytes "MinaMklTree%03d" padded with '*', read as a little-endian integer
+    std::vector<uint8_t> pre((size_t)depth * 32, 0);
+    for (uint32_t h = 0; h < depth; ++h) {
+        char buf[32]; snprintf(buf, sizeof buf, "MinaMklTree%03u", h);
+        size_t len = strlen(buf);
+        for (size_t i = 0; i < 20; ++i) pre[(size_t)h * 32 + i] = (uint8_t)(i < len ? buf[i] : '*');
+    }
+    int rc;
+    if ((rc = c->merkle_salts[field].ensure((size_t)depth * 3 * sizeof(fe_t)))) return rc;
+    if ((rc = h2d(c, c->L->tmp_d, pre.data(), pre.size()))) return rc;
+    DISPATCH_FIELD(field, { merkle_salt_kernel<F_><<<cdiv(depth, 64), 64, 0, c->L->stream>>>(depth, c->fk[F_], c->pparams[field].as<PoseidonParams>(), c->L->tmp_d.as<uint32_t>(), c->merkle_salts[field].as<fe_t>()); });
+    HIPC(hipGetLastError());
+    HIPC(hipStreamSynchronize(c->L->stream));
+    c->merkle_depth[field] = depth;
+    return MINA_OK;
+}
+
+extern "C" int mina_merkle_roots(mina_ctx *c, int field, size_t n, uint32_t depth, const uint8_t *leaves, const uint8_t *siblings,
+                                 const uint8_t *dirs, uint8_t *roots_out) {
+    if (!c || (n && (!leaves || !roots_out)) || (n && depth && (!siblings || !dirs))) return fail(MINA_ERR_ARG, "null argument");
+    if (bad_field(field)) return fail(MINA_ERR_ARG, "bad field");
+    if (depth > 64) return fail(MINA_ERR_ARG, "depth must be <= 64");
+    if (n > (1u << 24)) return fail(MINA_ERR_ARG, "n too large");
+    if (!c->have_pparams[field]) return fail(MINA_ERR_STATE, "Poseidon constants not installed for this field");
+    if (n == 0) return MINA_OK;
+    HIPC(hipSetDevice(c->device));
+    c->use_lane0();
+    int rc;
+    if (depth && (rc = merkle_prepare_salts(c, field, depth))) return rc;
+    if ((rc = h2d(c, c->L->tmp_a, leaves, n * 32))) return rc;
+    if ((rc = h2d(c, c->L->tmp_b, siblings, n * depth * 32))) return rc;
+    if ((rc = h2d(c, c->L->tmp_d, dirs, n * depth))) return rc;
+    if ((rc = c->L->tmp_c.ensure(n * 32))) return rc;
+    DISPATCH_FIELD(field, {
+        merkle_fold_quad_kernel<F_><<<cdiv(n * 4, 256), 256, 0, c->L->stream>>>((uint32_t)n, depth, c->fk[F_], c->pparams[field].as<PoseidonParams>(),
+            c->merkle_salts[field].as<fe_t>(), c->L->tmp_a.as<uint32_t>(), c->L->tmp_b.as<uint32_t>(), c->L->tmp_d.as<uint8_t>(), c->L->tmp_c.as<uint32_t>());
+    });
+    return d2h_sync(c, roots_out, c->L->tmp_c, n * 32);
+}
+
+extern "C" int mina_merkle_verify_batch(mina_ctx *c, int field, size_t n, uint32_t depth, const uint8_t *leaves, const uint8_t *siblings,
+                                        const uint8_t *dirs, const uint8_t *expected_roots, uint8_t *verdicts) {
+    if (!expected_roots || !verdicts) return fail(MINA_ERR_ARG, "null argument");
+    std::vector<uint8_t> roots(n * 32);
+    int rc = mina_merkle_roots(c, field, n, depth, leaves, siblings, dirs, roots.data());
+    if (rc) return rc;
+    for (size_t i = 0; i < n; ++i) verdicts[i] = memcmp(&roots[i * 32], expected_roots + i * 32, 32) == 0 ? 1 : 0;
+    return MINA_OK;
 }

@@ -86,6 +86,7 @@ struct mina_ctx {
     FieldK fk[2];
     SrsState srs[2];
     DevBuf pparams[2]; bool have_pparams[2] = {false, false};
+    DevBuf merkle_salts[2]; uint32_t merkle_depth[2] = {0, 0};   // salted initial states of the Merkle hash per height
     void use_lane0() { L = &lanes[0]; }
     void next_lane() { L = &lanes[rr++ % (unsigned)nlanes]; }
 };

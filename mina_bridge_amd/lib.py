@@ -26,7 +26,7 @@ EXPORTS = [
     "mina_msm", "mina_msm_srs", "mina_msm_srs_range", "mina_msm_srs_dev",
     "mina_b_poly", "mina_b_poly_coefficients", "mina_b_poly_fold", "mina_b_poly_fold_dev",
     "mina_poseidon_set_params", "mina_poseidon_permute", "mina_poseidon_permute_dev", "mina_poseidon_hash",
-    "mina_challenge_to_field", "mina_to_group",
+    "mina_challenge_to_field", "mina_to_group", "mina_merkle_roots", "mina_merkle_verify_batch",
     "mina_field_mul", "mina_field_inv", "mina_field_sqrt",
     "mina_accumulator_check_batch", "mina_accumulator_check_dev", "mina_ipa_batch_check",
 ]
@@ -248,6 +248,24 @@ class MinaContext:
         n = ch.size // 16
         out = np.empty((n, 32), np.uint8)
         self._ck(self._lib.mina_challenge_to_field(self._h, field, ctypes.c_size_t(n), _p(ch), _p(out)), "mina_challenge_to_field")
+        return out
+
+    # -- a16
+    def merkle_roots(self, field: int, leaves, siblings, dirs, depth: int) -> np.ndarray:
+        leaves, siblings, dirs = _u8(leaves), _u8(siblings), _u8(dirs)
+        n = leaves.size // 32
+        assert siblings.size == n * depth * 32 and dirs.size == n * depth
+        out = np.empty((n, 32), np.uint8)
+        self._ck(self._lib.mina_merkle_roots(self._h, field, ctypes.c_size_t(n), ctypes.c_uint32(depth), _p(leaves), _p(siblings), _p(dirs), _p(out)),
+                 "mina_merkle_roots")
+        return out
+
+    def merkle_verify_batch(self, field: int, leaves, siblings, dirs, depth: int, expected_roots) -> np.ndarray:
+        leaves, siblings, dirs, exp = _u8(leaves), _u8(siblings), _u8(dirs), _u8(expected_roots)
+        n = leaves.size // 32
+        out = np.empty(n, np.uint8)
+        self._ck(self._lib.mina_merkle_verify_batch(self._h, field, ctypes.c_size_t(n), ctypes.c_uint32(depth), _p(leaves), _p(siblings), _p(dirs),
+                                                    _p(exp), _p(out)), "mina_merkle_verify_batch")
         return out
 
     # -- K4

@@ -413,3 +413,31 @@ class Sponge:
         r = self.state[self.count]
         self.count += 1
         return r
+
+
+# --------------------------------------------------------------------------
+# a16: Merkle-path fold of Proof-of-Account (core/src/proof/account_proof.rs:9-14; README.md:358-362).
+# mina `hash_with_kimchi(MERKLE_PARAM[height], [left, right])`: the initial state of height h is the state after
+# absorbing the prefix element ("MinaMklTree%03d" padded to 20 bytes with '*', little-endian integer) and permuting.
+# [UPSTREAM-RECALL]: un-vendored (mina-tree / mina-hasher); direction convention as in mina's Merkle_path.implied_root:
+# `Left h`: the running node is the LEFT input and h the right one.
+# --------------------------------------------------------------------------
+def merkle_prefix_field(height: int) -> int:
+    s = ("MinaMklTree%03d" % height).encode()
+    s = s + b"*" * (20 - len(s))
+    return int.from_bytes(s, "little")
+
+
+def merkle_salt(height: int, pp: PoseidonParams):
+    return poseidon_permute([merkle_prefix_field(height) % pp.m, 0, 0], pp)
+
+
+def merkle_root(leaf: int, path, pp: PoseidonParams):
+    """path: list of (dir, sibling) with dir 0 = MerkleNode::Left(sibling), 1 = MerkleNode::Right(sibling)"""
+    node = leaf
+    for h, (d, sib) in enumerate(path):
+        st = merkle_salt(h, pp)
+        l, r = (node, sib) if d == 0 else (sib, node)
+        st = [(st[0] + l) % pp.m, (st[1] + r) % pp.m, st[2]]
+        node = poseidon_permute(st, pp)[0]
+    return node
