@@ -44,7 +44,8 @@ static int run_msm(mina_ctx *c, const MsmShape &sh, const uint32_t *d_scalars, c
     { ProfScope ps_(c, PS_DIGITS); msm_digits_kernel<<<cdiv(entries, 256), 256, 0, st>>>(sh, d_scalars, w.count.as<uint32_t>(), w.ekey.as<uint32_t>(),
                                                        w.eval.as<uint32_t>(), w.eoff.as<uint32_t>()); }
     { ProfScope ps_(c, PS_SCAN); msm_scan_kernel<<<1, 1024, 0, st>>>(nb_total, w.count.as<uint32_t>(), w.start.as<uint32_t>(), w.task_start.as<uint32_t>(),
-                                                                   w.rem_pos.as<uint32_t>(), w.rem_bucket.as<uint32_t>(), w.info.as<uint32_t>()); }
+                                                                   w.rem_pos.as<uint32_t>(), w.info.as<uint32_t>());
+                                 msm_rem_invert_kernel<<<cdiv(nb_total, 256), 256, 0, st>>>(nb_total, w.rem_pos.as<uint32_t>(), w.rem_bucket.as<uint32_t>()); }
     { ProfScope ps_(c, PS_SCATTER); msm_scatter_kernel<<<cdiv(entries, 256), 256, 0, st>>>(entries, w.ekey.as<uint32_t>(), w.eval.as<uint32_t>(),
                                                            w.eoff.as<uint32_t>(), w.start.as<uint32_t>(), w.sorted.as<uint32_t>()); }
     { ProfScope ps_(c, PS_ACCUMULATE); msm_accumulate_kernel<F><<<cdiv(max_tasks, 256), 256, 0, st>>>(nb_total, w.start.as<uint32_t>(), w.task_start.as<uint32_t>(),

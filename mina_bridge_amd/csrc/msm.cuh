@@ -78,95 +78,146 @@ static __global__ void msm_digits_kernel(MsmShape sh, const uint32_t *__restrict
     eoff[e] = atomicAdd(&count[bucket], 1u);
 }
 
-// K1b: single-block scan (1024 lanes, each owning a contiguous chunk of buckets read once with 16-byte loads).
-// Produces, per bucket b with cnt entries (f = cnt / L full tasks, r = cnt % L):
+// K1b: single-block scan.  Produces, per bucket b with cnt entries (f = cnt / L full tasks, r = cnt % L):
 //   start[b]       exclusive prefix of cnt                       (start[nb] = total entries)
 //   full_start[b]  exclusive prefix of f                         (full_start[nb] = Ft, number of full tasks)
 //   rem_pos[b]     index of b's remainder task among all remainder tasks, ordered by DESCENDING r so that the
 //                  lanes of a wave run the same number of adds; MSM_INVALID if r == 0
-//   rem_bucket[q]  inverse map; info[0] = Ft, info[1] = number of remainder tasks
+//   info[0] = Ft, info[1] = number of remainder tasks          (rem_bucket = inverse of rem_pos: K1b' below)
+// Memory pattern: the bucket array is walked in rows of 4096 (1024 lanes x uint4), so every global load and store is a
+// fully coalesced 16-byte-per-lane access (a lane-contiguous chunking made each store instruction touch 64 lines).
+// Pass 1 totals the remainder classes (their offsets are needed before ranks can be assigned), pass 2 emits.
+template <int NV>
+__device__ __forceinline__ void block_exclusive_scan(uint32_t (&v)[NV], uint32_t (&total)[NV], uint32_t (*s_tot)[16]) {
+    // in: per-lane values; out: v = exclusive prefix over the block (lane order), total = block totals
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    uint32_t own[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) own[k] = v[k];
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) { uint32_t t = __shfl_up(v[k], d, 64); if ((int)lane >= d) v[k] += t; }
+    }
+    __syncthreads();                                          // s_tot may still be read from the previous call
+    if (lane == 63) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) s_tot[k][wave] = v[k];
+    }
+    __syncthreads();
+    uint32_t before[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) { before[k] = 0; total[k] = 0; }
+    for (uint32_t w = 0; w < nwaves; ++w) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) { uint32_t t = s_tot[k][w]; total[k] += t; if (w < wave) before[k] += t; }
+    }
+#pragma unroll
+    for (int k = 0; k < NV; ++k) v[k] = before[k] + v[k] - own[k];
+}
+
 static __global__ void __launch_bounds__(1024)
 msm_scan_kernel(uint32_t nb_total, const uint32_t *__restrict__ count, uint32_t *__restrict__ start /* nb_total+1 */,
                 uint32_t *__restrict__ full_start /* nb_total+1 */, uint32_t *__restrict__ rem_pos /* nb_total */,
-                uint32_t *__restrict__ rem_bucket /* nb_total */, uint32_t *__restrict__ info /* 2 */) {
+                uint32_t *__restrict__ info /* 2 */) {
     constexpr int NCLS = MSM_TASK_LEN - 1;                     // class kappa = L-1-r  (r = L-1 .. 1)
-    __shared__ uint32_t s_cnt[1024], s_ful[1024], s_cls[NCLS][1024];
-    const uint32_t tid = threadIdx.x, nt = blockDim.x;
-    uint32_t per = (nb_total + nt - 1) / nt;
-    per = (per + 3u) & ~3u;                                   // multiple of 4 -> uint4 loads stay aligned
-    const uint32_t lo = min(tid * per, nb_total), hi = min(lo + per, nb_total);
-    constexpr uint32_t CACHE = 32;
-    uint32_t cached[CACHE];
-    const bool fits = per <= CACHE;
-    if (fits) {
+    constexpr int NV = 2 + NCLS;
+    __shared__ uint32_t s_tot[NV][16];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t row_elems = blockDim.x * 4;
+    const uint32_t nrows = (nb_total + row_elems - 1) / row_elems;       // nb_total is a multiple of 4 (power of two >= 128)
+    // all rows of a <= 32768-bucket problem are fetched up front (8 independent loads in flight: one memory latency
+    // instead of one per row and pass); larger problems re-read from L2
+    constexpr uint32_t ROWS_CACHED = 8;
+    uint4 rows_c[ROWS_CACHED];
 #pragma unroll
-        for (uint32_t q = 0; q < CACHE; q += 4) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (lo + q + 3 < hi) v = *reinterpret_cast<const uint4 *>(count + lo + q);
-            else { if (lo + q < hi) v.x = count[lo + q]; if (lo + q + 1 < hi) v.y = count[lo + q + 1]; if (lo + q + 2 < hi) v.z = count[lo + q + 2]; }
-            cached[q] = v.x; cached[q + 1] = v.y; cached[q + 2] = v.z; cached[q + 3] = v.w;
-        }
+    for (uint32_t r = 0; r < ROWS_CACHED; ++r) {
+        const uint32_t idx = r * row_elems + tid * 4;
+        rows_c[r] = (r < nrows && idx < nb_total) ? *reinterpret_cast<const uint4 *>(count + idx) : make_uint4(0, 0, 0, 0);
     }
-    uint32_t sc = 0, sf = 0, cls[NCLS];
+    auto load4 = [&](uint32_t row) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (row < ROWS_CACHED) {
 #pragma unroll
-    for (int k = 0; k < NCLS; ++k) cls[k] = 0;
-    auto tally = [&](uint32_t c) {
-        sc += c; sf += c / MSM_TASK_LEN;
-        const uint32_t r = c % MSM_TASK_LEN;
-#pragma unroll
-        for (int k = 0; k < NCLS; ++k) cls[k] += (r == (uint32_t)(MSM_TASK_LEN - 1 - k)) ? 1u : 0u;
+            for (uint32_t r = 0; r < ROWS_CACHED; ++r) if (r == row) v = rows_c[r];
+            return v;
+        }
+        const uint32_t idx = row * row_elems + tid * 4;
+        return (idx < nb_total) ? *reinterpret_cast<const uint4 *>(count + idx) : v;
     };
-    if (fits) {
+    // pass 1: class totals
+    uint32_t cls_tot[NV];
+    {
+        uint32_t v[NV];
 #pragma unroll
-        for (uint32_t q = 0; q < CACHE; ++q) tally(cached[q]);          // entries beyond hi are 0 (r = 0: no class)
-    } else {
-        for (uint32_t b = lo; b < hi; ++b) tally(count[b]);
-    }
-    s_cnt[tid] = sc; s_ful[tid] = sf;
+        for (int k = 0; k < NV; ++k) v[k] = 0;
+        for (uint32_t row = 0; row < nrows; ++row) {
+            const uint4 c4 = load4(row);
+            const uint32_t c[4] = {c4.x, c4.y, c4.z, c4.w};
 #pragma unroll
-    for (int k = 0; k < NCLS; ++k) s_cls[k][tid] = cls[k];
-    __syncthreads();
-    for (uint32_t d = 1; d < nt; d <<= 1) {
-        uint32_t vc = 0, vf = 0, vk[NCLS];
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t r = c[e] % MSM_TASK_LEN;
 #pragma unroll
-        for (int k = 0; k < NCLS; ++k) vk[k] = 0;
-        if (tid >= d) {
-            vc = s_cnt[tid - d]; vf = s_ful[tid - d];
-#pragma unroll
-            for (int k = 0; k < NCLS; ++k) vk[k] = s_cls[k][tid - d];
+                for (int k = 0; k < NCLS; ++k) v[2 + k] += (r == (uint32_t)(MSM_TASK_LEN - 1 - k)) ? 1u : 0u;
+            }
         }
-        __syncthreads();
-        s_cnt[tid] += vc; s_ful[tid] += vf;
-#pragma unroll
-        for (int k = 0; k < NCLS; ++k) s_cls[k][tid] += vk[k];
-        __syncthreads();
+        block_exclusive_scan<NV>(v, cls_tot, s_tot);
     }
-    uint32_t crank[NCLS]; uint32_t run = 0;
+    uint32_t carry[NV];                                       // running offsets: entries, full tasks, rank within each class
+    carry[0] = 0; carry[1] = 0;
+    {
+        uint32_t run = 0;
 #pragma unroll
-    for (int k = 0; k < NCLS; ++k) {
-        crank[k] = run + (s_cls[k][tid] - cls[k]);           // class offset + exclusive prefix within the class
-        run += s_cls[k][nt - 1];
+        for (int k = 0; k < NCLS; ++k) { carry[2 + k] = run; run += cls_tot[2 + k]; }
+        if (tid == 0) info[1] = run;
     }
-    uint32_t pc = s_cnt[tid] - sc, pf = s_ful[tid] - sf;     // exclusive prefixes of this lane's chunk
-    auto emit = [&](uint32_t b, uint32_t c) {
-        start[b] = pc; full_start[b] = pf;
-        pc += c; pf += c / MSM_TASK_LEN;
-        const uint32_t r = c % MSM_TASK_LEN;
-        uint32_t pos = MSM_INVALID;
-        if (r) {
+    // pass 2: emit
+    for (uint32_t row = 0; row < nrows; ++row) {
+        const uint4 c4 = load4(row);
+        const uint32_t c[4] = {c4.x, c4.y, c4.z, c4.w};
+        uint32_t v[NV], tot[NV];
 #pragma unroll
-            for (int k = 0; k < NCLS; ++k) if (r == (uint32_t)(MSM_TASK_LEN - 1 - k)) { pos = crank[k]; crank[k] += 1; }
-            rem_bucket[pos] = b;
+        for (int k = 0; k < NV; ++k) v[k] = 0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[0] += c[e]; v[1] += c[e] / MSM_TASK_LEN;
+            const uint32_t r = c[e] % MSM_TASK_LEN;
+#pragma unroll
+            for (int k = 0; k < NCLS; ++k) v[2 + k] += (r == (uint32_t)(MSM_TASK_LEN - 1 - k)) ? 1u : 0u;
         }
-        rem_pos[b] = pos;
-    };
-    if (fits) {
+        block_exclusive_scan<NV>(v, tot, s_tot);
+        uint32_t pc = carry[0] + v[0], pf = carry[1] + v[1], rk[NCLS];
 #pragma unroll
-        for (uint32_t q = 0; q < CACHE; ++q) if (lo + q < hi) emit(lo + q, cached[q]);
-    } else {
-        for (uint32_t b = lo; b < hi; ++b) emit(b, count[b]);
+        for (int k = 0; k < NCLS; ++k) rk[k] = carry[2 + k] + v[2 + k];
+        uint32_t o_start[4], o_full[4], o_rem[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            o_start[e] = pc; o_full[e] = pf;
+            pc += c[e]; pf += c[e] / MSM_TASK_LEN;
+            const uint32_t r = c[e] % MSM_TASK_LEN;
+            uint32_t pos = MSM_INVALID;
+#pragma unroll
+            for (int k = 0; k < NCLS; ++k) if (r == (uint32_t)(MSM_TASK_LEN - 1 - k)) { pos = rk[k]; rk[k] += 1; }
+            o_rem[e] = pos;
+        }
+        const uint32_t idx = row * row_elems + tid * 4;
+        if (idx < nb_total) {
+            *reinterpret_cast<uint4 *>(start + idx) = make_uint4(o_start[0], o_start[1], o_start[2], o_start[3]);
+            *reinterpret_cast<uint4 *>(full_start + idx) = make_uint4(o_full[0], o_full[1], o_full[2], o_full[3]);
+            *reinterpret_cast<uint4 *>(rem_pos + idx) = make_uint4(o_rem[0], o_rem[1], o_rem[2], o_rem[3]);
+        }
+#pragma unroll
+        for (int k = 0; k < NV; ++k) carry[k] += tot[k];
     }
-    if (tid == nt - 1) { start[nb_total] = s_cnt[tid]; full_start[nb_total] = s_ful[tid]; info[0] = s_ful[tid]; info[1] = run; }
+    if (tid == 0) { start[nb_total] = carry[0]; full_start[nb_total] = carry[1]; info[0] = carry[1]; }
+}
+
+// K1b': rem_bucket = inverse permutation of rem_pos (random 4-byte scatter, spread over the whole chip)
+static __global__ void msm_rem_invert_kernel(uint32_t nb_total, const uint32_t *__restrict__ rem_pos, uint32_t *__restrict__ rem_bucket) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb_total) return;
+    const uint32_t p = rem_pos[b];
+    if (p != MSM_INVALID) rem_bucket[p] = b;
 }
 
 // K1c: scatter point references into bucket order

@@ -137,3 +137,22 @@ def test_sharded_driver_single_rank_on_gpu(ctx_srs, oracle, srs_oracle):
         assert sh.verify_base_sliced(pre, sg, rho) is False
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("curve,n", [(1, 2048), (0, 5000), (1, 40000), (0, 65536)])
+def test_msm_variable_base_large(ctx, oracle, srs_oracle, curve, n):
+    """variable-base path at the window shapes n selects: c=11 (24 bucket sets of 1024) and c=14 (19 sets of 8192,
+    155 648 buckets in total: exercises the multi-row scan and the 64-row 2-D reduction), bit-exact vs the CPU oracle"""
+    g, _ = srs_oracle[curve]
+    bases = g[:n][::-1].copy()                       # any points: here the SRS in reverse order
+    sc = rand_scalars(n, SCALAR_MOD[curve], seed=31337 + n)
+    sc[::7] = 0                                     # sprinkle zero scalars
+    assert (ctx.msm(curve, bases, sc) == oracle.msm_pippenger(curve, bases, sc, threads=8)).all()
+
+
+def test_msm_variable_base_adversarial_large(ctx, oracle, srs_oracle):
+    """all scalars equal on 40 000 distinct points: one bucket per window holds everything (remainder-class overflow guard)"""
+    curve, n = 1, 40000
+    g, _ = srs_oracle[curve]
+    sc = np.repeat(rand_scalars(1, P, seed=99), n, axis=0)
+    assert (ctx.msm(curve, g[:n], sc) == oracle.msm_pippenger(curve, g[:n], sc, threads=8)).all()
