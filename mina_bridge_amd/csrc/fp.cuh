@@ -61,7 +61,7 @@ MB_HD fe_t fe_zero() { fe_t r;
     return r; }
 
 // r = a - p if a >= p else a        (a < 2p)
-template <int F> MB_HD fe_t fe_cond_sub_p(const fe_t &a) {
+template <int F> MB_HD fe_t fe_cond_sub_p_portable(const fe_t &a) {
     fe_t d; uint32_t br = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -72,6 +72,42 @@ template <int F> MB_HD fe_t fe_cond_sub_p(const fe_t &a) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) r.v[i] = br ? a.v[i] : d.v[i];
     return r;
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+template <int F> __device__ __forceinline__ fe_t fe_cond_sub_p_device(const fe_t &a) {
+    fe_t r;
+    uint32_t d0, d1, d2, d3, d4, d5, d6, d7;
+    asm("v_subrev_co_u32_e32 %0, vcc, 1, %8\n\t"
+        "v_subbrev_co_u32_e32 %1, vcc, %16, %9, vcc\n\t"
+        "v_subbrev_co_u32_e32 %2, vcc, %17, %10, vcc\n\t"
+        "v_subbrev_co_u32_e32 %3, vcc, %18, %11, vcc\n\t"
+        "v_subbrev_co_u32_e32 %4, vcc, 0, %12, vcc\n\t"
+        "v_subbrev_co_u32_e32 %5, vcc, 0, %13, vcc\n\t"
+        "v_subbrev_co_u32_e32 %6, vcc, 0, %14, vcc\n\t"
+        "v_subbrev_co_u32_e32 %7, vcc, %19, %15, vcc\n\t"
+        "v_cndmask_b32_e32 %0, %0, %8, vcc\n\t"
+        "v_cndmask_b32_e32 %1, %1, %9, vcc\n\t"
+        "v_cndmask_b32_e32 %2, %2, %10, vcc\n\t"
+        "v_cndmask_b32_e32 %3, %3, %11, vcc\n\t"
+        "v_cndmask_b32_e32 %4, %4, %12, vcc\n\t"
+        "v_cndmask_b32_e32 %5, %5, %13, vcc\n\t"
+        "v_cndmask_b32_e32 %6, %6, %14, vcc\n\t"
+        "v_cndmask_b32_e32 %7, %7, %15, vcc"
+        : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&v"(d4), "=&v"(d5), "=&v"(d6), "=&v"(d7)
+        : "v"(a.v[0]), "v"(a.v[1]), "v"(a.v[2]), "v"(a.v[3]), "v"(a.v[4]), "v"(a.v[5]), "v"(a.v[6]), "v"(a.v[7]),
+          "v"(FieldP<F>::P1), "v"(FieldP<F>::P2), "v"(FieldP<F>::P3), "v"(P7)
+        : "vcc");
+    r.v[0] = d0; r.v[1] = d1; r.v[2] = d2; r.v[3] = d3; r.v[4] = d4; r.v[5] = d5; r.v[6] = d6; r.v[7] = d7;
+    return r;
+}
+#endif
+template <int F> MB_HD fe_t fe_cond_sub_p(const fe_t &a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return fe_cond_sub_p_device<F>(a);
+#else
+    return fe_cond_sub_p_portable<F>(a);
+#endif
 }
 
 template <int F> MB_HD fe_t fe_add_portable(const fe_t &a, const fe_t &b) {
@@ -251,7 +287,7 @@ template <int F> __device__ __forceinline__ fe_t fe_mul_device(const fe_t &a, co
     // generated by tools/gen_fe_mul.py -- product scanning, one asm statement per column
     uint64_t acc = 0, cc; uint32_t hi = 0, lo, mid; fe_t r;
     uint32_t m0, m1, m2, m3, m4, m5, m6, m7;
-    const uint32_t p1 = FieldP<F>::P1, p2 = FieldP<F>::P2, p3 = FieldP<F>::P3;
+    const uint32_t p1 = FieldP<F>::P1, p2 = FieldP<F>::P2, p3 = FieldP<F>::P3, p7 = P7;
     // column 0: 1 products
     asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
         : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[0]));
@@ -287,46 +323,38 @@ template <int F> __device__ __forceinline__ fe_t fe_mul_device(const fe_t &a, co
         : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[6]), "v"(a.v[1]), "v"(b.v[5]), "v"(a.v[2]), "v"(b.v[4]), "v"(a.v[3]), "v"(b.v[3]), "v"(a.v[4]), "v"(b.v[2]), "v"(a.v[5]), "v"(b.v[1]), "v"(a.v[6]), "v"(b.v[0]), "v"(m3), "v"(p3), "v"(m4), "v"(p2), "v"(m5), "v"(p1));
     lo = (uint32_t)acc; mid = (uint32_t)(acc >> 32); m6 = 0u - lo;
     mb_fold_shift(acc, hi, lo, mid);                          // + m_k * p0 (low word -> 0), then >> 32
-    // column 7: 11 products
-    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
-        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[7]), "v"(a.v[1]), "v"(b.v[6]), "v"(a.v[2]), "v"(b.v[5]), "v"(a.v[3]), "v"(b.v[4]), "v"(a.v[4]), "v"(b.v[3]), "v"(a.v[5]), "v"(b.v[2]), "v"(a.v[6]), "v"(b.v[1]), "v"(a.v[7]), "v"(b.v[0]), "v"(m4), "v"(p3), "v"(m5), "v"(p2), "v"(m6), "v"(p1));
-    mb_acc_add(acc, hi, (uint64_t)m0 << 30);            // m0 * p7 (p7 = 2^30)
+    // column 7: 12 products
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %25, %26, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[7]), "v"(a.v[1]), "v"(b.v[6]), "v"(a.v[2]), "v"(b.v[5]), "v"(a.v[3]), "v"(b.v[4]), "v"(a.v[4]), "v"(b.v[3]), "v"(a.v[5]), "v"(b.v[2]), "v"(a.v[6]), "v"(b.v[1]), "v"(a.v[7]), "v"(b.v[0]), "v"(m0), "v"(p7), "v"(m4), "v"(p3), "v"(m5), "v"(p2), "v"(m6), "v"(p1));
     lo = (uint32_t)acc; mid = (uint32_t)(acc >> 32); m7 = 0u - lo;
     mb_fold_shift(acc, hi, lo, mid);                          // + m_k * p0 (low word -> 0), then >> 32
-    // column 8: 10 products
-    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
-        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a.v[1]), "v"(b.v[7]), "v"(a.v[2]), "v"(b.v[6]), "v"(a.v[3]), "v"(b.v[5]), "v"(a.v[4]), "v"(b.v[4]), "v"(a.v[5]), "v"(b.v[3]), "v"(a.v[6]), "v"(b.v[2]), "v"(a.v[7]), "v"(b.v[1]), "v"(m5), "v"(p3), "v"(m6), "v"(p2), "v"(m7), "v"(p1));
-    mb_acc_add(acc, hi, (uint64_t)m1 << 30);            // m1 * p7 (p7 = 2^30)
+    // column 8: 11 products
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a.v[1]), "v"(b.v[7]), "v"(a.v[2]), "v"(b.v[6]), "v"(a.v[3]), "v"(b.v[5]), "v"(a.v[4]), "v"(b.v[4]), "v"(a.v[5]), "v"(b.v[3]), "v"(a.v[6]), "v"(b.v[2]), "v"(a.v[7]), "v"(b.v[1]), "v"(m1), "v"(p7), "v"(m5), "v"(p3), "v"(m6), "v"(p2), "v"(m7), "v"(p1));
     r.v[0] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
-    // column 9: 8 products
-    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
-        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a.v[2]), "v"(b.v[7]), "v"(a.v[3]), "v"(b.v[6]), "v"(a.v[4]), "v"(b.v[5]), "v"(a.v[5]), "v"(b.v[4]), "v"(a.v[6]), "v"(b.v[3]), "v"(a.v[7]), "v"(b.v[2]), "v"(m6), "v"(p3), "v"(m7), "v"(p2));
-    mb_acc_add(acc, hi, (uint64_t)m2 << 30);            // m2 * p7 (p7 = 2^30)
+    // column 9: 9 products
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a.v[2]), "v"(b.v[7]), "v"(a.v[3]), "v"(b.v[6]), "v"(a.v[4]), "v"(b.v[5]), "v"(a.v[5]), "v"(b.v[4]), "v"(a.v[6]), "v"(b.v[3]), "v"(a.v[7]), "v"(b.v[2]), "v"(m2), "v"(p7), "v"(m6), "v"(p3), "v"(m7), "v"(p2));
     r.v[1] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
-    // column 10: 6 products
-    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
-        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a.v[3]), "v"(b.v[7]), "v"(a.v[4]), "v"(b.v[6]), "v"(a.v[5]), "v"(b.v[5]), "v"(a.v[6]), "v"(b.v[4]), "v"(a.v[7]), "v"(b.v[3]), "v"(m7), "v"(p3));
-    mb_acc_add(acc, hi, (uint64_t)m3 << 30);            // m3 * p7 (p7 = 2^30)
+    // column 10: 7 products
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a.v[3]), "v"(b.v[7]), "v"(a.v[4]), "v"(b.v[6]), "v"(a.v[5]), "v"(b.v[5]), "v"(a.v[6]), "v"(b.v[4]), "v"(a.v[7]), "v"(b.v[3]), "v"(m3), "v"(p7), "v"(m7), "v"(p3));
     r.v[2] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
-    // column 11: 4 products
-    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
-        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a.v[4]), "v"(b.v[7]), "v"(a.v[5]), "v"(b.v[6]), "v"(a.v[6]), "v"(b.v[5]), "v"(a.v[7]), "v"(b.v[4]));
-    mb_acc_add(acc, hi, (uint64_t)m4 << 30);            // m4 * p7 (p7 = 2^30)
+    // column 11: 5 products
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a.v[4]), "v"(b.v[7]), "v"(a.v[5]), "v"(b.v[6]), "v"(a.v[6]), "v"(b.v[5]), "v"(a.v[7]), "v"(b.v[4]), "v"(m4), "v"(p7));
     r.v[3] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
-    // column 12: 3 products
-    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
-        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a.v[5]), "v"(b.v[7]), "v"(a.v[6]), "v"(b.v[6]), "v"(a.v[7]), "v"(b.v[5]));
-    mb_acc_add(acc, hi, (uint64_t)m5 << 30);            // m5 * p7 (p7 = 2^30)
+    // column 12: 4 products
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a.v[5]), "v"(b.v[7]), "v"(a.v[6]), "v"(b.v[6]), "v"(a.v[7]), "v"(b.v[5]), "v"(m5), "v"(p7));
     r.v[4] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
-    // column 13: 2 products
-    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
-        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a.v[6]), "v"(b.v[7]), "v"(a.v[7]), "v"(b.v[6]));
-    mb_acc_add(acc, hi, (uint64_t)m6 << 30);            // m6 * p7 (p7 = 2^30)
+    // column 13: 3 products
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a.v[6]), "v"(b.v[7]), "v"(a.v[7]), "v"(b.v[6]), "v"(m6), "v"(p7));
     r.v[5] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
-    // column 14: 1 products
-    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
-        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a.v[7]), "v"(b.v[7]));
-    mb_acc_add(acc, hi, (uint64_t)m7 << 30);            // m7 * p7 (p7 = 2^30)
+    // column 14: 2 products
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a.v[7]), "v"(b.v[7]), "v"(m7), "v"(p7));
     r.v[6] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
     r.v[7] = (uint32_t)acc;                                       // result < 2p < 2^256
     return fe_cond_sub_p<F>(r);
