@@ -150,6 +150,10 @@ int mina_to_group(mina_ctx *ctx, int curve, size_t n, const uint8_t *t, uint8_t 
 int mina_field_mul(mina_ctx *ctx, int field, size_t n, const uint8_t *a, const uint8_t *b, uint8_t *out);
 int mina_field_inv(mina_ctx *ctx, int field, size_t n, const uint8_t *a, uint8_t *out);
 int mina_field_sqrt(mina_ctx *ctx, int field, size_t n, const uint8_t *a, uint8_t *out, uint8_t *out_is_square);
+/* group law: the same chain of XYZZ additions/doublings on (P_i, Q_i) with the single-lane and with the 4-lane cooperative
+ * routines; both results as affine points, same[i] = 1 iff the XYZZ coordinates agreed word for word at every step */
+int mina_selftest_group_law(mina_ctx *ctx, int curve, size_t n, const uint8_t *p_affine, const uint8_t *q_affine,
+                            uint8_t *out_serial, uint8_t *out_quad, uint8_t *same);
 
 /* ---- a8 / a10: combined IPA check ------------------------------------------------------------ */
 /* Accumulator check (a10) for `batch` proofs on the SRS of `curve`:

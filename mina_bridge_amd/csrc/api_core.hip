@@ -1,6 +1,7 @@
 // api_core.hip -- context lifetime, field constants, field self-test hooks, K4 group map entry point.
 #include "ctx.h"
 #include "sponge.cuh"
+#include "msm.cuh"
 
 static thread_local std::string g_err = "";
 int mb_fail(int code, const std::string &msg) { g_err = msg; return code; }
@@ -195,5 +196,63 @@ extern "C" int mina_prof_read(mina_ctx *c, char *buf, size_t cap) {
     o += "}";
     if (o.size() + 1 > cap) return fail(MINA_ERR_ARG, "buffer too small");
     memcpy(buf, o.c_str(), o.size() + 1);
+    return MINA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// self-test hook for the lane-cooperative group law: for each i runs the same chain of XYZZ operations
+//   acc = P_i + Q_i; acc += acc (doubling branch); acc += Q_i; acc = 2*acc; acc += (-acc_before) ...
+// once with the single-lane routines and once with the 4-lane cooperative ones; outputs both results (affine,
+// canonical) and whether the XYZZ coordinates agreed word for word at every step.
+template <int F>
+__global__ void __launch_bounds__(256)
+group_law_selftest_kernel(uint32_t n, FieldK fk, const uint32_t *__restrict__ pw, const uint32_t *__restrict__ qw,
+                          uint32_t *__restrict__ out_serial, uint32_t *__restrict__ out_quad, uint32_t *__restrict__ same) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x, i = gid >> 2, rho = gid & 3;
+    const bool live = i < n; const uint32_t ii = live ? i : 0;
+    auto ld = [&](const uint32_t *w) { affine_t a; for (int k = 0; k < 8; ++k) { a.x.v[k] = w[(size_t)ii * 16 + k]; a.y.v[k] = w[(size_t)ii * 16 + 8 + k]; }
+                                       a.x = fe_to_mont<F>(a.x, fk.r2); a.y = fe_to_mont<F>(a.y, fk.r2); return a; };
+    const affine_t P = ld(pw), Q = ld(qw);
+    const xyzz_t xp = xyzz_from_affine<F>(P, fk.one), xq = xyzz_from_affine<F>(Q, fk.one);
+    auto eq = [](const xyzz_t &a, const xyzz_t &b) { return fe_eq(a.x, b.x) && fe_eq(a.y, b.y) && fe_eq(a.zz, b.zz) && fe_eq(a.zzz, b.zzz); };
+    xyzz_t s = xp, c = xp; bool ok = true;
+    xyzz_add<F>(s, xq);            xyzz_add_quad<F>(c, xq);            ok &= eq(s, c);
+    { xyzz_t t = s; xyzz_add<F>(s, t); t = c; xyzz_add_quad<F>(c, t); } ok &= eq(s, c);      // P == Q branch
+    xyzz_add<F>(s, xq);            xyzz_add_quad<F>(c, xq);            ok &= eq(s, c);
+    s = xyzz_dbl<F>(s);            c = xyzz_dbl_quad<F>(c);            ok &= eq(s, c);
+    { xyzz_t t = s; xyzz_add<F>(t, xp); xyzz_t u = c; xyzz_add_quad<F>(u, xp);                // general add with non-trivial ZZ on both sides
+      xyzz_add<F>(s, t); xyzz_add_quad<F>(c, u); } ok &= eq(s, c);
+    { xyzz_t t = s; t.y = fe_neg<F>(t.y); xyzz_t z = s; xyzz_add<F>(z, t); xyzz_t u = c; u.y = fe_neg<F>(u.y); xyzz_t z2 = c; xyzz_add_quad<F>(z2, u);
+      ok &= xyzz_is_inf(z) && xyzz_is_inf(z2); }                                              // P == -Q branch
+    auto st = [&](const xyzz_t &t, uint32_t *o) {
+        if (xyzz_is_inf(t)) { for (int k = 0; k < 16; ++k) o[(size_t)i * 16 + k] = 0; return; }
+        fe_t zi = fe_inv<F>(fe_mul<F>(t.zz, t.zzz), fk);
+        fe_t x = fe_from_mont<F>(fe_mul<F>(t.x, fe_mul<F>(zi, t.zzz))), y = fe_from_mont<F>(fe_mul<F>(t.y, fe_mul<F>(zi, t.zz)));
+        for (int k = 0; k < 8; ++k) { o[(size_t)i * 16 + k] = x.v[k]; o[(size_t)i * 16 + 8 + k] = y.v[k]; } };
+    if (live && rho == 0) { st(s, out_serial); st(c, out_quad); same[i] = ok ? 1u : 0u; }
+}
+
+extern "C" int mina_selftest_group_law(mina_ctx *c, int curve, size_t n, const uint8_t *p, const uint8_t *q, uint8_t *out_serial,
+                                       uint8_t *out_quad, uint8_t *same) {
+    if (!c || (n && (!p || !q || !out_serial || !out_quad || !same))) return fail(MINA_ERR_ARG, "null argument");
+    if (curve != 0 && curve != 1) return fail(MINA_ERR_ARG, "bad curve");
+    if (n == 0) return MINA_OK;
+    HIPC(hipSetDevice(c->device));
+    c->use_lane0();
+    int rc;
+    if ((rc = h2d(c, c->L->tmp_a, p, n * 64))) return rc;
+    if ((rc = h2d(c, c->L->tmp_b, q, n * 64))) return rc;
+    if ((rc = c->L->tmp_c.ensure(n * 64))) return rc;
+    if ((rc = c->L->tmp_d.ensure(n * 64 + n * 4))) return rc;
+    uint32_t *d_quad = c->L->tmp_d.as<uint32_t>(), *d_same = d_quad + n * 16;
+    DISPATCH_FIELD(base_field_of(curve), {
+        group_law_selftest_kernel<F_><<<cdiv(n * 4, 256), 256, 0, c->L->stream>>>((uint32_t)n, c->fk[F_], c->L->tmp_a.as<uint32_t>(), c->L->tmp_b.as<uint32_t>(),
+                                                                              c->L->tmp_c.as<uint32_t>(), d_quad, d_same);
+    });
+    std::vector<uint32_t> sm(n);
+    HIPC(hipMemcpyAsync(out_quad, d_quad, n * 64, hipMemcpyDeviceToHost, c->L->stream));
+    HIPC(hipMemcpyAsync(sm.data(), d_same, n * 4, hipMemcpyDeviceToHost, c->L->stream));
+    if ((rc = d2h_sync(c, out_serial, c->L->tmp_c, n * 64))) return rc;
+    for (size_t i = 0; i < n; ++i) same[i] = sm[i] ? 1 : 0;
     return MINA_OK;
 }

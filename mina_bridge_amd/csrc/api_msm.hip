@@ -50,7 +50,7 @@ static int run_msm(mina_ctx *c, const MsmShape &sh, const uint32_t *d_scalars, c
                                                            w.eoff.as<uint32_t>(), w.start.as<uint32_t>(), w.sorted.as<uint32_t>()); }
     { ProfScope ps_(c, PS_ACCUMULATE); msm_accumulate_kernel<F><<<cdiv(max_tasks, 256), 256, 0, st>>>(nb_total, w.start.as<uint32_t>(), w.task_start.as<uint32_t>(),
                                                                    w.rem_bucket.as<uint32_t>(), w.info.as<uint32_t>(), w.sorted.as<uint32_t>(), d_points, fk.one, w.partial.as<xyzz_t>()); }
-    { ProfScope ps_(c, PS_BUCKET_SUM); msm_bucket_sum_kernel<F><<<cdiv(nb_total, 256), 256, 0, st>>>(nb_total, w.task_start.as<uint32_t>(), w.rem_pos.as<uint32_t>(), w.info.as<uint32_t>(), w.partial.as<xyzz_t>(),
+    { ProfScope ps_(c, PS_BUCKET_SUM); msm_bucket_sum_kernel<F><<<cdiv((size_t)nb_total * 4, 256), 256, 0, st>>>(nb_total, w.task_start.as<uint32_t>(), w.rem_pos.as<uint32_t>(), w.info.as<uint32_t>(), w.partial.as<xyzz_t>(),
                                                                   w.buckets.as<xyzz_t>()); }
     {
         // 2-D bucket reduction: C = 128 columns, R = NB / C rows (NB is a power of two in [128, 32768])
@@ -58,8 +58,8 @@ static int run_msm(mina_ctx *c, const MsmShape &sh, const uint32_t *d_scalars, c
         SegSum rows, cols;
         rows.nseg = R * sh.nsets; rows.per_set = R; rows.len = C; rows.seg_stride = C; rows.elem_stride = 1; rows.lanes = C / SEG_CHUNK;
         cols.nseg = C * sh.nsets; cols.per_set = C; cols.len = R; cols.seg_stride = 1; cols.elem_stride = C;
-        { uint32_t l = 1; while (l * SEG_CHUNK < R && l < 64) l <<= 1; cols.lanes = l; }
-        const uint32_t threads_rows = rows.nseg * rows.lanes, threads_cols = cols.nseg * cols.lanes;
+        { uint32_t l = 1; while (l * SEG_CHUNK < R && l < 16) l <<= 1; cols.lanes = l; }   // quads per column, <= 16 (one wave)
+        const uint32_t threads_rows = rows.nseg * rows.lanes * 4, threads_cols = cols.nseg * cols.lanes * 4;   // 4 lanes per quad
         const uint32_t blocks = cdiv(threads_rows > threads_cols ? threads_rows : threads_cols, 256);
         { ProfScope ps_(c, PS_REDUCE_A); msm_segsum_kernel<F><<<dim3(blocks, 2), 256, 0, st>>>(sh.NB, rows, cols, w.buckets.as<xyzz_t>(), w.red_r.as<xyzz_t>(), w.red_ws.as<xyzz_t>()); }
         { ProfScope ps_(c, PS_REDUCE_BC); msm_reduce2d_kernel<F><<<sh.nsets, 384, 0, st>>>(R, C, log2C, w.red_r.as<xyzz_t>(), w.red_ws.as<xyzz_t>(), w.set_total.as<xyzz_t>()); }

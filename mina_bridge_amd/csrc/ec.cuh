@@ -105,4 +105,77 @@ template <int F> MB_HD void xyzz_add(xyzz_t &acc, const xyzz_t &q) {
     acc.x = x3; acc.y = y3;
 }
 
+// ---------------------------------------------------------------- lane-cooperative group law (gfx950 device only)
+// Four lanes of one DPP quad hold IDENTICAL copies of the operands and cooperate on one XYZZ operation: the
+// independent field products of each dependency level run on different lanes (4 levels for add, 3 for double,
+// instead of 14 / 9 products in sequence), results are exchanged with quad_perm DPP moves.  Every lane ends with the
+// identical, bit-exact same XYZZ value the single-lane routines produce.  For the latency-bound stages of the MSM
+// (few live values, long dependency chains); all branches below are uniform within a quad.
+#if defined(__HIPCC__)
+template <int K> __device__ __forceinline__ fe_t quad_bcast(const fe_t &a) {
+    fe_t r = a;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        r.v[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)a.v[i], K * 0x55, 0xf, 0xf, true);   // quad_perm:[K,K,K,K]
+#endif
+    return r;
+}
+__device__ __forceinline__ fe_t quad_sel4(uint32_t rho, const fe_t &a, const fe_t &b, const fe_t &c, const fe_t &d) {
+    fe_t r; const bool b0 = rho & 1u, b1 = rho & 2u;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { uint32_t x = b0 ? b.v[i] : a.v[i], y = b0 ? d.v[i] : c.v[i]; r.v[i] = b1 ? y : x; }
+    return r;
+}
+template <int F> __device__ __forceinline__ xyzz_t xyzz_dbl_quad(const xyzz_t &p) {
+    if (xyzz_is_inf(p) || fe_is_zero(p.y)) return xyzz_inf();
+    const uint32_t rho = threadIdx.x & 3u;
+    const fe_t u = fe_dbl<F>(p.y);
+    fe_t a = quad_sel4(rho, u, p.x, u, u);
+    fe_t m = fe_mul<F>(a, a);
+    const fe_t v = quad_bcast<0>(m), xx = quad_bcast<1>(m);
+    const fe_t mm1 = fe_add<F>(fe_dbl<F>(xx), xx);                       // M = 3 X^2
+    a = quad_sel4(rho, u, p.x, p.zz, mm1);
+    fe_t b = quad_sel4(rho, v, v, v, mm1);
+    m = fe_mul<F>(a, b);
+    const fe_t w = quad_bcast<0>(m), s = quad_bcast<1>(m), zz3 = quad_bcast<2>(m), msq = quad_bcast<3>(m);
+    xyzz_t r;
+    r.x = fe_sub<F>(fe_sub<F>(msq, s), s);
+    a = quad_sel4(rho, mm1, w, w, w);
+    b = quad_sel4(rho, fe_sub<F>(s, r.x), p.y, p.zzz, p.zzz);
+    m = fe_mul<F>(a, b);
+    r.y = fe_sub<F>(quad_bcast<0>(m), quad_bcast<1>(m));
+    r.zz = zz3; r.zzz = quad_bcast<2>(m);
+    return r;
+}
+template <int F> __device__ __forceinline__ void xyzz_add_quad(xyzz_t &acc, const xyzz_t &q) {
+    if (xyzz_is_inf(q)) return;
+    if (xyzz_is_inf(acc)) { acc = q; return; }
+    const uint32_t rho = threadIdx.x & 3u;
+    fe_t a = quad_sel4(rho, acc.x, q.x, acc.y, q.y);
+    fe_t b = quad_sel4(rho, q.zz, acc.zz, q.zzz, acc.zzz);
+    fe_t m = fe_mul<F>(a, b);
+    const fe_t u1 = quad_bcast<0>(m), u2 = quad_bcast<1>(m), s1 = quad_bcast<2>(m), s2 = quad_bcast<3>(m);
+    const fe_t p = fe_sub<F>(u2, u1), r = fe_sub<F>(s2, s1);
+    if (fe_is_zero(p)) {
+        if (fe_is_zero(r)) acc = xyzz_dbl_quad<F>(acc); else acc = xyzz_inf();
+        return;
+    }
+    a = quad_sel4(rho, p, r, acc.zz, acc.zzz);
+    b = quad_sel4(rho, p, r, q.zz, q.zzz);
+    m = fe_mul<F>(a, b);
+    const fe_t pp = quad_bcast<0>(m), rr = quad_bcast<1>(m), zz12 = quad_bcast<2>(m), zzz12 = quad_bcast<3>(m);
+    a = quad_sel4(rho, p, u1, zz12, zz12);
+    m = fe_mul<F>(a, pp);
+    const fe_t ppp = quad_bcast<0>(m), qq = quad_bcast<1>(m), zz3 = quad_bcast<2>(m);
+    const fe_t x3 = fe_sub<F>(fe_sub<F>(fe_sub<F>(rr, ppp), qq), qq);
+    a = quad_sel4(rho, r, s1, zzz12, zzz12);
+    b = quad_sel4(rho, fe_sub<F>(qq, x3), ppp, ppp, ppp);
+    m = fe_mul<F>(a, b);
+    acc.x = x3;
+    acc.y = fe_sub<F>(quad_bcast<0>(m), quad_bcast<1>(m));
+    acc.zz = zz3; acc.zzz = quad_bcast<2>(m);
+}
+#endif
+
 }  // namespace mb

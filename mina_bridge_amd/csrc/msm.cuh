@@ -289,17 +289,19 @@ msm_accumulate_kernel(uint32_t nb_total, const uint32_t *__restrict__ start, con
     partial[t] = acc;
 }
 
-// K1e: level-2: bucket b = sum of its task partials (its full tasks are contiguous, plus at most one remainder task)
+// K1e: level-2: bucket b = sum of its task partials (its full tasks are contiguous, plus at most one remainder task).
+// Four lanes per bucket (cooperative group law): the chain of ~4-8 dependent XYZZ adds is the latency of this stage.
 template <int F>
 __global__ void __launch_bounds__(256)
 msm_bucket_sum_kernel(uint32_t nb_total, const uint32_t *__restrict__ full_start, const uint32_t *__restrict__ rem_pos,
                       const uint32_t *__restrict__ info, const xyzz_t *__restrict__ partial, xyzz_t *__restrict__ buckets) {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nb_total) return;
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t b = gid >> 2;
+    if (b >= nb_total) return;                               // whole quads leave together
     const uint32_t lo = full_start[b], hi = full_start[b + 1], rp = rem_pos[b];
     xyzz_t acc = (rp != MSM_INVALID) ? partial[info[0] + rp] : xyzz_inf();
-    for (uint32_t t = lo; t < hi; ++t) xyzz_add<F>(acc, partial[t]);
-    buckets[b] = acc;
+    for (uint32_t t = lo; t < hi; ++t) xyzz_add_quad<F>(acc, partial[t]);
+    if ((gid & 3u) == 0) buckets[b] = acc;
 }
 
 // ---------------------------------------------------------------- wave64 XYZZ collectives
@@ -357,25 +359,27 @@ template <int F>
 __global__ void __launch_bounds__(256)
 msm_segsum_kernel(uint32_t nb_per_set, SegSum rows, SegSum cols, const xyzz_t *__restrict__ buckets,
                   xyzz_t *__restrict__ out_rows, xyzz_t *__restrict__ out_cols) {
+    // `lanes` counts QUADS per segment here: four lanes cooperate on every add (lane-cooperative group law)
     const bool is_col = blockIdx.y != 0;
     const SegSum sg = is_col ? cols : rows;
     xyzz_t *__restrict__ out = is_col ? out_cols : out_rows;
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t seg = gid / sg.lanes, sub = gid % sg.lanes;
+    const uint32_t qid = gid >> 2;                            // quad index
+    const uint32_t seg = qid / sg.lanes, sub = qid % sg.lanes;
     const bool live = seg < sg.nseg;
     xyzz_t acc = xyzz_inf();
     if (live) {
         const size_t base = (size_t)(seg / sg.per_set) * nb_per_set + (size_t)(seg % sg.per_set) * sg.seg_stride;
         const uint32_t per_lane = (sg.len + sg.lanes - 1) / sg.lanes;
         const uint32_t e0 = sub * per_lane, e1 = min(e0 + per_lane, sg.len);
-        for (uint32_t e = e0; e < e1; ++e) xyzz_add<F>(acc, buckets[base + (size_t)e * sg.elem_stride]);
+        for (uint32_t e = e0; e < e1; ++e) xyzz_add_quad<F>(acc, buckets[base + (size_t)e * sg.elem_stride]);
     }
 #pragma unroll 1
-    for (uint32_t d = sg.lanes >> 1; d >= 1; d >>= 1) {      // whole wave executes the shuffles; groups never straddle a wave
-        xyzz_t o = shfl_down_xyzz(acc, (int)d);
-        if (sub + d < sg.lanes) xyzz_add<F>(acc, o);
+    for (uint32_t d = sg.lanes >> 1; d >= 1; d >>= 1) {      // partner quad = 4*d lanes further; groups never straddle a wave
+        xyzz_t o = shfl_down_xyzz(acc, (int)(4 * d));
+        if (sub + d < sg.lanes) xyzz_add_quad<F>(acc, o);
     }
-    if (live && sub == 0) out[seg] = acc;
+    if (live && sub == 0 && (gid & 3u) == 0) out[seg] = acc;
 }
 
 // K1g: one block of 6 waves per bucket set.  Waves 0-3: weighted sum over the (<= 256) rows; waves 4-5: over the
@@ -396,26 +400,29 @@ msm_reduce2d_kernel(uint32_t R, uint32_t C, uint32_t log2C, const xyzz_t *__rest
         if (lane == 0) { sh_s[wave] = sum; sh_w[wave] = ws; }
     }
     __syncthreads();
+    // final combination: three quads (lane-cooperative group law) work concurrently
     xyzz_t t = xyzz_inf();
-    if (threadIdx.x == 0) {
+    const uint32_t quad = threadIdx.x >> 2;
+    if (quad == 0) {
         // sum_r r*Row_r = W0+W1+W2+W3 + 64*(S1 + 2 S2 + 3 S3)
-        xyzz_t a = sh_s[1]; xyzz_add<F>(a, sh_s[3]);
-        xyzz_t b = sh_s[2]; xyzz_add<F>(b, sh_s[3]);
-        t = xyzz_dbl<F>(b); xyzz_add<F>(t, a);
-        for (int i = 0; i < 6; ++i) t = xyzz_dbl<F>(t);
-        xyzz_add<F>(t, sh_w[0]); xyzz_add<F>(t, sh_w[1]); xyzz_add<F>(t, sh_w[2]); xyzz_add<F>(t, sh_w[3]);
-        for (uint32_t i = 0; i < log2C; ++i) t = xyzz_dbl<F>(t);          // * C
-    } else if (threadIdx.x == 64) {
+        xyzz_t a = sh_s[1]; xyzz_add_quad<F>(a, sh_s[3]);
+        xyzz_t b = sh_s[2]; xyzz_add_quad<F>(b, sh_s[3]);
+        t = xyzz_dbl_quad<F>(b); xyzz_add_quad<F>(t, a);
+        for (int i = 0; i < 6; ++i) t = xyzz_dbl_quad<F>(t);
+        xyzz_t ww = sh_w[0]; xyzz_add_quad<F>(ww, sh_w[1]); xyzz_t w2 = sh_w[2]; xyzz_add_quad<F>(w2, sh_w[3]); xyzz_add_quad<F>(ww, w2);
+        xyzz_add_quad<F>(t, ww);
+        for (uint32_t i = 0; i < log2C; ++i) t = xyzz_dbl_quad<F>(t);     // * C
+    } else if (quad == 16) {
         xyzz_t u = sh_s[5];
-        for (int i = 0; i < 6; ++i) u = xyzz_dbl<F>(u);
-        xyzz_add<F>(u, sh_w[4]); xyzz_add<F>(u, sh_w[5]);
-        sh_colw = u;                                                       // sum_c c*Col_c
-    } else if (threadIdx.x == 128) {
-        xyzz_t u = sh_s[0]; xyzz_add<F>(u, sh_s[1]); xyzz_add<F>(u, sh_s[2]); xyzz_add<F>(u, sh_s[3]);
-        sh_tot = u;                                                        // Tot
+        for (int i = 0; i < 6; ++i) u = xyzz_dbl_quad<F>(u);
+        xyzz_add_quad<F>(u, sh_w[4]); xyzz_add_quad<F>(u, sh_w[5]);
+        if ((threadIdx.x & 3u) == 0) sh_colw = u;                          // sum_c c*Col_c
+    } else if (quad == 32) {
+        xyzz_t u = sh_s[0]; xyzz_add_quad<F>(u, sh_s[1]); xyzz_t v2 = sh_s[2]; xyzz_add_quad<F>(v2, sh_s[3]); xyzz_add_quad<F>(u, v2);
+        if ((threadIdx.x & 3u) == 0) sh_tot = u;                           // Tot
     }
     __syncthreads();
-    if (threadIdx.x == 0) { xyzz_add<F>(t, sh_colw); xyzz_add<F>(t, sh_tot); set_total[set] = t; }
+    if (quad == 0) { xyzz_add_quad<F>(t, sh_colw); xyzz_add_quad<F>(t, sh_tot); if (threadIdx.x == 0) set_total[set] = t; }
 }
 
 // K1h: Horner over bucket sets (variable-base), then normalise to affine (Montgomery) + canonical words.

@@ -167,15 +167,6 @@ poseidon_hash_kernel(uint32_t n, uint32_t len, FieldK fk, const PoseidonParams *
 // row q of the MDS product (3 products): 7 dependent products per round instead of 21 -- a 3x shorter critical path
 // for the sequential sponge work (Fiat-Shamir transcripts, Merkle paths) at batch sizes that cannot fill the chip.
 #if defined(__HIPCC__)
-template <int K> __device__ __forceinline__ fe_t quad_bcast(const fe_t &a) {
-    fe_t r = a;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-        r.v[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)a.v[i], K * 0x55, 0xf, 0xf, true);   // quad_perm:[K,K,K,K]
-#endif
-    return r;
-}
 template <int F>
 __device__ __forceinline__ void poseidon_permute_quad(fe_t &s, const PoseidonParams *__restrict__ pp) {
     const int q = threadIdx.x & 3, qq = q < 3 ? q : 2;

@@ -27,7 +27,7 @@ EXPORTS = [
     "mina_b_poly", "mina_b_poly_coefficients", "mina_b_poly_fold", "mina_b_poly_fold_dev",
     "mina_poseidon_set_params", "mina_poseidon_permute", "mina_poseidon_permute_dev", "mina_poseidon_hash",
     "mina_challenge_to_field", "mina_to_group", "mina_merkle_roots", "mina_merkle_verify_batch",
-    "mina_field_mul", "mina_field_inv", "mina_field_sqrt",
+    "mina_field_mul", "mina_field_inv", "mina_field_sqrt", "mina_selftest_group_law",
     "mina_accumulator_check_batch", "mina_accumulator_check_dev", "mina_ipa_batch_check",
 ]
 
@@ -298,6 +298,13 @@ class MinaContext:
         ok = np.empty(n, np.uint8)
         self._ck(self._lib.mina_field_sqrt(self._h, field, ctypes.c_size_t(n), _p(a), _p(out), _p(ok)), "mina_field_sqrt")
         return out, ok
+
+    def selftest_group_law(self, curve: int, p, q):
+        p, q = _u8(p), _u8(q)
+        n = p.size // 64
+        a, b, same = np.empty((n, 64), np.uint8), np.empty((n, 64), np.uint8), np.empty(n, np.uint8)
+        self._ck(self._lib.mina_selftest_group_law(self._h, curve, ctypes.c_size_t(n), _p(p), _p(q), _p(a), _p(b), _p(same)), "mina_selftest_group_law")
+        return a, b, same
 
     # -- a10 / a8
     def accumulator_check_batch(self, curve: int, k: int, prechallenges, sg, rho=None) -> np.ndarray:

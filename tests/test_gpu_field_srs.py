@@ -74,3 +74,29 @@ def test_srs_load_roundtrip_and_small_depth(ctx_srs, oracle):
         c3.close()
     finally:
         c2.close()
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+def test_cooperative_group_law_matches_single_lane(ctx, oracle, srs_oracle, curve):
+    """4-lane cooperative XYZZ add/double == single-lane routines word for word (incl. the P == Q, P == -Q and
+    infinity branches), and both == the CPU oracle on the resulting points."""
+    g, _ = srs_oracle[curve]
+    n = 300
+    p = g[:n].copy(); q = g[n:2 * n].copy()
+    q[5] = p[5]                      # P == Q at the first add
+    q[6] = p[6]; q[6, 32:] = oracle.int_to_le(MODS[0 if curve == 0 else 1] - oracle.le_to_int(p[6, 32:]))   # Q == -P
+    p[7] = 0                         # infinity inputs
+    q[8] = 0
+    p[9] = 0; q[9] = 0
+    a, b, same = ctx.selftest_group_law(curve, p, q)
+    assert same.all()
+    assert (a == b).all()
+    # oracle: S = ((P+Q)*2 + Q)*2 ; result = S + (S + P)
+    for i in (0, 1, 5, 6, 7, 8, 9, 123, n - 1):
+        s = oracle.point_add(curve, p[i], q[i])
+        s = oracle.point_add(curve, s, s)
+        s = oracle.point_add(curve, s, q[i])
+        s = oracle.point_add(curve, s, s)
+        t = oracle.point_add(curve, s, p[i])
+        s = oracle.point_add(curve, s, t)
+        assert (a[i] == s).all(), i
