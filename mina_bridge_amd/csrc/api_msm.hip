@@ -37,6 +37,8 @@ static int run_msm(mina_ctx *c, const MsmShape &sh, const uint32_t *d_scalars, c
     if (sh.NB < 128 || sh.NB > 32768) return fail(MINA_ERR_ARG, "unsupported bucket count");
     if ((rc = w.red_r.ensure((size_t)(sh.NB / 128) * sh.nsets * sizeof(xyzz_t)))) return rc;
     if ((rc = w.red_ws.ensure((size_t)128 * sh.nsets * sizeof(xyzz_t)))) return rc;
+    if ((rc = w.red2_r.ensure((size_t)24 * sh.nsets * sizeof(xyzz_t)))) return rc;
+    if ((rc = w.red2_w.ensure((size_t)24 * sh.nsets * sizeof(xyzz_t)))) return rc;
     if ((rc = w.set_total.ensure((size_t)sh.nsets * sizeof(xyzz_t)))) return rc;
 
     hipStream_t st = c->L->stream;
@@ -62,7 +64,10 @@ static int run_msm(mina_ctx *c, const MsmShape &sh, const uint32_t *d_scalars, c
         const uint32_t threads_rows = rows.nseg * rows.lanes * 4, threads_cols = cols.nseg * cols.lanes * 4;   // 4 lanes per quad
         const uint32_t blocks = cdiv(threads_rows > threads_cols ? threads_rows : threads_cols, 256);
         { ProfScope ps_(c, PS_REDUCE_A); msm_segsum_kernel<F><<<dim3(blocks, 2), 256, 0, st>>>(sh.NB, rows, cols, w.buckets.as<xyzz_t>(), w.red_r.as<xyzz_t>(), w.red_ws.as<xyzz_t>()); }
-        { ProfScope ps_(c, PS_REDUCE_BC); msm_reduce2d_kernel<F><<<sh.nsets, 384, 0, st>>>(R, C, log2C, w.red_r.as<xyzz_t>(), w.red_ws.as<xyzz_t>(), w.set_total.as<xyzz_t>()); }
+        const uint32_t Gr = (R + 15) / 16, Gc = C / 16;
+        { ProfScope ps_(c, PS_REDUCE_BC);
+          msm_wsum16_kernel<F><<<dim3(Gr + Gc, sh.nsets), 64, 0, st>>>(R, C, Gr, w.red_r.as<xyzz_t>(), w.red_ws.as<xyzz_t>(), w.red2_r.as<xyzz_t>(), w.red2_w.as<xyzz_t>());
+          msm_reduce2d_kernel<F><<<sh.nsets, 256, 0, st>>>(Gr, Gc, log2C, w.red2_r.as<xyzz_t>(), w.red2_w.as<xyzz_t>(), w.set_total.as<xyzz_t>()); }
     }
     { ProfScope ps_(c, PS_FINISH); msm_finish_kernel<F><<<1, 64, 0, st>>>(sh.nsets, sh.c, w.set_total.as<xyzz_t>(), fk.one, fk.pm2, d_out_xyzz, d_out_words); }
     HIPC(hipGetLastError());

@@ -382,47 +382,86 @@ msm_segsum_kernel(uint32_t nb_per_set, SegSum rows, SegSum cols, const xyzz_t *_
     if (live && sub == 0 && (gid & 3u) == 0) out[seg] = acc;
 }
 
-// K1g: one block of 6 waves per bucket set.  Waves 0-3: weighted sum over the (<= 256) rows; waves 4-5: over the
-// (<= 128) columns; then three lanes combine concurrently.
+// quad-replicated wave collectives: every value lives on the 4 lanes of a quad (16 values per wave), adds are
+// lane-cooperative.  quad 0 gets  sum_q v_q  (in `sum`) and  sum_q q * v_q  (returned), q < width <= 16.
+template <int F> __device__ __forceinline__ xyzz_t quadwave_sum(xyzz_t v, int width) {
+    const int q = (threadIdx.x & 63) >> 2;
+#pragma unroll 1
+    for (int d = width >> 1; d >= 1; d >>= 1) {
+        xyzz_t o = shfl_down_xyzz(v, 4 * d);
+        if (q + d < width) xyzz_add_quad<F>(v, o);
+    }
+    return v;
+}
+template <int F> __device__ __forceinline__ xyzz_t quadwave_weighted_sum(xyzz_t v, xyzz_t &sum, int width) {
+    const int q = (threadIdx.x & 63) >> 2;
+#pragma unroll 1
+    for (int d = 1; d < width; d <<= 1) {                    // suffix scan over quads
+        xyzz_t o = shfl_down_xyzz(v, 4 * d);
+        if (q + d < width) xyzz_add_quad<F>(v, o);
+    }
+    sum = v;
+    if (q == 0) v = xyzz_inf();
+    return quadwave_sum<F>(v, width);
+}
+
+// K1g: weighted sums over groups of 16 consecutive rows / columns.  Block (g, set), one wave:
+//   g <  Gr : rows  16g .. 16g+15  ->  (S, W) = (sum_i Row, sum_i i*Row)      g >= Gr : the same for columns
 template <int F>
-__global__ void __launch_bounds__(384)
-msm_reduce2d_kernel(uint32_t R, uint32_t C, uint32_t log2C, const xyzz_t *__restrict__ rows, const xyzz_t *__restrict__ cols,
+__global__ void __launch_bounds__(64)
+msm_wsum16_kernel(uint32_t R, uint32_t C, uint32_t Gr, const xyzz_t *__restrict__ rows, const xyzz_t *__restrict__ cols,
+                  xyzz_t *__restrict__ out_s, xyzz_t *__restrict__ out_w) {
+    const uint32_t g = blockIdx.x, set = blockIdx.y, q = threadIdx.x >> 2;
+    const uint32_t Gc = (C + 15) / 16, G = Gr + Gc;
+    xyzz_t v = xyzz_inf();
+    if (g < Gr) { const uint32_t r = g * 16 + q; if (r < R) v = rows[(size_t)set * R + r]; }
+    else { const uint32_t c = (g - Gr) * 16 + q; if (c < C) v = cols[(size_t)set * C + c]; }
+    xyzz_t sum;
+    xyzz_t ws = quadwave_weighted_sum<F>(v, sum, 16);
+    if (threadIdx.x == 0) { out_s[(size_t)set * G + g] = sum; out_w[(size_t)set * G + g] = ws; }
+}
+
+// K1g': one block of 4 waves per bucket set combines the group results:
+//   sum_r r*Row_r = 16 * sum_j j*S_j + sum_j W_j   (row groups j < Gr <= 16), likewise for the columns (Gc = 8), then
+//   set total = Tot + C * sum_r r*Row_r + sum_c c*Col_c,   Tot = sum_j S_j
+template <int F>
+__global__ void __launch_bounds__(256)
+msm_reduce2d_kernel(uint32_t Gr, uint32_t Gc, uint32_t log2C, const xyzz_t *__restrict__ in_s, const xyzz_t *__restrict__ in_w,
                     xyzz_t *__restrict__ set_total) {
-    const uint32_t set = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    __shared__ xyzz_t sh_s[6], sh_w[6], sh_colw, sh_tot;
-    {
-        xyzz_t v = xyzz_inf();
-        if (wave < 4) { uint32_t r = wave * 64 + lane; if (r < R) v = rows[(size_t)set * R + r]; }
-        else { uint32_t c = (wave - 4) * 64 + lane; if (c < C) v = cols[(size_t)set * C + c]; }
-        const bool needed = (wave < 4) ? (wave * 64 < R) : ((wave - 4) * 64 < C);
-        xyzz_t sum = xyzz_inf(), ws = xyzz_inf();
-        if (needed) ws = wave_weighted_sum<F>(v, sum);        // wave-uniform branch
-        if (lane == 0) { sh_s[wave] = sum; sh_w[wave] = ws; }
+    const uint32_t set = blockIdx.x, wave = threadIdx.x >> 6, q = (threadIdx.x & 63) >> 2, G = Gr + Gc;
+    __shared__ xyzz_t sh_tot, sh_roww, sh_ww[2], sh_colw;
+    const xyzz_t *s = in_s + (size_t)set * G, *w = in_w + (size_t)set * G;
+    auto p2 = [](uint32_t n) { int wd = 1; while (wd < (int)n) wd <<= 1; return wd; };
+    xyzz_t sw = xyzz_inf(), tot = xyzz_inf();
+    if (wave == 0) {                                          // rows: Tot and sum_j j*S_j
+        xyzz_t v = (q < Gr) ? s[q] : xyzz_inf();
+        sw = quadwave_weighted_sum<F>(v, tot, p2(Gr));
+    } else if (wave == 1) {                                   // rows: sum_j W_j
+        xyzz_t v = (q < Gr) ? w[q] : xyzz_inf();
+        v = quadwave_sum<F>(v, p2(Gr));
+        if (threadIdx.x == 64) sh_ww[0] = v;
+    } else if (wave == 2) {                                   // columns: sum_j j*S'_j
+        xyzz_t v = (q < Gc) ? s[Gr + q] : xyzz_inf();
+        xyzz_t dummy;
+        sw = quadwave_weighted_sum<F>(v, dummy, p2(Gc));
+    } else {                                                  // columns: sum_j W'_j
+        xyzz_t v = (q < Gc) ? w[Gr + q] : xyzz_inf();
+        v = quadwave_sum<F>(v, p2(Gc));
+        if (threadIdx.x == 192) sh_ww[1] = v;
     }
     __syncthreads();
-    // final combination: three quads (lane-cooperative group law) work concurrently
-    xyzz_t t = xyzz_inf();
-    const uint32_t quad = threadIdx.x >> 2;
-    if (quad == 0) {
-        // sum_r r*Row_r = W0+W1+W2+W3 + 64*(S1 + 2 S2 + 3 S3)
-        xyzz_t a = sh_s[1]; xyzz_add_quad<F>(a, sh_s[3]);
-        xyzz_t b = sh_s[2]; xyzz_add_quad<F>(b, sh_s[3]);
-        t = xyzz_dbl_quad<F>(b); xyzz_add_quad<F>(t, a);
-        for (int i = 0; i < 6; ++i) t = xyzz_dbl_quad<F>(t);
-        xyzz_t ww = sh_w[0]; xyzz_add_quad<F>(ww, sh_w[1]); xyzz_t w2 = sh_w[2]; xyzz_add_quad<F>(w2, sh_w[3]); xyzz_add_quad<F>(ww, w2);
-        xyzz_add_quad<F>(t, ww);
-        for (uint32_t i = 0; i < log2C; ++i) t = xyzz_dbl_quad<F>(t);     // * C
-    } else if (quad == 16) {
-        xyzz_t u = sh_s[5];
-        for (int i = 0; i < 6; ++i) u = xyzz_dbl_quad<F>(u);
-        xyzz_add_quad<F>(u, sh_w[4]); xyzz_add_quad<F>(u, sh_w[5]);
-        if ((threadIdx.x & 3u) == 0) sh_colw = u;                          // sum_c c*Col_c
-    } else if (quad == 32) {
-        xyzz_t u = sh_s[0]; xyzz_add_quad<F>(u, sh_s[1]); xyzz_t v2 = sh_s[2]; xyzz_add_quad<F>(v2, sh_s[3]); xyzz_add_quad<F>(u, v2);
-        if ((threadIdx.x & 3u) == 0) sh_tot = u;                           // Tot
+    if ((wave == 0 || wave == 2) && q == 0) {                 // quad 0 of waves 0 and 2: 16 * SW + WW
+        xyzz_t t = sw;
+        for (int i = 0; i < 4; ++i) t = xyzz_dbl_quad<F>(t);
+        xyzz_add_quad<F>(t, sh_ww[wave >> 1]);
+        if (wave == 0) { for (uint32_t i = 0; i < log2C; ++i) t = xyzz_dbl_quad<F>(t); }     // * C
+        if ((threadIdx.x & 63) == 0) { if (wave == 0) { sh_roww = t; sh_tot = tot; } else sh_colw = t; }
     }
     __syncthreads();
-    if (quad == 0) { xyzz_add_quad<F>(t, sh_colw); xyzz_add_quad<F>(t, sh_tot); if (threadIdx.x == 0) set_total[set] = t; }
+    if (threadIdx.x < 4) {
+        xyzz_t t = sh_roww; xyzz_add_quad<F>(t, sh_colw); xyzz_add_quad<F>(t, sh_tot);
+        if (threadIdx.x == 0) set_total[set] = t;
+    }
 }
 
 // K1h: Horner over bucket sets (variable-base), then normalise to affine (Montgomery) + canonical words.
