@@ -88,7 +88,8 @@ static __global__ void msm_digits_kernel(MsmShape sh, const uint32_t *__restrict
 // fully coalesced 16-byte-per-lane access (a lane-contiguous chunking made each store instruction touch 64 lines).
 // Pass 1 totals the remainder classes (their offsets are needed before ranks can be assigned), pass 2 emits.
 template <int NV>
-__device__ __forceinline__ void block_exclusive_scan(uint32_t (&v)[NV], uint32_t (&total)[NV], uint32_t (*s_tot)[16]) {
+__device__ __forceinline__ void block_exclusive_scan(uint32_t (&v)[NV], uint32_t (&total)[NV], uint32_t (*s_tot)[16],
+                                                     uint32_t (*s_pre)[16], uint32_t *s_all) {
     // in: per-lane values; out: v = exclusive prefix over the block (lane order), total = block totals
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
     uint32_t own[NV];
@@ -99,21 +100,33 @@ __device__ __forceinline__ void block_exclusive_scan(uint32_t (&v)[NV], uint32_t
 #pragma unroll
         for (int k = 0; k < NV; ++k) { uint32_t t = __shfl_up(v[k], d, 64); if ((int)lane >= d) v[k] += t; }
     }
-    __syncthreads();                                          // s_tot may still be read from the previous call
+    __syncthreads();                                          // LDS arrays may still be read from the previous call
     if (lane == 63) {
 #pragma unroll
         for (int k = 0; k < NV; ++k) s_tot[k][wave] = v[k];
     }
     __syncthreads();
-    uint32_t before[NV];
+    if (wave == 0) {                                          // one wave scans the (<= 16) wave totals
+        uint32_t t[NV], own_t[NV];
 #pragma unroll
-    for (int k = 0; k < NV; ++k) { before[k] = 0; total[k] = 0; }
-    for (uint32_t w = 0; w < nwaves; ++w) {
+        for (int k = 0; k < NV; ++k) { t[k] = (lane < nwaves) ? s_tot[k][lane & 15] : 0u; own_t[k] = t[k]; }
 #pragma unroll
-        for (int k = 0; k < NV; ++k) { uint32_t t = s_tot[k][w]; total[k] += t; if (w < wave) before[k] += t; }
+        for (int d = 1; d < 16; d <<= 1) {
+#pragma unroll
+            for (int k = 0; k < NV; ++k) { uint32_t u = __shfl_up(t[k], d, 64); if ((int)lane >= d) t[k] += u; }
+        }
+        if (lane < 16) {
+#pragma unroll
+            for (int k = 0; k < NV; ++k) s_pre[k][lane] = t[k] - own_t[k];
+        }
+        if (lane == 15) {
+#pragma unroll
+            for (int k = 0; k < NV; ++k) s_all[k] = t[k];
+        }
     }
+    __syncthreads();
 #pragma unroll
-    for (int k = 0; k < NV; ++k) v[k] = before[k] + v[k] - own[k];
+    for (int k = 0; k < NV; ++k) { total[k] = s_all[k]; v[k] = s_pre[k][wave] + v[k] - own[k]; }
 }
 
 static __global__ void __launch_bounds__(1024)
@@ -122,7 +135,7 @@ msm_scan_kernel(uint32_t nb_total, const uint32_t *__restrict__ count, uint32_t 
                 uint32_t *__restrict__ info /* 2 */) {
     constexpr int NCLS = MSM_TASK_LEN - 1;                     // class kappa = L-1-r  (r = L-1 .. 1)
     constexpr int NV = 2 + NCLS;
-    __shared__ uint32_t s_tot[NV][16];
+    __shared__ uint32_t s_tot[NV][16], s_pre[NV][16], s_all[NV];
     const uint32_t tid = threadIdx.x;
     const uint32_t row_elems = blockDim.x * 4;
     const uint32_t nrows = (nb_total + row_elems - 1) / row_elems;       // nb_total is a multiple of 4 (power of two >= 128)
@@ -161,7 +174,7 @@ msm_scan_kernel(uint32_t nb_total, const uint32_t *__restrict__ count, uint32_t 
                 for (int k = 0; k < NCLS; ++k) v[2 + k] += (r == (uint32_t)(MSM_TASK_LEN - 1 - k)) ? 1u : 0u;
             }
         }
-        block_exclusive_scan<NV>(v, cls_tot, s_tot);
+        block_exclusive_scan<NV>(v, cls_tot, s_tot, s_pre, s_all);
     }
     uint32_t carry[NV];                                       // running offsets: entries, full tasks, rank within each class
     carry[0] = 0; carry[1] = 0;
@@ -185,7 +198,7 @@ msm_scan_kernel(uint32_t nb_total, const uint32_t *__restrict__ count, uint32_t 
 #pragma unroll
             for (int k = 0; k < NCLS; ++k) v[2 + k] += (r == (uint32_t)(MSM_TASK_LEN - 1 - k)) ? 1u : 0u;
         }
-        block_exclusive_scan<NV>(v, tot, s_tot);
+        block_exclusive_scan<NV>(v, tot, s_tot, s_pre, s_all);
         uint32_t pc = carry[0] + v[0], pf = carry[1] + v[1], rk[NCLS];
 #pragma unroll
         for (int k = 0; k < NCLS; ++k) rk[k] = carry[2 + k] + v[2 + k];
