@@ -15,31 +15,37 @@
 
 namespace mb {
 
-// mina-poseidon `ArithmeticSponge` state machine (rate 2) over base field F, Montgomery state.
+// mina-poseidon `ArithmeticSponge` state machine (rate 2) over base field F, Montgomery state, lane-cooperative:
+// the three state elements live on lanes 0..2 of a DPP quad (`s` = this lane's element), the position (squeezed, count)
+// is replicated.  Absorbed values and squeezed results are replicated on all four lanes.
 template <int F> struct DevSponge {
-    fe_t s[3]; int squeezed; int count; const PoseidonParams *pp;
+    fe_t s; int squeezed; int count; const PoseidonParams *pp;
+    __device__ void add_at(int pos, const fe_t &x) { if ((int)(threadIdx.x & 3u) == pos) s = fe_add<F>(s, x); }
+    __device__ fe_t get(int pos) { return pos == 0 ? quad_bcast<0>(s) : (pos == 1 ? quad_bcast<1>(s) : quad_bcast<2>(s)); }
     __device__ void absorb(const fe_t &x) {
         if (!squeezed) {
-            if (count == 2) { poseidon_permute<F>(s, pp); s[0] = fe_add<F>(s[0], x); count = 1; }
-            else { s[count] = fe_add<F>(s[count], x); ++count; }
-        } else { s[0] = fe_add<F>(s[0], x); squeezed = 0; count = 1; }
+            if (count == 2) { poseidon_permute_quad<F>(s, pp); add_at(0, x); count = 1; }
+            else { add_at(count, x); ++count; }
+        } else { add_at(0, x); squeezed = 0; count = 1; }
     }
     __device__ fe_t squeeze() {
-        if (!squeezed || count == 2) { poseidon_permute<F>(s, pp); squeezed = 1; count = 1; return s[0]; }
-        return s[count++];
+        if (!squeezed || count == 2) { poseidon_permute_quad<F>(s, pp); squeezed = 1; count = 1; return get(0); }
+        return get(count++);
     }
 };
 
 struct IpaShape { uint32_t batch, k, npts, ncomms, per; };   // per = 2k + ncomms + 4 points per proof
 
 template <int F> __device__ __forceinline__ fe_t load_fe(const uint32_t *p) { fe_t r; for (int i = 0; i < 8; ++i) r.v[i] = p[i]; return r; }
-__device__ __forceinline__ void store_fe(uint32_t *p, const fe_t &a) { for (int i = 0; i < 8; ++i) p[i] = a.v[i]; }
+__device__ __forceinline__ void store_fe(uint32_t *p, const fe_t &a) { if ((threadIdx.x & 3u) == 0) for (int i = 0; i < 8; ++i) p[i] = a.v[i]; }
+__device__ __forceinline__ void store_pt(affine_t *p, const affine_t &a) { if ((threadIdx.x & 3u) == 0) *p = a; }
 
 template <int FB> __device__ __forceinline__ affine_t load_point_mont(const uint32_t *p, const FieldK &kb) {
     affine_t a; a.x = fe_to_mont<FB>(load_fe<FB>(p), kb.r2); a.y = fe_to_mont<FB>(load_fe<FB>(p + 8), kb.r2); return a;
 }
 
-// One lane per proof.  CURVE fixes (base field FB, scalar field FS).
+// One DPP quad per proof: the Fq-sponge runs lane-cooperatively (7 dependent products per Poseidon round instead of 21),
+// all other (scalar-field) work is computed redundantly by the four lanes, lane 0 writes.  CURVE fixes (FB, FS).
 template <int CURVE>
 __global__ void __launch_bounds__(64)
 ipa_prepare_kernel(IpaShape sh, FieldK kb, FieldK ks, const PoseidonParams *__restrict__ pp,
@@ -55,13 +61,15 @@ ipa_prepare_kernel(IpaShape sh, FieldK kb, FieldK ks, const PoseidonParams *__re
                    uint32_t *__restrict__ out_chals /* b*k*8 canonical */, uint32_t *__restrict__ out_sigma /* b*8 canonical */) {
     constexpr int FB = (CURVE == CURVE_PALLAS) ? FIELD_FP : FIELD_FQ;
     constexpr int FS = (CURVE == CURVE_PALLAS) ? FIELD_FQ : FIELD_FP;
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= sh.batch) return;
+    const uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+    if (b >= sh.batch) return;                                // whole quads leave together
     const uint32_t k = sh.k;
+    const bool writer = (threadIdx.x & 3u) == 0;
 
     // ---- Fq-sponge transcript (base field)
     DevSponge<FB> sp; sp.pp = pp; sp.squeezed = 0; sp.count = 0;
-    for (int i = 0; i < 3; ++i) sp.s[i] = fe_to_mont<FB>(load_fe<FB>(sponge_state + (size_t)b * 24 + i * 8), kb.r2);
+    { const uint32_t q = threadIdx.x & 3u, qq = q < 3 ? q : 2;
+      sp.s = fe_to_mont<FB>(load_fe<FB>(sponge_state + (size_t)b * 24 + qq * 8), kb.r2); }
     sp.squeezed = (int)sponge_pos[2 * b]; sp.count = (int)sponge_pos[2 * b + 1];
     const fe_t cip_m = fe_to_mont<FS>(load_fe<FS>(cip + (size_t)b * 8), ks.r2);
     {   // absorb_fr(shift_scalar(cip))
@@ -96,6 +104,7 @@ ipa_prepare_kernel(IpaShape sh, FieldK kb, FieldK ks, const PoseidonParams *__re
         }
     }
 
+    fe_t chal_m[20];                                          // k <= 20
     // challenges: absorb L_j, R_j ; squeeze 128 bits ; endo-expand.  Points go straight to the output list.
     // layout of the per-proof list: [h, sg, U, delta, L_0, R_0, ..., L_{k-1}, R_{k-1}, comm_0 .. comm_{m-1}]
     for (uint32_t j = 0; j < k; ++j) {
@@ -106,8 +115,9 @@ ipa_prepare_kernel(IpaShape sh, FieldK kb, FieldK ks, const PoseidonParams *__re
         fe_t sq = fe_from_mont<FB>(sp.squeeze());
         uint64_t lo = (uint64_t)sq.v[0] | ((uint64_t)sq.v[1] << 32), hi = (uint64_t)sq.v[2] | ((uint64_t)sq.v[3] << 32);
         fe_t chal = challenge_to_field<FS>(lo, hi, ks);
+        chal_m[j] = chal;                                     // Montgomery copy for the scalar work below
         store_fe(out_chals + ((size_t)b * k + j) * 8, fe_from_mont<FS>(chal));
-        pts[4 + 2 * j] = L; pts[5 + 2 * j] = R;
+        store_pt(&pts[4 + 2 * j], L); store_pt(&pts[5 + 2 * j], R);
     }
     const affine_t D = load_point_mont<FB>(delta + (size_t)b * 16, kb);
     sp.absorb(D.x); sp.absorb(D.y);
@@ -124,8 +134,7 @@ ipa_prepare_kernel(IpaShape sh, FieldK kb, FieldK ks, const PoseidonParams *__re
     for (uint32_t p = 0; p < sh.npts; ++p) {
         fe_t pw = fe_to_mont<FS>(load_fe<FS>(evalpoints + ((size_t)b * sh.npts + p) * 8), ks.r2), acc = ks.one;
         for (int i = (int)k - 1; i >= 0; --i) {
-            fe_t ch = fe_to_mont<FS>(load_fe<FS>(out_chals + ((size_t)b * k + i) * 8), ks.r2);
-            acc = fe_mul<FS>(acc, fe_add<FS>(ks.one, fe_mul<FS>(ch, pw)));
+            acc = fe_mul<FS>(acc, fe_add<FS>(ks.one, fe_mul<FS>(chal_m[i], pw)));
             pw = fe_sqr<FS>(pw);
         }
         b0 = fe_add<FS>(b0, fe_mul<FS>(scale, acc));
@@ -137,21 +146,27 @@ ipa_prepare_kernel(IpaShape sh, FieldK kb, FieldK ks, const PoseidonParams *__re
     const fe_t neg_rho = fe_neg<FS>(rho);
     const fe_t rho_c = fe_mul<FS>(rho, c);
 
-    pts[0] = *srs_h;                         store_fe(scs + 0 * 8, fe_from_mont<FS>(fe_mul<FS>(neg_rho, z2m)));
-    pts[1] = load_point_mont<FB>(sg + (size_t)b * 16, kb);
+    store_pt(&pts[0], *srs_h);               store_fe(scs + 0 * 8, fe_from_mont<FS>(fe_mul<FS>(neg_rho, z2m)));
+    store_pt(&pts[1], load_point_mont<FB>(sg + (size_t)b * 16, kb));
     store_fe(scs + 1 * 8, fe_from_mont<FS>(fe_sub<FS>(fe_mul<FS>(neg_rho, z1m), sigma)));
-    pts[2] = U;
+    store_pt(&pts[2], U);
     store_fe(scs + 2 * 8, fe_from_mont<FS>(fe_add<FS>(fe_mul<FS>(fe_mul<FS>(neg_rho, z1m), b0), fe_mul<FS>(rho_c, cip_m))));
-    pts[3] = D;                              store_fe(scs + 3 * 8, fe_from_mont<FS>(rho));
-    for (uint32_t j = 0; j < k; ++j) {
-        fe_t ch = fe_to_mont<FS>(load_fe<FS>(out_chals + ((size_t)b * k + j) * 8), ks.r2);
-        store_fe(scs + (size_t)(4 + 2 * j) * 8, fe_from_mont<FS>(fe_mul<FS>(rho_c, fe_inv<FS>(ch, ks))));
-        store_fe(scs + (size_t)(5 + 2 * j) * 8, fe_from_mont<FS>(fe_mul<FS>(rho_c, ch)));
+    store_pt(&pts[3], D);                    store_fe(scs + 3 * 8, fe_from_mont<FS>(rho));
+    {   // chal^-1 for all rounds with ONE inversion (Montgomery's trick, as upstream's ark_ff::batch_inversion)
+        fe_t pre[20]; fe_t run = ks.one;
+        for (uint32_t j = 0; j < k; ++j) { pre[j] = run; run = fe_mul<FS>(run, chal_m[j]); }
+        fe_t inv_run = fe_inv<FS>(run, ks);
+        for (int j = (int)k - 1; j >= 0; --j) {
+            const fe_t ch_inv = fe_mul<FS>(inv_run, pre[j]);
+            inv_run = fe_mul<FS>(inv_run, chal_m[j]);
+            store_fe(scs + (size_t)(4 + 2 * j) * 8, fe_from_mont<FS>(fe_mul<FS>(rho_c, ch_inv)));
+            store_fe(scs + (size_t)(5 + 2 * j) * 8, fe_from_mont<FS>(fe_mul<FS>(rho_c, chal_m[j])));
+        }
     }
     const fe_t xi = fe_to_mont<FS>(load_fe<FS>(polyscale + (size_t)b * 8), ks.r2);
     fe_t xi_i = ks.one;
     for (uint32_t i = 0; i < sh.ncomms; ++i) {
-        pts[4 + 2 * k + i] = load_point_mont<FB>(comms + ((size_t)b * sh.ncomms + i) * 16, kb);
+        store_pt(&pts[4 + 2 * k + i], load_point_mont<FB>(comms + ((size_t)b * sh.ncomms + i) * 16, kb));
         store_fe(scs + (size_t)(4 + 2 * k + i) * 8, fe_from_mont<FS>(fe_mul<FS>(rho_c, xi_i)));
         xi_i = fe_mul<FS>(xi_i, xi);
     }
@@ -312,7 +327,7 @@ extern "C" int mina_ipa_batch_check(mina_ctx *c, int curve, size_t batch, const 
     if ((rc = c->L->ipa_verdict.ensure(4))) return rc;
     const PoseidonParams *pp = c->pparams[FB].as<PoseidonParams>();
 #define IPA_PREP(CV)                                                                                                          \
-    mb::ipa_prepare_kernel<CV><<<cdiv(batch, 64), 64, 0, c->L->stream>>>(                                                         \
+    mb::ipa_prepare_kernel<CV><<<cdiv(batch * 4, 64), 64, 0, c->L->stream>>>(                                                         \
         sh, c->fk[FB], c->fk[FS], pp, W(o_state), W(o_pos), W(o_cip), W(o_lr), W(o_delta), W(o_sg), W(o_z1), W(o_z2), W(o_pts), W(o_r), \
         W(o_xi), W(o_comms), W(o_rb), W(o_sb), s.h.as<affine_t>(), c->L->ipa_points.as<affine_t>(), c->L->ipa_scalars.as<uint32_t>(), \
         c->L->ipa_chals.as<uint32_t>(), c->L->ipa_sigma.as<uint32_t>())
