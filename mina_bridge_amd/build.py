@@ -61,5 +61,14 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
+def build_microbench() -> str:
+    """the VALU instruction-rate probe (mina_bridge_amd/microbench), not part of the library"""
+    out = os.path.join(HERE, "microbench")
+    subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-o", out, os.path.join(CSRC, "microbench.hip")])
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    if "--microbench" in sys.argv:
+        print(build_microbench())
