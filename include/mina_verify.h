@@ -196,6 +196,28 @@ int mina_ipa_batch_check(mina_ctx *ctx, int curve, size_t batch, const mina_ipa_
                          const uint8_t *rand_base /* 32 */, const uint8_t *sg_rand_base /* 32 */,
                          uint8_t *verdict /* 1 byte: 1 = all openings valid */);
 
+/* ---- wire formats of the reference (a2, a3, a4) and the inclusion part of Proof-of-Account (a16) -----------------
+ * Host-side, no GPU needed for the parsers.  Layouts: api_wire.hip header / SURVEY.md 8a.  Malformed input -> MINA_ERR_FORMAT. */
+typedef struct {
+    uint8_t is_state_proof_from_devnet;
+    uint8_t bridge_tip_state_hash[32];
+    uint8_t candidate_chain_state_hashes[16][32];
+    uint8_t candidate_chain_ledger_hashes[16][32];
+} mina_state_pub_inputs;                       /* core/src/proof/state_proof.rs:10-25, 1057 bytes on the wire */
+int mina_parse_state_pub_inputs(const uint8_t *bytes, size_t len, mina_state_pub_inputs *out);
+/* MinaAccountPubInputs (account_proof.rs:18-25): ledger hash + where the ABI-encoded account sits in `bytes` */
+int mina_parse_account_pub_inputs(const uint8_t *bytes, size_t len, uint8_t *ledger_hash /* 32 */, size_t *encoded_offset,
+                                  size_t *encoded_len);
+/* merkle_path prefix of a bincode MinaAccountProof (account_proof.rs:9-14,30-35): dirs[i] = 0 Left / 1 Right */
+int mina_parse_merkle_path(const uint8_t *proof, size_t len, uint32_t max_depth, uint8_t *siblings /* max_depth*32 */,
+                           uint8_t *dirs /* max_depth */, uint32_t *depth, size_t *account_offset);
+/* Batched inclusion check of `verify_account_inclusion` (README.md:358-362): for each i parse proof i's Merkle path and
+ * pub input i's ledger hash, fold leaf_hashes[i] along the path on the GPU and compare.  The leaf (account) hash is
+ * supplied by the caller: hashing the binprot account is a "next" row.  Malformed entries -> verdict 0. */
+int mina_verify_account_inclusion(mina_ctx *ctx, size_t n, const uint8_t *const *proofs, const size_t *proof_lens,
+                                  const uint8_t *const *pub_inputs, const size_t *pub_lens, const uint8_t *leaf_hashes /* n*32 */,
+                                  uint8_t *verdicts /* n */);
+
 /* ---- top-level byte contract (a15, a16): NOT YET EXPORTED ------------------------------------
  * mina_verify_state / mina_verify_account (same (ptr,len,ptr,len) shape as Aligned's
  * verify_mina_state_ffi / verify_account_inclusion_ffi) need the bincode/binprot container parsers and

@@ -1,0 +1,106 @@
+// api_wire.hip -- the in-tree wire formats either side of the hot path and the
+// Proof-of-Account inclusion check built on the GPU Merkle fold (a16, inclusion part).
+//
+// Byte layouts (bincode 1.3 of the serde derives in the reference):
+//   MinaStatePubInputs   core/src/proof/state_proof.rs:10-25 + sol/serialization.rs:13-61  -- exactly 1057 bytes:
+//       [0] bool, [1..33) bridge tip state hash, [33..545) 16 state hashes, [545..1057) 16 ledger hashes
+//       (offsets double-pinned by MinaStateSettlementExample.sol:92,100,130-135)
+//   MinaAccountPubInputs core/src/proof/account_proof.rs:18-25 + sol/serialization.rs:63-86
+//       ledger_hash (32 B LE Fp) || u64-LE length || ABI-encoded account   (pinned by MinaAccountValidationExample.sol:70)
+//   MinaAccountProof     core/src/proof/account_proof.rs:9-14,30-35
+//       merkle_path: u64-LE count, then per node u32-LE variant (0 = Left, 1 = Right) + SerdeAs<Fp> = u64-LE 32 + 32 B
+//       ([UPSTREAM-RECALL] for the SerdeAs framing), then the binprot-derived account (not parsed here).
+// Field elements must be canonical (< p), as ark's `CanonicalDeserialize` enforces.
+#include "ctx.h"
+
+static bool fp_is_canonical(const uint8_t *b) {
+    // p (Fp) little-endian bytes
+    static const uint8_t P_LE[32] = {0x01, 0x00, 0x00, 0x00, 0xed, 0x30, 0x2d, 0x99, 0x1b, 0xf9, 0x4c, 0x09, 0xfc, 0x98, 0x46, 0x22,
+                                     0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x40};
+    for (int i = 31; i >= 0; --i) { if (b[i] != P_LE[i]) return b[i] < P_LE[i]; }
+    return false;
+}
+static uint64_t rd_u64(const uint8_t *p) { uint64_t v = 0; for (int i = 7; i >= 0; --i) v = (v << 8) | p[i]; return v; }
+static uint32_t rd_u32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+
+extern "C" int mina_parse_state_pub_inputs(const uint8_t *bytes, size_t len, mina_state_pub_inputs *out) {
+    if (!bytes || !out) return fail(MINA_ERR_ARG, "null argument");
+    if (len != 1057) return fail(MINA_ERR_FORMAT, "MinaStatePubInputs must be exactly 1057 bytes");
+    if (bytes[0] > 1) return fail(MINA_ERR_FORMAT, "bool byte must be 0 or 1");
+    for (int i = 0; i < 33; ++i)
+        if (!fp_is_canonical(bytes + 1 + 32 * i)) return fail(MINA_ERR_FORMAT, "hash is not a canonical field element");
+    out->is_state_proof_from_devnet = bytes[0];
+    memcpy(out->bridge_tip_state_hash, bytes + 1, 32);
+    memcpy(out->candidate_chain_state_hashes, bytes + 33, 512);
+    memcpy(out->candidate_chain_ledger_hashes, bytes + 545, 512);
+    return MINA_OK;
+}
+
+extern "C" int mina_parse_account_pub_inputs(const uint8_t *bytes, size_t len, uint8_t *ledger_hash, size_t *encoded_offset, size_t *encoded_len) {
+    if (!bytes || !ledger_hash || !encoded_offset || !encoded_len) return fail(MINA_ERR_ARG, "null argument");
+    if (len < 40) return fail(MINA_ERR_FORMAT, "MinaAccountPubInputs shorter than 40 bytes");
+    if (!fp_is_canonical(bytes)) return fail(MINA_ERR_FORMAT, "ledger hash is not a canonical field element");
+    const uint64_t n = rd_u64(bytes + 32);
+    if (n != len - 40) return fail(MINA_ERR_FORMAT, "encoded_account length prefix does not match the buffer");
+    memcpy(ledger_hash, bytes, 32);
+    *encoded_offset = 40; *encoded_len = (size_t)n;
+    return MINA_OK;
+}
+
+extern "C" int mina_parse_merkle_path(const uint8_t *proof, size_t len, uint32_t max_depth, uint8_t *siblings, uint8_t *dirs,
+                                      uint32_t *depth, size_t *account_offset) {
+    if (!proof || !siblings || !dirs || !depth || !account_offset) return fail(MINA_ERR_ARG, "null argument");
+    if (len < 8) return fail(MINA_ERR_FORMAT, "MinaAccountProof shorter than its length prefix");
+    const uint64_t n = rd_u64(proof);
+    if (n > max_depth) return fail(MINA_ERR_FORMAT, "merkle path longer than max_depth");
+    size_t off = 8;
+    for (uint64_t i = 0; i < n; ++i) {
+        if (len - off < 4 + 8 + 32) return fail(MINA_ERR_FORMAT, "truncated merkle node");
+        const uint32_t tag = rd_u32(proof + off);
+        if (tag > 1) return fail(MINA_ERR_FORMAT, "MerkleNode variant must be 0 (Left) or 1 (Right)");
+        if (rd_u64(proof + off + 4) != 32) return fail(MINA_ERR_FORMAT, "MerkleNode field element must be 32 bytes");
+        if (!fp_is_canonical(proof + off + 12)) return fail(MINA_ERR_FORMAT, "merkle node is not a canonical field element");
+        dirs[i] = (uint8_t)tag;
+        memcpy(siblings + 32 * i, proof + off + 12, 32);
+        off += 44;
+    }
+    *depth = (uint32_t)n; *account_offset = off;
+    return MINA_OK;
+}
+
+extern "C" int mina_verify_account_inclusion(mina_ctx *c, size_t n, const uint8_t *const *proofs, const size_t *proof_lens,
+                                             const uint8_t *const *pubs, const size_t *pub_lens, const uint8_t *leaf_hashes,
+                                             uint8_t *verdicts) {
+    if (!c || (n && (!proofs || !proof_lens || !pubs || !pub_lens || !leaf_hashes || !verdicts))) return fail(MINA_ERR_ARG, "null argument");
+    if (n == 0) return MINA_OK;
+    // parse everything on the host; malformed entries get verdict 0 and are left out of the GPU batch.
+    // Paths of one depth go to the GPU together (ledger depth is fixed per network, so normally one group).
+    constexpr uint32_t MAXD = 64;
+    std::vector<uint8_t> sib(n * MAXD * 32), dir(n * MAXD), ledger(n * 32);
+    std::vector<uint32_t> depth(n, 0); std::vector<uint8_t> ok(n, 0);
+    for (size_t i = 0; i < n; ++i) {
+        verdicts[i] = 0;
+        size_t acc_off = 0, eo = 0, el = 0;
+        if (!proofs[i] || !pubs[i]) continue;
+        if (mina_parse_merkle_path(proofs[i], proof_lens[i], MAXD, &sib[i * MAXD * 32], &dir[i * MAXD], &depth[i], &acc_off) != MINA_OK) continue;
+        if (mina_parse_account_pub_inputs(pubs[i], pub_lens[i], &ledger[i * 32], &eo, &el) != MINA_OK) continue;
+        if (!fp_is_canonical(leaf_hashes + 32 * i)) continue;
+        ok[i] = 1;
+    }
+    for (uint32_t d = 0; d <= MAXD; ++d) {
+        std::vector<size_t> idx;
+        for (size_t i = 0; i < n; ++i) if (ok[i] && depth[i] == d) idx.push_back(i);
+        if (idx.empty()) continue;
+        const size_t m = idx.size();
+        std::vector<uint8_t> l(m * 32), s((size_t)m * d * 32 + 1), dd((size_t)m * d + 1), r(m * 32), v(m);
+        for (size_t j = 0; j < m; ++j) {
+            memcpy(&l[j * 32], leaf_hashes + 32 * idx[j], 32);
+            if (d) { memcpy(&s[j * d * 32], &sib[idx[j] * MAXD * 32], (size_t)d * 32); memcpy(&dd[j * d], &dir[idx[j] * MAXD], d); }
+            memcpy(&r[j * 32], &ledger[idx[j] * 32], 32);
+        }
+        int rc = mina_merkle_verify_batch(c, MINA_FIELD_FP, m, d, l.data(), s.data(), dd.data(), r.data(), v.data());
+        if (rc) return rc;
+        for (size_t j = 0; j < m; ++j) verdicts[idx[j]] = v[j];
+    }
+    return MINA_OK;
+}

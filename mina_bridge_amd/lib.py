@@ -29,11 +29,52 @@ EXPORTS = [
     "mina_challenge_to_field", "mina_to_group", "mina_merkle_roots", "mina_merkle_verify_batch",
     "mina_field_mul", "mina_field_inv", "mina_field_sqrt", "mina_selftest_group_law",
     "mina_accumulator_check_batch", "mina_accumulator_check_dev", "mina_ipa_batch_check",
+    "mina_parse_state_pub_inputs", "mina_parse_account_pub_inputs", "mina_parse_merkle_path", "mina_verify_account_inclusion",
 ]
 
 
 class MinaError(RuntimeError):
     pass
+
+
+class StatePubInputs(ctypes.Structure):
+    _fields_ = [("is_state_proof_from_devnet", ctypes.c_uint8), ("bridge_tip_state_hash", ctypes.c_uint8 * 32),
+                ("candidate_chain_state_hashes", (ctypes.c_uint8 * 32) * 16), ("candidate_chain_ledger_hashes", (ctypes.c_uint8 * 32) * 16)]
+
+
+def parse_state_pub_inputs(data: bytes) -> dict:
+    """MinaStatePubInputs bytes (1057) -> dict; raises MinaError on malformed input.  No GPU needed."""
+    lib = load_library()
+    out = StatePubInputs()
+    b = _u8(data) if len(data) else np.zeros(1, np.uint8)
+    rc = lib.mina_parse_state_pub_inputs(_p(b), ctypes.c_size_t(len(data)), ctypes.byref(out))
+    if rc != 0:
+        raise MinaError(f"mina_parse_state_pub_inputs failed ({rc}): {lib.mina_last_error().decode()}")
+    return {"is_state_proof_from_devnet": bool(out.is_state_proof_from_devnet), "bridge_tip_state_hash": bytes(out.bridge_tip_state_hash),
+            "candidate_chain_state_hashes": [bytes(h) for h in out.candidate_chain_state_hashes],
+            "candidate_chain_ledger_hashes": [bytes(h) for h in out.candidate_chain_ledger_hashes]}
+
+
+def parse_account_pub_inputs(data: bytes):
+    lib = load_library()
+    b = _u8(data) if len(data) else np.zeros(1, np.uint8)
+    lh = np.empty(32, np.uint8); off = ctypes.c_size_t(0); ln = ctypes.c_size_t(0)
+    rc = lib.mina_parse_account_pub_inputs(_p(b), ctypes.c_size_t(len(data)), _p(lh), ctypes.byref(off), ctypes.byref(ln))
+    if rc != 0:
+        raise MinaError(f"mina_parse_account_pub_inputs failed ({rc}): {lib.mina_last_error().decode()}")
+    return lh.tobytes(), data[off.value: off.value + ln.value]
+
+
+def parse_merkle_path(proof: bytes, max_depth: int = 64):
+    lib = load_library()
+    b = _u8(proof) if len(proof) else np.zeros(1, np.uint8)
+    sib = np.empty(max_depth * 32, np.uint8); dirs = np.empty(max_depth, np.uint8)
+    depth = ctypes.c_uint32(0); off = ctypes.c_size_t(0)
+    rc = lib.mina_parse_merkle_path(_p(b), ctypes.c_size_t(len(proof)), ctypes.c_uint32(max_depth), _p(sib), _p(dirs), ctypes.byref(depth), ctypes.byref(off))
+    if rc != 0:
+        raise MinaError(f"mina_parse_merkle_path failed ({rc}): {lib.mina_last_error().decode()}")
+    d = depth.value
+    return sib[: d * 32].reshape(d, 32).copy(), dirs[:d].copy(), off.value
 
 
 class IpaOpening(ctypes.Structure):
@@ -266,6 +307,16 @@ class MinaContext:
         out = np.empty(n, np.uint8)
         self._ck(self._lib.mina_merkle_verify_batch(self._h, field, ctypes.c_size_t(n), ctypes.c_uint32(depth), _p(leaves), _p(siblings), _p(dirs),
                                                     _p(exp), _p(out)), "mina_merkle_verify_batch")
+        return out
+
+    def verify_account_inclusion(self, proofs: list, pub_inputs: list, leaf_hashes) -> np.ndarray:
+        n = len(proofs)
+        pa = [_u8(p) if len(p) else np.zeros(1, np.uint8) for p in proofs]
+        qa = [_u8(p) if len(p) else np.zeros(1, np.uint8) for p in pub_inputs]
+        PP = (ctypes.c_void_p * n)(*[a.ctypes.data for a in pa]); QQ = (ctypes.c_void_p * n)(*[a.ctypes.data for a in qa])
+        PL = (ctypes.c_size_t * n)(*[len(p) for p in proofs]); QL = (ctypes.c_size_t * n)(*[len(p) for p in pub_inputs])
+        lh = _u8(leaf_hashes); out = np.empty(n, np.uint8)
+        self._ck(self._lib.mina_verify_account_inclusion(self._h, ctypes.c_size_t(n), PP, PL, QQ, QL, _p(lh), _p(out)), "mina_verify_account_inclusion")
         return out
 
     # -- K4
