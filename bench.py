@@ -42,7 +42,9 @@ ACCUMULATE_TRAFFIC_BYTES = 88_290_000
 # VALU side of the roofline (the path is integer-multiply bound): one Montgomery product is 88
 # v_mad_u64_u32 (8 cycles per wave64 instruction, profiles/r01_microbench_valu.jsonl) -> issue floor 704 cycles.
 MODMUL_ISSUE_FLOOR_CYCLES = 88 * 8
-MIXED_ADDS_PER_MSM = 16 * N_BASES * (1 - 2 ** -16)    # one per non-zero signed 16-bit digit
+# entries E = one per non-zero signed 16-bit digit; the first entry of every task is a copy, not an add; with Poisson(32)
+# bucket sizes there are E[ceil(c/8)] = 4.4375 tasks per bucket -> adds = E - 32768 * 4.4375
+MIXED_ADDS_PER_MSM = 16 * N_BASES * (1 - 2 ** -16) - 32768 * 4.4375
 MODMUL_PER_MIXED_ADD = 10                                # XYZZ madd-2008-s: 8M + 2S
 CHIP_SIMDS, CLOCK_HZ = 1024, 2.4e9
 
