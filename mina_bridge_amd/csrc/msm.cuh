@@ -482,12 +482,13 @@ msm_reduce2d_kernel(uint32_t Gr, uint32_t Gc, uint32_t log2C, const xyzz_t *__re
 template <int F>
 __global__ void msm_finish_kernel(uint32_t nsets, uint32_t c, const xyzz_t *__restrict__ set_total, fe_t one,
                                   fe_t pm2, xyzz_t *__restrict__ out_xyzz, uint32_t *__restrict__ out_words) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (blockIdx.x != 0 || threadIdx.x >= 4) return;           // one quad: lane-cooperative doublings / adds
     xyzz_t t = set_total[nsets - 1];
     for (int w = (int)nsets - 2; w >= 0; --w) {
-        for (uint32_t i = 0; i < c; ++i) t = xyzz_dbl<F>(t);
-        xyzz_add<F>(t, set_total[w]);
+        for (uint32_t i = 0; i < c; ++i) t = xyzz_dbl_quad<F>(t);
+        xyzz_add_quad<F>(t, set_total[w]);
     }
+    if (threadIdx.x != 0) return;
     if (out_xyzz) *out_xyzz = t;
     if (!out_words) return;
     if (xyzz_is_inf(t)) { for (int i = 0; i < 16; ++i) out_words[i] = 0; out_words[16] = 1; return; }
