@@ -156,3 +156,41 @@ def test_msm_variable_base_adversarial_large(ctx, oracle, srs_oracle):
     g, _ = srs_oracle[curve]
     sc = np.repeat(rand_scalars(1, P, seed=99), n, axis=0)
     assert (ctx.msm(curve, g[:n], sc) == oracle.msm_pippenger(curve, g[:n], sc, threads=8)).all()
+
+
+def test_msm_randomised_stress(ctx_srs, oracle, srs_oracle):
+    """many small random instances with deliberately colliding inputs: repeated points (P == Q inside a bucket -> doubling
+    branches of the mixed, full and cooperative adds), negated repeats (P == -Q -> identity mid-sum), infinity bases,
+    zero / one / tiny / maximal scalars; both curves; variable-base and fixed-base entry points."""
+    rng = np.random.Generator(np.random.PCG64(20250928))
+    for trial in range(120):
+        curve = int(rng.integers(0, 2))
+        r = SCALAR_MOD[curve]; m = P if curve == 0 else Q
+        g, _ = srs_oracle[curve]
+        n = int(rng.choice([1, 2, 3, 7, 8, 9, 63, 64, 65, 200, 777, 2500]))
+        pool = g[rng.integers(0, max(2, n // 4), size=n)].copy()                  # few distinct points -> many repeats
+        neg_mask = rng.random(n) < 0.3
+        for i in np.nonzero(neg_mask)[0]:
+            y = oracle.le_to_int(pool[i, 32:])
+            pool[i, 32:] = oracle.int_to_le(m - y)
+        pool[rng.random(n) < 0.05] = 0                                             # some infinities
+        kind = trial % 4
+        if kind == 0:
+            sc = rand_scalars(n, r, seed=7000 + trial)
+        elif kind == 1:
+            sc = oracle.ints_to_le([int(x) for x in rng.integers(0, 5, size=n)])    # 0..4
+        elif kind == 2:
+            sc = np.repeat(rand_scalars(1, r, seed=7000 + trial), n, axis=0)        # all equal: every repeat collides
+        else:
+            sc = oracle.ints_to_le([(r - 1 - int(x)) for x in rng.integers(0, 3, size=n)])
+        got = ctx_srs.msm(curve, pool, sc)
+        exp = oracle.msm_pippenger(curve, pool, sc, threads=2) if n > 64 else oracle.msm_naive(curve, pool, sc)
+        assert (got == exp).all(), (trial, curve, n, kind)
+    # fixed-base path with tiny and equal scalars on short prefixes of the SRS
+    for trial in range(20):
+        curve = trial & 1
+        r = SCALAR_MOD[curve]
+        g, _ = srs_oracle[curve]
+        n = int(rng.choice([1, 5, 64, 1000, 4097]))
+        sc = oracle.ints_to_le([int(x) for x in rng.integers(0, 3, size=n)]) if trial % 2 else np.repeat(rand_scalars(1, r, seed=trial), n, axis=0)
+        assert (ctx_srs.msm_srs(curve, sc) == oracle.msm_pippenger(curve, g[:n], sc, threads=2)).all(), (trial, n)
