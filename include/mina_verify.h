@@ -218,6 +218,33 @@ int mina_verify_account_inclusion(mina_ctx *ctx, size_t n, const uint8_t *const 
                                   const uint8_t *const *pub_inputs, const size_t *pub_lens, const uint8_t *leaf_hashes /* n*32 */,
                                   uint8_t *verdicts /* n */);
 
+/* ---- Samasika chain selection (spec: reference README.md:619-735 + img/consensus0{3,7,8}.png) -------
+ * Host-side.  The verifier runs it between the candidate tip and the bridge's tip (README.md:290-294). */
+#define MINA_MAX_SUB_WINDOWS 16
+typedef struct {
+    uint32_t slots_per_sub_window;      /* v: window shift, in slots (mainnet 7) */
+    uint32_t sub_windows_per_window;    /* window length in sub-windows (mainnet 11) */
+} mina_consensus_params;
+typedef struct {                        /* fields of ProtocolState.body.consensus_state used by chain selection */
+    uint32_t blockchain_length;
+    uint32_t epoch_count;
+    uint32_t curr_global_slot;
+    uint32_t min_window_density;
+    uint32_t sub_window_densities[MINA_MAX_SUB_WINDOWS];
+    uint8_t staking_lock_checkpoint[32];   /* previous-epoch data */
+    uint8_t next_lock_checkpoint[32];      /* current-epoch data */
+    uint8_t last_vrf_output_hash[32];      /* digest compared lexicographically (hashLastVRF) */
+    uint8_t state_hash[32];                /* hashState, compared lexicographically */
+} mina_consensus_state;
+int mina_consensus_project_window(const mina_consensus_params *p, const mina_consensus_state *s, uint32_t next_global_slot,
+                                  uint32_t *out_window /* sub_windows_per_window entries */);
+int mina_consensus_relative_min_window_density(const mina_consensus_params *p, const mina_consensus_state *a,
+                                               const mina_consensus_state *b, uint32_t *out);
+int mina_consensus_is_short_range(const mina_consensus_state *a, const mina_consensus_state *b);   /* 1 / 0 */
+/* selectSecureChain for one candidate: *candidate_selected = 1 if the candidate replaces the current tip */
+int mina_consensus_select_secure_chain(const mina_consensus_params *p, const mina_consensus_state *tip,
+                                       const mina_consensus_state *candidate, int *candidate_selected);
+
 /* ---- top-level byte contract (a15, a16): NOT YET EXPORTED ------------------------------------
  * mina_verify_state / mina_verify_account (same (ptr,len,ptr,len) shape as Aligned's
  * verify_mina_state_ffi / verify_account_inclusion_ffi) need the bincode/binprot container parsers and

@@ -29,7 +29,8 @@ EXPORTS = [
     "mina_challenge_to_field", "mina_to_group", "mina_merkle_roots", "mina_merkle_verify_batch",
     "mina_field_mul", "mina_field_inv", "mina_field_sqrt", "mina_selftest_group_law",
     "mina_accumulator_check_batch", "mina_accumulator_check_dev", "mina_ipa_batch_check",
-    "mina_parse_state_pub_inputs", "mina_parse_account_pub_inputs", "mina_parse_merkle_path", "mina_verify_account_inclusion",
+    "mina_consensus_project_window", "mina_consensus_relative_min_window_density", "mina_consensus_is_short_range",
+    "mina_consensus_select_secure_chain", "mina_parse_state_pub_inputs", "mina_parse_account_pub_inputs", "mina_parse_merkle_path", "mina_verify_account_inclusion",
 ]
 
 
@@ -75,6 +76,63 @@ def parse_merkle_path(proof: bytes, max_depth: int = 64):
         raise MinaError(f"mina_parse_merkle_path failed ({rc}): {lib.mina_last_error().decode()}")
     d = depth.value
     return sib[: d * 32].reshape(d, 32).copy(), dirs[:d].copy(), off.value
+
+
+class ConsensusParams(ctypes.Structure):
+    _fields_ = [("slots_per_sub_window", ctypes.c_uint32), ("sub_windows_per_window", ctypes.c_uint32)]
+
+
+class ConsensusState(ctypes.Structure):
+    _fields_ = [("blockchain_length", ctypes.c_uint32), ("epoch_count", ctypes.c_uint32), ("curr_global_slot", ctypes.c_uint32),
+                ("min_window_density", ctypes.c_uint32), ("sub_window_densities", ctypes.c_uint32 * 16),
+                ("staking_lock_checkpoint", ctypes.c_uint8 * 32), ("next_lock_checkpoint", ctypes.c_uint8 * 32),
+                ("last_vrf_output_hash", ctypes.c_uint8 * 32), ("state_hash", ctypes.c_uint8 * 32)]
+
+    @classmethod
+    def make(cls, length, epoch, slot, min_density, window, staking_cp=b"", next_cp=b"", vrf=b"", state_hash=b""):
+        s = cls()
+        s.blockchain_length, s.epoch_count, s.curr_global_slot, s.min_window_density = length, epoch, slot, min_density
+        for i, d in enumerate(window):
+            s.sub_window_densities[i] = d
+        for name, val in (("staking_lock_checkpoint", staking_cp), ("next_lock_checkpoint", next_cp), ("last_vrf_output_hash", vrf), ("state_hash", state_hash)):
+            buf = bytes(val).ljust(32, b"\0")[:32]
+            ctypes.memmove(getattr(s, name), buf, 32)
+        return s
+
+
+MAINNET_CONSENSUS = ConsensusParams(7, 11)
+
+
+def consensus_project_window(state, next_slot, params=MAINNET_CONSENSUS):
+    lib = load_library()
+    out = (ctypes.c_uint32 * 16)()
+    rc = lib.mina_consensus_project_window(ctypes.byref(params), ctypes.byref(state), ctypes.c_uint32(next_slot), out)
+    if rc != 0:
+        raise MinaError(f"mina_consensus_project_window failed ({rc}): {lib.mina_last_error().decode()}")
+    return list(out)[: params.sub_windows_per_window]
+
+
+def consensus_relative_min_window_density(a, b, params=MAINNET_CONSENSUS) -> int:
+    lib = load_library()
+    out = ctypes.c_uint32(0)
+    rc = lib.mina_consensus_relative_min_window_density(ctypes.byref(params), ctypes.byref(a), ctypes.byref(b), ctypes.byref(out))
+    if rc != 0:
+        raise MinaError(f"mina_consensus_relative_min_window_density failed ({rc}): {lib.mina_last_error().decode()}")
+    return out.value
+
+
+def consensus_is_short_range(a, b) -> bool:
+    return bool(load_library().mina_consensus_is_short_range(ctypes.byref(a), ctypes.byref(b)))
+
+
+def consensus_select_secure_chain(tip, candidate, params=MAINNET_CONSENSUS) -> bool:
+    """True if the candidate replaces the tip (img/consensus07.png)"""
+    lib = load_library()
+    out = ctypes.c_int(0)
+    rc = lib.mina_consensus_select_secure_chain(ctypes.byref(params), ctypes.byref(tip), ctypes.byref(candidate), ctypes.byref(out))
+    if rc != 0:
+        raise MinaError(f"mina_consensus_select_secure_chain failed ({rc}): {lib.mina_last_error().decode()}")
+    return bool(out.value)
 
 
 class IpaOpening(ctypes.Structure):
