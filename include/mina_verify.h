@@ -92,6 +92,9 @@ uint32_t mina_srs_depth(mina_ctx *ctx, int curve);
 /* copy g[first..first+count) (affine, canonical bytes) / h to host */
 int mina_srs_get_g(mina_ctx *ctx, int curve, uint32_t first, uint32_t count, uint8_t *out_affine);
 int mina_srs_get_h(mina_ctx *ctx, int curve, uint8_t *out_affine);
+/* Lagrange-basis commitments of g[0..2^k) over the radix-2 domain of size 2^k (poly-commitment `SRS::add_lagrange_basis`,
+ * used by kimchi for the public-input commitment): out[i] = (1/n) sum_j w^(-ij) g[j], affine canonical bytes, n*64. */
+int mina_srs_lagrange_basis(mina_ctx *ctx, int curve, uint32_t log2_domain, uint8_t *out_affine);
 /* serialise back to the reference's file format; *len receives the size (2 293 801 for depth 2^16) */
 int mina_srs_serialize(mina_ctx *ctx, int curve, uint8_t *out, size_t cap, size_t *len);
 

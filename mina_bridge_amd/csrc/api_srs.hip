@@ -1,6 +1,7 @@
 // api_srs.hip -- SRS generation / loading / export and the fixed-base window tables (a6).
 #include "ctx.h"
 #include "msm.cuh"
+#include "lagrange.cuh"
 
 // ------------------------------------------------------------------------------------------------
 // SRS
@@ -146,3 +147,45 @@ extern "C" int mina_srs_serialize(mina_ctx *c, int curve, uint8_t *out, size_t c
     return MINA_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Lagrange-basis commitments (poly-commitment `SRS::add_lagrange_basis`)
+template <int FB, int FS>
+static int run_lagrange(mina_ctx *c, SrsState &s, uint32_t k, uint8_t *out_host) {
+    const uint32_t n = 1u << k, half = n / 2;
+    const FieldK &kb = c->fk[FB], &ks = c->fk[FS];
+    // w = root^(2^(32-k)) (primitive n-th root of unity), w_inv = w^(n-1), n_inv = n^(p-2)
+    fe_t w = ks.root;
+    for (uint32_t i = 0; i < 32 - k; ++i) w = fe_sqr<FS>(w);
+    fe_t e = fe_zero(); e.v[0] = n - 1;
+    const fe_t w_inv = fe_pow<FS>(w, e, ks.one);
+    fe_t nn = fe_zero(); nn.v[0] = n;
+    const fe_t n_inv = fe_inv<FS>(fe_to_mont<FS>(nn, ks.r2), ks);
+    int rc;
+    if ((rc = c->L->tmp_a.ensure(((size_t)half + 1) * 32))) return rc;          // twiddles
+    if ((rc = c->L->tmp_b.ensure((size_t)n * sizeof(xyzz_t)))) return rc;       // working array
+    if ((rc = c->L->tmp_c.ensure((size_t)n * sizeof(affine_t)))) return rc;     // affine result (Montgomery)
+    if ((rc = c->L->tmp_d.ensure((size_t)n * 64))) return rc;                   // canonical bytes
+    hipStream_t st = c->L->stream;
+    lagrange_twiddles_kernel<FS><<<cdiv((size_t)half + 1, 256), 256, 0, st>>>(half, ks, w_inv, n_inv, c->L->tmp_a.as<uint32_t>());
+    lagrange_load_bitrev_kernel<FB><<<cdiv(n, 256), 256, 0, st>>>(n, k, kb, s.table.as<affine_t>(), c->L->tmp_b.as<xyzz_t>());
+    for (uint32_t h = 1; h < n; h <<= 1)
+        lagrange_stage_kernel<FB><<<cdiv((size_t)half * 4, 256), 256, 0, st>>>(n, h, half / h, c->L->tmp_a.as<uint32_t>(), c->L->tmp_b.as<xyzz_t>());
+    lagrange_finish_kernel<FB><<<cdiv((size_t)n * 4, 256), 256, 0, st>>>(n, kb, c->L->tmp_a.as<uint32_t>() + (size_t)half * 8, c->L->tmp_b.as<xyzz_t>(), c->L->tmp_c.as<affine_t>());
+    points_from_mont_kernel<FB><<<cdiv(n, 256), 256, 0, st>>>(n, c->L->tmp_c.as<affine_t>(), c->L->tmp_d.as<uint32_t>());
+    HIPC(hipGetLastError());
+    return d2h_sync(c, out_host, c->L->tmp_d, (size_t)n * 64);
+}
+
+extern "C" int mina_srs_lagrange_basis(mina_ctx *c, int curve, uint32_t log2_domain, uint8_t *out_affine) {
+    if (!c || !out_affine) return fail(MINA_ERR_ARG, "null argument");
+    if (curve != 0 && curve != 1) return fail(MINA_ERR_ARG, "bad curve");
+    SrsState &s = c->srs[curve];
+    if (s.depth == 0) return fail(MINA_ERR_STATE, "SRS not loaded");
+    if (log2_domain > 20 || ((uint64_t)1 << log2_domain) > s.depth) return fail(MINA_ERR_ARG, "domain larger than the SRS");
+    HIPC(hipSetDevice(c->device));
+    c->use_lane0();
+    if (log2_domain == 0) return mina_srs_get_g(c, curve, 0, 1, out_affine);   // L_0 = g_0
+    if (curve == CURVE_PALLAS) return run_lagrange<FIELD_FP, FIELD_FQ>(c, s, log2_domain, out_affine);
+    return run_lagrange<FIELD_FQ, FIELD_FP>(c, s, log2_domain, out_affine);
+}

@@ -22,7 +22,7 @@ CURVE_PALLAS, CURVE_VESTA = 0, 1
 # every symbol include/mina_verify.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "mina_ctx_create", "mina_ctx_destroy", "mina_last_error", "mina_ctx_synchronize", "mina_ctx_stream", "mina_ctx_set_pipeline", "mina_prof_enable", "mina_prof_read",
-    "mina_srs_create", "mina_srs_load", "mina_srs_depth", "mina_srs_get_g", "mina_srs_get_h", "mina_srs_serialize",
+    "mina_srs_create", "mina_srs_load", "mina_srs_depth", "mina_srs_get_g", "mina_srs_get_h", "mina_srs_lagrange_basis", "mina_srs_serialize",
     "mina_msm", "mina_msm_srs", "mina_msm_srs_range", "mina_msm_srs_dev",
     "mina_b_poly", "mina_b_poly_coefficients", "mina_b_poly_fold", "mina_b_poly_fold_dev",
     "mina_poseidon_set_params", "mina_poseidon_permute", "mina_poseidon_permute_dev", "mina_poseidon_hash",
@@ -258,6 +258,12 @@ class MinaContext:
     def srs_get_h(self, curve: int) -> np.ndarray:
         out = np.empty(64, np.uint8)
         self._ck(self._lib.mina_srs_get_h(self._h, curve, _p(out)), "mina_srs_get_h")
+        return out
+
+    def srs_lagrange_basis(self, curve: int, log2_domain: int) -> np.ndarray:
+        n = 1 << log2_domain
+        out = np.empty((n, 64), np.uint8)
+        self._ck(self._lib.mina_srs_lagrange_basis(self._h, curve, ctypes.c_uint32(log2_domain), _p(out)), "mina_srs_lagrange_basis")
         return out
 
     def srs_serialize(self, curve: int) -> bytes:
