@@ -95,6 +95,10 @@ int mina_srs_get_h(mina_ctx *ctx, int curve, uint8_t *out_affine);
 /* Lagrange-basis commitments of g[0..2^k) over the radix-2 domain of size 2^k (poly-commitment `SRS::add_lagrange_basis`,
  * used by kimchi for the public-input commitment): out[i] = (1/n) sum_j w^(-ij) g[j], affine canonical bytes, n*64. */
 int mina_srs_lagrange_basis(mina_ctx *ctx, int curve, uint32_t log2_domain, uint8_t *out_affine);
+/* kimchi verifier's public-input commitment: h - sum_i public[i] * lagrange[i]  (i < npub; `mask_custom` with blinder 1).
+ * The Lagrange basis of the domain is computed once and cached in the context. */
+int mina_public_input_commitment(mina_ctx *ctx, int curve, uint32_t log2_domain, size_t npub, const uint8_t *public_inputs /* npub*32 */,
+                                 uint8_t *out_affine);
 /* serialise back to the reference's file format; *len receives the size (2 293 801 for depth 2^16) */
 int mina_srs_serialize(mina_ctx *ctx, int curve, uint8_t *out, size_t cap, size_t *len);
 
@@ -194,6 +198,11 @@ typedef struct {
     uint32_t sponge_mode;       /* ... 0 = Absorbed(count), 1 = Squeezed(count) (mina-poseidon SpongeState) */
     uint32_t sponge_count;
 } mina_ipa_opening;
+
+/* poly-commitment `combined_inner_product` (single-chunk polynomials, no degree bounds): sum_i xi^i sum_j r^j evals[i][j].
+ * Host-side (needs no context): the value goes into mina_ipa_opening.combined_inner_product. */
+int mina_combined_inner_product(int field, size_t n_polys, size_t n_points, const uint8_t *evals /* n_polys*n_points*32 */,
+                                const uint8_t *polyscale, const uint8_t *evalscale, uint8_t *out /* 32 */);
 
 int mina_ipa_batch_check(mina_ctx *ctx, int curve, size_t batch, const mina_ipa_opening *openings,
                          const uint8_t *rand_base /* 32 */, const uint8_t *sg_rand_base /* 32 */,

@@ -2,6 +2,7 @@
 #include "ctx.h"
 #include "msm.cuh"
 #include "lagrange.cuh"
+#include <type_traits>
 
 // ------------------------------------------------------------------------------------------------
 // SRS
@@ -16,6 +17,7 @@ template <int F> static int build_tables(mina_ctx *c, SrsState &s) {
 static int srs_alloc(mina_ctx *c, int curve, uint32_t depth) {
     SrsState &s = c->srs[curve];
     s.depth = 0; s.c = 16; s.W = 16;
+    s.lagrange_log2 = -1; s.lagrange_host.clear();
     int rc;
     if ((rc = s.table.ensure((size_t)s.W * depth * sizeof(affine_t)))) return rc;
     if ((rc = s.h.ensure(sizeof(affine_t)))) return rc;
@@ -188,4 +190,43 @@ extern "C" int mina_srs_lagrange_basis(mina_ctx *c, int curve, uint32_t log2_dom
     if (log2_domain == 0) return mina_srs_get_g(c, curve, 0, 1, out_affine);   // L_0 = g_0
     if (curve == CURVE_PALLAS) return run_lagrange<FIELD_FP, FIELD_FQ>(c, s, log2_domain, out_affine);
     return run_lagrange<FIELD_FQ, FIELD_FP>(c, s, log2_domain, out_affine);
+}
+
+// ------------------------------------------------------------------------------------------------
+// kimchi verifier: public-input commitment  public_comm = h - sum_i pub_i * lagrange_i   (a11; `mask_custom` with blinder 1)
+extern "C" int mina_public_input_commitment(mina_ctx *c, int curve, uint32_t log2_domain, size_t npub, const uint8_t *public_inputs,
+                                            uint8_t *out_affine) {
+    if (!c || !out_affine || (npub && !public_inputs)) return fail(MINA_ERR_ARG, "null argument");
+    if (curve != 0 && curve != 1) return fail(MINA_ERR_ARG, "bad curve");
+    SrsState &s = c->srs[curve];
+    if (s.depth == 0) return fail(MINA_ERR_STATE, "SRS not loaded");
+    if (log2_domain > 20 || ((uint64_t)1 << log2_domain) > s.depth || npub > ((size_t)1 << log2_domain)) return fail(MINA_ERR_ARG, "bad domain / npub");
+    HIPC(hipSetDevice(c->device));
+    c->use_lane0();
+    int rc;
+    // Lagrange basis of this domain, cached on the host in canonical form (one-off group iFFT on the GPU)
+    if (s.lagrange_log2 != (int)log2_domain || s.lagrange_host.empty()) {
+        s.lagrange_host.assign(((size_t)1 << log2_domain) * 64, 0);
+        if ((rc = mina_srs_lagrange_basis(c, curve, log2_domain, s.lagrange_host.data()))) { s.lagrange_host.clear(); return rc; }
+        s.lagrange_log2 = (int)log2_domain;
+    }
+    uint8_t acc[64]; memset(acc, 0, 64);
+    if (npub && (rc = mina_msm(c, curve, npub, s.lagrange_host.data(), public_inputs, acc))) return rc;
+    uint8_t hbytes[64];
+    if ((rc = mina_srs_get_h(c, curve, hbytes))) return rc;
+    // h - acc on the host with the same (host-compiled) field / group code the kernels use
+    auto finish = [&](auto tag) {
+        constexpr int F = decltype(tag)::value;
+        const FieldK &k = c->fk[F];
+        auto load = [&](const uint8_t *b) { affine_t a; memcpy(a.x.v, b, 32); memcpy(a.y.v, b + 32, 32); a.x = fe_to_mont<F>(a.x, k.r2); a.y = fe_to_mont<F>(a.y, k.r2); return a; };
+        affine_t H = load(hbytes), A = load(acc);
+        xyzz_t t = xyzz_from_affine<F>(H, k.one);
+        if (!aff_is_inf(A)) { A.y = fe_neg<F>(A.y); xyzz_add_affine<F>(t, A.x, A.y, k.one); }
+        if (xyzz_is_inf(t)) { memset(out_affine, 0, 64); return; }
+        fe_t zi = fe_inv<F>(fe_mul<F>(t.zz, t.zzz), k);
+        fe_t x = fe_from_mont<F>(fe_mul<F>(t.x, fe_mul<F>(zi, t.zzz))), y = fe_from_mont<F>(fe_mul<F>(t.y, fe_mul<F>(zi, t.zz)));
+        memcpy(out_affine, x.v, 32); memcpy(out_affine + 32, y.v, 32);
+    };
+    if (base_field_of(curve) == FIELD_FP) finish(std::integral_constant<int, FIELD_FP>{}); else finish(std::integral_constant<int, FIELD_FQ>{});
+    return MINA_OK;
 }

@@ -12,6 +12,7 @@
 //       ([UPSTREAM-RECALL] for the SerdeAs framing), then the binprot-derived account (not parsed here).
 // Field elements must be canonical (< p), as ark's `CanonicalDeserialize` enforces.
 #include "ctx.h"
+#include <type_traits>
 
 static bool fp_is_canonical(const uint8_t *b) {
     // p (Fp) little-endian bytes
@@ -102,5 +103,34 @@ extern "C" int mina_verify_account_inclusion(mina_ctx *c, size_t n, const uint8_
         if (rc) return rc;
         for (size_t j = 0; j < m; ++j) verdicts[idx[j]] = v[j];
     }
+    return MINA_OK;
+}
+
+// poly-commitment `combined_inner_product` for single-chunk polynomials without degree bounds (a11):
+//   cip = sum_i xi^i * sum_j r^j * evals[i][j]      (evals[i][j] = f_i(point_j))
+// O(n_polys * n_points) field operations: done on the host with the host build of fp.cuh.
+#include "groupmap.cuh"
+extern "C" int mina_combined_inner_product(int field, size_t n_polys, size_t n_points, const uint8_t *evals, const uint8_t *polyscale,
+                                           const uint8_t *evalscale, uint8_t *out) {
+    if ((n_polys && n_points && !evals) || !polyscale || !evalscale || !out) return fail(MINA_ERR_ARG, "null argument");
+    if (field != 0 && field != 1) return fail(MINA_ERR_ARG, "bad field");
+    auto run = [&](auto tag) {
+        constexpr int F = decltype(tag)::value;
+        fe_t one = fe_zero(); one.v[0] = 1;
+        fe_t r2 = one;                                               // R^2 mod p by doubling (no context needed here)
+        for (int i = 0; i < 512; ++i) r2 = fe_add<F>(r2, r2);
+        auto ld = [&](const uint8_t *b) { fe_t a; memcpy(a.v, b, 32); return fe_to_mont<F>(a, r2); };
+        const fe_t xi = ld(polyscale), r = ld(evalscale);
+        fe_t res = fe_zero(), xi_i = fe_to_mont<F>(one, r2);
+        for (size_t i = 0; i < n_polys; ++i) {
+            fe_t term = fe_zero();
+            for (size_t j = n_points; j-- > 0;) term = fe_add<F>(fe_mul<F>(term, r), ld(evals + (i * n_points + j) * 32));   // Horner in r
+            res = fe_add<F>(res, fe_mul<F>(xi_i, term));
+            xi_i = fe_mul<F>(xi_i, xi);
+        }
+        res = fe_from_mont<F>(res);
+        memcpy(out, res.v, 32);
+    };
+    if (field == FIELD_FP) run(std::integral_constant<int, FIELD_FP>{}); else run(std::integral_constant<int, FIELD_FQ>{});
     return MINA_OK;
 }

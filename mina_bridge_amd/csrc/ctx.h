@@ -41,6 +41,8 @@ struct SrsState {
     uint32_t c = 16, W = 16;           // fixed-base window shape
     DevBuf table;                      // W * depth affine_t; window 0 = g itself
     DevBuf h;                          // 1 affine_t
+    int lagrange_log2 = -1;            // cached Lagrange basis (canonical affine bytes, host side)
+    std::vector<uint8_t> lagrange_host;
 };
 
 struct MsmWorkspace {

@@ -22,7 +22,7 @@ CURVE_PALLAS, CURVE_VESTA = 0, 1
 # every symbol include/mina_verify.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "mina_ctx_create", "mina_ctx_destroy", "mina_last_error", "mina_ctx_synchronize", "mina_ctx_stream", "mina_ctx_set_pipeline", "mina_prof_enable", "mina_prof_read",
-    "mina_srs_create", "mina_srs_load", "mina_srs_depth", "mina_srs_get_g", "mina_srs_get_h", "mina_srs_lagrange_basis", "mina_srs_serialize",
+    "mina_srs_create", "mina_srs_load", "mina_srs_depth", "mina_srs_get_g", "mina_srs_get_h", "mina_srs_lagrange_basis", "mina_public_input_commitment", "mina_combined_inner_product", "mina_srs_serialize",
     "mina_msm", "mina_msm_srs", "mina_msm_srs_range", "mina_msm_srs_dev",
     "mina_b_poly", "mina_b_poly_coefficients", "mina_b_poly_fold", "mina_b_poly_fold_dev",
     "mina_poseidon_set_params", "mina_poseidon_permute", "mina_poseidon_permute_dev", "mina_poseidon_hash",
@@ -41,6 +41,16 @@ class MinaError(RuntimeError):
 class StatePubInputs(ctypes.Structure):
     _fields_ = [("is_state_proof_from_devnet", ctypes.c_uint8), ("bridge_tip_state_hash", ctypes.c_uint8 * 32),
                 ("candidate_chain_state_hashes", (ctypes.c_uint8 * 32) * 16), ("candidate_chain_ledger_hashes", (ctypes.c_uint8 * 32) * 16)]
+
+
+def combined_inner_product(field: int, evals, polyscale, evalscale, n_polys: int, n_points: int) -> np.ndarray:
+    lib = load_library()
+    ev = _u8(evals) if n_polys * n_points else np.zeros(32, np.uint8)
+    out = np.empty(32, np.uint8)
+    rc = lib.mina_combined_inner_product(field, ctypes.c_size_t(n_polys), ctypes.c_size_t(n_points), _p(ev), _p(_u8(polyscale)), _p(_u8(evalscale)), _p(out))
+    if rc != 0:
+        raise MinaError(f"mina_combined_inner_product failed ({rc}): {lib.mina_last_error().decode()}")
+    return out
 
 
 def parse_state_pub_inputs(data: bytes) -> dict:
@@ -264,6 +274,14 @@ class MinaContext:
         n = 1 << log2_domain
         out = np.empty((n, 64), np.uint8)
         self._ck(self._lib.mina_srs_lagrange_basis(self._h, curve, ctypes.c_uint32(log2_domain), _p(out)), "mina_srs_lagrange_basis")
+        return out
+
+    def public_input_commitment(self, curve: int, log2_domain: int, public_inputs) -> np.ndarray:
+        pub = _u8(public_inputs) if len(public_inputs) else np.zeros(32, np.uint8)
+        npub = 0 if not len(public_inputs) else pub.size // 32
+        out = np.empty(64, np.uint8)
+        self._ck(self._lib.mina_public_input_commitment(self._h, curve, ctypes.c_uint32(log2_domain), ctypes.c_size_t(npub), _p(pub), _p(out)),
+                 "mina_public_input_commitment")
         return out
 
     def srs_serialize(self, curve: int) -> bytes:

@@ -43,3 +43,39 @@ def test_lagrange_basis_wrap_domain(ctx_srs, oracle, srs_oracle):
     for i in (0, 1, 39, 12345, (1 << k) - 1):
         assert (got[i] == expected_basis_point(oracle, R, curve, g, k, i)).all(), i
     assert all(oracle.is_on_curve(curve, p) for p in got[:50])
+
+
+def test_public_input_commitment(ctx_srs, oracle, srs_oracle):
+    """kimchi: public_comm = h - sum_i pub_i * lagrange_i  == h - commit(interpolant of pub on the domain), checked through the
+    oracle by expanding the Lagrange basis: sum_i pub_i L_i = MSM(g, c) with c_j = (1/n) sum_i pub_i w^(-ij)"""
+    from conftest import rand_scalars
+    from oracle import pasta_ref as R
+    curve, k, npub = 0, 6, 40
+    g, h = srs_oracle[curve]
+    r = R.scalar_modulus(curve); n = 1 << k
+    pub = rand_scalars(npub, r, seed=77)
+    got = ctx_srs.public_input_commitment(curve, k, pub)
+    w = pow(R.two_adic_root_of_unity(r), 1 << (32 - k), r); w_inv, n_inv = pow(w, r - 2, r), pow(n, r - 2, r)
+    pubs = [oracle.le_to_int(x) for x in pub]
+    coeffs = [n_inv * sum(pubs[i] * pow(w_inv, (i * j) % n, r) for i in range(npub)) % r for j in range(n)]
+    msm = oracle.bytes_to_point(oracle.msm_pippenger(curve, g[:n], oracle.ints_to_le(coeffs), threads=4))
+    m = R.base_modulus(curve)
+    exp = R.add(oracle.bytes_to_point(h), R.neg(msm, m), m)
+    assert oracle.bytes_to_point(got) == exp
+    # no public inputs -> h itself; cached basis is reused (second call) and survives a different npub
+    assert (ctx_srs.public_input_commitment(curve, k, np.zeros((0, 32), np.uint8)) == h).all()
+    assert (ctx_srs.public_input_commitment(curve, k, pub) == got).all()
+
+
+def test_combined_inner_product_matches_restatement(oracle):
+    import mina_bridge_amd as m
+    from conftest import rand_scalars
+    from oracle import ipa_ref as I, pasta_ref as R
+    for field in (0, 1):
+        r = R.P if field == 0 else R.Q
+        n_polys, n_points = 7, 2
+        ev = rand_scalars(n_polys * n_points, r, seed=5 + field)
+        xi, rs = rand_scalars(2, r, seed=9 + field)
+        got = m.combined_inner_product(field, ev, xi, rs, n_polys, n_points)
+        evals = [[oracle.le_to_int(ev[i * n_points + j]) for j in range(n_points)] for i in range(n_polys)]
+        assert oracle.le_to_int(got) == I.combined_inner_product(evals, oracle.le_to_int(xi), oracle.le_to_int(rs), r)
