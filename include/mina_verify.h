@@ -150,6 +150,21 @@ int mina_merkle_roots(mina_ctx *ctx, int field, size_t n, uint32_t depth, const 
 int mina_merkle_verify_batch(mina_ctx *ctx, int field, size_t n, uint32_t depth, const uint8_t *leaves, const uint8_t *siblings,
                              const uint8_t *dirs, const uint8_t *expected_roots, uint8_t *verdicts);
 
+/* ---- a12: batched Fq-sponge transcripts (mina-poseidon `DefaultFqSponge` over the base field of `curve`) -------------
+ * Every proof of the batch runs the same `tape` of opcodes over its own input stream (inputs: per proof, the operands in
+ * tape order, 32 B per field element, 64 B per point; outputs: per proof, 32 B per squeeze opcode).  4 lanes per proof.
+ * init_state/init_pos (may both be NULL = fresh sponge): 3 field elements + {mode, count} per proof, as in mina_ipa_opening;
+ * final_state/final_pos (may be NULL) receive the sponge after the tape. */
+#define MINA_TAPE_ABSORB_FQ 0      /* base-field element */
+#define MINA_TAPE_ABSORB_G 1       /* affine point (x, y); infinity absorbs (0, 0) */
+#define MINA_TAPE_ABSORB_FR 2      /* scalar-field element: whole if r < q, else (x >> 1) then (x & 1) */
+#define MINA_TAPE_CHALLENGE 3      /* squeeze -> low 128 bits */
+#define MINA_TAPE_CHALLENGE_FQ 4   /* squeeze -> full base-field element */
+#define MINA_TAPE_CHALLENGE_ENDO 5 /* squeeze 128 bits -> ScalarChallenge::to_field */
+#define MINA_TAPE_DIGEST 6         /* squeeze -> scalar-field element if it fits, else 0 */
+int mina_fq_sponge_run(mina_ctx *ctx, int curve, size_t batch, const uint8_t *tape, size_t tape_len, const uint8_t *init_state,
+                       const uint32_t *init_pos, const uint8_t *inputs, uint8_t *outputs, uint8_t *final_state, uint32_t *final_pos);
+
 /* ---- K4: group map (a14) --------------------------------------------------------------------- */
 int mina_to_group(mina_ctx *ctx, int curve, size_t n, const uint8_t *t, uint8_t *out_affine);
 

@@ -34,11 +34,68 @@ template <int F> struct DevSponge {
     }
 };
 
-struct IpaShape { uint32_t batch, k, npts, ncomms, per; };   // per = 2k + ncomms + 4 points per proof
-
 template <int F> __device__ __forceinline__ fe_t load_fe(const uint32_t *p) { fe_t r; for (int i = 0; i < 8; ++i) r.v[i] = p[i]; return r; }
 __device__ __forceinline__ void store_fe(uint32_t *p, const fe_t &a) { if ((threadIdx.x & 3u) == 0) for (int i = 0; i < 8; ++i) p[i] = a.v[i]; }
 __device__ __forceinline__ void store_pt(affine_t *p, const affine_t &a) { if ((threadIdx.x & 3u) == 0) *p = a; }
+
+
+// ---------------------------------------------------------------- generic Fq-sponge transcript ("tape")
+// mina-poseidon `DefaultFqSponge` over the base field of CURVE (pins core/Cargo.toml:14; README.md:413-475 lists the order
+// kimchi absorbs/squeezes in).  Every proof of a batch runs the same tape of opcodes over its own input stream:
+enum : uint8_t {
+    TAPE_ABSORB_FQ = 0,        // one base-field element                                   (32 B in)
+    TAPE_ABSORB_G = 1,         // one affine point: x then y; infinity absorbs (0, 0)      (64 B in)
+    TAPE_ABSORB_FR = 2,        // one scalar-field element: whole if r < q, else (x >> 1, x & 1)   (32 B in)
+    TAPE_CHALLENGE = 3,        // squeeze, low 128 bits                                    (32 B out, upper 16 zero)
+    TAPE_CHALLENGE_FQ = 4,     // squeeze, full base-field element                         (32 B out)
+    TAPE_CHALLENGE_ENDO = 5,   // squeeze 128 bits -> ScalarChallenge::to_field (scalar field)      (32 B out)
+    TAPE_DIGEST = 6,           // squeeze; as a scalar-field element if it fits, else 0    (32 B out)
+};
+template <int CURVE>
+__global__ void __launch_bounds__(64)
+sponge_tape_kernel(uint32_t batch, uint32_t tape_len, uint32_t in_stride_words, uint32_t out_stride_words, FieldK kb, FieldK ks,
+                   const PoseidonParams *__restrict__ pp, const uint8_t *__restrict__ tape, const uint32_t *__restrict__ init_state /* b*24 or null */,
+                   const uint32_t *__restrict__ init_pos /* b*2 or null */, const uint32_t *__restrict__ inputs, uint32_t *__restrict__ outputs,
+                   uint32_t *__restrict__ final_state /* b*24 or null */, uint32_t *__restrict__ final_pos /* b*2 or null */) {
+    constexpr int FB = (CURVE == CURVE_PALLAS) ? FIELD_FP : FIELD_FQ;
+    constexpr int FS = (CURVE == CURVE_PALLAS) ? FIELD_FQ : FIELD_FP;
+    const uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) >> 2, q = threadIdx.x & 3u, qq = q < 3 ? q : 2;
+    if (b >= batch) return;
+    DevSponge<FB> sp; sp.pp = pp; sp.squeezed = 0; sp.count = 0; sp.s = fe_zero();
+    if (init_state) { sp.s = fe_to_mont<FB>(load_fe<FB>(init_state + (size_t)b * 24 + qq * 8), kb.r2); sp.squeezed = (int)init_pos[2 * b]; sp.count = (int)init_pos[2 * b + 1]; }
+    const uint32_t *in = inputs + (size_t)b * in_stride_words;
+    uint32_t *out = outputs + (size_t)b * out_stride_words;
+    for (uint32_t t = 0; t < tape_len; ++t) {
+        const uint8_t op = tape[t];
+        if (op == TAPE_ABSORB_FQ) { sp.absorb(fe_to_mont<FB>(load_fe<FB>(in), kb.r2)); in += 8; }
+        else if (op == TAPE_ABSORB_G) { sp.absorb(fe_to_mont<FB>(load_fe<FB>(in), kb.r2)); sp.absorb(fe_to_mont<FB>(load_fe<FB>(in + 8), kb.r2)); in += 16; }
+        else if (op == TAPE_ABSORB_FR) {
+            fe_t x = load_fe<FS>(in); in += 8;
+            if (CURVE == CURVE_PALLAS) {                       // scalar modulus (q) > base modulus (p): split off the low bit
+                fe_t lowbit = fe_zero(); lowbit.v[0] = x.v[0] & 1u;
+                fe_t hi = x; for (int i = 0; i < 7; ++i) hi.v[i] = (hi.v[i] >> 1) | (hi.v[i + 1] << 31); hi.v[7] >>= 1;
+                sp.absorb(fe_to_mont<FB>(hi, kb.r2)); sp.absorb(fe_to_mont<FB>(lowbit, kb.r2));
+            } else sp.absorb(fe_to_mont<FB>(x, kb.r2));
+        } else {
+            fe_t sq = fe_from_mont<FB>(sp.squeeze()), o = fe_zero();
+            if (op == TAPE_CHALLENGE) { o.v[0] = sq.v[0]; o.v[1] = sq.v[1]; o.v[2] = sq.v[2]; o.v[3] = sq.v[3]; }
+            else if (op == TAPE_CHALLENGE_FQ) o = sq;
+            else if (op == TAPE_CHALLENGE_ENDO) {
+                uint64_t lo = (uint64_t)sq.v[0] | ((uint64_t)sq.v[1] << 32), hi = (uint64_t)sq.v[2] | ((uint64_t)sq.v[3] << 32);
+                o = fe_from_mont<FS>(challenge_to_field<FS>(lo, hi, ks));
+            } else {                                          // TAPE_DIGEST: fits the scalar field?  (compare with its modulus)
+                bool fits = false;
+                for (int i = 7; i >= 0; --i) { uint32_t m = modulus_limb<FS>(i); if (sq.v[i] != m) { fits = sq.v[i] < m; break; } }
+                if (fits) o = sq;
+            }
+            store_fe(out, o); out += 8;
+        }
+    }
+    if (final_state && q < 3) { fe_t w = fe_from_mont<FB>(sp.s); for (int i = 0; i < 8; ++i) final_state[(size_t)b * 24 + q * 8 + i] = w.v[i]; }
+    if (final_pos && q == 0) { final_pos[2 * b] = (uint32_t)sp.squeezed; final_pos[2 * b + 1] = (uint32_t)sp.count; }
+}
+
+struct IpaShape { uint32_t batch, k, npts, ncomms, per; };   // per = 2k + ncomms + 4 points per proof
 
 template <int FB> __device__ __forceinline__ affine_t load_point_mont(const uint32_t *p, const FieldK &kb) {
     affine_t a; a.x = fe_to_mont<FB>(load_fe<FB>(p), kb.r2); a.y = fe_to_mont<FB>(load_fe<FB>(p + 8), kb.r2); return a;
@@ -342,4 +399,50 @@ extern "C" int mina_ipa_batch_check(mina_ctx *c, int curve, size_t batch, const 
     if ((rc = d2h_sync(c, &v, c->L->ipa_verdict, 4))) return rc;
     *verdict = v ? 1 : 0;
     return MINA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// a12: batched Fq-sponge transcripts
+extern "C" int mina_fq_sponge_run(mina_ctx *c, int curve, size_t batch, const uint8_t *tape, size_t tape_len, const uint8_t *init_state,
+                                  const uint32_t *init_pos, const uint8_t *inputs, uint8_t *outputs, uint8_t *final_state, uint32_t *final_pos) {
+    if (!c || !tape || (batch && tape_len && !outputs && !final_state)) return fail(MINA_ERR_ARG, "null argument");
+    if (curve != 0 && curve != 1) return fail(MINA_ERR_ARG, "bad curve");
+    if ((init_state == nullptr) != (init_pos == nullptr)) return fail(MINA_ERR_ARG, "init_state and init_pos go together");
+    if (batch == 0) return MINA_OK;
+    if (batch > (1u << 22) || tape_len > (1u << 16)) return fail(MINA_ERR_ARG, "batch or tape too large");
+    const int FB = base_field_of(curve);
+    if (!c->have_pparams[FB]) return fail(MINA_ERR_STATE, "Poseidon constants not installed for the base field");
+    size_t in_words = 0, out_words = 0;
+    for (size_t t = 0; t < tape_len; ++t) {
+        switch (tape[t]) {
+            case TAPE_ABSORB_FQ: case TAPE_ABSORB_FR: in_words += 8; break;
+            case TAPE_ABSORB_G: in_words += 16; break;
+            case TAPE_CHALLENGE: case TAPE_CHALLENGE_FQ: case TAPE_CHALLENGE_ENDO: case TAPE_DIGEST: out_words += 8; break;
+            default: return fail(MINA_ERR_ARG, "unknown tape opcode");
+        }
+    }
+    if ((in_words && !inputs) || (out_words && !outputs)) return fail(MINA_ERR_ARG, "null argument");
+    if (init_pos) for (size_t b = 0; b < batch; ++b) if (init_pos[2 * b] > 1 || init_pos[2 * b + 1] > 2) return fail(MINA_ERR_ARG, "bad sponge position");
+    HIPC(hipSetDevice(c->device));
+    c->use_lane0();
+    int rc;
+    Lane &L = *c->L;
+    if ((rc = h2d(c, L.ipa_in_a, tape, tape_len))) return rc;
+    if ((rc = h2d(c, L.ipa_in_b, inputs, batch * in_words * 4))) return rc;
+    if (init_state) { if ((rc = h2d(c, L.ipa_in_c, init_state, batch * 96))) return rc; if ((rc = h2d(c, L.ipa_sigma, init_pos, batch * 8))) return rc; }
+    if ((rc = L.ipa_scalars.ensure(batch * (out_words ? out_words : 8) * 4))) return rc;
+    if ((rc = L.ipa_points.ensure(batch * 96))) return rc;
+    if ((rc = L.ipa_chals.ensure(batch * 8))) return rc;
+    const PoseidonParams *pp = c->pparams[FB].as<PoseidonParams>();
+    const int FS = scalar_field_of(curve);
+#define RUN_TAPE(CV)                                                                                                                       \
+    mb::sponge_tape_kernel<CV><<<cdiv(batch * 4, 64), 64, 0, L.stream>>>((uint32_t)batch, (uint32_t)tape_len, (uint32_t)in_words, (uint32_t)out_words, \
+        c->fk[FB], c->fk[FS], pp, L.ipa_in_a.as<uint8_t>(), init_state ? L.ipa_in_c.as<uint32_t>() : nullptr, init_state ? L.ipa_sigma.as<uint32_t>() : nullptr, \
+        L.ipa_in_b.as<uint32_t>(), L.ipa_scalars.as<uint32_t>(), L.ipa_points.as<uint32_t>(), L.ipa_chals.as<uint32_t>())
+    if (curve == CURVE_PALLAS) RUN_TAPE(CURVE_PALLAS); else RUN_TAPE(CURVE_VESTA);
+#undef RUN_TAPE
+    HIPC(hipGetLastError());
+    if (final_state) HIPC(hipMemcpyAsync(final_state, L.ipa_points.p, batch * 96, hipMemcpyDeviceToHost, L.stream));
+    if (final_pos) HIPC(hipMemcpyAsync(final_pos, L.ipa_chals.p, batch * 8, hipMemcpyDeviceToHost, L.stream));
+    return d2h_sync(c, outputs, L.ipa_scalars, batch * out_words * 4);
 }

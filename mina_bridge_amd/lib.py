@@ -26,7 +26,7 @@ EXPORTS = [
     "mina_msm", "mina_msm_srs", "mina_msm_srs_range", "mina_msm_srs_dev",
     "mina_b_poly", "mina_b_poly_coefficients", "mina_b_poly_fold", "mina_b_poly_fold_dev",
     "mina_poseidon_set_params", "mina_poseidon_permute", "mina_poseidon_permute_dev", "mina_poseidon_hash",
-    "mina_challenge_to_field", "mina_to_group", "mina_merkle_roots", "mina_merkle_verify_batch",
+    "mina_challenge_to_field", "mina_fq_sponge_run", "mina_to_group", "mina_merkle_roots", "mina_merkle_verify_batch",
     "mina_field_mul", "mina_field_inv", "mina_field_sqrt", "mina_selftest_group_law",
     "mina_accumulator_check_batch", "mina_accumulator_check_dev", "mina_ipa_batch_check",
     "mina_consensus_project_window", "mina_consensus_relative_min_window_density", "mina_consensus_is_short_range",
@@ -372,6 +372,23 @@ class MinaContext:
         out = np.empty((n, 32), np.uint8)
         self._ck(self._lib.mina_challenge_to_field(self._h, field, ctypes.c_size_t(n), _p(ch), _p(out)), "mina_challenge_to_field")
         return out
+
+    def fq_sponge_run(self, curve: int, batch: int, tape: bytes, inputs, init=None, want_final=False):
+        """init: None or (states[batch,96] uint8, pos[batch,2] uint32).  Returns outputs[batch, n_squeeze, 32] (and final state/pos)."""
+        tp = _u8(tape)
+        n_out = sum(1 for t in tape if t >= 3)
+        inp = _u8(inputs) if len(inputs) else np.zeros(32, np.uint8)
+        out = np.zeros((batch, max(n_out, 1), 32), np.uint8)
+        st = pos = None
+        if init is not None:
+            st, pos = _u8(init[0]), np.ascontiguousarray(init[1], dtype=np.uint32)
+        fs = np.zeros((batch, 96), np.uint8) if want_final else None
+        fp = np.zeros((batch, 2), np.uint32) if want_final else None
+        self._ck(self._lib.mina_fq_sponge_run(self._h, curve, ctypes.c_size_t(batch), _p(tp), ctypes.c_size_t(len(tape)), _p(st),
+                                              pos.ctypes.data_as(ctypes.c_void_p) if pos is not None else None, _p(inp), _p(out), _p(fs),
+                                              fp.ctypes.data_as(ctypes.c_void_p) if fp is not None else None), "mina_fq_sponge_run")
+        out = out[:, :n_out]
+        return (out, fs, fp) if want_final else out
 
     # -- a16
     def merkle_roots(self, field: int, leaves, siblings, dirs, depth: int) -> np.ndarray:
