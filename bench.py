@@ -34,7 +34,7 @@ K_ROUNDS = 16
 N_BASES = 1 << K_ROUNDS
 MSM_ALGORITHMIC_BYTES = N_BASES * (64 + 32) + 96      # 6 291 552 B for n = 2^16
 HBM_PEAK_GBPS = 8000.0                                # MI355X_MICROARCH.md: 8 TB/s spec
-PS_ACCUMULATE_BIT = 1 << 3
+PS_ACCUMULATE_BIT = 1 << 3      # ProfStage::PS_ACCUMULATE in csrc/ctx.h
 # HBM-side bytes per launch of the dominant kernel from the rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, KiB * 1024;
 # profiles/r01b_rocprof.md section 2).  14x the algorithmic bytes by design: the fixed-base window tables gather 16
 # precomputed 64-B points per base and write 128-B XYZZ partials.

@@ -46,12 +46,12 @@ struct SrsState {
 };
 
 struct MsmWorkspace {
-    DevBuf scalars, points, ekey, eval, eoff, count, start, task_start, rem_pos, rem_bucket, info, sorted, partial, buckets, red_r, red_ws, red2_r, red2_w, red2_p, set_total, out_words, out_xyzz;
+    DevBuf scalars, points, ekey, eval, eoff, count, start, task_start, rem_pos, rem_bucket, info, sorted, partial, buckets, red_r, red_ws, red2_r, red2_w, set_total, out_words, out_xyzz;
 };
 
 // HIP-event stage timing on the context stream (off by default; bench.py turns it on for the timed region)
-enum ProfStage : int { PS_DIGITS = 0, PS_SCAN, PS_SCATTER, PS_ACCUMULATE, PS_BUCKET_SUM, PS_REDUCE_A, PS_REDUCE_BC, PS_REDUCE_C, PS_FINISH,
-                       PS_BPOLY_TABLES, PS_BPOLY_FOLD, PS_BPOLY_FINISH, PS_CHALLENGES, PS_COMPARE, PS_COUNT };
+enum ProfStage : int { PS_DIGITS = 0, PS_SCAN, PS_SCATTER, PS_ACCUMULATE, PS_BUCKET_SUM, PS_REDUCE_A, PS_REDUCE_BC, PS_FINISH,
+                       PS_BPOLY_TABLES, PS_BPOLY_FOLD, PS_BPOLY_FINISH, PS_COUNT };
 struct ProfState {
     int mask = 0;                                   // bit per stage; 0 = off
     struct Rec { hipEvent_t a, b; int stage; };
@@ -70,7 +70,7 @@ struct Lane {
     void release_all() {
         MsmWorkspace &w = ws;
         DevBuf *all[] = {&w.scalars, &w.points, &w.ekey, &w.eval, &w.eoff, &w.count, &w.start, &w.task_start, &w.rem_pos, &w.rem_bucket, &w.info, &w.sorted, &w.partial,
-                         &w.buckets, &w.red_r, &w.red_ws, &w.red2_r, &w.red2_w, &w.red2_p, &w.set_total, &w.out_words, &w.out_xyzz, &tmp_a, &tmp_b, &tmp_c, &tmp_d,
+                         &w.buckets, &w.red_r, &w.red_ws, &w.red2_r, &w.red2_w, &w.set_total, &w.out_words, &w.out_xyzz, &tmp_a, &tmp_b, &tmp_c, &tmp_d,
                          &bp_ltab, &bp_htab, &bp_partial, &ipa_chals, &ipa_folded, &ipa_xyzz_a, &ipa_xyzz_b, &ipa_points, &ipa_scalars,
                          &ipa_sigma, &ipa_in_a, &ipa_in_b, &ipa_in_c, &ipa_verdict};
         for (DevBuf *b : all) b->release();

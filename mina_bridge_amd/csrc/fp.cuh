@@ -267,15 +267,7 @@ template <int F> MB_HD fe_t fe_mul_portable(const fe_t &a, const fe_t &b) {
 // ---- gfx950 device version: product scanning (FIPS) with a 96-bit column accumulator (acc:64, hi:32).
 // One `v_mad_u64_u32` per 32x32 product accumulates straight into `acc`; its carry-out goes to an SGPR pair
 // that the following `v_addc_co_u32` folds into `hi` -- no 64-bit addend assembly, no v_mov traffic.
-// 64 (a*b) + 24 (m*p1..p3) multiply-accumulates; p0 = 1 and p7 = 2^30 are adds/shifts.
-__device__ __forceinline__ void mb_mac(uint64_t &acc, uint32_t &hi, uint32_t x, uint32_t y) {
-    uint64_t cc;
-    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
-        : "+v"(acc), "+v"(hi), "=&s"(cc) : "v"(x), "v"(y));
-}
-__device__ __forceinline__ void mb_acc_add(uint64_t &acc, uint32_t &hi, uint64_t v) {
-    acc += v; hi += (acc < v) ? 1u : 0u;
-}
+// 64 (a*b) + 32 (m*p1, p2, p3, p7) multiply-accumulates; p0 = 1 is a carry fold (mb_fold_shift).
 // acc(96 bit) += m * p0 where m = -lo: the low word becomes 0 and carries (lo != 0) into the upper 64 bits; then >> 32.
 __device__ __forceinline__ void mb_fold_shift(uint64_t &acc, uint32_t &hi, uint32_t lo, uint32_t mid) {
     uint32_t nlo, nhi;

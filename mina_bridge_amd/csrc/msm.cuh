@@ -328,30 +328,6 @@ __device__ __forceinline__ xyzz_t shfl_down_xyzz(const xyzz_t &a, int d) {
     xyzz_t r; r.x = shfl_down_fe(a.x, d); r.y = shfl_down_fe(a.y, d);
     r.zz = shfl_down_fe(a.zz, d); r.zzz = shfl_down_fe(a.zzz, d); return r;
 }
-// lane 0 gets the sum over lanes [0, width) of v  (width = power of two <= 64; lanes >= width must hold infinity)
-template <int F> __device__ __forceinline__ xyzz_t wave_sum(xyzz_t v, int width = 64) {
-    const int lane = threadIdx.x & 63;
-#pragma unroll 1
-    for (int d = width >> 1; d >= 1; d >>= 1) {
-        xyzz_t o = shfl_down_xyzz(v, d);
-        if (lane + d < width) xyzz_add<F>(v, o);
-    }
-    return v;
-}
-// lane 0 gets  sum_l v_l  (in `sum`) and  sum_l l * v_l  (returned), l < width
-template <int F> __device__ __forceinline__ xyzz_t wave_weighted_sum(xyzz_t v, xyzz_t &sum, int width = 64) {
-    const int lane = threadIdx.x & 63;
-    // suffix scan: s_l = sum_{i >= l} v_i
-#pragma unroll 1
-    for (int d = 1; d < width; d <<= 1) {
-        xyzz_t o = shfl_down_xyzz(v, d);
-        if (lane + d < width) xyzz_add<F>(v, o);
-    }
-    sum = v;                                   // lane 0: total
-    if (lane == 0) v = xyzz_inf();             // sum_{l>=1} s_l = sum_l l * v_l
-    return wave_sum<F>(v, width);
-}
-
 // ---------------------------------------------------------------- bucket reduction  sum_b (b+1) * B_b
 // 2-D scheme: view a bucket set as R rows x C columns (b = r*C + c, C = 128).  Then
 //     sum_b (b+1) B_b = Tot + C * sum_r r*Row_r + sum_c c*Col_c,    Row_r = sum_c B[r][c], Col_c = sum_r B[r][c], Tot = sum_r Row_r
