@@ -162,6 +162,8 @@ int mina_merkle_verify_batch(mina_ctx *ctx, int field, size_t n, uint32_t depth,
 #define MINA_TAPE_CHALLENGE_FQ 4   /* squeeze -> full base-field element */
 #define MINA_TAPE_CHALLENGE_ENDO 5 /* squeeze 128 bits -> ScalarChallenge::to_field */
 #define MINA_TAPE_DIGEST 6         /* squeeze -> scalar-field element if it fits, else 0 */
+#define MINA_TAPE_CHALLENGE_ENDO_OWN 7 /* squeeze 128 bits -> to_field in the sponge's own field: kimchi's Fr-sponge
+                                        (`DefaultFrSponge`) = this tape on the curve whose base field is the proof's scalar field */
 int mina_fq_sponge_run(mina_ctx *ctx, int curve, size_t batch, const uint8_t *tape, size_t tape_len, const uint8_t *init_state,
                        const uint32_t *init_pos, const uint8_t *inputs, uint8_t *outputs, uint8_t *final_state, uint32_t *final_pos);
 

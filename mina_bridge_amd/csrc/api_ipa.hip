@@ -50,6 +50,8 @@ enum : uint8_t {
     TAPE_CHALLENGE_FQ = 4,     // squeeze, full base-field element                         (32 B out)
     TAPE_CHALLENGE_ENDO = 5,   // squeeze 128 bits -> ScalarChallenge::to_field (scalar field)      (32 B out)
     TAPE_DIGEST = 6,           // squeeze; as a scalar-field element if it fits, else 0    (32 B out)
+    TAPE_CHALLENGE_ENDO_OWN = 7, // squeeze 128 bits -> to_field in the sponge's OWN field (kimchi `DefaultFrSponge::challenge`:
+                               // run the tape on the curve whose BASE field is the proof's scalar field)      (32 B out)
 };
 template <int CURVE>
 __global__ void __launch_bounds__(64)
@@ -83,6 +85,9 @@ sponge_tape_kernel(uint32_t batch, uint32_t tape_len, uint32_t in_stride_words, 
             else if (op == TAPE_CHALLENGE_ENDO) {
                 uint64_t lo = (uint64_t)sq.v[0] | ((uint64_t)sq.v[1] << 32), hi = (uint64_t)sq.v[2] | ((uint64_t)sq.v[3] << 32);
                 o = fe_from_mont<FS>(challenge_to_field<FS>(lo, hi, ks));
+            } else if (op == TAPE_CHALLENGE_ENDO_OWN) {
+                uint64_t lo = (uint64_t)sq.v[0] | ((uint64_t)sq.v[1] << 32), hi = (uint64_t)sq.v[2] | ((uint64_t)sq.v[3] << 32);
+                o = fe_from_mont<FB>(challenge_to_field<FB>(lo, hi, kb));
             } else {                                          // TAPE_DIGEST: fits the scalar field?  (compare with its modulus)
                 bool fits = false;
                 for (int i = 7; i >= 0; --i) { uint32_t m = modulus_limb<FS>(i); if (sq.v[i] != m) { fits = sq.v[i] < m; break; } }
@@ -417,7 +422,7 @@ extern "C" int mina_fq_sponge_run(mina_ctx *c, int curve, size_t batch, const ui
         switch (tape[t]) {
             case TAPE_ABSORB_FQ: case TAPE_ABSORB_FR: in_words += 8; break;
             case TAPE_ABSORB_G: in_words += 16; break;
-            case TAPE_CHALLENGE: case TAPE_CHALLENGE_FQ: case TAPE_CHALLENGE_ENDO: case TAPE_DIGEST: out_words += 8; break;
+            case TAPE_CHALLENGE: case TAPE_CHALLENGE_FQ: case TAPE_CHALLENGE_ENDO: case TAPE_DIGEST: case TAPE_CHALLENGE_ENDO_OWN: out_words += 8; break;
             default: return fail(MINA_ERR_ARG, "unknown tape opcode");
         }
     }

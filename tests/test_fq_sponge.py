@@ -8,7 +8,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
-ABS_FQ, ABS_G, ABS_FR, CHAL, CHAL_FQ, CHAL_ENDO, DIGEST = range(7)
+ABS_FQ, ABS_G, ABS_FR, CHAL, CHAL_FQ, CHAL_ENDO, DIGEST, CHAL_ENDO_OWN = range(8)
 
 
 def run_reference(oracle, I, R, curve, pp, tape, inputs_ints, init=None):
@@ -30,6 +30,10 @@ def run_reference(oracle, I, R, curve, pp, tape, inputs_ints, init=None):
             outs.append(sp.challenge_fq())
         elif op == CHAL_ENDO:
             outs.append(R.challenge_to_field(sp.challenge(), R.endo_r(curve), r))
+        elif op == CHAL_ENDO_OWN:
+            # Fr-sponge: the sponge's field is the scalar field of the OTHER curve; its endo_r lives in that field
+            other = 1 - curve
+            outs.append(R.challenge_to_field(sp.challenge(), R.endo_r(other), R.scalar_modulus(other)))
         else:
             d = sp.challenge_fq()
             outs.append(d if d < r else 0)
@@ -44,7 +48,7 @@ def test_tape_matches_restatement(ctx, oracle, srs_oracle, curve):
     q, r = R.base_modulus(curve), R.scalar_modulus(curve)
     g, _ = srs_oracle[curve]
     rng = random.Random(100 + curve)
-    tape = [ABS_G, ABS_G, CHAL, ABS_FR, CHAL_ENDO, ABS_FQ, ABS_FQ, ABS_FQ, CHAL_FQ, CHAL, ABS_G, DIGEST, ABS_FR, ABS_FR, CHAL_ENDO, CHAL_FQ, CHAL_FQ, CHAL_FQ, ABS_FQ, DIGEST]
+    tape = [ABS_G, ABS_G, CHAL, ABS_FR, CHAL_ENDO, ABS_FQ, ABS_FQ, ABS_FQ, CHAL_FQ, CHAL, ABS_G, DIGEST, ABS_FR, ABS_FR, CHAL_ENDO, CHAL_FQ, CHAL_FQ, CHAL_FQ, ABS_FQ, DIGEST, ABS_FQ, ABS_FQ, CHAL_ENDO_OWN, CHAL_ENDO_OWN]
     batch = 9
     all_inputs, per_proof = [], []
     for b in range(batch):
