@@ -106,8 +106,10 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        args.gpus = world
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            print(f"bench.py: --gpus {args.gpus} without a torch.distributed.run launch (WORLD_SIZE=1): measuring 1 GPU", file=sys.stderr)
+        args.gpus = world                      # the number of ranks actually running is what is reported
     dist_on = world > 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
