@@ -36,7 +36,7 @@ template <int F> MB_HD xyzz_t xyzz_dbl_affine(const fe_t &x, const fe_t &y) {
     fe_t x2 = fe_sqr<F>(x);
     fe_t m = fe_add<F>(fe_dbl<F>(x2), x2);
     r.x = fe_sub<F>(fe_sub<F>(fe_sqr<F>(m), s), s);
-    r.y = fe_sub<F>(fe_mul<F>(m, fe_sub<F>(s, r.x)), fe_mul<F>(w, y));
+    r.y = fe_dot2<F>(m, fe_sub<F>(s, r.x), w, fe_neg<F>(y));       // m (s - x3) - w y, one reduction
     r.zz = v; r.zzz = w;
     return r;
 }
@@ -52,7 +52,7 @@ template <int F> MB_HD xyzz_t xyzz_dbl(const xyzz_t &p) {
     fe_t x2 = fe_sqr<F>(p.x);
     fe_t m = fe_add<F>(fe_dbl<F>(x2), x2);
     r.x = fe_sub<F>(fe_sub<F>(fe_sqr<F>(m), s), s);
-    r.y = fe_sub<F>(fe_mul<F>(m, fe_sub<F>(s, r.x)), fe_mul<F>(w, p.y));
+    r.y = fe_dot2<F>(m, fe_sub<F>(s, r.x), w, fe_neg<F>(p.y));
     r.zz = fe_mul<F>(v, p.zz);
     r.zzz = fe_mul<F>(w, p.zzz);
     return r;
@@ -74,7 +74,7 @@ template <int F> MB_HD void xyzz_add_affine(xyzz_t &acc, const fe_t &qx, const f
     fe_t ppp = fe_mul<F>(p, pp);
     fe_t q = fe_mul<F>(acc.x, pp);
     fe_t x3 = fe_sub<F>(fe_sub<F>(fe_sub<F>(fe_sqr<F>(r), ppp), q), q);
-    fe_t y3 = fe_sub<F>(fe_mul<F>(r, fe_sub<F>(q, x3)), fe_mul<F>(acc.y, ppp));
+    fe_t y3 = fe_dot2<F>(r, fe_sub<F>(q, x3), fe_neg<F>(acc.y), ppp);   // r (q - x3) - y1 ppp, one reduction
     acc.zz = fe_mul<F>(acc.zz, pp);
     acc.zzz = fe_mul<F>(acc.zzz, ppp);
     acc.x = x3; acc.y = y3;
@@ -99,7 +99,7 @@ template <int F> MB_HD void xyzz_add(xyzz_t &acc, const xyzz_t &q) {
     fe_t ppp = fe_mul<F>(p, pp);
     fe_t qq = fe_mul<F>(u1, pp);
     fe_t x3 = fe_sub<F>(fe_sub<F>(fe_sub<F>(fe_sqr<F>(r), ppp), qq), qq);
-    fe_t y3 = fe_sub<F>(fe_mul<F>(r, fe_sub<F>(qq, x3)), fe_mul<F>(s1, ppp));
+    fe_t y3 = fe_dot2<F>(r, fe_sub<F>(qq, x3), fe_neg<F>(s1), ppp);
     acc.zz = fe_mul<F>(fe_mul<F>(acc.zz, q.zz), pp);
     acc.zzz = fe_mul<F>(fe_mul<F>(acc.zzz, q.zzz), ppp);
     acc.x = x3; acc.y = y3;

@@ -276,7 +276,7 @@ __device__ __forceinline__ void mb_fold_shift(uint64_t &acc, uint32_t &hi, uint3
     acc = ((uint64_t)nhi << 32) | nlo; hi = 0;
 }
 template <int F> __device__ __forceinline__ fe_t fe_mul_device(const fe_t &a, const fe_t &b) {
-    // generated by tools/gen_fe_mul.py -- product scanning, one asm statement per column
+    // generated by tools/gen_fe_mul.py -- product scanning, one Montgomery reduction
     uint64_t acc = 0, cc; uint32_t hi = 0, lo, mid; fe_t r;
     uint32_t m0, m1, m2, m3, m4, m5, m6, m7;
     const uint32_t p1 = FieldP<F>::P1, p2 = FieldP<F>::P2, p3 = FieldP<F>::P3, p7 = P7;
@@ -351,6 +351,192 @@ template <int F> __device__ __forceinline__ fe_t fe_mul_device(const fe_t &a, co
     r.v[7] = (uint32_t)acc;                                       // result < 2p < 2^256
     return fe_cond_sub_p<F>(r);
 }
+template <int F> __device__ __forceinline__ fe_t fe_dot2_device(const fe_t &a0, const fe_t &b0, const fe_t &a1, const fe_t &b1) {
+    // generated by tools/gen_fe_mul.py -- product scanning, one Montgomery reduction
+    uint64_t acc = 0, cc; uint32_t hi = 0, lo, mid; fe_t r;
+    uint32_t m0, m1, m2, m3, m4, m5, m6, m7;
+    const uint32_t p1 = FieldP<F>::P1, p2 = FieldP<F>::P2, p3 = FieldP<F>::P3, p7 = P7;
+    // column 0: 2 products
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[0]));
+    lo = (uint32_t)acc; mid = (uint32_t)(acc >> 32); m0 = 0u - lo;
+    mb_fold_shift(acc, hi, lo, mid);                          // + m_k * p0 (low word -> 0), then >> 32
+    // column 1: 5 products
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[1]), "v"(a0.v[1]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[1]), "v"(a1.v[1]), "v"(b1.v[0]), "v"(m0), "v"(p1));
+    lo = (uint32_t)acc; mid = (uint32_t)(acc >> 32); m1 = 0u - lo;
+    mb_fold_shift(acc, hi, lo, mid);                          // + m_k * p0 (low word -> 0), then >> 32
+    // column 2: 8 products
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[2]), "v"(a0.v[1]), "v"(b0.v[1]), "v"(a0.v[2]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[2]), "v"(a1.v[1]), "v"(b1.v[1]), "v"(a1.v[2]), "v"(b1.v[0]), "v"(m0), "v"(p2), "v"(m1), "v"(p1));
+    lo = (uint32_t)acc; mid = (uint32_t)(acc >> 32); m2 = 0u - lo;
+    mb_fold_shift(acc, hi, lo, mid);                          // + m_k * p0 (low word -> 0), then >> 32
+    // column 3: 11 products
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[3]), "v"(a0.v[1]), "v"(b0.v[2]), "v"(a0.v[2]), "v"(b0.v[1]), "v"(a0.v[3]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[3]), "v"(a1.v[1]), "v"(b1.v[2]), "v"(a1.v[2]), "v"(b1.v[1]), "v"(a1.v[3]), "v"(b1.v[0]), "v"(m0), "v"(p3), "v"(m1), "v"(p2), "v"(m2), "v"(p1));
+    lo = (uint32_t)acc; mid = (uint32_t)(acc >> 32); m3 = 0u - lo;
+    mb_fold_shift(acc, hi, lo, mid);                          // + m_k * p0 (low word -> 0), then >> 32
+    // column 4: 13 products
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %25, %26, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[4]), "v"(a0.v[1]), "v"(b0.v[3]), "v"(a0.v[2]), "v"(b0.v[2]), "v"(a0.v[3]), "v"(b0.v[1]), "v"(a0.v[4]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[4]), "v"(a1.v[1]), "v"(b1.v[3]), "v"(a1.v[2]), "v"(b1.v[2]), "v"(a1.v[3]), "v"(b1.v[1]), "v"(a1.v[4]), "v"(b1.v[0]), "v"(m1), "v"(p3), "v"(m2), "v"(p2));
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(m3), "v"(p1));
+    lo = (uint32_t)acc; mid = (uint32_t)(acc >> 32); m4 = 0u - lo;
+    mb_fold_shift(acc, hi, lo, mid);                          // + m_k * p0 (low word -> 0), then >> 32
+    // column 5: 15 products
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %25, %26, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[5]), "v"(a0.v[1]), "v"(b0.v[4]), "v"(a0.v[2]), "v"(b0.v[3]), "v"(a0.v[3]), "v"(b0.v[2]), "v"(a0.v[4]), "v"(b0.v[1]), "v"(a0.v[5]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[5]), "v"(a1.v[1]), "v"(b1.v[4]), "v"(a1.v[2]), "v"(b1.v[3]), "v"(a1.v[3]), "v"(b1.v[2]), "v"(a1.v[4]), "v"(b1.v[1]), "v"(a1.v[5]), "v"(b1.v[0]));
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(m2), "v"(p3), "v"(m3), "v"(p2), "v"(m4), "v"(p1));
+    lo = (uint32_t)acc; mid = (uint32_t)(acc >> 32); m5 = 0u - lo;
+    mb_fold_shift(acc, hi, lo, mid);                          // + m_k * p0 (low word -> 0), then >> 32
+    // column 6: 17 products
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %25, %26, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[6]), "v"(a0.v[1]), "v"(b0.v[5]), "v"(a0.v[2]), "v"(b0.v[4]), "v"(a0.v[3]), "v"(b0.v[3]), "v"(a0.v[4]), "v"(b0.v[2]), "v"(a0.v[5]), "v"(b0.v[1]), "v"(a0.v[6]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[6]), "v"(a1.v[1]), "v"(b1.v[5]), "v"(a1.v[2]), "v"(b1.v[4]), "v"(a1.v[3]), "v"(b1.v[3]), "v"(a1.v[4]), "v"(b1.v[2]));
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a1.v[5]), "v"(b1.v[1]), "v"(a1.v[6]), "v"(b1.v[0]), "v"(m3), "v"(p3), "v"(m4), "v"(p2), "v"(m5), "v"(p1));
+    lo = (uint32_t)acc; mid = (uint32_t)(acc >> 32); m6 = 0u - lo;
+    mb_fold_shift(acc, hi, lo, mid);                          // + m_k * p0 (low word -> 0), then >> 32
+    // column 7: 20 products
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %25, %26, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[7]), "v"(a0.v[1]), "v"(b0.v[6]), "v"(a0.v[2]), "v"(b0.v[5]), "v"(a0.v[3]), "v"(b0.v[4]), "v"(a0.v[4]), "v"(b0.v[3]), "v"(a0.v[5]), "v"(b0.v[2]), "v"(a0.v[6]), "v"(b0.v[1]), "v"(a0.v[7]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[7]), "v"(a1.v[1]), "v"(b1.v[6]), "v"(a1.v[2]), "v"(b1.v[5]), "v"(a1.v[3]), "v"(b1.v[4]));
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a1.v[4]), "v"(b1.v[3]), "v"(a1.v[5]), "v"(b1.v[2]), "v"(a1.v[6]), "v"(b1.v[1]), "v"(a1.v[7]), "v"(b1.v[0]), "v"(m0), "v"(p7), "v"(m4), "v"(p3), "v"(m5), "v"(p2), "v"(m6), "v"(p1));
+    lo = (uint32_t)acc; mid = (uint32_t)(acc >> 32); m7 = 0u - lo;
+    mb_fold_shift(acc, hi, lo, mid);                          // + m_k * p0 (low word -> 0), then >> 32
+    // column 8: 18 products
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %25, %26, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[1]), "v"(b0.v[7]), "v"(a0.v[2]), "v"(b0.v[6]), "v"(a0.v[3]), "v"(b0.v[5]), "v"(a0.v[4]), "v"(b0.v[4]), "v"(a0.v[5]), "v"(b0.v[3]), "v"(a0.v[6]), "v"(b0.v[2]), "v"(a0.v[7]), "v"(b0.v[1]), "v"(a1.v[1]), "v"(b1.v[7]), "v"(a1.v[2]), "v"(b1.v[6]), "v"(a1.v[3]), "v"(b1.v[5]), "v"(a1.v[4]), "v"(b1.v[4]), "v"(a1.v[5]), "v"(b1.v[3]));
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a1.v[6]), "v"(b1.v[2]), "v"(a1.v[7]), "v"(b1.v[1]), "v"(m1), "v"(p7), "v"(m5), "v"(p3), "v"(m6), "v"(p2), "v"(m7), "v"(p1));
+    r.v[0] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
+    // column 9: 15 products
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %25, %26, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[2]), "v"(b0.v[7]), "v"(a0.v[3]), "v"(b0.v[6]), "v"(a0.v[4]), "v"(b0.v[5]), "v"(a0.v[5]), "v"(b0.v[4]), "v"(a0.v[6]), "v"(b0.v[3]), "v"(a0.v[7]), "v"(b0.v[2]), "v"(a1.v[2]), "v"(b1.v[7]), "v"(a1.v[3]), "v"(b1.v[6]), "v"(a1.v[4]), "v"(b1.v[5]), "v"(a1.v[5]), "v"(b1.v[4]), "v"(a1.v[6]), "v"(b1.v[3]), "v"(a1.v[7]), "v"(b1.v[2]));
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(m2), "v"(p7), "v"(m6), "v"(p3), "v"(m7), "v"(p2));
+    r.v[1] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
+    // column 10: 12 products
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %25, %26, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[3]), "v"(b0.v[7]), "v"(a0.v[4]), "v"(b0.v[6]), "v"(a0.v[5]), "v"(b0.v[5]), "v"(a0.v[6]), "v"(b0.v[4]), "v"(a0.v[7]), "v"(b0.v[3]), "v"(a1.v[3]), "v"(b1.v[7]), "v"(a1.v[4]), "v"(b1.v[6]), "v"(a1.v[5]), "v"(b1.v[5]), "v"(a1.v[6]), "v"(b1.v[4]), "v"(a1.v[7]), "v"(b1.v[3]), "v"(m3), "v"(p7), "v"(m7), "v"(p3));
+    r.v[2] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
+    // column 11: 9 products
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[4]), "v"(b0.v[7]), "v"(a0.v[5]), "v"(b0.v[6]), "v"(a0.v[6]), "v"(b0.v[5]), "v"(a0.v[7]), "v"(b0.v[4]), "v"(a1.v[4]), "v"(b1.v[7]), "v"(a1.v[5]), "v"(b1.v[6]), "v"(a1.v[6]), "v"(b1.v[5]), "v"(a1.v[7]), "v"(b1.v[4]), "v"(m4), "v"(p7));
+    r.v[3] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
+    // column 12: 7 products
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[5]), "v"(b0.v[7]), "v"(a0.v[6]), "v"(b0.v[6]), "v"(a0.v[7]), "v"(b0.v[5]), "v"(a1.v[5]), "v"(b1.v[7]), "v"(a1.v[6]), "v"(b1.v[6]), "v"(a1.v[7]), "v"(b1.v[5]), "v"(m5), "v"(p7));
+    r.v[4] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
+    // column 13: 5 products
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[6]), "v"(b0.v[7]), "v"(a0.v[7]), "v"(b0.v[6]), "v"(a1.v[6]), "v"(b1.v[7]), "v"(a1.v[7]), "v"(b1.v[6]), "v"(m6), "v"(p7));
+    r.v[5] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
+    // column 14: 3 products
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[7]), "v"(b0.v[7]), "v"(a1.v[7]), "v"(b1.v[7]), "v"(m7), "v"(p7));
+    r.v[6] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
+    r.v[7] = (uint32_t)acc;                                       // result < 2p < 2^256
+    return fe_cond_sub_p<F>(r);
+}
+template <int F> __device__ __forceinline__ fe_t fe_dot3_device(const fe_t &a0, const fe_t &b0, const fe_t &a1, const fe_t &b1, const fe_t &a2, const fe_t &b2) {
+    // generated by tools/gen_fe_mul.py -- product scanning, one Montgomery reduction
+    uint64_t acc = 0, cc; uint32_t hi = 0, lo, mid; fe_t r;
+    uint32_t m0, m1, m2, m3, m4, m5, m6, m7;
+    const uint32_t p1 = FieldP<F>::P1, p2 = FieldP<F>::P2, p3 = FieldP<F>::P3, p7 = P7;
+    // column 0: 3 products
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[0]), "v"(a2.v[0]), "v"(b2.v[0]));
+    lo = (uint32_t)acc; mid = (uint32_t)(acc >> 32); m0 = 0u - lo;
+    mb_fold_shift(acc, hi, lo, mid);                          // + m_k * p0 (low word -> 0), then >> 32
+    // column 1: 7 products
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[1]), "v"(a0.v[1]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[1]), "v"(a1.v[1]), "v"(b1.v[0]), "v"(a2.v[0]), "v"(b2.v[1]), "v"(a2.v[1]), "v"(b2.v[0]), "v"(m0), "v"(p1));
+    lo = (uint32_t)acc; mid = (uint32_t)(acc >> 32); m1 = 0u - lo;
+    mb_fold_shift(acc, hi, lo, mid);                          // + m_k * p0 (low word -> 0), then >> 32
+    // column 2: 11 products
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[2]), "v"(a0.v[1]), "v"(b0.v[1]), "v"(a0.v[2]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[2]), "v"(a1.v[1]), "v"(b1.v[1]), "v"(a1.v[2]), "v"(b1.v[0]), "v"(a2.v[0]), "v"(b2.v[2]), "v"(a2.v[1]), "v"(b2.v[1]), "v"(a2.v[2]), "v"(b2.v[0]), "v"(m0), "v"(p2), "v"(m1), "v"(p1));
+    lo = (uint32_t)acc; mid = (uint32_t)(acc >> 32); m2 = 0u - lo;
+    mb_fold_shift(acc, hi, lo, mid);                          // + m_k * p0 (low word -> 0), then >> 32
+    // column 3: 15 products
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %25, %26, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[3]), "v"(a0.v[1]), "v"(b0.v[2]), "v"(a0.v[2]), "v"(b0.v[1]), "v"(a0.v[3]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[3]), "v"(a1.v[1]), "v"(b1.v[2]), "v"(a1.v[2]), "v"(b1.v[1]), "v"(a1.v[3]), "v"(b1.v[0]), "v"(a2.v[0]), "v"(b2.v[3]), "v"(a2.v[1]), "v"(b2.v[2]), "v"(a2.v[2]), "v"(b2.v[1]), "v"(a2.v[3]), "v"(b2.v[0]));
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(m0), "v"(p3), "v"(m1), "v"(p2), "v"(m2), "v"(p1));
+    lo = (uint32_t)acc; mid = (uint32_t)(acc >> 32); m3 = 0u - lo;
+    mb_fold_shift(acc, hi, lo, mid);                          // + m_k * p0 (low word -> 0), then >> 32
+    // column 4: 18 products
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %25, %26, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[4]), "v"(a0.v[1]), "v"(b0.v[3]), "v"(a0.v[2]), "v"(b0.v[2]), "v"(a0.v[3]), "v"(b0.v[1]), "v"(a0.v[4]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[4]), "v"(a1.v[1]), "v"(b1.v[3]), "v"(a1.v[2]), "v"(b1.v[2]), "v"(a1.v[3]), "v"(b1.v[1]), "v"(a1.v[4]), "v"(b1.v[0]), "v"(a2.v[0]), "v"(b2.v[4]), "v"(a2.v[1]), "v"(b2.v[3]));
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a2.v[2]), "v"(b2.v[2]), "v"(a2.v[3]), "v"(b2.v[1]), "v"(a2.v[4]), "v"(b2.v[0]), "v"(m1), "v"(p3), "v"(m2), "v"(p2), "v"(m3), "v"(p1));
+    lo = (uint32_t)acc; mid = (uint32_t)(acc >> 32); m4 = 0u - lo;
+    mb_fold_shift(acc, hi, lo, mid);                          // + m_k * p0 (low word -> 0), then >> 32
+    // column 5: 21 products
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %25, %26, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[5]), "v"(a0.v[1]), "v"(b0.v[4]), "v"(a0.v[2]), "v"(b0.v[3]), "v"(a0.v[3]), "v"(b0.v[2]), "v"(a0.v[4]), "v"(b0.v[1]), "v"(a0.v[5]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[5]), "v"(a1.v[1]), "v"(b1.v[4]), "v"(a1.v[2]), "v"(b1.v[3]), "v"(a1.v[3]), "v"(b1.v[2]), "v"(a1.v[4]), "v"(b1.v[1]), "v"(a1.v[5]), "v"(b1.v[0]));
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a2.v[0]), "v"(b2.v[5]), "v"(a2.v[1]), "v"(b2.v[4]), "v"(a2.v[2]), "v"(b2.v[3]), "v"(a2.v[3]), "v"(b2.v[2]), "v"(a2.v[4]), "v"(b2.v[1]), "v"(a2.v[5]), "v"(b2.v[0]), "v"(m2), "v"(p3), "v"(m3), "v"(p2), "v"(m4), "v"(p1));
+    lo = (uint32_t)acc; mid = (uint32_t)(acc >> 32); m5 = 0u - lo;
+    mb_fold_shift(acc, hi, lo, mid);                          // + m_k * p0 (low word -> 0), then >> 32
+    // column 6: 24 products
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %25, %26, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[6]), "v"(a0.v[1]), "v"(b0.v[5]), "v"(a0.v[2]), "v"(b0.v[4]), "v"(a0.v[3]), "v"(b0.v[3]), "v"(a0.v[4]), "v"(b0.v[2]), "v"(a0.v[5]), "v"(b0.v[1]), "v"(a0.v[6]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[6]), "v"(a1.v[1]), "v"(b1.v[5]), "v"(a1.v[2]), "v"(b1.v[4]), "v"(a1.v[3]), "v"(b1.v[3]), "v"(a1.v[4]), "v"(b1.v[2]));
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %25, %26, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a1.v[5]), "v"(b1.v[1]), "v"(a1.v[6]), "v"(b1.v[0]), "v"(a2.v[0]), "v"(b2.v[6]), "v"(a2.v[1]), "v"(b2.v[5]), "v"(a2.v[2]), "v"(b2.v[4]), "v"(a2.v[3]), "v"(b2.v[3]), "v"(a2.v[4]), "v"(b2.v[2]), "v"(a2.v[5]), "v"(b2.v[1]), "v"(a2.v[6]), "v"(b2.v[0]), "v"(m3), "v"(p3), "v"(m4), "v"(p2), "v"(m5), "v"(p1));
+    lo = (uint32_t)acc; mid = (uint32_t)(acc >> 32); m6 = 0u - lo;
+    mb_fold_shift(acc, hi, lo, mid);                          // + m_k * p0 (low word -> 0), then >> 32
+    // column 7: 28 products
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %25, %26, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[7]), "v"(a0.v[1]), "v"(b0.v[6]), "v"(a0.v[2]), "v"(b0.v[5]), "v"(a0.v[3]), "v"(b0.v[4]), "v"(a0.v[4]), "v"(b0.v[3]), "v"(a0.v[5]), "v"(b0.v[2]), "v"(a0.v[6]), "v"(b0.v[1]), "v"(a0.v[7]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[7]), "v"(a1.v[1]), "v"(b1.v[6]), "v"(a1.v[2]), "v"(b1.v[5]), "v"(a1.v[3]), "v"(b1.v[4]));
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %25, %26, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a1.v[4]), "v"(b1.v[3]), "v"(a1.v[5]), "v"(b1.v[2]), "v"(a1.v[6]), "v"(b1.v[1]), "v"(a1.v[7]), "v"(b1.v[0]), "v"(a2.v[0]), "v"(b2.v[7]), "v"(a2.v[1]), "v"(b2.v[6]), "v"(a2.v[2]), "v"(b2.v[5]), "v"(a2.v[3]), "v"(b2.v[4]), "v"(a2.v[4]), "v"(b2.v[3]), "v"(a2.v[5]), "v"(b2.v[2]), "v"(a2.v[6]), "v"(b2.v[1]), "v"(a2.v[7]), "v"(b2.v[0]));
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(m0), "v"(p7), "v"(m4), "v"(p3), "v"(m5), "v"(p2), "v"(m6), "v"(p1));
+    lo = (uint32_t)acc; mid = (uint32_t)(acc >> 32); m7 = 0u - lo;
+    mb_fold_shift(acc, hi, lo, mid);                          // + m_k * p0 (low word -> 0), then >> 32
+    // column 8: 25 products
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %25, %26, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[1]), "v"(b0.v[7]), "v"(a0.v[2]), "v"(b0.v[6]), "v"(a0.v[3]), "v"(b0.v[5]), "v"(a0.v[4]), "v"(b0.v[4]), "v"(a0.v[5]), "v"(b0.v[3]), "v"(a0.v[6]), "v"(b0.v[2]), "v"(a0.v[7]), "v"(b0.v[1]), "v"(a1.v[1]), "v"(b1.v[7]), "v"(a1.v[2]), "v"(b1.v[6]), "v"(a1.v[3]), "v"(b1.v[5]), "v"(a1.v[4]), "v"(b1.v[4]), "v"(a1.v[5]), "v"(b1.v[3]));
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %25, %26, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a1.v[6]), "v"(b1.v[2]), "v"(a1.v[7]), "v"(b1.v[1]), "v"(a2.v[1]), "v"(b2.v[7]), "v"(a2.v[2]), "v"(b2.v[6]), "v"(a2.v[3]), "v"(b2.v[5]), "v"(a2.v[4]), "v"(b2.v[4]), "v"(a2.v[5]), "v"(b2.v[3]), "v"(a2.v[6]), "v"(b2.v[2]), "v"(a2.v[7]), "v"(b2.v[1]), "v"(m1), "v"(p7), "v"(m5), "v"(p3), "v"(m6), "v"(p2));
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(m7), "v"(p1));
+    r.v[0] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
+    // column 9: 21 products
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %25, %26, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[2]), "v"(b0.v[7]), "v"(a0.v[3]), "v"(b0.v[6]), "v"(a0.v[4]), "v"(b0.v[5]), "v"(a0.v[5]), "v"(b0.v[4]), "v"(a0.v[6]), "v"(b0.v[3]), "v"(a0.v[7]), "v"(b0.v[2]), "v"(a1.v[2]), "v"(b1.v[7]), "v"(a1.v[3]), "v"(b1.v[6]), "v"(a1.v[4]), "v"(b1.v[5]), "v"(a1.v[5]), "v"(b1.v[4]), "v"(a1.v[6]), "v"(b1.v[3]), "v"(a1.v[7]), "v"(b1.v[2]));
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a2.v[2]), "v"(b2.v[7]), "v"(a2.v[3]), "v"(b2.v[6]), "v"(a2.v[4]), "v"(b2.v[5]), "v"(a2.v[5]), "v"(b2.v[4]), "v"(a2.v[6]), "v"(b2.v[3]), "v"(a2.v[7]), "v"(b2.v[2]), "v"(m2), "v"(p7), "v"(m6), "v"(p3), "v"(m7), "v"(p2));
+    r.v[1] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
+    // column 10: 17 products
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %25, %26, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[3]), "v"(b0.v[7]), "v"(a0.v[4]), "v"(b0.v[6]), "v"(a0.v[5]), "v"(b0.v[5]), "v"(a0.v[6]), "v"(b0.v[4]), "v"(a0.v[7]), "v"(b0.v[3]), "v"(a1.v[3]), "v"(b1.v[7]), "v"(a1.v[4]), "v"(b1.v[6]), "v"(a1.v[5]), "v"(b1.v[5]), "v"(a1.v[6]), "v"(b1.v[4]), "v"(a1.v[7]), "v"(b1.v[3]), "v"(a2.v[3]), "v"(b2.v[7]), "v"(a2.v[4]), "v"(b2.v[6]));
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a2.v[5]), "v"(b2.v[5]), "v"(a2.v[6]), "v"(b2.v[4]), "v"(a2.v[7]), "v"(b2.v[3]), "v"(m3), "v"(p7), "v"(m7), "v"(p3));
+    r.v[2] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
+    // column 11: 13 products
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %25, %26, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[4]), "v"(b0.v[7]), "v"(a0.v[5]), "v"(b0.v[6]), "v"(a0.v[6]), "v"(b0.v[5]), "v"(a0.v[7]), "v"(b0.v[4]), "v"(a1.v[4]), "v"(b1.v[7]), "v"(a1.v[5]), "v"(b1.v[6]), "v"(a1.v[6]), "v"(b1.v[5]), "v"(a1.v[7]), "v"(b1.v[4]), "v"(a2.v[4]), "v"(b2.v[7]), "v"(a2.v[5]), "v"(b2.v[6]), "v"(a2.v[6]), "v"(b2.v[5]), "v"(a2.v[7]), "v"(b2.v[4]));
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(m4), "v"(p7));
+    r.v[3] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
+    // column 12: 10 products
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[5]), "v"(b0.v[7]), "v"(a0.v[6]), "v"(b0.v[6]), "v"(a0.v[7]), "v"(b0.v[5]), "v"(a1.v[5]), "v"(b1.v[7]), "v"(a1.v[6]), "v"(b1.v[6]), "v"(a1.v[7]), "v"(b1.v[5]), "v"(a2.v[5]), "v"(b2.v[7]), "v"(a2.v[6]), "v"(b2.v[6]), "v"(a2.v[7]), "v"(b2.v[5]), "v"(m5), "v"(p7));
+    r.v[4] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
+    // column 13: 7 products
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[6]), "v"(b0.v[7]), "v"(a0.v[7]), "v"(b0.v[6]), "v"(a1.v[6]), "v"(b1.v[7]), "v"(a1.v[7]), "v"(b1.v[6]), "v"(a2.v[6]), "v"(b2.v[7]), "v"(a2.v[7]), "v"(b2.v[6]), "v"(m6), "v"(p7));
+    r.v[5] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
+    // column 14: 4 products
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[7]), "v"(b0.v[7]), "v"(a1.v[7]), "v"(b1.v[7]), "v"(a2.v[7]), "v"(b2.v[7]), "v"(m7), "v"(p7));
+    r.v[6] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
+    r.v[7] = (uint32_t)acc;                                       // result < 2p < 2^256
+    return fe_cond_sub_p<F>(r);
+}
 
 #endif
 template <int F> MB_HD fe_t fe_mul(const fe_t &a, const fe_t &b) {
@@ -361,6 +547,21 @@ template <int F> MB_HD fe_t fe_mul(const fe_t &a, const fe_t &b) {
 #endif
 }
 template <int F> MB_HD fe_t fe_sqr(const fe_t &a) { return fe_mul<F>(a, a); }
+// a0*b0 + a1*b1 (+ a2*b2) with a single Montgomery reduction on the device (see tools/gen_fe_mul.py)
+template <int F> MB_HD fe_t fe_dot2(const fe_t &a0, const fe_t &b0, const fe_t &a1, const fe_t &b1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return fe_dot2_device<F>(a0, b0, a1, b1);
+#else
+    return fe_add<F>(fe_mul<F>(a0, b0), fe_mul<F>(a1, b1));
+#endif
+}
+template <int F> MB_HD fe_t fe_dot3(const fe_t &a0, const fe_t &b0, const fe_t &a1, const fe_t &b1, const fe_t &a2, const fe_t &b2) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return fe_dot3_device<F>(a0, b0, a1, b1, a2, b2);
+#else
+    return fe_add<F>(fe_add<F>(fe_mul<F>(a0, b0), fe_mul<F>(a1, b1)), fe_mul<F>(a2, b2));
+#endif
+}
 
 // Constants (computed once on the host, see fp_host.h) that kernels need by value.
 template <int F> struct FieldConsts {

@@ -61,7 +61,17 @@ bpoly_fold_kernel(BpolyShape sh, uint32_t slices, const fe_t *__restrict__ ltab,
     fe_t acc[BP_HT];
 #pragma unroll
     for (int t = 0; t < BP_HT; ++t) acc[t] = fe_zero();
-    for (uint32_t b = b0; b < b1; ++b) {
+    uint32_t b = b0;
+    for (; b + 3 <= b1; b += 3) {                          // three proofs per step: one reduction per dot product
+        const fe_t l0 = ltab[(size_t)b * nl + lo], l1 = ltab[(size_t)(b + 1) * nl + lo], l2 = ltab[(size_t)(b + 2) * nl + lo];
+#pragma unroll
+        for (int t = 0; t < BP_HT; ++t) {
+            uint32_t hi = tile * BP_HT + t;
+            if (hi < nh) acc[t] = fe_add<F>(acc[t], fe_dot3<F>(l0, htab[(size_t)b * nh + hi], l1, htab[(size_t)(b + 1) * nh + hi],
+                                                               l2, htab[(size_t)(b + 2) * nh + hi]));
+        }
+    }
+    for (; b < b1; ++b) {
         const fe_t l = ltab[(size_t)b * nl + lo];
 #pragma unroll
         for (int t = 0; t < BP_HT; ++t) {
@@ -122,10 +132,8 @@ __device__ __forceinline__ void poseidon_permute(fe_t s[3], const PoseidonParams
         }
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            fe_t acc = fe_mul<F>(pp->mds[i][0], t[0]);
-            acc = fe_add<F>(acc, fe_mul<F>(pp->mds[i][1], t[1]));
-            acc = fe_add<F>(acc, fe_mul<F>(pp->mds[i][2], t[2]));
-            s[i] = fe_add<F>(acc, pp->rc[r][i]);
+            // MDS row as one dot product: a single Montgomery reduction for the three products
+            s[i] = fe_add<F>(fe_dot3<F>(pp->mds[i][0], t[0], pp->mds[i][1], t[1], pp->mds[i][2], t[2]), pp->rc[r][i]);
         }
     }
 }
@@ -177,10 +185,7 @@ __device__ __forceinline__ void poseidon_permute_quad(fe_t &s, const PoseidonPar
         fe_t x4 = fe_sqr<F>(x2);
         fe_t t = fe_mul<F>(fe_mul<F>(x4, x2), s);
         fe_t t0 = quad_bcast<0>(t), t1 = quad_bcast<1>(t), t2 = quad_bcast<2>(t);
-        fe_t acc = fe_mul<F>(m0, t0);
-        acc = fe_add<F>(acc, fe_mul<F>(m1, t1));
-        acc = fe_add<F>(acc, fe_mul<F>(m2, t2));
-        s = fe_add<F>(acc, pp->rc[r][qq]);
+        s = fe_add<F>(fe_dot3<F>(m0, t0, m1, t1, m2, t2), pp->rc[r][qq]);
     }
 }
 
