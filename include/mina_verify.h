@@ -99,6 +99,10 @@ int mina_srs_lagrange_basis(mina_ctx *ctx, int curve, uint32_t log2_domain, uint
  * The Lagrange basis of the domain is computed once and cached in the context. */
 int mina_public_input_commitment(mina_ctx *ctx, int curve, uint32_t log2_domain, size_t npub, const uint8_t *public_inputs /* npub*32 */,
                                  uint8_t *out_affine);
+/* `batch` public-input commitments at once (batch_verify computes one per proof): out[m] = h - sum_i public[m][i] * lagrange[i].
+ * The first npub basis points get a fixed-base window table once; every proof is one problem of the multi-problem MSM. */
+int mina_public_input_commitment_batch(mina_ctx *ctx, int curve, uint32_t log2_domain, size_t npub, size_t batch,
+                                       const uint8_t *public_inputs /* batch*npub*32 */, uint8_t *out_affine /* batch*64 */);
 /* serialise back to the reference's file format; *len receives the size (2 293 801 for depth 2^16) */
 int mina_srs_serialize(mina_ctx *ctx, int curve, uint8_t *out, size_t cap, size_t *len);
 
@@ -110,6 +114,11 @@ int mina_msm(mina_ctx *ctx, int curve, size_t n, const uint8_t *bases_affine, co
 int mina_msm_srs(mina_ctx *ctx, int curve, size_t n, const uint8_t *scalars, uint8_t *out_affine);
 /* out = sum_i scalars[i] * g[first + i]: the slice of the SRS owned by one rank when an MSM is sharded by bases. */
 int mina_msm_srs_range(mina_ctx *ctx, int curve, uint32_t first, size_t n, const uint8_t *scalars, uint8_t *out_affine);
+/* nprob MSMs over the same SRS bases in ONE kernel pipeline: out[m] = sum_i scalars[m][i] * g[i], i < n.
+ * (poly-commitment `SRS::commit_non_hiding` of nprob polynomials -- kimchi commits ~45 per proof; also nprob un-folded
+ * accumulator MSMs.)  Each problem owns one set of 2^15 buckets; everything else is shared. */
+int mina_msm_srs_multi(mina_ctx *ctx, int curve, size_t n, size_t nprob, const uint8_t *scalars /* nprob*n*32 */,
+                       uint8_t *out_affine /* nprob*64 */);
 /* Same with scalars already in HBM (n x 32 bytes, canonical).  Queued on the context stream; the
  * 68-byte result record {x[32], y[32], u32 is_infinity} is written to `d_out` (device memory). */
 int mina_msm_srs_dev(mina_ctx *ctx, int curve, size_t n, const void *d_scalars, void *d_out);

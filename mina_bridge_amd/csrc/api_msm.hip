@@ -1,25 +1,28 @@
 // api_msm.hip -- K1 host driver: queues the MSM kernel pipeline of msm.cuh on the context stream.
 #include "ctx.h"
 #include "msm.cuh"
+#include <vector>
 
 // ------------------------------------------------------------------------------------------------
 // MSM driver
 static MsmShape fixed_shape(const SrsState &s, uint32_t first, uint32_t n) {
-    MsmShape sh; sh.n = n; sh.c = s.c; sh.W = s.W; sh.NB = 1u << (s.c - 1); sh.nsets = 1; sh.table_stride = s.depth; sh.base_first = first; return sh;
+    MsmShape sh; sh.n = n; sh.c = s.c; sh.W = s.W; sh.NB = 1u << (s.c - 1); sh.nsets = 1; sh.table_stride = s.depth; sh.base_first = first; sh.nprob = 1; return sh;
 }
 static MsmShape variable_shape(uint32_t n) {
     MsmShape sh; sh.n = n;
     sh.c = n < 2048 ? 8 : (n < 32768 ? 11 : 14);
-    sh.W = (256 + sh.c - 1) / sh.c; sh.NB = 1u << (sh.c - 1); sh.nsets = sh.W; sh.table_stride = 0; sh.base_first = 0; return sh;
+    sh.W = (256 + sh.c - 1) / sh.c; sh.NB = 1u << (sh.c - 1); sh.nsets = sh.W; sh.table_stride = 0; sh.base_first = 0; sh.nprob = 1; return sh;
 }
 
 template <int F>
 static int run_msm(mina_ctx *c, const MsmShape &sh, const uint32_t *d_scalars, const affine_t *d_points,
-                   uint32_t *d_out_words /* 17 words */, xyzz_t *d_out_xyzz) {
+                   uint32_t *d_out_words /* 17 words per problem */, xyzz_t *d_out_xyzz /* one per problem */) {
     MsmWorkspace &w = c->L->ws;
     const FieldK &fk = c->fk[F];
+    if (sh.nprob == 0 || sh.nsets % sh.nprob) return fail(MINA_ERR_ARG, "bad problem count");
+    if ((uint64_t)sh.NB * sh.nsets > (1u << 26) || (uint64_t)sh.n * sh.W * sh.nprob > (1u << 28)) return fail(MINA_ERR_ARG, "MSM batch too large for one pipeline");
     const uint32_t nb_total = sh.NB * sh.nsets;
-    const size_t entries = (size_t)sh.n * sh.W;
+    const size_t entries = (size_t)sh.n * sh.W * sh.nprob;
     const size_t max_tasks = entries / MSM_TASK_LEN + nb_total + 1;
     int rc;
     if ((rc = w.ekey.ensure(entries * 4))) return rc;
@@ -69,7 +72,7 @@ static int run_msm(mina_ctx *c, const MsmShape &sh, const uint32_t *d_scalars, c
           msm_wsum16_kernel<F><<<dim3(Gr + Gc, sh.nsets), 64, 0, st>>>(R, C, Gr, w.red_r.as<xyzz_t>(), w.red_ws.as<xyzz_t>(), w.red2_r.as<xyzz_t>(), w.red2_w.as<xyzz_t>());
           msm_reduce2d_kernel<F><<<sh.nsets, 256, 0, st>>>(Gr, Gc, log2C, w.red2_r.as<xyzz_t>(), w.red2_w.as<xyzz_t>(), w.set_total.as<xyzz_t>()); }
     }
-    { ProfScope ps_(c, PS_FINISH); msm_finish_kernel<F><<<1, 64, 0, st>>>(sh.nsets, sh.c, w.set_total.as<xyzz_t>(), fk.one, fk.pm2, d_out_xyzz, d_out_words); }
+    { ProfScope ps_(c, PS_FINISH); msm_finish_kernel<F><<<sh.nprob, 64, 0, st>>>(sh.nsets / sh.nprob, sh.c, w.set_total.as<xyzz_t>(), fk.one, fk.pm2, d_out_xyzz, d_out_words); }
     HIPC(hipGetLastError());
     return MINA_OK;
 }
@@ -86,6 +89,16 @@ int mb_msm_fixed(mina_ctx *c, int curve, uint32_t n, const uint32_t *d_scalars, 
     MsmShape sh = fixed_shape(s, first, n);
     int rc = MINA_OK;
     DISPATCH_FIELD(base_field_of(curve), { rc = run_msm<F_>(c, sh, d_scalars, s.table.as<affine_t>(), d_out_words, (xyzz_t *)d_out_xyzz); });
+    return rc;
+}
+
+// nprob MSMs over one fixed-base window table (table[w * stride + i] = 2^(cbits w) * base_i): results per problem
+int mb_msm_table(mina_ctx *c, int curve, const void *d_table, uint32_t stride, uint32_t cbits, uint32_t W, uint32_t first, uint32_t n,
+                 uint32_t nprob, const uint32_t *d_scalars, uint32_t *d_out_words, void *d_out_xyzz) {
+    if (n == 0 || nprob == 0 || (uint64_t)first + n > stride) return fail(MINA_ERR_ARG, "bad table MSM shape");
+    MsmShape sh; sh.n = n; sh.c = cbits; sh.W = W; sh.NB = 1u << (cbits - 1); sh.nsets = nprob; sh.table_stride = stride; sh.base_first = first; sh.nprob = nprob;
+    int rc = MINA_OK;
+    DISPATCH_FIELD(base_field_of(curve), { rc = run_msm<F_>(c, sh, d_scalars, (const affine_t *)d_table, d_out_words, (xyzz_t *)d_out_xyzz); });
     return rc;
 }
 
@@ -149,6 +162,29 @@ extern "C" int mina_msm_srs(mina_ctx *c, int curve, size_t n, const uint8_t *sca
     HIPC(hipMemcpyAsync(hw, c->L->ws.out_words.p, sizeof hw, hipMemcpyDeviceToHost, c->L->stream));
     HIPC(hipStreamSynchronize(c->L->stream));
     words_to_point_bytes(hw, out);
+    return MINA_OK;
+}
+
+extern "C" int mina_msm_srs_multi(mina_ctx *c, int curve, size_t n, size_t nprob, const uint8_t *scalars, uint8_t *out) {
+    if (!c || !out || (n && nprob && !scalars)) return fail(MINA_ERR_ARG, "null argument");
+    if (curve != 0 && curve != 1) return fail(MINA_ERR_ARG, "bad curve");
+    if (nprob == 0) return MINA_OK;
+    if (n == 0) { memset(out, 0, nprob * 64); return MINA_OK; }
+    SrsState &s = c->srs[curve];
+    if (s.depth == 0) return fail(MINA_ERR_STATE, "SRS not loaded for this curve");
+    if (n > s.depth || nprob > 4096) return fail(MINA_ERR_ARG, "n / nprob out of range");
+    HIPC(hipSetDevice(c->device));
+    c->use_lane0();
+    int rc;
+    MsmWorkspace &w = c->L->ws;
+    if ((rc = w.scalars.ensure(nprob * n * 32))) return rc;
+    if ((rc = w.out_words.ensure(nprob * 17 * 4))) return rc;
+    HIPC(hipMemcpyAsync(w.scalars.p, scalars, nprob * n * 32, hipMemcpyHostToDevice, c->L->stream));
+    if ((rc = mb_msm_table(c, curve, s.table.p, s.depth, s.c, s.W, 0, (uint32_t)n, (uint32_t)nprob, w.scalars.as<uint32_t>(), w.out_words.as<uint32_t>(), nullptr))) return rc;
+    std::vector<uint32_t> hw(nprob * 17);
+    HIPC(hipMemcpyAsync(hw.data(), w.out_words.p, hw.size() * 4, hipMemcpyDeviceToHost, c->L->stream));
+    HIPC(hipStreamSynchronize(c->L->stream));
+    for (size_t m = 0; m < nprob; ++m) words_to_point_bytes(&hw[m * 17], out + m * 64);
     return MINA_OK;
 }
 

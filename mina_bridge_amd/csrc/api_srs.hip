@@ -3,6 +3,7 @@
 #include "msm.cuh"
 #include "lagrange.cuh"
 #include <type_traits>
+#include <vector>
 
 // ------------------------------------------------------------------------------------------------
 // SRS
@@ -192,6 +193,18 @@ extern "C" int mina_srs_lagrange_basis(mina_ctx *c, int curve, uint32_t log2_dom
     return run_lagrange<FIELD_FQ, FIELD_FP>(c, s, log2_domain, out_affine);
 }
 
+// Lagrange basis of this domain, cached on the host in canonical form (one-off group iFFT on the GPU)
+static int ensure_lagrange_host(mina_ctx *c, int curve, uint32_t log2_domain) {
+    SrsState &s = c->srs[curve];
+    if (s.lagrange_log2 == (int)log2_domain && !s.lagrange_host.empty()) return MINA_OK;
+    int rc;
+    s.lagrange_host.assign(((size_t)1 << log2_domain) * 64, 0);
+    s.lagrange_log2 = -1; s.lagrange_table_log2 = -1;
+    if ((rc = mina_srs_lagrange_basis(c, curve, log2_domain, s.lagrange_host.data()))) { s.lagrange_host.clear(); return rc; }
+    s.lagrange_log2 = (int)log2_domain;
+    return MINA_OK;
+}
+
 // ------------------------------------------------------------------------------------------------
 // kimchi verifier: public-input commitment  public_comm = h - sum_i pub_i * lagrange_i   (a11; `mask_custom` with blinder 1)
 extern "C" int mina_public_input_commitment(mina_ctx *c, int curve, uint32_t log2_domain, size_t npub, const uint8_t *public_inputs,
@@ -204,12 +217,7 @@ extern "C" int mina_public_input_commitment(mina_ctx *c, int curve, uint32_t log
     HIPC(hipSetDevice(c->device));
     c->use_lane0();
     int rc;
-    // Lagrange basis of this domain, cached on the host in canonical form (one-off group iFFT on the GPU)
-    if (s.lagrange_log2 != (int)log2_domain || s.lagrange_host.empty()) {
-        s.lagrange_host.assign(((size_t)1 << log2_domain) * 64, 0);
-        if ((rc = mina_srs_lagrange_basis(c, curve, log2_domain, s.lagrange_host.data()))) { s.lagrange_host.clear(); return rc; }
-        s.lagrange_log2 = (int)log2_domain;
-    }
+    if ((rc = ensure_lagrange_host(c, curve, log2_domain))) return rc;
     uint8_t acc[64]; memset(acc, 0, 64);
     if (npub && (rc = mina_msm(c, curve, npub, s.lagrange_host.data(), public_inputs, acc))) return rc;
     uint8_t hbytes[64];
@@ -228,5 +236,67 @@ extern "C" int mina_public_input_commitment(mina_ctx *c, int curve, uint32_t log
         memcpy(out_affine, x.v, 32); memcpy(out_affine + 32, y.v, 32);
     };
     if (base_field_of(curve) == FIELD_FP) finish(std::integral_constant<int, FIELD_FP>{}); else finish(std::integral_constant<int, FIELD_FQ>{});
+    return MINA_OK;
+}
+
+// Batched form: `batch` proofs' public-input commitments in one pipeline.  The first npub Lagrange points get a window
+// table (c = 8, W = 32: 2^(8w) * L_i) once; every commitment is then one fixed-base problem of the multi-problem MSM
+// (128 signed buckets per proof, no doubling chain), finished by h - A on the device.
+static constexpr uint32_t LAG_C = 8, LAG_W = 32;
+template <int F> static int build_lagrange_table(mina_ctx *c, SrsState &s, uint32_t n_tab) {
+    const FieldK &fk = c->fk[F];
+    int rc;
+    if ((rc = s.lagrange_table.ensure((size_t)LAG_W * n_tab * sizeof(affine_t)))) return rc;
+    if ((rc = c->L->tmp_a.ensure((size_t)n_tab * 64))) return rc;
+    if ((rc = h2d(c, c->L->tmp_a, s.lagrange_host.data(), (size_t)n_tab * 64))) return rc;
+    points_to_mont_kernel<F><<<cdiv(n_tab, 256), 256, 0, c->L->stream>>>(n_tab, c->L->tmp_a.as<uint32_t>(), fk.r2, s.lagrange_table.as<affine_t>());
+    msm_build_table_kernel<F><<<cdiv(n_tab, 256), 256, 0, c->L->stream>>>(n_tab, n_tab, LAG_C, LAG_W, fk.one, fk.pm2, s.lagrange_table.as<affine_t>());
+    HIPC(hipGetLastError());
+    HIPC(hipStreamSynchronize(c->L->stream));
+    return MINA_OK;
+}
+
+extern "C" int mina_public_input_commitment_batch(mina_ctx *c, int curve, uint32_t log2_domain, size_t npub, size_t batch,
+                                                  const uint8_t *public_inputs, uint8_t *out_affine) {
+    if (!c || (batch && !out_affine) || (npub && batch && !public_inputs)) return fail(MINA_ERR_ARG, "null argument");
+    if (curve != 0 && curve != 1) return fail(MINA_ERR_ARG, "bad curve");
+    SrsState &s = c->srs[curve];
+    if (s.depth == 0) return fail(MINA_ERR_STATE, "SRS not loaded");
+    if (log2_domain > 20 || ((uint64_t)1 << log2_domain) > s.depth || npub > ((size_t)1 << log2_domain)) return fail(MINA_ERR_ARG, "bad domain / npub");
+    if (npub > 4096 || batch > 65536) return fail(MINA_ERR_ARG, "npub / batch out of range");
+    if (batch == 0) return MINA_OK;
+    HIPC(hipSetDevice(c->device));
+    c->use_lane0();
+    int rc;
+    if (npub == 0) {                                            // empty public input: h itself
+        uint8_t hb[64];
+        if ((rc = mina_srs_get_h(c, curve, hb))) return rc;
+        for (size_t m = 0; m < batch; ++m) memcpy(out_affine + m * 64, hb, 64);
+        return MINA_OK;
+    }
+    if ((rc = ensure_lagrange_host(c, curve, log2_domain))) return rc;
+    const int FB = base_field_of(curve);
+    if (s.lagrange_table_log2 != (int)log2_domain || s.lagrange_table_n < npub) {
+        uint32_t n_tab = (uint32_t)(npub < 64 ? 64 : npub);
+        if (n_tab > (1u << log2_domain)) n_tab = 1u << log2_domain;
+        s.lagrange_table_log2 = -1;
+        DISPATCH_FIELD(FB, { rc = build_lagrange_table<F_>(c, s, n_tab); });
+        if (rc) return rc;
+        s.lagrange_table_n = n_tab; s.lagrange_table_log2 = (int)log2_domain;
+    }
+    MsmWorkspace &w = c->L->ws;
+    if ((rc = w.scalars.ensure(batch * npub * 32))) return rc;
+    if ((rc = c->L->tmp_b.ensure(batch * sizeof(xyzz_t)))) return rc;
+    if ((rc = w.out_words.ensure(batch * 17 * 4))) return rc;
+    if ((rc = h2d(c, w.scalars, public_inputs, batch * npub * 32))) return rc;
+    if ((rc = mb_msm_table(c, curve, s.lagrange_table.p, s.lagrange_table_n, LAG_C, LAG_W, 0, (uint32_t)npub, (uint32_t)batch,
+                           w.scalars.as<uint32_t>(), nullptr, c->L->tmp_b.p))) return rc;
+    DISPATCH_FIELD(FB, { pubcomm_finish_kernel<F_><<<cdiv(batch, 64), 64, 0, c->L->stream>>>((uint32_t)batch, c->fk[F_], s.h.as<affine_t>(), c->L->tmp_b.as<xyzz_t>(), w.out_words.as<uint32_t>()); });
+    HIPC(hipGetLastError());
+    std::vector<uint32_t> hw(batch * 17);
+    if ((rc = d2h_sync(c, hw.data(), w.out_words, hw.size() * 4))) return rc;
+    for (size_t m = 0; m < batch; ++m) {
+        if (hw[m * 17 + 16]) memset(out_affine + m * 64, 0, 64); else memcpy(out_affine + m * 64, &hw[m * 17], 64);
+    }
     return MINA_OK;
 }

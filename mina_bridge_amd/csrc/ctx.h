@@ -43,6 +43,9 @@ struct SrsState {
     DevBuf h;                          // 1 affine_t
     int lagrange_log2 = -1;            // cached Lagrange basis (canonical affine bytes, host side)
     std::vector<uint8_t> lagrange_host;
+    DevBuf lagrange_table;             // window table (c = 8, W = 32) of the first lagrange_table_n basis points, for
+    uint32_t lagrange_table_n = 0;     //   batched public-input commitments
+    int lagrange_table_log2 = -1;
 };
 
 struct MsmWorkspace {
@@ -131,6 +134,8 @@ struct xyzz_dev;   // opaque: mb::xyzz_t in HBM
 int mb_msm_fixed(mina_ctx *c, int curve, uint32_t n, const uint32_t *d_scalars, uint32_t *d_out_words, void *d_out_xyzz, uint32_t first = 0);
 // variable-base MSM over Montgomery affine points already in HBM
 // K2 fold on the current lane (no lane switch)
+int mb_msm_table(mina_ctx *c, int curve, const void *d_table, uint32_t stride, uint32_t cbits, uint32_t W, uint32_t first, uint32_t n,
+                 uint32_t nprob, const uint32_t *d_scalars, uint32_t *d_out_words, void *d_out_xyzz);
 int mb_bpoly_fold(mina_ctx *c, int field, uint32_t k, size_t batch, const uint32_t *d_chals, const uint32_t *d_weights, uint32_t *d_out);
 int mb_msm_variable(mina_ctx *c, int curve, uint32_t n, const uint32_t *d_scalars, const void *d_points_mont,
                     uint32_t *d_out_words, void *d_out_xyzz);

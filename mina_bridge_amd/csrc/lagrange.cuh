@@ -86,4 +86,23 @@ lagrange_finish_kernel(uint32_t n, FieldK kb, const uint32_t *__restrict__ n_inv
     out[i] = r;
 }
 
+// batched public-input commitments: out[m] = h - A[m], A[m] = sum_i pub[m][i] * lagrange_i from the table MSM.
+// One lane per problem; 17 canonical words each (x || y, infinity flag).
+template <int FB>
+__global__ void __launch_bounds__(64)
+pubcomm_finish_kernel(uint32_t batch, FieldK kb, const affine_t *__restrict__ h, const xyzz_t *__restrict__ a, uint32_t *__restrict__ out_words) {
+    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= batch) return;
+    xyzz_t t = a[m];
+    t.y = fe_neg<FB>(t.y);
+    const affine_t H = *h;
+    xyzz_add_affine<FB>(t, H.x, H.y, kb.one);
+    uint32_t *o = out_words + (size_t)m * 17;
+    if (xyzz_is_inf(t)) { for (int i = 0; i < 16; ++i) o[i] = 0; o[16] = 1; return; }
+    const fe_t zi = fe_inv<FB>(fe_mul<FB>(t.zz, t.zzz), kb);
+    const fe_t x = fe_from_mont<FB>(fe_mul<FB>(t.x, fe_mul<FB>(zi, t.zzz))), y = fe_from_mont<FB>(fe_mul<FB>(t.y, fe_mul<FB>(zi, t.zz)));
+    for (int i = 0; i < 8; ++i) { o[i] = x.v[i]; o[8 + i] = y.v[i]; }
+    o[16] = 0;
+}
+
 }  // namespace mb

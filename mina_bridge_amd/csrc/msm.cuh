@@ -28,9 +28,11 @@ struct MsmShape {
     uint32_t c;        // window bits
     uint32_t W;        // windows (W*c >= 256)
     uint32_t NB;       // buckets per bucket set = 2^(c-1)
-    uint32_t nsets;    // 1 (shared buckets, fixed-base table) or W (variable-base)
+    uint32_t nsets;    // bucket sets in total = nprob * (1 for a fixed-base table | W for variable-base)
     uint32_t table_stride;  // fixed-base: points per window in the table (>= n); 0 for variable-base
     uint32_t base_first;    // fixed-base: index of the first SRS base used (scalar i multiplies g[base_first + i])
+    uint32_t nprob;    // independent problems over the SAME bases in one pipeline (scalars laid out [nprob][n]); each
+                       // problem owns its bucket sets and gets its own result
 };
 
 // ---------------------------------------------------------------- device helpers
@@ -54,10 +56,13 @@ static __global__ void msm_digits_kernel(MsmShape sh, const uint32_t *__restrict
                                          uint32_t *__restrict__ count, uint32_t *__restrict__ ekey,
                                          uint32_t *__restrict__ eval, uint32_t *__restrict__ eoff) {
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= (size_t)sh.n * sh.W) return;
-    const uint32_t w = (uint32_t)(e / sh.n), i = (uint32_t)(e % sh.n);
+    const size_t per_prob = (size_t)sh.n * sh.W;
+    if (e >= per_prob * sh.nprob) return;
+    const uint32_t m = (uint32_t)(e / per_prob);
+    const uint32_t ep = (uint32_t)(e - (size_t)m * per_prob);
+    const uint32_t w = ep / sh.n, i = ep % sh.n;
     uint32_t s[8];
-    const uint4 *sp = reinterpret_cast<const uint4 *>(scalars + (size_t)i * 8);
+    const uint4 *sp = reinterpret_cast<const uint4 *>(scalars + ((size_t)m * sh.n + i) * 8);
     uint4 a = sp[0], b = sp[1];
     s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
     const uint32_t half = 1u << (sh.c - 1);
@@ -72,7 +77,7 @@ static __global__ void msm_digits_kernel(MsmShape sh, const uint32_t *__restrict
     uint32_t neg = 0;
     if (d > half) { d = (1u << sh.c) - d; neg = 1; }
     if (d == 0) { ekey[e] = MSM_INVALID; return; }
-    const uint32_t bucket = (sh.nsets == 1 ? 0u : w * sh.NB) + (d - 1);
+    const uint32_t bucket = (sh.table_stride ? m : m * sh.W + w) * sh.NB + (d - 1);
     ekey[e] = bucket;
     eval[e] = (sh.table_stride ? w * sh.table_stride + sh.base_first + i : i) | (neg << 31);
     eoff[e] = atomicAdd(&count[bucket], 1u);
@@ -453,12 +458,16 @@ msm_reduce2d_kernel(uint32_t Gr, uint32_t Gc, uint32_t log2C, const xyzz_t *__re
     }
 }
 
-// K1h: Horner over bucket sets (variable-base), then normalise to affine (Montgomery) + canonical words.
-//   out_words[0..16) = x||y canonical little-endian words, out_words[16] = 1 if infinity.
+// K1h: per problem (one block each): Horner over its bucket sets (variable-base; a fixed-base problem has one set),
+// then normalise to affine (Montgomery) + canonical words.
+//   out_words[17 m + 0..16) = x||y canonical little-endian words, out_words[17 m + 16] = 1 if infinity; out_xyzz[m].
 template <int F>
-__global__ void msm_finish_kernel(uint32_t nsets, uint32_t c, const xyzz_t *__restrict__ set_total, fe_t one,
+__global__ void msm_finish_kernel(uint32_t nsets /* per problem */, uint32_t c, const xyzz_t *__restrict__ set_total, fe_t one,
                                   fe_t pm2, xyzz_t *__restrict__ out_xyzz, uint32_t *__restrict__ out_words) {
-    if (blockIdx.x != 0 || threadIdx.x >= 4) return;           // one quad: lane-cooperative doublings / adds
+    if (threadIdx.x >= 4) return;                              // one quad: lane-cooperative doublings / adds
+    set_total += (size_t)blockIdx.x * nsets;
+    if (out_xyzz) out_xyzz += blockIdx.x;
+    if (out_words) out_words += (size_t)blockIdx.x * 17;
     xyzz_t t = set_total[nsets - 1];
     for (int w = (int)nsets - 2; w >= 0; --w) {
         for (uint32_t i = 0; i < c; ++i) t = xyzz_dbl_quad<F>(t);

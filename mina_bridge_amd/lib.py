@@ -22,8 +22,8 @@ CURVE_PALLAS, CURVE_VESTA = 0, 1
 # every symbol include/mina_verify.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "mina_ctx_create", "mina_ctx_destroy", "mina_last_error", "mina_ctx_synchronize", "mina_ctx_stream", "mina_ctx_set_pipeline", "mina_prof_enable", "mina_prof_read",
-    "mina_srs_create", "mina_srs_load", "mina_srs_depth", "mina_srs_get_g", "mina_srs_get_h", "mina_srs_lagrange_basis", "mina_public_input_commitment", "mina_combined_inner_product", "mina_srs_serialize",
-    "mina_msm", "mina_msm_srs", "mina_msm_srs_range", "mina_msm_srs_dev",
+    "mina_srs_create", "mina_srs_load", "mina_srs_depth", "mina_srs_get_g", "mina_srs_get_h", "mina_srs_lagrange_basis", "mina_public_input_commitment", "mina_public_input_commitment_batch", "mina_combined_inner_product", "mina_srs_serialize",
+    "mina_msm", "mina_msm_srs", "mina_msm_srs_range", "mina_msm_srs_multi", "mina_msm_srs_dev",
     "mina_b_poly", "mina_b_poly_coefficients", "mina_b_poly_fold", "mina_b_poly_fold_dev",
     "mina_poseidon_set_params", "mina_poseidon_permute", "mina_poseidon_permute_dev", "mina_poseidon_hash",
     "mina_challenge_to_field", "mina_fq_sponge_run", "mina_to_group", "mina_merkle_roots", "mina_merkle_verify_batch",
@@ -284,6 +284,15 @@ class MinaContext:
                  "mina_public_input_commitment")
         return out
 
+    def public_input_commitment_batch(self, curve: int, log2_domain: int, public_inputs, batch: int) -> np.ndarray:
+        """public_inputs: batch x npub x 32 bytes -> batch x 64 (one commitment per proof)"""
+        pub = _u8(public_inputs) if batch and len(public_inputs) else np.zeros(32, np.uint8)
+        npub = (pub.size // 32) // batch if batch and len(public_inputs) else 0
+        out = np.empty((max(batch, 1), 64), np.uint8)
+        self._ck(self._lib.mina_public_input_commitment_batch(self._h, curve, ctypes.c_uint32(log2_domain), ctypes.c_size_t(npub), ctypes.c_size_t(batch),
+                                                              _p(pub), _p(out)), "mina_public_input_commitment_batch")
+        return out[:batch]
+
     def srs_serialize(self, curve: int) -> bytes:
         depth = self.srs_depth(curve)
         cap = 6 + (depth + 1) * 35
@@ -314,6 +323,15 @@ class MinaContext:
         out = np.empty(64, np.uint8)
         self._ck(self._lib.mina_msm_srs_range(self._h, curve, ctypes.c_uint32(first), ctypes.c_size_t(n), _p(scalars), _p(out)), "mina_msm_srs_range")
         return out
+
+    def msm_srs_multi(self, curve: int, scalars, nprob: int) -> np.ndarray:
+        """scalars: nprob x n x 32 bytes -> nprob x 64: out[m] = sum_i scalars[m][i] * g[i] in one kernel pipeline"""
+        scalars = _u8(scalars)
+        n = (scalars.size // 32) // nprob if nprob else 0
+        assert nprob == 0 or scalars.size == nprob * n * 32
+        out = np.empty((max(nprob, 1), 64), np.uint8)
+        self._ck(self._lib.mina_msm_srs_multi(self._h, curve, ctypes.c_size_t(n), ctypes.c_size_t(nprob), _p(scalars), _p(out)), "mina_msm_srs_multi")
+        return out[:nprob]
 
     def msm_srs_dev(self, curve: int, n: int, d_scalars: int, d_out: int):
         self._ck(self._lib.mina_msm_srs_dev(self._h, curve, ctypes.c_size_t(n), ctypes.c_void_p(d_scalars), ctypes.c_void_p(d_out)), "mina_msm_srs_dev")

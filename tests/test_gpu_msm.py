@@ -194,3 +194,36 @@ def test_msm_randomised_stress(ctx_srs, oracle, srs_oracle):
         n = int(rng.choice([1, 5, 64, 1000, 4097]))
         sc = oracle.ints_to_le([int(x) for x in rng.integers(0, 3, size=n)]) if trial % 2 else np.repeat(rand_scalars(1, r, seed=trial), n, axis=0)
         assert (ctx_srs.msm_srs(curve, sc) == oracle.msm_pippenger(curve, g[:n], sc, threads=2)).all(), (trial, n)
+
+
+@pytest.mark.parametrize("curve,n,nprob", [(1, 65536, 3), (0, 32768, 2), (1, 1000, 7), (0, 1, 4), (1, 65536, 1)])
+def test_msm_srs_multi_matches_single(ctx_srs, oracle, srs_oracle, curve, n, nprob):
+    """nprob MSMs over the SRS in one pipeline (one bucket set per problem) == nprob single fixed-base MSMs == oracle"""
+    from conftest import rand_scalars
+    from oracle import pasta_ref as R
+    g, _ = srs_oracle[curve]
+    r = R.scalar_modulus(curve)
+    sc = rand_scalars(nprob * n, r, seed=4242 + n + nprob).reshape(nprob, n, 32)
+    sc[0, :, :] = 0                                              # problem 0: all-zero scalars -> infinity
+    if nprob > 1 and n > 8:
+        sc[1, 8:, :] = 0                                         # problem 1: only 8 non-zero scalars
+    got = ctx_srs.msm_srs_multi(curve, sc, nprob)
+    assert got.shape == (nprob, 64)
+    assert not got[0].any()
+    for m in range(nprob):
+        assert (got[m] == ctx_srs.msm_srs(curve, sc[m])).all(), m
+    last = nprob - 1
+    assert (got[last] == oracle.msm_pippenger(curve, g[:n], sc[last], threads=8)).all()
+
+
+def test_msm_srs_multi_many_problems(ctx_srs, oracle, srs_oracle):
+    """45 commitments of degree-2^12 polynomials (the per-proof commitment count of kimchi) in one call"""
+    from conftest import rand_scalars
+    from oracle import pasta_ref as R
+    curve, n, nprob = 0, 4096, 45
+    g, _ = srs_oracle[curve]
+    sc = rand_scalars(nprob * n, R.scalar_modulus(curve), seed=99).reshape(nprob, n, 32)
+    got = ctx_srs.msm_srs_multi(curve, sc, nprob)
+    for m in (0, 22, 44):
+        assert (got[m] == oracle.msm_pippenger(curve, g[:n], sc[m], threads=8)).all(), m
+    assert len({bytes(x) for x in got}) == nprob

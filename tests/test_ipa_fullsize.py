@@ -1,4 +1,5 @@
-"""a8 at full size: the committed opening proof over 2^15 Pallas bases (tests/golden/ipa_pallas_k15.json, minted by
+"""a8 at full size: the committed opening proofs over 2^15 Pallas bases (tests/golden/ipa_pallas_k15.json with 4
+commitments and ipa_pallas_k15_c45.json with the 45 commitments of the wrap-proof shape; both minted by
 tests/golden/gen_ipa_fixture.py with the oracle prover).  CPU leg: the verifier restatement accepts it / rejects a
 tampered copy.  GPU leg: `mina_ipa_batch_check` does the same, alone and replicated in a batch."""
 import json
@@ -7,12 +8,14 @@ import os
 import numpy as np
 import pytest
 
-FX = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ipa_pallas_k15.json")))
+FIXTURES = {n: json.load(open(os.path.join(os.path.dirname(__file__), "golden", n + ".json")))
+            for n in ("ipa_pallas_k15", "ipa_pallas_k15_c45")}
+FX = FIXTURES["ipa_pallas_k15"]
 
 
-def abi_entry():
+def abi_entry(fx=None):
     out = {}
-    for k, v in FX["fields"].items():
+    for k, v in (fx or FX)["fields"].items():
         out[k] = np.frombuffer(bytes.fromhex(v), dtype=np.uint8).copy() if isinstance(v, str) else v
     return out
 
@@ -33,24 +36,39 @@ def to_oracle_entry(oracle, a):
                         "z1": oracle.le_to_int(a["z1"]), "z2": oracle.le_to_int(a["z2"])}}
 
 
-def test_oracle_accepts_fullsize_fixture(oracle, srs_oracle):
+@pytest.mark.parametrize("name", sorted(FIXTURES))
+def test_oracle_accepts_fullsize_fixture(oracle, srs_oracle, name):
     from oracle import ipa_ref as I
-    curve = FX["curve"]
+    fx = FIXTURES[name]
+    curve = fx["curve"]
     g, h = srs_oracle[curve]
-    a = abi_entry()
+    a = abi_entry(fx)
+    assert a["n_comms"] == (45 if name.endswith("c45") else 4)
     n = 1 << a["k"]
     assert I.ipa_verify_batch(curve, g[:n], oracle.bytes_to_point(h), [to_oracle_entry(oracle, a)], 7, 11)
-    bad = abi_entry(); bad["z2"][5] ^= 4
+    bad = abi_entry(fx); bad["z2"][5] ^= 4
     assert not I.ipa_verify_batch(curve, g[:n], oracle.bytes_to_point(h), [to_oracle_entry(oracle, bad)], 7, 11)
 
 
 @pytest.mark.gpu
-def test_gpu_accepts_fullsize_fixture(ctx_srs, oracle):
-    curve = FX["curve"]
+@pytest.mark.parametrize("name", sorted(FIXTURES))
+def test_gpu_accepts_fullsize_fixture(ctx_srs, oracle, name):
+    fx = FIXTURES[name]
+    curve = fx["curve"]
     rb, sb = oracle.int_to_le(0xABCDEF0123456789ABCDEF), oracle.int_to_le(0x1234567)
-    a = abi_entry()
+    a = abi_entry(fx)
     assert ctx_srs.ipa_batch_check(curve, [a], rb, sb) is True
     assert ctx_srs.ipa_batch_check(curve, [a] * 5, rb, sb) is True            # batch of identical valid openings
     for key, idx in (("z1", 0), ("lr", 700), ("comms", 100), ("combined_inner_product", 3), ("sponge_state", 40)):
-        bad = abi_entry(); bad[key][idx] ^= 1
+        bad = abi_entry(fx); bad[key][idx] ^= 1
         assert ctx_srs.ipa_batch_check(curve, [a, bad, a], rb, sb) is False, key
+
+
+@pytest.mark.gpu
+def test_gpu_mixed_shapes_in_one_batch(ctx_srs, oracle):
+    """openings with different commitment counts (4 and 45) combine into one check"""
+    rb, sb = oracle.int_to_le(77), oracle.int_to_le(99)
+    a4, a45 = abi_entry(FIXTURES["ipa_pallas_k15"]), abi_entry(FIXTURES["ipa_pallas_k15_c45"])
+    assert ctx_srs.ipa_batch_check(0, [a4, a45, a45, a4], rb, sb) is True
+    bad = abi_entry(FIXTURES["ipa_pallas_k15_c45"]); bad["comms"][64 * 44 + 7] ^= 2      # last commitment of the 45
+    assert ctx_srs.ipa_batch_check(0, [a4, bad], rb, sb) is False

@@ -67,6 +67,35 @@ def test_public_input_commitment(ctx_srs, oracle, srs_oracle):
     assert (ctx_srs.public_input_commitment(curve, k, pub) == got).all()
 
 
+@pytest.mark.parametrize("curve,k,npub,batch", [(0, 6, 40, 5), (1, 5, 32, 3), (0, 15, 40, 17), (0, 7, 1, 2), (0, 8, 100, 4)])
+def test_public_input_commitment_batch(ctx_srs, oracle, srs_oracle, curve, k, npub, batch):
+    """batched form (one fixed-base problem per proof over the Lagrange window table) == the single-proof entry point
+    (variable-base MSM), which test_public_input_commitment pins to the oracle; plus a direct oracle check of row 0"""
+    from conftest import rand_scalars
+    from oracle import pasta_ref as R
+    g, h = srs_oracle[curve]
+    r = R.scalar_modulus(curve)
+    pub = rand_scalars(batch * npub, r, seed=1000 + 7 * k + npub).reshape(batch, npub, 32)
+    pub[1, :, :] = 0                                            # an all-zero public input -> h
+    if batch > 2:
+        pub[2, :, :] = 0; pub[2, npub - 1, 0] = 1               # a single unit scalar -> h - L_{npub-1}
+    got = ctx_srs.public_input_commitment_batch(curve, k, pub, batch)
+    assert got.shape == (batch, 64)
+    for m in range(batch):
+        assert (got[m] == ctx_srs.public_input_commitment(curve, k, pub[m])).all(), m
+    assert (got[1] == h).all()
+    basis = ctx_srs.srs_lagrange_basis(curve, k)
+    mod = R.base_modulus(curve)
+    a0 = oracle.bytes_to_point(oracle.msm_naive(curve, basis[:npub], pub[0]))
+    assert oracle.bytes_to_point(got[0]) == R.add(oracle.bytes_to_point(h), R.neg(a0, mod), mod)
+    # table is reused for a smaller npub and rebuilt for a larger one
+    small = ctx_srs.public_input_commitment_batch(curve, k, pub[:, :1, :].copy(), batch)
+    assert (small[0] == ctx_srs.public_input_commitment(curve, k, pub[0, :1])).all()
+    # empty public input and empty batch
+    assert (ctx_srs.public_input_commitment_batch(curve, k, np.zeros((0, 32), np.uint8), 3) == np.broadcast_to(h, (3, 64))).all()
+    assert ctx_srs.public_input_commitment_batch(curve, k, np.zeros((0, 32), np.uint8), 0).shape == (0, 64)
+
+
 def test_combined_inner_product_matches_restatement(oracle):
     import mina_bridge_amd as m
     from conftest import rand_scalars
