@@ -490,8 +490,10 @@ class MinaContext:
                                                        ctypes.c_void_p(d_sg), ctypes.c_void_p(d_rho) if d_rho else None, ctypes.c_void_p(d_verdict)),
                  "mina_accumulator_check_dev")
 
-    def ipa_batch_check(self, curve: int, openings: list, rand_base, sg_rand_base) -> bool:
-        """`openings`: list of dicts with the fields of `mina_ipa_opening` (numpy uint8 arrays)."""
+    @staticmethod
+    def pack_ipa_openings(openings: list):
+        """list of dicts with the fields of `mina_ipa_opening` (numpy uint8 arrays) -> (ctypes array, keep-alive list).
+        Packing is pure host work; callers that verify the same batch repeatedly (timing tools) do it once."""
         keep = []
         arr = (IpaOpening * len(openings))()
 
@@ -513,7 +515,13 @@ class MinaContext:
             e.polyscale, e.evalscale = ptr(o["polyscale"]), ptr(o["evalscale"])
             e.sponge_state = ptr(o["sponge_state"])
             e.sponge_mode, e.sponge_count = int(o["sponge_mode"]), int(o["sponge_count"])
+        return arr, keep
+
+    def ipa_batch_check(self, curve: int, openings, rand_base, sg_rand_base) -> bool:
+        """`openings`: list of dicts with the fields of `mina_ipa_opening` (numpy uint8 arrays), or the result of
+        `pack_ipa_openings`."""
+        arr, keep = openings if isinstance(openings, tuple) else self.pack_ipa_openings(openings)
         rb, sb = _u8(rand_base), _u8(sg_rand_base)
         v = np.zeros(1, np.uint8)
-        self._ck(self._lib.mina_ipa_batch_check(self._h, curve, ctypes.c_size_t(len(openings)), arr, _p(rb), _p(sb), _p(v)), "mina_ipa_batch_check")
+        self._ck(self._lib.mina_ipa_batch_check(self._h, curve, ctypes.c_size_t(len(arr)), arr, _p(rb), _p(sb), _p(v)), "mina_ipa_batch_check")
         return bool(v[0])

@@ -12,7 +12,7 @@ for f in (0, 1): ctx.poseidon_set_params(f, m.poseidon_params.default_params_byt
 ctx.srs_create(0, 65536)
 rb = np.zeros(32, np.uint8); rb[:8] = 7; sb = np.zeros(32, np.uint8); sb[:8] = 9
 for B in (1, 16, 256, 1024):
-    ops = [a] * B
+    ops = ctx.pack_ipa_openings([a] * B)              # ctypes packing once: time the C entry point
     assert ctx.ipa_batch_check(0, ops, rb, sb)
     t0 = time.perf_counter(); reps = 5
     for _ in range(reps): ok = ctx.ipa_batch_check(0, ops, rb, sb)
