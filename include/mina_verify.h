@@ -230,6 +230,7 @@ typedef struct {
 int mina_combined_inner_product(int field, size_t n_polys, size_t n_points, const uint8_t *evals /* n_polys*n_points*32 */,
                                 const uint8_t *polyscale, const uint8_t *evalscale, uint8_t *out /* 32 */);
 
+/* The openings of one call share k and n_evalpoints; n_comms may differ (proofs of different circuits). */
 int mina_ipa_batch_check(mina_ctx *ctx, int curve, size_t batch, const mina_ipa_opening *openings,
                          const uint8_t *rand_base /* 32 */, const uint8_t *sg_rand_base /* 32 */,
                          uint8_t *verdict /* 1 byte: 1 = all openings valid */);

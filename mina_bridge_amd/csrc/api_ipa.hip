@@ -338,13 +338,16 @@ extern "C" int mina_ipa_batch_check(mina_ctx *c, int curve, size_t batch, const 
     if (s.depth == 0) return fail(MINA_ERR_STATE, "SRS not loaded for this curve");
     const int FB = base_field_of(curve), FS = scalar_field_of(curve);
     if (!c->have_pparams[FB]) return fail(MINA_ERR_STATE, "Poseidon constants not installed for the base field");
-    const uint32_t k = op[0].k, npts = op[0].n_evalpoints, m = op[0].n_comms;
+    const uint32_t k = op[0].k, npts = op[0].n_evalpoints;
+    uint32_t m = 0;                                             // commitments per opening in the device layout = the maximum;
+    for (size_t b = 0; b < batch; ++b) if (op[b].n_comms > m) m = op[b].n_comms;   // shorter lists are padded with infinity
+    if (m > 4096) return fail(MINA_ERR_ARG, "too many commitments in one opening");
     if (k < 1 || k > 20 || ((size_t)1 << k) > s.depth) return fail(MINA_ERR_ARG, "2^k exceeds the SRS depth");
     for (size_t b = 0; b < batch; ++b) {
         const mina_ipa_opening &o = op[b];
-        if (o.k != k || o.n_evalpoints != npts || o.n_comms != m) return fail(MINA_ERR_ARG, "openings of one batch must share k, n_evalpoints, n_comms");
+        if (o.k != k || o.n_evalpoints != npts) return fail(MINA_ERR_ARG, "openings of one batch must share k and n_evalpoints");
         if (!o.lr || !o.delta || !o.sg || !o.z1 || !o.z2 || !o.combined_inner_product || !o.polyscale || !o.evalscale || !o.sponge_state ||
-            (npts && !o.evalpoints) || (m && !o.comms)) return fail(MINA_ERR_ARG, "null field in opening");
+            (npts && !o.evalpoints) || (o.n_comms && !o.comms)) return fail(MINA_ERR_ARG, "null field in opening");
     }
     HIPC(hipSetDevice(c->device));
     c->use_lane0();
@@ -370,7 +373,7 @@ extern "C" int mina_ipa_batch_check(mina_ctx *c, int curve, size_t batch, const 
         if (npts) memcpy(&blob[o_pts + b * npts * 32], o.evalpoints, (size_t)npts * 32);
         memcpy(&blob[o_r + b * 32], o.evalscale, 32);
         memcpy(&blob[o_xi + b * 32], o.polyscale, 32);
-        if (m) memcpy(&blob[o_comms + b * m * 64], o.comms, (size_t)m * 64);
+        if (o.n_comms) memcpy(&blob[o_comms + b * m * 64], o.comms, (size_t)o.n_comms * 64);   // rest stays (0, 0) = infinity: contributes nothing
     }
     memcpy(&blob[o_rb], rand_base, 32);
     memcpy(&blob[o_sb], sg_rand_base, 32);

@@ -10,7 +10,9 @@ static MsmShape fixed_shape(const SrsState &s, uint32_t first, uint32_t n) {
 }
 static MsmShape variable_shape(uint32_t n) {
     MsmShape sh; sh.n = n;
-    sh.c = n < 2048 ? 8 : (n < 32768 ? 11 : 14);
+    // window widths whose TOP window is not degenerate for 255-bit scalars: c = 8 (top digit < 64), 13 (W = 20, top digit
+    // < 128), 15 (W = 18, the 18th window is always empty); c = 11 / 14 put a quarter of a window's entries in one bucket
+    sh.c = n < 2048 ? 8 : (n < (1u << 17) ? 13 : 15);
     sh.W = (256 + sh.c - 1) / sh.c; sh.NB = 1u << (sh.c - 1); sh.nsets = sh.W; sh.table_stride = 0; sh.base_first = 0; sh.nprob = 1; return sh;
 }
 
@@ -36,6 +38,7 @@ static int run_msm(mina_ctx *c, const MsmShape &sh, const uint32_t *d_scalars, c
     if ((rc = w.rem_bucket.ensure((size_t)nb_total * 4))) return rc;
     if ((rc = w.info.ensure(16))) return rc;
     if ((rc = w.partial.ensure(max_tasks * sizeof(xyzz_t)))) return rc;
+    if ((rc = w.heavy.ensure((max_tasks / MSM_HEAVY_TASKS + 2) * 4))) return rc;
     if ((rc = w.buckets.ensure((size_t)nb_total * sizeof(xyzz_t)))) return rc;
     if (sh.NB < 128 || sh.NB > 32768) return fail(MINA_ERR_ARG, "unsupported bucket count");
     if ((rc = w.red_r.ensure((size_t)(sh.NB / 128) * sh.nsets * sizeof(xyzz_t)))) return rc;
@@ -56,7 +59,9 @@ static int run_msm(mina_ctx *c, const MsmShape &sh, const uint32_t *d_scalars, c
     { ProfScope ps_(c, PS_ACCUMULATE); msm_accumulate_kernel<F><<<cdiv(max_tasks, 256), 256, 0, st>>>(nb_total, w.start.as<uint32_t>(), w.task_start.as<uint32_t>(),
                                                                    w.rem_bucket.as<uint32_t>(), w.info.as<uint32_t>(), w.sorted.as<uint32_t>(), d_points, fk.one, w.partial.as<xyzz_t>()); }
     { ProfScope ps_(c, PS_BUCKET_SUM); msm_bucket_sum_kernel<F><<<cdiv((size_t)nb_total * 4, 256), 256, 0, st>>>(nb_total, w.task_start.as<uint32_t>(), w.rem_pos.as<uint32_t>(), w.info.as<uint32_t>(), w.partial.as<xyzz_t>(),
-                                                                  w.buckets.as<xyzz_t>()); }
+                                                                  w.buckets.as<xyzz_t>(), w.heavy.as<uint32_t>());
+                                       msm_bucket_sum_heavy_kernel<F><<<128, 256, 0, st>>>(w.task_start.as<uint32_t>(), w.rem_pos.as<uint32_t>(), w.info.as<uint32_t>(), w.partial.as<xyzz_t>(),
+                                                                  w.buckets.as<xyzz_t>(), w.heavy.as<uint32_t>()); }
     {
         // 2-D bucket reduction: C = 128 columns, R = NB / C rows (NB is a power of two in [128, 32768])
         const uint32_t C = 128, log2C = 7, R = sh.NB / C;

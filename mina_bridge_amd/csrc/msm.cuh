@@ -89,6 +89,7 @@ static __global__ void msm_digits_kernel(MsmShape sh, const uint32_t *__restrict
 //   rem_pos[b]     index of b's remainder task among all remainder tasks, ordered by DESCENDING r so that the
 //                  lanes of a wave run the same number of adds; MSM_INVALID if r == 0
 //   info[0] = Ft, info[1] = number of remainder tasks          (rem_bucket = inverse of rem_pos: K1b' below)
+//   info[2] = 0: counter of heavy buckets, filled by K1e
 // Memory pattern: the bucket array is walked in rows of 4096 (1024 lanes x uint4), so every global load and store is a
 // fully coalesced 16-byte-per-lane access (a lane-contiguous chunking made each store instruction touch 64 lines).
 // Pass 1 totals the remainder classes (their offsets are needed before ranks can be assigned), pass 2 emits.
@@ -227,7 +228,7 @@ msm_scan_kernel(uint32_t nb_total, const uint32_t *__restrict__ count, uint32_t 
 #pragma unroll
         for (int k = 0; k < NV; ++k) carry[k] += tot[k];
     }
-    if (tid == 0) { start[nb_total] = carry[0]; full_start[nb_total] = carry[1]; info[0] = carry[1]; }
+    if (tid == 0) { start[nb_total] = carry[0]; full_start[nb_total] = carry[1]; info[0] = carry[1]; info[2] = 0; }   // info[2]: heavy-bucket counter (K1e)
 }
 
 // K1b': rem_bucket = inverse permutation of rem_pos (random 4-byte scatter, spread over the whole chip)
@@ -309,14 +310,22 @@ msm_accumulate_kernel(uint32_t nb_total, const uint32_t *__restrict__ start, con
 
 // K1e: level-2: bucket b = sum of its task partials (its full tasks are contiguous, plus at most one remainder task).
 // Four lanes per bucket (cooperative group law): the chain of ~4-8 dependent XYZZ adds is the latency of this stage.
+// A bucket with more than MSM_HEAVY_TASKS partials (skewed digits: a short top window, equal or structured scalars)
+// is not summed here -- one quad would walk thousands of dependent adds -- but queued for K1e'.
+static constexpr uint32_t MSM_HEAVY_TASKS = 24;
 template <int F>
 __global__ void __launch_bounds__(256)
 msm_bucket_sum_kernel(uint32_t nb_total, const uint32_t *__restrict__ full_start, const uint32_t *__restrict__ rem_pos,
-                      const uint32_t *__restrict__ info, const xyzz_t *__restrict__ partial, xyzz_t *__restrict__ buckets) {
+                      uint32_t *__restrict__ info, const xyzz_t *__restrict__ partial, xyzz_t *__restrict__ buckets,
+                      uint32_t *__restrict__ heavy) {
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t b = gid >> 2;
     if (b >= nb_total) return;                               // whole quads leave together
     const uint32_t lo = full_start[b], hi = full_start[b + 1], rp = rem_pos[b];
+    if (hi - lo > MSM_HEAVY_TASKS) {                         // uniform within the quad
+        if ((gid & 3u) == 0) heavy[atomicAdd(&info[2], 1u)] = b;
+        return;
+    }
     xyzz_t acc = (rp != MSM_INVALID) ? partial[info[0] + rp] : xyzz_inf();
     for (uint32_t t = lo; t < hi; ++t) xyzz_add_quad<F>(acc, partial[t]);
     if ((gid & 3u) == 0) buckets[b] = acc;
@@ -333,6 +342,42 @@ __device__ __forceinline__ xyzz_t shfl_down_xyzz(const xyzz_t &a, int d) {
     xyzz_t r; r.x = shfl_down_fe(a.x, d); r.y = shfl_down_fe(a.y, d);
     r.zz = shfl_down_fe(a.zz, d); r.zzz = shfl_down_fe(a.zzz, d); return r;
 }
+// sum over the `width` (power of two <= 16) quads of a wave; every lane of quad 0 ends with the total
+template <int F> __device__ __forceinline__ xyzz_t quadwave_sum(xyzz_t v, int width) {
+    const int q = (threadIdx.x & 63) >> 2;
+#pragma unroll 1
+    for (int d = width >> 1; d >= 1; d >>= 1) {
+        xyzz_t o = shfl_down_xyzz(v, 4 * d);
+        if (q + d < width) xyzz_add_quad<F>(v, o);
+    }
+    return v;
+}
+
+// K1e': heavy buckets, one 256-lane block (64 quads) each: quad q sums partials lo+q, lo+q+64, ... , then a wave tree
+// and a 4-wave tree through LDS.  Grid-stride over the list K1e built; the launch is fixed-size (no host round trip).
+template <int F>
+__global__ void __launch_bounds__(256)
+msm_bucket_sum_heavy_kernel(const uint32_t *__restrict__ full_start, const uint32_t *__restrict__ rem_pos, const uint32_t *__restrict__ info,
+                            const xyzz_t *__restrict__ partial, xyzz_t *__restrict__ buckets, const uint32_t *__restrict__ heavy) {
+    __shared__ xyzz_t sh[4];
+    const uint32_t nheavy = info[2], q = threadIdx.x >> 2, wave = threadIdx.x >> 6;
+    for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
+        const uint32_t b = heavy[h];
+        const uint32_t lo = full_start[b], hi = full_start[b + 1], rp = rem_pos[b];
+        xyzz_t acc = (q == 0 && rp != MSM_INVALID) ? partial[info[0] + rp] : xyzz_inf();
+        for (uint32_t t = lo + q; t < hi; t += 64) xyzz_add_quad<F>(acc, partial[t]);
+        acc = quadwave_sum<F>(acc, 16);
+        __syncthreads();                                     // sh may still be read from the previous bucket
+        if ((threadIdx.x & 63) == 0) sh[wave] = acc;
+        __syncthreads();
+        if (wave == 0) {
+            xyzz_t v = (q < 4) ? sh[q] : xyzz_inf();
+            v = quadwave_sum<F>(v, 4);
+            if (threadIdx.x == 0) buckets[b] = v;
+        }
+    }
+}
+
 // ---------------------------------------------------------------- bucket reduction  sum_b (b+1) * B_b
 // 2-D scheme: view a bucket set as R rows x C columns (b = r*C + c, C = 128).  Then
 //     sum_b (b+1) B_b = Tot + C * sum_r r*Row_r + sum_c c*Col_c,    Row_r = sum_c B[r][c], Col_c = sum_r B[r][c], Tot = sum_r Row_r
@@ -378,15 +423,6 @@ msm_segsum_kernel(uint32_t nb_per_set, SegSum rows, SegSum cols, const xyzz_t *_
 
 // quad-replicated wave collectives: every value lives on the 4 lanes of a quad (16 values per wave), adds are
 // lane-cooperative.  quad 0 gets  sum_q v_q  (in `sum`) and  sum_q q * v_q  (returned), q < width <= 16.
-template <int F> __device__ __forceinline__ xyzz_t quadwave_sum(xyzz_t v, int width) {
-    const int q = (threadIdx.x & 63) >> 2;
-#pragma unroll 1
-    for (int d = width >> 1; d >= 1; d >>= 1) {
-        xyzz_t o = shfl_down_xyzz(v, 4 * d);
-        if (q + d < width) xyzz_add_quad<F>(v, o);
-    }
-    return v;
-}
 template <int F> __device__ __forceinline__ xyzz_t quadwave_weighted_sum(xyzz_t v, xyzz_t &sum, int width) {
     const int q = (threadIdx.x & 63) >> 2;
 #pragma unroll 1

@@ -227,3 +227,26 @@ def test_msm_srs_multi_many_problems(ctx_srs, oracle, srs_oracle):
     for m in (0, 22, 44):
         assert (got[m] == oracle.msm_pippenger(curve, g[:n], sc[m], threads=8)).all(), m
     assert len({bytes(x) for x in got}) == nprob
+
+
+@pytest.mark.parametrize("n", [300, 5000, 70000, 140000])
+def test_msm_heavy_buckets_mixed_with_light(ctx, oracle, srs_oracle, n):
+    """a third of the scalars are equal (their buckets hold thousands of task partials -> the block-wide heavy-bucket sum),
+    the rest uniform (ordinary quads), on repeated points so that heavy buckets also hit P + P; every variable-base window
+    shape (c = 8 / 13 / 15) is crossed by the sizes"""
+    curve = 0
+    g, _ = srs_oracle[curve]
+    base = g[np.arange(n) % 65536].copy()                     # n > 65536 reuses points
+    sc = rand_scalars(n, Q, seed=31 + n)
+    sc[::3] = sc[0]
+    sc[1::7] = oracle.int_to_le(Q - 1)                        # and a second heavy family with all-ones digits
+    assert (ctx.msm(curve, base, sc) == oracle.msm_pippenger(curve, base, sc, threads=8)).all()
+
+
+def test_msm_srs_fixed_base_heavy_buckets(ctx_srs, oracle, srs_oracle):
+    """fixed-base path, 2^16 equal scalars: each of the 16 windows puts all 65536 table points into one bucket"""
+    curve, n = 1, 65536
+    g, _ = srs_oracle[curve]
+    sc = np.repeat(rand_scalars(1, P, seed=5), n, axis=0)
+    sc[12345] = rand_scalars(1, P, seed=6)[0]
+    assert (ctx_srs.msm_srs(curve, sc) == oracle.msm_pippenger(curve, g[:n], sc, threads=8)).all()
