@@ -2,6 +2,7 @@
 #include "ctx.h"
 #include "msm.cuh"
 #include <vector>
+#include <cstdlib>
 
 // ------------------------------------------------------------------------------------------------
 // MSM driver
@@ -27,9 +28,21 @@ static int run_msm(mina_ctx *c, const MsmShape &sh, const uint32_t *d_scalars, c
     const size_t entries = (size_t)sh.n * sh.W * sh.nprob;
     const size_t max_tasks = entries / MSM_TASK_LEN + nb_total + 1;
     int rc;
-    if ((rc = w.ekey.ensure(entries * 4))) return rc;
-    if ((rc = w.eval.ensure(entries * 4))) return rc;
-    if ((rc = w.eoff.ensure(entries * 4))) return rc;
+    // sort plan: partitioned LDS sort when the partition table fits (P <= 1024 with <= 2048 buckets per partition),
+    // else the atomic counting sort
+    SortShape ss; ss.fbits = 8; ss.G = cdiv((size_t)sh.n * sh.nprob, 256);
+    while (ss.fbits < 11 && cdiv(nb_total, 1u << ss.fbits) > 256) ++ss.fbits;
+    ss.P = cdiv(nb_total, 1u << ss.fbits);
+    static const bool force_atomic_sort = getenv("MINA_MSM_ATOMIC_SORT") != nullptr;      // A/B switch for profiling
+    const bool part_sort = !force_atomic_sort && ss.P <= 1024 && (uint64_t)ss.P * ss.G <= (1u << 22);
+    if (part_sort) {
+        if ((rc = w.ghist.ensure(((size_t)ss.P * ss.G + 8) * 4))) return rc;
+        if ((rc = w.stage.ensure(entries * 8))) return rc;
+    } else {
+        if ((rc = w.ekey.ensure(entries * 4))) return rc;
+        if ((rc = w.eval.ensure(entries * 4))) return rc;
+        if ((rc = w.eoff.ensure(entries * 4))) return rc;
+    }
     if ((rc = w.sorted.ensure(entries * 4))) return rc;
     if ((rc = w.count.ensure((size_t)nb_total * 4))) return rc;
     if ((rc = w.start.ensure(((size_t)nb_total + 1) * 4))) return rc;
@@ -48,17 +61,34 @@ static int run_msm(mina_ctx *c, const MsmShape &sh, const uint32_t *d_scalars, c
     if ((rc = w.set_total.ensure((size_t)sh.nsets * sizeof(xyzz_t)))) return rc;
 
     hipStream_t st = c->L->stream;
-    HIPC(hipMemsetAsync(w.count.p, 0, (size_t)nb_total * 4, st));
-    { ProfScope ps_(c, PS_DIGITS); msm_digits_kernel<<<cdiv(entries, 256), 256, 0, st>>>(sh, d_scalars, w.count.as<uint32_t>(), w.ekey.as<uint32_t>(),
-                                                       w.eval.as<uint32_t>(), w.eoff.as<uint32_t>()); }
-    { ProfScope ps_(c, PS_SCAN); msm_scan_kernel<<<1, 1024, 0, st>>>(nb_total, w.count.as<uint32_t>(), w.start.as<uint32_t>(), w.task_start.as<uint32_t>(),
-                                                                   w.rem_pos.as<uint32_t>(), w.info.as<uint32_t>());
-                                 msm_rem_invert_kernel<<<cdiv(nb_total, 256), 256, 0, st>>>(nb_total, w.rem_pos.as<uint32_t>(), w.rem_bucket.as<uint32_t>()); }
-    { ProfScope ps_(c, PS_SCATTER); msm_scatter_kernel<<<cdiv(entries, 256), 256, 0, st>>>(entries, w.ekey.as<uint32_t>(), w.eval.as<uint32_t>(),
-                                                           w.eoff.as<uint32_t>(), w.start.as<uint32_t>(), w.sorted.as<uint32_t>()); }
+    if (part_sort) {
+        { ProfScope ps_(c, PS_DIGITS);
+          msm_part_kernel<false><<<ss.G, 1024, 0, st>>>(sh, ss, d_scalars, w.ghist.as<uint32_t>(), nullptr);
+          msm_excl_scan_kernel<<<1, 1024, 0, st>>>(ss.P * ss.G, w.ghist.as<uint32_t>()); }
+        { ProfScope ps_(c, PS_SCATTER);
+          msm_part_kernel<true><<<ss.G, 1024, 0, st>>>(sh, ss, d_scalars, w.ghist.as<uint32_t>(), w.stage.as<uint2>());
+          msm_part_sort_kernel<<<ss.P, 1024, 0, st>>>(ss, nb_total, w.ghist.as<uint32_t>(), w.stage.as<uint2>(), w.count.as<uint32_t>(), w.sorted.as<uint32_t>()); }
+        { ProfScope ps_(c, PS_SCAN); msm_scan_kernel<<<1, 1024, 0, st>>>(nb_total, w.count.as<uint32_t>(), w.start.as<uint32_t>(), w.task_start.as<uint32_t>(),
+                                                                       w.rem_pos.as<uint32_t>(), w.info.as<uint32_t>());
+                                     msm_rem_invert_kernel<<<cdiv(nb_total, 256), 256, 0, st>>>(nb_total, w.rem_pos.as<uint32_t>(), w.rem_bucket.as<uint32_t>()); }
+    } else {
+        HIPC(hipMemsetAsync(w.count.p, 0, (size_t)nb_total * 4, st));
+        { ProfScope ps_(c, PS_DIGITS); msm_digits_kernel<<<cdiv(entries, 256), 256, 0, st>>>(sh, d_scalars, w.count.as<uint32_t>(), w.ekey.as<uint32_t>(),
+                                                           w.eval.as<uint32_t>(), w.eoff.as<uint32_t>()); }
+        { ProfScope ps_(c, PS_SCAN); msm_scan_kernel<<<1, 1024, 0, st>>>(nb_total, w.count.as<uint32_t>(), w.start.as<uint32_t>(), w.task_start.as<uint32_t>(),
+                                                                       w.rem_pos.as<uint32_t>(), w.info.as<uint32_t>());
+                                     msm_rem_invert_kernel<<<cdiv(nb_total, 256), 256, 0, st>>>(nb_total, w.rem_pos.as<uint32_t>(), w.rem_bucket.as<uint32_t>()); }
+        { ProfScope ps_(c, PS_SCATTER); msm_scatter_kernel<<<cdiv(entries, 256), 256, 0, st>>>(entries, w.ekey.as<uint32_t>(), w.eval.as<uint32_t>(),
+                                                               w.eoff.as<uint32_t>(), w.start.as<uint32_t>(), w.sorted.as<uint32_t>()); }
+    }
     { ProfScope ps_(c, PS_ACCUMULATE); msm_accumulate_kernel<F><<<cdiv(max_tasks, 256), 256, 0, st>>>(nb_total, w.start.as<uint32_t>(), w.task_start.as<uint32_t>(),
                                                                    w.rem_bucket.as<uint32_t>(), w.info.as<uint32_t>(), w.sorted.as<uint32_t>(), d_points, fk.one, w.partial.as<xyzz_t>()); }
-    { ProfScope ps_(c, PS_BUCKET_SUM); msm_bucket_sum_kernel<F><<<cdiv((size_t)nb_total * 4, 256), 256, 0, st>>>(nb_total, w.task_start.as<uint32_t>(), w.rem_pos.as<uint32_t>(), w.info.as<uint32_t>(), w.partial.as<xyzz_t>(),
+    { ProfScope ps_(c, PS_BUCKET_SUM);
+      if (c->nlanes > 1)
+          msm_bucket_sum_lane_kernel<F><<<cdiv(nb_total, 256), 256, 0, st>>>(nb_total, w.task_start.as<uint32_t>(), w.rem_pos.as<uint32_t>(), w.info.as<uint32_t>(), w.partial.as<xyzz_t>(),
+                                                                  w.buckets.as<xyzz_t>(), w.heavy.as<uint32_t>());
+      else
+          msm_bucket_sum_kernel<F><<<cdiv((size_t)nb_total * 4, 256), 256, 0, st>>>(nb_total, w.task_start.as<uint32_t>(), w.rem_pos.as<uint32_t>(), w.info.as<uint32_t>(), w.partial.as<xyzz_t>(),
                                                                   w.buckets.as<xyzz_t>(), w.heavy.as<uint32_t>());
                                        msm_bucket_sum_heavy_kernel<F><<<128, 256, 0, st>>>(w.task_start.as<uint32_t>(), w.rem_pos.as<uint32_t>(), w.info.as<uint32_t>(), w.partial.as<xyzz_t>(),
                                                                   w.buckets.as<xyzz_t>(), w.heavy.as<uint32_t>()); }

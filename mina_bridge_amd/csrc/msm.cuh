@@ -48,23 +48,16 @@ __device__ __forceinline__ uint32_t scalar_bits(const uint32_t *s, uint32_t lo, 
 // raw unsigned digit of window w
 __device__ __forceinline__ uint32_t raw_digit(const uint32_t *s, uint32_t w, uint32_t c) { return scalar_bits(s, w * c, c); }
 
-// K1a: signed digits + per-bucket slot via one returning atomic.  One lane per (window, scalar): every atomic
-// of the launch is independent, so their latency overlaps (a lane that walked its 16 windows serially paid 16
-// dependent round trips).  Digit rule: d = raw + carry_in; d > 2^(c-1) -> d - 2^c, carry out.  carry_in of window w
-// is resolved by looking at the lower windows, which almost always stops at w-1.
-static __global__ void msm_digits_kernel(MsmShape sh, const uint32_t *__restrict__ scalars /* n x 8 */,
-                                         uint32_t *__restrict__ count, uint32_t *__restrict__ ekey,
-                                         uint32_t *__restrict__ eval, uint32_t *__restrict__ eoff) {
-    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t per_prob = (size_t)sh.n * sh.W;
-    if (e >= per_prob * sh.nprob) return;
-    const uint32_t m = (uint32_t)(e / per_prob);
-    const uint32_t ep = (uint32_t)(e - (size_t)m * per_prob);
-    const uint32_t w = ep / sh.n, i = ep % sh.n;
-    uint32_t s[8];
-    const uint4 *sp = reinterpret_cast<const uint4 *>(scalars + ((size_t)m * sh.n + i) * 8);
-    uint4 a = sp[0], b = sp[1];
+__device__ __forceinline__ void load_scalar(const uint32_t *__restrict__ p, uint32_t (&s)[8]) {
+    const uint4 *sp = reinterpret_cast<const uint4 *>(p);
+    const uint4 a = sp[0], b = sp[1];
     s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w;
+}
+// One (problem m, window w, scalar i) entry: signed digit -> (bucket, point reference | sign << 31); false if the digit is 0.
+// Digit rule: d = raw + carry_in; d > 2^(c-1) -> d - 2^c, carry out.  carry_in of window w is resolved by looking at
+// the lower windows, which almost always stops at w-1.
+__device__ __forceinline__ bool msm_entry(const MsmShape &sh, const uint32_t (&s)[8], uint32_t m, uint32_t w, uint32_t i,
+                                          uint32_t &bucket, uint32_t &ref) {
     const uint32_t half = 1u << (sh.c - 1);
     uint32_t carry = 0;
     for (int j = (int)w - 1; j >= 0; --j) {
@@ -76,10 +69,30 @@ static __global__ void msm_digits_kernel(MsmShape sh, const uint32_t *__restrict
     uint32_t d = raw_digit(s, w, sh.c) + carry;
     uint32_t neg = 0;
     if (d > half) { d = (1u << sh.c) - d; neg = 1; }
-    if (d == 0) { ekey[e] = MSM_INVALID; return; }
-    const uint32_t bucket = (sh.table_stride ? m : m * sh.W + w) * sh.NB + (d - 1);
+    if (d == 0) return false;
+    bucket = (sh.table_stride ? m : m * sh.W + w) * sh.NB + (d - 1);
+    ref = (sh.table_stride ? w * sh.table_stride + sh.base_first + i : i) | (neg << 31);
+    return true;
+}
+
+// K1a: signed digits + per-bucket slot via one returning atomic.  One lane per (window, scalar): every atomic
+// of the launch is independent, so their latency overlaps (a lane that walked its 16 windows serially paid 16
+// dependent round trips).  Fallback sort for bucket counts beyond the partitioned sort below (K1p).
+static __global__ void msm_digits_kernel(MsmShape sh, const uint32_t *__restrict__ scalars /* n x 8 */,
+                                         uint32_t *__restrict__ count, uint32_t *__restrict__ ekey,
+                                         uint32_t *__restrict__ eval, uint32_t *__restrict__ eoff) {
+    const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t per_prob = (size_t)sh.n * sh.W;
+    if (e >= per_prob * sh.nprob) return;
+    const uint32_t m = (uint32_t)(e / per_prob);
+    const uint32_t ep = (uint32_t)(e - (size_t)m * per_prob);
+    const uint32_t w = ep / sh.n, i = ep % sh.n;
+    uint32_t s[8];
+    load_scalar(scalars + ((size_t)m * sh.n + i) * 8, s);
+    uint32_t bucket, ref;
+    if (!msm_entry(sh, s, m, w, i, bucket, ref)) { ekey[e] = MSM_INVALID; return; }
     ekey[e] = bucket;
-    eval[e] = (sh.table_stride ? w * sh.table_stride + sh.base_first + i : i) | (neg << 31);
+    eval[e] = ref;
     eoff[e] = atomicAdd(&count[bucket], 1u);
 }
 
@@ -231,6 +244,108 @@ msm_scan_kernel(uint32_t nb_total, const uint32_t *__restrict__ count, uint32_t 
     if (tid == 0) { start[nb_total] = carry[0]; full_start[nb_total] = carry[1]; info[0] = carry[1]; info[2] = 0; }   // info[2]: heavy-bucket counter (K1e)
 }
 
+// ---------------------------------------------------------------- K1p: partitioned counting sort (no global atomics)
+// The atomic sort above costs 1 M device-scope returning atomics and 1 M random 4-byte stores per 2^16 MSM (92 MB of
+// fabric traffic for 12 MB of payload); with 16 MSMs in flight it is 28 % of the step time.  K1p sorts in two levels
+// with LDS histograms only:
+//   level 1: partition = bucket >> fbits (P <= 1024 partitions).  Blocks of 1024 lanes own 256 scalars x all windows
+//            (each scalar is read once): K1p-a counts per (partition, block), one block scans the P x G table, K1p-c
+//            recomputes the digits and writes {ref, fine key} into its slots of the staging array (LDS cursors) --
+//            every 64-B line of the staging array is written by ONE block (one XCD's L2 merges the stores);
+//   level 2: one block per partition: LDS histogram over its 2^fbits buckets, block scan, bucket counts out (coalesced),
+//            references placed at their final positions inside the partition's contiguous range of `sorted`.
+struct SortShape {
+    uint32_t fbits;    // fine key bits: buckets per partition = 2^fbits (<= 2048)
+    uint32_t P;        // partitions = ceil(nb_total / 2^fbits) (<= 1024)
+    uint32_t G;        // level-1 blocks = ceil(n * nprob / 256)
+};
+
+// K1p-a / K1p-c.  SCATTER = false: gh[p * G + blk] = entries of block blk in partition p.
+//                 SCATTER = true : gh holds the exclusive scan; entries go to staging[goff[p][blk] + rank].
+template <bool SCATTER>
+static __global__ void __launch_bounds__(1024)
+msm_part_kernel(MsmShape sh, SortShape ss, const uint32_t *__restrict__ scalars, uint32_t *__restrict__ gh, uint2 *__restrict__ staging) {
+    __shared__ uint32_t cur[1024];
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t j = tid; j < ss.P; j += 1024) cur[j] = SCATTER ? gh[(size_t)j * ss.G + blockIdx.x] : 0u;
+    __syncthreads();
+    const uint32_t si = blockIdx.x * 256 + (tid & 255);           // scalar index over nprob * n
+    if (si < sh.n * sh.nprob) {
+        const uint32_t m = si / sh.n, i = si - m * sh.n;
+        uint32_t s[8];
+        load_scalar(scalars + (size_t)si * 8, s);
+        for (uint32_t w = tid >> 8; w < sh.W; w += 4) {
+            uint32_t bucket, ref;
+            if (!msm_entry(sh, s, m, w, i, bucket, ref)) continue;
+            const uint32_t part = bucket >> ss.fbits;
+            if (SCATTER) {
+                const uint32_t pos = atomicAdd(&cur[part], 1u);
+                staging[pos] = make_uint2(ref, bucket & ((1u << ss.fbits) - 1u));
+            } else {
+                atomicAdd(&cur[part], 1u);
+            }
+        }
+    }
+    if (!SCATTER) {
+        __syncthreads();
+        for (uint32_t j = tid; j < ss.P; j += 1024) gh[(size_t)j * ss.G + blockIdx.x] = cur[j];
+    }
+}
+
+// K1p-b: in-place exclusive scan of n values by one block (rows of 4096, coalesced uint4); data[n] = total.
+// The buffer is padded to a multiple of 4 words past n.
+static __global__ void __launch_bounds__(1024) msm_excl_scan_kernel(uint32_t n, uint32_t *__restrict__ data) {
+    __shared__ uint32_t s_tot[1][16], s_pre[1][16], s_all[1];
+    const uint32_t tid = threadIdx.x, row_elems = blockDim.x * 4, nrows = (n + row_elems - 1) / row_elems;
+    uint32_t carry = 0;
+    for (uint32_t row = 0; row < nrows; ++row) {
+        const uint32_t idx = row * row_elems + tid * 4;
+        uint4 c4 = make_uint4(0, 0, 0, 0);
+        if (idx < n) c4 = *reinterpret_cast<const uint4 *>(data + idx);
+        uint32_t c[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (idx + e >= n) c[e] = 0;                 // padding words are not data
+        uint32_t v[1] = {c[0] + c[1] + c[2] + c[3]}, tot[1];
+        block_exclusive_scan<1>(v, tot, s_tot, s_pre, s_all);
+        const uint32_t p0 = carry + v[0];
+        if (idx < n) *reinterpret_cast<uint4 *>(data + idx) = make_uint4(p0, p0 + c[0], p0 + c[0] + c[1], p0 + c[0] + c[1] + c[2]);
+        carry += tot[0];
+    }
+    __syncthreads();
+    if (tid == 0) data[n] = carry;                                              // after every row's padded uint4 store
+}
+
+// K1p-d: level 2, one block per partition.
+static __global__ void __launch_bounds__(1024)
+msm_part_sort_kernel(SortShape ss, uint32_t nb_total, const uint32_t *__restrict__ goff, const uint2 *__restrict__ staging,
+                     uint32_t *__restrict__ count, uint32_t *__restrict__ sorted) {
+    __shared__ uint32_t hist[2048];
+    __shared__ uint32_t s_tot[1][16], s_pre[1][16], s_all[1];
+    const uint32_t tid = threadIdx.x, p = blockIdx.x, nf = 1u << ss.fbits;
+    const uint32_t begin = goff[(size_t)p * ss.G], end = goff[(size_t)(p + 1) * ss.G];     // goff[P * G] = total
+    for (uint32_t j = tid; j < nf; j += 1024) hist[j] = 0;
+    __syncthreads();
+    for (uint32_t e = begin + tid; e < end; e += 1024) atomicAdd(&hist[staging[e].y], 1u);
+    __syncthreads();
+    // exclusive scan of hist[0 .. nf): lane t owns elements 2t, 2t+1 (nf <= 2048)
+    const uint32_t h0 = (2 * tid < nf) ? hist[2 * tid] : 0u, h1 = (2 * tid + 1 < nf) ? hist[2 * tid + 1] : 0u;
+    uint32_t v[1] = {h0 + h1}, tot[1];
+    block_exclusive_scan<1>(v, tot, s_tot, s_pre, s_all);
+    const uint32_t b0 = p * nf + 2 * tid;
+    if (2 * tid < nf) {
+        if (b0 < nb_total) count[b0] = h0;
+        if (b0 + 1 < nb_total && 2 * tid + 1 < nf) count[b0 + 1] = h1;
+    }
+    __syncthreads();                                                            // all reads of hist done
+    if (2 * tid < nf) hist[2 * tid] = v[0];                                     // hist becomes the cursor array
+    if (2 * tid + 1 < nf) hist[2 * tid + 1] = v[0] + h0;
+    __syncthreads();
+    for (uint32_t e = begin + tid; e < end; e += 1024) {
+        const uint2 x = staging[e];
+        sorted[begin + atomicAdd(&hist[x.y], 1u)] = x.x;
+    }
+}
+
 // K1b': rem_bucket = inverse permutation of rem_pos (random 4-byte scatter, spread over the whole chip)
 static __global__ void msm_rem_invert_kernel(uint32_t nb_total, const uint32_t *__restrict__ rem_pos, uint32_t *__restrict__ rem_bucket) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -329,6 +444,22 @@ msm_bucket_sum_kernel(uint32_t nb_total, const uint32_t *__restrict__ full_start
     xyzz_t acc = (rp != MSM_INVALID) ? partial[info[0] + rp] : xyzz_inf();
     for (uint32_t t = lo; t < hi; ++t) xyzz_add_quad<F>(acc, partial[t]);
     if ((gid & 3u) == 0) buckets[b] = acc;
+}
+// Throughput form of K1e (one lane per bucket, plain XYZZ adds): 30 % fewer issue slots than the cooperative form, 3.5x
+// its latency.  Used when the context pipelines independent MSMs over several lanes (the chip is then VALU-bound and
+// the latency of one MSM's tail is hidden by the others).
+template <int F>
+__global__ void __launch_bounds__(256)
+msm_bucket_sum_lane_kernel(uint32_t nb_total, const uint32_t *__restrict__ full_start, const uint32_t *__restrict__ rem_pos,
+                           uint32_t *__restrict__ info, const xyzz_t *__restrict__ partial, xyzz_t *__restrict__ buckets,
+                           uint32_t *__restrict__ heavy) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb_total) return;
+    const uint32_t lo = full_start[b], hi = full_start[b + 1], rp = rem_pos[b];
+    if (hi - lo > MSM_HEAVY_TASKS) { heavy[atomicAdd(&info[2], 1u)] = b; return; }
+    xyzz_t acc = (rp != MSM_INVALID) ? partial[info[0] + rp] : xyzz_inf();
+    for (uint32_t t = lo; t < hi; ++t) xyzz_add<F>(acc, partial[t]);
+    buckets[b] = acc;
 }
 
 // ---------------------------------------------------------------- wave64 XYZZ collectives
