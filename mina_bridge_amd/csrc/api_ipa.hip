@@ -275,8 +275,12 @@ static int accumulator_check_dev(mina_ctx *c, int curve, uint32_t k, size_t batc
     if ((rc = c->L->ipa_folded.ensure((size_t)n * 32))) return rc;
     if ((rc = c->L->ipa_xyzz_a.ensure(sizeof(xyzz_t)))) return rc;
     if ((rc = c->L->ipa_xyzz_b.ensure(sizeof(xyzz_t)))) return rc;
-    DISPATCH_FIELD(FS, { challenge_to_field_kernel<F_><<<cdiv(batch * k, 64), 64, 0, c->L->stream>>>((uint32_t)(batch * k), c->fk[F_], d_prechal, c->L->ipa_chals.as<uint32_t>()); });
-    if ((rc = mb_bpoly_fold(c, FS, k, batch, c->L->ipa_chals.as<uint32_t>(), batch > 1 ? d_rho : nullptr, c->L->ipa_folded.as<uint32_t>()))) return rc;
+    if (batch == 1) {                                            // prechallenges -> coefficients in one launch
+        if ((rc = mb_bpoly_single_from_prechallenges(c, FS, k, d_prechal, c->L->ipa_folded.as<uint32_t>()))) return rc;
+    } else {
+        DISPATCH_FIELD(FS, { challenge_to_field_kernel<F_><<<cdiv(batch * k, 64), 64, 0, c->L->stream>>>((uint32_t)(batch * k), c->fk[F_], d_prechal, c->L->ipa_chals.as<uint32_t>()); });
+        if ((rc = mb_bpoly_fold(c, FS, k, batch, c->L->ipa_chals.as<uint32_t>(), d_rho, c->L->ipa_folded.as<uint32_t>()))) return rc;
+    }
     if ((rc = mb_msm_fixed(c, curve, n, c->L->ipa_folded.as<uint32_t>(), nullptr, c->L->ipa_xyzz_a.p))) return rc;
     if (batch == 1) {
         DISPATCH_FIELD(FB, { xyzz_eq_affine_kernel<F_><<<1, 64, 0, c->L->stream>>>(c->L->ipa_xyzz_a.as<xyzz_t>(), d_sg_words, c->fk[F_].r2, d_verdict); });

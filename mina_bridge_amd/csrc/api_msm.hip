@@ -61,6 +61,8 @@ static int run_msm(mina_ctx *c, const MsmShape &sh, const uint32_t *d_scalars, c
     if ((rc = w.set_total.ensure((size_t)sh.nsets * sizeof(xyzz_t)))) return rc;
 
     hipStream_t st = c->L->stream;
+    // one bucket set per problem and no affine output wanted: the reduction kernel's result IS the answer (no finish launch)
+    const bool fused_finish = sh.nsets == sh.nprob && !d_out_words && d_out_xyzz;
     if (part_sort) {
         { ProfScope ps_(c, PS_DIGITS);
           msm_part_kernel<false><<<ss.G, 1024, 0, st>>>(sh, ss, d_scalars, w.ghist.as<uint32_t>(), nullptr);
@@ -105,9 +107,9 @@ static int run_msm(mina_ctx *c, const MsmShape &sh, const uint32_t *d_scalars, c
         const uint32_t Gr = (R + 15) / 16, Gc = C / 16;
         { ProfScope ps_(c, PS_REDUCE_BC);
           msm_wsum16_kernel<F><<<dim3(Gr + Gc, sh.nsets), 64, 0, st>>>(R, C, Gr, w.red_r.as<xyzz_t>(), w.red_ws.as<xyzz_t>(), w.red2_r.as<xyzz_t>(), w.red2_w.as<xyzz_t>());
-          msm_reduce2d_kernel<F><<<sh.nsets, 256, 0, st>>>(Gr, Gc, log2C, w.red2_r.as<xyzz_t>(), w.red2_w.as<xyzz_t>(), w.set_total.as<xyzz_t>()); }
+          msm_reduce2d_kernel<F><<<sh.nsets, 256, 0, st>>>(Gr, Gc, log2C, w.red2_r.as<xyzz_t>(), w.red2_w.as<xyzz_t>(), w.set_total.as<xyzz_t>(), fused_finish ? d_out_xyzz : nullptr); }
     }
-    { ProfScope ps_(c, PS_FINISH); msm_finish_kernel<F><<<sh.nprob, 64, 0, st>>>(sh.nsets / sh.nprob, sh.c, w.set_total.as<xyzz_t>(), fk.one, fk.pm2, d_out_xyzz, d_out_words); }
+    if (!fused_finish) { ProfScope ps_(c, PS_FINISH); msm_finish_kernel<F><<<sh.nprob, 64, 0, st>>>(sh.nsets / sh.nprob, sh.c, w.set_total.as<xyzz_t>(), fk.one, fk.pm2, d_out_xyzz, d_out_words); }
     HIPC(hipGetLastError());
     return MINA_OK;
 }

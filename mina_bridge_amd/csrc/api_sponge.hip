@@ -15,12 +15,31 @@ static int run_bpoly_fold(mina_ctx *c, uint32_t k, size_t batch, const uint32_t 
     // enough blocks to fill 256 CUs x 4 when the batch is large
     while (slices * 2 <= batch && (size_t)lo_blocks * hi_tiles * slices < 2048 && slices < 64) slices *= 2;
     int rc;
+    if (batch == 1 && !d_weights) {                              // b_poly_coefficients of one proof: one launch
+        ProfScope ps_(c, PS_BPOLY_FOLD);
+        bpoly_single_kernel<F><<<cdiv(nl, 256) * nh, nl < 256 ? (nl < 64 ? 64 : nl) : 256, 0, c->L->stream>>>(sh, c->fk[F], d_chals, nullptr, d_out);
+        HIPC(hipGetLastError());
+        return MINA_OK;
+    }
     if ((rc = c->L->bp_ltab.ensure(batch * nl * sizeof(fe_t)))) return rc;
     if ((rc = c->L->bp_htab.ensure(batch * nh * sizeof(fe_t)))) return rc;
     if ((rc = c->L->bp_partial.ensure((size_t)slices * n * sizeof(fe_t)))) return rc;
     { ProfScope ps_(c, PS_BPOLY_TABLES); bpoly_tables_kernel<F><<<cdiv(batch * (nl + nh), 256), 256, 0, c->L->stream>>>(sh, c->fk[F], d_chals, d_weights, c->L->bp_ltab.as<fe_t>(), c->L->bp_htab.as<fe_t>()); }
     { ProfScope ps_(c, PS_BPOLY_FOLD); bpoly_fold_kernel<F><<<lo_blocks * hi_tiles * slices, 256, 0, c->L->stream>>>(sh, slices, c->L->bp_ltab.as<fe_t>(), c->L->bp_htab.as<fe_t>(), c->L->bp_partial.as<fe_t>()); }
     { ProfScope ps_(c, PS_BPOLY_FINISH); bpoly_finish_kernel<F><<<cdiv(n, 256), 256, 0, c->L->stream>>>(n, slices, c->L->bp_partial.as<fe_t>(), d_out); }
+    HIPC(hipGetLastError());
+    return MINA_OK;
+}
+
+// b_poly_coefficients of ONE proof straight from its 128-bit prechallenges (accumulator check, batch == 1)
+int mb_bpoly_single_from_prechallenges(mina_ctx *c, int field, uint32_t k, const uint32_t *d_prechal, uint32_t *d_out) {
+    if (bad_field(field) || k < 1 || k > 20) return fail(MINA_ERR_ARG, "bad field or k");
+    DISPATCH_FIELD(field, {
+        BpolyShape sh = bp_shape(k, 1);
+        const uint32_t nl = 1u << sh.lb, nh = 1u << sh.hb;
+        ProfScope ps_(c, PS_BPOLY_FOLD);
+        bpoly_single_kernel<F_><<<cdiv(nl, 256) * nh, nl < 256 ? (nl < 64 ? 64 : nl) : 256, 0, c->L->stream>>>(sh, c->fk[F_], nullptr, d_prechal, d_out);
+    });
     HIPC(hipGetLastError());
     return MINA_OK;
 }

@@ -260,6 +260,29 @@ struct SortShape {
     uint32_t G;        // level-1 blocks = ceil(n * nprob / 256)
 };
 
+// K1p-b: in-place exclusive scan of n values by one 1024-lane block (rows of 4096, coalesced uint4); data[n] = total.
+// The buffer is padded to a multiple of 4 words past n.
+__device__ __forceinline__ void block_excl_scan_inplace(uint32_t n, uint32_t *__restrict__ data, uint32_t (*s_tot)[16], uint32_t (*s_pre)[16],
+                                                        uint32_t *s_all) {
+    const uint32_t tid = threadIdx.x, row_elems = blockDim.x * 4, nrows = (n + row_elems - 1) / row_elems;
+    uint32_t carry = 0;
+    for (uint32_t row = 0; row < nrows; ++row) {
+        const uint32_t idx = row * row_elems + tid * 4;
+        uint4 c4 = make_uint4(0, 0, 0, 0);
+        if (idx < n) c4 = *reinterpret_cast<const uint4 *>(data + idx);
+        uint32_t c[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (idx + e >= n) c[e] = 0;                 // padding words are not data
+        uint32_t v[1] = {c[0] + c[1] + c[2] + c[3]}, tot[1];
+        block_exclusive_scan<1>(v, tot, s_tot, s_pre, s_all);
+        const uint32_t p0 = carry + v[0];
+        if (idx < n) *reinterpret_cast<uint4 *>(data + idx) = make_uint4(p0, p0 + c[0], p0 + c[0] + c[1], p0 + c[0] + c[1] + c[2]);
+        carry += tot[0];
+    }
+    __syncthreads();
+    if (tid == 0) data[n] = carry;                                              // after every row's padded uint4 store
+}
+
 // K1p-a / K1p-c.  SCATTER = false: gh[p * G + blk] = entries of block blk in partition p.
 //                 SCATTER = true : gh holds the exclusive scan; entries go to staging[goff[p][blk] + rank].
 template <bool SCATTER>
@@ -292,27 +315,11 @@ msm_part_kernel(MsmShape sh, SortShape ss, const uint32_t *__restrict__ scalars,
     }
 }
 
-// K1p-b: in-place exclusive scan of n values by one block (rows of 4096, coalesced uint4); data[n] = total.
-// The buffer is padded to a multiple of 4 words past n.
+// K1p-b as its own one-block launch.  (Letting the last block of K1p-a do it -- device-scope fence + ticket -- was 5x
+// slower: every block's release fence writes back its XCD's whole L2.)
 static __global__ void __launch_bounds__(1024) msm_excl_scan_kernel(uint32_t n, uint32_t *__restrict__ data) {
     __shared__ uint32_t s_tot[1][16], s_pre[1][16], s_all[1];
-    const uint32_t tid = threadIdx.x, row_elems = blockDim.x * 4, nrows = (n + row_elems - 1) / row_elems;
-    uint32_t carry = 0;
-    for (uint32_t row = 0; row < nrows; ++row) {
-        const uint32_t idx = row * row_elems + tid * 4;
-        uint4 c4 = make_uint4(0, 0, 0, 0);
-        if (idx < n) c4 = *reinterpret_cast<const uint4 *>(data + idx);
-        uint32_t c[4] = {c4.x, c4.y, c4.z, c4.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) if (idx + e >= n) c[e] = 0;                 // padding words are not data
-        uint32_t v[1] = {c[0] + c[1] + c[2] + c[3]}, tot[1];
-        block_exclusive_scan<1>(v, tot, s_tot, s_pre, s_all);
-        const uint32_t p0 = carry + v[0];
-        if (idx < n) *reinterpret_cast<uint4 *>(data + idx) = make_uint4(p0, p0 + c[0], p0 + c[0] + c[1], p0 + c[0] + c[1] + c[2]);
-        carry += tot[0];
-    }
-    __syncthreads();
-    if (tid == 0) data[n] = carry;                                              // after every row's padded uint4 store
+    block_excl_scan_inplace(n, data, s_tot, s_pre, s_all);
 }
 
 // K1p-d: level 2, one block per partition.
@@ -588,7 +595,7 @@ msm_wsum16_kernel(uint32_t R, uint32_t C, uint32_t Gr, const xyzz_t *__restrict_
 template <int F>
 __global__ void __launch_bounds__(256)
 msm_reduce2d_kernel(uint32_t Gr, uint32_t Gc, uint32_t log2C, const xyzz_t *__restrict__ in_s, const xyzz_t *__restrict__ in_w,
-                    xyzz_t *__restrict__ set_total) {
+                    xyzz_t *__restrict__ set_total, xyzz_t *__restrict__ out_xyzz /* may be null: also the result of problem `set` */) {
     const uint32_t set = blockIdx.x, wave = threadIdx.x >> 6, q = (threadIdx.x & 63) >> 2, G = Gr + Gc;
     __shared__ xyzz_t sh_tot, sh_roww, sh_ww[2], sh_colw;
     const xyzz_t *s = in_s + (size_t)set * G, *w = in_w + (size_t)set * G;
@@ -621,7 +628,7 @@ msm_reduce2d_kernel(uint32_t Gr, uint32_t Gc, uint32_t log2C, const xyzz_t *__re
     __syncthreads();
     if (threadIdx.x < 4) {
         xyzz_t t = sh_roww; xyzz_add_quad<F>(t, sh_colw); xyzz_add_quad<F>(t, sh_tot);
-        if (threadIdx.x == 0) set_total[set] = t;
+        if (threadIdx.x == 0) { set_total[set] = t; if (out_xyzz) out_xyzz[set] = t; }
     }
 }
 

@@ -272,6 +272,43 @@ template <int F> MB_HD fe_t challenge_to_field(uint64_t lo, uint64_t hi, const F
     return fe_add<F>(fe_mul<F>(fe_to_mont<F>(a, fk.r2), fk.endo), fe_to_mont<F>(b, fk.r2));
 }
 
+// Single proof, no weights: out[j] = L[lo] * H[hi] in ONE launch (the batch path above needs tables + fold + finish).
+// Block = one `hi`, lanes = `lo`s; every lane multiplies out its own L[lo] and the block's H[hi] (two independent
+// chains of <= 10 products).  Challenges come either as field elements (`chals`) or as the 128-bit prechallenges
+// (`prechal`, 4 words each), converted by the first k lanes of every block (ScalarChallenge::to_field).
+#if defined(__HIPCC__)
+template <int F>
+__global__ void __launch_bounds__(256)
+bpoly_single_kernel(BpolyShape sh, FieldK fk, const uint32_t *__restrict__ chals, const uint32_t *__restrict__ prechal,
+                    uint32_t *__restrict__ out_words) {
+    __shared__ fe_t ch[20];
+    const uint32_t nl = 1u << sh.lb, lo_blocks = (nl + blockDim.x - 1) / blockDim.x;
+    const uint32_t hi = blockIdx.x / lo_blocks, lo = (blockIdx.x % lo_blocks) * blockDim.x + threadIdx.x;
+    if (threadIdx.x < sh.k) {
+        fe_t c;
+        if (prechal) {
+            const uint32_t *pc = prechal + (size_t)threadIdx.x * 4;
+            c = challenge_to_field<F>((uint64_t)pc[0] | ((uint64_t)pc[1] << 32), (uint64_t)pc[2] | ((uint64_t)pc[3] << 32), fk);
+        } else {
+            for (int i = 0; i < 8; ++i) c.v[i] = chals[(size_t)threadIdx.x * 8 + i];
+            c = fe_to_mont<F>(c, fk.r2);
+        }
+        ch[threadIdx.x] = c;
+    }
+    __syncthreads();
+    if (lo >= nl) return;
+    fe_t l = fk.one, h = fk.one;
+    for (uint32_t q = 0; q < sh.hb || q < sh.lb; ++q) {          // bit q of lo uses chals[k-1-q], bit q of hi chals[k-1-lb-q]
+        if (q < sh.lb && ((lo >> q) & 1u)) l = fe_mul<F>(l, ch[sh.k - 1 - q]);
+        if (q < sh.hb && ((hi >> q) & 1u)) h = fe_mul<F>(h, ch[sh.k - 1 - sh.lb - q]);
+    }
+    const fe_t r = fe_from_mont<F>(fe_mul<F>(l, h));
+    uint4 *o = reinterpret_cast<uint4 *>(out_words + ((size_t)hi * nl + lo) * 8);
+    o[0] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
+    o[1] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
+}
+#endif
+
 #if defined(__HIPCC__)
 template <int F>
 __global__ void challenge_to_field_kernel(uint32_t n, FieldK fk, const uint32_t *__restrict__ chal /* n*4 words */, uint32_t *__restrict__ out_words) {
