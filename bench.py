@@ -4,9 +4,12 @@
 A "step" = one pass of the hot path over one batch of synthetic state proofs: for each proof the 2^16-base
 Vesta IPA accumulator check of BASELINE config C2 -- 16 128-bit prechallenges (already in HBM) ->
 ScalarChallenge::to_field -> b_poly_coefficients (K2) -> 2^16-point MSM over the Vesta SRS (K1) -> compare
-with the proof's sg -- through the C-ABI (`mina_accumulator_check_dev`), verdict left in HBM.
+with the proof's sg -- through the C-ABI, verdicts left in HBM.  Default: the `--group` (8) proofs of a step are
+verified INDEPENDENTLY (no random folding, one verdict each) by one kernel pipeline
+(`mina_accumulator_check_multi_dev`: every MSM is computed in full; the group only shares the ~14 dependent
+dispatches).  `--batch B` instead folds B proofs into one MSM with random weights (`mina_accumulator_check_dev`).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--group G] [--batch B]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Multi-GPU: proof-level sharding, no data-path collective (SURVEY.md 8e variant 1): every rank verifies its
@@ -36,9 +39,9 @@ MSM_ALGORITHMIC_BYTES = N_BASES * (64 + 32) + 96      # 6 291 55
 HBM_PEAK_GBPS = 8000.0                                # MI355X_MICROARCH.md: 8 TB/s spec
 PS_ACCUMULATE_BIT = 1 << 3      # ProfStage::PS_ACCUMULATE in csrc/ctx.h
 # HBM-side bytes per launch of the dominant kernel from the rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, KiB * 1024;
-# profiles/r01b_rocprof.md section 2).  14x the algorithmic bytes by design: the fixed-base window tables gather 16
+# profiles/r01f_rocprof.md section 2).  14x the algorithmic bytes by design: the fixed-base window tables gather 16
 # precomputed 64-B points per base and write 128-B XYZZ partials.
-ACCUMULATE_TRAFFIC_BYTES = 88_290_000
+ACCUMULATE_TRAFFIC_BYTES = 88_243_000
 # VALU side of the roofline (the path is integer-multiply bound): one Montgomery product is 88
 # v_mad_u64_u32 (8 cycles per wave64 instruction, profiles/r01_microbench_valu.jsonl) -> issue floor 704 cycles.
 MODMUL_ISSUE_FLOOR_CYCLES = 88 * 8
@@ -93,7 +96,9 @@ def cpu_baseline(pre_one: np.ndarray, sg_one: np.ndarray, budget_s: float = 12.0
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--group", type=int, default=8, help="independent (un-folded) proofs verified per step by one kernel pipeline")
+    ap.add_argument("--no-probes", action="store_true", help="skip the single-proof latency and folded-batch probes (profiling runs)")
     ap.add_argument("--warmup", type=int, default=64)
     ap.add_argument("--batch", type=int, default=1, help="proofs folded into one MSM per step")
     ap.add_argument("--pipeline", type=int, default=16, help="internal stream lanes over which consecutive steps are issued")
@@ -123,24 +128,34 @@ def main():
     ctx.srs_create(CURVE_VESTA, N_BASES)                       # SRS regenerated on the GPU (K4) + window tables
     ctx.set_pipeline(args.pipeline)
     B = args.batch
-    pre, sgs = make_instances(ctx, B, seed=0x6D696E61 + rank)
+    G = args.group if B == 1 else 1                            # un-folded proofs per step; folding and grouping are alternatives
+    if not 1 <= G <= 64:
+        raise SystemExit("--group must be in 1..64")
+    pre, sgs = make_instances(ctx, max(B, min(G, 4)), seed=0x6D696E61 + rank)
+    if G > 1:                                                  # G proofs per step from 4 distinct instances
+        pre = np.stack([pre[i % len(pre)] for i in range(G)]); sgs = np.stack([sgs[i % len(sgs)] for i in range(G)])
     dev = torch.device("cuda", local_rank)
     d_pre = torch.from_numpy(pre.reshape(-1)).to(dev)
     d_sg = torch.from_numpy(sgs.reshape(-1)).to(dev)
     rho = np.random.Generator(np.random.PCG64(99 + rank)).integers(0, 256, size=(B, 32), dtype=np.uint8)
     rho[:, 31] &= 0x3F
     d_rho = torch.from_numpy(rho.reshape(-1)).to(dev)
-    d_verdict = torch.zeros(1, dtype=torch.int32, device=dev)
+    d_verdict = torch.zeros(G, dtype=torch.int32, device=dev)
     torch.cuda.synchronize()
 
     def step():
-        ctx.accumulator_check_dev(CURVE_VESTA, K_ROUNDS, B, d_pre.data_ptr(), d_sg.data_ptr(),
-                                  d_rho.data_ptr() if B > 1 else 0, d_verdict.data_ptr())
+        if B == 1:
+            ctx.accumulator_check_multi_dev(CURVE_VESTA, K_ROUNDS, G, d_pre.data_ptr(), d_sg.data_ptr(), d_verdict.data_ptr())
+        else:
+            ctx.accumulator_check_dev(CURVE_VESTA, K_ROUNDS, B, d_pre.data_ptr(), d_sg.data_ptr(), d_rho.data_ptr(), d_verdict.data_ptr())
+
+    def verdicts_ok():
+        return d_verdict.cpu().numpy().tolist() == [1] * G
 
     for _ in range(max(args.warmup, args.pipeline)):          # every lane allocates its workspace during warm-up
         step()
     ctx.synchronize()
-    assert int(d_verdict.item()) == 1, "warm-up verdict must be ACCEPT"
+    assert verdicts_ok(), "warm-up verdicts must be ACCEPT"
 
     def barrier():
         if dist_on:
@@ -155,27 +170,35 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = ctx.prof_read()
     ctx.prof_enable(0)
-    assert int(d_verdict.item()) == 1, "timed-region verdict must be ACCEPT"
+    assert verdicts_ok(), "timed-region verdicts must be ACCEPT"
     # the same kernel with nothing else on the GPU: one lane, HIP events on that lane's stream
     ctx.set_pipeline(1)
     for _ in range(4):
         step()
     ctx.synchronize()
     ctx.prof_enable(PS_ACCUMULATE_BIT)
-    for _ in range(32):
+    for _ in range(16):
         step()
     prof_iso = ctx.prof_read()
     ctx.prof_enable(0)
-    # single-stream latency of one step (one lane, nothing overlapped)
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for _ in range(64):
-        step()
-    ctx.synchronize()
-    latency_ms = (time.perf_counter() - t1) / 64 * 1e3
+    # single-stream latency of ONE proof alone (one lane, nothing overlapped, no group)
+    latency_ms = None
+    if not args.no_probes:
+        d_v1 = torch.zeros(1, dtype=torch.int32, device=dev)
+        def step1():
+            ctx.accumulator_check_dev(CURVE_VESTA, K_ROUNDS, 1, d_pre.data_ptr(), d_sg.data_ptr(), 0, d_v1.data_ptr())
+        for _ in range(4):
+            step1()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(64):
+            step1()
+        ctx.synchronize()
+        latency_ms = (time.perf_counter() - t1) / 64 * 1e3
+        assert int(d_v1.item()) == 1
     # the design's batch mode: B proofs folded into ONE MSM per step (kimchi batch_verify's shape), same entry point
     extra = {}
-    if B == 1 and rank == 0:
+    if B == 1 and rank == 0 and not args.no_probes:
         BB = 256
         pre_b, sg_b = make_instances(ctx, 4, seed=77)
         pre_b = np.tile(pre_b, (BB // 4, 1, 1)); sg_b = np.tile(sg_b, (BB // 4, 1))
@@ -208,10 +231,11 @@ def main():
         overlapped_us = (total_ms_o / launches_o) * 1e3 if launches_o else None
         launches, total_ms = prof_iso.get("msm_accumulate", [0, 0.0])
         kern_s = (total_ms / launches) * 1e-3 if launches else float("nan")
-        achieved = MSM_ALGORITHMIC_BYTES / kern_s / 1e9 if launches else None
+        msms = G                                               # MSMs one msm_accumulate launch processes
+        achieved = msms * MSM_ALGORITHMIC_BYTES / kern_s / 1e9 if launches else None
         out = {
             "metric": "Mina state proofs verified/sec (batch)",
-            "value": args.gpus * args.steps * B / elapsed,
+            "value": args.gpus * args.steps * B * G / elapsed,
             "unit": "proofs/s",
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
@@ -220,20 +244,21 @@ def main():
             "dtype": "u32x8-montgomery (255-bit prime field, integer)", "data": "synthetic",
             "config": {"workload": "C2: per-proof 2^16-base Vesta IPA accumulator check (to_field + b_poly_coefficients + MSM over "
                                    "vesta.srs + compare), bit-exact vs CPU oracle", "curve": "vesta", "n_bases": N_BASES,
-                       "proofs_per_step": B, "pipeline_lanes": args.pipeline, "sharding": f"proof-level, {args.gpus} rank(s), no collective"},
+                       "proofs_per_step": B * G, "mode": (f"{G} independent checks per kernel pipeline, no folding" if B == 1 else f"{B} proofs folded into one MSM"),
+                       "pipeline_lanes": args.pipeline, "sharding": f"proof-level, {args.gpus} rank(s), no collective"},
             "roofline": {"bound": "hbm", "kernel": "msm_accumulate_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": ACCUMULATE_TRAFFIC_BYTES,
-                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r01b_rocprof.md",
-                         "traffic_GBps": ACCUMULATE_TRAFFIC_BYTES / kern_s / 1e9 if launches else None,
-                         "algorithmic_bytes_per_launch": MSM_ALGORITHMIC_BYTES, "avg_launch_us": kern_s * 1e6,
+                         "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": msms * ACCUMULATE_TRAFFIC_BYTES,
+                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r01f_rocprof.md",
+                         "traffic_GBps": msms * ACCUMULATE_TRAFFIC_BYTES / kern_s / 1e9 if launches else None,
+                         "algorithmic_bytes_per_launch": msms * MSM_ALGORITHMIC_BYTES, "msms_per_launch": msms, "avg_launch_us": kern_s * 1e6,
                          "avg_launch_us_in_timed_region": overlapped_us,
-                         "note": "avg_launch_us: HIP events on the lane stream, 32 launches with nothing else on the GPU, right after the "
+                         "note": "avg_launch_us: HIP events on the lane stream, 16 launches with nothing else on the GPU, right after the "
                                  "timed region; in the timed region the launches of 16 lanes overlap and time-share the CUs (second figure). "
                                  "Integer-VALU-bound path (SURVEY.md 8d): HBM fraction reported as the metric demands, see roofline_valu"},
         }
         if launches:
             peak = CHIP_SIMDS * 64 * CLOCK_HZ / MODMUL_ISSUE_FLOOR_CYCLES          # modmul/s if only the 88 mads issued
-            got = MIXED_ADDS_PER_MSM * MODMUL_PER_MIXED_ADD / kern_s
+            got = msms * MIXED_ADDS_PER_MSM * MODMUL_PER_MIXED_ADD / kern_s
             out["roofline_valu"] = {"bound": "int32 multiply issue (v_mad_u64_u32)", "achieved": got / 1e9, "peak": peak / 1e9,
                                     "unit": "G modmul/s", "frac": got / peak,
                                     "note": "same isolated launches as roofline"}

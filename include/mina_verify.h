@@ -204,6 +204,16 @@ int mina_accumulator_check_batch(mina_ctx *ctx, int curve, uint32_t k, size_t ba
 int mina_accumulator_check_dev(mina_ctx *ctx, int curve, uint32_t k, size_t batch, const void *d_prechallenges,
                                const void *d_sg, const void *d_rho, void *d_verdict);
 
+/* `count` (<= 64) INDEPENDENT accumulator checks -- no random folding, one u32 verdict each at d_verdicts[i] -- issued as ONE
+ * kernel pipeline (the MSMs are problems of the multi-problem pipeline): the fixed per-check dispatch latency is paid once
+ * per group.  prechallenges count*k*16 B, sg count*64 B, all in HBM; queued, no host synchronisation. */
+int mina_accumulator_check_multi_dev(mina_ctx *ctx, int curve, uint32_t k, size_t count, const void *d_prechallenges,
+                                     const void *d_sg, void *d_verdicts);
+/* Host-buffer form, any count (groups of 16 per pipeline): verdicts[i] = 1 iff proof i's check holds.  Deterministic --
+ * the alternative to the folded check when the caller has no randomness to hand over. */
+int mina_accumulator_check_multi(mina_ctx *ctx, int curve, uint32_t k, size_t count, const uint8_t *prechallenges /* count*k*16 */,
+                                 const uint8_t *sg /* count*64 */, uint8_t *verdicts /* count */);
+
 /* Combined IPA opening check `SRS::verify` (a8).  One entry = one upstream `BatchEvaluationProof`
  * (sponge, evaluation_points, polyscale, evalscale, evaluations[].commitment, opening,
  * combined_inner_product), single-chunk commitments without degree bounds. */

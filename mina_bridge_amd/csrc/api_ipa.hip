@@ -250,7 +250,8 @@ __global__ void xyzz_compare_kernel(const xyzz_t *__restrict__ a, const xyzz_t *
 // A (xyzz) == affine point q (canonical words; zeros = infinity) ?
 template <int F>
 __global__ void xyzz_eq_affine_kernel(const xyzz_t *__restrict__ a, const uint32_t *__restrict__ q_words, fe_t r2, uint32_t *__restrict__ verdict) {
-    if (threadIdx.x || blockIdx.x) return;
+    if (threadIdx.x) return;                                  // one block per comparison: a[b] vs q_words[16 b ..] -> verdict[b]
+    a += blockIdx.x; q_words += (size_t)blockIdx.x * 16; verdict += blockIdx.x;
     xyzz_t A = *a;
     fe_t qx = fe_to_mont<F>(load_fe<F>(q_words), r2), qy = fe_to_mont<F>(load_fe<F>(q_words + 8), r2);
     bool qi = fe_is_zero(qx) && fe_is_zero(qy), ai = xyzz_is_inf(A), eq;
@@ -276,7 +277,7 @@ static int accumulator_check_dev(mina_ctx *c, int curve, uint32_t k, size_t batc
     if ((rc = c->L->ipa_xyzz_a.ensure(sizeof(xyzz_t)))) return rc;
     if ((rc = c->L->ipa_xyzz_b.ensure(sizeof(xyzz_t)))) return rc;
     if (batch == 1) {                                            // prechallenges -> coefficients in one launch
-        if ((rc = mb_bpoly_single_from_prechallenges(c, FS, k, d_prechal, c->L->ipa_folded.as<uint32_t>()))) return rc;
+        if ((rc = mb_bpoly_single_from_prechallenges(c, FS, k, d_prechal, c->L->ipa_folded.as<uint32_t>(), 1))) return rc;
     } else {
         DISPATCH_FIELD(FS, { challenge_to_field_kernel<F_><<<cdiv(batch * k, 64), 64, 0, c->L->stream>>>((uint32_t)(batch * k), c->fk[F_], d_prechal, c->L->ipa_chals.as<uint32_t>()); });
         if ((rc = mb_bpoly_fold(c, FS, k, batch, c->L->ipa_chals.as<uint32_t>(), d_rho, c->L->ipa_folded.as<uint32_t>()))) return rc;
@@ -294,6 +295,35 @@ static int accumulator_check_dev(mina_ctx *c, int curve, uint32_t k, size_t batc
     return MINA_OK;
 }
 
+// `count` INDEPENDENT checks (no random folding: one verdict word each) through ONE kernel pipeline: the count MSMs are
+// problems of the multi-problem pipeline, so the ~14 dependent dispatches of a check are paid once per group.
+static int accumulator_check_multi_dev(mina_ctx *c, int curve, uint32_t k, size_t count, const uint32_t *d_prechal,
+                                       const uint32_t *d_sg_words, uint32_t *d_verdicts) {
+    SrsState &s = c->srs[curve];
+    if (s.depth == 0) return fail(MINA_ERR_STATE, "SRS not loaded for this curve");
+    if (k < 1 || k > 20 || ((size_t)1 << k) > s.depth) return fail(MINA_ERR_ARG, "2^k exceeds the SRS depth");
+    const int FS = scalar_field_of(curve), FB = base_field_of(curve);
+    const uint32_t n = 1u << k;
+    int rc;
+    if ((rc = c->L->ipa_folded.ensure(count * n * 32))) return rc;
+    if ((rc = c->L->ipa_xyzz_a.ensure(count * sizeof(xyzz_t)))) return rc;
+    if ((rc = mb_bpoly_single_from_prechallenges(c, FS, k, d_prechal, c->L->ipa_folded.as<uint32_t>(), (uint32_t)count))) return rc;
+    if ((rc = mb_msm_table(c, curve, s.table.p, s.depth, s.c, s.W, 0, n, (uint32_t)count, c->L->ipa_folded.as<uint32_t>(), nullptr, c->L->ipa_xyzz_a.p))) return rc;
+    DISPATCH_FIELD(FB, { xyzz_eq_affine_kernel<F_><<<(uint32_t)count, 64, 0, c->L->stream>>>(c->L->ipa_xyzz_a.as<xyzz_t>(), d_sg_words, c->fk[F_].r2, d_verdicts); });
+    HIPC(hipGetLastError());
+    return MINA_OK;
+}
+
+extern "C" int mina_accumulator_check_multi_dev(mina_ctx *c, int curve, uint32_t k, size_t count, const void *d_prechallenges,
+                                                const void *d_sg, void *d_verdicts) {
+    if (!c || !d_prechallenges || !d_sg || !d_verdicts) return fail(MINA_ERR_ARG, "null argument");
+    if (curve != 0 && curve != 1) return fail(MINA_ERR_ARG, "bad curve");
+    if (count == 0 || count > 64) return fail(MINA_ERR_ARG, "count must be in 1..64");
+    HIPC(hipSetDevice(c->device));
+    c->next_lane();
+    return accumulator_check_multi_dev(c, curve, k, count, (const uint32_t *)d_prechallenges, (const uint32_t *)d_sg, (uint32_t *)d_verdicts);
+}
+
 extern "C" int mina_accumulator_check_dev(mina_ctx *c, int curve, uint32_t k, size_t batch, const void *d_prechallenges,
                                           const void *d_sg, const void *d_rho, void *d_verdict) {
     if (!c || !d_prechallenges || !d_sg || !d_verdict || (batch > 1 && !d_rho)) return fail(MINA_ERR_ARG, "null argument");
@@ -302,6 +332,22 @@ extern "C" int mina_accumulator_check_dev(mina_ctx *c, int curve, uint32_t k, si
     HIPC(hipSetDevice(c->device));
     c->next_lane();
     return accumulator_check_dev(c, curve, k, batch, (const uint32_t *)d_prechallenges, (const uint32_t *)d_sg, (const uint32_t *)d_rho, (uint32_t *)d_verdict);
+}
+
+// per-proof verdicts for the `count` proofs already staged in ipa_in_a (prechallenges) / ipa_in_b (sg) of the current lane
+static int accumulator_check_each(mina_ctx *c, int curve, uint32_t k, size_t count, uint8_t *verdicts) {
+    constexpr size_t GROUP = 16;
+    int rc;
+    if ((rc = c->L->ipa_verdict.ensure(GROUP * 4))) return rc;
+    for (size_t b = 0; b < count; b += GROUP) {
+        const size_t g = count - b < GROUP ? count - b : GROUP;
+        if ((rc = accumulator_check_multi_dev(c, curve, k, g, c->L->ipa_in_a.as<uint32_t>() + b * k * 4, c->L->ipa_in_b.as<uint32_t>() + b * 16,
+                                              c->L->ipa_verdict.as<uint32_t>()))) return rc;
+        uint32_t v[GROUP];
+        if ((rc = d2h_sync(c, v, c->L->ipa_verdict, g * 4))) return rc;
+        for (size_t i = 0; i < g; ++i) verdicts[b + i] = v[i] ? 1 : 0;
+    }
+    return MINA_OK;
 }
 
 extern "C" int mina_accumulator_check_batch(mina_ctx *c, int curve, uint32_t k, size_t batch, const uint8_t *prechallenges,
@@ -315,20 +361,28 @@ extern "C" int mina_accumulator_check_batch(mina_ctx *c, int curve, uint32_t k, 
     if ((rc = h2d(c, c->L->ipa_in_a, prechallenges, batch * k * 16))) return rc;
     if ((rc = h2d(c, c->L->ipa_in_b, sg, batch * 64))) return rc;
     if (batch > 1 && (rc = h2d(c, c->L->ipa_in_c, rho, batch * 32))) return rc;
-    if ((rc = c->L->ipa_verdict.ensure(4))) return rc;
+    if ((rc = c->L->ipa_verdict.ensure(64))) return rc;
     if ((rc = accumulator_check_dev(c, curve, k, batch, c->L->ipa_in_a.as<uint32_t>(), c->L->ipa_in_b.as<uint32_t>(),
                                     batch > 1 ? c->L->ipa_in_c.as<uint32_t>() : nullptr, c->L->ipa_verdict.as<uint32_t>()))) return rc;
     uint32_t v = 0;
     if ((rc = d2h_sync(c, &v, c->L->ipa_verdict, 4))) return rc;
     if (v || batch == 1) { memset(verdicts, v ? 1 : 0, batch); return MINA_OK; }
-    // the folded check failed: find the culprits one proof at a time (rare path)
-    for (size_t b = 0; b < batch; ++b) {
-        if ((rc = accumulator_check_dev(c, curve, k, 1, c->L->ipa_in_a.as<uint32_t>() + b * k * 4, c->L->ipa_in_b.as<uint32_t>() + b * 16,
-                                        nullptr, c->L->ipa_verdict.as<uint32_t>()))) return rc;
-        if ((rc = d2h_sync(c, &v, c->L->ipa_verdict, 4))) return rc;
-        verdicts[b] = v ? 1 : 0;
-    }
-    return MINA_OK;
+    // the folded check failed: every proof on its own (rare path), groups of independent checks per pipeline
+    return accumulator_check_each(c, curve, k, batch, verdicts);
+}
+
+// host-buffer form of the un-folded group check: per-proof verdicts, no randomness involved
+extern "C" int mina_accumulator_check_multi(mina_ctx *c, int curve, uint32_t k, size_t count, const uint8_t *prechallenges,
+                                            const uint8_t *sg, uint8_t *verdicts) {
+    if (!c || !prechallenges || !sg || !verdicts) return fail(MINA_ERR_ARG, "null argument");
+    if (curve != 0 && curve != 1) return fail(MINA_ERR_ARG, "bad curve");
+    if (count == 0 || count > (1u << 20)) return fail(MINA_ERR_ARG, "bad count");
+    HIPC(hipSetDevice(c->device));
+    c->use_lane0();
+    int rc;
+    if ((rc = h2d(c, c->L->ipa_in_a, prechallenges, count * k * 16))) return rc;
+    if ((rc = h2d(c, c->L->ipa_in_b, sg, count * 64))) return rc;
+    return accumulator_check_each(c, curve, k, count, verdicts);
 }
 
 // ------------------------------------------------------------------------------------------------

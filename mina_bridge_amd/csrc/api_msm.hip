@@ -30,13 +30,14 @@ static int run_msm(mina_ctx *c, const MsmShape &sh, const uint32_t *d_scalars, c
     int rc;
     // sort plan: partitioned LDS sort when the partition table fits (P <= 1024 with <= 2048 buckets per partition),
     // else the atomic counting sort
-    SortShape ss; ss.fbits = 8; ss.G = cdiv((size_t)sh.n * sh.nprob, 256);
-    while (ss.fbits < 11 && cdiv(nb_total, 1u << ss.fbits) > 256) ++ss.fbits;
-    ss.P = cdiv(nb_total, 1u << ss.fbits);
+    SortShape ss; ss.fbits = 8; ss.Gl = cdiv(sh.n, 256); ss.SB = sh.NB * (sh.nsets / sh.nprob);
+    while (ss.fbits < 11 && cdiv(ss.SB, 1u << ss.fbits) > 256) ++ss.fbits;
+    ss.Pl = cdiv(ss.SB, 1u << ss.fbits);
+    const uint64_t gh_words = (uint64_t)ss.Pl * ss.Gl * sh.nprob;
     static const bool force_atomic_sort = getenv("MINA_MSM_ATOMIC_SORT") != nullptr;      // A/B switch for profiling
-    const bool part_sort = !force_atomic_sort && ss.P <= 1024 && (uint64_t)ss.P * ss.G <= (1u << 22);
+    const bool part_sort = !force_atomic_sort && ss.Pl <= 1024 && gh_words <= (1u << 22);
     if (part_sort) {
-        if ((rc = w.ghist.ensure(((size_t)ss.P * ss.G + 8) * 4))) return rc;
+        if ((rc = w.ghist.ensure((gh_words + 8) * 4))) return rc;
         if ((rc = w.stage.ensure(entries * 8))) return rc;
     } else {
         if ((rc = w.ekey.ensure(entries * 4))) return rc;
@@ -65,11 +66,11 @@ static int run_msm(mina_ctx *c, const MsmShape &sh, const uint32_t *d_scalars, c
     const bool fused_finish = sh.nsets == sh.nprob && !d_out_words && d_out_xyzz;
     if (part_sort) {
         { ProfScope ps_(c, PS_DIGITS);
-          msm_part_kernel<false><<<ss.G, 1024, 0, st>>>(sh, ss, d_scalars, w.ghist.as<uint32_t>(), nullptr);
-          msm_excl_scan_kernel<<<1, 1024, 0, st>>>(ss.P * ss.G, w.ghist.as<uint32_t>()); }
+          msm_part_kernel<false><<<ss.Gl * sh.nprob, 1024, 0, st>>>(sh, ss, d_scalars, w.ghist.as<uint32_t>(), nullptr);
+          msm_excl_scan_kernel<<<1, 1024, 0, st>>>((uint32_t)gh_words, w.ghist.as<uint32_t>()); }
         { ProfScope ps_(c, PS_SCATTER);
-          msm_part_kernel<true><<<ss.G, 1024, 0, st>>>(sh, ss, d_scalars, w.ghist.as<uint32_t>(), w.stage.as<uint2>());
-          msm_part_sort_kernel<<<ss.P, 1024, 0, st>>>(ss, nb_total, w.ghist.as<uint32_t>(), w.stage.as<uint2>(), w.count.as<uint32_t>(), w.sorted.as<uint32_t>()); }
+          msm_part_kernel<true><<<ss.Gl * sh.nprob, 1024, 0, st>>>(sh, ss, d_scalars, w.ghist.as<uint32_t>(), w.stage.as<uint2>());
+          msm_part_sort_kernel<<<ss.Pl * sh.nprob, 1024, 0, st>>>(ss, w.ghist.as<uint32_t>(), w.stage.as<uint2>(), w.count.as<uint32_t>(), w.sorted.as<uint32_t>()); }
         { ProfScope ps_(c, PS_SCAN); msm_scan_kernel<<<1, 1024, 0, st>>>(nb_total, w.count.as<uint32_t>(), w.start.as<uint32_t>(), w.task_start.as<uint32_t>(),
                                                                        w.rem_pos.as<uint32_t>(), w.info.as<uint32_t>());
                                      msm_rem_invert_kernel<<<cdiv(nb_total, 256), 256, 0, st>>>(nb_total, w.rem_pos.as<uint32_t>(), w.rem_bucket.as<uint32_t>()); }

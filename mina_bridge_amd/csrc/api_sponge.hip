@@ -31,14 +31,14 @@ static int run_bpoly_fold(mina_ctx *c, uint32_t k, size_t batch, const uint32_t 
     return MINA_OK;
 }
 
-// b_poly_coefficients of ONE proof straight from its 128-bit prechallenges (accumulator check, batch == 1)
-int mb_bpoly_single_from_prechallenges(mina_ctx *c, int field, uint32_t k, const uint32_t *d_prechal, uint32_t *d_out) {
+// b_poly_coefficients of `count` proofs (grid.y), each straight from its k 128-bit prechallenges -> count * 2^k scalars
+int mb_bpoly_single_from_prechallenges(mina_ctx *c, int field, uint32_t k, const uint32_t *d_prechal, uint32_t *d_out, uint32_t count) {
     if (bad_field(field) || k < 1 || k > 20) return fail(MINA_ERR_ARG, "bad field or k");
     DISPATCH_FIELD(field, {
         BpolyShape sh = bp_shape(k, 1);
         const uint32_t nl = 1u << sh.lb, nh = 1u << sh.hb;
         ProfScope ps_(c, PS_BPOLY_FOLD);
-        bpoly_single_kernel<F_><<<cdiv(nl, 256) * nh, nl < 256 ? (nl < 64 ? 64 : nl) : 256, 0, c->L->stream>>>(sh, c->fk[F_], nullptr, d_prechal, d_out);
+        bpoly_single_kernel<F_><<<dim3(cdiv(nl, 256) * nh, count), nl < 256 ? (nl < 64 ? 64 : nl) : 256, 0, c->L->stream>>>(sh, c->fk[F_], nullptr, d_prechal, d_out);
     });
     HIPC(hipGetLastError());
     return MINA_OK;

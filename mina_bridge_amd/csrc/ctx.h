@@ -136,7 +136,7 @@ int mb_msm_fixed(mina_ctx *c, int curve, uint32_t n, const uint32_t *d_scalars, 
 // K2 fold on the current lane (no lane switch)
 int mb_msm_table(mina_ctx *c, int curve, const void *d_table, uint32_t stride, uint32_t cbits, uint32_t W, uint32_t first, uint32_t n,
                  uint32_t nprob, const uint32_t *d_scalars, uint32_t *d_out_words, void *d_out_xyzz);
-int mb_bpoly_single_from_prechallenges(mina_ctx *c, int field, uint32_t k, const uint32_t *d_prechal, uint32_t *d_out);
+int mb_bpoly_single_from_prechallenges(mina_ctx *c, int field, uint32_t k, const uint32_t *d_prechal, uint32_t *d_out, uint32_t count);
 int mb_bpoly_fold(mina_ctx *c, int field, uint32_t k, size_t batch, const uint32_t *d_chals, const uint32_t *d_weights, uint32_t *d_out);
 int mb_msm_variable(mina_ctx *c, int curve, uint32_t n, const uint32_t *d_scalars, const void *d_points_mont,
                     uint32_t *d_out_words, void *d_out_xyzz);

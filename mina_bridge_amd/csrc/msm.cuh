@@ -248,7 +248,7 @@ msm_scan_kernel(uint32_t nb_total, const uint32_t *__restrict__ count, uint32_t 
 // The atomic sort above costs 1 M device-scope returning atomics and 1 M random 4-byte stores per 2^16 MSM (92 MB of
 // fabric traffic for 12 MB of payload); with 16 MSMs in flight it is 28 % of the step time.  K1p sorts in two levels
 // with LDS histograms only:
-//   level 1: partition = bucket >> fbits (P <= 1024 partitions).  Blocks of 1024 lanes own 256 scalars x all windows
+//   level 1: partition = (bucket within its problem) >> fbits (<= 1024 partitions per problem).  Blocks of 1024 lanes own 256 scalars x all windows
 //            (each scalar is read once): K1p-a counts per (partition, block), one block scans the P x G table, K1p-c
 //            recomputes the digits and writes {ref, fine key} into its slots of the staging array (LDS cursors) --
 //            every 64-B line of the staging array is written by ONE block (one XCD's L2 merges the stores);
@@ -256,9 +256,12 @@ msm_scan_kernel(uint32_t nb_total, const uint32_t *__restrict__ count, uint32_t 
 //            references placed at their final positions inside the partition's contiguous range of `sorted`.
 struct SortShape {
     uint32_t fbits;    // fine key bits: buckets per partition = 2^fbits (<= 2048)
-    uint32_t P;        // partitions = ceil(nb_total / 2^fbits) (<= 1024)
-    uint32_t G;        // level-1 blocks = ceil(n * nprob / 256)
+    uint32_t Pl;       // partitions per problem = ceil(buckets per problem / 2^fbits) (<= 1024)
+    uint32_t Gl;       // level-1 blocks per problem = ceil(n / 256)
+    uint32_t SB;       // buckets per problem = NB * (bucket sets per problem)
 };
+// With nprob problems the partition table is block-diagonal (a block only meets its own problem's buckets): it is stored
+// as gh[(m * Pl + p) * Gl + g] -- linear in nprob -- and its exclusive scan, taken in that order, is the bucket order.
 
 // K1p-b: in-place exclusive scan of n values by one 1024-lane block (rows of 4096, coalesced uint4); data[n] = total.
 // The buffer is padded to a multiple of 4 words past n.
@@ -290,20 +293,21 @@ static __global__ void __launch_bounds__(1024)
 msm_part_kernel(MsmShape sh, SortShape ss, const uint32_t *__restrict__ scalars, uint32_t *__restrict__ gh, uint2 *__restrict__ staging) {
     __shared__ uint32_t cur[1024];
     const uint32_t tid = threadIdx.x;
-    for (uint32_t j = tid; j < ss.P; j += 1024) cur[j] = SCATTER ? gh[(size_t)j * ss.G + blockIdx.x] : 0u;
+    const uint32_t m = blockIdx.x / ss.Gl, g = blockIdx.x - m * ss.Gl;            // problem, block within the problem
+    uint32_t *ghm = gh + (size_t)m * ss.Pl * ss.Gl + g;
+    for (uint32_t j = tid; j < ss.Pl; j += 1024) cur[j] = SCATTER ? ghm[(size_t)j * ss.Gl] : 0u;
     __syncthreads();
-    const uint32_t si = blockIdx.x * 256 + (tid & 255);           // scalar index over nprob * n
-    if (si < sh.n * sh.nprob) {
-        const uint32_t m = si / sh.n, i = si - m * sh.n;
+    const uint32_t i = g * 256 + (tid & 255);                                     // scalar index within the problem
+    if (i < sh.n) {
         uint32_t s[8];
-        load_scalar(scalars + (size_t)si * 8, s);
+        load_scalar(scalars + ((size_t)m * sh.n + i) * 8, s);
         for (uint32_t w = tid >> 8; w < sh.W; w += 4) {
             uint32_t bucket, ref;
             if (!msm_entry(sh, s, m, w, i, bucket, ref)) continue;
-            const uint32_t part = bucket >> ss.fbits;
+            const uint32_t lb = bucket - m * ss.SB, part = lb >> ss.fbits;
             if (SCATTER) {
                 const uint32_t pos = atomicAdd(&cur[part], 1u);
-                staging[pos] = make_uint2(ref, bucket & ((1u << ss.fbits) - 1u));
+                staging[pos] = make_uint2(ref, lb & ((1u << ss.fbits) - 1u));
             } else {
                 atomicAdd(&cur[part], 1u);
             }
@@ -311,7 +315,7 @@ msm_part_kernel(MsmShape sh, SortShape ss, const uint32_t *__restrict__ scalars,
     }
     if (!SCATTER) {
         __syncthreads();
-        for (uint32_t j = tid; j < ss.P; j += 1024) gh[(size_t)j * ss.G + blockIdx.x] = cur[j];
+        for (uint32_t j = tid; j < ss.Pl; j += 1024) ghm[(size_t)j * ss.Gl] = cur[j];
     }
 }
 
@@ -322,14 +326,16 @@ static __global__ void __launch_bounds__(1024) msm_excl_scan_kernel(uint32_t n, 
     block_excl_scan_inplace(n, data, s_tot, s_pre, s_all);
 }
 
-// K1p-d: level 2, one block per partition.
+// K1p-d: level 2, one block per (problem, partition).
 static __global__ void __launch_bounds__(1024)
-msm_part_sort_kernel(SortShape ss, uint32_t nb_total, const uint32_t *__restrict__ goff, const uint2 *__restrict__ staging,
+msm_part_sort_kernel(SortShape ss, const uint32_t *__restrict__ goff, const uint2 *__restrict__ staging,
                      uint32_t *__restrict__ count, uint32_t *__restrict__ sorted) {
     __shared__ uint32_t hist[2048];
     __shared__ uint32_t s_tot[1][16], s_pre[1][16], s_all[1];
-    const uint32_t tid = threadIdx.x, p = blockIdx.x, nf = 1u << ss.fbits;
-    const uint32_t begin = goff[(size_t)p * ss.G], end = goff[(size_t)(p + 1) * ss.G];     // goff[P * G] = total
+    const uint32_t tid = threadIdx.x, pg = blockIdx.x, nf = 1u << ss.fbits;
+    const uint32_t m = pg / ss.Pl, p = pg - m * ss.Pl;
+    const uint32_t nvalid = (ss.SB - p * nf < nf) ? ss.SB - p * nf : nf;          // buckets of this partition (last one may be short)
+    const uint32_t begin = goff[(size_t)pg * ss.Gl], end = goff[(size_t)(pg + 1) * ss.Gl];   // goff[nprob * Pl * Gl] = total
     for (uint32_t j = tid; j < nf; j += 1024) hist[j] = 0;
     __syncthreads();
     for (uint32_t e = begin + tid; e < end; e += 1024) atomicAdd(&hist[staging[e].y], 1u);
@@ -338,11 +344,9 @@ msm_part_sort_kernel(SortShape ss, uint32_t nb_total, const uint32_t *__restrict
     const uint32_t h0 = (2 * tid < nf) ? hist[2 * tid] : 0u, h1 = (2 * tid + 1 < nf) ? hist[2 * tid + 1] : 0u;
     uint32_t v[1] = {h0 + h1}, tot[1];
     block_exclusive_scan<1>(v, tot, s_tot, s_pre, s_all);
-    const uint32_t b0 = p * nf + 2 * tid;
-    if (2 * tid < nf) {
-        if (b0 < nb_total) count[b0] = h0;
-        if (b0 + 1 < nb_total && 2 * tid + 1 < nf) count[b0 + 1] = h1;
-    }
+    const uint32_t b0 = m * ss.SB + p * nf + 2 * tid;
+    if (2 * tid < nvalid) count[b0] = h0;
+    if (2 * tid + 1 < nvalid) count[b0 + 1] = h1;
     __syncthreads();                                                            // all reads of hist done
     if (2 * tid < nf) hist[2 * tid] = v[0];                                     // hist becomes the cursor array
     if (2 * tid + 1 < nf) hist[2 * tid + 1] = v[0] + h0;

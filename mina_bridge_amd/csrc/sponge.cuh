@@ -282,6 +282,9 @@ __global__ void __launch_bounds__(256)
 bpoly_single_kernel(BpolyShape sh, FieldK fk, const uint32_t *__restrict__ chals, const uint32_t *__restrict__ prechal,
                     uint32_t *__restrict__ out_words) {
     __shared__ fe_t ch[20];
+    if (chals) chals += (size_t)blockIdx.y * sh.k * 8;           // grid.y = proof
+    if (prechal) prechal += (size_t)blockIdx.y * sh.k * 4;
+    out_words += ((size_t)blockIdx.y << sh.k) * 8;
     const uint32_t nl = 1u << sh.lb, lo_blocks = (nl + blockDim.x - 1) / blockDim.x;
     const uint32_t hi = blockIdx.x / lo_blocks, lo = (blockIdx.x % lo_blocks) * blockDim.x + threadIdx.x;
     if (threadIdx.x < sh.k) {

@@ -28,7 +28,7 @@ EXPORTS = [
     "mina_poseidon_set_params", "mina_poseidon_permute", "mina_poseidon_permute_dev", "mina_poseidon_hash",
     "mina_challenge_to_field", "mina_fq_sponge_run", "mina_to_group", "mina_merkle_roots", "mina_merkle_verify_batch",
     "mina_field_mul", "mina_field_inv", "mina_field_sqrt", "mina_selftest_group_law",
-    "mina_accumulator_check_batch", "mina_accumulator_check_dev", "mina_ipa_batch_check",
+    "mina_accumulator_check_batch", "mina_accumulator_check_dev", "mina_accumulator_check_multi_dev", "mina_accumulator_check_multi", "mina_ipa_batch_check",
     "mina_consensus_project_window", "mina_consensus_relative_min_window_density", "mina_consensus_is_short_range",
     "mina_consensus_select_secure_chain", "mina_parse_state_pub_inputs", "mina_parse_account_pub_inputs", "mina_parse_merkle_path", "mina_verify_account_inclusion",
 ]
@@ -489,6 +489,21 @@ class MinaContext:
         self._ck(self._lib.mina_accumulator_check_dev(self._h, curve, ctypes.c_uint32(k), ctypes.c_size_t(batch), ctypes.c_void_p(d_pre),
                                                        ctypes.c_void_p(d_sg), ctypes.c_void_p(d_rho) if d_rho else None, ctypes.c_void_p(d_verdict)),
                  "mina_accumulator_check_dev")
+
+    def accumulator_check_multi(self, curve: int, k: int, prechallenges, sg) -> np.ndarray:
+        """un-folded: one deterministic verdict per proof (groups of 16 checks per kernel pipeline)"""
+        pre, sg = _u8(prechallenges), _u8(sg)
+        count = sg.size // 64
+        assert pre.size == count * k * 16
+        out = np.zeros(count, np.uint8)
+        self._ck(self._lib.mina_accumulator_check_multi(self._h, curve, ctypes.c_uint32(k), ctypes.c_size_t(count), _p(pre), _p(sg), _p(out)),
+                 "mina_accumulator_check_multi")
+        return out
+
+    def accumulator_check_multi_dev(self, curve: int, k: int, count: int, d_pre: int, d_sg: int, d_verdicts: int):
+        """`count` independent checks in one kernel pipeline; d_verdicts: count u32 words"""
+        self._ck(self._lib.mina_accumulator_check_multi_dev(self._h, curve, ctypes.c_uint32(k), ctypes.c_size_t(count), ctypes.c_void_p(d_pre),
+                                                            ctypes.c_void_p(d_sg), ctypes.c_void_p(d_verdicts)), "mina_accumulator_check_multi_dev")
 
     @staticmethod
     def pack_ipa_openings(openings: list):

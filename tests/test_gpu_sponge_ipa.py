@@ -106,3 +106,24 @@ def test_accumulator_check_batch_with_culprit(ctx_srs, oracle, srs_oracle):
     assert ctx_srs.accumulator_check_batch(curve, k, pre, sg, rho).tolist() == [1] * batch
     sg_bad = sg.copy(); sg_bad[4] = sg[0]
     assert ctx_srs.accumulator_check_batch(curve, k, pre, sg_bad, rho).tolist() == [1, 1, 1, 1, 0, 1]
+
+
+@pytest.mark.parametrize("curve,k,count", [(1, 16, 5), (0, 15, 3), (1, 10, 37), (1, 8, 1)])
+def test_accumulator_check_multi_unfolded(ctx_srs, oracle, srs_oracle, curve, k, count):
+    """`count` independent checks per kernel pipeline (the MSMs are problems of the multi-problem pipeline): per-proof
+    verdicts equal the single-proof entry point's, with tampered proofs anywhere in a group"""
+    distinct = min(count, 4)
+    inst = [make_accumulator_instance(oracle, srs_oracle, curve, k, seed=900 + 13 * k + b) for b in range(distinct)]
+    pre = np.concatenate([inst[b % distinct][0] for b in range(count)]); sg = np.stack([inst[b % distinct][1] for b in range(count)])
+    assert ctx_srs.accumulator_check_multi(curve, k, pre, sg).tolist() == [1] * count
+    bad_pre, bad_sg = pre.copy(), sg.copy()
+    expect = [1] * count
+    bad_pre[0 * k + 2, 5] ^= 0x10; expect[0] = 0                       # a flipped prechallenge bit in proof 0
+    if count > 2:
+        bad_sg[count - 1] = sg[(count - 2) % count] if distinct > 1 else oracle.point_add(curve, sg[0], sg[0]); expect[count - 1] = 0
+    if count > 20:
+        bad_sg[17] = 0; expect[17] = 0                                  # infinity instead of the commitment, second group
+    got = ctx_srs.accumulator_check_multi(curve, k, bad_pre, bad_sg).tolist()
+    assert got == expect
+    for b in sorted({0, count - 1}):
+        assert ctx_srs.accumulator_check_batch(curve, k, bad_pre[b * k:(b + 1) * k], bad_sg[b]).tolist() == [expect[b]]
