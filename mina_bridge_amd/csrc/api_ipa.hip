@@ -15,28 +15,29 @@
 
 namespace mb {
 
-// mina-poseidon `ArithmeticSponge` state machine (rate 2) over base field F, Montgomery state, lane-cooperative:
-// the three state elements live on lanes 0..2 of a DPP quad (`s` = this lane's element), the position (squeezed, count)
-// is replicated.  Absorbed values and squeezed results are replicated on all four lanes.
-template <int F> struct DevSponge {
+// mina-poseidon `ArithmeticSponge` state machine (rate 2) over base field F, Montgomery state, lane-cooperative over
+// LANES = 4 or 8 lanes (sponge.cuh): `s` = the state element this lane owns (coop_elem), the position (squeezed, count)
+// is replicated.  Absorbed values and squeezed results are replicated on all lanes of the group.
+template <int F, int LANES> struct DevSponge {
     fe_t s; int squeezed; int count; const PoseidonParams *pp;
-    __device__ void add_at(int pos, const fe_t &x) { if ((int)(threadIdx.x & 3u) == pos) s = fe_add<F>(s, x); }
-    __device__ fe_t get(int pos) { return pos == 0 ? quad_bcast<0>(s) : (pos == 1 ? quad_bcast<1>(s) : quad_bcast<2>(s)); }
+    __device__ void add_at(int pos, const fe_t &x) { if ((int)coop_elem<LANES>() == pos) s = fe_add<F>(s, x); }
+    __device__ fe_t get(int pos) { return coop_get<LANES>(s, pos); }
     __device__ void absorb(const fe_t &x) {
         if (!squeezed) {
-            if (count == 2) { poseidon_permute_quad<F>(s, pp); add_at(0, x); count = 1; }
+            if (count == 2) { poseidon_permute_coop<F, LANES>(s, pp); add_at(0, x); count = 1; }
             else { add_at(count, x); ++count; }
         } else { add_at(0, x); squeezed = 0; count = 1; }
     }
     __device__ fe_t squeeze() {
-        if (!squeezed || count == 2) { poseidon_permute_quad<F>(s, pp); squeezed = 1; count = 1; return get(0); }
+        if (!squeezed || count == 2) { poseidon_permute_coop<F, LANES>(s, pp); squeezed = 1; count = 1; return get(0); }
         return get(count++);
     }
 };
 
 template <int F> __device__ __forceinline__ fe_t load_fe(const uint32_t *p) { fe_t r; for (int i = 0; i < 8; ++i) r.v[i] = p[i]; return r; }
-__device__ __forceinline__ void store_fe(uint32_t *p, const fe_t &a) { if ((threadIdx.x & 3u) == 0) for (int i = 0; i < 8; ++i) p[i] = a.v[i]; }
-__device__ __forceinline__ void store_pt(affine_t *p, const affine_t &a) { if ((threadIdx.x & 3u) == 0) *p = a; }
+template <int LANES> __device__ __forceinline__ bool coop_writer() { return (threadIdx.x & (LANES - 1)) == 0; }
+template <int LANES> __device__ __forceinline__ void store_fe(uint32_t *p, const fe_t &a) { if (coop_writer<LANES>()) for (int i = 0; i < 8; ++i) p[i] = a.v[i]; }
+template <int LANES> __device__ __forceinline__ void store_pt(affine_t *p, const affine_t &a) { if (coop_writer<LANES>()) *p = a; }
 
 
 // ---------------------------------------------------------------- generic Fq-sponge transcript ("tape")
@@ -53,7 +54,7 @@ enum : uint8_t {
     TAPE_CHALLENGE_ENDO_OWN = 7, // squeeze 128 bits -> to_field in the sponge's OWN field (kimchi `DefaultFrSponge::challenge`:
                                // run the tape on the curve whose BASE field is the proof's scalar field)      (32 B out)
 };
-template <int CURVE>
+template <int CURVE, int LANES>
 __global__ void __launch_bounds__(64)
 sponge_tape_kernel(uint32_t batch, uint32_t tape_len, uint32_t in_stride_words, uint32_t out_stride_words, FieldK kb, FieldK ks,
                    const PoseidonParams *__restrict__ pp, const uint8_t *__restrict__ tape, const uint32_t *__restrict__ init_state /* b*24 or null */,
@@ -61,9 +62,9 @@ sponge_tape_kernel(uint32_t batch, uint32_t tape_len, uint32_t in_stride_words, 
                    uint32_t *__restrict__ final_state /* b*24 or null */, uint32_t *__restrict__ final_pos /* b*2 or null */) {
     constexpr int FB = (CURVE == CURVE_PALLAS) ? FIELD_FP : FIELD_FQ;
     constexpr int FS = (CURVE == CURVE_PALLAS) ? FIELD_FQ : FIELD_FP;
-    const uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) >> 2, q = threadIdx.x & 3u, qq = q < 3 ? q : 2;
-    if (b >= batch) return;
-    DevSponge<FB> sp; sp.pp = pp; sp.squeezed = 0; sp.count = 0; sp.s = fe_zero();
+    const uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) / LANES, l = threadIdx.x & (LANES - 1), qq = coop_elem<LANES>();
+    if (b >= batch) return;                                   // whole lane groups leave together
+    DevSponge<FB, LANES> sp; sp.pp = pp; sp.squeezed = 0; sp.count = 0; sp.s = fe_zero();
     if (init_state) { sp.s = fe_to_mont<FB>(load_fe<FB>(init_state + (size_t)b * 24 + qq * 8), kb.r2); sp.squeezed = (int)init_pos[2 * b]; sp.count = (int)init_pos[2 * b + 1]; }
     const uint32_t *in = inputs + (size_t)b * in_stride_words;
     uint32_t *out = outputs + (size_t)b * out_stride_words;
@@ -93,11 +94,12 @@ sponge_tape_kernel(uint32_t batch, uint32_t tape_len, uint32_t in_stride_words, 
                 for (int i = 7; i >= 0; --i) { uint32_t m = modulus_limb<FS>(i); if (sq.v[i] != m) { fits = sq.v[i] < m; break; } }
                 if (fits) o = sq;
             }
-            store_fe(out, o); out += 8;
+            store_fe<LANES>(out, o); out += 8;
         }
     }
-    if (final_state && q < 3) { fe_t w = fe_from_mont<FB>(sp.s); for (int i = 0; i < 8; ++i) final_state[(size_t)b * 24 + q * 8 + i] = w.v[i]; }
-    if (final_pos && q == 0) { final_pos[2 * b] = (uint32_t)sp.squeezed; final_pos[2 * b + 1] = (uint32_t)sp.count; }
+    const bool owner = LANES == 8 ? (l < 6 && !(l & 1u)) : (l < 3);      // one lane per state element writes it
+    if (final_state && owner) { fe_t w = fe_from_mont<FB>(sp.s); for (int i = 0; i < 8; ++i) final_state[(size_t)b * 24 + qq * 8 + i] = w.v[i]; }
+    if (final_pos && l == 0) { final_pos[2 * b] = (uint32_t)sp.squeezed; final_pos[2 * b + 1] = (uint32_t)sp.count; }
 }
 
 struct IpaShape { uint32_t batch, k, npts, ncomms, per; };   // per = 2k + ncomms + 4 points per proof
@@ -106,9 +108,10 @@ template <int FB> __device__ __forceinline__ affine_t load_point_mont(const uint
     affine_t a; a.x = fe_to_mont<FB>(load_fe<FB>(p), kb.r2); a.y = fe_to_mont<FB>(load_fe<FB>(p + 8), kb.r2); return a;
 }
 
-// One DPP quad per proof: the Fq-sponge runs lane-cooperatively (7 dependent products per Poseidon round instead of 21),
-// all other (scalar-field) work is computed redundantly by the four lanes, lane 0 writes.  CURVE fixes (FB, FS).
-template <int CURVE>
+// One lane group (4 or 8 lanes) per proof: the Fq-sponge runs lane-cooperatively (6.3 / 4.65 dependent product latencies per
+// Poseidon round instead of 21), all other (scalar-field) work is computed redundantly by the lanes, lane 0 writes.
+// CURVE fixes (FB, FS).
+template <int CURVE, int LANES>
 __global__ void __launch_bounds__(64)
 ipa_prepare_kernel(IpaShape sh, FieldK kb, FieldK ks, const PoseidonParams *__restrict__ pp,
                    const uint32_t *__restrict__ sponge_state /* b*24 */, const uint32_t *__restrict__ sponge_pos /* b*2 */,
@@ -123,15 +126,13 @@ ipa_prepare_kernel(IpaShape sh, FieldK kb, FieldK ks, const PoseidonParams *__re
                    uint32_t *__restrict__ out_chals /* b*k*8 canonical */, uint32_t *__restrict__ out_sigma /* b*8 canonical */) {
     constexpr int FB = (CURVE == CURVE_PALLAS) ? FIELD_FP : FIELD_FQ;
     constexpr int FS = (CURVE == CURVE_PALLAS) ? FIELD_FQ : FIELD_FP;
-    const uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) >> 2;
-    if (b >= sh.batch) return;                                // whole quads leave together
+    const uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) / LANES;
+    if (b >= sh.batch) return;                                // whole lane groups leave together
     const uint32_t k = sh.k;
-    const bool writer = (threadIdx.x & 3u) == 0;
 
     // ---- Fq-sponge transcript (base field)
-    DevSponge<FB> sp; sp.pp = pp; sp.squeezed = 0; sp.count = 0;
-    { const uint32_t q = threadIdx.x & 3u, qq = q < 3 ? q : 2;
-      sp.s = fe_to_mont<FB>(load_fe<FB>(sponge_state + (size_t)b * 24 + qq * 8), kb.r2); }
+    DevSponge<FB, LANES> sp; sp.pp = pp; sp.squeezed = 0; sp.count = 0;
+    sp.s = fe_to_mont<FB>(load_fe<FB>(sponge_state + (size_t)b * 24 + coop_elem<LANES>() * 8), kb.r2);
     sp.squeezed = (int)sponge_pos[2 * b]; sp.count = (int)sponge_pos[2 * b + 1];
     const fe_t cip_m = fe_to_mont<FS>(load_fe<FS>(cip + (size_t)b * 8), ks.r2);
     {   // absorb_fr(shift_scalar(cip))
@@ -178,8 +179,8 @@ ipa_prepare_kernel(IpaShape sh, FieldK kb, FieldK ks, const PoseidonParams *__re
         uint64_t lo = (uint64_t)sq.v[0] | ((uint64_t)sq.v[1] << 32), hi = (uint64_t)sq.v[2] | ((uint64_t)sq.v[3] << 32);
         fe_t chal = challenge_to_field<FS>(lo, hi, ks);
         chal_m[j] = chal;                                     // Montgomery copy for the scalar work below
-        store_fe(out_chals + ((size_t)b * k + j) * 8, fe_from_mont<FS>(chal));
-        store_pt(&pts[4 + 2 * j], L); store_pt(&pts[5 + 2 * j], R);
+        store_fe<LANES>(out_chals + ((size_t)b * k + j) * 8, fe_from_mont<FS>(chal));
+        store_pt<LANES>(&pts[4 + 2 * j], L); store_pt<LANES>(&pts[5 + 2 * j], R);
     }
     const affine_t D = load_point_mont<FB>(delta + (size_t)b * 16, kb);
     sp.absorb(D.x); sp.absorb(D.y);
@@ -208,12 +209,12 @@ ipa_prepare_kernel(IpaShape sh, FieldK kb, FieldK ks, const PoseidonParams *__re
     const fe_t neg_rho = fe_neg<FS>(rho);
     const fe_t rho_c = fe_mul<FS>(rho, c);
 
-    store_pt(&pts[0], *srs_h);               store_fe(scs + 0 * 8, fe_from_mont<FS>(fe_mul<FS>(neg_rho, z2m)));
-    store_pt(&pts[1], load_point_mont<FB>(sg + (size_t)b * 16, kb));
-    store_fe(scs + 1 * 8, fe_from_mont<FS>(fe_sub<FS>(fe_mul<FS>(neg_rho, z1m), sigma)));
-    store_pt(&pts[2], U);
-    store_fe(scs + 2 * 8, fe_from_mont<FS>(fe_add<FS>(fe_mul<FS>(fe_mul<FS>(neg_rho, z1m), b0), fe_mul<FS>(rho_c, cip_m))));
-    store_pt(&pts[3], D);                    store_fe(scs + 3 * 8, fe_from_mont<FS>(rho));
+    store_pt<LANES>(&pts[0], *srs_h);               store_fe<LANES>(scs + 0 * 8, fe_from_mont<FS>(fe_mul<FS>(neg_rho, z2m)));
+    store_pt<LANES>(&pts[1], load_point_mont<FB>(sg + (size_t)b * 16, kb));
+    store_fe<LANES>(scs + 1 * 8, fe_from_mont<FS>(fe_sub<FS>(fe_mul<FS>(neg_rho, z1m), sigma)));
+    store_pt<LANES>(&pts[2], U);
+    store_fe<LANES>(scs + 2 * 8, fe_from_mont<FS>(fe_add<FS>(fe_mul<FS>(fe_mul<FS>(neg_rho, z1m), b0), fe_mul<FS>(rho_c, cip_m))));
+    store_pt<LANES>(&pts[3], D);                    store_fe<LANES>(scs + 3 * 8, fe_from_mont<FS>(rho));
     {   // chal^-1 for all rounds with ONE inversion (Montgomery's trick, as upstream's ark_ff::batch_inversion)
         fe_t pre[20]; fe_t run = ks.one;
         for (uint32_t j = 0; j < k; ++j) { pre[j] = run; run = fe_mul<FS>(run, chal_m[j]); }
@@ -221,18 +222,18 @@ ipa_prepare_kernel(IpaShape sh, FieldK kb, FieldK ks, const PoseidonParams *__re
         for (int j = (int)k - 1; j >= 0; --j) {
             const fe_t ch_inv = fe_mul<FS>(inv_run, pre[j]);
             inv_run = fe_mul<FS>(inv_run, chal_m[j]);
-            store_fe(scs + (size_t)(4 + 2 * j) * 8, fe_from_mont<FS>(fe_mul<FS>(rho_c, ch_inv)));
-            store_fe(scs + (size_t)(5 + 2 * j) * 8, fe_from_mont<FS>(fe_mul<FS>(rho_c, chal_m[j])));
+            store_fe<LANES>(scs + (size_t)(4 + 2 * j) * 8, fe_from_mont<FS>(fe_mul<FS>(rho_c, ch_inv)));
+            store_fe<LANES>(scs + (size_t)(5 + 2 * j) * 8, fe_from_mont<FS>(fe_mul<FS>(rho_c, chal_m[j])));
         }
     }
     const fe_t xi = fe_to_mont<FS>(load_fe<FS>(polyscale + (size_t)b * 8), ks.r2);
     fe_t xi_i = ks.one;
     for (uint32_t i = 0; i < sh.ncomms; ++i) {
-        store_pt(&pts[4 + 2 * k + i], load_point_mont<FB>(comms + ((size_t)b * sh.ncomms + i) * 16, kb));
-        store_fe(scs + (size_t)(4 + 2 * k + i) * 8, fe_from_mont<FS>(fe_mul<FS>(rho_c, xi_i)));
+        store_pt<LANES>(&pts[4 + 2 * k + i], load_point_mont<FB>(comms + ((size_t)b * sh.ncomms + i) * 16, kb));
+        store_fe<LANES>(scs + (size_t)(4 + 2 * k + i) * 8, fe_from_mont<FS>(fe_mul<FS>(rho_c, xi_i)));
         xi_i = fe_mul<FS>(xi_i, xi);
     }
-    store_fe(out_sigma + (size_t)b * 8, fe_from_mont<FS>(sigma));
+    store_fe<LANES>(out_sigma + (size_t)b * 8, fe_from_mont<FS>(sigma));
 }
 
 // verdict[0] = 1 iff  A + sign * B == identity  (sign = +1: A == -B ; sign = -1: A == B)
@@ -449,12 +450,14 @@ extern "C" int mina_ipa_batch_check(mina_ctx *c, int curve, size_t batch, const 
     if ((rc = c->L->ipa_xyzz_b.ensure(sizeof(xyzz_t)))) return rc;
     if ((rc = c->L->ipa_verdict.ensure(4))) return rc;
     const PoseidonParams *pp = c->pparams[FB].as<PoseidonParams>();
-#define IPA_PREP(CV)                                                                                                          \
-    mb::ipa_prepare_kernel<CV><<<cdiv(batch * 4, 64), 64, 0, c->L->stream>>>(                                                         \
+#define IPA_PREP(CV, LN)                                                                                                      \
+    mb::ipa_prepare_kernel<CV, LN><<<cdiv(batch * LN, 64), 64, 0, c->L->stream>>>(                                                    \
         sh, c->fk[FB], c->fk[FS], pp, W(o_state), W(o_pos), W(o_cip), W(o_lr), W(o_delta), W(o_sg), W(o_z1), W(o_z2), W(o_pts), W(o_r), \
         W(o_xi), W(o_comms), W(o_rb), W(o_sb), s.h.as<affine_t>(), c->L->ipa_points.as<affine_t>(), c->L->ipa_scalars.as<uint32_t>(), \
         c->L->ipa_chals.as<uint32_t>(), c->L->ipa_sigma.as<uint32_t>())
-    if (curve == CURVE_PALLAS) IPA_PREP(CURVE_PALLAS); else IPA_PREP(CURVE_VESTA);
+    // latency-bound batches: 8 lanes per transcript; larger ones 4
+    if (batch <= COOP8_MAX_GROUPS) { if (curve == CURVE_PALLAS) IPA_PREP(CURVE_PALLAS, 8); else IPA_PREP(CURVE_VESTA, 8); }
+    else { if (curve == CURVE_PALLAS) IPA_PREP(CURVE_PALLAS, 4); else IPA_PREP(CURVE_VESTA, 4); }
 #undef IPA_PREP
     HIPC(hipGetLastError());
     if ((rc = mb_bpoly_fold(c, FS, k, batch, c->L->ipa_chals.as<uint32_t>(), c->L->ipa_sigma.as<uint32_t>(), c->L->ipa_folded.as<uint32_t>()))) return rc;
@@ -501,11 +504,12 @@ extern "C" int mina_fq_sponge_run(mina_ctx *c, int curve, size_t batch, const ui
     if ((rc = L.ipa_chals.ensure(batch * 8))) return rc;
     const PoseidonParams *pp = c->pparams[FB].as<PoseidonParams>();
     const int FS = scalar_field_of(curve);
-#define RUN_TAPE(CV)                                                                                                                       \
-    mb::sponge_tape_kernel<CV><<<cdiv(batch * 4, 64), 64, 0, L.stream>>>((uint32_t)batch, (uint32_t)tape_len, (uint32_t)in_words, (uint32_t)out_words, \
+#define RUN_TAPE(CV, LN)                                                                                                                   \
+    mb::sponge_tape_kernel<CV, LN><<<cdiv(batch * LN, 64), 64, 0, L.stream>>>((uint32_t)batch, (uint32_t)tape_len, (uint32_t)in_words, (uint32_t)out_words, \
         c->fk[FB], c->fk[FS], pp, L.ipa_in_a.as<uint8_t>(), init_state ? L.ipa_in_c.as<uint32_t>() : nullptr, init_state ? L.ipa_sigma.as<uint32_t>() : nullptr, \
         L.ipa_in_b.as<uint32_t>(), L.ipa_scalars.as<uint32_t>(), L.ipa_points.as<uint32_t>(), L.ipa_chals.as<uint32_t>())
-    if (curve == CURVE_PALLAS) RUN_TAPE(CURVE_PALLAS); else RUN_TAPE(CURVE_VESTA);
+    if (batch <= COOP8_MAX_GROUPS) { if (curve == CURVE_PALLAS) RUN_TAPE(CURVE_PALLAS, 8); else RUN_TAPE(CURVE_VESTA, 8); }
+    else { if (curve == CURVE_PALLAS) RUN_TAPE(CURVE_PALLAS, 4); else RUN_TAPE(CURVE_VESTA, 4); }
 #undef RUN_TAPE
     HIPC(hipGetLastError());
     if (final_state) HIPC(hipMemcpyAsync(final_state, L.ipa_points.p, batch * 96, hipMemcpyDeviceToHost, L.stream));

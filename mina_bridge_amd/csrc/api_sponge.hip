@@ -155,8 +155,11 @@ extern "C" int mina_poseidon_hash(mina_ctx *c, int field, size_t n, size_t len, 
     if ((rc = h2d(c, c->L->tmp_a, inputs, n * len * 32))) return rc;
     if ((rc = c->L->tmp_c.ensure(n * 32))) return rc;
     // below ~64k sponges the chip is not full with one lane per sponge: use the 4-lane cooperative form (3x shorter chain)
-    if (n < 65536) {
-        DISPATCH_FIELD(field, { poseidon_hash_quad_kernel<F_><<<cdiv(n * 4, 256), 256, 0, c->L->stream>>>((uint32_t)n, (uint32_t)len, c->fk[F_], c->pparams[field].as<PoseidonParams>(), c->L->tmp_a.as<uint32_t>(), c->L->tmp_c.as<uint32_t>()); });
+    // and below ~8k the 8-lane form (a quarter shorter chain again, 1.5x the issue slots)
+    if (n <= COOP8_MAX_GROUPS) {
+        DISPATCH_FIELD(field, { poseidon_hash_coop_kernel<F_, 8><<<cdiv(n * 8, 256), 256, 0, c->L->stream>>>((uint32_t)n, (uint32_t)len, c->fk[F_], c->pparams[field].as<PoseidonParams>(), c->L->tmp_a.as<uint32_t>(), c->L->tmp_c.as<uint32_t>()); });
+    } else if (n < 65536) {
+        DISPATCH_FIELD(field, { poseidon_hash_coop_kernel<F_, 4><<<cdiv(n * 4, 256), 256, 0, c->L->stream>>>((uint32_t)n, (uint32_t)len, c->fk[F_], c->pparams[field].as<PoseidonParams>(), c->L->tmp_a.as<uint32_t>(), c->L->tmp_c.as<uint32_t>()); });
     } else {
         DISPATCH_FIELD(field, { poseidon_hash_kernel<F_><<<cdiv(n, 256), 256, 0, c->L->stream>>>((uint32_t)n, (uint32_t)len, c->fk[F_], c->pparams[field].as<PoseidonParams>(), c->L->tmp_a.as<uint32_t>(), c->L->tmp_c.as<uint32_t>()); });
     }
@@ -213,10 +216,17 @@ extern "C" int mina_merkle_roots(mina_ctx *c, int field, size_t n, uint32_t dept
     if ((rc = h2d(c, c->L->tmp_b, siblings, n * depth * 32))) return rc;
     if ((rc = h2d(c, c->L->tmp_d, dirs, n * depth))) return rc;
     if ((rc = c->L->tmp_c.ensure(n * 32))) return rc;
-    DISPATCH_FIELD(field, {
-        merkle_fold_quad_kernel<F_><<<cdiv(n * 4, 256), 256, 0, c->L->stream>>>((uint32_t)n, depth, c->fk[F_], c->pparams[field].as<PoseidonParams>(),
-            c->merkle_salts[field].as<fe_t>(), c->L->tmp_a.as<uint32_t>(), c->L->tmp_b.as<uint32_t>(), c->L->tmp_d.as<uint8_t>(), c->L->tmp_c.as<uint32_t>());
-    });
+    if (n <= COOP8_MAX_GROUPS) {                                 // latency-bound batch: 8 lanes per path
+        DISPATCH_FIELD(field, {
+            merkle_fold_coop_kernel<F_, 8><<<cdiv(n * 8, 256), 256, 0, c->L->stream>>>((uint32_t)n, depth, c->fk[F_], c->pparams[field].as<PoseidonParams>(),
+                c->merkle_salts[field].as<fe_t>(), c->L->tmp_a.as<uint32_t>(), c->L->tmp_b.as<uint32_t>(), c->L->tmp_d.as<uint8_t>(), c->L->tmp_c.as<uint32_t>());
+        });
+    } else {
+        DISPATCH_FIELD(field, {
+            merkle_fold_coop_kernel<F_, 4><<<cdiv(n * 4, 256), 256, 0, c->L->stream>>>((uint32_t)n, depth, c->fk[F_], c->pparams[field].as<PoseidonParams>(),
+                c->merkle_salts[field].as<fe_t>(), c->L->tmp_a.as<uint32_t>(), c->L->tmp_b.as<uint32_t>(), c->L->tmp_d.as<uint8_t>(), c->L->tmp_c.as<uint32_t>());
+        });
+    }
     return d2h_sync(c, roots_out, c->L->tmp_c, n * 32);
 }
 

@@ -96,6 +96,10 @@ struct mina_ctx {
     void next_lane() { L = &lanes[rr++ % (unsigned)nlanes]; }
 };
 
+// lane-cooperative Poseidon: batches of at most this many sponges use 8 lanes each (shorter dependency chain, 1.5x the
+// issue slots), larger ones 4 lanes, chip-filling ones 1 lane
+static constexpr size_t COOP8_MAX_GROUPS = 8192;
+
 static inline int base_field_of(int curve) { return curve == CURVE_PALLAS ? FIELD_FP : FIELD_FQ; }
 static inline int scalar_field_of(int curve) { return curve == CURVE_PALLAS ? FIELD_FQ : FIELD_FP; }
 static inline bool bad_field(int f) { return f != 0 && f != 1; }

@@ -189,32 +189,82 @@ __device__ __forceinline__ void poseidon_permute_quad(fe_t &s, const PoseidonPar
     }
 }
 
-// a16: Merkle-path fold.  One quad per path.  node <- H_height(left, right) with the per-height salted initial state
+// Eight lanes per sponge (half a DPP row): the pair of lanes (2e, 2e+1) owns state element e (lanes 6, 7 mirror e = 2).
+// x^7 takes 3 dependent products instead of 4 (x2; then x4 on the even lane and x3 on the odd lane, swapped inside the
+// pair; then x4 * x3) and an MDS row 1.65 instead of 2.3 (even lane: a two-term dot product, odd lane: the third product,
+// as a dot product with a zero term so that both lanes run the same instructions; the halves are swapped and added):
+// 4.65 product latencies per round against 6.3 for the quad form, bit-identical state.  Costs 1.5x the issue slots per
+// permutation, so only for batches that leave the chip latency-bound (host picks the form).
+__device__ __forceinline__ fe_t pair_swap(const fe_t &a) {
+    fe_t r = a;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)a.v[i], 0xB1, 0xf, 0xf, true);   // quad_perm:[1,0,3,2]
+#endif
+    return r;
+}
+template <int K> __device__ __forceinline__ fe_t oct_bcast(const fe_t &a) {            // lane K of every octet -> its 8 lanes
+    fe_t r;
+    const int src = (int)((threadIdx.x & 63u) & ~7u) | K;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = (uint32_t)__shfl((int)a.v[i], src, 64);
+    return r;
+}
+template <int F>
+__device__ __forceinline__ void poseidon_permute_oct(fe_t &s, const PoseidonParams *__restrict__ pp) {
+    const uint32_t o = threadIdx.x & 7u, e = (o >> 1) < 3 ? (o >> 1) : 2;
+    const bool odd = o & 1u;
+    const fe_t zero = fe_zero();
+    const fe_t ma = odd ? pp->mds[e][2] : pp->mds[e][0], mb = odd ? zero : pp->mds[e][1];
+#pragma unroll 1
+    for (int r = 0; r < 55; ++r) {
+        const fe_t x2 = fe_sqr<F>(s);
+        const fe_t y = fe_mul<F>(x2, odd ? s : x2);                  // even: x^4, odd: x^3
+        const fe_t t = fe_mul<F>(y, pair_swap(y));                   // x^7 on both lanes of the pair
+        const fe_t t0 = oct_bcast<0>(t), t1 = oct_bcast<2>(t), t2 = oct_bcast<4>(t);
+        const fe_t u = fe_dot2<F>(ma, odd ? t2 : t0, mb, t1);        // even: m0 t0 + m1 t1, odd: m2 t2 (+ 0 * t1)
+        s = fe_add<F>(fe_add<F>(u, pair_swap(u)), pp->rc[r][e]);
+    }
+}
+// LANES-lane cooperative permutation / element ownership, LANES = 4 (quad) or 8 (octet)
+template <int F, int LANES> __device__ __forceinline__ void poseidon_permute_coop(fe_t &s, const PoseidonParams *__restrict__ pp) {
+    if (LANES == 8) poseidon_permute_oct<F>(s, pp); else poseidon_permute_quad<F>(s, pp);
+}
+template <int LANES> __device__ __forceinline__ uint32_t coop_elem() {                 // state element this lane owns
+    const uint32_t l = threadIdx.x & (LANES - 1), e = LANES == 8 ? (l >> 1) : l;
+    return e < 3 ? e : 2;
+}
+template <int LANES> __device__ __forceinline__ fe_t coop_get(const fe_t &s, int pos) { // element `pos` -> all lanes of the group
+    if (LANES == 8) return pos == 0 ? oct_bcast<0>(s) : (pos == 1 ? oct_bcast<2>(s) : oct_bcast<4>(s));
+    return pos == 0 ? quad_bcast<0>(s) : (pos == 1 ? quad_bcast<1>(s) : quad_bcast<2>(s));
+}
+
+// a16: Merkle-path fold.  One lane group (4 or 8 lanes) per path.  node <- H_height(left, right) with the per-height salted initial state
 // (mina `hash_with_kimchi(MERKLE_PARAM[height], [l, r])`): state = salt[height]; state[0] += l; state[1] += r; permute;
 // node = state[0].  dir 0 = MerkleNode::Left(h): node is the left input, h the right one; dir 1 = MerkleNode::Right(h).
-template <int F>
+template <int F, int LANES>
 __global__ void __launch_bounds__(256)
-merkle_fold_quad_kernel(uint32_t n, uint32_t depth, FieldK fk, const PoseidonParams *__restrict__ pp,
+merkle_fold_coop_kernel(uint32_t n, uint32_t depth, FieldK fk, const PoseidonParams *__restrict__ pp,
                         const fe_t *__restrict__ salts /* depth x 3, Montgomery */, const uint32_t *__restrict__ leaves,
                         const uint32_t *__restrict__ siblings /* n*depth*8 */, const uint8_t *__restrict__ dirs,
                         uint32_t *__restrict__ roots) {
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t path = gid >> 2, q = gid & 3;
+    const uint32_t path = gid / LANES, e = coop_elem<LANES>();
     const bool live = path < n;
-    const uint32_t pidx = live ? path : 0;                     // dead quads shadow path 0 (whole wave runs the DPP moves)
+    const uint32_t pidx = live ? path : 0;                     // dead groups shadow path 0 (whole wave runs the cross-lane moves)
     fe_t node; for (int i = 0; i < 8; ++i) node.v[i] = leaves[(size_t)pidx * 8 + i];
     node = fe_to_mont<F>(node, fk.r2);
     for (uint32_t h = 0; h < depth; ++h) {
         fe_t sib; for (int i = 0; i < 8; ++i) sib.v[i] = siblings[((size_t)pidx * depth + h) * 8 + i];
         sib = fe_to_mont<F>(sib, fk.r2);
         const bool node_is_left = dirs[(size_t)pidx * depth + h] == 0;
-        fe_t st = salts[(size_t)h * 3 + (q < 3 ? q : 2)];
-        if (q == 0) st = fe_add<F>(st, node_is_left ? node : sib);
-        if (q == 1) st = fe_add<F>(st, node_is_left ? sib : node);
-        poseidon_permute_quad<F>(st, pp);
-        node = quad_bcast<0>(st);
+        fe_t st = salts[(size_t)h * 3 + e];
+        if (e == 0) st = fe_add<F>(st, node_is_left ? node : sib);
+        if (e == 1) st = fe_add<F>(st, node_is_left ? sib : node);
+        poseidon_permute_coop<F, LANES>(st, pp);
+        node = coop_get<LANES>(st, 0);
     }
-    if (live && q == 0) { fe_t o = fe_from_mont<F>(node); for (int i = 0; i < 8; ++i) roots[(size_t)path * 8 + i] = o.v[i]; }
+    if (live && (gid % LANES) == 0) { fe_t o = fe_from_mont<F>(node); for (int i = 0; i < 8; ++i) roots[(size_t)path * 8 + i] = o.v[i]; }
 }
 
 // salt[h] = state after absorbing the prefix element of height h into the zero state and permuting
@@ -230,27 +280,28 @@ __global__ void merkle_salt_kernel(uint32_t depth, FieldK fk, const PoseidonPara
     for (int j = 0; j < 3; ++j) salts[(size_t)h * 3 + j] = s[j];
 }
 
-// n independent sponges, quad-cooperative: absorb len elements, squeeze one (same contract as poseidon_hash_kernel)
-template <int F>
+// n independent sponges, lane-cooperative (4 or 8 lanes each): absorb len elements, squeeze one (same contract as poseidon_hash_kernel)
+template <int F, int LANES>
 __global__ void __launch_bounds__(256)
-poseidon_hash_quad_kernel(uint32_t n, uint32_t len, FieldK fk, const PoseidonParams *__restrict__ pp,
+poseidon_hash_coop_kernel(uint32_t n, uint32_t len, FieldK fk, const PoseidonParams *__restrict__ pp,
                           const uint32_t *__restrict__ inputs, uint32_t *__restrict__ out_words) {
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t sp = gid >> 2, q = gid & 3;
+    const uint32_t sp = gid / LANES, e = coop_elem<LANES>();
     const bool live = sp < n;
     const uint32_t idx = live ? sp : 0;
     fe_t s = fe_zero();
     uint32_t count = 0;
-    for (uint32_t e = 0; e < len; ++e) {
-        if (count == 2) { poseidon_permute_quad<F>(s, pp); count = 0; }
-        if (q == count) {
-            fe_t w; for (int i = 0; i < 8; ++i) w.v[i] = inputs[((size_t)idx * len + e) * 8 + i];
+    for (uint32_t el = 0; el < len; ++el) {
+        if (count == 2) { poseidon_permute_coop<F, LANES>(s, pp); count = 0; }
+        if (e == count) {                                                 // count is 0 or 1: the lane(s) owning that element
+            fe_t w; for (int i = 0; i < 8; ++i) w.v[i] = inputs[((size_t)idx * len + el) * 8 + i];
             s = fe_add<F>(s, fe_to_mont<F>(w, fk.r2));
         }
         ++count;
     }
-    poseidon_permute_quad<F>(s, pp);
-    if (live && q == 0) { fe_t w = fe_from_mont<F>(s); for (int i = 0; i < 8; ++i) out_words[(size_t)sp * 8 + i] = w.v[i]; }
+    poseidon_permute_coop<F, LANES>(s, pp);
+    s = coop_get<LANES>(s, 0);
+    if (live && (gid % LANES) == 0) { fe_t w = fe_from_mont<F>(s); for (int i = 0; i < 8; ++i) out_words[(size_t)sp * 8 + i] = w.v[i]; }
 }
 #endif
 
