@@ -37,6 +37,8 @@ template <int F> static FieldK make_field_consts() {
     k.bw_inv3 = fe_inv<F>(three, k);
     fe_t w = fe_pow<F>(k.five, fe_div3(pm1), k.one);
     k.endo = fe_sqr<F>(w);
+    k.inv2 = fe_inv<F>(two, k);
+    k.two255 = k.one; for (int i = 0; i < 255; ++i) k.two255 = fe_dbl<F>(k.two255);
     return k;
 }
 

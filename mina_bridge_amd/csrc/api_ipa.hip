@@ -136,7 +136,7 @@ ipa_prepare_kernel(IpaShape sh, FieldK kb, FieldK ks, const PoseidonParams *__re
     sp.squeezed = (int)sponge_pos[2 * b]; sp.count = (int)sponge_pos[2 * b + 1];
     const fe_t cip_m = fe_to_mont<FS>(load_fe<FS>(cip + (size_t)b * 8), ks.r2);
     {   // absorb_fr(shift_scalar(cip))
-        fe_t two255 = ks.one; for (int i = 0; i < 255; ++i) two255 = fe_dbl<FS>(two255);
+        const fe_t two255 = ks.two255;
         if (CURVE == CURVE_PALLAS) {
             // scalar modulus > base modulus: x = cip - 2^255 ; absorb (x >> 1), then (x & 1)
             fe_t x = fe_from_mont<FS>(fe_sub<FS>(cip_m, two255));
@@ -146,8 +146,7 @@ ipa_prepare_kernel(IpaShape sh, FieldK kb, FieldK ks, const PoseidonParams *__re
             sp.absorb(fe_to_mont<FB>(lowbit, kb.r2));
         } else {
             // scalar modulus < base modulus: x = (cip - (2^255 + 1)) / 2, absorbed as one base-field element
-            fe_t inv2 = fe_inv<FS>(fe_dbl<FS>(ks.one), ks);
-            fe_t x = fe_from_mont<FS>(fe_mul<FS>(fe_sub<FS>(cip_m, fe_add<FS>(two255, ks.one)), inv2));
+            fe_t x = fe_from_mont<FS>(fe_mul<FS>(fe_sub<FS>(cip_m, fe_add<FS>(two255, ks.one)), ks.inv2));
             sp.absorb(fe_to_mont<FB>(x, kb.r2));
         }
     }

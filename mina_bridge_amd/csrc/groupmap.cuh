@@ -19,6 +19,7 @@ struct FieldK {
     fe_t bw_fu, bw_s, bw_c, bw_inv3;   // group map: f(u)=6, sqrt(-3), (sqrt(-3)-1)/2, 1/3
     fe_t endo;                   // endo_r of the curve whose SCALAR field this is: (5^((p-1)/3))^2
     fe_t half;                   // (p-1)/2 plain, for the y-sign flag of the point codec
+    fe_t two255, inv2;           // 2^255 and 1/2, Montgomery (shift_scalar of the Fq-sponge's absorb_fr)
 };
 
 template <int F> MB_HD fe_t fe_inv(const fe_t &a, const FieldK &k) { return fe_pow<F>(a, k.pm2, k.one); }
