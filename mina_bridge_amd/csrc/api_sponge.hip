@@ -17,7 +17,7 @@ static int run_bpoly_fold(mina_ctx *c, uint32_t k, size_t batch, const uint32_t 
     int rc;
     if (batch == 1 && !d_weights) {                              // b_poly_coefficients of one proof: one launch
         ProfScope ps_(c, PS_BPOLY_FOLD);
-        bpoly_single_kernel<F><<<cdiv(nl, 256) * nh, nl < 256 ? (nl < 64 ? 64 : nl) : 256, 0, c->L->stream>>>(sh, c->fk[F], d_chals, nullptr, d_out);
+        bpoly_single_kernel<F><<<cdiv(nl, 256) * cdiv(nh, BP1_HT), nl < 256 ? (nl < 64 ? 64 : nl) : 256, 0, c->L->stream>>>(sh, c->fk[F], d_chals, nullptr, d_out);
         HIPC(hipGetLastError());
         return MINA_OK;
     }
@@ -38,7 +38,7 @@ int mb_bpoly_single_from_prechallenges(mina_ctx *c, int field, uint32_t k, const
         BpolyShape sh = bp_shape(k, 1);
         const uint32_t nl = 1u << sh.lb, nh = 1u << sh.hb;
         ProfScope ps_(c, PS_BPOLY_FOLD);
-        bpoly_single_kernel<F_><<<dim3(cdiv(nl, 256) * nh, count), nl < 256 ? (nl < 64 ? 64 : nl) : 256, 0, c->L->stream>>>(sh, c->fk[F_], nullptr, d_prechal, d_out);
+        bpoly_single_kernel<F_><<<dim3(cdiv(nl, 256) * cdiv(nh, BP1_HT), count), nl < 256 ? (nl < 64 ? 64 : nl) : 256, 0, c->L->stream>>>(sh, c->fk[F_], nullptr, d_prechal, d_out);
     });
     HIPC(hipGetLastError());
     return MINA_OK;

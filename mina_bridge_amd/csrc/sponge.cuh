@@ -323,21 +323,26 @@ template <int F> MB_HD fe_t challenge_to_field(uint64_t lo, uint64_t hi, const F
     return fe_add<F>(fe_mul<F>(fe_to_mont<F>(a, fk.r2), fk.endo), fe_to_mont<F>(b, fk.r2));
 }
 
-// Single proof, no weights: out[j] = L[lo] * H[hi] in ONE launch (the batch path above needs tables + fold + finish).
-// Block = one `hi`, lanes = `lo`s; every lane multiplies out its own L[lo] and the block's H[hi] (two independent
-// chains of <= 10 products).  Challenges come either as field elements (`chals`) or as the 128-bit prechallenges
-// (`prechal`, 4 words each), converted by the first k lanes of every block (ScalarChallenge::to_field).
+// Per proof, no weights: out[j] = L[lo] * H[hi] in ONE launch (the batch path above needs tables + fold + finish).
+// Block = BP1_HT consecutive `hi` values x the `lo`s of its lanes; grid.y = proof.  Every lane multiplies out its own
+// L[lo] (<= 10 products, Montgomery); BP1_HT lanes of the last wave multiply out the block's H[hi] and take them OUT of
+// Montgomery form, so that each output is a single product L * h (= l h, canonical) -- 1.5 products per coefficient
+// instead of 10 when every lane rebuilt both factors.  Challenges come either as field elements (`chals`) or as the
+// 128-bit prechallenges (`prechal`, 4 words each), converted by the first k lanes of every block (ScalarChallenge::to_field).
 #if defined(__HIPCC__)
+static constexpr uint32_t BP1_HT = 4;
 template <int F>
 __global__ void __launch_bounds__(256)
 bpoly_single_kernel(BpolyShape sh, FieldK fk, const uint32_t *__restrict__ chals, const uint32_t *__restrict__ prechal,
                     uint32_t *__restrict__ out_words) {
     __shared__ fe_t ch[20];
+    __shared__ fe_t hs[BP1_HT];
     if (chals) chals += (size_t)blockIdx.y * sh.k * 8;           // grid.y = proof
     if (prechal) prechal += (size_t)blockIdx.y * sh.k * 4;
     out_words += ((size_t)blockIdx.y << sh.k) * 8;
-    const uint32_t nl = 1u << sh.lb, lo_blocks = (nl + blockDim.x - 1) / blockDim.x;
-    const uint32_t hi = blockIdx.x / lo_blocks, lo = (blockIdx.x % lo_blocks) * blockDim.x + threadIdx.x;
+    const uint32_t nl = 1u << sh.lb, nh = 1u << sh.hb, lo_blocks = (nl + blockDim.x - 1) / blockDim.x;
+    const uint32_t ht = nh < BP1_HT ? nh : BP1_HT;
+    const uint32_t hi0 = (blockIdx.x / lo_blocks) * ht, lo = (blockIdx.x % lo_blocks) * blockDim.x + threadIdx.x;
     if (threadIdx.x < sh.k) {
         fe_t c;
         if (prechal) {
@@ -350,16 +355,23 @@ bpoly_single_kernel(BpolyShape sh, FieldK fk, const uint32_t *__restrict__ chals
         ch[threadIdx.x] = c;
     }
     __syncthreads();
-    if (lo >= nl) return;
-    fe_t l = fk.one, h = fk.one;
-    for (uint32_t q = 0; q < sh.hb || q < sh.lb; ++q) {          // bit q of lo uses chals[k-1-q], bit q of hi chals[k-1-lb-q]
-        if (q < sh.lb && ((lo >> q) & 1u)) l = fe_mul<F>(l, ch[sh.k - 1 - q]);
-        if (q < sh.hb && ((hi >> q) & 1u)) h = fe_mul<F>(h, ch[sh.k - 1 - sh.lb - q]);
+    const uint32_t hlane = blockDim.x - 1 - threadIdx.x;         // the LAST lanes of the block build the H values
+    if (hlane < ht) {
+        const uint32_t hi = hi0 + hlane;
+        fe_t h = fk.one;
+        for (uint32_t q = 0; q < sh.hb; ++q) if ((hi >> q) & 1u) h = fe_mul<F>(h, ch[sh.k - 1 - sh.lb - q]);   // bit q of hi: chals[k-1-lb-q]
+        hs[hlane] = fe_from_mont<F>(h);
     }
-    const fe_t r = fe_from_mont<F>(fe_mul<F>(l, h));
-    uint4 *o = reinterpret_cast<uint4 *>(out_words + ((size_t)hi * nl + lo) * 8);
-    o[0] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
-    o[1] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
+    fe_t l = fk.one;
+    if (lo < nl) for (uint32_t q = 0; q < sh.lb; ++q) if ((lo >> q) & 1u) l = fe_mul<F>(l, ch[sh.k - 1 - q]);  // bit q of lo: chals[k-1-q]
+    __syncthreads();
+    if (lo >= nl) return;
+    for (uint32_t t = 0; t < ht; ++t) {
+        const fe_t r = fe_mul<F>(l, hs[t]);                      // (l R)(h) R^-1 = l h, canonical
+        uint4 *o = reinterpret_cast<uint4 *>(out_words + ((size_t)(hi0 + t) * nl + lo) * 8);
+        o[0] = make_uint4(r.v[0], r.v[1], r.v[2], r.v[3]);
+        o[1] = make_uint4(r.v[4], r.v[5], r.v[6], r.v[7]);
+    }
 }
 #endif
 
