@@ -74,6 +74,12 @@ void *mina_ctx_stream(mina_ctx *ctx);
 /* Pipelining: the `_dev` entry points are issued round-robin over `lanes` internal streams (1..16, default 1),
  * each with its own workspace, so independent calls overlap on the GPU.  mina_ctx_synchronize waits for all. */
 int mina_ctx_set_pipeline(mina_ctx *ctx, int lanes);
+/* Device memory for the `_dev` entry points, for callers without a HIP binding of their own (the copies are synchronous;
+ * download first waits for everything queued on the context). */
+int mina_dev_malloc(mina_ctx *ctx, size_t bytes, void **out);
+int mina_dev_free(mina_ctx *ctx, void *p);
+int mina_dev_upload(mina_ctx *ctx, void *dst, const void *src, size_t bytes);
+int mina_dev_download(mina_ctx *ctx, void *dst, const void *src, size_t bytes);
 
 /* HIP-event stage timing on the context stream.  `stage_mask` has one bit per pipeline stage (0 = off,
  * -1 = all; bit 3 = the MSM bucket-accumulate kernel).  mina_prof_read synchronises and writes a JSON object

@@ -258,3 +258,33 @@ extern "C" int mina_selftest_group_law(mina_ctx *c, int curve, size_t n, const u
     for (size_t i = 0; i < n; ++i) same[i] = sm[i] ? 1 : 0;
     return MINA_OK;
 }
+
+// ------------------------------------------------------------------------------------------------
+// plain device-memory helpers for callers of the `_dev` entry points that have no HIP binding of their own
+extern "C" int mina_dev_malloc(mina_ctx *c, size_t bytes, void **out) {
+    if (!c || !out) return fail(MINA_ERR_ARG, "null argument");
+    *out = nullptr;
+    HIPC(hipSetDevice(c->device));
+    if (hipMalloc(out, bytes ? bytes : 4) != hipSuccess) return fail(MINA_ERR_HIP, "hipMalloc failed");
+    return MINA_OK;
+}
+extern "C" int mina_dev_free(mina_ctx *c, void *p) {
+    if (!c) return fail(MINA_ERR_ARG, "null argument");
+    HIPC(hipSetDevice(c->device));
+    if (p) HIPC(hipFree(p));
+    return MINA_OK;
+}
+// synchronous copies (they wait for the context's lanes first, so results of queued `_dev` calls are visible)
+extern "C" int mina_dev_upload(mina_ctx *c, void *dst, const void *src, size_t bytes) {
+    if (!c || (bytes && (!dst || !src))) return fail(MINA_ERR_ARG, "null argument");
+    HIPC(hipSetDevice(c->device));
+    if (bytes) HIPC(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return MINA_OK;
+}
+extern "C" int mina_dev_download(mina_ctx *c, void *dst, const void *src, size_t bytes) {
+    if (!c || (bytes && (!dst || !src))) return fail(MINA_ERR_ARG, "null argument");
+    int rc = mina_ctx_synchronize(c);
+    if (rc) return rc;
+    if (bytes) HIPC(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return MINA_OK;
+}

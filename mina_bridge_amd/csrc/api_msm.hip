@@ -99,12 +99,16 @@ static int run_msm(mina_ctx *c, const MsmShape &sh, const uint32_t *d_scalars, c
         // 2-D bucket reduction: C = 128 columns, R = NB / C rows (NB is a power of two in [128, 32768])
         const uint32_t C = 128, log2C = 7, R = sh.NB / C;
         SegSum rows, cols;
-        rows.nseg = R * sh.nsets; rows.per_set = R; rows.len = C; rows.seg_stride = C; rows.elem_stride = 1; rows.lanes = C / SEG_CHUNK;
+        const bool coop = c->nlanes == 1;                      // one MSM at a time: latency form; pipelined lanes: throughput form
+        const uint32_t chunk = coop ? SEG_CHUNK : 16, lpg = coop ? 4 : 1;
+        rows.nseg = R * sh.nsets; rows.per_set = R; rows.len = C; rows.seg_stride = C; rows.elem_stride = 1; rows.lanes = C / chunk;
         cols.nseg = C * sh.nsets; cols.per_set = C; cols.len = R; cols.seg_stride = 1; cols.elem_stride = C;
-        { uint32_t l = 1; while (l * SEG_CHUNK < R && l < 16) l <<= 1; cols.lanes = l; }   // quads per column, <= 16 (one wave)
-        const uint32_t threads_rows = rows.nseg * rows.lanes * 4, threads_cols = cols.nseg * cols.lanes * 4;   // 4 lanes per quad
+        { uint32_t l = 1; while (l * chunk < R && l < 16) l <<= 1; cols.lanes = l; }   // workers per column, <= 16 (one wave even in the quad form)
+        const uint32_t threads_rows = rows.nseg * rows.lanes * lpg, threads_cols = cols.nseg * cols.lanes * lpg;
         const uint32_t blocks = cdiv(threads_rows > threads_cols ? threads_rows : threads_cols, 256);
-        { ProfScope ps_(c, PS_REDUCE_A); msm_segsum_kernel<F><<<dim3(blocks, 2), 256, 0, st>>>(sh.NB, rows, cols, w.buckets.as<xyzz_t>(), w.red_r.as<xyzz_t>(), w.red_ws.as<xyzz_t>()); }
+        { ProfScope ps_(c, PS_REDUCE_A);
+          if (coop) msm_segsum_kernel<F, true><<<dim3(blocks, 2), 256, 0, st>>>(sh.NB, rows, cols, w.buckets.as<xyzz_t>(), w.red_r.as<xyzz_t>(), w.red_ws.as<xyzz_t>());
+          else msm_segsum_kernel<F, false><<<dim3(blocks, 2), 256, 0, st>>>(sh.NB, rows, cols, w.buckets.as<xyzz_t>(), w.red_r.as<xyzz_t>(), w.red_ws.as<xyzz_t>()); }
         const uint32_t Gr = (R + 15) / 16, Gc = C / 16;
         { ProfScope ps_(c, PS_REDUCE_BC);
           msm_wsum16_kernel<F><<<dim3(Gr + Gc, sh.nsets), 64, 0, st>>>(R, C, Gr, w.red_r.as<xyzz_t>(), w.red_ws.as<xyzz_t>(), w.red2_r.as<xyzz_t>(), w.red2_w.as<xyzz_t>());

@@ -536,16 +536,18 @@ struct SegSum {            // one family of segments (rows or columns)
 };
 static constexpr int SEG_CHUNK = 8;
 
-template <int F>
+template <int F, bool COOP>
 __global__ void __launch_bounds__(256)
 msm_segsum_kernel(uint32_t nb_per_set, SegSum rows, SegSum cols, const xyzz_t *__restrict__ buckets,
                   xyzz_t *__restrict__ out_rows, xyzz_t *__restrict__ out_cols) {
-    // `lanes` counts QUADS per segment here: four lanes cooperate on every add (lane-cooperative group law)
+    // COOP: `lanes` counts QUADS per segment, four lanes cooperate on every add (lane-cooperative group law; latency form).
+    // !COOP: `lanes` counts single lanes per segment, plain XYZZ adds (throughput form: a third fewer issue slots).
+    constexpr uint32_t LPG = COOP ? 4 : 1;                    // lanes per worker
     const bool is_col = blockIdx.y != 0;
     const SegSum sg = is_col ? cols : rows;
     xyzz_t *__restrict__ out = is_col ? out_cols : out_rows;
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t qid = gid >> 2;                            // quad index
+    const uint32_t qid = gid / LPG;                           // worker index
     const uint32_t seg = qid / sg.lanes, sub = qid % sg.lanes;
     const bool live = seg < sg.nseg;
     xyzz_t acc = xyzz_inf();
@@ -553,14 +555,17 @@ msm_segsum_kernel(uint32_t nb_per_set, SegSum rows, SegSum cols, const xyzz_t *_
         const size_t base = (size_t)(seg / sg.per_set) * nb_per_set + (size_t)(seg % sg.per_set) * sg.seg_stride;
         const uint32_t per_lane = (sg.len + sg.lanes - 1) / sg.lanes;
         const uint32_t e0 = sub * per_lane, e1 = min(e0 + per_lane, sg.len);
-        for (uint32_t e = e0; e < e1; ++e) xyzz_add_quad<F>(acc, buckets[base + (size_t)e * sg.elem_stride]);
+        for (uint32_t e = e0; e < e1; ++e) {
+            if (COOP) xyzz_add_quad<F>(acc, buckets[base + (size_t)e * sg.elem_stride]);
+            else xyzz_add<F>(acc, buckets[base + (size_t)e * sg.elem_stride]);
+        }
     }
 #pragma unroll 1
-    for (uint32_t d = sg.lanes >> 1; d >= 1; d >>= 1) {      // partner quad = 4*d lanes further; groups never straddle a wave
-        xyzz_t o = shfl_down_xyzz(acc, (int)(4 * d));
-        if (sub + d < sg.lanes) xyzz_add_quad<F>(acc, o);
+    for (uint32_t d = sg.lanes >> 1; d >= 1; d >>= 1) {      // partner worker = LPG*d lanes further; groups never straddle a wave
+        xyzz_t o = shfl_down_xyzz(acc, (int)(LPG * d));
+        if (sub + d < sg.lanes) { if (COOP) xyzz_add_quad<F>(acc, o); else xyzz_add<F>(acc, o); }
     }
-    if (live && sub == 0 && (gid & 3u) == 0) out[seg] = acc;
+    if (live && sub == 0 && (gid % LPG) == 0) out[seg] = acc;
 }
 
 // quad-replicated wave collectives: every value lives on the 4 lanes of a quad (16 values per wave), adds are

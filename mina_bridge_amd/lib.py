@@ -22,6 +22,7 @@ CURVE_PALLAS, CURVE_VESTA = 0, 1
 # every symbol include/mina_verify.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "mina_ctx_create", "mina_ctx_destroy", "mina_last_error", "mina_ctx_synchronize", "mina_ctx_stream", "mina_ctx_set_pipeline", "mina_prof_enable", "mina_prof_read",
+    "mina_dev_malloc", "mina_dev_free", "mina_dev_upload", "mina_dev_download",
     "mina_srs_create", "mina_srs_load", "mina_srs_depth", "mina_srs_get_g", "mina_srs_get_h", "mina_srs_lagrange_basis", "mina_public_input_commitment", "mina_public_input_commitment_batch", "mina_combined_inner_product", "mina_srs_serialize",
     "mina_msm", "mina_msm_srs", "mina_msm_srs_range", "mina_msm_srs_multi", "mina_msm_srs_dev",
     "mina_b_poly", "mina_b_poly_coefficients", "mina_b_poly_fold", "mina_b_poly_fold_dev",
@@ -239,6 +240,25 @@ class MinaContext:
 
     def set_pipeline(self, lanes: int):
         self._ck(self._lib.mina_ctx_set_pipeline(self._h, int(lanes)), "mina_ctx_set_pipeline")
+
+    # -- device memory for the `_dev` entry points (no torch needed)
+    def dev_malloc(self, nbytes: int) -> int:
+        p = ctypes.c_void_p()
+        self._ck(self._lib.mina_dev_malloc(self._h, ctypes.c_size_t(nbytes), ctypes.byref(p)), "mina_dev_malloc")
+        return p.value
+
+    def dev_free(self, ptr: int):
+        self._ck(self._lib.mina_dev_free(self._h, ctypes.c_void_p(ptr)), "mina_dev_free")
+
+    def dev_upload(self, ptr: int, data) -> int:
+        a = _u8(data)
+        self._ck(self._lib.mina_dev_upload(self._h, ctypes.c_void_p(ptr), _p(a), ctypes.c_size_t(a.size)), "mina_dev_upload")
+        return ptr
+
+    def dev_download(self, ptr: int, nbytes: int) -> np.ndarray:
+        out = np.empty(nbytes, np.uint8)
+        self._ck(self._lib.mina_dev_download(self._h, _p(out), ctypes.c_void_p(ptr), ctypes.c_size_t(nbytes)), "mina_dev_download")
+        return out
 
     def prof_enable(self, stage_mask: int = -1):
         self._ck(self._lib.mina_prof_enable(self._h, int(stage_mask)), "mina_prof_enable")
