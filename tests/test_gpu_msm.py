@@ -250,3 +250,29 @@ def test_msm_srs_fixed_base_heavy_buckets(ctx_srs, oracle, srs_oracle):
     sc = np.repeat(rand_scalars(1, P, seed=5), n, axis=0)
     sc[12345] = rand_scalars(1, P, seed=6)[0]
     assert (ctx_srs.msm_srs(curve, sc) == oracle.msm_pippenger(curve, g[:n], sc, threads=8)).all()
+
+
+def test_msm_srs_multi_randomised_shapes(ctx_srs, oracle, srs_oracle):
+    """random (n, nprob) incl. n not a multiple of the 256-scalar sort blocks, with zero / equal / tiny / maximal scalar
+    rows mixed in: every problem's result == the oracle's; in both context modes (latency and throughput kernel forms)"""
+    rng = np.random.Generator(np.random.PCG64(777))
+    for trial in range(14):
+        curve = int(rng.integers(0, 2))
+        r = SCALAR_MOD[curve]
+        g, _ = srs_oracle[curve]
+        n = int(rng.choice([1, 2, 255, 256, 257, 700, 1023, 4097, 10000]))
+        nprob = int(rng.integers(1, 13))
+        sc = rand_scalars(nprob * n, r, seed=5000 + trial).reshape(nprob, n, 32)
+        for m in range(nprob):
+            kind = int(rng.integers(0, 6))
+            if kind == 0: sc[m] = 0
+            elif kind == 1: sc[m] = sc[m, 0]
+            elif kind == 2: sc[m, :, 2:] = 0
+            elif kind == 3: sc[m] = oracle.int_to_le(r - 1)
+        ctx_srs.set_pipeline(1 if trial % 2 == 0 else 3)
+        try:
+            got = ctx_srs.msm_srs_multi(curve, sc, nprob)
+        finally:
+            ctx_srs.set_pipeline(1)
+        for m in range(nprob):
+            assert (got[m] == oracle.msm_pippenger(curve, g[:n], sc[m], threads=8)).all(), (trial, curve, n, nprob, m)
