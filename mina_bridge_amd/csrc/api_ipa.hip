@@ -416,7 +416,10 @@ extern "C" int mina_ipa_batch_check(mina_ctx *c, int curve, size_t batch, const 
                  o_sg = o_delta + batch * 64, o_z1 = o_sg + batch * 64, o_z2 = o_z1 + batch * 32, o_pts = o_z2 + batch * 32,
                  o_r = o_pts + batch * npts * 32, o_xi = o_r + batch * 32, o_comms = o_xi + batch * 32, o_rb = o_comms + batch * m * 64,
                  o_sb = o_rb + 32, o_pos = o_sb + 32, total = o_pos + batch * 8;
-    std::vector<uint8_t> blob(total);
+    int rc;
+    if ((rc = c->L->host_stage.ensure(total))) return rc;       // packed straight into page-locked memory
+    uint8_t *blob = (uint8_t *)c->L->host_stage.p;
+    memset(blob + o_comms, 0, batch * m * 64);                   // shorter commitment lists are padded with infinity = (0, 0)
     for (size_t b = 0; b < batch; ++b) {
         const mina_ipa_opening &o = op[b];
         memcpy(&blob[o_state + b * 96], o.sponge_state, 96);
@@ -435,8 +438,7 @@ extern "C" int mina_ipa_batch_check(mina_ctx *c, int curve, size_t batch, const 
     }
     memcpy(&blob[o_rb], rand_base, 32);
     memcpy(&blob[o_sb], sg_rand_base, 32);
-    int rc;
-    if ((rc = h2d(c, c->L->ipa_in_a, blob.data(), total))) return rc;
+    if ((rc = h2d(c, c->L->ipa_in_a, blob, total))) return rc;
     const uint8_t *d = c->L->ipa_in_a.as<uint8_t>();
     auto W = [&](size_t off) { return reinterpret_cast<const uint32_t *>(d + off); };
     const size_t npoints = batch * sh.per;

@@ -36,6 +36,19 @@ struct DevBuf {
     template <class T> T *as() { return reinterpret_cast<T *>(p); }
 };
 
+// page-locked host staging (grow-only): packing straight into it makes the H2D copy a real DMA at PCIe speed
+struct PinnedBuf {
+    void *p = nullptr; size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return MINA_OK;
+        if (p) { (void)hipHostFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 4 + 4096;
+        if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) return fail(MINA_ERR_HIP, "hipHostMalloc failed");
+        cap = want; return MINA_OK;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
 struct SrsState {
     uint32_t depth = 0;
     uint32_t c = 16, W = 16;           // fixed-base window shape
@@ -68,6 +81,7 @@ struct Lane {
     hipStream_t stream = nullptr;
     MsmWorkspace ws;
     DevBuf tmp_a, tmp_b, tmp_c, tmp_d;       // staging for the host-buffer entry points
+    PinnedBuf host_stage;                    // pinned host side of the big H2D blobs (synchronous entry points only)
     DevBuf bp_ltab, bp_htab, bp_partial;
     DevBuf ipa_chals, ipa_folded, ipa_xyzz_a, ipa_xyzz_b, ipa_points, ipa_scalars, ipa_sigma, ipa_in_a, ipa_in_b, ipa_in_c, ipa_verdict;
     void release_all() {
@@ -77,6 +91,7 @@ struct Lane {
                          &bp_ltab, &bp_htab, &bp_partial, &ipa_chals, &ipa_folded, &ipa_xyzz_a, &ipa_xyzz_b, &ipa_points, &ipa_scalars,
                          &ipa_sigma, &ipa_in_a, &ipa_in_b, &ipa_in_c, &ipa_verdict};
         for (DevBuf *b : all) b->release();
+        host_stage.release();
     }
 };
 static constexpr int MB_MAX_LANES = 16;
