@@ -154,11 +154,11 @@ extern "C" int mina_poseidon_hash(mina_ctx *c, int field, size_t n, size_t len, 
     int rc;
     if ((rc = h2d(c, c->L->tmp_a, inputs, n * len * 32))) return rc;
     if ((rc = c->L->tmp_c.ensure(n * 32))) return rc;
-    // below ~64k sponges the chip is not full with one lane per sponge: use the 4-lane cooperative form (3x shorter chain)
+    // below ~200k sponges the chip is not full with one lane per sponge: use the 4-lane cooperative form (3x shorter chain)
     // and below ~8k the 8-lane form (a quarter shorter chain again, 1.5x the issue slots)
     if (n <= COOP8_MAX_GROUPS) {
         DISPATCH_FIELD(field, { poseidon_hash_coop_kernel<F_, 8><<<cdiv(n * 8, 256), 256, 0, c->L->stream>>>((uint32_t)n, (uint32_t)len, c->fk[F_], c->pparams[field].as<PoseidonParams>(), c->L->tmp_a.as<uint32_t>(), c->L->tmp_c.as<uint32_t>()); });
-    } else if (n < 65536) {
+    } else if (n < 200000) {                                   // one lane per sponge only pays with >= 3 waves per SIMD (measured crossover ~200 k)
         DISPATCH_FIELD(field, { poseidon_hash_coop_kernel<F_, 4><<<cdiv(n * 4, 256), 256, 0, c->L->stream>>>((uint32_t)n, (uint32_t)len, c->fk[F_], c->pparams[field].as<PoseidonParams>(), c->L->tmp_a.as<uint32_t>(), c->L->tmp_c.as<uint32_t>()); });
     } else {
         DISPATCH_FIELD(field, { poseidon_hash_kernel<F_><<<cdiv(n, 256), 256, 0, c->L->stream>>>((uint32_t)n, (uint32_t)len, c->fk[F_], c->pparams[field].as<PoseidonParams>(), c->L->tmp_a.as<uint32_t>(), c->L->tmp_c.as<uint32_t>()); });

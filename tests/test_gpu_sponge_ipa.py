@@ -127,3 +127,20 @@ def test_accumulator_check_multi_unfolded(ctx_srs, oracle, srs_oracle, curve, k,
     assert got == expect
     for b in sorted({0, count - 1}):
         assert ctx_srs.accumulator_check_batch(curve, k, bad_pre[b * k:(b + 1) * k], bad_sg[b]).tolist() == [expect[b]]
+
+
+@pytest.mark.parametrize("n", [8192, 8193, 199999, 200000])
+def test_poseidon_hash_every_kernel_form(ctx, oracle, n):
+    """the sponge-hash entry point picks its kernel by batch size: 8 lanes per sponge (<= 8192), 4 lanes (< 200 000), one lane;
+    each side of both thresholds against the oracle (sampled sponges; the inputs repeat with period 1009)"""
+    import mina_bridge_amd as m
+    field, length = 0, 5
+    params = m.poseidon_params.default_params_bytes(field)
+    base = rand_scalars(1009 * length, MODS[field], seed=4242).reshape(1009, length * 32)
+    inp = base[np.arange(n) % 1009].copy()
+    got = ctx.poseidon_hash(field, inp, n, length)
+    exp = {i: oracle.poseidon_hash(field, params, base[i].reshape(length, 32)) for i in (0, 1, 500, 1008)}
+    for i in (0, 1, 500, 1008, 1009, n - 1, n // 2):
+        ref = exp.get(i % 1009)
+        assert (got[i] == (ref if ref is not None else got[i % 1009])).all(), i
+    assert (got[:1009] == got[1009:2018]).all()                    # same inputs, other lanes / waves
