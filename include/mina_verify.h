@@ -29,7 +29,8 @@
  *     and streams inside a `mina_ctx`.  No exceptions cross the ABI: every function returns 0 (MINA_OK)
  *     or a negative error code; verdicts are separate outputs.
  *   - field element: 32-byte little-endian canonical integer (< modulus), the ark `CanonicalSerialize`
- *     form used at core/src/sol/serialization.rs:63-86.
+ *     form used at core/src/sol/serialization.rs:63-86.  Values >= modulus are a caller error (upstream's
+ *     deserialiser rejects them before this boundary); the kernels do not re-check and the result is then unspecified.
  *   - affine point: x || y, 64 bytes; the point at infinity is 64 zero bytes.
  *   - `field`: 0 = Fp (Pallas base, Vesta scalar), 1 = Fq (Vesta base, Pallas scalar).
  *   - `curve`: 0 = Pallas (base Fp, scalar Fq), 1 = Vesta (base Fq, scalar Fp).
