@@ -30,7 +30,9 @@
  *     or a negative error code; verdicts are separate outputs.
  *   - field element: 32-byte little-endian canonical integer (< modulus), the ark `CanonicalSerialize`
  *     form used at core/src/sol/serialization.rs:63-86.  Values >= modulus are a caller error (upstream's
- *     deserialiser rejects them before this boundary); the kernels do not re-check and the result is then unspecified.
+ *     deserialiser rejects them before this boundary); the arithmetic entry points (MSM, b_poly, Poseidon, Merkle) do
+ *     not re-check and the result is then unspecified.  The proof-level entry points (mina_ipa_batch_check, the wire
+ *     parsers) do validate and reject.
  *   - affine point: x || y, 64 bytes; the point at infinity is 64 zero bytes.
  *   - `field`: 0 = Fp (Pallas base, Vesta scalar), 1 = Fq (Vesta base, Pallas scalar).
  *   - `curve`: 0 = Pallas (base Fp, scalar Fq), 1 = Vesta (base Fq, scalar Fp).
@@ -247,7 +249,10 @@ typedef struct {
 int mina_combined_inner_product(int field, size_t n_polys, size_t n_points, const uint8_t *evals /* n_polys*n_points*32 */,
                                 const uint8_t *polyscale, const uint8_t *evalscale, uint8_t *out /* 32 */);
 
-/* The openings of one call share k and n_evalpoints; n_comms may differ (proofs of different circuits). */
+/* The openings of one call share k and n_evalpoints; n_comms may differ (proofs of different circuits).
+ * The proof data is validated the way upstream's deserialiser validates it before `SRS::verify` runs: every field element
+ * canonical, every point on the curve (or the all-zero encoding of infinity); a malformed opening anywhere in the batch
+ * gives verdict 0, never an error code (README.md:281-310: every failure is `false`). */
 int mina_ipa_batch_check(mina_ctx *ctx, int curve, size_t batch, const mina_ipa_opening *openings,
                          const uint8_t *rand_base /* 32 */, const uint8_t *sg_rand_base /* 32 */,
                          uint8_t *verdict /* 1 byte: 1 = all openings valid */);

@@ -107,6 +107,21 @@ struct IpaShape { uint32_t batch, k, npts, ncomms, per; };   // per = 2k + ncomm
 template <int FB> __device__ __forceinline__ affine_t load_point_mont(const uint32_t *p, const FieldK &kb) {
     affine_t a; a.x = fe_to_mont<FB>(load_fe<FB>(p), kb.r2); a.y = fe_to_mont<FB>(load_fe<FB>(p + 8), kb.r2); return a;
 }
+template <int F> __device__ __forceinline__ bool fe_words_canonical(const fe_t &a) {             // plain integer < modulus ?
+    for (int i = 7; i >= 0; --i) { const uint32_t m = modulus_limb<F>(i); if (a.v[i] != m) return a.v[i] < m; }
+    return false;
+}
+// The same with the checks upstream's deserialiser makes before `SRS::verify` ever sees a point: coordinates canonical and
+// the point on y^2 = x^3 + 5 (or the (0,0) encoding of infinity).  A proof carrying anything else must be REJECTED -- off-curve
+// points would otherwise enter the combined MSM -- so `ok` feeds the batch verdict.
+template <int FB> __device__ __forceinline__ affine_t load_point_checked(const uint32_t *p, const FieldK &kb, bool &ok) {
+    const fe_t xw = load_fe<FB>(p), yw = load_fe<FB>(p + 8);
+    affine_t a; a.x = fe_to_mont<FB>(xw, kb.r2); a.y = fe_to_mont<FB>(yw, kb.r2);
+    bool good = fe_words_canonical<FB>(xw) && fe_words_canonical<FB>(yw);
+    if (good && !aff_is_inf(a)) good = fe_eq(fe_sqr<FB>(a.y), fe_add<FB>(fe_mul<FB>(fe_sqr<FB>(a.x), a.x), kb.five));
+    ok = ok && good;
+    return a;
+}
 
 // One lane group (4 or 8 lanes) per proof: the Fq-sponge runs lane-cooperatively (6.3 / 4.65 dependent product latencies per
 // Poseidon round instead of 21), all other (scalar-field) work is computed redundantly by the lanes, lane 0 writes.
@@ -123,18 +138,31 @@ ipa_prepare_kernel(IpaShape sh, FieldK kb, FieldK ks, const PoseidonParams *__re
                    const uint32_t *__restrict__ rand_base, const uint32_t *__restrict__ sg_rand_base,
                    const affine_t *__restrict__ srs_h,
                    affine_t *__restrict__ out_points /* b*per */, uint32_t *__restrict__ out_scalars /* b*per*8 canonical */,
-                   uint32_t *__restrict__ out_chals /* b*k*8 canonical */, uint32_t *__restrict__ out_sigma /* b*8 canonical */) {
+                   uint32_t *__restrict__ out_chals /* b*k*8 canonical */, uint32_t *__restrict__ out_sigma /* b*8 canonical */,
+                   uint32_t *__restrict__ bad_input /* zeroed by the host; set to 1 on a malformed point */) {
     constexpr int FB = (CURVE == CURVE_PALLAS) ? FIELD_FP : FIELD_FQ;
     constexpr int FS = (CURVE == CURVE_PALLAS) ? FIELD_FQ : FIELD_FP;
     const uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) / LANES;
     if (b >= sh.batch) return;                                // whole lane groups leave together
     const uint32_t k = sh.k;
+    bool pts_ok = true;                                       // every input well-formed (canonical field elements, points on the curve)
 
     // ---- Fq-sponge transcript (base field)
     DevSponge<FB, LANES> sp; sp.pp = pp; sp.squeezed = 0; sp.count = 0;
-    sp.s = fe_to_mont<FB>(load_fe<FB>(sponge_state + (size_t)b * 24 + coop_elem<LANES>() * 8), kb.r2);
+    {
+        const fe_t w = load_fe<FB>(sponge_state + (size_t)b * 24 + coop_elem<LANES>() * 8);
+        bool okw = true;                                      // all three state elements, checked redundantly by every lane
+        for (int e = 0; e < 3; ++e) okw = okw && fe_words_canonical<FB>(load_fe<FB>(sponge_state + (size_t)b * 24 + e * 8));
+        pts_ok = pts_ok && okw;
+        sp.s = fe_to_mont<FB>(w, kb.r2);
+    }
     sp.squeezed = (int)sponge_pos[2 * b]; sp.count = (int)sponge_pos[2 * b + 1];
-    const fe_t cip_m = fe_to_mont<FS>(load_fe<FS>(cip + (size_t)b * 8), ks.r2);
+    auto load_scalar_checked = [&](const uint32_t *p) {           // scalar-field element: canonical or the batch is rejected
+        const fe_t w = load_fe<FS>(p);
+        pts_ok = pts_ok && fe_words_canonical<FS>(w);
+        return fe_to_mont<FS>(w, ks.r2);
+    };
+    const fe_t cip_m = load_scalar_checked(cip + (size_t)b * 8);
     {   // absorb_fr(shift_scalar(cip))
         const fe_t two255 = ks.two255;
         if (CURVE == CURVE_PALLAS) {
@@ -171,7 +199,7 @@ ipa_prepare_kernel(IpaShape sh, FieldK kb, FieldK ks, const PoseidonParams *__re
     // layout of the per-proof list: [h, sg, U, delta, L_0, R_0, ..., L_{k-1}, R_{k-1}, comm_0 .. comm_{m-1}]
     for (uint32_t j = 0; j < k; ++j) {
         const uint32_t *lp = lr + ((size_t)b * 2 * k + 2 * j) * 16;
-        affine_t L = load_point_mont<FB>(lp, kb), R = load_point_mont<FB>(lp + 16, kb);
+        affine_t L = load_point_checked<FB>(lp, kb, pts_ok), R = load_point_checked<FB>(lp + 16, kb, pts_ok);
         sp.absorb(L.x); sp.absorb(L.y);                     // infinity is (0,0): absorbs two zeros, as upstream
         sp.absorb(R.x); sp.absorb(R.y);
         fe_t sq = fe_from_mont<FB>(sp.squeeze());
@@ -181,7 +209,7 @@ ipa_prepare_kernel(IpaShape sh, FieldK kb, FieldK ks, const PoseidonParams *__re
         store_fe<LANES>(out_chals + ((size_t)b * k + j) * 8, fe_from_mont<FS>(chal));
         store_pt<LANES>(&pts[4 + 2 * j], L); store_pt<LANES>(&pts[5 + 2 * j], R);
     }
-    const affine_t D = load_point_mont<FB>(delta + (size_t)b * 16, kb);
+    const affine_t D = load_point_checked<FB>(delta + (size_t)b * 16, kb, pts_ok);
     sp.absorb(D.x); sp.absorb(D.y);
     fe_t c;
     {
@@ -191,10 +219,10 @@ ipa_prepare_kernel(IpaShape sh, FieldK kb, FieldK ks, const PoseidonParams *__re
     }
 
     // b0 = sum_p r^p * b_poly(chal, pt_p)
-    const fe_t r = fe_to_mont<FS>(load_fe<FS>(evalscale + (size_t)b * 8), ks.r2);
+    const fe_t r = load_scalar_checked(evalscale + (size_t)b * 8);
     fe_t b0 = fe_zero(), scale = ks.one;
     for (uint32_t p = 0; p < sh.npts; ++p) {
-        fe_t pw = fe_to_mont<FS>(load_fe<FS>(evalpoints + ((size_t)b * sh.npts + p) * 8), ks.r2), acc = ks.one;
+        fe_t pw = load_scalar_checked(evalpoints + ((size_t)b * sh.npts + p) * 8), acc = ks.one;
         for (int i = (int)k - 1; i >= 0; --i) {
             acc = fe_mul<FS>(acc, fe_add<FS>(ks.one, fe_mul<FS>(chal_m[i], pw)));
             pw = fe_sqr<FS>(pw);
@@ -203,13 +231,13 @@ ipa_prepare_kernel(IpaShape sh, FieldK kb, FieldK ks, const PoseidonParams *__re
         scale = fe_mul<FS>(scale, r);
     }
 
-    const fe_t z1m = fe_to_mont<FS>(load_fe<FS>(z1 + (size_t)b * 8), ks.r2);
-    const fe_t z2m = fe_to_mont<FS>(load_fe<FS>(z2 + (size_t)b * 8), ks.r2);
+    const fe_t z1m = load_scalar_checked(z1 + (size_t)b * 8);
+    const fe_t z2m = load_scalar_checked(z2 + (size_t)b * 8);
     const fe_t neg_rho = fe_neg<FS>(rho);
     const fe_t rho_c = fe_mul<FS>(rho, c);
 
     store_pt<LANES>(&pts[0], *srs_h);               store_fe<LANES>(scs + 0 * 8, fe_from_mont<FS>(fe_mul<FS>(neg_rho, z2m)));
-    store_pt<LANES>(&pts[1], load_point_mont<FB>(sg + (size_t)b * 16, kb));
+    store_pt<LANES>(&pts[1], load_point_checked<FB>(sg + (size_t)b * 16, kb, pts_ok));
     store_fe<LANES>(scs + 1 * 8, fe_from_mont<FS>(fe_sub<FS>(fe_mul<FS>(neg_rho, z1m), sigma)));
     store_pt<LANES>(&pts[2], U);
     store_fe<LANES>(scs + 2 * 8, fe_from_mont<FS>(fe_add<FS>(fe_mul<FS>(fe_mul<FS>(neg_rho, z1m), b0), fe_mul<FS>(rho_c, cip_m))));
@@ -225,20 +253,23 @@ ipa_prepare_kernel(IpaShape sh, FieldK kb, FieldK ks, const PoseidonParams *__re
             store_fe<LANES>(scs + (size_t)(5 + 2 * j) * 8, fe_from_mont<FS>(fe_mul<FS>(rho_c, chal_m[j])));
         }
     }
-    const fe_t xi = fe_to_mont<FS>(load_fe<FS>(polyscale + (size_t)b * 8), ks.r2);
+    const fe_t xi = load_scalar_checked(polyscale + (size_t)b * 8);
     fe_t xi_i = ks.one;
     for (uint32_t i = 0; i < sh.ncomms; ++i) {
-        store_pt<LANES>(&pts[4 + 2 * k + i], load_point_mont<FB>(comms + ((size_t)b * sh.ncomms + i) * 16, kb));
+        store_pt<LANES>(&pts[4 + 2 * k + i], load_point_checked<FB>(comms + ((size_t)b * sh.ncomms + i) * 16, kb, pts_ok));
         store_fe<LANES>(scs + (size_t)(4 + 2 * k + i) * 8, fe_from_mont<FS>(fe_mul<FS>(rho_c, xi_i)));
         xi_i = fe_mul<FS>(xi_i, xi);
     }
     store_fe<LANES>(out_sigma + (size_t)b * 8, fe_from_mont<FS>(sigma));
+    if (!pts_ok && coop_writer<LANES>()) *bad_input = 1u;         // any malformed point in any proof: the batch verdict is 0
 }
 
 // verdict[0] = 1 iff  A + sign * B == identity  (sign = +1: A == -B ; sign = -1: A == B)
 template <int F>
-__global__ void xyzz_compare_kernel(const xyzz_t *__restrict__ a, const xyzz_t *__restrict__ b, int negate_b, uint32_t *__restrict__ verdict) {
+__global__ void xyzz_compare_kernel(const xyzz_t *__restrict__ a, const xyzz_t *__restrict__ b, int negate_b, uint32_t *__restrict__ verdict,
+                                    const uint32_t *__restrict__ bad_input = nullptr) {
     if (threadIdx.x || blockIdx.x) return;
+    if (bad_input && *bad_input) { *verdict = 0u; return; }
     xyzz_t A = *a, B = *b;
     if (negate_b) B.y = fe_neg<F>(B.y);
     bool ai = xyzz_is_inf(A), bi = xyzz_is_inf(B), eq;
@@ -449,13 +480,14 @@ extern "C" int mina_ipa_batch_check(mina_ctx *c, int curve, size_t batch, const 
     if ((rc = c->L->ipa_folded.ensure(((size_t)1 << k) * 32))) return rc;
     if ((rc = c->L->ipa_xyzz_a.ensure(sizeof(xyzz_t)))) return rc;
     if ((rc = c->L->ipa_xyzz_b.ensure(sizeof(xyzz_t)))) return rc;
-    if ((rc = c->L->ipa_verdict.ensure(4))) return rc;
+    if ((rc = c->L->ipa_verdict.ensure(8))) return rc;          // [0] verdict, [1] malformed-input flag
+    HIPC(hipMemsetAsync(c->L->ipa_verdict.p, 0, 8, c->L->stream));
     const PoseidonParams *pp = c->pparams[FB].as<PoseidonParams>();
 #define IPA_PREP(CV, LN)                                                                                                      \
     mb::ipa_prepare_kernel<CV, LN><<<cdiv(batch * LN, 64), 64, 0, c->L->stream>>>(                                                    \
         sh, c->fk[FB], c->fk[FS], pp, W(o_state), W(o_pos), W(o_cip), W(o_lr), W(o_delta), W(o_sg), W(o_z1), W(o_z2), W(o_pts), W(o_r), \
         W(o_xi), W(o_comms), W(o_rb), W(o_sb), s.h.as<affine_t>(), c->L->ipa_points.as<affine_t>(), c->L->ipa_scalars.as<uint32_t>(), \
-        c->L->ipa_chals.as<uint32_t>(), c->L->ipa_sigma.as<uint32_t>())
+        c->L->ipa_chals.as<uint32_t>(), c->L->ipa_sigma.as<uint32_t>(), c->L->ipa_verdict.as<uint32_t>() + 1)
     // latency-bound batches: 8 lanes per transcript; larger ones 4
     if (batch <= COOP8_MAX_GROUPS) { if (curve == CURVE_PALLAS) IPA_PREP(CURVE_PALLAS, 8); else IPA_PREP(CURVE_VESTA, 8); }
     else { if (curve == CURVE_PALLAS) IPA_PREP(CURVE_PALLAS, 4); else IPA_PREP(CURVE_VESTA, 4); }
@@ -464,7 +496,7 @@ extern "C" int mina_ipa_batch_check(mina_ctx *c, int curve, size_t batch, const 
     if ((rc = mb_bpoly_fold(c, FS, k, batch, c->L->ipa_chals.as<uint32_t>(), c->L->ipa_sigma.as<uint32_t>(), c->L->ipa_folded.as<uint32_t>()))) return rc;
     if ((rc = mb_msm_fixed(c, curve, 1u << k, c->L->ipa_folded.as<uint32_t>(), nullptr, c->L->ipa_xyzz_a.p))) return rc;
     if ((rc = mb_msm_variable(c, curve, (uint32_t)npoints, c->L->ipa_scalars.as<uint32_t>(), c->L->ipa_points.p, nullptr, c->L->ipa_xyzz_b.p))) return rc;
-    DISPATCH_FIELD(FB, { xyzz_compare_kernel<F_><<<1, 64, 0, c->L->stream>>>(c->L->ipa_xyzz_a.as<xyzz_t>(), c->L->ipa_xyzz_b.as<xyzz_t>(), 1, c->L->ipa_verdict.as<uint32_t>()); });
+    DISPATCH_FIELD(FB, { xyzz_compare_kernel<F_><<<1, 64, 0, c->L->stream>>>(c->L->ipa_xyzz_a.as<xyzz_t>(), c->L->ipa_xyzz_b.as<xyzz_t>(), 1, c->L->ipa_verdict.as<uint32_t>(), c->L->ipa_verdict.as<uint32_t>() + 1); });
     uint32_t v = 0;
     if ((rc = d2h_sync(c, &v, c->L->ipa_verdict, 4))) return rc;
     *verdict = v ? 1 : 0;

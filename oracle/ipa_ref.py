@@ -228,7 +228,7 @@ def ipa_verify_batch(curve, g_bytes, h, batch, rand_base, sg_rand_base) -> bool:
     return not O.msm_pippenger(curve, all_pts, all_scs, threads=8).any()
 
 
-def make_instance(curve, g_bytes, h, pp: R.PoseidonParams, k: int, n_polys: int, n_points: int, seed: int):
+def make_instance(curve, g_bytes, h, pp: R.PoseidonParams, k: int, n_polys: int, n_points: int, seed: int, xi=None):
     """A valid (commitments, evaluations, opening) instance over g[0..2^k) with a fresh transcript.
     Returns (verifier_entry_without_sponge, sponge_before) so that callers can clone the sponge."""
     rng = random.Random(seed)
@@ -238,7 +238,8 @@ def make_instance(curve, g_bytes, h, pp: R.PoseidonParams, k: int, n_polys: int,
     blinders = [rng.randrange(r) for _ in range(n_polys)]
     comms = [commit(curve, g_bytes[:n], h, f, bl) for f, bl in zip(polys, blinders)]
     evalpoints = [rng.randrange(r) for _ in range(n_points)]
-    xi, rscale = rng.randrange(r), rng.randrange(r)
+    xi_rand, rscale = rng.randrange(r), rng.randrange(r)
+    xi = xi_rand if xi is None else xi          # tests force polyscale = 0 to get commitments with zero weight
     evals = [[eval_poly(f, pt, r) for pt in evalpoints] for f in polys]
     sponge = FqSponge(curve, pp)
     sponge.absorb_g(comms)                      # some transcript prefix, as kimchi's oracles would leave it

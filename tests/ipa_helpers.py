@@ -9,9 +9,9 @@ def poseidon_pp(curve):
     return R.PoseidonParams(R.base_modulus(curve), mds, rc, PP.NAME)
 
 
-def mint(curve, g, h, k, n_polys, n_points, seed):
+def mint(curve, g, h, k, n_polys, n_points, seed, xi=None):
     from oracle import ipa_ref as I, oracle as O
-    entry, sponge = I.make_instance(curve, g, O.bytes_to_point(h), poseidon_pp(curve), k, n_polys, n_points, seed)
+    entry, sponge = I.make_instance(curve, g, O.bytes_to_point(h), poseidon_pp(curve), k, n_polys, n_points, seed, xi=xi)
     return entry, sponge
 
 

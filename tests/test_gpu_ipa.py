@@ -52,3 +52,58 @@ def test_ipa_batch_check_accepts_and_rejects(ctx_srs, oracle, srs_oracle, curve,
     # wrong sponge position
     bad = [dict(o) for o in ops]; bad[0]["sponge_mode"] = 1 - bad[0]["sponge_mode"]
     assert ctx_srs.ipa_batch_check(curve, bad, rb, sb) is False
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+def test_ipa_rejects_malformed_points_the_equation_cannot_see(ctx_srs, oracle, srs_oracle, curve):
+    """With polyscale = 0 the commitments after the first enter the combined MSM with scalar 0, so the equation holds
+    whatever they are.  Upstream never gets that far with a malformed point (its deserialiser checks canonical
+    coordinates and the curve equation): the library must reject off-curve and non-canonical encodings itself, and must
+    still accept a different VALID point in a zero-weight slot."""
+    from oracle import ipa_ref as I
+    k = 5
+    g, h = srs_oracle[curve]
+    p = P if curve == 0 else Q                                   # base field of the curve
+    e, sp = mint(curve, g, h, k, n_polys=3, n_points=2, seed=4100 + curve, xi=0)
+    rb, sb = oracle.int_to_le(77), oracle.int_to_le(1234567)
+    cpu = dict(e); cpu["sponge"] = sp.clone()
+    assert I.ipa_verify_batch(curve, g[: 1 << k], oracle.bytes_to_point(h), [cpu], 77, 1234567)
+    op = to_abi(e, sp)
+    assert ctx_srs.ipa_batch_check(curve, [op], rb, sb) is True
+
+    def with_comm(idx, point_bytes):
+        o = dict(op); c = o["comms"].copy().reshape(-1, 64); c[idx] = point_bytes; o["comms"] = c.reshape(-1); return o
+    # a different valid point (and infinity) in the zero-weight slot: still a valid opening
+    assert ctx_srs.ipa_batch_check(curve, [with_comm(1, g[11])], rb, sb) is True
+    assert ctx_srs.ipa_batch_check(curve, [with_comm(2, np.zeros(64, np.uint8))], rb, sb) is True
+    # off-curve point there: the equation cannot notice, the input check must
+    off = g[11].copy(); off[32] ^= 1
+    assert not oracle.is_on_curve(curve, off)
+    assert ctx_srs.ipa_batch_check(curve, [with_comm(1, off)], rb, sb) is False
+    assert ctx_srs.ipa_batch_check(curve, [op, with_comm(2, off), op], rb, sb) is False      # anywhere in a batch
+    # non-canonical alias of a valid point (x + p): same group element, rejected encoding
+    x = oracle.le_to_int(g[11][:32])
+    alias = g[11].copy(); alias[:32] = np.frombuffer((x + p).to_bytes(32, "little"), np.uint8)
+    assert ctx_srs.ipa_batch_check(curve, [with_comm(1, alias)], rb, sb) is False
+    # the same checks guard L/R, delta and sg (weight non-zero there, but the verdict must come from the input check too)
+    for key, idx in (("lr", 3), ("delta", 0), ("sg", 0)):
+        o = dict(op); a = o[key].copy().reshape(-1, 64); a[idx, 32] ^= 1; o[key] = a.reshape(-1)
+        assert ctx_srs.ipa_batch_check(curve, [o], rb, sb) is False, key
+
+
+def test_ipa_rejects_non_canonical_field_elements(ctx_srs, oracle, srs_oracle):
+    """x and x + modulus are the same field element; upstream's deserialiser only admits the canonical one"""
+    curve, k = 0, 4
+    g, h = srs_oracle[curve]
+    e, sp = mint(curve, g, h, k, n_polys=2, n_points=2, seed=4300)
+    rb, sb = oracle.int_to_le(5), oracle.int_to_le(6)
+    op = to_abi(e, sp)
+    assert ctx_srs.ipa_batch_check(curve, [op], rb, sb) is True
+    for key, mod in (("z1", Q), ("z2", Q), ("combined_inner_product", Q), ("polyscale", Q), ("evalscale", Q), ("evalpoints", Q), ("sponge_state", P)):
+        o = dict(op); a = o[key].copy()
+        v = oracle.le_to_int(a[-32:])
+        if v + mod >= 1 << 256:
+            continue
+        a[-32:] = np.frombuffer((v + mod).to_bytes(32, "little"), np.uint8)
+        o[key] = a
+        assert ctx_srs.ipa_batch_check(curve, [o], rb, sb) is False, key
