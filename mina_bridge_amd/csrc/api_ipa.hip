@@ -284,7 +284,9 @@ __global__ void xyzz_eq_affine_kernel(const xyzz_t *__restrict__ a, const uint32
     if (threadIdx.x) return;                                  // one block per comparison: a[b] vs q_words[16 b ..] -> verdict[b]
     a += blockIdx.x; q_words += (size_t)blockIdx.x * 16; verdict += blockIdx.x;
     xyzz_t A = *a;
-    fe_t qx = fe_to_mont<F>(load_fe<F>(q_words), r2), qy = fe_to_mont<F>(load_fe<F>(q_words + 8), r2);
+    const fe_t qxw = load_fe<F>(q_words), qyw = load_fe<F>(q_words + 8);
+    if (!fe_words_canonical<F>(qxw) || !fe_words_canonical<F>(qyw)) { *verdict = 0u; return; }   // alias encodings are rejected, as upstream's deserialiser does
+    fe_t qx = fe_to_mont<F>(qxw, r2), qy = fe_to_mont<F>(qyw, r2);
     bool qi = fe_is_zero(qx) && fe_is_zero(qy), ai = xyzz_is_inf(A), eq;
     if (ai || qi) eq = ai && qi;
     else eq = fe_eq(fe_mul<F>(qx, A.zz), A.x) && fe_eq(fe_mul<F>(qy, A.zzz), A.y);

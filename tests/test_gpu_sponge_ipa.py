@@ -144,3 +144,14 @@ def test_poseidon_hash_every_kernel_form(ctx, oracle, n):
         ref = exp.get(i % 1009)
         assert (got[i] == (ref if ref is not None else got[i % 1009])).all(), i
     assert (got[:1009] == got[1009:2018]).all()                    # same inputs, other lanes / waves
+
+
+def test_accumulator_check_rejects_alias_encoding_of_sg(ctx_srs, oracle, srs_oracle):
+    """(x + p, y) names the same point as (x, y); only the canonical encoding is a valid proof field"""
+    curve, k = 1, 8
+    pre, sg = make_accumulator_instance(oracle, srs_oracle, curve, k, seed=4400)
+    assert ctx_srs.accumulator_check_batch(curve, k, pre, sg).tolist() == [1]
+    x = oracle.le_to_int(sg[:32])
+    alias = sg.copy(); alias[:32] = np.frombuffer((x + Q).to_bytes(32, "little"), np.uint8)     # Vesta base field = Fq
+    assert ctx_srs.accumulator_check_batch(curve, k, pre, alias).tolist() == [0]
+    assert ctx_srs.accumulator_check_multi(curve, k, np.concatenate([pre, pre]), np.stack([alias, sg])).tolist() == [0, 1]
