@@ -278,6 +278,18 @@ __global__ void xyzz_compare_kernel(const xyzz_t *__restrict__ a, const xyzz_t *
     *verdict = eq ? 1u : 0u;
 }
 
+// sg points of a folded batch: canonical words -> Montgomery, with the deserialiser's checks (canonical, on the curve);
+// any malformed point raises the batch's flag (the folded verdict is then 0 and the caller falls back to per-proof checks)
+template <int F>
+__global__ void points_to_mont_checked_kernel(uint32_t n, const uint32_t *__restrict__ in_words, FieldK kb, affine_t *__restrict__ out,
+                                              uint32_t *__restrict__ bad_input) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    bool ok = true;
+    out[i] = load_point_checked<F>(in_words + (size_t)i * 16, kb, ok);
+    if (!ok) *bad_input = 1u;
+}
+
 // A (xyzz) == affine point q (canonical words; zeros = infinity) ?
 template <int F>
 __global__ void xyzz_eq_affine_kernel(const xyzz_t *__restrict__ a, const uint32_t *__restrict__ q_words, fe_t r2, uint32_t *__restrict__ verdict) {
@@ -320,9 +332,11 @@ static int accumulator_check_dev(mina_ctx *c, int curve, uint32_t k, size_t batc
         DISPATCH_FIELD(FB, { xyzz_eq_affine_kernel<F_><<<1, 64, 0, c->L->stream>>>(c->L->ipa_xyzz_a.as<xyzz_t>(), d_sg_words, c->fk[F_].r2, d_verdict); });
     } else {
         if ((rc = c->L->ipa_points.ensure(batch * sizeof(affine_t)))) return rc;
-        DISPATCH_FIELD(FB, { points_to_mont_kernel<F_><<<cdiv(batch, 256), 256, 0, c->L->stream>>>((uint32_t)batch, d_sg_words, c->fk[F_].r2, c->L->ipa_points.as<affine_t>()); });
+        if ((rc = c->L->ipa_sigma.ensure(4))) return rc;            // malformed-input flag of this folded batch
+        HIPC(hipMemsetAsync(c->L->ipa_sigma.p, 0, 4, c->L->stream));
+        DISPATCH_FIELD(FB, { points_to_mont_checked_kernel<F_><<<cdiv(batch, 256), 256, 0, c->L->stream>>>((uint32_t)batch, d_sg_words, c->fk[F_], c->L->ipa_points.as<affine_t>(), c->L->ipa_sigma.as<uint32_t>()); });
         if ((rc = mb_msm_variable(c, curve, (uint32_t)batch, d_rho, c->L->ipa_points.p, nullptr, c->L->ipa_xyzz_b.p))) return rc;
-        DISPATCH_FIELD(FB, { xyzz_compare_kernel<F_><<<1, 64, 0, c->L->stream>>>(c->L->ipa_xyzz_a.as<xyzz_t>(), c->L->ipa_xyzz_b.as<xyzz_t>(), 0, d_verdict); });
+        DISPATCH_FIELD(FB, { xyzz_compare_kernel<F_><<<1, 64, 0, c->L->stream>>>(c->L->ipa_xyzz_a.as<xyzz_t>(), c->L->ipa_xyzz_b.as<xyzz_t>(), 0, d_verdict, c->L->ipa_sigma.as<uint32_t>()); });
     }
     HIPC(hipGetLastError());
     return MINA_OK;

@@ -155,3 +155,17 @@ def test_accumulator_check_rejects_alias_encoding_of_sg(ctx_srs, oracle, srs_ora
     alias = sg.copy(); alias[:32] = np.frombuffer((x + Q).to_bytes(32, "little"), np.uint8)     # Vesta base field = Fq
     assert ctx_srs.accumulator_check_batch(curve, k, pre, alias).tolist() == [0]
     assert ctx_srs.accumulator_check_multi(curve, k, np.concatenate([pre, pre]), np.stack([alias, sg])).tolist() == [0, 1]
+
+
+def test_folded_accumulator_check_validates_sg(ctx_srs, oracle, srs_oracle):
+    """folded (random-combination) path: a malformed sg -- alias encoding or off-curve -- fails the batch and is singled out"""
+    curve, k = 1, 8
+    inst = [make_accumulator_instance(oracle, srs_oracle, curve, k, seed=4500 + b) for b in range(3)]
+    pre = np.concatenate([i[0] for i in inst]); sg = np.stack([i[1] for i in inst])
+    rho = rand_scalars(3, P, seed=9)
+    assert ctx_srs.accumulator_check_batch(curve, k, pre, sg, rho).tolist() == [1, 1, 1]
+    x = oracle.le_to_int(sg[1][:32])
+    alias = sg.copy(); alias[1, :32] = np.frombuffer((x + Q).to_bytes(32, "little"), np.uint8)
+    assert ctx_srs.accumulator_check_batch(curve, k, pre, alias, rho).tolist() == [1, 0, 1]
+    off = sg.copy(); off[2, 40] ^= 4
+    assert ctx_srs.accumulator_check_batch(curve, k, pre, off, rho).tolist() == [1, 1, 0]
