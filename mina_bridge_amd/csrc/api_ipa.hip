@@ -107,10 +107,6 @@ struct IpaShape { uint32_t batch, k, npts, ncomms, per; };   // per = 2k + ncomm
 template <int FB> __device__ __forceinline__ affine_t load_point_mont(const uint32_t *p, const FieldK &kb) {
     affine_t a; a.x = fe_to_mont<FB>(load_fe<FB>(p), kb.r2); a.y = fe_to_mont<FB>(load_fe<FB>(p + 8), kb.r2); return a;
 }
-template <int F> __device__ __forceinline__ bool fe_words_canonical(const fe_t &a) {             // plain integer < modulus ?
-    for (int i = 7; i >= 0; --i) { const uint32_t m = modulus_limb<F>(i); if (a.v[i] != m) return a.v[i] < m; }
-    return false;
-}
 // The same with the checks upstream's deserialiser makes before `SRS::verify` ever sees a point: coordinates canonical and
 // the point on y^2 = x^3 + 5 (or the (0,0) encoding of infinity).  A proof carrying anything else must be REJECTED -- off-curve
 // points would otherwise enter the combined MSM -- so `ok` feeds the batch verdict.

@@ -61,6 +61,11 @@ MB_HD fe_t fe_zero() { fe_t r;
     return r; }
 
 // r = a - p if a >= p else a        (a < 2p)
+// plain 256-bit integer (not Montgomery) strictly below the modulus?  (ark's `CanonicalDeserialize` admits nothing else)
+template <int F> MB_HD bool fe_words_canonical(const fe_t &a) {
+    for (int i = 7; i >= 0; --i) { const uint32_t m = modulus_limb<F>(i); if (a.v[i] != m) return a.v[i] < m; }
+    return false;
+}
 template <int F> MB_HD fe_t fe_cond_sub_p_portable(const fe_t &a) {
     fe_t d; uint32_t br = 0;
 #pragma unroll

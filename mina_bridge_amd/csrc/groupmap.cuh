@@ -155,7 +155,8 @@ __global__ void to_group_kernel(uint32_t n, FieldK k, const uint32_t *__restrict
     for (int j = 0; j < 8; ++j) { out_words[(size_t)i * 16 + j] = x.v[j]; out_words[(size_t)i * 16 + 8 + j] = y.v[j]; }
 }
 
-// compressed (ark-serialize 0.3) -> Montgomery affine.  in: 33 bytes per point.  ok[i]=0 if x is not on the curve.
+// compressed (ark-serialize 0.3) -> Montgomery affine.  in: 33 bytes per point.  *bad counts points that ark would not
+// deserialise: non-canonical x, stray bits in the flag byte, x not on the curve.
 template <int F>
 __global__ void decompress_kernel(uint32_t n, FieldK k, const uint8_t *__restrict__ in, affine_t *__restrict__ out,
                                   uint32_t *__restrict__ bad) {
@@ -163,9 +164,12 @@ __global__ void decompress_kernel(uint32_t n, FieldK k, const uint8_t *__restric
     if (i >= n) return;
     const uint8_t *b = in + (size_t)i * 33;
     affine_t p; p.x = fe_zero(); p.y = fe_zero();
-    if (b[32] & 0x40) { out[i] = p; return; }
     fe_t x;
     for (int j = 0; j < 8; ++j) x.v[j] = (uint32_t)b[4 * j] | ((uint32_t)b[4 * j + 1] << 8) | ((uint32_t)b[4 * j + 2] << 16) | ((uint32_t)b[4 * j + 3] << 24);
+    // ark reads x (with the two flag bits on top of byte 32) as ONE canonical field element: the other six bits of the
+    // flag byte are its bits 256..261 and must be zero, and x itself must be below the modulus -- also for infinity
+    if ((b[32] & 0x3f) || !fe_words_canonical<F>(x)) { atomicAdd(bad, 1u); out[i] = p; return; }
+    if (b[32] & 0x40) { out[i] = p; return; }
     fe_t xm = fe_to_mont<F>(x, k.r2);
     fe_t y2 = fe_add<F>(fe_mul<F>(fe_sqr<F>(xm), xm), k.five), y;
     if (!fe_sqrt<F>(y, y2, k)) { atomicAdd(bad, 1u); out[i] = p; return; }

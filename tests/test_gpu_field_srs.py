@@ -71,6 +71,18 @@ def test_srs_load_roundtrip_and_small_depth(ctx_srs, oracle):
             c3.srs_load(1, bytes(bad))
         except m.MinaError:
             pass
+        # encodings ark's deserialiser refuses: x + q (non-canonical alias of a valid x), stray bits in the flag byte
+        Q = 0x40000000000000000000000000000000224698FC0994A8DD8C46EB2100000001      # Vesta base field
+        off = 6 + 2                                   # first point: 6-byte header, then c4 21, 33 bytes
+        x = int.from_bytes(blob[off:off + 32], "little")
+        alias = bytearray(blob); alias[off:off + 32] = (x + Q).to_bytes(32, "little")
+        with pytest.raises(m.MinaError):
+            c3.srs_load(1, bytes(alias))
+        stray = bytearray(blob); stray[off + 32] |= 0x01
+        with pytest.raises(m.MinaError):
+            c3.srs_load(1, bytes(stray))
+        c3.srs_load(1, blob)                          # and the context still works afterwards
+        assert (c3.srs_get_g(1, 0, 300) == g_small).all()
         c3.close()
     finally:
         c2.close()
