@@ -1,0 +1,51 @@
+"""Error behaviour at the boundary: bad arguments come back as negative return codes with a message (`MinaError` through the
+ctypes wrapper), never as a crash or a silent wrong answer; the context stays usable afterwards."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_bad_arguments_are_errors_not_crashes(ctx_srs):
+    import mina_bridge_amd as m
+    c = ctx_srs
+    lib = c._lib
+    z32, z64 = np.zeros(32, np.uint8), np.zeros(64, np.uint8)
+    pre = np.zeros(16 * 16, np.uint8)
+    with pytest.raises(m.MinaError):
+        c.msm_srs(2, z32)                                            # bad curve
+    with pytest.raises(m.MinaError):
+        c.msm_srs_multi(1, np.zeros((65537, 32), np.uint8), 1)       # n beyond the SRS depth
+    with pytest.raises(m.MinaError):
+        c.accumulator_check_batch(1, 21, np.zeros(21 * 16, np.uint8), z64)     # k > 20
+    with pytest.raises(m.MinaError):
+        c.accumulator_check_batch(1, 17, np.zeros(17 * 16, np.uint8), z64)     # 2^k beyond the SRS depth
+    with pytest.raises(m.MinaError):
+        c.public_input_commitment_batch(0, 17, np.zeros((1, 32), np.uint8), 1)  # domain beyond the SRS depth
+    with pytest.raises(m.MinaError):
+        c.public_input_commitment_batch(0, 3, np.zeros((9, 32), np.uint8), 1)   # more public inputs than the domain
+    with pytest.raises(m.MinaError):
+        c.set_pipeline(0)
+    with pytest.raises(m.MinaError):
+        c.set_pipeline(17)
+    d = c.dev_malloc(64)
+    try:
+        with pytest.raises(m.MinaError):
+            c.accumulator_check_multi_dev(1, 16, 0, d, d, d)          # empty group
+        with pytest.raises(m.MinaError):
+            c.accumulator_check_multi_dev(1, 16, 65, d, d, d)         # group larger than 64
+        with pytest.raises(m.MinaError):
+            c.accumulator_check_multi_dev(1, 16, 1, 0, d, d)          # null device pointer
+    finally:
+        c.dev_free(d)
+    # raw C calls with null pointers
+    assert lib.mina_msm_srs(c._h, 1, ctypes.c_size_t(4), None, None) < 0
+    assert lib.mina_dev_malloc(c._h, ctypes.c_size_t(16), None) < 0
+    assert lib.mina_accumulator_check_multi(c._h, 1, ctypes.c_uint32(16), ctypes.c_size_t(1), None, None, None) < 0
+    assert b"null" in lib.mina_last_error()
+    # and the context still computes
+    one = np.zeros(32, np.uint8); one[0] = 1
+    assert (c.msm_srs(1, one) == c.srs_get_g(1, 0, 1)[0]).all()
+    assert c.accumulator_check_multi(1, 16, pre, z64).tolist() == [0]
