@@ -39,6 +39,7 @@ static int run_msm(mina_ctx *c, const MsmShape &sh, const uint32_t *d_scalars, c
     if (part_sort) {
         if ((rc = w.ghist.ensure((gh_words + 8) * 4))) return rc;
         if ((rc = w.stage.ensure(entries * 8))) return rc;
+        if ((rc = w.ekey.ensure(entries * 4))) return rc;
     } else {
         if ((rc = w.ekey.ensure(entries * 4))) return rc;
         if ((rc = w.eval.ensure(entries * 4))) return rc;
@@ -66,10 +67,10 @@ static int run_msm(mina_ctx *c, const MsmShape &sh, const uint32_t *d_scalars, c
     const bool fused_finish = sh.nsets == sh.nprob && !d_out_words && d_out_xyzz;
     if (part_sort) {
         { ProfScope ps_(c, PS_DIGITS);
-          msm_part_kernel<false><<<ss.Gl * sh.nprob, 1024, 0, st>>>(sh, ss, d_scalars, w.ghist.as<uint32_t>(), nullptr);
+          msm_part_kernel<false><<<ss.Gl * sh.nprob, 1024, 0, st>>>(sh, ss, d_scalars, w.ghist.as<uint32_t>(), nullptr, w.ekey.as<uint32_t>());
           msm_excl_scan_kernel<<<1, 1024, 0, st>>>((uint32_t)gh_words, w.ghist.as<uint32_t>()); }
         { ProfScope ps_(c, PS_SCATTER);
-          msm_part_kernel<true><<<ss.Gl * sh.nprob, 1024, 0, st>>>(sh, ss, d_scalars, w.ghist.as<uint32_t>(), w.stage.as<uint2>());
+          msm_part_kernel<true><<<ss.Gl * sh.nprob, 1024, 0, st>>>(sh, ss, d_scalars, w.ghist.as<uint32_t>(), w.stage.as<uint2>(), w.ekey.as<uint32_t>());
           msm_part_sort_kernel<<<ss.Pl * sh.nprob, 1024, 0, st>>>(ss, w.ghist.as<uint32_t>(), w.stage.as<uint2>(), w.count.as<uint32_t>(), w.sorted.as<uint32_t>()); }
         { ProfScope ps_(c, PS_SCAN); msm_scan_kernel<<<1, 1024, 0, st>>>(nb_total, w.count.as<uint32_t>(), w.start.as<uint32_t>(), w.task_start.as<uint32_t>(),
                                                                        w.rem_pos.as<uint32_t>(), w.info.as<uint32_t>());

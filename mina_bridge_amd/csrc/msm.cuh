@@ -290,7 +290,9 @@ __device__ __forceinline__ void block_excl_scan_inplace(uint32_t n, uint32_t *__
 //                 SCATTER = true : gh holds the exclusive scan; entries go to staging[goff[p][blk] + rank].
 template <bool SCATTER>
 static __global__ void __launch_bounds__(1024)
-msm_part_kernel(MsmShape sh, SortShape ss, const uint32_t *__restrict__ scalars, uint32_t *__restrict__ gh, uint2 *__restrict__ staging) {
+msm_part_kernel(MsmShape sh, SortShape ss, const uint32_t *__restrict__ scalars, uint32_t *__restrict__ gh, uint2 *__restrict__ staging,
+                uint32_t *__restrict__ ekey /* n * W * nprob: (bucket within the problem | sign << 31) or MSM_INVALID, written by the
+                                               count pass so that the scatter pass does not cut the digits again */) {
     __shared__ uint32_t cur[1024];
     const uint32_t tid = threadIdx.x;
     const uint32_t m = blockIdx.x / ss.Gl, g = blockIdx.x - m * ss.Gl;            // problem, block within the problem
@@ -299,17 +301,25 @@ msm_part_kernel(MsmShape sh, SortShape ss, const uint32_t *__restrict__ scalars,
     __syncthreads();
     const uint32_t i = g * 256 + (tid & 255);                                     // scalar index within the problem
     if (i < sh.n) {
-        uint32_t s[8];
-        load_scalar(scalars + ((size_t)m * sh.n + i) * 8, s);
-        for (uint32_t w = tid >> 8; w < sh.W; w += 4) {
-            uint32_t bucket, ref;
-            if (!msm_entry(sh, s, m, w, i, bucket, ref)) continue;
-            const uint32_t lb = bucket - m * ss.SB, part = lb >> ss.fbits;
-            if (SCATTER) {
-                const uint32_t pos = atomicAdd(&cur[part], 1u);
+        uint32_t *ek = ekey + (size_t)m * sh.W * sh.n + i;                         // + w * n: coalesced over the 256 scalars of a window
+        if (SCATTER) {
+            for (uint32_t w = tid >> 8; w < sh.W; w += 4) {
+                const uint32_t key = ek[(size_t)w * sh.n];
+                if (key == MSM_INVALID) continue;
+                const uint32_t lb = key & 0x7fffffffu;
+                const uint32_t ref = (sh.table_stride ? w * sh.table_stride + sh.base_first + i : i) | (key & 0x80000000u);
+                const uint32_t pos = atomicAdd(&cur[lb >> ss.fbits], 1u);
                 staging[pos] = make_uint2(ref, lb & ((1u << ss.fbits) - 1u));
-            } else {
-                atomicAdd(&cur[part], 1u);
+            }
+        } else {
+            uint32_t s[8];
+            load_scalar(scalars + ((size_t)m * sh.n + i) * 8, s);
+            for (uint32_t w = tid >> 8; w < sh.W; w += 4) {
+                uint32_t bucket, ref;
+                if (!msm_entry(sh, s, m, w, i, bucket, ref)) { ek[(size_t)w * sh.n] = MSM_INVALID; continue; }
+                const uint32_t lb = bucket - m * ss.SB;
+                ek[(size_t)w * sh.n] = lb | (ref & 0x80000000u);
+                atomicAdd(&cur[lb >> ss.fbits], 1u);
             }
         }
     }
