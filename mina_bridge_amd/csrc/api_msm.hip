@@ -53,7 +53,7 @@ static int run_msm(mina_ctx *c, const MsmShape &sh, const uint32_t *d_scalars, c
     if ((rc = w.rem_bucket.ensure((size_t)nb_total * 4))) return rc;
     if ((rc = w.info.ensure(16))) return rc;
     if ((rc = w.partial.ensure(max_tasks * sizeof(xyzz_t)))) return rc;
-    if ((rc = w.heavy.ensure((max_tasks / MSM_HEAVY_TASKS + 2) * 4))) return rc;
+    if ((rc = w.heavy.ensure((max_tasks / MSM_HEAVY_TASKS + entries / MSM_HEAVY_ENTRIES + 2) * 4))) return rc;
     if ((rc = w.buckets.ensure((size_t)nb_total * sizeof(xyzz_t)))) return rc;
     if (sh.NB < 128 || sh.NB > 32768) return fail(MINA_ERR_ARG, "unsupported bucket count");
     if ((rc = w.red_r.ensure((size_t)(sh.NB / 128) * sh.nsets * sizeof(xyzz_t)))) return rc;
@@ -63,6 +63,10 @@ static int run_msm(mina_ctx *c, const MsmShape &sh, const uint32_t *d_scalars, c
     if ((rc = w.set_total.ensure((size_t)sh.nsets * sizeof(xyzz_t)))) return rc;
 
     hipStream_t st = c->L->stream;
+    // throughput form (one lane per bucket over count-ranked buckets) when enough buckets are in flight to fill the chip
+    static const bool no_bucket_lanes = getenv("MINA_MSM_TASKS") != nullptr;             // A/B switch for profiling
+    const bool bucket_lanes = !no_bucket_lanes && part_sort && (c->nlanes > 1 || sh.nprob >= 4);
+    if (bucket_lanes && (rc = w.order.ensure((size_t)nb_total * 4))) return rc;
     // one bucket set per problem and no affine output wanted: the reduction kernel's result IS the answer (no finish launch)
     const bool fused_finish = sh.nsets == sh.nprob && !d_out_words && d_out_xyzz;
     if (part_sort) {
@@ -72,9 +76,14 @@ static int run_msm(mina_ctx *c, const MsmShape &sh, const uint32_t *d_scalars, c
         { ProfScope ps_(c, PS_SCATTER);
           msm_part_kernel<true><<<ss.Gl * sh.nprob, 1024, 0, st>>>(sh, ss, d_scalars, w.ghist.as<uint32_t>(), w.stage.as<uint2>(), w.ekey.as<uint32_t>());
           msm_part_sort_kernel<<<ss.Pl * sh.nprob, 1024, 0, st>>>(ss, w.ghist.as<uint32_t>(), w.stage.as<uint2>(), w.count.as<uint32_t>(), w.sorted.as<uint32_t>()); }
-        { ProfScope ps_(c, PS_SCAN); msm_scan_kernel<<<1, 1024, 0, st>>>(nb_total, w.count.as<uint32_t>(), w.start.as<uint32_t>(), w.task_start.as<uint32_t>(),
+        if (bucket_lanes) {
+            ProfScope ps_(c, PS_SCAN);
+            msm_order_kernel<<<1, 1024, 0, st>>>(nb_total, w.count.as<uint32_t>(), w.start.as<uint32_t>(), w.order.as<uint32_t>(), w.info.as<uint32_t>(), w.heavy.as<uint32_t>());
+        } else {
+            ProfScope ps_(c, PS_SCAN); msm_scan_kernel<<<1, 1024, 0, st>>>(nb_total, w.count.as<uint32_t>(), w.start.as<uint32_t>(), w.task_start.as<uint32_t>(),
                                                                        w.rem_pos.as<uint32_t>(), w.info.as<uint32_t>());
-                                     msm_rem_invert_kernel<<<cdiv(nb_total, 256), 256, 0, st>>>(nb_total, w.rem_pos.as<uint32_t>(), w.rem_bucket.as<uint32_t>()); }
+                                     msm_rem_invert_kernel<<<cdiv(nb_total, 256), 256, 0, st>>>(nb_total, w.rem_pos.as<uint32_t>(), w.rem_bucket.as<uint32_t>());
+        }
     } else {
         HIPC(hipMemsetAsync(w.count.p, 0, (size_t)nb_total * 4, st));
         { ProfScope ps_(c, PS_DIGITS); msm_digits_kernel<<<cdiv(entries, 256), 256, 0, st>>>(sh, d_scalars, w.count.as<uint32_t>(), w.ekey.as<uint32_t>(),
@@ -85,17 +94,24 @@ static int run_msm(mina_ctx *c, const MsmShape &sh, const uint32_t *d_scalars, c
         { ProfScope ps_(c, PS_SCATTER); msm_scatter_kernel<<<cdiv(entries, 256), 256, 0, st>>>(entries, w.ekey.as<uint32_t>(), w.eval.as<uint32_t>(),
                                                                w.eoff.as<uint32_t>(), w.start.as<uint32_t>(), w.sorted.as<uint32_t>()); }
     }
-    { ProfScope ps_(c, PS_ACCUMULATE); msm_accumulate_kernel<F><<<cdiv(max_tasks, 256), 256, 0, st>>>(nb_total, w.start.as<uint32_t>(), w.task_start.as<uint32_t>(),
-                                                                   w.rem_bucket.as<uint32_t>(), w.info.as<uint32_t>(), w.sorted.as<uint32_t>(), d_points, fk.one, w.partial.as<xyzz_t>()); }
-    { ProfScope ps_(c, PS_BUCKET_SUM);
-      if (c->nlanes > 1)
-          msm_bucket_sum_lane_kernel<F><<<cdiv(nb_total, 256), 256, 0, st>>>(nb_total, w.task_start.as<uint32_t>(), w.rem_pos.as<uint32_t>(), w.info.as<uint32_t>(), w.partial.as<xyzz_t>(),
-                                                                  w.buckets.as<xyzz_t>(), w.heavy.as<uint32_t>());
-      else
-          msm_bucket_sum_kernel<F><<<cdiv((size_t)nb_total * 4, 256), 256, 0, st>>>(nb_total, w.task_start.as<uint32_t>(), w.rem_pos.as<uint32_t>(), w.info.as<uint32_t>(), w.partial.as<xyzz_t>(),
-                                                                  w.buckets.as<xyzz_t>(), w.heavy.as<uint32_t>());
-                                       msm_bucket_sum_heavy_kernel<F><<<128, 256, 0, st>>>(w.task_start.as<uint32_t>(), w.rem_pos.as<uint32_t>(), w.info.as<uint32_t>(), w.partial.as<xyzz_t>(),
-                                                                  w.buckets.as<xyzz_t>(), w.heavy.as<uint32_t>()); }
+    if (bucket_lanes) {
+        { ProfScope ps_(c, PS_ACCUMULATE);
+          msm_accumulate_bucket_kernel<F><<<cdiv(nb_total, 256), 256, 0, st>>>(nb_total, w.start.as<uint32_t>(), w.order.as<uint32_t>(), w.sorted.as<uint32_t>(), d_points, fk.one, w.buckets.as<xyzz_t>()); }
+        { ProfScope ps_(c, PS_BUCKET_SUM);
+          msm_bucket_heavy_entries_kernel<F><<<128, 256, 0, st>>>(w.start.as<uint32_t>(), w.info.as<uint32_t>(), w.heavy.as<uint32_t>(), w.sorted.as<uint32_t>(), d_points, fk.one, w.buckets.as<xyzz_t>()); }
+    } else {
+        { ProfScope ps_(c, PS_ACCUMULATE); msm_accumulate_kernel<F><<<cdiv(max_tasks, 256), 256, 0, st>>>(nb_total, w.start.as<uint32_t>(), w.task_start.as<uint32_t>(),
+                                                                       w.rem_bucket.as<uint32_t>(), w.info.as<uint32_t>(), w.sorted.as<uint32_t>(), d_points, fk.one, w.partial.as<xyzz_t>()); }
+        { ProfScope ps_(c, PS_BUCKET_SUM);
+          if (c->nlanes > 1)
+              msm_bucket_sum_lane_kernel<F><<<cdiv(nb_total, 256), 256, 0, st>>>(nb_total, w.task_start.as<uint32_t>(), w.rem_pos.as<uint32_t>(), w.info.as<uint32_t>(), w.partial.as<xyzz_t>(),
+                                                                      w.buckets.as<xyzz_t>(), w.heavy.as<uint32_t>());
+          else
+              msm_bucket_sum_kernel<F><<<cdiv((size_t)nb_total * 4, 256), 256, 0, st>>>(nb_total, w.task_start.as<uint32_t>(), w.rem_pos.as<uint32_t>(), w.info.as<uint32_t>(), w.partial.as<xyzz_t>(),
+                                                                      w.buckets.as<xyzz_t>(), w.heavy.as<uint32_t>());
+                                           msm_bucket_sum_heavy_kernel<F><<<128, 256, 0, st>>>(w.task_start.as<uint32_t>(), w.rem_pos.as<uint32_t>(), w.info.as<uint32_t>(), w.partial.as<xyzz_t>(),
+                                                                      w.buckets.as<xyzz_t>(), w.heavy.as<uint32_t>()); }
+    }
     {
         // 2-D bucket reduction: C = 128 columns, R = NB / C rows (NB is a power of two in [128, 32768])
         const uint32_t C = 128, log2C = 7, R = sh.NB / C;

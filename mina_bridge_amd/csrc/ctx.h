@@ -62,7 +62,7 @@ struct SrsState {
 };
 
 struct MsmWorkspace {
-    DevBuf scalars, points, ekey, eval, eoff, count, start, task_start, rem_pos, rem_bucket, info, sorted, partial, heavy, ghist, stage, buckets, red_r, red_ws, red2_r, red2_w, set_total, out_words, out_xyzz;
+    DevBuf scalars, points, ekey, eval, eoff, count, start, task_start, rem_pos, rem_bucket, info, sorted, partial, heavy, order, ghist, stage, buckets, red_r, red_ws, red2_r, red2_w, set_total, out_words, out_xyzz;
 };
 
 // HIP-event stage timing on the context stream (off by default; bench.py turns it on for the timed region)
@@ -86,7 +86,7 @@ struct Lane {
     DevBuf ipa_chals, ipa_folded, ipa_xyzz_a, ipa_xyzz_b, ipa_points, ipa_scalars, ipa_sigma, ipa_in_a, ipa_in_b, ipa_in_c, ipa_verdict;
     void release_all() {
         MsmWorkspace &w = ws;
-        DevBuf *all[] = {&w.scalars, &w.points, &w.ekey, &w.eval, &w.eoff, &w.count, &w.start, &w.task_start, &w.rem_pos, &w.rem_bucket, &w.info, &w.sorted, &w.partial, &w.heavy, &w.ghist, &w.stage,
+        DevBuf *all[] = {&w.scalars, &w.points, &w.ekey, &w.eval, &w.eoff, &w.count, &w.start, &w.task_start, &w.rem_pos, &w.rem_bucket, &w.info, &w.sorted, &w.partial, &w.heavy, &w.order, &w.ghist, &w.stage,
                          &w.buckets, &w.red_r, &w.red_ws, &w.red2_r, &w.red2_w, &w.set_total, &w.out_words, &w.out_xyzz, &tmp_a, &tmp_b, &tmp_c, &tmp_d,
                          &bp_ltab, &bp_htab, &bp_partial, &ipa_chals, &ipa_folded, &ipa_xyzz_a, &ipa_xyzz_b, &ipa_points, &ipa_scalars,
                          &ipa_sigma, &ipa_in_a, &ipa_in_b, &ipa_in_c, &ipa_verdict};

@@ -505,6 +505,130 @@ template <int F> __device__ __forceinline__ xyzz_t quadwave_sum(xyzz_t v, int wi
     return v;
 }
 
+// ---------------------------------------------------------------- K1t: throughput form of K1b/K1d/K1e
+// With many MSMs in flight (pipelined lanes, groups of problems) there are enough buckets to give every bucket its OWN
+// lane: no tasks, no partials, no level-2 sums -- 31 mixed adds per bucket instead of 27.6 mixed + 3.4 full adds, and
+// 38 MB less traffic per MSM.  Lanes of a wave must then run equally long: K1t-a ranks the buckets by entry count
+// (descending, 64 classes; ties in any order), so a wave holds 64 buckets of one class and the longest waves start first.
+// Buckets beyond MSM_HEAVY_ENTRIES entries are queued for the block-wide kernel K1t-c.
+static constexpr uint32_t MSM_HEAVY_ENTRIES = 192;
+static constexpr uint32_t MSM_COUNT_CLASSES = 64;
+
+// K1t-a: one block.  start[b] = exclusive prefix of count (start[nb] = total); order[rank] = bucket, ranked by
+// min(count, 63) descending; heavy[] / info[2] = buckets with more than MSM_HEAVY_ENTRIES entries.
+static __global__ void __launch_bounds__(1024)
+msm_order_kernel(uint32_t nb_total, const uint32_t *__restrict__ count, uint32_t *__restrict__ start, uint32_t *__restrict__ order,
+                 uint32_t *__restrict__ info, uint32_t *__restrict__ heavy) {
+    __shared__ uint32_t s_tot[1][16], s_pre[1][16], s_all[1];
+    __shared__ uint32_t cls_n[MSM_COUNT_CLASSES], cls_cur[MSM_COUNT_CLASSES], n_heavy;
+    const uint32_t tid = threadIdx.x, row_elems = blockDim.x * 4, nrows = (nb_total + row_elems - 1) / row_elems;
+    if (tid < MSM_COUNT_CLASSES) cls_n[tid] = 0;
+    if (tid == 0) n_heavy = 0;
+    __syncthreads();
+    uint32_t carry = 0;
+    for (uint32_t row = 0; row < nrows; ++row) {                 // pass 1: prefix of the counts + class histogram
+        const uint32_t idx = row * row_elems + tid * 4;
+        uint4 c4 = make_uint4(0, 0, 0, 0);
+        if (idx < nb_total) c4 = *reinterpret_cast<const uint4 *>(count + idx);
+        const uint32_t c[4] = {c4.x, c4.y, c4.z, c4.w};
+        uint32_t v[1] = {c[0] + c[1] + c[2] + c[3]}, tot[1];
+        block_exclusive_scan<1>(v, tot, s_tot, s_pre, s_all);
+        const uint32_t p0 = carry + v[0];
+        if (idx < nb_total) {
+            *reinterpret_cast<uint4 *>(start + idx) = make_uint4(p0, p0 + c[0], p0 + c[0] + c[1], p0 + c[0] + c[1] + c[2]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomicAdd(&cls_n[c[e] < MSM_COUNT_CLASSES - 1 ? c[e] : MSM_COUNT_CLASSES - 1], 1u);
+        }
+        carry += tot[0];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        start[nb_total] = carry;
+        uint32_t run = 0;                                        // descending classes: 63, 62, ..., 0
+        for (int k = MSM_COUNT_CLASSES - 1; k >= 0; --k) { cls_cur[k] = run; run += cls_n[k]; }
+    }
+    __syncthreads();
+    for (uint32_t row = 0; row < nrows; ++row) {                 // pass 2: ranks
+        const uint32_t idx = row * row_elems + tid * 4;
+        if (idx >= nb_total) continue;
+        const uint4 c4 = *reinterpret_cast<const uint4 *>(count + idx);
+        const uint32_t c[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const uint32_t k = c[e] < MSM_COUNT_CLASSES - 1 ? c[e] : MSM_COUNT_CLASSES - 1;
+            order[atomicAdd(&cls_cur[k], 1u)] = idx + e;
+            if (c[e] > MSM_HEAVY_ENTRIES) heavy[atomicAdd(&n_heavy, 1u)] = idx + e;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) info[2] = n_heavy;
+}
+
+// K1t-b: bucket = sum of its sorted entries, one lane per bucket in rank order.
+template <int F>
+__global__ void __launch_bounds__(256)
+msm_accumulate_bucket_kernel(uint32_t nb_total, const uint32_t *__restrict__ start, const uint32_t *__restrict__ order,
+                             const uint32_t *__restrict__ sorted, const affine_t *__restrict__ points, fe_t one,
+                             xyzz_t *__restrict__ buckets) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nb_total) return;
+    const uint32_t b = order[r];
+    const uint32_t beg = start[b], cnt = start[b + 1] - beg;
+    if (cnt > MSM_HEAVY_ENTRIES) return;                         // K1t-c writes it
+    xyzz_t acc = xyzz_inf();
+    if (cnt) {
+        uint32_t ref = sorted[beg], ref_n = cnt > 1 ? sorted[beg + 1] : 0u;
+        affine_t nxt = load_affine(points + (ref & 0x7fffffffu));
+#pragma unroll 1
+        for (uint32_t e = 0; e < cnt; ++e) {                     // the point of entry e+1 and the reference of e+2 are in flight
+            affine_t p = nxt;
+            const uint32_t cur = ref;
+            ref = ref_n;
+            if (e + 1 < cnt) nxt = load_affine(points + (ref & 0x7fffffffu));
+            if (e + 2 < cnt) ref_n = sorted[beg + e + 2];
+            if (aff_is_inf(p)) continue;
+            if (cur >> 31) p.y = fe_neg<F>(p.y);
+            xyzz_add_affine<F>(acc, p.x, p.y, one);
+        }
+    }
+    buckets[b] = acc;
+}
+
+// K1t-c: heavy buckets, one 256-lane block each (grid-stride over the queue): lane t sums entries t, t+256, ..., then a
+// wave tree (shuffles) and a 4-wave tree through LDS.
+template <int F>
+__global__ void __launch_bounds__(256)
+msm_bucket_heavy_entries_kernel(const uint32_t *__restrict__ start, const uint32_t *__restrict__ info, const uint32_t *__restrict__ heavy,
+                                const uint32_t *__restrict__ sorted, const affine_t *__restrict__ points, fe_t one,
+                                xyzz_t *__restrict__ buckets) {
+    __shared__ xyzz_t sh[4];
+    const uint32_t nheavy = info[2], lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
+        const uint32_t b = heavy[h], beg = start[b], end = start[b + 1];
+        xyzz_t acc = xyzz_inf();
+        for (uint32_t e = beg + threadIdx.x; e < end; e += 256) {
+            const uint32_t ref = sorted[e];
+            affine_t p = load_affine(points + (ref & 0x7fffffffu));
+            if (aff_is_inf(p)) continue;
+            if (ref >> 31) p.y = fe_neg<F>(p.y);
+            xyzz_add_affine<F>(acc, p.x, p.y, one);
+        }
+#pragma unroll 1
+        for (int d = 32; d >= 1; d >>= 1) {
+            xyzz_t o = shfl_down_xyzz(acc, d);
+            if ((int)lane + d < 64) xyzz_add<F>(acc, o);
+        }
+        __syncthreads();                                         // sh may still be read from the previous bucket
+        if (lane == 0) sh[wave] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            xyzz_t v = sh[0];
+            xyzz_add<F>(v, sh[1]); xyzz_add<F>(v, sh[2]); xyzz_add<F>(v, sh[3]);
+            buckets[b] = v;
+        }
+    }
+}
+
 // K1e': heavy buckets, one 256-lane block (64 quads) each: quad q sums partials lo+q, lo+q+64, ... , then a wave tree
 // and a 4-wave tree through LDS.  Grid-stride over the list K1e built; the launch is fixed-size (no host round trip).
 template <int F>
