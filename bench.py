@@ -45,9 +45,9 @@ ACCUMULATE_TRAFFIC_BYTES = 86_810_000
 # VALU side of the roofline (the path is integer-multiply bound): one Montgomery product is 88
 # v_mad_u64_u32 (8 cycles per wave64 instruction, profiles/r01_microbench_valu.jsonl) -> issue floor 704 cycles.
 MODMUL_ISSUE_FLOOR_CYCLES = 88 * 8
-# entries E = one per non-zero signed 16-bit digit; the first entry of every task is a copy, not an add; with Poisson(32)
-# bucket sizes there are E[ceil(c/8)] = 4.4375 tasks per bucket -> adds = E - 32768 * 4.4375
-MIXED_ADDS_PER_MSM = 16 * N_BASES * (1 - 2 ** -16) - 32768 * 4.4375
+# entries E = one per non-zero signed 16-bit digit; in the throughput form of the accumulate kernel (one lane per bucket,
+# used from 4 MSMs per launch or with pipelined lanes) the first entry of each of the 32768 buckets is a copy, not an add
+MIXED_ADDS_PER_MSM = 16 * N_BASES * (1 - 2 ** -16) - 32768
 MODMUL_PER_MIXED_ADD = 10                                # XYZZ madd-2008-s: 8M + 2S
 CHIP_SIMDS, CLOCK_HZ = 1024, 2.4e9
 
@@ -246,7 +246,7 @@ def main():
                                    "vesta.srs + compare), bit-exact vs CPU oracle", "curve": "vesta", "n_bases": N_BASES,
                        "proofs_per_step": B * G, "mode": (f"{G} independent checks per kernel pipeline, no folding" if B == 1 else f"{B} proofs folded into one MSM"),
                        "pipeline_lanes": args.pipeline, "sharding": f"proof-level, {args.gpus} rank(s), no collective"},
-            "roofline": {"bound": "hbm", "kernel": "msm_accumulate_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "msm_accumulate_bucket_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": msms * ACCUMULATE_TRAFFIC_BYTES,
                          "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r01h_rocprof.md",
                          "traffic_GBps": msms * ACCUMULATE_TRAFFIC_BYTES / kern_s / 1e9 if launches else None,
