@@ -63,9 +63,10 @@ static int run_msm(mina_ctx *c, const MsmShape &sh, const uint32_t *d_scalars, c
     if ((rc = w.set_total.ensure((size_t)sh.nsets * sizeof(xyzz_t)))) return rc;
 
     hipStream_t st = c->L->stream;
-    // throughput form (one lane per bucket over count-ranked buckets) when enough buckets are in flight to fill the chip
+    // throughput form (one lane per pair of count-ranked buckets) when one launch carries enough buckets to fill the chip;
+    // a single MSM's 32768 buckets would leave it latency-bound (16 pipelined lanes: 6.2 k proofs/s against 7.6 k with tasks)
     static const bool no_bucket_lanes = getenv("MINA_MSM_TASKS") != nullptr;             // A/B switch for profiling
-    const bool bucket_lanes = !no_bucket_lanes && part_sort && (c->nlanes > 1 || sh.nprob >= 4);
+    const bool bucket_lanes = !no_bucket_lanes && part_sort && sh.nprob >= 4;             // >= 64 k lanes of ~62 adds each
     if (bucket_lanes && (rc = w.order.ensure((size_t)nb_total * 4))) return rc;
     // one bucket set per problem and no affine output wanted: the reduction kernel's result IS the answer (no finish launch)
     const bool fused_finish = sh.nsets == sh.nprob && !d_out_words && d_out_xyzz;
