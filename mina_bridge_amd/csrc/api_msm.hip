@@ -48,11 +48,20 @@ static int run_msm(mina_ctx *c, const MsmShape &sh, const uint32_t *d_scalars, c
     if ((rc = w.sorted.ensure(entries * 4))) return rc;
     if ((rc = w.count.ensure((size_t)nb_total * 4))) return rc;
     if ((rc = w.start.ensure(((size_t)nb_total + 1) * 4))) return rc;
-    if ((rc = w.task_start.ensure(((size_t)nb_total + 1) * 4))) return rc;
-    if ((rc = w.rem_pos.ensure((size_t)nb_total * 4))) return rc;
-    if ((rc = w.rem_bucket.ensure((size_t)nb_total * 4))) return rc;
+    // throughput form of the accumulate (one lane per pair of count-ranked buckets, K1t) when one launch carries enough
+    // buckets to fill the chip; a single MSM's 32768 buckets would leave it latency-bound (16 pipelined lanes: 6.2 k
+    // proofs/s against 7.6 k with tasks)
+    static const bool no_bucket_lanes = getenv("MINA_MSM_TASKS") != nullptr;             // A/B switch for profiling
+    const bool bucket_lanes = !no_bucket_lanes && part_sort && sh.nprob >= 4;             // >= 64 k lanes of ~62 adds each
+    if (bucket_lanes) {
+        if ((rc = w.order.ensure((size_t)nb_total * 4))) return rc;
+    } else {                                                    // task numbering and the 128-B task partials
+        if ((rc = w.task_start.ensure(((size_t)nb_total + 1) * 4))) return rc;
+        if ((rc = w.rem_pos.ensure((size_t)nb_total * 4))) return rc;
+        if ((rc = w.rem_bucket.ensure((size_t)nb_total * 4))) return rc;
+        if ((rc = w.partial.ensure(max_tasks * sizeof(xyzz_t)))) return rc;
+    }
     if ((rc = w.info.ensure(16))) return rc;
-    if ((rc = w.partial.ensure(max_tasks * sizeof(xyzz_t)))) return rc;
     if ((rc = w.heavy.ensure((max_tasks / MSM_HEAVY_TASKS + entries / MSM_HEAVY_ENTRIES + 2) * 4))) return rc;
     if ((rc = w.buckets.ensure((size_t)nb_total * sizeof(xyzz_t)))) return rc;
     if (sh.NB < 128 || sh.NB > 32768) return fail(MINA_ERR_ARG, "unsupported bucket count");
@@ -63,11 +72,6 @@ static int run_msm(mina_ctx *c, const MsmShape &sh, const uint32_t *d_scalars, c
     if ((rc = w.set_total.ensure((size_t)sh.nsets * sizeof(xyzz_t)))) return rc;
 
     hipStream_t st = c->L->stream;
-    // throughput form (one lane per pair of count-ranked buckets) when one launch carries enough buckets to fill the chip;
-    // a single MSM's 32768 buckets would leave it latency-bound (16 pipelined lanes: 6.2 k proofs/s against 7.6 k with tasks)
-    static const bool no_bucket_lanes = getenv("MINA_MSM_TASKS") != nullptr;             // A/B switch for profiling
-    const bool bucket_lanes = !no_bucket_lanes && part_sort && sh.nprob >= 4;             // >= 64 k lanes of ~62 adds each
-    if (bucket_lanes && (rc = w.order.ensure((size_t)nb_total * 4))) return rc;
     // one bucket set per problem and no affine output wanted: the reduction kernel's result IS the answer (no finish launch)
     const bool fused_finish = sh.nsets == sh.nprob && !d_out_words && d_out_xyzz;
     if (part_sort) {
