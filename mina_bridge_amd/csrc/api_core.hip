@@ -72,7 +72,11 @@ extern "C" void mina_ctx_destroy(mina_ctx *c) {
     for (int i = 0; i < 2; ++i) { c->srs[i].table.release(); c->srs[i].h.release(); c->pparams[i].release(); c->merkle_salts[i].release(); }
     for (int i = 0; i < MB_MAX_LANES; ++i) c->lanes[i].release_all();
     for (auto &r : c->prof.recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
-    for (int i = 0; i < MB_MAX_LANES; ++i) if (c->lanes[i].stream) (void)hipStreamDestroy(c->lanes[i].stream);
+    for (int i = 0; i < MB_MAX_LANES; ++i) {
+        Lane &L = c->lanes[i];
+        if (L.aux) { (void)hipStreamSynchronize(L.aux); (void)hipStreamDestroy(L.aux); (void)hipEventDestroy(L.ev_fork); (void)hipEventDestroy(L.ev_join); }
+        if (L.stream) (void)hipStreamDestroy(L.stream);
+    }
     delete c;
 }
 

@@ -122,7 +122,12 @@ template <int FB> __device__ __forceinline__ affine_t load_point_checked(const u
 // One lane group (4 or 8 lanes) per proof: the Fq-sponge runs lane-cooperatively (6.3 / 4.65 dependent product latencies per
 // Poseidon round instead of 21), all other (scalar-field) work is computed redundantly by the lanes, lane 0 writes.
 // CURVE fixes (FB, FS).
-template <int CURVE, int LANES>
+// PHASE 0: the whole transcript.  PHASE 1 / 2: split at the first squeeze -- `U = to_group(t)` (an inversion and 1-3 square
+// roots, ~0.75 ms of dependent products) is not fed back into the sponge, so it runs as its own kernel on a second stream
+// while PHASE 2 continues the transcript; the sponge is handed over through `xfer` (40 words per proof: state in
+// Montgomery form, position, t).
+static constexpr uint32_t IPA_XFER_WORDS = 40;
+template <int CURVE, int LANES, int PHASE>
 __global__ void __launch_bounds__(64)
 ipa_prepare_kernel(IpaShape sh, FieldK kb, FieldK ks, const PoseidonParams *__restrict__ pp,
                    const uint32_t *__restrict__ sponge_state /* b*24 */, const uint32_t *__restrict__ sponge_pos /* b*2 */,
@@ -135,31 +140,38 @@ ipa_prepare_kernel(IpaShape sh, FieldK kb, FieldK ks, const PoseidonParams *__re
                    const affine_t *__restrict__ srs_h,
                    affine_t *__restrict__ out_points /* b*per */, uint32_t *__restrict__ out_scalars /* b*per*8 canonical */,
                    uint32_t *__restrict__ out_chals /* b*k*8 canonical */, uint32_t *__restrict__ out_sigma /* b*8 canonical */,
-                   uint32_t *__restrict__ bad_input /* zeroed by the host; set to 1 on a malformed point */) {
+                   uint32_t *__restrict__ bad_input /* zeroed by the host; set to 1 on a malformed point */,
+                   uint32_t *__restrict__ xfer /* PHASE 1 writes, PHASE 2 reads: b * IPA_XFER_WORDS */) {
     constexpr int FB = (CURVE == CURVE_PALLAS) ? FIELD_FP : FIELD_FQ;
     constexpr int FS = (CURVE == CURVE_PALLAS) ? FIELD_FQ : FIELD_FP;
     const uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) / LANES;
     if (b >= sh.batch) return;                                // whole lane groups leave together
     const uint32_t k = sh.k;
     bool pts_ok = true;                                       // every input well-formed (canonical field elements, points on the curve)
+    const uint32_t ln = threadIdx.x & (LANES - 1);
+    uint32_t *xf = xfer ? xfer + (size_t)b * IPA_XFER_WORDS : nullptr;
 
     // ---- Fq-sponge transcript (base field)
     DevSponge<FB, LANES> sp; sp.pp = pp; sp.squeezed = 0; sp.count = 0;
-    {
+    if (PHASE == 2) {                                         // resume after the first squeeze
+        sp.s = load_fe<FB>(xf + coop_elem<LANES>() * 8);
+        sp.squeezed = (int)xf[24]; sp.count = (int)xf[25];
+    } else {
         const fe_t w = load_fe<FB>(sponge_state + (size_t)b * 24 + coop_elem<LANES>() * 8);
         bool okw = true;                                      // all three state elements, checked redundantly by every lane
         for (int e = 0; e < 3; ++e) okw = okw && fe_words_canonical<FB>(load_fe<FB>(sponge_state + (size_t)b * 24 + e * 8));
         pts_ok = pts_ok && okw;
         sp.s = fe_to_mont<FB>(w, kb.r2);
     }
-    sp.squeezed = (int)sponge_pos[2 * b]; sp.count = (int)sponge_pos[2 * b + 1];
+    if (PHASE != 2) { sp.squeezed = (int)sponge_pos[2 * b]; sp.count = (int)sponge_pos[2 * b + 1]; }
     auto load_scalar_checked = [&](const uint32_t *p) {           // scalar-field element: canonical or the batch is rejected
         const fe_t w = load_fe<FS>(p);
         pts_ok = pts_ok && fe_words_canonical<FS>(w);
         return fe_to_mont<FS>(w, ks.r2);
     };
-    const fe_t cip_m = load_scalar_checked(cip + (size_t)b * 8);
-    {   // absorb_fr(shift_scalar(cip))
+    const fe_t cip_m = PHASE == 2 ? fe_to_mont<FS>(load_fe<FS>(cip + (size_t)b * 8), ks.r2) : load_scalar_checked(cip + (size_t)b * 8);
+    affine_t U; U.x = fe_zero(); U.y = fe_zero();
+    if (PHASE != 2) {   // absorb_fr(shift_scalar(cip))
         const fe_t two255 = ks.two255;
         if (CURVE == CURVE_PALLAS) {
             // scalar modulus > base modulus: x = cip - 2^255 ; absorb (x >> 1), then (x & 1)
@@ -173,9 +185,16 @@ ipa_prepare_kernel(IpaShape sh, FieldK kb, FieldK ks, const PoseidonParams *__re
             fe_t x = fe_from_mont<FS>(fe_mul<FS>(fe_sub<FS>(cip_m, fe_add<FS>(two255, ks.one)), ks.inv2));
             sp.absorb(fe_to_mont<FB>(x, kb.r2));
         }
+        const fe_t t = sp.squeeze();                          // challenge_fq
+        if (PHASE == 1) {                                     // hand over: state (owner lanes), position, t; flag; done
+            const bool owner = LANES == 8 ? (ln < 6 && !(ln & 1u)) : (ln < 3);
+            if (owner) for (int i = 0; i < 8; ++i) xf[coop_elem<LANES>() * 8 + i] = sp.s.v[i];
+            if (ln == 0) { xf[24] = (uint32_t)sp.squeezed; xf[25] = (uint32_t)sp.count; for (int i = 0; i < 8; ++i) xf[26 + i] = t.v[i]; }
+            if (!pts_ok && ln == 0) *bad_input = 1u;
+            return;
+        }
+        U = bw_to_group<FB>(t, kb);
     }
-    const fe_t t = sp.squeeze();                              // challenge_fq
-    const affine_t U = bw_to_group<FB>(t, kb);
 
     affine_t *pts = out_points + (size_t)b * sh.per;
     uint32_t *scs = out_scalars + (size_t)b * sh.per * 8;
@@ -235,7 +254,7 @@ ipa_prepare_kernel(IpaShape sh, FieldK kb, FieldK ks, const PoseidonParams *__re
     store_pt<LANES>(&pts[0], *srs_h);               store_fe<LANES>(scs + 0 * 8, fe_from_mont<FS>(fe_mul<FS>(neg_rho, z2m)));
     store_pt<LANES>(&pts[1], load_point_checked<FB>(sg + (size_t)b * 16, kb, pts_ok));
     store_fe<LANES>(scs + 1 * 8, fe_from_mont<FS>(fe_sub<FS>(fe_mul<FS>(neg_rho, z1m), sigma)));
-    store_pt<LANES>(&pts[2], U);
+    if (PHASE == 0) store_pt<LANES>(&pts[2], U);                // PHASE 2: written by ipa_to_group_kernel
     store_fe<LANES>(scs + 2 * 8, fe_from_mont<FS>(fe_add<FS>(fe_mul<FS>(fe_mul<FS>(neg_rho, z1m), b0), fe_mul<FS>(rho_c, cip_m))));
     store_pt<LANES>(&pts[3], D);                    store_fe<LANES>(scs + 3 * 8, fe_from_mont<FS>(rho));
     {   // chal^-1 for all rounds with ONE inversion (Montgomery's trick, as upstream's ark_ff::batch_inversion)
@@ -258,6 +277,16 @@ ipa_prepare_kernel(IpaShape sh, FieldK kb, FieldK ks, const PoseidonParams *__re
     }
     store_fe<LANES>(out_sigma + (size_t)b * 8, fe_from_mont<FS>(sigma));
     if (!pts_ok && coop_writer<LANES>()) *bad_input = 1u;         // any malformed point in any proof: the batch verdict is 0
+}
+
+// U_b = to_group(t_b) for the split transcript: one lane per proof, t in Montgomery form from the hand-over buffer
+template <int FB>
+__global__ void __launch_bounds__(64)
+ipa_to_group_kernel(uint32_t batch, uint32_t per, FieldK kb, const uint32_t *__restrict__ xfer, affine_t *__restrict__ out_points) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    const fe_t t = load_fe<FB>(xfer + (size_t)b * IPA_XFER_WORDS + 26);
+    out_points[(size_t)b * per + 2] = bw_to_group<FB>(t, kb);
 }
 
 // verdict[0] = 1 iff  A + sign * B == identity  (sign = +1: A == -B ; sign = -1: A == B)
@@ -495,14 +524,26 @@ extern "C" int mina_ipa_batch_check(mina_ctx *c, int curve, size_t batch, const 
     if ((rc = c->L->ipa_verdict.ensure(8))) return rc;          // [0] verdict, [1] malformed-input flag
     HIPC(hipMemsetAsync(c->L->ipa_verdict.p, 0, 8, c->L->stream));
     const PoseidonParams *pp = c->pparams[FB].as<PoseidonParams>();
-#define IPA_PREP(CV, LN)                                                                                                      \
-    mb::ipa_prepare_kernel<CV, LN><<<cdiv(batch * LN, 64), 64, 0, c->L->stream>>>(                                                    \
+#define IPA_PREP(CV, LN, PH, STREAM)                                                                                          \
+    mb::ipa_prepare_kernel<CV, LN, PH><<<cdiv(batch * LN, 64), 64, 0, STREAM>>>(                                                      \
         sh, c->fk[FB], c->fk[FS], pp, W(o_state), W(o_pos), W(o_cip), W(o_lr), W(o_delta), W(o_sg), W(o_z1), W(o_z2), W(o_pts), W(o_r), \
         W(o_xi), W(o_comms), W(o_rb), W(o_sb), s.h.as<affine_t>(), c->L->ipa_points.as<affine_t>(), c->L->ipa_scalars.as<uint32_t>(), \
-        c->L->ipa_chals.as<uint32_t>(), c->L->ipa_sigma.as<uint32_t>(), c->L->ipa_verdict.as<uint32_t>() + 1)
-    // latency-bound batches: 8 lanes per transcript; larger ones 4
-    if (batch <= COOP8_MAX_GROUPS) { if (curve == CURVE_PALLAS) IPA_PREP(CURVE_PALLAS, 8); else IPA_PREP(CURVE_VESTA, 8); }
-    else { if (curve == CURVE_PALLAS) IPA_PREP(CURVE_PALLAS, 4); else IPA_PREP(CURVE_VESTA, 4); }
+        c->L->ipa_chals.as<uint32_t>(), c->L->ipa_sigma.as<uint32_t>(), c->L->ipa_verdict.as<uint32_t>() + 1, c->L->ipa_xfer.as<uint32_t>())
+    if (batch <= COOP8_MAX_GROUPS) {
+        // latency-bound batch: 8 lanes per transcript, and to_group on a second stream beside the rest of the transcript
+        Lane &L = *c->L;
+        if ((rc = L.ipa_xfer.ensure(batch * mb::IPA_XFER_WORDS * 4))) return rc;
+        if (!L.aux) { HIPC(hipStreamCreateWithFlags(&L.aux, hipStreamNonBlocking)); HIPC(hipEventCreateWithFlags(&L.ev_fork, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&L.ev_join, hipEventDisableTiming)); }
+        if (curve == CURVE_PALLAS) IPA_PREP(CURVE_PALLAS, 8, 1, L.stream); else IPA_PREP(CURVE_VESTA, 8, 1, L.stream);
+        HIPC(hipEventRecord(L.ev_fork, L.stream));
+        HIPC(hipStreamWaitEvent(L.aux, L.ev_fork, 0));
+        DISPATCH_FIELD(FB, { mb::ipa_to_group_kernel<F_><<<cdiv(batch, 64), 64, 0, L.aux>>>((uint32_t)batch, sh.per, c->fk[F_], L.ipa_xfer.as<uint32_t>(), L.ipa_points.as<affine_t>()); });
+        HIPC(hipEventRecord(L.ev_join, L.aux));
+        if (curve == CURVE_PALLAS) IPA_PREP(CURVE_PALLAS, 8, 2, L.stream); else IPA_PREP(CURVE_VESTA, 8, 2, L.stream);
+        HIPC(hipStreamWaitEvent(L.stream, L.ev_join, 0));
+    } else {
+        if (curve == CURVE_PALLAS) IPA_PREP(CURVE_PALLAS, 4, 0, c->L->stream); else IPA_PREP(CURVE_VESTA, 4, 0, c->L->stream);
+    }
 #undef IPA_PREP
     HIPC(hipGetLastError());
     if ((rc = mb_bpoly_fold(c, FS, k, batch, c->L->ipa_chals.as<uint32_t>(), c->L->ipa_sigma.as<uint32_t>(), c->L->ipa_folded.as<uint32_t>()))) return rc;

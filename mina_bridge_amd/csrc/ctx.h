@@ -79,17 +79,19 @@ struct ProfState {
 // the next (SRS tables, field constants and Poseidon constants are shared, read-only).
 struct Lane {
     hipStream_t stream = nullptr;
+    hipStream_t aux = nullptr;               // second stream for work that can run beside the lane's main stream (IPA to_group)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     MsmWorkspace ws;
     DevBuf tmp_a, tmp_b, tmp_c, tmp_d;       // staging for the host-buffer entry points
     PinnedBuf host_stage;                    // pinned host side of the big H2D blobs (synchronous entry points only)
     DevBuf bp_ltab, bp_htab, bp_partial;
-    DevBuf ipa_chals, ipa_folded, ipa_xyzz_a, ipa_xyzz_b, ipa_points, ipa_scalars, ipa_sigma, ipa_in_a, ipa_in_b, ipa_in_c, ipa_verdict;
+    DevBuf ipa_chals, ipa_folded, ipa_xyzz_a, ipa_xyzz_b, ipa_points, ipa_scalars, ipa_sigma, ipa_in_a, ipa_in_b, ipa_in_c, ipa_verdict, ipa_xfer;
     void release_all() {
         MsmWorkspace &w = ws;
         DevBuf *all[] = {&w.scalars, &w.points, &w.ekey, &w.eval, &w.eoff, &w.count, &w.start, &w.task_start, &w.rem_pos, &w.rem_bucket, &w.info, &w.sorted, &w.partial, &w.heavy, &w.order, &w.ghist, &w.stage,
                          &w.buckets, &w.red_r, &w.red_ws, &w.red2_r, &w.red2_w, &w.set_total, &w.out_words, &w.out_xyzz, &tmp_a, &tmp_b, &tmp_c, &tmp_d,
                          &bp_ltab, &bp_htab, &bp_partial, &ipa_chals, &ipa_folded, &ipa_xyzz_a, &ipa_xyzz_b, &ipa_points, &ipa_scalars,
-                         &ipa_sigma, &ipa_in_a, &ipa_in_b, &ipa_in_c, &ipa_verdict};
+                         &ipa_sigma, &ipa_in_a, &ipa_in_b, &ipa_in_c, &ipa_verdict, &ipa_xfer};
         for (DevBuf *b : all) b->release();
         host_stage.release();
     }
