@@ -336,35 +336,54 @@ static __global__ void __launch_bounds__(1024) msm_excl_scan_kernel(uint32_t n, 
     block_excl_scan_inplace(n, data, s_tot, s_pre, s_all);
 }
 
-// K1p-d: level 2, one block per (problem, partition).
+// K1p-d: level 2, one block per (problem, partition).  One pass over the staging entries: a lane keeps its (up to
+// PS_KEEP) entries in registers together with the rank a returning LDS atomic gave them inside their bucket; after the
+// block scan they go straight to their final positions.  Partitions beyond PS_KEEP * 1024 entries (skewed digits) rank
+// the overflow in a second pass behind the kept entries.
+static constexpr int PS_KEEP = 12;
 static __global__ void __launch_bounds__(1024)
 msm_part_sort_kernel(SortShape ss, const uint32_t *__restrict__ goff, const uint2 *__restrict__ staging,
                      uint32_t *__restrict__ count, uint32_t *__restrict__ sorted) {
-    __shared__ uint32_t hist[2048];
+    __shared__ uint32_t hist[2048], over[2048];
     __shared__ uint32_t s_tot[1][16], s_pre[1][16], s_all[1];
     const uint32_t tid = threadIdx.x, pg = blockIdx.x, nf = 1u << ss.fbits;
     const uint32_t m = pg / ss.Pl, p = pg - m * ss.Pl;
     const uint32_t nvalid = (ss.SB - p * nf < nf) ? ss.SB - p * nf : nf;          // buckets of this partition (last one may be short)
     const uint32_t begin = goff[(size_t)pg * ss.Gl], end = goff[(size_t)(pg + 1) * ss.Gl];   // goff[nprob * Pl * Gl] = total
-    for (uint32_t j = tid; j < nf; j += 1024) hist[j] = 0;
+    const bool has_over = end - begin > (uint32_t)PS_KEEP * 1024u;
+    for (uint32_t j = tid; j < nf; j += 1024) { hist[j] = 0; over[j] = 0; }
     __syncthreads();
-    for (uint32_t e = begin + tid; e < end; e += 1024) atomicAdd(&hist[staging[e].y], 1u);
+    uint2 ent[PS_KEEP]; uint32_t rk[PS_KEEP];
+#pragma unroll
+    for (int j = 0; j < PS_KEEP; ++j) {
+        const uint32_t e = begin + tid + (uint32_t)j * 1024u;
+        if (e < end) { ent[j] = staging[e]; rk[j] = atomicAdd(&hist[ent[j].y], 1u); }
+    }
+    if (has_over)
+        for (uint32_t e = begin + tid + (uint32_t)PS_KEEP * 1024u; e < end; e += 1024) atomicAdd(&over[staging[e].y], 1u);
     __syncthreads();
-    // exclusive scan of hist[0 .. nf): lane t owns elements 2t, 2t+1 (nf <= 2048)
-    const uint32_t h0 = (2 * tid < nf) ? hist[2 * tid] : 0u, h1 = (2 * tid + 1 < nf) ? hist[2 * tid + 1] : 0u;
+    // exclusive scan of the bucket sizes hist + over: lane t owns buckets 2t, 2t+1 (nf <= 2048)
+    const uint32_t k0 = (2 * tid < nf) ? hist[2 * tid] : 0u, k1 = (2 * tid + 1 < nf) ? hist[2 * tid + 1] : 0u;
+    const uint32_t h0 = k0 + ((2 * tid < nf) ? over[2 * tid] : 0u), h1 = k1 + ((2 * tid + 1 < nf) ? over[2 * tid + 1] : 0u);
     uint32_t v[1] = {h0 + h1}, tot[1];
     block_exclusive_scan<1>(v, tot, s_tot, s_pre, s_all);
     const uint32_t b0 = m * ss.SB + p * nf + 2 * tid;
     if (2 * tid < nvalid) count[b0] = h0;
     if (2 * tid + 1 < nvalid) count[b0 + 1] = h1;
-    __syncthreads();                                                            // all reads of hist done
-    if (2 * tid < nf) hist[2 * tid] = v[0];                                     // hist becomes the cursor array
-    if (2 * tid + 1 < nf) hist[2 * tid + 1] = v[0] + h0;
+    __syncthreads();                                                            // all reads of hist / over done
+    if (2 * tid < nf) { hist[2 * tid] = v[0]; over[2 * tid] = v[0] + k0; }        // hist: bucket start, over: cursor behind the kept entries
+    if (2 * tid + 1 < nf) { hist[2 * tid + 1] = v[0] + h0; over[2 * tid + 1] = v[0] + h0 + k1; }
     __syncthreads();
-    for (uint32_t e = begin + tid; e < end; e += 1024) {
-        const uint2 x = staging[e];
-        sorted[begin + atomicAdd(&hist[x.y], 1u)] = x.x;
+#pragma unroll
+    for (int j = 0; j < PS_KEEP; ++j) {
+        const uint32_t e = begin + tid + (uint32_t)j * 1024u;
+        if (e < end) sorted[begin + hist[ent[j].y] + rk[j]] = ent[j].x;
     }
+    if (has_over)
+        for (uint32_t e = begin + tid + (uint32_t)PS_KEEP * 1024u; e < end; e += 1024) {
+            const uint2 x = staging[e];
+            sorted[begin + atomicAdd(&over[x.y], 1u)] = x.x;
+        }
 }
 
 // K1b': rem_bucket = inverse permutation of rem_pos (random 4-byte scatter, spread over the whole chip)
