@@ -80,10 +80,10 @@ static int run_msm(mina_ctx *c, const MsmShape &sh, const uint32_t *d_scalars, c
           msm_excl_scan_kernel<<<1, 1024, 0, st>>>((uint32_t)gh_words, w.ghist.as<uint32_t>()); }
         { ProfScope ps_(c, PS_SCATTER);
           msm_part_kernel<true><<<ss.Gl * sh.nprob, 1024, 0, st>>>(sh, ss, d_scalars, w.ghist.as<uint32_t>(), w.stage.as<uint2>(), w.ekey.as<uint32_t>());
-          msm_part_sort_kernel<<<ss.Pl * sh.nprob, 1024, 0, st>>>(ss, w.ghist.as<uint32_t>(), w.stage.as<uint2>(), w.count.as<uint32_t>(), w.sorted.as<uint32_t>()); }
+          msm_part_sort_kernel<<<ss.Pl * sh.nprob, 1024, 0, st>>>(ss, w.ghist.as<uint32_t>(), w.stage.as<uint2>(), w.count.as<uint32_t>(), w.sorted.as<uint32_t>(), w.info.as<uint32_t>()); }
         if (bucket_lanes) {
             ProfScope ps_(c, PS_SCAN);
-            msm_order_kernel<<<1, 1024, 0, st>>>(nb_total, w.count.as<uint32_t>(), w.start.as<uint32_t>(), w.order.as<uint32_t>(), w.info.as<uint32_t>(), w.heavy.as<uint32_t>());
+            msm_order_kernel<<<sh.nprob, 1024, 0, st>>>(ss, sh.nprob, w.ghist.as<uint32_t>(), w.count.as<uint32_t>(), w.start.as<uint32_t>(), w.order.as<uint32_t>(), w.info.as<uint32_t>(), w.heavy.as<uint32_t>());
         } else {
             ProfScope ps_(c, PS_SCAN); msm_scan_kernel<<<1, 1024, 0, st>>>(nb_total, w.count.as<uint32_t>(), w.start.as<uint32_t>(), w.task_start.as<uint32_t>(),
                                                                        w.rem_pos.as<uint32_t>(), w.info.as<uint32_t>());
@@ -101,7 +101,7 @@ static int run_msm(mina_ctx *c, const MsmShape &sh, const uint32_t *d_scalars, c
     }
     if (bucket_lanes) {
         { ProfScope ps_(c, PS_ACCUMULATE);
-          msm_accumulate_bucket_kernel<F><<<cdiv(nb_total / 2, 256), 256, 0, st>>>(nb_total, w.start.as<uint32_t>(), w.order.as<uint32_t>(), w.sorted.as<uint32_t>(), d_points, fk.one, w.buckets.as<xyzz_t>()); }
+          msm_accumulate_bucket_kernel<F><<<cdiv(nb_total / 2, 256), 256, 0, st>>>(nb_total, ss.SB, w.start.as<uint32_t>(), w.order.as<uint32_t>(), w.sorted.as<uint32_t>(), d_points, fk.one, w.buckets.as<xyzz_t>()); }
         { ProfScope ps_(c, PS_BUCKET_SUM);
           msm_bucket_heavy_entries_kernel<F><<<128, 256, 0, st>>>(w.start.as<uint32_t>(), w.info.as<uint32_t>(), w.heavy.as<uint32_t>(), w.sorted.as<uint32_t>(), d_points, fk.one, w.buckets.as<xyzz_t>()); }
     } else {

@@ -343,7 +343,8 @@ static __global__ void __launch_bounds__(1024) msm_excl_scan_kernel(uint32_t n, 
 static constexpr int PS_KEEP = 12;
 static __global__ void __launch_bounds__(1024)
 msm_part_sort_kernel(SortShape ss, const uint32_t *__restrict__ goff, const uint2 *__restrict__ staging,
-                     uint32_t *__restrict__ count, uint32_t *__restrict__ sorted) {
+                     uint32_t *__restrict__ count, uint32_t *__restrict__ sorted, uint32_t *__restrict__ info) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) info[2] = 0;                       // heavy-bucket counter of K1t-a (K1b zeroes its own)
     __shared__ uint32_t hist[2048], over[2048];
     __shared__ uint32_t s_tot[1][16], s_pre[1][16], s_all[1];
     const uint32_t tid = threadIdx.x, pg = blockIdx.x, nf = 1u << ss.fbits;
@@ -533,27 +534,31 @@ template <int F> __device__ __forceinline__ xyzz_t quadwave_sum(xyzz_t v, int wi
 static constexpr uint32_t MSM_HEAVY_ENTRIES = 192;
 static constexpr uint32_t MSM_COUNT_CLASSES = 64;
 
-// K1t-a: one block.  start[b] = exclusive prefix of count (start[nb] = total); order[rank] = bucket, ranked by
-// min(count, 63) descending; heavy[] / info[2] = buckets with more than MSM_HEAVY_ENTRIES entries.
+// K1t-a: one block per problem (its SB buckets; ranks are taken within the problem -- the problems of a launch are
+// statistically alike, so this balances as well as a global ranking and scales with the group size).
+//   start[b] = exclusive prefix of count, based at the problem's first entry (goff of its first partition);
+//   order[m * SB + rank] = bucket, ranked by min(count, 63) descending;
+//   heavy[] / info[2] = buckets with more than MSM_HEAVY_ENTRIES entries (info[2] is zeroed by K1p-d).
 static __global__ void __launch_bounds__(1024)
-msm_order_kernel(uint32_t nb_total, const uint32_t *__restrict__ count, uint32_t *__restrict__ start, uint32_t *__restrict__ order,
-                 uint32_t *__restrict__ info, uint32_t *__restrict__ heavy) {
+msm_order_kernel(SortShape ss, uint32_t nprob, const uint32_t *__restrict__ goff, const uint32_t *__restrict__ count,
+                 uint32_t *__restrict__ start, uint32_t *__restrict__ order, uint32_t *__restrict__ info, uint32_t *__restrict__ heavy) {
     __shared__ uint32_t s_tot[1][16], s_pre[1][16], s_all[1];
-    __shared__ uint32_t cls_n[MSM_COUNT_CLASSES], cls_cur[MSM_COUNT_CLASSES], n_heavy;
-    const uint32_t tid = threadIdx.x, row_elems = blockDim.x * 4, nrows = (nb_total + row_elems - 1) / row_elems;
+    __shared__ uint32_t cls_n[MSM_COUNT_CLASSES], cls_cur[MSM_COUNT_CLASSES];
+    const uint32_t tid = threadIdx.x, m = blockIdx.x, nb = ss.SB, row_elems = blockDim.x * 4, nrows = (nb + row_elems - 1) / row_elems;
+    const uint32_t first = m * nb;                               // SB is a multiple of 128
+    count += first; start += first; order += first;
     if (tid < MSM_COUNT_CLASSES) cls_n[tid] = 0;
-    if (tid == 0) n_heavy = 0;
     __syncthreads();
-    uint32_t carry = 0;
+    uint32_t carry = goff[(size_t)m * ss.Pl * ss.Gl];            // entries of the problems before this one
     for (uint32_t row = 0; row < nrows; ++row) {                 // pass 1: prefix of the counts + class histogram
         const uint32_t idx = row * row_elems + tid * 4;
         uint4 c4 = make_uint4(0, 0, 0, 0);
-        if (idx < nb_total) c4 = *reinterpret_cast<const uint4 *>(count + idx);
+        if (idx < nb) c4 = *reinterpret_cast<const uint4 *>(count + idx);
         const uint32_t c[4] = {c4.x, c4.y, c4.z, c4.w};
         uint32_t v[1] = {c[0] + c[1] + c[2] + c[3]}, tot[1];
         block_exclusive_scan<1>(v, tot, s_tot, s_pre, s_all);
         const uint32_t p0 = carry + v[0];
-        if (idx < nb_total) {
+        if (idx < nb) {
             *reinterpret_cast<uint4 *>(start + idx) = make_uint4(p0, p0 + c[0], p0 + c[0] + c[1], p0 + c[0] + c[1] + c[2]);
 #pragma unroll
             for (int e = 0; e < 4; ++e) atomicAdd(&cls_n[c[e] < MSM_COUNT_CLASSES - 1 ? c[e] : MSM_COUNT_CLASSES - 1], 1u);
@@ -562,40 +567,39 @@ msm_order_kernel(uint32_t nb_total, const uint32_t *__restrict__ count, uint32_t
     }
     __syncthreads();
     if (tid == 0) {
-        start[nb_total] = carry;
+        if (m == nprob - 1) start[nb] = carry;                   // start[nb_total] = total entries
         uint32_t run = 0;                                        // descending classes: 63, 62, ..., 0
         for (int k = MSM_COUNT_CLASSES - 1; k >= 0; --k) { cls_cur[k] = run; run += cls_n[k]; }
     }
     __syncthreads();
     for (uint32_t row = 0; row < nrows; ++row) {                 // pass 2: ranks
         const uint32_t idx = row * row_elems + tid * 4;
-        if (idx >= nb_total) continue;
+        if (idx >= nb) continue;
         const uint4 c4 = *reinterpret_cast<const uint4 *>(count + idx);
         const uint32_t c[4] = {c4.x, c4.y, c4.z, c4.w};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const uint32_t k = c[e] < MSM_COUNT_CLASSES - 1 ? c[e] : MSM_COUNT_CLASSES - 1;
-            order[atomicAdd(&cls_cur[k], 1u)] = idx + e;
-            if (c[e] > MSM_HEAVY_ENTRIES) heavy[atomicAdd(&n_heavy, 1u)] = idx + e;
+            order[atomicAdd(&cls_cur[k], 1u)] = first + idx + e;
+            if (c[e] > MSM_HEAVY_ENTRIES) heavy[atomicAdd(&info[2], 1u)] = first + idx + e;
         }
     }
-    __syncthreads();
-    if (tid == 0) info[2] = n_heavy;
 }
 
-// K1t-b: bucket = sum of its sorted entries.  Lane r takes the buckets of rank r and nb-1-r (the longest with the
+// K1t-b: bucket = sum of its sorted entries.  Lane r takes the buckets of rank r and nb-1-r of its problem (the longest with the
 // shortest, ...): every lane then runs ~2x the mean entry count, so the waves of a launch end together instead of
 // leaving the SIMDs with one long wave each (isolated 8-MSM launch: 696 -> 58x us).
 template <int F>
 __global__ void __launch_bounds__(256)
-msm_accumulate_bucket_kernel(uint32_t nb_total, const uint32_t *__restrict__ start, const uint32_t *__restrict__ order,
+msm_accumulate_bucket_kernel(uint32_t nb_total, uint32_t nb_prob, const uint32_t *__restrict__ start, const uint32_t *__restrict__ order,
                              const uint32_t *__restrict__ sorted, const affine_t *__restrict__ points, fe_t one,
                              xyzz_t *__restrict__ buckets) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= nb_total / 2) return;                               // nb_total is a multiple of 128
+    if (r >= nb_total / 2) return;                               // bucket counts are multiples of 128
+    const uint32_t m = r / (nb_prob / 2), lr = r - m * (nb_prob / 2);   // ranks are per problem
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
-        const uint32_t b = order[half ? nb_total - 1 - r : r];
+        const uint32_t b = order[m * nb_prob + (half ? nb_prob - 1 - lr : lr)];
         const uint32_t beg = start[b], cnt = start[b + 1] - beg;
         if (cnt > MSM_HEAVY_ENTRIES) continue;                   // K1t-c writes it
         xyzz_t acc = xyzz_inf();
