@@ -39,9 +39,9 @@ MSM_ALGORITHMIC_BYTES = N_BASES * (64 + 32) + 96      # 6 291 55
 HBM_PEAK_GBPS = 8000.0                                # MI355X_MICROARCH.md: 8 TB/s spec
 PS_ACCUMULATE_BIT = 1 << 3      # ProfStage::PS_ACCUMULATE in csrc/ctx.h
 # HBM-side bytes per launch of the dominant kernel from the rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, KiB * 1024;
-# profiles/r01i_rocprof.md section 2).  14x the algorithmic bytes by design: the fixed-base window tables gather 16
+# profiles/r01j_rocprof.md section 2).  14x the algorithmic bytes by design: the fixed-base window tables gather 16
 # precomputed 64-B points per base and write 128-B XYZZ partials.
-ACCUMULATE_TRAFFIC_BYTES = 79_660_000
+ACCUMULATE_TRAFFIC_BYTES = 80_470_000
 # VALU side of the roofline (the path is integer-multiply bound): one Montgomery product is 88
 # v_mad_u64_u32 (8 cycles per wave64 instruction, profiles/r01_microbench_valu.jsonl) -> issue floor 704 cycles.
 MODMUL_ISSUE_FLOOR_CYCLES = 88 * 8
@@ -248,7 +248,7 @@ def main():
                        "pipeline_lanes": args.pipeline, "sharding": f"proof-level, {args.gpus} rank(s), no collective"},
             "roofline": {"bound": "hbm", "kernel": "msm_accumulate_bucket_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": msms * ACCUMULATE_TRAFFIC_BYTES,
-                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r01i_rocprof.md",
+                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r01j_rocprof.md",
                          "traffic_GBps": msms * ACCUMULATE_TRAFFIC_BYTES / kern_s / 1e9 if launches else None,
                          "algorithmic_bytes_per_launch": msms * MSM_ALGORITHMIC_BYTES, "msms_per_launch": msms, "avg_launch_us": kern_s * 1e6,
                          "avg_launch_us_in_timed_region": overlapped_us,
