@@ -118,11 +118,19 @@ def main():
     dist_on = world > 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    # MINA_BENCH_SHARE_GPU=1 (test hook): every rank uses GPU 0 and the ranks rendezvous over gloo -- lets the N > 1 code path
+    # (barriers, MAX over ranks, aggregate value) be exercised on a 1-GPU box; never set by the driver
+    share_gpu = os.environ.get("MINA_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     ctx = m.MinaContext(local_rank)
     ctx.srs_create(CURVE_VESTA, N_BASES)                       # SRS regenerated on the GPU (K4) + window tables
@@ -222,7 +230,7 @@ def main():
                                        "note": "same C-ABI entry, 256 proofs folded with random rho into one 2^16 MSM + one 256-point variable-base MSM"}}
 
     if dist_on:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
