@@ -306,6 +306,73 @@ int mina_consensus_is_short_range(const mina_consensus_state *a, const mina_cons
 int mina_consensus_select_secure_chain(const mina_consensus_params *p, const mina_consensus_state *tip,
                                        const mina_consensus_state *candidate, int *candidate_selected);
 
+/* ---- protocol states: `MinaHash(ProtocolState)` (core/src/mina.rs:143-168, core/src/utils/constants.rs:22-24) -------
+ * A serialized `MinaStateProtocolStateValueStableV2` (bin_prot as the reference reads it at core/src/mina.rs:164, or the bincode-of-serde
+ * form inside `MinaStateProof`, core/src/proof/state_proof.rs:28-41) is flattened on the host into a fixed-size RECORD of
+ * MINA_PSTATE_SLOTS field elements: slot 0 = previous_state_hash, slots 1..1+n = the body's `to_input` fields
+ * (`Protocol_state.Body.to_input` packed as openmina's `Inputs::to_fields`).  The GPU then computes
+ *     state_hash = H_"MinaProtoState"(previous_state_hash, H_"MinaProtoStateBody"(body fields)).
+ * Host-side parsers need no context. */
+#define MINA_PSTATE_SLOTS 64
+#define MINA_STATES_PER_PROOF 17   /* 16 candidate-chain states (oldest .. tip) + the bridge tip state (state_proof.rs:28-41) */
+#define MINA_ENC_BINPROT 0
+#define MINA_ENC_BINCODE 1
+typedef struct {
+    uint8_t previous_state_hash[32];
+    uint8_t genesis_state_hash[32];
+    uint8_t snarked_ledger_hash[32];       /* body.blockchain_state.ledger_proof_statement.target.first_pass_ledger */
+    uint32_t n_body_fields;
+    uint32_t k, slots_per_epoch, slots_per_sub_window, sub_windows_per_window, grace_period_slots, delta;   /* body.constants (+ window length) */
+    mina_consensus_state consensus;        /* state_hash is left zero: fill it with the computed hash before chain selection */
+} mina_protocol_state_info;
+/* *consumed (may be NULL: then the state must fill `len` exactly) receives the number of bytes read */
+int mina_protocol_state_pack(const uint8_t *bytes, size_t len, int encoding, uint8_t *record /* MINA_PSTATE_SLOTS*32 */,
+                             uint32_t *n_body_fields, mina_protocol_state_info *info /* may be NULL */, size_t *consumed);
+/* n records -> n state hashes (and, if body_hashes_out != NULL, the n body hashes) on the GPU */
+int mina_protocol_state_hash_batch(mina_ctx *ctx, size_t n, const uint8_t *records /* n*MINA_PSTATE_SLOTS*32 */,
+                                   const uint32_t *n_body_fields /* n */, uint8_t *hashes_out /* n*32 */, uint8_t *body_hashes_out /* n*32 or NULL */);
+/* serialized states in, state hashes out */
+int mina_protocol_state_hash_bytes(mina_ctx *ctx, int encoding, size_t n, const uint8_t *const *states, const size_t *lens,
+                                   uint8_t *hashes_out /* n*32 */);
+
+/* ---- the Proof-of-State job (BASELINE config C3; README.md:281-310) ------------------------------------------------
+ * `batch` state proofs through ONE device pipeline: per proof the 17 protocol-state hashes + public-input comparison + chain
+ * linkage, the wrap proof's public-input commitment (Pallas Lagrange MSM; its result replaces commitment `pub_comm_slot` of
+ * the opening), the wrap proof's combined IPA opening (folded over the batch) and the step accumulator check (Vesta 2^acc_k
+ * bases, folded with acc_rho).  Sections are structure-of-arrays over the batch; layouts as in mina_ipa_opening /
+ * mina_accumulator_check_batch.  A section is skipped when its `with_*` flag (or npub) is 0. */
+typedef struct {
+    size_t batch;
+    /* (1) protocol states */
+    int with_states;
+    const void *state_records;    /* batch*17 records (mina_protocol_state_pack) */
+    const void *state_nfields;    /* batch*17 u32 */
+    const void *expected_hashes;  /* batch*17*32: candidate_chain_state_hashes[16] then bridge_tip_state_hash (state_proof.rs:10-25) */
+    const void *precheck;         /* batch bytes from host-side checks (ledger hashes, consensus), NULL = all pass */
+    /* (2) wrap proof public input (scalar field of Pallas) */
+    uint32_t log2_domain, npub, pub_comm_slot;
+    const void *public_inputs;    /* batch*npub*32 */
+    /* (3) wrap proof opening (Pallas) */
+    int with_ipa;
+    uint32_t k, n_evalpoints, n_comms;
+    const void *sponge_state /* b*96 */, *sponge_pos /* b*2 u32 {mode, count} */, *cip /* b*32 */, *lr /* b*2k*64 */, *delta /* b*64 */,
+               *sg /* b*64 */, *z1, *z2 /* b*32 */, *evalpoints /* b*n_evalpoints*32 */, *evalscale, *polyscale /* b*32 */, *comms /* b*n_comms*64 */;
+    const void *rand_base, *sg_rand_base;   /* 32 each */
+    /* (4) step accumulator (Vesta) */
+    int with_accumulator;
+    uint32_t acc_k;
+    const void *acc_prechallenges /* b*acc_k*16 */, *acc_sg /* b*64 */, *acc_rho /* b*32 */;
+} mina_state_jobs;
+/* one-off set-up that needs host synchronisation (prefix salts; Lagrange basis of the domain + window table of its first npub points) */
+int mina_state_jobs_prepare(mina_ctx *ctx, uint32_t log2_domain, uint32_t npub);
+/* Every pointer of `jobs` is a DEVICE pointer.  Queued on the next pipeline lane, no host synchronisation.
+ * d_verdicts: batch u32, 1 = proof accepted.  d_flags (may be NULL): 4 u32 {folded IPA ok, IPA input malformed, folded accumulator ok, 0};
+ * when a folded check fails every verdict of the batch is 0 (the host-buffer form below then finds the culprits). */
+int mina_state_job_batch_dev(mina_ctx *ctx, const mina_state_jobs *jobs, void *d_verdicts, void *d_flags);
+/* Host-buffer form: one upload, the pipeline, one download; on a folded failure the batch is bisected so that every proof gets
+ * its own verdict byte. */
+int mina_state_job_batch(mina_ctx *ctx, const mina_state_jobs *jobs, uint8_t *verdicts /* batch */);
+
 /* ---- top-level byte contract (a15, a16): NOT YET EXPORTED ------------------------------------
  * mina_verify_state / mina_verify_account (same (ptr,len,ptr,len) shape as Aligned's
  * verify_mina_state_ffi / verify_account_inclusion_ffi) need the bincode/binprot container parsers and

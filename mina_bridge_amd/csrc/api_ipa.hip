@@ -102,7 +102,6 @@ sponge_tape_kernel(uint32_t batch, uint32_t tape_len, uint32_t in_stride_words, 
     if (final_pos && l == 0) { final_pos[2 * b] = (uint32_t)sp.squeezed; final_pos[2 * b + 1] = (uint32_t)sp.count; }
 }
 
-struct IpaShape { uint32_t batch, k, npts, ncomms, per; };   // per = 2k + ncomms + 4 points per proof
 
 template <int FB> __device__ __forceinline__ affine_t load_point_mont(const uint32_t *p, const FieldK &kb) {
     affine_t a; a.x = fe_to_mont<FB>(load_fe<FB>(p), kb.r2); a.y = fe_to_mont<FB>(load_fe<FB>(p + 8), kb.r2); return a;
@@ -136,6 +135,7 @@ ipa_prepare_kernel(IpaShape sh, FieldK kb, FieldK ks, const PoseidonParams *__re
                    const uint32_t *__restrict__ sg /* b*16 */, const uint32_t *__restrict__ z1, const uint32_t *__restrict__ z2,
                    const uint32_t *__restrict__ evalpoints /* b*npts*8 */, const uint32_t *__restrict__ evalscale,
                    const uint32_t *__restrict__ polyscale, const uint32_t *__restrict__ comms /* b*ncomms*16 */,
+                   const uint32_t *__restrict__ comm_override /* b*16 or null */,
                    const uint32_t *__restrict__ rand_base, const uint32_t *__restrict__ sg_rand_base,
                    const affine_t *__restrict__ srs_h,
                    affine_t *__restrict__ out_points /* b*per */, uint32_t *__restrict__ out_scalars /* b*per*8 canonical */,
@@ -271,7 +271,8 @@ ipa_prepare_kernel(IpaShape sh, FieldK kb, FieldK ks, const PoseidonParams *__re
     const fe_t xi = load_scalar_checked(polyscale + (size_t)b * 8);
     fe_t xi_i = ks.one;
     for (uint32_t i = 0; i < sh.ncomms; ++i) {
-        store_pt<LANES>(&pts[4 + 2 * k + i], load_point_checked<FB>(comms + ((size_t)b * sh.ncomms + i) * 16, kb, pts_ok));
+        const uint32_t *cp = (i == sh.override_slot && comm_override) ? comm_override + (size_t)b * 16 : comms + ((size_t)b * sh.ncomms + i) * 16;
+        store_pt<LANES>(&pts[4 + 2 * k + i], load_point_checked<FB>(cp, kb, pts_ok));
         store_fe<LANES>(scs + (size_t)(4 + 2 * k + i) * 8, fe_from_mont<FS>(fe_mul<FS>(rho_c, xi_i)));
         xi_i = fe_mul<FS>(xi_i, xi);
     }
@@ -334,7 +335,7 @@ __global__ void xyzz_eq_affine_kernel(const xyzz_t *__restrict__ a, const uint32
 
 // ------------------------------------------------------------------------------------------------
 // a10: accumulator check
-static int accumulator_check_dev(mina_ctx *c, int curve, uint32_t k, size_t batch, const uint32_t *d_prechal,
+int mb_accumulator_check_dev(mina_ctx *c, int curve, uint32_t k, size_t batch, const uint32_t *d_prechal,
                                  const uint32_t *d_sg_words, const uint32_t *d_rho, uint32_t *d_verdict) {
     SrsState &s = c->srs[curve];
     if (s.depth == 0) return fail(MINA_ERR_STATE, "SRS not loaded for this curve");
@@ -403,7 +404,7 @@ extern "C" int mina_accumulator_check_dev(mina_ctx *c, int curve, uint32_t k, si
     if (batch == 0 || batch > (1u << 20)) return fail(MINA_ERR_ARG, "bad batch");
     HIPC(hipSetDevice(c->device));
     c->next_lane();
-    return accumulator_check_dev(c, curve, k, batch, (const uint32_t *)d_prechallenges, (const uint32_t *)d_sg, (const uint32_t *)d_rho, (uint32_t *)d_verdict);
+    return mb_accumulator_check_dev(c, curve, k, batch, (const uint32_t *)d_prechallenges, (const uint32_t *)d_sg, (const uint32_t *)d_rho, (uint32_t *)d_verdict);
 }
 
 // per-proof verdicts for the `count` proofs already staged in ipa_in_a (prechallenges) / ipa_in_b (sg) of the current lane
@@ -434,7 +435,7 @@ extern "C" int mina_accumulator_check_batch(mina_ctx *c, int curve, uint32_t k, 
     if ((rc = h2d(c, c->L->ipa_in_b, sg, batch * 64))) return rc;
     if (batch > 1 && (rc = h2d(c, c->L->ipa_in_c, rho, batch * 32))) return rc;
     if ((rc = c->L->ipa_verdict.ensure(64))) return rc;
-    if ((rc = accumulator_check_dev(c, curve, k, batch, c->L->ipa_in_a.as<uint32_t>(), c->L->ipa_in_b.as<uint32_t>(),
+    if ((rc = mb_accumulator_check_dev(c, curve, k, batch, c->L->ipa_in_a.as<uint32_t>(), c->L->ipa_in_b.as<uint32_t>(),
                                     batch > 1 ? c->L->ipa_in_c.as<uint32_t>() : nullptr, c->L->ipa_verdict.as<uint32_t>()))) return rc;
     uint32_t v = 0;
     if ((rc = d2h_sync(c, &v, c->L->ipa_verdict, 4))) return rc;
@@ -455,6 +456,54 @@ extern "C" int mina_accumulator_check_multi(mina_ctx *c, int curve, uint32_t k, 
     if ((rc = h2d(c, c->L->ipa_in_a, prechallenges, count * k * 16))) return rc;
     if ((rc = h2d(c, c->L->ipa_in_b, sg, count * 64))) return rc;
     return accumulator_check_each(c, curve, k, count, verdicts);
+}
+
+// ------------------------------------------------------------------------------------------------
+// a8: combined opening check, inputs resident in HBM (structure-of-arrays, see IpaDevIn).  Queued on the current lane, no host
+// synchronisation: d_verdict[0] = 1 iff the folded check holds, d_verdict[1] = malformed-input flag.
+int mb_ipa_batch_check_dev(mina_ctx *c, int curve, mb::IpaShape sh, const mb::IpaDevIn &in, uint32_t *d_verdict) {
+    SrsState &s = c->srs[curve];
+    const int FB = base_field_of(curve), FS = scalar_field_of(curve);
+    const size_t batch = sh.batch; const uint32_t k = sh.k;
+    int rc;
+    const size_t npoints = batch * sh.per;
+    if ((rc = c->L->ipa_points.ensure(npoints * sizeof(affine_t)))) return rc;
+    if ((rc = c->L->ipa_scalars.ensure(npoints * 32))) return rc;
+    if ((rc = c->L->ipa_chals.ensure(batch * k * 32))) return rc;
+    if ((rc = c->L->ipa_sigma.ensure(batch * 32))) return rc;
+    if ((rc = c->L->ipa_folded.ensure(((size_t)1 << k) * 32))) return rc;
+    if ((rc = c->L->ipa_xyzz_a.ensure(sizeof(xyzz_t)))) return rc;
+    if ((rc = c->L->ipa_xyzz_b.ensure(sizeof(xyzz_t)))) return rc;
+    HIPC(hipMemsetAsync(d_verdict, 0, 8, c->L->stream));
+    const PoseidonParams *pp = c->pparams[FB].as<PoseidonParams>();
+#define IPA_PREP(CV, LN, PH, STREAM)                                                                                          \
+    mb::ipa_prepare_kernel<CV, LN, PH><<<cdiv(batch * LN, 64), 64, 0, STREAM>>>(                                                      \
+        sh, c->fk[FB], c->fk[FS], pp, in.state, in.pos, in.cip, in.lr, in.delta, in.sg, in.z1, in.z2, in.pts, in.r, \
+        in.xi, in.comms, in.comm_override, in.rb, in.sb, s.h.as<affine_t>(), c->L->ipa_points.as<affine_t>(), c->L->ipa_scalars.as<uint32_t>(), \
+        c->L->ipa_chals.as<uint32_t>(), c->L->ipa_sigma.as<uint32_t>(), d_verdict + 1, c->L->ipa_xfer.as<uint32_t>())
+    if (batch <= COOP8_MAX_GROUPS) {
+        // latency-bound batch: 8 lanes per transcript, and to_group on a second stream beside the rest of the transcript
+        Lane &L = *c->L;
+        if ((rc = L.ipa_xfer.ensure(batch * mb::IPA_XFER_WORDS * 4))) return rc;
+        if (!L.aux) { HIPC(hipStreamCreateWithFlags(&L.aux, hipStreamNonBlocking)); HIPC(hipEventCreateWithFlags(&L.ev_fork, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&L.ev_join, hipEventDisableTiming)); }
+        if (curve == CURVE_PALLAS) IPA_PREP(CURVE_PALLAS, 8, 1, L.stream); else IPA_PREP(CURVE_VESTA, 8, 1, L.stream);
+        HIPC(hipEventRecord(L.ev_fork, L.stream));
+        HIPC(hipStreamWaitEvent(L.aux, L.ev_fork, 0));
+        DISPATCH_FIELD(FB, { mb::ipa_to_group_kernel<F_><<<cdiv(batch, 64), 64, 0, L.aux>>>((uint32_t)batch, sh.per, c->fk[F_], L.ipa_xfer.as<uint32_t>(), L.ipa_points.as<affine_t>()); });
+        HIPC(hipEventRecord(L.ev_join, L.aux));
+        if (curve == CURVE_PALLAS) IPA_PREP(CURVE_PALLAS, 8, 2, L.stream); else IPA_PREP(CURVE_VESTA, 8, 2, L.stream);
+        HIPC(hipStreamWaitEvent(L.stream, L.ev_join, 0));
+    } else {
+        if (curve == CURVE_PALLAS) IPA_PREP(CURVE_PALLAS, 4, 0, c->L->stream); else IPA_PREP(CURVE_VESTA, 4, 0, c->L->stream);
+    }
+#undef IPA_PREP
+    HIPC(hipGetLastError());
+    if ((rc = mb_bpoly_fold(c, FS, k, batch, c->L->ipa_chals.as<uint32_t>(), c->L->ipa_sigma.as<uint32_t>(), c->L->ipa_folded.as<uint32_t>()))) return rc;
+    if ((rc = mb_msm_fixed(c, curve, 1u << k, c->L->ipa_folded.as<uint32_t>(), nullptr, c->L->ipa_xyzz_a.p))) return rc;
+    if ((rc = mb_msm_variable(c, curve, (uint32_t)npoints, c->L->ipa_scalars.as<uint32_t>(), c->L->ipa_points.p, nullptr, c->L->ipa_xyzz_b.p))) return rc;
+    DISPATCH_FIELD(FB, { xyzz_compare_kernel<F_><<<1, 64, 0, c->L->stream>>>(c->L->ipa_xyzz_a.as<xyzz_t>(), c->L->ipa_xyzz_b.as<xyzz_t>(), 1, d_verdict, d_verdict + 1); });
+    HIPC(hipGetLastError());
+    return MINA_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -513,43 +562,9 @@ extern "C" int mina_ipa_batch_check(mina_ctx *c, int curve, size_t batch, const 
     if ((rc = h2d(c, c->L->ipa_in_a, blob, total))) return rc;
     const uint8_t *d = c->L->ipa_in_a.as<uint8_t>();
     auto W = [&](size_t off) { return reinterpret_cast<const uint32_t *>(d + off); };
-    const size_t npoints = batch * sh.per;
-    if ((rc = c->L->ipa_points.ensure(npoints * sizeof(affine_t)))) return rc;
-    if ((rc = c->L->ipa_scalars.ensure(npoints * 32))) return rc;
-    if ((rc = c->L->ipa_chals.ensure(batch * k * 32))) return rc;
-    if ((rc = c->L->ipa_sigma.ensure(batch * 32))) return rc;
-    if ((rc = c->L->ipa_folded.ensure(((size_t)1 << k) * 32))) return rc;
-    if ((rc = c->L->ipa_xyzz_a.ensure(sizeof(xyzz_t)))) return rc;
-    if ((rc = c->L->ipa_xyzz_b.ensure(sizeof(xyzz_t)))) return rc;
+    mb::IpaDevIn in{W(o_state), W(o_pos), W(o_cip), W(o_lr), W(o_delta), W(o_sg), W(o_z1), W(o_z2), W(o_pts), W(o_r), W(o_xi), W(o_comms), nullptr, W(o_rb), W(o_sb)};
     if ((rc = c->L->ipa_verdict.ensure(8))) return rc;          // [0] verdict, [1] malformed-input flag
-    HIPC(hipMemsetAsync(c->L->ipa_verdict.p, 0, 8, c->L->stream));
-    const PoseidonParams *pp = c->pparams[FB].as<PoseidonParams>();
-#define IPA_PREP(CV, LN, PH, STREAM)                                                                                          \
-    mb::ipa_prepare_kernel<CV, LN, PH><<<cdiv(batch * LN, 64), 64, 0, STREAM>>>(                                                      \
-        sh, c->fk[FB], c->fk[FS], pp, W(o_state), W(o_pos), W(o_cip), W(o_lr), W(o_delta), W(o_sg), W(o_z1), W(o_z2), W(o_pts), W(o_r), \
-        W(o_xi), W(o_comms), W(o_rb), W(o_sb), s.h.as<affine_t>(), c->L->ipa_points.as<affine_t>(), c->L->ipa_scalars.as<uint32_t>(), \
-        c->L->ipa_chals.as<uint32_t>(), c->L->ipa_sigma.as<uint32_t>(), c->L->ipa_verdict.as<uint32_t>() + 1, c->L->ipa_xfer.as<uint32_t>())
-    if (batch <= COOP8_MAX_GROUPS) {
-        // latency-bound batch: 8 lanes per transcript, and to_group on a second stream beside the rest of the transcript
-        Lane &L = *c->L;
-        if ((rc = L.ipa_xfer.ensure(batch * mb::IPA_XFER_WORDS * 4))) return rc;
-        if (!L.aux) { HIPC(hipStreamCreateWithFlags(&L.aux, hipStreamNonBlocking)); HIPC(hipEventCreateWithFlags(&L.ev_fork, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&L.ev_join, hipEventDisableTiming)); }
-        if (curve == CURVE_PALLAS) IPA_PREP(CURVE_PALLAS, 8, 1, L.stream); else IPA_PREP(CURVE_VESTA, 8, 1, L.stream);
-        HIPC(hipEventRecord(L.ev_fork, L.stream));
-        HIPC(hipStreamWaitEvent(L.aux, L.ev_fork, 0));
-        DISPATCH_FIELD(FB, { mb::ipa_to_group_kernel<F_><<<cdiv(batch, 64), 64, 0, L.aux>>>((uint32_t)batch, sh.per, c->fk[F_], L.ipa_xfer.as<uint32_t>(), L.ipa_points.as<affine_t>()); });
-        HIPC(hipEventRecord(L.ev_join, L.aux));
-        if (curve == CURVE_PALLAS) IPA_PREP(CURVE_PALLAS, 8, 2, L.stream); else IPA_PREP(CURVE_VESTA, 8, 2, L.stream);
-        HIPC(hipStreamWaitEvent(L.stream, L.ev_join, 0));
-    } else {
-        if (curve == CURVE_PALLAS) IPA_PREP(CURVE_PALLAS, 4, 0, c->L->stream); else IPA_PREP(CURVE_VESTA, 4, 0, c->L->stream);
-    }
-#undef IPA_PREP
-    HIPC(hipGetLastError());
-    if ((rc = mb_bpoly_fold(c, FS, k, batch, c->L->ipa_chals.as<uint32_t>(), c->L->ipa_sigma.as<uint32_t>(), c->L->ipa_folded.as<uint32_t>()))) return rc;
-    if ((rc = mb_msm_fixed(c, curve, 1u << k, c->L->ipa_folded.as<uint32_t>(), nullptr, c->L->ipa_xyzz_a.p))) return rc;
-    if ((rc = mb_msm_variable(c, curve, (uint32_t)npoints, c->L->ipa_scalars.as<uint32_t>(), c->L->ipa_points.p, nullptr, c->L->ipa_xyzz_b.p))) return rc;
-    DISPATCH_FIELD(FB, { xyzz_compare_kernel<F_><<<1, 64, 0, c->L->stream>>>(c->L->ipa_xyzz_a.as<xyzz_t>(), c->L->ipa_xyzz_b.as<xyzz_t>(), 1, c->L->ipa_verdict.as<uint32_t>(), c->L->ipa_verdict.as<uint32_t>() + 1); });
+    if ((rc = mb_ipa_batch_check_dev(c, curve, sh, in, c->L->ipa_verdict.as<uint32_t>()))) return rc;
     uint32_t v = 0;
     if ((rc = d2h_sync(c, &v, c->L->ipa_verdict, 4))) return rc;
     *verdict = v ? 1 : 0;

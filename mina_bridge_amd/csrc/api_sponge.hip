@@ -113,6 +113,7 @@ extern "C" int mina_poseidon_set_params(mina_ctx *c, int field, const uint8_t *p
     HIPC(hipStreamSynchronize(c->L->stream));
     c->have_pparams[field] = true;
     c->merkle_depth[field] = 0;
+    if (field == FIELD_FP) c->have_state_salts = false;
     return MINA_OK;
 }
 

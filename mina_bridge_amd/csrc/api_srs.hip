@@ -256,6 +256,25 @@ template <int F> static int build_lagrange_table(mina_ctx *c, SrsState &s, uint3
     return MINA_OK;
 }
 
+// Lagrange basis of the domain (host cache) + the window table of its first npub points; synchronises when it has to build
+int mb_ensure_lagrange_table(mina_ctx *c, int curve, uint32_t log2_domain, uint32_t npub) {
+    SrsState &s = c->srs[curve];
+    if (s.depth == 0) return fail(MINA_ERR_STATE, "SRS not loaded");
+    if (log2_domain > 20 || ((uint64_t)1 << log2_domain) > s.depth || npub > ((size_t)1 << log2_domain)) return fail(MINA_ERR_ARG, "bad domain / npub");
+    int rc;
+    if ((rc = ensure_lagrange_host(c, curve, log2_domain))) return rc;
+    const int FB = base_field_of(curve);
+    if (s.lagrange_table_log2 != (int)log2_domain || s.lagrange_table_n < npub) {
+        uint32_t n_tab = (uint32_t)(npub < 64 ? 64 : npub);
+        if (n_tab > (1u << log2_domain)) n_tab = 1u << log2_domain;
+        s.lagrange_table_log2 = -1;
+        DISPATCH_FIELD(FB, { rc = build_lagrange_table<F_>(c, s, n_tab); });
+        if (rc) return rc;
+        s.lagrange_table_n = n_tab; s.lagrange_table_log2 = (int)log2_domain;
+    }
+    return MINA_OK;
+}
+
 extern "C" int mina_public_input_commitment_batch(mina_ctx *c, int curve, uint32_t log2_domain, size_t npub, size_t batch,
                                                   const uint8_t *public_inputs, uint8_t *out_affine) {
     if (!c || (batch && !out_affine) || (npub && batch && !public_inputs)) return fail(MINA_ERR_ARG, "null argument");
@@ -274,16 +293,8 @@ extern "C" int mina_public_input_commitment_batch(mina_ctx *c, int curve, uint32
         for (size_t m = 0; m < batch; ++m) memcpy(out_affine + m * 64, hb, 64);
         return MINA_OK;
     }
-    if ((rc = ensure_lagrange_host(c, curve, log2_domain))) return rc;
+    if ((rc = mb_ensure_lagrange_table(c, curve, log2_domain, (uint32_t)npub))) return rc;
     const int FB = base_field_of(curve);
-    if (s.lagrange_table_log2 != (int)log2_domain || s.lagrange_table_n < npub) {
-        uint32_t n_tab = (uint32_t)(npub < 64 ? 64 : npub);
-        if (n_tab > (1u << log2_domain)) n_tab = 1u << log2_domain;
-        s.lagrange_table_log2 = -1;
-        DISPATCH_FIELD(FB, { rc = build_lagrange_table<F_>(c, s, n_tab); });
-        if (rc) return rc;
-        s.lagrange_table_n = n_tab; s.lagrange_table_log2 = (int)log2_domain;
-    }
     MsmWorkspace &w = c->L->ws;
     if ((rc = w.scalars.ensure(batch * npub * 32))) return rc;
     if ((rc = c->L->tmp_b.ensure(batch * sizeof(xyzz_t)))) return rc;

@@ -1,0 +1,396 @@
+// api_state.hip -- the Proof-of-State job behind `verify_mina_state` (8f-1; BASELINE config C3).
+//
+// What the reference's verifier does per state proof (README.md:281-310; Aligned `verify_mina_state_ffi`, un-vendored):
+//   1. hash the 16 candidate-chain protocol states and the bridge tip state (`MinaHash`: Poseidon over `to_input`, twice),
+//      compare with the public inputs, check that the states form a chain                       -> pstate_hash_kernel + chain check
+//   2. Pickles wrap verification of the tip proof:
+//        public-input commitment (Lagrange MSM, Pallas)                                         -> mb_msm_table + pubcomm finish
+//        Fiat-Shamir + combined IPA opening (k = 15)                                            -> mb_ipa_batch_check_dev
+//        step accumulator check (Vesta, 2^16 bases)                                             -> mb_accumulator_check_dev
+// All of it is queued on ONE lane with no host synchronisation between the stages; one verdict word per proof.
+#include "ctx.h"
+#include "msm.cuh"
+#include "sponge.cuh"
+#include "lagrange.cuh"
+#include "wire_state.h"
+
+namespace mb {
+
+template <int F> __device__ __forceinline__ fe_t ld_fe(const uint32_t *p) { fe_t r; for (int i = 0; i < 8; ++i) r.v[i] = p[i]; return r; }
+
+// `MinaHash(ProtocolState)`: body = H_{"MinaProtoStateBody"}(fields[1 .. 1+nf)); hash = H_{"MinaProtoState"}(fields[0], body).
+// One lane group (4 or 8 lanes) per state; record = MINA_PSTATE_SLOTS field elements, canonical words.
+template <int F, int LANES>
+__global__ void __launch_bounds__(256)
+pstate_hash_kernel(uint32_t n, FieldK fk, const PoseidonParams *__restrict__ pp, const fe_t *__restrict__ salts /* [0..3) body, [3..6) state */,
+                   const uint32_t *__restrict__ records, const uint32_t *__restrict__ nfields, uint32_t *__restrict__ out_hash /* n*8 */,
+                   uint32_t *__restrict__ out_body /* n*8 or null */) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t sp = gid / LANES, e = coop_elem<LANES>();
+    const bool live = sp < n;
+    const uint32_t idx = live ? sp : 0;                            // dead groups shadow state 0 (whole waves run the cross-lane moves)
+    const uint32_t *rec = records + (size_t)idx * MINA_PSTATE_SLOTS * 8;
+    uint32_t nf = nfields[idx]; if (nf > MINA_PSTATE_SLOTS - 1) nf = MINA_PSTATE_SLOTS - 1;
+    fe_t s = salts[e];
+    uint32_t count = 0;
+    for (uint32_t el = 0; el < nf; ++el) {
+        if (count == 2) { poseidon_permute_coop<F, LANES>(s, pp); count = 0; }
+        if (e == count) s = fe_add<F>(s, fe_to_mont<F>(ld_fe<F>(rec + (size_t)(1 + el) * 8), fk.r2));
+        ++count;
+    }
+    poseidon_permute_coop<F, LANES>(s, pp);
+    const fe_t body = coop_get<LANES>(s, 0);
+    s = salts[3 + e];
+    if (e == 0) s = fe_add<F>(s, fe_to_mont<F>(ld_fe<F>(rec), fk.r2));
+    if (e == 1) s = fe_add<F>(s, body);
+    poseidon_permute_coop<F, LANES>(s, pp);
+    s = coop_get<LANES>(s, 0);
+    if (live && (gid % LANES) == 0) {
+        const fe_t w = fe_from_mont<F>(s); for (int i = 0; i < 8; ++i) out_hash[(size_t)sp * 8 + i] = w.v[i];
+        if (out_body) { const fe_t bw = fe_from_mont<F>(body); for (int i = 0; i < 8; ++i) out_body[(size_t)sp * 8 + i] = bw.v[i]; }
+    }
+}
+
+// salts of the hash prefixes: state after absorbing the prefix element into the zero state and permuting (3 elements each)
+template <int F>
+__global__ void prefix_salt_kernel(uint32_t n, FieldK fk, const PoseidonParams *__restrict__ pp, const uint32_t *__restrict__ prefixes, fe_t *__restrict__ salts) {
+    const uint32_t h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= n) return;
+    fe_t s[3] = {fe_to_mont<F>(ld_fe<F>(prefixes + (size_t)h * 8), fk.r2), fe_zero(), fe_zero()};
+    poseidon_permute<F>(s, pp);
+    for (int j = 0; j < 3; ++j) salts[(size_t)h * 3 + j] = s[j];
+}
+
+// README.md:283-288 per proof: hashes of the 16 chain states and of the bridge tip state equal the public inputs, and
+// state i+1 names state i as its predecessor.  One lane per proof (pure comparisons).
+__global__ void pstate_chain_check_kernel(uint32_t batch, const uint32_t *__restrict__ hashes /* b*17*8 */, const uint32_t *__restrict__ expected /* b*17*8 */,
+                                          const uint32_t *__restrict__ records, const uint8_t *__restrict__ precheck /* b or null */, uint32_t *__restrict__ ok) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    bool good = precheck ? precheck[b] != 0 : true;
+    const uint32_t *h = hashes + (size_t)b * MINA_STATES_PER_PROOF * 8, *x = expected + (size_t)b * MINA_STATES_PER_PROOF * 8;
+    for (uint32_t i = 0; i < MINA_STATES_PER_PROOF * 8; ++i) good = good && (h[i] == x[i]);
+    for (uint32_t s = 1; s < MINA_STATES_PER_PROOF - 1; ++s) {          // candidate chain: states 0..15 (oldest .. tip); 16 = bridge tip (not linked)
+        const uint32_t *prev = records + ((size_t)b * MINA_STATES_PER_PROOF + s) * MINA_PSTATE_SLOTS * 8;   // slot 0 = previous_state_hash
+        for (int i = 0; i < 8; ++i) good = good && (prev[i] == h[(s - 1) * 8 + i]);
+    }
+    ok[b] = good ? 1u : 0u;
+}
+
+// public-input commitment h - A as canonical affine words (16 per proof, zeros = infinity): feeds ipa_prepare_kernel's override slot
+template <int FB>
+__global__ void __launch_bounds__(64)
+pubcomm_finish16_kernel(uint32_t batch, FieldK kb, const affine_t *__restrict__ h, const xyzz_t *__restrict__ a, uint32_t *__restrict__ out_words) {
+    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= batch) return;
+    xyzz_t t = a[m];
+    t.y = fe_neg<FB>(t.y);
+    const affine_t H = *h;
+    xyzz_add_affine<FB>(t, H.x, H.y, kb.one);
+    uint32_t *o = out_words + (size_t)m * 16;
+    if (xyzz_is_inf(t)) { for (int i = 0; i < 16; ++i) o[i] = 0; return; }
+    const fe_t zi = fe_inv<FB>(fe_mul<FB>(t.zz, t.zzz), kb);
+    const fe_t x = fe_from_mont<FB>(fe_mul<FB>(t.x, fe_mul<FB>(zi, t.zzz))), y = fe_from_mont<FB>(fe_mul<FB>(t.y, fe_mul<FB>(zi, t.zz)));
+    for (int i = 0; i < 8; ++i) { o[i] = x.v[i]; o[8 + i] = y.v[i]; }
+}
+
+__global__ void fill_u32_kernel(uint32_t n, uint32_t v, uint32_t *__restrict__ out) { const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) out[i] = v; }
+
+// verdict[b] = chain_ok[b] AND folded IPA verdict AND folded accumulator verdict; flags = {ipa, ipa malformed, acc, 0}
+__global__ void state_job_verdict_kernel(uint32_t batch, const uint32_t *__restrict__ chain_ok, const uint32_t *__restrict__ ipa_v /* [2] or null */,
+                                         const uint32_t *__restrict__ acc_v /* [1] or null */, uint32_t *__restrict__ verdicts, uint32_t *__restrict__ flags) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t iv = ipa_v ? ipa_v[0] : 1u, av = acc_v ? acc_v[0] : 1u;
+    if (b == 0 && flags) { flags[0] = iv; flags[1] = ipa_v ? ipa_v[1] : 0u; flags[2] = av; flags[3] = 0u; }
+    if (b < batch) verdicts[b] = (chain_ok[b] && iv && av) ? 1u : 0u;
+}
+
+}  // namespace mb
+
+// ------------------------------------------------------------------------------------------------ host: pack one state
+static void info_from_state(const mw::ProtocolState &s, mina_protocol_state_info *info, uint32_t nf) {
+    memset(info, 0, sizeof *info);
+    memcpy(info->previous_state_hash, s.previous_state_hash.b, 32);
+    memcpy(info->genesis_state_hash, s.genesis_state_hash.b, 32);
+    memcpy(info->snarked_ledger_hash, s.snarked_ledger_hash().b, 32);
+    info->n_body_fields = nf;
+    info->k = s.k; info->slots_per_epoch = s.c_slots_per_epoch; info->slots_per_sub_window = s.slots_per_sub_window;
+    info->sub_windows_per_window = (uint32_t)s.sub_window_densities.size(); info->grace_period_slots = s.grace_period_slots; info->delta = s.delta;
+    mina_consensus_state &c = info->consensus;
+    c.blockchain_length = s.blockchain_length; c.epoch_count = s.epoch_count; c.curr_global_slot = s.slot_number; c.min_window_density = s.min_window_density;
+    for (size_t i = 0; i < s.sub_window_densities.size() && i < MINA_MAX_SUB_WINDOWS; ++i) c.sub_window_densities[i] = s.sub_window_densities[i];
+    memcpy(c.staking_lock_checkpoint, s.staking.lock_checkpoint.b, 32);
+    memcpy(c.next_lock_checkpoint, s.next.lock_checkpoint.b, 32);
+    memcpy(c.last_vrf_output_hash, s.last_vrf_output.data(), 32);          // the truncated VRF output string itself (compared lexicographically)
+}
+
+int mb_pack_protocol_state(const mw::ProtocolState &s, uint8_t *record, uint32_t *n_body_fields, mina_protocol_state_info *info) {
+    std::vector<mw::B32> f;
+    mw::protocol_state_body_fields(s, f);
+    if (f.size() > MINA_PSTATE_SLOTS - 1) return fail(MINA_ERR_FORMAT, "protocol state body flattens to more field elements than a record holds");
+    memset(record, 0, (size_t)MINA_PSTATE_SLOTS * 32);
+    memcpy(record, s.previous_state_hash.b, 32);
+    for (size_t i = 0; i < f.size(); ++i) memcpy(record + 32 * (1 + i), f[i].b, 32);
+    *n_body_fields = (uint32_t)f.size();
+    if (info) info_from_state(s, info, (uint32_t)f.size());
+    return MINA_OK;
+}
+
+extern "C" int mina_protocol_state_pack(const uint8_t *bytes, size_t len, int encoding, uint8_t *record, uint32_t *n_body_fields,
+                                        mina_protocol_state_info *info, size_t *consumed) {
+    if (!bytes || !record || !n_body_fields) return fail(MINA_ERR_ARG, "null argument");
+    mw::ProtocolState s; bool ok; size_t used;
+    if (encoding == MINA_ENC_BINPROT) { mw::Binprot c(bytes, len); ok = mw::read_protocol_state(c, s); used = c.pos; }
+    else if (encoding == MINA_ENC_BINCODE) { mw::Bincode c(bytes, len); ok = mw::read_protocol_state(c, s); used = c.pos; }
+    else return fail(MINA_ERR_ARG, "encoding must be MINA_ENC_BINPROT or MINA_ENC_BINCODE");
+    if (!ok) return fail(MINA_ERR_FORMAT, "malformed protocol state");
+    if (consumed) *consumed = used; else if (used != len) return fail(MINA_ERR_FORMAT, "trailing bytes after the protocol state");
+    return mb_pack_protocol_state(s, record, n_body_fields, info);
+}
+
+// ------------------------------------------------------------------------------------------------ salts
+static int ensure_state_salts(mina_ctx *c) {
+    if (c->have_state_salts) return MINA_OK;
+    if (!c->have_pparams[FIELD_FP]) return fail(MINA_ERR_STATE, "Poseidon constants not installed for Fp");
+    const char *names[MB_N_PREFIX_SALTS] = {"MinaProtoStateBody", "MinaProtoState", "MinaAccount", "MinaZkappAccount", "MinaZkappUri", "MinaDeriveTokenId"};
+    uint8_t pre[MB_N_PREFIX_SALTS * 32];
+    for (int i = 0; i < MB_N_PREFIX_SALTS; ++i) { const mw::B32 f = mw::prefix_field(names[i]); memcpy(pre + 32 * i, f.b, 32); }
+    int rc;
+    if ((rc = c->state_salts.ensure(MB_N_PREFIX_SALTS * 3 * sizeof(fe_t)))) return rc;
+    DevBuf tmp;
+    if ((rc = tmp.ensure(sizeof pre))) return rc;
+    HIPC(hipMemcpyAsync(tmp.p, pre, sizeof pre, hipMemcpyHostToDevice, c->L->stream));
+    mb::prefix_salt_kernel<FIELD_FP><<<1, 64, 0, c->L->stream>>>(MB_N_PREFIX_SALTS, c->fk[FIELD_FP], c->pparams[FIELD_FP].as<PoseidonParams>(), tmp.as<uint32_t>(), c->state_salts.as<fe_t>());
+    HIPC(hipGetLastError());
+    HIPC(hipStreamSynchronize(c->L->stream));
+    tmp.release();
+    c->have_state_salts = true;
+    return MINA_OK;
+}
+
+static int pstate_hash_dev(mina_ctx *c, size_t n, const uint32_t *d_records, const uint32_t *d_nfields, uint32_t *d_hashes, uint32_t *d_bodies) {
+    const PoseidonParams *pp = c->pparams[FIELD_FP].as<PoseidonParams>();
+    const fe_t *salts = c->state_salts.as<fe_t>();
+    // below ~8 k states the chip is latency-bound: 8 lanes per state; above, 4 lanes
+    if (n <= COOP8_MAX_GROUPS)
+        mb::pstate_hash_kernel<FIELD_FP, 8><<<cdiv(n * 8, 256), 256, 0, c->L->stream>>>((uint32_t)n, c->fk[FIELD_FP], pp, salts, d_records, d_nfields, d_hashes, d_bodies);
+    else
+        mb::pstate_hash_kernel<FIELD_FP, 4><<<cdiv(n * 4, 256), 256, 0, c->L->stream>>>((uint32_t)n, c->fk[FIELD_FP], pp, salts, d_records, d_nfields, d_hashes, d_bodies);
+    HIPC(hipGetLastError());
+    return MINA_OK;
+}
+
+extern "C" int mina_protocol_state_hash_batch(mina_ctx *c, size_t n, const uint8_t *records, const uint32_t *n_body_fields, uint8_t *hashes_out,
+                                              uint8_t *body_hashes_out) {
+    if (!c || (n && (!records || !n_body_fields || !hashes_out))) return fail(MINA_ERR_ARG, "null argument");
+    if (n == 0) return MINA_OK;
+    if (n > (1u << 22)) return fail(MINA_ERR_ARG, "n too large");
+    for (size_t i = 0; i < n; ++i) if (n_body_fields[i] > MINA_PSTATE_SLOTS - 1) return fail(MINA_ERR_ARG, "n_body_fields exceeds the record");
+    HIPC(hipSetDevice(c->device));
+    c->use_lane0();
+    int rc;
+    if ((rc = ensure_state_salts(c))) return rc;
+    Lane &L = *c->L;
+    if ((rc = h2d(c, L.tmp_a, records, n * MINA_PSTATE_SLOTS * 32))) return rc;
+    if ((rc = h2d(c, L.tmp_b, n_body_fields, n * 4))) return rc;
+    if ((rc = L.tmp_c.ensure(n * 32))) return rc;
+    if ((rc = L.tmp_d.ensure(n * 32))) return rc;
+    if ((rc = pstate_hash_dev(c, n, L.tmp_a.as<uint32_t>(), L.tmp_b.as<uint32_t>(), L.tmp_c.as<uint32_t>(), body_hashes_out ? L.tmp_d.as<uint32_t>() : nullptr))) return rc;
+    if (body_hashes_out) HIPC(hipMemcpyAsync(body_hashes_out, L.tmp_d.p, n * 32, hipMemcpyDeviceToHost, L.stream));
+    return d2h_sync(c, hashes_out, L.tmp_c, n * 32);
+}
+
+// convenience: serialized states in, state hashes out (parse on the host, hash on the GPU); malformed state -> MINA_ERR_FORMAT
+extern "C" int mina_protocol_state_hash_bytes(mina_ctx *c, int encoding, size_t n, const uint8_t *const *states, const size_t *lens, uint8_t *hashes_out) {
+    if (!c || (n && (!states || !lens || !hashes_out))) return fail(MINA_ERR_ARG, "null argument");
+    std::vector<uint8_t> rec(n * MINA_PSTATE_SLOTS * 32); std::vector<uint32_t> nf(n);
+    for (size_t i = 0; i < n; ++i) {
+        if (!states[i]) return fail(MINA_ERR_ARG, "null state");
+        int rc = mina_protocol_state_pack(states[i], lens[i], encoding, &rec[i * MINA_PSTATE_SLOTS * 32], &nf[i], nullptr, nullptr);
+        if (rc) return rc;
+    }
+    return mina_protocol_state_hash_batch(c, n, rec.data(), nf.data(), hashes_out, nullptr);
+}
+
+// ------------------------------------------------------------------------------------------------ the composite job
+static int check_jobs(mina_ctx *c, const mina_state_jobs *j) {
+    if (!c || !j) return fail(MINA_ERR_ARG, "null argument");
+    if (j->batch == 0 || j->batch > 65536) return fail(MINA_ERR_ARG, "batch must be in 1..65536");
+    if (j->with_states && (!j->state_records || !j->state_nfields || !j->expected_hashes)) return fail(MINA_ERR_ARG, "null protocol-state section");
+    if (j->with_ipa) {
+        if (!j->sponge_state || !j->sponge_pos || !j->cip || !j->lr || !j->delta || !j->sg || !j->z1 || !j->z2 || !j->evalscale || !j->polyscale ||
+            !j->rand_base || !j->sg_rand_base || (j->n_evalpoints && !j->evalpoints) || (j->n_comms && !j->comms)) return fail(MINA_ERR_ARG, "null IPA section");
+        if (j->k < 1 || j->k > 20 || ((size_t)1 << j->k) > c->srs[CURVE_PALLAS].depth) return fail(c->srs[CURVE_PALLAS].depth ? MINA_ERR_ARG : MINA_ERR_STATE, "Pallas SRS missing or 2^k exceeds its depth");
+        if (j->n_comms > 4096 || j->n_evalpoints > 64) return fail(MINA_ERR_ARG, "too many commitments / evaluation points");
+        if (!c->have_pparams[FIELD_FP]) return fail(MINA_ERR_STATE, "Poseidon constants not installed for Fp");
+    }
+    if (j->npub) {
+        if (!j->public_inputs) return fail(MINA_ERR_ARG, "null public inputs");
+        if (!j->with_ipa || j->pub_comm_slot >= j->n_comms) return fail(MINA_ERR_ARG, "public-input commitment needs an IPA section and a valid commitment slot");
+        if (j->log2_domain > 20 || ((uint64_t)1 << j->log2_domain) > c->srs[CURVE_PALLAS].depth || j->npub > 4096 || j->npub > ((uint64_t)1 << j->log2_domain)) return fail(MINA_ERR_ARG, "bad domain / npub");
+    }
+    if (j->with_accumulator) {
+        if (!j->acc_prechallenges || !j->acc_sg || (j->batch > 1 && !j->acc_rho)) return fail(MINA_ERR_ARG, "null accumulator section");
+        if (j->acc_k < 1 || j->acc_k > 20 || ((size_t)1 << j->acc_k) > c->srs[CURVE_VESTA].depth) return fail(c->srs[CURVE_VESTA].depth ? MINA_ERR_ARG : MINA_ERR_STATE, "Vesta SRS missing or 2^k exceeds its depth");
+    }
+    return MINA_OK;
+}
+
+int mb_ensure_lagrange_table(mina_ctx *c, int curve, uint32_t log2_domain, uint32_t npub);   // api_srs.hip
+
+// everything that needs a host synchronisation (salts, Lagrange basis + its window table): done once, before the first job
+extern "C" int mina_state_jobs_prepare(mina_ctx *c, uint32_t log2_domain, uint32_t npub) {
+    if (!c) return fail(MINA_ERR_ARG, "null argument");
+    HIPC(hipSetDevice(c->device));
+    c->use_lane0();
+    int rc;
+    if ((rc = ensure_state_salts(c))) return rc;
+    if (npub && (rc = mb_ensure_lagrange_table(c, CURVE_PALLAS, log2_domain, npub))) return rc;
+    return MINA_OK;
+}
+
+// all pointers of `j` are device pointers; queued on the current lane
+static int state_jobs_on_lane(mina_ctx *c, const mina_state_jobs *j, uint32_t *d_verdicts, uint32_t *d_flags) {
+    Lane &L = *c->L;
+    const size_t B = j->batch;
+    int rc;
+    if ((rc = L.st_ok.ensure(B * 4))) return rc;
+    if (j->with_states) {
+        const size_t ns = B * MINA_STATES_PER_PROOF;
+        if ((rc = L.st_hashes.ensure(ns * 32))) return rc;
+        if ((rc = pstate_hash_dev(c, ns, (const uint32_t *)j->state_records, (const uint32_t *)j->state_nfields, L.st_hashes.as<uint32_t>(), nullptr))) return rc;
+        mb::pstate_chain_check_kernel<<<cdiv(B, 64), 64, 0, L.stream>>>((uint32_t)B, L.st_hashes.as<uint32_t>(), (const uint32_t *)j->expected_hashes,
+                                                                         (const uint32_t *)j->state_records, (const uint8_t *)j->precheck, L.st_ok.as<uint32_t>());
+    } else {
+        // no state leg: chain_ok = all ones
+        if (j->precheck) return fail(MINA_ERR_ARG, "precheck needs the protocol-state section");
+        mb::fill_u32_kernel<<<cdiv(B, 256), 256, 0, L.stream>>>((uint32_t)B, 1u, L.st_ok.as<uint32_t>());
+    }
+    HIPC(hipGetLastError());
+    const uint32_t *comm_override = nullptr;
+    if (j->npub) {
+        SrsState &s = c->srs[CURVE_PALLAS];
+        if (s.lagrange_table_log2 != (int)j->log2_domain || s.lagrange_table_n < j->npub) return fail(MINA_ERR_STATE, "call mina_state_jobs_prepare(log2_domain, npub) first");
+        if ((rc = L.st_pub_xyzz.ensure(B * sizeof(xyzz_t)))) return rc;
+        if ((rc = L.st_pubcomm.ensure(B * 64))) return rc;
+        if ((rc = mb_msm_table(c, CURVE_PALLAS, s.lagrange_table.p, s.lagrange_table_n, 8, 32, 0, j->npub, (uint32_t)B, (const uint32_t *)j->public_inputs, nullptr, L.st_pub_xyzz.p))) return rc;
+        mb::pubcomm_finish16_kernel<FIELD_FP><<<cdiv(B, 64), 64, 0, L.stream>>>((uint32_t)B, c->fk[FIELD_FP], s.h.as<affine_t>(), L.st_pub_xyzz.as<xyzz_t>(), L.st_pubcomm.as<uint32_t>());
+        HIPC(hipGetLastError());
+        comm_override = L.st_pubcomm.as<uint32_t>();
+    }
+    uint32_t *ipa_v = nullptr, *acc_v = nullptr;
+    if ((rc = L.st_flags.ensure(16 * 4))) return rc;
+    if (j->with_ipa) {
+        mb::IpaShape sh; sh.batch = (uint32_t)B; sh.k = j->k; sh.npts = j->n_evalpoints; sh.ncomms = j->n_comms; sh.per = 2 * j->k + j->n_comms + 4;
+        sh.override_slot = j->npub ? j->pub_comm_slot : 0xffffffffu;
+        auto W = [](const void *p) { return (const uint32_t *)p; };
+        mb::IpaDevIn in{W(j->sponge_state), W(j->sponge_pos), W(j->cip), W(j->lr), W(j->delta), W(j->sg), W(j->z1), W(j->z2), W(j->evalpoints), W(j->evalscale),
+                        W(j->polyscale), W(j->comms), comm_override, W(j->rand_base), W(j->sg_rand_base)};
+        ipa_v = L.st_flags.as<uint32_t>() + 4;
+        if ((rc = mb_ipa_batch_check_dev(c, CURVE_PALLAS, sh, in, ipa_v))) return rc;
+    }
+    if (j->with_accumulator) {
+        acc_v = L.st_flags.as<uint32_t>() + 8;
+        if ((rc = mb_accumulator_check_dev(c, CURVE_VESTA, j->acc_k, B, (const uint32_t *)j->acc_prechallenges, (const uint32_t *)j->acc_sg,
+                                           B > 1 ? (const uint32_t *)j->acc_rho : nullptr, acc_v))) return rc;
+    }
+    mb::state_job_verdict_kernel<<<cdiv(B, 64), 64, 0, L.stream>>>((uint32_t)B, L.st_ok.as<uint32_t>(), ipa_v, acc_v, d_verdicts, d_flags);
+    HIPC(hipGetLastError());
+    return MINA_OK;
+}
+
+extern "C" int mina_state_job_batch_dev(mina_ctx *c, const mina_state_jobs *jobs, void *d_verdicts, void *d_flags) {
+    int rc = check_jobs(c, jobs);
+    if (rc) return rc;
+    if (!d_verdicts) return fail(MINA_ERR_ARG, "null argument");
+    if (!c->have_state_salts && jobs->with_states) return fail(MINA_ERR_STATE, "call mina_state_jobs_prepare first");
+    HIPC(hipSetDevice(c->device));
+    c->next_lane();
+    return state_jobs_on_lane(c, jobs, (uint32_t *)d_verdicts, (uint32_t *)d_flags);
+}
+
+// host-buffer form: one upload of every section, the pipeline, one download; when a folded check fails the proofs are
+// re-checked in halves (bisection) so that every proof gets its own verdict (README.md:281-310: every failure is `false`)
+namespace {
+struct Section { const void **slot; size_t bytes; };
+}
+extern "C" int mina_state_job_batch(mina_ctx *c, const mina_state_jobs *jobs, uint8_t *verdicts) {
+    int rc = check_jobs(c, jobs);
+    if (rc) return rc;
+    if (!verdicts) return fail(MINA_ERR_ARG, "null argument");
+    HIPC(hipSetDevice(c->device));
+    c->use_lane0();
+    if ((rc = mina_state_jobs_prepare(c, jobs->log2_domain, jobs->npub))) return rc;
+    c->use_lane0();
+    Lane &L = *c->L;
+    mina_state_jobs d = *jobs;
+    const size_t B = jobs->batch, k = jobs->k, m = jobs->n_comms, np = jobs->n_evalpoints, S = MINA_STATES_PER_PROOF;
+    std::vector<Section> secs;
+    auto add = [&](const void *&slot, size_t bytes) { if (slot && bytes) secs.push_back({&slot, bytes}); };
+    if (d.with_states) { add(d.state_records, B * S * MINA_PSTATE_SLOTS * 32); add(d.state_nfields, B * S * 4); add(d.expected_hashes, B * S * 32); add(d.precheck, B); }
+    if (d.npub) add(d.public_inputs, B * d.npub * 32);
+    if (d.with_ipa) {
+        add(d.sponge_state, B * 96); add(d.sponge_pos, B * 8); add(d.cip, B * 32); add(d.lr, B * 2 * k * 64); add(d.delta, B * 64); add(d.sg, B * 64);
+        add(d.z1, B * 32); add(d.z2, B * 32); add(d.evalpoints, B * np * 32); add(d.evalscale, B * 32); add(d.polyscale, B * 32); add(d.comms, B * m * 64);
+        add(d.rand_base, 32); add(d.sg_rand_base, 32);
+    }
+    if (d.with_accumulator) { add(d.acc_prechallenges, B * d.acc_k * 16); add(d.acc_sg, B * 64); add(d.acc_rho, B * 32); }
+    size_t total = 0;
+    std::vector<size_t> offs;
+    for (auto &s : secs) { offs.push_back(total); total += (s.bytes + 255) & ~(size_t)255; }
+    if ((rc = L.host_stage.ensure(total + B * 4))) return rc;
+    uint8_t *blob = (uint8_t *)L.host_stage.p;
+    for (size_t i = 0; i < secs.size(); ++i) memcpy(blob + offs[i], *secs[i].slot, secs[i].bytes);
+    if ((rc = L.st_in.ensure(total))) return rc;
+    HIPC(hipMemcpyAsync(L.st_in.p, blob, total, hipMemcpyHostToDevice, L.stream));
+    for (size_t i = 0; i < secs.size(); ++i) *secs[i].slot = L.st_in.as<uint8_t>() + offs[i];
+    if ((rc = L.st_verdicts.ensure(B * 4 + 16))) return rc;
+    uint32_t *dv = L.st_verdicts.as<uint32_t>(), *df = dv + B;
+    if ((rc = state_jobs_on_lane(c, &d, dv, df))) return rc;
+    std::vector<uint32_t> hv(B + 4);
+    if ((rc = d2h_sync(c, hv.data(), L.st_verdicts, (B + 4) * 4))) return rc;
+    const bool ipa_ok = hv[B] != 0, acc_ok = hv[B + 2] != 0;
+    if (ipa_ok && acc_ok) { for (size_t b = 0; b < B; ++b) verdicts[b] = hv[b] ? 1 : 0; return MINA_OK; }
+    // a folded check failed somewhere: find the culprits.  chain_ok per proof comes from a run without the folded legs.
+    std::vector<uint8_t> ipa_each(B, 1), acc_each(B, 1), chain_each(B, 1);
+    {
+        mina_state_jobs only = d; only.with_ipa = 0; only.with_accumulator = 0; only.npub = 0;
+        if (only.with_states) {
+            if ((rc = state_jobs_on_lane(c, &only, dv, df))) return rc;
+            if ((rc = d2h_sync(c, hv.data(), L.st_verdicts, B * 4))) return rc;
+            for (size_t b = 0; b < B; ++b) chain_each[b] = hv[b] ? 1 : 0;
+        }
+    }
+    auto slice = [&](const mina_state_jobs &src, size_t lo, size_t cnt) {
+        mina_state_jobs s = src; s.batch = cnt; s.with_states = 0; s.precheck = nullptr;
+        auto adv = [&](const void *&p, size_t stride) { if (p) p = (const uint8_t *)p + lo * stride; };
+        adv(s.public_inputs, (size_t)s.npub * 32);
+        adv(s.sponge_state, 96); adv(s.sponge_pos, 8); adv(s.cip, 32); adv(s.lr, 2 * k * 64); adv(s.delta, 64); adv(s.sg, 64); adv(s.z1, 32); adv(s.z2, 32);
+        adv(s.evalpoints, np * 32); adv(s.evalscale, 32); adv(s.polyscale, 32); adv(s.comms, m * 64);
+        adv(s.acc_prechallenges, (size_t)s.acc_k * 16); adv(s.acc_sg, 64); adv(s.acc_rho, 32);
+        return s;
+    };
+    // recursive halving on one leg at a time
+    auto bisect = [&](bool ipa_leg, std::vector<uint8_t> &each) -> int {
+        std::vector<std::pair<size_t, size_t>> todo{{0, B}};
+        while (!todo.empty()) {
+            auto [lo, cnt] = todo.back(); todo.pop_back();
+            mina_state_jobs s = slice(d, lo, cnt);
+            if (ipa_leg) s.with_accumulator = 0; else { s.with_ipa = 0; s.npub = 0; }
+            int r = state_jobs_on_lane(c, &s, dv, df);
+            if (r) return r;
+            uint32_t f[4];
+            HIPC(hipMemcpyAsync(f, df, 16, hipMemcpyDeviceToHost, L.stream));
+            HIPC(hipStreamSynchronize(L.stream));
+            const bool ok = ipa_leg ? f[0] != 0 : f[2] != 0;
+            if (ok) continue;
+            if (cnt == 1) { each[lo] = 0; continue; }
+            todo.push_back({lo, cnt / 2}); todo.push_back({lo + cnt / 2, cnt - cnt / 2});
+        }
+        return MINA_OK;
+    };
+    if (!ipa_ok && (rc = bisect(true, ipa_each))) return rc;
+    if (!acc_ok && (rc = bisect(false, acc_each))) return rc;
+    for (size_t b = 0; b < B; ++b) verdicts[b] = (chain_each[b] && ipa_each[b] && acc_each[b]) ? 1 : 0;
+    return MINA_OK;
+}

@@ -86,17 +86,20 @@ struct Lane {
     PinnedBuf host_stage;                    // pinned host side of the big H2D blobs (synchronous entry points only)
     DevBuf bp_ltab, bp_htab, bp_partial;
     DevBuf ipa_chals, ipa_folded, ipa_xyzz_a, ipa_xyzz_b, ipa_points, ipa_scalars, ipa_sigma, ipa_in_a, ipa_in_b, ipa_in_c, ipa_verdict, ipa_xfer;
+    DevBuf st_ok, st_hashes, st_pub_xyzz, st_pubcomm, st_flags, st_in, st_verdicts;   // Proof-of-State job (api_state.hip)
     void release_all() {
         MsmWorkspace &w = ws;
         DevBuf *all[] = {&w.scalars, &w.points, &w.ekey, &w.eval, &w.eoff, &w.count, &w.start, &w.task_start, &w.rem_pos, &w.rem_bucket, &w.info, &w.sorted, &w.partial, &w.heavy, &w.order, &w.ghist, &w.stage,
                          &w.buckets, &w.red_r, &w.red_ws, &w.red2_r, &w.red2_w, &w.set_total, &w.out_words, &w.out_xyzz, &tmp_a, &tmp_b, &tmp_c, &tmp_d,
                          &bp_ltab, &bp_htab, &bp_partial, &ipa_chals, &ipa_folded, &ipa_xyzz_a, &ipa_xyzz_b, &ipa_points, &ipa_scalars,
-                         &ipa_sigma, &ipa_in_a, &ipa_in_b, &ipa_in_c, &ipa_verdict, &ipa_xfer};
+                         &ipa_sigma, &ipa_in_a, &ipa_in_b, &ipa_in_c, &ipa_verdict, &ipa_xfer,
+                         &st_ok, &st_hashes, &st_pub_xyzz, &st_pubcomm, &st_flags, &st_in, &st_verdicts};
         for (DevBuf *b : all) b->release();
         host_stage.release();
     }
 };
 static constexpr int MB_MAX_LANES = 16;
+enum : int { MB_SALT_PSTATE_BODY = 0, MB_SALT_PSTATE, MB_SALT_ACCOUNT, MB_SALT_ZKAPP_ACCOUNT, MB_SALT_ZKAPP_URI, MB_SALT_DERIVE_TOKEN_ID, MB_N_PREFIX_SALTS };
 
 struct mina_ctx {
     int device = 0;
@@ -109,6 +112,7 @@ struct mina_ctx {
     SrsState srs[2];
     DevBuf pparams[2]; bool have_pparams[2] = {false, false};
     DevBuf merkle_salts[2]; uint32_t merkle_depth[2] = {0, 0};   // salted initial states of the Merkle hash per height
+    DevBuf state_salts; bool have_state_salts = false;           // salted initial states of the named hash prefixes (Fp): MB_SALT_*
     void use_lane0() { L = &lanes[0]; }
     void next_lane() { L = &lanes[rr++ % (unsigned)nlanes]; }
 };
@@ -148,6 +152,18 @@ struct ProfScope {
     ProfScope(mina_ctx *c_, int s_) : c(c_), stage(s_) { if (c->prof.mask & (1 << stage)) mb_prof_begin(c, stage); }
     ~ProfScope() { if (c->prof.mask & (1 << stage)) mb_prof_end(c, stage); }
 };
+
+// combined IPA opening check with inputs in HBM (api_ipa.hip)
+namespace mb {
+struct IpaShape { uint32_t batch, k, npts, ncomms, per; uint32_t override_slot = 0xffffffffu; };   // per = 2k + ncomms + 4 points per proof;
+// override_slot: commitment index whose point comes from `comm_override` (b*16 canonical words, e.g. the public-input commitment computed on the GPU)
+struct IpaDevIn {     // structure-of-arrays over the batch, canonical little-endian words; layouts as in mina_ipa_opening
+    const uint32_t *state /* b*24 */, *pos /* b*2 */, *cip /* b*8 */, *lr /* b*2k*16 */, *delta /* b*16 */, *sg /* b*16 */, *z1, *z2 /* b*8 */,
+                   *pts /* b*npts*8 */, *r /* b*8 */, *xi /* b*8 */, *comms /* b*ncomms*16 */, *comm_override /* b*16 or null */, *rb /* 8 */, *sb /* 8 */;
+};
+}
+int mb_ipa_batch_check_dev(mina_ctx *c, int curve, mb::IpaShape sh, const mb::IpaDevIn &in, uint32_t *d_verdict /* [0] verdict, [1] malformed flag */);
+int mb_accumulator_check_dev(mina_ctx *c, int curve, uint32_t k, size_t batch, const uint32_t *d_prechal, const uint32_t *d_sg_words, const uint32_t *d_rho, uint32_t *d_verdict);
 
 // cross-file entry points (C++ linkage)
 struct xyzz_dev;   // opaque: mb::xyzz_t in HBM

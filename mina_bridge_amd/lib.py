@@ -31,6 +31,8 @@ EXPORTS = [
     "mina_field_mul", "mina_field_inv", "mina_field_sqrt", "mina_selftest_group_law",
     "mina_accumulator_check_batch", "mina_accumulator_check_dev", "mina_accumulator_check_multi_dev", "mina_accumulator_check_multi", "mina_ipa_batch_check",
     "mina_consensus_project_window", "mina_consensus_relative_min_window_density", "mina_consensus_is_short_range",
+    "mina_protocol_state_pack", "mina_protocol_state_hash_batch", "mina_protocol_state_hash_bytes",
+    "mina_state_jobs_prepare", "mina_state_job_batch_dev", "mina_state_job_batch",
     "mina_consensus_select_secure_chain", "mina_parse_state_pub_inputs", "mina_parse_account_pub_inputs", "mina_parse_merkle_path", "mina_verify_account_inclusion",
 ]
 
@@ -156,6 +158,49 @@ class IpaOpening(ctypes.Structure):
         ("combined_inner_product", ctypes.c_void_p), ("polyscale", ctypes.c_void_p), ("evalscale", ctypes.c_void_p),
         ("sponge_state", ctypes.c_void_p), ("sponge_mode", ctypes.c_uint32), ("sponge_count", ctypes.c_uint32),
     ]
+
+
+PSTATE_SLOTS, STATES_PER_PROOF = 64, 17
+ENC_BINPROT, ENC_BINCODE = 0, 1
+
+
+class ProtocolStateInfo(ctypes.Structure):
+    _fields_ = [("previous_state_hash", ctypes.c_uint8 * 32), ("genesis_state_hash", ctypes.c_uint8 * 32), ("snarked_ledger_hash", ctypes.c_uint8 * 32),
+                ("n_body_fields", ctypes.c_uint32), ("k", ctypes.c_uint32), ("slots_per_epoch", ctypes.c_uint32), ("slots_per_sub_window", ctypes.c_uint32),
+                ("sub_windows_per_window", ctypes.c_uint32), ("grace_period_slots", ctypes.c_uint32), ("delta", ctypes.c_uint32),
+                ("consensus", ConsensusState)]
+
+
+class StateJobs(ctypes.Structure):
+    """mirror of `mina_state_jobs` (include/mina_verify.h); every pointer is a host or a device address depending on the entry point"""
+    _fields_ = [
+        ("batch", ctypes.c_size_t),
+        ("with_states", ctypes.c_int), ("state_records", ctypes.c_void_p), ("state_nfields", ctypes.c_void_p), ("expected_hashes", ctypes.c_void_p),
+        ("precheck", ctypes.c_void_p),
+        ("log2_domain", ctypes.c_uint32), ("npub", ctypes.c_uint32), ("pub_comm_slot", ctypes.c_uint32), ("public_inputs", ctypes.c_void_p),
+        ("with_ipa", ctypes.c_int), ("k", ctypes.c_uint32), ("n_evalpoints", ctypes.c_uint32), ("n_comms", ctypes.c_uint32),
+        ("sponge_state", ctypes.c_void_p), ("sponge_pos", ctypes.c_void_p), ("cip", ctypes.c_void_p), ("lr", ctypes.c_void_p), ("delta", ctypes.c_void_p),
+        ("sg", ctypes.c_void_p), ("z1", ctypes.c_void_p), ("z2", ctypes.c_void_p), ("evalpoints", ctypes.c_void_p), ("evalscale", ctypes.c_void_p),
+        ("polyscale", ctypes.c_void_p), ("comms", ctypes.c_void_p), ("rand_base", ctypes.c_void_p), ("sg_rand_base", ctypes.c_void_p),
+        ("with_accumulator", ctypes.c_int), ("acc_k", ctypes.c_uint32), ("acc_prechallenges", ctypes.c_void_p), ("acc_sg", ctypes.c_void_p),
+        ("acc_rho", ctypes.c_void_p),
+    ]
+
+    POINTER_FIELDS = ("state_records", "state_nfields", "expected_hashes", "precheck", "public_inputs", "sponge_state", "sponge_pos", "cip", "lr",
+                      "delta", "sg", "z1", "z2", "evalpoints", "evalscale", "polyscale", "comms", "rand_base", "sg_rand_base", "acc_prechallenges",
+                      "acc_sg", "acc_rho")
+
+
+def protocol_state_pack(data: bytes, encoding: int = ENC_BINPROT, exact: bool = True):
+    """serialized protocol state -> (record[64*32] uint8, n_body_fields, info dict, consumed).  No GPU needed."""
+    lib = load_library()
+    b = _u8(data) if len(data) else np.zeros(1, np.uint8)
+    rec = np.zeros(PSTATE_SLOTS * 32, np.uint8); nf = ctypes.c_uint32(0); info = ProtocolStateInfo(); used = ctypes.c_size_t(0)
+    rc = lib.mina_protocol_state_pack(_p(b), ctypes.c_size_t(len(data)), int(encoding), _p(rec), ctypes.byref(nf), ctypes.byref(info),
+                                      None if exact else ctypes.byref(used))
+    if rc != 0:
+        raise MinaError(f"mina_protocol_state_pack failed ({rc}): {lib.mina_last_error().decode()}")
+    return rec, nf.value, info, (len(data) if exact else used.value)
 
 
 _lib = None
@@ -560,3 +605,65 @@ class MinaContext:
         v = np.zeros(1, np.uint8)
         self._ck(self._lib.mina_ipa_batch_check(self._h, curve, ctypes.c_size_t(len(arr)), arr, _p(rb), _p(sb), _p(v)), "mina_ipa_batch_check")
         return bool(v[0])
+
+    # -- protocol states / the Proof-of-State job
+    def protocol_state_hash_batch(self, records, nfields, want_body: bool = False):
+        rec = _u8(records); nf = np.ascontiguousarray(nfields, dtype=np.uint32)
+        n = nf.size
+        assert rec.size == n * PSTATE_SLOTS * 32
+        out = np.empty((n, 32), np.uint8); body = np.empty((n, 32), np.uint8) if want_body else None
+        self._ck(self._lib.mina_protocol_state_hash_batch(self._h, ctypes.c_size_t(n), _p(rec), nf.ctypes.data_as(ctypes.c_void_p), _p(out), _p(body)),
+                 "mina_protocol_state_hash_batch")
+        return (out, body) if want_body else out
+
+    def protocol_state_hash_bytes(self, states: list, encoding: int = ENC_BINPROT) -> np.ndarray:
+        n = len(states)
+        arrs = [_u8(s) for s in states]
+        PP = (ctypes.c_void_p * n)(*[a.ctypes.data for a in arrs]); PL = (ctypes.c_size_t * n)(*[len(s) for s in states])
+        out = np.empty((n, 32), np.uint8)
+        self._ck(self._lib.mina_protocol_state_hash_bytes(self._h, int(encoding), ctypes.c_size_t(n), PP, PL, _p(out)), "mina_protocol_state_hash_bytes")
+        return out
+
+    def state_jobs_prepare(self, log2_domain: int, npub: int):
+        self._ck(self._lib.mina_state_jobs_prepare(self._h, ctypes.c_uint32(log2_domain), ctypes.c_uint32(npub)), "mina_state_jobs_prepare")
+
+    @staticmethod
+    def make_state_jobs(batch: int, arrays: dict, **scalars):
+        """host-side `mina_state_jobs`: arrays maps pointer-field name -> numpy array (kept alive by the returned list)"""
+        j = StateJobs(); keep = []
+        j.batch = batch
+        for name, val in scalars.items():
+            setattr(j, name, val)
+        for name in StateJobs.POINTER_FIELDS:
+            a = arrays.get(name)
+            if a is None:
+                continue
+            a = np.ascontiguousarray(a); keep.append(a)
+            setattr(j, name, a.ctypes.data)
+        return j, keep
+
+    def state_job_batch(self, jobs) -> np.ndarray:
+        j, keep = jobs
+        out = np.zeros(j.batch, np.uint8)
+        self._ck(self._lib.mina_state_job_batch(self._h, ctypes.byref(j), _p(out)), "mina_state_job_batch")
+        return out
+
+    def state_jobs_to_device(self, jobs):
+        """upload every section of a host-side StateJobs; returns (device StateJobs, [device pointers to free])"""
+        j, keep = jobs
+        d = StateJobs(); ptrs = []
+        ctypes.memmove(ctypes.byref(d), ctypes.byref(j), ctypes.sizeof(StateJobs))
+        by_addr = {a.ctypes.data: a for a in keep}
+        for name in StateJobs.POINTER_FIELDS:
+            addr = getattr(j, name)
+            if not addr:
+                continue
+            a = by_addr[addr]
+            p = self.dev_malloc(max(a.nbytes, 4)); ptrs.append(p)
+            self.dev_upload(p, a.view(np.uint8).reshape(-1))
+            setattr(d, name, p)
+        return d, ptrs
+
+    def state_job_batch_dev(self, d_jobs, d_verdicts: int, d_flags: int = 0):
+        self._ck(self._lib.mina_state_job_batch_dev(self._h, ctypes.byref(d_jobs), ctypes.c_void_p(d_verdicts), ctypes.c_void_p(d_flags) if d_flags else None),
+                 "mina_state_job_batch_dev")

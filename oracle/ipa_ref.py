@@ -174,6 +174,84 @@ def ipa_open(curve, g_bytes, h, polys, blinders, evalpoints, xi, rscale, sponge:
     return {"lr": lr, "delta": delta, "z1": z1, "z2": z2, "sg": g0, "combined_inner_product": cip, "chals": chals}
 
 
+def ipa_open_fast(curve, g_bytes, h, polys, blinders, evalpoints, xi, rscale, sponge: FqSponge, rng: random.Random):
+    """Same proof as `ipa_open` (bit-identical for the same rng), without folding the bases point by point: the folded base
+    g^(j)[i] = sum_S prod_{r in S} chal_r * g[i + offset(S)] is a fixed linear combination of the ORIGINAL bases, so every
+    L_j / R_j is one MSM over g with scalars a[.] * W_j[top j bits of the index] (C oracle), and sg = <b_poly_coefficients, g>.
+    Makes k = 15 openings a matter of seconds (fixtures for the full-size Proof-of-State job)."""
+    r, m = R.scalar_modulus(curve), R.base_modulus(curve)
+    n = g_bytes.shape[0]
+    k = n.bit_length() - 1
+    assert 1 << k == n
+    endo = R.endo_r(curve)
+    bw = R.BWParams(m)
+    a = [0] * n
+    blind = 0
+    xi_i = 1
+    for f, bl in zip(polys, blinders):
+        if xi_i:
+            for j, c in enumerate(f):
+                if c:
+                    a[j] = (a[j] + xi_i * c) % r
+        blind = (blind + xi_i * bl) % r
+        xi_i = xi_i * xi % r
+    b = [0] * n
+    scale = 1
+    for pt in evalpoints:
+        pw = 1
+        for j in range(n):
+            b[j] = (b[j] + scale * pw) % r
+            pw = pw * pt % r
+        scale = scale * rscale % r
+    cip = sum(x * y for x, y in zip(a, b)) % r
+    sponge.absorb_fr([shift_scalar(curve, cip)])
+    u = bw.to_group(sponge.challenge_fq())
+    hu = np.stack([O.point_to_bytes(h), O.point_to_bytes(u)])
+    bases = np.concatenate([g_bytes, hu])
+
+    def msm_full(sc, extra):
+        return O.bytes_to_point(O.msm_pippenger(curve, bases, O.ints_to_le(sc + extra), threads=8))
+
+    lr, chals = [], []
+    r_prime = blind
+    W = [1]                                             # W_j[top]: weight of the original bases whose top j index bits are `top`
+    for j in range(k):
+        nj = n >> j
+        half = nj >> 1
+        a_lo, a_hi, b_lo, b_hi = a[:half], a[half:], b[:half], b[half:]
+        rand_l, rand_r = rng.randrange(r), rng.randrange(r)
+        ip_l = sum(x * y for x, y in zip(a_hi, b_lo)) % r
+        ip_r = sum(x * y for x, y in zip(a_lo, b_hi)) % r
+        sl, sr = [0] * n, [0] * n
+        for top, w in enumerate(W):
+            base = top * nj
+            for i in range(half):
+                sl[base + i] = a_hi[i] * w % r          # L: the low half of every block of n_j original bases
+                sr[base + half + i] = a_lo[i] * w % r   # R: the high half
+        L = msm_full(sl, [rand_l, ip_l])
+        Rp = msm_full(sr, [rand_r, ip_r])
+        lr.append((L, Rp))
+        sponge.absorb_g([L])
+        sponge.absorb_g([Rp])
+        ch = R.challenge_to_field(sponge.challenge(), endo, r)
+        ch_inv = R.inv(ch, r)
+        chals.append(ch)
+        a = [(lo + ch_inv * hi) % r for lo, hi in zip(a_lo, a_hi)]
+        b = [(lo + ch * hi) % r for lo, hi in zip(b_lo, b_hi)]
+        W = [w * f % r for w in W for f in (1, ch)]     # next index bit set -> factor chal_j
+        r_prime = (r_prime + rand_l * ch_inv + rand_r * ch) % r
+    a0, b0 = a[0], b[0]
+    s_vec = O.b_poly_coefficients(O.scalar_field_of(curve), O.ints_to_le(chals))
+    g0 = O.bytes_to_point(O.msm_pippenger(curve, g_bytes, s_vec, threads=8))
+    d, r_delta = rng.randrange(r), rng.randrange(r)
+    delta = R.add(R.scalar_mul(d, R.add(g0, R.scalar_mul(b0, u, m), m), m), R.scalar_mul(r_delta, h, m), m)
+    sponge.absorb_g([delta])
+    c = R.challenge_to_field(sponge.challenge(), endo, r)
+    z1 = (a0 * c + d) % r
+    z2 = (c * r_prime + r_delta) % r
+    return {"lr": lr, "delta": delta, "z1": z1, "z2": z2, "sg": g0, "combined_inner_product": cip, "chals": chals}
+
+
 def ipa_verify_batch(curve, g_bytes, h, batch, rand_base, sg_rand_base) -> bool:
     """poly-commitment `SRS::verify`.  `batch`: list of dicts with keys
     sponge (FqSponge, consumed), evalpoints, polyscale, evalscale, comms (list of points), opening (dict from ipa_open

@@ -1,0 +1,167 @@
+"""The Proof-of-State job (BASELINE config C3; README.md:281-310) through the C-ABI vs the CPU oracle composite
+(oracle/state_job_ref.py): every intermediate bit-exact (state hashes, body hashes, public-input commitment), the verdict,
+and tamper rejection per stage with culprit isolation."""
+import base64
+import copy
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _le(x):
+    return np.frombuffer(int(x).to_bytes(32, "little"), np.uint8)
+
+
+def test_state_hash_parity_reference_state_and_random(ctx, oracle):
+    """MinaHash(ProtocolState) on the GPU == oracle, for the reference's own serialized state (constants.rs:22) and random ones;
+    both lane-cooperative forms (8 lanes for small batches, 4 lanes above 8192 states)"""
+    import mina_bridge_amd as m
+    from oracle import mina_state_ref as S, state_job_ref as J
+    from state_job_helpers import pp_fp, state_records
+    pp = pp_fp()
+    fx = json.load(open(os.path.join(HERE, "golden", "tip_protocol_state.json")))
+    raw = base64.b64decode(fx["protocol_state_base64"])
+    rng = random.Random(5)
+    states = [S.parse_protocol_state(raw)] + [J.synth_state(rng, rng.randrange(S.P), i) for i in range(20)]
+    states[3]["body"]["consensus_state"]["sub_window_densities"] = []           # ragged: fewer packed chunks
+    states[4]["body"]["consensus_state"]["sub_window_densities"] = [7] * 16
+    blobs = [S.write_protocol_state(s) for s in states]
+    got = ctx.protocol_state_hash_bytes(blobs)
+    for s, g in zip(states, got):
+        assert oracle.le_to_int(g) == S.protocol_state_hash(s, pp)
+    recs, nf = state_records(states)
+    h, body = ctx.protocol_state_hash_batch(recs, nf, want_body=True)
+    assert (h == got).all()
+    for s, b in zip(states, body):
+        assert oracle.le_to_int(b) == S.protocol_state_body_hash(s["body"], pp)
+    # n_body_fields = 0 and 1 (degenerate records) against the oracle's sponge
+    r2 = np.zeros((2, 64 * 32), np.uint8); r2[0, :32] = _le(5); r2[1, :32] = _le(6); r2[1, 32:64] = _le(9)
+    h2 = ctx.protocol_state_hash_batch(r2, np.array([0, 1], np.uint32))
+    assert oracle.le_to_int(h2[0]) == S.hash_with_kimchi(S.PREFIX_PROTOCOL_STATE, [5, S.hash_with_kimchi(S.PREFIX_PROTOCOL_STATE_BODY, [], pp)], pp)
+    assert oracle.le_to_int(h2[1]) == S.hash_with_kimchi(S.PREFIX_PROTOCOL_STATE, [6, S.hash_with_kimchi(S.PREFIX_PROTOCOL_STATE_BODY, [9], pp)], pp)
+    # 4-lane form: 8200 records (the 21 above, tiled)
+    reps = 8200 // len(states) + 1
+    big = ctx.protocol_state_hash_batch(np.tile(recs, (reps, 1)), np.tile(nf, reps))
+    assert (big.reshape(reps, len(states), 32) == got[None]).all()
+
+
+SMALL = dict(k=7, log2_domain=7, npub=8, n_comms=6, slot=2, n_points=2, acc_k=8)
+
+
+@pytest.fixture(scope="module")
+def small_jobs(srs_oracle):
+    from state_job_helpers import mint_job
+    return [mint_job(srs_oracle[0], srs_oracle[1], 100 + 10 * i, **SMALL) for i in range(5)]
+
+
+def _run(ctx, m, jobs, **kw):
+    from state_job_helpers import build_jobs
+    sj = build_jobs(m, jobs, SMALL["k"], SMALL["log2_domain"], SMALL["slot"], SMALL["acc_k"], **kw)
+    return ctx.state_job_batch(sj)
+
+
+def test_state_job_accepts_and_matches_oracle_composite(ctx_srs, oracle, srs_oracle, small_jobs):
+    import mina_bridge_amd as m
+    from oracle import state_job_ref as J
+    from state_job_helpers import oracle_job, pp_fp
+    for B in (1, 5):
+        v = _run(ctx_srs, m, small_jobs[:B])
+        assert v.tolist() == [1] * B
+    # oracle composite on the same jobs: intermediates bit-exact
+    for job in small_jobs[:2]:
+        ref = J.verify_state_job(pp_fp(), srs_oracle[0], srs_oracle[1], oracle_job(job))
+        assert ref["verdict"] and ref["chain_ok"] and ref["ipa_ok"] and ref["acc_ok"]
+        got_h = ctx_srs.protocol_state_hash_batch(job["records"], job["nfields"])
+        assert [oracle.le_to_int(x) for x in got_h] == ref["hashes"]
+        pc = ctx_srs.public_input_commitment(0, SMALL["log2_domain"], oracle.ints_to_le(job["pubs"]))
+        assert oracle.bytes_to_point(pc) == ref["public_comm"] == job["entry"]["comms"][SMALL["slot"]]
+    # each leg alone
+    assert _run(ctx_srs, m, small_jobs[:3], with_ipa=False, with_acc=False).tolist() == [1, 1, 1]
+    assert _run(ctx_srs, m, small_jobs[:3], with_states=False, with_acc=False).tolist() == [1, 1, 1]
+    assert _run(ctx_srs, m, small_jobs[:3], with_states=False, with_ipa=False).tolist() == [1, 1, 1]
+
+
+def test_state_job_tamper_each_stage(ctx_srs, oracle, srs_oracle, small_jobs):
+    """one bad proof per stage inside a batch of 5: only the culprit is rejected, and the oracle composite agrees on why"""
+    import mina_bridge_amd as m
+    from oracle import state_job_ref as J
+    from state_job_helpers import entry_arrays, oracle_job, pp_fp, state_records
+    jobs = [copy.deepcopy(j) for j in small_jobs]
+    # job 0: a flipped bit in one state's body (the hash no longer matches the public input)
+    jobs[0]["states"][7]["body"]["consensus_state"]["total_currency"] ^= 1
+    jobs[0]["records"], jobs[0]["nfields"] = state_records(jobs[0]["states"])
+    # job 1: states hash to the public inputs but do not link (state 5 re-parented, its expected hash recomputed)
+    from oracle import mina_state_ref as S
+    jobs[1]["states"][5]["previous_state_hash"] = 12345
+    jobs[1]["records"], jobs[1]["nfields"] = state_records(jobs[1]["states"])
+    jobs[1]["expected"][5] = S.protocol_state_hash(jobs[1]["states"][5], pp_fp())
+    # job 2: one public input changed -> different public-input commitment -> the opening no longer verifies
+    jobs[2]["pubs"][3] = (jobs[2]["pubs"][3] + 1) % (1 << 200)
+    # job 3: accumulator commitment replaced by another valid point
+    jobs[3]["acc_sg"] = small_jobs[4]["acc_sg"].copy()
+    v = _run(ctx_srs, m, jobs)
+    assert v.tolist() == [0, 0, 0, 0, 1]
+    refs = [J.verify_state_job(pp_fp(), srs_oracle[0], srs_oracle[1], oracle_job(j)) for j in jobs]
+    assert [r["verdict"] for r in refs] == [False, False, False, False, True]
+    assert (refs[0]["chain_ok"], refs[1]["chain_ok"], refs[2]["ipa_ok"], refs[3]["acc_ok"]) == (False, False, False, False)
+    assert refs[2]["chain_ok"] and refs[2]["acc_ok"] and refs[3]["ipa_ok"]
+    # tampered opening scalar (z1) in the middle of the batch, malformed point (off-curve delta) at the end
+    jobs = [copy.deepcopy(j) for j in small_jobs]
+    jobs[2]["entry"]["opening"]["z1"] = (jobs[2]["entry"]["opening"]["z1"] + 1) % (1 << 250)
+    jobs[2]["abi"] = entry_arrays(jobs[2]["entry"], jobs[2]["sponge"])
+    jobs[4]["abi"] = dict(jobs[4]["abi"]); d = jobs[4]["abi"]["delta"].copy(); d[0] ^= 1; jobs[4]["abi"]["delta"] = d
+    assert _run(ctx_srs, m, jobs).tolist() == [1, 1, 0, 1, 0]
+    # the bridge tip hash (state 16) participates in the comparison
+    jobs = [copy.deepcopy(j) for j in small_jobs[:2]]
+    jobs[1]["expected"][16] ^= 1
+    assert _run(ctx_srs, m, jobs).tolist() == [1, 0]
+
+
+def test_state_job_device_resident_and_pipelined(ctx_srs, oracle, small_jobs):
+    """`_dev` entry: inputs in HBM, several jobs in flight over pipeline lanes, verdict words + flags read back at the end"""
+    import mina_bridge_amd as m
+    from state_job_helpers import build_jobs
+    sj = build_jobs(m, small_jobs, SMALL["k"], SMALL["log2_domain"], SMALL["slot"], SMALL["acc_k"])
+    ctx_srs.state_jobs_prepare(SMALL["log2_domain"], SMALL["npub"])
+    d, ptrs = ctx_srs.state_jobs_to_device(sj)
+    B = len(small_jobs)
+    ctx_srs.set_pipeline(4)
+    try:
+        outs = [ctx_srs.dev_malloc(4 * B + 16) for _ in range(6)]
+        for o in outs:
+            ctx_srs.state_job_batch_dev(d, o, o + 4 * B)
+        ctx_srs.synchronize()
+        for o in outs:
+            w = ctx_srs.dev_download(o, 4 * B + 16).view(np.uint32)
+            assert w[:B].tolist() == [1] * B and w[B:].tolist() == [1, 0, 1, 0]
+    finally:
+        ctx_srs.set_pipeline(1)
+        for p in outs + ptrs:
+            ctx_srs.dev_free(p)
+
+
+def test_state_job_full_size_c3(ctx_srs, oracle, srs_oracle):
+    """BASELINE config C3 at full size: 17 states, 40 public inputs over the 2^15 wrap domain, k = 15 opening with 45 commitments
+    and 2 points (committed oracle-minted fixture), 2^16 Vesta accumulator; B = 16 with one tampered proof"""
+    import mina_bridge_amd as m
+    from oracle import state_job_ref as J
+    from state_job_helpers import build_jobs, load_k15_openings, mint_job, oracle_job, pp_fp
+    fx, ops = load_k15_openings()
+    shape = dict(k=fx["k"], log2_domain=fx["log2_domain"], npub=fx["npub"], n_comms=fx["n_comms"], slot=fx["slot"], n_points=fx["n_points"], acc_k=16)
+    jobs = [mint_job(srs_oracle[0], srs_oracle[1], 500 + i, opening=ops[i % len(ops)], **shape) for i in range(16)]
+    sj = build_jobs(m, jobs, shape["k"], shape["log2_domain"], shape["slot"], 16)
+    assert ctx_srs.state_job_batch(sj).tolist() == [1] * 16
+    ref = J.verify_state_job(pp_fp(), srs_oracle[0], srs_oracle[1], oracle_job(jobs[3]))
+    assert ref["verdict"]
+    pc = ctx_srs.public_input_commitment(0, 15, oracle.ints_to_le(jobs[3]["pubs"]))
+    assert oracle.bytes_to_point(pc) == ref["public_comm"]
+    jobs[9] = copy.deepcopy(jobs[9]); jobs[9]["pubs"][39] ^= 1
+    sj = build_jobs(m, jobs, shape["k"], shape["log2_domain"], shape["slot"], 16)
+    assert ctx_srs.state_job_batch(sj).tolist() == [1] * 9 + [0] + [1] * 6
+    assert not J.verify_state_job(pp_fp(), srs_oracle[0], srs_oracle[1], oracle_job(jobs[9]))["ipa_ok"]
