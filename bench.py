@@ -1,25 +1,31 @@
 #!/usr/bin/env python3
-"""bench.py -- throughput of the MI355X-native Kimchi/Pickles IPA hot path (BASELINE.json metric).
+"""bench.py -- Mina state proofs verified/sec on the MI355X-native verifier hot path (BASELINE.json metric, config C3).
 
-A "step" = one pass of the hot path over one batch of synthetic state proofs: for each proof the 2^16-base
-Vesta IPA accumulator check of BASELINE config C2 -- 16 128-bit prechallenges (already in HBM) ->
-ScalarChallenge::to_field -> b_poly_coefficients (K2) -> 2^16-point MSM over the Vesta SRS (K1) -> compare
-with the proof's sg -- through the C-ABI, verdicts left in HBM.  Default: the `--group` (8) proofs of a step are
-verified INDEPENDENTLY (no random folding, one verdict each) by one kernel pipeline
-(`mina_accumulator_check_multi_dev`: every MSM is computed in full; the group only shares the ~14 dependent
-dispatches).  `--batch B` instead folds B proofs into one MSM with random weights (`mina_accumulator_check_dev`).
+A "step" = one pass of the Proof-of-State job over one batch of `--jobs` synthetic state proofs, all inputs resident in
+HBM, through ONE C-ABI call (`mina_state_job_batch_dev`, no host synchronisation inside): per proof
+  * the 17 protocol-state hashes (16 candidate-chain states + bridge tip; `MinaHash` = Poseidon over `to_input`), compared
+    with the public inputs, plus the chain linkage                                      (README.md:283-288)
+  * the wrap proof's public-input commitment: 40 scalars over the 2^15 Pallas Lagrange basis
+  * the wrap proof's combined IPA opening: k = 15 rounds, 45 commitments x 2 evaluation points, folded over the batch
+    into one 2^15 fixed-base MSM + one variable-base MSM                                (kimchi batch_verify / SRS::verify)
+  * the step accumulator check: b_poly_coefficients of 16 challenges -> 2^16-base Vesta MSM, folded over the batch
+Steps are issued round-robin over `--pipeline` lanes (independent batches overlap on the GPU).  What the job does NOT
+contain (not built / no data offline): kimchi's `oracles` + linearisation (the verifier index is absent), binprot parsing
+(host work, done before the timed region by the caller).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--group G] [--batch B]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--jobs B] [--pipeline L]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Multi-GPU: proof-level sharding, no data-path collective (SURVEY.md 8e variant 1): every rank verifies its
-own proofs against its replica of the SRS tables; weak scaling.  One JSON line on rank 0.
+Multi-GPU: proof-level sharding (SURVEY.md 8e variant 1): every rank verifies its own proofs against its replica of the
+SRS tables; the ranks' verdict words are all-gathered over RCCL inside the timed region; weak scaling.  One JSON line on rank 0.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import platform
+import random
 import sys
 import time
 
@@ -27,82 +33,177 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 # ROCm exposes 4 hardware queues per process by default; the pipeline lanes of the context need one each
 # to overlap (must be set before the HIP runtime initialises).
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
-CURVE_VESTA = 1
+CURVE_PALLAS, CURVE_VESTA = 0, 1
 FIELD_FP = 0
-K_ROUNDS = 16
-N_BASES = 1 << K_ROUNDS
-MSM_ALGORITHMIC_BYTES = N_BASES * (64 + 32) + 96      # 6 291 552 B for n = 2^16
+ACC_K, WRAP_K, LOG2_DOMAIN, NPUB, NCOMMS, NPTS, SLOT = 16, 15, 15, 40, 45, 2, 0
+STATES_PER_PROOF, PSTATE_SLOTS = 17, 64
 HBM_PEAK_GBPS = 8000.0                                # MI355X_MICROARCH.md: 8 TB/s spec
-PS_ACCUMULATE_BIT = 1 << 3      # ProfStage::PS_ACCUMULATE in csrc/ctx.h
-# HBM-side bytes per launch of the dominant kernel from the rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, KiB * 1024;
-# profiles/r01j_rocprof.md section 2).  14x the algorithmic bytes by design: the fixed-base window tables gather 16
-# precomputed 64-B points per base and write 128-B XYZZ partials.
-ACCUMULATE_TRAFFIC_BYTES = 80_470_000
 # VALU side of the roofline (the path is integer-multiply bound): one Montgomery product is 88
 # v_mad_u64_u32 (8 cycles per wave64 instruction, profiles/r01_microbench_valu.jsonl) -> issue floor 704 cycles.
 MODMUL_ISSUE_FLOOR_CYCLES = 88 * 8
-# entries E = one per non-zero signed 16-bit digit; in the throughput form of the accumulate kernel (one lane per bucket,
-# used from 4 MSMs per launch or with pipelined lanes) the first entry of each of the 32768 buckets is a copy, not an add
-MIXED_ADDS_PER_MSM = 16 * N_BASES * (1 - 2 ** -16) - 32768
-MODMUL_PER_MIXED_ADD = 10                                # XYZZ madd-2008-s: 8M + 2S
 CHIP_SIMDS, CLOCK_HZ = 1024, 2.4e9
+MODMUL_PER_PERMUTATION = 55 * (3 * 4 + 9)             # x^7 = 4 products x 3, MDS 9 products: 1155
+PROF_STAGES = {"pstate_hash": 11, "ipa_transcript": 12, "msm_accumulate": 3}
 
 
-def make_instances(ctx, count: int, seed: int):
-    """`count` synthetic accumulator-check instances made consistent with the GPU path itself
-    (sg = MSM(g, b_poly_coefficients(chals)) through the library; parity of that path vs the CPU oracle is
-    what tests/ establish).  Returns (prechallenges[count,16,16], sg[count,64])."""
+def le32(x: int) -> np.ndarray:
+    return np.frombuffer(int(x).to_bytes(32, "little"), np.uint8)
+
+
+def make_chains(ctx, m, n_chains: int, seed: int):
+    """`n_chains` synthetic candidate chains (16 linked states + bridge tip), serialized with the bin_prot writer, flattened by the
+    LIBRARY (mina_protocol_state_pack) and hashed by the GPU path itself, state by state, so that each state names its
+    predecessor's hash (parity of that path vs the CPU oracle is what tests/ establish).  Returns (records[n,17,2048], nfields[n,17],
+    hashes[n,17,32])."""
+    from oracle import mina_state_ref as S, state_job_ref as J
+    rng = random.Random(seed)
+    recs = np.zeros((n_chains, STATES_PER_PROOF, PSTATE_SLOTS * 32), np.uint8)
+    nf = np.zeros((n_chains, STATES_PER_PROOF), np.uint32)
+    hashes = np.zeros((n_chains, STATES_PER_PROOF, 32), np.uint8)
+    prev = [rng.randrange(S.P) for _ in range(n_chains)]
+    for s in range(STATES_PER_PROOF):
+        for c in range(n_chains):
+            st = J.synth_state(rng, prev[c] if s < 16 else rng.randrange(S.P), 1000 + s)
+            recs[c, s], nf[c, s], _, _ = m.lib.protocol_state_pack(S.write_protocol_state(st))
+        hashes[:, s] = ctx.protocol_state_hash_batch(recs[:, s].copy(), nf[:, s].copy())
+        prev = [int.from_bytes(hashes[c, s].tobytes(), "little") for c in range(n_chains)]
+    return recs, nf, hashes
+
+
+def make_accumulators(ctx, count: int, seed: int):
     rng = np.random.Generator(np.random.PCG64(seed))
-    pre = rng.integers(0, 256, size=(count, K_ROUNDS, 16), dtype=np.uint8)
+    pre = rng.integers(0, 256, size=(count, ACC_K, 16), dtype=np.uint8)
     sgs = np.empty((count, 64), np.uint8)
     for i in range(count):
-        chals = ctx.challenge_to_field(FIELD_FP, pre[i])
-        s = ctx.b_poly_coefficients(FIELD_FP, chals)
-        sgs[i] = ctx.msm_srs(CURVE_VESTA, s)
+        sgs[i] = ctx.msm_srs(CURVE_VESTA, ctx.b_poly_coefficients(FIELD_FP, ctx.challenge_to_field(FIELD_FP, pre[i])))
     return pre, sgs
 
 
-def cpu_baseline(pre_one: np.ndarray, sg_one: np.ndarray, budget_s: float = 12.0):
-    """The CPU restatement (oracle/, kind="port") of the same step, on the host cores of this box."""
-    from oracle import oracle as O
-    O.lib()
-    cores = min(os.cpu_count() or 1, 20)          # ark Pippenger has 20 windows at n = 2^16 -> 20 useful threads
-    g, _ = O.srs_create(CURVE_VESTA, N_BASES, threads=os.cpu_count() or 1)
-    _, endo_r = O.endo(CURVE_VESTA)
+def build_batch(ctx, m, B: int, seed: int):
+    """host-side `mina_state_jobs` of B jobs from 32 distinct chains, the committed full-size wrap openings
+    (tests/golden/state_job_k15.json) and 32 distinct accumulators"""
+    from state_job_helpers import entry_arrays, load_k15_openings
+    fx, ops = load_k15_openings()
+    assert (fx["k"], fx["log2_domain"], fx["npub"], fx["n_comms"], fx["n_points"], fx["slot"]) == (WRAP_K, LOG2_DOMAIN, NPUB, NCOMMS, NPTS, SLOT)
+    nd = min(B, 32)
+    recs, nf, hashes = make_chains(ctx, m, nd, seed)
+    pre, sgs = make_accumulators(ctx, nd, seed + 1)
+    abi = [entry_arrays(e, s) for (_, e, s) in ops]
+    pubs = [np.concatenate([le32(x) for x in p]) for (p, _, _) in ops]
+    idx = np.arange(B) % nd
+    oi = np.arange(B) % len(ops)
+    cat = lambda key: np.concatenate([np.asarray(abi[i][key], np.uint8).reshape(-1) for i in oi])
+    rho = np.random.Generator(np.random.PCG64(seed + 2)).integers(0, 256, (B, 32), dtype=np.uint8); rho[:, 31] &= 0x3F
+    arrays = dict(
+        state_records=recs[idx].reshape(-1), state_nfields=nf[idx].reshape(-1), expected_hashes=hashes[idx].reshape(-1),
+        public_inputs=np.concatenate([pubs[i] for i in oi]),
+        sponge_state=cat("sponge_state"), cip=cat("combined_inner_product"), lr=cat("lr"), delta=cat("delta"), sg=cat("sg"), z1=cat("z1"), z2=cat("z2"),
+        evalpoints=cat("evalpoints"), evalscale=cat("evalscale"), polyscale=cat("polyscale"), comms=cat("comms"),
+        sponge_pos=np.array([[abi[i]["sponge_mode"], abi[i]["sponge_count"]] for i in oi], np.uint32),
+        rand_base=le32(7), sg_rand_base=le32(9), acc_prechallenges=pre[idx].reshape(-1), acc_sg=sgs[idx].reshape(-1), acc_rho=rho.reshape(-1))
+    scal = dict(with_states=1, with_ipa=1, with_accumulator=1, log2_domain=LOG2_DOMAIN, npub=NPUB, pub_comm_slot=SLOT, k=WRAP_K, n_evalpoints=NPTS,
+                n_comms=NCOMMS, acc_k=ACC_K)
+    return m.MinaContext.make_state_jobs(B, arrays, **scal), (recs[0], nf[0], hashes[0], ops[0], pre[0], sgs[0])
 
-    def one():
-        chals = np.stack([O.challenge_to_field(FIELD_FP, pre_one[i].copy(), endo_r) for i in range(K_ROUNDS)])
-        s = O.b_poly_coefficients(FIELD_FP, chals)
-        return O.msm_pippenger(CURVE_VESTA, g, s, threads=cores)
 
-    ok = bool((one() == sg_one).all())
-    t0 = time.perf_counter()
-    reps = 0
-    while True:
-        one()
-        reps += 1
-        el = time.perf_counter() - t0
-        if el >= budget_s or reps >= 200:
-            break
-    return {"value": reps / el, "unit": "proofs/s", "cores": cores, "kind": "port",
-            "sample": f"{reps} single-proof accumulator checks (to_field + b_poly_coefficients + ark-style Pippenger c=13, "
-                      f"one thread per window) in {el:.1f}s; matches GPU sg: {ok}"}
+def algorithmic_bytes_per_proof() -> int:
+    """what one state proof hands to the verifier, as laid out in HBM ('proof_len + pub_len'; here the kernel-ready
+    form): 17 flattened states (50 field elements each) + their 17 expected hashes + 40 public inputs + the opening
+    (30 L/R + delta + sg + 45 commitments as 64-B points, 7 scalars + sponge state) + the accumulator (16 x 16 B + sg + rho)"""
+    return 17 * 50 * 32 + 17 * 32 + NPUB * 32 + (2 * WRAP_K + 2 + NCOMMS) * 64 + (7 + 3) * 32 + ACC_K * 16 + 64 + 32
+
+
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return platform.processor() or "unknown"
+
+
+def cpu_baseline(sample, budget_s: float = 20.0):
+    """The same composite on the CPU restatement (oracle/, kind="port" -- the reference's Rust verifier cannot be built here):
+    BASELINE config C1.  One proof at a time: 17 state hashes (C Poseidon), public-input commitment (iFFT + 2^15 MSM), the wrap
+    opening check (Python transcript + C b_poly / MSMs) and the 2^16 Vesta accumulator MSM (ark-style Pippenger, one thread per
+    window).  Timed with all useful host threads and with one."""
+    from oracle import ipa_ref as I, oracle as O, pasta_ref as R, state_job_ref as J
+    from state_job_helpers import pp_fp
+    import mina_bridge_amd.poseidon_params as PP
+    recs, nf, hashes, (pubs, entry, sponge), pre, sg = sample
+    nproc = os.cpu_count() or 1
+    srs = {c: O.srs_create(c, 1 << 16, threads=nproc) for c in (0, 1)}
+    params = PP.default_params_bytes(FIELD_FP)
+    pp = pp_fp()
+    from oracle import mina_state_ref as S
+    salts = [S.salt(S.PREFIX_PROTOCOL_STATE_BODY, pp), S.salt(S.PREFIX_PROTOCOL_STATE, pp)]
+
+    def state_hashes():
+        # 17 sponges advanced together, one C permutation call per absorbed block
+        st = np.tile(O.ints_to_le(salts[0]).reshape(1, 96), (STATES_PER_PROOF, 1)).copy()
+        fields = recs.reshape(STATES_PER_PROOF, PSTATE_SLOTS, 32)
+        n = int(nf.max())
+        ints = lambda a: [int.from_bytes(a[i].tobytes(), "little") for i in range(a.shape[0])]
+        state = [list(salts[0]) for _ in range(STATES_PER_PROOF)]
+        for blk in range(0, n, 2):
+            for s in range(STATES_PER_PROOF):
+                for t in range(2):
+                    if blk + t < nf[s]:
+                        state[s][t] = (state[s][t] + int.from_bytes(fields[s, 1 + blk + t].tobytes(), "little")) % R.P
+            perm = O.poseidon_permute(FIELD_FP, params, np.stack([O.ints_to_le(x).reshape(96) for x in state]))
+            state = [[int.from_bytes(perm[s, 32 * j: 32 * j + 32].tobytes(), "little") for j in range(3)] for s in range(STATES_PER_PROOF)]
+        body = [x[0] for x in state]
+        state = [[(salts[1][0] + int.from_bytes(fields[s, 0].tobytes(), "little")) % R.P, (salts[1][1] + body[s]) % R.P, salts[1][2]] for s in range(STATES_PER_PROOF)]
+        perm = O.poseidon_permute(FIELD_FP, params, np.stack([O.ints_to_le(x).reshape(96) for x in state]))
+        return perm[:, :32]
+
+    def one(threads):
+        global_threads = threads
+        ok = bool((state_hashes() == hashes).all())
+        g, h = srs[0]
+        hp = O.bytes_to_point(h)
+        coeffs = J.public_poly_coeffs(0, LOG2_DOMAIN, pubs)
+        pc = O.bytes_to_point(O.msm_pippenger(0, g[: 1 << LOG2_DOMAIN], O.ints_to_le(coeffs), threads=global_threads))
+        pc = R.add(pc, hp, R.P)
+        e = dict(entry); e["comms"] = [pc] + list(entry["comms"][1:]); e["sponge"] = sponge.clone()
+        ok = ok and I.ipa_verify_batch(0, g[: 1 << WRAP_K], hp, [e], 7, 9, threads=global_threads)
+        ok = ok and J.accumulator_ok(1, srs[1][0], ACC_K, pre, sg, threads=global_threads)
+        return ok
+
+    out = {}
+    for label, threads in (("all", min(nproc, 20)), ("single", 1)):
+        ok = one(threads)
+        t0 = time.perf_counter(); reps = 0
+        while True:
+            one(threads); reps += 1
+            el = time.perf_counter() - t0
+            if el >= budget_s / 2 or reps >= 50:
+                break
+        out[label] = (reps / el, threads, reps, el, ok)
+    v, threads, reps, el, ok = out["all"]
+    return {"value": v, "unit": "proofs/s", "cores": threads, "kind": "port", "cpu_model": cpu_model(), "nproc": nproc,
+            "single_thread_value": out["single"][0],
+            "sample": f"{reps} full Proof-of-State jobs (BASELINE config C1 = the bench's own job, one proof at a time: 17 state hashes + "
+                      f"public-input commitment + k=15 wrap opening check + 2^16 Vesta accumulator) on the repo's CPU restatement "
+                      f"(C field/MSM/Poseidon kernels under a Python driver; NOT the Rust reference, which cannot be built here) in {el:.1f}s, "
+                      f"MSMs threaded over {threads} windows; verdict ACCEPT: {ok}; single-thread: {out['single'][2]} jobs in {out['single'][3]:.1f}s"}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=400)
-    ap.add_argument("--group", type=int, default=8, help="independent (un-folded) proofs verified per step by one kernel pipeline")
-    ap.add_argument("--no-probes", action="store_true", help="skip the single-proof latency and folded-batch probes (profiling runs)")
-    ap.add_argument("--warmup", type=int, default=64)
-    ap.add_argument("--batch", type=int, default=1, help="proofs folded into one MSM per step")
-    ap.add_argument("--pipeline", type=int, default=16, help="internal stream lanes over which consecutive steps are issued")
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--jobs", type=int, default=8192, help="state proofs per step (one mina_state_job_batch_dev call)")
+    ap.add_argument("--pipeline", type=int, default=4, help="internal stream lanes over which consecutive steps are issued")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-probes", action="store_true", help="skip the isolated-kernel and C2 probes (profiling runs)")
     args = ap.parse_args()
 
     import torch
@@ -119,7 +220,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     # MINA_BENCH_SHARE_GPU=1 (test hook): every rank uses GPU 0 and the ranks rendezvous over gloo -- lets the N > 1 code path
-    # (barriers, MAX over ranks, aggregate value) be exercised on a 1-GPU box; never set by the driver
+    # (barriers, MAX over ranks, verdict all-gather, aggregate value) be exercised on a 1-GPU box; never set by the driver
     share_gpu = os.environ.get("MINA_BENCH_SHARE_GPU") == "1"
     if share_gpu:
         local_rank = 0
@@ -133,101 +234,92 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     ctx = m.MinaContext(local_rank)
-    ctx.srs_create(CURVE_VESTA, N_BASES)                       # SRS regenerated on the GPU (K4) + window tables
-    ctx.set_pipeline(args.pipeline)
-    B = args.batch
-    G = args.group if B == 1 else 1                            # un-folded proofs per step; folding and grouping are alternatives
-    if not 1 <= G <= 64:
-        raise SystemExit("--group must be in 1..64")
-    pre, sgs = make_instances(ctx, max(B, min(G, 4)), seed=0x6D696E61 + rank)
-    if G > 1:                                                  # G proofs per step from 4 distinct instances
-        pre = np.stack([pre[i % len(pre)] for i in range(G)]); sgs = np.stack([sgs[i % len(sgs)] for i in range(G)])
+    for f in (0, 1):
+        ctx.poseidon_set_params(f, m.poseidon_params.default_params_bytes(f))
+    ctx.srs_create(CURVE_VESTA, 1 << 16)                       # both SRS regenerated on the GPU (K4) + window tables
+    ctx.srs_create(CURVE_PALLAS, 1 << 16)
+    B = args.jobs
+    (hj, keep), sample = build_batch(ctx, m, B, seed=0x6D696E61 + rank)
     dev = torch.device("cuda", local_rank)
-    d_pre = torch.from_numpy(pre.reshape(-1)).to(dev)
-    d_sg = torch.from_numpy(sgs.reshape(-1)).to(dev)
-    rho = np.random.Generator(np.random.PCG64(99 + rank)).integers(0, 256, size=(B, 32), dtype=np.uint8)
-    rho[:, 31] &= 0x3F
-    d_rho = torch.from_numpy(rho.reshape(-1)).to(dev)
-    d_verdict = torch.zeros(G, dtype=torch.int32, device=dev)
+    dj = m.lib.StateJobs()
+    import ctypes
+    ctypes.memmove(ctypes.byref(dj), ctypes.byref(hj), ctypes.sizeof(m.lib.StateJobs))
+    by_addr = {a.ctypes.data: a for a in keep}
+    dtensors = []
+    for name in m.lib.StateJobs.POINTER_FIELDS:                # every section resident in HBM (torch owns the buffers)
+        addr = getattr(hj, name)
+        if addr:
+            t = torch.from_numpy(by_addr[addr].view(np.uint8).reshape(-1)).to(dev)
+            dtensors.append(t); setattr(dj, name, t.data_ptr())
+    ctx.state_jobs_prepare(LOG2_DOMAIN, NPUB)
+    ctx.set_pipeline(args.pipeline)
+    nslots = max(args.pipeline, 1)
+    d_out = [torch.zeros(B + 4, dtype=torch.int32, device=dev) for _ in range(nslots)]
     torch.cuda.synchronize()
+    it = [0]
 
     def step():
-        if B == 1:
-            ctx.accumulator_check_multi_dev(CURVE_VESTA, K_ROUNDS, G, d_pre.data_ptr(), d_sg.data_ptr(), d_verdict.data_ptr())
-        else:
-            ctx.accumulator_check_dev(CURVE_VESTA, K_ROUNDS, B, d_pre.data_ptr(), d_sg.data_ptr(), d_rho.data_ptr(), d_verdict.data_ptr())
+        o = d_out[it[0] % nslots]; it[0] += 1
+        ctx.state_job_batch_dev(dj, o.data_ptr(), o.data_ptr() + 4 * B)
 
     def verdicts_ok():
-        return d_verdict.cpu().numpy().tolist() == [1] * G
+        return all(o.cpu().numpy().tolist() == [1] * B + [1, 0, 1, 0] for o in d_out)
 
-    for _ in range(max(args.warmup, args.pipeline)):          # every lane allocates its workspace during warm-up
+    for _ in range(max(args.warmup, nslots)):                  # every lane allocates its workspace during warm-up
         step()
     ctx.synchronize()
     assert verdicts_ok(), "warm-up verdicts must be ACCEPT"
+    for o in d_out:
+        o.zero_()
 
     def barrier():
         if dist_on:
             dist.barrier()
 
-    ctx.prof_enable(PS_ACCUMULATE_BIT)                         # HIP events around the dominant kernel, on the ctx stream
+    gathered = None
+    mask = sum(1 << b for b in PROF_STAGES.values())
+    ctx.prof_enable(mask)                                      # HIP events around the candidate dominant kernels, on their lane streams
     barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    ctx.synchronize(); torch.cuda.synchronize(); barrier()
+    ctx.synchronize(); torch.cuda.synchronize()
+    if dist_on:                                                # the shards' verdict words travel over RCCL inside the timed region
+        mine = d_out[(it[0] - 1) % nslots][:B].contiguous()
+        if share_gpu:
+            mine = mine.cpu()
+        gathered = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        if not share_gpu:
+            torch.cuda.synchronize()
+    barrier()
     elapsed = time.perf_counter() - t0
     prof = ctx.prof_read()
     ctx.prof_enable(0)
     assert verdicts_ok(), "timed-region verdicts must be ACCEPT"
-    # the same kernel with nothing else on the GPU: one lane, HIP events on that lane's stream
-    ctx.set_pipeline(1)
-    for _ in range(4):
-        step()
-    ctx.synchronize()
-    ctx.prof_enable(PS_ACCUMULATE_BIT)
-    for _ in range(16):
-        step()
-    prof_iso = ctx.prof_read()
-    ctx.prof_enable(0)
-    # single-stream latency of ONE proof alone (one lane, nothing overlapped, no group)
-    latency_ms = None
+    if gathered is not None:
+        assert all(int(g.sum()) == B for g in gathered), "every rank's shard must be ACCEPT"
+
+    # the candidate dominant kernels with nothing else on the GPU: one lane, HIP events on that lane's stream
+    prof_iso = {}
     if not args.no_probes:
-        d_v1 = torch.zeros(1, dtype=torch.int32, device=dev)
-        def step1():
-            ctx.accumulator_check_dev(CURVE_VESTA, K_ROUNDS, 1, d_pre.data_ptr(), d_sg.data_ptr(), 0, d_v1.data_ptr())
+        ctx.set_pipeline(1)
+        for _ in range(2):
+            step()
+        ctx.synchronize()
+        ctx.prof_enable(mask)
+        for _ in range(6):
+            step()
+        prof_iso = ctx.prof_read()
+        ctx.prof_enable(0)
+        # latency of one call (B jobs) alone
+        torch.cuda.synchronize(); t1 = time.perf_counter()
         for _ in range(4):
-            step1()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(64):
-            step1()
+            step()
         ctx.synchronize()
-        latency_ms = (time.perf_counter() - t1) / 64 * 1e3
-        assert int(d_v1.item()) == 1
-    # the design's batch mode: B proofs folded into ONE MSM per step (kimchi batch_verify's shape), same entry point
-    extra = {}
-    if B == 1 and rank == 0 and not args.no_probes:
-        BB = 256
-        pre_b, sg_b = make_instances(ctx, 4, seed=77)
-        pre_b = np.tile(pre_b, (BB // 4, 1, 1)); sg_b = np.tile(sg_b, (BB // 4, 1))
-        rho_b = np.random.Generator(np.random.PCG64(5)).integers(0, 256, size=(BB, 32), dtype=np.uint8); rho_b[:, 31] &= 0x3F
-        dpb, dsb, drb = (torch.from_numpy(x.reshape(-1)).to(dev) for x in (pre_b, sg_b, rho_b))
-        dvb = torch.zeros(1, dtype=torch.int32, device=dev)
-        ctx.set_pipeline(args.pipeline)
-        def step_b():
-            ctx.accumulator_check_dev(CURVE_VESTA, K_ROUNDS, BB, dpb.data_ptr(), dsb.data_ptr(), drb.data_ptr(), dvb.data_ptr())
-        for _ in range(args.pipeline):
-            step_b()
-        ctx.synchronize(); torch.cuda.synchronize()
-        t2 = time.perf_counter()
-        nb_steps = 128
-        for _ in range(nb_steps):
-            step_b()
-        ctx.synchronize()
-        el_b = time.perf_counter() - t2
-        assert int(dvb.item()) == 1
-        extra = {"folded_batch_mode": {"proofs_per_step": BB, "value": BB * nb_steps / el_b, "unit": "proofs/s", "ms_per_step": el_b / nb_steps * 1e3,
-                                       "note": "same C-ABI entry, 256 proofs folded with random rho into one 2^16 MSM + one 256-point variable-base MSM"}}
+        call_latency_ms = (time.perf_counter() - t1) / 4 * 1e3
+    else:
+        call_latency_ms = None
 
     if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else dev)
@@ -235,44 +327,52 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
-        launches_o, total_ms_o = prof.get("msm_accumulate", [0, 0.0])
-        overlapped_us = (total_ms_o / launches_o) * 1e3 if launches_o else None
-        launches, total_ms = prof_iso.get("msm_accumulate", [0, 0.0])
-        kern_s = (total_ms / launches) * 1e-3 if launches else float("nan")
-        msms = G                                               # MSMs one msm_accumulate launch processes
-        achieved = msms * MSM_ALGORITHMIC_BYTES / kern_s / 1e9 if launches else None
+        def avg_us(p, name):
+            n, ms = p.get(name, [0, 0.0])
+            return (ms / n) * 1e3 if n else None
+        iso = {k: avg_us(prof_iso, k) for k in PROF_STAGES}
+        ovl = {k: avg_us(prof, k) for k in PROF_STAGES}
+        src = iso if iso.get("pstate_hash") else ovl
+        # dominant kernel of the job: the protocol-state hash (17 sponges of ~27 permutations per proof)
+        kern_us = src.get("pstate_hash")
+        nstates = B * STATES_PER_PROOF
+        perms = nstates * (25 + 1)                             # 49 body fields -> 25 permutations, + 1 for H(previous, body)
+        hash_bytes = nstates * (50 * 32 + 32)                  # per state: 50 field elements read, one hash written
+        achieved = hash_bytes / (kern_us * 1e-6) / 1e9 if kern_us else None
         out = {
             "metric": "Mina state proofs verified/sec (batch)",
-            "value": args.gpus * args.steps * B * G / elapsed,
+            "value": args.gpus * args.steps * B / elapsed,
             "unit": "proofs/s",
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
-            "single_stream_latency_ms": latency_ms,
+            "call_latency_ms": call_latency_ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u32x8-montgomery (255-bit prime field, integer)", "data": "synthetic",
-            "config": {"workload": "C2: per-proof 2^16-base Vesta IPA accumulator check (to_field + b_poly_coefficients + MSM over "
-                                   "vesta.srs + compare), bit-exact vs CPU oracle", "curve": "vesta", "n_bases": N_BASES,
-                       "proofs_per_step": B * G, "mode": (f"{G} independent checks per kernel pipeline, no folding" if B == 1 else f"{B} proofs folded into one MSM"),
-                       "pipeline_lanes": args.pipeline, "sharding": f"proof-level, {args.gpus} rank(s), no collective"},
-            "roofline": {"bound": "hbm", "kernel": "msm_accumulate_bucket_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": msms * ACCUMULATE_TRAFFIC_BYTES,
-                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r01j_rocprof.md",
-                         "traffic_GBps": msms * ACCUMULATE_TRAFFIC_BYTES / kern_s / 1e9 if launches else None,
-                         "algorithmic_bytes_per_launch": msms * MSM_ALGORITHMIC_BYTES, "msms_per_launch": msms, "avg_launch_us": kern_s * 1e6,
-                         "avg_launch_us_in_timed_region": overlapped_us,
-                         "note": "avg_launch_us: HIP events on the lane stream, 16 launches with nothing else on the GPU, right after the "
-                                 "timed region; in the timed region the launches of 16 lanes overlap and time-share the CUs (second figure). "
-                                 "Integer-VALU-bound path (SURVEY.md 8d): HBM fraction reported as the metric demands, see roofline_valu"},
+            "dtype": "u32x8-montgomery (255-bit prime fields, integer)", "data": "synthetic",
+            "config": {"workload": "C3: full Proof-of-State job per proof -- 17 protocol-state hashes (chain of 16 + bridge tip) vs public inputs + linkage, "
+                                   "wrap-proof public-input commitment (40 inputs, 2^15 Pallas domain), wrap IPA opening (k=15, 45 commitments x 2 points), "
+                                   "2^16-base Vesta step-accumulator check; verdict per proof, bit-exact vs the CPU oracle composite (tests/test_state_job.py)",
+                       "proofs_per_step": B, "pipeline_lanes": args.pipeline,
+                       "distinct_inputs": "32 chains, 8 wrap openings (tests/golden/state_job_k15.json), 32 accumulators per rank",
+                       "folding": "IPA and accumulator checks folded over the step's batch with caller-supplied randomisers (kimchi batch_verify's shape)",
+                       "not_in_job": "kimchi oracles/linearisation (no verifier index offline), binprot parsing (host, before the timed region)",
+                       "sharding": f"proof-level, {args.gpus} rank(s); verdict words all-gathered over RCCL" if dist_on else "single rank",
+                       "algorithmic_bytes_per_proof": algorithmic_bytes_per_proof()},
+            "roofline": {"bound": "hbm", "kernel": "pstate_hash_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": None,
+                         "algorithmic_bytes_per_launch": hash_bytes, "states_per_launch": nstates, "avg_launch_us": kern_us,
+                         "avg_launch_us_in_timed_region": ovl.get("pstate_hash"),
+                         "note": "avg_launch_us: HIP events on the lane stream around the kernel, launches with nothing else on the GPU right after the "
+                                 "timed region (second figure: inside it, lanes overlapping).  The path is integer-VALU bound (SURVEY.md 8d): the HBM "
+                                 "fraction is reported because the metric asks for it, roofline_valu is the bound that matters; traffic: see profiles/"},
+            "stage_us": {"isolated": iso, "in_timed_region": ovl},
         }
-        if launches:
-            peak = CHIP_SIMDS * 64 * CLOCK_HZ / MODMUL_ISSUE_FLOOR_CYCLES          # modmul/s if only the 88 mads issued
-            got = msms * MIXED_ADDS_PER_MSM * MODMUL_PER_MIXED_ADD / kern_s
-            out["roofline_valu"] = {"bound": "int32 multiply issue (v_mad_u64_u32)", "achieved": got / 1e9, "peak": peak / 1e9,
-                                    "unit": "G modmul/s", "frac": got / peak,
-                                    "note": "same isolated launches as roofline"}
-        out.update(extra)
+        if kern_us:
+            peak = CHIP_SIMDS * 64 * CLOCK_HZ / MODMUL_ISSUE_FLOOR_CYCLES
+            got = perms * MODMUL_PER_PERMUTATION / (kern_us * 1e-6)
+            out["roofline_valu"] = {"bound": "int32 multiply issue (v_mad_u64_u32)", "kernel": "pstate_hash_kernel", "achieved": got / 1e9, "peak": peak / 1e9,
+                                    "unit": "G modmul/s", "frac": got / peak, "permutations_per_launch": perms}
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(pre[0], sgs[0])
+            out["cpu_baseline"] = cpu_baseline(sample)
         print(json.dumps(out), flush=True)
     if dist_on:
         dist.barrier()

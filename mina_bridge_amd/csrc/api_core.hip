@@ -158,7 +158,7 @@ extern "C" int mina_field_sqrt(mina_ctx *c, int field, size_t n, const uint8_t *
 // ------------------------------------------------------------------------------------------------
 // stage timing
 static const char *PROF_NAMES[PS_COUNT] = {"msm_digits", "msm_scan", "msm_scatter", "msm_accumulate", "msm_bucket_sum", "msm_segsum",
-                                           "msm_reduce2d", "msm_finish", "bpoly_tables", "bpoly_fold", "bpoly_finish"};
+                                           "msm_reduce2d", "msm_finish", "bpoly_tables", "bpoly_fold", "bpoly_finish", "pstate_hash", "ipa_transcript"};
 void mb_prof_begin(mina_ctx *c, int stage) {
     ProfState &p = c->prof;
     if (p.used == p.recs.size()) {

@@ -481,6 +481,7 @@ int mb_ipa_batch_check_dev(mina_ctx *c, int curve, mb::IpaShape sh, const mb::Ip
         sh, c->fk[FB], c->fk[FS], pp, in.state, in.pos, in.cip, in.lr, in.delta, in.sg, in.z1, in.z2, in.pts, in.r, \
         in.xi, in.comms, in.comm_override, in.rb, in.sb, s.h.as<affine_t>(), c->L->ipa_points.as<affine_t>(), c->L->ipa_scalars.as<uint32_t>(), \
         c->L->ipa_chals.as<uint32_t>(), c->L->ipa_sigma.as<uint32_t>(), d_verdict + 1, c->L->ipa_xfer.as<uint32_t>())
+    { ProfScope ps_(c, PS_IPA_TRANSCRIPT);
     if (batch <= COOP8_MAX_GROUPS) {
         // latency-bound batch: 8 lanes per transcript, and to_group on a second stream beside the rest of the transcript
         Lane &L = *c->L;
@@ -495,6 +496,7 @@ int mb_ipa_batch_check_dev(mina_ctx *c, int curve, mb::IpaShape sh, const mb::Ip
         HIPC(hipStreamWaitEvent(L.stream, L.ev_join, 0));
     } else {
         if (curve == CURVE_PALLAS) IPA_PREP(CURVE_PALLAS, 4, 0, c->L->stream); else IPA_PREP(CURVE_VESTA, 4, 0, c->L->stream);
+    }
     }
 #undef IPA_PREP
     HIPC(hipGetLastError());

@@ -25,8 +25,8 @@ __global__ void __launch_bounds__(256)
 pstate_hash_kernel(uint32_t n, FieldK fk, const PoseidonParams *__restrict__ pp, const fe_t *__restrict__ salts /* [0..3) body, [3..6) state */,
                    const uint32_t *__restrict__ records, const uint32_t *__restrict__ nfields, uint32_t *__restrict__ out_hash /* n*8 */,
                    uint32_t *__restrict__ out_body /* n*8 or null */) {
-    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t sp = gid / LANES, e = coop_elem<LANES>();
+    bool writer;
+    const uint32_t sp = coop_sponge_index<LANES>(writer), e = coop_elem<LANES>();
     const bool live = sp < n;
     const uint32_t idx = live ? sp : 0;                            // dead groups shadow state 0 (whole waves run the cross-lane moves)
     const uint32_t *rec = records + (size_t)idx * MINA_PSTATE_SLOTS * 8;
@@ -45,7 +45,7 @@ pstate_hash_kernel(uint32_t n, FieldK fk, const PoseidonParams *__restrict__ pp,
     if (e == 1) s = fe_add<F>(s, body);
     poseidon_permute_coop<F, LANES>(s, pp);
     s = coop_get<LANES>(s, 0);
-    if (live && (gid % LANES) == 0) {
+    if (live && writer) {
         const fe_t w = fe_from_mont<F>(s); for (int i = 0; i < 8; ++i) out_hash[(size_t)sp * 8 + i] = w.v[i];
         if (out_body) { const fe_t bw = fe_from_mont<F>(body); for (int i = 0; i < 8; ++i) out_body[(size_t)sp * 8 + i] = bw.v[i]; }
     }
@@ -171,11 +171,12 @@ static int ensure_state_salts(mina_ctx *c) {
 static int pstate_hash_dev(mina_ctx *c, size_t n, const uint32_t *d_records, const uint32_t *d_nfields, uint32_t *d_hashes, uint32_t *d_bodies) {
     const PoseidonParams *pp = c->pparams[FIELD_FP].as<PoseidonParams>();
     const fe_t *salts = c->state_salts.as<fe_t>();
-    // below ~8 k states the chip is latency-bound: 8 lanes per state; above, 4 lanes
+    ProfScope ps_(c, PS_STATE_HASH);
+    // below ~8 k states the chip is latency-bound: 8 lanes per state (shortest chain); above, wave-packed triples (63 of 64 lanes busy)
     if (n <= COOP8_MAX_GROUPS)
         mb::pstate_hash_kernel<FIELD_FP, 8><<<cdiv(n * 8, 256), 256, 0, c->L->stream>>>((uint32_t)n, c->fk[FIELD_FP], pp, salts, d_records, d_nfields, d_hashes, d_bodies);
     else
-        mb::pstate_hash_kernel<FIELD_FP, 4><<<cdiv(n * 4, 256), 256, 0, c->L->stream>>>((uint32_t)n, c->fk[FIELD_FP], pp, salts, d_records, d_nfields, d_hashes, d_bodies);
+        mb::pstate_hash_kernel<FIELD_FP, 3><<<cdiv(coop_threads<3>(n), 256), 256, 0, c->L->stream>>>((uint32_t)n, c->fk[FIELD_FP], pp, salts, d_records, d_nfields, d_hashes, d_bodies);
     HIPC(hipGetLastError());
     return MINA_OK;
 }

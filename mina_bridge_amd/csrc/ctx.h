@@ -67,7 +67,7 @@ struct MsmWorkspace {
 
 // HIP-event stage timing on the context stream (off by default; bench.py turns it on for the timed region)
 enum ProfStage : int { PS_DIGITS = 0, PS_SCAN, PS_SCATTER, PS_ACCUMULATE, PS_BUCKET_SUM, PS_REDUCE_A, PS_REDUCE_BC, PS_FINISH,
-                       PS_BPOLY_TABLES, PS_BPOLY_FOLD, PS_BPOLY_FINISH, PS_COUNT };
+                       PS_BPOLY_TABLES, PS_BPOLY_FOLD, PS_BPOLY_FINISH, PS_STATE_HASH, PS_IPA_TRANSCRIPT, PS_COUNT };
 struct ProfState {
     int mask = 0;                                   // bit per stage; 0 = off
     struct Rec { hipEvent_t a, b; int stage; };

@@ -226,18 +226,56 @@ __device__ __forceinline__ void poseidon_permute_oct(fe_t &s, const PoseidonPara
         s = fe_add<F>(fe_add<F>(u, pair_swap(u)), pp->rc[r][e]);
     }
 }
-// LANES-lane cooperative permutation / element ownership, LANES = 4 (quad) or 8 (octet)
+// Three lanes per sponge: 21 sponges per wave64 (lanes 3g, 3g+1, 3g+2 own state elements 0, 1, 2 of sponge g; lane 63 shadows
+// group 20).  Same 7 dependent products per round as the quad form, but no idle fourth lane: 63 of 64 lanes work, which is
+// what the chip-filling batches want (the quad form caps at 75 % lane use).  The three x^7 are exchanged with ds_bpermute
+// (24 per round against ~1800 multiply-accumulates: free).  Bit-identical state.
+struct TriPos { uint32_t base, e; };
+__device__ __forceinline__ TriPos tri_pos() {
+    const uint32_t lane = threadIdx.x & 63u;
+    TriPos p; const uint32_t g = lane == 63u ? 20u : lane / 3u; p.base = 3u * g; p.e = lane == 63u ? 0u : lane - 3u * g; return p;
+}
+__device__ __forceinline__ fe_t tri_bcast(const fe_t &a, uint32_t src_lane) {
+    fe_t r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = (uint32_t)__shfl((int)a.v[i], (int)src_lane, 64);
+    return r;
+}
+template <int F>
+__device__ __forceinline__ void poseidon_permute_tri(fe_t &s, const PoseidonParams *__restrict__ pp) {
+    const TriPos tp = tri_pos();
+    const fe_t m0 = pp->mds[tp.e][0], m1 = pp->mds[tp.e][1], m2 = pp->mds[tp.e][2];
+#pragma unroll 1
+    for (int r = 0; r < 55; ++r) {
+        const fe_t x2 = fe_sqr<F>(s);
+        const fe_t x4 = fe_sqr<F>(x2);
+        const fe_t t = fe_mul<F>(fe_mul<F>(x4, x2), s);
+        const fe_t t0 = tri_bcast(t, tp.base), t1 = tri_bcast(t, tp.base + 1), t2 = tri_bcast(t, tp.base + 2);
+        s = fe_add<F>(fe_dot3<F>(m0, t0, m1, t1, m2, t2), pp->rc[r][tp.e]);
+    }
+}
+// LANES-lane cooperative permutation / element ownership, LANES = 3 (wave-packed triples), 4 (quad) or 8 (octet)
 template <int F, int LANES> __device__ __forceinline__ void poseidon_permute_coop(fe_t &s, const PoseidonParams *__restrict__ pp) {
-    if (LANES == 8) poseidon_permute_oct<F>(s, pp); else poseidon_permute_quad<F>(s, pp);
+    if (LANES == 8) poseidon_permute_oct<F>(s, pp); else if (LANES == 3) poseidon_permute_tri<F>(s, pp); else poseidon_permute_quad<F>(s, pp);
 }
 template <int LANES> __device__ __forceinline__ uint32_t coop_elem() {                 // state element this lane owns
+    if (LANES == 3) return tri_pos().e;
     const uint32_t l = threadIdx.x & (LANES - 1), e = LANES == 8 ? (l >> 1) : l;
     return e < 3 ? e : 2;
 }
 template <int LANES> __device__ __forceinline__ fe_t coop_get(const fe_t &s, int pos) { // element `pos` -> all lanes of the group
+    if (LANES == 3) return tri_bcast(s, tri_pos().base + (uint32_t)pos);
     if (LANES == 8) return pos == 0 ? oct_bcast<0>(s) : (pos == 1 ? oct_bcast<2>(s) : oct_bcast<4>(s));
     return pos == 0 ? quad_bcast<0>(s) : (pos == 1 ? quad_bcast<1>(s) : quad_bcast<2>(s));
 }
+// which sponge a thread works on and whether it is the group's writer; blockDim.x is a multiple of 64
+template <int LANES> __device__ __forceinline__ uint32_t coop_sponge_index(bool &writer) {
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (LANES == 3) { const uint32_t lane = threadIdx.x & 63u; writer = lane < 63u && lane % 3u == 0; return (gid >> 6) * 21u + (lane == 63u ? 20u : lane / 3u); }
+    writer = (gid % LANES) == 0; return gid / LANES;
+}
+// threads needed for n sponges
+template <int LANES> static inline size_t coop_threads(size_t n) { return LANES == 3 ? ((n + 20) / 21) * 64 : n * LANES; }
 
 // a16: Merkle-path fold.  One lane group (4 or 8 lanes) per path.  node <- H_height(left, right) with the per-height salted initial state
 // (mina `hash_with_kimchi(MERKLE_PARAM[height], [l, r])`): state = salt[height]; state[0] += l; state[1] += r; permute;

@@ -252,7 +252,7 @@ def ipa_open_fast(curve, g_bytes, h, polys, blinders, evalpoints, xi, rscale, sp
     return {"lr": lr, "delta": delta, "z1": z1, "z2": z2, "sg": g0, "combined_inner_product": cip, "chals": chals}
 
 
-def ipa_verify_batch(curve, g_bytes, h, batch, rand_base, sg_rand_base) -> bool:
+def ipa_verify_batch(curve, g_bytes, h, batch, rand_base, sg_rand_base, threads: int = 8) -> bool:
     """poly-commitment `SRS::verify`.  `batch`: list of dicts with keys
     sponge (FqSponge, consumed), evalpoints, polyscale, evalscale, comms (list of points), opening (dict from ipa_open
     or equivalent), combined_inner_product."""
@@ -303,7 +303,7 @@ def ipa_verify_batch(curve, g_bytes, h, batch, rand_base, sg_rand_base) -> bool:
         sigma = sigma * sg_rand_base % r
     all_pts = np.concatenate([O.point_to_bytes(h)[None, :], g_bytes, np.stack([O.point_to_bytes(p) for p in pts])])
     all_scs = O.ints_to_le([scalar_h] + scalars_g + scs)
-    return not O.msm_pippenger(curve, all_pts, all_scs, threads=8).any()
+    return not O.msm_pippenger(curve, all_pts, all_scs, threads=threads).any()
 
 
 def make_instance(curve, g_bytes, h, pp: R.PoseidonParams, k: int, n_polys: int, n_points: int, seed: int, xi=None):

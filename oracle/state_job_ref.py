@@ -175,12 +175,12 @@ def make_accumulator(curve, g_bytes, k: int, seed: int):
     return pre, sg
 
 
-def accumulator_ok(curve, g_bytes, k: int, pre, sg) -> bool:
+def accumulator_ok(curve, g_bytes, k: int, pre, sg, threads: int = 8) -> bool:
     fs = O.scalar_field_of(curve)
     _, endo_r = O.endo(curve)
     chals = np.stack([O.challenge_to_field(fs, np.ascontiguousarray(pre[i]), endo_r) for i in range(k)])
     s = O.b_poly_coefficients(fs, chals)
-    return bool((O.msm_pippenger(curve, g_bytes[: 1 << k], s, threads=8) == np.asarray(sg, dtype=np.uint8).reshape(64)).all())
+    return bool((O.msm_pippenger(curve, g_bytes[: 1 << k], s, threads=threads) == np.asarray(sg, dtype=np.uint8).reshape(64)).all())
 
 
 # ------------------------------------------------------------------------------------------------ the composite verdict
