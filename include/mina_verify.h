@@ -341,6 +341,7 @@ int mina_protocol_state_hash_bytes(mina_ctx *ctx, int encoding, size_t n, const 
  * the opening), the wrap proof's combined IPA opening (folded over the batch) and the step accumulator check (Vesta 2^acc_k
  * bases, folded with acc_rho).  Sections are structure-of-arrays over the batch; layouts as in mina_ipa_opening /
  * mina_accumulator_check_batch.  A section is skipped when its `with_*` flag (or npub) is 0. */
+struct mina_kimchi_proofs;
 typedef struct {
     size_t batch;
     /* (1) protocol states */
@@ -358,6 +359,11 @@ typedef struct {
     const void *sponge_state /* b*96 */, *sponge_pos /* b*2 u32 {mode, count} */, *cip /* b*32 */, *lr /* b*2k*64 */, *delta /* b*64 */,
                *sg /* b*64 */, *z1, *z2 /* b*32 */, *evalpoints /* b*n_evalpoints*32 */, *evalscale, *polyscale /* b*32 */, *comms /* b*n_comms*64 */;
     const void *rand_base, *sg_rand_base;   /* 32 each */
+    /* (3') instead of the derived rows above (sponge_state, sponge_pos, cip, evalpoints, evalscale, polyscale, comms): the raw wrap
+     * proofs; kimchi `oracles` + `to_batch` then run on the GPU against the installed verifier index (k = its domain, n_evalpoints = 2,
+     * n_comms = n_prev + 45; lr, delta, sg, z1, z2 still come from the fields above).  The struct lives on the host; its inner
+     * pointers are host or device addresses like every other section. */
+    const struct mina_kimchi_proofs *kimchi;
     /* (4) step accumulator (Vesta) */
     int with_accumulator;
     uint32_t acc_k;
@@ -373,11 +379,98 @@ int mina_state_job_batch_dev(mina_ctx *ctx, const mina_state_jobs *jobs, void *d
  * its own verdict byte. */
 int mina_state_job_batch(mina_ctx *ctx, const mina_state_jobs *jobs, uint8_t *verdicts /* batch */);
 
-/* ---- top-level byte contract (a15, a16): NOT YET EXPORTED ------------------------------------
- * mina_verify_state / mina_verify_account (same (ptr,len,ptr,len) shape as Aligned's
- * verify_mina_state_ffi / verify_account_inclusion_ffi) need the bincode/binprot container parsers and
- * the blockchain-snark verifier index, neither of which exists in the reference tree (SURVEY.md 8f rows
- * 1-2).  They are specified in INTEGRATION.md and will be added once those land. */
+/* ---- kimchi verifier for the Pickles wrap proof (a11): `oracles` + `to_batch` on the GPU ---------------------------------
+ * The verifier index is DATA: the reference tree does not hold the blockchain-snark index, so the engine takes domain, shifts,
+ * commitments and the linearization's constant term (a PolishToken program in the byte-code below) as a parameter. */
+#define MINA_TOK_ALPHA 0
+#define MINA_TOK_BETA 1
+#define MINA_TOK_GAMMA 2
+#define MINA_TOK_JOINT_COMBINER 3
+#define MINA_TOK_ENDO_COEFFICIENT 4
+#define MINA_TOK_MDS 5                    /* + u8 row, u8 col */
+#define MINA_TOK_LITERAL 6                /* + 32-byte scalar */
+#define MINA_TOK_CELL 7                   /* + u8 column (0 z, 1..6 selectors, 7..21 w, 22..36 coefficients, 37..42 sigma), u8 row (0 = zeta, 1 = zeta*omega) */
+#define MINA_TOK_DUP 8
+#define MINA_TOK_POW 9                    /* + u64 exponent */
+#define MINA_TOK_ADD 10
+#define MINA_TOK_MUL 11
+#define MINA_TOK_SUB 12
+#define MINA_TOK_VANISHES_ON_ZK_ROWS 13   /* VanishesOnZeroKnowledgeAndPreviousRows */
+#define MINA_TOK_UNNORMALIZED_LAGRANGE 14 /* + i32 row offset (negative: counted back from the first zero-knowledge row) */
+#define MINA_TOK_STORE 15
+#define MINA_TOK_LOAD 16                  /* + u16 cache slot */
+typedef struct {
+    uint32_t log2_domain;              /* evaluation domain = SRS chunk size = 2^log2_domain (wrap: 15) */
+    uint32_t zk_rows;                  /* 3 */
+    uint32_t perm_alpha_offset;        /* first power of alpha of the permutation argument (21) */
+    const uint8_t *shifts;             /* 7 * 32, scalar field (Fq) */
+    const uint8_t *sigma_comm;         /* 7 * 64 */
+    const uint8_t *coefficients_comm;  /* 15 * 64 */
+    const uint8_t *selector_comm;      /* 6 * 64: generic, poseidon, complete_add, mul, emul, endomul_scalar */
+    const uint8_t *constant_term;      /* PolishToken byte-code of linearization.constant_term */
+    size_t constant_term_len;
+} mina_verifier_index;
+int mina_verifier_index_install(mina_ctx *ctx, const mina_verifier_index *index);
+int mina_verifier_index_digest(mina_ctx *ctx, uint8_t *out32);   /* `VerifierIndex::digest` (base-field element) */
+typedef struct mina_kimchi_proofs {
+    size_t batch;
+    uint32_t n_prev, npub;             /* recursion challenges per proof (wrap: 2), public inputs per proof */
+    const void *public_inputs;         /* b * npub * 32 */
+    const void *prev_chals;            /* b * n_prev * k * 32 (expanded challenges, scalar field) */
+    const void *prev_comms;            /* b * n_prev * 64 */
+    const void *w_comm /* b*15*64 */, *z_comm /* b*64 */, *t_comm /* b*7*64 */;
+    const void *evals;                 /* b * 43 * 2 * 32: column order of MINA_TOK_CELL, [zeta, zeta*omega] */
+    const void *ft_eval1;              /* b * 32 */
+} mina_kimchi_proofs;
+typedef struct {                       /* one `BatchEvaluationProof` row per proof, host buffers */
+    uint8_t *sponge_state /* b*96 */; uint32_t *sponge_pos /* b*2 */; uint8_t *cip /* b*32 */, *evalpoints /* b*64: zeta, zeta*omega */,
+            *polyscale /* b*32: v */, *evalscale /* b*32: u */, *comms /* b*(n_prev+45)*64 */, *ft_eval0 /* b*32 or NULL */;
+    uint8_t *malformed;                /* 1 byte or NULL: some input was not canonical / not on the curve */
+} mina_kimchi_batch_out;
+int mina_kimchi_to_batch(mina_ctx *ctx, const mina_kimchi_proofs *proofs, mina_kimchi_batch_out *out);
+
+/* ---- containers (a1, a5, 8f-2) -------------------------------------------------------------------------------------
+ * Serialized Pickles wrap proof (`MinaBaseProofStableV2`; bin_prot as core/src/mina.rs:235-248 reads it, or the serde/bincode form
+ * at the head of `MinaStateProof`) -> one flat byte string in the fixed order the kernels consume:
+ *   alpha beta gamma zeta (16 each) | has_joint_combiner (1) joint_combiner (16) | feature_flags (8) | 16 step prechallenges (16 each)
+ *   | proofs_verified (1) domain_log2 (1) | sponge_digest (32) | step accumulator sg (64) | 2 x 15 wrap prechallenges
+ *   | u32 n, n points | u32 n, n x 16 prechallenges | prev public-input evals | u32 count, prev evals (each: u32 n, n x 32, u32 n, n x 32)
+ *   | optional-presence bytes | prev ft_eval1 | 15 w_comm, z_comm, 7 t_comm | evals w(15) coefficients(15) z s(6) selectors(6), (zeta, zeta*omega) each
+ *   | ft_eval1 | u32 n, n x (L, R) | z1 z2 delta sg.
+ * `out` may be NULL to query the length.  Host-side, no context. */
+int mina_wrap_proof_flatten(const uint8_t *bytes, size_t len, int encoding, uint8_t *out, size_t cap, size_t *out_len, size_t *consumed /* may be NULL: exact */);
+/* bincode `MinaStateProof` (core/src/proof/state_proof.rs:28-41): length of the leading proof, then where each of the 17 states sits */
+int mina_state_proof_split(const uint8_t *bytes, size_t len, size_t *proof_len, size_t *state_offsets /* 17 */, size_t *state_lens /* 17 */);
+
+/* ---- the reference-shaped boundary (README.md:275-279, 281-310, 358-362) --------------------------------
+ * Same (ptr, len, ptr, len) -> bool shape as Aligned's `verify_mina_state_ffi` / `verify_account_inclusion_ffi`, fed with exactly
+ * the bytes core/src/aligned.rs:31-58 produces.  Every failure is `false`; nothing unwinds; callable from any thread (one
+ * process-wide context on GPU $MINA_VERIFY_DEVICE (default 0), created on first use, serialised by a mutex). */
+#define MINA_CHECK_FORMAT 1u        /* pub inputs (1057 B) and bincode MinaStateProof parse */
+#define MINA_CHECK_LEDGER 2u        /* ledger hashes of the public input == the states' snarked ledger hashes   (README.md:287) */
+#define MINA_CHECK_CHAIN 4u         /* 17 state hashes == public input, states linked                          (README.md:285-288) */
+#define MINA_CHECK_CONSENSUS 8u     /* candidate tip selected over the bridge tip                              (README.md:290-294) */
+#define MINA_CHECK_ACCUMULATOR 16u  /* step accumulator: MSM(vesta.g, b_poly_coefficients) == challenge_polynomial_commitment */
+#define MINA_CHECK_KIMCHI 32u       /* kimchi verification of the wrap proof (needs an installed verifier index) */
+#define MINA_VERIFY_ALLOW_MISSING_KIMCHI 1u   /* verdict ignores MINA_CHECK_KIMCHI when no index is installed: NOT a full verification */
+#include <stdbool.h>
+bool mina_verify_state(const uint8_t *proof, size_t proof_len, const uint8_t *pub_input, size_t pub_len);
+int mina_verify_state_batch(size_t n, const uint8_t *const *proofs, const size_t *proof_lens, const uint8_t *const *pub_inputs,
+                            const size_t *pub_lens, uint8_t *verdicts_out /* n bytes 0/1 */);
+/* which steps ran and which passed (bit masks of MINA_CHECK_*) */
+int mina_verify_state_checks(const uint8_t *proof, size_t proof_len, const uint8_t *pub_input, size_t pub_len, uint32_t *passed_mask, uint32_t *ran_mask);
+/* the `--save-proof` files of the reference CLI (core/src/aligned.rs:60-69): mina_state.proof / mina_state.pub */
+bool mina_verify_state_files(const char *proof_path, const char *pub_path);
+bool mina_verify_account(const uint8_t *proof, size_t proof_len, const uint8_t *pub_input, size_t pub_len);
+int mina_verify_account_batch(size_t n, const uint8_t *const *proofs, const size_t *proof_lens, const uint8_t *const *pub_inputs,
+                              const size_t *pub_lens, uint8_t *verdicts_out);
+bool mina_verify_account_files(const char *proof_path, const char *pub_path);
+int mina_verify_configure(uint32_t flags);       /* MINA_VERIFY_* */
+int mina_verify_shutdown(void);                  /* destroy the process-wide context */
+mina_ctx *mina_verify_global_ctx(void);          /* e.g. to install a verifier index or other Poseidon tables; NULL without a GPU */
+/* the Poseidon constant set compiled into the library (name contains "UNPINNED" while it is a surrogate for fp_kimchi/fq_kimchi) */
+const char *mina_poseidon_params_name(void);
+int mina_poseidon_install_default_params(mina_ctx *ctx);
 
 #ifdef __cplusplus
 }

@@ -15,31 +15,6 @@
 
 namespace mb {
 
-// mina-poseidon `ArithmeticSponge` state machine (rate 2) over base field F, Montgomery state, lane-cooperative over
-// LANES = 4 or 8 lanes (sponge.cuh): `s` = the state element this lane owns (coop_elem), the position (squeezed, count)
-// is replicated.  Absorbed values and squeezed results are replicated on all lanes of the group.
-template <int F, int LANES> struct DevSponge {
-    fe_t s; int squeezed; int count; const PoseidonParams *pp;
-    __device__ void add_at(int pos, const fe_t &x) { if ((int)coop_elem<LANES>() == pos) s = fe_add<F>(s, x); }
-    __device__ fe_t get(int pos) { return coop_get<LANES>(s, pos); }
-    __device__ void absorb(const fe_t &x) {
-        if (!squeezed) {
-            if (count == 2) { poseidon_permute_coop<F, LANES>(s, pp); add_at(0, x); count = 1; }
-            else { add_at(count, x); ++count; }
-        } else { add_at(0, x); squeezed = 0; count = 1; }
-    }
-    __device__ fe_t squeeze() {
-        if (!squeezed || count == 2) { poseidon_permute_coop<F, LANES>(s, pp); squeezed = 1; count = 1; return get(0); }
-        return get(count++);
-    }
-};
-
-template <int F> __device__ __forceinline__ fe_t load_fe(const uint32_t *p) { fe_t r; for (int i = 0; i < 8; ++i) r.v[i] = p[i]; return r; }
-template <int LANES> __device__ __forceinline__ bool coop_writer() { return (threadIdx.x & (LANES - 1)) == 0; }
-template <int LANES> __device__ __forceinline__ void store_fe(uint32_t *p, const fe_t &a) { if (coop_writer<LANES>()) for (int i = 0; i < 8; ++i) p[i] = a.v[i]; }
-template <int LANES> __device__ __forceinline__ void store_pt(affine_t *p, const affine_t &a) { if (coop_writer<LANES>()) *p = a; }
-
-
 // ---------------------------------------------------------------- generic Fq-sponge transcript ("tape")
 // mina-poseidon `DefaultFqSponge` over the base field of CURVE (pins core/Cargo.toml:14; README.md:413-475 lists the order
 // kimchi absorbs/squeezes in).  Every proof of a batch runs the same tape of opcodes over its own input stream:
@@ -102,21 +77,6 @@ sponge_tape_kernel(uint32_t batch, uint32_t tape_len, uint32_t in_stride_words, 
     if (final_pos && l == 0) { final_pos[2 * b] = (uint32_t)sp.squeezed; final_pos[2 * b + 1] = (uint32_t)sp.count; }
 }
 
-
-template <int FB> __device__ __forceinline__ affine_t load_point_mont(const uint32_t *p, const FieldK &kb) {
-    affine_t a; a.x = fe_to_mont<FB>(load_fe<FB>(p), kb.r2); a.y = fe_to_mont<FB>(load_fe<FB>(p + 8), kb.r2); return a;
-}
-// The same with the checks upstream's deserialiser makes before `SRS::verify` ever sees a point: coordinates canonical and
-// the point on y^2 = x^3 + 5 (or the (0,0) encoding of infinity).  A proof carrying anything else must be REJECTED -- off-curve
-// points would otherwise enter the combined MSM -- so `ok` feeds the batch verdict.
-template <int FB> __device__ __forceinline__ affine_t load_point_checked(const uint32_t *p, const FieldK &kb, bool &ok) {
-    const fe_t xw = load_fe<FB>(p), yw = load_fe<FB>(p + 8);
-    affine_t a; a.x = fe_to_mont<FB>(xw, kb.r2); a.y = fe_to_mont<FB>(yw, kb.r2);
-    bool good = fe_words_canonical<FB>(xw) && fe_words_canonical<FB>(yw);
-    if (good && !aff_is_inf(a)) good = fe_eq(fe_sqr<FB>(a.y), fe_add<FB>(fe_mul<FB>(fe_sqr<FB>(a.x), a.x), kb.five));
-    ok = ok && good;
-    return a;
-}
 
 // One lane group (4 or 8 lanes) per proof: the Fq-sponge runs lane-cooperatively (6.3 / 4.65 dependent product latencies per
 // Poseidon round instead of 21), all other (scalar-field) work is computed redundantly by the lanes, lane 0 writes.

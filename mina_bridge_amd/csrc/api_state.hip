@@ -98,10 +98,12 @@ __global__ void fill_u32_kernel(uint32_t n, uint32_t v, uint32_t *__restrict__ o
 
 // verdict[b] = chain_ok[b] AND folded IPA verdict AND folded accumulator verdict; flags = {ipa, ipa malformed, acc, 0}
 __global__ void state_job_verdict_kernel(uint32_t batch, const uint32_t *__restrict__ chain_ok, const uint32_t *__restrict__ ipa_v /* [2] or null */,
-                                         const uint32_t *__restrict__ acc_v /* [1] or null */, uint32_t *__restrict__ verdicts, uint32_t *__restrict__ flags) {
+                                         const uint32_t *__restrict__ acc_v /* [1] or null */, const uint32_t *__restrict__ kimchi_bad /* [1] or null */,
+                                         uint32_t *__restrict__ verdicts, uint32_t *__restrict__ flags) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t iv = ipa_v ? ipa_v[0] : 1u, av = acc_v ? acc_v[0] : 1u;
-    if (b == 0 && flags) { flags[0] = iv; flags[1] = ipa_v ? ipa_v[1] : 0u; flags[2] = av; flags[3] = 0u; }
+    const uint32_t kb = kimchi_bad ? kimchi_bad[0] : 0u;
+    const uint32_t iv = (ipa_v ? ipa_v[0] : 1u) && !kb, av = acc_v ? acc_v[0] : 1u;
+    if (b == 0 && flags) { flags[0] = iv; flags[1] = (ipa_v ? ipa_v[1] : 0u) | kb; flags[2] = av; flags[3] = 0u; }
     if (b < batch) verdicts[b] = (chain_ok[b] && iv && av) ? 1u : 0u;
 }
 
@@ -219,15 +221,22 @@ static int check_jobs(mina_ctx *c, const mina_state_jobs *j) {
     if (j->batch == 0 || j->batch > 65536) return fail(MINA_ERR_ARG, "batch must be in 1..65536");
     if (j->with_states && (!j->state_records || !j->state_nfields || !j->expected_hashes)) return fail(MINA_ERR_ARG, "null protocol-state section");
     if (j->with_ipa) {
-        if (!j->sponge_state || !j->sponge_pos || !j->cip || !j->lr || !j->delta || !j->sg || !j->z1 || !j->z2 || !j->evalscale || !j->polyscale ||
-            !j->rand_base || !j->sg_rand_base || (j->n_evalpoints && !j->evalpoints) || (j->n_comms && !j->comms)) return fail(MINA_ERR_ARG, "null IPA section");
+        if (!j->lr || !j->delta || !j->sg || !j->z1 || !j->z2 || !j->rand_base || !j->sg_rand_base) return fail(MINA_ERR_ARG, "null IPA section");
+        if (j->kimchi) {
+            const mina_kimchi_proofs &kp = *j->kimchi;
+            if (!c->have_kimchi) return fail(MINA_ERR_STATE, "no verifier index installed");
+            if (kp.batch != j->batch || j->k != c->kimchi_log2 || j->log2_domain != c->kimchi_log2 || j->n_evalpoints != 2 || j->n_comms != kp.n_prev + 45 || kp.npub != j->npub || kp.n_prev > 8)
+                return fail(MINA_ERR_ARG, "kimchi section does not match the installed index / the job's shape");
+            if ((kp.n_prev && (!kp.prev_chals || !kp.prev_comms)) || !kp.w_comm || !kp.z_comm || !kp.t_comm || !kp.evals || !kp.ft_eval1 || (kp.npub && !kp.public_inputs)) return fail(MINA_ERR_ARG, "null kimchi section");
+        } else if (!j->sponge_state || !j->sponge_pos || !j->cip || !j->evalscale || !j->polyscale || (j->n_evalpoints && !j->evalpoints) || (j->n_comms && !j->comms))
+            return fail(MINA_ERR_ARG, "null IPA section");
         if (j->k < 1 || j->k > 20 || ((size_t)1 << j->k) > c->srs[CURVE_PALLAS].depth) return fail(c->srs[CURVE_PALLAS].depth ? MINA_ERR_ARG : MINA_ERR_STATE, "Pallas SRS missing or 2^k exceeds its depth");
         if (j->n_comms > 4096 || j->n_evalpoints > 64) return fail(MINA_ERR_ARG, "too many commitments / evaluation points");
         if (!c->have_pparams[FIELD_FP]) return fail(MINA_ERR_STATE, "Poseidon constants not installed for Fp");
     }
     if (j->npub) {
         if (!j->public_inputs) return fail(MINA_ERR_ARG, "null public inputs");
-        if (!j->with_ipa || j->pub_comm_slot >= j->n_comms) return fail(MINA_ERR_ARG, "public-input commitment needs an IPA section and a valid commitment slot");
+        if (!j->with_ipa || (!j->kimchi && j->pub_comm_slot >= j->n_comms)) return fail(MINA_ERR_ARG, "public-input commitment needs an IPA section and a valid commitment slot");
         if (j->log2_domain > 20 || ((uint64_t)1 << j->log2_domain) > c->srs[CURVE_PALLAS].depth || j->npub > 4096 || j->npub > ((uint64_t)1 << j->log2_domain)) return fail(MINA_ERR_ARG, "bad domain / npub");
     }
     if (j->with_accumulator) {
@@ -238,6 +247,28 @@ static int check_jobs(mina_ctx *c, const mina_state_jobs *j) {
 }
 
 int mb_ensure_lagrange_table(mina_ctx *c, int curve, uint32_t log2_domain, uint32_t npub);   // api_srs.hip
+namespace mb {   // api_kimchi.hip
+struct KimchiIn { const uint32_t *pub, *prev_chals, *prev_comms, *w_comm, *z_comm, *t_comm, *evals, *ft_eval1, *pubcomm; };
+struct KimchiOut { uint32_t *sponge_state, *sponge_pos, *cip, *evalpoints, *polyscale, *evalscale, *comms, *ft_eval0; };
+}
+int mb_kimchi_to_batch_dev(mina_ctx *c, size_t batch, uint32_t n_prev, uint32_t npub, const mb::KimchiIn &in, const mb::KimchiOut &out, uint32_t *d_bad);
+
+// public-input commitments h - sum_i pub_i L_i of `batch` proofs as canonical affine words (16 per proof) on the current lane
+int mb_pubcomm_dev(mina_ctx *c, size_t batch, uint32_t log2_domain, uint32_t npub, const uint32_t *d_pub, uint32_t *d_out16) {
+    Lane &L = *c->L;
+    SrsState &s = c->srs[CURVE_PALLAS];
+    int rc;
+    if ((rc = L.st_pub_xyzz.ensure(batch * sizeof(xyzz_t)))) return rc;
+    if (npub == 0) {                                                // empty public input: A = infinity, commitment = h
+        HIPC(hipMemsetAsync(L.st_pub_xyzz.p, 0, batch * sizeof(xyzz_t), L.stream));
+    } else {
+        if (s.lagrange_table_log2 != (int)log2_domain || s.lagrange_table_n < npub) return fail(MINA_ERR_STATE, "call mina_state_jobs_prepare(log2_domain, npub) first");
+        if ((rc = mb_msm_table(c, CURVE_PALLAS, s.lagrange_table.p, s.lagrange_table_n, 8, 32, 0, npub, (uint32_t)batch, d_pub, nullptr, L.st_pub_xyzz.p))) return rc;
+    }
+    mb::pubcomm_finish16_kernel<FIELD_FP><<<cdiv(batch, 64), 64, 0, L.stream>>>((uint32_t)batch, c->fk[FIELD_FP], s.h.as<affine_t>(), L.st_pub_xyzz.as<xyzz_t>(), d_out16);
+    HIPC(hipGetLastError());
+    return MINA_OK;
+}
 
 // everything that needs a host synchronisation (salts, Lagrange basis + its window table): done once, before the first job
 extern "C" int mina_state_jobs_prepare(mina_ctx *c, uint32_t log2_domain, uint32_t npub) {
@@ -269,33 +300,45 @@ static int state_jobs_on_lane(mina_ctx *c, const mina_state_jobs *j, uint32_t *d
     }
     HIPC(hipGetLastError());
     const uint32_t *comm_override = nullptr;
-    if (j->npub) {
-        SrsState &s = c->srs[CURVE_PALLAS];
-        if (s.lagrange_table_log2 != (int)j->log2_domain || s.lagrange_table_n < j->npub) return fail(MINA_ERR_STATE, "call mina_state_jobs_prepare(log2_domain, npub) first");
-        if ((rc = L.st_pub_xyzz.ensure(B * sizeof(xyzz_t)))) return rc;
+    if (j->npub || j->kimchi) {
         if ((rc = L.st_pubcomm.ensure(B * 64))) return rc;
-        if ((rc = mb_msm_table(c, CURVE_PALLAS, s.lagrange_table.p, s.lagrange_table_n, 8, 32, 0, j->npub, (uint32_t)B, (const uint32_t *)j->public_inputs, nullptr, L.st_pub_xyzz.p))) return rc;
-        mb::pubcomm_finish16_kernel<FIELD_FP><<<cdiv(B, 64), 64, 0, L.stream>>>((uint32_t)B, c->fk[FIELD_FP], s.h.as<affine_t>(), L.st_pub_xyzz.as<xyzz_t>(), L.st_pubcomm.as<uint32_t>());
-        HIPC(hipGetLastError());
+        if ((rc = mb_pubcomm_dev(c, B, j->log2_domain, j->npub, (const uint32_t *)j->public_inputs, L.st_pubcomm.as<uint32_t>()))) return rc;
         comm_override = L.st_pubcomm.as<uint32_t>();
     }
     uint32_t *ipa_v = nullptr, *acc_v = nullptr;
     if ((rc = L.st_flags.ensure(16 * 4))) return rc;
+    uint32_t *kimchi_bad = nullptr;
     if (j->with_ipa) {
         mb::IpaShape sh; sh.batch = (uint32_t)B; sh.k = j->k; sh.npts = j->n_evalpoints; sh.ncomms = j->n_comms; sh.per = 2 * j->k + j->n_comms + 4;
-        sh.override_slot = j->npub ? j->pub_comm_slot : 0xffffffffu;
         auto W = [](const void *p) { return (const uint32_t *)p; };
-        mb::IpaDevIn in{W(j->sponge_state), W(j->sponge_pos), W(j->cip), W(j->lr), W(j->delta), W(j->sg), W(j->z1), W(j->z2), W(j->evalpoints), W(j->evalscale),
-                        W(j->polyscale), W(j->comms), comm_override, W(j->rand_base), W(j->sg_rand_base)};
         ipa_v = L.st_flags.as<uint32_t>() + 4;
-        if ((rc = mb_ipa_batch_check_dev(c, CURVE_PALLAS, sh, in, ipa_v))) return rc;
+        if (j->kimchi) {
+            // kimchi oracles + to_batch produce the BatchEvaluationProof rows in lane buffers (the public-input commitment is already in the list)
+            const mina_kimchi_proofs &kp = *j->kimchi;
+            if ((rc = L.kc_state.ensure(B * 96)) || (rc = L.kc_pos.ensure(B * 8)) || (rc = L.kc_cip.ensure(B * 32)) || (rc = L.kc_pts.ensure(B * 64)) ||
+                (rc = L.kc_v.ensure(B * 32)) || (rc = L.kc_u.ensure(B * 32)) || (rc = L.kc_comms.ensure(B * (size_t)j->n_comms * 64))) return rc;
+            kimchi_bad = L.st_flags.as<uint32_t>() + 12;
+            HIPC(hipMemsetAsync(kimchi_bad, 0, 4, L.stream));
+            mb::KimchiIn in{W(kp.public_inputs), W(kp.prev_chals), W(kp.prev_comms), W(kp.w_comm), W(kp.z_comm), W(kp.t_comm), W(kp.evals), W(kp.ft_eval1), comm_override};
+            mb::KimchiOut out{L.kc_state.as<uint32_t>(), L.kc_pos.as<uint32_t>(), L.kc_cip.as<uint32_t>(), L.kc_pts.as<uint32_t>(), L.kc_v.as<uint32_t>(), L.kc_u.as<uint32_t>(),
+                              L.kc_comms.as<uint32_t>(), nullptr};
+            if ((rc = mb_kimchi_to_batch_dev(c, B, kp.n_prev, kp.npub, in, out, kimchi_bad))) return rc;
+            mb::IpaDevIn iin{out.sponge_state, out.sponge_pos, out.cip, W(j->lr), W(j->delta), W(j->sg), W(j->z1), W(j->z2), out.evalpoints, out.evalscale, out.polyscale,
+                             out.comms, nullptr, W(j->rand_base), W(j->sg_rand_base)};
+            if ((rc = mb_ipa_batch_check_dev(c, CURVE_PALLAS, sh, iin, ipa_v))) return rc;
+        } else {
+            sh.override_slot = j->npub ? j->pub_comm_slot : 0xffffffffu;
+            mb::IpaDevIn in{W(j->sponge_state), W(j->sponge_pos), W(j->cip), W(j->lr), W(j->delta), W(j->sg), W(j->z1), W(j->z2), W(j->evalpoints), W(j->evalscale),
+                            W(j->polyscale), W(j->comms), comm_override, W(j->rand_base), W(j->sg_rand_base)};
+            if ((rc = mb_ipa_batch_check_dev(c, CURVE_PALLAS, sh, in, ipa_v))) return rc;
+        }
     }
     if (j->with_accumulator) {
         acc_v = L.st_flags.as<uint32_t>() + 8;
         if ((rc = mb_accumulator_check_dev(c, CURVE_VESTA, j->acc_k, B, (const uint32_t *)j->acc_prechallenges, (const uint32_t *)j->acc_sg,
                                            B > 1 ? (const uint32_t *)j->acc_rho : nullptr, acc_v))) return rc;
     }
-    mb::state_job_verdict_kernel<<<cdiv(B, 64), 64, 0, L.stream>>>((uint32_t)B, L.st_ok.as<uint32_t>(), ipa_v, acc_v, d_verdicts, d_flags);
+    mb::state_job_verdict_kernel<<<cdiv(B, 64), 64, 0, L.stream>>>((uint32_t)B, L.st_ok.as<uint32_t>(), ipa_v, acc_v, kimchi_bad, d_verdicts, d_flags);
     HIPC(hipGetLastError());
     return MINA_OK;
 }
@@ -330,6 +373,14 @@ extern "C" int mina_state_job_batch(mina_ctx *c, const mina_state_jobs *jobs, ui
     auto add = [&](const void *&slot, size_t bytes) { if (slot && bytes) secs.push_back({&slot, bytes}); };
     if (d.with_states) { add(d.state_records, B * S * MINA_PSTATE_SLOTS * 32); add(d.state_nfields, B * S * 4); add(d.expected_hashes, B * S * 32); add(d.precheck, B); }
     if (d.npub) add(d.public_inputs, B * d.npub * 32);
+    mina_kimchi_proofs kd{};
+    if (d.with_ipa && d.kimchi) {
+        kd = *d.kimchi; d.kimchi = &kd;
+        kd.public_inputs = nullptr;                                   // the job's own public_inputs section is the one uploaded
+        add(kd.prev_chals, B * kd.n_prev * k * 32); add(kd.prev_comms, B * kd.n_prev * 64); add(kd.w_comm, B * 15 * 64); add(kd.z_comm, B * 64);
+        add(kd.t_comm, B * 7 * 64); add(kd.evals, B * 43 * 64); add(kd.ft_eval1, B * 32);
+        d.sponge_state = d.sponge_pos = d.cip = d.evalpoints = d.evalscale = d.polyscale = d.comms = nullptr;
+    }
     if (d.with_ipa) {
         add(d.sponge_state, B * 96); add(d.sponge_pos, B * 8); add(d.cip, B * 32); add(d.lr, B * 2 * k * 64); add(d.delta, B * 64); add(d.sg, B * 64);
         add(d.z1, B * 32); add(d.z2, B * 32); add(d.evalpoints, B * np * 32); add(d.evalscale, B * 32); add(d.polyscale, B * 32); add(d.comms, B * m * 64);
@@ -345,6 +396,7 @@ extern "C" int mina_state_job_batch(mina_ctx *c, const mina_state_jobs *jobs, ui
     if ((rc = L.st_in.ensure(total))) return rc;
     HIPC(hipMemcpyAsync(L.st_in.p, blob, total, hipMemcpyHostToDevice, L.stream));
     for (size_t i = 0; i < secs.size(); ++i) *secs[i].slot = L.st_in.as<uint8_t>() + offs[i];
+    if (d.kimchi) kd.public_inputs = d.public_inputs;
     if ((rc = L.st_verdicts.ensure(B * 4 + 16))) return rc;
     uint32_t *dv = L.st_verdicts.as<uint32_t>(), *df = dv + B;
     if ((rc = state_jobs_on_lane(c, &d, dv, df))) return rc;
@@ -355,16 +407,22 @@ extern "C" int mina_state_job_batch(mina_ctx *c, const mina_state_jobs *jobs, ui
     // a folded check failed somewhere: find the culprits.  chain_ok per proof comes from a run without the folded legs.
     std::vector<uint8_t> ipa_each(B, 1), acc_each(B, 1), chain_each(B, 1);
     {
-        mina_state_jobs only = d; only.with_ipa = 0; only.with_accumulator = 0; only.npub = 0;
+        mina_state_jobs only = d; only.with_ipa = 0; only.with_accumulator = 0; only.npub = 0; only.kimchi = nullptr;
         if (only.with_states) {
             if ((rc = state_jobs_on_lane(c, &only, dv, df))) return rc;
             if ((rc = d2h_sync(c, hv.data(), L.st_verdicts, B * 4))) return rc;
             for (size_t b = 0; b < B; ++b) chain_each[b] = hv[b] ? 1 : 0;
         }
     }
+    mina_kimchi_proofs kslice{};
     auto slice = [&](const mina_state_jobs &src, size_t lo, size_t cnt) {
         mina_state_jobs s = src; s.batch = cnt; s.with_states = 0; s.precheck = nullptr;
         auto adv = [&](const void *&p, size_t stride) { if (p) p = (const uint8_t *)p + lo * stride; };
+        if (s.kimchi) {
+            kslice = *s.kimchi; kslice.batch = cnt; s.kimchi = &kslice;
+            adv(kslice.public_inputs, (size_t)kslice.npub * 32); adv(kslice.prev_chals, (size_t)kslice.n_prev * k * 32); adv(kslice.prev_comms, (size_t)kslice.n_prev * 64);
+            adv(kslice.w_comm, 15 * 64); adv(kslice.z_comm, 64); adv(kslice.t_comm, 7 * 64); adv(kslice.evals, 43 * 64); adv(kslice.ft_eval1, 32);
+        }
         adv(s.public_inputs, (size_t)s.npub * 32);
         adv(s.sponge_state, 96); adv(s.sponge_pos, 8); adv(s.cip, 32); adv(s.lr, 2 * k * 64); adv(s.delta, 64); adv(s.sg, 64); adv(s.z1, 32); adv(s.z2, 32);
         adv(s.evalpoints, np * 32); adv(s.evalscale, 32); adv(s.polyscale, 32); adv(s.comms, m * 64);
@@ -377,7 +435,7 @@ extern "C" int mina_state_job_batch(mina_ctx *c, const mina_state_jobs *jobs, ui
         while (!todo.empty()) {
             auto [lo, cnt] = todo.back(); todo.pop_back();
             mina_state_jobs s = slice(d, lo, cnt);
-            if (ipa_leg) s.with_accumulator = 0; else { s.with_ipa = 0; s.npub = 0; }
+            if (ipa_leg) s.with_accumulator = 0; else { s.with_ipa = 0; s.npub = 0; s.kimchi = nullptr; }
             int r = state_jobs_on_lane(c, &s, dv, df);
             if (r) return r;
             uint32_t f[4];

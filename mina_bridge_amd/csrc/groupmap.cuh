@@ -81,7 +81,7 @@ template <int F> MB_HD affine_t bw_to_group(const fe_t &t, const FieldK &k) {
 // ---------------------------------------------------------------- BLAKE2b-512 (RFC 7693), <= 128-byte messages
 MB_HD uint64_t b2_rotr(uint64_t x, int n) { return (x >> n) | (x << (64 - n)); }
 
-MB_HD void blake2b512_short(const uint8_t *msg, uint32_t len, uint8_t out[64]) {
+MB_HD void blake2b_short(const uint8_t *msg, uint32_t len, uint8_t *out, uint32_t outlen /* 1..64 */) {
     const uint64_t iv[8] = {0x6a09e667f3bcc908ULL, 0xbb67ae8584caa73bULL, 0x3c6ef372fe94f82bULL, 0xa54ff53a5f1d36f1ULL,
                             0x510e527fade682d1ULL, 0x9b05688c2b3e6c1fULL, 0x1f83d9abfb41bd6bULL, 0x5be0cd19137e2179ULL};
     const uint8_t sigma[10][16] = {
@@ -92,7 +92,7 @@ MB_HD void blake2b512_short(const uint8_t *msg, uint32_t len, uint8_t out[64]) {
         {6, 15, 14, 9, 11, 3, 0, 8, 12, 2, 13, 7, 1, 4, 10, 5}, {10, 2, 8, 4, 7, 6, 1, 5, 15, 11, 9, 14, 3, 12, 13, 0}};
     uint64_t h[8], m[16], v[16];
     for (int i = 0; i < 8; ++i) h[i] = iv[i];
-    h[0] ^= 0x01010040ULL;                      // digest length 64, fanout 1, depth 1
+    h[0] ^= 0x01010000ULL ^ (uint64_t)outlen;   // digest length, fanout 1, depth 1
     for (int i = 0; i < 16; ++i) {
         uint64_t w = 0;
         for (int j = 7; j >= 0; --j) { uint32_t idx = 8 * i + j; w = (w << 8) | (idx < len ? msg[idx] : 0); }
@@ -114,9 +114,10 @@ MB_HD void blake2b512_short(const uint8_t *msg, uint32_t len, uint8_t out[64]) {
     }
     for (int i = 0; i < 8; ++i) {
         uint64_t w = h[i] ^ v[i] ^ v[i + 8];
-        for (int j = 0; j < 8; ++j) out[8 * i + j] = (uint8_t)(w >> (8 * j));
+        for (int j = 0; j < 8; ++j) if ((uint32_t)(8 * i + j) < outlen) out[8 * i + j] = (uint8_t)(w >> (8 * j));
     }
 }
+MB_HD void blake2b512_short(const uint8_t *msg, uint32_t len, uint8_t out[64]) { blake2b_short(msg, len, out, 64); }
 
 // first 31 digest bytes, each unpacked LSB-first, read as one big-endian bit string (248 bits < p)
 MB_HD fe_t digest_to_plain_fe(const uint8_t d[64]) {

@@ -11,6 +11,7 @@
 // Host C++ only (microseconds per state); the Poseidon work on the flattened fields is the GPU's (api_state.hip).
 #pragma once
 #include <cstdint>
+#include <array>
 #include <cstring>
 #include <vector>
 
@@ -72,6 +73,7 @@ struct Binprot : Cursor {                    // OCaml bin_prot, as mina-p2p-mess
     B32 big() { B32 r{}; const uint8_t *q = take(32); if (q) memcpy(r.b, q, 32); return r; }
     std::vector<uint8_t> string() { const size_t k = length(); const uint8_t *q = take(k); return q ? std::vector<uint8_t>(q, q + k) : std::vector<uint8_t>(); }
     uint8_t chr() { return u8(); }
+    void padded_end() { unit(); }            // `PaddedSeq<T, N>` = OCaml vector: N elements, then the unit that ends the nested pairs
 };
 
 struct Bincode : Cursor {                    // bincode 1.3 default options (fixed-width little-endian) of the serde derives
@@ -86,7 +88,8 @@ struct Bincode : Cursor {                    // bincode 1.3 default options (fix
     void unit() {}
     B32 big() { B32 r{}; const uint8_t *q = take(32); if (q) memcpy(r.b, q, 32); return r; }
     std::vector<uint8_t> string() { const size_t k = length(); const uint8_t *q = take(k); return q ? std::vector<uint8_t>(q, q + k) : std::vector<uint8_t>(); }
-    uint8_t chr() { return (uint8_t)le(4); }     // serde `char` = u32 code point in bincode... [UPSTREAM-RECALL]: written as UTF-8 by bincode 1.x
+    uint8_t chr() { return u8(); }           // mina-p2p-messages `Char(u8)`: one byte
+    void padded_end() {}                     // `PaddedSeq` = [T; N] in serde: a tuple, no terminator
 };
 
 // ---------------------------------------------------------------------------------------------- the record

@@ -33,6 +33,10 @@ EXPORTS = [
     "mina_consensus_project_window", "mina_consensus_relative_min_window_density", "mina_consensus_is_short_range",
     "mina_protocol_state_pack", "mina_protocol_state_hash_batch", "mina_protocol_state_hash_bytes",
     "mina_state_jobs_prepare", "mina_state_job_batch_dev", "mina_state_job_batch",
+    "mina_verifier_index_install", "mina_verifier_index_digest", "mina_kimchi_to_batch", "mina_wrap_proof_flatten", "mina_state_proof_split",
+    "mina_verify_state", "mina_verify_state_batch", "mina_verify_state_checks", "mina_verify_state_files", "mina_verify_account", "mina_verify_account_batch",
+    "mina_verify_account_files", "mina_verify_configure", "mina_verify_shutdown", "mina_verify_global_ctx", "mina_poseidon_params_name",
+    "mina_poseidon_install_default_params",
     "mina_consensus_select_secure_chain", "mina_parse_state_pub_inputs", "mina_parse_account_pub_inputs", "mina_parse_merkle_path", "mina_verify_account_inclusion",
 ]
 
@@ -182,6 +186,7 @@ class StateJobs(ctypes.Structure):
         ("sponge_state", ctypes.c_void_p), ("sponge_pos", ctypes.c_void_p), ("cip", ctypes.c_void_p), ("lr", ctypes.c_void_p), ("delta", ctypes.c_void_p),
         ("sg", ctypes.c_void_p), ("z1", ctypes.c_void_p), ("z2", ctypes.c_void_p), ("evalpoints", ctypes.c_void_p), ("evalscale", ctypes.c_void_p),
         ("polyscale", ctypes.c_void_p), ("comms", ctypes.c_void_p), ("rand_base", ctypes.c_void_p), ("sg_rand_base", ctypes.c_void_p),
+        ("kimchi", ctypes.c_void_p),
         ("with_accumulator", ctypes.c_int), ("acc_k", ctypes.c_uint32), ("acc_prechallenges", ctypes.c_void_p), ("acc_sg", ctypes.c_void_p),
         ("acc_rho", ctypes.c_void_p),
     ]
@@ -189,6 +194,142 @@ class StateJobs(ctypes.Structure):
     POINTER_FIELDS = ("state_records", "state_nfields", "expected_hashes", "precheck", "public_inputs", "sponge_state", "sponge_pos", "cip", "lr",
                       "delta", "sg", "z1", "z2", "evalpoints", "evalscale", "polyscale", "comms", "rand_base", "sg_rand_base", "acc_prechallenges",
                       "acc_sg", "acc_rho")
+
+
+class VerifierIndex(ctypes.Structure):
+    _fields_ = [("log2_domain", ctypes.c_uint32), ("zk_rows", ctypes.c_uint32), ("perm_alpha_offset", ctypes.c_uint32), ("shifts", ctypes.c_void_p),
+                ("sigma_comm", ctypes.c_void_p), ("coefficients_comm", ctypes.c_void_p), ("selector_comm", ctypes.c_void_p), ("constant_term", ctypes.c_void_p),
+                ("constant_term_len", ctypes.c_size_t)]
+
+
+class KimchiProofs(ctypes.Structure):
+    _fields_ = [("batch", ctypes.c_size_t), ("n_prev", ctypes.c_uint32), ("npub", ctypes.c_uint32), ("public_inputs", ctypes.c_void_p), ("prev_chals", ctypes.c_void_p),
+                ("prev_comms", ctypes.c_void_p), ("w_comm", ctypes.c_void_p), ("z_comm", ctypes.c_void_p), ("t_comm", ctypes.c_void_p), ("evals", ctypes.c_void_p),
+                ("ft_eval1", ctypes.c_void_p)]
+    POINTER_FIELDS = ("public_inputs", "prev_chals", "prev_comms", "w_comm", "z_comm", "t_comm", "evals", "ft_eval1")
+
+
+class KimchiBatchOut(ctypes.Structure):
+    _fields_ = [("sponge_state", ctypes.c_void_p), ("sponge_pos", ctypes.c_void_p), ("cip", ctypes.c_void_p), ("evalpoints", ctypes.c_void_p), ("polyscale", ctypes.c_void_p),
+                ("evalscale", ctypes.c_void_p), ("comms", ctypes.c_void_p), ("ft_eval0", ctypes.c_void_p), ("malformed", ctypes.c_void_p)]
+
+
+CHECK_FORMAT, CHECK_LEDGER, CHECK_CHAIN, CHECK_CONSENSUS, CHECK_ACCUMULATOR, CHECK_KIMCHI = 1, 2, 4, 8, 16, 32
+VERIFY_ALLOW_MISSING_KIMCHI = 1
+
+
+def _bytes_arg(b):
+    a = _u8(b) if len(b) else np.zeros(1, np.uint8)
+    return a, ctypes.c_size_t(len(b))
+
+
+def verify_state(proof: bytes, pub: bytes) -> bool:
+    """the reference-shaped entry point (Aligned's verify_mina_state_ffi): bincode MinaStateProof + MinaStatePubInputs -> bool"""
+    lib = load_library()
+    lib.mina_verify_state.restype = ctypes.c_bool
+    p, pl = _bytes_arg(proof); q, ql = _bytes_arg(pub)
+    return bool(lib.mina_verify_state(_p(p), pl, _p(q), ql))
+
+
+def verify_state_checks(proof: bytes, pub: bytes):
+    lib = load_library()
+    p, pl = _bytes_arg(proof); q, ql = _bytes_arg(pub)
+    passed, ran = ctypes.c_uint32(0), ctypes.c_uint32(0)
+    rc = lib.mina_verify_state_checks(_p(p), pl, _p(q), ql, ctypes.byref(passed), ctypes.byref(ran))
+    if rc != 0:
+        raise MinaError(f"mina_verify_state_checks failed ({rc}): {lib.mina_last_error().decode()}")
+    return passed.value, ran.value
+
+
+def _ptr_arrays(items):
+    arrs = [_u8(x) if len(x) else np.zeros(1, np.uint8) for x in items]
+    n = len(items)
+    return arrs, (ctypes.c_void_p * n)(*[a.ctypes.data for a in arrs]), (ctypes.c_size_t * n)(*[len(x) for x in items])
+
+
+def verify_state_batch(proofs: list, pubs: list) -> np.ndarray:
+    lib = load_library()
+    n = len(proofs)
+    pa, PP, PL = _ptr_arrays(proofs); qa, QQ, QL = _ptr_arrays(pubs)
+    out = np.zeros(max(n, 1), np.uint8)
+    rc = lib.mina_verify_state_batch(ctypes.c_size_t(n), PP, PL, QQ, QL, _p(out))
+    if rc != 0:
+        raise MinaError(f"mina_verify_state_batch failed ({rc}): {lib.mina_last_error().decode()}")
+    return out[:n]
+
+
+def verify_state_files(proof_path: str, pub_path: str) -> bool:
+    lib = load_library()
+    lib.mina_verify_state_files.restype = ctypes.c_bool
+    return bool(lib.mina_verify_state_files(proof_path.encode(), pub_path.encode()))
+
+
+def verify_account(proof: bytes, pub: bytes) -> bool:
+    lib = load_library()
+    lib.mina_verify_account.restype = ctypes.c_bool
+    p, pl = _bytes_arg(proof); q, ql = _bytes_arg(pub)
+    return bool(lib.mina_verify_account(_p(p), pl, _p(q), ql))
+
+
+def verify_account_batch(proofs: list, pubs: list) -> np.ndarray:
+    lib = load_library()
+    n = len(proofs)
+    pa, PP, PL = _ptr_arrays(proofs); qa, QQ, QL = _ptr_arrays(pubs)
+    out = np.zeros(max(n, 1), np.uint8)
+    rc = lib.mina_verify_account_batch(ctypes.c_size_t(n), PP, PL, QQ, QL, _p(out))
+    if rc != 0:
+        raise MinaError(f"mina_verify_account_batch failed ({rc}): {lib.mina_last_error().decode()}")
+    return out[:n]
+
+
+def verify_configure(flags: int):
+    load_library().mina_verify_configure(ctypes.c_uint32(flags))
+
+
+def verify_shutdown():
+    load_library().mina_verify_shutdown()
+
+
+def verify_global_ctx():
+    """the process-wide context of mina_verify_* as a non-owning MinaContext (e.g. to install a verifier index)"""
+    lib = load_library()
+    lib.mina_verify_global_ctx.restype = ctypes.c_void_p
+    h = lib.mina_verify_global_ctx()
+    if not h:
+        raise MinaError("no process-wide context: " + lib.mina_last_error().decode())
+    c = MinaContext.__new__(MinaContext)
+    c._lib, c._h, c.device, c._borrowed = lib, ctypes.c_void_p(h), 0, True
+    return c
+
+
+def poseidon_params_name() -> str:
+    lib = load_library()
+    lib.mina_poseidon_params_name.restype = ctypes.c_char_p
+    return lib.mina_poseidon_params_name().decode()
+
+
+def wrap_proof_flatten(data: bytes, encoding: int, exact: bool = True):
+    lib = load_library()
+    b, bl = _bytes_arg(data)
+    n = ctypes.c_size_t(0); used = ctypes.c_size_t(0)
+    rc = lib.mina_wrap_proof_flatten(_p(b), bl, int(encoding), None, ctypes.c_size_t(0), ctypes.byref(n), None if exact else ctypes.byref(used))
+    if rc != 0:
+        raise MinaError(f"mina_wrap_proof_flatten failed ({rc}): {lib.mina_last_error().decode()}")
+    out = np.zeros(n.value, np.uint8)
+    rc = lib.mina_wrap_proof_flatten(_p(b), bl, int(encoding), _p(out), ctypes.c_size_t(out.size), ctypes.byref(n), None if exact else ctypes.byref(used))
+    if rc != 0:
+        raise MinaError(f"mina_wrap_proof_flatten failed ({rc}): {lib.mina_last_error().decode()}")
+    return out.tobytes(), (len(data) if exact else used.value)
+
+
+def state_proof_split(data: bytes):
+    lib = load_library()
+    b, bl = _bytes_arg(data)
+    pl = ctypes.c_size_t(0); offs = (ctypes.c_size_t * 17)(); lens = (ctypes.c_size_t * 17)()
+    rc = lib.mina_state_proof_split(_p(b), bl, ctypes.byref(pl), offs, lens)
+    if rc != 0:
+        raise MinaError(f"mina_state_proof_split failed ({rc}): {lib.mina_last_error().decode()}")
+    return pl.value, list(offs), list(lens)
 
 
 def protocol_state_pack(data: bytes, encoding: int = ENC_BINPROT, exact: bool = True):
@@ -267,7 +408,8 @@ class MinaContext:
 
     def close(self):
         if getattr(self, "_h", None):
-            self._lib.mina_ctx_destroy(self._h)
+            if not getattr(self, "_borrowed", False):
+                self._lib.mina_ctx_destroy(self._h)
             self._h = None
 
     def __del__(self):
@@ -632,6 +774,9 @@ class MinaContext:
         """host-side `mina_state_jobs`: arrays maps pointer-field name -> numpy array (kept alive by the returned list)"""
         j = StateJobs(); keep = []
         j.batch = batch
+        kimchi = scalars.pop("kimchi", None)
+        if kimchi is not None:                      # (KimchiProofs, keep-alive list) from make_kimchi_proofs
+            j.kimchi = ctypes.addressof(kimchi[0]); keep.append(kimchi)
         for name, val in scalars.items():
             setattr(j, name, val)
         for name in StateJobs.POINTER_FIELDS:
@@ -641,6 +786,42 @@ class MinaContext:
             a = np.ascontiguousarray(a); keep.append(a)
             setattr(j, name, a.ctypes.data)
         return j, keep
+
+    @staticmethod
+    def make_kimchi_proofs(batch: int, n_prev: int, npub: int, arrays: dict):
+        kp = KimchiProofs(); keep = []
+        kp.batch, kp.n_prev, kp.npub = batch, n_prev, npub
+        for name in KimchiProofs.POINTER_FIELDS:
+            a = arrays.get(name)
+            if a is None:
+                continue
+            a = np.ascontiguousarray(a); keep.append(a)
+            setattr(kp, name, a.ctypes.data)
+        return kp, keep
+
+    def verifier_index_install(self, log2_domain: int, zk_rows: int, perm_alpha_offset: int, shifts, sigma_comm, coefficients_comm, selector_comm, constant_term: bytes):
+        vi = VerifierIndex(); arrs = [_u8(shifts), _u8(sigma_comm), _u8(coefficients_comm), _u8(selector_comm), _u8(constant_term) if len(constant_term) else np.zeros(1, np.uint8)]
+        vi.log2_domain, vi.zk_rows, vi.perm_alpha_offset = log2_domain, zk_rows, perm_alpha_offset
+        vi.shifts, vi.sigma_comm, vi.coefficients_comm, vi.selector_comm, vi.constant_term = (a.ctypes.data for a in arrs)
+        vi.constant_term_len = len(constant_term)
+        self._ck(self._lib.mina_verifier_index_install(self._h, ctypes.byref(vi)), "mina_verifier_index_install")
+
+    def verifier_index_digest(self) -> np.ndarray:
+        out = np.empty(32, np.uint8)
+        self._ck(self._lib.mina_verifier_index_digest(self._h, _p(out)), "mina_verifier_index_digest")
+        return out
+
+    def kimchi_to_batch(self, kimchi, k: int) -> dict:
+        kp, keep = kimchi
+        B, nc = kp.batch, kp.n_prev + 45
+        o = {"sponge_state": np.zeros((B, 96), np.uint8), "sponge_pos": np.zeros((B, 2), np.uint32), "cip": np.zeros((B, 32), np.uint8),
+             "evalpoints": np.zeros((B, 64), np.uint8), "polyscale": np.zeros((B, 32), np.uint8), "evalscale": np.zeros((B, 32), np.uint8),
+             "comms": np.zeros((B, nc, 64), np.uint8), "ft_eval0": np.zeros((B, 32), np.uint8), "malformed": np.zeros(1, np.uint8)}
+        out = KimchiBatchOut()
+        for name in o:
+            setattr(out, name, o[name].ctypes.data)
+        self._ck(self._lib.mina_kimchi_to_batch(self._h, ctypes.byref(kp), ctypes.byref(out)), "mina_kimchi_to_batch")
+        return o
 
     def state_job_batch(self, jobs) -> np.ndarray:
         j, keep = jobs
@@ -653,15 +834,31 @@ class MinaContext:
         j, keep = jobs
         d = StateJobs(); ptrs = []
         ctypes.memmove(ctypes.byref(d), ctypes.byref(j), ctypes.sizeof(StateJobs))
-        by_addr = {a.ctypes.data: a for a in keep}
-        for name in StateJobs.POINTER_FIELDS:
-            addr = getattr(j, name)
-            if not addr:
-                continue
+        flat = []
+        for x in keep:
+            flat.extend(x[1] if isinstance(x, tuple) else [x])
+        by_addr = {a.ctypes.data: a for a in flat}
+
+        def up(addr):
             a = by_addr[addr]
             p = self.dev_malloc(max(a.nbytes, 4)); ptrs.append(p)
             self.dev_upload(p, a.view(np.uint8).reshape(-1))
-            setattr(d, name, p)
+            return p
+
+        for name in StateJobs.POINTER_FIELDS:
+            addr = getattr(j, name)
+            if addr:
+                setattr(d, name, up(addr))
+        if j.kimchi:
+            src = ctypes.cast(j.kimchi, ctypes.POINTER(KimchiProofs)).contents
+            dk = KimchiProofs()
+            ctypes.memmove(ctypes.byref(dk), ctypes.byref(src), ctypes.sizeof(KimchiProofs))
+            for name in KimchiProofs.POINTER_FIELDS:
+                addr = getattr(src, name)
+                if addr:
+                    setattr(dk, name, d.public_inputs if name == "public_inputs" and j.public_inputs == addr else up(addr))
+            d.kimchi = ctypes.addressof(dk)
+            self._keep_dk = dk
         return d, ptrs
 
     def state_job_batch_dev(self, d_jobs, d_verdicts: int, d_flags: int = 0):

@@ -1,0 +1,58 @@
+"""shared by the kimchi tests: oracle index / proof -> the C-ABI's `mina_verifier_index` / `mina_kimchi_proofs` layouts"""
+import struct
+
+import numpy as np
+
+
+def encode_tokens(tokens) -> bytes:
+    from oracle import kimchi_ref as K
+    out = bytearray()
+    for t in tokens:
+        op = t[0]
+        out.append(op)
+        if op == K.T_MDS:
+            out += bytes([t[1], t[2]])
+        elif op == K.T_LITERAL:
+            out += int(t[1]).to_bytes(32, "little")
+        elif op == K.T_CELL:
+            out += bytes([t[1], t[2]])
+        elif op == K.T_POW:
+            out += struct.pack("<Q", t[1])
+        elif op == K.T_LAGRANGE:
+            out += struct.pack("<i", t[1])
+        elif op == K.T_LOAD:
+            out += struct.pack("<H", t[1])
+    return bytes(out)
+
+
+def pts(points):
+    from oracle import oracle as O
+    return np.concatenate([O.point_to_bytes(p) for p in points])
+
+
+def install_index(ctx, index):
+    from oracle import oracle as O
+    ctx.verifier_index_install(index.log2_domain, index.zk_rows, index.perm_alpha_offset, O.ints_to_le(index.shifts).reshape(-1), pts(index.sigma_comm),
+                               pts(index.coefficients_comm), pts(index.selector_comm), encode_tokens(index.constant_term))
+
+
+def kimchi_arrays(proofs, publics):
+    """list of oracle proofs (same shape) -> dict of arrays for MinaContext.make_kimchi_proofs + the opening arrays (lr, delta, sg, z1, z2)"""
+    from oracle import oracle as O
+    cat = lambda xs: np.concatenate(xs)
+    a = {
+        "prev_chals": cat([O.ints_to_le(ch).reshape(-1) for p in proofs for ch, _ in p["prev"]]) if proofs[0]["prev"] else None,
+        "prev_comms": cat([O.point_to_bytes(cm) for p in proofs for _, cm in p["prev"]]) if proofs[0]["prev"] else None,
+        "w_comm": cat([pts(p["w_comm"]) for p in proofs]), "z_comm": cat([O.point_to_bytes(p["z_comm"]) for p in proofs]),
+        "t_comm": cat([pts(p["t_comm"]) for p in proofs]),
+        "evals": cat([O.ints_to_le([e for pair in p["evals"] for e in pair]).reshape(-1) for p in proofs]),
+        "ft_eval1": cat([O.int_to_le(p["ft_eval1"]) for p in proofs]),
+    }
+    if publics and len(publics[0]):
+        a["public_inputs"] = cat([O.ints_to_le(pi).reshape(-1) for pi in publics])
+    op = {
+        "lr": cat([cat([cat([O.point_to_bytes(L), O.point_to_bytes(R)]) for L, R in p["opening"]["lr"]]) for p in proofs]),
+        "delta": cat([O.point_to_bytes(p["opening"]["delta"]) for p in proofs]), "sg": cat([O.point_to_bytes(p["opening"]["sg"]) for p in proofs]),
+        "z1": cat([O.int_to_le(p["opening"]["z1"]) for p in proofs]), "z2": cat([O.int_to_le(p["opening"]["z2"]) for p in proofs]),
+    }
+    return a, op

@@ -1,0 +1,100 @@
+"""kimchi `oracles` + `to_batch` on the GPU vs oracle/kimchi_ref.py on a synthetic verifier index: the
+BatchEvaluationProof the GPU builds equals the oracle's field for field; proofs minted by the oracle's miniature prover are
+accepted end to end through the Proof-of-State job's kimchi leg, tampered ones rejected (with the culprit isolated)."""
+import copy
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+K_LOG2, NPUB = 6, 5
+
+
+@pytest.fixture(scope="module")
+def circuit(srs_oracle):
+    from ipa_helpers import poseidon_pp
+    from oracle import kimchi_ref as K, oracle as O
+    g, h = srs_oracle[0]
+    return K.synthetic_circuit(0, g, O.bytes_to_point(h), poseidon_pp(0), poseidon_pp(1), K_LOG2, NPUB, seed=21)
+
+
+@pytest.fixture(scope="module")
+def proofs(srs_oracle, circuit):
+    from ipa_helpers import poseidon_pp
+    from oracle import kimchi_ref as K, oracle as O, pasta_ref as R
+    g, h = srs_oracle[0]
+    out = []
+    for s in range(4):
+        rng = random.Random(100 + s)
+        pubs = [rng.randrange(R.Q) for _ in range(NPUB)]
+        out.append((pubs, K.synthetic_proof(circuit, g, O.bytes_to_point(h), poseidon_pp(0), poseidon_pp(1), pubs, seed=200 + s)))
+    return out
+
+
+def _oracle(circuit, srs_oracle, pubs, proof):
+    from ipa_helpers import poseidon_pp
+    from oracle import kimchi_ref as K, oracle as O
+    g, h = srs_oracle[0]
+    return K.oracles_and_batch(circuit.index, proof, pubs, poseidon_pp(0), poseidon_pp(1), g, O.bytes_to_point(h))
+
+
+def test_index_digest_and_batch_rows_match_oracle(ctx_srs, oracle, srs_oracle, circuit, proofs):
+    import mina_bridge_amd as m
+    from kimchi_helpers import install_index, kimchi_arrays
+    install_index(ctx_srs, circuit.index)
+    assert oracle.le_to_int(ctx_srs.verifier_index_digest()) == circuit.index.digest
+    arrays, _ = kimchi_arrays([p for _, p in proofs], [pi for pi, _ in proofs])
+    kp = m.MinaContext.make_kimchi_proofs(len(proofs), 2, NPUB, arrays)
+    got = ctx_srs.kimchi_to_batch(kp, K_LOG2)
+    assert not got["malformed"][0]
+    for b, (pubs, proof) in enumerate(proofs):
+        o, entry = _oracle(circuit, srs_oracle, pubs, proof)
+        st, mode, cnt = o["sponge_after"].raw()
+        assert [oracle.le_to_int(got["sponge_state"][b, 32 * i: 32 * i + 32]) for i in range(3)] == st
+        assert got["sponge_pos"][b].tolist() == [mode, cnt]
+        assert oracle.le_to_int(got["ft_eval0"][b]) == o["ft_eval0"]
+        assert oracle.le_to_int(got["polyscale"][b]) == o["v"] and oracle.le_to_int(got["evalscale"][b]) == o["u"]
+        assert [oracle.le_to_int(got["evalpoints"][b, :32]), oracle.le_to_int(got["evalpoints"][b, 32:])] == entry["evalpoints"]
+        assert oracle.le_to_int(got["cip"][b]) == o["combined_inner_product"]
+        assert [oracle.bytes_to_point(c) for c in got["comms"][b]] == o["comms"]          # includes public_comm and the chunked ft_comm
+    # a non-canonical evaluation / an off-curve commitment raise the malformed flag
+    bad = dict(arrays); ev = arrays["evals"].copy(); ev[:32] = 0xFF; bad["evals"] = ev
+    assert ctx_srs.kimchi_to_batch(m.MinaContext.make_kimchi_proofs(len(proofs), 2, NPUB, bad), K_LOG2)["malformed"][0]
+    bad = dict(arrays); tc = arrays["t_comm"].copy(); tc[3 * 64] ^= 1; bad["t_comm"] = tc
+    assert ctx_srs.kimchi_to_batch(m.MinaContext.make_kimchi_proofs(len(proofs), 2, NPUB, bad), K_LOG2)["malformed"][0]
+
+
+def _kimchi_job(m, proofs_list, publics):
+    from kimchi_helpers import kimchi_arrays
+    from oracle import oracle as O
+    B = len(proofs_list)
+    arrays, op = kimchi_arrays(proofs_list, publics)
+    kp = m.MinaContext.make_kimchi_proofs(B, 2, NPUB, arrays)
+    ja = dict(op); ja["rand_base"] = O.int_to_le(7); ja["sg_rand_base"] = O.int_to_le(9); ja["public_inputs"] = arrays["public_inputs"]
+    return m.MinaContext.make_state_jobs(B, ja, with_ipa=1, kimchi=kp, k=K_LOG2, log2_domain=K_LOG2, npub=NPUB, n_evalpoints=2, n_comms=47)
+
+
+def test_kimchi_leg_accepts_minted_proofs_and_isolates_tampered_ones(ctx_srs, oracle, srs_oracle, circuit, proofs):
+    import mina_bridge_amd as m
+    from kimchi_helpers import install_index
+    from oracle import ipa_ref as I, pasta_ref as R
+    install_index(ctx_srs, circuit.index)
+    plist, pubs = [p for _, p in proofs], [pi for pi, _ in proofs]
+    assert ctx_srs.state_job_batch(_kimchi_job(m, plist, pubs)).tolist() == [1, 1, 1, 1]
+    assert ctx_srs.state_job_batch(_kimchi_job(m, plist[:1], pubs[:1])).tolist() == [1]
+    # tamper: an evaluation (proof 1), a public input (proof 2), ft_eval1 (proof 3); the oracle rejects the same ones
+    bad = [copy.deepcopy(p) for p in plist]; bpubs = [list(x) for x in pubs]
+    bad[1]["evals"][9] = ((bad[1]["evals"][9][0] + 1) % R.Q, bad[1]["evals"][9][1])
+    bpubs[2][0] = (bpubs[2][0] + 1) % R.Q
+    bad[3]["ft_eval1"] = (bad[3]["ft_eval1"] + 1) % R.Q
+    assert ctx_srs.state_job_batch(_kimchi_job(m, bad, bpubs)).tolist() == [1, 0, 0, 0]
+    g, h = srs_oracle[0]
+    for b in range(4):
+        _, entry = _oracle(circuit, srs_oracle, bpubs[b], bad[b])
+        assert I.ipa_verify_batch(0, g[: 1 << K_LOG2], oracle.bytes_to_point(h), [entry], 7, 9) == (b == 0)
+    # a commitment swapped for another valid point (w_comm[4] <- w_comm[5]) and a recursion challenge changed
+    bad = [copy.deepcopy(p) for p in plist]
+    bad[0]["w_comm"][4] = bad[0]["w_comm"][5]
+    ch, cm = bad[2]["prev"][1]; bad[2]["prev"][1] = ([(ch[0] + 1) % R.Q] + ch[1:], cm)
+    assert ctx_srs.state_job_batch(_kimchi_job(m, bad, pubs)).tolist() == [0, 1, 0, 1]
