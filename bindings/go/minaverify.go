@@ -51,6 +51,22 @@ func (c *Ctx) AccumulatorCheckMulti(curve int, k uint32, pre, sg []byte) ([]bool
 	return v, nil
 }
 
+// VerifyMinaState: drop-in for the operator's cgo call of verify_mina_state_ffi (bincode MinaStateProof + MinaStatePubInputs).
+func VerifyMinaState(proof, pub []byte) bool {
+	if len(proof) == 0 || len(pub) == 0 {
+		return false
+	}
+	return bool(C.mina_verify_state((*C.uint8_t)(unsafe.Pointer(&proof[0])), C.size_t(len(proof)), (*C.uint8_t)(unsafe.Pointer(&pub[0])), C.size_t(len(pub))))
+}
+
+// VerifyAccountInclusionFFI: drop-in for verify_account_inclusion_ffi (bincode MinaAccountProof + MinaAccountPubInputs).
+func VerifyAccountInclusionFFI(proof, pub []byte) bool {
+	if len(proof) == 0 || len(pub) == 0 {
+		return false
+	}
+	return bool(C.mina_verify_account((*C.uint8_t)(unsafe.Pointer(&proof[0])), C.size_t(len(proof)), (*C.uint8_t)(unsafe.Pointer(&pub[0])), C.size_t(len(pub))))
+}
+
 // VerifyAccountInclusion: the Merkle part of verify_account_inclusion_ffi on the reference's byte contract.
 func (c *Ctx) VerifyAccountInclusion(proof, pub, leafHash []byte) (bool, error) {
 	var verdict C.uint8_t

@@ -43,6 +43,25 @@ impl Ctx {
     }
 }
 
+/// Drop-in for Aligned's `verify_mina_state_ffi`: the bytes of `bincode::serialize(&MinaStateProof)` / `(&MinaStatePubInputs)`
+/// (core/src/aligned.rs:33-36).  Process-wide context, every failure is `false`.
+pub fn verify_mina_state(proof: &[u8], pub_input: &[u8]) -> bool {
+    unsafe { mina_verify_state(proof.as_ptr(), proof.len(), pub_input.as_ptr(), pub_input.len()) }
+}
+/// Drop-in for `verify_account_inclusion_ffi` (core/src/aligned.rs:46-49).
+pub fn verify_account_inclusion(proof: &[u8], pub_input: &[u8]) -> bool {
+    unsafe { mina_verify_account(proof.as_ptr(), proof.len(), pub_input.as_ptr(), pub_input.len()) }
+}
+/// Batch form: one GPU pipeline for all proofs, one verdict each.
+pub fn verify_mina_state_batch(proofs: &[&[u8]], pub_inputs: &[&[u8]]) -> Vec<bool> {
+    let n = proofs.len();
+    let (pp, pl): (Vec<_>, Vec<_>) = proofs.iter().map(|p| (p.as_ptr(), p.len())).unzip();
+    let (qp, ql): (Vec<_>, Vec<_>) = pub_inputs.iter().map(|p| (p.as_ptr(), p.len())).unzip();
+    let mut v = vec![0u8; n];
+    let rc = unsafe { mina_verify_state_batch(n, pp.as_ptr(), pl.as_ptr(), qp.as_ptr(), ql.as_ptr(), v.as_mut_ptr()) };
+    v.into_iter().map(|b| rc == 0 && b == 1).collect()
+}
+
 impl Drop for Ctx {
     fn drop(&mut self) { unsafe { mina_ctx_destroy(self.0) } }
 }

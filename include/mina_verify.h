@@ -452,6 +452,8 @@ int mina_state_proof_split(const uint8_t *bytes, size_t len, size_t *proof_len, 
 #define MINA_CHECK_CONSENSUS 8u     /* candidate tip selected over the bridge tip                              (README.md:290-294) */
 #define MINA_CHECK_ACCUMULATOR 16u  /* step accumulator: MSM(vesta.g, b_poly_coefficients) == challenge_polynomial_commitment */
 #define MINA_CHECK_KIMCHI 32u       /* kimchi verification of the wrap proof (needs an installed verifier index) */
+#define MINA_CHECK_ACCOUNT_ABI 64u  /* Proof of Account: encoded_account == ABI encoding re-derived from `account`    (README.md:349-352) */
+#define MINA_CHECK_MERKLE 128u      /* Proof of Account: account hash folded along the path == ledger hash            (README.md:345-347) */
 #define MINA_VERIFY_ALLOW_MISSING_KIMCHI 1u   /* verdict ignores MINA_CHECK_KIMCHI when no index is installed: NOT a full verification */
 #include <stdbool.h>
 bool mina_verify_state(const uint8_t *proof, size_t proof_len, const uint8_t *pub_input, size_t pub_len);
@@ -464,7 +466,15 @@ bool mina_verify_state_files(const char *proof_path, const char *pub_path);
 bool mina_verify_account(const uint8_t *proof, size_t proof_len, const uint8_t *pub_input, size_t pub_len);
 int mina_verify_account_batch(size_t n, const uint8_t *const *proofs, const size_t *proof_lens, const uint8_t *const *pub_inputs,
                               const size_t *pub_lens, uint8_t *verdicts_out);
-bool mina_verify_account_files(const char *proof_path, const char *pub_path);
+bool mina_verify_account_files(const char *proof_path, const char *pub_path);   /* mina_account.proof / mina_account.pub */
+int mina_verify_account_checks(const uint8_t *proof, size_t proof_len, const uint8_t *pub_input, size_t pub_len, uint32_t *passed_mask, uint32_t *ran_mask);
+/* the same on a caller-owned context (n pairs, masks per pair) */
+int mina_verify_account_ctx(mina_ctx *ctx, size_t n, const uint8_t *const *proofs, const size_t *proof_lens, const uint8_t *const *pub_inputs,
+                            const size_t *pub_lens, uint32_t *passed_masks, uint32_t *ran_masks);
+/* serialized `MinaBaseAccountBinableArgStableV2` (bin_prot as core/src/mina.rs:307-313 reads it, or the bincode form inside
+ * MinaAccountProof) -> account hashes on the GPU / the ABI bytes of sol/account.rs:25-314 (host only; out may be NULL to query the length) */
+int mina_account_hash_batch(mina_ctx *ctx, int encoding, size_t n, const uint8_t *const *accounts, const size_t *lens, uint8_t *hashes_out /* n*32 */);
+int mina_account_abi_encode(const uint8_t *account, size_t len, int encoding, uint8_t *out, size_t cap, size_t *out_len);
 int mina_verify_configure(uint32_t flags);       /* MINA_VERIFY_* */
 int mina_verify_shutdown(void);                  /* destroy the process-wide context */
 mina_ctx *mina_verify_global_ctx(void);          /* e.g. to install a verifier index or other Poseidon tables; NULL without a GPU */

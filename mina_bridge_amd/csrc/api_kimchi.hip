@@ -411,8 +411,8 @@ extern "C" int mina_kimchi_to_batch(mina_ctx *c, const mina_kimchi_proofs *p, mi
 // Gathers the wrap proofs' kimchi inputs into host arrays for mina_state_job_batch.  The wrap circuit's PUBLIC INPUT is the
 // Pickles statement packed into scalars (`tock_unpadded_public_input_of_statement`): that packing needs the step circuit's
 // deferred values (combined inner product, b, zeta powers, perm), which in turn need the STEP linearization -- data this tree does
-// not hold.  Until both indices are installed the statement's challenges/digests are passed in their wire order
-// [UPSTREAM-RECALL: first cut, flagged in DESIGN.md]; with the synthetic index of the tests the path is exercised end to end.
+// not hold.  Until that exists the wrap proof is verified with an EMPTY public input (npub = 0) [flagged in DESIGN.md]: a real
+// Mina proof cannot pass this leg yet; with the synthetic index of the tests the path is exercised end to end.
 int mb_kimchi_fill_jobs(mina_ctx *c, const mw::WrapProof *const *proofs, const uint8_t *const *tip_hashes, size_t n, mina_state_jobs *jobs,
                         std::vector<std::vector<uint8_t>> &storage) {
     (void)tip_hashes;
@@ -427,12 +427,12 @@ int mb_kimchi_fill_jobs(mina_ctx *c, const mw::WrapProof *const *proofs, const u
     for (size_t b = 0; b < n; ++b) {
         const mw::WrapProof &w = *proofs[b];
         if (w.lr.size() != k || w.step_challenge_polynomial_commitments.size() != n_prev) return fail(MINA_ERR_FORMAT, "wrap proof shape does not match the installed index");
-        // recursion challenges: old_bulletproof_challenges[2][15] endo-expanded in Fq happen on the GPU side of a full implementation;
-        // here the prechallenges are widened to field elements as they are (see header comment)
+        // recursion challenges of the wrap proof: messages_for_next_wrap_proof.old_bulletproof_challenges, expanded with the Pallas endo_r
         for (uint32_t a = 0; a < n_prev; ++a) for (uint32_t j = 0; j < k; ++j) {
-            uint8_t e[32] = {0}; const mw::Chal128 &ch = w.old_bulletproof_challenges[a][j < 15 ? j : 14];
-            for (int i = 0; i < 8; ++i) { e[i] = (uint8_t)(ch.lo >> (8 * i)); e[8 + i] = (uint8_t)(ch.hi >> (8 * i)); }
-            pch.insert(pch.end(), e, e + 32);
+            const mw::Chal128 &ch = w.old_bulletproof_challenges[a][j < 15 ? j : 14];
+            const fe_t e = fe_from_mont<FIELD_FQ>(challenge_to_field<FIELD_FQ>(ch.lo, ch.hi, c->fk[FIELD_FQ]));
+            const uint8_t *eb = (const uint8_t *)e.v;
+            pch.insert(pch.end(), eb, eb + 32);
         }
         for (uint32_t a = 0; a < n_prev; ++a) put_pt(pcm, w.step_challenge_polynomial_commitments[a]);
         for (int i = 0; i < 15; ++i) put_pt(wc, w.w_comm[i]);

@@ -201,6 +201,24 @@ static int merkle_prepare_salts(mina_ctx *c, int field, uint32_t depth) {
     return MINA_OK;
 }
 
+// Merkle fold of n paths with everything in HBM, queued on the current lane (salts must have been prepared: merkle_prepare_salts)
+int mb_merkle_fold_dev(mina_ctx *c, int field, size_t n, uint32_t depth, const uint32_t *d_leaves, const uint32_t *d_sib, const uint8_t *d_dirs, uint32_t *d_roots) {
+    if (n <= COOP8_MAX_GROUPS) {                                 // latency-bound batch: 8 lanes per path
+        DISPATCH_FIELD(field, {
+            merkle_fold_coop_kernel<F_, 8><<<cdiv(n * 8, 256), 256, 0, c->L->stream>>>((uint32_t)n, depth, c->fk[F_], c->pparams[field].as<PoseidonParams>(),
+                c->merkle_salts[field].as<fe_t>(), d_leaves, d_sib, d_dirs, d_roots);
+        });
+    } else {
+        DISPATCH_FIELD(field, {
+            merkle_fold_coop_kernel<F_, 4><<<cdiv(n * 4, 256), 256, 0, c->L->stream>>>((uint32_t)n, depth, c->fk[F_], c->pparams[field].as<PoseidonParams>(),
+                c->merkle_salts[field].as<fe_t>(), d_leaves, d_sib, d_dirs, d_roots);
+        });
+    }
+    HIPC(hipGetLastError());
+    return MINA_OK;
+}
+int mb_merkle_prepare_salts(mina_ctx *c, int field, uint32_t depth) { return merkle_prepare_salts(c, field, depth); }
+
 extern "C" int mina_merkle_roots(mina_ctx *c, int field, size_t n, uint32_t depth, const uint8_t *leaves, const uint8_t *siblings,
                                  const uint8_t *dirs, uint8_t *roots_out) {
     if (!c || (n && (!leaves || !roots_out)) || (n && depth && (!siblings || !dirs))) return fail(MINA_ERR_ARG, "null argument");
@@ -217,17 +235,7 @@ extern "C" int mina_merkle_roots(mina_ctx *c, int field, size_t n, uint32_t dept
     if ((rc = h2d(c, c->L->tmp_b, siblings, n * depth * 32))) return rc;
     if ((rc = h2d(c, c->L->tmp_d, dirs, n * depth))) return rc;
     if ((rc = c->L->tmp_c.ensure(n * 32))) return rc;
-    if (n <= COOP8_MAX_GROUPS) {                                 // latency-bound batch: 8 lanes per path
-        DISPATCH_FIELD(field, {
-            merkle_fold_coop_kernel<F_, 8><<<cdiv(n * 8, 256), 256, 0, c->L->stream>>>((uint32_t)n, depth, c->fk[F_], c->pparams[field].as<PoseidonParams>(),
-                c->merkle_salts[field].as<fe_t>(), c->L->tmp_a.as<uint32_t>(), c->L->tmp_b.as<uint32_t>(), c->L->tmp_d.as<uint8_t>(), c->L->tmp_c.as<uint32_t>());
-        });
-    } else {
-        DISPATCH_FIELD(field, {
-            merkle_fold_coop_kernel<F_, 4><<<cdiv(n * 4, 256), 256, 0, c->L->stream>>>((uint32_t)n, depth, c->fk[F_], c->pparams[field].as<PoseidonParams>(),
-                c->merkle_salts[field].as<fe_t>(), c->L->tmp_a.as<uint32_t>(), c->L->tmp_b.as<uint32_t>(), c->L->tmp_d.as<uint8_t>(), c->L->tmp_c.as<uint32_t>());
-        });
-    }
+    if ((rc = mb_merkle_fold_dev(c, field, n, depth, c->L->tmp_a.as<uint32_t>(), c->L->tmp_b.as<uint32_t>(), c->L->tmp_d.as<uint8_t>(), c->L->tmp_c.as<uint32_t>()))) return rc;
     return d2h_sync(c, roots_out, c->L->tmp_c, n * 32);
 }
 

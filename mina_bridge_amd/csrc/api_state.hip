@@ -154,7 +154,7 @@ extern "C" int mina_protocol_state_pack(const uint8_t *bytes, size_t len, int en
 static int ensure_state_salts(mina_ctx *c) {
     if (c->have_state_salts) return MINA_OK;
     if (!c->have_pparams[FIELD_FP]) return fail(MINA_ERR_STATE, "Poseidon constants not installed for Fp");
-    const char *names[MB_N_PREFIX_SALTS] = {"MinaProtoStateBody", "MinaProtoState", "MinaAccount", "MinaZkappAccount", "MinaZkappUri", "MinaDeriveTokenId"};
+    const char *names[MB_N_PREFIX_SALTS] = {"MinaProtoStateBody", "MinaProtoState", "MinaAccount", "MinaZkappAccount", "MinaZkappUri", "MinaSideLoadedVk"};
     uint8_t pre[MB_N_PREFIX_SALTS * 32];
     for (int i = 0; i < MB_N_PREFIX_SALTS; ++i) { const mw::B32 f = mw::prefix_field(names[i]); memcpy(pre + 32 * i, f.b, 32); }
     int rc;
@@ -169,6 +169,8 @@ static int ensure_state_salts(mina_ctx *c) {
     c->have_state_salts = true;
     return MINA_OK;
 }
+
+int mb_ensure_state_salts(mina_ctx *c) { return ensure_state_salts(c); }
 
 static int pstate_hash_dev(mina_ctx *c, size_t n, const uint32_t *d_records, const uint32_t *d_nfields, uint32_t *d_hashes, uint32_t *d_bodies) {
     const PoseidonParams *pp = c->pparams[FIELD_FP].as<PoseidonParams>();

@@ -75,7 +75,7 @@ void parse_state(const uint8_t *proof, size_t proof_len, const uint8_t *pub, siz
     if (!mw::read_state_proof(proof, proof_len, ps.box)) return;
     for (int i = 0; i < MINA_STATES_PER_PROOF; ++i)
         if (mb_pack_protocol_state(ps.box.states[i], ps.records[i], &ps.nfields[i], &ps.info[i]) != MINA_OK) return;
-    if (ps.box.tip_proof.lr.size() != 15 || ps.box.tip_proof.step_challenge_polynomial_commitments.size() != ps.box.tip_proof.step_old_bulletproof_challenges.size()) return;
+    if (ps.box.tip_proof.lr.empty() || ps.box.tip_proof.lr.size() > 20 || ps.box.tip_proof.step_challenge_polynomial_commitments.size() != ps.box.tip_proof.step_old_bulletproof_challenges.size()) return;
     ps.format_ok = true;
     bool ledger = true;
     for (int i = 0; i < 16; ++i) ledger = ledger && memcmp(ps.pub.candidate_chain_ledger_hashes[i], ps.info[i].snarked_ledger_hash, 32) == 0;
@@ -266,4 +266,40 @@ extern "C" int mina_state_proof_split(const uint8_t *bytes, size_t len, size_t *
     }
     if (c.pos != len) return fail(MINA_ERR_FORMAT, "trailing bytes after MinaStateProof");
     return MINA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ Proof of Account
+extern "C" int mina_verify_account_checks(const uint8_t *proof, size_t proof_len, const uint8_t *pub, size_t pub_len, uint32_t *passed_mask, uint32_t *ran_mask) {
+    if (!passed_mask || !ran_mask) return fail(MINA_ERR_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(g_mu);
+    mina_ctx *c = global_ctx();
+    if (!c) return MINA_ERR_HIP;
+    return mina_verify_account_ctx(c, 1, &proof, &proof_len, &pub, &pub_len, passed_mask, ran_mask);
+}
+extern "C" int mina_verify_account_batch(size_t n, const uint8_t *const *proofs, const size_t *proof_lens, const uint8_t *const *pubs, const size_t *pub_lens,
+                                         uint8_t *verdicts_out) {
+    if (n && (!proofs || !proof_lens || !pubs || !pub_lens || !verdicts_out)) return fail(MINA_ERR_ARG, "null argument");
+    for (size_t i = 0; i < n; ++i) verdicts_out[i] = 0;
+    if (n == 0) return MINA_OK;
+    std::vector<uint32_t> passed(n), ran(n);
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        mina_ctx *c = global_ctx();
+        if (!c) return MINA_ERR_HIP;
+        int rc = mina_verify_account_ctx(c, n, proofs, proof_lens, pubs, pub_lens, passed.data(), ran.data());
+        if (rc) return rc;
+    }
+    const uint32_t need = MINA_CHECK_FORMAT | MINA_CHECK_ACCOUNT_ABI | MINA_CHECK_MERKLE;
+    for (size_t i = 0; i < n; ++i) verdicts_out[i] = (passed[i] & need) == need ? 1 : 0;
+    return MINA_OK;
+}
+extern "C" bool mina_verify_account(const uint8_t *proof, size_t proof_len, const uint8_t *pub, size_t pub_len) {
+    uint8_t v = 0;
+    if (mina_verify_account_batch(1, &proof, &proof_len, &pub, &pub_len, &v) != MINA_OK) return false;
+    return v == 1;
+}
+extern "C" bool mina_verify_account_files(const char *proof_path, const char *pub_path) {
+    std::vector<uint8_t> p, q;
+    if (!proof_path || !pub_path || !read_file(proof_path, p, 1u << 20) || !read_file(pub_path, q, 1u << 20)) return false;
+    return mina_verify_account(p.data(), p.size(), q.data(), q.size());
 }

@@ -103,7 +103,7 @@ struct Lane {
     }
 };
 static constexpr int MB_MAX_LANES = 16;
-enum : int { MB_SALT_PSTATE_BODY = 0, MB_SALT_PSTATE, MB_SALT_ACCOUNT, MB_SALT_ZKAPP_ACCOUNT, MB_SALT_ZKAPP_URI, MB_SALT_DERIVE_TOKEN_ID, MB_N_PREFIX_SALTS };
+enum : int { MB_SALT_PSTATE_BODY = 0, MB_SALT_PSTATE, MB_SALT_ACCOUNT, MB_SALT_ZKAPP_ACCOUNT, MB_SALT_ZKAPP_URI, MB_SALT_SIDE_LOADED_VK, MB_N_PREFIX_SALTS };
 
 struct mina_ctx {
     int device = 0;

@@ -35,7 +35,7 @@ EXPORTS = [
     "mina_state_jobs_prepare", "mina_state_job_batch_dev", "mina_state_job_batch",
     "mina_verifier_index_install", "mina_verifier_index_digest", "mina_kimchi_to_batch", "mina_wrap_proof_flatten", "mina_state_proof_split",
     "mina_verify_state", "mina_verify_state_batch", "mina_verify_state_checks", "mina_verify_state_files", "mina_verify_account", "mina_verify_account_batch",
-    "mina_verify_account_files", "mina_verify_configure", "mina_verify_shutdown", "mina_verify_global_ctx", "mina_poseidon_params_name",
+    "mina_verify_account_files", "mina_verify_account_checks", "mina_verify_account_ctx", "mina_account_hash_batch", "mina_account_abi_encode", "mina_verify_configure", "mina_verify_shutdown", "mina_verify_global_ctx", "mina_poseidon_params_name",
     "mina_poseidon_install_default_params",
     "mina_consensus_select_secure_chain", "mina_parse_state_pub_inputs", "mina_parse_account_pub_inputs", "mina_parse_merkle_path", "mina_verify_account_inclusion",
 ]
@@ -214,7 +214,7 @@ class KimchiBatchOut(ctypes.Structure):
                 ("evalscale", ctypes.c_void_p), ("comms", ctypes.c_void_p), ("ft_eval0", ctypes.c_void_p), ("malformed", ctypes.c_void_p)]
 
 
-CHECK_FORMAT, CHECK_LEDGER, CHECK_CHAIN, CHECK_CONSENSUS, CHECK_ACCUMULATOR, CHECK_KIMCHI = 1, 2, 4, 8, 16, 32
+CHECK_FORMAT, CHECK_LEDGER, CHECK_CHAIN, CHECK_CONSENSUS, CHECK_ACCUMULATOR, CHECK_KIMCHI, CHECK_ACCOUNT_ABI, CHECK_MERKLE = 1, 2, 4, 8, 16, 32, 64, 128
 VERIFY_ALLOW_MISSING_KIMCHI = 1
 
 
@@ -280,6 +280,36 @@ def verify_account_batch(proofs: list, pubs: list) -> np.ndarray:
     if rc != 0:
         raise MinaError(f"mina_verify_account_batch failed ({rc}): {lib.mina_last_error().decode()}")
     return out[:n]
+
+
+def verify_account_checks(proof: bytes, pub: bytes):
+    lib = load_library()
+    p, pl = _bytes_arg(proof); q, ql = _bytes_arg(pub)
+    passed, ran = ctypes.c_uint32(0), ctypes.c_uint32(0)
+    rc = lib.mina_verify_account_checks(_p(p), pl, _p(q), ql, ctypes.byref(passed), ctypes.byref(ran))
+    if rc != 0:
+        raise MinaError(f"mina_verify_account_checks failed ({rc}): {lib.mina_last_error().decode()}")
+    return passed.value, ran.value
+
+
+def verify_account_files(proof_path: str, pub_path: str) -> bool:
+    lib = load_library()
+    lib.mina_verify_account_files.restype = ctypes.c_bool
+    return bool(lib.mina_verify_account_files(proof_path.encode(), pub_path.encode()))
+
+
+def account_abi_encode(account: bytes, encoding: int) -> bytes:
+    lib = load_library()
+    b, bl = _bytes_arg(account)
+    n = ctypes.c_size_t(0)
+    rc = lib.mina_account_abi_encode(_p(b), bl, int(encoding), None, ctypes.c_size_t(0), ctypes.byref(n))
+    if rc != 0:
+        raise MinaError(f"mina_account_abi_encode failed ({rc}): {lib.mina_last_error().decode()}")
+    out = np.zeros(n.value, np.uint8)
+    rc = lib.mina_account_abi_encode(_p(b), bl, int(encoding), _p(out), ctypes.c_size_t(out.size), ctypes.byref(n))
+    if rc != 0:
+        raise MinaError(f"mina_account_abi_encode failed ({rc}): {lib.mina_last_error().decode()}")
+    return out.tobytes()
 
 
 def verify_configure(flags: int):
@@ -765,6 +795,21 @@ class MinaContext:
         out = np.empty((n, 32), np.uint8)
         self._ck(self._lib.mina_protocol_state_hash_bytes(self._h, int(encoding), ctypes.c_size_t(n), PP, PL, _p(out)), "mina_protocol_state_hash_bytes")
         return out
+
+    def account_hash_batch(self, accounts: list, encoding: int = ENC_BINPROT) -> np.ndarray:
+        n = len(accounts)
+        arrs, PP, PL = _ptr_arrays(accounts)
+        out = np.empty((n, 32), np.uint8)
+        self._ck(self._lib.mina_account_hash_batch(self._h, int(encoding), ctypes.c_size_t(n), PP, PL, _p(out)), "mina_account_hash_batch")
+        return out
+
+    def verify_account_checks(self, proofs: list, pubs: list):
+        n = len(proofs)
+        pa, PP, PL = _ptr_arrays(proofs); qa, QQ, QL = _ptr_arrays(pubs)
+        passed = np.zeros(n, np.uint32); ran = np.zeros(n, np.uint32)
+        self._ck(self._lib.mina_verify_account_ctx(self._h, ctypes.c_size_t(n), PP, PL, QQ, QL, passed.ctypes.data_as(ctypes.c_void_p), ran.ctypes.data_as(ctypes.c_void_p)),
+                 "mina_verify_account_ctx")
+        return passed, ran
 
     def state_jobs_prepare(self, log2_domain: int, npub: int):
         self._ck(self._lib.mina_state_jobs_prepare(self._h, ctypes.c_uint32(log2_domain), ctypes.c_uint32(npub)), "mina_state_jobs_prepare")

@@ -306,7 +306,7 @@ def synthetic_circuit(curve, g_bytes, h, pp_base, pp_scalar, log2_domain: int, n
     return SyntheticCircuit(index, npub, coef, sel, sigma, cycles, coef_p, sel_p, sig_p)
 
 
-def synthetic_proof(circ: SyntheticCircuit, g_bytes, h, pp_base, pp_scalar, public_inputs, seed: int, n_prev: int = 2) -> dict:
+def synthetic_proof(circ: SyntheticCircuit, g_bytes, h, pp_base, pp_scalar, public_inputs, seed: int, n_prev: int = 2, prev_chals=None) -> dict:
     """An ACCEPTING kimchi-shaped proof for `circ` (miniature prover: witness, permutation accumulator, 7-chunk quotient on an 8n coset,
     evaluations, ft polynomial, recursion challenges with their b_poly commitments, the aggregated opening)."""
     rng = random.Random(seed)
@@ -338,8 +338,8 @@ def synthetic_proof(circ: SyntheticCircuit, g_bytes, h, pp_base, pp_scalar, publ
     wb = [blind() for _ in range(COLUMNS)]
     w_comm = [commit(p, b) for p, b in zip(wit_p, wb)]
     prev = []
-    for _ in range(n_prev):
-        chals = [rng.randrange(r) for _ in range(k)]
+    for pi in range(n_prev):
+        chals = list(prev_chals[pi]) if prev_chals is not None else [rng.randrange(r) for _ in range(k)]
         sc = [O.le_to_int(x) for x in O.b_poly_coefficients(O.scalar_field_of(curve), O.ints_to_le(chals))]
         prev.append((chals, sc, I.commit(curve, g_bytes[:n], hp, sc, 0)))
     # --- Fiat-Shamir up to beta, gamma

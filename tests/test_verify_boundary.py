@@ -1,0 +1,207 @@
+"""The reference-shaped boundary on the GPU: `mina_verify_state` / `mina_verify_account` fed with the
+bytes core/src/aligned.rs:31-58 produces (independent Python writers), every step reported by `*_checks`, tamper -> false,
+batch and `--save-proof` file forms, and the plain-C consumer."""
+import copy
+import os
+import random
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+K_LOG2 = 6
+
+
+def _chain(rng, pp):
+    """16 linked candidate states + a bridge tip the candidate tip beats by the short-range rule (same epoch, same staking lock
+    checkpoint, longer chain)"""
+    from oracle import mina_state_ref as S, state_job_ref as J
+    states, hashes = [], []
+    prev = rng.randrange(S.P)
+    lock = rng.randrange(S.P)
+    for i in range(17):
+        st = J.synth_state(rng, prev if i < 16 else rng.randrange(S.P), 1000 + i if i < 16 else 990)
+        if i >= 15:
+            st["body"]["consensus_state"]["epoch_count"] = 7
+            st["body"]["consensus_state"]["staking_epoch_data"]["lock_checkpoint"] = lock
+        h = S.protocol_state_hash(st, pp)
+        states.append(st); hashes.append(h); prev = h
+    return states, hashes
+
+
+@pytest.fixture(scope="module")
+def world(srs_oracle):
+    """global context with a synthetic wrap index installed + everything needed to mint state proofs for it"""
+    import mina_bridge_amd as m
+    from ipa_helpers import poseidon_pp
+    from kimchi_helpers import install_index
+    from oracle import kimchi_ref as K, oracle as O
+    g, h = srs_oracle[0]
+    circ = K.synthetic_circuit(0, g, O.bytes_to_point(h), poseidon_pp(0), poseidon_pp(1), K_LOG2, 0, seed=77)
+    gctx = m.lib.verify_global_ctx()
+    install_index(gctx, circ.index)
+    yield {"circ": circ, "gctx": gctx}
+    m.lib.verify_configure(0)
+
+
+def mint_state_proof(world, srs_oracle, seed):
+    from ipa_helpers import poseidon_pp
+    from oracle import kimchi_ref as K, oracle as O, pasta_ref as R, state_job_ref as J, mina_state_ref as S
+    from wire_writers import synth_wrap_proof
+    rng = random.Random(seed)
+    g, h = srs_oracle[0]; gv, _ = srs_oracle[1]
+    wrap = synth_wrap_proof(rng, k=K_LOG2)
+    # recursion challenges of the wrap proof: 128-bit prechallenges on the wire, endo-expanded by the verifier
+    pres = [[rng.getrandbits(128) for _ in range(15)] for _ in range(2)]
+    chals = [[R.challenge_to_field(p, R.endo_r(0), R.Q) for p in row[:K_LOG2]] for row in pres]
+    proof = K.synthetic_proof(world["circ"], g, O.bytes_to_point(h), poseidon_pp(0), poseidon_pp(1), [], seed=seed + 1, prev_chals=chals)
+    ev = proof["evals"]
+    wrap.update(old_bulletproof_challenges=pres, step_comms=[cm for _, cm in proof["prev"]], w_comm=proof["w_comm"], z_comm=proof["z_comm"], t_comm=proof["t_comm"],
+                z_eval=ev[0], selector_eval=ev[1:7], w_eval=ev[7:22], coefficients_eval=ev[22:37], s_eval=ev[37:43], ft_eval1=proof["ft_eval1"],
+                lr=proof["opening"]["lr"], z1=proof["opening"]["z1"], z2=proof["opening"]["z2"], delta=proof["opening"]["delta"], sg=proof["opening"]["sg"])
+    pre, sg = J.make_accumulator(1, gv, 16, seed + 2)
+    wrap["bulletproof_challenges"] = [int.from_bytes(pre[i].tobytes(), "little") for i in range(16)]
+    wrap["challenge_polynomial_commitment"] = O.bytes_to_point(sg)
+    states, hashes = _chain(rng, poseidon_pp(0))
+    return wrap, states, hashes
+
+
+def to_bytes(wrap, states, hashes, ledger=None):
+    from oracle import mina_state_ref as S
+    from wire_writers import state_proof_bytes, state_pub_bytes
+    ledger = ledger or [S.snarked_ledger_hash(s) for s in states[:16]]
+    return state_proof_bytes(wrap, states), state_pub_bytes(True, hashes[16], hashes[:16], ledger)
+
+
+ALL = 1 | 2 | 4 | 8 | 16 | 32
+
+
+def test_verify_state_end_to_end(world, srs_oracle, tmp_path):
+    import mina_bridge_amd as m
+    wrap, states, hashes = mint_state_proof(world, srs_oracle, 1000)
+    proof, pub = to_bytes(wrap, states, hashes)
+    assert len(pub) == 1057
+    assert m.lib.verify_state_checks(proof, pub) == (ALL, ALL)
+    assert m.lib.verify_state(proof, pub) is True
+    # the --save-proof file form (core/src/aligned.rs:60-69)
+    (tmp_path / "mina_state.proof").write_bytes(proof); (tmp_path / "mina_state.pub").write_bytes(pub)
+    assert m.lib.verify_state_files(str(tmp_path / "mina_state.proof"), str(tmp_path / "mina_state.pub")) is True
+    assert m.lib.verify_state_files(str(tmp_path / "missing"), str(tmp_path / "mina_state.pub")) is False
+    # every failure is `false`: garbage, truncation, wrong pub length
+    assert m.lib.verify_state(b"", pub) is False and m.lib.verify_state(proof[:-1], pub) is False and m.lib.verify_state(proof, pub[:-1]) is False
+    assert m.lib.verify_state_checks(proof[:100], pub) == (0, 1)
+
+    def masks(w=wrap, s=states, hs=hashes, ledger=None):
+        p, q = to_bytes(w, s, hs, ledger)
+        passed, ran = m.lib.verify_state_checks(p, q)
+        assert m.lib.verify_state(p, q) is (passed == ALL)
+        return passed
+    # LEDGER: a ledger hash of the public input that is not the state's
+    from oracle import mina_state_ref as S
+    led = [S.snarked_ledger_hash(s) for s in states[:16]]; led[3] ^= 1
+    assert masks(ledger=led) == ALL & ~2
+    # CHAIN: a state hash of the public input off by one; a broken link
+    hs = list(hashes); hs[5] ^= 1
+    assert masks(hs=hs) == ALL & ~4
+    # CONSENSUS: the bridge tip is the longer chain
+    st = copy.deepcopy(states); st[16]["body"]["consensus_state"]["blockchain_length"] = 5000
+    from ipa_helpers import poseidon_pp
+    hs = list(hashes); hs[16] = S.protocol_state_hash(st[16], poseidon_pp(0))
+    assert masks(s=st, hs=hs) == ALL & ~8
+    # ACCUMULATOR: one step prechallenge changed
+    w2 = dict(wrap); bc = list(wrap["bulletproof_challenges"]); bc[7] ^= 1; w2["bulletproof_challenges"] = bc
+    assert masks(w=w2) == ALL & ~16
+    # KIMCHI: an evaluation changed / an opening scalar changed
+    w2 = dict(wrap); we = list(wrap["w_eval"]); we[2] = ((we[2][0] + 1) % (1 << 254), we[2][1]); w2["w_eval"] = we
+    assert masks(w=w2) == ALL & ~32
+    w2 = dict(wrap); w2["z1"] = (wrap["z1"] + 1) % (1 << 254)
+    assert masks(w=w2) == ALL & ~32
+
+
+def test_verify_state_batch_and_missing_index_policy(world, srs_oracle):
+    import mina_bridge_amd as m
+    items = [mint_state_proof(world, srs_oracle, 2000 + 10 * i) for i in range(3)]
+    pairs = [to_bytes(*it) for it in items]
+    bad = dict(items[1][0]); bad["ft_eval1"] = (bad["ft_eval1"] + 1) % (1 << 254)
+    pairs[1] = to_bytes(bad, items[1][1], items[1][2])
+    v = m.lib.verify_state_batch([p for p, _ in pairs] + [b"junk"], [q for _, q in pairs] + [pairs[0][1]])
+    assert v.tolist() == [1, 0, 1, 0]
+    assert m.lib.verify_state_batch([], []).tolist() == []
+
+
+def test_verify_account_end_to_end(world, srs_oracle, ctx, tmp_path):
+    """MinaAccountProof + MinaAccountPubInputs bytes (independent writers) through mina_verify_account: ABI cross-check, account hash on the
+    GPU == oracle, Merkle fold == ledger hash; config C4 shape (depth 35)"""
+    import struct
+    import mina_bridge_amd as m
+    from ipa_helpers import poseidon_pp
+    from oracle import mina_account_ref as A, pasta_ref as R
+    pp = poseidon_pp(0)
+    rng = random.Random(31)
+    accounts = [A.synth_account(rng, zk, timed, deleg, with_vk=vk) for zk, timed, deleg, vk in
+                [(False, False, False, True), (True, True, True, True), (True, False, True, False), (False, True, True, True)]]
+    # account hash parity, both encodings
+    want = [A.account_hash(a, pp) for a in accounts]
+    for enc, bp in ((m.lib.ENC_BINPROT, True), (m.lib.ENC_BINCODE, False)):
+        got = ctx.account_hash_batch([A.write_account(a, bp) for a in accounts], enc)
+        assert [int.from_bytes(x.tobytes(), "little") for x in got] == want
+    proofs, pubs = [], []
+    for a, leaf in zip(accounts, want):
+        path = [(rng.randrange(2), rng.randrange(R.P)) for _ in range(35)]
+        root = R.merkle_root(leaf, path, pp)
+        enc = A.abi_encode_account(a)
+        proofs.append(A.write_account_proof(path, a)); pubs.append(root.to_bytes(32, "little") + struct.pack("<Q", len(enc)) + enc)
+    OK = 1 | 64 | 128
+    for p, q in zip(proofs, pubs):
+        assert m.lib.verify_account_checks(p, q) == (OK, OK) and m.lib.verify_account(p, q) is True
+    assert m.lib.verify_account_batch(proofs, pubs).tolist() == [1, 1, 1, 1]
+    (tmp_path / "mina_account.proof").write_bytes(proofs[1]); (tmp_path / "mina_account.pub").write_bytes(pubs[1])
+    assert m.lib.verify_account_files(str(tmp_path / "mina_account.proof"), str(tmp_path / "mina_account.pub")) is True
+    # tampering: the ABI bytes (balance word), the account itself (hash changes -> Merkle fails, ABI fails too), a sibling, the ledger hash
+    q = bytearray(pubs[0]); q[40 + 32 + 5 * 32 + 31] ^= 1
+    assert m.lib.verify_account_checks(proofs[0], bytes(q)) == (1 | 128, OK)
+    a2 = copy.deepcopy(accounts[0]); a2["nonce"] ^= 1
+    p2 = A.write_account_proof([(0, 1)] * 35, a2)
+    assert m.lib.verify_account_checks(p2, pubs[0])[0] == 1
+    p3 = bytearray(proofs[2]); p3[8 + 12 + 3] ^= 1
+    assert m.lib.verify_account_checks(bytes(p3), pubs[2])[0] in (1 | 64, 0)          # sibling changed (or no longer canonical)
+    q = bytearray(pubs[3]); q[0] ^= 1
+    assert m.lib.verify_account_checks(proofs[3], bytes(q))[0] == 1 | 64
+    assert m.lib.verify_account(b"", pubs[0]) is False and m.lib.verify_account(proofs[0][:-3], pubs[0]) is False
+    assert m.lib.verify_account_batch(proofs + [b"x"], pubs + [pubs[0]]).tolist() == [1, 1, 1, 1, 0]
+    # C4: 256 proofs in one batch (64 distinct accounts x 4), one tampered
+    big_p, big_q = proofs * 64, pubs * 64
+    big_q[100] = pubs[(100 + 1) % 4]
+    v = m.lib.verify_account_batch(big_p, big_q)
+    assert v.sum() == 255 and v[100] == 0
+
+
+def test_c_consumer_of_the_boundary(world, srs_oracle, tmp_path):
+    """plain C (gcc, no HIP headers): reads the two files and calls mina_verify_state like the operator's cgo stub would"""
+    import mina_bridge_amd as m
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "consumer.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <stdlib.h>
+#include "mina_verify.h"
+static unsigned char *slurp(const char *p, size_t *n) { FILE *f = fopen(p, "rb"); if (!f) return 0; fseek(f, 0, SEEK_END); *n = (size_t)ftell(f); rewind(f);
+  unsigned char *b = malloc(*n + 1); if (fread(b, 1, *n, f) != *n) { fclose(f); return 0; } fclose(f); return b; }
+int main(int argc, char **argv) {
+  size_t pl = 0, ql = 0; unsigned char *p = slurp(argv[1], &pl), *q = slurp(argv[2], &ql);
+  if (argc < 3 || !p || !q) return 2;
+  unsigned passed = 0, ran = 0;
+  if (mina_verify_state_checks(p, pl, q, ql, &passed, &ran) != MINA_OK) return 3;
+  printf("%s passed=%u ran=%u\n", mina_verify_state(p, pl, q, ql) ? "true" : "false", passed, ran);
+  return 0; }
+''')
+    exe = tmp_path / "consumer"
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(root, "include"), str(src), "-o", str(exe),
+                           "-L", os.path.dirname(m.LIB_PATH), "-lminaverify", "-Wl,-rpath," + os.path.dirname(m.LIB_PATH)])
+    wrap, states, hashes = mint_state_proof(world, srs_oracle, 3000)
+    proof, pub = to_bytes(wrap, states, hashes)
+    (tmp_path / "p").write_bytes(proof); (tmp_path / "q").write_bytes(pub)
+    r = subprocess.run([str(exe), str(tmp_path / "p"), str(tmp_path / "q")], capture_output=True, text=True, timeout=300)
+    # a fresh process has no verifier index installed: every other step passes, the verdict is false (MINA_CHECK_KIMCHI = 32 did not run)
+    assert r.returncode == 0 and r.stdout.strip() == "false passed=31 ran=31", r.stdout + r.stderr
