@@ -379,6 +379,21 @@ int mina_state_job_batch_dev(mina_ctx *ctx, const mina_state_jobs *jobs, void *d
  * its own verdict byte. */
 int mina_state_job_batch(mina_ctx *ctx, const mina_state_jobs *jobs, uint8_t *verdicts /* batch */);
 
+/* ---- multi-GPU building blocks --------------------------------------------------------------------
+ * One process per GPU; RCCL moves bytes (all-to-all of scalar slices, all-gather of partial points), these entry points are the
+ * reduction operators RCCL lacks.  Device pointers; queued on the next pipeline lane, no host synchronisation.
+ * Point record: 68 bytes {x[32], y[32], u32 is_infinity} as written by mina_msm_srs_dev. */
+int mina_challenge_to_field_dev(mina_ctx *ctx, int field, size_t n, const void *d_chal128 /* n*16 */, void *d_out /* n*32 */);
+/* out[j] = sum_r in[r][j] mod p for `rows` vectors of m canonical field elements: the fold of the peers' scalar slices */
+int mina_field_sum_rows_dev(mina_ctx *ctx, int field, size_t rows, size_t m, const void *d_in /* rows*m*32 */, void *d_out /* m*32 */);
+/* sum_i scalars[i] * g[first + i] over this rank's slice of the SRS */
+int mina_msm_srs_range_dev(mina_ctx *ctx, int curve, uint32_t first, size_t n, const void *d_scalars, void *d_out /* record */);
+/* variable-base MSM over canonical affine points in HBM */
+int mina_msm_dev(mina_ctx *ctx, int curve, size_t n, const void *d_bases /* n*64 */, const void *d_scalars /* n*32 */, void *d_out /* record */);
+/* sum of n point records (the all-gathered partial results) */
+int mina_points_sum_dev(mina_ctx *ctx, int curve, size_t n, const void *d_records /* n*68 */, void *d_out /* record */);
+int mina_point_records_equal_dev(mina_ctx *ctx, const void *d_a, const void *d_b, void *d_verdict /* u32 */);
+
 /* ---- kimchi verifier for the Pickles wrap proof (a11): `oracles` + `to_batch` on the GPU ---------------------------------
  * The verifier index is DATA: the reference tree does not hold the blockchain-snark index, so the engine takes domain, shifts,
  * commitments and the linearization's constant term (a PolishToken program in the byte-code below) as a parameter. */

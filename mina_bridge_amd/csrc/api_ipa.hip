@@ -388,6 +388,8 @@ extern "C" int mina_accumulator_check_batch(mina_ctx *c, int curve, uint32_t k, 
     if (!c || !prechallenges || !sg || !verdicts || (batch > 1 && !rho)) return fail(MINA_ERR_ARG, "null argument");
     if (curve != 0 && curve != 1) return fail(MINA_ERR_ARG, "bad curve");
     if (batch == 0 || batch > (1u << 20)) return fail(MINA_ERR_ARG, "bad batch");
+    if (c->srs[curve].depth == 0) return fail(MINA_ERR_STATE, "SRS not loaded for this curve");
+    if (k < 1 || k > 20 || ((size_t)1 << k) > c->srs[curve].depth) return fail(MINA_ERR_ARG, "k must be in 1..20 with 2^k <= SRS depth");
     HIPC(hipSetDevice(c->device));
     c->use_lane0();
     int rc;
@@ -410,6 +412,8 @@ extern "C" int mina_accumulator_check_multi(mina_ctx *c, int curve, uint32_t k, 
     if (!c || !prechallenges || !sg || !verdicts) return fail(MINA_ERR_ARG, "null argument");
     if (curve != 0 && curve != 1) return fail(MINA_ERR_ARG, "bad curve");
     if (count == 0 || count > (1u << 20)) return fail(MINA_ERR_ARG, "bad count");
+    if (c->srs[curve].depth == 0) return fail(MINA_ERR_STATE, "SRS not loaded for this curve");
+    if (k < 1 || k > 20 || ((size_t)1 << k) > c->srs[curve].depth) return fail(MINA_ERR_ARG, "k must be in 1..20 with 2^k <= SRS depth");
     HIPC(hipSetDevice(c->device));
     c->use_lane0();
     int rc;

@@ -180,6 +180,7 @@ extern "C" int mina_msm(mina_ctx *c, int curve, size_t n, const uint8_t *bases, 
     if (curve != 0 && curve != 1) return fail(MINA_ERR_ARG, "bad curve");
     if (n == 0) { memset(out, 0, 64); return MINA_OK; }
     if (n > (1u << 24)) return fail(MINA_ERR_ARG, "n too large");
+    if (!scalars_below_2_255(scalars, n)) return fail(MINA_ERR_ARG, "scalar >= 2^255");
     HIPC(hipSetDevice(c->device));
     c->use_lane0();
     int rc;
@@ -215,6 +216,7 @@ extern "C" int mina_msm_srs(mina_ctx *c, int curve, size_t n, const uint8_t *sca
     if (curve != 0 && curve != 1) return fail(MINA_ERR_ARG, "bad curve");
     if (n == 0) { memset(out, 0, 64); return MINA_OK; }
     if (n > 0xffffffffu) return fail(MINA_ERR_ARG, "n too large");
+    if (!scalars_below_2_255(scalars, n)) return fail(MINA_ERR_ARG, "scalar >= 2^255");
     HIPC(hipSetDevice(c->device));
     c->use_lane0();
     int rc;
@@ -237,6 +239,7 @@ extern "C" int mina_msm_srs_multi(mina_ctx *c, int curve, size_t n, size_t nprob
     SrsState &s = c->srs[curve];
     if (s.depth == 0) return fail(MINA_ERR_STATE, "SRS not loaded for this curve");
     if (n > s.depth || nprob > 4096) return fail(MINA_ERR_ARG, "n / nprob out of range");
+    if (!scalars_below_2_255(scalars, n * nprob)) return fail(MINA_ERR_ARG, "scalar >= 2^255");
     HIPC(hipSetDevice(c->device));
     c->use_lane0();
     int rc;
@@ -257,6 +260,7 @@ extern "C" int mina_msm_srs_range(mina_ctx *c, int curve, uint32_t first, size_t
     if (curve != 0 && curve != 1) return fail(MINA_ERR_ARG, "bad curve");
     if (n == 0) { memset(out, 0, 64); return MINA_OK; }
     if (n > 0xffffffffu) return fail(MINA_ERR_ARG, "n too large");
+    if (!scalars_below_2_255(scalars, n)) return fail(MINA_ERR_ARG, "scalar >= 2^255");
     HIPC(hipSetDevice(c->device));
     c->use_lane0();
     int rc;

@@ -48,13 +48,17 @@ extern "C" int mina_srs_create(mina_ctx *c, int curve, uint32_t depth) {
 extern "C" int mina_srs_load(mina_ctx *c, int curve, const uint8_t *d, size_t len) {
     if (!c || !d) return fail(MINA_ERR_ARG, "null argument");
     if (curve != 0 && curve != 1) return fail(MINA_ERR_ARG, "bad curve");
-    // fixarray(2) [ array32(n) [ bin8(33) ... ], bin8(33) ]
-    if (len < 6 || d[0] != 0x92 || d[1] != 0xdd) return fail(MINA_ERR_FORMAT, "not an SRS MessagePack blob");
-    uint32_t n = ((uint32_t)d[2] << 24) | ((uint32_t)d[3] << 16) | ((uint32_t)d[4] << 8) | d[5];
-    if (n == 0 || n > (1u << 20) || len != 6 + (size_t)(n + 1) * 35) return fail(MINA_ERR_FORMAT, "bad SRS length");
+    // fixarray(2) [ array(n) [ bin8(33) ... ], bin8(33) ]; rmp writes the shortest array header: fixarray (< 16), array16 (< 65536), array32
+    if (len < 3 || d[0] != 0x92) return fail(MINA_ERR_FORMAT, "not an SRS MessagePack blob");
+    uint32_t n; size_t hdr;
+    if ((d[1] & 0xf0) == 0x90) { n = d[1] & 0x0f; hdr = 2; }
+    else if (d[1] == 0xdc && len >= 4) { n = ((uint32_t)d[2] << 8) | d[3]; hdr = 4; }
+    else if (d[1] == 0xdd && len >= 6) { n = ((uint32_t)d[2] << 24) | ((uint32_t)d[3] << 16) | ((uint32_t)d[4] << 8) | d[5]; hdr = 6; }
+    else return fail(MINA_ERR_FORMAT, "not an SRS MessagePack blob");
+    if (n == 0 || n > (1u << 20) || len != hdr + (size_t)(n + 1) * 35) return fail(MINA_ERR_FORMAT, "bad SRS length");
     std::vector<uint8_t> blobs((size_t)(n + 1) * 33);
     for (size_t i = 0; i <= n; ++i) {
-        const uint8_t *e = d + 6 + i * 35;
+        const uint8_t *e = d + hdr + i * 35;
         if (e[0] != 0xc4 || e[1] != 33) return fail(MINA_ERR_FORMAT, "bad point header");
         memcpy(&blobs[i * 33], e + 2, 33);
     }
@@ -126,7 +130,8 @@ extern "C" int mina_srs_serialize(mina_ctx *c, int curve, uint8_t *out, size_t c
     if (curve != 0 && curve != 1) return fail(MINA_ERR_ARG, "bad curve");
     SrsState &s = c->srs[curve];
     if (s.depth == 0) return fail(MINA_ERR_STATE, "SRS not loaded");
-    const size_t need = 6 + (size_t)(s.depth + 1) * 35;
+    const size_t hdr = s.depth < 16 ? 2 : (s.depth < 65536 ? 4 : 6);          // the minimal array header, as rmp-serde writes it
+    const size_t need = hdr + (size_t)(s.depth + 1) * 35;
     *len = need;
     if (!out || cap < need) return fail(MINA_ERR_ARG, "output buffer too small");
     HIPC(hipSetDevice(c->device));
@@ -141,10 +146,12 @@ extern "C" int mina_srs_serialize(mina_ctx *c, int curve, uint8_t *out, size_t c
     std::vector<uint8_t> blobs((size_t)(s.depth + 1) * 33);
     HIPC(hipMemcpyAsync(blobs.data(), c->L->tmp_a.p, blobs.size(), hipMemcpyDeviceToHost, c->L->stream));
     HIPC(hipStreamSynchronize(c->L->stream));
-    out[0] = 0x92; out[1] = 0xdd;
-    out[2] = (uint8_t)(s.depth >> 24); out[3] = (uint8_t)(s.depth >> 16); out[4] = (uint8_t)(s.depth >> 8); out[5] = (uint8_t)s.depth;
+    out[0] = 0x92;
+    if (hdr == 2) out[1] = (uint8_t)(0x90 | s.depth);
+    else if (hdr == 4) { out[1] = 0xdc; out[2] = (uint8_t)(s.depth >> 8); out[3] = (uint8_t)s.depth; }
+    else { out[1] = 0xdd; out[2] = (uint8_t)(s.depth >> 24); out[3] = (uint8_t)(s.depth >> 16); out[4] = (uint8_t)(s.depth >> 8); out[5] = (uint8_t)s.depth; }
     for (size_t i = 0; i <= s.depth; ++i) {
-        uint8_t *e = out + 6 + i * 35;
+        uint8_t *e = out + hdr + i * 35;
         e[0] = 0xc4; e[1] = 33; memcpy(e + 2, &blobs[i * 33], 33);
     }
     return MINA_OK;
@@ -214,6 +221,7 @@ extern "C" int mina_public_input_commitment(mina_ctx *c, int curve, uint32_t log
     SrsState &s = c->srs[curve];
     if (s.depth == 0) return fail(MINA_ERR_STATE, "SRS not loaded");
     if (log2_domain > 20 || ((uint64_t)1 << log2_domain) > s.depth || npub > ((size_t)1 << log2_domain)) return fail(MINA_ERR_ARG, "bad domain / npub");
+    if (npub && !scalars_below_2_255(public_inputs, npub)) return fail(MINA_ERR_ARG, "scalar >= 2^255");
     HIPC(hipSetDevice(c->device));
     c->use_lane0();
     int rc;
@@ -283,6 +291,7 @@ extern "C" int mina_public_input_commitment_batch(mina_ctx *c, int curve, uint32
     if (s.depth == 0) return fail(MINA_ERR_STATE, "SRS not loaded");
     if (log2_domain > 20 || ((uint64_t)1 << log2_domain) > s.depth || npub > ((size_t)1 << log2_domain)) return fail(MINA_ERR_ARG, "bad domain / npub");
     if (npub > 4096 || batch > 65536) return fail(MINA_ERR_ARG, "npub / batch out of range");
+    if (npub && batch && !scalars_below_2_255(public_inputs, npub * batch)) return fail(MINA_ERR_ARG, "scalar >= 2^255");
     if (batch == 0) return MINA_OK;
     HIPC(hipSetDevice(c->device));
     c->use_lane0();

@@ -150,6 +150,10 @@ static inline int d2h_sync(mina_ctx *c, void *dst, const DevBuf &b, size_t bytes
     return MINA_OK;
 }
 
+// The signed-digit recoding of the MSM has no window for a carry out of bit 255: scalars must be < 2^255 (every canonical field
+// element is).  The host-buffer entry points reject anything else instead of returning a point that is off by 2^256 * P.
+static inline bool scalars_below_2_255(const uint8_t *scalars, size_t n) { for (size_t i = 0; i < n; ++i) if (scalars[i * 32 + 31] & 0x80) return false; return true; }
+
 void mb_prof_begin(mina_ctx *c, int stage);
 void mb_prof_end(mina_ctx *c, int stage);
 struct ProfScope {

@@ -3,6 +3,9 @@
 The library is HIP-only (gfx950).  There is NO CPU fallback: if the shared object is missing, or no
 GPU is visible, loading / context creation raises.  Nothing here imports `oracle/`.
 
+If PyTorch-ROCm shares the process (device tensors for the `_dev` entry points, torch.distributed), import torch and touch
+`torch.cuda` BEFORE creating the first MinaContext: the wheel bundles its own HIP runtime and must initialise first.
+
 Byte conventions (same as the C-ABI): field element = 32-byte LE canonical; affine point = x||y
 (64 B), infinity = zeros; numpy uint8 arrays in and out.
 """
@@ -33,6 +36,7 @@ EXPORTS = [
     "mina_consensus_project_window", "mina_consensus_relative_min_window_density", "mina_consensus_is_short_range",
     "mina_protocol_state_pack", "mina_protocol_state_hash_batch", "mina_protocol_state_hash_bytes",
     "mina_state_jobs_prepare", "mina_state_job_batch_dev", "mina_state_job_batch",
+    "mina_challenge_to_field_dev", "mina_field_sum_rows_dev", "mina_msm_srs_range_dev", "mina_msm_dev", "mina_points_sum_dev", "mina_point_records_equal_dev",
     "mina_verifier_index_install", "mina_verifier_index_digest", "mina_kimchi_to_batch", "mina_wrap_proof_flatten", "mina_state_proof_split",
     "mina_verify_state", "mina_verify_state_batch", "mina_verify_state_checks", "mina_verify_state_files", "mina_verify_account", "mina_verify_account_batch",
     "mina_verify_account_files", "mina_verify_account_checks", "mina_verify_account_ctx", "mina_account_hash_batch", "mina_account_abi_encode", "mina_verify_configure", "mina_verify_shutdown", "mina_verify_global_ctx", "mina_poseidon_params_name",
@@ -810,6 +814,25 @@ class MinaContext:
         self._ck(self._lib.mina_verify_account_ctx(self._h, ctypes.c_size_t(n), PP, PL, QQ, QL, passed.ctypes.data_as(ctypes.c_void_p), ran.ctypes.data_as(ctypes.c_void_p)),
                  "mina_verify_account_ctx")
         return passed, ran
+
+    # -- multi-GPU building blocks (device pointers)
+    def challenge_to_field_dev(self, field: int, n: int, d_chal: int, d_out: int):
+        self._ck(self._lib.mina_challenge_to_field_dev(self._h, field, ctypes.c_size_t(n), ctypes.c_void_p(d_chal), ctypes.c_void_p(d_out)), "mina_challenge_to_field_dev")
+
+    def field_sum_rows_dev(self, field: int, rows: int, m: int, d_in: int, d_out: int):
+        self._ck(self._lib.mina_field_sum_rows_dev(self._h, field, ctypes.c_size_t(rows), ctypes.c_size_t(m), ctypes.c_void_p(d_in), ctypes.c_void_p(d_out)), "mina_field_sum_rows_dev")
+
+    def msm_srs_range_dev(self, curve: int, first: int, n: int, d_scalars: int, d_out: int):
+        self._ck(self._lib.mina_msm_srs_range_dev(self._h, curve, ctypes.c_uint32(first), ctypes.c_size_t(n), ctypes.c_void_p(d_scalars), ctypes.c_void_p(d_out)), "mina_msm_srs_range_dev")
+
+    def msm_dev(self, curve: int, n: int, d_bases: int, d_scalars: int, d_out: int):
+        self._ck(self._lib.mina_msm_dev(self._h, curve, ctypes.c_size_t(n), ctypes.c_void_p(d_bases), ctypes.c_void_p(d_scalars), ctypes.c_void_p(d_out)), "mina_msm_dev")
+
+    def points_sum_dev(self, curve: int, n: int, d_records: int, d_out: int):
+        self._ck(self._lib.mina_points_sum_dev(self._h, curve, ctypes.c_size_t(n), ctypes.c_void_p(d_records), ctypes.c_void_p(d_out)), "mina_points_sum_dev")
+
+    def point_records_equal_dev(self, d_a: int, d_b: int, d_verdict: int):
+        self._ck(self._lib.mina_point_records_equal_dev(self._h, ctypes.c_void_p(d_a), ctypes.c_void_p(d_b), ctypes.c_void_p(d_verdict)), "mina_point_records_equal_dev")
 
     def state_jobs_prepare(self, log2_domain: int, npub: int):
         self._ck(self._lib.mina_state_jobs_prepare(self._h, ctypes.c_uint32(log2_domain), ctypes.c_uint32(npub)), "mina_state_jobs_prepare")

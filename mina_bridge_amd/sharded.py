@@ -1,19 +1,24 @@
 """Multi-GPU sharding of the batched IPA accumulator check, one process per GPU.
 
-Two exact strategies over a `torch.distributed` process group (backend "nccl" = RCCL over xGMI on the GPU box,
-"gloo" in the CPU tests):
+Two exact strategies over a `torch.distributed` process group (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the
+CPU tests).  Every rank holds ONLY its shard of the proofs; tensors stay on the rank's device from the first kernel to the
+verdict -- RCCL moves bytes between HBMs, nothing is staged through numpy.
 
-  * proof-level (default, zero data-path exchange): rank g verifies proofs [g*B/G, (g+1)*B/G) with its own folded
-    MSM against its replica of the SRS tables (4 MiB of bases, 64 MiB of window tables per curve per GPU); the only
-    traffic is the final all-gather of one verdict byte per proof.
-  * base-sliced (one exchange step; pays when B/G is small and the 2^16 MSM dominates): every rank folds the whole
-    batch's challenge polynomials but runs the MSM only over its slice g[r*n/G, (r+1)*n/G) of the SRS; the G partial
-    points (64 B each) are all-gathered and summed with the group law locally -- RCCL moves bytes, the reduction
-    operator (Pasta point addition) is ours, as RCCL has no such op.  Payload per GPU: 64 B out, 64*(G-1) B in, so the
-    step is latency-bound (~10-30 us on xGMI), never bandwidth-bound.
+  * proof-level (default, zero data-path exchange): rank g verifies its proofs with its own folded MSM against its replica of the
+    SRS tables (4 MiB of bases, 64 MiB of window tables per curve per GPU); the only traffic is the final all-gather of one
+    verdict byte per proof.
+  * base-sliced (one exchange step; pays when B/G is small and the 2^16 MSM dominates), exactly SURVEY.md 8e.2:
+      1. rank g folds ITS shard's challenge polynomials into a scalar vector  S_g[j] = sum_{b in shard} rho_b s_b[j]   (K2)
+      2. all-to-all over xGMI: rank r receives slice j in [r n/G, (r+1) n/G) of every S_g                  (G-1 x n/G x 32 B in)
+      3. modular-add kernel folds the G slices; K1 runs over the rank's n/G bases only
+      4. rank g also computes its share of the right-hand side  sum_{b in shard} rho_b sg_b  (small variable-base MSM)
+      5. all-gather of the 2 partial points per rank (68-byte records), local group-law fold, compare
+    RCCL has no field / curve reduction op: it only transports; the reduction operators are kernels of this library
+    (`mina_field_sum_rows_dev`, `mina_points_sum_dev`).  Payloads are tiny (<= 2 MiB per curve per GPU), so the step is latency-
+    bound on the 7 x ~153 GB/s links.
 
-Both produce the same verdicts as a single GPU.  The compute backend is any object with the `MinaContext` methods used
-below, so the distributed logic can be exercised on CPU-only machines (tests plug the CPU oracle there).
+Both produce the verdicts of a single GPU.  The compute backend is an object with the methods of `DeviceBackend` below (device
+tensors in, device tensors out), so the distributed logic runs on CPU-only machines too (tests plug an oracle-backed double).
 """
 from __future__ import annotations
 
@@ -25,57 +30,134 @@ def shard_range(n_items: int, rank: int, world: int):
     return (n_items * rank) // world, (n_items * (rank + 1)) // world
 
 
-def _all_gather_bytes(arr: np.ndarray, group, device):
-    import torch
-    import torch.distributed as dist
-    world = dist.get_world_size(group)
-    t = torch.from_numpy(np.ascontiguousarray(arr, dtype=np.uint8).reshape(-1)).to(device)
-    outs = [torch.empty_like(t) for _ in range(world)]
-    dist.all_gather(outs, t, group=group)
-    return [o.cpu().numpy() for o in outs]
+class DeviceBackend:
+    """MinaContext + torch device tensors: every method queues kernels on the context and returns tensors that live in HBM.
+    `sync()` orders the library's streams before / after torch collectives (which run on torch's stream)."""
+
+    RECORD = 68
+
+    def __init__(self, ctx, device):
+        import torch
+        self.ctx, self.dev, self.torch = ctx, device, torch
+
+    def _buf(self, nbytes):
+        return self.torch.empty(max(nbytes, 4), dtype=self.torch.uint8, device=self.dev)
+
+    def sync(self):
+        self.ctx.synchronize()
+        if self.torch.device(self.dev).type == "cuda":
+            self.torch.cuda.synchronize(self.dev)
+
+    def accumulator_verdicts(self, curve, k, pre, sg, rho):
+        """per-proof verdict bytes of this rank's shard: one folded check, per-proof checks only if it fails"""
+        torch = self.torch
+        b = sg.numel() // 64
+        if b == 0:
+            return torch.zeros(0, dtype=torch.uint8, device=self.dev)
+        v = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        self.ctx.accumulator_check_dev(curve, k, b, pre.data_ptr(), sg.data_ptr(), rho.data_ptr() if b > 1 else 0, v.data_ptr())
+        self.sync()
+        if int(v.item()) == 1:
+            return torch.ones(b, dtype=torch.uint8, device=self.dev)
+        out = torch.zeros(b, dtype=torch.int32, device=self.dev)
+        for lo in range(0, b, 64):
+            cnt = min(64, b - lo)
+            self.ctx.accumulator_check_multi_dev(curve, k, cnt, pre.data_ptr() + lo * k * 16, sg.data_ptr() + lo * 64, out.data_ptr() + 4 * lo)
+        self.sync()
+        return out.to(torch.uint8)
+
+    def fold_scalars(self, field, k, pre, rho):
+        """S[j] = sum_b rho_b * b_poly_coefficients(to_field(pre_b))[j]  ->  [2^k * 32] bytes"""
+        b = rho.numel() // 32
+        chals = self._buf(b * k * 32); out = self._buf((1 << k) * 32)
+        if b == 0:
+            return out.zero_()
+        self.ctx.challenge_to_field_dev(field, b * k, pre.data_ptr(), chals.data_ptr())
+        self.sync()
+        self.ctx.b_poly_fold_dev(field, k, b, chals.data_ptr(), rho.data_ptr(), out.data_ptr())
+        return out
+
+    def sum_rows(self, field, rows, m, stacked):
+        out = self._buf(m * 32)
+        self.ctx.field_sum_rows_dev(field, rows, m, stacked.data_ptr(), out.data_ptr())
+        return out
+
+    def msm_srs_range(self, curve, first, n, scalars):
+        out = self._buf(self.RECORD)
+        self.ctx.msm_srs_range_dev(curve, first, n, scalars.data_ptr(), out.data_ptr())
+        return out[: self.RECORD]
+
+    def msm(self, curve, n, bases, scalars):
+        out = self._buf(self.RECORD)
+        if n == 0:
+            out.zero_(); out[64] = 1
+            return out[: self.RECORD]
+        self.ctx.msm_dev(curve, n, bases.data_ptr(), scalars.data_ptr(), out.data_ptr())
+        return out[: self.RECORD]
+
+    def points_sum(self, curve, n, records):
+        out = self._buf(self.RECORD)
+        self.ctx.points_sum_dev(curve, n, records.data_ptr(), out.data_ptr())
+        return out[: self.RECORD]
+
+    def records_equal(self, a, b) -> bool:
+        v = self.torch.zeros(1, dtype=self.torch.int32, device=self.dev)
+        self.ctx.point_records_equal_dev(a.data_ptr(), b.data_ptr(), v.data_ptr())
+        self.sync()
+        return bool(int(v.item()))
 
 
 class ShardedAccumulatorCheck:
-    def __init__(self, backend, curve: int, k: int, group=None, device="cpu"):
+    def __init__(self, backend, curve: int, k: int, group=None):
         import torch.distributed as dist
         self.b, self.curve, self.k = backend, curve, k
         self.group = group
-        self.device = device
         self.rank = dist.get_rank(group)
         self.world = dist.get_world_size(group)
         self.scalar_field = 1 if curve == 0 else 0
 
     # ---- strategy 1
-    def verify_proof_level(self, prechallenges: np.ndarray, sg: np.ndarray, rho: np.ndarray) -> np.ndarray:
-        """prechallenges [B,k,16], sg [B,64], rho [B,32] (identical on every rank) -> verdict bytes [B] on every rank"""
-        B = sg.shape[0]
-        lo, hi = shard_range(B, self.rank, self.world)
-        mine = np.zeros(0, np.uint8)
-        if hi > lo:
-            mine = self.b.accumulator_check_batch(self.curve, self.k, prechallenges[lo:hi].reshape(-1), sg[lo:hi].reshape(-1),
-                                                  rho[lo:hi].reshape(-1) if hi - lo > 1 else None)
-        # ragged shards: pad to the largest shard for the all-gather
-        cap = max(shard_range(B, r, self.world)[1] - shard_range(B, r, self.world)[0] for r in range(self.world))
-        buf = np.zeros(cap, np.uint8)
+    def verify_proof_level(self, pre, sg, rho, total: int):
+        """pre [b*k*16], sg [b*64], rho [b*32]: THIS rank's shard (uint8 tensors on its device), b = its share of `total` by
+        `shard_range`.  Returns the `total` verdict bytes (same tensor on every rank)."""
+        import torch
+        import torch.distributed as dist
+        lo, hi = shard_range(total, self.rank, self.world)
+        assert sg.numel() == (hi - lo) * 64
+        mine = self.b.accumulator_verdicts(self.curve, self.k, pre, sg, rho)
+        cap = max(shard_range(total, r, self.world)[1] - shard_range(total, r, self.world)[0] for r in range(self.world))   # ragged shards: pad
+        buf = torch.zeros(cap, dtype=torch.uint8, device=mine.device)
         buf[: hi - lo] = mine
-        parts = _all_gather_bytes(buf, self.group, self.device)
-        out = np.zeros(B, np.uint8)
-        for r, p in enumerate(parts):
-            a, z = shard_range(B, r, self.world)
-            out[a:z] = p[: z - a]
-        return out
+        outs = [torch.empty_like(buf) for _ in range(self.world)]
+        self.b.sync()
+        dist.all_gather(outs, buf, group=self.group)
+        return torch.cat([outs[r][: shard_range(total, r, self.world)[1] - shard_range(total, r, self.world)[0]] for r in range(self.world)])
 
-    # ---- strategy 2
-    def verify_base_sliced(self, prechallenges: np.ndarray, sg: np.ndarray, rho: np.ndarray) -> bool:
-        """One folded check for the whole batch, MSM sharded over the SRS bases.  Returns the batch verdict."""
-        B = sg.shape[0]
-        n = 1 << self.k
-        chals = self.b.challenge_to_field(self.scalar_field, prechallenges.reshape(-1, 16))
-        folded = self.b.b_poly_fold(self.scalar_field, self.k, chals.reshape(-1), rho.reshape(-1))     # [n,32]
-        lo, hi = shard_range(n, self.rank, self.world)
-        part = self.b.msm_srs_range(self.curve, lo, folded[lo:hi].reshape(-1)) if hi > lo else np.zeros(64, np.uint8)
-        parts = np.stack(_all_gather_bytes(part, self.group, self.device))                              # [G,64]
-        ones = np.zeros((self.world, 32), np.uint8); ones[:, 0] = 1
-        lhs = self.b.msm(self.curve, parts.reshape(-1), ones.reshape(-1))                               # EC fold of the partials
-        rhs = self.b.msm(self.curve, sg.reshape(-1), rho.reshape(-1))                                   # sum_b rho_b * sg_b
-        return bool((lhs == rhs).all())
+    # ---- strategy 2 (SURVEY.md 8e.2)
+    def verify_base_sliced(self, pre, sg, rho) -> bool:
+        """One folded check for the whole batch; every rank passes its shard.  Returns the batch verdict (same on every rank)."""
+        import torch
+        import torch.distributed as dist
+        G, n = self.world, 1 << self.k
+        assert n % G == 0, "the SRS slice per rank must be whole"
+        m = n // G
+        nb = sg.numel() // 64
+        S = self.b.fold_scalars(self.scalar_field, self.k, pre, rho)            # 1. this shard's combined scalars, [n*32]
+        recv = torch.empty_like(S)
+        self.b.sync()
+        dist.all_to_all_single(recv, S, group=self.group)                      # 2. slice r of every peer's vector lands here
+        self.b.sync()                                                          #    (the collective ran on torch's stream, the kernels below on the library's)
+        mine = self.b.sum_rows(self.scalar_field, G, m, recv)                   # 3. fold the G slices ...
+        lhs = self.b.msm_srs_range(self.curve, self.rank * m, m, mine)          #    ... and commit over this rank's n/G bases
+        rhs = self.b.msm(self.curve, nb, sg, rho)                               # 4. this shard's share of sum_b rho_b sg_b
+        self.b.sync()                                                          # the records come off the library's stream: order them before torch touches them
+        pair = torch.cat([lhs, rhs])
+        outs = [torch.empty_like(pair) for _ in range(G)]
+        dist.all_gather(outs, pair, group=self.group)                          # 5. 2 x 68 B per rank
+        self.b.sync()
+        rec = DeviceBackend.RECORD
+        lrec, rrec = torch.cat([o[:rec] for o in outs]), torch.cat([o[rec:] for o in outs])
+        self.b.sync()                                                          # torch's stream built the record lists; the library's stream reads them
+        L = self.b.points_sum(self.curve, G, lrec)
+        R = self.b.points_sum(self.curve, G, rrec)
+        return self.b.records_equal(L, R)

@@ -20,7 +20,7 @@ CURVE_PALLAS, CURVE_VESTA = 0, 1
 
 
 def build(force: bool = False) -> str:
-    srcs = [os.path.join(_HERE, f) for f in ("pasta_oracle.c", "ipa_oracle.c", "Makefile")]
+    srcs = [os.path.join(_HERE, f) for f in ("pasta_oracle.c", "Makefile")]
     if force or not os.path.exists(_LIB_PATH) or any(
         os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs
     ):

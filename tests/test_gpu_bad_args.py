@@ -49,3 +49,33 @@ def test_bad_arguments_are_errors_not_crashes(ctx_srs):
     one = np.zeros(32, np.uint8); one[0] = 1
     assert (c.msm_srs(1, one) == c.srs_get_g(1, 0, 1)[0]).all()
     assert c.accumulator_check_multi(1, 16, pre, z64).tolist() == [0]
+
+
+@pytest.mark.gpu
+def test_scalars_with_bit_255_set_are_rejected_and_small_srs_roundtrips(ctx_srs, oracle, srs_oracle):
+    """the signed-digit recoding has no window for a carry out of bit 255 -> such scalars are an argument error, not a
+    silently wrong point; mina_srs_load / serialize use the minimal MessagePack array header (fixarray / array16 / array32)"""
+    import mina_bridge_amd as m
+    g, _ = srs_oracle[1]
+    sc = np.zeros((4, 32), np.uint8); sc[2, 31] = 0x80
+    for call in (lambda: ctx_srs.msm_srs(1, sc), lambda: ctx_srs.msm(1, g[:4], sc), lambda: ctx_srs.msm_srs_multi(1, sc, 2), lambda: ctx_srs.msm_srs_range(1, 0, sc),
+                 lambda: ctx_srs.public_input_commitment(0, 5, sc)):
+        with pytest.raises(m.MinaError, match="2\\^255"):
+            call()
+    sc[2, 31] = 0x7f                                            # non-canonical but below 2^255: still computed (digits are exact)
+    ctx_srs.msm_srs(1, sc)
+    with pytest.raises(m.MinaError):                            # k is validated before anything is sized from it
+        ctx_srs.accumulator_check_batch(1, 0, np.zeros(0, np.uint8), np.zeros(64, np.uint8))
+    with pytest.raises(m.MinaError):
+        ctx_srs.accumulator_check_multi(1, 40, np.zeros(40 * 16, np.uint8), np.zeros(64, np.uint8))
+    c2 = m.MinaContext(0)
+    try:
+        for depth, hdr in ((8, 2), (32, 4)):
+            c2.srs_create(1, depth)
+            blob = c2.srs_serialize(1)
+            assert len(blob) == hdr + (depth + 1) * 35 and blob[0] == 0x92 and blob[1] == ((0x90 | depth) if depth < 16 else 0xdc)
+            pts = c2.srs_get_g(1, 0, depth)
+            c2.srs_load(1, blob)
+            assert (c2.srs_get_g(1, 0, depth) == pts).all() and (pts == g[:depth]).all()
+    finally:
+        c2.close()
