@@ -49,6 +49,9 @@ MODMUL_ISSUE_FLOOR_CYCLES = 88 * 8
 CHIP_SIMDS, CLOCK_HZ = 1024, 2.4e9
 MODMUL_PER_PERMUTATION = 55 * (3 * 4 + 9)             # x^7 = 4 products x 3, MDS 9 products: 1155
 PROF_STAGES = {"pstate_hash": 11, "ipa_transcript": 12, "msm_accumulate": 3}
+# HBM-side bytes per protocol-state hash from the rocprofv3 PMC passes of profiles/r02b_rocprof.md (FETCH_SIZE x 2 -- the gfx950
+# correction of MI355X_MICROARCH.md for 16-B-per-lane loads -- + WRITE_SIZE, KiB x 1024, over the 139 264 states of one launch)
+PSTATE_TRAFFIC_BYTES_PER_STATE = (2 * 130426 + 4352) * 1024 / 139264
 
 
 def le32(x: int) -> np.ndarray:
@@ -318,8 +321,24 @@ def main():
             step()
         ctx.synchronize()
         call_latency_ms = (time.perf_counter() - t1) / 4 * 1e3
+        # secondary key (round 1's headline, BASELINE config C2): 8 independent 2^16 Vesta accumulator checks per call, 16 lanes
+        ctx.set_pipeline(16)
+        pre8, sg8 = make_accumulators(ctx, 8, 4242 + rank)
+        d_pre8 = torch.from_numpy(pre8.reshape(-1)).to(dev); d_sg8 = torch.from_numpy(sg8.reshape(-1)).to(dev)
+        d_v8 = torch.zeros(8, dtype=torch.int32, device=dev)
+        c2 = lambda: ctx.accumulator_check_multi_dev(CURVE_VESTA, ACC_K, 8, d_pre8.data_ptr(), d_sg8.data_ptr(), d_v8.data_ptr())
+        for _ in range(32):
+            c2()
+        ctx.synchronize(); torch.cuda.synchronize(); t2 = time.perf_counter()
+        for _ in range(400):
+            c2()
+        ctx.synchronize()
+        c2_rate = 8 * 400 / (time.perf_counter() - t2)
+        assert d_v8.cpu().numpy().tolist() == [1] * 8
+        ctx.set_pipeline(1)
     else:
         call_latency_ms = None
+        c2_rate = None
 
     if dist_on:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else dev)
@@ -358,13 +377,16 @@ def main():
                        "sharding": f"proof-level, {args.gpus} rank(s); verdict words all-gathered over RCCL" if dist_on else "single rank",
                        "algorithmic_bytes_per_proof": algorithmic_bytes_per_proof()},
             "roofline": {"bound": "hbm", "kernel": "pstate_hash_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": None,
+                         "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": nstates * PSTATE_TRAFFIC_BYTES_PER_STATE,
+                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), profiles/r02b_rocprof.md",
                          "algorithmic_bytes_per_launch": hash_bytes, "states_per_launch": nstates, "avg_launch_us": kern_us,
                          "avg_launch_us_in_timed_region": ovl.get("pstate_hash"),
                          "note": "avg_launch_us: HIP events on the lane stream around the kernel, launches with nothing else on the GPU right after the "
                                  "timed region (second figure: inside it, lanes overlapping).  The path is integer-VALU bound (SURVEY.md 8d): the HBM "
                                  "fraction is reported because the metric asks for it, roofline_valu is the bound that matters; traffic: see profiles/"},
             "stage_us": {"isolated": iso, "in_timed_region": ovl},
+            "c2_accumulator_only": {"value": c2_rate, "unit": "accumulator checks/s",
+                                    "note": "BASELINE config C2 alone (round 1's headline): un-folded 2^16-base Vesta IPA accumulator checks, 8 per call, 16 lanes"},
         }
         if kern_us:
             peak = CHIP_SIMDS * 64 * CLOCK_HZ / MODMUL_ISSUE_FLOOR_CYCLES

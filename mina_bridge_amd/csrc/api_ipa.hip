@@ -446,7 +446,7 @@ int mb_ipa_batch_check_dev(mina_ctx *c, int curve, mb::IpaShape sh, const mb::Ip
         in.xi, in.comms, in.comm_override, in.rb, in.sb, s.h.as<affine_t>(), c->L->ipa_points.as<affine_t>(), c->L->ipa_scalars.as<uint32_t>(), \
         c->L->ipa_chals.as<uint32_t>(), c->L->ipa_sigma.as<uint32_t>(), d_verdict + 1, c->L->ipa_xfer.as<uint32_t>())
     { ProfScope ps_(c, PS_IPA_TRANSCRIPT);
-    if (batch <= COOP8_MAX_GROUPS) {
+    if (use_coop8(c, batch)) {
         // latency-bound batch: 8 lanes per transcript, and to_group on a second stream beside the rest of the transcript
         Lane &L = *c->L;
         if ((rc = L.ipa_xfer.ensure(batch * mb::IPA_XFER_WORDS * 4))) return rc;

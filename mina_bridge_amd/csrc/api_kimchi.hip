@@ -346,7 +346,7 @@ int mb_kimchi_to_batch_dev(mina_ctx *c, size_t batch, uint32_t n_prev, uint32_t 
     if (!c->have_kimchi) return fail(MINA_ERR_STATE, "no verifier index installed");
     const PoseidonParams *ppb = c->pparams[FIELD_FP].as<PoseidonParams>(), *pps = c->pparams[FIELD_FQ].as<PoseidonParams>();
     ProfScope ps_(c, PS_KIMCHI);
-    if (batch <= COOP8_MAX_GROUPS)
+    if (use_coop8(c, batch))
         mb::kimchi_to_batch_kernel<8><<<cdiv(batch * 8, 64), 64, 0, c->L->stream>>>((uint32_t)batch, n_prev, npub, c->fk[FIELD_FP], c->fk[FIELD_FQ], ppb, pps,
             c->kimchi_index.as<mb::KimchiIndexDev>(), c->kimchi_tokens.as<mb::KimchiToken>(), c->kimchi_literals.as<fe_t>(), in, out, d_bad);
     else
