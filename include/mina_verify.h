@@ -249,7 +249,9 @@ typedef struct {
 int mina_combined_inner_product(int field, size_t n_polys, size_t n_points, const uint8_t *evals /* n_polys*n_points*32 */,
                                 const uint8_t *polyscale, const uint8_t *evalscale, uint8_t *out /* 32 */);
 
-/* The openings of one call share k and n_evalpoints; n_comms may differ (proofs of different circuits).
+/* The openings of one call share k and n_evalpoints; n_comms may differ (proofs of different circuits), at most 4096 per opening.
+ * `lr` is a bare pointer: the caller guarantees it holds 2*k points -- k is bounded (1..20, 2^k <= SRS depth) but the length of
+ * the caller's buffer cannot be checked here (the container readers, mina_verify_state, do check the proof's own L/R count).
  * The proof data is validated the way upstream's deserialiser validates it before `SRS::verify` runs: every field element
  * canonical, every point on the curve (or the all-zero encoding of infinity); a malformed opening anywhere in the batch
  * gives verdict 0, never an error code (README.md:281-310: every failure is `false`). */

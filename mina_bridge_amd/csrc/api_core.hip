@@ -76,6 +76,7 @@ extern "C" void mina_ctx_destroy(mina_ctx *c) {
     for (int i = 0; i < MB_MAX_LANES; ++i) {
         Lane &L = c->lanes[i];
         if (L.aux) { (void)hipStreamSynchronize(L.aux); (void)hipStreamDestroy(L.aux); (void)hipEventDestroy(L.ev_fork); (void)hipEventDestroy(L.ev_join); }
+        if (L.ev_leg) (void)hipEventDestroy(L.ev_leg);
         if (L.stream) (void)hipStreamDestroy(L.stream);
     }
     delete c;

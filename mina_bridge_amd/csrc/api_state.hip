@@ -284,8 +284,31 @@ extern "C" int mina_state_jobs_prepare(mina_ctx *c, uint32_t log2_domain, uint32
 }
 
 // all pointers of `j` are device pointers; queued on the current lane
-static int state_jobs_on_lane(mina_ctx *c, const mina_state_jobs *j, uint32_t *d_verdicts, uint32_t *d_flags) {
+// `split`: the three independent legs (protocol states / wrap opening / accumulator) go to three lanes of the context -- lane 0 plus
+// two helper lanes -- and are joined by events before the verdict kernel: for small, latency-bound batches the serial chain of
+// dependent Poseidon permutations of one leg hides behind the other legs (host-buffer entry point only).
+static int leg_fork(mina_ctx *c, Lane &from, Lane &to) {
+    if (!to.stream) HIPC(hipStreamCreateWithFlags(&to.stream, hipStreamNonBlocking));
+    if (!from.ev_leg) HIPC(hipEventCreateWithFlags(&from.ev_leg, hipEventDisableTiming));
+    HIPC(hipEventRecord(from.ev_leg, from.stream));
+    HIPC(hipStreamWaitEvent(to.stream, from.ev_leg, 0));
+    return MINA_OK;
+}
+static int leg_join(Lane &leg, Lane &into) {
+    if (!leg.ev_leg) HIPC(hipEventCreateWithFlags(&leg.ev_leg, hipEventDisableTiming));
+    HIPC(hipEventRecord(leg.ev_leg, leg.stream));
+    HIPC(hipStreamWaitEvent(into.stream, leg.ev_leg, 0));
+    return MINA_OK;
+}
+static int state_jobs_on_lane(mina_ctx *c, const mina_state_jobs *j, uint32_t *d_verdicts, uint32_t *d_flags, bool split = false) {
     Lane &L = *c->L;
+    Lane *const L0 = c->L;
+    Lane *LI = L0, *LA = L0;
+    if (split && L0 == &c->lanes[0] && c->nlanes == 1) {
+        LI = &c->lanes[1]; LA = &c->lanes[2];
+        int frc;
+        if ((frc = leg_fork(c, *L0, *LI)) || (frc = leg_fork(c, *L0, *LA))) return frc;
+    }
     const size_t B = j->batch;
     int rc;
     if ((rc = L.st_ok.ensure(B * 4))) return rc;
@@ -302,14 +325,17 @@ static int state_jobs_on_lane(mina_ctx *c, const mina_state_jobs *j, uint32_t *d
     }
     HIPC(hipGetLastError());
     const uint32_t *comm_override = nullptr;
+    uint32_t *ipa_v = nullptr, *acc_v = nullptr;
+    uint32_t *kimchi_bad = nullptr;
+    c->L = LI;                                                  // ---- wrap-proof leg
+    {
+    Lane &L = *LI;
+    if ((rc = L.st_flags.ensure(16 * 4))) { c->L = L0; return rc; }
     if (j->npub || j->kimchi) {
-        if ((rc = L.st_pubcomm.ensure(B * 64))) return rc;
-        if ((rc = mb_pubcomm_dev(c, B, j->log2_domain, j->npub, (const uint32_t *)j->public_inputs, L.st_pubcomm.as<uint32_t>()))) return rc;
+        if ((rc = L.st_pubcomm.ensure(B * 64))) { c->L = L0; return rc; }
+        if ((rc = mb_pubcomm_dev(c, B, j->log2_domain, j->npub, (const uint32_t *)j->public_inputs, L.st_pubcomm.as<uint32_t>()))) { c->L = L0; return rc; }
         comm_override = L.st_pubcomm.as<uint32_t>();
     }
-    uint32_t *ipa_v = nullptr, *acc_v = nullptr;
-    if ((rc = L.st_flags.ensure(16 * 4))) return rc;
-    uint32_t *kimchi_bad = nullptr;
     if (j->with_ipa) {
         mb::IpaShape sh; sh.batch = (uint32_t)B; sh.k = j->k; sh.npts = j->n_evalpoints; sh.ncomms = j->n_comms; sh.per = 2 * j->k + j->n_comms + 4;
         auto W = [](const void *p) { return (const uint32_t *)p; };
@@ -318,28 +344,33 @@ static int state_jobs_on_lane(mina_ctx *c, const mina_state_jobs *j, uint32_t *d
             // kimchi oracles + to_batch produce the BatchEvaluationProof rows in lane buffers (the public-input commitment is already in the list)
             const mina_kimchi_proofs &kp = *j->kimchi;
             if ((rc = L.kc_state.ensure(B * 96)) || (rc = L.kc_pos.ensure(B * 8)) || (rc = L.kc_cip.ensure(B * 32)) || (rc = L.kc_pts.ensure(B * 64)) ||
-                (rc = L.kc_v.ensure(B * 32)) || (rc = L.kc_u.ensure(B * 32)) || (rc = L.kc_comms.ensure(B * (size_t)j->n_comms * 64))) return rc;
+                (rc = L.kc_v.ensure(B * 32)) || (rc = L.kc_u.ensure(B * 32)) || (rc = L.kc_comms.ensure(B * (size_t)j->n_comms * 64))) { c->L = L0; return rc; }
             kimchi_bad = L.st_flags.as<uint32_t>() + 12;
             HIPC(hipMemsetAsync(kimchi_bad, 0, 4, L.stream));
             mb::KimchiIn in{W(kp.public_inputs), W(kp.prev_chals), W(kp.prev_comms), W(kp.w_comm), W(kp.z_comm), W(kp.t_comm), W(kp.evals), W(kp.ft_eval1), comm_override};
             mb::KimchiOut out{L.kc_state.as<uint32_t>(), L.kc_pos.as<uint32_t>(), L.kc_cip.as<uint32_t>(), L.kc_pts.as<uint32_t>(), L.kc_v.as<uint32_t>(), L.kc_u.as<uint32_t>(),
                               L.kc_comms.as<uint32_t>(), nullptr};
-            if ((rc = mb_kimchi_to_batch_dev(c, B, kp.n_prev, kp.npub, in, out, kimchi_bad))) return rc;
+            if ((rc = mb_kimchi_to_batch_dev(c, B, kp.n_prev, kp.npub, in, out, kimchi_bad))) { c->L = L0; return rc; }
             mb::IpaDevIn iin{out.sponge_state, out.sponge_pos, out.cip, W(j->lr), W(j->delta), W(j->sg), W(j->z1), W(j->z2), out.evalpoints, out.evalscale, out.polyscale,
                              out.comms, nullptr, W(j->rand_base), W(j->sg_rand_base)};
-            if ((rc = mb_ipa_batch_check_dev(c, CURVE_PALLAS, sh, iin, ipa_v))) return rc;
+            if ((rc = mb_ipa_batch_check_dev(c, CURVE_PALLAS, sh, iin, ipa_v))) { c->L = L0; return rc; }
         } else {
             sh.override_slot = j->npub ? j->pub_comm_slot : 0xffffffffu;
             mb::IpaDevIn in{W(j->sponge_state), W(j->sponge_pos), W(j->cip), W(j->lr), W(j->delta), W(j->sg), W(j->z1), W(j->z2), W(j->evalpoints), W(j->evalscale),
                             W(j->polyscale), W(j->comms), comm_override, W(j->rand_base), W(j->sg_rand_base)};
-            if ((rc = mb_ipa_batch_check_dev(c, CURVE_PALLAS, sh, in, ipa_v))) return rc;
+            if ((rc = mb_ipa_batch_check_dev(c, CURVE_PALLAS, sh, in, ipa_v))) { c->L = L0; return rc; }
         }
     }
-    if (j->with_accumulator) {
-        acc_v = L.st_flags.as<uint32_t>() + 8;
-        if ((rc = mb_accumulator_check_dev(c, CURVE_VESTA, j->acc_k, B, (const uint32_t *)j->acc_prechallenges, (const uint32_t *)j->acc_sg,
-                                           B > 1 ? (const uint32_t *)j->acc_rho : nullptr, acc_v))) return rc;
     }
+    c->L = LA;                                                  // ---- accumulator leg
+    if (j->with_accumulator) {
+        if ((rc = LA->st_flags.ensure(16 * 4))) { c->L = L0; return rc; }
+        acc_v = LA->st_flags.as<uint32_t>() + 8;
+        if ((rc = mb_accumulator_check_dev(c, CURVE_VESTA, j->acc_k, B, (const uint32_t *)j->acc_prechallenges, (const uint32_t *)j->acc_sg,
+                                           B > 1 ? (const uint32_t *)j->acc_rho : nullptr, acc_v))) { c->L = L0; return rc; }
+    }
+    c->L = L0;
+    if (LI != L0) { int jrc; if ((jrc = leg_join(*LI, *L0)) || (jrc = leg_join(*LA, *L0))) return jrc; }
     mb::state_job_verdict_kernel<<<cdiv(B, 64), 64, 0, L.stream>>>((uint32_t)B, L.st_ok.as<uint32_t>(), ipa_v, acc_v, kimchi_bad, d_verdicts, d_flags);
     HIPC(hipGetLastError());
     return MINA_OK;
@@ -401,7 +432,7 @@ extern "C" int mina_state_job_batch(mina_ctx *c, const mina_state_jobs *jobs, ui
     if (d.kimchi) kd.public_inputs = d.public_inputs;
     if ((rc = L.st_verdicts.ensure(B * 4 + 16))) return rc;
     uint32_t *dv = L.st_verdicts.as<uint32_t>(), *df = dv + B;
-    if ((rc = state_jobs_on_lane(c, &d, dv, df))) return rc;
+    if ((rc = state_jobs_on_lane(c, &d, dv, df, /*split=*/B <= 1024))) return rc;
     std::vector<uint32_t> hv(B + 4);
     if ((rc = d2h_sync(c, hv.data(), L.st_verdicts, (B + 4) * 4))) return rc;
     const bool ipa_ok = hv[B] != 0, acc_ok = hv[B + 2] != 0;

@@ -82,7 +82,7 @@ struct ProfState {
 struct Lane {
     hipStream_t stream = nullptr;
     hipStream_t aux = nullptr;               // second stream for work that can run beside the lane's main stream (IPA to_group)
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_leg = nullptr;   // ev_leg: fork / join of the Proof-of-State job's legs
     MsmWorkspace ws;
     DevBuf tmp_a, tmp_b, tmp_c, tmp_d;       // staging for the host-buffer entry points
     PinnedBuf host_stage;                    // pinned host side of the big H2D blobs (synchronous entry points only)

@@ -205,3 +205,54 @@ int main(int argc, char **argv) {
     r = subprocess.run([str(exe), str(tmp_path / "p"), str(tmp_path / "q")], capture_output=True, text=True, timeout=300)
     # a fresh process has no verifier index installed: every other step passes, the verdict is false (MINA_CHECK_KIMCHI = 32 did not run)
     assert r.returncode == 0 and r.stdout.strip() == "false passed=31 ran=31", r.stdout + r.stderr
+
+
+def test_c4_account_batch_concurrent_with_msm_mix(ctx_srs, oracle, srs_oracle):
+    """BASELINE config C4 ("256 Proof-of-Account verifies, Poseidon-heavy Merkle-path + MSM mix"): the 256-proof account batch on
+    one context while another context of the same GPU runs Proof-of-State jobs (MSM-heavy) from a second host thread; both results
+    stay exact"""
+    import struct
+    import threading
+    import mina_bridge_amd as m
+    from ipa_helpers import poseidon_pp
+    from oracle import mina_account_ref as A, pasta_ref as R
+    from state_job_helpers import build_jobs, mint_job
+    pp = poseidon_pp(0)
+    rng = random.Random(77)
+    accounts = [A.synth_account(rng, i % 3 == 0, i % 2 == 0, i % 5 != 0) for i in range(16)]
+    proofs, pubs = [], []
+    for a in accounts:
+        leaf = A.account_hash(a, pp)
+        path = [(rng.randrange(2), rng.randrange(R.P)) for _ in range(35)]
+        enc = A.abi_encode_account(a)
+        proofs.append(A.write_account_proof(path, a)); pubs.append(R.merkle_root(leaf, path, pp).to_bytes(32, "little") + struct.pack("<Q", len(enc)) + enc)
+    proofs, pubs = proofs * 16, pubs * 16                        # 256
+    pubs[200] = pubs[201]
+    shape = dict(k=7, log2_domain=7, npub=8, n_comms=6, slot=2, n_points=2, acc_k=16)          # 2^16 Vesta accumulator MSM per proof
+    jobs = [mint_job(srs_oracle[0], srs_oracle[1], 4000 + i, **shape) for i in range(4)]
+    sj = build_jobs(m, jobs, 7, 7, 2, 16)
+    acc_ctx = m.MinaContext(0)
+    for f in (0, 1):
+        acc_ctx.poseidon_set_params(f, m.poseidon_params.default_params_bytes(f))
+    res = {}
+
+    def accounts_thread():
+        for it in range(3):
+            res["acc%d" % it] = acc_ctx.verify_account_checks(proofs, pubs)[0]
+
+    def msm_thread():
+        for it in range(6):
+            res["job%d" % it] = ctx_srs.state_job_batch(sj)
+
+    try:
+        ts = [threading.Thread(target=accounts_thread), threading.Thread(target=msm_thread)]
+        for t in ts: t.start()
+        for t in ts: t.join()
+    finally:
+        acc_ctx.close()
+    OK = 1 | 64 | 128
+    for it in range(3):
+        v = res["acc%d" % it]
+        assert (v == OK).sum() == 255 and v[200] == 1          # another account's public input: neither the ABI bytes nor the ledger hash match
+    for it in range(6):
+        assert res["job%d" % it].tolist() == [1, 1, 1, 1]
