@@ -446,6 +446,26 @@ typedef struct {                       /* one `BatchEvaluationProof` row per pro
 } mina_kimchi_batch_out;
 int mina_kimchi_to_batch(mina_ctx *ctx, const mina_kimchi_proofs *proofs, mina_kimchi_batch_out *out);
 
+/* ---- Pickles glue of `verify_block` (a15): statement -> deferred values -> the wrap circuit's 40 public inputs ---------------
+ * openmina `compute_deferred_values` + the two message digests + `PreparedStatement::to_public_input`.  Needs, besides the wrap
+ * index, the STEP circuit's data (also absent from the reference tree): zero-knowledge rows, the 7 permutation shifts of every
+ * step domain in use, and the step linearization's constant term in the same PolishToken byte-code (columns: as MINA_TOK_CELL,
+ * optional evaluations following at 43, 44, ... in wire order).  With a step index installed the kimchi step of mina_verify_state
+ * runs on these public inputs (every statement field is then bound to the proof); without one it runs with none. */
+typedef struct {
+    uint32_t zk_rows;                 /* 3 */
+    uint32_t n_domains;               /* step domains in use */
+    const uint32_t *domain_log2;      /* n_domains */
+    const uint8_t *shifts;            /* n_domains * 7 * 32 (Fp) */
+    const uint8_t *constant_term;     /* PolishToken byte-code over Fp */
+    size_t constant_term_len;
+} mina_step_index;
+int mina_step_index_install(mina_ctx *ctx, const mina_step_index *index);
+/* one serialized wrap proof + the application state (the tip's protocol-state hash) -> public_input_out[40*32] (Fq) and, if
+ * derived_out != NULL, 7*32 bytes: combined_inner_product, b, zeta^(2^16), zeta^n, perm, xi, r (Fp).  Sponges run on the GPU. */
+int mina_pickles_public_input(mina_ctx *ctx, const uint8_t *wrap_proof, size_t len, int encoding, const uint8_t *app_state /* 32 */,
+                              uint8_t *public_input_out, uint8_t *derived_out);
+
 /* ---- containers (a1, a5, 8f-2) -------------------------------------------------------------------------------------
  * Serialized Pickles wrap proof (`MinaBaseProofStableV2`; bin_prot as core/src/mina.rs:235-248 reads it, or the serde/bincode form
  * at the head of `MinaStateProof`) -> one flat byte string in the fixed order the kernels consume:

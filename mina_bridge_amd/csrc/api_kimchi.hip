@@ -17,10 +17,11 @@
 #include "msm.cuh"
 #include "sponge.cuh"
 #include "wire_proof.h"
+#include "polish.h"
 
 namespace mb {
 
-static constexpr uint32_t KC_COLS = 43, KC_W0 = 7, KC_C0 = 22, KC_S0 = 37, KC_MAX_ZK = 8, KC_STACK = 24, KC_CACHE = 8;
+static constexpr uint32_t KC_COLS = 43, KC_W0 = 7, KC_C0 = 22, KC_S0 = 37, KC_MAX_ZK = 8;
 struct KimchiIndexDev {
     uint32_t log2_domain, zk_rows, perm_alpha_offset, n_tokens;
     fe_t shifts[7];                                    // scalar field, Montgomery
@@ -30,7 +31,6 @@ struct KimchiIndexDev {
     affine_t sigma6;                                   // base field, Montgomery
     uint32_t col_comm_words[(6 + 15 + 6) * 16];        // selectors, coefficients, sigma[0..6): canonical words, copied into every comms row
 };
-struct KimchiToken { uint32_t op, a, b, c; };
 struct KimchiIn { const uint32_t *pub, *prev_chals, *prev_comms, *w_comm, *z_comm, *t_comm, *evals, *ft_eval1, *pubcomm; };
 struct KimchiOut { uint32_t *sponge_state, *sponge_pos, *cip, *evalpoints, *polyscale, *evalscale, *comms, *ft_eval0; };
 
@@ -249,29 +249,6 @@ kimchi_to_batch_kernel(uint32_t batch, uint32_t n_prev, uint32_t npub, FieldK kb
 
 // ------------------------------------------------------------------------------------------------ the verifier index
 namespace {
-bool decode_tokens(const uint8_t *code, size_t len, std::vector<mb::KimchiToken> &toks, std::vector<std::array<uint8_t, 32>> &lits) {
-    size_t p = 0; int depth = 0, cache = 0;
-    auto need = [&](size_t k) { return len - p >= k; };
-    while (p < len) {
-        mb::KimchiToken t{code[p++], 0, 0, 0};
-        switch (t.op) {
-            case MINA_TOK_ALPHA: case MINA_TOK_BETA: case MINA_TOK_GAMMA: case MINA_TOK_JOINT_COMBINER: case MINA_TOK_ENDO_COEFFICIENT: case MINA_TOK_VANISHES_ON_ZK_ROWS: ++depth; break;
-            case MINA_TOK_MDS: if (!need(2)) return false; t.a = code[p]; t.b = code[p + 1]; p += 2; if (t.a > 2 || t.b > 2) return false; ++depth; break;
-            case MINA_TOK_LITERAL: { if (!need(32) || !mw::fq_canonical(code + p)) return false; std::array<uint8_t, 32> l; memcpy(l.data(), code + p, 32); p += 32; t.a = (uint32_t)lits.size(); lits.push_back(l); ++depth; break; }
-            case MINA_TOK_CELL: if (!need(2)) return false; t.a = code[p]; t.b = code[p + 1]; p += 2; if (t.a >= mb::KC_COLS || t.b > 1) return false; ++depth; break;
-            case MINA_TOK_DUP: if (depth < 1) return false; ++depth; break;
-            case MINA_TOK_POW: if (!need(8) || depth < 1) return false; memcpy(&t.a, code + p, 4); memcpy(&t.b, code + p + 4, 4); p += 8; break;
-            case MINA_TOK_ADD: case MINA_TOK_MUL: case MINA_TOK_SUB: if (depth < 2) return false; --depth; break;
-            case MINA_TOK_UNNORMALIZED_LAGRANGE: if (!need(4)) return false; memcpy(&t.a, code + p, 4); p += 4; ++depth; break;
-            case MINA_TOK_STORE: if (depth < 1 || cache >= (int)mb::KC_CACHE) return false; ++cache; break;
-            case MINA_TOK_LOAD: if (!need(2)) return false; t.a = code[p] | (code[p + 1] << 8); p += 2; if ((int)t.a >= cache) return false; ++depth; break;
-            default: return false;
-        }
-        if (depth > (int)mb::KC_STACK) return false;
-        toks.push_back(t);
-    }
-    return toks.empty() || depth == 1;
-}
 template <int F> fe_t host_mont(const uint8_t *b, const FieldK &k) { fe_t a; memcpy(a.v, b, 32); return fe_to_mont<F>(a, k.r2); }
 }  // namespace
 
@@ -283,7 +260,7 @@ extern "C" int mina_verifier_index_install(mina_ctx *c, const mina_verifier_inde
     if (((uint64_t)1 << vi->log2_domain) > c->srs[CURVE_PALLAS].depth) return fail(c->srs[CURVE_PALLAS].depth ? MINA_ERR_ARG : MINA_ERR_STATE, "Pallas SRS missing or smaller than the domain");
     if (!c->have_pparams[FIELD_FP] || !c->have_pparams[FIELD_FQ]) return fail(MINA_ERR_STATE, "Poseidon constants not installed");
     std::vector<mb::KimchiToken> toks; std::vector<std::array<uint8_t, 32>> lits;
-    if (!decode_tokens(vi->constant_term, vi->constant_term_len, toks, lits)) return fail(MINA_ERR_FORMAT, "malformed PolishToken program");
+    if (!mb::decode_tokens(vi->constant_term, vi->constant_term_len, FIELD_FQ, mb::KC_COLS, toks, lits)) return fail(MINA_ERR_FORMAT, "malformed PolishToken program");
     for (int i = 0; i < 7; ++i) if (!mw::fq_canonical(vi->shifts + 32 * i)) return fail(MINA_ERR_FORMAT, "shift is not a canonical scalar");
     const uint8_t *groups[3] = {vi->selector_comm, vi->coefficients_comm, vi->sigma_comm}; const int counts[3] = {6, 15, 7};
     for (int g = 0; g < 3; ++g) for (int i = 0; i < counts[g] * 2; ++i) if (!mw::fp_canonical(groups[g] + 32 * i)) return fail(MINA_ERR_FORMAT, "index commitment coordinate is not canonical");
@@ -330,6 +307,7 @@ extern "C" int mina_verifier_index_install(mina_ctx *c, const mina_verifier_inde
     HIPC(hipMemcpy(c->kimchi_index.p, ix, sizeof *ix, hipMemcpyHostToDevice));
     if (!toks.empty()) HIPC(hipMemcpy(c->kimchi_tokens.p, toks.data(), toks.size() * sizeof(mb::KimchiToken), hipMemcpyHostToDevice));
     HIPC(hipMemcpy(c->kimchi_literals.p, lm.data(), lm.size() * sizeof(fe_t), hipMemcpyHostToDevice));
+    memcpy(c->kimchi_comms_host, vi->sigma_comm, 7 * 64); memcpy(c->kimchi_comms_host + 7 * 64, vi->coefficients_comm, 15 * 64); memcpy(c->kimchi_comms_host + 22 * 64, vi->selector_comm, 6 * 64);
     c->kimchi_log2 = vi->log2_domain; c->have_kimchi = true;
     return MINA_OK;
 }
@@ -411,17 +389,25 @@ extern "C" int mina_kimchi_to_batch(mina_ctx *c, const mina_kimchi_proofs *p, mi
 // Gathers the wrap proofs' kimchi inputs into host arrays for mina_state_job_batch.  The wrap circuit's PUBLIC INPUT is the
 // Pickles statement packed into scalars (`tock_unpadded_public_input_of_statement`): that packing needs the step circuit's
 // deferred values (combined inner product, b, zeta powers, perm), which in turn need the STEP linearization -- data this tree does
-// not hold.  Until that exists the wrap proof is verified with an EMPTY public input (npub = 0) [flagged in DESIGN.md]: a real
-// Mina proof cannot pass this leg yet; with the synthetic index of the tests the path is exercised end to end.
+// not hold.  With a step index installed (mina_step_index_install) the 40 public inputs are derived from the statement
+// (api_pickles.hip); without one the wrap proof is verified with an EMPTY public input (npub = 0) [flagged in DESIGN.md].
+int mb_step_index_installed(mina_ctx *c);                                                                                          // api_pickles.hip
+int mb_pickles_public_inputs(mina_ctx *c, const mw::WrapProof *const *proofs, const uint8_t *const *app_states, size_t n, uint8_t *pub_out, uint8_t *derived_out, uint8_t *ok_out);
+
 int mb_kimchi_fill_jobs(mina_ctx *c, const mw::WrapProof *const *proofs, const uint8_t *const *tip_hashes, size_t n, mina_state_jobs *jobs,
-                        std::vector<std::vector<uint8_t>> &storage) {
-    (void)tip_hashes;
+                        std::vector<std::vector<uint8_t>> &storage, std::vector<uint8_t> &statement_ok) {
     const uint32_t k = c->kimchi_log2;
     storage.assign(16, {});
+    statement_ok.assign(n, 1);
     auto &pub = storage[0], &pch = storage[1], &pcm = storage[2], &wc = storage[3], &zc = storage[4], &tc = storage[5], &ev = storage[6], &ft1 = storage[7],
          &lr = storage[8], &dl = storage[9], &sg = storage[10], &z1 = storage[11], &z2 = storage[12], &rb = storage[13], &sb = storage[14], &kp = storage[15];
-    const uint32_t n_prev = 2, npub = 0;
-    (void)pub;
+    const uint32_t n_prev = 2;
+    uint32_t npub = 0;
+    if (mb_step_index_installed(c)) {           // the wrap circuit's public input = the Pickles statement, deferred values recomputed (api_pickles.hip)
+        npub = 40; pub.resize(n * 40 * 32);
+        int prc = mb_pickles_public_inputs(c, proofs, tip_hashes, n, pub.data(), nullptr, statement_ok.data());
+        if (prc) return prc;
+    }
     auto put_pt = [](std::vector<uint8_t> &v, const mw::Pt &p) { v.insert(v.end(), p.x.b, p.x.b + 32); v.insert(v.end(), p.y.b, p.y.b + 32); };
     auto put32 = [](std::vector<uint8_t> &v, const mw::B32 &x) { v.insert(v.end(), x.b, x.b + 32); };
     for (size_t b = 0; b < n; ++b) {
@@ -453,7 +439,8 @@ int mb_kimchi_fill_jobs(mina_ctx *c, const mw::WrapProof *const *proofs, const u
     kk.z_comm = zc.data(); kk.t_comm = tc.data(); kk.evals = ev.data(); kk.ft_eval1 = ft1.data();
     memcpy(kp.data(), &kk, sizeof kk);
     jobs->batch = n; jobs->with_ipa = 1; jobs->kimchi = (const mina_kimchi_proofs *)kp.data();
-    jobs->k = k; jobs->n_evalpoints = 2; jobs->n_comms = n_prev + 2 + mb::KC_COLS; jobs->log2_domain = k; jobs->npub = 0;
+    jobs->k = k; jobs->n_evalpoints = 2; jobs->n_comms = n_prev + 2 + mb::KC_COLS; jobs->log2_domain = k; jobs->npub = npub;
+    if (npub) { jobs->public_inputs = pub.data(); kk.public_inputs = pub.data(); memcpy(kp.data(), &kk, sizeof kk); }
     jobs->lr = lr.data(); jobs->delta = dl.data(); jobs->sg = sg.data(); jobs->z1 = z1.data(); jobs->z2 = z2.data(); jobs->rand_base = rb.data(); jobs->sg_rand_base = sb.data();
     return MINA_OK;
 }

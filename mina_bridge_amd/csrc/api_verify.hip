@@ -26,7 +26,7 @@
 int mb_pack_protocol_state(const mw::ProtocolState &s, uint8_t *record, uint32_t *n_body_fields, mina_protocol_state_info *info);   // api_state.hip
 int mb_kimchi_available(mina_ctx *c);                                                                                                  // api_kimchi.hip
 int mb_kimchi_fill_jobs(mina_ctx *c, const mw::WrapProof *const *proofs, const uint8_t *const *tip_hashes, size_t n, mina_state_jobs *jobs,
-                        std::vector<std::vector<uint8_t>> &storage);
+                        std::vector<std::vector<uint8_t>> &storage, std::vector<uint8_t> &statement_ok);
 
 extern "C" const char *mina_poseidon_params_name(void) { return MB_POSEIDON_SET_NAME; }
 extern "C" int mina_poseidon_install_default_params(mina_ctx *c) {
@@ -130,10 +130,10 @@ int run_state_jobs(mina_ctx *c, std::vector<ParsedState *> &ps, std::vector<uint
     if (mb_kimchi_available(c)) {   // KIMCHI: oracles + to_batch on the GPU, then the combined opening check
         std::vector<const mw::WrapProof *> wp(n); std::vector<const uint8_t *> th(n);
         for (size_t b = 0; b < n; ++b) { wp[b] = &ps[b]->box.tip_proof; th[b] = ps[b]->pub.candidate_chain_state_hashes[15]; }
-        mina_state_jobs j = base; std::vector<std::vector<uint8_t>> storage;
-        if ((rc = mb_kimchi_fill_jobs(c, wp.data(), th.data(), n, &j, storage))) return rc;
+        mina_state_jobs j = base; std::vector<std::vector<uint8_t>> storage; std::vector<uint8_t> stmt_ok;
+        if ((rc = mb_kimchi_fill_jobs(c, wp.data(), th.data(), n, &j, storage, stmt_ok))) return rc;
         if ((rc = run(j, v))) return rc;
-        for (size_t b = 0; b < n; ++b) { ran[b] |= MINA_CHECK_KIMCHI; if (v[b]) passed[b] |= MINA_CHECK_KIMCHI; }
+        for (size_t b = 0; b < n; ++b) { ran[b] |= MINA_CHECK_KIMCHI; if (v[b] && stmt_ok[b]) passed[b] |= MINA_CHECK_KIMCHI; }
     }
     return MINA_OK;
 }

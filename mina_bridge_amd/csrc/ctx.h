@@ -117,6 +117,7 @@ struct mina_ctx {
     DevBuf pparams[2]; bool have_pparams[2] = {false, false};
     DevBuf merkle_salts[2]; uint32_t merkle_depth[2] = {0, 0};   // salted initial states of the Merkle hash per height
     DevBuf kimchi_index, kimchi_tokens, kimchi_literals; bool have_kimchi = false; uint32_t kimchi_log2 = 0; uint8_t kimchi_digest[32] = {0};   // installed wrap verifier index
+    uint8_t kimchi_comms_host[28 * 64] = {0};   // its commitments as installed: sigma 7, coefficients 15, selectors 6 (messages_for_next_step_proof hashes them)
     DevBuf state_salts; bool have_state_salts = false;           // salted initial states of the named hash prefixes (Fp): MB_SALT_*
     void use_lane0() { L = &lanes[0]; }
     void next_lane() { L = &lanes[rr++ % (unsigned)nlanes]; }

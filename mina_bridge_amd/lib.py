@@ -37,6 +37,7 @@ EXPORTS = [
     "mina_protocol_state_pack", "mina_protocol_state_hash_batch", "mina_protocol_state_hash_bytes",
     "mina_state_jobs_prepare", "mina_state_job_batch_dev", "mina_state_job_batch",
     "mina_challenge_to_field_dev", "mina_field_sum_rows_dev", "mina_msm_srs_range_dev", "mina_msm_dev", "mina_points_sum_dev", "mina_point_records_equal_dev",
+    "mina_step_index_install", "mina_pickles_public_input",
     "mina_verifier_index_install", "mina_verifier_index_digest", "mina_kimchi_to_batch", "mina_wrap_proof_flatten", "mina_state_proof_split",
     "mina_verify_state", "mina_verify_state_batch", "mina_verify_state_checks", "mina_verify_state_files", "mina_verify_account", "mina_verify_account_batch",
     "mina_verify_account_files", "mina_verify_account_checks", "mina_verify_account_ctx", "mina_account_hash_batch", "mina_account_abi_encode", "mina_verify_configure", "mina_verify_shutdown", "mina_verify_global_ctx", "mina_poseidon_params_name",
@@ -873,6 +874,21 @@ class MinaContext:
         vi.shifts, vi.sigma_comm, vi.coefficients_comm, vi.selector_comm, vi.constant_term = (a.ctypes.data for a in arrs)
         vi.constant_term_len = len(constant_term)
         self._ck(self._lib.mina_verifier_index_install(self._h, ctypes.byref(vi)), "mina_verifier_index_install")
+
+    def step_index_install(self, zk_rows: int, domains: list, shifts, constant_term: bytes):
+        """domains: list of log2 sizes; shifts: len(domains) x 7 x 32 bytes (Fp)"""
+        class StepIndex(ctypes.Structure):
+            _fields_ = [("zk_rows", ctypes.c_uint32), ("n_domains", ctypes.c_uint32), ("domain_log2", ctypes.c_void_p), ("shifts", ctypes.c_void_p),
+                        ("constant_term", ctypes.c_void_p), ("constant_term_len", ctypes.c_size_t)]
+        d = np.ascontiguousarray(domains, dtype=np.uint32); sh = _u8(shifts); ct = _u8(constant_term) if len(constant_term) else np.zeros(1, np.uint8)
+        si = StepIndex(zk_rows, len(domains), d.ctypes.data, sh.ctypes.data, ct.ctypes.data, len(constant_term))
+        self._ck(self._lib.mina_step_index_install(self._h, ctypes.byref(si)), "mina_step_index_install")
+
+    def pickles_public_input(self, wrap_proof: bytes, encoding: int, app_state):
+        b = _u8(wrap_proof); a = _u8(app_state)
+        pub = np.zeros((40, 32), np.uint8); der = np.zeros((7, 32), np.uint8)
+        self._ck(self._lib.mina_pickles_public_input(self._h, _p(b), ctypes.c_size_t(len(wrap_proof)), int(encoding), _p(a), _p(pub), _p(der)), "mina_pickles_public_input")
+        return pub, der
 
     def verifier_index_digest(self) -> np.ndarray:
         out = np.empty(32, np.uint8)

@@ -38,11 +38,35 @@ def world(srs_oracle):
     from kimchi_helpers import install_index
     from oracle import kimchi_ref as K, oracle as O
     g, h = srs_oracle[0]
-    circ = K.synthetic_circuit(0, g, O.bytes_to_point(h), poseidon_pp(0), poseidon_pp(1), K_LOG2, 0, seed=77)
+    circ = K.synthetic_circuit(0, g, O.bytes_to_point(h), poseidon_pp(0), poseidon_pp(1), K_LOG2, 40, seed=77)
     gctx = m.lib.verify_global_ctx()
     install_index(gctx, circ.index)
-    yield {"circ": circ, "gctx": gctx}
+    step = make_step_index(99)
+    install_step_index(gctx, step)
+    yield {"circ": circ, "gctx": gctx, "step": step}
     m.lib.verify_configure(0)
+
+
+STEP_DOMAINS = list(range(10, 17))
+
+
+def make_step_index(seed):
+    """a synthetic STEP index: random shifts for every step domain and a constant-term program over the step evaluations"""
+    from ipa_helpers import poseidon_pp
+    from oracle import kimchi_ref as K, pickles_ref as PK, pasta_ref as R
+    rng = random.Random(seed)
+    toks = [(K.T_CELL, K.COL_W0 + 2, 0), (K.T_CELL, K.COL_COEFF0 + 1, 1), (K.T_MUL,), (K.T_CELL, K.COL_GENERIC, 0), (K.T_ADD,), (K.T_ALPHA,), (K.T_MUL,),
+            (K.T_ENDO,), (K.T_MDS, 2, 0), (K.T_MUL,), (K.T_ADD,), (K.T_LITERAL, 987654321), (K.T_SUB,), (K.T_VANISH_ZK,), (K.T_LAGRANGE, -2), (K.T_MUL,), (K.T_ADD,),
+            (K.T_BETA,), (K.T_GAMMA,), (K.T_MUL,), (K.T_POW, 5), (K.T_STORE,), (K.T_ADD,), (K.T_LOAD, 0), (K.T_SUB,)]
+    return PK.StepIndex(zk_rows=3, shifts={k: [1] + [rng.randrange(2, R.P) for _ in range(6)] for k in STEP_DOMAINS}, constant_term=toks,
+                        mds=[list(r) for r in poseidon_pp(0).mds])
+
+
+def install_step_index(ctx, step):
+    from kimchi_helpers import encode_tokens
+    from oracle import oracle as O
+    sh = np.concatenate([O.ints_to_le(step.shifts[k]).reshape(-1) for k in STEP_DOMAINS])
+    ctx.step_index_install(step.zk_rows, STEP_DOMAINS, sh, encode_tokens(step.constant_term))
 
 
 def mint_state_proof(world, srs_oracle, seed):
@@ -55,15 +79,29 @@ def mint_state_proof(world, srs_oracle, seed):
     # recursion challenges of the wrap proof: 128-bit prechallenges on the wire, endo-expanded by the verifier
     pres = [[rng.getrandbits(128) for _ in range(15)] for _ in range(2)]
     chals = [[R.challenge_to_field(p, R.endo_r(0), R.Q) for p in row[:K_LOG2]] for row in pres]
-    proof = K.synthetic_proof(world["circ"], g, O.bytes_to_point(h), poseidon_pp(0), poseidon_pp(1), [], seed=seed + 1, prev_chals=chals)
-    ev = proof["evals"]
-    wrap.update(old_bulletproof_challenges=pres, step_comms=[cm for _, cm in proof["prev"]], w_comm=proof["w_comm"], z_comm=proof["z_comm"], t_comm=proof["t_comm"],
-                z_eval=ev[0], selector_eval=ev[1:7], w_eval=ev[7:22], coefficients_eval=ev[22:37], s_eval=ev[37:43], ft_eval1=proof["ft_eval1"],
-                lr=proof["opening"]["lr"], z1=proof["opening"]["z1"], z2=proof["opening"]["z2"], delta=proof["opening"]["delta"], sg=proof["opening"]["sg"])
+    wrap["prev_optional"] = [None] * 19
+    wrap["old_bulletproof_challenges"] = pres
+    prev_comms = []
+    for ch in chals:                                            # the previous wrap accumulators: commitments of b_poly_coefficients(chals)
+        sc = [O.le_to_int(x) for x in O.b_poly_coefficients(1, O.ints_to_le(ch))]
+        from oracle import ipa_ref as I
+        prev_comms.append(I.commit(0, g[: 1 << K_LOG2], O.bytes_to_point(h), sc, 0))
+    wrap["step_comms"] = prev_comms
     pre, sg = J.make_accumulator(1, gv, 16, seed + 2)
     wrap["bulletproof_challenges"] = [int.from_bytes(pre[i].tobytes(), "little") for i in range(16)]
     wrap["challenge_polynomial_commitment"] = O.bytes_to_point(sg)
     states, hashes = _chain(rng, poseidon_pp(0))
+    # the wrap circuit's public input IS the statement: deferred values recomputed from prev_evals, the two message digests, packing
+    from oracle import pickles_ref as PK
+    ix = world["circ"].index
+    comms = list(ix.sigma_comm) + list(ix.coefficients_comm) + list(ix.selector_comm)
+    pubs, dv, mw_, ms_ = PK.statement_public_input(wrap, world["step"], comms, hashes[15], poseidon_pp(0), poseidon_pp(1))
+    proof = K.synthetic_proof(world["circ"], g, O.bytes_to_point(h), poseidon_pp(0), poseidon_pp(1), pubs, seed=seed + 1, prev_chals=chals)
+    assert [cm for _, cm in proof["prev"]] == prev_comms
+    ev = proof["evals"]
+    wrap.update(w_comm=proof["w_comm"], z_comm=proof["z_comm"], t_comm=proof["t_comm"],
+                z_eval=ev[0], selector_eval=ev[1:7], w_eval=ev[7:22], coefficients_eval=ev[22:37], s_eval=ev[37:43], ft_eval1=proof["ft_eval1"],
+                lr=proof["opening"]["lr"], z1=proof["opening"]["z1"], z2=proof["opening"]["z2"], delta=proof["opening"]["delta"], sg=proof["opening"]["sg"])
     return wrap, states, hashes
 
 
@@ -109,14 +147,24 @@ def test_verify_state_end_to_end(world, srs_oracle, tmp_path):
     from ipa_helpers import poseidon_pp
     hs = list(hashes); hs[16] = S.protocol_state_hash(st[16], poseidon_pp(0))
     assert masks(s=st, hs=hs) == ALL & ~8
-    # ACCUMULATOR: one step prechallenge changed
+    # ACCUMULATOR: one step prechallenge changed (the prechallenges are also part of the statement the kimchi step binds)
     w2 = dict(wrap); bc = list(wrap["bulletproof_challenges"]); bc[7] ^= 1; w2["bulletproof_challenges"] = bc
-    assert masks(w=w2) == ALL & ~16
+    assert masks(w=w2) == ALL & ~16 & ~32
     # KIMCHI: an evaluation changed / an opening scalar changed
     w2 = dict(wrap); we = list(wrap["w_eval"]); we[2] = ((we[2][0] + 1) % (1 << 254), we[2][1]); w2["w_eval"] = we
     assert masks(w=w2) == ALL & ~32
     w2 = dict(wrap); w2["z1"] = (wrap["z1"] + 1) % (1 << 254)
     assert masks(w=w2) == ALL & ~32
+    # KIMCHI binds the STATEMENT: any statement field that enters the public input (directly or through the deferred values / digests)
+    for field, mutate in (("alpha", lambda v: v ^ 1), ("sponge_digest", lambda v: [v[0] ^ 1] + v[1:]), ("prev_ft_eval1", lambda v: (v + 1) % (1 << 254)),
+                          ("domain_log2", lambda v: 10 if v != 10 else 11), ("feature_flags", lambda v: [not v[0]] + v[1:]),
+                          ("step_old_chals", lambda v: [[v[0][0] ^ 1] + v[0][1:]] + v[1:]), ("prev_evals", lambda v: [([v[0][0][0] ^ 1], v[0][1])] + v[1:])):
+        w2 = dict(wrap); w2[field] = mutate(wrap[field])
+        assert masks(w=w2) == ALL & ~32, field
+    # ... including the application state: a wrap proof made for another tip hash (state chain re-linked, all other steps still pass)
+    st2 = copy.deepcopy(states); st2[15]["body"]["consensus_state"]["total_currency"] ^= 1
+    hs2 = list(hashes); hs2[15] = S.protocol_state_hash(st2[15], poseidon_pp(0))
+    assert masks(s=st2, hs=hs2) == ALL & ~32
 
 
 def test_verify_state_batch_and_missing_index_policy(world, srs_oracle):
@@ -256,3 +304,32 @@ def test_c4_account_batch_concurrent_with_msm_mix(ctx_srs, oracle, srs_oracle):
         assert (v == OK).sum() == 255 and v[200] == 1          # another account's public input: neither the ABI bytes nor the ledger hash match
     for it in range(6):
         assert res["job%d" % it].tolist() == [1, 1, 1, 1]
+
+
+def test_pickles_public_input_matches_oracle(world, srs_oracle):
+    """compute_deferred_values + message digests + statement packing (api_pickles.hip, sponges on the GPU) == oracle/pickles_ref.py for
+    random statements: optional evaluations present, chunked evaluations, 0..3 previous accumulators, every step domain"""
+    import mina_bridge_amd as m
+    from ipa_helpers import poseidon_pp
+    from oracle import oracle as O, pickles_ref as PK
+    from wire_writers import synth_wrap_proof, wrap_proof_bytes
+    rng = random.Random(123)
+    ix = world["circ"].index
+    comms = list(ix.sigma_comm) + list(ix.coefficients_comm) + list(ix.selector_comm)
+    gctx = world["gctx"]
+    for case in range(8):
+        w = synth_wrap_proof(rng, k=K_LOG2)
+        if case % 2:
+            w["prev_evals"][5] = ([rng.randrange(PK.P), rng.randrange(PK.P)], [rng.randrange(PK.P), rng.randrange(PK.P)])        # two chunks
+        nprev = case % 4
+        w["step_comms"] = w["step_comms"][:1] * nprev if nprev else []
+        w["step_old_chals"] = [[rng.getrandbits(128) for _ in range(16)] for _ in range(nprev)]
+        app = rng.randrange(PK.P)
+        want, dv, mw_, ms_ = PK.statement_public_input(w, world["step"], comms, app, poseidon_pp(0), poseidon_pp(1))
+        for enc, bp in ((m.lib.ENC_BINPROT, True), (m.lib.ENC_BINCODE, False)):
+            pub, der = gctx.pickles_public_input(wrap_proof_bytes(w, bp), enc, O.int_to_le(app))
+            assert [O.le_to_int(x) for x in pub] == want, case
+            assert [O.le_to_int(x) for x in der] == [dv[k] for k in ("combined_inner_product", "b", "zeta_to_srs_length", "zeta_to_domain_size", "perm", "xi", "r")]
+    w["domain_log2"] = 9                                         # a step domain the installed index does not know
+    with pytest.raises(m.MinaError):
+        gctx.pickles_public_input(wrap_proof_bytes(w, True), m.lib.ENC_BINPROT, O.int_to_le(5))
