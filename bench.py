@@ -48,7 +48,7 @@ HBM_PEAK_GBPS = 8000.0                                # MI355X_MICROARCH.md: 8 T
 MODMUL_ISSUE_FLOOR_CYCLES = 88 * 8
 CHIP_SIMDS, CLOCK_HZ = 1024, 2.4e9
 MODMUL_PER_PERMUTATION = 55 * (3 * 4 + 9)             # x^7 = 4 products x 3, MDS 9 products: 1155
-PROF_STAGES = {"pstate_hash": 11, "ipa_transcript": 12, "msm_accumulate": 3}
+PROF_STAGES = {"pstate_hash": 11, "ipa_transcript": 12, "kimchi_to_batch": 13, "msm_accumulate": 3}
 # HBM-side bytes per protocol-state hash from the rocprofv3 PMC passes of profiles/r02b_rocprof.md (FETCH_SIZE x 2 -- the gfx950
 # correction of MI355X_MICROARCH.md for 16-B-per-lane loads -- + WRITE_SIZE, KiB x 1024, over the 139 264 states of one launch)
 PSTATE_TRAFFIC_BYTES_PER_STATE = (2 * 130426 + 4352) * 1024 / 139264
@@ -112,6 +112,21 @@ def build_batch(ctx, m, B: int, seed: int):
     scal = dict(with_states=1, with_ipa=1, with_accumulator=1, log2_domain=LOG2_DOMAIN, npub=NPUB, pub_comm_slot=SLOT, k=WRAP_K, n_evalpoints=NPTS,
                 n_comms=NCOMMS, acc_k=ACC_K)
     return m.MinaContext.make_state_jobs(B, arrays, **scal), (recs[0], nf[0], hashes[0], ops[0], pre[0], sgs[0])
+
+
+def build_kimchi_section(ctx, m, B: int):
+    """the raw wrap proofs of the committed wrap-size fixture, tiled to B: (KimchiProofs + keep, opening arrays, public inputs)"""
+    from kimchi_helpers import install_index, kimchi_arrays, load_k15_fixture
+    ix, proofs, fx = load_k15_fixture()
+    install_index(ctx, ix)
+    idx = np.arange(B) % len(proofs)
+    arrays, op = kimchi_arrays([p for _, p in proofs], [pi for pi, _ in proofs])
+    per = {"prev_chals": 2 * 15 * 32, "prev_comms": 2 * 64, "w_comm": 15 * 64, "z_comm": 64, "t_comm": 7 * 64, "evals": 43 * 64, "ft_eval1": 32, "public_inputs": 40 * 32,
+           "lr": 30 * 64, "delta": 64, "sg": 64, "z1": 32, "z2": 32}
+    tile = lambda a, n: np.ascontiguousarray(a.reshape(len(proofs), n)[idx].reshape(-1))
+    arrays = {k: tile(v, per[k]) for k, v in arrays.items() if v is not None}
+    op = {k: tile(v, per[k]) for k, v in op.items()}
+    return m.MinaContext.make_kimchi_proofs(B, 2, 40, arrays), op, arrays["public_inputs"]
 
 
 def algorithmic_bytes_per_proof() -> int:
@@ -206,6 +221,8 @@ def main():
     ap.add_argument("--jobs", type=int, default=8192, help="state proofs per step (one mina_state_job_batch_dev call)")
     ap.add_argument("--pipeline", type=int, default=4, help="internal stream lanes over which consecutive steps are issued")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kimchi", action="store_true", help="run the wrap leg from the raw proofs: kimchi oracles + to_batch on the GPU against the synthetic "
+                    "wrap-size index of tests/golden/kimchi_k15.json (4 distinct proofs), then the opening check")
     ap.add_argument("--no-probes", action="store_true", help="skip the isolated-kernel and C2 probes (profiling runs)")
     args = ap.parse_args()
 
@@ -243,17 +260,37 @@ def main():
     ctx.srs_create(CURVE_PALLAS, 1 << 16)
     B = args.jobs
     (hj, keep), sample = build_batch(ctx, m, B, seed=0x6D696E61 + rank)
+    if args.kimchi:                                            # the wrap leg from the raw proofs instead of pre-derived BatchEvaluationProof rows
+        kp, op, kpub = build_kimchi_section(ctx, m, B)
+        for name in ("sponge_state", "sponge_pos", "cip", "evalpoints", "evalscale", "polyscale", "comms"):
+            setattr(hj, name, None)
+        keep = [a for a in keep] + [kp]
+        for name, arr in list(op.items()) + [("public_inputs", kpub)]:
+            arr = np.ascontiguousarray(arr); keep.append(arr); setattr(hj, name, arr.ctypes.data)
+        hj.n_comms = 47
     dev = torch.device("cuda", local_rank)
     dj = m.lib.StateJobs()
     import ctypes
     ctypes.memmove(ctypes.byref(dj), ctypes.byref(hj), ctypes.sizeof(m.lib.StateJobs))
-    by_addr = {a.ctypes.data: a for a in keep}
+    by_addr = {a.ctypes.data: a for a in keep if isinstance(a, np.ndarray)}
     dtensors = []
     for name in m.lib.StateJobs.POINTER_FIELDS:                # every section resident in HBM (torch owns the buffers)
         addr = getattr(hj, name)
         if addr:
             t = torch.from_numpy(by_addr[addr].view(np.uint8).reshape(-1)).to(dev)
             dtensors.append(t); setattr(dj, name, t.data_ptr())
+    if args.kimchi:                                            # the kimchi section's arrays live in HBM as well
+        import ctypes as ct
+        dk = m.lib.KimchiProofs()
+        ct.memmove(ct.byref(dk), ct.byref(kp[0]), ct.sizeof(m.lib.KimchiProofs))
+        kaddr = {a.ctypes.data: a for a in kp[1]}
+        for name in m.lib.KimchiProofs.POINTER_FIELDS:
+            addr = getattr(kp[0], name)
+            if addr:
+                if name == "public_inputs":
+                    setattr(dk, name, dj.public_inputs); continue
+                t = torch.from_numpy(kaddr[addr].view(np.uint8).reshape(-1)).to(dev); dtensors.append(t); setattr(dk, name, t.data_ptr())
+        dj.kimchi = ct.addressof(dk)
     ctx.state_jobs_prepare(LOG2_DOMAIN, NPUB)
     ctx.set_pipeline(args.pipeline)
     nslots = max(args.pipeline, 1)
@@ -373,7 +410,10 @@ def main():
                        "proofs_per_step": B, "pipeline_lanes": args.pipeline,
                        "distinct_inputs": "32 chains, 8 wrap openings (tests/golden/state_job_k15.json), 32 accumulators per rank",
                        "folding": "IPA and accumulator checks folded over the step's batch with caller-supplied randomisers (kimchi batch_verify's shape)",
-                       "not_in_job": "kimchi oracles/linearisation (no verifier index offline), binprot parsing (host, before the timed region)",
+                       "not_in_job": ("binprot parsing and the Pickles statement -> public-input derivation (host + GPU sponges, before the timed region)" if args.kimchi else
+                                      "kimchi oracles/linearisation (run with --kimchi: synthetic wrap-size index), binprot parsing (host, before the timed region)"),
+                       "wrap_leg": ("kimchi oracles + to_batch on the GPU from the raw wrap proofs (synthetic index, domain 2^15, 40 public inputs, 47 commitments)" if args.kimchi
+                                    else "pre-derived BatchEvaluationProof rows (45 commitments)"),
                        "sharding": f"proof-level, {args.gpus} rank(s); verdict words all-gathered over RCCL" if dist_on else "single rank",
                        "algorithmic_bytes_per_proof": algorithmic_bytes_per_proof()},
             "roofline": {"bound": "hbm", "kernel": "pstate_hash_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",

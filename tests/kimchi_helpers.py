@@ -56,3 +56,23 @@ def kimchi_arrays(proofs, publics):
         "z1": cat([O.int_to_le(p["opening"]["z1"]) for p in proofs]), "z2": cat([O.int_to_le(p["opening"]["z2"]) for p in proofs]),
     }
     return a, op
+
+
+def load_k15_fixture():
+    """tests/golden/kimchi_k15.json -> (oracle VerifierIndex, [(pubs, proof dict)], raw json)"""
+    import json, os
+    from oracle import kimchi_ref as K, oracle as O
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kimchi_k15.json")))
+    pt = lambda hx: O.bytes_to_point(np.frombuffer(bytes.fromhex(hx), np.uint8))
+    ix = K.VerifierIndex(curve=0, log2_domain=fx["log2_domain"], zk_rows=fx["zk_rows"], shifts=[int(x) for x in fx["shifts"]],
+                         sigma_comm=[pt(x) for x in fx["sigma_comm"]], coefficients_comm=[pt(x) for x in fx["coefficients_comm"]],
+                         selector_comm=[pt(x) for x in fx["selector_comm"]], constant_term=[tuple(t) for t in fx["constant_term"]],
+                         perm_alpha_offset=fx["perm_alpha_offset"], digest=int(fx["digest"]))
+    proofs = []
+    for p in fx["proofs"]:
+        proof = {"prev": [([int(c) for c in ch], pt(cm)) for ch, cm in p["prev"]], "w_comm": [pt(x) for x in p["w_comm"]], "z_comm": pt(p["z_comm"]),
+                 "t_comm": [pt(x) for x in p["t_comm"]], "evals": [(int(a), int(b)) for a, b in p["evals"]], "ft_eval1": int(p["ft_eval1"]),
+                 "opening": {"lr": [(pt(l), pt(r)) for l, r in p["lr"]], "delta": pt(p["delta"]), "sg": pt(p["sg"]), "z1": int(p["z1"]), "z2": int(p["z2"])},
+                 "expect": p["expect"]}
+        proofs.append(([int(x) for x in p["pubs"]], proof))
+    return ix, proofs, fx

@@ -98,3 +98,35 @@ def test_kimchi_leg_accepts_minted_proofs_and_isolates_tampered_ones(ctx_srs, or
     bad[0]["w_comm"][4] = bad[0]["w_comm"][5]
     ch, cm = bad[2]["prev"][1]; bad[2]["prev"][1] = ([(ch[0] + 1) % R.Q] + ch[1:], cm)
     assert ctx_srs.state_job_batch(_kimchi_job(m, bad, pubs)).tolist() == [0, 1, 0, 1]
+
+
+def test_kimchi_full_size_wrap_domain(ctx_srs, oracle):
+    """the Pickles wrap size: domain 2^15 = SRS chunk, 40 public inputs, 2 recursion challenges, 47 commitments (committed fixture minted
+    by the oracle's prover): digest, ft_eval0, v, u, combined inner product and the chunked ft_comm equal the oracle's; all four proofs
+    are accepted through the job's kimchi leg, a tampered one is isolated"""
+    import mina_bridge_amd as m
+    from kimchi_helpers import install_index, kimchi_arrays, load_k15_fixture
+    ix, proofs, fx = load_k15_fixture()
+    install_index(ctx_srs, ix)
+    assert oracle.le_to_int(ctx_srs.verifier_index_digest()) == ix.digest
+    plist, pubs = [p for _, p in proofs], [pi for pi, _ in proofs]
+    arrays, op = kimchi_arrays(plist, pubs)
+    B, npub = len(plist), fx["npub"]
+    got = ctx_srs.kimchi_to_batch(m.MinaContext.make_kimchi_proofs(B, 2, npub, arrays), 15)
+    assert not got["malformed"][0]
+    for b, p in enumerate(plist):
+        e = p["expect"]
+        assert oracle.le_to_int(got["ft_eval0"][b]) == int(e["ft_eval0"]) and oracle.le_to_int(got["cip"][b]) == int(e["cip"])
+        assert oracle.le_to_int(got["polyscale"][b]) == int(e["v"]) and oracle.le_to_int(got["evalscale"][b]) == int(e["u"])
+        assert got["comms"][b, 3].tobytes().hex() == e["ft_comm"]
+
+    def job(pl, pu):
+        a, o = kimchi_arrays(pl, pu)
+        kp = m.MinaContext.make_kimchi_proofs(len(pl), 2, npub, a)
+        ja = dict(o); ja["rand_base"] = oracle.int_to_le(7); ja["sg_rand_base"] = oracle.int_to_le(9); ja["public_inputs"] = a["public_inputs"]
+        return m.MinaContext.make_state_jobs(len(pl), ja, with_ipa=1, kimchi=kp, k=15, log2_domain=15, npub=npub, n_evalpoints=2, n_comms=47)
+    assert ctx_srs.state_job_batch(job(plist, pubs)).tolist() == [1] * B
+    import copy
+    bad = [copy.deepcopy(p) for p in plist]
+    bad[2]["evals"][40] = (bad[2]["evals"][40][0], (bad[2]["evals"][40][1] + 1) % (1 << 254))
+    assert ctx_srs.state_job_batch(job(bad, pubs)).tolist() == [1, 1, 0, 1]
