@@ -1,14 +1,14 @@
 // api_kimchi.hip -- kimchi `verifier::{oracles, to_batch}` on the GPU (transcript order README.md:413-475).
 //
-// Replaces kimchi `ProverProof::oracles` + `to_batch` (pin core/Cargo.toml:14) for proofs over Pallas (the Pickles wrap proof):
-// one lane group (4 or 8 lanes) per proof runs
+// Replaces kimchi `ProverProof::oracles` + `to_batch` (pin core/Cargo.toml:14) for proofs over Pallas (the Pickles wrap proof).
+// Per proof, in six small kernels (see "the stages" below):
 //   * the Fq-sponge: index digest, recursion commitments, public-input commitment, w -> beta, gamma -> z -> alpha -> t -> zeta
 //   * the Fr-sponge: digest of the Fq-sponge, digest of the recursion challenges, ft_eval1, public evaluations, the 43 x 2 column
 //     evaluations -> v, u
 //   * the scalar-field work: negated public polynomial at zeta / zeta*omega, ft_eval0 (permutation part, boundary part, the
 //     linearization's constant term through a PolishToken interpreter), perm scalar, b_poly of the recursion challenges, the
 //     combined inner product
-//   * the chunked ft commitment  perm_scalar * sigma_6 - (zeta^n - 1) * sum_i zeta^(n i) t_i   (8 scalar multiplications over the lanes)
+//   * the chunked ft commitment  perm_scalar * sigma_6 - (zeta^n - 1) * sum_i zeta^(n i) t_i   (8 scalar multiplications over 8 lanes)
 // and emits one `BatchEvaluationProof` row per proof in the layout `mb_ipa_batch_check_dev` consumes.
 // The verifier index (domain, shifts, commitments, token program) is DATA installed by the caller (`mina_verifier_index`): the
 // reference tree does not hold the blockchain-snark index.  [UPSTREAM-RECALL] throughout; checked against oracle/kimchi_ref.py,
@@ -69,180 +69,289 @@ template <int FB> __device__ xyzz_t scalar_mul_affine(const fe_t &s_plain, const
     return acc;
 }
 
+// ---- the stages.  One monolithic kernel (round 2 first cut) held the Fq state, the Fr state, 86 evaluations' worth of scalar
+// temporaries and a 24-deep interpreter stack live at once: 255 VGPRs + 2.4 KB of scratch per lane, non-inlined calls, and the
+// sponges -- 9/10 of the dependent work -- ran 15x slower per permutation than `pstate_hash_kernel`.  Split by what each stage needs:
+//   fq      lane-cooperative (8 or 3 lanes):  group b < B runs proof b's Fq-sponge; group B + b runs the digest of proof b's
+//           recursion challenges (a scalar-field sponge that depends on nothing else) beside it
+//   pub     8 lanes per proof: the negated public polynomial at zeta, zeta*omega (8-term chunks spread over the lanes)
+//   fr      lane-cooperative: Fr-sponge -> v, u
+//   scalar  one lane per proof: ft_eval0, the PolishToken program (stack in LDS), perm scalar, b_poly evaluations, cip, ft scalars
+//   ftcomm  8 lanes per proof: the 8 scalar multiplications of the chunked ft commitment + shuffle tree
+//   rows    one thread per word: the commitment rows that are copies
+// Values pass between stages through `xf` (KC_XF scalar-field Montgomery elements per proof).
+enum { XF_BETA = 0, XF_GAMMA, XF_ALPHA, XF_ZETA, XF_DIGEST, XF_PFDIGEST, XF_PUB0, XF_PUB1, XF_V, XF_U, XF_FTSC = 10, KC_XF = 18 };
+
+template <int LANES> __device__ __forceinline__ uint32_t coop_lane() { return LANES == 3 ? tri_pos().e : (threadIdx.x & (LANES - 1)); }
+__device__ __forceinline__ fe_t fe_shfl_xor(const fe_t &a, int mask) {
+    fe_t r;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = (uint32_t)__shfl_xor((int)a.v[i], mask, 64);
+    return r;
+}
+// sum of `x` over the group's lanes, on every lane
+template <int F, int LANES> __device__ __forceinline__ fe_t coop_sum(const fe_t &x) {
+    if (LANES == 3) { const uint32_t base = tri_pos().base; return fe_add<F>(fe_add<F>(tri_bcast(x, base), tri_bcast(x, base + 1)), tri_bcast(x, base + 2)); }
+    fe_t a = x;
+    for (int m = 1; m < LANES; m <<= 1) a = fe_add<F>(a, fe_shfl_xor(a, m));
+    return a;
+}
+template <int F, int LANES> __device__ __forceinline__ void sponge_init(DevSponge<F, LANES> &s, const PoseidonParams *pp) { s.pp = pp; s.squeezed = 0; s.count = 0; s.s = fe_zero(); }
+
 template <int LANES>
 __global__ void __launch_bounds__(64)
-kimchi_to_batch_kernel(uint32_t batch, uint32_t n_prev, uint32_t npub, FieldK kb, FieldK ks, const PoseidonParams *__restrict__ pp_b,
-                       const PoseidonParams *__restrict__ pp_s, const KimchiIndexDev *__restrict__ ix, const KimchiToken *__restrict__ toks,
-                       const fe_t *__restrict__ lits, KimchiIn in, KimchiOut out, uint32_t *__restrict__ bad_input) {
+kimchi_fq_kernel(uint32_t batch, uint32_t n_prev, FieldK kb, FieldK ks, const PoseidonParams *__restrict__ pp_b, const PoseidonParams *__restrict__ pp_s,
+                 const KimchiIndexDev *__restrict__ ix, KimchiIn in, KimchiOut out, fe_t *__restrict__ xf, uint32_t *__restrict__ bad_input) {
     constexpr int FB = FIELD_FP, FS = FIELD_FQ;                 // Pallas: base Fp, scalar Fq
-    const uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) / LANES, ln = threadIdx.x & (LANES - 1);
-    if (b >= batch) return;
-    const uint32_t k = ix->log2_domain, ncomms = n_prev + 2 + KC_COLS;
+    bool writer; const uint32_t g = coop_sponge_index<LANES>(writer);
+    if (g >= 2 * batch) return;
     bool ok = true;
-    const uint32_t *ev = in.evals + (size_t)b * KC_COLS * 16;           // [col][zeta | zeta_omega][8]
-    uint32_t *comms_out = out.comms + (size_t)b * ncomms * 16;
-    auto copy_pt = [&](uint32_t *dst, const uint32_t *src) { if (ln == 0) for (int i = 0; i < 16; ++i) dst[i] = src[i]; };
-
-    // ---- Fq-sponge
-    DevSponge<FB, LANES> fq; fq.pp = pp_b; fq.squeezed = 0; fq.count = 0; fq.s = fe_zero();
+    if (g >= batch) {                                           // digest of the recursion challenges
+        const uint32_t b = g - batch, cnt = n_prev * ix->log2_domain;
+        const uint32_t *p = in.prev_chals + (size_t)b * cnt * 8;
+        DevSponge<FS, LANES> pf; sponge_init(pf, pp_s);
+#pragma unroll 1
+        for (uint32_t i = 0; i < cnt; ++i) pf.absorb(ld_checked<FS>(p + (size_t)i * 8, ks, ok));
+        const fe_t d = pf.squeeze();
+        if (writer) { xf[(size_t)b * KC_XF + XF_PFDIGEST] = d; if (!ok) *bad_input = 1u; }
+        return;
+    }
+    const uint32_t b = g;
+    DevSponge<FB, LANES> fq; sponge_init(fq, pp_b);
     fq.absorb(ix->digest);
-    auto absorb_pt = [&](const uint32_t *p) { const affine_t P = load_point_checked<FB>(p, kb, ok); fq.absorb(P.x); fq.absorb(P.y); };
-    for (uint32_t i = 0; i < n_prev; ++i) { const uint32_t *p = in.prev_comms + ((size_t)b * n_prev + i) * 16; absorb_pt(p); copy_pt(comms_out + i * 16, p); }
-    absorb_pt(in.pubcomm + (size_t)b * 16); copy_pt(comms_out + n_prev * 16, in.pubcomm + (size_t)b * 16);
-    for (uint32_t i = 0; i < 15; ++i) absorb_pt(in.w_comm + ((size_t)b * 15 + i) * 16);
-    const fe_t beta = chal128_plain<FS>(fe_from_mont<FB>(fq.squeeze()), ks);
-    const fe_t gamma = chal128_plain<FS>(fe_from_mont<FB>(fq.squeeze()), ks);
-    absorb_pt(in.z_comm + (size_t)b * 16);
-    const fe_t alpha = chal_endo<FS>(fe_from_mont<FB>(fq.squeeze()), ks);
-    for (uint32_t i = 0; i < 7; ++i) absorb_pt(in.t_comm + ((size_t)b * 7 + i) * 16);
-    const fe_t zeta = chal_endo<FS>(fe_from_mont<FB>(fq.squeeze()), ks);
-    {   // the sponge handed to the opening check
-        const bool owner = LANES == 8 ? (ln < 6 && !(ln & 1u)) : (ln < 3);
+    auto absorb_pts = [&](const uint32_t *p, uint32_t n) {
+#pragma unroll 1
+        for (uint32_t i = 0; i < n; ++i) { const affine_t P = load_point_checked<FB>(p + (size_t)i * 16, kb, ok); fq.absorb(P.x); fq.absorb(P.y); }
+    };
+    absorb_pts(in.prev_comms + (size_t)b * n_prev * 16, n_prev);
+    absorb_pts(in.pubcomm + (size_t)b * 16, 1);
+    absorb_pts(in.w_comm + (size_t)b * 15 * 16, 15);
+    fe_t *x = xf + (size_t)b * KC_XF;
+    { const fe_t beta = chal128_plain<FS>(fe_from_mont<FB>(fq.squeeze()), ks); if (writer) x[XF_BETA] = beta; }
+    { const fe_t gamma = chal128_plain<FS>(fe_from_mont<FB>(fq.squeeze()), ks); if (writer) x[XF_GAMMA] = gamma; }
+    absorb_pts(in.z_comm + (size_t)b * 16, 1);
+    { const fe_t alpha = chal_endo<FS>(fe_from_mont<FB>(fq.squeeze()), ks); if (writer) x[XF_ALPHA] = alpha; }
+    absorb_pts(in.t_comm + (size_t)b * 7 * 16, 7);
+    { const fe_t zeta = chal_endo<FS>(fe_from_mont<FB>(fq.squeeze()), ks); if (writer) x[XF_ZETA] = zeta; }
+    {   // the sponge handed to the opening check: element e of the state from the lane that owns it
+        const uint32_t ln = coop_lane<LANES>();
+        const bool owner = LANES == 8 ? (ln < 6 && !(ln & 1u)) : (LANES == 3 ? (threadIdx.x & 63u) < 63u : ln < 3);
         if (owner) { const fe_t w = fe_from_mont<FB>(fq.s); for (int i = 0; i < 8; ++i) out.sponge_state[(size_t)b * 24 + coop_elem<LANES>() * 8 + i] = w.v[i]; }
-        if (ln == 0) { out.sponge_pos[2 * b] = (uint32_t)fq.squeezed; out.sponge_pos[2 * b + 1] = (uint32_t)fq.count; }
+        if (writer) { out.sponge_pos[2 * b] = (uint32_t)fq.squeezed; out.sponge_pos[2 * b + 1] = (uint32_t)fq.count; }
     }
-    fe_t digest;
-    { DevSponge<FB, LANES> cl = fq; digest = fe_to_mont<FS>(fe_from_mont<FB>(cl.squeeze()), ks.r2); }     // p < q: always fits
+    const fe_t digest = fe_to_mont<FS>(fe_from_mont<FB>(fq.squeeze()), ks.r2);      // on a copy upstream; p < q: always fits.  fq is dead after this
+    if (writer) { x[XF_DIGEST] = digest; if (!ok) *bad_input = 1u; }
+}
 
-    // ---- Fr-sponge (Poseidon over the scalar field)
-    DevSponge<FS, LANES> fr; fr.pp = pp_s; fr.squeezed = 0; fr.count = 0; fr.s = fe_zero();
-    fr.absorb(digest);
-    {
-        DevSponge<FS, LANES> pf; pf.pp = pp_s; pf.squeezed = 0; pf.count = 0; pf.s = fe_zero();
-        for (uint32_t i = 0; i < n_prev * k; ++i) pf.absorb(ld_checked<FS>(in.prev_chals + ((size_t)b * n_prev * k + i) * 8, ks, ok));
-        fr.absorb(pf.squeeze());
-    }
-    const fe_t zeta1 = fe_pow2k<FS>(zeta, k), zetaw = fe_mul<FS>(zeta, ix->omega);
-    const fe_t zetaw1 = fe_pow2k<FS>(zetaw, k);
-    // negated public polynomial at zeta and zeta*omega:  -(x^n - 1)/n * sum_i p_i w^i / (x - w^i); denominators inverted 8 at a time
-    fe_t pub_e[2];
-    for (int side = 0; side < 2; ++side) {
-        const fe_t x = side ? zetaw : zeta;
-        fe_t acc = fe_zero(), wi = ks.one;
-        for (uint32_t base = 0; base < npub; base += 8) {
-            fe_t den[8], pre[8], wpow[8], run = ks.one;
-            const uint32_t cnt = npub - base < 8 ? npub - base : 8;
-            for (uint32_t j = 0; j < cnt; ++j) { wpow[j] = wi; den[j] = fe_sub<FS>(x, wi); pre[j] = run; run = fe_mul<FS>(run, den[j]); wi = fe_mul<FS>(wi, ix->omega); }
-            fe_t inv = fe_inv<FS>(run, ks);
-            for (int j = (int)cnt - 1; j >= 0; --j) {
-                const fe_t dinv = fe_mul<FS>(inv, pre[j]); inv = fe_mul<FS>(inv, den[j]);
-                const fe_t p = ld_checked<FS>(in.pub + ((size_t)b * npub + base + j) * 8, ks, ok);
-                acc = fe_sub<FS>(acc, fe_mul<FS>(fe_mul<FS>(dinv, p), wpow[j]));
-            }
+// negated public polynomial at zeta and zeta*omega:  -(x^n - 1)/n * sum_i p_i w^i / (x - w^i).  8 lanes per proof; work item = (side,
+// chunk of 8 terms), round-robin over the lanes, each inverts its 8 denominators with one field inversion; shuffle-tree sum
+__global__ void __launch_bounds__(64)
+kimchi_pub_kernel(uint32_t batch, uint32_t npub, FieldK ks, const KimchiIndexDev *__restrict__ ix, KimchiIn in, fe_t *__restrict__ xf, uint32_t *__restrict__ bad_input) {
+    constexpr int FS = FIELD_FQ;
+    const uint32_t gid = blockIdx.x * 64 + threadIdx.x, b = gid >> 3, ln = gid & 7u;
+    if (b >= batch) return;
+    bool ok = true;
+    fe_t *x = xf + (size_t)b * KC_XF;
+    const uint32_t k = ix->log2_domain;
+    const fe_t zeta = x[XF_ZETA], zetaw = fe_mul<FS>(zeta, ix->omega);
+    const fe_t omega8 = fe_pow2k<FS>(ix->omega, 3);
+    fe_t acc[2] = {fe_zero(), fe_zero()};
+    const uint32_t nchunks = (npub + 7) / 8;
+#pragma unroll 1
+    for (uint32_t it = ln; it < 2 * nchunks; it += 8) {
+        const uint32_t side = it & 1u, base = (it >> 1) * 8, cnt = npub - base < 8 ? npub - base : 8;
+        const fe_t pt = side ? zetaw : zeta;
+        fe_t wi = fe_pow_u64<FS>(omega8, it >> 1, ks.one);
+        fe_t den[8], pre[8], run = ks.one;
+#pragma unroll
+        for (uint32_t j = 0; j < 8; ++j) if (j < cnt) { den[j] = fe_sub<FS>(pt, wi); pre[j] = run; run = fe_mul<FS>(run, den[j]); wi = fe_mul<FS>(wi, ix->omega); }
+        fe_t inv = fe_inv<FS>(run, ks), part = fe_zero();
+#pragma unroll
+        for (int j = 7; j >= 0; --j) if ((uint32_t)j < cnt) {
+            const fe_t dinv = fe_mul<FS>(inv, pre[j]); inv = fe_mul<FS>(inv, den[j]);
+            const fe_t p = ld_checked<FS>(in.pub + ((size_t)b * npub + base + j) * 8, ks, ok);
+            part = fe_add<FS>(part, fe_mul<FS>(fe_mul<FS>(dinv, p), fe_sub<FS>(pt, den[j])));       // w^i = pt - (pt - w^i)
         }
-        pub_e[side] = fe_mul<FS>(fe_mul<FS>(acc, fe_sub<FS>(side ? zetaw1 : zeta1, ks.one)), ix->n_inv);
+        if (side) acc[1] = fe_sub<FS>(acc[1], part); else acc[0] = fe_sub<FS>(acc[0], part);
     }
+    for (int m = 1; m < 8; m <<= 1) { acc[0] = fe_add<FS>(acc[0], fe_shfl_xor(acc[0], m)); acc[1] = fe_add<FS>(acc[1], fe_shfl_xor(acc[1], m)); }
+    if (ln < 2) {
+        const fe_t ptn = fe_pow2k<FS>(ln ? zetaw : zeta, k);
+        x[XF_PUB0 + ln] = fe_mul<FS>(fe_mul<FS>(ln ? acc[1] : acc[0], fe_sub<FS>(ptn, ks.one)), ix->n_inv);
+    }
+    if (!ok) *bad_input = 1u;
+}
+
+template <int LANES>
+__global__ void __launch_bounds__(64)
+kimchi_fr_kernel(uint32_t batch, FieldK ks, const PoseidonParams *__restrict__ pp_s, KimchiIn in, fe_t *__restrict__ xf, uint32_t *__restrict__ bad_input) {
+    constexpr int FS = FIELD_FQ;
+    bool writer; const uint32_t b = coop_sponge_index<LANES>(writer);
+    if (b >= batch) return;
+    bool ok = true;
+    fe_t *x = xf + (size_t)b * KC_XF;
+    DevSponge<FS, LANES> fr; sponge_init(fr, pp_s);
+    fr.absorb(x[XF_DIGEST]);
+    fr.absorb(x[XF_PFDIGEST]);
     fr.absorb(ld_checked<FS>(in.ft_eval1 + (size_t)b * 8, ks, ok));
-    fr.absorb(pub_e[0]); fr.absorb(pub_e[1]);
+    fr.absorb(x[XF_PUB0]); fr.absorb(x[XF_PUB1]);
+    const uint32_t *ev = in.evals + (size_t)b * KC_COLS * 16;           // [col][zeta | zeta_omega][8]
+#pragma unroll 1
     for (uint32_t c = 0; c < KC_COLS * 2; ++c) fr.absorb(ld_checked<FS>(ev + (size_t)c * 8, ks, ok));
     const fe_t v = chal_endo<FS>(fe_from_mont<FS>(fr.squeeze()), ks);
     const fe_t u = chal_endo<FS>(fe_from_mont<FS>(fr.squeeze()), ks);
+    if (writer) { x[XF_V] = v; x[XF_U] = u; if (!ok) *bad_input = 1u; }
+}
 
-    // ---- scalar-field work (every lane redundantly; lane 0 writes)
+// one lane per proof; the interpreter's stack and cache live in LDS, word-major so that the 64 lanes of a slot hit 64 banks
+static constexpr int KC_SLOTS = KC_STACK + KC_CACHE;
+struct LdsStack {
+    uint32_t *base;
+    __device__ __forceinline__ void put(int slot, const fe_t &a) { for (int i = 0; i < 8; ++i) base[(slot * 8 + i) * 64] = a.v[i]; }
+    __device__ __forceinline__ fe_t get(int slot) const { fe_t a; for (int i = 0; i < 8; ++i) a.v[i] = base[(slot * 8 + i) * 64]; return a; }
+};
+__global__ void __launch_bounds__(64)
+kimchi_scalar_kernel(uint32_t batch, uint32_t n_prev, FieldK ks, const KimchiIndexDev *__restrict__ ix, const KimchiToken *__restrict__ toks,
+                     const fe_t *__restrict__ lits, KimchiIn in, KimchiOut out, fe_t *__restrict__ xf, uint32_t *__restrict__ bad_input) {
+    constexpr int FS = FIELD_FQ;
+    __shared__ uint32_t lds[KC_SLOTS * 8 * 64];
+    const uint32_t b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= batch) return;
+    LdsStack st{lds + threadIdx.x};
+    fe_t *x = xf + (size_t)b * KC_XF;
+    const uint32_t k = ix->log2_domain;
+    const uint32_t *ev = in.evals + (size_t)b * KC_COLS * 16;
     auto EV = [&](uint32_t col, uint32_t row) { return fe_to_mont<FS>(load_fe<FS>(ev + ((size_t)col * 2 + row) * 8), ks.r2); };
-    fe_t a0 = fe_pow_u64<FS>(alpha, ix->perm_alpha_offset, ks.one);
-    const fe_t a1 = fe_mul<FS>(a0, alpha), a2 = fe_mul<FS>(a1, alpha);
+    const fe_t beta = x[XF_BETA], gamma = x[XF_GAMMA], alpha = x[XF_ALPHA], zeta = x[XF_ZETA];
+    const fe_t zeta1 = fe_pow2k<FS>(zeta, k), zetaw = fe_mul<FS>(zeta, ix->omega);
+    const fe_t zm1 = fe_sub<FS>(zeta1, ks.one);
+    const fe_t a0 = fe_pow_u64<FS>(alpha, ix->perm_alpha_offset, ks.one);
     fe_t zkpm = ks.one;
     for (uint32_t i = 0; i < ix->zk_rows; ++i) zkpm = fe_mul<FS>(zkpm, fe_sub<FS>(zeta, ix->zk_roots[i]));
     const fe_t z0 = EV(0, 0), z1 = EV(0, 1);
     fe_t prod6 = ks.one;                                               // prod_{i<6} (gamma + beta s_i + w_i)
+#pragma unroll 1
     for (uint32_t i = 0; i < 6; ++i) prod6 = fe_mul<FS>(prod6, fe_add<FS>(fe_add<FS>(fe_mul<FS>(beta, EV(KC_S0 + i, 0)), EV(KC_W0 + i, 0)), gamma));
     const fe_t common = fe_mul<FS>(fe_mul<FS>(a0, zkpm), prod6);
     fe_t ft = fe_mul<FS>(fe_mul<FS>(fe_add<FS>(EV(KC_W0 + 6, 0), gamma), z1), common);
-    ft = fe_sub<FS>(ft, pub_e[0]);
+    ft = fe_sub<FS>(ft, x[XF_PUB0]);
     {
         fe_t t2 = fe_mul<FS>(fe_mul<FS>(a0, zkpm), z0);
         const fe_t bz = fe_mul<FS>(beta, zeta);
+#pragma unroll 1
         for (uint32_t i = 0; i < 7; ++i) t2 = fe_mul<FS>(t2, fe_add<FS>(fe_add<FS>(gamma, fe_mul<FS>(bz, ix->shifts[i])), EV(KC_W0 + i, 0)));
         ft = fe_sub<FS>(ft, t2);
-        const fe_t zm1 = fe_sub<FS>(zeta1, ks.one), dw = fe_sub<FS>(zeta, ix->omega_zk), d1 = fe_sub<FS>(zeta, ks.one);
+        const fe_t a1 = fe_mul<FS>(a0, alpha), a2 = fe_mul<FS>(a1, alpha);
+        const fe_t dw = fe_sub<FS>(zeta, ix->omega_zk), d1 = fe_sub<FS>(zeta, ks.one);
         const fe_t num = fe_mul<FS>(fe_add<FS>(fe_mul<FS>(fe_mul<FS>(zm1, a1), dw), fe_mul<FS>(fe_mul<FS>(zm1, a2), d1)), fe_sub<FS>(ks.one, z0));
         ft = fe_add<FS>(ft, fe_mul<FS>(num, fe_inv<FS>(fe_mul<FS>(dw, d1), ks)));
     }
-    {   // linearization constant term: PolishToken stack machine
-        fe_t stack[KC_STACK], cache[KC_CACHE]; int sp = 0, nc = 0; bool prog_ok = true;
+    bool ok = true;
+    if (ix->n_tokens) {   // linearization constant term: PolishToken stack machine (the program is uniform over the lanes: no divergence)
+        int sp = 0, nc = 0; bool prog_ok = true;
+#pragma unroll 1
         for (uint32_t t = 0; t < ix->n_tokens; ++t) {
             const KimchiToken tk = toks[t];
             switch (tk.op) {
-                case MINA_TOK_ALPHA: stack[sp++] = alpha; break;
-                case MINA_TOK_BETA: stack[sp++] = beta; break;
-                case MINA_TOK_GAMMA: stack[sp++] = gamma; break;
-                case MINA_TOK_JOINT_COMBINER: stack[sp++] = fe_zero(); break;
-                case MINA_TOK_ENDO_COEFFICIENT: stack[sp++] = ix->endo_coeff; break;
-                case MINA_TOK_MDS: stack[sp++] = ix->mds[tk.a * 3 + tk.b]; break;
-                case MINA_TOK_LITERAL: stack[sp++] = lits[tk.a]; break;
-                case MINA_TOK_CELL: stack[sp++] = EV(tk.a, tk.b); break;
-                case MINA_TOK_DUP: stack[sp] = stack[sp - 1]; ++sp; break;
-                case MINA_TOK_POW: stack[sp - 1] = fe_pow_u64<FS>(stack[sp - 1], (uint64_t)tk.a | ((uint64_t)tk.b << 32), ks.one); break;
-                case MINA_TOK_ADD: stack[sp - 2] = fe_add<FS>(stack[sp - 2], stack[sp - 1]); --sp; break;
-                case MINA_TOK_MUL: stack[sp - 2] = fe_mul<FS>(stack[sp - 2], stack[sp - 1]); --sp; break;
-                case MINA_TOK_SUB: stack[sp - 2] = fe_sub<FS>(stack[sp - 2], stack[sp - 1]); --sp; break;
-                case MINA_TOK_VANISHES_ON_ZK_ROWS: stack[sp++] = zkpm; break;
+                case MINA_TOK_ALPHA: st.put(sp++, alpha); break;
+                case MINA_TOK_BETA: st.put(sp++, beta); break;
+                case MINA_TOK_GAMMA: st.put(sp++, gamma); break;
+                case MINA_TOK_JOINT_COMBINER: st.put(sp++, fe_zero()); break;
+                case MINA_TOK_ENDO_COEFFICIENT: st.put(sp++, ix->endo_coeff); break;
+                case MINA_TOK_MDS: st.put(sp++, ix->mds[tk.a * 3 + tk.b]); break;
+                case MINA_TOK_LITERAL: st.put(sp++, lits[tk.a]); break;
+                case MINA_TOK_CELL: st.put(sp++, EV(tk.a, tk.b)); break;
+                case MINA_TOK_DUP: st.put(sp, st.get(sp - 1)); ++sp; break;
+                case MINA_TOK_POW: st.put(sp - 1, fe_pow_u64<FS>(st.get(sp - 1), (uint64_t)tk.a | ((uint64_t)tk.b << 32), ks.one)); break;
+                case MINA_TOK_ADD: st.put(sp - 2, fe_add<FS>(st.get(sp - 2), st.get(sp - 1))); --sp; break;
+                case MINA_TOK_MUL: st.put(sp - 2, fe_mul<FS>(st.get(sp - 2), st.get(sp - 1))); --sp; break;
+                case MINA_TOK_SUB: st.put(sp - 2, fe_sub<FS>(st.get(sp - 2), st.get(sp - 1))); --sp; break;
+                case MINA_TOK_VANISHES_ON_ZK_ROWS: st.put(sp++, zkpm); break;
                 case MINA_TOK_UNNORMALIZED_LAGRANGE: {
                     const int32_t off = (int32_t)tk.a;
                     const uint32_t row = off >= 0 ? (uint32_t)off : (1u << k) - ix->zk_rows - (uint32_t)(-off);
                     const fe_t wr = fe_pow_u64<FS>(ix->omega, row, ks.one);
-                    stack[sp++] = fe_mul<FS>(fe_sub<FS>(zeta1, ks.one), fe_inv<FS>(fe_sub<FS>(zeta, wr), ks)); break; }
-                case MINA_TOK_STORE: cache[nc++] = stack[sp - 1]; break;
-                case MINA_TOK_LOAD: stack[sp++] = cache[tk.a]; break;
+                    st.put(sp++, fe_mul<FS>(zm1, fe_inv<FS>(fe_sub<FS>(zeta, wr), ks))); break; }
+                case MINA_TOK_STORE: st.put(KC_STACK + nc++, st.get(sp - 1)); break;
+                case MINA_TOK_LOAD: st.put(sp++, st.get(KC_STACK + (int)tk.a)); break;
                 default: prog_ok = false;
             }
         }
-        if (ix->n_tokens) { if (sp != 1 || !prog_ok) ok = false; else ft = fe_sub<FS>(ft, stack[0]); }   // the host validated stack depth: defensive
+        if (sp != 1 || !prog_ok) ok = false; else ft = fe_sub<FS>(ft, st.get(0));   // the host validated stack depth: defensive
     }
-    const fe_t perm_scalar = fe_neg<FS>(fe_mul<FS>(fe_mul<FS>(z1, beta), common));
+    const fe_t v = x[XF_V], u = x[XF_U];
     // combined inner product over the evaluation list: recursion, public, ft, then the 43 columns
     fe_t cip = fe_zero(), vi = ks.one;
     auto term = [&](const fe_t &e0, const fe_t &e1) { cip = fe_add<FS>(cip, fe_mul<FS>(vi, fe_add<FS>(e0, fe_mul<FS>(u, e1)))); vi = fe_mul<FS>(vi, v); };
+#pragma unroll 1
     for (uint32_t i = 0; i < n_prev; ++i) {
-        fe_t e[2];
-        for (int side = 0; side < 2; ++side) {
-            fe_t pw = side ? zetaw : zeta, acc = ks.one;
-            for (int j = (int)k - 1; j >= 0; --j) {
-                const fe_t ch = fe_to_mont<FS>(load_fe<FS>(in.prev_chals + (((size_t)b * n_prev + i) * k + j) * 8), ks.r2);
-                acc = fe_mul<FS>(acc, fe_add<FS>(ks.one, fe_mul<FS>(ch, pw))); pw = fe_sqr<FS>(pw);
-            }
-            e[side] = acc;
+        fe_t pw0 = zeta, pw1 = zetaw, acc0 = ks.one, acc1 = ks.one;    // b_poly(chals, zeta), b_poly(chals, zeta*omega): two chains interleaved
+#pragma unroll 1
+        for (int j = (int)k - 1; j >= 0; --j) {
+            const fe_t ch = fe_to_mont<FS>(load_fe<FS>(in.prev_chals + (((size_t)b * n_prev + i) * k + j) * 8), ks.r2);
+            acc0 = fe_mul<FS>(acc0, fe_add<FS>(ks.one, fe_mul<FS>(ch, pw0))); pw0 = fe_sqr<FS>(pw0);
+            acc1 = fe_mul<FS>(acc1, fe_add<FS>(ks.one, fe_mul<FS>(ch, pw1))); pw1 = fe_sqr<FS>(pw1);
         }
-        term(e[0], e[1]);
+        term(acc0, acc1);
     }
-    term(pub_e[0], pub_e[1]);
+    term(x[XF_PUB0], x[XF_PUB1]);
     term(ft, fe_to_mont<FS>(load_fe<FS>(in.ft_eval1 + (size_t)b * 8), ks.r2));
+#pragma unroll 1
     for (uint32_t c = 0; c < KC_COLS; ++c) term(EV(c, 0), EV(c, 1));
-    store_fe<LANES>(out.cip + (size_t)b * 8, fe_from_mont<FS>(cip));
-    store_fe<LANES>(out.evalpoints + (size_t)b * 16, fe_from_mont<FS>(zeta)); store_fe<LANES>(out.evalpoints + (size_t)b * 16 + 8, fe_from_mont<FS>(zetaw));
-    store_fe<LANES>(out.polyscale + (size_t)b * 8, fe_from_mont<FS>(v)); store_fe<LANES>(out.evalscale + (size_t)b * 8, fe_from_mont<FS>(u));
-    if (out.ft_eval0) store_fe<LANES>(out.ft_eval0 + (size_t)b * 8, fe_from_mont<FS>(ft));
+    auto put = [](uint32_t *p, const fe_t &a) { for (int i = 0; i < 8; ++i) p[i] = a.v[i]; };
+    put(out.cip + (size_t)b * 8, fe_from_mont<FS>(cip));
+    put(out.evalpoints + (size_t)b * 16, fe_from_mont<FS>(zeta)); put(out.evalpoints + (size_t)b * 16 + 8, fe_from_mont<FS>(zetaw));
+    put(out.polyscale + (size_t)b * 8, fe_from_mont<FS>(v)); put(out.evalscale + (size_t)b * 8, fe_from_mont<FS>(u));
+    if (out.ft_eval0) put(out.ft_eval0 + (size_t)b * 8, fe_from_mont<FS>(ft));
+    // scalars of ft_comm = perm_scalar * sigma_6 - (zeta^n - 1) * sum_i zeta^(n i) t_i   (plain words: the bits drive double-and-add)
+    x[XF_FTSC] = fe_from_mont<FS>(fe_neg<FS>(fe_mul<FS>(fe_mul<FS>(z1, beta), common)));
+    fe_t sc = fe_neg<FS>(zm1);
+    for (uint32_t j = 1; j < 8; ++j) { x[XF_FTSC + j] = fe_from_mont<FS>(sc); sc = fe_mul<FS>(sc, zeta1); }
+    if (!ok) *bad_input = 1u;
+}
 
-    // ---- ft_comm = perm_scalar * sigma_6 - (zeta^n - 1) * sum_i zeta^(n i) t_i : term j on lane j mod LANES, then a shuffle tree
-    xyzz_t part = xyzz_inf();
-    {
-        fe_t zpow = ks.one;                                            // zeta^(n i)
-        const fe_t neg_zm1 = fe_neg<FS>(fe_sub<FS>(zeta1, ks.one));
-        for (uint32_t j = 0; j < 8; ++j) {
-            fe_t sc; affine_t P;
-            if (j == 0) { sc = perm_scalar; P = ix->sigma6; }
-            else { sc = fe_mul<FS>(neg_zm1, zpow); zpow = fe_mul<FS>(zpow, zeta1); bool dummy = true; P = load_point_checked<FB>(in.t_comm + ((size_t)b * 7 + (j - 1)) * 16, kb, dummy); }
-            if ((j & (LANES - 1)) == ln) { xyzz_t r = scalar_mul_affine<FB>(fe_from_mont<FS>(sc), P, kb); xyzz_add<FB>(part, r); }
-        }
-        for (int m = 1; m < LANES; m <<= 1) { const xyzz_t o2 = xyzz_shfl_xor(part, m); xyzz_add<FB>(part, o2); }
-    }
-    if (ln == 0) {
-        uint32_t *o = comms_out + (n_prev + 1) * 16;
+// 8 lanes per proof: term j on lane j, then a shuffle tree; lane 0 normalises and writes row n_prev + 1.  The t commitments were
+// checked by the fq stage (a malformed one already failed the batch)
+__global__ void __launch_bounds__(64)
+kimchi_ftcomm_kernel(uint32_t batch, uint32_t n_prev, FieldK kb, const KimchiIndexDev *__restrict__ ix, KimchiIn in, KimchiOut out, const fe_t *__restrict__ xf) {
+    constexpr int FB = FIELD_FP;
+    const uint32_t gid = blockIdx.x * 64 + threadIdx.x, b = gid >> 3, j = gid & 7u;
+    if (b >= batch) return;
+    const fe_t sc = xf[(size_t)b * KC_XF + XF_FTSC + j];
+    const affine_t P = j == 0 ? ix->sigma6 : load_point_mont<FB>(in.t_comm + ((size_t)b * 7 + (j - 1)) * 16, kb);
+    xyzz_t part = scalar_mul_affine<FB>(sc, P, kb);
+    for (int m = 1; m < 8; m <<= 1) { const xyzz_t o2 = xyzz_shfl_xor(part, m); xyzz_add<FB>(part, o2); }
+    if (j == 0) {
+        uint32_t *o = out.comms + ((size_t)b * (n_prev + 2 + KC_COLS) + n_prev + 1) * 16;
         if (xyzz_is_inf(part)) { for (int i = 0; i < 16; ++i) o[i] = 0; }
         else {
             const fe_t zi = fe_inv<FB>(fe_mul<FB>(part.zz, part.zzz), kb);
             const fe_t x = fe_from_mont<FB>(fe_mul<FB>(part.x, fe_mul<FB>(zi, part.zzz))), y = fe_from_mont<FB>(fe_mul<FB>(part.y, fe_mul<FB>(zi, part.zz)));
             for (int i = 0; i < 8; ++i) { o[i] = x.v[i]; o[8 + i] = y.v[i]; }
         }
-        // the 43 column commitments: z, 6 selectors (index), 15 w, 15 coefficients (index), 6 sigma (index)
-        uint32_t *cc = comms_out + (n_prev + 2) * 16;
-        for (int i = 0; i < 16; ++i) cc[i] = in.z_comm[(size_t)b * 16 + i];
-        for (int i = 0; i < 6 * 16; ++i) cc[16 + i] = ix->col_comm_words[i];
-        for (int i = 0; i < 15 * 16; ++i) cc[7 * 16 + i] = in.w_comm[(size_t)b * 15 * 16 + i];
-        for (int i = 0; i < 21 * 16; ++i) cc[22 * 16 + i] = ix->col_comm_words[6 * 16 + i];
-        if (!ok) *bad_input = 1u;
     }
+}
+
+// the rows of the commitment list that are copies: recursion accumulators, the public-input commitment, then the 43 columns
+// z, 6 selectors (index), 15 w, 15 coefficients (index), 6 sigma (index).  Row n_prev + 1 (ft) belongs to the ftcomm stage.
+__global__ void __launch_bounds__(256)
+kimchi_rows_kernel(uint32_t batch, uint32_t n_prev, const KimchiIndexDev *__restrict__ ix, KimchiIn in, uint32_t *__restrict__ comms) {
+    const uint32_t ncomms = n_prev + 2 + KC_COLS;
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (size_t)batch * ncomms * 16) return;
+    const uint32_t w = (uint32_t)(gid & 15u), row = (uint32_t)((gid >> 4) % ncomms); const size_t b = (gid >> 4) / ncomms;
+    uint32_t val;
+    if (row < n_prev) val = in.prev_comms[(b * n_prev + row) * 16 + w];
+    else if (row == n_prev) val = in.pubcomm[b * 16 + w];
+    else if (row == n_prev + 1) return;
+    else {
+        const uint32_t c = row - (n_prev + 2);
+        if (c == 0) val = in.z_comm[b * 16 + w];
+        else if (c < 7) val = ix->col_comm_words[(c - 1) * 16 + w];
+        else if (c < 22) val = in.w_comm[(b * 15 + (c - 7)) * 16 + w];
+        else val = ix->col_comm_words[(6 + (c - 22)) * 16 + w];
+    }
+    comms[gid] = val;
 }
 
 }  // namespace mb
@@ -324,12 +433,28 @@ int mb_kimchi_to_batch_dev(mina_ctx *c, size_t batch, uint32_t n_prev, uint32_t 
     if (!c->have_kimchi) return fail(MINA_ERR_STATE, "no verifier index installed");
     const PoseidonParams *ppb = c->pparams[FIELD_FP].as<PoseidonParams>(), *pps = c->pparams[FIELD_FQ].as<PoseidonParams>();
     ProfScope ps_(c, PS_KIMCHI);
-    if (use_coop8(c, batch))
-        mb::kimchi_to_batch_kernel<8><<<cdiv(batch * 8, 64), 64, 0, c->L->stream>>>((uint32_t)batch, n_prev, npub, c->fk[FIELD_FP], c->fk[FIELD_FQ], ppb, pps,
-            c->kimchi_index.as<mb::KimchiIndexDev>(), c->kimchi_tokens.as<mb::KimchiToken>(), c->kimchi_literals.as<fe_t>(), in, out, d_bad);
-    else
-        mb::kimchi_to_batch_kernel<4><<<cdiv(batch * 4, 64), 64, 0, c->L->stream>>>((uint32_t)batch, n_prev, npub, c->fk[FIELD_FP], c->fk[FIELD_FQ], ppb, pps,
-            c->kimchi_index.as<mb::KimchiIndexDev>(), c->kimchi_tokens.as<mb::KimchiToken>(), c->kimchi_literals.as<fe_t>(), in, out, d_bad);
+    Lane &L = *c->L;
+    int rc;
+    if ((rc = L.kc_xfer.ensure(batch * mb::KC_XF * sizeof(fe_t)))) return rc;
+    fe_t *xf = L.kc_xfer.as<fe_t>();
+    const mb::KimchiIndexDev *ix = c->kimchi_index.as<mb::KimchiIndexDev>();
+    const uint32_t B = (uint32_t)batch, ncomms = n_prev + 2 + mb::KC_COLS;
+    const FieldK &kb = c->fk[FIELD_FP], &ks = c->fk[FIELD_FQ];
+    mb::kimchi_rows_kernel<<<cdiv(batch * ncomms * 16, 256), 256, 0, L.stream>>>(B, n_prev, ix, in, out.comms);
+    // 8-lane sponges up to 1024 proofs per call (shortest dependent chain), 3-lane above: measured on bench.py --kimchi, 8192 proofs
+    // per step -- 16 x 512: 165 k/s (8-lane) vs 162 k/s; 4 x 2048: 137 k/s (8-lane) vs 150 k/s (3-lane).  MINA_KIMCHI_COOP8_MAX overrides (tuning)
+    static const size_t coop8_max = [] { const char *e = getenv("MINA_KIMCHI_COOP8_MAX"); return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)1024; }();
+    if (batch <= coop8_max) {
+        mb::kimchi_fq_kernel<8><<<cdiv(coop_threads<8>(2 * batch), 64), 64, 0, L.stream>>>(B, n_prev, kb, ks, ppb, pps, ix, in, out, xf, d_bad);
+        mb::kimchi_pub_kernel<<<cdiv(batch * 8, 64), 64, 0, L.stream>>>(B, npub, ks, ix, in, xf, d_bad);
+        mb::kimchi_fr_kernel<8><<<cdiv(coop_threads<8>(batch), 64), 64, 0, L.stream>>>(B, ks, pps, in, xf, d_bad);
+    } else {                        // chip-filling batch: 21 sponges per wave
+        mb::kimchi_fq_kernel<3><<<cdiv(coop_threads<3>(2 * batch), 64), 64, 0, L.stream>>>(B, n_prev, kb, ks, ppb, pps, ix, in, out, xf, d_bad);
+        mb::kimchi_pub_kernel<<<cdiv(batch * 8, 64), 64, 0, L.stream>>>(B, npub, ks, ix, in, xf, d_bad);
+        mb::kimchi_fr_kernel<3><<<cdiv(coop_threads<3>(batch), 64), 64, 0, L.stream>>>(B, ks, pps, in, xf, d_bad);
+    }
+    mb::kimchi_scalar_kernel<<<cdiv(batch, 64), 64, 0, L.stream>>>(B, n_prev, ks, ix, c->kimchi_tokens.as<mb::KimchiToken>(), c->kimchi_literals.as<fe_t>(), in, out, xf, d_bad);
+    mb::kimchi_ftcomm_kernel<<<cdiv(batch * 8, 64), 64, 0, L.stream>>>(B, n_prev, kb, ix, in, out, xf);
     HIPC(hipGetLastError());
     return MINA_OK;
 }
