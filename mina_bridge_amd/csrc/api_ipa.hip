@@ -95,7 +95,7 @@ ipa_prepare_kernel(IpaShape sh, FieldK kb, FieldK ks, const PoseidonParams *__re
                    const uint32_t *__restrict__ sg /* b*16 */, const uint32_t *__restrict__ z1, const uint32_t *__restrict__ z2,
                    const uint32_t *__restrict__ evalpoints /* b*npts*8 */, const uint32_t *__restrict__ evalscale,
                    const uint32_t *__restrict__ polyscale, const uint32_t *__restrict__ comms /* b*ncomms*16 */,
-                   const uint32_t *__restrict__ comm_override /* b*16 or null */,
+                   const uint32_t *__restrict__ comm_override /* b*16 or null */, IpaExpand ex,
                    const uint32_t *__restrict__ rand_base, const uint32_t *__restrict__ sg_rand_base,
                    const affine_t *__restrict__ srs_h,
                    affine_t *__restrict__ out_points /* b*per */, uint32_t *__restrict__ out_scalars /* b*per*8 canonical */,
@@ -230,10 +230,20 @@ ipa_prepare_kernel(IpaShape sh, FieldK kb, FieldK ks, const PoseidonParams *__re
     }
     const fe_t xi = load_scalar_checked(polyscale + (size_t)b * 8);
     fe_t xi_i = ks.one;
+    uint32_t o = 4 + 2 * k;
     for (uint32_t i = 0; i < sh.ncomms; ++i) {
-        const uint32_t *cp = (i == sh.override_slot && comm_override) ? comm_override + (size_t)b * 16 : comms + ((size_t)b * sh.ncomms + i) * 16;
-        store_pt<LANES>(&pts[4 + 2 * k + i], load_point_checked<FB>(cp, kb, pts_ok));
-        store_fe<LANES>(scs + (size_t)(4 + 2 * k + i) * 8, fe_from_mont<FS>(fe_mul<FS>(rho_c, xi_i)));
+        const fe_t wgt = fe_mul<FS>(rho_c, xi_i);
+        if (i == sh.expand_slot) {                            // a linear combination in place of the point: the MSM evaluates it
+            for (uint32_t j = 0; j < IPA_EXPAND; ++j, ++o) {
+                store_pt<LANES>(&pts[o], j == 0 ? *ex.p0 : load_point_checked<FB>(ex.pts + ((size_t)b * (IPA_EXPAND - 1) + (j - 1)) * 16, kb, pts_ok));
+                store_fe<LANES>(scs + (size_t)o * 8, fe_from_mont<FS>(fe_mul<FS>(wgt, ex.sc[(size_t)b * ex.stride + j])));
+            }
+        } else {
+            const uint32_t *cp = (i == sh.override_slot && comm_override) ? comm_override + (size_t)b * 16 : comms + ((size_t)b * sh.ncomms + i) * 16;
+            store_pt<LANES>(&pts[o], load_point_checked<FB>(cp, kb, pts_ok));
+            store_fe<LANES>(scs + (size_t)o * 8, fe_from_mont<FS>(wgt));
+            ++o;
+        }
         xi_i = fe_mul<FS>(xi_i, xi);
     }
     store_fe<LANES>(out_sigma + (size_t)b * 8, fe_from_mont<FS>(sigma));
@@ -443,7 +453,7 @@ int mb_ipa_batch_check_dev(mina_ctx *c, int curve, mb::IpaShape sh, const mb::Ip
 #define IPA_PREP(CV, LN, PH, STREAM)                                                                                          \
     mb::ipa_prepare_kernel<CV, LN, PH><<<cdiv(batch * LN, 64), 64, 0, STREAM>>>(                                                      \
         sh, c->fk[FB], c->fk[FS], pp, in.state, in.pos, in.cip, in.lr, in.delta, in.sg, in.z1, in.z2, in.pts, in.r, \
-        in.xi, in.comms, in.comm_override, in.rb, in.sb, s.h.as<affine_t>(), c->L->ipa_points.as<affine_t>(), c->L->ipa_scalars.as<uint32_t>(), \
+        in.xi, in.comms, in.comm_override, in.expand, in.rb, in.sb, s.h.as<affine_t>(), c->L->ipa_points.as<affine_t>(), c->L->ipa_scalars.as<uint32_t>(), \
         c->L->ipa_chals.as<uint32_t>(), c->L->ipa_sigma.as<uint32_t>(), d_verdict + 1, c->L->ipa_xfer.as<uint32_t>())
     { ProfScope ps_(c, PS_IPA_TRANSCRIPT);
     if (use_coop8(c, batch)) {

@@ -303,21 +303,22 @@ kimchi_scalar_kernel(uint32_t batch, uint32_t n_prev, FieldK ks, const KimchiInd
     put(out.evalpoints + (size_t)b * 16, fe_from_mont<FS>(zeta)); put(out.evalpoints + (size_t)b * 16 + 8, fe_from_mont<FS>(zetaw));
     put(out.polyscale + (size_t)b * 8, fe_from_mont<FS>(v)); put(out.evalscale + (size_t)b * 8, fe_from_mont<FS>(u));
     if (out.ft_eval0) put(out.ft_eval0 + (size_t)b * 8, fe_from_mont<FS>(ft));
-    // scalars of ft_comm = perm_scalar * sigma_6 - (zeta^n - 1) * sum_i zeta^(n i) t_i   (plain words: the bits drive double-and-add)
-    x[XF_FTSC] = fe_from_mont<FS>(fe_neg<FS>(fe_mul<FS>(fe_mul<FS>(z1, beta), common)));
+    // scalars of ft_comm = perm_scalar * sigma_6 - (zeta^n - 1) * sum_i zeta^(n i) t_i
+    x[XF_FTSC] = fe_neg<FS>(fe_mul<FS>(fe_mul<FS>(z1, beta), common));
     fe_t sc = fe_neg<FS>(zm1);
-    for (uint32_t j = 1; j < 8; ++j) { x[XF_FTSC + j] = fe_from_mont<FS>(sc); sc = fe_mul<FS>(sc, zeta1); }
+    for (uint32_t j = 1; j < 8; ++j) { x[XF_FTSC + j] = sc; sc = fe_mul<FS>(sc, zeta1); }
     if (!ok) *bad_input = 1u;
 }
 
 // 8 lanes per proof: term j on lane j, then a shuffle tree; lane 0 normalises and writes row n_prev + 1.  The t commitments were
-// checked by the fq stage (a malformed one already failed the batch)
+// checked by the fq stage (a malformed one already failed the batch).  Only the host-buffer form (`mina_kimchi_to_batch`, which
+// returns the rows) runs this: the verifier hands the 8 (point, scalar) pairs to the opening check's MSM instead (IpaExpand)
 __global__ void __launch_bounds__(64)
 kimchi_ftcomm_kernel(uint32_t batch, uint32_t n_prev, FieldK kb, const KimchiIndexDev *__restrict__ ix, KimchiIn in, KimchiOut out, const fe_t *__restrict__ xf) {
     constexpr int FB = FIELD_FP;
     const uint32_t gid = blockIdx.x * 64 + threadIdx.x, b = gid >> 3, j = gid & 7u;
     if (b >= batch) return;
-    const fe_t sc = xf[(size_t)b * KC_XF + XF_FTSC + j];
+    const fe_t sc = fe_from_mont<FIELD_FQ>(xf[(size_t)b * KC_XF + XF_FTSC + j]);      // plain words: the bits drive double-and-add
     const affine_t P = j == 0 ? ix->sigma6 : load_point_mont<FB>(in.t_comm + ((size_t)b * 7 + (j - 1)) * 16, kb);
     xyzz_t part = scalar_mul_affine<FB>(sc, P, kb);
     for (int m = 1; m < 8; m <<= 1) { const xyzz_t o2 = xyzz_shfl_xor(part, m); xyzz_add<FB>(part, o2); }
@@ -429,7 +430,9 @@ extern "C" int mina_verifier_index_digest(mina_ctx *c, uint8_t *out32) {
 }
 
 // queue oracles + to_batch for `batch` proofs on the current lane; every pointer is a device pointer
-int mb_kimchi_to_batch_dev(mina_ctx *c, size_t batch, uint32_t n_prev, uint32_t npub, const mb::KimchiIn &in, const mb::KimchiOut &out, uint32_t *d_bad) {
+// `expand` non-null: row n_prev + 1 of the commitment list is NOT computed; *expand describes it as 8 (point, scalar) pairs for
+// mb_ipa_batch_check_dev (IpaShape::expand_slot = n_prev + 1)
+int mb_kimchi_to_batch_dev(mina_ctx *c, size_t batch, uint32_t n_prev, uint32_t npub, const mb::KimchiIn &in, const mb::KimchiOut &out, uint32_t *d_bad, mb::IpaExpand *expand) {
     if (!c->have_kimchi) return fail(MINA_ERR_STATE, "no verifier index installed");
     const PoseidonParams *ppb = c->pparams[FIELD_FP].as<PoseidonParams>(), *pps = c->pparams[FIELD_FQ].as<PoseidonParams>();
     ProfScope ps_(c, PS_KIMCHI);
@@ -454,7 +457,8 @@ int mb_kimchi_to_batch_dev(mina_ctx *c, size_t batch, uint32_t n_prev, uint32_t 
         mb::kimchi_fr_kernel<3><<<cdiv(coop_threads<3>(batch), 64), 64, 0, L.stream>>>(B, ks, pps, in, xf, d_bad);
     }
     mb::kimchi_scalar_kernel<<<cdiv(batch, 64), 64, 0, L.stream>>>(B, n_prev, ks, ix, c->kimchi_tokens.as<mb::KimchiToken>(), c->kimchi_literals.as<fe_t>(), in, out, xf, d_bad);
-    mb::kimchi_ftcomm_kernel<<<cdiv(batch * 8, 64), 64, 0, L.stream>>>(B, n_prev, kb, ix, in, out, xf);
+    if (expand) { expand->p0 = &ix->sigma6; expand->pts = in.t_comm; expand->sc = xf + mb::XF_FTSC; expand->stride = mb::KC_XF; }
+    else mb::kimchi_ftcomm_kernel<<<cdiv(batch * 8, 64), 64, 0, L.stream>>>(B, n_prev, kb, ix, in, out, xf);
     HIPC(hipGetLastError());
     return MINA_OK;
 }
@@ -498,7 +502,7 @@ extern "C" int mina_kimchi_to_batch(mina_ctx *c, const mina_kimchi_proofs *p, mi
     else { std::vector<uint8_t> hb(B * 64); uint8_t h1[64]; if ((rc = mina_srs_get_h(c, CURVE_PALLAS, h1))) return rc; c->use_lane0(); for (size_t i = 0; i < B; ++i) memcpy(&hb[i * 64], h1, 64); HIPC(hipMemcpyAsync(d + o_pc, hb.data(), B * 64, hipMemcpyHostToDevice, L.stream)); HIPC(hipStreamSynchronize(L.stream)); }
     mb::KimchiIn in{W(secs[0].off), W(secs[1].off), W(secs[2].off), W(secs[3].off), W(secs[4].off), W(secs[5].off), W(secs[6].off), W(secs[7].off), W(o_pc)};
     mb::KimchiOut out{W(o_state), W(o_pos), W(o_cip), W(o_pts), W(o_v), W(o_u), W(o_comms), W(o_ft)};
-    if ((rc = mb_kimchi_to_batch_dev(c, B, p->n_prev, p->npub, in, out, W(o_bad)))) return rc;
+    if ((rc = mb_kimchi_to_batch_dev(c, B, p->n_prev, p->npub, in, out, W(o_bad), nullptr))) return rc;
     std::vector<uint8_t> back(all - o_state);
     HIPC(hipMemcpyAsync(back.data(), d + o_state, back.size(), hipMemcpyDeviceToHost, L.stream));
     HIPC(hipStreamSynchronize(L.stream));

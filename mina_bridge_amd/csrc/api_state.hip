@@ -253,7 +253,7 @@ namespace mb {   // api_kimchi.hip
 struct KimchiIn { const uint32_t *pub, *prev_chals, *prev_comms, *w_comm, *z_comm, *t_comm, *evals, *ft_eval1, *pubcomm; };
 struct KimchiOut { uint32_t *sponge_state, *sponge_pos, *cip, *evalpoints, *polyscale, *evalscale, *comms, *ft_eval0; };
 }
-int mb_kimchi_to_batch_dev(mina_ctx *c, size_t batch, uint32_t n_prev, uint32_t npub, const mb::KimchiIn &in, const mb::KimchiOut &out, uint32_t *d_bad);
+int mb_kimchi_to_batch_dev(mina_ctx *c, size_t batch, uint32_t n_prev, uint32_t npub, const mb::KimchiIn &in, const mb::KimchiOut &out, uint32_t *d_bad, mb::IpaExpand *expand);
 
 // public-input commitments h - sum_i pub_i L_i of `batch` proofs as canonical affine words (16 per proof) on the current lane
 int mb_pubcomm_dev(mina_ctx *c, size_t batch, uint32_t log2_domain, uint32_t npub, const uint32_t *d_pub, uint32_t *d_out16) {
@@ -350,9 +350,12 @@ static int state_jobs_on_lane(mina_ctx *c, const mina_state_jobs *j, uint32_t *d
             mb::KimchiIn in{W(kp.public_inputs), W(kp.prev_chals), W(kp.prev_comms), W(kp.w_comm), W(kp.z_comm), W(kp.t_comm), W(kp.evals), W(kp.ft_eval1), comm_override};
             mb::KimchiOut out{L.kc_state.as<uint32_t>(), L.kc_pos.as<uint32_t>(), L.kc_cip.as<uint32_t>(), L.kc_pts.as<uint32_t>(), L.kc_v.as<uint32_t>(), L.kc_u.as<uint32_t>(),
                               L.kc_comms.as<uint32_t>(), nullptr};
-            if ((rc = mb_kimchi_to_batch_dev(c, B, kp.n_prev, kp.npub, in, out, kimchi_bad))) { c->L = L0; return rc; }
+            mb::IpaExpand ex;
+            if ((rc = mb_kimchi_to_batch_dev(c, B, kp.n_prev, kp.npub, in, out, kimchi_bad, &ex))) { c->L = L0; return rc; }
+            sh.expand_slot = kp.n_prev + 1; sh.per += mb::IPA_EXPAND - 1;          // the ft commitment enters the MSM as its 8 terms
             mb::IpaDevIn iin{out.sponge_state, out.sponge_pos, out.cip, W(j->lr), W(j->delta), W(j->sg), W(j->z1), W(j->z2), out.evalpoints, out.evalscale, out.polyscale,
                              out.comms, nullptr, W(j->rand_base), W(j->sg_rand_base)};
+            iin.expand = ex;
             if ((rc = mb_ipa_batch_check_dev(c, CURVE_PALLAS, sh, iin, ipa_v))) { c->L = L0; return rc; }
         } else {
             sh.override_slot = j->npub ? j->pub_comm_slot : 0xffffffffu;

@@ -168,11 +168,18 @@ struct ProfScope {
 
 // combined IPA opening check with inputs in HBM (api_ipa.hip)
 namespace mb {
-struct IpaShape { uint32_t batch, k, npts, ncomms, per; uint32_t override_slot = 0xffffffffu; };   // per = 2k + ncomms + 4 points per proof;
+struct IpaShape { uint32_t batch, k, npts, ncomms, per; uint32_t override_slot = 0xffffffffu, expand_slot = 0xffffffffu; };   // per = 2k + ncomms + 4 points per proof
 // override_slot: commitment index whose point comes from `comm_override` (b*16 canonical words, e.g. the public-input commitment computed on the GPU)
+// expand_slot: commitment index given as a linear combination instead of a point (kimchi's chunked ft commitment): its list entry becomes
+//   IPA_EXPAND entries (point_j, weight * expand_sc[j]), so the combination is evaluated by the batch MSM; per grows by IPA_EXPAND - 1
+static constexpr uint32_t IPA_EXPAND = 8;
+struct IpaExpand {    // point 0 = *p0 (Montgomery, trusted index data), points 1..7 = pts + b*7*16 (canonical words, checked); scalars sc[b*stride + j] (Montgomery)
+    const affine_t *p0 = nullptr; const uint32_t *pts = nullptr; const fe_t *sc = nullptr; uint32_t stride = 0;
+};
 struct IpaDevIn {     // structure-of-arrays over the batch, canonical little-endian words; layouts as in mina_ipa_opening
     const uint32_t *state /* b*24 */, *pos /* b*2 */, *cip /* b*8 */, *lr /* b*2k*16 */, *delta /* b*16 */, *sg /* b*16 */, *z1, *z2 /* b*8 */,
                    *pts /* b*npts*8 */, *r /* b*8 */, *xi /* b*8 */, *comms /* b*ncomms*16 */, *comm_override /* b*16 or null */, *rb /* 8 */, *sb /* 8 */;
+    IpaExpand expand;
 };
 }
 int mb_ipa_batch_check_dev(mina_ctx *c, int curve, mb::IpaShape sh, const mb::IpaDevIn &in, uint32_t *d_verdict /* [0] verdict, [1] malformed flag */);
