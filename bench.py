@@ -48,7 +48,7 @@ HBM_PEAK_GBPS = 8000.0                                # MI355X_MICROARCH.md: 8 T
 MODMUL_ISSUE_FLOOR_CYCLES = 88 * 8
 CHIP_SIMDS, CLOCK_HZ = 1024, 2.4e9
 MODMUL_PER_PERMUTATION = 55 * (3 * 4 + 9)             # x^7 = 4 products x 3, MDS 9 products: 1155
-PROF_STAGES = {"pstate_hash": 11, "ipa_transcript": 12, "kimchi_to_batch": 13, "msm_accumulate": 3}
+PROF_STAGES = {"pstate_hash": 11, "ipa_transcript": 12, "kimchi_to_batch": 13, "pickles_statement": 14, "msm_accumulate": 3}
 # HBM-side bytes per protocol-state hash from the rocprofv3 PMC passes of profiles/r02b_rocprof.md (FETCH_SIZE x 2 -- the gfx950
 # correction of MI355X_MICROARCH.md for 16-B-per-lane loads -- + WRITE_SIZE, KiB x 1024, over the 139 264 states of one launch)
 PSTATE_TRAFFIC_BYTES_PER_STATE = (2 * 130426 + 4352) * 1024 / 139264

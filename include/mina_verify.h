@@ -396,6 +396,7 @@ int mina_msm_dev(mina_ctx *ctx, int curve, size_t n, const void *d_bases /* n*64
 int mina_points_sum_dev(mina_ctx *ctx, int curve, size_t n, const void *d_records /* n*68 */, void *d_out /* record */);
 int mina_point_records_equal_dev(mina_ctx *ctx, const void *d_a, const void *d_b, void *d_verdict /* u32 */);
 
+struct mina_pickles_statements;
 /* ---- kimchi verifier for the Pickles wrap proof (a11): `oracles` + `to_batch` on the GPU ---------------------------------
  * The verifier index is DATA: the reference tree does not hold the blockchain-snark index, so the engine takes domain, shifts,
  * commitments and the linearization's constant term (a PolishToken program in the byte-code below) as a parameter. */
@@ -438,6 +439,10 @@ typedef struct mina_kimchi_proofs {
     const void *w_comm /* b*15*64 */, *z_comm /* b*64 */, *t_comm /* b*7*64 */;
     const void *evals;                 /* b * 43 * 2 * 32: column order of MINA_TOK_CELL, [zeta, zeta*omega] */
     const void *ft_eval1;              /* b * 32 */
+    /* NULL, or the Pickles statements the public inputs are DERIVED from on the GPU (needs mina_step_index_install; npub must be 40
+     * and public_inputs is ignored): compute_deferred_values + the message digests + the packing run ahead of `oracles`, and a
+     * malformed statement fails its proof.  Host struct; inner pointers host or device like the sections above. */
+    const struct mina_pickles_statements *statements;
 } mina_kimchi_proofs;
 typedef struct {                       /* one `BatchEvaluationProof` row per proof, host buffers */
     uint8_t *sponge_state /* b*96 */; uint32_t *sponge_pos /* b*2 */; uint8_t *cip /* b*32 */, *evalpoints /* b*64: zeta, zeta*omega */,
@@ -454,13 +459,37 @@ int mina_kimchi_to_batch(mina_ctx *ctx, const mina_kimchi_proofs *proofs, mina_k
  * runs on these public inputs (every statement field is then bound to the proof); without one it runs with none. */
 typedef struct {
     uint32_t zk_rows;                 /* 3 */
-    uint32_t n_domains;               /* step domains in use */
+    uint32_t n_domains;               /* step domains in use (<= 8) */
     const uint32_t *domain_log2;      /* n_domains */
     const uint8_t *shifts;            /* n_domains * 7 * 32 (Fp) */
     const uint8_t *constant_term;     /* PolishToken byte-code over Fp */
     size_t constant_term_len;
 } mina_step_index;
 int mina_step_index_install(mina_ctx *ctx, const mina_step_index *index);
+/* The statements of `batch` wrap proofs, structure-of-arrays (what `compute_deferred_values` and the two message digests read).
+ * 128-bit challenges are 16 little-endian bytes; field elements 32.  Every proof of one call has the same n_old / n_evals. */
+typedef struct mina_pickles_statements {
+    uint32_t n_old;                     /* step-side previous accumulators per proof (0..4; Mina blockchain proof: 2) */
+    uint32_t n_evals;                   /* evaluation pairs of the step proof: 43 + the optional ones present (<= 62) */
+    const void *plonk;                  /* b * 64: alpha, beta, gamma, zeta */
+    const void *bulletproof_challenges; /* b * 16 * 16: deferred_values.bulletproof_challenges (step, Tick rounds) */
+    const void *step_old_challenges;    /* b * n_old * 16 * 16: messages_for_next_step_proof.old_bulletproof_challenges */
+    const void *step_comms;             /* b * n_old * 64: messages_for_next_step_proof.challenge_polynomial_commitments */
+    const void *wrap_old_challenges;    /* b * 2 * 15 * 16: messages_for_next_wrap_proof.old_bulletproof_challenges */
+    const void *wrap_sg;                /* b * 64: messages_for_next_wrap_proof.challenge_polynomial_commitment */
+    const void *sponge_digest;          /* b * 32: sponge_digest_before_evaluations (4 x u64, not reduced) */
+    const void *prev_evals;             /* b * n_evals * 64 (Fp): kimchi column order (MINA_TOK_CELL), then the optional ones; (zeta, zeta*omega)
+                                           pairs, chunked evaluations already combined with zeta^(2^16) */
+    const void *prev_public_input;      /* b * 64 (Fp): the step proof's public-input evaluations */
+    const void *prev_ft_eval1;          /* b * 32 (Fp) */
+    const void *app_state;              /* b * 32 (Fp): the application state = hash of the tip protocol state */
+    const void *misc;                   /* b * 32: [0] domain_log2, [1] proofs_verified (0..2), [2..10) feature flags, [10] has joint
+                                           combiner, [16..32) joint combiner */
+} mina_pickles_statements;
+/* statements -> the wrap circuit's 40 public inputs, entirely on the GPU (three sponge kernels, one scalar kernel).  Host buffers.
+ * ok[b] = 0: statement b is malformed (non-canonical element, unknown step domain); its public inputs are then unspecified. */
+int mina_pickles_public_inputs_batch(mina_ctx *ctx, const mina_pickles_statements *st, size_t batch, uint8_t *public_inputs_out /* b*40*32 */,
+                                     uint8_t *ok /* b */);
 /* one serialized wrap proof + the application state (the tip's protocol-state hash) -> public_input_out[40*32] (Fq) and, if
  * derived_out != NULL, 7*32 bytes: combined_inner_product, b, zeta^(2^16), zeta^n, perm, xi, r (Fp).  Sponges run on the GPU. */
 int mina_pickles_public_input(mina_ctx *ctx, const uint8_t *wrap_proof, size_t len, int encoding, const uint8_t *app_state /* 32 */,

@@ -71,6 +71,7 @@ extern "C" void mina_ctx_destroy(mina_ctx *c) {
     for (int i = 0; i < MB_MAX_LANES; ++i) if (c->lanes[i].stream) (void)hipStreamSynchronize(c->lanes[i].stream);
     for (int i = 0; i < 2; ++i) { c->srs[i].table.release(); c->srs[i].h.release(); c->pparams[i].release(); c->merkle_salts[i].release(); }
     c->state_salts.release(); c->kimchi_index.release(); c->kimchi_tokens.release(); c->kimchi_literals.release();
+    c->pickles_index.release(); c->pickles_tokens.release(); c->pickles_literals.release();
     for (int i = 0; i < MB_MAX_LANES; ++i) c->lanes[i].release_all();
     for (auto &r : c->prof.recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (int i = 0; i < MB_MAX_LANES; ++i) {
@@ -160,7 +161,7 @@ extern "C" int mina_field_sqrt(mina_ctx *c, int field, size_t n, const uint8_t *
 // ------------------------------------------------------------------------------------------------
 // stage timing
 static const char *PROF_NAMES[PS_COUNT] = {"msm_digits", "msm_scan", "msm_scatter", "msm_accumulate", "msm_bucket_sum", "msm_segsum",
-                                           "msm_reduce2d", "msm_finish", "bpoly_tables", "bpoly_fold", "bpoly_finish", "pstate_hash", "ipa_transcript", "kimchi_to_batch"};
+                                           "msm_reduce2d", "msm_finish", "bpoly_tables", "bpoly_fold", "bpoly_finish", "pstate_hash", "ipa_transcript", "kimchi_to_batch", "pickles_statement"};
 void mb_prof_begin(mina_ctx *c, int stage) {
     ProfState &p = c->prof;
     if (p.used == p.recs.size()) {

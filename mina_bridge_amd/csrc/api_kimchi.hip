@@ -17,11 +17,10 @@
 #include "msm.cuh"
 #include "sponge.cuh"
 #include "wire_proof.h"
-#include "polish.h"
+#include "kimchi_dev.cuh"
 
 namespace mb {
 
-static constexpr uint32_t KC_COLS = 43, KC_W0 = 7, KC_C0 = 22, KC_S0 = 37, KC_MAX_ZK = 8;
 struct KimchiIndexDev {
     uint32_t log2_domain, zk_rows, perm_alpha_offset, n_tokens;
     fe_t shifts[7];                                    // scalar field, Montgomery
@@ -34,24 +33,6 @@ struct KimchiIndexDev {
 struct KimchiIn { const uint32_t *pub, *prev_chals, *prev_comms, *w_comm, *z_comm, *t_comm, *evals, *ft_eval1, *pubcomm; };
 struct KimchiOut { uint32_t *sponge_state, *sponge_pos, *cip, *evalpoints, *polyscale, *evalscale, *comms, *ft_eval0; };
 
-template <int F> __device__ __forceinline__ fe_t ld_checked(const uint32_t *p, const FieldK &k, bool &ok) {
-    const fe_t w = load_fe<F>(p); ok = ok && fe_words_canonical<F>(w); return fe_to_mont<F>(w, k.r2);
-}
-template <int F> __device__ __forceinline__ fe_t fe_pow2k(fe_t a, uint32_t k) { for (uint32_t i = 0; i < k; ++i) a = fe_sqr<F>(a); return a; }
-template <int F> __device__ fe_t fe_pow_u64(const fe_t &a, uint64_t e, const fe_t &one) {
-    fe_t r = one, b = a;
-    for (; e; e >>= 1) { if (e & 1) r = fe_mul<F>(r, b); b = fe_sqr<F>(b); }
-    return r;
-}
-// 128-bit squeeze as a plain scalar-field element (kimchi `fq_sponge.challenge()`: beta, gamma)
-template <int FS> __device__ __forceinline__ fe_t chal128_plain(const fe_t &sq_plain, const FieldK &ks) {
-    fe_t o = fe_zero(); o.v[0] = sq_plain.v[0]; o.v[1] = sq_plain.v[1]; o.v[2] = sq_plain.v[2]; o.v[3] = sq_plain.v[3];
-    return fe_to_mont<FS>(o, ks.r2);
-}
-template <int FS> __device__ __forceinline__ fe_t chal_endo(const fe_t &sq_plain, const FieldK &ks) {
-    const uint64_t lo = (uint64_t)sq_plain.v[0] | ((uint64_t)sq_plain.v[1] << 32), hi = (uint64_t)sq_plain.v[2] | ((uint64_t)sq_plain.v[3] << 32);
-    return challenge_to_field<FS>(lo, hi, ks);
-}
 __device__ __forceinline__ xyzz_t xyzz_shfl_xor(const xyzz_t &a, int mask) {
     xyzz_t r;
     for (int i = 0; i < 8; ++i) { r.x.v[i] = (uint32_t)__shfl_xor((int)a.x.v[i], mask, 64); r.y.v[i] = (uint32_t)__shfl_xor((int)a.y.v[i], mask, 64);
@@ -82,7 +63,6 @@ template <int FB> __device__ xyzz_t scalar_mul_affine(const fe_t &s_plain, const
 // Values pass between stages through `xf` (KC_XF scalar-field Montgomery elements per proof).
 enum { XF_BETA = 0, XF_GAMMA, XF_ALPHA, XF_ZETA, XF_DIGEST, XF_PFDIGEST, XF_PUB0, XF_PUB1, XF_V, XF_U, XF_FTSC = 10, KC_XF = 18 };
 
-template <int LANES> __device__ __forceinline__ uint32_t coop_lane() { return LANES == 3 ? tri_pos().e : (threadIdx.x & (LANES - 1)); }
 __device__ __forceinline__ fe_t fe_shfl_xor(const fe_t &a, int mask) {
     fe_t r;
 #pragma unroll
@@ -96,7 +76,6 @@ template <int F, int LANES> __device__ __forceinline__ fe_t coop_sum(const fe_t 
     for (int m = 1; m < LANES; m <<= 1) a = fe_add<F>(a, fe_shfl_xor(a, m));
     return a;
 }
-template <int F, int LANES> __device__ __forceinline__ void sponge_init(DevSponge<F, LANES> &s, const PoseidonParams *pp) { s.pp = pp; s.squeezed = 0; s.count = 0; s.s = fe_zero(); }
 
 template <int LANES>
 __global__ void __launch_bounds__(64)
@@ -134,9 +113,7 @@ kimchi_fq_kernel(uint32_t batch, uint32_t n_prev, FieldK kb, FieldK ks, const Po
     absorb_pts(in.t_comm + (size_t)b * 7 * 16, 7);
     { const fe_t zeta = chal_endo<FS>(fe_from_mont<FB>(fq.squeeze()), ks); if (writer) x[XF_ZETA] = zeta; }
     {   // the sponge handed to the opening check: element e of the state from the lane that owns it
-        const uint32_t ln = coop_lane<LANES>();
-        const bool owner = LANES == 8 ? (ln < 6 && !(ln & 1u)) : (LANES == 3 ? (threadIdx.x & 63u) < 63u : ln < 3);
-        if (owner) { const fe_t w = fe_from_mont<FB>(fq.s); for (int i = 0; i < 8; ++i) out.sponge_state[(size_t)b * 24 + coop_elem<LANES>() * 8 + i] = w.v[i]; }
+        if (coop_state_owner<LANES>()) { const fe_t w = fe_from_mont<FB>(fq.s); for (int i = 0; i < 8; ++i) out.sponge_state[(size_t)b * 24 + coop_elem<LANES>() * 8 + i] = w.v[i]; }
         if (writer) { out.sponge_pos[2 * b] = (uint32_t)fq.squeezed; out.sponge_pos[2 * b + 1] = (uint32_t)fq.count; }
     }
     const fe_t digest = fe_to_mont<FS>(fe_from_mont<FB>(fq.squeeze()), ks.r2);      // on a copy upstream; p < q: always fits.  fq is dead after this
@@ -203,13 +180,7 @@ kimchi_fr_kernel(uint32_t batch, FieldK ks, const PoseidonParams *__restrict__ p
     if (writer) { x[XF_V] = v; x[XF_U] = u; if (!ok) *bad_input = 1u; }
 }
 
-// one lane per proof; the interpreter's stack and cache live in LDS, word-major so that the 64 lanes of a slot hit 64 banks
-static constexpr int KC_SLOTS = KC_STACK + KC_CACHE;
-struct LdsStack {
-    uint32_t *base;
-    __device__ __forceinline__ void put(int slot, const fe_t &a) { for (int i = 0; i < 8; ++i) base[(slot * 8 + i) * 64] = a.v[i]; }
-    __device__ __forceinline__ fe_t get(int slot) const { fe_t a; for (int i = 0; i < 8; ++i) a.v[i] = base[(slot * 8 + i) * 64]; return a; }
-};
+// one lane per proof; the interpreter's stack and cache live in LDS (kimchi_dev.cuh)
 __global__ void __launch_bounds__(64)
 kimchi_scalar_kernel(uint32_t batch, uint32_t n_prev, FieldK ks, const KimchiIndexDev *__restrict__ ix, const KimchiToken *__restrict__ toks,
                      const fe_t *__restrict__ lits, KimchiIn in, KimchiOut out, fe_t *__restrict__ xf, uint32_t *__restrict__ bad_input) {
@@ -222,63 +193,14 @@ kimchi_scalar_kernel(uint32_t batch, uint32_t n_prev, FieldK ks, const KimchiInd
     const uint32_t k = ix->log2_domain;
     const uint32_t *ev = in.evals + (size_t)b * KC_COLS * 16;
     auto EV = [&](uint32_t col, uint32_t row) { return fe_to_mont<FS>(load_fe<FS>(ev + ((size_t)col * 2 + row) * 8), ks.r2); };
-    const fe_t beta = x[XF_BETA], gamma = x[XF_GAMMA], alpha = x[XF_ALPHA], zeta = x[XF_ZETA];
+    const fe_t zeta = x[XF_ZETA];
     const fe_t zeta1 = fe_pow2k<FS>(zeta, k), zetaw = fe_mul<FS>(zeta, ix->omega);
     const fe_t zm1 = fe_sub<FS>(zeta1, ks.one);
-    const fe_t a0 = fe_pow_u64<FS>(alpha, ix->perm_alpha_offset, ks.one);
-    fe_t zkpm = ks.one;
-    for (uint32_t i = 0; i < ix->zk_rows; ++i) zkpm = fe_mul<FS>(zkpm, fe_sub<FS>(zeta, ix->zk_roots[i]));
-    const fe_t z0 = EV(0, 0), z1 = EV(0, 1);
-    fe_t prod6 = ks.one;                                               // prod_{i<6} (gamma + beta s_i + w_i)
-#pragma unroll 1
-    for (uint32_t i = 0; i < 6; ++i) prod6 = fe_mul<FS>(prod6, fe_add<FS>(fe_add<FS>(fe_mul<FS>(beta, EV(KC_S0 + i, 0)), EV(KC_W0 + i, 0)), gamma));
-    const fe_t common = fe_mul<FS>(fe_mul<FS>(a0, zkpm), prod6);
-    fe_t ft = fe_mul<FS>(fe_mul<FS>(fe_add<FS>(EV(KC_W0 + 6, 0), gamma), z1), common);
-    ft = fe_sub<FS>(ft, x[XF_PUB0]);
-    {
-        fe_t t2 = fe_mul<FS>(fe_mul<FS>(a0, zkpm), z0);
-        const fe_t bz = fe_mul<FS>(beta, zeta);
-#pragma unroll 1
-        for (uint32_t i = 0; i < 7; ++i) t2 = fe_mul<FS>(t2, fe_add<FS>(fe_add<FS>(gamma, fe_mul<FS>(bz, ix->shifts[i])), EV(KC_W0 + i, 0)));
-        ft = fe_sub<FS>(ft, t2);
-        const fe_t a1 = fe_mul<FS>(a0, alpha), a2 = fe_mul<FS>(a1, alpha);
-        const fe_t dw = fe_sub<FS>(zeta, ix->omega_zk), d1 = fe_sub<FS>(zeta, ks.one);
-        const fe_t num = fe_mul<FS>(fe_add<FS>(fe_mul<FS>(fe_mul<FS>(zm1, a1), dw), fe_mul<FS>(fe_mul<FS>(zm1, a2), d1)), fe_sub<FS>(ks.one, z0));
-        ft = fe_add<FS>(ft, fe_mul<FS>(num, fe_inv<FS>(fe_mul<FS>(dw, d1), ks)));
-    }
     bool ok = true;
-    if (ix->n_tokens) {   // linearization constant term: PolishToken stack machine (the program is uniform over the lanes: no divergence)
-        int sp = 0, nc = 0; bool prog_ok = true;
-#pragma unroll 1
-        for (uint32_t t = 0; t < ix->n_tokens; ++t) {
-            const KimchiToken tk = toks[t];
-            switch (tk.op) {
-                case MINA_TOK_ALPHA: st.put(sp++, alpha); break;
-                case MINA_TOK_BETA: st.put(sp++, beta); break;
-                case MINA_TOK_GAMMA: st.put(sp++, gamma); break;
-                case MINA_TOK_JOINT_COMBINER: st.put(sp++, fe_zero()); break;
-                case MINA_TOK_ENDO_COEFFICIENT: st.put(sp++, ix->endo_coeff); break;
-                case MINA_TOK_MDS: st.put(sp++, ix->mds[tk.a * 3 + tk.b]); break;
-                case MINA_TOK_LITERAL: st.put(sp++, lits[tk.a]); break;
-                case MINA_TOK_CELL: st.put(sp++, EV(tk.a, tk.b)); break;
-                case MINA_TOK_DUP: st.put(sp, st.get(sp - 1)); ++sp; break;
-                case MINA_TOK_POW: st.put(sp - 1, fe_pow_u64<FS>(st.get(sp - 1), (uint64_t)tk.a | ((uint64_t)tk.b << 32), ks.one)); break;
-                case MINA_TOK_ADD: st.put(sp - 2, fe_add<FS>(st.get(sp - 2), st.get(sp - 1))); --sp; break;
-                case MINA_TOK_MUL: st.put(sp - 2, fe_mul<FS>(st.get(sp - 2), st.get(sp - 1))); --sp; break;
-                case MINA_TOK_SUB: st.put(sp - 2, fe_sub<FS>(st.get(sp - 2), st.get(sp - 1))); --sp; break;
-                case MINA_TOK_VANISHES_ON_ZK_ROWS: st.put(sp++, zkpm); break;
-                case MINA_TOK_UNNORMALIZED_LAGRANGE: {
-                    const int32_t off = (int32_t)tk.a;
-                    const uint32_t row = off >= 0 ? (uint32_t)off : (1u << k) - ix->zk_rows - (uint32_t)(-off);
-                    const fe_t wr = fe_pow_u64<FS>(ix->omega, row, ks.one);
-                    st.put(sp++, fe_mul<FS>(zm1, fe_inv<FS>(fe_sub<FS>(zeta, wr), ks))); break; }
-                case MINA_TOK_STORE: st.put(KC_STACK + nc++, st.get(sp - 1)); break;
-                case MINA_TOK_LOAD: st.put(sp++, st.get(KC_STACK + (int)tk.a)); break;
-                default: prog_ok = false;
-            }
-        }
-        if (sp != 1 || !prog_ok) ok = false; else ft = fe_sub<FS>(ft, st.get(0));   // the host validated stack depth: defensive
-    }
+    fe_t perm_scalar;
+    FtEnv env{x[XF_ALPHA], x[XF_BETA], x[XF_GAMMA], zeta, zeta1, ix->omega, ix->omega_zk, ix->endo_coeff, ix->zk_roots, ix->shifts, ix->mds, lits, toks,
+              k, ix->zk_rows, ix->perm_alpha_offset, ix->n_tokens};
+    const fe_t ft = ft_eval0_dev<FS>(env, ks, x[XF_PUB0], EV, st, ok, perm_scalar);
     const fe_t v = x[XF_V], u = x[XF_U];
     // combined inner product over the evaluation list: recursion, public, ft, then the 43 columns
     fe_t cip = fe_zero(), vi = ks.one;
@@ -304,7 +226,7 @@ kimchi_scalar_kernel(uint32_t batch, uint32_t n_prev, FieldK ks, const KimchiInd
     put(out.polyscale + (size_t)b * 8, fe_from_mont<FS>(v)); put(out.evalscale + (size_t)b * 8, fe_from_mont<FS>(u));
     if (out.ft_eval0) put(out.ft_eval0 + (size_t)b * 8, fe_from_mont<FS>(ft));
     // scalars of ft_comm = perm_scalar * sigma_6 - (zeta^n - 1) * sum_i zeta^(n i) t_i
-    x[XF_FTSC] = fe_neg<FS>(fe_mul<FS>(fe_mul<FS>(z1, beta), common));
+    x[XF_FTSC] = perm_scalar;
     fe_t sc = fe_neg<FS>(zm1);
     for (uint32_t j = 1; j < 8; ++j) { x[XF_FTSC + j] = sc; sc = fe_mul<FS>(sc, zeta1); }
     if (!ok) *bad_input = 1u;
@@ -418,7 +340,7 @@ extern "C" int mina_verifier_index_install(mina_ctx *c, const mina_verifier_inde
     if (!toks.empty()) HIPC(hipMemcpy(c->kimchi_tokens.p, toks.data(), toks.size() * sizeof(mb::KimchiToken), hipMemcpyHostToDevice));
     HIPC(hipMemcpy(c->kimchi_literals.p, lm.data(), lm.size() * sizeof(fe_t), hipMemcpyHostToDevice));
     memcpy(c->kimchi_comms_host, vi->sigma_comm, 7 * 64); memcpy(c->kimchi_comms_host + 7 * 64, vi->coefficients_comm, 15 * 64); memcpy(c->kimchi_comms_host + 22 * 64, vi->selector_comm, 6 * 64);
-    c->kimchi_log2 = vi->log2_domain; c->have_kimchi = true;
+    c->kimchi_log2 = vi->log2_domain; c->have_kimchi = true; c->pickles_ms_valid = false;
     return MINA_OK;
 }
 
@@ -526,16 +448,67 @@ int mb_pickles_public_inputs(mina_ctx *c, const mw::WrapProof *const *proofs, co
 int mb_kimchi_fill_jobs(mina_ctx *c, const mw::WrapProof *const *proofs, const uint8_t *const *tip_hashes, size_t n, mina_state_jobs *jobs,
                         std::vector<std::vector<uint8_t>> &storage, std::vector<uint8_t> &statement_ok) {
     const uint32_t k = c->kimchi_log2;
-    storage.assign(16, {});
+    storage.assign(32, {});
     statement_ok.assign(n, 1);
     auto &pub = storage[0], &pch = storage[1], &pcm = storage[2], &wc = storage[3], &zc = storage[4], &tc = storage[5], &ev = storage[6], &ft1 = storage[7],
          &lr = storage[8], &dl = storage[9], &sg = storage[10], &z1 = storage[11], &z2 = storage[12], &rb = storage[13], &sb = storage[14], &kp = storage[15];
+    (void)pub; (void)tip_hashes;
     const uint32_t n_prev = 2;
     uint32_t npub = 0;
-    if (mb_step_index_installed(c)) {           // the wrap circuit's public input = the Pickles statement, deferred values recomputed (api_pickles.hip)
-        npub = 40; pub.resize(n * 40 * 32);
-        int prc = mb_pickles_public_inputs(c, proofs, tip_hashes, n, pub.data(), nullptr, statement_ok.data());
-        if (prc) return prc;
+    const bool with_statements = mb_step_index_installed(c) != 0;
+    if (with_statements) {          // the wrap circuit's public input = the Pickles statement; derived on the GPU inside the job (api_pickles.hip)
+        npub = 40;
+        auto &s_plonk = storage[16], &s_bp = storage[17], &s_old = storage[18], &s_cm = storage[19], &s_wold = storage[20], &s_wsg = storage[21], &s_dg = storage[22],
+             &s_ev = storage[23], &s_pi = storage[24], &s_ft = storage[25], &s_app = storage[26], &s_misc = storage[27], &s_struct = storage[28];
+        auto put_chal = [](std::vector<uint8_t> &v, const mw::Chal128 &ch) { uint8_t e[16]; memcpy(e, &ch.lo, 8); memcpy(e + 8, &ch.hi, 8); v.insert(v.end(), e, e + 16); };
+        auto put_b32 = [](std::vector<uint8_t> &v, const mw::B32 &x) { v.insert(v.end(), x.b, x.b + 32); };
+        const size_t n_old = n ? proofs[0]->step_old_bulletproof_challenges.size() : 0, n_ev = n ? proofs[0]->prev_evals.size() : 0;
+        if (n_old > 4 || n_ev < 43 || n_ev > 62) return fail(MINA_ERR_FORMAT, "wrap proof statement shape");
+        // wire order: w 15, coefficients 15, z, s 6, selectors 6, then the present optional ones -> kimchi column order
+        static const size_t order[43] = {30, 37, 38, 39, 40, 41, 42, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 31, 32, 33, 34, 35, 36};
+        const FieldK &kpf = c->fk[FIELD_FP];
+        for (size_t b = 0; b < n; ++b) {
+            const mw::WrapProof &w = *proofs[b];
+            if (w.step_old_bulletproof_challenges.size() != n_old || w.step_challenge_polynomial_commitments.size() != n_old || w.prev_evals.size() != n_ev)
+                return fail(MINA_ERR_ARG, "proofs of one call must share the evaluation / recursion shape");
+            put_chal(s_plonk, w.alpha); put_chal(s_plonk, w.beta); put_chal(s_plonk, w.gamma); put_chal(s_plonk, w.zeta);
+            for (int j = 0; j < 16; ++j) put_chal(s_bp, w.bulletproof_challenges[j]);
+            for (auto &row : w.step_old_bulletproof_challenges) for (int j = 0; j < 16; ++j) put_chal(s_old, row[j]);
+            for (auto &cm : w.step_challenge_polynomial_commitments) { put_b32(s_cm, cm.x); put_b32(s_cm, cm.y); }
+            for (int a = 0; a < 2; ++a) for (int j = 0; j < 15; ++j) put_chal(s_wold, w.old_bulletproof_challenges[a][j]);
+            put_b32(s_wsg, w.challenge_polynomial_commitment.x); put_b32(s_wsg, w.challenge_polynomial_commitment.y);
+            { uint8_t dg[32]; memcpy(dg, w.sponge_digest_before_evaluations, 32); s_dg.insert(s_dg.end(), dg, dg + 32); }
+            // evaluations: one chunk each in every Mina step proof; chunked ones are combined here with zeta^(2^16) (host field arithmetic)
+            bool chunked = w.prev_public_input.zeta.size() != 1 || w.prev_public_input.zeta_omega.size() != 1;
+            for (auto &e : w.prev_evals) chunked = chunked || e.zeta.size() != 1 || e.zeta_omega.size() != 1;
+            fe_t zn = fe_zero(), zwn = fe_zero();
+            if (chunked) {
+                const fe_t zeta = challenge_to_field<FIELD_FP>(w.zeta.lo, w.zeta.hi, kpf);
+                fe_t om = kpf.root; for (uint32_t j = 0; j + w.domain_log2 < 32; ++j) om = fe_sqr<FIELD_FP>(om);
+                zn = zeta; zwn = fe_mul<FIELD_FP>(zeta, om);
+                for (int j = 0; j < 16; ++j) { zn = fe_sqr<FIELD_FP>(zn); zwn = fe_sqr<FIELD_FP>(zwn); }
+            }
+            auto comb = [&](const std::vector<mw::B32> &chunks, const fe_t &ptn) {
+                if (chunks.size() == 1) { put_b32(s_ev, chunks[0]); return; }
+                fe_t acc = fe_zero();
+                for (size_t j = chunks.size(); j-- > 0;) { if (!mw::fp_canonical(chunks[j].b)) statement_ok[b] = 0; acc = fe_add<FIELD_FP>(fe_mul<FIELD_FP>(acc, ptn), host_mont<FIELD_FP>(chunks[j].b, kpf)); }
+                const fe_t pl = fe_from_mont<FIELD_FP>(acc); const uint8_t *pb = (const uint8_t *)pl.v; s_ev.insert(s_ev.end(), pb, pb + 32);
+            };
+            for (size_t j = 0; j < n_ev; ++j) { const mw::EvalPair &e = w.prev_evals[j < 43 ? order[j] : j]; comb(e.zeta, zn); comb(e.zeta_omega, zwn); }
+            if (w.prev_public_input.zeta.empty() || w.prev_public_input.zeta_omega.empty()) return fail(MINA_ERR_FORMAT, "wrap proof without public-input evaluations");
+            put_b32(s_pi, w.prev_public_input.zeta[0]); put_b32(s_pi, w.prev_public_input.zeta_omega[0]);
+            put_b32(s_ft, w.prev_ft_eval1);
+            s_app.insert(s_app.end(), tip_hashes[b], tip_hashes[b] + 32);
+            uint8_t misc[32] = {0};
+            misc[0] = w.domain_log2; misc[1] = w.proofs_verified; for (int j = 0; j < 8; ++j) misc[2 + j] = w.feature_flags[j] ? 1 : 0;
+            misc[10] = w.has_joint_combiner ? 1 : 0; if (w.has_joint_combiner) { memcpy(misc + 16, &w.joint_combiner.lo, 8); memcpy(misc + 24, &w.joint_combiner.hi, 8); }
+            s_misc.insert(s_misc.end(), misc, misc + 32);
+        }
+        mina_pickles_statements ps{};
+        ps.n_old = (uint32_t)n_old; ps.n_evals = (uint32_t)n_ev; ps.plonk = s_plonk.data(); ps.bulletproof_challenges = s_bp.data(); ps.step_old_challenges = s_old.data();
+        ps.step_comms = s_cm.data(); ps.wrap_old_challenges = s_wold.data(); ps.wrap_sg = s_wsg.data(); ps.sponge_digest = s_dg.data(); ps.prev_evals = s_ev.data();
+        ps.prev_public_input = s_pi.data(); ps.prev_ft_eval1 = s_ft.data(); ps.app_state = s_app.data(); ps.misc = s_misc.data();
+        s_struct.resize(sizeof ps); memcpy(s_struct.data(), &ps, sizeof ps);
     }
     auto put_pt = [](std::vector<uint8_t> &v, const mw::Pt &p) { v.insert(v.end(), p.x.b, p.x.b + 32); v.insert(v.end(), p.y.b, p.y.b + 32); };
     auto put32 = [](std::vector<uint8_t> &v, const mw::B32 &x) { v.insert(v.end(), x.b, x.b + 32); };
@@ -566,10 +539,11 @@ int mb_kimchi_fill_jobs(mina_ctx *c, const mw::WrapProof *const *proofs, const u
     kp.resize(sizeof(mina_kimchi_proofs));
     mina_kimchi_proofs kk{}; kk.batch = n; kk.n_prev = n_prev; kk.npub = npub; kk.prev_chals = pch.data(); kk.prev_comms = pcm.data(); kk.w_comm = wc.data();
     kk.z_comm = zc.data(); kk.t_comm = tc.data(); kk.evals = ev.data(); kk.ft_eval1 = ft1.data();
+    if (with_statements) kk.statements = (const mina_pickles_statements *)storage[28].data();
     memcpy(kp.data(), &kk, sizeof kk);
     jobs->batch = n; jobs->with_ipa = 1; jobs->kimchi = (const mina_kimchi_proofs *)kp.data();
     jobs->k = k; jobs->n_evalpoints = 2; jobs->n_comms = n_prev + 2 + mb::KC_COLS; jobs->log2_domain = k; jobs->npub = npub;
-    if (npub) { jobs->public_inputs = pub.data(); kk.public_inputs = pub.data(); memcpy(kp.data(), &kk, sizeof kk); }
+    jobs->public_inputs = nullptr;                  // derived on the GPU from kk.statements
     jobs->lr = lr.data(); jobs->delta = dl.data(); jobs->sg = sg.data(); jobs->z1 = z1.data(); jobs->z2 = z2.data(); jobs->rand_base = rb.data(); jobs->sg_rand_base = sb.data();
     return MINA_OK;
 }

@@ -14,7 +14,7 @@
 
 #include "ctx.h"
 #include "sponge.cuh"
-#include "polish.h"
+#include "kimchi_dev.cuh"
 #include "wire_proof.h"
 
 namespace {
@@ -43,6 +43,7 @@ struct StepIndexHost {
     bool installed = false; uint32_t zk_rows = 3;
     std::vector<uint32_t> domains; std::vector<std::array<fe_t, 7>> shifts;      // per domain, Montgomery (Fp)
     std::vector<mb::KimchiToken> toks; std::vector<fe_t> lits; fe_t mds[9]; fe_t endo_coeff;
+    uint32_t max_col = 0;                                                        // highest evaluation column the program names
 };
 StepIndexHost &step_of(mina_ctx *c) {           // one per context, kept beside it (host-only data)
     static std::mutex mu; static std::vector<std::pair<mina_ctx *, StepIndexHost *>> all;
@@ -57,10 +58,11 @@ struct Derived { fe_t cip, b, zeta_srs, zeta_dom, perm, xi, r; mw::Chal128 xi_ch
 }  // namespace
 
 int mb_step_index_installed(mina_ctx *c) { return step_of(c).installed ? 1 : 0; }
+static int upload_step_index(mina_ctx *c, const StepIndexHost &st);
 
 extern "C" int mina_step_index_install(mina_ctx *c, const mina_step_index *si) {
     if (!c || !si || !si->domain_log2 || !si->shifts || (si->constant_term_len && !si->constant_term)) return fail(MINA_ERR_ARG, "null argument");
-    if (si->n_domains == 0 || si->n_domains > 32 || si->zk_rows < 1 || si->zk_rows > 8) return fail(MINA_ERR_ARG, "bad n_domains / zk_rows");
+    if (si->n_domains == 0 || si->n_domains > 8 || si->zk_rows < 1 || si->zk_rows > 8) return fail(MINA_ERR_ARG, "bad n_domains / zk_rows");
     if (!c->have_pparams[FIELD_FP]) return fail(MINA_ERR_STATE, "Poseidon constants not installed");
     StepIndexHost st;
     std::vector<std::array<uint8_t, 32>> lits;
@@ -77,6 +79,9 @@ extern "C" int mina_step_index_install(mina_ctx *c, const mina_step_index *si) {
     { PoseidonParams pp; HIPC(hipMemcpy(&pp, c->pparams[FIELD_FP].p, sizeof pp, hipMemcpyDeviceToHost)); for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) st.mds[3 * i + j] = pp.mds[i][j]; }
     st.endo_coeff = fe_sqr<FIELD_FP>(k.endo);                      // endo_q of Pallas = cube root of unity in Fp: (w^2)^2 = w
     st.zk_rows = si->zk_rows; st.installed = true;
+    for (auto &t : st.toks) if (t.op == MINA_TOK_CELL && t.a > st.max_col) st.max_col = t.a;
+    int rc = upload_step_index(c, st);
+    if (rc) return rc;
     step_of(c) = st;
     return MINA_OK;
 }
@@ -251,4 +256,317 @@ extern "C" int mina_pickles_public_input(mina_ctx *c, const uint8_t *proof, size
     int rc = mb_pickles_public_inputs(c, &pw, &app_state, 1, public_input_out, derived_out, &good);
     if (rc) return rc;
     return good ? MINA_OK : fail(MINA_ERR_FORMAT, "statement does not fit the installed step index (domain, evaluation shape or a non-canonical element)");
+}
+
+// ------------------------------------------------------------------------------------------------ the same on the GPU
+// Batch form for the Proof-of-State job: statements (structure-of-arrays in HBM) -> 40 public inputs per proof, no host work.
+//   expand   one thread per challenge: endo-expansion (Fp for the step side, Fq for the wrap side), beta / gamma into the field
+//   digest   lane-cooperative sponges, three roles side by side: digest of the step-side old challenges (Tick), messages_for_next_
+//            wrap_proof (Tock), messages_for_next_step_proof (Tick, resumed after the 28 wrap index commitments -- absorbed once at
+//            set-up, the state cached in the index)
+//   tick     lane-cooperative: the Tick sponge over the step proof's evaluations -> xi, r
+//   scalar   one lane per proof: ft_eval0 of the step proof (kimchi_dev.cuh), derive_plonk, combined inner product, b, packing
+// Values pass between the stages through `xe` (PX_* elements per proof, Montgomery in their field).
+namespace mb {
+
+static constexpr uint32_t PK_MAX_DOMAINS = 8, PK_PUB = 40;
+struct PicklesIndexDev {
+    uint32_t zk_rows, n_tokens, n_domains, max_col;
+    uint32_t domain_log2[PK_MAX_DOMAINS];
+    fe_t shifts[PK_MAX_DOMAINS][7], omega[PK_MAX_DOMAINS], omega_zk[PK_MAX_DOMAINS], zk_roots[PK_MAX_DOMAINS][KC_MAX_ZK];   // Fp, Montgomery
+    fe_t mds[9], endo_coeff;
+    fe_t ms_state[3]; uint32_t ms_squeezed, ms_count;             // Tick sponge after the wrap index commitments (Montgomery)
+};
+enum { PX_ALPHA = 0, PX_ZETA, PX_BETA, PX_GAMMA, PX_CHD, PX_MW, PX_MS, PX_XIC, PX_XI, PX_R, PX_BP = 10, PX_OLD = 26 };
+__host__ __device__ static inline uint32_t px_wold(uint32_t n_old) { return PX_OLD + 16 * n_old; }
+__host__ __device__ static inline uint32_t px_stride(uint32_t n_old) { return PX_OLD + 16 * n_old + 30; }
+struct PicklesIn {
+    uint32_t n_old, n_evals;
+    const uint32_t *plonk, *bp, *old_chals, *step_comms, *wold, *wrap_sg, *digest, *evals, *pub_in, *ft_eval1, *app_state; const uint8_t *misc;
+};
+
+__device__ __forceinline__ void chal_words(const uint32_t *p, uint64_t &lo, uint64_t &hi) { lo = (uint64_t)p[0] | ((uint64_t)p[1] << 32); hi = (uint64_t)p[2] | ((uint64_t)p[3] << 32); }
+__device__ __forceinline__ fe_t u128_fe(const uint32_t *p) { fe_t a = fe_zero(); a.v[0] = p[0]; a.v[1] = p[1]; a.v[2] = p[2]; a.v[3] = p[3]; return a; }
+
+__global__ void __launch_bounds__(256)
+pickles_expand_kernel(uint32_t batch, FieldK kp, FieldK kq, PicklesIn in, fe_t *__restrict__ xe) {
+    const uint32_t per = 4 + 16 + 16 * in.n_old + 30;
+    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= (size_t)batch * per) return;
+    const uint32_t b = (uint32_t)(gid / per), it = (uint32_t)(gid % per);
+    fe_t *x = xe + (size_t)b * px_stride(in.n_old);
+    uint64_t lo, hi;
+    if (it < 4) {                                           // alpha, beta, gamma, zeta in wire order
+        const uint32_t *p = in.plonk + ((size_t)b * 4 + it) * 4;
+        if (it == 0 || it == 3) { chal_words(p, lo, hi); x[it == 0 ? PX_ALPHA : PX_ZETA] = challenge_to_field<FIELD_FP>(lo, hi, kp); }
+        else x[it == 1 ? PX_BETA : PX_GAMMA] = fe_to_mont<FIELD_FP>(u128_fe(p), kp.r2);
+    } else if (it < 20) {
+        chal_words(in.bp + ((size_t)b * 16 + (it - 4)) * 4, lo, hi); x[PX_BP + (it - 4)] = challenge_to_field<FIELD_FP>(lo, hi, kp);
+    } else if (it < 20 + 16 * in.n_old) {
+        const uint32_t j = it - 20;
+        chal_words(in.old_chals + ((size_t)b * 16 * in.n_old + j) * 4, lo, hi); x[PX_OLD + j] = challenge_to_field<FIELD_FP>(lo, hi, kp);
+    } else {
+        const uint32_t j = it - 20 - 16 * in.n_old;
+        chal_words(in.wold + ((size_t)b * 30 + j) * 4, lo, hi); x[px_wold(in.n_old) + j] = challenge_to_field<FIELD_FQ>(lo, hi, kq);
+    }
+}
+
+template <int LANES>
+__global__ void __launch_bounds__(64)
+pickles_digest_kernel(uint32_t batch, FieldK kp, FieldK kq, const PoseidonParams *__restrict__ pp_p, const PoseidonParams *__restrict__ pp_q,
+                      const PicklesIndexDev *__restrict__ ix, PicklesIn in, fe_t *__restrict__ xe, uint32_t *__restrict__ ok_out) {
+    bool writer; const uint32_t g = coop_sponge_index<LANES>(writer);
+    if (g >= 3 * batch) return;
+    const uint32_t role = g / batch, b = g - role * batch;
+    fe_t *x = xe + (size_t)b * px_stride(in.n_old);
+    bool ok = true;
+    if (role == 0) {                                        // digest of the step-side old challenges
+        DevSponge<FIELD_FP, LANES> sp; sponge_init(sp, pp_p);
+#pragma unroll 1
+        for (uint32_t i = 0; i < 16 * in.n_old; ++i) sp.absorb(x[PX_OLD + i]);
+        const fe_t d = sp.squeeze();
+        if (writer) x[PX_CHD] = d;
+    } else if (role == 1) {                                 // messages_for_next_wrap_proof (Tock)
+        DevSponge<FIELD_FQ, LANES> sp; sponge_init(sp, pp_q);
+#pragma unroll 1
+        for (uint32_t i = 0; i < 30; ++i) sp.absorb(x[px_wold(in.n_old) + i]);
+        sp.absorb(ld_checked<FIELD_FQ>(in.wrap_sg + (size_t)b * 16, kq, ok)); sp.absorb(ld_checked<FIELD_FQ>(in.wrap_sg + (size_t)b * 16 + 8, kq, ok));
+        const fe_t d = sp.squeeze();
+        if (writer) x[PX_MW] = d;
+    } else {                                                // messages_for_next_step_proof (Tick), after the index commitments
+        DevSponge<FIELD_FP, LANES> sp; sp.pp = pp_p; sp.s = ix->ms_state[coop_elem<LANES>()]; sp.squeezed = (int)ix->ms_squeezed; sp.count = (int)ix->ms_count;
+        sp.absorb(ld_checked<FIELD_FP>(in.app_state + (size_t)b * 8, kp, ok));
+#pragma unroll 1
+        for (uint32_t a = 0; a < in.n_old; ++a) {
+            const uint32_t *cm = in.step_comms + ((size_t)b * in.n_old + a) * 16;
+            sp.absorb(ld_checked<FIELD_FP>(cm, kp, ok)); sp.absorb(ld_checked<FIELD_FP>(cm + 8, kp, ok));
+#pragma unroll 1
+            for (uint32_t i = 0; i < 16; ++i) sp.absorb(x[PX_OLD + 16 * a + i]);
+        }
+        const fe_t d = sp.squeeze();
+        if (writer) x[PX_MS] = d;
+    }
+    if (!ok) ok_out[b] = 0u;
+}
+
+template <int LANES>
+__global__ void __launch_bounds__(64)
+pickles_tick_kernel(uint32_t batch, FieldK kp, const PoseidonParams *__restrict__ pp_p, PicklesIn in, fe_t *__restrict__ xe, uint32_t *__restrict__ ok_out) {
+    constexpr int F = FIELD_FP;
+    bool writer; const uint32_t b = coop_sponge_index<LANES>(writer);
+    if (b >= batch) return;
+    fe_t *x = xe + (size_t)b * px_stride(in.n_old);
+    bool ok = true;
+    DevSponge<F, LANES> sp; sponge_init(sp, pp_p);
+    sp.absorb(fe_to_mont<F>(load_fe<F>(in.digest + (size_t)b * 8), kp.r2));        // any 256-bit value: the Montgomery product reduces it
+    sp.absorb(x[PX_CHD]);
+    sp.absorb(ld_checked<F>(in.ft_eval1 + (size_t)b * 8, kp, ok));
+    sp.absorb(ld_checked<F>(in.pub_in + (size_t)b * 16, kp, ok)); sp.absorb(ld_checked<F>(in.pub_in + (size_t)b * 16 + 8, kp, ok));
+    const uint32_t *ev = in.evals + (size_t)b * in.n_evals * 16;
+#pragma unroll 1
+    for (uint32_t c = 0; c < 2 * in.n_evals; ++c) sp.absorb(ld_checked<F>(ev + (size_t)c * 8, kp, ok));
+    const fe_t xi_sq = fe_from_mont<F>(sp.squeeze()), r_sq = fe_from_mont<F>(sp.squeeze());
+    if (writer) {
+        fe_t xc = fe_zero(); xc.v[0] = xi_sq.v[0]; xc.v[1] = xi_sq.v[1]; xc.v[2] = xi_sq.v[2]; xc.v[3] = xi_sq.v[3];
+        x[PX_XIC] = xc; x[PX_XI] = chal_endo<F>(xi_sq, kp); x[PX_R] = chal_endo<F>(r_sq, kp);
+    }
+    if (!ok) ok_out[b] = 0u;
+}
+
+__global__ void __launch_bounds__(64)
+pickles_scalar_kernel(uint32_t batch, FieldK kp, FieldK kq, const PicklesIndexDev *__restrict__ ix, const KimchiToken *__restrict__ toks, const fe_t *__restrict__ lits,
+                      PicklesIn in, const fe_t *__restrict__ xe, uint32_t *__restrict__ pub_out, uint32_t *__restrict__ ok_out) {
+    constexpr int F = FIELD_FP;
+    __shared__ uint32_t lds[KC_SLOTS * 8 * 64];
+    const uint32_t b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= batch) return;
+    LdsStack st{lds + threadIdx.x};
+    const fe_t *x = xe + (size_t)b * px_stride(in.n_old);
+    const uint8_t *misc = in.misc + (size_t)b * 32;
+    bool ok = true;
+    uint32_t dom = 0; { bool found = false; for (uint32_t d = 0; d < ix->n_domains; ++d) if (ix->domain_log2[d] == misc[0]) { dom = d; found = true; } ok = ok && found; }
+    const uint32_t k = ix->domain_log2[dom];
+    const uint32_t *ev = in.evals + (size_t)b * in.n_evals * 16;
+    auto EV = [&](uint32_t col, uint32_t row) { return fe_to_mont<F>(load_fe<F>(ev + ((size_t)col * 2 + row) * 8), kp.r2); };
+    const fe_t zeta = x[PX_ZETA], zetaw = fe_mul<F>(zeta, ix->omega[dom]);
+    const fe_t zeta_dom = fe_pow2k<F>(zeta, k), zeta_srs = fe_pow2k<F>(zeta, 16);
+    const fe_t p0 = fe_to_mont<F>(load_fe<F>(in.pub_in + (size_t)b * 16), kp.r2), p1 = fe_to_mont<F>(load_fe<F>(in.pub_in + (size_t)b * 16 + 8), kp.r2);
+    fe_t perm;
+    FtEnv env{x[PX_ALPHA], x[PX_BETA], x[PX_GAMMA], zeta, zeta_dom, ix->omega[dom], ix->omega_zk[dom], ix->endo_coeff, ix->zk_roots[dom], ix->shifts[dom], ix->mds, lits, toks,
+              k, ix->zk_rows, 21u, ix->n_tokens};
+    const fe_t ft = ft_eval0_dev<F>(env, kp, p0, EV, st, ok, perm);
+    const fe_t xi = x[PX_XI], r = x[PX_R];
+    // combined inner product: Horner in xi over [b_poly(old_a, pt)..., public, ft, the evaluations], both points, second scaled by r
+    fe_t cip;
+    {
+        fe_t acc0 = fe_zero(), acc1 = fe_zero();
+#pragma unroll 1
+        for (int c = (int)in.n_evals - 1; c >= 0; --c) { acc0 = fe_add<F>(fe_mul<F>(acc0, xi), EV((uint32_t)c, 0)); acc1 = fe_add<F>(fe_mul<F>(acc1, xi), EV((uint32_t)c, 1)); }
+        acc0 = fe_add<F>(fe_mul<F>(acc0, xi), ft); acc1 = fe_add<F>(fe_mul<F>(acc1, xi), fe_to_mont<F>(load_fe<F>(in.ft_eval1 + (size_t)b * 8), kp.r2));
+        acc0 = fe_add<F>(fe_mul<F>(acc0, xi), p0); acc1 = fe_add<F>(fe_mul<F>(acc1, xi), p1);
+#pragma unroll 1
+        for (int a = (int)in.n_old - 1; a >= 0; --a) {
+            fe_t pw0 = zeta, pw1 = zetaw, e0 = kp.one, e1 = kp.one;
+#pragma unroll 1
+            for (int j = 15; j >= 0; --j) {
+                const fe_t ch = x[PX_OLD + 16 * a + j];
+                e0 = fe_mul<F>(e0, fe_add<F>(kp.one, fe_mul<F>(ch, pw0))); pw0 = fe_sqr<F>(pw0);
+                e1 = fe_mul<F>(e1, fe_add<F>(kp.one, fe_mul<F>(ch, pw1))); pw1 = fe_sqr<F>(pw1);
+            }
+            acc0 = fe_add<F>(fe_mul<F>(acc0, xi), e0); acc1 = fe_add<F>(fe_mul<F>(acc1, xi), e1);
+        }
+        cip = fe_add<F>(acc0, fe_mul<F>(r, acc1));
+    }
+    fe_t bval;
+    {
+        fe_t pw0 = zeta, pw1 = zetaw, e0 = kp.one, e1 = kp.one;
+#pragma unroll 1
+        for (int j = 15; j >= 0; --j) {
+            const fe_t ch = x[PX_BP + j];
+            e0 = fe_mul<F>(e0, fe_add<F>(kp.one, fe_mul<F>(ch, pw0))); pw0 = fe_sqr<F>(pw0);
+            e1 = fe_mul<F>(e1, fe_add<F>(kp.one, fe_mul<F>(ch, pw1))); pw1 = fe_sqr<F>(pw1);
+        }
+        bval = fe_add<F>(e0, fe_mul<F>(r, e1));
+    }
+    // ---- PreparedStatement::to_public_input(40): plain integers (every Fp value is < p < q: canonical in Fq as it stands)
+    uint32_t *po = pub_out + (size_t)b * PK_PUB * 8;
+    auto put = [&](uint32_t slot, const fe_t &plain) { for (int i = 0; i < 8; ++i) po[slot * 8 + i] = plain.v[i]; };
+    auto put128 = [&](uint32_t slot, const uint32_t *p) { for (int i = 0; i < 4; ++i) { po[slot * 8 + i] = p[i]; po[slot * 8 + 4 + i] = 0; } };
+    auto put_small = [&](uint32_t slot, uint32_t v) { po[slot * 8] = v; for (int i = 1; i < 8; ++i) po[slot * 8 + i] = 0; };
+    const fe_t shift = fe_add<F>(kp.two255, kp.one);
+    auto shifted = [&](const fe_t &v) { return fe_from_mont<F>(fe_mul<F>(fe_sub<F>(v, shift), kp.inv2)); };           // Shifted_value.Type1.of_field
+    put(0, shifted(cip)); put(1, shifted(bval)); put(2, shifted(zeta_srs)); put(3, shifted(zeta_dom)); put(4, shifted(perm));
+    const uint32_t *pl = in.plonk + (size_t)b * 16;
+    put128(5, pl + 4); put128(6, pl + 8);                   // beta, gamma
+    put128(7, pl); put128(8, pl + 12);                      // alpha, zeta
+    put(9, x[PX_XIC]);
+    put(10, fe_from_mont<FIELD_FQ>(fe_to_mont<FIELD_FQ>(load_fe<FIELD_FQ>(in.digest + (size_t)b * 8), kq.r2)));             // the digest mod q
+    put(11, fe_from_mont<FIELD_FQ>(x[PX_MW]));
+    put(12, fe_from_mont<F>(x[PX_MS]));
+    for (uint32_t j = 0; j < 16; ++j) put128(13 + j, in.bp + ((size_t)b * 16 + j) * 4);
+    { const uint32_t pv = misc[1]; ok = ok && pv <= 2; put_small(29, 4u * misc[0] + (pv == 0 ? 0u : (pv == 1 ? 2u : 3u))); }
+    for (uint32_t j = 0; j < 8; ++j) put_small(30 + j, misc[2 + j] ? 1u : 0u);
+    put_small(38, misc[10] ? 1u : 0u);
+    if (misc[10]) put128(39, (const uint32_t *)(misc + 16)); else put_small(39, 0u);
+    if (!ok) ok_out[b] = 0u;
+}
+
+}  // namespace mb
+
+// queue the four stages on the current lane: d_pub (b*40*8 words) and d_ok (b u32, 1 = well-formed) are device buffers
+int mb_pickles_dev(mina_ctx *c, size_t batch, const mb::PicklesIn &in, uint32_t *d_pub, uint32_t *d_ok) {
+    if (!c->have_pickles_dev) return fail(MINA_ERR_STATE, "no step index installed");
+    if (!c->have_kimchi) return fail(MINA_ERR_STATE, "no wrap verifier index installed");
+    if (in.n_old > 4 || in.n_evals < mb::KC_COLS || in.n_evals > N_STEP_COLS) return fail(MINA_ERR_ARG, "bad n_old / n_evals");
+    Lane &L = *c->L;
+    int rc;
+    if (!c->pickles_ms_valid) {     // the Tick sponge after the 28 wrap index commitments: once per (wrap index, step index) pair
+        Lane *keep = c->L;
+        std::vector<uint8_t> tape(28, MINA_TAPE_ABSORB_G), stt(96); uint32_t pos[2];
+        std::vector<uint8_t> dummy(32);
+        // the commitments are Pallas points (coordinates in Fp): absorbed by the Fp sponge = the CURVE_PALLAS tape
+        if ((rc = mina_fq_sponge_run(c, CURVE_PALLAS, 1, tape.data(), tape.size(), nullptr, nullptr, c->kimchi_comms_host, dummy.data(), stt.data(), pos))) return rc;
+        HIPC(hipStreamSynchronize(c->L->stream));
+        mb::PicklesIndexDev *ixd = c->pickles_index.as<mb::PicklesIndexDev>();
+        fe_t ms[3]; for (int e = 0; e < 3; ++e) ms[e] = to_mont_bytes<FIELD_FP>(stt.data() + 32 * e, c->fk[FIELD_FP]);
+        HIPC(hipMemcpy(&ixd->ms_state, ms, sizeof ms, hipMemcpyHostToDevice));
+        HIPC(hipMemcpy(&ixd->ms_squeezed, pos, 8, hipMemcpyHostToDevice));
+        c->pickles_ms_valid = true;
+        c->L = keep;
+    }
+    const mb::PicklesIndexDev *ix = c->pickles_index.as<mb::PicklesIndexDev>();
+    if ((rc = L.pk_xe.ensure(batch * mb::px_stride(in.n_old) * sizeof(fe_t)))) return rc;
+    fe_t *xe = L.pk_xe.as<fe_t>();
+    const FieldK &kp = c->fk[FIELD_FP], &kq = c->fk[FIELD_FQ];
+    const PoseidonParams *ppp = c->pparams[FIELD_FP].as<PoseidonParams>(), *ppq = c->pparams[FIELD_FQ].as<PoseidonParams>();
+    const uint32_t B = (uint32_t)batch;
+    ProfScope ps_(c, PS_PICKLES);
+    HIPC(hipMemsetD32Async((hipDeviceptr_t)d_ok, step_of(c).max_col < in.n_evals ? 1 : 0, batch, L.stream));   // a program naming a column the proofs lack fails them all
+    mb::pickles_expand_kernel<<<cdiv(batch * (50 + 16 * in.n_old), 256), 256, 0, L.stream>>>(B, kp, kq, in, xe);
+    if (batch <= 1024) {
+        mb::pickles_digest_kernel<8><<<cdiv(coop_threads<8>(3 * batch), 64), 64, 0, L.stream>>>(B, kp, kq, ppp, ppq, ix, in, xe, d_ok);
+        mb::pickles_tick_kernel<8><<<cdiv(coop_threads<8>(batch), 64), 64, 0, L.stream>>>(B, kp, ppp, in, xe, d_ok);
+    } else {
+        mb::pickles_digest_kernel<3><<<cdiv(coop_threads<3>(3 * batch), 64), 64, 0, L.stream>>>(B, kp, kq, ppp, ppq, ix, in, xe, d_ok);
+        mb::pickles_tick_kernel<3><<<cdiv(coop_threads<3>(batch), 64), 64, 0, L.stream>>>(B, kp, ppp, in, xe, d_ok);
+    }
+    mb::pickles_scalar_kernel<<<cdiv(batch, 64), 64, 0, L.stream>>>(B, kp, kq, ix, c->pickles_tokens.as<mb::KimchiToken>(), c->pickles_literals.as<fe_t>(), in, xe, d_pub, d_ok);
+    HIPC(hipGetLastError());
+    return MINA_OK;
+}
+
+static mb::PicklesIn pickles_in_of(const mina_pickles_statements &s) {
+    auto W = [](const void *p) { return (const uint32_t *)p; };
+    return mb::PicklesIn{s.n_old, s.n_evals, W(s.plonk), W(s.bulletproof_challenges), W(s.step_old_challenges), W(s.step_comms), W(s.wrap_old_challenges), W(s.wrap_sg),
+                         W(s.sponge_digest), W(s.prev_evals), W(s.prev_public_input), W(s.prev_ft_eval1), W(s.app_state), (const uint8_t *)s.misc};
+}
+int mb_pickles_check(mina_ctx *c, const mina_pickles_statements *s) {
+    if (!s || !s->plonk || !s->bulletproof_challenges || (s->n_old && (!s->step_old_challenges || !s->step_comms)) || !s->wrap_old_challenges || !s->wrap_sg || !s->sponge_digest ||
+        !s->prev_evals || !s->prev_public_input || !s->prev_ft_eval1 || !s->app_state || !s->misc) return fail(MINA_ERR_ARG, "null statement section");
+    if (s->n_old > 4 || s->n_evals < mb::KC_COLS || s->n_evals > N_STEP_COLS) return fail(MINA_ERR_ARG, "bad n_old / n_evals");
+    if (!c->have_pickles_dev) return fail(MINA_ERR_STATE, "no step index installed");
+    if (!c->have_kimchi) return fail(MINA_ERR_STATE, "no wrap verifier index installed");
+    return MINA_OK;
+}
+int mb_pickles_statements_dev(mina_ctx *c, size_t batch, const mina_pickles_statements *s, uint32_t *d_pub, uint32_t *d_ok) { return mb_pickles_dev(c, batch, pickles_in_of(*s), d_pub, d_ok); }
+// per-proof byte strides of the statement sections, in the order of `mb_pickles_sections`
+size_t mb_pickles_sections(const mina_pickles_statements *s, const void ***slots /* 12 */, size_t *strides /* 12 */, mina_pickles_statements *copy) {
+    *copy = *s;
+    const void **sl[12] = {&copy->plonk, &copy->bulletproof_challenges, &copy->step_old_challenges, &copy->step_comms, &copy->wrap_old_challenges, &copy->wrap_sg, &copy->sponge_digest,
+                           &copy->prev_evals, &copy->prev_public_input, &copy->prev_ft_eval1, &copy->app_state, &copy->misc};
+    const size_t st[12] = {64, 256, (size_t)s->n_old * 256, (size_t)s->n_old * 64, 480, 64, 32, (size_t)s->n_evals * 64, 64, 32, 32, 32};
+    for (int i = 0; i < 12; ++i) { slots[i] = sl[i]; strides[i] = st[i]; }
+    return 12;
+}
+
+extern "C" int mina_pickles_public_inputs_batch(mina_ctx *c, const mina_pickles_statements *s, size_t batch, uint8_t *pub_out, uint8_t *ok_out) {
+    if (!c || !pub_out || !ok_out) return fail(MINA_ERR_ARG, "null argument");
+    int rc = mb_pickles_check(c, s);
+    if (rc) return rc;
+    if (batch == 0 || batch > 65536) return fail(MINA_ERR_ARG, "bad batch");
+    HIPC(hipSetDevice(c->device));
+    c->use_lane0();
+    Lane &L = *c->L;
+    mina_pickles_statements d; const void **slots[12]; size_t strides[12];
+    mb_pickles_sections(s, slots, strides, &d);
+    size_t total = 0, offs[12];
+    for (int i = 0; i < 12; ++i) { offs[i] = total; total += (batch * strides[i] + 255) & ~(size_t)255; }
+    if ((rc = L.host_stage.ensure(total + 16))) return rc;
+    for (int i = 0; i < 12; ++i) if (strides[i]) memcpy((uint8_t *)L.host_stage.p + offs[i], *slots[i], batch * strides[i]);
+    if ((rc = L.st_in.ensure(total + 16))) return rc;
+    HIPC(hipMemcpyAsync(L.st_in.p, L.host_stage.p, total, hipMemcpyHostToDevice, L.stream));
+    for (int i = 0; i < 12; ++i) *slots[i] = L.st_in.as<uint8_t>() + offs[i];
+    if ((rc = L.pk_pub.ensure(batch * mb::PK_PUB * 32)) || (rc = L.pk_ok.ensure(batch * 4))) return rc;
+    if ((rc = mb_pickles_dev(c, batch, pickles_in_of(d), L.pk_pub.as<uint32_t>(), L.pk_ok.as<uint32_t>()))) return rc;
+    std::vector<uint32_t> okw(batch);
+    HIPC(hipMemcpyAsync(pub_out, L.pk_pub.p, batch * mb::PK_PUB * 32, hipMemcpyDeviceToHost, L.stream));
+    HIPC(hipMemcpyAsync(okw.data(), L.pk_ok.p, batch * 4, hipMemcpyDeviceToHost, L.stream));
+    HIPC(hipStreamSynchronize(L.stream));
+    for (size_t i = 0; i < batch; ++i) ok_out[i] = okw[i] ? 1 : 0;
+    return MINA_OK;
+}
+
+static int upload_step_index(mina_ctx *c, const StepIndexHost &st) {
+    const FieldK &k = c->fk[FIELD_FP];
+    std::unique_ptr<mb::PicklesIndexDev> ix(new mb::PicklesIndexDev());
+    memset(ix.get(), 0, sizeof *ix);
+    ix->zk_rows = st.zk_rows; ix->n_tokens = (uint32_t)st.toks.size(); ix->n_domains = (uint32_t)st.domains.size(); ix->max_col = st.max_col;
+    for (size_t d = 0; d < st.domains.size(); ++d) {
+        const uint32_t lg = st.domains[d]; const uint64_t n = (uint64_t)1 << lg;
+        ix->domain_log2[d] = lg;
+        for (int i = 0; i < 7; ++i) ix->shifts[d][i] = st.shifts[d][i];
+        fe_t w = k.root; for (uint32_t i = 0; i < 32 - lg; ++i) w = fe_sqr<FIELD_FP>(w);
+        ix->omega[d] = w; ix->omega_zk[d] = mb::host_pow_u64<FIELD_FP>(w, n - st.zk_rows, k.one);
+        for (uint32_t i = 0; i < st.zk_rows; ++i) ix->zk_roots[d][i] = mb::host_pow_u64<FIELD_FP>(w, n - st.zk_rows + i, k.one);
+    }
+    for (int i = 0; i < 9; ++i) ix->mds[i] = st.mds[i];
+    ix->endo_coeff = st.endo_coeff;
+    int rc;
+    if ((rc = c->pickles_index.ensure(sizeof *ix)) || (rc = c->pickles_tokens.ensure((st.toks.size() ? st.toks.size() : 1) * sizeof(mb::KimchiToken))) ||
+        (rc = c->pickles_literals.ensure((st.lits.size() ? st.lits.size() : 1) * sizeof(fe_t)))) return rc;
+    HIPC(hipMemcpy(c->pickles_index.p, ix.get(), sizeof *ix, hipMemcpyHostToDevice));
+    if (!st.toks.empty()) HIPC(hipMemcpy(c->pickles_tokens.p, st.toks.data(), st.toks.size() * sizeof(mb::KimchiToken), hipMemcpyHostToDevice));
+    if (!st.lits.empty()) HIPC(hipMemcpy(c->pickles_literals.p, st.lits.data(), st.lits.size() * sizeof(fe_t), hipMemcpyHostToDevice));
+    c->have_pickles_dev = true; c->pickles_ms_valid = false;
+    return MINA_OK;
 }

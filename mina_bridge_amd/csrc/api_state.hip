@@ -99,12 +99,13 @@ __global__ void fill_u32_kernel(uint32_t n, uint32_t v, uint32_t *__restrict__ o
 // verdict[b] = chain_ok[b] AND folded IPA verdict AND folded accumulator verdict; flags = {ipa, ipa malformed, acc, 0}
 __global__ void state_job_verdict_kernel(uint32_t batch, const uint32_t *__restrict__ chain_ok, const uint32_t *__restrict__ ipa_v /* [2] or null */,
                                          const uint32_t *__restrict__ acc_v /* [1] or null */, const uint32_t *__restrict__ kimchi_bad /* [1] or null */,
-                                         uint32_t *__restrict__ verdicts, uint32_t *__restrict__ flags) {
+                                         const uint32_t *__restrict__ stmt_ok /* [batch] or null: Pickles statement well-formed */,
+                                         uint32_t *__restrict__ verdicts, uint32_t *__restrict__ flags, uint32_t *__restrict__ stmt_out /* [batch] or null: copy of stmt_ok */) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t kb = kimchi_bad ? kimchi_bad[0] : 0u;
     const uint32_t iv = (ipa_v ? ipa_v[0] : 1u) && !kb, av = acc_v ? acc_v[0] : 1u;
     if (b == 0 && flags) { flags[0] = iv; flags[1] = (ipa_v ? ipa_v[1] : 0u) | kb; flags[2] = av; flags[3] = 0u; }
-    if (b < batch) verdicts[b] = (chain_ok[b] && iv && av) ? 1u : 0u;
+    if (b < batch) { const uint32_t so = stmt_ok ? stmt_ok[b] : 1u; verdicts[b] = (chain_ok[b] && iv && av && so) ? 1u : 0u; if (stmt_out) stmt_out[b] = so; }
 }
 
 }  // namespace mb
@@ -218,6 +219,9 @@ extern "C" int mina_protocol_state_hash_bytes(mina_ctx *c, int encoding, size_t 
 }
 
 // ------------------------------------------------------------------------------------------------ the composite job
+int mb_pickles_check(mina_ctx *c, const mina_pickles_statements *s);                                                    // api_pickles.hip
+int mb_pickles_statements_dev(mina_ctx *c, size_t batch, const mina_pickles_statements *s, uint32_t *d_pub, uint32_t *d_ok);
+size_t mb_pickles_sections(const mina_pickles_statements *s, const void ***slots, size_t *strides, mina_pickles_statements *copy);
 static int check_jobs(mina_ctx *c, const mina_state_jobs *j) {
     if (!c || !j) return fail(MINA_ERR_ARG, "null argument");
     if (j->batch == 0 || j->batch > 65536) return fail(MINA_ERR_ARG, "batch must be in 1..65536");
@@ -229,7 +233,8 @@ static int check_jobs(mina_ctx *c, const mina_state_jobs *j) {
             if (!c->have_kimchi) return fail(MINA_ERR_STATE, "no verifier index installed");
             if (kp.batch != j->batch || j->k != c->kimchi_log2 || j->log2_domain != c->kimchi_log2 || j->n_evalpoints != 2 || j->n_comms != kp.n_prev + 45 || kp.npub != j->npub || kp.n_prev > 8)
                 return fail(MINA_ERR_ARG, "kimchi section does not match the installed index / the job's shape");
-            if ((kp.n_prev && (!kp.prev_chals || !kp.prev_comms)) || !kp.w_comm || !kp.z_comm || !kp.t_comm || !kp.evals || !kp.ft_eval1 || (kp.npub && !kp.public_inputs)) return fail(MINA_ERR_ARG, "null kimchi section");
+            if ((kp.n_prev && (!kp.prev_chals || !kp.prev_comms)) || !kp.w_comm || !kp.z_comm || !kp.t_comm || !kp.evals || !kp.ft_eval1 || (kp.npub && !kp.public_inputs && !kp.statements)) return fail(MINA_ERR_ARG, "null kimchi section");
+            if (kp.statements) { if (kp.npub != 40) return fail(MINA_ERR_ARG, "statements derive exactly 40 public inputs"); int prc = mb_pickles_check(c, kp.statements); if (prc) return prc; }
         } else if (!j->sponge_state || !j->sponge_pos || !j->cip || !j->evalscale || !j->polyscale || (j->n_evalpoints && !j->evalpoints) || (j->n_comms && !j->comms))
             return fail(MINA_ERR_ARG, "null IPA section");
         if (j->k < 1 || j->k > 20 || ((size_t)1 << j->k) > c->srs[CURVE_PALLAS].depth) return fail(c->srs[CURVE_PALLAS].depth ? MINA_ERR_ARG : MINA_ERR_STATE, "Pallas SRS missing or 2^k exceeds its depth");
@@ -237,7 +242,7 @@ static int check_jobs(mina_ctx *c, const mina_state_jobs *j) {
         if (!c->have_pparams[FIELD_FP]) return fail(MINA_ERR_STATE, "Poseidon constants not installed for Fp");
     }
     if (j->npub) {
-        if (!j->public_inputs) return fail(MINA_ERR_ARG, "null public inputs");
+        if (!j->public_inputs && !(j->kimchi && j->kimchi->statements)) return fail(MINA_ERR_ARG, "null public inputs");
         if (!j->with_ipa || (!j->kimchi && j->pub_comm_slot >= j->n_comms)) return fail(MINA_ERR_ARG, "public-input commitment needs an IPA section and a valid commitment slot");
         if (j->log2_domain > 20 || ((uint64_t)1 << j->log2_domain) > c->srs[CURVE_PALLAS].depth || j->npub > 4096 || j->npub > ((uint64_t)1 << j->log2_domain)) return fail(MINA_ERR_ARG, "bad domain / npub");
     }
@@ -300,7 +305,7 @@ static int leg_join(Lane &leg, Lane &into) {
     HIPC(hipStreamWaitEvent(into.stream, leg.ev_leg, 0));
     return MINA_OK;
 }
-static int state_jobs_on_lane(mina_ctx *c, const mina_state_jobs *j, uint32_t *d_verdicts, uint32_t *d_flags, bool split = false) {
+static int state_jobs_on_lane(mina_ctx *c, const mina_state_jobs *j, uint32_t *d_verdicts, uint32_t *d_flags, bool split = false, uint32_t *d_stmt_out = nullptr) {
     Lane &L = *c->L;
     Lane *const L0 = c->L;
     Lane *LI = L0, *LA = L0;
@@ -326,14 +331,20 @@ static int state_jobs_on_lane(mina_ctx *c, const mina_state_jobs *j, uint32_t *d
     HIPC(hipGetLastError());
     const uint32_t *comm_override = nullptr;
     uint32_t *ipa_v = nullptr, *acc_v = nullptr;
-    uint32_t *kimchi_bad = nullptr;
+    uint32_t *kimchi_bad = nullptr; const uint32_t *stmt_ok = nullptr;
     c->L = LI;                                                  // ---- wrap-proof leg
     {
     Lane &L = *LI;
     if ((rc = L.st_flags.ensure(16 * 4))) { c->L = L0; return rc; }
+    const uint32_t *pub = (const uint32_t *)j->public_inputs;
+    if (j->kimchi && j->kimchi->statements) {      // the Pickles statement -> the wrap circuit's public inputs, on this lane ahead of everything that reads them
+        if ((rc = L.pk_pub.ensure(B * 40 * 32)) || (rc = L.pk_ok.ensure(B * 4))) { c->L = L0; return rc; }
+        if ((rc = mb_pickles_statements_dev(c, B, j->kimchi->statements, L.pk_pub.as<uint32_t>(), L.pk_ok.as<uint32_t>()))) { c->L = L0; return rc; }
+        pub = L.pk_pub.as<uint32_t>(); stmt_ok = L.pk_ok.as<uint32_t>();
+    }
     if (j->npub || j->kimchi) {
         if ((rc = L.st_pubcomm.ensure(B * 64))) { c->L = L0; return rc; }
-        if ((rc = mb_pubcomm_dev(c, B, j->log2_domain, j->npub, (const uint32_t *)j->public_inputs, L.st_pubcomm.as<uint32_t>()))) { c->L = L0; return rc; }
+        if ((rc = mb_pubcomm_dev(c, B, j->log2_domain, j->npub, pub, L.st_pubcomm.as<uint32_t>()))) { c->L = L0; return rc; }
         comm_override = L.st_pubcomm.as<uint32_t>();
     }
     if (j->with_ipa) {
@@ -347,7 +358,7 @@ static int state_jobs_on_lane(mina_ctx *c, const mina_state_jobs *j, uint32_t *d
                 (rc = L.kc_v.ensure(B * 32)) || (rc = L.kc_u.ensure(B * 32)) || (rc = L.kc_comms.ensure(B * (size_t)j->n_comms * 64))) { c->L = L0; return rc; }
             kimchi_bad = L.st_flags.as<uint32_t>() + 12;
             HIPC(hipMemsetAsync(kimchi_bad, 0, 4, L.stream));
-            mb::KimchiIn in{W(kp.public_inputs), W(kp.prev_chals), W(kp.prev_comms), W(kp.w_comm), W(kp.z_comm), W(kp.t_comm), W(kp.evals), W(kp.ft_eval1), comm_override};
+            mb::KimchiIn in{pub, W(kp.prev_chals), W(kp.prev_comms), W(kp.w_comm), W(kp.z_comm), W(kp.t_comm), W(kp.evals), W(kp.ft_eval1), comm_override};
             mb::KimchiOut out{L.kc_state.as<uint32_t>(), L.kc_pos.as<uint32_t>(), L.kc_cip.as<uint32_t>(), L.kc_pts.as<uint32_t>(), L.kc_v.as<uint32_t>(), L.kc_u.as<uint32_t>(),
                               L.kc_comms.as<uint32_t>(), nullptr};
             mb::IpaExpand ex;
@@ -374,7 +385,7 @@ static int state_jobs_on_lane(mina_ctx *c, const mina_state_jobs *j, uint32_t *d
     }
     c->L = L0;
     if (LI != L0) { int jrc; if ((jrc = leg_join(*LI, *L0)) || (jrc = leg_join(*LA, *L0))) return jrc; }
-    mb::state_job_verdict_kernel<<<cdiv(B, 64), 64, 0, L.stream>>>((uint32_t)B, L.st_ok.as<uint32_t>(), ipa_v, acc_v, kimchi_bad, d_verdicts, d_flags);
+    mb::state_job_verdict_kernel<<<cdiv(B, 64), 64, 0, L.stream>>>((uint32_t)B, L.st_ok.as<uint32_t>(), ipa_v, acc_v, kimchi_bad, stmt_ok, d_verdicts, d_flags, d_stmt_out);
     HIPC(hipGetLastError());
     return MINA_OK;
 }
@@ -409,12 +420,18 @@ extern "C" int mina_state_job_batch(mina_ctx *c, const mina_state_jobs *jobs, ui
     auto add = [&](const void *&slot, size_t bytes) { if (slot && bytes) secs.push_back({&slot, bytes}); };
     if (d.with_states) { add(d.state_records, B * S * MINA_PSTATE_SLOTS * 32); add(d.state_nfields, B * S * 4); add(d.expected_hashes, B * S * 32); add(d.precheck, B); }
     if (d.npub) add(d.public_inputs, B * d.npub * 32);
-    mina_kimchi_proofs kd{};
+    mina_kimchi_proofs kd{}; mina_pickles_statements sd{};
     if (d.with_ipa && d.kimchi) {
         kd = *d.kimchi; d.kimchi = &kd;
         kd.public_inputs = nullptr;                                   // the job's own public_inputs section is the one uploaded
         add(kd.prev_chals, B * kd.n_prev * k * 32); add(kd.prev_comms, B * kd.n_prev * 64); add(kd.w_comm, B * 15 * 64); add(kd.z_comm, B * 64);
         add(kd.t_comm, B * 7 * 64); add(kd.evals, B * 43 * 64); add(kd.ft_eval1, B * 32);
+        if (kd.statements) {
+            const void **slots[12]; size_t strides[12];
+            mb_pickles_sections(kd.statements, slots, strides, &sd);
+            kd.statements = &sd;
+            for (int i = 0; i < 12; ++i) add(*slots[i], B * strides[i]);
+        }
         d.sponge_state = d.sponge_pos = d.cip = d.evalpoints = d.evalscale = d.polyscale = d.comms = nullptr;
     }
     if (d.with_ipa) {
@@ -433,11 +450,12 @@ extern "C" int mina_state_job_batch(mina_ctx *c, const mina_state_jobs *jobs, ui
     HIPC(hipMemcpyAsync(L.st_in.p, blob, total, hipMemcpyHostToDevice, L.stream));
     for (size_t i = 0; i < secs.size(); ++i) *secs[i].slot = L.st_in.as<uint8_t>() + offs[i];
     if (d.kimchi) kd.public_inputs = d.public_inputs;
-    if ((rc = L.st_verdicts.ensure(B * 4 + 16))) return rc;
-    uint32_t *dv = L.st_verdicts.as<uint32_t>(), *df = dv + B;
-    if ((rc = state_jobs_on_lane(c, &d, dv, df, /*split=*/B <= 1024))) return rc;
-    std::vector<uint32_t> hv(B + 4);
-    if ((rc = d2h_sync(c, hv.data(), L.st_verdicts, (B + 4) * 4))) return rc;
+    if ((rc = L.st_verdicts.ensure(2 * B * 4 + 16))) return rc;
+    uint32_t *dv = L.st_verdicts.as<uint32_t>(), *df = dv + B, *ds = df + 4;
+    if ((rc = state_jobs_on_lane(c, &d, dv, df, /*split=*/B <= 1024, ds))) return rc;
+    std::vector<uint32_t> hv(2 * B + 4);
+    if ((rc = d2h_sync(c, hv.data(), L.st_verdicts, (2 * B + 4) * 4))) return rc;
+    std::vector<uint8_t> stmt_each(B); for (size_t b = 0; b < B; ++b) stmt_each[b] = hv[B + 4 + b] ? 1 : 0;
     const bool ipa_ok = hv[B] != 0, acc_ok = hv[B + 2] != 0;
     if (ipa_ok && acc_ok) { for (size_t b = 0; b < B; ++b) verdicts[b] = hv[b] ? 1 : 0; return MINA_OK; }
     // a folded check failed somewhere: find the culprits.  chain_ok per proof comes from a run without the folded legs.
@@ -450,7 +468,7 @@ extern "C" int mina_state_job_batch(mina_ctx *c, const mina_state_jobs *jobs, ui
             for (size_t b = 0; b < B; ++b) chain_each[b] = hv[b] ? 1 : 0;
         }
     }
-    mina_kimchi_proofs kslice{};
+    mina_kimchi_proofs kslice{}; mina_pickles_statements sslice{};
     auto slice = [&](const mina_state_jobs &src, size_t lo, size_t cnt) {
         mina_state_jobs s = src; s.batch = cnt; s.with_states = 0; s.precheck = nullptr;
         auto adv = [&](const void *&p, size_t stride) { if (p) p = (const uint8_t *)p + lo * stride; };
@@ -458,6 +476,12 @@ extern "C" int mina_state_job_batch(mina_ctx *c, const mina_state_jobs *jobs, ui
             kslice = *s.kimchi; kslice.batch = cnt; s.kimchi = &kslice;
             adv(kslice.public_inputs, (size_t)kslice.npub * 32); adv(kslice.prev_chals, (size_t)kslice.n_prev * k * 32); adv(kslice.prev_comms, (size_t)kslice.n_prev * 64);
             adv(kslice.w_comm, 15 * 64); adv(kslice.z_comm, 64); adv(kslice.t_comm, 7 * 64); adv(kslice.evals, 43 * 64); adv(kslice.ft_eval1, 32);
+            if (kslice.statements) {
+                const void **slots[12]; size_t strides[12];
+                mb_pickles_sections(kslice.statements, slots, strides, &sslice);
+                kslice.statements = &sslice;
+                for (int i = 0; i < 12; ++i) adv(*slots[i], strides[i]);
+            }
         }
         adv(s.public_inputs, (size_t)s.npub * 32);
         adv(s.sponge_state, 96); adv(s.sponge_pos, 8); adv(s.cip, 32); adv(s.lr, 2 * k * 64); adv(s.delta, 64); adv(s.sg, 64); adv(s.z1, 32); adv(s.z2, 32);
@@ -486,6 +510,6 @@ extern "C" int mina_state_job_batch(mina_ctx *c, const mina_state_jobs *jobs, ui
     };
     if (!ipa_ok && (rc = bisect(true, ipa_each))) return rc;
     if (!acc_ok && (rc = bisect(false, acc_each))) return rc;
-    for (size_t b = 0; b < B; ++b) verdicts[b] = (chain_each[b] && ipa_each[b] && acc_each[b]) ? 1 : 0;
+    for (size_t b = 0; b < B; ++b) verdicts[b] = (chain_each[b] && ipa_each[b] && acc_each[b] && stmt_each[b]) ? 1 : 0;
     return MINA_OK;
 }

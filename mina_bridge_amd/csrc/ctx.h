@@ -69,7 +69,7 @@ struct MsmWorkspace {
 
 // HIP-event stage timing on the context stream (off by default; bench.py turns it on for the timed region)
 enum ProfStage : int { PS_DIGITS = 0, PS_SCAN, PS_SCATTER, PS_ACCUMULATE, PS_BUCKET_SUM, PS_REDUCE_A, PS_REDUCE_BC, PS_FINISH,
-                       PS_BPOLY_TABLES, PS_BPOLY_FOLD, PS_BPOLY_FINISH, PS_STATE_HASH, PS_IPA_TRANSCRIPT, PS_KIMCHI, PS_COUNT };
+                       PS_BPOLY_TABLES, PS_BPOLY_FOLD, PS_BPOLY_FINISH, PS_STATE_HASH, PS_IPA_TRANSCRIPT, PS_KIMCHI, PS_PICKLES, PS_COUNT };
 struct ProfState {
     int mask = 0;                                   // bit per stage; 0 = off
     struct Rec { hipEvent_t a, b; int stage; };
@@ -89,7 +89,7 @@ struct Lane {
     DevBuf bp_ltab, bp_htab, bp_partial;
     DevBuf ipa_chals, ipa_folded, ipa_xyzz_a, ipa_xyzz_b, ipa_points, ipa_scalars, ipa_sigma, ipa_in_a, ipa_in_b, ipa_in_c, ipa_verdict, ipa_xfer;
     DevBuf st_ok, st_hashes, st_pub_xyzz, st_pubcomm, st_flags, st_in, st_verdicts;   // Proof-of-State job (api_state.hip)
-    DevBuf kc_state, kc_pos, kc_cip, kc_pts, kc_v, kc_u, kc_comms, kc_xfer;                  // kimchi to_batch output rows (api_kimchi.hip)
+    DevBuf kc_state, kc_pos, kc_cip, kc_pts, kc_v, kc_u, kc_comms, kc_xfer, pk_xe, pk_pub, pk_ok;                  // kimchi to_batch output rows (api_kimchi.hip)
     void release_all() {
         MsmWorkspace &w = ws;
         DevBuf *all[] = {&w.scalars, &w.points, &w.ekey, &w.eval, &w.eoff, &w.count, &w.start, &w.task_start, &w.rem_pos, &w.rem_bucket, &w.info, &w.sorted, &w.partial, &w.heavy, &w.order, &w.ghist, &w.stage,
@@ -97,7 +97,7 @@ struct Lane {
                          &bp_ltab, &bp_htab, &bp_partial, &ipa_chals, &ipa_folded, &ipa_xyzz_a, &ipa_xyzz_b, &ipa_points, &ipa_scalars,
                          &ipa_sigma, &ipa_in_a, &ipa_in_b, &ipa_in_c, &ipa_verdict, &ipa_xfer,
                          &st_ok, &st_hashes, &st_pub_xyzz, &st_pubcomm, &st_flags, &st_in, &st_verdicts,
-                         &kc_state, &kc_pos, &kc_cip, &kc_pts, &kc_v, &kc_u, &kc_comms, &kc_xfer};
+                         &kc_state, &kc_pos, &kc_cip, &kc_pts, &kc_v, &kc_u, &kc_comms, &kc_xfer, &pk_xe, &pk_pub, &pk_ok};
         for (DevBuf *b : all) b->release();
         host_stage.release();
     }
@@ -118,6 +118,7 @@ struct mina_ctx {
     DevBuf merkle_salts[2]; uint32_t merkle_depth[2] = {0, 0};   // salted initial states of the Merkle hash per height
     DevBuf kimchi_index, kimchi_tokens, kimchi_literals; bool have_kimchi = false; uint32_t kimchi_log2 = 0; uint8_t kimchi_digest[32] = {0};   // installed wrap verifier index
     uint8_t kimchi_comms_host[28 * 64] = {0};   // its commitments as installed: sigma 7, coefficients 15, selectors 6 (messages_for_next_step_proof hashes them)
+    DevBuf pickles_index, pickles_tokens, pickles_literals; bool have_pickles_dev = false, pickles_ms_valid = false;   // installed step index (api_pickles.hip); ms = the Tick sponge after the wrap index commitments
     DevBuf state_salts; bool have_state_salts = false;           // salted initial states of the named hash prefixes (Fp): MB_SALT_*
     void use_lane0() { L = &lanes[0]; }
     void next_lane() { L = &lanes[rr++ % (unsigned)nlanes]; }

@@ -38,7 +38,7 @@ EXPORTS = [
     "mina_state_jobs_prepare", "mina_state_job_batch_dev", "mina_state_job_batch",
     "mina_challenge_to_field_dev", "mina_field_sum_rows_dev", "mina_msm_srs_range_dev", "mina_msm_dev", "mina_points_sum_dev", "mina_point_records_equal_dev",
     "mina_step_index_install", "mina_pickles_public_input",
-    "mina_verifier_index_install", "mina_verifier_index_digest", "mina_kimchi_to_batch", "mina_wrap_proof_flatten", "mina_state_proof_split",
+    "mina_verifier_index_install", "mina_verifier_index_digest", "mina_kimchi_to_batch", "mina_pickles_public_inputs_batch", "mina_wrap_proof_flatten", "mina_state_proof_split",
     "mina_verify_state", "mina_verify_state_batch", "mina_verify_state_checks", "mina_verify_state_files", "mina_verify_account", "mina_verify_account_batch",
     "mina_verify_account_files", "mina_verify_account_checks", "mina_verify_account_ctx", "mina_account_hash_batch", "mina_account_abi_encode", "mina_verify_configure", "mina_verify_shutdown", "mina_verify_global_ctx", "mina_poseidon_params_name",
     "mina_poseidon_install_default_params",
@@ -210,8 +210,18 @@ class VerifierIndex(ctypes.Structure):
 class KimchiProofs(ctypes.Structure):
     _fields_ = [("batch", ctypes.c_size_t), ("n_prev", ctypes.c_uint32), ("npub", ctypes.c_uint32), ("public_inputs", ctypes.c_void_p), ("prev_chals", ctypes.c_void_p),
                 ("prev_comms", ctypes.c_void_p), ("w_comm", ctypes.c_void_p), ("z_comm", ctypes.c_void_p), ("t_comm", ctypes.c_void_p), ("evals", ctypes.c_void_p),
-                ("ft_eval1", ctypes.c_void_p)]
+                ("ft_eval1", ctypes.c_void_p), ("statements", ctypes.c_void_p)]
     POINTER_FIELDS = ("public_inputs", "prev_chals", "prev_comms", "w_comm", "z_comm", "t_comm", "evals", "ft_eval1")
+
+
+class PicklesStatements(ctypes.Structure):
+    """mina_pickles_statements: structure-of-arrays over the batch (include/mina_verify.h)"""
+    POINTER_FIELDS = ("plonk", "bulletproof_challenges", "step_old_challenges", "step_comms", "wrap_old_challenges", "wrap_sg", "sponge_digest", "prev_evals",
+                      "prev_public_input", "prev_ft_eval1", "app_state", "misc")
+    _fields_ = [("n_old", ctypes.c_uint32), ("n_evals", ctypes.c_uint32)] + [(n, ctypes.c_void_p) for n in POINTER_FIELDS]
+
+    def strides(self):
+        return dict(zip(self.POINTER_FIELDS, (64, 256, self.n_old * 256, self.n_old * 64, 480, 64, 32, self.n_evals * 64, 64, 32, 32, 32)))
 
 
 class KimchiBatchOut(ctypes.Structure):
@@ -857,7 +867,8 @@ class MinaContext:
         return j, keep
 
     @staticmethod
-    def make_kimchi_proofs(batch: int, n_prev: int, npub: int, arrays: dict):
+    def make_kimchi_proofs(batch: int, n_prev: int, npub: int, arrays: dict, statements=None):
+        """statements: (PicklesStatements, keep) from make_pickles_statements -- the public inputs are then derived on the GPU"""
         kp = KimchiProofs(); keep = []
         kp.batch, kp.n_prev, kp.npub = batch, n_prev, npub
         for name in KimchiProofs.POINTER_FIELDS:
@@ -866,7 +877,32 @@ class MinaContext:
                 continue
             a = np.ascontiguousarray(a); keep.append(a)
             setattr(kp, name, a.ctypes.data)
+        if statements is not None:
+            st, skeep = statements
+            kp.statements = ctypes.addressof(st); keep.append((st, skeep))
         return kp, keep
+
+    @staticmethod
+    def make_pickles_statements(n_old: int, n_evals: int, arrays: dict):
+        """arrays: section name -> host uint8 array or an int device address"""
+        st = PicklesStatements(); keep = []
+        st.n_old, st.n_evals = n_old, n_evals
+        for name in PicklesStatements.POINTER_FIELDS:
+            a = arrays.get(name)
+            if a is None:
+                continue
+            if isinstance(a, int):
+                setattr(st, name, a); continue
+            a = np.ascontiguousarray(a); keep.append(a)
+            setattr(st, name, a.ctypes.data)
+        return st, keep
+
+    def pickles_public_inputs_batch(self, statements, batch: int):
+        """statements -> (public inputs [batch, 40, 32], ok [batch]) through the GPU kernels (mina_pickles_public_inputs_batch)"""
+        st, _keep = statements
+        pub = np.zeros((batch, 40, 32), np.uint8); ok = np.zeros(batch, np.uint8)
+        self._ck(self._lib.mina_pickles_public_inputs_batch(self._h, ctypes.byref(st), ctypes.c_size_t(batch), _p(pub), _p(ok)), "mina_pickles_public_inputs_batch")
+        return pub, ok
 
     def verifier_index_install(self, log2_domain: int, zk_rows: int, perm_alpha_offset: int, shifts, sigma_comm, coefficients_comm, selector_comm, constant_term: bytes):
         vi = VerifierIndex(); arrs = [_u8(shifts), _u8(sigma_comm), _u8(coefficients_comm), _u8(selector_comm), _u8(constant_term) if len(constant_term) else np.zeros(1, np.uint8)]

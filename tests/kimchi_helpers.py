@@ -76,3 +76,50 @@ def load_k15_fixture():
                  "expect": p["expect"]}
         proofs.append(([int(x) for x in p["pubs"]], proof))
     return ix, proofs, fx
+
+
+def statements_soa(wraps, apps):
+    """wrap-proof dicts (tests/wire_writers.py layout) + application states -> the sections of `mina_pickles_statements` (numpy uint8).
+    Chunked evaluations are combined with zeta^(2^16) here, as the struct asks (the product's own container path does the same on the host)."""
+    import numpy as np
+    from oracle import kimchi_ref as K, pasta_ref as R, pickles_ref as PK
+    le = lambda x, n: int(x).to_bytes(n, "little")
+    sec = {n: bytearray() for n in ("plonk", "bulletproof_challenges", "step_old_challenges", "step_comms", "wrap_old_challenges", "wrap_sg", "sponge_digest", "prev_evals",
+                                    "prev_public_input", "prev_ft_eval1", "app_state", "misc")}
+    n_old = len(wraps[0]["step_old_chals"]); n_evals = None
+    for w, app in zip(wraps, apps):
+        assert len(w["step_old_chals"]) == n_old and len(w["step_comms"]) == n_old
+        for name in ("alpha", "beta", "gamma", "zeta"):
+            sec["plonk"] += le(w[name], 16)
+        for c in w["bulletproof_challenges"]:
+            sec["bulletproof_challenges"] += le(c, 16)
+        for row in w["step_old_chals"]:
+            for c in row:
+                sec["step_old_challenges"] += le(c, 16)
+        for x, y in w["step_comms"]:
+            sec["step_comms"] += le(x, 32) + le(y, 32)
+        for row in w["old_bulletproof_challenges"]:
+            for c in row:
+                sec["wrap_old_challenges"] += le(c, 16)
+        sg = w["challenge_polynomial_commitment"]
+        sec["wrap_sg"] += le(sg[0], 32) + le(sg[1], 32)
+        for l in w["sponge_digest"]:
+            sec["sponge_digest"] += le(l, 8)
+        zeta = R.challenge_to_field(w["zeta"], PK.endo_fp(), PK.P)
+        zetaw = zeta * K.O_domain_generator(PK.P, w["domain_log2"]) % PK.P
+        zn, zwn = pow(zeta, 1 << 16, PK.P), pow(zetaw, 1 << 16, PK.P)
+        seq = [PK.combine_chunks(pr, zn, zwn, PK.P) for pr in PK.prev_evals_sequence(w)]
+        n_evals = n_evals or len(seq); assert len(seq) == n_evals
+        for a, b in seq:
+            sec["prev_evals"] += le(a, 32) + le(b, 32)
+        sec["prev_public_input"] += le(w["prev_public_input"][0], 32) + le(w["prev_public_input"][1], 32)
+        sec["prev_ft_eval1"] += le(w["prev_ft_eval1"], 32)
+        sec["app_state"] += le(app, 32)
+        misc = bytearray(32)
+        misc[0] = w["domain_log2"]; misc[1] = w["proofs_verified"]
+        for j, f in enumerate(w["feature_flags"]):
+            misc[2 + j] = 1 if f else 0
+        if w["joint_combiner"] is not None:
+            misc[10] = 1; misc[16:32] = le(w["joint_combiner"], 16)
+        sec["misc"] += misc
+    return n_old, n_evals, {k: np.frombuffer(bytes(v), np.uint8).copy() if len(v) else np.zeros(1, np.uint8) for k, v in sec.items()}

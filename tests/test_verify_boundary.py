@@ -333,3 +333,51 @@ def test_pickles_public_input_matches_oracle(world, srs_oracle):
     w["domain_log2"] = 9                                         # a step domain the installed index does not know
     with pytest.raises(m.MinaError):
         gctx.pickles_public_input(wrap_proof_bytes(w, True), m.lib.ENC_BINPROT, O.int_to_le(5))
+
+
+def test_pickles_statements_on_the_gpu_match_oracle(world, srs_oracle):
+    """the batch form (expand / digest / tick / scalar kernels of api_pickles.hip, no host arithmetic) == oracle/pickles_ref.py, for both
+    sponge forms (8-lane up to 1024 statements per call, 3-lane above), 0..2 previous accumulators, optional + chunked evaluations; a
+    malformed statement is flagged without disturbing its neighbours"""
+    import mina_bridge_amd as m
+    from ipa_helpers import poseidon_pp
+    from kimchi_helpers import statements_soa
+    from oracle import pickles_ref as PK
+    from oracle import oracle as O
+    from wire_writers import synth_wrap_proof
+    rng = random.Random(321)
+    ix = world["circ"].index
+    comms = list(ix.sigma_comm) + list(ix.coefficients_comm) + list(ix.selector_comm)
+    gctx = world["gctx"]
+    for n_old, count in ((2, 5), (0, 3), (1, 4)):
+        optional = [rng.randrange(3) == 0 for _ in range(19)]
+        wraps, apps = [], []
+        for i in range(count):
+            w = synth_wrap_proof(rng, k=K_LOG2)
+            w["prev_optional"] = [(([rng.randrange(PK.P)], [rng.randrange(PK.P)]) if o else None) for o in optional]        # one shape per call
+            if i % 2:
+                w["prev_evals"][7] = ([rng.randrange(PK.P), rng.randrange(PK.P)], [rng.randrange(PK.P), rng.randrange(PK.P)])
+            w["step_comms"] = w["step_comms"][:n_old]
+            w["step_old_chals"] = w["step_old_chals"][:n_old]
+            wraps.append(w); apps.append(rng.randrange(PK.P))
+        want = [PK.statement_public_input(w, world["step"], comms, a, poseidon_pp(0), poseidon_pp(1))[0] for w, a in zip(wraps, apps)]
+        n_old_, n_evals, sec = statements_soa(wraps, apps)
+        st = gctx.make_pickles_statements(n_old_, n_evals, sec)
+        pub, ok = gctx.pickles_public_inputs_batch(st, count)
+        assert ok.tolist() == [1] * count
+        for b in range(count):
+            assert [O.le_to_int(x) for x in pub[b]] == want[b], (n_old, b)
+        # the 3-lane sponge form: the same statements tiled past the 1024 threshold
+        reps = 1030 // count + 1
+        big = {k: np.tile(v.reshape(count, -1), (reps, 1)).reshape(-1) if v.size >= count else v for k, v in sec.items()}
+        pub2, ok2 = gctx.pickles_public_inputs_batch(gctx.make_pickles_statements(n_old_, n_evals, big), count * reps)
+        assert ok2.all() and (pub2.reshape(reps, count, 40, 32) == pub[None]).all()
+        # malformed: a non-canonical evaluation, an unknown step domain, a bad branch byte -- each flags exactly its own statement
+        bad = {k: v.copy() for k, v in sec.items()}
+        bad["prev_evals"].reshape(count, -1)[1, :32] = 0xff
+        bad["misc"].reshape(count, 32)[2, 0] = 9
+        bad["misc"].reshape(count, 32)[0, 1] = 3
+        pub3, ok3 = gctx.pickles_public_inputs_batch(gctx.make_pickles_statements(n_old_, n_evals, bad), count)
+        assert ok3.tolist() == [0, 0, 0] + [1] * (count - 3)
+        for b in range(3, count):
+            assert (pub3[b] == pub[b]).all()
