@@ -2,16 +2,24 @@
 """bench.py -- Mina state proofs verified/sec on the MI355X-native verifier hot path (BASELINE.json metric, config C3).
 
 A "step" = one pass of the Proof-of-State job over one batch of `--jobs` synthetic state proofs, all inputs resident in
-HBM, through ONE C-ABI call (`mina_state_job_batch_dev`, no host synchronisation inside): per proof
+HBM, through ONE C-ABI call (`mina_state_job_batch_dev`, no host synchronisation inside).  Per proof, default `--mode full` -- the
+whole verifier from the PARSED proof, everything on the GPU:
   * the 17 protocol-state hashes (16 candidate-chain states + bridge tip; `MinaHash` = Poseidon over `to_input`), compared
     with the public inputs, plus the chain linkage                                      (README.md:283-288)
-  * the wrap proof's public-input commitment: 40 scalars over the 2^15 Pallas Lagrange basis
-  * the wrap proof's combined IPA opening: k = 15 rounds, 45 commitments x 2 evaluation points, folded over the batch
+  * the Pickles statement -> the wrap circuit's 40 public inputs: endo-expanded challenges, the Tick sponge over the step proof's
+    evaluations (xi, r), ft_eval0 of the step proof, derive_plonk, combined inner product, b, the two message digests, packing
+                                                                                        (openmina verify_block / compute_deferred_values)
+  * the wrap proof's public-input commitment: those 40 scalars over the 2^15 Pallas Lagrange basis
+  * kimchi `oracles` + `to_batch` of the wrap proof: Fq-sponge, Fr-sponge, public polynomial, ft_eval0 with the linearization's
+    constant term (PolishToken program), the combined inner product, the chunked ft commitment (handed to the MSM as its 8 terms)
+  * the wrap proof's combined IPA opening: k = 15 rounds, 47 commitments x 2 evaluation points, folded over the batch
     into one 2^15 fixed-base MSM + one variable-base MSM                                (kimchi batch_verify / SRS::verify)
   * the step accumulator check: b_poly_coefficients of 16 challenges -> 2^16-base Vesta MSM, folded over the batch
-Steps are issued round-robin over `--pipeline` lanes (independent batches overlap on the GPU).  What the job does NOT
-contain (not built / no data offline): kimchi's `oracles` + linearisation (the verifier index is absent), binprot parsing
-(host work, done before the timed region by the caller).
+`--mode kimchi` leaves the statement stage out (public inputs given), `--mode prepared` also the kimchi stage (BatchEvaluationProof
+rows given: round 2's first headline).  The wrap / step verifier indexes are synthetic at the real sizes (the blockchain-snark
+indexes are not offline); proofs are minted by the repo's CPU oracle and ACCEPT.  Steps are issued round-robin over
+`--pipeline` lanes (independent batches overlap on the GPU).  Not in the job: bin_prot / bincode parsing of the containers and the
+consensus pre-checks (host side of the boundary, done by the caller before the timed region).
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--jobs B] [--pipeline L]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -129,6 +137,30 @@ def build_kimchi_section(ctx, m, B: int):
     return m.MinaContext.make_kimchi_proofs(B, 2, 40, arrays), op, arrays["public_inputs"]
 
 
+def build_full_section(ctx, m, B: int):
+    """the complete wrap proofs of tests/golden/statement_k15.json (Pickles statement + wrap proof whose public input is its packing + the
+    step accumulator the statement carries), tiled to B: (KimchiProofs with statements + keep, opening arrays, accumulator arrays, sample)"""
+    from kimchi_helpers import install_index, install_step_index, kimchi_arrays, load_k15_fixture, load_statement_fixture, make_step_index, statements_soa
+    ix, _, _ = load_k15_fixture()
+    install_index(ctx, ix)
+    step = make_step_index(99)
+    install_step_index(ctx, step)
+    items, fx = load_statement_fixture()
+    n = len(items)
+    idx = np.arange(B) % n
+    arrays, op = kimchi_arrays([it["proof"] for it in items], [])
+    per = {"prev_chals": 2 * 15 * 32, "prev_comms": 2 * 64, "w_comm": 15 * 64, "z_comm": 64, "t_comm": 7 * 64, "evals": 43 * 64, "ft_eval1": 32,
+           "lr": 30 * 64, "delta": 64, "sg": 64, "z1": 32, "z2": 32}
+    tile = lambda a, w: np.ascontiguousarray(np.asarray(a, np.uint8).reshape(n, w)[idx].reshape(-1))
+    arrays = {k: tile(v, per[k]) for k, v in arrays.items() if v is not None}
+    op = {k: tile(v, per[k]) for k, v in op.items()}
+    n_old, n_evals, sec = statements_soa([it["wrap"] for it in items], [it["app"] for it in items])
+    sec = {k: tile(v, v.size // n) for k, v in sec.items()}
+    st = m.MinaContext.make_pickles_statements(n_old, n_evals, sec)
+    acc = {"acc_prechallenges": tile(np.stack([it["acc_pre"] for it in items]), ACC_K * 16), "acc_sg": tile(np.stack([it["acc_sg"] for it in items]), 64)}
+    return m.MinaContext.make_kimchi_proofs(B, 2, 40, arrays, statements=st), op, acc, (ix, step, items[0])
+
+
 def algorithmic_bytes_per_proof() -> int:
     """what one state proof hands to the verifier, as laid out in HBM ('proof_len + pub_len'; here the kernel-ready
     form): 17 flattened states (50 field elements each) + their 17 expected hashes + 40 public inputs + the opening
@@ -146,7 +178,7 @@ def cpu_model() -> str:
     return platform.processor() or "unknown"
 
 
-def cpu_baseline(sample, budget_s: float = 20.0):
+def cpu_baseline(sample, budget_s: float = 20.0, full_sample=None):
     """The same composite on the CPU restatement (oracle/, kind="port" -- the reference's Rust verifier cannot be built here):
     BASELINE config C1.  One proof at a time: 17 state hashes (C Poseidon), public-input commitment (iFFT + 2^15 MSM), the wrap
     opening check (Python transcript + C b_poly / MSMs) and the 2^16 Vesta accumulator MSM (ark-style Pippenger, one thread per
@@ -181,7 +213,25 @@ def cpu_baseline(sample, budget_s: float = 20.0):
         perm = O.poseidon_permute(FIELD_FP, params, np.stack([O.ints_to_le(x).reshape(96) for x in state]))
         return perm[:, :32]
 
+    def one_full(threads):
+        # the full path from the parsed proof: statement -> public inputs, kimchi oracles + to_batch (both Python over C kernels), opening, accumulator
+        from ipa_helpers import poseidon_pp
+        from oracle import kimchi_ref as K, pickles_ref as PK
+        ix, step, item = full_sample
+        ok = bool((state_hashes() == hashes).all())
+        g, h = srs[0]
+        hp = O.bytes_to_point(h)
+        pb, ps = poseidon_pp(0), poseidon_pp(1)
+        comms = list(ix.sigma_comm) + list(ix.coefficients_comm) + list(ix.selector_comm)
+        pubs_, _, _, _ = PK.statement_public_input(item["wrap"], step, comms, item["app"], pb, ps)
+        _, e = K.oracles_and_batch(ix, item["proof"], pubs_, pb, ps, g[: 1 << WRAP_K], hp)
+        ok = ok and I.ipa_verify_batch(0, g[: 1 << WRAP_K], hp, [e], 7, 9, threads=threads)
+        ok = ok and J.accumulator_ok(1, srs[1][0], ACC_K, item["acc_pre"], item["acc_sg"], threads=threads)
+        return ok
+
     def one(threads):
+        if full_sample is not None:
+            return one_full(threads)
         global_threads = threads
         ok = bool((state_hashes() == hashes).all())
         g, h = srs[0]
@@ -208,6 +258,7 @@ def cpu_baseline(sample, budget_s: float = 20.0):
     return {"value": v, "unit": "proofs/s", "cores": threads, "kind": "port", "cpu_model": cpu_model(), "nproc": nproc,
             "single_thread_value": out["single"][0],
             "sample": f"{reps} full Proof-of-State jobs (BASELINE config C1 = the bench's own job, one proof at a time: 17 state hashes + "
+                      + ("Pickles statement -> public inputs + kimchi oracles/to_batch + " if full_sample is not None else "") +
                       f"public-input commitment + k=15 wrap opening check + 2^16 Vesta accumulator) on the repo's CPU restatement "
                       f"(C field/MSM/Poseidon kernels under a Python driver; NOT the Rust reference, which cannot be built here) in {el:.1f}s, "
                       f"MSMs threaded over {threads} windows; verdict ACCEPT: {ok}; single-thread: {out['single'][2]} jobs in {out['single'][3]:.1f}s"}
@@ -221,10 +272,16 @@ def main():
     ap.add_argument("--jobs", type=int, default=8192, help="state proofs per step (one mina_state_job_batch_dev call)")
     ap.add_argument("--pipeline", type=int, default=4, help="internal stream lanes over which consecutive steps are issued")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--kimchi", action="store_true", help="run the wrap leg from the raw proofs: kimchi oracles + to_batch on the GPU against the synthetic "
-                    "wrap-size index of tests/golden/kimchi_k15.json (4 distinct proofs), then the opening check")
+    ap.add_argument("--mode", choices=("full", "kimchi", "prepared"), default="full",
+                    help="full (default): the whole verifier from parsed proofs -- Pickles statement -> public inputs, kimchi oracles + to_batch, opening check, "
+                         "accumulator, 17 state hashes (fixture tests/golden/statement_k15.json, 4 distinct proofs); kimchi: the same without the statement stage "
+                         "(public inputs given; tests/golden/kimchi_k15.json); prepared: pre-derived BatchEvaluationProof rows (round 2's first headline)")
+    ap.add_argument("--kimchi", action="store_true", help="alias of --mode kimchi")
     ap.add_argument("--no-probes", action="store_true", help="skip the isolated-kernel and C2 probes (profiling runs)")
     args = ap.parse_args()
+    if args.kimchi:
+        args.mode = "kimchi"
+    args.kimchi = args.mode != "prepared"                      # the wrap leg starts from the raw proof in both non-prepared modes
 
     import torch
     import mina_bridge_amd as m
@@ -260,12 +317,19 @@ def main():
     ctx.srs_create(CURVE_PALLAS, 1 << 16)
     B = args.jobs
     (hj, keep), sample = build_batch(ctx, m, B, seed=0x6D696E61 + rank)
+    full_sample = None
     if args.kimchi:                                            # the wrap leg from the raw proofs instead of pre-derived BatchEvaluationProof rows
-        kp, op, kpub = build_kimchi_section(ctx, m, B)
+        if args.mode == "full":
+            kp, op, acc, full_sample = build_full_section(ctx, m, B)
+            extra = list(op.items()) + list(acc.items())
+            hj.public_inputs = None                            # derived on the GPU from the statements
+        else:
+            kp, op, kpub = build_kimchi_section(ctx, m, B)
+            extra = list(op.items()) + [("public_inputs", kpub)]
         for name in ("sponge_state", "sponge_pos", "cip", "evalpoints", "evalscale", "polyscale", "comms"):
             setattr(hj, name, None)
         keep = [a for a in keep] + [kp]
-        for name, arr in list(op.items()) + [("public_inputs", kpub)]:
+        for name, arr in extra:
             arr = np.ascontiguousarray(arr); keep.append(arr); setattr(hj, name, arr.ctypes.data)
         hj.n_comms = 47
     dev = torch.device("cuda", local_rank)
@@ -277,19 +341,29 @@ def main():
     for name in m.lib.StateJobs.POINTER_FIELDS:                # every section resident in HBM (torch owns the buffers)
         addr = getattr(hj, name)
         if addr:
-            t = torch.from_numpy(by_addr[addr].view(np.uint8).reshape(-1)).to(dev)
+            t = torch.from_numpy(np.array(by_addr[addr].view(np.uint8).reshape(-1))).to(dev)
             dtensors.append(t); setattr(dj, name, t.data_ptr())
     if args.kimchi:                                            # the kimchi section's arrays live in HBM as well
         import ctypes as ct
         dk = m.lib.KimchiProofs()
         ct.memmove(ct.byref(dk), ct.byref(kp[0]), ct.sizeof(m.lib.KimchiProofs))
-        kaddr = {a.ctypes.data: a for a in kp[1]}
+        kaddr = {a.ctypes.data: a for a in kp[1] if isinstance(a, np.ndarray)}
         for name in m.lib.KimchiProofs.POINTER_FIELDS:
             addr = getattr(kp[0], name)
             if addr:
                 if name == "public_inputs":
                     setattr(dk, name, dj.public_inputs); continue
                 t = torch.from_numpy(kaddr[addr].view(np.uint8).reshape(-1)).to(dev); dtensors.append(t); setattr(dk, name, t.data_ptr())
+        if args.mode == "full":                                # the statement sections too
+            hst, hkeep = next(a for a in kp[1] if isinstance(a, tuple))
+            dst = m.lib.PicklesStatements()
+            ct.memmove(ct.byref(dst), ct.byref(hst), ct.sizeof(m.lib.PicklesStatements))
+            saddr = {a.ctypes.data: a for a in hkeep}
+            for name in m.lib.PicklesStatements.POINTER_FIELDS:
+                addr = getattr(hst, name)
+                if addr:
+                    t = torch.from_numpy(saddr[addr].view(np.uint8).reshape(-1)).to(dev); dtensors.append(t); setattr(dst, name, t.data_ptr())
+            dk.statements = ct.addressof(dst)
         dj.kimchi = ct.addressof(dk)
     ctx.state_jobs_prepare(LOG2_DOMAIN, NPUB)
     ctx.set_pipeline(args.pipeline)
@@ -405,15 +479,25 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32x8-montgomery (255-bit prime fields, integer)", "data": "synthetic",
             "config": {"workload": "C3: full Proof-of-State job per proof -- 17 protocol-state hashes (chain of 16 + bridge tip) vs public inputs + linkage, "
-                                   "wrap-proof public-input commitment (40 inputs, 2^15 Pallas domain), wrap IPA opening (k=15, 45 commitments x 2 points), "
+                                   + ("the Pickles statement's deferred values and digests, " if args.mode == "full" else "")
+                                   + ("kimchi oracles + to_batch of the wrap proof, " if args.kimchi else "") +
+                                   "wrap-proof public-input commitment (40 inputs, 2^15 Pallas domain), wrap IPA opening (k=15, 45+ commitments x 2 points), "
                                    "2^16-base Vesta step-accumulator check; verdict per proof, bit-exact vs the CPU oracle composite (tests/test_state_job.py)",
                        "proofs_per_step": B, "pipeline_lanes": args.pipeline,
-                       "distinct_inputs": "32 chains, 8 wrap openings (tests/golden/state_job_k15.json), 32 accumulators per rank",
+                       "mode": args.mode,
+                       "distinct_inputs": {"full": "32 chains, 4 complete wrap proofs (tests/golden/statement_k15.json: statement + proof + its accumulator) per rank; the statements' "
+                                                   "application state is the fixture's, not the hash of the chain tiled beside it (that binding: tests/test_verify_boundary.py)",
+                                           "kimchi": "32 chains, 4 wrap proofs (tests/golden/kimchi_k15.json), 32 accumulators per rank",
+                                           "prepared": "32 chains, 8 wrap openings (tests/golden/state_job_k15.json), 32 accumulators per rank"}[args.mode],
                        "folding": "IPA and accumulator checks folded over the step's batch with caller-supplied randomisers (kimchi batch_verify's shape)",
-                       "not_in_job": ("binprot parsing and the Pickles statement -> public-input derivation (host + GPU sponges, before the timed region)" if args.kimchi else
-                                      "kimchi oracles/linearisation (run with --kimchi: synthetic wrap-size index), binprot parsing (host, before the timed region)"),
-                       "wrap_leg": ("kimchi oracles + to_batch on the GPU from the raw wrap proofs (synthetic index, domain 2^15, 40 public inputs, 47 commitments)" if args.kimchi
-                                    else "pre-derived BatchEvaluationProof rows (45 commitments)"),
+                       "not_in_job": {"full": "bin_prot / bincode parsing of the containers and the consensus pre-checks (host side of the boundary, before the timed region)",
+                                      "kimchi": "parsing and the Pickles statement -> public-input derivation (public inputs given)",
+                                      "prepared": "kimchi oracles/linearisation, the statement derivation, parsing (BatchEvaluationProof rows given)"}[args.mode],
+                       "wrap_leg": {"full": "from the parsed wrap proof, all on the GPU: Pickles statement -> 40 public inputs (compute_deferred_values, the two message digests, "
+                                            "packing) -> public-input commitment -> kimchi oracles + to_batch -> combined opening check (synthetic wrap-size verifier index: "
+                                            "domain 2^15, 47 commitments; synthetic step index)",
+                                    "kimchi": "kimchi oracles + to_batch on the GPU from the raw wrap proofs (synthetic index, domain 2^15, 40 public inputs, 47 commitments)",
+                                    "prepared": "pre-derived BatchEvaluationProof rows (45 commitments)"}[args.mode],
                        "sharding": f"proof-level, {args.gpus} rank(s); verdict words all-gathered over RCCL" if dist_on else "single rank",
                        "algorithmic_bytes_per_proof": algorithmic_bytes_per_proof()},
             "roofline": {"bound": "hbm", "kernel": "pstate_hash_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -434,7 +518,7 @@ def main():
             out["roofline_valu"] = {"bound": "int32 multiply issue (v_mad_u64_u32)", "kernel": "pstate_hash_kernel", "achieved": got / 1e9, "peak": peak / 1e9,
                                     "unit": "G modmul/s", "frac": got / peak, "permutations_per_launch": perms}
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sample)
+            out["cpu_baseline"] = cpu_baseline(sample, full_sample=full_sample)
         print(json.dumps(out), flush=True)
     if dist_on:
         dist.barrier()

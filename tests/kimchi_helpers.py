@@ -123,3 +123,53 @@ def statements_soa(wraps, apps):
             misc[10] = 1; misc[16:32] = le(w["joint_combiner"], 16)
         sec["misc"] += misc
     return n_old, n_evals, {k: np.frombuffer(bytes(v), np.uint8).copy() if len(v) else np.zeros(1, np.uint8) for k, v in sec.items()}
+
+
+STEP_DOMAINS = list(range(10, 17))
+
+
+def make_step_index(seed):
+    """a synthetic STEP index: random shifts for every step domain and a constant-term program over the step evaluations"""
+    from ipa_helpers import poseidon_pp
+    from oracle import kimchi_ref as K, pickles_ref as PK, pasta_ref as R
+    import random
+    rng = random.Random(seed)
+    toks = [(K.T_CELL, K.COL_W0 + 2, 0), (K.T_CELL, K.COL_COEFF0 + 1, 1), (K.T_MUL,), (K.T_CELL, K.COL_GENERIC, 0), (K.T_ADD,), (K.T_ALPHA,), (K.T_MUL,),
+            (K.T_ENDO,), (K.T_MDS, 2, 0), (K.T_MUL,), (K.T_ADD,), (K.T_LITERAL, 987654321), (K.T_SUB,), (K.T_VANISH_ZK,), (K.T_LAGRANGE, -2), (K.T_MUL,), (K.T_ADD,),
+            (K.T_BETA,), (K.T_GAMMA,), (K.T_MUL,), (K.T_POW, 5), (K.T_STORE,), (K.T_ADD,), (K.T_LOAD, 0), (K.T_SUB,)]
+    return PK.StepIndex(zk_rows=3, shifts={k: [1] + [rng.randrange(2, R.P) for _ in range(6)] for k in STEP_DOMAINS}, constant_term=toks,
+                        mds=[list(r) for r in poseidon_pp(0).mds])
+
+
+def install_step_index(ctx, step):
+    from kimchi_helpers import encode_tokens
+    from oracle import oracle as O
+    sh = np.concatenate([O.ints_to_le(step.shifts[k]).reshape(-1) for k in STEP_DOMAINS])
+    ctx.step_index_install(step.zk_rows, STEP_DOMAINS, sh, encode_tokens(step.constant_term))
+
+
+def load_statement_fixture():
+    """tests/golden/statement_k15.json -> [dict(wrap=statement fields as in tests/wire_writers.py, app, pubs, acc_pre [16,16] u8, acc_sg [64] u8, proof)]
+    for the wrap index of kimchi_k15.json and the step index make_step_index(99)"""
+    import json, os
+    from oracle import oracle as O
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "statement_k15.json")))
+    pt = lambda hx: O.bytes_to_point(np.frombuffer(bytes.fromhex(hx), np.uint8))
+    dec = lambda v: None if v is None else v if isinstance(v, bool) else int(v) if isinstance(v, str) else [dec(x) for x in v]
+    out = []
+    for p in fx["proofs"]:
+        wrap = {k: dec(v) for k, v in p["statement"].items()}
+        for key in ("step_comms",):
+            wrap[key] = [tuple(x) for x in wrap[key]]
+        wrap["challenge_polynomial_commitment"] = tuple(wrap["challenge_polynomial_commitment"])
+        wrap["prev_public_input"] = tuple(wrap["prev_public_input"])
+        wrap["prev_evals"] = [tuple(x) for x in wrap["prev_evals"]]
+        proof = {"w_comm": [pt(x) for x in p["w_comm"]], "z_comm": pt(p["z_comm"]), "t_comm": [pt(x) for x in p["t_comm"]],
+                 "evals": [(int(a), int(b)) for a, b in p["evals"]], "ft_eval1": int(p["ft_eval1"]),
+                 "opening": {"lr": [(pt(l), pt(r)) for l, r in p["lr"]], "delta": pt(p["delta"]), "sg": pt(p["sg"]), "z1": int(p["z1"]), "z2": int(p["z2"])}}
+        from oracle import pasta_ref as R
+        proof["prev"] = [([R.challenge_to_field(c, R.endo_r(0), R.Q) for c in row], cm) for row, cm in zip(wrap["old_bulletproof_challenges"], wrap["step_comms"])]
+        out.append({"wrap": wrap, "app": int(p["app_state"]), "pubs": [int(x) for x in p["pubs"]],
+                    "acc_pre": np.frombuffer(bytes.fromhex(p["acc_pre"]), np.uint8).reshape(16, 16).copy(), "acc_sg": np.frombuffer(bytes.fromhex(p["acc_sg"]), np.uint8).copy(),
+                    "proof": proof})
+    return out, fx

@@ -130,3 +130,41 @@ def test_kimchi_full_size_wrap_domain(ctx_srs, oracle):
     bad = [copy.deepcopy(p) for p in plist]
     bad[2]["evals"][40] = (bad[2]["evals"][40][0], (bad[2]["evals"][40][1] + 1) % (1 << 254))
     assert ctx_srs.state_job_batch(job(bad, pubs)).tolist() == [1, 1, 0, 1]
+
+
+def test_statement_driven_job_full_size(ctx_srs, oracle):
+    """tests/golden/statement_k15.json: complete wrap proofs at the Pickles wrap size -- statement, the proof whose public input is its
+    packing, the accumulator it carries.  The job derives the public inputs on the GPU from the statements (mina_pickles_statements),
+    runs kimchi + the opening check + the accumulator check, accepts all; a change to ANY statement field (here: one feature flag, the
+    application state, one step evaluation) rejects exactly that proof -- every field is bound through the public input."""
+    import copy
+    import mina_bridge_amd as m
+    from kimchi_helpers import install_index, install_step_index, kimchi_arrays, load_k15_fixture, load_statement_fixture, make_step_index, statements_soa
+    ix, _, _ = load_k15_fixture()
+    install_index(ctx_srs, ix)
+    install_step_index(ctx_srs, make_step_index(99))
+    items, fx = load_statement_fixture()
+    B = len(items)
+    # the GPU derivation equals the packing the fixture's proofs were minted for
+    n_old, n_evals, sec = statements_soa([it["wrap"] for it in items], [it["app"] for it in items])
+    pub, ok = ctx_srs.pickles_public_inputs_batch(m.MinaContext.make_pickles_statements(n_old, n_evals, sec), B)
+    assert ok.tolist() == [1] * B
+    for b, it in enumerate(items):
+        assert [oracle.le_to_int(x) for x in pub[b]] == it["pubs"]
+
+    def job(wraps, apps):
+        a, o = kimchi_arrays([it["proof"] for it in items], [])
+        no, ne, s = statements_soa(wraps, apps)
+        kp = m.MinaContext.make_kimchi_proofs(B, 2, 40, a, statements=m.MinaContext.make_pickles_statements(no, ne, s))
+        ja = dict(o); ja["rand_base"] = oracle.int_to_le(7); ja["sg_rand_base"] = oracle.int_to_le(9)
+        ja["acc_prechallenges"] = np.concatenate([it["acc_pre"].reshape(-1) for it in items]); ja["acc_sg"] = np.concatenate([it["acc_sg"] for it in items])
+        rho = np.random.Generator(np.random.PCG64(5)).integers(0, 256, (B, 32), dtype=np.uint8); rho[:, 31] &= 0x3F
+        ja["acc_rho"] = rho.reshape(-1)
+        return m.MinaContext.make_state_jobs(B, ja, with_ipa=1, with_accumulator=1, kimchi=kp, k=15, log2_domain=15, npub=40, n_evalpoints=2, n_comms=47, acc_k=16)
+    wraps, apps = [it["wrap"] for it in items], [it["app"] for it in items]
+    assert ctx_srs.state_job_batch(job(wraps, apps)).tolist() == [1] * B
+    bad = copy.deepcopy(wraps); bapps = list(apps)
+    bad[0]["feature_flags"][3] = not bad[0]["feature_flags"][3]
+    bapps[1] = (bapps[1] + 1) % (1 << 254)
+    e = bad[3]["prev_evals"][20]; bad[3]["prev_evals"][20] = ([(e[0][0] + 1) % (1 << 254)], e[1])
+    assert ctx_srs.state_job_batch(job(bad, bapps)).tolist() == [0, 0, 1, 0]

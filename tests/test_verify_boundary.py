@@ -47,26 +47,7 @@ def world(srs_oracle):
     m.lib.verify_configure(0)
 
 
-STEP_DOMAINS = list(range(10, 17))
-
-
-def make_step_index(seed):
-    """a synthetic STEP index: random shifts for every step domain and a constant-term program over the step evaluations"""
-    from ipa_helpers import poseidon_pp
-    from oracle import kimchi_ref as K, pickles_ref as PK, pasta_ref as R
-    rng = random.Random(seed)
-    toks = [(K.T_CELL, K.COL_W0 + 2, 0), (K.T_CELL, K.COL_COEFF0 + 1, 1), (K.T_MUL,), (K.T_CELL, K.COL_GENERIC, 0), (K.T_ADD,), (K.T_ALPHA,), (K.T_MUL,),
-            (K.T_ENDO,), (K.T_MDS, 2, 0), (K.T_MUL,), (K.T_ADD,), (K.T_LITERAL, 987654321), (K.T_SUB,), (K.T_VANISH_ZK,), (K.T_LAGRANGE, -2), (K.T_MUL,), (K.T_ADD,),
-            (K.T_BETA,), (K.T_GAMMA,), (K.T_MUL,), (K.T_POW, 5), (K.T_STORE,), (K.T_ADD,), (K.T_LOAD, 0), (K.T_SUB,)]
-    return PK.StepIndex(zk_rows=3, shifts={k: [1] + [rng.randrange(2, R.P) for _ in range(6)] for k in STEP_DOMAINS}, constant_term=toks,
-                        mds=[list(r) for r in poseidon_pp(0).mds])
-
-
-def install_step_index(ctx, step):
-    from kimchi_helpers import encode_tokens
-    from oracle import oracle as O
-    sh = np.concatenate([O.ints_to_le(step.shifts[k]).reshape(-1) for k in STEP_DOMAINS])
-    ctx.step_index_install(step.zk_rows, STEP_DOMAINS, sh, encode_tokens(step.constant_term))
+from kimchi_helpers import STEP_DOMAINS, install_step_index, make_step_index  # noqa: E402
 
 
 def mint_state_proof(world, srs_oracle, seed):
