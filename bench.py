@@ -270,7 +270,7 @@ def main():
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--jobs", type=int, default=8192, help="state proofs per step (one mina_state_job_batch_dev call)")
-    ap.add_argument("--pipeline", type=int, default=4, help="internal stream lanes over which consecutive steps are issued")
+    ap.add_argument("--pipeline", type=int, default=16, help="internal stream lanes over which consecutive steps are issued")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", choices=("full", "kimchi", "prepared"), default="full",
                     help="full (default): the whole verifier from parsed proofs -- Pickles statement -> public inputs, kimchi oracles + to_batch, opening check, "

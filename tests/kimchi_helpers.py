@@ -68,6 +68,8 @@ def load_k15_fixture():
                          sigma_comm=[pt(x) for x in fx["sigma_comm"]], coefficients_comm=[pt(x) for x in fx["coefficients_comm"]],
                          selector_comm=[pt(x) for x in fx["selector_comm"]], constant_term=[tuple(t) for t in fx["constant_term"]],
                          perm_alpha_offset=fx["perm_alpha_offset"], digest=int(fx["digest"]))
+    from ipa_helpers import poseidon_pp
+    ix.mds = [list(row) for row in poseidon_pp(1).mds]       # Constants.mds of the scalar field, as synthetic_circuit sets it
     proofs = []
     for p in fx["proofs"]:
         proof = {"prev": [([int(c) for c in ch], pt(cm)) for ch, cm in p["prev"]], "w_comm": [pt(x) for x in p["w_comm"]], "z_comm": pt(p["z_comm"]),

@@ -73,7 +73,8 @@ def test_srs_load_roundtrip_and_small_depth(ctx_srs, oracle):
             pass
         # encodings ark's deserialiser refuses: x + q (non-canonical alias of a valid x), stray bits in the flag byte
         Q = 0x40000000000000000000000000000000224698FC0994A8DD8C46EB2100000001      # Vesta base field
-        off = 6 + 2                                   # first point: 6-byte header, then c4 21, 33 bytes
+        assert blob[0] == 0x92 and blob[1] == 0xdc      # 300 points: rmp's array16 header
+        off = 4 + 2                                   # first point: 4-byte header, then c4 21, 33 bytes
         x = int.from_bytes(blob[off:off + 32], "little")
         alias = bytearray(blob); alias[off:off + 32] = (x + Q).to_bytes(32, "little")
         with pytest.raises(m.MinaError):

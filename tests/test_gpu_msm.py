@@ -112,33 +112,6 @@ def test_msm_srs_range_slices_sum_to_full(ctx_srs, oracle, srs_oracle):
         assert (acc == full).all()
 
 
-def test_sharded_driver_single_rank_on_gpu(ctx_srs, oracle, srs_oracle):
-    """the real MinaContext behind ShardedAccumulatorCheck (world_size 1, gloo group for the collectives)"""
-    import socket
-    import torch.distributed as dist
-    from mina_bridge_amd.sharded import ShardedAccumulatorCheck
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
-    try:
-        curve, k, B = 1, 8, 4
-        g, _ = srs_oracle[curve]
-        _, endo_r = oracle.endo(curve)
-        pre = rand_scalars(B * k, P, seed=66, bits=128)[:, :16].reshape(B, k, 16).copy()
-        sg = np.empty((B, 64), np.uint8)
-        for b in range(B):
-            chals = np.stack([oracle.challenge_to_field(0, pre[b, i].copy(), endo_r) for i in range(k)])
-            sg[b] = oracle.msm_pippenger(curve, g[: 1 << k], oracle.b_poly_coefficients(0, chals), threads=4)
-        rho = rand_scalars(B, P, seed=67)
-        sh = ShardedAccumulatorCheck(ctx_srs, curve, k)
-        assert sh.verify_proof_level(pre, sg, rho).tolist() == [1] * B
-        assert sh.verify_base_sliced(pre, sg, rho) is True
-        sg[2] = g[0]
-        assert sh.verify_proof_level(pre, sg, rho).tolist() == [1, 1, 0, 1]
-        assert sh.verify_base_sliced(pre, sg, rho) is False
-    finally:
-        dist.destroy_process_group()
-
-
 @pytest.mark.parametrize("curve,n", [(1, 2048), (0, 5000), (1, 40000), (0, 65536)])
 def test_msm_variable_base_large(ctx, oracle, srs_oracle, curve, n):
     """variable-base path at the window shapes n selects: c=11 (24 bucket sets of 1024) and c=14 (19 sets of 8192,
