@@ -280,7 +280,7 @@ __device__ __forceinline__ void mb_fold_shift(uint64_t &acc, uint32_t &hi, uint3
         : "=&v"(nlo), "=&v"(nhi) : "v"(lo), "v"(mid), "v"(hi) : "vcc");
     acc = ((uint64_t)nhi << 32) | nlo; hi = 0;
 }
-template <int F> __device__ __forceinline__ fe_t fe_mul_device(const fe_t &a, const fe_t &b) {
+template <int F, bool RED = true> __device__ __forceinline__ fe_t fe_mul_device(const fe_t &a, const fe_t &b) {
     // generated by tools/gen_fe_mul.py -- product scanning, one Montgomery reduction
     uint64_t acc = 0, cc; uint32_t hi = 0, lo, mid; fe_t r;
     uint32_t m0, m1, m2, m3, m4, m5, m6, m7;
@@ -354,9 +354,9 @@ template <int F> __device__ __forceinline__ fe_t fe_mul_device(const fe_t &a, co
         : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a.v[7]), "v"(b.v[7]), "v"(m7), "v"(p7));
     r.v[6] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
     r.v[7] = (uint32_t)acc;                                       // result < 2p < 2^256
-    return fe_cond_sub_p<F>(r);
+    return RED ? fe_cond_sub_p<F>(r) : r;                 // RED = false: result < sum(a_i b_i) / 2^256 + p, left to the caller
 }
-template <int F> __device__ __forceinline__ fe_t fe_dot2_device(const fe_t &a0, const fe_t &b0, const fe_t &a1, const fe_t &b1) {
+template <int F, bool RED = true> __device__ __forceinline__ fe_t fe_dot2_device(const fe_t &a0, const fe_t &b0, const fe_t &a1, const fe_t &b1) {
     // generated by tools/gen_fe_mul.py -- product scanning, one Montgomery reduction
     uint64_t acc = 0, cc; uint32_t hi = 0, lo, mid; fe_t r;
     uint32_t m0, m1, m2, m3, m4, m5, m6, m7;
@@ -442,9 +442,9 @@ template <int F> __device__ __forceinline__ fe_t fe_dot2_device(const fe_t &a0, 
         : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[7]), "v"(b0.v[7]), "v"(a1.v[7]), "v"(b1.v[7]), "v"(m7), "v"(p7));
     r.v[6] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
     r.v[7] = (uint32_t)acc;                                       // result < 2p < 2^256
-    return fe_cond_sub_p<F>(r);
+    return RED ? fe_cond_sub_p<F>(r) : r;                 // RED = false: result < sum(a_i b_i) / 2^256 + p, left to the caller
 }
-template <int F> __device__ __forceinline__ fe_t fe_dot3_device(const fe_t &a0, const fe_t &b0, const fe_t &a1, const fe_t &b1, const fe_t &a2, const fe_t &b2) {
+template <int F, bool RED = true> __device__ __forceinline__ fe_t fe_dot3_device(const fe_t &a0, const fe_t &b0, const fe_t &a1, const fe_t &b1, const fe_t &a2, const fe_t &b2) {
     // generated by tools/gen_fe_mul.py -- product scanning, one Montgomery reduction
     uint64_t acc = 0, cc; uint32_t hi = 0, lo, mid; fe_t r;
     uint32_t m0, m1, m2, m3, m4, m5, m6, m7;
@@ -540,7 +540,7 @@ template <int F> __device__ __forceinline__ fe_t fe_dot3_device(const fe_t &a0, 
         : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[7]), "v"(b0.v[7]), "v"(a1.v[7]), "v"(b1.v[7]), "v"(a2.v[7]), "v"(b2.v[7]), "v"(m7), "v"(p7));
     r.v[6] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
     r.v[7] = (uint32_t)acc;                                       // result < 2p < 2^256
-    return fe_cond_sub_p<F>(r);
+    return RED ? fe_cond_sub_p<F>(r) : r;                 // RED = false: result < sum(a_i b_i) / 2^256 + p, left to the caller
 }
 
 #endif
@@ -575,6 +575,70 @@ template <int F> struct FieldConsts {
 };
 
 // canonical little-endian bytes (as 8 u32 words) <-> Montgomery
+// ---- lazy forms for the Poseidon rounds (sponge.cuh).  A Montgomery product of a, b returns t < a b / 2^256 + p; with p / 2^256 =
+// 1/4 + 2^-131 the bound "< 2p + small" is closed under products of values below 2p + small, and everything stays far below
+// 2^256 = 3.99 p.  So the x^7 chain and the MDS row skip their conditional subtractions (5 x 16 VALU instructions per round) and the
+// round ends with ONE: s = row + round constant (< 2.5p + p, plain 256-bit add), minus 2p if s >= 2p  ->  s < 2p.  The permutation
+// normalises its state to [0, p) before returning (fe_cond_sub_p), so nothing outside ever sees a non-canonical value.
+template <int F> MB_HD fe_t fe_mul_nr(const fe_t &a, const fe_t &b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return fe_mul_device<F, false>(a, b);
+#else
+    return fe_mul_portable<F>(a, b);
+#endif
+}
+template <int F> MB_HD fe_t fe_dot3_nr(const fe_t &a0, const fe_t &b0, const fe_t &a1, const fe_t &b1, const fe_t &a2, const fe_t &b2) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return fe_dot3_device<F, false>(a0, b0, a1, b1, a2, b2);
+#else
+    return fe_add<F>(fe_add<F>(fe_mul<F>(a0, b0), fe_mul<F>(a1, b1)), fe_mul<F>(a2, b2));
+#endif
+}
+template <int F> struct TwoP {      // 2p = (2, T1, T2, T3, 0, 0, 0, 0x80000000): P3 < 2^30, so nothing carries past limb 3
+    static constexpr uint32_t T1 = FieldP<F>::P1 << 1, T2 = (FieldP<F>::P2 << 1) | (FieldP<F>::P1 >> 31), T3 = (FieldP<F>::P3 << 1) | (FieldP<F>::P2 >> 31);
+};
+// a + b (no carry out of 256 bits: caller's bound), minus 2p if the sum is >= 2p
+template <int F> MB_HD fe_t fe_add_csub2p(const fe_t &a, const fe_t &b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    fe_t r;
+    uint32_t s0, s1, s2, s3, s4, s5, s6, s7, d0, d1, d2, d3, d4, d5, d6, d7;
+    asm("v_add_co_u32_e32 %0, vcc, %16, %24\n\t"
+        "v_addc_co_u32_e32 %1, vcc, %17, %25, vcc\n\t"
+        "v_addc_co_u32_e32 %2, vcc, %18, %26, vcc\n\t"
+        "v_addc_co_u32_e32 %3, vcc, %19, %27, vcc\n\t"
+        "v_addc_co_u32_e32 %4, vcc, %20, %28, vcc\n\t"
+        "v_addc_co_u32_e32 %5, vcc, %21, %29, vcc\n\t"
+        "v_addc_co_u32_e32 %6, vcc, %22, %30, vcc\n\t"
+        "v_addc_co_u32_e32 %7, vcc, %23, %31, vcc\n\t"
+        "v_subrev_co_u32_e32 %8, vcc, 2, %0\n\t"
+        "v_subbrev_co_u32_e32 %9, vcc, %32, %1, vcc\n\t"
+        "v_subbrev_co_u32_e32 %10, vcc, %33, %2, vcc\n\t"
+        "v_subbrev_co_u32_e32 %11, vcc, %34, %3, vcc\n\t"
+        "v_subbrev_co_u32_e32 %12, vcc, 0, %4, vcc\n\t"
+        "v_subbrev_co_u32_e32 %13, vcc, 0, %5, vcc\n\t"
+        "v_subbrev_co_u32_e32 %14, vcc, 0, %6, vcc\n\t"
+        "v_subbrev_co_u32_e32 %15, vcc, %35, %7, vcc\n\t"
+        "v_cndmask_b32_e32 %8, %8, %0, vcc\n\t"
+        "v_cndmask_b32_e32 %9, %9, %1, vcc\n\t"
+        "v_cndmask_b32_e32 %10, %10, %2, vcc\n\t"
+        "v_cndmask_b32_e32 %11, %11, %3, vcc\n\t"
+        "v_cndmask_b32_e32 %12, %12, %4, vcc\n\t"
+        "v_cndmask_b32_e32 %13, %13, %5, vcc\n\t"
+        "v_cndmask_b32_e32 %14, %14, %6, vcc\n\t"
+        "v_cndmask_b32_e32 %15, %15, %7, vcc"
+        : "=&v"(s0), "=&v"(s1), "=&v"(s2), "=&v"(s3), "=&v"(s4), "=&v"(s5), "=&v"(s6), "=&v"(s7),
+          "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&v"(d4), "=&v"(d5), "=&v"(d6), "=&v"(d7)
+        : "v"(a.v[0]), "v"(a.v[1]), "v"(a.v[2]), "v"(a.v[3]), "v"(a.v[4]), "v"(a.v[5]), "v"(a.v[6]), "v"(a.v[7]),
+          "v"(b.v[0]), "v"(b.v[1]), "v"(b.v[2]), "v"(b.v[3]), "v"(b.v[4]), "v"(b.v[5]), "v"(b.v[6]), "v"(b.v[7]),
+          "v"(TwoP<F>::T1), "v"(TwoP<F>::T2), "v"(TwoP<F>::T3), "v"(0x80000000u)
+        : "vcc");
+    r.v[0] = d0; r.v[1] = d1; r.v[2] = d2; r.v[3] = d3; r.v[4] = d4; r.v[5] = d5; r.v[6] = d6; r.v[7] = d7;
+    return r;
+#else
+    return fe_add<F>(a, b);      // host: canonical operands, canonical result (the lazy forms are a device-side economy)
+#endif
+}
+
 template <int F> MB_HD fe_t fe_to_mont(const fe_t &a, const fe_t &r2) { return fe_mul<F>(a, r2); }
 template <int F> MB_HD fe_t fe_from_mont(const fe_t &a) {
     fe_t one = fe_zero(); one.v[0] = 1; return fe_mul<F>(a, one);

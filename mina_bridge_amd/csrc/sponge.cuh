@@ -181,12 +181,14 @@ __device__ __forceinline__ void poseidon_permute_quad(fe_t &s, const PoseidonPar
     const fe_t m0 = pp->mds[qq][0], m1 = pp->mds[qq][1], m2 = pp->mds[qq][2];
 #pragma unroll 1
     for (int r = 0; r < 55; ++r) {
-        fe_t x2 = fe_sqr<F>(s);
-        fe_t x4 = fe_sqr<F>(x2);
-        fe_t t = fe_mul<F>(fe_mul<F>(x4, x2), s);
+        // lazy round (fp.cuh "lazy forms"): s < 2p in, every product unreduced, one conditional subtraction of 2p out
+        fe_t x2 = fe_mul_nr<F>(s, s);
+        fe_t x4 = fe_mul_nr<F>(x2, x2);
+        fe_t t = fe_mul_nr<F>(fe_mul_nr<F>(x4, x2), s);
         fe_t t0 = quad_bcast<0>(t), t1 = quad_bcast<1>(t), t2 = quad_bcast<2>(t);
-        s = fe_add<F>(fe_dot3<F>(m0, t0, m1, t1, m2, t2), pp->rc[r][qq]);
+        s = fe_add_csub2p<F>(fe_dot3_nr<F>(m0, t0, m1, t1, m2, t2), pp->rc[r][qq]);
     }
+    s = fe_cond_sub_p<F>(s);
 }
 
 // Eight lanes per sponge (half a DPP row): the pair of lanes (2e, 2e+1) owns state element e (lanes 6, 7 mirror e = 2).
@@ -218,9 +220,10 @@ __device__ __forceinline__ void poseidon_permute_oct(fe_t &s, const PoseidonPara
     const fe_t ma = odd ? pp->mds[e][2] : pp->mds[e][0], mb = odd ? zero : pp->mds[e][1];
 #pragma unroll 1
     for (int r = 0; r < 55; ++r) {
-        const fe_t x2 = fe_sqr<F>(s);
-        const fe_t y = fe_mul<F>(x2, odd ? s : x2);                  // even: x^4, odd: x^3
-        const fe_t t = fe_mul<F>(y, pair_swap(y));                   // x^7 on both lanes of the pair
+        // the x^7 chain unreduced (s < p in: x2 < 1.25p, y < 1.4p, t < 1.5p); the dot product below reduces (1.75p before its subtraction)
+        const fe_t x2 = fe_mul_nr<F>(s, s);
+        const fe_t y = fe_mul_nr<F>(x2, odd ? s : x2);               // even: x^4, odd: x^3
+        const fe_t t = fe_mul_nr<F>(y, pair_swap(y));                // x^7 on both lanes of the pair
         const fe_t t0 = oct_bcast<0>(t), t1 = oct_bcast<2>(t), t2 = oct_bcast<4>(t);
         const fe_t u = fe_dot2<F>(ma, odd ? t2 : t0, mb, t1);        // even: m0 t0 + m1 t1, odd: m2 t2 (+ 0 * t1)
         s = fe_add<F>(fe_add<F>(u, pair_swap(u)), pp->rc[r][e]);
@@ -247,12 +250,14 @@ __device__ __forceinline__ void poseidon_permute_tri(fe_t &s, const PoseidonPara
     const fe_t m0 = pp->mds[tp.e][0], m1 = pp->mds[tp.e][1], m2 = pp->mds[tp.e][2];
 #pragma unroll 1
     for (int r = 0; r < 55; ++r) {
-        const fe_t x2 = fe_sqr<F>(s);
-        const fe_t x4 = fe_sqr<F>(x2);
-        const fe_t t = fe_mul<F>(fe_mul<F>(x4, x2), s);
+        // lazy round (fp.cuh "lazy forms"): s < 2p in, every product unreduced, one conditional subtraction of 2p out
+        const fe_t x2 = fe_mul_nr<F>(s, s);
+        const fe_t x4 = fe_mul_nr<F>(x2, x2);
+        const fe_t t = fe_mul_nr<F>(fe_mul_nr<F>(x4, x2), s);
         const fe_t t0 = tri_bcast(t, tp.base), t1 = tri_bcast(t, tp.base + 1), t2 = tri_bcast(t, tp.base + 2);
-        s = fe_add<F>(fe_dot3<F>(m0, t0, m1, t1, m2, t2), pp->rc[r][tp.e]);
+        s = fe_add_csub2p<F>(fe_dot3_nr<F>(m0, t0, m1, t1, m2, t2), pp->rc[r][tp.e]);
     }
+    s = fe_cond_sub_p<F>(s);
 }
 // LANES-lane cooperative permutation / element ownership, LANES = 3 (wave-packed triples), 4 (quad) or 8 (octet)
 template <int F, int LANES> __device__ __forceinline__ void poseidon_permute_coop(fe_t &s, const PoseidonParams *__restrict__ pp) {
