@@ -104,11 +104,10 @@ ipa_prepare_kernel(IpaShape sh, FieldK kb, FieldK ks, const PoseidonParams *__re
                    uint32_t *__restrict__ xfer /* PHASE 1 writes, PHASE 2 reads: b * IPA_XFER_WORDS */) {
     constexpr int FB = (CURVE == CURVE_PALLAS) ? FIELD_FP : FIELD_FQ;
     constexpr int FS = (CURVE == CURVE_PALLAS) ? FIELD_FQ : FIELD_FP;
-    const uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) / LANES;
+    bool writer_; const uint32_t b = coop_sponge_index<LANES>(writer_);
     if (b >= sh.batch) return;                                // whole lane groups leave together
     const uint32_t k = sh.k;
     bool pts_ok = true;                                       // every input well-formed (canonical field elements, points on the curve)
-    const uint32_t ln = threadIdx.x & (LANES - 1);
     uint32_t *xf = xfer ? xfer + (size_t)b * IPA_XFER_WORDS : nullptr;
 
     // ---- Fq-sponge transcript (base field)
@@ -147,10 +146,9 @@ ipa_prepare_kernel(IpaShape sh, FieldK kb, FieldK ks, const PoseidonParams *__re
         }
         const fe_t t = sp.squeeze();                          // challenge_fq
         if (PHASE == 1) {                                     // hand over: state (owner lanes), position, t; flag; done
-            const bool owner = LANES == 8 ? (ln < 6 && !(ln & 1u)) : (ln < 3);
-            if (owner) for (int i = 0; i < 8; ++i) xf[coop_elem<LANES>() * 8 + i] = sp.s.v[i];
-            if (ln == 0) { xf[24] = (uint32_t)sp.squeezed; xf[25] = (uint32_t)sp.count; for (int i = 0; i < 8; ++i) xf[26 + i] = t.v[i]; }
-            if (!pts_ok && ln == 0) *bad_input = 1u;
+            if (coop_state_owner<LANES>()) for (int i = 0; i < 8; ++i) xf[coop_elem<LANES>() * 8 + i] = sp.s.v[i];
+            if (writer_) { xf[24] = (uint32_t)sp.squeezed; xf[25] = (uint32_t)sp.count; for (int i = 0; i < 8; ++i) xf[26 + i] = t.v[i]; }
+            if (!pts_ok && writer_) *bad_input = 1u;
             return;
         }
         U = bw_to_group<FB>(t, kb);
@@ -451,25 +449,29 @@ int mb_ipa_batch_check_dev(mina_ctx *c, int curve, mb::IpaShape sh, const mb::Ip
     HIPC(hipMemsetAsync(d_verdict, 0, 8, c->L->stream));
     const PoseidonParams *pp = c->pparams[FB].as<PoseidonParams>();
 #define IPA_PREP(CV, LN, PH, STREAM)                                                                                          \
-    mb::ipa_prepare_kernel<CV, LN, PH><<<cdiv(batch * LN, 64), 64, 0, STREAM>>>(                                                      \
+    mb::ipa_prepare_kernel<CV, LN, PH><<<cdiv(coop_threads<LN>(batch), 64), 64, 0, STREAM>>>(                                                      \
         sh, c->fk[FB], c->fk[FS], pp, in.state, in.pos, in.cip, in.lr, in.delta, in.sg, in.z1, in.z2, in.pts, in.r, \
         in.xi, in.comms, in.comm_override, in.expand, in.rb, in.sb, s.h.as<affine_t>(), c->L->ipa_points.as<affine_t>(), c->L->ipa_scalars.as<uint32_t>(), \
         c->L->ipa_chals.as<uint32_t>(), c->L->ipa_sigma.as<uint32_t>(), d_verdict + 1, c->L->ipa_xfer.as<uint32_t>())
     { ProfScope ps_(c, PS_IPA_TRANSCRIPT);
-    if (use_coop8(c, batch)) {
-        // latency-bound batch: 8 lanes per transcript, and to_group on a second stream beside the rest of the transcript
+    {
+        // the transcript splits at its first squeeze: to_group (one lane per proof) runs on a second stream beside the rest.  8 lanes per
+        // transcript up to 1024 proofs per call (shortest dependent chain); above that the 3-lane form: 21 transcripts per wave, 3/8 of the
+        // issue slots -- measured with 16 calls of 8192 proofs in flight (bench.py), where the VALU port is what saturates
+        static const size_t coop8_max = [] { const char *e = getenv("MINA_IPA_COOP8_MAX"); return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)1024; }();
+        const bool oct = batch <= coop8_max;
         Lane &L = *c->L;
         if ((rc = L.ipa_xfer.ensure(batch * mb::IPA_XFER_WORDS * 4))) return rc;
         if (!L.aux) { HIPC(hipStreamCreateWithFlags(&L.aux, hipStreamNonBlocking)); HIPC(hipEventCreateWithFlags(&L.ev_fork, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&L.ev_join, hipEventDisableTiming)); }
-        if (curve == CURVE_PALLAS) IPA_PREP(CURVE_PALLAS, 8, 1, L.stream); else IPA_PREP(CURVE_VESTA, 8, 1, L.stream);
+        if (oct) { if (curve == CURVE_PALLAS) IPA_PREP(CURVE_PALLAS, 8, 1, L.stream); else IPA_PREP(CURVE_VESTA, 8, 1, L.stream); }
+        else { if (curve == CURVE_PALLAS) IPA_PREP(CURVE_PALLAS, 3, 1, L.stream); else IPA_PREP(CURVE_VESTA, 3, 1, L.stream); }
         HIPC(hipEventRecord(L.ev_fork, L.stream));
         HIPC(hipStreamWaitEvent(L.aux, L.ev_fork, 0));
         DISPATCH_FIELD(FB, { mb::ipa_to_group_kernel<F_><<<cdiv(batch, 64), 64, 0, L.aux>>>((uint32_t)batch, sh.per, c->fk[F_], L.ipa_xfer.as<uint32_t>(), L.ipa_points.as<affine_t>()); });
         HIPC(hipEventRecord(L.ev_join, L.aux));
-        if (curve == CURVE_PALLAS) IPA_PREP(CURVE_PALLAS, 8, 2, L.stream); else IPA_PREP(CURVE_VESTA, 8, 2, L.stream);
+        if (oct) { if (curve == CURVE_PALLAS) IPA_PREP(CURVE_PALLAS, 8, 2, L.stream); else IPA_PREP(CURVE_VESTA, 8, 2, L.stream); }
+        else { if (curve == CURVE_PALLAS) IPA_PREP(CURVE_PALLAS, 3, 2, L.stream); else IPA_PREP(CURVE_VESTA, 3, 2, L.stream); }
         HIPC(hipStreamWaitEvent(L.stream, L.ev_join, 0));
-    } else {
-        if (curve == CURVE_PALLAS) IPA_PREP(CURVE_PALLAS, 4, 0, c->L->stream); else IPA_PREP(CURVE_VESTA, 4, 0, c->L->stream);
     }
     }
 #undef IPA_PREP

@@ -34,14 +34,7 @@ template <int FS> __device__ __forceinline__ fe_t chal_endo(const fe_t &sq_plain
     const uint64_t lo = (uint64_t)sq_plain.v[0] | ((uint64_t)sq_plain.v[1] << 32), hi = (uint64_t)sq_plain.v[2] | ((uint64_t)sq_plain.v[3] << 32);
     return challenge_to_field<FS>(lo, hi, ks);
 }
-template <int LANES> __device__ __forceinline__ uint32_t coop_lane() { return LANES == 3 ? tri_pos().e : (threadIdx.x & (LANES - 1)); }
 template <int F, int LANES> __device__ __forceinline__ void sponge_init(DevSponge<F, LANES> &s, const PoseidonParams *pp) { s.pp = pp; s.squeezed = 0; s.count = 0; s.s = fe_zero(); }
-// the lanes that hold state elements 0, 1, 2 of a cooperative sponge (one lane each)
-template <int LANES> __device__ __forceinline__ bool coop_state_owner() {
-    const uint32_t ln = coop_lane<LANES>();
-    return LANES == 8 ? (ln < 6 && !(ln & 1u)) : (LANES == 3 ? (threadIdx.x & 63u) < 63u : ln < 3);
-}
-
 // interpreter stack + cache of one lane in LDS, word-major: the 64 lanes of a slot hit 64 banks.  KC_SLOTS * 8 * 64 words per block of 64
 static constexpr int KC_SLOTS = KC_STACK + KC_CACHE;
 struct LdsStack {

@@ -302,7 +302,16 @@ template <int F, int LANES> struct DevSponge {
 };
 
 template <int F> __device__ __forceinline__ fe_t load_fe(const uint32_t *p) { fe_t r; for (int i = 0; i < 8; ++i) r.v[i] = p[i]; return r; }
-template <int LANES> __device__ __forceinline__ bool coop_writer() { return (threadIdx.x & (LANES - 1)) == 0; }
+template <int LANES> __device__ __forceinline__ bool coop_writer() {
+    if (LANES == 3) { const uint32_t lane = threadIdx.x & 63u; return lane < 63u && lane % 3u == 0; }
+    return (threadIdx.x & (LANES - 1)) == 0;
+}
+template <int LANES> __device__ __forceinline__ uint32_t coop_lane() { return LANES == 3 ? tri_pos().e : (threadIdx.x & (LANES - 1)); }
+// the lanes that hold state elements 0, 1, 2 of a cooperative sponge (one lane each)
+template <int LANES> __device__ __forceinline__ bool coop_state_owner() {
+    const uint32_t ln = coop_lane<LANES>();
+    return LANES == 8 ? (ln < 6 && !(ln & 1u)) : (LANES == 3 ? (threadIdx.x & 63u) < 63u : ln < 3);
+}
 template <int LANES> __device__ __forceinline__ void store_fe(uint32_t *p, const fe_t &a) { if (coop_writer<LANES>()) for (int i = 0; i < 8; ++i) p[i] = a.v[i]; }
 template <int LANES> __device__ __forceinline__ void store_pt(affine_t *p, const affine_t &a) { if (coop_writer<LANES>()) *p = a; }
 
