@@ -1,6 +1,7 @@
 // api_sponge.hip -- K2 (b_poly) and K3 (Poseidon, endo challenges) entry points.
 #include "ctx.h"
 #include "sponge.cuh"
+#include "bpoly_mfma.cuh"
 
 // ------------------------------------------------------------------------------------------------
 // // K2
@@ -18,6 +19,20 @@ static int run_bpoly_fold(mina_ctx *c, uint32_t k, size_t batch, const uint32_t 
     if (batch == 1 && !d_weights) {                              // b_poly_coefficients of one proof: one launch
         ProfScope ps_(c, PS_BPOLY_FOLD);
         bpoly_single_kernel<F><<<cdiv(nl, 256) * cdiv(nh, BP1_HT), nl < 256 ? (nl < 64 ? 64 : nl) : 256, 0, c->L->stream>>>(sh, c->fk[F], d_chals, nullptr, d_out);
+        HIPC(hipGetLastError());
+        return MINA_OK;
+    }
+    // large batches: the fold is a dense contraction over the batch -> int8 MFMA field-GEMM (bpoly_mfma.cuh).  MINA_BPOLY_MFMA=0 keeps the VALU kernel
+    static const bool mfma_on = [] { const char *e = getenv("MINA_BPOLY_MFMA"); return !(e && e[0] == '0'); }();
+    if (mfma_on && batch >= 256 && batch < (1u << 17) && sh.lb >= 1) {
+        Lane &L = *c->L;
+        const uint32_t kpad = (uint32_t)((batch + 63) & ~(size_t)63);
+        if ((rc = L.bp_ldig.ensure((size_t)nl * BPM_DIGITS * kpad)) || (rc = L.bp_hdig.ensure((size_t)nh * BPM_DIGITS * kpad)) ||
+            (rc = L.bp_colsum.ensure((size_t)nh * nl * BPM_COLS * 8))) return rc;
+        if (kpad != batch) { HIPC(hipMemsetAsync(L.bp_ldig.p, 0, (size_t)nl * BPM_DIGITS * kpad, L.stream)); HIPC(hipMemsetAsync(L.bp_hdig.p, 0, (size_t)nh * BPM_DIGITS * kpad, L.stream)); }
+        { ProfScope ps_(c, PS_BPOLY_TABLES); bpoly_tables_digits_kernel<F><<<cdiv(batch * (nl + nh), 256), 256, 0, L.stream>>>(sh, kpad, c->fk[F], d_chals, d_weights, L.bp_ldig.as<int8_t>(), L.bp_hdig.as<int8_t>()); }
+        { ProfScope ps_(c, PS_BPOLY_FOLD); bpoly_field_gemm_kernel<<<cdiv(nh, 4) * cdiv(nl, 4), 256, 0, L.stream>>>(nh, nl, kpad, L.bp_hdig.as<int8_t>(), L.bp_ldig.as<int8_t>(), L.bp_colsum.as<unsigned long long>()); }
+        { ProfScope ps_(c, PS_BPOLY_FINISH); bpoly_colsum_reduce_kernel<F><<<cdiv(n, 256), 256, 0, L.stream>>>(nh, nl, sh.lb, c->fk[F], L.bp_colsum.as<unsigned long long>(), d_out); }
         HIPC(hipGetLastError());
         return MINA_OK;
     }

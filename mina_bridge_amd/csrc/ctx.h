@@ -86,7 +86,7 @@ struct Lane {
     MsmWorkspace ws;
     DevBuf tmp_a, tmp_b, tmp_c, tmp_d;       // staging for the host-buffer entry points
     PinnedBuf host_stage;                    // pinned host side of the big H2D blobs (synchronous entry points only)
-    DevBuf bp_ltab, bp_htab, bp_partial;
+    DevBuf bp_ltab, bp_htab, bp_partial, bp_ldig, bp_hdig, bp_colsum;
     DevBuf ipa_chals, ipa_folded, ipa_xyzz_a, ipa_xyzz_b, ipa_points, ipa_scalars, ipa_sigma, ipa_in_a, ipa_in_b, ipa_in_c, ipa_verdict, ipa_xfer;
     DevBuf st_ok, st_hashes, st_pub_xyzz, st_pubcomm, st_flags, st_in, st_verdicts;   // Proof-of-State job (api_state.hip)
     DevBuf kc_state, kc_pos, kc_cip, kc_pts, kc_v, kc_u, kc_comms, kc_xfer, pk_xe, pk_pub, pk_ok;                  // kimchi to_batch output rows (api_kimchi.hip)
@@ -94,7 +94,7 @@ struct Lane {
         MsmWorkspace &w = ws;
         DevBuf *all[] = {&w.scalars, &w.points, &w.ekey, &w.eval, &w.eoff, &w.count, &w.start, &w.task_start, &w.rem_pos, &w.rem_bucket, &w.info, &w.sorted, &w.partial, &w.heavy, &w.order, &w.ghist, &w.stage,
                          &w.buckets, &w.red_r, &w.red_ws, &w.red2_r, &w.red2_w, &w.set_total, &w.out_words, &w.out_xyzz, &tmp_a, &tmp_b, &tmp_c, &tmp_d,
-                         &bp_ltab, &bp_htab, &bp_partial, &ipa_chals, &ipa_folded, &ipa_xyzz_a, &ipa_xyzz_b, &ipa_points, &ipa_scalars,
+                         &bp_ltab, &bp_htab, &bp_partial, &bp_ldig, &bp_hdig, &bp_colsum, &ipa_chals, &ipa_folded, &ipa_xyzz_a, &ipa_xyzz_b, &ipa_points, &ipa_scalars,
                          &ipa_sigma, &ipa_in_a, &ipa_in_b, &ipa_in_c, &ipa_verdict, &ipa_xfer,
                          &st_ok, &st_hashes, &st_pub_xyzz, &st_pubcomm, &st_flags, &st_in, &st_verdicts,
                          &kc_state, &kc_pos, &kc_cip, &kc_pts, &kc_v, &kc_u, &kc_comms, &kc_xfer, &pk_xe, &pk_pub, &pk_ok};

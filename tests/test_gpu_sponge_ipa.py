@@ -52,6 +52,30 @@ def test_b_poly_fold(ctx, oracle, field, k, batch):
 
 
 @pytest.mark.parametrize("field", [0, 1])
+@pytest.mark.parametrize("k,batch", [(7, 300), (9, 1030), (2, 256), (12, 257)])
+def test_b_poly_fold_matrix_core_path(ctx, oracle, field, k, batch):
+    """batches >= 256 take the int8 MFMA field-GEMM (bpoly_mfma.cuh): balanced base-256 digit planes, 32x32x32 tiles, anti-diagonal
+    sums, one reduction per output.  Bit-exact vs the CPU fold, with extreme values in the mix (0, 1, p - 1, 2^254 - 1 as challenges
+    and weights) so that every digit carry and the signed columns are exercised; batch sizes off the K-tile (padding columns)."""
+    m = MODS[field]
+    chals = rand_scalars(batch * k, m, seed=160 + k + batch)
+    w = rand_scalars(batch, m, seed=161)
+    ext = [0, 1, m - 1, (1 << 254) - 1, m - 2, 255, 256, (1 << 128) - 1]
+    for i in range(0, batch * k, 7):
+        chals[i] = oracle.int_to_le(ext[(i // 7) % len(ext)])
+    for i in range(0, batch, 5):
+        w[i] = oracle.int_to_le(ext[(i // 5 + 3) % len(ext)])
+    got = ctx.b_poly_fold(field, k, chals, w)
+    acc = [0] * (1 << k)
+    for b in range(batch):
+        s = oracle.b_poly_coefficients(field, chals[b * k:(b + 1) * k])
+        wb = oracle.le_to_int(w[b])
+        for j in range(1 << k):
+            acc[j] = (acc[j] + wb * int.from_bytes(s[j].tobytes(), "little")) % m
+    assert (got == oracle.ints_to_le(acc)).all()
+
+
+@pytest.mark.parametrize("field", [0, 1])
 def test_poseidon_permute_and_hash(ctx, oracle, field):
     import mina_bridge_amd as m
     params = m.poseidon_params.default_params_bytes(field)
