@@ -53,8 +53,8 @@ template <int FB> __device__ xyzz_t scalar_mul_affine(const fe_t &s_plain, const
 // ---- the stages.  One monolithic kernel (round 2 first cut) held the Fq state, the Fr state, 86 evaluations' worth of scalar
 // temporaries and a 24-deep interpreter stack live at once: 255 VGPRs + 2.4 KB of scratch per lane, non-inlined calls, and the
 // sponges -- 9/10 of the dependent work -- ran 15x slower per permutation than `pstate_hash_kernel`.  Split by what each stage needs:
-//   fq      lane-cooperative (8 or 3 lanes):  group b < B runs proof b's Fq-sponge; group B + b runs the digest of proof b's
-//           recursion challenges (a scalar-field sponge that depends on nothing else) beside it
+//   fq      lane-cooperative (8 or 3 lanes), two roles in separate waves of one launch: proof b's Fq-sponge, and beside it the digest of
+//           its recursion challenges (a scalar-field sponge that depends on nothing else)
 //   pub     8 lanes per proof: the negated public polynomial at zeta, zeta*omega (8-term chunks spread over the lanes)
 //   fr      lane-cooperative: Fr-sponge -> v, u
 //   scalar  one lane per proof: ft_eval0, the PolishToken program (stack in LDS), perm scalar, b_poly evaluations, cip, ft scalars
@@ -80,13 +80,13 @@ template <int F, int LANES> __device__ __forceinline__ fe_t coop_sum(const fe_t 
 template <int LANES>
 __global__ void __launch_bounds__(64)
 kimchi_fq_kernel(uint32_t batch, uint32_t n_prev, FieldK kb, FieldK ks, const PoseidonParams *__restrict__ pp_b, const PoseidonParams *__restrict__ pp_s,
-                 const KimchiIndexDev *__restrict__ ix, KimchiIn in, KimchiOut out, fe_t *__restrict__ xf, uint32_t *__restrict__ bad_input) {
+                 const KimchiIndexDev *__restrict__ ix, KimchiIn in, KimchiOut out, fe_t *__restrict__ xf, uint32_t *__restrict__ bad_input, uint32_t nblk) {
     constexpr int FB = FIELD_FP, FS = FIELD_FQ;                 // Pallas: base Fp, scalar Fq
-    bool writer; const uint32_t g = coop_sponge_index<LANES>(writer);
-    if (g >= 2 * batch) return;
+    bool writer; const uint32_t role = blockIdx.x / nblk, b = coop_role_item<LANES>(blockIdx.x % nblk, writer);       // one role per wave
+    if (b >= batch) return;
     bool ok = true;
-    if (g >= batch) {                                           // digest of the recursion challenges
-        const uint32_t b = g - batch, cnt = n_prev * ix->log2_domain;
+    if (role) {                                                 // digest of the recursion challenges
+        const uint32_t cnt = n_prev * ix->log2_domain;
         const uint32_t *p = in.prev_chals + (size_t)b * cnt * 8;
         DevSponge<FS, LANES> pf; sponge_init(pf, pp_s);
 #pragma unroll 1
@@ -95,7 +95,6 @@ kimchi_fq_kernel(uint32_t batch, uint32_t n_prev, FieldK kb, FieldK ks, const Po
         if (writer) { xf[(size_t)b * KC_XF + XF_PFDIGEST] = d; if (!ok) *bad_input = 1u; }
         return;
     }
-    const uint32_t b = g;
     DevSponge<FB, LANES> fq; sponge_init(fq, pp_b);
     fq.absorb(ix->digest);
     auto absorb_pts = [&](const uint32_t *p, uint32_t n) {
@@ -370,11 +369,11 @@ int mb_kimchi_to_batch_dev(mina_ctx *c, size_t batch, uint32_t n_prev, uint32_t 
     // per step -- 16 x 512: 165 k/s (8-lane) vs 162 k/s; 4 x 2048: 137 k/s (8-lane) vs 150 k/s (3-lane).  MINA_KIMCHI_COOP8_MAX overrides (tuning)
     static const size_t coop8_max = [] { const char *e = getenv("MINA_KIMCHI_COOP8_MAX"); return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)1024; }();
     if (batch <= coop8_max) {
-        mb::kimchi_fq_kernel<8><<<cdiv(coop_threads<8>(2 * batch), 64), 64, 0, L.stream>>>(B, n_prev, kb, ks, ppb, pps, ix, in, out, xf, d_bad);
+        mb::kimchi_fq_kernel<8><<<2 * coop_role_blocks<8>(batch), 64, 0, L.stream>>>(B, n_prev, kb, ks, ppb, pps, ix, in, out, xf, d_bad, coop_role_blocks<8>(batch));
         mb::kimchi_pub_kernel<<<cdiv(batch * 8, 64), 64, 0, L.stream>>>(B, npub, ks, ix, in, xf, d_bad);
         mb::kimchi_fr_kernel<8><<<cdiv(coop_threads<8>(batch), 64), 64, 0, L.stream>>>(B, ks, pps, in, xf, d_bad);
     } else {                        // chip-filling batch: 21 sponges per wave
-        mb::kimchi_fq_kernel<3><<<cdiv(coop_threads<3>(2 * batch), 64), 64, 0, L.stream>>>(B, n_prev, kb, ks, ppb, pps, ix, in, out, xf, d_bad);
+        mb::kimchi_fq_kernel<3><<<2 * coop_role_blocks<3>(batch), 64, 0, L.stream>>>(B, n_prev, kb, ks, ppb, pps, ix, in, out, xf, d_bad, coop_role_blocks<3>(batch));
         mb::kimchi_pub_kernel<<<cdiv(batch * 8, 64), 64, 0, L.stream>>>(B, npub, ks, ix, in, xf, d_bad);
         mb::kimchi_fr_kernel<3><<<cdiv(coop_threads<3>(batch), 64), 64, 0, L.stream>>>(B, ks, pps, in, xf, d_bad);
     }

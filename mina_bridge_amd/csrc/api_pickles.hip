@@ -261,7 +261,7 @@ extern "C" int mina_pickles_public_input(mina_ctx *c, const uint8_t *proof, size
 // ------------------------------------------------------------------------------------------------ the same on the GPU
 // Batch form for the Proof-of-State job: statements (structure-of-arrays in HBM) -> 40 public inputs per proof, no host work.
 //   expand   one thread per challenge: endo-expansion (Fp for the step side, Fq for the wrap side), beta / gamma into the field
-//   digest   lane-cooperative sponges, three roles side by side: digest of the step-side old challenges (Tick), messages_for_next_
+//   digest   lane-cooperative sponges, three roles side by side (each in its own waves): digest of the step-side old challenges (Tick), messages_for_next_
 //            wrap_proof (Tock), messages_for_next_step_proof (Tick, resumed after the 28 wrap index commitments -- absorbed once at
 //            set-up, the state cached in the index)
 //   tick     lane-cooperative: the Tick sponge over the step proof's evaluations -> xi, r
@@ -314,10 +314,9 @@ pickles_expand_kernel(uint32_t batch, FieldK kp, FieldK kq, PicklesIn in, fe_t *
 template <int LANES>
 __global__ void __launch_bounds__(64)
 pickles_digest_kernel(uint32_t batch, FieldK kp, FieldK kq, const PoseidonParams *__restrict__ pp_p, const PoseidonParams *__restrict__ pp_q,
-                      const PicklesIndexDev *__restrict__ ix, PicklesIn in, fe_t *__restrict__ xe, uint32_t *__restrict__ ok_out) {
-    bool writer; const uint32_t g = coop_sponge_index<LANES>(writer);
-    if (g >= 3 * batch) return;
-    const uint32_t role = g / batch, b = g - role * batch;
+                      const PicklesIndexDev *__restrict__ ix, PicklesIn in, fe_t *__restrict__ xe, uint32_t *__restrict__ ok_out, uint32_t nblk) {
+    bool writer; const uint32_t role = blockIdx.x / nblk, b = coop_role_item<LANES>(blockIdx.x % nblk, writer);       // one role per wave
+    if (b >= batch) return;
     fe_t *x = xe + (size_t)b * px_stride(in.n_old);
     bool ok = true;
     if (role == 0) {                                        // digest of the step-side old challenges
@@ -484,10 +483,10 @@ int mb_pickles_dev(mina_ctx *c, size_t batch, const mb::PicklesIn &in, uint32_t 
     HIPC(hipMemsetD32Async((hipDeviceptr_t)d_ok, step_of(c).max_col < in.n_evals ? 1 : 0, batch, L.stream));   // a program naming a column the proofs lack fails them all
     mb::pickles_expand_kernel<<<cdiv(batch * (50 + 16 * in.n_old), 256), 256, 0, L.stream>>>(B, kp, kq, in, xe);
     if (batch <= 1024) {
-        mb::pickles_digest_kernel<8><<<cdiv(coop_threads<8>(3 * batch), 64), 64, 0, L.stream>>>(B, kp, kq, ppp, ppq, ix, in, xe, d_ok);
+        mb::pickles_digest_kernel<8><<<3 * coop_role_blocks<8>(batch), 64, 0, L.stream>>>(B, kp, kq, ppp, ppq, ix, in, xe, d_ok, coop_role_blocks<8>(batch));
         mb::pickles_tick_kernel<8><<<cdiv(coop_threads<8>(batch), 64), 64, 0, L.stream>>>(B, kp, ppp, in, xe, d_ok);
     } else {
-        mb::pickles_digest_kernel<3><<<cdiv(coop_threads<3>(3 * batch), 64), 64, 0, L.stream>>>(B, kp, kq, ppp, ppq, ix, in, xe, d_ok);
+        mb::pickles_digest_kernel<3><<<3 * coop_role_blocks<3>(batch), 64, 0, L.stream>>>(B, kp, kq, ppp, ppq, ix, in, xe, d_ok, coop_role_blocks<3>(batch));
         mb::pickles_tick_kernel<3><<<cdiv(coop_threads<3>(batch), 64), 64, 0, L.stream>>>(B, kp, ppp, in, xe, d_ok);
     }
     mb::pickles_scalar_kernel<<<cdiv(batch, 64), 64, 0, L.stream>>>(B, kp, kq, ix, c->pickles_tokens.as<mb::KimchiToken>(), c->pickles_literals.as<fe_t>(), in, xe, d_pub, d_ok);

@@ -281,6 +281,15 @@ template <int LANES> __device__ __forceinline__ uint32_t coop_sponge_index(bool 
 }
 // threads needed for n sponges
 template <int LANES> static inline size_t coop_threads(size_t n) { return LANES == 3 ? ((n + 20) / 21) * 64 : n * LANES; }
+// Kernels that run several independent sponge ROLES per item (different absorb lists) put each role in its own blocks of 64, so that a
+// wave never holds two roles (divergent roles in one wave would run one after the other: 3x the latency of a one-proof call).
+// grid = roles * coop_role_blocks(n); inside: role = blockIdx.x / nblk, item = coop_role_item(blockIdx.x % nblk, writer)
+template <int LANES> static inline uint32_t coop_role_blocks(size_t n) { return (uint32_t)((coop_threads<LANES>(n) + 63) / 64); }
+template <int LANES> __device__ __forceinline__ uint32_t coop_role_item(uint32_t blk, bool &writer) {      // blockDim.x == 64
+    const uint32_t lane = threadIdx.x & 63u;
+    if (LANES == 3) { writer = lane < 63u && lane % 3u == 0; return blk * 21u + (lane == 63u ? 20u : lane / 3u); }
+    writer = (lane % LANES) == 0; return (blk * 64u + lane) / LANES;
+}
 
 // mina-poseidon `ArithmeticSponge` state machine (rate 2) over base field F, Montgomery state, lane-cooperative over
 // LANES = 4 or 8 lanes (sponge.cuh): `s` = the state element this lane owns (coop_elem), the position (squeezed, count)

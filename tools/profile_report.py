@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""profiles/<tag>_rocprof.md from one round's raw rocprofv3 output (tools/profile_round.sh + tools/profile_sq.sh) and the bench line.
+usage: profile_report.py <tag> <bench.json>     reads gpurun_out/prof_<tag>/, prints markdown"""
+import collections
+import csv
+import json
+import os
+import sys
+
+from profile_summary import pmc, short, stats_table
+
+tag, bench = sys.argv[1], sys.argv[2]
+d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "prof_" + tag)
+b = json.loads(open(bench).read().strip().split("\n")[-1])
+STEPS = 14                                                   # --steps 10 --warmup 4 of the single-lane passes
+print(f"# Round 2 profile ({tag}) -- `python bench.py` (default mode `{b['config'].get('mode', 'prepared')}`: {b['config']['proofs_per_step']} proofs per step, "
+      f"{b['config']['pipeline_lanes']} lanes) on one MI355X\n")
+print(f"Raw rocprofv3 output: `gpurun_out/prof_{tag}/` (scratch).  Commands: `tools/profile_round.sh {tag}` (kernel-trace + stats of the default bench command; "
+      f"FETCH_SIZE and WRITE_SIZE in separate `--pmc` passes with `--pipeline 1` so that kernels do not overlap) and `tools/profile_sq.sh {tag}` (SQ counters, own "
+      f"passes).  Bench line of the same build: `profiles/{tag}_bench.json` ({b['value'] / 1e3:.1f} k proofs/s, {b['ms_per_step']:.1f} ms per step).\n")
+print("## kernel-trace stats of the default command (16 lanes in flight: durations include time-sharing of the CUs)\n")
+print(stats_table(os.path.join(d, "trace", "t_kernel_stats.csv")))
+F, W = pmc(os.path.join(d, "fetch", "f_counter_collection.csv")), pmc(os.path.join(d, "write", "w_counter_collection.csv"))
+print("\n## PMC passes, KiB per launch (most frequent grid size of each kernel)\n")
+print("| kernel | grid | launches | FETCH_SIZE | WRITE_SIZE | bytes/launch |\n|---|---|---|---|---|---|")
+tot = {k: (F[k][0] + W.get(k, (0,))[0]) * 1024 for k in F}
+for k in sorted(tot, key=tot.get, reverse=True)[:14]:
+    print(f"| {k} | {F[k][2]} | {F[k][1]} | {F[k][0]:.0f} | {W.get(k, (0,))[0]:.0f} | {tot[k] / 1e6:.1f} MB |")
+# single-lane step budget from the FETCH pass's kernel trace
+rows = list(csv.DictReader(open(os.path.join(d, "fetch", "f_kernel_trace.csv"))))
+dur, cnt = collections.defaultdict(float), collections.Counter()
+for r in rows:
+    n = short(r["Kernel_Name"]); dur[n] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3; cnt[n] += 1
+print(f"\n## Single-lane step (`--pipeline 1`, kernels back to back): time per step of {b['config']['proofs_per_step']} proofs "
+      f"(sum {sum(dur.values()) / STEPS / 1e3:.1f} ms)\n")
+print("| kernel | launches/step | us/step |\n|---|---|---|")
+for k in sorted(dur, key=dur.get, reverse=True)[:26]:
+    print(f"| {k} | {cnt[k] / STEPS:.1f} | {dur[k] / STEPS:.0f} |")
+# VALU instruction budget from the SQ pass
+sq = os.path.join(d, "sq", "s_counter_collection.csv")
+if os.path.exists(sq):
+    agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    for r in csv.DictReader(open(sq)):
+        agg[short(r["Kernel_Name"])][r["Counter_Name"]] += float(r["Counter_Value"])
+    total = sum(v["SQ_INSTS_VALU"] for v in agg.values()) / STEPS
+    floor = total * 4 / (1024 * 2.4e9) * 1e3
+    print(f"\n## VALU instruction budget per step (SQ_INSTS_VALU, single lane)\n\nTotal {total / 1e9:.2f} G wave-instructions per step; at 4 cycles per wave64 instruction on "
+          f"1024 SIMDs and 2.4 GHz that is a floor of **{floor:.1f} ms** per step -- the pipelined step takes {b['ms_per_step']:.1f} ms "
+          f"(= {floor / b['ms_per_step'] * 100:.0f} % of VALU issue).\n")
+    print("| kernel | G instr/step | floor ms | waves/step |\n|---|---|---|---|")
+    for k in sorted(agg, key=lambda k: agg[k]["SQ_INSTS_VALU"], reverse=True)[:18]:
+        v = agg[k]; iv = v["SQ_INSTS_VALU"] / STEPS
+        print(f"| {k} | {iv / 1e9:.3f} | {iv * 4 / (1024 * 2.4e9) * 1e3:.2f} | {v['SQ_WAVES'] / STEPS:.0f} |")
+r, rv = b["roofline"], b.get("roofline_valu", {})
+print(f"\n## Dominant kernel `{r['kernel']}` (one launch = {r['states_per_launch']} protocol-state hashes)\n")
+print(f"* HIP events in bench.py: {r['avg_launch_us']:.0f} us isolated, {r['avg_launch_us_in_timed_region']:.0f} us inside the timed region (lanes time-share the CUs; "
+      f"rocprofv3's average over the same region is in the first table).")
+print(f"* algorithmic bytes per launch {r['algorithmic_bytes_per_launch']} B -> {r['achieved']:.2f} GB/s = {r['frac'] * 100:.3f} % of the 8 TB/s HBM peak; PMC traffic "
+      f"(FETCH x 2 for 16-B-per-lane loads + WRITE): see the table above; the kernel is integer-multiply bound.")
+if rv:
+    print(f"* multiply issue: {rv['permutations_per_launch']} permutations x 1155 modmul per launch = {rv['achieved']:.0f} G modmul/s of a {rv['peak']:.0f} G modmul/s "
+          f"floor rate = **{rv['frac']:.2f}**.")
