@@ -443,6 +443,9 @@ typedef struct mina_kimchi_proofs {
      * and public_inputs is ignored): compute_deferred_values + the message digests + the packing run ahead of `oracles`, and a
      * malformed statement fails its proof.  Host struct; inner pointers host or device like the sections above. */
     const struct mina_pickles_statements *statements;
+    /* NULL, or instead of prev_chals (which may then be NULL) the 128-bit prechallenges, b * n_prev * k * 16: expanded on the GPU
+     * (`ScalarChallenge::to_field` with the scalar field's endo coefficient) inside mina_state_job_batch[_dev] */
+    const void *prev_prechallenges;
 } mina_kimchi_proofs;
 typedef struct {                       /* one `BatchEvaluationProof` row per proof, host buffers */
     uint8_t *sponge_state /* b*96 */; uint32_t *sponge_pos /* b*2 */; uint8_t *cip /* b*32 */, *evalpoints /* b*64: zeta, zeta*omega */,

@@ -455,6 +455,12 @@ int mb_kimchi_fill_jobs(mina_ctx *c, const mw::WrapProof *const *proofs, const u
     const uint32_t n_prev = 2;
     uint32_t npub = 0;
     const bool with_statements = mb_step_index_installed(c) != 0;
+    {   // one allocation per section
+        const size_t per[16] = {0, n_prev * k * 16, n_prev * 64, 15 * 64, 64, 7 * 64, 43 * 64, 32, 2 * k * 64, 64, 64, 32, 32, 0, 0, 0};
+        for (int i = 0; i < 16; ++i) storage[i].reserve(n * per[i]);
+        const size_t sper[12] = {64, 256, 2 * 256, 2 * 64, 480, 64, 32, 62 * 64, 64, 32, 32, 32};
+        if (with_statements) for (int i = 0; i < 12; ++i) storage[16 + i].reserve(n * sper[i]);
+    }
     if (with_statements) {          // the wrap circuit's public input = the Pickles statement; derived on the GPU inside the job (api_pickles.hip)
         npub = 40;
         auto &s_plonk = storage[16], &s_bp = storage[17], &s_old = storage[18], &s_cm = storage[19], &s_wold = storage[20], &s_wsg = storage[21], &s_dg = storage[22],
@@ -515,11 +521,10 @@ int mb_kimchi_fill_jobs(mina_ctx *c, const mw::WrapProof *const *proofs, const u
         const mw::WrapProof &w = *proofs[b];
         if (w.lr.size() != k || w.step_challenge_polynomial_commitments.size() != n_prev) return fail(MINA_ERR_FORMAT, "wrap proof shape does not match the installed index");
         // recursion challenges of the wrap proof: messages_for_next_wrap_proof.old_bulletproof_challenges, expanded with the Pallas endo_r
-        for (uint32_t a = 0; a < n_prev; ++a) for (uint32_t j = 0; j < k; ++j) {
+        for (uint32_t a = 0; a < n_prev; ++a) for (uint32_t j = 0; j < k; ++j) {          // expanded on the GPU (prev_prechallenges)
             const mw::Chal128 &ch = w.old_bulletproof_challenges[a][j < 15 ? j : 14];
-            const fe_t e = fe_from_mont<FIELD_FQ>(challenge_to_field<FIELD_FQ>(ch.lo, ch.hi, c->fk[FIELD_FQ]));
-            const uint8_t *eb = (const uint8_t *)e.v;
-            pch.insert(pch.end(), eb, eb + 32);
+            uint8_t e[16]; memcpy(e, &ch.lo, 8); memcpy(e + 8, &ch.hi, 8);
+            pch.insert(pch.end(), e, e + 16);
         }
         for (uint32_t a = 0; a < n_prev; ++a) put_pt(pcm, w.step_challenge_polynomial_commitments[a]);
         for (int i = 0; i < 15; ++i) put_pt(wc, w.w_comm[i]);
@@ -536,7 +541,7 @@ int mb_kimchi_fill_jobs(mina_ctx *c, const mw::WrapProof *const *proofs, const u
     }
     rb.assign(32, 0); rb[0] = 7; sb.assign(32, 0); sb[0] = 9;
     kp.resize(sizeof(mina_kimchi_proofs));
-    mina_kimchi_proofs kk{}; kk.batch = n; kk.n_prev = n_prev; kk.npub = npub; kk.prev_chals = pch.data(); kk.prev_comms = pcm.data(); kk.w_comm = wc.data();
+    mina_kimchi_proofs kk{}; kk.batch = n; kk.n_prev = n_prev; kk.npub = npub; kk.prev_prechallenges = pch.data(); kk.prev_comms = pcm.data(); kk.w_comm = wc.data();
     kk.z_comm = zc.data(); kk.t_comm = tc.data(); kk.evals = ev.data(); kk.ft_eval1 = ft1.data();
     if (with_statements) kk.statements = (const mina_pickles_statements *)storage[28].data();
     memcpy(kp.data(), &kk, sizeof kk);

@@ -26,7 +26,7 @@ static int run_bpoly_fold(mina_ctx *c, uint32_t k, size_t batch, const uint32_t 
     static const bool mfma_on = [] { const char *e = getenv("MINA_BPOLY_MFMA"); return !(e && e[0] == '0'); }();
     if (mfma_on && batch >= 256 && batch < (1u << 17) && sh.lb >= 1) {
         Lane &L = *c->L;
-        const uint32_t kpad = (uint32_t)((batch + 63) & ~(size_t)63);
+        const uint32_t kpad = (uint32_t)(cdiv(batch, BPM_KALIGN) * BPM_KALIGN);
         if ((rc = L.bp_ldig.ensure((size_t)nl * BPM_DIGITS * kpad)) || (rc = L.bp_hdig.ensure((size_t)nh * BPM_DIGITS * kpad)) ||
             (rc = L.bp_colsum.ensure((size_t)nh * nl * BPM_COLS * 8))) return rc;
         if (kpad != batch) { HIPC(hipMemsetAsync(L.bp_ldig.p, 0, (size_t)nl * BPM_DIGITS * kpad, L.stream)); HIPC(hipMemsetAsync(L.bp_hdig.p, 0, (size_t)nh * BPM_DIGITS * kpad, L.stream)); }

@@ -233,7 +233,7 @@ static int check_jobs(mina_ctx *c, const mina_state_jobs *j) {
             if (!c->have_kimchi) return fail(MINA_ERR_STATE, "no verifier index installed");
             if (kp.batch != j->batch || j->k != c->kimchi_log2 || j->log2_domain != c->kimchi_log2 || j->n_evalpoints != 2 || j->n_comms != kp.n_prev + 45 || kp.npub != j->npub || kp.n_prev > 8)
                 return fail(MINA_ERR_ARG, "kimchi section does not match the installed index / the job's shape");
-            if ((kp.n_prev && (!kp.prev_chals || !kp.prev_comms)) || !kp.w_comm || !kp.z_comm || !kp.t_comm || !kp.evals || !kp.ft_eval1 || (kp.npub && !kp.public_inputs && !kp.statements)) return fail(MINA_ERR_ARG, "null kimchi section");
+            if ((kp.n_prev && ((!kp.prev_chals && !kp.prev_prechallenges) || !kp.prev_comms)) || !kp.w_comm || !kp.z_comm || !kp.t_comm || !kp.evals || !kp.ft_eval1 || (kp.npub && !kp.public_inputs && !kp.statements)) return fail(MINA_ERR_ARG, "null kimchi section");
             if (kp.statements) { if (kp.npub != 40) return fail(MINA_ERR_ARG, "statements derive exactly 40 public inputs"); int prc = mb_pickles_check(c, kp.statements); if (prc) return prc; }
         } else if (!j->sponge_state || !j->sponge_pos || !j->cip || !j->evalscale || !j->polyscale || (j->n_evalpoints && !j->evalpoints) || (j->n_comms && !j->comms))
             return fail(MINA_ERR_ARG, "null IPA section");
@@ -358,7 +358,14 @@ static int state_jobs_on_lane(mina_ctx *c, const mina_state_jobs *j, uint32_t *d
                 (rc = L.kc_v.ensure(B * 32)) || (rc = L.kc_u.ensure(B * 32)) || (rc = L.kc_comms.ensure(B * (size_t)j->n_comms * 64))) { c->L = L0; return rc; }
             kimchi_bad = L.st_flags.as<uint32_t>() + 12;
             HIPC(hipMemsetAsync(kimchi_bad, 0, 4, L.stream));
-            mb::KimchiIn in{pub, W(kp.prev_chals), W(kp.prev_comms), W(kp.w_comm), W(kp.z_comm), W(kp.t_comm), W(kp.evals), W(kp.ft_eval1), comm_override};
+            const uint32_t *prev_chals = W(kp.prev_chals);
+            if (kp.prev_prechallenges && kp.n_prev) {           // 128-bit prechallenges -> scalar-field challenges, on this lane ahead of the sponges
+                const size_t cnt = B * kp.n_prev * j->k;
+                if ((rc = L.kc_pch.ensure(cnt * 32))) { c->L = L0; return rc; }
+                challenge_to_field_kernel<FIELD_FQ><<<cdiv(cnt, 64), 64, 0, L.stream>>>((uint32_t)cnt, c->fk[FIELD_FQ], W(kp.prev_prechallenges), L.kc_pch.as<uint32_t>());
+                prev_chals = L.kc_pch.as<uint32_t>();
+            }
+            mb::KimchiIn in{pub, prev_chals, W(kp.prev_comms), W(kp.w_comm), W(kp.z_comm), W(kp.t_comm), W(kp.evals), W(kp.ft_eval1), comm_override};
             mb::KimchiOut out{L.kc_state.as<uint32_t>(), L.kc_pos.as<uint32_t>(), L.kc_cip.as<uint32_t>(), L.kc_pts.as<uint32_t>(), L.kc_v.as<uint32_t>(), L.kc_u.as<uint32_t>(),
                               L.kc_comms.as<uint32_t>(), nullptr};
             mb::IpaExpand ex;
@@ -424,7 +431,7 @@ extern "C" int mina_state_job_batch(mina_ctx *c, const mina_state_jobs *jobs, ui
     if (d.with_ipa && d.kimchi) {
         kd = *d.kimchi; d.kimchi = &kd;
         kd.public_inputs = nullptr;                                   // the job's own public_inputs section is the one uploaded
-        add(kd.prev_chals, B * kd.n_prev * k * 32); add(kd.prev_comms, B * kd.n_prev * 64); add(kd.w_comm, B * 15 * 64); add(kd.z_comm, B * 64);
+        add(kd.prev_chals, B * kd.n_prev * k * 32); add(kd.prev_prechallenges, B * kd.n_prev * k * 16); add(kd.prev_comms, B * kd.n_prev * 64); add(kd.w_comm, B * 15 * 64); add(kd.z_comm, B * 64);
         add(kd.t_comm, B * 7 * 64); add(kd.evals, B * 43 * 64); add(kd.ft_eval1, B * 32);
         if (kd.statements) {
             const void **slots[12]; size_t strides[12];
@@ -474,7 +481,7 @@ extern "C" int mina_state_job_batch(mina_ctx *c, const mina_state_jobs *jobs, ui
         auto adv = [&](const void *&p, size_t stride) { if (p) p = (const uint8_t *)p + lo * stride; };
         if (s.kimchi) {
             kslice = *s.kimchi; kslice.batch = cnt; s.kimchi = &kslice;
-            adv(kslice.public_inputs, (size_t)kslice.npub * 32); adv(kslice.prev_chals, (size_t)kslice.n_prev * k * 32); adv(kslice.prev_comms, (size_t)kslice.n_prev * 64);
+            adv(kslice.public_inputs, (size_t)kslice.npub * 32); adv(kslice.prev_chals, (size_t)kslice.n_prev * k * 32); adv(kslice.prev_prechallenges, (size_t)kslice.n_prev * k * 16); adv(kslice.prev_comms, (size_t)kslice.n_prev * 64);
             adv(kslice.w_comm, 15 * 64); adv(kslice.z_comm, 64); adv(kslice.t_comm, 7 * 64); adv(kslice.evals, 43 * 64); adv(kslice.ft_eval1, 32);
             if (kslice.statements) {
                 const void **slots[12]; size_t strides[12];

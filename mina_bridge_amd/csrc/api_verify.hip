@@ -17,7 +17,9 @@
 //                      reference tree does not hold; it runs when an index has been installed (mina_verifier_index_install),
 //                      otherwise the step cannot run and mina_verify_state answers `false` (mina_verify_state_checks tells
 //                      which steps ran and passed; MINA_VERIFY_ALLOW_MISSING_KIMCHI relaxes the verdict for integration tests).
+#include <chrono>
 #include <mutex>
+#include <thread>
 
 #include "ctx.h"
 #include "wire_proof.h"
@@ -59,6 +61,7 @@ extern "C" mina_ctx *mina_verify_global_ctx(void) { std::lock_guard<std::mutex> 
 // ------------------------------------------------------------------------------------------------ Proof of State
 namespace {
 struct ParsedState {
+    ParsedState() {}                     // user-provided: a vector of these is NOT zero-filled (40 KB each)
     bool format_ok = false, ledger_ok = false, consensus_ok = false;
     mina_state_pub_inputs pub;
     mw::StateProofContainer box;
@@ -67,6 +70,17 @@ struct ParsedState {
 };
 
 void chal_bytes(const mw::Chal128 &c, uint8_t *o) { for (int i = 0; i < 8; ++i) { o[i] = (uint8_t)(c.lo >> (8 * i)); o[8 + i] = (uint8_t)(c.hi >> (8 * i)); } }
+
+// independent per-item host work over up to 16 threads (items are ~0.1 ms each: threads only when there are enough of them)
+template <class Fn> void parallel_for(size_t n, Fn fn) {
+    const size_t hw = std::thread::hardware_concurrency();
+    const size_t nt = std::min<size_t>(std::min<size_t>(hw ? hw : 1, 16), (n + 15) / 16);
+    auto work = [&](size_t t) { for (size_t i = t; i < n; i += (nt ? nt : 1)) fn(i); };
+    if (nt <= 1) { work(0); return; }
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < nt; ++t) th.emplace_back(work, t);
+    for (auto &x : th) x.join();
+}
 
 // host part of one proof: FORMAT, LEDGER, CONSENSUS
 void parse_state(const uint8_t *proof, size_t proof_len, const uint8_t *pub, size_t pub_len, ParsedState &ps) {
@@ -94,12 +108,17 @@ void parse_state(const uint8_t *proof, size_t proof_len, const uint8_t *pub, siz
 }
 
 // GPU part of n proofs (those whose FORMAT passed): CHAIN + ACCUMULATOR (+ KIMCHI) through the Proof-of-State job
-int run_state_jobs(mina_ctx *c, std::vector<ParsedState *> &ps, std::vector<uint32_t> &passed, std::vector<uint32_t> &ran) {
+// `masks`: one job per step so that every step gets its own bit (mina_verify_state_checks); otherwise ONE job with all legs -- the
+// verdict-only entry points need nothing finer, and the legs overlap on the GPU
+int run_state_jobs(mina_ctx *c, std::vector<ParsedState *> &ps, std::vector<uint32_t> &passed, std::vector<uint32_t> &ran, bool masks) {
     const size_t n = ps.size();
     if (n == 0) return MINA_OK;
-    std::vector<uint8_t> recs(n * MINA_STATES_PER_PROOF * MINA_PSTATE_SLOTS * 32), exp(n * MINA_STATES_PER_PROOF * 32), pre(n * 16 * 16), sg(n * 64), rho(n * 32);
+    const auto tg = std::chrono::steady_clock::now();
+    std::unique_ptr<uint8_t[]> recs_(new uint8_t[n * MINA_STATES_PER_PROOF * MINA_PSTATE_SLOTS * 32]);      // 34 KB per proof: not zero-filled, every byte is written below
+    uint8_t *recs = recs_.get();
+    std::vector<uint8_t> exp(n * MINA_STATES_PER_PROOF * 32), pre(n * 16 * 16), sg(n * 64), rho(n * 32);
     std::vector<uint32_t> nf(n * MINA_STATES_PER_PROOF);
-    for (size_t b = 0; b < n; ++b) {
+    parallel_for(n, [&](size_t b) {
         memcpy(&recs[b * sizeof ps[b]->records], ps[b]->records, sizeof ps[b]->records);
         memcpy(&nf[b * MINA_STATES_PER_PROOF], ps[b]->nfields, sizeof ps[b]->nfields);
         memcpy(&exp[b * MINA_STATES_PER_PROOF * 32], ps[b]->pub.candidate_chain_state_hashes, 512);
@@ -107,7 +126,7 @@ int run_state_jobs(mina_ctx *c, std::vector<ParsedState *> &ps, std::vector<uint
         const mw::WrapProof &w = ps[b]->box.tip_proof;
         for (int i = 0; i < 16; ++i) chal_bytes(w.bulletproof_challenges[i], &pre[(b * 16 + i) * 16]);
         memcpy(&sg[b * 64], w.challenge_polynomial_commitment.x.b, 32); memcpy(&sg[b * 64 + 32], w.challenge_polynomial_commitment.y.b, 32);
-    }
+    });
     // batching randomisers of the folded accumulator check: SplitMix64 over the proof bytes' digest would make them unpredictable to
     // a prover; here a per-call counter-seeded stream (the folded check only needs them independent of the proofs' contents)
     { static uint64_t ctr = 0x6d696e61ULL; uint64_t st = (ctr += 0x9E3779B97F4A7C15ULL);
@@ -117,8 +136,26 @@ int run_state_jobs(mina_ctx *c, std::vector<ParsedState *> &ps, std::vector<uint
     mina_state_jobs base{}; base.batch = n;
     int rc;
     std::vector<uint8_t> v;
+    if (!masks) {
+        mina_state_jobs j = base; std::vector<std::vector<uint8_t>> storage; std::vector<uint8_t> stmt_ok(n, 1);
+        uint32_t steps = MINA_CHECK_CHAIN | MINA_CHECK_ACCUMULATOR;
+        if (mb_kimchi_available(c)) {
+            std::vector<const mw::WrapProof *> wp(n); std::vector<const uint8_t *> th(n);
+            for (size_t b = 0; b < n; ++b) { wp[b] = &ps[b]->box.tip_proof; th[b] = ps[b]->pub.candidate_chain_state_hashes[15]; }
+            if ((rc = mb_kimchi_fill_jobs(c, wp.data(), th.data(), n, &j, storage, stmt_ok))) return rc;
+            steps |= MINA_CHECK_KIMCHI;
+        }
+        j.with_states = 1; j.state_records = recs; j.state_nfields = nf.data(); j.expected_hashes = exp.data();
+        j.with_accumulator = 1; j.acc_k = 16; j.acc_prechallenges = pre.data(); j.acc_sg = sg.data(); j.acc_rho = rho.data();
+        const auto tj = std::chrono::steady_clock::now();
+        if ((rc = run(j, v))) return rc;
+        if (getenv("MINA_VERIFY_TIMING")) fprintf(stderr, "mina_verify:   gather+fill %.2f ms, mina_state_job_batch %.2f ms\n", std::chrono::duration<double, std::milli>(tj - tg).count(),
+                                                  std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tj).count());
+        for (size_t b = 0; b < n; ++b) { ran[b] |= steps; if (v[b] && stmt_ok[b]) passed[b] |= steps; }
+        return MINA_OK;
+    }
     {   // CHAIN
-        mina_state_jobs j = base; j.with_states = 1; j.state_records = recs.data(); j.state_nfields = nf.data(); j.expected_hashes = exp.data();
+        mina_state_jobs j = base; j.with_states = 1; j.state_records = recs; j.state_nfields = nf.data(); j.expected_hashes = exp.data();
         if ((rc = run(j, v))) return rc;
         for (size_t b = 0; b < n; ++b) { ran[b] |= MINA_CHECK_CHAIN; if (v[b]) passed[b] |= MINA_CHECK_CHAIN; }
     }
@@ -139,12 +176,17 @@ int run_state_jobs(mina_ctx *c, std::vector<ParsedState *> &ps, std::vector<uint
 }
 
 int verify_state_many(size_t n, const uint8_t *const *proofs, const size_t *proof_lens, const uint8_t *const *pubs, const size_t *pub_lens,
-                      uint32_t *passed_out, uint32_t *ran_out) {
+                      uint32_t *passed_out, uint32_t *ran_out, bool masks) {
+    static const bool timing = getenv("MINA_VERIFY_TIMING") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    const auto t0 = now();
     std::vector<ParsedState> ps(n);
     std::vector<uint32_t> passed(n, 0), ran(n, 0);
     std::vector<ParsedState *> live; std::vector<size_t> live_idx;
+    {   // host side of every proof (parse both containers, flatten 17 states, ledger + consensus checks): independent, ~0.1 ms each -> threads
+        parallel_for(n, [&](size_t i) { parse_state(proofs[i], proof_lens[i], pubs[i], pub_lens[i], ps[i]); });
+    }
     for (size_t i = 0; i < n; ++i) {
-        parse_state(proofs[i], proof_lens[i], pubs[i], pub_lens[i], ps[i]);
         ran[i] |= MINA_CHECK_FORMAT;
         if (!ps[i].format_ok) continue;
         passed[i] |= MINA_CHECK_FORMAT; ran[i] |= MINA_CHECK_LEDGER | MINA_CHECK_CONSENSUS;
@@ -152,16 +194,18 @@ int verify_state_many(size_t n, const uint8_t *const *proofs, const size_t *proo
         if (ps[i].consensus_ok) passed[i] |= MINA_CHECK_CONSENSUS;
         live.push_back(&ps[i]); live_idx.push_back(i);
     }
+    const auto t1 = now();
     if (!live.empty()) {
         std::lock_guard<std::mutex> lk(g_mu);
         mina_ctx *c = global_ctx();
         if (!c) return MINA_ERR_HIP;
         std::vector<uint32_t> lp(live.size(), 0), lr(live.size(), 0);
-        int rc = run_state_jobs(c, live, lp, lr);
+        int rc = run_state_jobs(c, live, lp, lr, masks);
         if (rc) return rc;
         for (size_t k = 0; k < live.size(); ++k) { passed[live_idx[k]] |= lp[k]; ran[live_idx[k]] |= lr[k]; }
     }
     for (size_t i = 0; i < n; ++i) { passed_out[i] = passed[i]; ran_out[i] = ran[i]; }
+    if (timing) fprintf(stderr, "mina_verify: n=%zu parse %.2f ms, jobs %.2f ms\n", n, std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(now() - t1).count());
     return MINA_OK;
 }
 
@@ -174,14 +218,14 @@ bool verdict_of(uint32_t passed, uint32_t ran, uint32_t flags) {
 
 extern "C" int mina_verify_state_checks(const uint8_t *proof, size_t proof_len, const uint8_t *pub, size_t pub_len, uint32_t *passed_mask, uint32_t *ran_mask) {
     if (!passed_mask || !ran_mask) return fail(MINA_ERR_ARG, "null argument");
-    return verify_state_many(1, &proof, &proof_len, &pub, &pub_len, passed_mask, ran_mask);
+    return verify_state_many(1, &proof, &proof_len, &pub, &pub_len, passed_mask, ran_mask, /*masks=*/true);
 }
 
 extern "C" int mina_verify_state_batch(size_t n, const uint8_t *const *proofs, const size_t *proof_lens, const uint8_t *const *pubs, const size_t *pub_lens,
                                        uint8_t *verdicts_out) {
     if (n && (!proofs || !proof_lens || !pubs || !pub_lens || !verdicts_out)) return fail(MINA_ERR_ARG, "null argument");
     std::vector<uint32_t> passed(n), ran(n);
-    int rc = verify_state_many(n, proofs, proof_lens, pubs, pub_lens, passed.data(), ran.data());
+    int rc = verify_state_many(n, proofs, proof_lens, pubs, pub_lens, passed.data(), ran.data(), /*masks=*/false);
     if (rc) { for (size_t i = 0; i < n; ++i) verdicts_out[i] = 0; return rc; }
     uint32_t flags; { std::lock_guard<std::mutex> lk(g_mu); flags = g_flags; }
     for (size_t i = 0; i < n; ++i) verdicts_out[i] = verdict_of(passed[i], ran[i], flags) ? 1 : 0;

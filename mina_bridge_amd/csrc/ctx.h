@@ -89,7 +89,7 @@ struct Lane {
     DevBuf bp_ltab, bp_htab, bp_partial, bp_ldig, bp_hdig, bp_colsum;
     DevBuf ipa_chals, ipa_folded, ipa_xyzz_a, ipa_xyzz_b, ipa_points, ipa_scalars, ipa_sigma, ipa_in_a, ipa_in_b, ipa_in_c, ipa_verdict, ipa_xfer;
     DevBuf st_ok, st_hashes, st_pub_xyzz, st_pubcomm, st_flags, st_in, st_verdicts;   // Proof-of-State job (api_state.hip)
-    DevBuf kc_state, kc_pos, kc_cip, kc_pts, kc_v, kc_u, kc_comms, kc_xfer, pk_xe, pk_pub, pk_ok;                  // kimchi to_batch output rows (api_kimchi.hip)
+    DevBuf kc_state, kc_pos, kc_cip, kc_pts, kc_v, kc_u, kc_comms, kc_xfer, kc_pch, pk_xe, pk_pub, pk_ok;                  // kimchi to_batch output rows (api_kimchi.hip)
     void release_all() {
         MsmWorkspace &w = ws;
         DevBuf *all[] = {&w.scalars, &w.points, &w.ekey, &w.eval, &w.eoff, &w.count, &w.start, &w.task_start, &w.rem_pos, &w.rem_bucket, &w.info, &w.sorted, &w.partial, &w.heavy, &w.order, &w.ghist, &w.stage,
@@ -97,7 +97,7 @@ struct Lane {
                          &bp_ltab, &bp_htab, &bp_partial, &bp_ldig, &bp_hdig, &bp_colsum, &ipa_chals, &ipa_folded, &ipa_xyzz_a, &ipa_xyzz_b, &ipa_points, &ipa_scalars,
                          &ipa_sigma, &ipa_in_a, &ipa_in_b, &ipa_in_c, &ipa_verdict, &ipa_xfer,
                          &st_ok, &st_hashes, &st_pub_xyzz, &st_pubcomm, &st_flags, &st_in, &st_verdicts,
-                         &kc_state, &kc_pos, &kc_cip, &kc_pts, &kc_v, &kc_u, &kc_comms, &kc_xfer, &pk_xe, &pk_pub, &pk_ok};
+                         &kc_state, &kc_pos, &kc_cip, &kc_pts, &kc_v, &kc_u, &kc_comms, &kc_xfer, &kc_pch, &pk_xe, &pk_pub, &pk_ok};
         for (DevBuf *b : all) b->release();
         host_stage.release();
     }

@@ -210,8 +210,8 @@ class VerifierIndex(ctypes.Structure):
 class KimchiProofs(ctypes.Structure):
     _fields_ = [("batch", ctypes.c_size_t), ("n_prev", ctypes.c_uint32), ("npub", ctypes.c_uint32), ("public_inputs", ctypes.c_void_p), ("prev_chals", ctypes.c_void_p),
                 ("prev_comms", ctypes.c_void_p), ("w_comm", ctypes.c_void_p), ("z_comm", ctypes.c_void_p), ("t_comm", ctypes.c_void_p), ("evals", ctypes.c_void_p),
-                ("ft_eval1", ctypes.c_void_p), ("statements", ctypes.c_void_p)]
-    POINTER_FIELDS = ("public_inputs", "prev_chals", "prev_comms", "w_comm", "z_comm", "t_comm", "evals", "ft_eval1")
+                ("ft_eval1", ctypes.c_void_p), ("statements", ctypes.c_void_p), ("prev_prechallenges", ctypes.c_void_p)]
+    POINTER_FIELDS = ("public_inputs", "prev_chals", "prev_comms", "w_comm", "z_comm", "t_comm", "evals", "ft_eval1", "prev_prechallenges")
 
 
 class PicklesStatements(ctypes.Structure):

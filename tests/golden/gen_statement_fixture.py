@@ -18,7 +18,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.setrecursionlimit(10000)
 from oracle import ipa_ref as I, kimchi_ref as K, oracle as O, pasta_ref as R, pickles_ref as PK, state_job_ref as J
 from ipa_helpers import poseidon_pp
-from kimchi_helpers import load_k15_fixture, make_step_index
+from kimchi_helpers import load_k15_fixture, make_chain, make_step_index
 from wire_writers import synth_wrap_proof
 import mina_bridge_amd.poseidon_params as PP
 
@@ -57,7 +57,9 @@ for i in range(count):
     pre, sg = J.make_accumulator(1, gv, ACC_K, 0xACC + i)
     wrap["bulletproof_challenges"] = [int.from_bytes(pre[j].tobytes(), "little") for j in range(16)]
     wrap["challenge_polynomial_commitment"] = O.bytes_to_point(sg)
-    app = rng.randrange(R.P)
+    # the application state the statement binds: the hash of the candidate tip (state 15) of the deterministic chain `make_chain(Random(chain_seed))`
+    chain_seed = 0xC4A1 + i
+    app = make_chain(random.Random(chain_seed), pb)[1][15]
     pubs, dv, mw_, ms_ = PK.statement_public_input(wrap, step, comms, app, pb, ps)
     proof = K.synthetic_proof(circ, g, hp, pb, ps, pubs, seed=9000 + i, prev_chals=chals)
     assert [cm for _, cm in proof["prev"]] == prev_comms
@@ -66,7 +68,7 @@ for i in range(count):
     assert J.accumulator_ok(1, gv, ACC_K, pre, sg)
     op = proof["opening"]
     enc = lambda v: (None if v is None else [enc(x) for x in v] if isinstance(v, (list, tuple)) else bool(v) if isinstance(v, bool) else str(v))
-    out["proofs"].append({"statement": {k: enc(wrap[k]) for k in STATEMENT_KEYS}, "app_state": str(app), "pubs": [str(x) for x in pubs],
+    out["proofs"].append({"statement": {k: enc(wrap[k]) for k in STATEMENT_KEYS}, "app_state": str(app), "chain_seed": chain_seed, "pubs": [str(x) for x in pubs],
                           "acc_pre": pre.tobytes().hex(), "acc_sg": bytes(sg).hex(),
                           "w_comm": [hx(p) for p in proof["w_comm"]], "z_comm": hx(proof["z_comm"]), "t_comm": [hx(p) for p in proof["t_comm"]],
                           "evals": [[str(a), str(b)] for a, b in proof["evals"]], "ft_eval1": str(proof["ft_eval1"]),

@@ -171,7 +171,24 @@ def load_statement_fixture():
                  "opening": {"lr": [(pt(l), pt(r)) for l, r in p["lr"]], "delta": pt(p["delta"]), "sg": pt(p["sg"]), "z1": int(p["z1"]), "z2": int(p["z2"])}}
         from oracle import pasta_ref as R
         proof["prev"] = [([R.challenge_to_field(c, R.endo_r(0), R.Q) for c in row], cm) for row, cm in zip(wrap["old_bulletproof_challenges"], wrap["step_comms"])]
-        out.append({"wrap": wrap, "app": int(p["app_state"]), "pubs": [int(x) for x in p["pubs"]],
+        out.append({"wrap": wrap, "app": int(p["app_state"]), "chain_seed": p.get("chain_seed"), "pubs": [int(x) for x in p["pubs"]],
                     "acc_pre": np.frombuffer(bytes.fromhex(p["acc_pre"]), np.uint8).reshape(16, 16).copy(), "acc_sg": np.frombuffer(bytes.fromhex(p["acc_sg"]), np.uint8).copy(),
                     "proof": proof})
     return out, fx
+
+
+def make_chain(rng, pp):
+    """16 linked candidate states + a bridge tip the candidate tip beats by the short-range rule (same epoch, same staking lock
+    checkpoint, longer chain)"""
+    from oracle import mina_state_ref as S, state_job_ref as J
+    states, hashes = [], []
+    prev = rng.randrange(S.P)
+    lock = rng.randrange(S.P)
+    for i in range(17):
+        st = J.synth_state(rng, prev if i < 16 else rng.randrange(S.P), 1000 + i if i < 16 else 990)
+        if i >= 15:
+            st["body"]["consensus_state"]["epoch_count"] = 7
+            st["body"]["consensus_state"]["staking_epoch_data"]["lock_checkpoint"] = lock
+        h = S.protocol_state_hash(st, pp)
+        states.append(st); hashes.append(h); prev = h
+    return states, hashes

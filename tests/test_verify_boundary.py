@@ -13,21 +13,7 @@ pytestmark = pytest.mark.gpu
 K_LOG2 = 6
 
 
-def _chain(rng, pp):
-    """16 linked candidate states + a bridge tip the candidate tip beats by the short-range rule (same epoch, same staking lock
-    checkpoint, longer chain)"""
-    from oracle import mina_state_ref as S, state_job_ref as J
-    states, hashes = [], []
-    prev = rng.randrange(S.P)
-    lock = rng.randrange(S.P)
-    for i in range(17):
-        st = J.synth_state(rng, prev if i < 16 else rng.randrange(S.P), 1000 + i if i < 16 else 990)
-        if i >= 15:
-            st["body"]["consensus_state"]["epoch_count"] = 7
-            st["body"]["consensus_state"]["staking_epoch_data"]["lock_checkpoint"] = lock
-        h = S.protocol_state_hash(st, pp)
-        states.append(st); hashes.append(h); prev = h
-    return states, hashes
+from kimchi_helpers import make_chain as _chain  # noqa: E402
 
 
 @pytest.fixture(scope="module")
