@@ -23,8 +23,7 @@ typedef int bp_v4i __attribute__((ext_vector_type(4)));
 typedef int bp_v16i __attribute__((ext_vector_type(16)));
 
 static constexpr uint32_t BPM_DIGITS = 32, BPM_COLS = 64;     // 63 anti-diagonals, padded to 64 bins per output
-static constexpr int BPM_DEPTH = 6;                           // k-steps (of 32) in flight per wave in the GEMM
-static constexpr uint32_t BPM_KALIGN = 32 * BPM_DEPTH;        // the batch dimension of the digit planes is padded to this
+static constexpr uint32_t BPM_KALIGN = 64;                    // the batch dimension of the digit planes is padded to this (MFMA k-step 32, 16-B rows)
 
 // table entry e of proof b (sponge.cuh `bpoly_tables_kernel`) as balanced digits.  Thread mapping: b fastest, so that the 64 lanes of a
 // wave write 64 consecutive bytes of a digit plane.  planes: Ld [nl * 32][kpad], Hd [nh * 32][kpad]; columns b >= batch stay zero.
@@ -85,26 +84,17 @@ bpoly_field_gemm_kernel(uint32_t mtiles, uint32_t ntiles, uint32_t kpad, const i
         ap[i] = A + ((size_t)((m_ok[i] ? mt0 + i : 0) * 32 + (lane & 31u))) * kpad + (lane >> 5) * 16;
         bp[i] = B + ((size_t)((n_ok[i] ? nt0 + i : 0) * 32 + (lane & 31u))) * kpad + (lane >> 5) * 16;
     }
-    // fragments come straight from L2 (the planes of one call are 96 - 128 MiB: Infinity-Cache resident); a ring of BPM_DEPTH k-steps is
-    // kept in flight per wave so that the MFMAs of step s overlap the loads of steps s+1 .. s+DEPTH-1 (kpad is a multiple of 32 * DEPTH)
-    bp_v4i ra[BPM_DEPTH][2], rb[BPM_DEPTH][2];
+    // fragments come straight from L2 (the planes of one call are 96 - 128 MiB).  Each load instruction of a wave touches 32 rows, i.e. 32 - 64
+    // cache lines: the texture addresser, not the matrix core, paces this loop (13 % of the int8 peak).  A ring of k-steps in flight was
+    // measured 10 % SLOWER (the bound is line throughput, not latency); LDS staging with row-contiguous loads is the known fix.
+    for (uint32_t k0 = 0; k0 < kpad; k0 += 32) {
+        bp_v4i a[2], b[2];
 #pragma unroll
-    for (int d = 0; d < BPM_DEPTH; ++d)
+        for (int i = 0; i < 2; ++i) { a[i] = *reinterpret_cast<const bp_v4i *>(ap[i] + k0); b[i] = *reinterpret_cast<const bp_v4i *>(bp[i] + k0); }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) { ra[d][i] = *reinterpret_cast<const bp_v4i *>(ap[i] + d * 32); rb[d][i] = *reinterpret_cast<const bp_v4i *>(bp[i] + d * 32); }
-    for (uint32_t k0 = 0; k0 < kpad; k0 += 32 * BPM_DEPTH) {
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int d = 0; d < BPM_DEPTH; ++d) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(ra[d][i], rb[d][j], acc[i][j], 0, 0, 0);
-            const uint32_t kn = k0 + (d + BPM_DEPTH) * 32;
-            if (kn < kpad) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) { ra[d][i] = *reinterpret_cast<const bp_v4i *>(ap[i] + kn); rb[d][i] = *reinterpret_cast<const bp_v4i *>(bp[i] + kn); }
-            }
-        }
+            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i], b[j], acc[i][j], 0, 0, 0);
     }
     // C/D layout: col = lane & 31 (the B row: digit c of lo), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (digit a of hi); bin a + c
     __syncthreads();
