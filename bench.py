@@ -49,7 +49,7 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 CURVE_PALLAS, CURVE_VESTA = 0, 1
 FIELD_FP = 0
 ACC_K, WRAP_K, LOG2_DOMAIN, NPUB, NCOMMS, NPTS, SLOT = 16, 15, 15, 40, 45, 2, 0
-STATES_PER_PROOF, PSTATE_SLOTS = 17, 64
+STATES_PER_PROOF, PSTATE_SLOTS, PSTATE_BODY_FIELDS = 17, 64, 49
 HBM_PEAK_GBPS = 8000.0                                # MI355X_MICROARCH.md: 8 TB/s spec
 # VALU side of the roofline (the path is integer-multiply bound): one Montgomery product is 88
 # v_mad_u64_u32 (8 cycles per wave64 instruction, profiles/r01_microbench_valu.jsonl) -> issue floor 704 cycles.
@@ -66,24 +66,27 @@ def le32(x: int) -> np.ndarray:
     return np.frombuffer(int(x).to_bytes(32, "little"), np.uint8)
 
 
-def make_chains(ctx, m, n_chains: int, seed: int):
-    """`n_chains` synthetic candidate chains (16 linked states + bridge tip), serialized with the bin_prot writer, flattened by the
-    LIBRARY (mina_protocol_state_pack) and hashed by the GPU path itself, state by state, so that each state names its
-    predecessor's hash (parity of that path vs the CPU oracle is what tests/ establish).  Returns (records[n,17,2048], nfields[n,17],
-    hashes[n,17,32])."""
-    from oracle import mina_state_ref as S, state_job_ref as J
-    rng = random.Random(seed)
-    recs = np.zeros((n_chains, STATES_PER_PROOF, PSTATE_SLOTS * 32), np.uint8)
-    nf = np.zeros((n_chains, STATES_PER_PROOF), np.uint32)
+def make_chains(ctx, n_chains: int, seed: int):
+    """`n_chains` synthetic candidate chains (16 linked states + bridge tip) as the job takes them: flattened protocol-state records
+    (include/mina_verify.h: slot 0 = previous_state_hash, slots 1..49 = the body's `to_input` field elements).  Random field content,
+    linked through hashes computed by the GPU path itself, state by state (the bin_prot / bincode readers and the `to_input` flattening
+    that produce such records from serialized states are the host side of the boundary: tests/test_protocol_state.py,
+    tests/test_verify_fullsize.py).  Returns (records[n,17,2048], nfields[n,17], hashes[n,17,32])."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    recs = np.zeros((n_chains, STATES_PER_PROOF, PSTATE_SLOTS, 32), np.uint8)
+    nf = np.full((n_chains, STATES_PER_PROOF), PSTATE_BODY_FIELDS, np.uint32)
     hashes = np.zeros((n_chains, STATES_PER_PROOF, 32), np.uint8)
-    prev = [rng.randrange(S.P) for _ in range(n_chains)]
+    body = rng.integers(0, 256, size=(n_chains, STATES_PER_PROOF, PSTATE_BODY_FIELDS, 32), dtype=np.uint8)
+    body[..., 31] &= 0x3F                                       # < 2^254 < p: canonical
+    recs[:, :, 1:1 + PSTATE_BODY_FIELDS] = body
+    prev = rng.integers(0, 256, size=(n_chains, 32), dtype=np.uint8); prev[:, 31] &= 0x3F
     for s in range(STATES_PER_PROOF):
-        for c in range(n_chains):
-            st = J.synth_state(rng, prev[c] if s < 16 else rng.randrange(S.P), 1000 + s)
-            recs[c, s], nf[c, s], _, _ = m.lib.protocol_state_pack(S.write_protocol_state(st))
-        hashes[:, s] = ctx.protocol_state_hash_batch(recs[:, s].copy(), nf[:, s].copy())
-        prev = [int.from_bytes(hashes[c, s].tobytes(), "little") for c in range(n_chains)]
-    return recs, nf, hashes
+        if s == 16:                                             # the bridge tip is not linked to the candidate chain
+            prev = rng.integers(0, 256, size=(n_chains, 32), dtype=np.uint8); prev[:, 31] &= 0x3F
+        recs[:, s, 0] = prev
+        hashes[:, s] = ctx.protocol_state_hash_batch(recs[:, s].reshape(n_chains, -1).copy(), nf[:, s].copy())
+        prev = hashes[:, s].copy()
+    return recs.reshape(n_chains, STATES_PER_PROOF, PSTATE_SLOTS * 32), nf, hashes
 
 
 def make_accumulators(ctx, count: int, seed: int):
@@ -95,70 +98,45 @@ def make_accumulators(ctx, count: int, seed: int):
     return pre, sgs
 
 
-def build_batch(ctx, m, B: int, seed: int):
-    """host-side `mina_state_jobs` of B jobs from 32 distinct chains, the committed full-size wrap openings
-    (tests/golden/state_job_k15.json) and 32 distinct accumulators"""
-    from state_job_helpers import entry_arrays, load_k15_openings
-    fx, ops = load_k15_openings()
-    assert (fx["k"], fx["log2_domain"], fx["npub"], fx["n_comms"], fx["n_points"], fx["slot"]) == (WRAP_K, LOG2_DOMAIN, NPUB, NCOMMS, NPTS, SLOT)
-    nd = min(B, 32)
-    recs, nf, hashes = make_chains(ctx, m, nd, seed)
-    pre, sgs = make_accumulators(ctx, nd, seed + 1)
-    abi = [entry_arrays(e, s) for (_, e, s) in ops]
-    pubs = [np.concatenate([le32(x) for x in p]) for (p, _, _) in ops]
-    idx = np.arange(B) % nd
-    oi = np.arange(B) % len(ops)
-    cat = lambda key: np.concatenate([np.asarray(abi[i][key], np.uint8).reshape(-1) for i in oi])
-    rho = np.random.Generator(np.random.PCG64(seed + 2)).integers(0, 256, (B, 32), dtype=np.uint8); rho[:, 31] &= 0x3F
-    arrays = dict(
-        state_records=recs[idx].reshape(-1), state_nfields=nf[idx].reshape(-1), expected_hashes=hashes[idx].reshape(-1),
-        public_inputs=np.concatenate([pubs[i] for i in oi]),
-        sponge_state=cat("sponge_state"), cip=cat("combined_inner_product"), lr=cat("lr"), delta=cat("delta"), sg=cat("sg"), z1=cat("z1"), z2=cat("z2"),
-        evalpoints=cat("evalpoints"), evalscale=cat("evalscale"), polyscale=cat("polyscale"), comms=cat("comms"),
-        sponge_pos=np.array([[abi[i]["sponge_mode"], abi[i]["sponge_count"]] for i in oi], np.uint32),
-        rand_base=le32(7), sg_rand_base=le32(9), acc_prechallenges=pre[idx].reshape(-1), acc_sg=sgs[idx].reshape(-1), acc_rho=rho.reshape(-1))
-    scal = dict(with_states=1, with_ipa=1, with_accumulator=1, log2_domain=LOG2_DOMAIN, npub=NPUB, pub_comm_slot=SLOT, k=WRAP_K, n_evalpoints=NPTS,
-                n_comms=NCOMMS, acc_k=ACC_K)
-    return m.MinaContext.make_state_jobs(B, arrays, **scal), (recs[0], nf[0], hashes[0], ops[0], pre[0], sgs[0])
+def load_encoded_fixture():
+    """tests/golden/statement_k15_encoded.json: the four complete wrap proofs in the C-ABI's byte layouts (written by
+    tests/golden/encode_statement_fixture.py from statement_k15.json; nothing under oracle/ is needed to read it)"""
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "statement_k15_encoded.json")))
+    un = lambda h: np.frombuffer(bytes.fromhex(h), np.uint8).copy() if h else np.zeros(1, np.uint8)
+    return fx, un
 
 
-def build_kimchi_section(ctx, m, B: int):
-    """the raw wrap proofs of the committed wrap-size fixture, tiled to B: (KimchiProofs + keep, opening arrays, public inputs)"""
-    from kimchi_helpers import install_index, kimchi_arrays, load_k15_fixture
-    ix, proofs, fx = load_k15_fixture()
-    install_index(ctx, ix)
-    idx = np.arange(B) % len(proofs)
-    arrays, op = kimchi_arrays([p for _, p in proofs], [pi for pi, _ in proofs])
-    per = {"prev_chals": 2 * 15 * 32, "prev_comms": 2 * 64, "w_comm": 15 * 64, "z_comm": 64, "t_comm": 7 * 64, "evals": 43 * 64, "ft_eval1": 32, "public_inputs": 40 * 32,
-           "lr": 30 * 64, "delta": 64, "sg": 64, "z1": 32, "z2": 32}
-    tile = lambda a, n: np.ascontiguousarray(a.reshape(len(proofs), n)[idx].reshape(-1))
-    arrays = {k: tile(v, per[k]) for k, v in arrays.items() if v is not None}
-    op = {k: tile(v, per[k]) for k, v in op.items()}
-    return m.MinaContext.make_kimchi_proofs(B, 2, 40, arrays), op, arrays["public_inputs"]
+def install_fixture_indexes(ctx, fx, un):
+    w, s = fx["wrap_index"], fx["step_index"]
+    ctx.verifier_index_install(w["log2_domain"], w["zk_rows"], w["perm_alpha_offset"], un(w["shifts"]), un(w["sigma_comm"]), un(w["coefficients_comm"]),
+                               un(w["selector_comm"]), bytes.fromhex(w["constant_term"]))
+    ctx.step_index_install(s["zk_rows"], s["domains"], un(s["shifts"]), bytes.fromhex(s["constant_term"]))
 
 
-def build_full_section(ctx, m, B: int):
-    """the complete wrap proofs of tests/golden/statement_k15.json (Pickles statement + wrap proof whose public input is its packing + the
-    step accumulator the statement carries), tiled to B: (KimchiProofs with statements + keep, opening arrays, accumulator arrays, sample)"""
-    from kimchi_helpers import install_index, install_step_index, kimchi_arrays, load_k15_fixture, load_statement_fixture, make_step_index, statements_soa
-    ix, _, _ = load_k15_fixture()
-    install_index(ctx, ix)
-    step = make_step_index(99)
-    install_step_index(ctx, step)
-    items, fx = load_statement_fixture()
+def build_full_job(ctx, m, B: int, seed: int):
+    """host-side `mina_state_jobs` of B complete jobs: 32 distinct chains + the 4 complete wrap proofs of the encoded fixture (statement,
+    wrap proof, opening, the accumulator the statement carries), tiled to B.  Returns (StateJobs + keep, KimchiProofs + keep)."""
+    import mina_bridge_amd.poseidon_params as PP
+    fx, un = load_encoded_fixture()
+    assert fx["poseidon_constants"] == PP.NAME, "the fixture was minted under another Poseidon constant set"
+    install_fixture_indexes(ctx, fx, un)
+    items = fx["proofs"]
     n = len(items)
     idx = np.arange(B) % n
-    arrays, op = kimchi_arrays([it["proof"] for it in items], [])
-    per = {"prev_chals": 2 * 15 * 32, "prev_comms": 2 * 64, "w_comm": 15 * 64, "z_comm": 64, "t_comm": 7 * 64, "evals": 43 * 64, "ft_eval1": 32,
-           "lr": 30 * 64, "delta": 64, "sg": 64, "z1": 32, "z2": 32}
-    tile = lambda a, w: np.ascontiguousarray(np.asarray(a, np.uint8).reshape(n, w)[idx].reshape(-1))
-    arrays = {k: tile(v, per[k]) for k, v in arrays.items() if v is not None}
-    op = {k: tile(v, per[k]) for k, v in op.items()}
-    n_old, n_evals, sec = statements_soa([it["wrap"] for it in items], [it["app"] for it in items])
-    sec = {k: tile(v, v.size // n) for k, v in sec.items()}
-    st = m.MinaContext.make_pickles_statements(n_old, n_evals, sec)
-    acc = {"acc_prechallenges": tile(np.stack([it["acc_pre"] for it in items]), ACC_K * 16), "acc_sg": tile(np.stack([it["acc_sg"] for it in items]), 64)}
-    return m.MinaContext.make_kimchi_proofs(B, 2, 40, arrays, statements=st), op, acc, (ix, step, items[0])
+    tile = lambda key, name: np.ascontiguousarray(np.stack([un(it[key][name]) if key else un(it[name]) for it in items])[idx].reshape(-1))
+    n_old, n_evals = items[0]["n_old"], items[0]["n_evals"]
+    st = m.MinaContext.make_pickles_statements(n_old, n_evals, {name: tile("statement", name) for name in m.lib.PicklesStatements.POINTER_FIELDS})
+    karr = {name: tile("kimchi", name) for name in items[0]["kimchi"]}
+    kp = m.MinaContext.make_kimchi_proofs(B, 2, NPUB, karr, statements=st)
+    nd = min(B, 32)
+    recs, nf, hashes = make_chains(ctx, nd, seed)
+    ci = np.arange(B) % nd
+    rho = np.random.Generator(np.random.PCG64(seed + 2)).integers(0, 256, (B, 32), dtype=np.uint8); rho[:, 31] &= 0x3F
+    arrays = dict(state_records=recs[ci].reshape(-1), state_nfields=nf[ci].reshape(-1), expected_hashes=hashes[ci].reshape(-1),
+                  rand_base=le32(7), sg_rand_base=le32(9), acc_prechallenges=tile(None, "acc_prechallenges"), acc_sg=tile(None, "acc_sg"), acc_rho=rho.reshape(-1),
+                  **{name: tile("opening", name) for name in ("lr", "delta", "sg", "z1", "z2")})
+    scal = dict(with_states=1, with_ipa=1, with_accumulator=1, log2_domain=LOG2_DOMAIN, npub=NPUB, k=WRAP_K, n_evalpoints=NPTS, n_comms=NCOMMS + 2, acc_k=ACC_K, kimchi=kp)
+    return m.MinaContext.make_state_jobs(B, arrays, **scal), kp, (recs[0], nf[0], hashes[0])
 
 
 def algorithmic_bytes_per_proof() -> int:
@@ -178,15 +156,24 @@ def cpu_model() -> str:
     return platform.processor() or "unknown"
 
 
-def cpu_baseline(sample, budget_s: float = 20.0, full_sample=None):
+def cpu_baseline(baseline_sample, budget_s: float = 20.0):
     """The same composite on the CPU restatement (oracle/, kind="port" -- the reference's Rust verifier cannot be built here):
-    BASELINE config C1.  One proof at a time: 17 state hashes (C Poseidon), public-input commitment (iFFT + 2^15 MSM), the wrap
-    opening check (Python transcript + C b_poly / MSMs) and the 2^16 Vesta accumulator MSM (ark-style Pippenger, one thread per
-    window).  Timed with all useful host threads and with one."""
+    BASELINE config C1.  One proof at a time: 17 state hashes (C Poseidon), [full mode: the Pickles statement -> public inputs and kimchi
+    oracles + to_batch, Python over the C kernels,] public-input commitment (iFFT + 2^15 MSM), the wrap opening check (Python transcript +
+    C b_poly / MSMs) and the 2^16 Vesta accumulator MSM (ark-style Pippenger, one thread per window).  Timed with all useful host threads
+    and with one.  This is the ONLY part of bench.py that touches oracle/ (and, for its inputs, the test helpers that decode the fixtures)."""
     from oracle import ipa_ref as I, oracle as O, pasta_ref as R, state_job_ref as J
     from state_job_helpers import pp_fp
     import mina_bridge_amd.poseidon_params as PP
-    recs, nf, hashes, (pubs, entry, sponge), pre, sg = sample
+    kind, sample = baseline_sample
+    full_sample = None
+    if kind == "full":
+        from kimchi_helpers import load_k15_fixture, load_statement_fixture, make_step_index
+        recs, nf, hashes = sample
+        ix, _, _ = load_k15_fixture()
+        full_sample = (ix, make_step_index(99), load_statement_fixture()[0][0])
+    else:
+        recs, nf, hashes, (pubs, entry, sponge), pre, sg = sample
     nproc = os.cpu_count() or 1
     srs = {c: O.srs_create(c, 1 << 16, threads=nproc) for c in (0, 1)}
     params = PP.default_params_bytes(FIELD_FP)
@@ -316,22 +303,24 @@ def main():
     ctx.srs_create(CURVE_VESTA, 1 << 16)                       # both SRS regenerated on the GPU (K4) + window tables
     ctx.srs_create(CURVE_PALLAS, 1 << 16)
     B = args.jobs
-    (hj, keep), sample = build_batch(ctx, m, B, seed=0x6D696E61 + rank)
-    full_sample = None
-    if args.kimchi:                                            # the wrap leg from the raw proofs instead of pre-derived BatchEvaluationProof rows
-        if args.mode == "full":
-            kp, op, acc, full_sample = build_full_section(ctx, m, B)
-            extra = list(op.items()) + list(acc.items())
-            hj.public_inputs = None                            # derived on the GPU from the statements
-        else:
-            kp, op, kpub = build_kimchi_section(ctx, m, B)
-            extra = list(op.items()) + [("public_inputs", kpub)]
-        for name in ("sponge_state", "sponge_pos", "cip", "evalpoints", "evalscale", "polyscale", "comms"):
-            setattr(hj, name, None)
-        keep = [a for a in keep] + [kp]
-        for name, arr in extra:
-            arr = np.ascontiguousarray(arr); keep.append(arr); setattr(hj, name, arr.ctypes.data)
-        hj.n_comms = 47
+    seed = 0x6D696E61 + rank
+    if args.mode == "full":
+        (hj, keep), kp, chain_sample = build_full_job(ctx, m, B, seed)
+        baseline_sample = ("full", chain_sample)
+    else:                                                      # partial jobs: inputs through the test helpers (tools/bench_partial_inputs.py)
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_partial_inputs as P
+        (hj, keep), sample = P.build_batch(ctx, m, B, seed)
+        kp = None
+        if args.mode == "kimchi":                              # the wrap leg from the raw proofs, public inputs given
+            kp, op, kpub = P.build_kimchi_section(ctx, m, B)
+            for name in ("sponge_state", "sponge_pos", "cip", "evalpoints", "evalscale", "polyscale", "comms"):
+                setattr(hj, name, None)
+            keep = [a for a in keep] + [kp]
+            for name, arr in list(op.items()) + [("public_inputs", kpub)]:
+                arr = np.ascontiguousarray(arr); keep.append(arr); setattr(hj, name, arr.ctypes.data)
+            hj.n_comms = NCOMMS + 2
+        baseline_sample = ("prepared", sample)                 # the CPU composite of the partial modes starts from the derived rows
     dev = torch.device("cuda", local_rank)
     dj = m.lib.StateJobs()
     import ctypes
@@ -343,7 +332,7 @@ def main():
         if addr:
             t = torch.from_numpy(np.array(by_addr[addr].view(np.uint8).reshape(-1))).to(dev)
             dtensors.append(t); setattr(dj, name, t.data_ptr())
-    if args.kimchi:                                            # the kimchi section's arrays live in HBM as well
+    if kp is not None:                                         # the kimchi section's arrays live in HBM as well
         import ctypes as ct
         dk = m.lib.KimchiProofs()
         ct.memmove(ct.byref(dk), ct.byref(kp[0]), ct.sizeof(m.lib.KimchiProofs))
@@ -354,7 +343,7 @@ def main():
                 if name == "public_inputs":
                     setattr(dk, name, dj.public_inputs); continue
                 t = torch.from_numpy(kaddr[addr].view(np.uint8).reshape(-1)).to(dev); dtensors.append(t); setattr(dk, name, t.data_ptr())
-        if args.mode == "full":                                # the statement sections too
+        if kp[0].statements:                                   # the statement sections too
             hst, hkeep = next(a for a in kp[1] if isinstance(a, tuple))
             dst = m.lib.PicklesStatements()
             ct.memmove(ct.byref(dst), ct.byref(hst), ct.sizeof(m.lib.PicklesStatements))
@@ -488,8 +477,10 @@ def main():
                                    "2^16-base Vesta step-accumulator check; verdict per proof, bit-exact vs the CPU oracle composite (tests/test_state_job.py)",
                        "proofs_per_step": B, "pipeline_lanes": args.pipeline, "warmup_steps_run": n_warm,
                        "mode": args.mode,
-                       "distinct_inputs": {"full": "32 chains, 4 complete wrap proofs (tests/golden/statement_k15.json: statement + proof + its accumulator) per rank; the statements' "
-                                                   "application state is the fixture's, not the hash of the chain tiled beside it (that binding: tests/test_verify_boundary.py)",
+                       "distinct_inputs": {"full": "32 chains of flattened protocol-state records (random field content, GPU-linked) and the 4 complete wrap proofs of "
+                                                   "tests/golden/statement_k15_encoded.json (statement + proof + its accumulator) per rank; the statements' application "
+                                                   "state is the fixture's, not the hash of the chain tiled beside it (that binding, on serialized states through the "
+                                                   "parsers: tests/test_verify_fullsize.py)",
                                            "kimchi": "32 chains, 4 wrap proofs (tests/golden/kimchi_k15.json), 32 accumulators per rank",
                                            "prepared": "32 chains, 8 wrap openings (tests/golden/state_job_k15.json), 32 accumulators per rank"}[args.mode],
                        "folding": "IPA and accumulator checks folded over the step's batch with caller-supplied randomisers (kimchi batch_verify's shape)",
@@ -521,7 +512,7 @@ def main():
             out["roofline_valu"] = {"bound": "int32 multiply issue (v_mad_u64_u32)", "kernel": "pstate_hash_kernel", "achieved": got / 1e9, "peak": peak / 1e9,
                                     "unit": "G modmul/s", "frac": got / peak, "permutations_per_launch": perms}
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(sample, full_sample=full_sample)
+            out["cpu_baseline"] = cpu_baseline(baseline_sample)
         print(json.dumps(out), flush=True)
     if dist_on:
         dist.barrier()

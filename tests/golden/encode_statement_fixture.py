@@ -1,0 +1,44 @@
+"""tests/golden/statement_k15.json (+ the wrap index of kimchi_k15.json, + kimchi_helpers.make_step_index(99)) -> tests/golden/
+statement_k15_encoded.json: the SAME inputs in the byte layouts of the C-ABI (include/mina_verify.h: mina_verifier_index, mina_step_index,
+mina_pickles_statements, mina_kimchi_proofs, the opening and accumulator sections of mina_state_jobs), hex per section.
+bench.py's default mode reads only this file, so that nothing under oracle/ is imported outside its cpu_baseline leg; the test
+tests/test_statement_fixture.py checks that it is what the helpers produce.  Run after gen_statement_fixture.py:
+    python tests/golden/encode_statement_fixture.py"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+from kimchi_helpers import STEP_DOMAINS, encode_tokens, kimchi_arrays, load_k15_fixture, load_statement_fixture, make_step_index, pts, statements_soa
+from oracle import oracle as O
+
+
+def encode():
+    ix, _, fxk = load_k15_fixture()
+    items, fx = load_statement_fixture()
+    step = make_step_index(99)
+    hx = lambda a: np.ascontiguousarray(a, dtype=np.uint8).reshape(-1).tobytes().hex()
+    out = {"poseidon_constants": fx["poseidon_constants"], "source": "tests/golden/statement_k15.json, tests/golden/kimchi_k15.json, kimchi_helpers.make_step_index(99)",
+           "wrap_index": {"log2_domain": ix.log2_domain, "zk_rows": ix.zk_rows, "perm_alpha_offset": ix.perm_alpha_offset, "shifts": hx(O.ints_to_le(ix.shifts)),
+                          "sigma_comm": hx(pts(ix.sigma_comm)), "coefficients_comm": hx(pts(ix.coefficients_comm)), "selector_comm": hx(pts(ix.selector_comm)),
+                          "constant_term": encode_tokens(ix.constant_term).hex()},
+           "step_index": {"zk_rows": step.zk_rows, "domains": STEP_DOMAINS, "shifts": hx(np.concatenate([O.ints_to_le(step.shifts[k]).reshape(-1) for k in STEP_DOMAINS])),
+                          "constant_term": encode_tokens(step.constant_term).hex()},
+           "proofs": []}
+    for it in items:
+        n_old, n_evals, sec = statements_soa([it["wrap"]], [it["app"]])
+        arrays, op = kimchi_arrays([it["proof"]], [])
+        arrays.pop("prev_chals")                                       # the 128-bit prechallenges travel instead (expanded on the GPU)
+        pre = b"".join(int(c).to_bytes(16, "little") for row in it["wrap"]["old_bulletproof_challenges"] for c in row)
+        out["proofs"].append({"n_old": n_old, "n_evals": n_evals, "statement": {k: hx(v) for k, v in sec.items()},
+                              "kimchi": dict({k: hx(v) for k, v in arrays.items() if v is not None}, prev_prechallenges=pre.hex()),
+                              "opening": {k: hx(v) for k, v in op.items()}, "acc_prechallenges": hx(it["acc_pre"]), "acc_sg": hx(it["acc_sg"]),
+                              "public_inputs": hx(O.ints_to_le(it["pubs"]))})
+    return out
+
+
+if __name__ == "__main__":
+    json.dump(encode(), open(os.path.join(ROOT, "tests/golden/statement_k15_encoded.json"), "w"), indent=0)
+    print("wrote tests/golden/statement_k15_encoded.json")

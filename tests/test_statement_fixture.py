@@ -14,3 +14,13 @@ def test_statement_fixture_is_what_the_oracle_derives():
     step = make_step_index(99)
     for it in items[:2]:
         assert PK.statement_public_input(it["wrap"], step, comms, it["app"], poseidon_pp(0), poseidon_pp(1))[0] == it["pubs"]
+
+
+def test_encoded_fixture_is_the_helpers_encoding_of_the_fixture():
+    """tests/golden/statement_k15_encoded.json (what bench.py's default mode reads, so that it needs nothing under oracle/) is exactly the
+    C-ABI encoding the test helpers produce from statement_k15.json / kimchi_k15.json / make_step_index(99)"""
+    import importlib.util, json, os
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("encode_statement_fixture", os.path.join(here, "golden", "encode_statement_fixture.py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    assert mod.encode() == json.load(open(os.path.join(here, "golden", "statement_k15_encoded.json")))
