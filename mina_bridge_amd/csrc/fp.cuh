@@ -272,229 +272,230 @@ template <int F> MB_HD fe_t fe_mul_portable(const fe_t &a, const fe_t &b) {
 // ---- gfx950 device version: product scanning (FIPS) with a 96-bit column accumulator (acc:64, hi:32).
 // One `v_mad_u64_u32` per 32x32 product accumulates straight into `acc`; its carry-out goes to an SGPR pair
 // that the following `v_addc_co_u32` folds into `hi` -- no 64-bit addend assembly, no v_mov traffic.
-// 64 (a*b) + 32 (m*p1, p2, p3, p7) multiply-accumulates; p0 = 1 is a carry fold (mb_fold_shift).
+// 64 (a*b) + 32 (m*p1, p2, p3, p7) multiply-accumulates; p0 = 1 is a carry fold (mb_fold_shift).  `hi` is zero at the start of every
+// column, so the column's first carry add computes 0 + 0 + carry INTO it: no per-column `v_mov hi, 0` (15 per product).
 // acc(96 bit) += m * p0 where m = -lo: the low word becomes 0 and carries (lo != 0) into the upper 64 bits; then >> 32.
 __device__ __forceinline__ void mb_fold_shift(uint64_t &acc, uint32_t &hi, uint32_t lo, uint32_t mid) {
     uint32_t nlo, nhi;
     asm("v_cmp_ne_u32_e32 vcc, 0, %2\n\tv_addc_co_u32_e32 %0, vcc, 0, %3, vcc\n\tv_addc_co_u32_e32 %1, vcc, 0, %4, vcc"
         : "=&v"(nlo), "=&v"(nhi) : "v"(lo), "v"(mid), "v"(hi) : "vcc");
-    acc = ((uint64_t)nhi << 32) | nlo; hi = 0;
+    acc = ((uint64_t)nhi << 32) | nlo;                       // `hi` is dead here: the next column's first carry add writes it
 }
 template <int F, bool RED = true> __device__ __forceinline__ fe_t fe_mul_device(const fe_t &a, const fe_t &b) {
     // generated by tools/gen_fe_mul.py -- product scanning, one Montgomery reduction
-    uint64_t acc = 0, cc; uint32_t hi = 0, lo, mid; fe_t r;
+    uint64_t acc = 0, cc; uint32_t hi, lo, mid; fe_t r;
     uint32_t m0, m1, m2, m3, m4, m5, m6, m7;
     const uint32_t p1 = FieldP<F>::P1, p2 = FieldP<F>::P2, p3 = FieldP<F>::P3, p7 = P7;
     // column 0: 1 products
-    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
-        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[0]));
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, 0, %2"
+        : "+&v"(acc), "=&v"(hi), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[0]));
     lo = (uint32_t)acc; mid = (uint32_t)(acc >> 32); m0 = 0u - lo;
     mb_fold_shift(acc, hi, lo, mid);                          // + m_k * p0 (low word -> 0), then >> 32
     // column 1: 3 products
-    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
-        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[1]), "v"(a.v[1]), "v"(b.v[0]), "v"(m0), "v"(p1));
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, 0, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "=&v"(hi), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[1]), "v"(a.v[1]), "v"(b.v[0]), "v"(m0), "v"(p1));
     lo = (uint32_t)acc; mid = (uint32_t)(acc >> 32); m1 = 0u - lo;
     mb_fold_shift(acc, hi, lo, mid);                          // + m_k * p0 (low word -> 0), then >> 32
     // column 2: 5 products
-    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
-        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[2]), "v"(a.v[1]), "v"(b.v[1]), "v"(a.v[2]), "v"(b.v[0]), "v"(m0), "v"(p2), "v"(m1), "v"(p1));
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, 0, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "=&v"(hi), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[2]), "v"(a.v[1]), "v"(b.v[1]), "v"(a.v[2]), "v"(b.v[0]), "v"(m0), "v"(p2), "v"(m1), "v"(p1));
     lo = (uint32_t)acc; mid = (uint32_t)(acc >> 32); m2 = 0u - lo;
     mb_fold_shift(acc, hi, lo, mid);                          // + m_k * p0 (low word -> 0), then >> 32
     // column 3: 7 products
-    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
-        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[3]), "v"(a.v[1]), "v"(b.v[2]), "v"(a.v[2]), "v"(b.v[1]), "v"(a.v[3]), "v"(b.v[0]), "v"(m0), "v"(p3), "v"(m1), "v"(p2), "v"(m2), "v"(p1));
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, 0, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "=&v"(hi), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[3]), "v"(a.v[1]), "v"(b.v[2]), "v"(a.v[2]), "v"(b.v[1]), "v"(a.v[3]), "v"(b.v[0]), "v"(m0), "v"(p3), "v"(m1), "v"(p2), "v"(m2), "v"(p1));
     lo = (uint32_t)acc; mid = (uint32_t)(acc >> 32); m3 = 0u - lo;
     mb_fold_shift(acc, hi, lo, mid);                          // + m_k * p0 (low word -> 0), then >> 32
     // column 4: 8 products
-    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
-        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[4]), "v"(a.v[1]), "v"(b.v[3]), "v"(a.v[2]), "v"(b.v[2]), "v"(a.v[3]), "v"(b.v[1]), "v"(a.v[4]), "v"(b.v[0]), "v"(m1), "v"(p3), "v"(m2), "v"(p2), "v"(m3), "v"(p1));
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, 0, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "=&v"(hi), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[4]), "v"(a.v[1]), "v"(b.v[3]), "v"(a.v[2]), "v"(b.v[2]), "v"(a.v[3]), "v"(b.v[1]), "v"(a.v[4]), "v"(b.v[0]), "v"(m1), "v"(p3), "v"(m2), "v"(p2), "v"(m3), "v"(p1));
     lo = (uint32_t)acc; mid = (uint32_t)(acc >> 32); m4 = 0u - lo;
     mb_fold_shift(acc, hi, lo, mid);                          // + m_k * p0 (low word -> 0), then >> 32
     // column 5: 9 products
-    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
-        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[5]), "v"(a.v[1]), "v"(b.v[4]), "v"(a.v[2]), "v"(b.v[3]), "v"(a.v[3]), "v"(b.v[2]), "v"(a.v[4]), "v"(b.v[1]), "v"(a.v[5]), "v"(b.v[0]), "v"(m2), "v"(p3), "v"(m3), "v"(p2), "v"(m4), "v"(p1));
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, 0, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "=&v"(hi), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[5]), "v"(a.v[1]), "v"(b.v[4]), "v"(a.v[2]), "v"(b.v[3]), "v"(a.v[3]), "v"(b.v[2]), "v"(a.v[4]), "v"(b.v[1]), "v"(a.v[5]), "v"(b.v[0]), "v"(m2), "v"(p3), "v"(m3), "v"(p2), "v"(m4), "v"(p1));
     lo = (uint32_t)acc; mid = (uint32_t)(acc >> 32); m5 = 0u - lo;
     mb_fold_shift(acc, hi, lo, mid);                          // + m_k * p0 (low word -> 0), then >> 32
     // column 6: 10 products
-    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
-        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[6]), "v"(a.v[1]), "v"(b.v[5]), "v"(a.v[2]), "v"(b.v[4]), "v"(a.v[3]), "v"(b.v[3]), "v"(a.v[4]), "v"(b.v[2]), "v"(a.v[5]), "v"(b.v[1]), "v"(a.v[6]), "v"(b.v[0]), "v"(m3), "v"(p3), "v"(m4), "v"(p2), "v"(m5), "v"(p1));
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, 0, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "=&v"(hi), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[6]), "v"(a.v[1]), "v"(b.v[5]), "v"(a.v[2]), "v"(b.v[4]), "v"(a.v[3]), "v"(b.v[3]), "v"(a.v[4]), "v"(b.v[2]), "v"(a.v[5]), "v"(b.v[1]), "v"(a.v[6]), "v"(b.v[0]), "v"(m3), "v"(p3), "v"(m4), "v"(p2), "v"(m5), "v"(p1));
     lo = (uint32_t)acc; mid = (uint32_t)(acc >> 32); m6 = 0u - lo;
     mb_fold_shift(acc, hi, lo, mid);                          // + m_k * p0 (low word -> 0), then >> 32
     // column 7: 12 products
-    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %25, %26, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
-        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[7]), "v"(a.v[1]), "v"(b.v[6]), "v"(a.v[2]), "v"(b.v[5]), "v"(a.v[3]), "v"(b.v[4]), "v"(a.v[4]), "v"(b.v[3]), "v"(a.v[5]), "v"(b.v[2]), "v"(a.v[6]), "v"(b.v[1]), "v"(a.v[7]), "v"(b.v[0]), "v"(m0), "v"(p7), "v"(m4), "v"(p3), "v"(m5), "v"(p2), "v"(m6), "v"(p1));
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, 0, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %25, %26, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "=&v"(hi), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[7]), "v"(a.v[1]), "v"(b.v[6]), "v"(a.v[2]), "v"(b.v[5]), "v"(a.v[3]), "v"(b.v[4]), "v"(a.v[4]), "v"(b.v[3]), "v"(a.v[5]), "v"(b.v[2]), "v"(a.v[6]), "v"(b.v[1]), "v"(a.v[7]), "v"(b.v[0]), "v"(m0), "v"(p7), "v"(m4), "v"(p3), "v"(m5), "v"(p2), "v"(m6), "v"(p1));
     lo = (uint32_t)acc; mid = (uint32_t)(acc >> 32); m7 = 0u - lo;
     mb_fold_shift(acc, hi, lo, mid);                          // + m_k * p0 (low word -> 0), then >> 32
     // column 8: 11 products
-    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
-        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a.v[1]), "v"(b.v[7]), "v"(a.v[2]), "v"(b.v[6]), "v"(a.v[3]), "v"(b.v[5]), "v"(a.v[4]), "v"(b.v[4]), "v"(a.v[5]), "v"(b.v[3]), "v"(a.v[6]), "v"(b.v[2]), "v"(a.v[7]), "v"(b.v[1]), "v"(m1), "v"(p7), "v"(m5), "v"(p3), "v"(m6), "v"(p2), "v"(m7), "v"(p1));
-    r.v[0] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, 0, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "=&v"(hi), "=&s"(cc) : "v"(a.v[1]), "v"(b.v[7]), "v"(a.v[2]), "v"(b.v[6]), "v"(a.v[3]), "v"(b.v[5]), "v"(a.v[4]), "v"(b.v[4]), "v"(a.v[5]), "v"(b.v[3]), "v"(a.v[6]), "v"(b.v[2]), "v"(a.v[7]), "v"(b.v[1]), "v"(m1), "v"(p7), "v"(m5), "v"(p3), "v"(m6), "v"(p2), "v"(m7), "v"(p1));
+    r.v[0] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32);
     // column 9: 9 products
-    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
-        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a.v[2]), "v"(b.v[7]), "v"(a.v[3]), "v"(b.v[6]), "v"(a.v[4]), "v"(b.v[5]), "v"(a.v[5]), "v"(b.v[4]), "v"(a.v[6]), "v"(b.v[3]), "v"(a.v[7]), "v"(b.v[2]), "v"(m2), "v"(p7), "v"(m6), "v"(p3), "v"(m7), "v"(p2));
-    r.v[1] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, 0, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "=&v"(hi), "=&s"(cc) : "v"(a.v[2]), "v"(b.v[7]), "v"(a.v[3]), "v"(b.v[6]), "v"(a.v[4]), "v"(b.v[5]), "v"(a.v[5]), "v"(b.v[4]), "v"(a.v[6]), "v"(b.v[3]), "v"(a.v[7]), "v"(b.v[2]), "v"(m2), "v"(p7), "v"(m6), "v"(p3), "v"(m7), "v"(p2));
+    r.v[1] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32);
     // column 10: 7 products
-    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
-        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a.v[3]), "v"(b.v[7]), "v"(a.v[4]), "v"(b.v[6]), "v"(a.v[5]), "v"(b.v[5]), "v"(a.v[6]), "v"(b.v[4]), "v"(a.v[7]), "v"(b.v[3]), "v"(m3), "v"(p7), "v"(m7), "v"(p3));
-    r.v[2] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, 0, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "=&v"(hi), "=&s"(cc) : "v"(a.v[3]), "v"(b.v[7]), "v"(a.v[4]), "v"(b.v[6]), "v"(a.v[5]), "v"(b.v[5]), "v"(a.v[6]), "v"(b.v[4]), "v"(a.v[7]), "v"(b.v[3]), "v"(m3), "v"(p7), "v"(m7), "v"(p3));
+    r.v[2] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32);
     // column 11: 5 products
-    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
-        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a.v[4]), "v"(b.v[7]), "v"(a.v[5]), "v"(b.v[6]), "v"(a.v[6]), "v"(b.v[5]), "v"(a.v[7]), "v"(b.v[4]), "v"(m4), "v"(p7));
-    r.v[3] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, 0, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "=&v"(hi), "=&s"(cc) : "v"(a.v[4]), "v"(b.v[7]), "v"(a.v[5]), "v"(b.v[6]), "v"(a.v[6]), "v"(b.v[5]), "v"(a.v[7]), "v"(b.v[4]), "v"(m4), "v"(p7));
+    r.v[3] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32);
     // column 12: 4 products
-    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
-        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a.v[5]), "v"(b.v[7]), "v"(a.v[6]), "v"(b.v[6]), "v"(a.v[7]), "v"(b.v[5]), "v"(m5), "v"(p7));
-    r.v[4] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, 0, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "=&v"(hi), "=&s"(cc) : "v"(a.v[5]), "v"(b.v[7]), "v"(a.v[6]), "v"(b.v[6]), "v"(a.v[7]), "v"(b.v[5]), "v"(m5), "v"(p7));
+    r.v[4] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32);
     // column 13: 3 products
-    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
-        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a.v[6]), "v"(b.v[7]), "v"(a.v[7]), "v"(b.v[6]), "v"(m6), "v"(p7));
-    r.v[5] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, 0, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "=&v"(hi), "=&s"(cc) : "v"(a.v[6]), "v"(b.v[7]), "v"(a.v[7]), "v"(b.v[6]), "v"(m6), "v"(p7));
+    r.v[5] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32);
     // column 14: 2 products
-    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
-        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a.v[7]), "v"(b.v[7]), "v"(m7), "v"(p7));
-    r.v[6] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, 0, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "=&v"(hi), "=&s"(cc) : "v"(a.v[7]), "v"(b.v[7]), "v"(m7), "v"(p7));
+    r.v[6] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32);
     r.v[7] = (uint32_t)acc;                                       // result < 2p < 2^256
     return RED ? fe_cond_sub_p<F>(r) : r;                 // RED = false: result < sum(a_i b_i) / 2^256 + p, left to the caller
 }
 template <int F, bool RED = true> __device__ __forceinline__ fe_t fe_dot2_device(const fe_t &a0, const fe_t &b0, const fe_t &a1, const fe_t &b1) {
     // generated by tools/gen_fe_mul.py -- product scanning, one Montgomery reduction
-    uint64_t acc = 0, cc; uint32_t hi = 0, lo, mid; fe_t r;
+    uint64_t acc = 0, cc; uint32_t hi, lo, mid; fe_t r;
     uint32_t m0, m1, m2, m3, m4, m5, m6, m7;
     const uint32_t p1 = FieldP<F>::P1, p2 = FieldP<F>::P2, p3 = FieldP<F>::P3, p7 = P7;
     // column 0: 2 products
-    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
-        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[0]));
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, 0, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "=&v"(hi), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[0]));
     lo = (uint32_t)acc; mid = (uint32_t)(acc >> 32); m0 = 0u - lo;
     mb_fold_shift(acc, hi, lo, mid);                          // + m_k * p0 (low word -> 0), then >> 32
     // column 1: 5 products
-    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
-        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[1]), "v"(a0.v[1]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[1]), "v"(a1.v[1]), "v"(b1.v[0]), "v"(m0), "v"(p1));
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, 0, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "=&v"(hi), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[1]), "v"(a0.v[1]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[1]), "v"(a1.v[1]), "v"(b1.v[0]), "v"(m0), "v"(p1));
     lo = (uint32_t)acc; mid = (uint32_t)(acc >> 32); m1 = 0u - lo;
     mb_fold_shift(acc, hi, lo, mid);                          // + m_k * p0 (low word -> 0), then >> 32
     // column 2: 8 products
-    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
-        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[2]), "v"(a0.v[1]), "v"(b0.v[1]), "v"(a0.v[2]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[2]), "v"(a1.v[1]), "v"(b1.v[1]), "v"(a1.v[2]), "v"(b1.v[0]), "v"(m0), "v"(p2), "v"(m1), "v"(p1));
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, 0, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "=&v"(hi), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[2]), "v"(a0.v[1]), "v"(b0.v[1]), "v"(a0.v[2]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[2]), "v"(a1.v[1]), "v"(b1.v[1]), "v"(a1.v[2]), "v"(b1.v[0]), "v"(m0), "v"(p2), "v"(m1), "v"(p1));
     lo = (uint32_t)acc; mid = (uint32_t)(acc >> 32); m2 = 0u - lo;
     mb_fold_shift(acc, hi, lo, mid);                          // + m_k * p0 (low word -> 0), then >> 32
     // column 3: 11 products
-    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
-        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[3]), "v"(a0.v[1]), "v"(b0.v[2]), "v"(a0.v[2]), "v"(b0.v[1]), "v"(a0.v[3]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[3]), "v"(a1.v[1]), "v"(b1.v[2]), "v"(a1.v[2]), "v"(b1.v[1]), "v"(a1.v[3]), "v"(b1.v[0]), "v"(m0), "v"(p3), "v"(m1), "v"(p2), "v"(m2), "v"(p1));
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, 0, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "=&v"(hi), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[3]), "v"(a0.v[1]), "v"(b0.v[2]), "v"(a0.v[2]), "v"(b0.v[1]), "v"(a0.v[3]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[3]), "v"(a1.v[1]), "v"(b1.v[2]), "v"(a1.v[2]), "v"(b1.v[1]), "v"(a1.v[3]), "v"(b1.v[0]), "v"(m0), "v"(p3), "v"(m1), "v"(p2), "v"(m2), "v"(p1));
     lo = (uint32_t)acc; mid = (uint32_t)(acc >> 32); m3 = 0u - lo;
     mb_fold_shift(acc, hi, lo, mid);                          // + m_k * p0 (low word -> 0), then >> 32
     // column 4: 13 products
-    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %25, %26, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
-        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[4]), "v"(a0.v[1]), "v"(b0.v[3]), "v"(a0.v[2]), "v"(b0.v[2]), "v"(a0.v[3]), "v"(b0.v[1]), "v"(a0.v[4]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[4]), "v"(a1.v[1]), "v"(b1.v[3]), "v"(a1.v[2]), "v"(b1.v[2]), "v"(a1.v[3]), "v"(b1.v[1]), "v"(a1.v[4]), "v"(b1.v[0]), "v"(m1), "v"(p3), "v"(m2), "v"(p2));
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, 0, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %25, %26, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "=&v"(hi), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[4]), "v"(a0.v[1]), "v"(b0.v[3]), "v"(a0.v[2]), "v"(b0.v[2]), "v"(a0.v[3]), "v"(b0.v[1]), "v"(a0.v[4]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[4]), "v"(a1.v[1]), "v"(b1.v[3]), "v"(a1.v[2]), "v"(b1.v[2]), "v"(a1.v[3]), "v"(b1.v[1]), "v"(a1.v[4]), "v"(b1.v[0]), "v"(m1), "v"(p3), "v"(m2), "v"(p2));
     asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
         : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(m3), "v"(p1));
     lo = (uint32_t)acc; mid = (uint32_t)(acc >> 32); m4 = 0u - lo;
     mb_fold_shift(acc, hi, lo, mid);                          // + m_k * p0 (low word -> 0), then >> 32
     // column 5: 15 products
-    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %25, %26, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
-        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[5]), "v"(a0.v[1]), "v"(b0.v[4]), "v"(a0.v[2]), "v"(b0.v[3]), "v"(a0.v[3]), "v"(b0.v[2]), "v"(a0.v[4]), "v"(b0.v[1]), "v"(a0.v[5]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[5]), "v"(a1.v[1]), "v"(b1.v[4]), "v"(a1.v[2]), "v"(b1.v[3]), "v"(a1.v[3]), "v"(b1.v[2]), "v"(a1.v[4]), "v"(b1.v[1]), "v"(a1.v[5]), "v"(b1.v[0]));
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, 0, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %25, %26, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "=&v"(hi), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[5]), "v"(a0.v[1]), "v"(b0.v[4]), "v"(a0.v[2]), "v"(b0.v[3]), "v"(a0.v[3]), "v"(b0.v[2]), "v"(a0.v[4]), "v"(b0.v[1]), "v"(a0.v[5]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[5]), "v"(a1.v[1]), "v"(b1.v[4]), "v"(a1.v[2]), "v"(b1.v[3]), "v"(a1.v[3]), "v"(b1.v[2]), "v"(a1.v[4]), "v"(b1.v[1]), "v"(a1.v[5]), "v"(b1.v[0]));
     asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
         : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(m2), "v"(p3), "v"(m3), "v"(p2), "v"(m4), "v"(p1));
     lo = (uint32_t)acc; mid = (uint32_t)(acc >> 32); m5 = 0u - lo;
     mb_fold_shift(acc, hi, lo, mid);                          // + m_k * p0 (low word -> 0), then >> 32
     // column 6: 17 products
-    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %25, %26, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
-        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[6]), "v"(a0.v[1]), "v"(b0.v[5]), "v"(a0.v[2]), "v"(b0.v[4]), "v"(a0.v[3]), "v"(b0.v[3]), "v"(a0.v[4]), "v"(b0.v[2]), "v"(a0.v[5]), "v"(b0.v[1]), "v"(a0.v[6]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[6]), "v"(a1.v[1]), "v"(b1.v[5]), "v"(a1.v[2]), "v"(b1.v[4]), "v"(a1.v[3]), "v"(b1.v[3]), "v"(a1.v[4]), "v"(b1.v[2]));
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, 0, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %25, %26, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "=&v"(hi), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[6]), "v"(a0.v[1]), "v"(b0.v[5]), "v"(a0.v[2]), "v"(b0.v[4]), "v"(a0.v[3]), "v"(b0.v[3]), "v"(a0.v[4]), "v"(b0.v[2]), "v"(a0.v[5]), "v"(b0.v[1]), "v"(a0.v[6]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[6]), "v"(a1.v[1]), "v"(b1.v[5]), "v"(a1.v[2]), "v"(b1.v[4]), "v"(a1.v[3]), "v"(b1.v[3]), "v"(a1.v[4]), "v"(b1.v[2]));
     asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
         : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a1.v[5]), "v"(b1.v[1]), "v"(a1.v[6]), "v"(b1.v[0]), "v"(m3), "v"(p3), "v"(m4), "v"(p2), "v"(m5), "v"(p1));
     lo = (uint32_t)acc; mid = (uint32_t)(acc >> 32); m6 = 0u - lo;
     mb_fold_shift(acc, hi, lo, mid);                          // + m_k * p0 (low word -> 0), then >> 32
     // column 7: 20 products
-    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %25, %26, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
-        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[7]), "v"(a0.v[1]), "v"(b0.v[6]), "v"(a0.v[2]), "v"(b0.v[5]), "v"(a0.v[3]), "v"(b0.v[4]), "v"(a0.v[4]), "v"(b0.v[3]), "v"(a0.v[5]), "v"(b0.v[2]), "v"(a0.v[6]), "v"(b0.v[1]), "v"(a0.v[7]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[7]), "v"(a1.v[1]), "v"(b1.v[6]), "v"(a1.v[2]), "v"(b1.v[5]), "v"(a1.v[3]), "v"(b1.v[4]));
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, 0, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %25, %26, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "=&v"(hi), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[7]), "v"(a0.v[1]), "v"(b0.v[6]), "v"(a0.v[2]), "v"(b0.v[5]), "v"(a0.v[3]), "v"(b0.v[4]), "v"(a0.v[4]), "v"(b0.v[3]), "v"(a0.v[5]), "v"(b0.v[2]), "v"(a0.v[6]), "v"(b0.v[1]), "v"(a0.v[7]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[7]), "v"(a1.v[1]), "v"(b1.v[6]), "v"(a1.v[2]), "v"(b1.v[5]), "v"(a1.v[3]), "v"(b1.v[4]));
     asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
         : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a1.v[4]), "v"(b1.v[3]), "v"(a1.v[5]), "v"(b1.v[2]), "v"(a1.v[6]), "v"(b1.v[1]), "v"(a1.v[7]), "v"(b1.v[0]), "v"(m0), "v"(p7), "v"(m4), "v"(p3), "v"(m5), "v"(p2), "v"(m6), "v"(p1));
     lo = (uint32_t)acc; mid = (uint32_t)(acc >> 32); m7 = 0u - lo;
     mb_fold_shift(acc, hi, lo, mid);                          // + m_k * p0 (low word -> 0), then >> 32
     // column 8: 18 products
-    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %25, %26, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
-        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[1]), "v"(b0.v[7]), "v"(a0.v[2]), "v"(b0.v[6]), "v"(a0.v[3]), "v"(b0.v[5]), "v"(a0.v[4]), "v"(b0.v[4]), "v"(a0.v[5]), "v"(b0.v[3]), "v"(a0.v[6]), "v"(b0.v[2]), "v"(a0.v[7]), "v"(b0.v[1]), "v"(a1.v[1]), "v"(b1.v[7]), "v"(a1.v[2]), "v"(b1.v[6]), "v"(a1.v[3]), "v"(b1.v[5]), "v"(a1.v[4]), "v"(b1.v[4]), "v"(a1.v[5]), "v"(b1.v[3]));
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, 0, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %25, %26, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "=&v"(hi), "=&s"(cc) : "v"(a0.v[1]), "v"(b0.v[7]), "v"(a0.v[2]), "v"(b0.v[6]), "v"(a0.v[3]), "v"(b0.v[5]), "v"(a0.v[4]), "v"(b0.v[4]), "v"(a0.v[5]), "v"(b0.v[3]), "v"(a0.v[6]), "v"(b0.v[2]), "v"(a0.v[7]), "v"(b0.v[1]), "v"(a1.v[1]), "v"(b1.v[7]), "v"(a1.v[2]), "v"(b1.v[6]), "v"(a1.v[3]), "v"(b1.v[5]), "v"(a1.v[4]), "v"(b1.v[4]), "v"(a1.v[5]), "v"(b1.v[3]));
     asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
         : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a1.v[6]), "v"(b1.v[2]), "v"(a1.v[7]), "v"(b1.v[1]), "v"(m1), "v"(p7), "v"(m5), "v"(p3), "v"(m6), "v"(p2), "v"(m7), "v"(p1));
-    r.v[0] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
+    r.v[0] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32);
     // column 9: 15 products
-    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %25, %26, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
-        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[2]), "v"(b0.v[7]), "v"(a0.v[3]), "v"(b0.v[6]), "v"(a0.v[4]), "v"(b0.v[5]), "v"(a0.v[5]), "v"(b0.v[4]), "v"(a0.v[6]), "v"(b0.v[3]), "v"(a0.v[7]), "v"(b0.v[2]), "v"(a1.v[2]), "v"(b1.v[7]), "v"(a1.v[3]), "v"(b1.v[6]), "v"(a1.v[4]), "v"(b1.v[5]), "v"(a1.v[5]), "v"(b1.v[4]), "v"(a1.v[6]), "v"(b1.v[3]), "v"(a1.v[7]), "v"(b1.v[2]));
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, 0, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %25, %26, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "=&v"(hi), "=&s"(cc) : "v"(a0.v[2]), "v"(b0.v[7]), "v"(a0.v[3]), "v"(b0.v[6]), "v"(a0.v[4]), "v"(b0.v[5]), "v"(a0.v[5]), "v"(b0.v[4]), "v"(a0.v[6]), "v"(b0.v[3]), "v"(a0.v[7]), "v"(b0.v[2]), "v"(a1.v[2]), "v"(b1.v[7]), "v"(a1.v[3]), "v"(b1.v[6]), "v"(a1.v[4]), "v"(b1.v[5]), "v"(a1.v[5]), "v"(b1.v[4]), "v"(a1.v[6]), "v"(b1.v[3]), "v"(a1.v[7]), "v"(b1.v[2]));
     asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
         : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(m2), "v"(p7), "v"(m6), "v"(p3), "v"(m7), "v"(p2));
-    r.v[1] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
+    r.v[1] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32);
     // column 10: 12 products
-    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %25, %26, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
-        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[3]), "v"(b0.v[7]), "v"(a0.v[4]), "v"(b0.v[6]), "v"(a0.v[5]), "v"(b0.v[5]), "v"(a0.v[6]), "v"(b0.v[4]), "v"(a0.v[7]), "v"(b0.v[3]), "v"(a1.v[3]), "v"(b1.v[7]), "v"(a1.v[4]), "v"(b1.v[6]), "v"(a1.v[5]), "v"(b1.v[5]), "v"(a1.v[6]), "v"(b1.v[4]), "v"(a1.v[7]), "v"(b1.v[3]), "v"(m3), "v"(p7), "v"(m7), "v"(p3));
-    r.v[2] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, 0, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %25, %26, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "=&v"(hi), "=&s"(cc) : "v"(a0.v[3]), "v"(b0.v[7]), "v"(a0.v[4]), "v"(b0.v[6]), "v"(a0.v[5]), "v"(b0.v[5]), "v"(a0.v[6]), "v"(b0.v[4]), "v"(a0.v[7]), "v"(b0.v[3]), "v"(a1.v[3]), "v"(b1.v[7]), "v"(a1.v[4]), "v"(b1.v[6]), "v"(a1.v[5]), "v"(b1.v[5]), "v"(a1.v[6]), "v"(b1.v[4]), "v"(a1.v[7]), "v"(b1.v[3]), "v"(m3), "v"(p7), "v"(m7), "v"(p3));
+    r.v[2] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32);
     // column 11: 9 products
-    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
-        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[4]), "v"(b0.v[7]), "v"(a0.v[5]), "v"(b0.v[6]), "v"(a0.v[6]), "v"(b0.v[5]), "v"(a0.v[7]), "v"(b0.v[4]), "v"(a1.v[4]), "v"(b1.v[7]), "v"(a1.v[5]), "v"(b1.v[6]), "v"(a1.v[6]), "v"(b1.v[5]), "v"(a1.v[7]), "v"(b1.v[4]), "v"(m4), "v"(p7));
-    r.v[3] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, 0, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "=&v"(hi), "=&s"(cc) : "v"(a0.v[4]), "v"(b0.v[7]), "v"(a0.v[5]), "v"(b0.v[6]), "v"(a0.v[6]), "v"(b0.v[5]), "v"(a0.v[7]), "v"(b0.v[4]), "v"(a1.v[4]), "v"(b1.v[7]), "v"(a1.v[5]), "v"(b1.v[6]), "v"(a1.v[6]), "v"(b1.v[5]), "v"(a1.v[7]), "v"(b1.v[4]), "v"(m4), "v"(p7));
+    r.v[3] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32);
     // column 12: 7 products
-    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
-        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[5]), "v"(b0.v[7]), "v"(a0.v[6]), "v"(b0.v[6]), "v"(a0.v[7]), "v"(b0.v[5]), "v"(a1.v[5]), "v"(b1.v[7]), "v"(a1.v[6]), "v"(b1.v[6]), "v"(a1.v[7]), "v"(b1.v[5]), "v"(m5), "v"(p7));
-    r.v[4] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, 0, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "=&v"(hi), "=&s"(cc) : "v"(a0.v[5]), "v"(b0.v[7]), "v"(a0.v[6]), "v"(b0.v[6]), "v"(a0.v[7]), "v"(b0.v[5]), "v"(a1.v[5]), "v"(b1.v[7]), "v"(a1.v[6]), "v"(b1.v[6]), "v"(a1.v[7]), "v"(b1.v[5]), "v"(m5), "v"(p7));
+    r.v[4] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32);
     // column 13: 5 products
-    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
-        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[6]), "v"(b0.v[7]), "v"(a0.v[7]), "v"(b0.v[6]), "v"(a1.v[6]), "v"(b1.v[7]), "v"(a1.v[7]), "v"(b1.v[6]), "v"(m6), "v"(p7));
-    r.v[5] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, 0, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "=&v"(hi), "=&s"(cc) : "v"(a0.v[6]), "v"(b0.v[7]), "v"(a0.v[7]), "v"(b0.v[6]), "v"(a1.v[6]), "v"(b1.v[7]), "v"(a1.v[7]), "v"(b1.v[6]), "v"(m6), "v"(p7));
+    r.v[5] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32);
     // column 14: 3 products
-    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
-        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[7]), "v"(b0.v[7]), "v"(a1.v[7]), "v"(b1.v[7]), "v"(m7), "v"(p7));
-    r.v[6] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, 0, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "=&v"(hi), "=&s"(cc) : "v"(a0.v[7]), "v"(b0.v[7]), "v"(a1.v[7]), "v"(b1.v[7]), "v"(m7), "v"(p7));
+    r.v[6] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32);
     r.v[7] = (uint32_t)acc;                                       // result < 2p < 2^256
     return RED ? fe_cond_sub_p<F>(r) : r;                 // RED = false: result < sum(a_i b_i) / 2^256 + p, left to the caller
 }
 template <int F, bool RED = true> __device__ __forceinline__ fe_t fe_dot3_device(const fe_t &a0, const fe_t &b0, const fe_t &a1, const fe_t &b1, const fe_t &a2, const fe_t &b2) {
     // generated by tools/gen_fe_mul.py -- product scanning, one Montgomery reduction
-    uint64_t acc = 0, cc; uint32_t hi = 0, lo, mid; fe_t r;
+    uint64_t acc = 0, cc; uint32_t hi, lo, mid; fe_t r;
     uint32_t m0, m1, m2, m3, m4, m5, m6, m7;
     const uint32_t p1 = FieldP<F>::P1, p2 = FieldP<F>::P2, p3 = FieldP<F>::P3, p7 = P7;
     // column 0: 3 products
-    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
-        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[0]), "v"(a2.v[0]), "v"(b2.v[0]));
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, 0, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "=&v"(hi), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[0]), "v"(a2.v[0]), "v"(b2.v[0]));
     lo = (uint32_t)acc; mid = (uint32_t)(acc >> 32); m0 = 0u - lo;
     mb_fold_shift(acc, hi, lo, mid);                          // + m_k * p0 (low word -> 0), then >> 32
     // column 1: 7 products
-    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
-        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[1]), "v"(a0.v[1]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[1]), "v"(a1.v[1]), "v"(b1.v[0]), "v"(a2.v[0]), "v"(b2.v[1]), "v"(a2.v[1]), "v"(b2.v[0]), "v"(m0), "v"(p1));
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, 0, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "=&v"(hi), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[1]), "v"(a0.v[1]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[1]), "v"(a1.v[1]), "v"(b1.v[0]), "v"(a2.v[0]), "v"(b2.v[1]), "v"(a2.v[1]), "v"(b2.v[0]), "v"(m0), "v"(p1));
     lo = (uint32_t)acc; mid = (uint32_t)(acc >> 32); m1 = 0u - lo;
     mb_fold_shift(acc, hi, lo, mid);                          // + m_k * p0 (low word -> 0), then >> 32
     // column 2: 11 products
-    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
-        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[2]), "v"(a0.v[1]), "v"(b0.v[1]), "v"(a0.v[2]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[2]), "v"(a1.v[1]), "v"(b1.v[1]), "v"(a1.v[2]), "v"(b1.v[0]), "v"(a2.v[0]), "v"(b2.v[2]), "v"(a2.v[1]), "v"(b2.v[1]), "v"(a2.v[2]), "v"(b2.v[0]), "v"(m0), "v"(p2), "v"(m1), "v"(p1));
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, 0, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "=&v"(hi), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[2]), "v"(a0.v[1]), "v"(b0.v[1]), "v"(a0.v[2]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[2]), "v"(a1.v[1]), "v"(b1.v[1]), "v"(a1.v[2]), "v"(b1.v[0]), "v"(a2.v[0]), "v"(b2.v[2]), "v"(a2.v[1]), "v"(b2.v[1]), "v"(a2.v[2]), "v"(b2.v[0]), "v"(m0), "v"(p2), "v"(m1), "v"(p1));
     lo = (uint32_t)acc; mid = (uint32_t)(acc >> 32); m2 = 0u - lo;
     mb_fold_shift(acc, hi, lo, mid);                          // + m_k * p0 (low word -> 0), then >> 32
     // column 3: 15 products
-    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %25, %26, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
-        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[3]), "v"(a0.v[1]), "v"(b0.v[2]), "v"(a0.v[2]), "v"(b0.v[1]), "v"(a0.v[3]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[3]), "v"(a1.v[1]), "v"(b1.v[2]), "v"(a1.v[2]), "v"(b1.v[1]), "v"(a1.v[3]), "v"(b1.v[0]), "v"(a2.v[0]), "v"(b2.v[3]), "v"(a2.v[1]), "v"(b2.v[2]), "v"(a2.v[2]), "v"(b2.v[1]), "v"(a2.v[3]), "v"(b2.v[0]));
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, 0, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %25, %26, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "=&v"(hi), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[3]), "v"(a0.v[1]), "v"(b0.v[2]), "v"(a0.v[2]), "v"(b0.v[1]), "v"(a0.v[3]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[3]), "v"(a1.v[1]), "v"(b1.v[2]), "v"(a1.v[2]), "v"(b1.v[1]), "v"(a1.v[3]), "v"(b1.v[0]), "v"(a2.v[0]), "v"(b2.v[3]), "v"(a2.v[1]), "v"(b2.v[2]), "v"(a2.v[2]), "v"(b2.v[1]), "v"(a2.v[3]), "v"(b2.v[0]));
     asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
         : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(m0), "v"(p3), "v"(m1), "v"(p2), "v"(m2), "v"(p1));
     lo = (uint32_t)acc; mid = (uint32_t)(acc >> 32); m3 = 0u - lo;
     mb_fold_shift(acc, hi, lo, mid);                          // + m_k * p0 (low word -> 0), then >> 32
     // column 4: 18 products
-    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %25, %26, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
-        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[4]), "v"(a0.v[1]), "v"(b0.v[3]), "v"(a0.v[2]), "v"(b0.v[2]), "v"(a0.v[3]), "v"(b0.v[1]), "v"(a0.v[4]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[4]), "v"(a1.v[1]), "v"(b1.v[3]), "v"(a1.v[2]), "v"(b1.v[2]), "v"(a1.v[3]), "v"(b1.v[1]), "v"(a1.v[4]), "v"(b1.v[0]), "v"(a2.v[0]), "v"(b2.v[4]), "v"(a2.v[1]), "v"(b2.v[3]));
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, 0, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %25, %26, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "=&v"(hi), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[4]), "v"(a0.v[1]), "v"(b0.v[3]), "v"(a0.v[2]), "v"(b0.v[2]), "v"(a0.v[3]), "v"(b0.v[1]), "v"(a0.v[4]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[4]), "v"(a1.v[1]), "v"(b1.v[3]), "v"(a1.v[2]), "v"(b1.v[2]), "v"(a1.v[3]), "v"(b1.v[1]), "v"(a1.v[4]), "v"(b1.v[0]), "v"(a2.v[0]), "v"(b2.v[4]), "v"(a2.v[1]), "v"(b2.v[3]));
     asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
         : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a2.v[2]), "v"(b2.v[2]), "v"(a2.v[3]), "v"(b2.v[1]), "v"(a2.v[4]), "v"(b2.v[0]), "v"(m1), "v"(p3), "v"(m2), "v"(p2), "v"(m3), "v"(p1));
     lo = (uint32_t)acc; mid = (uint32_t)(acc >> 32); m4 = 0u - lo;
     mb_fold_shift(acc, hi, lo, mid);                          // + m_k * p0 (low word -> 0), then >> 32
     // column 5: 21 products
-    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %25, %26, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
-        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[5]), "v"(a0.v[1]), "v"(b0.v[4]), "v"(a0.v[2]), "v"(b0.v[3]), "v"(a0.v[3]), "v"(b0.v[2]), "v"(a0.v[4]), "v"(b0.v[1]), "v"(a0.v[5]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[5]), "v"(a1.v[1]), "v"(b1.v[4]), "v"(a1.v[2]), "v"(b1.v[3]), "v"(a1.v[3]), "v"(b1.v[2]), "v"(a1.v[4]), "v"(b1.v[1]), "v"(a1.v[5]), "v"(b1.v[0]));
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, 0, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %25, %26, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "=&v"(hi), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[5]), "v"(a0.v[1]), "v"(b0.v[4]), "v"(a0.v[2]), "v"(b0.v[3]), "v"(a0.v[3]), "v"(b0.v[2]), "v"(a0.v[4]), "v"(b0.v[1]), "v"(a0.v[5]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[5]), "v"(a1.v[1]), "v"(b1.v[4]), "v"(a1.v[2]), "v"(b1.v[3]), "v"(a1.v[3]), "v"(b1.v[2]), "v"(a1.v[4]), "v"(b1.v[1]), "v"(a1.v[5]), "v"(b1.v[0]));
     asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
         : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a2.v[0]), "v"(b2.v[5]), "v"(a2.v[1]), "v"(b2.v[4]), "v"(a2.v[2]), "v"(b2.v[3]), "v"(a2.v[3]), "v"(b2.v[2]), "v"(a2.v[4]), "v"(b2.v[1]), "v"(a2.v[5]), "v"(b2.v[0]), "v"(m2), "v"(p3), "v"(m3), "v"(p2), "v"(m4), "v"(p1));
     lo = (uint32_t)acc; mid = (uint32_t)(acc >> 32); m5 = 0u - lo;
     mb_fold_shift(acc, hi, lo, mid);                          // + m_k * p0 (low word -> 0), then >> 32
     // column 6: 24 products
-    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %25, %26, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
-        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[6]), "v"(a0.v[1]), "v"(b0.v[5]), "v"(a0.v[2]), "v"(b0.v[4]), "v"(a0.v[3]), "v"(b0.v[3]), "v"(a0.v[4]), "v"(b0.v[2]), "v"(a0.v[5]), "v"(b0.v[1]), "v"(a0.v[6]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[6]), "v"(a1.v[1]), "v"(b1.v[5]), "v"(a1.v[2]), "v"(b1.v[4]), "v"(a1.v[3]), "v"(b1.v[3]), "v"(a1.v[4]), "v"(b1.v[2]));
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, 0, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %25, %26, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "=&v"(hi), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[6]), "v"(a0.v[1]), "v"(b0.v[5]), "v"(a0.v[2]), "v"(b0.v[4]), "v"(a0.v[3]), "v"(b0.v[3]), "v"(a0.v[4]), "v"(b0.v[2]), "v"(a0.v[5]), "v"(b0.v[1]), "v"(a0.v[6]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[6]), "v"(a1.v[1]), "v"(b1.v[5]), "v"(a1.v[2]), "v"(b1.v[4]), "v"(a1.v[3]), "v"(b1.v[3]), "v"(a1.v[4]), "v"(b1.v[2]));
     asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %25, %26, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
         : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a1.v[5]), "v"(b1.v[1]), "v"(a1.v[6]), "v"(b1.v[0]), "v"(a2.v[0]), "v"(b2.v[6]), "v"(a2.v[1]), "v"(b2.v[5]), "v"(a2.v[2]), "v"(b2.v[4]), "v"(a2.v[3]), "v"(b2.v[3]), "v"(a2.v[4]), "v"(b2.v[2]), "v"(a2.v[5]), "v"(b2.v[1]), "v"(a2.v[6]), "v"(b2.v[0]), "v"(m3), "v"(p3), "v"(m4), "v"(p2), "v"(m5), "v"(p1));
     lo = (uint32_t)acc; mid = (uint32_t)(acc >> 32); m6 = 0u - lo;
     mb_fold_shift(acc, hi, lo, mid);                          // + m_k * p0 (low word -> 0), then >> 32
     // column 7: 28 products
-    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %25, %26, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
-        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[7]), "v"(a0.v[1]), "v"(b0.v[6]), "v"(a0.v[2]), "v"(b0.v[5]), "v"(a0.v[3]), "v"(b0.v[4]), "v"(a0.v[4]), "v"(b0.v[3]), "v"(a0.v[5]), "v"(b0.v[2]), "v"(a0.v[6]), "v"(b0.v[1]), "v"(a0.v[7]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[7]), "v"(a1.v[1]), "v"(b1.v[6]), "v"(a1.v[2]), "v"(b1.v[5]), "v"(a1.v[3]), "v"(b1.v[4]));
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, 0, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %25, %26, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "=&v"(hi), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[7]), "v"(a0.v[1]), "v"(b0.v[6]), "v"(a0.v[2]), "v"(b0.v[5]), "v"(a0.v[3]), "v"(b0.v[4]), "v"(a0.v[4]), "v"(b0.v[3]), "v"(a0.v[5]), "v"(b0.v[2]), "v"(a0.v[6]), "v"(b0.v[1]), "v"(a0.v[7]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[7]), "v"(a1.v[1]), "v"(b1.v[6]), "v"(a1.v[2]), "v"(b1.v[5]), "v"(a1.v[3]), "v"(b1.v[4]));
     asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %25, %26, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
         : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a1.v[4]), "v"(b1.v[3]), "v"(a1.v[5]), "v"(b1.v[2]), "v"(a1.v[6]), "v"(b1.v[1]), "v"(a1.v[7]), "v"(b1.v[0]), "v"(a2.v[0]), "v"(b2.v[7]), "v"(a2.v[1]), "v"(b2.v[6]), "v"(a2.v[2]), "v"(b2.v[5]), "v"(a2.v[3]), "v"(b2.v[4]), "v"(a2.v[4]), "v"(b2.v[3]), "v"(a2.v[5]), "v"(b2.v[2]), "v"(a2.v[6]), "v"(b2.v[1]), "v"(a2.v[7]), "v"(b2.v[0]));
     asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
@@ -502,43 +503,43 @@ template <int F, bool RED = true> __device__ __forceinline__ fe_t fe_dot3_device
     lo = (uint32_t)acc; mid = (uint32_t)(acc >> 32); m7 = 0u - lo;
     mb_fold_shift(acc, hi, lo, mid);                          // + m_k * p0 (low word -> 0), then >> 32
     // column 8: 25 products
-    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %25, %26, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
-        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[1]), "v"(b0.v[7]), "v"(a0.v[2]), "v"(b0.v[6]), "v"(a0.v[3]), "v"(b0.v[5]), "v"(a0.v[4]), "v"(b0.v[4]), "v"(a0.v[5]), "v"(b0.v[3]), "v"(a0.v[6]), "v"(b0.v[2]), "v"(a0.v[7]), "v"(b0.v[1]), "v"(a1.v[1]), "v"(b1.v[7]), "v"(a1.v[2]), "v"(b1.v[6]), "v"(a1.v[3]), "v"(b1.v[5]), "v"(a1.v[4]), "v"(b1.v[4]), "v"(a1.v[5]), "v"(b1.v[3]));
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, 0, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %25, %26, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "=&v"(hi), "=&s"(cc) : "v"(a0.v[1]), "v"(b0.v[7]), "v"(a0.v[2]), "v"(b0.v[6]), "v"(a0.v[3]), "v"(b0.v[5]), "v"(a0.v[4]), "v"(b0.v[4]), "v"(a0.v[5]), "v"(b0.v[3]), "v"(a0.v[6]), "v"(b0.v[2]), "v"(a0.v[7]), "v"(b0.v[1]), "v"(a1.v[1]), "v"(b1.v[7]), "v"(a1.v[2]), "v"(b1.v[6]), "v"(a1.v[3]), "v"(b1.v[5]), "v"(a1.v[4]), "v"(b1.v[4]), "v"(a1.v[5]), "v"(b1.v[3]));
     asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %25, %26, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
         : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a1.v[6]), "v"(b1.v[2]), "v"(a1.v[7]), "v"(b1.v[1]), "v"(a2.v[1]), "v"(b2.v[7]), "v"(a2.v[2]), "v"(b2.v[6]), "v"(a2.v[3]), "v"(b2.v[5]), "v"(a2.v[4]), "v"(b2.v[4]), "v"(a2.v[5]), "v"(b2.v[3]), "v"(a2.v[6]), "v"(b2.v[2]), "v"(a2.v[7]), "v"(b2.v[1]), "v"(m1), "v"(p7), "v"(m5), "v"(p3), "v"(m6), "v"(p2));
     asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
         : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(m7), "v"(p1));
-    r.v[0] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
+    r.v[0] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32);
     // column 9: 21 products
-    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %25, %26, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
-        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[2]), "v"(b0.v[7]), "v"(a0.v[3]), "v"(b0.v[6]), "v"(a0.v[4]), "v"(b0.v[5]), "v"(a0.v[5]), "v"(b0.v[4]), "v"(a0.v[6]), "v"(b0.v[3]), "v"(a0.v[7]), "v"(b0.v[2]), "v"(a1.v[2]), "v"(b1.v[7]), "v"(a1.v[3]), "v"(b1.v[6]), "v"(a1.v[4]), "v"(b1.v[5]), "v"(a1.v[5]), "v"(b1.v[4]), "v"(a1.v[6]), "v"(b1.v[3]), "v"(a1.v[7]), "v"(b1.v[2]));
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, 0, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %25, %26, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "=&v"(hi), "=&s"(cc) : "v"(a0.v[2]), "v"(b0.v[7]), "v"(a0.v[3]), "v"(b0.v[6]), "v"(a0.v[4]), "v"(b0.v[5]), "v"(a0.v[5]), "v"(b0.v[4]), "v"(a0.v[6]), "v"(b0.v[3]), "v"(a0.v[7]), "v"(b0.v[2]), "v"(a1.v[2]), "v"(b1.v[7]), "v"(a1.v[3]), "v"(b1.v[6]), "v"(a1.v[4]), "v"(b1.v[5]), "v"(a1.v[5]), "v"(b1.v[4]), "v"(a1.v[6]), "v"(b1.v[3]), "v"(a1.v[7]), "v"(b1.v[2]));
     asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
         : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a2.v[2]), "v"(b2.v[7]), "v"(a2.v[3]), "v"(b2.v[6]), "v"(a2.v[4]), "v"(b2.v[5]), "v"(a2.v[5]), "v"(b2.v[4]), "v"(a2.v[6]), "v"(b2.v[3]), "v"(a2.v[7]), "v"(b2.v[2]), "v"(m2), "v"(p7), "v"(m6), "v"(p3), "v"(m7), "v"(p2));
-    r.v[1] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
+    r.v[1] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32);
     // column 10: 17 products
-    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %25, %26, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
-        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[3]), "v"(b0.v[7]), "v"(a0.v[4]), "v"(b0.v[6]), "v"(a0.v[5]), "v"(b0.v[5]), "v"(a0.v[6]), "v"(b0.v[4]), "v"(a0.v[7]), "v"(b0.v[3]), "v"(a1.v[3]), "v"(b1.v[7]), "v"(a1.v[4]), "v"(b1.v[6]), "v"(a1.v[5]), "v"(b1.v[5]), "v"(a1.v[6]), "v"(b1.v[4]), "v"(a1.v[7]), "v"(b1.v[3]), "v"(a2.v[3]), "v"(b2.v[7]), "v"(a2.v[4]), "v"(b2.v[6]));
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, 0, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %25, %26, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "=&v"(hi), "=&s"(cc) : "v"(a0.v[3]), "v"(b0.v[7]), "v"(a0.v[4]), "v"(b0.v[6]), "v"(a0.v[5]), "v"(b0.v[5]), "v"(a0.v[6]), "v"(b0.v[4]), "v"(a0.v[7]), "v"(b0.v[3]), "v"(a1.v[3]), "v"(b1.v[7]), "v"(a1.v[4]), "v"(b1.v[6]), "v"(a1.v[5]), "v"(b1.v[5]), "v"(a1.v[6]), "v"(b1.v[4]), "v"(a1.v[7]), "v"(b1.v[3]), "v"(a2.v[3]), "v"(b2.v[7]), "v"(a2.v[4]), "v"(b2.v[6]));
     asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
         : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a2.v[5]), "v"(b2.v[5]), "v"(a2.v[6]), "v"(b2.v[4]), "v"(a2.v[7]), "v"(b2.v[3]), "v"(m3), "v"(p7), "v"(m7), "v"(p3));
-    r.v[2] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
+    r.v[2] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32);
     // column 11: 13 products
-    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %25, %26, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
-        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[4]), "v"(b0.v[7]), "v"(a0.v[5]), "v"(b0.v[6]), "v"(a0.v[6]), "v"(b0.v[5]), "v"(a0.v[7]), "v"(b0.v[4]), "v"(a1.v[4]), "v"(b1.v[7]), "v"(a1.v[5]), "v"(b1.v[6]), "v"(a1.v[6]), "v"(b1.v[5]), "v"(a1.v[7]), "v"(b1.v[4]), "v"(a2.v[4]), "v"(b2.v[7]), "v"(a2.v[5]), "v"(b2.v[6]), "v"(a2.v[6]), "v"(b2.v[5]), "v"(a2.v[7]), "v"(b2.v[4]));
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, 0, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %23, %24, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %25, %26, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "=&v"(hi), "=&s"(cc) : "v"(a0.v[4]), "v"(b0.v[7]), "v"(a0.v[5]), "v"(b0.v[6]), "v"(a0.v[6]), "v"(b0.v[5]), "v"(a0.v[7]), "v"(b0.v[4]), "v"(a1.v[4]), "v"(b1.v[7]), "v"(a1.v[5]), "v"(b1.v[6]), "v"(a1.v[6]), "v"(b1.v[5]), "v"(a1.v[7]), "v"(b1.v[4]), "v"(a2.v[4]), "v"(b2.v[7]), "v"(a2.v[5]), "v"(b2.v[6]), "v"(a2.v[6]), "v"(b2.v[5]), "v"(a2.v[7]), "v"(b2.v[4]));
     asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
         : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(m4), "v"(p7));
-    r.v[3] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
+    r.v[3] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32);
     // column 12: 10 products
-    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
-        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[5]), "v"(b0.v[7]), "v"(a0.v[6]), "v"(b0.v[6]), "v"(a0.v[7]), "v"(b0.v[5]), "v"(a1.v[5]), "v"(b1.v[7]), "v"(a1.v[6]), "v"(b1.v[6]), "v"(a1.v[7]), "v"(b1.v[5]), "v"(a2.v[5]), "v"(b2.v[7]), "v"(a2.v[6]), "v"(b2.v[6]), "v"(a2.v[7]), "v"(b2.v[5]), "v"(m5), "v"(p7));
-    r.v[4] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, 0, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %17, %18, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %19, %20, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %21, %22, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "=&v"(hi), "=&s"(cc) : "v"(a0.v[5]), "v"(b0.v[7]), "v"(a0.v[6]), "v"(b0.v[6]), "v"(a0.v[7]), "v"(b0.v[5]), "v"(a1.v[5]), "v"(b1.v[7]), "v"(a1.v[6]), "v"(b1.v[6]), "v"(a1.v[7]), "v"(b1.v[5]), "v"(a2.v[5]), "v"(b2.v[7]), "v"(a2.v[6]), "v"(b2.v[6]), "v"(a2.v[7]), "v"(b2.v[5]), "v"(m5), "v"(p7));
+    r.v[4] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32);
     // column 13: 7 products
-    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
-        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[6]), "v"(b0.v[7]), "v"(a0.v[7]), "v"(b0.v[6]), "v"(a1.v[6]), "v"(b1.v[7]), "v"(a1.v[7]), "v"(b1.v[6]), "v"(a2.v[6]), "v"(b2.v[7]), "v"(a2.v[7]), "v"(b2.v[6]), "v"(m6), "v"(p7));
-    r.v[5] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, 0, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %11, %12, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %13, %14, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %15, %16, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "=&v"(hi), "=&s"(cc) : "v"(a0.v[6]), "v"(b0.v[7]), "v"(a0.v[7]), "v"(b0.v[6]), "v"(a1.v[6]), "v"(b1.v[7]), "v"(a1.v[7]), "v"(b1.v[6]), "v"(a2.v[6]), "v"(b2.v[7]), "v"(a2.v[7]), "v"(b2.v[6]), "v"(m6), "v"(p7));
+    r.v[5] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32);
     // column 14: 4 products
-    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
-        : "+&v"(acc), "+&v"(hi), "=&s"(cc) : "v"(a0.v[7]), "v"(b0.v[7]), "v"(a1.v[7]), "v"(b1.v[7]), "v"(a2.v[7]), "v"(b2.v[7]), "v"(m7), "v"(p7));
-    r.v[6] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32); hi = 0;
+    asm("v_mad_u64_u32 %0, %2, %3, %4, %0\n\tv_addc_co_u32 %1, %2, 0, 0, %2\n\tv_mad_u64_u32 %0, %2, %5, %6, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %7, %8, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2\n\tv_mad_u64_u32 %0, %2, %9, %10, %0\n\tv_addc_co_u32 %1, %2, 0, %1, %2"
+        : "+&v"(acc), "=&v"(hi), "=&s"(cc) : "v"(a0.v[7]), "v"(b0.v[7]), "v"(a1.v[7]), "v"(b1.v[7]), "v"(a2.v[7]), "v"(b2.v[7]), "v"(m7), "v"(p7));
+    r.v[6] = (uint32_t)acc; acc = (acc >> 32) | ((uint64_t)hi << 32);
     r.v[7] = (uint32_t)acc;                                       // result < 2p < 2^256
     return RED ? fe_cond_sub_p<F>(r) : r;                 // RED = false: result < sum(a_i b_i) / 2^256 + p, left to the caller
 }
