@@ -23,7 +23,7 @@ typedef int bp_v4i __attribute__((ext_vector_type(4)));
 typedef int bp_v16i __attribute__((ext_vector_type(16)));
 
 static constexpr uint32_t BPM_DIGITS = 32, BPM_COLS = 64;     // 63 anti-diagonals, padded to 64 bins per output
-static constexpr uint32_t BPM_KALIGN = 64;                    // the batch dimension of the digit planes is padded to this (MFMA k-step 32, 16-B rows)
+static constexpr uint32_t BPM_KALIGN = 128;                   // the batch dimension of the digit planes is padded to this (one LDS K tile)
 
 // table entry e of proof b (sponge.cuh `bpoly_tables_kernel`) as balanced digits.  Thread mapping: b fastest, so that the 64 lanes of a
 // wave write 64 consecutive bytes of a digit plane.  planes: Ld [nl * 32][kpad], Hd [nh * 32][kpad]; columns b >= batch stay zero.
@@ -60,13 +60,19 @@ bpoly_tables_digits_kernel(BpolyShape sh, uint32_t kpad, FieldK fk, const uint32
 }
 
 // C' = A B^T over int8 planes with K contiguous; block = 4 waves = 128 x 128 of C' (wave: 64 x 64 = 2 x 2 MFMA tiles = four
-// (hi, lo) pairs).  Output: the 63 anti-diagonal sums of every 32 x 32 tile, int64, colsum[(mtile * ntiles + ntile) * 64 + k].
+// (hi, lo) pairs).  K runs in tiles of 128 bytes staged through LDS, double-buffered: the 256 threads fetch the two 128 x 128-byte tiles
+// with row-contiguous 16-byte loads (8 lanes = one 128-byte line of a plane row; the direct-from-L2 form made every load instruction of
+// a wave touch 32 - 64 lines and ran at 13 % of the int8 peak), rows padded to 144 bytes in LDS so that the 16-byte fragment reads of 16
+// lanes fall into 16 distinct bank groups.  Output: the 63 anti-diagonal sums of every 32 x 32 tile, int64,
+// colsum[(mtile * ntiles + ntile) * 64 + k].
+static constexpr uint32_t BPM_KT = 128, BPM_ROW = 144;            // K bytes per LDS tile, padded row pitch
 __global__ void __launch_bounds__(256)
 bpoly_field_gemm_kernel(uint32_t mtiles, uint32_t ntiles, uint32_t kpad, const int8_t *__restrict__ A, const int8_t *__restrict__ B,
                         unsigned long long *__restrict__ colsum) {
+    __shared__ __attribute__((aligned(16))) int8_t tiles[2][2][128 * BPM_ROW];   // stage, A | B, 128 rows
     __shared__ unsigned long long bins[4][4][BPM_COLS];           // wave, tile of the wave, column
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t bm = blockIdx.x % ((mtiles + 3) / 4), bn = blockIdx.x / ((mtiles + 3) / 4);
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    const uint32_t bmn = (mtiles + 3) / 4, bm = blockIdx.x % bmn, bn = blockIdx.x / bmn;
     const uint32_t mt0 = bm * 4 + (wave & 1u) * 2, nt0 = bn * 4 + (wave >> 1) * 2;       // first of this wave's 2 x 2 tiles
     for (uint32_t i = lane; i < 4 * BPM_COLS; i += 64) (&bins[wave][0][0])[i] = 0ull;
     bp_v16i acc[2][2];
@@ -76,28 +82,53 @@ bpoly_field_gemm_kernel(uint32_t mtiles, uint32_t ntiles, uint32_t kpad, const i
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
-    // fragment of lane l: row (l & 31) of the tile, 16 consecutive k at (l >> 5) * 16
-    const bool m_ok[2] = {mt0 < mtiles, mt0 + 1 < mtiles}, n_ok[2] = {nt0 < ntiles, nt0 + 1 < ntiles};
-    const int8_t *ap[2], *bp[2];
+    // loader: thread t fetches rows t/8 + 32 i (i < 4) of the block's 128 A rows and 128 B rows, bytes (t % 8) * 16 .. + 16 of the K tile.
+    // Rows past the matrix (nh or nl < 4 tiles) read row 0: their products land in tiles that are never written out.
+    const uint32_t lrow = tid >> 3, lcol = (tid & 7u) * 16;
+    const int8_t *ga[4], *gb[4];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        ap[i] = A + ((size_t)((m_ok[i] ? mt0 + i : 0) * 32 + (lane & 31u))) * kpad + (lane >> 5) * 16;
-        bp[i] = B + ((size_t)((n_ok[i] ? nt0 + i : 0) * 32 + (lane & 31u))) * kpad + (lane >> 5) * 16;
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t ra = bm * 128 + lrow + 32 * i, rb = bn * 128 + lrow + 32 * i;
+        ga[i] = A + (size_t)(ra < mtiles * 32 ? ra : 0) * kpad + lcol;
+        gb[i] = B + (size_t)(rb < ntiles * 32 ? rb : 0) * kpad + lcol;
     }
-    // fragments come straight from L2 (the planes of one call are 96 - 128 MiB).  Each load instruction of a wave touches 32 rows, i.e. 32 - 64
-    // cache lines: the texture addresser, not the matrix core, paces this loop (13 % of the int8 peak).  A ring of k-steps in flight was
-    // measured 10 % SLOWER (the bound is line throughput, not latency); LDS staging with row-contiguous loads is the known fix.
-    for (uint32_t k0 = 0; k0 < kpad; k0 += 32) {
-        bp_v4i a[2], b[2];
+    bp_v4i ra4[4], rb4[4];
+    auto fetch = [&](uint32_t k0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) { a[i] = *reinterpret_cast<const bp_v4i *>(ap[i] + k0); b[i] = *reinterpret_cast<const bp_v4i *>(bp[i] + k0); }
+        for (int i = 0; i < 4; ++i) { ra4[i] = *reinterpret_cast<const bp_v4i *>(ga[i] + k0); rb4[i] = *reinterpret_cast<const bp_v4i *>(gb[i] + k0); }
+    };
+    auto stash = [&](int stage) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
-    // C/D layout: col = lane & 31 (the B row: digit c of lo), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (digit a of hi); bin a + c
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<bp_v4i *>(&tiles[stage][0][(lrow + 32 * i) * BPM_ROW + lcol]) = ra4[i];
+            *reinterpret_cast<bp_v4i *>(&tiles[stage][1][(lrow + 32 * i) * BPM_ROW + lcol]) = rb4[i];
+        }
+    };
+    // fragment of lane l: row (l & 31) of the MFMA tile, 16 consecutive k at (l >> 5) * 16 of each 32-byte k-step
+    const uint32_t fa = ((wave & 1u) * 64 + (lane & 31u)) * BPM_ROW + (lane >> 5) * 16, fb = ((wave >> 1) * 64 + (lane & 31u)) * BPM_ROW + (lane >> 5) * 16;
+    fetch(0); stash(0);
     __syncthreads();
+    int stage = 0;
+    for (uint32_t k0 = 0; k0 < kpad; k0 += BPM_KT) {
+        const bool more = k0 + BPM_KT < kpad;
+        if (more) fetch(k0 + BPM_KT);                              // global loads of the next tile fly during this tile's MFMAs
+        const int8_t *ta = tiles[stage][0], *tb = tiles[stage][1];
+#pragma unroll
+        for (uint32_t ks = 0; ks < BPM_KT; ks += 32) {
+            bp_v4i a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) { a[i] = *reinterpret_cast<const bp_v4i *>(ta + fa + i * 32 * BPM_ROW + ks); b[i] = *reinterpret_cast<const bp_v4i *>(tb + fb + i * 32 * BPM_ROW + ks); }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[i], b[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) stash(stage ^ 1);
+        __syncthreads();
+        stage ^= 1;
+    }
+    const bool m_ok[2] = {mt0 < mtiles, mt0 + 1 < mtiles}, n_ok[2] = {nt0 < ntiles, nt0 + 1 < ntiles};
+    // C/D layout: col = lane & 31 (the B row: digit c of lo), row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (digit a of hi); bin a + c
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
