@@ -78,11 +78,6 @@ void parse_account(const uint8_t *proof, size_t proof_len, const uint8_t *pub, s
     pa.abi_ok = enc.size() == el && memcmp(enc.data(), pub + eo, el) == 0;
 }
 
-void put_record(std::vector<uint8_t> &recs, std::vector<uint32_t> &nf, size_t i, const std::vector<mw::B32> &f) {
-    const size_t k = f.size() < MINA_PSTATE_SLOTS ? f.size() : MINA_PSTATE_SLOTS;
-    for (size_t j = 0; j < k; ++j) memcpy(&recs[(i * MINA_PSTATE_SLOTS + j) * 32], f[j].b, 32);
-    nf[i] = (uint32_t)k;
-}
 }  // namespace
 
 // account hashes (and optionally Merkle roots along per-account paths of one common depth) of n parsed accounts, on the GPU
@@ -94,23 +89,30 @@ static int account_hashes(mina_ctx *c, const std::vector<const mw::Account *> &a
     if ((rc = mb_ensure_state_salts(c))) return rc;
     if (depth && (rc = mb_merkle_prepare_salts(c, FIELD_FP, depth))) return rc;
     Lane &L = *c->L;
-    // stage records: [0, n) zkapp-uri, [n, 2n) verification key, [2n, 3n) zkapp, [3n, 4n) account
-    std::vector<uint8_t> recs(4 * n * MINA_PSTATE_SLOTS * 32, 0); std::vector<uint32_t> nf(4 * n), salt(4 * n);
-    static const mw::ZkappAccount DEFAULT_ZKAPP;
-    for (size_t i = 0; i < n; ++i) {
-        const mw::Account &a = *accs[i];
-        const mw::ZkappAccount &z = a.has_zkapp ? a.zkapp : DEFAULT_ZKAPP;
-        std::vector<mw::B32> f;
-        mw::zkapp_uri_fields(z.zkapp_uri, f); put_record(recs, nf, i, f); salt[i] = MB_SALT_ZKAPP_URI;
-        mw::vk_fields(z.has_vk ? z.vk : mw::dummy_vk(), f); put_record(recs, nf, n + i, f); salt[n + i] = MB_SALT_SIDE_LOADED_VK;
-        mw::zkapp_fields(z, f); put_record(recs, nf, 2 * n + i, f); salt[2 * n + i] = MB_SALT_ZKAPP_ACCOUNT;
-        mw::account_fields(a, f); put_record(recs, nf, 3 * n + i, f); salt[3 * n + i] = MB_SALT_ACCOUNT;
-    }
-    const size_t o_nf = recs.size(), o_salt = o_nf + nf.size() * 4, o_sib = o_salt + salt.size() * 4, o_dir = o_sib + n * depth * 32,
+    // stage records straight into the pinned upload blob: [0, n) zkapp-uri, [n, 2n) verification key, [2n, 3n) zkapp, [3n, 4n) account
+    const size_t rec_bytes = 4 * n * MINA_PSTATE_SLOTS * 32;
+    const size_t o_nf = rec_bytes, o_salt = o_nf + 4 * n * 4, o_sib = o_salt + 4 * n * 4, o_dir = o_sib + n * depth * 32,
                  o_h = (o_dir + n * depth + 255) & ~(size_t)255, total = o_h + 5 * n * 32;      // hashes: uri, vk, zkapp, account, roots
     if ((rc = L.host_stage.ensure(o_h))) return rc;
     uint8_t *blob = (uint8_t *)L.host_stage.p;
-    memcpy(blob, recs.data(), recs.size()); memcpy(blob + o_nf, nf.data(), nf.size() * 4); memcpy(blob + o_salt, salt.data(), salt.size() * 4);
+    uint32_t *nf = (uint32_t *)(blob + o_nf), *salt = (uint32_t *)(blob + o_salt);
+    static const mw::ZkappAccount DEFAULT_ZKAPP;
+    auto put = [&](size_t slot, const std::vector<mw::B32> &f, uint32_t salt_id) {
+        const size_t k = f.size() < MINA_PSTATE_SLOTS ? f.size() : MINA_PSTATE_SLOTS;
+        uint8_t *r = blob + slot * MINA_PSTATE_SLOTS * 32;
+        for (size_t j = 0; j < k; ++j) memcpy(r + j * 32, f[j].b, 32);
+        memset(r + k * 32, 0, (MINA_PSTATE_SLOTS - k) * 32);
+        nf[slot] = (uint32_t)k; salt[slot] = salt_id;
+    };
+    mb_parallel_for(n, [&](size_t i) {                          // to_input flattening of the four hashes' inputs: independent per account
+        const mw::Account &a = *accs[i];
+        const mw::ZkappAccount &z = a.has_zkapp ? a.zkapp : DEFAULT_ZKAPP;
+        std::vector<mw::B32> f;
+        mw::zkapp_uri_fields(z.zkapp_uri, f); put(i, f, MB_SALT_ZKAPP_URI);
+        mw::vk_fields(z.has_vk ? z.vk : mw::dummy_vk(), f); put(n + i, f, MB_SALT_SIDE_LOADED_VK);
+        mw::zkapp_fields(z, f); put(2 * n + i, f, MB_SALT_ZKAPP_ACCOUNT);
+        mw::account_fields(a, f); put(3 * n + i, f, MB_SALT_ACCOUNT);
+    });
     if (depth) { memcpy(blob + o_sib, sib, n * depth * 32); memcpy(blob + o_dir, dirs, n * depth); }
     if ((rc = L.st_in.ensure(total))) return rc;
     uint8_t *d = L.st_in.as<uint8_t>();
@@ -171,8 +173,8 @@ extern "C" int mina_verify_account_ctx(mina_ctx *c, size_t n, const uint8_t *con
     if (!c->have_pparams[FIELD_FP]) return fail(MINA_ERR_STATE, "Poseidon constants not installed for Fp");
     HIPC(hipSetDevice(c->device));
     std::vector<ParsedAccount> pa(n);
+    mb_parallel_for(n, [&](size_t i) { parse_account(proofs[i], proof_lens[i], pubs[i], pub_lens[i], pa[i]); });
     for (size_t i = 0; i < n; ++i) {
-        parse_account(proofs[i], proof_lens[i], pubs[i], pub_lens[i], pa[i]);
         ran[i] = MINA_CHECK_FORMAT; passed[i] = 0;
         if (!pa[i].ok) continue;
         passed[i] |= MINA_CHECK_FORMAT; ran[i] |= MINA_CHECK_ACCOUNT_ABI | MINA_CHECK_MERKLE;

@@ -71,17 +71,6 @@ struct ParsedState {
 
 void chal_bytes(const mw::Chal128 &c, uint8_t *o) { for (int i = 0; i < 8; ++i) { o[i] = (uint8_t)(c.lo >> (8 * i)); o[8 + i] = (uint8_t)(c.hi >> (8 * i)); } }
 
-// independent per-item host work over up to 16 threads (items are ~0.1 ms each: threads only when there are enough of them)
-template <class Fn> void parallel_for(size_t n, Fn fn) {
-    const size_t hw = std::thread::hardware_concurrency();
-    const size_t nt = std::min<size_t>(std::min<size_t>(hw ? hw : 1, 16), (n + 15) / 16);
-    auto work = [&](size_t t) { for (size_t i = t; i < n; i += (nt ? nt : 1)) fn(i); };
-    if (nt <= 1) { work(0); return; }
-    std::vector<std::thread> th;
-    for (size_t t = 0; t < nt; ++t) th.emplace_back(work, t);
-    for (auto &x : th) x.join();
-}
-
 // host part of one proof: FORMAT, LEDGER, CONSENSUS
 void parse_state(const uint8_t *proof, size_t proof_len, const uint8_t *pub, size_t pub_len, ParsedState &ps) {
     if (!proof || !pub) return;
@@ -118,7 +107,7 @@ int run_state_jobs(mina_ctx *c, std::vector<ParsedState *> &ps, std::vector<uint
     uint8_t *recs = recs_.get();
     std::vector<uint8_t> exp(n * MINA_STATES_PER_PROOF * 32), pre(n * 16 * 16), sg(n * 64), rho(n * 32);
     std::vector<uint32_t> nf(n * MINA_STATES_PER_PROOF);
-    parallel_for(n, [&](size_t b) {
+    mb_parallel_for(n, [&](size_t b) {
         memcpy(&recs[b * sizeof ps[b]->records], ps[b]->records, sizeof ps[b]->records);
         memcpy(&nf[b * MINA_STATES_PER_PROOF], ps[b]->nfields, sizeof ps[b]->nfields);
         memcpy(&exp[b * MINA_STATES_PER_PROOF * 32], ps[b]->pub.candidate_chain_state_hashes, 512);
@@ -184,7 +173,7 @@ int verify_state_many(size_t n, const uint8_t *const *proofs, const size_t *proo
     std::vector<uint32_t> passed(n, 0), ran(n, 0);
     std::vector<ParsedState *> live; std::vector<size_t> live_idx;
     {   // host side of every proof (parse both containers, flatten 17 states, ledger + consensus checks): independent, ~0.1 ms each -> threads
-        parallel_for(n, [&](size_t i) { parse_state(proofs[i], proof_lens[i], pubs[i], pub_lens[i], ps[i]); });
+        mb_parallel_for(n, [&](size_t i) { parse_state(proofs[i], proof_lens[i], pubs[i], pub_lens[i], ps[i]); });
     }
     for (size_t i = 0; i < n; ++i) {
         ran[i] |= MINA_CHECK_FORMAT;

@@ -7,6 +7,8 @@
 #include <cstring>
 #include <array>
 #include <memory>
+#include <thread>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -130,6 +132,17 @@ static constexpr size_t COOP8_MAX_GROUPS = 8192;
 // (measured: switching to the cheaper forms earlier when several pipeline lanes are in flight LOSES 10 % at 2048 proofs per call --
 // the 8-lane transcript with to_group on a second stream is also the better throughput form there)
 static inline bool use_coop8(const mina_ctx *, size_t groups) { return groups <= COOP8_MAX_GROUPS; }
+
+// independent per-item host work over up to 16 threads (items are ~0.01 - 0.1 ms each: threads only when there are enough of them)
+template <class Fn> static inline void mb_parallel_for(size_t n, Fn fn) {
+    const size_t hw = std::thread::hardware_concurrency();
+    const size_t nt = std::min<size_t>(std::min<size_t>(hw ? hw : 1, 16), n / 64);     // a thread costs ~50 us to start: at least 64 items each
+    auto work = [&](size_t t) { for (size_t i = t; i < n; i += (nt ? nt : 1)) fn(i); };
+    if (nt <= 1) { work(0); return; }
+    std::vector<std::thread> th;
+    for (size_t t = 0; t < nt; ++t) th.emplace_back(work, t);
+    for (auto &x : th) x.join();
+}
 
 static inline int base_field_of(int curve) { return curve == CURVE_PALLAS ? FIELD_FP : FIELD_FQ; }
 static inline int scalar_field_of(int curve) { return curve == CURVE_PALLAS ? FIELD_FQ : FIELD_FP; }
