@@ -42,9 +42,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-# ROCm exposes 4 hardware queues per process by default; the pipeline lanes of the context need one each
-# to overlap (must be set before the HIP runtime initialises).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# ROCm exposes 4 hardware queues per process by default; the pipeline lanes of the context need one each to overlap, and the
+# process holds a few more streams (the null stream, torch's): with exactly 16 queues two lanes share one and run behind each
+# other (measured: 16 -> 24 queues = +5 % at 8192 proofs per call, +19 % at 1024, +31 % at 256).  Must be set before HIP initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 CURVE_PALLAS, CURVE_VESTA = 0, 1
 FIELD_FP = 0

@@ -462,16 +462,22 @@ int mb_ipa_batch_check_dev(mina_ctx *c, int curve, mb::IpaShape sh, const mb::Ip
         const bool oct = batch <= coop8_max;
         Lane &L = *c->L;
         if ((rc = L.ipa_xfer.ensure(batch * mb::IPA_XFER_WORDS * 4))) return rc;
-        if (!L.aux) { HIPC(hipStreamCreateWithFlags(&L.aux, hipStreamNonBlocking)); HIPC(hipEventCreateWithFlags(&L.ev_fork, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&L.ev_join, hipEventDisableTiming)); }
+        // second stream only for a context that runs ONE call at a time: with pipeline lanes in flight the other lanes fill the chip, and a
+        // side stream per lane would make 2 x lanes streams share the 16 hardware queues (lanes then serialise behind each other's kernels)
+        const bool side = c->nlanes == 1 && getenv("MINA_IPA_NO_SIDE_STREAM") == nullptr;
+        hipStream_t tg = L.stream;
+        if (side) {
+            if (!L.aux) { HIPC(hipStreamCreateWithFlags(&L.aux, hipStreamNonBlocking)); HIPC(hipEventCreateWithFlags(&L.ev_fork, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&L.ev_join, hipEventDisableTiming)); }
+            tg = L.aux;
+        }
         if (oct) { if (curve == CURVE_PALLAS) IPA_PREP(CURVE_PALLAS, 8, 1, L.stream); else IPA_PREP(CURVE_VESTA, 8, 1, L.stream); }
         else { if (curve == CURVE_PALLAS) IPA_PREP(CURVE_PALLAS, 3, 1, L.stream); else IPA_PREP(CURVE_VESTA, 3, 1, L.stream); }
-        HIPC(hipEventRecord(L.ev_fork, L.stream));
-        HIPC(hipStreamWaitEvent(L.aux, L.ev_fork, 0));
-        DISPATCH_FIELD(FB, { mb::ipa_to_group_kernel<F_><<<cdiv(batch, 64), 64, 0, L.aux>>>((uint32_t)batch, sh.per, c->fk[F_], L.ipa_xfer.as<uint32_t>(), L.ipa_points.as<affine_t>()); });
-        HIPC(hipEventRecord(L.ev_join, L.aux));
+        if (side) { HIPC(hipEventRecord(L.ev_fork, L.stream)); HIPC(hipStreamWaitEvent(L.aux, L.ev_fork, 0)); }
+        DISPATCH_FIELD(FB, { mb::ipa_to_group_kernel<F_><<<cdiv(batch, 64), 64, 0, tg>>>((uint32_t)batch, sh.per, c->fk[F_], L.ipa_xfer.as<uint32_t>(), L.ipa_points.as<affine_t>()); });
+        if (side) HIPC(hipEventRecord(L.ev_join, L.aux));
         if (oct) { if (curve == CURVE_PALLAS) IPA_PREP(CURVE_PALLAS, 8, 2, L.stream); else IPA_PREP(CURVE_VESTA, 8, 2, L.stream); }
         else { if (curve == CURVE_PALLAS) IPA_PREP(CURVE_PALLAS, 3, 2, L.stream); else IPA_PREP(CURVE_VESTA, 3, 2, L.stream); }
-        HIPC(hipStreamWaitEvent(L.stream, L.ev_join, 0));
+        if (side) HIPC(hipStreamWaitEvent(L.stream, L.ev_join, 0));
     }
     }
 #undef IPA_PREP
