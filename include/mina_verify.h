@@ -74,7 +74,7 @@ int mina_ctx_synchronize(mina_ctx *ctx);
 /* the hipStream_t the `_dev` entry points are queued on (for event timing by the caller) */
 void *mina_ctx_stream(mina_ctx *ctx);
 
-/* Pipelining: the `_dev` entry points are issued round-robin over `lanes` internal streams (1..16, default 1),
+/* Pipelining: the `_dev` entry points are issued round-robin over `lanes` internal streams (1..32, default 1),
  * each with its own workspace, so independent calls overlap on the GPU.  mina_ctx_synchronize waits for all. */
 int mina_ctx_set_pipeline(mina_ctx *ctx, int lanes);
 /* Device memory for the `_dev` entry points, for callers without a HIP binding of their own (the copies are synchronous;

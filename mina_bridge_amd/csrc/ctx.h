@@ -104,7 +104,7 @@ struct Lane {
         host_stage.release();
     }
 };
-static constexpr int MB_MAX_LANES = 16;
+static constexpr int MB_MAX_LANES = 32;
 enum : int { MB_SALT_PSTATE_BODY = 0, MB_SALT_PSTATE, MB_SALT_ACCOUNT, MB_SALT_ZKAPP_ACCOUNT, MB_SALT_ZKAPP_URI, MB_SALT_SIDE_LOADED_VK, MB_N_PREFIX_SALTS };
 
 struct mina_ctx {

@@ -29,7 +29,7 @@ def test_bad_arguments_are_errors_not_crashes(ctx_srs):
     with pytest.raises(m.MinaError):
         c.set_pipeline(0)
     with pytest.raises(m.MinaError):
-        c.set_pipeline(17)
+        c.set_pipeline(33)
     d = c.dev_malloc(64)
     try:
         with pytest.raises(m.MinaError):
