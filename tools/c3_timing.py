@@ -8,7 +8,7 @@
 # kimchi's oracles / linearisation scalars and the binprot parsing (not built).
 import json, os, sys, time
 import numpy as np
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import mina_bridge_amd as m

@@ -2,7 +2,7 @@
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 import ctypes
 import numpy as np
 import torch; torch.cuda.is_available()
