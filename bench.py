@@ -512,7 +512,7 @@ def main():
             got = perms * MODMUL_PER_PERMUTATION / (kern_us * 1e-6)
             out["roofline_valu"] = {"bound": "int32 multiply issue (v_mad_u64_u32)", "kernel": "pstate_hash_kernel", "achieved": got / 1e9, "peak": peak / 1e9,
                                     "unit": "G modmul/s", "frac": got / peak, "permutations_per_launch": perms}
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and args.gpus == 1:       # the CPU leg is timed at N = 1 only (rank 0)
             out["cpu_baseline"] = cpu_baseline(baseline_sample)
         print(json.dumps(out), flush=True)
     if dist_on:
