@@ -79,3 +79,57 @@ def test_scalars_with_bit_255_set_are_rejected_and_small_srs_roundtrips(ctx_srs,
             assert (c2.srs_get_g(1, 0, depth) == pts).all() and (pts == g[:depth]).all()
     finally:
         c2.close()
+
+
+@pytest.mark.gpu
+def test_statement_and_kimchi_sections_reject_bad_shapes(oracle):
+    """round-2 entry points: misuse is an error code, never a crash or a silent wrong answer -- the statement stage without a step index,
+    impossible shapes, null sections, a kimchi section whose statements do not derive exactly 40 public inputs"""
+    import ctypes
+    import mina_bridge_amd as m
+    from kimchi_helpers import install_index, install_step_index, load_k15_fixture, make_step_index, statements_soa
+    from wire_writers import synth_wrap_proof
+    import random
+    rng = random.Random(2)
+    c = m.MinaContext(0)
+    try:
+        for f in (0, 1):
+            c.poseidon_set_params(f, m.poseidon_params.default_params_bytes(f))
+        c.srs_create(0, 1 << 15)
+        w = synth_wrap_proof(rng, k=15); w["prev_optional"] = [None] * 19
+        n_old, n_evals, sec = statements_soa([w], [5])
+        st = c.make_pickles_statements(n_old, n_evals, sec)
+        with pytest.raises(m.MinaError, match="index"):          # no step index / no wrap index yet
+            c.pickles_public_inputs_batch(st, 1)
+        ix, _, _ = load_k15_fixture()
+        install_index(c, ix)
+        with pytest.raises(m.MinaError, match="step index"):
+            c.pickles_public_inputs_batch(st, 1)
+        install_step_index(c, make_step_index(99))
+        pub, ok = c.pickles_public_inputs_batch(st, 1)
+        assert ok.tolist() == [1]
+        for n_old_bad, n_evals_bad in ((5, n_evals), (n_old, 42), (n_old, 63)):
+            with pytest.raises(m.MinaError):
+                c.pickles_public_inputs_batch(c.make_pickles_statements(n_old_bad, n_evals_bad, sec), 1)
+        missing = dict(sec); missing.pop("prev_evals")
+        with pytest.raises(m.MinaError, match="null"):
+            c.pickles_public_inputs_batch(c.make_pickles_statements(n_old, n_evals, missing), 1)
+        with pytest.raises(m.MinaError):
+            c.pickles_public_inputs_batch(st, 0)
+        # a job whose kimchi section carries statements must ask for exactly 40 public inputs
+        z = np.zeros(64 * 64, np.uint8)
+        karr = {"prev_prechallenges": z, "prev_comms": z, "w_comm": z, "z_comm": z, "t_comm": z, "evals": z, "ft_eval1": z}
+        kp = c.make_kimchi_proofs(1, 2, 39, karr, statements=st)
+        ja = {"lr": z, "delta": z, "sg": z, "z1": z, "z2": z, "rand_base": oracle.int_to_le(7), "sg_rand_base": oracle.int_to_le(9)}
+        with pytest.raises(m.MinaError):
+            c.state_job_batch(c.make_state_jobs(1, ja, with_ipa=1, kimchi=kp, k=15, log2_domain=15, npub=39, n_evalpoints=2, n_comms=47))
+        # a step index with more than 8 domains, or a malformed constant term, is refused
+        with pytest.raises(m.MinaError):
+            c.step_index_install(3, list(range(5, 14)), np.zeros(9 * 7 * 32, np.uint8), b"")
+        with pytest.raises(m.MinaError):
+            c.step_index_install(3, [10], np.zeros(7 * 32, np.uint8), bytes([250]))
+        # and the context still works
+        pub2, ok2 = c.pickles_public_inputs_batch(st, 1)
+        assert (pub2 == pub).all() and ok2.tolist() == [1]
+    finally:
+        c.close()
