@@ -78,7 +78,7 @@ sponge_tape_kernel(uint32_t batch, uint32_t tape_len, uint32_t in_stride_words, 
 }
 
 
-// One lane group (4 or 8 lanes) per proof: the Fq-sponge runs lane-cooperatively (6.3 / 4.65 dependent product latencies per
+// One lane group (8 lanes, or a wave-packed triple above 1024 proofs per call) per proof: the Fq-sponge runs lane-cooperatively (6.3 / 4.65 dependent product latencies per
 // Poseidon round instead of 21), all other (scalar-field) work is computed redundantly by the lanes, lane 0 writes.
 // CURVE fixes (FB, FS).
 // PHASE 0: the whole transcript.  PHASE 1 / 2: split at the first squeeze -- `U = to_group(t)` (an inversion and 1-3 square

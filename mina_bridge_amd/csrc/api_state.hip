@@ -19,7 +19,7 @@ namespace mb {
 template <int F> __device__ __forceinline__ fe_t ld_fe(const uint32_t *p) { fe_t r; for (int i = 0; i < 8; ++i) r.v[i] = p[i]; return r; }
 
 // `MinaHash(ProtocolState)`: body = H_{"MinaProtoStateBody"}(fields[1 .. 1+nf)); hash = H_{"MinaProtoState"}(fields[0], body).
-// One lane group (4 or 8 lanes) per state; record = MINA_PSTATE_SLOTS field elements, canonical words.
+// One lane group (8 lanes, or a wave-packed triple for chip-filling batches) per state; record = MINA_PSTATE_SLOTS field elements, canonical words.
 template <int F, int LANES>
 __global__ void __launch_bounds__(256)
 pstate_hash_kernel(uint32_t n, FieldK fk, const PoseidonParams *__restrict__ pp, const fe_t *__restrict__ salts /* [0..3) body, [3..6) state */,

@@ -292,7 +292,7 @@ template <int LANES> __device__ __forceinline__ uint32_t coop_role_item(uint32_t
 }
 
 // mina-poseidon `ArithmeticSponge` state machine (rate 2) over base field F, Montgomery state, lane-cooperative over
-// LANES = 4 or 8 lanes (sponge.cuh): `s` = the state element this lane owns (coop_elem), the position (squeezed, count)
+// LANES = 3 (wave-packed triples), 4 or 8 lanes: `s` = the state element this lane owns (coop_elem), the position (squeezed, count)
 // is replicated.  Absorbed values and squeezed results are replicated on all lanes of the group.
 template <int F, int LANES> struct DevSponge {
     fe_t s; int squeezed; int count; const PoseidonParams *pp;
