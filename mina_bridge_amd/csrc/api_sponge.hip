@@ -120,11 +120,23 @@ extern "C" int mina_poseidon_set_params(mina_ctx *c, int field, const uint8_t *p
     if (bad_field(field)) return fail(MINA_ERR_ARG, "bad field");
     HIPC(hipSetDevice(c->device));
     c->use_lane0();
-    PoseidonParams pp;
-    DISPATCH_FIELD(field, { params_to_mont<F_>(params, c->fk[F_], pp); });
+    struct { PoseidonParams pp; PoseidonParams29 q; } both;
+    PoseidonParams &pp = both.pp;
+    static_assert(sizeof(both) == sizeof(PoseidonParams) + sizeof(PoseidonParams29), "PoseidonParams29 sits right behind PoseidonParams");
+    memset(&both, 0, sizeof both);
+    DISPATCH_FIELD(field, {
+        params_to_mont<F_>(params, c->fk[F_], pp);
+        // the 29-bit-limb copy (fp29.cuh): x 2^256 (what pp holds) times 2^5 = x 2^261, as an integer below p
+        const FieldK &k = c->fk[F_];
+        fe_t two5 = fe_zero(); two5.v[0] = 1u << 5; two5 = fe_to_mont<F_>(two5, k.r2);
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) both.q.mds[i][j] = fe29_from_words(fe_mul<F_>(pp.mds[i][j], two5));
+        for (int r = 0; r < 55; ++r) for (int i = 0; i < 3; ++i) both.q.rc[r][i] = fe29_from_words(fe_mul<F_>(pp.rc[r][i], two5));
+        both.q.enter = fe29_from_words(fe_mul<F_>(two5, two5));   // Mont(2^10) = 2^10 2^256 = 2^266 mod p: (x 2^256)(2^266) / 2^261 = x 2^261
+        both.q.leave = fe29_from_words(k.one);                   // Mont(1) = 2^256 mod p:           (x 2^261)(2^256) / 2^261 = x 2^256
+    });
     int rc;
-    if ((rc = c->pparams[field].ensure(sizeof pp))) return rc;
-    HIPC(hipMemcpyAsync(c->pparams[field].p, &pp, sizeof pp, hipMemcpyHostToDevice, c->L->stream));
+    if ((rc = c->pparams[field].ensure(sizeof both))) return rc;
+    HIPC(hipMemcpyAsync(c->pparams[field].p, &both, sizeof both, hipMemcpyHostToDevice, c->L->stream));
     HIPC(hipStreamSynchronize(c->L->stream));
     c->have_pparams[field] = true;
     c->merkle_depth[field] = 0;

@@ -7,6 +7,7 @@
 //   kimchi `ScalarChallenge::to_field`.
 #pragma once
 #include "groupmap.cuh"
+#include "fp29.cuh"
 
 namespace mb {
 
@@ -118,6 +119,10 @@ __global__ void bpoly_eval_kernel(uint32_t k, uint32_t npoints, FieldK fk, const
 
 // ---------------------------------------------------------------- K3
 struct PoseidonParams { fe_t mds[3][3]; fe_t rc[55][3]; };     // Montgomery, in HBM (read with uniform addresses)
+// the same constants for the 3-lane permutation's 29-bit-limb arithmetic (fp29.cuh): Montgomery with R = 2^261, plus the two re-basing
+// constants.  Lives in the same device buffer right behind PoseidonParams (api_sponge.hip: mina_poseidon_set_params).
+struct PoseidonParams29 { fe29_t mds[3][3]; fe29_t rc[55][3]; fe29_t enter /* 2^266 mod p */, leave /* 2^256 mod p */; uint32_t pad[4]; /* size: a multiple of 16 */ };
+__host__ __device__ static inline const PoseidonParams29 *pparams29_of(const PoseidonParams *pp) { return reinterpret_cast<const PoseidonParams29 *>(pp + 1); }
 
 template <int F>
 __device__ __forceinline__ void poseidon_permute(fe_t s[3], const PoseidonParams *__restrict__ pp) {
@@ -244,20 +249,32 @@ __device__ __forceinline__ fe_t tri_bcast(const fe_t &a, uint32_t src_lane) {
     for (int i = 0; i < 8; ++i) r.v[i] = (uint32_t)__shfl((int)a.v[i], (int)src_lane, 64);
     return r;
 }
+__device__ __forceinline__ fe29_t tri_bcast29(const fe29_t &a, uint32_t src_lane) {
+    fe29_t r;
+#pragma unroll
+    for (int i = 0; i < L29; ++i) r.v[i] = (uint32_t)__shfl((int)a.v[i], (int)src_lane, 64);
+    return r;
+}
 template <int F>
 __device__ __forceinline__ void poseidon_permute_tri(fe_t &s, const PoseidonParams *__restrict__ pp) {
+    // the rounds run in the carry-free 29-bit-limb representation (fp29.cuh); state in and out as 8 x 32 Montgomery-2^256, canonical
+#if defined(__HIP_DEVICE_COMPILE__)
     const TriPos tp = tri_pos();
-    const fe_t m0 = pp->mds[tp.e][0], m1 = pp->mds[tp.e][1], m2 = pp->mds[tp.e][2];
+    const PoseidonParams29 *__restrict__ q = pparams29_of(pp);
+    const fe29_t m0 = q->mds[tp.e][0], m1 = q->mds[tp.e][1], m2 = q->mds[tp.e][2];
+    fe29_t x = fe29_mul_asm<F>(fe29_from_words(s), q->enter);        // x 2^256 -> x 2^261
 #pragma unroll 1
     for (int r = 0; r < 55; ++r) {
-        // lazy round (fp.cuh "lazy forms"): s < 2p in, every product unreduced, one conditional subtraction of 2p out
-        const fe_t x2 = fe_mul_nr<F>(s, s);
-        const fe_t x4 = fe_mul_nr<F>(x2, x2);
-        const fe_t t = fe_mul_nr<F>(fe_mul_nr<F>(x4, x2), s);
-        const fe_t t0 = tri_bcast(t, tp.base), t1 = tri_bcast(t, tp.base + 1), t2 = tri_bcast(t, tp.base + 2);
-        s = fe_add_csub2p<F>(fe_dot3_nr<F>(m0, t0, m1, t1, m2, t2), pp->rc[r][tp.e]);
+        const fe29_t x2 = fe29_sqr_asm<F>(x);
+        const fe29_t x4 = fe29_sqr_asm<F>(x2);
+        const fe29_t t = fe29_mul_asm<F>(fe29_mul_asm<F>(x4, x2), x);
+        const fe29_t t0 = tri_bcast29(t, tp.base), t1 = tri_bcast29(t, tp.base + 1), t2 = tri_bcast29(t, tp.base + 2);
+        x = fe29_add(fe29_dot3_asm<F>(m0, t0, m1, t1, m2, t2), q->rc[r][tp.e]);     // < 2.2 p, normalised limbs: no subtraction
     }
-    s = fe_cond_sub_p<F>(s);
+    s = fe_cond_sub_p<F>(fe29_to_words(fe29_mul_asm<F>(x, q->leave)));   // x 2^261 -> x 2^256, below 1.01 p: one conditional subtraction
+#else
+    (void)s; (void)pp;                                               // device-only (the host pass never calls it)
+#endif
 }
 // LANES-lane cooperative permutation / element ownership, LANES = 3 (wave-packed triples), 4 (quad) or 8 (octet)
 template <int F, int LANES> __device__ __forceinline__ void poseidon_permute_coop(fe_t &s, const PoseidonParams *__restrict__ pp) {
