@@ -34,6 +34,17 @@ __global__ void __launch_bounds__(256) probe(uint32_t *out, uint32_t seed) {
             if (OP == 8) asm volatile("v_mul_hi_u32_u24 %0, %0, %1" : "+v"(a[i]) : "v"(b[i]));
             if (OP == 9) asm volatile("v_lshlrev_b64 %0, 3, %0" : "+v"(acc[i]));
             if (OP == 10) asm volatile("v_mad_u64_u32 %0, vcc, %1, %2, %0\n\tv_addc_co_u32 %3, vcc, 0, %3, vcc" : "+v"(acc[i]), "+v"(a[i]) : "v"(a[(i + 1) % UNROLL]), "v"(b[i]) : "vcc");
+            // the carry-free form of fp29.cuh: the carry-out goes to a scratch SGPR pair nobody reads (one pair / four pairs in rotation)
+            if (OP == 11) asm volatile("v_mad_u64_u32 %0, s[20:21], %1, %2, %0" : "+v"(acc[i]) : "v"(a[i]), "v"(b[i]) : "s20", "s21");
+            if (OP == 12) {
+                if ((i & 3) == 0) asm volatile("v_mad_u64_u32 %0, s[20:21], %1, %2, %0" : "+v"(acc[i]) : "v"(a[i]), "v"(b[i]) : "s20", "s21");
+                if ((i & 3) == 1) asm volatile("v_mad_u64_u32 %0, s[22:23], %1, %2, %0" : "+v"(acc[i]) : "v"(a[i]), "v"(b[i]) : "s22", "s23");
+                if ((i & 3) == 2) asm volatile("v_mad_u64_u32 %0, s[24:25], %1, %2, %0" : "+v"(acc[i]) : "v"(a[i]), "v"(b[i]) : "s24", "s25");
+                if ((i & 3) == 3) asm volatile("v_mad_u64_u32 %0, s[26:27], %1, %2, %0" : "+v"(acc[i]) : "v"(a[i]), "v"(b[i]) : "s26", "s27");
+            }
+            if (OP == 13) asm volatile("v_mad_u64_u32 %0, s[20:21], %1, %2, %0" : "+v"(acc[0]) : "v"(a[i]), "v"(b[i]) : "s20", "s21");      // ONE accumulator: the dependent column chain
+            if (OP == 14) asm volatile("v_lshrrev_b64 %0, 29, %0" : "+v"(acc[i]));
+            if (OP == 15) asm volatile("v_and_b32 %0, 0x1fffffff, %0" : "+v"(a[i]));
         }
     }
     uint32_t r = 0;
@@ -80,7 +91,9 @@ int main() {
     const int blocks = cus * waves_per_simd;          // 256-thread blocks: 4 waves -> one per SIMD
     uint32_t *out; CHECK(hipMalloc(&out, (size_t)blocks * 256 * 4));
     const char *names[] = {"v_mad_u64_u32", "v_mul_lo_u32", "v_mul_hi_u32", "v_mad_u32_u24", "v_fma_f64", "add_co+addc_co(2 instr)",
-                           "v_add_u32", "v_mul_u32_u24", "v_mul_hi_u32_u24", "v_lshlrev_b64", "mad_u64_u32+addc(2 instr)"};
+                           "v_add_u32", "v_mul_u32_u24", "v_mul_hi_u32_u24", "v_lshlrev_b64", "mad_u64_u32+addc(2 instr)",
+                           "v_mad_u64_u32 (carry to a scratch sgpr pair)", "v_mad_u64_u32 (4 scratch pairs in rotation)", "v_mad_u64_u32 (one accumulator: dependent chain)",
+                           "v_lshrrev_b64", "v_and_b32 (literal)"};
 #define RUN(OP)                                                                                              \
     {                                                                                                        \
         double t = time_kernel([&] { probe<OP><<<blocks, 256>>>(out, 12345u); }, 5);                         \
@@ -88,7 +101,7 @@ int main() {
         printf("{\"probe\": \"%s\", \"cycles_per_wave_instr_per_simd\": %.2f, \"time_us\": %.1f}\n", names[OP], \
                t * clk / wave_instr_per_simd, t * 1e6);                                                      \
     }
-    RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8) RUN(9) RUN(10)
+    RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8) RUN(9) RUN(10) RUN(11) RUN(12) RUN(13) RUN(14) RUN(15)
     const char *fnames[] = {"fe_mul (dependent)", "fe_sqr (dependent)", "fe_add", "fe_sub", "xyzz_add_affine", "2x fe_mul (independent)"};
     for (int wps = 1; wps <= 3; ++wps) {
         const int fb = cus * wps;
