@@ -52,11 +52,13 @@ FIELD_FP = 0
 ACC_K, WRAP_K, LOG2_DOMAIN, NPUB, NCOMMS, NPTS, SLOT = 16, 15, 15, 40, 45, 2, 0
 STATES_PER_PROOF, PSTATE_SLOTS, PSTATE_BODY_FIELDS = 17, 64, 49
 HBM_PEAK_GBPS = 8000.0                                # MI355X_MICROARCH.md: 8 TB/s spec
-# VALU side of the roofline (the path is integer-multiply bound): one Montgomery product is 88
-# v_mad_u64_u32 (8 cycles per wave64 instruction, profiles/r01_microbench_valu.jsonl) -> issue floor 704 cycles.
-MODMUL_ISSUE_FLOOR_CYCLES = 88 * 8
+# VALU side of the roofline (the path is integer-multiply bound).  The dominant kernel runs its Poseidon rounds on 9 limbs of
+# 29 bits (fp29.cuh): per lane and round 2 squarings (99 limb multiply-accumulates each), 2 products (135) and one 3-term dot product (297)
+# = 765 `v_mad_u64_u32`, which issue at 7.0 cycles per wave64 instruction (profiles/r02_microbench_valu.jsonl, 8 waves per SIMD); the
+# round's other ~290 instructions (shifts, masks) take the remaining issue slots.
+MADS_PER_LANE_ROUND = 2 * 99 + 2 * 135 + 297
+MAD_ISSUE_CYCLES = 7.0
 CHIP_SIMDS, CLOCK_HZ = 1024, 2.4e9
-MODMUL_PER_PERMUTATION = 55 * (3 * 4 + 9)             # x^7 = 4 products x 3, MDS 9 products: 1155
 PROF_STAGES = {"pstate_hash": 11, "ipa_transcript": 12, "kimchi_to_batch": 13, "pickles_statement": 14, "msm_accumulate": 3}
 # HBM-side bytes per protocol-state hash from the rocprofv3 PMC passes of profiles/r02b_rocprof.md (FETCH_SIZE x 2 -- the gfx950
 # correction of MI355X_MICROARCH.md for 16-B-per-lane loads -- + WRITE_SIZE, KiB x 1024, over the 139 264 states of one launch)
@@ -508,10 +510,12 @@ def main():
                                     "note": "BASELINE config C2 alone (round 1's headline): un-folded 2^16-base Vesta IPA accumulator checks, 8 per call, 16 lanes"},
         }
         if kern_us:
-            peak = CHIP_SIMDS * 64 * CLOCK_HZ / MODMUL_ISSUE_FLOOR_CYCLES
-            got = perms * MODMUL_PER_PERMUTATION / (kern_us * 1e-6)
-            out["roofline_valu"] = {"bound": "int32 multiply issue (v_mad_u64_u32)", "kernel": "pstate_hash_kernel", "achieved": got / 1e9, "peak": peak / 1e9,
-                                    "unit": "G modmul/s", "frac": got / peak, "permutations_per_launch": perms}
+            peak = CHIP_SIMDS * 64 * CLOCK_HZ / MAD_ISSUE_CYCLES
+            got = perms * 3 * 55 * MADS_PER_LANE_ROUND / (kern_us * 1e-6)
+            out["roofline_valu"] = {"bound": "64-bit multiply-accumulate issue (v_mad_u64_u32, 7.0 cycles per wave64 instruction)", "kernel": "pstate_hash_kernel",
+                                    "achieved": got / 1e12, "peak": peak / 1e12, "unit": "T limb-MAC/s", "frac": got / peak, "permutations_per_launch": perms,
+                                    "limb_macs_per_permutation": 3 * 55 * MADS_PER_LANE_ROUND,
+                                    "note": "9 x 29-bit limbs, no carry instructions: 765 of a round's ~1055 VALU instructions are multiply-accumulates"}
         if not args.no_cpu_baseline and args.gpus == 1:       # the CPU leg is timed at N = 1 only (rank 0)
             out["cpu_baseline"] = cpu_baseline(baseline_sample)
         print(json.dumps(out), flush=True)

@@ -87,9 +87,10 @@ int main() {
     hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount; const double clk = prop.clockRate * 1e3;   // Hz
     printf("{\"device\": \"%s\", \"cus\": %d, \"clock_mhz\": %.0f}\n", prop.gcnArchName, cus, clk / 1e6);
-    const int waves_per_simd = 2;                     // 2 waves/SIMD: enough to cover VALU latency with UNROLL=16
+    uint32_t *out; CHECK(hipMalloc(&out, (size_t)cus * 8 * 256 * 4));
+    for (int waves_per_simd = 2; waves_per_simd <= 8; waves_per_simd *= 2) {    // 2 waves/SIMD already cover VALU latency with UNROLL=16; more must not change the rates
+    printf("{\"waves_per_simd\": %d}\n", waves_per_simd);
     const int blocks = cus * waves_per_simd;          // 256-thread blocks: 4 waves -> one per SIMD
-    uint32_t *out; CHECK(hipMalloc(&out, (size_t)blocks * 256 * 4));
     const char *names[] = {"v_mad_u64_u32", "v_mul_lo_u32", "v_mul_hi_u32", "v_mad_u32_u24", "v_fma_f64", "add_co+addc_co(2 instr)",
                            "v_add_u32", "v_mul_u32_u24", "v_mul_hi_u32_u24", "v_lshlrev_b64", "mad_u64_u32+addc(2 instr)",
                            "v_mad_u64_u32 (carry to a scratch sgpr pair)", "v_mad_u64_u32 (4 scratch pairs in rotation)", "v_mad_u64_u32 (one accumulator: dependent chain)",
@@ -101,7 +102,9 @@ int main() {
         printf("{\"probe\": \"%s\", \"cycles_per_wave_instr_per_simd\": %.2f, \"time_us\": %.1f}\n", names[OP], \
                t * clk / wave_instr_per_simd, t * 1e6);                                                      \
     }
-    RUN(0) RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(6) RUN(7) RUN(8) RUN(9) RUN(10) RUN(11) RUN(12) RUN(13) RUN(14) RUN(15)
+    if (waves_per_simd == 2) { RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(7) RUN(8) RUN(9) }
+    RUN(0) RUN(6) RUN(10) RUN(11) RUN(12) RUN(13) RUN(14) RUN(15)
+    }
     const char *fnames[] = {"fe_mul (dependent)", "fe_sqr (dependent)", "fe_add", "fe_sub", "xyzz_add_affine", "2x fe_mul (independent)"};
     for (int wps = 1; wps <= 3; ++wps) {
         const int fb = cus * wps;

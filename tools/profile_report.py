@@ -58,5 +58,5 @@ print(f"* HIP events in bench.py: {r['avg_launch_us']:.0f} us isolated, {r['avg_
 print(f"* algorithmic bytes per launch {r['algorithmic_bytes_per_launch']} B -> {r['achieved']:.2f} GB/s = {r['frac'] * 100:.3f} % of the 8 TB/s HBM peak; PMC traffic "
       f"(FETCH x 2 for 16-B-per-lane loads + WRITE): see the table above; the kernel is integer-multiply bound.")
 if rv:
-    print(f"* multiply issue: {rv['permutations_per_launch']} permutations x 1155 modmul per launch = {rv['achieved']:.0f} G modmul/s of a {rv['peak']:.0f} G modmul/s "
-          f"floor rate = **{rv['frac']:.2f}**.")
+    print(f"* multiply-accumulate issue: {rv['permutations_per_launch']} permutations x {rv.get('limb_macs_per_permutation', 0)} limb MACs per launch = {rv['achieved']:.1f} {rv['unit']} of a {rv['peak']:.1f} "
+          f"{rv['unit']} issue rate ({rv['bound']}) = **{rv['frac']:.2f}**.")
