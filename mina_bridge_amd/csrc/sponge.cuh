@@ -219,20 +219,38 @@ template <int K> __device__ __forceinline__ fe_t oct_bcast(const fe_t &a) {     
 }
 template <int F>
 __device__ __forceinline__ void poseidon_permute_oct(fe_t &s, const PoseidonParams *__restrict__ pp) {
+    // rounds in the carry-free 29-bit-limb representation (fp29.cuh), as the 3-lane form below: the dependent chain of a product is 135
+    // multiply-accumulates instead of 96 multiply + carry-add pairs, and nothing is conditionally subtracted on the way
+#if defined(__HIP_DEVICE_COMPILE__)
     const uint32_t o = threadIdx.x & 7u, e = (o >> 1) < 3 ? (o >> 1) : 2;
     const bool odd = o & 1u;
-    const fe_t zero = fe_zero();
-    const fe_t ma = odd ? pp->mds[e][2] : pp->mds[e][0], mb = odd ? zero : pp->mds[e][1];
+    const PoseidonParams29 *__restrict__ q = pparams29_of(pp);
+    fe29_t zero29;
+#pragma unroll
+    for (int i = 0; i < L29; ++i) zero29.v[i] = 0u;
+    const fe29_t ma = odd ? q->mds[e][2] : q->mds[e][0], mb = odd ? zero29 : q->mds[e][1];
+    auto swap29 = [](const fe29_t &a) { fe29_t r;
+#pragma unroll
+        for (int i = 0; i < L29; ++i) r.v[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)a.v[i], 0xB1, 0xf, 0xf, true);   // quad_perm:[1,0,3,2]
+        return r; };
+    auto bcast29 = [](const fe29_t &a, int k) { fe29_t r; const int src = (int)((threadIdx.x & 63u) & ~7u) | k;
+#pragma unroll
+        for (int i = 0; i < L29; ++i) r.v[i] = (uint32_t)__shfl((int)a.v[i], src, 64);
+        return r; };
+    fe29_t x = fe29_mul_asm<F>(fe29_from_words(s), q->enter);        // x 2^256 -> x 2^261
 #pragma unroll 1
     for (int r = 0; r < 55; ++r) {
-        // the x^7 chain unreduced (s < p in: x2 < 1.25p, y < 1.4p, t < 1.5p); the dot product below reduces (1.75p before its subtraction)
-        const fe_t x2 = fe_mul_nr<F>(s, s);
-        const fe_t y = fe_mul_nr<F>(x2, odd ? s : x2);               // even: x^4, odd: x^3
-        const fe_t t = fe_mul_nr<F>(y, pair_swap(y));                // x^7 on both lanes of the pair
-        const fe_t t0 = oct_bcast<0>(t), t1 = oct_bcast<2>(t), t2 = oct_bcast<4>(t);
-        const fe_t u = fe_dot2<F>(ma, odd ? t2 : t0, mb, t1);        // even: m0 t0 + m1 t1, odd: m2 t2 (+ 0 * t1)
-        s = fe_add<F>(fe_add<F>(u, pair_swap(u)), pp->rc[r][e]);
+        const fe29_t x2 = fe29_sqr_asm<F>(x);
+        const fe29_t y = fe29_mul_asm<F>(x2, odd ? x : x2);          // even: x^4, odd: x^3
+        const fe29_t t = fe29_mul_asm<F>(y, swap29(y));              // x^7 on both lanes of the pair
+        const fe29_t t0 = bcast29(t, 0), t1 = bcast29(t, 2), t2 = bcast29(t, 4);
+        const fe29_t u = fe29_dot2_asm<F>(ma, odd ? t2 : t0, mb, t1);   // even: m0 t0 + m1 t1, odd: m2 t2 (+ 0 * t1)
+        x = fe29_add(fe29_add(u, swap29(u)), q->rc[r][e]);           // < 3.3 p < 2^256, limbs normalised
     }
+    s = fe_cond_sub_p<F>(fe29_to_words(fe29_mul_asm<F>(x, q->leave)));   // x 2^261 -> x 2^256, below 1.01 p
+#else
+    (void)s; (void)pp;
+#endif
 }
 // Three lanes per sponge: 21 sponges per wave64 (lanes 3g, 3g+1, 3g+2 own state elements 0, 1, 2 of sponge g; lane 63 shadows
 // group 20).  Same 7 dependent products per round as the quad form, but no idle fourth lane: 63 of 64 lanes work, which is
