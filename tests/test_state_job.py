@@ -165,3 +165,42 @@ def test_state_job_full_size_c3(ctx_srs, oracle, srs_oracle):
     sj = build_jobs(m, jobs, shape["k"], shape["log2_domain"], shape["slot"], 16)
     assert ctx_srs.state_job_batch(sj).tolist() == [1] * 9 + [0] + [1] * 6
     assert not J.verify_state_job(pp_fp(), srs_oracle[0], srs_oracle[1], oracle_job(jobs[9]))["ipa_ok"]
+
+
+def test_state_hash_extreme_field_values_in_both_lane_forms(ctx, oracle):
+    """the permutation's own arithmetic (9 limbs of 29 bits, no carries, no conditional subtractions: fp29.cuh) on the values that stress
+    it -- 0, 1, p - 1, p - 2, 2^254 - 1 (all limbs full), 2^29 - 1, 2^29, single-limb boundaries -- as state fields: the 8-lane form
+    (100 states) and the wave-packed 3-lane form (8200 states) both equal the CPU oracle's sponge"""
+    import mina_bridge_amd as m
+    import mina_bridge_amd.poseidon_params as PP
+    from oracle import mina_state_ref as S, pasta_ref as R
+    from state_job_helpers import pp_fp
+    P = R.P
+    ext = [0, 1, P - 1, P - 2, (1 << 254) - 1, (1 << 29) - 1, 1 << 29, (1 << 58) - 1, 1 << 232, (1 << 232) - 1, (1 << 253) + 12345, P >> 1]
+    rng = np.random.Generator(np.random.PCG64(77))
+    nrec, nbody, slots = 12, 49, 64
+    recs = np.zeros((nrec, slots, 32), np.uint8)
+    vals = [[ext[(r * 7 + j * 5) % len(ext)] if (j + r) % 3 else int(rng.integers(0, 1 << 62)) * ext[4] % P for j in range(nbody + 1)] for r in range(nrec)]
+    for r in range(nrec):
+        for j in range(nbody + 1):
+            recs[r, j] = oracle.int_to_le(vals[r][j])
+    nf = np.full(nrec, nbody, np.uint32)
+    # expected: H_"MinaProtoState"(previous, H_"MinaProtoStateBody"(body fields)) with the oracle's permutation
+    pp = pp_fp(); params = PP.default_params_bytes(0)
+    salts = [S.salt(S.PREFIX_PROTOCOL_STATE_BODY, pp), S.salt(S.PREFIX_PROTOCOL_STATE, pp)]
+    perm = lambda st: [int.from_bytes(x.tobytes(), "little") for x in oracle.poseidon_permute(0, params, oracle.ints_to_le(st).reshape(1, 96)).reshape(3, 32)]
+    want = []
+    for r in range(nrec):
+        st = list(salts[0])
+        for blk in range(0, nbody, 2):
+            for t in range(2):
+                if blk + t < nbody:
+                    st[t] = (st[t] + vals[r][1 + blk + t]) % P
+            st = perm(st)
+        st = perm([(salts[1][0] + vals[r][0]) % P, (salts[1][1] + st[0]) % P, salts[1][2]])
+        want.append(st[0])
+    for n in (100, 8200):
+        idx = np.arange(n) % nrec
+        got = ctx.protocol_state_hash_batch(recs[idx].reshape(n, -1).copy(), nf[idx].copy())
+        assert [oracle.le_to_int(x) for x in got[:nrec]] == want, n
+        assert (got == got[idx % nrec][: n]).all() and (got[nrec:2 * nrec] == got[:nrec]).all(), n
