@@ -182,14 +182,13 @@ extern "C" int mina_poseidon_hash(mina_ctx *c, int field, size_t n, size_t len, 
     int rc;
     if ((rc = h2d(c, c->L->tmp_a, inputs, n * len * 32))) return rc;
     if ((rc = c->L->tmp_c.ensure(n * 32))) return rc;
-    // below ~200k sponges the chip is not full with one lane per sponge: use the 4-lane cooperative form (3x shorter chain)
-    // and below ~8k the 8-lane form (a quarter shorter chain again, 1.5x the issue slots)
+    // up to 8192 sponges: 8 lanes per sponge (shortest dependent chain); above: wave-packed triples (21 sponges per wave) -- both run their
+    // rounds on the 29-bit limbs (fp29.cuh), which beats one lane per sponge on the saturated 8 x 32 form at every size (19 k against 25 k
+    // cycles per sponge-round), so the single-lane and 4-lane kernels are no longer dispatched here
     if (n <= COOP8_MAX_GROUPS) {
         DISPATCH_FIELD(field, { poseidon_hash_coop_kernel<F_, 8><<<cdiv(n * 8, 256), 256, 0, c->L->stream>>>((uint32_t)n, (uint32_t)len, c->fk[F_], c->pparams[field].as<PoseidonParams>(), c->L->tmp_a.as<uint32_t>(), c->L->tmp_c.as<uint32_t>()); });
-    } else if (n < 200000) {                                   // one lane per sponge only pays with >= 3 waves per SIMD (measured crossover ~200 k)
-        DISPATCH_FIELD(field, { poseidon_hash_coop_kernel<F_, 4><<<cdiv(n * 4, 256), 256, 0, c->L->stream>>>((uint32_t)n, (uint32_t)len, c->fk[F_], c->pparams[field].as<PoseidonParams>(), c->L->tmp_a.as<uint32_t>(), c->L->tmp_c.as<uint32_t>()); });
     } else {
-        DISPATCH_FIELD(field, { poseidon_hash_kernel<F_><<<cdiv(n, 256), 256, 0, c->L->stream>>>((uint32_t)n, (uint32_t)len, c->fk[F_], c->pparams[field].as<PoseidonParams>(), c->L->tmp_a.as<uint32_t>(), c->L->tmp_c.as<uint32_t>()); });
+        DISPATCH_FIELD(field, { poseidon_hash_coop_kernel<F_, 3><<<cdiv(coop_threads<3>(n), 256), 256, 0, c->L->stream>>>((uint32_t)n, (uint32_t)len, c->fk[F_], c->pparams[field].as<PoseidonParams>(), c->L->tmp_a.as<uint32_t>(), c->L->tmp_c.as<uint32_t>()); });
     }
     return d2h_sync(c, out, c->L->tmp_c, n * 32);
 }
@@ -237,7 +236,7 @@ int mb_merkle_fold_dev(mina_ctx *c, int field, size_t n, uint32_t depth, const u
         });
     } else {
         DISPATCH_FIELD(field, {
-            merkle_fold_coop_kernel<F_, 4><<<cdiv(n * 4, 256), 256, 0, c->L->stream>>>((uint32_t)n, depth, c->fk[F_], c->pparams[field].as<PoseidonParams>(),
+            merkle_fold_coop_kernel<F_, 3><<<cdiv(coop_threads<3>(n), 256), 256, 0, c->L->stream>>>((uint32_t)n, depth, c->fk[F_], c->pparams[field].as<PoseidonParams>(),
                 c->merkle_salts[field].as<fe_t>(), d_leaves, d_sib, d_dirs, d_roots);
         });
     }

@@ -377,7 +377,7 @@ template <int FB> __device__ __forceinline__ affine_t load_point_checked(const u
 }
 
 
-// a16: Merkle-path fold.  One lane group (4 or 8 lanes) per path.  node <- H_height(left, right) with the per-height salted initial state
+// a16: Merkle-path fold.  One lane group (8 lanes, or a wave-packed triple for chip-filling batches) per path.  node <- H_height(left, right) with the per-height salted initial state
 // (mina `hash_with_kimchi(MERKLE_PARAM[height], [l, r])`): state = salt[height]; state[0] += l; state[1] += r; permute;
 // node = state[0].  dir 0 = MerkleNode::Left(h): node is the left input, h the right one; dir 1 = MerkleNode::Right(h).
 template <int F, int LANES>
@@ -386,8 +386,7 @@ merkle_fold_coop_kernel(uint32_t n, uint32_t depth, FieldK fk, const PoseidonPar
                         const fe_t *__restrict__ salts /* depth x 3, Montgomery */, const uint32_t *__restrict__ leaves,
                         const uint32_t *__restrict__ siblings /* n*depth*8 */, const uint8_t *__restrict__ dirs,
                         uint32_t *__restrict__ roots) {
-    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t path = gid / LANES, e = coop_elem<LANES>();
+    bool writer; const uint32_t path = coop_sponge_index<LANES>(writer), e = coop_elem<LANES>();
     const bool live = path < n;
     const uint32_t pidx = live ? path : 0;                     // dead groups shadow path 0 (whole wave runs the cross-lane moves)
     fe_t node; for (int i = 0; i < 8; ++i) node.v[i] = leaves[(size_t)pidx * 8 + i];
@@ -402,7 +401,7 @@ merkle_fold_coop_kernel(uint32_t n, uint32_t depth, FieldK fk, const PoseidonPar
         poseidon_permute_coop<F, LANES>(st, pp);
         node = coop_get<LANES>(st, 0);
     }
-    if (live && (gid % LANES) == 0) { fe_t o = fe_from_mont<F>(node); for (int i = 0; i < 8; ++i) roots[(size_t)path * 8 + i] = o.v[i]; }
+    if (live && writer) { fe_t o = fe_from_mont<F>(node); for (int i = 0; i < 8; ++i) roots[(size_t)path * 8 + i] = o.v[i]; }
 }
 
 // salt[h] = state after absorbing the prefix element of height h into the zero state and permuting
@@ -418,13 +417,12 @@ __global__ void merkle_salt_kernel(uint32_t depth, FieldK fk, const PoseidonPara
     for (int j = 0; j < 3; ++j) salts[(size_t)h * 3 + j] = s[j];
 }
 
-// n independent sponges, lane-cooperative (4 or 8 lanes each): absorb len elements, squeeze one (same contract as poseidon_hash_kernel)
+// n independent sponges, lane-cooperative (8 lanes each, or wave-packed triples): absorb len elements, squeeze one (same contract as poseidon_hash_kernel)
 template <int F, int LANES>
 __global__ void __launch_bounds__(256)
 poseidon_hash_coop_kernel(uint32_t n, uint32_t len, FieldK fk, const PoseidonParams *__restrict__ pp,
                           const uint32_t *__restrict__ inputs, uint32_t *__restrict__ out_words) {
-    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t sp = gid / LANES, e = coop_elem<LANES>();
+    bool writer; const uint32_t sp = coop_sponge_index<LANES>(writer), e = coop_elem<LANES>();
     const bool live = sp < n;
     const uint32_t idx = live ? sp : 0;
     fe_t s = fe_zero();
@@ -439,7 +437,7 @@ poseidon_hash_coop_kernel(uint32_t n, uint32_t len, FieldK fk, const PoseidonPar
     }
     poseidon_permute_coop<F, LANES>(s, pp);
     s = coop_get<LANES>(s, 0);
-    if (live && (gid % LANES) == 0) { fe_t w = fe_from_mont<F>(s); for (int i = 0; i < 8; ++i) out_words[(size_t)sp * 8 + i] = w.v[i]; }
+    if (live && writer) { fe_t w = fe_from_mont<F>(s); for (int i = 0; i < 8; ++i) out_words[(size_t)sp * 8 + i] = w.v[i]; }
 }
 #endif
 
