@@ -126,11 +126,11 @@ struct mina_ctx {
     void next_lane() { L = &lanes[rr++ % (unsigned)nlanes]; }
 };
 
-// lane-cooperative Poseidon: batches of at most this many sponges use 8 lanes each (shorter dependency chain, 1.5x the
-// issue slots), larger ones 4 lanes, chip-filling ones 1 lane
+// lane-cooperative Poseidon: batches of at most this many sponges use 8 lanes each (shortest dependency chain, 2.6x the issue
+// slots), larger ones the wave-packed 3-lane form (21 sponges per wave); both run their rounds on the 29-bit limbs (fp29.cuh).
+// The per-proof transcripts of a job (kimchi, Pickles statement, opening) switch at 1024 proofs per call instead (api_kimchi.hip,
+// api_pickles.hip, api_ipa.hip: measured with 16 calls in flight).
 static constexpr size_t COOP8_MAX_GROUPS = 8192;
-// (measured: switching to the cheaper forms earlier when several pipeline lanes are in flight LOSES 10 % at 2048 proofs per call --
-// the 8-lane transcript with to_group on a second stream is also the better throughput form there)
 static inline bool use_coop8(const mina_ctx *, size_t groups) { return groups <= COOP8_MAX_GROUPS; }
 
 // independent per-item host work over up to 16 threads (items are ~0.01 - 0.1 ms each: threads only when there are enough of them)
