@@ -37,7 +37,7 @@ sponge_tape_kernel(uint32_t batch, uint32_t tape_len, uint32_t in_stride_words, 
                    uint32_t *__restrict__ final_state /* b*24 or null */, uint32_t *__restrict__ final_pos /* b*2 or null */) {
     constexpr int FB = (CURVE == CURVE_PALLAS) ? FIELD_FP : FIELD_FQ;
     constexpr int FS = (CURVE == CURVE_PALLAS) ? FIELD_FQ : FIELD_FP;
-    const uint32_t b = (blockIdx.x * blockDim.x + threadIdx.x) / LANES, l = threadIdx.x & (LANES - 1), qq = coop_elem<LANES>();
+    bool writer_; const uint32_t b = coop_sponge_index<LANES>(writer_), qq = coop_elem<LANES>();
     if (b >= batch) return;                                   // whole lane groups leave together
     DevSponge<FB, LANES> sp; sp.pp = pp; sp.squeezed = 0; sp.count = 0; sp.s = fe_zero();
     if (init_state) { sp.s = fe_to_mont<FB>(load_fe<FB>(init_state + (size_t)b * 24 + qq * 8), kb.r2); sp.squeezed = (int)init_pos[2 * b]; sp.count = (int)init_pos[2 * b + 1]; }
@@ -72,9 +72,8 @@ sponge_tape_kernel(uint32_t batch, uint32_t tape_len, uint32_t in_stride_words, 
             store_fe<LANES>(out, o); out += 8;
         }
     }
-    const bool owner = LANES == 8 ? (l < 6 && !(l & 1u)) : (l < 3);      // one lane per state element writes it
-    if (final_state && owner) { fe_t w = fe_from_mont<FB>(sp.s); for (int i = 0; i < 8; ++i) final_state[(size_t)b * 24 + qq * 8 + i] = w.v[i]; }
-    if (final_pos && l == 0) { final_pos[2 * b] = (uint32_t)sp.squeezed; final_pos[2 * b + 1] = (uint32_t)sp.count; }
+    if (final_state && coop_state_owner<LANES>()) { fe_t w = fe_from_mont<FB>(sp.s); for (int i = 0; i < 8; ++i) final_state[(size_t)b * 24 + qq * 8 + i] = w.v[i]; }
+    if (final_pos && writer_) { final_pos[2 * b] = (uint32_t)sp.squeezed; final_pos[2 * b + 1] = (uint32_t)sp.count; }
 }
 
 
@@ -590,11 +589,11 @@ extern "C" int mina_fq_sponge_run(mina_ctx *c, int curve, size_t batch, const ui
     const PoseidonParams *pp = c->pparams[FB].as<PoseidonParams>();
     const int FS = scalar_field_of(curve);
 #define RUN_TAPE(CV, LN)                                                                                                                   \
-    mb::sponge_tape_kernel<CV, LN><<<cdiv(batch * LN, 64), 64, 0, L.stream>>>((uint32_t)batch, (uint32_t)tape_len, (uint32_t)in_words, (uint32_t)out_words, \
+    mb::sponge_tape_kernel<CV, LN><<<cdiv(coop_threads<LN>(batch), 64), 64, 0, L.stream>>>((uint32_t)batch, (uint32_t)tape_len, (uint32_t)in_words, (uint32_t)out_words, \
         c->fk[FB], c->fk[FS], pp, L.ipa_in_a.as<uint8_t>(), init_state ? L.ipa_in_c.as<uint32_t>() : nullptr, init_state ? L.ipa_sigma.as<uint32_t>() : nullptr, \
         L.ipa_in_b.as<uint32_t>(), L.ipa_scalars.as<uint32_t>(), L.ipa_points.as<uint32_t>(), L.ipa_chals.as<uint32_t>())
     if (batch <= COOP8_MAX_GROUPS) { if (curve == CURVE_PALLAS) RUN_TAPE(CURVE_PALLAS, 8); else RUN_TAPE(CURVE_VESTA, 8); }
-    else { if (curve == CURVE_PALLAS) RUN_TAPE(CURVE_PALLAS, 4); else RUN_TAPE(CURVE_VESTA, 4); }
+    else { if (curve == CURVE_PALLAS) RUN_TAPE(CURVE_PALLAS, 3); else RUN_TAPE(CURVE_VESTA, 3); }
 #undef RUN_TAPE
     HIPC(hipGetLastError());
     if (final_state) HIPC(hipMemcpyAsync(final_state, L.ipa_points.p, batch * 96, hipMemcpyDeviceToHost, L.stream));

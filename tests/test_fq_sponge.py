@@ -71,6 +71,11 @@ def test_tape_matches_restatement(ctx, oracle, srs_oracle, curve):
         assert [oracle.le_to_int(x) for x in got[b]] == exp, b
         st, mode, count = sp.raw()
         assert [oracle.le_to_int(fstate[b][32 * i: 32 * i + 32]) for i in range(3)] == st and fpos[b].tolist() == [mode, count]
+    # the same transcripts tiled past 8192 sponges: the wave-packed 3-lane form gives the same outputs, final states and positions
+    reps = 8200 // batch + 1
+    got_big, fs_big, fp_big = ctx.fq_sponge_run(curve, batch * reps, bytes(tape), np.tile(np.concatenate(all_inputs), reps), want_final=True)
+    assert (got_big.reshape(reps, batch, -1) == got.reshape(1, batch, -1)).all()
+    assert (fs_big.reshape(reps, batch, 96) == fstate.reshape(1, batch, 96)).all() and (fp_big.reshape(reps, batch, 2) == fpos.reshape(1, batch, 2)).all()
     # resume from the handed-over state: continuing on the GPU == continuing in the restatement
     tape2 = [ABS_FQ, CHAL, ABS_G, CHAL_FQ]
     ins2, pp2 = [], []
