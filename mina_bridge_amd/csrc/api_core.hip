@@ -83,6 +83,11 @@ extern "C" void mina_ctx_destroy(mina_ctx *c) {
     delete c;
 }
 
+// The lanes of a context (and the concurrent culprit search of mina_state_job_batch) are separate streams; they only run side by side
+// on separate hardware queues, and the runtime's default is 4.  The HIP runtime reads the variable when it initialises, so this takes
+// effect when the library is loaded before the process's first HIP call (the operator's cgo binding); a value set by the user is kept.
+__attribute__((constructor)) static void mb_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "24", 0); }
+
 extern "C" int mina_ctx_synchronize(mina_ctx *c) {
     if (!c) return fail(MINA_ERR_ARG, "null ctx");
     HIPC(hipSetDevice(c->device));

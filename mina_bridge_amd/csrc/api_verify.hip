@@ -18,6 +18,7 @@
 //                      otherwise the step cannot run and mina_verify_state answers `false` (mina_verify_state_checks tells
 //                      which steps ran and passed; MINA_VERIFY_ALLOW_MISSING_KIMCHI relaxes the verdict for integration tests).
 #include <chrono>
+#include <condition_variable>
 #include <mutex>
 #include <thread>
 
@@ -57,6 +58,44 @@ extern "C" int mina_verify_configure(uint32_t flags) { std::lock_guard<std::mute
 extern "C" int mina_verify_shutdown(void) { std::lock_guard<std::mutex> lk(g_mu); if (g_ctx) mina_ctx_destroy(g_ctx); g_ctx = nullptr; return MINA_OK; }
 // the process-wide context, e.g. to install a verifier index or different Poseidon tables; NULL if no GPU / set-up failed
 extern "C" mina_ctx *mina_verify_global_ctx(void) { std::lock_guard<std::mutex> lk(g_mu); return global_ctx(); }
+
+// ------------------------------------------------------------------------------------------------ merging of concurrent single-proof calls
+// The reference's entry points take ONE proof and are called from many goroutines / tokio tasks at once.  One proof is
+// a 25 ms dependent chain that leaves the chip idle, so concurrent callers are merged (group commit): the first caller runs a job with
+// everything queued at that moment; calls arriving while it runs wait and leave together as the next job, led by one of them.  A lone
+// caller pays nothing; N concurrent callers share one job of N proofs.  Verdicts are per proof either way (the batch entry points
+// isolate failing proofs).  MINA_VERIFY_NO_MERGE=1 sends every call through on its own.
+namespace {
+struct PendingCall { const uint8_t *proof; size_t proof_len; const uint8_t *pub; size_t pub_len; uint8_t verdict = 0; bool done = false; };
+typedef int (*batch_fn_t)(size_t, const uint8_t *const *, const size_t *, const uint8_t *const *, const size_t *, uint8_t *);
+struct CallMerger {
+    std::mutex mu; std::condition_variable cv; std::vector<PendingCall *> waiting; bool leader = false;
+    static constexpr size_t MAX_JOB = 8192;
+    bool run(batch_fn_t batch, PendingCall &me) {
+        static const bool off = getenv("MINA_VERIFY_NO_MERGE") != nullptr;
+        if (off) { uint8_t v = 0; return batch(1, &me.proof, &me.proof_len, &me.pub, &me.pub_len, &v) == MINA_OK && v == 1; }
+        std::unique_lock<std::mutex> lk(mu);
+        waiting.push_back(&me);
+        while (!me.done) {
+            if (leader) { cv.wait(lk); continue; }
+            leader = true;                                                    // lead the next job: everything queued so far (this call included, unless MAX_JOB cut it off)
+            const size_t n = std::min(waiting.size(), MAX_JOB);
+            std::vector<PendingCall *> job(waiting.begin(), waiting.begin() + n);
+            waiting.erase(waiting.begin(), waiting.begin() + n);
+            lk.unlock();
+            std::vector<const uint8_t *> pr(n), pu(n); std::vector<size_t> pl(n), ul(n); std::vector<uint8_t> v(n, 0);
+            for (size_t i = 0; i < n; ++i) { pr[i] = job[i]->proof; pl[i] = job[i]->proof_len; pu[i] = job[i]->pub; ul[i] = job[i]->pub_len; }
+            const int rc = batch(n, pr.data(), pl.data(), pu.data(), ul.data(), v.data());
+            lk.lock();
+            for (size_t i = 0; i < n; ++i) { job[i]->verdict = rc == MINA_OK ? v[i] : 0; job[i]->done = true; }
+            leader = false;
+            cv.notify_all();
+        }
+        return me.verdict == 1;
+    }
+};
+CallMerger g_state_calls, g_account_calls;
+}  // namespace
 
 // ------------------------------------------------------------------------------------------------ Proof of State
 namespace {
@@ -222,9 +261,8 @@ extern "C" int mina_verify_state_batch(size_t n, const uint8_t *const *proofs, c
 }
 
 extern "C" bool mina_verify_state(const uint8_t *proof, size_t proof_len, const uint8_t *pub, size_t pub_len) {
-    uint8_t v = 0;
-    if (mina_verify_state_batch(1, &proof, &proof_len, &pub, &pub_len, &v) != MINA_OK) return false;
-    return v == 1;
+    PendingCall me{proof, proof_len, pub, pub_len};
+    return g_state_calls.run(mina_verify_state_batch, me);
 }
 
 // the `--save-proof` form (core/src/aligned.rs:60-69): two files holding exactly the two byte strings
@@ -327,9 +365,8 @@ extern "C" int mina_verify_account_batch(size_t n, const uint8_t *const *proofs,
     return MINA_OK;
 }
 extern "C" bool mina_verify_account(const uint8_t *proof, size_t proof_len, const uint8_t *pub, size_t pub_len) {
-    uint8_t v = 0;
-    if (mina_verify_account_batch(1, &proof, &proof_len, &pub, &pub_len, &v) != MINA_OK) return false;
-    return v == 1;
+    PendingCall me{proof, proof_len, pub, pub_len};
+    return g_account_calls.run(mina_verify_account_batch, me);
 }
 extern "C" bool mina_verify_account_files(const char *proof_path, const char *pub_path) {
     std::vector<uint8_t> p, q;

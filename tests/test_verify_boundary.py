@@ -190,6 +190,16 @@ def test_verify_account_end_to_end(world, srs_oracle, ctx, tmp_path):
     big_q[100] = pubs[(100 + 1) % 4]
     v = m.lib.verify_account_batch(big_p, big_q)
     assert v.sum() == 255 and v[100] == 0
+    # the reference's call pattern: one proof per call from many threads at once -- every caller its own verdict (calls that arrive while a
+    # job runs are merged into the next one, api_verify.hip)
+    import threading
+    calls = [(big_p[i], big_q[i], i != 100) for i in range(90, 122)]
+    got = [None] * len(calls)
+    def worker(i): got[i] = m.lib.verify_account(calls[i][0], calls[i][1])
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(len(calls))]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert got == [c[2] for c in calls]
 
 
 def test_c_consumer_of_the_boundary(world, srs_oracle, tmp_path):

@@ -65,3 +65,40 @@ def test_full_size_batch_and_one_tamper_per_stage(big):
     assert ran == ALL and passed == ALL & ~32, "a changed statement field fails exactly the kimchi step"
     passed, ran = m.lib.verify_state_checks(proofs[7], pubs[7])
     assert ran == ALL and not passed & 16 and not passed & 32, "a changed step prechallenge fails the accumulator check and, through the statement, the kimchi step"
+
+
+def test_concurrent_single_proof_calls_are_merged_into_shared_jobs(big):
+    """The reference's entry point takes ONE proof and is called from many threads at once.  24 threads call
+    mina_verify_state concurrently (good proofs and the tampered ones of the test above, interleaved): every caller gets its own
+    verdict, and because calls that arrive while a job runs leave together as the next job, the whole burst takes far less than 24
+    single-proof latencies."""
+    import copy
+    import threading
+    import time
+    from wire_writers import state_proof_bytes
+    m, cases = big["m"], big["cases"]
+    w_bad = copy.deepcopy(cases[2]["wrap"]); w_bad["z1"] = (w_bad["z1"] + 1) % (1 << 254)
+    bad_pub = bytearray(cases[0]["pub"]); bad_pub[40] ^= 1
+    calls = []
+    for i in range(24):
+        c = cases[i % 4]
+        if i % 6 == 4: calls.append((state_proof_bytes(w_bad, cases[2]["states"]), cases[2]["pub"], False))
+        elif i % 6 == 5: calls.append((cases[0]["proof"], bytes(bad_pub), False))
+        else: calls.append((c["proof"], c["pub"], True))
+    assert m.lib.verify_state(*calls[0][:2]) is True               # warm: context, tables, buffers
+    t0 = time.perf_counter()
+    for p, q, want in calls[:4]: assert m.lib.verify_state(p, q) is want
+    one = (time.perf_counter() - t0) / 4
+    def burst_of_calls():
+        got = [None] * len(calls)
+        def worker(i): got[i] = m.lib.verify_state(calls[i][0], calls[i][1])
+        th = [threading.Thread(target=worker, args=(i,)) for i in range(len(calls))]
+        t0 = time.perf_counter()
+        for t in th: t.start()
+        for t in th: t.join()
+        return got, time.perf_counter() - t0
+    got, _ = burst_of_calls()                                       # the first search for culprits sets up its lanes' buffers
+    assert got == [c[2] for c in calls]
+    got, burst = burst_of_calls()
+    assert got == [c[2] for c in calls]
+    assert burst < 0.5 * len(calls) * one, f"24 concurrent calls took {burst * 1e3:.1f} ms against {one * 1e3:.1f} ms for one: they were not merged"
