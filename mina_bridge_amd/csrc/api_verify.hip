@@ -64,30 +64,37 @@ extern "C" mina_ctx *mina_verify_global_ctx(void) { std::lock_guard<std::mutex> 
 // a 25 ms dependent chain that leaves the chip idle, so concurrent callers are merged (group commit): the first caller runs a job with
 // everything queued at that moment; calls arriving while it runs wait and leave together as the next job, led by one of them.  A lone
 // caller pays nothing; N concurrent callers share one job of N proofs.  Verdicts are per proof either way (the batch entry points
-// isolate failing proofs).  MINA_VERIFY_NO_MERGE=1 sends every call through on its own.
+// isolate failing proofs).  MINA_VERIFY_NO_MERGE=1 sends every call through on its own; MINA_VERIFY_LINGER_US (default 500) is how long
+// the leader of a job waits for the callers of the previous job to come back before it leaves.
 namespace {
-struct PendingCall { const uint8_t *proof; size_t proof_len; const uint8_t *pub; size_t pub_len; uint8_t verdict = 0; bool done = false; };
-typedef int (*batch_fn_t)(size_t, const uint8_t *const *, const size_t *, const uint8_t *const *, const size_t *, uint8_t *);
+struct PendingCall { const uint8_t *proof; size_t proof_len; const uint8_t *pub; size_t pub_len; void *parsed = nullptr; uint8_t verdict = 0; bool done = false; };
+typedef void (*exec_fn_t)(std::vector<PendingCall *> &job);           // sets `verdict` of every call of the job
 struct CallMerger {
-    std::mutex mu; std::condition_variable cv; std::vector<PendingCall *> waiting; bool leader = false;
+    std::mutex mu; std::condition_variable cv, arrived; std::vector<PendingCall *> waiting; bool leader = false;
+    size_t last_job = 0;                 // calls merged into the previous job: its callers return together and call again within microseconds
     static constexpr size_t MAX_JOB = 8192;
-    bool run(batch_fn_t batch, PendingCall &me) {
+    bool run(exec_fn_t exec, PendingCall &me) {
         static const bool off = getenv("MINA_VERIFY_NO_MERGE") != nullptr;
-        if (off) { uint8_t v = 0; return batch(1, &me.proof, &me.proof_len, &me.pub, &me.pub_len, &v) == MINA_OK && v == 1; }
+        if (off) { std::vector<PendingCall *> job{&me}; exec(job); return me.verdict == 1; }
+        static const long linger_us = getenv("MINA_VERIFY_LINGER_US") ? atol(getenv("MINA_VERIFY_LINGER_US")) : 500;
         std::unique_lock<std::mutex> lk(mu);
         waiting.push_back(&me);
+        arrived.notify_one();
         while (!me.done) {
             if (leader) { cv.wait(lk); continue; }
             leader = true;                                                    // lead the next job: everything queued so far (this call included, unless MAX_JOB cut it off)
+            if (last_job > 1 && linger_us > 0) {                              // the callers of the job that just ended are on their way back: give them a moment,
+                const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(linger_us);   // else this call leaves alone and they wait two latencies
+                while (waiting.size() < last_job && arrived.wait_until(lk, deadline) != std::cv_status::timeout) {}
+            }
             const size_t n = std::min(waiting.size(), MAX_JOB);
             std::vector<PendingCall *> job(waiting.begin(), waiting.begin() + n);
             waiting.erase(waiting.begin(), waiting.begin() + n);
             lk.unlock();
-            std::vector<const uint8_t *> pr(n), pu(n); std::vector<size_t> pl(n), ul(n); std::vector<uint8_t> v(n, 0);
-            for (size_t i = 0; i < n; ++i) { pr[i] = job[i]->proof; pl[i] = job[i]->proof_len; pu[i] = job[i]->pub; ul[i] = job[i]->pub_len; }
-            const int rc = batch(n, pr.data(), pl.data(), pu.data(), ul.data(), v.data());
+            exec(job);
             lk.lock();
-            for (size_t i = 0; i < n; ++i) { job[i]->verdict = rc == MINA_OK ? v[i] : 0; job[i]->done = true; }
+            for (PendingCall *p : job) p->done = true;
+            last_job = n;
             leader = false;
             cv.notify_all();
         }
@@ -203,26 +210,19 @@ int run_state_jobs(mina_ctx *c, std::vector<ParsedState *> &ps, std::vector<uint
     return MINA_OK;
 }
 
-int verify_state_many(size_t n, const uint8_t *const *proofs, const size_t *proof_lens, const uint8_t *const *pubs, const size_t *pub_lens,
-                      uint32_t *passed_out, uint32_t *ran_out, bool masks) {
-    static const bool timing = getenv("MINA_VERIFY_TIMING") != nullptr;
-    auto now = [] { return std::chrono::steady_clock::now(); };
-    const auto t0 = now();
-    std::vector<ParsedState> ps(n);
+// n parsed proofs: host verdict bits, then ONE pass over the GPU for those whose FORMAT passed
+int verify_parsed(std::vector<ParsedState *> &ps, uint32_t *passed_out, uint32_t *ran_out, bool masks) {
+    const size_t n = ps.size();
     std::vector<uint32_t> passed(n, 0), ran(n, 0);
     std::vector<ParsedState *> live; std::vector<size_t> live_idx;
-    {   // host side of every proof (parse both containers, flatten 17 states, ledger + consensus checks): independent, ~0.1 ms each -> threads
-        mb_parallel_for(n, [&](size_t i) { parse_state(proofs[i], proof_lens[i], pubs[i], pub_lens[i], ps[i]); });
-    }
     for (size_t i = 0; i < n; ++i) {
         ran[i] |= MINA_CHECK_FORMAT;
-        if (!ps[i].format_ok) continue;
+        if (!ps[i]->format_ok) continue;
         passed[i] |= MINA_CHECK_FORMAT; ran[i] |= MINA_CHECK_LEDGER | MINA_CHECK_CONSENSUS;
-        if (ps[i].ledger_ok) passed[i] |= MINA_CHECK_LEDGER;
-        if (ps[i].consensus_ok) passed[i] |= MINA_CHECK_CONSENSUS;
-        live.push_back(&ps[i]); live_idx.push_back(i);
+        if (ps[i]->ledger_ok) passed[i] |= MINA_CHECK_LEDGER;
+        if (ps[i]->consensus_ok) passed[i] |= MINA_CHECK_CONSENSUS;
+        live.push_back(ps[i]); live_idx.push_back(i);
     }
-    const auto t1 = now();
     if (!live.empty()) {
         std::lock_guard<std::mutex> lk(g_mu);
         mina_ctx *c = global_ctx();
@@ -233,8 +233,22 @@ int verify_state_many(size_t n, const uint8_t *const *proofs, const size_t *proo
         for (size_t k = 0; k < live.size(); ++k) { passed[live_idx[k]] |= lp[k]; ran[live_idx[k]] |= lr[k]; }
     }
     for (size_t i = 0; i < n; ++i) { passed_out[i] = passed[i]; ran_out[i] = ran[i]; }
-    if (timing) fprintf(stderr, "mina_verify: n=%zu parse %.2f ms, jobs %.2f ms\n", n, std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(now() - t1).count());
     return MINA_OK;
+}
+
+int verify_state_many(size_t n, const uint8_t *const *proofs, const size_t *proof_lens, const uint8_t *const *pubs, const size_t *pub_lens,
+                      uint32_t *passed_out, uint32_t *ran_out, bool masks) {
+    static const bool timing = getenv("MINA_VERIFY_TIMING") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    const auto t0 = now();
+    std::vector<ParsedState> ps(n);
+    // host side of every proof (parse both containers, flatten 17 states, ledger + consensus checks): independent, ~0.1 ms each -> threads
+    mb_parallel_for(n, [&](size_t i) { parse_state(proofs[i], proof_lens[i], pubs[i], pub_lens[i], ps[i]); });
+    std::vector<ParsedState *> ptr(n); for (size_t i = 0; i < n; ++i) ptr[i] = &ps[i];
+    const auto t1 = now();
+    int rc = verify_parsed(ptr, passed_out, ran_out, masks);
+    if (timing) fprintf(stderr, "mina_verify: n=%zu parse %.2f ms, jobs %.2f ms\n", n, std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(now() - t1).count());
+    return rc;
 }
 
 bool verdict_of(uint32_t passed, uint32_t ran, uint32_t flags) {
@@ -260,9 +274,22 @@ extern "C" int mina_verify_state_batch(size_t n, const uint8_t *const *proofs, c
     return MINA_OK;
 }
 
+// the merged job of single-proof callers: every caller parsed its own proof on its own thread before queueing
+static void exec_state_calls(std::vector<PendingCall *> &job) {
+    const size_t n = job.size();
+    std::vector<ParsedState *> ps(n); for (size_t i = 0; i < n; ++i) ps[i] = (ParsedState *)job[i]->parsed;
+    std::vector<uint32_t> passed(n), ran(n);
+    const int rc = verify_parsed(ps, passed.data(), ran.data(), /*masks=*/false);
+    uint32_t flags; { std::lock_guard<std::mutex> lk(g_mu); flags = g_flags; }
+    for (size_t i = 0; i < n; ++i) job[i]->verdict = (rc == MINA_OK && verdict_of(passed[i], ran[i], flags)) ? 1 : 0;
+}
 extern "C" bool mina_verify_state(const uint8_t *proof, size_t proof_len, const uint8_t *pub, size_t pub_len) {
+    std::unique_ptr<ParsedState> ps(new (std::nothrow) ParsedState);
+    if (!ps) return false;
+    parse_state(proof, proof_len, pub, pub_len, *ps);
     PendingCall me{proof, proof_len, pub, pub_len};
-    return g_state_calls.run(mina_verify_state_batch, me);
+    me.parsed = ps.get();
+    return g_state_calls.run(exec_state_calls, me);
 }
 
 // the `--save-proof` form (core/src/aligned.rs:60-69): two files holding exactly the two byte strings
@@ -364,9 +391,16 @@ extern "C" int mina_verify_account_batch(size_t n, const uint8_t *const *proofs,
     for (size_t i = 0; i < n; ++i) verdicts_out[i] = (passed[i] & need) == need ? 1 : 0;
     return MINA_OK;
 }
+static void exec_account_calls(std::vector<PendingCall *> &job) {
+    const size_t n = job.size();
+    std::vector<const uint8_t *> pr(n), pu(n); std::vector<size_t> pl(n), ul(n); std::vector<uint8_t> v(n, 0);
+    for (size_t i = 0; i < n; ++i) { pr[i] = job[i]->proof; pl[i] = job[i]->proof_len; pu[i] = job[i]->pub; ul[i] = job[i]->pub_len; }
+    const int rc = mina_verify_account_batch(n, pr.data(), pl.data(), pu.data(), ul.data(), v.data());
+    for (size_t i = 0; i < n; ++i) job[i]->verdict = rc == MINA_OK ? v[i] : 0;
+}
 extern "C" bool mina_verify_account(const uint8_t *proof, size_t proof_len, const uint8_t *pub, size_t pub_len) {
     PendingCall me{proof, proof_len, pub, pub_len};
-    return g_account_calls.run(mina_verify_account_batch, me);
+    return g_account_calls.run(exec_account_calls, me);
 }
 extern "C" bool mina_verify_account_files(const char *proof_path, const char *pub_path) {
     std::vector<uint8_t> p, q;
