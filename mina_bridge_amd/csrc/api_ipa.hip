@@ -486,6 +486,30 @@ int mb_ipa_batch_check_dev(mina_ctx *c, int curve, mb::IpaShape sh, const mb::Ip
     if ((rc = mb_msm_variable(c, curve, (uint32_t)npoints, c->L->ipa_scalars.as<uint32_t>(), c->L->ipa_points.p, nullptr, c->L->ipa_xyzz_b.p))) return rc;
     DISPATCH_FIELD(FB, { xyzz_compare_kernel<F_><<<1, 64, 0, c->L->stream>>>(c->L->ipa_xyzz_a.as<xyzz_t>(), c->L->ipa_xyzz_b.as<xyzz_t>(), 1, d_verdict, d_verdict + 1); });
     HIPC(hipGetLastError());
+    c->ipa_rows = c->L; c->ipa_rows_batch = sh.batch; c->ipa_rows_k = k; c->ipa_rows_per = sh.per; c->ipa_rows_curve = curve;
+    return MINA_OK;
+}
+
+// The rows ipa_prepare_kernel left on a lane (per proof: `per` (point, scalar) pairs, the k challenges and the fold weight) already carry the
+// batch's randomisers rho^b, sigma^b, so the rows of any subset of proofs ARE a folded check of that subset: fold + the two MSMs + the
+// comparison, no transcript work.  mina_state_job_batch's search for the culprits of a failed batch runs this on slices, one lane each.
+// The caller has synchronised the lane that holds the rows.
+int mb_ipa_recheck_rows(mina_ctx *c, size_t lo, size_t cnt, uint32_t *d_verdict) {
+    Lane *src = c->ipa_rows;
+    if (!src || cnt == 0 || lo + cnt > c->ipa_rows_batch) return fail(MINA_ERR_STATE, "no prepared rows for that range");
+    const int curve = c->ipa_rows_curve, FB = base_field_of(curve), FS = scalar_field_of(curve);
+    const uint32_t k = c->ipa_rows_k, per = c->ipa_rows_per;
+    Lane &L = *c->L;
+    int rc;
+    if ((rc = L.ipa_folded.ensure(((size_t)1 << k) * 32))) return rc;
+    if ((rc = L.ipa_xyzz_a.ensure(sizeof(xyzz_t)))) return rc;
+    if ((rc = L.ipa_xyzz_b.ensure(sizeof(xyzz_t)))) return rc;
+    HIPC(hipMemsetAsync(d_verdict, 0, 8, L.stream));
+    if ((rc = mb_bpoly_fold(c, FS, k, cnt, src->ipa_chals.as<uint32_t>() + lo * k * 8, src->ipa_sigma.as<uint32_t>() + lo * 8, L.ipa_folded.as<uint32_t>()))) return rc;
+    if ((rc = mb_msm_fixed(c, curve, 1u << k, L.ipa_folded.as<uint32_t>(), nullptr, L.ipa_xyzz_a.p))) return rc;
+    if ((rc = mb_msm_variable(c, curve, (uint32_t)(cnt * per), src->ipa_scalars.as<uint32_t>() + lo * per * 8, src->ipa_points.as<affine_t>() + lo * per, nullptr, L.ipa_xyzz_b.p))) return rc;
+    DISPATCH_FIELD(FB, { xyzz_compare_kernel<F_><<<1, 64, 0, L.stream>>>(L.ipa_xyzz_a.as<xyzz_t>(), L.ipa_xyzz_b.as<xyzz_t>(), 1, d_verdict, d_verdict + 1); });
+    HIPC(hipGetLastError());
     return MINA_OK;
 }
 

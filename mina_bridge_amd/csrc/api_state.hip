@@ -501,6 +501,9 @@ extern "C" int mina_state_job_batch(mina_ctx *c, const mina_state_jobs *jobs, ui
     // context (inputs stay where lane 0 uploaded them; every lane has its own verdict words); parts that fail are cut again.
     // Depth log_FAN(B) rounds of ~one job latency each, where a bisection ran log2(B) jobs one after the other per culprit
     // (24 proofs with 8 bad ones: 820 ms -> 150 ms).
+    // The opening leg of well-formed proofs does not repeat its transcripts: the prepared rows of the failed batch are still on their
+    // lane and any slice of them is the folded check of that slice (mb_ipa_recheck_rows): a round costs a fold + two MSMs per part.
+    const bool rows_ok = hv[B + 1] == 0 && c->ipa_rows && c->ipa_rows_batch == B && getenv("MINA_STATE_SEARCH_FULL") == nullptr;
     auto search = [&](bool ipa_leg, std::vector<uint8_t> &each) -> int {
         constexpr size_t FAN = MB_MAX_LANES;
         static const bool timing = getenv("MINA_VERIFY_TIMING") != nullptr;
@@ -527,6 +530,7 @@ extern "C" int mina_state_job_batch(mina_ctx *c, const mina_state_jobs *jobs, ui
                     if (r) return r;
                     uint32_t *v = c->L->st_verdicts.as<uint32_t>();
                     flags_at[q] = v + cnt;
+                    if (ipa_leg && rows_ok) { if ((r = mb_ipa_recheck_rows(c, lo, cnt, flags_at[q]))) return r; continue; }
                     mina_state_jobs sj = slice(d, lo, cnt);
                     if (ipa_leg) sj.with_accumulator = 0; else { sj.with_ipa = 0; sj.npub = 0; sj.kimchi = nullptr; }
                     if ((r = state_jobs_on_lane(c, &sj, v, flags_at[q]))) return r;

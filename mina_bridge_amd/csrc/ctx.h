@@ -114,6 +114,7 @@ struct mina_ctx {
     int nlanes = 1;
     unsigned rr = 0;                 // round-robin cursor of the `_dev` entry points
     Lane *L = nullptr;               // lane the current call runs on
+    Lane *ipa_rows = nullptr; uint32_t ipa_rows_batch = 0, ipa_rows_k = 0, ipa_rows_per = 0; int ipa_rows_curve = -1;   // lane holding the prepared rows of the last folded opening check (mb_ipa_recheck_rows)
     FieldK fk[2];
     SrsState srs[2];
     DevBuf pparams[2]; bool have_pparams[2] = {false, false};
@@ -197,6 +198,7 @@ struct IpaDevIn {     // structure-of-arrays over the batch, canonical little-en
 };
 }
 int mb_ipa_batch_check_dev(mina_ctx *c, int curve, mb::IpaShape sh, const mb::IpaDevIn &in, uint32_t *d_verdict /* [0] verdict, [1] malformed flag */);
+int mb_ipa_recheck_rows(mina_ctx *c, size_t lo, size_t cnt, uint32_t *d_verdict /* [0] verdict */);   // folded check of proofs [lo, lo + cnt) of the batch prepared last, from its rows; on the current lane
 int mb_accumulator_check_dev(mina_ctx *c, int curve, uint32_t k, size_t batch, const uint32_t *d_prechal, const uint32_t *d_sg_words, const uint32_t *d_rho, uint32_t *d_verdict);
 
 // cross-file entry points (C++ linkage)

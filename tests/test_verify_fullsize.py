@@ -61,6 +61,20 @@ def test_full_size_batch_and_one_tamper_per_stage(big):
     proofs += [cases[0]["proof"], state_proof_bytes(w1, cases[1]["states"]), state_proof_bytes(w2, cases[2]["states"]), state_proof_bytes(w3, cases[3]["states"])]
     pubs += [bytes(bad_pub), cases[1]["pub"], cases[2]["pub"], cases[3]["pub"]]
     assert m.lib.verify_state_batch(proofs, pubs).tolist() == [1, 1, 1, 1, 0, 0, 0, 0]
+    # the culprits of the failed folded opening check were found from the prepared rows of the batch (slices of them re-checked); the same
+    # verdicts when every part repeats its transcripts instead
+    import os
+    os.environ["MINA_STATE_SEARCH_FULL"] = "1"
+    try:
+        assert m.lib.verify_state_batch(proofs, pubs).tolist() == [1, 1, 1, 1, 0, 0, 0, 0]
+    finally:
+        del os.environ["MINA_STATE_SEARCH_FULL"]
+    # a bigger batch with culprits at both ends and in the middle: two rounds of cuts
+    many_p = [proofs[i % 4] for i in range(70)]; many_q = [pubs[i % 4] for i in range(70)]
+    for i in (0, 33, 34, 69): many_p[i] = proofs[6]; many_q[i] = pubs[6]
+    many_p[50] = proofs[7]; many_q[50] = pubs[7]
+    want = [0 if i in (0, 33, 34, 50, 69) else 1 for i in range(70)]
+    assert m.lib.verify_state_batch(many_p, many_q).tolist() == want
     passed, ran = m.lib.verify_state_checks(proofs[5], pubs[5])
     assert ran == ALL and passed == ALL & ~32, "a changed statement field fails exactly the kimchi step"
     passed, ran = m.lib.verify_state_checks(proofs[7], pubs[7])
