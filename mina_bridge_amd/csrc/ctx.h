@@ -132,7 +132,14 @@ struct mina_ctx {
 // The per-proof transcripts of a job (kimchi, Pickles statement, opening) switch at 1024 proofs per call instead (api_kimchi.hip,
 // api_pickles.hip, api_ipa.hip: measured with 16 calls in flight).
 static constexpr size_t COOP8_MAX_GROUPS = 8192;
-static inline bool use_coop8(const mina_ctx *, size_t groups) { return groups <= COOP8_MAX_GROUPS; }
+// `groups` sponges per call, `nlanes` calls in flight: the choice looks at the work in flight (256 proofs per call on 16 lanes are 69 k state
+// hashes at once -- the 8-lane form then spends 2.1x the issue slots of a saturated chip: 480 proofs per call 66 -> 75 k/s).
+// MINA_COOP8_MAX overrides the limit, MINA_COOP8_PER_CALL=1 ignores the lanes (A/B switches).
+static inline bool use_coop8(const mina_ctx *c, size_t groups) {
+    static const size_t lim = getenv("MINA_COOP8_MAX") ? (size_t)strtoull(getenv("MINA_COOP8_MAX"), nullptr, 10) : COOP8_MAX_GROUPS;
+    static const bool per_call = getenv("MINA_COOP8_PER_CALL") != nullptr;
+    return groups * (size_t)((c && !per_call) ? c->nlanes : 1) <= lim;
+}
 
 // independent per-item host work over up to 16 threads (items are ~0.01 - 0.1 ms each: threads only when there are enough of them)
 template <class Fn> static inline void mb_parallel_for(size_t n, Fn fn) {
