@@ -358,3 +358,58 @@ def test_pickles_statements_on_the_gpu_match_oracle(world, srs_oracle):
         assert ok3.tolist() == [0, 0, 0] + [1] * (count - 3)
         for b in range(3, count):
             assert (pub3[b] == pub[b]).all()
+
+
+def test_c_consumer_many_threads_one_proof_per_call(world, srs_oracle, tmp_path):
+    """plain C with pthreads, the operator's call pattern without an interpreter lock in the way: 16 threads x 6 calls of mina_verify_state, one
+    proof per call, every fourth thread with a public input whose tip hash is wrong.  A fresh process has no verifier index, so the
+    verdicts are taken with MINA_VERIFY_ALLOW_MISSING_KIMCHI (every other step runs).  Each caller must get the verdict of ITS proof
+    although the calls are merged into shared jobs."""
+    import mina_bridge_amd as m
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = tmp_path / "threads.c"
+    src.write_text(r'''
+#include <pthread.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include "mina_verify.h"
+static unsigned char *slurp(const char *p, size_t *n) { FILE *f = fopen(p, "rb"); if (!f) return 0; fseek(f, 0, SEEK_END); *n = (size_t)ftell(f); rewind(f);
+  unsigned char *b = malloc(*n + 1); if (fread(b, 1, *n, f) != *n) { fclose(f); return 0; } fclose(f); return b; }
+static unsigned char *proof, *pub, *bad_pub; static size_t pl, ql; static int wrong[64];
+enum { THREADS = 16, CALLS = 6 };
+static void *worker(void *arg) { long t = (long)arg;
+  for (int k = 0; k < CALLS; ++k) { const int bad = t % 4 == 3; bool v = mina_verify_state(proof, pl, bad ? bad_pub : pub, ql); if (v != !bad) wrong[t]++; }
+  return 0; }
+int main(int argc, char **argv) {
+  if (argc < 3 || !(proof = slurp(argv[1], &pl)) || !(pub = slurp(argv[2], &ql))) return 2;
+  bad_pub = malloc(ql); memcpy(bad_pub, pub, ql); bad_pub[1 + 7] ^= 1;             /* bridge tip state hash */
+  mina_verify_configure(MINA_VERIFY_ALLOW_MISSING_KIMCHI);
+  if (!mina_verify_state(proof, pl, pub, ql) || mina_verify_state(proof, pl, bad_pub, ql)) return 3;     /* warm, and the lone-caller path */
+  struct timespec a, b; clock_gettime(CLOCK_MONOTONIC, &a);
+  for (int k = 0; k < CALLS; ++k) if (!mina_verify_state(proof, pl, pub, ql)) return 4;
+  clock_gettime(CLOCK_MONOTONIC, &b);
+  const double one = ((b.tv_sec - a.tv_sec) * 1e3 + (b.tv_nsec - a.tv_nsec) * 1e-6) / CALLS;
+  pthread_t th[THREADS]; clock_gettime(CLOCK_MONOTONIC, &a);
+  for (long t = 0; t < THREADS; ++t) pthread_create(&th[t], 0, worker, (void *)t);
+  for (int t = 0; t < THREADS; ++t) pthread_join(th[t], 0);
+  clock_gettime(CLOCK_MONOTONIC, &b);
+  const double all = (b.tv_sec - a.tv_sec) * 1e3 + (b.tv_nsec - a.tv_nsec) * 1e-6;
+  int w = 0; for (int t = 0; t < THREADS; ++t) w += wrong[t];
+  printf("wrong=%d one_call_ms=%.2f threads=%d calls=%d all_ms=%.2f\n", w, one, THREADS, THREADS * CALLS, all);
+  return 0; }
+''')
+    exe = tmp_path / "threads"
+    subprocess.check_call(["gcc", "-std=gnu99", "-Wall", "-Wextra", "-Werror", "-pthread", "-I", os.path.join(root, "include"), str(src), "-o", str(exe),
+                           "-L", os.path.dirname(m.LIB_PATH), "-lminaverify", "-Wl,-rpath," + os.path.dirname(m.LIB_PATH)])
+    wrap, states, hashes = mint_state_proof(world, srs_oracle, 3100)
+    proof, pub = to_bytes(wrap, states, hashes)
+    (tmp_path / "p").write_bytes(proof); (tmp_path / "q").write_bytes(pub)
+    r = subprocess.run([str(exe), str(tmp_path / "p"), str(tmp_path / "q")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    f = dict(kv.split("=") for kv in r.stdout.split())
+    assert f["wrong"] == "0", r.stdout
+    # 96 calls one after the other would take 96 x one_call_ms; merged they share a handful of jobs
+    assert float(f["all_ms"]) < 0.5 * 96 * float(f["one_call_ms"]), r.stdout
+    print(r.stdout.strip())
