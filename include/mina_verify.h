@@ -516,7 +516,7 @@ int mina_state_proof_split(const uint8_t *bytes, size_t len, size_t *proof_len, 
  * Same (ptr, len, ptr, len) -> bool shape as Aligned's `verify_mina_state_ffi` / `verify_account_inclusion_ffi`, fed with exactly
  * the bytes core/src/aligned.rs:31-58 produces.  Every failure is `false`; nothing unwinds; callable from any thread (one
  * process-wide context on GPU $MINA_VERIFY_DEVICE (default 0), created on first use).  Concurrent calls of the single-proof entry
- * points are merged: calls that arrive while a job runs on the GPU leave together as the next job (one proof is a 25 ms dependent
+ * points are merged: calls that arrive while a job runs on the GPU leave together as the next job (one proof is a 23 ms dependent
  * chain that leaves the chip idle; 256 threads calling at once see 4.4 k proofs/s instead of 40).  Every caller still gets the
  * verdict of its own proof.  Environment: MINA_VERIFY_NO_MERGE=1 sends each call through on its own; MINA_VERIFY_LINGER_US (default 500)
  * bounds how long the leader of a job waits for the callers of the previous job to come back. */

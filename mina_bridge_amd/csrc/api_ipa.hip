@@ -469,12 +469,15 @@ int mb_ipa_batch_check_dev(mina_ctx *c, int curve, mb::IpaShape sh, const mb::Ip
             if (!L.aux) { HIPC(hipStreamCreateWithFlags(&L.aux, hipStreamNonBlocking)); HIPC(hipEventCreateWithFlags(&L.ev_fork, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&L.ev_join, hipEventDisableTiming)); }
             tg = L.aux;
         }
-        if (oct) { if (curve == CURVE_PALLAS) IPA_PREP(CURVE_PALLAS, 8, 1, L.stream); else IPA_PREP(CURVE_VESTA, 8, 1, L.stream); }
+        const bool hex = use_coop16(c, batch);
+        if (hex) { if (curve == CURVE_PALLAS) IPA_PREP(CURVE_PALLAS, 16, 1, L.stream); else IPA_PREP(CURVE_VESTA, 16, 1, L.stream); }
+        else if (oct) { if (curve == CURVE_PALLAS) IPA_PREP(CURVE_PALLAS, 8, 1, L.stream); else IPA_PREP(CURVE_VESTA, 8, 1, L.stream); }
         else { if (curve == CURVE_PALLAS) IPA_PREP(CURVE_PALLAS, 3, 1, L.stream); else IPA_PREP(CURVE_VESTA, 3, 1, L.stream); }
         if (side) { HIPC(hipEventRecord(L.ev_fork, L.stream)); HIPC(hipStreamWaitEvent(L.aux, L.ev_fork, 0)); }
         DISPATCH_FIELD(FB, { mb::ipa_to_group_kernel<F_><<<cdiv(batch, 64), 64, 0, tg>>>((uint32_t)batch, sh.per, c->fk[F_], L.ipa_xfer.as<uint32_t>(), L.ipa_points.as<affine_t>()); });
         if (side) HIPC(hipEventRecord(L.ev_join, L.aux));
-        if (oct) { if (curve == CURVE_PALLAS) IPA_PREP(CURVE_PALLAS, 8, 2, L.stream); else IPA_PREP(CURVE_VESTA, 8, 2, L.stream); }
+        if (hex) { if (curve == CURVE_PALLAS) IPA_PREP(CURVE_PALLAS, 16, 2, L.stream); else IPA_PREP(CURVE_VESTA, 16, 2, L.stream); }
+        else if (oct) { if (curve == CURVE_PALLAS) IPA_PREP(CURVE_PALLAS, 8, 2, L.stream); else IPA_PREP(CURVE_VESTA, 8, 2, L.stream); }
         else { if (curve == CURVE_PALLAS) IPA_PREP(CURVE_PALLAS, 3, 2, L.stream); else IPA_PREP(CURVE_VESTA, 3, 2, L.stream); }
         if (side) HIPC(hipStreamWaitEvent(L.stream, L.ev_join, 0));
     }

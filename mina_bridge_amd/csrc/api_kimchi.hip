@@ -368,7 +368,11 @@ int mb_kimchi_to_batch_dev(mina_ctx *c, size_t batch, uint32_t n_prev, uint32_t 
     // 8-lane sponges up to 1024 proofs per call (shortest dependent chain), 3-lane above: measured on bench.py --kimchi, 8192 proofs
     // per step -- 16 x 512: 165 k/s (8-lane) vs 162 k/s; 4 x 2048: 137 k/s (8-lane) vs 150 k/s (3-lane).  MINA_KIMCHI_COOP8_MAX overrides (tuning)
     static const size_t coop8_max = [] { const char *e = getenv("MINA_KIMCHI_COOP8_MAX"); return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)1024; }();
-    if (batch <= coop8_max) {
+    if (use_coop16(c, batch)) {
+        mb::kimchi_fq_kernel<16><<<2 * coop_role_blocks<16>(batch), 64, 0, L.stream>>>(B, n_prev, kb, ks, ppb, pps, ix, in, out, xf, d_bad, coop_role_blocks<16>(batch));
+        mb::kimchi_pub_kernel<<<cdiv(batch * 8, 64), 64, 0, L.stream>>>(B, npub, ks, ix, in, xf, d_bad);
+        mb::kimchi_fr_kernel<16><<<cdiv(coop_threads<16>(batch), 64), 64, 0, L.stream>>>(B, ks, pps, in, xf, d_bad);
+    } else if (batch <= coop8_max) {
         mb::kimchi_fq_kernel<8><<<2 * coop_role_blocks<8>(batch), 64, 0, L.stream>>>(B, n_prev, kb, ks, ppb, pps, ix, in, out, xf, d_bad, coop_role_blocks<8>(batch));
         mb::kimchi_pub_kernel<<<cdiv(batch * 8, 64), 64, 0, L.stream>>>(B, npub, ks, ix, in, xf, d_bad);
         mb::kimchi_fr_kernel<8><<<cdiv(coop_threads<8>(batch), 64), 64, 0, L.stream>>>(B, ks, pps, in, xf, d_bad);

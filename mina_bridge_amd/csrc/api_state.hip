@@ -179,7 +179,9 @@ static int pstate_hash_dev(mina_ctx *c, size_t n, const uint32_t *d_records, con
     const fe_t *salts = c->state_salts.as<fe_t>();
     ProfScope ps_(c, PS_STATE_HASH);
     // below ~8 k states the chip is latency-bound: 8 lanes per state (shortest chain); above, wave-packed triples (63 of 64 lanes busy)
-    if (use_coop8(c, n))
+    if (use_coop16(c, (n + MINA_STATES_PER_PROOF - 1) / MINA_STATES_PER_PROOF))
+        mb::pstate_hash_kernel<FIELD_FP, 16><<<cdiv(n * 16, 256), 256, 0, c->L->stream>>>((uint32_t)n, c->fk[FIELD_FP], pp, salts, d_records, d_nfields, d_hashes, d_bodies);
+    else if (use_coop8(c, n))
         mb::pstate_hash_kernel<FIELD_FP, 8><<<cdiv(n * 8, 256), 256, 0, c->L->stream>>>((uint32_t)n, c->fk[FIELD_FP], pp, salts, d_records, d_nfields, d_hashes, d_bodies);
     else
         mb::pstate_hash_kernel<FIELD_FP, 3><<<cdiv(coop_threads<3>(n), 256), 256, 0, c->L->stream>>>((uint32_t)n, c->fk[FIELD_FP], pp, salts, d_records, d_nfields, d_hashes, d_bodies);

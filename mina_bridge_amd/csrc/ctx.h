@@ -141,6 +141,14 @@ static inline bool use_coop8(const mina_ctx *c, size_t groups) {
     return groups * (size_t)((c && !per_call) ? c->nlanes : 1) <= lim;
 }
 
+// One proof or a handful in flight (the reference's call pattern): 16 lanes per sponge -- the shortest dependent chain, at 5.3x the issue
+// slots of the 3-lane form (poseidon_permute_hex).  `proofs` per call x lanes in flight, up to 64 (one proof 25.5 -> 23.1 ms, 16 proofs
+// 22.9 -> 21.2 ms; at 256 the 8-lane form is as fast); MINA_COOP16_MAX overrides (0 disables).
+static inline bool use_coop16(const mina_ctx *c, size_t proofs) {
+    static const size_t lim = getenv("MINA_COOP16_MAX") ? (size_t)strtoull(getenv("MINA_COOP16_MAX"), nullptr, 10) : (size_t)64;
+    return proofs * (size_t)(c ? c->nlanes : 1) <= lim;
+}
+
 // independent per-item host work over up to 16 threads (items are ~0.01 - 0.1 ms each: threads only when there are enough of them)
 template <class Fn> static inline void mb_parallel_for(size_t n, Fn fn) {
     const size_t hw = std::thread::hardware_concurrency();

@@ -294,17 +294,56 @@ __device__ __forceinline__ void poseidon_permute_tri(fe_t &s, const PoseidonPara
     (void)s; (void)pp;                                               // device-only (the host pass never calls it)
 #endif
 }
-// LANES-lane cooperative permutation / element ownership, LANES = 3 (wave-packed triples), 4 (quad) or 8 (octet)
+// Sixteen lanes per sponge (4 sponges per wave), for ONE proof or a handful -- the reference's call pattern, where nothing but the length
+// of the dependent chain counts.  Quad q of the group holds state element / MDS row q (quad 3 shadows quad 2).  Inside a quad, lanes 0 and 1
+// are the x^7 pair of the 8-lane form (lanes 2, 3 shadow them), and lanes 0, 1, 2 multiply the row's three MDS entries by the three x^7 --
+// ONE product each, where the 8-lane form's two lanes per row need a two-term dot: a round's chain is 99 + 3 x 135 multiply-accumulates
+// instead of 99 + 2 x 135 + 216.  Row sums and the pair exchange are quad_perm DPP moves; the three x^7 travel by ds_bpermute.
+template <int F>
+__device__ __forceinline__ void poseidon_permute_hex(fe_t &s, const PoseidonParams *__restrict__ pp) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t o = threadIdx.x & 15u, qd = o >> 2, c = o & 3u, e = qd < 3 ? qd : 2u, col = c < 3 ? c : 2u;
+    const bool odd = c & 1u;
+    const PoseidonParams29 *__restrict__ q = pparams29_of(pp);
+    const fe29_t m = q->mds[e][col];
+#define MB_QUAD29(NAME, CTRL) auto NAME = [](const fe29_t &a) { fe29_t r; _Pragma("unroll") for (int i = 0; i < L29; ++i) r.v[i] = (uint32_t)__builtin_amdgcn_mov_dpp((int)a.v[i], CTRL, 0xf, 0xf, true); return r; }
+    MB_QUAD29(swap29, 0xB1);                                          // quad_perm:[1,0,3,2]
+    MB_QUAD29(rot1, 0x09);                                            // quad_perm:[1,2,0,0]: lanes 0..2 read their right neighbour (cyclically), lane 3 as lane 2
+    MB_QUAD29(rot2, 0x52);                                            // quad_perm:[2,0,1,1]
+#undef MB_QUAD29
+    const int src = (int)(((threadIdx.x & 63u) & ~15u) | (col << 2));  // lane 0 of quad `col`: x_col^7
+    fe29_t x = fe29_mul_asm<F>(fe29_from_words(s), q->enter);        // x 2^256 -> x 2^261
+#pragma unroll 1
+    for (int r = 0; r < 55; ++r) {
+        const fe29_t x2 = fe29_sqr_asm<F>(x);
+        const fe29_t y = fe29_mul_asm<F>(x2, odd ? x : x2);          // even: x^4, odd: x^3
+        const fe29_t t = fe29_mul_asm<F>(y, swap29(y));              // x_e^7 on every lane of quad e
+        fe29_t tc;
+#pragma unroll
+        for (int i = 0; i < L29; ++i) tc.v[i] = (uint32_t)__shfl((int)t.v[i], src, 64);
+        const fe29_t pr = fe29_mul_asm<F>(m, tc);                    // mds[e][col] x_col^7 (lane 3 repeats column 2)
+        x = fe29_add(fe29_add(fe29_add(pr, rot1(pr)), rot2(pr)), q->rc[r][e]);   // the row's three terms + round constant: < 4.4 p, limbs normalised
+    }
+    s = fe_cond_sub_p<F>(fe29_to_words(fe29_mul_asm<F>(x, q->leave)));   // x 2^261 -> x 2^256, below 1.01 p
+#else
+    (void)s; (void)pp;
+#endif
+}
+// LANES-lane cooperative permutation / element ownership, LANES = 3 (wave-packed triples), 4 (quad), 8 (octet) or 16
 template <int F, int LANES> __device__ __forceinline__ void poseidon_permute_coop(fe_t &s, const PoseidonParams *__restrict__ pp) {
-    if (LANES == 8) poseidon_permute_oct<F>(s, pp); else if (LANES == 3) poseidon_permute_tri<F>(s, pp); else poseidon_permute_quad<F>(s, pp);
+    if (LANES == 16) poseidon_permute_hex<F>(s, pp); else if (LANES == 8) poseidon_permute_oct<F>(s, pp); else if (LANES == 3) poseidon_permute_tri<F>(s, pp); else poseidon_permute_quad<F>(s, pp);
 }
 template <int LANES> __device__ __forceinline__ uint32_t coop_elem() {                 // state element this lane owns
     if (LANES == 3) return tri_pos().e;
-    const uint32_t l = threadIdx.x & (LANES - 1), e = LANES == 8 ? (l >> 1) : l;
+    const uint32_t l = threadIdx.x & (LANES - 1), e = LANES == 16 ? (l >> 2) : (LANES == 8 ? (l >> 1) : l);
     return e < 3 ? e : 2;
 }
 template <int LANES> __device__ __forceinline__ fe_t coop_get(const fe_t &s, int pos) { // element `pos` -> all lanes of the group
     if (LANES == 3) return tri_bcast(s, tri_pos().base + (uint32_t)pos);
+    if (LANES == 16) { fe_t r; const int src = (int)(((threadIdx.x & 63u) & ~15u) | ((uint32_t)pos << 2));
+#pragma unroll
+        for (int i = 0; i < 8; ++i) r.v[i] = (uint32_t)__shfl((int)s.v[i], src, 64);
+        return r; }
     if (LANES == 8) return pos == 0 ? oct_bcast<0>(s) : (pos == 1 ? oct_bcast<2>(s) : oct_bcast<4>(s));
     return pos == 0 ? quad_bcast<0>(s) : (pos == 1 ? quad_bcast<1>(s) : quad_bcast<2>(s));
 }
@@ -354,7 +393,7 @@ template <int LANES> __device__ __forceinline__ uint32_t coop_lane() { return LA
 // the lanes that hold state elements 0, 1, 2 of a cooperative sponge (one lane each)
 template <int LANES> __device__ __forceinline__ bool coop_state_owner() {
     const uint32_t ln = coop_lane<LANES>();
-    return LANES == 8 ? (ln < 6 && !(ln & 1u)) : (LANES == 3 ? (threadIdx.x & 63u) < 63u : ln < 3);
+    return LANES == 16 ? (ln < 12 && !(ln & 3u)) : (LANES == 8 ? (ln < 6 && !(ln & 1u)) : (LANES == 3 ? (threadIdx.x & 63u) < 63u : ln < 3));
 }
 template <int LANES> __device__ __forceinline__ void store_fe(uint32_t *p, const fe_t &a) { if (coop_writer<LANES>()) for (int i = 0; i < 8; ++i) p[i] = a.v[i]; }
 template <int LANES> __device__ __forceinline__ void store_pt(affine_t *p, const affine_t &a) { if (coop_writer<LANES>()) *p = a; }

@@ -167,10 +167,10 @@ def test_state_job_full_size_c3(ctx_srs, oracle, srs_oracle):
     assert not J.verify_state_job(pp_fp(), srs_oracle[0], srs_oracle[1], oracle_job(jobs[9]))["ipa_ok"]
 
 
-def test_state_hash_extreme_field_values_in_both_lane_forms(ctx, oracle):
+def test_state_hash_extreme_field_values_in_every_lane_form(ctx, oracle):
     """the permutation's own arithmetic (9 limbs of 29 bits, no carries, no conditional subtractions: fp29.cuh) on the values that stress
-    it -- 0, 1, p - 1, p - 2, 2^254 - 1 (all limbs full), 2^29 - 1, 2^29, single-limb boundaries -- as state fields: the 8-lane form
-    (100 states) and the wave-packed 3-lane form (8200 states) both equal the CPU oracle's sponge"""
+    it -- 0, 1, p - 1, p - 2, 2^254 - 1 (all limbs full), 2^29 - 1, 2^29, single-limb boundaries -- as state fields: the 16-lane form
+    (100 states), the 8-lane form (2000) and the wave-packed 3-lane form (8200 states) all equal the CPU oracle's sponge"""
     import mina_bridge_amd as m
     import mina_bridge_amd.poseidon_params as PP
     from oracle import mina_state_ref as S, pasta_ref as R
@@ -199,7 +199,7 @@ def test_state_hash_extreme_field_values_in_both_lane_forms(ctx, oracle):
             st = perm(st)
         st = perm([(salts[1][0] + vals[r][0]) % P, (salts[1][1] + st[0]) % P, salts[1][2]])
         want.append(st[0])
-    for n in (100, 8200):
+    for n in (100, 2000, 8200):
         idx = np.arange(n) % nrec
         got = ctx.protocol_state_hash_batch(recs[idx].reshape(n, -1).copy(), nf[idx].copy())
         assert [oracle.le_to_int(x) for x in got[:nrec]] == want, n

@@ -314,7 +314,7 @@ def test_pickles_public_input_matches_oracle(world, srs_oracle):
 
 def test_pickles_statements_on_the_gpu_match_oracle(world, srs_oracle):
     """the batch form (expand / digest / tick / scalar kernels of api_pickles.hip, no host arithmetic) == oracle/pickles_ref.py, for both
-    sponge forms (8-lane up to 1024 statements per call, 3-lane above), 0..2 previous accumulators, optional + chunked evaluations; a
+    sponge forms (16-lane up to 64 statements per call, 8-lane up to 1024, 3-lane above), 0..2 previous accumulators, optional + chunked evaluations; a
     malformed statement is flagged without disturbing its neighbours"""
     import mina_bridge_amd as m
     from ipa_helpers import poseidon_pp
@@ -344,11 +344,12 @@ def test_pickles_statements_on_the_gpu_match_oracle(world, srs_oracle):
         assert ok.tolist() == [1] * count
         for b in range(count):
             assert [O.le_to_int(x) for x in pub[b]] == want[b], (n_old, b)
-        # the 3-lane sponge form: the same statements tiled past the 1024 threshold
-        reps = 1030 // count + 1
-        big = {k: np.tile(v.reshape(count, -1), (reps, 1)).reshape(-1) if v.size >= count else v for k, v in sec.items()}
-        pub2, ok2 = gctx.pickles_public_inputs_batch(gctx.make_pickles_statements(n_old_, n_evals, big), count * reps)
-        assert ok2.all() and (pub2.reshape(reps, count, 40, 32) == pub[None]).all()
+        # `count` statements ran in the 16-lane sponge form (up to 64 per call); the 8-lane form (up to 1024) and the 3-lane form (above):
+        # the same statements tiled past either threshold
+        for reps in (70 // count + 1, 1030 // count + 1):
+            big = {k: np.tile(v.reshape(count, -1), (reps, 1)).reshape(-1) if v.size >= count else v for k, v in sec.items()}
+            pub2, ok2 = gctx.pickles_public_inputs_batch(gctx.make_pickles_statements(n_old_, n_evals, big), count * reps)
+            assert ok2.all() and (pub2.reshape(reps, count, 40, 32) == pub[None]).all()
         # malformed: a non-canonical evaluation, an unknown step domain, a bad branch byte -- each flags exactly its own statement
         bad = {k: v.copy() for k, v in sec.items()}
         bad["prev_evals"].reshape(count, -1)[1, :32] = 0xff
