@@ -54,7 +54,9 @@ static int salted_hash_dev(mina_ctx *c, size_t n, const uint32_t *salt_idx, cons
     const PoseidonParams *pp = c->pparams[FIELD_FP].as<PoseidonParams>();
     const fe_t *salts = c->state_salts.as<fe_t>();
     ProfScope ps_(c, PS_STATE_HASH);
-    if (use_coop8(c, n))
+    if (use_coop16(c, n))
+        mb::salted_hash_kernel<FIELD_FP, 16><<<cdiv(n * 16, 256), 256, 0, c->L->stream>>>((uint32_t)n, c->fk[FIELD_FP], pp, salts, salt_idx, recs, nf, pa, sa, pb, sb, out);
+    else if (use_coop8(c, n))
         mb::salted_hash_kernel<FIELD_FP, 8><<<cdiv(n * 8, 256), 256, 0, c->L->stream>>>((uint32_t)n, c->fk[FIELD_FP], pp, salts, salt_idx, recs, nf, pa, sa, pb, sb, out);
     else
         mb::salted_hash_kernel<FIELD_FP, 3><<<cdiv(coop_threads<3>(n), 256), 256, 0, c->L->stream>>>((uint32_t)n, c->fk[FIELD_FP], pp, salts, salt_idx, recs, nf, pa, sa, pb, sb, out);

@@ -229,7 +229,12 @@ static int merkle_prepare_salts(mina_ctx *c, int field, uint32_t depth) {
 
 // Merkle fold of n paths with everything in HBM, queued on the current lane (salts must have been prepared: merkle_prepare_salts)
 int mb_merkle_fold_dev(mina_ctx *c, int field, size_t n, uint32_t depth, const uint32_t *d_leaves, const uint32_t *d_sib, const uint8_t *d_dirs, uint32_t *d_roots) {
-    if (n <= COOP8_MAX_GROUPS) {                                 // latency-bound batch: 8 lanes per path
+    if (use_coop16(c, n)) {                                      // a few paths: 16 lanes each (shortest chain)
+        DISPATCH_FIELD(field, {
+            merkle_fold_coop_kernel<F_, 16><<<cdiv(n * 16, 256), 256, 0, c->L->stream>>>((uint32_t)n, depth, c->fk[F_], c->pparams[field].as<PoseidonParams>(),
+                c->merkle_salts[field].as<fe_t>(), d_leaves, d_sib, d_dirs, d_roots);
+        });
+    } else if (n <= COOP8_MAX_GROUPS) {                          // latency-bound batch: 8 lanes per path
         DISPATCH_FIELD(field, {
             merkle_fold_coop_kernel<F_, 8><<<cdiv(n * 8, 256), 256, 0, c->L->stream>>>((uint32_t)n, depth, c->fk[F_], c->pparams[field].as<PoseidonParams>(),
                 c->merkle_salts[field].as<fe_t>(), d_leaves, d_sib, d_dirs, d_roots);
