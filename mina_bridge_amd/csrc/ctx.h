@@ -149,10 +149,12 @@ static inline bool use_coop16(const mina_ctx *c, size_t proofs) {
     return proofs * (size_t)(c ? c->nlanes : 1) <= lim;
 }
 
-// independent per-item host work over up to 16 threads (items are ~0.01 - 0.1 ms each: threads only when there are enough of them)
+// independent per-item host work over up to 64 threads, at most half the cores ($MINA_HOST_THREADS overrides the cap; items are ~0.01 - 0.1 ms
+// each: threads only when there are enough of them)
 template <class Fn> static inline void mb_parallel_for(size_t n, Fn fn) {
-    const size_t hw = std::thread::hardware_concurrency();
-    const size_t nt = std::min<size_t>(std::min<size_t>(hw ? hw : 1, 16), n / 64);     // a thread costs ~50 us to start: at least 64 items each
+    static const size_t cap = [] { if (const char *e = getenv("MINA_HOST_THREADS")) return (size_t)std::max(1L, atol(e));
+                                   const size_t hw = std::thread::hardware_concurrency(); return std::max<size_t>(1, std::min<size_t>(hw / 2, 64)); }();
+    const size_t nt = std::min<size_t>(cap, n / 64);     // a thread costs ~50 us to start: at least 64 items each
     auto work = [&](size_t t) { for (size_t i = t; i < n; i += (nt ? nt : 1)) fn(i); };
     if (nt <= 1) { work(0); return; }
     std::vector<std::thread> th;

@@ -257,8 +257,10 @@ def verify_state_checks(proof: bytes, pub: bytes):
 
 
 def _ptr_arrays(items):
-    arrs = [_u8(x) if len(x) else np.zeros(1, np.uint8) for x in items]
     n = len(items)
+    if all(type(x) is bytes for x in items):               # zero-copy: the pointers are the bytes objects' own buffers (kept alive by `items`)
+        return items, (ctypes.c_char_p * n)(*items), (ctypes.c_size_t * n)(*map(len, items))
+    arrs = [_u8(x) if len(x) else np.zeros(1, np.uint8) for x in items]
     return arrs, (ctypes.c_void_p * n)(*[a.ctypes.data for a in arrs]), (ctypes.c_size_t * n)(*[len(x) for x in items])
 
 
