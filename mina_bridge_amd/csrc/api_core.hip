@@ -69,7 +69,7 @@ extern "C" void mina_ctx_destroy(mina_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     for (int i = 0; i < MB_MAX_LANES; ++i) if (c->lanes[i].stream) (void)hipStreamSynchronize(c->lanes[i].stream);
-    for (int i = 0; i < 2; ++i) { c->srs[i].table.release(); c->srs[i].h.release(); c->pparams[i].release(); c->merkle_salts[i].release(); }
+    for (int i = 0; i < 2; ++i) { c->srs[i].table.release(); c->srs[i].h.release(); c->srs[i].lagrange_table.release(); c->srs[i].lagrange_digits.release(); c->pparams[i].release(); c->merkle_salts[i].release(); }
     c->state_salts.release(); c->kimchi_index.release(); c->kimchi_tokens.release(); c->kimchi_literals.release();
     c->pickles_index.release(); c->pickles_tokens.release(); c->pickles_literals.release();
     for (int i = 0; i < MB_MAX_LANES; ++i) c->lanes[i].release_all();

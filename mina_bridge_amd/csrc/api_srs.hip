@@ -260,7 +260,14 @@ template <int F> static int build_lagrange_table(mina_ctx *c, SrsState &s, uint3
     points_to_mont_kernel<F><<<cdiv(n_tab, 256), 256, 0, c->L->stream>>>(n_tab, c->L->tmp_a.as<uint32_t>(), fk.r2, s.lagrange_table.as<affine_t>());
     msm_build_table_kernel<F><<<cdiv(n_tab, 256), 256, 0, c->L->stream>>>(n_tab, n_tab, LAG_C, LAG_W, fk.one, fk.pm2, s.lagrange_table.as<affine_t>());
     HIPC(hipGetLastError());
+    // the first <= 64 points also get their 128 digit multiples per window (direct commitments, lagrange.cuh)
+    const uint32_t n_dig = std::min<uint32_t>(n_tab, mb::LAGD_MAX_POINTS);
+    s.lagrange_digits_n = 0;
+    if ((rc = s.lagrange_digits.ensure((size_t)n_dig * mb::LAGD_WINDOWS * mb::LAGD_DIGITS * sizeof(affine_t)))) return rc;
+    mb::lagrange_digit_table_kernel<F><<<cdiv(n_dig * mb::LAGD_WINDOWS, 64), 64, 0, c->L->stream>>>(n_dig, n_tab, fk, s.lagrange_table.as<affine_t>(), s.lagrange_digits.as<affine_t>());
+    HIPC(hipGetLastError());
     HIPC(hipStreamSynchronize(c->L->stream));
+    s.lagrange_digits_n = n_dig;
     return MINA_OK;
 }
 

@@ -273,7 +273,14 @@ int mb_pubcomm_dev(mina_ctx *c, size_t batch, uint32_t log2_domain, uint32_t npu
         HIPC(hipMemsetAsync(L.st_pub_xyzz.p, 0, batch * sizeof(xyzz_t), L.stream));
     } else {
         if (s.lagrange_table_log2 != (int)log2_domain || s.lagrange_table_n < npub) return fail(MINA_ERR_STATE, "call mina_state_jobs_prepare(log2_domain, npub) first");
-        if ((rc = mb_msm_table(c, CURVE_PALLAS, s.lagrange_table.p, s.lagrange_table_n, 8, 32, 0, npub, (uint32_t)batch, d_pub, nullptr, L.st_pub_xyzz.p))) return rc;
+        static const bool generic = getenv("MINA_PUBCOMM_GENERIC_MSM") != nullptr;      // A/B switch: the multi-problem bucket MSM
+        if (!generic && npub <= s.lagrange_digits_n) {
+            ProfScope ps_(c, PS_ACCUMULATE);
+            if (batch * (size_t)c->nlanes <= 1024)
+                mb::pubcomm_direct_kernel<FIELD_FP, 64><<<(uint32_t)batch, 64, 0, L.stream>>>((uint32_t)batch, npub, c->fk[FIELD_FP], s.lagrange_digits.as<affine_t>(), d_pub, L.st_pub_xyzz.as<xyzz_t>());
+            else
+                mb::pubcomm_direct_kernel<FIELD_FP, 8><<<cdiv(batch * 8, 64), 64, 0, L.stream>>>((uint32_t)batch, npub, c->fk[FIELD_FP], s.lagrange_digits.as<affine_t>(), d_pub, L.st_pub_xyzz.as<xyzz_t>());
+        } else if ((rc = mb_msm_table(c, CURVE_PALLAS, s.lagrange_table.p, s.lagrange_table_n, 8, 32, 0, npub, (uint32_t)batch, d_pub, nullptr, L.st_pub_xyzz.p))) return rc;
     }
     mb::pubcomm_finish16_kernel<FIELD_FP><<<cdiv(batch, 64), 64, 0, L.stream>>>((uint32_t)batch, c->fk[FIELD_FP], s.h.as<affine_t>(), L.st_pub_xyzz.as<xyzz_t>(), d_out16);
     HIPC(hipGetLastError());

@@ -63,6 +63,8 @@ struct SrsState {
     DevBuf lagrange_table;             // window table (c = 8, W = 32) of the first lagrange_table_n basis points, for
     uint32_t lagrange_table_n = 0;     //   batched public-input commitments
     int lagrange_table_log2 = -1;
+    DevBuf lagrange_digits;            // d * 2^(8w) * L_i, d = 1..128, of the first lagrange_digits_n (<= 64) basis points (lagrange.cuh: direct commitments)
+    uint32_t lagrange_digits_n = 0;
 };
 
 struct MsmWorkspace {

@@ -105,4 +105,67 @@ pubcomm_finish_kernel(uint32_t batch, FieldK kb, const affine_t *__restrict__ h,
     o[16] = 0;
 }
 
+// ---------------------------------------------------------------- direct public-input commitments (the batch's per-proof 40-term MSMs)
+// The generic multi-problem MSM gives every proof its own 128 buckets: sort, accumulate, 2-D bucket reduction -- 1.64 G of a step's 19.4 G
+// VALU instructions and ten launches, a third of it the reduction of buckets that hold ~10 points each.  With npub <= 64 fixed bases the
+// multiples themselves fit a table (d * 2^(8w) * L_i for d = 1..128: npub x 32 x 128 points = 10.5 MB at npub = 40), so a commitment is
+// 32 npub table lookups added straight into one accumulator: no buckets, no sort, no reduction, ONE launch.  Eight lanes per proof take
+// the scalars round-robin (5 each at npub = 40) and their partial sums are added by shuffles.  Same signed-digit rule as msm_entry.
+static constexpr uint32_t LAGD_MAX_POINTS = 64, LAGD_WINDOWS = 32, LAGD_DIGITS = 128;
+// digits[((i * 32 + w) * 128) + (d - 1)] = d * window[w * stride + i], Montgomery affine, (0, 0) = infinity; one thread per (i, w)
+template <int F>
+__global__ void lagrange_digit_table_kernel(uint32_t n_pts, uint32_t stride, FieldK fk, const affine_t *__restrict__ window, affine_t *__restrict__ digits) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_pts * LAGD_WINDOWS) return;
+    const uint32_t i = t / LAGD_WINDOWS, w = t % LAGD_WINDOWS;
+    const affine_t P = window[(size_t)w * stride + i];
+    affine_t *out = digits + (size_t)t * LAGD_DIGITS;
+    xyzz_t acc = xyzz_inf();
+#pragma unroll 1
+    for (uint32_t d = 0; d < LAGD_DIGITS; ++d) {
+        affine_t o; o.x = fe_zero(); o.y = fe_zero();
+        if (!aff_is_inf(P)) {
+            xyzz_add_affine<F>(acc, P.x, P.y, fk.one);           // (d + 1) P
+            if (!xyzz_is_inf(acc)) {
+                const fe_t zi = fe_inv<F>(fe_mul<F>(acc.zz, acc.zzz), fk);
+                o.x = fe_mul<F>(acc.x, fe_mul<F>(zi, acc.zzz)); o.y = fe_mul<F>(acc.y, fe_mul<F>(zi, acc.zz));
+            }
+        }
+        out[d] = o;
+    }
+}
+// out[b] = sum_i pub[b][i] * L_i (XYZZ); pub = canonical 32-byte scalars below 2^255 (words); LPP lanes per proof: 8 for chip-filling
+// batches (5 scalars = 160 additions per lane at npub = 40), 64 for small ones (one scalar = 32 additions per lane, then a 6-level sum)
+template <int F, int LPP>
+__global__ void __launch_bounds__(64)
+pubcomm_direct_kernel(uint32_t batch, uint32_t npub, FieldK fk, const affine_t *__restrict__ digits, const uint32_t *__restrict__ pub, xyzz_t *__restrict__ out) {
+    const uint32_t gid = blockIdx.x * 64 + threadIdx.x, b = gid / LPP, l = gid % LPP;
+    const bool live = b < batch;
+    xyzz_t acc = xyzz_inf();
+    if (live) {
+#pragma unroll 1
+        for (uint32_t i = l; i < npub; i += LPP) {
+            const uint32_t *sc = pub + ((size_t)b * npub + i) * 8;
+            const affine_t *row = digits + (size_t)i * LAGD_WINDOWS * LAGD_DIGITS;
+            uint32_t carry = 0, word = 0;
+#pragma unroll 1
+            for (uint32_t w = 0; w < LAGD_WINDOWS; ++w) {
+                if ((w & 3u) == 0) word = sc[w >> 2];
+                uint32_t d = ((word >> (8 * (w & 3u))) & 0xffu) + carry;
+                const bool neg = d > 128u;
+                carry = neg ? 1u : 0u;
+                if (neg) d = 256u - d;
+                if (d == 0) continue;
+                affine_t P = row[(size_t)w * LAGD_DIGITS + (d - 1)];
+                if (aff_is_inf(P)) continue;
+                if (neg) P.y = fe_neg<F>(P.y);
+                xyzz_add_affine<F>(acc, P.x, P.y, fk.one);
+            }
+        }
+    }
+#pragma unroll 1
+    for (int d = LPP / 2; d >= 1; d >>= 1) { const xyzz_t o = shfl_down_xyzz(acc, d); if ((int)l + d < LPP) xyzz_add<F>(acc, o); }
+    if (live && l == 0) out[b] = acc;
+}
+
 }  // namespace mb
