@@ -290,6 +290,25 @@ int mb_ensure_lagrange_table(mina_ctx *c, int curve, uint32_t log2_domain, uint3
     return MINA_OK;
 }
 
+// sum_i scalars[b][i] * L_i for `batch` proofs (XYZZ, one per proof) on the current lane; the table must be current (mb_ensure_lagrange_table).
+// <= 64 inputs: straight from the digit table (lagrange.cuh), else one bucket problem per proof of the multi-problem MSM.
+int mb_lagrange_sums_dev(mina_ctx *c, int curve, uint32_t npub, size_t batch, const uint32_t *d_scalars, void *d_out_xyzz) {
+    SrsState &s = c->srs[curve];
+    static const bool generic = getenv("MINA_PUBCOMM_GENERIC_MSM") != nullptr;      // A/B switch: always the bucket MSM
+    if (generic || npub > s.lagrange_digits_n)
+        return mb_msm_table(c, curve, s.lagrange_table.p, s.lagrange_table_n, LAG_C, LAG_W, 0, npub, (uint32_t)batch, d_scalars, nullptr, d_out_xyzz);
+    ProfScope ps_(c, PS_ACCUMULATE);
+    const int FB = base_field_of(curve);
+    hipStream_t st = c->L->stream;
+    if (batch * (size_t)c->nlanes <= 1024) {
+        DISPATCH_FIELD(FB, { mb::pubcomm_direct_kernel<F_, 64><<<(uint32_t)batch, 64, 0, st>>>((uint32_t)batch, npub, c->fk[F_], s.lagrange_digits.as<affine_t>(), d_scalars, (xyzz_t *)d_out_xyzz); });
+    } else {
+        DISPATCH_FIELD(FB, { mb::pubcomm_direct_kernel<F_, 8><<<cdiv(batch * 8, 64), 64, 0, st>>>((uint32_t)batch, npub, c->fk[F_], s.lagrange_digits.as<affine_t>(), d_scalars, (xyzz_t *)d_out_xyzz); });
+    }
+    HIPC(hipGetLastError());
+    return MINA_OK;
+}
+
 extern "C" int mina_public_input_commitment_batch(mina_ctx *c, int curve, uint32_t log2_domain, size_t npub, size_t batch,
                                                   const uint8_t *public_inputs, uint8_t *out_affine) {
     if (!c || (batch && !out_affine) || (npub && batch && !public_inputs)) return fail(MINA_ERR_ARG, "null argument");
@@ -316,8 +335,7 @@ extern "C" int mina_public_input_commitment_batch(mina_ctx *c, int curve, uint32
     if ((rc = c->L->tmp_b.ensure(batch * sizeof(xyzz_t)))) return rc;
     if ((rc = w.out_words.ensure(batch * 17 * 4))) return rc;
     if ((rc = h2d(c, w.scalars, public_inputs, batch * npub * 32))) return rc;
-    if ((rc = mb_msm_table(c, curve, s.lagrange_table.p, s.lagrange_table_n, LAG_C, LAG_W, 0, (uint32_t)npub, (uint32_t)batch,
-                           w.scalars.as<uint32_t>(), nullptr, c->L->tmp_b.p))) return rc;
+    if ((rc = mb_lagrange_sums_dev(c, curve, (uint32_t)npub, batch, w.scalars.as<uint32_t>(), c->L->tmp_b.p))) return rc;
     DISPATCH_FIELD(FB, { pubcomm_finish_kernel<F_><<<cdiv(batch, 64), 64, 0, c->L->stream>>>((uint32_t)batch, c->fk[F_], s.h.as<affine_t>(), c->L->tmp_b.as<xyzz_t>(), w.out_words.as<uint32_t>()); });
     HIPC(hipGetLastError());
     std::vector<uint32_t> hw(batch * 17);

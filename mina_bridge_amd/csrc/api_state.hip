@@ -257,6 +257,7 @@ static int check_jobs(mina_ctx *c, const mina_state_jobs *j) {
 }
 
 int mb_ensure_lagrange_table(mina_ctx *c, int curve, uint32_t log2_domain, uint32_t npub);   // api_srs.hip
+int mb_lagrange_sums_dev(mina_ctx *c, int curve, uint32_t npub, size_t batch, const uint32_t *d_scalars, void *d_out_xyzz);
 namespace mb {   // api_kimchi.hip
 struct KimchiIn { const uint32_t *pub, *prev_chals, *prev_comms, *w_comm, *z_comm, *t_comm, *evals, *ft_eval1, *pubcomm; };
 struct KimchiOut { uint32_t *sponge_state, *sponge_pos, *cip, *evalpoints, *polyscale, *evalscale, *comms, *ft_eval0; };
@@ -273,14 +274,7 @@ int mb_pubcomm_dev(mina_ctx *c, size_t batch, uint32_t log2_domain, uint32_t npu
         HIPC(hipMemsetAsync(L.st_pub_xyzz.p, 0, batch * sizeof(xyzz_t), L.stream));
     } else {
         if (s.lagrange_table_log2 != (int)log2_domain || s.lagrange_table_n < npub) return fail(MINA_ERR_STATE, "call mina_state_jobs_prepare(log2_domain, npub) first");
-        static const bool generic = getenv("MINA_PUBCOMM_GENERIC_MSM") != nullptr;      // A/B switch: the multi-problem bucket MSM
-        if (!generic && npub <= s.lagrange_digits_n) {
-            ProfScope ps_(c, PS_ACCUMULATE);
-            if (batch * (size_t)c->nlanes <= 1024)
-                mb::pubcomm_direct_kernel<FIELD_FP, 64><<<(uint32_t)batch, 64, 0, L.stream>>>((uint32_t)batch, npub, c->fk[FIELD_FP], s.lagrange_digits.as<affine_t>(), d_pub, L.st_pub_xyzz.as<xyzz_t>());
-            else
-                mb::pubcomm_direct_kernel<FIELD_FP, 8><<<cdiv(batch * 8, 64), 64, 0, L.stream>>>((uint32_t)batch, npub, c->fk[FIELD_FP], s.lagrange_digits.as<affine_t>(), d_pub, L.st_pub_xyzz.as<xyzz_t>());
-        } else if ((rc = mb_msm_table(c, CURVE_PALLAS, s.lagrange_table.p, s.lagrange_table_n, 8, 32, 0, npub, (uint32_t)batch, d_pub, nullptr, L.st_pub_xyzz.p))) return rc;
+        if ((rc = mb_lagrange_sums_dev(c, CURVE_PALLAS, npub, batch, d_pub, L.st_pub_xyzz.p))) return rc;
     }
     mb::pubcomm_finish16_kernel<FIELD_FP><<<cdiv(batch, 64), 64, 0, L.stream>>>((uint32_t)batch, c->fk[FIELD_FP], s.h.as<affine_t>(), L.st_pub_xyzz.as<xyzz_t>(), d_out16);
     HIPC(hipGetLastError());

@@ -96,6 +96,33 @@ def test_public_input_commitment_batch(ctx_srs, oracle, srs_oracle, curve, k, np
     assert ctx_srs.public_input_commitment_batch(curve, k, np.zeros((0, 32), np.uint8), 0).shape == (0, 64)
 
 
+def test_public_input_commitment_digit_table_edge_scalars(ctx_srs, oracle, srs_oracle):
+    """commitments of <= 64 inputs come straight from the table of digit multiples d * 2^(8w) * L_i (lagrange.cuh): scalars whose bytes sit
+    on the signed-digit boundaries (0x80, 0x7f, 0xff runs that carry through every window, r - 1, powers of two, zero) in the 64-lane form
+    (small batch) and the 8-lane form (> 1024 proofs), against the oracle's naive sum; the tiled rows must repeat"""
+    from oracle import pasta_ref as R
+    curve, k, npub = 0, 6, 40
+    g, h = srs_oracle[curve]
+    r = R.scalar_modulus(curve); mod = R.base_modulus(curve)
+    pats = [0, 1, r - 1, r - 2, (1 << 254) - 1, int.from_bytes(b"\x80" * 31 + b"\x00", "little"), int.from_bytes(b"\x7f" * 31 + b"\x3f", "little"),
+            int.from_bytes(b"\xff" * 31 + b"\x1f", "little"), int.from_bytes(b"\x81\x7f" * 15 + b"\x80\x00", "little"), 1 << 248, (1 << 248) - 1, 128, 129, 255, 256, (1 << 128) - 1]
+    rng = np.random.Generator(np.random.PCG64(5))
+    rows = 6
+    vals = [[pats[(m * 7 + i * 3) % len(pats)] if (m + i) % 4 else int(rng.integers(0, 1 << 62)) * pats[4] % r for i in range(npub)] for m in range(rows)]
+    pub = np.stack([oracle.ints_to_le(v) for v in vals])
+    basis = ctx_srs.srs_lagrange_basis(curve, k)
+    want = []
+    for m in range(rows):
+        a = oracle.bytes_to_point(oracle.msm_naive(curve, basis[:npub], pub[m]))
+        want.append(R.add(oracle.bytes_to_point(h), R.neg(a, mod), mod))
+    got = ctx_srs.public_input_commitment_batch(curve, k, pub, rows)
+    assert [oracle.bytes_to_point(x) for x in got] == want
+    reps = 1100 // rows + 1
+    big = np.tile(pub, (reps, 1, 1))
+    got2 = ctx_srs.public_input_commitment_batch(curve, k, big, rows * reps)
+    assert (got2.reshape(reps, rows, 64) == got[None]).all()
+
+
 def test_combined_inner_product_matches_restatement(oracle):
     import mina_bridge_amd as m
     from conftest import rand_scalars
