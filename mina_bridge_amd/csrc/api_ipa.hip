@@ -100,7 +100,8 @@ ipa_prepare_kernel(IpaShape sh, FieldK kb, FieldK ks, const PoseidonParams *__re
                    affine_t *__restrict__ out_points /* b*per */, uint32_t *__restrict__ out_scalars /* b*per*8 canonical */,
                    uint32_t *__restrict__ out_chals /* b*k*8 canonical */, uint32_t *__restrict__ out_sigma /* b*8 canonical */,
                    uint32_t *__restrict__ bad_input /* zeroed by the host; set to 1 on a malformed point */,
-                   uint32_t *__restrict__ xfer /* PHASE 1 writes, PHASE 2 reads: b * IPA_XFER_WORDS */) {
+                   uint32_t *__restrict__ xfer /* PHASE 1 writes, PHASE 2 reads: b * IPA_XFER_WORDS */,
+                   uint32_t *__restrict__ shared_sc /* b * nshared * 8 canonical, or null */, uint32_t *__restrict__ shared_off /* nshared list offsets */) {
     constexpr int FB = (CURVE == CURVE_PALLAS) ? FIELD_FP : FIELD_FQ;
     constexpr int FS = (CURVE == CURVE_PALLAS) ? FIELD_FQ : FIELD_FP;
     bool writer_; const uint32_t b = coop_sponge_index<LANES>(writer_);
@@ -155,6 +156,17 @@ ipa_prepare_kernel(IpaShape sh, FieldK kb, FieldK ks, const PoseidonParams *__re
 
     affine_t *pts = out_points + (size_t)b * sh.per;
     uint32_t *scs = out_scalars + (size_t)b * sh.per * 8;
+    // entries whose point is shared by the whole batch: zero scalar in the list, the real one in the side matrix, the point once at the tail
+    uint32_t shq = 0;
+    auto put = [&](uint32_t o, const affine_t &P, const fe_t &sc_canon, bool shared) {
+        store_pt<LANES>(&pts[o], P);
+        if (shared && sh.nshared) {
+            store_fe<LANES>(scs + (size_t)o * 8, fe_zero());
+            store_fe<LANES>(shared_sc + ((size_t)b * sh.nshared + shq) * 8, sc_canon);
+            if (b == 0) { store_pt<LANES>(out_points + (size_t)sh.batch * sh.per + shq, P); if (coop_writer<LANES>()) shared_off[shq] = o; }
+            ++shq;
+        } else store_fe<LANES>(scs + (size_t)o * 8, sc_canon);
+    };
 
     // rho = rand_base^b, sigma = sg_rand_base^b
     fe_t rho = ks.one, sigma = ks.one;
@@ -208,7 +220,7 @@ ipa_prepare_kernel(IpaShape sh, FieldK kb, FieldK ks, const PoseidonParams *__re
     const fe_t neg_rho = fe_neg<FS>(rho);
     const fe_t rho_c = fe_mul<FS>(rho, c);
 
-    store_pt<LANES>(&pts[0], *srs_h);               store_fe<LANES>(scs + 0 * 8, fe_from_mont<FS>(fe_mul<FS>(neg_rho, z2m)));
+    put(0, *srs_h, fe_from_mont<FS>(fe_mul<FS>(neg_rho, z2m)), sh.shared_h != 0);
     store_pt<LANES>(&pts[1], load_point_checked<FB>(sg + (size_t)b * 16, kb, pts_ok));
     store_fe<LANES>(scs + 1 * 8, fe_from_mont<FS>(fe_sub<FS>(fe_mul<FS>(neg_rho, z1m), sigma)));
     if (PHASE == 0) store_pt<LANES>(&pts[2], U);                // PHASE 2: written by ipa_to_group_kernel
@@ -232,19 +244,41 @@ ipa_prepare_kernel(IpaShape sh, FieldK kb, FieldK ks, const PoseidonParams *__re
         const fe_t wgt = fe_mul<FS>(rho_c, xi_i);
         if (i == sh.expand_slot) {                            // a linear combination in place of the point: the MSM evaluates it
             for (uint32_t j = 0; j < IPA_EXPAND; ++j, ++o) {
-                store_pt<LANES>(&pts[o], j == 0 ? *ex.p0 : load_point_checked<FB>(ex.pts + ((size_t)b * (IPA_EXPAND - 1) + (j - 1)) * 16, kb, pts_ok));
-                store_fe<LANES>(scs + (size_t)o * 8, fe_from_mont<FS>(fe_mul<FS>(wgt, ex.sc[(size_t)b * ex.stride + j])));
+                put(o, j == 0 ? *ex.p0 : load_point_checked<FB>(ex.pts + ((size_t)b * (IPA_EXPAND - 1) + (j - 1)) * 16, kb, pts_ok),
+                    fe_from_mont<FS>(fe_mul<FS>(wgt, ex.sc[(size_t)b * ex.stride + j])), j == 0 && sh.shared_expand0 != 0);
             }
         } else {
             const uint32_t *cp = (i == sh.override_slot && comm_override) ? comm_override + (size_t)b * 16 : comms + ((size_t)b * sh.ncomms + i) * 16;
-            store_pt<LANES>(&pts[o], load_point_checked<FB>(cp, kb, pts_ok));
-            store_fe<LANES>(scs + (size_t)o * 8, fe_from_mont<FS>(wgt));
+            put(o, load_point_checked<FB>(cp, kb, pts_ok), fe_from_mont<FS>(wgt), i < 64 && (((i < 32 ? sh.shared_lo >> i : sh.shared_hi >> (i - 32)) & 1u) != 0));
             ++o;
         }
         xi_i = fe_mul<FS>(xi_i, xi);
     }
     store_fe<LANES>(out_sigma + (size_t)b * 8, fe_from_mont<FS>(sigma));
     if (!pts_ok && coop_writer<LANES>()) *bad_input = 1u;         // any malformed point in any proof: the batch verdict is 0
+}
+
+// Scalars of the batch-shared points (IpaShape::shared_*): their sum over the batch -> the `nsh` tail entries of the list (canonical words; a sum
+// mod r does not care about the representation).  One block per shared entry.
+template <int FS>
+__global__ void __launch_bounds__(256)
+ipa_shared_tail_kernel(uint32_t batch, uint32_t nsh, uint32_t per, const uint32_t *__restrict__ shared_sc, uint32_t *__restrict__ scalars) {
+    __shared__ fe_t red[256];
+    const uint32_t q = blockIdx.x, tid = threadIdx.x;
+    fe_t acc = fe_zero();
+    for (uint32_t b = tid; b < batch; b += 256) acc = fe_add<FS>(acc, load_fe<FS>(shared_sc + ((size_t)b * nsh + q) * 8));
+    red[tid] = acc;
+    __syncthreads();
+    for (uint32_t s = 128; s; s >>= 1) { if (tid < s) red[tid] = fe_add<FS>(red[tid], red[tid + s]); __syncthreads(); }
+    if (tid == 0) for (int i = 0; i < 8; ++i) scalars[((size_t)batch * per + q) * 8 + i] = red[0].v[i];
+}
+// the culprit search re-checks slices of the rows: give the proofs [lo, lo + cnt) their own scalars of the shared points back
+__global__ void ipa_shared_restore_kernel(uint32_t lo, uint32_t cnt, uint32_t nsh, uint32_t per, const uint32_t *__restrict__ shared_off,
+                                          const uint32_t *__restrict__ shared_sc, uint32_t *__restrict__ scalars) {
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (size_t)cnt * nsh * 8) return;
+    const uint32_t w = (uint32_t)(gid & 7u), q = (uint32_t)((gid >> 3) % nsh); const size_t b = lo + (gid >> 3) / nsh;
+    scalars[(b * per + shared_off[q]) * 8 + w] = shared_sc[(b * nsh + q) * 8 + w];
 }
 
 // U_b = to_group(t_b) for the split transcript: one lane per proof, t in Montgomery form from the hand-over buffer
@@ -437,7 +471,8 @@ int mb_ipa_batch_check_dev(mina_ctx *c, int curve, mb::IpaShape sh, const mb::Ip
     const int FB = base_field_of(curve), FS = scalar_field_of(curve);
     const size_t batch = sh.batch; const uint32_t k = sh.k;
     int rc;
-    const size_t npoints = batch * sh.per;
+    if (sh.nshared && (sh.ncomms > 64 || sh.nshared > 64)) return fail(MINA_ERR_ARG, "shared entries need <= 64 commitments");
+    const size_t npoints = batch * sh.per + sh.nshared;           // per-proof lists, then the batch-shared points once
     if ((rc = c->L->ipa_points.ensure(npoints * sizeof(affine_t)))) return rc;
     if ((rc = c->L->ipa_scalars.ensure(npoints * 32))) return rc;
     if ((rc = c->L->ipa_chals.ensure(batch * k * 32))) return rc;
@@ -445,13 +480,15 @@ int mb_ipa_batch_check_dev(mina_ctx *c, int curve, mb::IpaShape sh, const mb::Ip
     if ((rc = c->L->ipa_folded.ensure(((size_t)1 << k) * 32))) return rc;
     if ((rc = c->L->ipa_xyzz_a.ensure(sizeof(xyzz_t)))) return rc;
     if ((rc = c->L->ipa_xyzz_b.ensure(sizeof(xyzz_t)))) return rc;
+    if (sh.nshared) { if ((rc = c->L->ipa_shared.ensure(batch * sh.nshared * 32))) return rc; if ((rc = c->L->ipa_shared_off.ensure(sh.nshared * 4))) return rc; }
     HIPC(hipMemsetAsync(d_verdict, 0, 8, c->L->stream));
     const PoseidonParams *pp = c->pparams[FB].as<PoseidonParams>();
 #define IPA_PREP(CV, LN, PH, STREAM)                                                                                          \
     mb::ipa_prepare_kernel<CV, LN, PH><<<cdiv(coop_threads<LN>(batch), 64), 64, 0, STREAM>>>(                                                      \
         sh, c->fk[FB], c->fk[FS], pp, in.state, in.pos, in.cip, in.lr, in.delta, in.sg, in.z1, in.z2, in.pts, in.r, \
         in.xi, in.comms, in.comm_override, in.expand, in.rb, in.sb, s.h.as<affine_t>(), c->L->ipa_points.as<affine_t>(), c->L->ipa_scalars.as<uint32_t>(), \
-        c->L->ipa_chals.as<uint32_t>(), c->L->ipa_sigma.as<uint32_t>(), d_verdict + 1, c->L->ipa_xfer.as<uint32_t>())
+        c->L->ipa_chals.as<uint32_t>(), c->L->ipa_sigma.as<uint32_t>(), d_verdict + 1, c->L->ipa_xfer.as<uint32_t>(),          \
+        c->L->ipa_shared.as<uint32_t>(), c->L->ipa_shared_off.as<uint32_t>())
     { ProfScope ps_(c, PS_IPA_TRANSCRIPT);
     {
         // the transcript splits at its first squeeze: to_group (one lane per proof) runs on a second stream beside the rest.  8 lanes per
@@ -484,12 +521,13 @@ int mb_ipa_batch_check_dev(mina_ctx *c, int curve, mb::IpaShape sh, const mb::Ip
     }
 #undef IPA_PREP
     HIPC(hipGetLastError());
+    if (sh.nshared) { DISPATCH_FIELD(FS, { mb::ipa_shared_tail_kernel<F_><<<sh.nshared, 256, 0, c->L->stream>>>(sh.batch, sh.nshared, sh.per, c->L->ipa_shared.as<uint32_t>(), c->L->ipa_scalars.as<uint32_t>()); }); }
     if ((rc = mb_bpoly_fold(c, FS, k, batch, c->L->ipa_chals.as<uint32_t>(), c->L->ipa_sigma.as<uint32_t>(), c->L->ipa_folded.as<uint32_t>()))) return rc;
     if ((rc = mb_msm_fixed(c, curve, 1u << k, c->L->ipa_folded.as<uint32_t>(), nullptr, c->L->ipa_xyzz_a.p))) return rc;
     if ((rc = mb_msm_variable(c, curve, (uint32_t)npoints, c->L->ipa_scalars.as<uint32_t>(), c->L->ipa_points.p, nullptr, c->L->ipa_xyzz_b.p))) return rc;
     DISPATCH_FIELD(FB, { xyzz_compare_kernel<F_><<<1, 64, 0, c->L->stream>>>(c->L->ipa_xyzz_a.as<xyzz_t>(), c->L->ipa_xyzz_b.as<xyzz_t>(), 1, d_verdict, d_verdict + 1); });
     HIPC(hipGetLastError());
-    c->ipa_rows = c->L; c->ipa_rows_batch = sh.batch; c->ipa_rows_k = k; c->ipa_rows_per = sh.per; c->ipa_rows_curve = curve;
+    c->ipa_rows = c->L; c->ipa_rows_batch = sh.batch; c->ipa_rows_k = k; c->ipa_rows_per = sh.per; c->ipa_rows_nshared = sh.nshared; c->ipa_rows_curve = curve;
     return MINA_OK;
 }
 
@@ -508,6 +546,8 @@ int mb_ipa_recheck_rows(mina_ctx *c, size_t lo, size_t cnt, uint32_t *d_verdict)
     if ((rc = L.ipa_xyzz_a.ensure(sizeof(xyzz_t)))) return rc;
     if ((rc = L.ipa_xyzz_b.ensure(sizeof(xyzz_t)))) return rc;
     HIPC(hipMemsetAsync(d_verdict, 0, 8, L.stream));
+    if (const uint32_t nsh = c->ipa_rows_nshared)              // the slice's proofs get their own scalars of the batch-shared points back (idempotent)
+        mb::ipa_shared_restore_kernel<<<cdiv(cnt * nsh * 8, 256), 256, 0, L.stream>>>((uint32_t)lo, (uint32_t)cnt, nsh, per, src->ipa_shared_off.as<uint32_t>(), src->ipa_shared.as<uint32_t>(), src->ipa_scalars.as<uint32_t>());
     if ((rc = mb_bpoly_fold(c, FS, k, cnt, src->ipa_chals.as<uint32_t>() + lo * k * 8, src->ipa_sigma.as<uint32_t>() + lo * 8, L.ipa_folded.as<uint32_t>()))) return rc;
     if ((rc = mb_msm_fixed(c, curve, 1u << k, L.ipa_folded.as<uint32_t>(), nullptr, L.ipa_xyzz_a.p))) return rc;
     if ((rc = mb_msm_variable(c, curve, (uint32_t)(cnt * per), src->ipa_scalars.as<uint32_t>() + lo * per * 8, src->ipa_points.as<affine_t>() + lo * per, nullptr, L.ipa_xyzz_b.p))) return rc;

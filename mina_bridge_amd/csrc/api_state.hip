@@ -375,6 +375,12 @@ static int state_jobs_on_lane(mina_ctx *c, const mina_state_jobs *j, uint32_t *d
             mb::IpaExpand ex;
             if ((rc = mb_kimchi_to_batch_dev(c, B, kp.n_prev, kp.npub, in, out, kimchi_bad, &ex))) { c->L = L0; return rc; }
             sh.expand_slot = kp.n_prev + 1; sh.per += mb::IPA_EXPAND - 1;          // the ft commitment enters the MSM as its 8 terms
+            if (getenv("MINA_IPA_NO_SHARED") == nullptr && kp.n_prev + 45 <= 64) {   // h, the 27 index columns and the index point of the ft combination are the same
+                uint64_t m = 0;                                                       // points for every proof: their scalars are summed first (29 of 88 entries per proof)
+                for (uint32_t i = kp.n_prev + 3; i < kp.n_prev + 9; ++i) m |= (uint64_t)1 << i;        // 6 selectors
+                for (uint32_t i = kp.n_prev + 24; i < kp.n_prev + 45; ++i) m |= (uint64_t)1 << i;      // 15 coefficients + 6 sigma
+                sh.shared_lo = (uint32_t)m; sh.shared_hi = (uint32_t)(m >> 32); sh.shared_h = 1; sh.shared_expand0 = 1; sh.nshared = 29;
+            }
             mb::IpaDevIn iin{out.sponge_state, out.sponge_pos, out.cip, W(j->lr), W(j->delta), W(j->sg), W(j->z1), W(j->z2), out.evalpoints, out.evalscale, out.polyscale,
                              out.comms, nullptr, W(j->rand_base), W(j->sg_rand_base)};
             iin.expand = ex;

@@ -91,7 +91,7 @@ struct Lane {
     DevBuf tmp_a, tmp_b, tmp_c, tmp_d;       // staging for the host-buffer entry points
     PinnedBuf host_stage;                    // pinned host side of the big H2D blobs (synchronous entry points only)
     DevBuf bp_ltab, bp_htab, bp_partial, bp_ldig, bp_hdig, bp_colsum;
-    DevBuf ipa_chals, ipa_folded, ipa_xyzz_a, ipa_xyzz_b, ipa_points, ipa_scalars, ipa_sigma, ipa_in_a, ipa_in_b, ipa_in_c, ipa_verdict, ipa_xfer;
+    DevBuf ipa_chals, ipa_folded, ipa_xyzz_a, ipa_xyzz_b, ipa_points, ipa_scalars, ipa_sigma, ipa_in_a, ipa_in_b, ipa_in_c, ipa_verdict, ipa_xfer, ipa_shared, ipa_shared_off;
     DevBuf st_ok, st_hashes, st_pub_xyzz, st_pubcomm, st_flags, st_in, st_verdicts;   // Proof-of-State job (api_state.hip)
     DevBuf kc_state, kc_pos, kc_cip, kc_pts, kc_v, kc_u, kc_comms, kc_xfer, kc_pch, pk_xe, pk_pub, pk_ok;                  // kimchi to_batch output rows (api_kimchi.hip)
     void release_all() {
@@ -99,7 +99,7 @@ struct Lane {
         DevBuf *all[] = {&w.scalars, &w.points, &w.ekey, &w.eval, &w.eoff, &w.count, &w.start, &w.task_start, &w.rem_pos, &w.rem_bucket, &w.info, &w.sorted, &w.partial, &w.heavy, &w.order, &w.ghist, &w.stage,
                          &w.buckets, &w.red_r, &w.red_ws, &w.red2_r, &w.red2_w, &w.set_total, &w.out_words, &w.out_xyzz, &tmp_a, &tmp_b, &tmp_c, &tmp_d,
                          &bp_ltab, &bp_htab, &bp_partial, &bp_ldig, &bp_hdig, &bp_colsum, &ipa_chals, &ipa_folded, &ipa_xyzz_a, &ipa_xyzz_b, &ipa_points, &ipa_scalars,
-                         &ipa_sigma, &ipa_in_a, &ipa_in_b, &ipa_in_c, &ipa_verdict, &ipa_xfer,
+                         &ipa_sigma, &ipa_in_a, &ipa_in_b, &ipa_in_c, &ipa_verdict, &ipa_xfer, &ipa_shared, &ipa_shared_off,
                          &st_ok, &st_hashes, &st_pub_xyzz, &st_pubcomm, &st_flags, &st_in, &st_verdicts,
                          &kc_state, &kc_pos, &kc_cip, &kc_pts, &kc_v, &kc_u, &kc_comms, &kc_xfer, &kc_pch, &pk_xe, &pk_pub, &pk_ok};
         for (DevBuf *b : all) b->release();
@@ -116,7 +116,7 @@ struct mina_ctx {
     int nlanes = 1;
     unsigned rr = 0;                 // round-robin cursor of the `_dev` entry points
     Lane *L = nullptr;               // lane the current call runs on
-    Lane *ipa_rows = nullptr; uint32_t ipa_rows_batch = 0, ipa_rows_k = 0, ipa_rows_per = 0; int ipa_rows_curve = -1;   // lane holding the prepared rows of the last folded opening check (mb_ipa_recheck_rows)
+    Lane *ipa_rows = nullptr; uint32_t ipa_rows_batch = 0, ipa_rows_k = 0, ipa_rows_per = 0, ipa_rows_nshared = 0; int ipa_rows_curve = -1;   // lane holding the prepared rows of the last folded opening check (mb_ipa_recheck_rows)
     FieldK fk[2];
     SrsState srs[2];
     DevBuf pparams[2]; bool have_pparams[2] = {false, false};
@@ -202,7 +202,12 @@ struct ProfScope {
 
 // combined IPA opening check with inputs in HBM (api_ipa.hip)
 namespace mb {
-struct IpaShape { uint32_t batch, k, npts, ncomms, per; uint32_t override_slot = 0xffffffffu, expand_slot = 0xffffffffu; };   // per = 2k + ncomms + 4 points per proof
+struct IpaShape { uint32_t batch, k, npts, ncomms, per; uint32_t override_slot = 0xffffffffu, expand_slot = 0xffffffffu;
+                  uint32_t shared_lo = 0, shared_hi = 0, shared_h = 0, shared_expand0 = 0, nshared = 0; };   // per = 2k + ncomms + 4 points per proof
+// shared_*: list entries whose POINT is the same for every proof of the batch (the caller vouches: h, verifier-index commitments -- bits of
+//   shared_lo/hi over the commitment index, ncomms <= 64 --, the index point of the expanded slot).  Their scalars are summed over the batch
+//   first and enter the MSM ONCE, as `nshared` entries behind the per-proof lists (a third of a kimchi batch's 88 points per proof);
+//   the per-proof entries keep a zero scalar (the MSM drops zero digits) and the real one in a side matrix (culprit search restores it)
 // override_slot: commitment index whose point comes from `comm_override` (b*16 canonical words, e.g. the public-input commitment computed on the GPU)
 // expand_slot: commitment index given as a linear combination instead of a point (kimchi's chunked ft commitment): its list entry becomes
 //   IPA_EXPAND entries (point_j, weight * expand_sc[j]), so the combination is evaluated by the batch MSM; per grows by IPA_EXPAND - 1
