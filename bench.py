@@ -129,7 +129,9 @@ def build_full_job(ctx, m, B: int, seed: int):
     tile = lambda key, name: np.ascontiguousarray(np.stack([un(it[key][name]) if key else un(it[name]) for it in items])[idx].reshape(-1))
     n_old, n_evals = items[0]["n_old"], items[0]["n_evals"]
     st = m.MinaContext.make_pickles_statements(n_old, n_evals, {name: tile("statement", name) for name in m.lib.PicklesStatements.POINTER_FIELDS})
-    karr = {name: tile("kimchi", name) for name in items[0]["kimchi"]}
+    # no recursion challenges beside the statement: they are its messages_for_next_wrap_proof.old_bulletproof_challenges (the one source a
+    # verifier has; the library expands them and takes kimchi's digest of them on the way through the statement's own sponge)
+    karr = {name: tile("kimchi", name) for name in items[0]["kimchi"] if name not in ("prev_prechallenges", "prev_chals")}
     kp = m.MinaContext.make_kimchi_proofs(B, 2, NPUB, karr, statements=st)
     nd = min(B, 32)
     recs, nf, hashes = make_chains(ctx, nd, seed)

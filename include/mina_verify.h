@@ -445,7 +445,10 @@ typedef struct mina_kimchi_proofs {
      * malformed statement fails its proof.  Host struct; inner pointers host or device like the sections above. */
     const struct mina_pickles_statements *statements;
     /* NULL, or instead of prev_chals (which may then be NULL) the 128-bit prechallenges, b * n_prev * k * 16: expanded on the GPU
-     * (`ScalarChallenge::to_field` with the scalar field's endo coefficient) inside mina_state_job_batch[_dev] */
+     * (`ScalarChallenge::to_field` with the scalar field's endo coefficient) inside mina_state_job_batch[_dev].
+     * BOTH may be NULL when `statements` is given (n_prev = 2, k = 15): the recursion challenges are then the statement's
+     * messages_for_next_wrap_proof.old_bulletproof_challenges (`wrap_old_challenges`) -- the one source a verifier has -- and kimchi's
+     * digest of them comes out of the statement's own sponge (15 permutations per proof that are not repeated). */
     const void *prev_prechallenges;
 } mina_kimchi_proofs;
 typedef struct {                       /* one `BatchEvaluationProof` row per proof, host buffers */

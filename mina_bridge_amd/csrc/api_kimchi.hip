@@ -80,7 +80,8 @@ template <int F, int LANES> __device__ __forceinline__ fe_t coop_sum(const fe_t 
 template <int LANES>
 __global__ void __launch_bounds__(64)
 kimchi_fq_kernel(uint32_t batch, uint32_t n_prev, FieldK kb, FieldK ks, const PoseidonParams *__restrict__ pp_b, const PoseidonParams *__restrict__ pp_s,
-                 const KimchiIndexDev *__restrict__ ix, KimchiIn in, KimchiOut out, fe_t *__restrict__ xf, uint32_t *__restrict__ bad_input, uint32_t nblk) {
+                 const KimchiIndexDev *__restrict__ ix, KimchiIn in, KimchiOut out, fe_t *__restrict__ xf, uint32_t *__restrict__ bad_input, uint32_t nblk,
+                 const fe_t *__restrict__ pf_digest /* or null: role 1 computes it */, uint32_t pf_stride) {
     constexpr int FB = FIELD_FP, FS = FIELD_FQ;                 // Pallas: base Fp, scalar Fq
     bool writer; const uint32_t role = blockIdx.x / nblk, b = coop_role_item<LANES>(blockIdx.x % nblk, writer);       // one role per wave
     if (b >= batch) return;
@@ -95,6 +96,7 @@ kimchi_fq_kernel(uint32_t batch, uint32_t n_prev, FieldK kb, FieldK ks, const Po
         if (writer) { xf[(size_t)b * KC_XF + XF_PFDIGEST] = d; if (!ok) *bad_input = 1u; }
         return;
     }
+    if (pf_digest && writer) xf[(size_t)b * KC_XF + XF_PFDIGEST] = pf_digest[(size_t)b * pf_stride];     // the statement stage ran that sponge already (api_pickles.hip)
     DevSponge<FB, LANES> fq; sponge_init(fq, pp_b);
     fq.absorb(ix->digest);
     auto absorb_pts = [&](const uint32_t *p, uint32_t n) {
@@ -353,7 +355,8 @@ extern "C" int mina_verifier_index_digest(mina_ctx *c, uint8_t *out32) {
 // queue oracles + to_batch for `batch` proofs on the current lane; every pointer is a device pointer
 // `expand` non-null: row n_prev + 1 of the commitment list is NOT computed; *expand describes it as 8 (point, scalar) pairs for
 // mb_ipa_batch_check_dev (IpaShape::expand_slot = n_prev + 1)
-int mb_kimchi_to_batch_dev(mina_ctx *c, size_t batch, uint32_t n_prev, uint32_t npub, const mb::KimchiIn &in, const mb::KimchiOut &out, uint32_t *d_bad, mb::IpaExpand *expand) {
+int mb_kimchi_to_batch_dev(mina_ctx *c, size_t batch, uint32_t n_prev, uint32_t npub, const mb::KimchiIn &in, const mb::KimchiOut &out, uint32_t *d_bad, mb::IpaExpand *expand,
+                           const void *pf_digest, uint32_t pf_stride) {
     if (!c->have_kimchi) return fail(MINA_ERR_STATE, "no verifier index installed");
     const PoseidonParams *ppb = c->pparams[FIELD_FP].as<PoseidonParams>(), *pps = c->pparams[FIELD_FQ].as<PoseidonParams>();
     ProfScope ps_(c, PS_KIMCHI);
@@ -368,16 +371,17 @@ int mb_kimchi_to_batch_dev(mina_ctx *c, size_t batch, uint32_t n_prev, uint32_t 
     // 8-lane sponges up to 1024 proofs per call (shortest dependent chain), 3-lane above: measured on bench.py --kimchi, 8192 proofs
     // per step -- 16 x 512: 165 k/s (8-lane) vs 162 k/s; 4 x 2048: 137 k/s (8-lane) vs 150 k/s (3-lane).  MINA_KIMCHI_COOP8_MAX overrides (tuning)
     static const size_t coop8_max = [] { const char *e = getenv("MINA_KIMCHI_COOP8_MAX"); return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)1024; }();
+    const uint32_t fq_roles = pf_digest ? 1u : 2u;              // role 1 = the digest of the recursion challenges, unless the statement stage supplies it
     if (use_coop16(c, batch)) {
-        mb::kimchi_fq_kernel<16><<<2 * coop_role_blocks<16>(batch), 64, 0, L.stream>>>(B, n_prev, kb, ks, ppb, pps, ix, in, out, xf, d_bad, coop_role_blocks<16>(batch));
+        mb::kimchi_fq_kernel<16><<<fq_roles * coop_role_blocks<16>(batch), 64, 0, L.stream>>>(B, n_prev, kb, ks, ppb, pps, ix, in, out, xf, d_bad, coop_role_blocks<16>(batch), (const fe_t *)pf_digest, pf_stride);
         mb::kimchi_pub_kernel<<<cdiv(batch * 8, 64), 64, 0, L.stream>>>(B, npub, ks, ix, in, xf, d_bad);
         mb::kimchi_fr_kernel<16><<<cdiv(coop_threads<16>(batch), 64), 64, 0, L.stream>>>(B, ks, pps, in, xf, d_bad);
     } else if (batch <= coop8_max) {
-        mb::kimchi_fq_kernel<8><<<2 * coop_role_blocks<8>(batch), 64, 0, L.stream>>>(B, n_prev, kb, ks, ppb, pps, ix, in, out, xf, d_bad, coop_role_blocks<8>(batch));
+        mb::kimchi_fq_kernel<8><<<fq_roles * coop_role_blocks<8>(batch), 64, 0, L.stream>>>(B, n_prev, kb, ks, ppb, pps, ix, in, out, xf, d_bad, coop_role_blocks<8>(batch), (const fe_t *)pf_digest, pf_stride);
         mb::kimchi_pub_kernel<<<cdiv(batch * 8, 64), 64, 0, L.stream>>>(B, npub, ks, ix, in, xf, d_bad);
         mb::kimchi_fr_kernel<8><<<cdiv(coop_threads<8>(batch), 64), 64, 0, L.stream>>>(B, ks, pps, in, xf, d_bad);
     } else {                        // chip-filling batch: 21 sponges per wave
-        mb::kimchi_fq_kernel<3><<<2 * coop_role_blocks<3>(batch), 64, 0, L.stream>>>(B, n_prev, kb, ks, ppb, pps, ix, in, out, xf, d_bad, coop_role_blocks<3>(batch));
+        mb::kimchi_fq_kernel<3><<<fq_roles * coop_role_blocks<3>(batch), 64, 0, L.stream>>>(B, n_prev, kb, ks, ppb, pps, ix, in, out, xf, d_bad, coop_role_blocks<3>(batch), (const fe_t *)pf_digest, pf_stride);
         mb::kimchi_pub_kernel<<<cdiv(batch * 8, 64), 64, 0, L.stream>>>(B, npub, ks, ix, in, xf, d_bad);
         mb::kimchi_fr_kernel<3><<<cdiv(coop_threads<3>(batch), 64), 64, 0, L.stream>>>(B, ks, pps, in, xf, d_bad);
     }
@@ -427,7 +431,7 @@ extern "C" int mina_kimchi_to_batch(mina_ctx *c, const mina_kimchi_proofs *p, mi
     else { std::vector<uint8_t> hb(B * 64); uint8_t h1[64]; if ((rc = mina_srs_get_h(c, CURVE_PALLAS, h1))) return rc; c->use_lane0(); for (size_t i = 0; i < B; ++i) memcpy(&hb[i * 64], h1, 64); HIPC(hipMemcpyAsync(d + o_pc, hb.data(), B * 64, hipMemcpyHostToDevice, L.stream)); HIPC(hipStreamSynchronize(L.stream)); }
     mb::KimchiIn in{W(secs[0].off), W(secs[1].off), W(secs[2].off), W(secs[3].off), W(secs[4].off), W(secs[5].off), W(secs[6].off), W(secs[7].off), W(o_pc)};
     mb::KimchiOut out{W(o_state), W(o_pos), W(o_cip), W(o_pts), W(o_v), W(o_u), W(o_comms), W(o_ft)};
-    if ((rc = mb_kimchi_to_batch_dev(c, B, p->n_prev, p->npub, in, out, W(o_bad), nullptr))) return rc;
+    if ((rc = mb_kimchi_to_batch_dev(c, B, p->n_prev, p->npub, in, out, W(o_bad), nullptr, nullptr, 0))) return rc;
     std::vector<uint8_t> back(all - o_state);
     HIPC(hipMemcpyAsync(back.data(), d + o_state, back.size(), hipMemcpyDeviceToHost, L.stream));
     HIPC(hipStreamSynchronize(L.stream));
@@ -545,7 +549,7 @@ int mb_kimchi_fill_jobs(mina_ctx *c, const mw::WrapProof *const *proofs, const u
     }
     rb.assign(32, 0); rb[0] = 7; sb.assign(32, 0); sb[0] = 9;
     kp.resize(sizeof(mina_kimchi_proofs));
-    mina_kimchi_proofs kk{}; kk.batch = n; kk.n_prev = n_prev; kk.npub = npub; kk.prev_prechallenges = pch.data(); kk.prev_comms = pcm.data(); kk.w_comm = wc.data();
+    mina_kimchi_proofs kk{}; kk.batch = n; kk.n_prev = n_prev; kk.npub = npub; kk.prev_prechallenges = (with_statements && n_prev == 2 && k == 15) ? nullptr : pch.data();   /* the statements' wrap_old_challenges are these very challenges */ kk.prev_comms = pcm.data(); kk.w_comm = wc.data();
     kk.z_comm = zc.data(); kk.t_comm = tc.data(); kk.evals = ev.data(); kk.ft_eval1 = ft1.data();
     if (with_statements) kk.statements = (const mina_pickles_statements *)storage[28].data();
     memcpy(kp.data(), &kk, sizeof kk);

@@ -279,7 +279,8 @@ struct PicklesIndexDev {
 };
 enum { PX_ALPHA = 0, PX_ZETA, PX_BETA, PX_GAMMA, PX_CHD, PX_MW, PX_MS, PX_XIC, PX_XI, PX_R, PX_BP = 10, PX_OLD = 26 };
 __host__ __device__ static inline uint32_t px_wold(uint32_t n_old) { return PX_OLD + 16 * n_old; }
-__host__ __device__ static inline uint32_t px_stride(uint32_t n_old) { return PX_OLD + 16 * n_old + 30; }
+__host__ __device__ static inline uint32_t px_kdig(uint32_t n_old) { return PX_OLD + 16 * n_old + 30; }      // kimchi's digest of the wrap-side old challenges (Fq)
+__host__ __device__ static inline uint32_t px_stride(uint32_t n_old) { return PX_OLD + 16 * n_old + 31; }
 struct PicklesIn {
     uint32_t n_old, n_evals;
     const uint32_t *plonk, *bp, *old_chals, *step_comms, *wold, *wrap_sg, *digest, *evals, *pub_in, *ft_eval1, *app_state; const uint8_t *misc;
@@ -329,6 +330,12 @@ pickles_digest_kernel(uint32_t batch, FieldK kp, FieldK kq, const PoseidonParams
         DevSponge<FIELD_FQ, LANES> sp; sponge_init(sp, pp_q);
 #pragma unroll 1
         for (uint32_t i = 0; i < 30; ++i) sp.absorb(x[px_wold(in.n_old) + i]);
+        // The wrap proof's kimchi verification digests exactly these 30 challenges with the same sponge (`challenges_digest`: absorb all,
+        // squeeze): its squeeze is the permutation the next absorb here would trigger.  Run it once, hand state[0] to the kimchi stage
+        // (15 permutations per proof it no longer repeats) and go on as if the absorb had triggered it.
+        poseidon_permute_coop<FIELD_FQ, LANES>(sp.s, sp.pp);
+        { const fe_t kd = sp.get(0); if (writer) x[px_kdig(in.n_old)] = kd; }
+        sp.count = 0;
         sp.absorb(ld_checked<FIELD_FQ>(in.wrap_sg + (size_t)b * 16, kq, ok)); sp.absorb(ld_checked<FIELD_FQ>(in.wrap_sg + (size_t)b * 16 + 8, kq, ok));
         const fe_t d = sp.squeeze();
         if (writer) x[PX_MW] = d;
@@ -511,6 +518,10 @@ int mb_pickles_check(mina_ctx *c, const mina_pickles_statements *s) {
     return MINA_OK;
 }
 int mb_pickles_statements_dev(mina_ctx *c, size_t batch, const mina_pickles_statements *s, uint32_t *d_pub, uint32_t *d_ok) { return mb_pickles_dev(c, batch, pickles_in_of(*s), d_pub, d_ok); }
+// where the statements kernel of the current lane left kimchi's digest of the wrap-side old challenges: first element and stride (fe_t units)
+void mb_pickles_kimchi_digest(mina_ctx *c, const mina_pickles_statements *s, const void **first, uint32_t *stride) {
+    *first = c->L->pk_xe.as<fe_t>() + mb::px_kdig(s->n_old); *stride = mb::px_stride(s->n_old);
+}
 // per-proof byte strides of the statement sections, in the order of `mb_pickles_sections`
 size_t mb_pickles_sections(const mina_pickles_statements *s, const void ***slots /* 12 */, size_t *strides /* 12 */, mina_pickles_statements *copy) {
     *copy = *s;

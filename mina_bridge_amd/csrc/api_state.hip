@@ -236,7 +236,7 @@ static int check_jobs(mina_ctx *c, const mina_state_jobs *j) {
             if (!c->have_kimchi) return fail(MINA_ERR_STATE, "no verifier index installed");
             if (kp.batch != j->batch || j->k != c->kimchi_log2 || j->log2_domain != c->kimchi_log2 || j->n_evalpoints != 2 || j->n_comms != kp.n_prev + 45 || kp.npub != j->npub || kp.n_prev > 8)
                 return fail(MINA_ERR_ARG, "kimchi section does not match the installed index / the job's shape");
-            if ((kp.n_prev && ((!kp.prev_chals && !kp.prev_prechallenges) || !kp.prev_comms)) || !kp.w_comm || !kp.z_comm || !kp.t_comm || !kp.evals || !kp.ft_eval1 || (kp.npub && !kp.public_inputs && !kp.statements)) return fail(MINA_ERR_ARG, "null kimchi section");
+            if ((kp.n_prev && ((!kp.prev_chals && !kp.prev_prechallenges && !(kp.statements && kp.n_prev == 2 && j->k == 15)) || !kp.prev_comms)) || !kp.w_comm || !kp.z_comm || !kp.t_comm || !kp.evals || !kp.ft_eval1 || (kp.npub && !kp.public_inputs && !kp.statements)) return fail(MINA_ERR_ARG, "null kimchi section");
             if (kp.statements) { if (kp.npub != 40) return fail(MINA_ERR_ARG, "statements derive exactly 40 public inputs"); int prc = mb_pickles_check(c, kp.statements); if (prc) return prc; }
         } else if (!j->sponge_state || !j->sponge_pos || !j->cip || !j->evalscale || !j->polyscale || (j->n_evalpoints && !j->evalpoints) || (j->n_comms && !j->comms))
             return fail(MINA_ERR_ARG, "null IPA section");
@@ -262,7 +262,9 @@ namespace mb {   // api_kimchi.hip
 struct KimchiIn { const uint32_t *pub, *prev_chals, *prev_comms, *w_comm, *z_comm, *t_comm, *evals, *ft_eval1, *pubcomm; };
 struct KimchiOut { uint32_t *sponge_state, *sponge_pos, *cip, *evalpoints, *polyscale, *evalscale, *comms, *ft_eval0; };
 }
-int mb_kimchi_to_batch_dev(mina_ctx *c, size_t batch, uint32_t n_prev, uint32_t npub, const mb::KimchiIn &in, const mb::KimchiOut &out, uint32_t *d_bad, mb::IpaExpand *expand);
+int mb_kimchi_to_batch_dev(mina_ctx *c, size_t batch, uint32_t n_prev, uint32_t npub, const mb::KimchiIn &in, const mb::KimchiOut &out, uint32_t *d_bad, mb::IpaExpand *expand,
+                           const void *pf_digest, uint32_t pf_stride);
+void mb_pickles_kimchi_digest(mina_ctx *c, const mina_pickles_statements *s, const void **first, uint32_t *stride);   // api_pickles.hip
 
 // public-input commitments h - sum_i pub_i L_i of `batch` proofs as canonical affine words (16 per proof) on the current lane
 int mb_pubcomm_dev(mina_ctx *c, size_t batch, uint32_t log2_domain, uint32_t npub, const uint32_t *d_pub, uint32_t *d_out16) {
@@ -363,17 +365,23 @@ static int state_jobs_on_lane(mina_ctx *c, const mina_state_jobs *j, uint32_t *d
             kimchi_bad = L.st_flags.as<uint32_t>() + 12;
             HIPC(hipMemsetAsync(kimchi_bad, 0, 4, L.stream));
             const uint32_t *prev_chals = W(kp.prev_chals);
-            if (kp.prev_prechallenges && kp.n_prev) {           // 128-bit prechallenges -> scalar-field challenges, on this lane ahead of the sponges
+            // no recursion challenges given beside a statement: they ARE the statement's messages_for_next_wrap_proof.old_bulletproof_challenges
+            // (2 x 15; the one source a verifier has), and their digest was taken on the way by the statement stage
+            const bool from_statement = !kp.prev_chals && !kp.prev_prechallenges && kp.statements && kp.n_prev == 2 && j->k == 15;
+            const void *pre = from_statement ? kp.statements->wrap_old_challenges : kp.prev_prechallenges;
+            const void *pf_digest = nullptr; uint32_t pf_stride = 0;
+            if (from_statement && getenv("MINA_KIMCHI_OWN_DIGEST") == nullptr) mb_pickles_kimchi_digest(c, kp.statements, &pf_digest, &pf_stride);
+            if (pre && kp.n_prev) {                             // 128-bit prechallenges -> scalar-field challenges, on this lane ahead of the sponges
                 const size_t cnt = B * kp.n_prev * j->k;
                 if ((rc = L.kc_pch.ensure(cnt * 32))) { c->L = L0; return rc; }
-                challenge_to_field_kernel<FIELD_FQ><<<cdiv(cnt, 64), 64, 0, L.stream>>>((uint32_t)cnt, c->fk[FIELD_FQ], W(kp.prev_prechallenges), L.kc_pch.as<uint32_t>());
+                challenge_to_field_kernel<FIELD_FQ><<<cdiv(cnt, 64), 64, 0, L.stream>>>((uint32_t)cnt, c->fk[FIELD_FQ], W(pre), L.kc_pch.as<uint32_t>());
                 prev_chals = L.kc_pch.as<uint32_t>();
             }
             mb::KimchiIn in{pub, prev_chals, W(kp.prev_comms), W(kp.w_comm), W(kp.z_comm), W(kp.t_comm), W(kp.evals), W(kp.ft_eval1), comm_override};
             mb::KimchiOut out{L.kc_state.as<uint32_t>(), L.kc_pos.as<uint32_t>(), L.kc_cip.as<uint32_t>(), L.kc_pts.as<uint32_t>(), L.kc_v.as<uint32_t>(), L.kc_u.as<uint32_t>(),
                               L.kc_comms.as<uint32_t>(), nullptr};
             mb::IpaExpand ex;
-            if ((rc = mb_kimchi_to_batch_dev(c, B, kp.n_prev, kp.npub, in, out, kimchi_bad, &ex))) { c->L = L0; return rc; }
+            if ((rc = mb_kimchi_to_batch_dev(c, B, kp.n_prev, kp.npub, in, out, kimchi_bad, &ex, pf_digest, pf_stride))) { c->L = L0; return rc; }
             sh.expand_slot = kp.n_prev + 1; sh.per += mb::IPA_EXPAND - 1;          // the ft commitment enters the MSM as its 8 terms
             if (getenv("MINA_IPA_NO_SHARED") == nullptr && kp.n_prev + 45 <= 64) {   // h, the 27 index columns and the index point of the ft combination are the same
                 uint64_t m = 0;                                                       // points for every proof: their scalars are summed first (29 of 88 entries per proof)

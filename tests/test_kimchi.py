@@ -168,3 +168,16 @@ def test_statement_driven_job_full_size(ctx_srs, oracle):
     bapps[1] = (bapps[1] + 1) % (1 << 254)
     e = bad[3]["prev_evals"][20]; bad[3]["prev_evals"][20] = ([(e[0][0] + 1) % (1 << 254)], e[1])
     assert ctx_srs.state_job_batch(job(bad, bapps)).tolist() == [0, 0, 1, 0]
+
+    # the recursion challenges left out: the job takes them from the statement (messages_for_next_wrap_proof.old_bulletproof_challenges --
+    # the one source a verifier has) and kimchi's digest of them from the statement's own sponge; same verdicts, and a changed challenge in
+    # the statement now fails that proof twice over (its digest in the public input, and the challenge polynomial the opening evaluates)
+    def job_from_statement(wraps, apps):
+        j, keep = job(wraps, apps)
+        kp = m.lib.KimchiProofs.from_address(j.kimchi)
+        kp.prev_chals = 0; kp.prev_prechallenges = 0
+        return j, keep
+    assert ctx_srs.state_job_batch(job_from_statement(wraps, apps)).tolist() == [1] * B
+    assert ctx_srs.state_job_batch(job_from_statement(bad, bapps)).tolist() == [0, 0, 1, 0]
+    bad2 = copy.deepcopy(wraps); bad2[2]["old_bulletproof_challenges"][1][7] ^= 1 << 77
+    assert ctx_srs.state_job_batch(job_from_statement(bad2, apps)).tolist() == [1, 1, 0, 1]
