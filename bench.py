@@ -60,9 +60,9 @@ MADS_PER_LANE_ROUND = 2 * 99 + 2 * 135 + 297
 MAD_ISSUE_CYCLES = 7.0
 CHIP_SIMDS, CLOCK_HZ = 1024, 2.4e9
 PROF_STAGES = {"pstate_hash": 11, "ipa_transcript": 12, "kimchi_to_batch": 13, "pickles_statement": 14, "msm_accumulate": 3}
-# HBM-side bytes per protocol-state hash from the rocprofv3 PMC passes of profiles/r02i_rocprof.md (FETCH_SIZE x 2 -- the gfx950
+# HBM-side bytes per protocol-state hash from the rocprofv3 PMC passes of profiles/r02j_rocprof.md (FETCH_SIZE x 2 -- the gfx950
 # correction of MI355X_MICROARCH.md for 16-B-per-lane loads -- + WRITE_SIZE, KiB x 1024, over the 139 264 states of one launch)
-PSTATE_TRAFFIC_BYTES_PER_STATE = (2 * 130115 + 4352) * 1024 / 139264
+PSTATE_TRAFFIC_BYTES_PER_STATE = (2 * 130102 + 4352) * 1024 / 139264
 
 
 def le32(x: int) -> np.ndarray:
@@ -501,7 +501,7 @@ def main():
                        "algorithmic_bytes_per_proof": algorithmic_bytes_per_proof()},
             "roofline": {"bound": "hbm", "kernel": "pstate_hash_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": nstates * PSTATE_TRAFFIC_BYTES_PER_STATE,
-                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), profiles/r02i_rocprof.md",
+                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), profiles/r02j_rocprof.md",
                          "algorithmic_bytes_per_launch": hash_bytes, "states_per_launch": nstates, "avg_launch_us": kern_us,
                          "avg_launch_us_in_timed_region": ovl.get("pstate_hash"),
                          "note": "avg_launch_us: HIP events on the lane stream around the kernel, launches with nothing else on the GPU right after the "
