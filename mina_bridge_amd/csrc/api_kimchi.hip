@@ -122,7 +122,10 @@ kimchi_fq_kernel(uint32_t batch, uint32_t n_prev, FieldK kb, FieldK ks, const Po
 }
 
 // negated public polynomial at zeta and zeta*omega:  -(x^n - 1)/n * sum_i p_i w^i / (x - w^i).  8 lanes per proof; work item = (side,
-// chunk of 8 terms), round-robin over the lanes, each inverts its 8 denominators with one field inversion; shuffle-tree sum
+// chunk of CH terms), round-robin over the lanes, each inverts its CH denominators with one field inversion; shuffle-tree sum.
+// CH = 10 makes the 40 public inputs of a wrap proof exactly 8 items -- one pass of the lanes; with chunks of 8 they are 10 items and the
+// wave runs a second pass (inversion included) for two of its eight lanes.
+template <int CH>
 __global__ void __launch_bounds__(64)
 kimchi_pub_kernel(uint32_t batch, uint32_t npub, FieldK ks, const KimchiIndexDev *__restrict__ ix, KimchiIn in, fe_t *__restrict__ xf, uint32_t *__restrict__ bad_input) {
     constexpr int FS = FIELD_FQ;
@@ -132,20 +135,20 @@ kimchi_pub_kernel(uint32_t batch, uint32_t npub, FieldK ks, const KimchiIndexDev
     fe_t *x = xf + (size_t)b * KC_XF;
     const uint32_t k = ix->log2_domain;
     const fe_t zeta = x[XF_ZETA], zetaw = fe_mul<FS>(zeta, ix->omega);
-    const fe_t omega8 = fe_pow2k<FS>(ix->omega, 3);
+    const fe_t omega_ch = fe_pow_u64<FS>(ix->omega, (uint64_t)CH, ks.one);
     fe_t acc[2] = {fe_zero(), fe_zero()};
-    const uint32_t nchunks = (npub + 7) / 8;
+    const uint32_t nchunks = (npub + CH - 1) / CH;
 #pragma unroll 1
     for (uint32_t it = ln; it < 2 * nchunks; it += 8) {
-        const uint32_t side = it & 1u, base = (it >> 1) * 8, cnt = npub - base < 8 ? npub - base : 8;
+        const uint32_t side = it & 1u, base = (it >> 1) * CH, cnt = npub - base < (uint32_t)CH ? npub - base : (uint32_t)CH;
         const fe_t pt = side ? zetaw : zeta;
-        fe_t wi = fe_pow_u64<FS>(omega8, it >> 1, ks.one);
-        fe_t den[8], pre[8], run = ks.one;
+        fe_t wi = fe_pow_u64<FS>(omega_ch, it >> 1, ks.one);
+        fe_t den[CH], pre[CH], run = ks.one;
 #pragma unroll
-        for (uint32_t j = 0; j < 8; ++j) if (j < cnt) { den[j] = fe_sub<FS>(pt, wi); pre[j] = run; run = fe_mul<FS>(run, den[j]); wi = fe_mul<FS>(wi, ix->omega); }
+        for (uint32_t j = 0; j < (uint32_t)CH; ++j) if (j < cnt) { den[j] = fe_sub<FS>(pt, wi); pre[j] = run; run = fe_mul<FS>(run, den[j]); wi = fe_mul<FS>(wi, ix->omega); }
         fe_t inv = fe_inv<FS>(run, ks), part = fe_zero();
 #pragma unroll
-        for (int j = 7; j >= 0; --j) if ((uint32_t)j < cnt) {
+        for (int j = CH - 1; j >= 0; --j) if ((uint32_t)j < cnt) {
             const fe_t dinv = fe_mul<FS>(inv, pre[j]); inv = fe_mul<FS>(inv, den[j]);
             const fe_t p = ld_checked<FS>(in.pub + ((size_t)b * npub + base + j) * 8, ks, ok);
             part = fe_add<FS>(part, fe_mul<FS>(fe_mul<FS>(dinv, p), fe_sub<FS>(pt, den[j])));       // w^i = pt - (pt - w^i)
@@ -374,15 +377,18 @@ int mb_kimchi_to_batch_dev(mina_ctx *c, size_t batch, uint32_t n_prev, uint32_t 
     const uint32_t fq_roles = pf_digest ? 1u : 2u;              // role 1 = the digest of the recursion challenges, unless the statement stage supplies it
     if (use_coop16(c, batch)) {
         mb::kimchi_fq_kernel<16><<<fq_roles * coop_role_blocks<16>(batch), 64, 0, L.stream>>>(B, n_prev, kb, ks, ppb, pps, ix, in, out, xf, d_bad, coop_role_blocks<16>(batch), (const fe_t *)pf_digest, pf_stride);
-        mb::kimchi_pub_kernel<<<cdiv(batch * 8, 64), 64, 0, L.stream>>>(B, npub, ks, ix, in, xf, d_bad);
+        if (npub > 32 && npub <= 40) mb::kimchi_pub_kernel<10><<<cdiv(batch * 8, 64), 64, 0, L.stream>>>(B, npub, ks, ix, in, xf, d_bad);
+        else mb::kimchi_pub_kernel<8><<<cdiv(batch * 8, 64), 64, 0, L.stream>>>(B, npub, ks, ix, in, xf, d_bad);
         mb::kimchi_fr_kernel<16><<<cdiv(coop_threads<16>(batch), 64), 64, 0, L.stream>>>(B, ks, pps, in, xf, d_bad);
     } else if (batch <= coop8_max) {
         mb::kimchi_fq_kernel<8><<<fq_roles * coop_role_blocks<8>(batch), 64, 0, L.stream>>>(B, n_prev, kb, ks, ppb, pps, ix, in, out, xf, d_bad, coop_role_blocks<8>(batch), (const fe_t *)pf_digest, pf_stride);
-        mb::kimchi_pub_kernel<<<cdiv(batch * 8, 64), 64, 0, L.stream>>>(B, npub, ks, ix, in, xf, d_bad);
+        if (npub > 32 && npub <= 40) mb::kimchi_pub_kernel<10><<<cdiv(batch * 8, 64), 64, 0, L.stream>>>(B, npub, ks, ix, in, xf, d_bad);
+        else mb::kimchi_pub_kernel<8><<<cdiv(batch * 8, 64), 64, 0, L.stream>>>(B, npub, ks, ix, in, xf, d_bad);
         mb::kimchi_fr_kernel<8><<<cdiv(coop_threads<8>(batch), 64), 64, 0, L.stream>>>(B, ks, pps, in, xf, d_bad);
     } else {                        // chip-filling batch: 21 sponges per wave
         mb::kimchi_fq_kernel<3><<<fq_roles * coop_role_blocks<3>(batch), 64, 0, L.stream>>>(B, n_prev, kb, ks, ppb, pps, ix, in, out, xf, d_bad, coop_role_blocks<3>(batch), (const fe_t *)pf_digest, pf_stride);
-        mb::kimchi_pub_kernel<<<cdiv(batch * 8, 64), 64, 0, L.stream>>>(B, npub, ks, ix, in, xf, d_bad);
+        if (npub > 32 && npub <= 40) mb::kimchi_pub_kernel<10><<<cdiv(batch * 8, 64), 64, 0, L.stream>>>(B, npub, ks, ix, in, xf, d_bad);
+        else mb::kimchi_pub_kernel<8><<<cdiv(batch * 8, 64), 64, 0, L.stream>>>(B, npub, ks, ix, in, xf, d_bad);
         mb::kimchi_fr_kernel<3><<<cdiv(coop_threads<3>(batch), 64), 64, 0, L.stream>>>(B, ks, pps, in, xf, d_bad);
     }
     mb::kimchi_scalar_kernel<<<cdiv(batch, 64), 64, 0, L.stream>>>(B, n_prev, ks, ix, c->kimchi_tokens.as<mb::KimchiToken>(), c->kimchi_literals.as<fe_t>(), in, out, xf, d_bad);
