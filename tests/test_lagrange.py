@@ -67,9 +67,9 @@ def test_public_input_commitment(ctx_srs, oracle, srs_oracle):
     assert (ctx_srs.public_input_commitment(curve, k, pub) == got).all()
 
 
-@pytest.mark.parametrize("curve,k,npub,batch", [(0, 6, 40, 5), (1, 5, 32, 3), (0, 15, 40, 17), (0, 7, 1, 2), (0, 8, 100, 4)])
+@pytest.mark.parametrize("curve,k,npub,batch", [(0, 6, 40, 5), (1, 5, 32, 3), (0, 15, 40, 17), (0, 7, 1, 2), (0, 8, 100, 4), (1, 7, 64, 3), (0, 7, 65, 3)])
 def test_public_input_commitment_batch(ctx_srs, oracle, srs_oracle, curve, k, npub, batch):
-    """batched form (one fixed-base problem per proof over the Lagrange window table) == the single-proof entry point
+    """batched form (<= 64 inputs: straight from the digit table; more: one fixed-base problem per proof over the Lagrange window table) == the single-proof entry point
     (variable-base MSM), which test_public_input_commitment pins to the oracle; plus a direct oracle check of row 0"""
     from conftest import rand_scalars
     from oracle import pasta_ref as R
