@@ -380,7 +380,7 @@ int mb_kimchi_to_batch_dev(mina_ctx *c, size_t batch, uint32_t n_prev, uint32_t 
         if (npub > 32 && npub <= 40) mb::kimchi_pub_kernel<10><<<cdiv(batch * 8, 64), 64, 0, L.stream>>>(B, npub, ks, ix, in, xf, d_bad);
         else mb::kimchi_pub_kernel<8><<<cdiv(batch * 8, 64), 64, 0, L.stream>>>(B, npub, ks, ix, in, xf, d_bad);
         mb::kimchi_fr_kernel<16><<<cdiv(coop_threads<16>(batch), 64), 64, 0, L.stream>>>(B, ks, pps, in, xf, d_bad);
-    } else if (batch <= coop8_max) {
+    } else if (use_coop8_transcripts(c, batch, coop8_max)) {
         mb::kimchi_fq_kernel<8><<<fq_roles * coop_role_blocks<8>(batch), 64, 0, L.stream>>>(B, n_prev, kb, ks, ppb, pps, ix, in, out, xf, d_bad, coop_role_blocks<8>(batch), (const fe_t *)pf_digest, pf_stride);
         if (npub > 32 && npub <= 40) mb::kimchi_pub_kernel<10><<<cdiv(batch * 8, 64), 64, 0, L.stream>>>(B, npub, ks, ix, in, xf, d_bad);
         else mb::kimchi_pub_kernel<8><<<cdiv(batch * 8, 64), 64, 0, L.stream>>>(B, npub, ks, ix, in, xf, d_bad);

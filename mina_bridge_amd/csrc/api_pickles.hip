@@ -492,7 +492,7 @@ int mb_pickles_dev(mina_ctx *c, size_t batch, const mb::PicklesIn &in, uint32_t 
     if (use_coop16(c, batch)) {
         mb::pickles_digest_kernel<16><<<3 * coop_role_blocks<16>(batch), 64, 0, L.stream>>>(B, kp, kq, ppp, ppq, ix, in, xe, d_ok, coop_role_blocks<16>(batch));
         mb::pickles_tick_kernel<16><<<cdiv(coop_threads<16>(batch), 64), 64, 0, L.stream>>>(B, kp, ppp, in, xe, d_ok);
-    } else if (batch <= 1024) {
+    } else if (use_coop8_transcripts(c, batch, 1024)) {
         mb::pickles_digest_kernel<8><<<3 * coop_role_blocks<8>(batch), 64, 0, L.stream>>>(B, kp, kq, ppp, ppq, ix, in, xe, d_ok, coop_role_blocks<8>(batch));
         mb::pickles_tick_kernel<8><<<cdiv(coop_threads<8>(batch), 64), 64, 0, L.stream>>>(B, kp, ppp, in, xe, d_ok);
     } else {

@@ -151,6 +151,15 @@ static inline bool use_coop16(const mina_ctx *c, size_t proofs) {
     return proofs * (size_t)(c ? c->nlanes : 1) <= lim;
 }
 
+// The per-proof transcripts (statement, kimchi, opening): 8 lanes per sponge while the proofs in flight (per call x lanes) leave the chip
+// latency-bound (<= 1024 per call and <= 2048 in flight: with 16 lanes 1024 per call ran 123 k/s in the 8-lane form, 138 k/s in the 3-lane
+// form; 512: 83 / 91 k; 256: 54 / 58 k), the wave-packed 3-lane form beyond.  MINA_TRANSCRIPT_COOP8_MAX overrides (proofs in flight).
+static inline bool use_coop8_transcripts(const mina_ctx *c, size_t batch, size_t per_call_limit) {
+    static const size_t lim = getenv("MINA_TRANSCRIPT_COOP8_MAX") ? (size_t)strtoull(getenv("MINA_TRANSCRIPT_COOP8_MAX"), nullptr, 10) : (size_t)0;
+    const size_t in_flight = batch * (size_t)(c ? c->nlanes : 1);
+    return lim ? in_flight <= lim : (batch <= per_call_limit && in_flight <= 2048);
+}
+
 // independent per-item host work over up to 64 threads, at most half the cores ($MINA_HOST_THREADS overrides the cap; items are ~0.01 - 0.1 ms
 // each: threads only when there are enough of them)
 template <class Fn> static inline void mb_parallel_for(size_t n, Fn fn) {
