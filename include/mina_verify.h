@@ -531,7 +531,12 @@ int mina_state_proof_split(const uint8_t *bytes, size_t len, size_t *proof_len, 
 #define MINA_CHECK_KIMCHI 32u       /* kimchi verification of the wrap proof (needs an installed verifier index) */
 #define MINA_CHECK_ACCOUNT_ABI 64u  /* Proof of Account: encoded_account == ABI encoding re-derived from `account`    (README.md:349-352) */
 #define MINA_CHECK_MERKLE 128u      /* Proof of Account: account hash folded along the path == ledger hash            (README.md:345-347) */
-#define MINA_VERIFY_ALLOW_MISSING_KIMCHI 1u   /* verdict ignores MINA_CHECK_KIMCHI when no index is installed: NOT a full verification */
+#define MINA_VERIFY_ALLOW_MISSING_KIMCHI 1u   /* verdict ignores MINA_CHECK_KIMCHI when the kimchi step cannot run: NOT a full verification */
+#define MINA_VERIFY_ALLOW_UNBOUND_STATEMENT 2u /* a wrap index WITHOUT a step index: run the kimchi step with an EMPTY public input (the proof is then
+                                                  not bound to the Pickles statement / the candidate tip).  Test hook; never in a deployment. */
+#define MINA_VERIFY_ALLOW_SURROGATE 4u        /* verify although the installed Poseidon tables are the library's surrogate (mina_poseidon_params_name()
+                                                  contains "UNPINNED"): hashes then agree with this repo's oracle, not with the Mina network.  Without the
+                                                  flag every mina_verify_* verdict is `false` on such a context. */
 #include <stdbool.h>
 bool mina_verify_state(const uint8_t *proof, size_t proof_len, const uint8_t *pub_input, size_t pub_len);
 int mina_verify_state_batch(size_t n, const uint8_t *const *proofs, const size_t *proof_lens, const uint8_t *const *pub_inputs,
@@ -553,8 +558,17 @@ int mina_verify_account_ctx(mina_ctx *ctx, size_t n, const uint8_t *const *proof
 int mina_account_hash_batch(mina_ctx *ctx, int encoding, size_t n, const uint8_t *const *accounts, const size_t *lens, uint8_t *hashes_out /* n*32 */);
 int mina_account_abi_encode(const uint8_t *account, size_t len, int encoding, uint8_t *out, size_t cap, size_t *out_len);
 int mina_verify_configure(uint32_t flags);       /* MINA_VERIFY_* */
-int mina_verify_shutdown(void);                  /* destroy the process-wide context */
-mina_ctx *mina_verify_global_ctx(void);          /* e.g. to install a verifier index or other Poseidon tables; NULL without a GPU */
+int mina_verify_shutdown(void);                  /* destroy the process-wide contexts */
+mina_ctx *mina_verify_global_ctx(void);          /* the first device's context, e.g. to install a verifier index; NULL without a GPU */
+/* Multi-GPU behind the boundary: the process holds one context per GPU named by $MINA_VERIFY_DEVICES ("all" | comma list of
+ * ordinals; an ordinal may repeat = several logical contexts on one GPU; default: $MINA_VERIFY_DEVICE or 0).  mina_verify_state_batch cuts
+ * its proofs into contiguous shards, one per device, each with its own folding randomisers and its own culprit search; merged single-proof
+ * jobs are dealt round-robin.  The installers below put the same data on EVERY device. */
+int mina_verify_device_count(void);
+mina_ctx *mina_verify_device_ctx(int i);
+int mina_verify_install_verifier_index(const mina_verifier_index *index);
+int mina_verify_install_step_index(const mina_step_index *index);
+int mina_verify_set_poseidon_params(int field, const uint8_t *params /* (9+165)*32 */);
 /* the Poseidon constant set compiled into the library (name contains "UNPINNED" while it is a surrogate for fp_kimchi/fq_kimchi) */
 const char *mina_poseidon_params_name(void);
 int mina_poseidon_install_default_params(mina_ctx *ctx);

@@ -3,8 +3,86 @@
 #include "sponge.cuh"
 #include "msm.cuh"
 
+#include <sys/random.h>
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+
 static thread_local std::string g_err = "";
 int mb_fail(int code, const std::string &msg) { g_err = msg; return code; }
+
+// ------------------------------------------------------------------------------------------------ CSPRNG
+bool mb_secure_random(void *buf, size_t n) {
+    uint8_t *p = (uint8_t *)buf; size_t got = 0;
+    while (got < n) {
+        const ssize_t r = getrandom(p + got, n - got, 0);
+        if (r > 0) { got += (size_t)r; continue; }
+        if (r < 0 && errno == EINTR) continue;
+        break;
+    }
+    if (got == n) return true;
+    FILE *f = fopen("/dev/urandom", "rb");                       // kernels without the system call
+    if (!f) return false;
+    const size_t k = fread(p + got, 1, n - got, f);
+    fclose(f);
+    return got + k == n;
+}
+
+// ------------------------------------------------------------------------------------------------ host worker pool
+struct MbPoolJob { std::function<void(size_t)> fn; size_t n = 0; std::atomic<size_t> next{0}, done{0}; std::mutex mu; std::condition_variable cv; };
+namespace {
+struct HostPool {
+    std::mutex mu; std::condition_variable cv; std::deque<std::shared_ptr<MbPoolJob>> jobs; std::vector<std::thread> th;
+    static void drain(MbPoolJob &j) {
+        for (;;) {
+            const size_t i = j.next.fetch_add(1);
+            if (i >= j.n) return;
+            j.fn(i);
+            if (j.done.fetch_add(1) + 1 == j.n) { std::lock_guard<std::mutex> lk(j.mu); j.cv.notify_all(); }
+        }
+    }
+    void worker() {
+        for (;;) {
+            std::shared_ptr<MbPoolJob> j;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                for (;;) {
+                    while (!jobs.empty() && jobs.front()->next.load() >= jobs.front()->n) jobs.pop_front();
+                    if (!jobs.empty()) { j = jobs.front(); break; }
+                    cv.wait(lk);
+                }
+            }
+            drain(*j);
+        }
+    }
+    explicit HostPool(size_t nt) { for (size_t t = 0; t < nt; ++t) { th.emplace_back([this] { worker(); }); th.back().detach(); } }
+};
+HostPool *host_pool() {                                              // never destroyed: its threads outlive static destructors
+    static HostPool *p = [] {
+        size_t nt;
+        if (const char *e = getenv("MINA_HOST_THREADS")) nt = (size_t)std::max(1L, atol(e));
+        else { const size_t hw = std::thread::hardware_concurrency(); nt = std::max<size_t>(1, std::min<size_t>(hw / 2, 64)); }
+        return new HostPool(nt);
+    }();
+    return p;
+}
+}  // namespace
+size_t mb_pool_threads() { return host_pool()->th.size(); }
+std::shared_ptr<MbPoolJob> mb_pool_submit(size_t n, std::function<void(size_t)> fn) {
+    auto j = std::make_shared<MbPoolJob>(); j->fn = std::move(fn); j->n = n;
+    if (n == 0) return j;
+    HostPool *p = host_pool();
+    { std::lock_guard<std::mutex> lk(p->mu); p->jobs.push_back(j); }
+    p->cv.notify_all();
+    return j;
+}
+void mb_pool_wait(const std::shared_ptr<MbPoolJob> &j) {
+    if (!j || j->n == 0) return;
+    HostPool::drain(*j);                                             // the caller works too
+    std::unique_lock<std::mutex> lk(j->mu);
+    j->cv.wait(lk, [&] { return j->done.load() >= j->n; });
+}
 
 // ------------------------------------------------------------------------------------------------
 // Host-side derivation of the per-field constants (no table of magic numbers: everything follows
@@ -72,6 +150,8 @@ extern "C" void mina_ctx_destroy(mina_ctx *c) {
     for (int i = 0; i < 2; ++i) { c->srs[i].table.release(); c->srs[i].h.release(); c->srs[i].lagrange_table.release(); c->srs[i].lagrange_digits.release(); c->pparams[i].release(); c->merkle_salts[i].release(); }
     c->state_salts.release(); c->kimchi_index.release(); c->kimchi_tokens.release(); c->kimchi_literals.release();
     c->pickles_index.release(); c->pickles_tokens.release(); c->pickles_literals.release();
+    if (c->step_host && c->step_host_free) c->step_host_free(c->step_host);
+    c->step_host = nullptr;
     for (int i = 0; i < MB_MAX_LANES; ++i) c->lanes[i].release_all();
     for (auto &r : c->prof.recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     for (int i = 0; i < MB_MAX_LANES; ++i) {

@@ -448,120 +448,3 @@ extern "C" int mina_kimchi_to_batch(mina_ctx *c, const mina_kimchi_proofs *p, mi
     if (o->malformed) { uint32_t f; memcpy(&f, R(o_bad), 4); *o->malformed = f ? 1 : 0; }
     return MINA_OK;
 }
-
-// ------------------------------------------------------------------------------------------------ WrapProof -> kimchi section (verify_mina_state)
-// Gathers the wrap proofs' kimchi inputs into host arrays for mina_state_job_batch.  The wrap circuit's PUBLIC INPUT is the
-// Pickles statement packed into scalars (`tock_unpadded_public_input_of_statement`): that packing needs the step circuit's
-// deferred values (combined inner product, b, zeta powers, perm), which in turn need the STEP linearization -- data this tree does
-// not hold.  With a step index installed (mina_step_index_install) the 40 public inputs are derived from the statement
-// (api_pickles.hip); without one the wrap proof is verified with an EMPTY public input (npub = 0) [flagged in DESIGN.md].
-int mb_step_index_installed(mina_ctx *c);                                                                                          // api_pickles.hip
-int mb_pickles_public_inputs(mina_ctx *c, const mw::WrapProof *const *proofs, const uint8_t *const *app_states, size_t n, uint8_t *pub_out, uint8_t *derived_out, uint8_t *ok_out);
-
-int mb_kimchi_fill_jobs(mina_ctx *c, const mw::WrapProof *const *proofs, const uint8_t *const *tip_hashes, size_t n, mina_state_jobs *jobs,
-                        std::vector<std::vector<uint8_t>> &storage, std::vector<uint8_t> &statement_ok) {
-    const uint32_t k = c->kimchi_log2;
-    storage.assign(32, {});
-    statement_ok.assign(n, 1);
-    auto &pub = storage[0], &pch = storage[1], &pcm = storage[2], &wc = storage[3], &zc = storage[4], &tc = storage[5], &ev = storage[6], &ft1 = storage[7],
-         &lr = storage[8], &dl = storage[9], &sg = storage[10], &z1 = storage[11], &z2 = storage[12], &rb = storage[13], &sb = storage[14], &kp = storage[15];
-    (void)pub; (void)tip_hashes;
-    const uint32_t n_prev = 2;
-    uint32_t npub = 0;
-    const bool with_statements = mb_step_index_installed(c) != 0;
-    {   // one allocation per section
-        const size_t per[16] = {0, n_prev * k * 16, n_prev * 64, 15 * 64, 64, 7 * 64, 43 * 64, 32, 2 * k * 64, 64, 64, 32, 32, 0, 0, 0};
-        for (int i = 0; i < 16; ++i) storage[i].reserve(n * per[i]);
-        const size_t sper[12] = {64, 256, 2 * 256, 2 * 64, 480, 64, 32, 62 * 64, 64, 32, 32, 32};
-        if (with_statements) for (int i = 0; i < 12; ++i) storage[16 + i].reserve(n * sper[i]);
-    }
-    if (with_statements) {          // the wrap circuit's public input = the Pickles statement; derived on the GPU inside the job (api_pickles.hip)
-        npub = 40;
-        auto &s_plonk = storage[16], &s_bp = storage[17], &s_old = storage[18], &s_cm = storage[19], &s_wold = storage[20], &s_wsg = storage[21], &s_dg = storage[22],
-             &s_ev = storage[23], &s_pi = storage[24], &s_ft = storage[25], &s_app = storage[26], &s_misc = storage[27], &s_struct = storage[28];
-        auto put_chal = [](std::vector<uint8_t> &v, const mw::Chal128 &ch) { uint8_t e[16]; memcpy(e, &ch.lo, 8); memcpy(e + 8, &ch.hi, 8); v.insert(v.end(), e, e + 16); };
-        auto put_b32 = [](std::vector<uint8_t> &v, const mw::B32 &x) { v.insert(v.end(), x.b, x.b + 32); };
-        const size_t n_old = n ? proofs[0]->step_old_bulletproof_challenges.size() : 0, n_ev = n ? proofs[0]->prev_evals.size() : 0;
-        if (n_old > 4 || n_ev < 43 || n_ev > 62) return fail(MINA_ERR_FORMAT, "wrap proof statement shape");
-        // wire order: w 15, coefficients 15, z, s 6, selectors 6, then the present optional ones -> kimchi column order
-        static const size_t order[43] = {30, 37, 38, 39, 40, 41, 42, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 31, 32, 33, 34, 35, 36};
-        const FieldK &kpf = c->fk[FIELD_FP];
-        for (size_t b = 0; b < n; ++b) {
-            const mw::WrapProof &w = *proofs[b];
-            if (w.step_old_bulletproof_challenges.size() != n_old || w.step_challenge_polynomial_commitments.size() != n_old || w.prev_evals.size() != n_ev)
-                return fail(MINA_ERR_ARG, "proofs of one call must share the evaluation / recursion shape");
-            put_chal(s_plonk, w.alpha); put_chal(s_plonk, w.beta); put_chal(s_plonk, w.gamma); put_chal(s_plonk, w.zeta);
-            for (int j = 0; j < 16; ++j) put_chal(s_bp, w.bulletproof_challenges[j]);
-            for (auto &row : w.step_old_bulletproof_challenges) for (int j = 0; j < 16; ++j) put_chal(s_old, row[j]);
-            for (auto &cm : w.step_challenge_polynomial_commitments) { put_b32(s_cm, cm.x); put_b32(s_cm, cm.y); }
-            for (int a = 0; a < 2; ++a) for (int j = 0; j < 15; ++j) put_chal(s_wold, w.old_bulletproof_challenges[a][j]);
-            put_b32(s_wsg, w.challenge_polynomial_commitment.x); put_b32(s_wsg, w.challenge_polynomial_commitment.y);
-            { uint8_t dg[32]; memcpy(dg, w.sponge_digest_before_evaluations, 32); s_dg.insert(s_dg.end(), dg, dg + 32); }
-            // evaluations: one chunk each in every Mina step proof; chunked ones are combined here with zeta^(2^16) (host field arithmetic)
-            bool chunked = w.prev_public_input.zeta.size() != 1 || w.prev_public_input.zeta_omega.size() != 1;
-            for (auto &e : w.prev_evals) chunked = chunked || e.zeta.size() != 1 || e.zeta_omega.size() != 1;
-            fe_t zn = fe_zero(), zwn = fe_zero();
-            if (chunked) {
-                const fe_t zeta = challenge_to_field<FIELD_FP>(w.zeta.lo, w.zeta.hi, kpf);
-                fe_t om = kpf.root; for (uint32_t j = 0; j + w.domain_log2 < 32; ++j) om = fe_sqr<FIELD_FP>(om);
-                zn = zeta; zwn = fe_mul<FIELD_FP>(zeta, om);
-                for (int j = 0; j < 16; ++j) { zn = fe_sqr<FIELD_FP>(zn); zwn = fe_sqr<FIELD_FP>(zwn); }
-            }
-            auto comb = [&](const std::vector<mw::B32> &chunks, const fe_t &ptn) {
-                if (chunks.size() == 1) { put_b32(s_ev, chunks[0]); return; }
-                fe_t acc = fe_zero();
-                for (size_t j = chunks.size(); j-- > 0;) { if (!mw::fp_canonical(chunks[j].b)) statement_ok[b] = 0; acc = fe_add<FIELD_FP>(fe_mul<FIELD_FP>(acc, ptn), host_mont<FIELD_FP>(chunks[j].b, kpf)); }
-                const fe_t pl = fe_from_mont<FIELD_FP>(acc); const uint8_t *pb = (const uint8_t *)pl.v; s_ev.insert(s_ev.end(), pb, pb + 32);
-            };
-            for (size_t j = 0; j < n_ev; ++j) { const mw::EvalPair &e = w.prev_evals[j < 43 ? order[j] : j]; comb(e.zeta, zn); comb(e.zeta_omega, zwn); }
-            if (w.prev_public_input.zeta.empty() || w.prev_public_input.zeta_omega.empty()) return fail(MINA_ERR_FORMAT, "wrap proof without public-input evaluations");
-            put_b32(s_pi, w.prev_public_input.zeta[0]); put_b32(s_pi, w.prev_public_input.zeta_omega[0]);
-            put_b32(s_ft, w.prev_ft_eval1);
-            s_app.insert(s_app.end(), tip_hashes[b], tip_hashes[b] + 32);
-            uint8_t misc[32] = {0};
-            misc[0] = w.domain_log2; misc[1] = w.proofs_verified; for (int j = 0; j < 8; ++j) misc[2 + j] = w.feature_flags[j] ? 1 : 0;
-            misc[10] = w.has_joint_combiner ? 1 : 0; if (w.has_joint_combiner) { memcpy(misc + 16, &w.joint_combiner.lo, 8); memcpy(misc + 24, &w.joint_combiner.hi, 8); }
-            s_misc.insert(s_misc.end(), misc, misc + 32);
-        }
-        mina_pickles_statements ps{};
-        ps.n_old = (uint32_t)n_old; ps.n_evals = (uint32_t)n_ev; ps.plonk = s_plonk.data(); ps.bulletproof_challenges = s_bp.data(); ps.step_old_challenges = s_old.data();
-        ps.step_comms = s_cm.data(); ps.wrap_old_challenges = s_wold.data(); ps.wrap_sg = s_wsg.data(); ps.sponge_digest = s_dg.data(); ps.prev_evals = s_ev.data();
-        ps.prev_public_input = s_pi.data(); ps.prev_ft_eval1 = s_ft.data(); ps.app_state = s_app.data(); ps.misc = s_misc.data();
-        s_struct.resize(sizeof ps); memcpy(s_struct.data(), &ps, sizeof ps);
-    }
-    auto put_pt = [](std::vector<uint8_t> &v, const mw::Pt &p) { v.insert(v.end(), p.x.b, p.x.b + 32); v.insert(v.end(), p.y.b, p.y.b + 32); };
-    auto put32 = [](std::vector<uint8_t> &v, const mw::B32 &x) { v.insert(v.end(), x.b, x.b + 32); };
-    for (size_t b = 0; b < n; ++b) {
-        const mw::WrapProof &w = *proofs[b];
-        if (w.lr.size() != k || w.step_challenge_polynomial_commitments.size() != n_prev) return fail(MINA_ERR_FORMAT, "wrap proof shape does not match the installed index");
-        // recursion challenges of the wrap proof: messages_for_next_wrap_proof.old_bulletproof_challenges, expanded with the Pallas endo_r
-        for (uint32_t a = 0; a < n_prev; ++a) for (uint32_t j = 0; j < k; ++j) {          // expanded on the GPU (prev_prechallenges)
-            const mw::Chal128 &ch = w.old_bulletproof_challenges[a][j < 15 ? j : 14];
-            uint8_t e[16]; memcpy(e, &ch.lo, 8); memcpy(e + 8, &ch.hi, 8);
-            pch.insert(pch.end(), e, e + 16);
-        }
-        for (uint32_t a = 0; a < n_prev; ++a) put_pt(pcm, w.step_challenge_polynomial_commitments[a]);
-        for (int i = 0; i < 15; ++i) put_pt(wc, w.w_comm[i]);
-        put_pt(zc, w.z_comm);
-        for (int i = 0; i < 7; ++i) put_pt(tc, w.t_comm[i]);
-        put32(ev, w.z_eval[0]); put32(ev, w.z_eval[1]);
-        for (int i = 0; i < 6; ++i) { put32(ev, w.selector_eval[i][0]); put32(ev, w.selector_eval[i][1]); }
-        for (int i = 0; i < 15; ++i) { put32(ev, w.w_eval[i][0]); put32(ev, w.w_eval[i][1]); }
-        for (int i = 0; i < 15; ++i) { put32(ev, w.coefficients_eval[i][0]); put32(ev, w.coefficients_eval[i][1]); }
-        for (int i = 0; i < 6; ++i) { put32(ev, w.s_eval[i][0]); put32(ev, w.s_eval[i][1]); }
-        put32(ft1, w.ft_eval1);
-        for (auto &q : w.lr) { put_pt(lr, q.first); put_pt(lr, q.second); }
-        put_pt(dl, w.delta); put_pt(sg, w.sg); put32(z1, w.z1); put32(z2, w.z2);
-    }
-    rb.assign(32, 0); rb[0] = 7; sb.assign(32, 0); sb[0] = 9;
-    kp.resize(sizeof(mina_kimchi_proofs));
-    mina_kimchi_proofs kk{}; kk.batch = n; kk.n_prev = n_prev; kk.npub = npub; kk.prev_prechallenges = (with_statements && n_prev == 2 && k == 15) ? nullptr : pch.data();   /* the statements' wrap_old_challenges are these very challenges */ kk.prev_comms = pcm.data(); kk.w_comm = wc.data();
-    kk.z_comm = zc.data(); kk.t_comm = tc.data(); kk.evals = ev.data(); kk.ft_eval1 = ft1.data();
-    if (with_statements) kk.statements = (const mina_pickles_statements *)storage[28].data();
-    memcpy(kp.data(), &kk, sizeof kk);
-    jobs->batch = n; jobs->with_ipa = 1; jobs->kimchi = (const mina_kimchi_proofs *)kp.data();
-    jobs->k = k; jobs->n_evalpoints = 2; jobs->n_comms = n_prev + 2 + mb::KC_COLS; jobs->log2_domain = k; jobs->npub = npub;
-    jobs->public_inputs = nullptr;                  // derived on the GPU from kk.statements
-    jobs->lr = lr.data(); jobs->delta = dl.data(); jobs->sg = sg.data(); jobs->z1 = z1.data(); jobs->z2 = z2.data(); jobs->rand_base = rb.data(); jobs->sg_rand_base = sb.data();
-    return MINA_OK;
-}

@@ -45,19 +45,18 @@ struct StepIndexHost {
     std::vector<mb::KimchiToken> toks; std::vector<fe_t> lits; fe_t mds[9]; fe_t endo_coeff;
     uint32_t max_col = 0;                                                        // highest evaluation column the program names
 };
-StepIndexHost &step_of(mina_ctx *c) {           // one per context, kept beside it (host-only data)
-    static std::mutex mu; static std::vector<std::pair<mina_ctx *, StepIndexHost *>> all;
+StepIndexHost &step_of(mina_ctx *c) {           // host half of the step index: owned by the context, freed with it (mina_ctx_destroy)
+    static std::mutex mu;
     std::lock_guard<std::mutex> lk(mu);
-    for (auto &p : all) if (p.first == c) return *p.second;
-    all.emplace_back(c, new StepIndexHost());
-    return *all.back().second;
+    if (!c->step_host) { c->step_host = new StepIndexHost(); c->step_host_free = [](void *p) { delete (StepIndexHost *)p; }; }
+    return *(StepIndexHost *)c->step_host;
 }
 
 struct Derived { fe_t cip, b, zeta_srs, zeta_dom, perm, xi, r; mw::Chal128 xi_chal; };
 
 }  // namespace
 
-int mb_step_index_installed(mina_ctx *c) { return step_of(c).installed ? 1 : 0; }
+int mb_step_index_installed(mina_ctx *c) { return (c->step_host && c->have_pickles_dev && step_of(c).installed) ? 1 : 0; }
 static int upload_step_index(mina_ctx *c, const StepIndexHost &st);
 
 extern "C" int mina_step_index_install(mina_ctx *c, const mina_step_index *si) {
@@ -119,7 +118,7 @@ int mb_pickles_public_inputs(mina_ctx *c, const mw::WrapProof *const *proofs, co
         fe_t zn = x.zeta, zwn = x.zetaw; for (uint32_t j = 0; j < SRS_LENGTH_LOG2; ++j) { zn = fe_sqr<FIELD_FP>(zn); zwn = fe_sqr<FIELD_FP>(zwn); }
         // wire order: w 15, coefficients 15, z, s 6, selectors 6, then the present optional ones -> kimchi column order
         const size_t order[43] = {30, 37, 38, 39, 40, 41, 42, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 31, 32, 33, 34, 35, 36};
-        auto comb = [&](const std::vector<mw::B32> &chunks, const fe_t &ptn, bool &good) { fe_t acc = fe_zero(); for (size_t j = chunks.size(); j-- > 0;) { good = good && mw::fp_canonical(chunks[j].b); acc = fe_add<FIELD_FP>(fe_mul<FIELD_FP>(acc, ptn), to_mont_bytes<FIELD_FP>(chunks[j].b, kp)); } return acc; };
+        auto comb = [&](const mw::SmallVec<mw::B32, 16> &chunks, const fe_t &ptn, bool &good) { fe_t acc = fe_zero(); for (size_t j = chunks.size(); j-- > 0;) { good = good && mw::fp_canonical(chunks[j].b); acc = fe_add<FIELD_FP>(fe_mul<FIELD_FP>(acc, ptn), to_mont_bytes<FIELD_FP>(chunks[j].b, kp)); } return acc; };
         bool good = w.prev_evals.size() >= 43;
         for (size_t j = 0; j < w.prev_evals.size() && good; ++j) {
             const mw::EvalPair &e = w.prev_evals[j < 43 ? order[j] : j];

@@ -115,6 +115,7 @@ template <int F> static void params_to_mont(const uint8_t *params, const FieldK 
     for (int r = 0; r < 55; ++r) for (int j = 0; j < 3; ++j) pp.rc[r][j] = load(9 + 3 * r + j);
 }
 
+bool mb_params_are_surrogate(int field, const uint8_t *params);   // api_verify.hip (the compiled-in tables)
 extern "C" int mina_poseidon_set_params(mina_ctx *c, int field, const uint8_t *params) {
     if (!c || !params) return fail(MINA_ERR_ARG, "null argument");
     if (bad_field(field)) return fail(MINA_ERR_ARG, "bad field");
@@ -139,6 +140,7 @@ extern "C" int mina_poseidon_set_params(mina_ctx *c, int field, const uint8_t *p
     HIPC(hipMemcpyAsync(c->pparams[field].p, &both, sizeof both, hipMemcpyHostToDevice, c->L->stream));
     HIPC(hipStreamSynchronize(c->L->stream));
     c->have_pparams[field] = true;
+    c->pparams_surrogate[field] = mb_params_are_surrogate(field, params);
     c->merkle_depth[field] = 0;
     if (field == FIELD_FP) c->have_state_salts = false;
     return MINA_OK;

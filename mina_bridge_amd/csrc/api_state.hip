@@ -129,14 +129,15 @@ static void info_from_state(const mw::ProtocolState &s, mina_protocol_state_info
 }
 
 int mb_pack_protocol_state(const mw::ProtocolState &s, uint8_t *record, uint32_t *n_body_fields, mina_protocol_state_info *info) {
-    std::vector<mw::B32> f;
-    mw::protocol_state_body_fields(s, f);
-    if (f.size() > MINA_PSTATE_SLOTS - 1) return fail(MINA_ERR_FORMAT, "protocol state body flattens to more field elements than a record holds");
-    memset(record, 0, (size_t)MINA_PSTATE_SLOTS * 32);
+    mw::Inputs in;
+    mw::protocol_state_body_inputs(s, in);
+    const size_t nf = in.count();
+    if (in.overflow || nf > MINA_PSTATE_SLOTS - 1) return fail(MINA_ERR_FORMAT, "protocol state body flattens to more field elements than a record holds");
     memcpy(record, s.previous_state_hash.b, 32);
-    for (size_t i = 0; i < f.size(); ++i) memcpy(record + 32 * (1 + i), f[i].b, 32);
-    *n_body_fields = (uint32_t)f.size();
-    if (info) info_from_state(s, info, (uint32_t)f.size());
+    in.write(record + 32);
+    memset(record + 32 * (1 + nf), 0, (size_t)(MINA_PSTATE_SLOTS - 1 - nf) * 32);
+    *n_body_fields = (uint32_t)nf;
+    if (info) info_from_state(s, info, (uint32_t)nf);
     return MINA_OK;
 }
 
@@ -311,12 +312,13 @@ static int leg_join(Lane &leg, Lane &into) {
     HIPC(hipStreamWaitEvent(into.stream, leg.ev_leg, 0));
     return MINA_OK;
 }
-static int state_jobs_on_lane(mina_ctx *c, const mina_state_jobs *j, uint32_t *d_verdicts, uint32_t *d_flags, bool split = false, uint32_t *d_stmt_out = nullptr) {
+// LI / LA: helper lanes of the wrap-proof leg and the accumulator leg (nullptr = everything on the current lane, in order)
+int mb_state_jobs_on_lane(mina_ctx *c, const mina_state_jobs *j, uint32_t *d_verdicts, uint32_t *d_flags, Lane *LI_, Lane *LA_, uint32_t *d_stmt_out) {
     Lane &L = *c->L;
     Lane *const L0 = c->L;
     Lane *LI = L0, *LA = L0;
-    if (split && L0 == &c->lanes[0] && c->nlanes == 1) {
-        LI = &c->lanes[1]; LA = &c->lanes[2];
+    if (LI_ && LA_ && LI_ != L0 && LA_ != L0 && LI_ != LA_) {
+        LI = LI_; LA = LA_;
         int frc;
         if ((frc = leg_fork(c, *L0, *LI)) || (frc = leg_fork(c, *L0, *LA))) return frc;
     }
@@ -422,7 +424,7 @@ extern "C" int mina_state_job_batch_dev(mina_ctx *c, const mina_state_jobs *jobs
     if (!c->have_state_salts && jobs->with_states) return fail(MINA_ERR_STATE, "call mina_state_jobs_prepare first");
     HIPC(hipSetDevice(c->device));
     c->next_lane();
-    return state_jobs_on_lane(c, jobs, (uint32_t *)d_verdicts, (uint32_t *)d_flags);
+    return mb_state_jobs_on_lane(c, jobs, (uint32_t *)d_verdicts, (uint32_t *)d_flags, nullptr, nullptr, nullptr);
 }
 
 // host-buffer form: one upload of every section, the pipeline, one download; when a folded check fails the proofs are
@@ -477,7 +479,9 @@ extern "C" int mina_state_job_batch(mina_ctx *c, const mina_state_jobs *jobs, ui
     if (d.kimchi) kd.public_inputs = d.public_inputs;
     if ((rc = L.st_verdicts.ensure(2 * B * 4 + 16))) return rc;
     uint32_t *dv = L.st_verdicts.as<uint32_t>(), *df = dv + B, *ds = df + 4;
-    if ((rc = state_jobs_on_lane(c, &d, dv, df, /*split=*/B <= 1024, ds))) return rc;
+    // small, latency-bound batches: the three independent legs go to three lanes (lane 0 plus two helpers), joined by events
+    const bool split = B <= 1024 && c->nlanes == 1;
+    if ((rc = mb_state_jobs_on_lane(c, &d, dv, df, split ? &c->lanes[1] : nullptr, split ? &c->lanes[2] : nullptr, ds))) return rc;
     std::vector<uint32_t> hv(2 * B + 4);
     if ((rc = d2h_sync(c, hv.data(), L.st_verdicts, (2 * B + 4) * 4))) return rc;
     std::vector<uint8_t> stmt_each(B); for (size_t b = 0; b < B; ++b) stmt_each[b] = hv[B + 4 + b] ? 1 : 0;
@@ -488,7 +492,7 @@ extern "C" int mina_state_job_batch(mina_ctx *c, const mina_state_jobs *jobs, ui
     {
         mina_state_jobs only = d; only.with_ipa = 0; only.with_accumulator = 0; only.npub = 0; only.kimchi = nullptr;
         if (only.with_states) {
-            if ((rc = state_jobs_on_lane(c, &only, dv, df))) return rc;
+            if ((rc = mb_state_jobs_on_lane(c, &only, dv, df, nullptr, nullptr, nullptr))) return rc;
             if ((rc = d2h_sync(c, hv.data(), L.st_verdicts, B * 4))) return rc;
             for (size_t b = 0; b < B; ++b) chain_each[b] = hv[b] ? 1 : 0;
         }
@@ -550,7 +554,7 @@ extern "C" int mina_state_job_batch(mina_ctx *c, const mina_state_jobs *jobs, ui
                     if (ipa_leg && rows_ok) { if ((r = mb_ipa_recheck_rows(c, lo, cnt, flags_at[q]))) return r; continue; }
                     mina_state_jobs sj = slice(d, lo, cnt);
                     if (ipa_leg) sj.with_accumulator = 0; else { sj.with_ipa = 0; sj.npub = 0; sj.kimchi = nullptr; }
-                    if ((r = state_jobs_on_lane(c, &sj, v, flags_at[q]))) return r;
+                    if ((r = mb_state_jobs_on_lane(c, &sj, v, flags_at[q], nullptr, nullptr, nullptr))) return r;
                 }
                 for (size_t q = 0; q < w; ++q) {
                     uint32_t f[4];

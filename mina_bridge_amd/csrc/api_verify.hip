@@ -17,57 +17,127 @@
 //                      reference tree does not hold; it runs when an index has been installed (mina_verifier_index_install),
 //                      otherwise the step cannot run and mina_verify_state answers `false` (mina_verify_state_checks tells
 //                      which steps ran and passed; MINA_VERIFY_ALLOW_MISSING_KIMCHI relaxes the verdict for integration tests).
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <mutex>
 #include <thread>
 
 #include "ctx.h"
+#include "sponge.cuh"
 #include "wire_proof.h"
 #include "poseidon_tables.inc"
 
 int mb_pack_protocol_state(const mw::ProtocolState &s, uint8_t *record, uint32_t *n_body_fields, mina_protocol_state_info *info);   // api_state.hip
 int mb_kimchi_available(mina_ctx *c);                                                                                                  // api_kimchi.hip
-int mb_kimchi_fill_jobs(mina_ctx *c, const mw::WrapProof *const *proofs, const uint8_t *const *tip_hashes, size_t n, mina_state_jobs *jobs,
-                        std::vector<std::vector<uint8_t>> &storage, std::vector<uint8_t> &statement_ok);
+int mb_step_index_installed(mina_ctx *c);                                                                                              // api_pickles.hip
+int mb_state_jobs_on_lane(mina_ctx *c, const mina_state_jobs *j, uint32_t *d_verdicts, uint32_t *d_flags, Lane *LI, Lane *LA, uint32_t *d_stmt_out);   // api_state.hip
 
 extern "C" const char *mina_poseidon_params_name(void) { return MB_POSEIDON_SET_NAME; }
+// the compiled-in tables are a surrogate while their name says UNPINNED: a context running on them is flagged (mina_verify_state refuses)
+bool mb_params_are_surrogate(int field, const uint8_t *params) {
+    return strstr(MB_POSEIDON_SET_NAME, "UNPINNED") != nullptr && (field == 0 || field == 1) && memcmp(params, MB_POSEIDON_TABLES[field], (9 + 165) * 32) == 0;
+}
 extern "C" int mina_poseidon_install_default_params(mina_ctx *c) {
     if (!c) return fail(MINA_ERR_ARG, "null argument");
     for (int f = 0; f < 2; ++f) { int rc = mina_poseidon_set_params(c, f, MB_POSEIDON_TABLES[f]); if (rc) return rc; }
     return MINA_OK;
 }
 
-// ------------------------------------------------------------------------------------------------ process-wide context
-static std::mutex g_mu;
-static mina_ctx *g_ctx = nullptr;
-static uint32_t g_flags = 0;
+// ------------------------------------------------------------------------------------------------ process-wide devices
+// One context per GPU the process may use: $MINA_VERIFY_DEVICES = "all" | comma list of device ordinals (an ordinal may repeat: several
+// logical contexts on one GPU, the test hook for the sharding code on a 1-GPU box); default: GPU $MINA_VERIFY_DEVICE, or 0.  Every
+// context holds both SRS, the Poseidon tables and -- once installed through mina_verify_install_* -- the verifier / step index.
+// mina_verify_state_batch cuts its proofs into contiguous shards, one per device (zero exchange, verdict bytes gathered
+// on the host); merged single-proof jobs are dealt round-robin.
+namespace {
+constexpr int NSLOT = 16;                  // chunks in flight per device: slot s runs on lane s of the context (helper lanes 16.. for forked legs)
+struct Slot { PinnedBuf host, out; DevBuf dev; hipEvent_t ev = nullptr; bool busy = false; };
+struct Device {
+    mina_ctx *c = nullptr; int ordinal = 0;
+    std::mutex mu;                         // serialises every call into `c` (a context has ONE current-lane cursor)
+    std::mutex slot_mu; std::condition_variable slot_cv; Slot slots[NSLOT];
+    uint32_t prepared_npub = 0xffffffffu;
+    std::atomic<unsigned> inflight{0};
+};
+std::mutex g_mu;                           // guards the device list, the flags and set-up
+std::vector<Device *> g_devs; bool g_init_failed = false;
+uint32_t g_flags = 0;
+std::atomic<unsigned> g_rr{0};
 
-static mina_ctx *global_ctx() {            // caller holds g_mu
-    if (g_ctx) return g_ctx;
-    int dev = 0;
-    if (const char *e = getenv("MINA_VERIFY_DEVICE")) dev = atoi(e);
+int create_device(int ordinal, Device **out) {
     mina_ctx *c = nullptr;
-    if (mina_ctx_create(dev, &c) != MINA_OK) return nullptr;
-    if (mina_poseidon_install_default_params(c) != MINA_OK || mina_srs_create(c, CURVE_VESTA, 1u << 16) != MINA_OK ||
-        mina_srs_create(c, CURVE_PALLAS, 1u << 16) != MINA_OK) { mina_ctx_destroy(c); return nullptr; }
-    g_ctx = c;
-    return g_ctx;
+    int rc = mina_ctx_create(ordinal, &c);
+    if (rc) return rc;
+    if ((rc = mina_poseidon_install_default_params(c)) || (rc = mina_srs_create(c, CURVE_VESTA, 1u << 16)) || (rc = mina_srs_create(c, CURVE_PALLAS, 1u << 16))) { mina_ctx_destroy(c); return rc; }
+    Device *d = new Device(); d->c = c; d->ordinal = ordinal;
+    *out = d;
+    return MINA_OK;
 }
+std::vector<Device *> &devices() {          // caller holds g_mu
+    if (!g_devs.empty() || g_init_failed) return g_devs;
+    std::vector<int> ords;
+    if (const char *e = getenv("MINA_VERIFY_DEVICES")) {
+        if (!strcmp(e, "all")) { int n = 0; if (hipGetDeviceCount(&n) == hipSuccess) for (int i = 0; i < n; ++i) ords.push_back(i); }
+        else for (const char *p = e; *p;) { char *q; const long v = strtol(p, &q, 10); if (q == p) break; ords.push_back((int)v); p = *q == ',' ? q + 1 : q; }
+    }
+    if (ords.empty()) ords.push_back(getenv("MINA_VERIFY_DEVICE") ? atoi(getenv("MINA_VERIFY_DEVICE")) : 0);
+    for (int o : ords) {
+        Device *d = nullptr;
+        if (create_device(o, &d) != MINA_OK) { for (Device *x : g_devs) { mina_ctx_destroy(x->c); delete x; } g_devs.clear(); g_init_failed = true; break; }
+        g_devs.push_back(d);
+    }
+    return g_devs;
+}
+void destroy_devices() {                    // caller holds g_mu
+    for (Device *d : g_devs) {
+        { std::lock_guard<std::mutex> lk(d->mu);
+          (void)hipSetDevice(d->c->device);
+          for (Slot &s : d->slots) { if (s.ev) { (void)hipEventSynchronize(s.ev); (void)hipEventDestroy(s.ev); } s.host.release(); s.out.release(); s.dev.release(); }
+          mina_ctx_destroy(d->c); }
+        delete d;
+    }
+    g_devs.clear(); g_init_failed = false;
+}
+}  // namespace
+
 extern "C" int mina_verify_configure(uint32_t flags) { std::lock_guard<std::mutex> lk(g_mu); g_flags = flags; return MINA_OK; }
-extern "C" int mina_verify_shutdown(void) { std::lock_guard<std::mutex> lk(g_mu); if (g_ctx) mina_ctx_destroy(g_ctx); g_ctx = nullptr; return MINA_OK; }
-// the process-wide context, e.g. to install a verifier index or different Poseidon tables; NULL if no GPU / set-up failed
-extern "C" mina_ctx *mina_verify_global_ctx(void) { std::lock_guard<std::mutex> lk(g_mu); return global_ctx(); }
+extern "C" int mina_verify_shutdown(void) { std::lock_guard<std::mutex> lk(g_mu); destroy_devices(); return MINA_OK; }
+// the first device's context (a process with one GPU: THE context), e.g. to install a verifier index or other Poseidon tables; NULL if no
+// GPU / set-up failed.  Install before the first verification: installing is not synchronised against calls in flight.
+extern "C" mina_ctx *mina_verify_global_ctx(void) { std::lock_guard<std::mutex> lk(g_mu); auto &d = devices(); return d.empty() ? nullptr : d[0]->c; }
+extern "C" int mina_verify_device_count(void) { std::lock_guard<std::mutex> lk(g_mu); return (int)devices().size(); }
+extern "C" mina_ctx *mina_verify_device_ctx(int i) { std::lock_guard<std::mutex> lk(g_mu); auto &d = devices(); return (i < 0 || (size_t)i >= d.size()) ? nullptr : d[(size_t)i]->c; }
+// the same data on EVERY device of the process (what a multi-GPU deployment calls instead of the per-context installers)
+extern "C" int mina_verify_install_verifier_index(const mina_verifier_index *ix) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto &ds = devices(); if (ds.empty()) return fail(MINA_ERR_HIP, "no device");
+    for (Device *d : ds) { std::lock_guard<std::mutex> dl(d->mu); int rc = mina_verifier_index_install(d->c, ix); if (rc) return rc; d->prepared_npub = 0xffffffffu; }
+    return MINA_OK;
+}
+extern "C" int mina_verify_install_step_index(const mina_step_index *ix) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto &ds = devices(); if (ds.empty()) return fail(MINA_ERR_HIP, "no device");
+    for (Device *d : ds) { std::lock_guard<std::mutex> dl(d->mu); int rc = mina_step_index_install(d->c, ix); if (rc) return rc; }
+    return MINA_OK;
+}
+extern "C" int mina_verify_set_poseidon_params(int field, const uint8_t *params) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto &ds = devices(); if (ds.empty()) return fail(MINA_ERR_HIP, "no device");
+    for (Device *d : ds) { std::lock_guard<std::mutex> dl(d->mu); int rc = mina_poseidon_set_params(d->c, field, params); if (rc) return rc; }
+    return MINA_OK;
+}
 
 // ------------------------------------------------------------------------------------------------ merging of concurrent single-proof calls
 // The reference's entry points take ONE proof and are called from many goroutines / tokio tasks at once.  One proof is
 // a 25 ms dependent chain that leaves the chip idle, so concurrent callers are merged (group commit): the first caller runs a job with
 // everything queued at that moment; calls arriving while it runs wait and leave together as the next job, led by one of them.  A lone
-// caller pays nothing; N concurrent callers share one job of N proofs.  Verdicts are per proof either way (the batch entry points
-// isolate failing proofs).  MINA_VERIFY_NO_MERGE=1 sends every call through on its own; MINA_VERIFY_LINGER_US (default 500) is how long
-// the leader of a job waits for the callers of the previous job to come back before it leaves.
+// caller pays nothing; N concurrent callers share one job of N proofs.  Verdicts are per proof either way: the folded checks of a job use
+// randomisers drawn from the operating system's CSPRNG after every proof of the job is fixed (as upstream's `batch_verify` draws its own),
+// so one caller's proof cannot be built to cancel another's.  MINA_VERIFY_NO_MERGE=1 sends every call through on its own;
+// MINA_VERIFY_LINGER_US (default 500) is how long the leader of a job waits for the callers of the previous job to come back before it leaves.
 namespace {
-struct PendingCall { const uint8_t *proof; size_t proof_len; const uint8_t *pub; size_t pub_len; void *parsed = nullptr; uint8_t verdict = 0; bool done = false; };
+struct PendingCall { const uint8_t *proof; size_t proof_len; const uint8_t *pub; size_t pub_len; uint8_t verdict = 0; bool done = false; };
 typedef void (*exec_fn_t)(std::vector<PendingCall *> &job);           // sets `verdict` of every call of the job
 struct CallMerger {
     std::mutex mu; std::condition_variable cv, arrived; std::vector<PendingCall *> waiting; bool leader = false;
@@ -105,190 +175,475 @@ CallMerger g_state_calls, g_account_calls;
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ Proof of State
+// bytes -> bools, pipelined (core/src/aligned.rs:31-58 builds the bytes; core/src/proof/state_proof.rs:10-41 their layout):
+//   the proofs of a call are cut into chunks of ~1024; the host pool parses chunk i + 1 STRAIGHT INTO the page-locked structure-of-arrays
+//   staging of its slot (bincode containers, 17 protocol states flattened by `to_input`, ledger / consensus checks) while chunk i is copied
+//   to the GPU and chunk i - 1 runs on its lane (mb_state_jobs_on_lane: no host synchronisation inside); verdict words come back through
+//   page-locked memory.  No per-call allocation, no gather copy.  A chunk whose folded check fails goes through the culprit search of
+//   mina_state_job_batch from the same staging.
 namespace {
-struct ParsedState {
-    ParsedState() {}                     // user-provided: a vector of these is NOT zero-filled (40 KB each)
-    bool format_ok = false, ledger_ok = false, consensus_ok = false;
-    mina_state_pub_inputs pub;
-    mw::StateProofContainer box;
-    uint8_t records[MINA_STATES_PER_PROOF][MINA_PSTATE_SLOTS * 32]; uint32_t nfields[MINA_STATES_PER_PROOF];
-    mina_protocol_state_info info[MINA_STATES_PER_PROOF];
+struct Shape { bool kimchi = false, statements = false; uint32_t k = 0, n_prev = 2, n_old = 0, n_ev = 0; };
+enum Sec : int { S_REC = 0, S_NF, S_EXP, S_PRE, S_APRE, S_ASG, S_ARHO, S_LR, S_DELTA, S_SG, S_Z1, S_Z2, S_PCM, S_WC, S_ZC, S_TC, S_EV, S_FT1, S_PCH,
+                 S_PLONK, S_BP, S_OLD, S_CM, S_WOLD, S_WSG, S_DG, S_SEV, S_PI, S_SFT, S_APP, S_MISC, S_RB, S_SB, NSEC };
+struct Layout {
+    size_t stride[NSEC] = {0}, off[NSEC] = {0}, total = 0, cap = 0;
+    void build(const Shape &sh, size_t cap_) {
+        cap = cap_;
+        for (size_t &x : stride) x = 0;
+        stride[S_REC] = (size_t)MINA_STATES_PER_PROOF * MINA_PSTATE_SLOTS * 32; stride[S_NF] = MINA_STATES_PER_PROOF * 4; stride[S_EXP] = MINA_STATES_PER_PROOF * 32; stride[S_PRE] = 1;
+        stride[S_APRE] = 16 * 16; stride[S_ASG] = 64; stride[S_ARHO] = 32;
+        if (sh.kimchi) {
+            stride[S_LR] = 2 * (size_t)sh.k * 64; stride[S_DELTA] = 64; stride[S_SG] = 64; stride[S_Z1] = 32; stride[S_Z2] = 32;
+            stride[S_PCM] = sh.n_prev * 64; stride[S_WC] = 15 * 64; stride[S_ZC] = 64; stride[S_TC] = 7 * 64; stride[S_EV] = 43 * 64; stride[S_FT1] = 32;
+            if (!sh.statements || sh.k != 15 || sh.n_prev != 2) stride[S_PCH] = (size_t)sh.n_prev * sh.k * 16;   // else the statement's wrap_old_challenges ARE the recursion challenges
+            if (sh.statements) {
+                stride[S_PLONK] = 64; stride[S_BP] = 256; stride[S_OLD] = (size_t)sh.n_old * 256; stride[S_CM] = (size_t)sh.n_old * 64; stride[S_WOLD] = 480; stride[S_WSG] = 64;
+                stride[S_DG] = 32; stride[S_SEV] = (size_t)sh.n_ev * 64; stride[S_PI] = 64; stride[S_SFT] = 32; stride[S_APP] = 32; stride[S_MISC] = 32;
+            }
+        }
+        total = 0;
+        for (int i = 0; i < NSEC; ++i) {
+            off[i] = total;
+            const size_t bytes = (i == S_RB || i == S_SB) ? (sh.kimchi ? 32 : 0) : stride[i] * cap;
+            total += (bytes + 255) & ~(size_t)255;
+        }
+    }
+    uint8_t *at(uint8_t *base, int sec, size_t b) const { return base + off[sec] + b * stride[sec]; }
+    const uint8_t *at(const uint8_t *base, int sec, size_t b) const { return base + off[sec] + b * stride[sec]; }
+    size_t out_off() const { return total; }                         // device side only: verdict words behind the inputs
+    static size_t out_bytes(size_t B) { return (2 * B + 4) * 4; }
 };
+// per-proof outcome of the host side
+struct HostBits { uint8_t parsed = 0, ledger = 0, consensus = 0, shape = 0, deferred = 0; };
 
-void chal_bytes(const mw::Chal128 &c, uint8_t *o) { for (int i = 0; i < 8; ++i) { o[i] = (uint8_t)(c.lo >> (8 * i)); o[8 + i] = (uint8_t)(c.hi >> (8 * i)); } }
+void put_chal(uint8_t *o, const mw::Chal128 &c) { memcpy(o, &c.lo, 8); memcpy(o + 8, &c.hi, 8); }
+void chal_bytes(const mw::Chal128 &c, uint8_t *o) { put_chal(o, c); }
+template <int F> fe_t host_mont(const uint8_t *b, const FieldK &k) { fe_t a; memcpy(a.v, b, 32); return fe_to_mont<F>(a, k.r2); }
+void put_pt(uint8_t *o, const mw::Pt &p) { memcpy(o, p.x.b, 32); memcpy(o + 32, p.y.b, 32); }
 
-// host part of one proof: FORMAT, LEDGER, CONSENSUS
-void parse_state(const uint8_t *proof, size_t proof_len, const uint8_t *pub, size_t pub_len, ParsedState &ps) {
+// kimchi gates whose constraints read lookup tables (or the joint combiner): the installed linearization carries no lookup terms
+// (kimchi_dev.cuh evaluates MINA_TOK_JOINT_COMBINER as zero), so a statement that switches one on is REJECTED at the kimchi step instead of
+// being evaluated with zeros.  feature_flags: range_check0, range_check1, foreign_field_add, foreign_field_mul, xor, rot, lookup, runtime_tables.
+bool uses_lookups(const mw::WrapProof &w) {
+    return w.has_joint_combiner || w.feature_flags[0] || w.feature_flags[1] || w.feature_flags[3] || w.feature_flags[4] || w.feature_flags[5] || w.feature_flags[6] || w.feature_flags[7];
+}
+
+mw::StateProofContainer &tl_box() { static thread_local std::unique_ptr<mw::StateProofContainer> b; if (!b) b.reset(new mw::StateProofContainer()); return *b; }
+
+// host part of one proof: FORMAT, LEDGER, CONSENSUS + its entry of the staging.  `sh.n_old / n_ev == 0xffffffff`: take them from the proof
+// (single-proof diagnostic form).  Returns with hb.parsed = 0 and an untouched entry when the bytes are malformed.
+void parse_into(const Shape &sh, const Layout &lay, uint8_t *base, size_t b, const uint8_t *proof, size_t proof_len, const uint8_t *pub, size_t pub_len, HostBits &hb, const mina_ctx *c) {
+    hb = HostBits{};
     if (!proof || !pub) return;
-    if (mina_parse_state_pub_inputs(pub, pub_len, &ps.pub) != MINA_OK) return;
-    if (!mw::read_state_proof(proof, proof_len, ps.box)) return;
+    mina_state_pub_inputs pi;
+    if (mina_parse_state_pub_inputs(pub, pub_len, &pi) != MINA_OK) return;
+    mw::StateProofContainer &box = tl_box();
+    if (!mw::read_state_proof(proof, proof_len, box)) return;
+    const mw::WrapProof &w = box.tip_proof;
+    if (w.lr.empty() || w.lr.size() > 20 || w.step_challenge_polynomial_commitments.size() != w.step_old_bulletproof_challenges.size()) return;
+    mina_protocol_state_info info[MINA_STATES_PER_PROOF];
+    uint8_t *recs = lay.at(base, S_REC, b); uint32_t *nf = (uint32_t *)lay.at(base, S_NF, b);
     for (int i = 0; i < MINA_STATES_PER_PROOF; ++i)
-        if (mb_pack_protocol_state(ps.box.states[i], ps.records[i], &ps.nfields[i], &ps.info[i]) != MINA_OK) return;
-    if (ps.box.tip_proof.lr.empty() || ps.box.tip_proof.lr.size() > 20 || ps.box.tip_proof.step_challenge_polynomial_commitments.size() != ps.box.tip_proof.step_old_bulletproof_challenges.size()) return;
-    ps.format_ok = true;
+        if (mb_pack_protocol_state(box.states[i], recs + (size_t)i * MINA_PSTATE_SLOTS * 32, &nf[i], &info[i]) != MINA_OK) return;
+    hb.parsed = 1;
     bool ledger = true;
-    for (int i = 0; i < 16; ++i) ledger = ledger && memcmp(ps.pub.candidate_chain_ledger_hashes[i], ps.info[i].snarked_ledger_hash, 32) == 0;
-    ps.ledger_ok = ledger;
+    for (int i = 0; i < 16; ++i) ledger = ledger && memcmp(pi.candidate_chain_ledger_hashes[i], info[i].snarked_ledger_hash, 32) == 0;
+    hb.ledger = ledger;
     // chain selection between the bridge tip (state 16) and the candidate tip (state 15); tie-breaks use the hashes the public
     // input names (the CHAIN step proves them) and Blake2b-256 of the last VRF output (`hashLastVRF`)
-    mina_consensus_state tip = ps.info[16].consensus, cand = ps.info[15].consensus;
-    memcpy(tip.state_hash, ps.pub.bridge_tip_state_hash, 32); memcpy(cand.state_hash, ps.pub.candidate_chain_state_hashes[15], 32);
-    blake2b_short(ps.box.states[16].last_vrf_output.data(), 32, tip.last_vrf_output_hash, 32);
-    blake2b_short(ps.box.states[15].last_vrf_output.data(), 32, cand.last_vrf_output_hash, 32);
-    mina_consensus_params cp{ps.info[15].slots_per_sub_window, ps.info[15].sub_windows_per_window};
+    mina_consensus_state tip = info[16].consensus, cand = info[15].consensus;
+    memcpy(tip.state_hash, pi.bridge_tip_state_hash, 32); memcpy(cand.state_hash, pi.candidate_chain_state_hashes[15], 32);
+    blake2b_short(box.states[16].last_vrf_output.data(), 32, tip.last_vrf_output_hash, 32);
+    blake2b_short(box.states[15].last_vrf_output.data(), 32, cand.last_vrf_output_hash, 32);
+    mina_consensus_params cp{info[15].slots_per_sub_window, info[15].sub_windows_per_window};
     int sel = 0;
-    if (ps.info[16].sub_windows_per_window == cp.sub_windows_per_window && cp.sub_windows_per_window >= 1 && cp.sub_windows_per_window <= MINA_MAX_SUB_WINDOWS &&
+    if (info[16].sub_windows_per_window == cp.sub_windows_per_window && cp.sub_windows_per_window >= 1 && cp.sub_windows_per_window <= MINA_MAX_SUB_WINDOWS &&
         cp.slots_per_sub_window >= 1 && mina_consensus_select_secure_chain(&cp, &tip, &cand, &sel) == MINA_OK)
-        ps.consensus_ok = sel == 1;
-}
-
-// GPU part of n proofs (those whose FORMAT passed): CHAIN + ACCUMULATOR (+ KIMCHI) through the Proof-of-State job
-// `masks`: one job per step so that every step gets its own bit (mina_verify_state_checks); otherwise ONE job with all legs -- the
-// verdict-only entry points need nothing finer, and the legs overlap on the GPU
-int run_state_jobs(mina_ctx *c, std::vector<ParsedState *> &ps, std::vector<uint32_t> &passed, std::vector<uint32_t> &ran, bool masks) {
-    const size_t n = ps.size();
-    if (n == 0) return MINA_OK;
-    const auto tg = std::chrono::steady_clock::now();
-    std::unique_ptr<uint8_t[]> recs_(new uint8_t[n * MINA_STATES_PER_PROOF * MINA_PSTATE_SLOTS * 32]);      // 34 KB per proof: not zero-filled, every byte is written below
-    uint8_t *recs = recs_.get();
-    std::vector<uint8_t> exp(n * MINA_STATES_PER_PROOF * 32), pre(n * 16 * 16), sg(n * 64), rho(n * 32);
-    std::vector<uint32_t> nf(n * MINA_STATES_PER_PROOF);
-    mb_parallel_for(n, [&](size_t b) {
-        memcpy(&recs[b * sizeof ps[b]->records], ps[b]->records, sizeof ps[b]->records);
-        memcpy(&nf[b * MINA_STATES_PER_PROOF], ps[b]->nfields, sizeof ps[b]->nfields);
-        memcpy(&exp[b * MINA_STATES_PER_PROOF * 32], ps[b]->pub.candidate_chain_state_hashes, 512);
-        memcpy(&exp[b * MINA_STATES_PER_PROOF * 32 + 512], ps[b]->pub.bridge_tip_state_hash, 32);
-        const mw::WrapProof &w = ps[b]->box.tip_proof;
-        for (int i = 0; i < 16; ++i) chal_bytes(w.bulletproof_challenges[i], &pre[(b * 16 + i) * 16]);
-        memcpy(&sg[b * 64], w.challenge_polynomial_commitment.x.b, 32); memcpy(&sg[b * 64 + 32], w.challenge_polynomial_commitment.y.b, 32);
-    });
-    // batching randomisers of the folded accumulator check: SplitMix64 over the proof bytes' digest would make them unpredictable to
-    // a prover; here a per-call counter-seeded stream (the folded check only needs them independent of the proofs' contents)
-    { static uint64_t ctr = 0x6d696e61ULL; uint64_t st = (ctr += 0x9E3779B97F4A7C15ULL);
-      for (size_t i = 0; i < rho.size(); i += 8) { uint64_t z = (st += 0x9E3779B97F4A7C15ULL); z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL; z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL; z ^= z >> 31; memcpy(&rho[i], &z, 8); }
-      for (size_t b = 0; b < n; ++b) rho[b * 32 + 31] &= 0x3f; }
-    auto run = [&](mina_state_jobs &j, std::vector<uint8_t> &v) { v.assign(n, 0); return mina_state_job_batch(c, &j, v.data()); };
-    mina_state_jobs base{}; base.batch = n;
-    int rc;
-    std::vector<uint8_t> v;
-    if (!masks) {
-        mina_state_jobs j = base; std::vector<std::vector<uint8_t>> storage; std::vector<uint8_t> stmt_ok(n, 1);
-        uint32_t steps = MINA_CHECK_CHAIN | MINA_CHECK_ACCUMULATOR;
-        if (mb_kimchi_available(c)) {
-            std::vector<const mw::WrapProof *> wp(n); std::vector<const uint8_t *> th(n);
-            for (size_t b = 0; b < n; ++b) { wp[b] = &ps[b]->box.tip_proof; th[b] = ps[b]->pub.candidate_chain_state_hashes[15]; }
-            if ((rc = mb_kimchi_fill_jobs(c, wp.data(), th.data(), n, &j, storage, stmt_ok))) return rc;
-            steps |= MINA_CHECK_KIMCHI;
+        hb.consensus = sel == 1;
+    uint8_t *exp = lay.at(base, S_EXP, b);
+    memcpy(exp, pi.candidate_chain_state_hashes, 512); memcpy(exp + 512, pi.bridge_tip_state_hash, 32);
+    uint8_t *apre = lay.at(base, S_APRE, b);
+    for (int i = 0; i < 16; ++i) put_chal(apre + 16 * i, w.bulletproof_challenges[i]);
+    put_pt(lay.at(base, S_ASG, b), w.challenge_polynomial_commitment);
+    hb.shape = 1;
+    if (sh.kimchi) {
+        // the wrap proof must have the shape of the installed index: k rounds, n_prev step-side accumulators, no lookup features; a well-formed
+        // proof of another evaluation / recursion shape is verified in a job of its own (`deferred`), a malformed one fails here
+        const size_t n_old = w.step_old_bulletproof_challenges.size(), n_ev = w.prev_evals.size();
+        if (w.lr.size() != sh.k || w.step_challenge_polynomial_commitments.size() != sh.n_prev || uses_lookups(w) || n_old > 4 || n_ev < 43 || n_ev > 62 ||
+            w.prev_public_input.zeta.empty() || w.prev_public_input.zeta_omega.empty()) hb.shape = 0;
+        else if (sh.statements && (n_old != sh.n_old || n_ev != sh.n_ev)) { hb.shape = 0; hb.deferred = 1; }
+    }
+    if (sh.kimchi && hb.shape) {
+        uint8_t *lr = lay.at(base, S_LR, b);
+        for (size_t i = 0; i < w.lr.size(); ++i) { put_pt(lr + 128 * i, w.lr[i].first); put_pt(lr + 128 * i + 64, w.lr[i].second); }
+        put_pt(lay.at(base, S_DELTA, b), w.delta); put_pt(lay.at(base, S_SG, b), w.sg);
+        memcpy(lay.at(base, S_Z1, b), w.z1.b, 32); memcpy(lay.at(base, S_Z2, b), w.z2.b, 32);
+        uint8_t *pcm = lay.at(base, S_PCM, b);
+        for (uint32_t a = 0; a < sh.n_prev; ++a) put_pt(pcm + 64 * a, w.step_challenge_polynomial_commitments[a]);
+        uint8_t *wc = lay.at(base, S_WC, b); for (int i = 0; i < 15; ++i) put_pt(wc + 64 * i, w.w_comm[i]);
+        put_pt(lay.at(base, S_ZC, b), w.z_comm);
+        uint8_t *tc = lay.at(base, S_TC, b); for (int i = 0; i < 7; ++i) put_pt(tc + 64 * i, w.t_comm[i]);
+        uint8_t *ev = lay.at(base, S_EV, b);       // kimchi column order: z, 6 selectors, 15 w, 15 coefficients, 6 sigma; (zeta, zeta * omega) each
+        auto pair = [&](const mw::B32 (&e)[2]) { memcpy(ev, e[0].b, 32); memcpy(ev + 32, e[1].b, 32); ev += 64; };
+        pair(w.z_eval); for (int i = 0; i < 6; ++i) pair(w.selector_eval[i]); for (int i = 0; i < 15; ++i) pair(w.w_eval[i]);
+        for (int i = 0; i < 15; ++i) pair(w.coefficients_eval[i]); for (int i = 0; i < 6; ++i) pair(w.s_eval[i]);
+        memcpy(lay.at(base, S_FT1, b), w.ft_eval1.b, 32);
+        if (lay.stride[S_PCH]) {                   // recursion challenges of the wrap proof: messages_for_next_wrap_proof.old_bulletproof_challenges (expanded on the GPU)
+            uint8_t *pch = lay.at(base, S_PCH, b);
+            for (uint32_t a = 0; a < sh.n_prev; ++a) for (uint32_t j = 0; j < sh.k; ++j) put_chal(pch + 16 * (a * sh.k + j), w.old_bulletproof_challenges[a < 2 ? a : 1][j < 15 ? j : 14]);
         }
-        j.with_states = 1; j.state_records = recs; j.state_nfields = nf.data(); j.expected_hashes = exp.data();
-        j.with_accumulator = 1; j.acc_k = 16; j.acc_prechallenges = pre.data(); j.acc_sg = sg.data(); j.acc_rho = rho.data();
-        const auto tj = std::chrono::steady_clock::now();
-        if ((rc = run(j, v))) return rc;
-        if (getenv("MINA_VERIFY_TIMING")) fprintf(stderr, "mina_verify:   gather+fill %.2f ms, mina_state_job_batch %.2f ms\n", std::chrono::duration<double, std::milli>(tj - tg).count(),
-                                                  std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tj).count());
-        for (size_t b = 0; b < n; ++b) { ran[b] |= steps; if (v[b] && stmt_ok[b]) passed[b] |= steps; }
-        return MINA_OK;
+        if (sh.statements) {
+            // the wrap circuit's public input = the Pickles statement: derived on the GPU inside the job (api_pickles.hip)
+            uint8_t *pl = lay.at(base, S_PLONK, b); put_chal(pl, w.alpha); put_chal(pl + 16, w.beta); put_chal(pl + 32, w.gamma); put_chal(pl + 48, w.zeta);
+            uint8_t *bp = lay.at(base, S_BP, b); for (int j = 0; j < 16; ++j) put_chal(bp + 16 * j, w.bulletproof_challenges[j]);
+            uint8_t *old = lay.at(base, S_OLD, b); for (size_t a = 0; a < sh.n_old; ++a) for (int j = 0; j < 16; ++j) put_chal(old + 256 * a + 16 * j, w.step_old_bulletproof_challenges[a][j]);
+            uint8_t *cm = lay.at(base, S_CM, b); for (size_t a = 0; a < sh.n_old; ++a) put_pt(cm + 64 * a, w.step_challenge_polynomial_commitments[a]);
+            uint8_t *wo = lay.at(base, S_WOLD, b); for (int a = 0; a < 2; ++a) for (int j = 0; j < 15; ++j) put_chal(wo + 16 * (15 * a + j), w.old_bulletproof_challenges[a][j]);
+            put_pt(lay.at(base, S_WSG, b), w.challenge_polynomial_commitment);
+            memcpy(lay.at(base, S_DG, b), w.sponge_digest_before_evaluations, 32);
+            // evaluations: one chunk each in every Mina step proof; chunked ones are combined here with zeta^(2^16) (host field arithmetic)
+            static const size_t order[43] = {30, 37, 38, 39, 40, 41, 42, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 31, 32, 33, 34, 35, 36};
+            bool chunked = w.prev_public_input.zeta.size() != 1 || w.prev_public_input.zeta_omega.size() != 1;
+            for (const mw::EvalPair &e : w.prev_evals) chunked = chunked || e.zeta.size() != 1 || e.zeta_omega.size() != 1;
+            const FieldK &kpf = c->fk[FIELD_FP];
+            fe_t zn = fe_zero(), zwn = fe_zero();
+            if (chunked) {
+                const fe_t zeta = challenge_to_field<FIELD_FP>(w.zeta.lo, w.zeta.hi, kpf);
+                fe_t om = kpf.root; for (uint32_t j = 0; j + w.domain_log2 < 32; ++j) om = fe_sqr<FIELD_FP>(om);
+                zn = zeta; zwn = fe_mul<FIELD_FP>(zeta, om);
+                for (int j = 0; j < 16; ++j) { zn = fe_sqr<FIELD_FP>(zn); zwn = fe_sqr<FIELD_FP>(zwn); }
+            }
+            uint8_t *sev = lay.at(base, S_SEV, b);
+            auto comb = [&](const mw::SmallVec<mw::B32, 16> &chunks, const fe_t &ptn) {
+                if (chunks.size() == 1) { memcpy(sev, chunks[0].b, 32); sev += 32; return; }
+                fe_t acc = fe_zero();
+                for (size_t j = chunks.size(); j-- > 0;) { if (!mw::fp_canonical(chunks[j].b)) hb.shape = 0; acc = fe_add<FIELD_FP>(fe_mul<FIELD_FP>(acc, ptn), host_mont<FIELD_FP>(chunks[j].b, kpf)); }
+                const fe_t pl_ = fe_from_mont<FIELD_FP>(acc); memcpy(sev, pl_.v, 32); sev += 32;
+            };
+            for (size_t j = 0; j < sh.n_ev; ++j) { const mw::EvalPair &e = w.prev_evals[j < 43 ? order[j] : j]; comb(e.zeta, zn); comb(e.zeta_omega, zwn); }
+            uint8_t *ppi = lay.at(base, S_PI, b); memcpy(ppi, w.prev_public_input.zeta[0].b, 32); memcpy(ppi + 32, w.prev_public_input.zeta_omega[0].b, 32);
+            memcpy(lay.at(base, S_SFT, b), w.prev_ft_eval1.b, 32);
+            memcpy(lay.at(base, S_APP, b), pi.candidate_chain_state_hashes[15], 32);          // the application state = hash of the candidate tip
+            uint8_t *misc = lay.at(base, S_MISC, b); memset(misc, 0, 32);
+            misc[0] = w.domain_log2; misc[1] = w.proofs_verified; for (int j = 0; j < 8; ++j) misc[2 + j] = w.feature_flags[j] ? 1 : 0;
+            misc[10] = w.has_joint_combiner ? 1 : 0; if (w.has_joint_combiner) put_chal(misc + 16, w.joint_combiner);
+        }
     }
-    {   // CHAIN
-        mina_state_jobs j = base; j.with_states = 1; j.state_records = recs; j.state_nfields = nf.data(); j.expected_hashes = exp.data();
-        if ((rc = run(j, v))) return rc;
-        for (size_t b = 0; b < n; ++b) { ran[b] |= MINA_CHECK_CHAIN; if (v[b]) passed[b] |= MINA_CHECK_CHAIN; }
-    }
-    {   // ACCUMULATOR
-        mina_state_jobs j = base; j.with_accumulator = 1; j.acc_k = 16; j.acc_prechallenges = pre.data(); j.acc_sg = sg.data(); j.acc_rho = rho.data();
-        if ((rc = run(j, v))) return rc;
-        for (size_t b = 0; b < n; ++b) { ran[b] |= MINA_CHECK_ACCUMULATOR; if (v[b]) passed[b] |= MINA_CHECK_ACCUMULATOR; }
-    }
-    if (mb_kimchi_available(c)) {   // KIMCHI: oracles + to_batch on the GPU, then the combined opening check
-        std::vector<const mw::WrapProof *> wp(n); std::vector<const uint8_t *> th(n);
-        for (size_t b = 0; b < n; ++b) { wp[b] = &ps[b]->box.tip_proof; th[b] = ps[b]->pub.candidate_chain_state_hashes[15]; }
-        mina_state_jobs j = base; std::vector<std::vector<uint8_t>> storage; std::vector<uint8_t> stmt_ok;
-        if ((rc = mb_kimchi_fill_jobs(c, wp.data(), th.data(), n, &j, storage, stmt_ok))) return rc;
-        if ((rc = run(j, v))) return rc;
-        for (size_t b = 0; b < n; ++b) { ran[b] |= MINA_CHECK_KIMCHI; if (v[b] && stmt_ok[b]) passed[b] |= MINA_CHECK_KIMCHI; }
-    }
-    return MINA_OK;
+    *lay.at(base, S_PRE, b) = (hb.ledger && hb.consensus && hb.shape) ? 1 : 0;
 }
 
-// n parsed proofs: host verdict bits, then ONE pass over the GPU for those whose FORMAT passed
-int verify_parsed(std::vector<ParsedState *> &ps, uint32_t *passed_out, uint32_t *ran_out, bool masks) {
-    const size_t n = ps.size();
-    std::vector<uint32_t> passed(n, 0), ran(n, 0);
-    std::vector<ParsedState *> live; std::vector<size_t> live_idx;
-    for (size_t i = 0; i < n; ++i) {
-        ran[i] |= MINA_CHECK_FORMAT;
-        if (!ps[i]->format_ok) continue;
-        passed[i] |= MINA_CHECK_FORMAT; ran[i] |= MINA_CHECK_LEDGER | MINA_CHECK_CONSENSUS;
-        if (ps[i]->ledger_ok) passed[i] |= MINA_CHECK_LEDGER;
-        if (ps[i]->consensus_ok) passed[i] |= MINA_CHECK_CONSENSUS;
-        live.push_back(ps[i]); live_idx.push_back(i);
+// the job over entries [0, B) of a staging at `base` (host or device addresses alike)
+struct JobStructs { mina_state_jobs j; mina_kimchi_proofs k; mina_pickles_statements s; };
+void make_jobs(const Shape &sh, const Layout &lay, uint8_t *base, size_t B, bool with_states, bool with_acc, bool with_kimchi, JobStructs &o) {
+    memset(&o.j, 0, sizeof o.j); memset(&o.k, 0, sizeof o.k); memset(&o.s, 0, sizeof o.s);
+    mina_state_jobs &j = o.j; j.batch = B;
+    if (with_states) { j.with_states = 1; j.state_records = lay.at(base, S_REC, 0); j.state_nfields = lay.at(base, S_NF, 0); j.expected_hashes = lay.at(base, S_EXP, 0); j.precheck = lay.at(base, S_PRE, 0); }
+    if (with_acc) { j.with_accumulator = 1; j.acc_k = 16; j.acc_prechallenges = lay.at(base, S_APRE, 0); j.acc_sg = lay.at(base, S_ASG, 0); j.acc_rho = lay.at(base, S_ARHO, 0); }
+    if (with_kimchi && sh.kimchi) {
+        mina_kimchi_proofs &k = o.k; k.batch = B; k.n_prev = sh.n_prev; k.npub = sh.statements ? 40 : 0;
+        k.prev_comms = lay.at(base, S_PCM, 0); k.w_comm = lay.at(base, S_WC, 0); k.z_comm = lay.at(base, S_ZC, 0); k.t_comm = lay.at(base, S_TC, 0); k.evals = lay.at(base, S_EV, 0); k.ft_eval1 = lay.at(base, S_FT1, 0);
+        if (sh.statements) {
+            mina_pickles_statements &s = o.s; s.n_old = sh.n_old; s.n_evals = sh.n_ev;
+            s.plonk = lay.at(base, S_PLONK, 0); s.bulletproof_challenges = lay.at(base, S_BP, 0); s.step_old_challenges = lay.at(base, S_OLD, 0); s.step_comms = lay.at(base, S_CM, 0);
+            s.wrap_old_challenges = lay.at(base, S_WOLD, 0); s.wrap_sg = lay.at(base, S_WSG, 0); s.sponge_digest = lay.at(base, S_DG, 0); s.prev_evals = lay.at(base, S_SEV, 0);
+            s.prev_public_input = lay.at(base, S_PI, 0); s.prev_ft_eval1 = lay.at(base, S_SFT, 0); s.app_state = lay.at(base, S_APP, 0); s.misc = lay.at(base, S_MISC, 0);
+            k.statements = &o.s;
+        }
+        if (lay.stride[S_PCH]) k.prev_prechallenges = lay.at(base, S_PCH, 0);
+        j.with_ipa = 1; j.kimchi = &o.k; j.k = sh.k; j.n_evalpoints = 2; j.n_comms = sh.n_prev + 2 + 43; j.log2_domain = sh.k; j.npub = k.npub;
+        j.lr = lay.at(base, S_LR, 0); j.delta = lay.at(base, S_DELTA, 0); j.sg = lay.at(base, S_SG, 0); j.z1 = lay.at(base, S_Z1, 0); j.z2 = lay.at(base, S_Z2, 0);
+        j.rand_base = lay.at(base, S_RB, 0); j.sg_rand_base = lay.at(base, S_SB, 0);
     }
-    if (!live.empty()) {
-        std::lock_guard<std::mutex> lk(g_mu);
-        mina_ctx *c = global_ctx();
-        if (!c) return MINA_ERR_HIP;
-        std::vector<uint32_t> lp(live.size(), 0), lr(live.size(), 0);
-        int rc = run_state_jobs(c, live, lp, lr, masks);
+}
+
+// The folding randomisers of one job: rand_base, sg_rand_base (powers fold the opening checks, `SRS::verify`) and one rho per accumulator
+// check, all from the operating system's CSPRNG, drawn AFTER the job's proofs are fixed and never reused across jobs -- upstream
+// `batch_verify` draws its own the same way.  Field elements below 2^254 (< both moduli).  false = no entropy: the job fails closed.
+bool draw_randomisers(const Shape &sh, const Layout &lay, uint8_t *base, size_t B) {
+    if (!mb_secure_random(lay.at(base, S_ARHO, 0), B * 32)) return false;
+    for (size_t b = 0; b < B; ++b) lay.at(base, S_ARHO, b)[31] &= 0x3f;
+    if (sh.kimchi) {
+        if (!mb_secure_random(lay.at(base, S_RB, 0), 32) || !mb_secure_random(lay.at(base, S_SB, 0), 32)) return false;
+        lay.at(base, S_RB, 0)[31] &= 0x3f; lay.at(base, S_SB, 0)[31] &= 0x3f;
+    }
+    return true;
+}
+
+// entries that did not parse / do not have the job's shape borrow a well-formed entry's bytes (their own verdict is already 0 through
+// `precheck`), so that they do not fail the job's folded checks for everyone else
+void copy_entry(const Layout &lay, uint8_t *base, size_t dst, size_t src) {
+    for (int i = 0; i < NSEC; ++i) if (lay.stride[i] && i != S_PRE) memcpy(lay.at(base, i, dst), lay.at(base, i, src), lay.stride[i]);
+}
+
+struct Config { bool usable = false, kimchi = false, statements = false; uint32_t k = 0; };
+Config read_config(Device &D, uint32_t flags) {
+    std::lock_guard<std::mutex> lk(D.mu);
+    mina_ctx *c = D.c; Config cf;
+    // a deployment on the library's surrogate Poseidon tables agrees with nothing on the Mina network: refuse unless the caller said so
+    const bool surrogate = c->pparams_surrogate[0] || c->pparams_surrogate[1];
+    cf.usable = !surrogate || (flags & MINA_VERIFY_ALLOW_SURROGATE);
+    cf.statements = mb_step_index_installed(c) != 0;
+    // without a step index the wrap proof's public input cannot be derived from the statement: the kimchi step is then NOT runnable
+    // (the proof would not be bound to the candidate tip) unless the caller explicitly accepts the unbound form
+    cf.kimchi = mb_kimchi_available(c) && (cf.statements || (flags & MINA_VERIFY_ALLOW_UNBOUND_STATEMENT));
+    cf.k = c->kimchi_log2;
+    return cf;
+}
+
+struct CallIn { const uint8_t *const *proofs; const size_t *proof_lens; const uint8_t *const *pubs; const size_t *pub_lens; };
+
+struct Chunk { size_t lo = 0, n = 0; Slot *slot = nullptr; int slot_ix = -1; std::shared_ptr<MbPoolJob> job; std::vector<HostBits> hb; bool issued = false, skipped = false, harvested = false; };
+
+const bool g_timing = getenv("MINA_VERIFY_TIMING") != nullptr;
+double ms_since(std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); }
+
+// verdict bytes of the proofs idx[0..m) of the call on device D
+int run_device(Device &D, const CallIn &in, const std::vector<size_t> &idx, uint8_t *verdicts, uint32_t flags, int depth = 0) {
+    const size_t m = idx.size();
+    for (size_t i = 0; i < m; ++i) verdicts[idx[i]] = 0;
+    if (m == 0) return MINA_OK;
+    const auto t_call = std::chrono::steady_clock::now();
+    const Config cf = read_config(D, flags);
+    if (!cf.usable) return MINA_OK;
+    if (!cf.kimchi && !(flags & MINA_VERIFY_ALLOW_MISSING_KIMCHI)) return MINA_OK;          // the kimchi step cannot run: nothing can pass
+    Shape sh; sh.kimchi = cf.kimchi; sh.statements = cf.kimchi && cf.statements; sh.k = cf.k;
+    if (sh.statements) {           // evaluation / recursion shape of the job: the first proof that parses names it (Mina's blockchain proofs all share one)
+        bool found = false;
+        for (size_t i = 0; i < m && !found; ++i) {
+            const size_t q = idx[i];
+            if (!in.proofs[q]) continue;
+            mw::StateProofContainer &box = tl_box();
+            mw::Bincode cur(in.proofs[q], in.proof_lens[q]);
+            if (!mw::read_wrap_proof(cur, box.tip_proof)) continue;
+            const size_t n_old = box.tip_proof.step_old_bulletproof_challenges.size(), n_ev = box.tip_proof.prev_evals.size();
+            if (n_old > 4 || n_ev < 43 || n_ev > 62) continue;
+            sh.n_old = (uint32_t)n_old; sh.n_ev = (uint32_t)n_ev; found = true;
+        }
+        if (!found) return MINA_OK;                                                          // nothing parses
+    }
+    static const size_t chunk_target = getenv("MINA_VERIFY_CHUNK") ? (size_t)std::max(1L, atol(getenv("MINA_VERIFY_CHUNK"))) : (size_t)1024;
+    static const size_t single_max = getenv("MINA_VERIFY_SINGLE_MAX") ? (size_t)std::max(1L, atol(getenv("MINA_VERIFY_SINGLE_MAX"))) : (size_t)1536;
+    const size_t nchunks = m <= single_max ? 1 : (m + chunk_target - 1) / chunk_target;
+    std::vector<Chunk> chunks(nchunks);
+    for (size_t q = 0; q < nchunks; ++q) { chunks[q].lo = m * q / nchunks; chunks[q].n = m * (q + 1) / nchunks - chunks[q].lo; chunks[q].hb.resize(chunks[q].n); }
+    const size_t cap = (m + nchunks - 1) / nchunks;
+    Layout lay; lay.build(sh, cap);
+    mina_ctx *c = D.c;
+    int rc_all = MINA_OK;
+    std::vector<size_t> deferred;
+    D.inflight.fetch_add((unsigned)nchunks);
+
+    auto try_acquire = [&]() -> int {
+        std::lock_guard<std::mutex> lk(D.slot_mu);
+        for (int s = 0; s < NSLOT; ++s) if (!D.slots[s].busy) { D.slots[s].busy = true; return s; }
+        return -1;
+    };
+    auto release = [&](int s) { { std::lock_guard<std::mutex> lk(D.slot_mu); D.slots[s].busy = false; } D.slot_cv.notify_all(); };
+
+    auto fallback = [&](Chunk &ch) -> int {     // a folded check of the chunk failed: per-proof verdicts through the culprit search, from the same staging
+        std::lock_guard<std::mutex> lk(D.mu);
+        JobStructs js; make_jobs(sh, lay, (uint8_t *)ch.slot->host.p, ch.n, true, true, true, js);
+        std::vector<uint8_t> v(ch.n, 0);
+        const auto t = std::chrono::steady_clock::now();
+        int rc = mina_state_job_batch(c, &js.j, v.data());
+        if (g_timing) fprintf(stderr, "mina_verify: chunk of %zu: folded check failed, culprit search %.2f ms (rc %d)\n", ch.n, ms_since(t), rc);
         if (rc) return rc;
-        for (size_t k = 0; k < live.size(); ++k) { passed[live_idx[k]] |= lp[k]; ran[live_idx[k]] |= lr[k]; }
+        for (size_t b = 0; b < ch.n; ++b) verdicts[idx[ch.lo + b]] = (v[b] && ch.hb[b].parsed && ch.hb[b].shape) ? 1 : 0;
+        return MINA_OK;
+    };
+    auto harvest = [&](Chunk &ch) {
+        if (ch.harvested) return;
+        ch.harvested = true;
+        if (ch.issued) {
+            bool ok = hipEventSynchronize(ch.slot->ev) == hipSuccess;
+            const uint32_t *o = (const uint32_t *)ch.slot->out.p;
+            if (ok) {
+                const bool ipa_ok = !sh.kimchi || o[ch.n] != 0, acc_ok = o[ch.n + 2] != 0;
+                if (ipa_ok && acc_ok) { for (size_t b = 0; b < ch.n; ++b) verdicts[idx[ch.lo + b]] = (o[b] && ch.hb[b].parsed && ch.hb[b].shape) ? 1 : 0; }
+                else { int rc = fallback(ch); if (rc && !rc_all) rc_all = rc; }
+            } else if (!rc_all) rc_all = MINA_ERR_HIP;
+        }
+        if (ch.slot_ix >= 0) release(ch.slot_ix);
+        D.inflight.fetch_sub(1);
+    };
+
+    auto issue = [&](Chunk &ch) -> int {
+        uint8_t *hbase = (uint8_t *)ch.slot->host.p;
+        // host side of the chunk: collect the other shapes, patch what cannot go to the GPU as it is
+        size_t donor = SIZE_MAX;
+        for (size_t b = 0; b < ch.n; ++b) { if (ch.hb[b].parsed && ch.hb[b].shape && donor == SIZE_MAX) donor = b; if (ch.hb[b].deferred) deferred.push_back(idx[ch.lo + b]); }
+        if (donor == SIZE_MAX) { ch.skipped = true; return MINA_OK; }                         // nothing of this chunk can pass
+        for (size_t b = 0; b < ch.n; ++b) if (!(ch.hb[b].parsed && ch.hb[b].shape)) { copy_entry(lay, hbase, b, donor); *lay.at(hbase, S_PRE, b) = 0; }
+        if (!draw_randomisers(sh, lay, hbase, ch.n)) return fail(MINA_ERR_STATE, "no entropy for the folding randomisers");
+        std::lock_guard<std::mutex> lk(D.mu);
+        HIPC(hipSetDevice(c->device));
+        int rc;
+        if (D.prepared_npub != (sh.statements ? 40u : 0u)) {
+            if ((rc = mina_state_jobs_prepare(c, sh.k ? sh.k : 15, sh.statements ? 40 : 0))) return rc;
+            D.prepared_npub = sh.statements ? 40u : 0u;
+        }
+        Slot &S = *ch.slot;
+        if ((rc = S.dev.ensure(lay.total + Layout::out_bytes(lay.cap)))) return rc;
+        if (!S.ev) HIPC(hipEventCreateWithFlags(&S.ev, hipEventDisableTiming));
+        Lane &L = c->lanes[ch.slot_ix];
+        if (!L.stream) HIPC(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
+        // the lane forms of the sponge kernels follow the work in flight on the device (ctx.h use_coop*)
+        c->nlanes = (int)std::max(1u, std::min<unsigned>(D.inflight.load(), NSLOT));
+        c->L = &L;
+        uint8_t *dbase = S.dev.as<uint8_t>();
+        HIPC(hipMemcpyAsync(dbase, hbase, lay.total, hipMemcpyHostToDevice, L.stream));
+        JobStructs js; make_jobs(sh, lay, dbase, ch.n, true, true, true, js);
+        uint32_t *dv = (uint32_t *)(dbase + lay.out_off()), *df = dv + ch.n, *ds = df + 4;
+        // few chunks in flight: the three legs of a job (state hashes / wrap proof / accumulator) go to three streams
+        static const unsigned split_max = getenv("MINA_VERIFY_SPLIT_MAX") ? (unsigned)atoi(getenv("MINA_VERIFY_SPLIT_MAX")) : 2u;
+        Lane *LI = nullptr, *LA = nullptr;
+        if (D.inflight.load() <= split_max && ch.slot_ix < 8) { LI = &c->lanes[16 + 2 * ch.slot_ix]; LA = &c->lanes[17 + 2 * ch.slot_ix]; }
+        rc = mb_state_jobs_on_lane(c, &js.j, dv, df, LI, LA, ds);
+        c->use_lane0();
+        if (rc) return rc;
+        HIPC(hipMemcpyAsync(S.out.p, dv, Layout::out_bytes(ch.n), hipMemcpyDeviceToHost, L.stream));
+        HIPC(hipEventRecord(S.ev, L.stream));
+        ch.issued = true;
+        return MINA_OK;
+    };
+
+    size_t next_submit = 0, next_issue = 0, oldest = 0;
+    while (next_issue < nchunks && !rc_all) {
+        while (next_submit < nchunks) {
+            const int s = try_acquire();
+            if (s < 0) break;
+            Chunk &ch = chunks[next_submit];
+            ch.slot = &D.slots[s]; ch.slot_ix = s;
+            if (ch.slot->host.ensure(lay.total) || ch.slot->out.ensure(Layout::out_bytes(lay.cap))) { rc_all = MINA_ERR_HIP; break; }
+            uint8_t *hbase = (uint8_t *)ch.slot->host.p;
+            Chunk *chp = &ch;
+            ch.job = mb_pool_submit(ch.n, [&, chp, hbase](size_t b) {
+                const size_t q = idx[chp->lo + b];
+                parse_into(sh, lay, hbase, b, in.proofs[q], in.proof_lens[q], in.pubs[q], in.pub_lens[q], chp->hb[b], c);
+            });
+            ++next_submit;
+        }
+        if (rc_all) break;
+        if (next_issue == next_submit) {                 // no slot for the next chunk: take back the oldest of this call, or wait for another caller's
+            if (oldest < next_issue) { harvest(chunks[oldest++]); continue; }
+            std::unique_lock<std::mutex> lk(D.slot_mu);
+            D.slot_cv.wait_for(lk, std::chrono::milliseconds(2));
+            continue;
+        }
+        Chunk &ch = chunks[next_issue];
+        mb_pool_wait(ch.job);
+        int rc = issue(ch);
+        if (rc && !rc_all) rc_all = rc;
+        ++next_issue;
     }
-    for (size_t i = 0; i < n; ++i) { passed_out[i] = passed[i]; ran_out[i] = ran[i]; }
+    for (size_t q = 0; q < next_submit; ++q) mb_pool_wait(chunks[q].job);     // nothing may still write into a slot (error paths)
+    for (size_t q = 0; q < nchunks; ++q) {
+        if (q < next_submit) harvest(chunks[q]);
+        else D.inflight.fetch_sub(1);
+    }
+    if (g_timing) fprintf(stderr, "mina_verify: device %d: %zu proofs in %zu chunk(s), %.2f ms\n", D.ordinal, m, nchunks, ms_since(t_call));
+    if (rc_all) { for (size_t i = 0; i < m; ++i) verdicts[idx[i]] = 0; return rc_all; }
+    if (!deferred.empty() && depth < 128) return run_device(D, in, deferred, verdicts, flags, depth + 1);   // well-formed proofs of another shape: a job of their own
     return MINA_OK;
 }
 
-int verify_state_many(size_t n, const uint8_t *const *proofs, const size_t *proof_lens, const uint8_t *const *pubs, const size_t *pub_lens,
-                      uint32_t *passed_out, uint32_t *ran_out, bool masks) {
-    static const bool timing = getenv("MINA_VERIFY_TIMING") != nullptr;
-    auto now = [] { return std::chrono::steady_clock::now(); };
-    const auto t0 = now();
-    std::vector<ParsedState> ps(n);
-    // host side of every proof (parse both containers, flatten 17 states, ledger + consensus checks): independent, ~0.1 ms each -> threads
-    mb_parallel_for(n, [&](size_t i) { parse_state(proofs[i], proof_lens[i], pubs[i], pub_lens[i], ps[i]); });
-    std::vector<ParsedState *> ptr(n); for (size_t i = 0; i < n; ++i) ptr[i] = &ps[i];
-    const auto t1 = now();
-    int rc = verify_parsed(ptr, passed_out, ran_out, masks);
-    if (timing) fprintf(stderr, "mina_verify: n=%zu parse %.2f ms, jobs %.2f ms\n", n, std::chrono::duration<double, std::milli>(t1 - t0).count(), std::chrono::duration<double, std::milli>(now() - t1).count());
-    return rc;
+// n proofs over the devices of the process: contiguous shards, one host thread per extra device
+int verify_state_many(const CallIn &in, size_t n, uint8_t *verdicts) {
+    std::vector<Device *> devs; uint32_t flags;
+    { std::lock_guard<std::mutex> lk(g_mu); devs = devices(); flags = g_flags; }
+    for (size_t i = 0; i < n; ++i) verdicts[i] = 0;
+    if (devs.empty()) return MINA_ERR_HIP;
+    if (n == 0) return MINA_OK;
+    const size_t G = devs.size();
+    static const size_t min_shard = getenv("MINA_VERIFY_MIN_SHARD") ? (size_t)std::max(1L, atol(getenv("MINA_VERIFY_MIN_SHARD"))) : (size_t)64;
+    const size_t use = std::max<size_t>(1, std::min(G, n / min_shard));    // tiny calls stay on one device (dealt round-robin)
+    if (use == 1) {
+        std::vector<size_t> idx(n); for (size_t i = 0; i < n; ++i) idx[i] = i;
+        return run_device(*devs[g_rr.fetch_add(1) % G], in, idx, verdicts, flags);
+    }
+    std::vector<int> rcs(use, MINA_OK); std::vector<std::thread> th;
+    auto shard = [&](size_t g) {
+        const size_t lo = n * g / use, hi = n * (g + 1) / use;
+        std::vector<size_t> idx(hi - lo); for (size_t i = lo; i < hi; ++i) idx[i - lo] = i;
+        rcs[g] = run_device(*devs[g], in, idx, verdicts, flags);
+    };
+    for (size_t g = 1; g < use; ++g) th.emplace_back(shard, g);
+    shard(0);
+    for (auto &t : th) t.join();
+    for (int rc : rcs) if (rc) return rc;
+    return MINA_OK;
 }
 
-bool verdict_of(uint32_t passed, uint32_t ran, uint32_t flags) {
-    uint32_t need = MINA_CHECK_FORMAT | MINA_CHECK_LEDGER | MINA_CHECK_CHAIN | MINA_CHECK_CONSENSUS | MINA_CHECK_ACCUMULATOR | MINA_CHECK_KIMCHI;
-    if ((flags & MINA_VERIFY_ALLOW_MISSING_KIMCHI) && !(ran & MINA_CHECK_KIMCHI)) need &= ~(uint32_t)MINA_CHECK_KIMCHI;
-    return (passed & need) == need;
+// single-proof diagnostic form: one job per step so that every step gets its own bit
+int state_checks(const uint8_t *proof, size_t proof_len, const uint8_t *pub, size_t pub_len, uint32_t *passed_out, uint32_t *ran_out) {
+    Device *D; uint32_t flags;
+    { std::lock_guard<std::mutex> lk(g_mu); auto &ds = devices(); if (ds.empty()) return MINA_ERR_HIP; D = ds[0]; flags = g_flags; }
+    const Config cf = read_config(*D, flags | MINA_VERIFY_ALLOW_SURROGATE);
+    Shape sh; sh.kimchi = cf.kimchi; sh.statements = cf.kimchi && cf.statements; sh.k = cf.k;
+    uint32_t passed = 0, ran = MINA_CHECK_FORMAT;
+    *passed_out = 0; *ran_out = ran;
+    if (sh.statements) {
+        mw::StateProofContainer &box = tl_box();
+        mw::Bincode cur(proof, proof ? proof_len : 0);
+        if (!proof || !mw::read_wrap_proof(cur, box.tip_proof)) return MINA_OK;
+        sh.n_old = (uint32_t)std::min<size_t>(box.tip_proof.step_old_bulletproof_challenges.size(), 4); sh.n_ev = (uint32_t)std::min<size_t>(std::max<size_t>(box.tip_proof.prev_evals.size(), 43), 62);
+    }
+    Layout lay; lay.build(sh, 1);
+    std::vector<uint8_t> stage(lay.total + 256);
+    HostBits hb;
+    parse_into(sh, lay, stage.data(), 0, proof, proof_len, pub, pub_len, hb, D->c);
+    if (!hb.parsed) return MINA_OK;
+    passed |= MINA_CHECK_FORMAT; ran |= MINA_CHECK_LEDGER | MINA_CHECK_CONSENSUS;
+    if (hb.ledger) passed |= MINA_CHECK_LEDGER;
+    if (hb.consensus) passed |= MINA_CHECK_CONSENSUS;
+    *lay.at(stage.data(), S_PRE, 0) = 1;                               // the host checks have their own bits here
+    if (!draw_randomisers(sh, lay, stage.data(), 1)) return fail(MINA_ERR_STATE, "no entropy for the folding randomisers");
+    std::lock_guard<std::mutex> lk(D->mu);
+    mina_ctx *c = D->c;
+    auto leg = [&](bool st, bool acc, bool kim, uint32_t bit, bool extra_ok) -> int {
+        JobStructs js; make_jobs(sh, lay, stage.data(), 1, st, acc, kim, js);
+        uint8_t v = 0;
+        int rc = mina_state_job_batch(c, &js.j, &v);
+        if (rc) return rc;
+        ran |= bit; if (v && extra_ok) passed |= bit;
+        return MINA_OK;
+    };
+    int rc;
+    if ((rc = leg(true, false, false, MINA_CHECK_CHAIN, true))) return rc;
+    if ((rc = leg(false, true, false, MINA_CHECK_ACCUMULATOR, true))) return rc;
+    if (sh.kimchi) {
+        if (hb.shape) { if ((rc = leg(false, false, true, MINA_CHECK_KIMCHI, true))) return rc; }
+        else ran |= MINA_CHECK_KIMCHI;                                 // wrong shape for the installed index / a lookup feature switched on: the step ran and failed
+    }
+    *passed_out = passed; *ran_out = ran;
+    return MINA_OK;
 }
 }  // namespace
 
 extern "C" int mina_verify_state_checks(const uint8_t *proof, size_t proof_len, const uint8_t *pub, size_t pub_len, uint32_t *passed_mask, uint32_t *ran_mask) {
     if (!passed_mask || !ran_mask) return fail(MINA_ERR_ARG, "null argument");
-    return verify_state_many(1, &proof, &proof_len, &pub, &pub_len, passed_mask, ran_mask, /*masks=*/true);
+    return state_checks(proof, proof_len, pub, pub_len, passed_mask, ran_mask);
 }
 
 extern "C" int mina_verify_state_batch(size_t n, const uint8_t *const *proofs, const size_t *proof_lens, const uint8_t *const *pubs, const size_t *pub_lens,
                                        uint8_t *verdicts_out) {
     if (n && (!proofs || !proof_lens || !pubs || !pub_lens || !verdicts_out)) return fail(MINA_ERR_ARG, "null argument");
-    std::vector<uint32_t> passed(n), ran(n);
-    int rc = verify_state_many(n, proofs, proof_lens, pubs, pub_lens, passed.data(), ran.data(), /*masks=*/false);
-    if (rc) { for (size_t i = 0; i < n; ++i) verdicts_out[i] = 0; return rc; }
-    uint32_t flags; { std::lock_guard<std::mutex> lk(g_mu); flags = g_flags; }
-    for (size_t i = 0; i < n; ++i) verdicts_out[i] = verdict_of(passed[i], ran[i], flags) ? 1 : 0;
-    return MINA_OK;
+    CallIn in{proofs, proof_lens, pubs, pub_lens};
+    return verify_state_many(in, n, verdicts_out);
 }
 
-// the merged job of single-proof callers: every caller parsed its own proof on its own thread before queueing
+// the merged job of single-proof callers
 static void exec_state_calls(std::vector<PendingCall *> &job) {
     const size_t n = job.size();
-    std::vector<ParsedState *> ps(n); for (size_t i = 0; i < n; ++i) ps[i] = (ParsedState *)job[i]->parsed;
-    std::vector<uint32_t> passed(n), ran(n);
-    const int rc = verify_parsed(ps, passed.data(), ran.data(), /*masks=*/false);
-    uint32_t flags; { std::lock_guard<std::mutex> lk(g_mu); flags = g_flags; }
-    for (size_t i = 0; i < n; ++i) job[i]->verdict = (rc == MINA_OK && verdict_of(passed[i], ran[i], flags)) ? 1 : 0;
+    std::vector<const uint8_t *> pr(n), pu(n); std::vector<size_t> pl(n), ul(n); std::vector<uint8_t> v(n, 0);
+    for (size_t i = 0; i < n; ++i) { pr[i] = job[i]->proof; pl[i] = job[i]->proof_len; pu[i] = job[i]->pub; ul[i] = job[i]->pub_len; }
+    CallIn in{pr.data(), pl.data(), pu.data(), ul.data()};
+    const int rc = verify_state_many(in, n, v.data());
+    for (size_t i = 0; i < n; ++i) job[i]->verdict = rc == MINA_OK ? v[i] : 0;
 }
 extern "C" bool mina_verify_state(const uint8_t *proof, size_t proof_len, const uint8_t *pub, size_t pub_len) {
-    std::unique_ptr<ParsedState> ps(new (std::nothrow) ParsedState);
-    if (!ps) return false;
-    parse_state(proof, proof_len, pub, pub_len, *ps);
     PendingCall me{proof, proof_len, pub, pub_len};
-    me.parsed = ps.get();
     return g_state_calls.run(exec_state_calls, me);
 }
 
@@ -369,10 +724,10 @@ extern "C" int mina_state_proof_split(const uint8_t *bytes, size_t len, size_t *
 // ------------------------------------------------------------------------------------------------ Proof of Account
 extern "C" int mina_verify_account_checks(const uint8_t *proof, size_t proof_len, const uint8_t *pub, size_t pub_len, uint32_t *passed_mask, uint32_t *ran_mask) {
     if (!passed_mask || !ran_mask) return fail(MINA_ERR_ARG, "null argument");
-    std::lock_guard<std::mutex> lk(g_mu);
-    mina_ctx *c = global_ctx();
-    if (!c) return MINA_ERR_HIP;
-    return mina_verify_account_ctx(c, 1, &proof, &proof_len, &pub, &pub_len, passed_mask, ran_mask);
+    Device *D;
+    { std::lock_guard<std::mutex> lk(g_mu); auto &ds = devices(); if (ds.empty()) return MINA_ERR_HIP; D = ds[0]; }
+    std::lock_guard<std::mutex> lk(D->mu);
+    return mina_verify_account_ctx(D->c, 1, &proof, &proof_len, &pub, &pub_len, passed_mask, ran_mask);
 }
 extern "C" int mina_verify_account_batch(size_t n, const uint8_t *const *proofs, const size_t *proof_lens, const uint8_t *const *pubs, const size_t *pub_lens,
                                          uint8_t *verdicts_out) {
@@ -381,10 +736,11 @@ extern "C" int mina_verify_account_batch(size_t n, const uint8_t *const *proofs,
     if (n == 0) return MINA_OK;
     std::vector<uint32_t> passed(n), ran(n);
     {
-        std::lock_guard<std::mutex> lk(g_mu);
-        mina_ctx *c = global_ctx();
-        if (!c) return MINA_ERR_HIP;
-        int rc = mina_verify_account_ctx(c, n, proofs, proof_lens, pubs, pub_lens, passed.data(), ran.data());
+        Device *D; uint32_t flags;
+        { std::lock_guard<std::mutex> lk(g_mu); auto &ds = devices(); if (ds.empty()) return MINA_ERR_HIP; D = ds[g_rr.fetch_add(1) % ds.size()]; flags = g_flags; }
+        std::lock_guard<std::mutex> lk(D->mu);
+        if ((D->c->pparams_surrogate[0] || D->c->pparams_surrogate[1]) && !(flags & MINA_VERIFY_ALLOW_SURROGATE)) return MINA_OK;   // surrogate Poseidon tables: refuse (see read_config)
+        int rc = mina_verify_account_ctx(D->c, n, proofs, proof_lens, pubs, pub_lens, passed.data(), ran.data());
         if (rc) return rc;
     }
     const uint32_t need = MINA_CHECK_FORMAT | MINA_CHECK_ACCOUNT_ABI | MINA_CHECK_MERKLE;

@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <array>
+#include <functional>
 #include <memory>
 #include <thread>
 #include <algorithm>
@@ -124,6 +125,8 @@ struct mina_ctx {
     DevBuf kimchi_index, kimchi_tokens, kimchi_literals; bool have_kimchi = false; uint32_t kimchi_log2 = 0; uint8_t kimchi_digest[32] = {0};   // installed wrap verifier index
     uint8_t kimchi_comms_host[28 * 64] = {0};   // its commitments as installed: sigma 7, coefficients 15, selectors 6 (messages_for_next_step_proof hashes them)
     DevBuf pickles_index, pickles_tokens, pickles_literals; bool have_pickles_dev = false, pickles_ms_valid = false;   // installed step index (api_pickles.hip); ms = the Tick sponge after the wrap index commitments
+    void *step_host = nullptr; void (*step_host_free)(void *) = nullptr;   // host half of the installed step index (api_pickles.hip), owned by the context
+    bool pparams_surrogate[2] = {false, false};                  // the installed Poseidon tables are the library's UNPINNED surrogate set
     DevBuf state_salts; bool have_state_salts = false;           // salted initial states of the named hash prefixes (Fp): MB_SALT_*
     void use_lane0() { L = &lanes[0]; }
     void next_lane() { L = &lanes[rr++ % (unsigned)nlanes]; }
@@ -160,18 +163,20 @@ static inline bool use_coop8_transcripts(const mina_ctx *c, size_t batch, size_t
     return lim ? in_flight <= lim : (batch <= per_call_limit && in_flight <= 2048);
 }
 
-// independent per-item host work over up to 64 threads, at most half the cores ($MINA_HOST_THREADS overrides the cap; items are ~0.01 - 0.1 ms
-// each: threads only when there are enough of them)
+// ---- host-side worker pool (api_core.hip): persistent threads, created on first use -- min(hardware threads / 2, 64), $MINA_HOST_THREADS
+// overrides.  A job is `n` independent items handed out in index order; `mb_pool_submit` returns at once (the boundary's pipeline parses
+// chunk i + 1 while chunk i is on the GPU), `mb_pool_wait` joins in on the remaining items and returns when all are done.
+struct MbPoolJob;
+std::shared_ptr<MbPoolJob> mb_pool_submit(size_t n, std::function<void(size_t)> fn);
+void mb_pool_wait(const std::shared_ptr<MbPoolJob> &job);
+size_t mb_pool_threads();
+// independent per-item host work (items are ~0.01 - 0.1 ms each: the pool only when there are enough of them)
 template <class Fn> static inline void mb_parallel_for(size_t n, Fn fn) {
-    static const size_t cap = [] { if (const char *e = getenv("MINA_HOST_THREADS")) return (size_t)std::max(1L, atol(e));
-                                   const size_t hw = std::thread::hardware_concurrency(); return std::max<size_t>(1, std::min<size_t>(hw / 2, 64)); }();
-    const size_t nt = std::min<size_t>(cap, n / 64);     // a thread costs ~50 us to start: at least 64 items each
-    auto work = [&](size_t t) { for (size_t i = t; i < n; i += (nt ? nt : 1)) fn(i); };
-    if (nt <= 1) { work(0); return; }
-    std::vector<std::thread> th;
-    for (size_t t = 0; t < nt; ++t) th.emplace_back(work, t);
-    for (auto &x : th) x.join();
+    if (n < 128 || mb_pool_threads() <= 1) { for (size_t i = 0; i < n; ++i) fn(i); return; }
+    mb_pool_wait(mb_pool_submit(n, std::function<void(size_t)>(fn)));
 }
+// `n` bytes from the operating system's CSPRNG (getrandom(2), /dev/urandom as the fallback); false = none available: callers fail closed
+bool mb_secure_random(void *buf, size_t n);
 
 static inline int base_field_of(int curve) { return curve == CURVE_PALLAS ? FIELD_FP : FIELD_FQ; }
 static inline int scalar_field_of(int curve) { return curve == CURVE_PALLAS ? FIELD_FQ : FIELD_FP; }

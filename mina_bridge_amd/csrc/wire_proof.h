@@ -19,7 +19,7 @@ namespace mw {
 
 struct Pt { B32 x, y; };                                  // affine point, coordinates as the container holds them (32-byte LE)
 struct Chal128 { uint64_t lo, hi; };                      // two 64-bit limbs, least-significant first
-struct EvalPair { std::vector<B32> zeta, zeta_omega; };   // chunked evaluations at zeta / zeta*omega (one chunk each in practice)
+struct EvalPair { SmallVec<B32, 16> zeta, zeta_omega; };   // chunked evaluations at zeta / zeta*omega (one chunk each in practice)
 
 struct WrapProof {
     // statement.proof_state.deferred_values
@@ -32,44 +32,44 @@ struct WrapProof {
     Pt challenge_polynomial_commitment;                   // the step accumulator `sg` (Vesta point: coordinates in Fq)
     Chal128 old_bulletproof_challenges[2][15];
     // statement.messages_for_next_step_proof
-    std::vector<Pt> step_challenge_polynomial_commitments;           // Pallas points
-    std::vector<std::array<Chal128, 16>> step_old_bulletproof_challenges;
+    SmallVec<Pt, 8> step_challenge_polynomial_commitments;           // Pallas points
+    SmallVec<std::array<Chal128, 16>, 8> step_old_bulletproof_challenges;
     // prev_evals (evaluations of the step proof: Fp)
-    EvalPair prev_public_input; std::vector<EvalPair> prev_evals;    // fixed order, see read_all_evals
-    std::vector<uint8_t> prev_evals_present;                         // 1 per optional slot
+    EvalPair prev_public_input; SmallVec<EvalPair, 62> prev_evals;   // fixed order, see read_all_evals
+    SmallVec<uint8_t, 32> prev_evals_present;                        // 1 per optional slot
     B32 prev_ft_eval1;
     // proof (wire form of the wrap ProverProof: commitments are Pallas points, evaluations in Fq)
     Pt w_comm[15], z_comm, t_comm[7];
     B32 w_eval[15][2], coefficients_eval[15][2], z_eval[2], s_eval[6][2], selector_eval[6][2];   // [zeta, zeta*omega]
     B32 ft_eval1;
-    std::vector<std::pair<Pt, Pt>> lr; B32 z1, z2; Pt delta, sg;
+    SmallVec<std::pair<Pt, Pt>, 32> lr; B32 z1, z2; Pt delta, sg;
 };
 
 template <class C> static Chal128 rd_chal(C &c) {          // PaddedSeq<Hex64, 2>
     Chal128 r; r.lo = (uint64_t)c.i64(); r.hi = (uint64_t)c.i64(); c.padded_end(); return r;
 }
 template <class C> static Pt rd_pt(C &c) { Pt p; p.x = c.big(); p.y = c.big(); return p; }
-template <class C> static EvalPair rd_eval_vecs(C &c) {    // (Vec<BigInt>, Vec<BigInt>)
-    EvalPair e;
+template <class C> static void rd_eval_vecs(C &c, EvalPair &e) {    // (Vec<BigInt>, Vec<BigInt>); at most 16 chunks a side (Mina's step proofs have one)
+    e.zeta.clear(); e.zeta_omega.clear();
     for (int side = 0; side < 2; ++side) {
-        const size_t m = c.length(); if (m > 64) { c.fail(); return e; }
-        std::vector<B32> &v = side ? e.zeta_omega : e.zeta;
+        const size_t m = c.length(); if (m > 16) { c.fail(); return; }
+        SmallVec<B32, 16> &v = side ? e.zeta_omega : e.zeta;
         for (size_t i = 0; i < m && c.ok; ++i) v.push_back(c.big());
     }
-    return e;
 }
 static constexpr int N_PREV_FIXED = 15 + 15 + 1 + 6 + 6;     // w, coefficients, z, s, the six always-present selectors
 static constexpr int N_PREV_OPTIONAL = 6 + 2 + 5 + 6;        // 6 optional gate selectors, lookup_aggregation/table, 5 lookup_sorted, 6 lookup selectors / runtime tables
 template <class C> static void rd_all_evals(C &c, WrapProof &p) {
-    for (int i = 0; i < 15; ++i) p.prev_evals.push_back(rd_eval_vecs(c));
+    p.prev_evals.clear(); p.prev_evals_present.clear();
+    for (int i = 0; i < 15; ++i) rd_eval_vecs(c, p.prev_evals.emplace_back());
     c.padded_end();                                                              // w
-    for (int i = 0; i < 15; ++i) p.prev_evals.push_back(rd_eval_vecs(c));
+    for (int i = 0; i < 15; ++i) rd_eval_vecs(c, p.prev_evals.emplace_back());
     c.padded_end();                                                              // coefficients
-    p.prev_evals.push_back(rd_eval_vecs(c));                                     // z
-    for (int i = 0; i < 6; ++i) p.prev_evals.push_back(rd_eval_vecs(c));
+    rd_eval_vecs(c, p.prev_evals.emplace_back());                                // z
+    for (int i = 0; i < 6; ++i) rd_eval_vecs(c, p.prev_evals.emplace_back());
     c.padded_end();                                                              // s
-    for (int i = 0; i < 6; ++i) p.prev_evals.push_back(rd_eval_vecs(c));         // generic, poseidon, complete_add, mul, emul, endomul_scalar
-    auto opt = [&]() { const bool some = c.option(); p.prev_evals_present.push_back(some ? 1 : 0); if (some) p.prev_evals.push_back(rd_eval_vecs(c)); };
+    for (int i = 0; i < 6; ++i) rd_eval_vecs(c, p.prev_evals.emplace_back());    // generic, poseidon, complete_add, mul, emul, endomul_scalar
+    auto opt = [&]() { const bool some = c.option(); p.prev_evals_present.push_back(some ? 1 : 0); if (some) rd_eval_vecs(c, p.prev_evals.emplace_back()); };
     for (int i = 0; i < 6; ++i) opt();                                           // range_check0/1, foreign_field_add/mul, xor, rot selectors
     opt(); opt();                                                                // lookup_aggregation, lookup_table
     for (int i = 0; i < 5; ++i) opt();
@@ -92,11 +92,12 @@ template <class C> static bool read_wrap_proof(C &c, WrapProof &p) {
     c.padded_end();
     // ---- statement.messages_for_next_step_proof
     c.unit();                                                                    // app_state
+    p.step_challenge_polynomial_commitments.clear(); p.step_old_bulletproof_challenges.clear(); p.lr.clear();
     { const size_t m = c.length(); if (m > 8) c.fail(); for (size_t i = 0; i < m && c.ok; ++i) p.step_challenge_polynomial_commitments.push_back(rd_pt(c)); }
     { const size_t m = c.length(); if (m > 8) c.fail();
-      for (size_t i = 0; i < m && c.ok; ++i) { std::array<Chal128, 16> a; for (int j = 0; j < 16; ++j) a[j] = rd_chal(c); c.padded_end(); p.step_old_bulletproof_challenges.push_back(a); } }
+      for (size_t i = 0; i < m && c.ok; ++i) { std::array<Chal128, 16> &a = p.step_old_bulletproof_challenges.emplace_back(); for (int j = 0; j < 16; ++j) a[j] = rd_chal(c); c.padded_end(); } }
     // ---- prev_evals
-    { EvalPair e; e.zeta.push_back(c.big()); e.zeta_omega.push_back(c.big()); p.prev_public_input = e; }
+    { EvalPair &e = p.prev_public_input; e.zeta.clear(); e.zeta_omega.clear(); e.zeta.push_back(c.big()); e.zeta_omega.push_back(c.big()); }
     rd_all_evals(c, p);
     p.prev_ft_eval1 = c.big();
     // ---- proof.commitments
@@ -117,9 +118,9 @@ template <class C> static bool read_wrap_proof(C &c, WrapProof &p) {
     for (int i = 0; i < 6; ++i) pair2(p.selector_eval[i]);
     p.ft_eval1 = c.big();
     // ---- proof.bulletproof
-    { const size_t m = c.length(); if (m > 32) c.fail(); for (size_t i = 0; i < m && c.ok; ++i) { Pt l = rd_pt(c), r = rd_pt(c); p.lr.emplace_back(l, r); } }
+    { const size_t m = c.length(); if (m > 32) c.fail(); for (size_t i = 0; i < m && c.ok; ++i) { std::pair<Pt, Pt> &q = p.lr.emplace_back(); q.first = rd_pt(c); q.second = rd_pt(c); } }
     p.z1 = c.big(); p.z2 = c.big(); p.delta = rd_pt(c); p.sg = rd_pt(c);
-    return c.ok;
+    return c.ok && !p.prev_evals.overflow && !p.prev_evals_present.overflow;
 }
 
 // MinaStateProof (state_proof.rs:28-41), bincode: the proof, then [ProtocolState; 16], then the bridge tip state

@@ -20,6 +20,24 @@ namespace mw {
 struct B32 { uint8_t b[32]; };
 static inline bool b32_eq(const B32 &a, const B32 &b) { return memcmp(a.b, b.b, 32) == 0; }
 
+// Fixed-capacity vector: the containers are parsed once per proof on the boundary's host threads, so nothing on that path allocates.
+// push_back beyond N is dropped and sets `overflow` (the readers bound every length before they push).
+template <class T, size_t N> struct SmallVec {
+    T d[N]; size_t n = 0; bool overflow = false;
+    void clear() { n = 0; overflow = false; }
+    void push_back(const T &x) { if (n < N) d[n++] = x; else overflow = true; }
+    T &emplace_back() { if (n < N) return d[n++]; overflow = true; return d[N - 1]; }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    T &operator[](size_t i) { return d[i]; }
+    const T &operator[](size_t i) const { return d[i]; }
+    T *begin() { return d; } T *end() { return d + n; }
+    const T *begin() const { return d; } const T *end() const { return d + n; }
+    T *data() { return d; } const T *data() const { return d; }
+};
+// a length-prefixed byte string that is 32 bytes in every well-formed state (longer ones are cut and keep their length: rejected later)
+struct Str32 { uint8_t d[32] = {0}; size_t n = 0; const uint8_t *data() const { return d; } size_t size() const { return n; } };
+
 static inline bool fp_canonical(const uint8_t *b) {
     static const uint8_t P_LE[32] = {0x01, 0x00, 0x00, 0x00, 0xed, 0x30, 0x2d, 0x99, 0x1b, 0xf9, 0x4c, 0x09, 0xfc, 0x98, 0x46, 0x22,
                                      0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x40};
@@ -72,6 +90,7 @@ struct Binprot : Cursor {                    // OCaml bin_prot, as mina-p2p-mess
     void unit() { if (u8() != 0) fail(); }
     B32 big() { B32 r{}; const uint8_t *q = take(32); if (q) memcpy(r.b, q, 32); return r; }
     std::vector<uint8_t> string() { const size_t k = length(); const uint8_t *q = take(k); return q ? std::vector<uint8_t>(q, q + k) : std::vector<uint8_t>(); }
+    Str32 str32() { Str32 r; r.n = length(); const uint8_t *q = take(r.n); if (q) memcpy(r.d, q, r.n < 32 ? r.n : 32); return r; }
     uint8_t chr() { return u8(); }
     void padded_end() { unit(); }            // `PaddedSeq<T, N>` = OCaml vector: N elements, then the unit that ends the nested pairs
 };
@@ -88,6 +107,7 @@ struct Bincode : Cursor {                    // bincode 1.3 default options (fix
     void unit() {}
     B32 big() { B32 r{}; const uint8_t *q = take(32); if (q) memcpy(r.b, q, 32); return r; }
     std::vector<uint8_t> string() { const size_t k = length(); const uint8_t *q = take(k); return q ? std::vector<uint8_t>(q, q + k) : std::vector<uint8_t>(); }
+    Str32 str32() { Str32 r; r.n = length(); const uint8_t *q = take(r.n); if (q) memcpy(r.d, q, r.n < 32 ? r.n : 32); return r; }
     uint8_t chr() { return u8(); }           // mina-p2p-messages `Char(u8)`: one byte
     void padded_end() {}                     // `PaddedSeq` = [T; N] in serde: a tuple, no terminator
 };
@@ -102,12 +122,12 @@ struct PubKey { B32 x; bool is_odd; };
 struct ProtocolState {
     B32 previous_state_hash, genesis_state_hash;
     B32 staged_ledger_hash, pending_coinbase_hash, genesis_ledger_hash;
-    std::vector<uint8_t> aux_hash, pending_coinbase_aux, body_reference, last_vrf_output;
+    Str32 aux_hash, pending_coinbase_aux, body_reference, last_vrf_output;
     Registers source, target;
     B32 connecting_ledger_left, connecting_ledger_right;
     SignedAmount supply_increase, fee_excess_l, fee_excess_r; B32 fee_token_l, fee_token_r;
     uint64_t timestamp;
-    uint32_t blockchain_length, epoch_count, min_window_density; std::vector<uint32_t> sub_window_densities;
+    uint32_t blockchain_length, epoch_count, min_window_density; SmallVec<uint32_t, 64> sub_window_densities;
     uint64_t total_currency; uint32_t slot_number, slots_per_epoch, global_slot_since_genesis;
     EpochData staking, next;
     bool has_ancestor_in_same_checkpoint_window, supercharge_coinbase; PubKey block_stake_winner, block_creator, coinbase_receiver;
@@ -135,16 +155,16 @@ template <class C> static uint32_t rd_tagged_u32(C &c) { if (c.variant() != 0) c
 
 template <class C> static bool read_protocol_state(C &c, ProtocolState &s) {
     s.previous_state_hash = c.big(); s.genesis_state_hash = c.big();
-    s.staged_ledger_hash = c.big(); s.aux_hash = c.string(); s.pending_coinbase_aux = c.string(); s.pending_coinbase_hash = c.big();
+    s.staged_ledger_hash = c.big(); s.aux_hash = c.str32(); s.pending_coinbase_aux = c.str32(); s.pending_coinbase_hash = c.big();
     s.genesis_ledger_hash = c.big();
     rd_registers(c, s.source); rd_registers(c, s.target);
     s.connecting_ledger_left = c.big(); s.connecting_ledger_right = c.big(); rd_signed(c, s.supply_increase);
     s.fee_token_l = c.big(); rd_signed(c, s.fee_excess_l); s.fee_token_r = c.big(); rd_signed(c, s.fee_excess_r);
     c.unit();                                                     // sok_digest
-    s.timestamp = c.u64(); s.body_reference = c.string();
+    s.timestamp = c.u64(); s.body_reference = c.str32();
     s.blockchain_length = c.u32(); s.epoch_count = c.u32(); s.min_window_density = c.u32();
     { const size_t m = c.length(); if (m > 64) c.fail(); s.sub_window_densities.clear(); for (size_t i = 0; i < m && c.ok; ++i) s.sub_window_densities.push_back(c.u32()); }
-    s.last_vrf_output = c.string(); s.total_currency = c.u64();
+    s.last_vrf_output = c.str32(); s.total_currency = c.u64();
     s.slot_number = rd_tagged_u32(c); s.slots_per_epoch = c.u32(); s.global_slot_since_genesis = rd_tagged_u32(c);
     rd_epoch(c, s.staking); rd_epoch(c, s.next);
     s.has_ancestor_in_same_checkpoint_window = c.boolean();
@@ -209,27 +229,56 @@ struct Sha256 {
 
 // ---------------------------------------------------------------------------------------------- to_input
 // openmina `Inputs`: whole field elements first, then (value, bits) chunks packed greedily into elements of < 255 bits.
+// Allocation-free (the boundary flattens 17 states per proof on the host): fields and the packed elements live in fixed arrays and the
+// greedy packing runs as the chunks arrive -- it never looks at the whole fields, so streaming it changes nothing.  `overflow` = more
+// elements than a record could ever hold (callers treat it as malformed input).
 struct Inputs {
-    std::vector<B32> fields; std::vector<std::pair<uint64_t, uint32_t>> packeds;
-    void field(const B32 &x) { fields.push_back(x); }
-    void packed(uint64_t x, uint32_t bits) { packeds.emplace_back(x, bits); }
+    static constexpr size_t MAX_FIELDS = 128, MAX_PACKED = 64;
+    B32 fields[MAX_FIELDS]; size_t nfields = 0;
+    B32 packed_out[MAX_PACKED]; size_t npacked = 0;
+    uint64_t cur[4] = {0, 0, 0, 0}; uint32_t nbits = 0; bool overflow = false;
+    void field(const B32 &x) { if (nfields < MAX_FIELDS) fields[nfields++] = x; else overflow = true; }
+    void flush() {
+        if (npacked >= MAX_PACKED) { overflow = true; return; }
+        B32 &r = packed_out[npacked++];
+        for (int i = 0; i < 4; ++i) for (int j = 0; j < 8; ++j) r.b[8 * i + j] = (uint8_t)(cur[i] >> (8 * j));
+    }
+    void shift_in(uint64_t x, uint32_t b) {                          // cur = (cur << b) + x, 1 <= b <= 64
+        if (b == 64) { cur[3] = cur[2]; cur[2] = cur[1]; cur[1] = cur[0]; cur[0] = x; }
+        else { cur[3] = (cur[3] << b) | (cur[2] >> (64 - b)); cur[2] = (cur[2] << b) | (cur[1] >> (64 - b)); cur[1] = (cur[1] << b) | (cur[0] >> (64 - b)); cur[0] = (cur[0] << b) | x; }
+    }
+    void packed(uint64_t x, uint32_t b) {
+        nbits += b;
+        if (nbits < 255) shift_in(x, b);
+        else { flush(); cur[0] = x; cur[1] = cur[2] = cur[3] = 0; nbits = b; }
+    }
     void boolean(bool b) { packed(b ? 1 : 0, 1); }
     void u32(uint32_t x) { packed(x, 32); }
     void u64(uint64_t x) { packed(x, 64); }
-    void bytes_lsb_first(const uint8_t *p, size_t nbytes, size_t nbits) { for (size_t i = 0; i < nbits && i < nbytes * 8; ++i) boolean((p[i >> 3] >> (i & 7)) & 1); }
-    void to_fields(std::vector<B32> &out) const {
-        out = fields;
-        uint64_t cur[4] = {0, 0, 0, 0}; uint32_t nbits = 0;
-        auto flush = [&]() { B32 r; for (int i = 0; i < 4; ++i) for (int j = 0; j < 8; ++j) r.b[8 * i + j] = (uint8_t)(cur[i] >> (8 * j)); out.push_back(r); };
-        for (const auto &pr : packeds) {
-            const uint64_t x = pr.first; const uint32_t b = pr.second;
-            nbits += b;
-            if (nbits < 255) {                                       // cur = (cur << b) + x, b <= 64
-                if (b == 64) { cur[3] = cur[2]; cur[2] = cur[1]; cur[1] = cur[0]; cur[0] = x; }
-                else { cur[3] = (cur[3] << b) | (cur[2] >> (64 - b)); cur[2] = (cur[2] << b) | (cur[1] >> (64 - b)); cur[1] = (cur[1] << b) | (cur[0] >> (64 - b)); cur[0] = (cur[0] << b) | x; }
-            } else { flush(); cur[0] = x; cur[1] = cur[2] = cur[3] = 0; nbits = b; }
+    // nbits single-bit chunks, least-significant bit of each byte first.  Same result as `boolean()` per bit: a run of one-bit chunks fills an
+    // element up to 254 bits, so up to 64 of them are shifted in at once.
+    void bytes_lsb_first(const uint8_t *p, size_t nbytes, size_t nb) {
+        if (nb > nbytes * 8) nb = nbytes * 8;
+        size_t i = 0;
+        while (i < nb) {
+            const uint32_t room = 254 - nbits;
+            if (room == 0) { flush(); cur[0] = cur[1] = cur[2] = cur[3] = 0; nbits = 0; continue; }
+            uint32_t t = (uint32_t)(nb - i < 64 ? nb - i : 64); if (t > room) t = room;
+            uint64_t v = 0;
+            for (uint32_t j = 0; j < t; ++j, ++i) v = (v << 1) | ((p[i >> 3] >> (i & 7)) & 1);
+            shift_in(v, t); nbits += t;
         }
-        if (nbits > 0) flush();
+    }
+    size_t count() const { return nfields + npacked + (nbits > 0 ? 1 : 0); }
+    // the flattened elements into `dst` (count() * 32 bytes); returns the count
+    size_t write(uint8_t *dst) {
+        if (nbits > 0) { flush(); nbits = 0; cur[0] = cur[1] = cur[2] = cur[3] = 0; }
+        memcpy(dst, fields, nfields * 32); memcpy(dst + nfields * 32, packed_out, npacked * 32);
+        return nfields + npacked;
+    }
+    void to_fields(std::vector<B32> &out) {
+        if (nbits > 0) { flush(); nbits = 0; cur[0] = cur[1] = cur[2] = cur[3] = 0; }
+        out.assign(fields, fields + nfields); out.insert(out.end(), packed_out, packed_out + npacked);
     }
 };
 
@@ -247,8 +296,7 @@ static inline void in_epoch(Inputs &in, const EpochData &e) {
 static inline void in_pk(Inputs &in, const PubKey &k) { in.field(k.x); in.boolean(k.is_odd); }
 
 // body `to_input` -> the field elements `hash_with_kimchi("MinaProtoStateBody", .)` absorbs
-static inline void protocol_state_body_fields(const ProtocolState &s, std::vector<B32> &out) {
-    Inputs in;
+static inline void protocol_state_body_inputs(const ProtocolState &s, Inputs &in) {
     in.field(s.genesis_state_hash);
     {   // Staged_ledger_hash.Non_snark: SHA-256(ledger hash as 32 big-endian bytes || aux_hash || pending_coinbase_aux), bit by bit
         uint8_t be[32], dg[32]; for (int i = 0; i < 32; ++i) be[i] = s.staged_ledger_hash.b[31 - i];
@@ -268,8 +316,8 @@ static inline void protocol_state_body_fields(const ProtocolState &s, std::vecto
     in_epoch(in, s.staking); in_epoch(in, s.next);
     in_pk(in, s.block_stake_winner); in_pk(in, s.block_creator); in_pk(in, s.coinbase_receiver);
     in.u32(s.k); in.u32(s.delta); in.u32(s.c_slots_per_epoch); in.u32(s.slots_per_sub_window); in.u32(s.grace_period_slots); in.u64(s.genesis_state_timestamp);
-    in.to_fields(out);
 }
+static inline void protocol_state_body_fields(const ProtocolState &s, std::vector<B32> &out) { Inputs in; protocol_state_body_inputs(s, in); in.to_fields(out); }
 
 // 20-byte '*'-padded hash prefix as a little-endian field element (mina `Hash_prefix_create.salt` input)
 static inline B32 prefix_field(const char *s) {

@@ -41,6 +41,7 @@ EXPORTS = [
     "mina_verifier_index_install", "mina_verifier_index_digest", "mina_kimchi_to_batch", "mina_pickles_public_inputs_batch", "mina_wrap_proof_flatten", "mina_state_proof_split",
     "mina_verify_state", "mina_verify_state_batch", "mina_verify_state_checks", "mina_verify_state_files", "mina_verify_account", "mina_verify_account_batch",
     "mina_verify_account_files", "mina_verify_account_checks", "mina_verify_account_ctx", "mina_account_hash_batch", "mina_account_abi_encode", "mina_verify_configure", "mina_verify_shutdown", "mina_verify_global_ctx", "mina_poseidon_params_name",
+    "mina_verify_device_count", "mina_verify_device_ctx", "mina_verify_install_verifier_index", "mina_verify_install_step_index", "mina_verify_set_poseidon_params",
     "mina_poseidon_install_default_params",
     "mina_consensus_select_secure_chain", "mina_parse_state_pub_inputs", "mina_parse_account_pub_inputs", "mina_parse_merkle_path", "mina_verify_account_inclusion",
 ]
@@ -230,7 +231,7 @@ class KimchiBatchOut(ctypes.Structure):
 
 
 CHECK_FORMAT, CHECK_LEDGER, CHECK_CHAIN, CHECK_CONSENSUS, CHECK_ACCUMULATOR, CHECK_KIMCHI, CHECK_ACCOUNT_ABI, CHECK_MERKLE = 1, 2, 4, 8, 16, 32, 64, 128
-VERIFY_ALLOW_MISSING_KIMCHI = 1
+VERIFY_ALLOW_MISSING_KIMCHI, VERIFY_ALLOW_UNBOUND_STATEMENT, VERIFY_ALLOW_SURROGATE = 1, 2, 4
 
 
 def _bytes_arg(b):
@@ -337,16 +338,60 @@ def verify_shutdown():
     load_library().mina_verify_shutdown()
 
 
+def _borrowed_ctx(lib, h):
+    c = MinaContext.__new__(MinaContext)
+    c._lib, c._h, c.device, c._borrowed = lib, ctypes.c_void_p(h), 0, True
+    return c
+
+
 def verify_global_ctx():
-    """the process-wide context of mina_verify_* as a non-owning MinaContext (e.g. to install a verifier index)"""
+    """the process-wide context of mina_verify_* (the first device's) as a non-owning MinaContext (e.g. to install a verifier index)"""
     lib = load_library()
     lib.mina_verify_global_ctx.restype = ctypes.c_void_p
     h = lib.mina_verify_global_ctx()
     if not h:
         raise MinaError("no process-wide context: " + lib.mina_last_error().decode())
-    c = MinaContext.__new__(MinaContext)
-    c._lib, c._h, c.device, c._borrowed = lib, ctypes.c_void_p(h), 0, True
-    return c
+    return _borrowed_ctx(lib, h)
+
+
+def verify_device_count() -> int:
+    return int(load_library().mina_verify_device_count())
+
+
+def verify_device_ctx(i: int):
+    lib = load_library()
+    lib.mina_verify_device_ctx.restype = ctypes.c_void_p
+    h = lib.mina_verify_device_ctx(int(i))
+    if not h:
+        raise MinaError(f"no device context {i}")
+    return _borrowed_ctx(lib, h)
+
+
+class AllDevices:
+    """the installers that put the same data on EVERY device of the process (mina_verify_install_*): same method names as MinaContext,
+    so the helpers that install an index on a context work on this object too"""
+    def __init__(self):
+        self._lib = load_library()
+
+    def _ck(self, rc, what):
+        if rc != 0:
+            raise MinaError(f"{what} failed ({rc}): {self._lib.mina_last_error().decode()}")
+
+    def verifier_index_install(self, *a):
+        vi, keep = MinaContext._verifier_index_struct(*a)
+        self._ck(self._lib.mina_verify_install_verifier_index(ctypes.byref(vi)), "mina_verify_install_verifier_index")
+
+    def step_index_install(self, *a):
+        si, keep = MinaContext._step_index_struct(*a)
+        self._ck(self._lib.mina_verify_install_step_index(ctypes.byref(si)), "mina_verify_install_step_index")
+
+    def poseidon_set_params(self, field: int, params):
+        a = _u8(params)
+        self._ck(self._lib.mina_verify_set_poseidon_params(int(field), _p(a)), "mina_verify_set_poseidon_params")
+
+
+def verify_all_devices() -> AllDevices:
+    return AllDevices()
 
 
 def poseidon_params_name() -> str:
@@ -906,20 +951,29 @@ class MinaContext:
         self._ck(self._lib.mina_pickles_public_inputs_batch(self._h, ctypes.byref(st), ctypes.c_size_t(batch), _p(pub), _p(ok)), "mina_pickles_public_inputs_batch")
         return pub, ok
 
-    def verifier_index_install(self, log2_domain: int, zk_rows: int, perm_alpha_offset: int, shifts, sigma_comm, coefficients_comm, selector_comm, constant_term: bytes):
+    @staticmethod
+    def _verifier_index_struct(log2_domain: int, zk_rows: int, perm_alpha_offset: int, shifts, sigma_comm, coefficients_comm, selector_comm, constant_term: bytes):
         vi = VerifierIndex(); arrs = [_u8(shifts), _u8(sigma_comm), _u8(coefficients_comm), _u8(selector_comm), _u8(constant_term) if len(constant_term) else np.zeros(1, np.uint8)]
         vi.log2_domain, vi.zk_rows, vi.perm_alpha_offset = log2_domain, zk_rows, perm_alpha_offset
         vi.shifts, vi.sigma_comm, vi.coefficients_comm, vi.selector_comm, vi.constant_term = (a.ctypes.data for a in arrs)
         vi.constant_term_len = len(constant_term)
+        return vi, arrs
+
+    def verifier_index_install(self, *a):
+        vi, keep = self._verifier_index_struct(*a)
         self._ck(self._lib.mina_verifier_index_install(self._h, ctypes.byref(vi)), "mina_verifier_index_install")
 
-    def step_index_install(self, zk_rows: int, domains: list, shifts, constant_term: bytes):
+    @staticmethod
+    def _step_index_struct(zk_rows: int, domains: list, shifts, constant_term: bytes):
         """domains: list of log2 sizes; shifts: len(domains) x 7 x 32 bytes (Fp)"""
         class StepIndex(ctypes.Structure):
             _fields_ = [("zk_rows", ctypes.c_uint32), ("n_domains", ctypes.c_uint32), ("domain_log2", ctypes.c_void_p), ("shifts", ctypes.c_void_p),
                         ("constant_term", ctypes.c_void_p), ("constant_term_len", ctypes.c_size_t)]
         d = np.ascontiguousarray(domains, dtype=np.uint32); sh = _u8(shifts); ct = _u8(constant_term) if len(constant_term) else np.zeros(1, np.uint8)
-        si = StepIndex(zk_rows, len(domains), d.ctypes.data, sh.ctypes.data, ct.ctypes.data, len(constant_term))
+        return StepIndex(zk_rows, len(domains), d.ctypes.data, sh.ctypes.data, ct.ctypes.data, len(constant_term)), (d, sh, ct)
+
+    def step_index_install(self, *a):
+        si, keep = self._step_index_struct(*a)
         self._ck(self._lib.mina_step_index_install(self._h, ctypes.byref(si)), "mina_step_index_install")
 
     def pickles_public_input(self, wrap_proof: bytes, encoding: int, app_state):

@@ -44,7 +44,7 @@ STATEMENT_KEYS = ("alpha", "beta", "gamma", "zeta", "joint_combiner", "feature_f
 for i in range(count):
     t0 = time.time()
     rng = random.Random(0x57A7 + i)
-    wrap = synth_wrap_proof(rng, k=K_LOG2)
+    wrap = synth_wrap_proof(rng, k=K_LOG2, lookups=False)
     pres = [[rng.getrandbits(128) for _ in range(15)] for _ in range(2)]
     chals = [[R.challenge_to_field(p, R.endo_r(0), R.Q) for p in row] for row in pres]
     wrap["prev_optional"] = [None] * 19

@@ -22,6 +22,7 @@ def big(oracle):
     from wire_writers import state_proof_bytes, state_pub_bytes
     ix, _, _ = load_k15_fixture()
     items, fx = load_statement_fixture()
+    m.lib.verify_configure(m.lib.VERIFY_ALLOW_SURROGATE)      # the tests run on the surrogate Poseidon tables (the real ones are not offline)
     gctx = m.lib.verify_global_ctx()
     install_index(gctx, ix)
     install_step_index(gctx, make_step_index(99))

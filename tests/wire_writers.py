@@ -44,8 +44,18 @@ class W:
     def chr(self, v): self.o.append(v)
 
 
-def synth_wrap_proof(rng: random.Random, k: int = 15) -> dict:
-    """random field content in the shape of a wrap proof (no cryptographic meaning)"""
+def synth_wrap_proof(rng: random.Random, k: int = 15, lookups: bool = True) -> dict:
+    """random field content in the shape of a wrap proof (no cryptographic meaning).  lookups=False: the feature flags of gates that read
+    lookup tables stay off and there is no joint combiner -- the shape of Mina's blockchain proofs, and the only one the boundary accepts
+    (mina_verify_state rejects lookup features: the linearization carries no lookup terms); foreign_field_add stays random."""
+    d = _synth_wrap_proof(rng, k)
+    if not lookups:
+        d["joint_combiner"] = None
+        d["feature_flags"] = [False, False, d["feature_flags"][2], False, False, False, False, False]
+    return d
+
+
+def _synth_wrap_proof(rng: random.Random, k: int = 15) -> dict:
     P = 0x40000000000000000000000000000000224698FC094CF91B992D30ED00000001
     rf = lambda: rng.randrange(P)
     c128 = lambda: rng.getrandbits(128) if rng.randrange(4) else rng.choice([0, 1, (1 << 128) - 1, 1 << 63, (1 << 64) - 1, 0x7f, 0x80, 0x7fff, 0x8000, (1 << 64) - 0x80])

@@ -13,6 +13,7 @@ from wire_writers import state_proof_bytes, state_pub_bytes
 
 ix, _, _ = load_k15_fixture()
 items, _ = load_statement_fixture()
+m.lib.verify_configure(m.lib.VERIFY_ALLOW_SURROGATE)
 gctx = m.lib.verify_global_ctx()
 install_index(gctx, ix); install_step_index(gctx, make_step_index(99))
 proofs, pubs = [], []

@@ -23,6 +23,7 @@ from wire_writers import state_proof_bytes, state_pub_bytes
 per_thread = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 ix, _, _ = load_k15_fixture()
 items, _ = load_statement_fixture()
+m.lib.verify_configure(m.lib.VERIFY_ALLOW_SURROGATE)
 gctx = m.lib.verify_global_ctx()
 install_index(gctx, ix); install_step_index(gctx, make_step_index(99))
 cases = []

@@ -28,6 +28,7 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 seed0 = int(time.time()); rng = random.Random(seed0)
 ix, _, _ = load_k15_fixture()
 items, _ = load_statement_fixture()
+m.lib.verify_configure(m.lib.VERIFY_ALLOW_SURROGATE)
 gctx = m.lib.verify_global_ctx()
 install_index(gctx, ix); install_step_index(gctx, make_step_index(99))
 cases = []
