@@ -60,13 +60,26 @@ MADS_PER_LANE_ROUND = 2 * 99 + 2 * 135 + 297
 MAD_ISSUE_CYCLES = 7.0
 CHIP_SIMDS, CLOCK_HZ = 1024, 2.4e9
 PROF_STAGES = {"pstate_hash": 11, "ipa_transcript": 12, "kimchi_to_batch": 13, "pickles_statement": 14, "msm_accumulate": 3}
-# HBM-side bytes per protocol-state hash from the rocprofv3 PMC passes of profiles/r02j_rocprof.md (FETCH_SIZE x 2 -- the gfx950
-# correction of MI355X_MICROARCH.md for 16-B-per-lane loads -- + WRITE_SIZE, KiB x 1024, over the 139 264 states of one launch)
-PSTATE_TRAFFIC_BYTES_PER_STATE = (2 * 130102 + 4352) * 1024 / 139264
+# HBM-side bytes per protocol-state hash: read from the tracked summary of the rocprofv3 PMC passes (FETCH_SIZE x 2 -- the gfx950 correction
+# of MI355X_MICROARCH.md for 16-B-per-lane loads -- + WRITE_SIZE, KiB, over the states of one launch); null when the file is missing
+TRAFFIC_FILE = os.path.join("profiles", "pstate_hash_traffic.json")
+
+
+def pstate_traffic():
+    try:
+        t = json.load(open(os.path.join(ROOT, TRAFFIC_FILE)))
+        return (2 * t["fetch_size_kib"] + t["write_size_kib"]) * 1024 / t["states_per_launch"], t.get("source", TRAFFIC_FILE)
+    except (OSError, KeyError, ValueError):
+        return None, None
 
 
 def le32(x: int) -> np.ndarray:
     return np.frombuffer(int(x).to_bytes(32, "little"), np.uint8)
+
+
+def fresh_randomiser() -> np.ndarray:
+    r = np.frombuffer(os.urandom(32), np.uint8).copy(); r[31] &= 0x3F
+    return r
 
 
 def make_chains(ctx, n_chains: int, seed: int):
@@ -136,9 +149,11 @@ def build_full_job(ctx, m, B: int, seed: int):
     nd = min(B, 32)
     recs, nf, hashes = make_chains(ctx, nd, seed)
     ci = np.arange(B) % nd
-    rho = np.random.Generator(np.random.PCG64(seed + 2)).integers(0, 256, (B, 32), dtype=np.uint8); rho[:, 31] &= 0x3F
+    # folding randomisers of the kernel-level job are the CALLER's to supply (include/mina_verify.h): drawn from the OS CSPRNG, as the
+    # reference-shaped boundary does per job (api_verify.hip draw_randomisers); their values do not change the work
+    rho = np.frombuffer(os.urandom(B * 32), np.uint8).reshape(B, 32).copy(); rho[:, 31] &= 0x3F
     arrays = dict(state_records=recs[ci].reshape(-1), state_nfields=nf[ci].reshape(-1), expected_hashes=hashes[ci].reshape(-1),
-                  rand_base=le32(7), sg_rand_base=le32(9), acc_prechallenges=tile(None, "acc_prechallenges"), acc_sg=tile(None, "acc_sg"), acc_rho=rho.reshape(-1),
+                  rand_base=fresh_randomiser(), sg_rand_base=fresh_randomiser(), acc_prechallenges=tile(None, "acc_prechallenges"), acc_sg=tile(None, "acc_sg"), acc_rho=rho.reshape(-1),
                   **{name: tile("opening", name) for name in ("lr", "delta", "sg", "z1", "z2")})
     scal = dict(with_states=1, with_ipa=1, with_accumulator=1, log2_domain=LOG2_DOMAIN, npub=NPUB, k=WRAP_K, n_evalpoints=NPTS, n_comms=NCOMMS + 2, acc_k=ACC_K, kimchi=kp)
     return m.MinaContext.make_state_jobs(B, arrays, **scal), kp, (recs[0], nf[0], hashes[0])
@@ -256,10 +271,77 @@ def cpu_baseline(baseline_sample, budget_s: float = 20.0):
                       f"MSMs threaded over {threads} windows; verdict ACCEPT: {ok}; single-thread: {out['single'][2]} jobs in {out['single'][3]:.1f}s"}
 
 
+def boundary_leg(m, local_rank: int, B: int, min_seconds: float = 2.0):
+    """Secondary key `boundary_bytes_to_bools`: the reference-shaped boundary itself -- `mina_verify_state_batch` over B full-size bincode
+    `MinaStateProof`s + 1057-byte public inputs (tests/golden/state_proofs_k15_bytes.json: the headline's four proofs as the caller of
+    core/src/aligned.rs:31-58 would send them, tiled to B), host bytes in, verdict bytes out: parsing, `to_input` flattening, the ledger and
+    consensus checks, the page-locked staging, PCIe both ways and the GPU job, back-to-back synchronous calls for >= `min_seconds`; then the
+    same with two caller threads (a batcher's tasks).  Never `value`."""
+    import ctypes
+    import threading
+    path = os.path.join(ROOT, "tests", "golden", "state_proofs_k15_bytes.json")
+    if not os.path.exists(path):
+        return {"skipped": "tests/golden/state_proofs_k15_bytes.json missing"}
+    fxb = json.load(open(path))
+    fx, un = load_encoded_fixture()
+    import mina_bridge_amd.poseidon_params as PP
+    if fxb["poseidon_constants"] != PP.NAME:
+        return {"skipped": "byte fixture minted under another Poseidon constant set"}
+    os.environ["MINA_VERIFY_DEVICE"] = str(local_rank)
+    m.lib.verify_configure(m.lib.VERIFY_ALLOW_SURROGATE)            # the compiled-in Poseidon tables are the surrogate set (named in the output)
+    install_fixture_indexes(m.lib.verify_all_devices(), fx, un)
+    items = [(bytes.fromhex(it["proof"]), bytes.fromhex(it["pub"])) for it in fxb["proofs"]]
+    P = [items[i % len(items)][0] for i in range(B)]; Q = [items[i % len(items)][1] for i in range(B)]
+    lib = m.load_library()
+    PP_ = (ctypes.c_char_p * B)(*P); PL = (ctypes.c_size_t * B)(*map(len, P)); QQ = (ctypes.c_char_p * B)(*Q); QL = (ctypes.c_size_t * B)(*map(len, Q))
+
+    def call(out):
+        rc = lib.mina_verify_state_batch(ctypes.c_size_t(B), PP_, PL, QQ, QL, out.ctypes.data_as(ctypes.c_void_p))
+        assert rc == 0, lib.mina_last_error().decode()
+    out = np.zeros(B, np.uint8)
+    for _ in range(3):                                                # warm: contexts, tables, slots' page-locked buffers
+        call(out)
+    assert out.all(), "boundary verdicts must be ACCEPT"
+    # one tampered proof in the batch: exactly its verdict byte is 0 (the culprit search of its chunk), untimed
+    bad = bytearray(items[0][1]); bad[40] ^= 1
+    QQ[B // 3] = bytes(bad)
+    call(out)
+    assert out.sum() == B - 1 and out[B // 3] == 0, f"a tampered public input must fail exactly its own proof: {int(out.sum())} of {B} accepted, rejected {np.flatnonzero(out == 0)[:16].tolist()}"
+    QQ[B // 3] = Q[B // 3]
+    calls, t0 = 0, time.perf_counter()
+    while True:
+        call(out); calls += 1
+        el = time.perf_counter() - t0
+        if el >= min_seconds:
+            break
+    assert out.all()
+    single = {"proofs_per_s": calls * B / el, "ms_per_call": el / calls * 1e3, "calls": calls}
+    outs = [np.zeros(B, np.uint8) for _ in range(2)]
+    counts = [0, 0]; stop = time.perf_counter() + min_seconds
+    def worker(i):
+        while time.perf_counter() < stop:
+            call(outs[i]); counts[i] += 1
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+    t0 = time.perf_counter()
+    for t in th: t.start()
+    for t in th: t.join()
+    el2 = time.perf_counter() - t0
+    assert all(o.all() for o in outs)
+    res = {"value": single["proofs_per_s"], "unit": "proofs/s", "proofs_per_call": B, "ms_per_call": single["ms_per_call"], "calls_timed": calls,
+           "bytes_per_proof": len(P[0]) + len(Q[0]), "host_threads": int(os.environ.get("MINA_HOST_THREADS", min((os.cpu_count() or 2) // 2, 64))),
+           "two_caller_threads": {"value": sum(counts) * B / el2, "unit": "proofs/s", "calls": sum(counts)},
+           "entry_point": "mina_verify_state_batch (include/mina_verify.h): bincode MinaStateProof + MinaStatePubInputs bytes -> verdict bytes",
+           "poseidon_constants": m.lib.poseidon_params_name(),
+           "note": "host bytes in, bools out: parsing, to_input flattening, ledger + consensus checks, pinned staging, PCIe both ways, the GPU job (folding "
+                   "randomisers from the OS CSPRNG per chunk); one tampered proof in a warm-up call failed alone"}
+    m.lib.verify_shutdown()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--steps", type=int, default=80)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--jobs", type=int, default=8192, help="state proofs per step (one mina_state_job_batch_dev call)")
     ap.add_argument("--pipeline", type=int, default=16, help="internal stream lanes over which consecutive steps are issued")
@@ -270,6 +352,7 @@ def main():
                          "(public inputs given; tests/golden/kimchi_k15.json); prepared: pre-derived BatchEvaluationProof rows (round 2's first headline)")
     ap.add_argument("--kimchi", action="store_true", help="alias of --mode kimchi")
     ap.add_argument("--no-probes", action="store_true", help="skip the isolated-kernel and C2 probes (profiling runs)")
+    ap.add_argument("--no-boundary", action="store_true", help="skip the bytes -> bools leg (mina_verify_state_batch on serialized proofs)")
     args = ap.parse_args()
     if args.kimchi:
         args.mode = "kimchi"
@@ -327,8 +410,8 @@ def main():
             hj.n_comms = NCOMMS + 2
         baseline_sample = ("prepared", sample)                 # the CPU composite of the partial modes starts from the derived rows
     dev = torch.device("cuda", local_rank)
-    dj = m.lib.StateJobs()
     import ctypes
+    dj = m.lib.StateJobs()
     ctypes.memmove(ctypes.byref(dj), ctypes.byref(hj), ctypes.sizeof(m.lib.StateJobs))
     by_addr = {a.ctypes.data: a for a in keep if isinstance(a, np.ndarray)}
     dtensors = []
@@ -411,6 +494,46 @@ def main():
     if gathered is not None:
         assert all(int(g.sum()) == B for g in gathered), "every rank's shard must be ACCEPT"
 
+    # the same loop for >= 2 s whatever --steps was (pipeline fill / drain is then a small part of the sample); secondary key
+    sustained = None
+    if elapsed < 2.0:
+        n_sus = int(args.steps * 2.2 / max(elapsed, 1e-3)) + 1
+        barrier(); torch.cuda.synchronize(); ts = time.perf_counter()
+        for _ in range(n_sus):
+            step()
+        ctx.synchronize(); torch.cuda.synchronize(); barrier()
+        el_s = time.perf_counter() - ts
+        assert verdicts_ok(n_sus)
+        sustained = {"steps": n_sus, "seconds": el_s, "value": args.gpus * n_sus * B / el_s, "unit": "proofs/s"}
+
+    # BASELINE config C5 as written: 4096 state proofs in total, split over the ranks (strong scaling) -- 4096 / N per rank and step
+    c5 = None
+    if B >= 4096 // max(world, 1) and 4096 % max(world, 1) == 0:
+        B5 = 4096 // world
+        dj5 = m.lib.StateJobs(); ctypes.memmove(ctypes.byref(dj5), ctypes.byref(dj), ctypes.sizeof(m.lib.StateJobs)); dj5.batch = B5
+        keep5 = []
+        if kp is not None:
+            dk5 = m.lib.KimchiProofs(); ctypes.memmove(ctypes.byref(dk5), ctypes.byref(dk), ctypes.sizeof(m.lib.KimchiProofs)); dk5.batch = B5
+            dj5.kimchi = ctypes.addressof(dk5); keep5.append(dk5)
+        def step5():
+            o = d_out[it[0] % nslots]; it[0] += 1
+            ctx.state_job_batch_dev(dj5, o.data_ptr(), o.data_ptr() + 4 * B5)
+        for _ in range(nslots):
+            step5()
+        ctx.synchronize()
+        n5 = max(32, args.steps)
+        barrier(); torch.cuda.synchronize(); t5 = time.perf_counter()
+        for _ in range(n5):
+            step5()
+        ctx.synchronize(); torch.cuda.synchronize(); barrier()
+        el5 = time.perf_counter() - t5
+        last = d_out[(it[0] - 1) % nslots].cpu().numpy()
+        assert last[:B5].tolist() == [1] * B5 and last[B5:B5 + 4].tolist() == [1, 0, 1, 0], "C5 verdicts must be ACCEPT"
+        c5 = {"value": n5 * 4096 / el5, "unit": "proofs/s", "proofs_total_per_step": 4096, "proofs_per_rank_per_step": B5, "steps": n5, "scaling": "strong",
+              "ms_per_step": el5 / n5 * 1e3}
+        for o in d_out:
+            o.zero_()
+
     # the candidate dominant kernels with nothing else on the GPU: one lane, HIP events on that lane's stream
     prof_iso = {}
     if not args.no_probes:
@@ -449,9 +572,21 @@ def main():
         c2_rate = None
 
     if dist_on:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else dev)
+        t = torch.tensor([elapsed, sustained["seconds"] if sustained else 0.0, c5["ms_per_step"] if c5 else 0.0], dtype=torch.float64, device="cpu" if share_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = float(t[0].item())
+        if sustained:
+            sustained["seconds"] = float(t[1].item()); sustained["value"] = args.gpus * sustained["steps"] * B / sustained["seconds"]
+        if c5:
+            c5["ms_per_step"] = float(t[2].item()); c5["value"] = 4096 / (c5["ms_per_step"] * 1e-3)
+    ctx.close()
+    boundary = None
+    if not args.no_boundary and not share_gpu:                     # every rank drives its own GPU through the C-ABI boundary; rank 0 reports the sum
+        boundary = boundary_leg(m, local_rank, B)
+        if dist_on and "value" in boundary:
+            tb = torch.tensor([boundary["value"], boundary["two_caller_threads"]["value"]], dtype=torch.float64, device=dev)
+            dist.all_reduce(tb, op=dist.ReduceOp.SUM)
+            boundary["value_all_ranks"] = float(tb[0].item()); boundary["two_caller_threads"]["value_all_ranks"] = float(tb[1].item())
 
     if rank == 0:
         def avg_us(p, name):
@@ -466,6 +601,7 @@ def main():
         perms = nstates * (25 + 1)                             # 49 body fields -> 25 permutations, + 1 for H(previous, body)
         hash_bytes = nstates * (50 * 32 + 32)                  # per state: 50 field elements read, one hash written
         achieved = hash_bytes / (kern_us * 1e-6) / 1e9 if kern_us else None
+        traffic_per_state, traffic_src = pstate_traffic()
         out = {
             "metric": "Mina state proofs verified/sec (batch)",
             "value": args.gpus * args.steps * B / elapsed,
@@ -488,7 +624,7 @@ def main():
                                                    "parsers: tests/test_verify_fullsize.py)",
                                            "kimchi": "32 chains, 4 wrap proofs (tests/golden/kimchi_k15.json), 32 accumulators per rank",
                                            "prepared": "32 chains, 8 wrap openings (tests/golden/state_job_k15.json), 32 accumulators per rank"}[args.mode],
-                       "folding": "IPA and accumulator checks folded over the step's batch with caller-supplied randomisers (kimchi batch_verify's shape)",
+                       "folding": "IPA and accumulator checks folded over the step's batch (kimchi batch_verify's shape); randomisers drawn from the OS CSPRNG by the caller",
                        "not_in_job": {"full": "bin_prot / bincode parsing of the containers and the consensus pre-checks (host side of the boundary, before the timed region)",
                                       "kimchi": "parsing and the Pickles statement -> public-input derivation (public inputs given)",
                                       "prepared": "kimchi oracles/linearisation, the statement derivation, parsing (BatchEvaluationProof rows given)"}[args.mode],
@@ -500,14 +636,17 @@ def main():
                        "sharding": f"proof-level, {args.gpus} rank(s); verdict words all-gathered over RCCL" if dist_on else "single rank",
                        "algorithmic_bytes_per_proof": algorithmic_bytes_per_proof()},
             "roofline": {"bound": "hbm", "kernel": "pstate_hash_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": nstates * PSTATE_TRAFFIC_BYTES_PER_STATE,
-                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), profiles/r02j_rocprof.md",
+                         "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": (nstates * traffic_per_state) if traffic_per_state else None,
+                         "traffic_source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), read from {TRAFFIC_FILE} ({traffic_src})" if traffic_per_state else None,
                          "algorithmic_bytes_per_launch": hash_bytes, "states_per_launch": nstates, "avg_launch_us": kern_us,
                          "avg_launch_us_in_timed_region": ovl.get("pstate_hash"),
                          "note": "avg_launch_us: HIP events on the lane stream around the kernel, launches with nothing else on the GPU right after the "
                                  "timed region (second figure: inside it, lanes overlapping).  The path is integer-VALU bound (SURVEY.md 8d): the HBM "
                                  "fraction is reported because the metric asks for it, roofline_valu is the bound that matters; traffic: see profiles/"},
             "stage_us": {"isolated": iso, "in_timed_region": ovl},
+            "sustained": sustained,
+            "c5_4096_total_strong": c5,
+            "boundary_bytes_to_bools": boundary,
             "c2_accumulator_only": {"value": c2_rate, "unit": "accumulator checks/s",
                                     "note": "BASELINE config C2 alone (round 1's headline): un-folded 2^16-base Vesta IPA accumulator checks, 8 per call, 16 lanes"},
         }
@@ -524,7 +663,6 @@ def main():
     if dist_on:
         dist.barrier()
         dist.destroy_process_group()
-    ctx.close()
 
 
 if __name__ == "__main__":

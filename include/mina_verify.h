@@ -149,6 +149,13 @@ int mina_b_poly_fold_dev(mina_ctx *ctx, int field, uint32_t k, size_t batch, con
  * The constants are parameters of the engine (the real fp_kimchi/fq_kimchi tables are not in the
  * reference tree). */
 int mina_poseidon_set_params(mina_ctx *ctx, int field, const uint8_t *params /* (9+165)*32 */);
+/* The same from the text forms upstream publishes the tables in: the JSON object of o1js' constants.ts ({"mds": [[...]], "roundConstants":
+ * [[...]], ...}) or the Rust table of mina-poseidon's fp_kimchi.rs / fq_kimchi.rs (`mds: vec![...]`, `round_constants: vec![...]`); decimal
+ * or 0x-hex literals, quoted or not.  Exactly 9 + 55 x 3 canonical field elements, else MINA_ERR_FORMAT.  The process-wide contexts of
+ * mina_verify_* load $MINA_POSEIDON_PARAMS_FP / $MINA_POSEIDON_PARAMS_FQ (file paths) at start-up instead of the compiled-in surrogate. */
+int mina_poseidon_params_parse(int field, const char *text, size_t len, uint8_t *params_out /* (9+165)*32 */);   /* host-side, no context */
+int mina_poseidon_load_params(mina_ctx *ctx, int field, const char *text, size_t len);
+int mina_poseidon_load_params_file(mina_ctx *ctx, int field, const char *path);
 /* in-place permutation of n states (3 field elements each) */
 int mina_poseidon_permute(mina_ctx *ctx, int field, size_t n, uint8_t *states /* n*96 */);
 int mina_poseidon_permute_dev(mina_ctx *ctx, int field, size_t n, void *d_states);

@@ -30,6 +30,7 @@
 
 int mb_pack_protocol_state(const mw::ProtocolState &s, uint8_t *record, uint32_t *n_body_fields, mina_protocol_state_info *info);   // api_state.hip
 int mb_kimchi_available(mina_ctx *c);                                                                                                  // api_kimchi.hip
+int mb_poseidon_env_params(mina_ctx *c);                                                                                               // api_loaders.hip
 int mb_step_index_installed(mina_ctx *c);                                                                                              // api_pickles.hip
 int mb_state_jobs_on_lane(mina_ctx *c, const mina_state_jobs *j, uint32_t *d_verdicts, uint32_t *d_flags, Lane *LI, Lane *LA, uint32_t *d_stmt_out);   // api_state.hip
 
@@ -52,7 +53,7 @@ extern "C" int mina_poseidon_install_default_params(mina_ctx *c) {
 // on the host); merged single-proof jobs are dealt round-robin.
 namespace {
 constexpr int NSLOT = 16;                  // chunks in flight per device: slot s runs on lane s of the context (helper lanes 16.. for forked legs)
-struct Slot { PinnedBuf host, out; DevBuf dev; hipEvent_t ev = nullptr; bool busy = false; };
+struct Slot { PinnedBuf host, out; DevBuf dev; hipEvent_t ev = nullptr; hipEvent_t tev[3] = {nullptr, nullptr, nullptr}; bool busy = false; };
 struct Device {
     mina_ctx *c = nullptr; int ordinal = 0;
     std::mutex mu;                         // serialises every call into `c` (a context has ONE current-lane cursor)
@@ -69,7 +70,7 @@ int create_device(int ordinal, Device **out) {
     mina_ctx *c = nullptr;
     int rc = mina_ctx_create(ordinal, &c);
     if (rc) return rc;
-    if ((rc = mina_poseidon_install_default_params(c)) || (rc = mina_srs_create(c, CURVE_VESTA, 1u << 16)) || (rc = mina_srs_create(c, CURVE_PALLAS, 1u << 16))) { mina_ctx_destroy(c); return rc; }
+    if ((rc = mina_poseidon_install_default_params(c)) || (rc = mb_poseidon_env_params(c)) || (rc = mina_srs_create(c, CURVE_VESTA, 1u << 16)) || (rc = mina_srs_create(c, CURVE_PALLAS, 1u << 16))) { mina_ctx_destroy(c); return rc; }
     Device *d = new Device(); d->c = c; d->ordinal = ordinal;
     *out = d;
     return MINA_OK;
@@ -93,7 +94,7 @@ void destroy_devices() {                    // caller holds g_mu
     for (Device *d : g_devs) {
         { std::lock_guard<std::mutex> lk(d->mu);
           (void)hipSetDevice(d->c->device);
-          for (Slot &s : d->slots) { if (s.ev) { (void)hipEventSynchronize(s.ev); (void)hipEventDestroy(s.ev); } s.host.release(); s.out.release(); s.dev.release(); }
+          for (Slot &s : d->slots) { if (s.ev) { (void)hipEventSynchronize(s.ev); (void)hipEventDestroy(s.ev); } for (auto &e : s.tev) if (e) (void)hipEventDestroy(e); s.host.release(); s.out.release(); s.dev.release(); }
           mina_ctx_destroy(d->c); }
         delete d;
     }
@@ -422,8 +423,9 @@ int run_device(Device &D, const CallIn &in, const std::vector<size_t> &idx, uint
         }
         if (!found) return MINA_OK;                                                          // nothing parses
     }
-    static const size_t chunk_target = getenv("MINA_VERIFY_CHUNK") ? (size_t)std::max(1L, atol(getenv("MINA_VERIFY_CHUNK"))) : (size_t)1024;
-    static const size_t single_max = getenv("MINA_VERIFY_SINGLE_MAX") ? (size_t)std::max(1L, atol(getenv("MINA_VERIFY_SINGLE_MAX"))) : (size_t)1536;
+    // read per call (tests force tiny chunks / shards to drive the pipeline's slot recycling with a handful of proofs)
+    const size_t chunk_target = getenv("MINA_VERIFY_CHUNK") ? (size_t)std::max(1L, atol(getenv("MINA_VERIFY_CHUNK"))) : (size_t)1024;
+    const size_t single_max = getenv("MINA_VERIFY_SINGLE_MAX") ? (size_t)std::max(1L, atol(getenv("MINA_VERIFY_SINGLE_MAX"))) : (size_t)1536;
     const size_t nchunks = m <= single_max ? 1 : (m + chunk_target - 1) / chunk_target;
     std::vector<Chunk> chunks(nchunks);
     for (size_t q = 0; q < nchunks; ++q) { chunks[q].lo = m * q / nchunks; chunks[q].n = m * (q + 1) / nchunks - chunks[q].lo; chunks[q].hb.resize(chunks[q].n); }
@@ -457,6 +459,8 @@ int run_device(Device &D, const CallIn &in, const std::vector<size_t> &idx, uint
         ch.harvested = true;
         if (ch.issued) {
             bool ok = hipEventSynchronize(ch.slot->ev) == hipSuccess;
+            if (g_timing && ok && ch.slot->tev[2]) { float a = 0, b = 0; (void)hipEventElapsedTime(&a, ch.slot->tev[0], ch.slot->tev[1]); (void)hipEventElapsedTime(&b, ch.slot->tev[1], ch.slot->tev[2]);
+                fprintf(stderr, "mina_verify:   chunk at %zu: upload of %.1f MB %.2f ms, job %.2f ms (on its lane)\n", ch.lo, lay.total / 1e6, a, b); }
             const uint32_t *o = (const uint32_t *)ch.slot->out.p;
             if (ok) {
                 const bool ipa_ok = !sh.kimchi || o[ch.n] != 0, acc_ok = o[ch.n + 2] != 0;
@@ -492,16 +496,19 @@ int run_device(Device &D, const CallIn &in, const std::vector<size_t> &idx, uint
         c->nlanes = (int)std::max(1u, std::min<unsigned>(D.inflight.load(), NSLOT));
         c->L = &L;
         uint8_t *dbase = S.dev.as<uint8_t>();
+        if (g_timing) { for (auto &e : S.tev) if (!e) HIPC(hipEventCreate(&e)); HIPC(hipEventRecord(S.tev[0], L.stream)); }
         HIPC(hipMemcpyAsync(dbase, hbase, lay.total, hipMemcpyHostToDevice, L.stream));
+        if (g_timing) HIPC(hipEventRecord(S.tev[1], L.stream));
         JobStructs js; make_jobs(sh, lay, dbase, ch.n, true, true, true, js);
         uint32_t *dv = (uint32_t *)(dbase + lay.out_off()), *df = dv + ch.n, *ds = df + 4;
         // few chunks in flight: the three legs of a job (state hashes / wrap proof / accumulator) go to three streams
-        static const unsigned split_max = getenv("MINA_VERIFY_SPLIT_MAX") ? (unsigned)atoi(getenv("MINA_VERIFY_SPLIT_MAX")) : 2u;
+        const unsigned split_max = getenv("MINA_VERIFY_SPLIT_MAX") ? (unsigned)atoi(getenv("MINA_VERIFY_SPLIT_MAX")) : 2u;
         Lane *LI = nullptr, *LA = nullptr;
         if (D.inflight.load() <= split_max && ch.slot_ix < 8) { LI = &c->lanes[16 + 2 * ch.slot_ix]; LA = &c->lanes[17 + 2 * ch.slot_ix]; }
         rc = mb_state_jobs_on_lane(c, &js.j, dv, df, LI, LA, ds);
         c->use_lane0();
         if (rc) return rc;
+        if (g_timing) HIPC(hipEventRecord(S.tev[2], L.stream));
         HIPC(hipMemcpyAsync(S.out.p, dv, Layout::out_bytes(ch.n), hipMemcpyDeviceToHost, L.stream));
         HIPC(hipEventRecord(S.ev, L.stream));
         ch.issued = true;
@@ -533,13 +540,15 @@ int run_device(Device &D, const CallIn &in, const std::vector<size_t> &idx, uint
         }
         Chunk &ch = chunks[next_issue];
         mb_pool_wait(ch.job);
+        const double t_parsed = g_timing ? ms_since(t_call) : 0;
         int rc = issue(ch);
+        if (g_timing) fprintf(stderr, "mina_verify:   chunk %zu (%zu proofs): parsed at %.2f ms, issued at %.2f ms\n", next_issue, ch.n, t_parsed, ms_since(t_call));
         if (rc && !rc_all) rc_all = rc;
         ++next_issue;
     }
     for (size_t q = 0; q < next_submit; ++q) mb_pool_wait(chunks[q].job);     // nothing may still write into a slot (error paths)
     for (size_t q = 0; q < nchunks; ++q) {
-        if (q < next_submit) harvest(chunks[q]);
+        if (q < next_submit) { harvest(chunks[q]); if (g_timing) fprintf(stderr, "mina_verify:   chunk %zu harvested at %.2f ms\n", q, ms_since(t_call)); }
         else D.inflight.fetch_sub(1);
     }
     if (g_timing) fprintf(stderr, "mina_verify: device %d: %zu proofs in %zu chunk(s), %.2f ms\n", D.ordinal, m, nchunks, ms_since(t_call));
@@ -556,7 +565,7 @@ int verify_state_many(const CallIn &in, size_t n, uint8_t *verdicts) {
     if (devs.empty()) return MINA_ERR_HIP;
     if (n == 0) return MINA_OK;
     const size_t G = devs.size();
-    static const size_t min_shard = getenv("MINA_VERIFY_MIN_SHARD") ? (size_t)std::max(1L, atol(getenv("MINA_VERIFY_MIN_SHARD"))) : (size_t)64;
+    const size_t min_shard = getenv("MINA_VERIFY_MIN_SHARD") ? (size_t)std::max(1L, atol(getenv("MINA_VERIFY_MIN_SHARD"))) : (size_t)64;
     const size_t use = std::max<size_t>(1, std::min(G, n / min_shard));    // tiny calls stay on one device (dealt round-robin)
     if (use == 1) {
         std::vector<size_t> idx(n); for (size_t i = 0; i < n; ++i) idx[i] = i;

@@ -29,7 +29,7 @@ EXPORTS = [
     "mina_srs_create", "mina_srs_load", "mina_srs_depth", "mina_srs_get_g", "mina_srs_get_h", "mina_srs_lagrange_basis", "mina_public_input_commitment", "mina_public_input_commitment_batch", "mina_combined_inner_product", "mina_srs_serialize",
     "mina_msm", "mina_msm_srs", "mina_msm_srs_range", "mina_msm_srs_multi", "mina_msm_srs_dev",
     "mina_b_poly", "mina_b_poly_coefficients", "mina_b_poly_fold", "mina_b_poly_fold_dev",
-    "mina_poseidon_set_params", "mina_poseidon_permute", "mina_poseidon_permute_dev", "mina_poseidon_hash",
+    "mina_poseidon_set_params", "mina_poseidon_params_parse", "mina_poseidon_load_params", "mina_poseidon_load_params_file", "mina_poseidon_permute", "mina_poseidon_permute_dev", "mina_poseidon_hash",
     "mina_challenge_to_field", "mina_fq_sponge_run", "mina_to_group", "mina_merkle_roots", "mina_merkle_verify_batch",
     "mina_field_mul", "mina_field_inv", "mina_field_sqrt", "mina_selftest_group_law",
     "mina_accumulator_check_batch", "mina_accumulator_check_dev", "mina_accumulator_check_multi_dev", "mina_accumulator_check_multi", "mina_ipa_batch_check",
@@ -328,6 +328,17 @@ def account_abi_encode(account: bytes, encoding: int) -> bytes:
     if rc != 0:
         raise MinaError(f"mina_account_abi_encode failed ({rc}): {lib.mina_last_error().decode()}")
     return out.tobytes()
+
+
+def poseidon_params_parse(field: int, text: str) -> np.ndarray:
+    """upstream's text form of a Poseidon table (o1js JSON / mina-poseidon Rust source) -> the (9 + 165) x 32-byte layout; host-side"""
+    lib = load_library()
+    t = text.encode()
+    out = np.zeros((9 + 165) * 32, np.uint8)
+    rc = lib.mina_poseidon_params_parse(int(field), ctypes.c_char_p(t), ctypes.c_size_t(len(t)), _p(out))
+    if rc != 0:
+        raise MinaError(f"mina_poseidon_params_parse failed ({rc}): {lib.mina_last_error().decode()}")
+    return out
 
 
 def verify_configure(flags: int):

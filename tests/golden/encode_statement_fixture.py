@@ -39,6 +39,31 @@ def encode():
     return out
 
 
+def encode_boundary_bytes():
+    """the same four proofs as the reference's caller would send them (core/src/aligned.rs:31-58): bincode `MinaStateProof` (wrap proof + the 16
+    + 1 protocol states of the deterministic chain whose candidate tip the statement binds) and the 1057-byte `MinaStatePubInputs`, hex.
+    bench.py's `boundary_bytes_to_bools` leg reads this file (nothing under oracle/ outside its cpu_baseline leg)."""
+    import random
+    from ipa_helpers import poseidon_pp
+    from kimchi_helpers import make_chain
+    from oracle import mina_state_ref as S
+    from wire_writers import state_proof_bytes, state_pub_bytes
+    items, fx = load_statement_fixture()
+    out = {"poseidon_constants": fx["poseidon_constants"], "source": "tests/golden/statement_k15.json through tests/wire_writers.py", "proofs": []}
+    for it in items:
+        states, hashes = make_chain(random.Random(it["chain_seed"]), poseidon_pp(0))
+        assert hashes[15] == it["app"]
+        p, ev = it["proof"], it["proof"]["evals"]
+        wrap = dict(it["wrap"])
+        wrap.update(w_comm=p["w_comm"], z_comm=p["z_comm"], t_comm=p["t_comm"], z_eval=ev[0], selector_eval=ev[1:7], w_eval=ev[7:22], coefficients_eval=ev[22:37], s_eval=ev[37:43],
+                    ft_eval1=p["ft_eval1"], lr=p["opening"]["lr"], z1=p["opening"]["z1"], z2=p["opening"]["z2"], delta=p["opening"]["delta"], sg=p["opening"]["sg"])
+        out["proofs"].append({"proof": state_proof_bytes(wrap, states).hex(),
+                              "pub": state_pub_bytes(True, hashes[16], hashes[:16], [S.snarked_ledger_hash(s) for s in states[:16]]).hex()})
+    return out
+
+
 if __name__ == "__main__":
     json.dump(encode(), open(os.path.join(ROOT, "tests/golden/statement_k15_encoded.json"), "w"), indent=0)
     print("wrote tests/golden/statement_k15_encoded.json")
+    json.dump(encode_boundary_bytes(), open(os.path.join(ROOT, "tests/golden/state_proofs_k15_bytes.json"), "w"), indent=0)
+    print("wrote tests/golden/state_proofs_k15_bytes.json")

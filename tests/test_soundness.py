@@ -88,6 +88,53 @@ def test_accumulator_fold_cancelling_sg_pair_needs_the_randomisers(ctx_srs, orac
 
 
 # ------------------------------------------------------------------------------------------------ the boundary: CSPRNG per job
+# (this one first: it runs in a process state WITHOUT indexes and shuts the process-wide context down; `big` below sets its own up)
+def test_boundary_rejects_cancelling_sg_pairs_on_the_accumulator_leg(oracle, srs_oracle):
+    """the accumulator leg on its own at the boundary: a process WITHOUT a verifier index under MINA_VERIFY_ALLOW_MISSING_KIMCHI runs the
+    chain and accumulator steps only (with an index the statement binds `challenge_polynomial_commitment`, so the tampered accumulators
+    would fail the kimchi step as well).  sg_0' = sg_0 + T, sg_1' = sg_1 - r T for several guesses r of rho_0 / rho_1: both `false`."""
+    import mina_bridge_amd as m
+    from ipa_helpers import poseidon_pp
+    from kimchi_helpers import load_statement_fixture, make_chain
+    from oracle import mina_state_ref as S, pasta_ref as R
+    from wire_writers import state_proof_bytes, state_pub_bytes
+    O = oracle
+    items, _ = load_statement_fixture()
+    m.lib.verify_shutdown()
+    m.lib.verify_configure(m.lib.VERIFY_ALLOW_SURROGATE | m.lib.VERIFY_ALLOW_MISSING_KIMCHI)
+    try:
+        cases = []
+        for it in items[:3]:
+            states, hashes = make_chain(random.Random(it["chain_seed"]), poseidon_pp(0))
+            p, ev = it["proof"], it["proof"]["evals"]
+            wrap = dict(it["wrap"])
+            wrap.update(w_comm=p["w_comm"], z_comm=p["z_comm"], t_comm=p["t_comm"], z_eval=ev[0], selector_eval=ev[1:7], w_eval=ev[7:22], coefficients_eval=ev[22:37],
+                        s_eval=ev[37:43], ft_eval1=p["ft_eval1"], lr=p["opening"]["lr"], z1=p["opening"]["z1"], z2=p["opening"]["z2"], delta=p["opening"]["delta"], sg=p["opening"]["sg"])
+            pub = state_pub_bytes(True, hashes[16], hashes[:16], [S.snarked_ledger_hash(s) for s in states[:16]])
+            cases.append((wrap, states, pub))
+        good = [state_proof_bytes(w, s) for w, s, _ in cases]; pubs = [q for _, _, q in cases]
+        assert m.lib.verify_state_batch(good, pubs).tolist() == [1, 1, 1]
+        T = O.bytes_to_point(srs_oracle[1][0][11])
+        rng = random.Random(77)
+        for r in [1, 2, R.P - 1] + [rng.randrange(1, R.P) for _ in range(3)]:
+            w0 = copy.deepcopy(cases[0][0]); w1 = copy.deepcopy(cases[1][0])
+            w0["challenge_polynomial_commitment"] = R.add(w0["challenge_polynomial_commitment"], T, R.Q)
+            w1["challenge_polynomial_commitment"] = R.add(w1["challenge_polynomial_commitment"], R.neg(R.scalar_mul(r, T, R.Q), R.Q), R.Q)
+            bad = [state_proof_bytes(w0, cases[0][1]), state_proof_bytes(w1, cases[1][1]), good[2]]
+            assert m.lib.verify_state_batch(bad, pubs).tolist() == [0, 0, 1], r
+            got = [None, None, None]
+            gate = threading.Barrier(3)
+            def worker(i):
+                gate.wait(); got[i] = m.lib.verify_state(bad[i], pubs[i])
+            th = [threading.Thread(target=worker, args=(i,)) for i in range(3)]
+            for t in th: t.start()
+            for t in th: t.join()
+            assert got == [False, False, True], r
+    finally:
+        m.lib.verify_configure(0)
+        m.lib.verify_shutdown()
+
+
 @pytest.fixture(scope="module")
 def big(oracle):
     import mina_bridge_amd as m
@@ -159,52 +206,6 @@ def test_merged_concurrent_calls_reject_cancelling_pairs(big):
         for t in th: t.start()
         for t in th: t.join()
         assert got == [c[2] for c in calls]
-
-
-def test_boundary_rejects_cancelling_sg_pairs_on_the_accumulator_leg(oracle, srs_oracle):
-    """the accumulator leg on its own at the boundary: a process WITHOUT a verifier index under MINA_VERIFY_ALLOW_MISSING_KIMCHI runs the
-    chain and accumulator steps only (with an index the statement binds `challenge_polynomial_commitment`, so the tampered accumulators
-    would fail the kimchi step as well).  sg_0' = sg_0 + T, sg_1' = sg_1 - r T for several guesses r of rho_0 / rho_1: both `false`."""
-    import mina_bridge_amd as m
-    from ipa_helpers import poseidon_pp
-    from kimchi_helpers import load_statement_fixture, make_chain
-    from oracle import mina_state_ref as S, pasta_ref as R
-    from wire_writers import state_proof_bytes, state_pub_bytes
-    O = oracle
-    items, _ = load_statement_fixture()
-    m.lib.verify_shutdown()
-    m.lib.verify_configure(m.lib.VERIFY_ALLOW_SURROGATE | m.lib.VERIFY_ALLOW_MISSING_KIMCHI)
-    try:
-        cases = []
-        for it in items[:3]:
-            states, hashes = make_chain(random.Random(it["chain_seed"]), poseidon_pp(0))
-            p, ev = it["proof"], it["proof"]["evals"]
-            wrap = dict(it["wrap"])
-            wrap.update(w_comm=p["w_comm"], z_comm=p["z_comm"], t_comm=p["t_comm"], z_eval=ev[0], selector_eval=ev[1:7], w_eval=ev[7:22], coefficients_eval=ev[22:37],
-                        s_eval=ev[37:43], ft_eval1=p["ft_eval1"], lr=p["opening"]["lr"], z1=p["opening"]["z1"], z2=p["opening"]["z2"], delta=p["opening"]["delta"], sg=p["opening"]["sg"])
-            pub = state_pub_bytes(True, hashes[16], hashes[:16], [S.snarked_ledger_hash(s) for s in states[:16]])
-            cases.append((wrap, states, pub))
-        good = [state_proof_bytes(w, s) for w, s, _ in cases]; pubs = [q for _, _, q in cases]
-        assert m.lib.verify_state_batch(good, pubs).tolist() == [1, 1, 1]
-        T = O.bytes_to_point(srs_oracle[1][0][11])
-        rng = random.Random(77)
-        for r in [1, 2, R.P - 1] + [rng.randrange(1, R.P) for _ in range(3)]:
-            w0 = copy.deepcopy(cases[0][0]); w1 = copy.deepcopy(cases[1][0])
-            w0["challenge_polynomial_commitment"] = R.add(w0["challenge_polynomial_commitment"], T, R.Q)
-            w1["challenge_polynomial_commitment"] = R.add(w1["challenge_polynomial_commitment"], R.neg(R.scalar_mul(r, T, R.Q), R.Q), R.Q)
-            bad = [state_proof_bytes(w0, cases[0][1]), state_proof_bytes(w1, cases[1][1]), good[2]]
-            assert m.lib.verify_state_batch(bad, pubs).tolist() == [0, 0, 1], r
-            got = [None, None, None]
-            gate = threading.Barrier(3)
-            def worker(i):
-                gate.wait(); got[i] = m.lib.verify_state(bad[i], pubs[i])
-            th = [threading.Thread(target=worker, args=(i,)) for i in range(3)]
-            for t in th: t.start()
-            for t in th: t.join()
-            assert got == [False, False, True], r
-    finally:
-        m.lib.verify_configure(0)
-        m.lib.verify_shutdown()
 
 
 def test_surrogate_tables_and_half_configured_contexts_fail_closed(big):

@@ -415,3 +415,50 @@ int main(int argc, char **argv) {
     # 96 calls one after the other would take 96 x one_call_ms; merged they share a handful of jobs
     assert float(f["all_ms"]) < 0.5 * 96 * float(f["one_call_ms"]), r.stdout
     print(r.stdout.strip())
+
+
+def test_boundary_pipeline_chunks_and_device_shards_give_the_same_verdicts(world, srs_oracle):
+    """The bytes -> bools pipeline behind mina_verify_state_batch: the same 37 proofs (good ones, a tampered opening, a tampered public
+    input, garbage) as ONE chunk, as chunks of 5 on one device, as chunks of 2 (19 chunks over the 16 slots of a device: slots are
+    recycled), and cut into 3 contiguous shards over three contexts ($MINA_VERIFY_DEVICES=0,0,0: the multi-GPU path of SURVEY.md 8e.1
+    on one GPU; ragged shards, bad proofs in every shard, chunked inside each shard) -- verdict bytes identical every time."""
+    import mina_bridge_amd as m
+    from kimchi_helpers import install_index
+    minted = [mint_state_proof(world, srs_oracle, 4000 + i) for i in range(3)]
+    good = [to_bytes(*x) for x in minted]
+    w_bad = copy.deepcopy(minted[1][0]); w_bad["z2"] = (w_bad["z2"] + 1) % (1 << 254)
+    bad_open = to_bytes(w_bad, minted[1][1], minted[1][2])
+    bad_pub = bytearray(good[2][1]); bad_pub[77] ^= 4
+    proofs, pubs, want = [], [], []
+    for i in range(37):
+        if i in (0, 12, 13, 36): p, q, v = bad_open[0], bad_open[1], 0
+        elif i in (5, 25): p, q, v = good[2][0], bytes(bad_pub), 0
+        elif i == 30: p, q, v = b"\x01\x02\x03", good[0][1], 0
+        else: p, q, v = good[i % 3][0], good[i % 3][1], 1
+        proofs.append(p); pubs.append(q); want.append(v)
+    assert m.lib.verify_state_batch(proofs, pubs).tolist() == want
+    env = {"MINA_VERIFY_CHUNK": None, "MINA_VERIFY_SINGLE_MAX": None, "MINA_VERIFY_MIN_SHARD": None, "MINA_VERIFY_DEVICES": None}
+    keep = {k: os.environ.get(k) for k in env}
+    try:
+        os.environ["MINA_VERIFY_SINGLE_MAX"] = "1"
+        for chunk in ("5", "2"):
+            os.environ["MINA_VERIFY_CHUNK"] = chunk
+            assert m.lib.verify_state_batch(proofs, pubs).tolist() == want, f"chunks of {chunk}"
+        # three logical devices on GPU 0
+        m.lib.verify_shutdown()
+        os.environ["MINA_VERIFY_DEVICES"] = "0,0,0"; os.environ["MINA_VERIFY_MIN_SHARD"] = "1"; os.environ["MINA_VERIFY_CHUNK"] = "4"
+        assert m.lib.verify_device_count() == 3
+        alld = m.lib.verify_all_devices()
+        install_index(alld, world["circ"].index); install_step_index(alld, world["step"])
+        assert m.lib.verify_state_batch(proofs, pubs).tolist() == want, "3 shards"
+        assert m.lib.verify_state_batch(proofs[:2], pubs[:2]).tolist() == want[:2]
+        assert m.lib.verify_state(*good[0]) is True and m.lib.verify_state(*bad_open) is False      # single calls are dealt round-robin over the devices
+        assert m.lib.verify_state(*good[1]) is True and m.lib.verify_state(*good[2]) is True
+    finally:
+        for k, v in keep.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
+        m.lib.verify_shutdown()
+        gctx = m.lib.verify_global_ctx()
+        install_index(gctx, world["circ"].index); install_step_index(gctx, world["step"])
+        world["gctx"] = gctx

@@ -4,6 +4,7 @@
 import json, os, random, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")      # before HIP initialises: the pipeline's lanes need a hardware queue each
 import torch; torch.cuda.is_available()
 import mina_bridge_amd as m
 from ipa_helpers import poseidon_pp
@@ -25,10 +26,11 @@ for it in items:
                 ft_eval1=p["ft_eval1"], lr=p["opening"]["lr"], z1=p["opening"]["z1"], z2=p["opening"]["z2"], delta=p["opening"]["delta"], sg=p["opening"]["sg"])
     proofs.append(state_proof_bytes(wrap, states)); pubs.append(state_pub_bytes(True, hashes[16], hashes[:16], [S.snarked_ledger_hash(s) for s in states[:16]]))
 print(json.dumps({"proof_bytes": len(proofs[0]), "pub_bytes": len(pubs[0])}))
-for n in (1, 64, 1024, 4096):
+sizes = [int(x) for x in sys.argv[1:]] or [1, 64, 1024, 4096, 8192]
+for n in sizes:
     P = [proofs[i % 4] for i in range(n)]; Q = [pubs[i % 4] for i in range(n)]
     assert m.lib.verify_state_batch(P, Q).all()
-    t = time.perf_counter(); reps = 3
+    t = time.perf_counter(); reps = 5
     for _ in range(reps):
         m.lib.verify_state_batch(P, Q)
     dt = (time.perf_counter() - t) / reps

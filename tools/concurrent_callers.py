@@ -13,6 +13,7 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.setrecursionlimit(10000)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")      # before HIP initialises: the pipeline's lanes need a hardware queue each
 import torch; torch.cuda.is_available()
 import mina_bridge_amd as m
 from ipa_helpers import poseidon_pp

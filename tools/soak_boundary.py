@@ -44,7 +44,8 @@ for it in items:
 def tampered(kind, c):
     w = copy.deepcopy(c["wrap"]); pub = c["pub"]
     if kind == "pub": b = bytearray(pub); b[1 + rng.randrange(17 * 32)] ^= 1 << rng.randrange(8); return c["proof"], bytes(b)
-    if kind == "z1": w["z1"] = (w["z1"] + 1 + rng.randrange(5)) % (1 << 254)
+    if kind == "flag2": w["feature_flags"][2] = not w["feature_flags"][2]      # foreign_field_add: the one flag the boundary lets through to the statement
+    elif kind == "z1": w["z1"] = (w["z1"] + 1 + rng.randrange(5)) % (1 << 254)
     elif kind == "bp": w["bulletproof_challenges"][rng.randrange(16)] ^= 1 << rng.randrange(128)
     elif kind == "flag": i = rng.randrange(len(w["feature_flags"])); w["feature_flags"][i] = not w["feature_flags"][i]
     elif kind == "offcurve": x, y = w["w_comm"][rng.randrange(15)]; w["w_comm"][0] = (x, (y + 1) % S.P if hasattr(S, "P") else y + 1)
@@ -52,12 +53,24 @@ def tampered(kind, c):
     return state_proof_bytes(w, c["states"]), pub
 
 pool = [(c["proof"], c["pub"], True) for c in cases]
-kinds = ["pub", "z1", "bp", "flag", "offcurve", "trunc"]
+kinds = ["pub", "z1", "bp", "flag", "flag2", "offcurve", "trunc"]
+Q_MOD = 0x40000000000000000000000000000000224698FC0994A8DD8C46EB2100000001
+
+
+def cancelling_pair():
+    """two INVALID proofs whose opening errors cancel in a fold with rho_1 / rho_0 = `guess` (z2 is not bound by the transcript and rides on the
+    batch-shared point h): z2_a += guess * t, z2_b -= t.  The round-2 build folded with rand_base = 7 and accepted the pair for guess = 7."""
+    i, j = rng.sample(range(4), 2)
+    guess = rng.choice([7, 9, 49, 1, 2]) if rng.randrange(3) == 0 else rng.randrange(1, Q_MOD)
+    t = rng.randrange(1, Q_MOD)
+    a = copy.deepcopy(cases[i]["wrap"]); b = copy.deepcopy(cases[j]["wrap"])
+    a["z2"] = (a["z2"] + guess * t) % Q_MOD; b["z2"] = (b["z2"] - t) % Q_MOD
+    return (state_proof_bytes(a, cases[i]["states"]), cases[i]["pub"], False), (state_proof_bytes(b, cases[j]["states"]), cases[j]["pub"], False)
 bad_pool = {k: [tampered(k, cases[i % 4]) + (False,) for i in range(6)] for k in kinds}
 for k in kinds:                                             # every tampering must be rejected on its own, through the lone-call path
     for p, q, _ in bad_pool[k][:2]:
         assert m.lib.verify_state(p, q) is False, ("tampering not rejected", k)
-counts = {"batches": 0, "proofs": 0, "bad": 0, "thread_bursts": 0}
+counts = {"batches": 0, "proofs": 0, "bad": 0, "thread_bursts": 0, "cancelling_pairs": 0}
 t_end = time.time() + budget; rnd = 0
 while time.time() < t_end:
     rnd += 1
@@ -66,6 +79,11 @@ while time.time() < t_end:
     batch = [pool[rng.randrange(4)] for _ in range(n)]
     for pos in rng.sample(range(n), min(nbad, n)):
         batch[pos] = rng.choice(bad_pool[rng.choice(kinds)])
+    if n >= 2 and rng.randrange(3) == 0:                    # a cancelling pair, adjacent or apart, in either order
+        pa, pb = cancelling_pair()
+        i, j = rng.sample(range(n), 2)
+        batch[i], batch[j] = pa, pb
+        counts["cancelling_pairs"] += 1
     want = [int(b[2]) for b in batch]
     if rnd % 4 == 0 and n <= 40:
         got = [None] * n
