@@ -21,11 +21,15 @@ template <int F> __device__ __forceinline__ fe_t ld_fe(const uint32_t *p) { fe_t
 
 // `MinaHash(ProtocolState)`: body = H_{"MinaProtoStateBody"}(fields[1 .. 1+nf)); hash = H_{"MinaProtoState"}(fields[0], body).
 // One lane group (8 lanes, or a wave-packed triple for chip-filling batches) per state; record = MINA_PSTATE_SLOTS field elements, canonical words.
-template <int F, int LANES>
+// ROOM: the kernel claims 128 VGPRs (4 waves per SIMD instead of 5), so that ONE wave slot per SIMD stays free while this chip-filling
+// kernel runs: the legs of a job forked onto other streams (the latency-bound Fiat-Shamir chain of the wrap proof: a few hundred waves per
+// kernel) then start at once instead of queueing behind waves that live for most of this kernel's 20 ms.
+template <int F, int LANES, bool ROOM = false>
 __global__ void __launch_bounds__(256)
 pstate_hash_kernel(uint32_t n, FieldK fk, const PoseidonParams *__restrict__ pp, const fe_t *__restrict__ salts /* [0..3) body, [3..6) state */,
                    const uint32_t *__restrict__ records, const uint32_t *__restrict__ nfields, uint32_t *__restrict__ out_hash /* n*8 */,
                    uint32_t *__restrict__ out_body /* n*8 or null */) {
+    if (ROOM) asm volatile("" ::: "v127");
     bool writer;
     const uint32_t sp = coop_sponge_index<LANES>(writer), e = coop_elem<LANES>();
     const bool live = sp < n;
@@ -184,6 +188,8 @@ static int pstate_hash_dev(mina_ctx *c, size_t n, const uint32_t *d_records, con
         mb::pstate_hash_kernel<FIELD_FP, 16><<<cdiv(n * 16, 256), 256, 0, c->L->stream>>>((uint32_t)n, c->fk[FIELD_FP], pp, salts, d_records, d_nfields, d_hashes, d_bodies);
     else if (use_coop8(c, n))
         mb::pstate_hash_kernel<FIELD_FP, 8><<<cdiv(n * 8, 256), 256, 0, c->L->stream>>>((uint32_t)n, c->fk[FIELD_FP], pp, salts, d_records, d_nfields, d_hashes, d_bodies);
+    else if (c->legs_forked)
+        mb::pstate_hash_kernel<FIELD_FP, 3, true><<<cdiv(coop_threads<3>(n), 256), 256, 0, c->L->stream>>>((uint32_t)n, c->fk[FIELD_FP], pp, salts, d_records, d_nfields, d_hashes, d_bodies);
     else
         mb::pstate_hash_kernel<FIELD_FP, 3><<<cdiv(coop_threads<3>(n), 256), 256, 0, c->L->stream>>>((uint32_t)n, c->fk[FIELD_FP], pp, salts, d_records, d_nfields, d_hashes, d_bodies);
     HIPC(hipGetLastError());
@@ -319,11 +325,13 @@ int mb_state_jobs_on_lane(mina_ctx *c, const mina_state_jobs *j, uint32_t *d_ver
     Lane *LI = L0, *LA = L0;
     if (LI_ && LA_ && LI_ != L0 && LA_ != L0 && LI_ != LA_) {
         LI = LI_; LA = LA_;
+        c->legs_forked = true;
         int frc;
         if ((frc = leg_fork(c, *L0, *LI)) || (frc = leg_fork(c, *L0, *LA))) return frc;
     }
     const size_t B = j->batch;
     int rc;
+    struct Unfork { mina_ctx *c; ~Unfork() { c->legs_forked = false; } } unfork{c};
     if ((rc = L.st_ok.ensure(B * 4))) return rc;
     if (j->with_states) {
         const size_t ns = B * MINA_STATES_PER_PROOF;
@@ -340,6 +348,22 @@ int mb_state_jobs_on_lane(mina_ctx *c, const mina_state_jobs *j, uint32_t *d_ver
     const uint32_t *comm_override = nullptr;
     uint32_t *ipa_v = nullptr, *acc_v = nullptr;
     uint32_t *kimchi_bad = nullptr; const uint32_t *stmt_ok = nullptr;
+    // ---- accumulator leg.  It shares scratch buffers with the opening check (ipa_chals / ipa_sigma / ipa_points of its lane), and the
+    // culprit search re-checks slices of a failed batch from the rows the opening check LEFT in those buffers (mb_ipa_recheck_rows): on the
+    // wrap leg's own lane the accumulator therefore runs FIRST (run after it, as it did until round 3, it overwrote the rows: every
+    // part of a search then failed and a batch of more than 1024 proofs with one bad opening was rejected whole).
+    auto accumulator_leg = [&]() -> int {
+        c->L = LA;
+        if (j->with_accumulator) {
+            int r;
+            if ((r = LA->st_flags.ensure(16 * 4))) return r;
+            acc_v = LA->st_flags.as<uint32_t>() + 8;
+            if ((r = mb_accumulator_check_dev(c, CURVE_VESTA, j->acc_k, B, (const uint32_t *)j->acc_prechallenges, (const uint32_t *)j->acc_sg,
+                                              B > 1 ? (const uint32_t *)j->acc_rho : nullptr, acc_v))) return r;
+        }
+        return MINA_OK;
+    };
+    if (LA == LI && (rc = accumulator_leg())) { c->L = L0; return rc; }
     c->L = LI;                                                  // ---- wrap-proof leg
     {
     Lane &L = *LI;
@@ -403,13 +427,7 @@ int mb_state_jobs_on_lane(mina_ctx *c, const mina_state_jobs *j, uint32_t *d_ver
         }
     }
     }
-    c->L = LA;                                                  // ---- accumulator leg
-    if (j->with_accumulator) {
-        if ((rc = LA->st_flags.ensure(16 * 4))) { c->L = L0; return rc; }
-        acc_v = LA->st_flags.as<uint32_t>() + 8;
-        if ((rc = mb_accumulator_check_dev(c, CURVE_VESTA, j->acc_k, B, (const uint32_t *)j->acc_prechallenges, (const uint32_t *)j->acc_sg,
-                                           B > 1 ? (const uint32_t *)j->acc_rho : nullptr, acc_v))) { c->L = L0; return rc; }
-    }
+    if (LA != LI && (rc = accumulator_leg())) { c->L = L0; return rc; }
     c->L = L0;
     if (LI != L0) { int jrc; if ((jrc = leg_join(*LI, *L0)) || (jrc = leg_join(*LA, *L0))) return jrc; }
     mb::state_job_verdict_kernel<<<cdiv(B, 64), 64, 0, L.stream>>>((uint32_t)B, L.st_ok.as<uint32_t>(), ipa_v, acc_v, kimchi_bad, stmt_ok, d_verdicts, d_flags, d_stmt_out);
