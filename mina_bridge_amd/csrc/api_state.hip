@@ -21,15 +21,11 @@ template <int F> __device__ __forceinline__ fe_t ld_fe(const uint32_t *p) { fe_t
 
 // `MinaHash(ProtocolState)`: body = H_{"MinaProtoStateBody"}(fields[1 .. 1+nf)); hash = H_{"MinaProtoState"}(fields[0], body).
 // One lane group (8 lanes, or a wave-packed triple for chip-filling batches) per state; record = MINA_PSTATE_SLOTS field elements, canonical words.
-// ROOM: the kernel claims 128 VGPRs (4 waves per SIMD instead of 5), so that ONE wave slot per SIMD stays free while this chip-filling
-// kernel runs: the legs of a job forked onto other streams (the latency-bound Fiat-Shamir chain of the wrap proof: a few hundred waves per
-// kernel) then start at once instead of queueing behind waves that live for most of this kernel's 20 ms.
-template <int F, int LANES, bool ROOM = false>
+template <int F, int LANES>
 __global__ void __launch_bounds__(256)
 pstate_hash_kernel(uint32_t n, FieldK fk, const PoseidonParams *__restrict__ pp, const fe_t *__restrict__ salts /* [0..3) body, [3..6) state */,
                    const uint32_t *__restrict__ records, const uint32_t *__restrict__ nfields, uint32_t *__restrict__ out_hash /* n*8 */,
                    uint32_t *__restrict__ out_body /* n*8 or null */) {
-    if (ROOM) asm volatile("" ::: "v127");
     bool writer;
     const uint32_t sp = coop_sponge_index<LANES>(writer), e = coop_elem<LANES>();
     const bool live = sp < n;
@@ -188,9 +184,17 @@ static int pstate_hash_dev(mina_ctx *c, size_t n, const uint32_t *d_records, con
         mb::pstate_hash_kernel<FIELD_FP, 16><<<cdiv(n * 16, 256), 256, 0, c->L->stream>>>((uint32_t)n, c->fk[FIELD_FP], pp, salts, d_records, d_nfields, d_hashes, d_bodies);
     else if (use_coop8(c, n))
         mb::pstate_hash_kernel<FIELD_FP, 8><<<cdiv(n * 8, 256), 256, 0, c->L->stream>>>((uint32_t)n, c->fk[FIELD_FP], pp, salts, d_records, d_nfields, d_hashes, d_bodies);
-    else if (c->legs_forked)
-        mb::pstate_hash_kernel<FIELD_FP, 3, true><<<cdiv(coop_threads<3>(n), 256), 256, 0, c->L->stream>>>((uint32_t)n, c->fk[FIELD_FP], pp, salts, d_records, d_nfields, d_hashes, d_bodies);
-    else
+    else if (c->hash_piece_waves && (n + 20) / 21 > c->hash_piece_waves) {
+        // The whole launch would hold every wave slot its 88 VGPRs allow (5 per SIMD) for most of its 20 ms, and the kernels of the other legs /
+        // chunks of a call (a few hundred waves each, one behind the other) would wait for slots.  In pieces of `hash_piece_waves` waves
+        // (~2 per SIMD: the multiplier is still saturated) the rest of the register file stays free for them.
+        const size_t per = (size_t)c->hash_piece_waves * 21;
+        for (size_t lo = 0; lo < n; lo += per) {
+            const size_t cnt = std::min(per, n - lo);
+            mb::pstate_hash_kernel<FIELD_FP, 3><<<cdiv(coop_threads<3>(cnt), 256), 256, 0, c->L->stream>>>((uint32_t)cnt, c->fk[FIELD_FP], pp, salts, d_records + lo * MINA_PSTATE_SLOTS * 8,
+                                                                                                             d_nfields + lo, d_hashes + lo * 8, d_bodies ? d_bodies + lo * 8 : nullptr);
+        }
+    } else
         mb::pstate_hash_kernel<FIELD_FP, 3><<<cdiv(coop_threads<3>(n), 256), 256, 0, c->L->stream>>>((uint32_t)n, c->fk[FIELD_FP], pp, salts, d_records, d_nfields, d_hashes, d_bodies);
     HIPC(hipGetLastError());
     return MINA_OK;

@@ -424,8 +424,12 @@ int run_device(Device &D, const CallIn &in, const std::vector<size_t> &idx, uint
         if (!found) return MINA_OK;                                                          // nothing parses
     }
     // read per call (tests force tiny chunks / shards to drive the pipeline's slot recycling with a handful of proofs)
-    const size_t chunk_target = getenv("MINA_VERIFY_CHUNK") ? (size_t)std::max(1L, atol(getenv("MINA_VERIFY_CHUNK"))) : (size_t)1024;
-    const size_t single_max = getenv("MINA_VERIFY_SINGLE_MAX") ? (size_t)std::max(1L, atol(getenv("MINA_VERIFY_SINGLE_MAX"))) : (size_t)1536;
+    // Measured on one MI355X, 8192 full-size proofs per call (tools/boundary_sweep.sh): ONE chunk 64 - 69 ms, 2 x 4096: 74 ms, 8 x 1024: 87 ms,
+    // 16 x 512: 92 ms -- a job is a ~30 ms dependent chain of small kernels whatever its size, and jobs that start together do not fill each
+    // other's gaps the way the staggered steps of a long-running pipeline do.  So: one chunk up to 8192 proofs, chunks of 4096 beyond (their
+    // parsing and upload then overlap the previous chunk's job, and one bad proof costs a culprit search over 4096, not over everything).
+    const size_t chunk_target = getenv("MINA_VERIFY_CHUNK") ? (size_t)std::max(1L, atol(getenv("MINA_VERIFY_CHUNK"))) : (size_t)4096;
+    const size_t single_max = getenv("MINA_VERIFY_SINGLE_MAX") ? (size_t)std::max(1L, atol(getenv("MINA_VERIFY_SINGLE_MAX"))) : (size_t)8192;
     const size_t nchunks = m <= single_max ? 1 : (m + chunk_target - 1) / chunk_target;
     std::vector<Chunk> chunks(nchunks);
     for (size_t q = 0; q < nchunks; ++q) { chunks[q].lo = m * q / nchunks; chunks[q].n = m * (q + 1) / nchunks - chunks[q].lo; chunks[q].hb.resize(chunks[q].n); }
@@ -494,6 +498,7 @@ int run_device(Device &D, const CallIn &in, const std::vector<size_t> &idx, uint
         if (!L.stream) HIPC(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
         // the lane forms of the sponge kernels follow the work in flight on the device (ctx.h use_coop*)
         c->nlanes = (int)std::max(1u, std::min<unsigned>(D.inflight.load(), NSLOT));
+        c->hash_piece_waves = getenv("MINA_VERIFY_HASH_PIECE") ? (uint32_t)atoi(getenv("MINA_VERIFY_HASH_PIECE")) : 1024u;
         c->L = &L;
         uint8_t *dbase = S.dev.as<uint8_t>();
         if (g_timing) { for (auto &e : S.tev) if (!e) HIPC(hipEventCreate(&e)); HIPC(hipEventRecord(S.tev[0], L.stream)); }
@@ -506,6 +511,7 @@ int run_device(Device &D, const CallIn &in, const std::vector<size_t> &idx, uint
         Lane *LI = nullptr, *LA = nullptr;
         if (D.inflight.load() <= split_max && ch.slot_ix < 8) { LI = &c->lanes[16 + 2 * ch.slot_ix]; LA = &c->lanes[17 + 2 * ch.slot_ix]; }
         rc = mb_state_jobs_on_lane(c, &js.j, dv, df, LI, LA, ds);
+        c->hash_piece_waves = 0;
         c->use_lane0();
         if (rc) return rc;
         if (g_timing) HIPC(hipEventRecord(S.tev[2], L.stream));
