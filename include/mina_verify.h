@@ -422,7 +422,7 @@ struct mina_pickles_statements;
 #define MINA_TOK_MUL 11
 #define MINA_TOK_SUB 12
 #define MINA_TOK_VANISHES_ON_ZK_ROWS 13   /* VanishesOnZeroKnowledgeAndPreviousRows */
-#define MINA_TOK_UNNORMALIZED_LAGRANGE 14 /* + i32 row offset (negative: counted back from the first zero-knowledge row) */
+#define MINA_TOK_UNNORMALIZED_LAGRANGE 14 /* + i32 row offset (negative: counted back from the first zero-knowledge row; INT32_MIN: that row itself) */
 #define MINA_TOK_STORE 15
 #define MINA_TOK_LOAD 16                  /* + u16 cache slot */
 typedef struct {
@@ -438,6 +438,22 @@ typedef struct {
 } mina_verifier_index;
 int mina_verifier_index_install(mina_ctx *ctx, const mina_verifier_index *index);
 int mina_verifier_index_digest(mina_ctx *ctx, uint8_t *out32);   /* `VerifierIndex::digest` (base-field element) */
+/* File-drop forms [UPSTREAM-RECALL for every key / enum spelling; pinned by round trips against independent writers, tests/test_loaders.py]:
+ * `serde_json` of kimchi's `Vec<PolishToken>` (externally tagged: "Alpha", {"Mds": {"row": r, "col": c}}, {"Literal": "<hex>"},
+ * {"Cell": {"col": {"Witness": i} | "Z" | {"Index": "<gate>"} | {"Coefficient": i} | {"Permutation": i}, "row": "Curr" | "Next"}}, "Dup",
+ * {"Pow": n}, "Add", "Mul", "Sub", "VanishesOnZeroKnowledgeAndPreviousRows", {"UnnormalizedLagrangeBasis": {"zk_rows": b, "offset": i}},
+ * "Store", {"Load": i}, {"SkipIf" | "SkipIfNot": [<feature>, n]}; also {"Challenge": ..} / {"Constant": ..}) -> the byte-code above.
+ * SkipIf / SkipIfNot are resolved against `enabled_features` (bit i = optional gate i of range_check0, range_check1, foreign_field_add,
+ * foreign_field_mul, xor, rot; 6 = lookup tables; 7 = runtime tables; 8.. = lookup patterns); `optional_present`: bit i = the proofs carry
+ * optional evaluation i (wire order), which fixes the column numbers 43.. .  `out` may be NULL to query the length.  Host-side. */
+int mina_polish_tokens_from_json(int field, const char *json, size_t len, uint32_t enabled_features, uint32_t optional_present, uint8_t *out,
+                                 size_t cap, size_t *out_len);
+/* `serde_json` of kimchi `VerifierIndex<Pallas>` (domain, zk_rows, shift, sigma_comm, coefficients_comm, generic_comm, psm_comm,
+ * complete_add_comm, mul_comm, emul_comm, endomul_scalar_comm; o1-utils SerdeAs hex; 33-byte compressed points) + the constant term of its
+ * linearization (`serde_json::to_string(&index.linearization.constant_term)` -- the index itself skips it) -> mina_verifier_index_install.
+ * An index that enables optional gates or lookups is refused. */
+int mina_verifier_index_load_json(mina_ctx *ctx, const char *index_json, size_t index_len, const char *constant_term_json, size_t ct_len,
+                                  uint32_t perm_alpha_offset /* 21 for kimchi's gate set */);
 typedef struct mina_kimchi_proofs {
     size_t batch;
     uint32_t n_prev, npub;             /* recursion challenges per proof (wrap: 2), public inputs per proof */
@@ -480,6 +496,10 @@ typedef struct {
     size_t constant_term_len;
 } mina_step_index;
 int mina_step_index_install(mina_ctx *ctx, const mina_step_index *index);
+/* the step side from files: one `VerifierIndex<Vesta>` JSON per step domain in use (domain, zk_rows and shift are read) + the step
+ * linearization's constant term -> mina_step_index_install */
+int mina_step_index_load_json(mina_ctx *ctx, size_t n_indexes, const char *const *index_jsons, const size_t *index_lens, const char *constant_term_json,
+                              size_t ct_len, uint32_t enabled_features, uint32_t optional_present);
 /* The statements of `batch` wrap proofs, structure-of-arrays (what `compute_deferred_values` and the two message digests read).
  * 128-bit challenges are 16 little-endian bytes; field elements 32.  Every proof of one call has the same n_old / n_evals. */
 typedef struct mina_pickles_statements {

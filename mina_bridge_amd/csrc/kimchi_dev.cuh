@@ -97,7 +97,7 @@ __device__ fe_t ft_eval0_dev(const FtEnv &e, const FieldK &fk, const fe_t &pub0,
                 case MINA_TOK_VANISHES_ON_ZK_ROWS: st.put(sp++, zkpm); break;
                 case MINA_TOK_UNNORMALIZED_LAGRANGE: {
                     const int32_t off = (int32_t)tk.a;
-                    const uint64_t row = off >= 0 ? (uint64_t)off : ((uint64_t)1 << e.k) - e.zk_rows - (uint64_t)(-off);
+                    const uint64_t row = off >= 0 ? (uint64_t)off : ((uint64_t)1 << e.k) - e.zk_rows - (off == INT32_MIN ? 0 : (uint64_t)(-(int64_t)off));   // INT32_MIN: the first zero-knowledge row itself
                     const fe_t wr = fe_pow_u64<F>(e.omega, row, fk.one);
                     st.put(sp++, fe_mul<F>(zm1, fe_inv<F>(fe_sub<F>(e.zeta, wr), fk))); break; }
                 case MINA_TOK_STORE: st.put(KC_STACK + nc++, st.get(sp - 1)); break;

@@ -67,7 +67,7 @@ template <int F> static inline bool polish_eval_host(const std::vector<KimchiTok
             case MINA_TOK_VANISHES_ON_ZK_ROWS: stack[sp++] = env.zkpm; break;
             case MINA_TOK_UNNORMALIZED_LAGRANGE: {
                 const int32_t off = (int32_t)tk.a;
-                const uint64_t row = off >= 0 ? (uint64_t)off : ((uint64_t)1 << env.log2_domain) - env.zk_rows - (uint64_t)(-off);
+                const uint64_t row = off >= 0 ? (uint64_t)off : ((uint64_t)1 << env.log2_domain) - env.zk_rows - (off == INT32_MIN ? 0 : (uint64_t)(-(int64_t)off));   // INT32_MIN: the first zero-knowledge row itself
                 stack[sp++] = fe_mul<F>(fe_sub<F>(env.zeta1, k.one), fe_inv<F>(fe_sub<F>(env.zeta, host_pow_u64<F>(env.omega, row, k.one)), k)); break; }
             case MINA_TOK_STORE: cache[nc++] = stack[sp - 1]; break;
             case MINA_TOK_LOAD: stack[sp++] = cache[tk.a]; break;

@@ -37,7 +37,7 @@ EXPORTS = [
     "mina_protocol_state_pack", "mina_protocol_state_hash_batch", "mina_protocol_state_hash_bytes",
     "mina_state_jobs_prepare", "mina_state_job_batch_dev", "mina_state_job_batch",
     "mina_challenge_to_field_dev", "mina_field_sum_rows_dev", "mina_msm_srs_range_dev", "mina_msm_dev", "mina_points_sum_dev", "mina_point_records_equal_dev",
-    "mina_step_index_install", "mina_pickles_public_input",
+    "mina_step_index_install", "mina_step_index_load_json", "mina_polish_tokens_from_json", "mina_verifier_index_load_json", "mina_pickles_public_input",
     "mina_verifier_index_install", "mina_verifier_index_digest", "mina_kimchi_to_batch", "mina_pickles_public_inputs_batch", "mina_wrap_proof_flatten", "mina_state_proof_split",
     "mina_verify_state", "mina_verify_state_batch", "mina_verify_state_checks", "mina_verify_state_files", "mina_verify_account", "mina_verify_account_batch",
     "mina_verify_account_files", "mina_verify_account_checks", "mina_verify_account_ctx", "mina_account_hash_batch", "mina_account_abi_encode", "mina_verify_configure", "mina_verify_shutdown", "mina_verify_global_ctx", "mina_poseidon_params_name",
@@ -339,6 +339,20 @@ def poseidon_params_parse(field: int, text: str) -> np.ndarray:
     if rc != 0:
         raise MinaError(f"mina_poseidon_params_parse failed ({rc}): {lib.mina_last_error().decode()}")
     return out
+
+
+def polish_tokens_from_json(field: int, text: str, enabled_features: int = 0, optional_present: int = 0) -> bytes:
+    """serde_json of kimchi's Vec<PolishToken> -> the library's byte-code; host-side"""
+    lib = load_library()
+    t = text.encode(); n = ctypes.c_size_t(0)
+    rc = lib.mina_polish_tokens_from_json(int(field), ctypes.c_char_p(t), ctypes.c_size_t(len(t)), ctypes.c_uint32(enabled_features), ctypes.c_uint32(optional_present), None, ctypes.c_size_t(0), ctypes.byref(n))
+    if rc != 0:
+        raise MinaError(f"mina_polish_tokens_from_json failed ({rc}): {lib.mina_last_error().decode()}")
+    out = np.zeros(max(n.value, 1), np.uint8)
+    rc = lib.mina_polish_tokens_from_json(int(field), ctypes.c_char_p(t), ctypes.c_size_t(len(t)), ctypes.c_uint32(enabled_features), ctypes.c_uint32(optional_present), _p(out), ctypes.c_size_t(out.size), ctypes.byref(n))
+    if rc != 0:
+        raise MinaError(f"mina_polish_tokens_from_json failed ({rc}): {lib.mina_last_error().decode()}")
+    return out[: n.value].tobytes()
 
 
 def verify_configure(flags: int):
@@ -986,6 +1000,21 @@ class MinaContext:
     def step_index_install(self, *a):
         si, keep = self._step_index_struct(*a)
         self._ck(self._lib.mina_step_index_install(self._h, ctypes.byref(si)), "mina_step_index_install")
+
+    def verifier_index_load_json(self, index_json: str, constant_term_json: str, perm_alpha_offset: int = 21):
+        a, b = index_json.encode(), constant_term_json.encode()
+        self._ck(self._lib.mina_verifier_index_load_json(self._h, ctypes.c_char_p(a), ctypes.c_size_t(len(a)), ctypes.c_char_p(b), ctypes.c_size_t(len(b)), ctypes.c_uint32(perm_alpha_offset)),
+                 "mina_verifier_index_load_json")
+
+    def step_index_load_json(self, index_jsons: list, constant_term_json: str, enabled_features: int = 0, optional_present: int = 0):
+        enc = [j.encode() for j in index_jsons]; ct = constant_term_json.encode()
+        arr = (ctypes.c_char_p * len(enc))(*enc); lens = (ctypes.c_size_t * len(enc))(*map(len, enc))
+        self._ck(self._lib.mina_step_index_load_json(self._h, ctypes.c_size_t(len(enc)), arr, lens, ctypes.c_char_p(ct), ctypes.c_size_t(len(ct)), ctypes.c_uint32(enabled_features),
+                                                     ctypes.c_uint32(optional_present)), "mina_step_index_load_json")
+
+    def poseidon_load_params(self, field: int, text: str):
+        t = text.encode()
+        self._ck(self._lib.mina_poseidon_load_params(self._h, int(field), ctypes.c_char_p(t), ctypes.c_size_t(len(t))), "mina_poseidon_load_params")
 
     def pickles_public_input(self, wrap_proof: bytes, encoding: int, app_state):
         b = _u8(wrap_proof); a = _u8(app_state)

@@ -98,7 +98,7 @@ def polish_evaluate(tokens, index: VerifierIndex, pt: int, evals, consts: dict, 
         elif op == T_VANISH_ZK: stack.append(zk_polynomial_eval(index, pt, r))
         elif op == T_LAGRANGE:                                 # unnormalized Lagrange basis of row `offset` (negative: counted from the zk rows)
             off = tok[1]
-            i = off if off >= 0 else n - index.zk_rows + off
+            i = off if off >= 0 else n - index.zk_rows + (0 if off == -(1 << 31) else off)     # -2^31: the first zero-knowledge row itself
             stack.append((pow(pt, n, r) - 1) * R.inv((pt - pow(w, i, r)) % r, r) % r)
         elif op == T_STORE: cache.append(stack[-1])
         elif op == T_LOAD: stack.append(cache[tok[1]])
