@@ -5,8 +5,8 @@ TAG=${1:-r01b}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace -o t -- python $GRAFT_REPO_ROOT/bench.py --no-probes --no-cpu-baseline > $OUT/bench_trace.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $OUT/fetch -o f -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 4 --pipeline 1 --no-probes --no-cpu-baseline > $OUT/bench_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d $OUT/write -o w -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 4 --pipeline 1 --no-probes --no-cpu-baseline > $OUT/bench_write.log 2>&1
+rocprofv3 --kernel-trace --stats -f csv -d $OUT/trace -o t -- python $GRAFT_REPO_ROOT/bench.py --no-probes --no-cpu-baseline --no-boundary > $OUT/bench_trace.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -f csv -d $OUT/fetch -o f -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 4 --pipeline 1 --no-probes --no-cpu-baseline --no-boundary > $OUT/bench_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -f csv -d $OUT/write -o w -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 4 --pipeline 1 --no-probes --no-cpu-baseline --no-boundary > $OUT/bench_write.log 2>&1
 find $OUT -name "*.csv" | head -20
 grep -h '"metric"' $OUT/bench_trace.log | cut -c1-200
