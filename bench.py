@@ -193,105 +193,41 @@ def cpu_model() -> str:
     return platform.processor() or "unknown"
 
 
-def _cpu_worker(path: str, budget_s: float):
-    """one worker PROCESS of the CPU leg: verifies the same proof over and over, single-threaded, for `budget_s` seconds"""
-    data = np.load(path, allow_pickle=True)
-    one = _cpu_composite(str(data["kind"]), data, threads=1)
-    ok = one()
-    t0 = time.perf_counter(); reps = 0
-    while True:
-        ok = one() and ok; reps += 1
-        el = time.perf_counter() - t0
-        if el >= budget_s:
-            break
-    return reps, el, bool(ok)
-
-
-def _cpu_composite(kind: str, data, threads: int):
-    """BASELINE config C1 on the CPU restatement (oracle/): one full Proof-of-State verification -- 17 state hashes (C Poseidon), [full mode: the
-    Pickles statement -> public inputs and kimchi oracles + to_batch, Python over the C kernels,] public-input commitment, the wrap opening check
-    (transcript + C b_poly / MSMs) and the 2^16 Vesta accumulator MSM (ark-style Pippenger).  Returns a closure that verifies once."""
-    from oracle import ipa_ref as I, oracle as O, pasta_ref as R, state_job_ref as J
-    from state_job_helpers import pp_fp
-    import mina_bridge_amd.poseidon_params as PP
-    srs = {0: (data["g0"], data["h0"]), 1: (data["g1"], data["h1"])}
-    recs, nf, hashes = data["recs"], data["nf"], data["hashes"]
-    params = PP.default_params_bytes(FIELD_FP)
-    pp = pp_fp()
-    from oracle import mina_state_ref as S
-    salts = [S.salt(S.PREFIX_PROTOCOL_STATE_BODY, pp), S.salt(S.PREFIX_PROTOCOL_STATE, pp)]
-
-    def state_hashes():
-        # 17 sponges advanced together, one C permutation call per absorbed block
-        fields = recs.reshape(STATES_PER_PROOF, PSTATE_SLOTS, 32)
-        n = int(nf.max())
-        state = [list(salts[0]) for _ in range(STATES_PER_PROOF)]
-        for blk in range(0, n, 2):
-            for s in range(STATES_PER_PROOF):
-                for t in range(2):
-                    if blk + t < nf[s]:
-                        state[s][t] = (state[s][t] + int.from_bytes(fields[s, 1 + blk + t].tobytes(), "little")) % R.P
-            perm = O.poseidon_permute(FIELD_FP, params, np.stack([O.ints_to_le(x).reshape(96) for x in state]))
-            state = [[int.from_bytes(perm[s, 32 * j: 32 * j + 32].tobytes(), "little") for j in range(3)] for s in range(STATES_PER_PROOF)]
-        body = [x[0] for x in state]
-        state = [[(salts[1][0] + int.from_bytes(fields[s, 0].tobytes(), "little")) % R.P, (salts[1][1] + body[s]) % R.P, salts[1][2]] for s in range(STATES_PER_PROOF)]
-        perm = O.poseidon_permute(FIELD_FP, params, np.stack([O.ints_to_le(x).reshape(96) for x in state]))
-        return perm[:, :32]
-
-    if kind == "full":
-        from ipa_helpers import poseidon_pp
-        from kimchi_helpers import load_k15_fixture, load_statement_fixture, make_step_index
-        from oracle import kimchi_ref as K, pickles_ref as PK
-        ix, _, _ = load_k15_fixture()
-        step, item = make_step_index(99), load_statement_fixture()[0][0]
-        g, h = srs[0]
-        hp = O.bytes_to_point(h)
-        pb, ps = poseidon_pp(0), poseidon_pp(1)
-        comms = list(ix.sigma_comm) + list(ix.coefficients_comm) + list(ix.selector_comm)
-
-        def one():
-            # the full path from the parsed proof: statement -> public inputs, kimchi oracles + to_batch, opening, accumulator
-            ok = bool((state_hashes() == hashes).all())
-            pubs_, _, _, _ = PK.statement_public_input(item["wrap"], step, comms, item["app"], pb, ps)
-            _, e = K.oracles_and_batch(ix, item["proof"], pubs_, pb, ps, g[: 1 << WRAP_K], hp)
-            ok = ok and I.ipa_verify_batch(0, g[: 1 << WRAP_K], hp, [e], 7, 9, threads=threads)
-            return ok and J.accumulator_ok(1, srs[1][0], ACC_K, item["acc_pre"], item["acc_sg"], threads=threads)
-        return one
-    raise ValueError("the CPU leg runs the full job (partial modes are profiled on the GPU only)")
-
-
 def cpu_baseline(baseline_sample, budget_s: float = 12.0):
-    """The same composite on the CPU restatement (oracle/, kind="port" -- the reference's Rust verifier cannot be built here): BASELINE config C1,
-    threaded ACROSS PROOFS as a CPU verifier farm would be: one single-threaded worker process per host core in use (up to 128), every worker
-    verifying whole proofs one after the other for `budget_s` seconds; value = proofs verified by all workers / wall time.  C field / MSM /
-    Poseidon kernels under a Python transcript driver.  This is the ONLY part of bench.py that touches oracle/ (and, for its inputs, the
-    test helpers that decode the fixtures)."""
-    import tempfile
-    from concurrent.futures import ProcessPoolExecutor
-    import multiprocessing as mp
-    from oracle import oracle as O
+    """BASELINE config C1 on the CPU restatement, NATIVE: oracle/composite_oracle.c (C, 4 x u64 Montgomery) verifies whole Proof-of-State jobs --
+    17 state hashes + linkage, Pickles statement -> 40 public inputs, public-input commitment over cached Lagrange commitments, kimchi oracles +
+    to_batch, the k = 15 wrap opening check (one 2^15 + ~100-point ark-style Pippenger MSM), the 2^16 Vesta accumulator MSM -- with pthreads
+    ACROSS PROOFS, one thread per core the cgroup really grants (`usable_cores`), every thread a proof at a time.  Same bytes as the GPU job (the
+    encoded fixture's four proofs); cross-checked value by value against the Python composite in tests/test_native_composite.py.  kind="port":
+    the reference's Rust verifier cannot be built here.  This is the ONLY part of bench.py that touches oracle/."""
+    from oracle import composite as C, oracle as O
+    import mina_bridge_amd.poseidon_params as PP
     kind, sample = baseline_sample
     if kind != "full":
         return {"skipped": "the CPU leg runs the full job only"}
     recs, nf, hashes = sample
     nproc = os.cpu_count() or 1
-    workers = min(usable_cores(), 128)                                      # one per core the cgroup quota / affinity really grants
-    srs = {c: O.srs_create(c, 1 << 16, threads=workers) for c in (0, 1)}
-    with tempfile.TemporaryDirectory() as td:
-        path = os.path.join(td, "cpu_leg.npz")
-        np.savez(path, kind="full", g0=srs[0][0], h0=srs[0][1], g1=srs[1][0], h1=srs[1][1], recs=recs, nf=nf, hashes=hashes)
-        t0 = time.perf_counter()
-        with ProcessPoolExecutor(max_workers=workers, mp_context=mp.get_context("spawn")) as ex:
-            res = list(ex.map(_cpu_worker, [path] * workers, [budget_s] * workers))
-        wall = time.perf_counter() - t0
-    total = sum(r[0] for r in res); ok = all(r[2] for r in res)
-    value = sum(r[0] / r[1] for r in res)                                   # workers run side by side: the farm's rate is the sum of theirs
-    return {"value": value, "unit": "proofs/s", "cores": workers, "kind": "port", "cpu_model": cpu_model(), "nproc": nproc, "usable_cores": usable_cores(),
-            "single_thread_value": value / workers, "wall_s": wall,
-            "sample": f"{total} full Proof-of-State verifications (BASELINE config C1 = the bench's own job: 17 state hashes + Pickles statement -> public inputs + "
-                      f"kimchi oracles/to_batch + public-input commitment + k=15 wrap opening check + 2^16 Vesta accumulator) by {workers} single-threaded worker "
-                      f"processes side by side, {budget_s:.0f} s each (plus start-up), on the repo's CPU restatement (C field/MSM/Poseidon kernels under a Python "
-                      f"driver; NOT the Rust reference, which cannot be built here); verdict ACCEPT: {ok}"}
+    threads = min(usable_cores(), 128)
+    fx, _ = load_encoded_fixture()
+    srs = {c: O.srs_create(c, 1 << 16, threads=threads) for c in (0, 1)}
+    t0 = time.perf_counter()
+    C.setup(srs[0], srs[1], PP.default_params_bytes(0), PP.default_params_bytes(1), fx["wrap_index"], fx["step_index"], threads=threads)
+    setup_s = time.perf_counter() - t0
+    proofs = [C.make_proof(fx["proofs"][i % len(fx["proofs"])], recs, nf, hashes) for i in range(threads)]
+    t0 = time.perf_counter(); v1 = C.verify_many(proofs[:1], 1); one_s = time.perf_counter() - t0          # one proof on one thread
+    rounds, t0 = 0, time.perf_counter()
+    ok = bool(v1.all())
+    while True:
+        ok = bool(C.verify_many(proofs, threads).all()) and ok; rounds += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s:
+            break
+    total = rounds * len(proofs)
+    return {"value": total / el, "unit": "proofs/s", "cores": threads, "kind": "port", "implementation": "native C restatement (oracle/composite_oracle.c), pthreads across proofs",
+            "cpu_model": cpu_model(), "nproc": nproc, "usable_cores": usable_cores(), "single_thread_value": 1.0 / one_s, "setup_s": setup_s,
+            "sample": f"{total} full Proof-of-State verifications (BASELINE config C1 = the bench's own job per proof: 17 state hashes + Pickles statement -> public inputs + "
+                      f"public-input commitment + kimchi oracles/to_batch + k=15 wrap opening check + 2^16 Vesta accumulator) in {el:.1f} s on {threads} threads, one proof per "
+                      f"thread at a time; native C restatement of the o1-labs / arkworks algorithms (NOT the Rust reference, which cannot be built here); verdict ACCEPT: {ok}"}
 
 
 def boundary_leg(m, local_rank: int, B: int, min_seconds: float = 2.0):
