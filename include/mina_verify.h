@@ -591,6 +591,9 @@ mina_ctx *mina_verify_global_ctx(void);          /* the first device's context, 
  * ordinals; an ordinal may repeat = several logical contexts on one GPU; default: $MINA_VERIFY_DEVICE or 0).  mina_verify_state_batch cuts
  * its proofs into contiguous shards, one per device, each with its own folding randomisers and its own culprit search; merged single-proof
  * jobs are dealt round-robin.  The installers below put the same data on EVERY device. */
+/* which network the installed indexes belong to: 0 = mainnet, 1 = devnet, -1 (default) = not declared.  Once declared, a proof whose public
+ * input claims the other network (`is_state_proof_from_devnet`, core/src/proof/state_proof.rs:10-25) fails the kimchi step. */
+int mina_verify_set_network(int devnet);
 int mina_verify_device_count(void);
 mina_ctx *mina_verify_device_ctx(int i);
 int mina_verify_install_verifier_index(const mina_verifier_index *index);

@@ -64,6 +64,7 @@ struct Device {
 std::mutex g_mu;                           // guards the device list, the flags and set-up
 std::vector<Device *> g_devs; bool g_init_failed = false;
 uint32_t g_flags = 0;
+int g_network = -1;                        // which network the installed indexes belong to: -1 = not declared, 0 = mainnet, 1 = devnet (mina_verify_set_network)
 std::atomic<unsigned> g_rr{0};
 
 int create_device(int ordinal, Device **out) {
@@ -103,6 +104,10 @@ void destroy_devices() {                    // caller holds g_mu
 }  // namespace
 
 extern "C" int mina_verify_configure(uint32_t flags) { std::lock_guard<std::mutex> lk(g_mu); g_flags = flags; return MINA_OK; }
+// `is_state_proof_from_devnet` of the public input (core/src/proof/state_proof.rs:10-25) selects, upstream, the devnet or the mainnet
+// verifier index.  This library holds ONE index pair: declare which network it belongs to and proofs that claim the other one are rejected
+// at the kimchi step (their own verdict only); -1 (the default) = not declared, the flag is not looked at.
+extern "C" int mina_verify_set_network(int devnet) { if (devnet < -1 || devnet > 1) return fail(MINA_ERR_ARG, "network must be -1, 0 or 1"); std::lock_guard<std::mutex> lk(g_mu); g_network = devnet; return MINA_OK; }
 extern "C" int mina_verify_shutdown(void) { std::lock_guard<std::mutex> lk(g_mu); destroy_devices(); return MINA_OK; }
 // the first device's context (a process with one GPU: THE context), e.g. to install a verifier index or other Poseidon tables; NULL if no
 // GPU / set-up failed.  Install before the first verification: installing is not synchronised against calls in flight.
@@ -183,7 +188,7 @@ CallMerger g_state_calls, g_account_calls;
 //   page-locked memory.  No per-call allocation, no gather copy.  A chunk whose folded check fails goes through the culprit search of
 //   mina_state_job_batch from the same staging.
 namespace {
-struct Shape { bool kimchi = false, statements = false; uint32_t k = 0, n_prev = 2, n_old = 0, n_ev = 0; };
+struct Shape { bool kimchi = false, statements = false; uint32_t k = 0, n_prev = 2, n_old = 0, n_ev = 0; int network = -1; };
 enum Sec : int { S_REC = 0, S_NF, S_EXP, S_PRE, S_APRE, S_ASG, S_ARHO, S_LR, S_DELTA, S_SG, S_Z1, S_Z2, S_PCM, S_WC, S_ZC, S_TC, S_EV, S_FT1, S_PCH,
                  S_PLONK, S_BP, S_OLD, S_CM, S_WOLD, S_WSG, S_DG, S_SEV, S_PI, S_SFT, S_APP, S_MISC, S_RB, S_SB, NSEC };
 struct Layout {
@@ -272,7 +277,7 @@ void parse_into(const Shape &sh, const Layout &lay, uint8_t *base, size_t b, con
         // proof of another evaluation / recursion shape is verified in a job of its own (`deferred`), a malformed one fails here
         const size_t n_old = w.step_old_bulletproof_challenges.size(), n_ev = w.prev_evals.size();
         if (w.lr.size() != sh.k || w.step_challenge_polynomial_commitments.size() != sh.n_prev || uses_lookups(w) || n_old > 4 || n_ev < 43 || n_ev > 62 ||
-            w.prev_public_input.zeta.empty() || w.prev_public_input.zeta_omega.empty()) hb.shape = 0;
+            w.prev_public_input.zeta.empty() || w.prev_public_input.zeta_omega.empty() || (sh.network >= 0 && (int)pi.is_state_proof_from_devnet != sh.network)) hb.shape = 0;
         else if (sh.statements && (n_old != sh.n_old || n_ev != sh.n_ev)) { hb.shape = 0; hb.deferred = 1; }
     }
     if (sh.kimchi && hb.shape) {
@@ -377,7 +382,7 @@ void copy_entry(const Layout &lay, uint8_t *base, size_t dst, size_t src) {
     for (int i = 0; i < NSEC; ++i) if (lay.stride[i] && i != S_PRE) memcpy(lay.at(base, i, dst), lay.at(base, i, src), lay.stride[i]);
 }
 
-struct Config { bool usable = false, kimchi = false, statements = false; uint32_t k = 0; };
+struct Config { bool usable = false, kimchi = false, statements = false; uint32_t k = 0; int network = -1; };
 Config read_config(Device &D, uint32_t flags) {
     std::lock_guard<std::mutex> lk(D.mu);
     mina_ctx *c = D.c; Config cf;
@@ -389,6 +394,7 @@ Config read_config(Device &D, uint32_t flags) {
     // (the proof would not be bound to the candidate tip) unless the caller explicitly accepts the unbound form
     cf.kimchi = mb_kimchi_available(c) && (cf.statements || (flags & MINA_VERIFY_ALLOW_UNBOUND_STATEMENT));
     cf.k = c->kimchi_log2;
+    { std::lock_guard<std::mutex> gl(g_mu); cf.network = g_network; }
     return cf;
 }
 
@@ -408,7 +414,7 @@ int run_device(Device &D, const CallIn &in, const std::vector<size_t> &idx, uint
     const Config cf = read_config(D, flags);
     if (!cf.usable) return MINA_OK;
     if (!cf.kimchi && !(flags & MINA_VERIFY_ALLOW_MISSING_KIMCHI)) return MINA_OK;          // the kimchi step cannot run: nothing can pass
-    Shape sh; sh.kimchi = cf.kimchi; sh.statements = cf.kimchi && cf.statements; sh.k = cf.k;
+    Shape sh; sh.kimchi = cf.kimchi; sh.statements = cf.kimchi && cf.statements; sh.k = cf.k; sh.network = cf.network;
     if (sh.statements) {           // evaluation / recursion shape of the job: the first proof that parses names it (Mina's blockchain proofs all share one)
         bool found = false;
         for (size_t i = 0; i < m && !found; ++i) {
@@ -487,9 +493,10 @@ int run_device(Device &D, const CallIn &in, const std::vector<size_t> &idx, uint
         std::lock_guard<std::mutex> lk(D.mu);
         HIPC(hipSetDevice(c->device));
         int rc;
-        if (D.prepared_npub != (sh.statements ? 40u : 0u)) {
+        const uint32_t prep_key = ((sh.k ? sh.k : 15u) << 16) | (sh.statements ? 40u : 0u);      // the Lagrange table belongs to (domain, npub): another index -> prepare again
+        if (D.prepared_npub != prep_key) {
             if ((rc = mina_state_jobs_prepare(c, sh.k ? sh.k : 15, sh.statements ? 40 : 0))) return rc;
-            D.prepared_npub = sh.statements ? 40u : 0u;
+            D.prepared_npub = prep_key;
         }
         Slot &S = *ch.slot;
         if ((rc = S.dev.ensure(lay.total + Layout::out_bytes(lay.cap)))) return rc;
@@ -595,7 +602,7 @@ int state_checks(const uint8_t *proof, size_t proof_len, const uint8_t *pub, siz
     Device *D; uint32_t flags;
     { std::lock_guard<std::mutex> lk(g_mu); auto &ds = devices(); if (ds.empty()) return MINA_ERR_HIP; D = ds[0]; flags = g_flags; }
     const Config cf = read_config(*D, flags | MINA_VERIFY_ALLOW_SURROGATE);
-    Shape sh; sh.kimchi = cf.kimchi; sh.statements = cf.kimchi && cf.statements; sh.k = cf.k;
+    Shape sh; sh.kimchi = cf.kimchi; sh.statements = cf.kimchi && cf.statements; sh.k = cf.k; sh.network = cf.network;
     uint32_t passed = 0, ran = MINA_CHECK_FORMAT;
     *passed_out = 0; *ran_out = ran;
     if (sh.statements) {

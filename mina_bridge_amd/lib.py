@@ -41,7 +41,7 @@ EXPORTS = [
     "mina_verifier_index_install", "mina_verifier_index_digest", "mina_kimchi_to_batch", "mina_pickles_public_inputs_batch", "mina_wrap_proof_flatten", "mina_state_proof_split",
     "mina_verify_state", "mina_verify_state_batch", "mina_verify_state_checks", "mina_verify_state_files", "mina_verify_account", "mina_verify_account_batch",
     "mina_verify_account_files", "mina_verify_account_checks", "mina_verify_account_ctx", "mina_account_hash_batch", "mina_account_abi_encode", "mina_verify_configure", "mina_verify_shutdown", "mina_verify_global_ctx", "mina_poseidon_params_name",
-    "mina_verify_device_count", "mina_verify_device_ctx", "mina_verify_install_verifier_index", "mina_verify_install_step_index", "mina_verify_set_poseidon_params",
+    "mina_verify_device_count", "mina_verify_device_ctx", "mina_verify_set_network", "mina_verify_install_verifier_index", "mina_verify_install_step_index", "mina_verify_set_poseidon_params",
     "mina_poseidon_install_default_params",
     "mina_consensus_select_secure_chain", "mina_parse_state_pub_inputs", "mina_parse_account_pub_inputs", "mina_parse_merkle_path", "mina_verify_account_inclusion",
 ]
@@ -357,6 +357,12 @@ def polish_tokens_from_json(field: int, text: str, enabled_features: int = 0, op
 
 def verify_configure(flags: int):
     load_library().mina_verify_configure(ctypes.c_uint32(flags))
+
+
+def verify_set_network(devnet: int):
+    rc = load_library().mina_verify_set_network(int(devnet))
+    if rc != 0:
+        raise MinaError(f"mina_verify_set_network failed ({rc})")
 
 
 def verify_shutdown():

@@ -243,3 +243,23 @@ def test_one_malformed_shape_does_not_fail_the_other_callers(big):
     assert ran & 32 and not passed & 32
     # all entries of a call unusable: nothing reaches the GPU, all false
     assert m.lib.verify_state_batch([short, b""], [cases[1]["pub"], cases[0]["pub"]]).tolist() == [0, 0]
+
+
+def test_network_flag_of_the_public_input_must_match_the_declared_network(big):
+    """upstream picks the devnet or the mainnet verifier index by `is_state_proof_from_devnet`; this library holds one index pair, so
+    once its network is declared a proof that claims the other one fails (its own verdict only, at the kimchi step)"""
+    m, cases = big["m"], big["cases"]
+    c = cases[0]
+    assert c["pub"][0] == 1                                        # the fixtures' public inputs say devnet
+    try:
+        m.lib.verify_set_network(1)
+        assert m.lib.verify_state(c["proof"], c["pub"]) is True
+        m.lib.verify_set_network(0)
+        assert m.lib.verify_state(c["proof"], c["pub"]) is False
+        passed, ran = m.lib.verify_state_checks(c["proof"], c["pub"])
+        assert ran & 32 and not passed & 32 and passed & (1 | 2 | 4 | 8 | 16) == (1 | 2 | 4 | 8 | 16)
+        main = bytes([0]) + c["pub"][1:]                           # the same proof claiming mainnet: accepted by the (synthetic) mainnet index
+        assert m.lib.verify_state_batch([c["proof"], c["proof"]], [main, c["pub"]]).tolist() == [1, 0]
+    finally:
+        m.lib.verify_set_network(-1)
+    assert m.lib.verify_state(c["proof"], c["pub"]) is True

@@ -37,7 +37,7 @@ def world(srs_oracle):
 from kimchi_helpers import STEP_DOMAINS, install_step_index, make_step_index  # noqa: E402
 
 
-def mint_state_proof(world, srs_oracle, seed):
+def mint_state_proof(world, srs_oracle, seed, optional_slots=()):
     from ipa_helpers import poseidon_pp
     from oracle import kimchi_ref as K, oracle as O, pasta_ref as R, state_job_ref as J, mina_state_ref as S
     from wire_writers import synth_wrap_proof
@@ -47,7 +47,7 @@ def mint_state_proof(world, srs_oracle, seed):
     # recursion challenges of the wrap proof: 128-bit prechallenges on the wire, endo-expanded by the verifier
     pres = [[rng.getrandbits(128) for _ in range(15)] for _ in range(2)]
     chals = [[R.challenge_to_field(p, R.endo_r(0), R.Q) for p in row[:K_LOG2]] for row in pres]
-    wrap["prev_optional"] = [None] * 19
+    wrap["prev_optional"] = [(([rng.randrange(R.P)], [rng.randrange(R.P)]) if i in optional_slots else None) for i in range(19)]
     wrap["old_bulletproof_challenges"] = pres
     prev_comms = []
     for ch in chals:                                            # the previous wrap accumulators: commitments of b_poly_coefficients(chals)
@@ -462,3 +462,32 @@ def test_boundary_pipeline_chunks_and_device_shards_give_the_same_verdicts(world
         gctx = m.lib.verify_global_ctx()
         install_index(gctx, world["circ"].index); install_step_index(gctx, world["step"])
         world["gctx"] = gctx
+
+
+def test_proofs_of_different_evaluation_shapes_in_one_call(world, srs_oracle):
+    """Step proofs may carry optional evaluations (43 + the ones present): a job has ONE shape, so well-formed proofs of another shape are
+    verified in a job of their own (the `deferred` pass of run_device) instead of failing -- three shapes interleaved in one call, a tampered
+    proof in two of them, and the same through merged single-proof calls."""
+    import threading
+    import mina_bridge_amd as m
+    a = [to_bytes(*mint_state_proof(world, srs_oracle, 5000 + i)) for i in range(2)]                                    # 43 evaluations
+    b = [to_bytes(*mint_state_proof(world, srs_oracle, 5100 + i, optional_slots=(2,))) for i in range(2)]                # 44
+    c = [to_bytes(*mint_state_proof(world, srs_oracle, 5200, optional_slots=(2, 9, 17)))]                                # 46
+    wb, sb, hb = mint_state_proof(world, srs_oracle, 5100, optional_slots=(2,))
+    wb = dict(wb); wb["z1"] = (wb["z1"] + 1) % (1 << 254)
+    bad_b = to_bytes(wb, sb, hb)
+    bad_pub = bytearray(a[1][1]); bad_pub[100] ^= 2
+    calls = [a[0], b[0], c[0], bad_b, a[1], b[1], (a[1][0], bytes(bad_pub)), c[0], a[0]]
+    want = [1, 1, 1, 0, 1, 1, 0, 1, 1]
+    assert m.lib.verify_state_batch([x[0] for x in calls], [x[1] for x in calls]).tolist() == want
+    # the first proof decides the first job's shape: any order gives the same verdicts
+    order = [2, 3, 0, 8, 6, 1, 5, 7, 4]
+    assert m.lib.verify_state_batch([calls[i][0] for i in order], [calls[i][1] for i in order]).tolist() == [want[i] for i in order]
+    got = [None] * len(calls)
+    gate = threading.Barrier(len(calls))
+    def worker(i):
+        gate.wait(); got[i] = int(m.lib.verify_state(*calls[i]))
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(len(calls))]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert got == want
