@@ -425,6 +425,11 @@ struct mina_pickles_statements;
 #define MINA_TOK_UNNORMALIZED_LAGRANGE 14 /* + i32 row offset (negative: counted back from the first zero-knowledge row; INT32_MIN: that row itself) */
 #define MINA_TOK_STORE 15
 #define MINA_TOK_LOAD 16                  /* + u16 cache slot */
+#define MINA_TOK_SKIP_IF 17               /* + u8 feature code, u16 n: if the proof has the feature, push 0 and skip the next n tokens (kimchi SkipIf) */
+#define MINA_TOK_SKIP_IF_NOT 18           /* + u8 feature code, u16 n: the same when the proof does NOT have it.  Feature codes: 0..5 the optional gates
+                                             (range_check0, range_check1, foreign_field_add, foreign_field_mul, xor, rot), 6 LookupTables, 7 RuntimeLookupTables,
+                                             8..11 LookupPattern Xor / Lookup / RangeCheck / ForeignFieldMul, 12 + w TableWidth(w <= 3), 16 + n LookupsPerRow(n <= 4);
+                                             derived per proof from the statement's eight feature flags (csrc/polish.h).  A skipped region must net one value. */
 typedef struct {
     uint32_t log2_domain;              /* evaluation domain = SRS chunk size = 2^log2_domain (wrap: 15) */
     uint32_t zk_rows;                  /* 3 */
@@ -443,9 +448,11 @@ int mina_verifier_index_digest(mina_ctx *ctx, uint8_t *out32);   /* `VerifierInd
  * {"Cell": {"col": {"Witness": i} | "Z" | {"Index": "<gate>"} | {"Coefficient": i} | {"Permutation": i}, "row": "Curr" | "Next"}}, "Dup",
  * {"Pow": n}, "Add", "Mul", "Sub", "VanishesOnZeroKnowledgeAndPreviousRows", {"UnnormalizedLagrangeBasis": {"zk_rows": b, "offset": i}},
  * "Store", {"Load": i}, {"SkipIf" | "SkipIfNot": [<feature>, n]}; also {"Challenge": ..} / {"Constant": ..}) -> the byte-code above.
- * SkipIf / SkipIfNot are resolved against `enabled_features` (bit i = optional gate i of range_check0, range_check1, foreign_field_add,
- * foreign_field_mul, xor, rot; 6 = lookup tables; 7 = runtime tables; 8.. = lookup patterns); `optional_present`: bit i = the proofs carry
- * optional evaluation i (wire order), which fixes the column numbers 43.. .  `out` may be NULL to query the length.  Host-side. */
+ * SkipIf / SkipIfNot: with `enabled_features` = MINA_FEATURES_RUNTIME they become MINA_TOK_SKIP_IF / _NOT and every proof's own flags decide
+ * (the step index); otherwise they are resolved here against `enabled_features` (bit = feature code, see MINA_TOK_SKIP_IF_NOT; a fixed circuit
+ * such as the wrap index: 0).  `optional_present`: bit i = the proofs carry optional evaluation i (wire order) -- naming another one is an
+ * error -- or MINA_FEATURES_RUNTIME for "any" (the proof's presence mask decides).  `out` may be NULL to query the length.  Host-side. */
+#define MINA_FEATURES_RUNTIME 0xffffffffu
 int mina_polish_tokens_from_json(int field, const char *json, size_t len, uint32_t enabled_features, uint32_t optional_present, uint8_t *out,
                                  size_t cap, size_t *out_len);
 /* `serde_json` of kimchi `VerifierIndex<Pallas>` (domain, zk_rows, shift, sigma_comm, coefficients_comm, generic_comm, psm_comm,
@@ -492,7 +499,10 @@ typedef struct {
     uint32_t n_domains;               /* step domains in use (<= 8) */
     const uint32_t *domain_log2;      /* n_domains */
     const uint8_t *shifts;            /* n_domains * 7 * 32 (Fp) */
-    const uint8_t *constant_term;     /* PolishToken byte-code over Fp */
+    const uint8_t *constant_term;     /* PolishToken byte-code over Fp.  A CELL column c >= 43 names optional evaluation SLOT c - 43 (wire order);
+                                         the proof's presence mask (`misc`) says where it sits among the evaluations the proof carries; naming a
+                                         slot the proof lacks, outside a skipped region, fails that proof.  MINA_TOK_JOINT_COMBINER is the statement's
+                                         joint combiner (endo-expanded; 0 without one); SkipIf / SkipIfNot look at the statement's feature flags. */
     size_t constant_term_len;
 } mina_step_index;
 int mina_step_index_install(mina_ctx *ctx, const mina_step_index *index);
@@ -518,7 +528,9 @@ typedef struct mina_pickles_statements {
     const void *prev_ft_eval1;          /* b * 32 (Fp) */
     const void *app_state;              /* b * 32 (Fp): the application state = hash of the tip protocol state */
     const void *misc;                   /* b * 32: [0] domain_log2, [1] proofs_verified (0..2), [2..10) feature flags, [10] has joint
-                                           combiner, [16..32) joint combiner */
+                                           combiner, [11..14) little-endian presence mask of the 19 optional evaluations (wire order: 6 optional
+                                           gate selectors, lookup aggregation, lookup table, 5 lookup sorted, runtime table, runtime selector,
+                                           4 lookup-pattern selectors); its popcount must be n_evals - 43, [16..32) joint combiner */
 } mina_pickles_statements;
 /* statements -> the wrap circuit's 40 public inputs, entirely on the GPU (three sponge kernels, one scalar kernel).  Host buffers.
  * ok[b] = 0: statement b is malformed (non-canonical element, unknown step domain); its public inputs are then unspecified. */

@@ -210,24 +210,25 @@ const char *GATE_SELECTORS[6] = {"Generic", "Poseidon", "CompleteAdd", "VarBaseM
 const char *OPTIONAL_GATES[6] = {"RangeCheck0", "RangeCheck1", "ForeignFieldAdd", "ForeignFieldMul", "Xor16", "Rot64"};
 const char *LOOKUP_PATTERNS[4] = {"Xor", "Lookup", "RangeCheck", "ForeignFieldMul"};
 
-int feature_bit(const JVal &f) {            // FeatureFlag: the 6 optional gates (bits 0..5), LookupTables (6), RuntimeLookupTables (7), LookupPattern(p) (8 + p), TableWidth / LookupsPerRow (always as given)
-    if (f.kind == JVal::STR) {
+int feature_bit(const JVal &f) {            // kimchi FeatureFlag -> the byte-code's feature code (csrc/polish.h): gates 0..5, LookupTables 6, RuntimeLookupTables 7,
+    if (f.kind == JVal::STR) {              // LookupPattern(p) 8 + p, TableWidth(w) 12 + w, LookupsPerRow(n) 16 + n
         for (int i = 0; i < 6; ++i) if (f.str == OPTIONAL_GATES[i]) return i;
         if (f.str == "Xor") return 4; if (f.str == "Rot") return 5;
         if (f.str == "LookupTables") return 6; if (f.str == "RuntimeLookupTables") return 7;
         return -1;
     }
     if (f.kind == JVal::OBJ && f.obj.size() == 1) {
-        if (f.obj[0].first == "LookupPattern" && f.obj[0].second.kind == JVal::STR) { for (int i = 0; i < 4; ++i) if (f.obj[0].second.str == LOOKUP_PATTERNS[i]) return 8 + i; }
-        if (f.obj[0].first == "TableWidth" || f.obj[0].first == "LookupsPerRow") return 12;      // lookup shape queries: off unless lookups are on
+        const JVal &v = f.obj[0].second;
+        if (f.obj[0].first == "LookupPattern" && v.kind == JVal::STR) { for (int i = 0; i < 4; ++i) if (v.str == LOOKUP_PATTERNS[i]) return 8 + i; }
+        if (f.obj[0].first == "TableWidth" && v.kind == JVal::NUM && v.num_is_int && v.inum >= 0 && v.inum <= 3) return 12 + (int)v.inum;
+        if (f.obj[0].first == "LookupsPerRow" && v.kind == JVal::NUM && v.num_is_int && v.inum >= 0 && v.inum <= 4) return 16 + (int)v.inum;
     }
     return -1;
 }
 bool column_index(const JVal &col, uint32_t optional_present, uint32_t &out, std::string &err) {
-    auto optional = [&](int slot) -> bool {                          // the slot's rank among the optional evaluations the proofs carry
-        if (!(optional_present >> slot & 1)) { err = "the program names an optional evaluation the proofs do not carry"; return false; }
-        uint32_t rank = 0; for (int i = 0; i < slot; ++i) rank += optional_present >> i & 1;
-        out = 43 + rank; return true;
+    auto optional = [&](int slot) -> bool {                          // the byte-code names the SLOT (43 + slot, wire order); the proof's presence mask places it
+        if (optional_present != 0xffffffffu && !(optional_present >> slot & 1)) { err = "the program names an optional evaluation the proofs do not carry"; return false; }
+        out = 43 + (uint32_t)slot; return true;
     };
     if (col.kind == JVal::STR) {
         if (col.str == "Z") { out = 0; return true; }
@@ -313,7 +314,12 @@ bool tokens_from_json(const JVal &root, int field, uint32_t enabled_features, ui
             if (v.kind != JVal::ARR || v.arr.size() != 2 || v.arr[1].kind != JVal::NUM || !v.arr[1].num_is_int || v.arr[1].inum < 0) return bad("malformed skip");
             const int bit = feature_bit(v.arr[0]);
             if (bit < 0) return bad("unknown feature flag");
-            const bool on = bit < 12 ? (enabled_features >> bit & 1) : (enabled_features >> 6 & 1);
+            if (enabled_features == 0xffffffffu) {                   // run-time form: the interpreter looks at each proof's own flags
+                if (v.arr[1].inum == 0 || v.arr[1].inum > 65535) return bad("skip count out of range");
+                put(k == "SkipIf" ? MINA_TOK_SKIP_IF : MINA_TOK_SKIP_IF_NOT); put((uint8_t)bit); put((uint8_t)v.arr[1].inum); put((uint8_t)(v.arr[1].inum >> 8));
+                continue;
+            }
+            const bool on = (enabled_features >> bit) & 1;
             if ((k == "SkipIf") == on) {
                 const size_t cnt = (size_t)v.arr[1].inum;
                 if (cnt > root.arr.size() - 1 - i) return bad("skip runs past the end of the program");

@@ -44,6 +44,7 @@ struct StepIndexHost {
     std::vector<uint32_t> domains; std::vector<std::array<fe_t, 7>> shifts;      // per domain, Montgomery (Fp)
     std::vector<mb::KimchiToken> toks; std::vector<fe_t> lits; fe_t mds[9]; fe_t endo_coeff;
     uint32_t max_col = 0;                                                        // highest evaluation column the program names
+    bool feature_aware = false;                                                  // the program looks at the proof's features: SkipIf / SkipIfNot, the joint combiner or an optional column
 };
 StepIndexHost &step_of(mina_ctx *c) {           // host half of the step index: owned by the context, freed with it (mina_ctx_destroy)
     static std::mutex mu;
@@ -56,6 +57,7 @@ struct Derived { fe_t cip, b, zeta_srs, zeta_dom, perm, xi, r; mw::Chal128 xi_ch
 
 }  // namespace
 
+int mb_step_index_feature_aware(mina_ctx *c) { return (c->step_host && step_of(c).installed && step_of(c).feature_aware) ? 1 : 0; }
 int mb_step_index_installed(mina_ctx *c) { return (c->step_host && c->have_pickles_dev && step_of(c).installed) ? 1 : 0; }
 static int upload_step_index(mina_ctx *c, const StepIndexHost &st);
 
@@ -79,6 +81,7 @@ extern "C" int mina_step_index_install(mina_ctx *c, const mina_step_index *si) {
     st.endo_coeff = fe_sqr<FIELD_FP>(k.endo);                      // endo_q of Pallas = cube root of unity in Fp: (w^2)^2 = w
     st.zk_rows = si->zk_rows; st.installed = true;
     for (auto &t : st.toks) if (t.op == MINA_TOK_CELL && t.a > st.max_col) st.max_col = t.a;
+    for (auto &t : st.toks) if (t.op == MINA_TOK_SKIP_IF || t.op == MINA_TOK_SKIP_IF_NOT || t.op == MINA_TOK_JOINT_COMBINER || (t.op == MINA_TOK_CELL && t.a >= mb::KC_COLS)) st.feature_aware = true;
     int rc = upload_step_index(c, st);
     if (rc) return rc;
     step_of(c) = st;
@@ -196,6 +199,10 @@ int mb_pickles_public_inputs(mina_ctx *c, const mw::WrapProof *const *proofs, co
         ft = fe_add<FIELD_FP>(ft, fe_mul<FIELD_FP>(num, fe_inv<FIELD_FP>(fe_mul<FIELD_FP>(dw, d1), kp)));
         if (!st.toks.empty()) {
             mb::PolishEnv<FIELD_FP> env{x.alpha, x.beta, x.gamma, st.endo_coeff, zkp, x.zeta, zeta_dom, x.omega, st.mds, x.k, st.zk_rows, &x.seq};
+            { uint8_t ff[8]; for (int j = 0; j < 8; ++j) ff[j] = w.feature_flags[j] ? 1 : 0; env.features = mb::feature_mask_of_flags(ff); }
+            if (w.has_joint_combiner) env.joint_combiner = challenge_to_field<FIELD_FP>(w.joint_combiner.lo, w.joint_combiner.hi, kp);
+            env.slots = true; env.present = 0;
+            for (size_t j = 0; j < w.prev_evals_present.size() && j < 19; ++j) if (w.prev_evals_present[j]) env.present |= 1u << j;
             fe_t ct;
             if (!mb::polish_eval_host<FIELD_FP>(st.toks, st.lits, env, kp, ct)) { ok_out[i] = 0; ct = fe_zero(); }
             ft = fe_sub<FIELD_FP>(ft, ct);
@@ -392,13 +399,22 @@ pickles_scalar_kernel(uint32_t batch, FieldK kp, FieldK kq, const PicklesIndexDe
     uint32_t dom = 0; { bool found = false; for (uint32_t d = 0; d < ix->n_domains; ++d) if (ix->domain_log2[d] == misc[0]) { dom = d; found = true; } ok = ok && found; }
     const uint32_t k = ix->domain_log2[dom];
     const uint32_t *ev = in.evals + (size_t)b * in.n_evals * 16;
-    auto EV = [&](uint32_t col, uint32_t row) { return fe_to_mont<F>(load_fe<F>(ev + ((size_t)col * 2 + row) * 8), kp.r2); };
+    // optional evaluations: the program names SLOTS (43 + slot, wire order), the proof carries the ones its presence mask marks
+    const uint32_t present = (uint32_t)misc[11] | ((uint32_t)misc[12] << 8) | ((uint32_t)misc[13] << 16);
+    ok = ok && (present >> 19) == 0 && (uint32_t)__popc(present) == in.n_evals - KC_COLS;
+    auto EV = [&](uint32_t col, uint32_t row) {
+        if (col >= KC_COLS) { const uint32_t slot = col - KC_COLS; if (slot >= 19 || !((present >> slot) & 1u)) { ok = false; return fe_zero(); } col = KC_COLS + (uint32_t)__popc(present & ((1u << slot) - 1)); }
+        return fe_to_mont<F>(load_fe<F>(ev + ((size_t)col * 2 + row) * 8), kp.r2);
+    };
+    auto EVI = [&](uint32_t idx, uint32_t row) { return fe_to_mont<F>(load_fe<F>(ev + ((size_t)idx * 2 + row) * 8), kp.r2); };     // by position (the combined inner product runs over all of them)
     const fe_t zeta = x[PX_ZETA], zetaw = fe_mul<F>(zeta, ix->omega[dom]);
     const fe_t zeta_dom = fe_pow2k<F>(zeta, k), zeta_srs = fe_pow2k<F>(zeta, 16);
     const fe_t p0 = fe_to_mont<F>(load_fe<F>(in.pub_in + (size_t)b * 16), kp.r2), p1 = fe_to_mont<F>(load_fe<F>(in.pub_in + (size_t)b * 16 + 8), kp.r2);
     fe_t perm;
     FtEnv env{x[PX_ALPHA], x[PX_BETA], x[PX_GAMMA], zeta, zeta_dom, ix->omega[dom], ix->omega_zk[dom], ix->endo_coeff, ix->zk_roots[dom], ix->shifts[dom], ix->mds, lits, toks,
               k, ix->zk_rows, 21u, ix->n_tokens};
+    env.features = feature_mask_of_flags(misc + 2);
+    if (misc[10]) { const uint32_t *jc = (const uint32_t *)(misc + 16); env.joint = challenge_to_field<F>((uint64_t)jc[0] | ((uint64_t)jc[1] << 32), (uint64_t)jc[2] | ((uint64_t)jc[3] << 32), kp); }
     const fe_t ft = ft_eval0_dev<F>(env, kp, p0, EV, st, ok, perm);
     const fe_t xi = x[PX_XI], r = x[PX_R];
     // combined inner product: Horner in xi over [b_poly(old_a, pt)..., public, ft, the evaluations], both points, second scaled by r
@@ -406,7 +422,7 @@ pickles_scalar_kernel(uint32_t batch, FieldK kp, FieldK kq, const PicklesIndexDe
     {
         fe_t acc0 = fe_zero(), acc1 = fe_zero();
 #pragma unroll 1
-        for (int c = (int)in.n_evals - 1; c >= 0; --c) { acc0 = fe_add<F>(fe_mul<F>(acc0, xi), EV((uint32_t)c, 0)); acc1 = fe_add<F>(fe_mul<F>(acc1, xi), EV((uint32_t)c, 1)); }
+        for (int c = (int)in.n_evals - 1; c >= 0; --c) { acc0 = fe_add<F>(fe_mul<F>(acc0, xi), EVI((uint32_t)c, 0)); acc1 = fe_add<F>(fe_mul<F>(acc1, xi), EVI((uint32_t)c, 1)); }
         acc0 = fe_add<F>(fe_mul<F>(acc0, xi), ft); acc1 = fe_add<F>(fe_mul<F>(acc1, xi), fe_to_mont<F>(load_fe<F>(in.ft_eval1 + (size_t)b * 8), kp.r2));
         acc0 = fe_add<F>(fe_mul<F>(acc0, xi), p0); acc1 = fe_add<F>(fe_mul<F>(acc1, xi), p1);
 #pragma unroll 1
@@ -486,7 +502,7 @@ int mb_pickles_dev(mina_ctx *c, size_t batch, const mb::PicklesIn &in, uint32_t 
     const PoseidonParams *ppp = c->pparams[FIELD_FP].as<PoseidonParams>(), *ppq = c->pparams[FIELD_FQ].as<PoseidonParams>();
     const uint32_t B = (uint32_t)batch;
     ProfScope ps_(c, PS_PICKLES);
-    HIPC(hipMemsetD32Async((hipDeviceptr_t)d_ok, step_of(c).max_col < in.n_evals ? 1 : 0, batch, L.stream));   // a program naming a column the proofs lack fails them all
+    HIPC(hipMemsetD32Async((hipDeviceptr_t)d_ok, 1, batch, L.stream));   // a program that names an optional evaluation a proof lacks (outside a skipped region) fails THAT proof (pickles_scalar_kernel)
     mb::pickles_expand_kernel<<<cdiv(batch * (50 + 16 * in.n_old), 256), 256, 0, L.stream>>>(B, kp, kq, in, xe);
     if (use_coop16(c, batch)) {
         mb::pickles_digest_kernel<16><<<3 * coop_role_blocks<16>(batch), 64, 0, L.stream>>>(B, kp, kq, ppp, ppq, ix, in, xe, d_ok, coop_role_blocks<16>(batch));

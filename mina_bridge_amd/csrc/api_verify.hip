@@ -31,6 +31,7 @@
 int mb_pack_protocol_state(const mw::ProtocolState &s, uint8_t *record, uint32_t *n_body_fields, mina_protocol_state_info *info);   // api_state.hip
 int mb_kimchi_available(mina_ctx *c);                                                                                                  // api_kimchi.hip
 int mb_poseidon_env_params(mina_ctx *c);                                                                                               // api_loaders.hip
+int mb_step_index_feature_aware(mina_ctx *c);                                                                                         // api_pickles.hip
 int mb_step_index_installed(mina_ctx *c);                                                                                              // api_pickles.hip
 int mb_state_jobs_on_lane(mina_ctx *c, const mina_state_jobs *j, uint32_t *d_verdicts, uint32_t *d_flags, Lane *LI, Lane *LA, uint32_t *d_stmt_out);   // api_state.hip
 
@@ -188,7 +189,7 @@ CallMerger g_state_calls, g_account_calls;
 //   page-locked memory.  No per-call allocation, no gather copy.  A chunk whose folded check fails goes through the culprit search of
 //   mina_state_job_batch from the same staging.
 namespace {
-struct Shape { bool kimchi = false, statements = false; uint32_t k = 0, n_prev = 2, n_old = 0, n_ev = 0; int network = -1; };
+struct Shape { bool kimchi = false, statements = false, feature_aware = false; uint32_t k = 0, n_prev = 2, n_old = 0, n_ev = 0; int network = -1; };
 enum Sec : int { S_REC = 0, S_NF, S_EXP, S_PRE, S_APRE, S_ASG, S_ARHO, S_LR, S_DELTA, S_SG, S_Z1, S_Z2, S_PCM, S_WC, S_ZC, S_TC, S_EV, S_FT1, S_PCH,
                  S_PLONK, S_BP, S_OLD, S_CM, S_WOLD, S_WSG, S_DG, S_SEV, S_PI, S_SFT, S_APP, S_MISC, S_RB, S_SB, NSEC };
 struct Layout {
@@ -227,9 +228,11 @@ void chal_bytes(const mw::Chal128 &c, uint8_t *o) { put_chal(o, c); }
 template <int F> fe_t host_mont(const uint8_t *b, const FieldK &k) { fe_t a; memcpy(a.v, b, 32); return fe_to_mont<F>(a, k.r2); }
 void put_pt(uint8_t *o, const mw::Pt &p) { memcpy(o, p.x.b, 32); memcpy(o + 32, p.y.b, 32); }
 
-// kimchi gates whose constraints read lookup tables (or the joint combiner): the installed linearization carries no lookup terms
-// (kimchi_dev.cuh evaluates MINA_TOK_JOINT_COMBINER as zero), so a statement that switches one on is REJECTED at the kimchi step instead of
-// being evaluated with zeros.  feature_flags: range_check0, range_check1, foreign_field_add, foreign_field_mul, xor, rot, lookup, runtime_tables.
+// kimchi gates whose constraints read lookup tables (or the joint combiner).  A step linearization installed WITHOUT feature-dependent
+// tokens (no SkipIf / SkipIfNot, no joint combiner, no optional column) cannot evaluate such a proof faithfully, so a statement that switches
+// one on is then REJECTED at the kimchi step instead of being evaluated as if the feature were off; a feature-aware program
+// (mb_step_index_feature_aware) is evaluated with the statement's flags, joint combiner and optional evaluations (kimchi_dev.cuh).
+// feature_flags: range_check0, range_check1, foreign_field_add, foreign_field_mul, xor, rot, lookup, runtime_tables.
 bool uses_lookups(const mw::WrapProof &w) {
     return w.has_joint_combiner || w.feature_flags[0] || w.feature_flags[1] || w.feature_flags[3] || w.feature_flags[4] || w.feature_flags[5] || w.feature_flags[6] || w.feature_flags[7];
 }
@@ -276,7 +279,7 @@ void parse_into(const Shape &sh, const Layout &lay, uint8_t *base, size_t b, con
         // the wrap proof must have the shape of the installed index: k rounds, n_prev step-side accumulators, no lookup features; a well-formed
         // proof of another evaluation / recursion shape is verified in a job of its own (`deferred`), a malformed one fails here
         const size_t n_old = w.step_old_bulletproof_challenges.size(), n_ev = w.prev_evals.size();
-        if (w.lr.size() != sh.k || w.step_challenge_polynomial_commitments.size() != sh.n_prev || uses_lookups(w) || n_old > 4 || n_ev < 43 || n_ev > 62 ||
+        if (w.lr.size() != sh.k || w.step_challenge_polynomial_commitments.size() != sh.n_prev || (uses_lookups(w) && !sh.feature_aware) || n_old > 4 || n_ev < 43 || n_ev > 62 ||
             w.prev_public_input.zeta.empty() || w.prev_public_input.zeta_omega.empty() || (sh.network >= 0 && (int)pi.is_state_proof_from_devnet != sh.network)) hb.shape = 0;
         else if (sh.statements && (n_old != sh.n_old || n_ev != sh.n_ev)) { hb.shape = 0; hb.deferred = 1; }
     }
@@ -334,6 +337,8 @@ void parse_into(const Shape &sh, const Layout &lay, uint8_t *base, size_t b, con
             uint8_t *misc = lay.at(base, S_MISC, b); memset(misc, 0, 32);
             misc[0] = w.domain_log2; misc[1] = w.proofs_verified; for (int j = 0; j < 8; ++j) misc[2 + j] = w.feature_flags[j] ? 1 : 0;
             misc[10] = w.has_joint_combiner ? 1 : 0; if (w.has_joint_combiner) put_chal(misc + 16, w.joint_combiner);
+            { uint32_t present = 0; for (size_t j = 0; j < w.prev_evals_present.size() && j < 19; ++j) if (w.prev_evals_present[j]) present |= 1u << j;
+              misc[11] = (uint8_t)present; misc[12] = (uint8_t)(present >> 8); misc[13] = (uint8_t)(present >> 16); }
         }
     }
     *lay.at(base, S_PRE, b) = (hb.ledger && hb.consensus && hb.shape) ? 1 : 0;
@@ -382,7 +387,7 @@ void copy_entry(const Layout &lay, uint8_t *base, size_t dst, size_t src) {
     for (int i = 0; i < NSEC; ++i) if (lay.stride[i] && i != S_PRE) memcpy(lay.at(base, i, dst), lay.at(base, i, src), lay.stride[i]);
 }
 
-struct Config { bool usable = false, kimchi = false, statements = false; uint32_t k = 0; int network = -1; };
+struct Config { bool usable = false, kimchi = false, statements = false, feature_aware = false; uint32_t k = 0; int network = -1; };
 Config read_config(Device &D, uint32_t flags) {
     std::lock_guard<std::mutex> lk(D.mu);
     mina_ctx *c = D.c; Config cf;
@@ -394,6 +399,7 @@ Config read_config(Device &D, uint32_t flags) {
     // (the proof would not be bound to the candidate tip) unless the caller explicitly accepts the unbound form
     cf.kimchi = mb_kimchi_available(c) && (cf.statements || (flags & MINA_VERIFY_ALLOW_UNBOUND_STATEMENT));
     cf.k = c->kimchi_log2;
+    cf.feature_aware = cf.statements && mb_step_index_feature_aware(c) != 0;
     { std::lock_guard<std::mutex> gl(g_mu); cf.network = g_network; }
     return cf;
 }
@@ -414,7 +420,7 @@ int run_device(Device &D, const CallIn &in, const std::vector<size_t> &idx, uint
     const Config cf = read_config(D, flags);
     if (!cf.usable) return MINA_OK;
     if (!cf.kimchi && !(flags & MINA_VERIFY_ALLOW_MISSING_KIMCHI)) return MINA_OK;          // the kimchi step cannot run: nothing can pass
-    Shape sh; sh.kimchi = cf.kimchi; sh.statements = cf.kimchi && cf.statements; sh.k = cf.k; sh.network = cf.network;
+    Shape sh; sh.kimchi = cf.kimchi; sh.statements = cf.kimchi && cf.statements; sh.k = cf.k; sh.network = cf.network; sh.feature_aware = cf.feature_aware;
     if (sh.statements) {           // evaluation / recursion shape of the job: the first proof that parses names it (Mina's blockchain proofs all share one)
         bool found = false;
         for (size_t i = 0; i < m && !found; ++i) {
@@ -602,7 +608,7 @@ int state_checks(const uint8_t *proof, size_t proof_len, const uint8_t *pub, siz
     Device *D; uint32_t flags;
     { std::lock_guard<std::mutex> lk(g_mu); auto &ds = devices(); if (ds.empty()) return MINA_ERR_HIP; D = ds[0]; flags = g_flags; }
     const Config cf = read_config(*D, flags | MINA_VERIFY_ALLOW_SURROGATE);
-    Shape sh; sh.kimchi = cf.kimchi; sh.statements = cf.kimchi && cf.statements; sh.k = cf.k; sh.network = cf.network;
+    Shape sh; sh.kimchi = cf.kimchi; sh.statements = cf.kimchi && cf.statements; sh.k = cf.k; sh.network = cf.network; sh.feature_aware = cf.feature_aware;
     uint32_t passed = 0, ran = MINA_CHECK_FORMAT;
     *passed_out = 0; *ran_out = ran;
     if (sh.statements) {

@@ -48,6 +48,7 @@ struct FtEnv {
     fe_t alpha, beta, gamma, zeta, zeta_n;                        // zeta_n = zeta^(2^k)
     fe_t omega, omega_zk, endo; const fe_t *zk_roots, *shifts, *mds, *lits; const KimchiToken *toks;
     uint32_t k, zk_rows, alpha0, n_tokens;
+    fe_t joint = fe_zero(); uint32_t features = 0;                // the proof's joint combiner (0 without one) and feature mask (polish.h feature_mask_of_flags)
 };
 // returns ft_eval0; `perm_scalar` = -z(zeta w) beta a0 zkpm prod_{i<6}(gamma + beta s_i + w_i); ok = false on a broken program.
 // EV(col, row): the proof's evaluation of column `col` at zeta (row 0) / zeta*omega (row 1), Montgomery.
@@ -76,15 +77,20 @@ __device__ fe_t ft_eval0_dev(const FtEnv &e, const FieldK &fk, const fe_t &pub0,
         ft = fe_add<F>(ft, fe_mul<F>(num, fe_inv<F>(fe_mul<F>(dw, d1), fk)));
     }
     if (e.n_tokens) {   // linearization constant term: PolishToken stack machine (the program is uniform over the lanes: no divergence)
-        int sp = 0, nc = 0; bool prog_ok = true;
+        int sp = 0, nc = 0; bool prog_ok = true; uint32_t skip = 0;      // `skip` is per lane (the proofs' feature flags differ); the token loop itself stays uniform
 #pragma unroll 1
         for (uint32_t t = 0; t < e.n_tokens; ++t) {
             const KimchiToken tk = e.toks[t];
+            if (skip) { --skip; if (tk.op == MINA_TOK_STORE) st.put(KC_STACK + nc++, fe_zero()); continue; }
             switch (tk.op) {
+                case MINA_TOK_SKIP_IF: case MINA_TOK_SKIP_IF_NOT: {
+                    const bool on = (e.features >> tk.a) & 1u;
+                    if (on == (tk.op == MINA_TOK_SKIP_IF)) { skip = tk.b; st.put(sp++, fe_zero()); }
+                    break; }
                 case MINA_TOK_ALPHA: st.put(sp++, e.alpha); break;
                 case MINA_TOK_BETA: st.put(sp++, e.beta); break;
                 case MINA_TOK_GAMMA: st.put(sp++, e.gamma); break;
-                case MINA_TOK_JOINT_COMBINER: st.put(sp++, fe_zero()); break;
+                case MINA_TOK_JOINT_COMBINER: st.put(sp++, e.joint); break;
                 case MINA_TOK_ENDO_COEFFICIENT: st.put(sp++, e.endo); break;
                 case MINA_TOK_MDS: st.put(sp++, e.mds[tk.a * 3 + tk.b]); break;
                 case MINA_TOK_LITERAL: st.put(sp++, e.lits[tk.a]); break;

@@ -23,7 +23,27 @@ from . import pasta_ref as R
 
 COLUMNS, PERMUTS = 15, 7
 # PolishToken opcodes of the engine's byte-code (include/mina_verify.h MINA_TOK_*)
-(T_ALPHA, T_BETA, T_GAMMA, T_JOINT, T_ENDO, T_MDS, T_LITERAL, T_CELL, T_DUP, T_POW, T_ADD, T_MUL, T_SUB, T_VANISH_ZK, T_LAGRANGE, T_STORE, T_LOAD) = range(17)
+(T_ALPHA, T_BETA, T_GAMMA, T_JOINT, T_ENDO, T_MDS, T_LITERAL, T_CELL, T_DUP, T_POW, T_ADD, T_MUL, T_SUB, T_VANISH_ZK, T_LAGRANGE, T_STORE, T_LOAD,
+ T_SKIP_IF, T_SKIP_IF_NOT) = range(19)
+
+
+def feature_mask(flags) -> int:
+    """kimchi `FeatureFlag`s of a proof from the eight Pickles statement flags (range_check0, range_check1, foreign_field_add, foreign_field_mul,
+    xor, rot, lookup, runtime_tables) [UPSTREAM-RECALL]: codes 0..5 the optional gates, 6 LookupTables, 7 RuntimeLookupTables, 8..11 LookupPattern
+    Xor / Lookup / RangeCheck / ForeignFieldMul, 12 + w TableWidth(w), 16 + n LookupsPerRow(n) (the maxima over the patterns in use:
+    Xor 3 / 4, Lookup 2 / 3, RangeCheck 1 / 4, ForeignFieldMul 2 / 2)"""
+    rc0, rc1, ffadd, ffmul, x, rot, lk, rt = (bool(f) for f in flags)
+    pats = {"xor": x, "lookup": lk, "rc": rc0 or rc1 or rot, "ffmul": ffmul}
+    any_ = any(pats.values())
+    width = max([w for p, w in (("xor", 3), ("lookup", 2), ("rc", 1), ("ffmul", 2)) if pats[p]], default=0)
+    per_row = max([n for p, n in (("xor", 4), ("lookup", 3), ("rc", 4), ("ffmul", 2)) if pats[p]], default=0)
+    m = sum(1 << i for i, f in enumerate((rc0, rc1, ffadd, ffmul, x, rot)) if f)
+    m |= (any_ << 6) | (rt << 7) | (pats["xor"] << 8) | (pats["lookup"] << 9) | (pats["rc"] << 10) | (pats["ffmul"] << 11)
+    for w in range(4):
+        if width >= w and (w == 0 or any_): m |= 1 << (12 + w)
+    for n in range(5):
+        if per_row >= n and (n == 0 or any_): m |= 1 << (16 + n)
+    return m
 # evaluation columns, in the order the transcript absorbs them / the evaluation list names them
 COL_Z, COL_GENERIC, COL_POSEIDON, COL_COMPLETE_ADD, COL_MUL, COL_EMUL, COL_ENDOMUL_SCALAR = range(7)
 COL_W0, COL_COEFF0, COL_S0 = 7, 7 + COLUMNS, 7 + 2 * COLUMNS
@@ -80,8 +100,18 @@ def polish_evaluate(tokens, index: VerifierIndex, pt: int, evals, consts: dict, 
     stack, cache = [], []
     n = index.n
     w = O_domain_generator(r, index.log2_domain)
+    features, present, skip = consts.get("features", 0), consts.get("present"), 0
     for tok in tokens:
         op = tok[0]
+        if skip:                                                   # inside a skipped region: nothing runs; a STORE still takes its cache slot
+            skip -= 1
+            if op == T_STORE: cache.append(0)
+            continue
+        if op in (T_SKIP_IF, T_SKIP_IF_NOT):                       # kimchi SkipIf / SkipIfNot: push zero and skip `count` tokens when the condition holds
+            on = bool((features >> tok[1]) & 1)
+            if on == (op == T_SKIP_IF):
+                skip = tok[2]; stack.append(0)
+            continue
         if op == T_ALPHA: stack.append(consts["alpha"])
         elif op == T_BETA: stack.append(consts["beta"])
         elif op == T_GAMMA: stack.append(consts["gamma"])
@@ -89,7 +119,13 @@ def polish_evaluate(tokens, index: VerifierIndex, pt: int, evals, consts: dict, 
         elif op == T_ENDO: stack.append(consts["endo"])
         elif op == T_MDS: stack.append(consts["mds"][tok[1]][tok[2]])
         elif op == T_LITERAL: stack.append(tok[1] % r)
-        elif op == T_CELL: stack.append(evals[tok[1]][tok[2]])
+        elif op == T_CELL:
+            col = tok[1]
+            if present is not None and col >= N_EVAL_COLS:        # the step side: optional SLOT col - 43, found through the proof's presence mask
+                slot = col - N_EVAL_COLS
+                if not (present >> slot) & 1: raise KeyError("the program names an optional evaluation the proof does not carry")
+                col = N_EVAL_COLS + bin(present & ((1 << slot) - 1)).count("1")
+            stack.append(evals[col][tok[2]])
         elif op == T_DUP: stack.append(stack[-1])
         elif op == T_POW: stack.append(pow(stack.pop(), tok[1], r))
         elif op == T_ADD: b = stack.pop(); a = stack.pop(); stack.append((a + b) % r)

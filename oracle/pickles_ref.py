@@ -136,7 +136,9 @@ def compute_deferred_values(w: dict, step: StepIndex, pp_fp) -> dict:
     ft = (ft + num * R.inv((zeta - wz) * (zeta - 1) % P, P)) % P
     idx = K.VerifierIndex(curve=1, log2_domain=k, zk_rows=step.zk_rows, shifts=shifts, sigma_comm=[], coefficients_comm=[], selector_comm=[],
                           constant_term=step.constant_term, mds=step.mds)
-    consts = {"alpha": alpha, "beta": beta, "gamma": gamma, "endo": R.endo_q(0), "mds": step.mds}
+    present = sum(1 << j for j, x in enumerate(w["prev_optional"]) if x is not None)
+    consts = {"alpha": alpha, "beta": beta, "gamma": gamma, "endo": R.endo_q(0), "mds": step.mds, "features": K.feature_mask(w["feature_flags"]), "present": present,
+              "joint_combiner": to_f(w["joint_combiner"]) if w["joint_combiner"] is not None else 0}
     ft = (ft - K.polish_evaluate(step.constant_term, idx, zeta, seq, consts, P)) % P if step.constant_term else ft
     perm = z1 * beta % P * a0 % P * zkp % P
     for i in range(6):

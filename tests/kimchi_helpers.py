@@ -22,6 +22,8 @@ def encode_tokens(tokens) -> bytes:
             out += struct.pack("<i", t[1])
         elif op == K.T_LOAD:
             out += struct.pack("<H", t[1])
+        elif op in (K.T_SKIP_IF, K.T_SKIP_IF_NOT):
+            out += bytes([t[1]]) + struct.pack("<H", t[2])
     return bytes(out)
 
 
@@ -123,6 +125,8 @@ def statements_soa(wraps, apps):
             misc[2 + j] = 1 if f else 0
         if w["joint_combiner"] is not None:
             misc[10] = 1; misc[16:32] = le(w["joint_combiner"], 16)
+        present = sum(1 << j for j, e in enumerate(w["prev_optional"]) if e is not None)      # which of the 19 optional evaluations the proof carries (wire order)
+        misc[11:14] = present.to_bytes(3, "little")
         sec["misc"] += misc
     return n_old, n_evals, {k: np.frombuffer(bytes(v), np.uint8).copy() if len(v) else np.zeros(1, np.uint8) for k, v in sec.items()}
 
@@ -141,6 +145,26 @@ def make_step_index(seed):
             (K.T_BETA,), (K.T_GAMMA,), (K.T_MUL,), (K.T_POW, 5), (K.T_STORE,), (K.T_ADD,), (K.T_LOAD, 0), (K.T_SUB,)]
     return PK.StepIndex(zk_rows=3, shifts={k: [1] + [rng.randrange(2, R.P) for _ in range(6)] for k in STEP_DOMAINS}, constant_term=toks,
                         mds=[list(r) for r in poseidon_pp(0).mds])
+
+
+def make_feature_step_index(seed):
+    """a FEATURE-AWARE synthetic step index: on top of make_step_index's program, regions guarded by kimchi's SkipIf / SkipIfNot that read
+    optional evaluations (lookup aggregation / table, the range_check0 selector, a lookup-pattern selector), the joint combiner, and a value
+    STOREd inside a region and LOADed after it -- the shape kimchi's feature-flagged linearization compiles to:
+        if_feature(f, e1, e2)  ->  SkipIfNot(f, |e1|) e1 SkipIf(f, |e2|) e2 Add"""
+    from oracle import kimchi_ref as K
+    base = make_step_index(seed)
+    OPT = K.N_EVAL_COLS                                                   # 43 + slot (wire order of the optional evaluations)
+    e1 = [(K.T_CELL, OPT + 6, 1), (K.T_JOINT,), (K.T_MUL,), (K.T_CELL, OPT + 7, 0), (K.T_ADD,), (K.T_STORE,)]            # lookup aggregation(zeta w) * joint + table(zeta), cached
+    e2 = [(K.T_LITERAL, 31337), (K.T_ALPHA,), (K.T_MUL,)]
+    r1 = [(K.T_SKIP_IF_NOT, 6, len(e1))] + e1 + [(K.T_SKIP_IF, 6, len(e2))] + e2 + [(K.T_ADD,)]                          # if_feature(LookupTables, e1, e2)
+    e3 = [(K.T_CELL, OPT + 0, 0), (K.T_BETA,), (K.T_MUL,)]
+    r2 = [(K.T_SKIP_IF_NOT, 0, len(e3))] + e3                                                                           # range_check0 selector, else zero
+    inner = [(K.T_CELL, OPT + 17, 1), (K.T_GAMMA,), (K.T_ADD,)]
+    e4 = [(K.T_ENDO,), (K.T_SKIP_IF_NOT, 10, len(inner))] + inner + [(K.T_MUL,)]                                        # nested: LookupPattern RangeCheck inside TableWidth(1)
+    r3 = [(K.T_SKIP_IF_NOT, 13, len(e4))] + e4
+    toks = list(base.constant_term) + r1 + [(K.T_ADD,)] + r2 + [(K.T_ADD,)] + r3 + [(K.T_SUB,)] + [(K.T_LOAD, 1), (K.T_ADD,)]
+    return type(base)(zk_rows=base.zk_rows, shifts=base.shifts, constant_term=toks, mds=base.mds)
 
 
 def install_step_index(ctx, step):

@@ -37,7 +37,7 @@ def world(srs_oracle):
 from kimchi_helpers import STEP_DOMAINS, install_step_index, make_step_index  # noqa: E402
 
 
-def mint_state_proof(world, srs_oracle, seed, optional_slots=()):
+def mint_state_proof(world, srs_oracle, seed, optional_slots=(), statement_overrides=None):
     from ipa_helpers import poseidon_pp
     from oracle import kimchi_ref as K, oracle as O, pasta_ref as R, state_job_ref as J, mina_state_ref as S
     from wire_writers import synth_wrap_proof
@@ -48,6 +48,7 @@ def mint_state_proof(world, srs_oracle, seed, optional_slots=()):
     pres = [[rng.getrandbits(128) for _ in range(15)] for _ in range(2)]
     chals = [[R.challenge_to_field(p, R.endo_r(0), R.Q) for p in row[:K_LOG2]] for row in pres]
     wrap["prev_optional"] = [(([rng.randrange(R.P)], [rng.randrange(R.P)]) if i in optional_slots else None) for i in range(19)]
+    wrap.update(statement_overrides or {})
     wrap["old_bulletproof_challenges"] = pres
     prev_comms = []
     for ch in chals:                                            # the previous wrap accumulators: commitments of b_poly_coefficients(chals)
@@ -491,3 +492,115 @@ def test_proofs_of_different_evaluation_shapes_in_one_call(world, srs_oracle):
     for t in th: t.start()
     for t in th: t.join()
     assert got == want
+
+
+def _feature_statement(rng, flags, extra_slots=(), joint=True, k=K_LOG2):
+    """a random statement whose feature flags are `flags` and which carries exactly the optional evaluations the feature-aware program of
+    kimchi_helpers.make_feature_step_index reads for them (+ `extra_slots`)"""
+    from oracle import kimchi_ref as K, pickles_ref as PK
+    from wire_writers import synth_wrap_proof
+    w = synth_wrap_proof(rng, k=k)
+    w["feature_flags"] = list(flags)
+    fm = K.feature_mask(flags)
+    need = set(extra_slots)
+    if fm >> 6 & 1: need |= {6, 7}                  # LookupTables: lookup aggregation, lookup table
+    if fm >> 0 & 1: need |= {0}                     # the range_check0 selector
+    if (fm >> 13 & 1) and (fm >> 10 & 1): need |= {17}      # TableWidth(1) and LookupPattern RangeCheck: its selector
+    w["prev_optional"] = [(([rng.randrange(PK.P)], [rng.randrange(PK.P)]) if j in need else None) for j in range(19)]
+    w["joint_combiner"] = rng.getrandbits(128) if joint else None
+    return w
+
+
+def test_feature_aware_step_linearization_matches_oracle(world, srs_oracle):
+    """kimchi's feature-flagged linearization on the GPU: SkipIf / SkipIfNot regions decided by every proof's OWN flags (LookupTables, a gate
+    flag, a lookup pattern nested inside TableWidth), optional evaluations found through the proof's presence mask, the joint combiner, a value
+    cached inside a region -- the statements' 40 public inputs == oracle/pickles_ref.py for every flag combination; a proof that switches a
+    feature on without carrying the evaluation its term reads fails ALONE"""
+    import mina_bridge_amd as m
+    from ipa_helpers import poseidon_pp
+    from kimchi_helpers import install_step_index, make_feature_step_index, statements_soa
+    from oracle import oracle as O, pickles_ref as PK
+    rng = random.Random(777)
+    ix = world["circ"].index
+    comms = list(ix.sigma_comm) + list(ix.coefficients_comm) + list(ix.selector_comm)
+    gctx = world["gctx"]
+    fstep = make_feature_step_index(99)
+    install_step_index(gctx, fstep)
+    try:
+        combos = [[False] * 8, [True] + [False] * 7, [False] * 4 + [True] + [False] * 3, [False] * 6 + [True, False], [False, True, False, True, False, False, False, True],
+                  [True] * 8, [False, False, True, False, False, True, False, False], [False] * 3 + [True] + [False] * 4]
+        by_shape = {}
+        for flags in combos:
+            for extra in ((), (3, 12)):
+                for joint in (True, False):
+                    w = _feature_statement(rng, flags, extra, joint)
+                    by_shape.setdefault(sum(e is not None for e in w["prev_optional"]), []).append(w)
+        total = 0
+        for n_opt, wraps in by_shape.items():
+            apps = [rng.randrange(PK.P) for _ in wraps]
+            want = [PK.statement_public_input(w, fstep, comms, a, poseidon_pp(0), poseidon_pp(1))[0] for w, a in zip(wraps, apps)]
+            n_old, n_evals, sec = statements_soa(wraps, apps)
+            assert n_evals == 43 + n_opt
+            pub, ok = gctx.pickles_public_inputs_batch(gctx.make_pickles_statements(n_old, n_evals, sec), len(wraps))
+            assert ok.tolist() == [1] * len(wraps)
+            for b in range(len(wraps)):
+                assert [O.le_to_int(x) for x in pub[b]] == want[b], (n_opt, b, wraps[b]["feature_flags"])
+            total += len(wraps)
+            # the single-proof host form agrees (its interpreter is polish.h's)
+            from wire_writers import wrap_proof_bytes
+            pub1, _ = gctx.pickles_public_input(wrap_proof_bytes(wraps[0], True), m.lib.ENC_BINPROT, O.int_to_le(apps[0]))
+            assert [O.le_to_int(x) for x in pub1] == want[0]
+        assert total == 32
+        # a feature switched on without the evaluation its term reads: that statement alone is flagged (same count of optional evaluations, other slots)
+        good = _feature_statement(rng, [False] * 6 + [True, False])                       # lookup: carries slots 6, 7
+        bad = copy.deepcopy(good); bad["prev_optional"][7], bad["prev_optional"][9] = None, bad["prev_optional"][7]
+        n_old, n_evals, sec = statements_soa([good, bad, good], [5, 6, 7])
+        pub, ok = gctx.pickles_public_inputs_batch(gctx.make_pickles_statements(n_old, n_evals, sec), 3)
+        assert ok.tolist() == [1, 0, 1]
+        with pytest.raises(KeyError):
+            PK.statement_public_input(bad, fstep, comms, 6, poseidon_pp(0), poseidon_pp(1))
+        # a presence mask that does not match the number of evaluations carried: malformed
+        sec2 = {k: v.copy() for k, v in sec.items()}; sec2["misc"].reshape(3, 32)[0, 11] ^= 1
+        assert gctx.pickles_public_inputs_batch(gctx.make_pickles_statements(n_old, n_evals, sec2), 3)[1].tolist() == [0, 0, 1]
+    finally:
+        install_step_index(gctx, world["step"])
+
+
+def test_boundary_accepts_lookup_features_only_with_a_feature_aware_step_index(world, srs_oracle):
+    """mina_verify_state on proofs whose statement switches lookup features on: rejected at the kimchi step while the installed step
+    linearization has no feature-dependent tokens (it could not evaluate them faithfully), verified -- and tamper-rejected -- once a
+    feature-aware one is installed"""
+    import mina_bridge_amd as m
+    from kimchi_helpers import install_step_index, make_feature_step_index
+    from oracle import kimchi_ref as K, oracle as O, pickles_ref as PK
+    gctx = world["gctx"]
+    fstep = make_feature_step_index(99)
+    rng = random.Random(4242)
+    plain_world = dict(world)
+    feat_world = dict(world); feat_world["step"] = fstep
+
+    def mint(w_, seed, flags, joint):
+        # as mint_state_proof, with the statement's features chosen and the optional evaluations the feature-aware program reads
+        st = _feature_statement(random.Random(seed), flags, joint=joint)
+        wrap, states, hashes = mint_state_proof(w_, srs_oracle, seed, statement_overrides={k: st[k] for k in ("feature_flags", "prev_optional", "joint_combiner")})
+        return to_bytes(wrap, states, hashes), wrap, states, hashes
+    lookup_flags = [False, False, True, False, False, False, True, False]             # foreign_field_add + lookup
+    rc_flags = [True, False, False, False, False, True, False, False]                 # range_check0 + rot
+    install_step_index(gctx, fstep)
+    try:
+        a, wa, sa, ha = mint(feat_world, 6100, lookup_flags, True)
+        b, _, _, _ = mint(feat_world, 6200, rc_flags, False)
+        c, _, _, _ = mint(feat_world, 6300, [False] * 8, False)
+        assert m.lib.verify_state(*a) is True and m.lib.verify_state(*b) is True and m.lib.verify_state(*c) is True
+        assert m.lib.verify_state_checks(*a) == (ALL, ALL)
+        wt = dict(wa); wt["joint_combiner"] = wa["joint_combiner"] ^ 1                 # the joint combiner enters ft_eval0 AND the packing
+        assert m.lib.verify_state(*to_bytes(wt, sa, ha)) is False
+        wt = dict(wa); po = list(wa["prev_optional"]); e = po[6]; po[6] = ([(e[0][0] + 1) % PK.P], e[1]); wt["prev_optional"] = po     # the lookup aggregation evaluation
+        assert m.lib.verify_state(*to_bytes(wt, sa, ha)) is False
+        assert m.lib.verify_state_batch([a[0], b[0], c[0], a[0]], [a[1], b[1], c[1], a[1]]).tolist() == [1, 1, 1, 1]      # three evaluation shapes in one call
+        install_step_index(gctx, world["step"])                                        # the plain linearization: lookup features are refused, the others go on
+        assert m.lib.verify_state(*a) is False and m.lib.verify_state(*b) is False
+        passed, ran = m.lib.verify_state_checks(*a)
+        assert ran & 32 and not passed & 32
+    finally:
+        install_step_index(gctx, world["step"])
