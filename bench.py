@@ -290,7 +290,7 @@ def boundary_leg(m, local_rank: int, B: int, min_seconds: float = 2.0):
            "bytes_per_proof": len(P[0]) + len(Q[0]), "host_threads": int(os.environ.get("MINA_HOST_THREADS", min((os.cpu_count() or 2) // 2, 64))), "usable_cores": usable_cores(),
            "two_caller_threads": {"value": sum(counts) * B / el2, "unit": "proofs/s", "calls": sum(counts)},
            "entry_point": "mina_verify_state_batch (include/mina_verify.h): bincode MinaStateProof + MinaStatePubInputs bytes -> verdict bytes",
-           "poseidon_constants": m.lib.poseidon_params_name(),
+           "poseidon_constants": m.lib.poseidon_params_name(), "process": "a fresh process holding only libminaverify.so (no torch): the operator's verifier process",
            "note": "host bytes in, bools out: parsing, to_input flattening, ledger + consensus checks, pinned staging, PCIe both ways, the GPU job (folding "
                    "randomisers from the OS CSPRNG per chunk); one tampered proof in a warm-up call failed alone"}
     m.lib.verify_shutdown()
@@ -317,12 +317,27 @@ def main():
         args.mode = "kimchi"
     args.kimchi = args.mode != "prepared"                      # the wrap leg starts from the raw proof in both non-prepared modes
 
-    import torch
-    import mina_bridge_amd as m
-
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # The bytes -> bools leg runs FIRST, in a process of its own that holds only the library (no torch): the operator's verifier process.  It must
+    # not share the GPU with another process's queues (a second process holding 24 hardware queues makes the scheduler time-slice them: the
+    # same call took 288 ms instead of 55), and inside THIS process the 40-odd streams of the headline's context would populate the runtime's
+    # queue pool first (67 - 72 ms).  GPU_MAX_HW_QUEUES=16 there: with the system runtime a lone job's three legs overlap best at <= 16 (54.6 ms;
+    # 24: 68.4 ms), while the 16-lane pipeline of the headline below wants one queue per lane plus a few (24).
+    boundary = None
+    if not args.no_boundary and os.environ.get("MINA_BENCH_SHARE_GPU") != "1":
+        import subprocess
+        env = dict(os.environ); env["GPU_MAX_HW_QUEUES"] = os.environ.get("MINA_BOUNDARY_HW_QUEUES", "16")
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--boundary-only", str(local_rank), str(args.jobs)], capture_output=True, text=True, timeout=900, env=env)
+            boundary = json.loads(r.stdout.strip().split("\n")[-1]) if r.returncode == 0 and r.stdout.strip() else {"error": (r.stderr or r.stdout)[-400:]}
+        except (subprocess.TimeoutExpired, ValueError) as e:
+            boundary = {"error": repr(e)[:400]}
+
+    import torch
+    import mina_bridge_amd as m
+
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             print(f"bench.py: --gpus {args.gpus} without a torch.distributed.run launch (WORLD_SIZE=1): measuring 1 GPU", file=sys.stderr)
@@ -539,13 +554,12 @@ def main():
         if c5:
             c5["ms_per_step"] = float(t[2].item()); c5["value"] = 4096 / (c5["ms_per_step"] * 1e-3)
     ctx.close()
-    boundary = None
-    if not args.no_boundary and not share_gpu:                     # every rank drives its own GPU through the C-ABI boundary; rank 0 reports the sum
-        boundary = boundary_leg(m, local_rank, B)
-        if dist_on and "value" in boundary:
-            tb = torch.tensor([boundary["value"], boundary["two_caller_threads"]["value"]], dtype=torch.float64, device=dev)
-            dist.all_reduce(tb, op=dist.ReduceOp.SUM)
-            boundary["value_all_ranks"] = float(tb[0].item()); boundary["two_caller_threads"]["value_all_ranks"] = float(tb[1].item())
+    if boundary is not None and dist_on:                           # every rank ran its own leg on its own GPU; rank 0 reports the sum (a failed leg counts 0)
+        tb = torch.tensor([boundary.get("value", 0.0), boundary.get("two_caller_threads", {}).get("value", 0.0)], dtype=torch.float64, device=dev)
+        dist.all_reduce(tb, op=dist.ReduceOp.SUM)
+        boundary["value_all_ranks"] = float(tb[0].item())
+        if "two_caller_threads" in boundary:
+            boundary["two_caller_threads"]["value_all_ranks"] = float(tb[1].item())
 
     if rank == 0:
         def avg_us(p, name):
@@ -625,4 +639,8 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) >= 4 and sys.argv[1] == "--boundary-only":     # the bytes -> bools leg in a process of its own (see main): only the library, no torch
+        import mina_bridge_amd as _m
+        print(json.dumps(boundary_leg(_m, int(sys.argv[2]), int(sys.argv[3]))), flush=True)
+    else:
+        main()

@@ -322,33 +322,38 @@ static int leg_join(Lane &leg, Lane &into) {
     HIPC(hipStreamWaitEvent(into.stream, leg.ev_leg, 0));
     return MINA_OK;
 }
-// LI / LA: helper lanes of the wrap-proof leg and the accumulator leg (nullptr = everything on the current lane, in order)
-int mb_state_jobs_on_lane(mina_ctx *c, const mina_state_jobs *j, uint32_t *d_verdicts, uint32_t *d_flags, Lane *LI_, Lane *LA_, uint32_t *d_stmt_out) {
+// LI / LA: helper lanes of the wrap-proof leg and the accumulator leg (nullptr = everything on the current lane, in order); LS: a lane of
+// its own for the protocol-state leg as well (the boundary gives the chain and the hashes streams with disjoint CU masks, api_verify.hip)
+int mb_state_jobs_on_lane(mina_ctx *c, const mina_state_jobs *j, uint32_t *d_verdicts, uint32_t *d_flags, Lane *LI_, Lane *LA_, uint32_t *d_stmt_out, Lane *LS_) {
     Lane &L = *c->L;
     Lane *const L0 = c->L;
-    Lane *LI = L0, *LA = L0;
+    Lane *LI = L0, *LA = L0, *LS = L0;
     if (LI_ && LA_ && LI_ != L0 && LA_ != L0 && LI_ != LA_) {
         LI = LI_; LA = LA_;
+        if (LS_ && LS_ != L0 && LS_ != LI && LS_ != LA) LS = LS_;
         c->legs_forked = true;
         int frc;
-        if ((frc = leg_fork(c, *L0, *LI)) || (frc = leg_fork(c, *L0, *LA))) return frc;
+        if ((frc = leg_fork(c, *L0, *LI)) || (frc = leg_fork(c, *L0, *LA)) || (LS != L0 && (frc = leg_fork(c, *L0, *LS)))) return frc;
     }
     const size_t B = j->batch;
     int rc;
-    struct Unfork { mina_ctx *c; ~Unfork() { c->legs_forked = false; } } unfork{c};
-    if ((rc = L.st_ok.ensure(B * 4))) return rc;
+    struct Unfork { mina_ctx *c; Lane *l0; ~Unfork() { c->legs_forked = false; c->L = l0; } } unfork{c, L0};
+    Lane &S = *LS;                                              // ---- protocol-state leg
+    c->L = LS;
+    if ((rc = S.st_ok.ensure(B * 4))) return rc;
     if (j->with_states) {
         const size_t ns = B * MINA_STATES_PER_PROOF;
-        if ((rc = L.st_hashes.ensure(ns * 32))) return rc;
-        if ((rc = pstate_hash_dev(c, ns, (const uint32_t *)j->state_records, (const uint32_t *)j->state_nfields, L.st_hashes.as<uint32_t>(), nullptr))) return rc;
-        mb::pstate_chain_check_kernel<<<cdiv(B, 64), 64, 0, L.stream>>>((uint32_t)B, L.st_hashes.as<uint32_t>(), (const uint32_t *)j->expected_hashes,
-                                                                         (const uint32_t *)j->state_records, (const uint8_t *)j->precheck, L.st_ok.as<uint32_t>());
+        if ((rc = S.st_hashes.ensure(ns * 32))) return rc;
+        if ((rc = pstate_hash_dev(c, ns, (const uint32_t *)j->state_records, (const uint32_t *)j->state_nfields, S.st_hashes.as<uint32_t>(), nullptr))) return rc;
+        mb::pstate_chain_check_kernel<<<cdiv(B, 64), 64, 0, S.stream>>>((uint32_t)B, S.st_hashes.as<uint32_t>(), (const uint32_t *)j->expected_hashes,
+                                                                         (const uint32_t *)j->state_records, (const uint8_t *)j->precheck, S.st_ok.as<uint32_t>());
     } else {
         // no state leg: chain_ok = all ones
         if (j->precheck) return fail(MINA_ERR_ARG, "precheck needs the protocol-state section");
-        mb::fill_u32_kernel<<<cdiv(B, 256), 256, 0, L.stream>>>((uint32_t)B, 1u, L.st_ok.as<uint32_t>());
+        mb::fill_u32_kernel<<<cdiv(B, 256), 256, 0, S.stream>>>((uint32_t)B, 1u, S.st_ok.as<uint32_t>());
     }
     HIPC(hipGetLastError());
+    c->L = L0;
     const uint32_t *comm_override = nullptr;
     uint32_t *ipa_v = nullptr, *acc_v = nullptr;
     uint32_t *kimchi_bad = nullptr; const uint32_t *stmt_ok = nullptr;
@@ -433,8 +438,8 @@ int mb_state_jobs_on_lane(mina_ctx *c, const mina_state_jobs *j, uint32_t *d_ver
     }
     if (LA != LI && (rc = accumulator_leg())) { c->L = L0; return rc; }
     c->L = L0;
-    if (LI != L0) { int jrc; if ((jrc = leg_join(*LI, *L0)) || (jrc = leg_join(*LA, *L0))) return jrc; }
-    mb::state_job_verdict_kernel<<<cdiv(B, 64), 64, 0, L.stream>>>((uint32_t)B, L.st_ok.as<uint32_t>(), ipa_v, acc_v, kimchi_bad, stmt_ok, d_verdicts, d_flags, d_stmt_out);
+    if (LI != L0) { int jrc; if ((jrc = leg_join(*LI, *L0)) || (jrc = leg_join(*LA, *L0)) || (LS != L0 && (jrc = leg_join(*LS, *L0)))) return jrc; }
+    mb::state_job_verdict_kernel<<<cdiv(B, 64), 64, 0, L.stream>>>((uint32_t)B, S.st_ok.as<uint32_t>(), ipa_v, acc_v, kimchi_bad, stmt_ok, d_verdicts, d_flags, d_stmt_out);
     HIPC(hipGetLastError());
     return MINA_OK;
 }
@@ -446,7 +451,7 @@ extern "C" int mina_state_job_batch_dev(mina_ctx *c, const mina_state_jobs *jobs
     if (!c->have_state_salts && jobs->with_states) return fail(MINA_ERR_STATE, "call mina_state_jobs_prepare first");
     HIPC(hipSetDevice(c->device));
     c->next_lane();
-    return mb_state_jobs_on_lane(c, jobs, (uint32_t *)d_verdicts, (uint32_t *)d_flags, nullptr, nullptr, nullptr);
+    return mb_state_jobs_on_lane(c, jobs, (uint32_t *)d_verdicts, (uint32_t *)d_flags, nullptr, nullptr, nullptr, nullptr);
 }
 
 // host-buffer form: one upload of every section, the pipeline, one download; when a folded check fails the proofs are
@@ -503,7 +508,7 @@ extern "C" int mina_state_job_batch(mina_ctx *c, const mina_state_jobs *jobs, ui
     uint32_t *dv = L.st_verdicts.as<uint32_t>(), *df = dv + B, *ds = df + 4;
     // small, latency-bound batches: the three independent legs go to three lanes (lane 0 plus two helpers), joined by events
     const bool split = B <= 1024 && c->nlanes == 1;
-    if ((rc = mb_state_jobs_on_lane(c, &d, dv, df, split ? &c->lanes[1] : nullptr, split ? &c->lanes[2] : nullptr, ds))) return rc;
+    if ((rc = mb_state_jobs_on_lane(c, &d, dv, df, split ? &c->lanes[1] : nullptr, split ? &c->lanes[2] : nullptr, ds, nullptr))) return rc;
     std::vector<uint32_t> hv(2 * B + 4);
     if ((rc = d2h_sync(c, hv.data(), L.st_verdicts, (2 * B + 4) * 4))) return rc;
     std::vector<uint8_t> stmt_each(B); for (size_t b = 0; b < B; ++b) stmt_each[b] = hv[B + 4 + b] ? 1 : 0;
@@ -514,7 +519,7 @@ extern "C" int mina_state_job_batch(mina_ctx *c, const mina_state_jobs *jobs, ui
     {
         mina_state_jobs only = d; only.with_ipa = 0; only.with_accumulator = 0; only.npub = 0; only.kimchi = nullptr;
         if (only.with_states) {
-            if ((rc = mb_state_jobs_on_lane(c, &only, dv, df, nullptr, nullptr, nullptr))) return rc;
+            if ((rc = mb_state_jobs_on_lane(c, &only, dv, df, nullptr, nullptr, nullptr, nullptr))) return rc;
             if ((rc = d2h_sync(c, hv.data(), L.st_verdicts, B * 4))) return rc;
             for (size_t b = 0; b < B; ++b) chain_each[b] = hv[b] ? 1 : 0;
         }
@@ -576,7 +581,7 @@ extern "C" int mina_state_job_batch(mina_ctx *c, const mina_state_jobs *jobs, ui
                     if (ipa_leg && rows_ok) { if ((r = mb_ipa_recheck_rows(c, lo, cnt, flags_at[q]))) return r; continue; }
                     mina_state_jobs sj = slice(d, lo, cnt);
                     if (ipa_leg) sj.with_accumulator = 0; else { sj.with_ipa = 0; sj.npub = 0; sj.kimchi = nullptr; }
-                    if ((r = mb_state_jobs_on_lane(c, &sj, v, flags_at[q], nullptr, nullptr, nullptr))) return r;
+                    if ((r = mb_state_jobs_on_lane(c, &sj, v, flags_at[q], nullptr, nullptr, nullptr, nullptr))) return r;
                 }
                 for (size_t q = 0; q < w; ++q) {
                     uint32_t f[4];

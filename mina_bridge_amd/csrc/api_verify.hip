@@ -33,7 +33,7 @@ int mb_kimchi_available(mina_ctx *c);                                           
 int mb_poseidon_env_params(mina_ctx *c);                                                                                               // api_loaders.hip
 int mb_step_index_feature_aware(mina_ctx *c);                                                                                         // api_pickles.hip
 int mb_step_index_installed(mina_ctx *c);                                                                                              // api_pickles.hip
-int mb_state_jobs_on_lane(mina_ctx *c, const mina_state_jobs *j, uint32_t *d_verdicts, uint32_t *d_flags, Lane *LI, Lane *LA, uint32_t *d_stmt_out);   // api_state.hip
+int mb_state_jobs_on_lane(mina_ctx *c, const mina_state_jobs *j, uint32_t *d_verdicts, uint32_t *d_flags, Lane *LI, Lane *LA, uint32_t *d_stmt_out, Lane *LS);   // api_state.hip
 
 extern "C" const char *mina_poseidon_params_name(void) { return MB_POSEIDON_SET_NAME; }
 // the compiled-in tables are a surrogate while their name says UNPINNED: a context running on them is flagged (mina_verify_state refuses)
@@ -436,11 +436,12 @@ int run_device(Device &D, const CallIn &in, const std::vector<size_t> &idx, uint
         if (!found) return MINA_OK;                                                          // nothing parses
     }
     // read per call (tests force tiny chunks / shards to drive the pipeline's slot recycling with a handful of proofs)
-    // Measured on one MI355X, 8192 full-size proofs per call (tools/boundary_sweep.sh): ONE chunk 64 - 69 ms, 2 x 4096: 74 ms, 8 x 1024: 87 ms,
-    // 16 x 512: 92 ms -- a job is a ~30 ms dependent chain of small kernels whatever its size, and jobs that start together do not fill each
-    // other's gaps the way the staggered steps of a long-running pipeline do.  So: one chunk up to 8192 proofs, chunks of 4096 beyond (their
-    // parsing and upload then overlap the previous chunk's job, and one bad proof costs a culprit search over 4096, not over everything).
-    const size_t chunk_target = getenv("MINA_VERIFY_CHUNK") ? (size_t)std::max(1L, atol(getenv("MINA_VERIFY_CHUNK"))) : (size_t)4096;
+    // Measured on one MI355X (tools/boundary_sweep.sh, bench.py --boundary-only): 8192 full-size proofs as ONE chunk 55 - 58 ms, 2 x 4096: 74 ms,
+    // 8 x 1024: 87 ms, 16 x 512: 92 ms -- a job is a ~30 ms dependent chain of small kernels whatever its size, and jobs that start together do
+    // not fill each other's gaps the way the staggered steps of a long-running pipeline do.  Bigger calls in chunks of 8192 (16 384 proofs: 92 ms
+    // against 121 ms in chunks of 4096; 65 536: 305 against 336 ms = 215 k proofs/s): their parsing and upload overlap the previous chunk's job,
+    // and one bad proof costs a culprit search over 8192, not over everything.
+    const size_t chunk_target = getenv("MINA_VERIFY_CHUNK") ? (size_t)std::max(1L, atol(getenv("MINA_VERIFY_CHUNK"))) : (size_t)8192;
     const size_t single_max = getenv("MINA_VERIFY_SINGLE_MAX") ? (size_t)std::max(1L, atol(getenv("MINA_VERIFY_SINGLE_MAX"))) : (size_t)8192;
     const size_t nchunks = m <= single_max ? 1 : (m + chunk_target - 1) / chunk_target;
     std::vector<Chunk> chunks(nchunks);
@@ -521,9 +522,29 @@ int run_device(Device &D, const CallIn &in, const std::vector<size_t> &idx, uint
         uint32_t *dv = (uint32_t *)(dbase + lay.out_off()), *df = dv + ch.n, *ds = df + 4;
         // few chunks in flight: the three legs of a job (state hashes / wrap proof / accumulator) go to three streams
         const unsigned split_max = getenv("MINA_VERIFY_SPLIT_MAX") ? (unsigned)atoi(getenv("MINA_VERIFY_SPLIT_MAX")) : 2u;
-        Lane *LI = nullptr, *LA = nullptr;
-        if (D.inflight.load() <= split_max && ch.slot_ix < 8) { LI = &c->lanes[16 + 2 * ch.slot_ix]; LA = &c->lanes[17 + 2 * ch.slot_ix]; }
-        rc = mb_state_jobs_on_lane(c, &js.j, dv, df, LI, LA, ds);
+        Lane *LI = nullptr, *LA = nullptr, *LS = nullptr;
+        if (D.inflight.load() <= split_max && ch.slot_ix < 5) {
+            LI = &c->lanes[16 + 3 * ch.slot_ix]; LA = &c->lanes[17 + 3 * ch.slot_ix]; LS = &c->lanes[18 + 3 * ch.slot_ix];
+            // Alone on the GPU a job is a latency-bound chain of small kernels (~390 waves each, one behind the other) beside 20 ms of chip-filling
+            // hashes; where their waves share a SIMD both run at half speed, and the call waits for the chain (rocprofv3 timeline: the statement
+            // digests 10.7 ms beside the hashes against 4.1 ms alone).  So the chain's stream and the hashes' stream get DISJOINT CU masks: the chain
+            // `chain_cus` CUs -- 128 = a SIMD per wave; fewer and a kernel lasts as long as its doubled-up SIMDs: 96 CUs cost +16 ms -- the hashes the
+            // rest (bit i of a mask = CU i / 8 of XCD i % 8, tools/probes/cumask_probe.hip).  8192 proofs per call: 62.6 -> 57.7 ms.
+            const uint32_t chain_cus = getenv("MINA_VERIFY_CHAIN_CUS") ? (uint32_t)atoi(getenv("MINA_VERIFY_CHAIN_CUS")) : 128u;
+            int ncu = 0; (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device);
+            if (chain_cus > 0 && chain_cus < (uint32_t)ncu && ncu <= 256) {
+                const uint32_t period = getenv("MINA_VERIFY_CU_PERIOD") ? (uint32_t)atoi(getenv("MINA_VERIFY_CU_PERIOD")) : 256u;
+                auto masked = [&](Lane &ln, bool chain) -> int {
+                    if (ln.stream) return MINA_OK;
+                    uint32_t mk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                    for (uint32_t b2 = 0; b2 < (uint32_t)ncu; ++b2) { const bool in_chain = (b2 % period) < chain_cus * period / 256; if (in_chain == chain) mk[b2 >> 5] |= 1u << (b2 & 31); }
+                    HIPC(hipExtStreamCreateWithCUMask(&ln.stream, 8, mk));
+                    return MINA_OK;
+                };
+                if ((rc = masked(*LI, true)) || (rc = masked(*LS, false))) return rc;
+            } else LS = nullptr;
+        }
+        rc = mb_state_jobs_on_lane(c, &js.j, dv, df, LI, LA, ds, LS);
         c->hash_piece_waves = 0;
         c->use_lane0();
         if (rc) return rc;
