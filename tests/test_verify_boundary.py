@@ -604,3 +604,40 @@ def test_boundary_accepts_lookup_features_only_with_a_feature_aware_step_index(w
         assert ran & 32 and not passed & 32
     finally:
         install_step_index(gctx, world["step"])
+
+
+def test_concurrent_batch_callers_share_the_pipeline(world, srs_oracle):
+    """mina_verify_state_batch from several threads at once (a batcher's tasks): the callers share the device's slots and lanes, a call whose
+    chunk fails its folded check runs its culprit search while other callers' chunks are in flight -- every caller gets exactly its verdicts"""
+    import threading
+    import mina_bridge_amd as m
+    minted = [mint_state_proof(world, srs_oracle, 7000 + i) for i in range(3)]
+    good = [to_bytes(*x) for x in minted]
+    w_bad = copy.deepcopy(minted[0][0]); w_bad["z1"] = (w_bad["z1"] + 1) % (1 << 254)
+    bad = to_bytes(w_bad, minted[0][1], minted[0][2])
+    rng = random.Random(99)
+    plans = []
+    for t in range(6):
+        calls = []
+        for _ in range(4):
+            n = rng.choice([1, 3, 9, 20])
+            items = [(bad, 0) if rng.randrange(5) == 0 else (good[rng.randrange(3)], 1) for _ in range(n)]
+            calls.append(items)
+        plans.append(calls)
+    errors = []
+    keep = {k: os.environ.get(k) for k in ("MINA_VERIFY_CHUNK", "MINA_VERIFY_SINGLE_MAX")}
+    os.environ["MINA_VERIFY_CHUNK"] = "4"; os.environ["MINA_VERIFY_SINGLE_MAX"] = "6"          # some calls in several chunks
+    try:
+        def worker(t):
+            for items in plans[t]:
+                got = m.lib.verify_state_batch([x[0][0] for x in items], [x[0][1] for x in items]).tolist()
+                if got != [x[1] for x in items]:
+                    errors.append((t, got, [x[1] for x in items]))
+        th = [threading.Thread(target=worker, args=(t,)) for t in range(len(plans))]
+        for t in th: t.start()
+        for t in th: t.join()
+    finally:
+        for k, v in keep.items():
+            if v is None: os.environ.pop(k, None)
+            else: os.environ[k] = v
+    assert not errors, errors[:2]
