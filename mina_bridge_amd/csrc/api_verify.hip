@@ -571,7 +571,7 @@ int run_device(Device &D, const CallIn &in, const std::vector<size_t> &idx, uint
             if (s < 0) break;
             Chunk &ch = chunks[next_submit];
             ch.slot = &D.slots[s]; ch.slot_ix = s;
-            if (ch.slot->host.ensure(lay.total) || ch.slot->out.ensure(Layout::out_bytes(lay.cap))) { rc_all = MINA_ERR_HIP; break; }
+            if (ch.slot->host.ensure(lay.total) || ch.slot->out.ensure(Layout::out_bytes(lay.cap))) { release(s); ch.slot = nullptr; ch.slot_ix = -1; rc_all = MINA_ERR_HIP; break; }
             uint8_t *hbase = (uint8_t *)ch.slot->host.p;
             Chunk *chp = &ch;
             ch.job = mb_pool_submit(ch.n, [&, chp, hbase](size_t b) {
