@@ -322,6 +322,23 @@ static int leg_join(Lane &leg, Lane &into) {
     HIPC(hipStreamWaitEvent(into.stream, leg.ev_leg, 0));
     return MINA_OK;
 }
+// Early start of a job's protocol-state leg: the boundary (api_verify.hip) streams the records of a chunk to the GPU while the rest of the
+// chunk is still being parsed, and queues the hashes of states [lo, lo + cnt) -- of a job of `ns_total` states whose state leg will run on
+// lane LS -- behind `after` (the upload of those records).  mb_state_jobs_on_lane then takes `c->state_hashes_early` states as hashed.
+int mb_state_hashes_early(mina_ctx *c, Lane *LS, size_t ns_total, size_t lo, size_t cnt, const uint32_t *d_records, const uint32_t *d_nfields, hipEvent_t after) {
+    if (!LS || lo + cnt > ns_total) return fail(MINA_ERR_ARG, "bad early state range");
+    if (!c->have_state_salts) return fail(MINA_ERR_STATE, "call mina_state_jobs_prepare first");
+    if (!LS->stream) HIPC(hipStreamCreateWithFlags(&LS->stream, hipStreamNonBlocking));
+    int rc;
+    if ((rc = LS->st_hashes.ensure(ns_total * 32))) return rc;
+    if (after) HIPC(hipStreamWaitEvent(LS->stream, after, 0));
+    Lane *const L0 = c->L;
+    c->L = LS;
+    rc = pstate_hash_dev(c, cnt, d_records + lo * MINA_PSTATE_SLOTS * 8, d_nfields + lo, LS->st_hashes.as<uint32_t>() + lo * 8, nullptr);
+    c->L = L0;
+    return rc;
+}
+
 // LI / LA: helper lanes of the wrap-proof leg and the accumulator leg (nullptr = everything on the current lane, in order); LS: a lane of
 // its own for the protocol-state leg as well (the boundary gives the chain and the hashes streams with disjoint CU masks, api_verify.hip)
 int mb_state_jobs_on_lane(mina_ctx *c, const mina_state_jobs *j, uint32_t *d_verdicts, uint32_t *d_flags, Lane *LI_, Lane *LA_, uint32_t *d_stmt_out, Lane *LS_) {
@@ -344,7 +361,10 @@ int mb_state_jobs_on_lane(mina_ctx *c, const mina_state_jobs *j, uint32_t *d_ver
     if (j->with_states) {
         const size_t ns = B * MINA_STATES_PER_PROOF;
         if ((rc = S.st_hashes.ensure(ns * 32))) return rc;
-        if ((rc = pstate_hash_dev(c, ns, (const uint32_t *)j->state_records, (const uint32_t *)j->state_nfields, S.st_hashes.as<uint32_t>(), nullptr))) return rc;
+        const size_t early = std::min(c->state_hashes_early, ns);      // already queued on this lane by mb_state_hashes_early
+        c->state_hashes_early = 0;
+        if (early < ns && (rc = pstate_hash_dev(c, ns - early, (const uint32_t *)j->state_records + early * MINA_PSTATE_SLOTS * 8, (const uint32_t *)j->state_nfields + early,
+                                                S.st_hashes.as<uint32_t>() + early * 8, nullptr))) return rc;
         mb::pstate_chain_check_kernel<<<cdiv(B, 64), 64, 0, S.stream>>>((uint32_t)B, S.st_hashes.as<uint32_t>(), (const uint32_t *)j->expected_hashes,
                                                                          (const uint32_t *)j->state_records, (const uint8_t *)j->precheck, S.st_ok.as<uint32_t>());
     } else {

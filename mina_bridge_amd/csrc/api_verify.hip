@@ -34,6 +34,7 @@ int mb_poseidon_env_params(mina_ctx *c);                                        
 int mb_step_index_feature_aware(mina_ctx *c);                                                                                         // api_pickles.hip
 int mb_step_index_installed(mina_ctx *c);                                                                                              // api_pickles.hip
 int mb_state_jobs_on_lane(mina_ctx *c, const mina_state_jobs *j, uint32_t *d_verdicts, uint32_t *d_flags, Lane *LI, Lane *LA, uint32_t *d_stmt_out, Lane *LS);   // api_state.hip
+int mb_state_hashes_early(mina_ctx *c, Lane *LS, size_t ns_total, size_t lo, size_t cnt, const uint32_t *d_records, const uint32_t *d_nfields, hipEvent_t after);     // api_state.hip
 
 extern "C" const char *mina_poseidon_params_name(void) { return MB_POSEIDON_SET_NAME; }
 // the compiled-in tables are a surrogate while their name says UNPINNED: a context running on them is flagged (mina_verify_state refuses)
@@ -54,7 +55,7 @@ extern "C" int mina_poseidon_install_default_params(mina_ctx *c) {
 // on the host); merged single-proof jobs are dealt round-robin.
 namespace {
 constexpr int NSLOT = 16;                  // chunks in flight per device: slot s runs on lane s of the context (helper lanes 16.. for forked legs)
-struct Slot { PinnedBuf host, out; DevBuf dev; hipEvent_t ev = nullptr; hipEvent_t tev[3] = {nullptr, nullptr, nullptr}; bool busy = false; };
+struct Slot { PinnedBuf host, out; DevBuf dev; hipEvent_t ev = nullptr; hipEvent_t tev[3] = {nullptr, nullptr, nullptr}; std::vector<hipEvent_t> rec_ev; bool busy = false; };
 struct Device {
     mina_ctx *c = nullptr; int ordinal = 0;
     std::mutex mu;                         // serialises every call into `c` (a context has ONE current-lane cursor)
@@ -415,7 +416,14 @@ Config read_config(Device &D, uint32_t flags) {
 
 struct CallIn { const uint8_t *const *proofs; const size_t *proof_lens; const uint8_t *const *pubs; const size_t *pub_lens; };
 
-struct Chunk { size_t lo = 0, n = 0; Slot *slot = nullptr; int slot_ix = -1; std::shared_ptr<MbPoolJob> job; std::vector<HostBits> hb; bool issued = false, skipped = false, harvested = false; };
+struct Chunk {
+    size_t lo = 0, n = 0; Slot *slot = nullptr; int slot_ix = -1; std::shared_ptr<MbPoolJob> job; std::vector<HostBits> hb; bool issued = false, skipped = false, harvested = false;
+    // streamed form (big chunks): the entries are parsed in `nsub` runs of `sub`; the records of a run go to the GPU, and their hashes are queued, as soon as it is parsed
+    size_t sub = 0, nsub = 0; std::unique_ptr<std::atomic<uint32_t>[]> sub_left; std::mutex mu; std::condition_variable cv;
+    size_t streamed = 0;                      // entries whose records are on their way to the GPU
+    size_t hashed = 0;                        // ... and whose 17 state hashes are queued on LS
+    bool legs_set = false, early_started = false; Lane *LI = nullptr, *LA = nullptr, *LS = nullptr;
+};
 
 const bool g_timing = getenv("MINA_VERIFY_TIMING") != nullptr;
 double ms_since(std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); }
@@ -453,6 +461,9 @@ int run_device(Device &D, const CallIn &in, const std::vector<size_t> &idx, uint
     const size_t chunk_target = getenv("MINA_VERIFY_CHUNK") ? (size_t)std::max(1L, atol(getenv("MINA_VERIFY_CHUNK"))) : (size_t)8192;
     const size_t single_max = getenv("MINA_VERIFY_SINGLE_MAX") ? (size_t)std::max(1L, atol(getenv("MINA_VERIFY_SINGLE_MAX"))) : (size_t)8192;
     const size_t nchunks = m <= single_max ? 1 : (m + chunk_target - 1) / chunk_target;
+    // streamed form of a chunk (stream_records below): from `early_min` entries, in runs of `early_sub` (0 = off)
+    const size_t early_min = getenv("MINA_VERIFY_EARLY_MIN") ? (size_t)std::max(1L, atol(getenv("MINA_VERIFY_EARLY_MIN"))) : (size_t)2048;
+    const size_t early_sub = getenv("MINA_VERIFY_EARLY_SUB") ? (size_t)std::max(0L, atol(getenv("MINA_VERIFY_EARLY_SUB"))) : (size_t)1024;
     std::vector<Chunk> chunks(nchunks);
     for (size_t q = 0; q < nchunks; ++q) { chunks[q].lo = m * q / nchunks; chunks[q].n = m * (q + 1) / nchunks - chunks[q].lo; chunks[q].hb.resize(chunks[q].n); }
     const size_t cap = (m + nchunks - 1) / nchunks;
@@ -494,19 +505,18 @@ int run_device(Device &D, const CallIn &in, const std::vector<size_t> &idx, uint
                 else { int rc = fallback(ch); if (rc && !rc_all) rc_all = rc; }
             } else if (!rc_all) rc_all = MINA_ERR_HIP;
         }
+        else if (ch.early_started) {                                  // the job was never queued, but uploads / hashes of the streamed runs may be: nothing of them may outlive the slot
+            std::lock_guard<std::mutex> lk(D.mu);
+            (void)hipSetDevice(c->device);
+            if (c->lanes[ch.slot_ix].stream) (void)hipStreamSynchronize(c->lanes[ch.slot_ix].stream);
+            if (ch.LS && ch.LS->stream) (void)hipStreamSynchronize(ch.LS->stream);
+        }
         if (ch.slot_ix >= 0) release(ch.slot_ix);
         D.inflight.fetch_sub(1);
     };
 
-    auto issue = [&](Chunk &ch) -> int {
-        uint8_t *hbase = (uint8_t *)ch.slot->host.p;
-        // host side of the chunk: collect the other shapes, patch what cannot go to the GPU as it is
-        size_t donor = SIZE_MAX;
-        for (size_t b = 0; b < ch.n; ++b) { if (ch.hb[b].parsed && ch.hb[b].shape && donor == SIZE_MAX) donor = b; if (ch.hb[b].deferred) deferred.push_back(idx[ch.lo + b]); }
-        if (donor == SIZE_MAX) { ch.skipped = true; return MINA_OK; }                         // nothing of this chunk can pass
-        for (size_t b = 0; b < ch.n; ++b) if (!(ch.hb[b].parsed && ch.hb[b].shape)) { copy_entry(lay, hbase, b, donor); *lay.at(hbase, S_PRE, b) = 0; }
-        if (!draw_randomisers(sh, lay, hbase, ch.n)) return fail(MINA_ERR_STATE, "no entropy for the folding randomisers");
-        std::lock_guard<std::mutex> lk(D.mu);
+    // device side of a chunk's slot, before anything is queued on it (idempotent).  Caller holds D.mu.
+    auto setup_slot = [&](Chunk &ch) -> int {
         HIPC(hipSetDevice(c->device));
         int rc;
         const uint32_t prep_key = ((sh.k ? sh.k : 15u) << 16) | (sh.statements ? 40u : 0u);      // the Lagrange table belongs to (domain, npub): another index -> prepare again
@@ -519,41 +529,115 @@ int run_device(Device &D, const CallIn &in, const std::vector<size_t> &idx, uint
         if (!S.ev) HIPC(hipEventCreateWithFlags(&S.ev, hipEventDisableTiming));
         Lane &L = c->lanes[ch.slot_ix];
         if (!L.stream) HIPC(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
-        // the lane forms of the sponge kernels follow the work in flight on the device (ctx.h use_coop*)
+        if (g_timing) for (auto &e : S.tev) if (!e) HIPC(hipEventCreate(&e));
+        return MINA_OK;
+    };
+    // the lanes of a chunk's job, decided once per chunk.  Caller holds D.mu.
+    auto setup_legs = [&](Chunk &ch) -> int {
+        if (ch.legs_set) return MINA_OK;
+        ch.legs_set = true;
+        // few chunks in flight: the three legs of a job (state hashes / wrap proof / accumulator) go to three streams
+        const unsigned split_max = getenv("MINA_VERIFY_SPLIT_MAX") ? (unsigned)atoi(getenv("MINA_VERIFY_SPLIT_MAX")) : 2u;
+        if (!(D.inflight.load() <= split_max && ch.slot_ix < 5)) return MINA_OK;
+        Lane *LI = &c->lanes[16 + 3 * ch.slot_ix], *LA = &c->lanes[17 + 3 * ch.slot_ix], *LS = &c->lanes[18 + 3 * ch.slot_ix];
+        // Alone on the GPU a job is a latency-bound chain of small kernels (~390 waves each, one behind the other) beside 20 ms of chip-filling
+        // hashes; where their waves share a SIMD both run at half speed, and the call waits for the chain (rocprofv3 timeline: the statement
+        // digests 10.7 ms beside the hashes against 4.1 ms alone).  So the chain's stream and the hashes' stream get DISJOINT CU masks: the chain
+        // `chain_cus` CUs -- 128 = a SIMD per wave; fewer and a kernel lasts as long as its doubled-up SIMDs: 96 CUs cost +16 ms -- the hashes the
+        // rest (bit i of a mask = CU i / 8 of XCD i % 8, tools/probes/cumask_probe.hip).  8192 proofs per call: 62.6 -> 57.7 ms.
+        const uint32_t chain_cus = getenv("MINA_VERIFY_CHAIN_CUS") ? (uint32_t)atoi(getenv("MINA_VERIFY_CHAIN_CUS")) : 128u;
+        int ncu = 0; (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device);
+        if (chain_cus > 0 && chain_cus < (uint32_t)ncu && ncu <= 256) {
+            const uint32_t period = getenv("MINA_VERIFY_CU_PERIOD") ? (uint32_t)atoi(getenv("MINA_VERIFY_CU_PERIOD")) : 256u;
+            auto masked = [&](Lane &ln, bool chain) -> int {
+                if (ln.stream) return MINA_OK;
+                uint32_t mk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (uint32_t b2 = 0; b2 < (uint32_t)ncu; ++b2) { const bool in_chain = (b2 % period) < chain_cus * period / 256; if (in_chain == chain) mk[b2 >> 5] |= 1u << (b2 & 31); }
+                HIPC(hipExtStreamCreateWithCUMask(&ln.stream, 8, mk));
+                return MINA_OK;
+            };
+            int rc;
+            if ((rc = masked(*LI, true)) || (rc = masked(*LS, false))) return rc;
+        } else LS = nullptr;
+        ch.LI = LI; ch.LA = LA; ch.LS = LS;
+        return MINA_OK;
+    };
+    auto lane_forms = [&]() {       // the lane forms of the sponge kernels follow the work in flight on the device (ctx.h use_coop*)
         c->nlanes = (int)std::max(1u, std::min<unsigned>(D.inflight.load(), NSLOT));
         c->hash_piece_waves = getenv("MINA_VERIFY_HASH_PIECE") ? (uint32_t)atoi(getenv("MINA_VERIFY_HASH_PIECE")) : 1024u;
+    };
+
+    // Streamed form of a big chunk: as soon as a run of its entries is parsed (and every entry of the run is well-formed), the run's protocol-state
+    // records -- 34 KB of an entry's 47 KB -- go to the GPU and their hashes are queued on the state leg's lane, while the pool is still parsing the
+    // rest.  The state leg is the long one of a job running alone (its 128 CUs, ~40 ms for 8192 proofs): it now starts ~1.5 ms into the call instead
+    // of behind the parsing and the whole upload (~13 ms).  A run holding an entry that needs patching ends the streaming: the rest goes up in issue().
+    auto stream_records = [&](Chunk &ch) -> int {
+        if (!ch.nsub) return MINA_OK;
+        uint8_t *hbase = (uint8_t *)ch.slot->host.p;
+        Slot &S = *ch.slot;
+        for (size_t r = 0; r < ch.nsub; ++r) {
+            { std::unique_lock<std::mutex> lk(ch.mu); ch.cv.wait(lk, [&] { return ch.sub_left[r].load() == 0; }); }
+            const size_t lo = r * ch.sub, hi = std::min(ch.n, lo + ch.sub);
+            bool good = true;
+            for (size_t b = lo; b < hi && good; ++b) good = ch.hb[b].parsed && ch.hb[b].shape;
+            if (!good) break;
+            std::lock_guard<std::mutex> lk(D.mu);
+            int rc;
+            if ((rc = setup_slot(ch)) || (rc = setup_legs(ch))) return rc;
+            Lane &L = c->lanes[ch.slot_ix];
+            uint8_t *dbase = S.dev.as<uint8_t>();
+            if (S.rec_ev.size() < ch.nsub) S.rec_ev.resize(ch.nsub, nullptr);
+            if (!S.rec_ev[r]) HIPC(hipEventCreateWithFlags(&S.rec_ev[r], hipEventDisableTiming));
+            if (g_timing && !ch.early_started) HIPC(hipEventRecord(S.tev[0], L.stream));
+            ch.early_started = true;
+            HIPC(hipMemcpyAsync(lay.at(dbase, S_REC, lo), lay.at(hbase, S_REC, lo), (hi - lo) * lay.stride[S_REC], hipMemcpyHostToDevice, L.stream));
+            HIPC(hipMemcpyAsync(lay.at(dbase, S_NF, lo), lay.at(hbase, S_NF, lo), (hi - lo) * lay.stride[S_NF], hipMemcpyHostToDevice, L.stream));
+            HIPC(hipEventRecord(S.rec_ev[r], L.stream));
+            ch.streamed = hi;
+            if (ch.LS) {
+                lane_forms();
+                rc = mb_state_hashes_early(c, ch.LS, ch.n * MINA_STATES_PER_PROOF, lo * MINA_STATES_PER_PROOF, (hi - lo) * MINA_STATES_PER_PROOF,
+                                           (const uint32_t *)lay.at(dbase, S_REC, 0), (const uint32_t *)lay.at(dbase, S_NF, 0), S.rec_ev[r]);
+                c->hash_piece_waves = 0;
+                c->use_lane0();
+                if (rc) return rc;
+                ch.hashed = hi;
+            }
+        }
+        return MINA_OK;
+    };
+
+    auto issue = [&](Chunk &ch) -> int {
+        uint8_t *hbase = (uint8_t *)ch.slot->host.p;
+        // host side of the chunk: collect the other shapes, patch what cannot go to the GPU as it is
+        size_t donor = SIZE_MAX;
+        for (size_t b = 0; b < ch.n; ++b) { if (ch.hb[b].parsed && ch.hb[b].shape && donor == SIZE_MAX) donor = b; if (ch.hb[b].deferred) deferred.push_back(idx[ch.lo + b]); }
+        if (donor == SIZE_MAX) { ch.skipped = true; return MINA_OK; }                         // nothing of this chunk can pass
+        for (size_t b = ch.streamed; b < ch.n; ++b) if (!(ch.hb[b].parsed && ch.hb[b].shape)) { copy_entry(lay, hbase, b, donor); *lay.at(hbase, S_PRE, b) = 0; }   // streamed runs hold no such entry
+        if (!draw_randomisers(sh, lay, hbase, ch.n)) return fail(MINA_ERR_STATE, "no entropy for the folding randomisers");
+        std::lock_guard<std::mutex> lk(D.mu);
+        int rc;
+        if ((rc = setup_slot(ch)) || (rc = setup_legs(ch))) return rc;
+        Slot &S = *ch.slot;
+        Lane &L = c->lanes[ch.slot_ix];
+        lane_forms();
         c->L = &L;
         uint8_t *dbase = S.dev.as<uint8_t>();
-        if (g_timing) { for (auto &e : S.tev) if (!e) HIPC(hipEventCreate(&e)); HIPC(hipEventRecord(S.tev[0], L.stream)); }
-        HIPC(hipMemcpyAsync(dbase, hbase, lay.total, hipMemcpyHostToDevice, L.stream));
+        if (g_timing && !ch.early_started) HIPC(hipEventRecord(S.tev[0], L.stream));
+        if (ch.streamed == 0) HIPC(hipMemcpyAsync(dbase, hbase, lay.total, hipMemcpyHostToDevice, L.stream));
+        else {                                                                                 // what the streamed runs have not taken
+            if (ch.streamed < ch.n) {
+                HIPC(hipMemcpyAsync(lay.at(dbase, S_REC, ch.streamed), lay.at(hbase, S_REC, ch.streamed), (ch.n - ch.streamed) * lay.stride[S_REC], hipMemcpyHostToDevice, L.stream));
+                HIPC(hipMemcpyAsync(lay.at(dbase, S_NF, ch.streamed), lay.at(hbase, S_NF, ch.streamed), (ch.n - ch.streamed) * lay.stride[S_NF], hipMemcpyHostToDevice, L.stream));
+            }
+            HIPC(hipMemcpyAsync(dbase + lay.off[S_EXP], hbase + lay.off[S_EXP], lay.total - lay.off[S_EXP], hipMemcpyHostToDevice, L.stream));
+        }
         if (g_timing) HIPC(hipEventRecord(S.tev[1], L.stream));
         JobStructs js; make_jobs(sh, lay, dbase, ch.n, true, true, true, js);
         uint32_t *dv = (uint32_t *)(dbase + lay.out_off()), *df = dv + ch.n, *ds = df + 4;
-        // few chunks in flight: the three legs of a job (state hashes / wrap proof / accumulator) go to three streams
-        const unsigned split_max = getenv("MINA_VERIFY_SPLIT_MAX") ? (unsigned)atoi(getenv("MINA_VERIFY_SPLIT_MAX")) : 2u;
-        Lane *LI = nullptr, *LA = nullptr, *LS = nullptr;
-        if (D.inflight.load() <= split_max && ch.slot_ix < 5) {
-            LI = &c->lanes[16 + 3 * ch.slot_ix]; LA = &c->lanes[17 + 3 * ch.slot_ix]; LS = &c->lanes[18 + 3 * ch.slot_ix];
-            // Alone on the GPU a job is a latency-bound chain of small kernels (~390 waves each, one behind the other) beside 20 ms of chip-filling
-            // hashes; where their waves share a SIMD both run at half speed, and the call waits for the chain (rocprofv3 timeline: the statement
-            // digests 10.7 ms beside the hashes against 4.1 ms alone).  So the chain's stream and the hashes' stream get DISJOINT CU masks: the chain
-            // `chain_cus` CUs -- 128 = a SIMD per wave; fewer and a kernel lasts as long as its doubled-up SIMDs: 96 CUs cost +16 ms -- the hashes the
-            // rest (bit i of a mask = CU i / 8 of XCD i % 8, tools/probes/cumask_probe.hip).  8192 proofs per call: 62.6 -> 57.7 ms.
-            const uint32_t chain_cus = getenv("MINA_VERIFY_CHAIN_CUS") ? (uint32_t)atoi(getenv("MINA_VERIFY_CHAIN_CUS")) : 128u;
-            int ncu = 0; (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device);
-            if (chain_cus > 0 && chain_cus < (uint32_t)ncu && ncu <= 256) {
-                const uint32_t period = getenv("MINA_VERIFY_CU_PERIOD") ? (uint32_t)atoi(getenv("MINA_VERIFY_CU_PERIOD")) : 256u;
-                auto masked = [&](Lane &ln, bool chain) -> int {
-                    if (ln.stream) return MINA_OK;
-                    uint32_t mk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                    for (uint32_t b2 = 0; b2 < (uint32_t)ncu; ++b2) { const bool in_chain = (b2 % period) < chain_cus * period / 256; if (in_chain == chain) mk[b2 >> 5] |= 1u << (b2 & 31); }
-                    HIPC(hipExtStreamCreateWithCUMask(&ln.stream, 8, mk));
-                    return MINA_OK;
-                };
-                if ((rc = masked(*LI, true)) || (rc = masked(*LS, false))) return rc;
-            } else LS = nullptr;
-        }
-        rc = mb_state_jobs_on_lane(c, &js.j, dv, df, LI, LA, ds, LS);
+        c->state_hashes_early = ch.LS ? ch.hashed * MINA_STATES_PER_PROOF : 0;
+        rc = mb_state_jobs_on_lane(c, &js.j, dv, df, ch.LI, ch.LA, ds, ch.LS);
+        c->state_hashes_early = 0;
         c->hash_piece_waves = 0;
         c->use_lane0();
         if (rc) return rc;
@@ -574,9 +658,15 @@ int run_device(Device &D, const CallIn &in, const std::vector<size_t> &idx, uint
             if (ch.slot->host.ensure(lay.total) || ch.slot->out.ensure(Layout::out_bytes(lay.cap))) { release(s); ch.slot = nullptr; ch.slot_ix = -1; rc_all = MINA_ERR_HIP; break; }
             uint8_t *hbase = (uint8_t *)ch.slot->host.p;
             Chunk *chp = &ch;
+            if (early_sub && ch.n >= early_min) {
+                ch.sub = early_sub; ch.nsub = (ch.n + early_sub - 1) / early_sub;
+                ch.sub_left.reset(new std::atomic<uint32_t>[ch.nsub]);
+                for (size_t r = 0; r < ch.nsub; ++r) ch.sub_left[r].store((uint32_t)(std::min(ch.n, (r + 1) * early_sub) - r * early_sub));
+            }
             ch.job = mb_pool_submit(ch.n, [&, chp, hbase](size_t b) {
                 const size_t q = idx[chp->lo + b];
                 parse_into(sh, lay, hbase, b, in.proofs[q], in.proof_lens[q], in.pubs[q], in.pub_lens[q], chp->hb[b], c);
+                if (chp->nsub && chp->sub_left[b / chp->sub].fetch_sub(1) == 1) { std::lock_guard<std::mutex> lk(chp->mu); chp->cv.notify_all(); }
             });
             ++next_submit;
         }
@@ -588,9 +678,10 @@ int run_device(Device &D, const CallIn &in, const std::vector<size_t> &idx, uint
             continue;
         }
         Chunk &ch = chunks[next_issue];
+        int rc = stream_records(ch);
         mb_pool_wait(ch.job);
         const double t_parsed = g_timing ? ms_since(t_call) : 0;
-        int rc = issue(ch);
+        if (!rc) rc = issue(ch);
         if (g_timing) fprintf(stderr, "mina_verify:   chunk %zu (%zu proofs): parsed at %.2f ms, issued at %.2f ms\n", next_issue, ch.n, t_parsed, ms_since(t_call));
         if (rc && !rc_all) rc_all = rc;
         ++next_issue;

@@ -129,6 +129,7 @@ struct mina_ctx {
     bool pparams_surrogate[2] = {false, false};                  // the installed Poseidon tables are the library's UNPINNED surrogate set
     DevBuf state_salts; bool have_state_salts = false;           // salted initial states of the named hash prefixes (Fp): MB_SALT_*
     bool legs_forked = false;        // the job being queued runs its legs on separate streams (api_state.hip)
+    size_t state_hashes_early = 0;   // states of the next job's protocol-state leg already queued on its lane (mb_state_hashes_early), consumed by mb_state_jobs_on_lane
     uint32_t hash_piece_waves = 0;   // > 0: the protocol-state hashes of a job are launched in pieces of this many waves (api_state.hip pstate_hash_dev)
     void use_lane0() { L = &lanes[0]; }
     void next_lane() { L = &lanes[rr++ % (unsigned)nlanes]; }

@@ -438,13 +438,24 @@ def test_boundary_pipeline_chunks_and_device_shards_give_the_same_verdicts(world
         else: p, q, v = good[i % 3][0], good[i % 3][1], 1
         proofs.append(p); pubs.append(q); want.append(v)
     assert m.lib.verify_state_batch(proofs, pubs).tolist() == want
-    env = {"MINA_VERIFY_CHUNK": None, "MINA_VERIFY_SINGLE_MAX": None, "MINA_VERIFY_MIN_SHARD": None, "MINA_VERIFY_DEVICES": None}
+    env = {"MINA_VERIFY_CHUNK": None, "MINA_VERIFY_SINGLE_MAX": None, "MINA_VERIFY_MIN_SHARD": None, "MINA_VERIFY_DEVICES": None, "MINA_VERIFY_EARLY_MIN": None, "MINA_VERIFY_EARLY_SUB": None}
     keep = {k: os.environ.get(k) for k in env}
     try:
         os.environ["MINA_VERIFY_SINGLE_MAX"] = "1"
         for chunk in ("5", "2"):
             os.environ["MINA_VERIFY_CHUNK"] = chunk
             assert m.lib.verify_state_batch(proofs, pubs).tolist() == want, f"chunks of {chunk}"
+        # the streamed form of a chunk (records uploaded and hashed run by run while the rest is parsed): runs of 3 -- the garbage entry at 30
+        # ends the streaming, the rest goes up after the patching -- as one chunk, in chunks of 5 (runs of 2), and a call that streams to the end
+        os.environ["MINA_VERIFY_EARLY_MIN"] = "1"
+        for single, chunk, sub in (("8192", "8192", "3"), ("1", "5", "2"), ("8192", "8192", "1")):
+            os.environ["MINA_VERIFY_SINGLE_MAX"] = single; os.environ["MINA_VERIFY_CHUNK"] = chunk; os.environ["MINA_VERIFY_EARLY_SUB"] = sub
+            assert m.lib.verify_state_batch(proofs, pubs).tolist() == want, f"streamed, runs of {sub}, chunks of {chunk}"
+            assert m.lib.verify_state_batch(proofs[1:12], pubs[1:12]).tolist() == want[1:12], "streamed to the end"
+            assert m.lib.verify_state_batch(proofs[14:25], pubs[14:25]).tolist() == want[14:25], "streamed to the end, all valid"
+        os.environ["MINA_VERIFY_EARLY_SUB"] = "0"
+        assert m.lib.verify_state_batch(proofs, pubs).tolist() == want, "streaming off"
+        os.environ["MINA_VERIFY_EARLY_SUB"] = "4"; os.environ["MINA_VERIFY_SINGLE_MAX"] = "1"
         # three logical devices on GPU 0
         m.lib.verify_shutdown()
         os.environ["MINA_VERIFY_DEVICES"] = "0,0,0"; os.environ["MINA_VERIFY_MIN_SHARD"] = "1"; os.environ["MINA_VERIFY_CHUNK"] = "4"
