@@ -78,7 +78,7 @@ std::shared_ptr<MbPoolJob> mb_pool_submit(size_t n, std::function<void(size_t)> 
     return j;
 }
 void mb_pool_wait(const std::shared_ptr<MbPoolJob> &j) {
-    if (!j || j->n == 0) return;
+    if (!j || j->n == 0 || j->done.load() >= j->n) return;
     HostPool::drain(*j);                                             // the caller works too
     std::unique_lock<std::mutex> lk(j->mu);
     j->cv.wait(lk, [&] { return j->done.load() >= j->n; });

@@ -341,7 +341,11 @@ int mb_state_hashes_early(mina_ctx *c, Lane *LS, size_t ns_total, size_t lo, siz
 
 // LI / LA: helper lanes of the wrap-proof leg and the accumulator leg (nullptr = everything on the current lane, in order); LS: a lane of
 // its own for the protocol-state leg as well (the boundary gives the chain and the hashes streams with disjoint CU masks, api_verify.hip)
-int mb_state_jobs_on_lane(mina_ctx *c, const mina_state_jobs *j, uint32_t *d_verdicts, uint32_t *d_flags, Lane *LI_, Lane *LA_, uint32_t *d_stmt_out, Lane *LS_) {
+// `phase`: MB_JOB_ALL queues the whole job.  The boundary queues a job in two steps, because the wrap-proof half of its input is parsed (and
+// uploaded) before the protocol states are: MB_JOB_LEGS = the accumulator and wrap-proof legs (their verdict pointers are kept in `carry`),
+// later MB_JOB_FINISH = the protocol-state leg (minus what mb_state_hashes_early queued already), the joins and the verdict kernel.
+int mb_state_jobs_on_lane(mina_ctx *c, const mina_state_jobs *j, uint32_t *d_verdicts, uint32_t *d_flags, Lane *LI_, Lane *LA_, uint32_t *d_stmt_out, Lane *LS_, uint32_t phase, StateJobCarry *carry) {
+    if (phase != MB_JOB_ALL && !carry) return fail(MINA_ERR_ARG, "a split job needs a carry");
     Lane &L = *c->L;
     Lane *const L0 = c->L;
     Lane *LI = L0, *LA = L0, *LS = L0;
@@ -350,7 +354,8 @@ int mb_state_jobs_on_lane(mina_ctx *c, const mina_state_jobs *j, uint32_t *d_ver
         if (LS_ && LS_ != L0 && LS_ != LI && LS_ != LA) LS = LS_;
         c->legs_forked = true;
         int frc;
-        if ((frc = leg_fork(c, *L0, *LI)) || (frc = leg_fork(c, *L0, *LA)) || (LS != L0 && (frc = leg_fork(c, *L0, *LS)))) return frc;
+        if ((phase & MB_JOB_LEGS) && ((frc = leg_fork(c, *L0, *LI)) || (frc = leg_fork(c, *L0, *LA)))) return frc;
+        if ((phase & MB_JOB_FINISH) && LS != L0 && (frc = leg_fork(c, *L0, *LS))) return frc;
     }
     const size_t B = j->batch;
     int rc;
@@ -358,7 +363,8 @@ int mb_state_jobs_on_lane(mina_ctx *c, const mina_state_jobs *j, uint32_t *d_ver
     Lane &S = *LS;                                              // ---- protocol-state leg
     c->L = LS;
     if ((rc = S.st_ok.ensure(B * 4))) return rc;
-    if (j->with_states) {
+    if (!(phase & MB_JOB_FINISH)) {}
+    else if (j->with_states) {
         const size_t ns = B * MINA_STATES_PER_PROOF;
         if ((rc = S.st_hashes.ensure(ns * 32))) return rc;
         const size_t early = std::min(c->state_hashes_early, ns);      // already queued on this lane by mb_state_hashes_early
@@ -392,9 +398,9 @@ int mb_state_jobs_on_lane(mina_ctx *c, const mina_state_jobs *j, uint32_t *d_ver
         }
         return MINA_OK;
     };
-    if (LA == LI && (rc = accumulator_leg())) { c->L = L0; return rc; }
+    if ((phase & MB_JOB_LEGS) && LA == LI && (rc = accumulator_leg())) { c->L = L0; return rc; }
     c->L = LI;                                                  // ---- wrap-proof leg
-    {
+    if (phase & MB_JOB_LEGS) {
     Lane &L = *LI;
     if ((rc = L.st_flags.ensure(16 * 4))) { c->L = L0; return rc; }
     const uint32_t *pub = (const uint32_t *)j->public_inputs;
@@ -456,8 +462,10 @@ int mb_state_jobs_on_lane(mina_ctx *c, const mina_state_jobs *j, uint32_t *d_ver
         }
     }
     }
-    if (LA != LI && (rc = accumulator_leg())) { c->L = L0; return rc; }
+    if ((phase & MB_JOB_LEGS) && LA != LI && (rc = accumulator_leg())) { c->L = L0; return rc; }
     c->L = L0;
+    if (phase == MB_JOB_LEGS) { carry->ipa_v = ipa_v; carry->acc_v = acc_v; carry->kimchi_bad = kimchi_bad; carry->stmt_ok = stmt_ok; return MINA_OK; }
+    if (phase == MB_JOB_FINISH) { ipa_v = carry->ipa_v; acc_v = carry->acc_v; kimchi_bad = carry->kimchi_bad; stmt_ok = carry->stmt_ok; }
     if (LI != L0) { int jrc; if ((jrc = leg_join(*LI, *L0)) || (jrc = leg_join(*LA, *L0)) || (LS != L0 && (jrc = leg_join(*LS, *L0)))) return jrc; }
     mb::state_job_verdict_kernel<<<cdiv(B, 64), 64, 0, L.stream>>>((uint32_t)B, S.st_ok.as<uint32_t>(), ipa_v, acc_v, kimchi_bad, stmt_ok, d_verdicts, d_flags, d_stmt_out);
     HIPC(hipGetLastError());

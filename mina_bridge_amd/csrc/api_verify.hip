@@ -33,8 +33,6 @@ int mb_kimchi_available(mina_ctx *c);                                           
 int mb_poseidon_env_params(mina_ctx *c);                                                                                               // api_loaders.hip
 int mb_step_index_feature_aware(mina_ctx *c);                                                                                         // api_pickles.hip
 int mb_step_index_installed(mina_ctx *c);                                                                                              // api_pickles.hip
-int mb_state_jobs_on_lane(mina_ctx *c, const mina_state_jobs *j, uint32_t *d_verdicts, uint32_t *d_flags, Lane *LI, Lane *LA, uint32_t *d_stmt_out, Lane *LS);   // api_state.hip
-int mb_state_hashes_early(mina_ctx *c, Lane *LS, size_t ns_total, size_t lo, size_t cnt, const uint32_t *d_records, const uint32_t *d_nfields, hipEvent_t after);     // api_state.hip
 
 extern "C" const char *mina_poseidon_params_name(void) { return MB_POSEIDON_SET_NAME; }
 // the compiled-in tables are a surrogate while their name says UNPINNED: a context running on them is flagged (mina_verify_state refuses)
@@ -55,6 +53,8 @@ extern "C" int mina_poseidon_install_default_params(mina_ctx *c) {
 // on the host); merged single-proof jobs are dealt round-robin.
 namespace {
 constexpr int NSLOT = 16;                  // chunks in flight per device: slot s runs on lane s of the context (helper lanes 16.. for forked legs)
+// (Uploads go through the slot's lane stream.  On a stream of their own -- so that a copy never queues behind a kernel -- calls of 65 536 proofs got
+// slower, 312 -> 337 ms, and calls of 8192 did not change: tools/boundary_ab.py, round 3.)
 struct Slot { PinnedBuf host, out; DevBuf dev; hipEvent_t ev = nullptr; hipEvent_t tev[3] = {nullptr, nullptr, nullptr}; std::vector<hipEvent_t> rec_ev; bool busy = false; };
 struct Device {
     mina_ctx *c = nullptr; int ordinal = 0;
@@ -97,7 +97,7 @@ void destroy_devices() {                    // caller holds g_mu
     for (Device *d : g_devs) {
         { std::lock_guard<std::mutex> lk(d->mu);
           (void)hipSetDevice(d->c->device);
-          for (Slot &s : d->slots) { if (s.ev) { (void)hipEventSynchronize(s.ev); (void)hipEventDestroy(s.ev); } for (auto &e : s.tev) if (e) (void)hipEventDestroy(e); s.host.release(); s.out.release(); s.dev.release(); }
+          for (Slot &s : d->slots) { if (s.ev) { (void)hipEventSynchronize(s.ev); (void)hipEventDestroy(s.ev); } for (auto &e : s.tev) if (e) (void)hipEventDestroy(e); for (auto &e : s.rec_ev) if (e) (void)hipEventDestroy(e); s.rec_ev.clear(); s.host.release(); s.out.release(); s.dev.release(); }
           mina_ctx_destroy(d->c); }
         delete d;
     }
@@ -231,7 +231,7 @@ struct Layout {
     static size_t out_bytes(size_t B) { return (2 * B + 4) * 4; }
 };
 // per-proof outcome of the host side
-struct HostBits { uint8_t parsed = 0, ledger = 0, consensus = 0, shape = 0, deferred = 0; };
+struct HostBits { uint8_t proof_ok = 0, parsed = 0, ledger = 0, consensus = 0, shape = 0, deferred = 0; uint32_t states_at = 0; };   // proof_ok: the wrap-proof half parsed; parsed: all of it
 
 void put_chal(uint8_t *o, const mw::Chal128 &c) { memcpy(o, &c.lo, 8); memcpy(o + 8, &c.hi, 8); }
 void chal_bytes(const mw::Chal128 &c, uint8_t *o) { put_chal(o, c); }
@@ -249,36 +249,23 @@ bool uses_lookups(const mw::WrapProof &w) {
 
 mw::StateProofContainer &tl_box() { static thread_local std::unique_ptr<mw::StateProofContainer> b; if (!b) b.reset(new mw::StateProofContainer()); return *b; }
 
-// host part of one proof: FORMAT, LEDGER, CONSENSUS + its entry of the staging.  `sh.n_old / n_ev == 0xffffffff`: take them from the proof
-// (single-proof diagnostic form).  Returns with hb.parsed = 0 and an untouched entry when the bytes are malformed.
-void parse_into(const Shape &sh, const Layout &lay, uint8_t *base, size_t b, const uint8_t *proof, size_t proof_len, const uint8_t *pub, size_t pub_len, HostBits &hb, const mina_ctx *c) {
+// host part of one proof: FORMAT, LEDGER, CONSENSUS + its entry of the staging, in two halves -- a MinaStateProof is the wrap proof followed by
+// the 17 protocol states (core/src/proof/state_proof.rs:28-41), and the pipeline sends the first half to the GPU while the second is parsed.
+// `sh.n_old / n_ev == 0xffffffff`: take them from the proof (single-proof diagnostic form).
+// First half: the public inputs and the wrap proof -> every section but the protocol-state records, their field counts and `precheck`.
+// hb.proof_ok = 0 (entry untouched) when the bytes are malformed.
+void parse_proof_half(const Shape &sh, const Layout &lay, uint8_t *base, size_t b, const uint8_t *proof, size_t proof_len, const uint8_t *pub, size_t pub_len, HostBits &hb, const mina_ctx *c) {
     hb = HostBits{};
     if (!proof || !pub) return;
     mina_state_pub_inputs pi;
     if (mina_parse_state_pub_inputs(pub, pub_len, &pi) != MINA_OK) return;
     mw::StateProofContainer &box = tl_box();
-    if (!mw::read_state_proof(proof, proof_len, box)) return;
+    mw::Bincode cur(proof, proof_len);
+    if (!mw::read_wrap_proof(cur, box.tip_proof) || !cur.ok || cur.pos > 0xffffffffu) return;
     const mw::WrapProof &w = box.tip_proof;
     if (w.lr.empty() || w.lr.size() > 20 || w.step_challenge_polynomial_commitments.size() != w.step_old_bulletproof_challenges.size()) return;
-    mina_protocol_state_info info[MINA_STATES_PER_PROOF];
-    uint8_t *recs = lay.at(base, S_REC, b); uint32_t *nf = (uint32_t *)lay.at(base, S_NF, b);
-    for (int i = 0; i < MINA_STATES_PER_PROOF; ++i)
-        if (mb_pack_protocol_state(box.states[i], recs + (size_t)i * MINA_PSTATE_SLOTS * 32, &nf[i], &info[i]) != MINA_OK) return;
-    hb.parsed = 1;
-    bool ledger = true;
-    for (int i = 0; i < 16; ++i) ledger = ledger && memcmp(pi.candidate_chain_ledger_hashes[i], info[i].snarked_ledger_hash, 32) == 0;
-    hb.ledger = ledger;
-    // chain selection between the bridge tip (state 16) and the candidate tip (state 15); tie-breaks use the hashes the public
-    // input names (the CHAIN step proves them) and Blake2b-256 of the last VRF output (`hashLastVRF`)
-    mina_consensus_state tip = info[16].consensus, cand = info[15].consensus;
-    memcpy(tip.state_hash, pi.bridge_tip_state_hash, 32); memcpy(cand.state_hash, pi.candidate_chain_state_hashes[15], 32);
-    blake2b_short(box.states[16].last_vrf_output.data(), 32, tip.last_vrf_output_hash, 32);
-    blake2b_short(box.states[15].last_vrf_output.data(), 32, cand.last_vrf_output_hash, 32);
-    mina_consensus_params cp{info[15].slots_per_sub_window, info[15].sub_windows_per_window};
-    int sel = 0;
-    if (info[16].sub_windows_per_window == cp.sub_windows_per_window && cp.sub_windows_per_window >= 1 && cp.sub_windows_per_window <= MINA_MAX_SUB_WINDOWS &&
-        cp.slots_per_sub_window >= 1 && mina_consensus_select_secure_chain(&cp, &tip, &cand, &sel) == MINA_OK)
-        hb.consensus = sel == 1;
+    hb.states_at = (uint32_t)cur.pos;
+    hb.proof_ok = 1;
     uint8_t *exp = lay.at(base, S_EXP, b);
     memcpy(exp, pi.candidate_chain_state_hashes, 512); memcpy(exp + 512, pi.bridge_tip_state_hash, 32);
     uint8_t *apre = lay.at(base, S_APRE, b);
@@ -351,7 +338,44 @@ void parse_into(const Shape &sh, const Layout &lay, uint8_t *base, size_t b, con
               misc[11] = (uint8_t)present; misc[12] = (uint8_t)(present >> 8); misc[13] = (uint8_t)(present >> 16); }
         }
     }
+}
+
+// Second half: the 17 protocol states behind the wrap proof -> records + field counts, the LEDGER and CONSENSUS checks, `precheck`.
+// hb.parsed = 1 when the whole container was well-formed; otherwise the records of the entry are left undefined (the caller zeroes them).
+void parse_states_half(const Layout &lay, uint8_t *base, size_t b, const uint8_t *proof, size_t proof_len, const uint8_t *pub, size_t pub_len, HostBits &hb) {
+    *lay.at(base, S_PRE, b) = 0;
+    if (!hb.proof_ok) return;
+    mina_state_pub_inputs pi;
+    if (mina_parse_state_pub_inputs(pub, pub_len, &pi) != MINA_OK) return;
+    mw::StateProofContainer &box = tl_box();
+    mw::Bincode cur(proof, proof_len);
+    cur.pos = hb.states_at;
+    for (int i = 0; i < MINA_STATES_PER_PROOF; ++i) if (!mw::read_protocol_state(cur, box.states[i])) return;
+    if (!cur.ok || cur.pos != proof_len) return;
+    mina_protocol_state_info info[MINA_STATES_PER_PROOF];
+    uint8_t *recs = lay.at(base, S_REC, b); uint32_t *nf = (uint32_t *)lay.at(base, S_NF, b);
+    for (int i = 0; i < MINA_STATES_PER_PROOF; ++i)
+        if (mb_pack_protocol_state(box.states[i], recs + (size_t)i * MINA_PSTATE_SLOTS * 32, &nf[i], &info[i]) != MINA_OK) return;
+    hb.parsed = 1;
+    bool ledger = true;
+    for (int i = 0; i < 16; ++i) ledger = ledger && memcmp(pi.candidate_chain_ledger_hashes[i], info[i].snarked_ledger_hash, 32) == 0;
+    hb.ledger = ledger;
+    // chain selection between the bridge tip (state 16) and the candidate tip (state 15); tie-breaks use the hashes the public
+    // input names (the CHAIN step proves them) and Blake2b-256 of the last VRF output (`hashLastVRF`)
+    mina_consensus_state tip = info[16].consensus, cand = info[15].consensus;
+    memcpy(tip.state_hash, pi.bridge_tip_state_hash, 32); memcpy(cand.state_hash, pi.candidate_chain_state_hashes[15], 32);
+    blake2b_short(box.states[16].last_vrf_output.data(), 32, tip.last_vrf_output_hash, 32);
+    blake2b_short(box.states[15].last_vrf_output.data(), 32, cand.last_vrf_output_hash, 32);
+    mina_consensus_params cp{info[15].slots_per_sub_window, info[15].sub_windows_per_window};
+    int sel = 0;
+    if (info[16].sub_windows_per_window == cp.sub_windows_per_window && cp.sub_windows_per_window >= 1 && cp.sub_windows_per_window <= MINA_MAX_SUB_WINDOWS &&
+        cp.slots_per_sub_window >= 1 && mina_consensus_select_secure_chain(&cp, &tip, &cand, &sel) == MINA_OK)
+        hb.consensus = sel == 1;
     *lay.at(base, S_PRE, b) = (hb.ledger && hb.consensus && hb.shape) ? 1 : 0;
+}
+void parse_into(const Shape &sh, const Layout &lay, uint8_t *base, size_t b, const uint8_t *proof, size_t proof_len, const uint8_t *pub, size_t pub_len, HostBits &hb, const mina_ctx *c) {
+    parse_proof_half(sh, lay, base, b, proof, proof_len, pub, pub_len, hb, c);
+    parse_states_half(lay, base, b, proof, proof_len, pub, pub_len, hb);
 }
 
 // the job over entries [0, B) of a staging at `base` (host or device addresses alike)
@@ -393,9 +417,10 @@ bool draw_randomisers(const Shape &sh, const Layout &lay, uint8_t *base, size_t 
 
 // entries that did not parse / do not have the job's shape borrow a well-formed entry's bytes (their own verdict is already 0 through
 // `precheck`), so that they do not fail the job's folded checks for everyone else
-void copy_entry(const Layout &lay, uint8_t *base, size_t dst, size_t src) {
-    for (int i = 0; i < NSEC; ++i) if (lay.stride[i] && i != S_PRE) memcpy(lay.at(base, i, dst), lay.at(base, i, src), lay.stride[i]);
+void copy_proof_half(const Layout &lay, uint8_t *base, size_t dst, size_t src) {      // what parse_proof_half writes; the records of such an entry are zeroed (clear_states_half)
+    for (int i = 0; i < NSEC; ++i) if (lay.stride[i] && i != S_PRE && i != S_REC && i != S_NF) memcpy(lay.at(base, i, dst), lay.at(base, i, src), lay.stride[i]);
 }
+void clear_states_half(const Layout &lay, uint8_t *base, size_t b) { memset(lay.at(base, S_REC, b), 0, lay.stride[S_REC]); memset(lay.at(base, S_NF, b), 0, lay.stride[S_NF]); *lay.at(base, S_PRE, b) = 0; }
 
 struct Config { bool usable = false, kimchi = false, statements = false, feature_aware = false; uint32_t k = 0; int network = -1; };
 Config read_config(Device &D, uint32_t flags) {
@@ -417,12 +442,13 @@ Config read_config(Device &D, uint32_t flags) {
 struct CallIn { const uint8_t *const *proofs; const size_t *proof_lens; const uint8_t *const *pubs; const size_t *pub_lens; };
 
 struct Chunk {
-    size_t lo = 0, n = 0; Slot *slot = nullptr; int slot_ix = -1; std::shared_ptr<MbPoolJob> job; std::vector<HostBits> hb; bool issued = false, skipped = false, harvested = false;
-    // streamed form (big chunks): the entries are parsed in `nsub` runs of `sub`; the records of a run go to the GPU, and their hashes are queued, as soon as it is parsed
+    size_t lo = 0, n = 0; Slot *slot = nullptr; int slot_ix = -1; std::vector<HostBits> hb; bool issued = false, skipped = false, harvested = false;
+    // two pool jobs per chunk: the wrap-proof halves of its entries (A), then the protocol-state halves (B) in `nsub` runs of `sub` entries -- the
+    // records of a run go to the GPU, and their hashes are queued, as soon as the run is parsed
+    std::shared_ptr<MbPoolJob> jobA, jobB;
     size_t sub = 0, nsub = 0; std::unique_ptr<std::atomic<uint32_t>[]> sub_left; std::mutex mu; std::condition_variable cv;
-    size_t streamed = 0;                      // entries whose records are on their way to the GPU
-    size_t hashed = 0;                        // ... and whose 17 state hashes are queued on LS
-    bool legs_set = false, early_started = false; Lane *LI = nullptr, *LA = nullptr, *LS = nullptr;
+    size_t hashed = 0;                        // protocol states whose hashes are queued
+    bool legs_set = false, queued = false; Lane *LI = nullptr, *LA = nullptr, *LS = nullptr; StateJobCarry carry;
 };
 
 const bool g_timing = getenv("MINA_VERIFY_TIMING") != nullptr;
@@ -505,11 +531,10 @@ int run_device(Device &D, const CallIn &in, const std::vector<size_t> &idx, uint
                 else { int rc = fallback(ch); if (rc && !rc_all) rc_all = rc; }
             } else if (!rc_all) rc_all = MINA_ERR_HIP;
         }
-        else if (ch.early_started) {                                  // the job was never queued, but uploads / hashes of the streamed runs may be: nothing of them may outlive the slot
+        else if (ch.queued) {                                         // the job was not completed, but parts of it are queued: nothing of them may outlive the slot
             std::lock_guard<std::mutex> lk(D.mu);
             (void)hipSetDevice(c->device);
-            if (c->lanes[ch.slot_ix].stream) (void)hipStreamSynchronize(c->lanes[ch.slot_ix].stream);
-            if (ch.LS && ch.LS->stream) (void)hipStreamSynchronize(ch.LS->stream);
+            (void)hipDeviceSynchronize();
         }
         if (ch.slot_ix >= 0) release(ch.slot_ix);
         D.inflight.fetch_sub(1);
@@ -567,53 +592,19 @@ int run_device(Device &D, const CallIn &in, const std::vector<size_t> &idx, uint
         c->hash_piece_waves = getenv("MINA_VERIFY_HASH_PIECE") ? (uint32_t)atoi(getenv("MINA_VERIFY_HASH_PIECE")) : 1024u;
     };
 
-    // Streamed form of a big chunk: as soon as a run of its entries is parsed (and every entry of the run is well-formed), the run's protocol-state
-    // records -- 34 KB of an entry's 47 KB -- go to the GPU and their hashes are queued on the state leg's lane, while the pool is still parsing the
-    // rest.  The state leg is the long one of a job running alone (its 128 CUs, ~40 ms for 8192 proofs): it now starts ~1.5 ms into the call instead
-    // of behind the parsing and the whole upload (~13 ms).  A run holding an entry that needs patching ends the streaming: the rest goes up in issue().
-    auto stream_records = [&](Chunk &ch) -> int {
-        if (!ch.nsub) return MINA_OK;
-        uint8_t *hbase = (uint8_t *)ch.slot->host.p;
-        Slot &S = *ch.slot;
-        for (size_t r = 0; r < ch.nsub; ++r) {
-            { std::unique_lock<std::mutex> lk(ch.mu); ch.cv.wait(lk, [&] { return ch.sub_left[r].load() == 0; }); }
-            const size_t lo = r * ch.sub, hi = std::min(ch.n, lo + ch.sub);
-            bool good = true;
-            for (size_t b = lo; b < hi && good; ++b) good = ch.hb[b].parsed && ch.hb[b].shape;
-            if (!good) break;
-            std::lock_guard<std::mutex> lk(D.mu);
-            int rc;
-            if ((rc = setup_slot(ch)) || (rc = setup_legs(ch))) return rc;
-            Lane &L = c->lanes[ch.slot_ix];
-            uint8_t *dbase = S.dev.as<uint8_t>();
-            if (S.rec_ev.size() < ch.nsub) S.rec_ev.resize(ch.nsub, nullptr);
-            if (!S.rec_ev[r]) HIPC(hipEventCreateWithFlags(&S.rec_ev[r], hipEventDisableTiming));
-            if (g_timing && !ch.early_started) HIPC(hipEventRecord(S.tev[0], L.stream));
-            ch.early_started = true;
-            HIPC(hipMemcpyAsync(lay.at(dbase, S_REC, lo), lay.at(hbase, S_REC, lo), (hi - lo) * lay.stride[S_REC], hipMemcpyHostToDevice, L.stream));
-            HIPC(hipMemcpyAsync(lay.at(dbase, S_NF, lo), lay.at(hbase, S_NF, lo), (hi - lo) * lay.stride[S_NF], hipMemcpyHostToDevice, L.stream));
-            HIPC(hipEventRecord(S.rec_ev[r], L.stream));
-            ch.streamed = hi;
-            if (ch.LS) {
-                lane_forms();
-                rc = mb_state_hashes_early(c, ch.LS, ch.n * MINA_STATES_PER_PROOF, lo * MINA_STATES_PER_PROOF, (hi - lo) * MINA_STATES_PER_PROOF,
-                                           (const uint32_t *)lay.at(dbase, S_REC, 0), (const uint32_t *)lay.at(dbase, S_NF, 0), S.rec_ev[r]);
-                c->hash_piece_waves = 0;
-                c->use_lane0();
-                if (rc) return rc;
-                ch.hashed = hi;
-            }
-        }
-        return MINA_OK;
-    };
-
-    auto issue = [&](Chunk &ch) -> int {
+    // A chunk goes to the GPU in three steps, each as soon as its input is parsed (8192 full-size proofs per call: the job's wrap-proof chain
+    // takes ~42 ms on its CUs and the state hashes ~43 ms on theirs, so the call is as long as the later of the two STARTS):
+    //   issue_legs      after the wrap-proof halves (pool job A, ~1/3 of the parsing): patch, draw the randomisers, upload everything but the records,
+    //                   queue the accumulator and wrap-proof legs
+    //   stream_records  run by run of pool job B: upload the run's protocol-state records (34 KB of an entry's 47 KB) and queue their hashes
+    //   finish          upload `precheck`, queue the rest of the state leg, the joins and the verdict kernel, the download
+    auto issue_legs = [&](Chunk &ch) -> int {
         uint8_t *hbase = (uint8_t *)ch.slot->host.p;
         // host side of the chunk: collect the other shapes, patch what cannot go to the GPU as it is
         size_t donor = SIZE_MAX;
-        for (size_t b = 0; b < ch.n; ++b) { if (ch.hb[b].parsed && ch.hb[b].shape && donor == SIZE_MAX) donor = b; if (ch.hb[b].deferred) deferred.push_back(idx[ch.lo + b]); }
+        for (size_t b = 0; b < ch.n; ++b) { if (ch.hb[b].proof_ok && ch.hb[b].shape && donor == SIZE_MAX) donor = b; if (ch.hb[b].deferred) deferred.push_back(idx[ch.lo + b]); }
         if (donor == SIZE_MAX) { ch.skipped = true; return MINA_OK; }                         // nothing of this chunk can pass
-        for (size_t b = ch.streamed; b < ch.n; ++b) if (!(ch.hb[b].parsed && ch.hb[b].shape)) { copy_entry(lay, hbase, b, donor); *lay.at(hbase, S_PRE, b) = 0; }   // streamed runs hold no such entry
+        for (size_t b = 0; b < ch.n; ++b) if (!(ch.hb[b].proof_ok && ch.hb[b].shape)) copy_proof_half(lay, hbase, b, donor);
         if (!draw_randomisers(sh, lay, hbase, ch.n)) return fail(MINA_ERR_STATE, "no entropy for the folding randomisers");
         std::lock_guard<std::mutex> lk(D.mu);
         int rc;
@@ -623,20 +614,63 @@ int run_device(Device &D, const CallIn &in, const std::vector<size_t> &idx, uint
         lane_forms();
         c->L = &L;
         uint8_t *dbase = S.dev.as<uint8_t>();
-        if (g_timing && !ch.early_started) HIPC(hipEventRecord(S.tev[0], L.stream));
-        if (ch.streamed == 0) HIPC(hipMemcpyAsync(dbase, hbase, lay.total, hipMemcpyHostToDevice, L.stream));
-        else {                                                                                 // what the streamed runs have not taken
-            if (ch.streamed < ch.n) {
-                HIPC(hipMemcpyAsync(lay.at(dbase, S_REC, ch.streamed), lay.at(hbase, S_REC, ch.streamed), (ch.n - ch.streamed) * lay.stride[S_REC], hipMemcpyHostToDevice, L.stream));
-                HIPC(hipMemcpyAsync(lay.at(dbase, S_NF, ch.streamed), lay.at(hbase, S_NF, ch.streamed), (ch.n - ch.streamed) * lay.stride[S_NF], hipMemcpyHostToDevice, L.stream));
-            }
-            HIPC(hipMemcpyAsync(dbase + lay.off[S_EXP], hbase + lay.off[S_EXP], lay.total - lay.off[S_EXP], hipMemcpyHostToDevice, L.stream));
+        if (g_timing) HIPC(hipEventRecord(S.tev[0], L.stream));
+        ch.queued = true;
+        HIPC(hipMemcpyAsync(dbase + lay.off[S_EXP], hbase + lay.off[S_EXP], lay.total - lay.off[S_EXP], hipMemcpyHostToDevice, L.stream));    // `precheck` lies in there: sent again by finish()
+        JobStructs js; make_jobs(sh, lay, dbase, ch.n, true, true, true, js);
+        uint32_t *dv = (uint32_t *)(dbase + lay.out_off()), *df = dv + ch.n, *ds = df + 4;
+        rc = mb_state_jobs_on_lane(c, &js.j, dv, df, ch.LI, ch.LA, ds, ch.LS, MB_JOB_LEGS, &ch.carry);
+        c->hash_piece_waves = 0;
+        c->use_lane0();
+        return rc;
+    };
+    auto stream_records = [&](Chunk &ch) -> int {
+        uint8_t *hbase = (uint8_t *)ch.slot->host.p;
+        Slot &S = *ch.slot;
+        for (size_t r = 0; r < ch.nsub; ++r) {
+            { std::unique_lock<std::mutex> lk(ch.mu); ch.cv.wait(lk, [&] { return ch.sub_left[r].load() == 0; }); }
+            const size_t lo = r * ch.sub, hi = std::min(ch.n, lo + ch.sub);
+            for (size_t b = lo; b < hi; ++b) if (!ch.hb[b].parsed) clear_states_half(lay, hbase, b);      // malformed, or patched above: defined records, verdict 0 through `precheck`
+            std::lock_guard<std::mutex> lk(D.mu);
+            HIPC(hipSetDevice(c->device));
+            Lane &L = c->lanes[ch.slot_ix];
+            uint8_t *dbase = S.dev.as<uint8_t>();
+            if (S.rec_ev.size() < ch.nsub) S.rec_ev.resize(ch.nsub, nullptr);
+            if (!S.rec_ev[r]) HIPC(hipEventCreateWithFlags(&S.rec_ev[r], hipEventDisableTiming));
+            HIPC(hipMemcpyAsync(lay.at(dbase, S_REC, lo), lay.at(hbase, S_REC, lo), (hi - lo) * lay.stride[S_REC], hipMemcpyHostToDevice, L.stream));
+            HIPC(hipMemcpyAsync(lay.at(dbase, S_NF, lo), lay.at(hbase, S_NF, lo), (hi - lo) * lay.stride[S_NF], hipMemcpyHostToDevice, L.stream));
+            HIPC(hipEventRecord(S.rec_ev[r], L.stream));
+            lane_forms();
+            // hashes in WHOLE pieces (a piece = `hash_piece_waves` waves of 21 states = two waves on every SIMD of the state leg's 128 CUs): a run of
+            // 1024 entries is 829 waves -- launched run by run, a fifth of the leg's SIMDs would hold one wave where the others hold two, for as long
+            const size_t piece = (size_t)c->hash_piece_waves * 21, ready = hi * MINA_STATES_PER_PROOF;
+            const size_t upto = (r + 1 == ch.nsub || !piece) ? ready : ready / piece * piece;
+            int rc = MINA_OK;
+            if (upto > ch.hashed)
+                rc = mb_state_hashes_early(c, ch.LS ? ch.LS : &L, ch.n * MINA_STATES_PER_PROOF, ch.hashed, upto - ch.hashed,
+                                           (const uint32_t *)lay.at(dbase, S_REC, 0), (const uint32_t *)lay.at(dbase, S_NF, 0), S.rec_ev[r]);
+            c->hash_piece_waves = 0;
+            c->use_lane0();
+            if (rc) return rc;
+            ch.hashed = std::max(ch.hashed, upto);
         }
+        return MINA_OK;
+    };
+    auto finish = [&](Chunk &ch) -> int {
+        uint8_t *hbase = (uint8_t *)ch.slot->host.p;
+        std::lock_guard<std::mutex> lk(D.mu);
+        HIPC(hipSetDevice(c->device));
+        Slot &S = *ch.slot;
+        Lane &L = c->lanes[ch.slot_ix];
+        lane_forms();
+        c->L = &L;
+        uint8_t *dbase = S.dev.as<uint8_t>();
+        HIPC(hipMemcpyAsync(lay.at(dbase, S_PRE, 0), lay.at(hbase, S_PRE, 0), ch.n * lay.stride[S_PRE], hipMemcpyHostToDevice, L.stream));
         if (g_timing) HIPC(hipEventRecord(S.tev[1], L.stream));
         JobStructs js; make_jobs(sh, lay, dbase, ch.n, true, true, true, js);
         uint32_t *dv = (uint32_t *)(dbase + lay.out_off()), *df = dv + ch.n, *ds = df + 4;
-        c->state_hashes_early = ch.LS ? ch.hashed * MINA_STATES_PER_PROOF : 0;
-        rc = mb_state_jobs_on_lane(c, &js.j, dv, df, ch.LI, ch.LA, ds, ch.LS);
+        c->state_hashes_early = ch.hashed;
+        int rc = mb_state_jobs_on_lane(c, &js.j, dv, df, ch.LI, ch.LA, ds, ch.LS, MB_JOB_FINISH, &ch.carry);
         c->state_hashes_early = 0;
         c->hash_piece_waves = 0;
         c->use_lane0();
@@ -658,15 +692,18 @@ int run_device(Device &D, const CallIn &in, const std::vector<size_t> &idx, uint
             if (ch.slot->host.ensure(lay.total) || ch.slot->out.ensure(Layout::out_bytes(lay.cap))) { release(s); ch.slot = nullptr; ch.slot_ix = -1; rc_all = MINA_ERR_HIP; break; }
             uint8_t *hbase = (uint8_t *)ch.slot->host.p;
             Chunk *chp = &ch;
-            if (early_sub && ch.n >= early_min) {
-                ch.sub = early_sub; ch.nsub = (ch.n + early_sub - 1) / early_sub;
-                ch.sub_left.reset(new std::atomic<uint32_t>[ch.nsub]);
-                for (size_t r = 0; r < ch.nsub; ++r) ch.sub_left[r].store((uint32_t)(std::min(ch.n, (r + 1) * early_sub) - r * early_sub));
-            }
-            ch.job = mb_pool_submit(ch.n, [&, chp, hbase](size_t b) {
+            ch.sub = (early_sub && ch.n >= early_min) ? early_sub : ch.n; ch.nsub = (ch.n + ch.sub - 1) / ch.sub;
+            ch.sub_left.reset(new std::atomic<uint32_t>[ch.nsub]);
+            for (size_t r = 0; r < ch.nsub; ++r) ch.sub_left[r].store((uint32_t)(std::min(ch.n, (r + 1) * ch.sub) - r * ch.sub));
+            ch.jobA = mb_pool_submit(ch.n, [&, chp, hbase](size_t b) {
                 const size_t q = idx[chp->lo + b];
-                parse_into(sh, lay, hbase, b, in.proofs[q], in.proof_lens[q], in.pubs[q], in.pub_lens[q], chp->hb[b], c);
-                if (chp->nsub && chp->sub_left[b / chp->sub].fetch_sub(1) == 1) { std::lock_guard<std::mutex> lk(chp->mu); chp->cv.notify_all(); }
+                parse_proof_half(sh, lay, hbase, b, in.proofs[q], in.proof_lens[q], in.pubs[q], in.pub_lens[q], chp->hb[b], c);
+            });
+            ch.jobB = mb_pool_submit(ch.n, [&, chp, hbase](size_t b) {
+                mb_pool_wait(chp->jobA);                                  // the pool hands jobs out in order, but the last items of A may still be running
+                const size_t q = idx[chp->lo + b];
+                parse_states_half(lay, hbase, b, in.proofs[q], in.proof_lens[q], in.pubs[q], in.pub_lens[q], chp->hb[b]);
+                if (chp->sub_left[b / chp->sub].fetch_sub(1) == 1) { std::lock_guard<std::mutex> lk(chp->mu); chp->cv.notify_all(); }
             });
             ++next_submit;
         }
@@ -678,15 +715,19 @@ int run_device(Device &D, const CallIn &in, const std::vector<size_t> &idx, uint
             continue;
         }
         Chunk &ch = chunks[next_issue];
-        int rc = stream_records(ch);
-        mb_pool_wait(ch.job);
+        mb_pool_wait(ch.jobA);
+        const double t_a = g_timing ? ms_since(t_call) : 0;
+        int rc = issue_legs(ch);
+        const double t_legs = g_timing ? ms_since(t_call) : 0;
+        if (!rc && !ch.skipped) rc = stream_records(ch);
+        mb_pool_wait(ch.jobB);
         const double t_parsed = g_timing ? ms_since(t_call) : 0;
-        if (!rc) rc = issue(ch);
-        if (g_timing) fprintf(stderr, "mina_verify:   chunk %zu (%zu proofs): parsed at %.2f ms, issued at %.2f ms\n", next_issue, ch.n, t_parsed, ms_since(t_call));
+        if (!rc && !ch.skipped) rc = finish(ch);
+        if (g_timing) fprintf(stderr, "mina_verify:   chunk %zu (%zu proofs): wrap proofs parsed at %.2f ms, legs queued at %.2f, states parsed at %.2f, all queued at %.2f ms\n", next_issue, ch.n, t_a, t_legs, t_parsed, ms_since(t_call));
         if (rc && !rc_all) rc_all = rc;
         ++next_issue;
     }
-    for (size_t q = 0; q < next_submit; ++q) mb_pool_wait(chunks[q].job);     // nothing may still write into a slot (error paths)
+    for (size_t q = 0; q < next_submit; ++q) { mb_pool_wait(chunks[q].jobA); mb_pool_wait(chunks[q].jobB); }     // nothing may still write into a slot (error paths)
     for (size_t q = 0; q < nchunks; ++q) {
         if (q < next_submit) { harvest(chunks[q]); if (g_timing) fprintf(stderr, "mina_verify:   chunk %zu harvested at %.2f ms\n", q, ms_since(t_call)); }
         else D.inflight.fetch_sub(1);

@@ -166,6 +166,13 @@ static inline bool use_coop8_transcripts(const mina_ctx *c, size_t batch, size_t
     return lim ? in_flight <= lim : (batch <= per_call_limit && in_flight <= 2048);
 }
 
+// ---- the Proof-of-State job on the lanes of a context (api_state.hip); every pointer of `j` is a device pointer
+enum : uint32_t { MB_JOB_LEGS = 1, MB_JOB_FINISH = 2, MB_JOB_ALL = 3 };
+struct StateJobCarry { uint32_t *ipa_v = nullptr, *acc_v = nullptr, *kimchi_bad = nullptr; const uint32_t *stmt_ok = nullptr; };
+int mb_state_jobs_on_lane(mina_ctx *c, const mina_state_jobs *j, uint32_t *d_verdicts, uint32_t *d_flags, Lane *LI, Lane *LA, uint32_t *d_stmt_out, Lane *LS,
+                          uint32_t phase = MB_JOB_ALL, StateJobCarry *carry = nullptr);
+int mb_state_hashes_early(mina_ctx *c, Lane *LS, size_t ns_total, size_t lo, size_t cnt, const uint32_t *d_records, const uint32_t *d_nfields, hipEvent_t after);
+
 // ---- host-side worker pool (api_core.hip): persistent threads, created on first use -- min(hardware threads / 2, 64), $MINA_HOST_THREADS
 // overrides.  A job is `n` independent items handed out in index order; `mb_pool_submit` returns at once (the boundary's pipeline parses
 // chunk i + 1 while chunk i is on the GPU), `mb_pool_wait` joins in on the remaining items and returns when all are done.

@@ -1,0 +1,21 @@
+# dev tool: kernel timeline of the LAST boundary call in a rocprofv3 --kernel-trace CSV (run: tools/boundary_ab.py SIZE 2 under rocprofv3)
+# usage: python tools/call_timeline.py KERNEL_TRACE.csv [WINDOW_MS]
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+win = float(sys.argv[2]) if len(sys.argv) > 2 else 70.0
+for r in rows: r["s"] = int(r["Start_Timestamp"]); r["e"] = int(r["End_Timestamp"])
+end = max(r["e"] for r in rows)
+last = [r for r in rows if r["s"] >= end - win * 1e6]
+# the call starts at the first kernel after a gap of > 3 ms
+last.sort(key=lambda r: r["s"])
+start_i = 0
+for i in range(1, len(last)):
+    if last[i]["s"] - max(x["e"] for x in last[:i]) > 3e6: start_i = i
+last = last[start_i:]
+t0 = last[0]["s"]
+def short(n): return n.replace("mb::", "").split("(")[0][:44]
+print(f"{'start':>8} {'dur':>8}  queue  kernel")
+for r in last:
+    d = (r["e"] - r["s"]) / 1e6
+    if d >= 0.25: print(f"{(r['s'] - t0) / 1e6:8.2f} {d:8.2f}  {r.get('Queue_Id', '?'):>5}  {short(r['Kernel_Name'])}")
+print(f"total {(max(r['e'] for r in last) - t0) / 1e6:.2f} ms, {len(last)} kernels")
