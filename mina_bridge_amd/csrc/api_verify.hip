@@ -53,9 +53,10 @@ extern "C" int mina_poseidon_install_default_params(mina_ctx *c) {
 // on the host); merged single-proof jobs are dealt round-robin.
 namespace {
 constexpr int NSLOT = 16;                  // chunks in flight per device: slot s runs on lane s of the context (helper lanes 16.. for forked legs)
-// (Uploads go through the slot's lane stream.  On a stream of their own -- so that a copy never queues behind a kernel -- calls of 65 536 proofs got
-// slower, 312 -> 337 ms, and calls of 8192 did not change: tools/boundary_ab.py, round 3.)
-struct Slot { PinnedBuf host, out; DevBuf dev; hipEvent_t ev = nullptr; hipEvent_t tev[3] = {nullptr, nullptr, nullptr}; std::vector<hipEvent_t> rec_ev; bool busy = false; };
+// `up`: the slot's upload stream.  No copy of the pipeline waits for a kernel: the copy engines take their commands in order, and one that waits for a
+// kernel of its stream holds up the uploads of every other chunk queued behind it (calls of 65 536 proofs: the jobs of the 8 chunks started up to 300 ms
+// apart, rocprofv3 timeline).  So uploads have a stream of their own, and the verdict words go back through a kernel that writes the page-locked buffer.
+struct Slot { PinnedBuf host, out; DevBuf dev; hipStream_t up = nullptr; hipEvent_t ev = nullptr, ev_up = nullptr; hipEvent_t tev[3] = {nullptr, nullptr, nullptr}; std::vector<hipEvent_t> rec_ev; bool busy = false; };
 struct Device {
     mina_ctx *c = nullptr; int ordinal = 0;
     std::mutex mu;                         // serialises every call into `c` (a context has ONE current-lane cursor)
@@ -97,7 +98,7 @@ void destroy_devices() {                    // caller holds g_mu
     for (Device *d : g_devs) {
         { std::lock_guard<std::mutex> lk(d->mu);
           (void)hipSetDevice(d->c->device);
-          for (Slot &s : d->slots) { if (s.ev) { (void)hipEventSynchronize(s.ev); (void)hipEventDestroy(s.ev); } for (auto &e : s.tev) if (e) (void)hipEventDestroy(e); for (auto &e : s.rec_ev) if (e) (void)hipEventDestroy(e); s.rec_ev.clear(); s.host.release(); s.out.release(); s.dev.release(); }
+          for (Slot &s : d->slots) { if (s.ev) { (void)hipEventSynchronize(s.ev); (void)hipEventDestroy(s.ev); } for (auto &e : s.tev) if (e) (void)hipEventDestroy(e); for (auto &e : s.rec_ev) if (e) (void)hipEventDestroy(e); s.rec_ev.clear(); if (s.ev_up) (void)hipEventDestroy(s.ev_up); if (s.up) (void)hipStreamDestroy(s.up); s.ev_up = nullptr; s.up = nullptr; s.host.release(); s.out.release(); s.dev.release(); }
           mina_ctx_destroy(d->c); }
         delete d;
     }
@@ -190,6 +191,9 @@ struct CallMerger {
 };
 CallMerger g_state_calls, g_account_calls;
 }  // namespace
+
+// verdict words of a job, device staging -> the slot's page-locked buffer (see Slot::up)
+__global__ void words_out_kernel(uint32_t n, const uint32_t *__restrict__ src, uint32_t *__restrict__ dst) { const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) dst[i] = src[i]; }
 
 // ------------------------------------------------------------------------------------------------ Proof of State
 // bytes -> bools, pipelined (core/src/aligned.rs:31-58 builds the bytes; core/src/proof/state_proof.rs:10-41 their layout):
@@ -552,6 +556,8 @@ int run_device(Device &D, const CallIn &in, const std::vector<size_t> &idx, uint
         Slot &S = *ch.slot;
         if ((rc = S.dev.ensure(lay.total + Layout::out_bytes(lay.cap)))) return rc;
         if (!S.ev) HIPC(hipEventCreateWithFlags(&S.ev, hipEventDisableTiming));
+        if (!S.ev_up) HIPC(hipEventCreateWithFlags(&S.ev_up, hipEventDisableTiming));
+        if (!S.up) HIPC(hipStreamCreateWithFlags(&S.up, hipStreamNonBlocking));
         Lane &L = c->lanes[ch.slot_ix];
         if (!L.stream) HIPC(hipStreamCreateWithFlags(&L.stream, hipStreamNonBlocking));
         if (g_timing) for (auto &e : S.tev) if (!e) HIPC(hipEventCreate(&e));
@@ -587,6 +593,7 @@ int run_device(Device &D, const CallIn &in, const std::vector<size_t> &idx, uint
         ch.LI = LI; ch.LA = LA; ch.LS = LS;
         return MINA_OK;
     };
+    const bool own_up = getenv("MINA_VERIFY_UP_STREAM") ? atoi(getenv("MINA_VERIFY_UP_STREAM")) != 0 : true;
     auto lane_forms = [&]() {       // the lane forms of the sponge kernels follow the work in flight on the device (ctx.h use_coop*)
         c->nlanes = (int)std::max(1u, std::min<unsigned>(D.inflight.load(), NSLOT));
         c->hash_piece_waves = getenv("MINA_VERIFY_HASH_PIECE") ? (uint32_t)atoi(getenv("MINA_VERIFY_HASH_PIECE")) : 1024u;
@@ -614,9 +621,11 @@ int run_device(Device &D, const CallIn &in, const std::vector<size_t> &idx, uint
         lane_forms();
         c->L = &L;
         uint8_t *dbase = S.dev.as<uint8_t>();
-        if (g_timing) HIPC(hipEventRecord(S.tev[0], L.stream));
+        hipStream_t up = own_up ? S.up : L.stream;
+        if (g_timing) HIPC(hipEventRecord(S.tev[0], up));
         ch.queued = true;
-        HIPC(hipMemcpyAsync(dbase + lay.off[S_EXP], hbase + lay.off[S_EXP], lay.total - lay.off[S_EXP], hipMemcpyHostToDevice, L.stream));    // `precheck` lies in there: sent again by finish()
+        HIPC(hipMemcpyAsync(dbase + lay.off[S_EXP], hbase + lay.off[S_EXP], lay.total - lay.off[S_EXP], hipMemcpyHostToDevice, up));    // `precheck` lies in there: sent again by finish()
+        if (own_up) { HIPC(hipEventRecord(S.ev_up, up)); HIPC(hipStreamWaitEvent(L.stream, S.ev_up, 0)); }
         JobStructs js; make_jobs(sh, lay, dbase, ch.n, true, true, true, js);
         uint32_t *dv = (uint32_t *)(dbase + lay.out_off()), *df = dv + ch.n, *ds = df + 4;
         rc = mb_state_jobs_on_lane(c, &js.j, dv, df, ch.LI, ch.LA, ds, ch.LS, MB_JOB_LEGS, &ch.carry);
@@ -637,9 +646,10 @@ int run_device(Device &D, const CallIn &in, const std::vector<size_t> &idx, uint
             uint8_t *dbase = S.dev.as<uint8_t>();
             if (S.rec_ev.size() < ch.nsub) S.rec_ev.resize(ch.nsub, nullptr);
             if (!S.rec_ev[r]) HIPC(hipEventCreateWithFlags(&S.rec_ev[r], hipEventDisableTiming));
-            HIPC(hipMemcpyAsync(lay.at(dbase, S_REC, lo), lay.at(hbase, S_REC, lo), (hi - lo) * lay.stride[S_REC], hipMemcpyHostToDevice, L.stream));
-            HIPC(hipMemcpyAsync(lay.at(dbase, S_NF, lo), lay.at(hbase, S_NF, lo), (hi - lo) * lay.stride[S_NF], hipMemcpyHostToDevice, L.stream));
-            HIPC(hipEventRecord(S.rec_ev[r], L.stream));
+            hipStream_t up = own_up ? S.up : L.stream;
+            HIPC(hipMemcpyAsync(lay.at(dbase, S_REC, lo), lay.at(hbase, S_REC, lo), (hi - lo) * lay.stride[S_REC], hipMemcpyHostToDevice, up));
+            HIPC(hipMemcpyAsync(lay.at(dbase, S_NF, lo), lay.at(hbase, S_NF, lo), (hi - lo) * lay.stride[S_NF], hipMemcpyHostToDevice, up));
+            HIPC(hipEventRecord(S.rec_ev[r], up));
             lane_forms();
             // hashes in WHOLE pieces (a piece = `hash_piece_waves` waves of 21 states = two waves on every SIMD of the state leg's 128 CUs): a run of
             // 1024 entries is 829 waves -- launched run by run, a fifth of the leg's SIMDs would hold one wave where the others hold two, for as long
@@ -665,8 +675,10 @@ int run_device(Device &D, const CallIn &in, const std::vector<size_t> &idx, uint
         lane_forms();
         c->L = &L;
         uint8_t *dbase = S.dev.as<uint8_t>();
-        HIPC(hipMemcpyAsync(lay.at(dbase, S_PRE, 0), lay.at(hbase, S_PRE, 0), ch.n * lay.stride[S_PRE], hipMemcpyHostToDevice, L.stream));
-        if (g_timing) HIPC(hipEventRecord(S.tev[1], L.stream));
+        hipStream_t up = own_up ? S.up : L.stream;
+        HIPC(hipMemcpyAsync(lay.at(dbase, S_PRE, 0), lay.at(hbase, S_PRE, 0), ch.n * lay.stride[S_PRE], hipMemcpyHostToDevice, up));
+        if (g_timing) HIPC(hipEventRecord(S.tev[1], up));
+        if (own_up) { HIPC(hipEventRecord(S.ev_up, up)); HIPC(hipStreamWaitEvent(L.stream, S.ev_up, 0)); }
         JobStructs js; make_jobs(sh, lay, dbase, ch.n, true, true, true, js);
         uint32_t *dv = (uint32_t *)(dbase + lay.out_off()), *df = dv + ch.n, *ds = df + 4;
         c->state_hashes_early = ch.hashed;
@@ -676,7 +688,8 @@ int run_device(Device &D, const CallIn &in, const std::vector<size_t> &idx, uint
         c->use_lane0();
         if (rc) return rc;
         if (g_timing) HIPC(hipEventRecord(S.tev[2], L.stream));
-        HIPC(hipMemcpyAsync(S.out.p, dv, Layout::out_bytes(ch.n), hipMemcpyDeviceToHost, L.stream));
+        if (own_up) { const uint32_t words = (uint32_t)(Layout::out_bytes(ch.n) / 4); words_out_kernel<<<(words + 255) / 256, 256, 0, L.stream>>>(words, dv, (uint32_t *)S.out.p); HIPC(hipGetLastError()); }
+        else HIPC(hipMemcpyAsync(S.out.p, dv, Layout::out_bytes(ch.n), hipMemcpyDeviceToHost, L.stream));
         HIPC(hipEventRecord(S.ev, L.stream));
         ch.issued = true;
         return MINA_OK;
