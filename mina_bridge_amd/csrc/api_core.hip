@@ -181,7 +181,7 @@ extern "C" void *mina_ctx_stream(mina_ctx *c) { return c ? (void *)c->lanes[0].s
 
 extern "C" int mina_ctx_set_pipeline(mina_ctx *c, int lanes) {
     if (!c) return fail(MINA_ERR_ARG, "null ctx");
-    if (lanes < 1 || lanes > MB_MAX_LANES) return fail(MINA_ERR_ARG, "lanes must be in 1..32");
+    if (lanes < 1 || lanes > MB_PIPE_LANES) return fail(MINA_ERR_ARG, "lanes must be in 1..32");
     HIPC(hipSetDevice(c->device));
     for (int i = 0; i < c->nlanes; ++i) HIPC(hipStreamSynchronize(c->lanes[i].stream));
     for (int i = 0; i < lanes; ++i)

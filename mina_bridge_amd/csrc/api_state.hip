@@ -581,7 +581,7 @@ extern "C" int mina_state_job_batch(mina_ctx *c, const mina_state_jobs *jobs, ui
     // lane and any slice of them is the folded check of that slice (mb_ipa_recheck_rows): a round costs a fold + two MSMs per part.
     const bool rows_ok = hv[B + 1] == 0 && c->ipa_rows && c->ipa_rows_batch == B && getenv("MINA_STATE_SEARCH_FULL") == nullptr;
     auto search = [&](bool ipa_leg, std::vector<uint8_t> &each) -> int {
-        constexpr size_t FAN = MB_MAX_LANES;
+        constexpr size_t FAN = MB_PIPE_LANES;
         static const bool timing = getenv("MINA_VERIFY_TIMING") != nullptr;
         for (size_t i = 0; i < FAN; ++i)
             if (!c->lanes[i].stream) HIPC(hipStreamCreateWithFlags(&c->lanes[i].stream, hipStreamNonBlocking));

@@ -52,7 +52,7 @@ extern "C" int mina_poseidon_install_default_params(mina_ctx *c) {
 // mina_verify_state_batch cuts its proofs into contiguous shards, one per device (zero exchange, verdict bytes gathered
 // on the host); merged single-proof jobs are dealt round-robin.
 namespace {
-constexpr int NSLOT = 16;                  // chunks in flight per device: slot s runs on lane s of the context (helper lanes 16.. for forked legs)
+constexpr int NSLOT = 16;                  // chunks in flight per device: slot s runs on lane s of the context (helper lanes MB_PIPE_LANES + 3 s .. for its forked legs)
 // `up`: the slot's upload stream.  No copy of the pipeline waits for a kernel: the copy engines take their commands in order, and one that waits for a
 // kernel of its stream holds up the uploads of every other chunk queued behind it (calls of 65 536 proofs: the jobs of the 8 chunks started up to 300 ms
 // apart, rocprofv3 timeline).  So uploads have a stream of their own, and the verdict words go back through a kernel that writes the page-locked buffer.
@@ -568,9 +568,10 @@ int run_device(Device &D, const CallIn &in, const std::vector<size_t> &idx, uint
         if (ch.legs_set) return MINA_OK;
         ch.legs_set = true;
         // few chunks in flight: the three legs of a job (state hashes / wrap proof / accumulator) go to three streams
-        const unsigned split_max = getenv("MINA_VERIFY_SPLIT_MAX") ? (unsigned)atoi(getenv("MINA_VERIFY_SPLIT_MAX")) : 2u;
-        if (!(D.inflight.load() <= split_max && ch.slot_ix < 5)) return MINA_OK;
-        Lane *LI = &c->lanes[16 + 3 * ch.slot_ix], *LA = &c->lanes[17 + 3 * ch.slot_ix], *LS = &c->lanes[18 + 3 * ch.slot_ix];
+        // (up to 4 chunks in flight -- 32 768 proofs per call 186 -> 152 ms, three callers of 8192: 138 -> 158 k proofs/s; with 8 the streams outnumber the hardware queues: 322 -> 360 ms)
+        const unsigned split_max = getenv("MINA_VERIFY_SPLIT_MAX") ? (unsigned)atoi(getenv("MINA_VERIFY_SPLIT_MAX")) : 4u;
+        if (D.inflight.load() > split_max) return MINA_OK;
+        Lane *LI = &c->lanes[MB_PIPE_LANES + 3 * ch.slot_ix], *LA = &c->lanes[MB_PIPE_LANES + 3 * ch.slot_ix + 1], *LS = &c->lanes[MB_PIPE_LANES + 3 * ch.slot_ix + 2];
         // Alone on the GPU a job is a latency-bound chain of small kernels (~390 waves each, one behind the other) beside 20 ms of chip-filling
         // hashes; where their waves share a SIMD both run at half speed, and the call waits for the chain (rocprofv3 timeline: the statement
         // digests 10.7 ms beside the hashes against 4.1 ms alone).  So the chain's stream and the hashes' stream get DISJOINT CU masks: the chain

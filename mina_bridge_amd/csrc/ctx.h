@@ -107,7 +107,8 @@ struct Lane {
         host_stage.release();
     }
 };
-static constexpr int MB_MAX_LANES = 32;
+static constexpr int MB_PIPE_LANES = 32;                   // lanes a caller may pipeline over (mina_ctx_set_pipeline) = the fan-out of the culprit search
+static constexpr int MB_MAX_LANES = MB_PIPE_LANES + 3 * 16;  // + the helper lanes of the boundary's 16 slots (api_verify.hip: wrap-proof / accumulator / state legs of slot s on lanes 32 + 3 s ..)
 enum : int { MB_SALT_PSTATE_BODY = 0, MB_SALT_PSTATE, MB_SALT_ACCOUNT, MB_SALT_ZKAPP_ACCOUNT, MB_SALT_ZKAPP_URI, MB_SALT_SIDE_LOADED_VK, MB_N_PREFIX_SALTS };
 
 struct mina_ctx {
