@@ -452,7 +452,7 @@ struct Chunk {
     std::shared_ptr<MbPoolJob> jobA, jobB;
     size_t sub = 0, nsub = 0; std::unique_ptr<std::atomic<uint32_t>[]> sub_left; std::mutex mu; std::condition_variable cv;
     size_t hashed = 0;                        // protocol states whose hashes are queued
-    bool legs_set = false, queued = false; Lane *LI = nullptr, *LA = nullptr, *LS = nullptr; StateJobCarry carry;
+    bool legs_set = false, queued = false, counted = false; Lane *LI = nullptr, *LA = nullptr, *LS = nullptr; StateJobCarry carry;
 };
 
 const bool g_timing = getenv("MINA_VERIFY_TIMING") != nullptr;
@@ -491,6 +491,18 @@ int run_device(Device &D, const CallIn &in, const std::vector<size_t> &idx, uint
     const size_t chunk_target = getenv("MINA_VERIFY_CHUNK") ? (size_t)std::max(1L, atol(getenv("MINA_VERIFY_CHUNK"))) : (size_t)8192;
     const size_t single_max = getenv("MINA_VERIFY_SINGLE_MAX") ? (size_t)std::max(1L, atol(getenv("MINA_VERIFY_SINGLE_MAX"))) : (size_t)8192;
     const size_t nchunks = m <= single_max ? 1 : (m + chunk_target - 1) / chunk_target;
+    // chunks of ONE call on the GPU at a time (the next ones are parsed meanwhile)
+    // A call of more chunks than the window is a pipeline: jobs that enter the GPU together also leave it together (4 jobs started within 15 ms: all done
+    // at ~185 ms, then the next 4 -- 65 536 proofs: 345 ms), jobs one period apart keep the chip filled while one of them drains (four caller threads
+    // with 8192 proofs each reach 238 k proofs/s that way).  So the first `window` chunks of such a call are issued `pace_ms` apart.
+    const double pace_ms = getenv("MINA_VERIFY_PACE_MS") ? atof(getenv("MINA_VERIFY_PACE_MS")) : 0.0;
+    // (no parsing ahead of the window: a slot is a staging buffer AND four streams, and with more streams in use than the runtime's 16 hardware queues the
+    // jobs' legs wait for each other -- 65 536 proofs per call: 342 ms with two chunks parsed ahead, 285 ms with none; the wrap-proof halves of a chunk take 1 ms)
+    // slots of the device in use, over all callers: 4 jobs with their legs forked = 16 streams = the runtime's hardware queues (two callers of 32 768 proofs
+    // with 16 slots: 125 k proofs/s, six callers of 8192: 205 k -- against 235 k for four)
+    const int nslot = getenv("MINA_VERIFY_SLOTS") ? std::min(NSLOT, std::max(1, atoi(getenv("MINA_VERIFY_SLOTS")))) : 4;
+    const size_t ahead = getenv("MINA_VERIFY_AHEAD") ? (size_t)std::max(0L, atol(getenv("MINA_VERIFY_AHEAD"))) : (size_t)0;
+    const size_t window = getenv("MINA_VERIFY_WINDOW") ? (size_t)std::max(1L, atol(getenv("MINA_VERIFY_WINDOW"))) : (size_t)4;
     // streamed form of a chunk (stream_records below): from `early_min` entries, in runs of `early_sub` (0 = off)
     const size_t early_min = getenv("MINA_VERIFY_EARLY_MIN") ? (size_t)std::max(1L, atol(getenv("MINA_VERIFY_EARLY_MIN"))) : (size_t)2048;
     const size_t early_sub = getenv("MINA_VERIFY_EARLY_SUB") ? (size_t)std::max(0L, atol(getenv("MINA_VERIFY_EARLY_SUB"))) : (size_t)1024;
@@ -501,11 +513,10 @@ int run_device(Device &D, const CallIn &in, const std::vector<size_t> &idx, uint
     mina_ctx *c = D.c;
     int rc_all = MINA_OK;
     std::vector<size_t> deferred;
-    D.inflight.fetch_add((unsigned)nchunks);
 
     auto try_acquire = [&]() -> int {
         std::lock_guard<std::mutex> lk(D.slot_mu);
-        for (int s = 0; s < NSLOT; ++s) if (!D.slots[s].busy) { D.slots[s].busy = true; return s; }
+        for (int s = 0; s < nslot; ++s) if (!D.slots[s].busy) { D.slots[s].busy = true; return s; }
         return -1;
     };
     auto release = [&](int s) { { std::lock_guard<std::mutex> lk(D.slot_mu); D.slots[s].busy = false; } D.slot_cv.notify_all(); };
@@ -541,7 +552,7 @@ int run_device(Device &D, const CallIn &in, const std::vector<size_t> &idx, uint
             (void)hipDeviceSynchronize();
         }
         if (ch.slot_ix >= 0) release(ch.slot_ix);
-        D.inflight.fetch_sub(1);
+        if (ch.counted) D.inflight.fetch_sub(1);
     };
 
     // device side of a chunk's slot, before anything is queued on it (idempotent).  Caller holds D.mu.
@@ -697,8 +708,9 @@ int run_device(Device &D, const CallIn &in, const std::vector<size_t> &idx, uint
     };
 
     size_t next_submit = 0, next_issue = 0, oldest = 0;
+    auto t_issued = t_call;
     while (next_issue < nchunks && !rc_all) {
-        while (next_submit < nchunks) {
+        while (next_submit < nchunks && next_submit < oldest + window + ahead) {        // parsing runs `ahead` chunks ahead of the window
             const int s = try_acquire();
             if (s < 0) break;
             Chunk &ch = chunks[next_submit];
@@ -728,7 +740,14 @@ int run_device(Device &D, const CallIn &in, const std::vector<size_t> &idx, uint
             D.slot_cv.wait_for(lk, std::chrono::milliseconds(2));
             continue;
         }
+        if (next_issue - oldest >= window) { harvest(chunks[oldest++]); continue; }
+        if (pace_ms > 0 && nchunks > window && next_issue > 0 && next_issue < window) {      // fill the window one job period apart (see `pace_ms`)
+            const double wait = pace_ms - ms_since(t_issued);
+            if (wait > 0) std::this_thread::sleep_for(std::chrono::duration<double, std::milli>(wait));
+        }
+        t_issued = std::chrono::steady_clock::now();
         Chunk &ch = chunks[next_issue];
+        ch.counted = true; D.inflight.fetch_add(1);
         mb_pool_wait(ch.jobA);
         const double t_a = g_timing ? ms_since(t_call) : 0;
         int rc = issue_legs(ch);
@@ -744,7 +763,6 @@ int run_device(Device &D, const CallIn &in, const std::vector<size_t> &idx, uint
     for (size_t q = 0; q < next_submit; ++q) { mb_pool_wait(chunks[q].jobA); mb_pool_wait(chunks[q].jobB); }     // nothing may still write into a slot (error paths)
     for (size_t q = 0; q < nchunks; ++q) {
         if (q < next_submit) { harvest(chunks[q]); if (g_timing) fprintf(stderr, "mina_verify:   chunk %zu harvested at %.2f ms\n", q, ms_since(t_call)); }
-        else D.inflight.fetch_sub(1);
     }
     if (g_timing) fprintf(stderr, "mina_verify: device %d: %zu proofs in %zu chunk(s), %.2f ms\n", D.ordinal, m, nchunks, ms_since(t_call));
     if (rc_all) { for (size_t i = 0; i < m; ++i) verdicts[idx[i]] = 0; return rc_all; }

@@ -438,7 +438,7 @@ def test_boundary_pipeline_chunks_and_device_shards_give_the_same_verdicts(world
         else: p, q, v = good[i % 3][0], good[i % 3][1], 1
         proofs.append(p); pubs.append(q); want.append(v)
     assert m.lib.verify_state_batch(proofs, pubs).tolist() == want
-    env = {"MINA_VERIFY_CHUNK": None, "MINA_VERIFY_SINGLE_MAX": None, "MINA_VERIFY_MIN_SHARD": None, "MINA_VERIFY_DEVICES": None, "MINA_VERIFY_EARLY_MIN": None, "MINA_VERIFY_EARLY_SUB": None}
+    env = {"MINA_VERIFY_CHUNK": None, "MINA_VERIFY_SINGLE_MAX": None, "MINA_VERIFY_MIN_SHARD": None, "MINA_VERIFY_DEVICES": None, "MINA_VERIFY_EARLY_MIN": None, "MINA_VERIFY_EARLY_SUB": None, "MINA_VERIFY_WINDOW": None, "MINA_VERIFY_AHEAD": None}
     keep = {k: os.environ.get(k) for k in env}
     try:
         os.environ["MINA_VERIFY_SINGLE_MAX"] = "1"
@@ -455,6 +455,12 @@ def test_boundary_pipeline_chunks_and_device_shards_give_the_same_verdicts(world
             assert m.lib.verify_state_batch(proofs[14:25], pubs[14:25]).tolist() == want[14:25], "streamed to the end, all valid"
         os.environ["MINA_VERIFY_EARLY_SUB"] = "0"
         assert m.lib.verify_state_batch(proofs, pubs).tolist() == want, "streaming off"
+        # the window of chunks on the GPU at a time, and chunks parsed ahead of it (19 chunks of 2)
+        os.environ["MINA_VERIFY_SINGLE_MAX"] = "1"; os.environ["MINA_VERIFY_CHUNK"] = "2"; os.environ["MINA_VERIFY_EARLY_SUB"] = "1"
+        for window, ahead in (("1", "0"), ("3", "2"), ("16", "4")):
+            os.environ["MINA_VERIFY_WINDOW"] = window; os.environ["MINA_VERIFY_AHEAD"] = ahead
+            assert m.lib.verify_state_batch(proofs, pubs).tolist() == want, f"window {window}, {ahead} ahead"
+        os.environ.pop("MINA_VERIFY_WINDOW"); os.environ.pop("MINA_VERIFY_AHEAD")
         os.environ["MINA_VERIFY_EARLY_SUB"] = "4"; os.environ["MINA_VERIFY_SINGLE_MAX"] = "1"
         # three logical devices on GPU 0
         m.lib.verify_shutdown()

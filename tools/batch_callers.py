@@ -1,5 +1,7 @@
+# dev tool: N threads calling mina_verify_state_batch with SIZE full-size proofs each, CALLS times (a batcher's tasks): aggregate rate
+# usage: python tools/batch_callers.py THREADS SIZE CALLS
 import ctypes, json, os, sys, threading, time
-ROOT='/root/repo'
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 import numpy as np
@@ -20,7 +22,10 @@ def worker(k):
     out = np.zeros(size, np.uint8)
     for _ in range(k):
         rc = lib.mina_verify_state_batch(ctypes.c_size_t(size), PP, PL, QQ, QL, L._p(out)); assert rc == 0 and out.all()
-worker(2)
+# warm-up with the same number of threads: every slot the run will use allocates its page-locked staging (~480 MB each) on first use
+wu=[threading.Thread(target=worker,args=(2,)) for _ in range(nthreads)]
+for x in wu: x.start()
+for x in wu: x.join()
 th=[threading.Thread(target=worker,args=(calls,)) for _ in range(nthreads)]
 t=time.perf_counter()
 for x in th: x.start()
