@@ -50,10 +50,12 @@ def tampered(kind, c):
     elif kind == "flag": i = rng.randrange(len(w["feature_flags"])); w["feature_flags"][i] = not w["feature_flags"][i]
     elif kind == "offcurve": x, y = w["w_comm"][rng.randrange(15)]; w["w_comm"][0] = (x, (y + 1) % S.P if hasattr(S, "P") else y + 1)
     elif kind == "trunc": return c["proof"][: rng.randrange(len(c["proof"]))], pub
+    elif kind == "trunc_states": return c["proof"][: len(c["proof"]) - 1 - rng.randrange(17 * 1400)], pub        # the wrap-proof half parses, the protocol states do not
+    elif kind == "trailing": return c["proof"] + bytes([rng.randrange(256)]), pub
     return state_proof_bytes(w, c["states"]), pub
 
 pool = [(c["proof"], c["pub"], True) for c in cases]
-kinds = ["pub", "z1", "bp", "flag", "flag2", "offcurve", "trunc"]
+kinds = ["pub", "z1", "bp", "flag", "flag2", "offcurve", "trunc", "trunc_states", "trailing"]
 Q_MOD = 0x40000000000000000000000000000000224698FC0994A8DD8C46EB2100000001
 
 
@@ -85,6 +87,13 @@ while time.time() < t_end:
         batch[i], batch[j] = pa, pb
         counts["cancelling_pairs"] += 1
     want = [int(b[2]) for b in batch]
+    # the pipeline's shape, at random: chunks of a few entries, runs of a few entries, the window of chunks and the parsing ahead of it
+    for k in ("MINA_VERIFY_CHUNK", "MINA_VERIFY_SINGLE_MAX", "MINA_VERIFY_EARLY_MIN", "MINA_VERIFY_EARLY_SUB", "MINA_VERIFY_WINDOW", "MINA_VERIFY_AHEAD"): os.environ.pop(k, None)
+    if rng.randrange(2):
+        os.environ["MINA_VERIFY_CHUNK"] = str(rng.choice([2, 3, 7, 16])); os.environ["MINA_VERIFY_SINGLE_MAX"] = "1"
+        os.environ["MINA_VERIFY_WINDOW"] = str(rng.choice([1, 2, 4])); os.environ["MINA_VERIFY_AHEAD"] = str(rng.choice([0, 1, 3]))
+    if rng.randrange(2):
+        os.environ["MINA_VERIFY_EARLY_MIN"] = "1"; os.environ["MINA_VERIFY_EARLY_SUB"] = str(rng.choice([0, 1, 2, 5]))
     if rnd % 4 == 0 and n <= 40:
         got = [None] * n
         def worker(i): got[i] = int(m.lib.verify_state(batch[i][0], batch[i][1]))
