@@ -37,6 +37,39 @@ for it in items:
     ledger = [S.snarked_ledger_hash(s) for s in states[:16]]
     cases.append((state_proof_bytes(wrap, states), state_pub_bytes(True, hashes[16], hashes[:16], ledger)))
 assert all(m.lib.verify_state(p, q) for p, q in cases)
+# the callers as pthreads of a small C helper (no interpreter lock between a verdict and the next call: what a Rust / Go operator's tasks do)
+import ctypes, subprocess, tempfile
+helper_src = r"""
+#include <pthread.h>
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+bool mina_verify_state(const uint8_t *proof, size_t proof_len, const uint8_t *pub, size_t pub_len);
+struct job { const uint8_t *const *proofs; const size_t *pl; const uint8_t *const *pubs; const size_t *ql; int ncases, calls, t; long bad; };
+static void *worker(void *a) { struct job *j = a; for (int k = 0; k < j->calls; ++k) { int c = (j->t + k) % j->ncases; if (!mina_verify_state(j->proofs[c], j->pl[c], j->pubs[c], j->ql[c])) j->bad++; } return 0; }
+long run_callers(int nthreads, int calls, int ncases, const uint8_t *const *proofs, const size_t *pl, const uint8_t *const *pubs, const size_t *ql) {
+  pthread_t th[1024]; struct job jobs[1024]; long bad = 0;
+  for (int t = 0; t < nthreads; ++t) { jobs[t] = (struct job){proofs, pl, pubs, ql, ncases, calls, t, 0}; pthread_create(&th[t], 0, worker, &jobs[t]); }
+  for (int t = 0; t < nthreads; ++t) { pthread_join(th[t], 0); bad += jobs[t].bad; }
+  return bad; }
+"""
+tmp = tempfile.mkdtemp()
+open(os.path.join(tmp, "callers.c"), "w").write(helper_src)
+libdir = os.path.dirname(m.LIB_PATH)
+subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-pthread", os.path.join(tmp, "callers.c"), "-o", os.path.join(tmp, "libcallers.so"), "-L", libdir, "-lminaverify", "-Wl,-rpath," + libdir])
+helper = ctypes.CDLL(os.path.join(tmp, "libcallers.so"))
+helper.run_callers.restype = ctypes.c_long
+nc = len(cases)
+c_pr = (ctypes.c_char_p * nc)(*[c[0] for c in cases]); c_pl = (ctypes.c_size_t * nc)(*[len(c[0]) for c in cases])
+c_pu = (ctypes.c_char_p * nc)(*[c[1] for c in cases]); c_ql = (ctypes.c_size_t * nc)(*[len(c[1]) for c in cases])
+for nthreads in (1, 4, 16, 64, 256, 1024):
+    helper.run_callers(nthreads, 2, nc, c_pr, c_pl, c_pu, c_ql)
+    t0 = time.perf_counter()
+    bad = helper.run_callers(nthreads, per_thread, nc, c_pr, c_pl, c_pu, c_ql)
+    dt = time.perf_counter() - t0
+    assert bad == 0
+    print(json.dumps({"callers": "pthreads", "threads": nthreads, "calls": nthreads * per_thread, "seconds": round(dt, 4), "proofs_per_s": round(nthreads * per_thread / dt, 1),
+                      "ms_per_call_seen_by_a_thread": round(dt / per_thread * 1e3, 2)}))
 for nthreads in (1, 4, 16, 64, 256):
     bad = [0]
     def worker(t):
