@@ -347,7 +347,7 @@ def main():
     # queue pool first (67 - 72 ms).  GPU_MAX_HW_QUEUES=16 there: with the system runtime a lone job's three legs overlap best at <= 16 (54.6 ms;
     # 24: 68.4 ms), while the 16-lane pipeline of the headline below wants one queue per lane plus a few (24).
     boundary = None
-    if not args.no_boundary and os.environ.get("MINA_BENCH_SHARE_GPU") != "1":
+    if not args.no_boundary and os.environ.get("MINA_BENCH_SHARE_GPU") != "1" and int(os.environ.get("RANK", "0")) == 0:      # rank 0 reports it; the others wait at the first barrier
         import subprocess
         env = dict(os.environ); env["GPU_MAX_HW_QUEUES"] = os.environ.get("MINA_BOUNDARY_HW_QUEUES", "16")
         try:
