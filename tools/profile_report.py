@@ -13,7 +13,8 @@ tag, bench = sys.argv[1], sys.argv[2]
 d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "prof_" + tag)
 b = json.loads(open(bench).read().strip().split("\n")[-1])
 STEPS = 14                                                   # --steps 10 --warmup 4 of the single-lane passes
-print(f"# Round 2 profile ({tag}) -- `python bench.py` (default mode `{b['config'].get('mode', 'prepared')}`: {b['config']['proofs_per_step']} proofs per step, "
+rnd = tag[1:3].lstrip("0")
+print(f"# Round {rnd} profile ({tag}) -- `python bench.py` (default mode `{b['config'].get('mode', 'prepared')}`: {b['config']['proofs_per_step']} proofs per step, "
       f"{b['config']['pipeline_lanes']} lanes) on one MI355X\n")
 print(f"Raw rocprofv3 output: `gpurun_out/prof_{tag}/` (scratch).  Commands: `tools/profile_round.sh {tag}` (kernel-trace + stats of the default bench command; "
       f"FETCH_SIZE and WRITE_SIZE in separate `--pmc` passes with `--pipeline 1` so that kernels do not overlap) and `tools/profile_sq.sh {tag}` (SQ counters, own "
