@@ -602,7 +602,10 @@ int run_device(Device &D, const CallIn &in, const std::vector<size_t> &idx, uint
                 if (ln.stream) return MINA_OK;
                 uint32_t mk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
                 for (uint32_t b2 = 0; b2 < (uint32_t)ncu; ++b2) { const bool in_chain = (b2 % period) < chain_cus * period / 256; if (in_chain == chain) mk[b2 >> 5] |= 1u << (b2 & 31); }
-                HIPC(hipExtStreamCreateWithCUMask(&ln.stream, 8, mk));
+                if (hipExtStreamCreateWithCUMask(&ln.stream, 8, mk) != hipSuccess) {       // a runtime without CU masks: plain streams, the legs share the CUs
+                    (void)hipGetLastError(); ln.stream = nullptr;
+                    HIPC(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
+                }
                 return MINA_OK;
             };
             int rc;
