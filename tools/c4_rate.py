@@ -19,11 +19,12 @@ for a in accounts:
     path = [(rng.randrange(2), rng.randrange(R.P)) for _ in range(35)]
     enc = A.abi_encode_account(a)
     proofs.append(A.write_account_proof(path, a)); pubs.append(R.merkle_root(leaf, path, pp).to_bytes(32, "little") + struct.pack("<Q", len(enc)) + enc)
+m.lib.verify_configure(m.lib.VERIFY_ALLOW_SURROGATE)            # the compiled-in Poseidon tables are the surrogate set: the boundary answers `false` without the flag
 print(json.dumps({"proof_bytes": [len(p) for p in proofs], "pub_bytes": [len(q) for q in pubs]}))
 for n in (1, 256, 4096, 16384):
     P = [proofs[i % 4] for i in range(n)]; Q = [pubs[i % 4] for i in range(n)]
     assert m.lib.verify_account_batch(P, Q).all()
-    t = time.perf_counter(); reps = 3
+    t = time.perf_counter(); reps = 8
     for _ in range(reps):
         m.lib.verify_account_batch(P, Q)
     dt = (time.perf_counter() - t) / reps

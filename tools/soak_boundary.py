@@ -77,7 +77,8 @@ t_end = time.time() + budget; rnd = 0
 while time.time() < t_end:
     rnd += 1
     n = rng.choice([1, 2, 3, 5, 8, 13, 24, 33, 40, 70, 130])
-    nbad = rng.choice([0, 0, 1, 1, 2, 3, n // 4])
+    if rnd % 25 == 0: n = rng.choice([2100, 4500, 9000, 17000])      # the streamed form at its real sizes: runs of 1024, hash pieces, several chunks
+    nbad = rng.choice([0, 0, 1, 1, 2, 3, n // 4]) if n < 2000 else rng.choice([0, 1, 3, 40])
     batch = [pool[rng.randrange(4)] for _ in range(n)]
     for pos in rng.sample(range(n), min(nbad, n)):
         batch[pos] = rng.choice(bad_pool[rng.choice(kinds)])
@@ -89,10 +90,11 @@ while time.time() < t_end:
     want = [int(b[2]) for b in batch]
     # the pipeline's shape, at random: chunks of a few entries, runs of a few entries, the window of chunks and the parsing ahead of it
     for k in ("MINA_VERIFY_CHUNK", "MINA_VERIFY_SINGLE_MAX", "MINA_VERIFY_EARLY_MIN", "MINA_VERIFY_EARLY_SUB", "MINA_VERIFY_WINDOW", "MINA_VERIFY_AHEAD"): os.environ.pop(k, None)
-    if rng.randrange(2):
+    if n >= 2000: pass                                     # library defaults
+    elif rng.randrange(2):
         os.environ["MINA_VERIFY_CHUNK"] = str(rng.choice([2, 3, 7, 16])); os.environ["MINA_VERIFY_SINGLE_MAX"] = "1"
         os.environ["MINA_VERIFY_WINDOW"] = str(rng.choice([1, 2, 4])); os.environ["MINA_VERIFY_AHEAD"] = str(rng.choice([0, 1, 3]))
-    if rng.randrange(2):
+    if n < 2000 and rng.randrange(2):
         os.environ["MINA_VERIFY_EARLY_MIN"] = "1"; os.environ["MINA_VERIFY_EARLY_SUB"] = str(rng.choice([0, 1, 2, 5]))
     if rnd % 4 == 0 and n <= 40:
         got = [None] * n
