@@ -52,7 +52,7 @@ extern "C" int mina_poseidon_install_default_params(mina_ctx *c) {
 // mina_verify_state_batch cuts its proofs into contiguous shards, one per device (zero exchange, verdict bytes gathered
 // on the host); merged single-proof jobs are dealt round-robin.
 namespace {
-constexpr int NSLOT = 16;                  // chunks in flight per device: slot s runs on lane s of the context (helper lanes MB_PIPE_LANES + 3 s .. for its forked legs)
+constexpr int NSLOT = 16;                  // most chunks in flight per device ($MINA_VERIFY_SLOTS of them in use: 4): slot s runs on lane s of the context (helper lanes MB_PIPE_LANES + 3 s .. for its forked legs)
 // `up`: the slot's upload stream.  No copy of the pipeline waits for a kernel: the copy engines take their commands in order, and one that waits for a
 // kernel of its stream holds up the uploads of every other chunk queued behind it (calls of 65 536 proofs: the jobs of the 8 chunks started up to 300 ms
 // apart, rocprofv3 timeline).  So uploads have a stream of their own, and the verdict words go back through a kernel that writes the page-locked buffer.
@@ -203,11 +203,11 @@ __global__ void words_out_kernel(uint32_t n, const uint32_t *__restrict__ src, u
 
 // ------------------------------------------------------------------------------------------------ Proof of State
 // bytes -> bools, pipelined (core/src/aligned.rs:31-58 builds the bytes; core/src/proof/state_proof.rs:10-41 their layout):
-//   the proofs of a call are cut into chunks of ~1024; the host pool parses chunk i + 1 STRAIGHT INTO the page-locked structure-of-arrays
-//   staging of its slot (bincode containers, 17 protocol states flattened by `to_input`, ledger / consensus checks) while chunk i is copied
-//   to the GPU and chunk i - 1 runs on its lane (mb_state_jobs_on_lane: no host synchronisation inside); verdict words come back through
-//   page-locked memory.  No per-call allocation, no gather copy.  A chunk whose folded check fails goes through the culprit search of
-//   mina_state_job_batch from the same staging.
+//   a call is cut into chunks of 8192 proofs; the host pool parses a chunk STRAIGHT INTO the page-locked structure-of-arrays staging of its
+//   slot, in two halves -- the wrap proofs, then the 17 protocol states per proof (`to_input` flattening, ledger / consensus checks) -- and each
+//   half goes to the GPU as soon as it exists (issue_legs / stream_records / finish in run_device; mb_state_jobs_on_lane: no host synchronisation
+//   inside); up to four chunks are on the GPU at a time, verdict words come back through page-locked memory.  No per-call allocation, no gather
+//   copy.  A chunk whose folded check fails goes through the culprit search of mina_state_job_batch from the same staging.
 namespace {
 struct Shape { bool kimchi = false, statements = false, feature_aware = false; uint32_t k = 0, n_prev = 2, n_old = 0, n_ev = 0; int network = -1; };
 enum Sec : int { S_REC = 0, S_NF, S_EXP, S_PRE, S_APRE, S_ASG, S_ARHO, S_LR, S_DELTA, S_SG, S_Z1, S_Z2, S_PCM, S_WC, S_ZC, S_TC, S_EV, S_FT1, S_PCH,
