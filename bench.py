@@ -642,7 +642,13 @@ def main():
             "c5_4096_total_strong": c5,
             "boundary_bytes_to_bools": boundary,
             "c2_accumulator_only": {"value": c2_rate, "unit": "accumulator checks/s",
-                                    "note": "BASELINE config C2 alone (round 1's headline): un-folded 2^16-base Vesta IPA accumulator checks, 8 per call, 16 lanes"},
+                                    "note": "BASELINE config C2 alone (round 1's headline): un-folded 2^16-base Vesta IPA accumulator checks, 8 per call, 16 lanes",
+                                    # the metric's second half ("MSM HBM GB/s vs peak"): one check = one 2^16-base MSM; algorithmic bytes = bases + scalars
+                                    "msm_hbm": None if not c2_rate else {"algorithmic_bytes_per_msm": 65536 * (64 + 32), "achieved_GBps": c2_rate * 65536 * 96 / 1e9, "peak_GBps": HBM_PEAK_GBPS,
+                                                                         "frac": c2_rate * 65536 * 96 / 1e9 / HBM_PEAK_GBPS,
+                                                                         "note": "the bucket MSM is bound by the group law's multiply-accumulates (msm_accumulate_bucket_kernel 58 % of a check, "
+                                                                                 "bucket reductions 19 %: tools/c2_rate.py under rocprofv3), not by HBM; with the 16-window fixed-base tables the kernel "
+                                                                                 "actually reads 64 MiB per MSM (~10x the algorithmic bytes) and is still far from the HBM roof"}},
         }
         if kern_us:
             peak = CHIP_SIMDS * 64 * CLOCK_HZ / MAD_ISSUE_CYCLES
