@@ -674,8 +674,10 @@ int run_device(Device &D, const CallIn &in, const std::vector<size_t> &idx, uint
             lane_forms();
             // hashes in WHOLE pieces (a piece = `hash_piece_waves` waves of 21 states = two waves on every SIMD of the state leg's 128 CUs): a run of
             // 1024 entries is 829 waves -- launched run by run, a fifth of the leg's SIMDs would hold one wave where the others hold two, for as long
-            const size_t piece = (size_t)c->hash_piece_waves * 21, ready = hi * MINA_STATES_PER_PROOF;
-            const size_t upto = (r + 1 == ch.nsub || !piece) ? ready : ready / piece * piece;
+            // The odd piece goes FIRST: it is complete after fewer runs, so the leg starts earlier, and it ends with a full piece instead of a half-empty one.
+            const size_t piece = (size_t)c->hash_piece_waves * 21, ready = hi * MINA_STATES_PER_PROOF, total = ch.n * MINA_STATES_PER_PROOF;
+            const size_t first = piece ? (total % piece ? total % piece : piece) : 0;
+            const size_t upto = (r + 1 == ch.nsub || !piece) ? ready : (ready < first ? 0 : first + (ready - first) / piece * piece);
             int rc = MINA_OK;
             if (upto > ch.hashed)
                 rc = mb_state_hashes_early(c, ch.LS ? ch.LS : &L, ch.n * MINA_STATES_PER_PROOF, ch.hashed, upto - ch.hashed,
