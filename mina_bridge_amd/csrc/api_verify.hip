@@ -148,13 +148,14 @@ extern "C" int mina_verify_set_poseidon_params(int field, const uint8_t *params)
 // so one caller's proof cannot be built to cancel another's.  MINA_VERIFY_NO_MERGE=1 sends every call through on its own;
 // MINA_VERIFY_LINGER_US (default 500) is how long the leader of a job waits for the callers of the previous job to come back before it leaves.
 namespace {
-struct PendingCall { const uint8_t *proof; size_t proof_len; const uint8_t *pub; size_t pub_len; uint8_t verdict = 0; bool done = false, claimed = false; int rc = MINA_OK; };
+struct PendingCall { const uint8_t *proof; size_t proof_len; const uint8_t *pub; size_t pub_len; uint8_t verdict = 0; bool done = false, claimed = false; int rc = MINA_OK; size_t owner = 0; };
 typedef void (*exec_fn_t)(std::vector<PendingCall *> &job);           // sets `verdict` of every call of the job
 struct CallMerger {
     std::mutex mu; std::condition_variable cv, arrived; std::vector<PendingCall *> waiting;
     bool collecting = false;             // a leader is gathering its job (the linger): arrivals join it instead of leading jobs of their own
     size_t active = 0;                   // jobs running: up to MAX_ACTIVE overlap on the device (the pipeline's slots; a job is a latency-bound chain)
     size_t last_job = 0;                 // calls merged into the previous job: its callers return together and call again within microseconds
+    std::vector<std::pair<size_t, size_t>> last_owners;   // ... by calling thread
     static constexpr size_t MAX_JOB = 8192;
     bool run(exec_fn_t exec, PendingCall &me) { run_group(exec, &me, 1); return me.verdict == 1; }
     // the calls of one caller -- one proof (the reference's entry point) or a small batch -- wait here for a job to take them
@@ -165,18 +166,21 @@ struct CallMerger {
         static const size_t max_active = getenv("MINA_VERIFY_MAX_JOBS") ? (size_t)std::max(1L, atol(getenv("MINA_VERIFY_MAX_JOBS"))) : (size_t)1;
         auto all_done = [&] { for (size_t i = 0; i < count; ++i) if (!mine[i].done) return false; return true; };
         auto all_claimed = [&] { for (size_t i = 0; i < count; ++i) if (!mine[i].claimed) return false; return true; };
+        const size_t me = std::hash<std::thread::id>()(std::this_thread::get_id());
         std::unique_lock<std::mutex> lk(mu);
-        for (size_t i = 0; i < count; ++i) waiting.push_back(&mine[i]);
+        for (size_t i = 0; i < count; ++i) { mine[i].owner = me; waiting.push_back(&mine[i]); }
         arrived.notify_all();
         while (!all_done()) {
             if (all_claimed() || collecting || active >= max_active) { cv.wait(lk); continue; }   // my calls are in jobs / a leader is gathering / every job slot is taken: woken on every change
             ++active; collecting = true;                                      // lead the next job: everything queued by the time it leaves (these calls included)
-            if ((last_job > 0 || active > 1) && linger_us > 0) {              // other callers are about: those of the job that just ended are on their way back (in
+            size_t foreign = last_job;                                        // calls of OTHER threads in the job that just ended (a caller alone with the library waits for nobody)
+            { auto it = std::lower_bound(last_owners.begin(), last_owners.end(), std::make_pair(me, (size_t)0)); if (it != last_owners.end() && it->first == me) foreign -= std::min(foreign, it->second); }
+            if ((foreign > 0 || active > 1) && linger_us > 0) {               // other callers are about: those of the job that just ended are on their way back (in
                 // ADDITION to the ones that queued up while it ran -- leaving without them splits the callers into two groups that take turns, each call
                 // then lasting two jobs: 16 threads saw 43 ms per call, 23 ms once the leader waits), and while another job runs a moment's wait costs nothing
                 // (waking N threads and getting them back here takes longer the more there are: 2 us per caller of the last job on top, 4 ms at most)
-                const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(linger_us + (long)std::min<size_t>(2 * last_job, 4000));
-                const size_t expect = waiting.size() + std::max<size_t>(last_job, 1);
+                const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(linger_us + (long)std::min<size_t>(2 * foreign, 4000));
+                const size_t expect = waiting.size() + std::max<size_t>(foreign, 1);
                 while (waiting.size() < expect && arrived.wait_until(lk, deadline) != std::cv_status::timeout) {}
             }
             const size_t n = std::min(waiting.size(), MAX_JOB);
@@ -190,6 +194,9 @@ struct CallMerger {
             lk.lock();
             for (PendingCall *p : job) p->done = true;
             last_job = n;
+            last_owners.clear();
+            { std::vector<size_t> ow; ow.reserve(n); for (PendingCall *p : job) ow.push_back(p->owner); std::sort(ow.begin(), ow.end());
+              for (size_t i = 0; i < ow.size();) { size_t j = i; while (j < ow.size() && ow[j] == ow[i]) ++j; last_owners.push_back({ow[i], j - i}); i = j; } }
             --active;
             cv.notify_all();
         }
@@ -976,9 +983,7 @@ extern "C" int mina_verify_account_checks(const uint8_t *proof, size_t proof_len
     std::lock_guard<std::mutex> lk(D->mu);
     return mina_verify_account_ctx(D->c, 1, &proof, &proof_len, &pub, &pub_len, passed_mask, ran_mask);
 }
-extern "C" int mina_verify_account_batch(size_t n, const uint8_t *const *proofs, const size_t *proof_lens, const uint8_t *const *pubs, const size_t *pub_lens,
-                                         uint8_t *verdicts_out) {
-    if (n && (!proofs || !proof_lens || !pubs || !pub_lens || !verdicts_out)) return fail(MINA_ERR_ARG, "null argument");
+static int account_batch_direct(size_t n, const uint8_t *const *proofs, const size_t *proof_lens, const uint8_t *const *pubs, const size_t *pub_lens, uint8_t *verdicts_out) {
     for (size_t i = 0; i < n; ++i) verdicts_out[i] = 0;
     if (n == 0) return MINA_OK;
     std::vector<uint32_t> passed(n), ran(n);
@@ -998,8 +1003,25 @@ static void exec_account_calls(std::vector<PendingCall *> &job) {
     const size_t n = job.size();
     std::vector<const uint8_t *> pr(n), pu(n); std::vector<size_t> pl(n), ul(n); std::vector<uint8_t> v(n, 0);
     for (size_t i = 0; i < n; ++i) { pr[i] = job[i]->proof; pl[i] = job[i]->proof_len; pu[i] = job[i]->pub; ul[i] = job[i]->pub_len; }
-    const int rc = mina_verify_account_batch(n, pr.data(), pl.data(), pu.data(), ul.data(), v.data());
-    for (size_t i = 0; i < n; ++i) job[i]->verdict = rc == MINA_OK ? v[i] : 0;
+    const int rc = account_batch_direct(n, pr.data(), pl.data(), pu.data(), ul.data(), v.data());
+    for (size_t i = 0; i < n; ++i) { job[i]->verdict = rc == MINA_OK ? v[i] : 0; job[i]->rc = rc; }
+}
+extern "C" int mina_verify_account_batch(size_t n, const uint8_t *const *proofs, const size_t *proof_lens, const uint8_t *const *pubs, const size_t *pub_lens,
+                                         uint8_t *verdicts_out) {
+    if (n && (!proofs || !proof_lens || !pubs || !pub_lens || !verdicts_out)) return fail(MINA_ERR_ARG, "null argument");
+    // BASELINE C4's batch of 256 is a latency-bound job (a dependent chain of ~70 permutations: 8 ms for 1 or for 1024 proofs): concurrent small
+    // batches share jobs the way single-proof calls do
+    static const size_t merge_max = getenv("MINA_VERIFY_MERGE_BATCH_MAX") ? (size_t)std::max(0L, atol(getenv("MINA_VERIFY_MERGE_BATCH_MAX"))) : (size_t)512;
+    if (n && n <= merge_max && getenv("MINA_VERIFY_NO_MERGE") == nullptr) {
+        std::vector<PendingCall> calls(n);
+        for (size_t i = 0; i < n; ++i) { calls[i].proof = proofs[i]; calls[i].proof_len = proof_lens[i]; calls[i].pub = pubs[i]; calls[i].pub_len = pub_lens[i]; }
+        g_account_calls.run_group(exec_account_calls, calls.data(), n);
+        int rc = MINA_OK;
+        for (size_t i = 0; i < n; ++i) { verdicts_out[i] = calls[i].verdict; if (calls[i].rc && !rc) rc = calls[i].rc; }
+        if (rc) for (size_t i = 0; i < n; ++i) verdicts_out[i] = 0;
+        return rc;
+    }
+    return account_batch_direct(n, proofs, proof_lens, pubs, pub_lens, verdicts_out);
 }
 extern "C" bool mina_verify_account(const uint8_t *proof, size_t proof_len, const uint8_t *pub, size_t pub_len) {
     PendingCall me{proof, proof_len, pub, pub_len};
