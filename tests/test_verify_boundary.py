@@ -202,6 +202,16 @@ def test_verify_account_end_to_end(world, srs_oracle, ctx, tmp_path):
     for t in th: t.start()
     for t in th: t.join()
     assert got == [c[2] for c in calls]
+    # small BATCHES from several threads share jobs the same way: thread t's batch of 12 has a tampered public input at index t, another at 11
+    outs = [None] * 6
+    def batch_worker(t):
+        P = [proofs[(t + j) % 4] for j in range(12)]; Q = [pubs[(t + j) % 4] for j in range(12)]
+        Q[t] = pubs[(t + t + 1) % 4]; Q[11] = pubs[(t + 11 + 2) % 4]
+        for _ in range(3): outs[t] = m.lib.verify_account_batch(P, Q).tolist()
+    th = [threading.Thread(target=batch_worker, args=(t,)) for t in range(6)]
+    for t in th: t.start()
+    for t in th: t.join()
+    for t in range(6): assert outs[t] == [0 if j in (t, 11) else 1 for j in range(12)], (t, outs[t])
 
 
 def test_c_consumer_of_the_boundary(world, srs_oracle, tmp_path):
