@@ -384,7 +384,7 @@ int mina_state_jobs_prepare(mina_ctx *ctx, uint32_t log2_domain, uint32_t npub);
  * d_verdicts: batch u32, 1 = proof accepted.  d_flags (may be NULL): 4 u32 {folded IPA ok, IPA input malformed, folded accumulator ok, 0};
  * when a folded check fails every verdict of the batch is 0 (the host-buffer form below then finds the culprits). */
 int mina_state_job_batch_dev(mina_ctx *ctx, const mina_state_jobs *jobs, void *d_verdicts, void *d_flags);
-/* Host-buffer form: one upload, the pipeline, one download; on a folded failure the failing range is cut into up to 32 parts that are
+/* Host-buffer form: one upload, the pipeline, one download; on a folded failure the failing range is cut into four parts ($MINA_SEARCH_FAN) that are
  * re-checked concurrently (and failing parts cut again) so that every proof gets its own verdict byte; the opening check of well-formed
  * proofs is re-checked from the rows of the failed batch, without repeating the transcripts. */
 int mina_state_job_batch(mina_ctx *ctx, const mina_state_jobs *jobs, uint8_t *verdicts /* batch */);

@@ -573,19 +573,25 @@ extern "C" int mina_state_job_batch(mina_ctx *c, const mina_state_jobs *jobs, ui
         adv(s.acc_prechallenges, (size_t)s.acc_k * 16); adv(s.acc_sg, 64); adv(s.acc_rho, 32);
         return s;
     };
-    // the culprits of one folded leg: a failing range is cut into up to FAN = 32 parts whose jobs run CONCURRENTLY on lanes 0..FAN-1 of the
-    // context (inputs stay where lane 0 uploaded them; every lane has its own verdict words); parts that fail are cut again.
-    // Depth log_FAN(B) rounds of ~one job latency each, where a bisection ran log2(B) jobs one after the other per culprit
-    // (24 proofs with 8 bad ones: 820 ms -> 150 ms).
+    // the culprits of one folded leg: a failing range is cut into FAN parts whose jobs run CONCURRENTLY on lanes 0..FAN-1 of the context
+    // (inputs stay where lane 0 uploaded them; every lane has its own verdict words); parts that fail are cut again: depth log_FAN(B) rounds
+    // of ~one job latency each, where a bisection ran log2(B) jobs one after the other per culprit.  FAN = 4 ($MINA_SEARCH_FAN): with 32 -- the
+    // fan-out until the end of round 3 -- a search over 8192 proofs took 370 ms instead of 165, and the 28 streams it created left the process
+    // with more streams than the runtime has hardware queues: every later call of the boundary was 30 % slower, for the life of the process
+    // (tools/after_search.py; destroying the streams afterwards does not undo it).
     // The opening leg of well-formed proofs does not repeat its transcripts: the prepared rows of the failed batch are still on their
     // lane and any slice of them is the folded check of that slice (mb_ipa_recheck_rows): a round costs a fold + two MSMs per part.
     const bool rows_ok = hv[B + 1] == 0 && c->ipa_rows && c->ipa_rows_batch == B && getenv("MINA_STATE_SEARCH_FULL") == nullptr;
     auto search = [&](bool ipa_leg, std::vector<uint8_t> &each) -> int {
-        constexpr size_t FAN = MB_PIPE_LANES;
+        static const size_t FAN = getenv("MINA_SEARCH_FAN") ? std::min<size_t>(MB_PIPE_LANES, std::max<long>(2, atol(getenv("MINA_SEARCH_FAN")))) : (size_t)4;
         static const bool timing = getenv("MINA_VERIFY_TIMING") != nullptr;
+        // streams this search had to create are destroyed when it is done
+        struct Restore {
+            mina_ctx *c; std::vector<size_t> made;
+            ~Restore() { for (size_t i : made) if (c->lanes[i].stream) { (void)hipStreamSynchronize(c->lanes[i].stream); (void)hipStreamDestroy(c->lanes[i].stream); c->lanes[i].stream = nullptr; } c->use_lane0(); }
+        } restore{c, {}};
         for (size_t i = 0; i < FAN; ++i)
-            if (!c->lanes[i].stream) HIPC(hipStreamCreateWithFlags(&c->lanes[i].stream, hipStreamNonBlocking));
-        struct Restore { mina_ctx *c; ~Restore() { c->use_lane0(); } } restore{c};
+            if (!c->lanes[i].stream) { HIPC(hipStreamCreateWithFlags(&c->lanes[i].stream, hipStreamNonBlocking)); restore.made.push_back(i); }
         std::vector<std::pair<size_t, size_t>> failing{{0, B}};
         while (!failing.empty()) {
             std::vector<std::pair<size_t, size_t>> parts;
@@ -598,7 +604,7 @@ extern "C" int mina_state_job_batch(mina_ctx *c, const mina_state_jobs *jobs, ui
             const auto t_round = std::chrono::steady_clock::now();
             for (size_t base = 0; base < parts.size(); base += FAN) {
                 const size_t w = std::min(FAN, parts.size() - base);
-                uint32_t *flags_at[FAN];
+                uint32_t *flags_at[MB_PIPE_LANES];
                 for (size_t q = 0; q < w; ++q) {                      // issue: nothing here waits for the GPU
                     const auto [lo, cnt] = parts[base + q];
                     c->L = &c->lanes[q];
