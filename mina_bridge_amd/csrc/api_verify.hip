@@ -617,6 +617,10 @@ int run_device(Device &D, const CallIn &in, const std::vector<size_t> &idx, uint
             };
             int rc;
             if ((rc = masked(*LI, true)) || (rc = masked(*LS, false))) return rc;
+            // the accumulator leg (fold GEMM + one MSM: chip-filling kernels, done within ~8 ms) shares the chain's CUs: the hashes are the later leg of a lone
+            // job, and unmasked this leg slowed their first pieces (8192 per call: 45.4 -> 44.5 ms; $MINA_VERIFY_ACC_MASK = chain | hash | none)
+            { const char *am = getenv("MINA_VERIFY_ACC_MASK");
+              if (!am || !strcmp(am, "chain")) { if ((rc = masked(*LA, true))) return rc; } else if (!strcmp(am, "hash")) { if ((rc = masked(*LA, false))) return rc; } }
         } else LS = nullptr;
         ch.LI = LI; ch.LA = LA; ch.LS = LS;
         return MINA_OK;
