@@ -462,7 +462,7 @@ struct Chunk {
     size_t lo = 0, n = 0; Slot *slot = nullptr; int slot_ix = -1; std::vector<HostBits> hb; bool issued = false, skipped = false, harvested = false;
     // two pool jobs per chunk: the wrap-proof halves of its entries (A), then the protocol-state halves (B) in `nsub` runs of `sub` entries -- the
     // records of a run go to the GPU, and their hashes are queued, as soon as the run is parsed
-    std::shared_ptr<MbPoolJob> jobA, jobB;
+    std::shared_ptr<MbPoolJob> jobH, jobA, jobB; size_t head = 0;
     size_t sub = 0, nsub = 0; std::unique_ptr<std::atomic<uint32_t>[]> sub_left; std::mutex mu; std::condition_variable cv;
     size_t hashed = 0;                        // protocol states whose hashes are queued
     bool legs_set = false, queued = false, counted = false, randomised = false; Lane *LI = nullptr, *LA = nullptr, *LS = nullptr; StateJobCarry carry;
@@ -513,6 +513,7 @@ int run_device(Device &D, const CallIn &in, const std::vector<size_t> &idx, uint
     // jobs' legs wait for each other -- 65 536 proofs per call: 342 ms with two chunks parsed ahead, 285 ms with none; the wrap-proof halves of a chunk take 1 ms)
     // slots of the device in use, over all callers: 4 jobs with their legs forked = 16 streams = the runtime's hardware queues (two callers of 32 768 proofs
     // with 16 slots: 125 k proofs/s, six callers of 8192: 205 k -- against 235 k for four)
+    const size_t head_min = getenv("MINA_VERIFY_HEAD_MIN") ? (size_t)std::max(0L, atol(getenv("MINA_VERIFY_HEAD_MIN"))) : (size_t)6144;      // 0: every streamed chunk; huge: never
     const int nslot = getenv("MINA_VERIFY_SLOTS") ? std::min(NSLOT, std::max(1, atoi(getenv("MINA_VERIFY_SLOTS")))) : 4;
     const size_t ahead = getenv("MINA_VERIFY_AHEAD") ? (size_t)std::max(0L, atol(getenv("MINA_VERIFY_AHEAD"))) : (size_t)0;
     const size_t window = getenv("MINA_VERIFY_WINDOW") ? (size_t)std::max(1L, atol(getenv("MINA_VERIFY_WINDOW"))) : (size_t)4;
@@ -654,7 +655,7 @@ int run_device(Device &D, const CallIn &in, const std::vector<size_t> &idx, uint
         c->L = &L;
         uint8_t *dbase = S.dev.as<uint8_t>();
         hipStream_t up = own_up ? S.up : L.stream;
-        if (g_timing) HIPC(hipEventRecord(S.tev[0], up));
+        if (g_timing && !ch.queued) HIPC(hipEventRecord(S.tev[0], up));
         ch.queued = true;
         HIPC(hipMemcpyAsync(dbase + lay.off[S_EXP], hbase + lay.off[S_EXP], lay.total - lay.off[S_EXP], hipMemcpyHostToDevice, up));    // `precheck` lies in there: sent again by finish()
         if (own_up) { HIPC(hipEventRecord(S.ev_up, up)); HIPC(hipStreamWaitEvent(L.stream, S.ev_up, 0)); }
@@ -665,16 +666,18 @@ int run_device(Device &D, const CallIn &in, const std::vector<size_t> &idx, uint
         c->use_lane0();
         return rc;
     };
-    auto stream_records = [&](Chunk &ch) -> int {
+    auto stream_records = [&](Chunk &ch, size_t r_lo, size_t r_hi) -> int {
         uint8_t *hbase = (uint8_t *)ch.slot->host.p;
         Slot &S = *ch.slot;
-        for (size_t r = 0; r < ch.nsub; ++r) {
+        for (size_t r = r_lo; r < r_hi && r < ch.nsub; ++r) {
             { std::unique_lock<std::mutex> lk(ch.mu); ch.cv.wait(lk, [&] { return ch.sub_left[r].load() == 0; }); }
             const size_t lo = r * ch.sub, hi = std::min(ch.n, lo + ch.sub);
-            for (size_t b = lo; b < hi; ++b) if (!ch.hb[b].parsed) clear_states_half(lay, hbase, b);      // malformed, or patched above: defined records, verdict 0 through `precheck`
+            for (size_t b = lo; b < hi; ++b) if (!ch.hb[b].parsed) clear_states_half(lay, hbase, b);      // malformed (or of another shape / to be patched): defined records, verdict 0 through `precheck`
             std::lock_guard<std::mutex> lk(D.mu);
-            HIPC(hipSetDevice(c->device));
+            { int src; if ((src = setup_slot(ch)) || (src = setup_legs(ch))) return src; }
             Lane &L = c->lanes[ch.slot_ix];
+            if (g_timing && !ch.queued) HIPC(hipEventRecord(S.tev[0], own_up ? S.up : L.stream));
+            ch.queued = true;
             uint8_t *dbase = S.dev.as<uint8_t>();
             if (S.rec_ev.size() < ch.nsub) S.rec_ev.resize(ch.nsub, nullptr);
             if (!S.rec_ev[r]) HIPC(hipEventCreateWithFlags(&S.rec_ev[r], hipEventDisableTiming));
@@ -743,15 +746,27 @@ int run_device(Device &D, const CallIn &in, const std::vector<size_t> &idx, uint
             ch.sub = (early_sub && ch.n >= early_min) ? early_sub : ch.n; ch.nsub = (ch.n + ch.sub - 1) / ch.sub;
             ch.sub_left.reset(new std::atomic<uint32_t>[ch.nsub]);
             for (size_t r = 0; r < ch.nsub; ++r) ch.sub_left[r].store((uint32_t)(std::min(ch.n, (r + 1) * ch.sub) - r * ch.sub));
-            ch.jobA = mb_pool_submit(ch.n, [&, chp, hbase](size_t b) {
+            // the pool's order per chunk: the FIRST run whole (both halves: the state leg is the later one of a lone job, its first piece of hashes needs
+            // ~600 entries), then the wrap-proof halves of the rest (A), then their protocol states (B)
+            // (from ~6000 entries: below, the wrap-proof chain is the later leg and must not wait -- 4096 per call: 34.6 ms without, 35.4 with; 8192: 45.8 / 44.4)
+            const size_t head = (ch.nsub > 1 && ch.n >= head_min) ? ch.sub : 0;
+            ch.head = head;
+            auto run_done = [chp](size_t b) { if (chp->sub_left[b / chp->sub].fetch_sub(1) == 1) { std::lock_guard<std::mutex> lk(chp->mu); chp->cv.notify_all(); } };
+            ch.jobH = mb_pool_submit(head, [&, chp, hbase, run_done](size_t b) {
                 const size_t q = idx[chp->lo + b];
                 parse_proof_half(sh, lay, hbase, b, in.proofs[q], in.proof_lens[q], in.pubs[q], in.pub_lens[q], chp->hb[b], c);
-            });
-            ch.jobB = mb_pool_submit(ch.n, [&, chp, hbase](size_t b) {
-                mb_pool_wait(chp->jobA);                                  // the pool hands jobs out in order, but the last items of A may still be running
-                const size_t q = idx[chp->lo + b];
                 parse_states_half(lay, hbase, b, in.proofs[q], in.proof_lens[q], in.pubs[q], in.pub_lens[q], chp->hb[b]);
-                if (chp->sub_left[b / chp->sub].fetch_sub(1) == 1) { std::lock_guard<std::mutex> lk(chp->mu); chp->cv.notify_all(); }
+                run_done(b);
+            });
+            ch.jobA = mb_pool_submit(ch.n - head, [&, chp, hbase, head](size_t i) {
+                const size_t b = head + i, q = idx[chp->lo + b];
+                parse_proof_half(sh, lay, hbase, b, in.proofs[q], in.proof_lens[q], in.pubs[q], in.pub_lens[q], chp->hb[b], c);
+            });
+            ch.jobB = mb_pool_submit(ch.n - head, [&, chp, hbase, head, run_done](size_t i) {
+                mb_pool_wait(chp->jobA);                                  // the pool hands jobs out in order, but the last items of A may still be running
+                const size_t b = head + i, q = idx[chp->lo + b];
+                parse_states_half(lay, hbase, b, in.proofs[q], in.proof_lens[q], in.pubs[q], in.pub_lens[q], chp->hb[b]);
+                run_done(b);
             });
             ++next_submit;
         }
@@ -773,11 +788,12 @@ int run_device(Device &D, const CallIn &in, const std::vector<size_t> &idx, uint
         // the folding randomisers of the chunk's job (262 KB from the OS for 8192 proofs: ~0.5 ms), while the pool parses: the proofs are the caller's
         // bytes, fixed since the call was made, and the values never leave the process
         ch.randomised = draw_randomisers(sh, lay, (uint8_t *)ch.slot->host.p, ch.n);
-        mb_pool_wait(ch.jobA);
+        int rc = ch.head ? stream_records(ch, 0, 1) : MINA_OK;          // the first run's records and hashes, ahead of everything else
+        mb_pool_wait(ch.jobH); mb_pool_wait(ch.jobA);
         const double t_a = g_timing ? ms_since(t_call) : 0;
-        int rc = issue_legs(ch);
+        if (!rc) rc = issue_legs(ch);
         const double t_legs = g_timing ? ms_since(t_call) : 0;
-        if (!rc && !ch.skipped) rc = stream_records(ch);
+        if (!rc && !ch.skipped) rc = stream_records(ch, ch.head ? 1 : 0, ch.nsub);
         mb_pool_wait(ch.jobB);
         const double t_parsed = g_timing ? ms_since(t_call) : 0;
         if (!rc && !ch.skipped) rc = finish(ch);
@@ -785,7 +801,7 @@ int run_device(Device &D, const CallIn &in, const std::vector<size_t> &idx, uint
         if (rc && !rc_all) rc_all = rc;
         ++next_issue;
     }
-    for (size_t q = 0; q < next_submit; ++q) { mb_pool_wait(chunks[q].jobA); mb_pool_wait(chunks[q].jobB); }     // nothing may still write into a slot (error paths)
+    for (size_t q = 0; q < next_submit; ++q) { mb_pool_wait(chunks[q].jobH); mb_pool_wait(chunks[q].jobA); mb_pool_wait(chunks[q].jobB); }     // nothing may still write into a slot (error paths)
     for (size_t q = 0; q < nchunks; ++q) {
         if (q < next_submit) { harvest(chunks[q]); if (g_timing) fprintf(stderr, "mina_verify:   chunk %zu harvested at %.2f ms\n", q, ms_since(t_call)); }
     }

@@ -448,7 +448,7 @@ def test_boundary_pipeline_chunks_and_device_shards_give_the_same_verdicts(world
         else: p, q, v = good[i % 3][0], good[i % 3][1], 1
         proofs.append(p); pubs.append(q); want.append(v)
     assert m.lib.verify_state_batch(proofs, pubs).tolist() == want
-    env = {"MINA_VERIFY_CHUNK": None, "MINA_VERIFY_SINGLE_MAX": None, "MINA_VERIFY_MIN_SHARD": None, "MINA_VERIFY_DEVICES": None, "MINA_VERIFY_EARLY_MIN": None, "MINA_VERIFY_EARLY_SUB": None, "MINA_VERIFY_WINDOW": None, "MINA_VERIFY_AHEAD": None}
+    env = {"MINA_VERIFY_CHUNK": None, "MINA_VERIFY_SINGLE_MAX": None, "MINA_VERIFY_MIN_SHARD": None, "MINA_VERIFY_DEVICES": None, "MINA_VERIFY_EARLY_MIN": None, "MINA_VERIFY_EARLY_SUB": None, "MINA_VERIFY_WINDOW": None, "MINA_VERIFY_AHEAD": None, "MINA_VERIFY_HEAD_MIN": None}
     keep = {k: os.environ.get(k) for k in env}
     try:
         os.environ["MINA_VERIFY_SINGLE_MAX"] = "1"
@@ -457,7 +457,7 @@ def test_boundary_pipeline_chunks_and_device_shards_give_the_same_verdicts(world
             assert m.lib.verify_state_batch(proofs, pubs).tolist() == want, f"chunks of {chunk}"
         # the streamed form of a chunk (records uploaded and hashed run by run while the rest is parsed): runs of 3 -- the garbage entry at 30
         # ends the streaming, the rest goes up after the patching -- as one chunk, in chunks of 5 (runs of 2), and a call that streams to the end
-        os.environ["MINA_VERIFY_EARLY_MIN"] = "1"
+        os.environ["MINA_VERIFY_EARLY_MIN"] = "1"; os.environ["MINA_VERIFY_HEAD_MIN"] = "0"      # + the first run parsed whole and hashed ahead of everything else
         for single, chunk, sub in (("8192", "8192", "3"), ("1", "5", "2"), ("8192", "8192", "1")):
             os.environ["MINA_VERIFY_SINGLE_MAX"] = single; os.environ["MINA_VERIFY_CHUNK"] = chunk; os.environ["MINA_VERIFY_EARLY_SUB"] = sub
             assert m.lib.verify_state_batch(proofs, pubs).tolist() == want, f"streamed, runs of {sub}, chunks of {chunk}"
