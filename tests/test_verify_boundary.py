@@ -668,3 +668,55 @@ def test_concurrent_batch_callers_share_the_pipeline(world, srs_oracle):
             if v is None: os.environ.pop(k, None)
             else: os.environ[k] = v
     assert not errors, errors[:2]
+
+
+def test_state_and_account_callers_at_once(world, srs_oracle):
+    """Everything an operator process does at the same time: single state proofs, state batches (one with a tampered opening: its job runs a
+    culprit search), single account proofs and account batches (tampered public inputs), from ten threads -- the host pool, the device lock,
+    the two call mergers and the slots are shared; every caller gets exactly its own verdicts."""
+    import struct
+    import threading
+    import mina_bridge_amd as m
+    from ipa_helpers import poseidon_pp
+    from oracle import mina_account_ref as A, pasta_ref as R
+    minted = [mint_state_proof(world, srs_oracle, 7100 + i) for i in range(2)]
+    good = [to_bytes(*x) for x in minted]
+    w_bad = copy.deepcopy(minted[1][0]); w_bad["z1"] = (w_bad["z1"] + 3) % (1 << 254)
+    bad = to_bytes(w_bad, minted[1][1], minted[1][2])
+    pp = poseidon_pp(0)
+    rng = random.Random(5)
+    accounts = [A.synth_account(rng, zk, timed, deleg, with_vk=vk) for zk, timed, deleg, vk in [(False, False, False, True), (True, True, True, True), (True, False, True, False)]]
+    aproofs, apubs = [], []
+    for a in accounts:
+        path = [(rng.randrange(2), rng.randrange(R.P)) for _ in range(35)]
+        enc = A.abi_encode_account(a)
+        aproofs.append(A.write_account_proof(path, a)); apubs.append(R.merkle_root(A.account_hash(a, pp), path, pp).to_bytes(32, "little") + struct.pack("<Q", len(enc)) + enc)
+    errors = []
+
+    def state_single(t):
+        for k in range(5):
+            is_bad = (t + k) % 3 == 0
+            if m.lib.verify_state(*(bad if is_bad else good[k % 2])) is not (not is_bad): errors.append(("state single", t, k))
+
+    def state_batch(t):
+        for k in range(3):
+            items = [(bad, 0) if (j == t + k) else (good[j % 2], 1) for j in range(9)]
+            got = m.lib.verify_state_batch([x[0][0] for x in items], [x[0][1] for x in items]).tolist()
+            if got != [x[1] for x in items]: errors.append(("state batch", t, k, got))
+
+    def account_single(t):
+        for k in range(8):
+            i = (t + k) % 3; is_bad = k % 4 == 1
+            if m.lib.verify_account(aproofs[i], apubs[(i + 1) % 3] if is_bad else apubs[i]) is not (not is_bad): errors.append(("account single", t, k))
+
+    def account_batch(t):
+        for k in range(4):
+            P = [aproofs[j % 3] for j in range(10)]; Q = [apubs[j % 3] for j in range(10)]
+            Q[(t + k) % 10] = apubs[((t + k) % 10 + 1) % 3]
+            got = m.lib.verify_account_batch(P, Q).tolist()
+            if got != [0 if j == (t + k) % 10 else 1 for j in range(10)]: errors.append(("account batch", t, k, got))
+
+    th = [threading.Thread(target=f, args=(t,)) for t, f in enumerate([state_single, state_single, state_single, state_batch, state_batch, account_single, account_single, account_single, account_batch, account_batch])]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert not errors, errors[:3]
