@@ -7,12 +7,11 @@ min_ms = float(sys.argv[3]) if len(sys.argv) > 3 else 0.25
 for r in rows: r["s"] = int(r["Start_Timestamp"]); r["e"] = int(r["End_Timestamp"])
 end = max(r["e"] for r in rows)
 last = [r for r in rows if r["s"] >= end - win * 1e6]
-# the call starts at the first kernel after a gap of > 3 ms
+# the last call: everything after the previous call's verdict words left the GPU (words_out_kernel, or the verdict kernel of older builds)
 last.sort(key=lambda r: r["s"])
-start_i = 0
-for i in range(1, len(last)):
-    if last[i]["s"] - max(x["e"] for x in last[:i]) > 3e6: start_i = i
-last = last[start_i:]
+ends = [r["e"] for r in last if "words_out_kernel" in r["Kernel_Name"]] or [r["e"] for r in last if "state_job_verdict_kernel" in r["Kernel_Name"]]
+if len(ends) >= 2:
+    last = [r for r in last if r["s"] >= ends[-2] and r["s"] <= ends[-1]]
 t0 = last[0]["s"]
 def short(n): return n.replace("mb::", "").split("(")[0][:44]
 print(f"{'start':>8} {'dur':>8}  queue  kernel")
