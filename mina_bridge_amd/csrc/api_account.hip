@@ -28,6 +28,9 @@ __global__ void __launch_bounds__(256)
 salted_hash_kernel(uint32_t n, FieldK fk, const PoseidonParams *__restrict__ pp, const fe_t *__restrict__ salts, const uint32_t *__restrict__ salt_idx,
                    const uint32_t *__restrict__ records /* n * MINA_PSTATE_SLOTS * 8 */, const uint32_t *__restrict__ nfields,
                    const uint32_t *__restrict__ patch_a, uint32_t slot_a, const uint32_t *__restrict__ patch_b, uint32_t slot_b, uint32_t *__restrict__ out /* n*8 */) {
+    // a Proof-of-Account job is a short dependent chain (~70 permutations); beside the state-proof pipeline its waves share SIMDs with chip-filling
+    // hash kernels: issue priority keeps the chain at its own pace, the others take the cycles it leaves
+    __builtin_amdgcn_s_setprio(3);
     bool writer;
     const uint32_t sp = coop_sponge_index<LANES>(writer), e = coop_elem<LANES>();
     const bool live = sp < n;
@@ -85,14 +88,28 @@ void parse_account(const uint8_t *proof, size_t proof_len, const uint8_t *pub, s
 }  // namespace
 
 // account hashes (and optionally Merkle roots along per-account paths of one common depth) of n parsed accounts, on the GPU
-static int account_hashes(mina_ctx *c, const std::vector<const mw::Account *> &accs, uint8_t *hashes_out, uint32_t depth, const uint8_t *sib, const uint8_t *dirs, uint8_t *roots_out) {
+// `lane` / `enq_mu` (the boundary): the job runs on a lane of its own, and `enq_mu` -- the lock of everything that touches the context's lane cursor --
+// is held only while kernels are QUEUED, not while the host flattens the inputs or waits for the GPU (an account job is a latency-bound chain of
+// ~8 ms: held throughout, state-proof callers of the same process could not queue their jobs meanwhile -- and their rate fell by a third)
+static int account_hashes(mina_ctx *c, const std::vector<const mw::Account *> &accs, uint8_t *hashes_out, uint32_t depth, const uint8_t *sib, const uint8_t *dirs, uint8_t *roots_out,
+                          Lane *lane = nullptr, std::mutex *enq_mu = nullptr) {
     const size_t n = accs.size();
     if (n == 0) return MINA_OK;
     int rc;
-    c->use_lane0();
+    struct Enq {                                                 // the lane cursor is set inside the lock and put back before it is released
+        mina_ctx *c; Lane *lane; std::mutex *mu; bool held = false;
+        void lock() { if (mu) mu->lock(); held = true; if (lane) c->L = lane; else c->use_lane0(); }
+        void unlock() { if (held) { c->use_lane0(); if (mu) mu->unlock(); held = false; } }
+        ~Enq() { unlock(); }
+    } enq{c, lane, enq_mu};
+    enq.lock();
+    if (lane && !lane->stream) HIPC(hipStreamCreateWithFlags(&lane->stream, hipStreamNonBlocking));
     if ((rc = mb_ensure_state_salts(c))) return rc;
+    if (lane) c->L = lane;
     if (depth && (rc = mb_merkle_prepare_salts(c, FIELD_FP, depth))) return rc;
+    if (lane) c->L = lane;
     Lane &L = *c->L;
+    enq.unlock();
     // stage records straight into the pinned upload blob: [0, n) zkapp-uri, [n, 2n) verification key, [2n, 3n) zkapp, [3n, 4n) account
     const size_t rec_bytes = 4 * n * MINA_PSTATE_SLOTS * 32;
     const size_t o_nf = rec_bytes, o_salt = o_nf + 4 * n * 4, o_sib = o_salt + 4 * n * 4, o_dir = o_sib + n * depth * 32,
@@ -122,6 +139,7 @@ static int account_hashes(mina_ctx *c, const std::vector<const mw::Account *> &a
     const auto t_flat = std::chrono::steady_clock::now();
     if ((rc = L.st_in.ensure(total))) return rc;
     uint8_t *d = L.st_in.as<uint8_t>();
+    enq.lock();
     HIPC(hipMemcpyAsync(d, blob, o_h, hipMemcpyHostToDevice, L.stream));
     auto R = [&](size_t stage) { return (const uint32_t *)(d + stage * n * MINA_PSTATE_SLOTS * 32); };
     auto NF = [&](size_t stage) { return (const uint32_t *)(d + o_nf) + stage * n; };
@@ -136,6 +154,7 @@ static int account_hashes(mina_ctx *c, const std::vector<const mw::Account *> &a
         HIPC(hipMemcpyAsync(roots_out, H(4), n * 32, hipMemcpyDeviceToHost, L.stream));
     }
     if (hashes_out) HIPC(hipMemcpyAsync(hashes_out, H(3), n * 32, hipMemcpyDeviceToHost, L.stream));
+    enq.unlock();
     HIPC(hipStreamSynchronize(L.stream));
     if (timing) fprintf(stderr, "mina_verify:   %zu accounts: upload + GPU + download %.2f ms (%.1f MB up)\n", n, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_flat).count(), o_h / 1e6);
     return MINA_OK;
@@ -176,6 +195,10 @@ extern "C" int mina_account_abi_encode(const uint8_t *account, size_t len, int e
 // Proof-of-Account for n (proof, pub) pairs on context c: passed / ran masks per proof
 extern "C" int mina_verify_account_ctx(mina_ctx *c, size_t n, const uint8_t *const *proofs, const size_t *proof_lens, const uint8_t *const *pubs, const size_t *pub_lens,
                                        uint32_t *passed, uint32_t *ran) {
+    return mb_verify_account_on(c, n, proofs, proof_lens, pubs, pub_lens, passed, ran, nullptr, nullptr);
+}
+int mb_verify_account_on(mina_ctx *c, size_t n, const uint8_t *const *proofs, const size_t *proof_lens, const uint8_t *const *pubs, const size_t *pub_lens,
+                         uint32_t *passed, uint32_t *ran, Lane *lane, std::mutex *enq_mu) {
     if (!c || (n && (!proofs || !proof_lens || !pubs || !pub_lens || !passed || !ran))) return fail(MINA_ERR_ARG, "null argument");
     if (!c->have_pparams[FIELD_FP]) return fail(MINA_ERR_STATE, "Poseidon constants not installed for Fp");
     HIPC(hipSetDevice(c->device));
@@ -199,7 +222,7 @@ extern "C" int mina_verify_account_ctx(mina_ctx *c, size_t n, const uint8_t *con
         const size_t m = idx.size();
         std::vector<const mw::Account *> accs(m); std::vector<uint8_t> sib(m * d * 32 + 1), dirs(m * d + 1), roots(m * 32);
         for (size_t j = 0; j < m; ++j) { accs[j] = &pa[idx[j]].acc; if (d) { memcpy(&sib[j * d * 32], pa[idx[j]].sib, (size_t)d * 32); memcpy(&dirs[j * d], pa[idx[j]].dirs, d); } }
-        int rc = account_hashes(c, accs, nullptr, d, sib.data(), dirs.data(), roots.data());
+        int rc = account_hashes(c, accs, nullptr, d, sib.data(), dirs.data(), roots.data(), lane, enq_mu);
         if (rc) return rc;
         for (size_t j = 0; j < m; ++j) if (memcmp(&roots[j * 32], pa[idx[j]].ledger, 32) == 0) passed[idx[j]] |= MINA_CHECK_MERKLE;
     }

@@ -60,6 +60,7 @@ struct Slot { PinnedBuf host, out; DevBuf dev; hipStream_t up = nullptr; hipEven
 struct Device {
     mina_ctx *c = nullptr; int ordinal = 0;
     std::mutex mu;                         // serialises every call into `c` (a context has ONE current-lane cursor)
+    std::mutex acct_mu;                    // one Proof-of-Account job at a time (its lane's buffers)
     std::mutex slot_mu; std::condition_variable slot_cv; Slot slots[NSLOT];
     uint32_t prepared_npub = 0xffffffffu;
     std::atomic<unsigned> inflight{0};
@@ -1010,9 +1011,12 @@ static int account_batch_direct(size_t n, const uint8_t *const *proofs, const si
     {
         Device *D; uint32_t flags;
         { std::lock_guard<std::mutex> lk(g_mu); auto &ds = devices(); if (ds.empty()) return MINA_ERR_HIP; D = ds[g_rr.fetch_add(1) % ds.size()]; flags = g_flags; }
-        std::lock_guard<std::mutex> lk(D->mu);
-        if ((D->c->pparams_surrogate[0] || D->c->pparams_surrogate[1]) && !(flags & MINA_VERIFY_ALLOW_SURROGATE)) return MINA_OK;   // surrogate Poseidon tables: refuse (see read_config)
-        int rc = mina_verify_account_ctx(D->c, n, proofs, proof_lens, pubs, pub_lens, passed.data(), ran.data());
+        { std::lock_guard<std::mutex> lk(D->mu);
+          if ((D->c->pparams_surrogate[0] || D->c->pparams_surrogate[1]) && !(flags & MINA_VERIFY_ALLOW_SURROGATE)) return MINA_OK; }   // surrogate Poseidon tables: refuse (see read_config)
+        // one account job per device at a time, on a lane of its own (the last pipeline lane: no slot, no culprit search uses it); the device's lock is
+        // taken only while its kernels are queued, so the state-proof pipeline of the same process keeps its jobs coming
+        std::lock_guard<std::mutex> acct(D->acct_mu);
+        int rc = mb_verify_account_on(D->c, n, proofs, proof_lens, pubs, pub_lens, passed.data(), ran.data(), &D->c->lanes[MB_PIPE_LANES - 1], &D->mu);
         if (rc) return rc;
     }
     const uint32_t need = MINA_CHECK_FORMAT | MINA_CHECK_ACCOUNT_ABI | MINA_CHECK_MERKLE;

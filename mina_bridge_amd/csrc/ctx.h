@@ -8,6 +8,7 @@
 #include <array>
 #include <functional>
 #include <memory>
+#include <mutex>
 #include <thread>
 #include <algorithm>
 #include <string>
@@ -172,6 +173,8 @@ enum : uint32_t { MB_JOB_LEGS = 1, MB_JOB_FINISH = 2, MB_JOB_ALL = 3 };
 struct StateJobCarry { uint32_t *ipa_v = nullptr, *acc_v = nullptr, *kimchi_bad = nullptr; const uint32_t *stmt_ok = nullptr; };
 int mb_state_jobs_on_lane(mina_ctx *c, const mina_state_jobs *j, uint32_t *d_verdicts, uint32_t *d_flags, Lane *LI, Lane *LA, uint32_t *d_stmt_out, Lane *LS,
                           uint32_t phase = MB_JOB_ALL, StateJobCarry *carry = nullptr);
+int mb_verify_account_on(mina_ctx *c, size_t n, const uint8_t *const *proofs, const size_t *proof_lens, const uint8_t *const *pubs, const size_t *pub_lens,
+                         uint32_t *passed, uint32_t *ran, Lane *lane, std::mutex *enq_mu);   // api_account.hip: Proof-of-Account on a lane of the caller's choice
 int mb_state_hashes_early(mina_ctx *c, Lane *LS, size_t ns_total, size_t lo, size_t cnt, const uint32_t *d_records, const uint32_t *d_nfields, hipEvent_t after);
 
 // ---- host-side worker pool (api_core.hip): persistent threads, created on first use -- min(hardware threads / 2, 64), $MINA_HOST_THREADS

@@ -425,6 +425,7 @@ merkle_fold_coop_kernel(uint32_t n, uint32_t depth, FieldK fk, const PoseidonPar
                         const fe_t *__restrict__ salts /* depth x 3, Montgomery */, const uint32_t *__restrict__ leaves,
                         const uint32_t *__restrict__ siblings /* n*depth*8 */, const uint8_t *__restrict__ dirs,
                         uint32_t *__restrict__ roots) {
+    __builtin_amdgcn_s_setprio(3);                               // a short dependent chain: see salted_hash_kernel (api_account.hip)
     bool writer; const uint32_t path = coop_sponge_index<LANES>(writer), e = coop_elem<LANES>();
     const bool live = path < n;
     const uint32_t pidx = live ? path : 0;                     // dead groups shadow path 0 (whole wave runs the cross-lane moves)
