@@ -590,6 +590,17 @@ bool mina_verify_account(const uint8_t *proof, size_t proof_len, const uint8_t *
 int mina_verify_account_batch(size_t n, const uint8_t *const *proofs, const size_t *proof_lens, const uint8_t *const *pub_inputs,
                               const size_t *pub_lens, uint8_t *verdicts_out);
 bool mina_verify_account_files(const char *proof_path, const char *pub_path);   /* mina_account.proof / mina_account.pub */
+/* The symbol names Aligned's operator binds (README.md:277-279, 358-362; proving-system tags `Mina` / `MinaAccount`, core/src/aligned.rs:40,53):
+ * the library can be linked in place of the Rust verifier crate without a shim.  The caller passes its fixed-size buffers (48 KiB proof, 6 KiB public
+ * input at the pinned revision: MINA_FFI_MAX_PROOF_SIZE / MINA_FFI_MAX_PUB_INPUT_SIZE) and the used lengths; a Proof-of-State length beyond the buffer
+ * is `false` (the account entry reads `len` bytes whatever the buffer: its operator's buffer sizes are not in the tree).
+ * Later Aligned versions pass the lengths as u32: the `_u32` forms.  Same semantics as mina_verify_state / mina_verify_account. */
+#define MINA_FFI_MAX_PROOF_SIZE (48u * 1024u)
+#define MINA_FFI_MAX_PUB_INPUT_SIZE (6u * 1024u)
+bool verify_mina_state_ffi(const uint8_t *proof_buffer, size_t proof_len, const uint8_t *pub_input_buffer, size_t pub_input_len);
+bool verify_account_inclusion_ffi(const uint8_t *proof_buffer, size_t proof_len, const uint8_t *pub_input_buffer, size_t pub_input_len);
+bool verify_mina_state_ffi_u32(const uint8_t *proof_buffer, uint32_t proof_len, const uint8_t *pub_input_buffer, uint32_t pub_input_len);
+bool verify_account_inclusion_ffi_u32(const uint8_t *proof_buffer, uint32_t proof_len, const uint8_t *pub_input_buffer, uint32_t pub_input_len);
 int mina_verify_account_checks(const uint8_t *proof, size_t proof_len, const uint8_t *pub_input, size_t pub_len, uint32_t *passed_mask, uint32_t *ran_mask);
 /* the same on a caller-owned context (n pairs, masks per pair) */
 int mina_verify_account_ctx(mina_ctx *ctx, size_t n, const uint8_t *const *proofs, const size_t *proof_lens, const uint8_t *const *pub_inputs,
@@ -599,6 +610,54 @@ int mina_verify_account_ctx(mina_ctx *ctx, size_t n, const uint8_t *const *proof
 int mina_account_hash_batch(mina_ctx *ctx, int encoding, size_t n, const uint8_t *const *accounts, const size_t *lens, uint8_t *hashes_out /* n*32 */);
 int mina_account_abi_encode(const uint8_t *account, size_t len, int encoding, uint8_t *out, size_t cap, size_t *out_len);
 int mina_verify_configure(uint32_t flags);       /* MINA_VERIFY_* */
+/* Tuning: every knob of the library in ONE struct instead of environment switches (the defaults are the measured optima on one MI355X, DESIGN.md
+ * section 5; tests force other shapes to prove the verdicts do not depend on them).  Process-wide; set it before the first verification or between
+ * calls -- not while calls are in flight.  mina_verify_configure_ex(NULL) restores the defaults.  The environment is read only for deployment facts:
+ * MINA_VERIFY_DEVICES / MINA_VERIFY_DEVICE (which GPUs), MINA_HOST_THREADS (parser pool), MINA_POSEIDON_PARAMS_FP / _FQ (table files),
+ * MINA_VERIFY_TIMING (stderr timeline). */
+typedef struct mina_verify_tuning {
+    uint32_t struct_size;          /* sizeof(mina_verify_tuning), filled by mina_verify_tuning_default */
+    /* bytes -> bools pipeline of mina_verify_state_batch (api_verify.hip run_device) */
+    uint32_t chunk;                /* 8192  proofs per chunk of a call beyond `single_max` */
+    uint32_t single_max;           /* 8192  calls up to this many proofs are ONE chunk */
+    uint32_t slots;                /* 4     chunks in flight per device over all callers (<= 16) */
+    uint32_t window;               /* 4     chunks of one call on the GPU at a time */
+    uint32_t ahead;                /* 0     chunks parsed ahead of the window */
+    uint32_t early_min;            /* 2048  chunks from this many entries are streamed: records uploaded and hashed run by run */
+    uint32_t early_sub;            /* 1024  entries per run (0 = no streaming) */
+    uint32_t head_min;             /* 6144  streamed chunks from this many entries parse their first run whole, ahead of everything else */
+    uint32_t split_max;            /* 4     up to this many chunks in flight the three legs of a job fork onto three streams */
+    uint32_t chain_cus;            /* 128   CUs of the wrap-proof chain's stream mask (the state hashes get the rest; 0 = no CU masks) */
+    uint32_t cu_period;            /* 256   period of the mask pattern over the CU index */
+    uint32_t acc_mask;             /* 0     accumulator leg under: 0 the chain's mask, 1 the hashes', 2 none */
+    uint32_t hash_piece_waves;     /* 1024  state hashes are launched in pieces of this many waves */
+    uint32_t up_stream;            /* 1     uploads on a stream of their own */
+    uint32_t min_shard;            /* 64    fewer proofs per device than this: the call stays on one device */
+    uint32_t pace_us;              /* 0     gap between the first `window` chunk issues of a long call */
+    /* merging of concurrent single-proof / small-batch callers */
+    uint32_t merge;                /* 1     0 = every call runs on its own */
+    uint32_t merge_batch_max;      /* 512   batch calls up to this size join merged jobs */
+    uint32_t linger_us;            /* 500   how long a job's leader waits for the previous job's callers to come back */
+    uint32_t max_jobs;             /* 1     merged jobs overlapping on the device */
+    /* lane forms of the Poseidon kernels: sponges (or proofs) in flight up to which the 16- / 8-lane latency forms are used */
+    uint32_t coop16_max;           /* 64 */
+    uint32_t coop8_max;            /* 8192 */
+    uint32_t coop8_per_call;       /* 0     1 = the limits look at one call, not at calls x lanes in flight */
+    uint32_t transcript_coop8_max; /* 0     0 = built-in rule (ctx.h use_coop8_transcripts) */
+    uint32_t ipa_coop8_max;        /* 1024 */
+    uint32_t kimchi_coop8_max;     /* 1024 */
+    /* shortcuts, each with a slower equivalent path kept for cross-checking */
+    uint32_t bpoly_mfma;           /* 1     b_poly fold of batches >= 256 on the matrix cores (0: VALU fold) */
+    uint32_t pubcomm_direct;       /* 1     public-input commitments by digit-table lookups (0: bucket MSM) */
+    uint32_t ipa_shared_points;    /* 1     batch-shared points of the opening check enter the MSM once */
+    uint32_t kimchi_shared_digest; /* 1     kimchi's challenge digest taken from the statement's sponge */
+    uint32_t ipa_side_stream;      /* 1     U = to_group(t) beside the transcript on a second stream */
+    uint32_t search_fan;           /* 4     fan-out of the culprit search (2 .. 32) */
+    uint32_t search_full;          /* 0     1 = every part of a culprit search repeats its transcripts */
+} mina_verify_tuning;
+void mina_verify_tuning_default(mina_verify_tuning *out);
+int mina_verify_tuning_get(mina_verify_tuning *out);
+int mina_verify_configure_ex(const mina_verify_tuning *tuning);
 int mina_verify_shutdown(void);                  /* destroy the process-wide contexts */
 mina_ctx *mina_verify_global_ctx(void);          /* the first device's context, e.g. to install a verifier index; NULL without a GPU */
 /* Multi-GPU behind the boundary: the process holds one context per GPU named by $MINA_VERIFY_DEVICES ("all" | comma list of

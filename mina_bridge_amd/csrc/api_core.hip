@@ -12,6 +12,35 @@
 static thread_local std::string g_err = "";
 int mb_fail(int code, const std::string &msg) { g_err = msg; return code; }
 
+// ------------------------------------------------------------------------------------------------ tuning (include/mina_verify.h)
+static mina_verify_tuning tuning_defaults() {
+    mina_verify_tuning t; memset(&t, 0, sizeof t);
+    t.struct_size = (uint32_t)sizeof t;
+    t.chunk = 8192; t.single_max = 8192; t.slots = 4; t.window = 4; t.ahead = 0; t.early_min = 2048; t.early_sub = 1024; t.head_min = 6144; t.split_max = 4;
+    t.chain_cus = 128; t.cu_period = 256; t.acc_mask = 0; t.hash_piece_waves = 1024; t.up_stream = 1; t.min_shard = 64; t.pace_us = 0;
+    t.merge = 1; t.merge_batch_max = 512; t.linger_us = 500; t.max_jobs = 1;
+    t.coop16_max = 64; t.coop8_max = 8192; t.coop8_per_call = 0; t.transcript_coop8_max = 0; t.ipa_coop8_max = 1024; t.kimchi_coop8_max = 1024;
+    t.bpoly_mfma = 1; t.pubcomm_direct = 1; t.ipa_shared_points = 1; t.kimchi_shared_digest = 1; t.ipa_side_stream = 1; t.search_fan = 4; t.search_full = 0;
+    return t;
+}
+static mina_verify_tuning g_tune = tuning_defaults();
+static std::mutex g_tune_mu;
+mina_verify_tuning mb_tune() { std::lock_guard<std::mutex> lk(g_tune_mu); return g_tune; }
+extern "C" void mina_verify_tuning_default(mina_verify_tuning *out) { if (out) *out = tuning_defaults(); }
+extern "C" int mina_verify_tuning_get(mina_verify_tuning *out) { if (!out) return fail(MINA_ERR_ARG, "null argument"); *out = mb_tune(); return MINA_OK; }
+extern "C" int mina_verify_configure_ex(const mina_verify_tuning *t) {
+    mina_verify_tuning n = tuning_defaults();
+    if (t) {
+        if (t->struct_size != sizeof n) return fail(MINA_ERR_ARG, "mina_verify_tuning.struct_size does not match this library: start from mina_verify_tuning_default");
+        n = *t;
+        if (!n.chunk || !n.single_max || !n.slots || n.slots > 16 || !n.window || !n.early_min || !n.min_shard || !n.max_jobs || n.acc_mask > 2 || !n.cu_period || n.search_fan < 2 || n.search_fan > 32)
+            return fail(MINA_ERR_ARG, "mina_verify_tuning: chunk, single_max, slots (<= 16), window, early_min, min_shard, max_jobs, cu_period must be positive; acc_mask <= 2; search_fan in 2..32");
+    }
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    g_tune = n;
+    return MINA_OK;
+}
+
 // ------------------------------------------------------------------------------------------------ CSPRNG
 bool mb_secure_random(void *buf, size_t n) {
     uint8_t *p = (uint8_t *)buf; size_t got = 0;

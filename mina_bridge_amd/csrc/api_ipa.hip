@@ -494,13 +494,13 @@ int mb_ipa_batch_check_dev(mina_ctx *c, int curve, mb::IpaShape sh, const mb::Ip
         // the transcript splits at its first squeeze: to_group (one lane per proof) runs on a second stream beside the rest.  8 lanes per
         // transcript up to 1024 proofs per call (shortest dependent chain); above that the 3-lane form: 21 transcripts per wave, 3/8 of the
         // issue slots -- measured with 16 calls of 8192 proofs in flight (bench.py), where the VALU port is what saturates
-        static const size_t coop8_max = [] { const char *e = getenv("MINA_IPA_COOP8_MAX"); return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)1024; }();
-        const bool oct = use_coop8_transcripts(c, batch, coop8_max);
+        const mina_verify_tuning tune = mb_tune();
+        const bool oct = use_coop8_transcripts(c, batch, (size_t)tune.ipa_coop8_max);
         Lane &L = *c->L;
         if ((rc = L.ipa_xfer.ensure(batch * mb::IPA_XFER_WORDS * 4))) return rc;
         // second stream only for a context that runs ONE call at a time: with pipeline lanes in flight the other lanes fill the chip, and a
         // side stream per lane would make 2 x lanes streams share the 16 hardware queues (lanes then serialise behind each other's kernels)
-        const bool side = c->nlanes == 1 && getenv("MINA_IPA_NO_SIDE_STREAM") == nullptr;
+        const bool side = c->nlanes == 1 && tune.ipa_side_stream != 0;
         hipStream_t tg = L.stream;
         if (side) {
             if (!L.aux) { HIPC(hipStreamCreateWithFlags(&L.aux, hipStreamNonBlocking)); HIPC(hipEventCreateWithFlags(&L.ev_fork, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&L.ev_join, hipEventDisableTiming)); }

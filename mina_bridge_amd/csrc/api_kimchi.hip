@@ -372,8 +372,8 @@ int mb_kimchi_to_batch_dev(mina_ctx *c, size_t batch, uint32_t n_prev, uint32_t 
     const FieldK &kb = c->fk[FIELD_FP], &ks = c->fk[FIELD_FQ];
     mb::kimchi_rows_kernel<<<cdiv(batch * ncomms * 16, 256), 256, 0, L.stream>>>(B, n_prev, ix, in, out.comms);
     // 8-lane sponges up to 1024 proofs per call (shortest dependent chain), 3-lane above: measured on bench.py --kimchi, 8192 proofs
-    // per step -- 16 x 512: 165 k/s (8-lane) vs 162 k/s; 4 x 2048: 137 k/s (8-lane) vs 150 k/s (3-lane).  MINA_KIMCHI_COOP8_MAX overrides (tuning)
-    static const size_t coop8_max = [] { const char *e = getenv("MINA_KIMCHI_COOP8_MAX"); return e ? (size_t)strtoull(e, nullptr, 10) : (size_t)1024; }();
+    // per step -- 16 x 512: 165 k/s (8-lane) vs 162 k/s; 4 x 2048: 137 k/s (8-lane) vs 150 k/s (3-lane).  mina_verify_tuning.kimchi_coop8_max overrides
+    const size_t coop8_max = (size_t)mb_tune().kimchi_coop8_max;
     const uint32_t fq_roles = pf_digest ? 1u : 2u;              // role 1 = the digest of the recursion challenges, unless the statement stage supplies it
     if (use_coop16(c, batch)) {
         mb::kimchi_fq_kernel<16><<<fq_roles * coop_role_blocks<16>(batch), 64, 0, L.stream>>>(B, n_prev, kb, ks, ppb, pps, ix, in, out, xf, d_bad, coop_role_blocks<16>(batch), (const fe_t *)pf_digest, pf_stride);

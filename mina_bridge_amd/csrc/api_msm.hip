@@ -34,8 +34,7 @@ static int run_msm(mina_ctx *c, const MsmShape &sh, const uint32_t *d_scalars, c
     while (ss.fbits < 11 && cdiv(ss.SB, 1u << ss.fbits) > 256) ++ss.fbits;
     ss.Pl = cdiv(ss.SB, 1u << ss.fbits);
     const uint64_t gh_words = (uint64_t)ss.Pl * ss.Gl * sh.nprob;
-    static const bool force_atomic_sort = getenv("MINA_MSM_ATOMIC_SORT") != nullptr;      // A/B switch for profiling
-    const bool part_sort = !force_atomic_sort && ss.Pl <= 1024 && gh_words <= (1u << 22);
+    const bool part_sort = ss.Pl <= 1024 && gh_words <= (1u << 22);
     if (part_sort) {
         if ((rc = w.ghist.ensure((gh_words + 8) * 4))) return rc;
         if ((rc = w.stage.ensure(entries * 8))) return rc;
@@ -51,8 +50,7 @@ static int run_msm(mina_ctx *c, const MsmShape &sh, const uint32_t *d_scalars, c
     // throughput form of the accumulate (one lane per pair of count-ranked buckets, K1t) when one launch carries enough
     // buckets to fill the chip; a single MSM's 32768 buckets would leave it latency-bound (16 pipelined lanes: 6.2 k
     // proofs/s against 7.6 k with tasks)
-    static const bool no_bucket_lanes = getenv("MINA_MSM_TASKS") != nullptr;             // A/B switch for profiling
-    const bool bucket_lanes = !no_bucket_lanes && part_sort && sh.nprob >= 4;             // >= 64 k lanes of ~62 adds each
+    const bool bucket_lanes = part_sort && sh.nprob >= 4;                                 // >= 64 k lanes of ~62 adds each
     if (bucket_lanes) {
         if ((rc = w.order.ensure((size_t)nb_total * 4))) return rc;
     } else {                                                    // task numbering and the 128-B task partials

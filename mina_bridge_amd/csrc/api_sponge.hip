@@ -22,8 +22,8 @@ static int run_bpoly_fold(mina_ctx *c, uint32_t k, size_t batch, const uint32_t 
         HIPC(hipGetLastError());
         return MINA_OK;
     }
-    // large batches: the fold is a dense contraction over the batch -> int8 MFMA field-GEMM (bpoly_mfma.cuh).  MINA_BPOLY_MFMA=0 keeps the VALU kernel
-    static const bool mfma_on = [] { const char *e = getenv("MINA_BPOLY_MFMA"); return !(e && e[0] == '0'); }();
+    // large batches: the fold is a dense contraction over the batch -> int8 MFMA field-GEMM (bpoly_mfma.cuh).  mina_verify_tuning.bpoly_mfma = 0 keeps the VALU kernel
+    const bool mfma_on = mb_tune().bpoly_mfma != 0;
     if (mfma_on && batch >= 256 && batch < (1u << 17) && sh.lb >= 1) {
         Lane &L = *c->L;
         const uint32_t kpad = (uint32_t)(cdiv(batch, BPM_KALIGN) * BPM_KALIGN);

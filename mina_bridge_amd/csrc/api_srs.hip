@@ -294,7 +294,7 @@ int mb_ensure_lagrange_table(mina_ctx *c, int curve, uint32_t log2_domain, uint3
 // <= 64 inputs: straight from the digit table (lagrange.cuh), else one bucket problem per proof of the multi-problem MSM.
 int mb_lagrange_sums_dev(mina_ctx *c, int curve, uint32_t npub, size_t batch, const uint32_t *d_scalars, void *d_out_xyzz) {
     SrsState &s = c->srs[curve];
-    static const bool generic = getenv("MINA_PUBCOMM_GENERIC_MSM") != nullptr;      // A/B switch: always the bucket MSM
+    const bool generic = mb_tune().pubcomm_direct == 0;                             // cross-check switch: always the bucket MSM
     if (generic || npub > s.lagrange_digits_n)
         return mb_msm_table(c, curve, s.lagrange_table.p, s.lagrange_table_n, LAG_C, LAG_W, 0, npub, (uint32_t)batch, d_scalars, nullptr, d_out_xyzz);
     ProfScope ps_(c, PS_ACCUMULATE);

@@ -431,7 +431,7 @@ int mb_state_jobs_on_lane(mina_ctx *c, const mina_state_jobs *j, uint32_t *d_ver
             const bool from_statement = !kp.prev_chals && !kp.prev_prechallenges && kp.statements && kp.n_prev == 2 && j->k == 15;
             const void *pre = from_statement ? kp.statements->wrap_old_challenges : kp.prev_prechallenges;
             const void *pf_digest = nullptr; uint32_t pf_stride = 0;
-            if (from_statement && getenv("MINA_KIMCHI_OWN_DIGEST") == nullptr) mb_pickles_kimchi_digest(c, kp.statements, &pf_digest, &pf_stride);
+            if (from_statement && mb_tune().kimchi_shared_digest) mb_pickles_kimchi_digest(c, kp.statements, &pf_digest, &pf_stride);
             if (pre && kp.n_prev) {                             // 128-bit prechallenges -> scalar-field challenges, on this lane ahead of the sponges
                 const size_t cnt = B * kp.n_prev * j->k;
                 if ((rc = L.kc_pch.ensure(cnt * 32))) { c->L = L0; return rc; }
@@ -444,7 +444,7 @@ int mb_state_jobs_on_lane(mina_ctx *c, const mina_state_jobs *j, uint32_t *d_ver
             mb::IpaExpand ex;
             if ((rc = mb_kimchi_to_batch_dev(c, B, kp.n_prev, kp.npub, in, out, kimchi_bad, &ex, pf_digest, pf_stride))) { c->L = L0; return rc; }
             sh.expand_slot = kp.n_prev + 1; sh.per += mb::IPA_EXPAND - 1;          // the ft commitment enters the MSM as its 8 terms
-            if (getenv("MINA_IPA_NO_SHARED") == nullptr && kp.n_prev + 45 <= 64) {   // h, the 27 index columns and the index point of the ft combination are the same
+            if (mb_tune().ipa_shared_points && kp.n_prev + 45 <= 64) {   // h, the 27 index columns and the index point of the ft combination are the same
                 uint64_t m = 0;                                                       // points for every proof: their scalars are summed first (29 of 88 entries per proof)
                 for (uint32_t i = kp.n_prev + 3; i < kp.n_prev + 9; ++i) m |= (uint64_t)1 << i;        // 6 selectors
                 for (uint32_t i = kp.n_prev + 24; i < kp.n_prev + 45; ++i) m |= (uint64_t)1 << i;      // 15 coefficients + 6 sigma
@@ -575,15 +575,15 @@ extern "C" int mina_state_job_batch(mina_ctx *c, const mina_state_jobs *jobs, ui
     };
     // the culprits of one folded leg: a failing range is cut into FAN parts whose jobs run CONCURRENTLY on lanes 0..FAN-1 of the context
     // (inputs stay where lane 0 uploaded them; every lane has its own verdict words); parts that fail are cut again: depth log_FAN(B) rounds
-    // of ~one job latency each, where a bisection ran log2(B) jobs one after the other per culprit.  FAN = 4 ($MINA_SEARCH_FAN): with 32 -- the
+    // of ~one job latency each, where a bisection ran log2(B) jobs one after the other per culprit.  FAN = 4 (mina_verify_tuning.search_fan): with 32 -- the
     // fan-out until the end of round 3 -- a search over 8192 proofs took 370 ms instead of 165, and the 28 streams it created left the process
     // with more streams than the runtime has hardware queues: every later call of the boundary was 30 % slower, for the life of the process
     // (tools/after_search.py; destroying the streams afterwards does not undo it).
     // The opening leg of well-formed proofs does not repeat its transcripts: the prepared rows of the failed batch are still on their
     // lane and any slice of them is the folded check of that slice (mb_ipa_recheck_rows): a round costs a fold + two MSMs per part.
-    const bool rows_ok = hv[B + 1] == 0 && c->ipa_rows && c->ipa_rows_batch == B && getenv("MINA_STATE_SEARCH_FULL") == nullptr;
+    const bool rows_ok = hv[B + 1] == 0 && c->ipa_rows && c->ipa_rows_batch == B && !mb_tune().search_full;
     auto search = [&](bool ipa_leg, std::vector<uint8_t> &each) -> int {
-        static const size_t FAN = getenv("MINA_SEARCH_FAN") ? std::min<size_t>(MB_PIPE_LANES, std::max<long>(2, atol(getenv("MINA_SEARCH_FAN")))) : (size_t)4;
+        const size_t FAN = std::min<size_t>(MB_PIPE_LANES, std::max<size_t>(2, (size_t)mb_tune().search_fan));
         static const bool timing = getenv("MINA_VERIFY_TIMING") != nullptr;
         // streams this search had to create are destroyed when it is done
         struct Restore {

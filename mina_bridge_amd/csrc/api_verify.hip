@@ -142,12 +142,12 @@ extern "C" int mina_verify_set_poseidon_params(int field, const uint8_t *params)
 // The reference's entry points take ONE proof and are called from many goroutines / tokio tasks at once.  One proof is
 // a 25 ms dependent chain that leaves the chip idle, so concurrent callers are merged (group commit): the first caller runs a job with
 // everything queued at that moment; calls arriving while it runs wait and leave together as the next job, led by one of them.  A lone
-// caller pays nothing; N concurrent callers share one job of N proofs.  ($MINA_VERIFY_MAX_JOBS lets that many merged jobs overlap on the
+// caller pays nothing; N concurrent callers share one job of N proofs.  (mina_verify_tuning.max_jobs lets that many merged jobs overlap on the
 // device; measured with 256 calling threads: 1 job at a time 4.7 k proofs/s, 2: 3.8 k, 4: 2.4 k -- small jobs are latency-bound chains that
 // slow each other down and split the batches, so the default stays 1.)  Verdicts are per proof either way: the folded checks of a job use
 // randomisers drawn from the operating system's CSPRNG after every proof of the job is fixed (as upstream's `batch_verify` draws its own),
-// so one caller's proof cannot be built to cancel another's.  MINA_VERIFY_NO_MERGE=1 sends every call through on its own;
-// MINA_VERIFY_LINGER_US (default 500) is how long the leader of a job waits for the callers of the previous job to come back before it leaves.
+// so one caller's proof cannot be built to cancel another's.  mina_verify_tuning.merge = 0 sends every call through on its own;
+// .linger_us (default 500) is how long the leader of a job waits for the callers of the previous job to come back before it leaves.
 namespace {
 struct PendingCall { const uint8_t *proof; size_t proof_len; const uint8_t *pub; size_t pub_len; uint8_t verdict = 0; bool done = false, claimed = false; int rc = MINA_OK; size_t owner = 0; };
 typedef void (*exec_fn_t)(std::vector<PendingCall *> &job);           // sets `verdict` of every call of the job
@@ -161,10 +161,10 @@ struct CallMerger {
     bool run(exec_fn_t exec, PendingCall &me) { run_group(exec, &me, 1); return me.verdict == 1; }
     // the calls of one caller -- one proof (the reference's entry point) or a small batch -- wait here for a job to take them
     void run_group(exec_fn_t exec, PendingCall *mine, size_t count) {
-        static const bool off = getenv("MINA_VERIFY_NO_MERGE") != nullptr;
-        if (off || count == 0) { std::vector<PendingCall *> job; for (size_t i = 0; i < count; ++i) job.push_back(&mine[i]); if (count) exec(job); return; }
-        static const long linger_us = getenv("MINA_VERIFY_LINGER_US") ? atol(getenv("MINA_VERIFY_LINGER_US")) : 500;
-        static const size_t max_active = getenv("MINA_VERIFY_MAX_JOBS") ? (size_t)std::max(1L, atol(getenv("MINA_VERIFY_MAX_JOBS"))) : (size_t)1;
+        const mina_verify_tuning tune = mb_tune();
+        if (!tune.merge || count == 0) { std::vector<PendingCall *> job; for (size_t i = 0; i < count; ++i) job.push_back(&mine[i]); if (count) exec(job); return; }
+        const long linger_us = (long)tune.linger_us;
+        const size_t max_active = std::max<size_t>(1, tune.max_jobs);
         auto all_done = [&] { for (size_t i = 0; i < count; ++i) if (!mine[i].done) return false; return true; };
         auto all_claimed = [&] { for (size_t i = 0; i < count; ++i) if (!mine[i].claimed) return false; return true; };
         const size_t me = std::hash<std::thread::id>()(std::this_thread::get_id());
@@ -441,7 +441,9 @@ void copy_proof_half(const Layout &lay, uint8_t *base, size_t dst, size_t src) {
 void clear_states_half(const Layout &lay, uint8_t *base, size_t b) { memset(lay.at(base, S_REC, b), 0, lay.stride[S_REC]); memset(lay.at(base, S_NF, b), 0, lay.stride[S_NF]); *lay.at(base, S_PRE, b) = 0; }
 
 struct Config { bool usable = false, kimchi = false, statements = false, feature_aware = false; uint32_t k = 0; int network = -1; };
-Config read_config(Device &D, uint32_t flags) {
+// Lock order everywhere: g_mu, then a device's mu.  `network` (and `flags`) are copied under g_mu by the caller BEFORE this takes D.mu -- the
+// installers hold g_mu while they take every D.mu, so taking g_mu in here would invert the order (a job and an install in flight: deadlock).
+Config read_config(Device &D, uint32_t flags, int network) {
     std::lock_guard<std::mutex> lk(D.mu);
     mina_ctx *c = D.c; Config cf;
     // a deployment on the library's surrogate Poseidon tables agrees with nothing on the Mina network: refuse unless the caller said so
@@ -453,7 +455,7 @@ Config read_config(Device &D, uint32_t flags) {
     cf.kimchi = mb_kimchi_available(c) && (cf.statements || (flags & MINA_VERIFY_ALLOW_UNBOUND_STATEMENT));
     cf.k = c->kimchi_log2;
     cf.feature_aware = cf.statements && mb_step_index_feature_aware(c) != 0;
-    { std::lock_guard<std::mutex> gl(g_mu); cf.network = g_network; }
+    cf.network = network;
     return cf;
 }
 
@@ -472,28 +474,44 @@ struct Chunk {
 const bool g_timing = getenv("MINA_VERIFY_TIMING") != nullptr;
 double ms_since(std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); }
 
-// verdict bytes of the proofs idx[0..m) of the call on device D
-int run_device(Device &D, const CallIn &in, const std::vector<size_t> &idx, uint8_t *verdicts, uint32_t flags, int depth = 0) {
+// what a caller of the pipeline copied under g_mu (lock order: g_mu before any D.mu) + the tuning of the call
+struct CallEnv { uint32_t flags = 0; int network = -1; mina_verify_tuning tu; };
+
+// verdict bytes of the proofs idx[0..m) of the call on device D that share ONE evaluation / recursion shape; well-formed proofs of another
+// shape are returned in `deferred` (their verdict bytes stay 0 until the caller runs them as a job of their own)
+int run_device_shape(Device &D, const CallIn &in, const std::vector<size_t> &idx, uint8_t *verdicts, const CallEnv &env, std::vector<size_t> &deferred) {
     const size_t m = idx.size();
+    const uint32_t flags = env.flags; const mina_verify_tuning &tu = env.tu;
+    deferred.clear();
     for (size_t i = 0; i < m; ++i) verdicts[idx[i]] = 0;
     if (m == 0) return MINA_OK;
     const auto t_call = std::chrono::steady_clock::now();
-    const Config cf = read_config(D, flags);
+    const Config cf = read_config(D, flags, env.network);
     if (!cf.usable) return MINA_OK;
     if (!cf.kimchi && !(flags & MINA_VERIFY_ALLOW_MISSING_KIMCHI)) return MINA_OK;          // the kimchi step cannot run: nothing can pass
     Shape sh; sh.kimchi = cf.kimchi; sh.statements = cf.kimchi && cf.statements; sh.k = cf.k; sh.network = cf.network; sh.feature_aware = cf.feature_aware;
-    if (sh.statements) {           // evaluation / recursion shape of the job: the first proof that parses names it (Mina's blockchain proofs all share one)
-        bool found = false;
-        for (size_t i = 0; i < m && !found; ++i) {
-            const size_t q = idx[i];
-            if (!in.proofs[q]) continue;
+    if (sh.statements) {           // evaluation / recursion shape of the job (Mina's blockchain proofs all share one): the most frequent shape among up to 9
+        // proofs spread over the call -- one odd-shaped proof at the head of a merged job must not send every other caller's proof through a second job --
+        // and, when none of the sampled ones parses, the first proof that does
+        auto shape_of = [&](size_t q, uint32_t &n_old, uint32_t &n_ev) -> bool {
+            if (!in.proofs[q]) return false;
             mw::StateProofContainer &box = tl_box();
             mw::Bincode cur(in.proofs[q], in.proof_lens[q]);
-            if (!mw::read_wrap_proof(cur, box.tip_proof)) continue;
-            const size_t n_old = box.tip_proof.step_old_bulletproof_challenges.size(), n_ev = box.tip_proof.prev_evals.size();
-            if (n_old > 4 || n_ev < 43 || n_ev > 62) continue;
-            sh.n_old = (uint32_t)n_old; sh.n_ev = (uint32_t)n_ev; found = true;
+            if (!mw::read_wrap_proof(cur, box.tip_proof)) return false;
+            const size_t a = box.tip_proof.step_old_bulletproof_challenges.size(), b = box.tip_proof.prev_evals.size();
+            if (a > 4 || b < 43 || b > 62) return false;
+            n_old = (uint32_t)a; n_ev = (uint32_t)b; return true;
+        };
+        std::vector<std::pair<uint32_t, uint32_t>> votes;
+        const size_t samples = std::min<size_t>(m, 9);
+        for (size_t i = 0; i < samples; ++i) { uint32_t a, b; if (shape_of(idx[samples > 1 ? i * (m - 1) / (samples - 1) : 0], a, b)) votes.push_back({a, b}); }
+        bool found = false;
+        if (!votes.empty()) {
+            size_t best = 0;
+            for (auto &v : votes) { const size_t cnt = (size_t)std::count(votes.begin(), votes.end(), v); if (cnt > best) { best = cnt; sh.n_old = v.first; sh.n_ev = v.second; } }
+            found = true;
         }
+        for (size_t i = 0; i < m && !found; ++i) found = shape_of(idx[i], sh.n_old, sh.n_ev);
         if (!found) return MINA_OK;                                                          // nothing parses
     }
     // read per call (tests force tiny chunks / shards to drive the pipeline's slot recycling with a handful of proofs)
@@ -502,32 +520,31 @@ int run_device(Device &D, const CallIn &in, const std::vector<size_t> &idx, uint
     // not fill each other's gaps the way the staggered steps of a long-running pipeline do.  Bigger calls in chunks of 8192 (16 384 proofs: 92 ms
     // against 121 ms in chunks of 4096; 65 536: 305 against 336 ms = 215 k proofs/s): their parsing and upload overlap the previous chunk's job,
     // and one bad proof costs a culprit search over 8192, not over everything.
-    const size_t chunk_target = getenv("MINA_VERIFY_CHUNK") ? (size_t)std::max(1L, atol(getenv("MINA_VERIFY_CHUNK"))) : (size_t)8192;
-    const size_t single_max = getenv("MINA_VERIFY_SINGLE_MAX") ? (size_t)std::max(1L, atol(getenv("MINA_VERIFY_SINGLE_MAX"))) : (size_t)8192;
+    const size_t chunk_target = std::max<size_t>(1, tu.chunk);
+    const size_t single_max = std::max<size_t>(1, tu.single_max);
     const size_t nchunks = m <= single_max ? 1 : (m + chunk_target - 1) / chunk_target;
     // chunks of ONE call on the GPU at a time (the next ones are parsed meanwhile)
     // A call of more chunks than the window is a pipeline: jobs that enter the GPU together also leave it together (4 jobs started within 15 ms: all done
     // at ~185 ms, then the next 4 -- 65 536 proofs: 345 ms), jobs one period apart keep the chip filled while one of them drains (four caller threads
     // with 8192 proofs each reach 238 k proofs/s that way).  So the first `window` chunks of such a call are issued `pace_ms` apart.
-    const double pace_ms = getenv("MINA_VERIFY_PACE_MS") ? atof(getenv("MINA_VERIFY_PACE_MS")) : 0.0;
+    const double pace_ms = tu.pace_us * 1e-3;
     // (no parsing ahead of the window: a slot is a staging buffer AND four streams, and with more streams in use than the runtime's 16 hardware queues the
     // jobs' legs wait for each other -- 65 536 proofs per call: 342 ms with two chunks parsed ahead, 285 ms with none; the wrap-proof halves of a chunk take 1 ms)
     // slots of the device in use, over all callers: 4 jobs with their legs forked = 16 streams = the runtime's hardware queues (two callers of 32 768 proofs
     // with 16 slots: 125 k proofs/s, six callers of 8192: 205 k -- against 235 k for four)
-    const size_t head_min = getenv("MINA_VERIFY_HEAD_MIN") ? (size_t)std::max(0L, atol(getenv("MINA_VERIFY_HEAD_MIN"))) : (size_t)6144;      // 0: every streamed chunk; huge: never
-    const int nslot = getenv("MINA_VERIFY_SLOTS") ? std::min(NSLOT, std::max(1, atoi(getenv("MINA_VERIFY_SLOTS")))) : 4;
-    const size_t ahead = getenv("MINA_VERIFY_AHEAD") ? (size_t)std::max(0L, atol(getenv("MINA_VERIFY_AHEAD"))) : (size_t)0;
-    const size_t window = getenv("MINA_VERIFY_WINDOW") ? (size_t)std::max(1L, atol(getenv("MINA_VERIFY_WINDOW"))) : (size_t)4;
+    const size_t head_min = tu.head_min;      // 0: every streamed chunk; huge: never
+    const int nslot = std::min(NSLOT, std::max(1, (int)tu.slots));
+    const size_t ahead = tu.ahead;
+    const size_t window = std::max<size_t>(1, tu.window);
     // streamed form of a chunk (stream_records below): from `early_min` entries, in runs of `early_sub` (0 = off)
-    const size_t early_min = getenv("MINA_VERIFY_EARLY_MIN") ? (size_t)std::max(1L, atol(getenv("MINA_VERIFY_EARLY_MIN"))) : (size_t)2048;
-    const size_t early_sub = getenv("MINA_VERIFY_EARLY_SUB") ? (size_t)std::max(0L, atol(getenv("MINA_VERIFY_EARLY_SUB"))) : (size_t)1024;
+    const size_t early_min = std::max<size_t>(1, tu.early_min);
+    const size_t early_sub = tu.early_sub;
     std::vector<Chunk> chunks(nchunks);
     for (size_t q = 0; q < nchunks; ++q) { chunks[q].lo = m * q / nchunks; chunks[q].n = m * (q + 1) / nchunks - chunks[q].lo; chunks[q].hb.resize(chunks[q].n); }
     const size_t cap = (m + nchunks - 1) / nchunks;
     Layout lay; lay.build(sh, cap);
     mina_ctx *c = D.c;
     int rc_all = MINA_OK;
-    std::vector<size_t> deferred;
 
     auto try_acquire = [&]() -> int {
         std::lock_guard<std::mutex> lk(D.slot_mu);
@@ -538,6 +555,12 @@ int run_device(Device &D, const CallIn &in, const std::vector<size_t> &idx, uint
 
     auto fallback = [&](Chunk &ch) -> int {     // a folded check of the chunk failed: per-proof verdicts through the culprit search, from the same staging
         std::lock_guard<std::mutex> lk(D.mu);
+        // The search runs synchronous jobs on lane 0 and fans out over lanes 0 .. search_fan - 1 (and the forked-leg helpers of lane 0) -- the lanes of the
+        // slots other chunks / callers have in flight.  So the device is drained first: everything queued so far completes (queued work needs no host
+        // action), and nothing new can be queued while D.mu is held.  The search then has the GPU to itself: its lane forms are those of ONE call.
+        (void)hipSetDevice(c->device);
+        if (hipDeviceSynchronize() != hipSuccess) return fail(MINA_ERR_HIP, "hipDeviceSynchronize before the culprit search");
+        c->nlanes = 1;
         JobStructs js; make_jobs(sh, lay, (uint8_t *)ch.slot->host.p, ch.n, true, true, true, js);
         std::vector<uint8_t> v(ch.n, 0);
         const auto t = std::chrono::steady_clock::now();
@@ -595,18 +618,17 @@ int run_device(Device &D, const CallIn &in, const std::vector<size_t> &idx, uint
         ch.legs_set = true;
         // few chunks in flight: the three legs of a job (state hashes / wrap proof / accumulator) go to three streams
         // (up to 4 chunks in flight -- 32 768 proofs per call 186 -> 152 ms, three callers of 8192: 138 -> 158 k proofs/s; with 8 the streams outnumber the hardware queues: 322 -> 360 ms)
-        const unsigned split_max = getenv("MINA_VERIFY_SPLIT_MAX") ? (unsigned)atoi(getenv("MINA_VERIFY_SPLIT_MAX")) : 4u;
-        if (D.inflight.load() > split_max) return MINA_OK;
+        if (D.inflight.load() > tu.split_max) return MINA_OK;
         Lane *LI = &c->lanes[MB_PIPE_LANES + 3 * ch.slot_ix], *LA = &c->lanes[MB_PIPE_LANES + 3 * ch.slot_ix + 1], *LS = &c->lanes[MB_PIPE_LANES + 3 * ch.slot_ix + 2];
         // Alone on the GPU a job is a latency-bound chain of small kernels (~390 waves each, one behind the other) beside 20 ms of chip-filling
         // hashes; where their waves share a SIMD both run at half speed, and the call waits for the chain (rocprofv3 timeline: the statement
         // digests 10.7 ms beside the hashes against 4.1 ms alone).  So the chain's stream and the hashes' stream get DISJOINT CU masks: the chain
         // `chain_cus` CUs -- 128 = a SIMD per wave; fewer and a kernel lasts as long as its doubled-up SIMDs: 96 CUs cost +16 ms -- the hashes the
         // rest (bit i of a mask = CU i / 8 of XCD i % 8, tools/probes/cumask_probe.hip).  8192 proofs per call: 62.6 -> 57.7 ms.
-        const uint32_t chain_cus = getenv("MINA_VERIFY_CHAIN_CUS") ? (uint32_t)atoi(getenv("MINA_VERIFY_CHAIN_CUS")) : 128u;
+        const uint32_t chain_cus = tu.chain_cus;
         int ncu = 0; (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device);
         if (chain_cus > 0 && chain_cus < (uint32_t)ncu && ncu <= 256) {
-            const uint32_t period = getenv("MINA_VERIFY_CU_PERIOD") ? (uint32_t)atoi(getenv("MINA_VERIFY_CU_PERIOD")) : 256u;
+            const uint32_t period = std::max(1u, tu.cu_period);
             auto masked = [&](Lane &ln, bool chain) -> int {
                 if (ln.stream) return MINA_OK;
                 uint32_t mk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -620,17 +642,16 @@ int run_device(Device &D, const CallIn &in, const std::vector<size_t> &idx, uint
             int rc;
             if ((rc = masked(*LI, true)) || (rc = masked(*LS, false))) return rc;
             // the accumulator leg (fold GEMM + one MSM: chip-filling kernels, done within ~8 ms) shares the chain's CUs: the hashes are the later leg of a lone
-            // job, and unmasked this leg slowed their first pieces (8192 per call: 45.4 -> 44.5 ms; $MINA_VERIFY_ACC_MASK = chain | hash | none)
-            { const char *am = getenv("MINA_VERIFY_ACC_MASK");
-              if (!am || !strcmp(am, "chain")) { if ((rc = masked(*LA, true))) return rc; } else if (!strcmp(am, "hash")) { if ((rc = masked(*LA, false))) return rc; } }
+            // job, and unmasked this leg slowed their first pieces (8192 per call: 45.4 -> 44.5 ms; mina_verify_tuning.acc_mask = 0 chain | 1 hash | 2 none)
+            if (tu.acc_mask == 0) { if ((rc = masked(*LA, true))) return rc; } else if (tu.acc_mask == 1) { if ((rc = masked(*LA, false))) return rc; }
         } else LS = nullptr;
         ch.LI = LI; ch.LA = LA; ch.LS = LS;
         return MINA_OK;
     };
-    const bool own_up = getenv("MINA_VERIFY_UP_STREAM") ? atoi(getenv("MINA_VERIFY_UP_STREAM")) != 0 : true;
+    const bool own_up = tu.up_stream != 0;
     auto lane_forms = [&]() {       // the lane forms of the sponge kernels follow the work in flight on the device (ctx.h use_coop*)
         c->nlanes = (int)std::max(1u, std::min<unsigned>(D.inflight.load(), NSLOT));
-        c->hash_piece_waves = getenv("MINA_VERIFY_HASH_PIECE") ? (uint32_t)atoi(getenv("MINA_VERIFY_HASH_PIECE")) : 1024u;
+        c->hash_piece_waves = tu.hash_piece_waves;
     };
 
     // A chunk goes to the GPU in three steps, each as soon as its input is parsed (8192 full-size proofs per call: the job's wrap-proof chain
@@ -807,30 +828,45 @@ int run_device(Device &D, const CallIn &in, const std::vector<size_t> &idx, uint
         if (q < next_submit) { harvest(chunks[q]); if (g_timing) fprintf(stderr, "mina_verify:   chunk %zu harvested at %.2f ms\n", q, ms_since(t_call)); }
     }
     if (g_timing) fprintf(stderr, "mina_verify: device %d: %zu proofs in %zu chunk(s), %.2f ms\n", D.ordinal, m, nchunks, ms_since(t_call));
-    if (rc_all) { for (size_t i = 0; i < m; ++i) verdicts[idx[i]] = 0; return rc_all; }
-    if (!deferred.empty() && depth < 128) return run_device(D, in, deferred, verdicts, flags, depth + 1);   // well-formed proofs of another shape: a job of their own
+    if (rc_all) { for (size_t i = 0; i < m; ++i) verdicts[idx[i]] = 0; deferred.clear(); return rc_all; }
     return MINA_OK;
+}
+
+// verdict bytes of the proofs idx[0..m) of the call on device D: one pass per evaluation / recursion shape among them (Mina's blockchain proofs share
+// one; every pass takes at least the proofs of its own shape, so there are at most as many passes as distinct shapes: 5 x 20 by the parser's bounds)
+int run_device(Device &D, const CallIn &in, const std::vector<size_t> &idx, uint8_t *verdicts, const CallEnv &env) {
+    std::vector<size_t> cur, next;
+    int rc = run_device_shape(D, in, idx, verdicts, env, next);
+    for (int pass = 1; !rc && !next.empty(); ++pass) {
+        cur.swap(next);
+        if (pass > 128) { for (size_t q : cur) verdicts[q] = 0; rc = fail(MINA_ERR_STATE, "more than 128 distinct proof shapes in one call"); break; }
+        rc = run_device_shape(D, in, cur, verdicts, env, next);
+        if (!rc && next.size() >= cur.size()) { for (size_t q : next) verdicts[q] = 0; rc = fail(MINA_ERR_STATE, "a pass over deferred proofs made no progress"); break; }
+    }
+    if (rc) for (size_t q : idx) verdicts[q] = 0;
+    return rc;
 }
 
 // n proofs over the devices of the process: contiguous shards, one host thread per extra device
 int verify_state_many(const CallIn &in, size_t n, uint8_t *verdicts) {
-    std::vector<Device *> devs; uint32_t flags;
-    { std::lock_guard<std::mutex> lk(g_mu); devs = devices(); flags = g_flags; }
+    std::vector<Device *> devs; CallEnv env;
+    { std::lock_guard<std::mutex> lk(g_mu); devs = devices(); env.flags = g_flags; env.network = g_network; }
+    env.tu = mb_tune();
     for (size_t i = 0; i < n; ++i) verdicts[i] = 0;
     if (devs.empty()) return MINA_ERR_HIP;
     if (n == 0) return MINA_OK;
     const size_t G = devs.size();
-    const size_t min_shard = getenv("MINA_VERIFY_MIN_SHARD") ? (size_t)std::max(1L, atol(getenv("MINA_VERIFY_MIN_SHARD"))) : (size_t)64;
+    const size_t min_shard = std::max<size_t>(1, env.tu.min_shard);
     const size_t use = std::max<size_t>(1, std::min(G, n / min_shard));    // tiny calls stay on one device (dealt round-robin)
     if (use == 1) {
         std::vector<size_t> idx(n); for (size_t i = 0; i < n; ++i) idx[i] = i;
-        return run_device(*devs[g_rr.fetch_add(1) % G], in, idx, verdicts, flags);
+        return run_device(*devs[g_rr.fetch_add(1) % G], in, idx, verdicts, env);
     }
     std::vector<int> rcs(use, MINA_OK); std::vector<std::thread> th;
     auto shard = [&](size_t g) {
         const size_t lo = n * g / use, hi = n * (g + 1) / use;
         std::vector<size_t> idx(hi - lo); for (size_t i = lo; i < hi; ++i) idx[i - lo] = i;
-        rcs[g] = run_device(*devs[g], in, idx, verdicts, flags);
+        rcs[g] = run_device(*devs[g], in, idx, verdicts, env);
     };
     for (size_t g = 1; g < use; ++g) th.emplace_back(shard, g);
     shard(0);
@@ -841,9 +877,9 @@ int verify_state_many(const CallIn &in, size_t n, uint8_t *verdicts) {
 
 // single-proof diagnostic form: one job per step so that every step gets its own bit
 int state_checks(const uint8_t *proof, size_t proof_len, const uint8_t *pub, size_t pub_len, uint32_t *passed_out, uint32_t *ran_out) {
-    Device *D; uint32_t flags;
-    { std::lock_guard<std::mutex> lk(g_mu); auto &ds = devices(); if (ds.empty()) return MINA_ERR_HIP; D = ds[0]; flags = g_flags; }
-    const Config cf = read_config(*D, flags | MINA_VERIFY_ALLOW_SURROGATE);
+    Device *D; uint32_t flags; int network;
+    { std::lock_guard<std::mutex> lk(g_mu); auto &ds = devices(); if (ds.empty()) return MINA_ERR_HIP; D = ds[0]; flags = g_flags; network = g_network; }
+    const Config cf = read_config(*D, flags | MINA_VERIFY_ALLOW_SURROGATE, network);
     Shape sh; sh.kimchi = cf.kimchi; sh.statements = cf.kimchi && cf.statements; sh.k = cf.k; sh.network = cf.network; sh.feature_aware = cf.feature_aware;
     uint32_t passed = 0, ran = MINA_CHECK_FORMAT;
     *passed_out = 0; *ran_out = ran;
@@ -904,8 +940,8 @@ extern "C" int mina_verify_state_batch(size_t n, const uint8_t *const *proofs, c
     if (n && (!proofs || !proof_lens || !pubs || !pub_lens || !verdicts_out)) return fail(MINA_ERR_ARG, "null argument");
     // a small batch is a latency-bound job whatever its size (64 proofs: 21 ms, 1024: 25 ms): concurrent small batches share jobs the way
     // single-proof calls do (16 callers of 64 proofs: 8.7 k -> proofs/s of one 1024-proof job per ~25 ms)
-    static const size_t merge_max = getenv("MINA_VERIFY_MERGE_BATCH_MAX") ? (size_t)std::max(0L, atol(getenv("MINA_VERIFY_MERGE_BATCH_MAX"))) : (size_t)512;
-    if (n && n <= merge_max && getenv("MINA_VERIFY_NO_MERGE") == nullptr) {
+    const mina_verify_tuning tune = mb_tune();
+    if (n && n <= tune.merge_batch_max && tune.merge) {
         std::vector<PendingCall> calls(n);
         for (size_t i = 0; i < n; ++i) { calls[i].proof = proofs[i]; calls[i].proof_len = proof_lens[i]; calls[i].pub = pubs[i]; calls[i].pub_len = pub_lens[i]; }
         g_state_calls.run_group(exec_state_calls, calls.data(), n);
@@ -1035,8 +1071,8 @@ extern "C" int mina_verify_account_batch(size_t n, const uint8_t *const *proofs,
     if (n && (!proofs || !proof_lens || !pubs || !pub_lens || !verdicts_out)) return fail(MINA_ERR_ARG, "null argument");
     // BASELINE C4's batch of 256 is a latency-bound job (a dependent chain of ~70 permutations: 8 ms for 1 or for 1024 proofs): concurrent small
     // batches share jobs the way single-proof calls do
-    static const size_t merge_max = getenv("MINA_VERIFY_MERGE_BATCH_MAX") ? (size_t)std::max(0L, atol(getenv("MINA_VERIFY_MERGE_BATCH_MAX"))) : (size_t)512;
-    if (n && n <= merge_max && getenv("MINA_VERIFY_NO_MERGE") == nullptr) {
+    const mina_verify_tuning tune = mb_tune();
+    if (n && n <= tune.merge_batch_max && tune.merge) {
         std::vector<PendingCall> calls(n);
         for (size_t i = 0; i < n; ++i) { calls[i].proof = proofs[i]; calls[i].proof_len = proof_lens[i]; calls[i].pub = pubs[i]; calls[i].pub_len = pub_lens[i]; }
         g_account_calls.run_group(exec_account_calls, calls.data(), n);
@@ -1055,4 +1091,25 @@ extern "C" bool mina_verify_account_files(const char *proof_path, const char *pu
     std::vector<uint8_t> p, q;
     if (!proof_path || !pub_path || !read_file(proof_path, p, 1u << 20) || !read_file(pub_path, q, 1u << 20)) return false;
     return mina_verify_account(p.data(), p.size(), q.data(), q.size());
+}
+
+// ------------------------------------------------------------------------------------------------ the reference's own symbol names
+// What Aligned's operator (cgo) and batcher (Rust) bind: README.md:277-279 (`verify_mina_state_ffi`), :358-362 (`verify_account_inclusion_ffi`);
+// proving-system tags core/src/aligned.rs:40,53.  Fixed-size caller-owned buffers + used lengths: a length beyond the buffer is
+// `false`, like every other failure; nothing unwinds (the callees catch nothing because nothing throws across them: allocation failure aside, the
+// pipeline reports through return codes).  The `_u32` forms are the length type of later Aligned versions.
+extern "C" bool verify_mina_state_ffi(const uint8_t *proof_buffer, size_t proof_len, const uint8_t *pub_input_buffer, size_t pub_input_len) {
+    if (!proof_buffer || !pub_input_buffer || proof_len > MINA_FFI_MAX_PROOF_SIZE || pub_input_len > MINA_FFI_MAX_PUB_INPUT_SIZE) return false;
+    try { return mina_verify_state(proof_buffer, proof_len, pub_input_buffer, pub_input_len); } catch (...) { return false; }
+}
+extern "C" bool verify_account_inclusion_ffi(const uint8_t *proof_buffer, size_t proof_len, const uint8_t *pub_input_buffer, size_t pub_input_len) {
+    // (no cap of its own: the account operator's buffer sizes are not in the tree -- a zkApp account's ABI form can exceed 6 KiB -- and only `len` bytes are read)
+    if (!proof_buffer || !pub_input_buffer) return false;
+    try { return mina_verify_account(proof_buffer, proof_len, pub_input_buffer, pub_input_len); } catch (...) { return false; }
+}
+extern "C" bool verify_mina_state_ffi_u32(const uint8_t *proof_buffer, uint32_t proof_len, const uint8_t *pub_input_buffer, uint32_t pub_input_len) {
+    return verify_mina_state_ffi(proof_buffer, (size_t)proof_len, pub_input_buffer, (size_t)pub_input_len);
+}
+extern "C" bool verify_account_inclusion_ffi_u32(const uint8_t *proof_buffer, uint32_t proof_len, const uint8_t *pub_input_buffer, uint32_t pub_input_len) {
+    return verify_account_inclusion_ffi(proof_buffer, (size_t)proof_len, pub_input_buffer, (size_t)pub_input_len);
 }

@@ -20,6 +20,7 @@
 using namespace mb;
 
 int mb_fail(int code, const std::string &msg);      // records the thread-local error text, returns code
+mina_verify_tuning mb_tune();                        // the process-wide tuning (api_core.hip; mina_verify_configure_ex), by value
 #define fail mb_fail
 
 #define HIPC(expr)                                                                                 \
@@ -141,29 +142,27 @@ struct mina_ctx {
 // slots), larger ones the wave-packed 3-lane form (21 sponges per wave); both run their rounds on the 29-bit limbs (fp29.cuh).
 // The per-proof transcripts of a job (kimchi, Pickles statement, opening) switch at 1024 proofs per call instead (api_kimchi.hip,
 // api_pickles.hip, api_ipa.hip: measured with 16 calls in flight).
-static constexpr size_t COOP8_MAX_GROUPS = 8192;
+static constexpr size_t COOP8_MAX_GROUPS = 8192;   // (the default of mina_verify_tuning.coop8_max)
 // `groups` sponges per call, `nlanes` calls in flight: the choice looks at the work in flight (256 proofs per call on 16 lanes are 69 k state
 // hashes at once -- the 8-lane form then spends 2.1x the issue slots of a saturated chip: 480 proofs per call 66 -> 75 k/s).
-// MINA_COOP8_MAX overrides the limit, MINA_COOP8_PER_CALL=1 ignores the lanes (A/B switches).
+// mina_verify_tuning.coop8_max overrides the limit, .coop8_per_call = 1 ignores the lanes.
 static inline bool use_coop8(const mina_ctx *c, size_t groups) {
-    static const size_t lim = getenv("MINA_COOP8_MAX") ? (size_t)strtoull(getenv("MINA_COOP8_MAX"), nullptr, 10) : COOP8_MAX_GROUPS;
-    static const bool per_call = getenv("MINA_COOP8_PER_CALL") != nullptr;
-    return groups * (size_t)((c && !per_call) ? c->nlanes : 1) <= lim;
+    const mina_verify_tuning t = mb_tune();
+    return groups * (size_t)((c && !t.coop8_per_call) ? c->nlanes : 1) <= (size_t)t.coop8_max;
 }
 
 // One proof or a handful in flight (the reference's call pattern): 16 lanes per sponge -- the shortest dependent chain, at 5.3x the issue
 // slots of the 3-lane form (poseidon_permute_hex).  `proofs` per call x lanes in flight, up to 64 (one proof 25.5 -> 23.1 ms, 16 proofs
-// 22.9 -> 21.2 ms; at 256 the 8-lane form is as fast); MINA_COOP16_MAX overrides (0 disables).
+// 22.9 -> 21.2 ms; at 256 the 8-lane form is as fast); mina_verify_tuning.coop16_max overrides (0 disables).
 static inline bool use_coop16(const mina_ctx *c, size_t proofs) {
-    static const size_t lim = getenv("MINA_COOP16_MAX") ? (size_t)strtoull(getenv("MINA_COOP16_MAX"), nullptr, 10) : (size_t)64;
-    return proofs * (size_t)(c ? c->nlanes : 1) <= lim;
+    return proofs * (size_t)(c ? c->nlanes : 1) <= (size_t)mb_tune().coop16_max;
 }
 
 // The per-proof transcripts (statement, kimchi, opening): 8 lanes per sponge while the proofs in flight (per call x lanes) leave the chip
 // latency-bound (<= 1024 per call and <= 2048 in flight: with 16 lanes 1024 per call ran 123 k/s in the 8-lane form, 138 k/s in the 3-lane
-// form; 512: 83 / 91 k; 256: 54 / 58 k), the wave-packed 3-lane form beyond.  MINA_TRANSCRIPT_COOP8_MAX overrides (proofs in flight).
+// form; 512: 83 / 91 k; 256: 54 / 58 k), the wave-packed 3-lane form beyond.  mina_verify_tuning.transcript_coop8_max overrides (proofs in flight).
 static inline bool use_coop8_transcripts(const mina_ctx *c, size_t batch, size_t per_call_limit) {
-    static const size_t lim = getenv("MINA_TRANSCRIPT_COOP8_MAX") ? (size_t)strtoull(getenv("MINA_TRANSCRIPT_COOP8_MAX"), nullptr, 10) : (size_t)0;
+    const size_t lim = (size_t)mb_tune().transcript_coop8_max;
     const size_t in_flight = batch * (size_t)(c ? c->nlanes : 1);
     return lim ? in_flight <= lim : ((batch <= per_call_limit && in_flight <= 2048) || in_flight <= 2560);   // a call alone on the GPU: 1536 proofs 29.2 -> 26.8 ms, 2048: 30.2 -> 28.4, 3072: flat, 4096: +3 ms
 }

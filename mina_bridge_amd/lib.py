@@ -43,6 +43,8 @@ EXPORTS = [
     "mina_verify_account_files", "mina_verify_account_checks", "mina_verify_account_ctx", "mina_account_hash_batch", "mina_account_abi_encode", "mina_verify_configure", "mina_verify_shutdown", "mina_verify_global_ctx", "mina_poseidon_params_name",
     "mina_verify_device_count", "mina_verify_device_ctx", "mina_verify_set_network", "mina_verify_install_verifier_index", "mina_verify_install_step_index", "mina_verify_set_poseidon_params",
     "mina_poseidon_install_default_params",
+    "verify_mina_state_ffi", "verify_account_inclusion_ffi", "verify_mina_state_ffi_u32", "verify_account_inclusion_ffi_u32",
+    "mina_verify_tuning_default", "mina_verify_tuning_get", "mina_verify_configure_ex",
     "mina_consensus_select_secure_chain", "mina_parse_state_pub_inputs", "mina_parse_account_pub_inputs", "mina_parse_merkle_path", "mina_verify_account_inclusion",
 ]
 
@@ -357,6 +359,69 @@ def polish_tokens_from_json(field: int, text: str, enabled_features: int = 0, op
 
 def verify_configure(flags: int):
     load_library().mina_verify_configure(ctypes.c_uint32(flags))
+
+
+class Tuning(ctypes.Structure):
+    """`mina_verify_tuning` (include/mina_verify.h): every knob of the library, process-wide"""
+    FIELDS = ("struct_size", "chunk", "single_max", "slots", "window", "ahead", "early_min", "early_sub", "head_min", "split_max", "chain_cus", "cu_period", "acc_mask",
+              "hash_piece_waves", "up_stream", "min_shard", "pace_us", "merge", "merge_batch_max", "linger_us", "max_jobs", "coop16_max", "coop8_max", "coop8_per_call",
+              "transcript_coop8_max", "ipa_coop8_max", "kimchi_coop8_max", "bpoly_mfma", "pubcomm_direct", "ipa_shared_points", "kimchi_shared_digest", "ipa_side_stream",
+              "search_fan", "search_full")
+    _fields_ = [(n, ctypes.c_uint32) for n in FIELDS]
+
+
+def verify_tuning_default() -> Tuning:
+    t = Tuning()
+    load_library().mina_verify_tuning_default(ctypes.byref(t))
+    return t
+
+
+def verify_tuning_get() -> Tuning:
+    t = Tuning()
+    load_library().mina_verify_tuning_get(ctypes.byref(t))
+    return t
+
+
+def verify_configure_ex(t: "Tuning | None"):
+    lib = load_library()
+    rc = lib.mina_verify_configure_ex(ctypes.byref(t) if t is not None else None)
+    if rc != 0:
+        raise MinaError(f"mina_verify_configure_ex failed ({rc}): {lib.mina_last_error().decode()}")
+
+
+class tuning:
+    """`with m.lib.tuning(chunk=4, single_max=1): ...` -- the library's defaults with the named fields changed for the block (tests force pipeline /
+    lane shapes this way: the verdicts must not depend on them).  Nested blocks stack; the previous tuning is restored on exit."""
+    def __init__(self, **fields):
+        self.fields = fields
+
+    def __enter__(self):
+        self.prev = verify_tuning_get()
+        t = verify_tuning_get()
+        for k, v in self.fields.items():
+            if k not in Tuning.FIELDS or k == "struct_size":
+                raise KeyError(k)
+            setattr(t, k, int(v))
+        verify_configure_ex(t)
+        return t
+
+    def __exit__(self, *exc):
+        verify_configure_ex(self.prev)
+        return False
+
+
+def tune_from_string(spec: str):
+    """"chunk=4,slots=16" -> mina_verify_configure_ex with those fields over the defaults (tools/ pass their --tune / $MINA_TUNE strings here; the
+    library itself reads no tuning from the environment)"""
+    if not spec:
+        return
+    t = verify_tuning_default()
+    for item in spec.split(","):
+        k, v = item.split("=")
+        if k.strip() not in Tuning.FIELDS:
+            raise KeyError(k)
+        setattr(t, k.strip(), int(v))
+    verify_configure_ex(t)
 
 
 def verify_set_network(devnet: int):

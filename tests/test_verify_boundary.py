@@ -448,44 +448,41 @@ def test_boundary_pipeline_chunks_and_device_shards_give_the_same_verdicts(world
         else: p, q, v = good[i % 3][0], good[i % 3][1], 1
         proofs.append(p); pubs.append(q); want.append(v)
     assert m.lib.verify_state_batch(proofs, pubs).tolist() == want
-    env = {"MINA_VERIFY_CHUNK": None, "MINA_VERIFY_SINGLE_MAX": None, "MINA_VERIFY_MIN_SHARD": None, "MINA_VERIFY_DEVICES": None, "MINA_VERIFY_EARLY_MIN": None, "MINA_VERIFY_EARLY_SUB": None, "MINA_VERIFY_WINDOW": None, "MINA_VERIFY_AHEAD": None, "MINA_VERIFY_HEAD_MIN": None}
-    keep = {k: os.environ.get(k) for k in env}
+    T = m.lib.tuning
+    keep_dev = os.environ.get("MINA_VERIFY_DEVICES")
     try:
-        os.environ["MINA_VERIFY_SINGLE_MAX"] = "1"
-        for chunk in ("5", "2"):
-            os.environ["MINA_VERIFY_CHUNK"] = chunk
-            assert m.lib.verify_state_batch(proofs, pubs).tolist() == want, f"chunks of {chunk}"
+        for chunk in (5, 2):
+            with T(single_max=1, chunk=chunk):
+                assert m.lib.verify_state_batch(proofs, pubs).tolist() == want, f"chunks of {chunk}"
         # the streamed form of a chunk (records uploaded and hashed run by run while the rest is parsed): runs of 3 -- the garbage entry at 30
         # ends the streaming, the rest goes up after the patching -- as one chunk, in chunks of 5 (runs of 2), and a call that streams to the end
-        os.environ["MINA_VERIFY_EARLY_MIN"] = "1"; os.environ["MINA_VERIFY_HEAD_MIN"] = "0"      # + the first run parsed whole and hashed ahead of everything else
-        for single, chunk, sub in (("8192", "8192", "3"), ("1", "5", "2"), ("8192", "8192", "1")):
-            os.environ["MINA_VERIFY_SINGLE_MAX"] = single; os.environ["MINA_VERIFY_CHUNK"] = chunk; os.environ["MINA_VERIFY_EARLY_SUB"] = sub
-            assert m.lib.verify_state_batch(proofs, pubs).tolist() == want, f"streamed, runs of {sub}, chunks of {chunk}"
-            assert m.lib.verify_state_batch(proofs[1:12], pubs[1:12]).tolist() == want[1:12], "streamed to the end"
-            assert m.lib.verify_state_batch(proofs[14:25], pubs[14:25]).tolist() == want[14:25], "streamed to the end, all valid"
-        os.environ["MINA_VERIFY_EARLY_SUB"] = "0"
-        assert m.lib.verify_state_batch(proofs, pubs).tolist() == want, "streaming off"
+        # (early_min = 1, head_min = 0: + the first run parsed whole and hashed ahead of everything else)
+        for single, chunk, sub in ((8192, 8192, 3), (1, 5, 2), (8192, 8192, 1)):
+            with T(early_min=1, head_min=0, single_max=single, chunk=chunk, early_sub=sub):
+                assert m.lib.verify_state_batch(proofs, pubs).tolist() == want, f"streamed, runs of {sub}, chunks of {chunk}"
+                assert m.lib.verify_state_batch(proofs[1:12], pubs[1:12]).tolist() == want[1:12], "streamed to the end"
+                assert m.lib.verify_state_batch(proofs[14:25], pubs[14:25]).tolist() == want[14:25], "streamed to the end, all valid"
+        with T(early_min=1, head_min=0, early_sub=0):
+            assert m.lib.verify_state_batch(proofs, pubs).tolist() == want, "streaming off"
         # the window of chunks on the GPU at a time, and chunks parsed ahead of it (19 chunks of 2)
-        os.environ["MINA_VERIFY_SINGLE_MAX"] = "1"; os.environ["MINA_VERIFY_CHUNK"] = "2"; os.environ["MINA_VERIFY_EARLY_SUB"] = "1"
-        for window, ahead in (("1", "0"), ("3", "2"), ("16", "4")):
-            os.environ["MINA_VERIFY_WINDOW"] = window; os.environ["MINA_VERIFY_AHEAD"] = ahead
-            assert m.lib.verify_state_batch(proofs, pubs).tolist() == want, f"window {window}, {ahead} ahead"
-        os.environ.pop("MINA_VERIFY_WINDOW"); os.environ.pop("MINA_VERIFY_AHEAD")
-        os.environ["MINA_VERIFY_EARLY_SUB"] = "4"; os.environ["MINA_VERIFY_SINGLE_MAX"] = "1"
+        for window, ahead in ((1, 0), (3, 2), (16, 4)):
+            with T(early_min=1, head_min=0, single_max=1, chunk=2, early_sub=1, window=window, ahead=ahead, slots=16):
+                assert m.lib.verify_state_batch(proofs, pubs).tolist() == want, f"window {window}, {ahead} ahead"
         # three logical devices on GPU 0
         m.lib.verify_shutdown()
-        os.environ["MINA_VERIFY_DEVICES"] = "0,0,0"; os.environ["MINA_VERIFY_MIN_SHARD"] = "1"; os.environ["MINA_VERIFY_CHUNK"] = "4"
-        assert m.lib.verify_device_count() == 3
-        alld = m.lib.verify_all_devices()
-        install_index(alld, world["circ"].index); install_step_index(alld, world["step"])
-        assert m.lib.verify_state_batch(proofs, pubs).tolist() == want, "3 shards"
-        assert m.lib.verify_state_batch(proofs[:2], pubs[:2]).tolist() == want[:2]
-        assert m.lib.verify_state(*good[0]) is True and m.lib.verify_state(*bad_open) is False      # single calls are dealt round-robin over the devices
-        assert m.lib.verify_state(*good[1]) is True and m.lib.verify_state(*good[2]) is True
+        os.environ["MINA_VERIFY_DEVICES"] = "0,0,0"
+        with T(early_min=1, head_min=0, early_sub=4, single_max=1, min_shard=1, chunk=4):
+            assert m.lib.verify_device_count() == 3
+            alld = m.lib.verify_all_devices()
+            install_index(alld, world["circ"].index); install_step_index(alld, world["step"])
+            assert m.lib.verify_state_batch(proofs, pubs).tolist() == want, "3 shards"
+            assert m.lib.verify_state_batch(proofs[:2], pubs[:2]).tolist() == want[:2]
+            assert m.lib.verify_state(*good[0]) is True and m.lib.verify_state(*bad_open) is False      # single calls are dealt round-robin over the devices
+            assert m.lib.verify_state(*good[1]) is True and m.lib.verify_state(*good[2]) is True
     finally:
-        for k, v in keep.items():
-            if v is None: os.environ.pop(k, None)
-            else: os.environ[k] = v
+        if keep_dev is None: os.environ.pop("MINA_VERIFY_DEVICES", None)
+        else: os.environ["MINA_VERIFY_DEVICES"] = keep_dev
+        m.lib.verify_configure_ex(None)
         m.lib.verify_shutdown()
         gctx = m.lib.verify_global_ctx()
         install_index(gctx, world["circ"].index); install_step_index(gctx, world["step"])
@@ -651,23 +648,21 @@ def test_concurrent_batch_callers_share_the_pipeline(world, srs_oracle):
             items = [(bad, 0) if rng.randrange(5) == 0 else (good[rng.randrange(3)], 1) for _ in range(n)]
             calls.append(items)
         plans.append(calls)
-    errors = []
-    keep = {k: os.environ.get(k) for k in ("MINA_VERIFY_CHUNK", "MINA_VERIFY_SINGLE_MAX")}
-    os.environ["MINA_VERIFY_CHUNK"] = "4"; os.environ["MINA_VERIFY_SINGLE_MAX"] = "6"          # some calls in several chunks
-    try:
-        def worker(t):
-            for items in plans[t]:
-                got = m.lib.verify_state_batch([x[0][0] for x in items], [x[0][1] for x in items]).tolist()
-                if got != [x[1] for x in items]:
-                    errors.append((t, got, [x[1] for x in items]))
-        th = [threading.Thread(target=worker, args=(t,)) for t in range(len(plans))]
-        for t in th: t.start()
-        for t in th: t.join()
-    finally:
-        for k, v in keep.items():
-            if v is None: os.environ.pop(k, None)
-            else: os.environ[k] = v
-    assert not errors, errors[:2]
+    # chunk = 4, single_max = 6: some calls in several chunks.  Twice: the callers' small batches merged into shared jobs (the default), and every call
+    # through the pipeline on its own (merge = 0) -- then a chunk's culprit search really runs while other callers' chunks are in flight on the lanes it
+    # uses (it drains the device first and holds its lock: api_verify.hip `fallback`)
+    for merge in (1, 0):
+        errors = []
+        with m.lib.tuning(chunk=4, single_max=6, merge=merge):
+            def worker(t):
+                for items in plans[t]:
+                    got = m.lib.verify_state_batch([x[0][0] for x in items], [x[0][1] for x in items]).tolist()
+                    if got != [x[1] for x in items]:
+                        errors.append((t, got, [x[1] for x in items]))
+            th = [threading.Thread(target=worker, args=(t,)) for t in range(len(plans))]
+            for t in th: t.start()
+            for t in th: t.join()
+        assert not errors, (merge, errors[:2])
 
 
 def test_state_and_account_callers_at_once(world, srs_oracle):

@@ -64,12 +64,8 @@ def test_full_size_batch_and_one_tamper_per_stage(big):
     assert m.lib.verify_state_batch(proofs, pubs).tolist() == [1, 1, 1, 1, 0, 0, 0, 0]
     # the culprits of the failed folded opening check were found from the prepared rows of the batch (slices of them re-checked); the same
     # verdicts when every part repeats its transcripts instead
-    import os
-    os.environ["MINA_STATE_SEARCH_FULL"] = "1"
-    try:
+    with m.lib.tuning(search_full=1):
         assert m.lib.verify_state_batch(proofs, pubs).tolist() == [1, 1, 1, 1, 0, 0, 0, 0]
-    finally:
-        del os.environ["MINA_STATE_SEARCH_FULL"]
     # a bigger batch with culprits at both ends and in the middle: two rounds of cuts
     many_p = [proofs[i % 4] for i in range(70)]; many_q = [pubs[i % 4] for i in range(70)]
     for i in (0, 33, 34, 69): many_p[i] = proofs[6]; many_q[i] = pubs[6]

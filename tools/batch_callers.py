@@ -18,6 +18,7 @@ proofs = [bytes.fromhex(p["proof"]) for p in fx["proofs"]]; pubs = [bytes.fromhe
 P = [proofs[i % len(proofs)] for i in range(size)]; Q = [pubs[i % len(pubs)] for i in range(size)]
 pa, PP, PL = L._ptr_arrays(P); qa, QQ, QL = L._ptr_arrays(Q)
 lib = L.load_library()
+L.tune_from_string(os.environ.get("MINA_TUNE", ""))      # e.g. MINA_TUNE=split_max=0,slots=8
 def worker(k):
     out = np.zeros(size, np.uint8)
     for _ in range(k):
@@ -31,4 +32,4 @@ t=time.perf_counter()
 for x in th: x.start()
 for x in th: x.join()
 dt=time.perf_counter()-t
-print(json.dumps({"threads":nthreads,"size":size,"proofs_per_s":round(nthreads*calls*size/dt),"ms_per_call":round(dt/calls*1e3,2), "split_max": os.environ.get("MINA_VERIFY_SPLIT_MAX","default")}))
+print(json.dumps({"threads":nthreads,"size":size,"proofs_per_s":round(nthreads*calls*size/dt),"ms_per_call":round(dt/calls*1e3,2), "tune": os.environ.get("MINA_TUNE", "default")}))

@@ -1,6 +1,6 @@
 # dev tool: A/B of the boundary pipeline's knobs INSIDE one process (boxes differ by more than the knobs do): the settings are cycled call by
-# call -- run_device reads its knobs from the environment per call -- and the median time per setting is reported.
-# usage: python tools/boundary_ab.py SIZE ROUNDS "ENV=a ENV2=b" "ENV=c" ...      ("-" = library defaults)
+# call -- fields of mina_verify_tuning (include/mina_verify.h), set through mina_verify_configure_ex between calls -- and the median time per setting is reported.
+# usage: python tools/boundary_ab.py SIZE ROUNDS "chunk=4096,slots=8" "hash_piece_waves=512" ...      ("-" = library defaults)
 import ctypes, json, os, random, statistics, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -28,12 +28,9 @@ def call():
     dt = time.perf_counter() - t
     assert rc == 0 and out.all()
     return dt * 1e3
-touched = set()
 def apply(cfg):
-    for k in touched: os.environ.pop(k, None)
-    if cfg != "-":
-        for kv in cfg.split():
-            k, v = kv.split("="); os.environ[k] = v; touched.add(k)
+    if cfg == "-": m.lib.verify_configure_ex(None)
+    else: m.lib.tune_from_string(cfg.replace(" ", ","))
 for cfg in configs: apply(cfg); call(); call()
 times = {cfg: [] for cfg in configs}
 for r in range(rounds):

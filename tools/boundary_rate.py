@@ -7,6 +7,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")      # before HIP initialises: the pipeline's lanes need a hardware queue each
 import torch; torch.cuda.is_available()
 import mina_bridge_amd as m
+m.lib.tune_from_string(os.environ.get("MINA_TUNE", ""))      # e.g. MINA_TUNE=chunk=4096,slots=8 (fields of mina_verify_tuning)
 from ipa_helpers import poseidon_pp
 from kimchi_helpers import install_index, install_step_index, load_k15_fixture, load_statement_fixture, make_chain, make_step_index
 from oracle import mina_state_ref as S

@@ -1,6 +1,6 @@
 #!/bin/bash
 # dev tool: bytes -> bools rate of mina_verify_state_batch (tools/boundary_rate.py) under the pipeline's knobs; one process per setting
-# usage: tools/boundary_sweep.sh SIZE "ENV1=a ENV2=b" "ENV1=c" ...
+# usage: tools/boundary_sweep.sh SIZE "MINA_TUNE=chunk=4096,slots=8" "MINA_TUNE=early_sub=512" ...   (fields of mina_verify_tuning; process-level settings such as GPU_MAX_HW_QUEUES as plain env)
 size=$1; shift
 for cfg in "$@"; do
   echo "== $cfg"

@@ -89,13 +89,13 @@ while time.time() < t_end:
         counts["cancelling_pairs"] += 1
     want = [int(b[2]) for b in batch]
     # the pipeline's shape, at random: chunks of a few entries, runs of a few entries, the window of chunks and the parsing ahead of it
-    for k in ("MINA_VERIFY_CHUNK", "MINA_VERIFY_SINGLE_MAX", "MINA_VERIFY_EARLY_MIN", "MINA_VERIFY_EARLY_SUB", "MINA_VERIFY_WINDOW", "MINA_VERIFY_AHEAD", "MINA_VERIFY_HEAD_MIN"): os.environ.pop(k, None)
+    tune = {}
     if n >= 2000: pass                                     # library defaults
     elif rng.randrange(2):
-        os.environ["MINA_VERIFY_CHUNK"] = str(rng.choice([2, 3, 7, 16])); os.environ["MINA_VERIFY_SINGLE_MAX"] = "1"
-        os.environ["MINA_VERIFY_WINDOW"] = str(rng.choice([1, 2, 4])); os.environ["MINA_VERIFY_AHEAD"] = str(rng.choice([0, 1, 3]))
+        tune.update(chunk=rng.choice([2, 3, 7, 16]), single_max=1, window=rng.choice([1, 2, 4]), ahead=rng.choice([0, 1, 3]), slots=16)
     if n < 2000 and rng.randrange(2):
-        os.environ["MINA_VERIFY_EARLY_MIN"] = "1"; os.environ["MINA_VERIFY_EARLY_SUB"] = str(rng.choice([0, 1, 2, 5])); os.environ["MINA_VERIFY_HEAD_MIN"] = str(rng.choice([0, 1000000]))
+        tune.update(early_min=1, early_sub=rng.choice([0, 1, 2, 5]), head_min=rng.choice([0, 1000000]))
+    m.lib.tune_from_string(",".join(f"{k}={v}" for k, v in tune.items()) or "chunk=8192")
     if rnd % 4 == 0 and n <= 40:
         got = [None] * n
         def worker(i): got[i] = int(m.lib.verify_state(batch[i][0], batch[i][1]))
