@@ -26,6 +26,11 @@ consensus pre-checks (host side of the boundary, done by the caller before the t
 
 Multi-GPU: proof-level sharding (SURVEY.md 8e variant 1): every rank verifies its own proofs against its replica of the
 SRS tables; the ranks' verdict words are all-gathered over RCCL inside the timed region; weak scaling.  One JSON line on rank 0.
+`python bench.py --gpus N` WITHOUT a torch.distributed launch (WORLD_SIZE unset) starts its N ranks itself (`launch_ranks`): one child
+process per GPU with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rank 0's JSON line passed through.  On a box with fewer than N GPUs the
+ranks share GPU 0 and rendezvous over gloo (`"shared_gpu": true`, `"gpus_physical"` in the line): the N > 1 code path is exercised, the
+figure is NOT a scaling number.  At N > 1 rank 0 also times the PRODUCT's own multi-device path -- ONE process, $MINA_VERIFY_DEVICES = the N
+GPUs, `mina_verify_state_batch` on serialized proofs (`boundary_bytes_to_bools.all_devices`) -- while the other ranks wait.
 """
 from __future__ import annotations
 
@@ -230,14 +235,9 @@ def cpu_baseline(baseline_sample, budget_s: float = 12.0):
                       f"thread at a time; native C restatement of the o1-labs / arkworks algorithms (NOT the Rust reference, which cannot be built here); verdict ACCEPT: {ok}"}
 
 
-def boundary_leg(m, local_rank: int, B: int, min_seconds: float = 2.0):
-    """Secondary key `boundary_bytes_to_bools`: the reference-shaped boundary itself -- `mina_verify_state_batch` over B full-size bincode
-    `MinaStateProof`s + 1057-byte public inputs (tests/golden/state_proofs_k15_bytes.json: the headline's four proofs as the caller of
-    core/src/aligned.rs:31-58 would send them, tiled to B), host bytes in, verdict bytes out: parsing, `to_input` flattening, the ledger and
-    consensus checks, the page-locked staging, PCIe both ways and the GPU job, back-to-back synchronous calls for >= `min_seconds`; then the
-    same with two caller threads (a batcher's tasks).  Never `value`."""
-    import ctypes
-    import threading
+def _boundary_setup(m, devices: str):
+    """the verifier process of the boundary legs: contexts on `devices` ("3" = GPU 3; "0,1,2,3" = one context per GPU, a call's proofs cut into
+    contiguous shards, api_verify.hip verify_state_many), the fixture's synthetic indexes on every device.  Returns (lib, items, ndev) or a skip record."""
     path = os.path.join(ROOT, "tests", "golden", "state_proofs_k15_bytes.json")
     if not os.path.exists(path):
         return {"skipped": "tests/golden/state_proofs_k15_bytes.json missing"}
@@ -246,41 +246,75 @@ def boundary_leg(m, local_rank: int, B: int, min_seconds: float = 2.0):
     import mina_bridge_amd.poseidon_params as PP
     if fxb["poseidon_constants"] != PP.NAME:
         return {"skipped": "byte fixture minted under another Poseidon constant set"}
-    os.environ["MINA_VERIFY_DEVICE"] = str(local_rank)
+    os.environ["MINA_VERIFY_DEVICES"] = devices
+    ndev = len(devices.split(","))
     m.lib.verify_configure(m.lib.VERIFY_ALLOW_SURROGATE)            # the compiled-in Poseidon tables are the surrogate set (named in the output)
+    assert m.lib.verify_device_count() == ndev
     install_fixture_indexes(m.lib.verify_all_devices(), fx, un)
     items = [(bytes.fromhex(it["proof"]), bytes.fromhex(it["pub"])) for it in fxb["proofs"]]
-    P = [items[i % len(items)][0] for i in range(B)]; Q = [items[i % len(items)][1] for i in range(B)]
-    lib = m.load_library()
-    PP_ = (ctypes.c_char_p * B)(*P); PL = (ctypes.c_size_t * B)(*map(len, P)); QQ = (ctypes.c_char_p * B)(*Q); QL = (ctypes.c_size_t * B)(*map(len, Q))
+    return m.load_library(), items, ndev
 
-    def call(out):
-        rc = lib.mina_verify_state_batch(ctypes.c_size_t(B), PP_, PL, QQ, QL, out.ctypes.data_as(ctypes.c_void_p))
-        assert rc == 0, lib.mina_last_error().decode()
-    out = np.zeros(B, np.uint8)
+
+class _Batch:
+    """n serialized proofs (the fixture's four, tiled) as the pointer / length arrays of `mina_verify_state_batch`"""
+    def __init__(self, lib, items, n):
+        import ctypes
+        self.lib, self.n, self.items = lib, n, items
+        self.P = [items[i % len(items)][0] for i in range(n)]; self.Q = [items[i % len(items)][1] for i in range(n)]
+        self.PP = (ctypes.c_char_p * n)(*self.P); self.PL = (ctypes.c_size_t * n)(*map(len, self.P))
+        self.QQ = (ctypes.c_char_p * n)(*self.Q); self.QL = (ctypes.c_size_t * n)(*map(len, self.Q))
+        self.out = np.zeros(n, np.uint8)
+
+    def call(self, out=None):
+        import ctypes
+        out = self.out if out is None else out
+        rc = self.lib.mina_verify_state_batch(ctypes.c_size_t(self.n), self.PP, self.PL, self.QQ, self.QL, out.ctypes.data_as(ctypes.c_void_p))
+        assert rc == 0, self.lib.mina_last_error().decode()
+
+    def tamper_check(self, positions):
+        """a tampered public input at each of `positions`: exactly those verdict bytes are 0 (the culprit search of their chunks), untimed"""
+        bad = bytearray(self.items[0][1]); bad[40] ^= 1
+        for pos in positions: self.QQ[pos] = bytes(bad)
+        self.call()
+        got = np.flatnonzero(self.out == 0).tolist()
+        assert got == sorted(positions), f"tampered public inputs at {sorted(positions)} must fail exactly those proofs: rejected {got[:16]}"
+        for pos in positions: self.QQ[pos] = self.Q[pos]
+
+    def timed(self, min_seconds, min_calls=1):
+        calls, t0 = 0, time.perf_counter()
+        while True:
+            self.call(); calls += 1
+            el = time.perf_counter() - t0
+            if el >= min_seconds and calls >= min_calls:
+                break
+        assert self.out.all()
+        return {"value": calls * self.n / el, "unit": "proofs/s", "proofs_per_call": self.n, "ms_per_call": el / calls * 1e3, "calls": calls}
+
+
+def boundary_leg(m, devices: str, B: int, min_seconds: float = 2.0):
+    """Secondary key `boundary_bytes_to_bools`: the reference-shaped boundary itself -- `mina_verify_state_batch` over B full-size bincode
+    `MinaStateProof`s + 1057-byte public inputs (tests/golden/state_proofs_k15_bytes.json: the headline's four proofs as the caller of
+    core/src/aligned.rs:31-58 would send them, tiled to B), host bytes in, verdict bytes out: parsing, `to_input` flattening, the ledger and
+    consensus checks, the page-locked staging, PCIe both ways and the GPU job, back-to-back synchronous calls for >= `min_seconds`; then the
+    same with two / four caller threads (a batcher's tasks), one call of 8 B proofs, and BASELINE config C5's batch (4096 per call).  Never `value`."""
+    import threading
+    setup = _boundary_setup(m, devices)
+    if isinstance(setup, dict):
+        return setup
+    lib, items, ndev = setup
+    job = _Batch(lib, items, B)
     for _ in range(3):                                                # warm: contexts, tables, slots' page-locked buffers
-        call(out)
-    assert out.all(), "boundary verdicts must be ACCEPT"
-    # one tampered proof in the batch: exactly its verdict byte is 0 (the culprit search of its chunk), untimed
-    bad = bytearray(items[0][1]); bad[40] ^= 1
-    QQ[B // 3] = bytes(bad)
-    call(out)
-    assert out.sum() == B - 1 and out[B // 3] == 0, f"a tampered public input must fail exactly its own proof: {int(out.sum())} of {B} accepted, rejected {np.flatnonzero(out == 0)[:16].tolist()}"
-    QQ[B // 3] = Q[B // 3]
-    calls, t0 = 0, time.perf_counter()
-    while True:
-        call(out); calls += 1
-        el = time.perf_counter() - t0
-        if el >= min_seconds:
-            break
-    assert out.all()
-    single = {"proofs_per_s": calls * B / el, "ms_per_call": el / calls * 1e3, "calls": calls}
+        job.call()
+    assert job.out.all(), "boundary verdicts must be ACCEPT"
+    job.tamper_check([B // 3])
+    single = job.timed(min_seconds)
+
     def callers(k):
         outs = [np.zeros(B, np.uint8) for _ in range(k)]
         counts = [0] * k; stop = [time.perf_counter() + 1e9]
         def worker(i):
             while time.perf_counter() < stop[0]:
-                call(outs[i]); counts[i] += 1
+                job.call(outs[i]); counts[i] += 1
         for warm in (True, False):                                    # every slot the callers use allocates its page-locked staging on first use
             stop[0] = time.perf_counter() + (0.3 if warm else min_seconds)
             for i in range(k): counts[i] = 0
@@ -295,27 +329,100 @@ def boundary_leg(m, local_rank: int, B: int, min_seconds: float = 2.0):
     # one call of 8 x B proofs: chunks of B, at most four on the GPU at a time
     big = None
     if B == 8192:
-        n8 = 8 * B
-        P8 = (ctypes.c_char_p * n8)(*(P * 8)); PL8 = (ctypes.c_size_t * n8)(*(list(map(len, P)) * 8)); Q8 = (ctypes.c_char_p * n8)(*(Q * 8)); QL8 = (ctypes.c_size_t * n8)(*(list(map(len, Q)) * 8))
-        out8 = np.zeros(n8, np.uint8)
-        def call8():
-            rc = lib.mina_verify_state_batch(ctypes.c_size_t(n8), P8, PL8, Q8, QL8, out8.ctypes.data_as(ctypes.c_void_p))
-            assert rc == 0, lib.mina_last_error().decode()
-        call8(); t0 = time.perf_counter(); k8 = 0
-        while k8 < 3 or time.perf_counter() - t0 < 1.0:
-            call8(); k8 += 1
-        el8 = time.perf_counter() - t0
-        assert out8.all()
-        big = {"value": k8 * n8 / el8, "unit": "proofs/s", "proofs_per_call": n8, "ms_per_call": el8 / k8 * 1e3, "calls": k8}
-    res = {"value": single["proofs_per_s"], "unit": "proofs/s", "proofs_per_call": B, "ms_per_call": single["ms_per_call"], "calls_timed": calls,
-           "bytes_per_proof": len(P[0]) + len(Q[0]), "host_threads": int(os.environ.get("MINA_HOST_THREADS", min((os.cpu_count() or 2) // 2, 64))), "usable_cores": usable_cores(),
-           "two_caller_threads": two, "four_caller_threads": four, "one_call_of_65536": big,
+        big_job = _Batch(lib, items, 8 * B)
+        big_job.call()
+        big = big_job.timed(1.0, min_calls=3)
+    c5 = None
+    if B >= 4096:                                                     # BASELINE config C5's batch through the boundary: 4096 serialized proofs per call
+        c5_job = _Batch(lib, items, 4096)
+        c5_job.call()
+        c5 = c5_job.timed(1.0, min_calls=3)
+    res = {"value": single["value"], "unit": "proofs/s", "proofs_per_call": B, "ms_per_call": single["ms_per_call"], "calls_timed": single["calls"],
+           "bytes_per_proof": len(job.P[0]) + len(job.Q[0]), "host_threads": int(os.environ.get("MINA_HOST_THREADS", min((os.cpu_count() or 2) // 2, 64))), "usable_cores": usable_cores(),
+           "two_caller_threads": two, "four_caller_threads": four, "one_call_of_65536": big, "c5_4096_per_call": c5, "devices": devices,
            "entry_point": "mina_verify_state_batch (include/mina_verify.h): bincode MinaStateProof + MinaStatePubInputs bytes -> verdict bytes",
            "poseidon_constants": m.lib.poseidon_params_name(), "process": "a fresh process holding only libminaverify.so (no torch): the operator's verifier process",
            "note": "host bytes in, bools out: parsing, to_input flattening, ledger + consensus checks, pinned staging, PCIe both ways, the GPU job (folding "
                    "randomisers from the OS CSPRNG per chunk); one tampered proof in a warm-up call failed alone"}
     m.lib.verify_shutdown()
     return res
+
+
+def boundary_all_devices_leg(m, devices: str, B: int, min_seconds: float = 2.0):
+    """`boundary_bytes_to_bools.all_devices`: the PRODUCT's multi-GPU path (SURVEY.md 8e.1 behind the C-ABI) -- ONE process, one context per device of
+    `devices`, `mina_verify_state_batch` cuts each call's proofs into contiguous shards, one host thread + pipeline per device, verdict bytes gathered on
+    the host (api_verify.hip verify_state_many; no collective: the shards' folded checks are independent).  Two call sizes: ndev x B proofs (every device
+    a full chunk) and BASELINE config C5 as written -- 4096 serialized proofs per call over the devices.  A tampered proof in every shard fails alone."""
+    setup = _boundary_setup(m, devices)
+    if isinstance(setup, dict):
+        return setup
+    lib, items, ndev = setup
+    n_big = ndev * B
+    big = _Batch(lib, items, n_big)
+    for _ in range(3):
+        big.call()
+    assert big.out.all(), "boundary verdicts must be ACCEPT"
+    big.tamper_check([g * B + B // 3 for g in range(ndev)])           # one per shard
+    full = big.timed(min_seconds, min_calls=3)
+    c5_job = _Batch(lib, items, 4096)
+    c5_job.call(); c5_job.call()
+    c5_job.tamper_check([4096 * g // ndev + 5 for g in range(ndev)])
+    c5 = c5_job.timed(min_seconds / 2, min_calls=3)
+    res = {"devices": devices, "n_devices": ndev, "distinct_gpus": len(set(devices.split(","))), "value_all_devices": full["value"], "unit": "proofs/s",
+           "proofs_per_call": n_big, "ms_per_call": full["ms_per_call"], "calls": full["calls"], "c5_4096_per_call": c5,
+           "entry_point": "mina_verify_state_batch with $MINA_VERIFY_DEVICES = the devices: contiguous shards, one pipeline per device, no collective",
+           "note": "one tampered proof per shard in a warm-up call failed alone" + ("" if len(set(devices.split(","))) == ndev else
+                   "; LOGICAL contexts on one GPU (a box with fewer GPUs than --gpus): the sharding code path, not a scaling figure")}
+    m.lib.verify_shutdown()
+    return res
+
+
+def physical_gpus() -> int:
+    """GPUs this process can see, counted in a child process (the launcher itself never initialises HIP: a process that holds a runtime on the GPUs
+    beside the ranks is not the configuration measured)"""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True, timeout=600)
+        return int(r.stdout.strip().split()[-1]) if r.returncode == 0 and r.stdout.strip() else 0
+    except (subprocess.TimeoutExpired, ValueError):
+        return 0
+
+
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` with no torch.distributed launcher around it: start the N ranks here -- what `python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1` would do -- and pass rank 0's JSON line through.  Fewer than N GPUs on the box: the ranks share GPU 0
+    (MINA_BENCH_SHARE_GPU=1: gloo rendezvous, the line says "shared_gpu": true) so that the N > 1 path still runs end to end."""
+    import socket
+    import subprocess
+    n = args.gpus
+    have = physical_gpus()
+    if have < 1:
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   MINA_BENCH_GPUS_PHYSICAL=str(have), MINA_BENCH_LAUNCHER="bench.py launch_ranks")
+        if have < n:
+            env["MINA_BENCH_SHARE_GPU"] = "1"
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    # a rank that dies takes the others down with it (they would wait for it at the next collective until the backend's timeout)
+    import threading
+    out0 = []
+    reader = threading.Thread(target=lambda: out0.append(procs[0].stdout.read())); reader.start()
+    failed = None
+    while failed is None and any(p_.poll() is None for p_ in procs):
+        for p_ in procs:
+            if p_.poll() not in (None, 0): failed = p_.returncode
+        time.sleep(0.2)
+    if failed is not None:
+        for p_ in procs:
+            if p_.poll() is None: p_.terminate()                # the exact children started above
+    rcs = [p_.wait() for p_ in procs]
+    reader.join()
+    sys.stdout.write(out0[0] if out0 else ""); sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
 
 
 def main():
@@ -332,53 +439,67 @@ def main():
                          "(public inputs given; tests/golden/kimchi_k15.json); prepared: pre-derived BatchEvaluationProof rows (round 2's first headline)")
     ap.add_argument("--kimchi", action="store_true", help="alias of --mode kimchi")
     ap.add_argument("--no-probes", action="store_true", help="skip the isolated-kernel / C2 probes and the sustained / C5 legs (profiling runs: only the timed loop launches kernels)")
-    ap.add_argument("--no-boundary", action="store_true", help="skip the bytes -> bools leg (mina_verify_state_batch on serialized proofs)")
+    ap.add_argument("--no-boundary", action="store_true", help="skip the bytes -> bools legs (mina_verify_state_batch on serialized proofs)")
+    ap.add_argument("--boundary-jobs", type=int, default=0, help="proofs per call of the bytes -> bools legs (default: --jobs)")
     args = ap.parse_args()
     if args.kimchi:
         args.mode = "kimchi"
     args.kimchi = args.mode != "prepared"                      # the wrap leg starts from the raw proof in both non-prepared modes
 
+    if "WORLD_SIZE" not in os.environ and os.environ.get("MINA_BENCH_FORCE_DIST") == "1":
+        os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:     # no launcher around this process: be the launcher
+        raise SystemExit(launch_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # MINA_BENCH_SHARE_GPU=1 (set by launch_ranks on a box with fewer GPUs than ranks, and by the tests): every rank uses GPU 0 and the ranks rendezvous
+    # over gloo -- the N > 1 code path (barriers, MAX over ranks, verdict all-gather, aggregate value) end to end on a 1-GPU box
+    share_gpu = os.environ.get("MINA_BENCH_SHARE_GPU") == "1"
+    dist_on = world > 1 or os.environ.get("MINA_BENCH_FORCE_DIST") == "1"      # (test hook: the collectives of the N > 1 path on a 1-rank RCCL group)
+    if dist_on:                                              # control plane first, on the CPU: the other ranks wait here while rank 0 runs the boundary legs
+        import torch
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo" if share_gpu else "cpu:gloo,cuda:nccl")
     # The bytes -> bools leg runs FIRST, in a process of its own that holds only the library (no torch): the operator's verifier process.  It must
     # not share the GPU with another process's queues (a second process holding 24 hardware queues makes the scheduler time-slice them: the
     # same call took 288 ms instead of 55), and inside THIS process the 40-odd streams of the headline's context would populate the runtime's
     # queue pool first (67 - 72 ms).  GPU_MAX_HW_QUEUES=16 there: with the system runtime a lone job's three legs overlap best at <= 16 (54.6 ms;
     # 24: 68.4 ms), while the 16-lane pipeline of the headline below wants one queue per lane plus a few (24).
+    # At N > 1 rank 0 runs a second leg the same way: the product's own multi-device path, ONE process with a context on each of the N GPUs
+    # (boundary_all_devices_leg).  The other ranks have not touched their GPUs yet: they wait at the CPU barrier below.
     boundary = None
-    if not args.no_boundary and os.environ.get("MINA_BENCH_SHARE_GPU") != "1" and int(os.environ.get("RANK", "0")) == 0:      # rank 0 reports it; the others wait at the first barrier
+    if not args.no_boundary and rank == 0:
         import subprocess
         env = dict(os.environ); env["GPU_MAX_HW_QUEUES"] = os.environ.get("MINA_BOUNDARY_HW_QUEUES", "16")
-        try:
-            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--boundary-only", str(local_rank), str(args.jobs)], capture_output=True, text=True, timeout=900, env=env)
-            boundary = json.loads(r.stdout.strip().split("\n")[-1]) if r.returncode == 0 and r.stdout.strip() else {"error": (r.stderr or r.stdout)[-400:]}
-        except (subprocess.TimeoutExpired, ValueError) as e:
-            boundary = {"error": repr(e)[:400]}
+        for k_ in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"): env.pop(k_, None)
+        def leg(*argv):
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__)] + list(argv), capture_output=True, text=True, timeout=900, env=env)
+                return json.loads(r.stdout.strip().split("\n")[-1]) if r.returncode == 0 and r.stdout.strip() else {"error": (r.stderr or r.stdout)[-400:]}
+            except (subprocess.TimeoutExpired, ValueError) as e:
+                return {"error": repr(e)[:400]}
+        bsize = min(args.jobs, args.boundary_jobs) if args.boundary_jobs else args.jobs
+        boundary = leg("--boundary-only", "0" if share_gpu else str(local_rank), str(bsize))
+        if world > 1:
+            devs = ",".join("0" if share_gpu else str(g) for g in range(world))
+            boundary["all_devices"] = leg("--boundary-all-devices", devs, str(bsize))
+            boundary["value_all_devices"] = boundary["all_devices"].get("value_all_devices")
+    if dist_on:
+        dist.all_reduce(torch.zeros(1))                      # CPU tensor -> gloo: rank 0 arrives when its boundary legs are done
 
     import torch
     import mina_bridge_amd as m
 
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            print(f"bench.py: --gpus {args.gpus} without a torch.distributed.run launch (WORLD_SIZE=1): measuring 1 GPU", file=sys.stderr)
+        print(f"bench.py: --gpus {args.gpus} under a launcher with WORLD_SIZE={world}: reporting the {world} rank(s) that run", file=sys.stderr)
         args.gpus = world                      # the number of ranks actually running is what is reported
-    dist_on = world > 1
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
-    # MINA_BENCH_SHARE_GPU=1 (test hook): every rank uses GPU 0 and the ranks rendezvous over gloo -- lets the N > 1 code path
-    # (barriers, MAX over ranks, verdict all-gather, aggregate value) be exercised on a 1-GPU box; never set by the driver
-    share_gpu = os.environ.get("MINA_BENCH_SHARE_GPU") == "1"
     if share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    if dist_on:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if share_gpu:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     ctx = m.MinaContext(local_rank)
     for f in (0, 1):
@@ -463,7 +584,8 @@ def main():
 
     def barrier():
         if dist_on:
-            dist.barrier()
+            if share_gpu: dist.barrier()
+            else: dist.barrier(device_ids=[local_rank])          # RCCL
 
     gathered = None
     mask = sum(1 << b for b in PROF_STAGES.values())
@@ -575,12 +697,6 @@ def main():
         if c5:
             c5["ms_per_step"] = float(t[2].item()); c5["value"] = 4096 / (c5["ms_per_step"] * 1e-3)
     ctx.close()
-    if boundary is not None and dist_on:                           # every rank ran its own leg on its own GPU; rank 0 reports the sum (a failed leg counts 0)
-        tb = torch.tensor([boundary.get("value", 0.0), boundary.get("two_caller_threads", {}).get("value", 0.0)], dtype=torch.float64, device=dev)
-        dist.all_reduce(tb, op=dist.ReduceOp.SUM)
-        boundary["value_all_ranks"] = float(tb[0].item())
-        if "two_caller_threads" in boundary:
-            boundary["two_caller_threads"]["value_all_ranks"] = float(tb[1].item())
 
     if rank == 0:
         def avg_us(p, name):
@@ -601,6 +717,10 @@ def main():
             "value": args.gpus * args.steps * B / elapsed,
             "unit": "proofs/s",
             "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+            **({"shared_gpu": True, "gpus_physical": int(os.environ.get("MINA_BENCH_GPUS_PHYSICAL", "1")),
+                "shared_gpu_note": f"{args.gpus} ranks time-share ONE GPU (a box with fewer GPUs than --gpus, or the test hook): the N > 1 code path end to end, NOT a scaling figure"}
+               if share_gpu and dist_on else {}),
+            "launcher": os.environ.get("MINA_BENCH_LAUNCHER", "torch.distributed.run" if dist_on else "none"),
             "ms_per_step": elapsed / args.steps * 1e3,
             "call_latency_ms": call_latency_ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -627,7 +747,7 @@ def main():
                                             "domain 2^15, 47 commitments; synthetic step index)",
                                     "kimchi": "kimchi oracles + to_batch on the GPU from the raw wrap proofs (synthetic index, domain 2^15, 40 public inputs, 47 commitments)",
                                     "prepared": "pre-derived BatchEvaluationProof rows (45 commitments)"}[args.mode],
-                       "sharding": f"proof-level, {args.gpus} rank(s); verdict words all-gathered over RCCL" if dist_on else "single rank",
+                       "sharding": f"proof-level, {args.gpus} rank(s); verdict words all-gathered over {'gloo (ranks share one GPU)' if share_gpu else 'RCCL'}" if dist_on else "single rank",
                        "algorithmic_bytes_per_proof": algorithmic_bytes_per_proof()},
             "roofline": {"bound": "hbm", "kernel": "pstate_hash_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": (nstates * traffic_per_state) if traffic_per_state else None,
@@ -661,13 +781,14 @@ def main():
             out["cpu_baseline"] = cpu_baseline(baseline_sample)
         print(json.dumps(out), flush=True)
     if dist_on:
-        dist.barrier()
+        barrier()
         dist.destroy_process_group()
 
 
 if __name__ == "__main__":
-    if len(sys.argv) >= 4 and sys.argv[1] == "--boundary-only":     # the bytes -> bools leg in a process of its own (see main): only the library, no torch
+    if len(sys.argv) >= 4 and sys.argv[1] in ("--boundary-only", "--boundary-all-devices"):     # a bytes -> bools leg in a process of its own (see main): only the library, no torch
         import mina_bridge_amd as _m
-        print(json.dumps(boundary_leg(_m, int(sys.argv[2]), int(sys.argv[3]))), flush=True)
+        fn = boundary_leg if sys.argv[1] == "--boundary-only" else boundary_all_devices_leg
+        print(json.dumps(fn(_m, sys.argv[2], int(sys.argv[3]))), flush=True)
     else:
         main()

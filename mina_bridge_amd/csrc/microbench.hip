@@ -46,6 +46,19 @@ __global__ void __launch_bounds__(256) probe(uint32_t *out, uint32_t seed) {
             if (OP == 14) asm volatile("v_lshrrev_b64 %0, 29, %0" : "+v"(acc[i]));
             if (OP == 15) asm volatile("v_and_b32 %0, 0x1fffffff, %0" : "+v"(a[i]));
         }
+        // OP 16: the instruction mix of one lane-round of the 29-bit-limb Poseidon permutation (fp29.cuh): 765 multiply-accumulates and ~290 simple
+        // instructions (64-bit column shifts, limb masks), interleaved as the generated routines interleave them (a carry after every ~2.6 products).
+        // Does the mix issue at the multiply-accumulate rate alone (the simple instructions hide in its shadow) or does every instruction take its slot?
+        if (OP == 16) {
+#pragma unroll
+            for (int j = 0; j < 153; ++j) {
+                asm volatile("v_mad_u64_u32 %0, s[20:21], %1, %2, %0" : "+v"(acc[j % UNROLL]) : "v"(a[j % UNROLL]), "v"(b[(j + 5) % UNROLL]) : "s20", "s21");
+                if ((j * 58) / 153 != ((j + 1) * 58) / 153) {
+                    if (j & 1) asm volatile("v_lshrrev_b64 %0, 29, %1" : "=v"(acc[(j + 7) % UNROLL]) : "v"(acc[(j + 8) % UNROLL]));
+                    else asm volatile("v_and_b32 %0, 0x1fffffff, %1" : "=v"(a[(j + 3) % UNROLL]) : "v"(b[(j + 9) % UNROLL]));
+                }
+            }
+        }
     }
     uint32_t r = 0;
     for (int i = 0; i < UNROLL; ++i) r ^= a[i] ^ b[i] ^ (uint32_t)acc[i] ^ (uint32_t)(acc[i] >> 32) ^ (uint32_t)d[i];
@@ -94,7 +107,7 @@ int main() {
     const char *names[] = {"v_mad_u64_u32", "v_mul_lo_u32", "v_mul_hi_u32", "v_mad_u32_u24", "v_fma_f64", "add_co+addc_co(2 instr)",
                            "v_add_u32", "v_mul_u32_u24", "v_mul_hi_u32_u24", "v_lshlrev_b64", "mad_u64_u32+addc(2 instr)",
                            "v_mad_u64_u32 (carry to a scratch sgpr pair)", "v_mad_u64_u32 (4 scratch pairs in rotation)", "v_mad_u64_u32 (one accumulator: dependent chain)",
-                           "v_lshrrev_b64", "v_and_b32 (literal)"};
+                           "v_lshrrev_b64", "v_and_b32 (literal)", "fp29 round mix: 153 v_mad_u64_u32 + 29 v_lshrrev_b64 + 29 v_and_b32 per trip"};
 #define RUN(OP)                                                                                              \
     {                                                                                                        \
         double t = time_kernel([&] { probe<OP><<<blocks, 256>>>(out, 12345u); }, 5);                         \
@@ -104,6 +117,11 @@ int main() {
     }
     if (waves_per_simd == 2) { RUN(1) RUN(2) RUN(3) RUN(4) RUN(5) RUN(7) RUN(8) RUN(9) }
     RUN(0) RUN(6) RUN(10) RUN(11) RUN(12) RUN(13) RUN(14) RUN(15)
+    {   // the mix: cycles per multiply-accumulate OF THE MIX (153 per trip) and per instruction (211 per trip)
+        double t = time_kernel([&] { probe<16><<<blocks, 256>>>(out, 12345u); }, 5);
+        const double macs = (double)ITERS * 153 * waves_per_simd, instr = (double)ITERS * 211 * waves_per_simd;
+        printf("{\"probe\": \"%s\", \"cycles_per_mac_of_the_mix\": %.2f, \"cycles_per_instr_of_the_mix\": %.2f, \"time_us\": %.1f}\n", names[16], t * clk / macs, t * clk / instr, t * 1e6);
+    }
     }
     const char *fnames[] = {"fe_mul (dependent)", "fe_sqr (dependent)", "fe_add", "fe_sub", "xyzz_add_affine", "2x fe_mul (independent)"};
     for (int wps = 1; wps <= 3; ++wps) {

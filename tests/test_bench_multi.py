@@ -1,0 +1,64 @@
+"""bench.py's N > 1 path (BASELINE config C5): `python bench.py --gpus N` without a launcher starts its own ranks, on a box with
+fewer GPUs the ranks share GPU 0 over gloo; rank 0 also runs the product's own multi-device leg (ONE process, one context per device).  The
+collectives of the real-GPU path run on a 1-rank RCCL group."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+SMALL = ["--steps", "2", "--warmup", "1", "--jobs", "64", "--pipeline", "2", "--no-probes", "--no-cpu-baseline"]
+
+
+def clean_env(**extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "MINA_BENCH_SHARE_GPU",
+                                                               "MINA_BENCH_FORCE_DIST", "MINA_VERIFY_DEVICES", "MINA_VERIFY_DEVICE")}
+    env.update(extra)
+    return env
+
+
+def test_gpus_2_without_a_gpu_fails_loudly():
+    """no GPU, no CPU path: the launcher refuses instead of measuring something else"""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            pytest.skip("GPU present")
+    except ImportError:
+        pass
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2"] + SMALL, capture_output=True, text=True, timeout=600, env=clean_env())
+    assert r.returncode != 0 and "needs a GPU" in (r.stderr + r.stdout)
+
+
+@pytest.mark.gpu
+def test_gpus_2_starts_two_ranks_and_reports_them():
+    """`python bench.py --gpus 2` as the driver runs it (no torch.distributed launcher): two ranks, barriers, MAX over ranks, verdict all-gather, the
+    aggregate value, and the multi-device boundary leg with a tampered proof in every shard"""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--boundary-jobs", "64"] + SMALL, capture_output=True, text=True, timeout=1500, env=clean_env())
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    line = json.loads(r.stdout.strip().split("\n")[-1])
+    assert line["n_gpus"] == 2 and line["launcher"] == "bench.py launch_ranks"
+    assert line["value"] > 0 and abs(line["value"] - 2 * 2 * 64 / (line["ms_per_step"] * 2 * 1e-3)) < 1e-6 * line["value"], "value = proofs of BOTH ranks / max-over-ranks time"
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert line["shared_gpu"] is True and line["gpus_physical"] == torch.cuda.device_count()
+        assert "gloo" in line["config"]["sharding"]
+    else:
+        assert "shared_gpu" not in line and "RCCL" in line["config"]["sharding"]
+    b = line["boundary_bytes_to_bools"]
+    assert "error" not in b and b["value"] > 0, b
+    ad = b["all_devices"]
+    assert "error" not in ad, ad
+    assert ad["n_devices"] == 2 and ad["proofs_per_call"] == 128 and ad["value_all_devices"] > 0 and b["value_all_devices"] == ad["value_all_devices"]
+    assert ad["c5_4096_per_call"]["proofs_per_call"] == 4096 and ad["c5_4096_per_call"]["value"] > 0
+
+
+@pytest.mark.gpu
+def test_collectives_of_the_multi_gpu_path_on_a_one_rank_rccl_group():
+    """the non-shared path (gloo control plane + RCCL barriers / all-gather / MAX all-reduce) on the real backend with one rank"""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--no-boundary"] + SMALL, capture_output=True, text=True, timeout=1200, env=clean_env(MINA_BENCH_FORCE_DIST="1"))
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    line = json.loads(r.stdout.strip().split("\n")[-1])
+    assert line["n_gpus"] == 1 and "RCCL" in line["config"]["sharding"] and line["value"] > 0
