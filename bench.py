@@ -779,10 +779,13 @@ def main():
                                     "note": "9 x 29-bit limbs, no carry instructions: 765 of a round's ~1055 VALU instructions are multiply-accumulates"}
         if not args.no_cpu_baseline and args.gpus == 1:       # the CPU leg is timed at N = 1 only (rank 0)
             out["cpu_baseline"] = cpu_baseline(baseline_sample)
-        print(json.dumps(out), flush=True)
+        line = json.dumps(out)
     if dist_on:
         barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        print(line, flush=True)                                # the ONE JSON line, after everything a backend may write to stdout (RCCL prints its library path)
 
 
 if __name__ == "__main__":

@@ -13,6 +13,12 @@ BENCH = os.path.join(ROOT, "bench.py")
 SMALL = ["--steps", "2", "--warmup", "1", "--jobs", "64", "--pipeline", "2", "--no-probes", "--no-cpu-baseline"]
 
 
+def json_line(stdout: str) -> dict:
+    lines = [ln for ln in stdout.strip().split("\n") if ln.startswith('{"metric"')]
+    assert len(lines) == 1, f"exactly ONE JSON line: {stdout[-500:]}"
+    return json.loads(lines[0])
+
+
 def clean_env(**extra):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "MINA_BENCH_SHARE_GPU",
                                                                "MINA_BENCH_FORCE_DIST", "MINA_VERIFY_DEVICES", "MINA_VERIFY_DEVICE")}
@@ -38,7 +44,7 @@ def test_gpus_2_starts_two_ranks_and_reports_them():
     aggregate value, and the multi-device boundary leg with a tampered proof in every shard"""
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--boundary-jobs", "64"] + SMALL, capture_output=True, text=True, timeout=1500, env=clean_env())
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
-    line = json.loads(r.stdout.strip().split("\n")[-1])
+    line = json_line(r.stdout)
     assert line["n_gpus"] == 2 and line["launcher"] == "bench.py launch_ranks"
     assert line["value"] > 0 and abs(line["value"] - 2 * 2 * 64 / (line["ms_per_step"] * 2 * 1e-3)) < 1e-6 * line["value"], "value = proofs of BOTH ranks / max-over-ranks time"
     import torch
@@ -60,5 +66,5 @@ def test_collectives_of_the_multi_gpu_path_on_a_one_rank_rccl_group():
     """the non-shared path (gloo control plane + RCCL barriers / all-gather / MAX all-reduce) on the real backend with one rank"""
     r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--no-boundary"] + SMALL, capture_output=True, text=True, timeout=1200, env=clean_env(MINA_BENCH_FORCE_DIST="1"))
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
-    line = json.loads(r.stdout.strip().split("\n")[-1])
+    line = json_line(r.stdout)
     assert line["n_gpus"] == 1 and "RCCL" in line["config"]["sharding"] and line["value"] > 0
