@@ -12,61 +12,28 @@
 //       ([UPSTREAM-RECALL] for the SerdeAs framing), then the binprot-derived account (not parsed here).
 // Field elements must be canonical (< p), as ark's `CanonicalDeserialize` enforces.
 #include "ctx.h"
+#include "wire_pub.h"
 #include <type_traits>
 
-static bool fp_is_canonical(const uint8_t *b) {
-    // p (Fp) little-endian bytes
-    static const uint8_t P_LE[32] = {0x01, 0x00, 0x00, 0x00, 0xed, 0x30, 0x2d, 0x99, 0x1b, 0xf9, 0x4c, 0x09, 0xfc, 0x98, 0x46, 0x22,
-                                     0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x00, 0x40};
-    for (int i = 31; i >= 0; --i) { if (b[i] != P_LE[i]) return b[i] < P_LE[i]; }
-    return false;
-}
-static uint64_t rd_u64(const uint8_t *p) { uint64_t v = 0; for (int i = 7; i >= 0; --i) v = (v << 8) | p[i]; return v; }
-static uint32_t rd_u32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+static bool fp_is_canonical(const uint8_t *b) { return mw::fp_canonical(b); }
 
 extern "C" int mina_parse_state_pub_inputs(const uint8_t *bytes, size_t len, mina_state_pub_inputs *out) {
     if (!bytes || !out) return fail(MINA_ERR_ARG, "null argument");
-    if (len != 1057) return fail(MINA_ERR_FORMAT, "MinaStatePubInputs must be exactly 1057 bytes");
-    if (bytes[0] > 1) return fail(MINA_ERR_FORMAT, "bool byte must be 0 or 1");
-    for (int i = 0; i < 33; ++i)
-        if (!fp_is_canonical(bytes + 1 + 32 * i)) return fail(MINA_ERR_FORMAT, "hash is not a canonical field element");
-    out->is_state_proof_from_devnet = bytes[0];
-    memcpy(out->bridge_tip_state_hash, bytes + 1, 32);
-    memcpy(out->candidate_chain_state_hashes, bytes + 33, 512);
-    memcpy(out->candidate_chain_ledger_hashes, bytes + 545, 512);
-    return MINA_OK;
+    const char *why = ""; const int rc = mw::parse_state_pub_inputs(bytes, len, out, &why);
+    return rc ? fail(rc, why) : MINA_OK;
 }
 
 extern "C" int mina_parse_account_pub_inputs(const uint8_t *bytes, size_t len, uint8_t *ledger_hash, size_t *encoded_offset, size_t *encoded_len) {
     if (!bytes || !ledger_hash || !encoded_offset || !encoded_len) return fail(MINA_ERR_ARG, "null argument");
-    if (len < 40) return fail(MINA_ERR_FORMAT, "MinaAccountPubInputs shorter than 40 bytes");
-    if (!fp_is_canonical(bytes)) return fail(MINA_ERR_FORMAT, "ledger hash is not a canonical field element");
-    const uint64_t n = rd_u64(bytes + 32);
-    if (n != len - 40) return fail(MINA_ERR_FORMAT, "encoded_account length prefix does not match the buffer");
-    memcpy(ledger_hash, bytes, 32);
-    *encoded_offset = 40; *encoded_len = (size_t)n;
-    return MINA_OK;
+    const char *why = ""; const int rc = mw::parse_account_pub_inputs(bytes, len, ledger_hash, encoded_offset, encoded_len, &why);
+    return rc ? fail(rc, why) : MINA_OK;
 }
 
 extern "C" int mina_parse_merkle_path(const uint8_t *proof, size_t len, uint32_t max_depth, uint8_t *siblings, uint8_t *dirs,
                                       uint32_t *depth, size_t *account_offset) {
     if (!proof || !siblings || !dirs || !depth || !account_offset) return fail(MINA_ERR_ARG, "null argument");
-    if (len < 8) return fail(MINA_ERR_FORMAT, "MinaAccountProof shorter than its length prefix");
-    const uint64_t n = rd_u64(proof);
-    if (n > max_depth) return fail(MINA_ERR_FORMAT, "merkle path longer than max_depth");
-    size_t off = 8;
-    for (uint64_t i = 0; i < n; ++i) {
-        if (len - off < 4 + 8 + 32) return fail(MINA_ERR_FORMAT, "truncated merkle node");
-        const uint32_t tag = rd_u32(proof + off);
-        if (tag > 1) return fail(MINA_ERR_FORMAT, "MerkleNode variant must be 0 (Left) or 1 (Right)");
-        if (rd_u64(proof + off + 4) != 32) return fail(MINA_ERR_FORMAT, "MerkleNode field element must be 32 bytes");
-        if (!fp_is_canonical(proof + off + 12)) return fail(MINA_ERR_FORMAT, "merkle node is not a canonical field element");
-        dirs[i] = (uint8_t)tag;
-        memcpy(siblings + 32 * i, proof + off + 12, 32);
-        off += 44;
-    }
-    *depth = (uint32_t)n; *account_offset = off;
-    return MINA_OK;
+    const char *why = ""; const int rc = mw::parse_merkle_path(proof, len, max_depth, siblings, dirs, depth, account_offset, &why);
+    return rc ? fail(rc, why) : MINA_OK;
 }
 
 extern "C" int mina_verify_account_inclusion(mina_ctx *c, size_t n, const uint8_t *const *proofs, const size_t *proof_lens,
