@@ -231,7 +231,23 @@ def cpu_baseline(baseline_sample, budget_s: float = 12.0):
         if el >= budget_s:
             break
     total = rounds * len(proofs)
-    return {"value": total / el, "unit": "proofs/s", "cores": threads, "kind": "port", "implementation": "native C restatement (oracle/composite_oracle.c), pthreads across proofs",
+    # the like-for-like figure: the SAME fold the GPU job does (kimchi batch_verify's shape) -- per-proof transcripts on all threads, then ONE MSM per curve
+    # over the batch (composite_oracle.c oc_verify_folded); batch = 16 proofs per thread, randomisers from the OS CSPRNG per batch
+    fbatch = [proofs[i % len(proofs)] for i in range(16 * threads)]
+    okf, _ = C.verify_folded(fbatch[:threads], threads)                # warm
+    frounds, t1 = 0, time.perf_counter()
+    while True:
+        ok_b, vf = C.verify_folded(fbatch, threads); okf = okf and ok_b and bool(vf.all()); frounds += 1
+        elf = time.perf_counter() - t1
+        if elf >= budget_s * 0.6:
+            break
+    folded = {"value": frounds * len(fbatch) / elf, "unit": "proofs/s", "cores": threads, "kind": "port", "proofs_per_batch": len(fbatch), "batches": frounds, "seconds": elf,
+              "sample": f"{frounds} batches of {len(fbatch)} full Proof-of-State verifications, folded as the GPU job folds them: per-proof transcripts (17 state hashes, statement, "
+                        f"kimchi oracles, opening transcript, b_poly coefficients) on {threads} threads, then ONE 2^15 + {len(fbatch)} x 81-point Pallas MSM and ONE 2^16 Vesta MSM per batch "
+                        f"(ark-style Pippenger, a thread per window); verdict ACCEPT: {okf}",
+              "note": "the reference's FFI verifies one proof per call (cpu_baseline: two full MSMs per proof); this is the same algorithm with the batch fold of kimchi batch_verify, "
+                      "the shape the GPU headline is measured on"}
+    return {"value": total / el, "unit": "proofs/s", "cores": threads, "kind": "port", "implementation": "native C restatement (oracle/composite_oracle.c), pthreads across proofs", "folded": folded,
             "cpu_model": cpu_model(), "nproc": nproc, "usable_cores": usable_cores(), "single_thread_value": 1.0 / one_s, "setup_s": setup_s,
             "sample": f"{total} full Proof-of-State verifications (BASELINE config C1 = the bench's own job per proof: 17 state hashes + Pickles statement -> public inputs + "
                       f"public-input commitment + kimchi oracles/to_batch + k=15 wrap opening check + 2^16 Vesta accumulator) in {el:.1f} s on {threads} threads, one proof per "
@@ -788,6 +804,8 @@ def main():
                                             "the fullest SIMD holds ceil(waves / 1024)) x frac_on_the_fullest_simd (ds_bpermute exchanges, round-constant loads, waits)"}
         if not args.no_cpu_baseline and args.gpus == 1:       # the CPU leg is timed at N = 1 only (rank 0)
             out["cpu_baseline"] = cpu_baseline(baseline_sample)
+            if isinstance(out["cpu_baseline"], dict) and "folded" in out["cpu_baseline"]:
+                out["cpu_baseline_folded"] = out["cpu_baseline"].pop("folded")     # beside it: the same CPU code with the GPU job's batch fold
         line = json.dumps(out)
     if dist_on:
         barrier()

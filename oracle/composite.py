@@ -94,3 +94,16 @@ def verify_many(proofs, threads: int) -> np.ndarray:
     out = np.zeros(len(proofs), np.uint8)
     lib().oc_verify_many(arr, ctypes.c_size_t(len(proofs)), int(threads), out.ctypes.data_as(ctypes.c_void_p))
     return out
+
+
+def verify_folded(proofs, threads: int, rand: bytes = None):
+    """the batch folded as the GPU job folds it (composite_oracle.c oc_verify_folded): per-proof transcripts on `threads` pthreads, then ONE MSM per
+    curve over the whole batch under randomisers derived from `rand` (3 x 32 bytes; default: the OS CSPRNG).  Returns (batch_ok, verdicts[n])."""
+    import os
+    rand = os.urandom(96) if rand is None else rand
+    assert len(rand) == 96
+    arr = (OcProof * len(proofs))(*[p for p, _ in proofs])
+    out = np.zeros(len(proofs), np.uint8)
+    lib().oc_verify_folded.restype = ctypes.c_int
+    ok = lib().oc_verify_folded(arr, ctypes.c_size_t(len(proofs)), int(threads), ctypes.c_char_p(rand), out.ctypes.data_as(ctypes.c_void_p))
+    return bool(ok), out

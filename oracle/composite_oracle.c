@@ -338,7 +338,9 @@ static int pickles_public_input(const oc_proof *p, oc_result *r, fe pubs[40]) {
 }
 
 /* ---- 3. kimchi oracles + to_batch, then the combined opening check of that one proof (oracle/kimchi_ref.py, oracle/ipa_ref.py) */
-static int kimchi_and_opening(const oc_proof *p, oc_result *r, const fe pubs[40]) {
+/* what the transcript of one opening leaves for the MSM: the (point, scalar) list is a function of it and of the folding randomisers (rho, sigma) */
+typedef struct { int k, ncomms; fe chal[16], chal_inv[16], c, b0, cip, v, zz1, zz2; uint8_t U[64], comms[47 * 64]; const oc_proof *p; } opening_prep;
+static int kimchi_and_opening_prepare(const oc_proof *p, oc_result *r, const fe pubs[40], opening_prep *o) {
     const fctx *fp = &F[0], *fq = &F[1];
     const int k = G.log2_domain; const uint64_t n = (uint64_t)1 << k;
     fe endo_r; endo_of(&endo_r, fq, 1);                                   /* Pallas endo_r (in Fq) */
@@ -442,23 +444,49 @@ static int kimchi_and_opening(const oc_proof *p, oc_result *r, const fe pubs[40]
     fe b0, bz, bzw; b_poly_eval(&bz, chal, k, &zeta, fq); b_poly_eval(&bzw, chal, k, &zetaw, fq); f_mul(&b0, &u, &bzw, fq); f_add(&b0, &b0, &bz, fq);
     if (!mw_canonical(p->z1, fq) || !mw_canonical(p->z2, fq)) return 0;
     fe zz1, zz2; f_load(&zz1, p->z1, fq); f_load(&zz2, p->z2, fq);
+    o->k = k; o->ncomms = ncomms; o->c = c; o->b0 = b0; o->cip = cip; o->v = v; o->zz1 = zz1; o->zz2 = zz2; o->p = p;
+    memcpy(o->chal, chal, sizeof(fe) * (size_t)k); memcpy(o->chal_inv, chal_inv, sizeof(fe) * (size_t)k); memcpy(o->U, Ub, 64); memcpy(o->comms, comms, (size_t)ncomms * 64);
+    return 1;
+}
+/* the 2k + ncomms + 4 per-proof entries of SRS::verify's MSM under the randomisers (rho, sigma); returns their count.
+ * Not in the list: h (scalar -rho z2) and the SRS part g[j] (scalar sigma s[j]): the caller folds those over the batch. */
+static size_t opening_small_list(const opening_prep *o, const fe *rho, const fe *sigma, uint8_t *pts, uint8_t *scs) {
+    const fctx *fq = &F[1]; const oc_proof *p = o->p; const int k = o->k;
+    size_t q = 0; fe s, rc, xi_i;
+#define PUT(ptr, sc) do { memcpy(pts + 64 * q, (ptr), 64); f_store(scs + 32 * q, (sc), fq); ++q; } while (0)
+    f_mul(&s, rho, &o->zz1, fq); f_neg(&s, &s, fq); f_sub(&s, &s, sigma, fq); PUT(p->sg, &s);                 /* sg: -rho z1 - sigma */
+    f_mul(&s, rho, &o->zz1, fq); f_neg(&s, &s, fq); f_mul(&s, &s, &o->b0, fq); PUT(o->U, &s);                  /* U: -rho z1 b0 */
+    f_mul(&rc, rho, &o->c, fq);
+    for (int j = 0; j < k; ++j) { f_mul(&s, &rc, &o->chal_inv[j], fq); PUT(p->lr + (size_t)j * 128, &s); f_mul(&s, &rc, &o->chal[j], fq); PUT(p->lr + (size_t)j * 128 + 64, &s); }
+    xi_i = fq->one;
+    for (int i = 0; i < o->ncomms; ++i) { f_mul(&s, &rc, &xi_i, fq); PUT(o->comms + 64 * i, &s); f_mul(&xi_i, &xi_i, &o->v, fq); }
+    f_mul(&s, &rc, &o->cip, fq); PUT(o->U, &s);
+    PUT(p->delta, rho);
+#undef PUT
+    return q;
+}
+static int points_on_curve_or_zero(int curve, const uint8_t *pts, size_t q) {
+    for (size_t i = 0; i < q; ++i) if (!oracle_is_on_curve(curve, pts + 64 * i)) { int z = 1; for (int b = 0; b < 64; ++b) if (pts[64 * i + b]) z = 0; if (!z) return 0; }
+    return 1;
+}
+static void bpoly_coeffs_mont(fe *s, const fe *c, int k, const fctx *f) {      /* oracle_b_poly_coefficients, Montgomery in and out */
+    const size_t n = (size_t)1 << k; s[0] = f->one; int kk = 0; size_t pw = 1;
+    for (size_t i = 1; i < n; ++i) { if (i == (pw << 1)) { ++kk; pw <<= 1; } f_mul(&s[i], &s[i - pw], &c[k - 1 - kk], f); }
+}
+static int kimchi_and_opening(const oc_proof *p, oc_result *r, const fe pubs[40]) {
+    const fctx *fq = &F[1];
+    opening_prep o;
+    if (!kimchi_and_opening_prepare(p, r, pubs, &o)) return 0;
+    const int k = o.k; const uint64_t n = (uint64_t)1 << k; const int ncomms = o.ncomms;
+    const fe *chal = o.chal; const fe zz2 = o.zz2;
     const size_t np = 1 + n + (size_t)(2 * k + ncomms + 4);
     uint8_t *pts = (uint8_t *)malloc(np * 64), *scs = (uint8_t *)malloc(np * 32);
     memcpy(pts, G.h_pallas, 64); { fe s; f_neg(&s, &zz2, fq); f_store(scs, &s, fq); }
     memcpy(pts + 64, G.g_pallas, n * 64);
     { uint8_t chb[32 * 32]; for (int j = 0; j < k; ++j) f_store(chb + 32 * j, &chal[j], fq); oracle_b_poly_coefficients(1, k, chb, scs + 32); }      /* sigma = 1 */
     size_t q = 1 + n;
-#define PUT(ptr, sc) do { memcpy(pts + 64 * q, (ptr), 64); f_store(scs + 32 * q, (sc), fq); ++q; } while (0)
-    fe s; f_neg(&s, &zz1, fq); f_sub(&s, &s, &fq->one, fq); PUT(p->sg, &s);                             /* sg: -z1 - 1 */
-    f_neg(&s, &zz1, fq); f_mul(&s, &s, &b0, fq); PUT(Ub, &s);                                           /* U: -z1 b0 */
-    for (int j = 0; j < k; ++j) { f_mul(&s, &c, &chal_inv[j], fq); PUT(p->lr + (size_t)j * 128, &s); f_mul(&s, &c, &chal[j], fq); PUT(p->lr + (size_t)j * 128 + 64, &s); }
-    xi_i = fq->one;
-    for (int i = 0; i < ncomms; ++i) { f_mul(&s, &c, &xi_i, fq); PUT(comms + 64 * i, &s); f_mul(&xi_i, &xi_i, &v, fq); }
-    f_mul(&s, &c, &cip, fq); PUT(Ub, &s);
-    PUT(p->delta, &fq->one);
-#undef PUT
-    uint8_t out[64]; int bad = 0;
-    for (size_t i = 0; i < q && !bad; ++i) if (!oracle_is_on_curve(0, pts + 64 * i)) { int z = 1; for (int b = 0; b < 64; ++b) if (pts[64 * i + b]) z = 0; if (!z) bad = 1; }
+    q += opening_small_list(&o, &fq->one, &fq->one, pts + 64 * q, scs + 32 * q);                         /* rho = sigma = 1 */
+    uint8_t out[64]; const int bad = !points_on_curve_or_zero(0, pts, q);
     oracle_msm_pippenger(0, q, pts, scs, out, 1);
     free(pts); free(scs);
     if (bad) return 0;
@@ -502,6 +530,96 @@ int oc_verify_many(const oc_proof *proofs, size_t n, int threads, uint8_t *verdi
     for (int t = 0; t < threads; ++t) pthread_join(th[t], NULL);
     free(th); free(jobs);
     return 0;
+}
+/* ---------------------------------------------------------------------------------------------- the batch FOLDED as the GPU job folds it
+ * kimchi `batch_verify` / poly-commitment `SRS::verify` on n proofs at once: the per-proof transcripts run on `threads`
+ * pthreads (a proof per thread at a time), then ONE MSM per curve for the whole batch --
+ *   Pallas:  sum_b [ sigma_b s_b(G) - rho_b z2_b H + (per-proof entries under rho_b, sigma_b) ]  == 0,   rho_b = r^b, sigma_b = t^b
+ *   Vesta:   sum_b rho'_b [ s'_b(G) - sg_b ]                                                      == 0    (the step accumulators, openmina accumulator_check)
+ * with r, t, rho' drawn by the caller (`rand32`: 3 x 32 bytes, e.g. from the OS CSPRNG).  The folded check answers for the whole batch; per-proof
+ * verdicts = the per-proof legs (chain, statement, well-formedness) AND the fold -- a batch with a bad opening comes back all-zero here (the product's
+ * culprit search has no counterpart in this baseline: it is timed on accepting batches).  cpu_baseline_folded of bench.py: the like-for-like algorithm. */
+typedef struct { const oc_proof *p; size_t n; int t, nt; uint8_t *ok; opening_prep *prep; fe *Sg, *Tg; fe *h_acc; const fe *rho, *sigma, *rho_acc; uint8_t *pts, *scs; size_t per; } fold_job;
+static void *fold_worker(void *a) {
+    fold_job *j = (fold_job *)a; const fctx *fp = &F[0], *fq = &F[1];
+    const int k = G.log2_domain; const size_t n = (size_t)1 << k, nacc = (size_t)1 << 16;
+    fe *s = (fe *)malloc(sizeof(fe) * nacc);
+    fe endo_p; endo_of(&endo_p, fp, 1);
+    memset(j->Sg, 0, sizeof(fe) * n); memset(j->Tg, 0, sizeof(fe) * nacc); memset(j->h_acc, 0, sizeof(fe));
+    for (size_t b = (size_t)j->t; b < j->n; b += (size_t)j->nt) {
+        oc_result r; fe pubs[40]; memset(&r, 0, sizeof r);
+        const oc_proof *p = &j->p[b];
+        int ok = state_hashes(p, &r);
+        ok = pickles_public_input(p, &r, pubs) && ok;
+        opening_prep *o = &j->prep[b];
+        const int have = kimchi_and_opening_prepare(p, &r, pubs, o);
+        uint8_t *pts = j->pts + b * j->per * 64, *scs = j->scs + b * j->per * 32;
+        memset(pts, 0, j->per * 64); memset(scs, 0, j->per * 32);
+        if (have) {
+            const size_t q = opening_small_list(o, &j->rho[b], &j->sigma[b], pts, scs);
+            if (!points_on_curve_or_zero(0, pts, q)) { ok = 0; memset(scs, 0, j->per * 32); }
+            else {
+                bpoly_coeffs_mont(s, o->chal, k, fq);
+                for (size_t i = 0; i < n; ++i) { fe t; f_mul(&t, &s[i], &j->sigma[b], fq); f_add(&j->Sg[i], &j->Sg[i], &t, fq); }
+                fe t; f_mul(&t, &j->rho[b], &o->zz2, fq); f_sub(j->h_acc, j->h_acc, &t, fq);
+            }
+        } else ok = 0;
+        /* the step accumulator: rho'_b (s'_b(G) - sg_b); its point goes behind the opening's entries */
+        { fe c[16]; for (int i = 0; i < 16; ++i) chal_to_field(&c[i], p->acc_pre + 16 * i, &endo_p, fp);
+          bpoly_coeffs_mont(s, c, 16, fp);
+          for (size_t i = 0; i < nacc; ++i) { fe t; f_mul(&t, &s[i], &j->rho_acc[b], fp); f_add(&j->Tg[i], &j->Tg[i], &t, fp); }
+          if (!oracle_is_on_curve(1, p->acc_sg)) ok = 0; }
+        j->ok[b] = (uint8_t)ok;
+    }
+    free(s);
+    return NULL;
+}
+int oc_verify_folded(const oc_proof *proofs, size_t nproofs, int threads, const uint8_t *rand32 /* 3 x 32 */, uint8_t *verdicts) {
+    const fctx *fp = &F[0], *fq = &F[1];
+    if (nproofs == 0) return 0;
+    if (threads < 1) threads = 1;
+    if ((size_t)threads > nproofs) threads = (int)nproofs;
+    const int k = G.log2_domain; const size_t n = (size_t)1 << k, nacc = (size_t)1 << 16, per = (size_t)(2 * k + 47 + 4);
+    { oc_result r; state_hashes(&proofs[0], &r); }                   /* warm the function-static salts before the threads start */
+    /* rho_b = r^b, sigma_b = t^b (upstream's shape), rho'_b = u^b */
+    fe base[3], *rho = (fe *)malloc(sizeof(fe) * nproofs), *sigma = (fe *)malloc(sizeof(fe) * nproofs), *rho_acc = (fe *)malloc(sizeof(fe) * nproofs);
+    f_from_le256_reduce(&base[0], rand32, fq); f_from_le256_reduce(&base[1], rand32 + 32, fq); f_from_le256_reduce(&base[2], rand32 + 64, fp);
+    rho[0] = fq->one; sigma[0] = fq->one; rho_acc[0] = fp->one;
+    for (size_t b = 1; b < nproofs; ++b) { f_mul(&rho[b], &rho[b - 1], &base[0], fq); f_mul(&sigma[b], &sigma[b - 1], &base[1], fq); f_mul(&rho_acc[b], &rho_acc[b - 1], &base[2], fp); }
+    opening_prep *prep = (opening_prep *)malloc(sizeof(opening_prep) * nproofs);
+    uint8_t *ok = (uint8_t *)calloc(nproofs, 1), *pts = (uint8_t *)malloc(nproofs * per * 64), *scs = (uint8_t *)malloc(nproofs * per * 32);
+    fe *Sg = (fe *)malloc(sizeof(fe) * n * (size_t)threads), *Tg = (fe *)malloc(sizeof(fe) * nacc * (size_t)threads), *h_acc = (fe *)malloc(sizeof(fe) * (size_t)threads);
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)threads); fold_job *jobs = (fold_job *)malloc(sizeof(fold_job) * (size_t)threads);
+    for (int t = 0; t < threads; ++t) {
+        jobs[t] = (fold_job){proofs, nproofs, t, threads, ok, prep, Sg + n * (size_t)t, Tg + nacc * (size_t)t, h_acc + t, rho, sigma, rho_acc, pts, scs, per};
+        pthread_create(&th[t], NULL, fold_worker, &jobs[t]);
+    }
+    for (int t = 0; t < threads; ++t) pthread_join(th[t], NULL);
+    for (int t = 1; t < threads; ++t) {
+        for (size_t i = 0; i < n; ++i) f_add(&Sg[i], &Sg[i], &Sg[n * (size_t)t + i], fq);
+        for (size_t i = 0; i < nacc; ++i) f_add(&Tg[i], &Tg[i], &Tg[nacc * (size_t)t + i], fp);
+        f_add(&h_acc[0], &h_acc[0], &h_acc[t], fq);
+    }
+    /* Pallas: g[0..n) with the folded scalars, h, then every proof's entries (zero scalars where a proof was malformed) */
+    const size_t qp = n + 1 + nproofs * per;
+    uint8_t *P = (uint8_t *)malloc(qp * 64), *S = (uint8_t *)malloc(qp * 32), out[64];
+    memcpy(P, G.g_pallas, n * 64); for (size_t i = 0; i < n; ++i) f_store(S + 32 * i, &Sg[i], fq);
+    memcpy(P + n * 64, G.h_pallas, 64); f_store(S + 32 * n, &h_acc[0], fq);
+    memcpy(P + (n + 1) * 64, pts, nproofs * per * 64); memcpy(S + (n + 1) * 32, scs, nproofs * per * 32);
+    oracle_msm_pippenger(0, qp, P, S, out, threads);
+    int ipa_ok = 1; for (int i = 0; i < 64; ++i) if (out[i]) ipa_ok = 0;
+    free(P); free(S);
+    /* Vesta: g[0..2^16) with the folded scalars, then -rho'_b sg_b */
+    const size_t qv = nacc + nproofs;
+    P = (uint8_t *)malloc(qv * 64); S = (uint8_t *)malloc(qv * 32);
+    memcpy(P, G.g_vesta, nacc * 64); for (size_t i = 0; i < nacc; ++i) f_store(S + 32 * i, &Tg[i], fp);
+    for (size_t b = 0; b < nproofs; ++b) { fe t; f_neg(&t, &rho_acc[b], fp); memcpy(P + (nacc + b) * 64, proofs[b].acc_sg, 64); f_store(S + 32 * (nacc + b), &t, fp); }
+    oracle_msm_pippenger(1, qv, P, S, out, threads);
+    int acc_ok = 1; for (int i = 0; i < 64; ++i) if (out[i]) acc_ok = 0;
+    free(P); free(S);
+    for (size_t b = 0; b < nproofs; ++b) verdicts[b] = (uint8_t)(ok[b] && ipa_ok && acc_ok);
+    free(rho); free(sigma); free(rho_acc); free(prep); free(ok); free(pts); free(scs); free(Sg); free(Tg); free(h_acc); free(th); free(jobs);
+    return ipa_ok && acc_ok;
 }
 size_t oc_sizeof_proof(void) { return sizeof(oc_proof); }
 size_t oc_sizeof_result(void) { return sizeof(oc_result); }

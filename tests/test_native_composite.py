@@ -82,3 +82,43 @@ def test_native_composite_rejects_a_tamper_of_every_leg(native):
     # threaded across proofs: verdict bytes per proof
     proofs = [C.make_proof(fx["proofs"][i % 4], *chains[i % 4][:3]) for i in range(6)] + [C.make_proof(cases["opening scalar"][0], recs, nf, exp)]
     assert C.verify_many(proofs, threads=4).tolist() == [1] * 6 + [0]
+
+
+def test_folded_batch_equals_the_per_proof_verdicts(native):
+    """oc_verify_folded (bench.py's cpu_baseline_folded: per-proof transcripts, then ONE MSM per curve over the batch, as kimchi batch_verify and the GPU
+    job fold it) against the per-proof composite: an accepting batch is accepted under several randomisers; a batch with ONE bad opening, ONE bad
+    accumulator or ONE bad public hash is rejected (the fold answers for the batch; the per-proof legs keep their own bits); equal-and-opposite
+    errors in two proofs -- z2 + t in one, z2 - t in the other -- cancel under rho = sigma = 1 and are caught under random ones."""
+    import time
+    C, fx, chains = native["C"], native["fx"], native["chains"]
+    good = [C.make_proof(fx["proofs"][i % 4], *chains[i % 4][:3]) for i in range(9)]
+    for rand in (None, bytes(range(96)), b"\x01" + bytes(31) + b"\x01" + bytes(31) + b"\x01" + bytes(31)):       # the last: every randomiser = 1
+        ok, v = C.verify_folded(good, 4, rand)
+        assert ok and v.tolist() == [1] * 9
+    assert C.verify_many(good, 4).tolist() == [1] * 9
+
+    def flip(hexstr, byte, bit=0):
+        b = bytearray(bytes.fromhex(hexstr)); b[byte] ^= 1 << bit; return bytes(b).hex()
+    recs, nf, exp, _ = chains[1]
+    it = copy.deepcopy(fx["proofs"][1]); it["opening"]["z1"] = flip(it["opening"]["z1"], 0)
+    ok, v = C.verify_folded(good[:5] + [C.make_proof(it, recs, nf, exp)] + good[5:], 3)
+    assert not ok and v.tolist() == [0] * 10
+    it = copy.deepcopy(fx["proofs"][1]); it["acc_prechallenges"] = flip(it["acc_prechallenges"], 17)
+    ok, v = C.verify_folded([C.make_proof(it, recs, nf, exp)] + good, 3)
+    assert not ok and not v.any()
+    e2 = exp.copy(); e2[4, 0] ^= 1
+    ok, v = C.verify_folded(good[:2] + [C.make_proof(fx["proofs"][1], recs, nf, e2)] + good[2:], 2)
+    assert ok and v.tolist() == [1, 1, 0] + [1] * 7, "a wrong public hash fails its own proof only: the folds do not depend on it"
+    # cancelling pair on z2 (the h term: -rho_b z2_b): proofs a, b with z2_a + t, z2_b - t
+    Q = 0x40000000000000000000000000000000224698fc0994a8dd8c46eb2100000001
+    a, b = copy.deepcopy(fx["proofs"][0]), copy.deepcopy(fx["proofs"][2])
+    za, zb = int.from_bytes(bytes.fromhex(a["opening"]["z2"]), "little"), int.from_bytes(bytes.fromhex(b["opening"]["z2"]), "little")
+    a["opening"]["z2"] = ((za + 12345) % Q).to_bytes(32, "little").hex(); b["opening"]["z2"] = ((zb - 12345) % Q).to_bytes(32, "little").hex()
+    pair = [C.make_proof(a, *chains[0][:3]), C.make_proof(b, *chains[2][:3])]
+    assert C.verify_many(pair, 2).tolist() == [0, 0], "each is invalid on its own"
+    ok1, _ = C.verify_folded(pair, 2, b"\x01" + bytes(31) + b"\x01" + bytes(31) + b"\x01" + bytes(31))
+    assert ok1, "with every randomiser = 1 the two errors cancel: why the randomisers must be unpredictable"
+    ok2, v2 = C.verify_folded(pair, 2)
+    assert not ok2 and not v2.any()
+    t0 = time.perf_counter(); C.verify_folded(good * 4, 4); dt = time.perf_counter() - t0
+    print(f"folded: {len(good) * 4 / dt:.1f} proofs/s on 4 threads")
