@@ -81,7 +81,7 @@ __device__ fe_t ft_eval0_dev(const FtEnv &e, const FieldK &fk, const fe_t &pub0,
 #pragma unroll 1
         for (uint32_t t = 0; t < e.n_tokens; ++t) {
             const KimchiToken tk = e.toks[t];
-            if (skip) { --skip; if (tk.op == MINA_TOK_STORE) st.put(KC_STACK + nc++, fe_zero()); continue; }
+            if (skip) { --skip; continue; }                              // a skipped token has no effect (polish.h: upstream's convention)
             switch (tk.op) {
                 case MINA_TOK_SKIP_IF: case MINA_TOK_SKIP_IF_NOT: {
                     const bool on = (e.features >> tk.a) & 1u;
@@ -107,7 +107,7 @@ __device__ fe_t ft_eval0_dev(const FtEnv &e, const FieldK &fk, const fe_t &pub0,
                     const fe_t wr = fe_pow_u64<F>(e.omega, row, fk.one);
                     st.put(sp++, fe_mul<F>(zm1, fe_inv<F>(fe_sub<F>(e.zeta, wr), fk))); break; }
                 case MINA_TOK_STORE: st.put(KC_STACK + nc++, st.get(sp - 1)); break;
-                case MINA_TOK_LOAD: st.put(sp++, st.get(KC_STACK + (int)tk.a)); break;
+                case MINA_TOK_LOAD: if ((int)tk.a >= nc) prog_ok = false; st.put(sp++, st.get(KC_STACK + ((int)tk.a < nc ? (int)tk.a : 0))); break;   // a slot no executed STORE filled: this proof fails
                 default: prog_ok = false;
             }
         }

@@ -44,8 +44,12 @@ static inline bool decode_tokens(const uint8_t *code, size_t len, int field, uin
     size_t p = 0; int depth = 0, cache = 0;
     auto need = [&](size_t k) { return len - p >= k; };
     // SkipIf / SkipIfNot regions: (index of the region's last token, depth the stack must have there).  kimchi pushes ZERO and skips the
-    // region when the condition holds, so a region must net exactly one value whichever way it goes; a STORE inside a skipped region still
-    // takes its cache slot (it stores the zero), so that LOAD indices do not depend on the flags.
+    // region when the condition holds, so a region must net exactly one value whichever way it goes.  ONE convention everywhere, upstream's
+    // (kimchi `PolishToken::evaluate`: `if skip_count > 0 { skip_count -= 1; continue; }`, `Store => cache.push(top)`, `Load(i) => cache[i]`):
+    // SKIPPED TOKENS HAVE NO EFFECT -- a skipped STORE takes no cache slot, so after a region with a STORE in it the index a later STORE lands on
+    // depends on the proof's flags.  The static resolution of api_loaders.hip (skipped tokens dropped for a fixed feature set) is the same function.
+    // Here `cache` counts the STOREs so far as if every region ran: the capacity bound, and a NECESSARY bound for LOAD indices; the interpreters
+    // check every LOAD against the slots really filled and fail the proof otherwise (upstream would panic on the out-of-range index).
     std::vector<std::pair<size_t, int>> regions;
     while (p < len) {
         KimchiToken t{code[p++], 0, 0, 0};
@@ -88,7 +92,7 @@ template <int F> static inline fe_t host_pow_u64(fe_t base, uint64_t e, const fe
 template <int F> static inline bool polish_eval_host(const std::vector<KimchiToken> &toks, const std::vector<fe_t> &lits, const PolishEnv<F> &env, const FieldK &k, fe_t &out) {
     fe_t stack[KC_STACK], cache[KC_CACHE]; int sp = 0, nc = 0; uint32_t skip = 0;
     for (const KimchiToken &tk : toks) {
-        if (skip) { --skip; if (tk.op == MINA_TOK_STORE) cache[nc++] = fe_zero(); continue; }
+        if (skip) { --skip; continue; }                                  // a skipped token has no effect (no cache slot for a skipped STORE)
         switch (tk.op) {
             case MINA_TOK_SKIP_IF: case MINA_TOK_SKIP_IF_NOT: {
                 const bool on = (env.features >> tk.a) & 1u;
@@ -117,7 +121,7 @@ template <int F> static inline bool polish_eval_host(const std::vector<KimchiTok
                 const uint64_t row = off >= 0 ? (uint64_t)off : ((uint64_t)1 << env.log2_domain) - env.zk_rows - (off == INT32_MIN ? 0 : (uint64_t)(-(int64_t)off));   // INT32_MIN: the first zero-knowledge row itself
                 stack[sp++] = fe_mul<F>(fe_sub<F>(env.zeta1, k.one), fe_inv<F>(fe_sub<F>(env.zeta, host_pow_u64<F>(env.omega, row, k.one)), k)); break; }
             case MINA_TOK_STORE: cache[nc++] = stack[sp - 1]; break;
-            case MINA_TOK_LOAD: stack[sp++] = cache[tk.a]; break;
+            case MINA_TOK_LOAD: if ((int)tk.a >= nc) return false; stack[sp++] = cache[tk.a]; break;      // a slot no executed STORE has filled
             default: return false;
         }
     }

@@ -103,9 +103,8 @@ def polish_evaluate(tokens, index: VerifierIndex, pt: int, evals, consts: dict, 
     features, present, skip = consts.get("features", 0), consts.get("present"), 0
     for tok in tokens:
         op = tok[0]
-        if skip:                                                   # inside a skipped region: nothing runs; a STORE still takes its cache slot
-            skip -= 1
-            if op == T_STORE: cache.append(0)
+        if skip:                                                   # inside a skipped region: nothing runs (kimchi PolishToken::evaluate: `skip_count -= 1; continue`) --
+            skip -= 1                                              # a skipped STORE takes no cache slot
             continue
         if op in (T_SKIP_IF, T_SKIP_IF_NOT):                       # kimchi SkipIf / SkipIfNot: push zero and skip `count` tokens when the condition holds
             on = bool((features >> tok[1]) & 1)
@@ -137,7 +136,9 @@ def polish_evaluate(tokens, index: VerifierIndex, pt: int, evals, consts: dict, 
             i = off if off >= 0 else n - index.zk_rows + (0 if off == -(1 << 31) else off)     # -2^31: the first zero-knowledge row itself
             stack.append((pow(pt, n, r) - 1) * R.inv((pt - pow(w, i, r)) % r, r) % r)
         elif op == T_STORE: cache.append(stack[-1])
-        elif op == T_LOAD: stack.append(cache[tok[1]])
+        elif op == T_LOAD:
+            if tok[1] >= len(cache): raise KeyError("LOAD of a cache slot no executed STORE has filled")
+            stack.append(cache[tok[1]])
         else: raise ValueError("unknown token %r" % (tok,))
     assert len(stack) == 1
     return stack[0]

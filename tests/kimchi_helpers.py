@@ -149,13 +149,16 @@ def make_step_index(seed):
 
 def make_feature_step_index(seed):
     """a FEATURE-AWARE synthetic step index: on top of make_step_index's program, regions guarded by kimchi's SkipIf / SkipIfNot that read
-    optional evaluations (lookup aggregation / table, the range_check0 selector, a lookup-pattern selector), the joint combiner, and a value
-    STOREd inside a region and LOADed after it -- the shape kimchi's feature-flagged linearization compiles to:
+    optional evaluations (lookup aggregation / table, the range_check0 selector, a lookup-pattern selector), the joint combiner, a value STOREd
+    and LOADed inside a region, and -- behind the regions -- an outer STORE whose cache slot depends on whether that region ran (kimchi's
+    `evaluate` pushes a slot per EXECUTED Store: skipped tokens have no effect), followed by a LOAD of slot 1: the region's value when
+    LookupTables is on, the outer one when it is off.  The shape kimchi's feature-flagged linearization compiles to:
         if_feature(f, e1, e2)  ->  SkipIfNot(f, |e1|) e1 SkipIf(f, |e2|) e2 Add"""
     from oracle import kimchi_ref as K
     base = make_step_index(seed)
+    assert sum(t[0] == K.T_STORE for t in base.constant_term) == 1      # slot 0 is the base program's
     OPT = K.N_EVAL_COLS                                                   # 43 + slot (wire order of the optional evaluations)
-    e1 = [(K.T_CELL, OPT + 6, 1), (K.T_JOINT,), (K.T_MUL,), (K.T_CELL, OPT + 7, 0), (K.T_ADD,), (K.T_STORE,)]            # lookup aggregation(zeta w) * joint + table(zeta), cached
+    e1 = [(K.T_CELL, OPT + 6, 1), (K.T_JOINT,), (K.T_MUL,), (K.T_CELL, OPT + 7, 0), (K.T_ADD,), (K.T_STORE,), (K.T_LOAD, 1), (K.T_MUL,)]   # (aggregation(zeta w) * joint + table(zeta))^2 through the cache
     e2 = [(K.T_LITERAL, 31337), (K.T_ALPHA,), (K.T_MUL,)]
     r1 = [(K.T_SKIP_IF_NOT, 6, len(e1))] + e1 + [(K.T_SKIP_IF, 6, len(e2))] + e2 + [(K.T_ADD,)]                          # if_feature(LookupTables, e1, e2)
     e3 = [(K.T_CELL, OPT + 0, 0), (K.T_BETA,), (K.T_MUL,)]
@@ -163,7 +166,8 @@ def make_feature_step_index(seed):
     inner = [(K.T_CELL, OPT + 17, 1), (K.T_GAMMA,), (K.T_ADD,)]
     e4 = [(K.T_ENDO,), (K.T_SKIP_IF_NOT, 10, len(inner))] + inner + [(K.T_MUL,)]                                        # nested: LookupPattern RangeCheck inside TableWidth(1)
     r3 = [(K.T_SKIP_IF_NOT, 13, len(e4))] + e4
-    toks = list(base.constant_term) + r1 + [(K.T_ADD,)] + r2 + [(K.T_ADD,)] + r3 + [(K.T_SUB,)] + [(K.T_LOAD, 1), (K.T_ADD,)]
+    tail = [(K.T_ALPHA,), (K.T_STORE,), (K.T_LOAD, 1), (K.T_MUL,), (K.T_ADD,)]                                          # slot 1 (region skipped) or 2 (region ran)
+    toks = list(base.constant_term) + r1 + [(K.T_ADD,)] + r2 + [(K.T_ADD,)] + r3 + [(K.T_SUB,)] + tail
     return type(base)(zk_rows=base.zk_rows, shifts=base.shifts, constant_term=toks, mds=base.mds)
 
 

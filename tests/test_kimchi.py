@@ -181,3 +181,4 @@ def test_statement_driven_job_full_size(ctx_srs, oracle):
     assert ctx_srs.state_job_batch(job_from_statement(bad, bapps)).tolist() == [0, 0, 1, 0]
     bad2 = copy.deepcopy(wraps); bad2[2]["old_bulletproof_challenges"][1][7] ^= 1 << 77
     assert ctx_srs.state_job_batch(job_from_statement(bad2, apps)).tolist() == [1, 1, 0, 1]
+
