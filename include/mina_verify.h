@@ -654,6 +654,7 @@ typedef struct mina_verify_tuning {
     uint32_t ipa_side_stream;      /* 1     U = to_group(t) beside the transcript on a second stream */
     uint32_t search_fan;           /* 4     fan-out of the culprit search (2 .. 32) */
     uint32_t search_full;          /* 0     1 = every part of a culprit search repeats its transcripts */
+    uint32_t msm_fp29;             /* 1     SRS-table MSMs accumulate their buckets on 29-bit limbs (0: the 8 x 32-bit law) */
 } mina_verify_tuning;
 void mina_verify_tuning_default(mina_verify_tuning *out);
 int mina_verify_tuning_get(mina_verify_tuning *out);

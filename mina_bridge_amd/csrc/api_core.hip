@@ -20,7 +20,7 @@ static mina_verify_tuning tuning_defaults() {
     t.chain_cus = 128; t.cu_period = 256; t.acc_mask = 0; t.hash_piece_waves = 1024; t.up_stream = 1; t.min_shard = 64; t.pace_us = 0;
     t.merge = 1; t.merge_batch_max = 512; t.linger_us = 500; t.max_jobs = 1;
     t.coop16_max = 64; t.coop8_max = 8192; t.coop8_per_call = 0; t.transcript_coop8_max = 0; t.ipa_coop8_max = 1024; t.kimchi_coop8_max = 1024;
-    t.bpoly_mfma = 1; t.pubcomm_direct = 1; t.ipa_shared_points = 1; t.kimchi_shared_digest = 1; t.ipa_side_stream = 1; t.search_fan = 4; t.search_full = 0;
+    t.bpoly_mfma = 1; t.pubcomm_direct = 1; t.ipa_shared_points = 1; t.kimchi_shared_digest = 1; t.ipa_side_stream = 1; t.search_fan = 4; t.search_full = 0; t.msm_fp29 = 1;
     return t;
 }
 static mina_verify_tuning g_tune = tuning_defaults();
@@ -146,6 +146,7 @@ template <int F> static FieldK make_field_consts() {
     k.endo = fe_sqr<F>(w);
     k.inv2 = fe_inv<F>(two, k);
     k.two255 = k.one; for (int i = 0; i < 255; ++i) k.two255 = fe_dbl<F>(k.two255);
+    { fe_t t = fe_zero(); t.v[0] = 32; k.m32 = fe_to_mont<F>(t, k.r2); }
     return k;
 }
 
@@ -176,7 +177,7 @@ extern "C" void mina_ctx_destroy(mina_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     for (int i = 0; i < MB_MAX_LANES; ++i) if (c->lanes[i].stream) (void)hipStreamSynchronize(c->lanes[i].stream);
-    for (int i = 0; i < 2; ++i) { c->srs[i].table.release(); c->srs[i].h.release(); c->srs[i].lagrange_table.release(); c->srs[i].lagrange_digits.release(); c->pparams[i].release(); c->merkle_salts[i].release(); }
+    for (int i = 0; i < 2; ++i) { c->srs[i].table.release(); c->srs[i].table29.release(); c->srs[i].h.release(); c->srs[i].lagrange_table.release(); c->srs[i].lagrange_digits.release(); c->pparams[i].release(); c->merkle_salts[i].release(); }
     c->state_salts.release(); c->kimchi_index.release(); c->kimchi_tokens.release(); c->kimchi_literals.release();
     c->pickles_index.release(); c->pickles_tokens.release(); c->pickles_literals.release();
     if (c->step_host && c->step_host_free) c->step_host_free(c->step_host);

@@ -11,6 +11,9 @@ template <int F> static int build_tables(mina_ctx *c, SrsState &s) {
     const FieldK &fk = c->fk[F];
     msm_build_table_kernel<F><<<cdiv(s.depth, 256), 256, 0, c->L->stream>>>(s.depth, s.depth, s.c, s.W, fk.one, fk.pm2, s.table.as<affine_t>());
     HIPC(hipGetLastError());
+    const size_t npts = (size_t)s.W * s.depth;                     // the 2^261-domain twin the fp29 accumulate kernels gather from (ec29.cuh)
+    msm_table29_kernel<F><<<cdiv(npts, 256), 256, 0, c->L->stream>>>(npts, s.table.as<affine_t>(), fk.m32, s.table29.as<affine_t>());
+    HIPC(hipGetLastError());
     HIPC(hipStreamSynchronize(c->L->stream));
     return MINA_OK;
 }
@@ -21,6 +24,7 @@ static int srs_alloc(mina_ctx *c, int curve, uint32_t depth) {
     s.lagrange_log2 = -1; s.lagrange_host.clear();
     int rc;
     if ((rc = s.table.ensure((size_t)s.W * depth * sizeof(affine_t)))) return rc;
+    if ((rc = s.table29.ensure((size_t)s.W * depth * sizeof(affine_t)))) return rc;
     if ((rc = s.h.ensure(sizeof(affine_t)))) return rc;
     return MINA_OK;
 }

@@ -1,0 +1,83 @@
+// ec29.cuh -- the XYZZ mixed add of the MSM's accumulate kernels on 9 limbs of 29 bits (fp29.cuh: Montgomery 2^261, no carry instructions, lazy
+// reduction).  Round 4: the accumulate kernel -- >= 1 M mixed adds per 2^16 MSM -- is bound by multiply-accumulate issue; in the saturated 8 x 32 form
+// a limb product is a `v_mad_u64_u32` + a `v_addc`, here it is the multiply-accumulate alone, a squaring is 99 of them instead of 135, and no
+// conditional subtraction exists.  Measured on MI355X (tools/probes/batch_affine_probe.hip, 8.4 M gathered adds per launch, bit-identical buckets):
+// 16.2 - 16.8 G adds/s against 12.4 - 13.2 for the 8 x 32 law (+ 27 - 31 %); profiles/r04_group_law_probe.md.
+//
+// Value discipline (p = 2^254 + c; 2^256 ~ 4 p; a normalised 9-limb value holds up to 2^261):
+//   * a product / square of operands below 16 p is below 16 * 16 p^2 / 2^261 + p = 3 p; a two-term dot product of the magnitudes below: < 2 p
+//   * a - b is a + K p - b, K = 4 or 8, with K p in a redundant limb form whose every limb exceeds any normalised limb of b: the limb-wise difference
+//     never goes negative and ONE carry pass normalises it; needs b < K p
+//   * accumulator coordinates stay below 6 p (x), 2 p (y), 3 p (zz, zzz); table coordinates are canonical (< p), stored as x * 2^261 mod p
+// The exceptional cases of the group law (the two points equal or opposite: P = 0 mod p) are found EXACTLY: a multiple k p = k 2^254 + k c of p below
+// 16 p has limbs 5..7 and the low 22 bits of limb 8 zero (k c < 2^129) -- four instructions per add -- and only then limbs 0..4 are compared with k c;
+// such an add takes the 8 x 32 law through a domain change (never on SRS points; it keeps the kernels exact on any input).
+#pragma once
+#include "ec.cuh"
+#include "fp29.cuh"
+
+namespace mb {
+
+struct xyzz29_t { fe29_t x, y, zz, zzz; };
+
+template <int F, uint32_t MULT> struct KP29 {   // MULT * p in normalised 29-bit limbs n_0 .. n_5, n_8 (n_6 = n_7 = 0)
+    static constexpr uint64_t t0 = (uint64_t)MULT * 1u, n0 = t0 & M29, t1 = (uint64_t)MULT * P29<F>::L1 + (t0 >> 29), n1 = t1 & M29, t2 = (uint64_t)MULT * P29<F>::L2 + (t1 >> 29), n2 = t2 & M29,
+                              t3 = (uint64_t)MULT * P29<F>::L3 + (t2 >> 29), n3 = t3 & M29, t4 = (uint64_t)MULT * P29<F>::L4 + (t3 >> 29), n4 = t4 & M29, n5 = t4 >> 29, n8 = (uint64_t)MULT * P29<F>::L8;
+    static_assert(n5 < (1u << 29) && n8 >= 2 && n8 < (1u << 29), "limb shape of MULT * p");
+};
+// a + MULT p - b, normalised; needs b < MULT p (both operands normalised).  K_0 = n_0 + 2^30, K_i = n_i + 2^30 - 2 (0 < i < 8), K_8 = n_8 - 2: the same integer
+template <int F, uint32_t MULT> MB_HD fe29_t fe29_sub_kp(const fe29_t &a, const fe29_t &b) {
+    typedef KP29<F, MULT> K;
+    const uint32_t k[9] = {(uint32_t)K::n0 + (1u << 30), (uint32_t)K::n1 + (1u << 30) - 2, (uint32_t)K::n2 + (1u << 30) - 2, (uint32_t)K::n3 + (1u << 30) - 2, (uint32_t)K::n4 + (1u << 30) - 2,
+                           (uint32_t)K::n5 + (1u << 30) - 2, (1u << 30) - 2, (1u << 30) - 2, (uint32_t)K::n8 - 2};
+    fe29_t r; uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < L29; ++i) { const uint32_t t = a.v[i] + k[i] - b.v[i] + c; if (i < L29 - 1) { r.v[i] = t & M29; c = t >> 29; } else r.v[i] = t; }
+    return r;
+}
+MB_HD fe29_t fe29_zero() { fe29_t r; for (int i = 0; i < L29; ++i) r.v[i] = 0; return r; }
+
+// a (normalised, below 16 p) == 0 mod p?  exact
+template <int F> MB_HD bool fe29_is_multiple_of_p(const fe29_t &a) {
+    if ((a.v[5] | a.v[6] | a.v[7] | (a.v[8] & 0x3fffffu)) != 0u) return false;          // the cheap necessary test, inlined again at the call site
+    const uint64_t k = a.v[8] >> 22;                                                      // k p = k 2^254 + k c
+    const uint64_t t0 = k, t1 = k * P29<F>::L1 + (t0 >> 29), t2 = k * P29<F>::L2 + (t1 >> 29), t3 = k * P29<F>::L3 + (t2 >> 29), t4 = k * P29<F>::L4 + (t3 >> 29);
+    return a.v[0] == (uint32_t)(t0 & M29) && a.v[1] == (uint32_t)(t1 & M29) && a.v[2] == (uint32_t)(t2 & M29) && a.v[3] == (uint32_t)(t3 & M29) && a.v[4] == (uint32_t)(t4 & M29) && (t4 >> 29) == 0;
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// x * 2^261 (lazy, below 16 p) -> x * 2^256, canonical words; and back
+template <int F> __device__ __forceinline__ fe_t fe29_leave(const fe29_t &a, const fe29_t &leave /* the integer 2^256 mod p */) { return fe_cond_sub_p<F>(fe29_to_words(fe29_mul_asm<F>(a, leave))); }
+
+// the exceptional add (P = 0 mod p: the points are equal or opposite) through the 8 x 32 law; kept out of line: it never runs on SRS points
+template <int F> __device__ __noinline__ void xyzz29_add_affine_rare(xyzz29_t &acc, bool &inf, const fe29_t &qx, const fe29_t &qy, const fe_t &one, const fe_t &m32) {
+    const fe29_t leave = fe29_from_words(one);
+    xyzz_t a; a.x = fe29_leave<F>(acc.x, leave); a.y = fe29_leave<F>(acc.y, leave); a.zz = fe29_leave<F>(acc.zz, leave); a.zzz = fe29_leave<F>(acc.zzz, leave);
+    xyzz_add_affine<F>(a, fe29_leave<F>(qx, leave), fe29_leave<F>(qy, leave), one);
+    inf = xyzz_is_inf(a);
+    acc.x = fe29_from_words(fe_mul<F>(a.x, m32)); acc.y = fe29_from_words(fe_mul<F>(a.y, m32)); acc.zz = fe29_from_words(fe_mul<F>(a.zz, m32)); acc.zzz = fe29_from_words(fe_mul<F>(a.zzz, m32));
+}
+
+// acc += (qx, qy): affine, not infinity, coordinates canonical in the 2^261 domain  (madd-2008-s; ec.cuh xyzz_add_affine on the other limbs)
+template <int F> __device__ __forceinline__ void xyzz29_add_affine(xyzz29_t &acc, bool &inf, const fe29_t &qx, const fe29_t &qy, const fe_t &one, const fe_t &m32) {
+    if (inf) { acc.x = qx; acc.y = qy; acc.zz = fe29_from_words(m32); acc.zzz = acc.zz; inf = false; return; }      // 1 in the 2^261 domain = the integer 2^261 mod p
+    const fe29_t u2 = fe29_mul_asm<F>(qx, acc.zz), s2 = fe29_mul_asm<F>(qy, acc.zzz);                              // < 3 p
+    const fe29_t pd = fe29_sub_kp<F, 8>(u2, acc.x), r = fe29_sub_kp<F, 8>(s2, acc.y);                                // < 11 p
+    if (__builtin_expect((pd.v[5] | pd.v[6] | pd.v[7] | (pd.v[8] & 0x3fffffu)) == 0u, 0))
+        if (fe29_is_multiple_of_p<F>(pd)) { xyzz29_add_affine_rare<F>(acc, inf, qx, qy, one, m32); return; }
+    const fe29_t pp = fe29_sqr_asm<F>(pd), ppp = fe29_mul_asm<F>(pd, pp), q = fe29_mul_asm<F>(acc.x, pp);           // < 2 p, < 1.2 p, < 1.1 p
+    const fe29_t x3 = fe29_sub_kp<F, 4>(fe29_sqr_asm<F>(r), fe29_add(ppp, fe29_add(q, q)));                          // r^2 + 4 p - (ppp + 2 q) < 6 p
+    const fe29_t y3 = fe29_dot2_asm<F>(r, fe29_sub_kp<F, 8>(q, x3), fe29_sub_kp<F, 8>(fe29_zero(), acc.y), ppp);     // r (q - x3) - y1 ppp, one reduction: < 2 p
+    acc.zz = fe29_mul_asm<F>(acc.zz, pp); acc.zzz = fe29_mul_asm<F>(acc.zzz, ppp);
+    acc.x = x3; acc.y = y3;
+}
+// the bucket value in the 8 x 32 form the rest of the MSM reads (canonical Montgomery-2^256 XYZZ; infinity = zz 0)
+template <int F> __device__ __forceinline__ xyzz_t xyzz29_leave(const xyzz29_t &acc, bool inf, const fe_t &one) {
+    if (inf) return xyzz_inf();
+    const fe29_t leave = fe29_from_words(one);
+    xyzz_t o; o.x = fe29_leave<F>(acc.x, leave); o.y = fe29_leave<F>(acc.y, leave); o.zz = fe29_leave<F>(acc.zz, leave); o.zzz = fe29_leave<F>(acc.zzz, leave);
+    return o;
+}
+#endif
+
+}  // namespace mb

@@ -20,6 +20,7 @@ struct FieldK {
     fe_t endo;                   // endo_r of the curve whose SCALAR field this is: (5^((p-1)/3))^2
     fe_t half;                   // (p-1)/2 plain, for the y-sign flag of the point codec
     fe_t two255, inv2;           // 2^255 and 1/2, Montgomery (shift_scalar of the Fq-sponge's absorb_fr)
+    fe_t m32;                    // 32 in Montgomery form = the integer 2^261 mod p: one product by it moves a value from the 2^256 domain to fp29's 2^261 domain (ec29.cuh)
 };
 
 template <int F> MB_HD fe_t fe_inv(const fe_t &a, const FieldK &k) { return fe_pow<F>(a, k.pm2, k.one); }

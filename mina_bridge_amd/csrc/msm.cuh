@@ -17,6 +17,7 @@
 //     cross-lane shuffles (three levels of 64-way groups), no serial running sum.
 #pragma once
 #include "ec.cuh"
+#include "ec29.cuh"
 
 namespace mb {
 
@@ -622,6 +623,88 @@ msm_accumulate_bucket_kernel(uint32_t nb_total, uint32_t nb_prob, const uint32_t
         }
         buckets[b] = acc;
     }
+}
+
+// K1t-b on 29-bit limbs (ec29.cuh): the same lanes, the same order of additions, points gathered from the 2^261-domain twin of the window table; the
+// bucket leaves in the 8 x 32 form.  4 waves per SIMD (the limbs' working set is smaller: 16.5 against 16.2 G adds/s at 2, tools/probes/batch_affine_probe).
+template <int F>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4)))
+msm_accumulate_bucket29_kernel(uint32_t nb_total, uint32_t nb_prob, const uint32_t *__restrict__ start, const uint32_t *__restrict__ order,
+                               const uint32_t *__restrict__ sorted, const affine_t *__restrict__ points29, fe_t one, fe_t m32,
+                               xyzz_t *__restrict__ buckets) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nb_total / 2) return;
+    const uint32_t m = r / (nb_prob / 2), lr = r - m * (nb_prob / 2);
+#pragma unroll 1
+    for (int half = 0; half < 2; ++half) {
+        const uint32_t b = order[m * nb_prob + (half ? nb_prob - 1 - lr : lr)];
+        const uint32_t beg = start[b], cnt = start[b + 1] - beg;
+        if (cnt > MSM_HEAVY_ENTRIES) continue;                   // K1t-c writes it
+        xyzz29_t acc; bool inf = true;
+        if (cnt) {
+            uint32_t ref = sorted[beg], ref_n = cnt > 1 ? sorted[beg + 1] : 0u;
+            affine_t nxt = load_affine(points29 + (ref & 0x7fffffffu));
+#pragma unroll 1
+            for (uint32_t e = 0; e < cnt; ++e) {
+                const affine_t p = nxt;
+                const uint32_t cur = ref;
+                ref = ref_n;
+                if (e + 1 < cnt) nxt = load_affine(points29 + (ref & 0x7fffffffu));
+                if (e + 2 < cnt) ref_n = sorted[beg + e + 2];
+                if (aff_is_inf(p)) continue;
+                const fe29_t px = fe29_from_words(p.x), py = fe29_from_words(p.y);
+                xyzz29_add_affine<F>(acc, inf, px, (cur >> 31) ? fe29_sub_kp<F, 1>(fe29_zero(), py) : py, one, m32);     // -y = p - y: canonical again (y != 0 on these curves)
+            }
+        }
+        buckets[b] = xyzz29_leave<F>(acc, inf, one);
+    }
+#endif
+}
+// K1d on 29-bit limbs: one lane per task of <= 8 entries (the single-MSM form)
+template <int F>
+__global__ void __launch_bounds__(256)
+msm_accumulate29_kernel(uint32_t nb_total, const uint32_t *__restrict__ start, const uint32_t *__restrict__ full_start,
+                        const uint32_t *__restrict__ rem_bucket, const uint32_t *__restrict__ info,
+                        const uint32_t *__restrict__ sorted, const affine_t *__restrict__ points29, fe_t one, fe_t m32,
+                        xyzz_t *__restrict__ partial) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t nfull = info[0], nrem = info[1];
+    if (t >= nfull + nrem) return;
+    uint32_t b, j;
+    if (t < nfull) {
+        uint32_t lo = 0, hi = nb_total;
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (full_start[mid] <= t) lo = mid; else hi = mid; }
+        b = lo; j = t - full_start[b];
+    } else { b = rem_bucket[t - nfull]; j = (start[b + 1] - start[b]) / MSM_TASK_LEN; }
+    const uint32_t beg = start[b] + j * MSM_TASK_LEN;
+    const uint32_t cnt = min((uint32_t)MSM_TASK_LEN, start[b + 1] - beg);
+    uint32_t refs[MSM_TASK_LEN];
+#pragma unroll
+    for (int e = 0; e < MSM_TASK_LEN; ++e) refs[e] = ((uint32_t)e < cnt) ? sorted[beg + e] : 0u;
+    xyzz29_t acc; bool inf = true;
+    affine_t nxt = load_affine(points29 + (refs[0] & 0x7fffffffu));
+#pragma unroll 1
+    for (uint32_t e = 0; e < cnt; ++e) {
+        const affine_t p = nxt;
+        const uint32_t ref = refs[0];
+#pragma unroll
+        for (int q = 0; q + 1 < MSM_TASK_LEN; ++q) refs[q] = refs[q + 1];
+        if (e + 1 < cnt) nxt = load_affine(points29 + (refs[0] & 0x7fffffffu));
+        if (aff_is_inf(p)) continue;
+        const fe29_t px = fe29_from_words(p.x), py = fe29_from_words(p.y);
+        xyzz29_add_affine<F>(acc, inf, px, (ref >> 31) ? fe29_sub_kp<F, 1>(fe29_zero(), py) : py, one, m32);
+    }
+    partial[t] = xyzz29_leave<F>(acc, inf, one);
+#endif
+}
+// the 2^261-domain twin of a window table: every coordinate times 32 (one Montgomery product by mont(32)); infinity (0, 0) stays
+template <int F>
+__global__ void msm_table29_kernel(size_t n, const affine_t *__restrict__ in, fe_t m32, affine_t *__restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    affine_t p = in[i]; p.x = fe_mul<F>(p.x, m32); p.y = fe_mul<F>(p.y, m32); out[i] = p;
 }
 
 // K1t-c: heavy buckets, one 256-lane block each (grid-stride over the queue): lane t sums entries t, t+256, ..., then a

@@ -249,3 +249,68 @@ def test_msm_srs_multi_randomised_shapes(ctx_srs, oracle, srs_oracle):
             ctx_srs.set_pipeline(1)
         for m in range(nprob):
             assert (got[m] == oracle.msm_pippenger(curve, g[:n], sc[m], threads=8)).all(), (trial, curve, n, nprob, m)
+
+
+def _srs_blob(oracle, curve, g, h):
+    """SRS{g, h} in the reference's file format: fixarray(2)[ array32(n)[bin8(33) ...], bin8(33) ]"""
+    import struct
+    comp = oracle.point_compress(curve, np.concatenate([g, h.reshape(1, 64)]))
+    body = b"".join(b"\xc4\x21" + comp[i].tobytes() for i in range(len(g)))
+    return b"\x92" + b"\xdd" + struct.pack(">I", len(g)) + body + b"\xc4\x21" + comp[len(g)].tobytes()
+
+
+@pytest.mark.parametrize("curve", [1, 0])
+def test_fixed_base_msm_on_29_bit_limbs_equals_the_8x32_law_and_the_oracle(ctx_srs, oracle, srs_oracle, curve):
+    """round 4: SRS-table MSMs accumulate their buckets with the XYZZ mixed add on 9 x 29-bit limbs (ec29.cuh, lazy reduction, the table's 2^261-domain
+    twin).  Same result, bit for bit, as the 8 x 32 law (`mina_verify_tuning.msm_fp29 = 0`) and as the CPU oracle: single MSMs (task form) and groups of
+    6 (bucket-lane form), uniform / 128-bit / structured / all-equal scalars, values at the limb boundaries."""
+    import mina_bridge_amd as m
+    g, _ = srs_oracle[curve]
+    r = SCALAR_MOD[curve]
+    n = 4096
+    sets = {"uniform": rand_scalars(n, r, seed=501), "bits128": rand_scalars(n, r, seed=502, bits=128),
+            "all_equal": oracle.ints_to_le([0x1234567890ABCDEF1234567890ABCDEF % r] * n),
+            "limb_edges": oracle.ints_to_le([((1 << 29) - 1) << (29 * (i % 8)) | (1 << (29 * (i % 9))) % r for i in range(n)]),
+            "r_minus_1": oracle.ints_to_le([r - 1 - i for i in range(n)])}
+    for name, sc in sets.items():
+        want = oracle.msm_pippenger(curve, g[:n], sc, threads=8)
+        assert (ctx_srs.msm_srs(curve, sc) == want).all(), name
+        with m.lib.tuning(msm_fp29=0):
+            assert (ctx_srs.msm_srs(curve, sc) == want).all(), name + " (8 x 32)"
+    multi = np.stack([rand_scalars(n, r, seed=600 + i) for i in range(6)])
+    got = ctx_srs.msm_srs_multi(curve, multi, 6)
+    with m.lib.tuning(msm_fp29=0):
+        ref = ctx_srs.msm_srs_multi(curve, multi, 6)
+    assert (got == ref).all()
+    assert (got[3] == oracle.msm_pippenger(curve, g[:n], multi[3], threads=8)).all()
+
+
+def test_29_bit_group_law_handles_equal_and_opposite_points_exactly(oracle, srs_oracle):
+    """the exceptional cases of the mixed add (the accumulator equals the next point, or its negative) never occur on the real SRS; an SRS crafted to
+    contain them -- g[1] = g[0], g[3] = -g[2], g[5] = g[4] = g[6] -- loaded through mina_srs_load puts equal and opposite points into ONE bucket when their
+    scalars agree: the fp29 path must find P = 0 (mod p) on lazily reduced limbs and take the doubling / infinity branch (ec29.cuh xyzz29_add_affine_rare)"""
+    import mina_bridge_amd as m
+    curve, n = 1, 256
+    g, h = srs_oracle[curve]
+    g = g[:n].copy()
+    fq = 0x40000000000000000000000000000000224698FC0994A8DD8C46EB2100000001          # Vesta base field
+    neg = lambda pt: np.concatenate([pt[:32], np.frombuffer(((fq - int.from_bytes(pt[32:].tobytes(), "little")) % fq).to_bytes(32, "little"), np.uint8)])
+    g[1] = g[0]; g[3] = neg(g[2]); g[5] = g[4]; g[6] = g[4]
+    c = m.MinaContext(0)
+    try:
+        c.srs_load(curve, _srs_blob(oracle, curve, g, h))
+        assert (c.srs_get_g(curve, 0, n) == g).all()
+        rng = np.random.Generator(np.random.PCG64(77))
+        for trial in range(4):
+            sc = rand_scalars(n, P, seed=700 + trial)
+            k = rng.integers(0, 256, size=32, dtype=np.uint8); k[31] &= 0x3F
+            for i in (0, 1, 2, 3, 4, 5, 6): sc[i] = k                                  # equal scalars: the same digit in every window -> the same buckets
+            if trial == 1: sc[8:] = 0                                                   # nothing else in those buckets: acc == next point at the second entry
+            if trial == 2: sc[4] = 0; sc[5] = 0; sc[6] = 0                              # only the opposite pair: the bucket goes through infinity
+            want = oracle.msm_naive(curve, g, sc)
+            for fp29 in (1, 0):
+                with m.lib.tuning(msm_fp29=fp29):
+                    assert (c.msm_srs(curve, sc) == want).all(), (trial, fp29)
+                    assert (c.msm_srs_multi(curve, np.stack([sc] * 5), 5)[2] == want).all(), (trial, fp29, "bucket-lane form")
+    finally:
+        c.close()

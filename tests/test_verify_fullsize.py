@@ -202,7 +202,7 @@ FORCED_SHAPES = {
     "lanes8_everywhere": dict(coop16_max=0, coop8_max=1 << 30, transcript_coop8_max=1 << 30, ipa_coop8_max=1 << 30, kimchi_coop8_max=1 << 30),
     "lanes3_everywhere": dict(coop16_max=0, coop8_max=0, transcript_coop8_max=1),
     # every shortcut replaced by its slower equivalent
-    "shortcuts_off": dict(bpoly_mfma=0, pubcomm_direct=0, ipa_shared_points=0, kimchi_shared_digest=0, ipa_side_stream=0, search_full=1),
+    "shortcuts_off": dict(bpoly_mfma=0, pubcomm_direct=0, ipa_shared_points=0, kimchi_shared_digest=0, ipa_side_stream=0, search_full=1, msm_fp29=0),
     # the bytes -> bools pipeline bent every way its knobs allow
     "pipeline_streamed_entry_by_entry": dict(early_min=1, early_sub=1, head_min=0, hash_piece_waves=1),
     "pipeline_no_forks_no_masks": dict(split_max=0, chain_cus=0, up_stream=0, slots=16, ahead=3, merge_batch_max=0, acc_mask=2),

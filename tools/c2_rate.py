@@ -6,6 +6,7 @@ sys.path.insert(0, ROOT)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 import numpy as np, torch
 import mina_bridge_amd as m
+m.lib.tune_from_string(os.environ.get("MINA_TUNE", ""))      # e.g. MINA_TUNE=msm_fp29=0 (fields of mina_verify_tuning)
 from bench import make_accumulators, CURVE_VESTA, ACC_K
 lanes = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 calls = int(sys.argv[2]) if len(sys.argv) > 2 else 400

@@ -14,6 +14,7 @@
 #include <vector>
 #include "ec.cuh"
 #include "groupmap.cuh"
+#include "fp29.cuh"
 using namespace mb;
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 constexpr int F = FIELD_FQ;
@@ -38,6 +39,77 @@ xyzz_kernel(uint32_t lanes, uint32_t K, const uint32_t *__restrict__ refs, const
         xyzz_add_affine<F>(acc, p.x, p.y, one);
     }
     out[l] = acc;
+}
+
+// ---- C  xyzz29 : the same mixed add on 9 limbs of 29 bits (fp29.cuh: no carry instructions, lazy reduction -- every value stays below 16 p = 2^258,
+//                  subtractions add 8 p in a redundant limb form and renormalise); table coordinates are x * 2^261 mod p as 8 x 32-bit words
+template <int FF, uint32_t MULT> struct KMP {   // MULT * p in normalised 29-bit limbs n_i
+    static constexpr uint64_t t0 = (uint64_t)MULT * 1u, n0 = t0 & M29, t1 = (uint64_t)MULT * P29<FF>::L1 + (t0 >> 29), n1 = t1 & M29, t2 = (uint64_t)MULT * P29<FF>::L2 + (t1 >> 29), n2 = t2 & M29,
+                              t3 = (uint64_t)MULT * P29<FF>::L3 + (t2 >> 29), n3 = t3 & M29, t4 = (uint64_t)MULT * P29<FF>::L4 + (t3 >> 29), n4 = t4 & M29, n5 = t4 >> 29, n8 = (uint64_t)MULT * P29<FF>::L8;
+};
+// a + MULT p - b, normalised; needs b < MULT p.  MULT p enters in a redundant limb form -- K_0 = n_0 + 2^30, K_i = n_i + 2^30 - 2 (i = 1..7), K_8 = n_8 - 2: the same
+// integer, every limb above any b_i -- so the limb-wise difference never goes negative and ONE carry pass normalises it
+template <int FF, uint32_t MULT> __device__ __forceinline__ fe29_t fe29_sub_kp(const fe29_t &a, const fe29_t &b) {
+    typedef KMP<FF, MULT> K;
+    const uint32_t k[9] = {(uint32_t)K::n0 + (1u << 30), (uint32_t)K::n1 + (1u << 30) - 2, (uint32_t)K::n2 + (1u << 30) - 2, (uint32_t)K::n3 + (1u << 30) - 2, (uint32_t)K::n4 + (1u << 30) - 2,
+                           (uint32_t)K::n5 + (1u << 30) - 2, (1u << 30) - 2, (1u << 30) - 2, (uint32_t)K::n8 - 2};
+    fe29_t r; uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < L29; ++i) { const uint32_t t = a.v[i] + k[i] - b.v[i] + c; if (i < L29 - 1) { r.v[i] = t & M29; c = t >> 29; } else r.v[i] = t; }
+    return r;
+}
+template <int FF> __device__ __forceinline__ fe29_t fe29_sub8p(const fe29_t &a, const fe29_t &b) { return fe29_sub_kp<FF, 8>(a, b); }
+template <int FF> __device__ __forceinline__ fe29_t fe29_sub4p(const fe29_t &a, const fe29_t &b) { return fe29_sub_kp<FF, 4>(a, b); }
+struct xyzz29_t { fe29_t x, y, zz, zzz; };
+// p == 0 (mod p) for a lazily reduced value below 16 p: a multiple k p = k 2^254 + k c has limbs 5..7 and the low 22 bits of limb 8 zero (k c < 2^129): the cheap
+// necessary test; the exact one (limbs 0..4 == k c) only behind it
+template <int FF> __device__ __forceinline__ bool fe29_maybe_zero(const fe29_t &a) { return ((a.v[5] | a.v[6] | a.v[7] | (a.v[8] & 0x3fffffu)) == 0u); }
+template <int FF> __device__ __forceinline__ void xyzz29_add_affine(xyzz29_t &acc, bool &inf, const fe29_t &qx, const fe29_t &qy, const fe29_t &one29, uint32_t &rare) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (inf) { acc.x = qx; acc.y = qy; acc.zz = one29; acc.zzz = one29; inf = false; return; }
+    const fe29_t u2 = fe29_mul_asm<FF>(qx, acc.zz), s2 = fe29_mul_asm<FF>(qy, acc.zzz);
+    const fe29_t pd = fe29_sub8p<FF>(u2, acc.x), r = fe29_sub8p<FF>(s2, acc.y);
+    if (fe29_maybe_zero<FF>(pd)) { ++rare; }                     // (the library version falls back to the 8 x 32 law here: P == +-Q)
+    const fe29_t pp = fe29_sqr_asm<FF>(pd), ppp = fe29_mul_asm<FF>(pd, pp), q = fe29_mul_asm<FF>(acc.x, pp);
+    const fe29_t t = fe29_add(ppp, fe29_add(q, q));
+    const fe29_t x3 = fe29_sub4p<FF>(fe29_sqr_asm<FF>(r), t);                 // t < 3.4 p; x3 < 6 p: the 8 p of the next addition's subtractions covers it
+    fe29_t zero; for (int i = 0; i < L29; ++i) zero.v[i] = 0;
+    const fe29_t y3 = fe29_dot2_asm<FF>(r, fe29_sub8p<FF>(q, x3), fe29_sub8p<FF>(zero, acc.y), ppp);
+    acc.zz = fe29_mul_asm<FF>(acc.zz, pp); acc.zzz = fe29_mul_asm<FF>(acc.zzz, ppp);
+    acc.x = x3; acc.y = y3;
+#endif
+}
+template <int WAVES>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, WAVES)))
+xyzz29_kernel(uint32_t lanes, uint32_t K, const uint32_t *__restrict__ refs, const affine_t *__restrict__ table29, fe29_t one29, fe29_t leave, xyzz_t *__restrict__ out, uint32_t *__restrict__ rare_out) {
+    const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= lanes) return;
+    xyzz29_t acc; bool inf = true; uint32_t rare = 0;
+    affine_t nxt = load_affine(table29 + refs[(size_t)l * K]);
+#pragma unroll 1
+    for (uint32_t e = 0; e < K; ++e) {
+        const affine_t p = nxt;
+        if (e + 1 < K) nxt = load_affine(table29 + refs[(size_t)l * K + e + 1]);
+        xyzz29_add_affine<F>(acc, inf, fe29_from_words(p.x), fe29_from_words(p.y), one29, rare);
+    }
+    // back to 8 x 32 Montgomery-2^256, canonical: one product by 2^256 mod p each (result < 1.01 p) and a conditional subtraction
+#if defined(__HIP_DEVICE_COMPILE__)
+    xyzz_t o;
+    o.x = fe_cond_sub_p<F>(fe29_to_words(fe29_mul_asm<F>(acc.x, leave))); o.y = fe_cond_sub_p<F>(fe29_to_words(fe29_mul_asm<F>(acc.y, leave)));
+    o.zz = fe_cond_sub_p<F>(fe29_to_words(fe29_mul_asm<F>(acc.zz, leave))); o.zzz = fe_cond_sub_p<F>(fe29_to_words(fe29_mul_asm<F>(acc.zzz, leave)));
+    out[l] = o;
+    if (rare) atomicAdd(rare_out, rare);
+#endif
+}
+// table29[i] = table[i] * 2^5 (Montgomery-2^256 words of x -> words of x * 2^261 mod p): one product by mont(32) per coordinate
+__global__ void to_table29_kernel(uint32_t n, const affine_t *__restrict__ in, fe_t m32, affine_t *__restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= n) return;
+    affine_t p = in[i]; p.x = fe_mul<F>(p.x, m32); p.y = fe_mul<F>(p.y, m32); out[i] = p;
+}
+__global__ void cmp_xyzz_kernel(uint32_t n, const xyzz_t *__restrict__ a, const xyzz_t *__restrict__ b, uint32_t *bad) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i >= n) return;
+    bool same = true; for (int w = 0; w < 8; ++w) same = same && a[i].x.v[w] == b[i].x.v[w] && a[i].y.v[w] == b[i].y.v[w] && a[i].zz.v[w] == b[i].zz.v[w] && a[i].zzz.v[w] == b[i].zzz.v[w];
+    if (!same) atomicAdd(bad, 1u);
 }
 
 template <bool INVERT>
@@ -110,6 +182,30 @@ int main() {
         const uint32_t lanes = (uint32_t)(total_adds / K);
         const double t = time_kernel([&] { xyzz_kernel<<<(lanes + 255) / 256, 256>>>(lanes, K, d_refs, d_tab, fk.one, d_x); }, 3);
         printf("{\"form\": \"xyzz mixed add (8M + 2S)\", \"adds_per_lane\": %u, \"lanes\": %u, \"ns_per_add_chip\": %.4f, \"G_adds_per_s\": %.2f}\n", K, lanes, t * 1e9 / total_adds, total_adds / t / 1e9);
+    }
+    {   // C: the same additions on 29-bit limbs; results compared coordinate by coordinate with A's
+        affine_t *d_tab29; xyzz_t *d_x29; uint32_t *d_rare;
+        CHECK(hipMalloc(&d_tab29, M * sizeof(affine_t))); CHECK(hipMalloc(&d_x29, total_adds / 16 * sizeof(xyzz_t))); CHECK(hipMalloc(&d_rare, 4)); CHECK(hipMemset(d_rare, 0, 4));
+        fe_t thirty2 = fe_zero(); thirty2.v[0] = 32; const fe_t m32 = fe_to_mont<F>(thirty2, fk.r2);
+        to_table29_kernel<<<(M + 255) / 256, 256>>>(M, d_tab, m32, d_tab29);
+        // one29 = 2^261 mod p = mont256(32) as an integer; leave = 2^256 mod p in the 2^261 domain = (2^256 * 2^261) mod p = mont256(2^261 mod p ...): computed on the host with the 8 x 32 routines
+        const fe29_t one29 = fe29_from_words(m32);                                        // the integer 2^261 mod p
+        const fe_t r512_261 = fe_mul<F>(fe_mul<F>(fk.r2, fk.r2), fk.one);                 // mont mult: r2 * r2 / R = R^3 mod p ... see below
+        (void)r512_261;
+        // leave: multiplying x 2^261 by L with the 2^261-Montgomery product gives x 2^261 L / 2^261 = x L; we want x 2^256, so L = 2^256 mod p = the integer fk.one
+        const fe29_t leave = fe29_from_words(fk.one);
+        for (uint32_t K : {16u, 32u, 64u}) {
+            const uint32_t lanes = (uint32_t)(total_adds / K);
+            xyzz_kernel<<<(lanes + 255) / 256, 256>>>(lanes, K, d_refs, d_tab, fk.one, d_x);
+            const double t2 = time_kernel([&] { xyzz29_kernel<2><<<(lanes + 255) / 256, 256>>>(lanes, K, d_refs, d_tab29, one29, leave, d_x29, d_rare); }, 3);
+            CHECK(hipMemset(d_bad, 0, 4));
+            cmp_xyzz_kernel<<<(lanes + 255) / 256, 256>>>(lanes, d_x, d_x29, d_bad);
+            uint32_t bad = 0, rare = 0; CHECK(hipMemcpy(&bad, d_bad, 4, hipMemcpyDeviceToHost)); CHECK(hipMemcpy(&rare, d_rare, 4, hipMemcpyDeviceToHost));
+            const double t4 = time_kernel([&] { xyzz29_kernel<4><<<(lanes + 255) / 256, 256>>>(lanes, K, d_refs, d_tab29, one29, leave, d_x29, d_rare); }, 3);
+            printf("{\"form\": \"xyzz mixed add on 9 x 29-bit limbs (lazy reduction)\", \"adds_per_lane\": %u, \"lanes\": %u, \"ns_per_add_chip_2_waves_per_simd\": %.4f, \"G_adds_per_s_2_waves\": %.2f, "
+                   "\"ns_per_add_chip_4_waves_per_simd\": %.4f, \"G_adds_per_s_4_waves\": %.2f, \"buckets_differing_from_the_8x32_law\": %u, \"rare_path_hits\": %u}\n",
+                   K, lanes, t2 * 1e9 / total_adds, total_adds / t2 / 1e9, t4 * 1e9 / total_adds, total_adds / t4 / 1e9, bad, rare);
+        }
     }
     for (uint32_t n : {16u, 32u, 64u, 128u, 256u, 512u}) {        // B / B': batched affine, n adds per lane per inversion
         const uint32_t lanes = (uint32_t)(total_adds / n);
