@@ -62,6 +62,7 @@ static int run_msm(mina_ctx *c, const MsmShape &sh, const uint32_t *d_scalars, c
         if ((rc = w.partial.ensure(max_tasks * sizeof(xyzz_t)))) return rc;
     }
     if ((rc = w.info.ensure(16))) return rc;
+    if (d_points29 && (rc = w.redo.ensure((std::max<size_t>(max_tasks, nb_total) + 1) * 4))) return rc;
     if ((rc = w.heavy.ensure((max_tasks / MSM_HEAVY_TASKS + entries / MSM_HEAVY_ENTRIES + 2) * 4))) return rc;
     if ((rc = w.buckets.ensure((size_t)nb_total * sizeof(xyzz_t)))) return rc;
     if (sh.NB < 128 || sh.NB > 32768) return fail(MINA_ERR_ARG, "unsupported bucket count");
@@ -101,14 +102,23 @@ static int run_msm(mina_ctx *c, const MsmShape &sh, const uint32_t *d_scalars, c
     }
     if (bucket_lanes) {
         { ProfScope ps_(c, PS_ACCUMULATE);
-          if (d_points29) msm_accumulate_bucket29_kernel<F><<<cdiv(nb_total / 2, 256), 256, 0, st>>>(nb_total, ss.SB, w.start.as<uint32_t>(), w.order.as<uint32_t>(), w.sorted.as<uint32_t>(), d_points29, fk.one, fk.m32, w.buckets.as<xyzz_t>());
+          if (d_points29) {
+              msm_accumulate_bucket29_kernel<F><<<cdiv(nb_total / 2, 256), 256, 0, st>>>(nb_total, ss.SB, w.start.as<uint32_t>(), w.order.as<uint32_t>(), w.sorted.as<uint32_t>(), d_points29, fk.one, fk.m32,
+                                                                                     w.buckets.as<xyzz_t>(), w.info.as<uint32_t>(), w.redo.as<uint32_t>());
+              msm_bucket_redo_kernel<F><<<16, 64, 0, st>>>(w.start.as<uint32_t>(), w.info.as<uint32_t>(), w.redo.as<uint32_t>(), w.sorted.as<uint32_t>(), d_points, fk.one, w.buckets.as<xyzz_t>());
+          }
           else msm_accumulate_bucket_kernel<F><<<cdiv(nb_total / 2, 256), 256, 0, st>>>(nb_total, ss.SB, w.start.as<uint32_t>(), w.order.as<uint32_t>(), w.sorted.as<uint32_t>(), d_points, fk.one, w.buckets.as<xyzz_t>()); }
         { ProfScope ps_(c, PS_BUCKET_SUM);
           msm_bucket_heavy_entries_kernel<F><<<128, 256, 0, st>>>(w.start.as<uint32_t>(), w.info.as<uint32_t>(), w.heavy.as<uint32_t>(), w.sorted.as<uint32_t>(), d_points, fk.one, w.buckets.as<xyzz_t>()); }
     } else {
         { ProfScope ps_(c, PS_ACCUMULATE);
-          if (d_points29) msm_accumulate29_kernel<F><<<cdiv(max_tasks, 256), 256, 0, st>>>(nb_total, w.start.as<uint32_t>(), w.task_start.as<uint32_t>(),
-                                                                       w.rem_bucket.as<uint32_t>(), w.info.as<uint32_t>(), w.sorted.as<uint32_t>(), d_points29, fk.one, fk.m32, w.partial.as<xyzz_t>());
+          if (d_points29) {
+              msm_accumulate29_kernel<F><<<cdiv(max_tasks, 256), 256, 0, st>>>(nb_total, w.start.as<uint32_t>(), w.task_start.as<uint32_t>(), w.rem_bucket.as<uint32_t>(), w.info.as<uint32_t>(),
+                                                                       w.sorted.as<uint32_t>(), d_points29, fk.one, fk.m32, w.partial.as<xyzz_t>(), w.info.as<uint32_t>(), w.redo.as<uint32_t>());
+              // the tasks handed back (none on SRS points): the 8 x 32 kernel over the redo queue -- a full-size launch whose lanes beyond info[3] leave at once
+              msm_accumulate_kernel<F><<<cdiv(max_tasks, 256), 256, 0, st>>>(nb_total, w.start.as<uint32_t>(), w.task_start.as<uint32_t>(), w.rem_bucket.as<uint32_t>(), w.info.as<uint32_t>(),
+                                                                     w.sorted.as<uint32_t>(), d_points, fk.one, w.partial.as<xyzz_t>(), w.redo.as<uint32_t>());
+          }
           else msm_accumulate_kernel<F><<<cdiv(max_tasks, 256), 256, 0, st>>>(nb_total, w.start.as<uint32_t>(), w.task_start.as<uint32_t>(),
                                                                        w.rem_bucket.as<uint32_t>(), w.info.as<uint32_t>(), w.sorted.as<uint32_t>(), d_points, fk.one, w.partial.as<xyzz_t>()); }
         { ProfScope ps_(c, PS_BUCKET_SUM);

@@ -11,7 +11,7 @@
 //   * accumulator coordinates stay below 6 p (x), 2 p (y), 3 p (zz, zzz); table coordinates are canonical (< p), stored as x * 2^261 mod p
 // The exceptional cases of the group law (the two points equal or opposite: P = 0 mod p) are found EXACTLY: a multiple k p = k 2^254 + k c of p below
 // 16 p has limbs 5..7 and the low 22 bits of limb 8 zero (k c < 2^129) -- four instructions per add -- and only then limbs 0..4 are compared with k c;
-// such an add takes the 8 x 32 law through a domain change (never on SRS points; it keeps the kernels exact on any input).
+// the unit of work (bucket / task) that meets one is handed to the 8 x 32 law (never on SRS points; it keeps the kernels exact on any input).
 #pragma once
 #include "ec.cuh"
 #include "fp29.cuh"
@@ -49,27 +49,22 @@ template <int F> MB_HD bool fe29_is_multiple_of_p(const fe29_t &a) {
 // x * 2^261 (lazy, below 16 p) -> x * 2^256, canonical words; and back
 template <int F> __device__ __forceinline__ fe_t fe29_leave(const fe29_t &a, const fe29_t &leave /* the integer 2^256 mod p */) { return fe_cond_sub_p<F>(fe29_to_words(fe29_mul_asm<F>(a, leave))); }
 
-// the exceptional add (P = 0 mod p: the points are equal or opposite) through the 8 x 32 law; kept out of line: it never runs on SRS points
-template <int F> __device__ __noinline__ void xyzz29_add_affine_rare(xyzz29_t &acc, bool &inf, const fe29_t &qx, const fe29_t &qy, const fe_t &one, const fe_t &m32) {
-    const fe29_t leave = fe29_from_words(one);
-    xyzz_t a; a.x = fe29_leave<F>(acc.x, leave); a.y = fe29_leave<F>(acc.y, leave); a.zz = fe29_leave<F>(acc.zz, leave); a.zzz = fe29_leave<F>(acc.zzz, leave);
-    xyzz_add_affine<F>(a, fe29_leave<F>(qx, leave), fe29_leave<F>(qy, leave), one);
-    inf = xyzz_is_inf(a);
-    acc.x = fe29_from_words(fe_mul<F>(a.x, m32)); acc.y = fe29_from_words(fe_mul<F>(a.y, m32)); acc.zz = fe29_from_words(fe_mul<F>(a.zz, m32)); acc.zzz = fe29_from_words(fe_mul<F>(a.zzz, m32));
-}
-
-// acc += (qx, qy): affine, not infinity, coordinates canonical in the 2^261 domain  (madd-2008-s; ec.cuh xyzz_add_affine on the other limbs)
-template <int F> __device__ __forceinline__ void xyzz29_add_affine(xyzz29_t &acc, bool &inf, const fe29_t &qx, const fe29_t &qy, const fe_t &one, const fe_t &m32) {
-    if (inf) { acc.x = qx; acc.y = qy; acc.zz = fe29_from_words(m32); acc.zzz = acc.zz; inf = false; return; }      // 1 in the 2^261 domain = the integer 2^261 mod p
+// acc += (qx, qy): affine, not infinity, coordinates canonical in the 2^261 domain  (madd-2008-s; ec.cuh xyzz_add_affine on the other limbs).
+// Returns FALSE -- acc untouched -- in the exceptional case (the points are equal or opposite: P = 0 mod p): the caller hands its unit of work to the
+// 8 x 32 law (msm.cuh: the redo queue).  No call, no second code path inside the hot loop: an out-of-line fallback cost the kernel 53 VGPRs and 288 B of
+// scratch per lane (the call ABI) and made it SLOWER than the 8 x 32 kernel (C2: 8.6 k checks/s against 11.4 k).
+template <int F> __device__ __forceinline__ bool xyzz29_add_affine(xyzz29_t &acc, bool &inf, const fe29_t &qx, const fe29_t &qy, const fe_t &m32) {
+    if (inf) { acc.x = qx; acc.y = qy; acc.zz = fe29_from_words(m32); acc.zzz = acc.zz; inf = false; return true; }   // 1 in the 2^261 domain = the integer 2^261 mod p
     const fe29_t u2 = fe29_mul_asm<F>(qx, acc.zz), s2 = fe29_mul_asm<F>(qy, acc.zzz);                              // < 3 p
     const fe29_t pd = fe29_sub_kp<F, 8>(u2, acc.x), r = fe29_sub_kp<F, 8>(s2, acc.y);                                // < 11 p
     if (__builtin_expect((pd.v[5] | pd.v[6] | pd.v[7] | (pd.v[8] & 0x3fffffu)) == 0u, 0))
-        if (fe29_is_multiple_of_p<F>(pd)) { xyzz29_add_affine_rare<F>(acc, inf, qx, qy, one, m32); return; }
+        if (fe29_is_multiple_of_p<F>(pd)) return false;
     const fe29_t pp = fe29_sqr_asm<F>(pd), ppp = fe29_mul_asm<F>(pd, pp), q = fe29_mul_asm<F>(acc.x, pp);           // < 2 p, < 1.2 p, < 1.1 p
     const fe29_t x3 = fe29_sub_kp<F, 4>(fe29_sqr_asm<F>(r), fe29_add(ppp, fe29_add(q, q)));                          // r^2 + 4 p - (ppp + 2 q) < 6 p
     const fe29_t y3 = fe29_dot2_asm<F>(r, fe29_sub_kp<F, 8>(q, x3), fe29_sub_kp<F, 8>(fe29_zero(), acc.y), ppp);     // r (q - x3) - y1 ppp, one reduction: < 2 p
     acc.zz = fe29_mul_asm<F>(acc.zz, pp); acc.zzz = fe29_mul_asm<F>(acc.zzz, ppp);
     acc.x = x3; acc.y = y3;
+    return true;
 }
 // the bucket value in the 8 x 32 form the rest of the MSM reads (canonical Montgomery-2^256 XYZZ; infinity = zz 0)
 template <int F> __device__ __forceinline__ xyzz_t xyzz29_leave(const xyzz29_t &acc, bool inf, const fe_t &one) {

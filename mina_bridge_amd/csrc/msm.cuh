@@ -242,7 +242,7 @@ msm_scan_kernel(uint32_t nb_total, const uint32_t *__restrict__ count, uint32_t 
 #pragma unroll
         for (int k = 0; k < NV; ++k) carry[k] += tot[k];
     }
-    if (tid == 0) { start[nb_total] = carry[0]; full_start[nb_total] = carry[1]; info[0] = carry[1]; info[2] = 0; }   // info[2]: heavy-bucket counter (K1e)
+    if (tid == 0) { start[nb_total] = carry[0]; full_start[nb_total] = carry[1]; info[0] = carry[1]; info[2] = 0; info[3] = 0; }   // info[2]: heavy-bucket counter (K1e); info[3]: redo counter of the 29-bit accumulate kernels
 }
 
 // ---------------------------------------------------------------- K1p: partitioned counting sort (no global atomics)
@@ -345,7 +345,7 @@ static constexpr int PS_KEEP = 12;
 static __global__ void __launch_bounds__(1024)
 msm_part_sort_kernel(SortShape ss, const uint32_t *__restrict__ goff, const uint2 *__restrict__ staging,
                      uint32_t *__restrict__ count, uint32_t *__restrict__ sorted, uint32_t *__restrict__ info) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) info[2] = 0;                       // heavy-bucket counter of K1t-a (K1b zeroes its own)
+    if (blockIdx.x == 0 && threadIdx.x == 0) { info[2] = 0; info[3] = 0; }     // heavy-bucket counter of K1t-a (K1b zeroes its own); redo counter of the 29-bit accumulate kernels
     __shared__ uint32_t hist[2048], over[2048];
     __shared__ uint32_t s_tot[1][16], s_pre[1][16], s_all[1];
     const uint32_t tid = threadIdx.x, pg = blockIdx.x, nf = 1u << ss.fbits;
@@ -426,9 +426,10 @@ __global__ void __launch_bounds__(256)
 msm_accumulate_kernel(uint32_t nb_total, const uint32_t *__restrict__ start, const uint32_t *__restrict__ full_start,
                       const uint32_t *__restrict__ rem_bucket, const uint32_t *__restrict__ info,
                       const uint32_t *__restrict__ sorted, const affine_t *__restrict__ points, fe_t one,
-                      xyzz_t *__restrict__ partial) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+                      xyzz_t *__restrict__ partial, const uint32_t *__restrict__ redo = nullptr) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t nfull = info[0], nrem = info[1];
+    if (redo) { if (t >= info[3]) return; t = redo[t]; }        // redo mode: lane i takes task redo[i], the tasks the 29-bit kernel handed back; lanes beyond info[3] leave at once
     if (t >= nfull + nrem) return;
     uint32_t b, j;
     if (t < nfull) {
@@ -626,12 +627,13 @@ msm_accumulate_bucket_kernel(uint32_t nb_total, uint32_t nb_prob, const uint32_t
 }
 
 // K1t-b on 29-bit limbs (ec29.cuh): the same lanes, the same order of additions, points gathered from the 2^261-domain twin of the window table; the
-// bucket leaves in the 8 x 32 form.  4 waves per SIMD (the limbs' working set is smaller: 16.5 against 16.2 G adds/s at 2, tools/probes/batch_affine_probe).
+// bucket leaves in the 8 x 32 form.  8-MSM launch alone on the GPU: 575 us against 685 us for the 8 x 32 kernel (profiles/r04_k1.md); the residency cap makes
+// no difference here (2 / 3 / 4 / 8 waves per SIMD: 12.5 - 12.6 k checks/s): kept at the 8 x 32 kernel's 2.
 template <int F>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 4)))
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
 msm_accumulate_bucket29_kernel(uint32_t nb_total, uint32_t nb_prob, const uint32_t *__restrict__ start, const uint32_t *__restrict__ order,
                                const uint32_t *__restrict__ sorted, const affine_t *__restrict__ points29, fe_t one, fe_t m32,
-                               xyzz_t *__restrict__ buckets) {
+                               xyzz_t *__restrict__ buckets, uint32_t *__restrict__ info, uint32_t *__restrict__ redo) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= nb_total / 2) return;
@@ -641,25 +643,45 @@ msm_accumulate_bucket29_kernel(uint32_t nb_total, uint32_t nb_prob, const uint32
         const uint32_t b = order[m * nb_prob + (half ? nb_prob - 1 - lr : lr)];
         const uint32_t beg = start[b], cnt = start[b + 1] - beg;
         if (cnt > MSM_HEAVY_ENTRIES) continue;                   // K1t-c writes it
-        xyzz29_t acc; bool inf = true;
+        xyzz29_t acc; bool inf = true, exact = true;
         if (cnt) {
             uint32_t ref = sorted[beg], ref_n = cnt > 1 ? sorted[beg + 1] : 0u;
             affine_t nxt = load_affine(points29 + (ref & 0x7fffffffu));
 #pragma unroll 1
-            for (uint32_t e = 0; e < cnt; ++e) {
+            for (uint32_t e = 0; e < cnt && exact; ++e) {
                 const affine_t p = nxt;
                 const uint32_t cur = ref;
                 ref = ref_n;
                 if (e + 1 < cnt) nxt = load_affine(points29 + (ref & 0x7fffffffu));
                 if (e + 2 < cnt) ref_n = sorted[beg + e + 2];
-                if (aff_is_inf(p)) continue;
+                if (fe_is_zero(p.y)) continue;                   // infinity is (0, 0); no point of these prime-order curves has y = 0
                 const fe29_t px = fe29_from_words(p.x), py = fe29_from_words(p.y);
-                xyzz29_add_affine<F>(acc, inf, px, (cur >> 31) ? fe29_sub_kp<F, 1>(fe29_zero(), py) : py, one, m32);     // -y = p - y: canonical again (y != 0 on these curves)
+                exact = xyzz29_add_affine<F>(acc, inf, px, (cur >> 31) ? fe29_sub_kp<F, 1>(fe29_zero(), py) : py, m32);     // -y = p - y (y != 0 on these curves)
             }
         }
-        buckets[b] = xyzz29_leave<F>(acc, inf, one);
+        if (exact) buckets[b] = xyzz29_leave<F>(acc, inf, one);
+        else redo[atomicAdd(&info[3], 1u)] = b;                  // two of its points are equal or opposite: msm_bucket_redo_kernel sums this bucket with the 8 x 32 law
     }
 #endif
+}
+// the buckets the 29-bit kernel handed back (info[3] of them; none on SRS points): one lane each, the 8 x 32 law with all its cases.  Fixed-size launch.
+template <int F>
+__global__ void __launch_bounds__(64)
+msm_bucket_redo_kernel(const uint32_t *__restrict__ start, const uint32_t *__restrict__ info, const uint32_t *__restrict__ redo,
+                       const uint32_t *__restrict__ sorted, const affine_t *__restrict__ points, fe_t one, xyzz_t *__restrict__ buckets) {
+    const uint32_t n = info[3];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t b = redo[i], beg = start[b], end = start[b + 1];
+        xyzz_t acc = xyzz_inf();
+        for (uint32_t e = beg; e < end; ++e) {
+            const uint32_t ref = sorted[e];
+            affine_t p = load_affine(points + (ref & 0x7fffffffu));
+            if (aff_is_inf(p)) continue;
+            if (ref >> 31) p.y = fe_neg<F>(p.y);
+            xyzz_add_affine<F>(acc, p.x, p.y, one);
+        }
+        buckets[b] = acc;
+    }
 }
 // K1d on 29-bit limbs: one lane per task of <= 8 entries (the single-MSM form)
 template <int F>
@@ -667,7 +689,7 @@ __global__ void __launch_bounds__(256)
 msm_accumulate29_kernel(uint32_t nb_total, const uint32_t *__restrict__ start, const uint32_t *__restrict__ full_start,
                         const uint32_t *__restrict__ rem_bucket, const uint32_t *__restrict__ info,
                         const uint32_t *__restrict__ sorted, const affine_t *__restrict__ points29, fe_t one, fe_t m32,
-                        xyzz_t *__restrict__ partial) {
+                        xyzz_t *__restrict__ partial, uint32_t *__restrict__ info_rw, uint32_t *__restrict__ redo) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t nfull = info[0], nrem = info[1];
@@ -683,20 +705,21 @@ msm_accumulate29_kernel(uint32_t nb_total, const uint32_t *__restrict__ start, c
     uint32_t refs[MSM_TASK_LEN];
 #pragma unroll
     for (int e = 0; e < MSM_TASK_LEN; ++e) refs[e] = ((uint32_t)e < cnt) ? sorted[beg + e] : 0u;
-    xyzz29_t acc; bool inf = true;
+    xyzz29_t acc; bool inf = true, exact = true;
     affine_t nxt = load_affine(points29 + (refs[0] & 0x7fffffffu));
 #pragma unroll 1
-    for (uint32_t e = 0; e < cnt; ++e) {
+    for (uint32_t e = 0; e < cnt && exact; ++e) {
         const affine_t p = nxt;
         const uint32_t ref = refs[0];
 #pragma unroll
         for (int q = 0; q + 1 < MSM_TASK_LEN; ++q) refs[q] = refs[q + 1];
         if (e + 1 < cnt) nxt = load_affine(points29 + (refs[0] & 0x7fffffffu));
-        if (aff_is_inf(p)) continue;
+        if (fe_is_zero(p.y)) continue;                           // infinity is (0, 0); no point of these prime-order curves has y = 0
         const fe29_t px = fe29_from_words(p.x), py = fe29_from_words(p.y);
-        xyzz29_add_affine<F>(acc, inf, px, (ref >> 31) ? fe29_sub_kp<F, 1>(fe29_zero(), py) : py, one, m32);
+        exact = xyzz29_add_affine<F>(acc, inf, px, (ref >> 31) ? fe29_sub_kp<F, 1>(fe29_zero(), py) : py, m32);
     }
-    partial[t] = xyzz29_leave<F>(acc, inf, one);
+    if (exact) partial[t] = xyzz29_leave<F>(acc, inf, one);
+    else redo[atomicAdd(&info_rw[3], 1u)] = t;                   // msm_accumulate_kernel<F> in redo mode sums this task with the 8 x 32 law
 #endif
 }
 // the 2^261-domain twin of a window table: every coordinate times 32 (one Montgomery product by mont(32)); infinity (0, 0) stays
