@@ -81,6 +81,17 @@ def pstate_traffic():
         return None, None
 
 
+def msm_traffic(c2_rate):
+    """HBM-side bytes of one 2^16 accumulator check, every kernel of it, from the tracked summary of the rocprofv3 PMC passes (profiles/msm_traffic.json:
+    FETCH_SIZE with the gfx950 factor 2 on the coalesced streams and the CALIBRATED factor 1 on the accumulate kernels' random 64-B gathers, + WRITE_SIZE)"""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "msm_traffic.json")))
+        return {"traffic": t["hbm_bytes_per_check"], "traffic_ratio_to_algorithmic": t["ratio_to_algorithmic"], "traffic_GBps": c2_rate * t["hbm_bytes_per_check"] / 1e9,
+                "traffic_frac_of_peak": c2_rate * t["hbm_bytes_per_check"] / 1e9 / HBM_PEAK_GBPS, "traffic_source": "profiles/msm_traffic.json (" + t["source"] + ")"}
+    except (OSError, KeyError, ValueError):
+        return {"traffic": None}
+
+
 def le32(x: int) -> np.ndarray:
     return np.frombuffer(int(x).to_bytes(32, "little"), np.uint8)
 
@@ -783,11 +794,11 @@ def main():
             "c2_accumulator_only": {"value": c2_rate, "unit": "accumulator checks/s",
                                     "note": "BASELINE config C2 alone (round 1's headline): un-folded 2^16-base Vesta IPA accumulator checks, 8 per call, 16 lanes",
                                     # the metric's second half ("MSM HBM GB/s vs peak"): one check = one 2^16-base MSM; algorithmic bytes = bases + scalars
-                                    "msm_hbm": None if not c2_rate else {"algorithmic_bytes_per_msm": 65536 * (64 + 32), "achieved_GBps": c2_rate * 65536 * 96 / 1e9, "peak_GBps": HBM_PEAK_GBPS,
-                                                                         "frac": c2_rate * 65536 * 96 / 1e9 / HBM_PEAK_GBPS,
-                                                                         "note": "the bucket MSM is bound by the group law's multiply-accumulates (msm_accumulate_bucket_kernel 58 % of a check, "
-                                                                                 "bucket reductions 19 %: tools/c2_rate.py under rocprofv3), not by HBM; with the 16-window fixed-base tables the kernel "
-                                                                                 "actually reads 64 MiB per MSM (~10x the algorithmic bytes) and is still far from the HBM roof"}},
+                                    "msm_hbm": None if not c2_rate else {"algorithmic_bytes_per_msm": 65536 * (64 + 32) + 96, "achieved_GBps": c2_rate * (65536 * 96 + 96) / 1e9, "peak_GBps": HBM_PEAK_GBPS,
+                                                                         "frac": c2_rate * (65536 * 96 + 96) / 1e9 / HBM_PEAK_GBPS, **msm_traffic(c2_rate),
+                                                                         "note": "the bucket MSM is bound by the group law's multiply-accumulates (the accumulate kernel: 72 of the 79 us per check, on 29-bit limbs "
+                                                                                 "since round 4: profiles/r04_k1.md), not by HBM; the fixed-base window tables trade bandwidth for doubling chains: "
+                                                                                 "one 64-B point gathered per (base, window)"}},
         }
         if kern_us:
             peak = CHIP_SIMDS * 64 * CLOCK_HZ / MAD_ISSUE_CYCLES
