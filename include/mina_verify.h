@@ -384,6 +384,14 @@ int mina_state_jobs_prepare(mina_ctx *ctx, uint32_t log2_domain, uint32_t npub);
  * d_verdicts: batch u32, 1 = proof accepted.  d_flags (may be NULL): 4 u32 {folded IPA ok, IPA input malformed, folded accumulator ok, 0};
  * when a folded check fails every verdict of the batch is 0 (the host-buffer form below then finds the culprits). */
 int mina_state_job_batch_dev(mina_ctx *ctx, const mina_state_jobs *jobs, void *d_verdicts, void *d_flags);
+/* SURVEY.md 8e.2 for the whole job -- several GPUs, ONE exchange step (the multi-GPU variant north_star names): this shard's proofs through every stage of the
+ * job except the two fixed-base MSMs and their comparisons; the shard's folded scalar vectors and variable-base partial sums are handed to the caller instead
+ * (device buffers: d_ipa_scalars 2^k * 32 B and d_ipa_point 17 words for the wrap openings on Pallas -- fixed-base part + point must be infinity;
+ * d_acc_scalars 2^acc_k * 32 B and d_acc_point 17 words for the step accumulators on Vesta -- fixed-base part must equal the point).  The caller
+ * exchanges the vectors (all-to-all), commits over its slice of the SRS (mina_msm_srs_range_dev) and reduces the partial points (mina_points_sum_dev):
+ * mina_bridge_amd/sharded.py ShardedStateJob.  d_verdicts[b] = the per-proof checks only.  batch >= 2, with_ipa and with_accumulator set. */
+int mina_state_job_fold_dev(mina_ctx *ctx, const mina_state_jobs *jobs, void *d_verdicts, void *d_flags, void *d_ipa_scalars, void *d_ipa_point,
+                            void *d_acc_scalars, void *d_acc_point);
 /* Host-buffer form: one upload, the pipeline, one download; on a folded failure the failing range is cut into four parts ($MINA_SEARCH_FAN) that are
  * re-checked concurrently (and failing parts cut again) so that every proof gets its own verdict byte; the opening check of well-formed
  * proofs is re-checked from the rows of the failed batch, without repeating the transcripts. */

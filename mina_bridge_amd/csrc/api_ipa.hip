@@ -336,6 +336,9 @@ __global__ void xyzz_eq_affine_kernel(const xyzz_t *__restrict__ a, const uint32
 
 // ------------------------------------------------------------------------------------------------
 // a10: accumulator check
+// exchange variant: the shard's folded check is decided by the caller; here only "this shard held no malformed point"
+__global__ void fold_export_flag_kernel(const uint32_t *__restrict__ malformed, uint32_t *__restrict__ verdict) { if (threadIdx.x == 0) verdict[0] = malformed[0] ? 0u : 1u; }
+
 int mb_accumulator_check_dev(mina_ctx *c, int curve, uint32_t k, size_t batch, const uint32_t *d_prechal,
                                  const uint32_t *d_sg_words, const uint32_t *d_rho, uint32_t *d_verdict) {
     SrsState &s = c->srs[curve];
@@ -353,6 +356,17 @@ int mb_accumulator_check_dev(mina_ctx *c, int curve, uint32_t k, size_t batch, c
     } else {
         DISPATCH_FIELD(FS, { challenge_to_field_kernel<F_><<<cdiv(batch * k, 64), 64, 0, c->L->stream>>>((uint32_t)(batch * k), c->fk[F_], d_prechal, c->L->ipa_chals.as<uint32_t>()); });
         if ((rc = mb_bpoly_fold(c, FS, k, batch, c->L->ipa_chals.as<uint32_t>(), d_rho, c->L->ipa_folded.as<uint32_t>()))) return rc;
+    }
+    if (c->fold_export && batch > 1) {       // the exchange variant over several GPUs: the caller folds the shards' vectors and runs the MSM over its slice of the bases
+        HIPC(hipMemcpyAsync(c->fold_export->acc_scalars, c->L->ipa_folded.p, (size_t)n * 32, hipMemcpyDeviceToDevice, c->L->stream));
+        if ((rc = c->L->ipa_points.ensure(batch * sizeof(affine_t)))) return rc;
+        if ((rc = c->L->ipa_sigma.ensure(4))) return rc;
+        HIPC(hipMemsetAsync(c->L->ipa_sigma.p, 0, 4, c->L->stream));
+        DISPATCH_FIELD(FB, { points_to_mont_checked_kernel<F_><<<cdiv(batch, 256), 256, 0, c->L->stream>>>((uint32_t)batch, d_sg_words, c->fk[F_], c->L->ipa_points.as<affine_t>(), c->L->ipa_sigma.as<uint32_t>()); });
+        if ((rc = mb_msm_variable(c, curve, (uint32_t)batch, d_rho, c->L->ipa_points.p, c->fold_export->acc_point, nullptr))) return rc;
+        fold_export_flag_kernel<<<1, 64, 0, c->L->stream>>>(c->L->ipa_sigma.as<uint32_t>(), d_verdict);      // verdict word = "no malformed commitment in this shard"
+        HIPC(hipGetLastError());
+        return MINA_OK;
     }
     if ((rc = mb_msm_fixed(c, curve, n, c->L->ipa_folded.as<uint32_t>(), nullptr, c->L->ipa_xyzz_a.p))) return rc;
     if (batch == 1) {
@@ -523,6 +537,13 @@ int mb_ipa_batch_check_dev(mina_ctx *c, int curve, mb::IpaShape sh, const mb::Ip
     HIPC(hipGetLastError());
     if (sh.nshared) { DISPATCH_FIELD(FS, { mb::ipa_shared_tail_kernel<F_><<<sh.nshared, 256, 0, c->L->stream>>>(sh.batch, sh.nshared, sh.per, c->L->ipa_shared.as<uint32_t>(), c->L->ipa_scalars.as<uint32_t>()); }); }
     if ((rc = mb_bpoly_fold(c, FS, k, batch, c->L->ipa_chals.as<uint32_t>(), c->L->ipa_sigma.as<uint32_t>(), c->L->ipa_folded.as<uint32_t>()))) return rc;
+    if (c->fold_export) {                        // the exchange variant over several GPUs: scalars and the variable-base partial go to the caller
+        HIPC(hipMemcpyAsync(c->fold_export->ipa_scalars, c->L->ipa_folded.p, ((size_t)1 << k) * 32, hipMemcpyDeviceToDevice, c->L->stream));
+        if ((rc = mb_msm_variable(c, curve, (uint32_t)npoints, c->L->ipa_scalars.as<uint32_t>(), c->L->ipa_points.p, c->fold_export->ipa_point, nullptr))) return rc;
+        fold_export_flag_kernel<<<1, 64, 0, c->L->stream>>>(d_verdict + 1, d_verdict);     // [1] = malformed flag of the transcripts -> [0] = 1 unless malformed
+        HIPC(hipGetLastError());
+        return MINA_OK;
+    }
     if ((rc = mb_msm_fixed(c, curve, 1u << k, c->L->ipa_folded.as<uint32_t>(), nullptr, c->L->ipa_xyzz_a.p))) return rc;
     if ((rc = mb_msm_variable(c, curve, (uint32_t)npoints, c->L->ipa_scalars.as<uint32_t>(), c->L->ipa_points.p, nullptr, c->L->ipa_xyzz_b.p))) return rc;
     DISPATCH_FIELD(FB, { xyzz_compare_kernel<F_><<<1, 64, 0, c->L->stream>>>(c->L->ipa_xyzz_a.as<xyzz_t>(), c->L->ipa_xyzz_b.as<xyzz_t>(), 1, d_verdict, d_verdict + 1); });

@@ -482,6 +482,31 @@ extern "C" int mina_state_job_batch_dev(mina_ctx *c, const mina_state_jobs *jobs
     return mb_state_jobs_on_lane(c, jobs, (uint32_t *)d_verdicts, (uint32_t *)d_flags, nullptr, nullptr, nullptr, nullptr);
 }
 
+// SURVEY.md 8e.2 for the WHOLE job (the `north_star` variant: "a single reduce of partial sums over xGMI"): this shard's proofs go through every stage of the
+// job -- state hashes, statements, kimchi, the opening transcripts, both folds -- but the two fixed-base MSMs and their comparisons are left to the caller,
+// who exchanges the shards' folded scalar vectors (all-to-all), commits over its slice of the bases and reduces the partial points (mina_bridge_amd/sharded.py
+// ShardedStateJob).  Written here, all in HBM: d_ipa_scalars 2^k x 32 B (Pallas, the wrap openings' sum_b sigma_b s_b), d_ipa_point 17 words (the shard's
+// variable-base partial sum of the opening check, to be ADDED to the fixed-base part: the batch passes iff the total is the point at infinity),
+// d_acc_scalars 2^acc_k x 32 B (Vesta, sum_b rho_b s_b of the step accumulators), d_acc_point 17 words (sum_b rho_b sg_b: must EQUAL the fixed-base part).
+// d_verdicts[b] = every per-proof check of proof b (chain, linkage, statement, well-formed inputs) -- the folded checks are the caller's to AND in.
+// Needs at least 2 proofs and both folded legs (with_ipa, with_accumulator).  The folding randomisers of the job are the shard's own (independent of the
+// other shards').
+extern "C" int mina_state_job_fold_dev(mina_ctx *c, const mina_state_jobs *jobs, void *d_verdicts, void *d_flags, void *d_ipa_scalars, void *d_ipa_point,
+                                       void *d_acc_scalars, void *d_acc_point) {
+    int rc = check_jobs(c, jobs);
+    if (rc) return rc;
+    if (!d_verdicts || !d_ipa_scalars || !d_ipa_point || !d_acc_scalars || !d_acc_point) return fail(MINA_ERR_ARG, "null argument");
+    if (jobs->batch < 2 || !jobs->with_ipa || !jobs->with_accumulator || !jobs->acc_rho) return fail(MINA_ERR_ARG, "the exchange variant needs >= 2 proofs and both folded legs");
+    if (!c->have_state_salts && jobs->with_states) return fail(MINA_ERR_STATE, "call mina_state_jobs_prepare first");
+    HIPC(hipSetDevice(c->device));
+    c->next_lane();
+    mina_ctx::FoldExport fe; fe.ipa_scalars = (uint32_t *)d_ipa_scalars; fe.ipa_point = (uint32_t *)d_ipa_point; fe.acc_scalars = (uint32_t *)d_acc_scalars; fe.acc_point = (uint32_t *)d_acc_point;
+    c->fold_export = &fe;
+    rc = mb_state_jobs_on_lane(c, jobs, (uint32_t *)d_verdicts, (uint32_t *)d_flags, nullptr, nullptr, nullptr, nullptr);
+    c->fold_export = nullptr;
+    return rc;
+}
+
 // host-buffer form: one upload of every section, the pipeline, one download; when a folded check fails the proofs are
 // re-checked in parts (32-way cuts, the parts of a round concurrently) so that every proof gets its own verdict (README.md:281-310: every failure is `false`)
 namespace {

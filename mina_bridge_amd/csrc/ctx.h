@@ -135,6 +135,9 @@ struct mina_ctx {
     bool legs_forked = false;        // the job being queued runs its legs on separate streams (api_state.hip)
     size_t state_hashes_early = 0;   // states of the next job's protocol-state leg already queued on its lane (mb_state_hashes_early), consumed by mb_state_jobs_on_lane
     uint32_t hash_piece_waves = 0;   // > 0: the protocol-state hashes of a job are launched in pieces of this many waves (api_state.hip pstate_hash_dev)
+    // SURVEY.md 8e.2 (one exchange step over several GPUs): while set, the folded checks of a job do NOT run their fixed-base MSM and comparison -- they hand out
+    // this shard's folded scalar vector and the 17-word record of its variable-base partial sum instead (mina_state_job_fold_dev); device pointers
+    struct FoldExport { uint32_t *ipa_scalars = nullptr, *ipa_point = nullptr, *acc_scalars = nullptr, *acc_point = nullptr; } *fold_export = nullptr;
     void use_lane0() { L = &lanes[0]; }
     void next_lane() { L = &lanes[rr++ % (unsigned)nlanes]; }
 };

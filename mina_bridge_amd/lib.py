@@ -35,7 +35,7 @@ EXPORTS = [
     "mina_accumulator_check_batch", "mina_accumulator_check_dev", "mina_accumulator_check_multi_dev", "mina_accumulator_check_multi", "mina_ipa_batch_check",
     "mina_consensus_project_window", "mina_consensus_relative_min_window_density", "mina_consensus_is_short_range",
     "mina_protocol_state_pack", "mina_protocol_state_hash_batch", "mina_protocol_state_hash_bytes",
-    "mina_state_jobs_prepare", "mina_state_job_batch_dev", "mina_state_job_batch",
+    "mina_state_jobs_prepare", "mina_state_job_batch_dev", "mina_state_job_batch", "mina_state_job_fold_dev",
     "mina_challenge_to_field_dev", "mina_field_sum_rows_dev", "mina_msm_srs_range_dev", "mina_msm_dev", "mina_points_sum_dev", "mina_point_records_equal_dev",
     "mina_step_index_install", "mina_step_index_load_json", "mina_polish_tokens_from_json", "mina_verifier_index_load_json", "mina_pickles_public_input",
     "mina_verifier_index_install", "mina_verifier_index_digest", "mina_kimchi_to_batch", "mina_pickles_public_inputs_batch", "mina_wrap_proof_flatten", "mina_state_proof_split",
@@ -1147,6 +1147,12 @@ class MinaContext:
             d.kimchi = ctypes.addressof(dk)
             self._keep_dk = dk
         return d, ptrs
+
+    def state_job_fold_dev(self, d_jobs, d_verdicts: int, d_flags: int, d_ipa_scalars: int, d_ipa_point: int, d_acc_scalars: int, d_acc_point: int):
+        """SURVEY.md 8e.2 for the whole job: every stage but the two fixed-base MSMs; the shard's folded scalar vectors and variable-base partials go to the caller"""
+        self._ck(self._lib.mina_state_job_fold_dev(self._h, ctypes.byref(d_jobs), ctypes.c_void_p(d_verdicts), ctypes.c_void_p(d_flags) if d_flags else None,
+                                                   ctypes.c_void_p(d_ipa_scalars), ctypes.c_void_p(d_ipa_point), ctypes.c_void_p(d_acc_scalars), ctypes.c_void_p(d_acc_point)),
+                 "mina_state_job_fold_dev")
 
     def state_job_batch_dev(self, d_jobs, d_verdicts: int, d_flags: int = 0):
         self._ck(self._lib.mina_state_job_batch_dev(self._h, ctypes.byref(d_jobs), ctypes.c_void_p(d_verdicts), ctypes.c_void_p(d_flags) if d_flags else None),

@@ -48,6 +48,13 @@ class DeviceBackend:
         if self.torch.device(self.dev).type == "cuda":
             self.torch.cuda.synchronize(self.dev)
 
+    def _ready(self):
+        """torch's stream and the library's streams are asynchronous to each other: whatever torch queued (a `zeros`, a `cat`, a copy) must have happened before a
+        library kernel reads or writes the same memory.  (Found in round 4: `records_equal` zeroed its verdict word on torch's stream AFTER the library's
+        comparison kernel had written it -- a sporadic false 'not equal'.)"""
+        if self.torch.device(self.dev).type == "cuda":
+            self.torch.cuda.current_stream(self.dev).synchronize()
+
     def accumulator_verdicts(self, curve, k, pre, sg, rho):
         """per-proof verdict bytes of this rank's shard: one folded check, per-proof checks only if it fails"""
         torch = self.torch
@@ -55,11 +62,13 @@ class DeviceBackend:
         if b == 0:
             return torch.zeros(0, dtype=torch.uint8, device=self.dev)
         v = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        self._ready()
         self.ctx.accumulator_check_dev(curve, k, b, pre.data_ptr(), sg.data_ptr(), rho.data_ptr() if b > 1 else 0, v.data_ptr())
         self.sync()
         if int(v.item()) == 1:
             return torch.ones(b, dtype=torch.uint8, device=self.dev)
         out = torch.zeros(b, dtype=torch.int32, device=self.dev)
+        self._ready()
         for lo in range(0, b, 64):
             cnt = min(64, b - lo)
             self.ctx.accumulator_check_multi_dev(curve, k, cnt, pre.data_ptr() + lo * k * 16, sg.data_ptr() + lo * 64, out.data_ptr() + 4 * lo)
@@ -72,6 +81,7 @@ class DeviceBackend:
         chals = self._buf(b * k * 32); out = self._buf((1 << k) * 32)
         if b == 0:
             return out.zero_()
+        self._ready()
         self.ctx.challenge_to_field_dev(field, b * k, pre.data_ptr(), chals.data_ptr())
         self.sync()
         self.ctx.b_poly_fold_dev(field, k, b, chals.data_ptr(), rho.data_ptr(), out.data_ptr())
@@ -79,11 +89,13 @@ class DeviceBackend:
 
     def sum_rows(self, field, rows, m, stacked):
         out = self._buf(m * 32)
+        self._ready()
         self.ctx.field_sum_rows_dev(field, rows, m, stacked.data_ptr(), out.data_ptr())
         return out
 
     def msm_srs_range(self, curve, first, n, scalars):
         out = self._buf(self.RECORD)
+        self._ready()
         self.ctx.msm_srs_range_dev(curve, first, n, scalars.data_ptr(), out.data_ptr())
         return out[: self.RECORD]
 
@@ -92,16 +104,19 @@ class DeviceBackend:
         if n == 0:
             out.zero_(); out[64] = 1
             return out[: self.RECORD]
+        self._ready()
         self.ctx.msm_dev(curve, n, bases.data_ptr(), scalars.data_ptr(), out.data_ptr())
         return out[: self.RECORD]
 
     def points_sum(self, curve, n, records):
         out = self._buf(self.RECORD)
+        self._ready()
         self.ctx.points_sum_dev(curve, n, records.data_ptr(), out.data_ptr())
         return out[: self.RECORD]
 
     def records_equal(self, a, b) -> bool:
         v = self.torch.zeros(1, dtype=self.torch.int32, device=self.dev)
+        self._ready()
         self.ctx.point_records_equal_dev(a.data_ptr(), b.data_ptr(), v.data_ptr())
         self.sync()
         return bool(int(v.item()))
@@ -161,3 +176,87 @@ class ShardedAccumulatorCheck:
         L = self.b.points_sum(self.curve, G, lrec)
         R = self.b.points_sum(self.curve, G, rrec)
         return self.b.records_equal(L, R)
+
+
+class ShardedStateJob:
+    """SURVEY.md 8e.2 for the WHOLE Proof-of-State job -- the multi-GPU variant `north_star` names ("proof batches shard across the GPUs with a single
+    reduce of partial sums over xGMI"): every rank runs all per-proof stages of ITS shard (17 state hashes, Pickles statement, kimchi oracles, opening
+    transcripts, both folds; `mina_state_job_fold_dev`), then ONE exchange step decides both folded checks for the whole batch:
+      1. all-to-all of the shards' folded scalar vectors: rank r receives slice [r n/G, (r+1) n/G) of every shard's Pallas (2^k) and Vesta (2^acc_k) vector
+      2. a modular-add kernel folds the G slices; K1 runs over the rank's n/G bases of each curve (`mina_msm_srs_range_dev`)
+      3. all-gather of 4 point records per rank (its two fixed-base partials, its two variable-base partials) + one flag word
+      4. every rank folds the records with the group law (`mina_points_sum_dev`): Pallas total == infinity, Vesta fixed-base total == variable-base total
+    RCCL only transports; the reductions are this library's kernels.  The folding randomisers are per shard (independent draws): the combined check is the
+    random linear combination upstream's batch_verify forms, with the coefficients grouped by shard.
+    Returns (verdicts of THIS shard as a uint8 tensor, batch_ok).  When the batch fails, a shard whose OWN folded checks pass (it is re-run through the
+    ordinary job) keeps its per-proof verdicts; a shard that fails answers 0 for all its proofs -- the per-proof culprit search is the host-form entry point's
+    (`mina_state_job_batch`), which the caller runs on that shard alone."""
+
+    REC = 68
+
+    def __init__(self, ctx, device, k: int = 15, acc_k: int = 16, group=None):
+        import torch
+        import torch.distributed as dist
+        self.ctx, self.dev, self.k, self.acc_k, self.group = ctx, device, k, acc_k, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.cpu_collectives = dist.get_backend(group) == "gloo"          # gloo moves host tensors (the CPU / shared-GPU tests); RCCL moves HBM to HBM
+        self.be = DeviceBackend(ctx, device)
+        self.torch = torch
+
+    def _coll(self, t):
+        return t.cpu() if self.cpu_collectives else t
+
+    def _all_to_all(self, t):
+        import torch.distributed as dist
+        src = self._coll(t); out = self.torch.empty_like(src)
+        dist.all_to_all_single(out, src, group=self.group)
+        return out.to(self.dev)
+
+    def _all_gather(self, t):
+        import torch.distributed as dist
+        src = self._coll(t); outs = [self.torch.empty_like(src) for _ in range(self.world)]
+        dist.all_gather(outs, src, group=self.group)
+        return [o.to(self.dev) for o in outs]
+
+    def verify(self, d_jobs, batch: int, run_plain=None):
+        """d_jobs: the shard's `mina_state_jobs` with DEVICE pointers (lib.StateJobs), batch = its proof count (>= 2).  run_plain(d_verdicts_ptr, d_flags_ptr): the
+        ordinary job on the same shard (mina_state_job_batch_dev), used only when the exchanged check fails."""
+        torch, be, G, rec = self.torch, self.be, self.world, self.REC
+        n, na = 1 << self.k, 1 << self.acc_k
+        assert n % G == 0 and na % G == 0, "the SRS slices per rank must be whole"
+        out = torch.zeros(batch + 4, dtype=torch.int32, device=self.dev)
+        ipa_s, acc_s = be._buf(n * 32), be._buf(na * 32)
+        ipa_p, acc_p = be._buf(rec), be._buf(rec)
+        be._ready()                                                  # `out` was zeroed on torch's stream
+        self.ctx.state_job_fold_dev(d_jobs, out.data_ptr(), out.data_ptr() + 4 * batch, ipa_s.data_ptr(), ipa_p.data_ptr(), acc_s.data_ptr(), acc_p.data_ptr())
+        be.sync()
+        m, ma = n // G, na // G
+        # every tensor a queued kernel reads stays referenced until the next be.sync(): the library's streams are asynchronous to torch's allocator
+        recv_p, recv_v = self._all_to_all(ipa_s), self._all_to_all(acc_s)
+        mine_p, mine_v = be.sum_rows(1, G, m, recv_p), be.sum_rows(0, G, ma, recv_v)                        # Pallas scalars live in Fq, Vesta scalars in Fp
+        lhs_p = be.msm_srs_range(0, self.rank * m, m, mine_p)
+        lhs_v = be.msm_srs_range(1, self.rank * ma, ma, mine_v)
+        be.sync()
+        flags = out[batch: batch + 4].to(torch.uint8)                                                        # {opening legs well-formed, malformed flag, accumulators well-formed, 0}
+        mine = torch.cat([lhs_p[:rec], ipa_p[:rec], lhs_v[:rec], acc_p[:rec], flags])
+        parts = self._all_gather(mine)
+        col = lambda i: torch.cat([p[i * rec: (i + 1) * rec] for p in parts]).contiguous()
+        wellformed = all(int(p[4 * rec]) == 1 and int(p[4 * rec + 1]) == 0 and int(p[4 * rec + 2]) == 1 for p in parts)
+        inf = torch.zeros(rec, dtype=torch.uint8, device=self.dev); inf[64] = 1
+        pallas_all, vesta_l, vesta_r = torch.cat([col(0), col(1)]).contiguous(), col(2), col(3)        # (the backend orders torch's stream before the library reads them)
+        pallas_total = be.points_sum(0, 2 * G, pallas_all)                                                   # fixed-base parts + variable-base parts == infinity
+        L, R = be.points_sum(1, G, vesta_l), be.points_sum(1, G, vesta_r)
+        ok_ipa = be.records_equal(pallas_total, inf)
+        ok_acc = be.records_equal(L, R)
+        batch_ok = bool(wellformed and ok_ipa and ok_acc)
+        self.last = {"wellformed": bool(wellformed), "opening_fold_ok": bool(ok_ipa), "accumulator_fold_ok": bool(ok_acc), "flags": [p[4 * rec: 4 * rec + 4].cpu().tolist() for p in parts]}
+        local = out[:batch].to(torch.uint8)
+        if batch_ok:
+            return local, True
+        if run_plain is None:
+            return torch.zeros_like(local), False
+        plain = torch.zeros(batch + 4, dtype=torch.int32, device=self.dev)
+        be._ready()
+        run_plain(plain.data_ptr(), plain.data_ptr() + 4 * batch)
+        be.sync()
+        return plain[:batch].to(torch.uint8), False

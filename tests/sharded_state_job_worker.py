@@ -1,0 +1,49 @@
+"""One rank of tests/test_sharded_state_job.py: a shard of full-size Proof-of-State jobs through `ShardedStateJob` (SURVEY.md 8e.2 for the whole job).
+Launched with RANK / WORLD_SIZE / MASTER_* in the environment; every rank uses GPU 0 and the ranks rendezvous over gloo (a 1-GPU box), or its own GPU over
+RCCL when the box has enough of them.  argv: B_per_rank  scenario  (ok | bad_opening_on_last_rank | bad_accumulator_on_rank0).  Prints one JSON line."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
+import numpy as np
+import torch
+import torch.distributed as dist
+
+import bench
+import mina_bridge_amd as m
+from mina_bridge_amd.sharded import ShardedStateJob
+
+B, scenario = int(sys.argv[1]), sys.argv[2]
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+real = torch.cuda.device_count() >= world
+dist.init_process_group("nccl" if real else "gloo")
+dev_ix = rank if real else 0
+torch.cuda.set_device(dev_ix)
+dev = torch.device("cuda", dev_ix)
+ctx = m.MinaContext(dev_ix)
+for f in (0, 1):
+    ctx.poseidon_set_params(f, m.poseidon_params.default_params_bytes(f))
+ctx.srs_create(1, 1 << 16); ctx.srs_create(0, 1 << 16)
+(hj, keep), kp, _ = bench.build_full_job(ctx, m, B, seed=900 + rank)
+by_addr = {a.ctypes.data: a for a in keep if isinstance(a, np.ndarray)}
+bad_at = None
+if scenario == "bad_opening_on_last_rank" and rank == world - 1:
+    bad_at = B // 2; by_addr[hj.z1].view(np.uint8).reshape(B, 32)[bad_at, 0] ^= 1
+if scenario == "bad_accumulator_on_rank0" and rank == 0:
+    bad_at = 1; by_addr[hj.acc_prechallenges].view(np.uint8).reshape(B, 16, 16)[bad_at, 3, 0] ^= 1
+dj, dk, tensors = bench.device_jobs(m, hj, keep, kp, dev)
+ctx.state_jobs_prepare(bench.LOG2_DOMAIN, bench.NPUB)
+job = ShardedStateJob(ctx, dev, k=bench.WRAP_K, acc_k=bench.ACC_K)
+verdicts, ok = job.verify(dj, B, run_plain=lambda dv, df: ctx.state_job_batch_dev(dj, dv, df))
+# the ordinary single-GPU job on the same shard, for comparison
+plain = torch.zeros(B + 4, dtype=torch.int32, device=dev)
+torch.cuda.synchronize()
+ctx.state_job_batch_dev(dj, plain.data_ptr(), plain.data_ptr() + 4 * B); ctx.synchronize(); torch.cuda.synchronize()
+print(json.dumps({"rank": rank, "world": world, "backend": dist.get_backend(), "batch_ok": ok, "verdicts": verdicts.cpu().numpy().tolist(),
+                  "plain": plain[:B].cpu().numpy().tolist(), "plain_flags": plain[B:].cpu().numpy().tolist(), "bad_at": bad_at, "detail": job.last}), flush=True)
+dist.barrier()
+dist.destroy_process_group()
+ctx.close()

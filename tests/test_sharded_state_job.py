@@ -1,0 +1,50 @@
+"""SURVEY.md 8e.2 for the WHOLE Proof-of-State job (`ShardedStateJob`: per-proof stages on every rank, ONE exchange of folded scalar vectors and partial
+points, the two fixed-base MSMs base-sliced over the ranks) -- two ranks on the GPU box (sharing GPU 0 over gloo when it has one GPU, RCCL when it has two),
+full-size jobs (2^15 wrap domain, 2^16 accumulator, the committed statement fixture).  The exchanged verdict equals the single-GPU job's on every shard; a bad
+opening on one rank or a bad accumulator on the other fails the BATCH on every rank, and the fallback localises it to its shard."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_ranks(world, per_rank, scenario):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]
+    procs = []
+    for r in range(world):
+        env = {k: v for k, v in os.environ.items() if k not in ("MINA_VERIFY_DEVICES",)}
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "sharded_state_job_worker.py"), str(per_rank), scenario], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        so, se = p.communicate(timeout=900)
+        assert p.returncode == 0, (so + se)[-3000:]
+        outs.append(json.loads([ln for ln in so.splitlines() if ln.startswith('{"rank"')][-1]))
+    return sorted(outs, key=lambda o: o["rank"])
+
+
+def test_exchange_variant_equals_the_single_gpu_job_on_every_shard():
+    outs = run_ranks(2, 6, "ok")
+    for o in outs:
+        assert o["batch_ok"] is True and o["verdicts"] == [1] * 6 == o["plain"] and o["plain_flags"] == [1, 0, 1, 0], o
+
+
+def test_a_bad_opening_on_one_rank_fails_the_batch_everywhere_and_is_localised_to_its_shard():
+    outs = run_ranks(2, 6, "bad_opening_on_last_rank")
+    assert all(o["batch_ok"] is False for o in outs), "the exchanged fold answers for the whole batch: every rank sees it fail"
+    assert outs[0]["verdicts"] == [1] * 6, "the other shard's own folded checks pass: its verdicts stand"
+    assert outs[1]["verdicts"] == [0] * 6 and outs[1]["plain_flags"][0] == 0, "the failing shard answers 0 until its culprit search (mina_state_job_batch) runs"
+
+
+def test_a_bad_accumulator_fails_the_batch():
+    outs = run_ranks(2, 4, "bad_accumulator_on_rank0")
+    assert all(o["batch_ok"] is False for o in outs)
+    assert outs[0]["plain_flags"][2] == 0 and outs[0]["verdicts"] == [0] * 4 and outs[1]["verdicts"] == [1] * 4
