@@ -114,6 +114,27 @@ class DeviceBackend:
         self.ctx.points_sum_dev(curve, n, records.data_ptr(), out.data_ptr())
         return out[: self.RECORD]
 
+    def state_job_fold(self, d_jobs, batch: int, k: int, acc_k: int):
+        """this shard's job with the two fixed-base MSMs left out (mina_state_job_fold_dev): (per-proof verdicts uint8 [batch], flags uint8 [4] = {opening legs
+        well-formed, malformed flag, accumulators well-formed, 0}, folded Pallas scalars [2^k * 32], Pallas variable-base partial [68], folded Vesta scalars
+        [2^acc_k * 32], Vesta variable-base partial [68]) -- all in HBM"""
+        torch, rec = self.torch, self.RECORD
+        out = torch.zeros(batch + 4, dtype=torch.int32, device=self.dev)
+        ipa_s, acc_s, ipa_p, acc_p = self._buf((1 << k) * 32), self._buf((1 << acc_k) * 32), self._buf(rec), self._buf(rec)
+        self._ready()                                                # `out` was zeroed on torch's stream
+        self.ctx.state_job_fold_dev(d_jobs, out.data_ptr(), out.data_ptr() + 4 * batch, ipa_s.data_ptr(), ipa_p.data_ptr(), acc_s.data_ptr(), acc_p.data_ptr())
+        self.sync()
+        return out[:batch].to(torch.uint8), out[batch: batch + 4].to(torch.uint8), ipa_s, ipa_p[:rec], acc_s, acc_p[:rec]
+
+    def state_job_plain(self, d_jobs, batch: int):
+        """the ordinary job on the same shard (mina_state_job_batch_dev): per-proof verdicts with the shard's OWN folded checks"""
+        torch = self.torch
+        plain = torch.zeros(batch + 4, dtype=torch.int32, device=self.dev)
+        self._ready()
+        self.ctx.state_job_batch_dev(d_jobs, plain.data_ptr(), plain.data_ptr() + 4 * batch)
+        self.sync()
+        return plain[:batch].to(torch.uint8)
+
     def records_equal(self, a, b) -> bool:
         v = self.torch.zeros(1, dtype=self.torch.int32, device=self.dev)
         self._ready()
@@ -188,19 +209,19 @@ class ShardedStateJob:
       4. every rank folds the records with the group law (`mina_points_sum_dev`): Pallas total == infinity, Vesta fixed-base total == variable-base total
     RCCL only transports; the reductions are this library's kernels.  The folding randomisers are per shard (independent draws): the combined check is the
     random linear combination upstream's batch_verify forms, with the coefficients grouped by shard.
-    Returns (verdicts of THIS shard as a uint8 tensor, batch_ok).  When the batch fails, a shard whose OWN folded checks pass (it is re-run through the
-    ordinary job) keeps its per-proof verdicts; a shard that fails answers 0 for all its proofs -- the per-proof culprit search is the host-form entry point's
+    Returns (verdicts of THIS shard as a uint8 tensor, batch_ok).  When the batch fails every shard is re-run through the ordinary job: one whose OWN folded
+    checks pass keeps its per-proof verdicts; a shard that fails answers 0 for all its proofs -- the per-proof culprit search is the host-form entry point's
     (`mina_state_job_batch`), which the caller runs on that shard alone."""
 
     REC = 68
 
-    def __init__(self, ctx, device, k: int = 15, acc_k: int = 16, group=None):
+    def __init__(self, backend, k: int = 15, acc_k: int = 16, group=None):
+        """backend: DeviceBackend(ctx, device) on the GPU box; any object with its methods elsewhere (the CPU tests plug an oracle-backed double)"""
         import torch
         import torch.distributed as dist
-        self.ctx, self.dev, self.k, self.acc_k, self.group = ctx, device, k, acc_k, group
+        self.be, self.dev, self.k, self.acc_k, self.group = backend, backend.dev, k, acc_k, group
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         self.cpu_collectives = dist.get_backend(group) == "gloo"          # gloo moves host tensors (the CPU / shared-GPU tests); RCCL moves HBM to HBM
-        self.be = DeviceBackend(ctx, device)
         self.torch = torch
 
     def _coll(self, t):
@@ -208,28 +229,22 @@ class ShardedStateJob:
 
     def _all_to_all(self, t):
         import torch.distributed as dist
-        src = self._coll(t); out = self.torch.empty_like(src)
+        src = self._coll(t).contiguous(); out = self.torch.empty_like(src)
         dist.all_to_all_single(out, src, group=self.group)
         return out.to(self.dev)
 
     def _all_gather(self, t):
         import torch.distributed as dist
-        src = self._coll(t); outs = [self.torch.empty_like(src) for _ in range(self.world)]
+        src = self._coll(t).contiguous(); outs = [self.torch.empty_like(src) for _ in range(self.world)]
         dist.all_gather(outs, src, group=self.group)
         return [o.to(self.dev) for o in outs]
 
-    def verify(self, d_jobs, batch: int, run_plain=None):
-        """d_jobs: the shard's `mina_state_jobs` with DEVICE pointers (lib.StateJobs), batch = its proof count (>= 2).  run_plain(d_verdicts_ptr, d_flags_ptr): the
-        ordinary job on the same shard (mina_state_job_batch_dev), used only when the exchanged check fails."""
+    def verify(self, job, batch: int):
+        """job: the shard's `mina_state_jobs` with DEVICE pointers (lib.StateJobs; whatever the backend's state_job_fold takes), batch = its proof count (>= 2)"""
         torch, be, G, rec = self.torch, self.be, self.world, self.REC
         n, na = 1 << self.k, 1 << self.acc_k
         assert n % G == 0 and na % G == 0, "the SRS slices per rank must be whole"
-        out = torch.zeros(batch + 4, dtype=torch.int32, device=self.dev)
-        ipa_s, acc_s = be._buf(n * 32), be._buf(na * 32)
-        ipa_p, acc_p = be._buf(rec), be._buf(rec)
-        be._ready()                                                  # `out` was zeroed on torch's stream
-        self.ctx.state_job_fold_dev(d_jobs, out.data_ptr(), out.data_ptr() + 4 * batch, ipa_s.data_ptr(), ipa_p.data_ptr(), acc_s.data_ptr(), acc_p.data_ptr())
-        be.sync()
+        local, flags, ipa_s, ipa_p, acc_s, acc_p = be.state_job_fold(job, batch, self.k, self.acc_k)
         m, ma = n // G, na // G
         # every tensor a queued kernel reads stays referenced until the next be.sync(): the library's streams are asynchronous to torch's allocator
         recv_p, recv_v = self._all_to_all(ipa_s), self._all_to_all(acc_s)
@@ -237,7 +252,6 @@ class ShardedStateJob:
         lhs_p = be.msm_srs_range(0, self.rank * m, m, mine_p)
         lhs_v = be.msm_srs_range(1, self.rank * ma, ma, mine_v)
         be.sync()
-        flags = out[batch: batch + 4].to(torch.uint8)                                                        # {opening legs well-formed, malformed flag, accumulators well-formed, 0}
         mine = torch.cat([lhs_p[:rec], ipa_p[:rec], lhs_v[:rec], acc_p[:rec], flags])
         parts = self._all_gather(mine)
         col = lambda i: torch.cat([p[i * rec: (i + 1) * rec] for p in parts]).contiguous()
@@ -250,13 +264,6 @@ class ShardedStateJob:
         ok_acc = be.records_equal(L, R)
         batch_ok = bool(wellformed and ok_ipa and ok_acc)
         self.last = {"wellformed": bool(wellformed), "opening_fold_ok": bool(ok_ipa), "accumulator_fold_ok": bool(ok_acc), "flags": [p[4 * rec: 4 * rec + 4].cpu().tolist() for p in parts]}
-        local = out[:batch].to(torch.uint8)
         if batch_ok:
             return local, True
-        if run_plain is None:
-            return torch.zeros_like(local), False
-        plain = torch.zeros(batch + 4, dtype=torch.int32, device=self.dev)
-        be._ready()
-        run_plain(plain.data_ptr(), plain.data_ptr() + 4 * batch)
-        be.sync()
-        return plain[:batch].to(torch.uint8), False
+        return be.state_job_plain(job, batch), False

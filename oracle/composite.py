@@ -107,3 +107,17 @@ def verify_folded(proofs, threads: int, rand: bytes = None):
     lib().oc_verify_folded.restype = ctypes.c_int
     ok = lib().oc_verify_folded(arr, ctypes.c_size_t(len(proofs)), int(threads), ctypes.c_char_p(rand), out.ctypes.data_as(ctypes.c_void_p))
     return bool(ok), out
+
+
+def fold_export(proofs, threads: int, rand: bytes = None):
+    """one SHARD of the multi-GPU exchange variant on the CPU (composite_oracle.c oc_fold_export): (ipa_scalars [2^k,32], ipa_point [64], acc_scalars [2^16,32],
+    acc_point [64], ok [n]) -- the fold of `verify_folded` with the two fixed-base MSMs left to the caller.  k = the installed wrap index's domain."""
+    import os
+    rand = os.urandom(96) if rand is None else rand
+    arr = (OcProof * len(proofs))(*[p for p, _ in proofs])
+    k = 15
+    ipa_s, acc_s = np.zeros(((1 << k), 32), np.uint8), np.zeros((1 << 16, 32), np.uint8)
+    ipa_p, acc_p, ok = np.zeros(64, np.uint8), np.zeros(64, np.uint8), np.zeros(len(proofs), np.uint8)
+    P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    lib().oc_fold_export(arr, ctypes.c_size_t(len(proofs)), int(threads), ctypes.c_char_p(rand), P(ipa_s), P(ipa_p), P(acc_s), P(acc_p), P(ok))
+    return ipa_s, ipa_p, acc_s, acc_p, ok

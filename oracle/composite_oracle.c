@@ -574,9 +574,11 @@ static void *fold_worker(void *a) {
     free(s);
     return NULL;
 }
-int oc_verify_folded(const oc_proof *proofs, size_t nproofs, int threads, const uint8_t *rand32 /* 3 x 32 */, uint8_t *verdicts) {
+/* phase 1 + the reductions over threads: what the fixed-base MSMs of the batch would consume.  Sg / Tg: Montgomery, n / 2^16 entries; small lists per proof. */
+typedef struct { fe *Sg, *Tg, h_acc, *rho_acc; uint8_t *ok, *pts, *scs; size_t per, n; opening_prep *prep; fe *rho, *sigma; } fold_state;
+static void fold_free(fold_state *st) { free(st->Sg); free(st->Tg); free(st->rho_acc); free(st->ok); free(st->pts); free(st->scs); free(st->prep); free(st->rho); free(st->sigma); }
+static void fold_collect(const oc_proof *proofs, size_t nproofs, int threads, const uint8_t *rand32, fold_state *st) {
     const fctx *fp = &F[0], *fq = &F[1];
-    if (nproofs == 0) return 0;
     if (threads < 1) threads = 1;
     if ((size_t)threads > nproofs) threads = (int)nproofs;
     const int k = G.log2_domain; const size_t n = (size_t)1 << k, nacc = (size_t)1 << 16, per = (size_t)(2 * k + 47 + 4);
@@ -600,26 +602,60 @@ int oc_verify_folded(const oc_proof *proofs, size_t nproofs, int threads, const 
         for (size_t i = 0; i < nacc; ++i) f_add(&Tg[i], &Tg[i], &Tg[nacc * (size_t)t + i], fp);
         f_add(&h_acc[0], &h_acc[0], &h_acc[t], fq);
     }
+    st->Sg = Sg; st->Tg = Tg; st->h_acc = h_acc[0]; st->rho_acc = rho_acc; st->ok = ok; st->pts = pts; st->scs = scs; st->per = per; st->n = n; st->prep = prep; st->rho = rho; st->sigma = sigma;
+    free(h_acc); free(th); free(jobs);
+}
+int oc_verify_folded(const oc_proof *proofs, size_t nproofs, int threads, const uint8_t *rand32 /* 3 x 32 */, uint8_t *verdicts) {
+    const fctx *fp = &F[0], *fq = &F[1];
+    if (nproofs == 0) return 0;
+    fold_state st; fold_collect(proofs, nproofs, threads, rand32, &st);
+    const size_t n = st.n, nacc = (size_t)1 << 16, per = st.per;
     /* Pallas: g[0..n) with the folded scalars, h, then every proof's entries (zero scalars where a proof was malformed) */
     const size_t qp = n + 1 + nproofs * per;
     uint8_t *P = (uint8_t *)malloc(qp * 64), *S = (uint8_t *)malloc(qp * 32), out[64];
-    memcpy(P, G.g_pallas, n * 64); for (size_t i = 0; i < n; ++i) f_store(S + 32 * i, &Sg[i], fq);
-    memcpy(P + n * 64, G.h_pallas, 64); f_store(S + 32 * n, &h_acc[0], fq);
-    memcpy(P + (n + 1) * 64, pts, nproofs * per * 64); memcpy(S + (n + 1) * 32, scs, nproofs * per * 32);
+    memcpy(P, G.g_pallas, n * 64); for (size_t i = 0; i < n; ++i) f_store(S + 32 * i, &st.Sg[i], fq);
+    memcpy(P + n * 64, G.h_pallas, 64); f_store(S + 32 * n, &st.h_acc, fq);
+    memcpy(P + (n + 1) * 64, st.pts, nproofs * per * 64); memcpy(S + (n + 1) * 32, st.scs, nproofs * per * 32);
     oracle_msm_pippenger(0, qp, P, S, out, threads);
     int ipa_ok = 1; for (int i = 0; i < 64; ++i) if (out[i]) ipa_ok = 0;
     free(P); free(S);
     /* Vesta: g[0..2^16) with the folded scalars, then -rho'_b sg_b */
     const size_t qv = nacc + nproofs;
     P = (uint8_t *)malloc(qv * 64); S = (uint8_t *)malloc(qv * 32);
-    memcpy(P, G.g_vesta, nacc * 64); for (size_t i = 0; i < nacc; ++i) f_store(S + 32 * i, &Tg[i], fp);
-    for (size_t b = 0; b < nproofs; ++b) { fe t; f_neg(&t, &rho_acc[b], fp); memcpy(P + (nacc + b) * 64, proofs[b].acc_sg, 64); f_store(S + 32 * (nacc + b), &t, fp); }
+    memcpy(P, G.g_vesta, nacc * 64); for (size_t i = 0; i < nacc; ++i) f_store(S + 32 * i, &st.Tg[i], fp);
+    for (size_t b = 0; b < nproofs; ++b) { fe t; f_neg(&t, &st.rho_acc[b], fp); memcpy(P + (nacc + b) * 64, proofs[b].acc_sg, 64); f_store(S + 32 * (nacc + b), &t, fp); }
     oracle_msm_pippenger(1, qv, P, S, out, threads);
     int acc_ok = 1; for (int i = 0; i < 64; ++i) if (out[i]) acc_ok = 0;
     free(P); free(S);
-    for (size_t b = 0; b < nproofs; ++b) verdicts[b] = (uint8_t)(ok[b] && ipa_ok && acc_ok);
-    free(rho); free(sigma); free(rho_acc); free(prep); free(ok); free(pts); free(scs); free(Sg); free(Tg); free(h_acc); free(th); free(jobs);
+    for (size_t b = 0; b < nproofs; ++b) verdicts[b] = (uint8_t)(st.ok[b] && ipa_ok && acc_ok);
+    fold_free(&st);
     return ipa_ok && acc_ok;
+}
+/* The same fold with the fixed-base MSMs LEFT OUT: what one shard of the multi-GPU exchange variant (mina_state_job_fold_dev on the GPU) hands to
+ * the exchange step -- the folded scalar vectors (canonical bytes) and the variable-base partial sums (affine bytes; infinity = 64 zero bytes):
+ *   ipa_point = -rho-weighted h term + the per-proof entries  (to be ADDED to sum_j ipa_scalars[j] G_j: the total must be infinity)
+ *   acc_point = sum_b rho'_b sg_b                               (must EQUAL sum_j acc_scalars[j] G_j)
+ * ok[b] = the per-proof checks.  The CPU double of tests/test_sharded_gloo.py's whole-job test. */
+int oc_fold_export(const oc_proof *proofs, size_t nproofs, int threads, const uint8_t *rand32, uint8_t *ipa_scalars, uint8_t *ipa_point, uint8_t *acc_scalars, uint8_t *acc_point, uint8_t *ok) {
+    const fctx *fp = &F[0], *fq = &F[1];
+    if (nproofs == 0) return 0;
+    fold_state st; fold_collect(proofs, nproofs, threads, rand32, &st);
+    const size_t n = st.n, nacc = (size_t)1 << 16, per = st.per;
+    for (size_t i = 0; i < n; ++i) f_store(ipa_scalars + 32 * i, &st.Sg[i], fq);
+    for (size_t i = 0; i < nacc; ++i) f_store(acc_scalars + 32 * i, &st.Tg[i], fp);
+    const size_t qp = 1 + nproofs * per;
+    uint8_t *P = (uint8_t *)malloc(qp * 64), *S = (uint8_t *)malloc(qp * 32);
+    memcpy(P, G.h_pallas, 64); f_store(S, &st.h_acc, fq);
+    memcpy(P + 64, st.pts, nproofs * per * 64); memcpy(S + 32, st.scs, nproofs * per * 32);
+    oracle_msm_pippenger(0, qp, P, S, ipa_point, threads);
+    free(P); free(S);
+    P = (uint8_t *)malloc(nproofs * 64); S = (uint8_t *)malloc(nproofs * 32);
+    for (size_t b = 0; b < nproofs; ++b) { memcpy(P + b * 64, proofs[b].acc_sg, 64); f_store(S + 32 * b, &st.rho_acc[b], fp); }
+    oracle_msm_pippenger(1, nproofs, P, S, acc_point, threads);
+    free(P); free(S);
+    memcpy(ok, st.ok, nproofs);
+    fold_free(&st);
+    return 0;
 }
 size_t oc_sizeof_proof(void) { return sizeof(oc_proof); }
 size_t oc_sizeof_result(void) { return sizeof(oc_result); }

@@ -14,7 +14,7 @@ import torch.distributed as dist
 
 import bench
 import mina_bridge_amd as m
-from mina_bridge_amd.sharded import ShardedStateJob
+from mina_bridge_amd.sharded import DeviceBackend, ShardedStateJob
 
 B, scenario = int(sys.argv[1]), sys.argv[2]
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
@@ -36,8 +36,8 @@ if scenario == "bad_accumulator_on_rank0" and rank == 0:
     bad_at = 1; by_addr[hj.acc_prechallenges].view(np.uint8).reshape(B, 16, 16)[bad_at, 3, 0] ^= 1
 dj, dk, tensors = bench.device_jobs(m, hj, keep, kp, dev)
 ctx.state_jobs_prepare(bench.LOG2_DOMAIN, bench.NPUB)
-job = ShardedStateJob(ctx, dev, k=bench.WRAP_K, acc_k=bench.ACC_K)
-verdicts, ok = job.verify(dj, B, run_plain=lambda dv, df: ctx.state_job_batch_dev(dj, dv, df))
+job = ShardedStateJob(DeviceBackend(ctx, dev), k=bench.WRAP_K, acc_k=bench.ACC_K)
+verdicts, ok = job.verify(dj, B)
 # the ordinary single-GPU job on the same shard, for comparison
 plain = torch.zeros(B + 4, dtype=torch.int32, device=dev)
 torch.cuda.synchronize()

@@ -195,3 +195,115 @@ def test_device_backend_under_rccl_single_rank(ctx_srs, oracle, srs_oracle):
                 assert sh.verify_base_sliced(tp, ts, tr) is (len(tamper) == 0)
     finally:
         dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------- SURVEY.md 8e.2 for the WHOLE Proof-of-State job
+class OracleJobBackend:
+    """the backend interface of `ShardedStateJob` on CPU tensors, computed by oracle/ at FULL size (2^15 wrap domain, 2^16 accumulator): the native composite's
+    fold with the fixed-base MSMs left out (composite_oracle.c oc_fold_export) stands in for mina_state_job_fold_dev, ark-style Pippenger for the MSM kernels"""
+    RECORD = 68
+    dev = "cpu"
+
+    def __init__(self, threads=2):
+        import json
+        import torch
+        import mina_bridge_amd.poseidon_params as PP
+        from oracle import composite as C, oracle as O
+        self.O, self.C, self.torch, self.threads = O, C, torch, threads
+        self.srs = {c: O.srs_create(c, 1 << 16, threads=threads) for c in (0, 1)}
+        self.fx = json.load(open(os.path.join(ROOT, "tests", "golden", "statement_k15_encoded.json")))
+        C.setup(self.srs[0], self.srs[1], PP.default_params_bytes(0), PP.default_params_bytes(1), self.fx["wrap_index"], self.fx["step_index"], threads=threads)
+
+    def sync(self): pass
+
+    def _t(self, a): return self.torch.from_numpy(np.ascontiguousarray(a, dtype=np.uint8).reshape(-1).copy())
+
+    def _rec(self, pt64):
+        r = np.zeros(68, np.uint8); r[:64] = pt64
+        if not np.asarray(pt64).any(): r[64] = 1
+        return self._t(r)
+
+    def state_job_fold(self, job, batch, k, acc_k):
+        assert (k, acc_k) == (15, 16) and len(job) == batch
+        ipa_s, ipa_p, acc_s, acc_p, ok = self.C.fold_export(job, self.threads)
+        return self._t(ok), self._t(np.array([1, 0, 1, 0], np.uint8)), self._t(ipa_s), self._rec(ipa_p), self._t(acc_s), self._rec(acc_p)
+
+    def state_job_plain(self, job, batch):
+        return self._t(self.C.verify_folded(job, self.threads)[1])
+
+    def sum_rows(self, field, rows, m, stacked):
+        from oracle import pasta_ref as R
+        mod = R.P if field == 0 else R.Q
+        a = stacked.numpy().reshape(rows, m, 32)
+        return self._t(self.O.ints_to_le([sum(self.O.le_to_int(a[r, j]) for r in range(rows)) % mod for j in range(m)]))
+
+    def msm_srs_range(self, curve, first, n, scalars):
+        return self._rec(self.O.msm_pippenger(curve, self.srs[curve][0][first:first + n], scalars.numpy().reshape(-1, 32), threads=self.threads))
+
+    def points_sum(self, curve, n, records):
+        acc = np.zeros(64, np.uint8)
+        for r in records.numpy().reshape(n, 68):
+            if not r[64]: acc = self.O.point_add(curve, acc, r[:64].copy())
+        return self._rec(acc)
+
+    def records_equal(self, a, b): return bool((a == b).all())
+
+
+def _state_job_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import copy
+    import random
+    import torch.distributed as dist
+    from ipa_helpers import poseidon_pp
+    from kimchi_helpers import load_statement_fixture, make_chain
+    from mina_bridge_amd.sharded import ShardedStateJob
+    from oracle import mina_state_ref as S
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    be = OracleJobBackend()
+    items, _ = load_statement_fixture()
+
+    def proof(i, tamper=False):
+        it = items[i % 4]
+        states, hashes = make_chain(random.Random(it["chain_seed"]), poseidon_pp(0))
+        recs = np.zeros((17, 64, 32), np.uint8); nf = np.zeros(17, np.uint32)
+        for s_, st in enumerate(states):
+            f = [st["previous_state_hash"]] + S.body_to_input(st["body"]).to_fields()
+            nf[s_] = len(f) - 1
+            recs[s_, : len(f)] = np.frombuffer(b"".join(int(x).to_bytes(32, "little") for x in f), np.uint8).reshape(len(f), 32)
+        exp = np.frombuffer(b"".join(int(h).to_bytes(32, "little") for h in hashes), np.uint8).reshape(17, 32).copy()
+        enc = copy.deepcopy(be.fx["proofs"][i % 4])
+        if tamper:
+            b = bytearray(bytes.fromhex(enc["opening"]["z1"])); b[0] ^= 1; enc["opening"]["z1"] = bytes(b).hex()
+        return be.C.make_proof(enc, recs.reshape(17, -1), nf, exp)
+    job = ShardedStateJob(be, k=15, acc_k=16)
+    res = {}
+    shard = [proof(3 * rank + i) for i in range(3)]
+    v, ok = job.verify(shard, 3); res["ok"] = (v.numpy().tolist(), ok, dict(job.last))
+    shard_bad = [proof(3 * rank + i, tamper=(rank == 1 and i == 2)) for i in range(3)]
+    v, ok = job.verify(shard_bad, 3); res["bad"] = (v.numpy().tolist(), ok, dict(job.last))
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_exchange_variant_of_the_whole_state_job_on_the_cpu_double():
+    """`ShardedStateJob` (SURVEY.md 8e.2 for the whole Proof-of-State job: one all-to-all of folded scalar vectors, base-sliced MSMs, one all-gather of partial
+    points) under a 2-rank gloo group with the oracle-backed double at FULL size -- the distributed logic of the N > 1 path on CPU.  An accepting batch passes on
+    both ranks; ONE bad opening on rank 1 fails the exchanged check on both ranks and the fallback localises it to rank 1's shard.  (The GPU side of the same
+    class: tests/test_sharded_state_job.py.)"""
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_state_job_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs: p.start()
+    got = dict(q.get(timeout=900) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in (0, 1):
+        v, ok, detail = got[r]["ok"]
+        assert ok is True and v == [1, 1, 1], (r, detail)
+        v, ok, detail = got[r]["bad"]
+        assert ok is False and detail["opening_fold_ok"] is False and detail["accumulator_fold_ok"] is True, (r, detail)
+        assert v == ([1, 1, 1] if r == 0 else [0, 0, 0]), (r, v)
