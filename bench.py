@@ -693,6 +693,31 @@ def main():
             o.zero_()
         torch.cuda.synchronize()
 
+    # SURVEY.md 8e.2 for the whole job (the multi-GPU variant north_star names): ONE exchange step -- all-to-all of the shards' folded scalar vectors, the two
+    # fixed-base MSMs base-sliced over the ranks, all-gather of the partial points (mina_bridge_amd/sharded.py ShardedStateJob).  Secondary key at N > 1: it pays
+    # when the batch per GPU is small; at 8192 proofs per rank the proof-level sharding above (no data-path collective) is the faster form.
+    exchange = None
+    if dist_on and not args.no_probes and args.mode == "full":
+        from mina_bridge_amd.sharded import DeviceBackend, ShardedStateJob
+        sj = ShardedStateJob(DeviceBackend(ctx, dev), k=WRAP_K, acc_k=ACC_K)
+        Bx = min(B, 1024)
+        djx = m.lib.StateJobs(); ctypes.memmove(ctypes.byref(djx), ctypes.byref(dj), ctypes.sizeof(m.lib.StateJobs)); djx.batch = Bx
+        keepx = []
+        if kp is not None:
+            dkx = m.lib.KimchiProofs(); ctypes.memmove(ctypes.byref(dkx), ctypes.byref(dk), ctypes.sizeof(m.lib.KimchiProofs)); dkx.batch = Bx
+            djx.kimchi = ctypes.addressof(dkx); keepx.append(dkx)
+        vx, okx = sj.verify(djx, Bx)                               # warm
+        barrier(); torch.cuda.synchronize(); tx = time.perf_counter()
+        nx = 8
+        for _ in range(nx):
+            vx, okx = sj.verify(djx, Bx)
+        torch.cuda.synchronize(); barrier()
+        elx = time.perf_counter() - tx
+        assert okx and bool(vx.all()), "the exchanged check must ACCEPT"
+        exchange = {"value": args.gpus * nx * Bx / elx, "unit": "proofs/s", "proofs_per_rank_per_call": Bx, "calls": nx, "ms_per_call": elx / nx * 1e3,
+                    "collectives": "all_to_all_single (2 x folded scalars: 1 MiB + 2 MiB per rank) + all_gather (276 B per rank) over " + ("gloo, host tensors (shared GPU)" if share_gpu else "RCCL, HBM to HBM"),
+                    "note": "synchronous calls (no pipelining): the latency of ONE batch spread over the ranks with a single exchange step"}
+
     # the candidate dominant kernels with nothing else on the GPU: one lane, HIP events on that lane's stream
     prof_iso = {}
     if not args.no_probes:
@@ -803,6 +828,7 @@ def main():
             "stage_us": {"isolated": iso, "in_timed_region": ovl},
             "sustained": sustained,
             "c5_4096_total_strong": c5,
+            "exchange_variant_8e2": exchange,
             "boundary_bytes_to_bools": boundary,
             "c2_accumulator_only": {"value": c2_rate, "unit": "accumulator checks/s",
                                     "note": "BASELINE config C2 alone (round 1's headline): un-folded 2^16-base Vesta IPA accumulator checks, 8 per call, 16 lanes",

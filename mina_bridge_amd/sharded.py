@@ -249,6 +249,7 @@ class ShardedStateJob:
         # every tensor a queued kernel reads stays referenced until the next be.sync(): the library's streams are asynchronous to torch's allocator
         recv_p, recv_v = self._all_to_all(ipa_s), self._all_to_all(acc_s)
         mine_p, mine_v = be.sum_rows(1, G, m, recv_p), be.sum_rows(0, G, ma, recv_v)                        # Pallas scalars live in Fq, Vesta scalars in Fp
+        be.sync()                                                    # a context with several pipeline lanes issues consecutive calls on different streams
         lhs_p = be.msm_srs_range(0, self.rank * m, m, mine_p)
         lhs_v = be.msm_srs_range(1, self.rank * ma, ma, mine_v)
         be.sync()
@@ -260,6 +261,7 @@ class ShardedStateJob:
         pallas_all, vesta_l, vesta_r = torch.cat([col(0), col(1)]).contiguous(), col(2), col(3)        # (the backend orders torch's stream before the library reads them)
         pallas_total = be.points_sum(0, 2 * G, pallas_all)                                                   # fixed-base parts + variable-base parts == infinity
         L, R = be.points_sum(1, G, vesta_l), be.points_sum(1, G, vesta_r)
+        be.sync()
         ok_ipa = be.records_equal(pallas_total, inf)
         ok_acc = be.records_equal(L, R)
         batch_ok = bool(wellformed and ok_ipa and ok_acc)

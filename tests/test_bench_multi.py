@@ -68,3 +68,14 @@ def test_collectives_of_the_multi_gpu_path_on_a_one_rank_rccl_group():
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     line = json_line(r.stdout)
     assert line["n_gpus"] == 1 and "RCCL" in line["config"]["sharding"] and line["value"] > 0
+
+
+@pytest.mark.gpu
+def test_gpus_2_reports_the_exchange_variant():
+    """with the probes on, the N > 1 line also carries SURVEY.md 8e.2 for the whole job (`exchange_variant_8e2`: ShardedStateJob over the ranks)"""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--warmup", "1", "--jobs", "256", "--pipeline", "2", "--no-boundary", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=1500, env=clean_env())
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    line = json_line(r.stdout)
+    x = line["exchange_variant_8e2"]
+    assert line["n_gpus"] == 2 and x and x["value"] > 0 and x["proofs_per_rank_per_call"] == 256 and x["calls"] == 8
