@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <vector>
 #include "ec.cuh"
+#include "fp29.cuh"
 
 using namespace mb;
 
@@ -85,6 +86,66 @@ __global__ void __launch_bounds__(256) probe_field(uint32_t *out, uint32_t seed)
     out[blockIdx.x * blockDim.x + threadIdx.x] = r;
 }
 
+// ---- single-wave LATENCY probes (round 4, VERDICT r03 item 7: one proof per call is a dependent chain of ~300 permutations x 55 rounds; a round's chain is
+// 99 + 3 x 135 dependent multiply-accumulates of ONE wave).  Would splitting the 81 limb products of a 29-bit Montgomery product over the 9 lanes of a DPP row
+// shorten the chain enough?  (a) the product as it is, dependent chain, one wave per SIMD; (b) the INSTRUCTION SKELETON of a lane-split product -- the same
+// count and dependency shape of DPP broadcasts, multiply-accumulates, DPP-shifted 64-bit column adds, relaxed carry passes, the quotient product by -1/p, the
+// product by the sparse p, the final carry resolution and the move of the high half back to lanes 0..8 -- values are NOT a correct product: a lower bound on time.
+template <int OP>
+__global__ void __launch_bounds__(256) probe_latency(uint32_t *out, uint32_t seed) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (OP == 0) {
+        fe29_t x, y; for (int i = 0; i < 9; ++i) { x.v[i] = (seed * (i + 1) + threadIdx.x) & M29; y.v[i] = (seed ^ (0x85ebca6bu * (i + 2))) & M29; }
+        for (int it = 0; it < ITERS; ++it) x = fe29_mul_asm<FIELD_FQ>(x, y);
+        uint32_t r = 0; for (int i = 0; i < 9; ++i) r ^= x.v[i];
+        out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+    } else {
+        uint32_t x = seed + threadIdx.x, y = seed ^ threadIdx.x;
+        const uint32_t pc = 0x1234567u ^ (threadIdx.x & 15u);
+#define BCAST(v, n) (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), 0x150 + (n), 0xf, 0xf, false)
+#define SHR(v, n) (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), 0x110 + (n), 0xf, 0xf, true)
+        for (int it = 0; it < ITERS; ++it) {
+            uint64_t q[9];
+#pragma unroll
+            for (int j = 0; j < 9; ++j) { uint32_t yj = 0; switch (j) { case 0: yj = BCAST(y, 0); break; case 1: yj = BCAST(y, 1); break; case 2: yj = BCAST(y, 2); break; case 3: yj = BCAST(y, 3); break;
+                                            case 4: yj = BCAST(y, 4); break; case 5: yj = BCAST(y, 5); break; case 6: yj = BCAST(y, 6); break; case 7: yj = BCAST(y, 7); break; default: yj = BCAST(y, 8); }
+                                          q[j] = (uint64_t)x * yj; }
+            uint64_t acc = q[0];
+#define ADDSHR(n) { const uint32_t lo = SHR((uint32_t)q[n], n), hi = SHR((uint32_t)(q[n] >> 32), n); acc += ((uint64_t)hi << 32) | lo; }
+            ADDSHR(1) ADDSHR(2) ADDSHR(3) ADDSHR(4) ADDSHR(5) ADDSHR(6) ADDSHR(7) ADDSHR(8)
+#define RELAX() { const uint64_t hi = acc >> 29; acc = (acc & M29) + (((uint64_t)SHR((uint32_t)(hi >> 32), 1) << 32) | SHR((uint32_t)hi, 1)); }
+            RELAX() RELAX()
+            // m = T_low * (-1/p) mod 2^261: 9 products by per-lane constants, shifted column adds, relaxed carries
+            const uint32_t tl = (uint32_t)acc & M29;
+#pragma unroll
+            for (int j = 0; j < 9; ++j) q[j] = (uint64_t)tl * (pc + j);
+            uint64_t m = q[0];
+#undef ADDSHR
+#define ADDSHR(n) { const uint32_t lo = SHR((uint32_t)q[n], n), hi = SHR((uint32_t)(q[n] >> 32), n); m += ((uint64_t)hi << 32) | lo; }
+            ADDSHR(1) ADDSHR(2) ADDSHR(3) ADDSHR(4) ADDSHR(5) ADDSHR(6) ADDSHR(7) ADDSHR(8)
+            { const uint64_t hi = m >> 29; m = (m & M29) + (((uint64_t)SHR((uint32_t)(hi >> 32), 1) << 32) | SHR((uint32_t)hi, 1)); }
+            { const uint64_t hi = m >> 29; m = (m & M29) + (((uint64_t)SHR((uint32_t)(hi >> 32), 1) << 32) | SHR((uint32_t)hi, 1)); }
+            // T += m * p (6 non-zero limbs of p)
+            const uint32_t ml = (uint32_t)m & M29;
+#pragma unroll
+            for (int j = 0; j < 6; ++j) q[j] = (uint64_t)ml * (pc ^ j);
+#undef ADDSHR
+#define ADDSHR(n) { const uint32_t lo = SHR((uint32_t)q[n], n), hi = SHR((uint32_t)(q[n] >> 32), n); acc += ((uint64_t)hi << 32) | lo; }
+            acc += q[0]; ADDSHR(1) ADDSHR(2) ADDSHR(3) ADDSHR(4) ADDSHR(8)
+            // carry out of the low half: generate / propagate resolution over the row (4 steps), then the high half moves down 9 lanes, relaxed carries
+            uint32_t g = (uint32_t)(acc >> 29) != 0, pr = ((uint32_t)acc & M29) == M29;
+#pragma unroll
+            for (int d = 1; d <= 8; d <<= 1) { const uint32_t g2 = SHR(g, 1), p2 = SHR(pr, 1); g |= pr & g2; pr &= p2; }
+            const uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)((uint32_t)acc + g), 0x100 + 9, 0xf, 0xf, true), ny = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(acc >> 32), 0x100 + 9, 0xf, 0xf, true);
+            acc = ((uint64_t)ny << 32) | nx;
+            RELAX() RELAX()
+            x = (uint32_t)acc & M29;                             // the next product depends on this one
+        }
+        out[blockIdx.x * blockDim.x + threadIdx.x] = x;
+    }
+#endif
+}
+
 template <class K>
 static double time_kernel(K launch, int reps) {
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
@@ -133,6 +194,12 @@ int main() {
                fnames[OP], wps, t * clk / ITERS / wps, t * 1e9 / ITERS, (double)fb * 256 * ITERS / t / 1e9); \
     }
         RUNF(0) RUNF(1) RUNF(2) RUNF(3) RUNF(4) RUNF(5)
+    }
+    for (int wps = 1; wps <= 2; ++wps) {
+        const int fb = cus * wps;
+        const double t0 = time_kernel([&] { probe_latency<0><<<fb, 256>>>(out, 777u); }, 3), t1 = time_kernel([&] { probe_latency<1><<<fb, 256>>>(out, 777u); }, 3);
+        printf("{\"probe\": \"fe29_mul_asm (dependent chain, 135 MAC + ~43 simple)\", \"waves_per_simd\": %d, \"cycles_per_product\": %.0f, \"ns_per_product\": %.0f}\n", wps, t0 * clk / ITERS / wps, t0 * 1e9 / ITERS);
+        printf("{\"probe\": \"lane-split 29-bit Montgomery product over a DPP row, instruction skeleton (24 MAC + ~120 DPP / simple; a LOWER bound)\", \"waves_per_simd\": %d, \"cycles_per_product\": %.0f, \"ns_per_product\": %.0f}\n", wps, t1 * clk / ITERS / wps, t1 * 1e9 / ITERS);
     }
     CHECK(hipFree(out));
     return 0;
