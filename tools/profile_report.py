@@ -44,14 +44,15 @@ if os.path.exists(sq):
     for r in csv.DictReader(open(sq)):
         agg[short(r["Kernel_Name"])][r["Counter_Name"]] += float(r["Counter_Value"])
     total = sum(v["SQ_INSTS_VALU"] for v in agg.values()) / STEPS
-    floor = total * 4 / (1024 * 2.4e9) * 1e3
-    print(f"\n## VALU instruction budget per step (SQ_INSTS_VALU, single lane)\n\nTotal {total / 1e9:.2f} G wave-instructions per step; at 4 cycles per wave64 instruction on "
-          f"1024 SIMDs and 2.4 GHz that is a floor of **{floor:.1f} ms** per step -- the pipelined step takes {b['ms_per_step']:.1f} ms "
-          f"(= {floor / b['ms_per_step'] * 100:.0f} % of VALU issue).\n")
+    MIX = 4.38                                               # cycles per instruction of the Poseidon rounds' mix (765 multiply-accumulates : 290 simple), 8 waves per SIMD:
+    floor = total * MIX / (1024 * 2.4e9) * 1e3               # profiles/r04_microbench_valu.jsonl -- 86 % of a step's instructions are sponge kernels
+    print(f"\n## VALU instruction budget per step (SQ_INSTS_VALU, single lane)\n\nTotal {total / 1e9:.2f} G wave-instructions per step; at the MEASURED {MIX} cycles per wave64 "
+          f"instruction of the sponge kernels' mix (profiles/r04_valu_roofline.md) on 1024 SIMDs and 2.4 GHz that is **{floor:.1f} ms** per step -- the pipelined step takes "
+          f"{b['ms_per_step']:.1f} ms (= {floor / b['ms_per_step'] * 100:.0f} % of that issue rate; the 'floor ms' column below prices every instruction the same way).\n")
     print("| kernel | G instr/step | floor ms | waves/step |\n|---|---|---|---|")
     for k in sorted(agg, key=lambda k: agg[k]["SQ_INSTS_VALU"], reverse=True)[:18]:
         v = agg[k]; iv = v["SQ_INSTS_VALU"] / STEPS
-        print(f"| {k} | {iv / 1e9:.3f} | {iv * 4 / (1024 * 2.4e9) * 1e3:.2f} | {v['SQ_WAVES'] / STEPS:.0f} |")
+        print(f"| {k} | {iv / 1e9:.3f} | {iv * MIX / (1024 * 2.4e9) * 1e3:.2f} | {v['SQ_WAVES'] / STEPS:.0f} |")
 r, rv = b["roofline"], b.get("roofline_valu", {})
 print(f"\n## Dominant kernel `{r['kernel']}` (one launch = {r['states_per_launch']} protocol-state hashes)\n")
 print(f"* HIP events in bench.py: {r['avg_launch_us']:.0f} us isolated, {r['avg_launch_us_in_timed_region']:.0f} us inside the timed region (lanes time-share the CUs; "
