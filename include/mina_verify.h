@@ -568,10 +568,10 @@ int mina_state_proof_split(const uint8_t *bytes, size_t len, size_t *proof_len, 
  * process-wide context on GPU $MINA_VERIFY_DEVICE (default 0), created on first use).  Concurrent calls of the single-proof entry
  * points are merged: calls that arrive while a job runs on the GPU leave together as the next job (one proof is a 23 ms dependent
  * chain that leaves the chip idle; 256 threads calling at once see 9 k proofs/s instead of 40, each call lasting about one job).  Every caller still gets the
- * verdict of its own proof.  Batch calls of up to $MINA_VERIFY_MERGE_BATCH_MAX (default 512) proofs share jobs with concurrent callers the same
+ * verdict of its own proof.  Batch calls of up to mina_verify_tuning.merge_batch_max (default 512) proofs share jobs with concurrent callers the same
  * way; bigger ones are pipelined on their own (chunks of 8192: parsing, uploads and the GPU job of consecutive chunks overlap; at most four jobs
- * per device in flight over all callers).  Environment: MINA_VERIFY_NO_MERGE=1 sends each call through on its own; MINA_VERIFY_LINGER_US
- * (default 500, + 2 us per caller of the previous job) bounds how long the leader of a job waits for the callers of the previous job to come back. */
+ * per device in flight over all callers).  mina_verify_tuning (below): .merge = 0 sends each call through on its own; .linger_us (default 500, + 2 us per
+ * caller of the previous job) bounds how long the leader of a job waits for the callers of the previous job to come back. */
 #define MINA_CHECK_FORMAT 1u        /* pub inputs (1057 B) and bincode MinaStateProof parse */
 #define MINA_CHECK_LEDGER 2u        /* ledger hashes of the public input == the states' snarked ledger hashes   (README.md:287) */
 #define MINA_CHECK_CHAIN 4u         /* 17 state hashes == public input, states linked                          (README.md:285-288) */
