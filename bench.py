@@ -502,7 +502,9 @@ def main():
     ap.add_argument("--steps", type=int, default=80)
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--jobs", type=int, default=8192, help="state proofs per step (one mina_state_job_batch_dev call)")
-    ap.add_argument("--pipeline", type=int, default=16, help="internal stream lanes over which consecutive steps are issued")
+    # 20 lanes under 24 hardware queues (round 4 sweep, full mode, one MI355X): --steps 20: 10 lanes 247.5 k, 16: 245.9 k, 20: 262 - 267 k, 24: 250.5 k, 32: 248.2 k proofs/s;
+    # --steps 80: 16 lanes 256.2 k, 20: 258.3 k, 24: 242.7 k, 32: 250.9 k (with 32 - 40 queues nothing gains: 20 lanes 258.1 k, 32 lanes 228 - 243 k)
+    ap.add_argument("--pipeline", type=int, default=20, help="internal stream lanes over which consecutive steps are issued")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", choices=("full", "kimchi", "prepared"), default="full",
                     help="full (default): the whole verifier from parsed proofs -- Pickles statement -> public inputs, kimchi oracles + to_batch, opening check, "
@@ -537,7 +539,7 @@ def main():
     # not share the GPU with another process's queues (a second process holding 24 hardware queues makes the scheduler time-slice them: the
     # same call took 288 ms instead of 55), and inside THIS process the 40-odd streams of the headline's context would populate the runtime's
     # queue pool first (67 - 72 ms).  GPU_MAX_HW_QUEUES=16 there: with the system runtime a lone job's three legs overlap best at <= 16 (54.6 ms;
-    # 24: 68.4 ms), while the 16-lane pipeline of the headline below wants one queue per lane plus a few (24).
+    # 24: 68.4 ms), while the 20-lane pipeline of the headline below wants one queue per lane plus a few (24).
     # At N > 1 rank 0 runs a second leg the same way: the product's own multi-device path, ONE process with a context on each of the N GPUs
     # (boundary_all_devices_leg).  The other ranks have not touched their GPUs yet: they wait at the CPU barrier below.
     boundary = None
