@@ -501,7 +501,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=80)
     ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--jobs", type=int, default=8192, help="state proofs per step (one mina_state_job_batch_dev call)")
+    # 16384 proofs per step (round 4; rounds 2 - 3: 8192): --steps 20 over 20 lanes 8192 -> 261 k, 16384 -> 275 k, 24576 -> 273 k, 32768 -> 275 k proofs/s; --steps 80: 258 k -> 267 k.
+    # The timed region of the driver's --steps 20 is then 1.2 s instead of 0.6 s.  The bytes -> bools legs keep 8192 per call (the boundary's own chunk size).
+    ap.add_argument("--jobs", type=int, default=16384, help="state proofs per step (one mina_state_job_batch_dev call)")
     # 20 lanes under 24 hardware queues (round 4 sweep, full mode, one MI355X): --steps 20: 10 lanes 247.5 k, 16: 245.9 k, 20: 262 - 267 k, 24: 250.5 k, 32: 248.2 k proofs/s;
     # --steps 80: 16 lanes 256.2 k, 20: 258.3 k, 24: 242.7 k, 32: 250.9 k (with 32 - 40 queues nothing gains: 20 lanes 258.1 k, 32 lanes 228 - 243 k)
     ap.add_argument("--pipeline", type=int, default=20, help="internal stream lanes over which consecutive steps are issued")
@@ -513,7 +515,7 @@ def main():
     ap.add_argument("--kimchi", action="store_true", help="alias of --mode kimchi")
     ap.add_argument("--no-probes", action="store_true", help="skip the isolated-kernel / C2 probes and the sustained / C5 legs (profiling runs: only the timed loop launches kernels)")
     ap.add_argument("--no-boundary", action="store_true", help="skip the bytes -> bools legs (mina_verify_state_batch on serialized proofs)")
-    ap.add_argument("--boundary-jobs", type=int, default=0, help="proofs per call of the bytes -> bools legs (default: --jobs)")
+    ap.add_argument("--boundary-jobs", type=int, default=0, help="proofs per call of the bytes -> bools legs (default: min(--jobs, 8192))")
     args = ap.parse_args()
     if args.kimchi:
         args.mode = "kimchi"
@@ -553,7 +555,7 @@ def main():
                 return json.loads(r.stdout.strip().split("\n")[-1]) if r.returncode == 0 and r.stdout.strip() else {"error": (r.stderr or r.stdout)[-400:]}
             except (subprocess.TimeoutExpired, ValueError) as e:
                 return {"error": repr(e)[:400]}
-        bsize = min(args.jobs, args.boundary_jobs) if args.boundary_jobs else args.jobs
+        bsize = min(args.jobs, args.boundary_jobs) if args.boundary_jobs else min(args.jobs, 8192)
         boundary = leg("--boundary-only", "0" if share_gpu else str(local_rank), str(bsize))
         if world > 1:
             devs = ",".join("0" if share_gpu else str(g) for g in range(world))
@@ -845,7 +847,8 @@ def main():
             peak = CHIP_SIMDS * 64 * CLOCK_HZ / MAD_ISSUE_CYCLES
             got = perms * 3 * 55 * MADS_PER_LANE_ROUND / (kern_us * 1e-6)
             waves = -(-nstates // 21)                          # 21 sponges per wave64 (3 lanes each)
-            quant = (waves / CHIP_SIMDS) / -(-waves // CHIP_SIMDS)      # all waves are resident at once and equally long: the launch lasts as long as the fullest SIMD
+            quant = (waves / CHIP_SIMDS) / -(-waves // CHIP_SIMDS)      # equally long waves over 1024 SIMDs: the launch lasts as long as the fullest SIMD (6632 waves: 7 where the
+                                                                         # average is 6.48 = 0.925; 13 263 waves at 16384 proofs per step: 12.95 of 13 = 0.996, the slots refill as waves retire)
             out["roofline_valu"] = {"bound": "issue rate of the kernel's own instruction mix (765 v_mad_u64_u32 + ~290 shifts / masks per lane-round), measured: "
                                              f"{MAD_ISSUE_CYCLES} cycles at 2.4 GHz per wave64 multiply-accumulate per SIMD", "kernel": "pstate_hash_kernel",
                                     "achieved": got / 1e12, "peak": peak / 1e12, "unit": "T limb-MAC/s", "frac": got / peak, "permutations_per_launch": perms,
