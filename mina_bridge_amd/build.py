@@ -64,7 +64,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
 def build_microbench() -> str:
     """the VALU instruction-rate probe (mina_bridge_amd/microbench), not part of the library"""
     out = os.path.join(HERE, "microbench")
-    subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-o", out, os.path.join(CSRC, "microbench.hip")])
+    subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-ftemplate-depth=2048", "-o", out, os.path.join(CSRC, "microbench.hip")])
     return out
 
 

@@ -4,6 +4,8 @@
 // plus the library's fe_mul / fe_sqr / fe_add and the XYZZ mixed add.  Output: one JSON line per probe.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstring>
+#include <type_traits>
 #include <vector>
 #include "ec.cuh"
 #include "fp29.cuh"
@@ -63,6 +65,37 @@ __global__ void __launch_bounds__(256) probe(uint32_t *out, uint32_t seed) {
     }
     uint32_t r = 0;
     for (int i = 0; i < UNROLL; ++i) r ^= a[i] ^ b[i] ^ (uint32_t)acc[i] ^ (uint32_t)(acc[i] >> 32) ^ (uint32_t)d[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+
+// ---- how many simple VALU instructions hide behind a multiply-accumulate?  153 v_mad_u64_u32 per trip (16 independent accumulators) with S simple
+// instructions spread evenly between them: 64-bit shifts, masks, 32-bit shifts and add / add-with-carry pairs in rotation (the instructions a
+// Karatsuba recombination or a shift-add form of the reduction's power-of-two limb would add).  KIND 1: only add_co / addc_co pairs.
+template <int I, int N, class F> __device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+template <int S, int KIND>
+__global__ void __launch_bounds__(256) probe_ratio(uint32_t *out, uint32_t seed) {
+    uint32_t a[UNROLL], b[UNROLL];
+    uint64_t acc[UNROLL];
+    for (int i = 0; i < UNROLL; ++i) { a[i] = seed * (i + 3) + threadIdx.x; b[i] = seed ^ (0x9e3779b9u * (i + 1)); acc[i] = a[i]; }
+    for (int it = 0; it < ITERS; ++it) {
+        static_for<0, 153 + S>([&](auto tc) {              // one flat schedule resolved at compile time: slot t is a multiply-accumulate when the running count of them steps
+            constexpr int t = decltype(tc)::value, j = (t * 153) / (153 + S), e = t - j;
+            if constexpr (((t + 1) * 153) / (153 + S) != j) {
+                asm volatile("v_mad_u64_u32 %0, s[20:21], %1, %2, %0" : "+v"(acc[j % UNROLL]) : "v"(a[j % UNROLL]), "v"(b[(j + 5) % UNROLL]) : "s20", "s21");
+            } else {
+                constexpr int kind = KIND == 1 ? 2 + (e & 1) : e % 5;
+                if constexpr (kind == 0) asm volatile("v_lshrrev_b64 %0, 29, %1" : "=v"(acc[(j + 7) % UNROLL]) : "v"(acc[(j + 8) % UNROLL]));
+                if constexpr (kind == 1) asm volatile("v_and_b32 %0, 0x1fffffff, %1" : "=v"(a[(j + 3) % UNROLL]) : "v"(b[(j + 9) % UNROLL]));
+                if constexpr (kind == 2) asm volatile("v_add_co_u32 %0, vcc, %1, %2" : "=v"(a[(j + 4) % UNROLL]) : "v"(a[(j + 11) % UNROLL]), "v"(b[(j + 2) % UNROLL]) : "vcc");
+                if constexpr (kind == 3) asm volatile("v_addc_co_u32 %0, vcc, %1, %2, vcc" : "=v"(b[(j + 6) % UNROLL]) : "v"(a[(j + 12) % UNROLL]), "v"(b[(j + 13) % UNROLL]) : "vcc");
+                if constexpr (kind == 4) asm volatile("v_lshlrev_b32 %0, 22, %1" : "=v"(a[(j + 10) % UNROLL]) : "v"(b[(j + 1) % UNROLL]));
+            }
+        });
+    }
+    uint32_t r = 0;
+    for (int i = 0; i < UNROLL; ++i) r ^= a[i] ^ b[i] ^ (uint32_t)acc[i] ^ (uint32_t)(acc[i] >> 32);
     out[blockIdx.x * blockDim.x + threadIdx.x] = r;
 }
 
@@ -157,11 +190,26 @@ static double time_kernel(K launch, int reps) {
     return ms * 1e-3 / reps;
 }
 
-int main() {
+int main(int argc, char **argv) {
     hipDeviceProp_t prop; CHECK(hipGetDeviceProperties(&prop, 0));
     const int cus = prop.multiProcessorCount; const double clk = prop.clockRate * 1e3;   // Hz
     printf("{\"device\": \"%s\", \"cus\": %d, \"clock_mhz\": %.0f}\n", prop.gcnArchName, cus, clk / 1e6);
     uint32_t *out; CHECK(hipMalloc(&out, (size_t)cus * 8 * 256 * 4));
+    if (argc > 1 && !strcmp(argv[1], "--ratio")) {       // the sweep alone: cycles per multiply-accumulate against simple instructions per multiply-accumulate
+        for (int wps = 4; wps <= 8; wps *= 2) {
+            const int blocks = cus * wps;
+#define RATIO(S, KIND)                                                                                       \
+            {                                                                                                \
+                double t = time_kernel([&] { probe_ratio<S, KIND><<<blocks, 256>>>(out, 12345u); }, 5);      \
+                printf("{\"probe\": \"153 v_mad_u64_u32 + %d simple per trip (%s)\", \"waves_per_simd\": %d, \"simple_per_mac\": %.2f, \"cycles_per_mac\": %.2f, \"cycles_per_instr\": %.2f}\n", \
+                       S, KIND ? "add_co / addc_co pairs" : "shr64, and, add_co, addc_co, shl32 in rotation", wps, S / 153.0, t * clk / ((double)ITERS * 153 * wps), t * clk / ((double)ITERS * (153 + S) * wps)); \
+            }
+            RATIO(0, 0) RATIO(58, 0) RATIO(77, 0) RATIO(115, 0) RATIO(153, 0) RATIO(191, 0) RATIO(230, 0) RATIO(306, 0) RATIO(459, 0)
+            RATIO(77, 1) RATIO(153, 1) RATIO(230, 1) RATIO(306, 1)
+        }
+        CHECK(hipFree(out));
+        return 0;
+    }
     for (int waves_per_simd = 2; waves_per_simd <= 8; waves_per_simd *= 2) {    // 2 waves/SIMD already cover VALU latency with UNROLL=16; more must not change the rates
     printf("{\"waves_per_simd\": %d}\n", waves_per_simd);
     const int blocks = cus * waves_per_simd;          // 256-thread blocks: 4 waves -> one per SIMD

@@ -19,7 +19,7 @@ print(f"# Round {rnd} profile ({tag}) -- `python bench.py` (default mode `{b['co
 print(f"Raw rocprofv3 output: `gpurun_out/prof_{tag}/` (scratch).  Commands: `tools/profile_round.sh {tag}` (kernel-trace + stats of the default bench command; "
       f"FETCH_SIZE and WRITE_SIZE in separate `--pmc` passes with `--pipeline 1` so that kernels do not overlap) and `tools/profile_sq.sh {tag}` (SQ counters, own "
       f"passes).  Bench line of the same build: `profiles/{tag}_bench.json` ({b['value'] / 1e3:.1f} k proofs/s, {b['ms_per_step']:.1f} ms per step).\n")
-print("## kernel-trace stats of the default command (16 lanes in flight: durations include time-sharing of the CUs)\n")
+print(f"## kernel-trace stats of the default command ({b['config']['pipeline_lanes']} lanes in flight: durations include time-sharing of the CUs)\n")
 print(stats_table(os.path.join(d, "trace", "t_kernel_stats.csv")))
 F, W = pmc(os.path.join(d, "fetch", "f_counter_collection.csv")), pmc(os.path.join(d, "write", "w_counter_collection.csv"))
 print("\n## PMC passes, KiB per launch (most frequent grid size of each kernel)\n")
