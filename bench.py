@@ -650,6 +650,10 @@ def main():
             torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    if dist_on:                                                # MAX over ranks at once: every decision below that depends on `elapsed` is then the same on every rank
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0].item())
     prof = ctx.prof_read()
     ctx.prof_enable(0)
     assert verdicts_ok(args.steps), "timed-region verdicts must be ACCEPT"
@@ -763,7 +767,6 @@ def main():
     if dist_on:
         t = torch.tensor([elapsed, sustained["seconds"] if sustained else 0.0, c5["ms_per_step"] if c5 else 0.0], dtype=torch.float64, device="cpu" if share_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0].item())
         if sustained:
             sustained["seconds"] = float(t[1].item()); sustained["value"] = args.gpus * sustained["steps"] * B / sustained["seconds"]
         if c5:
