@@ -11,6 +11,14 @@
 // 8 x 32 form -- measured: v_mad_u64_u32 issues at ~6.5 cycles per wave, simple VALU at 4 (10 limbs of 28 bits were tried first: 910
 // multiply-accumulates per round, only -5 %).
 //
+// LAZY forms (fe29_sqr_lz / fe29_mul_lz / fe29_dot3rc_lz, round 4): the quotient digit of column k is m_k = -col mod 2^32, NOT masked to 29 bits.
+// Its three extra bits add h 2^29 p 2^(29 k) to the sum -- a multiple of p, and the low limb still cancels -- so the result is the same field
+// element, only larger: < (sum of products) / 2^261 + 8.0001 p.  Bounds: operands < 10 p (limbs 0..7 < 2^29, limb 8 < 2^26): a column holds at most
+// 27 products of < 2^58, four quotient terms m p_j < 2^61, m 2^22, m and the carry: < 0.93 x 2^64.  One mask per quotient digit saved (45 per
+// round), the accumulator starts from its first product, and the dot product adds a tenth operand before reducing (the round constant times
+// 2^261: 9 multiply-accumulates by 1 instead of a 27-instruction normalised addition).  The STRICT forms stay for everything whose result must be
+// below 1.13 p (the way out of the permutation, the group law of ec29.cuh).
+//
 // Only the wave-packed 3-lane permutation uses it (sponge.cuh): state enters as 8 x 32 Montgomery-2^256, is re-based with one product by
 // 2^266 mod p (x 2^256 -> x 2^261), runs its 55 rounds here, leaves with one product by 2^256 mod p and one conditional subtraction.
 // Bit-identical results (the value computed is the same field element): every sponge parity test runs through it.
@@ -477,6 +485,349 @@ template <int F> __device__ __forceinline__ fe29_t fe29_dot3_asm(const fe29_t &a
     asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0"
         : "+&v"(col), "=&s"(cc) : "v"(a2.v[6]), "v"(b2.v[2]), "v"(a2.v[7]), "v"(b2.v[1]), "v"(a2.v[8]), "v"(b2.v[0]), "v"(m7), "v"(p1), "v"(m6), "v"(p2), "v"(m5), "v"(p3), "v"(m4), "v"(p4), "v"(m0), "v"(p8));
     m8 = (0u - (uint32_t)col) & M29;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m8));
+    col >>= 29;
+    // column 9: 29 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[1]), "v"(b0.v[8]), "v"(a0.v[2]), "v"(b0.v[7]), "v"(a0.v[3]), "v"(b0.v[6]), "v"(a0.v[4]), "v"(b0.v[5]), "v"(a0.v[5]), "v"(b0.v[4]), "v"(a0.v[6]), "v"(b0.v[3]), "v"(a0.v[7]), "v"(b0.v[2]), "v"(a0.v[8]), "v"(b0.v[1]), "v"(a1.v[1]), "v"(b1.v[8]), "v"(a1.v[2]), "v"(b1.v[7]), "v"(a1.v[3]), "v"(b1.v[6]), "v"(a1.v[4]), "v"(b1.v[5]));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a1.v[5]), "v"(b1.v[4]), "v"(a1.v[6]), "v"(b1.v[3]), "v"(a1.v[7]), "v"(b1.v[2]), "v"(a1.v[8]), "v"(b1.v[1]), "v"(a2.v[1]), "v"(b2.v[8]), "v"(a2.v[2]), "v"(b2.v[7]), "v"(a2.v[3]), "v"(b2.v[6]), "v"(a2.v[4]), "v"(b2.v[5]), "v"(a2.v[5]), "v"(b2.v[4]), "v"(a2.v[6]), "v"(b2.v[3]), "v"(a2.v[7]), "v"(b2.v[2]), "v"(a2.v[8]), "v"(b2.v[1]));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m8), "v"(p1), "v"(m7), "v"(p2), "v"(m6), "v"(p3), "v"(m5), "v"(p4), "v"(m1), "v"(p8));
+    r.v[0] = (uint32_t)col & M29; col >>= 29;
+    // column 10: 25 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[2]), "v"(b0.v[8]), "v"(a0.v[3]), "v"(b0.v[7]), "v"(a0.v[4]), "v"(b0.v[6]), "v"(a0.v[5]), "v"(b0.v[5]), "v"(a0.v[6]), "v"(b0.v[4]), "v"(a0.v[7]), "v"(b0.v[3]), "v"(a0.v[8]), "v"(b0.v[2]), "v"(a1.v[2]), "v"(b1.v[8]), "v"(a1.v[3]), "v"(b1.v[7]), "v"(a1.v[4]), "v"(b1.v[6]), "v"(a1.v[5]), "v"(b1.v[5]), "v"(a1.v[6]), "v"(b1.v[4]));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a1.v[7]), "v"(b1.v[3]), "v"(a1.v[8]), "v"(b1.v[2]), "v"(a2.v[2]), "v"(b2.v[8]), "v"(a2.v[3]), "v"(b2.v[7]), "v"(a2.v[4]), "v"(b2.v[6]), "v"(a2.v[5]), "v"(b2.v[5]), "v"(a2.v[6]), "v"(b2.v[4]), "v"(a2.v[7]), "v"(b2.v[3]), "v"(a2.v[8]), "v"(b2.v[2]), "v"(m8), "v"(p2), "v"(m7), "v"(p3), "v"(m6), "v"(p4));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m2), "v"(p8));
+    r.v[1] = (uint32_t)col & M29; col >>= 29;
+    // column 11: 21 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[3]), "v"(b0.v[8]), "v"(a0.v[4]), "v"(b0.v[7]), "v"(a0.v[5]), "v"(b0.v[6]), "v"(a0.v[6]), "v"(b0.v[5]), "v"(a0.v[7]), "v"(b0.v[4]), "v"(a0.v[8]), "v"(b0.v[3]), "v"(a1.v[3]), "v"(b1.v[8]), "v"(a1.v[4]), "v"(b1.v[7]), "v"(a1.v[5]), "v"(b1.v[6]), "v"(a1.v[6]), "v"(b1.v[5]), "v"(a1.v[7]), "v"(b1.v[4]), "v"(a1.v[8]), "v"(b1.v[3]));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a2.v[3]), "v"(b2.v[8]), "v"(a2.v[4]), "v"(b2.v[7]), "v"(a2.v[5]), "v"(b2.v[6]), "v"(a2.v[6]), "v"(b2.v[5]), "v"(a2.v[7]), "v"(b2.v[4]), "v"(a2.v[8]), "v"(b2.v[3]), "v"(m8), "v"(p3), "v"(m7), "v"(p4), "v"(m3), "v"(p8));
+    r.v[2] = (uint32_t)col & M29; col >>= 29;
+    // column 12: 17 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[4]), "v"(b0.v[8]), "v"(a0.v[5]), "v"(b0.v[7]), "v"(a0.v[6]), "v"(b0.v[6]), "v"(a0.v[7]), "v"(b0.v[5]), "v"(a0.v[8]), "v"(b0.v[4]), "v"(a1.v[4]), "v"(b1.v[8]), "v"(a1.v[5]), "v"(b1.v[7]), "v"(a1.v[6]), "v"(b1.v[6]), "v"(a1.v[7]), "v"(b1.v[5]), "v"(a1.v[8]), "v"(b1.v[4]), "v"(a2.v[4]), "v"(b2.v[8]), "v"(a2.v[5]), "v"(b2.v[7]));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a2.v[6]), "v"(b2.v[6]), "v"(a2.v[7]), "v"(b2.v[5]), "v"(a2.v[8]), "v"(b2.v[4]), "v"(m8), "v"(p4), "v"(m4), "v"(p8));
+    r.v[3] = (uint32_t)col & M29; col >>= 29;
+    // column 13: 13 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[5]), "v"(b0.v[8]), "v"(a0.v[6]), "v"(b0.v[7]), "v"(a0.v[7]), "v"(b0.v[6]), "v"(a0.v[8]), "v"(b0.v[5]), "v"(a1.v[5]), "v"(b1.v[8]), "v"(a1.v[6]), "v"(b1.v[7]), "v"(a1.v[7]), "v"(b1.v[6]), "v"(a1.v[8]), "v"(b1.v[5]), "v"(a2.v[5]), "v"(b2.v[8]), "v"(a2.v[6]), "v"(b2.v[7]), "v"(a2.v[7]), "v"(b2.v[6]), "v"(a2.v[8]), "v"(b2.v[5]));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m5), "v"(p8));
+    r.v[4] = (uint32_t)col & M29; col >>= 29;
+    // column 14: 10 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[6]), "v"(b0.v[8]), "v"(a0.v[7]), "v"(b0.v[7]), "v"(a0.v[8]), "v"(b0.v[6]), "v"(a1.v[6]), "v"(b1.v[8]), "v"(a1.v[7]), "v"(b1.v[7]), "v"(a1.v[8]), "v"(b1.v[6]), "v"(a2.v[6]), "v"(b2.v[8]), "v"(a2.v[7]), "v"(b2.v[7]), "v"(a2.v[8]), "v"(b2.v[6]), "v"(m6), "v"(p8));
+    r.v[5] = (uint32_t)col & M29; col >>= 29;
+    // column 15: 7 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[7]), "v"(b0.v[8]), "v"(a0.v[8]), "v"(b0.v[7]), "v"(a1.v[7]), "v"(b1.v[8]), "v"(a1.v[8]), "v"(b1.v[7]), "v"(a2.v[7]), "v"(b2.v[8]), "v"(a2.v[8]), "v"(b2.v[7]), "v"(m7), "v"(p8));
+    r.v[6] = (uint32_t)col & M29; col >>= 29;
+    // column 16: 4 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[8]), "v"(b0.v[8]), "v"(a1.v[8]), "v"(b1.v[8]), "v"(a2.v[8]), "v"(b2.v[8]), "v"(m8), "v"(p8));
+    r.v[7] = (uint32_t)col & M29; col >>= 29;
+    r.v[8] = (uint32_t)col;
+    return r;
+}
+template <int F> __device__ __forceinline__ fe29_t fe29_mul_lz(const fe29_t &a, const fe29_t &b) {
+    uint64_t col, cc; fe29_t r;
+    uint32_t m0, m1, m2, m3, m4, m5, m6, m7, m8;
+    const uint32_t p1 = P29<F>::L1, p2 = P29<F>::L2, p3 = P29<F>::L3, p4 = P29<F>::L4, p8 = P29<F>::L8;
+    // column 0: 1 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 0"
+        : "=&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[0]));
+    m0 = 0u - (uint32_t)col;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m0));
+    col >>= 29;
+    // column 1: 3 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[1]), "v"(a.v[1]), "v"(b.v[0]), "v"(m0), "v"(p1));
+    m1 = 0u - (uint32_t)col;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m1));
+    col >>= 29;
+    // column 2: 5 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[2]), "v"(a.v[1]), "v"(b.v[1]), "v"(a.v[2]), "v"(b.v[0]), "v"(m1), "v"(p1), "v"(m0), "v"(p2));
+    m2 = 0u - (uint32_t)col;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m2));
+    col >>= 29;
+    // column 3: 7 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[3]), "v"(a.v[1]), "v"(b.v[2]), "v"(a.v[2]), "v"(b.v[1]), "v"(a.v[3]), "v"(b.v[0]), "v"(m2), "v"(p1), "v"(m1), "v"(p2), "v"(m0), "v"(p3));
+    m3 = 0u - (uint32_t)col;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m3));
+    col >>= 29;
+    // column 4: 9 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[4]), "v"(a.v[1]), "v"(b.v[3]), "v"(a.v[2]), "v"(b.v[2]), "v"(a.v[3]), "v"(b.v[1]), "v"(a.v[4]), "v"(b.v[0]), "v"(m3), "v"(p1), "v"(m2), "v"(p2), "v"(m1), "v"(p3), "v"(m0), "v"(p4));
+    m4 = 0u - (uint32_t)col;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m4));
+    col >>= 29;
+    // column 5: 10 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[5]), "v"(a.v[1]), "v"(b.v[4]), "v"(a.v[2]), "v"(b.v[3]), "v"(a.v[3]), "v"(b.v[2]), "v"(a.v[4]), "v"(b.v[1]), "v"(a.v[5]), "v"(b.v[0]), "v"(m4), "v"(p1), "v"(m3), "v"(p2), "v"(m2), "v"(p3), "v"(m1), "v"(p4));
+    m5 = 0u - (uint32_t)col;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m5));
+    col >>= 29;
+    // column 6: 11 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[6]), "v"(a.v[1]), "v"(b.v[5]), "v"(a.v[2]), "v"(b.v[4]), "v"(a.v[3]), "v"(b.v[3]), "v"(a.v[4]), "v"(b.v[2]), "v"(a.v[5]), "v"(b.v[1]), "v"(a.v[6]), "v"(b.v[0]), "v"(m5), "v"(p1), "v"(m4), "v"(p2), "v"(m3), "v"(p3), "v"(m2), "v"(p4));
+    m6 = 0u - (uint32_t)col;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m6));
+    col >>= 29;
+    // column 7: 12 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[7]), "v"(a.v[1]), "v"(b.v[6]), "v"(a.v[2]), "v"(b.v[5]), "v"(a.v[3]), "v"(b.v[4]), "v"(a.v[4]), "v"(b.v[3]), "v"(a.v[5]), "v"(b.v[2]), "v"(a.v[6]), "v"(b.v[1]), "v"(a.v[7]), "v"(b.v[0]), "v"(m6), "v"(p1), "v"(m5), "v"(p2), "v"(m4), "v"(p3), "v"(m3), "v"(p4));
+    m7 = 0u - (uint32_t)col;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m7));
+    col >>= 29;
+    // column 8: 14 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[8]), "v"(a.v[1]), "v"(b.v[7]), "v"(a.v[2]), "v"(b.v[6]), "v"(a.v[3]), "v"(b.v[5]), "v"(a.v[4]), "v"(b.v[4]), "v"(a.v[5]), "v"(b.v[3]), "v"(a.v[6]), "v"(b.v[2]), "v"(a.v[7]), "v"(b.v[1]), "v"(a.v[8]), "v"(b.v[0]), "v"(m7), "v"(p1), "v"(m6), "v"(p2), "v"(m5), "v"(p3));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m4), "v"(p4), "v"(m0), "v"(p8));
+    m8 = 0u - (uint32_t)col;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m8));
+    col >>= 29;
+    // column 9: 13 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[1]), "v"(b.v[8]), "v"(a.v[2]), "v"(b.v[7]), "v"(a.v[3]), "v"(b.v[6]), "v"(a.v[4]), "v"(b.v[5]), "v"(a.v[5]), "v"(b.v[4]), "v"(a.v[6]), "v"(b.v[3]), "v"(a.v[7]), "v"(b.v[2]), "v"(a.v[8]), "v"(b.v[1]), "v"(m8), "v"(p1), "v"(m7), "v"(p2), "v"(m6), "v"(p3), "v"(m5), "v"(p4));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m1), "v"(p8));
+    r.v[0] = (uint32_t)col & M29; col >>= 29;
+    // column 10: 11 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[2]), "v"(b.v[8]), "v"(a.v[3]), "v"(b.v[7]), "v"(a.v[4]), "v"(b.v[6]), "v"(a.v[5]), "v"(b.v[5]), "v"(a.v[6]), "v"(b.v[4]), "v"(a.v[7]), "v"(b.v[3]), "v"(a.v[8]), "v"(b.v[2]), "v"(m8), "v"(p2), "v"(m7), "v"(p3), "v"(m6), "v"(p4), "v"(m2), "v"(p8));
+    r.v[1] = (uint32_t)col & M29; col >>= 29;
+    // column 11: 9 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[3]), "v"(b.v[8]), "v"(a.v[4]), "v"(b.v[7]), "v"(a.v[5]), "v"(b.v[6]), "v"(a.v[6]), "v"(b.v[5]), "v"(a.v[7]), "v"(b.v[4]), "v"(a.v[8]), "v"(b.v[3]), "v"(m8), "v"(p3), "v"(m7), "v"(p4), "v"(m3), "v"(p8));
+    r.v[2] = (uint32_t)col & M29; col >>= 29;
+    // column 12: 7 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[4]), "v"(b.v[8]), "v"(a.v[5]), "v"(b.v[7]), "v"(a.v[6]), "v"(b.v[6]), "v"(a.v[7]), "v"(b.v[5]), "v"(a.v[8]), "v"(b.v[4]), "v"(m8), "v"(p4), "v"(m4), "v"(p8));
+    r.v[3] = (uint32_t)col & M29; col >>= 29;
+    // column 13: 5 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[5]), "v"(b.v[8]), "v"(a.v[6]), "v"(b.v[7]), "v"(a.v[7]), "v"(b.v[6]), "v"(a.v[8]), "v"(b.v[5]), "v"(m5), "v"(p8));
+    r.v[4] = (uint32_t)col & M29; col >>= 29;
+    // column 14: 4 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[6]), "v"(b.v[8]), "v"(a.v[7]), "v"(b.v[7]), "v"(a.v[8]), "v"(b.v[6]), "v"(m6), "v"(p8));
+    r.v[5] = (uint32_t)col & M29; col >>= 29;
+    // column 15: 3 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[7]), "v"(b.v[8]), "v"(a.v[8]), "v"(b.v[7]), "v"(m7), "v"(p8));
+    r.v[6] = (uint32_t)col & M29; col >>= 29;
+    // column 16: 2 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[8]), "v"(b.v[8]), "v"(m8), "v"(p8));
+    r.v[7] = (uint32_t)col & M29; col >>= 29;
+    r.v[8] = (uint32_t)col;
+    return r;
+}
+template <int F> __device__ __forceinline__ fe29_t fe29_sqr_lz(const fe29_t &a) {
+    const uint32_t d0 = a.v[0] << 1, d1 = a.v[1] << 1, d2 = a.v[2] << 1, d3 = a.v[3] << 1, d4 = a.v[4] << 1, d5 = a.v[5] << 1, d6 = a.v[6] << 1, d7 = a.v[7] << 1;   // limbs < 2^29: the doubled ones fit 32 bits
+    uint64_t col, cc; fe29_t r;
+    uint32_t m0, m1, m2, m3, m4, m5, m6, m7, m8;
+    const uint32_t p1 = P29<F>::L1, p2 = P29<F>::L2, p3 = P29<F>::L3, p4 = P29<F>::L4, p8 = P29<F>::L8;
+    // column 0: 1 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 0"
+        : "=&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(a.v[0]));
+    m0 = 0u - (uint32_t)col;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m0));
+    col >>= 29;
+    // column 1: 2 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d0), "v"(a.v[1]), "v"(m0), "v"(p1));
+    m1 = 0u - (uint32_t)col;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m1));
+    col >>= 29;
+    // column 2: 4 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d0), "v"(a.v[2]), "v"(a.v[1]), "v"(a.v[1]), "v"(m1), "v"(p1), "v"(m0), "v"(p2));
+    m2 = 0u - (uint32_t)col;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m2));
+    col >>= 29;
+    // column 3: 5 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d0), "v"(a.v[3]), "v"(d1), "v"(a.v[2]), "v"(m2), "v"(p1), "v"(m1), "v"(p2), "v"(m0), "v"(p3));
+    m3 = 0u - (uint32_t)col;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m3));
+    col >>= 29;
+    // column 4: 7 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d0), "v"(a.v[4]), "v"(d1), "v"(a.v[3]), "v"(a.v[2]), "v"(a.v[2]), "v"(m3), "v"(p1), "v"(m2), "v"(p2), "v"(m1), "v"(p3), "v"(m0), "v"(p4));
+    m4 = 0u - (uint32_t)col;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m4));
+    col >>= 29;
+    // column 5: 7 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d0), "v"(a.v[5]), "v"(d1), "v"(a.v[4]), "v"(d2), "v"(a.v[3]), "v"(m4), "v"(p1), "v"(m3), "v"(p2), "v"(m2), "v"(p3), "v"(m1), "v"(p4));
+    m5 = 0u - (uint32_t)col;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m5));
+    col >>= 29;
+    // column 6: 8 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d0), "v"(a.v[6]), "v"(d1), "v"(a.v[5]), "v"(d2), "v"(a.v[4]), "v"(a.v[3]), "v"(a.v[3]), "v"(m5), "v"(p1), "v"(m4), "v"(p2), "v"(m3), "v"(p3), "v"(m2), "v"(p4));
+    m6 = 0u - (uint32_t)col;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m6));
+    col >>= 29;
+    // column 7: 8 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d0), "v"(a.v[7]), "v"(d1), "v"(a.v[6]), "v"(d2), "v"(a.v[5]), "v"(d3), "v"(a.v[4]), "v"(m6), "v"(p1), "v"(m5), "v"(p2), "v"(m4), "v"(p3), "v"(m3), "v"(p4));
+    m7 = 0u - (uint32_t)col;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m7));
+    col >>= 29;
+    // column 8: 10 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d0), "v"(a.v[8]), "v"(d1), "v"(a.v[7]), "v"(d2), "v"(a.v[6]), "v"(d3), "v"(a.v[5]), "v"(a.v[4]), "v"(a.v[4]), "v"(m7), "v"(p1), "v"(m6), "v"(p2), "v"(m5), "v"(p3), "v"(m4), "v"(p4), "v"(m0), "v"(p8));
+    m8 = 0u - (uint32_t)col;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m8));
+    col >>= 29;
+    // column 9: 9 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d1), "v"(a.v[8]), "v"(d2), "v"(a.v[7]), "v"(d3), "v"(a.v[6]), "v"(d4), "v"(a.v[5]), "v"(m8), "v"(p1), "v"(m7), "v"(p2), "v"(m6), "v"(p3), "v"(m5), "v"(p4), "v"(m1), "v"(p8));
+    r.v[0] = (uint32_t)col & M29; col >>= 29;
+    // column 10: 8 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d2), "v"(a.v[8]), "v"(d3), "v"(a.v[7]), "v"(d4), "v"(a.v[6]), "v"(a.v[5]), "v"(a.v[5]), "v"(m8), "v"(p2), "v"(m7), "v"(p3), "v"(m6), "v"(p4), "v"(m2), "v"(p8));
+    r.v[1] = (uint32_t)col & M29; col >>= 29;
+    // column 11: 6 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d3), "v"(a.v[8]), "v"(d4), "v"(a.v[7]), "v"(d5), "v"(a.v[6]), "v"(m8), "v"(p3), "v"(m7), "v"(p4), "v"(m3), "v"(p8));
+    r.v[2] = (uint32_t)col & M29; col >>= 29;
+    // column 12: 5 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d4), "v"(a.v[8]), "v"(d5), "v"(a.v[7]), "v"(a.v[6]), "v"(a.v[6]), "v"(m8), "v"(p4), "v"(m4), "v"(p8));
+    r.v[3] = (uint32_t)col & M29; col >>= 29;
+    // column 13: 3 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d5), "v"(a.v[8]), "v"(d6), "v"(a.v[7]), "v"(m5), "v"(p8));
+    r.v[4] = (uint32_t)col & M29; col >>= 29;
+    // column 14: 3 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d6), "v"(a.v[8]), "v"(a.v[7]), "v"(a.v[7]), "v"(m6), "v"(p8));
+    r.v[5] = (uint32_t)col & M29; col >>= 29;
+    // column 15: 2 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d7), "v"(a.v[8]), "v"(m7), "v"(p8));
+    r.v[6] = (uint32_t)col & M29; col >>= 29;
+    // column 16: 2 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[8]), "v"(a.v[8]), "v"(m8), "v"(p8));
+    r.v[7] = (uint32_t)col & M29; col >>= 29;
+    r.v[8] = (uint32_t)col;
+    return r;
+}
+template <int F> __device__ __forceinline__ fe29_t fe29_dot3rc_lz(const fe29_t &a0, const fe29_t &b0, const fe29_t &a1, const fe29_t &b1, const fe29_t &a2, const fe29_t &b2, const fe29_t &c) {
+    uint64_t col, cc; fe29_t r;
+    uint32_t m0, m1, m2, m3, m4, m5, m6, m7, m8;
+    const uint32_t p1 = P29<F>::L1, p2 = P29<F>::L2, p3 = P29<F>::L3, p4 = P29<F>::L4, p8 = P29<F>::L8;
+    // column 0: 4 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, 1, %0"
+        : "=&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[0]), "v"(a2.v[0]), "v"(b2.v[0]), "v"(c.v[0]));
+    m0 = 0u - (uint32_t)col;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m0));
+    col >>= 29;
+    // column 1: 8 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, 1, %0\n\tv_mad_u64_u32 %0, %1, %15, %16, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[1]), "v"(a0.v[1]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[1]), "v"(a1.v[1]), "v"(b1.v[0]), "v"(a2.v[0]), "v"(b2.v[1]), "v"(a2.v[1]), "v"(b2.v[0]), "v"(c.v[1]), "v"(m0), "v"(p1));
+    m1 = 0u - (uint32_t)col;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m1));
+    col >>= 29;
+    // column 2: 12 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, 1, %0\n\tv_mad_u64_u32 %0, %1, %21, %22, %0\n\tv_mad_u64_u32 %0, %1, %23, %24, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[2]), "v"(a0.v[1]), "v"(b0.v[1]), "v"(a0.v[2]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[2]), "v"(a1.v[1]), "v"(b1.v[1]), "v"(a1.v[2]), "v"(b1.v[0]), "v"(a2.v[0]), "v"(b2.v[2]), "v"(a2.v[1]), "v"(b2.v[1]), "v"(a2.v[2]), "v"(b2.v[0]), "v"(c.v[2]), "v"(m1), "v"(p1), "v"(m0), "v"(p2));
+    m2 = 0u - (uint32_t)col;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m2));
+    col >>= 29;
+    // column 3: 16 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[3]), "v"(a0.v[1]), "v"(b0.v[2]), "v"(a0.v[2]), "v"(b0.v[1]), "v"(a0.v[3]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[3]), "v"(a1.v[1]), "v"(b1.v[2]), "v"(a1.v[2]), "v"(b1.v[1]), "v"(a1.v[3]), "v"(b1.v[0]), "v"(a2.v[0]), "v"(b2.v[3]), "v"(a2.v[1]), "v"(b2.v[2]), "v"(a2.v[2]), "v"(b2.v[1]), "v"(a2.v[3]), "v"(b2.v[0]));
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0\n\tv_mad_u64_u32 %0, %1, %3, %4, %0\n\tv_mad_u64_u32 %0, %1, %5, %6, %0\n\tv_mad_u64_u32 %0, %1, %7, %8, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(c.v[3]), "v"(m2), "v"(p1), "v"(m1), "v"(p2), "v"(m0), "v"(p3));
+    m3 = 0u - (uint32_t)col;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m3));
+    col >>= 29;
+    // column 4: 20 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[4]), "v"(a0.v[1]), "v"(b0.v[3]), "v"(a0.v[2]), "v"(b0.v[2]), "v"(a0.v[3]), "v"(b0.v[1]), "v"(a0.v[4]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[4]), "v"(a1.v[1]), "v"(b1.v[3]), "v"(a1.v[2]), "v"(b1.v[2]), "v"(a1.v[3]), "v"(b1.v[1]), "v"(a1.v[4]), "v"(b1.v[0]), "v"(a2.v[0]), "v"(b2.v[4]), "v"(a2.v[1]), "v"(b2.v[3]));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, 1, %0\n\tv_mad_u64_u32 %0, %1, %9, %10, %0\n\tv_mad_u64_u32 %0, %1, %11, %12, %0\n\tv_mad_u64_u32 %0, %1, %13, %14, %0\n\tv_mad_u64_u32 %0, %1, %15, %16, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a2.v[2]), "v"(b2.v[2]), "v"(a2.v[3]), "v"(b2.v[1]), "v"(a2.v[4]), "v"(b2.v[0]), "v"(c.v[4]), "v"(m3), "v"(p1), "v"(m2), "v"(p2), "v"(m1), "v"(p3), "v"(m0), "v"(p4));
+    m4 = 0u - (uint32_t)col;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m4));
+    col >>= 29;
+    // column 5: 23 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[5]), "v"(a0.v[1]), "v"(b0.v[4]), "v"(a0.v[2]), "v"(b0.v[3]), "v"(a0.v[3]), "v"(b0.v[2]), "v"(a0.v[4]), "v"(b0.v[1]), "v"(a0.v[5]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[5]), "v"(a1.v[1]), "v"(b1.v[4]), "v"(a1.v[2]), "v"(b1.v[3]), "v"(a1.v[3]), "v"(b1.v[2]), "v"(a1.v[4]), "v"(b1.v[1]), "v"(a1.v[5]), "v"(b1.v[0]));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, 1, %0\n\tv_mad_u64_u32 %0, %1, %15, %16, %0\n\tv_mad_u64_u32 %0, %1, %17, %18, %0\n\tv_mad_u64_u32 %0, %1, %19, %20, %0\n\tv_mad_u64_u32 %0, %1, %21, %22, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a2.v[0]), "v"(b2.v[5]), "v"(a2.v[1]), "v"(b2.v[4]), "v"(a2.v[2]), "v"(b2.v[3]), "v"(a2.v[3]), "v"(b2.v[2]), "v"(a2.v[4]), "v"(b2.v[1]), "v"(a2.v[5]), "v"(b2.v[0]), "v"(c.v[5]), "v"(m4), "v"(p1), "v"(m3), "v"(p2), "v"(m2), "v"(p3), "v"(m1), "v"(p4));
+    m5 = 0u - (uint32_t)col;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m5));
+    col >>= 29;
+    // column 6: 26 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[6]), "v"(a0.v[1]), "v"(b0.v[5]), "v"(a0.v[2]), "v"(b0.v[4]), "v"(a0.v[3]), "v"(b0.v[3]), "v"(a0.v[4]), "v"(b0.v[2]), "v"(a0.v[5]), "v"(b0.v[1]), "v"(a0.v[6]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[6]), "v"(a1.v[1]), "v"(b1.v[5]), "v"(a1.v[2]), "v"(b1.v[4]), "v"(a1.v[3]), "v"(b1.v[3]), "v"(a1.v[4]), "v"(b1.v[2]));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, 1, %0\n\tv_mad_u64_u32 %0, %1, %21, %22, %0\n\tv_mad_u64_u32 %0, %1, %23, %24, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a1.v[5]), "v"(b1.v[1]), "v"(a1.v[6]), "v"(b1.v[0]), "v"(a2.v[0]), "v"(b2.v[6]), "v"(a2.v[1]), "v"(b2.v[5]), "v"(a2.v[2]), "v"(b2.v[4]), "v"(a2.v[3]), "v"(b2.v[3]), "v"(a2.v[4]), "v"(b2.v[2]), "v"(a2.v[5]), "v"(b2.v[1]), "v"(a2.v[6]), "v"(b2.v[0]), "v"(c.v[6]), "v"(m5), "v"(p1), "v"(m4), "v"(p2));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m3), "v"(p3), "v"(m2), "v"(p4));
+    m6 = 0u - (uint32_t)col;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m6));
+    col >>= 29;
+    // column 7: 29 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[7]), "v"(a0.v[1]), "v"(b0.v[6]), "v"(a0.v[2]), "v"(b0.v[5]), "v"(a0.v[3]), "v"(b0.v[4]), "v"(a0.v[4]), "v"(b0.v[3]), "v"(a0.v[5]), "v"(b0.v[2]), "v"(a0.v[6]), "v"(b0.v[1]), "v"(a0.v[7]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[7]), "v"(a1.v[1]), "v"(b1.v[6]), "v"(a1.v[2]), "v"(b1.v[5]), "v"(a1.v[3]), "v"(b1.v[4]));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a1.v[4]), "v"(b1.v[3]), "v"(a1.v[5]), "v"(b1.v[2]), "v"(a1.v[6]), "v"(b1.v[1]), "v"(a1.v[7]), "v"(b1.v[0]), "v"(a2.v[0]), "v"(b2.v[7]), "v"(a2.v[1]), "v"(b2.v[6]), "v"(a2.v[2]), "v"(b2.v[5]), "v"(a2.v[3]), "v"(b2.v[4]), "v"(a2.v[4]), "v"(b2.v[3]), "v"(a2.v[5]), "v"(b2.v[2]), "v"(a2.v[6]), "v"(b2.v[1]), "v"(a2.v[7]), "v"(b2.v[0]));
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0\n\tv_mad_u64_u32 %0, %1, %3, %4, %0\n\tv_mad_u64_u32 %0, %1, %5, %6, %0\n\tv_mad_u64_u32 %0, %1, %7, %8, %0\n\tv_mad_u64_u32 %0, %1, %9, %10, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(c.v[7]), "v"(m6), "v"(p1), "v"(m5), "v"(p2), "v"(m4), "v"(p3), "v"(m3), "v"(p4));
+    m7 = 0u - (uint32_t)col;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m7));
+    col >>= 29;
+    // column 8: 33 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[8]), "v"(a0.v[1]), "v"(b0.v[7]), "v"(a0.v[2]), "v"(b0.v[6]), "v"(a0.v[3]), "v"(b0.v[5]), "v"(a0.v[4]), "v"(b0.v[4]), "v"(a0.v[5]), "v"(b0.v[3]), "v"(a0.v[6]), "v"(b0.v[2]), "v"(a0.v[7]), "v"(b0.v[1]), "v"(a0.v[8]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[8]), "v"(a1.v[1]), "v"(b1.v[7]), "v"(a1.v[2]), "v"(b1.v[6]));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a1.v[3]), "v"(b1.v[5]), "v"(a1.v[4]), "v"(b1.v[4]), "v"(a1.v[5]), "v"(b1.v[3]), "v"(a1.v[6]), "v"(b1.v[2]), "v"(a1.v[7]), "v"(b1.v[1]), "v"(a1.v[8]), "v"(b1.v[0]), "v"(a2.v[0]), "v"(b2.v[8]), "v"(a2.v[1]), "v"(b2.v[7]), "v"(a2.v[2]), "v"(b2.v[6]), "v"(a2.v[3]), "v"(b2.v[5]), "v"(a2.v[4]), "v"(b2.v[4]), "v"(a2.v[5]), "v"(b2.v[3]));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, 1, %0\n\tv_mad_u64_u32 %0, %1, %9, %10, %0\n\tv_mad_u64_u32 %0, %1, %11, %12, %0\n\tv_mad_u64_u32 %0, %1, %13, %14, %0\n\tv_mad_u64_u32 %0, %1, %15, %16, %0\n\tv_mad_u64_u32 %0, %1, %17, %18, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a2.v[6]), "v"(b2.v[2]), "v"(a2.v[7]), "v"(b2.v[1]), "v"(a2.v[8]), "v"(b2.v[0]), "v"(c.v[8]), "v"(m7), "v"(p1), "v"(m6), "v"(p2), "v"(m5), "v"(p3), "v"(m4), "v"(p4), "v"(m0), "v"(p8));
+    m8 = 0u - (uint32_t)col;
     asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
         : "+&v"(col), "=&s"(cc) : "v"(m8));
     col >>= 29;

@@ -121,7 +121,10 @@ __global__ void bpoly_eval_kernel(uint32_t k, uint32_t npoints, FieldK fk, const
 struct PoseidonParams { fe_t mds[3][3]; fe_t rc[55][3]; };     // Montgomery, in HBM (read with uniform addresses)
 // the same constants for the 3-lane permutation's 29-bit-limb arithmetic (fp29.cuh): Montgomery with R = 2^261, plus the two re-basing
 // constants.  Lives in the same device buffer right behind PoseidonParams (api_sponge.hip: mina_poseidon_set_params).
-struct PoseidonParams29 { fe29_t mds[3][3]; fe29_t rc[55][3]; fe29_t enter /* 2^266 mod p */, leave /* 2^256 mod p */; uint32_t pad[4]; /* size: a multiple of 16 */ };
+struct PoseidonParams29 { fe29_t mds[3][3]; fe29_t rc[55][3]; fe29_t enter /* 2^266 mod p */, leave /* 2^256 mod p */;
+                          fe29_t rc2[55][3];      // the round constants times 2^261 once more (rc 2^522 mod p): added BEFORE the reduction of the 3-lane form's MDS dot product
+                          uint32_t pad[3]; };     // size: a multiple of 16
+static_assert(sizeof(PoseidonParams29) % 16 == 0, "PoseidonParams29 is read with 16-byte loads");
 __host__ __device__ static inline const PoseidonParams29 *pparams29_of(const PoseidonParams *pp) { return reinterpret_cast<const PoseidonParams29 *>(pp + 1); }
 
 template <int F>
@@ -281,15 +284,18 @@ __device__ __forceinline__ void poseidon_permute_tri(fe_t &s, const PoseidonPara
     const PoseidonParams29 *__restrict__ q = pparams29_of(pp);
     const fe29_t m0 = q->mds[tp.e][0], m1 = q->mds[tp.e][1], m2 = q->mds[tp.e][2];
     fe29_t x = fe29_mul_asm<F>(fe29_from_words(s), q->enter);        // x 2^256 -> x 2^261
+    // The rounds use the LAZY products (fp29.cuh: quotient digits not masked, results < a b / 2^261 + 8.0001 p, limbs normalised).  Values along a round,
+    // in units of p, from x < 8.3: x^2 < 8.6, x^4 < 8.6, x^6 < 8.6, x^7 < 8.6, the MDS row with the round constant inside the reduction < 8.3 -- a fixed
+    // point below 2^258, so every limb product and every column stays inside 64 bits (tools/gen_fe29.py; the column maximum is 0.93 x 2^64).
 #pragma unroll 1
     for (int r = 0; r < 55; ++r) {
-        const fe29_t x2 = fe29_sqr_asm<F>(x);
-        const fe29_t x4 = fe29_sqr_asm<F>(x2);
-        const fe29_t t = fe29_mul_asm<F>(fe29_mul_asm<F>(x4, x2), x);
+        const fe29_t x2 = fe29_sqr_lz<F>(x);
+        const fe29_t x4 = fe29_sqr_lz<F>(x2);
+        const fe29_t t = fe29_mul_lz<F>(fe29_mul_lz<F>(x4, x2), x);
         const fe29_t t0 = tri_bcast29(t, tp.base), t1 = tri_bcast29(t, tp.base + 1), t2 = tri_bcast29(t, tp.base + 2);
-        x = fe29_add(fe29_dot3_asm<F>(m0, t0, m1, t1, m2, t2), q->rc[r][tp.e]);     // < 2.2 p, normalised limbs: no subtraction
+        x = fe29_dot3rc_lz<F>(m0, t0, m1, t1, m2, t2, q->rc2[r][tp.e]);
     }
-    s = fe_cond_sub_p<F>(fe29_to_words(fe29_mul_asm<F>(x, q->leave)));   // x 2^261 -> x 2^256, below 1.01 p: one conditional subtraction
+    s = fe_cond_sub_p<F>(fe29_to_words(fe29_mul_asm<F>(x, q->leave)));   // x 2^261 -> x 2^256; the strict product: 8.3 p p / 2^261 + p < 1.07 p: one conditional subtraction
 #else
     (void)s; (void)pp;                                               // device-only (the host pass never calls it)
 #endif

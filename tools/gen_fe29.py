@@ -4,6 +4,10 @@
     fe29_sqr_asm    a * a / R        cross terms once, against the doubled limbs (45 limb products instead of 81)
     fe29_dot2_asm   (a0 b0 + a1 b1) / R             one reduction (the 8-lane permutation's split MDS row)
     fe29_dot3_asm   (a0 b0 + a1 b1 + a2 b2) / R     one reduction
+and the LAZY forms the chip-filling 3-lane permutation runs its rounds in (fe29_sqr_lz, fe29_mul_lz, fe29_dot3rc_lz): the quotient digit
+m_k = -col mod 2^32 is NOT masked to 29 bits (its three high bits add a multiple of p 2^(29 k): the value stays the same field element,
+the result is < a b / R + 8.0001 p instead of < a b / R + p), the accumulator starts from the first product (no zeroing), and the dot
+product takes a tenth operand c added before the reduction ((sum + c) / R: the round constant, stored times R).  Bounds: fp29.cuh.
 One asm statement per chunk of <= 12 multiply-accumulates of a column (inline asm takes at most 30 operands); between the columns plain
 C++ (mask, shift).  The compiler's own schedule of the C++ form spreads a column over several accumulators and re-adds them (+116 64-bit
 adds and +70 products per Poseidon round); pinned like this a round is ~1150 VALU instructions instead of ~1610.
@@ -16,24 +20,25 @@ L = 9
 W = 29
 
 
-def mads(terms):
-    """asm statements accumulating `terms` (pairs of C expressions, or (expr, int literal)) into col"""
+def mads(terms, fresh=False):
+    """asm statements accumulating `terms` (pairs of C expressions, or (expr, int literal)) into col; fresh: col is not read (the first product starts it)"""
     out = []
     for c0 in range(0, len(terms), MAXT):
         chunk = terms[c0:c0 + MAXT]
         lines, ops = [], []
         n = 2
         for x, y in chunk:
+            addend = "0" if fresh and c0 == 0 and not lines else "%0"
             if isinstance(y, int):
-                lines.append(f"v_mad_u64_u32 %0, %1, %{n}, {y}, %0"); ops.append(f'"v"({x})'); n += 1
+                lines.append(f"v_mad_u64_u32 %0, %1, %{n}, {y}, {addend}"); ops.append(f'"v"({x})'); n += 1
             else:
-                lines.append(f"v_mad_u64_u32 %0, %1, %{n}, %{n + 1}, %0"); ops += [f'"v"({x})', f'"v"({y})']; n += 2
-        out.append('    asm("' + '\\n\\t'.join(lines) + '"\n        : "+&v"(col), "=&s"(cc) : ' + ", ".join(ops) + ");")
+                lines.append(f"v_mad_u64_u32 %0, %1, %{n}, %{n + 1}, {addend}"); ops += [f'"v"({x})', f'"v"({y})']; n += 2
+        out.append('    asm("' + '\\n\\t'.join(lines) + '"\n        : "' + ("=&v" if fresh and c0 == 0 else "+&v") + '"(col), "=&s"(cc) : ' + ", ".join(ops) + ");")
     return out
 
 
-def body(col_terms):
-    out = ["    uint64_t col = 0, cc; fe29_t r;", "    uint32_t " + ", ".join(f"m{i}" for i in range(L)) + ";",
+def body(col_terms, lazy=False):
+    out = ["    uint64_t col, cc; fe29_t r;" if lazy else "    uint64_t col = 0, cc; fe29_t r;", "    uint32_t " + ", ".join(f"m{i}" for i in range(L)) + ";",
            "    const uint32_t p1 = P29<F>::L1, p2 = P29<F>::L2, p3 = P29<F>::L3, p4 = P29<F>::L4, p8 = P29<F>::L8;"]
     for k in range(2 * L - 1):
         terms = list(col_terms(k))
@@ -45,9 +50,9 @@ def body(col_terms):
         if 0 <= i < L and i < k:
             terms.append((f"m{i}", "p8"))                        # p_8 = 2^22
         out.append(f"    // column {k}: {len(terms)} products")
-        out += mads(terms)
+        out += mads(terms, fresh=lazy and k == 0)
         if k < L:
-            out.append(f"    m{k} = (0u - (uint32_t)col) & M29;")
+            out.append(f"    m{k} = 0u - (uint32_t)col;" if lazy else f"    m{k} = (0u - (uint32_t)col) & M29;")
             out += mads([(f"m{k}", 1)])                          # + m_k p_0: the low limb cancels
             out.append(f"    col >>= {W};")
         else:
@@ -57,16 +62,16 @@ def body(col_terms):
     return out
 
 
-def emit_mul():
+def emit_mul(lazy=False):
     def terms(k):
         for i in range(L):
             j = k - i
             if 0 <= j < L:
                 yield (f"a.v[{i}]", f"b.v[{j}]")
-    return ["template <int F> __device__ __forceinline__ fe29_t fe29_mul_asm(const fe29_t &a, const fe29_t &b) {"] + body(terms) + ["}"]
+    return [f"template <int F> __device__ __forceinline__ fe29_t fe29_mul_{'lz' if lazy else 'asm'}(const fe29_t &a, const fe29_t &b) {{"] + body(terms, lazy) + ["}"]
 
 
-def emit_sqr():
+def emit_sqr(lazy=False):
     def terms(k):
         for i in range(L):
             j = k - i
@@ -74,9 +79,21 @@ def emit_sqr():
                 yield (f"d{i}", f"a.v[{j}]")
         if k % 2 == 0 and k // 2 < L:
             yield (f"a.v[{k // 2}]", f"a.v[{k // 2}]")
-    pre = ["template <int F> __device__ __forceinline__ fe29_t fe29_sqr_asm(const fe29_t &a) {",
+    pre = [f"template <int F> __device__ __forceinline__ fe29_t fe29_sqr_{'lz' if lazy else 'asm'}(const fe29_t &a) {{",
            "    const uint32_t " + ", ".join(f"d{i} = a.v[{i}] << 1" for i in range(L - 1)) + ";   // limbs < 2^29: the doubled ones fit 32 bits"]
-    return pre + body(terms) + ["}"]
+    return pre + body(terms, lazy) + ["}"]
+
+
+def emit_dot3rc_lz():
+    def terms(k):
+        for t in range(3):
+            for i in range(L):
+                j = k - i
+                if 0 <= j < L:
+                    yield (f"a{t}.v[{i}]", f"b{t}.v[{j}]")
+        if k < L:
+            yield (f"c.v[{k}]", 1)
+    return ["template <int F> __device__ __forceinline__ fe29_t fe29_dot3rc_lz(const fe29_t &a0, const fe29_t &b0, const fe29_t &a1, const fe29_t &b1, const fe29_t &a2, const fe29_t &b2, const fe29_t &c) {"] + body(terms, True) + ["}"]
 
 
 def emit_dot3():
@@ -100,7 +117,7 @@ def emit_dot2():
 
 
 def generated():
-    return "\n".join(["// ---- GENERATED by tools/gen_fe29.py: do not edit by hand"] + emit_mul() + emit_sqr() + emit_dot2() + emit_dot3() + ["// ---- END GENERATED"]) + "\n"
+    return "\n".join(["// ---- GENERATED by tools/gen_fe29.py: do not edit by hand"] + emit_mul() + emit_sqr() + emit_dot2() + emit_dot3() + emit_mul(True) + emit_sqr(True) + emit_dot3rc_lz() + ["// ---- END GENERATED"]) + "\n"
 
 
 if __name__ == "__main__":
