@@ -58,14 +58,14 @@ ACC_K, WRAP_K, LOG2_DOMAIN, NPUB, NCOMMS, NPTS, SLOT = 16, 15, 15, 40, 45, 2, 0
 STATES_PER_PROOF, PSTATE_SLOTS, PSTATE_BODY_FIELDS = 17, 64, 49
 HBM_PEAK_GBPS = 8000.0                                # MI355X_MICROARCH.md: 8 TB/s spec
 # VALU side of the roofline (the path is integer-multiply bound).  The dominant kernel runs its Poseidon rounds on 9 limbs of
-# 29 bits (fp29.cuh): per lane and round 2 squarings (99 limb multiply-accumulates each), 2 products (135) and one 3-term dot product (297)
-# = 765 `v_mad_u64_u32` beside ~290 simple instructions (64-bit column shifts, limb masks).  ONE model (profiles/r04_valu_roofline.md): the ceiling is
-# the measured rate of THAT MIX -- 153 multiply-accumulates interleaved with 29 shifts + 29 masks per trip, the round's ratio, 8 waves per SIMD
-# (mina_bridge_amd/microbench, profiles/r04_microbench_valu.jsonl): 6.04 nominal-clock cycles per multiply-accumulate OF THE MIX, i.e. 2.52 ns per
-# wave64 multiply-accumulate per SIMD with the simple instructions riding in its shadow (the pure stream: 6.3 - 7.0; round 3 priced 7.0 and called
-# the simple instructions free, a second model priced every instruction at 4 cycles: both are replaced by this measurement).
-MADS_PER_LANE_ROUND = 2 * 99 + 2 * 135 + 297
-MAD_ISSUE_CYCLES = 6.04
+# 29 bits (fp29.cuh, lazy forms): per lane and round 2 squarings (99 limb multiply-accumulates each), 2 products (135) and one 3-term dot product
+# with the round constant inside its reduction (306) = 774 `v_mad_u64_u32` beside ~190 simple instructions (64-bit column shifts, negations, limb
+# masks).  ONE model (profiles/r04_valu_roofline.md): every instruction takes its issue slot, and the ceiling is the measured rate of THAT MIX -- 153
+# multiply-accumulates interleaved with 16 shifts, 9 negations, 8 masks, 4 32-bit shifts per trip, 8 waves per SIMD (`microbench --ratio`,
+# profiles/r04_microbench_ratio.jsonl): 5.46 nominal-clock cycles per multiply-accumulate OF THE MIX = 2.28 ns per wave64 multiply-accumulate per SIMD
+# (a pure stream: 4.66; the strict forms' mix of 765 + ~290 until late in round 4: 5.9 - 6.04).
+MADS_PER_LANE_ROUND = 2 * 99 + 2 * 135 + 306
+MAD_ISSUE_CYCLES = 5.46
 CHIP_SIMDS, CLOCK_HZ = 1024, 2.4e9
 PROF_STAGES = {"pstate_hash": 11, "ipa_transcript": 12, "kimchi_to_batch": 13, "pickles_statement": 14, "msm_accumulate": 3}
 # HBM-side bytes per protocol-state hash: read from the tracked summary of the rocprofv3 PMC passes (FETCH_SIZE x 2 -- the gfx950 correction
@@ -850,16 +850,15 @@ def main():
             peak = CHIP_SIMDS * 64 * CLOCK_HZ / MAD_ISSUE_CYCLES
             got = perms * 3 * 55 * MADS_PER_LANE_ROUND / (kern_us * 1e-6)
             waves = -(-nstates // 21)                          # 21 sponges per wave64 (3 lanes each)
-            quant = (waves / CHIP_SIMDS) / -(-waves // CHIP_SIMDS)      # equally long waves over 1024 SIMDs: the launch lasts as long as the fullest SIMD (6632 waves: 7 where the
-                                                                         # average is 6.48 = 0.925; 13 263 waves at 16384 proofs per step: 12.95 of 13 = 0.996, the slots refill as waves retire)
-            out["roofline_valu"] = {"bound": "issue rate of the kernel's own instruction mix (765 v_mad_u64_u32 + ~290 shifts / masks per lane-round), measured: "
+            out["roofline_valu"] = {"bound": "issue rate of the kernel's own instruction mix (774 v_mad_u64_u32 + ~190 shifts / negations / masks per lane-round), measured: "
                                              f"{MAD_ISSUE_CYCLES} cycles at 2.4 GHz per wave64 multiply-accumulate per SIMD", "kernel": "pstate_hash_kernel",
                                     "achieved": got / 1e12, "peak": peak / 1e12, "unit": "T limb-MAC/s", "frac": got / peak, "permutations_per_launch": perms,
                                     "limb_macs_per_permutation": 3 * 55 * MADS_PER_LANE_ROUND,
-                                    "waves_per_launch": waves, "wave_quantisation": quant, "frac_on_the_fullest_simd": got / peak / quant,
-                                    "peak_source": "profiles/r04_microbench_valu.jsonl (mixed stream, 8 waves per SIMD); counters of the kernel: profiles/r04_valu_roofline.md",
-                                    "note": "9 x 29-bit limbs, no carry instructions.  frac = wave_quantisation (the launch's waves do not divide evenly over the 1024 SIMDs: "
-                                            "the fullest SIMD holds ceil(waves / 1024)) x frac_on_the_fullest_simd (ds_bpermute exchanges, round-constant loads, waits)"}
+                                    "waves_per_launch": waves, "waves_per_simd_in_launch": waves / CHIP_SIMDS, "resident_waves_per_simd": 5,
+                                    "peak_source": "profiles/r04_microbench_ratio.jsonl (the round's mix, 8 waves per SIMD); counters of the kernel: profiles/r04_valu_roofline.md",
+                                    "note": "9 x 29-bit limbs, no carry instructions.  The kernel holds 96 VGPRs: 5 waves per SIMD are resident (the mix issues at 5.7 cycles per "
+                                            "multiply-accumulate with 4 waves, 5.46 with 8), and a launch whose waves per SIMD are not a multiple of 5 ends on partly filled SIMDs "
+                                            "(8192 proofs: 6.5 waves per SIMD, isolated launch 0.82 of the ceiling; 16384: 12.95)"}
         if not args.no_cpu_baseline and args.gpus == 1:       # the CPU leg is timed at N = 1 only (rank 0)
             out["cpu_baseline"] = cpu_baseline(baseline_sample)
             if isinstance(out["cpu_baseline"], dict) and "folded" in out["cpu_baseline"]:

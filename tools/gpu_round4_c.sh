@@ -7,5 +7,5 @@ timeout 600 tools/probes/bin/batch_affine_probe > $O/batch_affine_probe.jsonl 2>
 ( time timeout 900 python bench.py ) > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; python - <<'PY'
 import json
 b=json.loads([l for l in open('gpurun_out/r04c/bench.json') if l.startswith('{"metric')][-1])
-print({k:b[k] for k in ('value','ms_per_step')}, b['roofline_valu']['frac'], b['roofline_valu']['wave_quantisation'], b['cpu_baseline']['value'], b.get('cpu_baseline_folded',{}).get('value'))
+print({k:b[k] for k in ('value','ms_per_step')}, b['roofline_valu']['frac'], b['roofline_valu'].get('waves_per_simd_in_launch'), b['cpu_baseline']['value'], b.get('cpu_baseline_folded',{}).get('value'))
 PY

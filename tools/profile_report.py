@@ -44,8 +44,8 @@ if os.path.exists(sq):
     for r in csv.DictReader(open(sq)):
         agg[short(r["Kernel_Name"])][r["Counter_Name"]] += float(r["Counter_Value"])
     total = sum(v["SQ_INSTS_VALU"] for v in agg.values()) / STEPS
-    MIX = 4.38                                               # cycles per instruction of the Poseidon rounds' mix (765 multiply-accumulates : 290 simple), 8 waves per SIMD:
-    floor = total * MIX / (1024 * 2.4e9) * 1e3               # profiles/r04_microbench_valu.jsonl -- 86 % of a step's instructions are sponge kernels
+    MIX = 4.40                                               # cycles per instruction of the Poseidon rounds' mix (774 multiply-accumulates : ~190 simple), 8 waves per SIMD:
+    floor = total * MIX / (1024 * 2.4e9) * 1e3               # profiles/r04_microbench_ratio.jsonl -- 86 % of a step's instructions are sponge kernels
     print(f"\n## VALU instruction budget per step (SQ_INSTS_VALU, single lane)\n\nTotal {total / 1e9:.2f} G wave-instructions per step; at the MEASURED {MIX} cycles per wave64 "
           f"instruction of the sponge kernels' mix (profiles/r04_valu_roofline.md) on 1024 SIMDs and 2.4 GHz that is **{floor:.1f} ms** per step -- the pipelined step takes "
           f"{b['ms_per_step']:.1f} ms (= {floor / b['ms_per_step'] * 100:.0f} % of that issue rate; the 'floor ms' column below prices every instruction the same way).\n")
