@@ -72,6 +72,14 @@ MB_HD fe29_t fe29_add(const fe29_t &a, const fe29_t &b) {
     return r;
 }
 
+// a + b + c with the carries propagated (limbs 0..7 of the operands below 2^29): one pass of 4 instructions per limb where two fe29_add take 6
+MB_HD fe29_t fe29_add3(const fe29_t &a, const fe29_t &b, const fe29_t &c) {
+    fe29_t r; uint32_t k = 0;
+#pragma unroll
+    for (int i = 0; i < L29; ++i) { const uint32_t t = a.v[i] + b.v[i] + c.v[i] + k; if (i < L29 - 1) { r.v[i] = t & M29; k = t >> 29; } else r.v[i] = t; }
+    return r;
+}
+
 #if defined(__HIP_DEVICE_COMPILE__)
 // Montgomery products, R = 2^261, operands normalised (limbs < 2^29), results normalised; every multiply-accumulate of a column pinned
 // in one asm statement (left to itself the compiler spreads a column over several accumulators and re-adds them).
@@ -876,6 +884,232 @@ template <int F> __device__ __forceinline__ fe29_t fe29_dot3rc_lz(const fe29_t &
     // column 16: 4 products
     asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0"
         : "+&v"(col), "=&s"(cc) : "v"(a0.v[8]), "v"(b0.v[8]), "v"(a1.v[8]), "v"(b1.v[8]), "v"(a2.v[8]), "v"(b2.v[8]), "v"(m8), "v"(p8));
+    r.v[7] = (uint32_t)col & M29; col >>= 29;
+    r.v[8] = (uint32_t)col;
+    return r;
+}
+template <int F> __device__ __forceinline__ fe29_t fe29_mulrc_lz(const fe29_t &a, const fe29_t &b, const fe29_t &c) {
+    uint64_t col, cc; fe29_t r;
+    uint32_t m0, m1, m2, m3, m4, m5, m6, m7, m8;
+    const uint32_t p1 = P29<F>::L1, p2 = P29<F>::L2, p3 = P29<F>::L3, p4 = P29<F>::L4, p8 = P29<F>::L8;
+    // column 0: 2 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 0\n\tv_mad_u64_u32 %0, %1, %4, 1, %0"
+        : "=&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[0]), "v"(c.v[0]));
+    m0 = 0u - (uint32_t)col;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m0));
+    col >>= 29;
+    // column 1: 4 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, 1, %0\n\tv_mad_u64_u32 %0, %1, %7, %8, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[1]), "v"(a.v[1]), "v"(b.v[0]), "v"(c.v[1]), "v"(m0), "v"(p1));
+    m1 = 0u - (uint32_t)col;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m1));
+    col >>= 29;
+    // column 2: 6 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, 1, %0\n\tv_mad_u64_u32 %0, %1, %9, %10, %0\n\tv_mad_u64_u32 %0, %1, %11, %12, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[2]), "v"(a.v[1]), "v"(b.v[1]), "v"(a.v[2]), "v"(b.v[0]), "v"(c.v[2]), "v"(m1), "v"(p1), "v"(m0), "v"(p2));
+    m2 = 0u - (uint32_t)col;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m2));
+    col >>= 29;
+    // column 3: 8 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, 1, %0\n\tv_mad_u64_u32 %0, %1, %11, %12, %0\n\tv_mad_u64_u32 %0, %1, %13, %14, %0\n\tv_mad_u64_u32 %0, %1, %15, %16, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[3]), "v"(a.v[1]), "v"(b.v[2]), "v"(a.v[2]), "v"(b.v[1]), "v"(a.v[3]), "v"(b.v[0]), "v"(c.v[3]), "v"(m2), "v"(p1), "v"(m1), "v"(p2), "v"(m0), "v"(p3));
+    m3 = 0u - (uint32_t)col;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m3));
+    col >>= 29;
+    // column 4: 10 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, 1, %0\n\tv_mad_u64_u32 %0, %1, %13, %14, %0\n\tv_mad_u64_u32 %0, %1, %15, %16, %0\n\tv_mad_u64_u32 %0, %1, %17, %18, %0\n\tv_mad_u64_u32 %0, %1, %19, %20, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[4]), "v"(a.v[1]), "v"(b.v[3]), "v"(a.v[2]), "v"(b.v[2]), "v"(a.v[3]), "v"(b.v[1]), "v"(a.v[4]), "v"(b.v[0]), "v"(c.v[4]), "v"(m3), "v"(p1), "v"(m2), "v"(p2), "v"(m1), "v"(p3), "v"(m0), "v"(p4));
+    m4 = 0u - (uint32_t)col;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m4));
+    col >>= 29;
+    // column 5: 11 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, 1, %0\n\tv_mad_u64_u32 %0, %1, %15, %16, %0\n\tv_mad_u64_u32 %0, %1, %17, %18, %0\n\tv_mad_u64_u32 %0, %1, %19, %20, %0\n\tv_mad_u64_u32 %0, %1, %21, %22, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[5]), "v"(a.v[1]), "v"(b.v[4]), "v"(a.v[2]), "v"(b.v[3]), "v"(a.v[3]), "v"(b.v[2]), "v"(a.v[4]), "v"(b.v[1]), "v"(a.v[5]), "v"(b.v[0]), "v"(c.v[5]), "v"(m4), "v"(p1), "v"(m3), "v"(p2), "v"(m2), "v"(p3), "v"(m1), "v"(p4));
+    m5 = 0u - (uint32_t)col;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m5));
+    col >>= 29;
+    // column 6: 12 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, 1, %0\n\tv_mad_u64_u32 %0, %1, %17, %18, %0\n\tv_mad_u64_u32 %0, %1, %19, %20, %0\n\tv_mad_u64_u32 %0, %1, %21, %22, %0\n\tv_mad_u64_u32 %0, %1, %23, %24, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[6]), "v"(a.v[1]), "v"(b.v[5]), "v"(a.v[2]), "v"(b.v[4]), "v"(a.v[3]), "v"(b.v[3]), "v"(a.v[4]), "v"(b.v[2]), "v"(a.v[5]), "v"(b.v[1]), "v"(a.v[6]), "v"(b.v[0]), "v"(c.v[6]), "v"(m5), "v"(p1), "v"(m4), "v"(p2), "v"(m3), "v"(p3), "v"(m2), "v"(p4));
+    m6 = 0u - (uint32_t)col;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m6));
+    col >>= 29;
+    // column 7: 13 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, 1, %0\n\tv_mad_u64_u32 %0, %1, %19, %20, %0\n\tv_mad_u64_u32 %0, %1, %21, %22, %0\n\tv_mad_u64_u32 %0, %1, %23, %24, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[7]), "v"(a.v[1]), "v"(b.v[6]), "v"(a.v[2]), "v"(b.v[5]), "v"(a.v[3]), "v"(b.v[4]), "v"(a.v[4]), "v"(b.v[3]), "v"(a.v[5]), "v"(b.v[2]), "v"(a.v[6]), "v"(b.v[1]), "v"(a.v[7]), "v"(b.v[0]), "v"(c.v[7]), "v"(m6), "v"(p1), "v"(m5), "v"(p2), "v"(m4), "v"(p3));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m3), "v"(p4));
+    m7 = 0u - (uint32_t)col;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m7));
+    col >>= 29;
+    // column 8: 15 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, 1, %0\n\tv_mad_u64_u32 %0, %1, %21, %22, %0\n\tv_mad_u64_u32 %0, %1, %23, %24, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[8]), "v"(a.v[1]), "v"(b.v[7]), "v"(a.v[2]), "v"(b.v[6]), "v"(a.v[3]), "v"(b.v[5]), "v"(a.v[4]), "v"(b.v[4]), "v"(a.v[5]), "v"(b.v[3]), "v"(a.v[6]), "v"(b.v[2]), "v"(a.v[7]), "v"(b.v[1]), "v"(a.v[8]), "v"(b.v[0]), "v"(c.v[8]), "v"(m7), "v"(p1), "v"(m6), "v"(p2));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m5), "v"(p3), "v"(m4), "v"(p4), "v"(m0), "v"(p8));
+    m8 = 0u - (uint32_t)col;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m8));
+    col >>= 29;
+    // column 9: 13 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[1]), "v"(b.v[8]), "v"(a.v[2]), "v"(b.v[7]), "v"(a.v[3]), "v"(b.v[6]), "v"(a.v[4]), "v"(b.v[5]), "v"(a.v[5]), "v"(b.v[4]), "v"(a.v[6]), "v"(b.v[3]), "v"(a.v[7]), "v"(b.v[2]), "v"(a.v[8]), "v"(b.v[1]), "v"(m8), "v"(p1), "v"(m7), "v"(p2), "v"(m6), "v"(p3), "v"(m5), "v"(p4));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m1), "v"(p8));
+    r.v[0] = (uint32_t)col & M29; col >>= 29;
+    // column 10: 11 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[2]), "v"(b.v[8]), "v"(a.v[3]), "v"(b.v[7]), "v"(a.v[4]), "v"(b.v[6]), "v"(a.v[5]), "v"(b.v[5]), "v"(a.v[6]), "v"(b.v[4]), "v"(a.v[7]), "v"(b.v[3]), "v"(a.v[8]), "v"(b.v[2]), "v"(m8), "v"(p2), "v"(m7), "v"(p3), "v"(m6), "v"(p4), "v"(m2), "v"(p8));
+    r.v[1] = (uint32_t)col & M29; col >>= 29;
+    // column 11: 9 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[3]), "v"(b.v[8]), "v"(a.v[4]), "v"(b.v[7]), "v"(a.v[5]), "v"(b.v[6]), "v"(a.v[6]), "v"(b.v[5]), "v"(a.v[7]), "v"(b.v[4]), "v"(a.v[8]), "v"(b.v[3]), "v"(m8), "v"(p3), "v"(m7), "v"(p4), "v"(m3), "v"(p8));
+    r.v[2] = (uint32_t)col & M29; col >>= 29;
+    // column 12: 7 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[4]), "v"(b.v[8]), "v"(a.v[5]), "v"(b.v[7]), "v"(a.v[6]), "v"(b.v[6]), "v"(a.v[7]), "v"(b.v[5]), "v"(a.v[8]), "v"(b.v[4]), "v"(m8), "v"(p4), "v"(m4), "v"(p8));
+    r.v[3] = (uint32_t)col & M29; col >>= 29;
+    // column 13: 5 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[5]), "v"(b.v[8]), "v"(a.v[6]), "v"(b.v[7]), "v"(a.v[7]), "v"(b.v[6]), "v"(a.v[8]), "v"(b.v[5]), "v"(m5), "v"(p8));
+    r.v[4] = (uint32_t)col & M29; col >>= 29;
+    // column 14: 4 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[6]), "v"(b.v[8]), "v"(a.v[7]), "v"(b.v[7]), "v"(a.v[8]), "v"(b.v[6]), "v"(m6), "v"(p8));
+    r.v[5] = (uint32_t)col & M29; col >>= 29;
+    // column 15: 3 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[7]), "v"(b.v[8]), "v"(a.v[8]), "v"(b.v[7]), "v"(m7), "v"(p8));
+    r.v[6] = (uint32_t)col & M29; col >>= 29;
+    // column 16: 2 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[8]), "v"(b.v[8]), "v"(m8), "v"(p8));
+    r.v[7] = (uint32_t)col & M29; col >>= 29;
+    r.v[8] = (uint32_t)col;
+    return r;
+}
+template <int F> __device__ __forceinline__ fe29_t fe29_dot2rc_lz(const fe29_t &a0, const fe29_t &b0, const fe29_t &a1, const fe29_t &b1, const fe29_t &c) {
+    uint64_t col, cc; fe29_t r;
+    uint32_t m0, m1, m2, m3, m4, m5, m6, m7, m8;
+    const uint32_t p1 = P29<F>::L1, p2 = P29<F>::L2, p3 = P29<F>::L3, p4 = P29<F>::L4, p8 = P29<F>::L8;
+    // column 0: 3 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, 1, %0"
+        : "=&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[0]), "v"(c.v[0]));
+    m0 = 0u - (uint32_t)col;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m0));
+    col >>= 29;
+    // column 1: 6 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, 1, %0\n\tv_mad_u64_u32 %0, %1, %11, %12, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[1]), "v"(a0.v[1]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[1]), "v"(a1.v[1]), "v"(b1.v[0]), "v"(c.v[1]), "v"(m0), "v"(p1));
+    m1 = 0u - (uint32_t)col;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m1));
+    col >>= 29;
+    // column 2: 9 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, 1, %0\n\tv_mad_u64_u32 %0, %1, %15, %16, %0\n\tv_mad_u64_u32 %0, %1, %17, %18, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[2]), "v"(a0.v[1]), "v"(b0.v[1]), "v"(a0.v[2]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[2]), "v"(a1.v[1]), "v"(b1.v[1]), "v"(a1.v[2]), "v"(b1.v[0]), "v"(c.v[2]), "v"(m1), "v"(p1), "v"(m0), "v"(p2));
+    m2 = 0u - (uint32_t)col;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m2));
+    col >>= 29;
+    // column 3: 12 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, 1, %0\n\tv_mad_u64_u32 %0, %1, %19, %20, %0\n\tv_mad_u64_u32 %0, %1, %21, %22, %0\n\tv_mad_u64_u32 %0, %1, %23, %24, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[3]), "v"(a0.v[1]), "v"(b0.v[2]), "v"(a0.v[2]), "v"(b0.v[1]), "v"(a0.v[3]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[3]), "v"(a1.v[1]), "v"(b1.v[2]), "v"(a1.v[2]), "v"(b1.v[1]), "v"(a1.v[3]), "v"(b1.v[0]), "v"(c.v[3]), "v"(m2), "v"(p1), "v"(m1), "v"(p2), "v"(m0), "v"(p3));
+    m3 = 0u - (uint32_t)col;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m3));
+    col >>= 29;
+    // column 4: 15 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, 1, %0\n\tv_mad_u64_u32 %0, %1, %23, %24, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[4]), "v"(a0.v[1]), "v"(b0.v[3]), "v"(a0.v[2]), "v"(b0.v[2]), "v"(a0.v[3]), "v"(b0.v[1]), "v"(a0.v[4]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[4]), "v"(a1.v[1]), "v"(b1.v[3]), "v"(a1.v[2]), "v"(b1.v[2]), "v"(a1.v[3]), "v"(b1.v[1]), "v"(a1.v[4]), "v"(b1.v[0]), "v"(c.v[4]), "v"(m3), "v"(p1));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m2), "v"(p2), "v"(m1), "v"(p3), "v"(m0), "v"(p4));
+    m4 = 0u - (uint32_t)col;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m4));
+    col >>= 29;
+    // column 5: 17 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[5]), "v"(a0.v[1]), "v"(b0.v[4]), "v"(a0.v[2]), "v"(b0.v[3]), "v"(a0.v[3]), "v"(b0.v[2]), "v"(a0.v[4]), "v"(b0.v[1]), "v"(a0.v[5]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[5]), "v"(a1.v[1]), "v"(b1.v[4]), "v"(a1.v[2]), "v"(b1.v[3]), "v"(a1.v[3]), "v"(b1.v[2]), "v"(a1.v[4]), "v"(b1.v[1]), "v"(a1.v[5]), "v"(b1.v[0]));
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0\n\tv_mad_u64_u32 %0, %1, %3, %4, %0\n\tv_mad_u64_u32 %0, %1, %5, %6, %0\n\tv_mad_u64_u32 %0, %1, %7, %8, %0\n\tv_mad_u64_u32 %0, %1, %9, %10, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(c.v[5]), "v"(m4), "v"(p1), "v"(m3), "v"(p2), "v"(m2), "v"(p3), "v"(m1), "v"(p4));
+    m5 = 0u - (uint32_t)col;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m5));
+    col >>= 29;
+    // column 6: 19 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[6]), "v"(a0.v[1]), "v"(b0.v[5]), "v"(a0.v[2]), "v"(b0.v[4]), "v"(a0.v[3]), "v"(b0.v[3]), "v"(a0.v[4]), "v"(b0.v[2]), "v"(a0.v[5]), "v"(b0.v[1]), "v"(a0.v[6]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[6]), "v"(a1.v[1]), "v"(b1.v[5]), "v"(a1.v[2]), "v"(b1.v[4]), "v"(a1.v[3]), "v"(b1.v[3]), "v"(a1.v[4]), "v"(b1.v[2]));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, 1, %0\n\tv_mad_u64_u32 %0, %1, %7, %8, %0\n\tv_mad_u64_u32 %0, %1, %9, %10, %0\n\tv_mad_u64_u32 %0, %1, %11, %12, %0\n\tv_mad_u64_u32 %0, %1, %13, %14, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a1.v[5]), "v"(b1.v[1]), "v"(a1.v[6]), "v"(b1.v[0]), "v"(c.v[6]), "v"(m5), "v"(p1), "v"(m4), "v"(p2), "v"(m3), "v"(p3), "v"(m2), "v"(p4));
+    m6 = 0u - (uint32_t)col;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m6));
+    col >>= 29;
+    // column 7: 21 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[7]), "v"(a0.v[1]), "v"(b0.v[6]), "v"(a0.v[2]), "v"(b0.v[5]), "v"(a0.v[3]), "v"(b0.v[4]), "v"(a0.v[4]), "v"(b0.v[3]), "v"(a0.v[5]), "v"(b0.v[2]), "v"(a0.v[6]), "v"(b0.v[1]), "v"(a0.v[7]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[7]), "v"(a1.v[1]), "v"(b1.v[6]), "v"(a1.v[2]), "v"(b1.v[5]), "v"(a1.v[3]), "v"(b1.v[4]));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, 1, %0\n\tv_mad_u64_u32 %0, %1, %11, %12, %0\n\tv_mad_u64_u32 %0, %1, %13, %14, %0\n\tv_mad_u64_u32 %0, %1, %15, %16, %0\n\tv_mad_u64_u32 %0, %1, %17, %18, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a1.v[4]), "v"(b1.v[3]), "v"(a1.v[5]), "v"(b1.v[2]), "v"(a1.v[6]), "v"(b1.v[1]), "v"(a1.v[7]), "v"(b1.v[0]), "v"(c.v[7]), "v"(m6), "v"(p1), "v"(m5), "v"(p2), "v"(m4), "v"(p3), "v"(m3), "v"(p4));
+    m7 = 0u - (uint32_t)col;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m7));
+    col >>= 29;
+    // column 8: 24 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[8]), "v"(a0.v[1]), "v"(b0.v[7]), "v"(a0.v[2]), "v"(b0.v[6]), "v"(a0.v[3]), "v"(b0.v[5]), "v"(a0.v[4]), "v"(b0.v[4]), "v"(a0.v[5]), "v"(b0.v[3]), "v"(a0.v[6]), "v"(b0.v[2]), "v"(a0.v[7]), "v"(b0.v[1]), "v"(a0.v[8]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[8]), "v"(a1.v[1]), "v"(b1.v[7]), "v"(a1.v[2]), "v"(b1.v[6]));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, 1, %0\n\tv_mad_u64_u32 %0, %1, %15, %16, %0\n\tv_mad_u64_u32 %0, %1, %17, %18, %0\n\tv_mad_u64_u32 %0, %1, %19, %20, %0\n\tv_mad_u64_u32 %0, %1, %21, %22, %0\n\tv_mad_u64_u32 %0, %1, %23, %24, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a1.v[3]), "v"(b1.v[5]), "v"(a1.v[4]), "v"(b1.v[4]), "v"(a1.v[5]), "v"(b1.v[3]), "v"(a1.v[6]), "v"(b1.v[2]), "v"(a1.v[7]), "v"(b1.v[1]), "v"(a1.v[8]), "v"(b1.v[0]), "v"(c.v[8]), "v"(m7), "v"(p1), "v"(m6), "v"(p2), "v"(m5), "v"(p3), "v"(m4), "v"(p4), "v"(m0), "v"(p8));
+    m8 = 0u - (uint32_t)col;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m8));
+    col >>= 29;
+    // column 9: 21 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[1]), "v"(b0.v[8]), "v"(a0.v[2]), "v"(b0.v[7]), "v"(a0.v[3]), "v"(b0.v[6]), "v"(a0.v[4]), "v"(b0.v[5]), "v"(a0.v[5]), "v"(b0.v[4]), "v"(a0.v[6]), "v"(b0.v[3]), "v"(a0.v[7]), "v"(b0.v[2]), "v"(a0.v[8]), "v"(b0.v[1]), "v"(a1.v[1]), "v"(b1.v[8]), "v"(a1.v[2]), "v"(b1.v[7]), "v"(a1.v[3]), "v"(b1.v[6]), "v"(a1.v[4]), "v"(b1.v[5]));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a1.v[5]), "v"(b1.v[4]), "v"(a1.v[6]), "v"(b1.v[3]), "v"(a1.v[7]), "v"(b1.v[2]), "v"(a1.v[8]), "v"(b1.v[1]), "v"(m8), "v"(p1), "v"(m7), "v"(p2), "v"(m6), "v"(p3), "v"(m5), "v"(p4), "v"(m1), "v"(p8));
+    r.v[0] = (uint32_t)col & M29; col >>= 29;
+    // column 10: 18 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[2]), "v"(b0.v[8]), "v"(a0.v[3]), "v"(b0.v[7]), "v"(a0.v[4]), "v"(b0.v[6]), "v"(a0.v[5]), "v"(b0.v[5]), "v"(a0.v[6]), "v"(b0.v[4]), "v"(a0.v[7]), "v"(b0.v[3]), "v"(a0.v[8]), "v"(b0.v[2]), "v"(a1.v[2]), "v"(b1.v[8]), "v"(a1.v[3]), "v"(b1.v[7]), "v"(a1.v[4]), "v"(b1.v[6]), "v"(a1.v[5]), "v"(b1.v[5]), "v"(a1.v[6]), "v"(b1.v[4]));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a1.v[7]), "v"(b1.v[3]), "v"(a1.v[8]), "v"(b1.v[2]), "v"(m8), "v"(p2), "v"(m7), "v"(p3), "v"(m6), "v"(p4), "v"(m2), "v"(p8));
+    r.v[1] = (uint32_t)col & M29; col >>= 29;
+    // column 11: 15 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[3]), "v"(b0.v[8]), "v"(a0.v[4]), "v"(b0.v[7]), "v"(a0.v[5]), "v"(b0.v[6]), "v"(a0.v[6]), "v"(b0.v[5]), "v"(a0.v[7]), "v"(b0.v[4]), "v"(a0.v[8]), "v"(b0.v[3]), "v"(a1.v[3]), "v"(b1.v[8]), "v"(a1.v[4]), "v"(b1.v[7]), "v"(a1.v[5]), "v"(b1.v[6]), "v"(a1.v[6]), "v"(b1.v[5]), "v"(a1.v[7]), "v"(b1.v[4]), "v"(a1.v[8]), "v"(b1.v[3]));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m8), "v"(p3), "v"(m7), "v"(p4), "v"(m3), "v"(p8));
+    r.v[2] = (uint32_t)col & M29; col >>= 29;
+    // column 12: 12 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[4]), "v"(b0.v[8]), "v"(a0.v[5]), "v"(b0.v[7]), "v"(a0.v[6]), "v"(b0.v[6]), "v"(a0.v[7]), "v"(b0.v[5]), "v"(a0.v[8]), "v"(b0.v[4]), "v"(a1.v[4]), "v"(b1.v[8]), "v"(a1.v[5]), "v"(b1.v[7]), "v"(a1.v[6]), "v"(b1.v[6]), "v"(a1.v[7]), "v"(b1.v[5]), "v"(a1.v[8]), "v"(b1.v[4]), "v"(m8), "v"(p4), "v"(m4), "v"(p8));
+    r.v[3] = (uint32_t)col & M29; col >>= 29;
+    // column 13: 9 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[5]), "v"(b0.v[8]), "v"(a0.v[6]), "v"(b0.v[7]), "v"(a0.v[7]), "v"(b0.v[6]), "v"(a0.v[8]), "v"(b0.v[5]), "v"(a1.v[5]), "v"(b1.v[8]), "v"(a1.v[6]), "v"(b1.v[7]), "v"(a1.v[7]), "v"(b1.v[6]), "v"(a1.v[8]), "v"(b1.v[5]), "v"(m5), "v"(p8));
+    r.v[4] = (uint32_t)col & M29; col >>= 29;
+    // column 14: 7 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[6]), "v"(b0.v[8]), "v"(a0.v[7]), "v"(b0.v[7]), "v"(a0.v[8]), "v"(b0.v[6]), "v"(a1.v[6]), "v"(b1.v[8]), "v"(a1.v[7]), "v"(b1.v[7]), "v"(a1.v[8]), "v"(b1.v[6]), "v"(m6), "v"(p8));
+    r.v[5] = (uint32_t)col & M29; col >>= 29;
+    // column 15: 5 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[7]), "v"(b0.v[8]), "v"(a0.v[8]), "v"(b0.v[7]), "v"(a1.v[7]), "v"(b1.v[8]), "v"(a1.v[8]), "v"(b1.v[7]), "v"(m7), "v"(p8));
+    r.v[6] = (uint32_t)col & M29; col >>= 29;
+    // column 16: 3 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[8]), "v"(b0.v[8]), "v"(a1.v[8]), "v"(b1.v[8]), "v"(m8), "v"(p8));
     r.v[7] = (uint32_t)col & M29; col >>= 29;
     r.v[8] = (uint32_t)col;
     return r;

@@ -104,6 +104,27 @@ __global__ void __launch_bounds__(256) probe_ratio(uint32_t *out, uint32_t seed)
     out[blockIdx.x * blockDim.x + threadIdx.x] = r;
 }
 
+// ---- the latency regime (one wave per SIMD): how fast does ONE wave issue multiply-accumulates that chain through the same accumulator, and how much do
+// independent accumulators help?  153 v_mad_u64_u32 per trip over NACC accumulators in rotation (NACC = 1: every one waits for the one before).
+// SIMPLE > 0: a dependent simple instruction (the column's mask) after every SIMPLE-th multiply-accumulate, as the field routines have.
+template <int NACC, int SIMPLE>
+__global__ void __launch_bounds__(256) probe_dep(uint32_t *out, uint32_t seed) {
+    uint32_t a[UNROLL], b[UNROLL];
+    uint64_t acc[UNROLL];
+    for (int i = 0; i < UNROLL; ++i) { a[i] = seed * (i + 3) + threadIdx.x; b[i] = seed ^ (0x9e3779b9u * (i + 1)); acc[i] = a[i]; }
+    for (int it = 0; it < ITERS; ++it) {
+        static_for<0, 153>([&](auto tc) {
+            constexpr int j = decltype(tc)::value, k = j % NACC;
+            asm volatile("v_mad_u64_u32 %0, s[20:21], %1, %2, %0" : "+v"(acc[k]) : "v"(a[(j + 1) % UNROLL]), "v"(b[(j + 6) % UNROLL]) : "s20", "s21");
+            if constexpr (SIMPLE > 0 && j % (SIMPLE > 0 ? SIMPLE : 1) == SIMPLE - 1)
+                asm volatile("v_lshrrev_b64 %0, 29, %0" : "+v"(acc[k]));
+        });
+    }
+    uint32_t r = 0;
+    for (int i = 0; i < UNROLL; ++i) r ^= a[i] ^ b[i] ^ (uint32_t)acc[i] ^ (uint32_t)(acc[i] >> 32);
+    out[blockIdx.x * blockDim.x + threadIdx.x] = r;
+}
+
 template <int OP>
 __global__ void __launch_bounds__(256) probe_field(uint32_t *out, uint32_t seed) {
     fe_t x, y;
@@ -200,6 +221,20 @@ int main(int argc, char **argv) {
     const int cus = prop.multiProcessorCount; const double clk = prop.clockRate * 1e3;   // Hz
     printf("{\"device\": \"%s\", \"cus\": %d, \"clock_mhz\": %.0f}\n", prop.gcnArchName, cus, clk / 1e6);
     uint32_t *out; CHECK(hipMalloc(&out, (size_t)cus * 8 * 256 * 4));
+    if (argc > 1 && !strcmp(argv[1], "--dep")) {          // one or two waves per SIMD: cycles per multiply-accumulate of ONE wave against the number of independent accumulators
+        for (int wps = 1; wps <= 2; ++wps) {
+            const int blocks = cus * wps;
+#define DEP(NACC, SIMPLE)                                                                                    \
+            {                                                                                                \
+                double t = time_kernel([&] { probe_dep<NACC, SIMPLE><<<blocks, 256>>>(out, 12345u); }, 5);   \
+                printf("{\"probe\": \"153 v_mad_u64_u32 per trip over %d accumulator(s)%s\", \"waves_per_simd\": %d, \"cycles_per_mac_per_wave\": %.2f}\n", \
+                       NACC, SIMPLE ? ", a dependent 64-bit shift after every 8th" : "", wps, t * clk / ((double)ITERS * 153));   \
+            }
+            DEP(1, 0) DEP(2, 0) DEP(3, 0) DEP(4, 0) DEP(8, 0) DEP(1, 8) DEP(2, 8)
+        }
+        CHECK(hipFree(out));
+        return 0;
+    }
     if (argc > 1 && !strcmp(argv[1], "--ratio")) {       // the sweep alone: cycles per multiply-accumulate against simple instructions per multiply-accumulate
         for (int wps = 4; wps <= 8; wps *= 2) {
             const int blocks = cus * wps;

@@ -123,7 +123,8 @@ struct PoseidonParams { fe_t mds[3][3]; fe_t rc[55][3]; };     // Montgomery, in
 // constants.  Lives in the same device buffer right behind PoseidonParams (api_sponge.hip: mina_poseidon_set_params).
 struct PoseidonParams29 { fe29_t mds[3][3]; fe29_t rc[55][3]; fe29_t enter /* 2^266 mod p */, leave /* 2^256 mod p */;
                           fe29_t rc2[55][3];      // the round constants times 2^261 once more (rc 2^522 mod p): added BEFORE the reduction of the 3-lane form's MDS dot product
-                          uint32_t pad[3]; };     // size: a multiple of 16
+                          fe29_t zero;            // 0: what the lanes that do not add the round constant read in its place (8- and 16-lane forms)
+                          uint32_t pad[2]; };     // size: a multiple of 16
 static_assert(sizeof(PoseidonParams29) % 16 == 0, "PoseidonParams29 is read with 16-byte loads");
 __host__ __device__ static inline const PoseidonParams29 *pparams29_of(const PoseidonParams *pp) { return reinterpret_cast<const PoseidonParams29 *>(pp + 1); }
 
@@ -241,16 +242,20 @@ __device__ __forceinline__ void poseidon_permute_oct(fe_t &s, const PoseidonPara
         for (int i = 0; i < L29; ++i) r.v[i] = (uint32_t)__shfl((int)a.v[i], src, 64);
         return r; };
     fe29_t x = fe29_mul_asm<F>(fe29_from_words(s), q->enter);        // x 2^256 -> x 2^261
+    // lazy products (fp29.cuh), as the 3-lane form; the even lane of a pair adds the round constant inside its reduction, the odd lane adds zero.
+    // In units of p: x < 16.4, x^2 < 10.2, x^3 / x^4 < 9.4, x^7 < 8.7, each half row < 8.2
+    const fe29_t *rcp = odd ? &q->zero : &q->rc2[0][e];
+    const size_t rcs = odd ? 0 : 3;                                  // fe29_t elements per round
 #pragma unroll 1
     for (int r = 0; r < 55; ++r) {
-        const fe29_t x2 = fe29_sqr_asm<F>(x);
-        const fe29_t y = fe29_mul_asm<F>(x2, odd ? x : x2);          // even: x^4, odd: x^3
-        const fe29_t t = fe29_mul_asm<F>(y, swap29(y));              // x^7 on both lanes of the pair
+        const fe29_t x2 = fe29_sqr_lz<F>(x);
+        const fe29_t y = fe29_mul_lz<F>(x2, odd ? x : x2);           // even: x^4, odd: x^3
+        const fe29_t t = fe29_mul_lz<F>(y, swap29(y));               // x^7 on both lanes of the pair
         const fe29_t t0 = bcast29(t, 0), t1 = bcast29(t, 2), t2 = bcast29(t, 4);
-        const fe29_t u = fe29_dot2_asm<F>(ma, odd ? t2 : t0, mb, t1);   // even: m0 t0 + m1 t1, odd: m2 t2 (+ 0 * t1)
-        x = fe29_add(fe29_add(u, swap29(u)), q->rc[r][e]);           // < 3.3 p < 2^256, limbs normalised
+        const fe29_t u = fe29_dot2rc_lz<F>(ma, odd ? t2 : t0, mb, t1, rcp[rcs * r]);   // even: m0 t0 + m1 t1 + rc, odd: m2 t2 (+ 0 * t1)
+        x = fe29_add(u, swap29(u));                                  // limbs normalised
     }
-    s = fe_cond_sub_p<F>(fe29_to_words(fe29_mul_asm<F>(x, q->leave)));   // x 2^261 -> x 2^256, below 1.01 p
+    s = fe_cond_sub_p<F>(fe29_to_words(fe29_mul_asm<F>(x, q->leave)));   // x 2^261 -> x 2^256; the strict product: 16.4 p p / 2^261 + p < 1.13 p
 #else
     (void)s; (void)pp;
 #endif
@@ -319,18 +324,24 @@ __device__ __forceinline__ void poseidon_permute_hex(fe_t &s, const PoseidonPara
 #undef MB_QUAD29
     const int src = (int)(((threadIdx.x & 63u) & ~15u) | (col << 2));  // lane 0 of quad `col`: x_col^7
     fe29_t x = fe29_mul_asm<F>(fe29_from_words(s), q->enter);        // x 2^256 -> x 2^261
+    // lazy products (fp29.cuh), as the 3-lane form: what counts here is the LENGTH of the dependent chain, and one wave issues an instruction every ~9
+    // cycles whatever their dependencies (microbench --dep) -- fewer instructions is the only lever.  Lane 0 of a quad adds the round constant inside its
+    // product's reduction (the others add zero); the row's three terms are summed in one carry pass.  In units of p: x < 24.3, x^2 < 12.7, x^3 / x^4 < 10.5,
+    // x^7 < 8.9, each term < 8.1
+    const fe29_t *rcp = c == 0 ? &q->rc2[0][e] : &q->zero;
+    const size_t rcs = c == 0 ? 3 : 0;                               // fe29_t elements per round
 #pragma unroll 1
     for (int r = 0; r < 55; ++r) {
-        const fe29_t x2 = fe29_sqr_asm<F>(x);
-        const fe29_t y = fe29_mul_asm<F>(x2, odd ? x : x2);          // even: x^4, odd: x^3
-        const fe29_t t = fe29_mul_asm<F>(y, swap29(y));              // x_e^7 on every lane of quad e
+        const fe29_t x2 = fe29_sqr_lz<F>(x);
+        const fe29_t y = fe29_mul_lz<F>(x2, odd ? x : x2);           // even: x^4, odd: x^3
+        const fe29_t t = fe29_mul_lz<F>(y, swap29(y));               // x_e^7 on every lane of quad e
         fe29_t tc;
 #pragma unroll
         for (int i = 0; i < L29; ++i) tc.v[i] = (uint32_t)__shfl((int)t.v[i], src, 64);
-        const fe29_t pr = fe29_mul_asm<F>(m, tc);                    // mds[e][col] x_col^7 (lane 3 repeats column 2)
-        x = fe29_add(fe29_add(fe29_add(pr, rot1(pr)), rot2(pr)), q->rc[r][e]);   // the row's three terms + round constant: < 4.4 p, limbs normalised
+        const fe29_t pr = fe29_mulrc_lz<F>(m, tc, rcp[rcs * r]);     // mds[e][col] x_col^7 (+ the round constant on lane 0; lane 3 repeats column 2)
+        x = fe29_add3(pr, rot1(pr), rot2(pr));                       // the row's three terms, limbs normalised
     }
-    s = fe_cond_sub_p<F>(fe29_to_words(fe29_mul_asm<F>(x, q->leave)));   // x 2^261 -> x 2^256, below 1.01 p
+    s = fe_cond_sub_p<F>(fe29_to_words(fe29_mul_asm<F>(x, q->leave)));   // x 2^261 -> x 2^256; the strict product: 24.3 p p / 2^261 + p < 1.2 p
 #else
     (void)s; (void)pp;
 #endif

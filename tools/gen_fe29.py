@@ -4,7 +4,7 @@
     fe29_sqr_asm    a * a / R        cross terms once, against the doubled limbs (45 limb products instead of 81)
     fe29_dot2_asm   (a0 b0 + a1 b1) / R             one reduction (the 8-lane permutation's split MDS row)
     fe29_dot3_asm   (a0 b0 + a1 b1 + a2 b2) / R     one reduction
-and the LAZY forms the chip-filling 3-lane permutation runs its rounds in (fe29_sqr_lz, fe29_mul_lz, fe29_dot3rc_lz): the quotient digit
+and the LAZY forms the chip-filling 3-lane permutation runs its rounds in (fe29_sqr_lz, fe29_mul_lz, fe29_dot3rc_lz; fe29_mulrc_lz / fe29_dot2rc_lz for the 16- and 8-lane latency forms): the quotient digit
 m_k = -col mod 2^32 is NOT masked to 29 bits (its three high bits add a multiple of p 2^(29 k): the value stays the same field element,
 the result is < a b / R + 8.0001 p instead of < a b / R + p), the accumulator starts from the first product (no zeroing), and the dot
 product takes a tenth operand c added before the reduction ((sum + c) / R: the round constant, stored times R).  Bounds: fp29.cuh.
@@ -71,6 +71,29 @@ def emit_mul(lazy=False):
     return [f"template <int F> __device__ __forceinline__ fe29_t fe29_mul_{'lz' if lazy else 'asm'}(const fe29_t &a, const fe29_t &b) {{"] + body(terms, lazy) + ["}"]
 
 
+def emit_mulrc_lz():
+    def terms(k):
+        for i in range(L):
+            j = k - i
+            if 0 <= j < L:
+                yield (f"a.v[{i}]", f"b.v[{j}]")
+        if k < L:
+            yield (f"c.v[{k}]", 1)
+    return ["template <int F> __device__ __forceinline__ fe29_t fe29_mulrc_lz(const fe29_t &a, const fe29_t &b, const fe29_t &c) {"] + body(terms, True) + ["}"]
+
+
+def emit_dot2rc_lz():
+    def terms(k):
+        for t in range(2):
+            for i in range(L):
+                j = k - i
+                if 0 <= j < L:
+                    yield (f"a{t}.v[{i}]", f"b{t}.v[{j}]")
+        if k < L:
+            yield (f"c.v[{k}]", 1)
+    return ["template <int F> __device__ __forceinline__ fe29_t fe29_dot2rc_lz(const fe29_t &a0, const fe29_t &b0, const fe29_t &a1, const fe29_t &b1, const fe29_t &c) {"] + body(terms, True) + ["}"]
+
+
 def emit_sqr(lazy=False):
     def terms(k):
         for i in range(L):
@@ -117,7 +140,7 @@ def emit_dot2():
 
 
 def generated():
-    return "\n".join(["// ---- GENERATED by tools/gen_fe29.py: do not edit by hand"] + emit_mul() + emit_sqr() + emit_dot2() + emit_dot3() + emit_mul(True) + emit_sqr(True) + emit_dot3rc_lz() + ["// ---- END GENERATED"]) + "\n"
+    return "\n".join(["// ---- GENERATED by tools/gen_fe29.py: do not edit by hand"] + emit_mul() + emit_sqr() + emit_dot2() + emit_dot3() + emit_mul(True) + emit_sqr(True) + emit_dot3rc_lz() + emit_mulrc_lz() + emit_dot2rc_lz() + ["// ---- END GENERATED"]) + "\n"
 
 
 if __name__ == "__main__":
