@@ -41,12 +41,17 @@ for k in sorted(dur, key=dur.get, reverse=True)[:26]:
 sq = os.path.join(d, "sq", "s_counter_collection.csv")
 if os.path.exists(sq):
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
+    disp = collections.defaultdict(set)
     for r in csv.DictReader(open(sq)):
-        agg[short(r["Kernel_Name"])][r["Counter_Name"]] += float(r["Counter_Value"])
+        agg[short(r["Kernel_Name"])][r["Counter_Name"]] += float(r["Counter_Value"]); disp[short(r["Kernel_Name"])].add(r["Dispatch_Id"])
+    # one-time kernels (SRS tables, the Lagrange basis' FFT stages: fewer launches than steps, or launches that come in one burst of a setup) are not part of a step
+    setup = {k for k in agg if len(disp[k]) < STEPS or k.startswith("mb::lagrange_stage_kernel") or k.startswith("mb::msm_build_table_kernel") or k.startswith("mb::lagrange_digit_table_kernel")}
+    setup_total = sum(agg[k]["SQ_INSTS_VALU"] for k in setup) / 1e9
+    for k in setup: del agg[k]
     total = sum(v["SQ_INSTS_VALU"] for v in agg.values()) / STEPS
     MIX = 4.40                                               # cycles per instruction of the Poseidon rounds' mix (774 multiply-accumulates : ~190 simple), 8 waves per SIMD:
     floor = total * MIX / (1024 * 2.4e9) * 1e3               # profiles/r04_microbench_ratio.jsonl -- 86 % of a step's instructions are sponge kernels
-    print(f"\n## VALU instruction budget per step (SQ_INSTS_VALU, single lane)\n\nTotal {total / 1e9:.2f} G wave-instructions per step; at the MEASURED {MIX} cycles per wave64 "
+    print(f"\n## VALU instruction budget per step (SQ_INSTS_VALU, single lane; one-time setup kernels -- {setup_total:.2f} G in all -- left out)\n\nTotal {total / 1e9:.2f} G wave-instructions per step; at the MEASURED {MIX} cycles per wave64 "
           f"instruction of the sponge kernels' mix (profiles/r04_valu_roofline.md) on 1024 SIMDs and 2.4 GHz that is **{floor:.1f} ms** per step -- the pipelined step takes "
           f"{b['ms_per_step']:.1f} ms (= {floor / b['ms_per_step'] * 100:.0f} % of that issue rate; the 'floor ms' column below prices every instruction the same way).\n")
     print("| kernel | G instr/step | floor ms | waves/step |\n|---|---|---|---|")
