@@ -531,6 +531,8 @@ def main():
     # MINA_BENCH_SHARE_GPU=1 (set by launch_ranks on a box with fewer GPUs than ranks, and by the tests): every rank uses GPU 0 and the ranks rendezvous
     # over gloo -- the N > 1 code path (barriers, MAX over ranks, verdict all-gather, aggregate value) end to end on a 1-GPU box
     share_gpu = os.environ.get("MINA_BENCH_SHARE_GPU") == "1"
+    if share_gpu and world > 4:                               # 20 lanes of 16384 proofs hold ~48 GiB per rank: eight ranks on ONE GPU do not fit 288 GB; fewer lanes each
+        args.pipeline = max(4, min(args.pipeline, 100 // world))
     dist_on = world > 1 or os.environ.get("MINA_BENCH_FORCE_DIST") == "1"      # (test hook: the collectives of the N > 1 path on a 1-rank RCCL group)
     if dist_on:                                              # control plane first, on the CPU: the other ranks wait here while rank 0 runs the boundary legs
         import torch
@@ -656,6 +658,7 @@ def main():
         elapsed = float(t[0].item())
     prof = ctx.prof_read()
     ctx.prof_enable(0)
+    hbm_free, hbm_total = torch.cuda.mem_get_info()            # device-wide: the library's allocations, torch's, every rank's when the GPU is shared
     assert verdicts_ok(args.steps), "timed-region verdicts must be ACCEPT"
     if gathered is not None:
         assert all(int(g.sum()) == B for g in gathered), "every rank's shard must be ACCEPT"
@@ -805,7 +808,7 @@ def main():
                                    + ("kimchi oracles + to_batch of the wrap proof, " if args.kimchi else "") +
                                    "wrap-proof public-input commitment (40 inputs, 2^15 Pallas domain), wrap IPA opening (k=15, 45+ commitments x 2 points), "
                                    "2^16-base Vesta step-accumulator check; verdict per proof, bit-exact vs the CPU oracle composite (tests/test_state_job.py)",
-                       "proofs_per_step": B, "pipeline_lanes": args.pipeline, "warmup_steps_run": n_warm,
+                       "proofs_per_step": B, "pipeline_lanes": args.pipeline, "hbm_in_use_GiB": round((hbm_total - hbm_free) / 2**30, 1), "hbm_total_GiB": round(hbm_total / 2**30, 1), "warmup_steps_run": n_warm,
                        "mode": args.mode,
                        "distinct_inputs": {"full": "32 chains of flattened protocol-state records (random field content, GPU-linked) and the 4 complete wrap proofs of "
                                                    "tests/golden/statement_k15_encoded.json (statement + proof + its accumulator) per rank; the statements' application "
