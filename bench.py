@@ -531,13 +531,16 @@ def main():
     # MINA_BENCH_SHARE_GPU=1 (set by launch_ranks on a box with fewer GPUs than ranks, and by the tests): every rank uses GPU 0 and the ranks rendezvous
     # over gloo -- the N > 1 code path (barriers, MAX over ranks, verdict all-gather, aggregate value) end to end on a 1-GPU box
     share_gpu = os.environ.get("MINA_BENCH_SHARE_GPU") == "1"
-    if share_gpu and world > 4:                               # 20 lanes of 16384 proofs hold ~48 GiB per rank: eight ranks on ONE GPU do not fit 288 GB; fewer lanes each
-        args.pipeline = max(4, min(args.pipeline, 100 // world))
     dist_on = world > 1 or os.environ.get("MINA_BENCH_FORCE_DIST") == "1"      # (test hook: the collectives of the N > 1 path on a 1-rank RCCL group)
     if dist_on:                                              # control plane first, on the CPU: the other ranks wait here while rank 0 runs the boundary legs
         import torch
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world > 1 and not share_gpu and torch.cuda.device_count() < world:      # an outside launcher (torch.distributed.run) on a box with fewer GPUs than ranks:
+            share_gpu = True                                                       # every rank sees the same count and takes the same turn
+            os.environ["MINA_BENCH_SHARE_GPU"] = "1"; os.environ.setdefault("MINA_BENCH_GPUS_PHYSICAL", str(torch.cuda.device_count()))
+        if share_gpu and world > 4:                          # 20 lanes of 16384 proofs hold ~48 GiB per rank: eight ranks on ONE GPU do not fit 288 GB; fewer lanes each
+            args.pipeline = max(4, min(args.pipeline, 100 // world))
         dist.init_process_group("gloo" if share_gpu else "cpu:gloo,cuda:nccl")
     # The bytes -> bools leg runs FIRST, in a process of its own that holds only the library (no torch): the operator's verifier process.  It must
     # not share the GPU with another process's queues (a second process holding 24 hardware queues makes the scheduler time-slice them: the
