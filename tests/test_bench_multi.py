@@ -79,3 +79,22 @@ def test_gpus_2_reports_the_exchange_variant():
     line = json_line(r.stdout)
     x = line["exchange_variant_8e2"]
     assert line["n_gpus"] == 2 and x and x["value"] > 0 and x["proofs_per_rank_per_call"] == 256 and x["calls"] == 8
+
+
+@pytest.mark.gpu
+def test_gpus_2_under_torch_distributed_run():
+    """the driver's own launch for N > 1: `python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port P bench.py --gpus 2`.
+    On a box with two GPUs each rank takes its own over RCCL; with one, the ranks find out by themselves and share GPU 0 (no rank asks for a GPU that is not there)."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                        BENCH, "--gpus", "2", "--no-boundary"] + SMALL, capture_output=True, text=True, timeout=1500, env=clean_env())
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    line = json_line(r.stdout)
+    assert line["n_gpus"] == 2 and line["launcher"] == "torch.distributed.run" and line["value"] > 0
+    import torch
+    if torch.cuda.device_count() < 2:
+        assert line["shared_gpu"] is True and line["gpus_physical"] == torch.cuda.device_count()
+    else:
+        assert "shared_gpu" not in line and "RCCL" in line["config"]["sharding"]
