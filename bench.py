@@ -506,6 +506,7 @@ def main():
     ap.add_argument("--jobs", type=int, default=16384, help="state proofs per step (one mina_state_job_batch_dev call)")
     # 20 lanes under 24 hardware queues (round 4 sweep, full mode, one MI355X): --steps 20: 10 lanes 247.5 k, 16: 245.9 k, 20: 262 - 267 k, 24: 250.5 k, 32: 248.2 k proofs/s;
     # --steps 80: 16 lanes 256.2 k, 20: 258.3 k, 24: 242.7 k, 32: 250.9 k (with 32 - 40 queues nothing gains: 20 lanes 258.1 k, 32 lanes 228 - 243 k)
+    # at 16384 proofs per step (final build, --steps 40): 12 lanes 273.1 k (29 GiB of HBM in use), 16: 275.3 k (38 GiB), 20: 279.7 / 280.8 k (48 GiB), 24: 260.7 k (56 GiB)
     ap.add_argument("--pipeline", type=int, default=20, help="internal stream lanes over which consecutive steps are issued")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", choices=("full", "kimchi", "prepared"), default="full",
