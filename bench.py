@@ -92,6 +92,19 @@ def msm_traffic(c2_rate):
         return {"traffic": None}
 
 
+def msm_valu(c2_rate):
+    """the VALU side of the MSM's roofline: wave-instructions of one 2^16 accumulator check, every kernel of it (profiles/msm_valu.json: rocprofv3 --pmc
+    SQ_INSTS_VALU, tools/profile_c2_sq.sh), priced at the measured issue rate of the 29-bit mix with the SIMDs full (4.4 cycles per wave64 instruction)"""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "msm_valu.json")))
+        floor_s = t["valu_wave_instructions_per_check"] * 4.4 / (CHIP_SIMDS * CLOCK_HZ)
+        return {"bound": "VALU instruction issue: every instruction takes its slot (profiles/r04_valu_roofline.md), 4.4 cycles at 2.4 GHz per wave64 instruction per SIMD",
+                "wave_instructions_per_check": t["valu_wave_instructions_per_check"], "floor_us_per_check": floor_s * 1e6, "achieved_us_per_check": 1e6 / c2_rate,
+                "frac": floor_s * c2_rate, "source": "profiles/msm_valu.json (" + t["source"] + ")"}
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def le32(x: int) -> np.ndarray:
     return np.frombuffer(int(x).to_bytes(32, "little"), np.uint8)
 
@@ -847,6 +860,7 @@ def main():
             "c2_accumulator_only": {"value": c2_rate, "unit": "accumulator checks/s",
                                     "note": "BASELINE config C2 alone (round 1's headline): un-folded 2^16-base Vesta IPA accumulator checks, 8 per call, 16 lanes",
                                     # the metric's second half ("MSM HBM GB/s vs peak"): one check = one 2^16-base MSM; algorithmic bytes = bases + scalars
+                                    "msm_valu": None if not c2_rate else msm_valu(c2_rate),
                                     "msm_hbm": None if not c2_rate else {"algorithmic_bytes_per_msm": 65536 * (64 + 32) + 96, "achieved_GBps": c2_rate * (65536 * 96 + 96) / 1e9, "peak_GBps": HBM_PEAK_GBPS,
                                                                          "frac": c2_rate * (65536 * 96 + 96) / 1e9 / HBM_PEAK_GBPS, **msm_traffic(c2_rate),
                                                                          "note": "the bucket MSM is bound by the group law's multiply-accumulates (the accumulate kernel: 72 of the 79 us per check, on 29-bit limbs "
