@@ -92,6 +92,20 @@ def msm_traffic(c2_rate):
         return {"traffic": None}
 
 
+def step_valu(ms_per_step, proofs_per_step):
+    """the whole step against VALU instruction issue: wave-instructions of one step, every kernel (profiles/step_valu.json: rocprofv3 --pmc SQ_INSTS_VALU over a
+    single-lane run, setup kernels left out), priced at the measured 4.4 cycles per wave64 instruction per SIMD of the 29-bit mix with the SIMDs full"""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "step_valu.json")))
+        if t["proofs_per_step"] != proofs_per_step:
+            return None
+        floor_ms = t["valu_wave_instructions_per_step"] * t["cycles_per_wave_instruction"] / (CHIP_SIMDS * CLOCK_HZ) * 1e3
+        return {"wave_instructions_per_step": t["valu_wave_instructions_per_step"], "floor_ms_per_step": floor_ms, "frac": floor_ms / ms_per_step,
+                "bound": "VALU instruction issue (every instruction takes its slot: profiles/r04_valu_roofline.md)", "source": "profiles/step_valu.json (" + t["source"] + ")"}
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def msm_valu(c2_rate):
     """the VALU side of the MSM's roofline: wave-instructions of one 2^16 accumulator check, every kernel of it (profiles/msm_valu.json: rocprofv3 --pmc
     SQ_INSTS_VALU, tools/profile_c2_sq.sh), priced at the measured issue rate of the 29-bit mix with the SIMDs full (4.4 cycles per wave64 instruction)"""
@@ -880,6 +894,8 @@ def main():
                                     "note": "9 x 29-bit limbs, no carry instructions.  The kernel holds 96 VGPRs: 5 waves per SIMD are resident (the mix issues at 5.7 cycles per "
                                             "multiply-accumulate with 4 waves, 5.46 with 8), and a launch whose waves per SIMD are not a multiple of 5 ends on partly filled SIMDs "
                                             "(8192 proofs: 6.5 waves per SIMD, isolated launch 0.82 of the ceiling; 16384: 12.95)"}
+        if args.mode == "full":
+            out["step_valu"] = step_valu(out["ms_per_step"], B)  # the pipelined step as a whole against instruction issue (secondary; `roofline` stays the dominant kernel's)
         if not args.no_cpu_baseline and args.gpus == 1:       # the CPU leg is timed at N = 1 only (rank 0)
             out["cpu_baseline"] = cpu_baseline(baseline_sample)
             if isinstance(out["cpu_baseline"], dict) and "folded" in out["cpu_baseline"]:

@@ -54,6 +54,10 @@ if os.path.exists(sq):
     print(f"\n## VALU instruction budget per step (SQ_INSTS_VALU, single lane; one-time setup kernels -- {setup_total:.2f} G in all -- left out)\n\nTotal {total / 1e9:.2f} G wave-instructions per step; at the MEASURED {MIX} cycles per wave64 "
           f"instruction of the sponge kernels' mix (profiles/r04_valu_roofline.md) on 1024 SIMDs and 2.4 GHz that is **{floor:.1f} ms** per step -- the pipelined step takes "
           f"{b['ms_per_step']:.1f} ms (= {floor / b['ms_per_step'] * 100:.0f} % of that issue rate; the 'floor ms' column below prices every instruction the same way).\n")
+    json.dump({"source": f"tools/profile_sq.sh {tag} + tools/profile_report.py: rocprofv3 --pmc SQ_INSTS_VALU over `bench.py --pipeline 1` ({STEPS} steps), one-time setup kernels left out",
+               "proofs_per_step": b["config"]["proofs_per_step"], "valu_wave_instructions_per_step": total, "cycles_per_wave_instruction": MIX,
+               "top_kernels_G_per_step": {k: round(agg[k]["SQ_INSTS_VALU"] / STEPS / 1e9, 3) for k in sorted(agg, key=lambda k: agg[k]["SQ_INSTS_VALU"], reverse=True)[:8]}},
+              open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "step_valu.json"), "w"), indent=1)
     print("| kernel | G instr/step | floor ms | waves/step |\n|---|---|---|---|")
     for k in sorted(agg, key=lambda k: agg[k]["SQ_INSTS_VALU"], reverse=True)[:18]:
         v = agg[k]; iv = v["SQ_INSTS_VALU"] / STEPS
