@@ -894,7 +894,7 @@ def main():
                                     "note": "9 x 29-bit limbs, no carry instructions.  The kernel holds 96 VGPRs: 5 waves per SIMD are resident (the mix issues at 5.7 cycles per "
                                             "multiply-accumulate with 4 waves, 5.46 with 8), and a launch whose waves per SIMD are not a multiple of 5 ends on partly filled SIMDs "
                                             "(8192 proofs: 6.5 waves per SIMD, isolated launch 0.82 of the ceiling; 16384: 12.95)"}
-        if args.mode == "full":
+        if args.mode == "full" and not share_gpu:            # (ranks sharing one GPU: a step's time is not one GPU's)
             out["step_valu"] = step_valu(out["ms_per_step"], B)  # the pipelined step as a whole against instruction issue (secondary; `roofline` stays the dominant kernel's)
         if not args.no_cpu_baseline and args.gpus == 1:       # the CPU leg is timed at N = 1 only (rank 0)
             out["cpu_baseline"] = cpu_baseline(baseline_sample)
