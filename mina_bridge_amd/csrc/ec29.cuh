@@ -35,6 +35,29 @@ template <int F, uint32_t MULT> MB_HD fe29_t fe29_sub_kp(const fe29_t &a, const 
     for (int i = 0; i < L29; ++i) { const uint32_t t = a.v[i] + k[i] - b.v[i] + c; if (i < L29 - 1) { r.v[i] = t & M29; c = t >> 29; } else r.v[i] = t; }
     return r;
 }
+// 4 p - a - 2 b limb by limb, every limb non-negative (NOT normalised: limbs up to 2^31 + 2^29): 4 p in the redundant form K_0 = n_0 + 2^31, K_i = n_i + 2^31 - 4
+// (0 < i < 8), K_8 = n_8 - 4 -- the same integer.  Needs a, b normalised with a_8 + 2 b_8 <= n_8 - 4 = 4 * 2^22 - 4 (a < 1.2 p, b < 1.1 p).  The operand h of
+// fe29_sqr_hi_asm: r^2 / 2^261 + (4 p - ppp - 2 q) in one reduction, where two normalised additions and a fe29_sub_kp took 81 instructions (27 + 9 now).
+template <int F> MB_HD fe29_t fe29_4p_minus_a_minus_2b(const fe29_t &a, const fe29_t &b) {
+    typedef KP29<F, 4> K;
+    const uint32_t k[9] = {(uint32_t)K::n0 + (1u << 31), (uint32_t)K::n1 + (1u << 31) - 4, (uint32_t)K::n2 + (1u << 31) - 4, (uint32_t)K::n3 + (1u << 31) - 4, (uint32_t)K::n4 + (1u << 31) - 4,
+                           (uint32_t)K::n5 + (1u << 31) - 4, (1u << 31) - 4, (1u << 31) - 4, (uint32_t)K::n8 - 4};
+    fe29_t r;
+#pragma unroll
+    for (int i = 0; i < L29; ++i) r.v[i] = k[i] - a.v[i] - 2u * b.v[i];
+    return r;
+}
+// MULT p - b limb by limb, every limb non-negative (not normalised), in the redundant form fe29_sub_kp uses: the operand h of fe29_mul_hi_asm -- a product and
+// "+ MULT p - b" in one reduction (9 subtractions + 9 multiply-accumulates by 1 where fe29_sub_kp's carry pass took 30 instructions).  Needs b < MULT p, normalised
+template <int F, uint32_t MULT> MB_HD fe29_t fe29_kp_minus(const fe29_t &b) {
+    typedef KP29<F, MULT> K;
+    const uint32_t k[9] = {(uint32_t)K::n0 + (1u << 30), (uint32_t)K::n1 + (1u << 30) - 2, (uint32_t)K::n2 + (1u << 30) - 2, (uint32_t)K::n3 + (1u << 30) - 2, (uint32_t)K::n4 + (1u << 30) - 2,
+                           (uint32_t)K::n5 + (1u << 30) - 2, (1u << 30) - 2, (1u << 30) - 2, (uint32_t)K::n8 - 2};
+    fe29_t r;
+#pragma unroll
+    for (int i = 0; i < L29; ++i) r.v[i] = k[i] - b.v[i];
+    return r;
+}
 MB_HD fe29_t fe29_zero() { fe29_t r; for (int i = 0; i < L29; ++i) r.v[i] = 0; return r; }
 
 // a (normalised, below 16 p) == 0 mod p?  exact
@@ -55,12 +78,11 @@ template <int F> __device__ __forceinline__ fe_t fe29_leave(const fe29_t &a, con
 // scratch per lane (the call ABI) and made it SLOWER than the 8 x 32 kernel (C2: 8.6 k checks/s against 11.4 k).
 template <int F> __device__ __forceinline__ bool xyzz29_add_affine(xyzz29_t &acc, bool &inf, const fe29_t &qx, const fe29_t &qy, const fe_t &m32) {
     if (inf) { acc.x = qx; acc.y = qy; acc.zz = fe29_from_words(m32); acc.zzz = acc.zz; inf = false; return true; }   // 1 in the 2^261 domain = the integer 2^261 mod p
-    const fe29_t u2 = fe29_mul_asm<F>(qx, acc.zz), s2 = fe29_mul_asm<F>(qy, acc.zzz);                              // < 3 p
-    const fe29_t pd = fe29_sub_kp<F, 8>(u2, acc.x), r = fe29_sub_kp<F, 8>(s2, acc.y);                                // < 11 p
+    const fe29_t pd = fe29_mul_hi_asm<F>(qx, acc.zz, fe29_kp_minus<F, 8>(acc.x)), r = fe29_mul_hi_asm<F>(qy, acc.zzz, fe29_kp_minus<F, 8>(acc.y));   // u2 + 8 p - x1, s2 + 8 p - y1: < 11 p
     if (__builtin_expect((pd.v[5] | pd.v[6] | pd.v[7] | (pd.v[8] & 0x3fffffu)) == 0u, 0))
         if (fe29_is_multiple_of_p<F>(pd)) return false;
     const fe29_t pp = fe29_sqr_asm<F>(pd), ppp = fe29_mul_asm<F>(pd, pp), q = fe29_mul_asm<F>(acc.x, pp);           // < 2 p, < 1.2 p, < 1.1 p
-    const fe29_t x3 = fe29_sub_kp<F, 4>(fe29_sqr_asm<F>(r), fe29_add(ppp, fe29_add(q, q)));                          // r^2 + 4 p - (ppp + 2 q) < 6 p
+    const fe29_t x3 = fe29_sqr_hi_asm<F>(r, fe29_4p_minus_a_minus_2b<F>(ppp, q));                                    // r^2 + 4 p - (ppp + 2 q) < 6 p, inside the square's reduction
     const fe29_t y3 = fe29_dot2_asm<F>(r, fe29_sub_kp<F, 8>(q, x3), fe29_sub_kp<F, 8>(fe29_zero(), acc.y), ppp);     // r (q - x3) - y1 ppp, one reduction: < 2 p
     acc.zz = fe29_mul_asm<F>(acc.zz, pp); acc.zzz = fe29_mul_asm<F>(acc.zzz, ppp);
     acc.x = x3; acc.y = y3;

@@ -1114,6 +1114,215 @@ template <int F> __device__ __forceinline__ fe29_t fe29_dot2rc_lz(const fe29_t &
     r.v[8] = (uint32_t)col;
     return r;
 }
+template <int F> __device__ __forceinline__ fe29_t fe29_sqr_hi_asm(const fe29_t &a, const fe29_t &h) {
+    const uint32_t d0 = a.v[0] << 1, d1 = a.v[1] << 1, d2 = a.v[2] << 1, d3 = a.v[3] << 1, d4 = a.v[4] << 1, d5 = a.v[5] << 1, d6 = a.v[6] << 1, d7 = a.v[7] << 1;
+    uint64_t col, cc; fe29_t r;
+    uint32_t m0, m1, m2, m3, m4, m5, m6, m7, m8;
+    const uint32_t p1 = P29<F>::L1, p2 = P29<F>::L2, p3 = P29<F>::L3, p4 = P29<F>::L4, p8 = P29<F>::L8;
+    // column 0: 1 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 0"
+        : "=&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(a.v[0]));
+    m0 = (0u - (uint32_t)col) & M29;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m0));
+    col >>= 29;
+    // column 1: 2 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d0), "v"(a.v[1]), "v"(m0), "v"(p1));
+    m1 = (0u - (uint32_t)col) & M29;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m1));
+    col >>= 29;
+    // column 2: 4 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d0), "v"(a.v[2]), "v"(a.v[1]), "v"(a.v[1]), "v"(m1), "v"(p1), "v"(m0), "v"(p2));
+    m2 = (0u - (uint32_t)col) & M29;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m2));
+    col >>= 29;
+    // column 3: 5 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d0), "v"(a.v[3]), "v"(d1), "v"(a.v[2]), "v"(m2), "v"(p1), "v"(m1), "v"(p2), "v"(m0), "v"(p3));
+    m3 = (0u - (uint32_t)col) & M29;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m3));
+    col >>= 29;
+    // column 4: 7 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d0), "v"(a.v[4]), "v"(d1), "v"(a.v[3]), "v"(a.v[2]), "v"(a.v[2]), "v"(m3), "v"(p1), "v"(m2), "v"(p2), "v"(m1), "v"(p3), "v"(m0), "v"(p4));
+    m4 = (0u - (uint32_t)col) & M29;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m4));
+    col >>= 29;
+    // column 5: 7 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d0), "v"(a.v[5]), "v"(d1), "v"(a.v[4]), "v"(d2), "v"(a.v[3]), "v"(m4), "v"(p1), "v"(m3), "v"(p2), "v"(m2), "v"(p3), "v"(m1), "v"(p4));
+    m5 = (0u - (uint32_t)col) & M29;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m5));
+    col >>= 29;
+    // column 6: 8 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d0), "v"(a.v[6]), "v"(d1), "v"(a.v[5]), "v"(d2), "v"(a.v[4]), "v"(a.v[3]), "v"(a.v[3]), "v"(m5), "v"(p1), "v"(m4), "v"(p2), "v"(m3), "v"(p3), "v"(m2), "v"(p4));
+    m6 = (0u - (uint32_t)col) & M29;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m6));
+    col >>= 29;
+    // column 7: 8 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d0), "v"(a.v[7]), "v"(d1), "v"(a.v[6]), "v"(d2), "v"(a.v[5]), "v"(d3), "v"(a.v[4]), "v"(m6), "v"(p1), "v"(m5), "v"(p2), "v"(m4), "v"(p3), "v"(m3), "v"(p4));
+    m7 = (0u - (uint32_t)col) & M29;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m7));
+    col >>= 29;
+    // column 8: 10 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d0), "v"(a.v[8]), "v"(d1), "v"(a.v[7]), "v"(d2), "v"(a.v[6]), "v"(d3), "v"(a.v[5]), "v"(a.v[4]), "v"(a.v[4]), "v"(m7), "v"(p1), "v"(m6), "v"(p2), "v"(m5), "v"(p3), "v"(m4), "v"(p4), "v"(m0), "v"(p8));
+    m8 = (0u - (uint32_t)col) & M29;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m8));
+    col >>= 29;
+    // column 9: 10 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d1), "v"(a.v[8]), "v"(d2), "v"(a.v[7]), "v"(d3), "v"(a.v[6]), "v"(d4), "v"(a.v[5]), "v"(m8), "v"(p1), "v"(m7), "v"(p2), "v"(m6), "v"(p3), "v"(m5), "v"(p4), "v"(m1), "v"(p8), "v"(h.v[0]));
+    r.v[0] = (uint32_t)col & M29; col >>= 29;
+    // column 10: 9 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d2), "v"(a.v[8]), "v"(d3), "v"(a.v[7]), "v"(d4), "v"(a.v[6]), "v"(a.v[5]), "v"(a.v[5]), "v"(m8), "v"(p2), "v"(m7), "v"(p3), "v"(m6), "v"(p4), "v"(m2), "v"(p8), "v"(h.v[1]));
+    r.v[1] = (uint32_t)col & M29; col >>= 29;
+    // column 11: 7 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d3), "v"(a.v[8]), "v"(d4), "v"(a.v[7]), "v"(d5), "v"(a.v[6]), "v"(m8), "v"(p3), "v"(m7), "v"(p4), "v"(m3), "v"(p8), "v"(h.v[2]));
+    r.v[2] = (uint32_t)col & M29; col >>= 29;
+    // column 12: 6 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d4), "v"(a.v[8]), "v"(d5), "v"(a.v[7]), "v"(a.v[6]), "v"(a.v[6]), "v"(m8), "v"(p4), "v"(m4), "v"(p8), "v"(h.v[3]));
+    r.v[3] = (uint32_t)col & M29; col >>= 29;
+    // column 13: 4 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d5), "v"(a.v[8]), "v"(d6), "v"(a.v[7]), "v"(m5), "v"(p8), "v"(h.v[4]));
+    r.v[4] = (uint32_t)col & M29; col >>= 29;
+    // column 14: 4 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d6), "v"(a.v[8]), "v"(a.v[7]), "v"(a.v[7]), "v"(m6), "v"(p8), "v"(h.v[5]));
+    r.v[5] = (uint32_t)col & M29; col >>= 29;
+    // column 15: 3 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d7), "v"(a.v[8]), "v"(m7), "v"(p8), "v"(h.v[6]));
+    r.v[6] = (uint32_t)col & M29; col >>= 29;
+    // column 16: 3 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[8]), "v"(a.v[8]), "v"(m8), "v"(p8), "v"(h.v[7]));
+    r.v[7] = (uint32_t)col & M29; col >>= 29;
+    r.v[8] = (uint32_t)col + h.v[8];
+    return r;
+}
+template <int F> __device__ __forceinline__ fe29_t fe29_mul_hi_asm(const fe29_t &a, const fe29_t &b, const fe29_t &h) {
+    uint64_t col, cc; fe29_t r;
+    uint32_t m0, m1, m2, m3, m4, m5, m6, m7, m8;
+    const uint32_t p1 = P29<F>::L1, p2 = P29<F>::L2, p3 = P29<F>::L3, p4 = P29<F>::L4, p8 = P29<F>::L8;
+    // column 0: 1 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 0"
+        : "=&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[0]));
+    m0 = (0u - (uint32_t)col) & M29;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m0));
+    col >>= 29;
+    // column 1: 3 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[1]), "v"(a.v[1]), "v"(b.v[0]), "v"(m0), "v"(p1));
+    m1 = (0u - (uint32_t)col) & M29;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m1));
+    col >>= 29;
+    // column 2: 5 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[2]), "v"(a.v[1]), "v"(b.v[1]), "v"(a.v[2]), "v"(b.v[0]), "v"(m1), "v"(p1), "v"(m0), "v"(p2));
+    m2 = (0u - (uint32_t)col) & M29;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m2));
+    col >>= 29;
+    // column 3: 7 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[3]), "v"(a.v[1]), "v"(b.v[2]), "v"(a.v[2]), "v"(b.v[1]), "v"(a.v[3]), "v"(b.v[0]), "v"(m2), "v"(p1), "v"(m1), "v"(p2), "v"(m0), "v"(p3));
+    m3 = (0u - (uint32_t)col) & M29;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m3));
+    col >>= 29;
+    // column 4: 9 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[4]), "v"(a.v[1]), "v"(b.v[3]), "v"(a.v[2]), "v"(b.v[2]), "v"(a.v[3]), "v"(b.v[1]), "v"(a.v[4]), "v"(b.v[0]), "v"(m3), "v"(p1), "v"(m2), "v"(p2), "v"(m1), "v"(p3), "v"(m0), "v"(p4));
+    m4 = (0u - (uint32_t)col) & M29;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m4));
+    col >>= 29;
+    // column 5: 10 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[5]), "v"(a.v[1]), "v"(b.v[4]), "v"(a.v[2]), "v"(b.v[3]), "v"(a.v[3]), "v"(b.v[2]), "v"(a.v[4]), "v"(b.v[1]), "v"(a.v[5]), "v"(b.v[0]), "v"(m4), "v"(p1), "v"(m3), "v"(p2), "v"(m2), "v"(p3), "v"(m1), "v"(p4));
+    m5 = (0u - (uint32_t)col) & M29;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m5));
+    col >>= 29;
+    // column 6: 11 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[6]), "v"(a.v[1]), "v"(b.v[5]), "v"(a.v[2]), "v"(b.v[4]), "v"(a.v[3]), "v"(b.v[3]), "v"(a.v[4]), "v"(b.v[2]), "v"(a.v[5]), "v"(b.v[1]), "v"(a.v[6]), "v"(b.v[0]), "v"(m5), "v"(p1), "v"(m4), "v"(p2), "v"(m3), "v"(p3), "v"(m2), "v"(p4));
+    m6 = (0u - (uint32_t)col) & M29;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m6));
+    col >>= 29;
+    // column 7: 12 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[7]), "v"(a.v[1]), "v"(b.v[6]), "v"(a.v[2]), "v"(b.v[5]), "v"(a.v[3]), "v"(b.v[4]), "v"(a.v[4]), "v"(b.v[3]), "v"(a.v[5]), "v"(b.v[2]), "v"(a.v[6]), "v"(b.v[1]), "v"(a.v[7]), "v"(b.v[0]), "v"(m6), "v"(p1), "v"(m5), "v"(p2), "v"(m4), "v"(p3), "v"(m3), "v"(p4));
+    m7 = (0u - (uint32_t)col) & M29;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m7));
+    col >>= 29;
+    // column 8: 14 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[8]), "v"(a.v[1]), "v"(b.v[7]), "v"(a.v[2]), "v"(b.v[6]), "v"(a.v[3]), "v"(b.v[5]), "v"(a.v[4]), "v"(b.v[4]), "v"(a.v[5]), "v"(b.v[3]), "v"(a.v[6]), "v"(b.v[2]), "v"(a.v[7]), "v"(b.v[1]), "v"(a.v[8]), "v"(b.v[0]), "v"(m7), "v"(p1), "v"(m6), "v"(p2), "v"(m5), "v"(p3));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m4), "v"(p4), "v"(m0), "v"(p8));
+    m8 = (0u - (uint32_t)col) & M29;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m8));
+    col >>= 29;
+    // column 9: 14 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[1]), "v"(b.v[8]), "v"(a.v[2]), "v"(b.v[7]), "v"(a.v[3]), "v"(b.v[6]), "v"(a.v[4]), "v"(b.v[5]), "v"(a.v[5]), "v"(b.v[4]), "v"(a.v[6]), "v"(b.v[3]), "v"(a.v[7]), "v"(b.v[2]), "v"(a.v[8]), "v"(b.v[1]), "v"(m8), "v"(p1), "v"(m7), "v"(p2), "v"(m6), "v"(p3), "v"(m5), "v"(p4));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m1), "v"(p8), "v"(h.v[0]));
+    r.v[0] = (uint32_t)col & M29; col >>= 29;
+    // column 10: 12 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[2]), "v"(b.v[8]), "v"(a.v[3]), "v"(b.v[7]), "v"(a.v[4]), "v"(b.v[6]), "v"(a.v[5]), "v"(b.v[5]), "v"(a.v[6]), "v"(b.v[4]), "v"(a.v[7]), "v"(b.v[3]), "v"(a.v[8]), "v"(b.v[2]), "v"(m8), "v"(p2), "v"(m7), "v"(p3), "v"(m6), "v"(p4), "v"(m2), "v"(p8), "v"(h.v[1]));
+    r.v[1] = (uint32_t)col & M29; col >>= 29;
+    // column 11: 10 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[3]), "v"(b.v[8]), "v"(a.v[4]), "v"(b.v[7]), "v"(a.v[5]), "v"(b.v[6]), "v"(a.v[6]), "v"(b.v[5]), "v"(a.v[7]), "v"(b.v[4]), "v"(a.v[8]), "v"(b.v[3]), "v"(m8), "v"(p3), "v"(m7), "v"(p4), "v"(m3), "v"(p8), "v"(h.v[2]));
+    r.v[2] = (uint32_t)col & M29; col >>= 29;
+    // column 12: 8 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[4]), "v"(b.v[8]), "v"(a.v[5]), "v"(b.v[7]), "v"(a.v[6]), "v"(b.v[6]), "v"(a.v[7]), "v"(b.v[5]), "v"(a.v[8]), "v"(b.v[4]), "v"(m8), "v"(p4), "v"(m4), "v"(p8), "v"(h.v[3]));
+    r.v[3] = (uint32_t)col & M29; col >>= 29;
+    // column 13: 6 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[5]), "v"(b.v[8]), "v"(a.v[6]), "v"(b.v[7]), "v"(a.v[7]), "v"(b.v[6]), "v"(a.v[8]), "v"(b.v[5]), "v"(m5), "v"(p8), "v"(h.v[4]));
+    r.v[4] = (uint32_t)col & M29; col >>= 29;
+    // column 14: 5 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[6]), "v"(b.v[8]), "v"(a.v[7]), "v"(b.v[7]), "v"(a.v[8]), "v"(b.v[6]), "v"(m6), "v"(p8), "v"(h.v[5]));
+    r.v[5] = (uint32_t)col & M29; col >>= 29;
+    // column 15: 4 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[7]), "v"(b.v[8]), "v"(a.v[8]), "v"(b.v[7]), "v"(m7), "v"(p8), "v"(h.v[6]));
+    r.v[6] = (uint32_t)col & M29; col >>= 29;
+    // column 16: 3 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[8]), "v"(b.v[8]), "v"(m8), "v"(p8), "v"(h.v[7]));
+    r.v[7] = (uint32_t)col & M29; col >>= 29;
+    r.v[8] = (uint32_t)col + h.v[8];
+    return r;
+}
 // ---- END GENERATED
 #endif
 

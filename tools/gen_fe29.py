@@ -4,6 +4,8 @@
     fe29_sqr_asm    a * a / R        cross terms once, against the doubled limbs (45 limb products instead of 81)
     fe29_dot2_asm   (a0 b0 + a1 b1) / R             one reduction (the 8-lane permutation's split MDS row)
     fe29_dot3_asm   (a0 b0 + a1 b1 + a2 b2) / R     one reduction
+    fe29_mul_hi_asm a * b / R + h    the same on a product (the group law's  x2 zz1 + (8 p - x1))
+    fe29_sqr_hi_asm a * a / R + h    h added limb by limb to the high half of the product (strict form; the group law's  r^2 + (4 p - ppp - 2 q))
 and the LAZY forms the chip-filling 3-lane permutation runs its rounds in (fe29_sqr_lz, fe29_mul_lz, fe29_dot3rc_lz; fe29_mulrc_lz / fe29_dot2rc_lz for the 16- and 8-lane latency forms): the quotient digit
 m_k = -col mod 2^32 is NOT masked to 29 bits (its three high bits add a multiple of p 2^(29 k): the value stays the same field element,
 the result is < a b / R + 8.0001 p instead of < a b / R + p), the accumulator starts from the first product (no zeroing), and the dot
@@ -37,8 +39,10 @@ def mads(terms, fresh=False):
     return out
 
 
-def body(col_terms, lazy=False):
-    out = ["    uint64_t col, cc; fe29_t r;" if lazy else "    uint64_t col = 0, cc; fe29_t r;", "    uint32_t " + ", ".join(f"m{i}" for i in range(L)) + ";",
+def body(col_terms, lazy=False, hi=None, fresh=None):
+    """hi: name of a 9-limb operand h (limbs below 2^32) added to the HIGH half -- columns 9 .. 17 -- before the carries: the result is (sum + m p) / 2^261 + h exactly"""
+    fresh = lazy if fresh is None else fresh
+    out = ["    uint64_t col, cc; fe29_t r;" if fresh else "    uint64_t col = 0, cc; fe29_t r;", "    uint32_t " + ", ".join(f"m{i}" for i in range(L)) + ";",
            "    const uint32_t p1 = P29<F>::L1, p2 = P29<F>::L2, p3 = P29<F>::L3, p4 = P29<F>::L4, p8 = P29<F>::L8;"]
     for k in range(2 * L - 1):
         terms = list(col_terms(k))
@@ -49,15 +53,17 @@ def body(col_terms, lazy=False):
         i = k - 8
         if 0 <= i < L and i < k:
             terms.append((f"m{i}", "p8"))                        # p_8 = 2^22
+        if hi is not None and k >= L:
+            terms.append((f"{hi}.v[{k - L}]", 1))
         out.append(f"    // column {k}: {len(terms)} products")
-        out += mads(terms, fresh=lazy and k == 0)
+        out += mads(terms, fresh=fresh and k == 0)
         if k < L:
             out.append(f"    m{k} = 0u - (uint32_t)col;" if lazy else f"    m{k} = (0u - (uint32_t)col) & M29;")
             out += mads([(f"m{k}", 1)])                          # + m_k p_0: the low limb cancels
             out.append(f"    col >>= {W};")
         else:
             out.append(f"    r.v[{k - L}] = (uint32_t)col & M29; col >>= {W};")
-    out.append(f"    r.v[{L - 1}] = (uint32_t)col;")
+    out.append(f"    r.v[{L - 1}] = (uint32_t)col;" if hi is None else f"    r.v[{L - 1}] = (uint32_t)col + {hi}.v[{L - 1}];")
     out.append("    return r;")
     return out
 
@@ -107,6 +113,28 @@ def emit_sqr(lazy=False):
     return pre + body(terms, lazy) + ["}"]
 
 
+def emit_sqr_hi():
+    def terms(k):
+        for i in range(L):
+            j = k - i
+            if 0 <= j < L and i < j:
+                yield (f"d{i}", f"a.v[{j}]")
+        if k % 2 == 0 and k // 2 < L:
+            yield (f"a.v[{k // 2}]", f"a.v[{k // 2}]")
+    pre = ["template <int F> __device__ __forceinline__ fe29_t fe29_sqr_hi_asm(const fe29_t &a, const fe29_t &h) {",
+           "    const uint32_t " + ", ".join(f"d{i} = a.v[{i}] << 1" for i in range(L - 1)) + ";"]
+    return pre + body(terms, False, hi="h", fresh=True) + ["}"]
+
+
+def emit_mul_hi():
+    def terms(k):
+        for i in range(L):
+            j = k - i
+            if 0 <= j < L:
+                yield (f"a.v[{i}]", f"b.v[{j}]")
+    return ["template <int F> __device__ __forceinline__ fe29_t fe29_mul_hi_asm(const fe29_t &a, const fe29_t &b, const fe29_t &h) {"] + body(terms, False, hi="h", fresh=True) + ["}"]
+
+
 def emit_dot3rc_lz():
     def terms(k):
         for t in range(3):
@@ -140,7 +168,7 @@ def emit_dot2():
 
 
 def generated():
-    return "\n".join(["// ---- GENERATED by tools/gen_fe29.py: do not edit by hand"] + emit_mul() + emit_sqr() + emit_dot2() + emit_dot3() + emit_mul(True) + emit_sqr(True) + emit_dot3rc_lz() + emit_mulrc_lz() + emit_dot2rc_lz() + ["// ---- END GENERATED"]) + "\n"
+    return "\n".join(["// ---- GENERATED by tools/gen_fe29.py: do not edit by hand"] + emit_mul() + emit_sqr() + emit_dot2() + emit_dot3() + emit_mul(True) + emit_sqr(True) + emit_dot3rc_lz() + emit_mulrc_lz() + emit_dot2rc_lz() + emit_sqr_hi() + emit_mul_hi() + ["// ---- END GENERATED"]) + "\n"
 
 
 if __name__ == "__main__":
