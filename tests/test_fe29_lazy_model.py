@@ -102,3 +102,59 @@ def test_value_bounds_of_the_lane_forms_are_fixed_points_of_a_round():
     assert 3 * lz(1, t, 1, 1) < x
     # every bound leaves the top limb far below 2^29 and the strict product on the way out below 2^256
     assert 26 * P[0] < 1 << (W * (L - 1) + 27) and (24.4 / 128 + 1) * P[1] < 1 << 256
+
+
+def strict_product_hi(p, a, b, h):
+    """gen_fe29.body(lazy=False, hi=h): quotient digits masked to 29 bits, the 9-limb addend h entering columns 9 .. 17"""
+    pl = limbs(p)
+    col, m, r, peak = 0, [0] * L, [0] * L, 0
+    for k in range(2 * L - 1):
+        for i in range(L):
+            if 0 <= k - i < L:
+                col += a[i] * b[k - i]
+        for j in (1, 2, 3, 4, 8):
+            if 0 <= k - j < L and k - j < k:
+                col += m[k - j] * pl[j]
+        if k >= L:
+            col += h[k - L]
+        peak = max(peak, col)
+        if k < L:
+            m[k] = (-col) & M29
+            col += m[k]
+            col >>= W
+        else:
+            r[k - L] = col & M29
+            col >>= W
+    r[L - 1] = col + h[L - 1]
+    assert r[L - 1] < 1 << 32
+    return r, peak
+
+
+def test_group_law_subtractions_inside_a_reduction():
+    """ec29.cuh: u2 + 8 p - x1 and r^2 + 4 p - ppp - 2 q as ONE product / square each -- the "K p - ..." operand in limbs that never go negative,
+    added to the high half of the product before the carries (fe29_mul_hi_asm / fe29_sqr_hi_asm): the same integers as fe29_sub_kp gave"""
+    rng = random.Random(7)
+    for F, p in P.items():
+        rinv = pow(R, -1, p)
+        n8, n4 = limbs(8 * p), limbs(4 * p)
+        k8 = [n8[0] + (1 << 30)] + [n8[i] + (1 << 30) - 2 for i in range(1, 8)] + [n8[8] - 2]
+        k4 = [n4[0] + (1 << 31)] + [n4[i] + (1 << 31) - 4 for i in range(1, 8)] + [n4[8] - 4]
+        assert value(k8) == 8 * p and value(k4) == 4 * p and all(0 <= x < 1 << 32 for x in k8 + k4)
+        for _ in range(3000):
+            edge = rng.random() < 0.2
+            x1 = 6 * p - 1 if edge else rng.randrange(6 * p)                     # accumulator x below 6 p
+            qx, zz = rng.randrange(p), (3 * p - 1 if edge else rng.randrange(3 * p))
+            h = [k8[i] - limbs(x1)[i] for i in range(L)]
+            assert all(0 <= v < 1 << 32 for v in h)
+            r, peak = strict_product_hi(p, limbs(qx), limbs(zz), h)
+            assert peak < 1 << 64 and all(v <= M29 for v in r[:-1])
+            got = value(r)
+            assert got % p == (qx * zz * rinv - x1) % p and got < 11 * p       # u2 + 8 p - x1, u2 < 3 p
+            ppp, q = (int(1.2 * p) - 1 if edge else rng.randrange(int(1.2 * p))), (int(1.1 * p) - 1 if edge else rng.randrange(int(1.1 * p)))
+            h = [k4[i] - limbs(ppp)[i] - 2 * limbs(q)[i] for i in range(L)]
+            assert all(0 <= v < 1 << 32 for v in h)
+            rr = limbs(11 * p - 1 if edge else rng.randrange(11 * p))
+            r, peak = strict_product_hi(p, rr, rr, h)
+            assert peak < 1 << 64
+            got = value(r)
+            assert got % p == (value(rr) ** 2 * rinv - ppp - 2 * q) % p and got < 6 * p
