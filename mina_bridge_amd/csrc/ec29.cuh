@@ -48,7 +48,8 @@ template <int F> MB_HD fe29_t fe29_4p_minus_a_minus_2b(const fe29_t &a, const fe
     return r;
 }
 // MULT p - b limb by limb, every limb non-negative (not normalised), in the redundant form fe29_sub_kp uses: the operand h of fe29_mul_hi_asm -- a product and
-// "+ MULT p - b" in one reduction (9 subtractions + 9 multiply-accumulates by 1 where fe29_sub_kp's carry pass took 30 instructions).  Needs b < MULT p, normalised
+// "+ MULT p - b" in one reduction (9 subtractions + 9 multiply-accumulates by 1 where fe29_sub_kp's carry pass took 36 instructions).  Needs b normalised and -- there
+// being no carry pass to lend to the top limb -- b_8 <= (MULT p)_8 - 2, i.e. b < (MULT - 2^-20) p: MULT at least one more than b's bound in units of p
 template <int F, uint32_t MULT> MB_HD fe29_t fe29_kp_minus(const fe29_t &b) {
     typedef KP29<F, MULT> K;
     const uint32_t k[9] = {(uint32_t)K::n0 + (1u << 30), (uint32_t)K::n1 + (1u << 30) - 2, (uint32_t)K::n2 + (1u << 30) - 2, (uint32_t)K::n3 + (1u << 30) - 2, (uint32_t)K::n4 + (1u << 30) - 2,
@@ -56,6 +57,15 @@ template <int F, uint32_t MULT> MB_HD fe29_t fe29_kp_minus(const fe29_t &b) {
     fe29_t r;
 #pragma unroll
     for (int i = 0; i < L29; ++i) r.v[i] = k[i] - b.v[i];
+    return r;
+}
+// a + MULT p - b limb by limb, not normalised (limbs up to 2^31): a product's operand as it is -- the strict two-term dot product of the group law holds
+// r (q + 8 p - x3) + (8 p - y1) ppp with BOTH differences in this raw form (column maximum 0.69 x 2^64: tests/test_fe29_lazy_model.py)
+template <int F, uint32_t MULT> MB_HD fe29_t fe29_add_kp_minus(const fe29_t &a, const fe29_t &b) {
+    const fe29_t k = fe29_kp_minus<F, MULT>(b);
+    fe29_t r;
+#pragma unroll
+    for (int i = 0; i < L29; ++i) r.v[i] = a.v[i] + k.v[i];
     return r;
 }
 MB_HD fe29_t fe29_zero() { fe29_t r; for (int i = 0; i < L29; ++i) r.v[i] = 0; return r; }
@@ -76,14 +86,20 @@ template <int F> __device__ __forceinline__ fe_t fe29_leave(const fe29_t &a, con
 // Returns FALSE -- acc untouched -- in the exceptional case (the points are equal or opposite: P = 0 mod p): the caller hands its unit of work to the
 // 8 x 32 law (msm.cuh: the redo queue).  No call, no second code path inside the hot loop: an out-of-line fallback cost the kernel 53 VGPRs and 288 B of
 // scratch per lane (the call ABI) and made it SLOWER than the 8 x 32 kernel (C2: 8.6 k checks/s against 11.4 k).
-template <int F> __device__ __forceinline__ bool xyzz29_add_affine(xyzz29_t &acc, bool &inf, const fe29_t &qx, const fe29_t &qy, const fe_t &m32) {
-    if (inf) { acc.x = qx; acc.y = qy; acc.zz = fe29_from_words(m32); acc.zzz = acc.zz; inf = false; return true; }   // 1 in the 2^261 domain = the integer 2^261 mod p
+// `neg`: the point added is (qx, -py) -- the signed-digit recoding's negative digits.  -py = p - py enters its product in the raw limb form (9 subtractions and a
+// select per limb; normalised only where it becomes the accumulator itself).
+template <int F> __device__ __forceinline__ bool xyzz29_add_affine(xyzz29_t &acc, bool &inf, const fe29_t &qx, const fe29_t &py, bool neg, const fe_t &m32) {
+    if (inf) { acc.x = qx; acc.y = neg ? fe29_sub_kp<F, 1>(fe29_zero(), py) : py; acc.zz = fe29_from_words(m32); acc.zzz = acc.zz; inf = false; return true; }   // 1 in the 2^261 domain = the integer 2^261 mod p
+    fe29_t qy = fe29_kp_minus<F, 2>(py);              // 2 p - py = -py, limbs below 2^30 + 2^29.  TWO p: the raw form has no carries, so its top limb n_8 - 2 - py_8 must not go
+                                                      // negative by itself, and a canonical py reaches 2^22 = the top limb of ONE p (py >= 2^254 - 2^233: one table point in 2^21)
+#pragma unroll
+    for (int i = 0; i < L29; ++i) qy.v[i] = neg ? qy.v[i] : py.v[i];
     const fe29_t pd = fe29_mul_hi_asm<F>(qx, acc.zz, fe29_kp_minus<F, 8>(acc.x)), r = fe29_mul_hi_asm<F>(qy, acc.zzz, fe29_kp_minus<F, 8>(acc.y));   // u2 + 8 p - x1, s2 + 8 p - y1: < 11 p
     if (__builtin_expect((pd.v[5] | pd.v[6] | pd.v[7] | (pd.v[8] & 0x3fffffu)) == 0u, 0))
         if (fe29_is_multiple_of_p<F>(pd)) return false;
     const fe29_t pp = fe29_sqr_asm<F>(pd), ppp = fe29_mul_asm<F>(pd, pp), q = fe29_mul_asm<F>(acc.x, pp);           // < 2 p, < 1.2 p, < 1.1 p
     const fe29_t x3 = fe29_sqr_hi_asm<F>(r, fe29_4p_minus_a_minus_2b<F>(ppp, q));                                    // r^2 + 4 p - (ppp + 2 q) < 6 p, inside the square's reduction
-    const fe29_t y3 = fe29_dot2_asm<F>(r, fe29_sub_kp<F, 8>(q, x3), fe29_sub_kp<F, 8>(fe29_zero(), acc.y), ppp);     // r (q - x3) - y1 ppp, one reduction: < 2 p
+    const fe29_t y3 = fe29_dot2_asm<F>(r, fe29_add_kp_minus<F, 8>(q, x3), fe29_kp_minus<F, 8>(acc.y), ppp);          // r (q - x3) - y1 ppp, one reduction, the differences not normalised: < 2 p
     acc.zz = fe29_mul_asm<F>(acc.zz, pp); acc.zzz = fe29_mul_asm<F>(acc.zzz, ppp);
     acc.x = x3; acc.y = y3;
     return true;

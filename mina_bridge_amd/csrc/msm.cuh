@@ -656,7 +656,7 @@ msm_accumulate_bucket29_kernel(uint32_t nb_total, uint32_t nb_prob, const uint32
                 if (e + 2 < cnt) ref_n = sorted[beg + e + 2];
                 if (fe_is_zero(p.y)) continue;                   // infinity is (0, 0); no point of these prime-order curves has y = 0
                 const fe29_t px = fe29_from_words(p.x), py = fe29_from_words(p.y);
-                exact = xyzz29_add_affine<F>(acc, inf, px, (cur >> 31) ? fe29_sub_kp<F, 1>(fe29_zero(), py) : py, m32);     // -y = p - y (y != 0 on these curves)
+                exact = xyzz29_add_affine<F>(acc, inf, px, py, (cur >> 31) != 0, m32);                                      // a negative digit adds (x, p - y) (y != 0 on these curves)
             }
         }
         if (exact) buckets[b] = xyzz29_leave<F>(acc, inf, one);
@@ -716,7 +716,7 @@ msm_accumulate29_kernel(uint32_t nb_total, const uint32_t *__restrict__ start, c
         if (e + 1 < cnt) nxt = load_affine(points29 + (refs[0] & 0x7fffffffu));
         if (fe_is_zero(p.y)) continue;                           // infinity is (0, 0); no point of these prime-order curves has y = 0
         const fe29_t px = fe29_from_words(p.x), py = fe29_from_words(p.y);
-        exact = xyzz29_add_affine<F>(acc, inf, px, (ref >> 31) ? fe29_sub_kp<F, 1>(fe29_zero(), py) : py, m32);
+        exact = xyzz29_add_affine<F>(acc, inf, px, py, (ref >> 31) != 0, m32);
     }
     if (exact) partial[t] = xyzz29_leave<F>(acc, inf, one);
     else redo[atomicAdd(&info_rw[3], 1u)] = t;                   // msm_accumulate_kernel<F> in redo mode sums this task with the 8 x 32 law

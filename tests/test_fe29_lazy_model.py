@@ -158,3 +158,65 @@ def test_group_law_subtractions_inside_a_reduction():
             assert peak < 1 << 64
             got = value(r)
             assert got % p == (value(rr) ** 2 * rinv - ppp - 2 * q) % p and got < 6 * p
+
+
+def test_group_law_dot_product_takes_its_differences_raw():
+    """ec29.cuh y3 = r (q + 8 p - x3) + (8 p - y1) ppp: both differences enter the strict two-term dot product limb by limb, NOT normalised (limbs up to 2^31).
+    The worst column -- every limb at its maximum -- stays inside 64 bits, and the value is the one the normalised operands gave."""
+    rng = random.Random(11)
+    for F, p in P.items():
+        rinv = pow(R, -1, p)
+        pl = limbs(p)
+        n8 = limbs(8 * p)
+        k8 = [n8[0] + (1 << 30)] + [n8[i] + (1 << 30) - 2 for i in range(1, 8)] + [n8[8] - 2]
+        amax = [k8[i] + M29 for i in range(8)] + [k8[8] + (int(1.1 * p) >> 232)]
+        rmax, pppmax = [M29] * 8 + [(11 * p) >> 232], [M29] * 8 + [int(1.2 * p) >> 232]
+        carry = worst = 0
+        for col in range(2 * L - 1):
+            s = sum(rmax[i] * amax[col - i] + k8[i] * pppmax[col - i] for i in range(L) if 0 <= col - i < L)
+            s += sum(M29 * pl[j] for j in (1, 2, 3, 4, 8) if 0 <= col - j < L and col - j < col) + M29 + carry
+            worst, carry = max(worst, s), s >> W
+        assert worst < 0.7 * 2**64
+        for _ in range(2000):
+            r_, q, x3, y1, ppp = rng.randrange(11 * p), rng.randrange(int(1.1 * p)), rng.randrange(6 * p), rng.randrange(2 * p), rng.randrange(int(1.2 * p))
+            a = [limbs(q)[i] + k8[i] - limbs(x3)[i] for i in range(L)]
+            b = [k8[i] - limbs(y1)[i] for i in range(L)]
+            assert all(0 <= v < 1 << 32 for v in a + b) and value(a) == q + 8 * p - x3 and value(b) == 8 * p - y1
+            zero = [0] * L
+            # the two-term dot product, strict: model it as two products accumulated (strict_product_hi takes one pair: add the second pair's columns through `h` is not possible -- run the columns here)
+            col, m, out = 0, [0] * L, [0] * L
+            for k in range(2 * L - 1):
+                for i in range(L):
+                    if 0 <= k - i < L:
+                        col += limbs(r_)[i] * a[k - i] + b[i] * limbs(ppp)[k - i]
+                for j in (1, 2, 3, 4, 8):
+                    if 0 <= k - j < L and k - j < k:
+                        col += m[k - j] * pl[j]
+                assert col < 1 << 64
+                if k < L:
+                    m[k] = (-col) & M29; col += m[k]; col >>= W
+                else:
+                    out[k - L] = col & M29; col >>= W
+            out[L - 1] = col
+            assert value(out) % p == ((r_ * (q - x3) - y1 * ppp) * rinv) % p and value(out) < 2 * p
+
+
+def test_negated_table_point_enters_its_product_raw():
+    """ec29.cuh: a negative digit adds (x, p - y); p - y is NOT normalised (limbs below 2^30 + 2^29) where it is a product's operand: s2 + 8 p - y1 = (p - y) zzz / 2^261 + h"""
+    rng = random.Random(13)
+    for F, p in P.items():
+        rinv = pow(R, -1, p)
+        n1, n8 = limbs(2 * p), limbs(8 * p)                   # TWO p: with one p the top limb 2^22 - 2 - y_8 goes negative for y >= 2^254 - 2^233 (no carry pass lends to it)
+        k1 = [n1[0] + (1 << 30)] + [n1[i] + (1 << 30) - 2 for i in range(1, 8)] + [n1[8] - 2]
+        k8 = [n8[0] + (1 << 30)] + [n8[i] + (1 << 30) - 2 for i in range(1, 8)] + [n8[8] - 2]
+        assert value(k1) == 2 * p and all(0 <= v < 1 << 32 for v in k1)
+        edge = [p - 1, p - 2, 1 << 254, (1 << 254) - 1, (1 << 254) - (1 << 232), (1 << 254) - (1 << 233) - 1, 1]
+        for it in range(2000):
+            y, zzz, y1 = (edge[it] if it < len(edge) else rng.randrange(1, p)), rng.randrange(3 * p), rng.randrange(2 * p)
+            qy = [k1[i] - limbs(y)[i] for i in range(L)]
+            h = [k8[i] - limbs(y1)[i] for i in range(L)]
+            assert all(0 <= v < (1 << 30) + (1 << 29) for v in qy)
+            r, peak = strict_product_hi(p, qy, limbs(zzz), h)
+            assert peak < 1 << 63 and value(r) % p == ((p - y) * zzz * rinv - y1) % p and value(r) < 11 * p and value(qy) == 2 * p - y
+        worst = strict_product_hi(p, list(k1), [M29] * 8 + [(3 * p) >> 232], list(k8))[1]
+        assert worst < 1 << 63
