@@ -314,3 +314,48 @@ def test_29_bit_group_law_handles_equal_and_opposite_points_exactly(oracle, srs_
                     assert (c.msm_srs_multi(curve, np.stack([sc] * 5), 5)[2] == want).all(), (trial, fp29, "bucket-lane form")
     finally:
         c.close()
+
+
+def test_29_bit_group_law_on_table_points_at_the_top_of_the_field(oracle, srs_oracle):
+    """A table coordinate enters the 29-bit law as y 2^261 mod p, canonical -- and one table point in 2^21 has that value at or above 2^254 - 2^233, where the
+    top limb of a canonical number reaches the top limb of p itself.  The law subtracts without carry passes (ec29.cuh: raw "K p - y" operands), so the top limb of
+    K p must cover it by itself: a first version negated table points as ONE p - y and failed the 2^18-point accumulator test on exactly such a point.  Here the
+    SRS is crafted to hold them: Vesta points whose y 2^261 mod p is 2^254 + 7, 2^254 - 2, 2^254 - 2^232 + 5, p - 2, 2^254 - 2^233 + 1 and 2^254 - 2^233 - 3 (found
+    by solving x^3 = y^2 - 5), met with negative AND positive digits of the signed recoding, in the task form and the bucket-lane form, against the naive oracle."""
+    import mina_bridge_amd as m
+    curve, n = 1, 256
+    fq = 0x40000000000000000000000000000000224698FC0994A8DD8C46EB2100000001
+    special = [(0x38f57ef5216d8ce7ee0d3eb9f8702dd5ad0bfab3bf2fd2b6f36a87367e5703d2, 0x1462ce285d1dfa8a3b27a9a36a11b0cc5aa9ed85d488ac0a38d491716d15c864, (1 << 254) + 7),
+               (0x38b4606582d3f626b64ad4061c925abfb54602e92cd584595b16fb0a9b59a29, 0x398857622e89b86aca86f41a73faf20ee374c427d70bd4df4258545ad51e5909, (1 << 254) - 2),
+               (0x181165aaea28a80fb9336acfd8efb429a51eab27376642157f8468dc204e53c6, 0xe6b258c8ba7b2f505ae9dbdde0ca2db1c1ca5e4ac47c93df6a3cf6de66b7a74, (1 << 254) - (1 << 232) + 5),
+               (0x24bde7e1b84d0791a80595f601a3ea4331f752b432a5b14b007a4e84c7823340, 0x3a0857622e89b86aca86f41a73faf20ee3b95159cf1efe30fd70e231171e5909, fq - 2),
+               (0x3f7afad333faf9c5165b4956f9b25d7a68245d3b4364145f725c2cca553ac76c, 0x27bd452e8bb23ca9abc85f2c60286f89f0216a149913bc5259d047a76df858c, (1 << 254) - (1 << 233) + 1),
+               (0x3c0e1b40033c82fc3861cb9c0c6df9f61333e8010fb1064b9596a3445bdc64cf, 0x368c831745ce94a02fca6e27adf86b16442e2058de3a8f499437ddbba51c379d, (1 << 254) - (1 << 233) - 3)]
+    g, h = srs_oracle[curve]
+    g = g[:n].copy()
+    for i, (x, y, y261) in enumerate(special):
+        assert (y * y - x * x * x - 5) % fq == 0 and (y << 261) % fq == y261
+        g[100 + i] = np.frombuffer(x.to_bytes(32, "little") + y.to_bytes(32, "little"), np.uint8)      # not first in their buckets: bases 10 + i share them (below)
+    c = m.MinaContext(0)
+    try:
+        c.srs_load(curve, _srs_blob(oracle, curve, g, h))
+        assert (c.srs_get_g(curve, 0, n) == g).all()
+        for trial in range(4):
+            sc = rand_scalars(n, P, seed=900 + trial)
+            for i in range(len(special)):
+                low = 0xC000 + 17 * i if (trial + i) % 2 == 0 else 0x1234 + i          # window 0 digit negative (>= 2^15) or positive
+                for base in (10 + i, 100 + i, 200 + i):                                 # the special point is the SECOND of three entries of its window-0 bucket:
+                    s = int.from_bytes(sc[base].tobytes(), "little")                    # the first entry only initialises the accumulator (a normalised copy)
+                    s = (s & ~0xFFFF) | low
+                    if trial == 2: s = low                                              # nothing of these bases in the other windows
+                    sc[base] = np.frombuffer((s % P).to_bytes(32, "little"), np.uint8)
+            if trial == 3:
+                keep = [b0 + i for i in range(len(special)) for b0 in (10, 100, 200)]
+                mask = np.ones(n, bool); mask[keep] = False; sc[mask] = 0
+            want = oracle.msm_naive(curve, g, sc)
+            for fp29 in (1, 0):
+                with m.lib.tuning(msm_fp29=fp29):
+                    assert (c.msm_srs(curve, sc) == want).all(), (trial, fp29)
+                    assert (c.msm_srs_multi(curve, np.stack([sc] * 5), 5)[3] == want).all(), (trial, fp29, "bucket-lane form")
+    finally:
+        c.close()
