@@ -316,16 +316,22 @@ def test_29_bit_group_law_handles_equal_and_opposite_points_exactly(oracle, srs_
         c.close()
 
 
-def test_29_bit_group_law_on_table_points_at_the_top_of_the_field(oracle, srs_oracle):
+@pytest.mark.parametrize("curve", [1, 0])
+def test_29_bit_group_law_on_table_points_at_the_top_of_the_field(oracle, srs_oracle, curve):
     """A table coordinate enters the 29-bit law as y 2^261 mod p, canonical -- and one table point in 2^21 has that value at or above 2^254 - 2^233, where the
     top limb of a canonical number reaches the top limb of p itself.  The law subtracts without carry passes (ec29.cuh: raw "K p - y" operands), so the top limb of
     K p must cover it by itself: a first version negated table points as ONE p - y and failed the 2^18-point accumulator test on exactly such a point.  Here the
     SRS is crafted to hold them: Vesta points whose y 2^261 mod p is 2^254 + 7, 2^254 - 2, 2^254 - 2^232 + 5, p - 2, 2^254 - 2^233 + 1 and 2^254 - 2^233 - 3 (found
     by solving x^3 = y^2 - 5), met with negative AND positive digits of the signed recoding, in the task form and the bucket-lane form, against the naive oracle."""
     import mina_bridge_amd as m
-    curve, n = 1, 256
-    fq = 0x40000000000000000000000000000000224698FC0994A8DD8C46EB2100000001
-    special = [(0x38f57ef5216d8ce7ee0d3eb9f8702dd5ad0bfab3bf2fd2b6f36a87367e5703d2, 0x1462ce285d1dfa8a3b27a9a36a11b0cc5aa9ed85d488ac0a38d491716d15c864, (1 << 254) + 7),
+    n = 256
+    fq = Q if curve == 1 else P                                 # the curve's BASE field (Vesta: Fq, Pallas: Fp); scalars are reduced mod the other one
+    pallas = [(0x3272e1925ed8260631c2cba71f0fbdb819950d0ce7acd0d44aee6cb848bf7f85, 0xcaeaa77ead33b5402930be6267ace798d45742f5f6caca2542aaa9fddd7b1e8, (1 << 254) + 3),
+              (0x19bc51b3d4e4b80289dec45ad8eb2d3dd6f7aa4d841c5509999ce51878e41d2f, 0x107071d8070eec395479a6b34881bb2cdbfa500198874c3acd685eec9362c4b3, (1 << 254) - 1),
+              (0xbfddbeaa272867f18119e4671db1e03ac21c3516fece33bf034ea2d464302b2, 0x3251558a152cc4abfd6cf419d985318694780a69cbefe07521059a663791d581, (1 << 254) - (1 << 232) - 3),
+              (0x3b787af542ee31938aa017d5573312e07cb19b13117b7e6be01e1f3e4d7dc245, 0x2964727046953a3d4cc08300d5114fc055e7720b93690b8afbb0db3645dbaefc, P - 10),
+              (0x38161fe0df7f6aa37e2e894f29604bb05ab97d2f2cd709da34351ed1d2834f49, 0xcaeaa7bead33b5402930be6267ace798d45743183d63c62e8fa3c5970aac0b8, (1 << 254) - (1 << 233) + 3)]
+    special = pallas if curve == 0 else [(0x38f57ef5216d8ce7ee0d3eb9f8702dd5ad0bfab3bf2fd2b6f36a87367e5703d2, 0x1462ce285d1dfa8a3b27a9a36a11b0cc5aa9ed85d488ac0a38d491716d15c864, (1 << 254) + 7),
                (0x38b4606582d3f626b64ad4061c925abfb54602e92cd584595b16fb0a9b59a29, 0x398857622e89b86aca86f41a73faf20ee374c427d70bd4df4258545ad51e5909, (1 << 254) - 2),
                (0x181165aaea28a80fb9336acfd8efb429a51eab27376642157f8468dc204e53c6, 0xe6b258c8ba7b2f505ae9dbdde0ca2db1c1ca5e4ac47c93df6a3cf6de66b7a74, (1 << 254) - (1 << 232) + 5),
                (0x24bde7e1b84d0791a80595f601a3ea4331f752b432a5b14b007a4e84c7823340, 0x3a0857622e89b86aca86f41a73faf20ee3b95159cf1efe30fd70e231171e5909, fq - 2),
@@ -341,14 +347,14 @@ def test_29_bit_group_law_on_table_points_at_the_top_of_the_field(oracle, srs_or
         c.srs_load(curve, _srs_blob(oracle, curve, g, h))
         assert (c.srs_get_g(curve, 0, n) == g).all()
         for trial in range(4):
-            sc = rand_scalars(n, P, seed=900 + trial)
+            sc = rand_scalars(n, SCALAR_MOD[curve], seed=900 + trial)
             for i in range(len(special)):
                 low = 0xC000 + 17 * i if (trial + i) % 2 == 0 else 0x1234 + i          # window 0 digit negative (>= 2^15) or positive
                 for base in (10 + i, 100 + i, 200 + i):                                 # the special point is the SECOND of three entries of its window-0 bucket:
                     s = int.from_bytes(sc[base].tobytes(), "little")                    # the first entry only initialises the accumulator (a normalised copy)
                     s = (s & ~0xFFFF) | low
                     if trial == 2: s = low                                              # nothing of these bases in the other windows
-                    sc[base] = np.frombuffer((s % P).to_bytes(32, "little"), np.uint8)
+                    sc[base] = np.frombuffer((s % SCALAR_MOD[curve]).to_bytes(32, "little"), np.uint8)
             if trial == 3:
                 keep = [b0 + i for i in range(len(special)) for b0 in (10, 100, 200)]
                 mask = np.ones(n, bool); mask[keep] = False; sc[mask] = 0
