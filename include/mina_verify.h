@@ -389,7 +389,10 @@ int mina_state_job_batch_dev(mina_ctx *ctx, const mina_state_jobs *jobs, void *d
  * (device buffers: d_ipa_scalars 2^k * 32 B and d_ipa_point 17 words for the wrap openings on Pallas -- fixed-base part + point must be infinity;
  * d_acc_scalars 2^acc_k * 32 B and d_acc_point 17 words for the step accumulators on Vesta -- fixed-base part must equal the point).  The caller
  * exchanges the vectors (all-to-all), commits over its slice of the SRS (mina_msm_srs_range_dev) and reduces the partial points (mina_points_sum_dev):
- * mina_bridge_amd/sharded.py ShardedStateJob.  d_verdicts[b] = the per-proof checks only.  batch >= 2, with_ipa and with_accumulator set. */
+ * mina_bridge_amd/sharded.py ShardedStateJob.  d_verdicts[b] = the per-proof checks only.  batch >= 2, with_ipa and with_accumulator set.
+ * Soundness of the sum over shards: here the opening fold runs with rho_b = rand_base^(b + 1), sigma_b = sg_rand_base^(b + 1) -- NOT upstream's ^b, whose first
+ * proof carries coefficient 1: partial sums of G shards are added, and G coefficient-1 proofs could cancel each other's discrepancies.  Every shard draws its own
+ * rand_base / sg_rand_base from a CSPRNG after its proofs are fixed, and EVERY acc_rho[b] (b = 0 included) must be such a draw too. */
 int mina_state_job_fold_dev(mina_ctx *ctx, const mina_state_jobs *jobs, void *d_verdicts, void *d_flags, void *d_ipa_scalars, void *d_ipa_point,
                             void *d_acc_scalars, void *d_acc_point);
 /* Host-buffer form: one upload, the pipeline, one download; on a folded failure the failing range is cut into four parts ($MINA_SEARCH_FAN) that are

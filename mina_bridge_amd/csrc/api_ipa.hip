@@ -168,11 +168,11 @@ ipa_prepare_kernel(IpaShape sh, FieldK kb, FieldK ks, const PoseidonParams *__re
         } else store_fe<LANES>(scs + (size_t)o * 8, sc_canon);
     };
 
-    // rho = rand_base^b, sigma = sg_rand_base^b
+    // rho = rand_base^(b + pow_first), sigma = sg_rand_base^(b + pow_first)   (pow_first = 0: upstream's rho_b = rand_base^b)
     fe_t rho = ks.one, sigma = ks.one;
     {
         fe_t rb = fe_to_mont<FS>(load_fe<FS>(rand_base), ks.r2), sb = fe_to_mont<FS>(load_fe<FS>(sg_rand_base), ks.r2);
-        for (uint32_t e = b; e; e >>= 1) {
+        for (uint32_t e = b + sh.pow_first; e; e >>= 1) {
             if (e & 1u) { rho = fe_mul<FS>(rho, rb); sigma = fe_mul<FS>(sigma, sb); }
             rb = fe_sqr<FS>(rb); sb = fe_sqr<FS>(sb);
         }
@@ -485,6 +485,7 @@ int mb_ipa_batch_check_dev(mina_ctx *c, int curve, mb::IpaShape sh, const mb::Ip
     const int FB = base_field_of(curve), FS = scalar_field_of(curve);
     const size_t batch = sh.batch; const uint32_t k = sh.k;
     int rc;
+    if (c->fold_export) sh.pow_first = 1;          // partial sums that the caller adds to other shards': no coefficient-1 proof (ctx.h IpaShape::pow_first)
     if (sh.nshared && (sh.ncomms > 64 || sh.nshared > 64)) return fail(MINA_ERR_ARG, "shared entries need <= 64 commitments");
     const size_t npoints = batch * sh.per + sh.nshared;           // per-proof lists, then the batch-shared points once
     if ((rc = c->L->ipa_points.ensure(npoints * sizeof(affine_t)))) return rc;

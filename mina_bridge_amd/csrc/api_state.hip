@@ -490,7 +490,8 @@ extern "C" int mina_state_job_batch_dev(mina_ctx *c, const mina_state_jobs *jobs
 // d_acc_scalars 2^acc_k x 32 B (Vesta, sum_b rho_b s_b of the step accumulators), d_acc_point 17 words (sum_b rho_b sg_b: must EQUAL the fixed-base part).
 // d_verdicts[b] = every per-proof check of proof b (chain, linkage, statement, well-formed inputs) -- the folded checks are the caller's to AND in.
 // Needs at least 2 proofs and both folded legs (with_ipa, with_accumulator).  The folding randomisers of the job are the shard's own (independent of the
-// other shards').
+// other shards'), and the opening fold's powers start at 1 (rho_b = rand_base^(b+1): IpaShape::pow_first) -- the shards' partials are ADDED, so no proof of any
+// shard may carry a fixed coefficient (round 4 shipped ^b: first proofs of two shards with discrepancies +tH / -tH cancelled).
 extern "C" int mina_state_job_fold_dev(mina_ctx *c, const mina_state_jobs *jobs, void *d_verdicts, void *d_flags, void *d_ipa_scalars, void *d_ipa_point,
                                        void *d_acc_scalars, void *d_acc_point) {
     int rc = check_jobs(c, jobs);

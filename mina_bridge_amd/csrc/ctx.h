@@ -234,7 +234,11 @@ struct ProfScope {
 // combined IPA opening check with inputs in HBM (api_ipa.hip)
 namespace mb {
 struct IpaShape { uint32_t batch, k, npts, ncomms, per; uint32_t override_slot = 0xffffffffu, expand_slot = 0xffffffffu;
-                  uint32_t shared_lo = 0, shared_hi = 0, shared_h = 0, shared_expand0 = 0, nshared = 0; };   // per = 2k + ncomms + 4 points per proof
+                  uint32_t shared_lo = 0, shared_hi = 0, shared_h = 0, shared_expand0 = 0, nshared = 0;
+                  uint32_t pow_first = 0; };   // per = 2k + ncomms + 4 points per proof
+// pow_first: rho_b = rand_base^(b + pow_first), sigma_b = sg_rand_base^(b + pow_first).  0 = upstream's batch_verify (proof 0 has coefficient 1: fine when the
+//   batch is ONE combination); 1 = the exchange variant (mina_state_job_fold_dev): the shards' partial sums are ADDED by the caller, so every coefficient of
+//   every shard must be random -- G shards whose first proofs all carry coefficient 1 let two first proofs with discrepancies +tH / -tH cancel
 // shared_*: list entries whose POINT is the same for every proof of the batch (the caller vouches: h, verifier-index commitments -- bits of
 //   shared_lo/hi over the commitment index, ncomms <= 64 --, the index point of the expanded slot).  Their scalars are summed over the batch
 //   first and enter the MSM ONCE, as `nshared` entries behind the per-proof lists (a third of a kimchi batch's 88 points per proof);

@@ -207,8 +207,12 @@ class ShardedStateJob:
       2. a modular-add kernel folds the G slices; K1 runs over the rank's n/G bases of each curve (`mina_msm_srs_range_dev`)
       3. all-gather of 4 point records per rank (its two fixed-base partials, its two variable-base partials) + one flag word
       4. every rank folds the records with the group law (`mina_points_sum_dev`): Pallas total == infinity, Vesta fixed-base total == variable-base total
-    RCCL only transports; the reductions are this library's kernels.  The folding randomisers are per shard (independent draws): the combined check is the
-    random linear combination upstream's batch_verify forms, with the coefficients grouped by shard.
+    RCCL only transports; the reductions are this library's kernels.  The folding randomisers are per shard (independent CSPRNG draws) and NO proof carries a
+    fixed coefficient: inside `mina_state_job_fold_dev` the opening fold uses rho_b = rand_base^(b+1), sigma_b = sg_rand_base^(b+1) (upstream's batch_verify uses
+    ^b -- one coefficient-1 proof is fine in ONE combination, but here G partial sums are added and G coefficient-1 proofs could cancel each other's
+    discrepancies: z2 + t first in shard A, z2 - t first in shard B), and the caller draws every `acc_rho[b]` (b = 0 included) at random.  The
+    combined check is then a polynomial of degree <= B in 2G + B independent uniform variables that vanishes identically only if every proof's discrepancy is
+    zero (Schwartz-Zippel: a bad batch passes with probability <= B / |F|).
     Returns (verdicts of THIS shard as a uint8 tensor, batch_ok).  When the batch fails every shard is re-run through the ordinary job: one whose OWN folded
     checks pass keeps its per-proof verdicts; a shard that fails answers 0 for all its proofs -- the per-proof culprit search is the host-form entry point's
     (`mina_state_job_batch`), which the caller runs on that shard alone."""

@@ -577,16 +577,17 @@ static void *fold_worker(void *a) {
 /* phase 1 + the reductions over threads: what the fixed-base MSMs of the batch would consume.  Sg / Tg: Montgomery, n / 2^16 entries; small lists per proof. */
 typedef struct { fe *Sg, *Tg, h_acc, *rho_acc; uint8_t *ok, *pts, *scs; size_t per, n; opening_prep *prep; fe *rho, *sigma; } fold_state;
 static void fold_free(fold_state *st) { free(st->Sg); free(st->Tg); free(st->rho_acc); free(st->ok); free(st->pts); free(st->scs); free(st->prep); free(st->rho); free(st->sigma); }
-static void fold_collect(const oc_proof *proofs, size_t nproofs, int threads, const uint8_t *rand32, fold_state *st) {
+static void fold_collect(const oc_proof *proofs, size_t nproofs, int threads, const uint8_t *rand32, int pow_first, fold_state *st) {
     const fctx *fp = &F[0], *fq = &F[1];
     if (threads < 1) threads = 1;
     if ((size_t)threads > nproofs) threads = (int)nproofs;
     const int k = G.log2_domain; const size_t n = (size_t)1 << k, nacc = (size_t)1 << 16, per = (size_t)(2 * k + 47 + 4);
     { oc_result r; state_hashes(&proofs[0], &r); }                   /* warm the function-static salts before the threads start */
-    /* rho_b = r^b, sigma_b = t^b (upstream's shape), rho'_b = u^b */
+    /* rho_b = r^(b + pow_first), sigma_b = t^(b + pow_first), rho'_b = u^(b + pow_first).  pow_first = 0: upstream's shape (proof 0 carries coefficient 1);
+     * pow_first = 1: one SHARD of the exchange variant -- partial sums of several shards are added, so no proof of any shard may carry a fixed coefficient */
     fe base[3], *rho = (fe *)malloc(sizeof(fe) * nproofs), *sigma = (fe *)malloc(sizeof(fe) * nproofs), *rho_acc = (fe *)malloc(sizeof(fe) * nproofs);
     f_from_le256_reduce(&base[0], rand32, fq); f_from_le256_reduce(&base[1], rand32 + 32, fq); f_from_le256_reduce(&base[2], rand32 + 64, fp);
-    rho[0] = fq->one; sigma[0] = fq->one; rho_acc[0] = fp->one;
+    if (pow_first) { rho[0] = base[0]; sigma[0] = base[1]; rho_acc[0] = base[2]; } else { rho[0] = fq->one; sigma[0] = fq->one; rho_acc[0] = fp->one; }
     for (size_t b = 1; b < nproofs; ++b) { f_mul(&rho[b], &rho[b - 1], &base[0], fq); f_mul(&sigma[b], &sigma[b - 1], &base[1], fq); f_mul(&rho_acc[b], &rho_acc[b - 1], &base[2], fp); }
     opening_prep *prep = (opening_prep *)malloc(sizeof(opening_prep) * nproofs);
     uint8_t *ok = (uint8_t *)calloc(nproofs, 1), *pts = (uint8_t *)malloc(nproofs * per * 64), *scs = (uint8_t *)malloc(nproofs * per * 32);
@@ -608,7 +609,7 @@ static void fold_collect(const oc_proof *proofs, size_t nproofs, int threads, co
 int oc_verify_folded(const oc_proof *proofs, size_t nproofs, int threads, const uint8_t *rand32 /* 3 x 32 */, uint8_t *verdicts) {
     const fctx *fp = &F[0], *fq = &F[1];
     if (nproofs == 0) return 0;
-    fold_state st; fold_collect(proofs, nproofs, threads, rand32, &st);
+    fold_state st; fold_collect(proofs, nproofs, threads, rand32, 0, &st);
     const size_t n = st.n, nacc = (size_t)1 << 16, per = st.per;
     /* Pallas: g[0..n) with the folded scalars, h, then every proof's entries (zero scalars where a proof was malformed) */
     const size_t qp = n + 1 + nproofs * per;
@@ -639,7 +640,7 @@ int oc_verify_folded(const oc_proof *proofs, size_t nproofs, int threads, const 
 int oc_fold_export(const oc_proof *proofs, size_t nproofs, int threads, const uint8_t *rand32, uint8_t *ipa_scalars, uint8_t *ipa_point, uint8_t *acc_scalars, uint8_t *acc_point, uint8_t *ok) {
     const fctx *fp = &F[0], *fq = &F[1];
     if (nproofs == 0) return 0;
-    fold_state st; fold_collect(proofs, nproofs, threads, rand32, &st);
+    fold_state st; fold_collect(proofs, nproofs, threads, rand32, 1, &st);
     const size_t n = st.n, nacc = (size_t)1 << 16, per = st.per;
     for (size_t i = 0; i < n; ++i) f_store(ipa_scalars + 32 * i, &st.Sg[i], fq);
     for (size_t i = 0; i < nacc; ++i) f_store(acc_scalars + 32 * i, &st.Tg[i], fp);

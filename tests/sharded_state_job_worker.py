@@ -1,6 +1,6 @@
 """One rank of tests/test_sharded_state_job.py: a shard of full-size Proof-of-State jobs through `ShardedStateJob` (SURVEY.md 8e.2 for the whole job).
 Launched with RANK / WORLD_SIZE / MASTER_* in the environment; every rank uses GPU 0 and the ranks rendezvous over gloo (a 1-GPU box), or its own GPU over
-RCCL when the box has enough of them.  argv: B_per_rank  scenario  (ok | bad_opening_on_last_rank | bad_accumulator_on_rank0).  Prints one JSON line."""
+RCCL when the box has enough of them.  argv: B_per_rank  scenario  (ok | bad_opening_on_last_rank | bad_accumulator_on_rank0 | opposite_z2_on_first_proofs).  Prints one JSON line."""
 import json
 import os
 import sys
@@ -34,6 +34,13 @@ if scenario == "bad_opening_on_last_rank" and rank == world - 1:
     bad_at = B // 2; by_addr[hj.z1].view(np.uint8).reshape(B, 32)[bad_at, 0] ^= 1
 if scenario == "bad_accumulator_on_rank0" and rank == 0:
     bad_at = 1; by_addr[hj.acc_prechallenges].view(np.uint8).reshape(B, 16, 16)[bad_at, 3, 0] ^= 1
+if scenario == "opposite_z2_on_first_proofs" and rank < 2:
+    # z2 + t on the first proof of rank 0's shard, z2 - t on the first proof of rank 1's: discrepancies -tH and +tH.  They cancelled in the
+    # exchanged total while every shard's first proof carried coefficient 1 (rho_b = rand_base^b per shard); with rho_b = rand_base^(b+1) they cannot.
+    Q = 0x40000000000000000000000000000000224698fc0994a8dd8c46eb2100000001          # Pallas scalar field (z2 lives there)
+    bad_at = 0; z2 = by_addr[hj.z2].view(np.uint8).reshape(B, 32)
+    v = (int.from_bytes(z2[0].tobytes(), "little") + (0x1234567 if rank == 0 else -0x1234567)) % Q
+    z2[0] = np.frombuffer(v.to_bytes(32, "little"), np.uint8)
 dj, dk, tensors = bench.device_jobs(m, hj, keep, kp, dev)
 ctx.state_jobs_prepare(bench.LOG2_DOMAIN, bench.NPUB)
 job = ShardedStateJob(DeviceBackend(ctx, dev), k=bench.WRAP_K, acc_k=bench.ACC_K)

@@ -262,7 +262,7 @@ def _state_job_worker(rank, world, port, q):
     be = OracleJobBackend()
     items, _ = load_statement_fixture()
 
-    def proof(i, tamper=False):
+    def proof(i, tamper=False, z2_delta=0):
         it = items[i % 4]
         states, hashes = make_chain(random.Random(it["chain_seed"]), poseidon_pp(0))
         recs = np.zeros((17, 64, 32), np.uint8); nf = np.zeros(17, np.uint32)
@@ -274,6 +274,10 @@ def _state_job_worker(rank, world, port, q):
         enc = copy.deepcopy(be.fx["proofs"][i % 4])
         if tamper:
             b = bytearray(bytes.fromhex(enc["opening"]["z1"])); b[0] ^= 1; enc["opening"]["z1"] = bytes(b).hex()
+        if z2_delta:                                   # z2 lives in the scalar field of Pallas (Fq): the opening's discrepancy becomes -z2_delta * H
+            from oracle import pasta_ref as R
+            z2 = (int.from_bytes(bytes.fromhex(enc["opening"]["z2"]), "little") + z2_delta) % R.Q
+            enc["opening"]["z2"] = z2.to_bytes(32, "little").hex()
         return be.C.make_proof(enc, recs.reshape(17, -1), nf, exp)
     job = ShardedStateJob(be, k=15, acc_k=16)
     res = {}
@@ -281,6 +285,11 @@ def _state_job_worker(rank, world, port, q):
     v, ok = job.verify(shard, 3); res["ok"] = (v.numpy().tolist(), ok, dict(job.last))
     shard_bad = [proof(3 * rank + i, tamper=(rank == 1 and i == 2)) for i in range(3)]
     v, ok = job.verify(shard_bad, 3); res["bad"] = (v.numpy().tolist(), ok, dict(job.last))
+    # the FIRST proof of rank 0's shard opens with z2 + t, the first proof of rank 1's with z2 - t.  While every shard's first proof carried
+    # coefficient 1 (rho_b = rand_base^b per shard) the two discrepancies -tH and +tH cancelled in the exchanged total and both invalid proofs were accepted.
+    t = 0x1234567
+    shard_pm = [proof(3 * rank + i, z2_delta=((t if rank == 0 else -t) if i == 0 else 0)) for i in range(3)]
+    v, ok = job.verify(shard_pm, 3); res["plus_minus"] = (v.numpy().tolist(), ok, dict(job.last))
     q.put((rank, res))
     dist.barrier()
     dist.destroy_process_group()
@@ -307,3 +316,6 @@ def test_two_rank_exchange_variant_of_the_whole_state_job_on_the_cpu_double():
         v, ok, detail = got[r]["bad"]
         assert ok is False and detail["opening_fold_ok"] is False and detail["accumulator_fold_ok"] is True, (r, detail)
         assert v == ([1, 1, 1] if r == 0 else [0, 0, 0]), (r, v)
+        v, ok, detail = got[r]["plus_minus"]                                   # opposite discrepancies on the two shards' first proofs do NOT cancel
+        assert ok is False and detail["opening_fold_ok"] is False, (r, detail)
+        assert v == [0, 0, 0], (r, v)

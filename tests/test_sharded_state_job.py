@@ -48,3 +48,12 @@ def test_a_bad_accumulator_fails_the_batch():
     outs = run_ranks(2, 4, "bad_accumulator_on_rank0")
     assert all(o["batch_ok"] is False for o in outs)
     assert outs[0]["plain_flags"][2] == 0 and outs[0]["verdicts"] == [0] * 4 and outs[1]["verdicts"] == [1] * 4
+
+
+def test_opposite_discrepancies_on_the_first_proofs_of_two_shards_do_not_cancel():
+    """proof 0 of EVERY shard used to carry coefficient 1 in its shard's fold (rho_b = rand_base^b), so z2 + t first in shard A and z2 - t first
+    in shard B summed to the identity in the exchanged total and both invalid proofs were accepted, with no knowledge of the randomisers.  The exchange variant
+    now folds with rho_b = rand_base^(b + 1) (ctx.h IpaShape::pow_first): both shards fail, on every rank."""
+    outs = run_ranks(2, 4, "opposite_z2_on_first_proofs")
+    assert all(o["batch_ok"] is False and o["detail"]["opening_fold_ok"] is False for o in outs), outs
+    assert outs[0]["verdicts"] == [0] * 4 and outs[1]["verdicts"] == [0] * 4, "each shard's own folded check fails too: nothing is accepted"
