@@ -66,6 +66,11 @@ HBM_PEAK_GBPS = 8000.0                                # MI355X_MICROARCH.md: 8 T
 # (a pure stream: 4.66; the strict forms' mix of 765 + ~290 until late in round 4: 5.9 - 6.04).
 MADS_PER_LANE_ROUND = 2 * 99 + 2 * 135 + 306
 MAD_ISSUE_CYCLES = 5.46
+# SURVEY.md 8d's peak: a PURE stream of v_mad_u64_u32 (16 independent accumulators, operands on distinct register banks, 8 waves per SIMD) issues one per 4.52
+# cycles at the nominal 2.4 GHz = 1.88 ns per wave64 instruction per SIMD (profiles/r04_microbench_ratio.jsonl, the S = 0 row): 34.8 T limb-MAC/s for the chip.
+# `roofline` is quoted against THIS peak (it forgives nothing: the round's ~190 shifts / negations / masks per 774 multiply-accumulates count as lost issue slots);
+# `roofline_valu` keeps the own-mix ceiling beside it.
+PURE_MAC_ISSUE_CYCLES = 4.52
 CHIP_SIMDS, CLOCK_HZ = 1024, 2.4e9
 PROF_STAGES = {"pstate_hash": 11, "ipa_transcript": 12, "kimchi_to_batch": 13, "pickles_statement": 14, "msm_accumulate": 3}
 # HBM-side bytes per protocol-state hash: read from the tracked summary of the rocprofv3 PMC passes (FETCH_SIZE x 2 -- the gfx950 correction
@@ -175,34 +180,60 @@ def install_fixture_indexes(ctx, fx, un):
     ctx.step_index_install(s["zk_rows"], s["domains"], un(s["shifts"]), bytes.fromhex(s["constant_term"]))
 
 
-def build_full_job(ctx, m, B: int, seed: int):
-    """host-side `mina_state_jobs` of B complete jobs: 32 distinct chains + the 4 complete wrap proofs of the encoded fixture (statement,
-    wrap proof, opening, the accumulator the statement carries), tiled to B.  Returns (StateJobs + keep, KimchiProofs + keep)."""
-    import mina_bridge_amd.poseidon_params as PP
+MANY_FIXTURE = os.path.join("tests", "golden", "statement_k15_many.npz")
+
+
+def load_wrap_sections():
+    """every distinct complete wrap proof the tree holds, in the C-ABI's byte layouts: {section: uint8 [n, bytes per proof]} with sections "statement.<name>",
+    "kimchi.<name>", "opening.<name>", "acc_prechallenges", "acc_sg" -- the 4 proofs of tests/golden/statement_k15_encoded.json followed by the proofs of
+    tests/golden/statement_k15_many.npz (minted by the same generator under the same indexes: tools/mint_many.sh, tests/golden/encode_statement_fixture.py --many)."""
     fx, un = load_encoded_fixture()
+    cols = {}
+    for it in fx["proofs"]:
+        flat = {"acc_prechallenges": it["acc_prechallenges"], "acc_sg": it["acc_sg"]}
+        for grp in ("statement", "kimchi", "opening"):
+            flat.update({grp + "." + k: v for k, v in it[grp].items()})
+        for k, v in flat.items():
+            cols.setdefault(k, []).append(un(v))
+    sec = {k: np.stack(v) for k, v in cols.items()}
+    try:
+        z = np.load(os.path.join(ROOT, MANY_FIXTURE))
+        if bytes(z["poseidon_constants"]).decode() == fx["poseidon_constants"]:
+            sec = {k: np.concatenate([v, z[k]]) for k, v in sec.items()}
+    except (OSError, KeyError, ValueError):
+        pass                                                       # only the 4 proofs of the JSON fixture: config.distinct_inputs says so
+    return fx, un, sec, fx["proofs"][0]["n_old"], fx["proofs"][0]["n_evals"]
+
+
+def build_full_job(ctx, m, B: int, seed: int, distinct_chains: int = 0):
+    """host-side `mina_state_jobs` of B complete jobs: `distinct_chains` distinct chains (default: one per proof) + every distinct complete wrap proof of the
+    fixtures (statement, wrap proof, opening, the accumulator the statement carries: `load_wrap_sections`), tiled to B.  Returns (StateJobs + keep, KimchiProofs +
+    keep, a chain sample, {"chains": .., "wrap_proofs": ..})."""
+    import mina_bridge_amd.poseidon_params as PP
+    fx, un, sec, n_old, n_evals = load_wrap_sections()
     assert fx["poseidon_constants"] == PP.NAME, "the fixture was minted under another Poseidon constant set"
     install_fixture_indexes(ctx, fx, un)
-    items = fx["proofs"]
-    n = len(items)
+    n = len(sec["acc_sg"])
     idx = np.arange(B) % n
-    tile = lambda key, name: np.ascontiguousarray(np.stack([un(it[key][name]) if key else un(it[name]) for it in items])[idx].reshape(-1))
-    n_old, n_evals = items[0]["n_old"], items[0]["n_evals"]
+    tile = lambda key, name: np.ascontiguousarray(sec[(key + "." + name) if key else name][idx].reshape(-1))
     st = m.MinaContext.make_pickles_statements(n_old, n_evals, {name: tile("statement", name) for name in m.lib.PicklesStatements.POINTER_FIELDS})
     # no recursion challenges beside the statement: they are its messages_for_next_wrap_proof.old_bulletproof_challenges (the one source a
     # verifier has; the library expands them and takes kimchi's digest of them on the way through the statement's own sponge)
-    karr = {name: tile("kimchi", name) for name in items[0]["kimchi"] if name not in ("prev_prechallenges", "prev_chals")}
+    karr = {name[len("kimchi."):]: tile("kimchi", name[len("kimchi."):]) for name in sec if name.startswith("kimchi.") and name not in ("kimchi.prev_prechallenges", "kimchi.prev_chals")}
     kp = m.MinaContext.make_kimchi_proofs(B, 2, NPUB, karr, statements=st)
-    nd = min(B, 32)
+    nd = min(B, distinct_chains or B)
     recs, nf, hashes = make_chains(ctx, nd, seed)
     ci = np.arange(B) % nd
     # folding randomisers of the kernel-level job are the CALLER's to supply (include/mina_verify.h): drawn from the OS CSPRNG, as the
     # reference-shaped boundary does per job (api_verify.hip draw_randomisers); their values do not change the work
     rho = np.frombuffer(os.urandom(B * 32), np.uint8).reshape(B, 32).copy(); rho[:, 31] &= 0x3F
-    arrays = dict(state_records=recs[ci].reshape(-1), state_nfields=nf[ci].reshape(-1), expected_hashes=hashes[ci].reshape(-1),
+    same = nd == B
+    arrays = dict(state_records=recs.reshape(-1) if same else recs[ci].reshape(-1), state_nfields=nf.reshape(-1) if same else nf[ci].reshape(-1),
+                  expected_hashes=hashes.reshape(-1) if same else hashes[ci].reshape(-1),
                   rand_base=fresh_randomiser(), sg_rand_base=fresh_randomiser(), acc_prechallenges=tile(None, "acc_prechallenges"), acc_sg=tile(None, "acc_sg"), acc_rho=rho.reshape(-1),
                   **{name: tile("opening", name) for name in ("lr", "delta", "sg", "z1", "z2")})
     scal = dict(with_states=1, with_ipa=1, with_accumulator=1, log2_domain=LOG2_DOMAIN, npub=NPUB, k=WRAP_K, n_evalpoints=NPTS, n_comms=NCOMMS + 2, acc_k=ACC_K, kimchi=kp)
-    return m.MinaContext.make_state_jobs(B, arrays, **scal), kp, (recs[0], nf[0], hashes[0])
+    return m.MinaContext.make_state_jobs(B, arrays, **scal), kp, (recs[0].copy(), nf[0].copy(), hashes[0].copy()), {"chains": int(nd), "wrap_proofs": int(min(n, B))}
 
 
 def device_jobs(m, hj, keep, kp, dev):
@@ -446,6 +477,91 @@ def boundary_leg(m, devices: str, B: int, min_seconds: float = 2.0):
     return res
 
 
+def account_leg(m, devices: str, min_seconds: float = 1.5):
+    """Secondary key `c4_account_256` -- BASELINE config C4: 256 Proof-of-Account verifications per `mina_verify_account_batch` call (the reference's
+    verify_account_inclusion_ffi per pair, /root/reference/README.md:358-362; containers core/src/proof/account_proof.rs:9-35), host bytes in, bools out: bincode parsing,
+    the Solidity-ABI cross-check (core/src/sol/account.rs:25-314), four dependent Poseidon stages of the account hash and the depth-35 Merkle fold on the GPU.
+    256 DISTINCT accounts (tests/golden/account_proofs_bytes.json).  Timed: a lone caller; 16 caller threads (a batcher's tasks: small calls share jobs); and the
+    config's "MSM mix" -- 4 account callers beside 2 callers of 8192 serialized state proofs in the same process."""
+    import base64
+    import ctypes
+    import threading
+    path = os.path.join(ROOT, "tests", "golden", "account_proofs_bytes.json")
+    if not os.path.exists(path):
+        return {"skipped": "tests/golden/account_proofs_bytes.json missing"}
+    fxa = json.load(open(path))
+    setup = _boundary_setup(m, devices)
+    if isinstance(setup, dict):
+        return setup
+    lib, items, ndev = setup
+    import mina_bridge_amd.poseidon_params as PP
+    if fxa["poseidon_constants"] != PP.NAME:
+        return {"skipped": "account fixture minted under another Poseidon constant set"}
+    n = 256
+    P = [base64.b64decode(fxa["proofs"][i % len(fxa["proofs"])]["proof"]) for i in range(n)]; Q = [base64.b64decode(fxa["proofs"][i % len(fxa["proofs"])]["pub"]) for i in range(n)]
+    PP_ = (ctypes.c_char_p * n)(*P); PL = (ctypes.c_size_t * n)(*map(len, P)); QQ = (ctypes.c_char_p * n)(*Q); QL = (ctypes.c_size_t * n)(*map(len, Q))
+
+    def call(out):
+        rc = lib.mina_verify_account_batch(ctypes.c_size_t(n), PP_, PL, QQ, QL, out.ctypes.data_as(ctypes.c_void_p))
+        assert rc == 0, lib.mina_last_error().decode()
+    out0 = np.zeros(n, np.uint8)
+    for _ in range(3):
+        call(out0)
+    assert out0.all(), "account verdicts must be ACCEPT"
+    bad = bytearray(Q[7]); bad[3] ^= 1; QQ[7] = bytes(bad)                # another ledger hash for pair 7: it alone fails
+    call(out0); assert np.flatnonzero(out0 == 0).tolist() == [7], "a tampered ledger hash must fail exactly its pair"
+    QQ[7] = Q[7]
+
+    def callers(k_acc, k_state, seconds):
+        stop = [False]; ca = [0] * k_acc; cs = [0] * k_state; lat = [[] for _ in range(k_acc)]
+        sjob = _Batch(lib, items, 8192) if k_state else None
+        if sjob:
+            sjob.call()
+        errs = []
+        def aw(i):
+            o = np.zeros(n, np.uint8)
+            try:
+                while not stop[0]:
+                    t = time.perf_counter(); call(o); lat[i].append(time.perf_counter() - t); ca[i] += 1
+                    if not o.all(): raise AssertionError("an account pair was rejected")
+            except Exception as e:                                   # a thread's exception does not reach the caller by itself
+                errs.append(repr(e)); stop[0] = True
+        def sw(i):
+            o = np.zeros(8192, np.uint8)
+            try:
+                while not stop[0]:
+                    sjob.call(o); cs[i] += 1
+                    if not o.all(): raise AssertionError("a state proof was rejected")
+            except Exception as e:
+                errs.append(repr(e)); stop[0] = True
+        th = [threading.Thread(target=aw, args=(i,)) for i in range(k_acc)] + [threading.Thread(target=sw, args=(i,)) for i in range(k_state)]
+        t0 = time.perf_counter()
+        for t in th: t.start()
+        time.sleep(seconds); stop[0] = True
+        for t in th: t.join()
+        el = time.perf_counter() - t0
+        assert not errs, errs[:2]
+        al = sorted(x for l in lat for x in l)
+        r = {"value": sum(ca) * n / el, "unit": "account proofs/s", "caller_threads": k_acc, "calls": sum(ca), "ms_per_call_median": al[len(al) // 2] * 1e3 if al else None}
+        if k_state:
+            r["state_caller_threads"] = k_state; r["state_proofs_per_s"] = sum(cs) * 8192 / el
+        return r
+    callers(16, 0, 0.3)                                              # warm: every slot's page-locked staging
+    lone, many = callers(1, 0, min_seconds), callers(16, 0, min_seconds)
+    callers(4, 2, 0.5)
+    mix = callers(4, 2, 2 * min_seconds)
+    res = {"value": lone["value"], "unit": "account proofs/s", "proofs_per_call": n, "distinct_accounts": len(fxa["proofs"]), "merkle_depth": fxa["merkle_depth"],
+           "ms_per_call": lone["ms_per_call_median"], "lone_caller": lone, "sixteen_caller_threads": many, "beside_state_batches": mix,
+           "bytes_per_pair": (sum(map(len, P)) + sum(map(len, Q))) // n, "devices": devices,
+           "entry_point": "mina_verify_account_batch (include/mina_verify.h): bincode MinaAccountProof + MinaAccountPubInputs bytes -> verdict bytes",
+           "poseidon_constants": m.lib.poseidon_params_name(),
+           "note": "BASELINE C4.  Poseidon only (a16 has no MSM): ~95 dependent permutations per pair, so ONE 256-pair call is a latency-bound chain on a mostly idle chip; "
+                   "callers that overlap share jobs (group commit).  beside_state_batches: the config's 'MSM mix' -- the account jobs ride a lane of their own at raised wave priority "
+                   "beside 2 callers x 8192 full state proofs; one tampered pair in a warm-up call failed alone"}
+    m.lib.verify_shutdown()
+    return res
+
+
 def boundary_all_devices_leg(m, devices: str, B: int, min_seconds: float = 2.0):
     """`boundary_bytes_to_bools.all_devices`: the PRODUCT's multi-GPU path (SURVEY.md 8e.1 behind the C-ABI) -- ONE process, one context per device of
     `devices`, `mina_verify_state_batch` cuts each call's proofs into contiguous shards, one host thread + pipeline per device, verdict bytes gathered on
@@ -535,6 +651,7 @@ def main():
     # --steps 80: 16 lanes 256.2 k, 20: 258.3 k, 24: 242.7 k, 32: 250.9 k (with 32 - 40 queues nothing gains: 20 lanes 258.1 k, 32 lanes 228 - 243 k)
     # at 16384 proofs per step (final build, --steps 40): 12 lanes 273.1 k (29 GiB of HBM in use), 16: 275.3 k (38 GiB), 20: 279.7 / 280.8 k (48 GiB), 24: 260.7 k (56 GiB)
     ap.add_argument("--pipeline", type=int, default=20, help="internal stream lanes over which consecutive steps are issued")
+    ap.add_argument("--distinct-chains", type=int, default=0, help="distinct candidate chains in the batch (default 0: one per proof)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", choices=("full", "kimchi", "prepared"), default="full",
                     help="full (default): the whole verifier from parsed proofs -- Pickles statement -> public inputs, kimchi oracles + to_batch, opening check, "
@@ -577,7 +694,7 @@ def main():
     # 24: 68.4 ms), while the 20-lane pipeline of the headline below wants one queue per lane plus a few (24).
     # At N > 1 rank 0 runs a second leg the same way: the product's own multi-device path, ONE process with a context on each of the N GPUs
     # (boundary_all_devices_leg).  The other ranks have not touched their GPUs yet: they wait at the CPU barrier below.
-    boundary = None
+    boundary = c4 = None
     if not args.no_boundary and rank == 0:
         import subprocess
         env = dict(os.environ); env["GPU_MAX_HW_QUEUES"] = os.environ.get("MINA_BOUNDARY_HW_QUEUES", "16")
@@ -590,6 +707,7 @@ def main():
                 return {"error": repr(e)[:400]}
         bsize = min(args.jobs, args.boundary_jobs) if args.boundary_jobs else min(args.jobs, 8192)
         boundary = leg("--boundary-only", "0" if share_gpu else str(local_rank), str(bsize))
+        c4 = leg("--account-only", "0" if share_gpu else str(local_rank), "256")
         if world > 1:
             devs = ",".join("0" if share_gpu else str(g) for g in range(world))
             boundary["all_devices"] = leg("--boundary-all-devices", devs, str(bsize))
@@ -616,8 +734,9 @@ def main():
     ctx.srs_create(CURVE_PALLAS, 1 << 16)
     B = args.jobs
     seed = 0x6D696E61 + rank
+    distinct = {}
     if args.mode == "full":
-        (hj, keep), kp, chain_sample = build_full_job(ctx, m, B, seed)
+        (hj, keep), kp, chain_sample, distinct = build_full_job(ctx, m, B, seed, args.distinct_chains)
         baseline_sample = ("full", chain_sample)
     else:                                                      # partial jobs: inputs through the test helpers (tools/bench_partial_inputs.py)
         sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -841,10 +960,10 @@ def main():
                                    "2^16-base Vesta step-accumulator check; verdict per proof, bit-exact vs the CPU oracle composite (tests/test_state_job.py)",
                        "proofs_per_step": B, "pipeline_lanes": args.pipeline, "hbm_in_use_GiB": round((hbm_total - hbm_free) / 2**30, 1), "hbm_total_GiB": round(hbm_total / 2**30, 1), "warmup_steps_run": n_warm,
                        "mode": args.mode,
-                       "distinct_inputs": {"full": "32 chains of flattened protocol-state records (random field content, GPU-linked) and the 4 complete wrap proofs of "
-                                                   "tests/golden/statement_k15_encoded.json (statement + proof + its accumulator) per rank; the statements' application "
-                                                   "state is the fixture's, not the hash of the chain tiled beside it (that binding, on serialized states through the "
-                                                   "parsers: tests/test_verify_fullsize.py)",
+                       "distinct_inputs": {"full": {**distinct, "note": "chains: flattened protocol-state records, random field content, GPU-linked, one per proof; wrap_proofs: complete "
+                                                             "(statement + wrap proof + opening + its step accumulator), minted by the repo's CPU prover under the synthetic indexes "
+                                                             "(tests/golden/statement_k15_encoded.json + statement_k15_many.npz), tiled to the batch; the statement's application state "
+                                                             "is the fixture's, not the hash of the chain beside it (that binding: tests/test_verify_fullsize.py)"},
                                            "kimchi": "32 chains, 4 wrap proofs (tests/golden/kimchi_k15.json), 32 accumulators per rank",
                                            "prepared": "32 chains, 8 wrap openings (tests/golden/state_job_k15.json), 32 accumulators per rank"}[args.mode],
                        "folding": "IPA and accumulator checks folded over the step's batch (kimchi batch_verify's shape); randomisers drawn from the OS CSPRNG by the caller",
@@ -858,19 +977,13 @@ def main():
                                     "prepared": "pre-derived BatchEvaluationProof rows (45 commitments)"}[args.mode],
                        "sharding": f"proof-level, {args.gpus} rank(s); verdict words all-gathered over {'gloo (ranks share one GPU)' if share_gpu else 'RCCL'}" if dist_on else "single rank",
                        "algorithmic_bytes_per_proof": algorithmic_bytes_per_proof()},
-            "roofline": {"bound": "hbm", "kernel": "pstate_hash_kernel", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": (nstates * traffic_per_state) if traffic_per_state else None,
-                         "traffic_source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), read from {TRAFFIC_FILE} ({traffic_src})" if traffic_per_state else None,
-                         "algorithmic_bytes_per_launch": hash_bytes, "states_per_launch": nstates, "avg_launch_us": kern_us,
-                         "avg_launch_us_in_timed_region": ovl.get("pstate_hash"),
-                         "note": "avg_launch_us: HIP events on the lane stream around the kernel, launches with nothing else on the GPU right after the "
-                                 "timed region (second figure: inside it, lanes overlapping).  The path is integer-VALU bound (SURVEY.md 8d): the HBM "
-                                 "fraction is reported because the metric asks for it, roofline_valu is the bound that matters; traffic: see profiles/"},
+            "roofline": None,                                  # filled below: the binding resource is integer VALU issue, the HBM view rides inside it
             "stage_us": {"isolated": iso, "in_timed_region": ovl},
             "sustained": sustained,
             "c5_4096_total_strong": c5,
             "exchange_variant_8e2": exchange,
             "boundary_bytes_to_bools": boundary,
+            "c4_account_256": c4,
             "c2_accumulator_only": {"value": c2_rate, "unit": "accumulator checks/s",
                                     "note": "BASELINE config C2 alone (round 1's headline): un-folded 2^16-base Vesta IPA accumulator checks, 8 per call, 16 lanes",
                                     # the metric's second half ("MSM HBM GB/s vs peak"): one check = one 2^16-base MSM; algorithmic bytes = bases + scalars
@@ -881,19 +994,39 @@ def main():
                                                                                  "since round 4: profiles/r04_k1.md), not by HBM; the fixed-base window tables trade bandwidth for doubling chains: "
                                                                                  "one 64-B point gathered per (base, window)"}},
         }
+        hbm_view = {"achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBPS) if achieved else None,
+                    "algorithmic_bytes_per_launch": hash_bytes, "traffic": (nstates * traffic_per_state) if traffic_per_state else None,
+                    "traffic_ratio_to_algorithmic": (nstates * traffic_per_state / hash_bytes) if traffic_per_state else None,
+                    "traffic_source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), read from {TRAFFIC_FILE} ({traffic_src})" if traffic_per_state else None,
+                    "note": "reported because the metric asks for it: 1632 algorithmic bytes per state against ~3.3 M limb multiply-accumulates -- the kernel cannot be HBM-bound"}
         if kern_us:
             peak = CHIP_SIMDS * 64 * CLOCK_HZ / MAD_ISSUE_CYCLES
+            pure_peak = CHIP_SIMDS * 64 * CLOCK_HZ / PURE_MAC_ISSUE_CYCLES
             got = perms * 3 * 55 * MADS_PER_LANE_ROUND / (kern_us * 1e-6)
             waves = -(-nstates // 21)                          # 21 sponges per wave64 (3 lanes each)
+            out["roofline"] = {"bound": "valu_int32", "kernel": "pstate_hash_kernel", "achieved": got / 1e12, "peak": pure_peak / 1e12, "unit": "T limb-MAC/s", "frac": got / pure_peak,
+                               "frac_of_own_mix_ceiling": got / peak, "traffic": hbm_view["traffic"], "hbm": hbm_view,
+                               "states_per_launch": nstates, "avg_launch_us": kern_us, "avg_launch_us_in_timed_region": ovl.get("pstate_hash"),
+                               "limb_macs_per_launch": perms * 3 * 55 * MADS_PER_LANE_ROUND,
+                               "peak_source": f"measured pure v_mad_u64_u32 stream, {PURE_MAC_ISSUE_CYCLES} cycles at 2.4 GHz per wave64 instruction per SIMD, 8 waves per SIMD "
+                                              "(profiles/r04_microbench_ratio.jsonl, S = 0; re-measured per round: profiles/README.md)",
+                               "note": "bound = the binding resource (SURVEY.md 8d: integer VALU, not HBM, not MFMA).  achieved = 29-bit limb multiply-accumulates per launch / the "
+                                       "launch's HIP-event duration on its lane stream (isolated launches right after the timed region; second figure: inside it).  frac counts every "
+                                       "non-multiply instruction of the round (191 of 965 per lane-round) as a lost slot; frac_of_own_mix_ceiling prices the kernel's own mix instead. "
+                                       "`hbm`: the metric's 'HBM GB/s vs peak' view of the same launch; `traffic` = its PMC bytes"}
             out["roofline_valu"] = {"bound": "issue rate of the kernel's own instruction mix (774 v_mad_u64_u32 + ~190 shifts / negations / masks per lane-round), measured: "
                                              f"{MAD_ISSUE_CYCLES} cycles at 2.4 GHz per wave64 multiply-accumulate per SIMD", "kernel": "pstate_hash_kernel",
-                                    "achieved": got / 1e12, "peak": peak / 1e12, "unit": "T limb-MAC/s", "frac": got / peak, "permutations_per_launch": perms,
+                                    "achieved": got / 1e12, "peak": peak / 1e12, "unit": "T limb-MAC/s", "frac": got / peak, "frac_of_pure_mac_peak": got / pure_peak, "pure_mac_peak": pure_peak / 1e12,
+                                    "permutations_per_launch": perms,
                                     "limb_macs_per_permutation": 3 * 55 * MADS_PER_LANE_ROUND,
                                     "waves_per_launch": waves, "waves_per_simd_in_launch": waves / CHIP_SIMDS, "resident_waves_per_simd": 5,
                                     "peak_source": "profiles/r04_microbench_ratio.jsonl (the round's mix, 8 waves per SIMD); counters of the kernel: profiles/r04_valu_roofline.md",
                                     "note": "9 x 29-bit limbs, no carry instructions.  The kernel holds 96 VGPRs: 5 waves per SIMD are resident (the mix issues at 5.7 cycles per "
                                             "multiply-accumulate with 4 waves, 5.46 with 8), and a launch whose waves per SIMD are not a multiple of 5 ends on partly filled SIMDs "
                                             "(8192 proofs: 6.5 waves per SIMD, isolated launch 0.82 of the ceiling; 16384: 12.95)"}
+        else:
+            out["roofline"] = {"bound": "valu_int32", "kernel": "pstate_hash_kernel", "achieved": None, "peak": CHIP_SIMDS * 64 * CLOCK_HZ / PURE_MAC_ISSUE_CYCLES / 1e12, "unit": "T limb-MAC/s",
+                               "frac": None, "traffic": hbm_view["traffic"], "hbm": hbm_view, "note": "no kernel timing in this run (--no-probes without the stage events)"}
         if args.mode == "full" and not share_gpu:            # (ranks sharing one GPU: a step's time is not one GPU's)
             out["step_valu"] = step_valu(out["ms_per_step"], B)  # the pipelined step as a whole against instruction issue (secondary; `roofline` stays the dominant kernel's)
         if not args.no_cpu_baseline and args.gpus == 1:       # the CPU leg is timed at N = 1 only (rank 0)
@@ -910,9 +1043,12 @@ def main():
 
 
 if __name__ == "__main__":
-    if len(sys.argv) >= 4 and sys.argv[1] in ("--boundary-only", "--boundary-all-devices"):     # a bytes -> bools leg in a process of its own (see main): only the library, no torch
+    if len(sys.argv) >= 4 and sys.argv[1] in ("--boundary-only", "--boundary-all-devices", "--account-only"):     # a bytes -> bools leg in a process of its own (see main): only the library, no torch
         import mina_bridge_amd as _m
-        fn = boundary_leg if sys.argv[1] == "--boundary-only" else boundary_all_devices_leg
-        print(json.dumps(fn(_m, sys.argv[2], int(sys.argv[3]))), flush=True)
+        if sys.argv[1] == "--account-only":
+            print(json.dumps(account_leg(_m, sys.argv[2])), flush=True)
+        else:
+            fn = boundary_leg if sys.argv[1] == "--boundary-only" else boundary_all_devices_leg
+            print(json.dumps(fn(_m, sys.argv[2], int(sys.argv[3]))), flush=True)
     else:
         main()

@@ -71,8 +71,12 @@ void mina_ctx_destroy(mina_ctx *ctx);
 const char *mina_last_error(void);
 /* block until everything queued on the context's stream has finished */
 int mina_ctx_synchronize(mina_ctx *ctx);
-/* the hipStream_t the `_dev` entry points are queued on (for event timing by the caller) */
+/* the hipStream_t the `_dev` entry points are queued on: lane 0's, or the pinned lane's (for event timing and for stream-ordered work of the caller) */
 void *mina_ctx_stream(mina_ctx *ctx);
+/* Pin every `_dev` entry point to pipeline lane `lane` (0 <= lane < lanes; negative: back to round-robin).  While pinned, all work the library queues is
+ * ordered on mina_ctx_stream(): a caller that queues its own copies / kernels / collectives on that stream needs no host synchronisation between calls
+ * (the multi-GPU exchange step, SURVEY.md 8e.2: mina_bridge_amd/sharded.py).  mina_ctx_set_pipeline unpins. */
+int mina_ctx_pin_lane(mina_ctx *ctx, int lane);
 
 /* Pipelining: the `_dev` entry points are issued round-robin over `lanes` internal streams (1..32, default 1),
  * each with its own workspace, so independent calls overlap on the GPU.  mina_ctx_synchronize waits for all. */

@@ -207,7 +207,16 @@ extern "C" int mina_ctx_synchronize(mina_ctx *c) {
     for (int i = 0; i < c->nlanes; ++i) HIPC(hipStreamSynchronize(c->lanes[i].stream));
     return MINA_OK;
 }
-extern "C" void *mina_ctx_stream(mina_ctx *c) { return c ? (void *)c->lanes[0].stream : nullptr; }
+extern "C" void *mina_ctx_stream(mina_ctx *c) { return c ? (void *)c->lanes[c->pinned >= 0 ? c->pinned : 0].stream : nullptr; }
+// Pin the `_dev` entry points to ONE pipeline lane (lane < 0: back to round-robin).  While pinned, everything they queue is ordered on mina_ctx_stream(): a caller
+// that queues its own kernels, copies and collectives on that stream (torch: ExternalStream) is ordered against the library by the stream itself -- no
+// hipDeviceSynchronize between the steps of a multi-GPU exchange (mina_bridge_amd/sharded.py ShardedStateJob).
+extern "C" int mina_ctx_pin_lane(mina_ctx *c, int lane) {
+    if (!c) return fail(MINA_ERR_ARG, "null ctx");
+    if (lane >= c->nlanes) return fail(MINA_ERR_ARG, "lane outside the pipeline (mina_ctx_set_pipeline)");
+    c->pinned = lane < 0 ? -1 : lane;
+    return MINA_OK;
+}
 
 extern "C" int mina_ctx_set_pipeline(mina_ctx *c, int lanes) {
     if (!c) return fail(MINA_ERR_ARG, "null ctx");
@@ -216,7 +225,7 @@ extern "C" int mina_ctx_set_pipeline(mina_ctx *c, int lanes) {
     for (int i = 0; i < c->nlanes; ++i) HIPC(hipStreamSynchronize(c->lanes[i].stream));
     for (int i = 0; i < lanes; ++i)
         if (!c->lanes[i].stream) HIPC(hipStreamCreateWithFlags(&c->lanes[i].stream, hipStreamNonBlocking));
-    c->nlanes = lanes; c->rr = 0; c->use_lane0();
+    c->nlanes = lanes; c->rr = 0; c->pinned = -1; c->use_lane0();
     return MINA_OK;
 }
 

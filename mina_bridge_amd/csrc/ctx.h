@@ -120,6 +120,7 @@ struct mina_ctx {
     Lane lanes[MB_MAX_LANES];
     int nlanes = 1;
     unsigned rr = 0;                 // round-robin cursor of the `_dev` entry points
+    int pinned = -1;                 // >= 0: every `_dev` entry point runs on this lane (mina_ctx_pin_lane): a caller that queues its own work on that lane's stream needs no host synchronisation
     Lane *L = nullptr;               // lane the current call runs on
     Lane *ipa_rows = nullptr; uint32_t ipa_rows_batch = 0, ipa_rows_k = 0, ipa_rows_per = 0, ipa_rows_nshared = 0; int ipa_rows_curve = -1;   // lane holding the prepared rows of the last folded opening check (mb_ipa_recheck_rows)
     FieldK fk[2];
@@ -139,7 +140,7 @@ struct mina_ctx {
     // this shard's folded scalar vector and the 17-word record of its variable-base partial sum instead (mina_state_job_fold_dev); device pointers
     struct FoldExport { uint32_t *ipa_scalars = nullptr, *ipa_point = nullptr, *acc_scalars = nullptr, *acc_point = nullptr; } *fold_export = nullptr;
     void use_lane0() { L = &lanes[0]; }
-    void next_lane() { L = &lanes[rr++ % (unsigned)nlanes]; }
+    void next_lane() { L = pinned >= 0 ? &lanes[pinned] : &lanes[rr++ % (unsigned)nlanes]; }
 };
 
 // lane-cooperative Poseidon: batches of at most this many sponges use 8 lanes each (shortest dependency chain, 2.6x the issue

@@ -24,7 +24,7 @@ CURVE_PALLAS, CURVE_VESTA = 0, 1
 
 # every symbol include/mina_verify.h declares (checked by tests/test_abi.py)
 EXPORTS = [
-    "mina_ctx_create", "mina_ctx_destroy", "mina_last_error", "mina_ctx_synchronize", "mina_ctx_stream", "mina_ctx_set_pipeline", "mina_prof_enable", "mina_prof_read",
+    "mina_ctx_create", "mina_ctx_destroy", "mina_last_error", "mina_ctx_synchronize", "mina_ctx_stream", "mina_ctx_pin_lane", "mina_ctx_set_pipeline", "mina_prof_enable", "mina_prof_read",
     "mina_dev_malloc", "mina_dev_free", "mina_dev_upload", "mina_dev_download",
     "mina_srs_create", "mina_srs_load", "mina_srs_depth", "mina_srs_get_g", "mina_srs_get_h", "mina_srs_lagrange_basis", "mina_public_input_commitment", "mina_public_input_commitment_batch", "mina_combined_inner_product", "mina_srs_serialize",
     "mina_msm", "mina_msm_srs", "mina_msm_srs_range", "mina_msm_srs_multi", "mina_msm_srs_dev",
@@ -612,6 +612,10 @@ class MinaContext:
     @property
     def stream(self) -> int:
         return int(self._lib.mina_ctx_stream(self._h) or 0)
+
+    def pin_lane(self, lane: int):
+        """every `_dev` entry point on ONE lane (negative: round-robin again): the library's work is then ordered on `self.stream`"""
+        self._ck(self._lib.mina_ctx_pin_lane(self._h, int(lane)), "mina_ctx_pin_lane")
 
     def set_pipeline(self, lanes: int):
         self._ck(self._lib.mina_ctx_set_pipeline(self._h, int(lanes)), "mina_ctx_set_pipeline")

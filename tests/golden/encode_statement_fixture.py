@@ -15,9 +15,10 @@ from kimchi_helpers import STEP_DOMAINS, encode_tokens, kimchi_arrays, load_k15_
 from oracle import oracle as O
 
 
-def encode():
+def encode(items=None, fx=None):
     ix, _, fxk = load_k15_fixture()
-    items, fx = load_statement_fixture()
+    if items is None:
+        items, fx = load_statement_fixture()
     step = make_step_index(99)
     hx = lambda a: np.ascontiguousarray(a, dtype=np.uint8).reshape(-1).tobytes().hex()
     out = {"poseidon_constants": fx["poseidon_constants"], "source": "tests/golden/statement_k15.json, tests/golden/kimchi_k15.json, kimchi_helpers.make_step_index(99)",
@@ -62,7 +63,35 @@ def encode_boundary_bytes():
     return out
 
 
+def encode_many():
+    """.mint_parts/part_*.json (tools/mint_many.sh: proofs 4, 5, ... of the same generator, same indexes) -> tests/golden/statement_k15_many.npz: the sections of
+    `encode()` as uint8 arrays [n_proofs, bytes_per_proof], one array per section ("statement.<name>", "kimchi.<name>", "opening.<name>", "acc_prechallenges",
+    "acc_sg", "public_inputs"), + "chain_seed".  bench.py tiles its headline batch from the 4 proofs of statement_k15_encoded.json + these (config.distinct_inputs)."""
+    import glob
+    parts = sorted(glob.glob(os.path.join(ROOT, ".mint_parts", "part_*.json")), key=lambda p: int(p.rsplit("_", 1)[1].split(".")[0]))
+    cols, seeds, consts = {}, [], None
+    for path in parts:
+        items, fx = load_statement_fixture(path)
+        consts = consts or fx["poseidon_constants"]
+        assert fx["poseidon_constants"] == consts
+        for rec, it in zip(encode(items, fx)["proofs"], items):
+            flat = {"acc_prechallenges": rec["acc_prechallenges"], "acc_sg": rec["acc_sg"], "public_inputs": rec["public_inputs"]}
+            for grp in ("statement", "kimchi", "opening"):
+                flat.update({grp + "." + k: v for k, v in rec[grp].items()})
+            for k, v in flat.items():
+                cols.setdefault(k, []).append(np.frombuffer(bytes.fromhex(v), np.uint8))
+            seeds.append(it["chain_seed"])
+    n = len(seeds)
+    assert n and all(len(v) == n for v in cols.values())
+    arrays = {k: np.stack(v) for k, v in cols.items()}
+    np.savez(os.path.join(ROOT, "tests/golden/statement_k15_many.npz"), chain_seed=np.array(seeds, np.int64), poseidon_constants=np.frombuffer(consts.encode(), np.uint8), **arrays)
+    return n
+
+
 if __name__ == "__main__":
+    if "--many" in sys.argv:
+        print("wrote tests/golden/statement_k15_many.npz:", encode_many(), "proofs")
+        sys.exit(0)
     json.dump(encode(), open(os.path.join(ROOT, "tests/golden/statement_k15_encoded.json"), "w"), indent=0)
     print("wrote tests/golden/statement_k15_encoded.json")
     json.dump(encode_boundary_bytes(), open(os.path.join(ROOT, "tests/golden/state_proofs_k15_bytes.json"), "w"), indent=0)

@@ -6,7 +6,9 @@ Minted by the repo's OWN CPU oracle (oracle/pickles_ref.py derives the public in
 proof, oracle/state_job_ref.py the accumulator) under the Poseidon constant set named in the file: inputs + expected ACCEPT for the
 full Proof-of-State job from raw statements at BASELINE size (bench.py, tests/test_state_job.py).  There is no reference
 implementation to import and no real proof offline.
-Run:  python tests/golden/gen_statement_fixture.py [count]   (~6 min per proof)"""
+Run:  python tests/golden/gen_statement_fixture.py [count]   (~6 min per proof)
+      python tests/golden/gen_statement_fixture.py count --start S --out FILE     proofs S .. S+count-1 (same seeds as a longer single run would use) into FILE:
+      the parts of tests/golden/statement_k15_many.npz (tests/golden/encode_statement_fixture.py --many; tools/mint_many.sh runs the parts in parallel)"""
 import json
 import os
 import random
@@ -24,6 +26,9 @@ import mina_bridge_amd.poseidon_params as PP
 
 K_LOG2, NPUB, ACC_K = 15, 40, 16
 count = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+start = int(sys.argv[sys.argv.index("--start") + 1]) if "--start" in sys.argv else 0
+out_path = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else os.path.join(ROOT, "tests/golden/statement_k15.json")
+R.inv = lambda a, m: pow(a, -1, m)                              # same value as the oracle's pow(a, m - 2, m), ~20x faster: the prover inverts 3 x 2^18 times per proof
 nthreads = os.cpu_count() or 4
 g, h = O.srs_create(0, 1 << K_LOG2, threads=nthreads)
 gv, _ = O.srs_create(1, 1 << ACC_K, threads=nthreads)
@@ -41,7 +46,7 @@ step = make_step_index(99)
 out = {"poseidon_constants": PP.NAME, "wrap_index": "tests/golden/kimchi_k15.json", "step_index": "kimchi_helpers.make_step_index(99)", "proofs": []}
 STATEMENT_KEYS = ("alpha", "beta", "gamma", "zeta", "joint_combiner", "feature_flags", "bulletproof_challenges", "proofs_verified", "domain_log2", "sponge_digest",
                   "challenge_polynomial_commitment", "old_bulletproof_challenges", "step_comms", "step_old_chals", "prev_public_input", "prev_evals", "prev_optional", "prev_ft_eval1")
-for i in range(count):
+for i in range(start, start + count):
     t0 = time.time()
     rng = random.Random(0x57A7 + i)
     wrap = synth_wrap_proof(rng, k=K_LOG2, lookups=False)
@@ -74,4 +79,4 @@ for i in range(count):
                           "evals": [[str(a), str(b)] for a, b in proof["evals"]], "ft_eval1": str(proof["ft_eval1"]),
                           "lr": [[hx(l), hx(r)] for l, r in op["lr"]], "delta": hx(op["delta"]), "sg": hx(op["sg"]), "z1": str(op["z1"]), "z2": str(op["z2"])})
     print("proof", i, "ok", round(time.time() - t0, 1), "s", flush=True)
-    json.dump(out, open(os.path.join(ROOT, "tests/golden/statement_k15.json"), "w"), indent=0)
+    json.dump(out, open(out_path, "w"), indent=0)

@@ -178,12 +178,12 @@ def install_step_index(ctx, step):
     ctx.step_index_install(step.zk_rows, STEP_DOMAINS, sh, encode_tokens(step.constant_term))
 
 
-def load_statement_fixture():
-    """tests/golden/statement_k15.json -> [dict(wrap=statement fields as in tests/wire_writers.py, app, pubs, acc_pre [16,16] u8, acc_sg [64] u8, proof)]
-    for the wrap index of kimchi_k15.json and the step index make_step_index(99)"""
+def load_statement_fixture(path=None):
+    """tests/golden/statement_k15.json (or another file of tests/golden/gen_statement_fixture.py) -> [dict(wrap=statement fields as in tests/wire_writers.py, app, pubs,
+    acc_pre [16,16] u8, acc_sg [64] u8, proof)] for the wrap index of kimchi_k15.json and the step index make_step_index(99)"""
     import json, os
     from oracle import oracle as O
-    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "statement_k15.json")))
+    fx = json.load(open(path or os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "statement_k15.json")))
     pt = lambda hx: O.bytes_to_point(np.frombuffer(bytes.fromhex(hx), np.uint8))
     dec = lambda v: None if v is None else v if isinstance(v, bool) else int(v) if isinstance(v, str) else [dec(x) for x in v]
     out = []

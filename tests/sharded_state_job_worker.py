@@ -27,7 +27,7 @@ ctx = m.MinaContext(dev_ix)
 for f in (0, 1):
     ctx.poseidon_set_params(f, m.poseidon_params.default_params_bytes(f))
 ctx.srs_create(1, 1 << 16); ctx.srs_create(0, 1 << 16)
-(hj, keep), kp, _ = bench.build_full_job(ctx, m, B, seed=900 + rank)
+(hj, keep), kp, _, _ = bench.build_full_job(ctx, m, B, seed=900 + rank)
 by_addr = {a.ctypes.data: a for a in keep if isinstance(a, np.ndarray)}
 bad_at = None
 if scenario == "bad_opening_on_last_rank" and rank == world - 1:
@@ -43,14 +43,16 @@ if scenario == "opposite_z2_on_first_proofs" and rank < 2:
     z2[0] = np.frombuffer(v.to_bytes(32, "little"), np.uint8)
 dj, dk, tensors = bench.device_jobs(m, hj, keep, kp, dev)
 ctx.state_jobs_prepare(bench.LOG2_DOMAIN, bench.NPUB)
-job = ShardedStateJob(DeviceBackend(ctx, dev), k=bench.WRAP_K, acc_k=bench.ACC_K)
+be = DeviceBackend(ctx, dev)
+job = ShardedStateJob(be, k=bench.WRAP_K, acc_k=bench.ACC_K)
 verdicts, ok = job.verify(dj, B)
+host_syncs, host_reads = be.host_syncs, job.host_reads          # of the exchange step alone (the fallback of a failed batch runs the ordinary job and synchronises)
 # the ordinary single-GPU job on the same shard, for comparison
 plain = torch.zeros(B + 4, dtype=torch.int32, device=dev)
 torch.cuda.synchronize()
 ctx.state_job_batch_dev(dj, plain.data_ptr(), plain.data_ptr() + 4 * B); ctx.synchronize(); torch.cuda.synchronize()
 print(json.dumps({"rank": rank, "world": world, "backend": dist.get_backend(), "batch_ok": ok, "verdicts": verdicts.cpu().numpy().tolist(),
-                  "plain": plain[:B].cpu().numpy().tolist(), "plain_flags": plain[B:].cpu().numpy().tolist(), "bad_at": bad_at, "detail": job.last}), flush=True)
+                  "plain": plain[:B].cpu().numpy().tolist(), "plain_flags": plain[B:].cpu().numpy().tolist(), "bad_at": bad_at, "detail": job.last, "host_syncs": host_syncs, "host_reads": host_reads}), flush=True)
 dist.barrier()
 dist.destroy_process_group()
 ctx.close()

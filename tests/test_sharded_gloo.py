@@ -248,6 +248,8 @@ class OracleJobBackend:
 
     def records_equal(self, a, b): return bool((a == b).all())
 
+    def records_equal_word(self, a, b): return self.torch.tensor([int(bool((a == b).all()))], dtype=self.torch.int32)
+
 
 def _state_job_worker(rank, world, port, q):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -35,6 +35,8 @@ def test_exchange_variant_equals_the_single_gpu_job_on_every_shard():
     outs = run_ranks(2, 6, "ok")
     for o in outs:
         assert o["batch_ok"] is True and o["verdicts"] == [1] * 6 == o["plain"] and o["plain_flags"] == [1, 0, 1, 0], o
+        # the exchange step is ordered by the context's pinned stream -- no full device synchronisation, ONE word read by the host
+        assert o["host_syncs"] == 0 and o["host_reads"] == 1, (o["host_syncs"], o["host_reads"])
 
 
 def test_a_bad_opening_on_one_rank_fails_the_batch_everywhere_and_is_localised_to_its_shard():

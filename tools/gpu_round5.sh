@@ -1,0 +1,26 @@
+#!/bin/bash
+# round 5: ONE script for every GPU-box call; stages named on the command line, outputs under gpurun_out/<tag>/.
+#   tools/gpu_round5.sh <tag> stage [stage ...]     stages: fe52 sharded pytest bench bench20 gpus2 microbench profile c2 account callers
+cd $GRAFT_REPO_ROOT
+TAG=$1; shift
+O=gpurun_out/$TAG; mkdir -p $O
+for st in "$@"; do
+  case $st in
+    fe52)     ( timeout 120 tools/probes/bin/fe52_probe --values | python tools/probes/fe52_check.py ) > $O/fe52_check.json 2>&1; cat $O/fe52_check.json
+              timeout 300 tools/probes/bin/fe52_probe > $O/fe52_probe.jsonl 2>&1; tail -12 $O/fe52_probe.jsonl ;;
+    sharded)  ( time timeout 1500 python -m pytest tests/test_sharded_state_job.py -m gpu -q -x ) > $O/pytest_sharded.log 2>&1; tail -5 $O/pytest_sharded.log ;;
+    pytest)   ( time timeout 3000 python -m pytest tests -m gpu -q --durations=8 ) > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log; tail -6 $O/pytest_gpu.log ;;
+    bench)    ( time timeout 900 python bench.py ) > $O/bench.json 2> $O/bench.err; echo "bench rc=$?"; cut -c1-1500 $O/bench.json ;;
+    bench20)  ( time timeout 900 python bench.py --steps 20 --warmup 3 ) > $O/bench_steps20.json 2>> $O/bench.err; echo "bench20 rc=$?" ;;
+    gpus2)    ( time timeout 1200 python bench.py --gpus 2 ) > $O/bench_gpus2_shared.json 2> $O/bench_gpus2.err; echo "gpus2 rc=$?" ;;
+    microbench) timeout 300 mina_bridge_amd/microbench > $O/microbench.jsonl 2>&1; timeout 300 mina_bridge_amd/microbench --ratio > $O/microbench_ratio.jsonl 2>&1 ;;
+    profile)  timeout 900 bash tools/profile_round.sh $TAG > $O/profile_round.log 2>&1; tail -2 $O/profile_round.log | cut -c1-200
+              timeout 900 bash tools/profile_sq.sh $TAG > $O/profile_sq.log 2>&1
+              python tools/profile_report.py $TAG $O/bench.json > $O/${TAG}_rocprof.md 2> $O/report.err; wc -l $O/${TAG}_rocprof.md ;;
+    c2)       timeout 900 bash tools/profile_c2.sh $TAG > $O/profile_c2.log 2>&1; tail -3 $O/profile_c2.log
+              timeout 300 python tools/c2_rate.py 16 400 2>/dev/null | tail -1 ;;
+    account)  timeout 600 python tools/c4_rate.py > $O/c4_rate.log 2>&1; tail -8 $O/c4_rate.log ;;
+    callers)  timeout 600 python tools/concurrent_callers.py 6 > $O/concurrent_callers.log 2>&1; tail -12 $O/concurrent_callers.log ;;
+    *) echo "unknown stage $st" ;;
+  esac
+done

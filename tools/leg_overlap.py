@@ -14,7 +14,7 @@ ctx = m.MinaContext(0)
 for f in (0, 1):
     ctx.poseidon_set_params(f, m.poseidon_params.default_params_bytes(f))
 ctx.srs_create(1, 1 << 16); ctx.srs_create(0, 1 << 16)
-(hj, keep), kp, _ = bench.build_full_job(ctx, m, B, 5)
+(hj, keep), kp, _, _ = bench.build_full_job(ctx, m, B, 5)
 dev = torch.device("cuda", 0)
 tens = []
 def up(struct, cls, keepl):

@@ -66,8 +66,9 @@ r, rv = b["roofline"], b.get("roofline_valu", {})
 print(f"\n## Dominant kernel `{r['kernel']}` (one launch = {r['states_per_launch']} protocol-state hashes)\n")
 print(f"* HIP events in bench.py: {r['avg_launch_us']:.0f} us isolated, {r['avg_launch_us_in_timed_region']:.0f} us inside the timed region (lanes time-share the CUs; "
       f"rocprofv3's average over the same region is in the first table).")
-print(f"* algorithmic bytes per launch {r['algorithmic_bytes_per_launch']} B -> {r['achieved']:.2f} GB/s = {r['frac'] * 100:.3f} % of the 8 TB/s HBM peak; PMC traffic "
+h = r.get("hbm", r)                                          # round 5: `roofline` is the VALU bound, the HBM view rides inside it
+print(f"* algorithmic bytes per launch {h['algorithmic_bytes_per_launch']} B -> {h['achieved']:.2f} GB/s = {h['frac'] * 100:.3f} % of the 8 TB/s HBM peak; PMC traffic "
       f"(FETCH x 2 for 16-B-per-lane loads + WRITE): see the table above; the kernel is integer-multiply bound.")
 if rv:
     print(f"* multiply-accumulate issue: {rv['permutations_per_launch']} permutations x {rv.get('limb_macs_per_permutation', 0)} limb MACs per launch = {rv['achieved']:.1f} {rv['unit']} of a {rv['peak']:.1f} "
-          f"{rv['unit']} issue rate ({rv['bound']}) = **{rv['frac']:.2f}**.")
+          f"{rv['unit']} issue rate ({rv['bound']}) = **{rv['frac']:.2f}**" + (f"; against the measured pure v_mad_u64_u32 peak of {rv['pure_mac_peak']:.1f}: **{rv['frac_of_pure_mac_peak']:.2f}** (`roofline.frac`)." if "pure_mac_peak" in rv else "."))
