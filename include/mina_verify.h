@@ -98,6 +98,10 @@ int mina_prof_read(mina_ctx *ctx, char *buf, size_t cap);
 /* Regenerate SRS{g[0..depth), h} exactly as poly-commitment `SRS::create(depth)` does
  * (BLAKE2b-512 -> field -> BW group map, K4 on the GPU) and build the MSM window tables in HBM. */
 int mina_srs_create(mina_ctx *ctx, int curve, uint32_t depth);
+/* Build (on != 0) or drop the pre-split form of the curve's window table: 128-byte records holding x, y and p - y as nine 29-bit limbs each, read by the accumulate
+ * kernels when mina_verify_tuning.msm_fp29 = 2 (no limb conversion, no negation; twice the gather traffic, 128 MiB per curve at depth 2^16).  Without it
+ * msm_fp29 = 2 behaves as 1.  Waits for the context's queued work. */
+int mina_srs_split_table(mina_ctx *ctx, int curve, int on);
 /* Load from the MessagePack bytes of srs/vesta.srs / srs/pallas.srs (33-byte compressed points). */
 int mina_srs_load(mina_ctx *ctx, int curve, const uint8_t *msgpack, size_t len);
 /* depth of the loaded SRS (0 if none) */
@@ -669,11 +673,16 @@ typedef struct mina_verify_tuning {
     uint32_t ipa_side_stream;      /* 1     U = to_group(t) beside the transcript on a second stream */
     uint32_t search_fan;           /* 4     fan-out of the culprit search (2 .. 32) */
     uint32_t search_full;          /* 0     1 = every part of a culprit search repeats its transcripts */
-    uint32_t msm_fp29;             /* 1     SRS-table MSMs accumulate their buckets on 29-bit limbs (0: the 8 x 32-bit law) */
+    uint32_t msm_fp29;             /* 1     SRS-table MSMs accumulate their buckets on 29-bit limbs: 1 = points gathered from the 64-byte twin table (8 x 32 words in the 2^261 domain),
+                                            2 = from the pre-split 128-byte records (x, y, p - y as 29-bit limbs: no conversion, no negation, twice the gather traffic); 0: the 8 x 32-bit law */
 } mina_verify_tuning;
 void mina_verify_tuning_default(mina_verify_tuning *out);
 int mina_verify_tuning_get(mina_verify_tuning *out);
 int mina_verify_configure_ex(const mina_verify_tuning *tuning);
+/* How many RETIRED tuning environment variables (MINA_VERIFY_CHUNK, MINA_VERIFY_NO_MERGE, MINA_COOP8_MAX ... -- the switches of rounds 1 - 3, now fields of
+ * mina_verify_tuning) the process environment still sets.  They are not read; the library says so once on stderr when it is loaded, naming the field that
+ * replaces each.  A strict deployment checks this for 0 at start-up. */
+int mina_verify_retired_env(void);
 int mina_verify_shutdown(void);                  /* destroy the process-wide contexts */
 mina_ctx *mina_verify_global_ctx(void);          /* the first device's context, e.g. to install a verifier index; NULL without a GPU */
 /* Multi-GPU behind the boundary: the process holds one context per GPU named by $MINA_VERIFY_DEVICES ("all" | comma list of

@@ -1,4 +1,5 @@
-// api_core.hip -- context lifetime, field constants, field self-test hooks, K4 group map entry point.
+// api_core.hip -- context lifetime, field constants, field self-test hooks, K4 group map entry point.  (The host-only infrastructure -- error text, tuning, CSPRNG,
+// worker pool -- lives in host_core.hip.)
 #include "ctx.h"
 #include "sponge.cuh"
 #include "msm.cuh"
@@ -8,110 +9,6 @@
 #include <condition_variable>
 #include <deque>
 #include <mutex>
-
-static thread_local std::string g_err = "";
-int mb_fail(int code, const std::string &msg) { g_err = msg; return code; }
-
-// ------------------------------------------------------------------------------------------------ tuning (include/mina_verify.h)
-static mina_verify_tuning tuning_defaults() {
-    mina_verify_tuning t; memset(&t, 0, sizeof t);
-    t.struct_size = (uint32_t)sizeof t;
-    t.chunk = 8192; t.single_max = 8192; t.slots = 4; t.window = 4; t.ahead = 0; t.early_min = 2048; t.early_sub = 1024; t.head_min = 6144; t.split_max = 4;
-    t.chain_cus = 128; t.cu_period = 256; t.acc_mask = 0; t.hash_piece_waves = 1024; t.up_stream = 1; t.min_shard = 64; t.pace_us = 0;
-    t.merge = 1; t.merge_batch_max = 512; t.linger_us = 500; t.max_jobs = 1;
-    t.coop16_max = 64; t.coop8_max = 8192; t.coop8_per_call = 0; t.transcript_coop8_max = 0; t.ipa_coop8_max = 1024; t.kimchi_coop8_max = 1024;
-    t.bpoly_mfma = 1; t.pubcomm_direct = 1; t.ipa_shared_points = 1; t.kimchi_shared_digest = 1; t.ipa_side_stream = 1; t.search_fan = 4; t.search_full = 0; t.msm_fp29 = 1;
-    return t;
-}
-static mina_verify_tuning g_tune = tuning_defaults();
-static std::mutex g_tune_mu;
-mina_verify_tuning mb_tune() { std::lock_guard<std::mutex> lk(g_tune_mu); return g_tune; }
-extern "C" void mina_verify_tuning_default(mina_verify_tuning *out) { if (out) *out = tuning_defaults(); }
-extern "C" int mina_verify_tuning_get(mina_verify_tuning *out) { if (!out) return fail(MINA_ERR_ARG, "null argument"); *out = mb_tune(); return MINA_OK; }
-extern "C" int mina_verify_configure_ex(const mina_verify_tuning *t) {
-    mina_verify_tuning n = tuning_defaults();
-    if (t) {
-        if (t->struct_size != sizeof n) return fail(MINA_ERR_ARG, "mina_verify_tuning.struct_size does not match this library: start from mina_verify_tuning_default");
-        n = *t;
-        if (!n.chunk || !n.single_max || !n.slots || n.slots > 16 || !n.window || !n.early_min || !n.min_shard || !n.max_jobs || n.acc_mask > 2 || !n.cu_period || n.search_fan < 2 || n.search_fan > 32)
-            return fail(MINA_ERR_ARG, "mina_verify_tuning: chunk, single_max, slots (<= 16), window, early_min, min_shard, max_jobs, cu_period must be positive; acc_mask <= 2; search_fan in 2..32");
-    }
-    std::lock_guard<std::mutex> lk(g_tune_mu);
-    g_tune = n;
-    return MINA_OK;
-}
-
-// ------------------------------------------------------------------------------------------------ CSPRNG
-bool mb_secure_random(void *buf, size_t n) {
-    uint8_t *p = (uint8_t *)buf; size_t got = 0;
-    while (got < n) {
-        const ssize_t r = getrandom(p + got, n - got, 0);
-        if (r > 0) { got += (size_t)r; continue; }
-        if (r < 0 && errno == EINTR) continue;
-        break;
-    }
-    if (got == n) return true;
-    FILE *f = fopen("/dev/urandom", "rb");                       // kernels without the system call
-    if (!f) return false;
-    const size_t k = fread(p + got, 1, n - got, f);
-    fclose(f);
-    return got + k == n;
-}
-
-// ------------------------------------------------------------------------------------------------ host worker pool
-struct MbPoolJob { std::function<void(size_t)> fn; size_t n = 0; std::atomic<size_t> next{0}, done{0}; std::mutex mu; std::condition_variable cv; };
-namespace {
-struct HostPool {
-    std::mutex mu; std::condition_variable cv; std::deque<std::shared_ptr<MbPoolJob>> jobs; std::vector<std::thread> th;
-    static void drain(MbPoolJob &j) {
-        for (;;) {
-            const size_t i = j.next.fetch_add(1);
-            if (i >= j.n) return;
-            j.fn(i);
-            if (j.done.fetch_add(1) + 1 == j.n) { std::lock_guard<std::mutex> lk(j.mu); j.cv.notify_all(); }
-        }
-    }
-    void worker() {
-        for (;;) {
-            std::shared_ptr<MbPoolJob> j;
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                for (;;) {
-                    while (!jobs.empty() && jobs.front()->next.load() >= jobs.front()->n) jobs.pop_front();
-                    if (!jobs.empty()) { j = jobs.front(); break; }
-                    cv.wait(lk);
-                }
-            }
-            drain(*j);
-        }
-    }
-    explicit HostPool(size_t nt) { for (size_t t = 0; t < nt; ++t) { th.emplace_back([this] { worker(); }); th.back().detach(); } }
-};
-HostPool *host_pool() {                                              // never destroyed: its threads outlive static destructors
-    static HostPool *p = [] {
-        size_t nt;
-        if (const char *e = getenv("MINA_HOST_THREADS")) nt = (size_t)std::max(1L, atol(e));
-        else { const size_t hw = std::thread::hardware_concurrency(); nt = std::max<size_t>(1, std::min<size_t>(hw / 2, 64)); }
-        return new HostPool(nt);
-    }();
-    return p;
-}
-}  // namespace
-size_t mb_pool_threads() { return host_pool()->th.size(); }
-std::shared_ptr<MbPoolJob> mb_pool_submit(size_t n, std::function<void(size_t)> fn) {
-    auto j = std::make_shared<MbPoolJob>(); j->fn = std::move(fn); j->n = n;
-    if (n == 0) return j;
-    HostPool *p = host_pool();
-    { std::lock_guard<std::mutex> lk(p->mu); p->jobs.push_back(j); }
-    p->cv.notify_all();
-    return j;
-}
-void mb_pool_wait(const std::shared_ptr<MbPoolJob> &j) {
-    if (!j || j->n == 0 || j->done.load() >= j->n) return;
-    HostPool::drain(*j);                                             // the caller works too
-    std::unique_lock<std::mutex> lk(j->mu);
-    j->cv.wait(lk, [&] { return j->done.load() >= j->n; });
-}
 
 // ------------------------------------------------------------------------------------------------
 // Host-side derivation of the per-field constants (no table of magic numbers: everything follows
@@ -152,7 +49,6 @@ template <int F> static FieldK make_field_consts() {
 
 // ------------------------------------------------------------------------------------------------
 // ------------------------------------------------------------------------------------------------
-extern "C" const char *mina_last_error(void) { return g_err.c_str(); }
 
 extern "C" int mina_ctx_create(int device_id, mina_ctx **out) {
     if (!out) return fail(MINA_ERR_ARG, "out is null");
@@ -177,7 +73,7 @@ extern "C" void mina_ctx_destroy(mina_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     for (int i = 0; i < MB_MAX_LANES; ++i) if (c->lanes[i].stream) (void)hipStreamSynchronize(c->lanes[i].stream);
-    for (int i = 0; i < 2; ++i) { c->srs[i].table.release(); c->srs[i].table29.release(); c->srs[i].h.release(); c->srs[i].lagrange_table.release(); c->srs[i].lagrange_digits.release(); c->pparams[i].release(); c->merkle_salts[i].release(); }
+    for (int i = 0; i < 2; ++i) { c->srs[i].table.release(); c->srs[i].table29.release(); c->srs[i].table29s.release(); c->srs[i].h.release(); c->srs[i].lagrange_table.release(); c->srs[i].lagrange_digits.release(); c->pparams[i].release(); c->merkle_salts[i].release(); }
     c->state_salts.release(); c->kimchi_index.release(); c->kimchi_tokens.release(); c->kimchi_literals.release();
     c->pickles_index.release(); c->pickles_tokens.release(); c->pickles_literals.release();
     if (c->step_host && c->step_host_free) c->step_host_free(c->step_host);

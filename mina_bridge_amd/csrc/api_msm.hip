@@ -20,8 +20,10 @@ static MsmShape variable_shape(uint32_t n) {
 template <int F>
 static int run_msm(mina_ctx *c, const MsmShape &sh, const uint32_t *d_scalars, const affine_t *d_points,
                    uint32_t *d_out_words /* 17 words per problem */, xyzz_t *d_out_xyzz /* one per problem */,
-                   const affine_t *d_points29 = nullptr /* the table's 2^261-domain twin (SrsState::table29): the accumulate kernels then run on 29-bit limbs (ec29.cuh) */) {
+                   const affine_t *d_points29 = nullptr /* the table's 2^261-domain twin (SrsState::table29): the accumulate kernels then run on 29-bit limbs (ec29.cuh) */,
+                   const void *d_points29s = nullptr /* ... or its pre-split form (SrsState::table29s, tab29_t records; mina_verify_tuning.msm_fp29 = 2) */) {
     if (d_points29 && !mb_tune().msm_fp29) d_points29 = nullptr;      // cross-check switch: the 8 x 32 law everywhere
+    const bool split = d_points29 && d_points29s && mb_tune().msm_fp29 >= 2;
     MsmWorkspace &w = c->L->ws;
     const FieldK &fk = c->fk[F];
     if (sh.nprob == 0 || sh.nsets % sh.nprob) return fail(MINA_ERR_ARG, "bad problem count");
@@ -103,8 +105,10 @@ static int run_msm(mina_ctx *c, const MsmShape &sh, const uint32_t *d_scalars, c
     if (bucket_lanes) {
         { ProfScope ps_(c, PS_ACCUMULATE);
           if (d_points29) {
-              msm_accumulate_bucket29_kernel<F><<<cdiv(nb_total / 2, 256), 256, 0, st>>>(nb_total, ss.SB, w.start.as<uint32_t>(), w.order.as<uint32_t>(), w.sorted.as<uint32_t>(), d_points29, fk.one, fk.m32,
-                                                                                     w.buckets.as<xyzz_t>(), w.info.as<uint32_t>(), w.redo.as<uint32_t>());
+              if (split) msm_accumulate_bucket29_kernel<F, 2><<<cdiv(nb_total / 2, 256), 256, 0, st>>>(nb_total, ss.SB, w.start.as<uint32_t>(), w.order.as<uint32_t>(), w.sorted.as<uint32_t>(), d_points29s, fk.one, fk.m32,
+                                                                                                 w.buckets.as<xyzz_t>(), w.info.as<uint32_t>(), w.redo.as<uint32_t>());
+              else msm_accumulate_bucket29_kernel<F, 1><<<cdiv(nb_total / 2, 256), 256, 0, st>>>(nb_total, ss.SB, w.start.as<uint32_t>(), w.order.as<uint32_t>(), w.sorted.as<uint32_t>(), d_points29, fk.one, fk.m32,
+                                                                                           w.buckets.as<xyzz_t>(), w.info.as<uint32_t>(), w.redo.as<uint32_t>());
               msm_bucket_redo_kernel<F><<<16, 64, 0, st>>>(w.start.as<uint32_t>(), w.info.as<uint32_t>(), w.redo.as<uint32_t>(), w.sorted.as<uint32_t>(), d_points, fk.one, w.buckets.as<xyzz_t>());
           }
           else msm_accumulate_bucket_kernel<F><<<cdiv(nb_total / 2, 256), 256, 0, st>>>(nb_total, ss.SB, w.start.as<uint32_t>(), w.order.as<uint32_t>(), w.sorted.as<uint32_t>(), d_points, fk.one, w.buckets.as<xyzz_t>()); }
@@ -113,8 +117,10 @@ static int run_msm(mina_ctx *c, const MsmShape &sh, const uint32_t *d_scalars, c
     } else {
         { ProfScope ps_(c, PS_ACCUMULATE);
           if (d_points29) {
-              msm_accumulate29_kernel<F><<<cdiv(max_tasks, 256), 256, 0, st>>>(nb_total, w.start.as<uint32_t>(), w.task_start.as<uint32_t>(), w.rem_bucket.as<uint32_t>(), w.info.as<uint32_t>(),
-                                                                       w.sorted.as<uint32_t>(), d_points29, fk.one, fk.m32, w.partial.as<xyzz_t>(), w.info.as<uint32_t>(), w.redo.as<uint32_t>());
+              if (split) msm_accumulate29_kernel<F, 2><<<cdiv(max_tasks, 256), 256, 0, st>>>(nb_total, w.start.as<uint32_t>(), w.task_start.as<uint32_t>(), w.rem_bucket.as<uint32_t>(), w.info.as<uint32_t>(),
+                                                                                   w.sorted.as<uint32_t>(), d_points29s, fk.one, fk.m32, w.partial.as<xyzz_t>(), w.info.as<uint32_t>(), w.redo.as<uint32_t>());
+              else msm_accumulate29_kernel<F, 1><<<cdiv(max_tasks, 256), 256, 0, st>>>(nb_total, w.start.as<uint32_t>(), w.task_start.as<uint32_t>(), w.rem_bucket.as<uint32_t>(), w.info.as<uint32_t>(),
+                                                                             w.sorted.as<uint32_t>(), d_points29, fk.one, fk.m32, w.partial.as<xyzz_t>(), w.info.as<uint32_t>(), w.redo.as<uint32_t>());
               // the tasks handed back (none on SRS points): the 8 x 32 kernel over the redo queue -- a full-size launch whose lanes beyond info[3] leave at once
               msm_accumulate_kernel<F><<<cdiv(max_tasks, 256), 256, 0, st>>>(nb_total, w.start.as<uint32_t>(), w.task_start.as<uint32_t>(), w.rem_bucket.as<uint32_t>(), w.info.as<uint32_t>(),
                                                                      w.sorted.as<uint32_t>(), d_points, fk.one, w.partial.as<xyzz_t>(), w.redo.as<uint32_t>());
@@ -166,7 +172,7 @@ int mb_msm_fixed(mina_ctx *c, int curve, uint32_t n, const uint32_t *d_scalars, 
     if (n == 0 || (uint64_t)first + n > s.depth) return fail(MINA_ERR_ARG, "base range must lie inside the SRS");
     MsmShape sh = fixed_shape(s, first, n);
     int rc = MINA_OK;
-    DISPATCH_FIELD(base_field_of(curve), { rc = run_msm<F_>(c, sh, d_scalars, s.table.as<affine_t>(), d_out_words, (xyzz_t *)d_out_xyzz, s.table29.as<affine_t>()); });
+    DISPATCH_FIELD(base_field_of(curve), { rc = run_msm<F_>(c, sh, d_scalars, s.table.as<affine_t>(), d_out_words, (xyzz_t *)d_out_xyzz, s.table29.as<affine_t>(), s.table29s.p); });
     return rc;
 }
 
@@ -178,7 +184,8 @@ int mb_msm_table(mina_ctx *c, int curve, const void *d_table, uint32_t stride, u
     int rc = MINA_OK;
     const SrsState &s = c->srs[curve];
     const affine_t *t29 = (d_table == s.table.p && s.table29.p) ? (const affine_t *)s.table29.p : nullptr;      // the SRS table has a 2^261-domain twin; other tables do not
-    DISPATCH_FIELD(base_field_of(curve), { rc = run_msm<F_>(c, sh, d_scalars, (const affine_t *)d_table, d_out_words, (xyzz_t *)d_out_xyzz, t29); });
+    const void *t29s = t29 ? s.table29s.p : nullptr;
+    DISPATCH_FIELD(base_field_of(curve), { rc = run_msm<F_>(c, sh, d_scalars, (const affine_t *)d_table, d_out_words, (xyzz_t *)d_out_xyzz, t29, t29s); });
     return rc;
 }
 

@@ -15,6 +15,28 @@ template <int F> static int build_tables(mina_ctx *c, SrsState &s) {
     msm_table29_kernel<F><<<cdiv(npts, 256), 256, 0, c->L->stream>>>(npts, s.table.as<affine_t>(), fk.m32, s.table29.as<affine_t>());
     HIPC(hipGetLastError());
     HIPC(hipStreamSynchronize(c->L->stream));
+    s.table29s.release();                                          // the pre-split form is built on request (mina_srs_split_table)
+    return MINA_OK;
+}
+// The pre-split form of the window table (msm.cuh tab29_t: x, y, p - y as 29-bit limbs, 128 B per point; mina_verify_tuning.msm_fp29 = 2 reads it).  Measured in
+// round 5 (profiles/r05_k1.md): 1714 instead of 1745 instructions per mixed add, + 0.5 % checks/s for twice the gather traffic and 128 MiB per curve -- NOT the
+// default; built only when a caller asks for it.
+extern "C" int mina_srs_split_table(mina_ctx *c, int curve, int on) {
+    if (!c) return fail(MINA_ERR_ARG, "null ctx");
+    if (curve != 0 && curve != 1) return fail(MINA_ERR_ARG, "bad curve");
+    SrsState &s = c->srs[curve];
+    if (s.depth == 0) return fail(MINA_ERR_STATE, "SRS not loaded for this curve");
+    HIPC(hipSetDevice(c->device));
+    for (int i = 0; i < c->nlanes; ++i) HIPC(hipStreamSynchronize(c->lanes[i].stream));      // an MSM in flight may be reading the table
+    if (!on) { s.table29s.release(); return MINA_OK; }
+    if (s.table29s.p) return MINA_OK;
+    c->use_lane0();
+    const size_t npts = (size_t)s.W * s.depth;
+    int rc;
+    if ((rc = s.table29s.ensure(npts * sizeof(tab29_t)))) return rc;
+    DISPATCH_FIELD(base_field_of(curve), { msm_table29s_kernel<F_><<<cdiv(npts, 256), 256, 0, c->L->stream>>>(npts, s.table.as<affine_t>(), c->fk[F_].m32, s.table29s.as<tab29_t>()); });
+    HIPC(hipGetLastError());
+    HIPC(hipStreamSynchronize(c->L->stream));
     return MINA_OK;
 }
 

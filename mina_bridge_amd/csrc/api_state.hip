@@ -111,48 +111,6 @@ __global__ void state_job_verdict_kernel(uint32_t batch, const uint32_t *__restr
 
 }  // namespace mb
 
-// ------------------------------------------------------------------------------------------------ host: pack one state
-static void info_from_state(const mw::ProtocolState &s, mina_protocol_state_info *info, uint32_t nf) {
-    memset(info, 0, sizeof *info);
-    memcpy(info->previous_state_hash, s.previous_state_hash.b, 32);
-    memcpy(info->genesis_state_hash, s.genesis_state_hash.b, 32);
-    memcpy(info->snarked_ledger_hash, s.snarked_ledger_hash().b, 32);
-    info->n_body_fields = nf;
-    info->k = s.k; info->slots_per_epoch = s.c_slots_per_epoch; info->slots_per_sub_window = s.slots_per_sub_window;
-    info->sub_windows_per_window = (uint32_t)s.sub_window_densities.size(); info->grace_period_slots = s.grace_period_slots; info->delta = s.delta;
-    mina_consensus_state &c = info->consensus;
-    c.blockchain_length = s.blockchain_length; c.epoch_count = s.epoch_count; c.curr_global_slot = s.slot_number; c.min_window_density = s.min_window_density;
-    for (size_t i = 0; i < s.sub_window_densities.size() && i < MINA_MAX_SUB_WINDOWS; ++i) c.sub_window_densities[i] = s.sub_window_densities[i];
-    memcpy(c.staking_lock_checkpoint, s.staking.lock_checkpoint.b, 32);
-    memcpy(c.next_lock_checkpoint, s.next.lock_checkpoint.b, 32);
-    memcpy(c.last_vrf_output_hash, s.last_vrf_output.data(), 32);          // the truncated VRF output string itself (compared lexicographically)
-}
-
-int mb_pack_protocol_state(const mw::ProtocolState &s, uint8_t *record, uint32_t *n_body_fields, mina_protocol_state_info *info) {
-    mw::Inputs in;
-    mw::protocol_state_body_inputs(s, in);
-    const size_t nf = in.count();
-    if (in.overflow || nf > MINA_PSTATE_SLOTS - 1) return fail(MINA_ERR_FORMAT, "protocol state body flattens to more field elements than a record holds");
-    memcpy(record, s.previous_state_hash.b, 32);
-    in.write(record + 32);
-    memset(record + 32 * (1 + nf), 0, (size_t)(MINA_PSTATE_SLOTS - 1 - nf) * 32);
-    *n_body_fields = (uint32_t)nf;
-    if (info) info_from_state(s, info, (uint32_t)nf);
-    return MINA_OK;
-}
-
-extern "C" int mina_protocol_state_pack(const uint8_t *bytes, size_t len, int encoding, uint8_t *record, uint32_t *n_body_fields,
-                                        mina_protocol_state_info *info, size_t *consumed) {
-    if (!bytes || !record || !n_body_fields) return fail(MINA_ERR_ARG, "null argument");
-    mw::ProtocolState s; bool ok; size_t used;
-    if (encoding == MINA_ENC_BINPROT) { mw::Binprot c(bytes, len); ok = mw::read_protocol_state(c, s); used = c.pos; }
-    else if (encoding == MINA_ENC_BINCODE) { mw::Bincode c(bytes, len); ok = mw::read_protocol_state(c, s); used = c.pos; }
-    else return fail(MINA_ERR_ARG, "encoding must be MINA_ENC_BINPROT or MINA_ENC_BINCODE");
-    if (!ok) return fail(MINA_ERR_FORMAT, "malformed protocol state");
-    if (consumed) *consumed = used; else if (used != len) return fail(MINA_ERR_FORMAT, "trailing bytes after the protocol state");
-    return mb_pack_protocol_state(s, record, n_body_fields, info);
-}
-
 // ------------------------------------------------------------------------------------------------ salts
 static int ensure_state_salts(mina_ctx *c) {
     if (c->have_state_salts) return MINA_OK;

@@ -208,6 +208,15 @@ CallMerger g_state_calls, g_account_calls;
 
 // verdict words of a job, device staging -> the slot's page-locked buffer (see Slot::up)
 __global__ void words_out_kernel(uint32_t n, const uint32_t *__restrict__ src, uint32_t *__restrict__ dst) { const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) dst[i] = src[i]; }
+// (the one kernel launch of this file, behind a function: the ThreadSanitizer tier builds the rest of the file -- pure host logic -- with g++ against a stand-in
+// runtime, tests/fuzz/hip_stub + tests/fuzz/tsan_boundary.cpp, where "device" memory is host memory and the copy is a memcpy)
+static inline void launch_words_out(hipStream_t st, uint32_t words, const uint32_t *src, uint32_t *dst) {
+#if defined(MB_HIP_STUB)
+    (void)st; memcpy(dst, src, (size_t)words * 4);
+#else
+    words_out_kernel<<<(words + 255) / 256, 256, 0, st>>>(words, src, dst);
+#endif
+}
 
 // ------------------------------------------------------------------------------------------------ Proof of State
 // bytes -> bools, pipelined (core/src/aligned.rs:31-58 builds the bytes; core/src/proof/state_proof.rs:10-41 their layout):
@@ -679,7 +688,11 @@ int run_device_shape(Device &D, const CallIn &in, const std::vector<size_t> &idx
         hipStream_t up = own_up ? S.up : L.stream;
         if (g_timing && !ch.queued) HIPC(hipEventRecord(S.tev[0], up));
         ch.queued = true;
-        HIPC(hipMemcpyAsync(dbase + lay.off[S_EXP], hbase + lay.off[S_EXP], lay.total - lay.off[S_EXP], hipMemcpyHostToDevice, up));    // `precheck` lies in there: sent again by finish()
+        // everything behind the records and their field counts, EXCEPT `precheck`: the pool is still writing those bytes (parse_states_half) -- finish() sends them.
+        // (Until round 5 the one copy ran over them too and finish() re-sent them: harmless, since only the FINISH phase reads `precheck`, but a read of memory
+        // another thread is writing -- the one report of the ThreadSanitizer tier, tests/fuzz/tsan_boundary.cpp.)
+        HIPC(hipMemcpyAsync(dbase + lay.off[S_EXP], hbase + lay.off[S_EXP], lay.off[S_PRE] - lay.off[S_EXP], hipMemcpyHostToDevice, up));
+        HIPC(hipMemcpyAsync(dbase + lay.off[S_APRE], hbase + lay.off[S_APRE], lay.total - lay.off[S_APRE], hipMemcpyHostToDevice, up));
         if (own_up) { HIPC(hipEventRecord(S.ev_up, up)); HIPC(hipStreamWaitEvent(L.stream, S.ev_up, 0)); }
         JobStructs js; make_jobs(sh, lay, dbase, ch.n, true, true, true, js);
         uint32_t *dv = (uint32_t *)(dbase + lay.out_off()), *df = dv + ch.n, *ds = df + 4;
@@ -747,7 +760,7 @@ int run_device_shape(Device &D, const CallIn &in, const std::vector<size_t> &idx
         c->use_lane0();
         if (rc) return rc;
         if (g_timing) HIPC(hipEventRecord(S.tev[2], L.stream));
-        if (own_up) { const uint32_t words = (uint32_t)(Layout::out_bytes(ch.n) / 4); words_out_kernel<<<(words + 255) / 256, 256, 0, L.stream>>>(words, dv, (uint32_t *)S.out.p); HIPC(hipGetLastError()); }
+        if (own_up) { const uint32_t words = (uint32_t)(Layout::out_bytes(ch.n) / 4); launch_words_out(L.stream, words, dv, (uint32_t *)S.out.p); HIPC(hipGetLastError()); }
         else HIPC(hipMemcpyAsync(S.out.p, dv, Layout::out_bytes(ch.n), hipMemcpyDeviceToHost, L.stream));
         HIPC(hipEventRecord(S.ev, L.stream));
         ch.issued = true;

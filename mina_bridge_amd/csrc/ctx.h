@@ -61,6 +61,7 @@ struct SrsState {
     uint32_t c = 16, W = 16;           // fixed-base window shape
     DevBuf table;                      // W * depth affine_t; window 0 = g itself
     DevBuf table29;                    // the same points with coordinates x * 2^261 mod p (8 x 32-bit words): what the fp29 accumulate kernels gather (ec29.cuh)
+    DevBuf table29s;                   // ... pre-split: x, y, p - y as 9 x 29-bit limbs + an infinity flag, 128 B per point (msm.cuh tab29_t; mina_verify_tuning.msm_fp29 = 2)
     DevBuf h;                          // 1 affine_t
     int lagrange_log2 = -1;            // cached Lagrange basis (canonical affine bytes, host side)
     std::vector<uint8_t> lagrange_host;

@@ -4,13 +4,17 @@
 // conditional subtraction exists.  Measured on MI355X (tools/probes/batch_affine_probe.hip, 8.4 M gathered adds per launch, bit-identical buckets):
 // 16.2 - 16.8 G adds/s against 12.4 - 13.2 for the 8 x 32 law (+ 27 - 31 %); profiles/r04_group_law_probe.md.
 //
-// Value discipline (p = 2^254 + c; 2^256 ~ 4 p; a normalised 9-limb value holds up to 2^261):
-//   * a product / square of operands below 16 p is below 16 * 16 p^2 / 2^261 + p = 3 p; a two-term dot product of the magnitudes below: < 2 p
-//   * a - b is a + K p - b, K = 4 or 8, with K p in a redundant limb form whose every limb exceeds any normalised limb of b: the limb-wise difference
-//     never goes negative and ONE carry pass normalises it; needs b < K p
-//   * accumulator coordinates stay below 6 p (x), 2 p (y), 3 p (zz, zzz); table coordinates are canonical (< p), stored as x * 2^261 mod p
+// Value discipline (p = 2^254 + c; 2^256 ~ 4 p; a normalised 9-limb value holds up to 2^261) -- PROVEN, not asserted: tools/fe29_bounds.py runs this law on
+// intervals (a maximum per limb and per value), tools/gen_fe29.py refuses to emit fp29.cuh when a rule fails, and the constants below (`EC29::*`, generated into
+// fp29.cuh) are the ones the proof ran with:
+//   * six of the nine products run LAZY (quotient digits unmasked: result < a b / 2^261 + 8.0001 p instead of + p; nine masks less each): pd, r, pp, ppp, zz3, zzz3 --
+//     every one whose result only feeds products or a "K p - b"; q, x3 and the dot product y3 stay strict (with a seventh lazy product the invariants have no fixed point)
+//   * a - b is a + K p - b with K p in a redundant limb form whose every limb exceeds any normalised limb of b: limb-wise, NO carry pass -- so the top limb must
+//     hold by itself: K at least one more than b's bound in units of p (the round-4 bug: ONE p under a canonical y)
+//   * accumulator coordinates stay below EC29::INV_X / INV_Y / INV_ZZ / INV_ZZZ times p (26, 6, 10, 9: the least fixed point of the lazy law); table coordinates
+//     are canonical (< p), in the 2^261 domain
 // The exceptional cases of the group law (the two points equal or opposite: P = 0 mod p) are found EXACTLY: a multiple k p = k 2^254 + k c of p below
-// 16 p has limbs 5..7 and the low 22 bits of limb 8 zero (k c < 2^129) -- four instructions per add -- and only then limbs 0..4 are compared with k c;
+// EC29::PD_MAX p has limbs 5..7 and the low 22 bits of limb 8 zero (k c < 2^131) -- four instructions per add -- and only then limbs 0..4 are compared with k c;
 // the unit of work (bucket / task) that meets one is handed to the 8 x 32 law (never on SRS points; it keeps the kernels exact on any input).
 #pragma once
 #include "ec.cuh"
@@ -35,11 +39,11 @@ template <int F, uint32_t MULT> MB_HD fe29_t fe29_sub_kp(const fe29_t &a, const 
     for (int i = 0; i < L29; ++i) { const uint32_t t = a.v[i] + k[i] - b.v[i] + c; if (i < L29 - 1) { r.v[i] = t & M29; c = t >> 29; } else r.v[i] = t; }
     return r;
 }
-// 4 p - a - 2 b limb by limb, every limb non-negative (NOT normalised: limbs up to 2^31 + 2^29): 4 p in the redundant form K_0 = n_0 + 2^31, K_i = n_i + 2^31 - 4
-// (0 < i < 8), K_8 = n_8 - 4 -- the same integer.  Needs a, b normalised with a_8 + 2 b_8 <= n_8 - 4 = 4 * 2^22 - 4 (a < 1.2 p, b < 1.1 p).  The operand h of
-// fe29_sqr_hi_asm: r^2 / 2^261 + (4 p - ppp - 2 q) in one reduction, where two normalised additions and a fe29_sub_kp took 81 instructions (27 + 9 now).
-template <int F> MB_HD fe29_t fe29_4p_minus_a_minus_2b(const fe29_t &a, const fe29_t &b) {
-    typedef KP29<F, 4> K;
+// MULT p - a - 2 b limb by limb, every limb non-negative (NOT normalised: limbs up to 2^31 + 2^29): MULT p in the redundant form K_0 = n_0 + 2^31, K_i = n_i + 2^31 - 4
+// (0 < i < 8), K_8 = n_8 - 4 -- the same integer.  Needs a, b normalised with a_8 + 2 b_8 <= n_8 - 4 (fe29_bounds.py kp_minus_a_minus_2b).  The operand h of
+// fe29_sqr_hi_asm: r^2 / 2^261 + (MULT p - ppp - 2 q) in one reduction, where two normalised additions and a fe29_sub_kp took 81 instructions (27 + 9 now).
+template <int F, uint32_t MULT> MB_HD fe29_t fe29_kp_minus_a_minus_2b(const fe29_t &a, const fe29_t &b) {
+    typedef KP29<F, MULT> K;
     const uint32_t k[9] = {(uint32_t)K::n0 + (1u << 31), (uint32_t)K::n1 + (1u << 31) - 4, (uint32_t)K::n2 + (1u << 31) - 4, (uint32_t)K::n3 + (1u << 31) - 4, (uint32_t)K::n4 + (1u << 31) - 4,
                            (uint32_t)K::n5 + (1u << 31) - 4, (1u << 31) - 4, (1u << 31) - 4, (uint32_t)K::n8 - 4};
     fe29_t r;
@@ -70,7 +74,7 @@ template <int F, uint32_t MULT> MB_HD fe29_t fe29_add_kp_minus(const fe29_t &a, 
 }
 MB_HD fe29_t fe29_zero() { fe29_t r; for (int i = 0; i < L29; ++i) r.v[i] = 0; return r; }
 
-// a (normalised, below 16 p) == 0 mod p?  exact
+// a (normalised, below EC29::PD_MAX p) == 0 mod p?  exact
 template <int F> MB_HD bool fe29_is_multiple_of_p(const fe29_t &a) {
     if ((a.v[5] | a.v[6] | a.v[7] | (a.v[8] & 0x3fffffu)) != 0u) return false;          // the cheap necessary test, inlined again at the call site
     const uint64_t k = a.v[8] >> 22;                                                      // k p = k 2^254 + k c
@@ -82,27 +86,35 @@ template <int F> MB_HD bool fe29_is_multiple_of_p(const fe29_t &a) {
 // x * 2^261 (lazy, below 16 p) -> x * 2^256, canonical words; and back
 template <int F> __device__ __forceinline__ fe_t fe29_leave(const fe29_t &a, const fe29_t &leave /* the integer 2^256 mod p */) { return fe_cond_sub_p<F>(fe29_to_words(fe29_mul_asm<F>(a, leave))); }
 
-// acc += (qx, qy): affine, not infinity, coordinates canonical in the 2^261 domain  (madd-2008-s; ec.cuh xyzz_add_affine on the other limbs).
+// acc += (qx, qy): affine, not infinity, qx canonical in the 2^261 domain; qy = the y coordinate of the point ADDED, either normalised (< p: the pre-split table holds
+// y and p - y) or the raw limb form 2 p - y of a negated point (the 8-word twin table: fe29_kp_minus)  (madd-2008-s; ec.cuh xyzz_add_affine on the other limbs).
+// `first_y()`: that coordinate NORMALISED, called only for the first point of a bucket (the accumulator becomes the point).
+// `operands_done()`: called once qx and qy have been consumed (after the first two products, 290 of the ~1750 instructions of an add): the caller issues its NEXT
+// gather there, INTO the registers of qx / qy -- the pipelined loop then needs no register copies (a `p = nxt` hand-over cost the pre-split table's kernel 111 v_mov).
 // Returns FALSE -- acc untouched -- in the exceptional case (the points are equal or opposite: P = 0 mod p): the caller hands its unit of work to the
 // 8 x 32 law (msm.cuh: the redo queue).  No call, no second code path inside the hot loop: an out-of-line fallback cost the kernel 53 VGPRs and 288 B of
 // scratch per lane (the call ABI) and made it SLOWER than the 8 x 32 kernel (C2: 8.6 k checks/s against 11.4 k).
-// `neg`: the point added is (qx, -py) -- the signed-digit recoding's negative digits.  -py = p - py enters its product in the raw limb form (9 subtractions and a
-// select per limb; normalised only where it becomes the accumulator itself).
-template <int F> __device__ __forceinline__ bool xyzz29_add_affine(xyzz29_t &acc, bool &inf, const fe29_t &qx, const fe29_t &py, bool neg, const fe_t &m32) {
-    if (inf) { acc.x = qx; acc.y = neg ? fe29_sub_kp<F, 1>(fe29_zero(), py) : py; acc.zz = fe29_from_words(m32); acc.zzz = acc.zz; inf = false; return true; }   // 1 in the 2^261 domain = the integer 2^261 mod p
-    fe29_t qy = fe29_kp_minus<F, 2>(py);              // 2 p - py = -py, limbs below 2^30 + 2^29.  TWO p: the raw form has no carries, so its top limb n_8 - 2 - py_8 must not go
-                                                      // negative by itself, and a canonical py reaches 2^22 = the top limb of ONE p (py >= 2^254 - 2^233: one table point in 2^21)
-#pragma unroll
-    for (int i = 0; i < L29; ++i) qy.v[i] = neg ? qy.v[i] : py.v[i];
-    const fe29_t pd = fe29_mul_hi_asm<F>(qx, acc.zz, fe29_kp_minus<F, 8>(acc.x)), r = fe29_mul_hi_asm<F>(qy, acc.zzz, fe29_kp_minus<F, 8>(acc.y));   // u2 + 8 p - x1, s2 + 8 p - y1: < 11 p
+template <int F, class FirstY, class Done> __device__ __forceinline__ bool xyzz29_add_affine(xyzz29_t &acc, bool &inf, const fe29_t &qx, const fe29_t &qy, FirstY first_y, Done operands_done, const fe_t &m32) {
+    if (inf) { acc.x = qx; acc.y = first_y(); acc.zz = fe29_from_words(m32); acc.zzz = acc.zz; inf = false; operands_done(); return true; }   // 1 in the 2^261 domain = the integer 2^261 mod p
+    const fe29_t pd = fe29_mul_hi_lz<F>(qx, acc.zz, fe29_kp_minus<F, EC29::SUB_X1_MULT>(acc.x)), r = fe29_mul_hi_lz<F>(qy, acc.zzz, fe29_kp_minus<F, EC29::SUB_Y1_MULT>(acc.y));   // u2 + K p - x1 < 35.1 p, s2 + K p - y1 < 15.2 p
+    operands_done();                                                                                                                           // qx, qy are dead from here
     if (__builtin_expect((pd.v[5] | pd.v[6] | pd.v[7] | (pd.v[8] & 0x3fffffu)) == 0u, 0))
         if (fe29_is_multiple_of_p<F>(pd)) return false;
-    const fe29_t pp = fe29_sqr_asm<F>(pd), ppp = fe29_mul_asm<F>(pd, pp), q = fe29_mul_asm<F>(acc.x, pp);           // < 2 p, < 1.2 p, < 1.1 p
-    const fe29_t x3 = fe29_sqr_hi_asm<F>(r, fe29_4p_minus_a_minus_2b<F>(ppp, q));                                    // r^2 + 4 p - (ppp + 2 q) < 6 p, inside the square's reduction
-    const fe29_t y3 = fe29_dot2_asm<F>(r, fe29_add_kp_minus<F, 8>(q, x3), fe29_kp_minus<F, 8>(acc.y), ppp);          // r (q - x3) - y1 ppp, one reduction, the differences not normalised: < 2 p
-    acc.zz = fe29_mul_asm<F>(acc.zz, pp); acc.zzz = fe29_mul_asm<F>(acc.zzz, ppp);
+    const fe29_t pp = fe29_sqr_lz<F>(pd), ppp = fe29_mul_lz<F>(pd, pp), q = fe29_mul_asm<F>(acc.x, pp);                                       // < 17.7 p, < 12.9 p, < 4.6 p (strict: it enters two raw sums)
+    const fe29_t x3 = fe29_sqr_hi_asm<F>(r, fe29_kp_minus_a_minus_2b<F, EC29::X3_SUB_MULT>(ppp, q));                                           // r^2 + K p - (ppp + 2 q) < 25.8 p, inside the square's reduction
+    const fe29_t y3 = fe29_dot2_asm<F>(r, fe29_add_kp_minus<F, EC29::SUB_X3_MULT>(q, x3), fe29_kp_minus<F, EC29::SUB_Y1_MULT>(acc.y), ppp);   // r (q - x3) - y1 ppp, one reduction, the differences not normalised: < 5.5 p
+    acc.zz = fe29_mul_lz<F>(acc.zz, pp); acc.zzz = fe29_mul_lz<F>(acc.zzz, ppp);                                                               // < 9.4 p, < 9 p
     acc.x = x3; acc.y = y3;
     return true;
+}
+// the 8-word twin table's entry (qx, py): `neg` adds (qx, -py); -py = 2 p - py enters its product in the raw limb form (9 subtractions and a select per limb;
+// normalised -- p - py with the carry pass -- only where it becomes the accumulator itself).  TWO p: the raw form has no carries, so its top limb n_8 - 2 - py_8 must
+// not go negative by itself, and a canonical py reaches 2^22 = the top limb of ONE p (py >= 2^254 - 2^233: one table point in 2^21)
+template <int F> __device__ __forceinline__ bool xyzz29_add_affine(xyzz29_t &acc, bool &inf, const fe29_t &qx, const fe29_t &py, bool neg, const fe_t &m32) {
+    fe29_t qy = fe29_kp_minus<F, EC29::NEG_Y_MULT>(py);
+#pragma unroll
+    for (int i = 0; i < L29; ++i) qy.v[i] = neg ? qy.v[i] : py.v[i];
+    return xyzz29_add_affine<F>(acc, inf, qx, qy, [&]() { return neg ? fe29_sub_kp<F, 1>(fe29_zero(), py) : py; }, []() {}, m32);
 }
 // the bucket value in the 8 x 32 form the rest of the MSM reads (canonical Montgomery-2^256 XYZZ; infinity = zz 0)
 template <int F> __device__ __forceinline__ xyzz_t xyzz29_leave(const xyzz29_t &acc, bool inf, const fe_t &one) {

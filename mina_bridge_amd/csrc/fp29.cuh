@@ -80,17 +80,39 @@ MB_HD fe29_t fe29_add3(const fe29_t &a, const fe29_t &b, const fe29_t &c) {
     return r;
 }
 
+// ---- PROVEN CONSTANTS (tools/gen_fe29.py <- tools/fe29_bounds.py): do not edit by hand
+// proven by tools/fe29_bounds.py (interval model of every routine and of the callers' value discipline; gen_fe29.py refuses to write this file otherwise):
+//   group law: worst column 0.684 x 2^64; Poseidon lane forms: worst column 0.538 x 2^64
+struct EC29 {      // xyzz29_add_affine: accumulator invariants (units of p) and the multiple of p in every limb-wise "K p - b" (no limb may go negative)
+    static constexpr uint32_t INV_X = 26;
+    static constexpr uint32_t INV_Y = 6;
+    static constexpr uint32_t INV_ZZ = 10;
+    static constexpr uint32_t INV_ZZZ = 9;
+    static constexpr uint32_t NEG_Y_MULT = 2;
+    static constexpr uint32_t SUB_X1_MULT = 27;
+    static constexpr uint32_t SUB_Y1_MULT = 7;
+    static constexpr uint32_t X3_SUB_MULT = 23;
+    static constexpr uint32_t SUB_X3_MULT = 27;
+    static constexpr uint32_t PD_MAX = 36;
+};
+struct SPONGE29 {   // the Poseidon lane forms' state bounds between rounds, in thousandths of p (fixed points of a lazy round)
+    static constexpr uint32_t LANES3_STATE_MILLI_P = 8300;
+    static constexpr uint32_t LANES8_STATE_MILLI_P = 16500;
+    static constexpr uint32_t LANES16_STATE_MILLI_P = 24400;
+};
+// ---- END PROVEN CONSTANTS
+
 #if defined(__HIP_DEVICE_COMPILE__)
 // Montgomery products, R = 2^261, operands normalised (limbs < 2^29), results normalised; every multiply-accumulate of a column pinned
 // in one asm statement (left to itself the compiler spreads a column over several accumulators and re-adds them).
 // ---- GENERATED by tools/gen_fe29.py: do not edit by hand
 template <int F> __device__ __forceinline__ fe29_t fe29_mul_asm(const fe29_t &a, const fe29_t &b) {
-    uint64_t col = 0, cc; fe29_t r;
+    uint64_t col, cc; fe29_t r;
     uint32_t m0, m1, m2, m3, m4, m5, m6, m7, m8;
     const uint32_t p1 = P29<F>::L1, p2 = P29<F>::L2, p3 = P29<F>::L3, p4 = P29<F>::L4, p8 = P29<F>::L8;
     // column 0: 1 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[0]));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 0"
+        : "=&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[0]));
     m0 = (0u - (uint32_t)col) & M29;
     asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
         : "+&v"(col), "=&s"(cc) : "v"(m0));
@@ -192,12 +214,12 @@ template <int F> __device__ __forceinline__ fe29_t fe29_mul_asm(const fe29_t &a,
 }
 template <int F> __device__ __forceinline__ fe29_t fe29_sqr_asm(const fe29_t &a) {
     const uint32_t d0 = a.v[0] << 1, d1 = a.v[1] << 1, d2 = a.v[2] << 1, d3 = a.v[3] << 1, d4 = a.v[4] << 1, d5 = a.v[5] << 1, d6 = a.v[6] << 1, d7 = a.v[7] << 1;   // limbs < 2^29: the doubled ones fit 32 bits
-    uint64_t col = 0, cc; fe29_t r;
+    uint64_t col, cc; fe29_t r;
     uint32_t m0, m1, m2, m3, m4, m5, m6, m7, m8;
     const uint32_t p1 = P29<F>::L1, p2 = P29<F>::L2, p3 = P29<F>::L3, p4 = P29<F>::L4, p8 = P29<F>::L8;
     // column 0: 1 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(a.v[0]));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 0"
+        : "=&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(a.v[0]));
     m0 = (0u - (uint32_t)col) & M29;
     asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
         : "+&v"(col), "=&s"(cc) : "v"(m0));
@@ -294,12 +316,12 @@ template <int F> __device__ __forceinline__ fe29_t fe29_sqr_asm(const fe29_t &a)
     return r;
 }
 template <int F> __device__ __forceinline__ fe29_t fe29_dot2_asm(const fe29_t &a0, const fe29_t &b0, const fe29_t &a1, const fe29_t &b1) {
-    uint64_t col = 0, cc; fe29_t r;
+    uint64_t col, cc; fe29_t r;
     uint32_t m0, m1, m2, m3, m4, m5, m6, m7, m8;
     const uint32_t p1 = P29<F>::L1, p2 = P29<F>::L2, p3 = P29<F>::L3, p4 = P29<F>::L4, p8 = P29<F>::L8;
     // column 0: 2 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[0]));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0"
+        : "=&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[0]));
     m0 = (0u - (uint32_t)col) & M29;
     asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
         : "+&v"(col), "=&s"(cc) : "v"(m0));
@@ -412,12 +434,12 @@ template <int F> __device__ __forceinline__ fe29_t fe29_dot2_asm(const fe29_t &a
     return r;
 }
 template <int F> __device__ __forceinline__ fe29_t fe29_dot3_asm(const fe29_t &a0, const fe29_t &b0, const fe29_t &a1, const fe29_t &b1, const fe29_t &a2, const fe29_t &b2) {
-    uint64_t col = 0, cc; fe29_t r;
+    uint64_t col, cc; fe29_t r;
     uint32_t m0, m1, m2, m3, m4, m5, m6, m7, m8;
     const uint32_t p1 = P29<F>::L1, p2 = P29<F>::L2, p3 = P29<F>::L3, p4 = P29<F>::L4, p8 = P29<F>::L8;
     // column 0: 3 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[0]), "v"(a2.v[0]), "v"(b2.v[0]));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0"
+        : "=&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[0]), "v"(a2.v[0]), "v"(b2.v[0]));
     m0 = (0u - (uint32_t)col) & M29;
     asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
         : "+&v"(col), "=&s"(cc) : "v"(m0));
@@ -1283,6 +1305,112 @@ template <int F> __device__ __forceinline__ fe29_t fe29_mul_hi_asm(const fe29_t 
     asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0"
         : "+&v"(col), "=&s"(cc) : "v"(m4), "v"(p4), "v"(m0), "v"(p8));
     m8 = (0u - (uint32_t)col) & M29;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m8));
+    col >>= 29;
+    // column 9: 14 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[1]), "v"(b.v[8]), "v"(a.v[2]), "v"(b.v[7]), "v"(a.v[3]), "v"(b.v[6]), "v"(a.v[4]), "v"(b.v[5]), "v"(a.v[5]), "v"(b.v[4]), "v"(a.v[6]), "v"(b.v[3]), "v"(a.v[7]), "v"(b.v[2]), "v"(a.v[8]), "v"(b.v[1]), "v"(m8), "v"(p1), "v"(m7), "v"(p2), "v"(m6), "v"(p3), "v"(m5), "v"(p4));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m1), "v"(p8), "v"(h.v[0]));
+    r.v[0] = (uint32_t)col & M29; col >>= 29;
+    // column 10: 12 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[2]), "v"(b.v[8]), "v"(a.v[3]), "v"(b.v[7]), "v"(a.v[4]), "v"(b.v[6]), "v"(a.v[5]), "v"(b.v[5]), "v"(a.v[6]), "v"(b.v[4]), "v"(a.v[7]), "v"(b.v[3]), "v"(a.v[8]), "v"(b.v[2]), "v"(m8), "v"(p2), "v"(m7), "v"(p3), "v"(m6), "v"(p4), "v"(m2), "v"(p8), "v"(h.v[1]));
+    r.v[1] = (uint32_t)col & M29; col >>= 29;
+    // column 11: 10 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[3]), "v"(b.v[8]), "v"(a.v[4]), "v"(b.v[7]), "v"(a.v[5]), "v"(b.v[6]), "v"(a.v[6]), "v"(b.v[5]), "v"(a.v[7]), "v"(b.v[4]), "v"(a.v[8]), "v"(b.v[3]), "v"(m8), "v"(p3), "v"(m7), "v"(p4), "v"(m3), "v"(p8), "v"(h.v[2]));
+    r.v[2] = (uint32_t)col & M29; col >>= 29;
+    // column 12: 8 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[4]), "v"(b.v[8]), "v"(a.v[5]), "v"(b.v[7]), "v"(a.v[6]), "v"(b.v[6]), "v"(a.v[7]), "v"(b.v[5]), "v"(a.v[8]), "v"(b.v[4]), "v"(m8), "v"(p4), "v"(m4), "v"(p8), "v"(h.v[3]));
+    r.v[3] = (uint32_t)col & M29; col >>= 29;
+    // column 13: 6 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[5]), "v"(b.v[8]), "v"(a.v[6]), "v"(b.v[7]), "v"(a.v[7]), "v"(b.v[6]), "v"(a.v[8]), "v"(b.v[5]), "v"(m5), "v"(p8), "v"(h.v[4]));
+    r.v[4] = (uint32_t)col & M29; col >>= 29;
+    // column 14: 5 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[6]), "v"(b.v[8]), "v"(a.v[7]), "v"(b.v[7]), "v"(a.v[8]), "v"(b.v[6]), "v"(m6), "v"(p8), "v"(h.v[5]));
+    r.v[5] = (uint32_t)col & M29; col >>= 29;
+    // column 15: 4 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[7]), "v"(b.v[8]), "v"(a.v[8]), "v"(b.v[7]), "v"(m7), "v"(p8), "v"(h.v[6]));
+    r.v[6] = (uint32_t)col & M29; col >>= 29;
+    // column 16: 3 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[8]), "v"(b.v[8]), "v"(m8), "v"(p8), "v"(h.v[7]));
+    r.v[7] = (uint32_t)col & M29; col >>= 29;
+    r.v[8] = (uint32_t)col + h.v[8];
+    return r;
+}
+template <int F> __device__ __forceinline__ fe29_t fe29_mul_hi_lz(const fe29_t &a, const fe29_t &b, const fe29_t &h) {
+    uint64_t col, cc; fe29_t r;
+    uint32_t m0, m1, m2, m3, m4, m5, m6, m7, m8;
+    const uint32_t p1 = P29<F>::L1, p2 = P29<F>::L2, p3 = P29<F>::L3, p4 = P29<F>::L4, p8 = P29<F>::L8;
+    // column 0: 1 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 0"
+        : "=&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[0]));
+    m0 = 0u - (uint32_t)col;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m0));
+    col >>= 29;
+    // column 1: 3 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[1]), "v"(a.v[1]), "v"(b.v[0]), "v"(m0), "v"(p1));
+    m1 = 0u - (uint32_t)col;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m1));
+    col >>= 29;
+    // column 2: 5 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[2]), "v"(a.v[1]), "v"(b.v[1]), "v"(a.v[2]), "v"(b.v[0]), "v"(m1), "v"(p1), "v"(m0), "v"(p2));
+    m2 = 0u - (uint32_t)col;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m2));
+    col >>= 29;
+    // column 3: 7 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[3]), "v"(a.v[1]), "v"(b.v[2]), "v"(a.v[2]), "v"(b.v[1]), "v"(a.v[3]), "v"(b.v[0]), "v"(m2), "v"(p1), "v"(m1), "v"(p2), "v"(m0), "v"(p3));
+    m3 = 0u - (uint32_t)col;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m3));
+    col >>= 29;
+    // column 4: 9 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[4]), "v"(a.v[1]), "v"(b.v[3]), "v"(a.v[2]), "v"(b.v[2]), "v"(a.v[3]), "v"(b.v[1]), "v"(a.v[4]), "v"(b.v[0]), "v"(m3), "v"(p1), "v"(m2), "v"(p2), "v"(m1), "v"(p3), "v"(m0), "v"(p4));
+    m4 = 0u - (uint32_t)col;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m4));
+    col >>= 29;
+    // column 5: 10 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[5]), "v"(a.v[1]), "v"(b.v[4]), "v"(a.v[2]), "v"(b.v[3]), "v"(a.v[3]), "v"(b.v[2]), "v"(a.v[4]), "v"(b.v[1]), "v"(a.v[5]), "v"(b.v[0]), "v"(m4), "v"(p1), "v"(m3), "v"(p2), "v"(m2), "v"(p3), "v"(m1), "v"(p4));
+    m5 = 0u - (uint32_t)col;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m5));
+    col >>= 29;
+    // column 6: 11 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[6]), "v"(a.v[1]), "v"(b.v[5]), "v"(a.v[2]), "v"(b.v[4]), "v"(a.v[3]), "v"(b.v[3]), "v"(a.v[4]), "v"(b.v[2]), "v"(a.v[5]), "v"(b.v[1]), "v"(a.v[6]), "v"(b.v[0]), "v"(m5), "v"(p1), "v"(m4), "v"(p2), "v"(m3), "v"(p3), "v"(m2), "v"(p4));
+    m6 = 0u - (uint32_t)col;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m6));
+    col >>= 29;
+    // column 7: 12 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[7]), "v"(a.v[1]), "v"(b.v[6]), "v"(a.v[2]), "v"(b.v[5]), "v"(a.v[3]), "v"(b.v[4]), "v"(a.v[4]), "v"(b.v[3]), "v"(a.v[5]), "v"(b.v[2]), "v"(a.v[6]), "v"(b.v[1]), "v"(a.v[7]), "v"(b.v[0]), "v"(m6), "v"(p1), "v"(m5), "v"(p2), "v"(m4), "v"(p3), "v"(m3), "v"(p4));
+    m7 = 0u - (uint32_t)col;
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m7));
+    col >>= 29;
+    // column 8: 14 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[8]), "v"(a.v[1]), "v"(b.v[7]), "v"(a.v[2]), "v"(b.v[6]), "v"(a.v[3]), "v"(b.v[5]), "v"(a.v[4]), "v"(b.v[4]), "v"(a.v[5]), "v"(b.v[3]), "v"(a.v[6]), "v"(b.v[2]), "v"(a.v[7]), "v"(b.v[1]), "v"(a.v[8]), "v"(b.v[0]), "v"(m7), "v"(p1), "v"(m6), "v"(p2), "v"(m5), "v"(p3));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m4), "v"(p4), "v"(m0), "v"(p8));
+    m8 = 0u - (uint32_t)col;
     asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
         : "+&v"(col), "=&s"(cc) : "v"(m8));
     col >>= 29;

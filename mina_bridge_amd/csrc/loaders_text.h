@@ -36,6 +36,18 @@ inline bool next_number(const char *s, size_t n, size_t &pos, U256 &out) {
         const unsigned char c = (unsigned char)s[pos];
         if (c == '"' && n - pos >= 66 && s[pos + 65] == '"') {
             bool hex = true; for (size_t i = 1; i <= 64 && hex; ++i) hex = isxdigit((unsigned char)s[pos + i]) != 0;
+            // 64 quoted characters that are ALL decimal digits are both a valid little-endian byte-hex element and a valid 64-digit decimal literal.  The
+            // spelling in front decides: `from_hex(` = byte-hex, `from_str(` = decimal (falls through to the decimal reader below); with neither the literal is
+            // AMBIGUOUS and the table is refused (false) rather than loaded as a constant that may be the wrong one (a random element is all-decimal with
+            // probability (10/16)^64 ~ 1e-13: no real table is refused)
+            bool all_decimal = hex;
+            for (size_t i = 1; i <= 64 && all_decimal; ++i) all_decimal = isdigit((unsigned char)s[pos + i]) != 0;
+            if (hex && all_decimal) {
+                size_t q = pos; while (q > 0 && isspace((unsigned char)s[q - 1])) --q;
+                auto ends_with = [&](const char *w) { const size_t wl = strlen(w); return q >= wl && memcmp(s + q - wl, w, wl) == 0; };
+                if (ends_with("from_str(")) hex = false;
+                else if (!ends_with("from_hex(")) { pos = n; return false; }
+            }
             if (hex) {
                 auto d = [](char ch) { return (uint64_t)(isdigit((unsigned char)ch) ? ch - '0' : tolower((unsigned char)ch) - 'a' + 10); };
                 out = U256{};

@@ -626,13 +626,44 @@ msm_accumulate_bucket_kernel(uint32_t nb_total, uint32_t nb_prob, const uint32_t
     }
 }
 
-// K1t-b on 29-bit limbs (ec29.cuh): the same lanes, the same order of additions, points gathered from the 2^261-domain twin of the window table; the
-// bucket leaves in the 8 x 32 form.  8-MSM launch alone on the GPU: 575 us against 685 us for the 8 x 32 kernel (profiles/r04_k1.md); the residency cap makes
-// no difference here (2 / 3 / 4 / 8 waves per SIMD: 12.5 - 12.6 k checks/s): kept at the 8 x 32 kernel's 2.
+// The pre-split window table (round 5; mina_verify_tuning.msm_fp29 = 2): one 128-byte record per point -- x, y AND p - y as nine 29-bit limbs each, in the 2^261
+// domain, plus an infinity flag -- so that the accumulate kernels neither convert 8 x 32 words into limbs (32 instructions per point) nor negate y (18): a negative
+// digit LOADS the other y.  Twice the gather traffic of the 64-byte twin (two 64-B lines per point instead of one), 128 MiB per curve instead of 64.
+struct alignas(128) tab29_t { uint32_t w[32]; };         // x: w[0..8]; infinity: w[9] != 0; y: w[12..20]; p - y: w[22..30]
+static constexpr int TAB29_X = 0, TAB29_INF = 9, TAB29_Y = 12, TAB29_NY = 22;
+struct tab29_pt { fe29_t x, y; uint32_t inf; };
+__device__ __forceinline__ tab29_pt load_tab29(const tab29_t *__restrict__ tab, uint32_t ref) {
+    const uint32_t *__restrict__ w = tab[ref & 0x7fffffffu].w;
+    const uint32_t *__restrict__ yw = w + ((ref >> 31) ? TAB29_NY : TAB29_Y);
+    tab29_pt p;
+#pragma unroll
+    for (int i = 0; i < L29; ++i) { p.x.v[i] = w[TAB29_X + i]; p.y.v[i] = yw[i]; }
+    p.inf = w[TAB29_INF];
+    return p;
+}
 template <int F>
+__global__ void msm_table29s_kernel(size_t n, const affine_t *__restrict__ in, fe_t m32, tab29_t *__restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const affine_t p = in[i];
+    tab29_t t; for (int k = 0; k < 32; ++k) t.w[k] = 0u;
+    if (aff_is_inf(p)) t.w[TAB29_INF] = 1u;               // the SAME predicate as the 8 x 32 kernels and the redo path (x | y == 0)
+    else {
+        const fe_t y = fe_mul<F>(p.y, m32);
+        const fe29_t x29 = fe29_from_words(fe_mul<F>(p.x, m32)), y29 = fe29_from_words(y), ny29 = fe29_from_words(fe_neg<F>(y));
+        for (int k = 0; k < L29; ++k) { t.w[TAB29_X + k] = x29.v[k]; t.w[TAB29_Y + k] = y29.v[k]; t.w[TAB29_NY + k] = ny29.v[k]; }
+    }
+    out[i] = t;
+}
+
+// K1t-b on 29-bit limbs (ec29.cuh): the same lanes, the same order of additions, points gathered from the 2^261-domain twin of the window table (TAB = 1: 64-byte
+// records of 8 x 32 words, converted and negated here) or from the pre-split table (TAB = 2: tab29_t); the bucket leaves in the 8 x 32 form.  8-MSM launch alone on
+// the GPU: 575 us against 685 us for the 8 x 32 kernel (profiles/r04_k1.md); the residency cap makes no difference here (2 / 3 / 4 / 8 waves per SIMD: 12.5 - 12.6 k
+// checks/s): kept at the 8 x 32 kernel's 2.
+template <int F, int TAB>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
 msm_accumulate_bucket29_kernel(uint32_t nb_total, uint32_t nb_prob, const uint32_t *__restrict__ start, const uint32_t *__restrict__ order,
-                               const uint32_t *__restrict__ sorted, const affine_t *__restrict__ points29, fe_t one, fe_t m32,
+                               const uint32_t *__restrict__ sorted, const void *__restrict__ points29_, fe_t one, fe_t m32,
                                xyzz_t *__restrict__ buckets, uint32_t *__restrict__ info, uint32_t *__restrict__ redo) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -646,17 +677,32 @@ msm_accumulate_bucket29_kernel(uint32_t nb_total, uint32_t nb_prob, const uint32
         xyzz29_t acc; bool inf = true, exact = true;
         if (cnt) {
             uint32_t ref = sorted[beg], ref_n = cnt > 1 ? sorted[beg + 1] : 0u;
-            affine_t nxt = load_affine(points29 + (ref & 0x7fffffffu));
+            if constexpr (TAB == 2) {
+                const tab29_t *__restrict__ tab = (const tab29_t *)points29_;
+                tab29_pt p = load_tab29(tab, ref);
 #pragma unroll 1
-            for (uint32_t e = 0; e < cnt && exact; ++e) {
-                const affine_t p = nxt;
-                const uint32_t cur = ref;
-                ref = ref_n;
-                if (e + 1 < cnt) nxt = load_affine(points29 + (ref & 0x7fffffffu));
-                if (e + 2 < cnt) ref_n = sorted[beg + e + 2];
-                if (fe_is_zero(p.y)) continue;                   // infinity is (0, 0); no point of these prime-order curves has y = 0
-                const fe29_t px = fe29_from_words(p.x), py = fe29_from_words(p.y);
-                exact = xyzz29_add_affine<F>(acc, inf, px, py, (cur >> 31) != 0, m32);                                      // a negative digit adds (x, p - y) (y != 0 on these curves)
+                for (uint32_t e = 0; e < cnt && exact; ++e) {
+                    ref = ref_n;
+                    if (e + 2 < cnt) ref_n = sorted[beg + e + 2];
+                    // the next point is gathered INTO p's registers as soon as this add has consumed them (after its first two products)
+                    auto next = [&]() { if (e + 1 < cnt) p = load_tab29(tab, ref); };
+                    if (p.inf) { next(); continue; }
+                    exact = xyzz29_add_affine<F>(acc, inf, p.x, p.y, [&]() { return p.y; }, next, m32);                         // the digit's sign chose y or p - y at the load
+                }
+            } else {
+                const affine_t *__restrict__ points29 = (const affine_t *)points29_;
+                affine_t p = load_affine(points29 + (ref & 0x7fffffffu));
+#pragma unroll 1
+                for (uint32_t e = 0; e < cnt && exact; ++e) {
+                    const bool is_inf = aff_is_inf(p);               // infinity is (0, 0): the predicate of the 8 x 32 kernels and of the redo path
+                    const fe29_t px = fe29_from_words(p.x), py = fe29_from_words(p.y);
+                    const uint32_t cur = ref;
+                    ref = ref_n;
+                    if (e + 1 < cnt) p = load_affine(points29 + (ref & 0x7fffffffu));      // the words are dead once converted: the next gather lands in their registers
+                    if (e + 2 < cnt) ref_n = sorted[beg + e + 2];
+                    if (is_inf) continue;
+                    exact = xyzz29_add_affine<F>(acc, inf, px, py, (cur >> 31) != 0, m32);                                      // a negative digit adds (x, p - y) (y != 0 on these curves)
+                }
             }
         }
         if (exact) buckets[b] = xyzz29_leave<F>(acc, inf, one);
@@ -683,12 +729,12 @@ msm_bucket_redo_kernel(const uint32_t *__restrict__ start, const uint32_t *__res
         buckets[b] = acc;
     }
 }
-// K1d on 29-bit limbs: one lane per task of <= 8 entries (the single-MSM form)
-template <int F>
+// K1d on 29-bit limbs: one lane per task of <= 8 entries (the single-MSM form); TAB as above
+template <int F, int TAB>
 __global__ void __launch_bounds__(256)
 msm_accumulate29_kernel(uint32_t nb_total, const uint32_t *__restrict__ start, const uint32_t *__restrict__ full_start,
                         const uint32_t *__restrict__ rem_bucket, const uint32_t *__restrict__ info,
-                        const uint32_t *__restrict__ sorted, const affine_t *__restrict__ points29, fe_t one, fe_t m32,
+                        const uint32_t *__restrict__ sorted, const void *__restrict__ points29_, fe_t one, fe_t m32,
                         xyzz_t *__restrict__ partial, uint32_t *__restrict__ info_rw, uint32_t *__restrict__ redo) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -706,17 +752,31 @@ msm_accumulate29_kernel(uint32_t nb_total, const uint32_t *__restrict__ start, c
 #pragma unroll
     for (int e = 0; e < MSM_TASK_LEN; ++e) refs[e] = ((uint32_t)e < cnt) ? sorted[beg + e] : 0u;
     xyzz29_t acc; bool inf = true, exact = true;
-    affine_t nxt = load_affine(points29 + (refs[0] & 0x7fffffffu));
+    if constexpr (TAB == 2) {
+        const tab29_t *__restrict__ tab = (const tab29_t *)points29_;
+        tab29_pt p = load_tab29(tab, refs[0]);
 #pragma unroll 1
-    for (uint32_t e = 0; e < cnt && exact; ++e) {
-        const affine_t p = nxt;
-        const uint32_t ref = refs[0];
+        for (uint32_t e = 0; e < cnt && exact; ++e) {
 #pragma unroll
-        for (int q = 0; q + 1 < MSM_TASK_LEN; ++q) refs[q] = refs[q + 1];
-        if (e + 1 < cnt) nxt = load_affine(points29 + (refs[0] & 0x7fffffffu));
-        if (fe_is_zero(p.y)) continue;                           // infinity is (0, 0); no point of these prime-order curves has y = 0
-        const fe29_t px = fe29_from_words(p.x), py = fe29_from_words(p.y);
-        exact = xyzz29_add_affine<F>(acc, inf, px, py, (ref >> 31) != 0, m32);
+            for (int q = 0; q + 1 < MSM_TASK_LEN; ++q) refs[q] = refs[q + 1];
+            auto next = [&]() { if (e + 1 < cnt) p = load_tab29(tab, refs[0]); };
+            if (p.inf) { next(); continue; }
+            exact = xyzz29_add_affine<F>(acc, inf, p.x, p.y, [&]() { return p.y; }, next, m32);
+        }
+    } else {
+        const affine_t *__restrict__ points29 = (const affine_t *)points29_;
+        affine_t p = load_affine(points29 + (refs[0] & 0x7fffffffu));
+#pragma unroll 1
+        for (uint32_t e = 0; e < cnt && exact; ++e) {
+            const bool is_inf = aff_is_inf(p);                   // infinity is (0, 0): the same predicate as the 8 x 32 kernels
+            const fe29_t px = fe29_from_words(p.x), py = fe29_from_words(p.y);
+            const uint32_t ref = refs[0];
+#pragma unroll
+            for (int q = 0; q + 1 < MSM_TASK_LEN; ++q) refs[q] = refs[q + 1];
+            if (e + 1 < cnt) p = load_affine(points29 + (refs[0] & 0x7fffffffu));
+            if (is_inf) continue;
+            exact = xyzz29_add_affine<F>(acc, inf, px, py, (ref >> 31) != 0, m32);
+        }
     }
     if (exact) partial[t] = xyzz29_leave<F>(acc, inf, one);
     else redo[atomicAdd(&info_rw[3], 1u)] = t;                   // msm_accumulate_kernel<F> in redo mode sums this task with the 8 x 32 law

@@ -26,7 +26,7 @@ CURVE_PALLAS, CURVE_VESTA = 0, 1
 EXPORTS = [
     "mina_ctx_create", "mina_ctx_destroy", "mina_last_error", "mina_ctx_synchronize", "mina_ctx_stream", "mina_ctx_pin_lane", "mina_ctx_set_pipeline", "mina_prof_enable", "mina_prof_read",
     "mina_dev_malloc", "mina_dev_free", "mina_dev_upload", "mina_dev_download",
-    "mina_srs_create", "mina_srs_load", "mina_srs_depth", "mina_srs_get_g", "mina_srs_get_h", "mina_srs_lagrange_basis", "mina_public_input_commitment", "mina_public_input_commitment_batch", "mina_combined_inner_product", "mina_srs_serialize",
+    "mina_srs_create", "mina_srs_split_table", "mina_srs_load", "mina_srs_depth", "mina_srs_get_g", "mina_srs_get_h", "mina_srs_lagrange_basis", "mina_public_input_commitment", "mina_public_input_commitment_batch", "mina_combined_inner_product", "mina_srs_serialize",
     "mina_msm", "mina_msm_srs", "mina_msm_srs_range", "mina_msm_srs_multi", "mina_msm_srs_dev",
     "mina_b_poly", "mina_b_poly_coefficients", "mina_b_poly_fold", "mina_b_poly_fold_dev",
     "mina_poseidon_set_params", "mina_poseidon_params_parse", "mina_poseidon_load_params", "mina_poseidon_load_params_file", "mina_poseidon_permute", "mina_poseidon_permute_dev", "mina_poseidon_hash",
@@ -44,7 +44,7 @@ EXPORTS = [
     "mina_verify_device_count", "mina_verify_device_ctx", "mina_verify_set_network", "mina_verify_install_verifier_index", "mina_verify_install_step_index", "mina_verify_set_poseidon_params",
     "mina_poseidon_install_default_params",
     "verify_mina_state_ffi", "verify_account_inclusion_ffi", "verify_mina_state_ffi_u32", "verify_account_inclusion_ffi_u32",
-    "mina_verify_tuning_default", "mina_verify_tuning_get", "mina_verify_configure_ex",
+    "mina_verify_tuning_default", "mina_verify_tuning_get", "mina_verify_configure_ex", "mina_verify_retired_env",
     "mina_consensus_select_secure_chain", "mina_parse_state_pub_inputs", "mina_parse_account_pub_inputs", "mina_parse_merkle_path", "mina_verify_account_inclusion",
 ]
 
@@ -612,6 +612,10 @@ class MinaContext:
     @property
     def stream(self) -> int:
         return int(self._lib.mina_ctx_stream(self._h) or 0)
+
+    def srs_split_table(self, curve: int, on: bool = True):
+        """build / drop the pre-split window table the accumulate kernels read under `tuning(msm_fp29=2)`"""
+        self._ck(self._lib.mina_srs_split_table(self._h, int(curve), 1 if on else 0), "mina_srs_split_table")
 
     def pin_lane(self, lane: int):
         """every `_dev` entry point on ONE lane (negative: round-robin again): the library's work is then ordered on `self.stream`"""

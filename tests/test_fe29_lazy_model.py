@@ -1,222 +1,261 @@
-"""The LAZY 29-bit-limb Montgomery products of mina_bridge_amd/csrc/fp29.cuh (tools/gen_fe29.py: fe29_mul_lz / fe29_sqr_lz / fe29_dot3rc_lz / fe29_mulrc_lz /
-fe29_dot2rc_lz), restated on Python integers column by column exactly as the generated code runs them (64-bit accumulator, quotient digit = -col mod 2^32
-NOT masked to 29 bits, the tenth operand added before the reduction).  What the GPU parity tests cannot reach -- the worst case of a column -- is checked here:
-  * no column ever exceeds 64 bits, for operands at the bounds the permutation's lane forms keep (analytic maximum + adversarial limb patterns);
-  * the result is the same field element as (sum of products + c) / 2^261 and stays below (sum + c) / 2^261 + 8.0001 p;
-  * the value bounds quoted in sponge.cuh for the 3-, 8- and 16-lane forms are fixed points of a round."""
-import random
+"""The 29-bit-limb routines of mina_bridge_amd/csrc/fp29.cuh / ec29.cuh against their PROOFS (tools/fe29_bounds.py) and against Python integers.
 
-P = {0: 0x40000000000000000000000000000000224698fc094cf91b992d30ed00000001, 1: 0x40000000000000000000000000000000224698fc0994a8dd8c46eb2100000001}
-L, W = 9, 29
-M29 = (1 << W) - 1
-R = 1 << (L * W)
+Round 5: the bounds are no longer restated here.  tools/fe29_bounds.py carries an interval for every operand and column of every routine and
+of the routines' callers (the XYZZ mixed add, the Poseidon lane forms); tools/gen_fe29.py refuses to write fp29.cuh when a rule fails and emits the constants the
+proofs ran with (`struct EC29`, `struct SPONGE29`) for the C++ to use by name.  This file
+  * runs the proofs, checks the committed fp29.cuh IS what the generator writes, and that ec29.cuh takes every multiple of p from `EC29::`;
+  * re-introduces the round-4 bug (ONE p under a canonical y) and other broken disciplines: the prover -- and the generator -- must refuse;
+  * restates the generated column loop on Python integers (64-bit accumulator, masked or unmasked quotient digits, the high-half addend, the tenth operand) and
+    runs the group law and the lane forms' rounds on random AND adversarial concrete values (coordinates at their invariants, y = p - 1, 2^254, 2^254 - 2^233 - 1 ...):
+    every column below 2^64, every limb-wise difference non-negative, every intermediate inside the interval the prover derived, every result the field element
+    the textbook formula gives.
+What the GPU parity tests cannot reach -- the worst case of a column, the rare table point -- is reached here, on the CPU tier."""
+import importlib.util
+import os
+import random
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _load(name):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, "tools", name + ".py"))
+    mod = importlib.util.module_from_spec(spec); spec.loader.exec_module(mod)
+    return mod
+
+
+B = _load("fe29_bounds")
+L, W, M29, R, P = B.L, B.W, B.M29, B.R, B.P
 
 
 def limbs(x):
-    return [(x >> (W * i)) & M29 for i in range(L - 1)] + [x >> (W * (L - 1))]
+    return B.limbs_of(x)
 
 
 def value(v):
     return sum(x << (W * i) for i, x in enumerate(v))
 
 
-def lazy_product(p, pairs, c=None):
-    """(result limbs, largest accumulator value seen): the column loop of gen_fe29.body(lazy=True)"""
+# ------------------------------------------------------------------------------------------------ the generated column loop on concrete integers
+def model_product(p, pairs, lazy=False, hi=None, c=None):
+    """tools/gen_fe29.py `body`: (result limbs, largest accumulator value seen)"""
     pl = limbs(p)
-    assert pl[0] == 1 and pl[5] == pl[6] == pl[7] == 0 and pl[8] == 1 << 22          # the shape P29<F> asserts
     col, m, r, peak = 0, [0] * L, [0] * L, 0
     for k in range(2 * L - 1):
         for a, b in pairs:
             for i in range(L):
                 if 0 <= k - i < L:
                     col += a[i] * b[k - i]
-        if c is not None and k < L:
-            col += c[k]
         for j in (1, 2, 3, 4, 8):
             if 0 <= k - j < L and k - j < k:
                 col += m[k - j] * pl[j]
+        if hi is not None and k >= L:
+            col += hi[k - L]
+        if c is not None and k < L:
+            col += c[k]
         peak = max(peak, col)
         if k < L:
-            m[k] = (-col) & 0xFFFFFFFF
+            m[k] = (-col) & (0xFFFFFFFF if lazy else M29)
             col += m[k]
             peak = max(peak, col)
-            assert col & 0xFFFFFFFF == 0
+            assert col & M29 == 0
             col >>= W
         else:
             r[k - L] = col & M29
             col >>= W
-    assert col < 1 << 32
-    r[L - 1] = col
+    r[L - 1] = col + (hi[L - 1] if hi is not None else 0)
+    assert peak < 1 << 64, "a column left its 64-bit accumulator"
+    assert r[L - 1] < 1 << 32
     return r, peak
 
 
-def test_analytic_column_maximum_fits_64_bits():
-    # a column of the 3-term dot product: 27 limb products, the quotient terms m p_1 .. m p_4 (m < 2^32, p_j < 2^29), m 2^22, m, the tenth operand, the carry
-    worst = 27 * M29 * M29 + 4 * (2**32 - 1) * M29 + (2**32 - 1) * (1 << 22) + (2**32 - 1) + M29 + (1 << 35)
-    assert worst < 1 << 64 and worst / 2**64 < 0.93
+def kp_minus(p, mult, b, lend=30):
+    k = B.kp_redundant(p, mult, lend)
+    out = [k[i] - b[i] for i in range(L)]
+    assert all(0 <= x < 1 << 32 for x in out), "a limb of K p - b went negative"
+    return out
 
 
+def inside(v, iv):
+    """concrete limbs `v` lie inside the interval the prover derived"""
+    return value(v) <= iv["vmax"] and v[8] <= iv["top_limb"]
+
+
+# ------------------------------------------------------------------------------------------------ the proofs and the generated header
+def test_the_shipped_constants_are_proven_and_the_header_is_what_the_generator_writes():
+    t = B.prove_all()
+    assert t["constants"]["EC29"] == B.EC29 and all(t["fields"][f]["group_law_worst_column"] < 1 and t["fields"][f]["sponge_worst_column"] < 1 for f in (0, 1))
+    gen = _load("gen_fe29")
+    path = os.path.join(ROOT, "mina_bridge_amd", "csrc", "fp29.cuh")
+    s = open(path).read()
+    assert gen.rewrite(s) == s, "run `python tools/gen_fe29.py --write` after changing the generator or tools/fe29_bounds.py"
+    for k, v in B.EC29.items():
+        assert f"static constexpr uint32_t {k} = {v};" in s
+    ec = open(os.path.join(ROOT, "mina_bridge_amd", "csrc", "ec29.cuh")).read()
+    law = ec[ec.index("template <int F, class FirstY, class Done>"):ec.index("// the bucket value in the 8 x 32 form")]
+    assert not re.search(r"fe29_(?:add_)?kp_minus(?:_a_minus_2b)?<F, \d+>", law), "ec29.cuh must take every multiple of p from EC29:: (the proven constants), not from a literal"
+    assert law.count("EC29::") >= 6
+
+
+def test_the_prover_refuses_the_round_4_bug_and_other_broken_disciplines():
+    for f in (0, 1):
+        with pytest.raises(B.BoundError, match="limb 8 of 1 p - b goes negative"):
+            B.prove_group_law(f, {"NEG_Y_MULT": 1})                        # -y = p - y, limb by limb: the top limb 2^22 - 2 - y_8 underflows for y >= 2^254 - 2^233
+        with pytest.raises(B.BoundError, match="goes negative"):
+            B.prove_group_law(f, {"SUB_X1_MULT": B.EC29["INV_X"]})         # K must exceed the subtrahend's bound by one: no carry pass lends to the top limb
+        with pytest.raises(B.BoundError, match="goes negative"):
+            B.prove_group_law(f, {"X3_SUB_MULT": 4})                       # round 4's 4 p under the LAZY ppp, q
+        with pytest.raises(B.BoundError, match="new acc"):
+            B.prove_group_law(f, {"INV_X": B.EC29["INV_X"] - 1})           # the invariants are the least fixed point
+        with pytest.raises(B.BoundError):
+            B.prove_group_law(f, lazy=B.EC29_LAZY + ("y3", "q", "x3"))     # every product lazy: the shipped constants do not hold (and no constants do: search_lazy_sets)
+        with pytest.raises(B.BoundError):
+            B.prove_sponge_rounds(f, {"LANES3_STATE_MILLI_P": 8000})       # 8.0 p is not a fixed point of a lazy round (8.0001 p comes from the quotient alone)
+
+
+def test_the_generator_writes_nothing_when_a_proof_fails(monkeypatch):
+    gen = _load("gen_fe29")
+    path = os.path.join(ROOT, "mina_bridge_amd", "csrc", "fp29.cuh")
+    s = open(path).read()
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fe29_bounds                                                    # the module object gen_fe29.proven_constants() imports
+    monkeypatch.setitem(fe29_bounds.EC29, "NEG_Y_MULT", 1)
+    with pytest.raises(fe29_bounds.BoundError):
+        gen.rewrite(s)
+    assert open(path).read() == s
+
+
+# ------------------------------------------------------------------------------------------------ concrete values against the intervals
 def test_lazy_products_are_the_same_field_element_and_columns_stay_below_2_64():
     rng = random.Random(2024)
     seen = 0
     for F, p in P.items():
         rinv = pow(R, -1, p)
-        top = (26 * p) >> (W * (L - 1))                       # the 16-lane form's bound on the state (24.3 p) with margin
+        bound = B.SPONGE["LANES16_STATE_MILLI_P"] * p // 1000            # the largest state bound any lane form keeps
+        top = bound >> B.TOP
         extreme = [M29] * (L - 1) + [top]
 
         def operand():
             t = rng.random()
             if t < 0.25: return list(extreme)
-            if t < 0.45: return limbs(rng.randrange(26 * p))
+            if t < 0.45: return limbs(rng.randrange(bound))
             if t < 0.55: return [rng.choice([0, M29]) for _ in range(L - 1)] + [rng.choice([0, top])]
             return limbs(rng.randrange(p))
-        for _ in range(1500):
+        for _ in range(1200):
             ops = [operand() for _ in range(6)]
-            c = limbs(rng.randrange(p)) if rng.random() < 0.7 else [M29] * (L - 1) + [p >> (W * (L - 1))]
+            c = limbs(rng.randrange(p)) if rng.random() < 0.7 else [M29] * (L - 1) + [p >> B.TOP]
             for pairs, cc in (([(ops[0], ops[1]), (ops[2], ops[3]), (ops[4], ops[5])], c), ([(ops[0], ops[1]), (ops[2], ops[3])], c), ([(ops[0], ops[1])], c), ([(ops[0], ops[1])], None),
                               ([(ops[0], ops[0])], None)):
-                r, peak = lazy_product(p, pairs, cc)
+                r, peak = model_product(p, pairs, lazy=True, c=cc)
                 total = sum(value(a) * value(b) for a, b in pairs) + (value(cc) if cc else 0)
-                assert peak < 1 << 64
                 assert value(r) % p == total * rinv % p
                 assert value(r) * R < total + 8.0001 * p * R
                 assert all(x <= M29 for x in r[:-1])
                 seen = max(seen, peak)
-    assert seen > 1 << 62                                      # the adversarial patterns do come near the top
+    assert seen > 1 << 62                                                 # the adversarial patterns do come near the top
 
 
-def test_value_bounds_of_the_lane_forms_are_fixed_points_of_a_round():
-    # in units of p; a lazy product of operands below A p and B p is below A B / 128 + 8.0001 (p / 2^261 < 2^-7), the round constant inside a reduction adds 2^-7
-    lz = lambda a, b, n=1, rc=0: n * a * b / 128 + rc / 128 + 8.0001
-    # 3-lane: x -> x^2, x^4, x^6, x^7, row (three terms, MDS entries below p, the round constant inside)
-    x = 8.3
-    x2 = lz(x, x); x4 = lz(x2, x2); x7 = lz(lz(x4, x2), x)
-    assert lz(1, x7, 3, 1) < x and max(x2, x4, x7) < 8.8
-    # 8-lane: x = u + swap(u), u a two-term half row
-    x = 16.5
-    x2 = lz(x, x); y = max(lz(x2, x), lz(x2, x2)); t = lz(y, y)
-    assert 2 * lz(1, t, 2, 1) < x
-    # 16-lane: x = sum of three single products
-    x = 24.4
-    x2 = lz(x, x); y = max(lz(x2, x), lz(x2, x2)); t = lz(y, y)
-    assert 3 * lz(1, t, 1, 1) < x
-    # every bound leaves the top limb far below 2^29 and the strict product on the way out below 2^256
-    assert 26 * P[0] < 1 << (W * (L - 1) + 27) and (24.4 / 128 + 1) * P[1] < 1 << 256
+def _law(p, acc, qx, qy, c):
+    """xyzz29_add_affine on concrete limbs (ec29.cuh, statement by statement); returns every intermediate"""
+    lz = B.EC29_LAZY
+    pd, _ = model_product(p, [(qx, acc["zz"])], lazy="pd" in lz, hi=kp_minus(p, c["SUB_X1_MULT"], acc["x"]))
+    r, _ = model_product(p, [(qy, acc["zzz"])], lazy="r" in lz, hi=kp_minus(p, c["SUB_Y1_MULT"], acc["y"]))
+    pp, _ = model_product(p, [(pd, pd)], lazy="pp" in lz)
+    ppp, _ = model_product(p, [(pd, pp)], lazy="ppp" in lz)
+    q, _ = model_product(p, [(acc["x"], pp)], lazy="q" in lz)
+    k = B.kp_redundant(p, c["X3_SUB_MULT"], 31)
+    h = [k[i] - ppp[i] - 2 * q[i] for i in range(L)]
+    assert all(0 <= x < 1 << 32 for x in h), "a limb of K p - ppp - 2 q went negative"
+    x3, _ = model_product(p, [(r, r)], lazy="x3" in lz, hi=h)
+    k3 = kp_minus(p, c["SUB_X3_MULT"], x3)
+    a = [q[i] + k3[i] for i in range(L)]
+    assert all(x < 1 << 32 for x in a)
+    y3, peak = model_product(p, [(r, a), (kp_minus(p, c["SUB_Y1_MULT"], acc["y"]), ppp)], lazy="y3" in lz)
+    zz, _ = model_product(p, [(acc["zz"], pp)], lazy="zz" in lz)
+    zzz, _ = model_product(p, [(acc["zzz"], ppp)], lazy="zzz" in lz)
+    return {"pd": pd, "r": r, "pp": pp, "ppp": ppp, "q": q, "x3": x3, "y3": y3, "zz": zz, "zzz": zzz}, peak
 
 
-def strict_product_hi(p, a, b, h):
-    """gen_fe29.body(lazy=False, hi=h): quotient digits masked to 29 bits, the 9-limb addend h entering columns 9 .. 17"""
-    pl = limbs(p)
-    col, m, r, peak = 0, [0] * L, [0] * L, 0
-    for k in range(2 * L - 1):
-        for i in range(L):
-            if 0 <= k - i < L:
-                col += a[i] * b[k - i]
-        for j in (1, 2, 3, 4, 8):
-            if 0 <= k - j < L and k - j < k:
-                col += m[k - j] * pl[j]
-        if k >= L:
-            col += h[k - L]
-        peak = max(peak, col)
-        if k < L:
-            m[k] = (-col) & M29
-            col += m[k]
-            col >>= W
-        else:
-            r[k - L] = col & M29
-            col >>= W
-    r[L - 1] = col + h[L - 1]
-    assert r[L - 1] < 1 << 32
-    return r, peak
-
-
-def test_group_law_subtractions_inside_a_reduction():
-    """ec29.cuh: u2 + 8 p - x1 and r^2 + 4 p - ppp - 2 q as ONE product / square each -- the "K p - ..." operand in limbs that never go negative,
-    added to the high half of the product before the carries (fe29_mul_hi_asm / fe29_sqr_hi_asm): the same integers as fe29_sub_kp gave"""
-    rng = random.Random(7)
+def test_the_group_law_on_concrete_values_stays_inside_the_proven_intervals_and_is_the_textbook_formula():
+    """madd-2008-s on XYZZ coordinates in the Montgomery-2^261 domain: with U2 = X2 ZZ1, S2 = Y2 ZZZ1, P = U2 - X1, R = S2 - Y1: X3 = R^2 - PPP - 2 Q, Y3 = R (Q - X3) - Y1 PPP,
+    ZZ3 = ZZ1 PP, ZZZ3 = ZZZ1 PPP (Q = X1 PP) -- each product carrying one factor 1/2^261"""
+    c = B.EC29
+    rng = random.Random(29)
+    worst = 0
     for F, p in P.items():
+        table = B.prove_all()["fields"][F]["group_law"]
         rinv = pow(R, -1, p)
-        n8, n4 = limbs(8 * p), limbs(4 * p)
-        k8 = [n8[0] + (1 << 30)] + [n8[i] + (1 << 30) - 2 for i in range(1, 8)] + [n8[8] - 2]
-        k4 = [n4[0] + (1 << 31)] + [n4[i] + (1 << 31) - 4 for i in range(1, 8)] + [n4[8] - 4]
-        assert value(k8) == 8 * p and value(k4) == 4 * p and all(0 <= x < 1 << 32 for x in k8 + k4)
-        for _ in range(3000):
-            edge = rng.random() < 0.2
-            x1 = 6 * p - 1 if edge else rng.randrange(6 * p)                     # accumulator x below 6 p
-            qx, zz = rng.randrange(p), (3 * p - 1 if edge else rng.randrange(3 * p))
-            h = [k8[i] - limbs(x1)[i] for i in range(L)]
-            assert all(0 <= v < 1 << 32 for v in h)
-            r, peak = strict_product_hi(p, limbs(qx), limbs(zz), h)
-            assert peak < 1 << 64 and all(v <= M29 for v in r[:-1])
-            got = value(r)
-            assert got % p == (qx * zz * rinv - x1) % p and got < 11 * p       # u2 + 8 p - x1, u2 < 3 p
-            ppp, q = (int(1.2 * p) - 1 if edge else rng.randrange(int(1.2 * p))), (int(1.1 * p) - 1 if edge else rng.randrange(int(1.1 * p)))
-            h = [k4[i] - limbs(ppp)[i] - 2 * limbs(q)[i] for i in range(L)]
-            assert all(0 <= v < 1 << 32 for v in h)
-            rr = limbs(11 * p - 1 if edge else rng.randrange(11 * p))
-            r, peak = strict_product_hi(p, rr, rr, h)
-            assert peak < 1 << 64
-            got = value(r)
-            assert got % p == (value(rr) ** 2 * rinv - ppp - 2 * q) % p and got < 6 * p
+        edge_y = [p - 1, p - 2, 1 << 254, (1 << 254) - 1, (1 << 254) - (1 << 232), (1 << 254) - (1 << 233) - 1, 1]
+        inv = {"x": c["INV_X"] * p, "y": c["INV_Y"] * p, "zz": c["INV_ZZ"] * p, "zzz": c["INV_ZZZ"] * p}
+        for it in range(1500):
+            at_edge = it % 5 == 0
+            acc_v = {k: (b - 1 - rng.randrange(4) if at_edge else rng.randrange(b)) for k, b in inv.items()}
+            acc = {k: limbs(v) for k, v in acc_v.items()}
+            x2 = p - 1 - rng.randrange(3) if at_edge else rng.randrange(p)
+            y = edge_y[it % len(edge_y)] if it < 4 * len(edge_y) else rng.randrange(1, p)
+            neg = rng.random() < 0.5
+            # the two table forms: the pre-split record holds p - y normalised; the 8-word twin negates limb by limb with NEG_Y_MULT p (raw)
+            for qy in ((limbs(p - y) if neg else limbs(y)), (kp_minus(p, c["NEG_Y_MULT"], limbs(y)) if neg else limbs(y))):
+                out, peak = _law(p, acc, limbs(x2), qy, c)
+                worst = max(worst, peak)
+                y2 = (p - y) % p if neg else y
+                U2, S2 = x2 * acc_v["zz"] * rinv, y2 * acc_v["zzz"] * rinv
+                Pd, Rr = (U2 - acc_v["x"]) % p, (S2 - acc_v["y"]) % p
+                PP = Pd * Pd * rinv % p; PPP = Pd * PP * rinv % p; Q = acc_v["x"] * PP * rinv % p
+                X3 = (Rr * Rr * rinv - PPP - 2 * Q) % p
+                Y3 = (Rr * (Q - X3) * rinv - acc_v["y"] * PPP * rinv) % p
+                want = {"pd": Pd, "r": Rr, "pp": PP, "ppp": PPP, "q": Q, "x3": X3, "y3": Y3, "zz": acc_v["zz"] * PP * rinv % p, "zzz": acc_v["zzz"] * PPP * rinv % p}
+                for name, v in out.items():
+                    assert value(v) % p == want[name], (F, it, name)
+                    assert inside(v, table[name]), (F, it, name, value(v) / p, table[name]["vmax"] / p)
+                    assert all(x <= M29 for x in v[:-1])
+                # the new accumulator is inside the invariants again
+                assert value(out["x3"]) < inv["x"] and value(out["y3"]) < inv["y"] and value(out["zz"]) < inv["zz"] and value(out["zzz"]) < inv["zzz"]
+    assert worst < 1 << 64
 
 
-def test_group_law_dot_product_takes_its_differences_raw():
-    """ec29.cuh y3 = r (q + 8 p - x3) + (8 p - y1) ppp: both differences enter the strict two-term dot product limb by limb, NOT normalised (limbs up to 2^31).
-    The worst column -- every limb at its maximum -- stays inside 64 bits, and the value is the one the normalised operands gave."""
-    rng = random.Random(11)
+def test_the_exact_zero_test_of_the_group_law_covers_every_multiple_of_p_below_its_bound():
+    """ec29.cuh fe29_is_multiple_of_p: a normalised value below EC29::PD_MAX p is 0 mod p iff limbs 5..7 and the low 22 bits of limb 8 are zero and limbs 0..4 equal k c"""
     for F, p in P.items():
-        rinv = pow(R, -1, p)
+        cpart = p - (1 << 254)
         pl = limbs(p)
-        n8 = limbs(8 * p)
-        k8 = [n8[0] + (1 << 30)] + [n8[i] + (1 << 30) - 2 for i in range(1, 8)] + [n8[8] - 2]
-        amax = [k8[i] + M29 for i in range(8)] + [k8[8] + (int(1.1 * p) >> 232)]
-        rmax, pppmax = [M29] * 8 + [(11 * p) >> 232], [M29] * 8 + [int(1.2 * p) >> 232]
-        carry = worst = 0
-        for col in range(2 * L - 1):
-            s = sum(rmax[i] * amax[col - i] + k8[i] * pppmax[col - i] for i in range(L) if 0 <= col - i < L)
-            s += sum(M29 * pl[j] for j in (1, 2, 3, 4, 8) if 0 <= col - j < L and col - j < col) + M29 + carry
-            worst, carry = max(worst, s), s >> W
-        assert worst < 0.7 * 2**64
-        for _ in range(2000):
-            r_, q, x3, y1, ppp = rng.randrange(11 * p), rng.randrange(int(1.1 * p)), rng.randrange(6 * p), rng.randrange(2 * p), rng.randrange(int(1.2 * p))
-            a = [limbs(q)[i] + k8[i] - limbs(x3)[i] for i in range(L)]
-            b = [k8[i] - limbs(y1)[i] for i in range(L)]
-            assert all(0 <= v < 1 << 32 for v in a + b) and value(a) == q + 8 * p - x3 and value(b) == 8 * p - y1
-            zero = [0] * L
-            # the two-term dot product, strict: model it as two products accumulated (strict_product_hi takes one pair: add the second pair's columns through `h` is not possible -- run the columns here)
-            col, m, out = 0, [0] * L, [0] * L
-            for k in range(2 * L - 1):
-                for i in range(L):
-                    if 0 <= k - i < L:
-                        col += limbs(r_)[i] * a[k - i] + b[i] * limbs(ppp)[k - i]
-                for j in (1, 2, 3, 4, 8):
-                    if 0 <= k - j < L and k - j < k:
-                        col += m[k - j] * pl[j]
-                assert col < 1 << 64
-                if k < L:
-                    m[k] = (-col) & M29; col += m[k]; col >>= W
-                else:
-                    out[k - L] = col & M29; col >>= W
-            out[L - 1] = col
-            assert value(out) % p == ((r_ * (q - x3) - y1 * ppp) * rinv) % p and value(out) < 2 * p
+
+        def is_multiple(a):
+            if a[5] | a[6] | a[7] | (a[8] & 0x3FFFFF): return False
+            k = a[8] >> 22
+            t, carry = [], 0
+            for j in range(5):
+                x = k * pl[j] + carry; t.append(x & M29); carry = x >> W
+            return a[:5] == t and carry == 0
+        rng = random.Random(5)
+        for k in list(range(B.EC29["PD_MAX"] + 1)) + [rng.randrange(1 << 19) for _ in range(50)]:
+            assert k * cpart < 1 << 145                                   # k c stays inside limbs 0..4
+            assert is_multiple(limbs(k * p))
+            for d in (1, 1 << 29, 1 << 145, 1 << 232):
+                assert not is_multiple(limbs(k * p + d))
 
 
-def test_negated_table_point_enters_its_product_raw():
-    """ec29.cuh: a negative digit adds (x, p - y); p - y is NOT normalised (limbs below 2^30 + 2^29) where it is a product's operand: s2 + 8 p - y1 = (p - y) zzz / 2^261 + h"""
-    rng = random.Random(13)
+def test_the_lane_forms_rounds_on_concrete_values_stay_inside_their_proven_bounds():
+    rng = random.Random(31)
     for F, p in P.items():
         rinv = pow(R, -1, p)
-        n1, n8 = limbs(2 * p), limbs(8 * p)                   # TWO p: with one p the top limb 2^22 - 2 - y_8 goes negative for y >= 2^254 - 2^233 (no carry pass lends to it)
-        k1 = [n1[0] + (1 << 30)] + [n1[i] + (1 << 30) - 2 for i in range(1, 8)] + [n1[8] - 2]
-        k8 = [n8[0] + (1 << 30)] + [n8[i] + (1 << 30) - 2 for i in range(1, 8)] + [n8[8] - 2]
-        assert value(k1) == 2 * p and all(0 <= v < 1 << 32 for v in k1)
-        edge = [p - 1, p - 2, 1 << 254, (1 << 254) - 1, (1 << 254) - (1 << 232), (1 << 254) - (1 << 233) - 1, 1]
-        for it in range(2000):
-            y, zzz, y1 = (edge[it] if it < len(edge) else rng.randrange(1, p)), rng.randrange(3 * p), rng.randrange(2 * p)
-            qy = [k1[i] - limbs(y)[i] for i in range(L)]
-            h = [k8[i] - limbs(y1)[i] for i in range(L)]
-            assert all(0 <= v < (1 << 30) + (1 << 29) for v in qy)
-            r, peak = strict_product_hi(p, qy, limbs(zzz), h)
-            assert peak < 1 << 63 and value(r) % p == ((p - y) * zzz * rinv - y1) % p and value(r) < 11 * p and value(qy) == 2 * p - y
-        worst = strict_product_hi(p, list(k1), [M29] * 8 + [(3 * p) >> 232], list(k8))[1]
-        assert worst < 1 << 63
+        table = B.prove_all()["fields"][F]["sponge"]
+        bound = B.SPONGE["LANES3_STATE_MILLI_P"] * p // 1000
+        for it in range(400):
+            st = [bound - 1 - rng.randrange(3) if it % 4 == 0 else rng.randrange(bound) for _ in range(3)]
+            mds = [[p - 1 - rng.randrange(2) if it % 4 == 0 else rng.randrange(p) for _ in range(3)] for _ in range(3)]
+            rc = [rng.randrange(p) for _ in range(3)]
+            x7 = []
+            for x in st:
+                xl = limbs(x)
+                x2, _ = model_product(p, [(xl, xl)], lazy=True); x4, _ = model_product(p, [(x2, x2)], lazy=True)
+                x6, _ = model_product(p, [(x4, x2)], lazy=True); t, _ = model_product(p, [(x6, xl)], lazy=True)
+                assert value(t) <= table["lanes3"]["x7"]["vmax"] and value(t) % p == pow(x, 7, p) * pow(rinv, 6, p) % p
+                x7.append(t)
+            for row in range(3):
+                out, _ = model_product(p, [(limbs(mds[row][cidx]), x7[cidx]) for cidx in range(3)], lazy=True, c=limbs(rc[row]))
+                assert value(out) < bound and value(out) <= table["lanes3"]["row"]["vmax"]
+                assert value(out) % p == (sum(mds[row][cidx] * value(x7[cidx]) for cidx in range(3)) + rc[row]) * rinv % p

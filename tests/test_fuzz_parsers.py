@@ -110,3 +110,21 @@ def test_libfuzzer_run_over_every_reader_is_clean(built, corpus, tmp_path):
     stats = dict(re.findall(r"^stat::(\w+):\s+(\d+)", r.stderr, flags=re.M))
     assert int(stats.get("number_of_executed_units", "0")) > 1000, tail
     print("libFuzzer:", stats)
+
+
+def test_boundary_host_logic_is_race_free_under_thread_sanitizer():
+    """the boundary's HOST logic -- api_verify.hip (slots, chunk pipeline, group commit of small callers, shape vote, device sharding, the
+    fallback that drains the device before a culprit search), host_core.hip (worker pool, tuning), the parsers and the fork choice -- built from the product's own
+    sources with clang -fsanitize=thread against a stand-in HIP runtime, the device layer stubbed with answers that depend on the job's bytes
+    (tests/fuzz/tsan_boundary.cpp), and hammered for 30 s: 6 state callers (single proofs that merge into shared jobs, small batches, multi-chunk calls over two
+    logical devices), 3 account callers, an installer re-installing the index and flipping the tuning mid-flight, a bad proof (folded failure -> culprit search)
+    or an unparseable one in every fifth call.  Done = no ThreadSanitizer report, every verdict as the stub device dictates, at least one culprit search ran.
+    The contract: "callable concurrently ... must be re-entrant" (the reference's callers: /root/reference/README.md:277-279)."""
+    subprocess.check_call(["make", "-C", FUZZ, "-s", "tsan"])
+    env = dict(os.environ, TSAN_OPTIONS="halt_on_error=0:second_deadlock_stack=1")
+    r = subprocess.run([os.path.join(FUZZ, "tsan_boundary"), os.path.join(ROOT, "tests", "golden", "state_proofs_k15_bytes.json"),
+                        os.path.join(ROOT, "tests", "golden", "account_proofs_bytes.json"), "30"], capture_output=True, text=True, timeout=600, env=env)
+    assert "ThreadSanitizer" not in r.stderr, r.stderr[-6000:]
+    assert r.returncode == 0, (r.returncode, r.stdout[-500:], r.stderr[-2000:])
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["wrong_verdicts"] == 0 and out["failed_calls"] == 0 and out["culprit_searches"] > 0 and out["device_jobs"] > 0 and out["account_jobs"] > 0 and out["installs"] > 10, out

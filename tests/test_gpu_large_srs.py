@@ -34,8 +34,13 @@ def test_srs_depth_2_18_matches_oracle(big):
 def test_msm_2_18_bases(big, oracle):
     c, curve, k, g, h = big
     n = 1 << k
+    import mina_bridge_amd as m
     sc = rand_scalars(n, P, seed=181)
-    assert (c.msm_srs(curve, sc) == oracle.msm_pippenger(curve, g, sc, threads=16)).all()
+    want = oracle.msm_pippenger(curve, g, sc, threads=16)
+    c.srs_split_table(curve)
+    for fp29 in (1, 2, 0):                                       # 4 M table points: the size that caught the one-p negation of round 4 (one table y in 2^21 reaches 2^254 - 2^233)
+        with m.lib.tuning(msm_fp29=fp29):
+            assert (c.msm_srs(curve, sc) == want).all(), fp29
     # a slice in the upper half of the table and the variable-base path on the same points
     assert (c.msm_srs_range(curve, 200000, sc[:50000]) == oracle.msm_pippenger(curve, g[200000:250000], sc[:50000], threads=16)).all()
     assert (c.msm(curve, g[100000:230000], sc[:130000]) == oracle.msm_pippenger(curve, g[100000:230000], sc[:130000], threads=16)).all()
@@ -50,5 +55,9 @@ def test_accumulator_check_k18(big, oracle):
     s = oracle.b_poly_coefficients(fs, chals)
     assert (c.b_poly_coefficients(fs, chals) == s).all()
     sg = oracle.msm_pippenger(curve, g, s, threads=16)
-    assert c.accumulator_check_batch(curve, k, pre, sg).tolist() == [1]
-    assert c.accumulator_check_multi(curve, k, np.concatenate([pre, pre]), np.stack([sg, g[7]])).tolist() == [1, 0]
+    import mina_bridge_amd as m
+    c.srs_split_table(curve)
+    for fp29 in (1, 2):
+        with m.lib.tuning(msm_fp29=fp29):
+            assert c.accumulator_check_batch(curve, k, pre, sg).tolist() == [1], fp29
+            assert c.accumulator_check_multi(curve, k, np.concatenate([pre, pre]), np.stack([sg, g[7]])).tolist() == [1, 0], fp29

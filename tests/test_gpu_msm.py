@@ -268,6 +268,7 @@ def test_fixed_base_msm_on_29_bit_limbs_equals_the_8x32_law_and_the_oracle(ctx_s
     g, _ = srs_oracle[curve]
     r = SCALAR_MOD[curve]
     n = 4096
+    ctx_srs.srs_split_table(curve)                                # msm_fp29 = 2 reads it (without it the setting behaves as 1)
     sets = {"uniform": rand_scalars(n, r, seed=501), "bits128": rand_scalars(n, r, seed=502, bits=128),
             "all_equal": oracle.ints_to_le([0x1234567890ABCDEF1234567890ABCDEF % r] * n),
             "limb_edges": oracle.ints_to_le([((1 << 29) - 1) << (29 * (i % 8)) | (1 << (29 * (i % 9))) % r for i in range(n)]),
@@ -275,20 +276,22 @@ def test_fixed_base_msm_on_29_bit_limbs_equals_the_8x32_law_and_the_oracle(ctx_s
     for name, sc in sets.items():
         want = oracle.msm_pippenger(curve, g[:n], sc, threads=8)
         assert (ctx_srs.msm_srs(curve, sc) == want).all(), name
-        with m.lib.tuning(msm_fp29=0):
-            assert (ctx_srs.msm_srs(curve, sc) == want).all(), name + " (8 x 32)"
+        for fp29, label in ((0, " (8 x 32)"), (1, " (29-bit limbs, 8-word twin table)"), (2, " (29-bit limbs, pre-split table)")):
+            with m.lib.tuning(msm_fp29=fp29):
+                assert (ctx_srs.msm_srs(curve, sc) == want).all(), name + label
     multi = np.stack([rand_scalars(n, r, seed=600 + i) for i in range(6)])
     got = ctx_srs.msm_srs_multi(curve, multi, 6)
-    with m.lib.tuning(msm_fp29=0):
-        ref = ctx_srs.msm_srs_multi(curve, multi, 6)
-    assert (got == ref).all()
+    for fp29 in (0, 1, 2):
+        with m.lib.tuning(msm_fp29=fp29):
+            ref = ctx_srs.msm_srs_multi(curve, multi, 6)
+        assert (got == ref).all(), fp29
     assert (got[3] == oracle.msm_pippenger(curve, g[:n], multi[3], threads=8)).all()
 
 
 def test_29_bit_group_law_handles_equal_and_opposite_points_exactly(oracle, srs_oracle):
     """the exceptional cases of the mixed add (the accumulator equals the next point, or its negative) never occur on the real SRS; an SRS crafted to
     contain them -- g[1] = g[0], g[3] = -g[2], g[5] = g[4] = g[6] -- loaded through mina_srs_load puts equal and opposite points into ONE bucket when their
-    scalars agree: the fp29 path must find P = 0 (mod p) on lazily reduced limbs and take the doubling / infinity branch (ec29.cuh xyzz29_add_affine_rare)"""
+    scalars agree: the fp29 path must find P = 0 (mod p) on lazily reduced limbs and hand the bucket to the 8 x 32 law's redo queue (ec29.cuh xyzz29_add_affine returns false; msm.cuh msm_bucket_redo_kernel)"""
     import mina_bridge_amd as m
     curve, n = 1, 256
     g, h = srs_oracle[curve]
@@ -299,6 +302,7 @@ def test_29_bit_group_law_handles_equal_and_opposite_points_exactly(oracle, srs_
     c = m.MinaContext(0)
     try:
         c.srs_load(curve, _srs_blob(oracle, curve, g, h))
+        c.srs_split_table(curve)
         assert (c.srs_get_g(curve, 0, n) == g).all()
         rng = np.random.Generator(np.random.PCG64(77))
         for trial in range(4):
@@ -308,7 +312,7 @@ def test_29_bit_group_law_handles_equal_and_opposite_points_exactly(oracle, srs_
             if trial == 1: sc[8:] = 0                                                   # nothing else in those buckets: acc == next point at the second entry
             if trial == 2: sc[4] = 0; sc[5] = 0; sc[6] = 0                              # only the opposite pair: the bucket goes through infinity
             want = oracle.msm_naive(curve, g, sc)
-            for fp29 in (1, 0):
+            for fp29 in (2, 1, 0):
                 with m.lib.tuning(msm_fp29=fp29):
                     assert (c.msm_srs(curve, sc) == want).all(), (trial, fp29)
                     assert (c.msm_srs_multi(curve, np.stack([sc] * 5), 5)[2] == want).all(), (trial, fp29, "bucket-lane form")
@@ -345,6 +349,7 @@ def test_29_bit_group_law_on_table_points_at_the_top_of_the_field(oracle, srs_or
     c = m.MinaContext(0)
     try:
         c.srs_load(curve, _srs_blob(oracle, curve, g, h))
+        c.srs_split_table(curve)
         assert (c.srs_get_g(curve, 0, n) == g).all()
         for trial in range(4):
             sc = rand_scalars(n, SCALAR_MOD[curve], seed=900 + trial)
@@ -359,7 +364,7 @@ def test_29_bit_group_law_on_table_points_at_the_top_of_the_field(oracle, srs_or
                 keep = [b0 + i for i in range(len(special)) for b0 in (10, 100, 200)]
                 mask = np.ones(n, bool); mask[keep] = False; sc[mask] = 0
             want = oracle.msm_naive(curve, g, sc)
-            for fp29 in (1, 0):
+            for fp29 in (2, 1, 0):
                 with m.lib.tuning(msm_fp29=fp29):
                     assert (c.msm_srs(curve, sc) == want).all(), (trial, fp29)
                     assert (c.msm_srs_multi(curve, np.stack([sc] * 5), 5)[3] == want).all(), (trial, fp29, "bucket-lane form")

@@ -14,6 +14,7 @@ dev = torch.device("cuda:0")
 ctx = m.MinaContext(0)
 ctx.poseidon_set_params(0, m.poseidon_params.default_params_bytes(0)); ctx.poseidon_set_params(1, m.poseidon_params.default_params_bytes(1))
 ctx.srs_create(CURVE_VESTA, 1 << 16)
+if m.lib.verify_tuning_get().msm_fp29 >= 2: ctx.srs_split_table(CURVE_VESTA)
 pre8, sg8 = make_accumulators(ctx, 8, 4242)
 d_pre8 = torch.from_numpy(pre8.reshape(-1)).to(dev); d_sg8 = torch.from_numpy(sg8.reshape(-1)).to(dev); d_v8 = torch.zeros(8, dtype=torch.int32, device=dev)
 ctx.set_pipeline(lanes)

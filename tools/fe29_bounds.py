@@ -1,0 +1,298 @@
+#!/usr/bin/env python3
+"""Interval proofs for the 9 x 29-bit-limb routines of mina_bridge_amd/csrc/fp29.cuh / ec29.cuh (VERDICT r04 "next" #5).
+
+The lazy forms trade normalisation for value growth: a column of `v_mad_u64_u32` products must stay below 2^64, a limb-wise "K p - b" must not go negative in
+ANY limb (there is no carry pass to lend to it -- the round-4 bug: `p - y` with ONE p underflowed the top limb for one table point in 2^21 and only a 2^18-point
+GPU test saw it), a top limb must fit its 32-bit register, and the value bounds the callers rely on must be fixed points of what they iterate.  Until round 5 those
+rules lived in comments.  Here every operand carries an INTERVAL -- a maximum per limb and a maximum for the integer -- every routine is the column loop of
+tools/gen_fe29.py on those maxima, and the users of the routines (the XYZZ mixed add, the Poseidon lane forms) are written once more as SPECS over intervals:
+
+    python tools/fe29_bounds.py            prints the proven table; exit code 1 (and no table) if any rule fails
+    tools/gen_fe29.py                      runs `prove_all()` first and REFUSES to write fp29.cuh when it fails; the constants the specs were proven with
+                                           (the K of every "K p - b", the invariants) are emitted into fp29.cuh as `struct EC29` -- ec29.cuh uses the names,
+                                           so the C++ cannot drift from what was proven
+    tests/test_fe29_lazy_model.py          imports the table (no restated numbers) and checks it against random and adversarial concrete values
+
+Arithmetic to match: ark-ff 0.3 `Fp256` over the Pasta primes (/root/reference/core/Cargo.toml:19-21) -- the same field elements in another limb form."""
+from __future__ import annotations
+
+L, W = 9, 29
+M29 = (1 << W) - 1
+R = 1 << (L * W)
+TOP = W * (L - 1)                                               # bit position of limb 8
+P = {0: 0x40000000000000000000000000000000224698fc094cf91b992d30ed00000001, 1: 0x40000000000000000000000000000000224698fc0994a8dd8c46eb2100000001}
+
+
+class BoundError(AssertionError):
+    pass
+
+
+def need(cond, msg):
+    if not cond:
+        raise BoundError(msg)
+
+
+def limbs_of(x: int):
+    return [(x >> (W * i)) & M29 for i in range(L - 1)] + [x >> TOP]
+
+
+class V:
+    """a 9-limb operand: `limb[i]` = largest value limb i can hold (all limbs are >= 0), `vmax` = largest value of the integer sum limb_i 2^(29 i);
+    `normal`: limbs 0..7 are below 2^29 (the value determines the limbs)"""
+
+    def __init__(self, limb, vmax, normal, name=""):
+        self.limb, self.vmax, self.normal, self.name = list(limb), int(vmax), normal, name
+        need(all(0 <= x < 1 << 32 for x in self.limb), f"{name}: a limb does not fit its 32-bit register: {[hex(x) for x in self.limb]}")
+
+    def __repr__(self):
+        return f"V({self.name}: < {self.vmax / P[0]:.4f} p, top limb <= {self.limb[8]:#x}, {'normalised' if self.normal else 'raw, limbs <= 2^%.2f' % __import__('math').log2(max(self.limb[:8]) + 1)})"
+
+
+def norm(vmax_exclusive: int, name="") -> V:
+    """a normalised value below `vmax_exclusive`"""
+    v = vmax_exclusive - 1
+    return V([M29] * (L - 1) + [v >> TOP], v, True, name)
+
+
+def kp_redundant(p: int, mult: int, lend: int):
+    """MULT p in the redundant limb form of ec29.cuh: limb 0 + 2^lend, limbs 1..7 + 2^lend - 2^(lend - 29), limb 8 - 2^(lend - 29): the same integer, every
+    limb of 0..7 at least 2^lend - 2^(lend-29) -- above any normalised subtrahend limb (lend = 30) or above a + 2 b of normalised limbs (lend = 31)"""
+    n = limbs_of(mult * p)
+    u = 1 << (lend - W)
+    k = [n[0] + (1 << lend)] + [n[i] + (1 << lend) - u for i in range(1, L - 1)] + [n[8] - u]
+    need(sum(x << (W * i) for i, x in enumerate(k)) == mult * p, "redundant form is not MULT p")
+    need(all(0 <= x < 1 << 32 for x in k), f"{mult} p: redundant limb outside 32 bits")
+    return k
+
+
+class Prover:
+    def __init__(self, field: int):
+        self.F, self.p = field, P[field]
+        self.pl = limbs_of(self.p)
+        need(self.pl[0] == 1 and self.pl[5] == self.pl[6] == self.pl[7] == 0 and self.pl[8] == 1 << 22, "Pasta prime shape")
+        self.log = []                                           # (routine, what, worst column / 2^64, result bound in p)
+
+    # ---- the generated column loop (tools/gen_fe29.py `body`) on maxima
+    def product(self, what, pairs, lazy=False, hi: V | None = None, c: V | None = None) -> V:
+        """sum of a_t * b_t over `pairs` (+ c before the reduction) / 2^261 (+ hi after it); lazy: quotient digits not masked (< 2^32)"""
+        p, pl = self.p, self.pl
+        mmax = (1 << 32) - 1 if lazy else M29
+        carry = 0
+        worst = 0
+        for k in range(2 * L - 1):
+            col = carry
+            for a, b in pairs:
+                for i in range(L):
+                    if 0 <= k - i < L:
+                        col += a.limb[i] * b.limb[k - i]
+            for j in (1, 2, 3, 4, 8):
+                i = k - j
+                if 0 <= i < L and i < k:
+                    col += mmax * pl[j]
+            if hi is not None and k >= L:
+                col += hi.limb[k - L]
+            if c is not None and k < L:
+                col += c.limb[k]
+            if k < L:
+                col += mmax                                     # + m_k p_0
+            worst = max(worst, col)
+            need(col < 1 << 64, f"{what}: column {k} can reach {col / 2**64:.3f} x 2^64")
+            carry = col >> W
+        tmax = sum(a.vmax * b.vmax for a, b in pairs) + (c.vmax if c is not None else 0)
+        mtot = sum(mmax << (W * k) for k in range(L))           # the quotient, as an integer
+        vmax = (tmax + mtot * p) // R + (hi.vmax if hi is not None else 0)
+        top = min(carry + (hi.limb[8] if hi is not None else 0), vmax >> TOP)
+        need(top < 1 << 32, f"{what}: the top limb can reach {top:#x}")
+        out = V([M29] * (L - 1) + [top], vmax, True, what)
+        self.log.append((what, "product" + (" (lazy)" if lazy else ""), worst / 2**64, vmax / p))
+        return out
+
+    def mul(self, what, a, b, **kw): return self.product(what, [(a, b)], **kw)
+    def sqr(self, what, a, **kw):
+        need(all(x < 1 << 31 for x in a.limb[:8]), f"{what}: a doubled limb (a_i << 1) does not fit 32 bits")
+        return self.product(what, [(a, a)], **kw)                   # (the doubled cross terms are the same column sums)
+
+    # ---- limb-wise forms of ec29.cuh (no carry pass unless said)
+    def kp_minus(self, what, mult: int, b: V) -> V:
+        """MULT p - b limb by limb, NOT normalised: every limb must stay >= 0 by itself"""
+        need(b.normal, f"{what}: subtrahend must be normalised")
+        k = kp_redundant(self.p, mult, 30)
+        for i in range(L):
+            need(k[i] - b.limb[i] >= 0, f"{what}: limb {i} of {mult} p - b goes negative (K_{i} = {k[i]:#x}, b_{i} up to {b.limb[i]:#x}): use a larger multiple of p")
+        out = V(k, mult * self.p, False, what)
+        self.log.append((what, f"{mult} p - b, raw", None, mult))
+        return out
+
+    def add_kp_minus(self, what, mult: int, a: V, b: V) -> V:
+        k = self.kp_minus(what, mult, b)
+        return V([a.limb[i] + k.limb[i] for i in range(L)], a.vmax + mult * self.p, False, what)
+
+    def kp_minus_a_minus_2b(self, what, mult: int, a: V, b: V) -> V:
+        need(a.normal and b.normal, f"{what}: operands must be normalised")
+        k = kp_redundant(self.p, mult, 31)
+        for i in range(L):
+            need(k[i] - a.limb[i] - 2 * b.limb[i] >= 0, f"{what}: limb {i} of {mult} p - a - 2 b goes negative (a_{i} up to {a.limb[i]:#x}, b_{i} up to {b.limb[i]:#x})")
+        self.log.append((what, f"{mult} p - a - 2 b, raw", None, mult))
+        return V(k, mult * self.p, False, what)
+
+    def sub_kp(self, what, mult: int, a: V, b: V) -> V:
+        """a + MULT p - b WITH the carry pass (normalised result): the lower limbs lend, so the condition is on the integers: b <= a + MULT p"""
+        need(a.normal and b.normal, f"{what}: operands must be normalised")
+        need(b.vmax <= mult * self.p, f"{what}: b can exceed {mult} p")
+        return norm(a.vmax + mult * self.p + 1, what)
+
+    def select(self, what, a: V, b: V) -> V:
+        return V([max(x, y) for x, y in zip(a.limb, b.limb)], max(a.vmax, b.vmax), a.normal and b.normal, what)
+
+
+# ------------------------------------------------------------------------------------------------ SPEC: the XYZZ mixed add of ec29.cuh
+# Invariants of the accumulator (units of p), the K of every limb-wise "K p - b", and which products run LAZY (quotient digits unmasked: 9 masks less, + 7 p on
+# the result).  Round 5: six of the nine products are lazy -- every one whose result only feeds products or a "K p - b" -- and the invariants grew to their new
+# fixed point (round 4: all strict, x < 6 p, y < 2 p, zz, zzz < 3 p, K = 8 / 8 / 4 / 8).  With a seventh lazy product (any of q, x3, y3) the invariants have NO fixed
+# point: the bounds feed each other (x3 -> K -> pd -> pp -> q -> x3) faster than the 1 / 128 of a product damps them and grow until a top limb leaves its register
+# (`search_lazy_sets`, all 36 + 9 + 1 larger subsets).  ec29.cuh is compiled with these names (`struct EC29` in fp29.cuh, emitted by gen_fe29.py).
+EC29 = {"INV_X": 26, "INV_Y": 6, "INV_ZZ": 10, "INV_ZZZ": 9, "NEG_Y_MULT": 2, "SUB_X1_MULT": 27, "SUB_Y1_MULT": 7, "X3_SUB_MULT": 23, "SUB_X3_MULT": 27, "PD_MAX": 36}
+EC29_LAZY = ("pd", "r", "pp", "ppp", "zz", "zzz")
+
+
+def prove_group_law(field: int, c=None, lazy=None):
+    """xyzz29_add_affine (ec29.cuh), statement by statement, on intervals.  Table coordinates canonical (< p) -- y or its negation, normalised (the pre-split table)
+    or the raw K p - y (the 8-word twin); accumulator within the invariants; the new accumulator must be within them again, and so must the first point's assignment."""
+    c = dict(EC29, **(c or {}))
+    lazy = EC29_LAZY if lazy is None else lazy
+    pr = Prover(field); p = pr.p
+    qx, py = norm(p, "table x"), norm(p, "table y")
+    acc = {"x": norm(c["INV_X"] * p, "acc.x"), "y": norm(c["INV_Y"] * p, "acc.y"), "zz": norm(c["INV_ZZ"] * p, "acc.zz"), "zzz": norm(c["INV_ZZZ"] * p, "acc.zzz")}
+    # first point of a bucket: acc = (qx, +-py, 1, 1); -py = 0 + 1 p - py with the carry pass (8-word twin) or the table's own normalised p - py
+    first_y = pr.select("first y", py, pr.sub_kp("p - py (first point)", 1, norm(1, "0"), py))
+    need(qx.vmax < c["INV_X"] * p and first_y.vmax < c["INV_Y"] * p, "the first point breaks the invariants")
+    qy = pr.select("qy", py, pr.kp_minus("-py = K p - py", c["NEG_Y_MULT"], py))
+    pd = pr.mul("pd = qx zz1 + K p - x1", qx, acc["zz"], hi=pr.kp_minus("K p - x1", c["SUB_X1_MULT"], acc["x"]), lazy="pd" in lazy)
+    r = pr.mul("r = qy zzz1 + K p - y1", qy, acc["zzz"], hi=pr.kp_minus("K p - y1", c["SUB_Y1_MULT"], acc["y"]), lazy="r" in lazy)
+    pp = pr.sqr("pp = pd^2", pd, lazy="pp" in lazy)
+    ppp = pr.mul("ppp = pd pp", pd, pp, lazy="ppp" in lazy)
+    q = pr.mul("q = x1 pp", acc["x"], pp, lazy="q" in lazy)
+    x3 = pr.sqr("x3 = r^2 + K p - ppp - 2 q", r, hi=pr.kp_minus_a_minus_2b("K p - ppp - 2 q", c["X3_SUB_MULT"], ppp, q), lazy="x3" in lazy)
+    y3 = pr.product("y3 = r (q + K p - x3) + (K p - y1) ppp", [(r, pr.add_kp_minus("q + K p - x3", c["SUB_X3_MULT"], q, x3)), (pr.kp_minus("K p - y1 (dot)", c["SUB_Y1_MULT"], acc["y"]), ppp)],
+                    lazy="y3" in lazy)
+    zz = pr.mul("zz3 = zz1 pp", acc["zz"], pp, lazy="zz" in lazy)
+    zzz = pr.mul("zzz3 = zzz1 ppp", acc["zzz"], ppp, lazy="zzz" in lazy)
+    for name, v, inv in (("x", x3, "INV_X"), ("y", y3, "INV_Y"), ("zz", zz, "INV_ZZ"), ("zzz", zzz, "INV_ZZZ")):
+        need(v.vmax < c[inv] * p, f"group law: new acc.{name} can reach {v.vmax / p:.3f} p, invariant {c[inv]} p")
+    # the exact zero test of pd (fe29_is_multiple_of_p: pd = k p with k = pd_8 >> 22, k c compared on limbs 0..4) needs k c < 2^145: k < 2^20; PD_MAX is what the comment quotes
+    need(pd.vmax < c["PD_MAX"] * p and c["PD_MAX"] < 1 << 20, f"pd can reach {pd.vmax / p:.2f} p: beyond PD_MAX")
+    # xyzz29_leave multiplies a coordinate by 2^256 mod p (strict product) and subtracts p at most once
+    for name in ("x", "y", "zz", "zzz"):
+        need(pr.mul(f"leave {name}", acc[name], norm(p, "2^256 mod p")).vmax < 2 * p, f"leaving acc.{name}: one conditional subtraction is not enough")
+    return pr, {"pd": pd, "r": r, "pp": pp, "ppp": ppp, "q": q, "x3": x3, "y3": y3, "zz": zz, "zzz": zzz, "qy": qy}
+
+
+def least_fixed_point(field: int, lazy):
+    """the smallest invariants / multiples under which `prove_group_law` holds for the lazy set, grown from round 4's; ("ok", constants) or ("fail", why)"""
+    inv = {"INV_X": 6, "INV_Y": 2, "INV_ZZ": 3, "INV_ZZZ": 3}
+    x3m = 4
+    for _ in range(4000):
+        c = dict(inv, NEG_Y_MULT=2, SUB_X1_MULT=inv["INV_X"] + 1, SUB_Y1_MULT=inv["INV_Y"] + 1, X3_SUB_MULT=x3m, SUB_X3_MULT=inv["INV_X"] + 1, PD_MAX=1 << 19)
+        try:
+            prove_group_law(field, c, lazy)
+            return "ok", c
+        except BoundError as e:
+            msg = str(e)
+            if "p - a - 2 b goes negative" in msg: x3m += 1
+            elif "q + K p - x3" in msg and "goes negative" in msg: inv["INV_X"] += 1
+            elif "new acc." in msg: inv[{"x": "INV_X", "y": "INV_Y", "zz": "INV_ZZ", "zzz": "INV_ZZZ"}[msg.split("new acc.")[1].split(" ")[0]]] += 1
+            else: return "fail", msg
+    return "fail", "no fixed point within 4000 steps"
+
+
+def search_lazy_sets():
+    """which subsets of the nine products can run lazy (both fields): the exploration that chose EC29_LAZY, kept runnable:  python -c "import fe29_bounds as b; b.search_lazy_sets()" """
+    import itertools
+    names = ["pd", "r", "pp", "ppp", "q", "x3", "y3", "zz", "zzz"]
+    for n in range(len(names), -1, -1):
+        found = []
+        for S in itertools.combinations(names, n):
+            r = [least_fixed_point(f, S) for f in (0, 1)]
+            if all(x[0] == "ok" for x in r):
+                found.append((S, {k: max(r[0][1][k], r[1][1][k]) for k in r[0][1] if k != "PD_MAX"}))
+        print(n, "lazy products:", len(found), "of", len(list(itertools.combinations(names, n))), "subsets have a fixed point")
+        for S, c in found:
+            print("   ", S, c)
+        if found:
+            return found
+
+
+# ------------------------------------------------------------------------------------------------ SPEC: the Poseidon rounds' lane forms (sponge.cuh)
+# state bound (units of p / 1000) each lane form keeps between rounds; MDS entries and round constants are canonical (< p)
+SPONGE = {"LANES3_STATE_MILLI_P": 8300, "LANES8_STATE_MILLI_P": 16500, "LANES16_STATE_MILLI_P": 24400}
+
+
+def prove_sponge_rounds(field: int, c=None):
+    c = dict(SPONGE, **(c or {}))
+    pr = Prover(field); p = pr.p
+    mds, rc = norm(p, "MDS entry"), norm(p, "round constant x 2^261")
+    out = {}
+    # 3 lanes per sponge (the chip-filling form): x^2, x^4, x^6, x^7 lazily, then the row: three products and the round constant in ONE lazy reduction
+    x = norm(c["LANES3_STATE_MILLI_P"] * p // 1000, "state (3-lane)")
+    x2 = pr.sqr("3-lane x^2", x, lazy=True); x4 = pr.sqr("3-lane x^4", x2, lazy=True); x6 = pr.mul("3-lane x^6", x4, x2, lazy=True); x7 = pr.mul("3-lane x^7", x6, x, lazy=True)
+    row = pr.product("3-lane MDS row + rc", [(mds, x7)] * 3, lazy=True, c=rc)
+    need(row.vmax < x.vmax + 1, f"3-lane: a round maps a state below {x.vmax / p:.3f} p to {row.vmax / p:.3f} p")
+    out["lanes3"] = {"x2": x2, "x4": x4, "x7": x7, "row": row}
+    # 8 lanes: the state element is u + swap(u), u a two-term half row (+ rc in one of the halves)
+    x = norm(c["LANES8_STATE_MILLI_P"] * p // 1000, "state (8-lane)")
+    x2 = pr.sqr("8-lane x^2", x, lazy=True); x3 = pr.mul("8-lane x^3", x2, x, lazy=True); x4 = pr.sqr("8-lane x^4", x2, lazy=True); x7 = pr.mul("8-lane x^7", x3, x4, lazy=True)
+    half = pr.product("8-lane half row + rc", [(mds, x7)] * 2, lazy=True, c=rc)
+    need(2 * half.vmax < x.vmax + 1, f"8-lane: a round maps a state below {x.vmax / p:.3f} p to {2 * half.vmax / p:.3f} p")
+    out["lanes8"] = {"x7": x7, "half": half}
+    # 16 lanes: the state element is the sum of three single products (one carries rc)
+    x = norm(c["LANES16_STATE_MILLI_P"] * p // 1000, "state (16-lane)")
+    x2 = pr.sqr("16-lane x^2", x, lazy=True); x3 = pr.mul("16-lane x^3", x2, x, lazy=True); x4 = pr.sqr("16-lane x^4", x2, lazy=True); x7 = pr.mul("16-lane x^7", x3, x4, lazy=True)
+    one = pr.product("16-lane product + rc", [(mds, x7)], lazy=True, c=rc)
+    need(3 * one.vmax < x.vmax + 1, f"16-lane: a round maps a state below {x.vmax / p:.3f} p to {3 * one.vmax / p:.3f} p")
+    out["lanes16"] = {"x7": x7, "one": one}
+    # the way out of every form: one STRICT product by 2^256 mod p must land below 2^256 (fe29_to_words) and below 2 p (one conditional subtraction)
+    for key in ("LANES3_STATE_MILLI_P", "LANES8_STATE_MILLI_P", "LANES16_STATE_MILLI_P"):
+        leave = pr.mul(f"leave ({key})", norm(c[key] * p // 1000), norm(p, "2^256 mod p"))
+        need(leave.vmax < 2 * p and leave.vmax < 1 << 256, f"{key}: leaving the permutation needs more than one conditional subtraction")
+    return pr, out
+
+
+def prove_all():
+    """every spec for both fields; returns {"ec29": {...}, "sponge": {...}, "log": [...]}, raises BoundError otherwise"""
+    table = {"constants": {"EC29": dict(EC29), "SPONGE": dict(SPONGE)}, "fields": {}}
+    for f in (0, 1):
+        g, gv = prove_group_law(f)
+        s, sv = prove_sponge_rounds(f)
+        table["fields"][f] = {"group_law": {k: {"vmax": v.vmax, "top_limb": v.limb[8]} for k, v in gv.items()},
+                              "group_law_worst_column": max(w for _, _, w, _ in g.log if w is not None),
+                              "sponge": {form: {k: {"vmax": v.vmax} for k, v in d.items()} for form, d in sv.items()},
+                              "sponge_worst_column": max(w for _, _, w, _ in s.log if w is not None),
+                              "log": g.log + s.log}
+    return table
+
+
+def emit_constants() -> str:
+    """the proven constants as C++ (pasted into fp29.cuh by gen_fe29.py --write; ec29.cuh / sponge.cuh read them)"""
+    t = prove_all()
+    wc = max(t["fields"][f]["group_law_worst_column"] for f in (0, 1)); ws = max(t["fields"][f]["sponge_worst_column"] for f in (0, 1))
+    lines = ["// proven by tools/fe29_bounds.py (interval model of every routine and of the callers' value discipline; gen_fe29.py refuses to write this file otherwise):",
+             f"//   group law: worst column {wc:.3f} x 2^64; Poseidon lane forms: worst column {ws:.3f} x 2^64",
+             "struct EC29 {      // xyzz29_add_affine: accumulator invariants (units of p) and the multiple of p in every limb-wise \"K p - b\" (no limb may go negative)"]
+    lines += [f"    static constexpr uint32_t {k} = {v};" for k, v in EC29.items()]
+    lines += ["};", "struct SPONGE29 {   // the Poseidon lane forms' state bounds between rounds, in thousandths of p (fixed points of a lazy round)"]
+    lines += [f"    static constexpr uint32_t {k} = {v};" for k, v in SPONGE.items()]
+    lines += ["};"]
+    return "\n".join(lines)
+
+
+if __name__ == "__main__":
+    import sys
+    try:
+        t = prove_all()
+    except BoundError as e:
+        print("fe29_bounds: NOT PROVEN --", e, file=sys.stderr)
+        sys.exit(1)
+    for f in (0, 1):
+        print(f"field {f}: group law worst column {t['fields'][f]['group_law_worst_column']:.3f} x 2^64, sponge worst column {t['fields'][f]['sponge_worst_column']:.3f} x 2^64")
+        for what, kind, w, vb in t["fields"][f]["log"]:
+            print(f"  {what:48s} {kind:22s} {'' if w is None else '%.3f x 2^64' % w:18s} < {vb:.4f} p")

@@ -39,9 +39,9 @@ def mads(terms, fresh=False):
     return out
 
 
-def body(col_terms, lazy=False, hi=None, fresh=None):
-    """hi: name of a 9-limb operand h (limbs below 2^32) added to the HIGH half -- columns 9 .. 17 -- before the carries: the result is (sum + m p) / 2^261 + h exactly"""
-    fresh = lazy if fresh is None else fresh
+def body(col_terms, lazy=False, hi=None, fresh=True):
+    """hi: name of a 9-limb operand h (limbs below 2^32) added to the HIGH half -- columns 9 .. 17 -- before the carries: the result is (sum + m p) / 2^261 + h exactly.
+    fresh (round 5: every form): the accumulator starts from the first product of column 0 instead of a zero (two v_mov less per routine)"""
     out = ["    uint64_t col, cc; fe29_t r;" if fresh else "    uint64_t col = 0, cc; fe29_t r;", "    uint32_t " + ", ".join(f"m{i}" for i in range(L)) + ";",
            "    const uint32_t p1 = P29<F>::L1, p2 = P29<F>::L2, p3 = P29<F>::L3, p4 = P29<F>::L4, p8 = P29<F>::L8;"]
     for k in range(2 * L - 1):
@@ -126,13 +126,13 @@ def emit_sqr_hi():
     return pre + body(terms, False, hi="h", fresh=True) + ["}"]
 
 
-def emit_mul_hi():
+def emit_mul_hi(lazy=False):
     def terms(k):
         for i in range(L):
             j = k - i
             if 0 <= j < L:
                 yield (f"a.v[{i}]", f"b.v[{j}]")
-    return ["template <int F> __device__ __forceinline__ fe29_t fe29_mul_hi_asm(const fe29_t &a, const fe29_t &b, const fe29_t &h) {"] + body(terms, False, hi="h", fresh=True) + ["}"]
+    return [f"template <int F> __device__ __forceinline__ fe29_t fe29_mul_hi_{'lz' if lazy else 'asm'}(const fe29_t &a, const fe29_t &b, const fe29_t &h) {{"] + body(terms, lazy, hi="h", fresh=True) + ["}"]
 
 
 def emit_dot3rc_lz():
@@ -168,16 +168,31 @@ def emit_dot2():
 
 
 def generated():
-    return "\n".join(["// ---- GENERATED by tools/gen_fe29.py: do not edit by hand"] + emit_mul() + emit_sqr() + emit_dot2() + emit_dot3() + emit_mul(True) + emit_sqr(True) + emit_dot3rc_lz() + emit_mulrc_lz() + emit_dot2rc_lz() + emit_sqr_hi() + emit_mul_hi() + ["// ---- END GENERATED"]) + "\n"
+    return "\n".join(["// ---- GENERATED by tools/gen_fe29.py: do not edit by hand"] + emit_mul() + emit_sqr() + emit_dot2() + emit_dot3() + emit_mul(True) + emit_sqr(True) + emit_dot3rc_lz() + emit_mulrc_lz() + emit_dot2rc_lz() + emit_sqr_hi() + emit_mul_hi() + emit_mul_hi(True) + ["// ---- END GENERATED"]) + "\n"
+
+
+def proven_constants():
+    """tools/fe29_bounds.py: the interval proofs of every routine above AND of their callers' value discipline (the XYZZ mixed add of ec29.cuh, the Poseidon lane
+    forms of sponge.cuh).  Raises fe29_bounds.BoundError -- nothing is written -- when a column can reach 2^64, a limb-wise "K p - b" can go negative in a limb,
+    a top limb can outgrow its register or an invariant is not a fixed point.  The constants the proofs ran with are emitted as C++ for the callers to use BY NAME."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import fe29_bounds
+    return "// ---- PROVEN CONSTANTS (tools/gen_fe29.py <- tools/fe29_bounds.py): do not edit by hand\n" + fe29_bounds.emit_constants() + "\n// ---- END PROVEN CONSTANTS\n"
+
+
+def rewrite(s: str) -> str:
+    """fp29.cuh with both generated regions replaced"""
+    text, consts = generated(), proven_constants()
+    a, b = s.index("// ---- GENERATED by tools/gen_fe29.py"), s.index("// ---- END GENERATED")
+    s = s[:a] + text.rstrip("\n") + s[b + len("// ---- END GENERATED"):]
+    a, b = s.index("// ---- PROVEN CONSTANTS"), s.index("// ---- END PROVEN CONSTANTS")
+    return s[:a] + consts.rstrip("\n") + s[b + len("// ---- END PROVEN CONSTANTS"):]
 
 
 if __name__ == "__main__":
-    text = generated()
     if "--write" in sys.argv:
         p = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mina_bridge_amd", "csrc", "fp29.cuh")
-        s = open(p).read()
-        a, b = s.index("// ---- GENERATED by tools/gen_fe29.py"), s.index("// ---- END GENERATED")
-        s = s[:a] + text.rstrip("\n") + s[b + len("// ---- END GENERATED"):]
-        open(p, "w").write(s)
+        new = rewrite(open(p).read())                              # a BoundError from the proofs is raised here: the file is only opened for writing afterwards
+        open(p, "w").write(new)
     else:
-        sys.stdout.write(text)
+        sys.stdout.write(proven_constants() + generated())
