@@ -455,6 +455,42 @@ def boundary_leg(m, devices: str, B: int, min_seconds: float = 2.0):
         assert all(o.all() for o in outs)
         return {"value": sum(counts) * B / el, "unit": "proofs/s", "calls": sum(counts)}
     two, four = callers(2), callers(4)
+    # What ONE bad opening per call costs everybody: a folded check that fails sends its chunk through the culprit search, which drains the device and holds
+    # its lock for the length of the search.  Caller 1 sends B good proofs per call; caller 2 sends B proofs with ONE bad opening (z1 with a flipped bit: the folded
+    # opening check of its chunk fails, the search finds exactly that proof); both for min_seconds.  Reported: the clean caller's rate beside it, and the searcher's call time.
+    search_cost = None
+    try:
+        flat, used = m.lib.wrap_proof_flatten(items[0][0], m.lib.ENC_BINCODE, exact=False)
+        z1 = bytes(flat[-192:-160])                                   # the flat form ends with z1 z2 delta sg (include/mina_verify.h)
+        at = items[0][0].find(z1)
+        if at >= 0 and items[0][0].find(z1, at + 1) < 0:
+            badp = bytearray(items[0][0]); badp[at] ^= 1
+            bad_job = _Batch(lib, items, B)
+            bad_pos = (B // 2) - ((B // 2) % len(items))                  # an entry that holds items[0]
+            bad_job.PP[bad_pos] = bytes(badp); bad_job.PL[bad_pos] = len(badp)
+            bad_job.call()
+            assert np.flatnonzero(bad_job.out == 0).tolist() == [bad_pos], "a bad opening must fail exactly its proof (culprit search)"
+            stop = [False]; counts = [0, 0]; lat = []
+            def clean_w():
+                o = np.zeros(B, np.uint8)
+                while not stop[0]:
+                    job.call(o); counts[0] += 1
+            def bad_w():
+                o = np.zeros(B, np.uint8)
+                while not stop[0]:
+                    t_ = time.perf_counter(); bad_job.call(o); lat.append(time.perf_counter() - t_); counts[1] += 1
+            th = [threading.Thread(target=clean_w), threading.Thread(target=bad_w)]
+            t0 = time.perf_counter()
+            for t in th: t.start()
+            time.sleep(min_seconds); stop[0] = True
+            for t in th: t.join()
+            el = time.perf_counter() - t0
+            search_cost = {"clean_caller_beside_a_searching_caller": counts[0] * B / el, "clean_caller_beside_a_clean_caller": two["value"] / 2, "unit": "proofs/s",
+                           "searching_caller_ms_per_call": sorted(lat)[len(lat) // 2] * 1e3 if lat else None, "searching_caller_calls": counts[1], "proofs_per_call": B,
+                           "note": "one bad opening per call of the second caller: its chunk's folded check fails and the 4-way culprit search runs with the device drained and its lock held "
+                                   "(api_verify.hip fallback); the first column is what a well-behaved caller keeps beside it"}
+    except Exception as e:                                            # noqa: BLE001 -- a diagnostic leg: never takes the line down
+        search_cost = {"error": repr(e)[:300]}
     # one call of 8 x B proofs: chunks of B, at most four on the GPU at a time
     big = None
     if B == 8192:
@@ -468,7 +504,7 @@ def boundary_leg(m, devices: str, B: int, min_seconds: float = 2.0):
         c5 = c5_job.timed(1.0, min_calls=3)
     res = {"value": single["value"], "unit": "proofs/s", "proofs_per_call": B, "ms_per_call": single["ms_per_call"], "calls_timed": single["calls"],
            "bytes_per_proof": len(job.P[0]) + len(job.Q[0]), "host_threads": int(os.environ.get("MINA_HOST_THREADS", min((os.cpu_count() or 2) // 2, 64))), "usable_cores": usable_cores(),
-           "two_caller_threads": two, "four_caller_threads": four, "one_call_of_65536": big, "c5_4096_per_call": c5, "devices": devices,
+           "two_caller_threads": two, "four_caller_threads": four, "one_bad_opening_per_call": search_cost, "one_call_of_65536": big, "c5_4096_per_call": c5, "devices": devices,
            "entry_point": "mina_verify_state_batch (include/mina_verify.h): bincode MinaStateProof + MinaStatePubInputs bytes -> verdict bytes",
            "poseidon_constants": m.lib.poseidon_params_name(), "process": "a fresh process holding only libminaverify.so (no torch): the operator's verifier process",
            "note": "host bytes in, bools out: parsing, to_input flattening, ledger + consensus checks, pinned staging, PCIe both ways, the GPU job (folding "
@@ -661,7 +697,13 @@ def main():
     ap.add_argument("--no-probes", action="store_true", help="skip the isolated-kernel / C2 probes and the sustained / C5 legs (profiling runs: only the timed loop launches kernels)")
     ap.add_argument("--no-boundary", action="store_true", help="skip the bytes -> bools legs (mina_verify_state_batch on serialized proofs)")
     ap.add_argument("--boundary-jobs", type=int, default=0, help="proofs per call of the bytes -> bools legs (default: min(--jobs, 8192))")
+    ap.add_argument("--preflight", action="store_true",
+                    help="the check to run FIRST on a multi-GPU node (VERDICT r04 next #7; no node was available to any round): every rank reports LOCAL_RANK, the device it bound and "
+                         "that device's PCI bus id, the rank count the collectives backend saw, runs ONE small step + the verdict all-gather; rank 0 prints one JSON line and the "
+                         "exit code is non-zero if two ranks share a device without shared_gpu, the backend saw != N ranks, or a verdict is wrong.  No throughput figure.")
     args = ap.parse_args()
+    if args.preflight:
+        args.steps, args.warmup, args.jobs, args.pipeline, args.no_probes, args.no_boundary, args.no_cpu_baseline = 1, 1, min(args.jobs, 64), 1, True, True, True
     if args.kimchi:
         args.mode = "kimchi"
     args.kimchi = args.mode != "prepared"                      # the wrap leg starts from the raw proof in both non-prepared modes
@@ -812,6 +854,54 @@ def main():
     assert verdicts_ok(args.steps), "timed-region verdicts must be ACCEPT"
     if gathered is not None:
         assert all(int(g.sum()) == B for g in gathered), "every rank's shard must be ACCEPT"
+
+    if args.preflight:
+        import socket
+        try:
+            bus = getattr(torch.cuda.get_device_properties(local_rank), "pci_bus_id", None)
+            dom = getattr(torch.cuda.get_device_properties(local_rank), "pci_domain_id", 0)
+            dv_ = getattr(torch.cuda.get_device_properties(local_rank), "pci_device_id", 0)
+            bus_id = None if bus is None else f"{dom:04x}:{bus:02x}:{dv_:02x}"
+        except Exception:                                        # noqa: BLE001 -- a torch without the PCI fields: the uuid names the device as well
+            bus_id = None
+        if bus_id is None:
+            bus_id = str(getattr(torch.cuda.get_device_properties(local_rank), "uuid", f"device{local_rank}"))
+        mine = {"rank": rank, "local_rank_env": int(os.environ.get("LOCAL_RANK", "0")), "device_bound": local_rank, "pci_bus_id": bus_id, "host": socket.gethostname(),
+                "devices_visible": torch.cuda.device_count(), "hbm_total_GiB": round(hbm_total / 2**30, 1), "verdicts_accept": bool(verdicts_ok(1))}
+        facts, backend_ranks, summed = [mine], 1, 1.0
+        if dist_on:
+            facts = [None] * world
+            dist.all_gather_object(facts, mine)
+            backend_ranks = dist.get_world_size()
+            one = torch.ones(1, dtype=torch.float32, device="cpu" if share_gpu else dev)
+            dist.all_reduce(one)                                 # on the data-path backend (RCCL unless the ranks share a GPU): every rank must have contributed
+            summed = float(one.item())
+        ctx.close()
+        rc = 0
+        if rank == 0:
+            problems = []
+            seen = {}
+            pretend = os.environ.get("MINA_BENCH_PREFLIGHT_PRETEND_DISTINCT") == "1"      # test hook: shared ranks that claim to own their GPUs -> the same-device rule must fire
+            if pretend: share_gpu = False
+            for f_ in facts:
+                key = (f_["host"], f_["pci_bus_id"])
+                if key in seen and not share_gpu: problems.append(f"ranks {seen[key]} and {f_['rank']} are bound to the same device {f_['pci_bus_id']} without shared_gpu")
+                seen.setdefault(key, f_["rank"])
+                if not f_["verdicts_accept"]: problems.append(f"rank {f_['rank']}: the step's verdicts are not all ACCEPT")
+                if not share_gpu and not pretend and f_["device_bound"] != f_["local_rank_env"]: problems.append(f"rank {f_['rank']} bound device {f_['device_bound']}, LOCAL_RANK says {f_['local_rank_env']}")
+            if backend_ranks != args.gpus or int(round(summed)) != args.gpus: problems.append(f"the backend saw {backend_ranks} ranks (all-reduce of ones = {summed}), --gpus says {args.gpus}")
+            if gathered is not None and len(gathered) != world: problems.append("the verdict all-gather did not return one shard per rank")
+            print(json.dumps({"preflight": True, "ok": not problems, "problems": problems, "n_gpus": args.gpus, "world_size": world, "shared_gpu": bool(share_gpu and dist_on),
+                              "backend": ("gloo (ranks share one GPU)" if share_gpu else "cpu:gloo,cuda:nccl (RCCL)") if dist_on else "none", "backend_ranks": backend_ranks,
+                              "all_reduce_of_ones": summed, "ranks": facts, "launcher": os.environ.get("MINA_BENCH_LAUNCHER", "torch.distributed.run" if dist_on else "none"),
+                              "step": {"proofs_per_rank": B, "verdict_all_gather_shards": len(gathered) if gathered is not None else 0}}), flush=True)
+            rc = 1 if problems else 0
+        if dist_on:
+            t = torch.tensor([rc], dtype=torch.int32)
+            dist.broadcast(t, src=0)                             # every rank leaves with rank 0's verdict (CPU tensor -> gloo)
+            rc = int(t.item())
+            dist.destroy_process_group()
+        raise SystemExit(rc)
 
     # the same loop for >= 2 s whatever --steps was (pipeline fill / drain is then a small part of the sample); secondary key
     sustained = None

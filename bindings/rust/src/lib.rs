@@ -43,12 +43,14 @@ impl Ctx {
     }
 }
 
-/// Drop-in for Aligned's `verify_mina_state_ffi`: the bytes of `bincode::serialize(&MinaStateProof)` / `(&MinaStatePubInputs)`
+/// Stands where Aligned's `verify_mina_state_ffi` stands: the bytes of `bincode::serialize(&MinaStateProof)` / `(&MinaStatePubInputs)`
 /// (core/src/aligned.rs:33-36).  Process-wide context, every failure is `false`.
+/// NEVER COMPILED: this crate is generated from include/mina_verify.h and diffed against it (tests/test_abi.py); the image it was written in has no cargo.
+/// Before calling it a drop-in, build it and link it under the caller of core/src/aligned.rs:31-58.
 pub fn verify_mina_state(proof: &[u8], pub_input: &[u8]) -> bool {
     unsafe { mina_verify_state(proof.as_ptr(), proof.len(), pub_input.as_ptr(), pub_input.len()) }
 }
-/// Drop-in for `verify_account_inclusion_ffi` (core/src/aligned.rs:46-49).
+/// Stands where `verify_account_inclusion_ffi` stands (core/src/aligned.rs:46-49); never compiled either (see above).
 pub fn verify_account_inclusion(proof: &[u8], pub_input: &[u8]) -> bool {
     unsafe { mina_verify_account(proof.as_ptr(), proof.len(), pub_input.as_ptr(), pub_input.len()) }
 }

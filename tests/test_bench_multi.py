@@ -98,3 +98,44 @@ def test_gpus_2_under_torch_distributed_run():
         assert line["shared_gpu"] is True and line["gpus_physical"] == torch.cuda.device_count()
     else:
         assert "shared_gpu" not in line and "RCCL" in line["config"]["sharding"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [2, 8])
+def test_preflight_reports_every_rank_and_passes_on_shared_ranks(n):
+    """`bench.py --gpus N --preflight` (the check to run first on a real multi-GPU node): one JSON line with every rank's LOCAL_RANK, bound device and
+    PCI bus id, the backend's rank count, one small step + the verdict all-gather; exit code 0.  On this 1-GPU box the N ranks share GPU 0 and the line says so."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", str(n), "--preflight"], capture_output=True, text=True, timeout=1800, env=clean_env())
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{"preflight"')][-1])
+    assert line["ok"] is True and line["problems"] == [] and line["n_gpus"] == n == line["world_size"] == line["backend_ranks"] and line["all_reduce_of_ones"] == float(n)
+    assert sorted(f["rank"] for f in line["ranks"]) == list(range(n)) and all(f["verdicts_accept"] and f["pci_bus_id"] for f in line["ranks"])
+    assert line["step"]["verdict_all_gather_shards"] == n
+    import torch
+    if torch.cuda.device_count() < n:
+        assert line["shared_gpu"] is True and len({f["pci_bus_id"] for f in line["ranks"]}) == torch.cuda.device_count()
+    else:
+        assert line["shared_gpu"] is False and len({f["pci_bus_id"] for f in line["ranks"]}) == n
+
+
+@pytest.mark.gpu
+def test_preflight_fails_when_two_ranks_bind_one_device_without_saying_so():
+    """two ranks forced onto device 0 while claiming their own GPUs: the preflight must exit non-zero and name the ranks (a 2-GPU box would run this as a real
+    mis-binding; on a 1-GPU box MINA_BENCH_PREFLIGHT_PRETEND_DISTINCT makes the shared ranks claim to be distinct)"""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--preflight"], capture_output=True, text=True, timeout=1800, env=clean_env(MINA_BENCH_PREFLIGHT_PRETEND_DISTINCT="1"))
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{"preflight"')][-1])
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two real GPUs: the ranks ARE distinct")
+    assert r.returncode != 0 and line["ok"] is False and any("same device" in p_ for p_ in line["problems"]), line
+
+
+@pytest.mark.gpu
+def test_c_abi_all_devices_leg_over_eight_logical_contexts():
+    """the product's own multi-device path (ONE process, $MINA_VERIFY_DEVICES = 0 x 8: eight logical contexts on this box's GPU): a call's proofs cut into eight shards,
+    one pipeline per context, a tampered proof in every shard fails alone, BASELINE C5's 4096-proof call over the eight"""
+    r = subprocess.run([sys.executable, BENCH, "--boundary-all-devices", "0,0,0,0,0,0,0,0", "64"], capture_output=True, text=True, timeout=1800, env=clean_env(GPU_MAX_HW_QUEUES="16"))
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    ad = json.loads(r.stdout.strip().splitlines()[-1])
+    assert "error" not in ad and "skipped" not in ad, ad
+    assert ad["n_devices"] == 8 and ad["distinct_gpus"] == 1 and ad["proofs_per_call"] == 512 and ad["value_all_devices"] > 0 and ad["c5_4096_per_call"]["value"] > 0

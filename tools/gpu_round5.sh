@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 5: ONE script for every GPU-box call; stages named on the command line, outputs under gpurun_out/<tag>/.
-#   tools/gpu_round5.sh <tag> stage [stage ...]     stages: fe52 sharded pytest msm c2ab bench bench20 gpus2 microbench profile c2 account callers
+#   tools/gpu_round5.sh <tag> stage [stage ...]     stages: fe52 sharded pytest msm c2ab abr04 multi bench bench20 gpus2 microbench profile c2 account callers
 cd $GRAFT_REPO_ROOT
 TAG=$1; shift
 O=gpurun_out/$TAG; mkdir -p $O
@@ -21,6 +21,8 @@ for st in "$@"; do
               timeout 300 python tools/c2_rate.py 16 400 2>/dev/null | tail -1 ;;
     msm)      ( time timeout 2400 python -m pytest tests/test_gpu_msm.py tests/test_gpu_large_srs.py tests/test_gpu_ipa.py tests/test_gpu_sponge_ipa.py -m gpu -q -x ) > $O/pytest_msm.log 2>&1; tail -5 $O/pytest_msm.log ;;
     c2ab)     for rep in 1 2 3; do for t in 2 1 0; do echo -n "msm_fp29=$t "; MINA_TUNE=msm_fp29=$t timeout 300 python tools/c2_rate.py 16 400 2>/dev/null | tail -1; done; done | tee $O/c2_ab.log ;;
+    multi)    ( time timeout 3000 python -m pytest tests/test_bench_multi.py tests/test_sharded_state_job.py -m gpu -q ) > $O/pytest_multi.log 2>&1; tail -6 $O/pytest_multi.log ;;
+    abr04)    bash tools/ab_c2.sh tools/probes/bin/lib_r04.so 3 2>&1 | tee $O/ab_c2_r04.log ;;   # A = this build, B = the round-4 library (tools/probes/bin/lib_r04.so, built from 4076b66), same box
     account)  timeout 600 python tools/c4_rate.py > $O/c4_rate.log 2>&1; tail -8 $O/c4_rate.log ;;
     callers)  timeout 600 python tools/concurrent_callers.py 6 > $O/concurrent_callers.log 2>&1; tail -12 $O/concurrent_callers.log ;;
     *) echo "unknown stage $st" ;;
