@@ -674,7 +674,8 @@ typedef struct mina_verify_tuning {
     uint32_t search_fan;           /* 4     fan-out of the culprit search (2 .. 32) */
     uint32_t search_full;          /* 0     1 = every part of a culprit search repeats its transcripts */
     uint32_t msm_fp29;             /* 1     SRS-table MSMs accumulate their buckets on 29-bit limbs: 1 = points gathered from the 64-byte twin table (8 x 32 words in the 2^261 domain),
-                                            2 = from the pre-split 128-byte records (x, y, p - y as 29-bit limbs: no conversion, no negation, twice the gather traffic); 0: the 8 x 32-bit law */
+                                            2 = from the pre-split 128-byte records (x, y, p - y as 29-bit limbs: no conversion, no negation, twice the gather traffic; needs mina_srs_split_table),
+                                            3 = as 1, and in the multi-MSM form the buckets STAY on 29-bit limbs through the 2-D bucket reduction; 0: the 8 x 32-bit law */
 } mina_verify_tuning;
 void mina_verify_tuning_default(mina_verify_tuning *out);
 int mina_verify_tuning_get(mina_verify_tuning *out);

@@ -23,7 +23,8 @@ static int run_msm(mina_ctx *c, const MsmShape &sh, const uint32_t *d_scalars, c
                    const affine_t *d_points29 = nullptr /* the table's 2^261-domain twin (SrsState::table29): the accumulate kernels then run on 29-bit limbs (ec29.cuh) */,
                    const void *d_points29s = nullptr /* ... or its pre-split form (SrsState::table29s, tab29_t records; mina_verify_tuning.msm_fp29 = 2) */) {
     if (d_points29 && !mb_tune().msm_fp29) d_points29 = nullptr;      // cross-check switch: the 8 x 32 law everywhere
-    const bool split = d_points29 && d_points29s && mb_tune().msm_fp29 >= 2;
+    const bool split = d_points29 && d_points29s && mb_tune().msm_fp29 == 2;
+    bool red29 = false;                                              // msm_fp29 = 3: the buckets of the multi-MSM form stay on 29-bit limbs and the 2-D reduction runs on them too
     MsmWorkspace &w = c->L->ws;
     const FieldK &fk = c->fk[F];
     if (sh.nprob == 0 || sh.nsets % sh.nprob) return fail(MINA_ERR_ARG, "bad problem count");
@@ -57,6 +58,8 @@ static int run_msm(mina_ctx *c, const MsmShape &sh, const uint32_t *d_scalars, c
     const bool bucket_lanes = part_sort && sh.nprob >= 4;                                 // >= 64 k lanes of ~62 adds each
     if (bucket_lanes) {
         if ((rc = w.order.ensure((size_t)nb_total * 4))) return rc;
+        red29 = d_points29 && !split && mb_tune().msm_fp29 == 3;
+        if (red29 && ((rc = w.buckets29.ensure((size_t)nb_total * sizeof(xyzz29_t))) || (rc = w.seg_bad.ensure(((size_t)(sh.NB / 128) + 128) * sh.nsets * 4)))) return rc;
     } else {                                                    // task numbering and the 128-B task partials
         if ((rc = w.task_start.ensure(((size_t)nb_total + 1) * 4))) return rc;
         if ((rc = w.rem_pos.ensure((size_t)nb_total * 4))) return rc;
@@ -106,14 +109,16 @@ static int run_msm(mina_ctx *c, const MsmShape &sh, const uint32_t *d_scalars, c
         { ProfScope ps_(c, PS_ACCUMULATE);
           if (d_points29) {
               if (split) msm_accumulate_bucket29_kernel<F, 2><<<cdiv(nb_total / 2, 256), 256, 0, st>>>(nb_total, ss.SB, w.start.as<uint32_t>(), w.order.as<uint32_t>(), w.sorted.as<uint32_t>(), d_points29s, fk.one, fk.m32,
-                                                                                                 w.buckets.as<xyzz_t>(), w.info.as<uint32_t>(), w.redo.as<uint32_t>());
+                                                                                                 w.buckets.as<xyzz_t>(), w.info.as<uint32_t>(), w.redo.as<uint32_t>(), nullptr);
               else msm_accumulate_bucket29_kernel<F, 1><<<cdiv(nb_total / 2, 256), 256, 0, st>>>(nb_total, ss.SB, w.start.as<uint32_t>(), w.order.as<uint32_t>(), w.sorted.as<uint32_t>(), d_points29, fk.one, fk.m32,
-                                                                                           w.buckets.as<xyzz_t>(), w.info.as<uint32_t>(), w.redo.as<uint32_t>());
+                                                                                           w.buckets.as<xyzz_t>(), w.info.as<uint32_t>(), w.redo.as<uint32_t>(), red29 ? w.buckets29.as<xyzz29_t>() : nullptr);
               msm_bucket_redo_kernel<F><<<16, 64, 0, st>>>(w.start.as<uint32_t>(), w.info.as<uint32_t>(), w.redo.as<uint32_t>(), w.sorted.as<uint32_t>(), d_points, fk.one, w.buckets.as<xyzz_t>());
           }
           else msm_accumulate_bucket_kernel<F><<<cdiv(nb_total / 2, 256), 256, 0, st>>>(nb_total, ss.SB, w.start.as<uint32_t>(), w.order.as<uint32_t>(), w.sorted.as<uint32_t>(), d_points, fk.one, w.buckets.as<xyzz_t>()); }
         { ProfScope ps_(c, PS_BUCKET_SUM);
-          msm_bucket_heavy_entries_kernel<F><<<128, 256, 0, st>>>(w.start.as<uint32_t>(), w.info.as<uint32_t>(), w.heavy.as<uint32_t>(), w.sorted.as<uint32_t>(), d_points, fk.one, w.buckets.as<xyzz_t>()); }
+          msm_bucket_heavy_entries_kernel<F><<<128, 256, 0, st>>>(w.start.as<uint32_t>(), w.info.as<uint32_t>(), w.heavy.as<uint32_t>(), w.sorted.as<uint32_t>(), d_points, fk.one, w.buckets.as<xyzz_t>());
+          // the buckets the two 8 x 32 kernels wrote join the others on 29-bit limbs (none on SRS points with unstructured scalars: a fixed-size launch that finds empty lists)
+          if (red29) msm_buckets_to29_kernel<F><<<16, 64, 0, st>>>(w.info.as<uint32_t>(), w.heavy.as<uint32_t>(), w.redo.as<uint32_t>(), w.buckets.as<xyzz_t>(), fk.m32, w.buckets29.as<xyzz29_t>()); }
     } else {
         { ProfScope ps_(c, PS_ACCUMULATE);
           if (d_points29) {
@@ -141,7 +146,7 @@ static int run_msm(mina_ctx *c, const MsmShape &sh, const uint32_t *d_scalars, c
         // 2-D bucket reduction: C = 128 columns, R = NB / C rows (NB is a power of two in [128, 32768])
         const uint32_t C = 128, log2C = 7, R = sh.NB / C;
         SegSum rows, cols;
-        const bool coop = c->nlanes == 1;                      // one MSM at a time: latency form; pipelined lanes: throughput form
+        const bool coop = c->nlanes == 1 && !red29;            // one MSM at a time: latency form; pipelined lanes: throughput form (the 29-bit reduction has the throughput form only)
         const uint32_t chunk = coop ? SEG_CHUNK : 16, lpg = coop ? 4 : 1;
         rows.nseg = R * sh.nsets; rows.per_set = R; rows.len = C; rows.seg_stride = C; rows.elem_stride = 1; rows.lanes = C / chunk;
         cols.nseg = C * sh.nsets; cols.per_set = C; cols.len = R; cols.seg_stride = 1; cols.elem_stride = C;
@@ -149,7 +154,13 @@ static int run_msm(mina_ctx *c, const MsmShape &sh, const uint32_t *d_scalars, c
         const uint32_t threads_rows = rows.nseg * rows.lanes * lpg, threads_cols = cols.nseg * cols.lanes * lpg;
         const uint32_t blocks = cdiv(threads_rows > threads_cols ? threads_rows : threads_cols, 256);
         { ProfScope ps_(c, PS_REDUCE_A);
-          if (coop) msm_segsum_kernel<F, true><<<dim3(blocks, 2), 256, 0, st>>>(sh.NB, rows, cols, w.buckets.as<xyzz_t>(), w.red_r.as<xyzz_t>(), w.red_ws.as<xyzz_t>());
+          if (red29) {
+              const uint32_t nseg = rows.nseg + cols.nseg;
+              HIPC(hipMemsetAsync(w.seg_bad.p, 0, (size_t)nseg * 4, st));
+              msm_segsum29_kernel<F><<<dim3(blocks, 2), 256, 0, st>>>(sh.NB, rows, cols, w.buckets29.as<xyzz29_t>(), fk.one, w.red_r.as<xyzz_t>(), w.red_ws.as<xyzz_t>(), w.seg_bad.as<uint32_t>());
+              msm_segsum29_redo_kernel<F><<<cdiv(nseg, 64), 64, 0, st>>>(sh.NB, rows, cols, w.buckets29.as<xyzz29_t>(), fk.one, w.red_r.as<xyzz_t>(), w.red_ws.as<xyzz_t>(), w.seg_bad.as<uint32_t>());
+          }
+          else if (coop) msm_segsum_kernel<F, true><<<dim3(blocks, 2), 256, 0, st>>>(sh.NB, rows, cols, w.buckets.as<xyzz_t>(), w.red_r.as<xyzz_t>(), w.red_ws.as<xyzz_t>());
           else msm_segsum_kernel<F, false><<<dim3(blocks, 2), 256, 0, st>>>(sh.NB, rows, cols, w.buckets.as<xyzz_t>(), w.red_r.as<xyzz_t>(), w.red_ws.as<xyzz_t>()); }
         const uint32_t Gr = (R + 15) / 16, Gc = C / 16;
         { ProfScope ps_(c, PS_REDUCE_BC);

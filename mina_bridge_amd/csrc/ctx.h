@@ -73,7 +73,7 @@ struct SrsState {
 };
 
 struct MsmWorkspace {
-    DevBuf scalars, points, ekey, eval, eoff, count, start, task_start, rem_pos, rem_bucket, info, sorted, partial, heavy, order, redo, ghist, stage, buckets, red_r, red_ws, red2_r, red2_w, set_total, out_words, out_xyzz;
+    DevBuf scalars, points, ekey, eval, eoff, count, start, task_start, rem_pos, rem_bucket, info, sorted, partial, heavy, order, redo, ghist, stage, buckets, red_r, red_ws, red2_r, red2_w, set_total, out_words, out_xyzz, buckets29, seg_bad;
 };
 
 // HIP-event stage timing on the context stream (off by default; bench.py turns it on for the timed region)
@@ -102,7 +102,7 @@ struct Lane {
     void release_all() {
         MsmWorkspace &w = ws;
         DevBuf *all[] = {&w.scalars, &w.points, &w.ekey, &w.eval, &w.eoff, &w.count, &w.start, &w.task_start, &w.rem_pos, &w.rem_bucket, &w.info, &w.sorted, &w.partial, &w.heavy, &w.order, &w.redo, &w.ghist, &w.stage,
-                         &w.buckets, &w.red_r, &w.red_ws, &w.red2_r, &w.red2_w, &w.set_total, &w.out_words, &w.out_xyzz, &tmp_a, &tmp_b, &tmp_c, &tmp_d,
+                         &w.buckets, &w.buckets29, &w.seg_bad, &w.red_r, &w.red_ws, &w.red2_r, &w.red2_w, &w.set_total, &w.out_words, &w.out_xyzz, &tmp_a, &tmp_b, &tmp_c, &tmp_d,
                          &bp_ltab, &bp_htab, &bp_partial, &bp_ldig, &bp_hdig, &bp_colsum, &ipa_chals, &ipa_folded, &ipa_xyzz_a, &ipa_xyzz_b, &ipa_points, &ipa_scalars,
                          &ipa_sigma, &ipa_in_a, &ipa_in_b, &ipa_in_c, &ipa_verdict, &ipa_xfer, &ipa_shared, &ipa_shared_off,
                          &st_ok, &st_hashes, &st_pub_xyzz, &st_pubcomm, &st_flags, &st_in, &st_verdicts,

@@ -116,6 +116,22 @@ template <int F> __device__ __forceinline__ bool xyzz29_add_affine(xyzz29_t &acc
     for (int i = 0; i < L29; ++i) qy.v[i] = neg ? qy.v[i] : py.v[i];
     return xyzz29_add_affine<F>(acc, inf, qx, qy, [&]() { return neg ? fe29_sub_kp<F, 1>(fe29_zero(), py) : py; }, []() {}, m32);
 }
+// a += b for two accumulators on 29-bit limbs, NEITHER infinity (add-2008-s on XYZZ: 12 products + 2 squares; the callers handle infinity).  Both within the
+// invariants of EC29, the sum within them again (fe29_bounds.py prove_group_add; multiples EC29::G_*).  Ten of the fourteen products lazy.
+// Returns FALSE -- a untouched -- when the points are equal or opposite (P = 0 mod p, found exactly as in the mixed add): the caller recomputes its unit of work
+// with the complete 8 x 32 law (msm.cuh: msm_segsum29_redo_kernel).
+template <int F> __device__ __forceinline__ bool xyzz29_add(xyzz29_t &a, const xyzz29_t &b) {
+    const fe29_t u1 = fe29_mul_lz<F>(a.x, b.zz), s1 = fe29_mul_lz<F>(a.y, b.zzz);                                                              // < 10.1 p, < 8.5 p
+    const fe29_t pd = fe29_mul_hi_lz<F>(b.x, a.zz, fe29_kp_minus<F, EC29::G_U1_MULT>(u1)), r = fe29_mul_hi_lz<F>(b.y, a.zzz, fe29_kp_minus<F, EC29::G_S1_MULT>(s1));   // u2 + K p - u1 < 22.1 p, s2 + K p - s1 < 18.5 p
+    if (__builtin_expect((pd.v[5] | pd.v[6] | pd.v[7] | (pd.v[8] & 0x3fffffu)) == 0u, 0))
+        if (fe29_is_multiple_of_p<F>(pd)) return false;
+    const fe29_t pp = fe29_sqr_lz<F>(pd), ppp = fe29_mul_lz<F>(pd, pp), q = fe29_mul_asm<F>(u1, pp);                                            // < 11.8 p, < 10.1 p, < 2 p
+    const fe29_t x3 = fe29_sqr_hi_asm<F>(r, fe29_kp_minus_a_minus_2b<F, EC29::G_X3_SUB_MULT>(ppp, q));                                         // < 19.7 p
+    const fe29_t y3 = fe29_dot2_asm<F>(r, fe29_add_kp_minus<F, EC29::G_SUB_X3_MULT>(q, x3), fe29_kp_minus<F, EC29::G_S1_MULT>(s1), ppp);       // r (q - x3) - s1 ppp < 5 p
+    a.zz = fe29_mul_lz<F>(fe29_mul_lz<F>(a.zz, b.zz), pp); a.zzz = fe29_mul_lz<F>(fe29_mul_lz<F>(a.zzz, b.zzz), ppp);                          // < 8.9 p, < 8.7 p
+    a.x = x3; a.y = y3;
+    return true;
+}
 // the bucket value in the 8 x 32 form the rest of the MSM reads (canonical Montgomery-2^256 XYZZ; infinity = zz 0)
 template <int F> __device__ __forceinline__ xyzz_t xyzz29_leave(const xyzz29_t &acc, bool inf, const fe_t &one) {
     if (inf) return xyzz_inf();

@@ -94,6 +94,11 @@ struct EC29 {      // xyzz29_add_affine: accumulator invariants (units of p) and
     static constexpr uint32_t X3_SUB_MULT = 23;
     static constexpr uint32_t SUB_X3_MULT = 27;
     static constexpr uint32_t PD_MAX = 36;
+    // xyzz29_add (two accumulators): the multiples under u1 = x1 zz2, s1 = y1 zzz2, ppp + 2 q and x3
+    static constexpr uint32_t G_U1_MULT = 12;
+    static constexpr uint32_t G_S1_MULT = 10;
+    static constexpr uint32_t G_X3_SUB_MULT = 16;
+    static constexpr uint32_t G_SUB_X3_MULT = 20;
 };
 struct SPONGE29 {   // the Poseidon lane forms' state bounds between rounds, in thousandths of p (fixed points of a lazy round)
     static constexpr uint32_t LANES3_STATE_MILLI_P = 8300;

@@ -664,10 +664,13 @@ template <int F, int TAB>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
 msm_accumulate_bucket29_kernel(uint32_t nb_total, uint32_t nb_prob, const uint32_t *__restrict__ start, const uint32_t *__restrict__ order,
                                const uint32_t *__restrict__ sorted, const void *__restrict__ points29_, fe_t one, fe_t m32,
-                               xyzz_t *__restrict__ buckets, uint32_t *__restrict__ info, uint32_t *__restrict__ redo) {
+                               xyzz_t *__restrict__ buckets, uint32_t *__restrict__ info, uint32_t *__restrict__ redo,
+                               xyzz29_t *__restrict__ buckets29 /* non-null: the bucket STAYS on 29-bit limbs (the 2-D reduction then runs on them too: msm_segsum29_kernel) */) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= nb_total / 2) return;
+    // lane r takes the buckets of rank r and nb-1-r (the waves of a launch end together).  One bucket per lane in rank order -- twice the waves, 4 per SIMD when a
+    // launch is alone -- was measured in round 5: the same rate with 16 lanes in flight (12.67 against 12.76 k checks/s on one box), 15 % slower alone (6.9 against 8.2 k)
     const uint32_t m = r / (nb_prob / 2), lr = r - m * (nb_prob / 2);
 #pragma unroll 1
     for (int half = 0; half < 2; ++half) {
@@ -705,10 +708,27 @@ msm_accumulate_bucket29_kernel(uint32_t nb_total, uint32_t nb_prob, const uint32
                 }
             }
         }
-        if (exact) buckets[b] = xyzz29_leave<F>(acc, inf, one);
-        else redo[atomicAdd(&info[3], 1u)] = b;                  // two of its points are equal or opposite: msm_bucket_redo_kernel sums this bucket with the 8 x 32 law
+        if (!exact) redo[atomicAdd(&info[3], 1u)] = b;           // two of its points are equal or opposite: msm_bucket_redo_kernel sums this bucket with the 8 x 32 law
+        else if (buckets29) { if (inf) { acc.x = fe29_zero(); acc.y = acc.x; acc.zz = acc.x; acc.zzz = acc.x; } buckets29[b] = acc; }      // infinity = zz 0, as in the 8 x 32 form
+        else buckets[b] = xyzz29_leave<F>(acc, inf, one);
     }
 #endif
+}
+// the buckets the 8 x 32 kernels wrote (the heavy ones, info[2], and the redone ones, info[3]) into the 29-bit form beside the others: x 2^256 -> x 2^261 is one
+// product by mont(32) per coordinate.  Fixed-size launch, grid-stride over both lists.
+template <int F>
+__global__ void __launch_bounds__(64)
+msm_buckets_to29_kernel(const uint32_t *__restrict__ info, const uint32_t *__restrict__ heavy, const uint32_t *__restrict__ redo, const xyzz_t *__restrict__ buckets, fe_t m32,
+                        xyzz29_t *__restrict__ buckets29) {
+    const uint32_t nh = info[2], nr = info[3];
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nh + nr; i += gridDim.x * blockDim.x) {
+        const uint32_t b = i < nh ? heavy[i] : redo[i - nh];
+        const xyzz_t v = buckets[b];
+        xyzz29_t o;
+        if (xyzz_is_inf(v)) { o.x = fe29_zero(); o.y = o.x; o.zz = o.x; o.zzz = o.x; }
+        else { o.x = fe29_from_words(fe_mul<F>(v.x, m32)); o.y = fe29_from_words(fe_mul<F>(v.y, m32)); o.zz = fe29_from_words(fe_mul<F>(v.zz, m32)); o.zzz = fe29_from_words(fe_mul<F>(v.zzz, m32)); }
+        buckets29[b] = o;
+    }
 }
 // the buckets the 29-bit kernel handed back (info[3] of them; none on SRS points): one lane each, the 8 x 32 law with all its cases.  Fixed-size launch.
 template <int F>
@@ -896,6 +916,78 @@ msm_segsum_kernel(uint32_t nb_per_set, SegSum rows, SegSum cols, const xyzz_t *_
         if (sub + d < sg.lanes) { if (COOP) xyzz_add_quad<F>(acc, o); else xyzz_add<F>(acc, o); }
     }
     if (live && sub == 0 && (gid % LPG) == 0) out[seg] = acc;
+}
+
+// K1f on 29-bit limbs (round 5; the multi-MSM form with buckets kept on 29-bit limbs): the same segments, workers and order of additions as msm_segsum_kernel<F, false>,
+// the adds are xyzz29_add (ec29.cuh) -- 14 lazy / strict products of 135 multiply-accumulates instead of 14 x (96 + 96 carry adds).  A segment that meets the
+// exceptional case of the law (two partial sums equal or opposite) is flagged and recomputed by msm_segsum29_redo_kernel with the complete 8 x 32 law; its
+// output slot is left alone here.  Sums leave in the 8 x 32 form the later stages read.
+__device__ __forceinline__ bool xyzz29_is_inf(const xyzz29_t &a) { uint32_t o = 0; for (int i = 0; i < L29; ++i) o |= a.zz.v[i]; return o == 0u; }
+__device__ __forceinline__ xyzz29_t shfl_down_xyzz29(const xyzz29_t &a, int d) {
+    xyzz29_t r;
+#pragma unroll
+    for (int i = 0; i < L29; ++i) { r.x.v[i] = (uint32_t)__shfl_down((int)a.x.v[i], d, 64); r.y.v[i] = (uint32_t)__shfl_down((int)a.y.v[i], d, 64);
+                                    r.zz.v[i] = (uint32_t)__shfl_down((int)a.zz.v[i], d, 64); r.zzz.v[i] = (uint32_t)__shfl_down((int)a.zzz.v[i], d, 64); }
+    return r;
+}
+template <int F>
+__global__ void __launch_bounds__(256)
+msm_segsum29_kernel(uint32_t nb_per_set, SegSum rows, SegSum cols, const xyzz29_t *__restrict__ buckets29, fe_t one, xyzz_t *__restrict__ out_rows, xyzz_t *__restrict__ out_cols,
+                    uint32_t *__restrict__ seg_bad /* rows.nseg + cols.nseg words, zeroed by the host */) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const bool is_col = blockIdx.y != 0;
+    const SegSum sg = is_col ? cols : rows;
+    xyzz_t *__restrict__ out = is_col ? out_cols : out_rows;
+    uint32_t *__restrict__ bad_out = seg_bad + (is_col ? rows.nseg : 0u);
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t seg = gid / sg.lanes, sub = gid % sg.lanes;
+    const bool live = seg < sg.nseg;
+    xyzz29_t acc; bool inf = true; uint32_t bad = 0;
+    acc.x = fe29_zero(); acc.y = acc.x; acc.zz = acc.x; acc.zzz = acc.x;
+    if (live) {
+        const size_t base = (size_t)(seg / sg.per_set) * nb_per_set + (size_t)(seg % sg.per_set) * sg.seg_stride;
+        const uint32_t per_lane = (sg.len + sg.lanes - 1) / sg.lanes;
+        const uint32_t e0 = sub * per_lane, e1 = min(e0 + per_lane, sg.len);
+#pragma unroll 1
+        for (uint32_t e = e0; e < e1 && !bad; ++e) {
+            const xyzz29_t v = buckets29[base + (size_t)e * sg.elem_stride];
+            if (xyzz29_is_inf(v)) continue;
+            if (inf) { acc = v; inf = false; }
+            else if (!xyzz29_add<F>(acc, v)) bad = 1;
+        }
+    }
+#pragma unroll 1
+    for (uint32_t d = sg.lanes >> 1; d >= 1; d >>= 1) {          // partner worker = d lanes further; groups never straddle a wave
+        const xyzz29_t o = shfl_down_xyzz29(acc, (int)d);
+        const uint32_t o_inf = (uint32_t)__shfl_down((int)(inf ? 1u : 0u), (int)d, 64), o_bad = (uint32_t)__shfl_down((int)bad, (int)d, 64);
+        if (sub + d < sg.lanes) {
+            bad |= o_bad;
+            if (!bad && !o_inf) { if (inf) { acc = o; inf = false; } else if (!xyzz29_add<F>(acc, o)) bad = 1; }
+        }
+    }
+    if (live && sub == 0) { if (bad) bad_out[seg] = 1u; else out[seg] = xyzz29_leave<F>(acc, inf, one); }
+#endif
+}
+// the segments msm_segsum29_kernel flagged (none on SRS points with honest scalars): one lane per segment, every bucket taken back to the 8 x 32 form and summed with the
+// complete law.  Launched over all segments; a lane whose flag is clear leaves at once.
+template <int F>
+__global__ void __launch_bounds__(64)
+msm_segsum29_redo_kernel(uint32_t nb_per_set, SegSum rows, SegSum cols, const xyzz29_t *__restrict__ buckets29, fe_t one, xyzz_t *__restrict__ out_rows, xyzz_t *__restrict__ out_cols,
+                         const uint32_t *__restrict__ seg_bad) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= rows.nseg + cols.nseg || !seg_bad[gid]) return;
+    const bool is_col = gid >= rows.nseg;
+    const SegSum sg = is_col ? cols : rows;
+    const uint32_t seg = is_col ? gid - rows.nseg : gid;
+    const size_t base = (size_t)(seg / sg.per_set) * nb_per_set + (size_t)(seg % sg.per_set) * sg.seg_stride;
+    xyzz_t acc = xyzz_inf();
+    for (uint32_t e = 0; e < sg.len; ++e) {
+        const xyzz29_t v = buckets29[base + (size_t)e * sg.elem_stride];
+        xyzz_add<F>(acc, xyzz29_leave<F>(v, xyzz29_is_inf(v), one));
+    }
+    (is_col ? out_cols : out_rows)[seg] = acc;
+#endif
 }
 
 // quad-replicated wave collectives: every value lives on the 4 lanes of a quad (16 values per wave), adds are

@@ -259,3 +259,42 @@ def test_the_lane_forms_rounds_on_concrete_values_stay_inside_their_proven_bound
                 out, _ = model_product(p, [(limbs(mds[row][cidx]), x7[cidx]) for cidx in range(3)], lazy=True, c=limbs(rc[row]))
                 assert value(out) < bound and value(out) <= table["lanes3"]["row"]["vmax"]
                 assert value(out) % p == (sum(mds[row][cidx] * value(x7[cidx]) for cidx in range(3)) + rc[row]) * rinv % p
+
+
+def test_the_general_add_on_concrete_values_stays_inside_the_proven_intervals_and_is_the_textbook_formula():
+    """ec29.cuh xyzz29_add (add-2008-s on XYZZ, both operands accumulators within the invariants): U1 = X1 ZZ2, U2 = X2 ZZ1, S1 = Y1 ZZZ2, S2 = Y2 ZZZ1, P = U2 - U1, R = S2 - S1,
+    X3 = R^2 - PPP - 2 Q (Q = U1 PP), Y3 = R (Q - X3) - S1 PPP, ZZ3 = ZZ1 ZZ2 PP, ZZZ3 = ZZZ1 ZZZ2 PPP -- each product carrying one factor 1 / 2^261"""
+    c, e, lz = B.EC29_GENERAL, B.EC29, B.EC29_GENERAL_LAZY
+    rng = random.Random(41)
+    for F, p in P.items():
+        table = B.prove_all()["fields"][F]["group_add"]
+        rinv = pow(R, -1, p)
+        inv = {"x": e["INV_X"] * p, "y": e["INV_Y"] * p, "zz": e["INV_ZZ"] * p, "zzz": e["INV_ZZZ"] * p}
+        for it in range(800):
+            edge = it % 4 == 0
+            av = {k: (b - 1 - rng.randrange(3) if edge else rng.randrange(b)) for k, b in inv.items()}
+            bv = {k: (b - 1 - rng.randrange(3) if edge and it % 8 == 0 else rng.randrange(b)) for k, b in inv.items()}
+            a = {k: limbs(v) for k, v in av.items()}; b = {k: limbs(v) for k, v in bv.items()}
+            u1, _ = model_product(p, [(a["x"], b["zz"])], lazy="u1" in lz); s1, _ = model_product(p, [(a["y"], b["zzz"])], lazy="s1" in lz)
+            pd, _ = model_product(p, [(b["x"], a["zz"])], lazy="pd" in lz, hi=kp_minus(p, c["G_U1_MULT"], u1))
+            r, _ = model_product(p, [(b["y"], a["zzz"])], lazy="r" in lz, hi=kp_minus(p, c["G_S1_MULT"], s1))
+            pp, _ = model_product(p, [(pd, pd)], lazy="pp" in lz); ppp, _ = model_product(p, [(pd, pp)], lazy="ppp" in lz); q, _ = model_product(p, [(u1, pp)], lazy="q" in lz)
+            k4 = B.kp_redundant(p, c["G_X3_SUB_MULT"], 31)
+            h = [k4[i] - ppp[i] - 2 * q[i] for i in range(L)]
+            assert all(0 <= x < 1 << 32 for x in h)
+            x3, _ = model_product(p, [(r, r)], lazy="x3" in lz, hi=h)
+            k3 = kp_minus(p, c["G_SUB_X3_MULT"], x3)
+            y3, _ = model_product(p, [(r, [q[i] + k3[i] for i in range(L)]), (kp_minus(p, c["G_S1_MULT"], s1), ppp)], lazy="y3" in lz)
+            zz12, _ = model_product(p, [(a["zz"], b["zz"])], lazy="zz12" in lz); zz, _ = model_product(p, [(zz12, pp)], lazy="zz" in lz)
+            zzz12, _ = model_product(p, [(a["zzz"], b["zzz"])], lazy="zzz12" in lz); zzz, _ = model_product(p, [(zzz12, ppp)], lazy="zzz" in lz)
+            U1, U2, S1, S2 = av["x"] * bv["zz"] * rinv % p, bv["x"] * av["zz"] * rinv % p, av["y"] * bv["zzz"] * rinv % p, bv["y"] * av["zzz"] * rinv % p
+            Pd, Rr = (U2 - U1) % p, (S2 - S1) % p
+            PP = Pd * Pd * rinv % p; PPP = Pd * PP * rinv % p; Q = U1 * PP * rinv % p
+            X3 = (Rr * Rr * rinv - PPP - 2 * Q) % p; Y3 = (Rr * (Q - X3) * rinv - S1 * PPP * rinv) % p
+            want = {"u1": U1, "s1": S1, "pd": Pd, "r": Rr, "pp": PP, "ppp": PPP, "q": Q, "x3": X3, "y3": Y3,
+                    "zz": av["zz"] * bv["zz"] * rinv % p * PP * rinv % p, "zzz": av["zzz"] * bv["zzz"] * rinv % p * PPP * rinv % p}
+            got = {"u1": u1, "s1": s1, "pd": pd, "r": r, "pp": pp, "ppp": ppp, "q": q, "x3": x3, "y3": y3, "zz": zz, "zzz": zzz}
+            for name, v in got.items():
+                assert value(v) % p == want[name], (F, it, name)
+                assert inside(v, table[name]), (F, it, name)
+            assert value(x3) < inv["x"] and value(y3) < inv["y"] and value(zz) < inv["zz"] and value(zzz) < inv["zzz"]

@@ -38,7 +38,7 @@ def test_msm_2_18_bases(big, oracle):
     sc = rand_scalars(n, P, seed=181)
     want = oracle.msm_pippenger(curve, g, sc, threads=16)
     c.srs_split_table(curve)
-    for fp29 in (1, 2, 0):                                       # 4 M table points: the size that caught the one-p negation of round 4 (one table y in 2^21 reaches 2^254 - 2^233)
+    for fp29 in (1, 2, 3, 0):                                    # 4 M table points: the size that caught the one-p negation of round 4 (one table y in 2^21 reaches 2^254 - 2^233)
         with m.lib.tuning(msm_fp29=fp29):
             assert (c.msm_srs(curve, sc) == want).all(), fp29
     # a slice in the upper half of the table and the variable-base path on the same points
@@ -57,7 +57,7 @@ def test_accumulator_check_k18(big, oracle):
     sg = oracle.msm_pippenger(curve, g, s, threads=16)
     import mina_bridge_amd as m
     c.srs_split_table(curve)
-    for fp29 in (1, 2):
+    for fp29 in (1, 2, 3):
         with m.lib.tuning(msm_fp29=fp29):
             assert c.accumulator_check_batch(curve, k, pre, sg).tolist() == [1], fp29
             assert c.accumulator_check_multi(curve, k, np.concatenate([pre, pre]), np.stack([sg, g[7]])).tolist() == [1, 0], fp29

@@ -276,12 +276,12 @@ def test_fixed_base_msm_on_29_bit_limbs_equals_the_8x32_law_and_the_oracle(ctx_s
     for name, sc in sets.items():
         want = oracle.msm_pippenger(curve, g[:n], sc, threads=8)
         assert (ctx_srs.msm_srs(curve, sc) == want).all(), name
-        for fp29, label in ((0, " (8 x 32)"), (1, " (29-bit limbs, 8-word twin table)"), (2, " (29-bit limbs, pre-split table)")):
+        for fp29, label in ((0, " (8 x 32)"), (1, " (29-bit limbs, 8-word twin table)"), (2, " (29-bit limbs, pre-split table)"), (3, " (29-bit limbs through the bucket reduction)")):
             with m.lib.tuning(msm_fp29=fp29):
                 assert (ctx_srs.msm_srs(curve, sc) == want).all(), name + label
     multi = np.stack([rand_scalars(n, r, seed=600 + i) for i in range(6)])
     got = ctx_srs.msm_srs_multi(curve, multi, 6)
-    for fp29 in (0, 1, 2):
+    for fp29 in (0, 1, 2, 3):
         with m.lib.tuning(msm_fp29=fp29):
             ref = ctx_srs.msm_srs_multi(curve, multi, 6)
         assert (got == ref).all(), fp29
@@ -312,10 +312,40 @@ def test_29_bit_group_law_handles_equal_and_opposite_points_exactly(oracle, srs_
             if trial == 1: sc[8:] = 0                                                   # nothing else in those buckets: acc == next point at the second entry
             if trial == 2: sc[4] = 0; sc[5] = 0; sc[6] = 0                              # only the opposite pair: the bucket goes through infinity
             want = oracle.msm_naive(curve, g, sc)
-            for fp29 in (2, 1, 0):
+            for fp29 in (3, 2, 1, 0):
                 with m.lib.tuning(msm_fp29=fp29):
                     assert (c.msm_srs(curve, sc) == want).all(), (trial, fp29)
                     assert (c.msm_srs_multi(curve, np.stack([sc] * 5), 5)[2] == want).all(), (trial, fp29, "bucket-lane form")
+    finally:
+        c.close()
+
+
+def test_29_bit_bucket_reduction_handles_equal_and_opposite_partial_sums(oracle, srs_oracle):
+    """round 5 (`msm_fp29 = 3`): in the multi-MSM form the buckets stay on 29-bit limbs and the 2-D bucket reduction adds them with the general XYZZ add on those limbs
+    (ec29.cuh xyzz29_add, msm.cuh msm_segsum29_kernel).  Its exceptional case -- two partial sums equal or opposite -- cannot occur on honest data; here an SRS with
+    g[1] = g[0], g[3] = -g[2], g[5] = g[4] and small scalars puts EQUAL points into neighbouring buckets of one row (one worker's serial loop), OPPOSITE points into
+    neighbouring buckets of another, and equal points into two different workers' chunks of a third (the shuffle tree): every such segment must be flagged and recomputed
+    with the complete law (msm_segsum29_redo_kernel), the result equal to the naive oracle; with random scalars on top of them as well."""
+    import mina_bridge_amd as m
+    curve, n = 1, 256
+    g, h = srs_oracle[curve]
+    g = g[:n].copy()
+    fq = 0x40000000000000000000000000000000224698FC0994A8DD8C46EB2100000001
+    neg = lambda pt: np.concatenate([pt[:32], np.frombuffer(((fq - int.from_bytes(pt[32:].tobytes(), "little")) % fq).to_bytes(32, "little"), np.uint8)])
+    g[1] = g[0]; g[3] = neg(g[2]); g[5] = g[4]
+    c = m.MinaContext(0)
+    try:
+        c.srs_load(curve, _srs_blob(oracle, curve, g, h))
+        small = {0: 5, 1: 6, 2: 300, 3: 301, 4: 1025, 5: 1041}                          # window-0 digits only: bucket = digit - 1
+        for trial in range(3):
+            sc = rand_scalars(n, P, seed=900 + trial) if trial == 2 else np.zeros((n, 32), np.uint8)
+            for i, v in small.items(): sc[i] = oracle.int_to_le(v)
+            if trial == 1: sc[7] = oracle.int_to_le(P - 5)                               # a negative top and a wrap-around beside them
+            want = oracle.msm_naive(curve, g, sc)
+            for fp29 in (3, 1, 0):
+                with m.lib.tuning(msm_fp29=fp29):
+                    got = c.msm_srs_multi(curve, np.stack([sc] * 5), 5)
+                    assert all((got[j] == want).all() for j in range(5)), (trial, fp29)
     finally:
         c.close()
 
@@ -364,7 +394,7 @@ def test_29_bit_group_law_on_table_points_at_the_top_of_the_field(oracle, srs_or
                 keep = [b0 + i for i in range(len(special)) for b0 in (10, 100, 200)]
                 mask = np.ones(n, bool); mask[keep] = False; sc[mask] = 0
             want = oracle.msm_naive(curve, g, sc)
-            for fp29 in (2, 1, 0):
+            for fp29 in (3, 2, 1, 0):
                 with m.lib.tuning(msm_fp29=fp29):
                     assert (c.msm_srs(curve, sc) == want).all(), (trial, fp29)
                     assert (c.msm_srs_multi(curve, np.stack([sc] * 5), 5)[3] == want).all(), (trial, fp29, "bucket-lane form")

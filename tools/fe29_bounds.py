@@ -153,6 +153,10 @@ class Prover:
 # (`search_lazy_sets`, all 36 + 9 + 1 larger subsets).  ec29.cuh is compiled with these names (`struct EC29` in fp29.cuh, emitted by gen_fe29.py).
 EC29 = {"INV_X": 26, "INV_Y": 6, "INV_ZZ": 10, "INV_ZZZ": 9, "NEG_Y_MULT": 2, "SUB_X1_MULT": 27, "SUB_Y1_MULT": 7, "X3_SUB_MULT": 23, "SUB_X3_MULT": 27, "PD_MAX": 36}
 EC29_LAZY = ("pd", "r", "pp", "ppp", "zz", "zzz")
+# the GENERAL add of two accumulators (the 2-D bucket reduction of the multi-MSM form, msm.cuh msm_segsum29_kernel): both operands within the invariants above,
+# the sum within them again; u1 = x1 zz2 and s1 = y1 zzz2 are products now, so the multiples under them are their own
+EC29_GENERAL = {"G_U1_MULT": 12, "G_S1_MULT": 10, "G_X3_SUB_MULT": 16, "G_SUB_X3_MULT": 20}
+EC29_GENERAL_LAZY = ("u1", "s1", "pd", "r", "pp", "ppp", "zz12", "zz", "zzz12", "zzz")
 
 
 def prove_group_law(field: int, c=None, lazy=None):
@@ -185,6 +189,33 @@ def prove_group_law(field: int, c=None, lazy=None):
     for name in ("x", "y", "zz", "zzz"):
         need(pr.mul(f"leave {name}", acc[name], norm(p, "2^256 mod p")).vmax < 2 * p, f"leaving acc.{name}: one conditional subtraction is not enough")
     return pr, {"pd": pd, "r": r, "pp": pp, "ppp": ppp, "q": q, "x3": x3, "y3": y3, "zz": zz, "zzz": zzz, "qy": qy}
+
+
+def prove_group_add(field: int, c=None, lazy=None):
+    """xyzz29_add (ec29.cuh): a + b for two accumulators, neither infinity (add-2008-s on XYZZ).  Inputs within the invariants of EC29; the sum must be within them too
+    (the reduction tree adds sums to sums) and pd below PD_MAX (the exact zero test)."""
+    e = dict(EC29)
+    c = dict(EC29_GENERAL, **(c or {}))
+    lazy = EC29_GENERAL_LAZY if lazy is None else lazy
+    pr = Prover(field); p = pr.p
+    mk = lambda tag: {"x": norm(e["INV_X"] * p, tag + ".x"), "y": norm(e["INV_Y"] * p, tag + ".y"), "zz": norm(e["INV_ZZ"] * p, tag + ".zz"), "zzz": norm(e["INV_ZZZ"] * p, tag + ".zzz")}
+    a, b = mk("a"), mk("b")
+    u1 = pr.mul("u1 = x1 zz2", a["x"], b["zz"], lazy="u1" in lazy)
+    s1 = pr.mul("s1 = y1 zzz2", a["y"], b["zzz"], lazy="s1" in lazy)
+    pd = pr.mul("pd = x2 zz1 + K p - u1", b["x"], a["zz"], hi=pr.kp_minus("K p - u1", c["G_U1_MULT"], u1), lazy="pd" in lazy)
+    r = pr.mul("r = y2 zzz1 + K p - s1", b["y"], a["zzz"], hi=pr.kp_minus("K p - s1", c["G_S1_MULT"], s1), lazy="r" in lazy)
+    pp = pr.sqr("pp = pd^2 (general)", pd, lazy="pp" in lazy)
+    ppp = pr.mul("ppp = pd pp (general)", pd, pp, lazy="ppp" in lazy)
+    q = pr.mul("q = u1 pp", u1, pp, lazy="q" in lazy)
+    x3 = pr.sqr("x3 = r^2 + K p - ppp - 2 q (general)", r, hi=pr.kp_minus_a_minus_2b("K p - ppp - 2 q (general)", c["G_X3_SUB_MULT"], ppp, q), lazy="x3" in lazy)
+    y3 = pr.product("y3 = r (q + K p - x3) + (K p - s1) ppp", [(r, pr.add_kp_minus("q + K p - x3 (general)", c["G_SUB_X3_MULT"], q, x3)), (pr.kp_minus("K p - s1 (dot)", c["G_S1_MULT"], s1), ppp)],
+                    lazy="y3" in lazy)
+    zz = pr.mul("zz3 = zz1 zz2 pp", pr.mul("zz1 zz2", a["zz"], b["zz"], lazy="zz12" in lazy), pp, lazy="zz" in lazy)
+    zzz = pr.mul("zzz3 = zzz1 zzz2 ppp", pr.mul("zzz1 zzz2", a["zzz"], b["zzz"], lazy="zzz12" in lazy), ppp, lazy="zzz" in lazy)
+    for name, v, inv in (("x", x3, "INV_X"), ("y", y3, "INV_Y"), ("zz", zz, "INV_ZZ"), ("zzz", zzz, "INV_ZZZ")):
+        need(v.vmax < e[inv] * p, f"general add: new {name} can reach {v.vmax / p:.3f} p, invariant {e[inv]} p")
+    need(pd.vmax < e["PD_MAX"] * p, f"general add: pd can reach {pd.vmax / p:.2f} p: beyond PD_MAX")
+    return pr, {"u1": u1, "s1": s1, "pd": pd, "r": r, "pp": pp, "ppp": ppp, "q": q, "x3": x3, "y3": y3, "zz": zz, "zzz": zzz}
 
 
 def least_fixed_point(field: int, lazy):
@@ -259,11 +290,14 @@ def prove_sponge_rounds(field: int, c=None):
 
 def prove_all():
     """every spec for both fields; returns {"ec29": {...}, "sponge": {...}, "log": [...]}, raises BoundError otherwise"""
-    table = {"constants": {"EC29": dict(EC29), "SPONGE": dict(SPONGE)}, "fields": {}}
+    table = {"constants": {"EC29": dict(EC29), "EC29_GENERAL": dict(EC29_GENERAL), "SPONGE": dict(SPONGE)}, "fields": {}}
     for f in (0, 1):
         g, gv = prove_group_law(f)
+        ga, gav = prove_group_add(f)
         s, sv = prove_sponge_rounds(f)
+        g.log += ga.log
         table["fields"][f] = {"group_law": {k: {"vmax": v.vmax, "top_limb": v.limb[8]} for k, v in gv.items()},
+                              "group_add": {k: {"vmax": v.vmax, "top_limb": v.limb[8]} for k, v in gav.items()},
                               "group_law_worst_column": max(w for _, _, w, _ in g.log if w is not None),
                               "sponge": {form: {k: {"vmax": v.vmax} for k, v in d.items()} for form, d in sv.items()},
                               "sponge_worst_column": max(w for _, _, w, _ in s.log if w is not None),
@@ -279,6 +313,8 @@ def emit_constants() -> str:
              f"//   group law: worst column {wc:.3f} x 2^64; Poseidon lane forms: worst column {ws:.3f} x 2^64",
              "struct EC29 {      // xyzz29_add_affine: accumulator invariants (units of p) and the multiple of p in every limb-wise \"K p - b\" (no limb may go negative)"]
     lines += [f"    static constexpr uint32_t {k} = {v};" for k, v in EC29.items()]
+    lines += ["    // xyzz29_add (two accumulators): the multiples under u1 = x1 zz2, s1 = y1 zzz2, ppp + 2 q and x3"]
+    lines += [f"    static constexpr uint32_t {k} = {v};" for k, v in EC29_GENERAL.items()]
     lines += ["};", "struct SPONGE29 {   // the Poseidon lane forms' state bounds between rounds, in thousandths of p (fixed points of a lazy round)"]
     lines += [f"    static constexpr uint32_t {k} = {v};" for k, v in SPONGE.items()]
     lines += ["};"]

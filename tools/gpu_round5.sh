@@ -20,7 +20,7 @@ for st in "$@"; do
     c2)       timeout 900 bash tools/profile_c2.sh $TAG > $O/profile_c2.log 2>&1; tail -3 $O/profile_c2.log
               timeout 300 python tools/c2_rate.py 16 400 2>/dev/null | tail -1 ;;
     msm)      ( time timeout 2400 python -m pytest tests/test_gpu_msm.py tests/test_gpu_large_srs.py tests/test_gpu_ipa.py tests/test_gpu_sponge_ipa.py -m gpu -q -x ) > $O/pytest_msm.log 2>&1; tail -5 $O/pytest_msm.log ;;
-    c2ab)     for rep in 1 2 3; do for t in 2 1 0; do echo -n "msm_fp29=$t "; MINA_TUNE=msm_fp29=$t timeout 300 python tools/c2_rate.py 16 400 2>/dev/null | tail -1; done; done | tee $O/c2_ab.log ;;
+    c2ab)     for rep in 1 2 3; do for t in ${C2AB:-3 2 1 0}; do echo -n "msm_fp29=$t "; MINA_TUNE=msm_fp29=$t timeout 300 python tools/c2_rate.py 16 400 2>/dev/null | tail -1; done; done | tee $O/c2_ab.log ;;
     multi)    ( time timeout 3000 python -m pytest tests/test_bench_multi.py tests/test_sharded_state_job.py -m gpu -q ) > $O/pytest_multi.log 2>&1; tail -6 $O/pytest_multi.log ;;
     abr04)    bash tools/ab_c2.sh tools/probes/bin/lib_r04.so 3 2>&1 | tee $O/ab_c2_r04.log ;;   # A = this build, B = the round-4 library (tools/probes/bin/lib_r04.so, built from 4076b66), same box
     account)  timeout 600 python tools/c4_rate.py > $O/c4_rate.log 2>&1; tail -8 $O/c4_rate.log ;;
