@@ -455,8 +455,8 @@ def boundary_leg(m, devices: str, B: int, min_seconds: float = 2.0):
         assert all(o.all() for o in outs)
         return {"value": sum(counts) * B / el, "unit": "proofs/s", "calls": sum(counts)}
     two, four = callers(2), callers(4)
-    # What ONE bad opening per call costs everybody: a folded check that fails sends its chunk through the culprit search, which drains the device and holds
-    # its lock for the length of the search.  Caller 1 sends B good proofs per call; caller 2 sends B proofs with ONE bad opening (z1 with a flipped bit: the folded
+    # What ONE bad opening per call costs everybody: a folded check that fails sends its chunk through the culprit search -- until round 5 with the device
+    # drained and its lock held for the length of the search; now on a view context of the device (api_verify.hip Device::sc).  Caller 1 sends B good proofs per call; caller 2 sends B proofs with ONE bad opening (z1 with a flipped bit: the folded
     # opening check of its chunk fails, the search finds exactly that proof); both for min_seconds.  Reported: the clean caller's rate beside it, and the searcher's call time.
     search_cost = None
     try:
@@ -487,8 +487,9 @@ def boundary_leg(m, devices: str, B: int, min_seconds: float = 2.0):
             el = time.perf_counter() - t0
             search_cost = {"clean_caller_beside_a_searching_caller": counts[0] * B / el, "clean_caller_beside_a_clean_caller": two["value"] / 2, "unit": "proofs/s",
                            "searching_caller_ms_per_call": sorted(lat)[len(lat) // 2] * 1e3 if lat else None, "searching_caller_calls": counts[1], "proofs_per_call": B,
-                           "note": "one bad opening per call of the second caller: its chunk's folded check fails and the 4-way culprit search runs with the device drained and its lock held "
-                                   "(api_verify.hip fallback); the first column is what a well-behaved caller keeps beside it"}
+                           "note": "one bad opening per call of the second caller: its chunk's folded check fails and the 4-way culprit search runs -- since round 5 on a VIEW context of "
+                                   "its device (own lanes and lock: mina_verify_tuning.search_ctx = 1; round 4 drained the device and held its lock: 32 - 51 k proofs/s left here); "
+                                   "the first column is what a well-behaved caller keeps beside it"}
     except Exception as e:                                            # noqa: BLE001 -- a diagnostic leg: never takes the line down
         search_cost = {"error": repr(e)[:300]}
     # one call of 8 x B proofs: chunks of B, at most four on the GPU at a time

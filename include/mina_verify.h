@@ -676,6 +676,8 @@ typedef struct mina_verify_tuning {
     uint32_t msm_fp29;             /* 1     SRS-table MSMs accumulate their buckets on 29-bit limbs: 1 = points gathered from the 64-byte twin table (8 x 32 words in the 2^261 domain),
                                             2 = from the pre-split 128-byte records (x, y, p - y as 29-bit limbs: no conversion, no negation, twice the gather traffic; needs mina_srs_split_table),
                                             3 = as 1, and in the multi-MSM form the buckets STAY on 29-bit limbs through the 2-D bucket reduction; 0: the 8 x 32-bit law */
+    uint32_t search_ctx;           /* 1     the culprit search of a failed chunk runs on a SECOND context of its device (its own lanes, workspaces and lock): valid traffic keeps
+                                            flowing beside it.  0 = round 4: on the device's one context, with the device drained and its lock held for the length of the search */
 } mina_verify_tuning;
 void mina_verify_tuning_default(mina_verify_tuning *out);
 int mina_verify_tuning_get(mina_verify_tuning *out);

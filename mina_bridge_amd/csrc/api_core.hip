@@ -69,6 +69,33 @@ extern "C" int mina_ctx_create(int device_id, mina_ctx **out) {
     return MINA_OK;
 }
 
+int mb_ctx_create_view(mina_ctx *parent, mina_ctx **out) {
+    if (!parent || !out) return fail(MINA_ERR_ARG, "null argument");
+    int rc = mina_ctx_create(parent->device, out);
+    if (rc) return rc;
+    mb_ctx_refresh_view(*out, parent);
+    return MINA_OK;
+}
+void mb_ctx_refresh_view(mina_ctx *v, mina_ctx *p) {
+    for (int i = 0; i < 2; ++i) {
+        v->fk[i] = p->fk[i];
+        SrsState &a = v->srs[i]; const SrsState &b = p->srs[i];
+        a.depth = b.depth; a.c = b.c; a.W = b.W;
+        a.table.alias(b.table); a.table29.alias(b.table29); a.table29s.alias(b.table29s); a.h.alias(b.h);
+        a.lagrange_log2 = b.lagrange_log2; if (a.lagrange_host.size() != b.lagrange_host.size() || a.lagrange_log2 != b.lagrange_log2) a.lagrange_host = b.lagrange_host;
+        a.lagrange_table.alias(b.lagrange_table); a.lagrange_table_n = b.lagrange_table_n; a.lagrange_table_log2 = b.lagrange_table_log2;
+        a.lagrange_digits.alias(b.lagrange_digits); a.lagrange_digits_n = b.lagrange_digits_n;
+        v->pparams[i].alias(p->pparams[i]); v->have_pparams[i] = p->have_pparams[i]; v->pparams_surrogate[i] = p->pparams_surrogate[i];
+        v->merkle_salts[i].alias(p->merkle_salts[i]); v->merkle_depth[i] = p->merkle_depth[i];
+    }
+    v->kimchi_index.alias(p->kimchi_index); v->kimchi_tokens.alias(p->kimchi_tokens); v->kimchi_literals.alias(p->kimchi_literals);
+    v->have_kimchi = p->have_kimchi; v->kimchi_log2 = p->kimchi_log2; memcpy(v->kimchi_digest, p->kimchi_digest, sizeof v->kimchi_digest); memcpy(v->kimchi_comms_host, p->kimchi_comms_host, sizeof v->kimchi_comms_host);
+    v->pickles_index.alias(p->pickles_index); v->pickles_tokens.alias(p->pickles_tokens); v->pickles_literals.alias(p->pickles_literals);
+    v->have_pickles_dev = p->have_pickles_dev; v->pickles_ms_valid = p->pickles_ms_valid;
+    v->step_host = p->step_host; v->step_host_free = nullptr;      // borrowed: the parent frees it
+    v->state_salts.alias(p->state_salts); v->have_state_salts = p->have_state_salts;
+}
+
 extern "C" void mina_ctx_destroy(mina_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);

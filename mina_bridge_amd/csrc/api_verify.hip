@@ -60,6 +60,12 @@ struct Slot { PinnedBuf host, out; DevBuf dev; hipStream_t up = nullptr; hipEven
 struct Device {
     mina_ctx *c = nullptr; int ordinal = 0;
     std::mutex mu;                         // serialises every call into `c` (a context has ONE current-lane cursor)
+    // The culprit search of a chunk whose folded check failed (mina_state_job_batch: synchronous jobs fanned over a few lanes) has a context of its OWN on the same
+    // GPU (round 5): until then it ran on `c` with the device drained and `mu` held for its whole length -- one bad proof from any caller stalled every
+    // other caller of the device (measured: a clean caller of 8192 proofs kept 51 of its 117 k proofs/s beside a caller whose every call carried one bad opening).
+    // A VIEW of `c` (ctx.h mb_ctx_create_view): own lanes and workspaces, tables and indexes borrowed.  Locked by `search_mu`: searches queue behind each other,
+    // traffic does not; the installers take `search_mu` before `mu` so that no search reads a buffer they replace.
+    mina_ctx *sc = nullptr; std::mutex search_mu;
     std::mutex acct_mu;                    // one Proof-of-Account job at a time (its lane's buffers)
     std::mutex slot_mu; std::condition_variable slot_cv; Slot slots[NSLOT];
     uint32_t prepared_npub = 0xffffffffu;
@@ -76,7 +82,9 @@ int create_device(int ordinal, Device **out) {
     int rc = mina_ctx_create(ordinal, &c);
     if (rc) return rc;
     if ((rc = mina_poseidon_install_default_params(c)) || (rc = mb_poseidon_env_params(c)) || (rc = mina_srs_create(c, CURVE_VESTA, 1u << 16)) || (rc = mina_srs_create(c, CURVE_PALLAS, 1u << 16))) { mina_ctx_destroy(c); return rc; }
-    Device *d = new Device(); d->c = c; d->ordinal = ordinal;
+    mina_ctx *sc = nullptr;                                  // a VIEW of c (ctx.h): own lanes and workspaces, the tables and indexes borrowed -- no second copy
+    if ((rc = mb_ctx_create_view(c, &sc))) { mina_ctx_destroy(c); return rc; }
+    Device *d = new Device(); d->c = c; d->sc = sc; d->ordinal = ordinal;
     *out = d;
     return MINA_OK;
 }
@@ -90,16 +98,18 @@ std::vector<Device *> &devices() {          // caller holds g_mu
     if (ords.empty()) ords.push_back(getenv("MINA_VERIFY_DEVICE") ? atoi(getenv("MINA_VERIFY_DEVICE")) : 0);
     for (int o : ords) {
         Device *d = nullptr;
-        if (create_device(o, &d) != MINA_OK) { for (Device *x : g_devs) { mina_ctx_destroy(x->c); delete x; } g_devs.clear(); g_init_failed = true; break; }
+        if (create_device(o, &d) != MINA_OK) { for (Device *x : g_devs) { mina_ctx_destroy(x->sc); mina_ctx_destroy(x->c); delete x; } g_devs.clear(); g_init_failed = true; break; }
         g_devs.push_back(d);
     }
     return g_devs;
 }
 void destroy_devices() {                    // caller holds g_mu
     for (Device *d : g_devs) {
-        { std::lock_guard<std::mutex> lk(d->mu);
+        { std::lock_guard<std::mutex> sl(d->search_mu);       // lock order: search_mu before mu (the installers', the fallback's)
+          std::lock_guard<std::mutex> lk(d->mu);
           (void)hipSetDevice(d->c->device);
           for (Slot &s : d->slots) { if (s.ev) { (void)hipEventSynchronize(s.ev); (void)hipEventDestroy(s.ev); } for (auto &e : s.tev) if (e) (void)hipEventDestroy(e); for (auto &e : s.rec_ev) if (e) (void)hipEventDestroy(e); s.rec_ev.clear(); if (s.ev_up) (void)hipEventDestroy(s.ev_up); if (s.up) (void)hipStreamDestroy(s.up); s.ev_up = nullptr; s.up = nullptr; s.host.release(); s.out.release(); s.dev.release(); }
+          mina_ctx_destroy(d->sc);                            // the view first: it borrows c's buffers
           mina_ctx_destroy(d->c); }
         delete d;
     }
@@ -122,19 +132,28 @@ extern "C" mina_ctx *mina_verify_device_ctx(int i) { std::lock_guard<std::mutex>
 extern "C" int mina_verify_install_verifier_index(const mina_verifier_index *ix) {
     std::lock_guard<std::mutex> lk(g_mu);
     auto &ds = devices(); if (ds.empty()) return fail(MINA_ERR_HIP, "no device");
-    for (Device *d : ds) { std::lock_guard<std::mutex> dl(d->mu); int rc = mina_verifier_index_install(d->c, ix); if (rc) return rc; d->prepared_npub = 0xffffffffu; }
+    for (Device *d : ds) {
+        std::lock_guard<std::mutex> sl(d->search_mu);      // no culprit search is reading the buffers being replaced (lock order: g_mu, search_mu, mu)
+        std::lock_guard<std::mutex> dl(d->mu); int rc = mina_verifier_index_install(d->c, ix); if (rc) return rc; d->prepared_npub = 0xffffffffu;
+    }
     return MINA_OK;
 }
 extern "C" int mina_verify_install_step_index(const mina_step_index *ix) {
     std::lock_guard<std::mutex> lk(g_mu);
     auto &ds = devices(); if (ds.empty()) return fail(MINA_ERR_HIP, "no device");
-    for (Device *d : ds) { std::lock_guard<std::mutex> dl(d->mu); int rc = mina_step_index_install(d->c, ix); if (rc) return rc; }
+    for (Device *d : ds) {
+        std::lock_guard<std::mutex> sl(d->search_mu);      // no culprit search is reading the buffers being replaced (lock order: g_mu, search_mu, mu)
+        std::lock_guard<std::mutex> dl(d->mu); int rc = mina_step_index_install(d->c, ix); if (rc) return rc;
+    }
     return MINA_OK;
 }
 extern "C" int mina_verify_set_poseidon_params(int field, const uint8_t *params) {
     std::lock_guard<std::mutex> lk(g_mu);
     auto &ds = devices(); if (ds.empty()) return fail(MINA_ERR_HIP, "no device");
-    for (Device *d : ds) { std::lock_guard<std::mutex> dl(d->mu); int rc = mina_poseidon_set_params(d->c, field, params); if (rc) return rc; }
+    for (Device *d : ds) {
+        std::lock_guard<std::mutex> sl(d->search_mu);      // no culprit search is reading the buffers being replaced (lock order: g_mu, search_mu, mu)
+        std::lock_guard<std::mutex> dl(d->mu); int rc = mina_poseidon_set_params(d->c, field, params); if (rc) return rc;
+    }
     return MINA_OK;
 }
 
@@ -563,17 +582,27 @@ int run_device_shape(Device &D, const CallIn &in, const std::vector<size_t> &idx
     auto release = [&](int s) { { std::lock_guard<std::mutex> lk(D.slot_mu); D.slots[s].busy = false; } D.slot_cv.notify_all(); };
 
     auto fallback = [&](Chunk &ch) -> int {     // a folded check of the chunk failed: per-proof verdicts through the culprit search, from the same staging
-        std::lock_guard<std::mutex> lk(D.mu);
-        // The search runs synchronous jobs on lane 0 and fans out over lanes 0 .. search_fan - 1 (and the forked-leg helpers of lane 0) -- the lanes of the
-        // slots other chunks / callers have in flight.  So the device is drained first: everything queued so far completes (queued work needs no host
-        // action), and nothing new can be queued while D.mu is held.  The search then has the GPU to itself: its lane forms are those of ONE call.
-        (void)hipSetDevice(c->device);
-        if (hipDeviceSynchronize() != hipSuccess) return fail(MINA_ERR_HIP, "hipDeviceSynchronize before the culprit search");
-        c->nlanes = 1;
         JobStructs js; make_jobs(sh, lay, (uint8_t *)ch.slot->host.p, ch.n, true, true, true, js);
         std::vector<uint8_t> v(ch.n, 0);
         const auto t = std::chrono::steady_clock::now();
-        int rc = mina_state_job_batch(c, &js.j, v.data());
+        int rc;
+        if (tu.search_ctx) {
+            // on the device's SECOND context (Device::sc): its own lanes, workspaces and lock -- nothing of `c` is touched, nothing is drained, D.mu is not taken:
+            // the other callers of the device keep queueing while the search runs beside their jobs
+            std::lock_guard<std::mutex> lk(D.search_mu);
+            (void)hipSetDevice(D.sc->device);
+            { std::lock_guard<std::mutex> dl(D.mu); mb_ctx_refresh_view(D.sc, c); }     // what is installed on c NOW (an install since the last search; tables prepared by the jobs)
+            rc = mina_state_job_batch(D.sc, &js.j, v.data());
+        } else {
+            std::lock_guard<std::mutex> lk(D.mu);
+            // (round 4) The search runs synchronous jobs on lane 0 and fans out over lanes 0 .. search_fan - 1 (and the forked-leg helpers of lane 0) -- the lanes of the
+            // slots other chunks / callers have in flight.  So the device is drained first: everything queued so far completes (queued work needs no host
+            // action), and nothing new can be queued while D.mu is held.  The search then has the GPU to itself: its lane forms are those of ONE call.
+            (void)hipSetDevice(c->device);
+            if (hipDeviceSynchronize() != hipSuccess) return fail(MINA_ERR_HIP, "hipDeviceSynchronize before the culprit search");
+            c->nlanes = 1;
+            rc = mina_state_job_batch(c, &js.j, v.data());
+        }
         if (g_timing) fprintf(stderr, "mina_verify: chunk of %zu: folded check failed, culprit search %.2f ms (rc %d)\n", ch.n, ms_since(t), rc);
         if (rc) return rc;
         for (size_t b = 0; b < ch.n; ++b) verdicts[idx[ch.lo + b]] = (v[b] && ch.hb[b].parsed && ch.hb[b].shape) ? 1 : 0;

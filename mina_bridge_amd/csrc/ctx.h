@@ -19,6 +19,13 @@
 
 using namespace mb;
 
+struct mina_ctx;
+// A VIEW of a context (round 5): its own lanes, streams and workspaces, while everything INSTALLED -- field constants, both SRS with their window tables, Poseidon
+// tables, salts, verifier / step index -- is borrowed from the parent (no second copy of the tables).  The boundary runs the culprit search of a failed chunk on a
+// view, so that the search needs neither the parent's lock nor a drained device (api_verify.hip Device::sc).  `refresh` re-reads the parent's installs; the caller
+// holds whatever serialises installs on the parent.  Destroy the view BEFORE the parent.
+int mb_ctx_create_view(mina_ctx *parent, mina_ctx **out);
+void mb_ctx_refresh_view(mina_ctx *view, mina_ctx *parent);
 int mb_fail(int code, const std::string &msg);      // records the thread-local error text, returns code
 mina_verify_tuning mb_tune();                        // the process-wide tuning (api_core.hip; mina_verify_configure_ex), by value
 #define fail mb_fail
@@ -32,14 +39,16 @@ mina_verify_tuning mb_tune();                        // the process-wide tuning 
 
 struct DevBuf {
     void *p = nullptr; size_t cap = 0;
+    bool borrowed = false;             // the memory belongs to another context's DevBuf (a VIEW context: mb_ctx_refresh_view): never freed here; outgrown -> replaced by an own allocation
     int ensure(size_t bytes) {
         if (bytes <= cap) return MINA_OK;
-        if (p) { if (hipFree(p) != hipSuccess) return MINA_ERR_HIP; p = nullptr; cap = 0; }
+        if (p) { if (!borrowed && hipFree(p) != hipSuccess) return MINA_ERR_HIP; p = nullptr; cap = 0; borrowed = false; }
         size_t want = bytes + bytes / 8 + 256;
         if (hipMalloc(&p, want) != hipSuccess) return fail(MINA_ERR_HIP, "hipMalloc failed");
         cap = want; return MINA_OK;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    void release() { if (p && !borrowed) (void)hipFree(p); p = nullptr; cap = 0; borrowed = false; }
+    void alias(const DevBuf &o) { release(); p = o.p; cap = o.cap; borrowed = o.p != nullptr; }
     template <class T> T *as() { return reinterpret_cast<T *>(p); }
 };
 

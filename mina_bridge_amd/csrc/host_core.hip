@@ -21,7 +21,7 @@ static mina_verify_tuning tuning_defaults() {
     t.chain_cus = 128; t.cu_period = 256; t.acc_mask = 0; t.hash_piece_waves = 1024; t.up_stream = 1; t.min_shard = 64; t.pace_us = 0;
     t.merge = 1; t.merge_batch_max = 512; t.linger_us = 500; t.max_jobs = 1;
     t.coop16_max = 64; t.coop8_max = 8192; t.coop8_per_call = 0; t.transcript_coop8_max = 0; t.ipa_coop8_max = 1024; t.kimchi_coop8_max = 1024;
-    t.bpoly_mfma = 1; t.pubcomm_direct = 1; t.ipa_shared_points = 1; t.kimchi_shared_digest = 1; t.ipa_side_stream = 1; t.search_fan = 4; t.search_full = 0; t.msm_fp29 = 1;
+    t.bpoly_mfma = 1; t.pubcomm_direct = 1; t.ipa_shared_points = 1; t.kimchi_shared_digest = 1; t.ipa_side_stream = 1; t.search_fan = 4; t.search_full = 0; t.msm_fp29 = 1; t.search_ctx = 1;
     return t;
 }
 // The environment switches of rounds 1 - 3 became fields of mina_verify_tuning (round 4).  A deployment that still exports one gets the DEFAULT now: say so, once,

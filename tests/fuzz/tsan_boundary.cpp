@@ -39,6 +39,8 @@ extern "C" int mina_ctx_create(int device_id, mina_ctx **out) {
     for (int i = 0; i < 4; ++i) (void)hipStreamCreateWithFlags(&c->lanes[i].stream, hipStreamNonBlocking);
     c->use_lane0(); *out = c; return MINA_OK;
 }
+int mb_ctx_create_view(mina_ctx *parent, mina_ctx **out) { int rc = mina_ctx_create(parent->device, out); if (!rc) mb_ctx_refresh_view(*out, parent); return rc; }
+void mb_ctx_refresh_view(mina_ctx *v, mina_ctx *p) { v->have_kimchi = p->have_kimchi; v->kimchi_log2 = p->kimchi_log2; v->have_state_salts = p->have_state_salts; }   // (read under the parent's lock by the caller)
 extern "C" void mina_ctx_destroy(mina_ctx *c) { if (!c) return; for (auto &l : c->lanes) { if (l.stream) (void)hipStreamDestroy(l.stream); l.release_all(); } delete c; }
 extern "C" int mina_poseidon_set_params(mina_ctx *c, int field, const uint8_t *) { c->have_pparams[field] = true; c->pparams_surrogate[field] = false; return MINA_OK; }
 extern "C" int mina_srs_create(mina_ctx *c, int curve, uint32_t depth) { c->srs[curve].depth = depth; return MINA_OK; }

@@ -17,7 +17,10 @@ for st in "$@"; do
     profile)  timeout 900 bash tools/profile_round.sh $TAG > $O/profile_round.log 2>&1; tail -2 $O/profile_round.log | cut -c1-200
               timeout 900 bash tools/profile_sq.sh $TAG > $O/profile_sq.log 2>&1
               python tools/profile_report.py $TAG $O/bench.json > $O/${TAG}_rocprof.md 2> $O/report.err; wc -l $O/${TAG}_rocprof.md ;;
+    gpus8)    ( time timeout 2400 python bench.py --gpus 8 --steps 10 ) > $O/bench_gpus8_shared.json 2> $O/bench_gpus8.err; echo "gpus8 rc=$?" ;;
+    preflight) ( timeout 1200 python bench.py --gpus 8 --preflight ) > $O/preflight_gpus8.json 2> $O/preflight.err; echo "preflight rc=$?"; cut -c1-400 $O/preflight_gpus8.json ;;
     c2)       timeout 900 bash tools/profile_c2.sh $TAG > $O/profile_c2.log 2>&1; tail -3 $O/profile_c2.log
+              timeout 900 bash tools/profile_c2_sq.sh $TAG > $O/profile_c2_sq.log 2>&1; tail -4 $O/profile_c2_sq.log
               timeout 300 python tools/c2_rate.py 16 400 2>/dev/null | tail -1 ;;
     msm)      ( time timeout 2400 python -m pytest tests/test_gpu_msm.py tests/test_gpu_large_srs.py tests/test_gpu_ipa.py tests/test_gpu_sponge_ipa.py -m gpu -q -x ) > $O/pytest_msm.log 2>&1; tail -5 $O/pytest_msm.log ;;
     c2ab)     for rep in 1 2 3; do for t in ${C2AB:-3 2 1 0}; do echo -n "msm_fp29=$t "; MINA_TUNE=msm_fp29=$t timeout 300 python tools/c2_rate.py 16 400 2>/dev/null | tail -1; done; done | tee $O/c2_ab.log ;;
