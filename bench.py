@@ -62,12 +62,12 @@ HBM_PEAK_GBPS = 8000.0                                # MI355X_MICROARCH.md: 8 T
 # with the round constant inside its reduction (306) = 774 `v_mad_u64_u32` beside ~190 simple instructions (64-bit column shifts, negations, limb
 # masks).  ONE model (profiles/r04_valu_roofline.md): every instruction takes its issue slot, and the ceiling is the measured rate of THAT MIX -- 153
 # multiply-accumulates interleaved with 16 shifts, 9 negations, 8 masks, 4 32-bit shifts per trip, 8 waves per SIMD (`microbench --ratio`,
-# profiles/r04_microbench_ratio.jsonl): 5.46 nominal-clock cycles per multiply-accumulate OF THE MIX = 2.28 ns per wave64 multiply-accumulate per SIMD
+# profiles/r05_microbench_ratio.jsonl): 5.38 nominal-clock cycles per multiply-accumulate OF THE MIX = 2.24 ns per wave64 multiply-accumulate per SIMD
 # (a pure stream: 4.66; the strict forms' mix of 765 + ~290 until late in round 4: 5.9 - 6.04).
 MADS_PER_LANE_ROUND = 2 * 99 + 2 * 135 + 306
-MAD_ISSUE_CYCLES = 5.46
+MAD_ISSUE_CYCLES = 5.38                               # re-measured in round 5 (profiles/r05_microbench_ratio.jsonl: 5.38; round 4's boxes: 5.46)
 # SURVEY.md 8d's peak: a PURE stream of v_mad_u64_u32 (16 independent accumulators, operands on distinct register banks, 8 waves per SIMD) issues one per 4.52
-# cycles at the nominal 2.4 GHz = 1.88 ns per wave64 instruction per SIMD (profiles/r04_microbench_ratio.jsonl, the S = 0 row): 34.8 T limb-MAC/s for the chip.
+# cycles at the nominal 2.4 GHz = 1.88 ns per wave64 instruction per SIMD (profiles/r05_microbench_ratio.jsonl, the S = 0 row; the same in round 4): 34.8 T limb-MAC/s for the chip.
 # `roofline` is quoted against THIS peak (it forgives nothing: the round's ~190 shifts / negations / masks per 774 multiply-accumulates count as lost issue slots);
 # `roofline_valu` keeps the own-mix ceiling beside it.
 PURE_MAC_ISSUE_CYCLES = 4.52
@@ -1081,9 +1081,9 @@ def main():
                                     "msm_valu": None if not c2_rate else msm_valu(c2_rate),
                                     "msm_hbm": None if not c2_rate else {"algorithmic_bytes_per_msm": 65536 * (64 + 32) + 96, "achieved_GBps": c2_rate * (65536 * 96 + 96) / 1e9, "peak_GBps": HBM_PEAK_GBPS,
                                                                          "frac": c2_rate * (65536 * 96 + 96) / 1e9 / HBM_PEAK_GBPS, **msm_traffic(c2_rate),
-                                                                         "note": "the bucket MSM is bound by the group law's multiply-accumulates (the accumulate kernel: 72 of the 79 us per check, on 29-bit limbs "
-                                                                                 "since round 4: profiles/r04_k1.md), not by HBM; the fixed-base window tables trade bandwidth for doubling chains: "
-                                                                                 "one 64-B point gathered per (base, window)"}},
+                                                                         "note": "the bucket MSM is bound by the group law's multiply-accumulates (the accumulate kernel: 78 % of a check's instructions, on 29-bit limbs "
+                                                                                 "since round 4, six of its nine products lazy since round 5: profiles/r05_k1.md), not by HBM; the fixed-base window tables "
+                                                                                 "trade bandwidth for doubling chains: one 64-B point gathered per (base, window)"}},
         }
         hbm_view = {"achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBPS) if achieved else None,
                     "algorithmic_bytes_per_launch": hash_bytes, "traffic": (nstates * traffic_per_state) if traffic_per_state else None,
@@ -1100,7 +1100,7 @@ def main():
                                "states_per_launch": nstates, "avg_launch_us": kern_us, "avg_launch_us_in_timed_region": ovl.get("pstate_hash"),
                                "limb_macs_per_launch": perms * 3 * 55 * MADS_PER_LANE_ROUND,
                                "peak_source": f"measured pure v_mad_u64_u32 stream, {PURE_MAC_ISSUE_CYCLES} cycles at 2.4 GHz per wave64 instruction per SIMD, 8 waves per SIMD "
-                                              "(profiles/r04_microbench_ratio.jsonl, S = 0; re-measured per round: profiles/README.md)",
+                                              "(profiles/r05_microbench_ratio.jsonl, S = 0; re-measured per round: profiles/README.md)",
                                "note": "bound = the binding resource (SURVEY.md 8d: integer VALU, not HBM, not MFMA).  achieved = 29-bit limb multiply-accumulates per launch / the "
                                        "launch's HIP-event duration on its lane stream (isolated launches right after the timed region; second figure: inside it).  frac counts every "
                                        "non-multiply instruction of the round (191 of 965 per lane-round) as a lost slot; frac_of_own_mix_ceiling prices the kernel's own mix instead. "
@@ -1111,9 +1111,9 @@ def main():
                                     "permutations_per_launch": perms,
                                     "limb_macs_per_permutation": 3 * 55 * MADS_PER_LANE_ROUND,
                                     "waves_per_launch": waves, "waves_per_simd_in_launch": waves / CHIP_SIMDS, "resident_waves_per_simd": 5,
-                                    "peak_source": "profiles/r04_microbench_ratio.jsonl (the round's mix, 8 waves per SIMD); counters of the kernel: profiles/r04_valu_roofline.md",
+                                    "peak_source": "profiles/r05_microbench_ratio.jsonl (the round's mix, 8 waves per SIMD); counters of the kernel: profiles/r04_valu_roofline.md",
                                     "note": "9 x 29-bit limbs, no carry instructions.  The kernel holds 96 VGPRs: 5 waves per SIMD are resident (the mix issues at 5.7 cycles per "
-                                            "multiply-accumulate with 4 waves, 5.46 with 8), and a launch whose waves per SIMD are not a multiple of 5 ends on partly filled SIMDs "
+                                            "multiply-accumulate with 4 waves, 5.38 with 8), and a launch whose waves per SIMD are not a multiple of 5 ends on partly filled SIMDs "
                                             "(8192 proofs: 6.5 waves per SIMD, isolated launch 0.82 of the ceiling; 16384: 12.95)"}
         else:
             out["roofline"] = {"bound": "valu_int32", "kernel": "pstate_hash_kernel", "achieved": None, "peak": CHIP_SIMDS * 64 * CLOCK_HZ / PURE_MAC_ISSUE_CYCLES / 1e12, "unit": "T limb-MAC/s",

@@ -42,7 +42,15 @@ sq = os.path.join(d, "sq", "s_counter_collection.csv")
 if os.path.exists(sq):
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     disp = collections.defaultdict(set)
-    for r in csv.DictReader(open(sq)):
+    rows_sq = list(csv.DictReader(open(sq)))
+    # the set-up launches some of the step's kernels too, on other grid sizes (round 5: the 16 384 distinct chains are hashed
+    # state by state, 17 launches of pstate_hash_kernel on 16 384 states each -- one step's worth of hashes that is not a step) and is left out
+    grids = collections.defaultdict(collections.Counter)
+    for r in rows_sq:
+        if r["Counter_Name"] == "SQ_WAVES": grids[short(r["Kernel_Name"])][r["Grid_Size"]] += 1
+    for r in rows_sq:                                        # a (kernel, grid) pair belongs to the steps when it was launched a whole number of times per step
+        n_ = grids[short(r["Kernel_Name"])][r["Grid_Size"]]
+        if n_ < STEPS or n_ % STEPS: continue
         agg[short(r["Kernel_Name"])][r["Counter_Name"]] += float(r["Counter_Value"]); disp[short(r["Kernel_Name"])].add(r["Dispatch_Id"])
     # one-time kernels (SRS tables, the Lagrange basis' FFT stages: fewer launches than steps, or launches that come in one burst of a setup) are not part of a step
     setup = {k for k in agg if len(disp[k]) < STEPS or k.startswith("mb::lagrange_stage_kernel") or k.startswith("mb::msm_build_table_kernel") or k.startswith("mb::lagrange_digit_table_kernel")}

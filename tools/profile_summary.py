@@ -32,7 +32,9 @@ def pmc(path):
         per[short(r["Kernel_Name"])][int(r["Grid_Size"])].append(float(r["Counter_Value"]))
     res = {}
     for k, grids in per.items():
-        g = max(grids, key=lambda g: len(grids[g]))
+        g = max(grids, key=lambda g: (len(grids[g]), g))         # the most frequent grid; ties and near-ties aside, the set-up's smaller launches must not win:
+        big = max(grids)                                          # prefer the LARGEST grid when it was launched at least 10 times (the steps' launches; round 5: the set-up hashes
+        if len(grids[big]) >= 10: g = big                         # 16 384 chains state by state -- 17 small launches of pstate_hash_kernel against 14 of the step's)
         v = grids[g]
         res[k] = (sum(v) / len(v), len(v), g)
     return res
