@@ -455,6 +455,17 @@ def boundary_leg(m, devices: str, B: int, min_seconds: float = 2.0):
         assert all(o.all() for o in outs)
         return {"value": sum(counts) * B / el, "unit": "proofs/s", "calls": sum(counts)}
     two, four = callers(2), callers(4)
+    # one call of 8 x B proofs: chunks of B, at most four on the GPU at a time
+    big = None
+    if B == 8192:
+        big_job = _Batch(lib, items, 8 * B)
+        big_job.call()
+        big = big_job.timed(1.0, min_calls=3)
+    c5 = None
+    if B >= 4096:                                                     # BASELINE config C5's batch through the boundary: 4096 serialized proofs per call
+        c5_job = _Batch(lib, items, 4096)
+        c5_job.call()
+        c5 = c5_job.timed(1.0, min_calls=3)
     # What ONE bad opening per call costs everybody: a folded check that fails sends its chunk through the culprit search -- until round 5 with the device
     # drained and its lock held for the length of the search; now on a view context of the device (api_verify.hip Device::sc).  Caller 1 sends B good proofs per call; caller 2 sends B proofs with ONE bad opening (z1 with a flipped bit: the folded
     # opening check of its chunk fails, the search finds exactly that proof); both for min_seconds.  Reported: the clean caller's rate beside it, and the searcher's call time.
@@ -492,20 +503,15 @@ def boundary_leg(m, devices: str, B: int, min_seconds: float = 2.0):
                                    "the first column is what a well-behaved caller keeps beside it"}
     except Exception as e:                                            # noqa: BLE001 -- a diagnostic leg: never takes the line down
         search_cost = {"error": repr(e)[:300]}
-    # one call of 8 x B proofs: chunks of B, at most four on the GPU at a time
-    big = None
-    if B == 8192:
-        big_job = _Batch(lib, items, 8 * B)
-        big_job.call()
-        big = big_job.timed(1.0, min_calls=3)
-    c5 = None
-    if B >= 4096:                                                     # BASELINE config C5's batch through the boundary: 4096 serialized proofs per call
-        c5_job = _Batch(lib, items, 4096)
-        c5_job.call()
-        c5 = c5_job.timed(1.0, min_calls=3)
+    # ... and does a process that HAS searched stay slower?  (Round 3 found exactly that with a 32-way fan-out: more streams than hardware queues, for the life of the
+    # process.)  BASELINE C5's call again, after the searches above.  Round 5: yes while a search created its own fan-out streams (45 -> 52 - 54 ms, either search form);
+    # not since it borrows the failed chunk's idle streams (45.5 -> 43.7, 45.9 -> 46.0 ms).
+    c5_after = None
+    if c5 is not None and search_cost and "error" not in search_cost:
+        c5_after = c5_job.timed(1.0, min_calls=3)
     res = {"value": single["value"], "unit": "proofs/s", "proofs_per_call": B, "ms_per_call": single["ms_per_call"], "calls_timed": single["calls"],
            "bytes_per_proof": len(job.P[0]) + len(job.Q[0]), "host_threads": int(os.environ.get("MINA_HOST_THREADS", min((os.cpu_count() or 2) // 2, 64))), "usable_cores": usable_cores(),
-           "two_caller_threads": two, "four_caller_threads": four, "one_bad_opening_per_call": search_cost, "one_call_of_65536": big, "c5_4096_per_call": c5, "devices": devices,
+           "two_caller_threads": two, "four_caller_threads": four, "one_bad_opening_per_call": search_cost, "one_call_of_65536": big, "c5_4096_per_call": c5, "c5_4096_per_call_after_culprit_searches": c5_after, "devices": devices,
            "entry_point": "mina_verify_state_batch (include/mina_verify.h): bincode MinaStateProof + MinaStatePubInputs bytes -> verdict bytes",
            "poseidon_constants": m.lib.poseidon_params_name(), "process": "a fresh process holding only libminaverify.so (no torch): the operator's verifier process",
            "note": "host bytes in, bools out: parsing, to_input flattening, ledger + consensus checks, pinned staging, PCIe both ways, the GPU job (folding "

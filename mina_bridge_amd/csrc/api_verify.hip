@@ -591,8 +591,23 @@ int run_device_shape(Device &D, const CallIn &in, const std::vector<size_t> &idx
             // the other callers of the device keep queueing while the search runs beside their jobs
             std::lock_guard<std::mutex> lk(D.search_mu);
             (void)hipSetDevice(D.sc->device);
-            { std::lock_guard<std::mutex> dl(D.mu); mb_ctx_refresh_view(D.sc, c); }     // what is installed on c NOW (an install since the last search; tables prepared by the jobs)
+            // The search fans its parts over lanes 1 .. 3 of the view beside lane 0.  They run on the streams of the failed chunk's OWN slot -- its lane and its three leg
+            // streams, idle now (the chunk has been harvested) and held by the slot until this returns -- so that a search creates NO stream: a process with more
+            // streams than hardware queues stays slower for its whole life (round 3: after_search.py; round 5: BASELINE C5's call 45 -> 52 - 54 ms after a few searches
+            // that created theirs, with either search form).
+            hipStream_t borrowed[3] = {nullptr, nullptr, nullptr};
+            {
+                std::lock_guard<std::mutex> dl(D.mu);
+                mb_ctx_refresh_view(D.sc, c);                        // what is installed on c NOW (an install since the last search; tables prepared by the jobs)
+                Lane *own[3] = {&c->lanes[MB_PIPE_LANES + 3 * ch.slot_ix], &c->lanes[MB_PIPE_LANES + 3 * ch.slot_ix + 1], &c->lanes[MB_PIPE_LANES + 3 * ch.slot_ix + 2]};
+                for (int q = 0; q < 3; ++q) {
+                    if (!own[q]->stream && hipStreamCreateWithFlags(&own[q]->stream, hipStreamNonBlocking) != hipSuccess) return fail(MINA_ERR_HIP, "hipStreamCreate for the culprit search");
+                    borrowed[q] = own[q]->stream;
+                }
+            }
+            for (int q = 0; q < 3; ++q) D.sc->lanes[1 + q].stream = borrowed[q];
             rc = mina_state_job_batch(D.sc, &js.j, v.data());
+            for (int q = 0; q < 3; ++q) { if (D.sc->lanes[1 + q].stream) (void)hipStreamSynchronize(D.sc->lanes[1 + q].stream); D.sc->lanes[1 + q].stream = nullptr; }
         } else {
             std::lock_guard<std::mutex> lk(D.mu);
             // (round 4) The search runs synchronous jobs on lane 0 and fans out over lanes 0 .. search_fan - 1 (and the forked-leg helpers of lane 0) -- the lanes of the

@@ -9,4 +9,5 @@ import bench
 m.lib.tune_from_string(os.environ.get("MINA_TUNE", ""))
 r = bench.boundary_leg(m, "0", int(sys.argv[1]) if len(sys.argv) > 1 else 8192, 2.0)
 print(json.dumps({"tune": os.environ.get("MINA_TUNE", ""), "lone": round(r["value"]), "two_callers": round(r["two_caller_threads"]["value"]), "four_callers": round(r["four_caller_threads"]["value"]),
-                  "one_bad_opening_per_call": r["one_bad_opening_per_call"]}))
+                  "c5_before_ms": round(r["c5_4096_per_call"]["ms_per_call"], 1), "c5_after_searches_ms": r["c5_4096_per_call_after_culprit_searches"] and round(r["c5_4096_per_call_after_culprit_searches"]["ms_per_call"], 1),
+                  "one_bad_opening_per_call": {k: v for k, v in r["one_bad_opening_per_call"].items() if k != "note"}}))
