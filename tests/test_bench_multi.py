@@ -139,3 +139,14 @@ def test_c_abi_all_devices_leg_over_eight_logical_contexts():
     ad = json.loads(r.stdout.strip().splitlines()[-1])
     assert "error" not in ad and "skipped" not in ad, ad
     assert ad["n_devices"] == 8 and ad["distinct_gpus"] == 1 and ad["proofs_per_call"] == 512 and ad["value_all_devices"] > 0 and ad["c5_4096_per_call"]["value"] > 0
+
+
+@pytest.mark.gpu
+def test_exchange_variant_leg_on_a_one_rank_rccl_group():
+    """with the probes on, the forced 1-rank RCCL run also times `exchange_variant_8e2` over the real backend: nccl collectives of HBM tensors on the context's pinned
+    stream -- the leg's code path on a real node (the 2-rank runs on this box move host tensors over gloo)"""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--no-boundary", "--no-cpu-baseline", "--steps", "2", "--warmup", "1", "--jobs", "1024", "--pipeline", "2"],
+                       capture_output=True, text=True, timeout=1500, env=clean_env(MINA_BENCH_FORCE_DIST="1"))
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    x = json_line(r.stdout)["exchange_variant_8e2"]
+    assert x and "error" not in x and x["value"] > 0 and "RCCL" in x["collectives"], x

@@ -59,3 +59,14 @@ def test_opposite_discrepancies_on_the_first_proofs_of_two_shards_do_not_cancel(
     outs = run_ranks(2, 4, "opposite_z2_on_first_proofs")
     assert all(o["batch_ok"] is False and o["detail"]["opening_fold_ok"] is False for o in outs), outs
     assert outs[0]["verdicts"] == [0] * 4 and outs[1]["verdicts"] == [0] * 4, "each shard's own folded check fails too: nothing is accepted"
+
+
+def test_exchange_variant_on_the_real_backend_with_one_rank():
+    """a box with ONE GPU still has RCCL: a 1-rank group runs `ShardedStateJob` with device tensors through nccl collectives ON THE CONTEXT'S PINNED STREAM
+    (torch ExternalStream) -- the code path of a real multi-GPU node (all_to_all_single / all_gather of HBM tensors, stream-ordered, one word read), which the
+    2-rank runs on this box cannot take (they share GPU 0 over gloo).  Verdicts as the single-GPU job's; a bad opening fails the batch."""
+    (o,) = run_ranks(1, 6, "ok")
+    assert o["backend"] == "nccl" and o["batch_ok"] is True and o["verdicts"] == [1] * 6 == o["plain"], o
+    assert o["host_syncs"] == 0 and o["host_reads"] == 1, o
+    (o,) = run_ranks(1, 6, "bad_opening_on_last_rank")
+    assert o["backend"] == "nccl" and o["batch_ok"] is False and o["verdicts"] == [0] * 6, o
