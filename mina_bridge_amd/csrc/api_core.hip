@@ -82,9 +82,10 @@ void mb_ctx_refresh_view(mina_ctx *v, mina_ctx *p) {
         SrsState &a = v->srs[i]; const SrsState &b = p->srs[i];
         a.depth = b.depth; a.c = b.c; a.W = b.W;
         a.table.alias(b.table); a.table29.alias(b.table29); a.table29s.alias(b.table29s); a.h.alias(b.h);
-        a.lagrange_log2 = b.lagrange_log2; if (a.lagrange_host.size() != b.lagrange_host.size() || a.lagrange_log2 != b.lagrange_log2) a.lagrange_host = b.lagrange_host;
+        // the host-side Lagrange basis is derived from the SRS: the view keeps its copy (or one it computed itself) until the parent's SRS or domain changes
+        if (a.srs_gen != b.srs_gen || a.lagrange_log2 != b.lagrange_log2 || (a.lagrange_host.empty() && !b.lagrange_host.empty())) { a.lagrange_host = b.lagrange_host; a.lagrange_log2 = b.lagrange_log2; a.srs_gen = b.srs_gen; }
         a.lagrange_table.alias(b.lagrange_table); a.lagrange_table_n = b.lagrange_table_n; a.lagrange_table_log2 = b.lagrange_table_log2;
-        a.lagrange_digits.alias(b.lagrange_digits); a.lagrange_digits_n = b.lagrange_digits_n;
+        a.lagrange_digits.alias(b.lagrange_digits); a.lagrange_digits29.alias(b.lagrange_digits29); a.lagrange_digits_n = b.lagrange_digits_n;
         v->pparams[i].alias(p->pparams[i]); v->have_pparams[i] = p->have_pparams[i]; v->pparams_surrogate[i] = p->pparams_surrogate[i];
         v->merkle_salts[i].alias(p->merkle_salts[i]); v->merkle_depth[i] = p->merkle_depth[i];
     }
@@ -100,7 +101,7 @@ extern "C" void mina_ctx_destroy(mina_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     for (int i = 0; i < MB_MAX_LANES; ++i) if (c->lanes[i].stream) (void)hipStreamSynchronize(c->lanes[i].stream);
-    for (int i = 0; i < 2; ++i) { c->srs[i].table.release(); c->srs[i].table29.release(); c->srs[i].table29s.release(); c->srs[i].h.release(); c->srs[i].lagrange_table.release(); c->srs[i].lagrange_digits.release(); c->pparams[i].release(); c->merkle_salts[i].release(); }
+    for (int i = 0; i < 2; ++i) { c->srs[i].table.release(); c->srs[i].table29.release(); c->srs[i].table29s.release(); c->srs[i].h.release(); c->srs[i].lagrange_table.release(); c->srs[i].lagrange_digits.release(); c->srs[i].lagrange_digits29.release(); c->pparams[i].release(); c->merkle_salts[i].release(); }
     c->state_salts.release(); c->kimchi_index.release(); c->kimchi_tokens.release(); c->kimchi_literals.release();
     c->pickles_index.release(); c->pickles_tokens.release(); c->pickles_literals.release();
     if (c->step_host && c->step_host_free) c->step_host_free(c->step_host);

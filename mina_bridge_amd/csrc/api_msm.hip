@@ -205,7 +205,17 @@ int mb_msm_variable(mina_ctx *c, int curve, uint32_t n, const uint32_t *d_scalar
     if (n == 0) return fail(MINA_ERR_ARG, "n must be positive");
     MsmShape sh = variable_shape(n);
     int rc = MINA_OK;
-    DISPATCH_FIELD(base_field_of(curve), { rc = run_msm<F_>(c, sh, d_scalars, (const affine_t *)d_points_mont, d_out_words, (xyzz_t *)d_out_xyzz); });
+    // Round 5: the accumulate kernels run the 29-bit group law on variable bases too.  The points get a 2^261-domain twin first (two products per point against
+    // W = 20 mixed adds of ten products each: 1 %); equal / opposite points -- proofs may repeat a commitment -- are found exactly on the lazy limbs and go through
+    // the 8 x 32 redo queue like everywhere else.  mina_verify_tuning.msm_fp29 = 0: the 8 x 32 law (cross-check).
+    const affine_t *twin = nullptr;
+    if (mb_tune().msm_fp29) {
+        MsmWorkspace &w = c->L->ws;
+        if ((rc = w.points29.ensure((size_t)n * sizeof(affine_t)))) return rc;
+        DISPATCH_FIELD(base_field_of(curve), { msm_table29_kernel<F_><<<cdiv(n, 256), 256, 0, c->L->stream>>>(n, (const affine_t *)d_points_mont, c->fk[F_].m32, w.points29.as<affine_t>()); });
+        twin = w.points29.as<affine_t>();
+    }
+    DISPATCH_FIELD(base_field_of(curve), { rc = run_msm<F_>(c, sh, d_scalars, (const affine_t *)d_points_mont, d_out_words, (xyzz_t *)d_out_xyzz, twin); });
     return rc;
 }
 

@@ -1,4 +1,5 @@
 // api_srs.hip -- SRS generation / loading / export and the fixed-base window tables (a6).
+#include <atomic>
 #include "ctx.h"
 #include "msm.cuh"
 #include "lagrange.cuh"
@@ -44,6 +45,8 @@ static int srs_alloc(mina_ctx *c, int curve, uint32_t depth) {
     SrsState &s = c->srs[curve];
     s.depth = 0; s.c = 16; s.W = 16;
     s.lagrange_log2 = -1; s.lagrange_host.clear();
+    static std::atomic<uint64_t> gen{0};
+    s.srs_gen = ++gen;
     int rc;
     if ((rc = s.table.ensure((size_t)s.W * depth * sizeof(affine_t)))) return rc;
     if ((rc = s.table29.ensure((size_t)s.W * depth * sizeof(affine_t)))) return rc;
@@ -292,6 +295,12 @@ template <int F> static int build_lagrange_table(mina_ctx *c, SrsState &s, uint3
     if ((rc = s.lagrange_digits.ensure((size_t)n_dig * mb::LAGD_WINDOWS * mb::LAGD_DIGITS * sizeof(affine_t)))) return rc;
     mb::lagrange_digit_table_kernel<F><<<cdiv(n_dig * mb::LAGD_WINDOWS, 64), 64, 0, c->L->stream>>>(n_dig, n_tab, fk, s.lagrange_table.as<affine_t>(), s.lagrange_digits.as<affine_t>());
     HIPC(hipGetLastError());
+    {   // ... and the digit table its 2^261-domain twin (the direct commitments add on 29-bit limbs)
+        const size_t npts = (size_t)n_dig * mb::LAGD_WINDOWS * mb::LAGD_DIGITS;
+        if ((rc = s.lagrange_digits29.ensure(npts * sizeof(affine_t)))) return rc;
+        msm_table29_kernel<F><<<cdiv(npts, 256), 256, 0, c->L->stream>>>(npts, s.lagrange_digits.as<affine_t>(), fk.m32, s.lagrange_digits29.as<affine_t>());
+        HIPC(hipGetLastError());
+    }
     HIPC(hipStreamSynchronize(c->L->stream));
     s.lagrange_digits_n = n_dig;
     return MINA_OK;
@@ -326,7 +335,13 @@ int mb_lagrange_sums_dev(mina_ctx *c, int curve, uint32_t npub, size_t batch, co
     ProfScope ps_(c, PS_ACCUMULATE);
     const int FB = base_field_of(curve);
     hipStream_t st = c->L->stream;
-    if (batch * (size_t)c->nlanes <= 1024) {
+    if (mb_tune().msm_fp29 && s.lagrange_digits29.p) {
+        if (batch * (size_t)c->nlanes <= 1024) {
+            DISPATCH_FIELD(FB, { mb::pubcomm_direct29_kernel<F_, 64><<<(uint32_t)batch, 64, 0, st>>>((uint32_t)batch, npub, c->fk[F_], s.lagrange_digits.as<affine_t>(), s.lagrange_digits29.as<affine_t>(), d_scalars, (xyzz_t *)d_out_xyzz); });
+        } else {
+            DISPATCH_FIELD(FB, { mb::pubcomm_direct29_kernel<F_, 8><<<cdiv(batch * 8, 64), 64, 0, st>>>((uint32_t)batch, npub, c->fk[F_], s.lagrange_digits.as<affine_t>(), s.lagrange_digits29.as<affine_t>(), d_scalars, (xyzz_t *)d_out_xyzz); });
+        }
+    } else if (batch * (size_t)c->nlanes <= 1024) {
         DISPATCH_FIELD(FB, { mb::pubcomm_direct_kernel<F_, 64><<<(uint32_t)batch, 64, 0, st>>>((uint32_t)batch, npub, c->fk[F_], s.lagrange_digits.as<affine_t>(), d_scalars, (xyzz_t *)d_out_xyzz); });
     } else {
         DISPATCH_FIELD(FB, { mb::pubcomm_direct_kernel<F_, 8><<<cdiv(batch * 8, 64), 64, 0, st>>>((uint32_t)batch, npub, c->fk[F_], s.lagrange_digits.as<affine_t>(), d_scalars, (xyzz_t *)d_out_xyzz); });

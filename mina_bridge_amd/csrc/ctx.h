@@ -74,15 +74,17 @@ struct SrsState {
     DevBuf h;                          // 1 affine_t
     int lagrange_log2 = -1;            // cached Lagrange basis (canonical affine bytes, host side)
     std::vector<uint8_t> lagrange_host;
+    uint64_t srs_gen = 0;              // process-unique stamp of the SRS these tables were built from (api_srs.hip srs_alloc): a view context re-copies what it derived on a change
     DevBuf lagrange_table;             // window table (c = 8, W = 32) of the first lagrange_table_n basis points, for
     uint32_t lagrange_table_n = 0;     //   batched public-input commitments
     int lagrange_table_log2 = -1;
     DevBuf lagrange_digits;            // d * 2^(8w) * L_i, d = 1..128, of the first lagrange_digits_n (<= 64) basis points (lagrange.cuh: direct commitments)
     uint32_t lagrange_digits_n = 0;
+    DevBuf lagrange_digits29;          // ... its 2^261-domain twin: the direct commitments' mixed adds run on 29-bit limbs (lagrange.cuh pubcomm_direct29_kernel)
 };
 
 struct MsmWorkspace {
-    DevBuf scalars, points, ekey, eval, eoff, count, start, task_start, rem_pos, rem_bucket, info, sorted, partial, heavy, order, redo, ghist, stage, buckets, red_r, red_ws, red2_r, red2_w, set_total, out_words, out_xyzz, buckets29, seg_bad;
+    DevBuf scalars, points, points29 /* the 2^261-domain twin of a variable-base MSM's points (api_msm.hip mb_msm_variable) */, ekey, eval, eoff, count, start, task_start, rem_pos, rem_bucket, info, sorted, partial, heavy, order, redo, ghist, stage, buckets, red_r, red_ws, red2_r, red2_w, set_total, out_words, out_xyzz, buckets29, seg_bad;
 };
 
 // HIP-event stage timing on the context stream (off by default; bench.py turns it on for the timed region)
@@ -110,7 +112,7 @@ struct Lane {
     DevBuf kc_state, kc_pos, kc_cip, kc_pts, kc_v, kc_u, kc_comms, kc_xfer, kc_pch, pk_xe, pk_pub, pk_ok;                  // kimchi to_batch output rows (api_kimchi.hip)
     void release_all() {
         MsmWorkspace &w = ws;
-        DevBuf *all[] = {&w.scalars, &w.points, &w.ekey, &w.eval, &w.eoff, &w.count, &w.start, &w.task_start, &w.rem_pos, &w.rem_bucket, &w.info, &w.sorted, &w.partial, &w.heavy, &w.order, &w.redo, &w.ghist, &w.stage,
+        DevBuf *all[] = {&w.scalars, &w.points, &w.points29, &w.ekey, &w.eval, &w.eoff, &w.count, &w.start, &w.task_start, &w.rem_pos, &w.rem_bucket, &w.info, &w.sorted, &w.partial, &w.heavy, &w.order, &w.redo, &w.ghist, &w.stage,
                          &w.buckets, &w.buckets29, &w.seg_bad, &w.red_r, &w.red_ws, &w.red2_r, &w.red2_w, &w.set_total, &w.out_words, &w.out_xyzz, &tmp_a, &tmp_b, &tmp_c, &tmp_d,
                          &bp_ltab, &bp_htab, &bp_partial, &bp_ldig, &bp_hdig, &bp_colsum, &ipa_chals, &ipa_folded, &ipa_xyzz_a, &ipa_xyzz_b, &ipa_points, &ipa_scalars,
                          &ipa_sigma, &ipa_in_a, &ipa_in_b, &ipa_in_c, &ipa_verdict, &ipa_xfer, &ipa_shared, &ipa_shared_off,

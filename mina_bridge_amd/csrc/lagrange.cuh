@@ -11,6 +11,7 @@
 // factor, done by ONE DPP quad with the lane-cooperative group law (double: 3 dependent products, add: 4).
 #pragma once
 #include "groupmap.cuh"
+#include "ec29.cuh"
 
 namespace mb {
 
@@ -166,6 +167,66 @@ pubcomm_direct_kernel(uint32_t batch, uint32_t npub, FieldK fk, const affine_t *
 #pragma unroll 1
     for (int d = LPP / 2; d >= 1; d >>= 1) { const xyzz_t o = shfl_down_xyzz(acc, d); if ((int)l + d < LPP) xyzz_add<F>(acc, o); }
     if (live && l == 0) out[b] = acc;
+}
+
+// The same sums with the mixed adds on 29-bit limbs (ec29.cuh: the lazy XYZZ law of the MSM's accumulate kernels; round 5).  digits29 = the digit table's
+// 2^261-domain twin (api_srs.hip build_lagrange_table).  A lane whose running sum meets one of the law's exceptional cases (P = +-acc; found exactly on the lazy limbs)
+// starts over with the complete 8 x 32 law on the 2^256-domain table -- no queue: the lanes are independent and the case does not occur for honest inputs.
+template <int F, int LPP>
+__global__ void __launch_bounds__(64)
+pubcomm_direct29_kernel(uint32_t batch, uint32_t npub, FieldK fk, const affine_t *__restrict__ digits, const affine_t *__restrict__ digits29, const uint32_t *__restrict__ pub,
+                        xyzz_t *__restrict__ out) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t gid = blockIdx.x * 64 + threadIdx.x, b = gid / LPP, l = gid % LPP;
+    const bool live = b < batch;
+    xyzz_t acc = xyzz_inf();
+    if (live) {
+        xyzz29_t a29; bool inf = true, exact = true;
+#pragma unroll 1
+        for (uint32_t i = l; i < npub && exact; i += LPP) {
+            const uint32_t *sc = pub + ((size_t)b * npub + i) * 8;
+            const affine_t *row = digits29 + (size_t)i * LAGD_WINDOWS * LAGD_DIGITS;
+            uint32_t carry = 0, word = 0;
+#pragma unroll 1
+            for (uint32_t w = 0; w < LAGD_WINDOWS && exact; ++w) {
+                if ((w & 3u) == 0) word = sc[w >> 2];
+                uint32_t d = ((word >> (8 * (w & 3u))) & 0xffu) + carry;
+                const bool neg = d > 128u;
+                carry = neg ? 1u : 0u;
+                if (neg) d = 256u - d;
+                if (d == 0) continue;
+                const affine_t P = row[(size_t)w * LAGD_DIGITS + (d - 1)];
+                if (aff_is_inf(P)) continue;
+                exact = xyzz29_add_affine<F>(a29, inf, fe29_from_words(P.x), fe29_from_words(P.y), neg, fk.m32);
+            }
+        }
+        if (exact) acc = xyzz29_leave<F>(a29, inf, fk.one);
+        else {
+#pragma unroll 1
+            for (uint32_t i = l; i < npub; i += LPP) {
+                const uint32_t *sc = pub + ((size_t)b * npub + i) * 8;
+                const affine_t *row = digits + (size_t)i * LAGD_WINDOWS * LAGD_DIGITS;
+                uint32_t carry = 0, word = 0;
+#pragma unroll 1
+                for (uint32_t w = 0; w < LAGD_WINDOWS; ++w) {
+                    if ((w & 3u) == 0) word = sc[w >> 2];
+                    uint32_t d = ((word >> (8 * (w & 3u))) & 0xffu) + carry;
+                    const bool neg = d > 128u;
+                    carry = neg ? 1u : 0u;
+                    if (neg) d = 256u - d;
+                    if (d == 0) continue;
+                    affine_t P = row[(size_t)w * LAGD_DIGITS + (d - 1)];
+                    if (aff_is_inf(P)) continue;
+                    if (neg) P.y = fe_neg<F>(P.y);
+                    xyzz_add_affine<F>(acc, P.x, P.y, fk.one);
+                }
+            }
+        }
+    }
+#pragma unroll 1
+    for (int d = LPP / 2; d >= 1; d >>= 1) { const xyzz_t o = shfl_down_xyzz(acc, d); if ((int)l + d < LPP) xyzz_add<F>(acc, o); }
+    if (live && l == 0) out[b] = acc;
+#endif
 }
 
 }  // namespace mb

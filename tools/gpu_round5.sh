@@ -28,6 +28,10 @@ for st in "$@"; do
     abr04)    bash tools/ab_c2.sh tools/probes/bin/lib_r04.so 3 2>&1 | tee $O/ab_c2_r04.log ;;   # A = this build, B = the round-4 library (tools/probes/bin/lib_r04.so, built from 4076b66), same box
     account)  timeout 600 python tools/c4_rate.py > $O/c4_rate.log 2>&1; tail -8 $O/c4_rate.log ;;
     callers)  timeout 600 python tools/concurrent_callers.py 6 > $O/concurrent_callers.log 2>&1; tail -12 $O/concurrent_callers.log ;;
+    law29)    # kernel time of the direct commitments and the variable-base MSM with the 29-bit law (msm_fp29=1) and without (=0): rocprofv3 kernel stats of tools/probes/law29_ab.py
+              ( cd /tmp && export TMPDIR=/tmp && for t in 1 0; do MINA_TUNE=msm_fp29=$t rocprofv3 --kernel-trace --stats -f csv -d $GRAFT_REPO_ROOT/$O/law29_$t -o t -- python $GRAFT_REPO_ROOT/tools/probes/law29_ab.py > $GRAFT_REPO_ROOT/$O/law29_$t.log 2>&1; done )
+              for t in 1 0; do echo "msm_fp29=$t $(tail -1 $O/law29_$t.log)"; f=$(find $O/law29_$t -name "*kernel_stats.csv" | head -1); grep -i "pubcomm\|msm_accumulate\|msm_table29" $f | cut -d, -f1-5 | cut -c1-160; done | tee $O/law29_ab.txt ;;
+    lawtests) ( time timeout 2400 python -m pytest tests/test_lagrange.py tests/test_gpu_msm.py tests/test_kimchi.py tests/test_state_job.py tests/test_native_composite.py tests/test_verify_boundary.py -m gpu -q -x ) > $O/pytest_law.log 2>&1; tail -5 $O/pytest_law.log ;;
     *) echo "unknown stage $st" ;;
   esac
 done
