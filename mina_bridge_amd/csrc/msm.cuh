@@ -312,6 +312,21 @@ msm_part_kernel(MsmShape sh, SortShape ss, const uint32_t *__restrict__ scalars,
                 const uint32_t pos = atomicAdd(&cur[lb >> ss.fbits], 1u);
                 staging[pos] = make_uint2(ref, lb & ((1u << ss.fbits) - 1u));
             }
+        } else if (sh.c == 16 && sh.W == 16 && sh.table_stride) {
+            // The SRS window tables (c = 16): window w's raw digit IS the w-th 16-bit half-word of the scalar, read straight from memory (four lanes share the 32-byte
+            // line; it stays in L1).  The generic path below cuts digits of any width out of s[8] with a run-time index -- a chain of selects: 114 instructions per entry
+            // against ~25 here (profiles/msm_valu.json: 14.9 M of a C2 call's 291 M wave-instructions were this pass).  Same digits, same carries (msm_entry's rule).
+            const uint16_t *__restrict__ hw = reinterpret_cast<const uint16_t *>(scalars + ((size_t)m * sh.n + i) * 8);
+            for (uint32_t w = tid >> 8; w < 16; w += 4) {
+                uint32_t carry = 0;
+                for (int j = (int)w - 1; j >= 0; --j) { const uint32_t r = hw[j]; if (r > 0x8000u) { carry = 1; break; } if (r < 0x8000u) break; }
+                uint32_t d = (uint32_t)hw[w] + carry, neg = 0;
+                if (d > 0x8000u) { d = 0x10000u - d; neg = 1; }
+                if (d == 0) { ek[(size_t)w * sh.n] = MSM_INVALID; continue; }
+                const uint32_t lb = m * sh.NB + (d - 1) - m * ss.SB;
+                ek[(size_t)w * sh.n] = lb | (neg << 31);
+                atomicAdd(&cur[lb >> ss.fbits], 1u);
+            }
         } else {
             uint32_t s[8];
             load_scalar(scalars + ((size_t)m * sh.n + i) * 8, s);

@@ -523,7 +523,7 @@ template <int F> MB_HD fe_t challenge_to_field(uint64_t lo, uint64_t hi, const F
 // instead of 10 when every lane rebuilt both factors.  Challenges come either as field elements (`chals`) or as the
 // 128-bit prechallenges (`prechal`, 4 words each), converted by the first k lanes of every block (ScalarChallenge::to_field).
 #if defined(__HIPCC__)
-static constexpr uint32_t BP1_HT = 4;
+static constexpr uint32_t BP1_HT = 16;         // round 5: 16 (was 4): a lane's <= 10 products for L[lo] are shared by 16 outputs -- (10 + 16) / 16 = 1.6 products per coefficient against 3.5
 template <int F>
 __global__ void __launch_bounds__(256)
 bpoly_single_kernel(BpolyShape sh, FieldK fk, const uint32_t *__restrict__ chals, const uint32_t *__restrict__ prechal,
