@@ -30,7 +30,9 @@ static int run_bpoly_fold(mina_ctx *c, uint32_t k, size_t batch, const uint32_t 
         if ((rc = L.bp_ldig.ensure((size_t)nl * BPM_DIGITS * kpad)) || (rc = L.bp_hdig.ensure((size_t)nh * BPM_DIGITS * kpad)) ||
             (rc = L.bp_colsum.ensure((size_t)nh * nl * BPM_COLS * 8))) return rc;
         if (kpad != batch) { HIPC(hipMemsetAsync(L.bp_ldig.p, 0, (size_t)nl * BPM_DIGITS * kpad, L.stream)); HIPC(hipMemsetAsync(L.bp_hdig.p, 0, (size_t)nh * BPM_DIGITS * kpad, L.stream)); }
-        { ProfScope ps_(c, PS_BPOLY_TABLES); bpoly_tables_digits_kernel<F><<<cdiv(batch * (nl + nh), 256), 256, 0, L.stream>>>(sh, kpad, c->fk[F], d_chals, d_weights, L.bp_ldig.as<int8_t>(), L.bp_hdig.as<int8_t>()); }
+        { ProfScope ps_(c, PS_BPOLY_TABLES);
+          if (sh.lb >= 3 && sh.hb >= 3) bpoly_tables_digits8_kernel<F><<<cdiv(batch * ((nl + nh) / 8), 256), 256, 0, L.stream>>>(sh, kpad, c->fk[F], d_chals, d_weights, L.bp_ldig.as<int8_t>(), L.bp_hdig.as<int8_t>());
+          else bpoly_tables_digits_kernel<F><<<cdiv(batch * (nl + nh), 256), 256, 0, L.stream>>>(sh, kpad, c->fk[F], d_chals, d_weights, L.bp_ldig.as<int8_t>(), L.bp_hdig.as<int8_t>()); }
         { ProfScope ps_(c, PS_BPOLY_FOLD); bpoly_field_gemm_kernel<<<cdiv(nh, 4) * cdiv(nl, 4), 256, 0, L.stream>>>(nh, nl, kpad, L.bp_hdig.as<int8_t>(), L.bp_ldig.as<int8_t>(), L.bp_colsum.as<unsigned long long>()); }
         { ProfScope ps_(c, PS_BPOLY_FINISH); bpoly_colsum_reduce_kernel<F><<<cdiv(n, 256), 256, 0, L.stream>>>(nh, nl, sh.lb, c->fk[F], L.bp_colsum.as<unsigned long long>(), d_out); }
         HIPC(hipGetLastError());

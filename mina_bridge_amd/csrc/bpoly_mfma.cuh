@@ -59,6 +59,51 @@ bpoly_tables_digits_kernel(BpolyShape sh, uint32_t kpad, FieldK fk, const uint32
     }
 }
 
+// The same planes, EIGHT table entries per lane (round 5): the entries that differ only in their three low index bits share the product over the high bits, and the
+// eight combinations of the low three cost seven products -- (2.5 + 3) conversions + 2.5 + 7 products per 8 entries, 1.9 per entry against ~8 when every entry
+// multiplied out all its set bits (2350 -> ~650 instructions per entry: these two launches were 0.54 G of a Proof-of-State step's 30.5 G wave-instructions).
+// Same values (canonical Montgomery products are order-independent), same plane layout, b fastest.  Needs lb, hb >= 3.
+template <int F>
+__device__ __forceinline__ void bpoly_emit_digits(const fe_t &acc, int8_t *__restrict__ plane, uint32_t kpad, uint32_t b) {
+    uint32_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) {
+        const uint32_t d = ((acc.v[i >> 2] >> (8 * (i & 3))) & 0xffu) + carry;      // 0..256
+        carry = d >= 128u ? 1u : 0u;
+        plane[(size_t)i * kpad + b] = (int8_t)(d - (carry << 8));                    // the top byte is <= 0x40: no carry out
+    }
+}
+template <int F>
+__global__ void __launch_bounds__(256)
+bpoly_tables_digits8_kernel(BpolyShape sh, uint32_t kpad, FieldK fk, const uint32_t *__restrict__ chals, const uint32_t *__restrict__ weights,
+                            int8_t *__restrict__ Ld, int8_t *__restrict__ Hd) {
+    const uint32_t nl8 = 1u << (sh.lb - 3), nh8 = 1u << (sh.hb - 3);
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (size_t)sh.batch * (nl8 + nh8)) return;
+    const uint32_t b = (uint32_t)(gid % sh.batch), g = (uint32_t)(gid / sh.batch);
+    const uint32_t *cb = chals + (size_t)b * sh.k * 8;
+    const bool low = g < nl8;
+    const uint32_t hi_bits = low ? g : g - nl8, base = low ? 0u : sh.lb, nbits = low ? sh.lb : sh.hb;
+    auto chal = [&](uint32_t q) {                                  // the challenge of index bit base + q, Montgomery
+        fe_t c; const uint32_t *cp = cb + (size_t)(sh.k - 1 - (base + q)) * 8;
+        for (int i = 0; i < 8; ++i) c.v[i] = cp[i];
+        return fe_to_mont<F>(c, fk.r2);
+    };
+    fe_t t0 = fk.one;
+    if (!low && weights) { fe_t w; for (int i = 0; i < 8; ++i) w.v[i] = weights[(size_t)b * 8 + i]; t0 = fe_to_mont<F>(w, fk.r2); }
+#pragma unroll 1
+    for (uint32_t q = 3; q < nbits; ++q) if ((hi_bits >> (q - 3)) & 1u) t0 = fe_mul<F>(t0, chal(q));
+    int8_t *plane = (low ? Ld : Hd) + (size_t)hi_bits * 8 * BPM_DIGITS * kpad;      // entry e = hi_bits * 8 + j: plane + j * 32 * kpad
+    const size_t estride = (size_t)BPM_DIGITS * kpad;
+    const fe_t c0 = chal(0), c1 = chal(1);
+    const fe_t t1 = fe_mul<F>(t0, c0), t2 = fe_mul<F>(t0, c1), t3 = fe_mul<F>(t1, c1);
+    bpoly_emit_digits<F>(t0, plane, kpad, b); bpoly_emit_digits<F>(t1, plane + estride, kpad, b);
+    bpoly_emit_digits<F>(t2, plane + 2 * estride, kpad, b); bpoly_emit_digits<F>(t3, plane + 3 * estride, kpad, b);
+    const fe_t c2 = chal(2);
+    bpoly_emit_digits<F>(fe_mul<F>(t0, c2), plane + 4 * estride, kpad, b); bpoly_emit_digits<F>(fe_mul<F>(t1, c2), plane + 5 * estride, kpad, b);
+    bpoly_emit_digits<F>(fe_mul<F>(t2, c2), plane + 6 * estride, kpad, b); bpoly_emit_digits<F>(fe_mul<F>(t3, c2), plane + 7 * estride, kpad, b);
+}
+
 // C' = A B^T over int8 planes with K contiguous; block = 4 waves = 128 x 128 of C' (wave: 64 x 64 = 2 x 2 MFMA tiles = four
 // (hi, lo) pairs).  K runs in tiles of 128 bytes staged through LDS, double-buffered: the 256 threads fetch the two 128 x 128-byte tiles
 // with row-contiguous 16-byte loads (8 lanes = one 128-byte line of a plane row; the direct-from-L2 form made every load instruction of
