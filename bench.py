@@ -58,17 +58,17 @@ ACC_K, WRAP_K, LOG2_DOMAIN, NPUB, NCOMMS, NPTS, SLOT = 16, 15, 15, 40, 45, 2, 0
 STATES_PER_PROOF, PSTATE_SLOTS, PSTATE_BODY_FIELDS = 17, 64, 49
 HBM_PEAK_GBPS = 8000.0                                # MI355X_MICROARCH.md: 8 TB/s spec
 # VALU side of the roofline (the path is integer-multiply bound).  The dominant kernel runs its Poseidon rounds on 9 limbs of
-# 29 bits (fp29.cuh, lazy forms): per lane and round 2 squarings (99 limb multiply-accumulates each), 2 products (135) and one 3-term dot product
-# with the round constant inside its reduction (306) = 774 `v_mad_u64_u32` beside ~190 simple instructions (64-bit column shifts, negations, limb
-# masks).  ONE model (profiles/r04_valu_roofline.md): every instruction takes its issue slot, and the ceiling is the measured rate of THAT MIX -- 153
-# multiply-accumulates interleaved with 16 shifts, 9 negations, 8 masks, 4 32-bit shifts per trip, 8 waves per SIMD (`microbench --ratio`,
-# profiles/r05_microbench_ratio.jsonl): 5.38 nominal-clock cycles per multiply-accumulate OF THE MIX = 2.24 ns per wave64 multiply-accumulate per SIMD
-# (a pure stream: 4.66; the strict forms' mix of 765 + ~290 until late in round 4: 5.9 - 6.04).
+# 29 bits (fp29.cuh, signed-quotient-digit forms since late round 5): per lane and round 2 squarings (99 limb multiply-accumulates each), 2 products (135) and one
+# 3-term dot product with the round constant inside its reduction (306) = 774 `v_mad_u64_u32` / `v_mad_i64_i32` beside ~150 simple instructions (64-bit column shifts,
+# limb masks, the doubled limbs of a squaring; the lazy forms' 45 digit negations are gone: 925 VALU instructions per lane-round, 965 before).  ONE model
+# (profiles/r04_valu_roofline.md): every instruction takes its issue slot, and the ceiling is the measured rate of THAT MIX -- 153 multiply-accumulates interleaved with
+# 16 shifts, 9 masks, 4 32-bit shifts per trip, 8 waves per SIMD (`microbench --ratio`, profiles/r05_microbench_ratio.jsonl): 5.20 nominal-clock cycles per
+# multiply-accumulate OF THE MIX (the lazy forms' mix on the same box: 5.47; a pure stream: 4.52).
 MADS_PER_LANE_ROUND = 2 * 99 + 2 * 135 + 306
-MAD_ISSUE_CYCLES = 5.38                               # re-measured in round 5 (profiles/r05_microbench_ratio.jsonl: 5.38; round 4's boxes: 5.46)
+MAD_ISSUE_CYCLES = 5.20                               # the signed-digit round's mix (profiles/r05_microbench_ratio.jsonl; the lazy mix: 5.38 - 5.47 over the boxes of round 5)
 # SURVEY.md 8d's peak: a PURE stream of v_mad_u64_u32 (16 independent accumulators, operands on distinct register banks, 8 waves per SIMD) issues one per 4.52
 # cycles at the nominal 2.4 GHz = 1.88 ns per wave64 instruction per SIMD (profiles/r05_microbench_ratio.jsonl, the S = 0 row; the same in round 4): 34.8 T limb-MAC/s for the chip.
-# `roofline` is quoted against THIS peak (it forgives nothing: the round's ~190 shifts / negations / masks per 774 multiply-accumulates count as lost issue slots);
+# `roofline` is quoted against THIS peak (it forgives nothing: the round's ~150 shifts / masks per 774 multiply-accumulates count as lost issue slots);
 # `roofline_valu` keeps the own-mix ceiling beside it.
 PURE_MAC_ISSUE_CYCLES = 4.52
 CHIP_SIMDS, CLOCK_HZ = 1024, 2.4e9
@@ -1116,9 +1116,9 @@ def main():
                                               "(profiles/r05_microbench_ratio.jsonl, S = 0; re-measured per round: profiles/README.md)",
                                "note": "bound = the binding resource (SURVEY.md 8d: integer VALU, not HBM, not MFMA).  achieved = 29-bit limb multiply-accumulates per launch / the "
                                        "launch's HIP-event duration on its lane stream (isolated launches right after the timed region; second figure: inside it).  frac counts every "
-                                       "non-multiply instruction of the round (191 of 965 per lane-round) as a lost slot; frac_of_own_mix_ceiling prices the kernel's own mix instead. "
+                                       "non-multiply instruction of the round (151 of 925 per lane-round) as a lost slot; frac_of_own_mix_ceiling prices the kernel's own mix instead. "
                                        "`hbm`: the metric's 'HBM GB/s vs peak' view of the same launch; `traffic` = its PMC bytes"}
-            out["roofline_valu"] = {"bound": "issue rate of the kernel's own instruction mix (774 v_mad_u64_u32 + ~190 shifts / negations / masks per lane-round), measured: "
+            out["roofline_valu"] = {"bound": "issue rate of the kernel's own instruction mix (774 multiply-accumulates + ~150 shifts / masks per lane-round), measured: "
                                              f"{MAD_ISSUE_CYCLES} cycles at 2.4 GHz per wave64 multiply-accumulate per SIMD", "kernel": "pstate_hash_kernel",
                                     "achieved": got / 1e12, "peak": peak / 1e12, "unit": "T limb-MAC/s", "frac": got / peak, "frac_of_pure_mac_peak": got / pure_peak, "pure_mac_peak": pure_peak / 1e12,
                                     "permutations_per_launch": perms,

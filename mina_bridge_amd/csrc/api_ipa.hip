@@ -30,7 +30,7 @@ enum : uint8_t {
                                // run the tape on the curve whose BASE field is the proof's scalar field)      (32 B out)
 };
 template <int CURVE, int LANES>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LANES == 3 ? 4 : 1, 8)))   // 3-lane form: the four waves per SIMD it had before the signed-digit forms (+ 6 VGPRs)
 sponge_tape_kernel(uint32_t batch, uint32_t tape_len, uint32_t in_stride_words, uint32_t out_stride_words, FieldK kb, FieldK ks,
                    const PoseidonParams *__restrict__ pp, const uint8_t *__restrict__ tape, const uint32_t *__restrict__ init_state /* b*24 or null */,
                    const uint32_t *__restrict__ init_pos /* b*2 or null */, const uint32_t *__restrict__ inputs, uint32_t *__restrict__ outputs,

@@ -78,7 +78,7 @@ template <int F, int LANES> __device__ __forceinline__ fe_t coop_sum(const fe_t 
 }
 
 template <int LANES>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LANES == 3 ? 4 : 1, 8)))   // 3-lane form: the four waves per SIMD it had before the signed-digit forms (+ 6 VGPRs)
 kimchi_fq_kernel(uint32_t batch, uint32_t n_prev, FieldK kb, FieldK ks, const PoseidonParams *__restrict__ pp_b, const PoseidonParams *__restrict__ pp_s,
                  const KimchiIndexDev *__restrict__ ix, KimchiIn in, KimchiOut out, fe_t *__restrict__ xf, uint32_t *__restrict__ bad_input, uint32_t nblk,
                  const fe_t *__restrict__ pf_digest /* or null: role 1 computes it */, uint32_t pf_stride) {

@@ -96,14 +96,14 @@ template <int F> __device__ __forceinline__ fe_t fe29_leave(const fe29_t &a, con
 // scratch per lane (the call ABI) and made it SLOWER than the 8 x 32 kernel (C2: 8.6 k checks/s against 11.4 k).
 template <int F, class FirstY, class Done> __device__ __forceinline__ bool xyzz29_add_affine(xyzz29_t &acc, bool &inf, const fe29_t &qx, const fe29_t &qy, FirstY first_y, Done operands_done, const fe_t &m32) {
     if (inf) { acc.x = qx; acc.y = first_y(); acc.zz = fe29_from_words(m32); acc.zzz = acc.zz; inf = false; operands_done(); return true; }   // 1 in the 2^261 domain = the integer 2^261 mod p
-    const fe29_t pd = fe29_mul_hi_lz<F>(qx, acc.zz, fe29_kp_minus<F, EC29::SUB_X1_MULT>(acc.x)), r = fe29_mul_hi_lz<F>(qy, acc.zzz, fe29_kp_minus<F, EC29::SUB_Y1_MULT>(acc.y));   // u2 + K p - x1 < 35.1 p, s2 + K p - y1 < 15.2 p
+    const fe29_t pd = fe29_mul_hi_sg<F>(qx, acc.zz, fe29_kp_minus<F, EC29::SUB_X1_MULT>(acc.x)), r = fe29_mul_hi_sg<F>(qy, acc.zzz, fe29_kp_minus<F, EC29::SUB_Y1_MULT>(acc.y));   // u2 + K p - x1 < 13.1 p, s2 + K p - y1 < 5.1 p (signed quotient digits: fp29.cuh)
     operands_done();                                                                                                                           // qx, qy are dead from here
     if (__builtin_expect((pd.v[5] | pd.v[6] | pd.v[7] | (pd.v[8] & 0x3fffffu)) == 0u, 0))
         if (fe29_is_multiple_of_p<F>(pd)) return false;
-    const fe29_t pp = fe29_sqr_lz<F>(pd), ppp = fe29_mul_lz<F>(pd, pp), q = fe29_mul_asm<F>(acc.x, pp);                                       // < 17.7 p, < 12.9 p, < 4.6 p (strict: it enters two raw sums)
-    const fe29_t x3 = fe29_sqr_hi_asm<F>(r, fe29_kp_minus_a_minus_2b<F, EC29::X3_SUB_MULT>(ppp, q));                                           // r^2 + K p - (ppp + 2 q) < 25.8 p, inside the square's reduction
-    const fe29_t y3 = fe29_dot2_asm<F>(r, fe29_add_kp_minus<F, EC29::SUB_X3_MULT>(q, x3), fe29_kp_minus<F, EC29::SUB_Y1_MULT>(acc.y), ppp);   // r (q - x3) - y1 ppp, one reduction, the differences not normalised: < 5.5 p
-    acc.zz = fe29_mul_lz<F>(acc.zz, pp); acc.zzz = fe29_mul_lz<F>(acc.zzz, ppp);                                                               // < 9.4 p, < 9 p
+    const fe29_t pp = fe29_sqr_sg<F>(pd), ppp = fe29_mul_sg<F>(pd, pp), q = fe29_mul_sg<F>(acc.x, pp);                                       // < 3.4 p, < 2.4 p, < 2.3 p
+    const fe29_t x3 = fe29_sqr_hi_sg<F>(r, fe29_kp_minus_a_minus_2b<F, EC29::X3_SUB_MULT>(ppp, q));                                           // r^2 + K p - (ppp + 2 q) < 9.2 p, inside the square's reduction
+    const fe29_t y3 = fe29_dot2_asm<F>(r, fe29_add_kp_minus<F, EC29::SUB_X3_MULT>(q, x3), fe29_kp_minus<F, EC29::SUB_Y1_MULT>(acc.y), ppp);   // r (q - x3) - y1 ppp, one reduction, the differences not normalised (the strict unsigned form: raw limbs up to 2^31 leave a signed column no room): < 1.6 p
+    acc.zz = fe29_mul_sg<F>(acc.zz, pp); acc.zzz = fe29_mul_sg<F>(acc.zzz, ppp);                                                               // < 2.1 p, < 2.1 p
     acc.x = x3; acc.y = y3;
     return true;
 }
@@ -117,18 +117,18 @@ template <int F> __device__ __forceinline__ bool xyzz29_add_affine(xyzz29_t &acc
     return xyzz29_add_affine<F>(acc, inf, qx, qy, [&]() { return neg ? fe29_sub_kp<F, 1>(fe29_zero(), py) : py; }, []() {}, m32);
 }
 // a += b for two accumulators on 29-bit limbs, NEITHER infinity (add-2008-s on XYZZ: 12 products + 2 squares; the callers handle infinity).  Both within the
-// invariants of EC29, the sum within them again (fe29_bounds.py prove_group_add; multiples EC29::G_*).  Ten of the fourteen products lazy.
+// invariants of EC29, the sum within them again (fe29_bounds.py prove_group_add; multiples EC29::G_*).  Twelve of the thirteen reductions with signed quotient digits.
 // Returns FALSE -- a untouched -- when the points are equal or opposite (P = 0 mod p, found exactly as in the mixed add): the caller recomputes its unit of work
 // with the complete 8 x 32 law (msm.cuh: msm_segsum29_redo_kernel).
 template <int F> __device__ __forceinline__ bool xyzz29_add(xyzz29_t &a, const xyzz29_t &b) {
-    const fe29_t u1 = fe29_mul_lz<F>(a.x, b.zz), s1 = fe29_mul_lz<F>(a.y, b.zzz);                                                              // < 10.1 p, < 8.5 p
-    const fe29_t pd = fe29_mul_hi_lz<F>(b.x, a.zz, fe29_kp_minus<F, EC29::G_U1_MULT>(u1)), r = fe29_mul_hi_lz<F>(b.y, a.zzz, fe29_kp_minus<F, EC29::G_S1_MULT>(s1));   // u2 + K p - u1 < 22.1 p, s2 + K p - s1 < 18.5 p
+    const fe29_t u1 = fe29_mul_sg<F>(a.x, b.zz), s1 = fe29_mul_sg<F>(a.y, b.zzz);                                                              // < 2.3 p, < 2.1 p
+    const fe29_t pd = fe29_mul_hi_sg<F>(b.x, a.zz, fe29_kp_minus<F, EC29::G_U1_MULT>(u1)), r = fe29_mul_hi_sg<F>(b.y, a.zzz, fe29_kp_minus<F, EC29::G_S1_MULT>(s1));   // u2 + K p - u1 < 5.3 p, s2 + K p - s1 < 5.1 p
     if (__builtin_expect((pd.v[5] | pd.v[6] | pd.v[7] | (pd.v[8] & 0x3fffffu)) == 0u, 0))
         if (fe29_is_multiple_of_p<F>(pd)) return false;
-    const fe29_t pp = fe29_sqr_lz<F>(pd), ppp = fe29_mul_lz<F>(pd, pp), q = fe29_mul_asm<F>(u1, pp);                                            // < 11.8 p, < 10.1 p, < 2 p
-    const fe29_t x3 = fe29_sqr_hi_asm<F>(r, fe29_kp_minus_a_minus_2b<F, EC29::G_X3_SUB_MULT>(ppp, q));                                         // < 19.7 p
-    const fe29_t y3 = fe29_dot2_asm<F>(r, fe29_add_kp_minus<F, EC29::G_SUB_X3_MULT>(q, x3), fe29_kp_minus<F, EC29::G_S1_MULT>(s1), ppp);       // r (q - x3) - s1 ppp < 5 p
-    a.zz = fe29_mul_lz<F>(fe29_mul_lz<F>(a.zz, b.zz), pp); a.zzz = fe29_mul_lz<F>(fe29_mul_lz<F>(a.zzz, b.zzz), ppp);                          // < 8.9 p, < 8.7 p
+    const fe29_t pp = fe29_sqr_sg<F>(pd), ppp = fe29_mul_sg<F>(pd, pp), q = fe29_mul_sg<F>(u1, pp);                                            // < 2.3 p, < 2.1 p, < 2.1 p
+    const fe29_t x3 = fe29_sqr_hi_sg<F>(r, fe29_kp_minus_a_minus_2b<F, EC29::G_X3_SUB_MULT>(ppp, q));                                         // < 9.2 p
+    const fe29_t y3 = fe29_dot2_asm<F>(r, fe29_add_kp_minus<F, EC29::G_SUB_X3_MULT>(q, x3), fe29_kp_minus<F, EC29::G_S1_MULT>(s1), ppp);       // r (q - x3) - s1 ppp < 1.6 p
+    a.zz = fe29_mul_sg<F>(fe29_mul_sg<F>(a.zz, b.zz), pp); a.zzz = fe29_mul_sg<F>(fe29_mul_sg<F>(a.zzz, b.zzz), ppp);                          // < 2.1 p, < 2.1 p
     a.x = x3; a.y = y3;
     return true;
 }

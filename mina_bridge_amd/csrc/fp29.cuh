@@ -19,6 +19,16 @@
 // 2^261: 9 multiply-accumulates by 1 instead of a 27-instruction normalised addition).  The STRICT forms stay for everything whose result must be
 // below 1.13 p (the way out of the permutation, the group law of ec29.cuh).
 //
+// SIGNED-DIGIT forms (fe29_mul_sg / fe29_sqr_sg / fe29_mul_hi_sg / fe29_sqr_hi_sg / fe29_mulrc_sg / fe29_dot2rc_sg / fe29_dot3rc_sg, late round 5) -- what the Poseidon rounds
+// and the group law of ec29.cuh run on now.  The quotient digit of column k < 8 is the column's own low word READ AS AN int32 and SUBTRACTED (`v_mad_i64_i32` against the
+// negated prime limbs, which ride the constant bus): no instruction makes the digit -- the statement that cancels the low limb writes the new column to other registers, so
+// the old low word simply stays where it is for the digit's five later uses.  Digit 8 is (col & M29) - 2^30 (one v_and_or): its sign is fixed, so the quotient
+// M = - sum s_k 2^(29 k) lies in ((1 - 2^-27) R, (2 + 2^-27) R) and the result is T / R + (1 p, 2 p] -- positive with no offset term, limbs 0..7 normalised, and TIGHTER
+// than the lazy forms' + 8 p (the invariants of every caller shrank: states below 2.1 p, the accumulator's x below 10 p).  The accumulator is a two's-complement 64-bit
+// value; tools/fe29_bounds.py `product_signed` proves the true column sum inside [-2^63, 2^63) for every caller (worst: the MDS row's 27 products per column, 0.92 of
+// it); what does not fit -- the group law's two-term dot product on raw operands -- keeps the strict unsigned form.  Per Poseidon lane-round 925 VALU instructions
+// (965 with the lazy forms), per mixed add 1673 (1745); measured on one dependent chain x <- x^3: + 4.6 % at 5 - 8 waves per SIMD, + 8.5 % at 2 (tools/probes/sg_probe.hip).
+//
 // Only the wave-packed 3-lane permutation uses it (sponge.cuh): state enters as 8 x 32 Montgomery-2^256, is re-based with one product by
 // 2^266 mod p (x 2^256 -> x 2^261), runs its 55 rounds here, leaves with one product by 2^256 mod p and one conditional subtraction.
 // Bit-identical results (the value computed is the same field element): every sponge parity test runs through it.
@@ -82,28 +92,28 @@ MB_HD fe29_t fe29_add3(const fe29_t &a, const fe29_t &b, const fe29_t &c) {
 
 // ---- PROVEN CONSTANTS (tools/gen_fe29.py <- tools/fe29_bounds.py): do not edit by hand
 // proven by tools/fe29_bounds.py (interval model of every routine and of the callers' value discipline; gen_fe29.py refuses to write this file otherwise):
-//   group law: worst column 0.684 x 2^64; Poseidon lane forms: worst column 0.538 x 2^64
+//   group law: worst column 0.697 x 2^64; Poseidon lane forms: worst column 0.457 x 2^64
 struct EC29 {      // xyzz29_add_affine: accumulator invariants (units of p) and the multiple of p in every limb-wise "K p - b" (no limb may go negative)
-    static constexpr uint32_t INV_X = 26;
-    static constexpr uint32_t INV_Y = 6;
-    static constexpr uint32_t INV_ZZ = 10;
-    static constexpr uint32_t INV_ZZZ = 9;
+    static constexpr uint32_t INV_X = 10;
+    static constexpr uint32_t INV_Y = 2;
+    static constexpr uint32_t INV_ZZ = 3;
+    static constexpr uint32_t INV_ZZZ = 3;
     static constexpr uint32_t NEG_Y_MULT = 2;
-    static constexpr uint32_t SUB_X1_MULT = 27;
-    static constexpr uint32_t SUB_Y1_MULT = 7;
-    static constexpr uint32_t X3_SUB_MULT = 23;
-    static constexpr uint32_t SUB_X3_MULT = 27;
-    static constexpr uint32_t PD_MAX = 36;
+    static constexpr uint32_t SUB_X1_MULT = 11;
+    static constexpr uint32_t SUB_Y1_MULT = 3;
+    static constexpr uint32_t X3_SUB_MULT = 7;
+    static constexpr uint32_t SUB_X3_MULT = 11;
+    static constexpr uint32_t PD_MAX = 14;
     // xyzz29_add (two accumulators): the multiples under u1 = x1 zz2, s1 = y1 zzz2, ppp + 2 q and x3
-    static constexpr uint32_t G_U1_MULT = 12;
-    static constexpr uint32_t G_S1_MULT = 10;
-    static constexpr uint32_t G_X3_SUB_MULT = 16;
-    static constexpr uint32_t G_SUB_X3_MULT = 20;
+    static constexpr uint32_t G_U1_MULT = 3;
+    static constexpr uint32_t G_S1_MULT = 3;
+    static constexpr uint32_t G_X3_SUB_MULT = 7;
+    static constexpr uint32_t G_SUB_X3_MULT = 10;
 };
 struct SPONGE29 {   // the Poseidon lane forms' state bounds between rounds, in thousandths of p (fixed points of a lazy round)
-    static constexpr uint32_t LANES3_STATE_MILLI_P = 8300;
-    static constexpr uint32_t LANES8_STATE_MILLI_P = 16500;
-    static constexpr uint32_t LANES16_STATE_MILLI_P = 24400;
+    static constexpr uint32_t LANES3_STATE_MILLI_P = 2100;
+    static constexpr uint32_t LANES8_STATE_MILLI_P = 4100;
+    static constexpr uint32_t LANES16_STATE_MILLI_P = 6100;
 };
 // ---- END PROVEN CONSTANTS
 
@@ -1454,6 +1464,919 @@ template <int F> __device__ __forceinline__ fe29_t fe29_mul_hi_lz(const fe29_t &
         : "+&v"(col), "=&s"(cc) : "v"(a.v[8]), "v"(b.v[8]), "v"(m8), "v"(p8), "v"(h.v[7]));
     r.v[7] = (uint32_t)col & M29; col >>= 29;
     r.v[8] = (uint32_t)col + h.v[8];
+    return r;
+}
+template <int F> __device__ __forceinline__ fe29_t fe29_mul_sg(const fe29_t &a, const fe29_t &b) {
+    uint64_t col, nc, cc; fe29_t r;
+    uint32_t m0, m1, m2, m3, m4, m5, m6, m7, m8;
+    const int32_t n1 = -(int32_t)P29<F>::L1, n2 = -(int32_t)P29<F>::L2, n3 = -(int32_t)P29<F>::L3, n4 = -(int32_t)P29<F>::L4, n8 = -(int32_t)P29<F>::L8;
+    // column 0: 1 + 0 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 0"
+        : "=&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[0]));
+    m0 = (uint32_t)col;
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m0), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 1: 2 + 1 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[1]), "v"(a.v[1]), "v"(b.v[0]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m0), "s"(n1));
+    m1 = (uint32_t)col;
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m1), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 2: 3 + 2 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[2]), "v"(a.v[1]), "v"(b.v[1]), "v"(a.v[2]), "v"(b.v[0]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m1), "s"(n1), "v"(m0), "s"(n2));
+    m2 = (uint32_t)col;
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m2), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 3: 4 + 3 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[3]), "v"(a.v[1]), "v"(b.v[2]), "v"(a.v[2]), "v"(b.v[1]), "v"(a.v[3]), "v"(b.v[0]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m2), "s"(n1), "v"(m1), "s"(n2), "v"(m0), "s"(n3));
+    m3 = (uint32_t)col;
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m3), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 4: 5 + 4 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[4]), "v"(a.v[1]), "v"(b.v[3]), "v"(a.v[2]), "v"(b.v[2]), "v"(a.v[3]), "v"(b.v[1]), "v"(a.v[4]), "v"(b.v[0]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m3), "s"(n1), "v"(m2), "s"(n2), "v"(m1), "s"(n3), "v"(m0), "s"(n4));
+    m4 = (uint32_t)col;
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m4), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 5: 6 + 4 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[5]), "v"(a.v[1]), "v"(b.v[4]), "v"(a.v[2]), "v"(b.v[3]), "v"(a.v[3]), "v"(b.v[2]), "v"(a.v[4]), "v"(b.v[1]), "v"(a.v[5]), "v"(b.v[0]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m4), "s"(n1), "v"(m3), "s"(n2), "v"(m2), "s"(n3), "v"(m1), "s"(n4));
+    m5 = (uint32_t)col;
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m5), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 6: 7 + 4 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[6]), "v"(a.v[1]), "v"(b.v[5]), "v"(a.v[2]), "v"(b.v[4]), "v"(a.v[3]), "v"(b.v[3]), "v"(a.v[4]), "v"(b.v[2]), "v"(a.v[5]), "v"(b.v[1]), "v"(a.v[6]), "v"(b.v[0]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m5), "s"(n1), "v"(m4), "s"(n2), "v"(m3), "s"(n3), "v"(m2), "s"(n4));
+    m6 = (uint32_t)col;
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m6), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 7: 8 + 4 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[7]), "v"(a.v[1]), "v"(b.v[6]), "v"(a.v[2]), "v"(b.v[5]), "v"(a.v[3]), "v"(b.v[4]), "v"(a.v[4]), "v"(b.v[3]), "v"(a.v[5]), "v"(b.v[2]), "v"(a.v[6]), "v"(b.v[1]), "v"(a.v[7]), "v"(b.v[0]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m6), "s"(n1), "v"(m5), "s"(n2), "v"(m4), "s"(n3), "v"(m3), "s"(n4));
+    m7 = (uint32_t)col;
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m7), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 8: 9 + 5 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[8]), "v"(a.v[1]), "v"(b.v[7]), "v"(a.v[2]), "v"(b.v[6]), "v"(a.v[3]), "v"(b.v[5]), "v"(a.v[4]), "v"(b.v[4]), "v"(a.v[5]), "v"(b.v[3]), "v"(a.v[6]), "v"(b.v[2]), "v"(a.v[7]), "v"(b.v[1]), "v"(a.v[8]), "v"(b.v[0]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0\n\tv_mad_i64_i32 %0, %1, %10, %11, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m7), "s"(n1), "v"(m6), "s"(n2), "v"(m5), "s"(n3), "v"(m4), "s"(n4), "v"(m0), "s"(n8));
+    m8 = ((uint32_t)col & M29) | 0xC0000000u;        // (col & M29) - 2^30: the one digit with a fixed sign
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m8), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 9: 8 + 5 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[1]), "v"(b.v[8]), "v"(a.v[2]), "v"(b.v[7]), "v"(a.v[3]), "v"(b.v[6]), "v"(a.v[4]), "v"(b.v[5]), "v"(a.v[5]), "v"(b.v[4]), "v"(a.v[6]), "v"(b.v[3]), "v"(a.v[7]), "v"(b.v[2]), "v"(a.v[8]), "v"(b.v[1]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0\n\tv_mad_i64_i32 %0, %1, %10, %11, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n1), "v"(m7), "s"(n2), "v"(m6), "s"(n3), "v"(m5), "s"(n4), "v"(m1), "s"(n8));
+    r.v[0] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
+    // column 10: 7 + 4 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[2]), "v"(b.v[8]), "v"(a.v[3]), "v"(b.v[7]), "v"(a.v[4]), "v"(b.v[6]), "v"(a.v[5]), "v"(b.v[5]), "v"(a.v[6]), "v"(b.v[4]), "v"(a.v[7]), "v"(b.v[3]), "v"(a.v[8]), "v"(b.v[2]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n2), "v"(m7), "s"(n3), "v"(m6), "s"(n4), "v"(m2), "s"(n8));
+    r.v[1] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
+    // column 11: 6 + 3 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[3]), "v"(b.v[8]), "v"(a.v[4]), "v"(b.v[7]), "v"(a.v[5]), "v"(b.v[6]), "v"(a.v[6]), "v"(b.v[5]), "v"(a.v[7]), "v"(b.v[4]), "v"(a.v[8]), "v"(b.v[3]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n3), "v"(m7), "s"(n4), "v"(m3), "s"(n8));
+    r.v[2] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
+    // column 12: 5 + 2 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[4]), "v"(b.v[8]), "v"(a.v[5]), "v"(b.v[7]), "v"(a.v[6]), "v"(b.v[6]), "v"(a.v[7]), "v"(b.v[5]), "v"(a.v[8]), "v"(b.v[4]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n4), "v"(m4), "s"(n8));
+    r.v[3] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
+    // column 13: 4 + 1 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[5]), "v"(b.v[8]), "v"(a.v[6]), "v"(b.v[7]), "v"(a.v[7]), "v"(b.v[6]), "v"(a.v[8]), "v"(b.v[5]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m5), "s"(n8));
+    r.v[4] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
+    // column 14: 3 + 1 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[6]), "v"(b.v[8]), "v"(a.v[7]), "v"(b.v[7]), "v"(a.v[8]), "v"(b.v[6]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m6), "s"(n8));
+    r.v[5] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
+    // column 15: 2 + 1 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[7]), "v"(b.v[8]), "v"(a.v[8]), "v"(b.v[7]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m7), "s"(n8));
+    r.v[6] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
+    // column 16: 1 + 1 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[8]), "v"(b.v[8]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n8));
+    r.v[7] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
+    r.v[8] = (uint32_t)col;
+    return r;
+}
+template <int F> __device__ __forceinline__ fe29_t fe29_sqr_sg(const fe29_t &a) {
+    const uint32_t d0 = a.v[0] << 1, d1 = a.v[1] << 1, d2 = a.v[2] << 1, d3 = a.v[3] << 1, d4 = a.v[4] << 1, d5 = a.v[5] << 1, d6 = a.v[6] << 1, d7 = a.v[7] << 1;
+    uint64_t col, nc, cc; fe29_t r;
+    uint32_t m0, m1, m2, m3, m4, m5, m6, m7, m8;
+    const int32_t n1 = -(int32_t)P29<F>::L1, n2 = -(int32_t)P29<F>::L2, n3 = -(int32_t)P29<F>::L3, n4 = -(int32_t)P29<F>::L4, n8 = -(int32_t)P29<F>::L8;
+    // column 0: 1 + 0 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 0"
+        : "=&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(a.v[0]));
+    m0 = (uint32_t)col;
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m0), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 1: 1 + 1 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d0), "v"(a.v[1]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m0), "s"(n1));
+    m1 = (uint32_t)col;
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m1), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 2: 2 + 2 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d0), "v"(a.v[2]), "v"(a.v[1]), "v"(a.v[1]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m1), "s"(n1), "v"(m0), "s"(n2));
+    m2 = (uint32_t)col;
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m2), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 3: 2 + 3 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d0), "v"(a.v[3]), "v"(d1), "v"(a.v[2]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m2), "s"(n1), "v"(m1), "s"(n2), "v"(m0), "s"(n3));
+    m3 = (uint32_t)col;
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m3), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 4: 3 + 4 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d0), "v"(a.v[4]), "v"(d1), "v"(a.v[3]), "v"(a.v[2]), "v"(a.v[2]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m3), "s"(n1), "v"(m2), "s"(n2), "v"(m1), "s"(n3), "v"(m0), "s"(n4));
+    m4 = (uint32_t)col;
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m4), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 5: 3 + 4 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d0), "v"(a.v[5]), "v"(d1), "v"(a.v[4]), "v"(d2), "v"(a.v[3]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m4), "s"(n1), "v"(m3), "s"(n2), "v"(m2), "s"(n3), "v"(m1), "s"(n4));
+    m5 = (uint32_t)col;
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m5), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 6: 4 + 4 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d0), "v"(a.v[6]), "v"(d1), "v"(a.v[5]), "v"(d2), "v"(a.v[4]), "v"(a.v[3]), "v"(a.v[3]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m5), "s"(n1), "v"(m4), "s"(n2), "v"(m3), "s"(n3), "v"(m2), "s"(n4));
+    m6 = (uint32_t)col;
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m6), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 7: 4 + 4 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d0), "v"(a.v[7]), "v"(d1), "v"(a.v[6]), "v"(d2), "v"(a.v[5]), "v"(d3), "v"(a.v[4]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m6), "s"(n1), "v"(m5), "s"(n2), "v"(m4), "s"(n3), "v"(m3), "s"(n4));
+    m7 = (uint32_t)col;
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m7), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 8: 5 + 5 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d0), "v"(a.v[8]), "v"(d1), "v"(a.v[7]), "v"(d2), "v"(a.v[6]), "v"(d3), "v"(a.v[5]), "v"(a.v[4]), "v"(a.v[4]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0\n\tv_mad_i64_i32 %0, %1, %10, %11, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m7), "s"(n1), "v"(m6), "s"(n2), "v"(m5), "s"(n3), "v"(m4), "s"(n4), "v"(m0), "s"(n8));
+    m8 = ((uint32_t)col & M29) | 0xC0000000u;        // (col & M29) - 2^30: the one digit with a fixed sign
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m8), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 9: 4 + 5 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d1), "v"(a.v[8]), "v"(d2), "v"(a.v[7]), "v"(d3), "v"(a.v[6]), "v"(d4), "v"(a.v[5]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0\n\tv_mad_i64_i32 %0, %1, %10, %11, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n1), "v"(m7), "s"(n2), "v"(m6), "s"(n3), "v"(m5), "s"(n4), "v"(m1), "s"(n8));
+    r.v[0] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
+    // column 10: 4 + 4 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d2), "v"(a.v[8]), "v"(d3), "v"(a.v[7]), "v"(d4), "v"(a.v[6]), "v"(a.v[5]), "v"(a.v[5]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n2), "v"(m7), "s"(n3), "v"(m6), "s"(n4), "v"(m2), "s"(n8));
+    r.v[1] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
+    // column 11: 3 + 3 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d3), "v"(a.v[8]), "v"(d4), "v"(a.v[7]), "v"(d5), "v"(a.v[6]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n3), "v"(m7), "s"(n4), "v"(m3), "s"(n8));
+    r.v[2] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
+    // column 12: 3 + 2 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d4), "v"(a.v[8]), "v"(d5), "v"(a.v[7]), "v"(a.v[6]), "v"(a.v[6]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n4), "v"(m4), "s"(n8));
+    r.v[3] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
+    // column 13: 2 + 1 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d5), "v"(a.v[8]), "v"(d6), "v"(a.v[7]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m5), "s"(n8));
+    r.v[4] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
+    // column 14: 2 + 1 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d6), "v"(a.v[8]), "v"(a.v[7]), "v"(a.v[7]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m6), "s"(n8));
+    r.v[5] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
+    // column 15: 1 + 1 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d7), "v"(a.v[8]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m7), "s"(n8));
+    r.v[6] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
+    // column 16: 1 + 1 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[8]), "v"(a.v[8]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n8));
+    r.v[7] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
+    r.v[8] = (uint32_t)col;
+    return r;
+}
+template <int F> __device__ __forceinline__ fe29_t fe29_mul_hi_sg(const fe29_t &a, const fe29_t &b, const fe29_t &h) {
+    uint64_t col, nc, cc; fe29_t r;
+    uint32_t m0, m1, m2, m3, m4, m5, m6, m7, m8;
+    const int32_t n1 = -(int32_t)P29<F>::L1, n2 = -(int32_t)P29<F>::L2, n3 = -(int32_t)P29<F>::L3, n4 = -(int32_t)P29<F>::L4, n8 = -(int32_t)P29<F>::L8;
+    // column 0: 1 + 0 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 0"
+        : "=&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[0]));
+    m0 = (uint32_t)col;
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m0), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 1: 2 + 1 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[1]), "v"(a.v[1]), "v"(b.v[0]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m0), "s"(n1));
+    m1 = (uint32_t)col;
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m1), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 2: 3 + 2 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[2]), "v"(a.v[1]), "v"(b.v[1]), "v"(a.v[2]), "v"(b.v[0]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m1), "s"(n1), "v"(m0), "s"(n2));
+    m2 = (uint32_t)col;
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m2), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 3: 4 + 3 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[3]), "v"(a.v[1]), "v"(b.v[2]), "v"(a.v[2]), "v"(b.v[1]), "v"(a.v[3]), "v"(b.v[0]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m2), "s"(n1), "v"(m1), "s"(n2), "v"(m0), "s"(n3));
+    m3 = (uint32_t)col;
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m3), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 4: 5 + 4 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[4]), "v"(a.v[1]), "v"(b.v[3]), "v"(a.v[2]), "v"(b.v[2]), "v"(a.v[3]), "v"(b.v[1]), "v"(a.v[4]), "v"(b.v[0]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m3), "s"(n1), "v"(m2), "s"(n2), "v"(m1), "s"(n3), "v"(m0), "s"(n4));
+    m4 = (uint32_t)col;
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m4), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 5: 6 + 4 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[5]), "v"(a.v[1]), "v"(b.v[4]), "v"(a.v[2]), "v"(b.v[3]), "v"(a.v[3]), "v"(b.v[2]), "v"(a.v[4]), "v"(b.v[1]), "v"(a.v[5]), "v"(b.v[0]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m4), "s"(n1), "v"(m3), "s"(n2), "v"(m2), "s"(n3), "v"(m1), "s"(n4));
+    m5 = (uint32_t)col;
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m5), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 6: 7 + 4 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[6]), "v"(a.v[1]), "v"(b.v[5]), "v"(a.v[2]), "v"(b.v[4]), "v"(a.v[3]), "v"(b.v[3]), "v"(a.v[4]), "v"(b.v[2]), "v"(a.v[5]), "v"(b.v[1]), "v"(a.v[6]), "v"(b.v[0]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m5), "s"(n1), "v"(m4), "s"(n2), "v"(m3), "s"(n3), "v"(m2), "s"(n4));
+    m6 = (uint32_t)col;
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m6), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 7: 8 + 4 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[7]), "v"(a.v[1]), "v"(b.v[6]), "v"(a.v[2]), "v"(b.v[5]), "v"(a.v[3]), "v"(b.v[4]), "v"(a.v[4]), "v"(b.v[3]), "v"(a.v[5]), "v"(b.v[2]), "v"(a.v[6]), "v"(b.v[1]), "v"(a.v[7]), "v"(b.v[0]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m6), "s"(n1), "v"(m5), "s"(n2), "v"(m4), "s"(n3), "v"(m3), "s"(n4));
+    m7 = (uint32_t)col;
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m7), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 8: 9 + 5 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[8]), "v"(a.v[1]), "v"(b.v[7]), "v"(a.v[2]), "v"(b.v[6]), "v"(a.v[3]), "v"(b.v[5]), "v"(a.v[4]), "v"(b.v[4]), "v"(a.v[5]), "v"(b.v[3]), "v"(a.v[6]), "v"(b.v[2]), "v"(a.v[7]), "v"(b.v[1]), "v"(a.v[8]), "v"(b.v[0]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0\n\tv_mad_i64_i32 %0, %1, %10, %11, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m7), "s"(n1), "v"(m6), "s"(n2), "v"(m5), "s"(n3), "v"(m4), "s"(n4), "v"(m0), "s"(n8));
+    m8 = ((uint32_t)col & M29) | 0xC0000000u;        // (col & M29) - 2^30: the one digit with a fixed sign
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m8), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 9: 9 + 5 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[1]), "v"(b.v[8]), "v"(a.v[2]), "v"(b.v[7]), "v"(a.v[3]), "v"(b.v[6]), "v"(a.v[4]), "v"(b.v[5]), "v"(a.v[5]), "v"(b.v[4]), "v"(a.v[6]), "v"(b.v[3]), "v"(a.v[7]), "v"(b.v[2]), "v"(a.v[8]), "v"(b.v[1]), "v"(h.v[0]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0\n\tv_mad_i64_i32 %0, %1, %10, %11, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n1), "v"(m7), "s"(n2), "v"(m6), "s"(n3), "v"(m5), "s"(n4), "v"(m1), "s"(n8));
+    r.v[0] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
+    // column 10: 8 + 4 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[2]), "v"(b.v[8]), "v"(a.v[3]), "v"(b.v[7]), "v"(a.v[4]), "v"(b.v[6]), "v"(a.v[5]), "v"(b.v[5]), "v"(a.v[6]), "v"(b.v[4]), "v"(a.v[7]), "v"(b.v[3]), "v"(a.v[8]), "v"(b.v[2]), "v"(h.v[1]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n2), "v"(m7), "s"(n3), "v"(m6), "s"(n4), "v"(m2), "s"(n8));
+    r.v[1] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
+    // column 11: 7 + 3 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[3]), "v"(b.v[8]), "v"(a.v[4]), "v"(b.v[7]), "v"(a.v[5]), "v"(b.v[6]), "v"(a.v[6]), "v"(b.v[5]), "v"(a.v[7]), "v"(b.v[4]), "v"(a.v[8]), "v"(b.v[3]), "v"(h.v[2]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n3), "v"(m7), "s"(n4), "v"(m3), "s"(n8));
+    r.v[2] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
+    // column 12: 6 + 2 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[4]), "v"(b.v[8]), "v"(a.v[5]), "v"(b.v[7]), "v"(a.v[6]), "v"(b.v[6]), "v"(a.v[7]), "v"(b.v[5]), "v"(a.v[8]), "v"(b.v[4]), "v"(h.v[3]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n4), "v"(m4), "s"(n8));
+    r.v[3] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
+    // column 13: 5 + 1 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[5]), "v"(b.v[8]), "v"(a.v[6]), "v"(b.v[7]), "v"(a.v[7]), "v"(b.v[6]), "v"(a.v[8]), "v"(b.v[5]), "v"(h.v[4]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m5), "s"(n8));
+    r.v[4] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
+    // column 14: 4 + 1 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[6]), "v"(b.v[8]), "v"(a.v[7]), "v"(b.v[7]), "v"(a.v[8]), "v"(b.v[6]), "v"(h.v[5]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m6), "s"(n8));
+    r.v[5] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
+    // column 15: 3 + 1 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[7]), "v"(b.v[8]), "v"(a.v[8]), "v"(b.v[7]), "v"(h.v[6]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m7), "s"(n8));
+    r.v[6] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
+    // column 16: 2 + 1 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[8]), "v"(b.v[8]), "v"(h.v[7]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n8));
+    r.v[7] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
+    r.v[8] = (uint32_t)col + h.v[8];
+    return r;
+}
+template <int F> __device__ __forceinline__ fe29_t fe29_sqr_hi_sg(const fe29_t &a, const fe29_t &h) {
+    const uint32_t d0 = a.v[0] << 1, d1 = a.v[1] << 1, d2 = a.v[2] << 1, d3 = a.v[3] << 1, d4 = a.v[4] << 1, d5 = a.v[5] << 1, d6 = a.v[6] << 1, d7 = a.v[7] << 1;
+    uint64_t col, nc, cc; fe29_t r;
+    uint32_t m0, m1, m2, m3, m4, m5, m6, m7, m8;
+    const int32_t n1 = -(int32_t)P29<F>::L1, n2 = -(int32_t)P29<F>::L2, n3 = -(int32_t)P29<F>::L3, n4 = -(int32_t)P29<F>::L4, n8 = -(int32_t)P29<F>::L8;
+    // column 0: 1 + 0 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 0"
+        : "=&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(a.v[0]));
+    m0 = (uint32_t)col;
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m0), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 1: 1 + 1 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d0), "v"(a.v[1]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m0), "s"(n1));
+    m1 = (uint32_t)col;
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m1), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 2: 2 + 2 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d0), "v"(a.v[2]), "v"(a.v[1]), "v"(a.v[1]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m1), "s"(n1), "v"(m0), "s"(n2));
+    m2 = (uint32_t)col;
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m2), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 3: 2 + 3 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d0), "v"(a.v[3]), "v"(d1), "v"(a.v[2]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m2), "s"(n1), "v"(m1), "s"(n2), "v"(m0), "s"(n3));
+    m3 = (uint32_t)col;
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m3), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 4: 3 + 4 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d0), "v"(a.v[4]), "v"(d1), "v"(a.v[3]), "v"(a.v[2]), "v"(a.v[2]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m3), "s"(n1), "v"(m2), "s"(n2), "v"(m1), "s"(n3), "v"(m0), "s"(n4));
+    m4 = (uint32_t)col;
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m4), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 5: 3 + 4 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d0), "v"(a.v[5]), "v"(d1), "v"(a.v[4]), "v"(d2), "v"(a.v[3]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m4), "s"(n1), "v"(m3), "s"(n2), "v"(m2), "s"(n3), "v"(m1), "s"(n4));
+    m5 = (uint32_t)col;
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m5), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 6: 4 + 4 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d0), "v"(a.v[6]), "v"(d1), "v"(a.v[5]), "v"(d2), "v"(a.v[4]), "v"(a.v[3]), "v"(a.v[3]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m5), "s"(n1), "v"(m4), "s"(n2), "v"(m3), "s"(n3), "v"(m2), "s"(n4));
+    m6 = (uint32_t)col;
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m6), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 7: 4 + 4 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d0), "v"(a.v[7]), "v"(d1), "v"(a.v[6]), "v"(d2), "v"(a.v[5]), "v"(d3), "v"(a.v[4]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m6), "s"(n1), "v"(m5), "s"(n2), "v"(m4), "s"(n3), "v"(m3), "s"(n4));
+    m7 = (uint32_t)col;
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m7), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 8: 5 + 5 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d0), "v"(a.v[8]), "v"(d1), "v"(a.v[7]), "v"(d2), "v"(a.v[6]), "v"(d3), "v"(a.v[5]), "v"(a.v[4]), "v"(a.v[4]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0\n\tv_mad_i64_i32 %0, %1, %10, %11, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m7), "s"(n1), "v"(m6), "s"(n2), "v"(m5), "s"(n3), "v"(m4), "s"(n4), "v"(m0), "s"(n8));
+    m8 = ((uint32_t)col & M29) | 0xC0000000u;        // (col & M29) - 2^30: the one digit with a fixed sign
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m8), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 9: 5 + 5 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d1), "v"(a.v[8]), "v"(d2), "v"(a.v[7]), "v"(d3), "v"(a.v[6]), "v"(d4), "v"(a.v[5]), "v"(h.v[0]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0\n\tv_mad_i64_i32 %0, %1, %10, %11, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n1), "v"(m7), "s"(n2), "v"(m6), "s"(n3), "v"(m5), "s"(n4), "v"(m1), "s"(n8));
+    r.v[0] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
+    // column 10: 5 + 4 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d2), "v"(a.v[8]), "v"(d3), "v"(a.v[7]), "v"(d4), "v"(a.v[6]), "v"(a.v[5]), "v"(a.v[5]), "v"(h.v[1]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n2), "v"(m7), "s"(n3), "v"(m6), "s"(n4), "v"(m2), "s"(n8));
+    r.v[1] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
+    // column 11: 4 + 3 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d3), "v"(a.v[8]), "v"(d4), "v"(a.v[7]), "v"(d5), "v"(a.v[6]), "v"(h.v[2]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n3), "v"(m7), "s"(n4), "v"(m3), "s"(n8));
+    r.v[2] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
+    // column 12: 4 + 2 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d4), "v"(a.v[8]), "v"(d5), "v"(a.v[7]), "v"(a.v[6]), "v"(a.v[6]), "v"(h.v[3]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n4), "v"(m4), "s"(n8));
+    r.v[3] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
+    // column 13: 3 + 1 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d5), "v"(a.v[8]), "v"(d6), "v"(a.v[7]), "v"(h.v[4]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m5), "s"(n8));
+    r.v[4] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
+    // column 14: 3 + 1 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d6), "v"(a.v[8]), "v"(a.v[7]), "v"(a.v[7]), "v"(h.v[5]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m6), "s"(n8));
+    r.v[5] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
+    // column 15: 2 + 1 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d7), "v"(a.v[8]), "v"(h.v[6]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m7), "s"(n8));
+    r.v[6] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
+    // column 16: 2 + 1 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[8]), "v"(a.v[8]), "v"(h.v[7]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n8));
+    r.v[7] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
+    r.v[8] = (uint32_t)col + h.v[8];
+    return r;
+}
+template <int F> __device__ __forceinline__ fe29_t fe29_mulrc_sg(const fe29_t &a, const fe29_t &b, const fe29_t &c) {
+    uint64_t col, nc, cc; fe29_t r;
+    uint32_t m0, m1, m2, m3, m4, m5, m6, m7, m8;
+    const int32_t n1 = -(int32_t)P29<F>::L1, n2 = -(int32_t)P29<F>::L2, n3 = -(int32_t)P29<F>::L3, n4 = -(int32_t)P29<F>::L4, n8 = -(int32_t)P29<F>::L8;
+    // column 0: 2 + 0 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 0\n\tv_mad_u64_u32 %0, %1, %4, 1, %0"
+        : "=&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[0]), "v"(c.v[0]));
+    m0 = (uint32_t)col;
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m0), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 1: 3 + 1 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[1]), "v"(a.v[1]), "v"(b.v[0]), "v"(c.v[1]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m0), "s"(n1));
+    m1 = (uint32_t)col;
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m1), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 2: 4 + 2 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[2]), "v"(a.v[1]), "v"(b.v[1]), "v"(a.v[2]), "v"(b.v[0]), "v"(c.v[2]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m1), "s"(n1), "v"(m0), "s"(n2));
+    m2 = (uint32_t)col;
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m2), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 3: 5 + 3 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[3]), "v"(a.v[1]), "v"(b.v[2]), "v"(a.v[2]), "v"(b.v[1]), "v"(a.v[3]), "v"(b.v[0]), "v"(c.v[3]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m2), "s"(n1), "v"(m1), "s"(n2), "v"(m0), "s"(n3));
+    m3 = (uint32_t)col;
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m3), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 4: 6 + 4 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[4]), "v"(a.v[1]), "v"(b.v[3]), "v"(a.v[2]), "v"(b.v[2]), "v"(a.v[3]), "v"(b.v[1]), "v"(a.v[4]), "v"(b.v[0]), "v"(c.v[4]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m3), "s"(n1), "v"(m2), "s"(n2), "v"(m1), "s"(n3), "v"(m0), "s"(n4));
+    m4 = (uint32_t)col;
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m4), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 5: 7 + 4 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[5]), "v"(a.v[1]), "v"(b.v[4]), "v"(a.v[2]), "v"(b.v[3]), "v"(a.v[3]), "v"(b.v[2]), "v"(a.v[4]), "v"(b.v[1]), "v"(a.v[5]), "v"(b.v[0]), "v"(c.v[5]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m4), "s"(n1), "v"(m3), "s"(n2), "v"(m2), "s"(n3), "v"(m1), "s"(n4));
+    m5 = (uint32_t)col;
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m5), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 6: 8 + 4 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[6]), "v"(a.v[1]), "v"(b.v[5]), "v"(a.v[2]), "v"(b.v[4]), "v"(a.v[3]), "v"(b.v[3]), "v"(a.v[4]), "v"(b.v[2]), "v"(a.v[5]), "v"(b.v[1]), "v"(a.v[6]), "v"(b.v[0]), "v"(c.v[6]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m5), "s"(n1), "v"(m4), "s"(n2), "v"(m3), "s"(n3), "v"(m2), "s"(n4));
+    m6 = (uint32_t)col;
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m6), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 7: 9 + 4 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[7]), "v"(a.v[1]), "v"(b.v[6]), "v"(a.v[2]), "v"(b.v[5]), "v"(a.v[3]), "v"(b.v[4]), "v"(a.v[4]), "v"(b.v[3]), "v"(a.v[5]), "v"(b.v[2]), "v"(a.v[6]), "v"(b.v[1]), "v"(a.v[7]), "v"(b.v[0]), "v"(c.v[7]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m6), "s"(n1), "v"(m5), "s"(n2), "v"(m4), "s"(n3), "v"(m3), "s"(n4));
+    m7 = (uint32_t)col;
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m7), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 8: 10 + 5 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[8]), "v"(a.v[1]), "v"(b.v[7]), "v"(a.v[2]), "v"(b.v[6]), "v"(a.v[3]), "v"(b.v[5]), "v"(a.v[4]), "v"(b.v[4]), "v"(a.v[5]), "v"(b.v[3]), "v"(a.v[6]), "v"(b.v[2]), "v"(a.v[7]), "v"(b.v[1]), "v"(a.v[8]), "v"(b.v[0]), "v"(c.v[8]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0\n\tv_mad_i64_i32 %0, %1, %10, %11, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m7), "s"(n1), "v"(m6), "s"(n2), "v"(m5), "s"(n3), "v"(m4), "s"(n4), "v"(m0), "s"(n8));
+    m8 = ((uint32_t)col & M29) | 0xC0000000u;        // (col & M29) - 2^30: the one digit with a fixed sign
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m8), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 9: 8 + 5 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[1]), "v"(b.v[8]), "v"(a.v[2]), "v"(b.v[7]), "v"(a.v[3]), "v"(b.v[6]), "v"(a.v[4]), "v"(b.v[5]), "v"(a.v[5]), "v"(b.v[4]), "v"(a.v[6]), "v"(b.v[3]), "v"(a.v[7]), "v"(b.v[2]), "v"(a.v[8]), "v"(b.v[1]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0\n\tv_mad_i64_i32 %0, %1, %10, %11, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n1), "v"(m7), "s"(n2), "v"(m6), "s"(n3), "v"(m5), "s"(n4), "v"(m1), "s"(n8));
+    r.v[0] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
+    // column 10: 7 + 4 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[2]), "v"(b.v[8]), "v"(a.v[3]), "v"(b.v[7]), "v"(a.v[4]), "v"(b.v[6]), "v"(a.v[5]), "v"(b.v[5]), "v"(a.v[6]), "v"(b.v[4]), "v"(a.v[7]), "v"(b.v[3]), "v"(a.v[8]), "v"(b.v[2]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n2), "v"(m7), "s"(n3), "v"(m6), "s"(n4), "v"(m2), "s"(n8));
+    r.v[1] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
+    // column 11: 6 + 3 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[3]), "v"(b.v[8]), "v"(a.v[4]), "v"(b.v[7]), "v"(a.v[5]), "v"(b.v[6]), "v"(a.v[6]), "v"(b.v[5]), "v"(a.v[7]), "v"(b.v[4]), "v"(a.v[8]), "v"(b.v[3]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n3), "v"(m7), "s"(n4), "v"(m3), "s"(n8));
+    r.v[2] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
+    // column 12: 5 + 2 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[4]), "v"(b.v[8]), "v"(a.v[5]), "v"(b.v[7]), "v"(a.v[6]), "v"(b.v[6]), "v"(a.v[7]), "v"(b.v[5]), "v"(a.v[8]), "v"(b.v[4]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n4), "v"(m4), "s"(n8));
+    r.v[3] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
+    // column 13: 4 + 1 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[5]), "v"(b.v[8]), "v"(a.v[6]), "v"(b.v[7]), "v"(a.v[7]), "v"(b.v[6]), "v"(a.v[8]), "v"(b.v[5]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m5), "s"(n8));
+    r.v[4] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
+    // column 14: 3 + 1 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[6]), "v"(b.v[8]), "v"(a.v[7]), "v"(b.v[7]), "v"(a.v[8]), "v"(b.v[6]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m6), "s"(n8));
+    r.v[5] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
+    // column 15: 2 + 1 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[7]), "v"(b.v[8]), "v"(a.v[8]), "v"(b.v[7]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m7), "s"(n8));
+    r.v[6] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
+    // column 16: 1 + 1 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[8]), "v"(b.v[8]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n8));
+    r.v[7] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
+    r.v[8] = (uint32_t)col;
+    return r;
+}
+template <int F> __device__ __forceinline__ fe29_t fe29_dot2rc_sg(const fe29_t &a0, const fe29_t &b0, const fe29_t &a1, const fe29_t &b1, const fe29_t &c) {
+    uint64_t col, nc, cc; fe29_t r;
+    uint32_t m0, m1, m2, m3, m4, m5, m6, m7, m8;
+    const int32_t n1 = -(int32_t)P29<F>::L1, n2 = -(int32_t)P29<F>::L2, n3 = -(int32_t)P29<F>::L3, n4 = -(int32_t)P29<F>::L4, n8 = -(int32_t)P29<F>::L8;
+    // column 0: 3 + 0 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, 1, %0"
+        : "=&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[0]), "v"(c.v[0]));
+    m0 = (uint32_t)col;
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m0), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 1: 5 + 1 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[1]), "v"(a0.v[1]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[1]), "v"(a1.v[1]), "v"(b1.v[0]), "v"(c.v[1]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m0), "s"(n1));
+    m1 = (uint32_t)col;
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m1), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 2: 7 + 2 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[2]), "v"(a0.v[1]), "v"(b0.v[1]), "v"(a0.v[2]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[2]), "v"(a1.v[1]), "v"(b1.v[1]), "v"(a1.v[2]), "v"(b1.v[0]), "v"(c.v[2]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m1), "s"(n1), "v"(m0), "s"(n2));
+    m2 = (uint32_t)col;
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m2), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 3: 9 + 3 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[3]), "v"(a0.v[1]), "v"(b0.v[2]), "v"(a0.v[2]), "v"(b0.v[1]), "v"(a0.v[3]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[3]), "v"(a1.v[1]), "v"(b1.v[2]), "v"(a1.v[2]), "v"(b1.v[1]), "v"(a1.v[3]), "v"(b1.v[0]), "v"(c.v[3]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m2), "s"(n1), "v"(m1), "s"(n2), "v"(m0), "s"(n3));
+    m3 = (uint32_t)col;
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m3), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 4: 11 + 4 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[4]), "v"(a0.v[1]), "v"(b0.v[3]), "v"(a0.v[2]), "v"(b0.v[2]), "v"(a0.v[3]), "v"(b0.v[1]), "v"(a0.v[4]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[4]), "v"(a1.v[1]), "v"(b1.v[3]), "v"(a1.v[2]), "v"(b1.v[2]), "v"(a1.v[3]), "v"(b1.v[1]), "v"(a1.v[4]), "v"(b1.v[0]), "v"(c.v[4]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m3), "s"(n1), "v"(m2), "s"(n2), "v"(m1), "s"(n3), "v"(m0), "s"(n4));
+    m4 = (uint32_t)col;
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m4), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 5: 13 + 4 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[5]), "v"(a0.v[1]), "v"(b0.v[4]), "v"(a0.v[2]), "v"(b0.v[3]), "v"(a0.v[3]), "v"(b0.v[2]), "v"(a0.v[4]), "v"(b0.v[1]), "v"(a0.v[5]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[5]), "v"(a1.v[1]), "v"(b1.v[4]), "v"(a1.v[2]), "v"(b1.v[3]), "v"(a1.v[3]), "v"(b1.v[2]), "v"(a1.v[4]), "v"(b1.v[1]), "v"(a1.v[5]), "v"(b1.v[0]));
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(c.v[5]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m4), "s"(n1), "v"(m3), "s"(n2), "v"(m2), "s"(n3), "v"(m1), "s"(n4));
+    m5 = (uint32_t)col;
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m5), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 6: 15 + 4 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[6]), "v"(a0.v[1]), "v"(b0.v[5]), "v"(a0.v[2]), "v"(b0.v[4]), "v"(a0.v[3]), "v"(b0.v[3]), "v"(a0.v[4]), "v"(b0.v[2]), "v"(a0.v[5]), "v"(b0.v[1]), "v"(a0.v[6]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[6]), "v"(a1.v[1]), "v"(b1.v[5]), "v"(a1.v[2]), "v"(b1.v[4]), "v"(a1.v[3]), "v"(b1.v[3]), "v"(a1.v[4]), "v"(b1.v[2]));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a1.v[5]), "v"(b1.v[1]), "v"(a1.v[6]), "v"(b1.v[0]), "v"(c.v[6]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m5), "s"(n1), "v"(m4), "s"(n2), "v"(m3), "s"(n3), "v"(m2), "s"(n4));
+    m6 = (uint32_t)col;
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m6), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 7: 17 + 4 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[7]), "v"(a0.v[1]), "v"(b0.v[6]), "v"(a0.v[2]), "v"(b0.v[5]), "v"(a0.v[3]), "v"(b0.v[4]), "v"(a0.v[4]), "v"(b0.v[3]), "v"(a0.v[5]), "v"(b0.v[2]), "v"(a0.v[6]), "v"(b0.v[1]), "v"(a0.v[7]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[7]), "v"(a1.v[1]), "v"(b1.v[6]), "v"(a1.v[2]), "v"(b1.v[5]), "v"(a1.v[3]), "v"(b1.v[4]));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a1.v[4]), "v"(b1.v[3]), "v"(a1.v[5]), "v"(b1.v[2]), "v"(a1.v[6]), "v"(b1.v[1]), "v"(a1.v[7]), "v"(b1.v[0]), "v"(c.v[7]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m6), "s"(n1), "v"(m5), "s"(n2), "v"(m4), "s"(n3), "v"(m3), "s"(n4));
+    m7 = (uint32_t)col;
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m7), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 8: 19 + 5 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[8]), "v"(a0.v[1]), "v"(b0.v[7]), "v"(a0.v[2]), "v"(b0.v[6]), "v"(a0.v[3]), "v"(b0.v[5]), "v"(a0.v[4]), "v"(b0.v[4]), "v"(a0.v[5]), "v"(b0.v[3]), "v"(a0.v[6]), "v"(b0.v[2]), "v"(a0.v[7]), "v"(b0.v[1]), "v"(a0.v[8]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[8]), "v"(a1.v[1]), "v"(b1.v[7]), "v"(a1.v[2]), "v"(b1.v[6]));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a1.v[3]), "v"(b1.v[5]), "v"(a1.v[4]), "v"(b1.v[4]), "v"(a1.v[5]), "v"(b1.v[3]), "v"(a1.v[6]), "v"(b1.v[2]), "v"(a1.v[7]), "v"(b1.v[1]), "v"(a1.v[8]), "v"(b1.v[0]), "v"(c.v[8]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0\n\tv_mad_i64_i32 %0, %1, %10, %11, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m7), "s"(n1), "v"(m6), "s"(n2), "v"(m5), "s"(n3), "v"(m4), "s"(n4), "v"(m0), "s"(n8));
+    m8 = ((uint32_t)col & M29) | 0xC0000000u;        // (col & M29) - 2^30: the one digit with a fixed sign
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m8), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 9: 16 + 5 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[1]), "v"(b0.v[8]), "v"(a0.v[2]), "v"(b0.v[7]), "v"(a0.v[3]), "v"(b0.v[6]), "v"(a0.v[4]), "v"(b0.v[5]), "v"(a0.v[5]), "v"(b0.v[4]), "v"(a0.v[6]), "v"(b0.v[3]), "v"(a0.v[7]), "v"(b0.v[2]), "v"(a0.v[8]), "v"(b0.v[1]), "v"(a1.v[1]), "v"(b1.v[8]), "v"(a1.v[2]), "v"(b1.v[7]), "v"(a1.v[3]), "v"(b1.v[6]), "v"(a1.v[4]), "v"(b1.v[5]));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a1.v[5]), "v"(b1.v[4]), "v"(a1.v[6]), "v"(b1.v[3]), "v"(a1.v[7]), "v"(b1.v[2]), "v"(a1.v[8]), "v"(b1.v[1]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0\n\tv_mad_i64_i32 %0, %1, %10, %11, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n1), "v"(m7), "s"(n2), "v"(m6), "s"(n3), "v"(m5), "s"(n4), "v"(m1), "s"(n8));
+    r.v[0] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
+    // column 10: 14 + 4 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[2]), "v"(b0.v[8]), "v"(a0.v[3]), "v"(b0.v[7]), "v"(a0.v[4]), "v"(b0.v[6]), "v"(a0.v[5]), "v"(b0.v[5]), "v"(a0.v[6]), "v"(b0.v[4]), "v"(a0.v[7]), "v"(b0.v[3]), "v"(a0.v[8]), "v"(b0.v[2]), "v"(a1.v[2]), "v"(b1.v[8]), "v"(a1.v[3]), "v"(b1.v[7]), "v"(a1.v[4]), "v"(b1.v[6]), "v"(a1.v[5]), "v"(b1.v[5]), "v"(a1.v[6]), "v"(b1.v[4]));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a1.v[7]), "v"(b1.v[3]), "v"(a1.v[8]), "v"(b1.v[2]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n2), "v"(m7), "s"(n3), "v"(m6), "s"(n4), "v"(m2), "s"(n8));
+    r.v[1] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
+    // column 11: 12 + 3 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[3]), "v"(b0.v[8]), "v"(a0.v[4]), "v"(b0.v[7]), "v"(a0.v[5]), "v"(b0.v[6]), "v"(a0.v[6]), "v"(b0.v[5]), "v"(a0.v[7]), "v"(b0.v[4]), "v"(a0.v[8]), "v"(b0.v[3]), "v"(a1.v[3]), "v"(b1.v[8]), "v"(a1.v[4]), "v"(b1.v[7]), "v"(a1.v[5]), "v"(b1.v[6]), "v"(a1.v[6]), "v"(b1.v[5]), "v"(a1.v[7]), "v"(b1.v[4]), "v"(a1.v[8]), "v"(b1.v[3]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n3), "v"(m7), "s"(n4), "v"(m3), "s"(n8));
+    r.v[2] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
+    // column 12: 10 + 2 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[4]), "v"(b0.v[8]), "v"(a0.v[5]), "v"(b0.v[7]), "v"(a0.v[6]), "v"(b0.v[6]), "v"(a0.v[7]), "v"(b0.v[5]), "v"(a0.v[8]), "v"(b0.v[4]), "v"(a1.v[4]), "v"(b1.v[8]), "v"(a1.v[5]), "v"(b1.v[7]), "v"(a1.v[6]), "v"(b1.v[6]), "v"(a1.v[7]), "v"(b1.v[5]), "v"(a1.v[8]), "v"(b1.v[4]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n4), "v"(m4), "s"(n8));
+    r.v[3] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
+    // column 13: 8 + 1 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[5]), "v"(b0.v[8]), "v"(a0.v[6]), "v"(b0.v[7]), "v"(a0.v[7]), "v"(b0.v[6]), "v"(a0.v[8]), "v"(b0.v[5]), "v"(a1.v[5]), "v"(b1.v[8]), "v"(a1.v[6]), "v"(b1.v[7]), "v"(a1.v[7]), "v"(b1.v[6]), "v"(a1.v[8]), "v"(b1.v[5]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m5), "s"(n8));
+    r.v[4] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
+    // column 14: 6 + 1 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[6]), "v"(b0.v[8]), "v"(a0.v[7]), "v"(b0.v[7]), "v"(a0.v[8]), "v"(b0.v[6]), "v"(a1.v[6]), "v"(b1.v[8]), "v"(a1.v[7]), "v"(b1.v[7]), "v"(a1.v[8]), "v"(b1.v[6]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m6), "s"(n8));
+    r.v[5] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
+    // column 15: 4 + 1 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[7]), "v"(b0.v[8]), "v"(a0.v[8]), "v"(b0.v[7]), "v"(a1.v[7]), "v"(b1.v[8]), "v"(a1.v[8]), "v"(b1.v[7]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m7), "s"(n8));
+    r.v[6] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
+    // column 16: 2 + 1 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[8]), "v"(b0.v[8]), "v"(a1.v[8]), "v"(b1.v[8]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n8));
+    r.v[7] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
+    r.v[8] = (uint32_t)col;
+    return r;
+}
+template <int F> __device__ __forceinline__ fe29_t fe29_dot3rc_sg(const fe29_t &a0, const fe29_t &b0, const fe29_t &a1, const fe29_t &b1, const fe29_t &a2, const fe29_t &b2, const fe29_t &c) {
+    uint64_t col, nc, cc; fe29_t r;
+    uint32_t m0, m1, m2, m3, m4, m5, m6, m7, m8;
+    const int32_t n1 = -(int32_t)P29<F>::L1, n2 = -(int32_t)P29<F>::L2, n3 = -(int32_t)P29<F>::L3, n4 = -(int32_t)P29<F>::L4, n8 = -(int32_t)P29<F>::L8;
+    // column 0: 4 + 0 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, 0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, 1, %0"
+        : "=&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[0]), "v"(a2.v[0]), "v"(b2.v[0]), "v"(c.v[0]));
+    m0 = (uint32_t)col;
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m0), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 1: 7 + 1 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[1]), "v"(a0.v[1]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[1]), "v"(a1.v[1]), "v"(b1.v[0]), "v"(a2.v[0]), "v"(b2.v[1]), "v"(a2.v[1]), "v"(b2.v[0]), "v"(c.v[1]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m0), "s"(n1));
+    m1 = (uint32_t)col;
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m1), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 2: 10 + 2 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[2]), "v"(a0.v[1]), "v"(b0.v[1]), "v"(a0.v[2]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[2]), "v"(a1.v[1]), "v"(b1.v[1]), "v"(a1.v[2]), "v"(b1.v[0]), "v"(a2.v[0]), "v"(b2.v[2]), "v"(a2.v[1]), "v"(b2.v[1]), "v"(a2.v[2]), "v"(b2.v[0]), "v"(c.v[2]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m1), "s"(n1), "v"(m0), "s"(n2));
+    m2 = (uint32_t)col;
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m2), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 3: 13 + 3 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[3]), "v"(a0.v[1]), "v"(b0.v[2]), "v"(a0.v[2]), "v"(b0.v[1]), "v"(a0.v[3]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[3]), "v"(a1.v[1]), "v"(b1.v[2]), "v"(a1.v[2]), "v"(b1.v[1]), "v"(a1.v[3]), "v"(b1.v[0]), "v"(a2.v[0]), "v"(b2.v[3]), "v"(a2.v[1]), "v"(b2.v[2]), "v"(a2.v[2]), "v"(b2.v[1]), "v"(a2.v[3]), "v"(b2.v[0]));
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(c.v[3]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m2), "s"(n1), "v"(m1), "s"(n2), "v"(m0), "s"(n3));
+    m3 = (uint32_t)col;
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m3), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 4: 16 + 4 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[4]), "v"(a0.v[1]), "v"(b0.v[3]), "v"(a0.v[2]), "v"(b0.v[2]), "v"(a0.v[3]), "v"(b0.v[1]), "v"(a0.v[4]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[4]), "v"(a1.v[1]), "v"(b1.v[3]), "v"(a1.v[2]), "v"(b1.v[2]), "v"(a1.v[3]), "v"(b1.v[1]), "v"(a1.v[4]), "v"(b1.v[0]), "v"(a2.v[0]), "v"(b2.v[4]), "v"(a2.v[1]), "v"(b2.v[3]));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a2.v[2]), "v"(b2.v[2]), "v"(a2.v[3]), "v"(b2.v[1]), "v"(a2.v[4]), "v"(b2.v[0]), "v"(c.v[4]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m3), "s"(n1), "v"(m2), "s"(n2), "v"(m1), "s"(n3), "v"(m0), "s"(n4));
+    m4 = (uint32_t)col;
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m4), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 5: 19 + 4 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[5]), "v"(a0.v[1]), "v"(b0.v[4]), "v"(a0.v[2]), "v"(b0.v[3]), "v"(a0.v[3]), "v"(b0.v[2]), "v"(a0.v[4]), "v"(b0.v[1]), "v"(a0.v[5]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[5]), "v"(a1.v[1]), "v"(b1.v[4]), "v"(a1.v[2]), "v"(b1.v[3]), "v"(a1.v[3]), "v"(b1.v[2]), "v"(a1.v[4]), "v"(b1.v[1]), "v"(a1.v[5]), "v"(b1.v[0]));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a2.v[0]), "v"(b2.v[5]), "v"(a2.v[1]), "v"(b2.v[4]), "v"(a2.v[2]), "v"(b2.v[3]), "v"(a2.v[3]), "v"(b2.v[2]), "v"(a2.v[4]), "v"(b2.v[1]), "v"(a2.v[5]), "v"(b2.v[0]), "v"(c.v[5]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m4), "s"(n1), "v"(m3), "s"(n2), "v"(m2), "s"(n3), "v"(m1), "s"(n4));
+    m5 = (uint32_t)col;
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m5), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 6: 22 + 4 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[6]), "v"(a0.v[1]), "v"(b0.v[5]), "v"(a0.v[2]), "v"(b0.v[4]), "v"(a0.v[3]), "v"(b0.v[3]), "v"(a0.v[4]), "v"(b0.v[2]), "v"(a0.v[5]), "v"(b0.v[1]), "v"(a0.v[6]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[6]), "v"(a1.v[1]), "v"(b1.v[5]), "v"(a1.v[2]), "v"(b1.v[4]), "v"(a1.v[3]), "v"(b1.v[3]), "v"(a1.v[4]), "v"(b1.v[2]));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a1.v[5]), "v"(b1.v[1]), "v"(a1.v[6]), "v"(b1.v[0]), "v"(a2.v[0]), "v"(b2.v[6]), "v"(a2.v[1]), "v"(b2.v[5]), "v"(a2.v[2]), "v"(b2.v[4]), "v"(a2.v[3]), "v"(b2.v[3]), "v"(a2.v[4]), "v"(b2.v[2]), "v"(a2.v[5]), "v"(b2.v[1]), "v"(a2.v[6]), "v"(b2.v[0]), "v"(c.v[6]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m5), "s"(n1), "v"(m4), "s"(n2), "v"(m3), "s"(n3), "v"(m2), "s"(n4));
+    m6 = (uint32_t)col;
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m6), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 7: 25 + 4 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[7]), "v"(a0.v[1]), "v"(b0.v[6]), "v"(a0.v[2]), "v"(b0.v[5]), "v"(a0.v[3]), "v"(b0.v[4]), "v"(a0.v[4]), "v"(b0.v[3]), "v"(a0.v[5]), "v"(b0.v[2]), "v"(a0.v[6]), "v"(b0.v[1]), "v"(a0.v[7]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[7]), "v"(a1.v[1]), "v"(b1.v[6]), "v"(a1.v[2]), "v"(b1.v[5]), "v"(a1.v[3]), "v"(b1.v[4]));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a1.v[4]), "v"(b1.v[3]), "v"(a1.v[5]), "v"(b1.v[2]), "v"(a1.v[6]), "v"(b1.v[1]), "v"(a1.v[7]), "v"(b1.v[0]), "v"(a2.v[0]), "v"(b2.v[7]), "v"(a2.v[1]), "v"(b2.v[6]), "v"(a2.v[2]), "v"(b2.v[5]), "v"(a2.v[3]), "v"(b2.v[4]), "v"(a2.v[4]), "v"(b2.v[3]), "v"(a2.v[5]), "v"(b2.v[2]), "v"(a2.v[6]), "v"(b2.v[1]), "v"(a2.v[7]), "v"(b2.v[0]));
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(c.v[7]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m6), "s"(n1), "v"(m5), "s"(n2), "v"(m4), "s"(n3), "v"(m3), "s"(n4));
+    m7 = (uint32_t)col;
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m7), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 8: 28 + 5 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[8]), "v"(a0.v[1]), "v"(b0.v[7]), "v"(a0.v[2]), "v"(b0.v[6]), "v"(a0.v[3]), "v"(b0.v[5]), "v"(a0.v[4]), "v"(b0.v[4]), "v"(a0.v[5]), "v"(b0.v[3]), "v"(a0.v[6]), "v"(b0.v[2]), "v"(a0.v[7]), "v"(b0.v[1]), "v"(a0.v[8]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[8]), "v"(a1.v[1]), "v"(b1.v[7]), "v"(a1.v[2]), "v"(b1.v[6]));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a1.v[3]), "v"(b1.v[5]), "v"(a1.v[4]), "v"(b1.v[4]), "v"(a1.v[5]), "v"(b1.v[3]), "v"(a1.v[6]), "v"(b1.v[2]), "v"(a1.v[7]), "v"(b1.v[1]), "v"(a1.v[8]), "v"(b1.v[0]), "v"(a2.v[0]), "v"(b2.v[8]), "v"(a2.v[1]), "v"(b2.v[7]), "v"(a2.v[2]), "v"(b2.v[6]), "v"(a2.v[3]), "v"(b2.v[5]), "v"(a2.v[4]), "v"(b2.v[4]), "v"(a2.v[5]), "v"(b2.v[3]));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, 1, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a2.v[6]), "v"(b2.v[2]), "v"(a2.v[7]), "v"(b2.v[1]), "v"(a2.v[8]), "v"(b2.v[0]), "v"(c.v[8]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0\n\tv_mad_i64_i32 %0, %1, %10, %11, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m7), "s"(n1), "v"(m6), "s"(n2), "v"(m5), "s"(n3), "v"(m4), "s"(n4), "v"(m0), "s"(n8));
+    m8 = ((uint32_t)col & M29) | 0xC0000000u;        // (col & M29) - 2^30: the one digit with a fixed sign
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m8), "v"(col));   // - s_k p_0: the low limb cancels
+    col = (uint64_t)((int64_t)nc >> 29);
+    // column 9: 24 + 5 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[1]), "v"(b0.v[8]), "v"(a0.v[2]), "v"(b0.v[7]), "v"(a0.v[3]), "v"(b0.v[6]), "v"(a0.v[4]), "v"(b0.v[5]), "v"(a0.v[5]), "v"(b0.v[4]), "v"(a0.v[6]), "v"(b0.v[3]), "v"(a0.v[7]), "v"(b0.v[2]), "v"(a0.v[8]), "v"(b0.v[1]), "v"(a1.v[1]), "v"(b1.v[8]), "v"(a1.v[2]), "v"(b1.v[7]), "v"(a1.v[3]), "v"(b1.v[6]), "v"(a1.v[4]), "v"(b1.v[5]));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a1.v[5]), "v"(b1.v[4]), "v"(a1.v[6]), "v"(b1.v[3]), "v"(a1.v[7]), "v"(b1.v[2]), "v"(a1.v[8]), "v"(b1.v[1]), "v"(a2.v[1]), "v"(b2.v[8]), "v"(a2.v[2]), "v"(b2.v[7]), "v"(a2.v[3]), "v"(b2.v[6]), "v"(a2.v[4]), "v"(b2.v[5]), "v"(a2.v[5]), "v"(b2.v[4]), "v"(a2.v[6]), "v"(b2.v[3]), "v"(a2.v[7]), "v"(b2.v[2]), "v"(a2.v[8]), "v"(b2.v[1]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0\n\tv_mad_i64_i32 %0, %1, %10, %11, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n1), "v"(m7), "s"(n2), "v"(m6), "s"(n3), "v"(m5), "s"(n4), "v"(m1), "s"(n8));
+    r.v[0] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
+    // column 10: 21 + 4 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[2]), "v"(b0.v[8]), "v"(a0.v[3]), "v"(b0.v[7]), "v"(a0.v[4]), "v"(b0.v[6]), "v"(a0.v[5]), "v"(b0.v[5]), "v"(a0.v[6]), "v"(b0.v[4]), "v"(a0.v[7]), "v"(b0.v[3]), "v"(a0.v[8]), "v"(b0.v[2]), "v"(a1.v[2]), "v"(b1.v[8]), "v"(a1.v[3]), "v"(b1.v[7]), "v"(a1.v[4]), "v"(b1.v[6]), "v"(a1.v[5]), "v"(b1.v[5]), "v"(a1.v[6]), "v"(b1.v[4]));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a1.v[7]), "v"(b1.v[3]), "v"(a1.v[8]), "v"(b1.v[2]), "v"(a2.v[2]), "v"(b2.v[8]), "v"(a2.v[3]), "v"(b2.v[7]), "v"(a2.v[4]), "v"(b2.v[6]), "v"(a2.v[5]), "v"(b2.v[5]), "v"(a2.v[6]), "v"(b2.v[4]), "v"(a2.v[7]), "v"(b2.v[3]), "v"(a2.v[8]), "v"(b2.v[2]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n2), "v"(m7), "s"(n3), "v"(m6), "s"(n4), "v"(m2), "s"(n8));
+    r.v[1] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
+    // column 11: 18 + 3 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[3]), "v"(b0.v[8]), "v"(a0.v[4]), "v"(b0.v[7]), "v"(a0.v[5]), "v"(b0.v[6]), "v"(a0.v[6]), "v"(b0.v[5]), "v"(a0.v[7]), "v"(b0.v[4]), "v"(a0.v[8]), "v"(b0.v[3]), "v"(a1.v[3]), "v"(b1.v[8]), "v"(a1.v[4]), "v"(b1.v[7]), "v"(a1.v[5]), "v"(b1.v[6]), "v"(a1.v[6]), "v"(b1.v[5]), "v"(a1.v[7]), "v"(b1.v[4]), "v"(a1.v[8]), "v"(b1.v[3]));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a2.v[3]), "v"(b2.v[8]), "v"(a2.v[4]), "v"(b2.v[7]), "v"(a2.v[5]), "v"(b2.v[6]), "v"(a2.v[6]), "v"(b2.v[5]), "v"(a2.v[7]), "v"(b2.v[4]), "v"(a2.v[8]), "v"(b2.v[3]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n3), "v"(m7), "s"(n4), "v"(m3), "s"(n8));
+    r.v[2] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
+    // column 12: 15 + 2 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[4]), "v"(b0.v[8]), "v"(a0.v[5]), "v"(b0.v[7]), "v"(a0.v[6]), "v"(b0.v[6]), "v"(a0.v[7]), "v"(b0.v[5]), "v"(a0.v[8]), "v"(b0.v[4]), "v"(a1.v[4]), "v"(b1.v[8]), "v"(a1.v[5]), "v"(b1.v[7]), "v"(a1.v[6]), "v"(b1.v[6]), "v"(a1.v[7]), "v"(b1.v[5]), "v"(a1.v[8]), "v"(b1.v[4]), "v"(a2.v[4]), "v"(b2.v[8]), "v"(a2.v[5]), "v"(b2.v[7]));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a2.v[6]), "v"(b2.v[6]), "v"(a2.v[7]), "v"(b2.v[5]), "v"(a2.v[8]), "v"(b2.v[4]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n4), "v"(m4), "s"(n8));
+    r.v[3] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
+    // column 13: 12 + 1 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[5]), "v"(b0.v[8]), "v"(a0.v[6]), "v"(b0.v[7]), "v"(a0.v[7]), "v"(b0.v[6]), "v"(a0.v[8]), "v"(b0.v[5]), "v"(a1.v[5]), "v"(b1.v[8]), "v"(a1.v[6]), "v"(b1.v[7]), "v"(a1.v[7]), "v"(b1.v[6]), "v"(a1.v[8]), "v"(b1.v[5]), "v"(a2.v[5]), "v"(b2.v[8]), "v"(a2.v[6]), "v"(b2.v[7]), "v"(a2.v[7]), "v"(b2.v[6]), "v"(a2.v[8]), "v"(b2.v[5]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m5), "s"(n8));
+    r.v[4] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
+    // column 14: 9 + 1 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[6]), "v"(b0.v[8]), "v"(a0.v[7]), "v"(b0.v[7]), "v"(a0.v[8]), "v"(b0.v[6]), "v"(a1.v[6]), "v"(b1.v[8]), "v"(a1.v[7]), "v"(b1.v[7]), "v"(a1.v[8]), "v"(b1.v[6]), "v"(a2.v[6]), "v"(b2.v[8]), "v"(a2.v[7]), "v"(b2.v[7]), "v"(a2.v[8]), "v"(b2.v[6]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m6), "s"(n8));
+    r.v[5] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
+    // column 15: 6 + 1 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[7]), "v"(b0.v[8]), "v"(a0.v[8]), "v"(b0.v[7]), "v"(a1.v[7]), "v"(b1.v[8]), "v"(a1.v[8]), "v"(b1.v[7]), "v"(a2.v[7]), "v"(b2.v[8]), "v"(a2.v[8]), "v"(b2.v[7]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m7), "s"(n8));
+    r.v[6] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
+    // column 16: 3 + 1 products
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[8]), "v"(b0.v[8]), "v"(a1.v[8]), "v"(b1.v[8]), "v"(a2.v[8]), "v"(b2.v[8]));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n8));
+    r.v[7] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
+    r.v[8] = (uint32_t)col;
     return r;
 }
 // ---- END GENERATED

@@ -89,7 +89,11 @@ __global__ void __launch_bounds__(256) probe_ratio(uint32_t *out, uint32_t seed)
                 // shifts, 45 negations, 40 masks, 17 + 5 32-bit shifts: 37 per 153 (16 shr64 = kind 0, 9 sub = kind 5, 8 and = kind 1, 4 shl = kind 4)
                 constexpr int e37 = e % 37;
                 constexpr int kind2 = e37 >= 32 ? (e37 == 33 ? 5 : 4) : (e37 % 2 == 0 ? 0 : (e37 % 4 == 1 ? 5 : 1));
-                constexpr int kind = KIND == 2 ? kind2 : KIND == 1 ? 2 + (e & 1) : e % 5;
+                // KIND 3: the SIGNED-digit 3-lane round (late round 5): per 774 multiply-accumulates 80 64-bit shifts, 40 masks, 5 and-or (the one digit a product still
+                // makes), 17 + 5 32-bit shifts -- 29 per 153 (16 shr64 = kind 0, 9 and = kind 1, 4 shl = kind 4); the quotient digits' 45 negations are gone
+                constexpr int k3tab[29] = {0, 1, 0, 4, 0, 1, 0, 1, 0, 4, 0, 1, 0, 1, 0, 4, 0, 1, 0, 1, 0, 4, 0, 1, 0, 1, 0, 0, 0};
+                constexpr int kind3 = k3tab[e % 29];
+                constexpr int kind = KIND == 3 ? kind3 : KIND == 2 ? kind2 : KIND == 1 ? 2 + (e & 1) : e % 5;
                 if constexpr (kind == 5) asm volatile("v_sub_u32 %0, 0, %1" : "=v"(a[(j + 14) % UNROLL]) : "v"(b[(j + 3) % UNROLL]));
                 if constexpr (kind == 0) asm volatile("v_lshrrev_b64 %0, 29, %1" : "=v"(acc[(j + 7) % UNROLL]) : "v"(acc[(j + 8) % UNROLL]));
                 if constexpr (kind == 1) asm volatile("v_and_b32 %0, 0x1fffffff, %1" : "=v"(a[(j + 3) % UNROLL]) : "v"(b[(j + 9) % UNROLL]));
@@ -242,11 +246,12 @@ int main(int argc, char **argv) {
             {                                                                                                \
                 double t = time_kernel([&] { probe_ratio<S, KIND><<<blocks, 256>>>(out, 12345u); }, 5);      \
                 printf("{\"probe\": \"153 v_mad_u64_u32 + %d simple per trip (%s)\", \"waves_per_simd\": %d, \"simple_per_mac\": %.2f, \"cycles_per_mac\": %.2f, \"cycles_per_instr\": %.2f}\n", \
-                       S, KIND == 2 ? "the lazy 3-lane round's mix: 16 shr64, 9 sub, 8 and, 4 shl32" : KIND ? "add_co / addc_co pairs" : "shr64, and, add_co, addc_co, shl32 in rotation", wps, S / 153.0, t * clk / ((double)ITERS * 153 * wps), t * clk / ((double)ITERS * (153 + S) * wps)); \
+                       S, KIND == 3 ? "the signed-digit 3-lane round's mix: 16 shr64, 9 and, 4 shl32" : KIND == 2 ? "the lazy 3-lane round's mix: 16 shr64, 9 sub, 8 and, 4 shl32" : KIND ? "add_co / addc_co pairs" : "shr64, and, add_co, addc_co, shl32 in rotation", wps, S / 153.0, t * clk / ((double)ITERS * 153 * wps), t * clk / ((double)ITERS * (153 + S) * wps)); \
             }
             RATIO(0, 0) RATIO(58, 0) RATIO(77, 0) RATIO(115, 0) RATIO(153, 0) RATIO(191, 0) RATIO(230, 0) RATIO(306, 0) RATIO(459, 0)
             RATIO(77, 1) RATIO(153, 1) RATIO(230, 1) RATIO(306, 1)
-            RATIO(37, 2)                                                   // the lazy 3-lane round's own mix: what bench.py prices a multiply-accumulate at
+            RATIO(37, 2)                                                   // the lazy 3-lane round's own mix (until late in round 5)
+            RATIO(29, 3)                                                   // the signed-digit round's own mix: what bench.py prices a multiply-accumulate at
         }
         CHECK(hipFree(out));
         return 0;

@@ -243,19 +243,19 @@ __device__ __forceinline__ void poseidon_permute_oct(fe_t &s, const PoseidonPara
         return r; };
     fe29_t x = fe29_mul_asm<F>(fe29_from_words(s), q->enter);        // x 2^256 -> x 2^261
     // lazy products (fp29.cuh), as the 3-lane form; the even lane of a pair adds the round constant inside its reduction, the odd lane adds zero.
-    // In units of p: x < 16.4, x^2 < 10.2, x^3 / x^4 < 9.4, x^7 < 8.7, each half row < 8.2
+    // In units of p (tools/fe29_bounds.py; every reduction with signed quotient digits since round 5): x < 4.1, x^2 < 2.2, x^3 / x^4 < 2.1, x^7 < 2.1, each half row < 2.04
     const fe29_t *rcp = odd ? &q->zero : &q->rc2[0][e];
     const size_t rcs = odd ? 0 : 3;                                  // fe29_t elements per round
 #pragma unroll 1
     for (int r = 0; r < 55; ++r) {
-        const fe29_t x2 = fe29_sqr_lz<F>(x);
-        const fe29_t y = fe29_mul_lz<F>(x2, odd ? x : x2);           // even: x^4, odd: x^3
-        const fe29_t t = fe29_mul_lz<F>(y, swap29(y));               // x^7 on both lanes of the pair
+        const fe29_t x2 = fe29_sqr_sg<F>(x);
+        const fe29_t y = fe29_mul_sg<F>(x2, odd ? x : x2);           // even: x^4, odd: x^3
+        const fe29_t t = fe29_mul_sg<F>(y, swap29(y));               // x^7 on both lanes of the pair
         const fe29_t t0 = bcast29(t, 0), t1 = bcast29(t, 2), t2 = bcast29(t, 4);
-        const fe29_t u = fe29_dot2rc_lz<F>(ma, odd ? t2 : t0, mb, t1, rcp[rcs * r]);   // even: m0 t0 + m1 t1 + rc, odd: m2 t2 (+ 0 * t1)
+        const fe29_t u = fe29_dot2rc_sg<F>(ma, odd ? t2 : t0, mb, t1, rcp[rcs * r]);   // even: m0 t0 + m1 t1 + rc, odd: m2 t2 (+ 0 * t1)
         x = fe29_add(u, swap29(u));                                  // limbs normalised
     }
-    s = fe_cond_sub_p<F>(fe29_to_words(fe29_mul_asm<F>(x, q->leave)));   // x 2^261 -> x 2^256; the strict product: 16.4 p p / 2^261 + p < 1.13 p
+    s = fe_cond_sub_p<F>(fe29_to_words(fe29_mul_asm<F>(x, q->leave)));   // x 2^261 -> x 2^256; the strict product: 4.1 p p / 2^261 + p < 1.04 p
 #else
     (void)s; (void)pp;
 #endif
@@ -289,18 +289,18 @@ __device__ __forceinline__ void poseidon_permute_tri(fe_t &s, const PoseidonPara
     const PoseidonParams29 *__restrict__ q = pparams29_of(pp);
     const fe29_t m0 = q->mds[tp.e][0], m1 = q->mds[tp.e][1], m2 = q->mds[tp.e][2];
     fe29_t x = fe29_mul_asm<F>(fe29_from_words(s), q->enter);        // x 2^256 -> x 2^261
-    // The rounds use the LAZY products (fp29.cuh: quotient digits not masked, results < a b / 2^261 + 8.0001 p, limbs normalised).  Values along a round,
-    // in units of p, from x < 8.3: x^2 < 8.6, x^4 < 8.6, x^6 < 8.6, x^7 < 8.6, the MDS row with the round constant inside the reduction < 8.3 -- a fixed
-    // point below 2^258, so every limb product and every column stays inside 64 bits (tools/gen_fe29.py; the column maximum is 0.93 x 2^64).
+    // Every reduction of a round uses SIGNED quotient digits (fp29.cuh fe29_sqr_sg / fe29_mul_sg / fe29_dot3rc_sg: no instruction per digit, results within (1 p, 2 p] of
+    // the exact quotient, limbs normalised; the round constant rides inside the row's reduction).  Values along a round, in units of p, from x < 2.1: every power and the
+    // row < 2.05 -- a fixed point (tools/fe29_bounds.py prove_sponge_rounds: the row's 27 limb products per column reach 0.92 of the signed accumulator, nothing else half).
 #pragma unroll 1
     for (int r = 0; r < 55; ++r) {
-        const fe29_t x2 = fe29_sqr_lz<F>(x);
-        const fe29_t x4 = fe29_sqr_lz<F>(x2);
-        const fe29_t t = fe29_mul_lz<F>(fe29_mul_lz<F>(x4, x2), x);
+        const fe29_t x2 = fe29_sqr_sg<F>(x);
+        const fe29_t x4 = fe29_sqr_sg<F>(x2);
+        const fe29_t t = fe29_mul_sg<F>(fe29_mul_sg<F>(x4, x2), x);
         const fe29_t t0 = tri_bcast29(t, tp.base), t1 = tri_bcast29(t, tp.base + 1), t2 = tri_bcast29(t, tp.base + 2);
-        x = fe29_dot3rc_lz<F>(m0, t0, m1, t1, m2, t2, q->rc2[r][tp.e]);
+        x = fe29_dot3rc_sg<F>(m0, t0, m1, t1, m2, t2, q->rc2[r][tp.e]);
     }
-    s = fe_cond_sub_p<F>(fe29_to_words(fe29_mul_asm<F>(x, q->leave)));   // x 2^261 -> x 2^256; the strict product: 8.3 p p / 2^261 + p < 1.07 p: one conditional subtraction
+    s = fe_cond_sub_p<F>(fe29_to_words(fe29_mul_asm<F>(x, q->leave)));   // x 2^261 -> x 2^256; the strict product: 2.1 p p / 2^261 + p < 1.02 p: one conditional subtraction
 #else
     (void)s; (void)pp;                                               // device-only (the host pass never calls it)
 #endif
@@ -332,16 +332,16 @@ __device__ __forceinline__ void poseidon_permute_hex(fe_t &s, const PoseidonPara
     const size_t rcs = c == 0 ? 3 : 0;                               // fe29_t elements per round
 #pragma unroll 1
     for (int r = 0; r < 55; ++r) {
-        const fe29_t x2 = fe29_sqr_lz<F>(x);
-        const fe29_t y = fe29_mul_lz<F>(x2, odd ? x : x2);           // even: x^4, odd: x^3
-        const fe29_t t = fe29_mul_lz<F>(y, swap29(y));               // x_e^7 on every lane of quad e
+        const fe29_t x2 = fe29_sqr_sg<F>(x);
+        const fe29_t y = fe29_mul_sg<F>(x2, odd ? x : x2);           // even: x^4, odd: x^3
+        const fe29_t t = fe29_mul_sg<F>(y, swap29(y));               // x_e^7 on every lane of quad e
         fe29_t tc;
 #pragma unroll
         for (int i = 0; i < L29; ++i) tc.v[i] = (uint32_t)__shfl((int)t.v[i], src, 64);
-        const fe29_t pr = fe29_mulrc_lz<F>(m, tc, rcp[rcs * r]);     // mds[e][col] x_col^7 (+ the round constant on lane 0; lane 3 repeats column 2)
+        const fe29_t pr = fe29_mulrc_sg<F>(m, tc, rcp[rcs * r]);     // mds[e][col] x_col^7 (+ the round constant on lane 0; lane 3 repeats column 2)
         x = fe29_add3(pr, rot1(pr), rot2(pr));                       // the row's three terms, limbs normalised
     }
-    s = fe_cond_sub_p<F>(fe29_to_words(fe29_mul_asm<F>(x, q->leave)));   // x 2^261 -> x 2^256; the strict product: 24.3 p p / 2^261 + p < 1.2 p
+    s = fe_cond_sub_p<F>(fe29_to_words(fe29_mul_asm<F>(x, q->leave)));   // x 2^261 -> x 2^256; the strict product: 6.1 p p / 2^261 + p < 1.05 p
 #else
     (void)s; (void)pp;
 #endif

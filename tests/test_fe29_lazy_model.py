@@ -5,7 +5,7 @@ of the routines' callers (the XYZZ mixed add, the Poseidon lane forms); tools/ge
 proofs ran with (`struct EC29`, `struct SPONGE29`) for the C++ to use by name.  This file
   * runs the proofs, checks the committed fp29.cuh IS what the generator writes, and that ec29.cuh takes every multiple of p from `EC29::`;
   * re-introduces the round-4 bug (ONE p under a canonical y) and other broken disciplines: the prover -- and the generator -- must refuse;
-  * restates the generated column loop on Python integers (64-bit accumulator, masked or unmasked quotient digits, the high-half addend, the tenth operand) and
+  * restates the generated column loops on Python integers (64-bit accumulator; masked, unmasked or SIGNED quotient digits; the high-half addend, the tenth operand) and
     runs the group law and the lane forms' rounds on random AND adversarial concrete values (coordinates at their invariants, y = p - 1, 2^254, 2^254 - 2^233 - 1 ...):
     every column below 2^64, every limb-wise difference non-negative, every intermediate inside the interval the prover derived, every result the field element
     the textbook formula gives.
@@ -39,8 +39,48 @@ def value(v):
 
 
 # ------------------------------------------------------------------------------------------------ the generated column loop on concrete integers
+def model_product_signed(p, pairs, hi=None, c=None):
+    """tools/gen_fe29.py `body_sg` on a 64-bit two's-complement accumulator: the digit of column k < 8 is the column's low word read as an int32 and SUBTRACTED against the
+    prime limbs; digit 8 is (col & M29) - 2^30.  Returns (result limbs, largest |true column value| seen); asserts that the wrapped register and the true value agree
+    whenever the column is shifted."""
+    pl = limbs(p)
+    MASK = (1 << 64) - 1
+    s64 = lambda x: x - (1 << 64) if x >> 63 else x
+    col, true, d, r, peak = 0, 0, [0] * L, [0] * L, 0
+    for k in range(2 * L - 1):
+        for a, b in pairs:
+            for i in range(L):
+                if 0 <= k - i < L:
+                    col = (col + a[i] * b[k - i]) & MASK; true += a[i] * b[k - i]
+        for j in (1, 2, 3, 4, 8):
+            if 0 <= k - j < L and k - j < k:
+                col = (col - d[k - j] * pl[j]) & MASK; true -= d[k - j] * pl[j]
+        if hi is not None and k >= L:
+            col = (col + hi[k - L]) & MASK; true += hi[k - L]
+        if c is not None and k < L:
+            col = (col + c[k]) & MASK; true += c[k]
+        if k < L:
+            lo = col & 0xFFFFFFFF
+            d[k] = (lo - (1 << 32) if lo >> 31 else lo) if k < L - 1 else (lo & M29) - (1 << 30)
+            col = (col - d[k]) & MASK; true -= d[k]
+            assert s64(col) == true and true & M29 == 0, "the signed accumulator wrapped"
+            peak = max(peak, abs(true))
+            true >>= W; col = (s64(col) >> W) & MASK
+        else:
+            assert s64(col) == true, "the signed accumulator wrapped"
+            peak = max(peak, abs(true))
+            r[k - L] = true & M29
+            true >>= W; col = (s64(col) >> W) & MASK
+    assert true >= 0, "negative top limb"
+    r[L - 1] = true + (hi[L - 1] if hi is not None else 0)
+    assert peak < 1 << 63 and r[L - 1] < 1 << 32
+    return r, peak
+
+
 def model_product(p, pairs, lazy=False, hi=None, c=None):
-    """tools/gen_fe29.py `body`: (result limbs, largest accumulator value seen)"""
+    """tools/gen_fe29.py `body`: (result limbs, largest accumulator value seen); lazy = "sg": the signed-digit loop"""
+    if lazy == "sg":
+        return model_product_signed(p, pairs, hi=hi, c=c)
     pl = limbs(p)
     col, m, r, peak = 0, [0] * L, [0] * L, 0
     for k in range(2 * L - 1):
@@ -112,7 +152,7 @@ def test_the_prover_refuses_the_round_4_bug_and_other_broken_disciplines():
         with pytest.raises(B.BoundError):
             B.prove_group_law(f, lazy=B.EC29_LAZY + ("y3", "q", "x3"))     # every product lazy: the shipped constants do not hold (and no constants do: search_lazy_sets)
         with pytest.raises(B.BoundError):
-            B.prove_sponge_rounds(f, {"LANES3_STATE_MILLI_P": 8000})       # 8.0 p is not a fixed point of a lazy round (8.0001 p comes from the quotient alone)
+            B.prove_sponge_rounds(f, {"LANES3_STATE_MILLI_P": 2000})       # 2.0 p is not a fixed point of a round (the signed quotient alone brings up to 2.0000001 p)
 
 
 def test_the_generator_writes_nothing_when_a_proof_fails(monkeypatch):
@@ -158,24 +198,66 @@ def test_lazy_products_are_the_same_field_element_and_columns_stay_below_2_64():
     assert seen > 1 << 62                                                 # the adversarial patterns do come near the top
 
 
+def test_signed_digit_products_are_the_same_field_element_inside_one_to_two_p_and_their_columns_fit_a_signed_accumulator():
+    """fe29_mul_sg / fe29_sqr_sg / fe29_mul_hi_sg / fe29_sqr_hi_sg (round 5): the digit is the column's own low word (int32), digit 8 = (col & M29) - 2^30.  The result is
+    the same field element as T / R, lies in (T / R + 0.99 p, T / R + 2.0001 p) -- positive without an offset term -- with limbs 0..7 normalised, and the TRUE column
+    value equals the wrapped 64-bit register at every shift.  Operands up to the largest value any caller feeds (pd < 14 p), all-ones limbs, zero, one."""
+    rng = random.Random(77)
+    seen = 0
+    for F, p in P.items():
+        rinv = pow(R, -1, p)
+        bound = B.EC29["PD_MAX"] * p
+        top = bound >> B.TOP
+        extreme = [M29] * (L - 1) + [top]
+
+        def operand():
+            t = rng.random()
+            if t < 0.2: return list(extreme)
+            if t < 0.3: return limbs(rng.choice([0, 1, 2, p - 1, p, p + 1]))
+            if t < 0.5: return limbs(rng.randrange(bound))
+            if t < 0.6: return [rng.choice([0, M29]) for _ in range(L - 1)] + [rng.choice([0, top])]
+            return limbs(rng.randrange(p))
+        for _ in range(1500):
+            a, b = operand(), operand()
+            k = B.kp_redundant(p, B.EC29["SUB_X1_MULT"], 30)
+            h = [k[i] - x for i, x in enumerate(limbs(rng.randrange(B.EC29["INV_X"] * p)))]
+            for pairs, hh in (([(a, b)], None), ([(a, a)], None), ([(a, b)], h), ([(a, a)], h)):
+                r, peak = model_product(p, pairs, lazy="sg", hi=hh)
+                total = sum(value(x) * value(y) for x, y in pairs)
+                extra = value(hh) if hh else 0
+                assert (value(r) - extra) % p == total * rinv % p
+                assert 0.99 * p * R < (value(r) - extra) * R - total < 2.0001 * p * R
+                assert all(x <= M29 for x in r[:-1])
+                seen = max(seen, peak)
+    assert (1 << 60) < seen < (1 << 63)
+    # what the signed form cannot carry is refused by the prover: the group law's two-term dot product on raw operands, a four-term row
+    for f in (0, 1):
+        with pytest.raises(B.BoundError, match="signed accumulator"):
+            B.prove_group_law(f, signed=B.EC29_SIGNED + ("y3",))
+        pr = B.Prover(f)
+        pr.product("row", [(B.norm(pr.p), B.norm(3 * pr.p))] * 3, lazy="sg", c=B.norm(pr.p))       # the MDS row (27 limb products per column) still fits: 0.92 of the range ...
+        with pytest.raises(B.BoundError, match="signed accumulator"):
+            pr.product("four-term row", [(B.norm(pr.p), B.norm(3 * pr.p))] * 4, lazy="sg", c=B.norm(pr.p))                                              # ... a fourth term would not
+
+
 def _law(p, acc, qx, qy, c):
     """xyzz29_add_affine on concrete limbs (ec29.cuh, statement by statement); returns every intermediate"""
-    lz = B.EC29_LAZY
-    pd, _ = model_product(p, [(qx, acc["zz"])], lazy="pd" in lz, hi=kp_minus(p, c["SUB_X1_MULT"], acc["x"]))
-    r, _ = model_product(p, [(qy, acc["zzz"])], lazy="r" in lz, hi=kp_minus(p, c["SUB_Y1_MULT"], acc["y"]))
-    pp, _ = model_product(p, [(pd, pd)], lazy="pp" in lz)
-    ppp, _ = model_product(p, [(pd, pp)], lazy="ppp" in lz)
-    q, _ = model_product(p, [(acc["x"], pp)], lazy="q" in lz)
+    md = lambda name: B.mode_of(name, B.EC29_LAZY, B.EC29_SIGNED)
+    pd, _ = model_product(p, [(qx, acc["zz"])], lazy=md("pd"), hi=kp_minus(p, c["SUB_X1_MULT"], acc["x"]))
+    r, _ = model_product(p, [(qy, acc["zzz"])], lazy=md("r"), hi=kp_minus(p, c["SUB_Y1_MULT"], acc["y"]))
+    pp, _ = model_product(p, [(pd, pd)], lazy=md("pp"))
+    ppp, _ = model_product(p, [(pd, pp)], lazy=md("ppp"))
+    q, _ = model_product(p, [(acc["x"], pp)], lazy=md("q"))
     k = B.kp_redundant(p, c["X3_SUB_MULT"], 31)
     h = [k[i] - ppp[i] - 2 * q[i] for i in range(L)]
     assert all(0 <= x < 1 << 32 for x in h), "a limb of K p - ppp - 2 q went negative"
-    x3, _ = model_product(p, [(r, r)], lazy="x3" in lz, hi=h)
+    x3, _ = model_product(p, [(r, r)], lazy=md("x3"), hi=h)
     k3 = kp_minus(p, c["SUB_X3_MULT"], x3)
     a = [q[i] + k3[i] for i in range(L)]
     assert all(x < 1 << 32 for x in a)
-    y3, peak = model_product(p, [(r, a), (kp_minus(p, c["SUB_Y1_MULT"], acc["y"]), ppp)], lazy="y3" in lz)
-    zz, _ = model_product(p, [(acc["zz"], pp)], lazy="zz" in lz)
-    zzz, _ = model_product(p, [(acc["zzz"], ppp)], lazy="zzz" in lz)
+    y3, peak = model_product(p, [(r, a), (kp_minus(p, c["SUB_Y1_MULT"], acc["y"]), ppp)], lazy=md("y3"))
+    zz, _ = model_product(p, [(acc["zz"], pp)], lazy=md("zz"))
+    zzz, _ = model_product(p, [(acc["zzz"], ppp)], lazy=md("zzz"))
     return {"pd": pd, "r": r, "pp": pp, "ppp": ppp, "q": q, "x3": x3, "y3": y3, "zz": zz, "zzz": zzz}, peak
 
 
@@ -251,12 +333,12 @@ def test_the_lane_forms_rounds_on_concrete_values_stay_inside_their_proven_bound
             x7 = []
             for x in st:
                 xl = limbs(x)
-                x2, _ = model_product(p, [(xl, xl)], lazy=True); x4, _ = model_product(p, [(x2, x2)], lazy=True)
-                x6, _ = model_product(p, [(x4, x2)], lazy=True); t, _ = model_product(p, [(x6, xl)], lazy=True)
+                x2, _ = model_product(p, [(xl, xl)], lazy="sg"); x4, _ = model_product(p, [(x2, x2)], lazy="sg")
+                x6, _ = model_product(p, [(x4, x2)], lazy="sg"); t, _ = model_product(p, [(x6, xl)], lazy="sg")
                 assert value(t) <= table["lanes3"]["x7"]["vmax"] and value(t) % p == pow(x, 7, p) * pow(rinv, 6, p) % p
                 x7.append(t)
             for row in range(3):
-                out, _ = model_product(p, [(limbs(mds[row][cidx]), x7[cidx]) for cidx in range(3)], lazy=True, c=limbs(rc[row]))
+                out, _ = model_product(p, [(limbs(mds[row][cidx]), x7[cidx]) for cidx in range(3)], lazy="sg", c=limbs(rc[row]))
                 assert value(out) < bound and value(out) <= table["lanes3"]["row"]["vmax"]
                 assert value(out) % p == (sum(mds[row][cidx] * value(x7[cidx]) for cidx in range(3)) + rc[row]) * rinv % p
 
@@ -264,7 +346,8 @@ def test_the_lane_forms_rounds_on_concrete_values_stay_inside_their_proven_bound
 def test_the_general_add_on_concrete_values_stays_inside_the_proven_intervals_and_is_the_textbook_formula():
     """ec29.cuh xyzz29_add (add-2008-s on XYZZ, both operands accumulators within the invariants): U1 = X1 ZZ2, U2 = X2 ZZ1, S1 = Y1 ZZZ2, S2 = Y2 ZZZ1, P = U2 - U1, R = S2 - S1,
     X3 = R^2 - PPP - 2 Q (Q = U1 PP), Y3 = R (Q - X3) - S1 PPP, ZZ3 = ZZ1 ZZ2 PP, ZZZ3 = ZZZ1 ZZZ2 PPP -- each product carrying one factor 1 / 2^261"""
-    c, e, lz = B.EC29_GENERAL, B.EC29, B.EC29_GENERAL_LAZY
+    c, e = B.EC29_GENERAL, B.EC29
+    md = lambda name: B.mode_of(name, B.EC29_GENERAL_LAZY, B.EC29_GENERAL_SIGNED)
     rng = random.Random(41)
     for F, p in P.items():
         table = B.prove_all()["fields"][F]["group_add"]
@@ -275,18 +358,18 @@ def test_the_general_add_on_concrete_values_stays_inside_the_proven_intervals_an
             av = {k: (b - 1 - rng.randrange(3) if edge else rng.randrange(b)) for k, b in inv.items()}
             bv = {k: (b - 1 - rng.randrange(3) if edge and it % 8 == 0 else rng.randrange(b)) for k, b in inv.items()}
             a = {k: limbs(v) for k, v in av.items()}; b = {k: limbs(v) for k, v in bv.items()}
-            u1, _ = model_product(p, [(a["x"], b["zz"])], lazy="u1" in lz); s1, _ = model_product(p, [(a["y"], b["zzz"])], lazy="s1" in lz)
-            pd, _ = model_product(p, [(b["x"], a["zz"])], lazy="pd" in lz, hi=kp_minus(p, c["G_U1_MULT"], u1))
-            r, _ = model_product(p, [(b["y"], a["zzz"])], lazy="r" in lz, hi=kp_minus(p, c["G_S1_MULT"], s1))
-            pp, _ = model_product(p, [(pd, pd)], lazy="pp" in lz); ppp, _ = model_product(p, [(pd, pp)], lazy="ppp" in lz); q, _ = model_product(p, [(u1, pp)], lazy="q" in lz)
+            u1, _ = model_product(p, [(a["x"], b["zz"])], lazy=md("u1")); s1, _ = model_product(p, [(a["y"], b["zzz"])], lazy=md("s1"))
+            pd, _ = model_product(p, [(b["x"], a["zz"])], lazy=md("pd"), hi=kp_minus(p, c["G_U1_MULT"], u1))
+            r, _ = model_product(p, [(b["y"], a["zzz"])], lazy=md("r"), hi=kp_minus(p, c["G_S1_MULT"], s1))
+            pp, _ = model_product(p, [(pd, pd)], lazy=md("pp")); ppp, _ = model_product(p, [(pd, pp)], lazy=md("ppp")); q, _ = model_product(p, [(u1, pp)], lazy=md("q"))
             k4 = B.kp_redundant(p, c["G_X3_SUB_MULT"], 31)
             h = [k4[i] - ppp[i] - 2 * q[i] for i in range(L)]
             assert all(0 <= x < 1 << 32 for x in h)
-            x3, _ = model_product(p, [(r, r)], lazy="x3" in lz, hi=h)
+            x3, _ = model_product(p, [(r, r)], lazy=md("x3"), hi=h)
             k3 = kp_minus(p, c["G_SUB_X3_MULT"], x3)
-            y3, _ = model_product(p, [(r, [q[i] + k3[i] for i in range(L)]), (kp_minus(p, c["G_S1_MULT"], s1), ppp)], lazy="y3" in lz)
-            zz12, _ = model_product(p, [(a["zz"], b["zz"])], lazy="zz12" in lz); zz, _ = model_product(p, [(zz12, pp)], lazy="zz" in lz)
-            zzz12, _ = model_product(p, [(a["zzz"], b["zzz"])], lazy="zzz12" in lz); zzz, _ = model_product(p, [(zzz12, ppp)], lazy="zzz" in lz)
+            y3, _ = model_product(p, [(r, [q[i] + k3[i] for i in range(L)]), (kp_minus(p, c["G_S1_MULT"], s1), ppp)], lazy=md("y3"))
+            zz12, _ = model_product(p, [(a["zz"], b["zz"])], lazy=md("zz12")); zz, _ = model_product(p, [(zz12, pp)], lazy=md("zz"))
+            zzz12, _ = model_product(p, [(a["zzz"], b["zzz"])], lazy=md("zzz12")); zzz, _ = model_product(p, [(zzz12, ppp)], lazy=md("zzz"))
             U1, U2, S1, S2 = av["x"] * bv["zz"] * rinv % p, bv["x"] * av["zz"] * rinv % p, av["y"] * bv["zzz"] * rinv % p, bv["y"] * av["zzz"] * rinv % p
             Pd, Rr = (U2 - U1) % p, (S2 - S1) % p
             PP = Pd * Pd * rinv % p; PPP = Pd * PP * rinv % p; Q = U1 * PP * rinv % p

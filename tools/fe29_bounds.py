@@ -74,7 +74,10 @@ class Prover:
 
     # ---- the generated column loop (tools/gen_fe29.py `body`) on maxima
     def product(self, what, pairs, lazy=False, hi: V | None = None, c: V | None = None) -> V:
-        """sum of a_t * b_t over `pairs` (+ c before the reduction) / 2^261 (+ hi after it); lazy: quotient digits not masked (< 2^32)"""
+        """sum of a_t * b_t over `pairs` (+ c before the reduction) / 2^261 (+ hi after it); lazy = True: quotient digits not masked (< 2^32);
+        lazy = "sg": SIGNED quotient digits (`product_signed`)"""
+        if lazy == "sg":
+            return self.product_signed(what, pairs, hi=hi, c=c)
         p, pl = self.p, self.pl
         mmax = (1 << 32) - 1 if lazy else M29
         carry = 0
@@ -105,6 +108,53 @@ class Prover:
         need(top < 1 << 32, f"{what}: the top limb can reach {top:#x}")
         out = V([M29] * (L - 1) + [top], vmax, True, what)
         self.log.append((what, "product" + (" (lazy)" if lazy else ""), worst / 2**64, vmax / p))
+        return out
+
+    # ---- the SIGNED-digit column loop (tools/gen_fe29.py `body_sg`, round 5): the quotient digit of column k < 8 is the column's own low word read as an int32,
+    # s_k in [-2^31, 2^31), SUBTRACTED with v_mad_i64_i32 against the negated prime limbs (no instruction makes the digit); digit 8 is (col & M29) - 2^30 in
+    # [-2^30, -2^29): its sign is fixed, so the quotient M = -sum s_k 2^(29 k) is POSITIVE -- between (1 - 2^-27) R and (2 + 2^-27) R -- and the result is
+    # T / R + (1 p, 2 p]: positive without an offset term, and tighter than the lazy forms' + 8 p.  The accumulator is a two's-complement 64-bit value: the TRUE
+    # column sum (limb products are non-negative, digit terms have either sign) must lie in [-2^63, 2^63) when it is shifted; partial sums may wrap.
+    SG_LO, SG_HI = -(1 << 31), (1 << 31) - 1                    # s_k, k < 8
+
+    def product_signed(self, what, pairs, hi: V | None = None, c: V | None = None) -> V:
+        p, pl = self.p, self.pl
+        lo8, hi8 = -(1 << 30), -(1 << 29)                       # s_8 = (col & M29) - 2^30, col & M29 in [0, 2^29): s_8 in [-2^30, -2^29 - ... ] -- the interval end -2^29 is excluded, -2^30 included
+        dig = lambda i: (self.SG_LO, self.SG_HI) if i < L - 1 else (lo8, hi8 - 1)
+        clo = chi = 0
+        worst = 0
+        for k in range(2 * L - 1):
+            lo, hi_ = clo, chi
+            for a, b in pairs:
+                for i in range(L):
+                    if 0 <= k - i < L:
+                        hi_ += a.limb[i] * b.limb[k - i]          # limb products: in [0, max]
+            for j in (1, 2, 3, 4, 8):
+                i = k - j
+                if 0 <= i < L and i < k:
+                    dl, dh = dig(i)                             # the term is - s_i p_j
+                    lo += -dh * pl[j]; hi_ += -dl * pl[j]
+            if hi is not None and k >= L:
+                hi_ += hi.limb[k - L]
+            if c is not None and k < L:
+                hi_ += c.limb[k]
+            if k < L:
+                dl, dh = dig(k)                                 # - s_k p_0: the low limb cancels
+                lo += -dh; hi_ += -dl
+            worst = max(worst, hi_, -lo)
+            need(hi_ < 1 << 63 and lo >= -(1 << 63), f"{what}: column {k} can leave the signed accumulator: [{lo / 2**63:.3f}, {hi_ / 2**63:.3f}] x 2^63")
+            clo, chi = lo >> W, hi_ >> W                        # arithmetic shift
+        tmax = sum(a.vmax * b.vmax for a, b in pairs) + (c.vmax if c is not None else 0)
+        m_hi = sum((1 << 31) << (W * k) for k in range(L - 1)) + ((1 << 30) << TOP)            # the quotient M = - sum s_k 2^(29 k): its range
+        m_lo = -sum(((1 << 31) - 1) << (W * k) for k in range(L - 1)) + (((1 << 29) + 1) << TOP)
+        need(m_lo > 0, f"{what}: the signed quotient can be negative")
+        vmax = (tmax + m_hi * p) // R + (hi.vmax if hi is not None else 0)
+        need(clo >= 0, f"{what}: the top limb can go negative")
+        top = min(chi + (hi.limb[8] if hi is not None else 0), vmax >> TOP)
+        need(top < 1 << 32, f"{what}: the top limb can reach {top:#x}")
+        out = V([M29] * (L - 1) + [top], vmax, True, what)
+        out.vmin = m_lo * p // R                                # > 0.99 p
+        self.log.append((what, "product (signed)", worst / 2**64, vmax / p))
         return out
 
     def mul(self, what, a, b, **kw): return self.product(what, [(a, b)], **kw)
@@ -151,19 +201,30 @@ class Prover:
 # fixed point (round 4: all strict, x < 6 p, y < 2 p, zz, zzz < 3 p, K = 8 / 8 / 4 / 8).  With a seventh lazy product (any of q, x3, y3) the invariants have NO fixed
 # point: the bounds feed each other (x3 -> K -> pd -> pp -> q -> x3) faster than the 1 / 128 of a product damps them and grow until a top limb leaves its register
 # (`search_lazy_sets`, all 36 + 9 + 1 larger subsets).  ec29.cuh is compiled with these names (`struct EC29` in fp29.cuh, emitted by gen_fe29.py).
-EC29 = {"INV_X": 26, "INV_Y": 6, "INV_ZZ": 10, "INV_ZZZ": 9, "NEG_Y_MULT": 2, "SUB_X1_MULT": 27, "SUB_Y1_MULT": 7, "X3_SUB_MULT": 23, "SUB_X3_MULT": 27, "PD_MAX": 36}
-EC29_LAZY = ("pd", "r", "pp", "ppp", "zz", "zzz")
+EC29 = {"INV_X": 10, "INV_Y": 2, "INV_ZZ": 3, "INV_ZZZ": 3, "NEG_Y_MULT": 2, "SUB_X1_MULT": 11, "SUB_Y1_MULT": 3, "X3_SUB_MULT": 7, "SUB_X3_MULT": 11, "PD_MAX": 14}
+EC29_LAZY = ()                                                  # (round 5, earlier: pd, r, pp, ppp, zz, zzz ran with unmasked UNSIGNED digits: + 8 p each)
+# Late round 5: eight of the nine reductions use SIGNED quotient digits (`Prover.product_signed`): no instruction per digit and the result within (1 p, 2 p] of the
+# exact quotient -- the invariants fall back to round 4's size.  y3 keeps the strict unsigned form: its raw operands (limbs up to 2^31) leave no room in a signed column.
+EC29_SIGNED = ("pd", "r", "pp", "ppp", "q", "x3", "zz", "zzz")
 # the GENERAL add of two accumulators (the 2-D bucket reduction of the multi-MSM form, msm.cuh msm_segsum29_kernel): both operands within the invariants above,
 # the sum within them again; u1 = x1 zz2 and s1 = y1 zzz2 are products now, so the multiples under them are their own
-EC29_GENERAL = {"G_U1_MULT": 12, "G_S1_MULT": 10, "G_X3_SUB_MULT": 16, "G_SUB_X3_MULT": 20}
-EC29_GENERAL_LAZY = ("u1", "s1", "pd", "r", "pp", "ppp", "zz12", "zz", "zzz12", "zzz")
+EC29_GENERAL = {"G_U1_MULT": 3, "G_S1_MULT": 3, "G_X3_SUB_MULT": 7, "G_SUB_X3_MULT": 10}
+EC29_GENERAL_LAZY = ()
+EC29_GENERAL_SIGNED = ("u1", "s1", "pd", "r", "pp", "ppp", "q", "x3", "zz12", "zz", "zzz12", "zzz")
 
 
-def prove_group_law(field: int, c=None, lazy=None):
+def mode_of(name, lazy, signed):
+    """the `lazy` argument of Prover.product for the reduction called `name`: "sg" (signed digits), True (unsigned, unmasked), False (strict)"""
+    return "sg" if name in signed else (name in lazy)
+
+
+def prove_group_law(field: int, c=None, lazy=None, signed=None):
     """xyzz29_add_affine (ec29.cuh), statement by statement, on intervals.  Table coordinates canonical (< p) -- y or its negation, normalised (the pre-split table)
     or the raw K p - y (the 8-word twin); accumulator within the invariants; the new accumulator must be within them again, and so must the first point's assignment."""
     c = dict(EC29, **(c or {}))
     lazy = EC29_LAZY if lazy is None else lazy
+    signed = EC29_SIGNED if signed is None else signed
+    md = lambda name: mode_of(name, lazy, signed)
     pr = Prover(field); p = pr.p
     qx, py = norm(p, "table x"), norm(p, "table y")
     acc = {"x": norm(c["INV_X"] * p, "acc.x"), "y": norm(c["INV_Y"] * p, "acc.y"), "zz": norm(c["INV_ZZ"] * p, "acc.zz"), "zzz": norm(c["INV_ZZZ"] * p, "acc.zzz")}
@@ -171,16 +232,16 @@ def prove_group_law(field: int, c=None, lazy=None):
     first_y = pr.select("first y", py, pr.sub_kp("p - py (first point)", 1, norm(1, "0"), py))
     need(qx.vmax < c["INV_X"] * p and first_y.vmax < c["INV_Y"] * p, "the first point breaks the invariants")
     qy = pr.select("qy", py, pr.kp_minus("-py = K p - py", c["NEG_Y_MULT"], py))
-    pd = pr.mul("pd = qx zz1 + K p - x1", qx, acc["zz"], hi=pr.kp_minus("K p - x1", c["SUB_X1_MULT"], acc["x"]), lazy="pd" in lazy)
-    r = pr.mul("r = qy zzz1 + K p - y1", qy, acc["zzz"], hi=pr.kp_minus("K p - y1", c["SUB_Y1_MULT"], acc["y"]), lazy="r" in lazy)
-    pp = pr.sqr("pp = pd^2", pd, lazy="pp" in lazy)
-    ppp = pr.mul("ppp = pd pp", pd, pp, lazy="ppp" in lazy)
-    q = pr.mul("q = x1 pp", acc["x"], pp, lazy="q" in lazy)
-    x3 = pr.sqr("x3 = r^2 + K p - ppp - 2 q", r, hi=pr.kp_minus_a_minus_2b("K p - ppp - 2 q", c["X3_SUB_MULT"], ppp, q), lazy="x3" in lazy)
+    pd = pr.mul("pd = qx zz1 + K p - x1", qx, acc["zz"], hi=pr.kp_minus("K p - x1", c["SUB_X1_MULT"], acc["x"]), lazy=md("pd"))
+    r = pr.mul("r = qy zzz1 + K p - y1", qy, acc["zzz"], hi=pr.kp_minus("K p - y1", c["SUB_Y1_MULT"], acc["y"]), lazy=md("r"))
+    pp = pr.sqr("pp = pd^2", pd, lazy=md("pp"))
+    ppp = pr.mul("ppp = pd pp", pd, pp, lazy=md("ppp"))
+    q = pr.mul("q = x1 pp", acc["x"], pp, lazy=md("q"))
+    x3 = pr.sqr("x3 = r^2 + K p - ppp - 2 q", r, hi=pr.kp_minus_a_minus_2b("K p - ppp - 2 q", c["X3_SUB_MULT"], ppp, q), lazy=md("x3"))
     y3 = pr.product("y3 = r (q + K p - x3) + (K p - y1) ppp", [(r, pr.add_kp_minus("q + K p - x3", c["SUB_X3_MULT"], q, x3)), (pr.kp_minus("K p - y1 (dot)", c["SUB_Y1_MULT"], acc["y"]), ppp)],
-                    lazy="y3" in lazy)
-    zz = pr.mul("zz3 = zz1 pp", acc["zz"], pp, lazy="zz" in lazy)
-    zzz = pr.mul("zzz3 = zzz1 ppp", acc["zzz"], ppp, lazy="zzz" in lazy)
+                    lazy=md("y3"))
+    zz = pr.mul("zz3 = zz1 pp", acc["zz"], pp, lazy=md("zz"))
+    zzz = pr.mul("zzz3 = zzz1 ppp", acc["zzz"], ppp, lazy=md("zzz"))
     for name, v, inv in (("x", x3, "INV_X"), ("y", y3, "INV_Y"), ("zz", zz, "INV_ZZ"), ("zzz", zzz, "INV_ZZZ")):
         need(v.vmax < c[inv] * p, f"group law: new acc.{name} can reach {v.vmax / p:.3f} p, invariant {c[inv]} p")
     # the exact zero test of pd (fe29_is_multiple_of_p: pd = k p with k = pd_8 >> 22, k c compared on limbs 0..4) needs k c < 2^145: k < 2^20; PD_MAX is what the comment quotes
@@ -191,41 +252,43 @@ def prove_group_law(field: int, c=None, lazy=None):
     return pr, {"pd": pd, "r": r, "pp": pp, "ppp": ppp, "q": q, "x3": x3, "y3": y3, "zz": zz, "zzz": zzz, "qy": qy}
 
 
-def prove_group_add(field: int, c=None, lazy=None):
+def prove_group_add(field: int, c=None, lazy=None, signed=None):
     """xyzz29_add (ec29.cuh): a + b for two accumulators, neither infinity (add-2008-s on XYZZ).  Inputs within the invariants of EC29; the sum must be within them too
     (the reduction tree adds sums to sums) and pd below PD_MAX (the exact zero test)."""
     e = dict(EC29)
     c = dict(EC29_GENERAL, **(c or {}))
     lazy = EC29_GENERAL_LAZY if lazy is None else lazy
+    signed = EC29_GENERAL_SIGNED if signed is None else signed
+    md = lambda name: mode_of(name, lazy, signed)
     pr = Prover(field); p = pr.p
     mk = lambda tag: {"x": norm(e["INV_X"] * p, tag + ".x"), "y": norm(e["INV_Y"] * p, tag + ".y"), "zz": norm(e["INV_ZZ"] * p, tag + ".zz"), "zzz": norm(e["INV_ZZZ"] * p, tag + ".zzz")}
     a, b = mk("a"), mk("b")
-    u1 = pr.mul("u1 = x1 zz2", a["x"], b["zz"], lazy="u1" in lazy)
-    s1 = pr.mul("s1 = y1 zzz2", a["y"], b["zzz"], lazy="s1" in lazy)
-    pd = pr.mul("pd = x2 zz1 + K p - u1", b["x"], a["zz"], hi=pr.kp_minus("K p - u1", c["G_U1_MULT"], u1), lazy="pd" in lazy)
-    r = pr.mul("r = y2 zzz1 + K p - s1", b["y"], a["zzz"], hi=pr.kp_minus("K p - s1", c["G_S1_MULT"], s1), lazy="r" in lazy)
-    pp = pr.sqr("pp = pd^2 (general)", pd, lazy="pp" in lazy)
-    ppp = pr.mul("ppp = pd pp (general)", pd, pp, lazy="ppp" in lazy)
-    q = pr.mul("q = u1 pp", u1, pp, lazy="q" in lazy)
-    x3 = pr.sqr("x3 = r^2 + K p - ppp - 2 q (general)", r, hi=pr.kp_minus_a_minus_2b("K p - ppp - 2 q (general)", c["G_X3_SUB_MULT"], ppp, q), lazy="x3" in lazy)
+    u1 = pr.mul("u1 = x1 zz2", a["x"], b["zz"], lazy=md("u1"))
+    s1 = pr.mul("s1 = y1 zzz2", a["y"], b["zzz"], lazy=md("s1"))
+    pd = pr.mul("pd = x2 zz1 + K p - u1", b["x"], a["zz"], hi=pr.kp_minus("K p - u1", c["G_U1_MULT"], u1), lazy=md("pd"))
+    r = pr.mul("r = y2 zzz1 + K p - s1", b["y"], a["zzz"], hi=pr.kp_minus("K p - s1", c["G_S1_MULT"], s1), lazy=md("r"))
+    pp = pr.sqr("pp = pd^2 (general)", pd, lazy=md("pp"))
+    ppp = pr.mul("ppp = pd pp (general)", pd, pp, lazy=md("ppp"))
+    q = pr.mul("q = u1 pp", u1, pp, lazy=md("q"))
+    x3 = pr.sqr("x3 = r^2 + K p - ppp - 2 q (general)", r, hi=pr.kp_minus_a_minus_2b("K p - ppp - 2 q (general)", c["G_X3_SUB_MULT"], ppp, q), lazy=md("x3"))
     y3 = pr.product("y3 = r (q + K p - x3) + (K p - s1) ppp", [(r, pr.add_kp_minus("q + K p - x3 (general)", c["G_SUB_X3_MULT"], q, x3)), (pr.kp_minus("K p - s1 (dot)", c["G_S1_MULT"], s1), ppp)],
-                    lazy="y3" in lazy)
-    zz = pr.mul("zz3 = zz1 zz2 pp", pr.mul("zz1 zz2", a["zz"], b["zz"], lazy="zz12" in lazy), pp, lazy="zz" in lazy)
-    zzz = pr.mul("zzz3 = zzz1 zzz2 ppp", pr.mul("zzz1 zzz2", a["zzz"], b["zzz"], lazy="zzz12" in lazy), ppp, lazy="zzz" in lazy)
+                    lazy=md("y3"))
+    zz = pr.mul("zz3 = zz1 zz2 pp", pr.mul("zz1 zz2", a["zz"], b["zz"], lazy=md("zz12")), pp, lazy=md("zz"))
+    zzz = pr.mul("zzz3 = zzz1 zzz2 ppp", pr.mul("zzz1 zzz2", a["zzz"], b["zzz"], lazy=md("zzz12")), ppp, lazy=md("zzz"))
     for name, v, inv in (("x", x3, "INV_X"), ("y", y3, "INV_Y"), ("zz", zz, "INV_ZZ"), ("zzz", zzz, "INV_ZZZ")):
         need(v.vmax < e[inv] * p, f"general add: new {name} can reach {v.vmax / p:.3f} p, invariant {e[inv]} p")
     need(pd.vmax < e["PD_MAX"] * p, f"general add: pd can reach {pd.vmax / p:.2f} p: beyond PD_MAX")
     return pr, {"u1": u1, "s1": s1, "pd": pd, "r": r, "pp": pp, "ppp": ppp, "q": q, "x3": x3, "y3": y3, "zz": zz, "zzz": zzz}
 
 
-def least_fixed_point(field: int, lazy):
-    """the smallest invariants / multiples under which `prove_group_law` holds for the lazy set, grown from round 4's; ("ok", constants) or ("fail", why)"""
-    inv = {"INV_X": 6, "INV_Y": 2, "INV_ZZ": 3, "INV_ZZZ": 3}
+def least_fixed_point(field: int, lazy, signed=()):
+    """the smallest invariants / multiples under which `prove_group_law` holds for the lazy / signed sets, grown from below; ("ok", constants) or ("fail", why)"""
+    inv = {"INV_X": 3, "INV_Y": 2, "INV_ZZ": 2, "INV_ZZZ": 2}
     x3m = 4
     for _ in range(4000):
         c = dict(inv, NEG_Y_MULT=2, SUB_X1_MULT=inv["INV_X"] + 1, SUB_Y1_MULT=inv["INV_Y"] + 1, X3_SUB_MULT=x3m, SUB_X3_MULT=inv["INV_X"] + 1, PD_MAX=1 << 19)
         try:
-            prove_group_law(field, c, lazy)
+            prove_group_law(field, c, lazy, signed)
             return "ok", c
         except BoundError as e:
             msg = str(e)
@@ -255,7 +318,7 @@ def search_lazy_sets():
 
 # ------------------------------------------------------------------------------------------------ SPEC: the Poseidon rounds' lane forms (sponge.cuh)
 # state bound (units of p / 1000) each lane form keeps between rounds; MDS entries and round constants are canonical (< p)
-SPONGE = {"LANES3_STATE_MILLI_P": 8300, "LANES8_STATE_MILLI_P": 16500, "LANES16_STATE_MILLI_P": 24400}
+SPONGE = {"LANES3_STATE_MILLI_P": 2100, "LANES8_STATE_MILLI_P": 4100, "LANES16_STATE_MILLI_P": 6100}
 
 
 def prove_sponge_rounds(field: int, c=None):
@@ -263,22 +326,22 @@ def prove_sponge_rounds(field: int, c=None):
     pr = Prover(field); p = pr.p
     mds, rc = norm(p, "MDS entry"), norm(p, "round constant x 2^261")
     out = {}
-    # 3 lanes per sponge (the chip-filling form): x^2, x^4, x^6, x^7 lazily, then the row: three products and the round constant in ONE lazy reduction
+    # 3 lanes per sponge (the chip-filling form): x^2, x^4, x^6, x^7, then the row -- three products and the round constant in ONE reduction --, all with signed quotient digits
     x = norm(c["LANES3_STATE_MILLI_P"] * p // 1000, "state (3-lane)")
-    x2 = pr.sqr("3-lane x^2", x, lazy=True); x4 = pr.sqr("3-lane x^4", x2, lazy=True); x6 = pr.mul("3-lane x^6", x4, x2, lazy=True); x7 = pr.mul("3-lane x^7", x6, x, lazy=True)
-    row = pr.product("3-lane MDS row + rc", [(mds, x7)] * 3, lazy=True, c=rc)
+    x2 = pr.sqr("3-lane x^2", x, lazy="sg"); x4 = pr.sqr("3-lane x^4", x2, lazy="sg"); x6 = pr.mul("3-lane x^6", x4, x2, lazy="sg"); x7 = pr.mul("3-lane x^7", x6, x, lazy="sg")
+    row = pr.product("3-lane MDS row + rc", [(mds, x7)] * 3, lazy="sg", c=rc)
     need(row.vmax < x.vmax + 1, f"3-lane: a round maps a state below {x.vmax / p:.3f} p to {row.vmax / p:.3f} p")
     out["lanes3"] = {"x2": x2, "x4": x4, "x7": x7, "row": row}
     # 8 lanes: the state element is u + swap(u), u a two-term half row (+ rc in one of the halves)
     x = norm(c["LANES8_STATE_MILLI_P"] * p // 1000, "state (8-lane)")
-    x2 = pr.sqr("8-lane x^2", x, lazy=True); x3 = pr.mul("8-lane x^3", x2, x, lazy=True); x4 = pr.sqr("8-lane x^4", x2, lazy=True); x7 = pr.mul("8-lane x^7", x3, x4, lazy=True)
-    half = pr.product("8-lane half row + rc", [(mds, x7)] * 2, lazy=True, c=rc)
+    x2 = pr.sqr("8-lane x^2", x, lazy="sg"); x3 = pr.mul("8-lane x^3", x2, x, lazy="sg"); x4 = pr.sqr("8-lane x^4", x2, lazy="sg"); x7 = pr.mul("8-lane x^7", x3, x4, lazy="sg")
+    half = pr.product("8-lane half row + rc", [(mds, x7)] * 2, lazy="sg", c=rc)
     need(2 * half.vmax < x.vmax + 1, f"8-lane: a round maps a state below {x.vmax / p:.3f} p to {2 * half.vmax / p:.3f} p")
     out["lanes8"] = {"x7": x7, "half": half}
     # 16 lanes: the state element is the sum of three single products (one carries rc)
     x = norm(c["LANES16_STATE_MILLI_P"] * p // 1000, "state (16-lane)")
-    x2 = pr.sqr("16-lane x^2", x, lazy=True); x3 = pr.mul("16-lane x^3", x2, x, lazy=True); x4 = pr.sqr("16-lane x^4", x2, lazy=True); x7 = pr.mul("16-lane x^7", x3, x4, lazy=True)
-    one = pr.product("16-lane product + rc", [(mds, x7)], lazy=True, c=rc)
+    x2 = pr.sqr("16-lane x^2", x, lazy="sg"); x3 = pr.mul("16-lane x^3", x2, x, lazy="sg"); x4 = pr.sqr("16-lane x^4", x2, lazy="sg"); x7 = pr.mul("16-lane x^7", x3, x4, lazy="sg")
+    one = pr.product("16-lane product + rc", [(mds, x7)], lazy="sg", c=rc)
     need(3 * one.vmax < x.vmax + 1, f"16-lane: a round maps a state below {x.vmax / p:.3f} p to {3 * one.vmax / p:.3f} p")
     out["lanes16"] = {"x7": x7, "one": one}
     # the way out of every form: one STRICT product by 2^256 mod p must land below 2^256 (fe29_to_words) and below 2 p (one conditional subtraction)

@@ -10,6 +10,10 @@ and the LAZY forms the chip-filling 3-lane permutation runs its rounds in (fe29_
 m_k = -col mod 2^32 is NOT masked to 29 bits (its three high bits add a multiple of p 2^(29 k): the value stays the same field element,
 the result is < a b / R + 8.0001 p instead of < a b / R + p), the accumulator starts from the first product (no zeroing), and the dot
 product takes a tenth operand c added before the reduction ((sum + c) / R: the round constant, stored times R).  Bounds: fp29.cuh.
+SIGNED-digit forms (round 5, fe29_mul_sg / fe29_sqr_sg / fe29_mul_hi_sg / fe29_sqr_hi_sg): the quotient digit of column k < 8 is the column's own low word read as an
+int32 -- NO instruction makes it (the lazy forms spend a v_sub per digit, the strict ones a v_sub and a v_and) -- and it is SUBTRACTED by `v_mad_i64_i32` against the
+negated prime limbs; digit 8 is (col & M29) - 2^30 (one v_and_or), always negative, so the quotient is positive without an offset term: the result is
+T / R + (1 p, 2 p], limbs 0..7 normalised (tools/fe29_bounds.py `product_signed`; measured: tools/probes/sg_probe.hip).
 One asm statement per chunk of <= 12 multiply-accumulates of a column (inline asm takes at most 30 operands); between the columns plain
 C++ (mask, shift).  The compiler's own schedule of the C++ form spreads a column over several accumulators and re-adds them (+116 64-bit
 adds and +70 products per Poseidon round); pinned like this a round is ~1150 VALU instructions instead of ~1610.
@@ -65,6 +69,86 @@ def body(col_terms, lazy=False, hi=None, fresh=True):
             out.append(f"    r.v[{k - L}] = (uint32_t)col & M29; col >>= {W};")
     out.append(f"    r.v[{L - 1}] = (uint32_t)col;" if hi is None else f"    r.v[{L - 1}] = (uint32_t)col + {hi}.v[{L - 1}];")
     out.append("    return r;")
+    return out
+
+
+def smads(terms):
+    """signed multiply-accumulates (quotient digit x negated prime limb) into col, in place"""
+    out = []
+    for c0 in range(0, len(terms), MAXT):
+        chunk = terms[c0:c0 + MAXT]
+        lines, ops, n = [], [], 2
+        for x, y in chunk:
+            lines.append(f"v_mad_i64_i32 %0, %1, %{n}, %{n + 1}, %0"); ops += [f'"v"({x})', f'"s"({y})']; n += 2      # the negated prime limb rides the constant bus: no VGPR
+        out.append('    asm("' + '\\n\\t'.join(lines) + '"\n        : "+&v"(col), "=&s"(cc) : ' + ", ".join(ops) + ");")
+    return out
+
+
+def body_sg(col_terms, hi=None):
+    """the column loop with SIGNED quotient digits.  m_k (k < 8) is the low register of the column itself: the statement that cancels the low limb writes the new column
+    to OTHER registers (early-clobber output), so the old low word stays where it is for the five later uses of the digit -- no copy, no negation, no mask."""
+    out = ["    uint64_t col, nc, cc; fe29_t r;", "    uint32_t " + ", ".join(f"m{i}" for i in range(L)) + ";",
+           "    const int32_t n1 = -(int32_t)P29<F>::L1, n2 = -(int32_t)P29<F>::L2, n3 = -(int32_t)P29<F>::L3, n4 = -(int32_t)P29<F>::L4, n8 = -(int32_t)P29<F>::L8;"]
+    for k in range(2 * L - 1):
+        terms, st = list(col_terms(k)), []
+        for j, nj in ((1, "n1"), (2, "n2"), (3, "n3"), (4, "n4"), (8, "n8")):
+            i = k - j
+            if 0 <= i < L and i < k:
+                st.append((f"m{i}", nj))
+        if hi is not None and k >= L:
+            terms.append((f"{hi}.v[{k - L}]", 1))
+        out.append(f"    // column {k}: {len(terms)} + {len(st)} products")
+        out += mads(terms, fresh=(k == 0))
+        out += smads(st)
+        if k < L:
+            out.append(f"    m{k} = (uint32_t)col;" if k < L - 1 else f"    m{k} = ((uint32_t)col & M29) | 0xC0000000u;        // (col & M29) - 2^30: the one digit with a fixed sign")
+            out.append(f'    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m{k}), "v"(col));   // - s_k p_0: the low limb cancels')
+            out.append(f"    col = (uint64_t)((int64_t)nc >> {W});")
+        else:
+            out.append(f"    r.v[{k - L}] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> {W});")
+    out.append(f"    r.v[{L - 1}] = (uint32_t)col;" if hi is None else f"    r.v[{L - 1}] = (uint32_t)col + {hi}.v[{L - 1}];")
+    out.append("    return r;")
+    return out
+
+
+def _mul_terms(k):
+    for i in range(L):
+        j = k - i
+        if 0 <= j < L:
+            yield (f"a.v[{i}]", f"b.v[{j}]")
+
+
+def _sqr_terms(k):
+    for i in range(L):
+        j = k - i
+        if 0 <= j < L and i < j:
+            yield (f"d{i}", f"a.v[{j}]")
+    if k % 2 == 0 and k // 2 < L:
+        yield (f"a.v[{k // 2}]", f"a.v[{k // 2}]")
+
+
+_DBL = "    const uint32_t " + ", ".join(f"d{i} = a.v[{i}] << 1" for i in range(L - 1)) + ";"
+
+
+def emit_signed():
+    out = ["template <int F> __device__ __forceinline__ fe29_t fe29_mul_sg(const fe29_t &a, const fe29_t &b) {"] + body_sg(_mul_terms) + ["}"]
+    out += ["template <int F> __device__ __forceinline__ fe29_t fe29_sqr_sg(const fe29_t &a) {", _DBL] + body_sg(_sqr_terms) + ["}"]
+    out += ["template <int F> __device__ __forceinline__ fe29_t fe29_mul_hi_sg(const fe29_t &a, const fe29_t &b, const fe29_t &h) {"] + body_sg(_mul_terms, hi="h") + ["}"]
+    out += ["template <int F> __device__ __forceinline__ fe29_t fe29_sqr_hi_sg(const fe29_t &a, const fe29_t &h) {", _DBL] + body_sg(_sqr_terms, hi="h") + ["}"]
+    # the Poseidon rows: n products and the round constant (stored times 2^261, added before the reduction) in ONE signed reduction
+    def dot_rc(n):
+        def terms(k):
+            for t in range(n):
+                for i in range(L):
+                    j = k - i
+                    if 0 <= j < L:
+                        yield (f"a{t}.v[{i}]", f"b{t}.v[{j}]") if n > 1 else (f"a.v[{i}]", f"b.v[{j}]")
+            if k < L:
+                yield (f"c.v[{k}]", 1)
+        return terms
+    out += ["template <int F> __device__ __forceinline__ fe29_t fe29_mulrc_sg(const fe29_t &a, const fe29_t &b, const fe29_t &c) {"] + body_sg(dot_rc(1)) + ["}"]
+    out += ["template <int F> __device__ __forceinline__ fe29_t fe29_dot2rc_sg(const fe29_t &a0, const fe29_t &b0, const fe29_t &a1, const fe29_t &b1, const fe29_t &c) {"] + body_sg(dot_rc(2)) + ["}"]
+    out += ["template <int F> __device__ __forceinline__ fe29_t fe29_dot3rc_sg(const fe29_t &a0, const fe29_t &b0, const fe29_t &a1, const fe29_t &b1, const fe29_t &a2, const fe29_t &b2, const fe29_t &c) {"] + body_sg(dot_rc(3)) + ["}"]
     return out
 
 
@@ -168,7 +252,7 @@ def emit_dot2():
 
 
 def generated():
-    return "\n".join(["// ---- GENERATED by tools/gen_fe29.py: do not edit by hand"] + emit_mul() + emit_sqr() + emit_dot2() + emit_dot3() + emit_mul(True) + emit_sqr(True) + emit_dot3rc_lz() + emit_mulrc_lz() + emit_dot2rc_lz() + emit_sqr_hi() + emit_mul_hi() + emit_mul_hi(True) + ["// ---- END GENERATED"]) + "\n"
+    return "\n".join(["// ---- GENERATED by tools/gen_fe29.py: do not edit by hand"] + emit_mul() + emit_sqr() + emit_dot2() + emit_dot3() + emit_mul(True) + emit_sqr(True) + emit_dot3rc_lz() + emit_mulrc_lz() + emit_dot2rc_lz() + emit_sqr_hi() + emit_mul_hi() + emit_mul_hi(True) + emit_signed() + ["// ---- END GENERATED"]) + "\n"
 
 
 def proven_constants():
