@@ -78,6 +78,57 @@ PROF_STAGES = {"pstate_hash": 11, "ipa_transcript": 12, "kimchi_to_batch": 13, "
 TRAFFIC_FILE = os.path.join("profiles", "pstate_hash_traffic.json")
 
 
+class PowerSampler:
+    """socket power and shader clock DURING the timed region, read from the amdgpu hwmon files of this rank's GPU every 0.2 s by a host thread (two small sysfs
+    reads: nothing is launched, nothing is forked).  Why it rides in the line: the step holds the chip at its socket power cap (1400 W) and the clock settles at
+    ~2.25 GHz, while the microbench that measures `roofline.peak` (register-only streams) stays below the cap at 2.39 GHz -- profiles/r05_clock_power.md."""
+
+    def __init__(self, pci_bus_id=None):
+        import glob
+        self.dir, self.rows, self._stop, self._th = None, [], False, None
+        cands = []
+        for h in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+            if os.path.exists(os.path.join(h, "power1_input")) and os.path.exists(os.path.join(h, "freq1_input")):
+                cands.append((os.path.basename(os.path.realpath(os.path.join(h, "..", ".."))).lower(), h))
+        if pci_bus_id:
+            cands = [c for c in cands if c[0] == pci_bus_id.lower()] or (cands if len(cands) == 1 else [])
+        if len(cands) >= 1 and (pci_bus_id or len(cands) == 1):
+            self.dir = cands[0][1]
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return float(f.read().split()[0])
+        except Exception:
+            return None
+
+    def _loop(self):
+        while not self._stop:
+            w, hz = self._read(os.path.join(self.dir, "power1_input")), self._read(os.path.join(self.dir, "freq1_input"))
+            if w is not None and hz is not None:
+                self.rows.append((w / 1e6, hz / 1e6))
+            time.sleep(0.2)
+
+    def start(self):
+        if self.dir:
+            import threading
+            self._th = threading.Thread(target=self._loop, daemon=True); self._th.start()
+        return self
+
+    def stop(self):
+        self._stop = True
+        if self._th: self._th.join()
+        if not self.rows:
+            return None
+        w, f = [r[0] for r in self.rows], [r[1] for r in self.rows]
+        cap = self._read(os.path.join(self.dir, "power1_cap"))
+        return {"socket_power_w_avg": sum(w) / len(w), "socket_power_w_max": max(w), "power_cap_w": cap / 1e6 if cap else None,
+                "sclk_mhz_avg": sum(f) / len(f), "sclk_mhz_min": min(f), "sclk_mhz_max": max(f), "samples": len(w),
+                "source": "amdgpu hwmon power1_input / freq1_input of this rank's GPU, sampled every 0.2 s inside the timed region",
+                "note": "nominal clock 2400 MHz; the cycle figures of roofline_valu / step_valu are quoted at the nominal clock"}
+
+
 def pstate_traffic():
     try:
         t = json.load(open(os.path.join(ROOT, TRAFFIC_FILE)))
@@ -836,7 +887,14 @@ def main():
     gathered = None
     mask = sum(1 << b for b in PROF_STAGES.values())
     ctx.prof_enable(mask)                                      # HIP events around the candidate dominant kernels, on their lane streams
+    try:
+        pr_ = torch.cuda.get_device_properties(local_rank)
+        bdf = "%04x:%02x:%02x.0" % (getattr(pr_, "pci_domain_id", 0), pr_.pci_bus_id, pr_.pci_device_id) if hasattr(pr_, "pci_bus_id") else None
+    except Exception:
+        bdf = None
+    sampler = PowerSampler(bdf)
     barrier(); torch.cuda.synchronize()
+    sampler.start()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -855,6 +913,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if share_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0].item())
+    power = sampler.stop()
     prof = ctx.prof_read()
     ctx.prof_enable(0)
     hbm_free, hbm_total = torch.cuda.mem_get_info()            # device-wide: the library's allocations, torch's, every rank's when the GPU is shared
@@ -1055,6 +1114,7 @@ def main():
             "launcher": os.environ.get("MINA_BENCH_LAUNCHER", "torch.distributed.run" if dist_on else "none"),
             "ms_per_step": elapsed / args.steps * 1e3,
             "call_latency_ms": call_latency_ms,
+            "power": power,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32x8-montgomery (255-bit prime fields, integer)", "data": "synthetic",
             "config": {"workload": "C3: full Proof-of-State job per proof -- 17 protocol-state hashes (chain of 16 + bridge tip) vs public inputs + linkage, "

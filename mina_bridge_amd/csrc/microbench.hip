@@ -209,6 +209,8 @@ __global__ void __launch_bounds__(256) probe_latency(uint32_t *out, uint32_t see
 #endif
 }
 
+static double wall_now() { timespec ts; clock_gettime(CLOCK_REALTIME, &ts); return ts.tv_sec + ts.tv_nsec * 1e-9; }
+
 template <class K>
 static double time_kernel(K launch, int reps) {
     hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
@@ -236,6 +238,27 @@ int main(int argc, char **argv) {
             }
             DEP(1, 0) DEP(2, 0) DEP(3, 0) DEP(4, 0) DEP(8, 0) DEP(1, 8) DEP(2, 8)
         }
+        CHECK(hipFree(out));
+        return 0;
+    }
+    if (argc > 1 && !strcmp(argv[1], "--sustain")) {     // the same two streams held for SECONDS each (default 6), rate per ~0.5 s window: the probes above are bursts of
+        // 0.1 - 0.5 ms, shorter than the power controller's averaging; the bench holds the chip at its 1400 W cap for seconds (profiles/r05_clock_power.md)
+        const double secs = argc > 2 ? atof(argv[2]) : 6.0;
+        const int wps = 8, blocks = cus * wps;
+#define SUSTAIN(S, KIND, LABEL)                                                                              \
+        {                                                                                                    \
+            double one = time_kernel([&] { probe_ratio<S, KIND><<<blocks, 256>>>(out, 12345u); }, 5);        \
+            const int reps = (int)(0.5 / one) + 1;                                                           \
+            for (double done = 0; done < secs;) {                                                            \
+                double t = time_kernel([&] { probe_ratio<S, KIND><<<blocks, 256>>>(out, 12345u); }, reps);   \
+                done += t * reps;                                                                            \
+                printf("{\"probe\": \"sustained: %s\", \"waves_per_simd\": %d, \"t_s\": %.2f, \"wall\": %.3f, \"nominal_cycles_per_mac\": %.3f, \"nominal_cycles_per_instr\": %.3f, \"T_mac_per_s\": %.2f}\n", \
+                       LABEL, wps, done, wall_now(), t * clk / ((double)ITERS * 153 * wps), t * clk / ((double)ITERS * (153 + S) * wps), (double)ITERS * 153 * blocks * 256 / t / 1e12); \
+                fflush(stdout);                                                                              \
+            }                                                                                                \
+        }
+        SUSTAIN(0, 0, "pure v_mad_u64_u32")
+        SUSTAIN(29, 3, "the signed-digit 3-lane round's mix (153 + 29)")
         CHECK(hipFree(out));
         return 0;
     }

@@ -1,6 +1,6 @@
 #!/bin/bash
 # what clock and socket power the chip runs at UNDER the bench's load (the "2.4 GHz" every cycle figure in profiles/ is nominal):
-# rocm-smi sampled every ~0.3 s beside (1) microbench --ratio (pure v_mad_u64_u32 rows), (2) the default bench step.  usage: tools/clock_sample.sh <tag>
+# rocm-smi sampled every ~0.3 s beside (1) microbench --sustain (the pure v_mad_u64_u32 stream and the round's mix held for 8 s each), (2) the default bench step.  usage: tools/clock_sample.sh <tag>
 cd $GRAFT_REPO_ROOT
 O=gpurun_out/$1; mkdir -p $O
 sample() {   # $1 = label, samples until the file $O/.stop exists
@@ -12,9 +12,9 @@ sample() {   # $1 = label, samples until the file $O/.stop exists
 rocm-smi -c -P --json > $O/idle.json 2>&1
 rocm-smi --showmaxpower --showperflevel --showclkfrq > $O/caps.txt 2>&1
 rm -f $O/.stop; sample microbench > $O/samples_microbench.jsonl & S=$!
-timeout 300 mina_bridge_amd/microbench --ratio > $O/microbench_ratio.jsonl 2>&1
+timeout 300 mina_bridge_amd/microbench --sustain 8 > $O/microbench_sustain.jsonl 2>&1
 touch $O/.stop; wait $S
 rm -f $O/.stop; sample bench > $O/samples_bench.jsonl & S=$!
 timeout 600 python bench.py --no-cpu-baseline --no-boundary --steps 200 --warmup 8 > $O/bench.json 2> $O/bench.err
 touch $O/.stop; wait $S; rm -f $O/.stop
-wc -l $O/samples_*.jsonl; head -c 600 $O/samples_bench.jsonl; cat $O/caps.txt | head -30
+wc -l $O/samples_*.jsonl; tail -4 $O/microbench_sustain.jsonl
