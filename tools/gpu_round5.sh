@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 5: ONE script for every GPU-box call; stages named on the command line, outputs under gpurun_out/<tag>/.
-#   tools/gpu_round5.sh <tag> stage [stage ...]     stages: fe52 sharded pytest msm c2ab abr04 multi bench bench20 gpus2 microbench profile c2 account callers
+#   tools/gpu_round5.sh <tag> stage [stage ...]     stages: fe52 sharded pytest msm c2ab abr04 multi bench bench20 gpus2 microbench profile c2 account callers soak
 cd $GRAFT_REPO_ROOT
 TAG=$1; shift
 O=gpurun_out/$TAG; mkdir -p $O
@@ -32,6 +32,10 @@ for st in "$@"; do
               ( cd /tmp && export TMPDIR=/tmp && for t in 1 0; do MINA_TUNE=msm_fp29=$t rocprofv3 --kernel-trace --stats -f csv -d $GRAFT_REPO_ROOT/$O/law29_$t -o t -- python $GRAFT_REPO_ROOT/tools/probes/law29_ab.py > $GRAFT_REPO_ROOT/$O/law29_$t.log 2>&1; done )
               for t in 1 0; do echo "msm_fp29=$t $(tail -1 $O/law29_$t.log)"; f=$(find $O/law29_$t -name "*kernel_stats.csv" | head -1); grep -i "pubcomm\|msm_accumulate\|msm_table29" $f | cut -d, -f1-5 | cut -c1-160; done | tee $O/law29_ab.txt ;;
     lawtests) ( time timeout 2400 python -m pytest tests/test_lagrange.py tests/test_gpu_msm.py tests/test_kimchi.py tests/test_state_job.py tests/test_native_composite.py tests/test_verify_boundary.py -m gpu -q -x ) > $O/pytest_law.log 2>&1; tail -5 $O/pytest_law.log ;;
+    soak)     # randomised differential soaks of the build against the oracle, fresh seeds; SOAK_SCALE multiplies the seconds (default 1: 19 min in all)
+              for t in "soak.py 180" "soak_ipa.py 120" "soak_sponge.py 180" "soak_lanes.py 180" "soak_verifier.py 180" "soak_boundary.py 300"; do set -- $t
+                secs=$(( $2 * ${SOAK_SCALE:-1} )); timeout $(( secs + 600 )) python tools/$1 $secs > $O/${1%.py}.log 2>&1; echo "$1 rc=$?" | tee -a $O/soak_rc.log; tail -1 $O/${1%.py}.log | cut -c1-400
+              done ;;
     *) echo "unknown stage $st" ;;
   esac
 done
