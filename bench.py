@@ -83,11 +83,11 @@ class PowerSampler:
     reads: nothing is launched, nothing is forked).  Why it rides in the line: the step holds the chip at its socket power cap (1400 W) and the clock settles at
     ~2.25 GHz, while the microbench that measures `roofline.peak` (register-only streams) stays below the cap at 2.39 GHz -- profiles/r05_clock_power.md."""
 
-    def __init__(self, pci_bus_id=None):
+    def __init__(self, pci_bus_id=None, interval=0.2, drm_root="/sys/class/drm"):
         import glob
-        self.dir, self.rows, self._stop, self._th = None, [], False, None
+        self.dir, self.rows, self._stop, self._th, self.interval = None, [], False, None, interval
         cands = []
-        for h in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
+        for h in sorted(glob.glob(os.path.join(drm_root, "card*", "device", "hwmon", "hwmon*"))):
             if os.path.exists(os.path.join(h, "power1_input")) and os.path.exists(os.path.join(h, "freq1_input")):
                 cands.append((os.path.basename(os.path.realpath(os.path.join(h, "..", ".."))).lower(), h))
         if pci_bus_id:
@@ -108,7 +108,7 @@ class PowerSampler:
             w, hz = self._read(os.path.join(self.dir, "power1_input")), self._read(os.path.join(self.dir, "freq1_input"))
             if w is not None and hz is not None:
                 self.rows.append((w / 1e6, hz / 1e6))
-            time.sleep(0.2)
+            time.sleep(self.interval)
 
     def start(self):
         if self.dir:
@@ -125,7 +125,7 @@ class PowerSampler:
         cap = self._read(os.path.join(self.dir, "power1_cap"))
         return {"socket_power_w_avg": sum(w) / len(w), "socket_power_w_max": max(w), "power_cap_w": cap / 1e6 if cap else None,
                 "sclk_mhz_avg": sum(f) / len(f), "sclk_mhz_min": min(f), "sclk_mhz_max": max(f), "samples": len(w),
-                "source": "amdgpu hwmon power1_input / freq1_input of this rank's GPU, sampled every 0.2 s inside the timed region",
+                "source": f"amdgpu hwmon power1_input / freq1_input of this rank's GPU, sampled every {self.interval} s inside the timed region",
                 "note": "nominal clock 2400 MHz; the cycle figures of roofline_valu / step_valu are quoted at the nominal clock"}
 
 
@@ -1069,16 +1069,19 @@ def main():
         c2 = lambda: ctx.accumulator_check_multi_dev(CURVE_VESTA, ACC_K, 8, d_pre8.data_ptr(), d_sg8.data_ptr(), d_v8.data_ptr())
         for _ in range(32):
             c2()
-        ctx.synchronize(); torch.cuda.synchronize(); t2 = time.perf_counter()
+        ctx.synchronize(); torch.cuda.synchronize()
+        c2_sampler = PowerSampler(bdf, interval=0.03).start(); t2 = time.perf_counter()
         for _ in range(400):
             c2()
         ctx.synchronize()
         c2_rate = 8 * 400 / (time.perf_counter() - t2)
+        c2_power = c2_sampler.stop()
         assert d_v8.cpu().numpy().tolist() == [1] * 8
         ctx.set_pipeline(1)
     else:
         call_latency_ms = None
         c2_rate = None
+        c2_power = None
 
     if dist_on:
         t = torch.tensor([elapsed, sustained["seconds"] if sustained else 0.0, c5["ms_per_step"] if c5 else 0.0], dtype=torch.float64, device="cpu" if share_gpu else dev)
@@ -1151,6 +1154,7 @@ def main():
             "c2_accumulator_only": {"value": c2_rate, "unit": "accumulator checks/s",
                                     "note": "BASELINE config C2 alone (round 1's headline): un-folded 2^16-base Vesta IPA accumulator checks, 8 per call, 16 lanes",
                                     # the metric's second half ("MSM HBM GB/s vs peak"): one check = one 2^16-base MSM; algorithmic bytes = bases + scalars
+                                    "power": c2_power,
                                     "msm_valu": None if not c2_rate else msm_valu(c2_rate),
                                     "msm_hbm": None if not c2_rate else {"algorithmic_bytes_per_msm": 65536 * (64 + 32) + 96, "achieved_GBps": c2_rate * (65536 * 96 + 96) / 1e9, "peak_GBps": HBM_PEAK_GBPS,
                                                                          "frac": c2_rate * (65536 * 96 + 96) / 1e9 / HBM_PEAK_GBPS, **msm_traffic(c2_rate),

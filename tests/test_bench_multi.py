@@ -150,3 +150,24 @@ def test_exchange_variant_leg_on_a_one_rank_rccl_group():
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     x = json_line(r.stdout)["exchange_variant_8e2"]
     assert x and "error" not in x and x["value"] > 0 and "RCCL" in x["collectives"], x
+
+
+def test_power_sampler_reads_the_hwmon_files_of_the_rank_s_own_gpu(tmp_path):
+    """bench.py's `power` key (profiles/r05_clock_power.md): socket power and sclk from amdgpu's hwmon files, sampled by a host thread inside the timed region.  On a fake
+    sysfs tree with two cards the sampler picks the card whose PCI address is the rank's device, averages what it read, and is silent (None) when nothing matches."""
+    import importlib.util
+    import time
+    spec = importlib.util.spec_from_file_location("bench_mod", BENCH)
+    b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+    drm = tmp_path / "drm"; drm.mkdir()
+    for i, (bdf, uw, hz) in enumerate([("0000:05:00.0", 1300000000, 2250000000), ("0000:15:00.0", 240000000, 95000000)]):
+        hw = tmp_path / "pci" / bdf / "hwmon" / f"hwmon{i + 3}"; hw.mkdir(parents=True)
+        (hw / "power1_input").write_text(f"{uw}\n"); (hw / "freq1_input").write_text(f"{hz}\n"); (hw / "power1_cap").write_text("1400000000\n")
+        (drm / f"card{i}").mkdir(); os.symlink(tmp_path / "pci" / bdf, drm / f"card{i}" / "device")
+    s = b.PowerSampler("0000:05:00.0", interval=0.01, drm_root=str(drm)).start(); time.sleep(0.1); r = s.stop()
+    assert r["samples"] >= 3 and r["socket_power_w_avg"] == 1300.0 and r["sclk_mhz_avg"] == 2250.0 and r["power_cap_w"] == 1400.0
+    s = b.PowerSampler("0000:15:00.0", interval=0.01, drm_root=str(drm)).start(); time.sleep(0.05); r = s.stop()
+    assert r["socket_power_w_max"] == 240.0 and r["sclk_mhz_min"] == 95.0
+    assert b.PowerSampler("0000:99:00.0", interval=0.01, drm_root=str(drm)).start().stop() is None      # two cards, neither is ours: no guess
+    assert b.PowerSampler(None, interval=0.01, drm_root=str(drm)).start().stop() is None                # no address and more than one card: no guess
+    assert b.PowerSampler(None, interval=0.01, drm_root=str(tmp_path / "nothing")).start().stop() is None

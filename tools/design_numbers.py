@@ -57,6 +57,9 @@ def table(b, b20=None):
          f"{r['hbm']['traffic'] / 1e6:.0f} MB = {r['hbm']['traffic_ratio_to_algorithmic']:.2f} x", "`roofline.hbm`"),
         ("the pipelined step against instruction issue", f"{b['step_valu']['wave_instructions_per_step'] / 1e9:.2f} G wave-instructions per step: floor {b['step_valu']['floor_ms_per_step']:.1f} ms = "
          f"**{b['step_valu']['frac']:.2f}**" if b.get("step_valu") else "n/a", "`step_valu`"),
+        *([("socket power and shader clock inside the timed region (amdgpu hwmon, sampled by `bench.py`; `profiles/r05_clock_power.md`)",
+            f"{b['power']['socket_power_w_avg']:.0f} W average, {b['power']['socket_power_w_max']:.0f} W peak of the {b['power']['power_cap_w']:.0f} W cap; sclk {b['power']['sclk_mhz_avg']:.0f} MHz average "
+            f"({b['power']['sclk_mhz_min']:.0f} – {b['power']['sclk_mhz_max']:.0f}) of the nominal 2400: the step is power-capped", "`power`")] if b.get("power") else []),
         (f"CPU restatement, same box ({b['cpu_baseline']['cores']} usable cores): one proof per call / with the GPU job's batch fold",
          f"{b['cpu_baseline']['value']:.1f} proofs/s / {b['cpu_baseline_folded']['value']:.0f} proofs/s", "`cpu_baseline`, `cpu_baseline_folded`"),
     ]
