@@ -107,7 +107,7 @@ class PowerSampler:
         while not self._stop:
             w, hz = self._read(os.path.join(self.dir, "power1_input")), self._read(os.path.join(self.dir, "freq1_input"))
             if w is not None and hz is not None:
-                self.rows.append((w / 1e6, hz / 1e6))
+                self.rows.append((w / 1e6, hz / 1e6, time.perf_counter()))
             time.sleep(self.interval)
 
     def start(self):
@@ -755,6 +755,7 @@ def main():
     ap.add_argument("--no-probes", action="store_true", help="skip the isolated-kernel / C2 probes and the sustained / C5 legs (profiling runs: only the timed loop launches kernels)")
     ap.add_argument("--no-boundary", action="store_true", help="skip the bytes -> bools legs (mina_verify_state_batch on serialized proofs)")
     ap.add_argument("--boundary-jobs", type=int, default=0, help="proofs per call of the bytes -> bools legs (default: min(--jobs, 8192))")
+    ap.add_argument("--power-trace", default="", help="write the timed region's raw (seconds, watts, MHz) hwmon samples to this file (sampled every 10 ms instead of 200)")
     ap.add_argument("--preflight", action="store_true",
                     help="the check to run FIRST on a multi-GPU node (VERDICT r04 next #7; no node was available to any round): every rank reports LOCAL_RANK, the device it bound and "
                          "that device's PCI bus id, the rank count the collectives backend saw, runs ONE small step + the verdict all-gather; rank 0 prints one JSON line and the "
@@ -892,7 +893,7 @@ def main():
         bdf = "%04x:%02x:%02x.0" % (getattr(pr_, "pci_domain_id", 0), pr_.pci_bus_id, pr_.pci_device_id) if hasattr(pr_, "pci_bus_id") else None
     except Exception:
         bdf = None
-    sampler = PowerSampler(bdf)
+    sampler = PowerSampler(bdf, interval=0.01 if args.power_trace else 0.2)
     barrier(); torch.cuda.synchronize()
     sampler.start()
     t0 = time.perf_counter()
@@ -914,6 +915,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0].item())
     power = sampler.stop()
+    if args.power_trace and sampler.rows:
+        with open(args.power_trace, "w") as f:
+            for w_, mhz_, t_ in sampler.rows: f.write(json.dumps({"t_s": round(t_ - t0, 4), "socket_power_w": w_, "sclk_mhz": mhz_}) + "\n")
     prof = ctx.prof_read()
     ctx.prof_enable(0)
     hbm_free, hbm_total = torch.cuda.mem_get_info()            # device-wide: the library's allocations, torch's, every rank's when the GPU is shared

@@ -287,18 +287,24 @@ __device__ __forceinline__ void poseidon_permute_tri(fe_t &s, const PoseidonPara
 #if defined(__HIP_DEVICE_COMPILE__)
     const TriPos tp = tri_pos();
     const PoseidonParams29 *__restrict__ q = pparams29_of(pp);
-    const fe29_t m0 = q->mds[tp.e][0], m1 = q->mds[tp.e][1], m2 = q->mds[tp.e][2];
+    // The row's own term needs no cross-lane move: lane e multiplies ITS x^7 by mds[e][e] and fetches only the two others (18 ds_bpermute per round instead of 27;
+    // the column sums of the dot product are the same integers in another order, so the state is bit-identical).  Measured on the round alone (tools/probes/sg_probe
+    // --rounds): the 27 moves cost 3.4 - 4.3 % of the round's rate -- two thirds of it waiting and issue, a third the clock they pull down on the power cap.
+    const uint32_t en = tp.e == 2u ? 0u : tp.e + 1u, ep = tp.e == 0u ? 2u : tp.e - 1u;
+    const fe29_t ms = q->mds[tp.e][tp.e], mn = q->mds[tp.e][en], mp = q->mds[tp.e][ep];
     fe29_t x = fe29_mul_asm<F>(fe29_from_words(s), q->enter);        // x 2^256 -> x 2^261
     // Every reduction of a round uses SIGNED quotient digits (fp29.cuh fe29_sqr_sg / fe29_mul_sg / fe29_dot3rc_sg: no instruction per digit, results within (1 p, 2 p] of
     // the exact quotient, limbs normalised; the round constant rides inside the row's reduction).  Values along a round, in units of p, from x < 2.1: every power and the
     // row < 2.05 -- a fixed point (tools/fe29_bounds.py prove_sponge_rounds: the row's 27 limb products per column reach 0.92 of the signed accumulator, nothing else half).
+    fe29_t rc = q->rc2[0][tp.e];
 #pragma unroll 1
     for (int r = 0; r < 55; ++r) {
         const fe29_t x2 = fe29_sqr_sg<F>(x);
         const fe29_t x4 = fe29_sqr_sg<F>(x2);
         const fe29_t t = fe29_mul_sg<F>(fe29_mul_sg<F>(x4, x2), x);
-        const fe29_t t0 = tri_bcast29(t, tp.base), t1 = tri_bcast29(t, tp.base + 1), t2 = tri_bcast29(t, tp.base + 2);
-        x = fe29_dot3rc_sg<F>(m0, t0, m1, t1, m2, t2, q->rc2[r][tp.e]);
+        const fe29_t tn = tri_bcast29(t, tp.base + en), tq = tri_bcast29(t, tp.base + ep);
+        x = fe29_dot3rc_sg<F>(ms, t, mn, tn, mp, tq, rc);
+        rc = q->rc2[r < 54 ? r + 1 : 54][tp.e];                     // the NEXT round's constant, a whole S-box ahead of its use (loaded beside its use it was three exposed load latencies per round)
     }
     s = fe_cond_sub_p<F>(fe29_to_words(fe29_mul_asm<F>(x, q->leave)));   // x 2^261 -> x 2^256; the strict product: 2.1 p p / 2^261 + p < 1.02 p: one conditional subtraction
 #else
