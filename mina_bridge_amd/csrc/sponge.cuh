@@ -262,8 +262,8 @@ __device__ __forceinline__ void poseidon_permute_oct(fe_t &s, const PoseidonPara
 }
 // Three lanes per sponge: 21 sponges per wave64 (lanes 3g, 3g+1, 3g+2 own state elements 0, 1, 2 of sponge g; lane 63 shadows
 // group 20).  Same 7 dependent products per round as the quad form, but no idle fourth lane: 63 of 64 lanes work, which is
-// what the chip-filling batches want (the quad form caps at 75 % lane use).  The three x^7 are exchanged with ds_bpermute
-// (24 per round against ~1800 multiply-accumulates: free).  Bit-identical state.
+// what the chip-filling batches want (the quad form caps at 75 % lane use).  The x^7 of the two other lanes arrive by ds_bpermute
+// (18 per round; measured on the round alone they cost ~3 %: profiles/r05_clock_power.md).  Bit-identical state.
 struct TriPos { uint32_t base, e; };
 __device__ __forceinline__ TriPos tri_pos() {
     const uint32_t lane = threadIdx.x & 63u;
