@@ -137,6 +137,7 @@ extern "C" int mina_poseidon_set_params(mina_ctx *c, int field, const uint8_t *p
         both.q.enter = fe29_from_words(fe_mul<F_>(two5, two5));   // Mont(2^10) = 2^10 2^256 = 2^266 mod p: (x 2^256)(2^266) / 2^261 = x 2^261
         const fe_t two522 = fe_to_mont<F_>(fe_mul<F_>(two5, two5), k.r2);   // (2^266)(2^512) / 2^256 = 2^522 mod p
         for (int r = 0; r < 55; ++r) for (int i = 0; i < 3; ++i) both.q.rc2[r][i] = fe29_from_words(fe_mul<F_>(pp.rc[r][i], two522));   // (rc 2^256)(2^522) / 2^256 = rc 2^522
+        both.q.absorb = fe29_from_words(two522);                 // the integer 2^522 mod p: (canonical words)(2^522) / 2^261 = x 2^261
         both.q.leave = fe29_from_words(k.one);                   // Mont(1) = 2^256 mod p:           (x 2^261)(2^256) / 2^261 = x 2^256
     });
     int rc;

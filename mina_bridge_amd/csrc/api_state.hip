@@ -34,6 +34,43 @@ pstate_hash_kernel(uint32_t n, FieldK fk, const PoseidonParams *__restrict__ pp,
     const uint32_t idx = live ? sp : 0;                            // dead groups shadow state 0 (whole waves run the cross-lane moves)
     const uint32_t *rec = records + (size_t)idx * MINA_PSTATE_SLOTS * 8;
     uint32_t nf = nfields[idx]; if (nf > MINA_PSTATE_SLOTS - 1) nf = MINA_PSTATE_SLOTS - 1;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (LANES == 3) {
+        // The chip-filling form keeps the state in the 29-bit form (x 2^261, lazily reduced) from the first absorb to the last squeeze: a field enters by ONE signed-digit
+        // product with 2^522 mod p -- both fields of a block at once, each on the lane that owns its state element; a lane with nothing to absorb multiplies zero, which
+        // gives a multiple of p -- instead of a Montgomery conversion per field (two divergent ones per permutation) and a product into and out of the 29-bit form around
+        // every permutation: ~ 600 of the ~ 51 500 instructions of a permutation.  Bounds: tools/fe29_bounds.py prove_sponge_rounds (row + absorbed field < 4.1 p).
+        const TriPos tp = tri_pos();
+        const PoseidonParams29 *__restrict__ q = pparams29_of(pp);
+        auto field29 = [&](const uint32_t *w, bool take) {           // (words)(2^522) / 2^261; nothing to take: a multiple of p
+            fe_t v = fe_zero();
+            if (take) v = ld_fe<F>(w);
+            return fe29_mul_sg<F>(fe29_from_words(v), q->absorb);
+        };
+        fe29_t x = fe29_mul_asm<F>(fe29_from_words(salts[e]), q->enter);
+        const uint32_t nblk = (nf + 1) / 2;
+#pragma unroll 1
+        for (uint32_t k = 0; k < nblk; ++k) {
+            if (k) poseidon_rounds_tri<F>(x, q, tp);
+            const uint32_t el = 2 * k + e;
+            x = fe29_add(x, field29(rec + (size_t)(1 + el) * 8, e < 2 && el < nf));
+        }
+        poseidon_rounds_tri<F>(x, q, tp);
+        const fe29_t body29 = tri_bcast29(x, tp.base);               // state element 0, still x 2^261, below 2.07 p
+        fe29_t y = fe29_mul_asm<F>(fe29_from_words(salts[3 + e]), q->enter);
+        fe29_t add = field29(rec, e == 0);
+        if (e == 1) add = body29;
+        y = fe29_add(y, add);
+        poseidon_rounds_tri<F>(y, q, tp);
+        if (live) {                                                  // out of the 29-bit form once per state (element 0 lives on the writer lane)
+            if (writer) {
+                const fe_t w = fe_from_mont<F>(fe_cond_sub_p<F>(fe29_to_words(fe29_mul_asm<F>(y, q->leave)))); for (int i = 0; i < 8; ++i) out_hash[(size_t)sp * 8 + i] = w.v[i];
+                if (out_body) { const fe_t bw = fe_from_mont<F>(fe_cond_sub_p<F>(fe29_to_words(fe29_mul_asm<F>(x, q->leave)))); for (int i = 0; i < 8; ++i) out_body[(size_t)sp * 8 + i] = bw.v[i]; }
+            }
+        }
+        return;
+    }
+#endif
     fe_t s = salts[e];
     uint32_t count = 0;
     for (uint32_t el = 0; el < nf; ++el) {

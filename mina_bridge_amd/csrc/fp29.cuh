@@ -111,7 +111,7 @@ struct EC29 {      // xyzz29_add_affine: accumulator invariants (units of p) and
     static constexpr uint32_t G_SUB_X3_MULT = 10;
 };
 struct SPONGE29 {   // the Poseidon lane forms' state bounds between rounds, in thousandths of p (fixed points of a lazy round)
-    static constexpr uint32_t LANES3_STATE_MILLI_P = 2100;
+    static constexpr uint32_t LANES3_STATE_MILLI_P = 4100;
     static constexpr uint32_t LANES8_STATE_MILLI_P = 4100;
     static constexpr uint32_t LANES16_STATE_MILLI_P = 6100;
 };

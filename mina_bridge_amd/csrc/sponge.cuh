@@ -124,7 +124,8 @@ struct PoseidonParams { fe_t mds[3][3]; fe_t rc[55][3]; };     // Montgomery, in
 struct PoseidonParams29 { fe29_t mds[3][3]; fe29_t rc[55][3]; fe29_t enter /* 2^266 mod p */, leave /* 2^256 mod p */;
                           fe29_t rc2[55][3];      // the round constants times 2^261 once more (rc 2^522 mod p): added BEFORE the reduction of the 3-lane form's MDS dot product
                           fe29_t zero;            // 0: what the lanes that do not add the round constant read in its place (8- and 16-lane forms)
-                          uint32_t pad[2]; };     // size: a multiple of 16
+                          fe29_t absorb;          // 2^522 mod p: (canonical words)(2^522) / 2^261 = x 2^261 -- a field absorbed without leaving the 29-bit form (pstate_hash_kernel<., 3>)
+                          uint32_t pad[1]; };     // size: a multiple of 16
 static_assert(sizeof(PoseidonParams29) % 16 == 0, "PoseidonParams29 is read with 16-byte loads");
 __host__ __device__ static inline const PoseidonParams29 *pparams29_of(const PoseidonParams *pp) { return reinterpret_cast<const PoseidonParams29 *>(pp + 1); }
 
@@ -281,21 +282,18 @@ __device__ __forceinline__ fe29_t tri_bcast29(const fe29_t &a, uint32_t src_lane
     for (int i = 0; i < L29; ++i) r.v[i] = (uint32_t)__shfl((int)a.v[i], (int)src_lane, 64);
     return r;
 }
+// the 55 rounds of the 3-lane form on a state element that is already in the 29-bit form (x 2^261, below SPONGE29::LANES3_STATE_MILLI_P / 1000 p, limbs normalised) and stays in it
 template <int F>
-__device__ __forceinline__ void poseidon_permute_tri(fe_t &s, const PoseidonParams *__restrict__ pp) {
-    // the rounds run in the carry-free 29-bit-limb representation (fp29.cuh); state in and out as 8 x 32 Montgomery-2^256, canonical
+__device__ __forceinline__ void poseidon_rounds_tri(fe29_t &x, const PoseidonParams29 *__restrict__ q, const TriPos &tp) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    const TriPos tp = tri_pos();
-    const PoseidonParams29 *__restrict__ q = pparams29_of(pp);
     // The row's own term needs no cross-lane move: lane e multiplies ITS x^7 by mds[e][e] and fetches only the two others (18 ds_bpermute per round instead of 27;
     // the column sums of the dot product are the same integers in another order, so the state is bit-identical).  Measured on the round alone (tools/probes/sg_probe
     // --rounds): the 27 moves cost 3.4 - 4.3 % of the round's rate -- two thirds of it waiting and issue, a third the clock they pull down on the power cap.
     const uint32_t en = tp.e == 2u ? 0u : tp.e + 1u, ep = tp.e == 0u ? 2u : tp.e - 1u;
     const fe29_t ms = q->mds[tp.e][tp.e], mn = q->mds[tp.e][en], mp = q->mds[tp.e][ep];
-    fe29_t x = fe29_mul_asm<F>(fe29_from_words(s), q->enter);        // x 2^256 -> x 2^261
     // Every reduction of a round uses SIGNED quotient digits (fp29.cuh fe29_sqr_sg / fe29_mul_sg / fe29_dot3rc_sg: no instruction per digit, results within (1 p, 2 p] of
-    // the exact quotient, limbs normalised; the round constant rides inside the row's reduction).  Values along a round, in units of p, from x < 2.1: every power and the
-    // row < 2.05 -- a fixed point (tools/fe29_bounds.py prove_sponge_rounds: the row's 27 limb products per column reach 0.92 of the signed accumulator, nothing else half).
+    // the exact quotient, limbs normalised; the round constant rides inside the row's reduction).  Values along a round, in units of p, from x < 4.1 (a row plus an absorbed
+    // field): x^2 < 2.14, every other power and the row < 2.07 (tools/fe29_bounds.py prove_sponge_rounds: the row's 27 limb products per column reach 0.92 of the signed accumulator).
     fe29_t rc = q->rc2[0][tp.e];
 #pragma unroll 1
     for (int r = 0; r < 55; ++r) {
@@ -306,7 +304,19 @@ __device__ __forceinline__ void poseidon_permute_tri(fe_t &s, const PoseidonPara
         x = fe29_dot3rc_sg<F>(ms, t, mn, tn, mp, tq, rc);
         rc = q->rc2[r < 54 ? r + 1 : 54][tp.e];                     // the NEXT round's constant, a whole S-box ahead of its use (loaded beside its use it was three exposed load latencies per round)
     }
-    s = fe_cond_sub_p<F>(fe29_to_words(fe29_mul_asm<F>(x, q->leave)));   // x 2^261 -> x 2^256; the strict product: 2.1 p p / 2^261 + p < 1.02 p: one conditional subtraction
+#else
+    (void)x; (void)q; (void)tp;                                      // device-only (the host pass never calls it)
+#endif
+}
+template <int F>
+__device__ __forceinline__ void poseidon_permute_tri(fe_t &s, const PoseidonParams *__restrict__ pp) {
+    // the rounds run in the carry-free 29-bit-limb representation (fp29.cuh); state in and out as 8 x 32 Montgomery-2^256, canonical
+#if defined(__HIP_DEVICE_COMPILE__)
+    const TriPos tp = tri_pos();
+    const PoseidonParams29 *__restrict__ q = pparams29_of(pp);
+    fe29_t x = fe29_mul_asm<F>(fe29_from_words(s), q->enter);        // x 2^256 -> x 2^261
+    poseidon_rounds_tri<F>(x, q, tp);
+    s = fe_cond_sub_p<F>(fe29_to_words(fe29_mul_asm<F>(x, q->leave)));   // x 2^261 -> x 2^256; the strict product: 4.1 p p / 2^261 + p < 1.04 p: one conditional subtraction
 #else
     (void)s; (void)pp;                                               // device-only (the host pass never calls it)
 #endif

@@ -318,7 +318,7 @@ def search_lazy_sets():
 
 # ------------------------------------------------------------------------------------------------ SPEC: the Poseidon rounds' lane forms (sponge.cuh)
 # state bound (units of p / 1000) each lane form keeps between rounds; MDS entries and round constants are canonical (< p)
-SPONGE = {"LANES3_STATE_MILLI_P": 2100, "LANES8_STATE_MILLI_P": 4100, "LANES16_STATE_MILLI_P": 6100}
+SPONGE = {"LANES3_STATE_MILLI_P": 4100, "LANES8_STATE_MILLI_P": 4100, "LANES16_STATE_MILLI_P": 6100}
 
 
 def prove_sponge_rounds(field: int, c=None):
@@ -331,7 +331,13 @@ def prove_sponge_rounds(field: int, c=None):
     x2 = pr.sqr("3-lane x^2", x, lazy="sg"); x4 = pr.sqr("3-lane x^4", x2, lazy="sg"); x6 = pr.mul("3-lane x^6", x4, x2, lazy="sg"); x7 = pr.mul("3-lane x^7", x6, x, lazy="sg")
     row = pr.product("3-lane MDS row + rc", [(mds, x7)] * 3, lazy="sg", c=rc)
     need(row.vmax < x.vmax + 1, f"3-lane: a round maps a state below {x.vmax / p:.3f} p to {row.vmax / p:.3f} p")
-    out["lanes3"] = {"x2": x2, "x4": x4, "x7": x7, "row": row}
+    # absorbing IN the 29-bit form (pstate_hash_kernel<., 3>: the state never leaves it between the permutations of a sponge): the absorbed field -- any 256-bit word
+    # string -- times 2^522 mod p with signed digits, added to the row with the carries propagated, is the next permutation's entry state
+    absorbed = pr.mul("3-lane absorb: words x 2^522", norm(1 << 256, "absorbed words"), norm(p, "2^522 mod p"), lazy="sg")
+    need(row.vmax + absorbed.vmax < x.vmax + 1, f"3-lane: row + absorbed field = {(row.vmax + absorbed.vmax) / p:.3f} p does not fit the state bound {x.vmax / p:.3f} p")
+    entered = pr.mul("3-lane enter: Montgomery-2^256 words x 2^266", norm(p, "salt"), norm(p, "2^266 mod p"))
+    need(entered.vmax + max(absorbed.vmax, row.vmax) < x.vmax + 1, "3-lane: salt + absorbed field / body hash does not fit the state bound")
+    out["lanes3"] = {"x2": x2, "x4": x4, "x7": x7, "row": row, "absorbed": absorbed}
     # 8 lanes: the state element is u + swap(u), u a two-term half row (+ rc in one of the halves)
     x = norm(c["LANES8_STATE_MILLI_P"] * p // 1000, "state (8-lane)")
     x2 = pr.sqr("8-lane x^2", x, lazy="sg"); x3 = pr.mul("8-lane x^3", x2, x, lazy="sg"); x4 = pr.sqr("8-lane x^4", x2, lazy="sg"); x7 = pr.mul("8-lane x^7", x3, x4, lazy="sg")
