@@ -1048,6 +1048,8 @@ def main():
 
     # the candidate dominant kernels with nothing else on the GPU: one lane, HIP events on that lane's stream
     prof_iso = {}
+    if dist_on and share_gpu and not args.no_probes:           # ranks that share ONE GPU take turns: "nothing else on the GPU" must hold for each of them (rank r waits for ranks 0 .. r-1;
+        for _ in range(rank): barrier()                        # unserialised, a rank's isolated launch landed behind the other's 16-lane C2 burst in about every second run: 1015 ms for 35)
     if not args.no_probes:
         ctx.set_pipeline(1)
         for _ in range(2):
@@ -1086,6 +1088,8 @@ def main():
         call_latency_ms = None
         c2_rate = None
         c2_power = None
+    if dist_on and share_gpu and not args.no_probes:
+        for _ in range(rank, world): barrier()
 
     if dist_on:
         t = torch.tensor([elapsed, sustained["seconds"] if sustained else 0.0, c5["ms_per_step"] if c5 else 0.0], dtype=torch.float64, device="cpu" if share_gpu else dev)
