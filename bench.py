@@ -1048,9 +1048,10 @@ def main():
 
     # the candidate dominant kernels with nothing else on the GPU: one lane, HIP events on that lane's stream
     prof_iso = {}
-    if dist_on and share_gpu and not args.no_probes:           # ranks that share ONE GPU take turns: "nothing else on the GPU" must hold for each of them (rank r waits for ranks 0 .. r-1;
-        for _ in range(rank): barrier()                        # unserialised, a rank's isolated launch landed behind the other's 16-lane C2 burst in about every second run: 1015 ms for 35)
-    if not args.no_probes:
+    # Ranks that share ONE GPU have no "nothing else on the GPU": in about every second shared run an isolated launch took 500 - 1000 ms for 35 (the other process's queues are
+    # time-sliced in by the hardware scheduler whether or not they hold work) and C2 read 740 - 2500 checks/s for 13 000.  Those keys are left out of a shared-GPU line.
+    iso_legs = not args.no_probes and not (dist_on and share_gpu)
+    if iso_legs:
         ctx.set_pipeline(1)
         for _ in range(2):
             step()
@@ -1088,9 +1089,6 @@ def main():
         call_latency_ms = None
         c2_rate = None
         c2_power = None
-    if dist_on and share_gpu and not args.no_probes:
-        for _ in range(rank, world): barrier()
-
     if dist_on:
         t = torch.tensor([elapsed, sustained["seconds"] if sustained else 0.0, c5["ms_per_step"] if c5 else 0.0], dtype=torch.float64, device="cpu" if share_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -1108,7 +1106,7 @@ def main():
         ovl = {k: avg_us(prof, k) for k in PROF_STAGES}
         src = iso if iso.get("pstate_hash") else ovl
         # dominant kernel of the job: the protocol-state hash (17 sponges of ~27 permutations per proof)
-        kern_us = src.get("pstate_hash")
+        kern_us = src.get("pstate_hash") if not (dist_on and share_gpu) else None      # no launch of a shared-GPU run is an isolated one
         nstates = B * STATES_PER_PROOF
         perms = nstates * (25 + 1)                             # 49 body fields -> 25 permutations, + 1 for H(previous, body)
         hash_bytes = nstates * (50 * 32 + 32)                  # per state: 50 field elements read, one hash written
@@ -1202,7 +1200,7 @@ def main():
                                             "(8192 proofs: 6.5 waves per SIMD, isolated launch 0.82 of the ceiling; 16384: 12.95)"}
         else:
             out["roofline"] = {"bound": "valu_int32", "kernel": "pstate_hash_kernel", "achieved": None, "peak": CHIP_SIMDS * 64 * CLOCK_HZ / PURE_MAC_ISSUE_CYCLES / 1e12, "unit": "T limb-MAC/s",
-                               "frac": None, "traffic": hbm_view["traffic"], "hbm": hbm_view, "note": "no kernel timing in this run (--no-probes without the stage events)"}
+                               "frac": None, "traffic": hbm_view["traffic"], "hbm": hbm_view, "note": "no isolated kernel timing in this run (--no-probes without the stage events, or ranks that share one GPU)"}
         if args.mode == "full" and not share_gpu:            # (ranks sharing one GPU: a step's time is not one GPU's)
             out["step_valu"] = step_valu(out["ms_per_step"], B)  # the pipelined step as a whole against instruction issue (secondary; `roofline` stays the dominant kernel's)
         if not args.no_cpu_baseline and args.gpus == 1:       # the CPU leg is timed at N = 1 only (rank 0)
