@@ -1474,119 +1474,80 @@ template <int F> __device__ __forceinline__ fe29_t fe29_mul_sg(const fe29_t &a, 
     asm("v_mad_u64_u32 %0, %1, %2, %3, 0"
         : "=&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[0]));
     m0 = (uint32_t)col;
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m0), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 1: 2 + 1 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[1]), "v"(a.v[1]), "v"(b.v[0]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m0), "s"(n1));
+    // column 1: 2 + 1 products; first: - s_0 p_0 (the low limb of column 0 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m0), "v"(col), "v"(a.v[0]), "v"(b.v[1]), "v"(a.v[1]), "v"(b.v[0]), "v"(m0), "s"(n1));
+    col = nc;
     m1 = (uint32_t)col;
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m1), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 2: 3 + 2 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[2]), "v"(a.v[1]), "v"(b.v[1]), "v"(a.v[2]), "v"(b.v[0]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m1), "s"(n1), "v"(m0), "s"(n2));
+    // column 2: 3 + 2 products; first: - s_1 p_0 (the low limb of column 1 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_i64_i32 %0, %1, %10, %11, %0\n\tv_mad_i64_i32 %0, %1, %12, %13, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m1), "v"(col), "v"(a.v[0]), "v"(b.v[2]), "v"(a.v[1]), "v"(b.v[1]), "v"(a.v[2]), "v"(b.v[0]), "v"(m1), "s"(n1), "v"(m0), "s"(n2));
+    col = nc;
     m2 = (uint32_t)col;
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m2), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 3: 4 + 3 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[3]), "v"(a.v[1]), "v"(b.v[2]), "v"(a.v[2]), "v"(b.v[1]), "v"(a.v[3]), "v"(b.v[0]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m2), "s"(n1), "v"(m1), "s"(n2), "v"(m0), "s"(n3));
+    // column 3: 4 + 3 products; first: - s_2 p_0 (the low limb of column 2 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_i64_i32 %0, %1, %12, %13, %0\n\tv_mad_i64_i32 %0, %1, %14, %15, %0\n\tv_mad_i64_i32 %0, %1, %16, %17, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m2), "v"(col), "v"(a.v[0]), "v"(b.v[3]), "v"(a.v[1]), "v"(b.v[2]), "v"(a.v[2]), "v"(b.v[1]), "v"(a.v[3]), "v"(b.v[0]), "v"(m2), "s"(n1), "v"(m1), "s"(n2), "v"(m0), "s"(n3));
+    col = nc;
     m3 = (uint32_t)col;
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m3), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 4: 5 + 4 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[4]), "v"(a.v[1]), "v"(b.v[3]), "v"(a.v[2]), "v"(b.v[2]), "v"(a.v[3]), "v"(b.v[1]), "v"(a.v[4]), "v"(b.v[0]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m3), "s"(n1), "v"(m2), "s"(n2), "v"(m1), "s"(n3), "v"(m0), "s"(n4));
+    // column 4: 5 + 4 products; first: - s_3 p_0 (the low limb of column 3 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_i64_i32 %0, %1, %14, %15, %0\n\tv_mad_i64_i32 %0, %1, %16, %17, %0\n\tv_mad_i64_i32 %0, %1, %18, %19, %0\n\tv_mad_i64_i32 %0, %1, %20, %21, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m3), "v"(col), "v"(a.v[0]), "v"(b.v[4]), "v"(a.v[1]), "v"(b.v[3]), "v"(a.v[2]), "v"(b.v[2]), "v"(a.v[3]), "v"(b.v[1]), "v"(a.v[4]), "v"(b.v[0]), "v"(m3), "s"(n1), "v"(m2), "s"(n2), "v"(m1), "s"(n3), "v"(m0), "s"(n4));
+    col = nc;
     m4 = (uint32_t)col;
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m4), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 5: 6 + 4 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[5]), "v"(a.v[1]), "v"(b.v[4]), "v"(a.v[2]), "v"(b.v[3]), "v"(a.v[3]), "v"(b.v[2]), "v"(a.v[4]), "v"(b.v[1]), "v"(a.v[5]), "v"(b.v[0]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m4), "s"(n1), "v"(m3), "s"(n2), "v"(m2), "s"(n3), "v"(m1), "s"(n4));
+    // column 5: 6 + 4 products; first: - s_4 p_0 (the low limb of column 4 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_i64_i32 %0, %1, %16, %17, %0\n\tv_mad_i64_i32 %0, %1, %18, %19, %0\n\tv_mad_i64_i32 %0, %1, %20, %21, %0\n\tv_mad_i64_i32 %0, %1, %22, %23, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m4), "v"(col), "v"(a.v[0]), "v"(b.v[5]), "v"(a.v[1]), "v"(b.v[4]), "v"(a.v[2]), "v"(b.v[3]), "v"(a.v[3]), "v"(b.v[2]), "v"(a.v[4]), "v"(b.v[1]), "v"(a.v[5]), "v"(b.v[0]), "v"(m4), "s"(n1), "v"(m3), "s"(n2), "v"(m2), "s"(n3), "v"(m1), "s"(n4));
+    col = nc;
     m5 = (uint32_t)col;
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m5), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 6: 7 + 4 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[6]), "v"(a.v[1]), "v"(b.v[5]), "v"(a.v[2]), "v"(b.v[4]), "v"(a.v[3]), "v"(b.v[3]), "v"(a.v[4]), "v"(b.v[2]), "v"(a.v[5]), "v"(b.v[1]), "v"(a.v[6]), "v"(b.v[0]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m5), "s"(n1), "v"(m4), "s"(n2), "v"(m3), "s"(n3), "v"(m2), "s"(n4));
+    // column 6: 7 + 4 products; first: - s_5 p_0 (the low limb of column 5 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_i64_i32 %0, %1, %18, %19, %0\n\tv_mad_i64_i32 %0, %1, %20, %21, %0\n\tv_mad_i64_i32 %0, %1, %22, %23, %0\n\tv_mad_i64_i32 %0, %1, %24, %25, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m5), "v"(col), "v"(a.v[0]), "v"(b.v[6]), "v"(a.v[1]), "v"(b.v[5]), "v"(a.v[2]), "v"(b.v[4]), "v"(a.v[3]), "v"(b.v[3]), "v"(a.v[4]), "v"(b.v[2]), "v"(a.v[5]), "v"(b.v[1]), "v"(a.v[6]), "v"(b.v[0]), "v"(m5), "s"(n1), "v"(m4), "s"(n2), "v"(m3), "s"(n3), "v"(m2), "s"(n4));
+    col = nc;
     m6 = (uint32_t)col;
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m6), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 7: 8 + 4 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[7]), "v"(a.v[1]), "v"(b.v[6]), "v"(a.v[2]), "v"(b.v[5]), "v"(a.v[3]), "v"(b.v[4]), "v"(a.v[4]), "v"(b.v[3]), "v"(a.v[5]), "v"(b.v[2]), "v"(a.v[6]), "v"(b.v[1]), "v"(a.v[7]), "v"(b.v[0]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m6), "s"(n1), "v"(m5), "s"(n2), "v"(m4), "s"(n3), "v"(m3), "s"(n4));
+    // column 7: 8 + 4 products; first: - s_6 p_0 (the low limb of column 6 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_i64_i32 %0, %1, %20, %21, %0\n\tv_mad_i64_i32 %0, %1, %22, %23, %0\n\tv_mad_i64_i32 %0, %1, %24, %25, %0\n\tv_mad_i64_i32 %0, %1, %26, %27, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m6), "v"(col), "v"(a.v[0]), "v"(b.v[7]), "v"(a.v[1]), "v"(b.v[6]), "v"(a.v[2]), "v"(b.v[5]), "v"(a.v[3]), "v"(b.v[4]), "v"(a.v[4]), "v"(b.v[3]), "v"(a.v[5]), "v"(b.v[2]), "v"(a.v[6]), "v"(b.v[1]), "v"(a.v[7]), "v"(b.v[0]), "v"(m6), "s"(n1), "v"(m5), "s"(n2), "v"(m4), "s"(n3), "v"(m3), "s"(n4));
+    col = nc;
     m7 = (uint32_t)col;
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m7), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 8: 9 + 5 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[8]), "v"(a.v[1]), "v"(b.v[7]), "v"(a.v[2]), "v"(b.v[6]), "v"(a.v[3]), "v"(b.v[5]), "v"(a.v[4]), "v"(b.v[4]), "v"(a.v[5]), "v"(b.v[3]), "v"(a.v[6]), "v"(b.v[2]), "v"(a.v[7]), "v"(b.v[1]), "v"(a.v[8]), "v"(b.v[0]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0\n\tv_mad_i64_i32 %0, %1, %10, %11, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m7), "s"(n1), "v"(m6), "s"(n2), "v"(m5), "s"(n3), "v"(m4), "s"(n4), "v"(m0), "s"(n8));
+    // column 8: 9 + 5 products; first: - s_7 p_0 (the low limb of column 7 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_i64_i32 %0, %1, %22, %23, %0\n\tv_mad_i64_i32 %0, %1, %24, %25, %0\n\tv_mad_i64_i32 %0, %1, %26, %27, %0\n\tv_mad_i64_i32 %0, %1, %28, %29, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m7), "v"(col), "v"(a.v[0]), "v"(b.v[8]), "v"(a.v[1]), "v"(b.v[7]), "v"(a.v[2]), "v"(b.v[6]), "v"(a.v[3]), "v"(b.v[5]), "v"(a.v[4]), "v"(b.v[4]), "v"(a.v[5]), "v"(b.v[3]), "v"(a.v[6]), "v"(b.v[2]), "v"(a.v[7]), "v"(b.v[1]), "v"(a.v[8]), "v"(b.v[0]), "v"(m7), "s"(n1), "v"(m6), "s"(n2), "v"(m5), "s"(n3), "v"(m4), "s"(n4));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
+        : "+&v"(nc), "=&s"(cc) : "v"(m0), "s"(n8));
+    col = nc;
     m8 = ((uint32_t)col & M29) | 0xC0000000u;        // (col & M29) - 2^30: the one digit with a fixed sign
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m8), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 9: 8 + 5 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a.v[1]), "v"(b.v[8]), "v"(a.v[2]), "v"(b.v[7]), "v"(a.v[3]), "v"(b.v[6]), "v"(a.v[4]), "v"(b.v[5]), "v"(a.v[5]), "v"(b.v[4]), "v"(a.v[6]), "v"(b.v[3]), "v"(a.v[7]), "v"(b.v[2]), "v"(a.v[8]), "v"(b.v[1]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0\n\tv_mad_i64_i32 %0, %1, %10, %11, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n1), "v"(m7), "s"(n2), "v"(m6), "s"(n3), "v"(m5), "s"(n4), "v"(m1), "s"(n8));
+    // column 9: 8 + 5 products; first: - s_8 p_0 (the low limb of column 8 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_i64_i32 %0, %1, %20, %21, %0\n\tv_mad_i64_i32 %0, %1, %22, %23, %0\n\tv_mad_i64_i32 %0, %1, %24, %25, %0\n\tv_mad_i64_i32 %0, %1, %26, %27, %0\n\tv_mad_i64_i32 %0, %1, %28, %29, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m8), "v"(col), "v"(a.v[1]), "v"(b.v[8]), "v"(a.v[2]), "v"(b.v[7]), "v"(a.v[3]), "v"(b.v[6]), "v"(a.v[4]), "v"(b.v[5]), "v"(a.v[5]), "v"(b.v[4]), "v"(a.v[6]), "v"(b.v[3]), "v"(a.v[7]), "v"(b.v[2]), "v"(a.v[8]), "v"(b.v[1]), "v"(m8), "s"(n1), "v"(m7), "s"(n2), "v"(m6), "s"(n3), "v"(m5), "s"(n4), "v"(m1), "s"(n8));
+    col = nc;
     r.v[0] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
     // column 10: 7 + 4 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a.v[2]), "v"(b.v[8]), "v"(a.v[3]), "v"(b.v[7]), "v"(a.v[4]), "v"(b.v[6]), "v"(a.v[5]), "v"(b.v[5]), "v"(a.v[6]), "v"(b.v[4]), "v"(a.v[7]), "v"(b.v[3]), "v"(a.v[8]), "v"(b.v[2]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n2), "v"(m7), "s"(n3), "v"(m6), "s"(n4), "v"(m2), "s"(n8));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_i64_i32 %0, %1, %16, %17, %0\n\tv_mad_i64_i32 %0, %1, %18, %19, %0\n\tv_mad_i64_i32 %0, %1, %20, %21, %0\n\tv_mad_i64_i32 %0, %1, %22, %23, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[2]), "v"(b.v[8]), "v"(a.v[3]), "v"(b.v[7]), "v"(a.v[4]), "v"(b.v[6]), "v"(a.v[5]), "v"(b.v[5]), "v"(a.v[6]), "v"(b.v[4]), "v"(a.v[7]), "v"(b.v[3]), "v"(a.v[8]), "v"(b.v[2]), "v"(m8), "s"(n2), "v"(m7), "s"(n3), "v"(m6), "s"(n4), "v"(m2), "s"(n8));
     r.v[1] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
     // column 11: 6 + 3 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a.v[3]), "v"(b.v[8]), "v"(a.v[4]), "v"(b.v[7]), "v"(a.v[5]), "v"(b.v[6]), "v"(a.v[6]), "v"(b.v[5]), "v"(a.v[7]), "v"(b.v[4]), "v"(a.v[8]), "v"(b.v[3]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n3), "v"(m7), "s"(n4), "v"(m3), "s"(n8));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_i64_i32 %0, %1, %14, %15, %0\n\tv_mad_i64_i32 %0, %1, %16, %17, %0\n\tv_mad_i64_i32 %0, %1, %18, %19, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[3]), "v"(b.v[8]), "v"(a.v[4]), "v"(b.v[7]), "v"(a.v[5]), "v"(b.v[6]), "v"(a.v[6]), "v"(b.v[5]), "v"(a.v[7]), "v"(b.v[4]), "v"(a.v[8]), "v"(b.v[3]), "v"(m8), "s"(n3), "v"(m7), "s"(n4), "v"(m3), "s"(n8));
     r.v[2] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
     // column 12: 5 + 2 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a.v[4]), "v"(b.v[8]), "v"(a.v[5]), "v"(b.v[7]), "v"(a.v[6]), "v"(b.v[6]), "v"(a.v[7]), "v"(b.v[5]), "v"(a.v[8]), "v"(b.v[4]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n4), "v"(m4), "s"(n8));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_i64_i32 %0, %1, %12, %13, %0\n\tv_mad_i64_i32 %0, %1, %14, %15, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[4]), "v"(b.v[8]), "v"(a.v[5]), "v"(b.v[7]), "v"(a.v[6]), "v"(b.v[6]), "v"(a.v[7]), "v"(b.v[5]), "v"(a.v[8]), "v"(b.v[4]), "v"(m8), "s"(n4), "v"(m4), "s"(n8));
     r.v[3] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
     // column 13: 4 + 1 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a.v[5]), "v"(b.v[8]), "v"(a.v[6]), "v"(b.v[7]), "v"(a.v[7]), "v"(b.v[6]), "v"(a.v[8]), "v"(b.v[5]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m5), "s"(n8));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_i64_i32 %0, %1, %10, %11, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[5]), "v"(b.v[8]), "v"(a.v[6]), "v"(b.v[7]), "v"(a.v[7]), "v"(b.v[6]), "v"(a.v[8]), "v"(b.v[5]), "v"(m5), "s"(n8));
     r.v[4] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
     // column 14: 3 + 1 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a.v[6]), "v"(b.v[8]), "v"(a.v[7]), "v"(b.v[7]), "v"(a.v[8]), "v"(b.v[6]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m6), "s"(n8));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[6]), "v"(b.v[8]), "v"(a.v[7]), "v"(b.v[7]), "v"(a.v[8]), "v"(b.v[6]), "v"(m6), "s"(n8));
     r.v[5] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
     // column 15: 2 + 1 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a.v[7]), "v"(b.v[8]), "v"(a.v[8]), "v"(b.v[7]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m7), "s"(n8));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[7]), "v"(b.v[8]), "v"(a.v[8]), "v"(b.v[7]), "v"(m7), "s"(n8));
     r.v[6] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
     // column 16: 1 + 1 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a.v[8]), "v"(b.v[8]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n8));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[8]), "v"(b.v[8]), "v"(m8), "s"(n8));
     r.v[7] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
     r.v[8] = (uint32_t)col;
     return r;
@@ -1600,119 +1561,78 @@ template <int F> __device__ __forceinline__ fe29_t fe29_sqr_sg(const fe29_t &a) 
     asm("v_mad_u64_u32 %0, %1, %2, %3, 0"
         : "=&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(a.v[0]));
     m0 = (uint32_t)col;
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m0), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 1: 1 + 1 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(d0), "v"(a.v[1]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m0), "s"(n1));
+    // column 1: 1 + 1 products; first: - s_0 p_0 (the low limb of column 0 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m0), "v"(col), "v"(d0), "v"(a.v[1]), "v"(m0), "s"(n1));
+    col = nc;
     m1 = (uint32_t)col;
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m1), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 2: 2 + 2 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(d0), "v"(a.v[2]), "v"(a.v[1]), "v"(a.v[1]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m1), "s"(n1), "v"(m0), "s"(n2));
+    // column 2: 2 + 2 products; first: - s_1 p_0 (the low limb of column 1 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0\n\tv_mad_i64_i32 %0, %1, %10, %11, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m1), "v"(col), "v"(d0), "v"(a.v[2]), "v"(a.v[1]), "v"(a.v[1]), "v"(m1), "s"(n1), "v"(m0), "s"(n2));
+    col = nc;
     m2 = (uint32_t)col;
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m2), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 3: 2 + 3 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(d0), "v"(a.v[3]), "v"(d1), "v"(a.v[2]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m2), "s"(n1), "v"(m1), "s"(n2), "v"(m0), "s"(n3));
+    // column 3: 2 + 3 products; first: - s_2 p_0 (the low limb of column 2 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0\n\tv_mad_i64_i32 %0, %1, %10, %11, %0\n\tv_mad_i64_i32 %0, %1, %12, %13, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m2), "v"(col), "v"(d0), "v"(a.v[3]), "v"(d1), "v"(a.v[2]), "v"(m2), "s"(n1), "v"(m1), "s"(n2), "v"(m0), "s"(n3));
+    col = nc;
     m3 = (uint32_t)col;
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m3), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 4: 3 + 4 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(d0), "v"(a.v[4]), "v"(d1), "v"(a.v[3]), "v"(a.v[2]), "v"(a.v[2]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m3), "s"(n1), "v"(m2), "s"(n2), "v"(m1), "s"(n3), "v"(m0), "s"(n4));
+    // column 4: 3 + 4 products; first: - s_3 p_0 (the low limb of column 3 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_i64_i32 %0, %1, %10, %11, %0\n\tv_mad_i64_i32 %0, %1, %12, %13, %0\n\tv_mad_i64_i32 %0, %1, %14, %15, %0\n\tv_mad_i64_i32 %0, %1, %16, %17, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m3), "v"(col), "v"(d0), "v"(a.v[4]), "v"(d1), "v"(a.v[3]), "v"(a.v[2]), "v"(a.v[2]), "v"(m3), "s"(n1), "v"(m2), "s"(n2), "v"(m1), "s"(n3), "v"(m0), "s"(n4));
+    col = nc;
     m4 = (uint32_t)col;
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m4), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 5: 3 + 4 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(d0), "v"(a.v[5]), "v"(d1), "v"(a.v[4]), "v"(d2), "v"(a.v[3]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m4), "s"(n1), "v"(m3), "s"(n2), "v"(m2), "s"(n3), "v"(m1), "s"(n4));
+    // column 5: 3 + 4 products; first: - s_4 p_0 (the low limb of column 4 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_i64_i32 %0, %1, %10, %11, %0\n\tv_mad_i64_i32 %0, %1, %12, %13, %0\n\tv_mad_i64_i32 %0, %1, %14, %15, %0\n\tv_mad_i64_i32 %0, %1, %16, %17, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m4), "v"(col), "v"(d0), "v"(a.v[5]), "v"(d1), "v"(a.v[4]), "v"(d2), "v"(a.v[3]), "v"(m4), "s"(n1), "v"(m3), "s"(n2), "v"(m2), "s"(n3), "v"(m1), "s"(n4));
+    col = nc;
     m5 = (uint32_t)col;
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m5), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 6: 4 + 4 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(d0), "v"(a.v[6]), "v"(d1), "v"(a.v[5]), "v"(d2), "v"(a.v[4]), "v"(a.v[3]), "v"(a.v[3]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m5), "s"(n1), "v"(m4), "s"(n2), "v"(m3), "s"(n3), "v"(m2), "s"(n4));
+    // column 6: 4 + 4 products; first: - s_5 p_0 (the low limb of column 5 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_i64_i32 %0, %1, %12, %13, %0\n\tv_mad_i64_i32 %0, %1, %14, %15, %0\n\tv_mad_i64_i32 %0, %1, %16, %17, %0\n\tv_mad_i64_i32 %0, %1, %18, %19, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m5), "v"(col), "v"(d0), "v"(a.v[6]), "v"(d1), "v"(a.v[5]), "v"(d2), "v"(a.v[4]), "v"(a.v[3]), "v"(a.v[3]), "v"(m5), "s"(n1), "v"(m4), "s"(n2), "v"(m3), "s"(n3), "v"(m2), "s"(n4));
+    col = nc;
     m6 = (uint32_t)col;
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m6), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 7: 4 + 4 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(d0), "v"(a.v[7]), "v"(d1), "v"(a.v[6]), "v"(d2), "v"(a.v[5]), "v"(d3), "v"(a.v[4]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m6), "s"(n1), "v"(m5), "s"(n2), "v"(m4), "s"(n3), "v"(m3), "s"(n4));
+    // column 7: 4 + 4 products; first: - s_6 p_0 (the low limb of column 6 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_i64_i32 %0, %1, %12, %13, %0\n\tv_mad_i64_i32 %0, %1, %14, %15, %0\n\tv_mad_i64_i32 %0, %1, %16, %17, %0\n\tv_mad_i64_i32 %0, %1, %18, %19, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m6), "v"(col), "v"(d0), "v"(a.v[7]), "v"(d1), "v"(a.v[6]), "v"(d2), "v"(a.v[5]), "v"(d3), "v"(a.v[4]), "v"(m6), "s"(n1), "v"(m5), "s"(n2), "v"(m4), "s"(n3), "v"(m3), "s"(n4));
+    col = nc;
     m7 = (uint32_t)col;
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m7), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 8: 5 + 5 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(d0), "v"(a.v[8]), "v"(d1), "v"(a.v[7]), "v"(d2), "v"(a.v[6]), "v"(d3), "v"(a.v[5]), "v"(a.v[4]), "v"(a.v[4]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0\n\tv_mad_i64_i32 %0, %1, %10, %11, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m7), "s"(n1), "v"(m6), "s"(n2), "v"(m5), "s"(n3), "v"(m4), "s"(n4), "v"(m0), "s"(n8));
+    // column 8: 5 + 5 products; first: - s_7 p_0 (the low limb of column 7 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_i64_i32 %0, %1, %14, %15, %0\n\tv_mad_i64_i32 %0, %1, %16, %17, %0\n\tv_mad_i64_i32 %0, %1, %18, %19, %0\n\tv_mad_i64_i32 %0, %1, %20, %21, %0\n\tv_mad_i64_i32 %0, %1, %22, %23, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m7), "v"(col), "v"(d0), "v"(a.v[8]), "v"(d1), "v"(a.v[7]), "v"(d2), "v"(a.v[6]), "v"(d3), "v"(a.v[5]), "v"(a.v[4]), "v"(a.v[4]), "v"(m7), "s"(n1), "v"(m6), "s"(n2), "v"(m5), "s"(n3), "v"(m4), "s"(n4), "v"(m0), "s"(n8));
+    col = nc;
     m8 = ((uint32_t)col & M29) | 0xC0000000u;        // (col & M29) - 2^30: the one digit with a fixed sign
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m8), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 9: 4 + 5 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(d1), "v"(a.v[8]), "v"(d2), "v"(a.v[7]), "v"(d3), "v"(a.v[6]), "v"(d4), "v"(a.v[5]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0\n\tv_mad_i64_i32 %0, %1, %10, %11, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n1), "v"(m7), "s"(n2), "v"(m6), "s"(n3), "v"(m5), "s"(n4), "v"(m1), "s"(n8));
+    // column 9: 4 + 5 products; first: - s_8 p_0 (the low limb of column 8 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_i64_i32 %0, %1, %12, %13, %0\n\tv_mad_i64_i32 %0, %1, %14, %15, %0\n\tv_mad_i64_i32 %0, %1, %16, %17, %0\n\tv_mad_i64_i32 %0, %1, %18, %19, %0\n\tv_mad_i64_i32 %0, %1, %20, %21, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m8), "v"(col), "v"(d1), "v"(a.v[8]), "v"(d2), "v"(a.v[7]), "v"(d3), "v"(a.v[6]), "v"(d4), "v"(a.v[5]), "v"(m8), "s"(n1), "v"(m7), "s"(n2), "v"(m6), "s"(n3), "v"(m5), "s"(n4), "v"(m1), "s"(n8));
+    col = nc;
     r.v[0] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
     // column 10: 4 + 4 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(d2), "v"(a.v[8]), "v"(d3), "v"(a.v[7]), "v"(d4), "v"(a.v[6]), "v"(a.v[5]), "v"(a.v[5]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n2), "v"(m7), "s"(n3), "v"(m6), "s"(n4), "v"(m2), "s"(n8));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_i64_i32 %0, %1, %10, %11, %0\n\tv_mad_i64_i32 %0, %1, %12, %13, %0\n\tv_mad_i64_i32 %0, %1, %14, %15, %0\n\tv_mad_i64_i32 %0, %1, %16, %17, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d2), "v"(a.v[8]), "v"(d3), "v"(a.v[7]), "v"(d4), "v"(a.v[6]), "v"(a.v[5]), "v"(a.v[5]), "v"(m8), "s"(n2), "v"(m7), "s"(n3), "v"(m6), "s"(n4), "v"(m2), "s"(n8));
     r.v[1] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
     // column 11: 3 + 3 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(d3), "v"(a.v[8]), "v"(d4), "v"(a.v[7]), "v"(d5), "v"(a.v[6]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n3), "v"(m7), "s"(n4), "v"(m3), "s"(n8));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0\n\tv_mad_i64_i32 %0, %1, %10, %11, %0\n\tv_mad_i64_i32 %0, %1, %12, %13, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d3), "v"(a.v[8]), "v"(d4), "v"(a.v[7]), "v"(d5), "v"(a.v[6]), "v"(m8), "s"(n3), "v"(m7), "s"(n4), "v"(m3), "s"(n8));
     r.v[2] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
     // column 12: 3 + 2 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(d4), "v"(a.v[8]), "v"(d5), "v"(a.v[7]), "v"(a.v[6]), "v"(a.v[6]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n4), "v"(m4), "s"(n8));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0\n\tv_mad_i64_i32 %0, %1, %10, %11, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d4), "v"(a.v[8]), "v"(d5), "v"(a.v[7]), "v"(a.v[6]), "v"(a.v[6]), "v"(m8), "s"(n4), "v"(m4), "s"(n8));
     r.v[3] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
     // column 13: 2 + 1 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(d5), "v"(a.v[8]), "v"(d6), "v"(a.v[7]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m5), "s"(n8));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d5), "v"(a.v[8]), "v"(d6), "v"(a.v[7]), "v"(m5), "s"(n8));
     r.v[4] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
     // column 14: 2 + 1 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(d6), "v"(a.v[8]), "v"(a.v[7]), "v"(a.v[7]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m6), "s"(n8));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d6), "v"(a.v[8]), "v"(a.v[7]), "v"(a.v[7]), "v"(m6), "s"(n8));
     r.v[5] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
     // column 15: 1 + 1 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(d7), "v"(a.v[8]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m7), "s"(n8));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d7), "v"(a.v[8]), "v"(m7), "s"(n8));
     r.v[6] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
     // column 16: 1 + 1 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a.v[8]), "v"(a.v[8]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n8));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[8]), "v"(a.v[8]), "v"(m8), "s"(n8));
     r.v[7] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
     r.v[8] = (uint32_t)col;
     return r;
@@ -1725,119 +1645,82 @@ template <int F> __device__ __forceinline__ fe29_t fe29_mul_hi_sg(const fe29_t &
     asm("v_mad_u64_u32 %0, %1, %2, %3, 0"
         : "=&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[0]));
     m0 = (uint32_t)col;
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m0), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 1: 2 + 1 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[1]), "v"(a.v[1]), "v"(b.v[0]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m0), "s"(n1));
+    // column 1: 2 + 1 products; first: - s_0 p_0 (the low limb of column 0 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m0), "v"(col), "v"(a.v[0]), "v"(b.v[1]), "v"(a.v[1]), "v"(b.v[0]), "v"(m0), "s"(n1));
+    col = nc;
     m1 = (uint32_t)col;
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m1), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 2: 3 + 2 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[2]), "v"(a.v[1]), "v"(b.v[1]), "v"(a.v[2]), "v"(b.v[0]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m1), "s"(n1), "v"(m0), "s"(n2));
+    // column 2: 3 + 2 products; first: - s_1 p_0 (the low limb of column 1 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_i64_i32 %0, %1, %10, %11, %0\n\tv_mad_i64_i32 %0, %1, %12, %13, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m1), "v"(col), "v"(a.v[0]), "v"(b.v[2]), "v"(a.v[1]), "v"(b.v[1]), "v"(a.v[2]), "v"(b.v[0]), "v"(m1), "s"(n1), "v"(m0), "s"(n2));
+    col = nc;
     m2 = (uint32_t)col;
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m2), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 3: 4 + 3 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[3]), "v"(a.v[1]), "v"(b.v[2]), "v"(a.v[2]), "v"(b.v[1]), "v"(a.v[3]), "v"(b.v[0]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m2), "s"(n1), "v"(m1), "s"(n2), "v"(m0), "s"(n3));
+    // column 3: 4 + 3 products; first: - s_2 p_0 (the low limb of column 2 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_i64_i32 %0, %1, %12, %13, %0\n\tv_mad_i64_i32 %0, %1, %14, %15, %0\n\tv_mad_i64_i32 %0, %1, %16, %17, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m2), "v"(col), "v"(a.v[0]), "v"(b.v[3]), "v"(a.v[1]), "v"(b.v[2]), "v"(a.v[2]), "v"(b.v[1]), "v"(a.v[3]), "v"(b.v[0]), "v"(m2), "s"(n1), "v"(m1), "s"(n2), "v"(m0), "s"(n3));
+    col = nc;
     m3 = (uint32_t)col;
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m3), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 4: 5 + 4 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[4]), "v"(a.v[1]), "v"(b.v[3]), "v"(a.v[2]), "v"(b.v[2]), "v"(a.v[3]), "v"(b.v[1]), "v"(a.v[4]), "v"(b.v[0]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m3), "s"(n1), "v"(m2), "s"(n2), "v"(m1), "s"(n3), "v"(m0), "s"(n4));
+    // column 4: 5 + 4 products; first: - s_3 p_0 (the low limb of column 3 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_i64_i32 %0, %1, %14, %15, %0\n\tv_mad_i64_i32 %0, %1, %16, %17, %0\n\tv_mad_i64_i32 %0, %1, %18, %19, %0\n\tv_mad_i64_i32 %0, %1, %20, %21, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m3), "v"(col), "v"(a.v[0]), "v"(b.v[4]), "v"(a.v[1]), "v"(b.v[3]), "v"(a.v[2]), "v"(b.v[2]), "v"(a.v[3]), "v"(b.v[1]), "v"(a.v[4]), "v"(b.v[0]), "v"(m3), "s"(n1), "v"(m2), "s"(n2), "v"(m1), "s"(n3), "v"(m0), "s"(n4));
+    col = nc;
     m4 = (uint32_t)col;
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m4), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 5: 6 + 4 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[5]), "v"(a.v[1]), "v"(b.v[4]), "v"(a.v[2]), "v"(b.v[3]), "v"(a.v[3]), "v"(b.v[2]), "v"(a.v[4]), "v"(b.v[1]), "v"(a.v[5]), "v"(b.v[0]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m4), "s"(n1), "v"(m3), "s"(n2), "v"(m2), "s"(n3), "v"(m1), "s"(n4));
+    // column 5: 6 + 4 products; first: - s_4 p_0 (the low limb of column 4 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_i64_i32 %0, %1, %16, %17, %0\n\tv_mad_i64_i32 %0, %1, %18, %19, %0\n\tv_mad_i64_i32 %0, %1, %20, %21, %0\n\tv_mad_i64_i32 %0, %1, %22, %23, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m4), "v"(col), "v"(a.v[0]), "v"(b.v[5]), "v"(a.v[1]), "v"(b.v[4]), "v"(a.v[2]), "v"(b.v[3]), "v"(a.v[3]), "v"(b.v[2]), "v"(a.v[4]), "v"(b.v[1]), "v"(a.v[5]), "v"(b.v[0]), "v"(m4), "s"(n1), "v"(m3), "s"(n2), "v"(m2), "s"(n3), "v"(m1), "s"(n4));
+    col = nc;
     m5 = (uint32_t)col;
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m5), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 6: 7 + 4 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[6]), "v"(a.v[1]), "v"(b.v[5]), "v"(a.v[2]), "v"(b.v[4]), "v"(a.v[3]), "v"(b.v[3]), "v"(a.v[4]), "v"(b.v[2]), "v"(a.v[5]), "v"(b.v[1]), "v"(a.v[6]), "v"(b.v[0]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m5), "s"(n1), "v"(m4), "s"(n2), "v"(m3), "s"(n3), "v"(m2), "s"(n4));
+    // column 6: 7 + 4 products; first: - s_5 p_0 (the low limb of column 5 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_i64_i32 %0, %1, %18, %19, %0\n\tv_mad_i64_i32 %0, %1, %20, %21, %0\n\tv_mad_i64_i32 %0, %1, %22, %23, %0\n\tv_mad_i64_i32 %0, %1, %24, %25, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m5), "v"(col), "v"(a.v[0]), "v"(b.v[6]), "v"(a.v[1]), "v"(b.v[5]), "v"(a.v[2]), "v"(b.v[4]), "v"(a.v[3]), "v"(b.v[3]), "v"(a.v[4]), "v"(b.v[2]), "v"(a.v[5]), "v"(b.v[1]), "v"(a.v[6]), "v"(b.v[0]), "v"(m5), "s"(n1), "v"(m4), "s"(n2), "v"(m3), "s"(n3), "v"(m2), "s"(n4));
+    col = nc;
     m6 = (uint32_t)col;
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m6), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 7: 8 + 4 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[7]), "v"(a.v[1]), "v"(b.v[6]), "v"(a.v[2]), "v"(b.v[5]), "v"(a.v[3]), "v"(b.v[4]), "v"(a.v[4]), "v"(b.v[3]), "v"(a.v[5]), "v"(b.v[2]), "v"(a.v[6]), "v"(b.v[1]), "v"(a.v[7]), "v"(b.v[0]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m6), "s"(n1), "v"(m5), "s"(n2), "v"(m4), "s"(n3), "v"(m3), "s"(n4));
+    // column 7: 8 + 4 products; first: - s_6 p_0 (the low limb of column 6 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_i64_i32 %0, %1, %20, %21, %0\n\tv_mad_i64_i32 %0, %1, %22, %23, %0\n\tv_mad_i64_i32 %0, %1, %24, %25, %0\n\tv_mad_i64_i32 %0, %1, %26, %27, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m6), "v"(col), "v"(a.v[0]), "v"(b.v[7]), "v"(a.v[1]), "v"(b.v[6]), "v"(a.v[2]), "v"(b.v[5]), "v"(a.v[3]), "v"(b.v[4]), "v"(a.v[4]), "v"(b.v[3]), "v"(a.v[5]), "v"(b.v[2]), "v"(a.v[6]), "v"(b.v[1]), "v"(a.v[7]), "v"(b.v[0]), "v"(m6), "s"(n1), "v"(m5), "s"(n2), "v"(m4), "s"(n3), "v"(m3), "s"(n4));
+    col = nc;
     m7 = (uint32_t)col;
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m7), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 8: 9 + 5 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[8]), "v"(a.v[1]), "v"(b.v[7]), "v"(a.v[2]), "v"(b.v[6]), "v"(a.v[3]), "v"(b.v[5]), "v"(a.v[4]), "v"(b.v[4]), "v"(a.v[5]), "v"(b.v[3]), "v"(a.v[6]), "v"(b.v[2]), "v"(a.v[7]), "v"(b.v[1]), "v"(a.v[8]), "v"(b.v[0]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0\n\tv_mad_i64_i32 %0, %1, %10, %11, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m7), "s"(n1), "v"(m6), "s"(n2), "v"(m5), "s"(n3), "v"(m4), "s"(n4), "v"(m0), "s"(n8));
+    // column 8: 9 + 5 products; first: - s_7 p_0 (the low limb of column 7 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_i64_i32 %0, %1, %22, %23, %0\n\tv_mad_i64_i32 %0, %1, %24, %25, %0\n\tv_mad_i64_i32 %0, %1, %26, %27, %0\n\tv_mad_i64_i32 %0, %1, %28, %29, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m7), "v"(col), "v"(a.v[0]), "v"(b.v[8]), "v"(a.v[1]), "v"(b.v[7]), "v"(a.v[2]), "v"(b.v[6]), "v"(a.v[3]), "v"(b.v[5]), "v"(a.v[4]), "v"(b.v[4]), "v"(a.v[5]), "v"(b.v[3]), "v"(a.v[6]), "v"(b.v[2]), "v"(a.v[7]), "v"(b.v[1]), "v"(a.v[8]), "v"(b.v[0]), "v"(m7), "s"(n1), "v"(m6), "s"(n2), "v"(m5), "s"(n3), "v"(m4), "s"(n4));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
+        : "+&v"(nc), "=&s"(cc) : "v"(m0), "s"(n8));
+    col = nc;
     m8 = ((uint32_t)col & M29) | 0xC0000000u;        // (col & M29) - 2^30: the one digit with a fixed sign
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m8), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 9: 9 + 5 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, 1, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a.v[1]), "v"(b.v[8]), "v"(a.v[2]), "v"(b.v[7]), "v"(a.v[3]), "v"(b.v[6]), "v"(a.v[4]), "v"(b.v[5]), "v"(a.v[5]), "v"(b.v[4]), "v"(a.v[6]), "v"(b.v[3]), "v"(a.v[7]), "v"(b.v[2]), "v"(a.v[8]), "v"(b.v[1]), "v"(h.v[0]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0\n\tv_mad_i64_i32 %0, %1, %10, %11, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n1), "v"(m7), "s"(n2), "v"(m6), "s"(n3), "v"(m5), "s"(n4), "v"(m1), "s"(n8));
+    // column 9: 9 + 5 products; first: - s_8 p_0 (the low limb of column 8 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, 1, %0\n\tv_mad_i64_i32 %0, %1, %21, %22, %0\n\tv_mad_i64_i32 %0, %1, %23, %24, %0\n\tv_mad_i64_i32 %0, %1, %25, %26, %0\n\tv_mad_i64_i32 %0, %1, %27, %28, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m8), "v"(col), "v"(a.v[1]), "v"(b.v[8]), "v"(a.v[2]), "v"(b.v[7]), "v"(a.v[3]), "v"(b.v[6]), "v"(a.v[4]), "v"(b.v[5]), "v"(a.v[5]), "v"(b.v[4]), "v"(a.v[6]), "v"(b.v[3]), "v"(a.v[7]), "v"(b.v[2]), "v"(a.v[8]), "v"(b.v[1]), "v"(h.v[0]), "v"(m8), "s"(n1), "v"(m7), "s"(n2), "v"(m6), "s"(n3), "v"(m5), "s"(n4));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
+        : "+&v"(nc), "=&s"(cc) : "v"(m1), "s"(n8));
+    col = nc;
     r.v[0] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
     // column 10: 8 + 4 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, 1, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a.v[2]), "v"(b.v[8]), "v"(a.v[3]), "v"(b.v[7]), "v"(a.v[4]), "v"(b.v[6]), "v"(a.v[5]), "v"(b.v[5]), "v"(a.v[6]), "v"(b.v[4]), "v"(a.v[7]), "v"(b.v[3]), "v"(a.v[8]), "v"(b.v[2]), "v"(h.v[1]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n2), "v"(m7), "s"(n3), "v"(m6), "s"(n4), "v"(m2), "s"(n8));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, 1, %0\n\tv_mad_i64_i32 %0, %1, %17, %18, %0\n\tv_mad_i64_i32 %0, %1, %19, %20, %0\n\tv_mad_i64_i32 %0, %1, %21, %22, %0\n\tv_mad_i64_i32 %0, %1, %23, %24, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[2]), "v"(b.v[8]), "v"(a.v[3]), "v"(b.v[7]), "v"(a.v[4]), "v"(b.v[6]), "v"(a.v[5]), "v"(b.v[5]), "v"(a.v[6]), "v"(b.v[4]), "v"(a.v[7]), "v"(b.v[3]), "v"(a.v[8]), "v"(b.v[2]), "v"(h.v[1]), "v"(m8), "s"(n2), "v"(m7), "s"(n3), "v"(m6), "s"(n4), "v"(m2), "s"(n8));
     r.v[1] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
     // column 11: 7 + 3 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, 1, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a.v[3]), "v"(b.v[8]), "v"(a.v[4]), "v"(b.v[7]), "v"(a.v[5]), "v"(b.v[6]), "v"(a.v[6]), "v"(b.v[5]), "v"(a.v[7]), "v"(b.v[4]), "v"(a.v[8]), "v"(b.v[3]), "v"(h.v[2]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n3), "v"(m7), "s"(n4), "v"(m3), "s"(n8));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, 1, %0\n\tv_mad_i64_i32 %0, %1, %15, %16, %0\n\tv_mad_i64_i32 %0, %1, %17, %18, %0\n\tv_mad_i64_i32 %0, %1, %19, %20, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[3]), "v"(b.v[8]), "v"(a.v[4]), "v"(b.v[7]), "v"(a.v[5]), "v"(b.v[6]), "v"(a.v[6]), "v"(b.v[5]), "v"(a.v[7]), "v"(b.v[4]), "v"(a.v[8]), "v"(b.v[3]), "v"(h.v[2]), "v"(m8), "s"(n3), "v"(m7), "s"(n4), "v"(m3), "s"(n8));
     r.v[2] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
     // column 12: 6 + 2 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, 1, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a.v[4]), "v"(b.v[8]), "v"(a.v[5]), "v"(b.v[7]), "v"(a.v[6]), "v"(b.v[6]), "v"(a.v[7]), "v"(b.v[5]), "v"(a.v[8]), "v"(b.v[4]), "v"(h.v[3]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n4), "v"(m4), "s"(n8));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, 1, %0\n\tv_mad_i64_i32 %0, %1, %13, %14, %0\n\tv_mad_i64_i32 %0, %1, %15, %16, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[4]), "v"(b.v[8]), "v"(a.v[5]), "v"(b.v[7]), "v"(a.v[6]), "v"(b.v[6]), "v"(a.v[7]), "v"(b.v[5]), "v"(a.v[8]), "v"(b.v[4]), "v"(h.v[3]), "v"(m8), "s"(n4), "v"(m4), "s"(n8));
     r.v[3] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
     // column 13: 5 + 1 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, 1, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a.v[5]), "v"(b.v[8]), "v"(a.v[6]), "v"(b.v[7]), "v"(a.v[7]), "v"(b.v[6]), "v"(a.v[8]), "v"(b.v[5]), "v"(h.v[4]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m5), "s"(n8));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, 1, %0\n\tv_mad_i64_i32 %0, %1, %11, %12, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[5]), "v"(b.v[8]), "v"(a.v[6]), "v"(b.v[7]), "v"(a.v[7]), "v"(b.v[6]), "v"(a.v[8]), "v"(b.v[5]), "v"(h.v[4]), "v"(m5), "s"(n8));
     r.v[4] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
     // column 14: 4 + 1 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, 1, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a.v[6]), "v"(b.v[8]), "v"(a.v[7]), "v"(b.v[7]), "v"(a.v[8]), "v"(b.v[6]), "v"(h.v[5]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m6), "s"(n8));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, 1, %0\n\tv_mad_i64_i32 %0, %1, %9, %10, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[6]), "v"(b.v[8]), "v"(a.v[7]), "v"(b.v[7]), "v"(a.v[8]), "v"(b.v[6]), "v"(h.v[5]), "v"(m6), "s"(n8));
     r.v[5] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
     // column 15: 3 + 1 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, 1, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a.v[7]), "v"(b.v[8]), "v"(a.v[8]), "v"(b.v[7]), "v"(h.v[6]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m7), "s"(n8));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, 1, %0\n\tv_mad_i64_i32 %0, %1, %7, %8, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[7]), "v"(b.v[8]), "v"(a.v[8]), "v"(b.v[7]), "v"(h.v[6]), "v"(m7), "s"(n8));
     r.v[6] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
     // column 16: 2 + 1 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, 1, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a.v[8]), "v"(b.v[8]), "v"(h.v[7]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n8));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, 1, %0\n\tv_mad_i64_i32 %0, %1, %5, %6, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[8]), "v"(b.v[8]), "v"(h.v[7]), "v"(m8), "s"(n8));
     r.v[7] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
     r.v[8] = (uint32_t)col + h.v[8];
     return r;
@@ -1851,119 +1734,78 @@ template <int F> __device__ __forceinline__ fe29_t fe29_sqr_hi_sg(const fe29_t &
     asm("v_mad_u64_u32 %0, %1, %2, %3, 0"
         : "=&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(a.v[0]));
     m0 = (uint32_t)col;
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m0), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 1: 1 + 1 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(d0), "v"(a.v[1]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m0), "s"(n1));
+    // column 1: 1 + 1 products; first: - s_0 p_0 (the low limb of column 0 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m0), "v"(col), "v"(d0), "v"(a.v[1]), "v"(m0), "s"(n1));
+    col = nc;
     m1 = (uint32_t)col;
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m1), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 2: 2 + 2 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(d0), "v"(a.v[2]), "v"(a.v[1]), "v"(a.v[1]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m1), "s"(n1), "v"(m0), "s"(n2));
+    // column 2: 2 + 2 products; first: - s_1 p_0 (the low limb of column 1 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0\n\tv_mad_i64_i32 %0, %1, %10, %11, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m1), "v"(col), "v"(d0), "v"(a.v[2]), "v"(a.v[1]), "v"(a.v[1]), "v"(m1), "s"(n1), "v"(m0), "s"(n2));
+    col = nc;
     m2 = (uint32_t)col;
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m2), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 3: 2 + 3 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(d0), "v"(a.v[3]), "v"(d1), "v"(a.v[2]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m2), "s"(n1), "v"(m1), "s"(n2), "v"(m0), "s"(n3));
+    // column 3: 2 + 3 products; first: - s_2 p_0 (the low limb of column 2 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0\n\tv_mad_i64_i32 %0, %1, %10, %11, %0\n\tv_mad_i64_i32 %0, %1, %12, %13, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m2), "v"(col), "v"(d0), "v"(a.v[3]), "v"(d1), "v"(a.v[2]), "v"(m2), "s"(n1), "v"(m1), "s"(n2), "v"(m0), "s"(n3));
+    col = nc;
     m3 = (uint32_t)col;
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m3), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 4: 3 + 4 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(d0), "v"(a.v[4]), "v"(d1), "v"(a.v[3]), "v"(a.v[2]), "v"(a.v[2]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m3), "s"(n1), "v"(m2), "s"(n2), "v"(m1), "s"(n3), "v"(m0), "s"(n4));
+    // column 4: 3 + 4 products; first: - s_3 p_0 (the low limb of column 3 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_i64_i32 %0, %1, %10, %11, %0\n\tv_mad_i64_i32 %0, %1, %12, %13, %0\n\tv_mad_i64_i32 %0, %1, %14, %15, %0\n\tv_mad_i64_i32 %0, %1, %16, %17, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m3), "v"(col), "v"(d0), "v"(a.v[4]), "v"(d1), "v"(a.v[3]), "v"(a.v[2]), "v"(a.v[2]), "v"(m3), "s"(n1), "v"(m2), "s"(n2), "v"(m1), "s"(n3), "v"(m0), "s"(n4));
+    col = nc;
     m4 = (uint32_t)col;
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m4), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 5: 3 + 4 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(d0), "v"(a.v[5]), "v"(d1), "v"(a.v[4]), "v"(d2), "v"(a.v[3]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m4), "s"(n1), "v"(m3), "s"(n2), "v"(m2), "s"(n3), "v"(m1), "s"(n4));
+    // column 5: 3 + 4 products; first: - s_4 p_0 (the low limb of column 4 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_i64_i32 %0, %1, %10, %11, %0\n\tv_mad_i64_i32 %0, %1, %12, %13, %0\n\tv_mad_i64_i32 %0, %1, %14, %15, %0\n\tv_mad_i64_i32 %0, %1, %16, %17, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m4), "v"(col), "v"(d0), "v"(a.v[5]), "v"(d1), "v"(a.v[4]), "v"(d2), "v"(a.v[3]), "v"(m4), "s"(n1), "v"(m3), "s"(n2), "v"(m2), "s"(n3), "v"(m1), "s"(n4));
+    col = nc;
     m5 = (uint32_t)col;
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m5), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 6: 4 + 4 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(d0), "v"(a.v[6]), "v"(d1), "v"(a.v[5]), "v"(d2), "v"(a.v[4]), "v"(a.v[3]), "v"(a.v[3]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m5), "s"(n1), "v"(m4), "s"(n2), "v"(m3), "s"(n3), "v"(m2), "s"(n4));
+    // column 6: 4 + 4 products; first: - s_5 p_0 (the low limb of column 5 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_i64_i32 %0, %1, %12, %13, %0\n\tv_mad_i64_i32 %0, %1, %14, %15, %0\n\tv_mad_i64_i32 %0, %1, %16, %17, %0\n\tv_mad_i64_i32 %0, %1, %18, %19, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m5), "v"(col), "v"(d0), "v"(a.v[6]), "v"(d1), "v"(a.v[5]), "v"(d2), "v"(a.v[4]), "v"(a.v[3]), "v"(a.v[3]), "v"(m5), "s"(n1), "v"(m4), "s"(n2), "v"(m3), "s"(n3), "v"(m2), "s"(n4));
+    col = nc;
     m6 = (uint32_t)col;
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m6), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 7: 4 + 4 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(d0), "v"(a.v[7]), "v"(d1), "v"(a.v[6]), "v"(d2), "v"(a.v[5]), "v"(d3), "v"(a.v[4]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m6), "s"(n1), "v"(m5), "s"(n2), "v"(m4), "s"(n3), "v"(m3), "s"(n4));
+    // column 7: 4 + 4 products; first: - s_6 p_0 (the low limb of column 6 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_i64_i32 %0, %1, %12, %13, %0\n\tv_mad_i64_i32 %0, %1, %14, %15, %0\n\tv_mad_i64_i32 %0, %1, %16, %17, %0\n\tv_mad_i64_i32 %0, %1, %18, %19, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m6), "v"(col), "v"(d0), "v"(a.v[7]), "v"(d1), "v"(a.v[6]), "v"(d2), "v"(a.v[5]), "v"(d3), "v"(a.v[4]), "v"(m6), "s"(n1), "v"(m5), "s"(n2), "v"(m4), "s"(n3), "v"(m3), "s"(n4));
+    col = nc;
     m7 = (uint32_t)col;
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m7), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 8: 5 + 5 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(d0), "v"(a.v[8]), "v"(d1), "v"(a.v[7]), "v"(d2), "v"(a.v[6]), "v"(d3), "v"(a.v[5]), "v"(a.v[4]), "v"(a.v[4]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0\n\tv_mad_i64_i32 %0, %1, %10, %11, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m7), "s"(n1), "v"(m6), "s"(n2), "v"(m5), "s"(n3), "v"(m4), "s"(n4), "v"(m0), "s"(n8));
+    // column 8: 5 + 5 products; first: - s_7 p_0 (the low limb of column 7 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_i64_i32 %0, %1, %14, %15, %0\n\tv_mad_i64_i32 %0, %1, %16, %17, %0\n\tv_mad_i64_i32 %0, %1, %18, %19, %0\n\tv_mad_i64_i32 %0, %1, %20, %21, %0\n\tv_mad_i64_i32 %0, %1, %22, %23, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m7), "v"(col), "v"(d0), "v"(a.v[8]), "v"(d1), "v"(a.v[7]), "v"(d2), "v"(a.v[6]), "v"(d3), "v"(a.v[5]), "v"(a.v[4]), "v"(a.v[4]), "v"(m7), "s"(n1), "v"(m6), "s"(n2), "v"(m5), "s"(n3), "v"(m4), "s"(n4), "v"(m0), "s"(n8));
+    col = nc;
     m8 = ((uint32_t)col & M29) | 0xC0000000u;        // (col & M29) - 2^30: the one digit with a fixed sign
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m8), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 9: 5 + 5 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, 1, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(d1), "v"(a.v[8]), "v"(d2), "v"(a.v[7]), "v"(d3), "v"(a.v[6]), "v"(d4), "v"(a.v[5]), "v"(h.v[0]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0\n\tv_mad_i64_i32 %0, %1, %10, %11, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n1), "v"(m7), "s"(n2), "v"(m6), "s"(n3), "v"(m5), "s"(n4), "v"(m1), "s"(n8));
+    // column 9: 5 + 5 products; first: - s_8 p_0 (the low limb of column 8 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, 1, %0\n\tv_mad_i64_i32 %0, %1, %13, %14, %0\n\tv_mad_i64_i32 %0, %1, %15, %16, %0\n\tv_mad_i64_i32 %0, %1, %17, %18, %0\n\tv_mad_i64_i32 %0, %1, %19, %20, %0\n\tv_mad_i64_i32 %0, %1, %21, %22, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m8), "v"(col), "v"(d1), "v"(a.v[8]), "v"(d2), "v"(a.v[7]), "v"(d3), "v"(a.v[6]), "v"(d4), "v"(a.v[5]), "v"(h.v[0]), "v"(m8), "s"(n1), "v"(m7), "s"(n2), "v"(m6), "s"(n3), "v"(m5), "s"(n4), "v"(m1), "s"(n8));
+    col = nc;
     r.v[0] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
     // column 10: 5 + 4 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, 1, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(d2), "v"(a.v[8]), "v"(d3), "v"(a.v[7]), "v"(d4), "v"(a.v[6]), "v"(a.v[5]), "v"(a.v[5]), "v"(h.v[1]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n2), "v"(m7), "s"(n3), "v"(m6), "s"(n4), "v"(m2), "s"(n8));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, 1, %0\n\tv_mad_i64_i32 %0, %1, %11, %12, %0\n\tv_mad_i64_i32 %0, %1, %13, %14, %0\n\tv_mad_i64_i32 %0, %1, %15, %16, %0\n\tv_mad_i64_i32 %0, %1, %17, %18, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d2), "v"(a.v[8]), "v"(d3), "v"(a.v[7]), "v"(d4), "v"(a.v[6]), "v"(a.v[5]), "v"(a.v[5]), "v"(h.v[1]), "v"(m8), "s"(n2), "v"(m7), "s"(n3), "v"(m6), "s"(n4), "v"(m2), "s"(n8));
     r.v[1] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
     // column 11: 4 + 3 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, 1, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(d3), "v"(a.v[8]), "v"(d4), "v"(a.v[7]), "v"(d5), "v"(a.v[6]), "v"(h.v[2]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n3), "v"(m7), "s"(n4), "v"(m3), "s"(n8));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, 1, %0\n\tv_mad_i64_i32 %0, %1, %9, %10, %0\n\tv_mad_i64_i32 %0, %1, %11, %12, %0\n\tv_mad_i64_i32 %0, %1, %13, %14, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d3), "v"(a.v[8]), "v"(d4), "v"(a.v[7]), "v"(d5), "v"(a.v[6]), "v"(h.v[2]), "v"(m8), "s"(n3), "v"(m7), "s"(n4), "v"(m3), "s"(n8));
     r.v[2] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
     // column 12: 4 + 2 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, 1, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(d4), "v"(a.v[8]), "v"(d5), "v"(a.v[7]), "v"(a.v[6]), "v"(a.v[6]), "v"(h.v[3]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n4), "v"(m4), "s"(n8));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, 1, %0\n\tv_mad_i64_i32 %0, %1, %9, %10, %0\n\tv_mad_i64_i32 %0, %1, %11, %12, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d4), "v"(a.v[8]), "v"(d5), "v"(a.v[7]), "v"(a.v[6]), "v"(a.v[6]), "v"(h.v[3]), "v"(m8), "s"(n4), "v"(m4), "s"(n8));
     r.v[3] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
     // column 13: 3 + 1 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, 1, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(d5), "v"(a.v[8]), "v"(d6), "v"(a.v[7]), "v"(h.v[4]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m5), "s"(n8));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, 1, %0\n\tv_mad_i64_i32 %0, %1, %7, %8, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d5), "v"(a.v[8]), "v"(d6), "v"(a.v[7]), "v"(h.v[4]), "v"(m5), "s"(n8));
     r.v[4] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
     // column 14: 3 + 1 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, 1, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(d6), "v"(a.v[8]), "v"(a.v[7]), "v"(a.v[7]), "v"(h.v[5]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m6), "s"(n8));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, 1, %0\n\tv_mad_i64_i32 %0, %1, %7, %8, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d6), "v"(a.v[8]), "v"(a.v[7]), "v"(a.v[7]), "v"(h.v[5]), "v"(m6), "s"(n8));
     r.v[5] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
     // column 15: 2 + 1 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, 1, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(d7), "v"(a.v[8]), "v"(h.v[6]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m7), "s"(n8));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, 1, %0\n\tv_mad_i64_i32 %0, %1, %5, %6, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(d7), "v"(a.v[8]), "v"(h.v[6]), "v"(m7), "s"(n8));
     r.v[6] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
     // column 16: 2 + 1 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, 1, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a.v[8]), "v"(a.v[8]), "v"(h.v[7]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n8));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, 1, %0\n\tv_mad_i64_i32 %0, %1, %5, %6, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[8]), "v"(a.v[8]), "v"(h.v[7]), "v"(m8), "s"(n8));
     r.v[7] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
     r.v[8] = (uint32_t)col + h.v[8];
     return r;
@@ -1976,119 +1818,80 @@ template <int F> __device__ __forceinline__ fe29_t fe29_mulrc_sg(const fe29_t &a
     asm("v_mad_u64_u32 %0, %1, %2, %3, 0\n\tv_mad_u64_u32 %0, %1, %4, 1, %0"
         : "=&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[0]), "v"(c.v[0]));
     m0 = (uint32_t)col;
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m0), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 1: 3 + 1 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, 1, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[1]), "v"(a.v[1]), "v"(b.v[0]), "v"(c.v[1]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m0), "s"(n1));
+    // column 1: 3 + 1 products; first: - s_0 p_0 (the low limb of column 0 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, 1, %0\n\tv_mad_i64_i32 %0, %1, %9, %10, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m0), "v"(col), "v"(a.v[0]), "v"(b.v[1]), "v"(a.v[1]), "v"(b.v[0]), "v"(c.v[1]), "v"(m0), "s"(n1));
+    col = nc;
     m1 = (uint32_t)col;
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m1), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 2: 4 + 2 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, 1, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[2]), "v"(a.v[1]), "v"(b.v[1]), "v"(a.v[2]), "v"(b.v[0]), "v"(c.v[2]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m1), "s"(n1), "v"(m0), "s"(n2));
+    // column 2: 4 + 2 products; first: - s_1 p_0 (the low limb of column 1 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, 1, %0\n\tv_mad_i64_i32 %0, %1, %11, %12, %0\n\tv_mad_i64_i32 %0, %1, %13, %14, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m1), "v"(col), "v"(a.v[0]), "v"(b.v[2]), "v"(a.v[1]), "v"(b.v[1]), "v"(a.v[2]), "v"(b.v[0]), "v"(c.v[2]), "v"(m1), "s"(n1), "v"(m0), "s"(n2));
+    col = nc;
     m2 = (uint32_t)col;
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m2), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 3: 5 + 3 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, 1, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[3]), "v"(a.v[1]), "v"(b.v[2]), "v"(a.v[2]), "v"(b.v[1]), "v"(a.v[3]), "v"(b.v[0]), "v"(c.v[3]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m2), "s"(n1), "v"(m1), "s"(n2), "v"(m0), "s"(n3));
+    // column 3: 5 + 3 products; first: - s_2 p_0 (the low limb of column 2 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, 1, %0\n\tv_mad_i64_i32 %0, %1, %13, %14, %0\n\tv_mad_i64_i32 %0, %1, %15, %16, %0\n\tv_mad_i64_i32 %0, %1, %17, %18, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m2), "v"(col), "v"(a.v[0]), "v"(b.v[3]), "v"(a.v[1]), "v"(b.v[2]), "v"(a.v[2]), "v"(b.v[1]), "v"(a.v[3]), "v"(b.v[0]), "v"(c.v[3]), "v"(m2), "s"(n1), "v"(m1), "s"(n2), "v"(m0), "s"(n3));
+    col = nc;
     m3 = (uint32_t)col;
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m3), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 4: 6 + 4 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, 1, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[4]), "v"(a.v[1]), "v"(b.v[3]), "v"(a.v[2]), "v"(b.v[2]), "v"(a.v[3]), "v"(b.v[1]), "v"(a.v[4]), "v"(b.v[0]), "v"(c.v[4]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m3), "s"(n1), "v"(m2), "s"(n2), "v"(m1), "s"(n3), "v"(m0), "s"(n4));
+    // column 4: 6 + 4 products; first: - s_3 p_0 (the low limb of column 3 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, 1, %0\n\tv_mad_i64_i32 %0, %1, %15, %16, %0\n\tv_mad_i64_i32 %0, %1, %17, %18, %0\n\tv_mad_i64_i32 %0, %1, %19, %20, %0\n\tv_mad_i64_i32 %0, %1, %21, %22, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m3), "v"(col), "v"(a.v[0]), "v"(b.v[4]), "v"(a.v[1]), "v"(b.v[3]), "v"(a.v[2]), "v"(b.v[2]), "v"(a.v[3]), "v"(b.v[1]), "v"(a.v[4]), "v"(b.v[0]), "v"(c.v[4]), "v"(m3), "s"(n1), "v"(m2), "s"(n2), "v"(m1), "s"(n3), "v"(m0), "s"(n4));
+    col = nc;
     m4 = (uint32_t)col;
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m4), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 5: 7 + 4 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, 1, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[5]), "v"(a.v[1]), "v"(b.v[4]), "v"(a.v[2]), "v"(b.v[3]), "v"(a.v[3]), "v"(b.v[2]), "v"(a.v[4]), "v"(b.v[1]), "v"(a.v[5]), "v"(b.v[0]), "v"(c.v[5]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m4), "s"(n1), "v"(m3), "s"(n2), "v"(m2), "s"(n3), "v"(m1), "s"(n4));
+    // column 5: 7 + 4 products; first: - s_4 p_0 (the low limb of column 4 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, 1, %0\n\tv_mad_i64_i32 %0, %1, %17, %18, %0\n\tv_mad_i64_i32 %0, %1, %19, %20, %0\n\tv_mad_i64_i32 %0, %1, %21, %22, %0\n\tv_mad_i64_i32 %0, %1, %23, %24, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m4), "v"(col), "v"(a.v[0]), "v"(b.v[5]), "v"(a.v[1]), "v"(b.v[4]), "v"(a.v[2]), "v"(b.v[3]), "v"(a.v[3]), "v"(b.v[2]), "v"(a.v[4]), "v"(b.v[1]), "v"(a.v[5]), "v"(b.v[0]), "v"(c.v[5]), "v"(m4), "s"(n1), "v"(m3), "s"(n2), "v"(m2), "s"(n3), "v"(m1), "s"(n4));
+    col = nc;
     m5 = (uint32_t)col;
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m5), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 6: 8 + 4 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, 1, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[6]), "v"(a.v[1]), "v"(b.v[5]), "v"(a.v[2]), "v"(b.v[4]), "v"(a.v[3]), "v"(b.v[3]), "v"(a.v[4]), "v"(b.v[2]), "v"(a.v[5]), "v"(b.v[1]), "v"(a.v[6]), "v"(b.v[0]), "v"(c.v[6]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m5), "s"(n1), "v"(m4), "s"(n2), "v"(m3), "s"(n3), "v"(m2), "s"(n4));
+    // column 6: 8 + 4 products; first: - s_5 p_0 (the low limb of column 5 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, 1, %0\n\tv_mad_i64_i32 %0, %1, %19, %20, %0\n\tv_mad_i64_i32 %0, %1, %21, %22, %0\n\tv_mad_i64_i32 %0, %1, %23, %24, %0\n\tv_mad_i64_i32 %0, %1, %25, %26, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m5), "v"(col), "v"(a.v[0]), "v"(b.v[6]), "v"(a.v[1]), "v"(b.v[5]), "v"(a.v[2]), "v"(b.v[4]), "v"(a.v[3]), "v"(b.v[3]), "v"(a.v[4]), "v"(b.v[2]), "v"(a.v[5]), "v"(b.v[1]), "v"(a.v[6]), "v"(b.v[0]), "v"(c.v[6]), "v"(m5), "s"(n1), "v"(m4), "s"(n2), "v"(m3), "s"(n3), "v"(m2), "s"(n4));
+    col = nc;
     m6 = (uint32_t)col;
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m6), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 7: 9 + 4 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, 1, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[7]), "v"(a.v[1]), "v"(b.v[6]), "v"(a.v[2]), "v"(b.v[5]), "v"(a.v[3]), "v"(b.v[4]), "v"(a.v[4]), "v"(b.v[3]), "v"(a.v[5]), "v"(b.v[2]), "v"(a.v[6]), "v"(b.v[1]), "v"(a.v[7]), "v"(b.v[0]), "v"(c.v[7]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m6), "s"(n1), "v"(m5), "s"(n2), "v"(m4), "s"(n3), "v"(m3), "s"(n4));
+    // column 7: 9 + 4 products; first: - s_6 p_0 (the low limb of column 6 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, 1, %0\n\tv_mad_i64_i32 %0, %1, %21, %22, %0\n\tv_mad_i64_i32 %0, %1, %23, %24, %0\n\tv_mad_i64_i32 %0, %1, %25, %26, %0\n\tv_mad_i64_i32 %0, %1, %27, %28, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m6), "v"(col), "v"(a.v[0]), "v"(b.v[7]), "v"(a.v[1]), "v"(b.v[6]), "v"(a.v[2]), "v"(b.v[5]), "v"(a.v[3]), "v"(b.v[4]), "v"(a.v[4]), "v"(b.v[3]), "v"(a.v[5]), "v"(b.v[2]), "v"(a.v[6]), "v"(b.v[1]), "v"(a.v[7]), "v"(b.v[0]), "v"(c.v[7]), "v"(m6), "s"(n1), "v"(m5), "s"(n2), "v"(m4), "s"(n3), "v"(m3), "s"(n4));
+    col = nc;
     m7 = (uint32_t)col;
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m7), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 8: 10 + 5 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, 1, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a.v[0]), "v"(b.v[8]), "v"(a.v[1]), "v"(b.v[7]), "v"(a.v[2]), "v"(b.v[6]), "v"(a.v[3]), "v"(b.v[5]), "v"(a.v[4]), "v"(b.v[4]), "v"(a.v[5]), "v"(b.v[3]), "v"(a.v[6]), "v"(b.v[2]), "v"(a.v[7]), "v"(b.v[1]), "v"(a.v[8]), "v"(b.v[0]), "v"(c.v[8]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0\n\tv_mad_i64_i32 %0, %1, %10, %11, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m7), "s"(n1), "v"(m6), "s"(n2), "v"(m5), "s"(n3), "v"(m4), "s"(n4), "v"(m0), "s"(n8));
+    // column 8: 10 + 5 products; first: - s_7 p_0 (the low limb of column 7 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, 1, %0\n\tv_mad_i64_i32 %0, %1, %23, %24, %0\n\tv_mad_i64_i32 %0, %1, %25, %26, %0\n\tv_mad_i64_i32 %0, %1, %27, %28, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m7), "v"(col), "v"(a.v[0]), "v"(b.v[8]), "v"(a.v[1]), "v"(b.v[7]), "v"(a.v[2]), "v"(b.v[6]), "v"(a.v[3]), "v"(b.v[5]), "v"(a.v[4]), "v"(b.v[4]), "v"(a.v[5]), "v"(b.v[3]), "v"(a.v[6]), "v"(b.v[2]), "v"(a.v[7]), "v"(b.v[1]), "v"(a.v[8]), "v"(b.v[0]), "v"(c.v[8]), "v"(m7), "s"(n1), "v"(m6), "s"(n2), "v"(m5), "s"(n3));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0"
+        : "+&v"(nc), "=&s"(cc) : "v"(m4), "s"(n4), "v"(m0), "s"(n8));
+    col = nc;
     m8 = ((uint32_t)col & M29) | 0xC0000000u;        // (col & M29) - 2^30: the one digit with a fixed sign
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m8), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 9: 8 + 5 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a.v[1]), "v"(b.v[8]), "v"(a.v[2]), "v"(b.v[7]), "v"(a.v[3]), "v"(b.v[6]), "v"(a.v[4]), "v"(b.v[5]), "v"(a.v[5]), "v"(b.v[4]), "v"(a.v[6]), "v"(b.v[3]), "v"(a.v[7]), "v"(b.v[2]), "v"(a.v[8]), "v"(b.v[1]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0\n\tv_mad_i64_i32 %0, %1, %10, %11, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n1), "v"(m7), "s"(n2), "v"(m6), "s"(n3), "v"(m5), "s"(n4), "v"(m1), "s"(n8));
+    // column 9: 8 + 5 products; first: - s_8 p_0 (the low limb of column 8 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_i64_i32 %0, %1, %20, %21, %0\n\tv_mad_i64_i32 %0, %1, %22, %23, %0\n\tv_mad_i64_i32 %0, %1, %24, %25, %0\n\tv_mad_i64_i32 %0, %1, %26, %27, %0\n\tv_mad_i64_i32 %0, %1, %28, %29, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m8), "v"(col), "v"(a.v[1]), "v"(b.v[8]), "v"(a.v[2]), "v"(b.v[7]), "v"(a.v[3]), "v"(b.v[6]), "v"(a.v[4]), "v"(b.v[5]), "v"(a.v[5]), "v"(b.v[4]), "v"(a.v[6]), "v"(b.v[3]), "v"(a.v[7]), "v"(b.v[2]), "v"(a.v[8]), "v"(b.v[1]), "v"(m8), "s"(n1), "v"(m7), "s"(n2), "v"(m6), "s"(n3), "v"(m5), "s"(n4), "v"(m1), "s"(n8));
+    col = nc;
     r.v[0] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
     // column 10: 7 + 4 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a.v[2]), "v"(b.v[8]), "v"(a.v[3]), "v"(b.v[7]), "v"(a.v[4]), "v"(b.v[6]), "v"(a.v[5]), "v"(b.v[5]), "v"(a.v[6]), "v"(b.v[4]), "v"(a.v[7]), "v"(b.v[3]), "v"(a.v[8]), "v"(b.v[2]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n2), "v"(m7), "s"(n3), "v"(m6), "s"(n4), "v"(m2), "s"(n8));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_i64_i32 %0, %1, %16, %17, %0\n\tv_mad_i64_i32 %0, %1, %18, %19, %0\n\tv_mad_i64_i32 %0, %1, %20, %21, %0\n\tv_mad_i64_i32 %0, %1, %22, %23, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[2]), "v"(b.v[8]), "v"(a.v[3]), "v"(b.v[7]), "v"(a.v[4]), "v"(b.v[6]), "v"(a.v[5]), "v"(b.v[5]), "v"(a.v[6]), "v"(b.v[4]), "v"(a.v[7]), "v"(b.v[3]), "v"(a.v[8]), "v"(b.v[2]), "v"(m8), "s"(n2), "v"(m7), "s"(n3), "v"(m6), "s"(n4), "v"(m2), "s"(n8));
     r.v[1] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
     // column 11: 6 + 3 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a.v[3]), "v"(b.v[8]), "v"(a.v[4]), "v"(b.v[7]), "v"(a.v[5]), "v"(b.v[6]), "v"(a.v[6]), "v"(b.v[5]), "v"(a.v[7]), "v"(b.v[4]), "v"(a.v[8]), "v"(b.v[3]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n3), "v"(m7), "s"(n4), "v"(m3), "s"(n8));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_i64_i32 %0, %1, %14, %15, %0\n\tv_mad_i64_i32 %0, %1, %16, %17, %0\n\tv_mad_i64_i32 %0, %1, %18, %19, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[3]), "v"(b.v[8]), "v"(a.v[4]), "v"(b.v[7]), "v"(a.v[5]), "v"(b.v[6]), "v"(a.v[6]), "v"(b.v[5]), "v"(a.v[7]), "v"(b.v[4]), "v"(a.v[8]), "v"(b.v[3]), "v"(m8), "s"(n3), "v"(m7), "s"(n4), "v"(m3), "s"(n8));
     r.v[2] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
     // column 12: 5 + 2 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a.v[4]), "v"(b.v[8]), "v"(a.v[5]), "v"(b.v[7]), "v"(a.v[6]), "v"(b.v[6]), "v"(a.v[7]), "v"(b.v[5]), "v"(a.v[8]), "v"(b.v[4]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n4), "v"(m4), "s"(n8));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_i64_i32 %0, %1, %12, %13, %0\n\tv_mad_i64_i32 %0, %1, %14, %15, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[4]), "v"(b.v[8]), "v"(a.v[5]), "v"(b.v[7]), "v"(a.v[6]), "v"(b.v[6]), "v"(a.v[7]), "v"(b.v[5]), "v"(a.v[8]), "v"(b.v[4]), "v"(m8), "s"(n4), "v"(m4), "s"(n8));
     r.v[3] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
     // column 13: 4 + 1 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a.v[5]), "v"(b.v[8]), "v"(a.v[6]), "v"(b.v[7]), "v"(a.v[7]), "v"(b.v[6]), "v"(a.v[8]), "v"(b.v[5]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m5), "s"(n8));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_i64_i32 %0, %1, %10, %11, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[5]), "v"(b.v[8]), "v"(a.v[6]), "v"(b.v[7]), "v"(a.v[7]), "v"(b.v[6]), "v"(a.v[8]), "v"(b.v[5]), "v"(m5), "s"(n8));
     r.v[4] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
     // column 14: 3 + 1 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a.v[6]), "v"(b.v[8]), "v"(a.v[7]), "v"(b.v[7]), "v"(a.v[8]), "v"(b.v[6]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m6), "s"(n8));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[6]), "v"(b.v[8]), "v"(a.v[7]), "v"(b.v[7]), "v"(a.v[8]), "v"(b.v[6]), "v"(m6), "s"(n8));
     r.v[5] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
     // column 15: 2 + 1 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a.v[7]), "v"(b.v[8]), "v"(a.v[8]), "v"(b.v[7]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m7), "s"(n8));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[7]), "v"(b.v[8]), "v"(a.v[8]), "v"(b.v[7]), "v"(m7), "s"(n8));
     r.v[6] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
     // column 16: 1 + 1 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a.v[8]), "v"(b.v[8]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n8));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a.v[8]), "v"(b.v[8]), "v"(m8), "s"(n8));
     r.v[7] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
     r.v[8] = (uint32_t)col;
     return r;
@@ -2101,131 +1904,94 @@ template <int F> __device__ __forceinline__ fe29_t fe29_dot2rc_sg(const fe29_t &
     asm("v_mad_u64_u32 %0, %1, %2, %3, 0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, 1, %0"
         : "=&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[0]), "v"(c.v[0]));
     m0 = (uint32_t)col;
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m0), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 1: 5 + 1 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, 1, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[1]), "v"(a0.v[1]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[1]), "v"(a1.v[1]), "v"(b1.v[0]), "v"(c.v[1]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m0), "s"(n1));
+    // column 1: 5 + 1 products; first: - s_0 p_0 (the low limb of column 0 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, 1, %0\n\tv_mad_i64_i32 %0, %1, %13, %14, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m0), "v"(col), "v"(a0.v[0]), "v"(b0.v[1]), "v"(a0.v[1]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[1]), "v"(a1.v[1]), "v"(b1.v[0]), "v"(c.v[1]), "v"(m0), "s"(n1));
+    col = nc;
     m1 = (uint32_t)col;
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m1), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 2: 7 + 2 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, 1, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[2]), "v"(a0.v[1]), "v"(b0.v[1]), "v"(a0.v[2]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[2]), "v"(a1.v[1]), "v"(b1.v[1]), "v"(a1.v[2]), "v"(b1.v[0]), "v"(c.v[2]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m1), "s"(n1), "v"(m0), "s"(n2));
+    // column 2: 7 + 2 products; first: - s_1 p_0 (the low limb of column 1 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, 1, %0\n\tv_mad_i64_i32 %0, %1, %17, %18, %0\n\tv_mad_i64_i32 %0, %1, %19, %20, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m1), "v"(col), "v"(a0.v[0]), "v"(b0.v[2]), "v"(a0.v[1]), "v"(b0.v[1]), "v"(a0.v[2]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[2]), "v"(a1.v[1]), "v"(b1.v[1]), "v"(a1.v[2]), "v"(b1.v[0]), "v"(c.v[2]), "v"(m1), "s"(n1), "v"(m0), "s"(n2));
+    col = nc;
     m2 = (uint32_t)col;
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m2), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 3: 9 + 3 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, 1, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[3]), "v"(a0.v[1]), "v"(b0.v[2]), "v"(a0.v[2]), "v"(b0.v[1]), "v"(a0.v[3]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[3]), "v"(a1.v[1]), "v"(b1.v[2]), "v"(a1.v[2]), "v"(b1.v[1]), "v"(a1.v[3]), "v"(b1.v[0]), "v"(c.v[3]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m2), "s"(n1), "v"(m1), "s"(n2), "v"(m0), "s"(n3));
+    // column 3: 9 + 3 products; first: - s_2 p_0 (the low limb of column 2 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, 1, %0\n\tv_mad_i64_i32 %0, %1, %21, %22, %0\n\tv_mad_i64_i32 %0, %1, %23, %24, %0\n\tv_mad_i64_i32 %0, %1, %25, %26, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m2), "v"(col), "v"(a0.v[0]), "v"(b0.v[3]), "v"(a0.v[1]), "v"(b0.v[2]), "v"(a0.v[2]), "v"(b0.v[1]), "v"(a0.v[3]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[3]), "v"(a1.v[1]), "v"(b1.v[2]), "v"(a1.v[2]), "v"(b1.v[1]), "v"(a1.v[3]), "v"(b1.v[0]), "v"(c.v[3]), "v"(m2), "s"(n1), "v"(m1), "s"(n2), "v"(m0), "s"(n3));
+    col = nc;
     m3 = (uint32_t)col;
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m3), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 4: 11 + 4 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, 1, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[4]), "v"(a0.v[1]), "v"(b0.v[3]), "v"(a0.v[2]), "v"(b0.v[2]), "v"(a0.v[3]), "v"(b0.v[1]), "v"(a0.v[4]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[4]), "v"(a1.v[1]), "v"(b1.v[3]), "v"(a1.v[2]), "v"(b1.v[2]), "v"(a1.v[3]), "v"(b1.v[1]), "v"(a1.v[4]), "v"(b1.v[0]), "v"(c.v[4]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m3), "s"(n1), "v"(m2), "s"(n2), "v"(m1), "s"(n3), "v"(m0), "s"(n4));
+    // column 4: 11 + 4 products; first: - s_3 p_0 (the low limb of column 3 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, 1, %0\n\tv_mad_i64_i32 %0, %1, %25, %26, %0\n\tv_mad_i64_i32 %0, %1, %27, %28, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m3), "v"(col), "v"(a0.v[0]), "v"(b0.v[4]), "v"(a0.v[1]), "v"(b0.v[3]), "v"(a0.v[2]), "v"(b0.v[2]), "v"(a0.v[3]), "v"(b0.v[1]), "v"(a0.v[4]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[4]), "v"(a1.v[1]), "v"(b1.v[3]), "v"(a1.v[2]), "v"(b1.v[2]), "v"(a1.v[3]), "v"(b1.v[1]), "v"(a1.v[4]), "v"(b1.v[0]), "v"(c.v[4]), "v"(m3), "s"(n1), "v"(m2), "s"(n2));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0"
+        : "+&v"(nc), "=&s"(cc) : "v"(m1), "s"(n3), "v"(m0), "s"(n4));
+    col = nc;
     m4 = (uint32_t)col;
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m4), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 5: 13 + 4 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[5]), "v"(a0.v[1]), "v"(b0.v[4]), "v"(a0.v[2]), "v"(b0.v[3]), "v"(a0.v[3]), "v"(b0.v[2]), "v"(a0.v[4]), "v"(b0.v[1]), "v"(a0.v[5]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[5]), "v"(a1.v[1]), "v"(b1.v[4]), "v"(a1.v[2]), "v"(b1.v[3]), "v"(a1.v[3]), "v"(b1.v[2]), "v"(a1.v[4]), "v"(b1.v[1]), "v"(a1.v[5]), "v"(b1.v[0]));
-    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(c.v[5]));
+    // column 5: 13 + 4 products; first: - s_4 p_0 (the low limb of column 4 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0\n\tv_mad_u64_u32 %0, %1, %26, %27, %0\n\tv_mad_u64_u32 %0, %1, %28, 1, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m4), "v"(col), "v"(a0.v[0]), "v"(b0.v[5]), "v"(a0.v[1]), "v"(b0.v[4]), "v"(a0.v[2]), "v"(b0.v[3]), "v"(a0.v[3]), "v"(b0.v[2]), "v"(a0.v[4]), "v"(b0.v[1]), "v"(a0.v[5]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[5]), "v"(a1.v[1]), "v"(b1.v[4]), "v"(a1.v[2]), "v"(b1.v[3]), "v"(a1.v[3]), "v"(b1.v[2]), "v"(a1.v[4]), "v"(b1.v[1]), "v"(a1.v[5]), "v"(b1.v[0]), "v"(c.v[5]));
     asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m4), "s"(n1), "v"(m3), "s"(n2), "v"(m2), "s"(n3), "v"(m1), "s"(n4));
+        : "+&v"(nc), "=&s"(cc) : "v"(m4), "s"(n1), "v"(m3), "s"(n2), "v"(m2), "s"(n3), "v"(m1), "s"(n4));
+    col = nc;
     m5 = (uint32_t)col;
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m5), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 6: 15 + 4 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[6]), "v"(a0.v[1]), "v"(b0.v[5]), "v"(a0.v[2]), "v"(b0.v[4]), "v"(a0.v[3]), "v"(b0.v[3]), "v"(a0.v[4]), "v"(b0.v[2]), "v"(a0.v[5]), "v"(b0.v[1]), "v"(a0.v[6]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[6]), "v"(a1.v[1]), "v"(b1.v[5]), "v"(a1.v[2]), "v"(b1.v[4]), "v"(a1.v[3]), "v"(b1.v[3]), "v"(a1.v[4]), "v"(b1.v[2]));
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, 1, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a1.v[5]), "v"(b1.v[1]), "v"(a1.v[6]), "v"(b1.v[0]), "v"(c.v[6]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m5), "s"(n1), "v"(m4), "s"(n2), "v"(m3), "s"(n3), "v"(m2), "s"(n4));
+    // column 6: 15 + 4 products; first: - s_5 p_0 (the low limb of column 5 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0\n\tv_mad_u64_u32 %0, %1, %26, %27, %0\n\tv_mad_u64_u32 %0, %1, %28, %29, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m5), "v"(col), "v"(a0.v[0]), "v"(b0.v[6]), "v"(a0.v[1]), "v"(b0.v[5]), "v"(a0.v[2]), "v"(b0.v[4]), "v"(a0.v[3]), "v"(b0.v[3]), "v"(a0.v[4]), "v"(b0.v[2]), "v"(a0.v[5]), "v"(b0.v[1]), "v"(a0.v[6]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[6]), "v"(a1.v[1]), "v"(b1.v[5]), "v"(a1.v[2]), "v"(b1.v[4]), "v"(a1.v[3]), "v"(b1.v[3]), "v"(a1.v[4]), "v"(b1.v[2]), "v"(a1.v[5]), "v"(b1.v[1]));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, 1, %0\n\tv_mad_i64_i32 %0, %1, %5, %6, %0\n\tv_mad_i64_i32 %0, %1, %7, %8, %0\n\tv_mad_i64_i32 %0, %1, %9, %10, %0\n\tv_mad_i64_i32 %0, %1, %11, %12, %0"
+        : "+&v"(nc), "=&s"(cc) : "v"(a1.v[6]), "v"(b1.v[0]), "v"(c.v[6]), "v"(m5), "s"(n1), "v"(m4), "s"(n2), "v"(m3), "s"(n3), "v"(m2), "s"(n4));
+    col = nc;
     m6 = (uint32_t)col;
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m6), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 7: 17 + 4 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[7]), "v"(a0.v[1]), "v"(b0.v[6]), "v"(a0.v[2]), "v"(b0.v[5]), "v"(a0.v[3]), "v"(b0.v[4]), "v"(a0.v[4]), "v"(b0.v[3]), "v"(a0.v[5]), "v"(b0.v[2]), "v"(a0.v[6]), "v"(b0.v[1]), "v"(a0.v[7]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[7]), "v"(a1.v[1]), "v"(b1.v[6]), "v"(a1.v[2]), "v"(b1.v[5]), "v"(a1.v[3]), "v"(b1.v[4]));
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, 1, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a1.v[4]), "v"(b1.v[3]), "v"(a1.v[5]), "v"(b1.v[2]), "v"(a1.v[6]), "v"(b1.v[1]), "v"(a1.v[7]), "v"(b1.v[0]), "v"(c.v[7]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m6), "s"(n1), "v"(m5), "s"(n2), "v"(m4), "s"(n3), "v"(m3), "s"(n4));
+    // column 7: 17 + 4 products; first: - s_6 p_0 (the low limb of column 6 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0\n\tv_mad_u64_u32 %0, %1, %26, %27, %0\n\tv_mad_u64_u32 %0, %1, %28, %29, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m6), "v"(col), "v"(a0.v[0]), "v"(b0.v[7]), "v"(a0.v[1]), "v"(b0.v[6]), "v"(a0.v[2]), "v"(b0.v[5]), "v"(a0.v[3]), "v"(b0.v[4]), "v"(a0.v[4]), "v"(b0.v[3]), "v"(a0.v[5]), "v"(b0.v[2]), "v"(a0.v[6]), "v"(b0.v[1]), "v"(a0.v[7]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[7]), "v"(a1.v[1]), "v"(b1.v[6]), "v"(a1.v[2]), "v"(b1.v[5]), "v"(a1.v[3]), "v"(b1.v[4]), "v"(a1.v[4]), "v"(b1.v[3]));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, 1, %0\n\tv_mad_i64_i32 %0, %1, %9, %10, %0\n\tv_mad_i64_i32 %0, %1, %11, %12, %0\n\tv_mad_i64_i32 %0, %1, %13, %14, %0\n\tv_mad_i64_i32 %0, %1, %15, %16, %0"
+        : "+&v"(nc), "=&s"(cc) : "v"(a1.v[5]), "v"(b1.v[2]), "v"(a1.v[6]), "v"(b1.v[1]), "v"(a1.v[7]), "v"(b1.v[0]), "v"(c.v[7]), "v"(m6), "s"(n1), "v"(m5), "s"(n2), "v"(m4), "s"(n3), "v"(m3), "s"(n4));
+    col = nc;
     m7 = (uint32_t)col;
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m7), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 8: 19 + 5 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[8]), "v"(a0.v[1]), "v"(b0.v[7]), "v"(a0.v[2]), "v"(b0.v[6]), "v"(a0.v[3]), "v"(b0.v[5]), "v"(a0.v[4]), "v"(b0.v[4]), "v"(a0.v[5]), "v"(b0.v[3]), "v"(a0.v[6]), "v"(b0.v[2]), "v"(a0.v[7]), "v"(b0.v[1]), "v"(a0.v[8]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[8]), "v"(a1.v[1]), "v"(b1.v[7]), "v"(a1.v[2]), "v"(b1.v[6]));
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, 1, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a1.v[3]), "v"(b1.v[5]), "v"(a1.v[4]), "v"(b1.v[4]), "v"(a1.v[5]), "v"(b1.v[3]), "v"(a1.v[6]), "v"(b1.v[2]), "v"(a1.v[7]), "v"(b1.v[1]), "v"(a1.v[8]), "v"(b1.v[0]), "v"(c.v[8]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0\n\tv_mad_i64_i32 %0, %1, %10, %11, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m7), "s"(n1), "v"(m6), "s"(n2), "v"(m5), "s"(n3), "v"(m4), "s"(n4), "v"(m0), "s"(n8));
+    // column 8: 19 + 5 products; first: - s_7 p_0 (the low limb of column 7 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0\n\tv_mad_u64_u32 %0, %1, %26, %27, %0\n\tv_mad_u64_u32 %0, %1, %28, %29, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m7), "v"(col), "v"(a0.v[0]), "v"(b0.v[8]), "v"(a0.v[1]), "v"(b0.v[7]), "v"(a0.v[2]), "v"(b0.v[6]), "v"(a0.v[3]), "v"(b0.v[5]), "v"(a0.v[4]), "v"(b0.v[4]), "v"(a0.v[5]), "v"(b0.v[3]), "v"(a0.v[6]), "v"(b0.v[2]), "v"(a0.v[7]), "v"(b0.v[1]), "v"(a0.v[8]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[8]), "v"(a1.v[1]), "v"(b1.v[7]), "v"(a1.v[2]), "v"(b1.v[6]), "v"(a1.v[3]), "v"(b1.v[5]));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, 1, %0\n\tv_mad_i64_i32 %0, %1, %13, %14, %0\n\tv_mad_i64_i32 %0, %1, %15, %16, %0\n\tv_mad_i64_i32 %0, %1, %17, %18, %0\n\tv_mad_i64_i32 %0, %1, %19, %20, %0\n\tv_mad_i64_i32 %0, %1, %21, %22, %0"
+        : "+&v"(nc), "=&s"(cc) : "v"(a1.v[4]), "v"(b1.v[4]), "v"(a1.v[5]), "v"(b1.v[3]), "v"(a1.v[6]), "v"(b1.v[2]), "v"(a1.v[7]), "v"(b1.v[1]), "v"(a1.v[8]), "v"(b1.v[0]), "v"(c.v[8]), "v"(m7), "s"(n1), "v"(m6), "s"(n2), "v"(m5), "s"(n3), "v"(m4), "s"(n4), "v"(m0), "s"(n8));
+    col = nc;
     m8 = ((uint32_t)col & M29) | 0xC0000000u;        // (col & M29) - 2^30: the one digit with a fixed sign
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m8), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 9: 16 + 5 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a0.v[1]), "v"(b0.v[8]), "v"(a0.v[2]), "v"(b0.v[7]), "v"(a0.v[3]), "v"(b0.v[6]), "v"(a0.v[4]), "v"(b0.v[5]), "v"(a0.v[5]), "v"(b0.v[4]), "v"(a0.v[6]), "v"(b0.v[3]), "v"(a0.v[7]), "v"(b0.v[2]), "v"(a0.v[8]), "v"(b0.v[1]), "v"(a1.v[1]), "v"(b1.v[8]), "v"(a1.v[2]), "v"(b1.v[7]), "v"(a1.v[3]), "v"(b1.v[6]), "v"(a1.v[4]), "v"(b1.v[5]));
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a1.v[5]), "v"(b1.v[4]), "v"(a1.v[6]), "v"(b1.v[3]), "v"(a1.v[7]), "v"(b1.v[2]), "v"(a1.v[8]), "v"(b1.v[1]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0\n\tv_mad_i64_i32 %0, %1, %10, %11, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n1), "v"(m7), "s"(n2), "v"(m6), "s"(n3), "v"(m5), "s"(n4), "v"(m1), "s"(n8));
+    // column 9: 16 + 5 products; first: - s_8 p_0 (the low limb of column 8 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0\n\tv_mad_u64_u32 %0, %1, %26, %27, %0\n\tv_mad_u64_u32 %0, %1, %28, %29, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m8), "v"(col), "v"(a0.v[1]), "v"(b0.v[8]), "v"(a0.v[2]), "v"(b0.v[7]), "v"(a0.v[3]), "v"(b0.v[6]), "v"(a0.v[4]), "v"(b0.v[5]), "v"(a0.v[5]), "v"(b0.v[4]), "v"(a0.v[6]), "v"(b0.v[3]), "v"(a0.v[7]), "v"(b0.v[2]), "v"(a0.v[8]), "v"(b0.v[1]), "v"(a1.v[1]), "v"(b1.v[8]), "v"(a1.v[2]), "v"(b1.v[7]), "v"(a1.v[3]), "v"(b1.v[6]), "v"(a1.v[4]), "v"(b1.v[5]), "v"(a1.v[5]), "v"(b1.v[4]));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0\n\tv_mad_i64_i32 %0, %1, %10, %11, %0\n\tv_mad_i64_i32 %0, %1, %12, %13, %0\n\tv_mad_i64_i32 %0, %1, %14, %15, %0\n\tv_mad_i64_i32 %0, %1, %16, %17, %0"
+        : "+&v"(nc), "=&s"(cc) : "v"(a1.v[6]), "v"(b1.v[3]), "v"(a1.v[7]), "v"(b1.v[2]), "v"(a1.v[8]), "v"(b1.v[1]), "v"(m8), "s"(n1), "v"(m7), "s"(n2), "v"(m6), "s"(n3), "v"(m5), "s"(n4), "v"(m1), "s"(n8));
+    col = nc;
     r.v[0] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
     // column 10: 14 + 4 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a0.v[2]), "v"(b0.v[8]), "v"(a0.v[3]), "v"(b0.v[7]), "v"(a0.v[4]), "v"(b0.v[6]), "v"(a0.v[5]), "v"(b0.v[5]), "v"(a0.v[6]), "v"(b0.v[4]), "v"(a0.v[7]), "v"(b0.v[3]), "v"(a0.v[8]), "v"(b0.v[2]), "v"(a1.v[2]), "v"(b1.v[8]), "v"(a1.v[3]), "v"(b1.v[7]), "v"(a1.v[4]), "v"(b1.v[6]), "v"(a1.v[5]), "v"(b1.v[5]), "v"(a1.v[6]), "v"(b1.v[4]));
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a1.v[7]), "v"(b1.v[3]), "v"(a1.v[8]), "v"(b1.v[2]));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0\n\tv_mad_u64_u32 %0, %1, %26, %27, %0\n\tv_mad_u64_u32 %0, %1, %28, %29, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[2]), "v"(b0.v[8]), "v"(a0.v[3]), "v"(b0.v[7]), "v"(a0.v[4]), "v"(b0.v[6]), "v"(a0.v[5]), "v"(b0.v[5]), "v"(a0.v[6]), "v"(b0.v[4]), "v"(a0.v[7]), "v"(b0.v[3]), "v"(a0.v[8]), "v"(b0.v[2]), "v"(a1.v[2]), "v"(b1.v[8]), "v"(a1.v[3]), "v"(b1.v[7]), "v"(a1.v[4]), "v"(b1.v[6]), "v"(a1.v[5]), "v"(b1.v[5]), "v"(a1.v[6]), "v"(b1.v[4]), "v"(a1.v[7]), "v"(b1.v[3]), "v"(a1.v[8]), "v"(b1.v[2]));
     asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
         : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n2), "v"(m7), "s"(n3), "v"(m6), "s"(n4), "v"(m2), "s"(n8));
     r.v[1] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
     // column 11: 12 + 3 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a0.v[3]), "v"(b0.v[8]), "v"(a0.v[4]), "v"(b0.v[7]), "v"(a0.v[5]), "v"(b0.v[6]), "v"(a0.v[6]), "v"(b0.v[5]), "v"(a0.v[7]), "v"(b0.v[4]), "v"(a0.v[8]), "v"(b0.v[3]), "v"(a1.v[3]), "v"(b1.v[8]), "v"(a1.v[4]), "v"(b1.v[7]), "v"(a1.v[5]), "v"(b1.v[6]), "v"(a1.v[6]), "v"(b1.v[5]), "v"(a1.v[7]), "v"(b1.v[4]), "v"(a1.v[8]), "v"(b1.v[3]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n3), "v"(m7), "s"(n4), "v"(m3), "s"(n8));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0\n\tv_mad_i64_i32 %0, %1, %26, %27, %0\n\tv_mad_i64_i32 %0, %1, %28, %29, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[3]), "v"(b0.v[8]), "v"(a0.v[4]), "v"(b0.v[7]), "v"(a0.v[5]), "v"(b0.v[6]), "v"(a0.v[6]), "v"(b0.v[5]), "v"(a0.v[7]), "v"(b0.v[4]), "v"(a0.v[8]), "v"(b0.v[3]), "v"(a1.v[3]), "v"(b1.v[8]), "v"(a1.v[4]), "v"(b1.v[7]), "v"(a1.v[5]), "v"(b1.v[6]), "v"(a1.v[6]), "v"(b1.v[5]), "v"(a1.v[7]), "v"(b1.v[4]), "v"(a1.v[8]), "v"(b1.v[3]), "v"(m8), "s"(n3), "v"(m7), "s"(n4));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(m3), "s"(n8));
     r.v[2] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
     // column 12: 10 + 2 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a0.v[4]), "v"(b0.v[8]), "v"(a0.v[5]), "v"(b0.v[7]), "v"(a0.v[6]), "v"(b0.v[6]), "v"(a0.v[7]), "v"(b0.v[5]), "v"(a0.v[8]), "v"(b0.v[4]), "v"(a1.v[4]), "v"(b1.v[8]), "v"(a1.v[5]), "v"(b1.v[7]), "v"(a1.v[6]), "v"(b1.v[6]), "v"(a1.v[7]), "v"(b1.v[5]), "v"(a1.v[8]), "v"(b1.v[4]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n4), "v"(m4), "s"(n8));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_i64_i32 %0, %1, %22, %23, %0\n\tv_mad_i64_i32 %0, %1, %24, %25, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[4]), "v"(b0.v[8]), "v"(a0.v[5]), "v"(b0.v[7]), "v"(a0.v[6]), "v"(b0.v[6]), "v"(a0.v[7]), "v"(b0.v[5]), "v"(a0.v[8]), "v"(b0.v[4]), "v"(a1.v[4]), "v"(b1.v[8]), "v"(a1.v[5]), "v"(b1.v[7]), "v"(a1.v[6]), "v"(b1.v[6]), "v"(a1.v[7]), "v"(b1.v[5]), "v"(a1.v[8]), "v"(b1.v[4]), "v"(m8), "s"(n4), "v"(m4), "s"(n8));
     r.v[3] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
     // column 13: 8 + 1 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a0.v[5]), "v"(b0.v[8]), "v"(a0.v[6]), "v"(b0.v[7]), "v"(a0.v[7]), "v"(b0.v[6]), "v"(a0.v[8]), "v"(b0.v[5]), "v"(a1.v[5]), "v"(b1.v[8]), "v"(a1.v[6]), "v"(b1.v[7]), "v"(a1.v[7]), "v"(b1.v[6]), "v"(a1.v[8]), "v"(b1.v[5]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m5), "s"(n8));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_i64_i32 %0, %1, %18, %19, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[5]), "v"(b0.v[8]), "v"(a0.v[6]), "v"(b0.v[7]), "v"(a0.v[7]), "v"(b0.v[6]), "v"(a0.v[8]), "v"(b0.v[5]), "v"(a1.v[5]), "v"(b1.v[8]), "v"(a1.v[6]), "v"(b1.v[7]), "v"(a1.v[7]), "v"(b1.v[6]), "v"(a1.v[8]), "v"(b1.v[5]), "v"(m5), "s"(n8));
     r.v[4] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
     // column 14: 6 + 1 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a0.v[6]), "v"(b0.v[8]), "v"(a0.v[7]), "v"(b0.v[7]), "v"(a0.v[8]), "v"(b0.v[6]), "v"(a1.v[6]), "v"(b1.v[8]), "v"(a1.v[7]), "v"(b1.v[7]), "v"(a1.v[8]), "v"(b1.v[6]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m6), "s"(n8));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_i64_i32 %0, %1, %14, %15, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[6]), "v"(b0.v[8]), "v"(a0.v[7]), "v"(b0.v[7]), "v"(a0.v[8]), "v"(b0.v[6]), "v"(a1.v[6]), "v"(b1.v[8]), "v"(a1.v[7]), "v"(b1.v[7]), "v"(a1.v[8]), "v"(b1.v[6]), "v"(m6), "s"(n8));
     r.v[5] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
     // column 15: 4 + 1 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a0.v[7]), "v"(b0.v[8]), "v"(a0.v[8]), "v"(b0.v[7]), "v"(a1.v[7]), "v"(b1.v[8]), "v"(a1.v[8]), "v"(b1.v[7]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m7), "s"(n8));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_i64_i32 %0, %1, %10, %11, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[7]), "v"(b0.v[8]), "v"(a0.v[8]), "v"(b0.v[7]), "v"(a1.v[7]), "v"(b1.v[8]), "v"(a1.v[8]), "v"(b1.v[7]), "v"(m7), "s"(n8));
     r.v[6] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
     // column 16: 2 + 1 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a0.v[8]), "v"(b0.v[8]), "v"(a1.v[8]), "v"(b1.v[8]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n8));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[8]), "v"(b0.v[8]), "v"(a1.v[8]), "v"(b1.v[8]), "v"(m8), "s"(n8));
     r.v[7] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
     r.v[8] = (uint32_t)col;
     return r;
@@ -2238,143 +2004,104 @@ template <int F> __device__ __forceinline__ fe29_t fe29_dot3rc_sg(const fe29_t &
     asm("v_mad_u64_u32 %0, %1, %2, %3, 0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, 1, %0"
         : "=&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[0]), "v"(a2.v[0]), "v"(b2.v[0]), "v"(c.v[0]));
     m0 = (uint32_t)col;
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m0), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 1: 7 + 1 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, 1, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[1]), "v"(a0.v[1]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[1]), "v"(a1.v[1]), "v"(b1.v[0]), "v"(a2.v[0]), "v"(b2.v[1]), "v"(a2.v[1]), "v"(b2.v[0]), "v"(c.v[1]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m0), "s"(n1));
+    // column 1: 7 + 1 products; first: - s_0 p_0 (the low limb of column 0 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, 1, %0\n\tv_mad_i64_i32 %0, %1, %17, %18, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m0), "v"(col), "v"(a0.v[0]), "v"(b0.v[1]), "v"(a0.v[1]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[1]), "v"(a1.v[1]), "v"(b1.v[0]), "v"(a2.v[0]), "v"(b2.v[1]), "v"(a2.v[1]), "v"(b2.v[0]), "v"(c.v[1]), "v"(m0), "s"(n1));
+    col = nc;
     m1 = (uint32_t)col;
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m1), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 2: 10 + 2 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, 1, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[2]), "v"(a0.v[1]), "v"(b0.v[1]), "v"(a0.v[2]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[2]), "v"(a1.v[1]), "v"(b1.v[1]), "v"(a1.v[2]), "v"(b1.v[0]), "v"(a2.v[0]), "v"(b2.v[2]), "v"(a2.v[1]), "v"(b2.v[1]), "v"(a2.v[2]), "v"(b2.v[0]), "v"(c.v[2]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m1), "s"(n1), "v"(m0), "s"(n2));
+    // column 2: 10 + 2 products; first: - s_1 p_0 (the low limb of column 1 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, 1, %0\n\tv_mad_i64_i32 %0, %1, %23, %24, %0\n\tv_mad_i64_i32 %0, %1, %25, %26, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m1), "v"(col), "v"(a0.v[0]), "v"(b0.v[2]), "v"(a0.v[1]), "v"(b0.v[1]), "v"(a0.v[2]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[2]), "v"(a1.v[1]), "v"(b1.v[1]), "v"(a1.v[2]), "v"(b1.v[0]), "v"(a2.v[0]), "v"(b2.v[2]), "v"(a2.v[1]), "v"(b2.v[1]), "v"(a2.v[2]), "v"(b2.v[0]), "v"(c.v[2]), "v"(m1), "s"(n1), "v"(m0), "s"(n2));
+    col = nc;
     m2 = (uint32_t)col;
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m2), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 3: 13 + 3 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[3]), "v"(a0.v[1]), "v"(b0.v[2]), "v"(a0.v[2]), "v"(b0.v[1]), "v"(a0.v[3]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[3]), "v"(a1.v[1]), "v"(b1.v[2]), "v"(a1.v[2]), "v"(b1.v[1]), "v"(a1.v[3]), "v"(b1.v[0]), "v"(a2.v[0]), "v"(b2.v[3]), "v"(a2.v[1]), "v"(b2.v[2]), "v"(a2.v[2]), "v"(b2.v[1]), "v"(a2.v[3]), "v"(b2.v[0]));
-    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(c.v[3]));
+    // column 3: 13 + 3 products; first: - s_2 p_0 (the low limb of column 2 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0\n\tv_mad_u64_u32 %0, %1, %26, %27, %0\n\tv_mad_u64_u32 %0, %1, %28, 1, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m2), "v"(col), "v"(a0.v[0]), "v"(b0.v[3]), "v"(a0.v[1]), "v"(b0.v[2]), "v"(a0.v[2]), "v"(b0.v[1]), "v"(a0.v[3]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[3]), "v"(a1.v[1]), "v"(b1.v[2]), "v"(a1.v[2]), "v"(b1.v[1]), "v"(a1.v[3]), "v"(b1.v[0]), "v"(a2.v[0]), "v"(b2.v[3]), "v"(a2.v[1]), "v"(b2.v[2]), "v"(a2.v[2]), "v"(b2.v[1]), "v"(a2.v[3]), "v"(b2.v[0]), "v"(c.v[3]));
     asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m2), "s"(n1), "v"(m1), "s"(n2), "v"(m0), "s"(n3));
+        : "+&v"(nc), "=&s"(cc) : "v"(m2), "s"(n1), "v"(m1), "s"(n2), "v"(m0), "s"(n3));
+    col = nc;
     m3 = (uint32_t)col;
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m3), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 4: 16 + 4 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[4]), "v"(a0.v[1]), "v"(b0.v[3]), "v"(a0.v[2]), "v"(b0.v[2]), "v"(a0.v[3]), "v"(b0.v[1]), "v"(a0.v[4]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[4]), "v"(a1.v[1]), "v"(b1.v[3]), "v"(a1.v[2]), "v"(b1.v[2]), "v"(a1.v[3]), "v"(b1.v[1]), "v"(a1.v[4]), "v"(b1.v[0]), "v"(a2.v[0]), "v"(b2.v[4]), "v"(a2.v[1]), "v"(b2.v[3]));
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, 1, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a2.v[2]), "v"(b2.v[2]), "v"(a2.v[3]), "v"(b2.v[1]), "v"(a2.v[4]), "v"(b2.v[0]), "v"(c.v[4]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m3), "s"(n1), "v"(m2), "s"(n2), "v"(m1), "s"(n3), "v"(m0), "s"(n4));
+    // column 4: 16 + 4 products; first: - s_3 p_0 (the low limb of column 3 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0\n\tv_mad_u64_u32 %0, %1, %26, %27, %0\n\tv_mad_u64_u32 %0, %1, %28, %29, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m3), "v"(col), "v"(a0.v[0]), "v"(b0.v[4]), "v"(a0.v[1]), "v"(b0.v[3]), "v"(a0.v[2]), "v"(b0.v[2]), "v"(a0.v[3]), "v"(b0.v[1]), "v"(a0.v[4]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[4]), "v"(a1.v[1]), "v"(b1.v[3]), "v"(a1.v[2]), "v"(b1.v[2]), "v"(a1.v[3]), "v"(b1.v[1]), "v"(a1.v[4]), "v"(b1.v[0]), "v"(a2.v[0]), "v"(b2.v[4]), "v"(a2.v[1]), "v"(b2.v[3]), "v"(a2.v[2]), "v"(b2.v[2]));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, 1, %0\n\tv_mad_i64_i32 %0, %1, %7, %8, %0\n\tv_mad_i64_i32 %0, %1, %9, %10, %0\n\tv_mad_i64_i32 %0, %1, %11, %12, %0\n\tv_mad_i64_i32 %0, %1, %13, %14, %0"
+        : "+&v"(nc), "=&s"(cc) : "v"(a2.v[3]), "v"(b2.v[1]), "v"(a2.v[4]), "v"(b2.v[0]), "v"(c.v[4]), "v"(m3), "s"(n1), "v"(m2), "s"(n2), "v"(m1), "s"(n3), "v"(m0), "s"(n4));
+    col = nc;
     m4 = (uint32_t)col;
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m4), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 5: 19 + 4 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[5]), "v"(a0.v[1]), "v"(b0.v[4]), "v"(a0.v[2]), "v"(b0.v[3]), "v"(a0.v[3]), "v"(b0.v[2]), "v"(a0.v[4]), "v"(b0.v[1]), "v"(a0.v[5]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[5]), "v"(a1.v[1]), "v"(b1.v[4]), "v"(a1.v[2]), "v"(b1.v[3]), "v"(a1.v[3]), "v"(b1.v[2]), "v"(a1.v[4]), "v"(b1.v[1]), "v"(a1.v[5]), "v"(b1.v[0]));
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, 1, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a2.v[0]), "v"(b2.v[5]), "v"(a2.v[1]), "v"(b2.v[4]), "v"(a2.v[2]), "v"(b2.v[3]), "v"(a2.v[3]), "v"(b2.v[2]), "v"(a2.v[4]), "v"(b2.v[1]), "v"(a2.v[5]), "v"(b2.v[0]), "v"(c.v[5]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m4), "s"(n1), "v"(m3), "s"(n2), "v"(m2), "s"(n3), "v"(m1), "s"(n4));
+    // column 5: 19 + 4 products; first: - s_4 p_0 (the low limb of column 4 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0\n\tv_mad_u64_u32 %0, %1, %26, %27, %0\n\tv_mad_u64_u32 %0, %1, %28, %29, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m4), "v"(col), "v"(a0.v[0]), "v"(b0.v[5]), "v"(a0.v[1]), "v"(b0.v[4]), "v"(a0.v[2]), "v"(b0.v[3]), "v"(a0.v[3]), "v"(b0.v[2]), "v"(a0.v[4]), "v"(b0.v[1]), "v"(a0.v[5]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[5]), "v"(a1.v[1]), "v"(b1.v[4]), "v"(a1.v[2]), "v"(b1.v[3]), "v"(a1.v[3]), "v"(b1.v[2]), "v"(a1.v[4]), "v"(b1.v[1]), "v"(a1.v[5]), "v"(b1.v[0]), "v"(a2.v[0]), "v"(b2.v[5]));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, 1, %0\n\tv_mad_i64_i32 %0, %1, %13, %14, %0\n\tv_mad_i64_i32 %0, %1, %15, %16, %0\n\tv_mad_i64_i32 %0, %1, %17, %18, %0\n\tv_mad_i64_i32 %0, %1, %19, %20, %0"
+        : "+&v"(nc), "=&s"(cc) : "v"(a2.v[1]), "v"(b2.v[4]), "v"(a2.v[2]), "v"(b2.v[3]), "v"(a2.v[3]), "v"(b2.v[2]), "v"(a2.v[4]), "v"(b2.v[1]), "v"(a2.v[5]), "v"(b2.v[0]), "v"(c.v[5]), "v"(m4), "s"(n1), "v"(m3), "s"(n2), "v"(m2), "s"(n3), "v"(m1), "s"(n4));
+    col = nc;
     m5 = (uint32_t)col;
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m5), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 6: 22 + 4 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[6]), "v"(a0.v[1]), "v"(b0.v[5]), "v"(a0.v[2]), "v"(b0.v[4]), "v"(a0.v[3]), "v"(b0.v[3]), "v"(a0.v[4]), "v"(b0.v[2]), "v"(a0.v[5]), "v"(b0.v[1]), "v"(a0.v[6]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[6]), "v"(a1.v[1]), "v"(b1.v[5]), "v"(a1.v[2]), "v"(b1.v[4]), "v"(a1.v[3]), "v"(b1.v[3]), "v"(a1.v[4]), "v"(b1.v[2]));
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, 1, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a1.v[5]), "v"(b1.v[1]), "v"(a1.v[6]), "v"(b1.v[0]), "v"(a2.v[0]), "v"(b2.v[6]), "v"(a2.v[1]), "v"(b2.v[5]), "v"(a2.v[2]), "v"(b2.v[4]), "v"(a2.v[3]), "v"(b2.v[3]), "v"(a2.v[4]), "v"(b2.v[2]), "v"(a2.v[5]), "v"(b2.v[1]), "v"(a2.v[6]), "v"(b2.v[0]), "v"(c.v[6]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m5), "s"(n1), "v"(m4), "s"(n2), "v"(m3), "s"(n3), "v"(m2), "s"(n4));
+    // column 6: 22 + 4 products; first: - s_5 p_0 (the low limb of column 5 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0\n\tv_mad_u64_u32 %0, %1, %26, %27, %0\n\tv_mad_u64_u32 %0, %1, %28, %29, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m5), "v"(col), "v"(a0.v[0]), "v"(b0.v[6]), "v"(a0.v[1]), "v"(b0.v[5]), "v"(a0.v[2]), "v"(b0.v[4]), "v"(a0.v[3]), "v"(b0.v[3]), "v"(a0.v[4]), "v"(b0.v[2]), "v"(a0.v[5]), "v"(b0.v[1]), "v"(a0.v[6]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[6]), "v"(a1.v[1]), "v"(b1.v[5]), "v"(a1.v[2]), "v"(b1.v[4]), "v"(a1.v[3]), "v"(b1.v[3]), "v"(a1.v[4]), "v"(b1.v[2]), "v"(a1.v[5]), "v"(b1.v[1]));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, 1, %0\n\tv_mad_i64_i32 %0, %1, %19, %20, %0\n\tv_mad_i64_i32 %0, %1, %21, %22, %0\n\tv_mad_i64_i32 %0, %1, %23, %24, %0\n\tv_mad_i64_i32 %0, %1, %25, %26, %0"
+        : "+&v"(nc), "=&s"(cc) : "v"(a1.v[6]), "v"(b1.v[0]), "v"(a2.v[0]), "v"(b2.v[6]), "v"(a2.v[1]), "v"(b2.v[5]), "v"(a2.v[2]), "v"(b2.v[4]), "v"(a2.v[3]), "v"(b2.v[3]), "v"(a2.v[4]), "v"(b2.v[2]), "v"(a2.v[5]), "v"(b2.v[1]), "v"(a2.v[6]), "v"(b2.v[0]), "v"(c.v[6]), "v"(m5), "s"(n1), "v"(m4), "s"(n2), "v"(m3), "s"(n3), "v"(m2), "s"(n4));
+    col = nc;
     m6 = (uint32_t)col;
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m6), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 7: 25 + 4 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[7]), "v"(a0.v[1]), "v"(b0.v[6]), "v"(a0.v[2]), "v"(b0.v[5]), "v"(a0.v[3]), "v"(b0.v[4]), "v"(a0.v[4]), "v"(b0.v[3]), "v"(a0.v[5]), "v"(b0.v[2]), "v"(a0.v[6]), "v"(b0.v[1]), "v"(a0.v[7]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[7]), "v"(a1.v[1]), "v"(b1.v[6]), "v"(a1.v[2]), "v"(b1.v[5]), "v"(a1.v[3]), "v"(b1.v[4]));
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a1.v[4]), "v"(b1.v[3]), "v"(a1.v[5]), "v"(b1.v[2]), "v"(a1.v[6]), "v"(b1.v[1]), "v"(a1.v[7]), "v"(b1.v[0]), "v"(a2.v[0]), "v"(b2.v[7]), "v"(a2.v[1]), "v"(b2.v[6]), "v"(a2.v[2]), "v"(b2.v[5]), "v"(a2.v[3]), "v"(b2.v[4]), "v"(a2.v[4]), "v"(b2.v[3]), "v"(a2.v[5]), "v"(b2.v[2]), "v"(a2.v[6]), "v"(b2.v[1]), "v"(a2.v[7]), "v"(b2.v[0]));
-    asm("v_mad_u64_u32 %0, %1, %2, 1, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(c.v[7]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m6), "s"(n1), "v"(m5), "s"(n2), "v"(m4), "s"(n3), "v"(m3), "s"(n4));
+    // column 7: 25 + 4 products; first: - s_6 p_0 (the low limb of column 6 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0\n\tv_mad_u64_u32 %0, %1, %26, %27, %0\n\tv_mad_u64_u32 %0, %1, %28, %29, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m6), "v"(col), "v"(a0.v[0]), "v"(b0.v[7]), "v"(a0.v[1]), "v"(b0.v[6]), "v"(a0.v[2]), "v"(b0.v[5]), "v"(a0.v[3]), "v"(b0.v[4]), "v"(a0.v[4]), "v"(b0.v[3]), "v"(a0.v[5]), "v"(b0.v[2]), "v"(a0.v[6]), "v"(b0.v[1]), "v"(a0.v[7]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[7]), "v"(a1.v[1]), "v"(b1.v[6]), "v"(a1.v[2]), "v"(b1.v[5]), "v"(a1.v[3]), "v"(b1.v[4]), "v"(a1.v[4]), "v"(b1.v[3]));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, 1, %0\n\tv_mad_i64_i32 %0, %1, %25, %26, %0\n\tv_mad_i64_i32 %0, %1, %27, %28, %0"
+        : "+&v"(nc), "=&s"(cc) : "v"(a1.v[5]), "v"(b1.v[2]), "v"(a1.v[6]), "v"(b1.v[1]), "v"(a1.v[7]), "v"(b1.v[0]), "v"(a2.v[0]), "v"(b2.v[7]), "v"(a2.v[1]), "v"(b2.v[6]), "v"(a2.v[2]), "v"(b2.v[5]), "v"(a2.v[3]), "v"(b2.v[4]), "v"(a2.v[4]), "v"(b2.v[3]), "v"(a2.v[5]), "v"(b2.v[2]), "v"(a2.v[6]), "v"(b2.v[1]), "v"(a2.v[7]), "v"(b2.v[0]), "v"(c.v[7]), "v"(m6), "s"(n1), "v"(m5), "s"(n2));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0"
+        : "+&v"(nc), "=&s"(cc) : "v"(m4), "s"(n3), "v"(m3), "s"(n4));
+    col = nc;
     m7 = (uint32_t)col;
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m7), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 8: 28 + 5 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a0.v[0]), "v"(b0.v[8]), "v"(a0.v[1]), "v"(b0.v[7]), "v"(a0.v[2]), "v"(b0.v[6]), "v"(a0.v[3]), "v"(b0.v[5]), "v"(a0.v[4]), "v"(b0.v[4]), "v"(a0.v[5]), "v"(b0.v[3]), "v"(a0.v[6]), "v"(b0.v[2]), "v"(a0.v[7]), "v"(b0.v[1]), "v"(a0.v[8]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[8]), "v"(a1.v[1]), "v"(b1.v[7]), "v"(a1.v[2]), "v"(b1.v[6]));
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a1.v[3]), "v"(b1.v[5]), "v"(a1.v[4]), "v"(b1.v[4]), "v"(a1.v[5]), "v"(b1.v[3]), "v"(a1.v[6]), "v"(b1.v[2]), "v"(a1.v[7]), "v"(b1.v[1]), "v"(a1.v[8]), "v"(b1.v[0]), "v"(a2.v[0]), "v"(b2.v[8]), "v"(a2.v[1]), "v"(b2.v[7]), "v"(a2.v[2]), "v"(b2.v[6]), "v"(a2.v[3]), "v"(b2.v[5]), "v"(a2.v[4]), "v"(b2.v[4]), "v"(a2.v[5]), "v"(b2.v[3]));
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, 1, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a2.v[6]), "v"(b2.v[2]), "v"(a2.v[7]), "v"(b2.v[1]), "v"(a2.v[8]), "v"(b2.v[0]), "v"(c.v[8]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0\n\tv_mad_i64_i32 %0, %1, %10, %11, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m7), "s"(n1), "v"(m6), "s"(n2), "v"(m5), "s"(n3), "v"(m4), "s"(n4), "v"(m0), "s"(n8));
+    // column 8: 28 + 5 products; first: - s_7 p_0 (the low limb of column 7 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0\n\tv_mad_u64_u32 %0, %1, %26, %27, %0\n\tv_mad_u64_u32 %0, %1, %28, %29, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m7), "v"(col), "v"(a0.v[0]), "v"(b0.v[8]), "v"(a0.v[1]), "v"(b0.v[7]), "v"(a0.v[2]), "v"(b0.v[6]), "v"(a0.v[3]), "v"(b0.v[5]), "v"(a0.v[4]), "v"(b0.v[4]), "v"(a0.v[5]), "v"(b0.v[3]), "v"(a0.v[6]), "v"(b0.v[2]), "v"(a0.v[7]), "v"(b0.v[1]), "v"(a0.v[8]), "v"(b0.v[0]), "v"(a1.v[0]), "v"(b1.v[8]), "v"(a1.v[1]), "v"(b1.v[7]), "v"(a1.v[2]), "v"(b1.v[6]), "v"(a1.v[3]), "v"(b1.v[5]));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0\n\tv_mad_u64_u32 %0, %1, %26, %27, %0\n\tv_mad_u64_u32 %0, %1, %28, %29, %0"
+        : "+&v"(nc), "=&s"(cc) : "v"(a1.v[4]), "v"(b1.v[4]), "v"(a1.v[5]), "v"(b1.v[3]), "v"(a1.v[6]), "v"(b1.v[2]), "v"(a1.v[7]), "v"(b1.v[1]), "v"(a1.v[8]), "v"(b1.v[0]), "v"(a2.v[0]), "v"(b2.v[8]), "v"(a2.v[1]), "v"(b2.v[7]), "v"(a2.v[2]), "v"(b2.v[6]), "v"(a2.v[3]), "v"(b2.v[5]), "v"(a2.v[4]), "v"(b2.v[4]), "v"(a2.v[5]), "v"(b2.v[3]), "v"(a2.v[6]), "v"(b2.v[2]), "v"(a2.v[7]), "v"(b2.v[1]), "v"(a2.v[8]), "v"(b2.v[0]));
+    asm("v_mad_u64_u32 %0, %1, %2, 1, %0\n\tv_mad_i64_i32 %0, %1, %3, %4, %0\n\tv_mad_i64_i32 %0, %1, %5, %6, %0\n\tv_mad_i64_i32 %0, %1, %7, %8, %0\n\tv_mad_i64_i32 %0, %1, %9, %10, %0\n\tv_mad_i64_i32 %0, %1, %11, %12, %0"
+        : "+&v"(nc), "=&s"(cc) : "v"(c.v[8]), "v"(m7), "s"(n1), "v"(m6), "s"(n2), "v"(m5), "s"(n3), "v"(m4), "s"(n4), "v"(m0), "s"(n8));
+    col = nc;
     m8 = ((uint32_t)col & M29) | 0xC0000000u;        // (col & M29) - 2^30: the one digit with a fixed sign
-    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m8), "v"(col));   // - s_k p_0: the low limb cancels
-    col = (uint64_t)((int64_t)nc >> 29);
-    // column 9: 24 + 5 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a0.v[1]), "v"(b0.v[8]), "v"(a0.v[2]), "v"(b0.v[7]), "v"(a0.v[3]), "v"(b0.v[6]), "v"(a0.v[4]), "v"(b0.v[5]), "v"(a0.v[5]), "v"(b0.v[4]), "v"(a0.v[6]), "v"(b0.v[3]), "v"(a0.v[7]), "v"(b0.v[2]), "v"(a0.v[8]), "v"(b0.v[1]), "v"(a1.v[1]), "v"(b1.v[8]), "v"(a1.v[2]), "v"(b1.v[7]), "v"(a1.v[3]), "v"(b1.v[6]), "v"(a1.v[4]), "v"(b1.v[5]));
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a1.v[5]), "v"(b1.v[4]), "v"(a1.v[6]), "v"(b1.v[3]), "v"(a1.v[7]), "v"(b1.v[2]), "v"(a1.v[8]), "v"(b1.v[1]), "v"(a2.v[1]), "v"(b2.v[8]), "v"(a2.v[2]), "v"(b2.v[7]), "v"(a2.v[3]), "v"(b2.v[6]), "v"(a2.v[4]), "v"(b2.v[5]), "v"(a2.v[5]), "v"(b2.v[4]), "v"(a2.v[6]), "v"(b2.v[3]), "v"(a2.v[7]), "v"(b2.v[2]), "v"(a2.v[8]), "v"(b2.v[1]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0\n\tv_mad_i64_i32 %0, %1, %10, %11, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n1), "v"(m7), "s"(n2), "v"(m6), "s"(n3), "v"(m5), "s"(n4), "v"(m1), "s"(n8));
+    // column 9: 24 + 5 products; first: - s_8 p_0 (the low limb of column 8 cancels) and its carry
+    asm("v_mad_i64_i32 %0, %1, %2, -1, %3\n\tv_ashrrev_i64 %0, 29, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0\n\tv_mad_u64_u32 %0, %1, %26, %27, %0\n\tv_mad_u64_u32 %0, %1, %28, %29, %0"
+        : "=&v"(nc), "=&s"(cc) : "v"(m8), "v"(col), "v"(a0.v[1]), "v"(b0.v[8]), "v"(a0.v[2]), "v"(b0.v[7]), "v"(a0.v[3]), "v"(b0.v[6]), "v"(a0.v[4]), "v"(b0.v[5]), "v"(a0.v[5]), "v"(b0.v[4]), "v"(a0.v[6]), "v"(b0.v[3]), "v"(a0.v[7]), "v"(b0.v[2]), "v"(a0.v[8]), "v"(b0.v[1]), "v"(a1.v[1]), "v"(b1.v[8]), "v"(a1.v[2]), "v"(b1.v[7]), "v"(a1.v[3]), "v"(b1.v[6]), "v"(a1.v[4]), "v"(b1.v[5]), "v"(a1.v[5]), "v"(b1.v[4]));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_i64_i32 %0, %1, %24, %25, %0\n\tv_mad_i64_i32 %0, %1, %26, %27, %0\n\tv_mad_i64_i32 %0, %1, %28, %29, %0"
+        : "+&v"(nc), "=&s"(cc) : "v"(a1.v[6]), "v"(b1.v[3]), "v"(a1.v[7]), "v"(b1.v[2]), "v"(a1.v[8]), "v"(b1.v[1]), "v"(a2.v[1]), "v"(b2.v[8]), "v"(a2.v[2]), "v"(b2.v[7]), "v"(a2.v[3]), "v"(b2.v[6]), "v"(a2.v[4]), "v"(b2.v[5]), "v"(a2.v[5]), "v"(b2.v[4]), "v"(a2.v[6]), "v"(b2.v[3]), "v"(a2.v[7]), "v"(b2.v[2]), "v"(a2.v[8]), "v"(b2.v[1]), "v"(m8), "s"(n1), "v"(m7), "s"(n2), "v"(m6), "s"(n3));
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0"
+        : "+&v"(nc), "=&s"(cc) : "v"(m5), "s"(n4), "v"(m1), "s"(n8));
+    col = nc;
     r.v[0] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
     // column 10: 21 + 4 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a0.v[2]), "v"(b0.v[8]), "v"(a0.v[3]), "v"(b0.v[7]), "v"(a0.v[4]), "v"(b0.v[6]), "v"(a0.v[5]), "v"(b0.v[5]), "v"(a0.v[6]), "v"(b0.v[4]), "v"(a0.v[7]), "v"(b0.v[3]), "v"(a0.v[8]), "v"(b0.v[2]), "v"(a1.v[2]), "v"(b1.v[8]), "v"(a1.v[3]), "v"(b1.v[7]), "v"(a1.v[4]), "v"(b1.v[6]), "v"(a1.v[5]), "v"(b1.v[5]), "v"(a1.v[6]), "v"(b1.v[4]));
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a1.v[7]), "v"(b1.v[3]), "v"(a1.v[8]), "v"(b1.v[2]), "v"(a2.v[2]), "v"(b2.v[8]), "v"(a2.v[3]), "v"(b2.v[7]), "v"(a2.v[4]), "v"(b2.v[6]), "v"(a2.v[5]), "v"(b2.v[5]), "v"(a2.v[6]), "v"(b2.v[4]), "v"(a2.v[7]), "v"(b2.v[3]), "v"(a2.v[8]), "v"(b2.v[2]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n2), "v"(m7), "s"(n3), "v"(m6), "s"(n4), "v"(m2), "s"(n8));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0\n\tv_mad_u64_u32 %0, %1, %26, %27, %0\n\tv_mad_u64_u32 %0, %1, %28, %29, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[2]), "v"(b0.v[8]), "v"(a0.v[3]), "v"(b0.v[7]), "v"(a0.v[4]), "v"(b0.v[6]), "v"(a0.v[5]), "v"(b0.v[5]), "v"(a0.v[6]), "v"(b0.v[4]), "v"(a0.v[7]), "v"(b0.v[3]), "v"(a0.v[8]), "v"(b0.v[2]), "v"(a1.v[2]), "v"(b1.v[8]), "v"(a1.v[3]), "v"(b1.v[7]), "v"(a1.v[4]), "v"(b1.v[6]), "v"(a1.v[5]), "v"(b1.v[5]), "v"(a1.v[6]), "v"(b1.v[4]), "v"(a1.v[7]), "v"(b1.v[3]), "v"(a1.v[8]), "v"(b1.v[2]));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_i64_i32 %0, %1, %16, %17, %0\n\tv_mad_i64_i32 %0, %1, %18, %19, %0\n\tv_mad_i64_i32 %0, %1, %20, %21, %0\n\tv_mad_i64_i32 %0, %1, %22, %23, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a2.v[2]), "v"(b2.v[8]), "v"(a2.v[3]), "v"(b2.v[7]), "v"(a2.v[4]), "v"(b2.v[6]), "v"(a2.v[5]), "v"(b2.v[5]), "v"(a2.v[6]), "v"(b2.v[4]), "v"(a2.v[7]), "v"(b2.v[3]), "v"(a2.v[8]), "v"(b2.v[2]), "v"(m8), "s"(n2), "v"(m7), "s"(n3), "v"(m6), "s"(n4), "v"(m2), "s"(n8));
     r.v[1] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
     // column 11: 18 + 3 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a0.v[3]), "v"(b0.v[8]), "v"(a0.v[4]), "v"(b0.v[7]), "v"(a0.v[5]), "v"(b0.v[6]), "v"(a0.v[6]), "v"(b0.v[5]), "v"(a0.v[7]), "v"(b0.v[4]), "v"(a0.v[8]), "v"(b0.v[3]), "v"(a1.v[3]), "v"(b1.v[8]), "v"(a1.v[4]), "v"(b1.v[7]), "v"(a1.v[5]), "v"(b1.v[6]), "v"(a1.v[6]), "v"(b1.v[5]), "v"(a1.v[7]), "v"(b1.v[4]), "v"(a1.v[8]), "v"(b1.v[3]));
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a2.v[3]), "v"(b2.v[8]), "v"(a2.v[4]), "v"(b2.v[7]), "v"(a2.v[5]), "v"(b2.v[6]), "v"(a2.v[6]), "v"(b2.v[5]), "v"(a2.v[7]), "v"(b2.v[4]), "v"(a2.v[8]), "v"(b2.v[3]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n3), "v"(m7), "s"(n4), "v"(m3), "s"(n8));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0\n\tv_mad_u64_u32 %0, %1, %26, %27, %0\n\tv_mad_u64_u32 %0, %1, %28, %29, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[3]), "v"(b0.v[8]), "v"(a0.v[4]), "v"(b0.v[7]), "v"(a0.v[5]), "v"(b0.v[6]), "v"(a0.v[6]), "v"(b0.v[5]), "v"(a0.v[7]), "v"(b0.v[4]), "v"(a0.v[8]), "v"(b0.v[3]), "v"(a1.v[3]), "v"(b1.v[8]), "v"(a1.v[4]), "v"(b1.v[7]), "v"(a1.v[5]), "v"(b1.v[6]), "v"(a1.v[6]), "v"(b1.v[5]), "v"(a1.v[7]), "v"(b1.v[4]), "v"(a1.v[8]), "v"(b1.v[3]), "v"(a2.v[3]), "v"(b2.v[8]), "v"(a2.v[4]), "v"(b2.v[7]));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_i64_i32 %0, %1, %10, %11, %0\n\tv_mad_i64_i32 %0, %1, %12, %13, %0\n\tv_mad_i64_i32 %0, %1, %14, %15, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a2.v[5]), "v"(b2.v[6]), "v"(a2.v[6]), "v"(b2.v[5]), "v"(a2.v[7]), "v"(b2.v[4]), "v"(a2.v[8]), "v"(b2.v[3]), "v"(m8), "s"(n3), "v"(m7), "s"(n4), "v"(m3), "s"(n8));
     r.v[2] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
     // column 12: 15 + 2 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a0.v[4]), "v"(b0.v[8]), "v"(a0.v[5]), "v"(b0.v[7]), "v"(a0.v[6]), "v"(b0.v[6]), "v"(a0.v[7]), "v"(b0.v[5]), "v"(a0.v[8]), "v"(b0.v[4]), "v"(a1.v[4]), "v"(b1.v[8]), "v"(a1.v[5]), "v"(b1.v[7]), "v"(a1.v[6]), "v"(b1.v[6]), "v"(a1.v[7]), "v"(b1.v[5]), "v"(a1.v[8]), "v"(b1.v[4]), "v"(a2.v[4]), "v"(b2.v[8]), "v"(a2.v[5]), "v"(b2.v[7]));
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a2.v[6]), "v"(b2.v[6]), "v"(a2.v[7]), "v"(b2.v[5]), "v"(a2.v[8]), "v"(b2.v[4]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n4), "v"(m4), "s"(n8));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0\n\tv_mad_u64_u32 %0, %1, %26, %27, %0\n\tv_mad_u64_u32 %0, %1, %28, %29, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[4]), "v"(b0.v[8]), "v"(a0.v[5]), "v"(b0.v[7]), "v"(a0.v[6]), "v"(b0.v[6]), "v"(a0.v[7]), "v"(b0.v[5]), "v"(a0.v[8]), "v"(b0.v[4]), "v"(a1.v[4]), "v"(b1.v[8]), "v"(a1.v[5]), "v"(b1.v[7]), "v"(a1.v[6]), "v"(b1.v[6]), "v"(a1.v[7]), "v"(b1.v[5]), "v"(a1.v[8]), "v"(b1.v[4]), "v"(a2.v[4]), "v"(b2.v[8]), "v"(a2.v[5]), "v"(b2.v[7]), "v"(a2.v[6]), "v"(b2.v[6]), "v"(a2.v[7]), "v"(b2.v[5]));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_i64_i32 %0, %1, %4, %5, %0\n\tv_mad_i64_i32 %0, %1, %6, %7, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a2.v[8]), "v"(b2.v[4]), "v"(m8), "s"(n4), "v"(m4), "s"(n8));
     r.v[3] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
     // column 13: 12 + 1 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a0.v[5]), "v"(b0.v[8]), "v"(a0.v[6]), "v"(b0.v[7]), "v"(a0.v[7]), "v"(b0.v[6]), "v"(a0.v[8]), "v"(b0.v[5]), "v"(a1.v[5]), "v"(b1.v[8]), "v"(a1.v[6]), "v"(b1.v[7]), "v"(a1.v[7]), "v"(b1.v[6]), "v"(a1.v[8]), "v"(b1.v[5]), "v"(a2.v[5]), "v"(b2.v[8]), "v"(a2.v[6]), "v"(b2.v[7]), "v"(a2.v[7]), "v"(b2.v[6]), "v"(a2.v[8]), "v"(b2.v[5]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m5), "s"(n8));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_u64_u32 %0, %1, %20, %21, %0\n\tv_mad_u64_u32 %0, %1, %22, %23, %0\n\tv_mad_u64_u32 %0, %1, %24, %25, %0\n\tv_mad_i64_i32 %0, %1, %26, %27, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[5]), "v"(b0.v[8]), "v"(a0.v[6]), "v"(b0.v[7]), "v"(a0.v[7]), "v"(b0.v[6]), "v"(a0.v[8]), "v"(b0.v[5]), "v"(a1.v[5]), "v"(b1.v[8]), "v"(a1.v[6]), "v"(b1.v[7]), "v"(a1.v[7]), "v"(b1.v[6]), "v"(a1.v[8]), "v"(b1.v[5]), "v"(a2.v[5]), "v"(b2.v[8]), "v"(a2.v[6]), "v"(b2.v[7]), "v"(a2.v[7]), "v"(b2.v[6]), "v"(a2.v[8]), "v"(b2.v[5]), "v"(m5), "s"(n8));
     r.v[4] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
     // column 14: 9 + 1 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a0.v[6]), "v"(b0.v[8]), "v"(a0.v[7]), "v"(b0.v[7]), "v"(a0.v[8]), "v"(b0.v[6]), "v"(a1.v[6]), "v"(b1.v[8]), "v"(a1.v[7]), "v"(b1.v[7]), "v"(a1.v[8]), "v"(b1.v[6]), "v"(a2.v[6]), "v"(b2.v[8]), "v"(a2.v[7]), "v"(b2.v[7]), "v"(a2.v[8]), "v"(b2.v[6]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m6), "s"(n8));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_u64_u32 %0, %1, %14, %15, %0\n\tv_mad_u64_u32 %0, %1, %16, %17, %0\n\tv_mad_u64_u32 %0, %1, %18, %19, %0\n\tv_mad_i64_i32 %0, %1, %20, %21, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[6]), "v"(b0.v[8]), "v"(a0.v[7]), "v"(b0.v[7]), "v"(a0.v[8]), "v"(b0.v[6]), "v"(a1.v[6]), "v"(b1.v[8]), "v"(a1.v[7]), "v"(b1.v[7]), "v"(a1.v[8]), "v"(b1.v[6]), "v"(a2.v[6]), "v"(b2.v[8]), "v"(a2.v[7]), "v"(b2.v[7]), "v"(a2.v[8]), "v"(b2.v[6]), "v"(m6), "s"(n8));
     r.v[5] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
     // column 15: 6 + 1 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a0.v[7]), "v"(b0.v[8]), "v"(a0.v[8]), "v"(b0.v[7]), "v"(a1.v[7]), "v"(b1.v[8]), "v"(a1.v[8]), "v"(b1.v[7]), "v"(a2.v[7]), "v"(b2.v[8]), "v"(a2.v[8]), "v"(b2.v[7]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m7), "s"(n8));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_u64_u32 %0, %1, %8, %9, %0\n\tv_mad_u64_u32 %0, %1, %10, %11, %0\n\tv_mad_u64_u32 %0, %1, %12, %13, %0\n\tv_mad_i64_i32 %0, %1, %14, %15, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[7]), "v"(b0.v[8]), "v"(a0.v[8]), "v"(b0.v[7]), "v"(a1.v[7]), "v"(b1.v[8]), "v"(a1.v[8]), "v"(b1.v[7]), "v"(a2.v[7]), "v"(b2.v[8]), "v"(a2.v[8]), "v"(b2.v[7]), "v"(m7), "s"(n8));
     r.v[6] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
     // column 16: 3 + 1 products
-    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(a0.v[8]), "v"(b0.v[8]), "v"(a1.v[8]), "v"(b1.v[8]), "v"(a2.v[8]), "v"(b2.v[8]));
-    asm("v_mad_i64_i32 %0, %1, %2, %3, %0"
-        : "+&v"(col), "=&s"(cc) : "v"(m8), "s"(n8));
+    asm("v_mad_u64_u32 %0, %1, %2, %3, %0\n\tv_mad_u64_u32 %0, %1, %4, %5, %0\n\tv_mad_u64_u32 %0, %1, %6, %7, %0\n\tv_mad_i64_i32 %0, %1, %8, %9, %0"
+        : "+&v"(col), "=&s"(cc) : "v"(a0.v[8]), "v"(b0.v[8]), "v"(a1.v[8]), "v"(b1.v[8]), "v"(a2.v[8]), "v"(b2.v[8]), "v"(m8), "s"(n8));
     r.v[7] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> 29);
     r.v[8] = (uint32_t)col;
     return r;

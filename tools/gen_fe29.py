@@ -84,9 +84,32 @@ def smads(terms):
     return out
 
 
+def _pack(units, first_out, var):
+    """units: (instruction text with %0 = the accumulator pair, %1 = the scratch carry pair and @i = its own i-th input, [input operands]); packed greedily into asm
+    statements of at most 28 inputs (+ 2 outputs = inline asm's 30).  first_out: constraint of the accumulator in the FIRST statement ("=&v": its first instruction
+    writes it without reading it); later statements of the same column read and write it ("+&v")."""
+    out, lines, ops = [], [], []
+    def flush():
+        nonlocal lines, ops
+        if lines:
+            out.append('    asm("' + '\\n\\t'.join(lines) + '"\n        : "' + (first_out if not out else "+&v") + f'"({var}), "=&s"(cc) : ' + ", ".join(ops) + ");")
+        lines, ops = [], []
+    for text, uops in units:
+        if len(ops) + len(uops) > 28:
+            flush()
+        for i, o in enumerate(uops):
+            text = text.replace(f"@{i}", f"%{2 + len(ops) + i}")
+        lines.append(text); ops += list(uops)
+    flush()
+    return out
+
+
 def body_sg(col_terms, hi=None):
-    """the column loop with SIGNED quotient digits.  m_k (k < 8) is the low register of the column itself: the statement that cancels the low limb writes the new column
-    to OTHER registers (early-clobber output), so the old low word stays where it is for the five later uses of the digit -- no copy, no negation, no mask."""
+    """the column loop with SIGNED quotient digits.  m_k (k < 8) is the low register of the column itself: the instruction that cancels the low limb writes the new column
+    to OTHER registers (early-clobber output), so the old low word stays where it is for the five later uses of the digit -- no copy, no negation, no mask.
+    ONE asm statement per column where the operand limit allows (end of round 5): cancel the previous column's low limb, carry, this column's products, its reduction
+    terms.  The compiler must put an `s_nop 0` after every asm statement whose result the next instruction reads (the gfx940 forwarding-hazard rule, which it has to assume of
+    an asm it cannot read); three statements per column were 43 of them per product, free at five waves per SIMD and 5 - 7 % of the chain at one."""
     out = ["    uint64_t col, nc, cc; fe29_t r;", "    uint32_t " + ", ".join(f"m{i}" for i in range(L)) + ";",
            "    const int32_t n1 = -(int32_t)P29<F>::L1, n2 = -(int32_t)P29<F>::L2, n3 = -(int32_t)P29<F>::L3, n4 = -(int32_t)P29<F>::L4, n8 = -(int32_t)P29<F>::L8;"]
     for k in range(2 * L - 1):
@@ -97,13 +120,27 @@ def body_sg(col_terms, hi=None):
                 st.append((f"m{i}", nj))
         if hi is not None and k >= L:
             terms.append((f"{hi}.v[{k - L}]", 1))
-        out.append(f"    // column {k}: {len(terms)} + {len(st)} products")
-        out += mads(terms, fresh=(k == 0))
-        out += smads(st)
+        cancel = 1 <= k <= L                                     # the previous column was a digit column: its low limb is cancelled and its carry taken HERE
+        out.append(f"    // column {k}: {len(terms)} + {len(st)} products" + (f"; first: - s_{k - 1} p_0 (the low limb of column {k - 1} cancels) and its carry" if cancel else ""))
+        units = []
+        if cancel:
+            units.append(("v_mad_i64_i32 %0, %1, @0, -1, @1", [f'"v"(m{k - 1})', '"v"(col)']))
+            units.append((f"v_ashrrev_i64 %0, {W}, %0", []))
+        for t, (x, y) in enumerate(terms):
+            addend = "0" if k == 0 and t == 0 else "%0"
+            if isinstance(y, int):
+                units.append((f"v_mad_u64_u32 %0, %1, @0, {y}, {addend}", [f'"v"({x})']))
+            else:
+                units.append((f"v_mad_u64_u32 %0, %1, @0, @1, {addend}", [f'"v"({x})', f'"v"({y})']))
+        for x, y in st:
+            units.append(("v_mad_i64_i32 %0, %1, @0, @1, %0", [f'"v"({x})', f'"s"({y})']))      # the negated prime limb rides the constant bus: no VGPR
+        if cancel:
+            out += _pack(units, "=&v", "nc")
+            out.append("    col = nc;")
+        else:
+            out += _pack(units, "=&v" if k == 0 else "+&v", "col")
         if k < L:
             out.append(f"    m{k} = (uint32_t)col;" if k < L - 1 else f"    m{k} = ((uint32_t)col & M29) | 0xC0000000u;        // (col & M29) - 2^30: the one digit with a fixed sign")
-            out.append(f'    asm("v_mad_i64_i32 %0, %1, %2, -1, %3" : "=&v"(nc), "=&s"(cc) : "v"(m{k}), "v"(col));   // - s_k p_0: the low limb cancels')
-            out.append(f"    col = (uint64_t)((int64_t)nc >> {W});")
         else:
             out.append(f"    r.v[{k - L}] = (uint32_t)col & M29; col = (uint64_t)((int64_t)col >> {W});")
     out.append(f"    r.v[{L - 1}] = (uint32_t)col;" if hi is None else f"    r.v[{L - 1}] = (uint32_t)col + {hi}.v[{L - 1}];")
