@@ -15,7 +15,7 @@ int32 -- NO instruction makes it (the lazy forms spend a v_sub per digit, the st
 negated prime limbs; digit 8 is (col & M29) - 2^30 (one v_and_or), always negative, so the quotient is positive without an offset term: the result is
 T / R + (1 p, 2 p], limbs 0..7 normalised (tools/fe29_bounds.py `product_signed`; measured: tools/probes/sg_probe.hip).
 One asm statement per chunk of <= 12 multiply-accumulates of a column (inline asm takes at most 30 operands); between the columns plain
-C++ (mask, shift).  The compiler's own schedule of the C++ form spreads a column over several accumulators and re-adds them (+116 64-bit
+C++ (mask, shift).  The signed-digit routines: one statement per COLUMN (cancel + carry + products + reduction terms), split only where 28 inputs do not suffice.  The compiler's own schedule of the C++ form spreads a column over several accumulators and re-adds them (+116 64-bit
 adds and +70 products per Poseidon round); pinned like this a round is ~1150 VALU instructions instead of ~1610.
     python tools/gen_fe29.py > /tmp/fe29_gen.inc   (pasted between the GENERATED markers of fp29.cuh by the same script with --write)"""
 import os
