@@ -148,6 +148,47 @@ def msm_traffic(c2_rate):
         return {"traffic": None}
 
 
+def clock_normalised(frac, power):
+    """`frac` is quoted at the nominal 2.4 GHz; the step holds the chip on its power cap and the clock it gets differs by box (2.10 - 2.30 GHz: profiles/r05_clock_power.md), so the
+    same build reads 0.76 on one box and 0.82 on another.  frac_at_sampled_clock = achieved / (peak x sclk_avg / 2400): comparable between boxes (VERDICT r05 next #3a).
+    The clock is the timed region's average (the isolated launches that time the kernel run right after it, same thermal state)."""
+    if not power or not power.get("sclk_mhz_avg") or frac is None:
+        return {"frac_at_sampled_clock": None}
+    return {"frac_at_sampled_clock": frac / (power["sclk_mhz_avg"] / (CLOCK_HZ / 1e6)), "sampled_sclk_mhz": power["sclk_mhz_avg"]}
+
+
+def toolchain():
+    """compiler and runtime the library was built with / runs under: the instruction counts, register numbers and s_nop counts the performance contract rests on are
+    properties of ONE compiler build (tests/test_code_object.py pins them)"""
+    import subprocess
+    out = {}
+    try:
+        v = subprocess.run(["hipcc", "--version"], capture_output=True, text=True, timeout=30).stdout
+        out["hipcc"] = " / ".join(l.strip() for l in v.splitlines() if l.startswith("HIP version") or "clang version" in l)[:200]
+    except Exception as e:                                       # noqa: BLE001
+        out["hipcc"] = "unavailable: " + repr(e)[:80]
+    try:
+        import torch
+        out["torch"] = torch.__version__; out["torch_hip"] = getattr(torch.version, "hip", None)
+    except Exception:                                            # noqa: BLE001
+        pass
+    try:
+        out["rocm_runtime"] = open("/opt/rocm/.info/version").read().strip()
+    except OSError:
+        pass
+    return out
+
+
+def msm_single_traffic(kern_us):
+    """HBM-side bytes of ONE lone 2^16 accumulator check (profiles/msm_traffic.json `single_check`: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over tools/c2_single.py)"""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "msm_traffic.json")))["single_check"]
+        return {"traffic": t["hbm_bytes_per_check"], "traffic_ratio_to_algorithmic": t["ratio_to_algorithmic"], "traffic_GBps_kernels": t["hbm_bytes_per_check"] / kern_us / 1e3 if kern_us else None,
+                "traffic_source": "profiles/msm_traffic.json single_check (" + t["source"] + ")"}
+    except (OSError, KeyError, ValueError):
+        return {"traffic": None}
+
+
 def step_valu(ms_per_step, proofs_per_step):
     """the whole step against VALU instruction issue: wave-instructions of one step, every kernel (profiles/step_valu.json: rocprofv3 --pmc SQ_INSTS_VALU over a
     single-lane run, setup kernels left out), priced at the measured 4.4 cycles per wave64 instruction per SIMD of the 29-bit mix with the SIMDs full"""
@@ -435,6 +476,54 @@ def _boundary_setup(m, devices: str):
     return m.load_library(), items, ndev
 
 
+_CALLERS_C = r"""
+#include <pthread.h>
+#include <stdbool.h>
+#include <stddef.h>
+#include <stdint.h>
+bool mina_verify_state(const uint8_t *proof, size_t proof_len, const uint8_t *pub, size_t pub_len);
+struct job { const uint8_t *const *proofs; const size_t *pl; const uint8_t *const *pubs; const size_t *ql; int ncases, calls, t; long bad; };
+static void *worker(void *a) { struct job *j = a; for (int k = 0; k < j->calls; ++k) { int c = (j->t + k) % j->ncases; if (!mina_verify_state(j->proofs[c], j->pl[c], j->pubs[c], j->ql[c])) j->bad++; } return 0; }
+long run_callers(int nthreads, int calls, int ncases, const uint8_t *const *proofs, const size_t *pl, const uint8_t *const *pubs, const size_t *ql) {
+  pthread_t th[1024]; struct job jobs[1024]; long bad = 0;
+  if (nthreads > 1024) return -1;
+  for (int t = 0; t < nthreads; ++t) { jobs[t] = (struct job){proofs, pl, pubs, ql, ncases, calls, t, 0}; pthread_create(&th[t], 0, worker, &jobs[t]); }
+  for (int t = 0; t < nthreads; ++t) { pthread_join(th[t], 0); bad += jobs[t].bad; }
+  return bad; }
+"""
+
+
+def one_proof_per_call(m, items, thread_counts=(1, 64, 1024), per_thread=4):
+    """The reference's real call shape: `verify_mina_state_ffi` / `mina_verify_state` takes ONE proof per call (/root/reference README.md:277-279; the caller is
+    core/src/aligned.rs:31-58 through Aligned's operator tasks).  N caller threads -- pthreads of a small C helper, no interpreter lock between a verdict and the next call --
+    each make `per_thread` calls; calls that arrive while a job runs leave together as the next job (api_verify.hip group commit).  Same measurement as
+    tools/concurrent_callers.py, in the line so that the driver times it."""
+    import ctypes, subprocess, tempfile
+    try:
+        tmp = tempfile.mkdtemp()
+        with open(os.path.join(tmp, "callers.c"), "w") as f: f.write(_CALLERS_C)
+        libdir = os.path.dirname(m.LIB_PATH)
+        subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-pthread", os.path.join(tmp, "callers.c"), "-o", os.path.join(tmp, "libcallers.so"), "-L", libdir, "-lminaverify",
+                               "-Wl,-rpath," + libdir], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        helper = ctypes.CDLL(os.path.join(tmp, "libcallers.so")); helper.run_callers.restype = ctypes.c_long
+        nc = len(items)
+        c_pr = (ctypes.c_char_p * nc)(*[c[0] for c in items]); c_pl = (ctypes.c_size_t * nc)(*[len(c[0]) for c in items])
+        c_pu = (ctypes.c_char_p * nc)(*[c[1] for c in items]); c_ql = (ctypes.c_size_t * nc)(*[len(c[1]) for c in items])
+        rows = {}
+        for nt in thread_counts:
+            calls = per_thread * (2 if nt == 1 else 1)
+            assert helper.run_callers(nt, 2, nc, c_pr, c_pl, c_pu, c_ql) == 0
+            t0 = time.perf_counter()
+            bad = helper.run_callers(nt, calls, nc, c_pr, c_pl, c_pu, c_ql)
+            dt = time.perf_counter() - t0
+            assert bad == 0, "a valid proof was rejected"
+            rows[str(nt)] = {"caller_threads": nt, "calls": nt * calls, "proofs_per_s": nt * calls / dt, "ms_per_call_seen_by_a_caller": dt / calls * 1e3}
+        return {"entry_point": "mina_verify_state (= verify_mina_state_ffi's path): ONE serialized proof per call, pthread callers", "by_caller_threads": rows,
+                "note": "the reference's call shape; the batch entry points above are this library's addition (INTEGRATION.md)"}
+    except Exception as e:                                            # noqa: BLE001 -- a secondary leg (needs gcc on the box): never takes the line down
+        return {"error": repr(e)[:300]}
+
+
 class _Batch:
     """n serialized proofs (the fixture's four, tiled) as the pointer / length arrays of `mina_verify_state_batch`"""
     def __init__(self, lib, items, n):
@@ -560,7 +649,8 @@ def boundary_leg(m, devices: str, B: int, min_seconds: float = 2.0):
     c5_after = None
     if c5 is not None and search_cost and "error" not in search_cost:
         c5_after = c5_job.timed(1.0, min_calls=3)
-    res = {"value": single["value"], "unit": "proofs/s", "proofs_per_call": B, "ms_per_call": single["ms_per_call"], "calls_timed": single["calls"],
+    one_per_call = one_proof_per_call(m, items)
+    res = {"value": single["value"], "unit": "proofs/s", "proofs_per_call": B, "ms_per_call": single["ms_per_call"], "calls_timed": single["calls"], "one_proof_per_call": one_per_call,
            "bytes_per_proof": len(job.P[0]) + len(job.Q[0]), "host_threads": int(os.environ.get("MINA_HOST_THREADS", min((os.cpu_count() or 2) // 2, 64))), "usable_cores": usable_cores(),
            "two_caller_threads": two, "four_caller_threads": four, "one_bad_opening_per_call": search_cost, "one_call_of_65536": big, "c5_4096_per_call": c5, "c5_4096_per_call_after_culprit_searches": c5_after, "devices": devices,
            "entry_point": "mina_verify_state_batch (include/mina_verify.h): bincode MinaStateProof + MinaStatePubInputs bytes -> verdict bytes",
@@ -744,7 +834,9 @@ def main():
     # 20 lanes under 24 hardware queues (round 4 sweep, full mode, one MI355X): --steps 20: 10 lanes 247.5 k, 16: 245.9 k, 20: 262 - 267 k, 24: 250.5 k, 32: 248.2 k proofs/s;
     # --steps 80: 16 lanes 256.2 k, 20: 258.3 k, 24: 242.7 k, 32: 250.9 k (with 32 - 40 queues nothing gains: 20 lanes 258.1 k, 32 lanes 228 - 243 k)
     # at 16384 proofs per step (final build, --steps 40): 12 lanes 273.1 k (29 GiB of HBM in use), 16: 275.3 k (38 GiB), 20: 279.7 / 280.8 k (48 GiB), 24: 260.7 k (56 GiB)
-    ap.add_argument("--pipeline", type=int, default=20, help="internal stream lanes over which consecutive steps are issued")
+    # round 6: the three legs of a job run on streams of their own (mina_verify_tuning.dev_fork) and every kernel but the state hash raises its wave priority: 4 lanes fill the
+    # chip (same box, 16384 per step: 4 lanes 307 k at 13 GiB, 3: 304 k at 10 GiB, 5: 309 k, 8: 297 - 300 k; the round-5 form, one stream per job: 20 lanes 291 k at 50 GiB -- profiles/r06_dev_fork.md)
+    ap.add_argument("--pipeline", type=int, default=4, help="internal stream lanes over which consecutive steps are issued")
     ap.add_argument("--distinct-chains", type=int, default=0, help="distinct candidate chains in the batch (default 0: one per proof)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--mode", choices=("full", "kimchi", "prepared"), default="full",
@@ -828,6 +920,8 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
 
+    if os.environ.get("MINA_TUNE"):                            # experiments only (tools/dev_fork_sweep.sh): fields of mina_verify_tuning over the defaults; named in the line
+        m.lib.tune_from_string(os.environ["MINA_TUNE"])
     ctx = m.MinaContext(local_rank)
     for f in (0, 1):
         ctx.poseidon_set_params(f, m.poseidon_params.default_params_bytes(f))
@@ -858,7 +952,7 @@ def main():
     dj, dk, dtensors = device_jobs(m, hj, keep, kp, dev)
     ctx.state_jobs_prepare(LOG2_DOMAIN, NPUB)
     ctx.set_pipeline(args.pipeline)
-    nslots = max(args.pipeline, 1)
+    nslots = max(args.pipeline, 8)                             # output slots: one per call in flight (the C5 leg below runs 6 lanes)
     d_out = [torch.zeros(B + 4, dtype=torch.int32, device=dev) for _ in range(nslots)]
     torch.cuda.synchronize()
     it = [0]
@@ -985,6 +1079,93 @@ def main():
         assert verdicts_ok(n_sus)
         sustained = {"steps": n_sus, "seconds": el_s, "value": args.gpus * n_sus * B / el_s, "unit": "proofs/s"}
 
+    def set_tune(extra=""):                                    # the library's defaults + $MINA_TUNE (experiments) + `extra`, between calls only
+        spec = ",".join(x for x in (os.environ.get("MINA_TUNE", ""), extra) if x)
+        m.lib.verify_configure_ex(None)
+        if spec: m.lib.tune_from_string(spec)
+
+    def sub_job(Bx):                                           # the first Bx proofs of the resident job
+        djx = m.lib.StateJobs(); ctypes.memmove(ctypes.byref(djx), ctypes.byref(dj), ctypes.sizeof(m.lib.StateJobs)); djx.batch = Bx
+        keepx = [djx]
+        if kp is not None:
+            dkx = m.lib.KimchiProofs(); ctypes.memmove(ctypes.byref(dkx), ctypes.byref(dk), ctypes.sizeof(m.lib.KimchiProofs)); dkx.batch = Bx
+            djx.kimchi = ctypes.addressof(dkx); keepx.append(dkx)
+        return djx, keepx
+
+    # latency of ONE call alone on the chip, by call size (the legs of the job forked, wave priorities on: what a caller without a pipeline sees); measured here, while the
+    # process holds only the pipeline's streams -- a process with more streams than hardware queues stays slower for life
+    call_latency_ms, call_latency_by_size = None, None
+    if not args.no_probes and not (dist_on and share_gpu):
+        ctx.set_pipeline(1)
+        call_latency_by_size = {}
+        for Bx in sorted({B, 8192, 4096, 1024}, reverse=True):
+            if Bx > B: continue
+            djx, keepx = sub_job(Bx)
+            o = d_out[0]
+            for _ in range(2):
+                ctx.state_job_batch_dev(djx, o.data_ptr(), o.data_ptr() + 4 * Bx)
+            ctx.synchronize(); t1 = time.perf_counter()
+            for _ in range(4):
+                ctx.state_job_batch_dev(djx, o.data_ptr(), o.data_ptr() + 4 * Bx); ctx.synchronize()
+            call_latency_by_size[str(Bx)] = (time.perf_counter() - t1) / 4 * 1e3
+            got = o.cpu().numpy()
+            assert got[:Bx].tolist() == [1] * Bx and got[Bx:Bx + 4].tolist() == [1, 0, 1, 0]
+        call_latency_ms = call_latency_by_size[str(B)]
+        ctx.set_pipeline(args.pipeline)
+        for o in d_out:
+            o.zero_()
+        torch.cuda.synchronize()
+
+    prof_iso = {}
+    # Ranks that share ONE GPU have no "nothing else on the GPU": in about every second shared run an isolated launch took 500 - 1000 ms for 35 (the other process's queues are
+    # time-sliced in by the hardware scheduler whether or not they hold work) and C2 read 740 - 2500 checks/s for 13 000.  Those keys are left out of a shared-GPU line.
+    iso_legs = not args.no_probes and not (dist_on and share_gpu)
+    # These legs run HERE, before anything creates more streams: a process holding more streams than the runtime has hardware queues (24 here: GPU_MAX_HW_QUEUES) keeps
+    # every later launch slower -- the same isolated state-hash launch read 33.4 ms after 4 forked lanes (20 streams) and 39.5 ms after 6 (30), for the rest of the process
+    # (tools/probes/iso_after_fork.py).  The C5 leg (6 lanes) and the 16-lane C2 leg come after.
+    # the candidate dominant kernels with nothing else on the GPU: one lane, HIP events on that lane's stream
+    c2_single = None
+    if iso_legs:
+        ctx.set_pipeline(1)
+        set_tune("dev_fork=0")                                    # ONE stream: nothing runs beside the kernel being timed (forked, a lone job's hashes share the chip with its chain)
+        for _ in range(2):
+            step()
+        ctx.synchronize()
+        ctx.prof_enable(mask)
+        for _ in range(6):
+            step()
+        prof_iso = ctx.prof_read()
+        ctx.prof_enable(0)
+        set_tune()
+        pre8, sg8 = make_accumulators(ctx, 8, 4242 + rank)
+        d_pre8 = torch.from_numpy(pre8.reshape(-1)).to(dev); d_sg8 = torch.from_numpy(sg8.reshape(-1)).to(dev)
+        d_v8 = torch.zeros(8, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()                                  # torch's stream is asynchronous to the library's lanes: the zeroes must land before a kernel writes verdicts
+        # BASELINE C2 as written (/root/reference README.md:534-544: "a single Kimchi proof batch_verify, 2^16-base Vesta IPA MSM"): ONE accumulator check, alone on the chip,
+        # one call at a time -- wall time per call (launch overhead and the host's wait included), the sum of its kernels' stage events, the MSM's algorithmic GB/s
+        one = lambda: ctx.accumulator_check_dev(CURVE_VESTA, ACC_K, 1, d_pre8.data_ptr(), d_sg8.data_ptr(), 0, d_v8.data_ptr())
+        for _ in range(8):
+            one()
+        ctx.synchronize()
+        ctx.prof_enable(0x7ff)                                    # every MSM and b_poly stage (ctx.h ProfStage 0 .. 10)
+        n1 = 64; t1 = time.perf_counter()
+        for _ in range(n1):
+            one(); ctx.synchronize()
+        wall_us = (time.perf_counter() - t1) / n1 * 1e6
+        p1 = ctx.prof_read(); ctx.prof_enable(0)
+        assert int(d_v8.cpu().numpy()[0]) == 1
+        kern_us_1 = sum(ms for _, ms in p1.values()) / n1 * 1e3
+        msm_bytes = 65536 * (64 + 32) + 96
+        c2_single = {"wall_us": wall_us, "kernel_us_sum": kern_us_1, "stages_us": {k: v[1] / n1 * 1e3 for k, v in p1.items() if v[0]},
+                     "algorithmic_bytes": msm_bytes, "algorithmic_GBps_wall": msm_bytes / wall_us / 1e3, "algorithmic_GBps_kernels": msm_bytes / kern_us_1 / 1e3 if kern_us_1 else None,
+                     "frac_of_hbm_peak_kernels": msm_bytes / kern_us_1 / 1e3 / HBM_PEAK_GBPS if kern_us_1 else None, **msm_single_traffic(kern_us_1),
+                     "note": "ONE un-folded 2^16 Vesta accumulator check per call, one call at a time, nothing else on the GPU (mina_accumulator_check_dev, batch 1: prechallenges -> "
+                             "b_poly coefficients -> fixed-base MSM in its one-MSM task form -> comparison); kernel_us_sum = HIP-event stage times on the lane's stream"}
+        ctx.set_pipeline(args.pipeline)
+        for o in d_out:
+            o.zero_()
+        torch.cuda.synchronize()
+
     # BASELINE config C5 as written: 4096 state proofs in total, split over the ranks (strong scaling) -- 4096 / N per rank and step
     c5 = None
     if B >= 4096 // max(world, 1) and 4096 % max(world, 1) == 0 and not args.no_probes:
@@ -997,6 +1178,8 @@ def main():
         def step5():
             o = d_out[it[0] % nslots]; it[0] += 1
             ctx.state_job_batch_dev(dj5, o.data_ptr(), o.data_ptr() + 4 * B5)
+        lanes5 = min(max(args.pipeline, 6), 8)                     # a 4096-proof job is 3316 hash waves and 196-wave chain kernels: more of them in flight (4 lanes 235 k, 5 - 6: 254 k)
+        ctx.set_pipeline(lanes5)
         for _ in range(nslots):
             step5()
         ctx.synchronize()
@@ -1009,7 +1192,8 @@ def main():
         last = d_out[(it[0] - 1) % nslots].cpu().numpy()
         assert last[:B5].tolist() == [1] * B5 and last[B5:B5 + 4].tolist() == [1, 0, 1, 0], "C5 verdicts must be ACCEPT"
         c5 = {"value": n5 * 4096 / el5, "unit": "proofs/s", "proofs_total_per_step": 4096, "proofs_per_rank_per_step": B5, "steps": n5, "scaling": "strong",
-              "ms_per_step": el5 / n5 * 1e3}
+              "ms_per_step": el5 / n5 * 1e3, "pipeline_lanes": lanes5}
+        ctx.set_pipeline(args.pipeline)
         for o in d_out:
             o.zero_()
         torch.cuda.synchronize()
@@ -1046,33 +1230,9 @@ def main():
                 try: barrier()
                 except Exception: pass                             # noqa: BLE001
 
-    # the candidate dominant kernels with nothing else on the GPU: one lane, HIP events on that lane's stream
-    prof_iso = {}
-    # Ranks that share ONE GPU have no "nothing else on the GPU": in about every second shared run an isolated launch took 500 - 1000 ms for 35 (the other process's queues are
-    # time-sliced in by the hardware scheduler whether or not they hold work) and C2 read 740 - 2500 checks/s for 13 000.  Those keys are left out of a shared-GPU line.
-    iso_legs = not args.no_probes and not (dist_on and share_gpu)
     if iso_legs:
-        ctx.set_pipeline(1)
-        for _ in range(2):
-            step()
-        ctx.synchronize()
-        ctx.prof_enable(mask)
-        for _ in range(6):
-            step()
-        prof_iso = ctx.prof_read()
-        ctx.prof_enable(0)
-        # latency of one call (B jobs) alone
-        torch.cuda.synchronize(); t1 = time.perf_counter()
-        for _ in range(4):
-            step()
-        ctx.synchronize()
-        call_latency_ms = (time.perf_counter() - t1) / 4 * 1e3
         # secondary key (round 1's headline, BASELINE config C2): 8 independent 2^16 Vesta accumulator checks per call, 16 lanes
         ctx.set_pipeline(16)
-        pre8, sg8 = make_accumulators(ctx, 8, 4242 + rank)
-        d_pre8 = torch.from_numpy(pre8.reshape(-1)).to(dev); d_sg8 = torch.from_numpy(sg8.reshape(-1)).to(dev)
-        d_v8 = torch.zeros(8, dtype=torch.int32, device=dev)
-        torch.cuda.synchronize()                                  # torch's stream is asynchronous to the library's lanes: the zeroes must land before a kernel writes verdicts
         c2 = lambda: ctx.accumulator_check_multi_dev(CURVE_VESTA, ACC_K, 8, d_pre8.data_ptr(), d_sg8.data_ptr(), d_v8.data_ptr())
         for _ in range(32):
             c2()
@@ -1086,7 +1246,6 @@ def main():
         assert d_v8.cpu().numpy().tolist() == [1] * 8
         ctx.set_pipeline(1)
     else:
-        call_latency_ms = None
         c2_rate = None
         c2_power = None
     if dist_on:
@@ -1123,7 +1282,10 @@ def main():
             "launcher": os.environ.get("MINA_BENCH_LAUNCHER", "torch.distributed.run" if dist_on else "none"),
             "ms_per_step": elapsed / args.steps * 1e3,
             "call_latency_ms": call_latency_ms,
+            "call_latency_ms_by_size": call_latency_by_size,
+            "joules_per_proof": (power["socket_power_w_avg"] * elapsed / (args.steps * B)) if power and not (dist_on and share_gpu) else None,
             "power": power,
+            "toolchain": toolchain(),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32x8-montgomery (255-bit prime fields, integer)", "data": "synthetic",
             "config": {"workload": "C3: full Proof-of-State job per proof -- 17 protocol-state hashes (chain of 16 + bridge tip) vs public inputs + linkage, "
@@ -1155,9 +1317,10 @@ def main():
             "sustained": sustained,
             "c5_4096_total_strong": c5,
             "exchange_variant_8e2": exchange,
+            "one_proof_per_call": (boundary or {}).get("one_proof_per_call") if isinstance(boundary, dict) else None,
             "boundary_bytes_to_bools": boundary,
             "c4_account_256": c4,
-            "c2_accumulator_only": {"value": c2_rate, "unit": "accumulator checks/s",
+            "c2_accumulator_only": {"value": c2_rate, "unit": "accumulator checks/s", "single_check": c2_single,
                                     "note": "BASELINE config C2 alone (round 1's headline): un-folded 2^16-base Vesta IPA accumulator checks, 8 per call, 16 lanes",
                                     # the metric's second half ("MSM HBM GB/s vs peak"): one check = one 2^16-base MSM; algorithmic bytes = bases + scalars
                                     "power": c2_power,
@@ -1179,7 +1342,7 @@ def main():
             got = perms * 3 * 55 * MADS_PER_LANE_ROUND / (kern_us * 1e-6)
             waves = -(-nstates // 21)                          # 21 sponges per wave64 (3 lanes each)
             out["roofline"] = {"bound": "valu_int32", "kernel": "pstate_hash_kernel", "achieved": got / 1e12, "peak": pure_peak / 1e12, "unit": "T limb-MAC/s", "frac": got / pure_peak,
-                               "frac_of_own_mix_ceiling": got / peak, "traffic": hbm_view["traffic"], "hbm": hbm_view,
+                               "frac_of_own_mix_ceiling": got / peak, **clock_normalised(got / pure_peak, power), "traffic": hbm_view["traffic"], "hbm": hbm_view,
                                "states_per_launch": nstates, "avg_launch_us": kern_us, "avg_launch_us_in_timed_region": ovl.get("pstate_hash"),
                                "limb_macs_per_launch": perms * 3 * 55 * MADS_PER_LANE_ROUND,
                                "peak_source": f"measured pure v_mad_u64_u32 stream, {PURE_MAC_ISSUE_CYCLES} cycles at 2.4 GHz per wave64 instruction per SIMD, 8 waves per SIMD "
@@ -1190,7 +1353,7 @@ def main():
                                        "`hbm`: the metric's 'HBM GB/s vs peak' view of the same launch; `traffic` = its PMC bytes"}
             out["roofline_valu"] = {"bound": "issue rate of the kernel's own instruction mix (774 multiply-accumulates + ~150 shifts / masks per lane-round), measured: "
                                              f"{MAD_ISSUE_CYCLES} cycles at 2.4 GHz per wave64 multiply-accumulate per SIMD", "kernel": "pstate_hash_kernel",
-                                    "achieved": got / 1e12, "peak": peak / 1e12, "unit": "T limb-MAC/s", "frac": got / peak, "frac_of_pure_mac_peak": got / pure_peak, "pure_mac_peak": pure_peak / 1e12,
+                                    "achieved": got / 1e12, "peak": peak / 1e12, "unit": "T limb-MAC/s", "frac": got / peak, **clock_normalised(got / peak, power), "frac_of_pure_mac_peak": got / pure_peak, "pure_mac_peak": pure_peak / 1e12,
                                     "permutations_per_launch": perms,
                                     "limb_macs_per_permutation": 3 * 55 * MADS_PER_LANE_ROUND,
                                     "waves_per_launch": waves, "waves_per_simd_in_launch": waves / CHIP_SIMDS, "resident_waves_per_simd": 5,
@@ -1203,6 +1366,8 @@ def main():
                                "frac": None, "traffic": hbm_view["traffic"], "hbm": hbm_view, "note": "no isolated kernel timing in this run (--no-probes without the stage events, or ranks that share one GPU)"}
         if args.mode == "full" and not share_gpu:            # (ranks sharing one GPU: a step's time is not one GPU's)
             out["step_valu"] = step_valu(out["ms_per_step"], B)  # the pipelined step as a whole against instruction issue (secondary; `roofline` stays the dominant kernel's)
+        if out.get("step_valu"):
+            out["step_valu"].update(clock_normalised(out["step_valu"]["frac"], power))
         if not args.no_cpu_baseline and args.gpus == 1:       # the CPU leg is timed at N = 1 only (rank 0)
             out["cpu_baseline"] = cpu_baseline(baseline_sample)
             if isinstance(out["cpu_baseline"], dict) and "folded" in out["cpu_baseline"]:

@@ -400,7 +400,9 @@ int mina_state_job_batch_dev(mina_ctx *ctx, const mina_state_jobs *jobs, void *d
  * mina_bridge_amd/sharded.py ShardedStateJob.  d_verdicts[b] = the per-proof checks only.  batch >= 2, with_ipa and with_accumulator set.
  * Soundness of the sum over shards: here the opening fold runs with rho_b = rand_base^(b + 1), sigma_b = sg_rand_base^(b + 1) -- NOT upstream's ^b, whose first
  * proof carries coefficient 1: partial sums of G shards are added, and G coefficient-1 proofs could cancel each other's discrepancies.  Every shard draws its own
- * rand_base / sg_rand_base from a CSPRNG after its proofs are fixed, and EVERY acc_rho[b] (b = 0 included) must be such a draw too. */
+ * rand_base / sg_rand_base from a CSPRNG after its proofs are fixed.  The accumulator fold no longer depends on the caller for that (round 6): the library multiplies
+ * every acc_rho[b] by ONE scalar it draws from the OS CSPRNG per call (both sides of the shard's check scale by it), so upstream's rho_0 = 1 or fixed test
+ * randomisers cannot re-open the cancellation between shards; random acc_rho (b = 0 included) remain the recommendation. */
 int mina_state_job_fold_dev(mina_ctx *ctx, const mina_state_jobs *jobs, void *d_verdicts, void *d_flags, void *d_ipa_scalars, void *d_ipa_point,
                             void *d_acc_scalars, void *d_acc_point);
 /* Host-buffer form: one upload, the pipeline, one download; on a folded failure the failing range is cut into four parts ($MINA_SEARCH_FAN) that are
@@ -678,6 +680,13 @@ typedef struct mina_verify_tuning {
                                             3 = as 1, and in the multi-MSM form the buckets STAY on 29-bit limbs through the 2-D bucket reduction; 0: the 8 x 32-bit law */
     uint32_t search_ctx;           /* 1     the culprit search of a failed chunk runs on a SECOND context of its device (its own lanes, workspaces and lock): valid traffic keeps
                                             flowing beside it.  0 = round 4: on the device's one context, with the device drained and its lock held for the length of the search */
+    /* device-resident jobs (mina_state_job_batch_dev): the three independent legs of ONE job -- protocol-state hashes / wrap-proof chain / accumulator -- on streams
+     * of their own, joined before the verdict kernel, so that a few jobs in flight fill the chip (round 6; until then one stream per job and ~20 jobs in flight) */
+    uint32_t dev_fork;             /* 1     bit 0: fork the legs (pipelines of up to 8 lanes); bit 1: the chain's and the hashes' streams get disjoint CU masks (`dev_chain_cus`);
+                                            bit 2: the wrap-proof chain's stream is created with the highest stream priority, the hashes' with the lowest */
+    uint32_t dev_chain_cus;        /* 96    CUs of the chain's mask when bit 1 of dev_fork is set */
+    uint32_t dev_piece_waves;      /* 0     a forked job's state hashes are launched in pieces of this many waves; 0 = 6144 / pipeline lanes (whole for a lone lane), 0xffffffff = never */
+    uint32_t dev_hash_lds_kb;      /* 0     > 0: KiB of LDS a state-hash workgroup reserves (33 = four waves per SIMD instead of five: room for a wave of another leg) */
 } mina_verify_tuning;
 void mina_verify_tuning_default(mina_verify_tuning *out);
 int mina_verify_tuning_get(mina_verify_tuning *out);

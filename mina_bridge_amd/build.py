@@ -14,7 +14,7 @@ OBJ_DIR = os.path.join(HERE, "build")
 
 SOURCES = ["host_core.hip", "api_core.hip", "api_msm.hip", "api_srs.hip", "api_sponge.hip", "api_ipa.hip", "api_wire.hip", "api_consensus.hip", "api_state.hip", "api_kimchi.hip", "api_verify.hip", "api_account.hip", "api_shard.hip", "api_pickles.hip", "api_loaders.hip"]
 HEADERS = ["fp.cuh", "fp29.cuh", "ec.cuh", "ec29.cuh", "msm.cuh", "groupmap.cuh", "sponge.cuh", "lagrange.cuh", "ctx.h", "wire_state.h", "wire_proof.h", "wire_account.h", "polish.h", "loaders_text.h", "wire_pub.h", "kimchi_dev.cuh", "bpoly_mfma.cuh", "poseidon_tables.inc"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result"] + os.environ.get("MINA_BUILD_EXTRA_FLAGS", "").split()   # experiments: -DMB_CHAIN_PRIO=0
 
 
 def _hipcc() -> str:

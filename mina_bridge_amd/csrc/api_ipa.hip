@@ -101,7 +101,7 @@ ipa_prepare_kernel(IpaShape sh, FieldK kb, FieldK ks, const PoseidonParams *__re
                    uint32_t *__restrict__ out_chals /* b*k*8 canonical */, uint32_t *__restrict__ out_sigma /* b*8 canonical */,
                    uint32_t *__restrict__ bad_input /* zeroed by the host; set to 1 on a malformed point */,
                    uint32_t *__restrict__ xfer /* PHASE 1 writes, PHASE 2 reads: b * IPA_XFER_WORDS */,
-                   uint32_t *__restrict__ shared_sc /* b * nshared * 8 canonical, or null */, uint32_t *__restrict__ shared_off /* nshared list offsets */) {
+                   uint32_t *__restrict__ shared_sc /* b * nshared * 8 canonical, or null */, uint32_t *__restrict__ shared_off /* nshared list offsets */) { mb_wave_prio();
     constexpr int FB = (CURVE == CURVE_PALLAS) ? FIELD_FP : FIELD_FQ;
     constexpr int FS = (CURVE == CURVE_PALLAS) ? FIELD_FQ : FIELD_FP;
     bool writer_; const uint32_t b = coop_sponge_index<LANES>(writer_);
@@ -262,7 +262,7 @@ ipa_prepare_kernel(IpaShape sh, FieldK kb, FieldK ks, const PoseidonParams *__re
 // mod r does not care about the representation).  One block per shared entry.
 template <int FS>
 __global__ void __launch_bounds__(256)
-ipa_shared_tail_kernel(uint32_t batch, uint32_t nsh, uint32_t per, const uint32_t *__restrict__ shared_sc, uint32_t *__restrict__ scalars) {
+ipa_shared_tail_kernel(uint32_t batch, uint32_t nsh, uint32_t per, const uint32_t *__restrict__ shared_sc, uint32_t *__restrict__ scalars) { mb_wave_prio();
     __shared__ fe_t red[256];
     const uint32_t q = blockIdx.x, tid = threadIdx.x;
     fe_t acc = fe_zero();
@@ -274,7 +274,7 @@ ipa_shared_tail_kernel(uint32_t batch, uint32_t nsh, uint32_t per, const uint32_
 }
 // the culprit search re-checks slices of the rows: give the proofs [lo, lo + cnt) their own scalars of the shared points back
 __global__ void ipa_shared_restore_kernel(uint32_t lo, uint32_t cnt, uint32_t nsh, uint32_t per, const uint32_t *__restrict__ shared_off,
-                                          const uint32_t *__restrict__ shared_sc, uint32_t *__restrict__ scalars) {
+                                          const uint32_t *__restrict__ shared_sc, uint32_t *__restrict__ scalars) { mb_wave_prio();
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (size_t)cnt * nsh * 8) return;
     const uint32_t w = (uint32_t)(gid & 7u), q = (uint32_t)((gid >> 3) % nsh); const size_t b = lo + (gid >> 3) / nsh;
@@ -284,7 +284,7 @@ __global__ void ipa_shared_restore_kernel(uint32_t lo, uint32_t cnt, uint32_t ns
 // U_b = to_group(t_b) for the split transcript: one lane per proof, t in Montgomery form from the hand-over buffer
 template <int FB>
 __global__ void __launch_bounds__(64)
-ipa_to_group_kernel(uint32_t batch, uint32_t per, FieldK kb, const uint32_t *__restrict__ xfer, affine_t *__restrict__ out_points) {
+ipa_to_group_kernel(uint32_t batch, uint32_t per, FieldK kb, const uint32_t *__restrict__ xfer, affine_t *__restrict__ out_points) { mb_wave_prio();
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= batch) return;
     const fe_t t = load_fe<FB>(xfer + (size_t)b * IPA_XFER_WORDS + 26);
@@ -294,7 +294,7 @@ ipa_to_group_kernel(uint32_t batch, uint32_t per, FieldK kb, const uint32_t *__r
 // verdict[0] = 1 iff  A + sign * B == identity  (sign = +1: A == -B ; sign = -1: A == B)
 template <int F>
 __global__ void xyzz_compare_kernel(const xyzz_t *__restrict__ a, const xyzz_t *__restrict__ b, int negate_b, uint32_t *__restrict__ verdict,
-                                    const uint32_t *__restrict__ bad_input = nullptr) {
+                                    const uint32_t *__restrict__ bad_input = nullptr) { mb_wave_prio();
     if (threadIdx.x || blockIdx.x) return;
     if (bad_input && *bad_input) { *verdict = 0u; return; }
     xyzz_t A = *a, B = *b;
@@ -309,7 +309,7 @@ __global__ void xyzz_compare_kernel(const xyzz_t *__restrict__ a, const xyzz_t *
 // any malformed point raises the batch's flag (the folded verdict is then 0 and the caller falls back to per-proof checks)
 template <int F>
 __global__ void points_to_mont_checked_kernel(uint32_t n, const uint32_t *__restrict__ in_words, FieldK kb, affine_t *__restrict__ out,
-                                              uint32_t *__restrict__ bad_input) {
+                                              uint32_t *__restrict__ bad_input) { mb_wave_prio();
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     bool ok = true;
@@ -339,6 +339,18 @@ __global__ void xyzz_eq_affine_kernel(const xyzz_t *__restrict__ a, const uint32
 // exchange variant: the shard's folded check is decided by the caller; here only "this shard held no malformed point"
 __global__ void fold_export_flag_kernel(const uint32_t *__restrict__ malformed, uint32_t *__restrict__ verdict) { if (threadIdx.x == 0) verdict[0] = malformed[0] ? 0u : 1u; }
 
+// out[i] = in[i] * lambda (canonical words in and out; lambda by value: no upload, no synchronisation)
+struct Words8 { uint32_t v[8]; };
+template <int F>
+__global__ void scale_words_kernel(uint32_t n, FieldK fk, const uint32_t *__restrict__ in, Words8 lambda, uint32_t *__restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fe_t a, l;
+    for (int j = 0; j < 8; ++j) { a.v[j] = in[(size_t)i * 8 + j]; l.v[j] = lambda.v[j]; }
+    const fe_t r = fe_from_mont<F>(fe_mul<F>(fe_to_mont<F>(a, fk.r2), fe_to_mont<F>(l, fk.r2)));
+    for (int j = 0; j < 8; ++j) out[(size_t)i * 8 + j] = r.v[j];
+}
+
 int mb_accumulator_check_dev(mina_ctx *c, int curve, uint32_t k, size_t batch, const uint32_t *d_prechal,
                                  const uint32_t *d_sg_words, const uint32_t *d_rho, uint32_t *d_verdict) {
     SrsState &s = c->srs[curve];
@@ -347,6 +359,20 @@ int mb_accumulator_check_dev(mina_ctx *c, int curve, uint32_t k, size_t batch, c
     const int FS = scalar_field_of(curve), FB = base_field_of(curve);
     const uint32_t n = 1u << k;
     int rc;
+    if (c->fold_export && batch > 1) {
+        // The exchange variant ADDS the shards' partial sums, so no proof of any shard may carry a coefficient an adversary can predict: the opening leg draws its
+        // own powers (pow_first), and until round 5 this leg trusted the caller's acc_rho (a caller following upstream's rho_0 = 1, or fixed test randomisers,
+        // re-opened the +t / -t cancellation between shards).  Now every acc_rho[b] is multiplied by ONE scalar this call draws from the OS CSPRNG:
+        // both sides of the shard's check scale by it, so a good shard stays good, and the cross-shard sum is a combination with G unknown coefficients.
+        Words8 lam; uint8_t raw[32];
+        if (!mb_secure_random(raw, 32)) return fail(MINA_ERR_STATE, "no entropy for the shard's accumulator randomiser");
+        raw[31] &= 0x3f; raw[0] |= 1;                                  // < 2^254 < p, and not zero
+        memcpy(lam.v, raw, 32);
+        if ((rc = c->L->acc_rho_scaled.ensure(batch * 32))) return rc;
+        DISPATCH_FIELD(FS, { scale_words_kernel<F_><<<cdiv(batch, 64), 64, 0, c->L->stream>>>((uint32_t)batch, c->fk[F_], d_rho, lam, c->L->acc_rho_scaled.as<uint32_t>()); });
+        HIPC(hipGetLastError());
+        d_rho = c->L->acc_rho_scaled.as<uint32_t>();
+    }
     if ((rc = c->L->ipa_chals.ensure(batch * k * 32))) return rc;
     if ((rc = c->L->ipa_folded.ensure((size_t)n * 32))) return rc;
     if ((rc = c->L->ipa_xyzz_a.ensure(sizeof(xyzz_t)))) return rc;

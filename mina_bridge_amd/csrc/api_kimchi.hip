@@ -81,7 +81,7 @@ template <int LANES>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(LANES == 3 ? 4 : 1, 8)))   // 3-lane form: the four waves per SIMD it had before the signed-digit forms (+ 6 VGPRs)
 kimchi_fq_kernel(uint32_t batch, uint32_t n_prev, FieldK kb, FieldK ks, const PoseidonParams *__restrict__ pp_b, const PoseidonParams *__restrict__ pp_s,
                  const KimchiIndexDev *__restrict__ ix, KimchiIn in, KimchiOut out, fe_t *__restrict__ xf, uint32_t *__restrict__ bad_input, uint32_t nblk,
-                 const fe_t *__restrict__ pf_digest /* or null: role 1 computes it */, uint32_t pf_stride) {
+                 const fe_t *__restrict__ pf_digest /* or null: role 1 computes it */, uint32_t pf_stride) { mb_wave_prio();
     constexpr int FB = FIELD_FP, FS = FIELD_FQ;                 // Pallas: base Fp, scalar Fq
     bool writer; const uint32_t role = blockIdx.x / nblk, b = coop_role_item<LANES>(blockIdx.x % nblk, writer);       // one role per wave
     if (b >= batch) return;
@@ -127,7 +127,7 @@ kimchi_fq_kernel(uint32_t batch, uint32_t n_prev, FieldK kb, FieldK ks, const Po
 // wave runs a second pass (inversion included) for two of its eight lanes.
 template <int CH>
 __global__ void __launch_bounds__(64)
-kimchi_pub_kernel(uint32_t batch, uint32_t npub, FieldK ks, const KimchiIndexDev *__restrict__ ix, KimchiIn in, fe_t *__restrict__ xf, uint32_t *__restrict__ bad_input) {
+kimchi_pub_kernel(uint32_t batch, uint32_t npub, FieldK ks, const KimchiIndexDev *__restrict__ ix, KimchiIn in, fe_t *__restrict__ xf, uint32_t *__restrict__ bad_input) { mb_wave_prio();
     constexpr int FS = FIELD_FQ;
     const uint32_t gid = blockIdx.x * 64 + threadIdx.x, b = gid >> 3, ln = gid & 7u;
     if (b >= batch) return;
@@ -165,7 +165,7 @@ kimchi_pub_kernel(uint32_t batch, uint32_t npub, FieldK ks, const KimchiIndexDev
 
 template <int LANES>
 __global__ void __launch_bounds__(64)
-kimchi_fr_kernel(uint32_t batch, FieldK ks, const PoseidonParams *__restrict__ pp_s, KimchiIn in, fe_t *__restrict__ xf, uint32_t *__restrict__ bad_input) {
+kimchi_fr_kernel(uint32_t batch, FieldK ks, const PoseidonParams *__restrict__ pp_s, KimchiIn in, fe_t *__restrict__ xf, uint32_t *__restrict__ bad_input) { mb_wave_prio();
     constexpr int FS = FIELD_FQ;
     bool writer; const uint32_t b = coop_sponge_index<LANES>(writer);
     if (b >= batch) return;
@@ -187,7 +187,7 @@ kimchi_fr_kernel(uint32_t batch, FieldK ks, const PoseidonParams *__restrict__ p
 // one lane per proof; the interpreter's stack and cache live in LDS (kimchi_dev.cuh)
 __global__ void __launch_bounds__(64)
 kimchi_scalar_kernel(uint32_t batch, uint32_t n_prev, FieldK ks, const KimchiIndexDev *__restrict__ ix, const KimchiToken *__restrict__ toks,
-                     const fe_t *__restrict__ lits, KimchiIn in, KimchiOut out, fe_t *__restrict__ xf, uint32_t *__restrict__ bad_input) {
+                     const fe_t *__restrict__ lits, KimchiIn in, KimchiOut out, fe_t *__restrict__ xf, uint32_t *__restrict__ bad_input) { mb_wave_prio();
     constexpr int FS = FIELD_FQ;
     __shared__ uint32_t lds[KC_SLOTS * 8 * 64];
     const uint32_t b = blockIdx.x * 64 + threadIdx.x;
@@ -240,7 +240,7 @@ kimchi_scalar_kernel(uint32_t batch, uint32_t n_prev, FieldK ks, const KimchiInd
 // checked by the fq stage (a malformed one already failed the batch).  Only the host-buffer form (`mina_kimchi_to_batch`, which
 // returns the rows) runs this: the verifier hands the 8 (point, scalar) pairs to the opening check's MSM instead (IpaExpand)
 __global__ void __launch_bounds__(64)
-kimchi_ftcomm_kernel(uint32_t batch, uint32_t n_prev, FieldK kb, const KimchiIndexDev *__restrict__ ix, KimchiIn in, KimchiOut out, const fe_t *__restrict__ xf) {
+kimchi_ftcomm_kernel(uint32_t batch, uint32_t n_prev, FieldK kb, const KimchiIndexDev *__restrict__ ix, KimchiIn in, KimchiOut out, const fe_t *__restrict__ xf) { mb_wave_prio();
     constexpr int FB = FIELD_FP;
     const uint32_t gid = blockIdx.x * 64 + threadIdx.x, b = gid >> 3, j = gid & 7u;
     if (b >= batch) return;
@@ -262,7 +262,7 @@ kimchi_ftcomm_kernel(uint32_t batch, uint32_t n_prev, FieldK kb, const KimchiInd
 // the rows of the commitment list that are copies: recursion accumulators, the public-input commitment, then the 43 columns
 // z, 6 selectors (index), 15 w, 15 coefficients (index), 6 sigma (index).  Row n_prev + 1 (ft) belongs to the ftcomm stage.
 __global__ void __launch_bounds__(256)
-kimchi_rows_kernel(uint32_t batch, uint32_t n_prev, const KimchiIndexDev *__restrict__ ix, KimchiIn in, uint32_t *__restrict__ comms) {
+kimchi_rows_kernel(uint32_t batch, uint32_t n_prev, const KimchiIndexDev *__restrict__ ix, KimchiIn in, uint32_t *__restrict__ comms) { mb_wave_prio();
     const uint32_t ncomms = n_prev + 2 + KC_COLS;
     const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (gid >= (size_t)batch * ncomms * 16) return;

@@ -296,7 +296,7 @@ __device__ __forceinline__ void chal_words(const uint32_t *p, uint64_t &lo, uint
 __device__ __forceinline__ fe_t u128_fe(const uint32_t *p) { fe_t a = fe_zero(); a.v[0] = p[0]; a.v[1] = p[1]; a.v[2] = p[2]; a.v[3] = p[3]; return a; }
 
 __global__ void __launch_bounds__(256)
-pickles_expand_kernel(uint32_t batch, FieldK kp, FieldK kq, PicklesIn in, fe_t *__restrict__ xe) {
+pickles_expand_kernel(uint32_t batch, FieldK kp, FieldK kq, PicklesIn in, fe_t *__restrict__ xe) { mb_wave_prio();
     const uint32_t per = 4 + 16 + 16 * in.n_old + 30;
     const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (gid >= (size_t)batch * per) return;
@@ -321,7 +321,7 @@ pickles_expand_kernel(uint32_t batch, FieldK kp, FieldK kq, PicklesIn in, fe_t *
 template <int LANES>
 __global__ void __launch_bounds__(64)
 pickles_digest_kernel(uint32_t batch, FieldK kp, FieldK kq, const PoseidonParams *__restrict__ pp_p, const PoseidonParams *__restrict__ pp_q,
-                      const PicklesIndexDev *__restrict__ ix, PicklesIn in, fe_t *__restrict__ xe, uint32_t *__restrict__ ok_out, uint32_t nblk) {
+                      const PicklesIndexDev *__restrict__ ix, PicklesIn in, fe_t *__restrict__ xe, uint32_t *__restrict__ ok_out, uint32_t nblk) { mb_wave_prio();
     bool writer; const uint32_t role = blockIdx.x / nblk, b = coop_role_item<LANES>(blockIdx.x % nblk, writer);       // one role per wave
     if (b >= batch) return;
     fe_t *x = xe + (size_t)b * px_stride(in.n_old);
@@ -363,7 +363,7 @@ pickles_digest_kernel(uint32_t batch, FieldK kp, FieldK kq, const PoseidonParams
 
 template <int LANES>
 __global__ void __launch_bounds__(64)
-pickles_tick_kernel(uint32_t batch, FieldK kp, const PoseidonParams *__restrict__ pp_p, PicklesIn in, fe_t *__restrict__ xe, uint32_t *__restrict__ ok_out) {
+pickles_tick_kernel(uint32_t batch, FieldK kp, const PoseidonParams *__restrict__ pp_p, PicklesIn in, fe_t *__restrict__ xe, uint32_t *__restrict__ ok_out) { mb_wave_prio();
     constexpr int F = FIELD_FP;
     bool writer; const uint32_t b = coop_sponge_index<LANES>(writer);
     if (b >= batch) return;
@@ -387,7 +387,7 @@ pickles_tick_kernel(uint32_t batch, FieldK kp, const PoseidonParams *__restrict_
 
 __global__ void __launch_bounds__(64)
 pickles_scalar_kernel(uint32_t batch, FieldK kp, FieldK kq, const PicklesIndexDev *__restrict__ ix, const KimchiToken *__restrict__ toks, const fe_t *__restrict__ lits,
-                      PicklesIn in, const fe_t *__restrict__ xe, uint32_t *__restrict__ pub_out, uint32_t *__restrict__ ok_out) {
+                      PicklesIn in, const fe_t *__restrict__ xe, uint32_t *__restrict__ pub_out, uint32_t *__restrict__ ok_out) { mb_wave_prio();
     constexpr int F = FIELD_FP;
     __shared__ uint32_t lds[KC_SLOTS * 8 * 64];
     const uint32_t b = blockIdx.x * 64 + threadIdx.x;

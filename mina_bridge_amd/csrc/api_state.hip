@@ -120,7 +120,7 @@ __global__ void pstate_chain_check_kernel(uint32_t batch, const uint32_t *__rest
 // public-input commitment h - A as canonical affine words (16 per proof, zeros = infinity): feeds ipa_prepare_kernel's override slot
 template <int FB>
 __global__ void __launch_bounds__(64)
-pubcomm_finish16_kernel(uint32_t batch, FieldK kb, const affine_t *__restrict__ h, const xyzz_t *__restrict__ a, uint32_t *__restrict__ out_words) {
+pubcomm_finish16_kernel(uint32_t batch, FieldK kb, const affine_t *__restrict__ h, const xyzz_t *__restrict__ a, uint32_t *__restrict__ out_words) { mb_wave_prio();
     const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= batch) return;
     xyzz_t t = a[m];
@@ -188,11 +188,11 @@ static int pstate_hash_dev(mina_ctx *c, size_t n, const uint32_t *d_records, con
         const size_t per = (size_t)c->hash_piece_waves * 21;
         for (size_t lo = 0; lo < n; lo += per) {
             const size_t cnt = std::min(per, n - lo);
-            mb::pstate_hash_kernel<FIELD_FP, 3><<<cdiv(coop_threads<3>(cnt), 256), 256, 0, c->L->stream>>>((uint32_t)cnt, c->fk[FIELD_FP], pp, salts, d_records + lo * MINA_PSTATE_SLOTS * 8,
+            mb::pstate_hash_kernel<FIELD_FP, 3><<<cdiv(coop_threads<3>(cnt), 256), 256, c->hash_lds_bytes, c->L->stream>>>((uint32_t)cnt, c->fk[FIELD_FP], pp, salts, d_records + lo * MINA_PSTATE_SLOTS * 8,
                                                                                                              d_nfields + lo, d_hashes + lo * 8, d_bodies ? d_bodies + lo * 8 : nullptr);
         }
     } else
-        mb::pstate_hash_kernel<FIELD_FP, 3><<<cdiv(coop_threads<3>(n), 256), 256, 0, c->L->stream>>>((uint32_t)n, c->fk[FIELD_FP], pp, salts, d_records, d_nfields, d_hashes, d_bodies);
+        mb::pstate_hash_kernel<FIELD_FP, 3><<<cdiv(coop_threads<3>(n), 256), 256, c->hash_lds_bytes, c->L->stream>>>((uint32_t)n, c->fk[FIELD_FP], pp, salts, d_records, d_nfields, d_hashes, d_bodies);
     HIPC(hipGetLastError());
     return MINA_OK;
 }
@@ -469,6 +469,50 @@ int mb_state_jobs_on_lane(mina_ctx *c, const mina_state_jobs *j, uint32_t *d_ver
     return MINA_OK;
 }
 
+// The legs of a device-resident job on streams of their own (mina_verify_tuning.dev_fork).  One stream per job needs ~20 jobs in flight to
+// fill the chip: the wrap-proof chain is ~15 dependent kernels of 781 waves (16 384 proofs in the 3-lane form) on 1024 SIMDs, and nothing of the SAME job may run
+// beside them -- 47.6 GiB of workspaces and 71 ms of call latency for the headline.  The three legs of a job are independent until the verdict kernel (the same
+// split the boundary makes per chunk, api_verify.hip setup_legs): pipeline lane i keeps the fork / join and the verdict kernel, its helper lanes
+// MB_DEV_HELPER0 + 3 i + {0, 1, 2} run the wrap-proof chain, the accumulator check and the state hashes.  Streams are created once per context under the tuning
+// then in force (a stream keeps its CU mask / priority for life); a pinned lane (mina_ctx_pin_lane: the caller orders its own work on ONE stream) never forks.
+static int dev_fork_lanes(mina_ctx *c, Lane **LI, Lane **LA, Lane **LS) {
+    const mina_verify_tuning tu = mb_tune();
+    const int li = (int)(c->L - c->lanes);
+    if (!(tu.dev_fork & 1u) || c->pinned >= 0 || c->nlanes > MB_DEV_FORK_MAX || li < 0 || li >= MB_DEV_FORK_MAX || c->fold_export) return MINA_OK;
+    Lane *h = &c->lanes[MB_DEV_HELPER0 + 3 * li];
+    if (!h[0].stream || !h[1].stream || !h[2].stream) {
+        const uint32_t mode = c->dev_fork_made ? c->dev_fork_made : tu.dev_fork;
+        c->dev_fork_made = mode;
+        int ncu = 0; (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, c->device);
+        int prio_lo = 0, prio_hi = 0; (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);      // numerically lower = higher priority
+        auto make = [&](Lane &ln, bool chain, bool masked, int prio) -> int {
+            if (ln.stream) return MINA_OK;
+            if (masked && tu.dev_chain_cus > 0 && tu.dev_chain_cus < (uint32_t)ncu && ncu <= 256) {
+                // bit i of a mask = CU i / 8 of XCD i % 8 (tools/probes/cumask_probe.hip): the first dev_chain_cus bits are the same CUs of every XCD
+                uint32_t mk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (uint32_t b2 = 0; b2 < (uint32_t)ncu; ++b2) if ((b2 < tu.dev_chain_cus) == chain) mk[b2 >> 5] |= 1u << (b2 & 31);
+                if (hipExtStreamCreateWithCUMask(&ln.stream, 8, mk) == hipSuccess) return MINA_OK;
+                (void)hipGetLastError(); ln.stream = nullptr;
+            }
+            if (prio_lo != prio_hi && (mode & 4u)) HIPC(hipStreamCreateWithPriority(&ln.stream, hipStreamNonBlocking, prio));
+            else HIPC(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
+            return MINA_OK;
+        };
+        int rc;
+        if ((rc = make(h[0], true, (mode & 2u) != 0, prio_hi)) || (rc = make(h[1], true, false, (prio_lo + prio_hi) / 2)) || (rc = make(h[2], false, (mode & 2u) != 0, prio_lo))) return rc;
+    }
+    *LI = &h[0]; *LA = &h[1]; *LS = &h[2];
+    // The hashes of a forked job go out in pieces, so that the jobs in flight together ask for ~6 state-hash waves per SIMD (five fit beside nothing else, 96 VGPRs):
+    // measured with the wave priorities on (lanes x piece grid at 4096 / 8192 / 16 384 proofs per call, profiles/r06_dev_fork.md) the best piece is ~6144 / lanes waves
+    // whatever the call size -- 2 lanes 3072, 3: 2048, 4: 1536, 6: 1024 -- and a lone call is best left whole.
+    uint32_t piece = tu.dev_piece_waves;
+    if (piece == 0 && c->nlanes >= 2) piece = 6144u / (uint32_t)c->nlanes;
+    if (piece == 0xffffffffu) piece = 0;
+    c->hash_piece_waves = piece;
+    c->hash_lds_bytes = tu.dev_hash_lds_kb * 1024u;
+    return MINA_OK;
+}
+
 extern "C" int mina_state_job_batch_dev(mina_ctx *c, const mina_state_jobs *jobs, void *d_verdicts, void *d_flags) {
     int rc = check_jobs(c, jobs);
     if (rc) return rc;
@@ -476,7 +520,11 @@ extern "C" int mina_state_job_batch_dev(mina_ctx *c, const mina_state_jobs *jobs
     if (!c->have_state_salts && jobs->with_states) return fail(MINA_ERR_STATE, "call mina_state_jobs_prepare first");
     HIPC(hipSetDevice(c->device));
     c->next_lane();
-    return mb_state_jobs_on_lane(c, jobs, (uint32_t *)d_verdicts, (uint32_t *)d_flags, nullptr, nullptr, nullptr, nullptr);
+    Lane *LI = nullptr, *LA = nullptr, *LS = nullptr;
+    if ((rc = dev_fork_lanes(c, &LI, &LA, &LS))) return rc;
+    rc = mb_state_jobs_on_lane(c, jobs, (uint32_t *)d_verdicts, (uint32_t *)d_flags, LI, LA, nullptr, LS);
+    c->hash_piece_waves = 0; c->hash_lds_bytes = 0;
+    return rc;
 }
 
 // SURVEY.md 8e.2 for the WHOLE job (the `north_star` variant: "a single reduce of partial sums over xGMI"): this shard's proofs go through every stage of the

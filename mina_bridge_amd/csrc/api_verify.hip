@@ -646,15 +646,30 @@ int run_device_shape(Device &D, const CallIn &in, const std::vector<size_t> &idx
         if (ch.counted) D.inflight.fetch_sub(1);
     };
 
-    // device side of a chunk's slot, before anything is queued on it (idempotent).  Caller holds D.mu.
+    // D.mu, taken with the tables of this call's (domain, npub) prepared.  A re-prepare (another index since the last call) frees and rewrites the Lagrange tables --
+    // buffers a culprit search on the view context D.sc may be reading through its aliases, holding search_mu only (round 5 re-prepared under
+    // D.mu alone).  So the re-prepare takes search_mu as well, FIRST (lock order g_mu, search_mu, mu: the installers', the fallback's); the common path -- already
+    // prepared -- never touches search_mu and never waits for a search.
+    const uint32_t prep_key = ((sh.k ? sh.k : 15u) << 16) | (sh.statements ? 40u : 0u);          // the Lagrange table belongs to (domain, npub): another index -> prepare again
+    auto lock_prepared = [&](std::unique_lock<std::mutex> &lk) -> int {
+        for (;;) {
+            lk = std::unique_lock<std::mutex>(D.mu);
+            if (D.prepared_npub == prep_key) return MINA_OK;
+            lk.unlock();
+            std::lock_guard<std::mutex> sl(D.search_mu);
+            std::lock_guard<std::mutex> dl(D.mu);
+            if (D.prepared_npub == prep_key) continue;
+            HIPC(hipSetDevice(c->device));
+            int rc = mina_state_jobs_prepare(c, sh.k ? sh.k : 15, sh.statements ? 40 : 0);
+            if (rc) return rc;
+            D.prepared_npub = prep_key;
+        }
+    };
+    // device side of a chunk's slot, before anything is queued on it (idempotent).  Caller holds D.mu through lock_prepared.
     auto setup_slot = [&](Chunk &ch) -> int {
         HIPC(hipSetDevice(c->device));
         int rc;
-        const uint32_t prep_key = ((sh.k ? sh.k : 15u) << 16) | (sh.statements ? 40u : 0u);      // the Lagrange table belongs to (domain, npub): another index -> prepare again
-        if (D.prepared_npub != prep_key) {
-            if ((rc = mina_state_jobs_prepare(c, sh.k ? sh.k : 15, sh.statements ? 40 : 0))) return rc;
-            D.prepared_npub = prep_key;
-        }
+        if (D.prepared_npub != prep_key) return fail(MINA_ERR_STATE, "slot set up without the prepared tables");
         Slot &S = *ch.slot;
         if ((rc = S.dev.ensure(lay.total + Layout::out_bytes(lay.cap)))) return rc;
         if (!S.ev) HIPC(hipEventCreateWithFlags(&S.ev, hipEventDisableTiming));
@@ -721,9 +736,9 @@ int run_device_shape(Device &D, const CallIn &in, const std::vector<size_t> &idx
         if (donor == SIZE_MAX) { ch.skipped = true; return MINA_OK; }                         // nothing of this chunk can pass
         for (size_t b = 0; b < ch.n; ++b) if (!(ch.hb[b].proof_ok && ch.hb[b].shape)) copy_proof_half(lay, hbase, b, donor);
         if (!ch.randomised) return fail(MINA_ERR_STATE, "no entropy for the folding randomisers");
-        std::lock_guard<std::mutex> lk(D.mu);
+        std::unique_lock<std::mutex> lk;
         int rc;
-        if ((rc = setup_slot(ch)) || (rc = setup_legs(ch))) return rc;
+        if ((rc = lock_prepared(lk)) || (rc = setup_slot(ch)) || (rc = setup_legs(ch))) return rc;
         Slot &S = *ch.slot;
         Lane &L = c->lanes[ch.slot_ix];
         lane_forms();
@@ -752,8 +767,8 @@ int run_device_shape(Device &D, const CallIn &in, const std::vector<size_t> &idx
             { std::unique_lock<std::mutex> lk(ch.mu); ch.cv.wait(lk, [&] { return ch.sub_left[r].load() == 0; }); }
             const size_t lo = r * ch.sub, hi = std::min(ch.n, lo + ch.sub);
             for (size_t b = lo; b < hi; ++b) if (!ch.hb[b].parsed) clear_states_half(lay, hbase, b);      // malformed (or of another shape / to be patched): defined records, verdict 0 through `precheck`
-            std::lock_guard<std::mutex> lk(D.mu);
-            { int src; if ((src = setup_slot(ch)) || (src = setup_legs(ch))) return src; }
+            std::unique_lock<std::mutex> lk;
+            { int src; if ((src = lock_prepared(lk)) || (src = setup_slot(ch)) || (src = setup_legs(ch))) return src; }
             Lane &L = c->lanes[ch.slot_ix];
             if (g_timing && !ch.queued) HIPC(hipEventRecord(S.tev[0], own_up ? S.up : L.stream));
             ch.queued = true;

@@ -107,7 +107,7 @@ struct Lane {
     DevBuf tmp_a, tmp_b, tmp_c, tmp_d;       // staging for the host-buffer entry points
     PinnedBuf host_stage;                    // pinned host side of the big H2D blobs (synchronous entry points only)
     DevBuf bp_ltab, bp_htab, bp_partial, bp_ldig, bp_hdig, bp_colsum;
-    DevBuf ipa_chals, ipa_folded, ipa_xyzz_a, ipa_xyzz_b, ipa_points, ipa_scalars, ipa_sigma, ipa_in_a, ipa_in_b, ipa_in_c, ipa_verdict, ipa_xfer, ipa_shared, ipa_shared_off;
+    DevBuf ipa_chals, ipa_folded, ipa_xyzz_a, ipa_xyzz_b, ipa_points, ipa_scalars, ipa_sigma, ipa_in_a, ipa_in_b, ipa_in_c, ipa_verdict, ipa_xfer, ipa_shared, ipa_shared_off, acc_rho_scaled /* exchange variant: the caller's acc_rho times the shard's own CSPRNG scalar */;
     DevBuf st_ok, st_hashes, st_pub_xyzz, st_pubcomm, st_flags, st_in, st_verdicts;   // Proof-of-State job (api_state.hip)
     DevBuf kc_state, kc_pos, kc_cip, kc_pts, kc_v, kc_u, kc_comms, kc_xfer, kc_pch, pk_xe, pk_pub, pk_ok;                  // kimchi to_batch output rows (api_kimchi.hip)
     void release_all() {
@@ -115,7 +115,7 @@ struct Lane {
         DevBuf *all[] = {&w.scalars, &w.points, &w.points29, &w.ekey, &w.eval, &w.eoff, &w.count, &w.start, &w.task_start, &w.rem_pos, &w.rem_bucket, &w.info, &w.sorted, &w.partial, &w.heavy, &w.order, &w.redo, &w.ghist, &w.stage,
                          &w.buckets, &w.buckets29, &w.seg_bad, &w.red_r, &w.red_ws, &w.red2_r, &w.red2_w, &w.set_total, &w.out_words, &w.out_xyzz, &tmp_a, &tmp_b, &tmp_c, &tmp_d,
                          &bp_ltab, &bp_htab, &bp_partial, &bp_ldig, &bp_hdig, &bp_colsum, &ipa_chals, &ipa_folded, &ipa_xyzz_a, &ipa_xyzz_b, &ipa_points, &ipa_scalars,
-                         &ipa_sigma, &ipa_in_a, &ipa_in_b, &ipa_in_c, &ipa_verdict, &ipa_xfer, &ipa_shared, &ipa_shared_off,
+                         &ipa_sigma, &ipa_in_a, &ipa_in_b, &ipa_in_c, &ipa_verdict, &ipa_xfer, &ipa_shared, &ipa_shared_off, &acc_rho_scaled,
                          &st_ok, &st_hashes, &st_pub_xyzz, &st_pubcomm, &st_flags, &st_in, &st_verdicts,
                          &kc_state, &kc_pos, &kc_cip, &kc_pts, &kc_v, &kc_u, &kc_comms, &kc_xfer, &kc_pch, &pk_xe, &pk_pub, &pk_ok};
         for (DevBuf *b : all) b->release();
@@ -123,7 +123,9 @@ struct Lane {
     }
 };
 static constexpr int MB_PIPE_LANES = 32;                   // lanes a caller may pipeline over (mina_ctx_set_pipeline) = the fan-out of the culprit search
-static constexpr int MB_MAX_LANES = MB_PIPE_LANES + 3 * 16;  // + the helper lanes of the boundary's 16 slots (api_verify.hip: wrap-proof / accumulator / state legs of slot s on lanes 32 + 3 s ..)
+static constexpr int MB_DEV_FORK_MAX = 8;                  // pipelines of up to this many lanes fork the legs of a device-resident job (mina_verify_tuning.dev_fork)
+static constexpr int MB_DEV_HELPER0 = MB_PIPE_LANES + 3 * 16;   // helper lanes of pipeline lane i: MB_DEV_HELPER0 + 3 i .. (wrap-proof chain / accumulator / state hashes)
+static constexpr int MB_MAX_LANES = MB_DEV_HELPER0 + 3 * MB_DEV_FORK_MAX;  // pipeline lanes + the helper lanes of the boundary's 16 slots (api_verify.hip: legs of slot s on lanes 32 + 3 s ..) + those of the forked device-resident jobs
 enum : int { MB_SALT_PSTATE_BODY = 0, MB_SALT_PSTATE, MB_SALT_ACCOUNT, MB_SALT_ZKAPP_ACCOUNT, MB_SALT_ZKAPP_URI, MB_SALT_SIDE_LOADED_VK, MB_N_PREFIX_SALTS };
 
 struct mina_ctx {
@@ -148,6 +150,8 @@ struct mina_ctx {
     bool legs_forked = false;        // the job being queued runs its legs on separate streams (api_state.hip)
     size_t state_hashes_early = 0;   // states of the next job's protocol-state leg already queued on its lane (mb_state_hashes_early), consumed by mb_state_jobs_on_lane
     uint32_t hash_piece_waves = 0;   // > 0: the protocol-state hashes of a job are launched in pieces of this many waves (api_state.hip pstate_hash_dev)
+    uint32_t hash_lds_bytes = 0;     // > 0: dynamic LDS a 3-lane state-hash workgroup reserves, to cap its waves per SIMD beside the other legs of a forked job (mina_verify_tuning.dev_hash_lds_kb)
+    uint32_t dev_fork_made = 0;      // the dev_fork value the helper lanes' streams were created under (streams keep their mask / priority for life)
     // SURVEY.md 8e.2 (one exchange step over several GPUs): while set, the folded checks of a job do NOT run their fixed-base MSM and comparison -- they hand out
     // this shard's folded scalar vector and the 17-word record of its variable-base partial sum instead (mina_state_job_fold_dev); device pointers
     struct FoldExport { uint32_t *ipa_scalars = nullptr, *ipa_point = nullptr, *acc_scalars = nullptr, *acc_point = nullptr; } *fold_export = nullptr;

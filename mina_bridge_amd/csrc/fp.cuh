@@ -19,6 +19,24 @@
 #define MB_HD inline
 #endif
 
+// Wave priority of every kernel of a job that is NOT the chip-filling state hash (round 6).  The legs of a device-resident job run on streams of their own
+// (api_state.hip dev_fork_lanes); where a wave of the wrap-proof chain -- ~15 dependent kernels of <= 1 wave per SIMD -- shares a SIMD with the four or five
+// resident state-hash waves, the instruction arbiter takes waves oldest first and the chain ran at a fifth of its speed: a lone 16 384-proof call took as long
+// forked as on one stream (68.7 against 70.5 ms; timeline: profiles/r06_dev_fork.md).  `s_setprio` raises the issuing wave's priority at the arbiter (0 = the
+// default every other wave keeps, 3 = highest): the chain keeps its own pace and the hashes take the issue slots it leaves.  -DMB_CHAIN_PRIO=0 builds without.
+#ifndef MB_CHAIN_PRIO
+#define MB_CHAIN_PRIO 2
+#endif
+#if defined(__HIPCC__)
+__device__ __forceinline__ void mb_wave_prio() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (MB_CHAIN_PRIO) __builtin_amdgcn_s_setprio(MB_CHAIN_PRIO);
+#endif
+}
+#else
+static inline void mb_wave_prio() {}      // the host-only builds of the ThreadSanitizer tier (tests/fuzz): kernels are stubs
+#endif
+
 namespace mb {
 
 enum : int { FIELD_FP = 0, FIELD_FQ = 1 };     // Fp: Pallas base / Vesta scalar.  Fq: Vesta base / Pallas scalar

@@ -91,7 +91,7 @@ lagrange_finish_kernel(uint32_t n, FieldK kb, const uint32_t *__restrict__ n_inv
 // One lane per problem; 17 canonical words each (x || y, infinity flag).
 template <int FB>
 __global__ void __launch_bounds__(64)
-pubcomm_finish_kernel(uint32_t batch, FieldK kb, const affine_t *__restrict__ h, const xyzz_t *__restrict__ a, uint32_t *__restrict__ out_words) {
+pubcomm_finish_kernel(uint32_t batch, FieldK kb, const affine_t *__restrict__ h, const xyzz_t *__restrict__ a, uint32_t *__restrict__ out_words) { mb_wave_prio();
     const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= batch) return;
     xyzz_t t = a[m];
@@ -139,7 +139,7 @@ __global__ void lagrange_digit_table_kernel(uint32_t n_pts, uint32_t stride, Fie
 // batches (5 scalars = 160 additions per lane at npub = 40), 64 for small ones (one scalar = 32 additions per lane, then a 6-level sum)
 template <int F, int LPP>
 __global__ void __launch_bounds__(64)
-pubcomm_direct_kernel(uint32_t batch, uint32_t npub, FieldK fk, const affine_t *__restrict__ digits, const uint32_t *__restrict__ pub, xyzz_t *__restrict__ out) {
+pubcomm_direct_kernel(uint32_t batch, uint32_t npub, FieldK fk, const affine_t *__restrict__ digits, const uint32_t *__restrict__ pub, xyzz_t *__restrict__ out) { mb_wave_prio();
     const uint32_t gid = blockIdx.x * 64 + threadIdx.x, b = gid / LPP, l = gid % LPP;
     const bool live = b < batch;
     xyzz_t acc = xyzz_inf();
@@ -175,7 +175,7 @@ pubcomm_direct_kernel(uint32_t batch, uint32_t npub, FieldK fk, const affine_t *
 template <int F, int LPP>
 __global__ void __launch_bounds__(64)
 pubcomm_direct29_kernel(uint32_t batch, uint32_t npub, FieldK fk, const affine_t *__restrict__ digits, const affine_t *__restrict__ digits29, const uint32_t *__restrict__ pub,
-                        xyzz_t *__restrict__ out) {
+                        xyzz_t *__restrict__ out) { mb_wave_prio();
 #if defined(__HIP_DEVICE_COMPILE__)
     const uint32_t gid = blockIdx.x * 64 + threadIdx.x, b = gid / LPP, l = gid % LPP;
     const bool live = b < batch;
