@@ -671,6 +671,11 @@ __global__ void msm_table29s_kernel(size_t n, const affine_t *__restrict__ in, f
     out[i] = t;
 }
 
+// timing probe only (tools/probes: -DMB_GATHER_MASK=0x3ffu makes every gather of the 29-bit accumulate kernels land in the first 64 KiB of the table -- WRONG sums, the
+// same instruction stream: what the kernels would run at if the gathers cost nothing; profiles/r06_k1.md)
+#ifndef MB_GATHER_MASK
+#define MB_GATHER_MASK 0x7fffffffu
+#endif
 // K1t-b on 29-bit limbs (ec29.cuh): the same lanes, the same order of additions, points gathered from the 2^261-domain twin of the window table (TAB = 1: 64-byte
 // records of 8 x 32 words, converted and negated here) or from the pre-split table (TAB = 2: tab29_t); the bucket leaves in the 8 x 32 form.  8-MSM launch alone on
 // the GPU: 575 us against 685 us for the 8 x 32 kernel (profiles/r04_k1.md); the residency cap makes no difference here (2 / 3 / 4 / 8 waves per SIMD: 12.5 - 12.6 k
@@ -709,14 +714,14 @@ msm_accumulate_bucket29_kernel(uint32_t nb_total, uint32_t nb_prob, const uint32
                 }
             } else {
                 const affine_t *__restrict__ points29 = (const affine_t *)points29_;
-                affine_t p = load_affine(points29 + (ref & 0x7fffffffu));
+                affine_t p = load_affine(points29 + (ref & MB_GATHER_MASK));
 #pragma unroll 1
                 for (uint32_t e = 0; e < cnt && exact; ++e) {
                     const bool is_inf = aff_is_inf(p);               // infinity is (0, 0): the predicate of the 8 x 32 kernels and of the redo path
                     const fe29_t px = fe29_from_words(p.x), py = fe29_from_words(p.y);
                     const uint32_t cur = ref;
                     ref = ref_n;
-                    if (e + 1 < cnt) p = load_affine(points29 + (ref & 0x7fffffffu));      // the words are dead once converted: the next gather lands in their registers
+                    if (e + 1 < cnt) p = load_affine(points29 + (ref & MB_GATHER_MASK));      // the words are dead once converted: the next gather lands in their registers
                     if (e + 2 < cnt) ref_n = sorted[beg + e + 2];
                     if (is_inf) continue;
                     exact = xyzz29_add_affine<F>(acc, inf, px, py, (cur >> 31) != 0, m32);                                      // a negative digit adds (x, p - y) (y != 0 on these curves)
@@ -800,7 +805,7 @@ msm_accumulate29_kernel(uint32_t nb_total, const uint32_t *__restrict__ start, c
         }
     } else {
         const affine_t *__restrict__ points29 = (const affine_t *)points29_;
-        affine_t p = load_affine(points29 + (refs[0] & 0x7fffffffu));
+        affine_t p = load_affine(points29 + (refs[0] & MB_GATHER_MASK));
 #pragma unroll 1
         for (uint32_t e = 0; e < cnt && exact; ++e) {
             const bool is_inf = aff_is_inf(p);                   // infinity is (0, 0): the same predicate as the 8 x 32 kernels
@@ -808,7 +813,7 @@ msm_accumulate29_kernel(uint32_t nb_total, const uint32_t *__restrict__ start, c
             const uint32_t ref = refs[0];
 #pragma unroll
             for (int q = 0; q + 1 < MSM_TASK_LEN; ++q) refs[q] = refs[q + 1];
-            if (e + 1 < cnt) p = load_affine(points29 + (refs[0] & 0x7fffffffu));
+            if (e + 1 < cnt) p = load_affine(points29 + (refs[0] & MB_GATHER_MASK));
             if (is_inf) continue;
             exact = xyzz29_add_affine<F>(acc, inf, px, py, (ref >> 31) != 0, m32);
         }

@@ -46,7 +46,10 @@ class DeviceBackend:
         self.host_syncs = 0                                          # full device / stream synchronisations issued through this backend (the exchange step's budget: tests read it)
 
     def ordered(self):
-        """context manager: pin the library to its lane 0 and make that lane's stream torch's current stream"""
+        """context manager: pin the library to its lane 0 and make that lane's stream torch's current stream.
+        Needs EXCLUSIVE use of the context for the length of the scope: the pin is state of the context, and another thread's `_dev` call during the scope would be
+        forced onto lane 0 as well.  Tensors allocated inside belong to the external stream's pool of torch's caching allocator: one that leaves the scope
+        must be handed to the caller's stream with `record_stream` (ShardedStateJob.verify does), or the allocator may reuse its block while that stream still reads it."""
         import contextlib
         torch = self.torch
         if torch.device(self.dev).type != "cuda":
@@ -269,18 +272,27 @@ class ShardedStateJob:
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         self.cpu_collectives = dist.get_backend(group) == "gloo"          # gloo moves host tensors (the CPU / shared-GPU tests); RCCL moves HBM to HBM
         self.torch = torch
+        self.coll_streams = []                                            # raw stream handle each collective of the last calls was queued on (GPU tests)
+        self.test_delay_cycles = 0                                        # test hook: a spin kernel of this many cycles on the ordering stream AHEAD of the shard's job
 
     def _coll(self, t):
         return t.cpu() if self.cpu_collectives else t
 
+    def _note_stream(self):
+        # which stream the collective is queued on (tests: it must be the context's pinned lane, or nothing orders it against the library's kernels)
+        if self.torch.device(self.dev).type == "cuda":
+            self.coll_streams.append(int(self.torch.cuda.current_stream(self.dev).cuda_stream))
+
     def _all_to_all(self, t):
         import torch.distributed as dist
+        self._note_stream()
         src = self._coll(t).contiguous(); out = self.torch.empty_like(src)
         dist.all_to_all_single(out, src, group=self.group)
         return out.to(self.dev)
 
     def _all_gather(self, t):
         import torch.distributed as dist
+        self._note_stream()
         src = self._coll(t).contiguous(); outs = [self.torch.empty_like(src) for _ in range(self.world)]
         dist.all_gather(outs, src, group=self.group)
         return [o.to(self.dev) for o in outs]
@@ -297,7 +309,13 @@ class ShardedStateJob:
         m, ma = n // G, na // G
         scope = be.ordered() if hasattr(be, "ordered") else None
         import contextlib
+        on_gpu = torch.device(self.dev).type == "cuda"
+        caller_stream = torch.cuda.current_stream(self.dev) if on_gpu else None
         with (scope if scope is not None else contextlib.nullcontext()):
+            if self.test_delay_cycles and on_gpu:
+                # everything below is queued at once by the host; with the stream held up here the library's kernels START late -- a collective on any other stream
+                # would read the shard's vectors before they exist (tests/test_sharded_state_job.py: ordering, not luck)
+                torch.cuda._sleep(int(self.test_delay_cycles))
             local, flags, ipa_s, ipa_p, acc_s, acc_p = be.state_job_fold(job, batch, self.k, self.acc_k)
             recv_p, recv_v = self._all_to_all(ipa_s), self._all_to_all(acc_s)
             mine_p, mine_v = be.sum_rows(1, G, m, recv_p), be.sum_rows(0, G, ma, recv_v)                        # Pallas scalars live in Fq, Vesta scalars in Fp
@@ -322,5 +340,6 @@ class ShardedStateJob:
             batch_ok = bits == 7
             self.last = {"wellformed": bool(bits & 1), "opening_fold_ok": bool(bits & 2), "accumulator_fold_ok": bool(bits & 4), "flags": fl.cpu().tolist() if not batch_ok else [[1, 0, 1, 0]] * G}
             if batch_ok:
+                if on_gpu and scope is not None: local.record_stream(caller_stream)      # allocated on the ordering stream, used by the caller on its own
                 return local, True
         return be.state_job_plain(job, batch), False

@@ -61,6 +61,15 @@ def test_opposite_discrepancies_on_the_first_proofs_of_two_shards_do_not_cancel(
     assert outs[0]["verdicts"] == [0] * 4 and outs[1]["verdicts"] == [0] * 4, "each shard's own folded check fails too: nothing is accepted"
 
 
+def test_opposite_accumulator_discrepancies_under_upstreams_rho0_do_not_cancel():
+    """sg + T first in shard A, sg - T first in shard B, acc_rho[0] = 1 on both (upstream's convention): until round 6 the accumulator leg of the
+    exchange variant folded with the caller's coefficients and the two discrepancies cancelled in the exchanged total.  The library now scales a shard's acc_rho by
+    a CSPRNG scalar of its own per call: the exchanged accumulator fold fails on every rank, and each shard's own check fails too."""
+    outs = run_ranks(2, 4, "opposite_acc_sg_fixed_rho")
+    assert all(o["batch_ok"] is False and o["detail"]["accumulator_fold_ok"] is False for o in outs), outs
+    assert outs[0]["verdicts"] == [0] * 4 and outs[1]["verdicts"] == [0] * 4 and all(o["plain_flags"][2] == 0 for o in outs)
+
+
 def test_exchange_variant_on_the_real_backend_with_one_rank():
     """a box with ONE GPU still has RCCL: a 1-rank group runs `ShardedStateJob` with device tensors through nccl collectives ON THE CONTEXT'S PINNED STREAM
     (torch ExternalStream) -- the code path of a real multi-GPU node (all_to_all_single / all_gather of HBM tensors, stream-ordered, one word read), which the
@@ -70,3 +79,15 @@ def test_exchange_variant_on_the_real_backend_with_one_rank():
     assert o["host_syncs"] == 0 and o["host_reads"] == 1, o
     (o,) = run_ranks(1, 6, "bad_opening_on_last_rank")
     assert o["backend"] == "nccl" and o["batch_ok"] is False and o["verdicts"] == [0] * 6, o
+
+
+def test_rccl_collectives_ride_the_pinned_lane_and_wait_for_a_delayed_job():
+    """VERDICT r05 next #5a, as far as one GPU allows: (1) every collective of the exchange step (2 x all_to_all_single, 1 x all_gather) is queued on the context's
+    pinned lane -- torch's current stream inside the scope IS `mina_ctx_stream` -- so the stream itself orders it behind the library's kernels; (2) ordering, not
+    luck: with ~0.2 s of spin queued on that stream AHEAD of the shard's job (the host has enqueued the collectives long before a single kernel of the job has
+    run) the exchanged partials are still the right ones: the batch verifies, and the call took at least the delay."""
+    (o,) = run_ranks(1, 6, "ok_delayed")
+    assert o["backend"] == "nccl" and o["batch_ok"] is True and o["verdicts"] == [1] * 6 == o["plain"], o
+    assert len(o["coll_streams"]) == 3 and o["ctx_stream"] != 0 and all(s_ == o["ctx_stream"] for s_ in o["coll_streams"]), (o["coll_streams"], o["ctx_stream"])
+    assert o["host_syncs"] == 0 and o["host_reads"] == 1, o
+    assert o["call_s"] > 0.1, f"the spin kernel did not hold the stream up ({o['call_s']:.3f} s): the test proves nothing"

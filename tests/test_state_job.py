@@ -146,6 +146,52 @@ def test_state_job_device_resident_and_pipelined(ctx_srs, oracle, small_jobs):
             ctx_srs.dev_free(p)
 
 
+@pytest.mark.parametrize("tune", [dict(dev_fork=0), dict(dev_fork=1), dict(dev_fork=1, dev_piece_waves=1, coop16_max=0, coop8_max=0), dict(dev_fork=1, dev_hash_lds_kb=33, coop16_max=0, coop8_max=0),
+                                  dict(dev_fork=3, dev_chain_cus=96), dict(dev_fork=5)])
+def test_state_job_dev_legs_forked_in_every_tuning(oracle, small_jobs, tune):
+    """round 6: the three legs of a device-resident job on streams of their own (mina_verify_tuning.dev_fork: plain / CU-masked / priority streams, the hashes in pieces --
+    coop*_max = 0 forces the wave-packed 3-lane form, the only one launched in pieces -- or with an LDS reservation) give the verdict words of the one-stream job, lane by
+    lane, with 1 and with 4 jobs in flight: all good; a state whose hash no longer matches fails ITS proof only; a changed public input fails the folded opening (flag 0);
+    another proof's accumulator commitment fails the folded accumulator check (flag 2).  A context of its own per tuning: streams keep their mask / priority for life."""
+    import mina_bridge_amd as m
+    from state_job_helpers import build_jobs, state_records
+    B = len(small_jobs)
+    variants = {"good": small_jobs}
+    j = [copy.deepcopy(x) for x in small_jobs]
+    j[0]["states"][7]["body"]["consensus_state"]["total_currency"] ^= 1
+    j[0]["records"], j[0]["nfields"] = state_records(j[0]["states"])
+    variants["bad_state"] = j
+    j = [copy.deepcopy(x) for x in small_jobs]; j[2]["pubs"][3] = (j[2]["pubs"][3] + 1) % (1 << 200)
+    variants["bad_opening"] = j
+    j = [copy.deepcopy(x) for x in small_jobs]; j[3]["acc_sg"] = small_jobs[4]["acc_sg"].copy()
+    variants["bad_accumulator"] = j
+    expect = {"good": ([1] * B, [1, 0, 1, 0]), "bad_state": ([0] + [1] * (B - 1), [1, 0, 1, 0]), "bad_opening": ([0] * B, [0, 0, 1, 0]), "bad_accumulator": ([0] * B, [1, 0, 0, 0])}
+    with m.lib.tuning(**tune):
+        c = m.MinaContext(0)
+        try:
+            for f in (0, 1):
+                c.poseidon_set_params(f, m.poseidon_params.default_params_bytes(f))
+            c.srs_create(0, 1 << 10); c.srs_create(1, 1 << 10)          # as smoke(): depth >= 2^k, 2^acc_k
+            c.state_jobs_prepare(SMALL["log2_domain"], SMALL["npub"])
+            dev = {name: c.state_jobs_to_device(build_jobs(m, jobs, SMALL["k"], SMALL["log2_domain"], SMALL["slot"], SMALL["acc_k"])) for name, jobs in variants.items()}
+            for lanes in (1, 4):
+                c.set_pipeline(lanes)
+                calls = [name for _ in range(2) for name in variants]                  # 8 calls back to back: with 4 lanes, 4 jobs of different kinds in flight
+                outs = [c.dev_malloc(4 * B + 16) for _ in calls]
+                for name, o in zip(calls, outs):
+                    c.state_job_batch_dev(dev[name][0], o, o + 4 * B)
+                c.synchronize()
+                for name, o in zip(calls, outs):
+                    w = c.dev_download(o, 4 * B + 16).view(np.uint32)
+                    assert (w[:B].tolist(), w[B:].tolist()) == expect[name], (tune, lanes, name, w.tolist())
+                    c.dev_free(o)
+            c.set_pipeline(1)
+            for d, ptrs in dev.values():
+                for p in ptrs: c.dev_free(p)
+        finally:
+            c.close()
+
+
 def test_state_job_full_size_c3(ctx_srs, oracle, srs_oracle):
     """BASELINE config C3 at full size: 17 states, 40 public inputs over the 2^15 wrap domain, k = 15 opening with 45 commitments
     and 2 points (committed oracle-minted fixture), 2^16 Vesta accumulator; B = 16 with one tampered proof"""
