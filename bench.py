@@ -966,7 +966,7 @@ def main():
         used = [d_out[(it[0] - 1 - i) % nslots] for i in range(min(last, nslots))]
         return all(o.cpu().numpy().tolist() == [1] * B + [1, 0, 1, 0] for o in used)
 
-    n_warm = max(args.warmup, nslots)                          # every lane allocates its workspace during warm-up
+    n_warm = max(args.warmup, args.pipeline, 1)                          # every lane allocates its workspace during warm-up
     for _ in range(n_warm):
         step()
     ctx.synchronize()

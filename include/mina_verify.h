@@ -686,7 +686,8 @@ typedef struct mina_verify_tuning {
                                             bit 2: the wrap-proof chain's stream is created with the highest stream priority, the hashes' with the lowest */
     uint32_t dev_chain_cus;        /* 96    CUs of the chain's mask when bit 1 of dev_fork is set */
     uint32_t dev_piece_waves;      /* 0     a forked job's state hashes are launched in pieces of this many waves; 0 = 6144 / pipeline lanes (whole for a lone lane), 0xffffffff = never */
-    uint32_t dev_hash_lds_kb;      /* 0     > 0: KiB of LDS a state-hash workgroup reserves (33 = four waves per SIMD instead of five: room for a wave of another leg) */
+    uint32_t dev_hash_lds_kb;      /* 0     KiB of LDS a forked job's state-hash workgroup reserves (33 = four waves per SIMD instead of five, 41 = three: room for the waves of the other legs);
+                                            0 = 41 for a lone lane, none with several lanes; 0xffffffff = never */
 } mina_verify_tuning;
 void mina_verify_tuning_default(mina_verify_tuning *out);
 int mina_verify_tuning_get(mina_verify_tuning *out);

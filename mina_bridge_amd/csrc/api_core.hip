@@ -73,6 +73,7 @@ int mb_ctx_create_view(mina_ctx *parent, mina_ctx **out) {
     if (!parent || !out) return fail(MINA_ERR_ARG, "null argument");
     int rc = mina_ctx_create(parent->device, out);
     if (rc) return rc;
+    (*out)->is_view = true;
     mb_ctx_refresh_view(*out, parent);
     return MINA_OK;
 }
@@ -93,7 +94,9 @@ void mb_ctx_refresh_view(mina_ctx *v, mina_ctx *p) {
     v->have_kimchi = p->have_kimchi; v->kimchi_log2 = p->kimchi_log2; memcpy(v->kimchi_digest, p->kimchi_digest, sizeof v->kimchi_digest); memcpy(v->kimchi_comms_host, p->kimchi_comms_host, sizeof v->kimchi_comms_host);
     v->pickles_index.alias(p->pickles_index); v->pickles_tokens.alias(p->pickles_tokens); v->pickles_literals.alias(p->pickles_literals);
     v->have_pickles_dev = p->have_pickles_dev; v->pickles_ms_valid = p->pickles_ms_valid;
-    v->step_host = p->step_host; v->step_host_free = nullptr;      // borrowed: the parent frees it
+    // borrowed: the parent frees it.  A host half the view had built for itself (step_of(view) before the parent had one) is freed first (it leaked)
+    if (v->step_host && v->step_host_free && v->step_host != p->step_host) v->step_host_free(v->step_host);
+    v->step_host = p->step_host; v->step_host_free = nullptr;
     v->state_salts.alias(p->state_salts); v->have_state_salts = p->have_state_salts;
 }
 

@@ -541,7 +541,7 @@ int mb_ipa_batch_check_dev(mina_ctx *c, int curve, mb::IpaShape sh, const mb::Ip
         if ((rc = L.ipa_xfer.ensure(batch * mb::IPA_XFER_WORDS * 4))) return rc;
         // second stream only for a context that runs ONE call at a time: with pipeline lanes in flight the other lanes fill the chip, and a
         // side stream per lane would make 2 x lanes streams share the 16 hardware queues (lanes then serialise behind each other's kernels)
-        const bool side = c->nlanes == 1 && tune.ipa_side_stream != 0;
+        const bool side = c->nlanes == 1 && tune.ipa_side_stream != 0 && !c->is_view;      // (a view context creates no streams: ctx.h)
         hipStream_t tg = L.stream;
         if (side) {
             if (!L.aux) { HIPC(hipStreamCreateWithFlags(&L.aux, hipStreamNonBlocking)); HIPC(hipEventCreateWithFlags(&L.ev_fork, hipEventDisableTiming)); HIPC(hipEventCreateWithFlags(&L.ev_join, hipEventDisableTiming)); }

@@ -107,12 +107,14 @@ static int run_msm(mina_ctx *c, const MsmShape &sh, const uint32_t *d_scalars, c
     }
     if (bucket_lanes) {
         { ProfScope ps_(c, PS_ACCUMULATE);
+          // the redo launch is sized by the bucket count (grid-stride over info[3]; lanes beyond it leave at once): a batch of repeated commitments may hand every bucket
+          // back, and 16 blocks -- the size until round 6 -- would have summed them on 1024 lanes
           if (d_points29) {
               if (split) msm_accumulate_bucket29_kernel<F, 2><<<cdiv(nb_total / 2, 256), 256, 0, st>>>(nb_total, ss.SB, w.start.as<uint32_t>(), w.order.as<uint32_t>(), w.sorted.as<uint32_t>(), d_points29s, fk.one, fk.m32,
                                                                                                  w.buckets.as<xyzz_t>(), w.info.as<uint32_t>(), w.redo.as<uint32_t>(), nullptr);
               else msm_accumulate_bucket29_kernel<F, 1><<<cdiv(nb_total / 2, 256), 256, 0, st>>>(nb_total, ss.SB, w.start.as<uint32_t>(), w.order.as<uint32_t>(), w.sorted.as<uint32_t>(), d_points29, fk.one, fk.m32,
                                                                                            w.buckets.as<xyzz_t>(), w.info.as<uint32_t>(), w.redo.as<uint32_t>(), red29 ? w.buckets29.as<xyzz29_t>() : nullptr);
-              msm_bucket_redo_kernel<F><<<16, 64, 0, st>>>(w.start.as<uint32_t>(), w.info.as<uint32_t>(), w.redo.as<uint32_t>(), w.sorted.as<uint32_t>(), d_points, fk.one, w.buckets.as<xyzz_t>());
+              msm_bucket_redo_kernel<F><<<std::min<uint32_t>(1024u, cdiv(nb_total, 64)), 64, 0, st>>>(w.start.as<uint32_t>(), w.info.as<uint32_t>(), w.redo.as<uint32_t>(), w.sorted.as<uint32_t>(), d_points, fk.one, w.buckets.as<xyzz_t>());
           }
           else msm_accumulate_bucket_kernel<F><<<cdiv(nb_total / 2, 256), 256, 0, st>>>(nb_total, ss.SB, w.start.as<uint32_t>(), w.order.as<uint32_t>(), w.sorted.as<uint32_t>(), d_points, fk.one, w.buckets.as<xyzz_t>()); }
         { ProfScope ps_(c, PS_BUCKET_SUM);
@@ -209,7 +211,8 @@ int mb_msm_variable(mina_ctx *c, int curve, uint32_t n, const uint32_t *d_scalar
     // W = 20 mixed adds of ten products each: 1 %); equal / opposite points -- proofs may repeat a commitment -- are found exactly on the lazy limbs and go through
     // the 8 x 32 redo queue like everywhere else.  mina_verify_tuning.msm_fp29 = 0: the 8 x 32 law (cross-check).
     const affine_t *twin = nullptr;
-    if (mb_tune().msm_fp29) {
+    // (below 32 points -- the part MSMs of a culprit search, single openings -- the twin's launch costs more than the 29-bit law saves: the 8 x 32 law, no redo queue)
+    if (mb_tune().msm_fp29 && n >= 32) {
         MsmWorkspace &w = c->L->ws;
         if ((rc = w.points29.ensure((size_t)n * sizeof(affine_t)))) return rc;
         DISPATCH_FIELD(base_field_of(curve), { msm_table29_kernel<F_><<<cdiv(n, 256), 256, 0, c->L->stream>>>(n, (const affine_t *)d_points_mont, c->fk[F_].m32, w.points29.as<affine_t>()); });

@@ -30,7 +30,7 @@ static constexpr uint32_t BPM_KALIGN = 128;                   // the batch dimen
 template <int F>
 __global__ void __launch_bounds__(256)
 bpoly_tables_digits_kernel(BpolyShape sh, uint32_t kpad, FieldK fk, const uint32_t *__restrict__ chals, const uint32_t *__restrict__ weights,
-                           int8_t *__restrict__ Ld, int8_t *__restrict__ Hd) { mb_wave_prio();
+                           int8_t *__restrict__ Ld, int8_t *__restrict__ Hd) { mb_wave_prio<1>();
     const uint32_t nl = 1u << sh.lb, nh = 1u << sh.hb;
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (size_t)sh.batch * (nl + nh)) return;
@@ -76,7 +76,7 @@ __device__ __forceinline__ void bpoly_emit_digits(const fe_t &acc, int8_t *__res
 template <int F>
 __global__ void __launch_bounds__(256)
 bpoly_tables_digits8_kernel(BpolyShape sh, uint32_t kpad, FieldK fk, const uint32_t *__restrict__ chals, const uint32_t *__restrict__ weights,
-                            int8_t *__restrict__ Ld, int8_t *__restrict__ Hd) { mb_wave_prio();
+                            int8_t *__restrict__ Ld, int8_t *__restrict__ Hd) { mb_wave_prio<1>();
     const uint32_t nl8 = 1u << (sh.lb - 3), nh8 = 1u << (sh.hb - 3);
     const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (size_t)sh.batch * (nl8 + nh8)) return;
@@ -113,7 +113,7 @@ bpoly_tables_digits8_kernel(BpolyShape sh, uint32_t kpad, FieldK fk, const uint3
 static constexpr uint32_t BPM_KT = 128, BPM_ROW = 144;            // K bytes per LDS tile, padded row pitch
 __global__ void __launch_bounds__(256)
 bpoly_field_gemm_kernel(uint32_t mtiles, uint32_t ntiles, uint32_t kpad, const int8_t *__restrict__ A, const int8_t *__restrict__ B,
-                        unsigned long long *__restrict__ colsum) { mb_wave_prio();
+                        unsigned long long *__restrict__ colsum) { mb_wave_prio<1>();
     __shared__ __attribute__((aligned(16))) int8_t tiles[2][2][128 * BPM_ROW];   // stage, A | B, 128 rows
     __shared__ unsigned long long bins[4][4][BPM_COLS];           // wave, tile of the wave, column
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
@@ -194,7 +194,7 @@ bpoly_field_gemm_kernel(uint32_t mtiles, uint32_t ntiles, uint32_t kpad, const i
 // one thread per output: 63 signed base-256 columns -> 17 limbs -> T / 2^256 mod p, canonical words at out[(hi << lb) + lo]
 template <int F>
 __global__ void __launch_bounds__(256)
-bpoly_colsum_reduce_kernel(uint32_t nh, uint32_t nl, uint32_t lb, FieldK fk, const unsigned long long *__restrict__ colsum, uint32_t *__restrict__ out_words) { mb_wave_prio();
+bpoly_colsum_reduce_kernel(uint32_t nh, uint32_t nl, uint32_t lb, FieldK fk, const unsigned long long *__restrict__ colsum, uint32_t *__restrict__ out_words) { mb_wave_prio<1>();
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= nh * nl) return;
     const uint32_t hi = gid / nl, lo = gid % nl;

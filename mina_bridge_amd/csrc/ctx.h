@@ -148,6 +148,7 @@ struct mina_ctx {
     bool pparams_surrogate[2] = {false, false};                  // the installed Poseidon tables are the library's UNPINNED surrogate set
     DevBuf state_salts; bool have_state_salts = false;           // salted initial states of the named hash prefixes (Fp): MB_SALT_*
     bool legs_forked = false;        // the job being queued runs its legs on separate streams (api_state.hip)
+    bool is_view = false;            // a view of another context (mb_ctx_create_view: the culprit search's): creates no stream beyond its lane 0 -- its lanes 1 .. 3 borrow the failed chunk's, and the opening check's side stream is off
     size_t state_hashes_early = 0;   // states of the next job's protocol-state leg already queued on its lane (mb_state_hashes_early), consumed by mb_state_jobs_on_lane
     uint32_t hash_piece_waves = 0;   // > 0: the protocol-state hashes of a job are launched in pieces of this many waves (api_state.hip pstate_hash_dev)
     uint32_t hash_lds_bytes = 0;     // > 0: dynamic LDS a 3-lane state-hash workgroup reserves, to cap its waves per SIMD beside the other legs of a forked job (mina_verify_tuning.dev_hash_lds_kb)

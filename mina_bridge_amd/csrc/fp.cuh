@@ -27,14 +27,18 @@
 #ifndef MB_CHAIN_PRIO
 #define MB_CHAIN_PRIO 2
 #endif
+#ifndef MB_LEG_PRIO                       // the chip-filling kernels of the accumulator leg and of the MSMs (b_poly tables / GEMM, sort, accumulate, reductions)
+#define MB_LEG_PRIO 2
+#endif
 #if defined(__HIPCC__)
-__device__ __forceinline__ void mb_wave_prio() {
+template <int LEG = 0> __device__ __forceinline__ void mb_wave_prio() {
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (MB_CHAIN_PRIO) __builtin_amdgcn_s_setprio(MB_CHAIN_PRIO);
+    constexpr int prio = LEG ? MB_LEG_PRIO : MB_CHAIN_PRIO;
+    if constexpr (prio != 0) __builtin_amdgcn_s_setprio(prio);
 #endif
 }
 #else
-static inline void mb_wave_prio() {}      // the host-only builds of the ThreadSanitizer tier (tests/fuzz): kernels are stubs
+template <int LEG = 0> static inline void mb_wave_prio() {}      // the host-only builds of the ThreadSanitizer tier (tests/fuzz): kernels are stubs
 #endif
 
 namespace mb {

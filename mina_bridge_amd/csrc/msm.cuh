@@ -81,7 +81,7 @@ __device__ __forceinline__ bool msm_entry(const MsmShape &sh, const uint32_t (&s
 // dependent round trips).  Fallback sort for bucket counts beyond the partitioned sort below (K1p).
 static __global__ void msm_digits_kernel(MsmShape sh, const uint32_t *__restrict__ scalars /* n x 8 */,
                                          uint32_t *__restrict__ count, uint32_t *__restrict__ ekey,
-                                         uint32_t *__restrict__ eval, uint32_t *__restrict__ eoff) { mb_wave_prio();
+                                         uint32_t *__restrict__ eval, uint32_t *__restrict__ eoff) { mb_wave_prio<1>();
     const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t per_prob = (size_t)sh.n * sh.W;
     if (e >= per_prob * sh.nprob) return;
@@ -152,7 +152,7 @@ __device__ __forceinline__ void block_exclusive_scan(uint32_t (&v)[NV], uint32_t
 static __global__ void __launch_bounds__(1024)
 msm_scan_kernel(uint32_t nb_total, const uint32_t *__restrict__ count, uint32_t *__restrict__ start /* nb_total+1 */,
                 uint32_t *__restrict__ full_start /* nb_total+1 */, uint32_t *__restrict__ rem_pos /* nb_total */,
-                uint32_t *__restrict__ info /* 2 */) { mb_wave_prio();
+                uint32_t *__restrict__ info /* 2 */) { mb_wave_prio<1>();
     constexpr int NCLS = MSM_TASK_LEN - 1;                     // class kappa = L-1-r  (r = L-1 .. 1)
     constexpr int NV = 2 + NCLS;
     __shared__ uint32_t s_tot[NV][16], s_pre[NV][16], s_all[NV];
@@ -293,7 +293,7 @@ template <bool SCATTER>
 static __global__ void __launch_bounds__(1024)
 msm_part_kernel(MsmShape sh, SortShape ss, const uint32_t *__restrict__ scalars, uint32_t *__restrict__ gh, uint2 *__restrict__ staging,
                 uint32_t *__restrict__ ekey /* n * W * nprob: (bucket within the problem | sign << 31) or MSM_INVALID, written by the
-                                               count pass so that the scatter pass does not cut the digits again */) { mb_wave_prio();
+                                               count pass so that the scatter pass does not cut the digits again */) { mb_wave_prio<1>();
     __shared__ uint32_t cur[1024];
     const uint32_t tid = threadIdx.x;
     const uint32_t m = blockIdx.x / ss.Gl, g = blockIdx.x - m * ss.Gl;            // problem, block within the problem
@@ -347,7 +347,7 @@ msm_part_kernel(MsmShape sh, SortShape ss, const uint32_t *__restrict__ scalars,
 
 // K1p-b as its own one-block launch.  (Letting the last block of K1p-a do it -- device-scope fence + ticket -- was 5x
 // slower: every block's release fence writes back its XCD's whole L2.)
-static __global__ void __launch_bounds__(1024) msm_excl_scan_kernel(uint32_t n, uint32_t *__restrict__ data) { mb_wave_prio();
+static __global__ void __launch_bounds__(1024) msm_excl_scan_kernel(uint32_t n, uint32_t *__restrict__ data) { mb_wave_prio<1>();
     __shared__ uint32_t s_tot[1][16], s_pre[1][16], s_all[1];
     block_excl_scan_inplace(n, data, s_tot, s_pre, s_all);
 }
@@ -359,7 +359,7 @@ static __global__ void __launch_bounds__(1024) msm_excl_scan_kernel(uint32_t n, 
 static constexpr int PS_KEEP = 12;
 static __global__ void __launch_bounds__(1024)
 msm_part_sort_kernel(SortShape ss, const uint32_t *__restrict__ goff, const uint2 *__restrict__ staging,
-                     uint32_t *__restrict__ count, uint32_t *__restrict__ sorted, uint32_t *__restrict__ info) { mb_wave_prio();
+                     uint32_t *__restrict__ count, uint32_t *__restrict__ sorted, uint32_t *__restrict__ info) { mb_wave_prio<1>();
     if (blockIdx.x == 0 && threadIdx.x == 0) { info[2] = 0; info[3] = 0; }     // heavy-bucket counter of K1t-a (K1b zeroes its own); redo counter of the 29-bit accumulate kernels
     __shared__ uint32_t hist[2048], over[2048];
     __shared__ uint32_t s_tot[1][16], s_pre[1][16], s_all[1];
@@ -404,7 +404,7 @@ msm_part_sort_kernel(SortShape ss, const uint32_t *__restrict__ goff, const uint
 }
 
 // K1b': rem_bucket = inverse permutation of rem_pos (random 4-byte scatter, spread over the whole chip)
-static __global__ void msm_rem_invert_kernel(uint32_t nb_total, const uint32_t *__restrict__ rem_pos, uint32_t *__restrict__ rem_bucket) { mb_wave_prio();
+static __global__ void msm_rem_invert_kernel(uint32_t nb_total, const uint32_t *__restrict__ rem_pos, uint32_t *__restrict__ rem_bucket) { mb_wave_prio<1>();
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nb_total) return;
     const uint32_t p = rem_pos[b];
@@ -414,7 +414,7 @@ static __global__ void msm_rem_invert_kernel(uint32_t nb_total, const uint32_t *
 // K1c: scatter point references into bucket order
 static __global__ void msm_scatter_kernel(size_t total, const uint32_t *__restrict__ ekey, const uint32_t *__restrict__ eval,
                                    const uint32_t *__restrict__ eoff, const uint32_t *__restrict__ start,
-                                   uint32_t *__restrict__ sorted) { mb_wave_prio();
+                                   uint32_t *__restrict__ sorted) { mb_wave_prio<1>();
     size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= total) return;
     uint32_t k = ekey[e];
@@ -441,7 +441,7 @@ __global__ void __launch_bounds__(256)
 msm_accumulate_kernel(uint32_t nb_total, const uint32_t *__restrict__ start, const uint32_t *__restrict__ full_start,
                       const uint32_t *__restrict__ rem_bucket, const uint32_t *__restrict__ info,
                       const uint32_t *__restrict__ sorted, const affine_t *__restrict__ points, fe_t one,
-                      xyzz_t *__restrict__ partial, const uint32_t *__restrict__ redo = nullptr) { mb_wave_prio();
+                      xyzz_t *__restrict__ partial, const uint32_t *__restrict__ redo = nullptr) { mb_wave_prio<1>();
     uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t nfull = info[0], nrem = info[1];
     if (redo) { if (t >= info[3]) return; t = redo[t]; }        // redo mode: lane i takes task redo[i], the tasks the 29-bit kernel handed back; lanes beyond info[3] leave at once
@@ -490,7 +490,7 @@ template <int F>
 __global__ void __launch_bounds__(256)
 msm_bucket_sum_kernel(uint32_t nb_total, const uint32_t *__restrict__ full_start, const uint32_t *__restrict__ rem_pos,
                       uint32_t *__restrict__ info, const xyzz_t *__restrict__ partial, xyzz_t *__restrict__ buckets,
-                      uint32_t *__restrict__ heavy) { mb_wave_prio();
+                      uint32_t *__restrict__ heavy) { mb_wave_prio<1>();
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t b = gid >> 2;
     if (b >= nb_total) return;                               // whole quads leave together
@@ -510,7 +510,7 @@ template <int F>
 __global__ void __launch_bounds__(256)
 msm_bucket_sum_lane_kernel(uint32_t nb_total, const uint32_t *__restrict__ full_start, const uint32_t *__restrict__ rem_pos,
                            uint32_t *__restrict__ info, const xyzz_t *__restrict__ partial, xyzz_t *__restrict__ buckets,
-                           uint32_t *__restrict__ heavy) { mb_wave_prio();
+                           uint32_t *__restrict__ heavy) { mb_wave_prio<1>();
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nb_total) return;
     const uint32_t lo = full_start[b], hi = full_start[b + 1], rp = rem_pos[b];
@@ -558,7 +558,7 @@ static constexpr uint32_t MSM_COUNT_CLASSES = 64;
 //   heavy[] / info[2] = buckets with more than MSM_HEAVY_ENTRIES entries (info[2] is zeroed by K1p-d).
 static __global__ void __launch_bounds__(1024)
 msm_order_kernel(SortShape ss, uint32_t nprob, const uint32_t *__restrict__ goff, const uint32_t *__restrict__ count,
-                 uint32_t *__restrict__ start, uint32_t *__restrict__ order, uint32_t *__restrict__ info, uint32_t *__restrict__ heavy) { mb_wave_prio();
+                 uint32_t *__restrict__ start, uint32_t *__restrict__ order, uint32_t *__restrict__ info, uint32_t *__restrict__ heavy) { mb_wave_prio<1>();
     __shared__ uint32_t s_tot[1][16], s_pre[1][16], s_all[1];
     __shared__ uint32_t cls_n[MSM_COUNT_CLASSES], cls_cur[MSM_COUNT_CLASSES];
     const uint32_t tid = threadIdx.x, m = blockIdx.x, nb = ss.SB, row_elems = blockDim.x * 4, nrows = (nb + row_elems - 1) / row_elems;
@@ -612,7 +612,7 @@ template <int F>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2)))
 msm_accumulate_bucket_kernel(uint32_t nb_total, uint32_t nb_prob, const uint32_t *__restrict__ start, const uint32_t *__restrict__ order,
                              const uint32_t *__restrict__ sorted, const affine_t *__restrict__ points, fe_t one,
-                             xyzz_t *__restrict__ buckets) { mb_wave_prio();
+                             xyzz_t *__restrict__ buckets) { mb_wave_prio<1>();
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= nb_total / 2) return;                               // bucket counts are multiples of 128
     const uint32_t m = r / (nb_prob / 2), lr = r - m * (nb_prob / 2);   // ranks are per problem
@@ -685,7 +685,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))
 msm_accumulate_bucket29_kernel(uint32_t nb_total, uint32_t nb_prob, const uint32_t *__restrict__ start, const uint32_t *__restrict__ order,
                                const uint32_t *__restrict__ sorted, const void *__restrict__ points29_, fe_t one, fe_t m32,
                                xyzz_t *__restrict__ buckets, uint32_t *__restrict__ info, uint32_t *__restrict__ redo,
-                               xyzz29_t *__restrict__ buckets29 /* non-null: the bucket STAYS on 29-bit limbs (the 2-D reduction then runs on them too: msm_segsum29_kernel) */) { mb_wave_prio();
+                               xyzz29_t *__restrict__ buckets29 /* non-null: the bucket STAYS on 29-bit limbs (the 2-D reduction then runs on them too: msm_segsum29_kernel) */) { mb_wave_prio<1>();
 #if defined(__HIP_DEVICE_COMPILE__)
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= nb_total / 2) return;
@@ -739,7 +739,7 @@ msm_accumulate_bucket29_kernel(uint32_t nb_total, uint32_t nb_prob, const uint32
 template <int F>
 __global__ void __launch_bounds__(64)
 msm_buckets_to29_kernel(const uint32_t *__restrict__ info, const uint32_t *__restrict__ heavy, const uint32_t *__restrict__ redo, const xyzz_t *__restrict__ buckets, fe_t m32,
-                        xyzz29_t *__restrict__ buckets29) { mb_wave_prio();
+                        xyzz29_t *__restrict__ buckets29) { mb_wave_prio<1>();
     const uint32_t nh = info[2], nr = info[3];
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nh + nr; i += gridDim.x * blockDim.x) {
         const uint32_t b = i < nh ? heavy[i] : redo[i - nh];
@@ -754,7 +754,7 @@ msm_buckets_to29_kernel(const uint32_t *__restrict__ info, const uint32_t *__res
 template <int F>
 __global__ void __launch_bounds__(64)
 msm_bucket_redo_kernel(const uint32_t *__restrict__ start, const uint32_t *__restrict__ info, const uint32_t *__restrict__ redo,
-                       const uint32_t *__restrict__ sorted, const affine_t *__restrict__ points, fe_t one, xyzz_t *__restrict__ buckets) { mb_wave_prio();
+                       const uint32_t *__restrict__ sorted, const affine_t *__restrict__ points, fe_t one, xyzz_t *__restrict__ buckets) { mb_wave_prio<1>();
     const uint32_t n = info[3];
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
         const uint32_t b = redo[i], beg = start[b], end = start[b + 1];
@@ -775,7 +775,7 @@ __global__ void __launch_bounds__(256)
 msm_accumulate29_kernel(uint32_t nb_total, const uint32_t *__restrict__ start, const uint32_t *__restrict__ full_start,
                         const uint32_t *__restrict__ rem_bucket, const uint32_t *__restrict__ info,
                         const uint32_t *__restrict__ sorted, const void *__restrict__ points29_, fe_t one, fe_t m32,
-                        xyzz_t *__restrict__ partial, uint32_t *__restrict__ info_rw, uint32_t *__restrict__ redo) { mb_wave_prio();
+                        xyzz_t *__restrict__ partial, uint32_t *__restrict__ info_rw, uint32_t *__restrict__ redo) { mb_wave_prio<1>();
 #if defined(__HIP_DEVICE_COMPILE__)
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t nfull = info[0], nrem = info[1];
@@ -836,7 +836,7 @@ template <int F>
 __global__ void __launch_bounds__(256)
 msm_bucket_heavy_entries_kernel(const uint32_t *__restrict__ start, const uint32_t *__restrict__ info, const uint32_t *__restrict__ heavy,
                                 const uint32_t *__restrict__ sorted, const affine_t *__restrict__ points, fe_t one,
-                                xyzz_t *__restrict__ buckets) { mb_wave_prio();
+                                xyzz_t *__restrict__ buckets) { mb_wave_prio<1>();
     __shared__ xyzz_t sh[4];
     const uint32_t nheavy = info[2], lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
     for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
@@ -870,7 +870,7 @@ msm_bucket_heavy_entries_kernel(const uint32_t *__restrict__ start, const uint32
 template <int F>
 __global__ void __launch_bounds__(256)
 msm_bucket_sum_heavy_kernel(const uint32_t *__restrict__ full_start, const uint32_t *__restrict__ rem_pos, const uint32_t *__restrict__ info,
-                            const xyzz_t *__restrict__ partial, xyzz_t *__restrict__ buckets, const uint32_t *__restrict__ heavy) { mb_wave_prio();
+                            const xyzz_t *__restrict__ partial, xyzz_t *__restrict__ buckets, const uint32_t *__restrict__ heavy) { mb_wave_prio<1>();
     __shared__ xyzz_t sh[4];
     const uint32_t nheavy = info[2], q = threadIdx.x >> 2, wave = threadIdx.x >> 6;
     for (uint32_t h = blockIdx.x; h < nheavy; h += gridDim.x) {
@@ -909,7 +909,7 @@ static constexpr int SEG_CHUNK = 8;
 template <int F, bool COOP>
 __global__ void __launch_bounds__(256)
 msm_segsum_kernel(uint32_t nb_per_set, SegSum rows, SegSum cols, const xyzz_t *__restrict__ buckets,
-                  xyzz_t *__restrict__ out_rows, xyzz_t *__restrict__ out_cols) { mb_wave_prio();
+                  xyzz_t *__restrict__ out_rows, xyzz_t *__restrict__ out_cols) { mb_wave_prio<1>();
     // COOP: `lanes` counts QUADS per segment, four lanes cooperate on every add (lane-cooperative group law; latency form).
     // !COOP: `lanes` counts single lanes per segment, plain XYZZ adds (throughput form: a third fewer issue slots).
     constexpr uint32_t LPG = COOP ? 4 : 1;                    // lanes per worker
@@ -953,7 +953,7 @@ __device__ __forceinline__ xyzz29_t shfl_down_xyzz29(const xyzz29_t &a, int d) {
 template <int F>
 __global__ void __launch_bounds__(256)
 msm_segsum29_kernel(uint32_t nb_per_set, SegSum rows, SegSum cols, const xyzz29_t *__restrict__ buckets29, fe_t one, xyzz_t *__restrict__ out_rows, xyzz_t *__restrict__ out_cols,
-                    uint32_t *__restrict__ seg_bad /* rows.nseg + cols.nseg words, zeroed by the host */) { mb_wave_prio();
+                    uint32_t *__restrict__ seg_bad /* rows.nseg + cols.nseg words, zeroed by the host */) { mb_wave_prio<1>();
 #if defined(__HIP_DEVICE_COMPILE__)
     const bool is_col = blockIdx.y != 0;
     const SegSum sg = is_col ? cols : rows;
@@ -993,7 +993,7 @@ msm_segsum29_kernel(uint32_t nb_per_set, SegSum rows, SegSum cols, const xyzz29_
 template <int F>
 __global__ void __launch_bounds__(64)
 msm_segsum29_redo_kernel(uint32_t nb_per_set, SegSum rows, SegSum cols, const xyzz29_t *__restrict__ buckets29, fe_t one, xyzz_t *__restrict__ out_rows, xyzz_t *__restrict__ out_cols,
-                         const uint32_t *__restrict__ seg_bad) { mb_wave_prio();
+                         const uint32_t *__restrict__ seg_bad) { mb_wave_prio<1>();
 #if defined(__HIP_DEVICE_COMPILE__)
     const uint32_t gid = blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= rows.nseg + cols.nseg || !seg_bad[gid]) return;
@@ -1029,7 +1029,7 @@ template <int F> __device__ __forceinline__ xyzz_t quadwave_weighted_sum(xyzz_t 
 template <int F>
 __global__ void __launch_bounds__(64)
 msm_wsum16_kernel(uint32_t R, uint32_t C, uint32_t Gr, const xyzz_t *__restrict__ rows, const xyzz_t *__restrict__ cols,
-                  xyzz_t *__restrict__ out_s, xyzz_t *__restrict__ out_w) { mb_wave_prio();
+                  xyzz_t *__restrict__ out_s, xyzz_t *__restrict__ out_w) { mb_wave_prio<1>();
     const uint32_t g = blockIdx.x, set = blockIdx.y, q = threadIdx.x >> 2;
     const uint32_t Gc = (C + 15) / 16, G = Gr + Gc;
     xyzz_t v = xyzz_inf();
@@ -1046,7 +1046,7 @@ msm_wsum16_kernel(uint32_t R, uint32_t C, uint32_t Gr, const xyzz_t *__restrict_
 template <int F>
 __global__ void __launch_bounds__(256)
 msm_reduce2d_kernel(uint32_t Gr, uint32_t Gc, uint32_t log2C, const xyzz_t *__restrict__ in_s, const xyzz_t *__restrict__ in_w,
-                    xyzz_t *__restrict__ set_total, xyzz_t *__restrict__ out_xyzz /* may be null: also the result of problem `set` */) { mb_wave_prio();
+                    xyzz_t *__restrict__ set_total, xyzz_t *__restrict__ out_xyzz /* may be null: also the result of problem `set` */) { mb_wave_prio<1>();
     const uint32_t set = blockIdx.x, wave = threadIdx.x >> 6, q = (threadIdx.x & 63) >> 2, G = Gr + Gc;
     __shared__ xyzz_t sh_tot, sh_roww, sh_ww[2], sh_colw;
     const xyzz_t *s = in_s + (size_t)set * G, *w = in_w + (size_t)set * G;
@@ -1088,7 +1088,7 @@ msm_reduce2d_kernel(uint32_t Gr, uint32_t Gc, uint32_t log2C, const xyzz_t *__re
 //   out_words[17 m + 0..16) = x||y canonical little-endian words, out_words[17 m + 16] = 1 if infinity; out_xyzz[m].
 template <int F>
 __global__ void msm_finish_kernel(uint32_t nsets /* per problem */, uint32_t c, const xyzz_t *__restrict__ set_total, fe_t one,
-                                  fe_t pm2, xyzz_t *__restrict__ out_xyzz, uint32_t *__restrict__ out_words) { mb_wave_prio();
+                                  fe_t pm2, xyzz_t *__restrict__ out_xyzz, uint32_t *__restrict__ out_words) { mb_wave_prio<1>();
     if (threadIdx.x >= 4) return;                              // one quad: lane-cooperative doublings / adds
     set_total += (size_t)blockIdx.x * nsets;
     if (out_xyzz) out_xyzz += blockIdx.x;

@@ -20,7 +20,7 @@ struct BpolyShape { uint32_t k, lb, hb, batch; };
 template <int F>
 __global__ void bpoly_tables_kernel(BpolyShape sh, FieldK fk, const uint32_t *__restrict__ chals /* batch*k*8 canonical */,
                                     const uint32_t *__restrict__ weights /* batch*8 canonical, may be null */,
-                                    fe_t *__restrict__ ltab, fe_t *__restrict__ htab) { mb_wave_prio();
+                                    fe_t *__restrict__ ltab, fe_t *__restrict__ htab) { mb_wave_prio<1>();
     const uint32_t nl = 1u << sh.lb, nh = 1u << sh.hb, per = nl + nh;
     size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (gid >= (size_t)sh.batch * per) return;
@@ -48,7 +48,7 @@ static constexpr int BP_HT = 4;
 template <int F>
 __global__ void __launch_bounds__(256)
 bpoly_fold_kernel(BpolyShape sh, uint32_t slices, const fe_t *__restrict__ ltab, const fe_t *__restrict__ htab,
-                  fe_t *__restrict__ partial) { mb_wave_prio();
+                  fe_t *__restrict__ partial) { mb_wave_prio<1>();
     const uint32_t nl = 1u << sh.lb, nh = 1u << sh.hb;
     const uint32_t lo_blocks = (nl + blockDim.x - 1) / blockDim.x;
     const uint32_t hi_tiles = (nh + BP_HT - 1) / BP_HT;
@@ -89,7 +89,7 @@ bpoly_fold_kernel(BpolyShape sh, uint32_t slices, const fe_t *__restrict__ ltab,
 
 // out[j] (canonical words) = sum over slices of partial[slice][j]
 template <int F>
-__global__ void bpoly_finish_kernel(uint32_t n, uint32_t slices, const fe_t *__restrict__ partial, uint32_t *__restrict__ out_words) { mb_wave_prio();
+__global__ void bpoly_finish_kernel(uint32_t n, uint32_t slices, const fe_t *__restrict__ partial, uint32_t *__restrict__ out_words) { mb_wave_prio<1>();
     uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n) return;
     fe_t acc = partial[j];

@@ -184,6 +184,25 @@ def test_kimchi_fq_spills_stay_outside_the_permutation(co):
         assert s["scratch"] == 0, (span, s)
 
 
+def test_wave_priorities(co):
+    """round 6: the legs of a device-resident job run on streams of their own, and every kernel of a job except the chip-filling hashes opens with `s_setprio 2`
+    (fp.cuh mb_wave_prio): where a wave of the wrap-proof chain shares a SIMD with resident state-hash waves the arbiter takes it first.  Half of the round's headline
+    gain (4 forked lanes: 286.6 -> 307.2 k proofs/s, same box) rests on that one instruction being there -- and on the hash kernels NOT raising theirs."""
+    def prios(kernel):
+        return [op for _, mn, op in co.instructions(kernel) if mn == "s_setprio"]
+    for k in ("pstate_hash_kernel<0, 3>", "pstate_hash_kernel<0, 8>", "pstate_hash_kernel<0, 16>"):
+        assert prios(k) == [], (k, prios(k))
+    # (the Proof-of-Account kernels have raised theirs to 3 since round 4: short dependent chains beside state jobs -- api_account.hip, sponge.cuh merkle_fold_coop_kernel)
+    for k in ("pickles_expand_kernel", "pickles_digest_kernel<3>", "pickles_tick_kernel<3>", "pickles_scalar_kernel", "kimchi_fq_kernel<3>", "kimchi_fr_kernel<3>", "kimchi_pub_kernel<10>",
+              "kimchi_scalar_kernel", "ipa_prepare_kernel<0, 3, 2>", "ipa_to_group_kernel<0>", "pubcomm_direct29_kernel<0, 8>", "pubcomm_finish16_kernel<0>", "challenge_to_field_kernel<0>",
+              "bpoly_tables_digits8_kernel<0>", "bpoly_field_gemm_kernel", "msm_part_sort_kernel", "msm_accumulate29_kernel<1, 1>", "msm_accumulate_bucket29_kernel<1, 1>",
+              "msm_segsum_kernel<1, true>", "msm_reduce2d_kernel<1>"):
+        p_ = prios(k)
+        assert p_ and p_[0].strip() in ("2", "0x2") and len(set(x.strip() for x in p_)) == 1, (k, p_)
+        first = [mn for _, mn, _ in co.instructions(k)][:40]
+        assert "s_setprio" in first, (k, "the priority is raised at the top of the kernel, before any long-latency work", first[:12])
+
+
 def test_compiler_recorded():
     v = CO.compiler_version()
     assert v.startswith("HIP "), v

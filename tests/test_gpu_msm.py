@@ -131,6 +131,32 @@ def test_msm_variable_base_adversarial_large(ctx, oracle, srs_oracle):
     assert (ctx.msm(curve, g[:n], sc) == oracle.msm_pippenger(curve, g[:n], sc, threads=8)).all()
 
 
+@pytest.mark.parametrize("n", [1, 7, 31, 32, 33, 4096, 40000])
+def test_msm_variable_base_heavily_duplicated_points(ctx, oracle, srs_oracle, n):
+    """a batch of repeated commitments (the same proof tiled; adversarial duplicates) -- three distinct points and their negatives over n entries, so that
+    nearly every bucket / task of the 29-bit accumulate holds equal or opposite points and goes through the 8 x 32 redo path; sizes on both sides of the 32-point threshold
+    below which the variable-base MSM stays on the 8 x 32 law.  Sum == the oracle's, whatever the path; lane 0 and the pipelined forms."""
+    curve = 0
+    g, _ = srs_oracle[curve]
+    three = g[[5, 6, 7]].copy()
+    neg = three.copy()
+    for i in range(3):                                                # Pallas' base field is P
+        y = (P - int.from_bytes(three[i, 32:].tobytes(), "little")) % P
+        neg[i, 32:] = np.frombuffer(y.to_bytes(32, "little"), np.uint8)
+    six = np.concatenate([three, neg])
+    rng = np.random.Generator(np.random.PCG64(1234 + n))
+    base = six[rng.integers(0, 6, size=n)].copy()
+    sc = rand_scalars(n, Q, seed=4321 + n)
+    if n >= 8: sc[: n // 2] = sc[0]                                   # ... and repeated scalars: the same (point, digit) pairs land in one bucket
+    want = oracle.msm_naive(curve, base, sc) if n <= 64 else oracle.msm_pippenger(curve, base, sc, threads=8)
+    assert (ctx.msm(curve, base, sc) == want).all()
+    ctx.set_pipeline(4)
+    try:
+        assert (ctx.msm(curve, base, sc) == want).all()
+    finally:
+        ctx.synchronize(); ctx.set_pipeline(1)
+
+
 def test_msm_randomised_stress(ctx_srs, oracle, srs_oracle):
     """many small random instances with deliberately colliding inputs: repeated points (P == Q inside a bucket -> doubling
     branches of the mixed, full and cooperative adds), negated repeats (P == -Q -> identity mid-sum), infinity bases,

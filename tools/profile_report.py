@@ -29,14 +29,22 @@ for k in sorted(tot, key=tot.get, reverse=True)[:14]:
     print(f"| {k} | {F[k][2]} | {F[k][1]} | {F[k][0]:.0f} | {W.get(k, (0,))[0]:.0f} | {tot[k] / 1e6:.1f} MB |")
 # single-lane step budget from the FETCH pass's kernel trace
 rows = list(csv.DictReader(open(os.path.join(d, "fetch", "f_kernel_trace.csv"))))
+# round 6 (VERDICT r05 next #3c): a (kernel, grid) pair launched a whole number of times per step belongs to the steps; everything else -- the set-up's launches of the
+# same kernels on other grids (the 16 384 chains are hashed state by state before the first step: 17 launches of pstate_hash_kernel) -- gets a row of its own, so that
+# the per-launch average of a step's kernels can be read off this table
+gcount = collections.Counter((short(r["Kernel_Name"]), r["Grid_Size"]) for r in rows)
 dur, cnt = collections.defaultdict(float), collections.Counter()
 for r in rows:
-    n = short(r["Kernel_Name"]); dur[n] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3; cnt[n] += 1
-print(f"\n## Single-lane step (`--pipeline 1`, kernels back to back): time per step of {b['config']['proofs_per_step']} proofs "
-      f"(sum {sum(dur.values()) / STEPS / 1e3:.1f} ms)\n")
-print("| kernel | launches/step | us/step |\n|---|---|---|")
-for k in sorted(dur, key=dur.get, reverse=True)[:26]:
-    print(f"| {k} | {cnt[k] / STEPS:.1f} | {dur[k] / STEPS:.0f} |")
+    n = short(r["Kernel_Name"]); g_ = gcount[(n, r["Grid_Size"])]
+    if g_ < STEPS or g_ % STEPS: n += " [set-up]"
+    dur[n] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3; cnt[n] += 1
+step_sum = sum(v for k, v in dur.items() if not k.endswith("[set-up]"))
+print(f"\n## Single-lane step (`--pipeline 1`, `dev_fork = 0`: ONE stream, kernels back to back): time per step of {b['config']['proofs_per_step']} proofs "
+      f"(sum over the steps' kernels {step_sum / STEPS / 1e3:.1f} ms; set-up launches on rows of their own, per run)\n")
+print("| kernel | launches/step | us/step | us/launch |\n|---|---|---|---|")
+for k in sorted(dur, key=dur.get, reverse=True)[:30]:
+    if k.endswith("[set-up]"): print(f"| {k} | ({cnt[k]} per run) | ({dur[k]:.0f} per run) | {dur[k] / cnt[k]:.0f} |")
+    else: print(f"| {k} | {cnt[k] / STEPS:.1f} | {dur[k] / STEPS:.0f} | {dur[k] / cnt[k]:.0f} |")
 # VALU instruction budget from the SQ pass
 sq = os.path.join(d, "sq", "s_counter_collection.csv")
 if os.path.exists(sq):
