@@ -649,8 +649,7 @@ def boundary_leg(m, devices: str, B: int, min_seconds: float = 2.0):
     c5_after = None
     if c5 is not None and search_cost and "error" not in search_cost:
         c5_after = c5_job.timed(1.0, min_calls=3)
-    one_per_call = one_proof_per_call(m, items)
-    res = {"value": single["value"], "unit": "proofs/s", "proofs_per_call": B, "ms_per_call": single["ms_per_call"], "calls_timed": single["calls"], "one_proof_per_call": one_per_call,
+    res = {"value": single["value"], "unit": "proofs/s", "proofs_per_call": B, "ms_per_call": single["ms_per_call"], "calls_timed": single["calls"],
            "bytes_per_proof": len(job.P[0]) + len(job.Q[0]), "host_threads": int(os.environ.get("MINA_HOST_THREADS", min((os.cpu_count() or 2) // 2, 64))), "usable_cores": usable_cores(),
            "two_caller_threads": two, "four_caller_threads": four, "one_bad_opening_per_call": search_cost, "one_call_of_65536": big, "c5_4096_per_call": c5, "c5_4096_per_call_after_culprit_searches": c5_after, "devices": devices,
            "entry_point": "mina_verify_state_batch (include/mina_verify.h): bincode MinaStateProof + MinaStatePubInputs bytes -> verdict bytes",
@@ -659,6 +658,65 @@ def boundary_leg(m, devices: str, B: int, min_seconds: float = 2.0):
                    "randomisers from the OS CSPRNG per chunk); one tampered proof in a warm-up call failed alone"}
     m.lib.verify_shutdown()
     return res
+
+
+def c2_leg(m, device: str, bdf: str = ""):
+    """Secondary key `c2_accumulator_only` -- BASELINE config C2 (round 1's headline), in a process of its own that holds only the library: (a) `single_check`: C2 AS WRITTEN
+    (/root/reference README.md:534-544: "a single Kimchi proof batch_verify, 2^16-base Vesta IPA MSM") -- ONE un-folded accumulator check per call, one call at a time, nothing
+    else on the chip: wall time per call, the sum of its kernels' stage events, the MSM's algorithmic GB/s; (b) the pipelined form: 8 independent checks per call over 16 lanes.
+    (Until round 6 this ran at the end of the main process: with the forked lanes' helper streams that process holds more streams than hardware queues by then, and every later
+    launch is slower for it -- 12.6 k checks/s there against 13.5 k in a fresh process, same box.)"""
+    ctx = m.MinaContext(int(device))
+    for f in (0, 1):
+        ctx.poseidon_set_params(f, m.poseidon_params.default_params_bytes(f))
+    ctx.srs_create(CURVE_VESTA, 1 << 16)
+    pre8, sg8 = make_accumulators(ctx, 8, 4242)
+    d_pre8 = ctx.dev_upload(ctx.dev_malloc(pre8.size), pre8.reshape(-1)); d_sg8 = ctx.dev_upload(ctx.dev_malloc(sg8.size), sg8.reshape(-1))
+    d_v8 = ctx.dev_upload(ctx.dev_malloc(32), np.zeros(32, np.uint8))
+    verdicts = lambda: ctx.dev_download(d_v8, 32).view(np.uint32).tolist()
+    one = lambda: ctx.accumulator_check_dev(CURVE_VESTA, ACC_K, 1, d_pre8, d_sg8, 0, d_v8)
+    for _ in range(8):
+        one()
+    ctx.synchronize()
+    ctx.prof_enable(0x7ff)                                        # every MSM and b_poly stage (ctx.h ProfStage 0 .. 10)
+    n1 = 64; t1 = time.perf_counter()
+    for _ in range(n1):
+        one(); ctx.synchronize()
+    wall_us = (time.perf_counter() - t1) / n1 * 1e6
+    p1 = ctx.prof_read(); ctx.prof_enable(0)
+    assert verdicts()[0] == 1
+    kern_us_1 = sum(ms for _, ms in p1.values()) / n1 * 1e3
+    msm_bytes = 65536 * (64 + 32) + 96
+    single = {"wall_us": wall_us, "kernel_us_sum": kern_us_1, "stages_us": {k: v[1] / n1 * 1e3 for k, v in p1.items() if v[0]},
+              "algorithmic_bytes": msm_bytes, "algorithmic_GBps_wall": msm_bytes / wall_us / 1e3, "algorithmic_GBps_kernels": msm_bytes / kern_us_1 / 1e3 if kern_us_1 else None,
+              "frac_of_hbm_peak_kernels": msm_bytes / kern_us_1 / 1e3 / HBM_PEAK_GBPS if kern_us_1 else None, **msm_single_traffic(kern_us_1),
+              "note": "ONE un-folded 2^16 Vesta accumulator check per call, one call at a time, nothing else on the GPU (mina_accumulator_check_dev, batch 1: prechallenges -> "
+                      "b_poly coefficients -> fixed-base MSM in its one-MSM task form -> comparison); kernel_us_sum = HIP-event stage times on the lane's stream"}
+    ctx.set_pipeline(16)
+    c2 = lambda: ctx.accumulator_check_multi_dev(CURVE_VESTA, ACC_K, 8, d_pre8, d_sg8, d_v8)
+    for _ in range(32):
+        c2()
+    ctx.synchronize()
+    sampler = PowerSampler(bdf or None, interval=0.03).start(); t2 = time.perf_counter()
+    for _ in range(400):
+        c2()
+    ctx.synchronize()
+    rate = 8 * 400 / (time.perf_counter() - t2)
+    power = sampler.stop()
+    assert verdicts() == [1] * 8
+    ctx.close()
+    return {"value": rate, "single_check": single, "power": power}
+
+
+def one_proof_leg(m, devices: str):
+    """`one_proof_per_call` in a process of its own (the operator's verifier process right after start-up: indexes installed, nothing else has run)"""
+    setup = _boundary_setup(m, devices)
+    if isinstance(setup, dict):
+        return setup
+    lib, items, ndev = setup
+    out = one_proof_per_call(m, items)
+    m.lib.verify_shutdown()
+    return out
 
 
 def account_leg(m, devices: str, min_seconds: float = 1.5):
@@ -887,7 +945,7 @@ def main():
     # 24: 68.4 ms), while the 20-lane pipeline of the headline below wants one queue per lane plus a few (24).
     # At N > 1 rank 0 runs a second leg the same way: the product's own multi-device path, ONE process with a context on each of the N GPUs
     # (boundary_all_devices_leg).  The other ranks have not touched their GPUs yet: they wait at the CPU barrier below.
-    boundary = c4 = None
+    boundary = c4 = one_pc = c2_own = None
     if not args.no_boundary and rank == 0:
         import subprocess
         env = dict(os.environ); env["GPU_MAX_HW_QUEUES"] = os.environ.get("MINA_BOUNDARY_HW_QUEUES", "16")
@@ -899,12 +957,22 @@ def main():
             except (subprocess.TimeoutExpired, ValueError) as e:
                 return {"error": repr(e)[:400]}
         bsize = min(args.jobs, args.boundary_jobs) if args.boundary_jobs else min(args.jobs, 8192)
+        one_pc = leg("--one-proof-only", "0" if share_gpu else str(local_rank), "0")       # first: a verifier process right after start-up
         boundary = leg("--boundary-only", "0" if share_gpu else str(local_rank), str(bsize))
         c4 = leg("--account-only", "0" if share_gpu else str(local_rank), "256")
         if world > 1:
             devs = ",".join("0" if share_gpu else str(g) for g in range(world))
             boundary["all_devices"] = leg("--boundary-all-devices", devs, str(bsize))
             boundary["value_all_devices"] = boundary["all_devices"].get("value_all_devices")
+    if not args.no_probes and rank == 0 and not (dist_on and share_gpu):
+        import subprocess
+        env2 = dict(os.environ)
+        for k_ in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"): env2.pop(k_, None)
+        try:
+            r_ = subprocess.run([sys.executable, os.path.abspath(__file__), "--c2-only", str(local_rank), "-"], capture_output=True, text=True, timeout=600, env=env2)
+            c2_own = json.loads(r_.stdout.strip().split("\n")[-1]) if r_.returncode == 0 and r_.stdout.strip() else {"error": (r_.stderr or r_.stdout)[-400:]}
+        except (subprocess.TimeoutExpired, ValueError) as e:
+            c2_own = {"error": repr(e)[:400]}
     if dist_on:
         dist.all_reduce(torch.zeros(1))                      # CPU tensor -> gloo: rank 0 arrives when its boundary legs are done
 
@@ -1122,9 +1190,8 @@ def main():
     iso_legs = not args.no_probes and not (dist_on and share_gpu)
     # These legs run HERE, before anything creates more streams: a process holding more streams than the runtime has hardware queues (24 here: GPU_MAX_HW_QUEUES) keeps
     # every later launch slower -- the same isolated state-hash launch read 33.4 ms after 4 forked lanes (20 streams) and 39.5 ms after 6 (30), for the rest of the process
-    # (tools/probes/iso_after_fork.py).  The C5 leg (6 lanes) and the 16-lane C2 leg come after.
+    # (tools/probes/iso_after_fork.py).  The C5 leg (5 lanes) comes after; the C2 and one-proof-per-call legs run in processes of their own.
     # the candidate dominant kernels with nothing else on the GPU: one lane, HIP events on that lane's stream
-    c2_single = None
     if iso_legs:
         ctx.set_pipeline(1)
         set_tune("dev_fork=0")                                    # ONE stream: nothing runs beside the kernel being timed (forked, a lone job's hashes share the chip with its chain)
@@ -1137,30 +1204,6 @@ def main():
         prof_iso = ctx.prof_read()
         ctx.prof_enable(0)
         set_tune()
-        pre8, sg8 = make_accumulators(ctx, 8, 4242 + rank)
-        d_pre8 = torch.from_numpy(pre8.reshape(-1)).to(dev); d_sg8 = torch.from_numpy(sg8.reshape(-1)).to(dev)
-        d_v8 = torch.zeros(8, dtype=torch.int32, device=dev)
-        torch.cuda.synchronize()                                  # torch's stream is asynchronous to the library's lanes: the zeroes must land before a kernel writes verdicts
-        # BASELINE C2 as written (/root/reference README.md:534-544: "a single Kimchi proof batch_verify, 2^16-base Vesta IPA MSM"): ONE accumulator check, alone on the chip,
-        # one call at a time -- wall time per call (launch overhead and the host's wait included), the sum of its kernels' stage events, the MSM's algorithmic GB/s
-        one = lambda: ctx.accumulator_check_dev(CURVE_VESTA, ACC_K, 1, d_pre8.data_ptr(), d_sg8.data_ptr(), 0, d_v8.data_ptr())
-        for _ in range(8):
-            one()
-        ctx.synchronize()
-        ctx.prof_enable(0x7ff)                                    # every MSM and b_poly stage (ctx.h ProfStage 0 .. 10)
-        n1 = 64; t1 = time.perf_counter()
-        for _ in range(n1):
-            one(); ctx.synchronize()
-        wall_us = (time.perf_counter() - t1) / n1 * 1e6
-        p1 = ctx.prof_read(); ctx.prof_enable(0)
-        assert int(d_v8.cpu().numpy()[0]) == 1
-        kern_us_1 = sum(ms for _, ms in p1.values()) / n1 * 1e3
-        msm_bytes = 65536 * (64 + 32) + 96
-        c2_single = {"wall_us": wall_us, "kernel_us_sum": kern_us_1, "stages_us": {k: v[1] / n1 * 1e3 for k, v in p1.items() if v[0]},
-                     "algorithmic_bytes": msm_bytes, "algorithmic_GBps_wall": msm_bytes / wall_us / 1e3, "algorithmic_GBps_kernels": msm_bytes / kern_us_1 / 1e3 if kern_us_1 else None,
-                     "frac_of_hbm_peak_kernels": msm_bytes / kern_us_1 / 1e3 / HBM_PEAK_GBPS if kern_us_1 else None, **msm_single_traffic(kern_us_1),
-                     "note": "ONE un-folded 2^16 Vesta accumulator check per call, one call at a time, nothing else on the GPU (mina_accumulator_check_dev, batch 1: prechallenges -> "
-                             "b_poly coefficients -> fixed-base MSM in its one-MSM task form -> comparison); kernel_us_sum = HIP-event stage times on the lane's stream"}
         ctx.set_pipeline(args.pipeline)
         for o in d_out:
             o.zero_()
@@ -1178,7 +1221,8 @@ def main():
         def step5():
             o = d_out[it[0] % nslots]; it[0] += 1
             ctx.state_job_batch_dev(dj5, o.data_ptr(), o.data_ptr() + 4 * B5)
-        lanes5 = min(max(args.pipeline, 6), 8)                     # a 4096-proof job is 3316 hash waves and 196-wave chain kernels: more of them in flight (4 lanes 235 k, 5 - 6: 254 k)
+        lanes5 = min(max(args.pipeline, 5), 8)                     # a 4096-proof job is 3316 hash waves and 196-wave chain kernels: more of them in flight (4 lanes 235 k, 5 - 6: 254 k);
+                                                                   # 5: the process stays within its 24 hardware queues (5 lanes + 15 helper streams + a side stream)
         ctx.set_pipeline(lanes5)
         for _ in range(nslots):
             step5()
@@ -1230,24 +1274,6 @@ def main():
                 try: barrier()
                 except Exception: pass                             # noqa: BLE001
 
-    if iso_legs:
-        # secondary key (round 1's headline, BASELINE config C2): 8 independent 2^16 Vesta accumulator checks per call, 16 lanes
-        ctx.set_pipeline(16)
-        c2 = lambda: ctx.accumulator_check_multi_dev(CURVE_VESTA, ACC_K, 8, d_pre8.data_ptr(), d_sg8.data_ptr(), d_v8.data_ptr())
-        for _ in range(32):
-            c2()
-        ctx.synchronize(); torch.cuda.synchronize()
-        c2_sampler = PowerSampler(bdf, interval=0.03).start(); t2 = time.perf_counter()
-        for _ in range(400):
-            c2()
-        ctx.synchronize()
-        c2_rate = 8 * 400 / (time.perf_counter() - t2)
-        c2_power = c2_sampler.stop()
-        assert d_v8.cpu().numpy().tolist() == [1] * 8
-        ctx.set_pipeline(1)
-    else:
-        c2_rate = None
-        c2_power = None
     if dist_on:
         t = torch.tensor([elapsed, sustained["seconds"] if sustained else 0.0, c5["ms_per_step"] if c5 else 0.0], dtype=torch.float64, device="cpu" if share_gpu else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -1257,6 +1283,7 @@ def main():
             c5["ms_per_step"] = float(t[2].item()); c5["value"] = 4096 / (c5["ms_per_step"] * 1e-3)
     ctx.close()
 
+    c2_rate = (c2_own or {}).get("value"); c2_power = (c2_own or {}).get("power")
     if rank == 0:
         def avg_us(p, name):
             n, ms = p.get(name, [0, 0.0])
@@ -1317,10 +1344,11 @@ def main():
             "sustained": sustained,
             "c5_4096_total_strong": c5,
             "exchange_variant_8e2": exchange,
-            "one_proof_per_call": (boundary or {}).get("one_proof_per_call") if isinstance(boundary, dict) else None,
+            "one_proof_per_call": one_pc,
             "boundary_bytes_to_bools": boundary,
             "c4_account_256": c4,
-            "c2_accumulator_only": {"value": c2_rate, "unit": "accumulator checks/s", "single_check": c2_single,
+            "c2_accumulator_only": {"value": c2_rate, "unit": "accumulator checks/s", "single_check": (c2_own or {}).get("single_check"),
+                                    **({"error": c2_own["error"]} if c2_own and "error" in c2_own else {}), "process": "a fresh process holding only libminaverify.so",
                                     "note": "BASELINE config C2 alone (round 1's headline): un-folded 2^16-base Vesta IPA accumulator checks, 8 per call, 16 lanes",
                                     # the metric's second half ("MSM HBM GB/s vs peak"): one check = one 2^16-base MSM; algorithmic bytes = bases + scalars
                                     "power": c2_power,
@@ -1382,10 +1410,14 @@ def main():
 
 
 if __name__ == "__main__":
-    if len(sys.argv) >= 4 and sys.argv[1] in ("--boundary-only", "--boundary-all-devices", "--account-only"):     # a bytes -> bools leg in a process of its own (see main): only the library, no torch
+    if len(sys.argv) >= 4 and sys.argv[1] in ("--boundary-only", "--boundary-all-devices", "--account-only", "--one-proof-only", "--c2-only"):     # a bytes -> bools leg in a process of its own (see main): only the library, no torch
         import mina_bridge_amd as _m
         if sys.argv[1] == "--account-only":
             print(json.dumps(account_leg(_m, sys.argv[2])), flush=True)
+        elif sys.argv[1] == "--one-proof-only":
+            print(json.dumps(one_proof_leg(_m, sys.argv[2])), flush=True)
+        elif sys.argv[1] == "--c2-only":
+            print(json.dumps(c2_leg(_m, sys.argv[2], "" if sys.argv[3] == "-" else sys.argv[3])), flush=True)
         else:
             fn = boundary_leg if sys.argv[1] == "--boundary-only" else boundary_all_devices_leg
             print(json.dumps(fn(_m, sys.argv[2], int(sys.argv[3]))), flush=True)

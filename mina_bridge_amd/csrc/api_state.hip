@@ -23,7 +23,7 @@ template <int F> __device__ __forceinline__ fe_t ld_fe(const uint32_t *p) { fe_t
 // One lane group (8 lanes, or a wave-packed triple for chip-filling batches) per state; record = MINA_PSTATE_SLOTS field elements, canonical words.
 template <int F, int LANES>
 // LANES == 3: five waves per SIMD (96 VGPRs) as before the signed-digit forms, whose digits pin the low halves of register pairs (100 VGPRs unasked): the three values
-// the allocator parks in scratch are touched outside the round loops only (checked in the ISA)
+// the allocator parks in scratch are touched outside the round loops only (pinned from the code object: tests/test_code_object.py::test_dominant_kernel_round_loops)
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LANES == 3 ? 5 : 1, LANES == 3 ? 5 : 8)))
 pstate_hash_kernel(uint32_t n, FieldK fk, const PoseidonParams *__restrict__ pp, const fe_t *__restrict__ salts /* [0..3) body, [3..6) state */,
                    const uint32_t *__restrict__ records, const uint32_t *__restrict__ nfields, uint32_t *__restrict__ out_hash /* n*8 */,

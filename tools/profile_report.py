@@ -32,10 +32,11 @@ rows = list(csv.DictReader(open(os.path.join(d, "fetch", "f_kernel_trace.csv")))
 # round 6 (VERDICT r05 next #3c): a (kernel, grid) pair launched a whole number of times per step belongs to the steps; everything else -- the set-up's launches of the
 # same kernels on other grids (the 16 384 chains are hashed state by state before the first step: 17 launches of pstate_hash_kernel) -- gets a row of its own, so that
 # the per-launch average of a step's kernels can be read off this table
-gcount = collections.Counter((short(r["Kernel_Name"]), r["Grid_Size"]) for r in rows)
+gsz = lambda r: r.get("Grid_Size") or (r["Grid_Size_X"], r["Grid_Size_Y"], r["Grid_Size_Z"])      # the kernel-trace CSV names the three dimensions, the counter CSV their product
+gcount = collections.Counter((short(r["Kernel_Name"]), gsz(r)) for r in rows)
 dur, cnt = collections.defaultdict(float), collections.Counter()
 for r in rows:
-    n = short(r["Kernel_Name"]); g_ = gcount[(n, r["Grid_Size"])]
+    n = short(r["Kernel_Name"]); g_ = gcount[(n, gsz(r))]
     if g_ < STEPS or g_ % STEPS: n += " [set-up]"
     dur[n] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3; cnt[n] += 1
 step_sum = sum(v for k, v in dur.items() if not k.endswith("[set-up]"))
