@@ -688,6 +688,7 @@ typedef struct mina_verify_tuning {
     uint32_t dev_piece_waves;      /* 0     a forked job's state hashes are launched in pieces of this many waves; 0 = 6144 / pipeline lanes (whole for a lone lane), 0xffffffff = never */
     uint32_t dev_hash_lds_kb;      /* 0     KiB of LDS a forked job's state-hash workgroup reserves (33 = four waves per SIMD instead of five, 41 = three: room for the waves of the other legs);
                                             0 = 41 for a lone lane, none with several lanes; 0xffffffff = never */
+    uint32_t dev_acc_lane;         /* 0     the accumulator leg of a forked job: 0 = on a stream of its own, 1 = on the hashes' stream behind them, 2 = on the hashes' stream ahead of them */
 } mina_verify_tuning;
 void mina_verify_tuning_default(mina_verify_tuning *out);
 int mina_verify_tuning_get(mina_verify_tuning *out);

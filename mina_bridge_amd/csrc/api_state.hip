@@ -348,7 +348,7 @@ int mb_state_jobs_on_lane(mina_ctx *c, const mina_state_jobs *j, uint32_t *d_ver
     Lane *LI = L0, *LA = L0, *LS = L0;
     if (LI_ && LA_ && LI_ != L0 && LA_ != L0 && LI_ != LA_) {
         LI = LI_; LA = LA_;
-        if (LS_ && LS_ != L0 && LS_ != LI && LS_ != LA) LS = LS_;
+        if (LS_ && LS_ != L0 && LS_ != LI) LS = LS_;             // LS == LA: the accumulator leg shares the hashes' stream (behind them, or ahead: mina_ctx::acc_first)
         c->legs_forked = true;
         int frc;
         if ((phase & MB_JOB_LEGS) && ((frc = leg_fork(c, *L0, *LI)) || (frc = leg_fork(c, *L0, *LA)))) return frc;
@@ -357,6 +357,26 @@ int mb_state_jobs_on_lane(mina_ctx *c, const mina_state_jobs *j, uint32_t *d_ver
     const size_t B = j->batch;
     int rc;
     struct Unfork { mina_ctx *c; Lane *l0; ~Unfork() { c->legs_forked = false; c->L = l0; } } unfork{c, L0};
+    const uint32_t *comm_override = nullptr;
+    uint32_t *ipa_v = nullptr, *acc_v = nullptr;
+    uint32_t *kimchi_bad = nullptr; const uint32_t *stmt_ok = nullptr;
+    // ---- accumulator leg.  It shares scratch buffers with the opening check (ipa_chals / ipa_sigma / ipa_points of its lane), and the
+    // culprit search re-checks slices of a failed batch from the rows the opening check LEFT in those buffers (mb_ipa_recheck_rows): on the
+    // wrap leg's own lane the accumulator therefore runs FIRST (run after it, as it did until round 3, it overwrote the rows: every
+    // part of a search then failed and a batch of more than 1024 proofs with one bad opening was rejected whole).
+    auto accumulator_leg = [&]() -> int {
+        c->L = LA;
+        if (j->with_accumulator) {
+            int r;
+            if ((r = LA->st_flags.ensure(16 * 4))) return r;
+            acc_v = LA->st_flags.as<uint32_t>() + 8;
+            if ((r = mb_accumulator_check_dev(c, CURVE_VESTA, j->acc_k, B, (const uint32_t *)j->acc_prechallenges, (const uint32_t *)j->acc_sg,
+                                              B > 1 ? (const uint32_t *)j->acc_rho : nullptr, acc_v))) return r;
+        }
+        return MINA_OK;
+    };
+    const bool acc_ahead = c->acc_first && LA == LS && LS != L0 && phase == MB_JOB_ALL;      // (device-resident jobs only: the boundary queues a job in two phases)
+    if (acc_ahead && (rc = accumulator_leg())) { c->L = L0; return rc; }
     Lane &S = *LS;                                              // ---- protocol-state leg
     c->L = LS;
     if ((rc = S.st_ok.ensure(B * 4))) return rc;
@@ -377,24 +397,6 @@ int mb_state_jobs_on_lane(mina_ctx *c, const mina_state_jobs *j, uint32_t *d_ver
     }
     HIPC(hipGetLastError());
     c->L = L0;
-    const uint32_t *comm_override = nullptr;
-    uint32_t *ipa_v = nullptr, *acc_v = nullptr;
-    uint32_t *kimchi_bad = nullptr; const uint32_t *stmt_ok = nullptr;
-    // ---- accumulator leg.  It shares scratch buffers with the opening check (ipa_chals / ipa_sigma / ipa_points of its lane), and the
-    // culprit search re-checks slices of a failed batch from the rows the opening check LEFT in those buffers (mb_ipa_recheck_rows): on the
-    // wrap leg's own lane the accumulator therefore runs FIRST (run after it, as it did until round 3, it overwrote the rows: every
-    // part of a search then failed and a batch of more than 1024 proofs with one bad opening was rejected whole).
-    auto accumulator_leg = [&]() -> int {
-        c->L = LA;
-        if (j->with_accumulator) {
-            int r;
-            if ((r = LA->st_flags.ensure(16 * 4))) return r;
-            acc_v = LA->st_flags.as<uint32_t>() + 8;
-            if ((r = mb_accumulator_check_dev(c, CURVE_VESTA, j->acc_k, B, (const uint32_t *)j->acc_prechallenges, (const uint32_t *)j->acc_sg,
-                                              B > 1 ? (const uint32_t *)j->acc_rho : nullptr, acc_v))) return r;
-        }
-        return MINA_OK;
-    };
     if ((phase & MB_JOB_LEGS) && LA == LI && (rc = accumulator_leg())) { c->L = L0; return rc; }
     c->L = LI;                                                  // ---- wrap-proof leg
     if (phase & MB_JOB_LEGS) {
@@ -459,7 +461,7 @@ int mb_state_jobs_on_lane(mina_ctx *c, const mina_state_jobs *j, uint32_t *d_ver
         }
     }
     }
-    if ((phase & MB_JOB_LEGS) && LA != LI && (rc = accumulator_leg())) { c->L = L0; return rc; }
+    if ((phase & MB_JOB_LEGS) && LA != LI && !acc_ahead && (rc = accumulator_leg())) { c->L = L0; return rc; }
     c->L = L0;
     if (phase == MB_JOB_LEGS) { carry->ipa_v = ipa_v; carry->acc_v = acc_v; carry->kimchi_bad = kimchi_bad; carry->stmt_ok = stmt_ok; return MINA_OK; }
     if (phase == MB_JOB_FINISH) { ipa_v = carry->ipa_v; acc_v = carry->acc_v; kimchi_bad = carry->kimchi_bad; stmt_ok = carry->stmt_ok; }
@@ -501,7 +503,8 @@ static int dev_fork_lanes(mina_ctx *c, Lane **LI, Lane **LA, Lane **LS) {
         int rc;
         if ((rc = make(h[0], true, (mode & 2u) != 0, prio_hi)) || (rc = make(h[1], true, false, (prio_lo + prio_hi) / 2)) || (rc = make(h[2], false, (mode & 2u) != 0, prio_lo))) return rc;
     }
-    *LI = &h[0]; *LA = &h[1]; *LS = &h[2];
+    *LI = &h[0]; *LA = tu.dev_acc_lane ? &h[2] : &h[1]; *LS = &h[2];      // dev_acc_lane: the accumulator leg on the hashes' stream (1: behind them, 2: ahead)
+    c->acc_first = tu.dev_acc_lane == 2;
     // The hashes of a forked job go out in pieces, so that the jobs in flight together ask for ~6 state-hash waves per SIMD (five fit beside nothing else, 96 VGPRs):
     // measured with the wave priorities on (lanes x piece grid at 4096 / 8192 / 16 384 proofs per call, profiles/r06_dev_fork.md) the best piece is ~6144 / lanes waves
     // whatever the call size -- 2 lanes 3072, 3: 2048, 4: 1536, 6: 1024 -- and a lone call is best left whole.
@@ -529,7 +532,7 @@ extern "C" int mina_state_job_batch_dev(mina_ctx *c, const mina_state_jobs *jobs
     Lane *LI = nullptr, *LA = nullptr, *LS = nullptr;
     if ((rc = dev_fork_lanes(c, &LI, &LA, &LS))) return rc;
     rc = mb_state_jobs_on_lane(c, jobs, (uint32_t *)d_verdicts, (uint32_t *)d_flags, LI, LA, nullptr, LS);
-    c->hash_piece_waves = 0; c->hash_lds_bytes = 0;
+    c->hash_piece_waves = 0; c->hash_lds_bytes = 0; c->acc_first = false;
     return rc;
 }
 

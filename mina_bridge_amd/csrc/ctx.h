@@ -152,6 +152,7 @@ struct mina_ctx {
     size_t state_hashes_early = 0;   // states of the next job's protocol-state leg already queued on its lane (mb_state_hashes_early), consumed by mb_state_jobs_on_lane
     uint32_t hash_piece_waves = 0;   // > 0: the protocol-state hashes of a job are launched in pieces of this many waves (api_state.hip pstate_hash_dev)
     uint32_t hash_lds_bytes = 0;     // > 0: dynamic LDS a 3-lane state-hash workgroup reserves, to cap its waves per SIMD beside the other legs of a forked job (mina_verify_tuning.dev_hash_lds_kb)
+    bool acc_first = false;          // forked device-resident job whose accumulator leg shares the hashes' stream: queue it AHEAD of them (mina_verify_tuning.dev_acc_lane = 2)
     uint32_t dev_fork_made = 0;      // the dev_fork value the helper lanes' streams were created under (streams keep their mask / priority for life)
     // SURVEY.md 8e.2 (one exchange step over several GPUs): while set, the folded checks of a job do NOT run their fixed-base MSM and comparison -- they hand out
     // this shard's folded scalar vector and the 17-word record of its variable-base partial sum instead (mina_state_job_fold_dev); device pointers

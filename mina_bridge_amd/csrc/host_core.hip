@@ -22,7 +22,7 @@ static mina_verify_tuning tuning_defaults() {
     t.merge = 1; t.merge_batch_max = 512; t.linger_us = 500; t.max_jobs = 1;
     t.coop16_max = 64; t.coop8_max = 8192; t.coop8_per_call = 0; t.transcript_coop8_max = 0; t.ipa_coop8_max = 1024; t.kimchi_coop8_max = 1024;
     t.bpoly_mfma = 1; t.pubcomm_direct = 1; t.ipa_shared_points = 1; t.kimchi_shared_digest = 1; t.ipa_side_stream = 1; t.search_fan = 4; t.search_full = 0; t.msm_fp29 = 1; t.search_ctx = 1;
-    t.dev_fork = 1; t.dev_chain_cus = 96; t.dev_piece_waves = 0; t.dev_hash_lds_kb = 0;
+    t.dev_fork = 1; t.dev_chain_cus = 96; t.dev_piece_waves = 0; t.dev_hash_lds_kb = 0; t.dev_acc_lane = 0;
     return t;
 }
 // The environment switches of rounds 1 - 3 became fields of mina_verify_tuning (round 4).  A deployment that still exports one gets the DEFAULT now: say so, once,

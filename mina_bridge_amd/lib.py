@@ -366,7 +366,7 @@ class Tuning(ctypes.Structure):
     FIELDS = ("struct_size", "chunk", "single_max", "slots", "window", "ahead", "early_min", "early_sub", "head_min", "split_max", "chain_cus", "cu_period", "acc_mask",
               "hash_piece_waves", "up_stream", "min_shard", "pace_us", "merge", "merge_batch_max", "linger_us", "max_jobs", "coop16_max", "coop8_max", "coop8_per_call",
               "transcript_coop8_max", "ipa_coop8_max", "kimchi_coop8_max", "bpoly_mfma", "pubcomm_direct", "ipa_shared_points", "kimchi_shared_digest", "ipa_side_stream",
-              "search_fan", "search_full", "msm_fp29", "search_ctx", "dev_fork", "dev_chain_cus", "dev_piece_waves", "dev_hash_lds_kb")
+              "search_fan", "search_full", "msm_fp29", "search_ctx", "dev_fork", "dev_chain_cus", "dev_piece_waves", "dev_hash_lds_kb", "dev_acc_lane")
     _fields_ = [(n, ctypes.c_uint32) for n in FIELDS]
 
 

@@ -147,10 +147,11 @@ def test_state_job_device_resident_and_pipelined(ctx_srs, oracle, small_jobs):
 
 
 @pytest.mark.parametrize("tune", [dict(dev_fork=0), dict(dev_fork=1), dict(dev_fork=1, dev_piece_waves=1, coop16_max=0, coop8_max=0), dict(dev_fork=1, dev_hash_lds_kb=33, coop16_max=0, coop8_max=0),
-                                  dict(dev_fork=3, dev_chain_cus=96), dict(dev_fork=5)])
+                                  dict(dev_fork=3, dev_chain_cus=96), dict(dev_fork=5), dict(dev_fork=1, dev_acc_lane=1), dict(dev_fork=1, dev_acc_lane=2)])
 def test_state_job_dev_legs_forked_in_every_tuning(oracle, small_jobs, tune):
     """round 6: the three legs of a device-resident job on streams of their own (mina_verify_tuning.dev_fork: plain / CU-masked / priority streams, the hashes in pieces --
-    coop*_max = 0 forces the wave-packed 3-lane form, the only one launched in pieces -- or with an LDS reservation) give the verdict words of the one-stream job, lane by
+    coop*_max = 0 forces the wave-packed 3-lane form, the only one launched in pieces -- or with an LDS reservation; the accumulator leg on a stream of its own or on the
+    hashes' stream, behind or ahead of them) give the verdict words of the one-stream job, lane by
     lane, with 1 and with 4 jobs in flight: all good; a state whose hash no longer matches fails ITS proof only; a changed public input fails the folded opening (flag 0);
     another proof's accumulator commitment fails the folded accumulator check (flag 2).  A context of its own per tuning: streams keep their mask / priority for life."""
     import mina_bridge_amd as m
