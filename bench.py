@@ -18,7 +18,8 @@ whole verifier from the PARSED proof, everything on the GPU:
 `--mode kimchi` leaves the statement stage out (public inputs given), `--mode prepared` also the kimchi stage (BatchEvaluationProof
 rows given: round 2's first headline).  The wrap / step verifier indexes are synthetic at the real sizes (the blockchain-snark
 indexes are not offline); proofs are minted by the repo's CPU oracle and ACCEPT.  Steps are issued round-robin over
-`--pipeline` lanes (independent batches overlap on the GPU).  Not in the job: bin_prot / bincode parsing of the containers and the
+`--pipeline` lanes (independent batches overlap on the GPU; 4 since round 6: each lane forks a job's three legs -- state hashes / wrap-proof chain / accumulator --
+onto helper streams of its own and joins them before the verdict kernel, and every kernel but the state hash raises its wave priority: profiles/r06_dev_fork.md).  Not in the job: bin_prot / bincode parsing of the containers and the
 consensus pre-checks (host side of the boundary, done by the caller before the timed region).
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--jobs B] [--pipeline L]
@@ -31,6 +32,10 @@ process per GPU with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rank 0's JSO
 ranks share GPU 0 and rendezvous over gloo (`"shared_gpu": true`, `"gpus_physical"` in the line): the N > 1 code path is exercised, the
 figure is NOT a scaling number.  At N > 1 rank 0 also times the PRODUCT's own multi-device path -- ONE process, $MINA_VERIFY_DEVICES = the N
 GPUs, `mina_verify_state_batch` on serialized proofs (`boundary_bytes_to_bools.all_devices`) -- while the other ranks wait.
+
+Secondary legs that need a process of their own run in one (rank 0, before the main process touches the GPU): the bytes -> bools boundary, BASELINE C4, `one_proof_per_call` (the
+reference's call shape) and BASELINE C2 (`c2_accumulator_only`, incl. ONE check alone on the chip).  In the main process the lone-call latencies and the isolated launches that time the
+dominant kernel come BEFORE anything creates more streams than the process has hardware queues (such a process stays slower for life).
 """
 from __future__ import annotations
 
