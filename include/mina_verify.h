@@ -698,7 +698,10 @@ int mina_verify_configure_ex(const mina_verify_tuning *tuning);
  * replaces each.  A strict deployment checks this for 0 at start-up. */
 int mina_verify_retired_env(void);
 int mina_verify_shutdown(void);                  /* destroy the process-wide contexts */
-mina_ctx *mina_verify_global_ctx(void);          /* the first device's context, e.g. to install a verifier index; NULL without a GPU */
+mina_ctx *mina_verify_global_ctx(void);          /* the first device's context, e.g. to install a verifier index; NULL without a GPU.  Installing through this handle with the
+                                                    kernel-level installers (mina_verifier_index_install, mina_srs_*, mina_poseidon_set_params ...) takes none of the boundary's locks: do it
+                                                    BEFORE the first mina_verify_* call only.  While verification calls may be in flight use the mina_verify_install_* / mina_verify_set_*
+                                                    functions below: they serialise against running jobs and culprit searches (lock order g_mu, search_mu, mu) on every device. */
 /* Multi-GPU behind the boundary: the process holds one context per GPU named by $MINA_VERIFY_DEVICES ("all" | comma list of
  * ordinals; an ordinal may repeat = several logical contexts on one GPU; default: $MINA_VERIFY_DEVICE or 0).  mina_verify_state_batch cuts
  * its proofs into contiguous shards, one per device, each with its own folding randomisers and its own culprit search; merged single-proof
