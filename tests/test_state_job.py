@@ -193,6 +193,42 @@ def test_state_job_dev_legs_forked_in_every_tuning(oracle, small_jobs, tune):
             c.close()
 
 
+def test_full_size_forked_job_rejects_what_the_one_stream_job_rejects(ctx_srs):
+    """the bench's own job at full size (17 hashes, statement -> 40 public inputs, kimchi, k = 15 opening with the matrix-core fold, 2^16 accumulator; 512 proofs per call: the
+    wave-packed 3-lane forms) through `mina_state_job_batch_dev`, forked over 4 lanes and on one stream: the same verdict words and flags for a clean batch, for one whose proof 7 has a
+    flipped bit in a protocol state (its verdict alone), one with a flipped opening scalar (folded opening flag), one with a flipped accumulator prechallenge (folded accumulator flag)."""
+    torch = pytest.importorskip("torch")
+    import bench
+    import mina_bridge_amd as m
+    ctx, B = ctx_srs, 512
+    dev = torch.device("cuda", 0)
+    variants = {}
+    for name in ("good", "bad_state", "bad_opening", "bad_accumulator"):
+        (hj, keep), kp, _, _ = bench.build_full_job(ctx, m, B, seed=4100)
+        by_addr = {a.ctypes.data: a for a in keep if isinstance(a, np.ndarray)}
+        if name == "bad_state": by_addr[hj.state_records].view(np.uint8).reshape(B, 17, 64, 32)[7, 9, 20, 3] ^= 4
+        if name == "bad_opening": by_addr[hj.z1].view(np.uint8).reshape(B, 32)[300, 0] ^= 1
+        if name == "bad_accumulator": by_addr[hj.acc_prechallenges].view(np.uint8).reshape(B, 16, 16)[41, 3, 0] ^= 1
+        variants[name] = bench.device_jobs(m, hj, keep, kp, dev)
+    expect = {"good": ([1] * B, [1, 0, 1, 0]), "bad_state": ([1] * 7 + [0] + [1] * (B - 8), [1, 0, 1, 0]), "bad_opening": ([0] * B, [0, 0, 1, 0]), "bad_accumulator": ([0] * B, [1, 0, 0, 0])}
+    ctx.state_jobs_prepare(bench.LOG2_DOMAIN, bench.NPUB)
+    try:
+        for tune, lanes in ((dict(dev_fork=1), 4), (dict(dev_fork=0), 1), (dict(dev_fork=1), 1)):
+            with m.lib.tuning(**tune):
+                ctx.set_pipeline(lanes)
+                order = [n for _ in range(2) for n in variants]
+                outs = [torch.full((B + 4,), 9, dtype=torch.int32, device=dev) for _ in order]
+                torch.cuda.synchronize()
+                for n, o in zip(order, outs):
+                    ctx.state_job_batch_dev(variants[n][0], o.data_ptr(), o.data_ptr() + 4 * B)
+                ctx.synchronize()
+                for n, o in zip(order, outs):
+                    w = o.cpu().numpy().tolist()
+                    assert (w[:B], w[B:]) == expect[n], (tune, lanes, n, [i for i, (a, e) in enumerate(zip(w[:B], expect[n][0])) if a != e][:8], w[B:])
+    finally:
+        ctx.synchronize(); ctx.set_pipeline(1)
+
+
 def test_state_job_full_size_c3(ctx_srs, oracle, srs_oracle):
     """BASELINE config C3 at full size: 17 states, 40 public inputs over the 2^15 wrap domain, k = 15 opening with 45 commitments
     and 2 points (committed oracle-minted fixture), 2^16 Vesta accumulator; B = 16 with one tampered proof"""

@@ -36,7 +36,7 @@ for st in "$@"; do
     gpus8)    ( time timeout 2400 python bench.py --gpus 8 --steps 10 ) > $O/bench_gpus8_shared.json 2> $O/bench_gpus8.err; echo "gpus8 rc=$?" ;;
     preflight) ( timeout 1200 python bench.py --gpus 8 --preflight ) > $O/preflight_gpus8.json 2> $O/preflight.err; echo "preflight rc=$?"; cut -c1-400 $O/preflight_gpus8.json ;;
     callers)  timeout 600 python tools/concurrent_callers.py 6 > $O/concurrent_callers.log 2>&1; tail -12 $O/concurrent_callers.log ;;
-    soak)     for t in "soak.py 120" "soak_ipa.py 90" "soak_sponge.py 120" "soak_lanes.py 120" "soak_verifier.py 180" "soak_boundary.py 300"; do set -- $t
+    soak)     for t in "soak.py 120" "soak_ipa.py 90" "soak_sponge.py 120" "soak_lanes.py 120" "soak_fork.py 120" "soak_verifier.py 180" "soak_boundary.py 300"; do set -- $t
                 secs=$(( $2 * ${SOAK_SCALE:-1} )); timeout $(( secs + 600 )) python tools/$1 $secs > $O/${1%.py}.log 2>&1; echo "$1 rc=$?" | tee -a $O/soak_rc.log; tail -1 $O/${1%.py}.log | cut -c1-400
               done ;;
     *) echo "unknown stage $st" ;;
