@@ -513,7 +513,8 @@ static int dev_fork_lanes(mina_ctx *c, Lane **LI, Lane **LA, Lane **LS) {
     if (piece == 0xffffffffu) piece = 0;
     c->hash_piece_waves = piece;
     // A lone forked job: its hashes would hold every wave slot their 96 VGPRs allow (5 per SIMD) and the chain's waves would wait for one to retire (~13 ms): the
-    // hash workgroups reserve 41 KiB of LDS each -- three per CU = 3 waves per SIMD, 224 VGPRs left for a wave of any chain kernel (the widest: 194).  Lone calls
+    // hash workgroups reserve 41 KiB of LDS each -- three per CU = 3 waves per SIMD, 224 VGPRs left: room for a wave of every chain kernel but the two PolishToken
+    // interpreters (244 / 194 VGPRs + 64 KiB of LDS: they wait for a CU to drain either way).  Lone calls
     // 16 384: 63.6 -> 61.5 ms, 8192: 38.7 -> 36.2 ms; with several jobs in flight the pieces do that job and the reservation costs 1 - 3 % (profiles/r06_dev_fork.md).
     uint32_t lds_kb = tu.dev_hash_lds_kb;
     if (lds_kb == 0 && c->nlanes == 1) lds_kb = 41;
