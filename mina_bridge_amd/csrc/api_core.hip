@@ -124,8 +124,8 @@ extern "C" void mina_ctx_destroy(mina_ctx *c) {
 // on separate hardware queues, and the runtime's default is 4.  The HIP runtime reads the variable when it initialises, so this takes
 // effect when the library is loaded before the process's first HIP call (the operator's cgo binding); a value set by the user is kept.
 // 16: what the reference-shaped boundary wants -- a lone job's three legs + the other slots; measured with the system runtime (ROCm 7.2), 8192
-// proofs per mina_verify_state_batch call: 4 - 16 queues 54.6 - 56 ms, 24 queues 68.4 ms.  A process that pipelines 16 device-resident jobs
-// itself (bench.py's headline, the test-suite) sets 24 -- one queue per lane plus the helpers (+5 % there).
+// proofs per mina_verify_state_batch call: 4 - 16 queues 54.6 - 56 ms, 24 queues 68.4 ms.  A process that pipelines device-resident jobs
+// itself (bench.py's headline: 4 lanes x 4 streams since round 6; the test-suite) sets 24 -- one queue per stream plus a few; a process should never hold more streams than that.
 __attribute__((constructor)) static void mb_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
 
 extern "C" int mina_ctx_synchronize(mina_ctx *c) {
