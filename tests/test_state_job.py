@@ -175,9 +175,9 @@ def test_state_job_dev_legs_forked_in_every_tuning(oracle, small_jobs, tune):
             c.srs_create(0, 1 << 10); c.srs_create(1, 1 << 10)          # as smoke(): depth >= 2^k, 2^acc_k
             c.state_jobs_prepare(SMALL["log2_domain"], SMALL["npub"])
             dev = {name: c.state_jobs_to_device(build_jobs(m, jobs, SMALL["k"], SMALL["log2_domain"], SMALL["slot"], SMALL["acc_k"])) for name, jobs in variants.items()}
-            for lanes in (1, 4):
+            for lanes in (1, 4, 10):                                                  # 10: more lanes than a forked pipeline has (8) -- every job on one stream again
                 c.set_pipeline(lanes)
-                calls = [name for _ in range(2) for name in variants]                  # 8 calls back to back: with 4 lanes, 4 jobs of different kinds in flight
+                calls = [name for _ in range(3) for name in variants]                  # 12 calls back to back: with 4 lanes, 4 jobs of different kinds in flight
                 outs = [c.dev_malloc(4 * B + 16) for _ in calls]
                 for name, o in zip(calls, outs):
                     c.state_job_batch_dev(dev[name][0], o, o + 4 * B)

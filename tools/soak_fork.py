@@ -53,7 +53,7 @@ def batch():
 t0 = time.time(); rounds = calls_total = words_total = 0
 while time.time() - t0 < budget:
     rounds += 1
-    lanes = int(rng.choice([1, 2, 3, 4, 6, 8]))
+    lanes = int(rng.choice([1, 2, 3, 4, 6, 8, 11]))                      # 11: beyond the forked pipelines (<= 8 lanes): one stream per job whatever dev_fork says
     tune = dict(dev_fork=int(rng.choice([0, 1, 1, 1])), dev_piece_waves=int(rng.choice([0, 1, 2, 0xffffffff])), dev_hash_lds_kb=int(rng.choice([0, 33, 41, 0xffffffff])),
                 dev_acc_lane=int(rng.choice([0, 1, 2])))
     if rng.random() < 0.5: tune.update(coop16_max=0, coop8_max=0)            # the wave-packed 3-lane forms (the ones launched in pieces / with the LDS reservation)
