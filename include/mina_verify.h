@@ -682,7 +682,7 @@ typedef struct mina_verify_tuning {
                                             flowing beside it.  0 = round 4: on the device's one context, with the device drained and its lock held for the length of the search */
     /* device-resident jobs (mina_state_job_batch_dev): the three independent legs of ONE job -- protocol-state hashes / wrap-proof chain / accumulator -- on streams
      * of their own, joined before the verdict kernel, so that a few jobs in flight fill the chip (round 6; until then one stream per job and ~20 jobs in flight) */
-    uint32_t dev_fork;             /* 1     bit 0: fork the legs (pipelines of up to 8 lanes); bit 1: the chain's and the hashes' streams get disjoint CU masks (`dev_chain_cus`);
+    uint32_t dev_fork;             /* 1     bit 0: fork the legs (pipelines of up to 8 lanes; a pinned lane and mina_state_job_fold_dev fork as well: fork and join are events on the lane's stream); bit 1: the chain's and the hashes' streams get disjoint CU masks (`dev_chain_cus`);
                                             bit 2: the wrap-proof chain's stream is created with the highest stream priority, the hashes' with the lowest */
     uint32_t dev_chain_cus;        /* 96    CUs of the chain's mask when bit 1 of dev_fork is set */
     uint32_t dev_piece_waves;      /* 0     a forked job's state hashes are launched in pieces of this many waves; 0 = 6144 / pipeline lanes (whole for a lone lane), 0xffffffff = never */

@@ -476,11 +476,14 @@ int mb_state_jobs_on_lane(mina_ctx *c, const mina_state_jobs *j, uint32_t *d_ver
 // beside them -- 47.6 GiB of workspaces and 71 ms of call latency for the headline.  The three legs of a job are independent until the verdict kernel (the same
 // split the boundary makes per chunk, api_verify.hip setup_legs): pipeline lane i keeps the fork / join and the verdict kernel, its helper lanes
 // MB_DEV_HELPER0 + 3 i + {0, 1, 2} run the wrap-proof chain, the accumulator check and the state hashes.  Streams are created once per context under the tuning
-// then in force (a stream keeps its CU mask / priority for life); a pinned lane (mina_ctx_pin_lane: the caller orders its own work on ONE stream) never forks.
+// then in force (a stream keeps its CU mask / priority for life).  A pinned lane (mina_ctx_pin_lane: the caller queues its own work on that lane's stream) forks as well: the legs
+// start behind an event recorded on the lane and the lane waits for them before its verdict kernel, so everything the caller queued before the call is seen by every leg and
+// everything it queues after the call sees every leg's output -- the exchange variant (mina_state_job_fold_dev under sharded.py's `ordered()` scope) keeps its ONE ordering stream.
 static int dev_fork_lanes(mina_ctx *c, Lane **LI, Lane **LA, Lane **LS) {
     const mina_verify_tuning tu = mb_tune();
     const int li = (int)(c->L - c->lanes);
-    if (!(tu.dev_fork & 1u) || c->pinned >= 0 || c->nlanes > MB_DEV_FORK_MAX || li < 0 || li >= MB_DEV_FORK_MAX || c->fold_export) return MINA_OK;
+    if (!(tu.dev_fork & 1u) || c->nlanes > MB_DEV_FORK_MAX || li < 0 || li >= MB_DEV_FORK_MAX) return MINA_OK;
+    const int in_flight = c->pinned >= 0 ? 1 : c->nlanes;          // a pinned context runs one job at a time
     Lane *h = &c->lanes[MB_DEV_HELPER0 + 3 * li];
     if (!h[0].stream || !h[1].stream || !h[2].stream) {
         const uint32_t mode = c->dev_fork_made ? c->dev_fork_made : tu.dev_fork;
@@ -509,7 +512,7 @@ static int dev_fork_lanes(mina_ctx *c, Lane **LI, Lane **LA, Lane **LS) {
     // measured with the wave priorities on (lanes x piece grid at 4096 / 8192 / 16 384 proofs per call, profiles/r06_dev_fork.md) the best piece is ~6144 / lanes waves
     // whatever the call size -- 2 lanes 3072, 3: 2048, 4: 1536, 6: 1024 -- and a lone call is best left whole.
     uint32_t piece = tu.dev_piece_waves;
-    if (piece == 0 && c->nlanes >= 2) piece = 6144u / (uint32_t)c->nlanes;
+    if (piece == 0 && in_flight >= 2) piece = 6144u / (uint32_t)in_flight;
     if (piece == 0xffffffffu) piece = 0;
     c->hash_piece_waves = piece;
     // A lone forked job: its hashes would hold every wave slot their 96 VGPRs allow (5 per SIMD) and the chain's waves would wait for one to retire (~13 ms): the
@@ -517,7 +520,7 @@ static int dev_fork_lanes(mina_ctx *c, Lane **LI, Lane **LA, Lane **LS) {
     // interpreters (244 / 194 VGPRs + 64 KiB of LDS: they wait for a CU to drain either way).  Lone calls
     // 16 384: 63.6 -> 61.5 ms, 8192: 38.7 -> 36.2 ms; with several jobs in flight the pieces do that job and the reservation costs 1 - 3 % (profiles/r06_dev_fork.md).
     uint32_t lds_kb = tu.dev_hash_lds_kb;
-    if (lds_kb == 0 && c->nlanes == 1) lds_kb = 41;
+    if (lds_kb == 0 && in_flight == 1) lds_kb = 41;
     if (lds_kb == 0xffffffffu || lds_kb > 160) lds_kb = 0;
     c->hash_lds_bytes = lds_kb * 1024u;
     return MINA_OK;
@@ -558,7 +561,9 @@ extern "C" int mina_state_job_fold_dev(mina_ctx *c, const mina_state_jobs *jobs,
     c->next_lane();
     mina_ctx::FoldExport fe; fe.ipa_scalars = (uint32_t *)d_ipa_scalars; fe.ipa_point = (uint32_t *)d_ipa_point; fe.acc_scalars = (uint32_t *)d_acc_scalars; fe.acc_point = (uint32_t *)d_acc_point;
     c->fold_export = &fe;
-    rc = mb_state_jobs_on_lane(c, jobs, (uint32_t *)d_verdicts, (uint32_t *)d_flags, nullptr, nullptr, nullptr, nullptr);
+    Lane *LI = nullptr, *LA = nullptr, *LS = nullptr;
+    if (!(rc = dev_fork_lanes(c, &LI, &LA, &LS))) rc = mb_state_jobs_on_lane(c, jobs, (uint32_t *)d_verdicts, (uint32_t *)d_flags, LI, LA, nullptr, LS);
+    c->hash_piece_waves = 0; c->hash_lds_bytes = 0; c->acc_first = false;
     c->fold_export = nullptr;
     return rc;
 }
