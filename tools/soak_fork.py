@@ -50,7 +50,7 @@ def batch():
     return jobs, words, [1 if ipa_ok else 0, 0, 1 if acc_ok else 0, 0]
 
 
-t0 = time.time(); rounds = calls_total = words_total = 0
+t0 = time.time(); rounds = calls_total = words_total = folds_total = 0
 while time.time() - t0 < budget:
     rounds += 1
     lanes = int(rng.choice([1, 2, 3, 4, 6, 8, 11]))                      # 11: beyond the forked pipelines (<= 8 lanes): one stream per job whatever dev_fork says
@@ -77,5 +77,28 @@ while time.time() - t0 < budget:
             for p in ptrs + [o]: ctx.dev_free(p)
             words_total += B
         calls_total += ncalls
+    # the exchange variant's shard job (mina_state_job_fold_dev: both folds exported instead of checked) forked against one-stream, same job, same opening randomisers: the
+    # per-proof verdict words, the flags, the folded Pallas scalar vector and the variable-base partial point must be the same bytes (the accumulator side carries a fresh
+    # CSPRNG scalar per call and is not compared)
+    if rounds % 4 == 0:
+        jobs, words, flags = batch()
+        chain_only = None
+        outs = []
+        for fork in (0, 1):
+            ctx.synchronize()
+            with m.lib.tuning(dev_fork=fork, **({"coop16_max": 0, "coop8_max": 0} if rng.random() < 0.5 else {})):
+                ctx.set_pipeline(1)
+                d, ptrs = ctx.state_jobs_to_device(build_jobs(m, jobs, SMALL["k"], SMALL["log2_domain"], SMALL["slot"], SMALL["acc_k"], rand_base=12345 + rounds, sg_rand_base=777 + rounds, rho_seed=rounds))
+                B = len(jobs)
+                o = ctx.dev_upload(ctx.dev_malloc(4 * B + 16), np.full(B + 4, 9, np.uint32).view(np.uint8))
+                n_ipa, n_acc = (1 << SMALL["k"]) * 32, (1 << SMALL["acc_k"]) * 32
+                bufs = [ctx.dev_upload(ctx.dev_malloc(n), np.zeros(n, np.uint8)) for n in (n_ipa, 68, n_acc, 68)]
+                ctx.state_job_fold_dev(d, o, o + 4 * B, *bufs)
+                ctx.synchronize()
+                w = ctx.dev_download(o, 4 * B + 16).view(np.uint32).tolist()
+                outs.append((w, ctx.dev_download(bufs[0], n_ipa).tobytes(), ctx.dev_download(bufs[1], 68).tobytes()))
+                for p in ptrs + [o] + bufs: ctx.dev_free(p)
+        assert outs[0] == outs[1], ("fold soak", seed, rounds, outs[0][0], outs[1][0])
+        folds_total += 1
 ctx.synchronize(); ctx.set_pipeline(1)
-print(f"fork soak ok: {rounds} rounds, {calls_total} jobs, {words_total} verdict words in {time.time() - t0:.0f}s")
+print(f"fork soak ok: {rounds} rounds, {calls_total} jobs, {words_total} verdict words, {folds_total} forked-vs-one-stream fold exports in {time.time() - t0:.0f}s")
